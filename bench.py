@@ -1,0 +1,199 @@
+#!/usr/bin/env python
+"""bench.py -- ICP iterations/s, 100k-point scan vs 1M-point map (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--chain p2p|p2plane]
+
+One "step" is one registration of the hot path in throughput mode: a fixed 20 ICP iterations
+(Counter checker only) of one synthetic 100k-point scan against the 1M-point map,
+with the scan already resident in HBM.  value = ICP iterations executed by all ranks / wall time
+(max over ranks, barrier + device sync on both sides).  Ranks hold a replica of the map and their own
+scan (independent seeds): the path shards across scans with no data-path collective => weak scaling.
+
+Extra objects on the JSON line:
+  roofline     -- the NN kernel: algorithmic bytes per launch (N*16 query read + M*16 map read +
+                  N*8 result write) / mean launch duration measured with HIP events
+                  on the library's stream (profile mode), against the 8 TB/s HBM peak.
+  cpu_baseline -- the CPU oracle (a port: libpointmatcher is not installed) timed on this host on a
+                  bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+ITERS_PER_STEP = 20
+M_MAP = 1_000_000
+N_SCAN = 100_000
+HBM_PEAK_GBS = 8000.0
+
+CHAINS = {
+    # config 2 of BASELINE.json: point-to-point
+    "p2p": dict(minimizer=1, max_dist=2.0, outliers=[(4, 0.85)]),
+    # config 3: point-to-plane (analytic normals on the map)
+    "p2plane": dict(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)]),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--chain", default="p2p", choices=list(CHAINS))
+    ap.add_argument("--map-points", type=int, default=M_MAP)
+    ap.add_argument("--scan-points", type=int, default=N_SCAN)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-iters", type=int, default=10)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    dev = local_rank if world > 1 else 0
+    torch.cuda.set_device(dev)
+
+    import norlab_icp_mapper_amd as pkg
+
+    # ---- workload: replicated map, one scan stream per rank ----
+    sc = pkg.synth.make_scene(m=args.map_points, n=args.scan_points, seed_scan=43 + 1000 * rank)
+    chain = dict(CHAINS[args.chain])
+    icp = pkg.ICPSequence(device=dev, max_iterations=ITERS_PER_STEP, **chain)
+    d_map = torch.from_numpy(sc["map"]).cuda()
+    d_nrm = torch.from_numpy(sc["normals"]).cuda()
+    d_scan = torch.from_numpy(sc["scan"]).cuda()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    assert icp.setMapDev(d_map.data_ptr(), d_map.shape[0], d_nrm.data_ptr())
+    set_map_ms = (time.perf_counter() - t0) * 1e3
+
+    def step():
+        return icp.registerDev(d_scan.data_ptr(), d_scan.shape[0], fixed_iterations=ITERS_PER_STEP)
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    loop_ms = 0.0
+    for _ in range(args.steps):
+        T = step()
+        loop_ms += icp.stats.loop_ms
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    iters_total = world * args.steps * ITERS_PER_STEP
+    value = iters_total / elapsed
+
+    out = {
+        "metric": "ICP iterations/sec, 100k-pt scan vs 1M-pt map",
+        "value": value,
+        "unit": "iterations/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"single synthetic {args.scan_points}-pt scan vs {args.map_points}-pt map, "
+                        f"{'point-to-point' if args.chain == 'p2p' else 'point-to-plane'} ICP, KDTreeMatcher knn 1 maxDist 2.0 "
+                        f"epsilon 0, TrimmedDist 0.85, fixed {ITERS_PER_STEP} iterations per registration",
+            "chain": args.chain,
+            "iterations_per_step": ITERS_PER_STEP,
+            "scene": "box+pillars sigma=0.01 seeds 42/43/44 (SURVEY.md 8d)",
+            "parallelism": f"scan-sharded x{world}, map replicated",
+        },
+    }
+
+    if rank == 0:
+        gi = icp.gridInfo()
+        out["device_loop_ms_per_step"] = loop_ms / args.steps
+        out["set_map_ms"] = set_map_ms
+        out["grid"] = gi
+        gt_t, gt_r = pkg.synth.pose_error(T, sc["T_gt"])
+        out["pose_err_vs_ground_truth"] = {"m": gt_t, "rad": gt_r}
+
+        # ---- roofline of the NN kernel: profile mode = eager launches, HIP events around each NN launch
+        prof = pkg.ICPSequence(device=dev, max_iterations=ITERS_PER_STEP, profile=1, **chain)
+        prof.setMapDev(d_map.data_ptr(), d_map.shape[0], d_nrm.data_ptr())
+        nn_ms, nn_cnt = 0.0, 0
+        for r in range(3 + 5):
+            prof.registerDev(d_scan.data_ptr(), d_scan.shape[0], fixed_iterations=ITERS_PER_STEP)
+            if r >= 3:
+                nn_ms += prof.stats.nn_ms_avg * prof.stats.nn_launches
+                nn_cnt += prof.stats.nn_launches
+        nn_avg_ms = nn_ms / max(nn_cnt, 1)
+        alg_bytes = args.scan_points * 16 + args.map_points * 16 + args.scan_points * 8
+        achieved = alg_bytes / (nn_avg_ms * 1e-3) / 1e9 if nn_avg_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "nn_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {"bound": "hbm", "kernel": "nn1_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                           "avg_launch_us": nn_avg_ms * 1e3, "launches_timed": nn_cnt}
+        del prof
+
+        # ---- CPU baseline: the oracle on this host, bounded sample of the same workload ----
+        if not args.no_cpu:
+            import oracle_bindings as ob
+            cores = len(os.sched_getaffinity(0))
+            nthreads = min(cores, 64)
+            okw = dict(minimizer=chain["minimizer"], max_dist=chain["max_dist"], outliers=chain["outliers"])
+            oicp = ob.OracleICP(ob.make_config(max_iterations=ITERS_PER_STEP, nthreads=nthreads, **okw))
+            tb = time.perf_counter()
+            oicp.setMap(sc["map"], sc["normals"])
+            build_s = time.perf_counter() - tb
+            err, T_cpu = oicp(sc["scan"])
+            mt_its = oicp.stats.iterations / oicp.stats.seconds_total
+            o1 = ob.OracleICP(ob.make_config(max_iterations=max(2, args.cpu_iters // 3), nthreads=1, **okw))
+            o1.setMap(sc["map"], sc["normals"])
+            o1(sc["scan"])
+            st_its = o1.stats.iterations / o1.stats.seconds_total
+            dt, dr = pkg.synth.pose_error(T, T_cpu)
+            out["pose_err_vs_cpu"] = {"m": dt, "rad": dr, "tolerance": {"m": 1e-4, "rad": 1e-4}}
+            out["cpu_baseline"] = {
+                "value": max(mt_its, st_its), "unit": "iterations/s", "cores": nthreads if mt_its >= st_its else 1, "kind": "port",
+                "sample": f"oracle (C restatement, gcc -O3, OpenMP over the kNN queries), same map and scan: one "
+                          f"{ITERS_PER_STEP}-iteration registration on {nthreads} threads ({mt_its:.2f} it/s) and "
+                          f"{o1.stats.iterations} iterations on 1 thread ({st_its:.2f} it/s); kd-tree build {build_s:.2f} s excluded",
+                "value_1thread": st_its, "value_multithread": mt_its, "host_cores": cores,
+            }
+            out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,199 @@
+/*
+ * include/icpmi.h -- C ABI of the MI355X-native ICP registration core ("icpmi").
+ *
+ * This is the drop-in boundary for the hot path of norlab_icp_mapper (reference tree
+ * /root/reference, v2.1.0).  The reference has no FFI of its own: the path is entered through the
+ * in-process C++ object `PM::ICPSequence icp` (norlab_icp_mapper/Mapper.h:23) and the MapperModule
+ * virtuals (norlab_icp_mapper/MapperModules/MapperModule.h:20-29).  Each entry point below names the
+ * reference interface it replaces; INTEGRATION.md shows the C++ shim (`GpuICPSequence`,
+ * `Gpu*MapperModule`) a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - plain C, no torch / Eigen / HIP types in any signature;
+ *   - clouds are `features` blocks of PM::DataPoints: 4 x N column-major float (x,y,z,1), i.e. N
+ *     consecutive float4; normals are 3 x N column-major float (descriptor "normals");
+ *   - 4x4 transforms are column-major float[16] (Eigen's default, PM::TransformationParameters);
+ *   - pointers are HOST pointers unless the function name ends in `_dev`, in which case cloud
+ *     pointers are device (HBM) pointers on the handle's GPU; the callee never retains caller
+ *     memory (DataPoints value semantics, SURVEY.md 8b "Ownership");
+ *   - every function returns an icpmi_status; icpmi_last_error(h) gives the message.  The reference
+ *     reports the same conditions as C++ exceptions (PM::ConvergenceError, ...); the mapping is
+ *     given next to each status code;
+ *   - one HIP stream per handle; calls on one handle must be serialised by the caller (the reference
+ *     serialises icp() and icp.setMap() with icpMapLock, Mapper.cpp:212, Map.cpp:527-529);
+ *     different handles are independent (one per GPU).
+ */
+#ifndef ICPMI_H
+#define ICPMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ICPMI_VERSION 1
+
+typedef struct icpmi_ctx* icpmi_handle;
+
+typedef enum {
+    ICPMI_OK = 0,
+    ICPMI_ERR_INVALID_ARG = 1,          /* PM::Parametrizable::InvalidParameter / std::invalid_argument */
+    ICPMI_ERR_HIP = 2,                  /* device runtime failure (no reference analogue)               */
+    ICPMI_ERR_NO_POINT_TO_MINIMIZE = 3, /* PM::ConvergenceError("ErrorMnimizer: no point to minimize")  */
+    ICPMI_ERR_NO_OUTLIER_TO_FILTER = 4, /* PM::ConvergenceError("no outlier to filter")                 */
+    ICPMI_ERR_BOUND = 5,                /* PM::ConvergenceError from BoundTransformationChecker         */
+    ICPMI_ERR_NAN = 6,                  /* PM::ConvergenceError("abs rotation norm not a number")       */
+    ICPMI_ERR_MISSING_NORMALS = 7,      /* PM::DataPoints::InvalidField("normals")                      */
+    ICPMI_ERR_UNSUPPORTED = 8
+} icpmi_status;
+
+/* ErrorMinimizer selection (icp.errorMinimizer in the YAML chain, Mapper.cpp:72) */
+typedef enum {
+    ICPMI_MIN_IDENTITY = 0,       /* IdentityErrorMinimizer (examples/config.yaml:62-63) */
+    ICPMI_MIN_POINT_TO_POINT = 1, /* PointToPointErrorMinimizer                          */
+    ICPMI_MIN_POINT_TO_PLANE = 2  /* PointToPlaneErrorMinimizer (docs/MapperConfiguration.md:174-189) */
+} icpmi_minimizer;
+
+/* OutlierFilters (icp.outlierFilters) */
+typedef enum {
+    ICPMI_OUT_MAXDIST = 1,      /* MaxDistOutlierFilter{maxDist}        w = d2 <= maxDist^2          */
+    ICPMI_OUT_MINDIST = 2,      /* MinDistOutlierFilter{minDist}        w = d2 >= minDist^2          */
+    ICPMI_OUT_MEDIANDIST = 3,   /* MedianDistOutlierFilter{factor}      w = d2 <= factor*median(d2)  */
+    ICPMI_OUT_TRIMMEDDIST = 4,  /* TrimmedDistOutlierFilter{ratio}      w = d2 <= quantile(d2,ratio) */
+    ICPMI_OUT_SURFACENORMAL = 5 /* SurfaceNormalOutlierFilter{maxAngle} w = n_read.n_ref > cos(maxAngle) */
+} icpmi_outlier_type;
+
+typedef struct {
+    int32_t type; /* icpmi_outlier_type */
+    float   param;
+} icpmi_outlier;
+
+typedef enum { ICPMI_STOP_NONE = 0, ICPMI_STOP_COUNTER = 1, ICPMI_STOP_DIFFERENTIAL = 2 } icpmi_stop_reason;
+
+/* The ICP chain of PM::ICPSequence::loadFromYamlNode (Mapper.cpp:72) restricted to the modules on
+ * the hot path.  icpmi_config_default() fills libpointmatcher's defaults for those modules. */
+typedef struct {
+    int32_t device;            /* HIP device ordinal                                              */
+    /* matcher: KDTreeMatcher */
+    int32_t knn;               /* default 1                                                       */
+    float   max_dist;          /* default +inf                                                    */
+    float   epsilon;           /* default 0; > 0 is accepted and served by the EXACT search (a     */
+                               /* valid epsilon-answer, but not libnabo's pick -- SURVEY.md 0.4)   */
+    /* outlier filters, applied in order, weights multiply */
+    int32_t n_outlier;
+    icpmi_outlier outlier[8];
+    /* error minimiser */
+    int32_t minimizer;         /* icpmi_minimizer                                                 */
+    /* transformation checkers */
+    int32_t max_iterations;    /* CounterTransformationChecker.maxIterationCount, default 40      */
+    int32_t use_differential;  /* DifferentialTransformationChecker present                       */
+    float   min_diff_rot;      /* default 0.001                                                   */
+    float   min_diff_trans;    /* default 0.001                                                   */
+    int32_t smooth_length;     /* default 3 (<= 16)                                               */
+    int32_t use_bound;         /* BoundTransformationChecker present                              */
+    float   max_rot_norm;      /* default 1                                                       */
+    float   max_trans_norm;    /* default 1                                                       */
+    /* engine knobs (no reference analogue) */
+    float   grid_cell;         /* NN grid cell edge in metres; 0 = choose from the map density     */
+    int32_t use_graph;         /* 1 = replay the iteration as a hipGraph (default), 0 = eager     */
+    int32_t profile;           /* 1 = eager launches with HIP events around every NN launch        */
+    int32_t reserved[8];
+} icpmi_config;
+
+/* What PM::ICPSequence exposes after a call: errorMinimizer->getOverlap() (Mapper.cpp:219) is
+ * weighted_point_used_ratio; the inspector statistics of SURVEY.md section 5 are the rest. */
+typedef struct {
+    int32_t iterations;
+    int32_t stop_reason;               /* icpmi_stop_reason                                       */
+    int64_t pairs;                     /* P of the last iteration                                 */
+    float   point_used_ratio;          /* P / (knn N)                                             */
+    float   weighted_point_used_ratio; /* sum w / (knn N) == getOverlap()                         */
+    float   trimmed_limit;             /* last quantile limit on d^2 (Trimmed / Median), else -1  */
+    float   loop_ms;                   /* device time of the iteration loop (HIP events)          */
+    float   nn_ms_avg;                 /* profile mode: mean duration of one NN launch            */
+    int32_t nn_launches;               /* profile mode: number of NN launches averaged            */
+    int64_t hard_queries;              /* NN queries that left the ring search for the brute pass */
+    int32_t reserved[6];
+} icpmi_stats;
+
+void icpmi_config_default(icpmi_config* cfg);
+
+/* Replaces constructing / configuring `PM::ICPSequence icp` (Mapper.h:23, Mapper.cpp:72,77). */
+icpmi_status icpmi_create(const icpmi_config* cfg, icpmi_handle* out);
+void         icpmi_destroy(icpmi_handle h);
+const char*  icpmi_last_error(icpmi_handle h); /* h may be NULL: error of the last failed create */
+
+/* Replaces `bool PM::ICPSequence::setMap(const DataPoints&)` (Map.cpp:111,178,528,581): copies the
+ * cloud, centres it on its centroid, builds the NN index on the device.  *accepted = 0 and state
+ * unchanged when m == 0 (upstream returns false and warns).  normals3 may be NULL. */
+icpmi_status icpmi_set_map(icpmi_handle h, const float* map4, int64_t m, const float* normals3, int32_t* accepted);
+icpmi_status icpmi_set_map_dev(icpmi_handle h, const float* d_map4, int64_t m, const float* d_normals3, int32_t* accepted);
+/* `icp.hasMap()` */
+int32_t      icpmi_has_map(icpmi_handle h);
+/* centroid used for centring (T_refIn_refMean translation) */
+icpmi_status icpmi_get_map_mean(icpmi_handle h, float mean3[3]);
+
+/* Replaces `TransformationParameters PM::ICPSequence::operator()(const DataPoints&)`
+ * (Mapper.cpp:213): scan4 is the reading already moved by the prior (Mapper.cpp:197); T_out is the
+ * correction in the map frame (so that correctedPose = T_out * estimatedPose, Mapper.cpp:215).
+ * Without a map returns identity and ICPMI_OK like upstream. scan_normals3 may be NULL. */
+icpmi_status icpmi_register(icpmi_handle h, const float* scan4, int64_t n, const float* scan_normals3,
+                            float T_out[16], icpmi_stats* stats);
+icpmi_status icpmi_register_dev(icpmi_handle h, const float* d_scan4, int64_t n, const float* d_scan_normals3,
+                                float T_out[16], icpmi_stats* stats);
+/* Throughput mode: run exactly `iterations` loop passes (Counter only) -- what the bench times. */
+icpmi_status icpmi_register_fixed_dev(icpmi_handle h, const float* d_scan4, int64_t n, const float* d_scan_normals3,
+                                      int32_t iterations, float T_out[16], icpmi_stats* stats);
+
+/* ---- stage-level entry points (the per-stage virtuals of SURVEY.md 8b B2; used by parity tests) ---- */
+
+/* `Transformation::compute(cloud, T)` (Mapper.cpp:197,221; Map.cpp:523,525): out4 = T * in4;
+ * normals (3 x n, may be NULL) are rotated by the top-left 3x3. Rejects |1 - det R| > 1e-3
+ * (TransformationError) with ICPMI_ERR_INVALID_ARG. */
+icpmi_status icpmi_transform(icpmi_handle h, const float T[16], const float* in4, int64_t n, float* out4,
+                             const float* in_normals3, float* out_normals3);
+
+/* `Matcher::findClosests` == `Nabo::NNS::knn` against the CENTRED map of the handle
+ * (queries are given in the centred frame). ids: k x n int32 (-1 unfilled, ORIGINAL map indices),
+ * d2: k x n float (+inf unfilled), ascending by (d2, id). allow_self = 0 reproduces optionFlags = 0
+ * of PointDistanceMapperModule.cpp:36. max_dist may be +inf. */
+icpmi_status icpmi_knn(icpmi_handle h, const float* q4, int64_t n, int32_t k, float max_dist, int32_t allow_self,
+                       int32_t* ids, float* d2);
+
+/* `OutlierFilters::compute` for the handle's chain on given matches (host arrays, k x n). */
+icpmi_status icpmi_outlier_weights(icpmi_handle h, const float* d2, const int32_t* ids, int32_t k, int64_t n,
+                                   const float* read_normals3, float* weights, float* limit_out);
+
+/* `ErrorMinimizer::compute`: one minimisation step for a reading given in the centred map frame,
+ * with T_iter applied on the device first (T_iter may be NULL = identity). Runs NN + outlier
+ * filters + minimiser of the handle's chain once. Outputs: T_step (4x4), and for inspection
+ * sums[32] (double): point-to-plane -> A (upper 21, row-major packed) then b (6); point-to-point ->
+ * sum w, sum w p (3), sum w q (3), sum w q p^T (9). Any output pointer may be NULL. */
+icpmi_status icpmi_minimize_step(icpmi_handle h, const float* reading4, int64_t n, const float* T_iter,
+                                 float T_step[16], double sums[32], icpmi_stats* stats);
+
+/* ---- map-side operators on the path ---- */
+
+/* `SurfaceNormalDataPointsFilter{knn}` (Map.cpp:524 via examples/config.yaml:26-27). */
+icpmi_status icpmi_surface_normals(icpmi_handle h, const float* pts4, int64_t m, int32_t knn, float* normals3);
+
+/* `PointDistanceMapperModule::inPlaceUpdateMap` keep mask (PointDistanceMapperModule.cpp:28-50):
+ * keep[i] = 1 iff the exact NN of input i in map (self match excluded) has d2 >= min_dist^2. */
+icpmi_status icpmi_point_distance_keep(icpmi_handle h, const float* map4, int64_t m, const float* in4, int64_t n,
+                                       float min_dist, uint8_t* keep);
+
+/* `Map::unloadCells` binning (Map.cpp:206-209,232-235): ijk3[3 i + r] = floor(p_r / cell_size). */
+icpmi_status icpmi_bin_cells(icpmi_handle h, const float* pts4, int64_t n, float cell_size, int32_t* ijk3);
+
+/* ---- plumbing ---- */
+/* Use an externally owned hipStream_t (e.g. torch's current stream) instead of the handle's own. */
+icpmi_status icpmi_set_stream(icpmi_handle h, void* hip_stream);
+/* Grid parameters chosen by the last set_map: cell edge, dims[3], number of cells (for DESIGN/bench). */
+icpmi_status icpmi_get_grid_info(icpmi_handle h, float* cell, int32_t dims[3], int64_t* n_cells, int64_t* n_occupied);
+int32_t      icpmi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,362 @@
+// api.hip -- the extern "C" surface declared in include/icpmi.h (see that header for the reference
+// interface each entry point replaces).
+#include "common.h"
+#include <cstring>
+#include <new>
+
+static std::string g_create_error;
+
+#define CHECK_H(h)                                                           \
+    do {                                                                     \
+        if (!(h)) return ICPMI_ERR_INVALID_ARG;                              \
+        hipError_t _e = hipSetDevice((h)->device);                           \
+        if (_e != hipSuccess) {                                              \
+            (h)->last_error = std::string("hipSetDevice: ") + hipGetErrorString(_e); \
+            return ICPMI_ERR_HIP;                                            \
+        }                                                                    \
+    } while (0)
+
+extern "C" {
+
+int32_t icpmi_version(void) { return ICPMI_VERSION; }
+
+void icpmi_config_default(icpmi_config* cfg)
+{
+    memset(cfg, 0, sizeof *cfg);
+    cfg->device = 0;
+    cfg->knn = 1;
+    cfg->max_dist = INFINITY;
+    cfg->epsilon = 0.f;
+    cfg->n_outlier = 0;
+    cfg->minimizer = ICPMI_MIN_POINT_TO_PLANE;
+    cfg->max_iterations = 40;
+    cfg->use_differential = 0;
+    cfg->min_diff_rot = 0.001f;
+    cfg->min_diff_trans = 0.001f;
+    cfg->smooth_length = 3;
+    cfg->use_bound = 0;
+    cfg->max_rot_norm = 1.f;
+    cfg->max_trans_norm = 1.f;
+    cfg->grid_cell = 0.f;
+    cfg->use_graph = 1;
+    cfg->profile = 0;
+}
+
+static icpmi_status validate_config(const icpmi_config* cfg, std::string& err)
+{
+    if (cfg->knn < 1 || cfg->knn > ICPMI_MAX_K) { err = "InvalidParameter: knn must be in [1, 32]"; return ICPMI_ERR_INVALID_ARG; }
+    if (!(cfg->max_dist > 0.f)) { err = "InvalidParameter: maxDist must be > 0"; return ICPMI_ERR_INVALID_ARG; }
+    if (cfg->epsilon < 0.f) { err = "InvalidParameter: epsilon must be >= 0"; return ICPMI_ERR_INVALID_ARG; }
+    if (cfg->n_outlier < 0 || cfg->n_outlier > ICPMI_MAX_OUTLIER) { err = "InvalidParameter: at most 8 outlier filters"; return ICPMI_ERR_INVALID_ARG; }
+    for (int f = 0; f < cfg->n_outlier; ++f) {
+        const int t = cfg->outlier[f].type;
+        const float p = cfg->outlier[f].param;
+        if (t < ICPMI_OUT_MAXDIST || t > ICPMI_OUT_SURFACENORMAL) { err = "InvalidParameter: unknown outlier filter type"; return ICPMI_ERR_INVALID_ARG; }
+        if (t == ICPMI_OUT_TRIMMEDDIST && !(p >= 0.f && p <= 1.f)) { err = "InvalidParameter: TrimmedDist ratio must be in [0, 1]"; return ICPMI_ERR_INVALID_ARG; }
+        if ((t == ICPMI_OUT_MAXDIST || t == ICPMI_OUT_MINDIST || t == ICPMI_OUT_MEDIANDIST) && !(p >= 0.f)) { err = "InvalidParameter: negative outlier filter parameter"; return ICPMI_ERR_INVALID_ARG; }
+    }
+    if (cfg->minimizer < ICPMI_MIN_IDENTITY || cfg->minimizer > ICPMI_MIN_POINT_TO_PLANE) { err = "InvalidParameter: unknown error minimizer"; return ICPMI_ERR_INVALID_ARG; }
+    if (cfg->max_iterations < 1) { err = "InvalidParameter: maxIterationCount must be >= 1"; return ICPMI_ERR_INVALID_ARG; }
+    if (cfg->use_differential && (cfg->smooth_length < 1 || cfg->smooth_length > ICPMI_MAX_SMOOTH)) { err = "InvalidParameter: smoothLength must be in [1, 16]"; return ICPMI_ERR_INVALID_ARG; }
+    if (cfg->grid_cell < 0.f) { err = "InvalidParameter: grid_cell must be >= 0"; return ICPMI_ERR_INVALID_ARG; }
+    return ICPMI_OK;
+}
+
+icpmi_status icpmi_create(const icpmi_config* cfg, icpmi_handle* out)
+{
+    if (!cfg || !out) { g_create_error = "icpmi_create: null argument"; return ICPMI_ERR_INVALID_ARG; }
+    *out = nullptr;
+    icpmi_status vs = validate_config(cfg, g_create_error);
+    if (vs != ICPMI_OK) return vs;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_error = std::string("icpmi_create: no HIP device available (") + hipGetErrorString(e) + ")";
+        return ICPMI_ERR_HIP;
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) { g_create_error = "icpmi_create: device ordinal out of range"; return ICPMI_ERR_INVALID_ARG; }
+    icpmi_ctx* c = new (std::nothrow) icpmi_ctx();
+    if (!c) { g_create_error = "icpmi_create: out of host memory"; return ICPMI_ERR_HIP; }
+    c->cfg = *cfg;
+    c->device = cfg->device;
+#define CR(expr)                                                                                      \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) {                                                                       \
+            g_create_error = std::string(#expr) + ": " + hipGetErrorString(_e);                       \
+            icpmi_destroy(c);                                                                         \
+            return ICPMI_ERR_HIP;                                                                     \
+        }                                                                                             \
+    } while (0)
+    CR(hipSetDevice(c->device));
+    CR(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+    CR(hipMalloc((void**)&c->d_state, sizeof(IcpState)));
+    CR(hipMemset(c->d_state, 0, sizeof(IcpState)));
+    CR(hipMalloc((void**)&c->d_selhist, ICPMI_SEL_BINS * sizeof(unsigned)));
+    CR(hipMemset(c->d_selhist, 0, ICPMI_SEL_BINS * sizeof(unsigned)));
+    CR(hipHostMalloc((void**)&c->h_state, sizeof(IcpState), hipHostMallocDefault));
+    CR(hipEventCreate(&c->ev0));
+    CR(hipEventCreate(&c->ev1));
+#undef CR
+    *out = c;
+    return ICPMI_OK;
+}
+
+void icpmi_destroy(icpmi_handle c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
+    hipFree(c->d_map_sorted); hipFree(c->d_normals_sorted); hipFree(c->d_cell_start);
+    hipFree(c->d_keys); hipFree(c->d_fill); hipFree(c->d_blocksums); hipFree(c->d_red);
+    hipFree(c->d_reading); hipFree(c->d_read_normals); hipFree(c->d_stage_in); hipFree(c->d_stage_n3);
+    hipFree(c->d_sidx); hipFree(c->d_d2); hipFree(c->d_hard); hipFree(c->d_partials); hipFree(c->d_selhist);
+    hipFree(c->d_state);
+    if (c->h_state) hipHostFree(c->h_state);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    for (hipEvent_t e : c->nn_events) hipEventDestroy(e);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* icpmi_last_error(icpmi_handle h) { return h ? h->last_error.c_str() : g_create_error.c_str(); }
+
+icpmi_status icpmi_set_stream(icpmi_handle h, void* hip_stream)
+{
+    CHECK_H(h);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    h->stream = (hipStream_t)hip_stream;
+    h->own_stream = false;
+    if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; h->graph_n = -1; }
+    return ICPMI_OK;
+}
+
+int32_t icpmi_has_map(icpmi_handle h) { return h && h->m > 0 ? 1 : 0; }
+
+icpmi_status icpmi_get_map_mean(icpmi_handle h, float mean3[3])
+{
+    if (!h || !mean3) return ICPMI_ERR_INVALID_ARG;
+    memcpy(mean3, h->mean, 3 * sizeof(float));
+    return ICPMI_OK;
+}
+
+icpmi_status icpmi_get_grid_info(icpmi_handle h, float* cell, int32_t dims[3], int64_t* n_cells, int64_t* n_occupied)
+{
+    if (!h) return ICPMI_ERR_INVALID_ARG;
+    if (cell) *cell = h->grid.cell;
+    if (dims) { dims[0] = h->grid.nx; dims[1] = h->grid.ny; dims[2] = h->grid.nz; }
+    if (n_cells) *n_cells = h->grid.ncells;
+    if (n_occupied) *n_occupied = h->n_occupied;
+    return ICPMI_OK;
+}
+
+icpmi_status icpmi_set_map_dev(icpmi_handle h, const float* d_map4, int64_t m, const float* d_normals3, int32_t* accepted)
+{
+    CHECK_H(h);
+    if (accepted) *accepted = 0;
+    if (m < 0 || (m > 0 && !d_map4)) { h->last_error = "set_map: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
+    if (m == 0) return ICPMI_OK; // upstream: "Ignoring attempt to setMap with an empty map", returns false
+    if (m > 0x7fffffff) { h->last_error = "set_map: more than 2^31-1 points"; return ICPMI_ERR_UNSUPPORTED; }
+    if (h->cfg.minimizer == ICPMI_MIN_POINT_TO_PLANE && !d_normals3) {
+        // upstream fails later, inside the minimiser, with InvalidField("normals"); keep the map and
+        // let icpmi_register report it
+    }
+    icpmi_status s = map_build(h, (const float4*)d_map4, m, d_normals3);
+    if (s != ICPMI_OK) return s;
+    if (accepted) *accepted = 1;
+    return ICPMI_OK;
+}
+
+icpmi_status icpmi_set_map(icpmi_handle h, const float* map4, int64_t m, const float* normals3, int32_t* accepted)
+{
+    CHECK_H(h);
+    if (accepted) *accepted = 0;
+    if (m < 0 || (m > 0 && !map4)) { h->last_error = "set_map: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
+    if (m == 0) return ICPMI_OK;
+    if (ensure_cap(h, &h->d_stage_in, &h->cap_stage_in, (size_t)m) != ICPMI_OK) return ICPMI_ERR_HIP;
+    HIP_TRY(h, hipMemcpyAsync(h->d_stage_in, map4, (size_t)m * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+    if (normals3) {
+        if (ensure_cap(h, &h->d_stage_n3, &h->cap_stage_n3, (size_t)m * 3) != ICPMI_OK) return ICPMI_ERR_HIP;
+        HIP_TRY(h, hipMemcpyAsync(h->d_stage_n3, normals3, (size_t)m * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    }
+    return icpmi_set_map_dev(h, (const float*)h->d_stage_in, m, normals3 ? h->d_stage_n3 : nullptr, accepted);
+}
+
+static void identity16(float* T) { for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.f : 0.f; }
+
+static icpmi_status register_impl(icpmi_handle h, const float* d_scan4, int64_t n, const float* d_n3, int fixed_iters,
+                                  float T_out[16], icpmi_stats* stats)
+{
+    if (!T_out) { h->last_error = "register: T_out is null"; return ICPMI_ERR_INVALID_ARG; }
+    if (stats) memset(stats, 0, sizeof *stats);
+    identity16(T_out);
+    if (n < 0 || (n > 0 && !d_scan4)) { h->last_error = "register: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
+    if (h->m <= 0) return ICPMI_OK; // "Ignoring attempt to perform ICP with an empty map" -> identity
+    if (n > 0x7fffffff / ICPMI_MAX_K) { h->last_error = "register: too many points"; return ICPMI_ERR_UNSUPPORTED; }
+    if (h->cfg.minimizer == ICPMI_MIN_POINT_TO_PLANE && !h->has_normals) {
+        h->last_error = "InvalidField: PointToPlaneErrorMinimizer needs the descriptor 'normals' on the map";
+        return ICPMI_ERR_MISSING_NORMALS;
+    }
+    bool needs_rn = false;
+    for (int f = 0; f < h->cfg.n_outlier; ++f) needs_rn |= h->cfg.outlier[f].type == ICPMI_OUT_SURFACENORMAL;
+    if (needs_rn && (!d_n3 || !h->has_normals)) {
+        h->last_error = "InvalidField: SurfaceNormalOutlierFilter needs 'normals' on both reading and map";
+        return ICPMI_ERR_MISSING_NORMALS;
+    }
+    LoopCfg lc = make_loop_cfg(h, fixed_iters);
+    lc.has_read_normals = needs_rn ? 1 : 0;
+    if (n == 0) {
+        // upstream: Trimmed/Median throw "no outlier to filter", otherwise "no point to minimize"
+        bool quant = false;
+        for (int f = 0; f < lc.n_out; ++f) quant |= lc.out_type[f] == ICPMI_OUT_TRIMMEDDIST || lc.out_type[f] == ICPMI_OUT_MEDIANDIST;
+        h->last_error = quant ? "ConvergenceError: no outlier to filter" : "ConvergenceError: ErrorMinimizer: no point to minimize";
+        return quant ? ICPMI_ERR_NO_OUTLIER_TO_FILTER : ICPMI_ERR_NO_POINT_TO_MINIMIZE;
+    }
+    icpmi_status s = loop_prepare_reading(h, (const float4*)d_scan4, n, needs_rn ? d_n3 : nullptr);
+    if (s != ICPMI_OK) return s;
+    return loop_run(h, n, lc, fixed_iters > 0, T_out, stats);
+}
+
+icpmi_status icpmi_register_dev(icpmi_handle h, const float* d_scan4, int64_t n, const float* d_scan_normals3, float T_out[16],
+                                icpmi_stats* stats)
+{
+    CHECK_H(h);
+    return register_impl(h, d_scan4, n, d_scan_normals3, 0, T_out, stats);
+}
+
+icpmi_status icpmi_register_fixed_dev(icpmi_handle h, const float* d_scan4, int64_t n, const float* d_scan_normals3,
+                                      int32_t iterations, float T_out[16], icpmi_stats* stats)
+{
+    CHECK_H(h);
+    if (iterations < 1) { h->last_error = "register_fixed: iterations must be >= 1"; return ICPMI_ERR_INVALID_ARG; }
+    return register_impl(h, d_scan4, n, d_scan_normals3, iterations, T_out, stats);
+}
+
+icpmi_status icpmi_register(icpmi_handle h, const float* scan4, int64_t n, const float* scan_normals3, float T_out[16],
+                            icpmi_stats* stats)
+{
+    CHECK_H(h);
+    if (n < 0 || (n > 0 && !scan4)) { h->last_error = "register: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
+    const float* d_scan = nullptr;
+    const float* d_n3 = nullptr;
+    if (n > 0 && h->m > 0) {
+        if (ensure_cap(h, &h->d_stage_in, &h->cap_stage_in, (size_t)n) != ICPMI_OK) return ICPMI_ERR_HIP;
+        HIP_TRY(h, hipMemcpyAsync(h->d_stage_in, scan4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+        d_scan = (const float*)h->d_stage_in;
+        if (scan_normals3) {
+            if (ensure_cap(h, &h->d_stage_n3, &h->cap_stage_n3, (size_t)n * 3) != ICPMI_OK) return ICPMI_ERR_HIP;
+            HIP_TRY(h, hipMemcpyAsync(h->d_stage_n3, scan_normals3, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+            d_n3 = h->d_stage_n3;
+        }
+    } else if (n > 0) {
+        d_scan = scan4; // no map: never dereferenced
+    }
+    return register_impl(h, d_scan, n, d_n3, 0, T_out, stats);
+}
+
+icpmi_status icpmi_transform(icpmi_handle h, const float T[16], const float* in4, int64_t n, float* out4, const float* in_normals3,
+                             float* out_normals3)
+{
+    CHECK_H(h);
+    if (!T || n < 0 || (n > 0 && (!in4 || !out4))) { h->last_error = "transform: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
+    return ops_transform(h, T, in4, n, out4, in_normals3, out_normals3);
+}
+
+icpmi_status icpmi_knn(icpmi_handle h, const float* q4, int64_t n, int32_t k, float max_dist, int32_t allow_self, int32_t* ids,
+                       float* d2)
+{
+    CHECK_H(h);
+    if (n < 0 || k < 1 || k > ICPMI_MAX_K || (n > 0 && (!q4 || !ids || !d2)) || !(max_dist > 0.f)) {
+        h->last_error = "knn: bad arguments"; return ICPMI_ERR_INVALID_ARG;
+    }
+    if (n == 0) return ICPMI_OK;
+    if (h->m <= 0) {
+        for (int64_t i = 0; i < n * k; ++i) { ids[i] = -1; d2[i] = INFINITY; }
+        return ICPMI_OK;
+    }
+    const size_t cnt = (size_t)n * k + 1;
+    if (ensure_cap(h, &h->d_reading, &h->cap_reading, (size_t)n + 1) != ICPMI_OK || ensure_cap(h, &h->d_sidx, &h->cap_sidx, cnt) != ICPMI_OK ||
+        ensure_cap(h, &h->d_d2, &h->cap_d2, cnt) != ICPMI_OK || ensure_cap(h, &h->d_hard, &h->cap_hard, (size_t)n + 1) != ICPMI_OK)
+        return ICPMI_ERR_HIP;
+    HIP_TRY(h, hipMemcpyAsync(h->d_reading, q4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_state, 0, sizeof(IcpState), h->stream));
+    LoopCfg lc = make_loop_cfg(h, 1);
+    lc.k = k; lc.max_dist = max_dist;
+    lc.maxr2 = std::isinf(max_dist) ? INFINITY : max_dist * max_dist;
+    if (std::isfinite(max_dist)) {
+        const int need = (int)ceilf(max_dist / h->grid.cell) + 1;
+        lc.ring_max = need < 16 ? need : 16;
+    } else lc.ring_max = 6;
+    icpmi_status s = nn_launch_k(h, h->d_reading, n, nullptr, lc, allow_self, h->d_sidx, h->d_d2, h->d_state);
+    if (s != ICPMI_OK) return s;
+    int* d_ids = nullptr;
+    HIP_TRY(h, hipMalloc((void**)&d_ids, (size_t)n * k * sizeof(int)));
+    s = nn_ids_to_original(h, h->d_sidx, n * k, d_ids);
+    hipError_t e = hipSuccess;
+    if (s == ICPMI_OK) {
+        e = hipMemcpyAsync(ids, d_ids, (size_t)n * k * sizeof(int), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d2, h->d_d2, (size_t)n * k * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    }
+    hipFree(d_ids);
+    if (s != ICPMI_OK) return s;
+    HIP_TRY(h, e);
+    return ICPMI_OK;
+}
+
+icpmi_status icpmi_outlier_weights(icpmi_handle h, const float* d2, const int32_t* ids, int32_t k, int64_t n,
+                                   const float* read_normals3, float* weights, float* limit_out)
+{
+    CHECK_H(h);
+    if (k < 1 || n < 0 || (n > 0 && (!d2 || !weights))) { h->last_error = "outlier_weights: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
+    if (n == 0) return ICPMI_OK;
+    LoopCfg lc = make_loop_cfg(h, 1);
+    return loop_outlier_weights(h, lc, d2, ids, k, n, read_normals3, weights, limit_out);
+}
+
+icpmi_status icpmi_minimize_step(icpmi_handle h, const float* reading4, int64_t n, const float* T_iter, float T_step[16],
+                                 double sums[32], icpmi_stats* stats)
+{
+    CHECK_H(h);
+    if (n <= 0 || !reading4) { h->last_error = "minimize_step: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
+    if (h->m <= 0) { h->last_error = "minimize_step: no map"; return ICPMI_ERR_INVALID_ARG; }
+    if (h->cfg.minimizer == ICPMI_MIN_POINT_TO_PLANE && !h->has_normals) {
+        h->last_error = "InvalidField: PointToPlaneErrorMinimizer needs the descriptor 'normals' on the map";
+        return ICPMI_ERR_MISSING_NORMALS;
+    }
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (ensure_cap(h, &h->d_reading, &h->cap_reading, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    HIP_TRY(h, hipMemcpyAsync(h->d_reading, reading4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+    LoopCfg lc = make_loop_cfg(h, 1);
+    for (int f = 0; f < lc.n_out; ++f)
+        if (lc.out_type[f] == ICPMI_OUT_SURFACENORMAL) { h->last_error = "minimize_step: SurfaceNormal filter needs icpmi_register"; return ICPMI_ERR_UNSUPPORTED; }
+    return loop_single_step(h, n, lc, T_iter, T_step, sums, stats);
+}
+
+icpmi_status icpmi_surface_normals(icpmi_handle h, const float* pts4, int64_t m, int32_t knn, float* normals3)
+{
+    CHECK_H(h);
+    if (m < 0 || (m > 0 && (!pts4 || !normals3))) { h->last_error = "surface_normals: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
+    return ops_surface_normals(h, pts4, m, knn, normals3);
+}
+
+icpmi_status icpmi_point_distance_keep(icpmi_handle h, const float* map4, int64_t m, const float* in4, int64_t n, float min_dist,
+                                       uint8_t* keep)
+{
+    CHECK_H(h);
+    if (m < 0 || n < 0 || (m > 0 && !map4) || (n > 0 && (!in4 || !keep))) { h->last_error = "point_distance_keep: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
+    return ops_point_distance_keep(h, map4, m, in4, n, min_dist, keep);
+}
+
+icpmi_status icpmi_bin_cells(icpmi_handle h, const float* pts4, int64_t n, float cell_size, int32_t* ijk3)
+{
+    CHECK_H(h);
+    if (n < 0 || !(cell_size > 0.f) || (n > 0 && (!pts4 || !ijk3))) { h->last_error = "bin_cells: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
+    return ops_bin_cells(h, pts4, n, cell_size, ijk3);
+}
+
+} // extern "C"

@@ -1,0 +1,185 @@
+// common.h -- internal declarations shared by the HIP translation units of libicpmi.so.
+// Target: gfx950 (MI355X, CDNA4), wave64. Not a public header (the public one is include/icpmi.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include <string>
+#include <vector>
+#include <unordered_map>
+
+#include "../../include/icpmi.h"
+
+#define ICPMI_MAX_OUTLIER 8
+#define ICPMI_MAX_SMOOTH 16
+#define ICPMI_SEL_BINS 2048
+#define ICPMI_NV 32            // doubles per block partial in the minimiser reduction
+#define ICPMI_MAX_K 32
+
+// ------------------------------------------------------------------------------------------------
+// NN grid (built by set_map on the centred map).  Dense uniform grid; cells are x-fastest so the
+// three x-neighbours of a cell row are one contiguous run of the cell-sorted point array.
+// ------------------------------------------------------------------------------------------------
+struct GridParams {
+    float ox, oy, oz;      // min corner (centred frame)
+    float cell, inv_cell;  // cell edge and its reciprocal
+    float slack;           // conservative distance slack for prune / termination tests
+    int   nx, ny, nz;
+    int   ncells;
+};
+
+// Device-side description of the ICP chain for one registration (passed by value to kernels).
+struct LoopCfg {
+    int   k;
+    float max_dist;        // un-squared; +inf allowed
+    float maxr2;           // max_dist^2 (+inf allowed)
+    int   ring_max;        // rings searched on the grid before a query goes to the brute pass
+    int   minimizer;
+    int   n_out;
+    int   out_type[ICPMI_MAX_OUTLIER];
+    float out_param[ICPMI_MAX_OUTLIER];
+    int   max_iter;
+    int   use_diff;
+    float min_rot, min_trans;
+    int   smooth;
+    int   use_bound;
+    float max_rot, max_trans;
+    int   has_read_normals;
+};
+
+// Device-resident loop state (one per handle).  Everything the iteration needs between kernels
+// lives here so that the loop never synchronises with the host.
+struct IcpState {
+    float T_iter[16];
+    int   iter;
+    int   done;
+    int   error;           // icpmi_status (0 = ok)
+    int   stop_reason;
+    int   counter;
+    int   hist_n;          // number of poses pushed to the differential checker
+    double hq[(ICPMI_MAX_SMOOTH + 1) * 4];
+    double ht[(ICPMI_MAX_SMOOTH + 1) * 3];
+    double init_q[4];
+    // quantile selection
+    unsigned sel_prefix;
+    unsigned sel_rank;
+    unsigned n_valid;
+    float limits[ICPMI_MAX_OUTLIER];
+    // statistics of the last iteration
+    long long pairs;
+    double wsum;
+    unsigned hard_count;
+    unsigned long long hard_total;
+    // result
+    float T_out[16];
+};
+
+struct icpmi_ctx {
+    icpmi_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string last_error;
+
+    // map
+    int64_t m = 0;
+    float mean[3] = {0, 0, 0};
+    GridParams grid{};
+    int64_t n_occupied = 0;
+    float4* d_map_sorted = nullptr;     // xyz centred, w = bits of the original index
+    float4* d_normals_sorted = nullptr; // xyz normal, w unused; nullptr if the map has no normals
+    unsigned* d_cell_start = nullptr;   // ncells + 1
+    size_t cap_map = 0, cap_cells = 0, cap_normals = 0;
+    bool has_normals = false;
+
+    // scratch for set_map
+    unsigned* d_keys = nullptr; size_t cap_keys = 0;
+    unsigned* d_fill = nullptr; size_t cap_fill = 0;
+    unsigned* d_blocksums = nullptr; size_t cap_blocksums = 0;
+    double* d_red = nullptr; size_t cap_red = 0;
+
+    // reading-side buffers (capacity in entries)
+    float4* d_reading = nullptr; size_t cap_reading = 0;       // centred reading
+    float4* d_read_normals = nullptr; size_t cap_read_normals = 0;
+    float4* d_stage_in = nullptr; size_t cap_stage_in = 0;     // host->device staging
+    float*  d_stage_n3 = nullptr; size_t cap_stage_n3 = 0;
+    int*    d_sidx = nullptr; size_t cap_sidx = 0;             // k x n sorted-map index (-1 none)
+    float*  d_d2 = nullptr; size_t cap_d2 = 0;                 // k x n
+    unsigned* d_hard = nullptr; size_t cap_hard = 0;           // hard query list
+    double* d_partials = nullptr; size_t cap_partials = 0;
+    unsigned* d_selhist = nullptr;                             // ICPMI_SEL_BINS
+    IcpState* d_state = nullptr;
+    IcpState* h_state = nullptr;                               // pinned mirror
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> nn_events;
+
+    // cached graph of one full fixed-count loop
+    hipGraphExec_t graph_exec = nullptr;
+    int64_t graph_n = -1; int graph_iters = -1; uint64_t graph_sig = 0;
+};
+
+#define HIP_TRY(ctx, expr)                                                                     \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(_e);             \
+            return ICPMI_ERR_HIP;                                                              \
+        }                                                                                      \
+    } while (0)
+
+template <typename T>
+static inline icpmi_status ensure_cap(icpmi_ctx* c, T** p, size_t* cap, size_t need)
+{
+    if (need <= *cap && *p) return ICPMI_OK;
+    if (*p) { HIP_TRY(c, hipFree(*p)); *p = nullptr; *cap = 0; }
+    size_t want = need + need / 4 + 64;
+    HIP_TRY(c, hipMalloc((void**)p, want * sizeof(T)));
+    *cap = want;
+    return ICPMI_OK;
+}
+
+// ---- device helpers -------------------------------------------------------------------------
+__device__ __forceinline__ float3 xf_point(const float* __restrict__ T, float x, float y, float z, float w)
+{
+    // Same evaluation order as the oracle: column-by-column accumulation with fused multiply-adds.
+    float3 o;
+    o.x = fmaf(T[12], w, fmaf(T[8], z, fmaf(T[4], y, T[0] * x)));
+    o.y = fmaf(T[13], w, fmaf(T[9], z, fmaf(T[5], y, T[1] * x)));
+    o.z = fmaf(T[14], w, fmaf(T[10], z, fmaf(T[6], y, T[2] * x)));
+    return o;
+}
+
+__device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz)
+{
+    const float dx = ax - bx, dy = ay - by, dz = az - bz;
+    return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+}
+
+__device__ __forceinline__ unsigned long long pack_key(float d2, unsigned id)
+{
+    return ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)id;
+}
+
+// ---- cross-TU host entry points ---------------------------------------------------------------
+icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float* d_normals3);
+icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, const float* d_T, const LoopCfg& lc,
+                          int allow_self, int* d_sidx, float* d_d2, IcpState* d_state);
+icpmi_status nn_launch_k(icpmi_ctx* c, const float4* d_reading, int64_t n, const float* d_T, const LoopCfg& lc,
+                         int allow_self, int* d_sidx, float* d_d2, IcpState* d_state);
+icpmi_status nn_ids_to_original(icpmi_ctx* c, const int* d_sidx, int64_t count, int* d_ids);
+icpmi_status loop_run(icpmi_ctx* c, int64_t n, const LoopCfg& lc, bool fixed, float T_out[16], icpmi_stats* stats);
+icpmi_status loop_prepare_reading(icpmi_ctx* c, const float4* d_scan, int64_t n, const float* d_normals3);
+icpmi_status loop_single_step(icpmi_ctx* c, int64_t n, const LoopCfg& lc, const float* T_iter_host, float T_step[16],
+                              double sums[32], icpmi_stats* stats);
+icpmi_status loop_outlier_weights(icpmi_ctx* c, const LoopCfg& lc, const float* d2, const int32_t* ids, int k, int64_t n,
+                                  const float* read_normals3, float* weights, float* limit_out);
+LoopCfg make_loop_cfg(const icpmi_ctx* c, int fixed_iterations);
+
+icpmi_status ops_transform(icpmi_ctx* c, const float T[16], const float* in4, int64_t n, float* out4,
+                           const float* in_n3, float* out_n3);
+icpmi_status ops_surface_normals(icpmi_ctx* c, const float* pts4, int64_t m, int knn, float* normals3);
+icpmi_status ops_point_distance_keep(icpmi_ctx* c, const float* map4, int64_t m, const float* in4, int64_t n,
+                                     float min_dist, uint8_t* keep);
+icpmi_status ops_bin_cells(icpmi_ctx* c, const float* pts4, int64_t n, float cell_size, int32_t* ijk3);

@@ -1,0 +1,916 @@
+// loop.hip -- the device-resident ICP iteration (PM::ICPSequence::operator(), reference call site
+// norlab_icp_mapper/Mapper.cpp:213; loop body SURVEY.md B.1):
+//     transform (fused into the NN query load) -> kNN -> outlier weights -> pair sums -> solve ->
+//     compose -> checkers
+// Per iteration the stream carries: the NN kernel (nn.hip), for each quantile-type outlier filter a
+// 3-pass radix select on the float bits of d^2 (exact nth_element equivalent), one accumulation
+// kernel and one single-wave solve kernel.  All decisions (convergence, errors) stay on the device
+// in IcpState; kernels of a finished loop exit on st->done.
+#include "common.h"
+#include <cstring>
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// quantile selection == Matches::getDistsQuantile: over entries that are finite
+// and > 0, element of rank (size_t)(count * quantile) [float product], quantile == 1 -> max.
+// d2 >= 0 so the IEEE bit pattern orders like an unsigned integer: 3 radix passes 11/11/10 bits.
+// ---------------------------------------------------------------------------------------------
+template <int PASS>
+__global__ __launch_bounds__(256) void sel_hist_kernel(const float* __restrict__ d2, int64_t count,
+                                                       const IcpState* __restrict__ st, unsigned* __restrict__ ghist)
+{
+    if (st->done) return;
+    __shared__ unsigned h[ICPMI_SEL_BINS];
+    for (int b = threadIdx.x; b < ICPMI_SEL_BINS; b += 256) h[b] = 0;
+    __syncthreads();
+    const unsigned prefix = st->sel_prefix;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+        const float v = d2[i];
+        if (!(v != INFINITY && v > 0.f)) continue;
+        const unsigned bits = __float_as_uint(v);
+        if (PASS == 0) atomicAdd(&h[bits >> 21], 1u);
+        else if (PASS == 1) { if ((bits >> 21) == prefix) atomicAdd(&h[(bits >> 10) & 2047u], 1u); }
+        else { if ((bits >> 10) == prefix) atomicAdd(&h[bits & 1023u], 1u); }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < ICPMI_SEL_BINS; b += 256)
+        if (h[b]) atomicAdd(&ghist[b], h[b]);
+}
+
+// single workgroup: locate the bin holding the wanted rank, narrow prefix / rank, clear the histogram
+template <int PASS>
+__global__ __launch_bounds__(256) void sel_scan_kernel(IcpState* __restrict__ st, unsigned* __restrict__ ghist, float quantile,
+                                                       int filter_slot, int is_median, float factor)
+{
+    if (st->done) return;
+    __shared__ unsigned sh[256];
+    __shared__ unsigned s_rank;
+    const int t = threadIdx.x;
+    unsigned v[8], s = 0;
+    for (int e = 0; e < 8; ++e) { v[e] = ghist[t * 8 + e]; s += v[e]; ghist[t * 8 + e] = 0; }
+    sh[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        unsigned add = t >= off ? sh[t - off] : 0u;
+        __syncthreads();
+        sh[t] += add;
+        __syncthreads();
+    }
+    const unsigned incl = sh[t], excl = incl - s, total = sh[255];
+    if (t == 0) {
+        if (PASS == 0) {
+            st->n_valid = total;
+            if (total == 0) { st->error = ICPMI_ERR_NO_OUTLIER_TO_FILTER; st->done = 1; s_rank = 0; }
+            else {
+                unsigned r;
+                if (quantile == 1.0f) r = total - 1;
+                else {
+                    r = (unsigned)((float)total * quantile);
+                    if (r > total - 1) r = total - 1;
+                }
+                s_rank = r;
+            }
+        } else s_rank = st->sel_rank;
+    }
+    __syncthreads();
+    if (total == 0) return;
+    const unsigned rank = s_rank;
+    if (rank >= excl && rank < incl) {
+        unsigned acc = excl;
+        int bin = t * 8;
+        for (int e = 0; e < 8; ++e) {
+            if (rank < acc + v[e]) { bin = t * 8 + e; break; }
+            acc += v[e];
+        }
+        const unsigned prev = PASS == 0 ? 0u : st->sel_prefix;
+        const unsigned np = PASS == 0 ? (unsigned)bin : (PASS == 1 ? ((prev << 11) | (unsigned)bin) : ((prev << 10) | (unsigned)bin));
+        st->sel_prefix = np;
+        st->sel_rank = rank - acc;
+        if (PASS == 2) {
+            const float q = __uint_as_float(np);
+            st->limits[filter_slot] = is_median ? factor * q : q;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// outlier weight of one match (OutlierFilters::compute; weights multiply)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float match_weight(const LoopCfg& lc, const IcpState* __restrict__ st, float d2,
+                                              const float* __restrict__ T, const float4* __restrict__ read_normals, int qi,
+                                              const float4* __restrict__ ref_normals, int sidx)
+{
+    float w = 1.f;
+    for (int f = 0; f < lc.n_out; ++f) {
+        const int type = lc.out_type[f];
+        const float prm = lc.out_param[f];
+        if (type == ICPMI_OUT_MAXDIST) w *= (d2 <= prm * prm) ? 1.f : 0.f;
+        else if (type == ICPMI_OUT_MINDIST) w *= (d2 >= prm * prm) ? 1.f : 0.f;
+        else if (type == ICPMI_OUT_MEDIANDIST || type == ICPMI_OUT_TRIMMEDDIST) w *= (d2 <= st->limits[f]) ? 1.f : 0.f;
+        else if (type == ICPMI_OUT_SURFACENORMAL) {
+            const float4 a = read_normals[qi];
+            float ax = a.x, ay = a.y, az = a.z;
+            if (T) { // descriptors named "normals" rotate with the cloud
+                const float rx = fmaf(T[8], az, fmaf(T[4], ay, T[0] * ax));
+                const float ry = fmaf(T[9], az, fmaf(T[5], ay, T[1] * ax));
+                const float rz = fmaf(T[10], az, fmaf(T[6], ay, T[2] * ax));
+                ax = rx; ay = ry; az = rz;
+            }
+            const float4 b = ref_normals[sidx];
+            const float dot = fmaf(az, b.z, fmaf(ay, b.y, ax * b.x));
+            w *= (dot > cosf(prm)) ? 1.f : 0.f;
+        }
+    }
+    return w;
+}
+
+// ---------------------------------------------------------------------------------------------
+// pair sums (ErrorMinimizer::compute gather + the products of SURVEY.md B.5 / B.6)
+// layout of the ICPMI_NV doubles:
+//   point-to-plane: [0..20] upper triangle of A row-major, [21..26] b
+//   point-to-point: [0] sum w, [1..3] sum w p, [4..6] sum w q, [7 + 3c + r] sum w q_r p_c
+//   always:         [27] sum w, [28] number of pairs
+// ---------------------------------------------------------------------------------------------
+template <int MIN>
+__global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restrict__ reading, int n, LoopCfg lc,
+                                                         const IcpState* __restrict__ st, const float4* __restrict__ map,
+                                                         const float4* __restrict__ normals,
+                                                         const float4* __restrict__ read_normals,
+                                                         const int* __restrict__ sidx, const float* __restrict__ d2a,
+                                                         double* __restrict__ partials)
+{
+    if (st->done) return;
+    constexpr int NVAL = MIN == ICPMI_MIN_POINT_TO_PLANE ? 27 : (MIN == ICPMI_MIN_POINT_TO_POINT ? 16 : 0);
+    double acc[NVAL > 0 ? NVAL : 1];
+#pragma unroll
+    for (int i = 0; i < (NVAL > 0 ? NVAL : 1); ++i) acc[i] = 0.0;
+    double wsum = 0.0, cnt = 0.0;
+    const float* T = st->T_iter;
+    const int64_t count = (int64_t)n * lc.k;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < count; e += (int64_t)gridDim.x * 256) {
+        const float d2 = d2a[e];
+        if (d2 == INFINITY) continue;
+        const int s = sidx[e];
+        const int qi = (int)(e / lc.k);
+        const float w = match_weight(lc, st, d2, T, read_normals, qi, normals, s);
+        if (w == 0.f) continue;
+        wsum += w; cnt += 1.0;
+        if (MIN == ICPMI_MIN_IDENTITY) continue;
+        const float4 r = reading[qi];
+        const float3 p = xf_point(T, r.x, r.y, r.z, r.w);
+        const float4 q = map[s];
+        if (MIN == ICPMI_MIN_POINT_TO_POINT) {
+            const double dw = w;
+            acc[0] += dw;
+            acc[1] += dw * p.x; acc[2] += dw * p.y; acc[3] += dw * p.z;
+            acc[4] += dw * q.x; acc[5] += dw * q.y; acc[6] += dw * q.z;
+            const double wq[3] = {dw * q.x, dw * q.y, dw * q.z};
+            const float pc[3] = {p.x, p.y, p.z};
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr) acc[7 + 3 * c + rr] += wq[rr] * pc[c];
+        } else if (MIN == ICPMI_MIN_POINT_TO_PLANE) {
+            const float4 nn = normals[s];
+            // per-pair quantities in float exactly as the oracle (and Eigen) form them
+            const float F[6] = {p.y * nn.z - p.z * nn.y, p.z * nn.x - p.x * nn.z, p.x * nn.y - p.y * nn.x, nn.x, nn.y, nn.z};
+            const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+            const float dot = dx * nn.x + dy * nn.y + dz * nn.z;
+            int idx = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                const double wf = (double)w * F[a];
+#pragma unroll
+                for (int b = a; b < 6; ++b) acc[idx++] += wf * F[b];
+                acc[21 + a] -= wf * dot;
+            }
+        }
+    }
+    // ---- workgroup reduction: wave64 shuffles, then LDS across the 4 waves ----
+    __shared__ double sh[4][ICPMI_NV];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NVAL; ++i) {
+        double v = acc[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) sh[wv][i] = v;
+    }
+    {
+        double v = wsum, c2 = cnt;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { v += __shfl_down(v, off, 64); c2 += __shfl_down(c2, off, 64); }
+        if (lane == 0) { sh[wv][27] = v; sh[wv][28] = c2; }
+    }
+    __syncthreads();
+    if (threadIdx.x < ICPMI_NV) {
+        const int i = threadIdx.x;
+        double v = 0.0;
+        if (i < NVAL || i == 27 || i == 28) v = sh[0][i] + sh[1][i] + sh[2][i] + sh[3][i];
+        partials[(size_t)blockIdx.x * ICPMI_NV + i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// small dense algebra for the single-lane solve
+// ---------------------------------------------------------------------------------------------
+__device__ void mat4_mul_dev(const float* A, const float* B, float* C)
+{
+    float R[16];
+    for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 4; ++i) {
+            float s = A[i] * B[4 * j];
+            for (int kk = 1; kk < 4; ++kk) s = fmaf(A[4 * kk + i], B[4 * j + kk], s);
+            R[4 * j + i] = s;
+        }
+    for (int i = 0; i < 16; ++i) C[i] = R[i];
+}
+
+// symmetric Jacobi eigen-decomposition (double), n <= 6, col-major
+__device__ void jacobi_eig(int n, const double* Ain, double* w, double* Q)
+{
+    double A[36];
+    for (int i = 0; i < n * n; ++i) A[i] = Ain[i];
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) Q[n * j + i] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0;
+        for (int p = 0; p < n; ++p) for (int q = p + 1; q < n; ++q) off += A[n * q + p] * A[n * q + p];
+        if (off < 1e-300) break;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = A[n * q + p];
+                if (apq == 0.0) continue;
+                const double theta = (A[n * q + q] - A[n * p + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int kk = 0; kk < n; ++kk) {
+                    const double akp = A[n * p + kk], akq = A[n * q + kk];
+                    A[n * p + kk] = c * akp - s * akq; A[n * q + kk] = s * akp + c * akq;
+                }
+                for (int kk = 0; kk < n; ++kk) {
+                    const double apk = A[n * kk + p], aqk = A[n * kk + q];
+                    A[n * kk + p] = c * apk - s * aqk; A[n * kk + q] = s * apk + c * aqk;
+                }
+                for (int kk = 0; kk < n; ++kk) {
+                    const double qkp = Q[n * p + kk], qkq = Q[n * q + kk];
+                    Q[n * p + kk] = c * qkp - s * qkq; Q[n * q + kk] = s * qkp + c * qkq;
+                }
+            }
+    }
+    for (int i = 0; i < n; ++i) w[i] = A[n * i + i];
+}
+
+// Rotation of the point-to-point minimiser: R = U V^T of the float 3x3 H = U S V^T,
+// with the last row of V^T negated when det(R) < 0.  The SVD is a one-sided (Hestenes) Jacobi in
+// float -- the numeric spec shared with the oracle: cyclic (0,1),(0,2),(1,2) sweeps on the columns,
+// rotation skipped below 1e-9 relative off-diagonal, stop at 1e-7, singular values sorted
+// descending, columns of U belonging to (near) zero singular values completed by cross products.
+__device__ void svd3f_dev(const float* H, float* U, float* s, float* V)
+{
+    float a[9], v[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int i = 0; i < 9; ++i) a[i] = H[i];
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        float off = 0.f;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                float alpha = 0, beta = 0, gamma = 0;
+                for (int i = 0; i < 3; ++i) {
+                    alpha += a[3 * p + i] * a[3 * p + i];
+                    beta += a[3 * q + i] * a[3 * q + i];
+                    gamma += a[3 * p + i] * a[3 * q + i];
+                }
+                if (gamma == 0.f) continue;
+                const float lim = fabsf(gamma) / sqrtf(fmaxf(alpha * beta, 1.17549435e-38f));
+                if (lim > off) off = lim;
+                if (lim <= 1e-9f) continue;
+                const float zeta = (beta - alpha) / (2.f * gamma);
+                const float tt = (zeta >= 0.f ? 1.f : -1.f) / (fabsf(zeta) + sqrtf(1.f + zeta * zeta));
+                const float c = 1.f / sqrtf(1.f + tt * tt), sn = c * tt;
+                for (int i = 0; i < 3; ++i) {
+                    const float ap = a[3 * p + i], aq = a[3 * q + i];
+                    a[3 * p + i] = c * ap - sn * aq; a[3 * q + i] = sn * ap + c * aq;
+                    const float vp = v[3 * p + i], vq = v[3 * q + i];
+                    v[3 * p + i] = c * vp - sn * vq; v[3 * q + i] = sn * vp + c * vq;
+                }
+            }
+        if (off <= 1e-7f) break;
+    }
+    float sv[3];
+    for (int j = 0; j < 3; ++j) sv[j] = sqrtf(a[3 * j] * a[3 * j] + a[3 * j + 1] * a[3 * j + 1] + a[3 * j + 2] * a[3 * j + 2]);
+    int ord[3] = {0, 1, 2};
+    for (int i = 0; i < 2; ++i)
+        for (int j = i + 1; j < 3; ++j)
+            if (sv[ord[j]] > sv[ord[i]]) { const int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
+    for (int j = 0; j < 3; ++j) {
+        const int o = ord[j];
+        s[j] = sv[o];
+        for (int i = 0; i < 3; ++i) { V[3 * j + i] = v[3 * o + i]; U[3 * j + i] = a[3 * o + i]; }
+    }
+    const float tiny = s[0] * 1e-6f;
+    bool good[3];
+    for (int j = 0; j < 3; ++j) {
+        good[j] = s[j] > tiny && s[j] > 0.f;
+        if (good[j]) for (int i = 0; i < 3; ++i) U[3 * j + i] /= s[j];
+    }
+    if (!good[0]) { for (int i = 0; i < 9; ++i) U[i] = (i % 4 == 0) ? 1.f : 0.f; return; }
+    if (!good[1]) {
+        const int m = fabsf(U[0]) < fabsf(U[1]) ? (fabsf(U[0]) < fabsf(U[2]) ? 0 : 2) : (fabsf(U[1]) < fabsf(U[2]) ? 1 : 2);
+        float e[3] = {0, 0, 0}; e[m] = 1.f;
+        const float d = U[m];
+        const float w[3] = {e[0] - d * U[0], e[1] - d * U[1], e[2] - d * U[2]};
+        const float nw = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+        for (int i = 0; i < 3; ++i) U[3 + i] = w[i] / nw;
+    }
+    if (!good[2] || !good[1]) {
+        U[6] = U[1] * U[5] - U[2] * U[4];
+        U[7] = U[2] * U[3] - U[0] * U[5];
+        U[8] = U[0] * U[4] - U[1] * U[3];
+    }
+}
+
+__device__ float det3f(const float* R)
+{
+    return R[0] * (R[4] * R[8] - R[7] * R[5]) - R[3] * (R[1] * R[8] - R[7] * R[2]) + R[6] * (R[1] * R[5] - R[4] * R[2]);
+}
+
+__device__ void rotation_from_H(const float* H, float* R)
+{
+    float U[9], s[3], V[9];
+    svd3f_dev(H, U, s, V);
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int j = 0; j < 3; ++j)
+            for (int i = 0; i < 3; ++i) {
+                float acc = 0.f;
+                for (int kk = 0; kk < 3; ++kk) acc += U[3 * kk + i] * V[3 * kk + j];
+                R[3 * j + i] = acc;
+            }
+        if (pass == 0 && det3f(R) < 0.f) { for (int i = 0; i < 3; ++i) V[6 + i] = -V[6 + i]; }
+        else break;
+    }
+}
+
+// solvePossiblyUnderdeterminedLinearSystem: float LLT when A is invertible, else
+// the minimum-norm solution (double symmetric pseudo-inverse) -- same rule as the oracle.
+__device__ void solve6(const float* A, const float* b, float* x)
+{
+    double Ad[36], w[6], Q[36];
+    for (int i = 0; i < 36; ++i) Ad[i] = A[i];
+    jacobi_eig(6, Ad, w, Q);
+    double wmax = 0, wmin = INFINITY;
+    for (int i = 0; i < 6; ++i) { if (fabs(w[i]) > wmax) wmax = fabs(w[i]); if (w[i] < wmin) wmin = w[i]; }
+    const double thr = 6.0 * 1.1920928955078125e-07 * wmax;
+    if (wmin > thr) {
+        float L[36];
+        for (int i = 0; i < 36; ++i) L[i] = 0.f;
+        bool ok = true;
+        for (int j = 0; j < 6 && ok; ++j) {
+            float d = A[6 * j + j];
+            for (int kk = 0; kk < j; ++kk) d -= L[6 * kk + j] * L[6 * kk + j];
+            if (!(d > 0.f)) { ok = false; break; }
+            const float ljj = sqrtf(d);
+            L[6 * j + j] = ljj;
+            for (int i = j + 1; i < 6; ++i) {
+                float s = A[6 * j + i];
+                for (int kk = 0; kk < j; ++kk) s -= L[6 * kk + i] * L[6 * kk + j];
+                L[6 * j + i] = s / ljj;
+            }
+        }
+        if (ok) {
+            float y[6];
+            for (int i = 0; i < 6; ++i) {
+                float s = b[i];
+                for (int kk = 0; kk < i; ++kk) s -= L[6 * kk + i] * y[kk];
+                y[i] = s / L[6 * i + i];
+            }
+            for (int i = 5; i >= 0; --i) {
+                float s = y[i];
+                for (int kk = i + 1; kk < 6; ++kk) s -= L[6 * i + kk] * x[kk];
+                x[i] = s / L[6 * i + i];
+            }
+            return;
+        }
+    }
+    double xd[6] = {0, 0, 0, 0, 0, 0};
+    for (int e = 0; e < 6; ++e) {
+        if (!(w[e] > thr)) continue;
+        double proj = 0;
+        for (int i = 0; i < 6; ++i) proj += Q[6 * e + i] * (double)b[i];
+        proj /= w[e];
+        for (int i = 0; i < 6; ++i) xd[i] += proj * Q[6 * e + i];
+    }
+    for (int i = 0; i < 6; ++i) x[i] = (float)xd[i];
+}
+
+__device__ void angle_axis_T(const float* x3, float* T)
+{
+    for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.f : 0.f;
+    const float nrm = sqrtf(x3[0] * x3[0] + x3[1] * x3[1] + x3[2] * x3[2]);
+    if (!(nrm > 0.f)) return;
+    const float ax = x3[0] / nrm, ay = x3[1] / nrm, az = x3[2] / nrm;
+    // sin / cos through double so that host libm and device ocml round to the same float
+    const float s = (float)sin((double)nrm), c = (float)cos((double)nrm);
+    const float sx = s * ax, sy = s * ay, sz = s * az;
+    const float cx = (1.f - c) * ax, cy = (1.f - c) * ay, cz = (1.f - c) * az;
+    float tmp;
+    tmp = cx * ay; T[4 * 1 + 0] = tmp - sz; T[4 * 0 + 1] = tmp + sz;
+    tmp = cx * az; T[4 * 2 + 0] = tmp + sy; T[4 * 0 + 2] = tmp - sy;
+    tmp = cy * az; T[4 * 2 + 1] = tmp - sx; T[4 * 1 + 2] = tmp + sx;
+    T[0] = cx * ax + c; T[5] = cy * ay + c; T[10] = cz * az + c;
+}
+
+__device__ void quat_from_T(const float* T, double* q)
+{
+    const double m00 = T[0], m11 = T[5], m22 = T[10];
+    double t = m00 + m11 + m22;
+    if (t > 0) {
+        t = sqrt(t + 1.0);
+        q[0] = 0.5 * t; t = 0.5 / t;
+        q[1] = ((double)T[4 * 1 + 2] - (double)T[4 * 2 + 1]) * t;
+        q[2] = ((double)T[4 * 2 + 0] - (double)T[4 * 0 + 2]) * t;
+        q[3] = ((double)T[4 * 0 + 1] - (double)T[4 * 1 + 0]) * t;
+    } else {
+        int i = 0;
+        if (m11 > m00) i = 1;
+        if (m22 > (i == 0 ? m00 : m11)) i = 2;
+        const int j = (i + 1) % 3, kk = (j + 1) % 3;
+        auto M = [&](int r, int c) { return (double)T[4 * c + r]; };
+        t = sqrt(M(i, i) - M(j, j) - M(kk, kk) + 1.0);
+        double v[3];
+        v[i] = 0.5 * t; t = 0.5 / t;
+        q[0] = (M(kk, j) - M(j, kk)) * t;
+        v[j] = (M(j, i) + M(i, j)) * t;
+        v[kk] = (M(kk, i) + M(i, kk)) * t;
+        q[1] = v[0]; q[2] = v[1]; q[3] = v[2];
+    }
+}
+
+__device__ double quat_angdist(const double* a, const double* b)
+{
+    const double w = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+    const double x = -a[0] * b[1] + a[1] * b[0] - a[2] * b[3] + a[3] * b[2];
+    const double y = -a[0] * b[2] + a[1] * b[3] + a[2] * b[0] - a[3] * b[1];
+    const double z = -a[0] * b[3] - a[1] * b[2] + a[2] * b[1] + a[3] * b[0];
+    return 2.0 * atan2(sqrt(x * x + y * y + z * z), fabs(w));
+}
+
+// ---------------------------------------------------------------------------------------------
+// single-wave kernel: ordered reduction of the block partials, solve, compose, checkers
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void solve_kernel(IcpState* __restrict__ st, const double* __restrict__ partials, int nblocks,
+                                                   LoopCfg lc, int n, float* __restrict__ T_step_out, double* __restrict__ sums_out)
+{
+    if (st->done) return;
+    __shared__ double tot[ICPMI_NV];
+    const int t = threadIdx.x;
+    if (t < ICPMI_NV) {
+        double s = 0.0;
+        for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * ICPMI_NV + t];
+        tot[t] = s;
+        if (sums_out) sums_out[t] = s;
+    }
+    __syncthreads();
+    if (t != 0) return;
+
+    const double wsum = tot[27];
+    const long long P = (long long)(tot[28] + 0.5);
+    st->pairs = P;
+    st->wsum = wsum;
+    if (P == 0) { st->error = ICPMI_ERR_NO_POINT_TO_MINIMIZE; st->done = 1; return; }
+
+    float Ts[16];
+    for (int i = 0; i < 16; ++i) Ts[i] = (i % 5 == 0) ? 1.f : 0.f;
+    if (lc.minimizer == ICPMI_MIN_POINT_TO_POINT) {
+        // H = sum w q p^T - (sum w q)(sum w p)^T / sum w, rounded to float like the reference's
+        // float matrices, then R = U V^T; t = mean_q - R mean_p
+        float H[9];
+        for (int c = 0; c < 3; ++c)
+            for (int r = 0; r < 3; ++r) H[3 * c + r] = (float)(tot[7 + 3 * c + r] - tot[4 + r] * tot[1 + c] / wsum);
+        float R[9];
+        rotation_from_H(H, R);
+        const float mp[3] = {(float)(tot[1] / wsum), (float)(tot[2] / wsum), (float)(tot[3] / wsum)};
+        const float mq[3] = {(float)(tot[4] / wsum), (float)(tot[5] / wsum), (float)(tot[6] / wsum)};
+        for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) Ts[4 * c + r] = R[3 * c + r];
+        for (int r = 0; r < 3; ++r) Ts[12 + r] = mq[r] - (R[r] * mp[0] + R[3 + r] * mp[1] + R[6 + r] * mp[2]);
+    } else if (lc.minimizer == ICPMI_MIN_POINT_TO_PLANE) {
+        float A[36], b[6], x[6];
+        int idx = 0;
+        for (int a = 0; a < 6; ++a)
+            for (int bb = a; bb < 6; ++bb) { const float v = (float)tot[idx++]; A[6 * a + bb] = v; A[6 * bb + a] = v; }
+        for (int a = 0; a < 6; ++a) b[a] = (float)tot[21 + a];
+        solve6(A, b, x);
+        angle_axis_T(x, Ts);
+        Ts[12] = x[3]; Ts[13] = x[4]; Ts[14] = x[5];
+    }
+    for (int i = 0; i < 16; ++i)
+        if (Ts[i] != Ts[i]) { st->error = ICPMI_ERR_NAN; st->done = 1; return; }
+    if (T_step_out) for (int i = 0; i < 16; ++i) T_step_out[i] = Ts[i];
+
+    float Ti[16];
+    mat4_mul_dev(Ts, st->T_iter, Ti);
+    for (int i = 0; i < 16; ++i) st->T_iter[i] = Ti[i];
+    st->iter += 1;
+
+    // ---- TransformationCheckers ----
+    bool iterate = true;
+    int reason = ICPMI_STOP_NONE;
+    st->counter += 1;
+    if (st->counter >= lc.max_iter) { iterate = false; reason = ICPMI_STOP_COUNTER; }
+    if (lc.use_diff) {
+        const int SL = lc.smooth;
+        const int RING = ICPMI_MAX_SMOOTH + 1;
+        const int slot = st->hist_n % RING;
+        quat_from_T(Ti, st->hq + 4 * slot);
+        for (int r = 0; r < 3; ++r) st->ht[3 * slot + r] = Ti[12 + r];
+        st->hist_n += 1;
+        const int hn = st->hist_n;
+        if (hn > SL) {
+            double rot = 0, tr = 0;
+            for (int i = hn - 1; i >= hn - SL; --i) {
+                const int a = i % RING, bq = (i - 1) % RING;
+                rot += fabs(quat_angdist(st->hq + 4 * a, st->hq + 4 * bq));
+                const double dx = st->ht[3 * a] - st->ht[3 * bq], dy = st->ht[3 * a + 1] - st->ht[3 * bq + 1],
+                             dz = st->ht[3 * a + 2] - st->ht[3 * bq + 2];
+                tr += sqrt(dx * dx + dy * dy + dz * dz);
+            }
+            rot /= SL; tr /= SL;
+            if (rot != rot || tr != tr) { st->error = ICPMI_ERR_NAN; st->done = 1; return; }
+            if (rot < (double)lc.min_rot && tr < (double)lc.min_trans) {
+                if (iterate) reason = ICPMI_STOP_DIFFERENTIAL;
+                iterate = false;
+            }
+        }
+    }
+    if (lc.use_bound) {
+        double q[4];
+        quat_from_T(Ti, q);
+        const double rot = fabs(quat_angdist(q, st->init_q));
+        const double nt = sqrt((double)Ti[12] * Ti[12] + (double)Ti[13] * Ti[13] + (double)Ti[14] * Ti[14]);
+        if (rot > (double)lc.max_rot || nt > (double)lc.max_trans) { st->error = ICPMI_ERR_BOUND; st->done = 1; return; }
+    }
+    if (!iterate) { st->done = 1; st->stop_reason = reason; }
+}
+
+__global__ __launch_bounds__(256) void centre_kernel(const float4* __restrict__ scan, int64_t n, float mx, float my, float mz,
+                                                     float4* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = scan[i];
+    // reading moved by T_refMean_dataIn = [I | -mean] through the same fmaf chain as a transform
+    out[i] = make_float4(fmaf(-mx, p.w, p.x), fmaf(-my, p.w, p.y), fmaf(-mz, p.w, p.z), p.w);
+}
+
+__global__ __launch_bounds__(256) void pad_normals_kernel(const float* __restrict__ n3, int64_t n, float4* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    out[i] = make_float4(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2], 0.f);
+}
+
+__global__ void init_state_kernel(IcpState* st, const float* T0)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int i = 0; i < 16; ++i) st->T_iter[i] = T0 ? T0[i] : ((i % 5 == 0) ? 1.f : 0.f);
+    st->iter = 0; st->done = 0; st->error = 0; st->stop_reason = 0; st->counter = 0;
+    quat_from_T(st->T_iter, st->hq);
+    for (int r = 0; r < 3; ++r) st->ht[r] = st->T_iter[12 + r];
+    for (int r = 0; r < 4; ++r) st->init_q[r] = st->hq[r];
+    st->hist_n = 1;
+    st->sel_prefix = 0; st->sel_rank = 0; st->n_valid = 0;
+    for (int f = 0; f < ICPMI_MAX_OUTLIER; ++f) st->limits[f] = -1.f;
+    st->pairs = 0; st->wsum = 0; st->hard_count = 0; st->hard_total = 0;
+}
+
+__global__ __launch_bounds__(256) void weights_kernel(int64_t count, LoopCfg lc, const IcpState* __restrict__ st,
+                                                      const float4* __restrict__ normals, const float4* __restrict__ read_normals,
+                                                      const int* __restrict__ sidx, const float* __restrict__ d2a,
+                                                      float* __restrict__ w)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= count) return;
+    const int s = sidx[e];
+    float wt = 1.f;
+    // the chain is evaluated on every entry like upstream (an invalid match has d2 = +inf and fails
+    // every "<= limit" test; SurfaceNormal needs a valid id)
+    bool needs_id = false;
+    for (int f = 0; f < lc.n_out; ++f) needs_id |= lc.out_type[f] == ICPMI_OUT_SURFACENORMAL;
+    if (needs_id && s < 0) wt = 0.f;
+    else wt = match_weight(lc, st, d2a[e], nullptr, read_normals, (int)(e / lc.k), normals, s < 0 ? 0 : s);
+    w[e] = wt;
+}
+
+uint64_t fnv(const void* p, size_t n, uint64_t h)
+{
+    const unsigned char* b = (const unsigned char*)p;
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+} // namespace
+
+LoopCfg make_loop_cfg(const icpmi_ctx* c, int fixed_iterations)
+{
+    LoopCfg lc;
+    memset(&lc, 0, sizeof lc);
+    const icpmi_config& cfg = c->cfg;
+    lc.k = cfg.knn < 1 ? 1 : cfg.knn;
+    lc.max_dist = cfg.max_dist;
+    lc.maxr2 = std::isinf(cfg.max_dist) ? INFINITY : cfg.max_dist * cfg.max_dist;
+    const int RING_CAP = 16;
+    if (std::isfinite(cfg.max_dist) && c->grid.cell > 0.f) {
+        const int need = (int)ceilf(cfg.max_dist / c->grid.cell) + 1;
+        lc.ring_max = need < RING_CAP ? need : RING_CAP;
+    } else lc.ring_max = 6;
+    if (lc.ring_max < 1) lc.ring_max = 1;
+    lc.minimizer = cfg.minimizer;
+    lc.n_out = cfg.n_outlier;
+    for (int f = 0; f < cfg.n_outlier && f < ICPMI_MAX_OUTLIER; ++f) {
+        lc.out_type[f] = cfg.outlier[f].type;
+        lc.out_param[f] = cfg.outlier[f].param;
+    }
+    if (fixed_iterations > 0) {
+        lc.max_iter = fixed_iterations; lc.use_diff = 0; lc.use_bound = 0;
+    } else {
+        lc.max_iter = cfg.max_iterations;
+        lc.use_diff = cfg.use_differential; lc.use_bound = cfg.use_bound;
+    }
+    lc.min_rot = cfg.min_diff_rot; lc.min_trans = cfg.min_diff_trans;
+    lc.smooth = cfg.smooth_length < 1 ? 1 : (cfg.smooth_length > ICPMI_MAX_SMOOTH ? ICPMI_MAX_SMOOTH : cfg.smooth_length);
+    lc.max_rot = cfg.max_rot_norm; lc.max_trans = cfg.max_trans_norm;
+    return lc;
+}
+
+icpmi_status loop_prepare_reading(icpmi_ctx* c, const float4* d_scan, int64_t n, const float* d_normals3)
+{
+    if (ensure_cap(c, &c->d_reading, &c->cap_reading, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    const int blocks = (int)((n + 255) / 256);
+    if (blocks) hipLaunchKernelGGL(centre_kernel, dim3(blocks), dim3(256), 0, c->stream, d_scan, n, c->mean[0], c->mean[1], c->mean[2], c->d_reading);
+    if (d_normals3) {
+        if (ensure_cap(c, &c->d_read_normals, &c->cap_read_normals, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+        if (blocks) hipLaunchKernelGGL(pad_normals_kernel, dim3(blocks), dim3(256), 0, c->stream, d_normals3, n, c->d_read_normals);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return ICPMI_OK;
+}
+
+static icpmi_status ensure_loop_buffers(icpmi_ctx* c, int64_t n, int k)
+{
+    const size_t cnt = (size_t)n * k + 1;
+    if (ensure_cap(c, &c->d_sidx, &c->cap_sidx, cnt) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (ensure_cap(c, &c->d_d2, &c->cap_d2, cnt) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (ensure_cap(c, &c->d_hard, &c->cap_hard, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    const size_t nb = (cnt + 255) / 256;
+    if (ensure_cap(c, &c->d_partials, &c->cap_partials, nb * ICPMI_NV) != ICPMI_OK) return ICPMI_ERR_HIP;
+    return ICPMI_OK;
+}
+
+static int acc_blocks(int64_t count) { return (int)((count + 255) / 256); }
+
+// enqueue the quantile selections needed by the chain (no host sync)
+static void enqueue_selection(icpmi_ctx* c, const LoopCfg& lc, int64_t count)
+{
+    for (int f = 0; f < lc.n_out; ++f) {
+        const int type = lc.out_type[f];
+        if (type != ICPMI_OUT_TRIMMEDDIST && type != ICPMI_OUT_MEDIANDIST) continue;
+        const int is_med = type == ICPMI_OUT_MEDIANDIST;
+        const float quant = is_med ? 0.5f : lc.out_param[f];
+        const float factor = lc.out_param[f];
+        int hb = (int)std::min<int64_t>((count + 1023) / 1024, 1024);
+        if (hb < 1) hb = 1;
+        hipLaunchKernelGGL(sel_hist_kernel<0>, dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist);
+        hipLaunchKernelGGL(sel_scan_kernel<0>, dim3(1), dim3(256), 0, c->stream, c->d_state, c->d_selhist, quant, f, is_med, factor);
+        hipLaunchKernelGGL(sel_hist_kernel<1>, dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist);
+        hipLaunchKernelGGL(sel_scan_kernel<1>, dim3(1), dim3(256), 0, c->stream, c->d_state, c->d_selhist, quant, f, is_med, factor);
+        hipLaunchKernelGGL(sel_hist_kernel<2>, dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist);
+        hipLaunchKernelGGL(sel_scan_kernel<2>, dim3(1), dim3(256), 0, c->stream, c->d_state, c->d_selhist, quant, f, is_med, factor);
+    }
+}
+
+static void enqueue_accumulate_solve(icpmi_ctx* c, int64_t n, const LoopCfg& lc, float* d_Tstep, double* d_sums)
+{
+    const int64_t count = n * lc.k;
+    const int nb = acc_blocks(count);
+    const float4* rn = lc.has_read_normals ? c->d_read_normals : nullptr;
+    if (lc.minimizer == ICPMI_MIN_POINT_TO_PLANE)
+        hipLaunchKernelGGL(accumulate_kernel<ICPMI_MIN_POINT_TO_PLANE>, dim3(nb), dim3(256), 0, c->stream, c->d_reading, (int)n, lc,
+                           c->d_state, c->d_map_sorted, c->d_normals_sorted, rn, c->d_sidx, c->d_d2, c->d_partials);
+    else if (lc.minimizer == ICPMI_MIN_POINT_TO_POINT)
+        hipLaunchKernelGGL(accumulate_kernel<ICPMI_MIN_POINT_TO_POINT>, dim3(nb), dim3(256), 0, c->stream, c->d_reading, (int)n, lc,
+                           c->d_state, c->d_map_sorted, c->d_normals_sorted, rn, c->d_sidx, c->d_d2, c->d_partials);
+    else
+        hipLaunchKernelGGL(accumulate_kernel<ICPMI_MIN_IDENTITY>, dim3(nb), dim3(256), 0, c->stream, c->d_reading, (int)n, lc,
+                           c->d_state, c->d_map_sorted, c->d_normals_sorted, rn, c->d_sidx, c->d_d2, c->d_partials);
+    hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(64), 0, c->stream, c->d_state, c->d_partials, nb, lc, (int)n, d_Tstep, d_sums);
+}
+
+static icpmi_status enqueue_iteration(icpmi_ctx* c, int64_t n, const LoopCfg& lc, hipEvent_t nn0, hipEvent_t nn1)
+{
+    if (nn0) HIP_TRY(c, hipEventRecord(nn0, c->stream));
+    icpmi_status s = nn_launch_k(c, c->d_reading, n, c->d_state->T_iter, lc, 1, c->d_sidx, c->d_d2, c->d_state);
+    if (s != ICPMI_OK) return s;
+    if (nn1) HIP_TRY(c, hipEventRecord(nn1, c->stream));
+    enqueue_selection(c, lc, n * lc.k);
+    enqueue_accumulate_solve(c, n, lc, nullptr, nullptr);
+    HIP_TRY(c, hipGetLastError());
+    return ICPMI_OK;
+}
+
+static void fill_stats(icpmi_ctx* c, const LoopCfg& lc, int64_t n, icpmi_stats* stats)
+{
+    if (!stats) return;
+    const IcpState* hs = c->h_state;
+    stats->iterations = hs->iter;
+    stats->stop_reason = hs->stop_reason;
+    stats->pairs = hs->pairs;
+    const double denom = (double)lc.k * (double)n;
+    stats->point_used_ratio = denom > 0 ? (float)hs->pairs / (float)denom : 0.f;
+    stats->weighted_point_used_ratio = denom > 0 ? (float)(hs->wsum / denom) : 0.f;
+    stats->trimmed_limit = -1.f;
+    for (int f = 0; f < lc.n_out; ++f)
+        if (lc.out_type[f] == ICPMI_OUT_TRIMMEDDIST || lc.out_type[f] == ICPMI_OUT_MEDIANDIST) stats->trimmed_limit = hs->limits[f];
+    stats->hard_queries = (int64_t)hs->hard_total;
+}
+
+static void host_mat4_mul(const float* A, const float* B, float* C)
+{
+    float R[16];
+    for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 4; ++i) {
+            float s = A[i] * B[4 * j];
+            for (int kk = 1; kk < 4; ++kk) s = fmaf(A[4 * kk + i], B[4 * j + kk], s);
+            R[4 * j + i] = s;
+        }
+    memcpy(C, R, sizeof R);
+}
+
+icpmi_status loop_run(icpmi_ctx* c, int64_t n, const LoopCfg& lc_in, bool fixed, float T_out[16], icpmi_stats* stats)
+{
+    LoopCfg lc = lc_in;
+    if (ensure_loop_buffers(c, n, lc.k) != ICPMI_OK) return ICPMI_ERR_HIP;
+    hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(64), 0, c->stream, c->d_state, (const float*)nullptr);
+    HIP_TRY(c, hipMemsetAsync(c->d_selhist, 0, ICPMI_SEL_BINS * sizeof(unsigned), c->stream));
+    HIP_TRY(c, hipGetLastError());
+
+    const bool profile = c->cfg.profile != 0;
+    const bool graph = c->cfg.use_graph != 0 && fixed && !profile;
+    float nn_ms_sum = 0.f; int nn_cnt = 0;
+
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    if (graph) {
+        uint64_t sig = 1469598103934665603ull;
+        sig = fnv(&lc, sizeof lc, sig);
+        const void* ptrs[] = {c->d_reading, c->d_read_normals, c->d_sidx, c->d_d2, c->d_hard, c->d_partials, c->d_state,
+                              c->d_map_sorted, c->d_normals_sorted, c->d_cell_start, c->d_selhist};
+        sig = fnv(ptrs, sizeof ptrs, sig);
+        sig = fnv(&c->grid, sizeof c->grid, sig);
+        if (!c->graph_exec || c->graph_n != n || c->graph_iters != lc.max_iter || c->graph_sig != sig) {
+            if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+            hipGraph_t g = nullptr;
+            HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            icpmi_status s = ICPMI_OK;
+            for (int it = 0; it < lc.max_iter && s == ICPMI_OK; ++it) s = enqueue_iteration(c, n, lc, nullptr, nullptr);
+            hipError_t ce = hipStreamEndCapture(c->stream, &g);
+            if (s != ICPMI_OK) { if (g) hipGraphDestroy(g); return s; }
+            HIP_TRY(c, ce);
+            hipError_t ie = hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0);
+            hipGraphDestroy(g);
+            HIP_TRY(c, ie);
+            c->graph_n = n; c->graph_iters = lc.max_iter; c->graph_sig = sig;
+        }
+        HIP_TRY(c, hipGraphLaunch(c->graph_exec, c->stream));
+    } else {
+        const int check_every = (lc.use_diff || lc.use_bound) ? 4 : lc.max_iter;
+        if (profile && c->nn_events.size() < (size_t)2 * lc.max_iter) {
+            while (c->nn_events.size() < (size_t)2 * lc.max_iter) {
+                hipEvent_t e; HIP_TRY(c, hipEventCreate(&e)); c->nn_events.push_back(e);
+            }
+        }
+        int launched = 0;
+        for (int it = 0; it < lc.max_iter; ++it) {
+            hipEvent_t e0 = profile ? c->nn_events[2 * it] : nullptr, e1 = profile ? c->nn_events[2 * it + 1] : nullptr;
+            icpmi_status s = enqueue_iteration(c, n, lc, e0, e1);
+            if (s != ICPMI_OK) return s;
+            ++launched;
+            if ((it + 1) % check_every == 0 && it + 1 < lc.max_iter) {
+                HIP_TRY(c, hipMemcpyAsync(&c->h_state->done, &c->d_state->done, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                if (c->h_state->done) break;
+            }
+        }
+        if (profile) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, hipMemcpy(c->h_state, c->d_state, sizeof(IcpState), hipMemcpyDeviceToHost));
+            const int iters_done = c->h_state->iter < launched ? c->h_state->iter : launched;
+            for (int it = 0; it < iters_done; ++it) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, c->nn_events[2 * it], c->nn_events[2 * it + 1]) == hipSuccess) { nn_ms_sum += ms; ++nn_cnt; }
+            }
+        }
+    }
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(IcpState), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+
+    fill_stats(c, lc, n, stats);
+    if (stats) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) stats->loop_ms = ms;
+        stats->nn_ms_avg = nn_cnt ? nn_ms_sum / nn_cnt : 0.f;
+        stats->nn_launches = nn_cnt;
+    }
+    const IcpState* hs = c->h_state;
+    if (hs->error) {
+        switch (hs->error) {
+            case ICPMI_ERR_NO_POINT_TO_MINIMIZE: c->last_error = "ConvergenceError: ErrorMinimizer: no point to minimize"; break;
+            case ICPMI_ERR_NO_OUTLIER_TO_FILTER: c->last_error = "ConvergenceError: no outlier to filter"; break;
+            case ICPMI_ERR_BOUND: c->last_error = "ConvergenceError: transformation exceeds BoundTransformationChecker limits"; break;
+            case ICPMI_ERR_NAN: c->last_error = "ConvergenceError: transformation is not a number"; break;
+            default: c->last_error = "device-side error"; break;
+        }
+        return (icpmi_status)hs->error;
+    }
+    // T_refIn_refMean * T_iter * T_refMean_dataIn
+    float Tm[16], Tmi[16], tmp[16];
+    for (int i = 0; i < 16; ++i) Tm[i] = Tmi[i] = (i % 5 == 0) ? 1.f : 0.f;
+    for (int r = 0; r < 3; ++r) { Tm[12 + r] = c->mean[r]; Tmi[12 + r] = -c->mean[r]; }
+    host_mat4_mul(hs->T_iter, Tmi, tmp);
+    host_mat4_mul(Tm, tmp, T_out);
+    return ICPMI_OK;
+}
+
+icpmi_status loop_single_step(icpmi_ctx* c, int64_t n, const LoopCfg& lc, const float* T_iter_host, float T_step[16],
+                              double sums[32], icpmi_stats* stats)
+{
+    if (ensure_loop_buffers(c, n, lc.k) != ICPMI_OK) return ICPMI_ERR_HIP;
+    float* d_T0 = nullptr;
+    float* d_Tstep = nullptr;
+    double* d_sums = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d_Tstep, 16 * sizeof(float) * 2));
+    HIP_TRY(c, hipMalloc((void**)&d_sums, ICPMI_NV * sizeof(double)));
+    d_T0 = d_Tstep + 16;
+    if (T_iter_host) HIP_TRY(c, hipMemcpyAsync(d_T0, T_iter_host, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(64), 0, c->stream, c->d_state, T_iter_host ? (const float*)d_T0 : (const float*)nullptr);
+    HIP_TRY(c, hipMemsetAsync(c->d_selhist, 0, ICPMI_SEL_BINS * sizeof(unsigned), c->stream));
+    HIP_TRY(c, hipMemsetAsync(d_Tstep, 0, 16 * sizeof(float), c->stream));
+    LoopCfg l1 = lc;
+    l1.max_iter = 1; l1.use_diff = 0; l1.use_bound = 0;
+    icpmi_status s = nn_launch_k(c, c->d_reading, n, c->d_state->T_iter, l1, 1, c->d_sidx, c->d_d2, c->d_state);
+    if (s == ICPMI_OK) {
+        enqueue_selection(c, l1, n * l1.k);
+        enqueue_accumulate_solve(c, n, l1, d_Tstep, d_sums);
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(c->h_state, c->d_state, sizeof(IcpState), hipMemcpyDeviceToHost, c->stream);
+    float hT[16]; double hS[ICPMI_NV];
+    if (e == hipSuccess) e = hipMemcpyAsync(hT, d_Tstep, sizeof hT, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hS, d_sums, sizeof hS, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d_Tstep); hipFree(d_sums);
+    if (s != ICPMI_OK) return s;
+    HIP_TRY(c, e);
+    fill_stats(c, l1, n, stats);
+    if (c->h_state->error) { c->last_error = "minimize_step: device-side convergence error"; return (icpmi_status)c->h_state->error; }
+    if (T_step) memcpy(T_step, hT, sizeof hT);
+    if (sums) memcpy(sums, hS, sizeof hS);
+    return ICPMI_OK;
+}
+
+icpmi_status loop_outlier_weights(icpmi_ctx* c, const LoopCfg& lc, const float* d2, const int32_t* ids, int k, int64_t n,
+                                  const float* read_normals3, float* weights, float* limit_out)
+{
+    // matches arrive with ORIGINAL ids; the device tables are in sorted order, so SurfaceNormal
+    // filtering through this stage entry point needs the inverse permutation -- not offered here.
+    for (int f = 0; f < lc.n_out; ++f)
+        if (lc.out_type[f] == ICPMI_OUT_SURFACENORMAL) {
+            c->last_error = "icpmi_outlier_weights: SurfaceNormalOutlierFilter is only available inside icpmi_register";
+            return ICPMI_ERR_UNSUPPORTED;
+        }
+    (void)ids; (void)read_normals3;
+    const int64_t count = (int64_t)k * n;
+    if (ensure_loop_buffers(c, n, k) != ICPMI_OK) return ICPMI_ERR_HIP;
+    LoopCfg l1 = lc; l1.k = k;
+    hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(64), 0, c->stream, c->d_state, (const float*)nullptr);
+    HIP_TRY(c, hipMemsetAsync(c->d_selhist, 0, ICPMI_SEL_BINS * sizeof(unsigned), c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_d2, d2, (size_t)count * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_sidx, 0, (size_t)count * sizeof(int), c->stream));
+    enqueue_selection(c, l1, count);
+    float* d_w = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d_w, (size_t)(count > 0 ? count : 1) * sizeof(float)));
+    const int blocks = (int)((count + 255) / 256);
+    if (blocks) hipLaunchKernelGGL(weights_kernel, dim3(blocks), dim3(256), 0, c->stream, count, l1, c->d_state, c->d_normals_sorted,
+                                   (const float4*)nullptr, c->d_sidx, c->d_d2, d_w);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(weights, d_w, (size_t)count * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->h_state, c->d_state, sizeof(IcpState), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d_w);
+    HIP_TRY(c, e);
+    if (c->h_state->error) { c->last_error = "ConvergenceError: no outlier to filter"; return (icpmi_status)c->h_state->error; }
+    if (limit_out) {
+        *limit_out = -1.f;
+        for (int f = 0; f < l1.n_out; ++f)
+            if (l1.out_type[f] == ICPMI_OUT_TRIMMEDDIST || l1.out_type[f] == ICPMI_OUT_MEDIANDIST) *limit_out = c->h_state->limits[f];
+    }
+    return ICPMI_OK;
+}

@@ -1,0 +1,447 @@
+// nn.hip -- exact nearest-neighbour search against the cell-sorted map.
+//
+// Replaces KDTreeMatcher::findClosests -> Nabo::NNS::knn (behind `icp(input)`,
+// norlab_icp_mapper/Mapper.cpp:213) and the direct libnabo calls of
+// MapperModules/PointDistanceMapperModule.cpp:33-36.  Contract: squared L2
+// distances, accept d2 <= maxRadius^2, unfilled slots id -1 / d2 +inf, results ascending; ties on
+// equal float d2 resolve to the smallest original map index (the deterministic rule shared with the
+// oracle, libnabo's own pick being traversal dependent).
+//
+// Algorithm (k = 1 fast path): G lanes of a wave64 cooperate on one query.  The query's 3x3x3 cell
+// neighbourhood is 9 x-rows, each ONE contiguous run of the cell-sorted float4 array; the 9
+// (start,end) pairs are fetched by different lanes in parallel, then the lanes stride over the
+// candidates with 16-byte loads and fold (d2, index) keys with a butterfly of wave shuffles.  The
+// result is exact when the best distance is within the query's margin to the block boundary;
+// otherwise rings 2..ring_max are searched the same way, and queries still undecided are queued for
+// a brute-force pass over the whole map (only reachable with an unbounded maxDist).
+#include "common.h"
+
+namespace {
+
+constexpr int NN_BLOCK = 256;
+
+struct Cand {
+    unsigned long long key; // (d2 bits << 32) | original index
+    int sidx;               // position in the sorted map
+};
+
+__device__ __forceinline__ void cand_min(Cand& a, unsigned long long key, int sidx)
+{
+    if (key < a.key) { a.key = key; a.sidx = sidx; }
+}
+
+template <int G>
+__device__ __forceinline__ void group_reduce(Cand& c)
+{
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) {
+        const unsigned long long ok = __shfl_xor(c.key, off, 64);
+        const int os = __shfl_xor(c.sidx, off, 64);
+        cand_min(c, ok, os);
+    }
+}
+
+__device__ __forceinline__ void scan_run(const float4* __restrict__ map, unsigned s, unsigned e, int sub, int G,
+                                         float px, float py, float pz, bool allow_self, Cand& best)
+{
+    for (unsigned i = s + sub; i < e; i += G) {
+        const float4 q = map[i];
+        const float d2 = sqdist3(px, py, pz, q.x, q.y, q.z);
+        if (allow_self || d2 > 1.1920929e-07f) cand_min(best, pack_key(d2, __float_as_uint(q.w)), (int)i);
+    }
+}
+
+// x-run [x0, x1] of row (y, z), clipped to the grid; returns an empty run when outside
+__device__ __forceinline__ void row_run(const GridParams& g, const unsigned* __restrict__ cs, int x0, int x1, int y, int z,
+                                        unsigned& s, unsigned& e)
+{
+    s = 0; e = 0;
+    if (y < 0 || y >= g.ny || z < 0 || z >= g.nz) return;
+    if (x0 < 0) x0 = 0;
+    if (x1 > g.nx - 1) x1 = g.nx - 1;
+    if (x0 > x1) return;
+    const int base = (z * g.ny + y) * g.nx;
+    s = cs[base + x0];
+    e = cs[base + x1 + 1];
+}
+
+template <int G>
+__global__ __launch_bounds__(NN_BLOCK) void nn1_kernel(const float4* __restrict__ reading, int n, const float* __restrict__ Tptr,
+                                                       GridParams g, const float4* __restrict__ map,
+                                                       const unsigned* __restrict__ cs, float maxr2, int ring_max,
+                                                       int allow_self, int* __restrict__ out_sidx, float* __restrict__ out_d2,
+                                                       IcpState* __restrict__ st, unsigned* __restrict__ hard)
+{
+    if (st && st->done) return;
+    const int tid = blockIdx.x * NN_BLOCK + threadIdx.x;
+    const int qi = tid / G;
+    const int sub = tid % G;
+    const bool active = qi < n;
+    const float4 r = reading[active ? qi : 0];
+    float3 p;
+    if (Tptr) p = xf_point(Tptr, r.x, r.y, r.z, r.w);
+    else p = make_float3(r.x, r.y, r.z);
+
+    const float fx = (p.x - g.ox) * g.inv_cell, fy = (p.y - g.oy) * g.inv_cell, fz = (p.z - g.oz) * g.inv_cell;
+    const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
+    // clamp far-away queries so that the integer cell arithmetic cannot overflow
+    const int cx = (int)fminf(fmaxf(flx, -1.0e6f), 1.0e6f);
+    const int cy = (int)fminf(fmaxf(fly, -1.0e6f), 1.0e6f);
+    const int cz = (int)fminf(fmaxf(flz, -1.0e6f), 1.0e6f);
+    // smallest fractional distance to a cell face over the three axes
+    float mf = fminf(fx - flx, 1.0f - (fx - flx));
+    mf = fminf(mf, fminf(fy - fly, 1.0f - (fy - fly)));
+    mf = fminf(mf, fminf(fz - flz, 1.0f - (fz - flz)));
+    if (!(mf >= 0.f)) mf = 0.f;
+
+    Cand best; best.key = ~0ull; best.sidx = -1;
+
+    // ---- ring 1: the 3x3x3 block = 9 x-rows, (start,end) fetched by 9 different lanes ----
+    unsigned s0 = 0, e0 = 0, s1 = 0, e1 = 0;
+    {
+        int rr = sub;
+        if (rr < 9) row_run(g, cs, cx - 1, cx + 1, cy + (rr % 3) - 1, cz + (rr / 3) - 1, s0, e0);
+        rr = sub + G;
+        if (G < 9 && rr < 9) row_run(g, cs, cx - 1, cx + 1, cy + (rr % 3) - 1, cz + (rr / 3) - 1, s1, e1);
+    }
+    const int lane = threadIdx.x & 63;
+    const int gbase = lane - sub;
+#pragma unroll
+    for (int rr = 0; rr < 9; ++rr) {
+        const int src = gbase + (rr % G);
+        const unsigned s = __shfl(rr < G ? s0 : s1, src, 64);
+        const unsigned e = __shfl(rr < G ? e0 : e1, src, 64);
+        scan_run(map, s, e, sub, G, p.x, p.y, p.z, allow_self != 0, best);
+    }
+    group_reduce<G>(best);
+
+    // ---- exactness test / ring expansion ----
+    int ring = 1;
+    bool decided;
+    bool covers;
+    {
+        const float margin = fmaxf(((float)ring + mf) * g.cell - g.slack, 0.f);
+        const float m2 = margin * margin;
+        const float bd2 = __uint_as_float((unsigned)(best.key >> 32));
+        covers = cx - ring <= 0 && cx + ring >= g.nx - 1 && cy - ring <= 0 && cy + ring >= g.ny - 1 && cz - ring <= 0 &&
+                 cz + ring >= g.nz - 1;
+        decided = (best.sidx >= 0 && bd2 <= m2) || m2 > maxr2 || covers;
+    }
+    while (!decided && ring < ring_max) {
+        ++ring;
+        const int side = 2 * ring + 1;
+        const int nrows = side * side;
+        for (int rr = sub; rr < nrows; rr += G) {
+            const int dy = rr % side - ring, dz = rr / side - ring;
+            const bool shell_row = (dy == -ring || dy == ring || dz == -ring || dz == ring);
+            unsigned s, e;
+            if (shell_row) {
+                row_run(g, cs, cx - ring, cx + ring, cy + dy, cz + dz, s, e);
+                scan_run(map, s, e, 0, 1, p.x, p.y, p.z, allow_self != 0, best);
+            } else {
+                if (cx - ring >= 0) {
+                    row_run(g, cs, cx - ring, cx - ring, cy + dy, cz + dz, s, e);
+                    scan_run(map, s, e, 0, 1, p.x, p.y, p.z, allow_self != 0, best);
+                }
+                if (cx + ring <= g.nx - 1) {
+                    row_run(g, cs, cx + ring, cx + ring, cy + dy, cz + dz, s, e);
+                    scan_run(map, s, e, 0, 1, p.x, p.y, p.z, allow_self != 0, best);
+                }
+            }
+        }
+        group_reduce<G>(best);
+        const float margin = fmaxf(((float)ring + mf) * g.cell - g.slack, 0.f);
+        const float m2 = margin * margin;
+        const float bd2 = __uint_as_float((unsigned)(best.key >> 32));
+        covers = cx - ring <= 0 && cx + ring >= g.nx - 1 && cy - ring <= 0 && cy + ring >= g.ny - 1 && cz - ring <= 0 &&
+                 cz + ring >= g.nz - 1;
+        decided = (best.sidx >= 0 && bd2 <= m2) || m2 > maxr2 || covers;
+    }
+
+    if (active && sub == 0) {
+        float bd2 = __uint_as_float((unsigned)(best.key >> 32));
+        int bs = best.sidx;
+        if (bs < 0 || !(bd2 <= maxr2)) { bs = -1; bd2 = INFINITY; }
+        out_sidx[qi] = bs;
+        out_d2[qi] = bd2;
+        if (!decided) {
+            // keep the best found so far as a seed; the brute pass overwrites it
+            const unsigned slot = atomicAdd(&st->hard_count, 1u);
+            hard[slot] = (unsigned)qi;
+        }
+    }
+}
+
+// Brute-force pass for the queued queries (k = 1): one workgroup per query streams the whole map.
+__global__ __launch_bounds__(NN_BLOCK) void nn1_hard_kernel(const float4* __restrict__ reading, const float* __restrict__ Tptr,
+                                                            const float4* __restrict__ map, int m, float maxr2, int allow_self,
+                                                            int* __restrict__ out_sidx, float* __restrict__ out_d2,
+                                                            IcpState* __restrict__ st, const unsigned* __restrict__ hard)
+{
+    if (st->done) return;
+    const unsigned nh = st->hard_count;
+    __shared__ unsigned long long shk[NN_BLOCK / 64];
+    __shared__ int shs[NN_BLOCK / 64];
+    for (unsigned h = blockIdx.x; h < nh; h += gridDim.x) {
+        const int qi = (int)hard[h];
+        const float4 r = reading[qi];
+        float3 p;
+        if (Tptr) p = xf_point(Tptr, r.x, r.y, r.z, r.w);
+        else p = make_float3(r.x, r.y, r.z);
+        Cand best; best.key = ~0ull; best.sidx = -1;
+        scan_run(map, 0u, (unsigned)m, threadIdx.x, NN_BLOCK, p.x, p.y, p.z, allow_self != 0, best);
+        group_reduce<64>(best);
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { shk[w] = best.key; shs[w] = best.sidx; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int i = 1; i < NN_BLOCK / 64; ++i) cand_min(best, shk[i], shs[i]);
+            float bd2 = __uint_as_float((unsigned)(best.key >> 32));
+            int bs = best.sidx;
+            if (bs < 0 || !(bd2 <= maxr2)) { bs = -1; bd2 = INFINITY; }
+            out_sidx[qi] = bs;
+            out_d2[qi] = bd2;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void hard_reset_kernel(IcpState* st)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) { st->hard_total += st->hard_count; st->hard_count = 0; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// General k (2..32): one lane per query, bounded sorted list in registers / scratch, the same ring
+// search.  Used by knn > 1 matchers (docs/MapperConfiguration.md:174-189 uses knn 6) and by the
+// surface-normal operator (knn 10 on the map itself).
+// ------------------------------------------------------------------------------------------------
+template <int KMAX>
+struct KList {
+    unsigned long long key[KMAX];
+    int sidx[KMAX];
+    int k, filled;
+    __device__ __forceinline__ void init(int kk)
+    {
+        k = kk; filled = 0;
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) { key[i] = ~0ull; sidx[i] = -1; }
+    }
+    __device__ __forceinline__ unsigned long long worst() const { return key[KMAX - 1]; }
+    // keeps the KMAX smallest; callers read the first k (k <= KMAX), so the list may hold more than
+    // k entries -- harmless, and it keeps all indexing static (registers, no scratch).
+    __device__ __forceinline__ void insert(unsigned long long kk, int s)
+    {
+        if (kk >= key[KMAX - 1]) return;
+#pragma unroll
+        for (int i = KMAX - 1; i >= 0; --i) {
+            const unsigned long long prev = i > 0 ? key[i - 1] : 0ull;
+            const int prevs = i > 0 ? sidx[i - 1] : -1;
+            if (i > 0 && kk < prev) { key[i] = prev; sidx[i] = prevs; }
+            else if (kk < key[i]) { key[i] = kk; sidx[i] = s; }
+        }
+        if (filled < KMAX) ++filled;
+    }
+};
+
+template <int KMAX>
+__device__ __forceinline__ void scan_run_k(const float4* __restrict__ map, unsigned s, unsigned e, float px, float py, float pz,
+                                           bool allow_self, KList<KMAX>& L)
+{
+    for (unsigned i = s; i < e; ++i) {
+        const float4 q = map[i];
+        const float d2 = sqdist3(px, py, pz, q.x, q.y, q.z);
+        if (allow_self || d2 > 1.1920929e-07f) L.insert(pack_key(d2, __float_as_uint(q.w)), (int)i);
+    }
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(NN_BLOCK) void nnk_kernel(const float4* __restrict__ reading, int n, const float* __restrict__ Tptr,
+                                                       GridParams g, const float4* __restrict__ map,
+                                                       const unsigned* __restrict__ cs, int k, float maxr2, int ring_max,
+                                                       int allow_self, int* __restrict__ out_sidx, float* __restrict__ out_d2,
+                                                       IcpState* __restrict__ st, unsigned* __restrict__ hard)
+{
+    if (st && st->done) return;
+    const int qi = blockIdx.x * NN_BLOCK + threadIdx.x;
+    if (qi >= n) return;
+    const float4 r = reading[qi];
+    float3 p;
+    if (Tptr) p = xf_point(Tptr, r.x, r.y, r.z, r.w);
+    else p = make_float3(r.x, r.y, r.z);
+    const float fx = (p.x - g.ox) * g.inv_cell, fy = (p.y - g.oy) * g.inv_cell, fz = (p.z - g.oz) * g.inv_cell;
+    const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
+    const int cx = (int)fminf(fmaxf(flx, -1.0e6f), 1.0e6f);
+    const int cy = (int)fminf(fmaxf(fly, -1.0e6f), 1.0e6f);
+    const int cz = (int)fminf(fmaxf(flz, -1.0e6f), 1.0e6f);
+    float mf = fminf(fx - flx, 1.0f - (fx - flx));
+    mf = fminf(mf, fminf(fy - fly, 1.0f - (fy - fly)));
+    mf = fminf(mf, fminf(fz - flz, 1.0f - (fz - flz)));
+    if (!(mf >= 0.f)) mf = 0.f;
+
+    KList<KMAX> L; L.init(k);
+    bool decided = false;
+    int ring = 0;
+    while (!decided && ring < ring_max) {
+        ++ring;
+        const int side = 2 * ring + 1;
+        for (int rr = 0; rr < side * side; ++rr) {
+            const int dy = rr % side - ring, dz = rr / side - ring;
+            const bool full_row = ring == 1 || (dy == -ring || dy == ring || dz == -ring || dz == ring);
+            unsigned s, e;
+            if (full_row) {
+                row_run(g, cs, cx - ring, cx + ring, cy + dy, cz + dz, s, e);
+                scan_run_k<KMAX>(map, s, e, p.x, p.y, p.z, allow_self != 0, L);
+            } else {
+                if (cx - ring >= 0) {
+                    row_run(g, cs, cx - ring, cx - ring, cy + dy, cz + dz, s, e);
+                    scan_run_k<KMAX>(map, s, e, p.x, p.y, p.z, allow_self != 0, L);
+                }
+                if (cx + ring <= g.nx - 1) {
+                    row_run(g, cs, cx + ring, cx + ring, cy + dy, cz + dz, s, e);
+                    scan_run_k<KMAX>(map, s, e, p.x, p.y, p.z, allow_self != 0, L);
+                }
+            }
+        }
+        const float margin = fmaxf(((float)ring + mf) * g.cell - g.slack, 0.f);
+        const float m2 = margin * margin;
+        const unsigned long long kth = L.key[k - 1];
+        const float kd2 = __uint_as_float((unsigned)(kth >> 32));
+        const bool covers = cx - ring <= 0 && cx + ring >= g.nx - 1 && cy - ring <= 0 && cy + ring >= g.ny - 1 &&
+                            cz - ring <= 0 && cz + ring >= g.nz - 1;
+        decided = (kth != ~0ull && kd2 <= m2) || m2 > maxr2 || covers;
+    }
+    for (int j = 0; j < k; ++j) {
+        float d2 = __uint_as_float((unsigned)(L.key[j] >> 32));
+        int s = L.sidx[j];
+        if (s < 0 || !(d2 <= maxr2)) { s = -1; d2 = INFINITY; }
+        out_sidx[(size_t)k * qi + j] = s;
+        out_d2[(size_t)k * qi + j] = d2;
+    }
+    if (!decided) {
+        const unsigned slot = atomicAdd(&st->hard_count, 1u);
+        hard[slot] = (unsigned)qi;
+    }
+}
+
+// brute pass for general k: the workgroup streams the map, every lane keeps its own list, then k
+// rounds of "extract the global minimum" merge the 256 lists.
+template <int KMAX>
+__global__ __launch_bounds__(NN_BLOCK) void nnk_hard_kernel(const float4* __restrict__ reading, const float* __restrict__ Tptr,
+                                                            const float4* __restrict__ map, int m, int k, float maxr2,
+                                                            int allow_self, int* __restrict__ out_sidx,
+                                                            float* __restrict__ out_d2, IcpState* __restrict__ st,
+                                                            const unsigned* __restrict__ hard)
+{
+    if (st->done) return;
+    const unsigned nh = st->hard_count;
+    __shared__ unsigned long long shk[NN_BLOCK / 64];
+    __shared__ int shs[NN_BLOCK / 64];
+    __shared__ unsigned long long win_key;
+    __shared__ int win_sidx;
+    for (unsigned h = blockIdx.x; h < nh; h += gridDim.x) {
+        const int qi = (int)hard[h];
+        const float4 r = reading[qi];
+        float3 p;
+        if (Tptr) p = xf_point(Tptr, r.x, r.y, r.z, r.w);
+        else p = make_float3(r.x, r.y, r.z);
+        KList<KMAX> L; L.init(k);
+        for (unsigned i = threadIdx.x; i < (unsigned)m; i += NN_BLOCK) {
+            const float4 q = map[i];
+            const float d2 = sqdist3(p.x, p.y, p.z, q.x, q.y, q.z);
+            if (allow_self || d2 > 1.1920929e-07f) L.insert(pack_key(d2, __float_as_uint(q.w)), (int)i);
+        }
+        int head = 0;
+        for (int j = 0; j < k; ++j) {
+            Cand c;
+            // static indexing: select the head entry with a compare chain
+            c.key = ~0ull; c.sidx = -1;
+#pragma unroll
+            for (int i = 0; i < KMAX; ++i) if (i == head) { c.key = L.key[i]; c.sidx = L.sidx[i]; }
+            const unsigned long long mine = c.key;
+            group_reduce<64>(c);
+            const int w = threadIdx.x >> 6;
+            if ((threadIdx.x & 63) == 0) { shk[w] = c.key; shs[w] = c.sidx; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                for (int i = 1; i < NN_BLOCK / 64; ++i) cand_min(c, shk[i], shs[i]);
+                win_key = c.key; win_sidx = c.sidx;
+                float d2 = __uint_as_float((unsigned)(c.key >> 32));
+                int s = c.sidx;
+                if (s < 0 || !(d2 <= maxr2)) { s = -1; d2 = INFINITY; }
+                out_sidx[(size_t)k * qi + j] = s;
+                out_d2[(size_t)k * qi + j] = d2;
+            }
+            __syncthreads();
+            if (mine == win_key && mine != ~0ull) ++head; // keys are unique (index in the low word)
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ids_kernel(const float4* __restrict__ map, const int* __restrict__ sidx, int64_t count,
+                                                  int* __restrict__ ids)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const int s = sidx[i];
+    ids[i] = s < 0 ? -1 : (int)__float_as_uint(map[s].w);
+}
+
+} // namespace
+
+icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, const float* d_T, const LoopCfg& lc, int allow_self,
+                          int* d_sidx, float* d_d2, IcpState* d_state)
+{
+    constexpr int G = 8;
+    const int64_t threads = n * G;
+    const int blocks = (int)((threads + NN_BLOCK - 1) / NN_BLOCK);
+    if (blocks == 0) return ICPMI_OK;
+    hipLaunchKernelGGL(nn1_kernel<G>, dim3(blocks), dim3(NN_BLOCK), 0, c->stream, d_reading, (int)n, d_T, c->grid, c->d_map_sorted,
+                       c->d_cell_start, lc.maxr2, lc.ring_max, allow_self, d_sidx, d_d2, d_state, c->d_hard);
+    if (!std::isfinite(lc.max_dist) || lc.ring_max < (int)ceilf(lc.max_dist / c->grid.cell) + 1) {
+        hipLaunchKernelGGL(nn1_hard_kernel, dim3(512), dim3(NN_BLOCK), 0, c->stream, d_reading, d_T, c->d_map_sorted, (int)c->m,
+                           lc.maxr2, allow_self, d_sidx, d_d2, d_state, c->d_hard);
+        hipLaunchKernelGGL(hard_reset_kernel, dim3(1), dim3(64), 0, c->stream, d_state);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return ICPMI_OK;
+}
+
+template <int KMAX>
+static icpmi_status nnk_launch_t(icpmi_ctx* c, const float4* d_reading, int64_t n, const float* d_T, const LoopCfg& lc,
+                                 int allow_self, int* d_sidx, float* d_d2, IcpState* d_state)
+{
+    const int blocks = (int)((n + NN_BLOCK - 1) / NN_BLOCK);
+    if (blocks == 0) return ICPMI_OK;
+    hipLaunchKernelGGL(nnk_kernel<KMAX>, dim3(blocks), dim3(NN_BLOCK), 0, c->stream, d_reading, (int)n, d_T, c->grid,
+                       c->d_map_sorted, c->d_cell_start, lc.k, lc.maxr2, lc.ring_max, allow_self, d_sidx, d_d2, d_state, c->d_hard);
+    if (!std::isfinite(lc.max_dist) || lc.ring_max < (int)ceilf(lc.max_dist / c->grid.cell) + 1) {
+        hipLaunchKernelGGL(nnk_hard_kernel<KMAX>, dim3(512), dim3(NN_BLOCK), 0, c->stream, d_reading, d_T, c->d_map_sorted,
+                           (int)c->m, lc.k, lc.maxr2, allow_self, d_sidx, d_d2, d_state, c->d_hard);
+        hipLaunchKernelGGL(hard_reset_kernel, dim3(1), dim3(64), 0, c->stream, d_state);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return ICPMI_OK;
+}
+
+icpmi_status nn_launch_k(icpmi_ctx* c, const float4* d_reading, int64_t n, const float* d_T, const LoopCfg& lc, int allow_self,
+                         int* d_sidx, float* d_d2, IcpState* d_state)
+{
+    if (lc.k == 1) return nn_launch_k1(c, d_reading, n, d_T, lc, allow_self, d_sidx, d_d2, d_state);
+    if (lc.k <= 4) return nnk_launch_t<4>(c, d_reading, n, d_T, lc, allow_self, d_sidx, d_d2, d_state);
+    if (lc.k <= 8) return nnk_launch_t<8>(c, d_reading, n, d_T, lc, allow_self, d_sidx, d_d2, d_state);
+    if (lc.k <= 16) return nnk_launch_t<16>(c, d_reading, n, d_T, lc, allow_self, d_sidx, d_d2, d_state);
+    if (lc.k <= 32) return nnk_launch_t<32>(c, d_reading, n, d_T, lc, allow_self, d_sidx, d_d2, d_state);
+    c->last_error = "knn > 32 is not supported";
+    return ICPMI_ERR_UNSUPPORTED;
+}
+
+icpmi_status nn_ids_to_original(icpmi_ctx* c, const int* d_sidx, int64_t count, int* d_ids)
+{
+    const int blocks = (int)((count + 255) / 256);
+    if (blocks == 0) return ICPMI_OK;
+    hipLaunchKernelGGL(ids_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_map_sorted, d_sidx, count, d_ids);
+    HIP_TRY(c, hipGetLastError());
+    return ICPMI_OK;
+}

@@ -1,0 +1,262 @@
+// ops.hip -- the map-side operators of the path that are not part of the ICP iteration itself:
+//   RigidTransformation::compute            (Mapper.cpp:197,221; Map.cpp:523,525)
+//   SurfaceNormalDataPointsFilter           (Map.cpp:524 through examples/config.yaml:26-27)
+//   PointDistanceMapperModule keep mask     (MapperModules/PointDistanceMapperModule.cpp:28-50)
+//   Map::unloadCells cell binning           (Map.cpp:206-209,232-235)
+#include "common.h"
+#include <cstring>
+
+namespace {
+
+__global__ __launch_bounds__(256) void transform_kernel(const float4* __restrict__ in, int64_t n, const float* __restrict__ T,
+                                                        float4* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = in[i];
+    const float3 o = xf_point(T, p.x, p.y, p.z, p.w);
+    const float w = fmaf(T[15], p.w, fmaf(T[11], p.z, fmaf(T[7], p.y, T[3] * p.x)));
+    out[i] = make_float4(o.x, o.y, o.z, w);
+}
+
+__global__ __launch_bounds__(256) void rotate3_kernel(const float* __restrict__ in3, int64_t n, const float* __restrict__ T,
+                                                      float* __restrict__ out3)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x = in3[3 * i], y = in3[3 * i + 1], z = in3[3 * i + 2];
+    out3[3 * i] = fmaf(T[8], z, fmaf(T[4], y, T[0] * x));
+    out3[3 * i + 1] = fmaf(T[9], z, fmaf(T[5], y, T[1] * x));
+    out3[3 * i + 2] = fmaf(T[10], z, fmaf(T[6], y, T[2] * x));
+}
+
+__global__ __launch_bounds__(256) void bin_kernel(const float4* __restrict__ in, int64_t n, float cell, int* __restrict__ ijk)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = in[i];
+    ijk[3 * i] = (int)floorf(p.x / cell);
+    ijk[3 * i + 1] = (int)floorf(p.y / cell);
+    ijk[3 * i + 2] = (int)floorf(p.z / cell);
+}
+
+__global__ __launch_bounds__(256) void keep_kernel(const float* __restrict__ d2, int64_t n, float lim, uint8_t* __restrict__ keep)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    keep[i] = d2[i] >= lim ? 1 : 0;
+}
+
+// one lane per point: mean + covariance of the kNN set in double, smallest eigenvector by Jacobi
+__global__ __launch_bounds__(128) void normals_kernel(const float4* __restrict__ map, const int* __restrict__ sidx, int64_t m, int k,
+                                                      float* __restrict__ normals3)
+{
+    const int64_t i = (int64_t)blockIdx.x * 128 + threadIdx.x;
+    if (i >= m) return;
+    double mean[3] = {0, 0, 0};
+    int real = 0;
+    for (int j = 0; j < k; ++j) {
+        const int s = sidx[(size_t)k * i + j];
+        if (s < 0) continue;
+        const float4 q = map[s];
+        mean[0] += q.x; mean[1] += q.y; mean[2] += q.z; ++real;
+    }
+    const double inv = 1.0 / (real > 0 ? real : 1);
+    mean[0] *= inv; mean[1] *= inv; mean[2] *= inv;
+    double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
+    for (int j = 0; j < k; ++j) {
+        const int s = sidx[(size_t)k * i + j];
+        if (s < 0) continue;
+        const float4 q = map[s];
+        const double x = q.x - mean[0], y = q.y - mean[1], z = q.z - mean[2];
+        c00 += x * x; c01 += x * y; c02 += x * z; c11 += y * y; c12 += y * z; c22 += z * z;
+    }
+    // cyclic Jacobi on the symmetric 3x3
+    double A[3][3] = {{c00, c01, c02}, {c01, c11, c12}, {c02, c12, c22}};
+    double Q[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+        if (off < 1e-300) break;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 3; ++q) {
+                const double apq = A[p][q];
+                if (apq == 0.0) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+                for (int kk = 0; kk < 3; ++kk) {
+                    const double akp = A[kk][p], akq = A[kk][q];
+                    A[kk][p] = c * akp - s * akq; A[kk][q] = s * akp + c * akq;
+                }
+#pragma unroll
+                for (int kk = 0; kk < 3; ++kk) {
+                    const double apk = A[p][kk], aqk = A[q][kk];
+                    A[p][kk] = c * apk - s * aqk; A[q][kk] = s * apk + c * aqk;
+                }
+#pragma unroll
+                for (int kk = 0; kk < 3; ++kk) {
+                    const double qkp = Q[kk][p], qkq = Q[kk][q];
+                    Q[kk][p] = c * qkp - s * qkq; Q[kk][q] = s * qkp + c * qkq;
+                }
+            }
+    }
+    const double w0 = A[0][0], w1 = A[1][1], w2 = A[2][2];
+    const double wmax = fmax(fabs(w0), fmax(fabs(w1), fabs(w2)));
+    const double thr = 3.0 * 1.1920928955078125e-07 * wmax;
+    const int rank = (wmax > 0) ? ((fabs(w0) > thr) + (fabs(w1) > thr) + (fabs(w2) > thr)) : 0;
+    float nx = 1.f, ny = 0.f, nz = 0.f; // upstream's degenerate answer: eigenvectors = identity
+    if (rank >= 2) {
+        int e = 0;
+        double wm = w0;
+        if (w1 < wm) { wm = w1; e = 1; }
+        if (w2 < wm) { wm = w2; e = 2; }
+        nx = (float)(e == 0 ? Q[0][0] : (e == 1 ? Q[0][1] : Q[0][2]));
+        ny = (float)(e == 0 ? Q[1][0] : (e == 1 ? Q[1][1] : Q[1][2]));
+        nz = (float)(e == 0 ? Q[2][0] : (e == 1 ? Q[2][1] : Q[2][2]));
+    }
+    normals3[3 * i] = nx; normals3[3 * i + 1] = ny; normals3[3 * i + 2] = nz;
+}
+
+} // namespace
+
+// helper: a private handle on the same device/stream used to index an arbitrary cloud without
+// disturbing the ICP map of the caller's handle
+struct TempCtx {
+    icpmi_handle h = nullptr;
+    ~TempCtx() { if (h) icpmi_destroy(h); }
+};
+
+static icpmi_status make_temp(icpmi_ctx* c, TempCtx& t)
+{
+    icpmi_config cfg = c->cfg;
+    icpmi_status s = icpmi_create(&cfg, &t.h);
+    if (s != ICPMI_OK) { c->last_error = icpmi_last_error(nullptr); return s; }
+    return ICPMI_OK;
+}
+
+icpmi_status ops_transform(icpmi_ctx* c, const float T[16], const float* in4, int64_t n, float* out4, const float* in_n3,
+                           float* out_n3)
+{
+    // Transformation::checkParameters: rotation part must be (close to) orthonormal with det +1
+    const double det = (double)T[0] * ((double)T[5] * T[10] - (double)T[9] * T[6]) - (double)T[4] * ((double)T[1] * T[10] - (double)T[9] * T[2]) +
+                       (double)T[8] * ((double)T[1] * T[6] - (double)T[5] * T[2]);
+    if (fabs(1.0 - det) > 1e-3) {
+        c->last_error = "TransformationError: RigidTransformation: rotation part is not orthonormal (|1 - det| > 1e-3)";
+        return ICPMI_ERR_INVALID_ARG;
+    }
+    if (n == 0) return ICPMI_OK;
+    float* d_T = nullptr;
+    float4 *d_in = nullptr, *d_out = nullptr;
+    float *d_n = nullptr, *d_no = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d_T, 16 * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void**)&d_in, (size_t)n * sizeof(float4)));
+    HIP_TRY(c, hipMalloc((void**)&d_out, (size_t)n * sizeof(float4)));
+    hipError_t e = hipMemcpyAsync(d_T, T, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, in4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream);
+    const int blocks = (int)((n + 255) / 256);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(transform_kernel, dim3(blocks), dim3(256), 0, c->stream, d_in, n, d_T, d_out);
+        e = hipMemcpyAsync(out4, d_out, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess && in_n3 && out_n3) {
+        e = hipMalloc((void**)&d_n, (size_t)n * 3 * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&d_no, (size_t)n * 3 * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpyAsync(d_n, in_n3, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(rotate3_kernel, dim3(blocks), dim3(256), 0, c->stream, d_n, n, d_T, d_no);
+            e = hipMemcpyAsync(out_n3, d_no, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+        }
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d_T); hipFree(d_in); hipFree(d_out); hipFree(d_n); hipFree(d_no);
+    HIP_TRY(c, e);
+    return ICPMI_OK;
+}
+
+icpmi_status ops_bin_cells(icpmi_ctx* c, const float* pts4, int64_t n, float cell_size, int32_t* ijk3)
+{
+    if (n == 0) return ICPMI_OK;
+    float4* d_in = nullptr; int* d_o = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d_in, (size_t)n * sizeof(float4)));
+    HIP_TRY(c, hipMalloc((void**)&d_o, (size_t)n * 3 * sizeof(int)));
+    hipError_t e = hipMemcpyAsync(d_in, pts4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(bin_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, d_in, n, cell_size, d_o);
+        e = hipMemcpyAsync(ijk3, d_o, (size_t)n * 3 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d_in); hipFree(d_o);
+    HIP_TRY(c, e);
+    return ICPMI_OK;
+}
+
+// shared by surface normals and point-distance: index `cloud4` in a temp handle, kNN `q4` against it
+static icpmi_status temp_knn(icpmi_ctx* c, TempCtx& t, const float* cloud4, int64_t m, const float* q4, int64_t n, int k,
+                             int allow_self, bool queries_are_cloud)
+{
+    icpmi_ctx* tc = t.h;
+    int32_t acc = 0;
+    icpmi_status s = icpmi_set_map(t.h, cloud4, m, nullptr, &acc);
+    if (s != ICPMI_OK) { c->last_error = tc->last_error; return s; }
+    // queries: stage + centre on the temp map's mean (the index lives in the centred frame)
+    if (ensure_cap(tc, &tc->d_stage_in, &tc->cap_stage_in, (size_t)n + 1) != ICPMI_OK) { c->last_error = tc->last_error; return ICPMI_ERR_HIP; }
+    HIP_TRY(c, hipMemcpyAsync(tc->d_stage_in, queries_are_cloud ? cloud4 : q4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, tc->stream));
+    s = loop_prepare_reading(tc, tc->d_stage_in, n, nullptr);
+    if (s != ICPMI_OK) { c->last_error = tc->last_error; return s; }
+    LoopCfg lc = make_loop_cfg(tc, 1);
+    lc.k = k; lc.max_dist = INFINITY; lc.maxr2 = INFINITY; lc.ring_max = 6;
+    const size_t cnt = (size_t)n * k + 1;
+    if (ensure_cap(tc, &tc->d_sidx, &tc->cap_sidx, cnt) != ICPMI_OK || ensure_cap(tc, &tc->d_d2, &tc->cap_d2, cnt) != ICPMI_OK ||
+        ensure_cap(tc, &tc->d_hard, &tc->cap_hard, (size_t)n + 1) != ICPMI_OK) { c->last_error = tc->last_error; return ICPMI_ERR_HIP; }
+    HIP_TRY(c, hipMemsetAsync(tc->d_state, 0, sizeof(IcpState), tc->stream));
+    s = nn_launch_k(tc, tc->d_reading, n, nullptr, lc, allow_self, tc->d_sidx, tc->d_d2, tc->d_state);
+    if (s != ICPMI_OK) { c->last_error = tc->last_error; return s; }
+    return ICPMI_OK;
+}
+
+icpmi_status ops_surface_normals(icpmi_ctx* c, const float* pts4, int64_t m, int knn, float* normals3)
+{
+    if (m == 0) return ICPMI_OK;
+    if (knn < 1 || knn > ICPMI_MAX_K) { c->last_error = "surface_normals: knn must be in [1, 32]"; return ICPMI_ERR_INVALID_ARG; }
+    TempCtx t;
+    icpmi_status s = make_temp(c, t);
+    if (s != ICPMI_OK) return s;
+    s = temp_knn(c, t, pts4, m, nullptr, m, knn, 1, true);
+    if (s != ICPMI_OK) return s;
+    icpmi_ctx* tc = t.h;
+    float* d_n = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d_n, (size_t)m * 3 * sizeof(float)));
+    hipLaunchKernelGGL(normals_kernel, dim3((int)((m + 127) / 128)), dim3(128), 0, tc->stream, tc->d_map_sorted, tc->d_sidx, m, knn, d_n);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(normals3, d_n, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost, tc->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(tc->stream);
+    hipFree(d_n);
+    HIP_TRY(c, e);
+    return ICPMI_OK;
+}
+
+icpmi_status ops_point_distance_keep(icpmi_ctx* c, const float* map4, int64_t m, const float* in4, int64_t n, float min_dist,
+                                     uint8_t* keep)
+{
+    if (n == 0) return ICPMI_OK;
+    if (m == 0) { memset(keep, 1, (size_t)n); return ICPMI_OK; } // no neighbour: d2 = +inf >= lim
+    TempCtx t;
+    icpmi_status s = make_temp(c, t);
+    if (s != ICPMI_OK) return s;
+    s = temp_knn(c, t, map4, m, in4, n, 1, 0, false);
+    if (s != ICPMI_OK) return s;
+    icpmi_ctx* tc = t.h;
+    uint8_t* d_keep = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d_keep, (size_t)n));
+    const float lim = powf(min_dist, 2.f);
+    hipLaunchKernelGGL(keep_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, tc->stream, tc->d_d2, n, lim, d_keep);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(keep, d_keep, (size_t)n, hipMemcpyDeviceToHost, tc->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(tc->stream);
+    hipFree(d_keep);
+    HIP_TRY(c, e);
+    return ICPMI_OK;
+}

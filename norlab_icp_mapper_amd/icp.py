@@ -1,0 +1,347 @@
+"""Python-side mirror of ``PM::ICPSequence`` (the object behind ``Mapper::processInput``,
+/root/reference norlab_icp_mapper/Mapper.h:23, Mapper.cpp:72,77,213,219; Map.cpp:111,178,528,581)
+over the C ABI of libicpmi.so.  Same method names and error behaviour as the reference object so
+that the parity tests read like tests of the reference would:
+
+    icp = ICPSequence.loadFromYaml(chain)     # icp.loadFromYamlNode(node["icp"])
+    icp.setMap(cloud, normals)                # bool, False on an empty cloud
+    T = icp(scan)                             # 4x4 correction in the map frame
+    icp.errorMinimizer.getOverlap()
+
+Clouds are numpy float32 arrays of shape (N, 4) (== a 4 x N column-major ``features`` block),
+normals (N, 3); transforms are ordinary 4x4 numpy matrices.  All compute happens in the HIP library.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _capi
+
+
+class ConvergenceError(RuntimeError):
+    """PM::ConvergenceError"""
+
+
+class InvalidField(RuntimeError):
+    """PM::DataPoints::InvalidField"""
+
+
+class InvalidParameter(ValueError):
+    """PM::Parametrizable::InvalidParameter"""
+
+
+class TransformationError(ValueError):
+    """PM::TransformationError"""
+
+
+class HipError(RuntimeError):
+    pass
+
+
+_STATUS_EXC = {
+    _capi.ERR_INVALID_ARG: InvalidParameter,
+    _capi.ERR_HIP: HipError,
+    _capi.ERR_NO_POINT_TO_MINIMIZE: ConvergenceError,
+    _capi.ERR_NO_OUTLIER_TO_FILTER: ConvergenceError,
+    _capi.ERR_BOUND: ConvergenceError,
+    _capi.ERR_NAN: ConvergenceError,
+    _capi.ERR_MISSING_NORMALS: InvalidField,
+    _capi.ERR_UNSUPPORTED: NotImplementedError,
+}
+
+_OUTLIER_NAMES = {
+    "MaxDistOutlierFilter": (_capi.OUT_MAXDIST, "maxDist", 1.0),
+    "MinDistOutlierFilter": (_capi.OUT_MINDIST, "minDist", 1.0),
+    "MedianDistOutlierFilter": (_capi.OUT_MEDIANDIST, "factor", 3.0),
+    "TrimmedDistOutlierFilter": (_capi.OUT_TRIMMEDDIST, "ratio", 0.85),
+    "SurfaceNormalOutlierFilter": (_capi.OUT_SURFACENORMAL, "maxAngle", 1.57),
+}
+_MINIMIZERS = {
+    "IdentityErrorMinimizer": _capi.MIN_IDENTITY,
+    "PointToPointErrorMinimizer": _capi.MIN_POINT_TO_POINT,
+    "PointToPlaneErrorMinimizer": _capi.MIN_POINT_TO_PLANE,
+}
+
+
+def _f32c(a, cols):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] != cols:
+        raise InvalidParameter(f"expected an (N, {cols}) float32 array, got {a.shape}")
+    return a
+
+
+def _T_to_c(T):
+    """4x4 numpy (row-major) -> column-major float[16]"""
+    T = np.asarray(T, dtype=np.float32)
+    return np.ascontiguousarray(T.T).ravel()
+
+
+def _T_from_c(buf):
+    return np.array(buf, dtype=np.float32).reshape(4, 4).T.copy()
+
+
+def default_config(**kw):
+    lib = _capi.load()
+    cfg = _capi.Config()
+    lib.icpmi_config_default(C.byref(cfg))
+    outliers = kw.pop("outliers", None)
+    for k, v in kw.items():
+        if not hasattr(cfg, k):
+            raise InvalidParameter(f"unknown config field {k}")
+        setattr(cfg, k, v)
+    if outliers is not None:
+        cfg.n_outlier = len(outliers)
+        for i, (t, p) in enumerate(outliers):
+            cfg.outlier[i].type = t
+            cfg.outlier[i].param = p
+    return cfg
+
+
+def config_from_yaml_chain(chain, **engine):
+    """Translate the ``icp:`` sub-tree of a mapper YAML (Mapper.cpp:72) into an icpmi_config.
+
+    Only the modules on the hot path are accepted; anything else raises like libpointmatcher's
+    registrar would for an unknown module.
+    """
+    chain = chain or {}
+    kw = {}
+    valid = {"matcher", "outlierFilters", "errorMinimizer", "transformationCheckers", "inspector", "logger",
+             "readingDataPointsFilters", "referenceDataPointsFilters", "readingStepDataPointsFilters"}
+    for key in chain:
+        if key not in valid:
+            raise InvalidParameter(f"unknown ICP chain key: {key}")
+    for key in ("readingDataPointsFilters", "referenceDataPointsFilters", "readingStepDataPointsFilters"):
+        if chain.get(key):
+            raise NotImplementedError(f"{key} inside the ICP chain are not on the accelerated path; apply them as input filters")
+
+    def single(node, what):
+        if isinstance(node, str):
+            return node, {}
+        if isinstance(node, dict) and len(node) == 1:
+            (name, params), = node.items()
+            return name, (params or {})
+        raise InvalidParameter(f"malformed {what} node: {node!r}")
+
+    matcher = chain.get("matcher", {"KDTreeMatcher": {}})
+    name, p = single(matcher, "matcher")
+    if name != "KDTreeMatcher":
+        raise InvalidParameter(f"unknown matcher {name}")
+    for key in p:
+        if key not in ("knn", "epsilon", "searchType", "maxDist", "maxDistField"):
+            raise InvalidParameter(f"KDTreeMatcher: unknown parameter {key}")
+    kw["knn"] = int(p.get("knn", 1))
+    kw["epsilon"] = float(p.get("epsilon", 0))
+    md = p.get("maxDist", math.inf)
+    kw["max_dist"] = math.inf if str(md) in ("inf", ".inf") else float(md)
+
+    outs = []
+    for node in chain.get("outlierFilters", []) or []:
+        name, p = single(node, "outlier filter")
+        if name not in _OUTLIER_NAMES:
+            raise InvalidParameter(f"unknown outlier filter {name}")
+        t, pname, default = _OUTLIER_NAMES[name]
+        for key in p:
+            if key != pname:
+                raise InvalidParameter(f"{name}: unknown parameter {key}")
+        outs.append((t, float(p.get(pname, default))))
+    kw["outliers"] = outs
+
+    name, p = single(chain.get("errorMinimizer", "PointToPlaneErrorMinimizer"), "errorMinimizer")
+    if name not in _MINIMIZERS:
+        raise InvalidParameter(f"unknown error minimizer {name}")
+    if any(int(p.get(k, 0)) for k in ("force2D", "force4DOF")):
+        raise NotImplementedError("force2D / force4DOF are not on the accelerated path")
+    kw["minimizer"] = _MINIMIZERS[name]
+
+    kw["max_iterations"] = 40
+    for node in chain.get("transformationCheckers", [{"CounterTransformationChecker": {}}]) or []:
+        name, p = single(node, "transformation checker")
+        if name == "CounterTransformationChecker":
+            kw["max_iterations"] = int(p.get("maxIterationCount", 40))
+        elif name == "DifferentialTransformationChecker":
+            kw["use_differential"] = 1
+            kw["min_diff_rot"] = float(p.get("minDiffRotErr", 0.001))
+            kw["min_diff_trans"] = float(p.get("minDiffTransErr", 0.001))
+            kw["smooth_length"] = int(p.get("smoothLength", 3))
+        elif name == "BoundTransformationChecker":
+            kw["use_bound"] = 1
+            kw["max_rot_norm"] = float(p.get("maxRotationNorm", 1))
+            kw["max_trans_norm"] = float(p.get("maxTranslationNorm", 1))
+        else:
+            raise InvalidParameter(f"unknown transformation checker {name}")
+    kw.update(engine)
+    return default_config(**kw)
+
+
+class _ErrorMinimizerView:
+    def __init__(self, owner):
+        self._o = owner
+
+    def getOverlap(self):
+        return float(self._o.stats.weighted_point_used_ratio)
+
+    def getPointUsedRatio(self):
+        return float(self._o.stats.point_used_ratio)
+
+    def getWeightedPointUsedRatio(self):
+        return float(self._o.stats.weighted_point_used_ratio)
+
+
+class ICPSequence:
+    """``PM::ICPSequence`` backed by one icpmi handle (one GPU, one stream)."""
+
+    def __init__(self, cfg=None, **kw):
+        self._lib = _capi.load()
+        self.cfg = cfg if cfg is not None else default_config(**kw)
+        h = C.c_void_p()
+        st = self._lib.icpmi_create(C.byref(self.cfg), C.byref(h))
+        if st != _capi.ICPMI_OK:
+            msg = self._lib.icpmi_last_error(None).decode()
+            raise _STATUS_EXC.get(st, RuntimeError)(msg)
+        self._h = h
+        self.stats = _capi.Stats()
+        self.errorMinimizer = _ErrorMinimizerView(self)
+
+    @classmethod
+    def loadFromYaml(cls, chain, **engine):
+        return cls(config_from_yaml_chain(chain, **engine))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.icpmi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st != _capi.ICPMI_OK:
+            msg = self._lib.icpmi_last_error(self._h).decode()
+            raise _STATUS_EXC.get(st, RuntimeError)(msg)
+
+    # ---- PM::ICPSequence surface ----
+    def setMap(self, cloud, normals=None):
+        cloud = _f32c(cloud, 4)
+        acc = C.c_int32(0)
+        nptr = None
+        if normals is not None:
+            normals = _f32c(normals, 3)
+            if normals.shape[0] != cloud.shape[0]:
+                raise InvalidParameter("normals / cloud size mismatch")
+            nptr = normals.ctypes.data
+        self._check(self._lib.icpmi_set_map(self._h, cloud.ctypes.data, cloud.shape[0], nptr, C.byref(acc)))
+        return bool(acc.value)
+
+    def setMapDev(self, d_cloud_ptr, m, d_normals_ptr=None):
+        acc = C.c_int32(0)
+        self._check(self._lib.icpmi_set_map_dev(self._h, d_cloud_ptr, m, d_normals_ptr, C.byref(acc)))
+        return bool(acc.value)
+
+    def hasMap(self):
+        return bool(self._lib.icpmi_has_map(self._h))
+
+    def getMapMean(self):
+        out = (C.c_float * 3)()
+        self._check(self._lib.icpmi_get_map_mean(self._h, out))
+        return np.array(out[:], dtype=np.float32)
+
+    def __call__(self, scan, scan_normals=None):
+        scan = _f32c(scan, 4)
+        nptr = None
+        if scan_normals is not None:
+            scan_normals = _f32c(scan_normals, 3)
+            nptr = scan_normals.ctypes.data
+        T = (C.c_float * 16)()
+        st = self._lib.icpmi_register(self._h, scan.ctypes.data, scan.shape[0], nptr, T, C.byref(self.stats))
+        self._check(st)
+        return _T_from_c(T[:])
+
+    def registerDev(self, d_scan_ptr, n, fixed_iterations=0, d_normals_ptr=None):
+        T = (C.c_float * 16)()
+        if fixed_iterations > 0:
+            st = self._lib.icpmi_register_fixed_dev(self._h, d_scan_ptr, n, d_normals_ptr, fixed_iterations, T, C.byref(self.stats))
+        else:
+            st = self._lib.icpmi_register_dev(self._h, d_scan_ptr, n, d_normals_ptr, T, C.byref(self.stats))
+        self._check(st)
+        return _T_from_c(T[:])
+
+    # ---- stage-level entry points ----
+    def transform(self, T, cloud, normals=None):
+        cloud = _f32c(cloud, 4)
+        out = np.empty_like(cloud)
+        Tc = _T_to_c(T)
+        nin = nout = None
+        outn = None
+        if normals is not None:
+            normals = _f32c(normals, 3)
+            outn = np.empty_like(normals)
+            nin, nout = normals.ctypes.data, outn.ctypes.data
+        st = self._lib.icpmi_transform(self._h, Tc.ctypes.data_as(C.POINTER(C.c_float)), cloud.ctypes.data, cloud.shape[0],
+                                       out.ctypes.data, nin, nout)
+        if st == _capi.ERR_INVALID_ARG:
+            raise TransformationError(self._lib.icpmi_last_error(self._h).decode())
+        self._check(st)
+        return (out, outn) if normals is not None else out
+
+    def knn(self, queries_centred, k=1, max_dist=math.inf, allow_self=True):
+        q = _f32c(queries_centred, 4)
+        ids = np.empty((q.shape[0], k), dtype=np.int32)
+        d2 = np.empty((q.shape[0], k), dtype=np.float32)
+        self._check(self._lib.icpmi_knn(self._h, q.ctypes.data, q.shape[0], k, max_dist, int(allow_self), ids.ctypes.data, d2.ctypes.data))
+        return ids, d2
+
+    def outlierWeights(self, d2, ids=None):
+        d2 = np.ascontiguousarray(d2, dtype=np.float32)
+        n, k = d2.shape
+        w = np.empty_like(d2)
+        lim = C.c_float(-1)
+        idp = None
+        if ids is not None:
+            ids = np.ascontiguousarray(ids, dtype=np.int32)
+            idp = ids.ctypes.data
+        self._check(self._lib.icpmi_outlier_weights(self._h, d2.ctypes.data, idp, k, n, None, w.ctypes.data, C.byref(lim)))
+        return w, float(lim.value)
+
+    def minimizeStep(self, reading_centred, T_iter=None):
+        r = _f32c(reading_centred, 4)
+        T = (C.c_float * 16)()
+        sums = (C.c_double * 32)()
+        tptr = None
+        if T_iter is not None:
+            Tc = _T_to_c(T_iter)
+            tptr = Tc.ctypes.data
+        self._check(self._lib.icpmi_minimize_step(self._h, r.ctypes.data, r.shape[0], tptr, T, sums, C.byref(self.stats)))
+        return _T_from_c(T[:]), np.array(sums[:])
+
+    def surfaceNormals(self, cloud, knn=5):
+        cloud = _f32c(cloud, 4)
+        out = np.empty((cloud.shape[0], 3), dtype=np.float32)
+        self._check(self._lib.icpmi_surface_normals(self._h, cloud.ctypes.data, cloud.shape[0], knn, out.ctypes.data))
+        return out
+
+    def pointDistanceKeep(self, map_cloud, input_cloud, min_dist):
+        m = _f32c(map_cloud, 4)
+        i = _f32c(input_cloud, 4)
+        keep = np.empty(i.shape[0], dtype=np.uint8)
+        self._check(self._lib.icpmi_point_distance_keep(self._h, m.ctypes.data, m.shape[0], i.ctypes.data, i.shape[0], min_dist, keep.ctypes.data))
+        return keep.astype(bool)
+
+    def binCells(self, cloud, cell_size=20.0):
+        c = _f32c(cloud, 4)
+        out = np.empty((c.shape[0], 3), dtype=np.int32)
+        self._check(self._lib.icpmi_bin_cells(self._h, c.ctypes.data, c.shape[0], cell_size, out.ctypes.data))
+        return out
+
+    def setStream(self, hip_stream_ptr):
+        self._check(self._lib.icpmi_set_stream(self._h, hip_stream_ptr))
+
+    def gridInfo(self):
+        cell = C.c_float()
+        dims = (C.c_int32 * 3)()
+        nc, no = C.c_int64(), C.c_int64()
+        self._check(self._lib.icpmi_get_grid_info(self._h, C.byref(cell), dims, C.byref(nc), C.byref(no)))
+        return {"cell": cell.value, "dims": list(dims), "n_cells": nc.value, "n_occupied": no.value}

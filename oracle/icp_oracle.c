@@ -1,0 +1,906 @@
+/*
+ * oracle/icp_oracle.c -- CPU restatement of the ICP registration hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see icp_oracle.h).  PARITY UNPINNED at the
+ * libpointmatcher / libnabo boundary: those libraries are absent from
+ * /root/reference and from this image; every function below restates their
+ * published algorithm as recorded in SURVEY.md Appendix B and cites the
+ * reference call site that exercises it.
+ */
+#include "icp_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * RigidTransformation::compute  (call sites Mapper.cpp:197,221; Map.cpp:523,525)
+ * features' = T * features; Eigen accumulates the product column by column.
+ * ---------------------------------------------------------------------------------------------- */
+static inline void xf_point(const float* T, const float* p, float* o)
+{
+    const float x = p[0], y = p[1], z = p[2], w = p[3];
+    for (int r = 0; r < 4; ++r)
+        o[r] = fmaf(T[12 + r], w, fmaf(T[8 + r], z, fmaf(T[4 + r], y, T[r] * x)));
+}
+
+void orc_transform(const float* T, const float* in4, float* out4, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        float o[4];
+        xf_point(T, in4 + 4 * i, o);
+        memcpy(out4 + 4 * i, o, sizeof o);
+    }
+}
+
+void orc_rotate3(const float* T, const float* in3, float* out3, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        const float x = in3[3 * i], y = in3[3 * i + 1], z = in3[3 * i + 2];
+        float o[3];
+        for (int r = 0; r < 3; ++r) o[r] = fmaf(T[8 + r], z, fmaf(T[4 + r], y, T[r] * x));
+        memcpy(out3 + 3 * i, o, sizeof o);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * libnabo kd-tree (NNS::create KDTREE_LINEAR_HEAP; reference call sites
+ * PointDistanceMapperModule.cpp:33-36, DynamicPointsMapperModule.cpp:75-78, and
+ * KDTreeMatcher::init/findClosests behind Mapper.cpp:213 / Map.cpp:528).
+ * Unbalanced tree, points in leaves, split on the dimension of largest extent at the median.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t dim;       /* split dimension, or -1 for a leaf                       */
+    float   cut;       /* split value                                             */
+    int32_t right;     /* index of right child (left child is node + 1) / bucket start for leaf */
+    int32_t count;     /* leaf: number of points                                  */
+} kd_node;
+
+struct orc_kdtree {
+    int      dim;
+    int64_t  m;
+    float*   pts;      /* dim-major copy: m x 4 (x,y,z,pad)                       */
+    int32_t* index;    /* permutation: bucket entries -> original index           */
+    float*   bpts;     /* points in bucket order (4 floats each)                  */
+    kd_node* nodes;
+    int64_t  n_nodes, cap_nodes;
+    int      bucket;
+};
+
+static inline float coord(const orc_kdtree* t, int32_t idx, int d) { return t->pts[4 * (int64_t)idx + d]; }
+
+/* quickselect on idx[lo..hi) so that idx[k] holds the element of rank k by (coord d, idx) */
+static void kd_select(const orc_kdtree* t, int32_t* idx, int64_t lo, int64_t hi, int64_t k, int d)
+{
+    while (hi - lo > 1) {
+        /* median of three pivot */
+        int64_t mid = lo + (hi - lo) / 2;
+        int32_t a = idx[lo], b = idx[mid], c = idx[hi - 1];
+        float fa = coord(t, a, d), fb = coord(t, b, d), fc = coord(t, c, d);
+        int32_t piv;
+        if ((fa <= fb && fb <= fc) || (fc <= fb && fb <= fa)) piv = b;
+        else if ((fb <= fa && fa <= fc) || (fc <= fa && fa <= fb)) piv = a;
+        else piv = c;
+        const float pv = coord(t, piv, d);
+        int64_t i = lo, j = hi - 1;
+        while (i <= j) {
+            while (coord(t, idx[i], d) < pv || (coord(t, idx[i], d) == pv && idx[i] < piv)) ++i;
+            while (coord(t, idx[j], d) > pv || (coord(t, idx[j], d) == pv && idx[j] > piv)) --j;
+            if (i <= j) { int32_t tmp = idx[i]; idx[i] = idx[j]; idx[j] = tmp; ++i; --j; }
+        }
+        if (k <= j) hi = j + 1;
+        else if (k >= i) lo = i;
+        else return;
+    }
+}
+
+static int32_t kd_new_node(orc_kdtree* t)
+{
+    if (t->n_nodes == t->cap_nodes) {
+        t->cap_nodes = t->cap_nodes ? 2 * t->cap_nodes : 1024;
+        t->nodes = (kd_node*)realloc(t->nodes, (size_t)t->cap_nodes * sizeof(kd_node));
+    }
+    return (int32_t)t->n_nodes++;
+}
+
+static void kd_build_rec(orc_kdtree* t, int32_t* idx, int64_t lo, int64_t hi)
+{
+    const int32_t me = kd_new_node(t);
+    const int64_t cnt = hi - lo;
+    if (cnt <= t->bucket) {
+        t->nodes[me].dim = -1; t->nodes[me].cut = 0.f;
+        t->nodes[me].right = (int32_t)lo; t->nodes[me].count = (int32_t)cnt;
+        return;
+    }
+    /* widest dimension of this subset */
+    float mn[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, mx[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+    for (int64_t i = lo; i < hi; ++i)
+        for (int d = 0; d < t->dim; ++d) {
+            const float v = coord(t, idx[i], d);
+            if (v < mn[d]) mn[d] = v;
+            if (v > mx[d]) mx[d] = v;
+        }
+    int sd = 0;
+    for (int d = 1; d < t->dim; ++d) if (mx[d] - mn[d] > mx[sd] - mn[sd]) sd = d;
+    const int64_t mid = lo + cnt / 2;
+    kd_select(t, idx, lo, hi, mid, sd);
+    const float cut = coord(t, idx[mid], sd);
+    kd_build_rec(t, idx, lo, mid);
+    const int32_t right = (int32_t)t->n_nodes;
+    kd_build_rec(t, idx, mid, hi);
+    t->nodes[me].dim = sd; t->nodes[me].cut = cut; t->nodes[me].right = right; t->nodes[me].count = 0;
+}
+
+orc_kdtree* orc_kdtree_build(const float* pts4, int64_t m, int dim, int bucket_size)
+{
+    orc_kdtree* t = (orc_kdtree*)calloc(1, sizeof *t);
+    t->dim = dim; t->m = m; t->bucket = bucket_size > 0 ? bucket_size : 8;
+    t->pts = (float*)malloc((size_t)(m > 0 ? m : 1) * 4 * sizeof(float));
+    memcpy(t->pts, pts4, (size_t)m * 4 * sizeof(float));
+    t->index = (int32_t*)malloc((size_t)(m > 0 ? m : 1) * sizeof(int32_t));
+    for (int64_t i = 0; i < m; ++i) t->index[i] = (int32_t)i;
+    if (m > 0) kd_build_rec(t, t->index, 0, m);
+    t->bpts = (float*)malloc((size_t)(m > 0 ? m : 1) * 4 * sizeof(float));
+    for (int64_t i = 0; i < m; ++i) memcpy(t->bpts + 4 * i, t->pts + 4 * (int64_t)t->index[i], 4 * sizeof(float));
+    return t;
+}
+
+void orc_kdtree_free(orc_kdtree* t)
+{
+    if (!t) return;
+    free(t->pts); free(t->index); free(t->bpts); free(t->nodes); free(t);
+}
+
+/* bounded result list kept ascending by (d2, id): libnabo's linear heap */
+typedef struct { int k; int filled; int32_t* id; float* d2; } knn_heap;
+
+static inline int cand_less(float da, int32_t ia, float db, int32_t ib)
+{
+    return da < db || (da == db && ia < ib);
+}
+
+static inline void heap_insert(knn_heap* h, float d2, int32_t id)
+{
+    int pos = h->filled < h->k ? h->filled : h->k - 1;
+    if (h->filled == h->k && !cand_less(d2, id, h->d2[pos], h->id[pos])) return;
+    while (pos > 0 && cand_less(d2, id, h->d2[pos - 1], h->id[pos - 1])) {
+        h->d2[pos] = h->d2[pos - 1]; h->id[pos] = h->id[pos - 1]; --pos;
+    }
+    h->d2[pos] = d2; h->id[pos] = id;
+    if (h->filled < h->k) ++h->filled;
+}
+
+static inline float heap_worst(const knn_heap* h) { return h->filled < h->k ? INFINITY : h->d2[h->k - 1]; }
+
+static inline float sqdist(const float* q, const float* p, int dim)
+{
+    const float dx = q[0] - p[0], dy = q[1] - p[1];
+    float d = fmaf(dy, dy, dx * dx);
+    if (dim > 2) { const float dz = q[2] - p[2]; d = fmaf(dz, dz, d); }
+    return d;
+}
+
+static void kd_search(const orc_kdtree* t, int32_t node, const float* q, float* off, float rd,
+                      float maxr2, int allow_self, knn_heap* h)
+{
+    const kd_node* nd = &t->nodes[node];
+    if (nd->dim < 0) {
+        const float* bp = t->bpts + 4 * (int64_t)nd->right;
+        for (int i = 0; i < nd->count; ++i, bp += 4) {
+            const float d2 = sqdist(q, bp, t->dim);
+            if (d2 <= maxr2 && (allow_self || d2 > FLT_EPSILON)) heap_insert(h, d2, t->index[nd->right + i]);
+        }
+        return;
+    }
+    const int d = nd->dim;
+    const float old_off = off[d];
+    const float new_off = q[d] - nd->cut;
+    int32_t near_c, far_c;
+    if (new_off > 0.f) { near_c = nd->right; far_c = node + 1; }
+    else { near_c = node + 1; far_c = nd->right; }
+    kd_search(t, near_c, q, off, rd, maxr2, allow_self, h);
+    /* incremental distance to the far half-space (Arya & Mount); a tiny relative slack keeps the
+     * prune conservative w.r.t. the fmaf-evaluated point distances */
+    const float nrd = rd - old_off * old_off + new_off * new_off;
+    const float bound = nrd * (1.0f - 4.0f * FLT_EPSILON) - FLT_MIN;
+    if (bound <= maxr2 && bound <= heap_worst(h)) {
+        off[d] = new_off;
+        kd_search(t, far_c, q, off, nrd, maxr2, allow_self, h);
+        off[d] = old_off;
+    }
+}
+
+static void knn_finish(knn_heap* h)
+{
+    for (int j = h->filled; j < h->k; ++j) { h->id[j] = -1; h->d2[j] = INFINITY; }
+}
+
+void orc_kdtree_knn(const orc_kdtree* t, const float* q4, int64_t n, int k, float max_radius,
+                    int allow_self, int32_t* ids, float* d2, int nthreads)
+{
+    const float maxr2 = isinf(max_radius) ? INFINITY : max_radius * max_radius;
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 256) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    for (int64_t i = 0; i < n; ++i) {
+        knn_heap h = { k, 0, ids + (int64_t)k * i, d2 + (int64_t)k * i };
+        if (t->m > 0) {
+            float off[3] = { 0.f, 0.f, 0.f };
+            kd_search(t, 0, q4 + 4 * i, off, 0.f, maxr2, allow_self, &h);
+        }
+        knn_finish(&h);
+    }
+}
+
+void orc_bruteforce_knn(const float* pts4, int64_t m, int dim, const float* q4, int64_t n, int k,
+                        float max_radius, int allow_self, int32_t* ids, float* d2)
+{
+    const float maxr2 = isinf(max_radius) ? INFINITY : max_radius * max_radius;
+    for (int64_t i = 0; i < n; ++i) {
+        knn_heap h = { k, 0, ids + (int64_t)k * i, d2 + (int64_t)k * i };
+        for (int64_t j = 0; j < m; ++j) {
+            const float dd = sqdist(q4 + 4 * i, pts4 + 4 * j, dim);
+            if (dd <= maxr2 && (allow_self || dd > FLT_EPSILON)) heap_insert(&h, dd, (int32_t)j);
+        }
+        knn_finish(&h);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Matches::getDistsQuantile: nth_element over the finite, strictly positive entries,
+ * index = size * quantile evaluated in float, quantile == 1 -> max.
+ * ---------------------------------------------------------------------------------------------- */
+static float select_rank(float* v, int64_t n, int64_t k)
+{
+    int64_t lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const float a = v[lo], b = v[lo + (hi - lo) / 2], c = v[hi];
+        float pv = (a < b) ? ((b < c) ? b : (a < c ? c : a)) : ((a < c) ? a : (b < c ? c : b));
+        int64_t i = lo, j = hi;
+        while (i <= j) {
+            while (v[i] < pv) ++i;
+            while (v[j] > pv) --j;
+            if (i <= j) { float tmp = v[i]; v[i] = v[j]; v[j] = tmp; ++i; --j; }
+        }
+        if (k <= j) hi = j;
+        else if (k >= i) lo = i;
+        else break;
+    }
+    return v[k];
+}
+
+float orc_dists_quantile(const float* d2, int64_t count, float quantile)
+{
+    float* vals = (float*)malloc((size_t)(count > 0 ? count : 1) * sizeof(float));
+    int64_t n = 0;
+    for (int64_t i = 0; i < count; ++i)
+        if (d2[i] != INFINITY && d2[i] > 0.f) vals[n++] = d2[i];
+    float r;
+    if (n == 0) r = -1.f;
+    else if (quantile == 1.0f) {
+        r = vals[0];
+        for (int64_t i = 1; i < n; ++i) if (vals[i] > r) r = vals[i];
+    } else {
+        int64_t k = (int64_t)((float)n * quantile);
+        if (k > n - 1) k = n - 1;
+        r = select_rank(vals, n, k);
+    }
+    free(vals);
+    return r;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * OutlierFilters::compute. Empty chain => all ones; filters multiply.
+ * ---------------------------------------------------------------------------------------------- */
+int orc_outlier_weights(const orc_config* cfg, const float* d2, const int32_t* ids, int k, int64_t n,
+                        const float* read_normals3, const float* ref_normals3, float* weights,
+                        float* limit_out)
+{
+    const int64_t cnt = (int64_t)k * n;
+    for (int64_t i = 0; i < cnt; ++i) weights[i] = 1.0f;
+    if (limit_out) *limit_out = -1.f;
+    for (int f = 0; f < cfg->n_outlier; ++f) {
+        const int type = cfg->outlier[f].type;
+        const float prm = cfg->outlier[f].param;
+        if (type == ORC_OUT_MAXDIST) {
+            const float lim = prm * prm;
+            for (int64_t i = 0; i < cnt; ++i) weights[i] *= (d2[i] <= lim) ? 1.f : 0.f;
+        } else if (type == ORC_OUT_MINDIST) {
+            const float lim = prm * prm;
+            for (int64_t i = 0; i < cnt; ++i) weights[i] *= (d2[i] >= lim) ? 1.f : 0.f;
+        } else if (type == ORC_OUT_MEDIANDIST || type == ORC_OUT_TRIMMEDDIST) {
+            float lim;
+            if (type == ORC_OUT_MEDIANDIST) {
+                const float med = orc_dists_quantile(d2, cnt, 0.5f);
+                if (med < 0.f) return ORC_ERR_NO_OUTLIER_TO_FILTER;
+                lim = prm * med;
+            } else {
+                lim = orc_dists_quantile(d2, cnt, prm);
+                if (lim < 0.f) return ORC_ERR_NO_OUTLIER_TO_FILTER;
+            }
+            if (limit_out) *limit_out = lim;
+            for (int64_t i = 0; i < cnt; ++i) weights[i] *= (d2[i] <= lim) ? 1.f : 0.f;
+        } else if (type == ORC_OUT_SURFACENORMAL) {
+            if (!read_normals3 || !ref_normals3) return ORC_ERR_ARG;
+            const float cosmax = cosf(prm);
+            for (int64_t i = 0; i < n; ++i)
+                for (int j = 0; j < k; ++j) {
+                    const int32_t id = ids[(int64_t)k * i + j];
+                    if (id < 0) { weights[(int64_t)k * i + j] = 0.f; continue; }
+                    const float* a = read_normals3 + 3 * i;
+                    const float* b = ref_normals3 + 3 * (int64_t)id;
+                    const float dot = fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0]));
+                    weights[(int64_t)k * i + j] *= (dot > cosmax) ? 1.f : 0.f;
+                }
+        } else {
+            return ORC_ERR_ARG;
+        }
+    }
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * small dense algebra (float, as Eigen on PM::Matrix = Matrix<float>)
+ * ---------------------------------------------------------------------------------------------- */
+static void mat4_mul(const float* A, const float* B, float* C) /* col-major C = A B */
+{
+    float R[16];
+    for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 4; ++i) {
+            float s = A[i] * B[4 * j];
+            for (int kk = 1; kk < 4; ++kk) s = fmaf(A[4 * kk + i], B[4 * j + kk], s);
+            R[4 * j + i] = s;
+        }
+    memcpy(C, R, sizeof R);
+}
+
+static void mat4_identity(float* T)
+{
+    memset(T, 0, 16 * sizeof(float));
+    T[0] = T[5] = T[10] = T[15] = 1.f;
+}
+
+/* one-sided (Hestenes) Jacobi SVD of a 3x3 float matrix, singular values sorted descending like
+ * Eigen::JacobiSVD. A = U diag(s) V^T. Columns of U for (near) zero singular values are completed
+ * by cross products so that U is orthonormal. */
+static void svd3f(const float* H, float* U, float* s, float* V)
+{
+    float a[9]; memcpy(a, H, sizeof a);                /* col-major working copy, columns rotate */
+    float v[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        float off = 0.f;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                float alpha = 0, beta = 0, gamma = 0;
+                for (int i = 0; i < 3; ++i) {
+                    alpha += a[3 * p + i] * a[3 * p + i];
+                    beta += a[3 * q + i] * a[3 * q + i];
+                    gamma += a[3 * p + i] * a[3 * q + i];
+                }
+                if (gamma == 0.f) continue;
+                const float lim = fabsf(gamma) / sqrtf(fmaxf(alpha * beta, FLT_MIN));
+                if (lim > off) off = lim;
+                if (lim <= 1e-9f) continue;
+                const float zeta = (beta - alpha) / (2.f * gamma);
+                const float tt = (zeta >= 0.f ? 1.f : -1.f) / (fabsf(zeta) + sqrtf(1.f + zeta * zeta));
+                const float c = 1.f / sqrtf(1.f + tt * tt), sn = c * tt;
+                for (int i = 0; i < 3; ++i) {
+                    const float ap = a[3 * p + i], aq = a[3 * q + i];
+                    a[3 * p + i] = c * ap - sn * aq; a[3 * q + i] = sn * ap + c * aq;
+                    const float vp = v[3 * p + i], vq = v[3 * q + i];
+                    v[3 * p + i] = c * vp - sn * vq; v[3 * q + i] = sn * vp + c * vq;
+                }
+            }
+        if (off <= 1e-7f) break;
+    }
+    float sv[3];
+    for (int j = 0; j < 3; ++j)
+        sv[j] = sqrtf(a[3 * j] * a[3 * j] + a[3 * j + 1] * a[3 * j + 1] + a[3 * j + 2] * a[3 * j + 2]);
+    int ord[3] = { 0, 1, 2 };
+    for (int i = 0; i < 2; ++i)
+        for (int j = i + 1; j < 3; ++j)
+            if (sv[ord[j]] > sv[ord[i]]) { int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
+    for (int j = 0; j < 3; ++j) {
+        const int o = ord[j];
+        s[j] = sv[o];
+        for (int i = 0; i < 3; ++i) { V[3 * j + i] = v[3 * o + i]; U[3 * j + i] = a[3 * o + i]; }
+    }
+    const float tiny = s[0] * 1e-6f;
+    int good[3];
+    for (int j = 0; j < 3; ++j) {
+        good[j] = s[j] > tiny && s[j] > 0.f;
+        if (good[j]) for (int i = 0; i < 3; ++i) U[3 * j + i] /= s[j];
+    }
+    if (!good[0]) { float I[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 }; memcpy(U, I, sizeof I); return; }
+    if (!good[1]) {
+        /* any unit vector orthogonal to u0 */
+        const float* u0 = U;
+        int m = fabsf(u0[0]) < fabsf(u0[1]) ? (fabsf(u0[0]) < fabsf(u0[2]) ? 0 : 2) : (fabsf(u0[1]) < fabsf(u0[2]) ? 1 : 2);
+        float e[3] = { 0, 0, 0 }; e[m] = 1.f;
+        const float d = u0[m];
+        float w[3] = { e[0] - d * u0[0], e[1] - d * u0[1], e[2] - d * u0[2] };
+        const float nw = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+        for (int i = 0; i < 3; ++i) U[3 + i] = w[i] / nw;
+    }
+    if (!good[2] || !good[1]) {
+        const float* u0 = U; const float* u1 = U + 3;
+        U[6] = u0[1] * u1[2] - u0[2] * u1[1];
+        U[7] = u0[2] * u1[0] - u0[0] * u1[2];
+        U[8] = u0[0] * u1[1] - u0[1] * u1[0];
+    }
+}
+
+static float det3(const float* R)
+{
+    return R[0] * (R[4] * R[8] - R[7] * R[5]) - R[3] * (R[1] * R[8] - R[7] * R[2]) + R[6] * (R[1] * R[5] - R[4] * R[2]);
+}
+
+/* PointToPointErrorMinimizer::compute tail: R = U V^T, reflection -> negate the last
+ * row of V^T */
+void orc_rotation_from_H(const float* H, float* R)
+{
+    float U[9], s[3], V[9];
+    svd3f(H, U, s, V);
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int j = 0; j < 3; ++j)
+            for (int i = 0; i < 3; ++i) {
+                float acc = 0.f;
+                for (int kk = 0; kk < 3; ++kk) acc += U[3 * kk + i] * V[3 * kk + j]; /* U(i,k) V(j,k) */
+                R[3 * j + i] = acc;
+            }
+        if (pass == 0 && det3(R) < 0.f) { for (int i = 0; i < 3; ++i) V[6 + i] = -V[6 + i]; }
+        else break;
+    }
+}
+
+/* symmetric Jacobi eigen-decomposition in double (n <= 6): A = Q diag(w) Q^T */
+static void jacobi_eig_sym(int n, const double* Ain, double* w, double* Q)
+{
+    double A[36];
+    for (int i = 0; i < n * n; ++i) A[i] = Ain[i];
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) Q[n * j + i] = (i == j);
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0;
+        for (int p = 0; p < n; ++p) for (int q = p + 1; q < n; ++q) off += A[n * q + p] * A[n * q + p];
+        if (off < 1e-300) break;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = A[n * q + p];
+                if (apq == 0.0) continue;
+                const double theta = (A[n * q + q] - A[n * p + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int kk = 0; kk < n; ++kk) {
+                    const double akp = A[n * p + kk], akq = A[n * q + kk];
+                    A[n * p + kk] = c * akp - s * akq; A[n * q + kk] = s * akp + c * akq;
+                }
+                for (int kk = 0; kk < n; ++kk) {
+                    const double apk = A[n * kk + p], aqk = A[n * kk + q];
+                    A[n * kk + p] = c * apk - s * aqk; A[n * kk + q] = s * apk + c * aqk;
+                }
+                for (int kk = 0; kk < n; ++kk) {
+                    const double qkp = Q[n * p + kk], qkq = Q[n * q + kk];
+                    Q[n * p + kk] = c * qkp - s * qkq; Q[n * q + kk] = s * qkp + c * qkq;
+                }
+            }
+    }
+    for (int i = 0; i < n; ++i) w[i] = A[n * i + i];
+}
+
+/* solvePossiblyUnderdeterminedLinearSystem: LLT when A is invertible, otherwise the
+ * minimum-norm solution. Deviation (documented): invertibility is judged on the eigenvalues of the
+ * symmetric A (lambda_min > 6 eps_f lambda_max) instead of the full-pivot QR rank, and the
+ * degenerate branch uses a double-precision symmetric pseudo-inverse; both give upstream's
+ * minimum-norm answer up to rounding. */
+void orc_solve6(const float* A, const float* b, float* x)
+{
+    double Ad[36], w[6], Q[36];
+    for (int i = 0; i < 36; ++i) Ad[i] = A[i];
+    jacobi_eig_sym(6, Ad, w, Q);
+    double wmax = 0, wmin = INFINITY;
+    for (int i = 0; i < 6; ++i) { if (fabs(w[i]) > wmax) wmax = fabs(w[i]); if (w[i] < wmin) wmin = w[i]; }
+    const double thr = 6.0 * (double)FLT_EPSILON * wmax;
+    if (wmin > thr) {
+        /* float Cholesky A = L L^T, forward / backward substitution */
+        float L[36]; memset(L, 0, sizeof L);
+        int ok = 1;
+        for (int j = 0; j < 6 && ok; ++j) {
+            float d = A[6 * j + j];
+            for (int kk = 0; kk < j; ++kk) d -= L[6 * kk + j] * L[6 * kk + j];
+            if (!(d > 0.f)) { ok = 0; break; }
+            const float ljj = sqrtf(d);
+            L[6 * j + j] = ljj;
+            for (int i = j + 1; i < 6; ++i) {
+                float s = A[6 * j + i];
+                for (int kk = 0; kk < j; ++kk) s -= L[6 * kk + i] * L[6 * kk + j];
+                L[6 * j + i] = s / ljj;
+            }
+        }
+        if (ok) {
+            float y[6];
+            for (int i = 0; i < 6; ++i) {
+                float s = b[i];
+                for (int kk = 0; kk < i; ++kk) s -= L[6 * kk + i] * y[kk];
+                y[i] = s / L[6 * i + i];
+            }
+            for (int i = 5; i >= 0; --i) {
+                float s = y[i];
+                for (int kk = i + 1; kk < 6; ++kk) s -= L[6 * i + kk] * x[kk];
+                x[i] = s / L[6 * i + i];
+            }
+            return;
+        }
+    }
+    /* minimum-norm least squares through the eigen-decomposition */
+    double xd[6] = { 0, 0, 0, 0, 0, 0 };
+    for (int e = 0; e < 6; ++e) {
+        if (!(w[e] > thr)) continue;
+        double proj = 0;
+        for (int i = 0; i < 6; ++i) proj += Q[6 * e + i] * (double)b[i];
+        proj /= w[e];
+        for (int i = 0; i < 6; ++i) xd[i] += proj * Q[6 * e + i];
+    }
+    for (int i = 0; i < 6; ++i) x[i] = (float)xd[i];
+}
+
+/* Eigen::AngleAxis(angle, axis).toRotationMatrix() in float */
+static void angle_axis_to_R(const float* x3, float* T)
+{
+    const float nrm = sqrtf(x3[0] * x3[0] + x3[1] * x3[1] + x3[2] * x3[2]);
+    mat4_identity(T);
+    if (!(nrm > 0.f)) return; /* degenerate: upstream replaces the NaN rotation by identity */
+    const float ax = x3[0] / nrm, ay = x3[1] / nrm, az = x3[2] / nrm;
+    /* sin / cos through double so that host libm and device ocml round to the same float */
+    const float s = (float)sin((double)nrm), c = (float)cos((double)nrm);
+    const float sx = s * ax, sy = s * ay, sz = s * az;
+    const float cx = (1.f - c) * ax, cy = (1.f - c) * ay, cz = (1.f - c) * az;
+    float tmp;
+    tmp = cx * ay; T[4 * 1 + 0] = tmp - sz; T[4 * 0 + 1] = tmp + sz;
+    tmp = cx * az; T[4 * 2 + 0] = tmp + sy; T[4 * 0 + 2] = tmp - sy;
+    tmp = cy * az; T[4 * 2 + 1] = tmp - sx; T[4 * 1 + 2] = tmp + sx;
+    T[0] = cx * ax + c; T[5] = cy * ay + c; T[10] = cz * az + c;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * ErrorMinimizer::compute: gather pairs (valid dist && w != 0), then solve.
+ * Sums over pairs are accumulated in double (documented deviation from Eigen's float
+ * accumulation: mathematically identical, removes summation-order noise from the comparison).
+ * ---------------------------------------------------------------------------------------------- */
+int orc_minimize(int minimizer, const float* reading4, int64_t n, const float* ref4,
+                 const float* ref_normals3, const int32_t* ids, const float* d2, const float* w, int k,
+                 float* T_out, double* A_out, double* b_out, float* x_out, orc_stats* st)
+{
+    int64_t P = 0;
+    double wsum = 0;
+    double sp[3] = { 0, 0, 0 }, sq[3] = { 0, 0, 0 }, Hs[9] = { 0 };
+    double A[36] = { 0 }, b[6] = { 0 };
+    for (int64_t i = 0; i < n; ++i)
+        for (int j = 0; j < k; ++j) {
+            const int64_t e = (int64_t)k * i + j;
+            if (d2[e] == INFINITY) continue;
+            const float we = w[e];
+            if (we == 0.f) continue;
+            ++P; wsum += we;
+            if (minimizer == ORC_MIN_IDENTITY) continue;
+            const float* p = reading4 + 4 * i;
+            const float* q = ref4 + 4 * (int64_t)ids[e];
+            if (minimizer == ORC_MIN_POINT_TO_POINT) {
+                for (int r = 0; r < 3; ++r) { sp[r] += (double)we * p[r]; sq[r] += (double)we * q[r]; }
+                for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) Hs[3 * c + r] += (double)we * q[r] * p[c];
+            } else {
+                const float* nn = ref_normals3 + 3 * (int64_t)ids[e];
+                /* cross = reading x normal, F = [cross; normal], dot = (p - q) . n  -- float per pair */
+                const float F[6] = { p[1] * nn[2] - p[2] * nn[1], p[2] * nn[0] - p[0] * nn[2],
+                                     p[0] * nn[1] - p[1] * nn[0], nn[0], nn[1], nn[2] };
+                const float dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
+                const float dot = dx * nn[0] + dy * nn[1] + dz * nn[2];
+                for (int c = 0; c < 6; ++c) {
+                    const double wf = (double)we * F[c];
+                    for (int r = 0; r < 6; ++r) A[6 * c + r] += wf * F[r];
+                    b[c] -= wf * dot;
+                }
+            }
+        }
+    if (st) {
+        st->pairs = P;
+        st->point_used_ratio = (float)P / (float)((int64_t)k * n);
+        st->weighted_point_used_ratio = (float)(wsum / (double)((int64_t)k * n));
+    }
+    if (P == 0) return ORC_ERR_NO_POINT_TO_MINIMIZE;
+    mat4_identity(T_out);
+    if (minimizer == ORC_MIN_IDENTITY) return ORC_OK;
+    if (minimizer == ORC_MIN_POINT_TO_POINT) {
+        /* H = sum w (q - mq)(p - mp)^T = sum w q p^T - (sum w q)(sum w p)^T / sum w */
+        float H[9], R[9];
+        double mp[3], mq[3];
+        for (int r = 0; r < 3; ++r) { mp[r] = sp[r] / wsum; mq[r] = sq[r] / wsum; }
+        for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) H[3 * c + r] = (float)(Hs[3 * c + r] - sq[r] * sp[c] / wsum);
+        if (A_out) for (int i = 0; i < 9; ++i) A_out[i] = H[i];
+        orc_rotation_from_H(H, R);
+        const float mpf[3] = { (float)mp[0], (float)mp[1], (float)mp[2] };
+        const float mqf[3] = { (float)mq[0], (float)mq[1], (float)mq[2] };
+        for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) T_out[4 * c + r] = R[3 * c + r];
+        for (int r = 0; r < 3; ++r)
+            T_out[12 + r] = mqf[r] - (R[r] * mpf[0] + R[3 + r] * mpf[1] + R[6 + r] * mpf[2]);
+        return ORC_OK;
+    }
+    float Af[36], bf[6], x[6];
+    for (int i = 0; i < 36; ++i) Af[i] = (float)A[i];
+    for (int i = 0; i < 6; ++i) bf[i] = (float)b[i];
+    if (A_out) memcpy(A_out, A, sizeof A);
+    if (b_out) memcpy(b_out, b, sizeof b);
+    orc_solve6(Af, bf, x);
+    if (x_out) memcpy(x_out, x, sizeof x);
+    angle_axis_to_R(x, T_out);
+    T_out[12] = x[3]; T_out[13] = x[4]; T_out[14] = x[5];
+    for (int i = 0; i < 16; ++i) if (T_out[i] != T_out[i]) return ORC_ERR_NAN;
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * TransformationCheckers
+ * ---------------------------------------------------------------------------------------------- */
+static void quat_from_R(const float* T, double* q /* w x y z */)
+{
+    /* Eigen::Quaternion(Matrix3) */
+    const double m00 = T[0], m11 = T[5], m22 = T[10];
+    double t = m00 + m11 + m22;
+    if (t > 0) {
+        t = sqrt(t + 1.0);
+        q[0] = 0.5 * t; t = 0.5 / t;
+        q[1] = (T[4 * 1 + 2] - T[4 * 2 + 1]) * t;
+        q[2] = (T[4 * 2 + 0] - T[4 * 0 + 2]) * t;
+        q[3] = (T[4 * 0 + 1] - T[4 * 1 + 0]) * t;
+    } else {
+        int i = 0;
+        if (m11 > m00) i = 1;
+        if (m22 > (i == 0 ? m00 : m11)) i = 2;
+        const int j = (i + 1) % 3, kk = (j + 1) % 3;
+#define M(r, c) ((double)T[4 * (c) + (r)])
+        t = sqrt(M(i, i) - M(j, j) - M(kk, kk) + 1.0);
+        double v[3];
+        v[i] = 0.5 * t; t = 0.5 / t;
+        q[0] = (M(kk, j) - M(j, kk)) * t;
+        v[j] = (M(j, i) + M(i, j)) * t;
+        v[kk] = (M(kk, i) + M(i, kk)) * t;
+#undef M
+        q[1] = v[0]; q[2] = v[1]; q[3] = v[2];
+    }
+}
+
+static double quat_angular_distance(const double* a, const double* b)
+{
+    /* d = a * conj(b); 2 atan2(|d.vec|, |d.w|) */
+    const double w = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+    const double x = -a[0] * b[1] + a[1] * b[0] - a[2] * b[3] + a[3] * b[2];
+    const double y = -a[0] * b[2] + a[1] * b[3] + a[2] * b[0] - a[3] * b[1];
+    const double z = -a[0] * b[3] - a[1] * b[2] + a[2] * b[1] + a[3] * b[0];
+    return 2.0 * atan2(sqrt(x * x + y * y + z * z), fabs(w));
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * ICPSequence (call sites Mapper.cpp:213, Map.cpp:111,178,528,581)
+ * ---------------------------------------------------------------------------------------------- */
+struct orc_icp {
+    orc_config cfg;
+    int64_t m;
+    float mean[3];
+    float* map4;       /* centred map                                       */
+    float* normals3;   /* or NULL                                           */
+    orc_kdtree* tree;
+};
+
+orc_icp* orc_icp_create(const orc_config* cfg)
+{
+    orc_icp* s = (orc_icp*)calloc(1, sizeof *s);
+    s->cfg = *cfg;
+    if (s->cfg.knn < 1) s->cfg.knn = 1;
+    if (s->cfg.nthreads < 1) s->cfg.nthreads = 1;
+    return s;
+}
+
+void orc_icp_destroy(orc_icp* s)
+{
+    if (!s) return;
+    free(s->map4); free(s->normals3); orc_kdtree_free(s->tree); free(s);
+}
+
+int orc_icp_has_map(const orc_icp* s) { return s->m > 0; }
+void orc_icp_get_mean(const orc_icp* s, float* mean3) { memcpy(mean3, s->mean, 3 * sizeof(float)); }
+
+int orc_icp_set_map(orc_icp* s, const float* map4, int64_t m, const float* normals3)
+{
+    if (m <= 0) return 0; /* ICPSequence::setMap rejects an empty cloud, state unchanged */
+    free(s->map4); free(s->normals3); orc_kdtree_free(s->tree);
+    s->normals3 = NULL;
+    s->m = m;
+    double sum[3] = { 0, 0, 0 };
+    for (int64_t i = 0; i < m; ++i) for (int r = 0; r < 3; ++r) sum[r] += map4[4 * i + r];
+    for (int r = 0; r < 3; ++r) s->mean[r] = (float)(sum[r] / (double)m);
+    s->map4 = (float*)malloc((size_t)m * 4 * sizeof(float));
+    for (int64_t i = 0; i < m; ++i) {
+        for (int r = 0; r < 3; ++r) s->map4[4 * i + r] = map4[4 * i + r] - s->mean[r];
+        s->map4[4 * i + 3] = map4[4 * i + 3];
+    }
+    if (normals3) {
+        s->normals3 = (float*)malloc((size_t)m * 3 * sizeof(float));
+        memcpy(s->normals3, normals3, (size_t)m * 3 * sizeof(float));
+    }
+    /* KDTreeMatcher::init: bucketSize = knn if knn > 1 else libnabo's default 8 */
+    s->tree = orc_kdtree_build(s->map4, m, 3, s->cfg.knn > 1 ? s->cfg.knn : 8);
+    return 1;
+}
+
+int orc_icp_register(orc_icp* s, const float* scan4, int64_t n, const float* scan_normals3,
+                     float* T_out, orc_stats* st)
+{
+    orc_stats local; if (!st) st = &local;
+    memset(st, 0, sizeof *st);
+    mat4_identity(T_out);
+    if (!orc_icp_has_map(s)) return ORC_OK; /* "Ignoring attempt to perform ICP with an empty map" */
+    const orc_config* cfg = &s->cfg;
+    const int k = cfg->knn;
+    if (cfg->minimizer == ORC_MIN_POINT_TO_PLANE && !s->normals3) return ORC_ERR_ARG;
+
+    float Tmean[16], Tmean_inv[16];
+    mat4_identity(Tmean); mat4_identity(Tmean_inv);
+    for (int r = 0; r < 3; ++r) { Tmean[12 + r] = s->mean[r]; Tmean_inv[12 + r] = -s->mean[r]; }
+
+    float* reading = (float*)malloc((size_t)(n > 0 ? n : 1) * 4 * sizeof(float));
+    float* step = (float*)malloc((size_t)(n > 0 ? n : 1) * 4 * sizeof(float));
+    float* step_normals = scan_normals3 ? (float*)malloc((size_t)(n > 0 ? n : 1) * 3 * sizeof(float)) : NULL;
+    int32_t* ids = (int32_t*)malloc((size_t)(n > 0 ? n : 1) * k * sizeof(int32_t));
+    float* d2 = (float*)malloc((size_t)(n > 0 ? n : 1) * k * sizeof(float));
+    float* w = (float*)malloc((size_t)(n > 0 ? n : 1) * k * sizeof(float));
+    orc_transform(Tmean_inv, scan4, reading, n);
+
+    float T_iter[16]; mat4_identity(T_iter);
+    /* checkers.init(T_iter) */
+    int counter = 0;
+    const int SL = cfg->smooth_length > 0 ? cfg->smooth_length : 3;
+    int hist_n = 0, hist_cap = cfg->max_iterations + 2;
+    if (hist_cap < 8) hist_cap = 8;
+    double* hq = (double*)malloc((size_t)hist_cap * 4 * sizeof(double));
+    double* ht = (double*)malloc((size_t)hist_cap * 3 * sizeof(double));
+    quat_from_R(T_iter, hq); ht[0] = ht[1] = ht[2] = 0; hist_n = 1;
+    float init_t[3] = { 0, 0, 0 }; double init_q[4]; memcpy(init_q, hq, sizeof init_q);
+
+    int err = ORC_OK, iterate = 1;
+    const double t0 = now_s();
+    while (iterate) {
+        orc_transform(T_iter, reading, step, n);
+        if (step_normals) orc_rotate3(T_iter, scan_normals3, step_normals, n);
+        const double tk = now_s();
+        orc_kdtree_knn(s->tree, step, n, k, cfg->max_dist, 1, ids, d2, cfg->nthreads);
+        st->seconds_knn += now_s() - tk;
+        err = orc_outlier_weights(cfg, d2, ids, k, n, step_normals, s->normals3, w, &st->trimmed_limit);
+        if (err) break;
+        float T_step[16];
+        err = orc_minimize(cfg->minimizer, step, n, s->map4, s->normals3, ids, d2, w, k, T_step, NULL, NULL, NULL, st);
+        if (err) break;
+        mat4_mul(T_step, T_iter, T_iter);
+        ++st->iterations;
+        /* Counter */
+        ++counter;
+        if (counter >= cfg->max_iterations) { iterate = 0; st->stop_reason = ORC_STOP_COUNTER; }
+        /* Differential */
+        if (cfg->use_differential) {
+            if (hist_n == hist_cap) {
+                hist_cap *= 2;
+                hq = (double*)realloc(hq, (size_t)hist_cap * 4 * sizeof(double));
+                ht = (double*)realloc(ht, (size_t)hist_cap * 3 * sizeof(double));
+            }
+            quat_from_R(T_iter, hq + 4 * hist_n);
+            for (int r = 0; r < 3; ++r) ht[3 * hist_n + r] = T_iter[12 + r];
+            ++hist_n;
+            if (hist_n > SL) {
+                double rot = 0, tr = 0;
+                for (int i = hist_n - 1; i >= hist_n - SL; --i) {
+                    rot += fabs(quat_angular_distance(hq + 4 * i, hq + 4 * (i - 1)));
+                    const double dx = ht[3 * i] - ht[3 * (i - 1)], dy = ht[3 * i + 1] - ht[3 * (i - 1) + 1],
+                                 dz = ht[3 * i + 2] - ht[3 * (i - 1) + 2];
+                    tr += sqrt(dx * dx + dy * dy + dz * dz);
+                }
+                rot /= SL; tr /= SL;
+                if (rot != rot || tr != tr) { err = ORC_ERR_NAN; break; }
+                if (rot < cfg->min_diff_rot && tr < cfg->min_diff_trans) {
+                    if (iterate) st->stop_reason = ORC_STOP_DIFFERENTIAL;
+                    iterate = 0;
+                }
+            }
+        }
+        /* Bound */
+        if (cfg->use_bound) {
+            double q[4]; quat_from_R(T_iter, q);
+            const double rot = fabs(quat_angular_distance(q, init_q));
+            const double dx = T_iter[12] - init_t[0], dy = T_iter[13] - init_t[1], dz = T_iter[14] - init_t[2];
+            if (rot > cfg->max_rot_norm || sqrt(dx * dx + dy * dy + dz * dz) > cfg->max_trans_norm) { err = ORC_ERR_BOUND; break; }
+        }
+    }
+    st->seconds_total = now_s() - t0;
+    st->error = err;
+    if (!err) {
+        float tmp[16];
+        mat4_mul(T_iter, Tmean_inv, tmp);
+        mat4_mul(Tmean, tmp, T_out);
+    }
+    free(reading); free(step); free(step_normals); free(ids); free(d2); free(w); free(hq); free(ht);
+    return err;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * SurfaceNormalDataPointsFilter (applied at Map.cpp:524 from examples/config.yaml:26)
+ * ---------------------------------------------------------------------------------------------- */
+void orc_surface_normals(const float* pts4, int64_t m, int knn, float* normals3, int nthreads)
+{
+    orc_kdtree* t = orc_kdtree_build(pts4, m, 3, knn > 1 ? knn : 8);
+    int32_t* ids = (int32_t*)malloc((size_t)m * knn * sizeof(int32_t));
+    float* d2 = (float*)malloc((size_t)m * knn * sizeof(float));
+    orc_kdtree_knn(t, pts4, m, knn, INFINITY, 1, ids, d2, nthreads);
+    for (int64_t i = 0; i < m; ++i) {
+        double mean[3] = { 0, 0, 0 };
+        int real = 0;
+        for (int j = 0; j < knn; ++j) {
+            const int32_t id = ids[(int64_t)knn * i + j];
+            if (id < 0) continue;
+            ++real;
+            for (int r = 0; r < 3; ++r) mean[r] += pts4[4 * (int64_t)id + r];
+        }
+        double C[9] = { 0 };
+        for (int r = 0; r < 3; ++r) mean[r] /= (real > 0 ? real : 1);
+        for (int j = 0; j < knn; ++j) {
+            const int32_t id = ids[(int64_t)knn * i + j];
+            if (id < 0) continue;
+            double v[3];
+            for (int r = 0; r < 3; ++r) v[r] = (double)pts4[4 * (int64_t)id + r] - mean[r];
+            for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) C[3 * c + r] += v[r] * v[c];
+        }
+        double w[3], Q[9];
+        jacobi_eig_sym(3, C, w, Q);
+        /* rank test of upstream: needs rank >= 2, otherwise eigenvalues 0 / eigenvectors identity */
+        double wmax = fmax(fabs(w[0]), fmax(fabs(w[1]), fabs(w[2])));
+        int rank = 0;
+        for (int e = 0; e < 3; ++e) if (fabs(w[e]) > 3.0 * FLT_EPSILON * wmax && wmax > 0) ++rank;
+        if (rank < 2) { normals3[3 * i] = 1.f; normals3[3 * i + 1] = 0.f; normals3[3 * i + 2] = 0.f; continue; }
+        int e = 0;
+        if (w[1] < w[e]) e = 1;
+        if (w[2] < w[e]) e = 2;
+        for (int r = 0; r < 3; ++r) normals3[3 * i + r] = (float)Q[3 * e + r];
+    }
+    free(ids); free(d2); orc_kdtree_free(t);
+}
+
+/* PointDistanceMapperModule::inPlaceUpdateMap keep mask (PointDistanceMapperModule.cpp:28-50):
+ * kd-tree on the MAP, k = 1, epsilon 0, optionFlags 0 (self match not allowed), no radius;
+ * keep iff dists(i) >= minDistNewPoint^2 (an unfilled slot is +inf => kept). */
+void orc_point_distance_keep(const float* map4, int64_t m, const float* in4, int64_t n, float min_dist,
+                             uint8_t* keep, int nthreads)
+{
+    orc_kdtree* t = orc_kdtree_build(map4, m, 3, 8);
+    int32_t* ids = (int32_t*)malloc((size_t)(n > 0 ? n : 1) * sizeof(int32_t));
+    float* d2 = (float*)malloc((size_t)(n > 0 ? n : 1) * sizeof(float));
+    orc_kdtree_knn(t, in4, n, 1, INFINITY, 0, ids, d2, nthreads);
+    const float lim = powf(min_dist, 2.f);
+    for (int64_t i = 0; i < n; ++i) keep[i] = d2[i] >= lim;
+    free(ids); free(d2); orc_kdtree_free(t);
+}
+
+/* Map::unloadCells binning (Map.cpp:206-209) with toGridCoordinate (Map.cpp:232-235) */
+void orc_cell_ids(const float* pts4, int64_t n, float cell_size, int32_t* ijk3)
+{
+    for (int64_t i = 0; i < n; ++i)
+        for (int r = 0; r < 3; ++r) ijk3[3 * i + r] = (int32_t)floorf(pts4[4 * i + r] / cell_size);
+}

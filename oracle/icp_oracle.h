@@ -1,0 +1,155 @@
+/*
+ * oracle/icp_oracle.h -- CPU restatement of the ICP registration hot path
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under norlab_icp_mapper_amd/ (the product)
+ * may include, link or call this.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py load liboracle.so, and only as the checker /
+ * timed CPU baseline.
+ *
+ * PARITY UNPINNED: the arithmetic of this path lives in libpointmatcher (pinned
+ * 1.4.3, /root/reference/CMakeLists.txt:33) and libnabo (unpinned,
+ * /root/reference/package.xml:14), neither of which is vendored under
+ * /root/reference nor installed in the build image, and the reference ships no
+ * tests or golden vectors.  This file restates the
+ * published algorithms of those libraries and is pinned
+ * instead by (1) ground-truth-by-construction synthetic scenes, (2) independent
+ * numpy / scipy cross-checks committed under tests/golden/ and (3) the
+ * bundled-data known answer (Identity minimiser => trajectory unchanged).
+ *
+ * Call sites in the reference that this restates (file:line in /root/reference):
+ *   icp(input)                       norlab_icp_mapper/Mapper.cpp:213
+ *   icp.setMap(localPointCloud)      norlab_icp_mapper/Map.cpp:111,178,528,581
+ *   transformation->compute(..)      norlab_icp_mapper/Mapper.cpp:197,221; Map.cpp:523,525
+ *   errorMinimizer->getOverlap()     norlab_icp_mapper/Mapper.cpp:219
+ *   NNS::create / nns->knn(..)       norlab_icp_mapper/MapperModules/PointDistanceMapperModule.cpp:33-36
+ *
+ * Numeric conventions (shared spec with the HIP path, written down in DESIGN.md):
+ *   - points are 4 x N column-major float (x,y,z,1), as PM::DataPoints::features;
+ *   - rigid transform of one coordinate: fmaf(T03,w, fmaf(T02,z, fmaf(T01,y, T00*x)))
+ *     (Eigen accumulates the 4x4 * 4xN product column by column);
+ *   - squared distance: fmaf(dz,dz, fmaf(dy,dy, dx*dx)), float;
+ *   - NN ties (equal float d^2) resolve to the smallest map index;
+ *   - all sums over pairs are accumulated in double, rounded to float before the
+ *     3x3 SVD / 6x6 LLT, which run in float like the reference's Eigen code.
+ */
+#ifndef ICP_ORACLE_H
+#define ICP_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- configuration: mirrors include/icpmi.h (kept textually independent) ---- */
+enum { ORC_MIN_IDENTITY = 0, ORC_MIN_POINT_TO_POINT = 1, ORC_MIN_POINT_TO_PLANE = 2 };
+enum { ORC_OUT_MAXDIST = 1, ORC_OUT_MINDIST = 2, ORC_OUT_MEDIANDIST = 3, ORC_OUT_TRIMMEDDIST = 4,
+       ORC_OUT_SURFACENORMAL = 5 };
+enum { ORC_OK = 0, ORC_ERR_NO_POINT_TO_MINIMIZE = 1, ORC_ERR_NO_OUTLIER_TO_FILTER = 2,
+       ORC_ERR_BOUND = 3, ORC_ERR_NAN = 4, ORC_ERR_ARG = 5 };
+enum { ORC_STOP_NONE = 0, ORC_STOP_COUNTER = 1, ORC_STOP_DIFFERENTIAL = 2 };
+
+typedef struct {
+    int   type;
+    float param;
+} orc_outlier;
+
+typedef struct {
+    int   knn;               /* KDTreeMatcher.knn (default 1)                     */
+    float max_dist;          /* KDTreeMatcher.maxDist (default +inf)              */
+    int   minimizer;         /* ORC_MIN_*                                         */
+    int   n_outlier;
+    orc_outlier outlier[8];
+    int   max_iterations;    /* CounterTransformationChecker.maxIterationCount    */
+    int   use_differential;  /* DifferentialTransformationChecker                 */
+    float min_diff_rot;
+    float min_diff_trans;
+    int   smooth_length;
+    int   use_bound;         /* BoundTransformationChecker                        */
+    float max_rot_norm;
+    float max_trans_norm;
+    int   nthreads;          /* OpenMP threads for the kNN query loop (>=1)       */
+} orc_config;
+
+typedef struct {
+    int   iterations;
+    int   stop_reason;
+    int   error;
+    int64_t pairs;                   /* P of the last iteration                        */
+    float point_used_ratio;          /* P / (knn N)                                    */
+    float weighted_point_used_ratio; /* sum(w) / (knn N)  == getOverlap()              */
+    float trimmed_limit;             /* last TrimmedDist / MedianDist limit (d^2)      */
+    double seconds_knn;              /* wall time spent in the kNN stage               */
+    double seconds_total;            /* wall time of the iteration loop                */
+} orc_stats;
+
+/* ---- stage-level functions ---- */
+
+/* RigidTransformation::compute on features. T is 4x4 column-major. */
+void orc_transform(const float* T, const float* in4, float* out4, int64_t n);
+/* rotate a 3 x n descriptor block (normals) by the top-left 3x3 of T */
+void orc_rotate3(const float* T, const float* in3, float* out3, int64_t n);
+
+typedef struct orc_kdtree orc_kdtree;
+/* libnabo-style kd-tree over the first `dim` rows of a 4 x m cloud (split on the widest
+ * dimension at the median, buckets <= bucket_size). The cloud is copied. */
+orc_kdtree* orc_kdtree_build(const float* pts4, int64_t m, int dim, int bucket_size);
+void orc_kdtree_free(orc_kdtree* t);
+/* NNS::knn contract: ids k x n (int32, -1 unfilled), d2 k x n (+inf unfilled),
+ * ascending by (d2, id); accepts d2 <= max_radius^2; allow_self==0 rejects d2 <= FLT_EPSILON. */
+void orc_kdtree_knn(const orc_kdtree* t, const float* q4, int64_t n, int k, float max_radius,
+                    int allow_self, int32_t* ids, float* d2, int nthreads);
+/* brute-force version with the identical contract (used to validate the kd-tree) */
+void orc_bruteforce_knn(const float* pts4, int64_t m, int dim, const float* q4, int64_t n, int k,
+                        float max_radius, int allow_self, int32_t* ids, float* d2);
+
+/* Matches::getDistsQuantile: quantile over finite, >0 entries. returns <0 if none */
+float orc_dists_quantile(const float* d2, int64_t count, float quantile);
+
+/* OutlierFilters::compute for the configured chain. ref_normals/read_normals (3 x .) may be NULL
+ * unless a SurfaceNormal filter is configured. weights is k x n. */
+int orc_outlier_weights(const orc_config* cfg, const float* d2, const int32_t* ids, int k, int64_t n,
+                        const float* read_normals3, const float* ref_normals3, float* weights,
+                        float* limit_out);
+
+/* ErrorMinimizer::compute: gathers pairs (valid dist && w != 0) then point-to-point (3x3 SVD) or
+ * point-to-plane (6x6 LLT). T_out 4x4 col-major. A_out (36, col-major) / b_out (6) / x_out (6) are
+ * filled for point-to-plane when non-NULL; H_out (9) for point-to-point. */
+int orc_minimize(int minimizer, const float* reading4, int64_t n, const float* ref4,
+                 const float* ref_normals3, const int32_t* ids, const float* d2, const float* w, int k,
+                 float* T_out, double* A_out, double* b_out, float* x_out, orc_stats* st);
+
+/* 3x3 SVD-based rotation (PointToPointErrorMinimizer) from a float 3x3 H (col-major): R = U V^T with
+ * the reflection fix. Exposed for unit tests. */
+void orc_rotation_from_H(const float* H, float* R);
+/* solvePossiblyUnderdeterminedLinearSystem restatement, A 6x6 col-major float. */
+void orc_solve6(const float* A, const float* b, float* x);
+
+/* ---- ICPSequence ---- */
+typedef struct orc_icp orc_icp;
+orc_icp* orc_icp_create(const orc_config* cfg);
+void orc_icp_destroy(orc_icp* s);
+/* returns 1 on success, 0 if the cloud is empty (state unchanged) */
+int orc_icp_set_map(orc_icp* s, const float* map4, int64_t m, const float* normals3);
+int orc_icp_has_map(const orc_icp* s);
+/* mean used for centring (3 floats) */
+void orc_icp_get_mean(const orc_icp* s, float* mean3);
+/* icp(cloudIn): T_out 4x4 col-major correction in the map frame. If fixed_iterations > 0 only the
+ * Counter checker is active with that count (throughput mode). Returns ORC_OK or ORC_ERR_*. */
+int orc_icp_register(orc_icp* s, const float* scan4, int64_t n, const float* scan_normals3,
+                     float* T_out, orc_stats* st);
+
+/* ---- map-side operators on the path ---- */
+/* SurfaceNormalDataPointsFilter: kNN (self included) + smallest-eigenvector normal */
+void orc_surface_normals(const float* pts4, int64_t m, int knn, float* normals3, int nthreads);
+/* PointDistanceMapperModule::inPlaceUpdateMap keep-mask (PointDistanceMapperModule.cpp:28-50):
+ * keep[i] = 1 iff exact NN (self match NOT allowed, no radius) has d2 >= minDist^2 */
+void orc_point_distance_keep(const float* map4, int64_t m, const float* in4, int64_t n, float min_dist,
+                             uint8_t* keep, int nthreads);
+/* cell index of Map::unloadCells (Map.cpp:206-209,232-235): floor(x / 20.0f) per axis */
+void orc_cell_ids(const float* pts4, int64_t n, float cell_size, int32_t* ijk3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,211 @@
+"""ctypes binding of oracle/liboracle.so (the CPU restatement; test infrastructure only)."""
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = os.path.join(_ROOT, "oracle", "liboracle.so")
+
+MIN_IDENTITY, MIN_POINT_TO_POINT, MIN_POINT_TO_PLANE = 0, 1, 2
+OUT_MAXDIST, OUT_MINDIST, OUT_MEDIANDIST, OUT_TRIMMEDDIST, OUT_SURFACENORMAL = 1, 2, 3, 4, 5
+STOP_COUNTER, STOP_DIFFERENTIAL = 1, 2
+
+
+class Outlier(C.Structure):
+    _fields_ = [("type", C.c_int), ("param", C.c_float)]
+
+
+class Config(C.Structure):
+    _fields_ = [("knn", C.c_int), ("max_dist", C.c_float), ("minimizer", C.c_int), ("n_outlier", C.c_int),
+                ("outlier", Outlier * 8), ("max_iterations", C.c_int), ("use_differential", C.c_int),
+                ("min_diff_rot", C.c_float), ("min_diff_trans", C.c_float), ("smooth_length", C.c_int),
+                ("use_bound", C.c_int), ("max_rot_norm", C.c_float), ("max_trans_norm", C.c_float),
+                ("nthreads", C.c_int)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("stop_reason", C.c_int), ("error", C.c_int), ("pairs", C.c_int64),
+                ("point_used_ratio", C.c_float), ("weighted_point_used_ratio", C.c_float),
+                ("trimmed_limit", C.c_float), ("seconds_knn", C.c_double), ("seconds_total", C.c_double)]
+
+
+_lib = None
+_P = C.c_void_p
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_ROOT, "oracle")])
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB):
+        build()
+    lib = C.CDLL(_LIB)
+    lib.orc_kdtree_build.restype = _P
+    lib.orc_kdtree_build.argtypes = [_P, C.c_int64, C.c_int, C.c_int]
+    lib.orc_kdtree_free.argtypes = [_P]
+    lib.orc_kdtree_knn.argtypes = [_P, _P, C.c_int64, C.c_int, C.c_float, C.c_int, _P, _P, C.c_int]
+    lib.orc_bruteforce_knn.argtypes = [_P, C.c_int64, C.c_int, _P, C.c_int64, C.c_int, C.c_float, C.c_int, _P, _P]
+    lib.orc_transform.argtypes = [_P, _P, _P, C.c_int64]
+    lib.orc_rotate3.argtypes = [_P, _P, _P, C.c_int64]
+    lib.orc_dists_quantile.restype = C.c_float
+    lib.orc_dists_quantile.argtypes = [_P, C.c_int64, C.c_float]
+    lib.orc_outlier_weights.argtypes = [C.POINTER(Config), _P, _P, C.c_int, C.c_int64, _P, _P, _P, C.POINTER(C.c_float)]
+    lib.orc_minimize.argtypes = [C.c_int, _P, C.c_int64, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, C.POINTER(Stats)]
+    lib.orc_rotation_from_H.argtypes = [_P, _P]
+    lib.orc_solve6.argtypes = [_P, _P, _P]
+    lib.orc_icp_create.restype = _P
+    lib.orc_icp_create.argtypes = [C.POINTER(Config)]
+    lib.orc_icp_destroy.argtypes = [_P]
+    lib.orc_icp_set_map.argtypes = [_P, _P, C.c_int64, _P]
+    lib.orc_icp_has_map.argtypes = [_P]
+    lib.orc_icp_get_mean.argtypes = [_P, _P]
+    lib.orc_icp_register.argtypes = [_P, _P, C.c_int64, _P, _P, C.POINTER(Stats)]
+    lib.orc_surface_normals.argtypes = [_P, C.c_int64, C.c_int, _P, C.c_int]
+    lib.orc_point_distance_keep.argtypes = [_P, C.c_int64, _P, C.c_int64, C.c_float, _P, C.c_int]
+    lib.orc_cell_ids.argtypes = [_P, C.c_int64, C.c_float, _P]
+    _lib = lib
+    return lib
+
+
+def make_config(knn=1, max_dist=math.inf, minimizer=MIN_POINT_TO_PLANE, outliers=(), max_iterations=40,
+                use_differential=0, min_diff_rot=1e-3, min_diff_trans=1e-3, smooth_length=3, use_bound=0,
+                max_rot_norm=1.0, max_trans_norm=1.0, nthreads=1):
+    cfg = Config()
+    cfg.knn, cfg.max_dist, cfg.minimizer = knn, max_dist, minimizer
+    cfg.n_outlier = len(outliers)
+    for i, (t, p) in enumerate(outliers):
+        cfg.outlier[i].type, cfg.outlier[i].param = t, p
+    cfg.max_iterations, cfg.use_differential = max_iterations, use_differential
+    cfg.min_diff_rot, cfg.min_diff_trans, cfg.smooth_length = min_diff_rot, min_diff_trans, smooth_length
+    cfg.use_bound, cfg.max_rot_norm, cfg.max_trans_norm = use_bound, max_rot_norm, max_trans_norm
+    cfg.nthreads = nthreads
+    return cfg
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def T_to_c(T):
+    return np.ascontiguousarray(np.asarray(T, dtype=np.float32).T).ravel()
+
+
+def T_from_c(buf):
+    return np.array(buf, dtype=np.float32).reshape(4, 4).T.copy()
+
+
+def transform(T, cloud):
+    lib = load(); cloud = _f32(cloud); out = np.empty_like(cloud); Tc = T_to_c(T)
+    lib.orc_transform(Tc.ctypes.data, cloud.ctypes.data, out.ctypes.data, cloud.shape[0])
+    return out
+
+
+def rotate3(T, normals):
+    lib = load(); normals = _f32(normals); out = np.empty_like(normals); Tc = T_to_c(T)
+    lib.orc_rotate3(Tc.ctypes.data, normals.ctypes.data, out.ctypes.data, normals.shape[0])
+    return out
+
+
+def knn(cloud, queries, k=1, max_dist=math.inf, allow_self=True, bucket=8, nthreads=1, brute=False):
+    lib = load(); cloud = _f32(cloud); q = _f32(queries)
+    ids = np.empty((q.shape[0], k), dtype=np.int32); d2 = np.empty((q.shape[0], k), dtype=np.float32)
+    if brute:
+        lib.orc_bruteforce_knn(cloud.ctypes.data, cloud.shape[0], 3, q.ctypes.data, q.shape[0], k, max_dist, int(allow_self),
+                               ids.ctypes.data, d2.ctypes.data)
+    else:
+        t = lib.orc_kdtree_build(cloud.ctypes.data, cloud.shape[0], 3, bucket)
+        lib.orc_kdtree_knn(t, q.ctypes.data, q.shape[0], k, max_dist, int(allow_self), ids.ctypes.data, d2.ctypes.data, nthreads)
+        lib.orc_kdtree_free(t)
+    return ids, d2
+
+
+def dists_quantile(d2, q):
+    lib = load(); d2 = _f32(d2).ravel()
+    return float(lib.orc_dists_quantile(d2.ctypes.data, d2.size, q))
+
+
+def outlier_weights(cfg, d2, ids, read_normals=None, ref_normals=None):
+    lib = load(); d2 = _f32(d2); ids = np.ascontiguousarray(ids, dtype=np.int32)
+    n, k = d2.shape
+    w = np.empty_like(d2); lim = C.c_float(-1)
+    rn = _f32(read_normals).ctypes.data if read_normals is not None else None
+    fn = _f32(ref_normals).ctypes.data if ref_normals is not None else None
+    err = lib.orc_outlier_weights(C.byref(cfg), d2.ctypes.data, ids.ctypes.data, k, n, rn, fn, w.ctypes.data, C.byref(lim))
+    return err, w, float(lim.value)
+
+
+def minimize(minimizer, reading, ref, ref_normals, ids, d2, w):
+    lib = load(); reading = _f32(reading); ref = _f32(ref)
+    ids = np.ascontiguousarray(ids, dtype=np.int32); d2 = _f32(d2); w = _f32(w)
+    n, k = d2.shape
+    T = np.zeros(16, dtype=np.float32); A = np.zeros(36); b = np.zeros(6); x = np.zeros(6, dtype=np.float32)
+    st = Stats()
+    nr = _f32(ref_normals) if ref_normals is not None else None
+    err = lib.orc_minimize(minimizer, reading.ctypes.data, n, ref.ctypes.data, nr.ctypes.data if nr is not None else None,
+                           ids.ctypes.data, d2.ctypes.data, w.ctypes.data, k, T.ctypes.data, A.ctypes.data, b.ctypes.data,
+                           x.ctypes.data, C.byref(st))
+    return err, T_from_c(T), A.reshape(6, 6).T.copy(), b, x, st
+
+
+def rotation_from_H(H):
+    lib = load(); Hc = np.ascontiguousarray(np.asarray(H, dtype=np.float32).T).ravel(); R = np.zeros(9, dtype=np.float32)
+    lib.orc_rotation_from_H(Hc.ctypes.data, R.ctypes.data)
+    return R.reshape(3, 3).T.copy()
+
+
+def solve6(A, b):
+    lib = load(); Ac = np.ascontiguousarray(np.asarray(A, dtype=np.float32).T).ravel(); bc = _f32(b); x = np.zeros(6, dtype=np.float32)
+    lib.orc_solve6(Ac.ctypes.data, bc.ctypes.data, x.ctypes.data)
+    return x
+
+
+class OracleICP:
+    def __init__(self, cfg):
+        self.lib = load(); self.cfg = cfg
+        self.h = self.lib.orc_icp_create(C.byref(cfg)); self.stats = Stats()
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.orc_icp_destroy(self.h); self.h = None
+        except Exception:
+            pass
+
+    def setMap(self, cloud, normals=None):
+        cloud = _f32(cloud); n = _f32(normals) if normals is not None else None
+        return bool(self.lib.orc_icp_set_map(self.h, cloud.ctypes.data, cloud.shape[0], n.ctypes.data if n is not None else None))
+
+    def getMapMean(self):
+        m = np.zeros(3, dtype=np.float32); self.lib.orc_icp_get_mean(self.h, m.ctypes.data); return m
+
+    def __call__(self, scan, scan_normals=None):
+        scan = _f32(scan); sn = _f32(scan_normals) if scan_normals is not None else None
+        T = np.zeros(16, dtype=np.float32)
+        err = self.lib.orc_icp_register(self.h, scan.ctypes.data, scan.shape[0], sn.ctypes.data if sn is not None else None,
+                                        T.ctypes.data, C.byref(self.stats))
+        return err, T_from_c(T)
+
+
+def surface_normals(cloud, knn=5, nthreads=1):
+    lib = load(); cloud = _f32(cloud); out = np.empty((cloud.shape[0], 3), dtype=np.float32)
+    lib.orc_surface_normals(cloud.ctypes.data, cloud.shape[0], knn, out.ctypes.data, nthreads)
+    return out
+
+
+def point_distance_keep(map_cloud, in_cloud, min_dist, nthreads=1):
+    lib = load(); m = _f32(map_cloud); i = _f32(in_cloud); keep = np.empty(i.shape[0], dtype=np.uint8)
+    lib.orc_point_distance_keep(m.ctypes.data, m.shape[0], i.ctypes.data, i.shape[0], min_dist, keep.ctypes.data, nthreads)
+    return keep.astype(bool)
+
+
+def cell_ids(cloud, cell_size=20.0):
+    lib = load(); c = _f32(cloud); out = np.empty((c.shape[0], 3), dtype=np.int32)
+    lib.orc_cell_ids(c.ctypes.data, c.shape[0], cell_size, out.ctypes.data)
+    return out

@@ -1,0 +1,235 @@
+"""GPU parity tests: the HIP path (through the C ABI of libicpmi.so) against the CPU oracle on the
+same seeded inputs.  Bars: bit-exact for indices, squared distances, weights and the quantile limit
+(integer / comparison work on identically specified float arithmetic); poses within 1e-4 m / 1e-4 rad
+(the tolerance BASELINE.json's north_star states)."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL_M = 1e-4
+POSE_TOL_RAD = 1e-4
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import norlab_icp_mapper_amd as pkg
+    return pkg
+
+
+def centred(cloud, mean):
+    out = cloud.copy()
+    out[:, :3] = cloud[:, :3] - mean[None, :]
+    return out
+
+
+def test_transform_bit_exact(amd, oracle, small_scene):
+    icp = amd.ICPSequence(minimizer=0)
+    T = amd.synth.make_T((0.3, -0.2, 0.5), (1.5, -2.0, 0.25))
+    out, outn = icp.transform(T, small_scene["scan"], small_scene["scan_normals"])
+    ref = oracle.transform(T, small_scene["scan"])
+    refn = oracle.rotate3(T, small_scene["scan_normals"])
+    assert np.array_equal(out, ref)
+    assert np.array_equal(outn, refn)
+    bad = np.eye(4); bad[0, 0] = 1.5
+    with pytest.raises(amd.TransformationError):
+        icp.transform(bad, small_scene["scan"])
+
+
+@pytest.mark.parametrize("k,max_dist", [(1, 2.0), (1, math.inf), (1, 0.05), (6, 2.0), (10, math.inf)])
+def test_knn_matches_oracle_exactly(amd, oracle, small_scene, k, max_dist):
+    icp = amd.ICPSequence(minimizer=0, knn=min(k, 32))
+    assert icp.setMap(small_scene["map"])
+    mean = icp.getMapMean()
+    ocfg = oracle.make_config()
+    oicp = oracle.OracleICP(ocfg); oicp.setMap(small_scene["map"])
+    assert np.array_equal(mean, oicp.getMapMean())
+    mapc = centred(small_scene["map"], mean)
+    q = centred(small_scene["scan"], mean)
+    ids, d2 = icp.knn(q, k=k, max_dist=max_dist)
+    rids, rd2 = oracle.knn(mapc, q, k=k, max_dist=max_dist, nthreads=8)
+    assert np.array_equal(d2, rd2)
+    assert np.array_equal(ids, rids)
+
+
+def test_knn_far_queries_and_self_match(amd, oracle, small_scene):
+    icp = amd.ICPSequence(minimizer=0)
+    m = small_scene["map"][:20000]
+    icp.setMap(m)
+    mean = icp.getMapMean()
+    mapc = centred(m, mean)
+    # queries far outside the bounding box, with and without a radius
+    rng = np.random.default_rng(5)
+    q = np.ones((300, 4), dtype=np.float32)
+    q[:, :3] = rng.uniform(-400, 400, size=(300, 3)).astype(np.float32)
+    for md in (math.inf, 30.0):
+        ids, d2 = icp.knn(q, k=1, max_dist=md)
+        rids, rd2 = oracle.knn(mapc, q, k=1, max_dist=md)
+        assert np.array_equal(d2, rd2) and np.array_equal(ids, rids)
+    # self match excluded (PointDistanceMapperModule.cpp:36 passes optionFlags = 0)
+    ids, d2 = icp.knn(mapc[:2000], k=1, allow_self=False)
+    rids, rd2 = oracle.knn(mapc, mapc[:2000], k=1, allow_self=False)
+    assert np.array_equal(d2, rd2) and np.array_equal(ids, rids)
+    assert (ids[:, 0] != np.arange(2000)).all()
+
+
+def test_trimmed_limit_and_weights_exact(amd, oracle, small_scene):
+    icp = amd.ICPSequence(minimizer=1, max_dist=2.0, outliers=[(4, 0.85)])
+    icp.setMap(small_scene["map"])
+    mean = icp.getMapMean()
+    q = centred(small_scene["scan"], mean)
+    ids, d2 = icp.knn(q, k=1, max_dist=2.0)
+    w, lim = icp.outlierWeights(d2, ids)
+    ocfg = oracle.make_config(max_dist=2.0, outliers=[(4, 0.85)])
+    err, rw, rlim = oracle.outlier_weights(ocfg, d2, ids)
+    assert err == 0
+    assert lim == rlim
+    assert np.array_equal(w, rw)
+    for chain in ([(3, 3.0)], [(1, 0.5), (4, 0.7)], [(2, 0.05)], [(4, 1.0)], [(4, 0.0)]):
+        icp2 = amd.ICPSequence(minimizer=1, max_dist=2.0, outliers=chain)
+        w, lim = icp2.outlierWeights(d2, ids)
+        err, rw, rlim = oracle.outlier_weights(oracle.make_config(outliers=chain), d2, ids)
+        assert err == 0 and np.array_equal(w, rw), chain
+        if any(t in (3, 4) for t, _ in chain):
+            assert lim == rlim
+
+
+@pytest.mark.parametrize("minimizer", [1, 2])
+def test_single_step_matches_oracle(amd, oracle, small_scene, minimizer):
+    sc = small_scene
+    icp = amd.ICPSequence(minimizer=minimizer, max_dist=2.0, outliers=[(4, 0.85)])
+    icp.setMap(sc["map"], sc["normals"])
+    mean = icp.getMapMean()
+    mapc = centred(sc["map"], mean)
+    q = centred(sc["scan"], mean)
+    T_iter = amd.synth.make_T((0.002, 0.001, -0.003), (0.02, 0.01, -0.01)).astype(np.float32)
+    T_step, sums = icp.minimizeStep(q, T_iter)
+    step = oracle.transform(T_iter, q)
+    ids, d2 = oracle.knn(mapc, step, k=1, max_dist=2.0)
+    ocfg = oracle.make_config(max_dist=2.0, outliers=[(4, 0.85)])
+    err, w, lim = oracle.outlier_weights(ocfg, d2, ids)
+    err, T_ref, A, b, x, st = oracle.minimize(minimizer, step, mapc, sc["normals"], ids, d2, w)
+    assert err == 0
+    assert icp.stats.pairs == st.pairs
+    assert icp.stats.trimmed_limit == lim
+    if minimizer == 2:
+        iu = np.triu_indices(6)
+        np.testing.assert_allclose(sums[:21], A[iu], rtol=1e-10, atol=1e-9)
+        np.testing.assert_allclose(sums[21:27], b, rtol=1e-10, atol=1e-9)
+    dt, dr = amd.synth.pose_error(T_step, T_ref)
+    assert dt < 1e-5 and dr < 1e-5
+
+
+CHAINS = {
+    "p2p": dict(minimizer=1, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=40, use_differential=1),
+    "p2plane": dict(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=40, use_differential=1),
+    "p2plane_knn6": dict(minimizer=2, knn=6, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=15),
+    "p2plane_nofilter_counter": dict(minimizer=2, max_dist=2.0, outliers=[], max_iterations=12),
+    "p2p_median_maxdist": dict(minimizer=1, max_dist=math.inf, outliers=[(1, 1.0), (3, 3.0)], max_iterations=10),
+    "identity": dict(minimizer=0, knn=6, max_dist=2.0, outliers=[], max_iterations=10),
+}
+
+
+@pytest.mark.parametrize("name", list(CHAINS))
+def test_full_registration_matches_oracle(amd, oracle, mid_scene, name):
+    sc = mid_scene
+    kw = dict(CHAINS[name])
+    icp = amd.ICPSequence(**kw)
+    assert icp.setMap(sc["map"], sc["normals"])
+    T = icp(sc["scan"])
+    okw = dict(kw); okw["nthreads"] = 8
+    oicp = oracle.OracleICP(oracle.make_config(**okw))
+    oicp.setMap(sc["map"], sc["normals"])
+    err, T_ref = oicp(sc["scan"])
+    assert err == 0
+    assert icp.stats.iterations == oicp.stats.iterations
+    assert icp.stats.stop_reason == oicp.stats.stop_reason
+    assert icp.stats.pairs == oicp.stats.pairs
+    dt, dr = amd.synth.pose_error(T, T_ref)
+    assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (dt, dr)
+    assert abs(icp.errorMinimizer.getOverlap() - oicp.stats.weighted_point_used_ratio) < 1e-6
+    if name == "p2plane":
+        # ground truth by construction
+        dt, dr = amd.synth.pose_error(T, sc["T_gt"])
+        assert dt < 5e-3 and dr < 5e-4
+    if name == "identity":
+        assert np.array_equal(T, np.eye(4, dtype=np.float32))
+
+
+def test_graph_and_eager_agree(amd, mid_scene):
+    import ctypes as C
+    sc = mid_scene
+    out = {}
+    for use_graph in (0, 1):
+        icp = amd.ICPSequence(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], use_graph=use_graph)
+        icp.setMap(sc["map"], sc["normals"])
+        import torch
+        d = torch.from_numpy(sc["scan"]).cuda()
+        T = icp.registerDev(d.data_ptr(), d.shape[0], fixed_iterations=8)
+        T2 = icp.registerDev(d.data_ptr(), d.shape[0], fixed_iterations=8)  # graph replay
+        assert np.array_equal(T, T2)
+        assert icp.stats.iterations == 8
+        out[use_graph] = T
+    assert np.array_equal(out[0], out[1])
+
+
+def test_error_paths(amd, small_scene):
+    sc = small_scene
+    icp = amd.ICPSequence(minimizer=2, max_dist=2.0)
+    # no map: identity, like upstream
+    assert not icp.hasMap()
+    assert np.array_equal(icp(sc["scan"]), np.eye(4, dtype=np.float32))
+    # empty map rejected, state unchanged
+    assert icp.setMap(np.zeros((0, 4), dtype=np.float32)) is False
+    assert not icp.hasMap()
+    # point-to-plane without normals
+    icp.setMap(sc["map"])
+    with pytest.raises(amd.InvalidField):
+        icp(sc["scan"])
+    icp.setMap(sc["map"], sc["normals"])
+    # empty reading
+    with pytest.raises(amd.ConvergenceError):
+        icp(np.zeros((0, 4), dtype=np.float32))
+    # reading entirely out of range: no pairs
+    far = sc["scan"].copy(); far[:, :3] += 1000.0
+    with pytest.raises(amd.ConvergenceError):
+        icp(far)
+    icp_t = amd.ICPSequence(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)])
+    icp_t.setMap(sc["map"], sc["normals"])
+    with pytest.raises(amd.ConvergenceError):
+        icp_t(far)
+    # bound checker
+    icp_b = amd.ICPSequence(minimizer=2, max_dist=2.0, use_bound=1, max_rot_norm=1e-4, max_trans_norm=1e-4)
+    icp_b.setMap(sc["map"], sc["normals"])
+    with pytest.raises(amd.ConvergenceError):
+        icp_b(sc["scan"])
+    with pytest.raises(amd.InvalidParameter):
+        amd.ICPSequence(knn=0)
+
+
+def test_surface_normals_match_oracle(amd, oracle, small_scene):
+    pts = small_scene["map"][:30000]
+    icp = amd.ICPSequence(minimizer=0)
+    n = icp.surfaceNormals(pts, knn=10)
+    rn = oracle.surface_normals(pts, knn=10, nthreads=8)
+    dots = np.abs(np.sum(n.astype(np.float64) * rn.astype(np.float64), axis=1))
+    # unoriented normals; well-conditioned neighbourhoods agree to float precision
+    assert np.quantile(dots, 0.01) > 1 - 1e-6
+    assert dots.min() > 0.99
+
+
+def test_point_distance_keep_and_bins_exact(amd, oracle, small_scene):
+    sc = small_scene
+    icp = amd.ICPSequence(minimizer=0)
+    m, i = sc["map"][:40000], sc["scan"]
+    keep = icp.pointDistanceKeep(m, i, 0.15)
+    rkeep = oracle.point_distance_keep(m, i, 0.15, nthreads=8)
+    assert np.array_equal(keep, rkeep)
+    # duplicates of map points are KEPT (self-match exclusion quirk)
+    keep2 = icp.pointDistanceKeep(m, m[:100], 1e-3)
+    rkeep2 = oracle.point_distance_keep(m, m[:100], 1e-3)
+    assert np.array_equal(keep2, rkeep2)
+    pts = sc["map"].copy(); pts[:, :3] *= 3.0
+    assert np.array_equal(icp.binCells(pts, 20.0), oracle.cell_ids(pts, 20.0))
