@@ -192,6 +192,8 @@ icpmi_status icpmi_set_stream(icpmi_handle h, void* hip_stream);
 /* Grid parameters chosen by the last set_map: cell edge, dims[3], number of cells (for DESIGN/bench). */
 icpmi_status icpmi_get_grid_info(icpmi_handle h, float* cell, int32_t dims[3], int64_t* n_cells, int64_t* n_occupied);
 int32_t      icpmi_version(void);
+/* Diagnostics of the last registration (engine internals, not part of the reference surface). */
+icpmi_status icpmi_debug_counters(icpmi_handle h, uint64_t out[24]);
 
 #ifdef __cplusplus
 }

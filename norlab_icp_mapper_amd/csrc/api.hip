@@ -93,8 +93,8 @@ icpmi_status icpmi_create(const icpmi_config* cfg, icpmi_handle* out)
     c->own_stream = true;
     CR(hipMalloc((void**)&c->d_state, sizeof(IcpState)));
     CR(hipMemset(c->d_state, 0, sizeof(IcpState)));
-    CR(hipMalloc((void**)&c->d_selhist, ICPMI_SEL_BINS * sizeof(unsigned)));
-    CR(hipMemset(c->d_selhist, 0, ICPMI_SEL_BINS * sizeof(unsigned)));
+    CR(hipMalloc((void**)&c->d_selhist, 3 * ICPMI_SEL_BINS * sizeof(unsigned)));
+    CR(hipMemset(c->d_selhist, 0, 3 * ICPMI_SEL_BINS * sizeof(unsigned)));
     CR(hipHostMalloc((void**)&c->h_state, sizeof(IcpState), hipHostMallocDefault));
     CR(hipEventCreate(&c->ev0));
     CR(hipEventCreate(&c->ev1));
@@ -111,6 +111,7 @@ void icpmi_destroy(icpmi_handle c)
     if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
     hipFree(c->d_map_sorted); hipFree(c->d_normals_sorted); hipFree(c->d_cell_start);
     hipFree(c->d_keys); hipFree(c->d_fill); hipFree(c->d_blocksums); hipFree(c->d_red);
+    hipFree(c->d_qsorted); hipFree(c->d_qindex); hipFree(c->d_qkeys); hipFree(c->d_qtile); hipFree(c->d_qitems);
     hipFree(c->d_reading); hipFree(c->d_read_normals); hipFree(c->d_stage_in); hipFree(c->d_stage_n3);
     hipFree(c->d_sidx); hipFree(c->d_d2); hipFree(c->d_hard); hipFree(c->d_partials); hipFree(c->d_selhist);
     hipFree(c->d_state);
@@ -141,6 +142,13 @@ icpmi_status icpmi_get_map_mean(icpmi_handle h, float mean3[3])
 {
     if (!h || !mean3) return ICPMI_ERR_INVALID_ARG;
     memcpy(mean3, h->mean, 3 * sizeof(float));
+    return ICPMI_OK;
+}
+
+icpmi_status icpmi_debug_counters(icpmi_handle h, uint64_t out[24])
+{
+    if (!h || !out) return ICPMI_ERR_INVALID_ARG;
+    for (int i = 0; i < 24; ++i) out[i] = h->h_state->dbg[i];
     return ICPMI_OK;
 }
 
@@ -284,6 +292,12 @@ icpmi_status icpmi_knn(icpmi_handle h, const float* q4, int64_t n, int32_t k, fl
         return ICPMI_ERR_HIP;
     HIP_TRY(h, hipMemcpyAsync(h->d_reading, q4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_state, 0, sizeof(IcpState), h->stream));
+    if (k == 1) {
+        icpmi_status ss = sort_queries(h, h->d_reading, n);
+        if (ss != ICPMI_OK) return ss;
+    } else {
+        h->qsorted_n = -1; h->qsorted_src = nullptr;
+    }
     LoopCfg lc = make_loop_cfg(h, 1);
     lc.k = k; lc.max_dist = max_dist;
     lc.maxr2 = std::isinf(max_dist) ? INFINITY : max_dist * max_dist;

@@ -16,6 +16,7 @@
 #define ICPMI_SEL_BINS 2048
 #define ICPMI_NV 32            // doubles per block partial in the minimiser reduction
 #define ICPMI_MAX_K 32
+#define ICPMI_TQ 128           // queries per workgroup of the tile NN kernel (= max work-item size)
 
 // ------------------------------------------------------------------------------------------------
 // NN grid (built by set_map on the centred map).  Dense uniform grid; cells are x-fastest so the
@@ -65,12 +66,15 @@ struct IcpState {
     unsigned sel_prefix;
     unsigned sel_rank;
     unsigned n_valid;
+    unsigned sel_prefix_l[3];  // fused selection: one slot per radix level (written by level L,
+    unsigned sel_rank_l[3];    // read by level L + 1 -- never both in one kernel)
     float limits[ICPMI_MAX_OUTLIER];
     // statistics of the last iteration
     long long pairs;
     double wsum;
     unsigned hard_count;
     unsigned long long hard_total;
+    unsigned long long dbg[24];  // NN diagnostics: [0] ring passes, [1] staged points, [2] work items to global, [3] queries to global, [4] scanned candidates
     // result
     float T_out[16];
 };
@@ -102,6 +106,14 @@ struct icpmi_ctx {
     // reading-side buffers (capacity in entries)
     float4* d_reading = nullptr; size_t cap_reading = 0;       // centred reading
     float4* d_read_normals = nullptr; size_t cap_read_normals = 0;
+    float4* d_qsorted = nullptr; size_t cap_qsorted = 0;       // centred reading sorted by tile (NN locality)
+    int*    d_qindex = nullptr; size_t cap_qindex = 0;         // sorted position -> original index
+    unsigned* d_qkeys = nullptr; size_t cap_qkeys = 0;
+    unsigned* d_qtile = nullptr; size_t cap_qtile = 0;
+    int64_t qsorted_n = -1; const float4* qsorted_src = nullptr; // which reading d_qsorted was built from
+    uint2* d_qitems = nullptr; size_t cap_qitems = 0;          // NN work items (start, count) in d_qsorted
+    unsigned* d_q_n_items = nullptr;                           // device word: number of work items
+    int q_max_items = 0;                                       // host upper bound = NN grid size
     float4* d_stage_in = nullptr; size_t cap_stage_in = 0;     // host->device staging
     float*  d_stage_n3 = nullptr; size_t cap_stage_n3 = 0;
     int*    d_sidx = nullptr; size_t cap_sidx = 0;             // k x n sorted-map index (-1 none)
@@ -164,6 +176,10 @@ __device__ __forceinline__ unsigned long long pack_key(float d2, unsigned id)
 
 // ---- cross-TU host entry points ---------------------------------------------------------------
 icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float* d_normals3);
+icpmi_status device_exclusive_scan(icpmi_ctx* c, unsigned* data, int n, unsigned total);
+icpmi_status sort_queries(icpmi_ctx* c, const float4* d_pts, int64_t n);
+icpmi_status nn_tile_launch_k1(icpmi_ctx* c, int64_t n, const float* d_T, const LoopCfg& lc, int allow_self, int* d_sidx,
+                               float* d_d2, IcpState* d_state);
 icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, const float* d_T, const LoopCfg& lc,
                           int allow_self, int* d_sidx, float* d_d2, IcpState* d_state);
 icpmi_status nn_launch_k(icpmi_ctx* c, const float4* d_reading, int64_t n, const float* d_T, const LoopCfg& lc,

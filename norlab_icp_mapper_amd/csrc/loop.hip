@@ -95,11 +95,113 @@ __global__ __launch_bounds__(256) void sel_scan_kernel(IcpState* __restrict__ st
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fused selection (exactly one quantile-type filter in the chain -- the common case): the scan of
+// level L's histogram is redone by EVERY workgroup of the kernel that builds level L + 1 (2048 bins
+// = 8 KB from L2, cheaper than a kernel boundary), so the chain per iteration is
+//   NN -> hist0 -> [scan0 + hist1] -> [scan1 + hist2] -> [scan2 + pair sums] -> solve.
+// Three histogram buffers; each is cleared by block 0 of a later kernel that no longer reads it.
+// ---------------------------------------------------------------------------------------------
+// All 256 threads call. Finds the bin of `hist` (ICPMI_SEL_BINS entries) holding element `rank`
+// (0-based, ascending); when from_quantile, rank = (unsigned)(float(total) * quantile) like
+// getDistsQuantile. Returns through references (uniform across the block).
+__device__ __forceinline__ void block_find_rank(const unsigned* __restrict__ hist, bool from_quantile, float quantile,
+                                                unsigned rank_in, unsigned* sh /* >= 16 words */, unsigned& bin,
+                                                unsigned& rank_rem, unsigned& total)
+{
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const uint4 a = reinterpret_cast<const uint4*>(hist)[2 * t];
+    const uint4 b = reinterpret_cast<const uint4*>(hist)[2 * t + 1];
+    const unsigned v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    unsigned s = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += v[e];
+    unsigned incl = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) sh[wv] = incl;
+    __syncthreads();
+    const unsigned w0 = sh[0], w1 = sh[1], w2 = sh[2], w3 = sh[3];
+    total = w0 + w1 + w2 + w3;
+    const unsigned wbase = wv == 0 ? 0u : (wv == 1 ? w0 : (wv == 2 ? w0 + w1 : w0 + w1 + w2));
+    incl += wbase;
+    const unsigned excl = incl - s;
+    unsigned rank = rank_in;
+    if (from_quantile) {
+        if (total == 0) rank = 0;
+        else if (quantile == 1.0f) rank = total - 1;
+        else {
+            rank = (unsigned)((float)total * quantile);
+            if (rank > total - 1) rank = total - 1;
+        }
+    }
+    if (total != 0 && rank >= excl && rank < incl) {
+        unsigned acc = excl, bsel = 7u;
+        bool found = false;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (!found) {
+                if (rank < acc + v[e]) { bsel = (unsigned)e; found = true; }
+                else acc += v[e];
+            }
+        }
+        sh[8] = (unsigned)t * 8u + bsel;
+        sh[9] = rank - acc; // rank inside the selected bin
+    }
+    __syncthreads();
+    bin = sh[8];
+    rank_rem = sh[9];
+    __syncthreads();
+}
+
+template <int PASS> // 1: scan level 0, build level 1;  2: scan level 1, build level 2
+__global__ __launch_bounds__(256) void sel_scan_hist_kernel(const float* __restrict__ d2, int64_t count, IcpState* __restrict__ st,
+                                                            unsigned* __restrict__ hists, float quantile)
+{
+    if (st->done) return;
+    __shared__ unsigned sh[16];
+    __shared__ unsigned h[ICPMI_SEL_BINS];
+    unsigned bin, rem, total;
+    const unsigned* hprev = hists + (PASS - 1) * ICPMI_SEL_BINS;
+    unsigned* hcur = hists + PASS * ICPMI_SEL_BINS;
+    block_find_rank(hprev, PASS == 1, quantile, PASS == 1 ? 0u : st->sel_rank_l[0], sh, bin, rem, total);
+    if (PASS == 1 && total == 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) { st->n_valid = 0; st->error = ICPMI_ERR_NO_OUTLIER_TO_FILTER; st->done = 1; }
+        return;
+    }
+    const unsigned prefix = PASS == 1 ? bin : ((st->sel_prefix_l[0] << 11) | bin);
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) {
+            st->sel_prefix_l[PASS - 1] = prefix;
+            st->sel_rank_l[PASS - 1] = rem;
+            if (PASS == 1) st->n_valid = total;
+        }
+        // level 0 is dead once level 1's scan kernels have run: PASS 2 clears it for the next iteration
+        if (PASS == 2) for (int b = threadIdx.x; b < ICPMI_SEL_BINS; b += 256) hists[b] = 0;
+    }
+    for (int b = threadIdx.x; b < ICPMI_SEL_BINS; b += 256) h[b] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+        const float v = d2[i];
+        if (!(v != INFINITY && v > 0.f)) continue;
+        const unsigned bits = __float_as_uint(v);
+        if (PASS == 1) { if ((bits >> 21) == prefix) atomicAdd(&h[(bits >> 10) & 2047u], 1u); }
+        else { if ((bits >> 10) == prefix) atomicAdd(&h[bits & 1023u], 1u); }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < ICPMI_SEL_BINS; b += 256)
+        if (h[b]) atomicAdd(&hcur[b], h[b]);
+}
+
+// ---------------------------------------------------------------------------------------------
 // outlier weight of one match (OutlierFilters::compute; weights multiply)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float match_weight(const LoopCfg& lc, const IcpState* __restrict__ st, float d2,
                                               const float* __restrict__ T, const float4* __restrict__ read_normals, int qi,
-                                              const float4* __restrict__ ref_normals, int sidx)
+                                              const float4* __restrict__ ref_normals, int sidx, int fused_slot = -1,
+                                              float fused_limit = 0.f)
 {
     float w = 1.f;
     for (int f = 0; f < lc.n_out; ++f) {
@@ -107,7 +209,7 @@ __device__ __forceinline__ float match_weight(const LoopCfg& lc, const IcpState*
         const float prm = lc.out_param[f];
         if (type == ICPMI_OUT_MAXDIST) w *= (d2 <= prm * prm) ? 1.f : 0.f;
         else if (type == ICPMI_OUT_MINDIST) w *= (d2 >= prm * prm) ? 1.f : 0.f;
-        else if (type == ICPMI_OUT_MEDIANDIST || type == ICPMI_OUT_TRIMMEDDIST) w *= (d2 <= st->limits[f]) ? 1.f : 0.f;
+        else if (type == ICPMI_OUT_MEDIANDIST || type == ICPMI_OUT_TRIMMEDDIST) w *= (d2 <= (f == fused_slot ? fused_limit : st->limits[f])) ? 1.f : 0.f;
         else if (type == ICPMI_OUT_SURFACENORMAL) {
             const float4 a = read_normals[qi];
             float ax = a.x, ay = a.y, az = a.z;
@@ -132,15 +234,30 @@ __device__ __forceinline__ float match_weight(const LoopCfg& lc, const IcpState*
 //   point-to-point: [0] sum w, [1..3] sum w p, [4..6] sum w q, [7 + 3c + r] sum w q_r p_c
 //   always:         [27] sum w, [28] number of pairs
 // ---------------------------------------------------------------------------------------------
-template <int MIN>
+template <int MIN, bool FUSED>
 __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restrict__ reading, int n, LoopCfg lc,
-                                                         const IcpState* __restrict__ st, const float4* __restrict__ map,
+                                                         IcpState* __restrict__ st, const float4* __restrict__ map,
                                                          const float4* __restrict__ normals,
                                                          const float4* __restrict__ read_normals,
                                                          const int* __restrict__ sidx, const float* __restrict__ d2a,
-                                                         double* __restrict__ partials)
+                                                         double* __restrict__ partials, unsigned* __restrict__ hists,
+                                                         int fused_slot, int is_median, float factor)
 {
     if (st->done) return;
+    float fused_limit = 0.f;
+    if (FUSED) {
+        // scan of the level-2 histogram: the selected element's bit pattern is prefix(22) | bin(10)
+        __shared__ unsigned shsel[16];
+        unsigned bin, rem, total;
+        block_find_rank(hists + 2 * ICPMI_SEL_BINS, false, 0.f, st->sel_rank_l[1], shsel, bin, rem, total);
+        const float q = __uint_as_float((st->sel_prefix_l[1] << 10) | bin);
+        fused_limit = is_median ? factor * q : q;
+        if (blockIdx.x == 0) {
+            if (threadIdx.x == 0) st->limits[fused_slot] = fused_limit;
+            // level 1 is dead once every level-2 builder has finished (previous kernel)
+            for (int b = threadIdx.x; b < ICPMI_SEL_BINS; b += 256) hists[ICPMI_SEL_BINS + b] = 0;
+        }
+    }
     constexpr int NVAL = MIN == ICPMI_MIN_POINT_TO_PLANE ? 27 : (MIN == ICPMI_MIN_POINT_TO_POINT ? 16 : 0);
     double acc[NVAL > 0 ? NVAL : 1];
 #pragma unroll
@@ -153,7 +270,7 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restric
         if (d2 == INFINITY) continue;
         const int s = sidx[e];
         const int qi = (int)(e / lc.k);
-        const float w = match_weight(lc, st, d2, T, read_normals, qi, normals, s);
+        const float w = match_weight(lc, st, d2, T, read_normals, qi, normals, s, FUSED ? fused_slot : -1, fused_limit);
         if (w == 0.f) continue;
         wsum += w; cnt += 1.0;
         if (MIN == ICPMI_MIN_IDENTITY) continue;
@@ -457,15 +574,36 @@ __device__ double quat_angdist(const double* a, const double* b)
 // ---------------------------------------------------------------------------------------------
 // single-wave kernel: ordered reduction of the block partials, solve, compose, checkers
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void solve_kernel(IcpState* __restrict__ st, const double* __restrict__ partials, int nblocks,
-                                                   LoopCfg lc, int n, float* __restrict__ T_step_out, double* __restrict__ sums_out)
+__global__ __launch_bounds__(256) void solve_kernel(IcpState* __restrict__ st, const double* __restrict__ partials, int nblocks,
+                                                    LoopCfg lc, int n, float* __restrict__ T_step_out, double* __restrict__ sums_out,
+                                                    unsigned* __restrict__ hists)
 {
     if (st->done) return;
+    // level-2 selection histogram is dead after the accumulation kernel: clear it for the next iteration
+    if (hists) for (int b = threadIdx.x; b < ICPMI_SEL_BINS; b += 256) hists[2 * ICPMI_SEL_BINS + b] = 0;
+    // ordered (deterministic) reduction of the block partials: 8 lanes per value, fixed row
+    // assignment, fixed combination order
+    __shared__ double part[8][ICPMI_NV];
     __shared__ double tot[ICPMI_NV];
     const int t = threadIdx.x;
+    {
+        const int v = t & (ICPMI_NV - 1), pr = t >> 5;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int b = pr;
+        for (; b + 24 < nblocks; b += 32) {
+            s0 += partials[(size_t)b * ICPMI_NV + v];
+            s1 += partials[(size_t)(b + 8) * ICPMI_NV + v];
+            s2 += partials[(size_t)(b + 16) * ICPMI_NV + v];
+            s3 += partials[(size_t)(b + 24) * ICPMI_NV + v];
+        }
+        for (; b < nblocks; b += 8) s0 += partials[(size_t)b * ICPMI_NV + v];
+        part[pr][v] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
     if (t < ICPMI_NV) {
         double s = 0.0;
-        for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * ICPMI_NV + t];
+#pragma unroll
+        for (int pr = 0; pr < 8; ++pr) s += part[pr][t];
         tot[t] = s;
         if (sums_out) sums_out[t] = s;
     }
@@ -580,6 +718,7 @@ __global__ void init_state_kernel(IcpState* st, const float* T0)
     st->sel_prefix = 0; st->sel_rank = 0; st->n_valid = 0;
     for (int f = 0; f < ICPMI_MAX_OUTLIER; ++f) st->limits[f] = -1.f;
     st->pairs = 0; st->wsum = 0; st->hard_count = 0; st->hard_total = 0;
+    for (int i = 0; i < 24; ++i) st->dbg[i] = 0;
 }
 
 __global__ __launch_bounds__(256) void weights_kernel(int64_t count, LoopCfg lc, const IcpState* __restrict__ st,
@@ -651,6 +790,8 @@ icpmi_status loop_prepare_reading(icpmi_ctx* c, const float4* d_scan, int64_t n,
         if (blocks) hipLaunchKernelGGL(pad_normals_kernel, dim3(blocks), dim3(256), 0, c->stream, d_normals3, n, c->d_read_normals);
     }
     HIP_TRY(c, hipGetLastError());
+    // tile order of the (centred) reading for the LDS-staged NN kernel
+    if (c->cfg.knn <= 1 && n > 0) return sort_queries(c, c->d_reading, n);
     return ICPMI_OK;
 }
 
@@ -665,19 +806,41 @@ static icpmi_status ensure_loop_buffers(icpmi_ctx* c, int64_t n, int k)
     return ICPMI_OK;
 }
 
-static int acc_blocks(int64_t count) { return (int)((count + 255) / 256); }
+static int acc_blocks(int64_t count)
+{
+    const int64_t nb = (count + 255) / 256;
+    return (int)(nb < 1 ? 1 : (nb > 256 ? 256 : nb));
+}
+
+// index of the single quantile-type filter of the chain, or -1 (none) / -2 (more than one)
+static int fused_filter_slot(const LoopCfg& lc)
+{
+    int slot = -1;
+    for (int f = 0; f < lc.n_out; ++f)
+        if (lc.out_type[f] == ICPMI_OUT_TRIMMEDDIST || lc.out_type[f] == ICPMI_OUT_MEDIANDIST) slot = slot == -1 ? f : -2;
+    return slot;
+}
 
 // enqueue the quantile selections needed by the chain (no host sync)
-static void enqueue_selection(icpmi_ctx* c, const LoopCfg& lc, int64_t count)
+static void enqueue_selection(icpmi_ctx* c, const LoopCfg& lc, int64_t count, bool legacy = false)
 {
+    const int slot = legacy ? -2 : fused_filter_slot(lc);
+    int hb = (int)std::min<int64_t>((count + 2047) / 2048, 256);
+    if (hb < 1) hb = 1;
+    if (slot >= 0) {
+        // fused chain: hist0 -> [scan0 + hist1] -> [scan1 + hist2]; scan2 happens inside the accumulation kernel
+        const float quant = lc.out_type[slot] == ICPMI_OUT_MEDIANDIST ? 0.5f : lc.out_param[slot];
+        hipLaunchKernelGGL(sel_hist_kernel<0>, dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist);
+        hipLaunchKernelGGL(sel_scan_hist_kernel<1>, dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist, quant);
+        hipLaunchKernelGGL(sel_scan_hist_kernel<2>, dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist, quant);
+        return;
+    }
     for (int f = 0; f < lc.n_out; ++f) {
         const int type = lc.out_type[f];
         if (type != ICPMI_OUT_TRIMMEDDIST && type != ICPMI_OUT_MEDIANDIST) continue;
         const int is_med = type == ICPMI_OUT_MEDIANDIST;
         const float quant = is_med ? 0.5f : lc.out_param[f];
         const float factor = lc.out_param[f];
-        int hb = (int)std::min<int64_t>((count + 1023) / 1024, 1024);
-        if (hb < 1) hb = 1;
         hipLaunchKernelGGL(sel_hist_kernel<0>, dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist);
         hipLaunchKernelGGL(sel_scan_kernel<0>, dim3(1), dim3(256), 0, c->stream, c->d_state, c->d_selhist, quant, f, is_med, factor);
         hipLaunchKernelGGL(sel_hist_kernel<1>, dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist);
@@ -687,21 +850,34 @@ static void enqueue_selection(icpmi_ctx* c, const LoopCfg& lc, int64_t count)
     }
 }
 
+template <int MIN, bool FUSED>
+static void launch_accumulate(icpmi_ctx* c, int64_t n, const LoopCfg& lc, int nb, int slot)
+{
+    const float4* rn = lc.has_read_normals ? c->d_read_normals : nullptr;
+    const int is_med = slot >= 0 && lc.out_type[slot] == ICPMI_OUT_MEDIANDIST;
+    const float factor = slot >= 0 ? lc.out_param[slot] : 0.f;
+    hipLaunchKernelGGL((accumulate_kernel<MIN, FUSED>), dim3(nb), dim3(256), 0, c->stream, c->d_reading, (int)n, lc, c->d_state,
+                       c->d_map_sorted, c->d_normals_sorted, rn, c->d_sidx, c->d_d2, c->d_partials, c->d_selhist, slot, is_med, factor);
+}
+
 static void enqueue_accumulate_solve(icpmi_ctx* c, int64_t n, const LoopCfg& lc, float* d_Tstep, double* d_sums)
 {
     const int64_t count = n * lc.k;
     const int nb = acc_blocks(count);
-    const float4* rn = lc.has_read_normals ? c->d_read_normals : nullptr;
-    if (lc.minimizer == ICPMI_MIN_POINT_TO_PLANE)
-        hipLaunchKernelGGL(accumulate_kernel<ICPMI_MIN_POINT_TO_PLANE>, dim3(nb), dim3(256), 0, c->stream, c->d_reading, (int)n, lc,
-                           c->d_state, c->d_map_sorted, c->d_normals_sorted, rn, c->d_sidx, c->d_d2, c->d_partials);
-    else if (lc.minimizer == ICPMI_MIN_POINT_TO_POINT)
-        hipLaunchKernelGGL(accumulate_kernel<ICPMI_MIN_POINT_TO_POINT>, dim3(nb), dim3(256), 0, c->stream, c->d_reading, (int)n, lc,
-                           c->d_state, c->d_map_sorted, c->d_normals_sorted, rn, c->d_sidx, c->d_d2, c->d_partials);
-    else
-        hipLaunchKernelGGL(accumulate_kernel<ICPMI_MIN_IDENTITY>, dim3(nb), dim3(256), 0, c->stream, c->d_reading, (int)n, lc,
-                           c->d_state, c->d_map_sorted, c->d_normals_sorted, rn, c->d_sidx, c->d_d2, c->d_partials);
-    hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(64), 0, c->stream, c->d_state, c->d_partials, nb, lc, (int)n, d_Tstep, d_sums);
+    const int slot = fused_filter_slot(lc);
+    const bool fused = slot >= 0;
+    if (lc.minimizer == ICPMI_MIN_POINT_TO_PLANE) {
+        if (fused) launch_accumulate<ICPMI_MIN_POINT_TO_PLANE, true>(c, n, lc, nb, slot);
+        else launch_accumulate<ICPMI_MIN_POINT_TO_PLANE, false>(c, n, lc, nb, slot);
+    } else if (lc.minimizer == ICPMI_MIN_POINT_TO_POINT) {
+        if (fused) launch_accumulate<ICPMI_MIN_POINT_TO_POINT, true>(c, n, lc, nb, slot);
+        else launch_accumulate<ICPMI_MIN_POINT_TO_POINT, false>(c, n, lc, nb, slot);
+    } else {
+        if (fused) launch_accumulate<ICPMI_MIN_IDENTITY, true>(c, n, lc, nb, slot);
+        else launch_accumulate<ICPMI_MIN_IDENTITY, false>(c, n, lc, nb, slot);
+    }
+    hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(256), 0, c->stream, c->d_state, c->d_partials, nb, lc, (int)n, d_Tstep, d_sums,
+                       fused ? c->d_selhist : (unsigned*)nullptr);
 }
 
 static icpmi_status enqueue_iteration(icpmi_ctx* c, int64_t n, const LoopCfg& lc, hipEvent_t nn0, hipEvent_t nn1)
@@ -730,6 +906,7 @@ static void fill_stats(icpmi_ctx* c, const LoopCfg& lc, int64_t n, icpmi_stats* 
     for (int f = 0; f < lc.n_out; ++f)
         if (lc.out_type[f] == ICPMI_OUT_TRIMMEDDIST || lc.out_type[f] == ICPMI_OUT_MEDIANDIST) stats->trimmed_limit = hs->limits[f];
     stats->hard_queries = (int64_t)hs->hard_total;
+    for (int i = 0; i < 3; ++i) { stats->reserved[2 * i] = (int32_t)(hs->dbg[i] & 0xffffffffu); stats->reserved[2 * i + 1] = (int32_t)(hs->dbg[i] >> 32); }
 }
 
 static void host_mat4_mul(const float* A, const float* B, float* C)
@@ -749,7 +926,7 @@ icpmi_status loop_run(icpmi_ctx* c, int64_t n, const LoopCfg& lc_in, bool fixed,
     LoopCfg lc = lc_in;
     if (ensure_loop_buffers(c, n, lc.k) != ICPMI_OK) return ICPMI_ERR_HIP;
     hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(64), 0, c->stream, c->d_state, (const float*)nullptr);
-    HIP_TRY(c, hipMemsetAsync(c->d_selhist, 0, ICPMI_SEL_BINS * sizeof(unsigned), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_selhist, 0, 3 * ICPMI_SEL_BINS * sizeof(unsigned), c->stream));
     HIP_TRY(c, hipGetLastError());
 
     const bool profile = c->cfg.profile != 0;
@@ -851,7 +1028,7 @@ icpmi_status loop_single_step(icpmi_ctx* c, int64_t n, const LoopCfg& lc, const 
     d_T0 = d_Tstep + 16;
     if (T_iter_host) HIP_TRY(c, hipMemcpyAsync(d_T0, T_iter_host, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(64), 0, c->stream, c->d_state, T_iter_host ? (const float*)d_T0 : (const float*)nullptr);
-    HIP_TRY(c, hipMemsetAsync(c->d_selhist, 0, ICPMI_SEL_BINS * sizeof(unsigned), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_selhist, 0, 3 * ICPMI_SEL_BINS * sizeof(unsigned), c->stream));
     HIP_TRY(c, hipMemsetAsync(d_Tstep, 0, 16 * sizeof(float), c->stream));
     LoopCfg l1 = lc;
     l1.max_iter = 1; l1.use_diff = 0; l1.use_bound = 0;
@@ -891,10 +1068,10 @@ icpmi_status loop_outlier_weights(icpmi_ctx* c, const LoopCfg& lc, const float* 
     if (ensure_loop_buffers(c, n, k) != ICPMI_OK) return ICPMI_ERR_HIP;
     LoopCfg l1 = lc; l1.k = k;
     hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(64), 0, c->stream, c->d_state, (const float*)nullptr);
-    HIP_TRY(c, hipMemsetAsync(c->d_selhist, 0, ICPMI_SEL_BINS * sizeof(unsigned), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_selhist, 0, 3 * ICPMI_SEL_BINS * sizeof(unsigned), c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_d2, d2, (size_t)count * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_sidx, 0, (size_t)count * sizeof(int), c->stream));
-    enqueue_selection(c, l1, count);
+    enqueue_selection(c, l1, count, true);
     float* d_w = nullptr;
     HIP_TRY(c, hipMalloc((void**)&d_w, (size_t)(count > 0 ? count : 1) * sizeof(float)));
     const int blocks = (int)((count + 255) / 256);

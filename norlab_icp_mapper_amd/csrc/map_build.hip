@@ -147,7 +147,122 @@ __global__ __launch_bounds__(256) void scatter_kernel(const float4* __restrict__
     if (out_n) out_n[pos] = make_float4(normals3[3 * i], normals3[3 * i + 1], normals3[3 * i + 2], 0.f);
 }
 
+// ---- query (reading) sort by super-tile: work list of the tile NN kernel -------------------------
+// super-tile = STX x STY x STZ grid cells (long in x: the cell-sorted map is x-fastest, so a staged
+// region is few long contiguous runs).  Queries outside the grid clamp to the border super-tile.
+// Every super-tile with c queries becomes ceil(c / ICPMI_TQ) work items (start, count); the NN kernel
+// runs one workgroup per item.  Order inside a super-tile is whatever the atomics give; results are
+// written back by ORIGINAL index and all downstream sums run in original order, so nothing
+// observable depends on it.
+constexpr int STX = 16, STY = 4, STZ = 4;
+
+__device__ __forceinline__ unsigned st_key(const float4 p, const GridParams& g, int tx, int ty)
+{
+    const int cx = (int)fminf(fmaxf(floorf((p.x - g.ox) * g.inv_cell), 0.f), (float)(g.nx - 1));
+    const int cy = (int)fminf(fmaxf(floorf((p.y - g.oy) * g.inv_cell), 0.f), (float)(g.ny - 1));
+    const int cz = (int)fminf(fmaxf(floorf((p.z - g.oz) * g.inv_cell), 0.f), (float)(g.nz - 1));
+    return (unsigned)(((cz / STZ) * ty + (cy / STY)) * tx + (cx / STX));
+}
+
+__global__ __launch_bounds__(256) void qkey_kernel(const float4* __restrict__ pts, int n, GridParams g, int tx, int ty,
+                                                   unsigned* __restrict__ keys, unsigned* __restrict__ count)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned key = st_key(pts[i], g, tx, ty);
+    keys[i] = key;
+    atomicAdd(&count[key], 1u);
+}
+
+// single workgroup: exclusive scans of the per-super-tile query counts and work-item counts, and the
+// work-item table itself.  count[] is turned into start[] in place; items[0] = number of items.
+__global__ __launch_bounds__(1024) void qtable_kernel(unsigned* __restrict__ count, int nst, uint2* __restrict__ items,
+                                                      unsigned* __restrict__ n_items)
+{
+    __shared__ unsigned sh_a[1024], sh_b[1024];
+    __shared__ unsigned carry_a, carry_b;
+    const int t = threadIdx.x;
+    if (t == 0) { carry_a = 0; carry_b = 0; }
+    __syncthreads();
+    for (int base = 0; base < nst; base += 1024) {
+        const int i = base + t;
+        const unsigned cnt = i < nst ? count[i] : 0u;
+        const unsigned nb = (cnt + ICPMI_TQ - 1) / ICPMI_TQ;
+        sh_a[t] = cnt; sh_b[t] = nb;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const unsigned aa = t >= off ? sh_a[t - off] : 0u, bb = t >= off ? sh_b[t - off] : 0u;
+            __syncthreads();
+            sh_a[t] += aa; sh_b[t] += bb;
+            __syncthreads();
+        }
+        const unsigned start = carry_a + sh_a[t] - cnt;
+        const unsigned bstart = carry_b + sh_b[t] - nb;
+        if (i < nst) count[i] = start;
+        for (unsigned b = 0; b < nb; ++b) {
+            const unsigned left = cnt - b * ICPMI_TQ;
+            items[bstart + b] = make_uint2(start + b * ICPMI_TQ, left < ICPMI_TQ ? left : (unsigned)ICPMI_TQ);
+        }
+        __syncthreads();
+        if (t == 1023) { carry_a += sh_a[1023]; carry_b += sh_b[1023]; }
+        __syncthreads();
+    }
+    if (t == 0) { count[nst] = carry_a; *n_items = carry_b; }
+}
+
+__global__ __launch_bounds__(256) void qscatter_kernel(const float4* __restrict__ pts, int n, const unsigned* __restrict__ keys,
+                                                       const unsigned* __restrict__ start, unsigned* __restrict__ fill,
+                                                       float4* __restrict__ out, int* __restrict__ out_index)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned key = keys[i];
+    const unsigned pos = start[key] + atomicAdd(&fill[key], 1u);
+    out[pos] = pts[i];
+    out_index[pos] = i;
+}
+
 } // namespace
+
+icpmi_status sort_queries(icpmi_ctx* c, const float4* d_pts, int64_t n)
+{
+    const GridParams& g = c->grid;
+    const int tx = (g.nx + STX - 1) / STX, ty = (g.ny + STY - 1) / STY, tz = (g.nz + STZ - 1) / STZ;
+    const int nst = tx * ty * tz;
+    const int64_t max_items = std::min<int64_t>(n, (n + ICPMI_TQ - 1) / ICPMI_TQ + nst);
+    if (ensure_cap(c, &c->d_qsorted, &c->cap_qsorted, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (ensure_cap(c, &c->d_qindex, &c->cap_qindex, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (ensure_cap(c, &c->d_qkeys, &c->cap_qkeys, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (ensure_cap(c, &c->d_qtile, &c->cap_qtile, (size_t)2 * nst + 8) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (ensure_cap(c, &c->d_qitems, &c->cap_qitems, (size_t)max_items + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    HIP_TRY(c, hipMemsetAsync(c->d_qtile, 0, ((size_t)2 * nst + 8) * sizeof(unsigned), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_qitems, 0, ((size_t)max_items + 1) * sizeof(uint2), c->stream)); // count 0 = no work
+    unsigned* start = c->d_qtile;
+    unsigned* fill = c->d_qtile + nst + 2;
+    unsigned* n_items = c->d_qtile + 2 * nst + 4;
+    const int blocks = (int)((n + 255) / 256);
+    if (blocks == 0) return ICPMI_OK;
+    hipLaunchKernelGGL(qkey_kernel, dim3(blocks), dim3(256), 0, c->stream, d_pts, (int)n, g, tx, ty, c->d_qkeys, start);
+    hipLaunchKernelGGL(qtable_kernel, dim3(1), dim3(1024), 0, c->stream, start, nst, c->d_qitems, n_items);
+    hipLaunchKernelGGL(qscatter_kernel, dim3(blocks), dim3(256), 0, c->stream, d_pts, (int)n, c->d_qkeys, start, fill, c->d_qsorted,
+                       c->d_qindex);
+    HIP_TRY(c, hipGetLastError());
+    c->qsorted_n = n; c->qsorted_src = d_pts;
+    c->q_max_items = (int)max_items; c->d_q_n_items = n_items;
+    return ICPMI_OK;
+}
+
+// in-place exclusive scan of data[0..n) (counts -> starts); data[n] = total
+icpmi_status device_exclusive_scan(icpmi_ctx* c, unsigned* data, int n, unsigned total)
+{
+    const int nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    if (ensure_cap(c, &c->d_blocksums, &c->cap_blocksums, (size_t)nb + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(nb), dim3(SCAN_T), 0, c->stream, data, n, c->d_blocksums);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_T), 0, c->stream, c->d_blocksums, nb);
+    hipLaunchKernelGGL(scan_final_kernel, dim3(nb), dim3(SCAN_T), 0, c->stream, data, n, c->d_blocksums, total);
+    HIP_TRY(c, hipGetLastError());
+    return ICPMI_OK;
+}
 
 static icpmi_status grid_count(icpmi_ctx* c, const float4* d_pts, int64_t m, const GridParams& g, unsigned* h_nocc)
 {
@@ -251,12 +366,7 @@ icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float
     c->n_occupied = n_occ;
 
     // ---- exclusive scan of the histogram ----
-    const int nb = (g.ncells + SCAN_CHUNK - 1) / SCAN_CHUNK;
-    if (ensure_cap(c, &c->d_blocksums, &c->cap_blocksums, (size_t)nb + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(nb), dim3(SCAN_T), 0, c->stream, c->d_cell_start, g.ncells, c->d_blocksums);
-    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_T), 0, c->stream, c->d_blocksums, nb);
-    hipLaunchKernelGGL(scan_final_kernel, dim3(nb), dim3(SCAN_T), 0, c->stream, c->d_cell_start, g.ncells, c->d_blocksums, (unsigned)m);
-    HIP_TRY(c, hipGetLastError());
+    if (device_exclusive_scan(c, c->d_cell_start, g.ncells, (unsigned)m) != ICPMI_OK) return ICPMI_ERR_HIP;
 
     // ---- scatter ----
     if (ensure_cap(c, &c->d_fill, &c->cap_fill, (size_t)g.ncells) != ICPMI_OK) return ICPMI_ERR_HIP;
@@ -270,6 +380,7 @@ icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->m = m;
+    c->qsorted_n = -1; c->qsorted_src = nullptr; // tiles are defined on the grid of the map
     // any cached loop graph captured pointers / grid parameters of the previous map
     if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; c->graph_n = -1; }
     return ICPMI_OK;

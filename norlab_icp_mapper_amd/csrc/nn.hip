@@ -390,9 +390,22 @@ __global__ __launch_bounds__(256) void ids_kernel(const float4* __restrict__ map
 
 } // namespace
 
+void nn_launch_hard_k1(icpmi_ctx* c, const float4* d_reading, const float* d_T, const LoopCfg& lc, int allow_self, int* d_sidx,
+                       float* d_d2, IcpState* d_state)
+{
+    hipLaunchKernelGGL(nn1_hard_kernel, dim3(512), dim3(NN_BLOCK), 0, c->stream, d_reading, d_T, c->d_map_sorted, (int)c->m, lc.maxr2,
+                       allow_self, d_sidx, d_d2, d_state, c->d_hard);
+    hipLaunchKernelGGL(hard_reset_kernel, dim3(1), dim3(64), 0, c->stream, d_state);
+}
+
 icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, const float* d_T, const LoopCfg& lc, int allow_self,
                           int* d_sidx, float* d_d2, IcpState* d_state)
 {
+    // tile-sorted LDS path when the caller prepared the sorted reading for exactly this cloud
+    static int use_tile = -1;
+    if (use_tile < 0) { const char* e = getenv("ICPMI_NN_TILE"); use_tile = e ? atoi(e) : 1; }
+    if (use_tile && c->qsorted_n == n && c->qsorted_src == d_reading && c->m < (1 << 30))
+        return nn_tile_launch_k1(c, n, d_T, lc, allow_self, d_sidx, d_d2, d_state);
     constexpr int G = 8;
     const int64_t threads = n * G;
     const int blocks = (int)((threads + NN_BLOCK - 1) / NN_BLOCK);

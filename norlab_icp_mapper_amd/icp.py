@@ -339,6 +339,11 @@ class ICPSequence:
     def setStream(self, hip_stream_ptr):
         self._check(self._lib.icpmi_set_stream(self._h, hip_stream_ptr))
 
+    def debugCounters(self):
+        out = (C.c_uint64 * 24)()
+        self._check(self._lib.icpmi_debug_counters(self._h, out))
+        return list(out)
+
     def gridInfo(self):
         cell = C.c_float()
         dims = (C.c_int32 * 3)()
