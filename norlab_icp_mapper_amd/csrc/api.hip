@@ -110,6 +110,8 @@ void icpmi_destroy(icpmi_handle c)
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
     hipFree(c->d_map_sorted); hipFree(c->d_normals_sorted); hipFree(c->d_cell_start);
+    for (int l = 0; l < ICPMI_MAXLEV; ++l) { hipFree(c->d_lvl_pts[l]); hipFree(c->d_lvl_cs[l]); hipFree(c->d_lvl_pos0[l]); }
+    hipFree(c->d_inv);
     hipFree(c->d_keys); hipFree(c->d_fill); hipFree(c->d_blocksums); hipFree(c->d_red);
     hipFree(c->d_qsorted); hipFree(c->d_qindex); hipFree(c->d_qkeys); hipFree(c->d_qtile); hipFree(c->d_qitems);
     hipFree(c->d_reading); hipFree(c->d_read_normals); hipFree(c->d_stage_in); hipFree(c->d_stage_n3);

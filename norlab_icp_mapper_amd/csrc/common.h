@@ -30,6 +30,19 @@ struct GridParams {
     int   ncells;
 };
 
+// Pyramid of grids over the same bounding box: level l has cell edge cell0 * 2^l and its own
+// cell-sorted copy of the map.  A query that cannot be decided inside the 3x3x3 block of level l
+// (best distance beyond its margin) repeats the identical 27-cell search one level up, where the
+// block is twice as wide -- no ring bookkeeping, and always one contiguous x-run per (y, z) row.
+#define ICPMI_MAXLEV 8
+struct GridLevels {
+    int nlev;
+    GridParams g[ICPMI_MAXLEV];
+    const float4* pts[ICPMI_MAXLEV];    // cell-sorted points of the level: xyz centred, w = original index bits
+    const unsigned* cs[ICPMI_MAXLEV];   // cell starts of the level (ncells + 1)
+    const unsigned* pos0[ICPMI_MAXLEV]; // level position -> level-0 position (nullptr for level 0)
+};
+
 // Device-side description of the ICP chain for one registration (passed by value to kernels).
 struct LoopCfg {
     int   k;
@@ -96,6 +109,12 @@ struct icpmi_ctx {
     unsigned* d_cell_start = nullptr;   // ncells + 1
     size_t cap_map = 0, cap_cells = 0, cap_normals = 0;
     bool has_normals = false;
+    // coarser pyramid levels (level 0 aliases d_map_sorted / d_cell_start)
+    GridLevels levels{};
+    float4* d_lvl_pts[ICPMI_MAXLEV] = {};   size_t cap_lvl_pts[ICPMI_MAXLEV] = {};
+    unsigned* d_lvl_cs[ICPMI_MAXLEV] = {};  size_t cap_lvl_cs[ICPMI_MAXLEV] = {};
+    unsigned* d_lvl_pos0[ICPMI_MAXLEV] = {}; size_t cap_lvl_pos0[ICPMI_MAXLEV] = {};
+    unsigned* d_inv = nullptr; size_t cap_inv = 0; // original index -> level-0 position
 
     // scratch for set_map
     unsigned* d_keys = nullptr; size_t cap_keys = 0;

@@ -353,7 +353,9 @@ __device__ void jacobi_eig(int n, const double* Ain, double* w, double* Q)
     for (int sweep = 0; sweep < 60; ++sweep) {
         double off = 0;
         for (int p = 0; p < n; ++p) for (int q = p + 1; q < n; ++q) off += A[n * q + p] * A[n * q + p];
-        if (off < 1e-300) break;
+        double dg = 0;
+        for (int p = 0; p < n; ++p) dg += A[n * p + p] * A[n * p + p];
+        if (off <= 1e-32 * dg || off < 1e-300) break;
         for (int p = 0; p < n - 1; ++p)
             for (int q = p + 1; q < n; ++q) {
                 const double apq = A[n * q + p];
@@ -471,20 +473,18 @@ __device__ void rotation_from_H(const float* H, float* R)
 // the minimum-norm solution (double symmetric pseudo-inverse) -- same rule as the oracle.
 __device__ void solve6(const float* A, const float* b, float* x)
 {
-    double Ad[36], w[6], Q[36];
-    for (int i = 0; i < 36; ++i) Ad[i] = A[i];
-    jacobi_eig(6, Ad, w, Q);
-    double wmax = 0, wmin = INFINITY;
-    for (int i = 0; i < 6; ++i) { if (fabs(w[i]) > wmax) wmax = fabs(w[i]); if (w[i] < wmin) wmin = w[i]; }
-    const double thr = 6.0 * 1.1920928955078125e-07 * wmax;
-    if (wmin > thr) {
+    // invertibility rule shared with the oracle: every float Cholesky pivot > 6 eps_f max_j A_jj
+    float dmax = 0.f;
+    for (int j = 0; j < 6; ++j) if (A[6 * j + j] > dmax) dmax = A[6 * j + j];
+    const float pthr = 6.0f * 1.1920928955078125e-07f * dmax;
+    {
         float L[36];
         for (int i = 0; i < 36; ++i) L[i] = 0.f;
         bool ok = true;
         for (int j = 0; j < 6 && ok; ++j) {
             float d = A[6 * j + j];
             for (int kk = 0; kk < j; ++kk) d -= L[6 * kk + j] * L[6 * kk + j];
-            if (!(d > 0.f)) { ok = false; break; }
+            if (!(d > pthr)) { ok = false; break; }
             const float ljj = sqrtf(d);
             L[6 * j + j] = ljj;
             for (int i = j + 1; i < 6; ++i) {
@@ -508,6 +508,12 @@ __device__ void solve6(const float* A, const float* b, float* x)
             return;
         }
     }
+    double Ad[36], w[6], Q[36];
+    for (int i = 0; i < 36; ++i) Ad[i] = A[i];
+    jacobi_eig(6, Ad, w, Q);
+    double wmax = 0;
+    for (int i = 0; i < 6; ++i) if (fabs(w[i]) > wmax) wmax = fabs(w[i]);
+    const double thr = 6.0 * 1.1920928955078125e-07 * wmax;
     double xd[6] = {0, 0, 0, 0, 0, 0};
     for (int e = 0; e < 6; ++e) {
         if (!(w[e] > thr)) continue;

@@ -147,6 +147,33 @@ __global__ __launch_bounds__(256) void scatter_kernel(const float4* __restrict__
     if (out_n) out_n[pos] = make_float4(normals3[3 * i], normals3[3 * i + 1], normals3[3 * i + 2], 0.f);
 }
 
+// ---- coarser pyramid levels are built from the level-0 (already centred, cell-sorted) array ----
+__global__ __launch_bounds__(256) void lvl_key_kernel(const float4* __restrict__ pts0, int64_t m, GridParams g,
+                                                      unsigned* __restrict__ keys, unsigned* __restrict__ count)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const float4 p = pts0[i];
+    const int cx = cell_of(p.x, g.ox, g.inv_cell, g.nx);
+    const int cy = cell_of(p.y, g.oy, g.inv_cell, g.ny);
+    const int cz = cell_of(p.z, g.oz, g.inv_cell, g.nz);
+    const unsigned key = (unsigned)((cz * g.ny + cy) * g.nx + cx);
+    keys[i] = key;
+    atomicAdd(&count[key], 1u);
+}
+
+__global__ __launch_bounds__(256) void lvl_scatter_kernel(const float4* __restrict__ pts0, int64_t m, const unsigned* __restrict__ keys,
+                                                          const unsigned* __restrict__ start, unsigned* __restrict__ fill,
+                                                          float4* __restrict__ out, unsigned* __restrict__ pos0)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const unsigned key = keys[i];
+    const unsigned pos = start[key] + atomicAdd(&fill[key], 1u);
+    out[pos] = pts0[i];
+    pos0[pos] = (unsigned)i;
+}
+
 // ---- query (reading) sort by super-tile: work list of the tile NN kernel -------------------------
 // super-tile = STX x STY x STZ grid cells (long in x: the cell-sorted map is x-fastest, so a staged
 // region is few long contiguous runs).  Queries outside the grid clamp to the border super-tile.
@@ -378,6 +405,31 @@ icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float
     hipLaunchKernelGGL(scatter_kernel, dim3(blocks), dim3(256), 0, c->stream, d_pts, d_normals3, m, c->mean[0], c->mean[1], c->mean[2],
                        c->d_keys, c->d_cell_start, c->d_fill, c->d_map_sorted, d_normals3 ? c->d_normals_sorted : nullptr);
     HIP_TRY(c, hipGetLastError());
+
+    // ---- coarser pyramid levels: cell edge doubles until one 3x3x3 block reaches past maxDist (or
+    //      the grid is at most 2 cells wide, where a block always covers it) ----
+    GridLevels& L = c->levels;
+    L.nlev = 1;
+    L.g[0] = g; L.pts[0] = c->d_map_sorted; L.cs[0] = c->d_cell_start; L.pos0[0] = nullptr;
+    for (int l = 1; l < ICPMI_MAXLEV; ++l) {
+        const GridParams& prev = L.g[l - 1];
+        const bool reaches = std::isfinite(c->cfg.max_dist) && (prev.cell - prev.slack) > c->cfg.max_dist;
+        const bool tiny = prev.nx <= 2 && prev.ny <= 2 && prev.nz <= 2;
+        if (reaches || tiny) break;
+        GridParams gl = make_grid(clo, chi, prev.cell * 2.0f, maxabs);
+        if (ensure_cap(c, &c->d_lvl_cs[l], &c->cap_lvl_cs[l], (size_t)gl.ncells + 2) != ICPMI_OK) return ICPMI_ERR_HIP;
+        if (ensure_cap(c, &c->d_lvl_pts[l], &c->cap_lvl_pts[l], (size_t)m) != ICPMI_OK) return ICPMI_ERR_HIP;
+        if (ensure_cap(c, &c->d_lvl_pos0[l], &c->cap_lvl_pos0[l], (size_t)m) != ICPMI_OK) return ICPMI_ERR_HIP;
+        HIP_TRY(c, hipMemsetAsync(c->d_lvl_cs[l], 0, ((size_t)gl.ncells + 2) * sizeof(unsigned), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_fill, 0, (size_t)gl.ncells * sizeof(unsigned), c->stream)); // ncells shrinks with l
+        hipLaunchKernelGGL(lvl_key_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_map_sorted, m, gl, c->d_keys, c->d_lvl_cs[l]);
+        if (device_exclusive_scan(c, c->d_lvl_cs[l], gl.ncells, (unsigned)m) != ICPMI_OK) return ICPMI_ERR_HIP;
+        hipLaunchKernelGGL(lvl_scatter_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_map_sorted, m, c->d_keys, c->d_lvl_cs[l],
+                           c->d_fill, c->d_lvl_pts[l], c->d_lvl_pos0[l]);
+        HIP_TRY(c, hipGetLastError());
+        L.g[l] = gl; L.pts[l] = c->d_lvl_pts[l]; L.cs[l] = c->d_lvl_cs[l]; L.pos0[l] = c->d_lvl_pos0[l];
+        L.nlev = l + 1;
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->m = m;
     c->qsorted_n = -1; c->qsorted_src = nullptr; // tiles are defined on the grid of the map

@@ -388,6 +388,176 @@ __global__ __launch_bounds__(256) void ids_kernel(const float4* __restrict__ map
     ids[i] = s < 0 ? -1 : (int)__float_as_uint(map[s].w);
 }
 
+// ------------------------------------------------------------------------------------------------
+// k = 1 over the grid pyramid (the default path).  G lanes per query; per level:
+//   (1) the 9 x-rows of the 3x3x3 block are looked up by 9 different lanes -- one round trip;
+//   (2) their (start, count) pairs are broadcast with wave shuffles and prefix-summed, which turns
+//       the 27 cells into ONE flat candidate list; lane `sub` takes candidates sub, sub + G, ... and
+//       keeps NB independent 16-byte loads in flight -- the map side of the search is a handful of
+//       coalesced streams per query, no dependent chain longer than two round trips per level;
+//   (3) (d^2, index) keys are folded with a shuffle butterfly and the level's exactness rule is
+//       applied; an undecided query repeats the same code one level up (cell edge x2).
+// Queries arrive sorted by super-tile (map_build.hip:sort_queries), so the lanes of a wave touch
+// neighbouring cells and most loads hit the CU's L1 / the XCD's L2.
+// ------------------------------------------------------------------------------------------------
+template <int G, int NB>
+__global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restrict__ queries, const int* __restrict__ qindex, int n,
+                                                          const float* __restrict__ Tptr, GridLevels L, float maxr2,
+                                                          int allow_self_i, int* __restrict__ out_sidx,
+                                                          float* __restrict__ out_d2, IcpState* __restrict__ st,
+                                                          unsigned* __restrict__ hard)
+{
+    static_assert(G == 8 || G == 16, "9 rows are spread over the first lanes of a group");
+    if (st->done) return;
+    const bool allow_self = allow_self_i != 0;
+    const int tid = blockIdx.x * NN_BLOCK + threadIdx.x;
+    const int qi = tid / G;
+    const int sub = tid % G;
+    const bool active = qi < n;
+    const float4 r = queries[active ? qi : 0];
+    const int orig = qindex ? qindex[active ? qi : 0] : qi;
+    float3 p;
+    if (Tptr) p = xf_point(Tptr, r.x, r.y, r.z, r.w);
+    else p = make_float3(r.x, r.y, r.z);
+    const int lane = threadIdx.x & 63;
+    const int gbase = lane - sub;
+
+    Cand best; best.key = ~0ull; best.sidx = -1; // sidx = position in its level | level << 28
+    bool decided = !active;
+
+    // Seed (iterations > 0 of one registration): the previous iteration's match of this query is a
+    // map point, so its distance under the current transform bounds the nearest-neighbour distance
+    // from above.  The search starts at the first level whose 3x3x3 block provably contains that
+    // ball, and only visits the rows / cells the ball reaches.  Exactness is untouched: every point
+    // within the bound is still scanned and the fold is over the same (d^2, index) keys.
+    int lev0 = 0;
+    float rub2 = INFINITY; // squared pruning radius (with slack), +inf = no pruning
+    if (active && allow_self && st->iter > 0) {
+        const int sp = out_sidx[orig];
+        if (sp >= 0) {
+            const float4 qs = L.pts[0][sp];
+            const float ub2 = sqdist3(p.x, p.y, p.z, qs.x, qs.y, qs.z);
+            const float ub = sqrtf(ub2);
+            for (int lev = 0; lev < L.nlev; ++lev) {
+                const GridParams gl = L.g[lev];
+                const float fx = (p.x - gl.ox) * gl.inv_cell, fy = (p.y - gl.oy) * gl.inv_cell, fz = (p.z - gl.oz) * gl.inv_cell;
+                float mfl = fminf(fx - floorf(fx), 1.0f - (fx - floorf(fx)));
+                mfl = fminf(mfl, fminf(fy - floorf(fy), 1.0f - (fy - floorf(fy))));
+                mfl = fminf(mfl, fminf(fz - floorf(fz), 1.0f - (fz - floorf(fz))));
+                if (!(mfl >= 0.f)) mfl = 0.f;
+                const float margin = (1.0f + mfl) * gl.cell - 2.0f * gl.slack;
+                if (ub * 1.000001f <= margin) {
+                    lev0 = lev;
+                    const float rub = ub * 1.000001f + gl.slack;
+                    rub2 = rub * rub;
+                    best.key = pack_key(ub2, __float_as_uint(qs.w));
+                    best.sidx = sp; // level 0 position
+                    break;
+                }
+            }
+        }
+    }
+    // lanes of a group must agree on the starting level and radius (they do: same inputs)
+
+    for (int lev = lev0; lev < L.nlev && !decided; ++lev) {
+        const GridParams g = L.g[lev];
+        const float4* __restrict__ map = L.pts[lev];
+        const unsigned* __restrict__ cs = L.cs[lev];
+        const float fx = (p.x - g.ox) * g.inv_cell, fy = (p.y - g.oy) * g.inv_cell, fz = (p.z - g.oz) * g.inv_cell;
+        const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
+        const int cx = (int)fminf(fmaxf(flx, -1.0e6f), 1.0e6f);
+        const int cy = (int)fminf(fmaxf(fly, -1.0e6f), 1.0e6f);
+        const int cz = (int)fminf(fmaxf(flz, -1.0e6f), 1.0e6f);
+        float mf = fminf(fx - flx, 1.0f - (fx - flx));
+        mf = fminf(mf, fminf(fy - fly, 1.0f - (fy - fly)));
+        mf = fminf(mf, fminf(fz - flz, 1.0f - (fz - flz)));
+        if (!(mf >= 0.f)) mf = 0.f;
+
+        // (1) row lookups: lane r < 9 of the group owns row r (G = 8: lane 0 also owns row 8)
+        unsigned s0 = 0, n0 = 0, s1 = 0, n1 = 0;
+        {
+            // distances from the query to the lower / upper faces of its cell along y and z
+            const float ylo = (fy - fly) * g.cell, yhi = (1.0f - (fy - fly)) * g.cell;
+            const float zlo = (fz - flz) * g.cell, zhi = (1.0f - (fz - flz)) * g.cell;
+            auto lookup = [&](int rr, unsigned& s, unsigned& cnt) {
+                const int dy = (rr % 3) - 1, dz = (rr / 3) - 1;
+                int xa = cx - 1, xb = cx + 1;
+                if (rub2 != INFINITY) {
+                    const float ddy = dy == 0 ? 0.f : (dy < 0 ? ylo : yhi);
+                    const float ddz = dz == 0 ? 0.f : (dz < 0 ? zlo : zhi);
+                    const float rem2 = rub2 - (ddy * ddy + ddz * ddz);
+                    if (rem2 < 0.f) { s = 0; cnt = 0; return; } // the ball does not reach this row
+                    const float rem = sqrtf(rem2);
+                    const int xl = (int)fmaxf(floorf((p.x - rem - g.ox) * g.inv_cell), -1.0e6f);
+                    const int xh = (int)fminf(floorf((p.x + rem - g.ox) * g.inv_cell), 1.0e6f);
+                    xa = xl > xa ? xl : xa;
+                    xb = xh < xb ? xh : xb;
+                }
+                unsigned e;
+                row_run(g, cs, xa, xb, cy + dy, cz + dz, s, e);
+                cnt = e - s;
+            };
+            if (sub < 9) lookup(sub, s0, n0);
+            if (G == 8 && sub == 0) lookup(8, s1, n1);
+        }
+        // (2) broadcast, prefix: candidate k of the flat list lives at map[k + off_r], P_r <= k < P_{r+1}
+        unsigned Pr[10], Or[9];
+        Pr[0] = 0;
+#pragma unroll
+        for (int rr = 0; rr < 9; ++rr) {
+            const int src = gbase + (rr < G ? rr : 0);
+            const unsigned s = __shfl(rr < G ? s0 : s1, src, 64);
+            const unsigned c = __shfl(rr < G ? n0 : n1, src, 64);
+            Or[rr] = s - Pr[rr];
+            Pr[rr + 1] = Pr[rr] + c;
+        }
+        const unsigned total = Pr[9];
+        for (unsigned k0 = (unsigned)sub; k0 < total; k0 += (unsigned)(G * NB)) {
+            float4 q[NB];
+            unsigned gi[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const unsigned k = k0 + (unsigned)(u * G);
+                const unsigned kk = k < total ? k : k0; // clamped duplicates of k0 are harmless
+                unsigned off = Or[0];
+#pragma unroll
+                for (int rr = 1; rr < 9; ++rr) off = kk >= Pr[rr] ? Or[rr] : off;
+                gi[u] = kk + off;
+                q[u] = map[gi[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const float d2 = sqdist3(p.x, p.y, p.z, q[u].x, q[u].y, q[u].z);
+                unsigned long long key = pack_key(d2, __float_as_uint(q[u].w));
+                if (!allow_self) key = d2 > 1.1920929e-07f ? key : ~0ull;
+                cand_min(best, key, (int)(gi[u] | ((unsigned)lev << 28)));
+            }
+        }
+        // (3) fold and decide
+        group_reduce<G>(best);
+        const float margin = fmaxf((1.0f + mf) * g.cell - g.slack, 0.f);
+        const float m2 = margin * margin;
+        const float bd2 = __uint_as_float((unsigned)(best.key >> 32));
+        const bool covers = cx - 1 <= 0 && cx + 1 >= g.nx - 1 && cy - 1 <= 0 && cy + 1 >= g.ny - 1 && cz - 1 <= 0 && cz + 1 >= g.nz - 1;
+        decided = (best.key != ~0ull && bd2 <= m2) || m2 > maxr2 || covers;
+    }
+
+    if (active && sub == 0) {
+        float bd2 = __uint_as_float((unsigned)(best.key >> 32));
+        int bs = -1;
+        if (best.key != ~0ull && bd2 <= maxr2) {
+            const unsigned lv = (unsigned)best.sidx >> 28, pos = (unsigned)best.sidx & 0x0fffffffu;
+            bs = lv == 0 ? (int)pos : (int)L.pos0[lv][pos];
+        } else bd2 = INFINITY;
+        out_sidx[orig] = bs;
+        out_d2[orig] = bd2;
+        if (!decided) {
+            const unsigned slot = atomicAdd(&st->hard_count, 1u);
+            hard[slot] = (unsigned)orig;
+        }
+    }
+}
+
 } // namespace
 
 void nn_launch_hard_k1(icpmi_ctx* c, const float4* d_reading, const float* d_T, const LoopCfg& lc, int allow_self, int* d_sidx,
@@ -401,11 +571,34 @@ void nn_launch_hard_k1(icpmi_ctx* c, const float4* d_reading, const float* d_T, 
 icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, const float* d_T, const LoopCfg& lc, int allow_self,
                           int* d_sidx, float* d_d2, IcpState* d_state)
 {
-    // tile-sorted LDS path when the caller prepared the sorted reading for exactly this cloud
-    static int use_tile = -1;
-    if (use_tile < 0) { const char* e = getenv("ICPMI_NN_TILE"); use_tile = e ? atoi(e) : 1; }
-    if (use_tile && c->qsorted_n == n && c->qsorted_src == d_reading && c->m < (1 << 30))
-        return nn_tile_launch_k1(c, n, d_T, lc, allow_self, d_sidx, d_d2, d_state);
+    static int variant = -1;
+    if (variant < 0) { const char* e = getenv("ICPMI_NN_VARIANT"); variant = e ? atoi(e) : 0; }
+    if (variant < 100 && c->m < (1 << 28)) {
+        // grid pyramid; sorted queries when the caller prepared them for exactly this cloud
+        const bool sorted = c->qsorted_n == n && c->qsorted_src == d_reading;
+        const float4* q = sorted ? c->d_qsorted : d_reading;
+        const int* qi = sorted ? c->d_qindex : nullptr;
+        if (n == 0) return ICPMI_OK;
+#define LAUNCH_ML(G_, NB_)                                                                                                      \
+    hipLaunchKernelGGL((nn1_ml_kernel<G_, NB_>), dim3((int)((n * G_ + NN_BLOCK - 1) / NN_BLOCK)), dim3(NN_BLOCK), 0, c->stream, q, qi, \
+                       (int)n, d_T, c->levels, lc.maxr2, allow_self, d_sidx, d_d2, d_state, c->d_hard)
+        switch (variant) {
+            case 1: LAUNCH_ML(8, 2); break;
+            case 2: LAUNCH_ML(8, 8); break;
+            case 3: LAUNCH_ML(16, 2); break;
+            case 4: LAUNCH_ML(16, 4); break;
+            default: LAUNCH_ML(8, 4); break;
+        }
+#undef LAUNCH_ML
+        const GridParams& top = c->levels.g[c->levels.nlev - 1];
+        if (!std::isfinite(lc.max_dist) || (top.cell - top.slack) <= lc.max_dist) {
+            hipLaunchKernelGGL(nn1_hard_kernel, dim3(512), dim3(NN_BLOCK), 0, c->stream, d_reading, d_T, c->d_map_sorted, (int)c->m,
+                               lc.maxr2, allow_self, d_sidx, d_d2, d_state, c->d_hard);
+            hipLaunchKernelGGL(hard_reset_kernel, dim3(1), dim3(64), 0, c->stream, d_state);
+        }
+        HIP_TRY(c, hipGetLastError());
+        return ICPMI_OK;
+    }
     constexpr int G = 8;
     const int64_t threads = n * G;
     const int blocks = (int)((threads + NN_BLOCK - 1) / NN_BLOCK);

@@ -76,7 +76,8 @@ __global__ __launch_bounds__(128) void normals_kernel(const float4* __restrict__
     double Q[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
     for (int sweep = 0; sweep < 30; ++sweep) {
         const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
-        if (off < 1e-300) break;
+        const double dg = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
+        if (off <= 1e-32 * dg || off < 1e-300) break;
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll

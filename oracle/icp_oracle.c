@@ -475,7 +475,9 @@ static void jacobi_eig_sym(int n, const double* Ain, double* w, double* Q)
     for (int sweep = 0; sweep < 60; ++sweep) {
         double off = 0;
         for (int p = 0; p < n; ++p) for (int q = p + 1; q < n; ++q) off += A[n * q + p] * A[n * q + p];
-        if (off < 1e-300) break;
+        double dg = 0;
+        for (int p = 0; p < n; ++p) dg += A[n * p + p] * A[n * p + p];
+        if (off <= 1e-32 * dg || off < 1e-300) break;
         for (int p = 0; p < n - 1; ++p)
             for (int q = p + 1; q < n; ++q) {
                 const double apq = A[n * q + p];
@@ -501,26 +503,23 @@ static void jacobi_eig_sym(int n, const double* Ain, double* w, double* Q)
 }
 
 /* solvePossiblyUnderdeterminedLinearSystem: LLT when A is invertible, otherwise the
- * minimum-norm solution. Deviation (documented): invertibility is judged on the eigenvalues of the
- * symmetric A (lambda_min > 6 eps_f lambda_max) instead of the full-pivot QR rank, and the
- * degenerate branch uses a double-precision symmetric pseudo-inverse; both give upstream's
- * minimum-norm answer up to rounding. */
+ * minimum-norm solution. Deviation (documented): invertibility is judged on the float Cholesky
+ * pivots (every pivot > 6 eps_f max_j A_jj) instead of the full-pivot QR rank, and the degenerate
+ * branch uses a double-precision symmetric pseudo-inverse; both give upstream's minimum-norm answer
+ * up to rounding. */
 void orc_solve6(const float* A, const float* b, float* x)
 {
-    double Ad[36], w[6], Q[36];
-    for (int i = 0; i < 36; ++i) Ad[i] = A[i];
-    jacobi_eig_sym(6, Ad, w, Q);
-    double wmax = 0, wmin = INFINITY;
-    for (int i = 0; i < 6; ++i) { if (fabs(w[i]) > wmax) wmax = fabs(w[i]); if (w[i] < wmin) wmin = w[i]; }
-    const double thr = 6.0 * (double)FLT_EPSILON * wmax;
-    if (wmin > thr) {
+    float dmax = 0.f;
+    for (int j = 0; j < 6; ++j) if (A[6 * j + j] > dmax) dmax = A[6 * j + j];
+    const float pthr = 6.0f * FLT_EPSILON * dmax;
+    {
         /* float Cholesky A = L L^T, forward / backward substitution */
         float L[36]; memset(L, 0, sizeof L);
         int ok = 1;
         for (int j = 0; j < 6 && ok; ++j) {
             float d = A[6 * j + j];
             for (int kk = 0; kk < j; ++kk) d -= L[6 * kk + j] * L[6 * kk + j];
-            if (!(d > 0.f)) { ok = 0; break; }
+            if (!(d > pthr)) { ok = 0; break; }
             const float ljj = sqrtf(d);
             L[6 * j + j] = ljj;
             for (int i = j + 1; i < 6; ++i) {
@@ -545,6 +544,12 @@ void orc_solve6(const float* A, const float* b, float* x)
         }
     }
     /* minimum-norm least squares through the eigen-decomposition */
+    double Ad[36], w[6], Q[36];
+    for (int i = 0; i < 36; ++i) Ad[i] = A[i];
+    jacobi_eig_sym(6, Ad, w, Q);
+    double wmax = 0;
+    for (int i = 0; i < 6; ++i) if (fabs(w[i]) > wmax) wmax = fabs(w[i]);
+    const double thr = 6.0 * (double)FLT_EPSILON * wmax;
     double xd[6] = { 0, 0, 0, 0, 0, 0 };
     for (int e = 0; e < 6; ++e) {
         if (!(w[e] > thr)) continue;
