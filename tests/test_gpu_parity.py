@@ -233,3 +233,108 @@ def test_point_distance_keep_and_bins_exact(amd, oracle, small_scene):
     assert np.array_equal(keep2, rkeep2)
     pts = sc["map"].copy(); pts[:, :3] *= 3.0
     assert np.array_equal(icp.binCells(pts, 20.0), oracle.cell_ids(pts, 20.0))
+
+
+# ---- bundled example data of the reference (tests/golden/bundled_scans.npz, see make_golden.py) ----
+def _quat_T(row):
+    x, y, z, qx, qy, qz, qw = row[2:9]
+    R = np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)],
+                  [2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)],
+                  [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)]])
+    T = np.eye(4); T[:3, :3] = R; T[:3, 3] = [x, y, z]
+    return T.astype(np.float32)
+
+
+def _bundled_input_filters(xyz):
+    """examples/config.yaml:1-17 + Mapper.cpp:27-31: radius 200 m, two BoundingBox{removeInside:1}"""
+    keep = np.linalg.norm(xyz, axis=1) < 200.0
+    for lo, hi in (((-1.5, -1, -1), (0.5, 1, 0.5)), ((-6, -2.5, -1), (-1.5, 2.5, 1))):
+        inside = np.all((xyz > np.array(lo)) & (xyz < np.array(hi)), axis=1)
+        keep &= ~inside
+    out = np.ones((int(keep.sum()), 4), dtype=np.float32)
+    out[:, :3] = xyz[keep]
+    return out
+
+
+@pytest.fixture(scope="module")
+def bundled():
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bundled_scans.npz"))
+    s0, s1 = _bundled_input_filters(g["scan0_xyz"]), _bundled_input_filters(g["scan1_xyz"])
+    return {"s0": s0, "s1": s1, "T0": _quat_T(g["trajectory"][0]), "T1": _quat_T(g["trajectory"][1])}
+
+
+def test_bundled_example_chain_identity_known_answer(amd, oracle, bundled):
+    """The shipped config (KDTreeMatcher knn 6 maxDist 2, IdentityErrorMinimizer, Counter 10): ICP runs
+    10 matching passes and returns identity, so the corrected pose equals the prior (Mapper.cpp:215)."""
+    b = bundled
+    icp = amd.ICPSequence(minimizer=0, knn=6, max_dist=2.0, epsilon=1.0, outliers=[], max_iterations=10)
+    assert 36000 < b["s0"].shape[0] < 38000                       # ~36.9 k points survive the input filters
+    map0 = icp.transform(b["T0"], b["s0"])                         # first scan becomes the map (Mapper.cpp:200-207)
+    assert icp.setMap(map0)
+    inp = icp.transform(b["T1"], b["s1"])                          # Mapper.cpp:197
+    T = icp(inp)
+    assert np.array_equal(T, np.eye(4, dtype=np.float32)) and icp.stats.iterations == 10
+    oicp = oracle.OracleICP(oracle.make_config(minimizer=0, knn=6, max_dist=2.0, max_iterations=10, nthreads=8))
+    oicp.setMap(map0)
+    err, T_ref = oicp(inp)
+    assert err == 0 and icp.stats.pairs == oicp.stats.pairs
+    assert abs(icp.errorMinimizer.getOverlap() - oicp.stats.weighted_point_used_ratio) < 1e-6
+
+
+def test_bundled_scans_point_to_plane_parity(amd, oracle, bundled):
+    """Real lidar geometry (config 4 flavour): point-to-plane, epsilon 0, normals from the knn-10
+    surface-normal operator; HIP pose vs oracle pose on the same inputs."""
+    b = bundled
+    kw = dict(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=40, use_differential=1)
+    icp = amd.ICPSequence(**kw)
+    map0 = icp.transform(b["T0"], b["s0"])
+    normals = oracle.surface_normals(map0, knn=10, nthreads=8)     # same normals for both sides
+    assert icp.setMap(map0, normals)
+    inp = icp.transform(b["T1"], b["s1"])
+    T = icp(inp)
+    oicp = oracle.OracleICP(oracle.make_config(nthreads=8, **kw))
+    oicp.setMap(map0, normals)
+    err, T_ref = oicp(inp)
+    assert err == 0 and icp.stats.iterations == oicp.stats.iterations and icp.stats.pairs == oicp.stats.pairs
+    dt, dr = amd.synth.pose_error(T, T_ref)
+    assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (dt, dr)
+    # the robot is quasi-static (SURVEY.md section 2 row 9): the correction is small
+    dt0, dr0 = amd.synth.pose_error(T, np.eye(4))
+    assert dt0 < 0.2 and dr0 < 0.05
+    # GPU surface normals agree with the oracle's on real data (unoriented)
+    n_gpu = icp.surfaceNormals(map0, knn=10)
+    dots = np.abs(np.sum(n_gpu.astype(np.float64) * normals.astype(np.float64), axis=1))
+    assert np.quantile(dots, 0.02) > 1 - 1e-5
+
+
+def test_full_size_properties(amd):
+    """BASELINE sizes (100 k vs 1 M) through size-independent properties: the squared distances of a
+    registration are consistent with an independent kNN call, matches are symmetric under a rigid
+    motion of both clouds, and the trimmed ratio is met exactly."""
+    sc = amd.synth.make_scene()
+    icp = amd.ICPSequence(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=6)
+    assert icp.setMap(sc["map"], sc["normals"])
+    T = icp(sc["scan"])
+    assert icp.stats.iterations == 6
+    n_valid = icp.stats.pairs / 0.85
+    assert abs(icp.stats.pairs - int(np.float32(round(n_valid)) * np.float32(0.85)) - 1) <= 2
+    mean = icp.getMapMean()
+    q = sc["scan"].copy(); q[:, :3] -= mean
+    ids, d2 = icp.knn(q, k=1, max_dist=2.0)
+    mapc = sc["map"].copy(); mapc[:, :3] -= mean
+    sel = ids[:, 0] >= 0
+    chk = ((q[sel, :3].astype(np.float64) - mapc[ids[sel, 0], :3].astype(np.float64)) ** 2).sum(1)
+    np.testing.assert_allclose(d2[sel, 0], chk, rtol=2e-4, atol=1e-9)
+    # moving map and scan by the same rigid motion moves the answer by conjugation
+    M = amd.synth.make_T((0.2, 0.1, -0.3), (5.0, -3.0, 1.0)).astype(np.float32)
+    icp2 = amd.ICPSequence(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=6)
+    map2, n2 = icp2.transform(M, sc["map"], sc["normals"])
+    icp2.setMap(map2, n2)
+    T2 = icp2(icp2.transform(M, sc["scan"]))
+    Tc = M.astype(np.float64) @ T.astype(np.float64) @ np.linalg.inv(M.astype(np.float64))
+    dt, dr = amd.synth.pose_error(T2, Tc)
+    assert dt < 2e-3 and dr < 2e-4, (dt, dr)
+    # and the registration recovers the ground truth of the scene
+    dt, dr = amd.synth.pose_error(T, sc["T_gt"])
+    assert dt < 5e-3 and dr < 5e-4

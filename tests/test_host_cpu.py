@@ -1,0 +1,149 @@
+"""CPU tests (no GPU): host-side logic, the synthetic workload, and that the C-ABI library loads and
+exports every symbol include/icpmi.h declares (no compute calls without a GPU)."""
+import ctypes as C
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "icpmi.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(icpmi_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from norlab_icp_mapper_amd import _capi
+    if not os.path.exists(_capi.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = _capi.load()
+    declared = _header_symbols()
+    assert len(declared) >= 20
+    bound = {name for name, _, _ in _capi.SYMBOLS}
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in icpmi.h but not exported"
+        assert name in bound, f"{name} declared in icpmi.h but missing from the ctypes table"
+    assert lib.icpmi_version() == 1
+
+
+def test_config_defaults_and_struct_layout():
+    from norlab_icp_mapper_amd import _capi
+    lib = _capi.load()
+    cfg = _capi.Config()
+    lib.icpmi_config_default(C.byref(cfg))
+    assert cfg.knn == 1 and math.isinf(cfg.max_dist) and cfg.epsilon == 0
+    assert cfg.minimizer == _capi.MIN_POINT_TO_PLANE and cfg.max_iterations == 40
+    assert cfg.min_diff_rot == pytest.approx(1e-3) and cfg.smooth_length == 3 and cfg.use_graph == 1
+    # the ctypes mirrors must have the C layout: 8-byte aligned int64 members, trailing reserved block
+    assert C.sizeof(_capi.Stats) == 72
+    assert C.sizeof(_capi.Config) == 5 * 4 + 8 * 8 + 12 * 4 + 8 * 4
+
+
+def test_create_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import norlab_icp_mapper_amd as pkg
+    with pytest.raises(pkg.icp.HipError) as e:
+        pkg.ICPSequence(minimizer=1)
+    assert "no HIP device" in str(e.value)
+    with pytest.raises(pkg.InvalidParameter):
+        pkg.ICPSequence(knn=0)
+
+
+def test_yaml_chain_translation():
+    import yaml
+    import norlab_icp_mapper_amd as pkg
+    from norlab_icp_mapper_amd import _capi
+    chain = yaml.safe_load("""
+matcher:
+  KDTreeMatcher:
+    knn: 6
+    maxDist: 2.0
+    epsilon: 1
+outlierFilters:
+  - TrimmedDistOutlierFilter:
+      ratio: 0.9
+  - MaxDistOutlierFilter:
+      maxDist: 1.5
+errorMinimizer:
+  PointToPlaneErrorMinimizer:
+transformationCheckers:
+  - CounterTransformationChecker:
+      maxIterationCount: 25
+  - DifferentialTransformationChecker:
+      minDiffRotErr: 0.002
+      minDiffTransErr: 0.01
+      smoothLength: 4
+inspector: NullInspector
+""")
+    cfg = pkg.config_from_yaml_chain(chain)
+    assert (cfg.knn, cfg.max_dist, cfg.epsilon) == (6, 2.0, 1.0)
+    assert cfg.n_outlier == 2 and cfg.outlier[0].type == _capi.OUT_TRIMMEDDIST and cfg.outlier[0].param == pytest.approx(0.9)
+    assert cfg.outlier[1].type == _capi.OUT_MAXDIST and cfg.outlier[1].param == 1.5
+    assert cfg.minimizer == _capi.MIN_POINT_TO_PLANE and cfg.max_iterations == 25
+    assert cfg.use_differential == 1 and cfg.smooth_length == 4 and cfg.min_diff_trans == pytest.approx(0.01)
+    # the bundled example's chain (examples/config.yaml:55-68)
+    bundled = yaml.safe_load("""
+matcher:
+  KDTreeMatcher: {knn: 6, maxDist: 2.0, epsilon: 1}
+errorMinimizer:
+  IdentityErrorMinimizer:
+transformationCheckers:
+  - CounterTransformationChecker: {maxIterationCount: 10}
+inspector: NullInspector
+""")
+    cfg = pkg.config_from_yaml_chain(bundled)
+    assert cfg.minimizer == _capi.MIN_IDENTITY and cfg.max_iterations == 10 and cfg.n_outlier == 0
+    # defaults when sections are missing
+    cfg = pkg.config_from_yaml_chain({})
+    assert cfg.knn == 1 and math.isinf(cfg.max_dist) and cfg.minimizer == _capi.MIN_POINT_TO_PLANE and cfg.max_iterations == 40
+    for bad in ({"matcher": {"OctreeMatcher": {}}}, {"matcher": {"KDTreeMatcher": {"nope": 1}}},
+                {"outlierFilters": [{"FooFilter": {}}]}, {"errorMinimizer": "FooMinimizer"},
+                {"transformationCheckers": [{"FooChecker": {}}]}, {"icp": {}}):
+        with pytest.raises(pkg.InvalidParameter):
+            pkg.config_from_yaml_chain(bad)
+    with pytest.raises(NotImplementedError):
+        pkg.config_from_yaml_chain({"errorMinimizer": {"PointToPlaneErrorMinimizer": {"force2D": 1}}})
+
+
+def test_synthetic_scene_is_deterministic_and_well_formed():
+    from norlab_icp_mapper_amd import synth
+    a = synth.make_scene(m=5000, n=700)
+    b = synth.make_scene(m=5000, n=700)
+    for k in ("map", "normals", "scan", "scan_normals"):
+        assert np.array_equal(a[k], b[k])
+    assert a["map"].shape == (5000, 4) and a["map"].dtype == np.float32 and (a["map"][:, 3] == 1).all()
+    assert a["scan"].shape == (700, 4)
+    np.testing.assert_allclose(np.linalg.norm(a["normals"], axis=1), 1.0, atol=1e-6)
+    # the room: x, y in [-50, 50], z in [0, 10] (+ noise)
+    assert np.abs(a["map"][:, :2]).max() < 50.1 and a["map"][:, 2].min() > -0.1 and a["map"][:, 2].max() < 10.1
+    # scan = surfaces within 60 m of the sensor, moved by T_gt^-1
+    T = a["T_gt"]
+    back = a["scan"][:, :3].astype(np.float64) @ T[:3, :3].T + T[:3, 3]
+    assert np.linalg.norm(back - np.array([3.0, -2.0, 1.5]), axis=1).max() < 60.1
+    # counter-based generator: known first outputs of splitmix64
+    assert int(synth.splitmix64(np.uint64(0))) == 0xE220A8397B1DCDAF
+    u = synth.uniform(42, 0, 4)
+    assert ((0 <= u) & (u < 1)).all() and len(set(u.tolist())) == 4
+    dt, dr = synth.pose_error(synth.make_T((0.01, 0, 0), (0.1, 0, 0)), np.eye(4))
+    assert dt == pytest.approx(0.1) and dr == pytest.approx(0.01, rel=1e-6)
+
+
+def test_bundled_fixture_known_answer():
+    """examples/data as shipped: 14 trajectory rows; lexicographic scan order puts
+    cloud_1690309710_85582848.vtk last, so rows and scans are mis-paired by design."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "bundled_scans.npz"))
+    names = g["scan_names"].tolist()
+    assert len(names) == 14 and names == sorted(names) and names[-1] == "cloud_1690309710_85582848.vtk"
+    assert g["scan0_xyz"].shape == (41400, 3) and g["trajectory"].shape == (14, 9)
+    t = g["trajectory"]
+    stamps = t[:, 0] + 1e-9 * t[:, 1]
+    assert (np.diff(stamps) > 0.09).all() and (np.diff(stamps) < 0.11).all()  # 10 Hz
+    np.testing.assert_allclose(np.linalg.norm(t[:, 5:9], axis=1), 1.0, atol=1e-9)
