@@ -93,8 +93,8 @@ icpmi_status icpmi_create(const icpmi_config* cfg, icpmi_handle* out)
     c->own_stream = true;
     CR(hipMalloc((void**)&c->d_state, sizeof(IcpState)));
     CR(hipMemset(c->d_state, 0, sizeof(IcpState)));
-    CR(hipMalloc((void**)&c->d_selhist, 3 * ICPMI_SEL_BINS * sizeof(unsigned)));
-    CR(hipMemset(c->d_selhist, 0, 3 * ICPMI_SEL_BINS * sizeof(unsigned)));
+    CR(hipMalloc((void**)&c->d_selhist, ICPMI_SELHIST_WORDS * sizeof(unsigned)));
+    CR(hipMemset(c->d_selhist, 0, ICPMI_SELHIST_WORDS * sizeof(unsigned)));
     CR(hipHostMalloc((void**)&c->h_state, sizeof(IcpState), hipHostMallocDefault));
     CR(hipEventCreate(&c->ev0));
     CR(hipEventCreate(&c->ev1));
@@ -307,6 +307,7 @@ icpmi_status icpmi_knn(icpmi_handle h, const float* q4, int64_t n, int32_t k, fl
         const int need = (int)ceilf(max_dist / h->grid.cell) + 1;
         lc.ring_max = need < 16 ? need : 16;
     } else lc.ring_max = 6;
+    h->nn_hist0 = nullptr; // stage call: no quantile selection follows
     icpmi_status s = nn_launch_k(h, h->d_reading, n, nullptr, lc, allow_self, h->d_sidx, h->d_d2, h->d_state);
     if (s != ICPMI_OK) return s;
     int* d_ids = nullptr;

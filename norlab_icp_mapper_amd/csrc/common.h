@@ -13,7 +13,13 @@
 
 #define ICPMI_MAX_OUTLIER 8
 #define ICPMI_MAX_SMOOTH 16
-#define ICPMI_SEL_BINS 2048
+#define ICPMI_SEL_BINS 2048     // legacy 11/11/10 selection (stage entry point, chains with > 1 quantile filter)
+#define ICPMI_FSEL_B0 2048      // fused selection: level 0 = top 11 bits of the d^2 pattern
+#define ICPMI_FSEL_B12 2048     //                  level 1 = next 11 bits, level 2 = last 10 bits
+#define ICPMI_FSEL_OFF0 4096    // word offsets of the fused histograms inside d_selhist
+#define ICPMI_FSEL_OFF1 8192
+#define ICPMI_FSEL_OFF2 12288
+#define ICPMI_SELHIST_WORDS 16384
 #define ICPMI_NV 32            // doubles per block partial in the minimiser reduction
 #define ICPMI_MAX_K 32
 #define ICPMI_TQ 128           // queries per workgroup of the tile NN kernel (= max work-item size)
@@ -140,6 +146,8 @@ struct icpmi_ctx {
     unsigned* d_hard = nullptr; size_t cap_hard = 0;           // hard query list
     double* d_partials = nullptr; size_t cap_partials = 0;
     unsigned* d_selhist = nullptr;                             // ICPMI_SEL_BINS
+    unsigned* nn_hist0 = nullptr;     // set by the loop when the NN kernel should build the level-0 histogram
+    bool nn_builds_hist0 = false;     // set by the NN launcher: true if the launched variant did build it
     IcpState* d_state = nullptr;
     IcpState* h_state = nullptr;                               // pinned mirror
 

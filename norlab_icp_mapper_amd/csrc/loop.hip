@@ -101,20 +101,34 @@ __global__ __launch_bounds__(256) void sel_scan_kernel(IcpState* __restrict__ st
 //   NN -> hist0 -> [scan0 + hist1] -> [scan1 + hist2] -> [scan2 + pair sums] -> solve.
 // Three histogram buffers; each is cleared by block 0 of a later kernel that no longer reads it.
 // ---------------------------------------------------------------------------------------------
-// All 256 threads call. Finds the bin of `hist` (ICPMI_SEL_BINS entries) holding element `rank`
+// Radix digits of the fused path: 8 / 12 / 12 bits of the IEEE pattern of d^2 (sign bit is 0).  Level 0
+// (256 bins, sign + top exponent bits) is built inside the NN kernel from an LDS histogram per
+// workgroup; levels 1 and 2 (4096 bins) only receive the elements of the selected coarser bin and take
+// device-scope atomics directly.
+//
+// All 256 threads call. Finds the bin of `hist` (256 * EPT entries) holding element `rank`
 // (0-based, ascending); when from_quantile, rank = (unsigned)(float(total) * quantile) like
 // getDistsQuantile. Returns through references (uniform across the block).
+template <int EPT>
 __device__ __forceinline__ void block_find_rank(const unsigned* __restrict__ hist, bool from_quantile, float quantile,
                                                 unsigned rank_in, unsigned* sh /* >= 16 words */, unsigned& bin,
                                                 unsigned& rank_rem, unsigned& total)
 {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const uint4 a = reinterpret_cast<const uint4*>(hist)[2 * t];
-    const uint4 b = reinterpret_cast<const uint4*>(hist)[2 * t + 1];
-    const unsigned v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    unsigned v[EPT];
+    if (EPT >= 4) {
+#pragma unroll
+        for (int e = 0; e < EPT / 4; ++e) {
+            const uint4 a = reinterpret_cast<const uint4*>(hist)[(EPT / 4) * t + e];
+            v[4 * e] = a.x; v[4 * e + 1] = a.y; v[4 * e + 2] = a.z; v[4 * e + 3] = a.w;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) v[e] = hist[EPT * t + e];
+    }
     unsigned s = 0;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) s += v[e];
+    for (int e = 0; e < EPT; ++e) s += v[e];
     unsigned incl = s;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -138,16 +152,16 @@ __device__ __forceinline__ void block_find_rank(const unsigned* __restrict__ his
         }
     }
     if (total != 0 && rank >= excl && rank < incl) {
-        unsigned acc = excl, bsel = 7u;
+        unsigned acc = excl, bsel = (unsigned)(EPT - 1);
         bool found = false;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < EPT; ++e) {
             if (!found) {
                 if (rank < acc + v[e]) { bsel = (unsigned)e; found = true; }
                 else acc += v[e];
             }
         }
-        sh[8] = (unsigned)t * 8u + bsel;
+        sh[8] = (unsigned)t * (unsigned)EPT + bsel;
         sh[9] = rank - acc; // rank inside the selected bin
     }
     __syncthreads();
@@ -156,17 +170,33 @@ __device__ __forceinline__ void block_find_rank(const unsigned* __restrict__ his
     __syncthreads();
 }
 
+// level-0 histogram as a stand-alone kernel (only for NN variants that do not build it themselves)
+__global__ __launch_bounds__(256) void fsel_hist0_kernel(const float* __restrict__ d2, int64_t count, const IcpState* __restrict__ st,
+                                                         unsigned* __restrict__ hists)
+{
+    if (st->done) return;
+    __shared__ unsigned h[ICPMI_FSEL_B0];
+    for (int b = threadIdx.x; b < ICPMI_FSEL_B0; b += 256) h[b] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+        const float v = d2[i];
+        if (v != INFINITY && v > 0.f) atomicAdd(&h[__float_as_uint(v) >> 21], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < ICPMI_FSEL_B0; b += 256)
+        if (h[b]) atomicAdd(&hists[ICPMI_FSEL_OFF0 + b], h[b]);
+}
+
 template <int PASS> // 1: scan level 0, build level 1;  2: scan level 1, build level 2
 __global__ __launch_bounds__(256) void sel_scan_hist_kernel(const float* __restrict__ d2, int64_t count, IcpState* __restrict__ st,
                                                             unsigned* __restrict__ hists, float quantile)
 {
     if (st->done) return;
     __shared__ unsigned sh[16];
-    __shared__ unsigned h[ICPMI_SEL_BINS];
     unsigned bin, rem, total;
-    const unsigned* hprev = hists + (PASS - 1) * ICPMI_SEL_BINS;
-    unsigned* hcur = hists + PASS * ICPMI_SEL_BINS;
-    block_find_rank(hprev, PASS == 1, quantile, PASS == 1 ? 0u : st->sel_rank_l[0], sh, bin, rem, total);
+    unsigned* hcur = hists + (PASS == 1 ? ICPMI_FSEL_OFF1 : ICPMI_FSEL_OFF2);
+    if (PASS == 1) block_find_rank<8>(hists + ICPMI_FSEL_OFF0, true, quantile, 0u, sh, bin, rem, total);
+    else block_find_rank<8>(hists + ICPMI_FSEL_OFF1, false, quantile, st->sel_rank_l[0], sh, bin, rem, total);
     if (PASS == 1 && total == 0) {
         if (blockIdx.x == 0 && threadIdx.x == 0) { st->n_valid = 0; st->error = ICPMI_ERR_NO_OUTLIER_TO_FILTER; st->done = 1; }
         return;
@@ -178,21 +208,18 @@ __global__ __launch_bounds__(256) void sel_scan_hist_kernel(const float* __restr
             st->sel_rank_l[PASS - 1] = rem;
             if (PASS == 1) st->n_valid = total;
         }
-        // level 0 is dead once level 1's scan kernels have run: PASS 2 clears it for the next iteration
-        if (PASS == 2) for (int b = threadIdx.x; b < ICPMI_SEL_BINS; b += 256) hists[b] = 0;
+        // level 0 is dead once level 1's builders have run: PASS 2 clears it for the next iteration
+        if (PASS == 2) for (int b = threadIdx.x; b < ICPMI_FSEL_B0; b += 256) hists[ICPMI_FSEL_OFF0 + b] = 0;
     }
-    for (int b = threadIdx.x; b < ICPMI_SEL_BINS; b += 256) h[b] = 0;
-    __syncthreads();
+    // Only the elements inside the selected coarser bin contribute and they spread over up to 4096
+    // bins: device-scope atomics straight to the level's histogram see little contention.
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
         const float v = d2[i];
         if (!(v != INFINITY && v > 0.f)) continue;
         const unsigned bits = __float_as_uint(v);
-        if (PASS == 1) { if ((bits >> 21) == prefix) atomicAdd(&h[(bits >> 10) & 2047u], 1u); }
-        else { if ((bits >> 10) == prefix) atomicAdd(&h[bits & 1023u], 1u); }
+        if (PASS == 1) { if ((bits >> 21) == prefix) atomicAdd(&hcur[(bits >> 10) & 2047u], 1u); }
+        else { if ((bits >> 10) == prefix) atomicAdd(&hcur[bits & 1023u], 1u); }
     }
-    __syncthreads();
-    for (int b = threadIdx.x; b < ICPMI_SEL_BINS; b += 256)
-        if (h[b]) atomicAdd(&hcur[b], h[b]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -249,13 +276,13 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restric
         // scan of the level-2 histogram: the selected element's bit pattern is prefix(22) | bin(10)
         __shared__ unsigned shsel[16];
         unsigned bin, rem, total;
-        block_find_rank(hists + 2 * ICPMI_SEL_BINS, false, 0.f, st->sel_rank_l[1], shsel, bin, rem, total);
+        block_find_rank<4>(hists + ICPMI_FSEL_OFF2, false, 0.f, st->sel_rank_l[1], shsel, bin, rem, total);
         const float q = __uint_as_float((st->sel_prefix_l[1] << 10) | bin);
         fused_limit = is_median ? factor * q : q;
         if (blockIdx.x == 0) {
             if (threadIdx.x == 0) st->limits[fused_slot] = fused_limit;
             // level 1 is dead once every level-2 builder has finished (previous kernel)
-            for (int b = threadIdx.x; b < ICPMI_SEL_BINS; b += 256) hists[ICPMI_SEL_BINS + b] = 0;
+            for (int b = threadIdx.x; b < ICPMI_FSEL_B12; b += 256) hists[ICPMI_FSEL_OFF1 + b] = 0;
         }
     }
     constexpr int NVAL = MIN == ICPMI_MIN_POINT_TO_PLANE ? 27 : (MIN == ICPMI_MIN_POINT_TO_POINT ? 16 : 0);
@@ -305,20 +332,32 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restric
         }
     }
     // ---- workgroup reduction: wave64 shuffles, then LDS across the 4 waves ----
+    // Transposed butterfly: at the step with partner lane ^ m every lane hands over the half of its
+    // values the partner keeps, so 32 values x 64 lanes fold with 16+8+4+2+1+1 = 32 exchanges instead
+    // of 32 x 6.  After the five halving steps lane l holds value bitrev5(l & 31) summed over its
+    // 32-lane half; the last exchange joins the halves.  Fixed pattern => deterministic sums.
     __shared__ double sh[4][ICPMI_NV];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double val[ICPMI_NV];
 #pragma unroll
-    for (int i = 0; i < NVAL; ++i) {
-        double v = acc[i];
+    for (int i = 0; i < ICPMI_NV; ++i) val[i] = i < NVAL ? acc[i < NVAL ? i : 0] : 0.0;
+    val[27] = wsum; val[28] = cnt;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0) sh[wv][i] = v;
+    for (int s = 0; s < 5; ++s) {
+        const int m = 1 << s;
+        const int nkeep = 16 >> s;
+        const bool upper = (lane & m) != 0;
+#pragma unroll
+        for (int i = 0; i < nkeep; ++i) {
+            const double send = upper ? val[i] : val[i + nkeep];
+            const double keep = upper ? val[i + nkeep] : val[i];
+            val[i] = keep + __shfl_xor(send, m, 64);
+        }
     }
-    {
-        double v = wsum, c2 = cnt;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { v += __shfl_down(v, off, 64); c2 += __shfl_down(c2, off, 64); }
-        if (lane == 0) { sh[wv][27] = v; sh[wv][28] = c2; }
+    val[0] += __shfl_xor(val[0], 32, 64);
+    if (lane < 32) {
+        const int idx = ((lane & 1) << 4) | ((lane & 2) << 2) | (lane & 4) | ((lane & 8) >> 2) | ((lane & 16) >> 4);
+        sh[wv][idx] = val[0];
     }
     __syncthreads();
     if (threadIdx.x < ICPMI_NV) {
@@ -335,12 +374,16 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restric
 __device__ void mat4_mul_dev(const float* A, const float* B, float* C)
 {
     float R[16];
+#pragma unroll
     for (int j = 0; j < 4; ++j)
+#pragma unroll
         for (int i = 0; i < 4; ++i) {
             float s = A[i] * B[4 * j];
+#pragma unroll
             for (int kk = 1; kk < 4; ++kk) s = fmaf(A[4 * kk + i], B[4 * j + kk], s);
             R[4 * j + i] = s;
         }
+#pragma unroll
     for (int i = 0; i < 16; ++i) C[i] = R[i];
 }
 
@@ -391,9 +434,12 @@ __device__ void svd3f_dev(const float* H, float* U, float* s, float* V)
     for (int i = 0; i < 9; ++i) a[i] = H[i];
     for (int sweep = 0; sweep < 30; ++sweep) {
         float off = 0.f;
+#pragma unroll
         for (int p = 0; p < 2; ++p)
+#pragma unroll
             for (int q = p + 1; q < 3; ++q) {
                 float alpha = 0, beta = 0, gamma = 0;
+#pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     alpha += a[3 * p + i] * a[3 * p + i];
                     beta += a[3 * q + i] * a[3 * q + i];
@@ -406,6 +452,7 @@ __device__ void svd3f_dev(const float* H, float* U, float* s, float* V)
                 const float zeta = (beta - alpha) / (2.f * gamma);
                 const float tt = (zeta >= 0.f ? 1.f : -1.f) / (fabsf(zeta) + sqrtf(1.f + zeta * zeta));
                 const float c = 1.f / sqrtf(1.f + tt * tt), sn = c * tt;
+#pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     const float ap = a[3 * p + i], aq = a[3 * q + i];
                     a[3 * p + i] = c * ap - sn * aq; a[3 * q + i] = sn * ap + c * aq;
@@ -471,43 +518,62 @@ __device__ void rotation_from_H(const float* H, float* R)
 
 // solvePossiblyUnderdeterminedLinearSystem: float LLT when A is invertible, else
 // the minimum-norm solution (double symmetric pseudo-inverse) -- same rule as the oracle.
+// minimum-norm branch of solve6 (rank-deficient A): rare, kept out of line so that its scratch-resident
+// arrays do not burden the common path
+__device__ __noinline__ void solve6_min_norm(const float* A, const float* b, float* x);
+
 __device__ void solve6(const float* A, const float* b, float* x)
 {
-    // invertibility rule shared with the oracle: every float Cholesky pivot > 6 eps_f max_j A_jj
+    // invertibility rule shared with the oracle: every float Cholesky pivot > 6 eps_f max_j A_jj.
+    // Every loop has compile-time bounds and is fully unrolled: L, y live in registers (a rolled
+    // triangular loop would put them in scratch memory, ~10 us of dependent scratch traffic).
     float dmax = 0.f;
-    for (int j = 0; j < 6; ++j) if (A[6 * j + j] > dmax) dmax = A[6 * j + j];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) dmax = A[6 * j + j] > dmax ? A[6 * j + j] : dmax;
     const float pthr = 6.0f * 1.1920928955078125e-07f * dmax;
-    {
-        float L[36];
-        for (int i = 0; i < 36; ++i) L[i] = 0.f;
-        bool ok = true;
-        for (int j = 0; j < 6 && ok; ++j) {
-            float d = A[6 * j + j];
-            for (int kk = 0; kk < j; ++kk) d -= L[6 * kk + j] * L[6 * kk + j];
-            if (!(d > pthr)) { ok = false; break; }
-            const float ljj = sqrtf(d);
-            L[6 * j + j] = ljj;
-            for (int i = j + 1; i < 6; ++i) {
+    float L[36];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        float d = A[6 * j + j];
+#pragma unroll
+        for (int kk = 0; kk < 6; ++kk) if (kk < j) d -= L[6 * kk + j] * L[6 * kk + j];
+        ok = ok && (d > pthr);
+        const float ljj = sqrtf(d);
+        L[6 * j + j] = ljj;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if (i > j) {
                 float s = A[6 * j + i];
-                for (int kk = 0; kk < j; ++kk) s -= L[6 * kk + i] * L[6 * kk + j];
+#pragma unroll
+                for (int kk = 0; kk < 6; ++kk) if (kk < j) s -= L[6 * kk + i] * L[6 * kk + j];
                 L[6 * j + i] = s / ljj;
             }
         }
-        if (ok) {
-            float y[6];
-            for (int i = 0; i < 6; ++i) {
-                float s = b[i];
-                for (int kk = 0; kk < i; ++kk) s -= L[6 * kk + i] * y[kk];
-                y[i] = s / L[6 * i + i];
-            }
-            for (int i = 5; i >= 0; --i) {
-                float s = y[i];
-                for (int kk = i + 1; kk < 6; ++kk) s -= L[6 * i + kk] * x[kk];
-                x[i] = s / L[6 * i + i];
-            }
-            return;
-        }
     }
+    if (ok) {
+        float y[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            float s = b[i];
+#pragma unroll
+            for (int kk = 0; kk < 6; ++kk) if (kk < i) s -= L[6 * kk + i] * y[kk];
+            y[i] = s / L[6 * i + i];
+        }
+#pragma unroll
+        for (int i = 5; i >= 0; --i) {
+            float s = y[i];
+#pragma unroll
+            for (int kk = 0; kk < 6; ++kk) if (kk > i) s -= L[6 * i + kk] * x[kk];
+            x[i] = s / L[6 * i + i];
+        }
+        return;
+    }
+    solve6_min_norm(A, b, x);
+}
+
+__device__ __noinline__ void solve6_min_norm(const float* A, const float* b, float* x)
+{
     double Ad[36], w[6], Q[36];
     for (int i = 0; i < 36; ++i) Ad[i] = A[i];
     jacobi_eig(6, Ad, w, Q);
@@ -586,7 +652,7 @@ __global__ __launch_bounds__(256) void solve_kernel(IcpState* __restrict__ st, c
 {
     if (st->done) return;
     // level-2 selection histogram is dead after the accumulation kernel: clear it for the next iteration
-    if (hists) for (int b = threadIdx.x; b < ICPMI_SEL_BINS; b += 256) hists[2 * ICPMI_SEL_BINS + b] = 0;
+    if (hists) for (int b = threadIdx.x; b < ICPMI_FSEL_B12; b += 256) hists[ICPMI_FSEL_OFF2 + b] = 0;
     // ordered (deterministic) reduction of the block partials: 8 lanes per value, fixed row
     // assignment, fixed combination order
     __shared__ double part[8][ICPMI_NV];
@@ -615,6 +681,7 @@ __global__ __launch_bounds__(256) void solve_kernel(IcpState* __restrict__ st, c
     }
     __syncthreads();
     if (t != 0) return;
+    const long long tsolve0 = clock64();
 
     const double wsum = tot[27];
     const long long P = (long long)(tot[28] + 0.5);
@@ -693,6 +760,8 @@ __global__ __launch_bounds__(256) void solve_kernel(IcpState* __restrict__ st, c
         if (rot > (double)lc.max_rot || nt > (double)lc.max_trans) { st->error = ICPMI_ERR_BOUND; st->done = 1; return; }
     }
     if (!iterate) { st->done = 1; st->stop_reason = reason; }
+    st->dbg[20] += (unsigned long long)(clock64() - tsolve0); // serial part of the solve (diagnostic)
+    st->dbg[21] += 1;
 }
 
 __global__ __launch_bounds__(256) void centre_kernel(const float4* __restrict__ scan, int64_t n, float mx, float my, float mz,
@@ -836,9 +905,12 @@ static void enqueue_selection(icpmi_ctx* c, const LoopCfg& lc, int64_t count, bo
     if (slot >= 0) {
         // fused chain: hist0 -> [scan0 + hist1] -> [scan1 + hist2]; scan2 happens inside the accumulation kernel
         const float quant = lc.out_type[slot] == ICPMI_OUT_MEDIANDIST ? 0.5f : lc.out_param[slot];
-        hipLaunchKernelGGL(sel_hist_kernel<0>, dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist);
-        hipLaunchKernelGGL(sel_scan_hist_kernel<1>, dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist, quant);
-        hipLaunchKernelGGL(sel_scan_hist_kernel<2>, dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist, quant);
+        if (!c->nn_builds_hist0)
+            hipLaunchKernelGGL(fsel_hist0_kernel, dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist);
+        int hb2 = (int)std::min<int64_t>((count + 511) / 512, 512);
+        if (hb2 < 1) hb2 = 1;
+        hipLaunchKernelGGL(sel_scan_hist_kernel<1>, dim3(hb2), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist, quant);
+        hipLaunchKernelGGL(sel_scan_hist_kernel<2>, dim3(hb2), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist, quant);
         return;
     }
     for (int f = 0; f < lc.n_out; ++f) {
@@ -889,6 +961,8 @@ static void enqueue_accumulate_solve(icpmi_ctx* c, int64_t n, const LoopCfg& lc,
 static icpmi_status enqueue_iteration(icpmi_ctx* c, int64_t n, const LoopCfg& lc, hipEvent_t nn0, hipEvent_t nn1)
 {
     if (nn0) HIP_TRY(c, hipEventRecord(nn0, c->stream));
+    c->nn_hist0 = fused_filter_slot(lc) >= 0 ? c->d_selhist + ICPMI_FSEL_OFF0 : nullptr;
+    c->nn_builds_hist0 = false;
     icpmi_status s = nn_launch_k(c, c->d_reading, n, c->d_state->T_iter, lc, 1, c->d_sidx, c->d_d2, c->d_state);
     if (s != ICPMI_OK) return s;
     if (nn1) HIP_TRY(c, hipEventRecord(nn1, c->stream));
@@ -932,7 +1006,7 @@ icpmi_status loop_run(icpmi_ctx* c, int64_t n, const LoopCfg& lc_in, bool fixed,
     LoopCfg lc = lc_in;
     if (ensure_loop_buffers(c, n, lc.k) != ICPMI_OK) return ICPMI_ERR_HIP;
     hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(64), 0, c->stream, c->d_state, (const float*)nullptr);
-    HIP_TRY(c, hipMemsetAsync(c->d_selhist, 0, 3 * ICPMI_SEL_BINS * sizeof(unsigned), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_selhist, 0, ICPMI_SELHIST_WORDS * sizeof(unsigned), c->stream));
     HIP_TRY(c, hipGetLastError());
 
     const bool profile = c->cfg.profile != 0;
@@ -1034,10 +1108,12 @@ icpmi_status loop_single_step(icpmi_ctx* c, int64_t n, const LoopCfg& lc, const 
     d_T0 = d_Tstep + 16;
     if (T_iter_host) HIP_TRY(c, hipMemcpyAsync(d_T0, T_iter_host, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(64), 0, c->stream, c->d_state, T_iter_host ? (const float*)d_T0 : (const float*)nullptr);
-    HIP_TRY(c, hipMemsetAsync(c->d_selhist, 0, 3 * ICPMI_SEL_BINS * sizeof(unsigned), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_selhist, 0, ICPMI_SELHIST_WORDS * sizeof(unsigned), c->stream));
     HIP_TRY(c, hipMemsetAsync(d_Tstep, 0, 16 * sizeof(float), c->stream));
     LoopCfg l1 = lc;
     l1.max_iter = 1; l1.use_diff = 0; l1.use_bound = 0;
+    c->nn_hist0 = fused_filter_slot(l1) >= 0 ? c->d_selhist + ICPMI_FSEL_OFF0 : nullptr;
+    c->nn_builds_hist0 = false;
     icpmi_status s = nn_launch_k(c, c->d_reading, n, c->d_state->T_iter, l1, 1, c->d_sidx, c->d_d2, c->d_state);
     if (s == ICPMI_OK) {
         enqueue_selection(c, l1, n * l1.k);
@@ -1074,7 +1150,7 @@ icpmi_status loop_outlier_weights(icpmi_ctx* c, const LoopCfg& lc, const float* 
     if (ensure_loop_buffers(c, n, k) != ICPMI_OK) return ICPMI_ERR_HIP;
     LoopCfg l1 = lc; l1.k = k;
     hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(64), 0, c->stream, c->d_state, (const float*)nullptr);
-    HIP_TRY(c, hipMemsetAsync(c->d_selhist, 0, 3 * ICPMI_SEL_BINS * sizeof(unsigned), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_selhist, 0, ICPMI_SELHIST_WORDS * sizeof(unsigned), c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_d2, d2, (size_t)count * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_sidx, 0, (size_t)count * sizeof(int), c->stream));
     enqueue_selection(c, l1, count, true);

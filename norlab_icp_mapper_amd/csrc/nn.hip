@@ -405,10 +405,16 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restri
                                                           const float* __restrict__ Tptr, GridLevels L, float maxr2,
                                                           int allow_self_i, int* __restrict__ out_sidx,
                                                           float* __restrict__ out_d2, IcpState* __restrict__ st,
-                                                          unsigned* __restrict__ hard)
+                                                          unsigned* __restrict__ hard, unsigned* __restrict__ hist0)
 {
     static_assert(G == 8 || G == 16, "9 rows are spread over the first lanes of a group");
     if (st->done) return;
+    // level-0 histogram of the quantile selection (top 8 bits of the d^2 pattern), per workgroup in LDS
+    __shared__ unsigned lh[ICPMI_FSEL_B0];
+    if (hist0) {
+        for (int b = threadIdx.x; b < ICPMI_FSEL_B0; b += NN_BLOCK) lh[b] = 0;
+        __syncthreads();
+    }
     const bool allow_self = allow_self_i != 0;
     const int tid = blockIdx.x * NN_BLOCK + threadIdx.x;
     const int qi = tid / G;
@@ -551,10 +557,16 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restri
         } else bd2 = INFINITY;
         out_sidx[orig] = bs;
         out_d2[orig] = bd2;
+        if (hist0 && bd2 != INFINITY && bd2 > 0.f) atomicAdd(&lh[__float_as_uint(bd2) >> 21], 1u);
         if (!decided) {
             const unsigned slot = atomicAdd(&st->hard_count, 1u);
             hard[slot] = (unsigned)orig;
         }
+    }
+    if (hist0) {
+        __syncthreads();
+        for (int b = threadIdx.x; b < ICPMI_FSEL_B0; b += NN_BLOCK)
+            if (lh[b]) atomicAdd(&hist0[b], lh[b]);
     }
 }
 
@@ -579,9 +591,20 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
         const float4* q = sorted ? c->d_qsorted : d_reading;
         const int* qi = sorted ? c->d_qindex : nullptr;
         if (n == 0) return ICPMI_OK;
+        // the brute pass may still overwrite d2 of queued queries: only build the histogram here when
+        // every query is decided on the pyramid
+        const GridParams& topg = c->levels.g[c->levels.nlev - 1];
+        const bool needs_hard = !std::isfinite(lc.max_dist) || (topg.cell - topg.slack) <= lc.max_dist;
+        // Measured (r1): building the level-0 histogram in this kernel costs +20 us -- 3125 workgroups
+        // flushing ~10 hot bins each serialise on a dozen L2 atomics addresses -- against 4.5 us for the
+        // stand-alone 49-workgroup histogram kernel.  Kept behind an env knob for re-evaluation.
+        static int fuse_h0 = -1;
+        if (fuse_h0 < 0) { const char* e = getenv("ICPMI_NN_FUSE_HIST0"); fuse_h0 = e ? atoi(e) : 0; }
+        unsigned* h0 = (needs_hard || !fuse_h0) ? nullptr : c->nn_hist0;
+        c->nn_builds_hist0 = h0 != nullptr;
 #define LAUNCH_ML(G_, NB_)                                                                                                      \
     hipLaunchKernelGGL((nn1_ml_kernel<G_, NB_>), dim3((int)((n * G_ + NN_BLOCK - 1) / NN_BLOCK)), dim3(NN_BLOCK), 0, c->stream, q, qi, \
-                       (int)n, d_T, c->levels, lc.maxr2, allow_self, d_sidx, d_d2, d_state, c->d_hard)
+                       (int)n, d_T, c->levels, lc.maxr2, allow_self, d_sidx, d_d2, d_state, c->d_hard, h0)
         switch (variant) {
             case 1: LAUNCH_ML(8, 2); break;
             case 2: LAUNCH_ML(8, 8); break;
@@ -599,6 +622,7 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
         HIP_TRY(c, hipGetLastError());
         return ICPMI_OK;
     }
+    c->nn_builds_hist0 = false;
     constexpr int G = 8;
     const int64_t threads = n * G;
     const int blocks = (int)((threads + NN_BLOCK - 1) / NN_BLOCK);

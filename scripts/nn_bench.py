@@ -23,6 +23,6 @@ print("grid", icp.gridInfo())
 for r in range(reps):
     icp.registerDev(ds.data_ptr(), ds.shape[0], fixed_iterations=20)
     dbg = icp.debugCounters()
-    print("   phase cycles per ring pass:", [round(x / max(dbg[0], 1)) for x in dbg[8:15]], "passes", dbg[0], "staged", dbg[1], "to_global", dbg[2])
+    print("   phase cycles per ring pass:", [round(x / max(dbg[0], 1)) for x in dbg[8:15]], "passes", dbg[0], "staged", dbg[1], "to_global", dbg[2], "solve serial cycles", round(dbg[20] / max(dbg[21], 1)))
     print(f"{mode}: nn avg {icp.stats.nn_ms_avg*1e3:.1f} us over {icp.stats.nn_launches} launches, loop {icp.stats.loop_ms:.3f} ms, pairs {icp.stats.pairs}, "
           f"dbg ring_passes/staged_pts/items_to_global = {[ (icp.stats.reserved[2*i] & 0xffffffff) | (icp.stats.reserved[2*i+1] << 32) for i in range(3)]}")
