@@ -308,6 +308,7 @@ icpmi_status icpmi_knn(icpmi_handle h, const float* q4, int64_t n, int32_t k, fl
         lc.ring_max = need < 16 ? need : 16;
     } else lc.ring_max = 6;
     h->nn_hist0 = nullptr; // stage call: no quantile selection follows
+    h->nn_iter_hint = 0;
     icpmi_status s = nn_launch_k(h, h->d_reading, n, nullptr, lc, allow_self, h->d_sidx, h->d_d2, h->d_state);
     if (s != ICPMI_OK) return s;
     int* d_ids = nullptr;

@@ -148,6 +148,7 @@ struct icpmi_ctx {
     unsigned* d_selhist = nullptr;                             // ICPMI_SEL_BINS
     unsigned* nn_hist0 = nullptr;     // set by the loop when the NN kernel should build the level-0 histogram
     bool nn_builds_hist0 = false;     // set by the NN launcher: true if the launched variant did build it
+    int nn_iter_hint = 0;             // iteration index of the launch being enqueued (> 0: seeded by the previous match)
     IcpState* d_state = nullptr;
     IcpState* h_state = nullptr;                               // pinned mirror
 

@@ -1026,7 +1026,7 @@ icpmi_status loop_run(icpmi_ctx* c, int64_t n, const LoopCfg& lc_in, bool fixed,
             hipGraph_t g = nullptr;
             HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
             icpmi_status s = ICPMI_OK;
-            for (int it = 0; it < lc.max_iter && s == ICPMI_OK; ++it) s = enqueue_iteration(c, n, lc, nullptr, nullptr);
+            for (int it = 0; it < lc.max_iter && s == ICPMI_OK; ++it) { c->nn_iter_hint = it; s = enqueue_iteration(c, n, lc, nullptr, nullptr); }
             hipError_t ce = hipStreamEndCapture(c->stream, &g);
             if (s != ICPMI_OK) { if (g) hipGraphDestroy(g); return s; }
             HIP_TRY(c, ce);
@@ -1046,6 +1046,7 @@ icpmi_status loop_run(icpmi_ctx* c, int64_t n, const LoopCfg& lc_in, bool fixed,
         int launched = 0;
         for (int it = 0; it < lc.max_iter; ++it) {
             hipEvent_t e0 = profile ? c->nn_events[2 * it] : nullptr, e1 = profile ? c->nn_events[2 * it + 1] : nullptr;
+            c->nn_iter_hint = it;
             icpmi_status s = enqueue_iteration(c, n, lc, e0, e1);
             if (s != ICPMI_OK) return s;
             ++launched;
@@ -1112,6 +1113,7 @@ icpmi_status loop_single_step(icpmi_ctx* c, int64_t n, const LoopCfg& lc, const 
     HIP_TRY(c, hipMemsetAsync(d_Tstep, 0, 16 * sizeof(float), c->stream));
     LoopCfg l1 = lc;
     l1.max_iter = 1; l1.use_diff = 0; l1.use_bound = 0;
+    c->nn_iter_hint = 0;
     c->nn_hist0 = fused_filter_slot(l1) >= 0 ? c->d_selhist + ICPMI_FSEL_OFF0 : nullptr;
     c->nn_builds_hist0 = false;
     icpmi_status s = nn_launch_k(c, c->d_reading, n, c->d_state->T_iter, l1, 1, c->d_sidx, c->d_d2, c->d_state);

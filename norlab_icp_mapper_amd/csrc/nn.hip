@@ -407,7 +407,8 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restri
                                                           float* __restrict__ out_d2, IcpState* __restrict__ st,
                                                           unsigned* __restrict__ hard, unsigned* __restrict__ hist0)
 {
-    static_assert(G == 8 || G == 16, "9 rows are spread over the first lanes of a group");
+    static_assert(G == 2 || G == 4 || G == 8 || G == 16, "lanes per query");
+    constexpr int NR = (9 + G - 1) / G; // rows owned per lane: row rr belongs to lane rr % G, slot rr / G
     if (st->done) return;
     // level-0 histogram of the quantile selection (top 8 bits of the d^2 pattern), per workgroup in LDS
     __shared__ unsigned lh[ICPMI_FSEL_B0];
@@ -416,7 +417,12 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restri
         __syncthreads();
     }
     const bool allow_self = allow_self_i != 0;
-    const int tid = blockIdx.x * NN_BLOCK + threadIdx.x;
+    // XCD-aware order: workgroup b runs on XCD b % 8 (observed placement, used for speed only), so
+    // giving each XCD one contiguous eighth of the tile-sorted queries keeps its share of the map
+    // (~1/8 of the cells) resident in that XCD's private 4 MiB L2.  The grid is padded to 8 * chunk.
+    const int chunk = gridDim.x >> 3;
+    const int lb = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    const int tid = lb * NN_BLOCK + threadIdx.x;
     const int qi = tid / G;
     const int sub = tid % G;
     const bool active = qi < n;
@@ -479,41 +485,49 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restri
         mf = fminf(mf, fminf(fz - flz, 1.0f - (fz - flz)));
         if (!(mf >= 0.f)) mf = 0.f;
 
-        // (1) row lookups: lane r < 9 of the group owns row r (G = 8: lane 0 also owns row 8)
-        unsigned s0 = 0, n0 = 0, s1 = 0, n1 = 0;
+        // (1) row lookups: row rr is owned by lane rr % G of the group (slot rr / G); all lookups of a
+        //     lane are independent loads
+        unsigned rs[NR], rn[NR];
         {
             // distances from the query to the lower / upper faces of its cell along y and z
             const float ylo = (fy - fly) * g.cell, yhi = (1.0f - (fy - fly)) * g.cell;
             const float zlo = (fz - flz) * g.cell, zhi = (1.0f - (fz - flz)) * g.cell;
-            auto lookup = [&](int rr, unsigned& s, unsigned& cnt) {
-                const int dy = (rr % 3) - 1, dz = (rr / 3) - 1;
-                int xa = cx - 1, xb = cx + 1;
-                if (rub2 != INFINITY) {
-                    const float ddy = dy == 0 ? 0.f : (dy < 0 ? ylo : yhi);
-                    const float ddz = dz == 0 ? 0.f : (dz < 0 ? zlo : zhi);
-                    const float rem2 = rub2 - (ddy * ddy + ddz * ddz);
-                    if (rem2 < 0.f) { s = 0; cnt = 0; return; } // the ball does not reach this row
-                    const float rem = sqrtf(rem2);
-                    const int xl = (int)fmaxf(floorf((p.x - rem - g.ox) * g.inv_cell), -1.0e6f);
-                    const int xh = (int)fminf(floorf((p.x + rem - g.ox) * g.inv_cell), 1.0e6f);
-                    xa = xl > xa ? xl : xa;
-                    xb = xh < xb ? xh : xb;
+#pragma unroll
+            for (int sl = 0; sl < NR; ++sl) {
+                const int rr = sub + sl * G;
+                unsigned s = 0, cnt = 0;
+                if (rr < 9) {
+                    const int dy = (rr % 3) - 1, dz = (rr / 3) - 1;
+                    int xa = cx - 1, xb = cx + 1;
+                    bool reach = true;
+                    if (rub2 != INFINITY) {
+                        const float ddy = dy == 0 ? 0.f : (dy < 0 ? ylo : yhi);
+                        const float ddz = dz == 0 ? 0.f : (dz < 0 ? zlo : zhi);
+                        const float rem2 = rub2 - (ddy * ddy + ddz * ddz);
+                        reach = rem2 >= 0.f; // else the ball does not reach this row
+                        const float rem = sqrtf(fmaxf(rem2, 0.f));
+                        const int xl = (int)fmaxf(floorf((p.x - rem - g.ox) * g.inv_cell), -1.0e6f);
+                        const int xh = (int)fminf(floorf((p.x + rem - g.ox) * g.inv_cell), 1.0e6f);
+                        xa = xl > xa ? xl : xa;
+                        xb = xh < xb ? xh : xb;
+                    }
+                    if (reach) {
+                        unsigned e;
+                        row_run(g, cs, xa, xb, cy + dy, cz + dz, s, e);
+                        cnt = e - s;
+                    }
                 }
-                unsigned e;
-                row_run(g, cs, xa, xb, cy + dy, cz + dz, s, e);
-                cnt = e - s;
-            };
-            if (sub < 9) lookup(sub, s0, n0);
-            if (G == 8 && sub == 0) lookup(8, s1, n1);
+                rs[sl] = s; rn[sl] = cnt;
+            }
         }
         // (2) broadcast, prefix: candidate k of the flat list lives at map[k + off_r], P_r <= k < P_{r+1}
         unsigned Pr[10], Or[9];
         Pr[0] = 0;
 #pragma unroll
         for (int rr = 0; rr < 9; ++rr) {
-            const int src = gbase + (rr < G ? rr : 0);
-            const unsigned s = __shfl(rr < G ? s0 : s1, src, 64);
-            const unsigned c = __shfl(rr < G ? n0 : n1, src, 64);
+            const int src = gbase + (rr % G);
+            const unsigned s = __shfl(rs[rr / G], src, 64);
+            const unsigned c = __shfl(rn[rr / G], src, 64);
             Or[rr] = s - Pr[rr];
             Pr[rr + 1] = Pr[rr] + c;
         }
@@ -603,13 +617,19 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
         unsigned* h0 = (needs_hard || !fuse_h0) ? nullptr : c->nn_hist0;
         c->nn_builds_hist0 = h0 != nullptr;
 #define LAUNCH_ML(G_, NB_)                                                                                                      \
-    hipLaunchKernelGGL((nn1_ml_kernel<G_, NB_>), dim3((int)((n * G_ + NN_BLOCK - 1) / NN_BLOCK)), dim3(NN_BLOCK), 0, c->stream, q, qi, \
-                       (int)n, d_T, c->levels, lc.maxr2, allow_self, d_sidx, d_d2, d_state, c->d_hard, h0)
-        switch (variant) {
-            case 1: LAUNCH_ML(8, 2); break;
-            case 2: LAUNCH_ML(8, 8); break;
+    hipLaunchKernelGGL((nn1_ml_kernel<G_, NB_>), dim3((int)(((n * G_ + NN_BLOCK - 1) / NN_BLOCK + 7) / 8 * 8)), dim3(NN_BLOCK), 0,  \
+                       c->stream, q, qi, (int)n, d_T, c->levels, lc.maxr2, allow_self, d_sidx, d_d2, d_state, c->d_hard, h0)
+        // iterations > 0 are seeded by the previous match (a handful of candidates per query): fewer
+        // lanes per query; the unseeded first pass scans whole 27-cell blocks: more lanes per query
+        const bool seeded = c->nn_iter_hint > 0 && allow_self;
+        const int v = seeded ? variant / 10 : variant % 10;
+        switch (v) {
+            case 1: LAUNCH_ML(2, 4); break;
+            case 2: LAUNCH_ML(4, 4); break;
             case 3: LAUNCH_ML(16, 2); break;
             case 4: LAUNCH_ML(16, 4); break;
+            case 5: LAUNCH_ML(4, 2); break;
+            case 6: LAUNCH_ML(8, 2); break;
             default: LAUNCH_ML(8, 4); break;
         }
 #undef LAUNCH_ML
