@@ -1,0 +1,100 @@
+// build_map_from_scans_and_trajectory -- counterpart of the reference's example harness
+// (examples/build_map_from_scans_and_trajectory.cpp:196-239) over the GPU-backed host shell:
+//   build_map_from_scans_and_trajectory <data dir> <config.yaml> [<trajectory_out.vtk>]
+// <data dir> holds scans/*.vtk and trajectory.csv (a ROS odometry dump: stamp.sec, stamp.nanosec,
+// frame ids, position xyz, orientation xyzw, ...).  Scans are paired with trajectory rows in
+// LEXICOGRAPHIC file order, as the reference does (its line 191) -- including the resulting
+// mis-pairing of cloud_1690309710_85582848.vtk in the bundled data.
+#include <dirent.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../norlab_icp_mapper_amd/host/Mapper.h"
+
+using namespace nim;
+
+struct StampedPose { Mat4 pose; long long ns; };
+
+static std::vector<StampedPose> readTrajectory(const std::string& path)
+{
+    std::ifstream in(path);
+    if (!in) throw std::runtime_error("cannot open " + path);
+    std::vector<StampedPose> out;
+    std::string line;
+    std::getline(in, line); // header
+    while (std::getline(in, line)) {
+        if (line.empty()) continue;
+        std::vector<std::string> f;
+        std::stringstream ss(line);
+        std::string tok;
+        while (std::getline(ss, tok, ',')) f.push_back(tok);
+        if (f.size() < 11) throw std::runtime_error("malformed trajectory row: " + line);
+        const long long sec = std::stoll(f[0]), nsec = std::stoll(f[1]);
+        const double x = std::stod(f[4]), y = std::stod(f[5]), z = std::stod(f[6]);
+        const double qx = std::stod(f[7]), qy = std::stod(f[8]), qz = std::stod(f[9]), qw = std::stod(f[10]);
+        Mat4 T = Mat4::identity();
+        T(0, 0) = (float)(1 - 2 * (qy * qy + qz * qz)); T(0, 1) = (float)(2 * (qx * qy - qz * qw)); T(0, 2) = (float)(2 * (qx * qz + qy * qw));
+        T(1, 0) = (float)(2 * (qx * qy + qz * qw)); T(1, 1) = (float)(1 - 2 * (qx * qx + qz * qz)); T(1, 2) = (float)(2 * (qy * qz - qx * qw));
+        T(2, 0) = (float)(2 * (qx * qz - qy * qw)); T(2, 1) = (float)(2 * (qy * qz + qx * qw)); T(2, 2) = (float)(1 - 2 * (qx * qx + qy * qy));
+        T(0, 3) = (float)x; T(1, 3) = (float)y; T(2, 3) = (float)z;
+        out.push_back(StampedPose{T, sec * 1000000000ll + nsec});
+    }
+    return out;
+}
+
+static std::vector<std::string> listScans(const std::string& dir)
+{
+    std::vector<std::string> files;
+    DIR* d = opendir(dir.c_str());
+    if (!d) throw std::runtime_error("cannot open " + dir);
+    while (dirent* e = readdir(d)) {
+        const std::string name = e->d_name;
+        if (name.size() > 4 && name.substr(name.size() - 4) == ".vtk") files.push_back(dir + "/" + name);
+    }
+    closedir(d);
+    std::sort(files.begin(), files.end());
+    return files;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 3) {
+        std::fprintf(stderr, "usage: %s <data dir> <config.yaml> [<trajectory_out.vtk>]\n", argv[0]);
+        return 2;
+    }
+    try {
+        const std::string dataDir = argv[1], config = argv[2];
+        const auto trajectory = readTrajectory(dataDir + "/trajectory.csv");
+        const auto scans = listScans(dataDir + "/scans");
+        if (trajectory.size() != scans.size()) throw std::runtime_error("trajectory rows and scan files differ in number");
+
+        Mapper mapper(config, /*is3D*/ true, /*isOnline*/ false, /*isMapping*/ true, /*saveMapCellsOnHardDrive*/ false);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (size_t i = 0; i < scans.size(); ++i) {
+            const TimePoint stamp{std::chrono::nanoseconds(trajectory[i].ns)};
+            DataPoints cloud = DataPoints::load(scans[i]);
+            mapper.applyInputFilters(cloud);
+            mapper.processInput(cloud, trajectory[i].pose, stamp);
+            const Mat4 p = mapper.getPose();
+            std::printf("scan %zu/%zu  %zu pts  pose %.4f %.4f %.4f  iterations %d  overlap %.3f\n", i + 1, scans.size(),
+                        cloud.getNbPoints(), p(0, 3), p(1, 3), p(2, 3), mapper.lastIcpStats().iterations,
+                        mapper.lastIcpStats().weighted_point_used_ratio);
+        }
+        const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        DataPoints map = mapper.getMap();
+        map.save(dataDir + "/map.vtk");
+        if (argc > 3) mapper.getTrajectory().save(argv[3]);
+        std::printf("map: %zu points, %zu scans in %.3f s -> %s/map.vtk\n", map.getNbPoints(), scans.size(), secs, dataDir.c_str());
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -121,6 +121,9 @@ void icpmi_config_default(icpmi_config* cfg);
 
 /* Replaces constructing / configuring `PM::ICPSequence icp` (Mapper.h:23, Mapper.cpp:72,77). */
 icpmi_status icpmi_create(const icpmi_config* cfg, icpmi_handle* out);
+/* Re-configure the chain of an existing handle (`icp.loadFromYamlNode` / `icp.setDefault()` called
+ * again on the same object): the handle, its device and its map stay. cfg->device must not change. */
+icpmi_status icpmi_set_config(icpmi_handle h, const icpmi_config* cfg);
 void         icpmi_destroy(icpmi_handle h);
 const char*  icpmi_last_error(icpmi_handle h); /* h may be NULL: error of the last failed create */
 

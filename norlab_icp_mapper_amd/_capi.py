@@ -70,6 +70,7 @@ SYMBOLS = [
     ("icpmi_version", C.c_int32, []),
     ("icpmi_config_default", None, [C.POINTER(Config)]),
     ("icpmi_create", C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
+    ("icpmi_set_config", C.c_int, [_P, C.POINTER(Config)]),
     ("icpmi_destroy", None, [_P]),
     ("icpmi_last_error", C.c_char_p, [_P]),
     ("icpmi_set_map", C.c_int, [_P, _P, C.c_int64, _P, C.POINTER(C.c_int32)]),

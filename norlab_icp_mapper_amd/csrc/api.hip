@@ -103,6 +103,20 @@ icpmi_status icpmi_create(const icpmi_config* cfg, icpmi_handle* out)
     return ICPMI_OK;
 }
 
+icpmi_status icpmi_set_config(icpmi_handle h, const icpmi_config* cfg)
+{
+    CHECK_H(h);
+    if (!cfg) { h->last_error = "set_config: null config"; return ICPMI_ERR_INVALID_ARG; }
+    icpmi_status vs = validate_config(cfg, h->last_error);
+    if (vs != ICPMI_OK) return vs;
+    if (cfg->device != h->device) { h->last_error = "set_config: the device of a handle cannot change"; return ICPMI_ERR_INVALID_ARG; }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->cfg = *cfg;
+    // the cached loop graph was captured for the previous chain
+    if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; h->graph_n = -1; }
+    return ICPMI_OK;
+}
+
 void icpmi_destroy(icpmi_handle c)
 {
     if (!c) return;

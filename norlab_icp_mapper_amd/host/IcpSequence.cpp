@@ -1,0 +1,418 @@
+// IcpSequence.cpp -- see IcpSequence.h.
+#include "IcpSequence.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <unordered_map>
+
+namespace nim {
+
+void GpuICPSequence::check(icpmi_handle h, icpmi_status s)
+{
+    if (s == ICPMI_OK) return;
+    const std::string msg = icpmi_last_error(h);
+    switch (s) {
+        case ICPMI_ERR_NO_POINT_TO_MINIMIZE:
+        case ICPMI_ERR_NO_OUTLIER_TO_FILTER:
+        case ICPMI_ERR_BOUND:
+        case ICPMI_ERR_NAN: throw ConvergenceError(msg);
+        case ICPMI_ERR_MISSING_NORMALS: throw InvalidField(msg);
+        case ICPMI_ERR_INVALID_ARG: throw InvalidParameter(msg);
+        default: throw std::runtime_error(msg);
+    }
+}
+
+GpuICPSequence::GpuICPSequence(int device)
+{
+    icpmi_config_default(&cfg);
+    cfg.device = device;
+    recreate();
+}
+
+GpuICPSequence::~GpuICPSequence() { icpmi_destroy(h); }
+
+void GpuICPSequence::recreate()
+{
+    // the handle is created once and re-configured afterwards: filters, modules and transformations
+    // created from it keep a valid GPU context across loadFromYamlNode / setDefault
+    if (h) check(h, icpmi_set_config(h, &cfg));
+    else check(nullptr, icpmi_create(&cfg, &h));
+}
+
+void GpuICPSequence::setDefault()
+{
+    // libpointmatcher's default chain: KDTreeMatcher knn 1, TrimmedDist 0.85, PointToPlane,
+    // Counter 40 + Differential(1e-3, 1e-3, 3).  Its RandomSampling reading filter and
+    // SamplingSurfaceNormal reference filter are not on the accelerated path: the reading is used
+    // whole and map normals, when the map carries none, come from the surface-normal operator.
+    const int dev = cfg.device;
+    icpmi_config_default(&cfg);
+    cfg.device = dev;
+    cfg.n_outlier = 1;
+    cfg.outlier[0].type = ICPMI_OUT_TRIMMEDDIST;
+    cfg.outlier[0].param = 0.85f;
+    cfg.minimizer = ICPMI_MIN_POINT_TO_PLANE;
+    cfg.use_differential = 1;
+    recreate();
+}
+
+static void requireKnown(const yaml::Node& params, std::initializer_list<const char*> known, const std::string& who)
+{
+    if (!params.IsMap()) return;
+    for (const auto& kv : params.map) {
+        bool ok = false;
+        for (const char* k : known) ok |= kv.first == k;
+        if (!ok) throw InvalidParameter(who + ": unknown parameter " + kv.first);
+    }
+}
+
+static std::pair<std::string, yaml::Node> singleEntry(const yaml::Node& n, const std::string& what)
+{
+    if (n.IsScalar()) return {n.scalar, yaml::Node()};
+    if (n.IsMap() && n.map.size() == 1) return {n.map[0].first, n.map[0].second};
+    throw InvalidParameter("malformed " + what + " entry");
+}
+
+void GpuICPSequence::loadFromYamlNode(const yaml::Node& icp)
+{
+    const int dev = cfg.device;
+    icpmi_config_default(&cfg);
+    cfg.device = dev;
+    if (icp.IsMap())
+        for (const auto& kv : icp.map) {
+            static const char* valid[] = {"matcher", "outlierFilters", "errorMinimizer", "transformationCheckers", "inspector", "logger",
+                                          "readingDataPointsFilters", "referenceDataPointsFilters", "readingStepDataPointsFilters"};
+            bool ok = false;
+            for (const char* v : valid) ok |= kv.first == v;
+            if (!ok) throw InvalidParameter("unknown ICP chain key: " + kv.first);
+        }
+    for (const char* key : {"readingDataPointsFilters", "referenceDataPointsFilters", "readingStepDataPointsFilters"})
+        if (icp[key] && icp[key].IsSequence() && !icp[key].seq.empty())
+            throw InvalidParameter(std::string(key) + " inside the ICP chain are not on the accelerated path; apply them as input filters");
+
+    if (icp["matcher"]) {
+        auto e = singleEntry(icp["matcher"], "matcher");
+        if (e.first != "KDTreeMatcher") throw InvalidParameter("unknown matcher " + e.first);
+        requireKnown(e.second, {"knn", "epsilon", "searchType", "maxDist", "maxDistField"}, "KDTreeMatcher");
+        if (e.second["knn"]) cfg.knn = e.second["knn"].as<int>();
+        if (e.second["epsilon"]) cfg.epsilon = e.second["epsilon"].as<float>();
+        if (e.second["maxDist"]) cfg.max_dist = e.second["maxDist"].as<float>();
+    }
+    cfg.n_outlier = 0;
+    if (icp["outlierFilters"].IsSequence())
+        for (const auto& item : icp["outlierFilters"].seq) {
+            auto e = singleEntry(item, "outlier filter");
+            icpmi_outlier o{};
+            auto param = [&](const char* key, float def) {
+                requireKnown(e.second, {key}, e.first);
+                return e.second[key] ? e.second[key].as<float>() : def;
+            };
+            if (e.first == "TrimmedDistOutlierFilter") { o.type = ICPMI_OUT_TRIMMEDDIST; o.param = param("ratio", 0.85f); }
+            else if (e.first == "MaxDistOutlierFilter") { o.type = ICPMI_OUT_MAXDIST; o.param = param("maxDist", 1.f); }
+            else if (e.first == "MinDistOutlierFilter") { o.type = ICPMI_OUT_MINDIST; o.param = param("minDist", 1.f); }
+            else if (e.first == "MedianDistOutlierFilter") { o.type = ICPMI_OUT_MEDIANDIST; o.param = param("factor", 3.f); }
+            else if (e.first == "SurfaceNormalOutlierFilter") { o.type = ICPMI_OUT_SURFACENORMAL; o.param = param("maxAngle", 1.57f); }
+            else throw InvalidParameter("unknown outlier filter " + e.first);
+            if (cfg.n_outlier >= 8) throw InvalidParameter("at most 8 outlier filters");
+            cfg.outlier[cfg.n_outlier++] = o;
+        }
+    if (icp["errorMinimizer"]) {
+        auto e = singleEntry(icp["errorMinimizer"], "errorMinimizer");
+        if (e.first == "IdentityErrorMinimizer") cfg.minimizer = ICPMI_MIN_IDENTITY;
+        else if (e.first == "PointToPointErrorMinimizer") cfg.minimizer = ICPMI_MIN_POINT_TO_POINT;
+        else if (e.first == "PointToPlaneErrorMinimizer") {
+            cfg.minimizer = ICPMI_MIN_POINT_TO_PLANE;
+            for (const char* k : {"force2D", "force4DOF"})
+                if (e.second[k] && e.second[k].as<int>() != 0) throw InvalidParameter(std::string(k) + " is not on the accelerated path");
+        } else throw InvalidParameter("unknown error minimizer " + e.first);
+    }
+    if (icp["transformationCheckers"].IsSequence())
+        for (const auto& item : icp["transformationCheckers"].seq) {
+            auto e = singleEntry(item, "transformation checker");
+            if (e.first == "CounterTransformationChecker") {
+                requireKnown(e.second, {"maxIterationCount"}, e.first);
+                if (e.second["maxIterationCount"]) cfg.max_iterations = e.second["maxIterationCount"].as<int>();
+            } else if (e.first == "DifferentialTransformationChecker") {
+                requireKnown(e.second, {"minDiffRotErr", "minDiffTransErr", "smoothLength"}, e.first);
+                cfg.use_differential = 1;
+                if (e.second["minDiffRotErr"]) cfg.min_diff_rot = e.second["minDiffRotErr"].as<float>();
+                if (e.second["minDiffTransErr"]) cfg.min_diff_trans = e.second["minDiffTransErr"].as<float>();
+                if (e.second["smoothLength"]) cfg.smooth_length = e.second["smoothLength"].as<int>();
+            } else if (e.first == "BoundTransformationChecker") {
+                requireKnown(e.second, {"maxRotationNorm", "maxTranslationNorm"}, e.first);
+                cfg.use_bound = 1;
+                if (e.second["maxRotationNorm"]) cfg.max_rot_norm = e.second["maxRotationNorm"].as<float>();
+                if (e.second["maxTranslationNorm"]) cfg.max_trans_norm = e.second["maxTranslationNorm"].as<float>();
+            } else throw InvalidParameter("unknown transformation checker " + e.first);
+        }
+    recreate();
+}
+
+bool GpuICPSequence::hasMap() const { return h && icpmi_has_map(h); }
+
+bool GpuICPSequence::setMap(const DataPoints& map)
+{
+    int32_t accepted = 0;
+    const float* normals = nullptr;
+    std::vector<float> computed;
+    if (map.descriptorExists("normals")) {
+        const Descriptor& d = map.getDescriptorByName("normals");
+        if (d.span != 3) throw InvalidField("descriptor normals must have 3 rows");
+        normals = d.data.data();
+    } else if (cfg.minimizer == ICPMI_MIN_POINT_TO_PLANE && map.getNbPoints() > 0) {
+        // stand-in for the reference filters of the default chain (see setDefault)
+        computed.resize(3 * map.getNbPoints());
+        check(h, icpmi_surface_normals(h, map.features.data(), (int64_t)map.getNbPoints(), 7, computed.data()));
+        normals = computed.data();
+    }
+    check(h, icpmi_set_map(h, map.features.data(), (int64_t)map.getNbPoints(), normals, &accepted));
+    return accepted != 0;
+}
+
+Mat4 GpuICPSequence::operator()(const DataPoints& reading)
+{
+    Mat4 T = Mat4::identity();
+    const float* normals = nullptr;
+    if (reading.descriptorExists("normals") && reading.getDescriptorByName("normals").span == 3)
+        normals = reading.getDescriptorByName("normals").data.data();
+    check(h, icpmi_register(h, reading.features.data(), (int64_t)reading.getNbPoints(), normals, T.data(), &lastStats));
+    return T;
+}
+
+// ------------------------------------------------------------------------------------------------
+DataPoints RigidTransformation::compute(const DataPoints& cloud, const Mat4& T) const
+{
+    DataPoints out = cloud;
+    const int64_t n = (int64_t)cloud.getNbPoints();
+    const int dn = cloud.findDescriptor("normals");
+    const float* nin = dn >= 0 && cloud.descriptors[dn].span == 3 ? cloud.descriptors[dn].data.data() : nullptr;
+    float* nout = nin ? out.descriptors[dn].data.data() : nullptr;
+    icpmi_status s = icpmi_transform(h, T.data(), cloud.features.data(), n, out.features.data(), nin, nout);
+    if (s == ICPMI_ERR_INVALID_ARG) throw TransformationError(icpmi_last_error(h));
+    GpuICPSequence::check(h, s);
+    const int dobs = cloud.findDescriptor("observationDirections");
+    if (dobs >= 0 && cloud.descriptors[dobs].span == 3 && n > 0) {
+        // rotate the second direction field with the same operator (features are recomputed, cheap)
+        std::vector<float> scratch(cloud.features.size());
+        GpuICPSequence::check(h, icpmi_transform(h, T.data(), cloud.features.data(), n, scratch.data(),
+                                                 cloud.descriptors[dobs].data.data(), out.descriptors[dobs].data.data()));
+    }
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// DataPointsFilters (semantics: SURVEY.md B.9)
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct DistanceLimitFilter : DataPointsFilter {
+    int dim = -1; float dist = 1.f; bool removeInside = true;
+    void inPlaceFilter(DataPoints& c) const override {
+        const size_t n = c.getNbPoints();
+        std::vector<uint8_t> keep(n);
+        const float ad = std::fabs(dist);
+        for (size_t i = 0; i < n; ++i) {
+            const float* p = c.col(i);
+            const float v = dim < 0 ? std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) : std::fabs(p[dim]);
+            keep[i] = removeInside ? v > ad : v < ad;
+        }
+        c.keepOnly(keep);
+    }
+};
+
+struct BoundingBoxFilter : DataPointsFilter {
+    float lo[3] = {-1, -1, -1}, hi[3] = {1, 1, 1}; bool removeInside = true;
+    void inPlaceFilter(DataPoints& c) const override {
+        const size_t n = c.getNbPoints();
+        std::vector<uint8_t> keep(n);
+        for (size_t i = 0; i < n; ++i) {
+            const float* p = c.col(i);
+            bool inside = true;
+            for (int r = 0; r < 3; ++r) inside &= p[r] > lo[r] && p[r] < hi[r];
+            keep[i] = removeInside ? !inside : inside;
+        }
+        c.keepOnly(keep);
+    }
+};
+
+struct AddDescriptorFilter : DataPointsFilter {
+    std::string name; int dimension = 1; std::vector<float> values;
+    void inPlaceFilter(DataPoints& c) const override {
+        const size_t n = c.getNbPoints();
+        std::vector<float> data((size_t)dimension * n);
+        for (size_t i = 0; i < n; ++i) for (int r = 0; r < dimension; ++r) data[(size_t)dimension * i + r] = values[r];
+        c.addDescriptor(name, dimension, std::move(data));
+    }
+};
+
+struct CutAtDescriptorThresholdFilter : DataPointsFilter {
+    std::string name; bool useLargerThan = true; float threshold = 0.f;
+    void inPlaceFilter(DataPoints& c) const override {
+        const Descriptor& d = c.getDescriptorByName(name);
+        const size_t n = c.getNbPoints();
+        std::vector<uint8_t> keep(n);
+        for (size_t i = 0; i < n; ++i) {
+            const float v = d.data[(size_t)d.span * i];
+            keep[i] = useLargerThan ? !(v > threshold) : !(v < threshold);
+        }
+        c.keepOnly(keep);
+    }
+};
+
+struct SurfaceNormalFilter : DataPointsFilter {
+    icpmi_handle h; int knn = 5;
+    void inPlaceFilter(DataPoints& c) const override {
+        const size_t n = c.getNbPoints();
+        std::vector<float> normals(3 * n);
+        GpuICPSequence::check(h, icpmi_surface_normals(h, c.features.data(), (int64_t)n, knn, normals.data()));
+        c.addDescriptor("normals", 3, std::move(normals));
+    }
+};
+
+struct RandomSamplingFilter : DataPointsFilter {
+    float prob = 0.75f;
+    void inPlaceFilter(DataPoints& c) const override {
+        const size_t n = c.getNbPoints();
+        std::vector<uint8_t> keep(n);
+        uint64_t s = 0x9E3779B97F4A7C15ull; // fixed seed: deterministic replays
+        for (size_t i = 0; i < n; ++i) {
+            s += 0x9E3779B97F4A7C15ull;
+            uint64_t z = s; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+            keep[i] = (double)(z >> 11) * (1.0 / 9007199254740992.0) < prob;
+        }
+        c.keepOnly(keep);
+    }
+};
+
+// OctreeGridDataPointsFilter stand-in: one point per occupied voxel of edge maxSizeByNode on a
+// lattice anchored at the cloud's bounding-box corner.  Upstream builds an octree over the bounding
+// CUBE, so its leaves are not lattice aligned; the two agree statistically, not point for point
+// (SURVEY.md B.9).  samplingMethod: 0 first point, 1 random point, 2 centroid, 3 medoid.
+struct VoxelGridFilter : DataPointsFilter {
+    float maxSize = 0.f; int method = 0; size_t maxPointByNode = 1;
+    void inPlaceFilter(DataPoints& c) const override {
+        const size_t n = c.getNbPoints();
+        if (n == 0 || !(maxSize > 0.f)) return;
+        float lo[3] = {c.col(0)[0], c.col(0)[1], c.col(0)[2]};
+        for (size_t i = 1; i < n; ++i) for (int r = 0; r < 3; ++r) lo[r] = std::min(lo[r], c.col(i)[r]);
+        struct Cell { size_t first; size_t count; double sum[3]; size_t pick; };
+        std::unordered_map<uint64_t, Cell> cells;
+        cells.reserve(n);
+        std::vector<uint64_t> keyOf(n);
+        uint64_t rng = 0x2545F4914F6CDD1Dull;
+        for (size_t i = 0; i < n; ++i) {
+            const float* p = c.col(i);
+            uint64_t key = 0;
+            for (int r = 0; r < 3; ++r) key = key * 2097152ull + (uint64_t)std::min<double>(2097151.0, std::floor((p[r] - lo[r]) / maxSize));
+            keyOf[i] = key;
+            auto it = cells.find(key);
+            if (it == cells.end()) cells.emplace(key, Cell{i, 1, {p[0], p[1], p[2]}, i});
+            else {
+                Cell& cl = it->second;
+                ++cl.count;
+                for (int r = 0; r < 3; ++r) cl.sum[r] += p[r];
+                if (method == 1) { // reservoir sampling: uniform pick among the cell's points
+                    rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
+                    if (rng % cl.count == 0) cl.pick = i;
+                }
+            }
+        }
+        if (method == 3) { // medoid: the point closest to the centroid
+            std::unordered_map<uint64_t, double> bestd;
+            for (size_t i = 0; i < n; ++i) {
+                Cell& cl = cells[keyOf[i]];
+                double d = 0;
+                for (int r = 0; r < 3; ++r) { const double e = c.col(i)[r] - cl.sum[r] / cl.count; d += e * e; }
+                auto it = bestd.find(keyOf[i]);
+                if (it == bestd.end() || d < it->second) { bestd[keyOf[i]] = d; cl.pick = i; }
+            }
+        }
+        std::vector<uint8_t> keep(n, 0);
+        for (auto& kv : cells) {
+            Cell& cl = kv.second;
+            const size_t rep = (method == 0 || method == 2) ? cl.first : cl.pick;
+            keep[rep] = 1;
+            if (method == 2) for (int r = 0; r < 3; ++r) c.col(rep)[r] = (float)(cl.sum[r] / cl.count);
+        }
+        c.keepOnly(keep);
+    }
+};
+
+float getf(const yaml::Node& p, const char* k, float def) { return p[k] ? p[k].as<float>() : def; }
+int geti(const yaml::Node& p, const char* k, int def) { return p[k] ? p[k].as<int>() : def; }
+
+} // namespace
+
+std::shared_ptr<DataPointsFilter> createDataPointsFilter(const std::string& name, const yaml::Node& p, icpmi_handle ctx)
+{
+    if (name == "DistanceLimitDataPointsFilter") {
+        requireKnown(p, {"dim", "dist", "removeInside"}, name);
+        auto f = std::make_shared<DistanceLimitFilter>();
+        f->dim = geti(p, "dim", -1); f->dist = getf(p, "dist", 1.f); f->removeInside = geti(p, "removeInside", 1) != 0;
+        if (f->dim > 2) throw InvalidParameter(name + ": dim out of range");
+        return f;
+    }
+    if (name == "BoundingBoxDataPointsFilter") {
+        requireKnown(p, {"xMin", "xMax", "yMin", "yMax", "zMin", "zMax", "removeInside"}, name);
+        auto f = std::make_shared<BoundingBoxFilter>();
+        f->lo[0] = getf(p, "xMin", -1); f->hi[0] = getf(p, "xMax", 1);
+        f->lo[1] = getf(p, "yMin", -1); f->hi[1] = getf(p, "yMax", 1);
+        f->lo[2] = getf(p, "zMin", -1); f->hi[2] = getf(p, "zMax", 1);
+        f->removeInside = geti(p, "removeInside", 1) != 0;
+        return f;
+    }
+    if (name == "AddDescriptorDataPointsFilter") {
+        requireKnown(p, {"descriptorName", "descriptorDimension", "descriptorValues"}, name);
+        auto f = std::make_shared<AddDescriptorFilter>();
+        if (!p["descriptorName"]) throw InvalidParameter(name + ": descriptorName is required");
+        f->name = p["descriptorName"].as<std::string>();
+        f->dimension = geti(p, "descriptorDimension", 1);
+        if (p["descriptorValues"].IsSequence()) for (const auto& v : p["descriptorValues"].seq) f->values.push_back(v.as<float>());
+        else if (p["descriptorValues"].IsScalar()) f->values.push_back(p["descriptorValues"].as<float>());
+        if ((int)f->values.size() != f->dimension) throw InvalidParameter(name + ": descriptorValues must have descriptorDimension entries");
+        return f;
+    }
+    if (name == "CutAtDescriptorThresholdDataPointsFilter") {
+        requireKnown(p, {"descName", "useLargerThan", "threshold"}, name);
+        auto f = std::make_shared<CutAtDescriptorThresholdFilter>();
+        f->name = p["descName"] ? p["descName"].as<std::string>() : "none";
+        f->useLargerThan = geti(p, "useLargerThan", 1) != 0; f->threshold = getf(p, "threshold", 0.f);
+        return f;
+    }
+    if (name == "SurfaceNormalDataPointsFilter") {
+        requireKnown(p, {"knn", "maxDist", "epsilon", "keepNormals", "keepDensities", "keepEigenValues", "keepEigenVectors",
+                         "keepMatchedIds", "keepMeanDist", "sortEigen", "smoothNormals"}, name);
+        for (const char* k : {"keepDensities", "keepEigenValues", "keepEigenVectors", "keepMatchedIds", "keepMeanDist", "smoothNormals"})
+            if (geti(p, k, 0) != 0) throw InvalidParameter(name + ": " + k + " is not on the accelerated path");
+        auto f = std::make_shared<SurfaceNormalFilter>();
+        f->h = ctx; f->knn = geti(p, "knn", 5);
+        return f;
+    }
+    if (name == "RandomSamplingDataPointsFilter") {
+        requireKnown(p, {"prob", "randomSamplingMethod", "seed"}, name);
+        auto f = std::make_shared<RandomSamplingFilter>();
+        f->prob = getf(p, "prob", 0.75f);
+        return f;
+    }
+    if (name == "OctreeGridDataPointsFilter") {
+        requireKnown(p, {"buildParallel", "maxPointByNode", "maxSizeByNode", "samplingMethod"}, name);
+        auto f = std::make_shared<VoxelGridFilter>();
+        f->maxSize = getf(p, "maxSizeByNode", 0.f); f->method = geti(p, "samplingMethod", 0);
+        f->maxPointByNode = (size_t)geti(p, "maxPointByNode", 1);
+        return f;
+    }
+    throw InvalidParameter("unknown DataPointsFilter " + name);
+}
+
+DataPointsFilters::DataPointsFilters(const yaml::Node& seq, icpmi_handle ctx)
+{
+    if (!seq) return;
+    if (!seq.IsSequence()) throw yaml::Exception("expected a sequence of filters");
+    for (const auto& item : seq.seq) {
+        auto e = singleEntry(item, "DataPointsFilter");
+        filters.push_back(createDataPointsFilter(e.first, e.second, ctx));
+    }
+}
+
+} // namespace nim

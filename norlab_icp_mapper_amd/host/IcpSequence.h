@@ -1,0 +1,82 @@
+// IcpSequence.h -- `GpuICPSequence`: the four calls norlab_icp_mapper makes on its
+// `PM::ICPSequence icp` member (Mapper.h:23), over the C ABI of include/icpmi.h:
+//   loadFromYamlNode / setDefault   Mapper.cpp:72,77
+//   setMap                          Map.cpp:111,178,528,581
+//   operator()                      Mapper.cpp:213
+//   errorMinimizer->getOverlap()    Mapper.cpp:219
+// plus the registrar-created helpers the mapper uses next to it: RigidTransformation (Mapper.cpp:22,
+// Map.cpp:14) and the DataPointsFilters of the shipped configuration (Mapper.cpp:27-31,82,92).
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/icpmi.h"
+#include "PointCloud.h"
+#include "Yaml.h"
+
+namespace nim {
+
+class GpuICPSequence {
+public:
+    struct ErrorMinimizerView {
+        const GpuICPSequence* owner;
+        float getOverlap() const { return owner->lastStats.weighted_point_used_ratio; }
+        float getPointUsedRatio() const { return owner->lastStats.point_used_ratio; }
+    };
+
+    explicit GpuICPSequence(int device = 0);
+    ~GpuICPSequence();
+    GpuICPSequence(const GpuICPSequence&) = delete;
+    GpuICPSequence& operator=(const GpuICPSequence&) = delete;
+
+    void setDefault();                                 // PM::ICPSequence::setDefault
+    void loadFromYamlNode(const yaml::Node& icpNode);  // the `icp:` sub-tree
+    bool setMap(const DataPoints& map);                // false on an empty cloud, state unchanged
+    bool hasMap() const;
+    Mat4 operator()(const DataPoints& reading);        // correction in the map frame
+    const ErrorMinimizerView* errorMinimizer = &minimizerView;
+
+    icpmi_handle handle() const { return h; }          // for the operators that share the GPU context
+    const icpmi_stats& stats() const { return lastStats; }
+    const icpmi_config& config() const { return cfg; }
+    static void check(icpmi_handle h, icpmi_status s); // status -> exception mapping
+
+private:
+    void recreate();
+    icpmi_handle h = nullptr;
+    icpmi_config cfg;
+    icpmi_stats lastStats{};
+    ErrorMinimizerView minimizerView{this};
+};
+
+// PM::Transformation created with "RigidTransformation": features' = T * features, descriptors named
+// "normals" / "observationDirections" rotated, everything else copied.
+class RigidTransformation {
+public:
+    explicit RigidTransformation(icpmi_handle ctx) : h(ctx) {}
+    DataPoints compute(const DataPoints& cloud, const Mat4& T) const;
+private:
+    icpmi_handle h;
+};
+
+// ---- DataPointsFilters used by the mapper and the shipped configuration -----------------------
+class DataPointsFilter {
+public:
+    virtual ~DataPointsFilter() = default;
+    virtual void inPlaceFilter(DataPoints& cloud) const = 0;
+};
+
+class DataPointsFilters {
+public:
+    DataPointsFilters() = default;
+    // a YAML sequence of single-key maps, e.g. the `input:` and `post:` sections (Mapper.cpp:82,92)
+    DataPointsFilters(const yaml::Node& seq, icpmi_handle ctx);
+    void apply(DataPoints& cloud) const { for (const auto& f : filters) f->inPlaceFilter(cloud); }
+    size_t size() const { return filters.size(); }
+    std::vector<std::shared_ptr<DataPointsFilter>> filters;
+};
+
+std::shared_ptr<DataPointsFilter> createDataPointsFilter(const std::string& name, const yaml::Node& params, icpmi_handle ctx);
+
+} // namespace nim

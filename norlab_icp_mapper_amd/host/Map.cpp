@@ -1,0 +1,271 @@
+// Map.cpp -- see Map.h.  Behavioural restatement of norlab_icp_mapper/Map.cpp over the GPU-backed
+// ICP object; cell paging is host logic over value-type clouds exactly like the reference.
+#include "Map.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+
+namespace nim {
+
+Map::Map(bool is3D_, bool isOnline_, bool saveCellsOnHardDrive, GpuICPSequence& icp_, std::mutex& icpMapLock_)
+    : is3D(is3D_), isOnline(isOnline_), icp(icp_), icpMapLock(icpMapLock_), transformation(icp_.handle())
+{
+    if (!is3D) throw InvalidParameter("the GPU path is 3-D only (is3D must be true)");
+    if (saveCellsOnHardDrive) throw InvalidParameter("HardDriveCellManager is out of scope (DESIGN.md section 8); use RAM cells");
+    cellManager.reset(new RAMCellManager());
+    if (isOnline) updateThread = std::thread(&Map::updateThreadFunction, this);
+}
+
+Map::~Map()
+{
+    if (isOnline) {
+        updateThreadLooping.store(false);
+        if (updateThread.joinable()) updateThread.join();
+    }
+}
+
+void Map::updateThreadFunction()
+{
+    while (updateThreadLooping.load()) {
+        bool have = false;
+        Update u{};
+        {
+            std::lock_guard<std::mutex> g(updateListLock);
+            if (!updateList.empty()) { u = updateList.front(); updateList.pop_front(); have = true; }
+        }
+        if (have) applyUpdate(u);
+        else std::this_thread::sleep_for(std::chrono::milliseconds(10));
+    }
+}
+
+void Map::scheduleUpdate(const Update& u)
+{
+    if (isOnline) {
+        std::lock_guard<std::mutex> g(updateListLock);
+        updateList.push_back(u);
+    } else applyUpdate(u);
+}
+
+void Map::loadCells(Box box)
+{
+    if (!is3D) box.lo[2] = box.hi[2] = 0;
+    DataPoints chunk;
+    for (int i = box.lo[0]; i <= box.hi[0]; ++i)
+        for (int j = box.lo[1]; j <= box.hi[1]; ++j)
+            for (int k = box.lo[2]; k <= box.hi[2]; ++k) {
+                DataPoints cell;
+                {
+                    std::lock_guard<std::mutex> g(cellManagerLock);
+                    cell = cellManager->retrieveCell(cellId(i, j, k));
+                }
+                if (cell.getNbPoints() > 0) chunk.concatenate(cell);
+            }
+    std::lock_guard<std::mutex> g(localPointCloudLock);
+    if (chunk.getNbPoints() > 0) {
+        localPointCloud.concatenate(chunk);
+        {
+            std::lock_guard<std::mutex> gi(icpMapLock);
+            icp.setMap(localPointCloud);
+        }
+        localPointCloudEmpty.store(false);
+        newLocalPointCloudAvailable = true;
+    }
+    for (int i = box.lo[0]; i <= box.hi[0]; ++i)
+        for (int j = box.lo[1]; j <= box.hi[1]; ++j)
+            for (int k = box.lo[2]; k <= box.hi[2]; ++k) loadedCellIds.insert(cellId(i, j, k));
+}
+
+void Map::unloadCells(Box box)
+{
+    if (!is3D) box.lo[2] = box.hi[2] = 0;
+    float start[3], end[3];
+    for (int a = 0; a < 3; ++a) {
+        start[a] = box.lo[a] * CELL_SIZE;                 // toInferiorWorldCoordinate
+        end[a] = ((float)box.hi[a] + 1.0f) * CELL_SIZE;   // toSuperiorWorldCoordinate (no int overflow at INT_MAX - 1)
+    }
+    DataPoints oldChunk;
+    {
+        std::lock_guard<std::mutex> g(localPointCloudLock);
+        const size_t n = localPointCloud.getNbPoints();
+        std::vector<uint8_t> leaves(n), stays(n);
+        for (size_t i = 0; i < n; ++i) {
+            const float* p = localPointCloud.col(i);
+            bool in = true;
+            for (int a = 0; a < 3; ++a) in &= p[a] >= start[a] && p[a] < end[a];
+            leaves[i] = in; stays[i] = !in;
+        }
+        oldChunk = localPointCloud;
+        oldChunk.keepOnly(leaves);
+        localPointCloud.keepOnly(stays);
+        {
+            std::lock_guard<std::mutex> gi(icpMapLock);
+            icp.setMap(localPointCloud); // an empty cloud is rejected and leaves the previous map in place
+        }
+        // forget the ids inside the box (iterate what is loaded: the first update's box is all of space)
+        for (auto it = loadedCellIds.begin(); it != loadedCellIds.end();) {
+            int c[3] = {0, 0, 0};
+            std::sscanf(it->c_str(), "%d_%d_%d", &c[0], &c[1], &c[2]);
+            bool in = true;
+            for (int a = 0; a < 3; ++a) in &= c[a] >= box.lo[a] && c[a] <= box.hi[a];
+            it = in ? loadedCellIds.erase(it) : std::next(it);
+        }
+        localPointCloudEmpty.store(localPointCloud.getNbPoints() == 0);
+        newLocalPointCloudAvailable = true;
+    }
+    // bin what left into 20 m cells; saveCell overwrites (RAMCellManager.cpp:13-16)
+    std::unordered_map<std::string, std::vector<uint8_t>> members;
+    const size_t nOld = oldChunk.getNbPoints();
+    for (size_t i = 0; i < nOld; ++i) {
+        const float* p = oldChunk.col(i);
+        auto& mask = members[cellId(toGridCoordinate(p[0]), toGridCoordinate(p[1]), toGridCoordinate(p[2]))];
+        if (mask.empty()) mask.assign(nOld, 0);
+        mask[i] = 1;
+    }
+    for (auto& kv : members) {
+        DataPoints cell = oldChunk;
+        cell.keepOnly(kv.second);
+        std::lock_guard<std::mutex> g(cellManagerLock);
+        cellManager->saveCell(kv.first, cell);
+    }
+}
+
+void Map::updatePose(const Mat4& pose)
+{
+    const int axes = is3D ? 3 : 2;
+    if (firstPoseUpdate.load()) {
+        for (int a = 0; a < axes; ++a) {
+            inferiorLast[a] = toInferiorGridCoordinate(pose(a, 3), sensorMaxRange);
+            superiorLast[a] = toSuperiorGridCoordinate(pose(a, 3), sensorMaxRange);
+        }
+        {
+            std::lock_guard<std::mutex> g(cellManagerLock);
+            cellManager->clearAllCells();
+        }
+        {
+            std::lock_guard<std::mutex> g(localPointCloudLock);
+            loadedCellIds.clear();
+        }
+        // page the whole local cloud out (used by setGlobalPointCloud to re-page a loaded map) ...
+        Box all;
+        for (int a = 0; a < 3; ++a) { all.lo[a] = INT_MIN; all.hi[a] = INT_MAX - 1; }
+        unloadCells(all);
+        // ... and the window (+ buffer) back in
+        Box win;
+        for (int a = 0; a < 3; ++a) { win.lo[a] = inferiorLast[a] - BUFFER_SIZE; win.hi[a] = superiorLast[a] + BUFFER_SIZE; }
+        loadCells(win);
+        firstPoseUpdate.store(false);
+        return;
+    }
+    // sliding window with a hysteresis of two cells per edge; a slab spans the current window (+ buffer)
+    // on the other axes
+    auto slab = [&](int axis, int lo, int hi, bool load) {
+        Update u;
+        for (int a = 0; a < 3; ++a) { u.box.lo[a] = inferiorLast[a] - BUFFER_SIZE; u.box.hi[a] = superiorLast[a] + BUFFER_SIZE; }
+        u.box.lo[axis] = lo; u.box.hi[axis] = hi; u.load = load;
+        scheduleUpdate(u);
+    };
+    for (int a = 0; a < axes; ++a) {
+        const int inf = toInferiorGridCoordinate(pose(a, 3), sensorMaxRange);
+        if (std::abs(inf - inferiorLast[a]) >= 2) {
+            if (inf < inferiorLast[a]) {             // window grows at its low edge: bring cells in
+                const int nb = inferiorLast[a] - inf;
+                slab(a, inf - BUFFER_SIZE, inf - BUFFER_SIZE + nb - 1, true);
+            } else {                                  // low edge retreats: page cells out
+                const int nb = inf - inferiorLast[a];
+                slab(a, inferiorLast[a] - BUFFER_SIZE, inferiorLast[a] - BUFFER_SIZE + nb - 1, false);
+            }
+            inferiorLast[a] = inf;
+        }
+        const int sup = toSuperiorGridCoordinate(pose(a, 3), sensorMaxRange);
+        if (std::abs(sup - superiorLast[a]) >= 2) {
+            if (sup < superiorLast[a]) {             // high edge retreats
+                const int nb = superiorLast[a] - sup;
+                slab(a, superiorLast[a] + BUFFER_SIZE - nb + 1, superiorLast[a] + BUFFER_SIZE, false);
+            } else {                                  // window grows at its high edge
+                const int nb = sup - superiorLast[a];
+                slab(a, sup + BUFFER_SIZE - nb + 1, sup + BUFFER_SIZE, true);
+            }
+            superiorLast[a] = sup;
+        }
+    }
+}
+
+DataPoints Map::getLocalPointCloud()
+{
+    std::lock_guard<std::mutex> g(localPointCloudLock);
+    return localPointCloud;
+}
+
+void Map::updateLocalPointCloud(DataPoints input, Mat4 pose, DataPointsFilters postFilters)
+{
+    std::lock_guard<std::mutex> g(localPointCloudLock);
+    if (mapperModuleVec.empty()) throw InvalidParameter("no mapper module configured");
+    if (isLocalPointCloudEmpty()) {
+        // the first module creates the map, the others update it with the same scan
+        auto it = mapperModuleVec.begin();
+        localPointCloud = (*it)->createMap(input, pose);
+        for (++it; it != mapperModuleVec.end(); ++it) (*it)->inPlaceUpdateMap(input, localPointCloud, pose);
+    } else {
+        for (const auto& module : mapperModuleVec) module->inPlaceUpdateMap(input, localPointCloud, pose);
+    }
+    // post filters run in the sensor frame
+    DataPoints inSensorFrame = transformation.compute(localPointCloud, pose.inverse());
+    postFilters.apply(inSensorFrame);
+    localPointCloud = transformation.compute(inSensorFrame, pose);
+    {
+        std::lock_guard<std::mutex> gi(icpMapLock);
+        icp.setMap(localPointCloud);
+    }
+    localPointCloudEmpty.store(localPointCloud.getNbPoints() == 0);
+    newLocalPointCloudAvailable = true;
+}
+
+bool Map::getNewLocalPointCloud(DataPoints& out)
+{
+    std::lock_guard<std::mutex> g(localPointCloudLock);
+    if (!newLocalPointCloudAvailable) return false;
+    out = localPointCloud;
+    newLocalPointCloudAvailable = false;
+    return true;
+}
+
+DataPoints Map::getGlobalPointCloud()
+{
+    DataPoints global;
+    std::unordered_set<std::string> loaded;
+    {
+        std::lock_guard<std::mutex> g(localPointCloudLock);
+        global = localPointCloud;
+        loaded = loadedCellIds;
+    }
+    std::vector<std::string> saved;
+    {
+        std::lock_guard<std::mutex> g(cellManagerLock);
+        saved = cellManager->getAllCellIds();
+    }
+    for (const auto& id : saved) {
+        if (loaded.count(id)) continue;
+        DataPoints cell;
+        {
+            std::lock_guard<std::mutex> g(cellManagerLock);
+            cell = cellManager->retrieveCell(id);
+        }
+        global.concatenate(cell);
+    }
+    return global;
+}
+
+void Map::setGlobalPointCloud(const DataPoints& cloud)
+{
+    std::lock_guard<std::mutex> g(localPointCloudLock);
+    localPointCloud = cloud;
+    {
+        std::lock_guard<std::mutex> gi(icpMapLock);
+        icp.setMap(localPointCloud);
+    }
+    localPointCloudEmpty.store(localPointCloud.getNbPoints() == 0);
+    firstPoseUpdate.store(true); // the next updatePose re-pages the cloud into cells
+}
+
+} // namespace nim

@@ -1,0 +1,86 @@
+// Mapper.h -- the orchestrator (reference: norlab_icp_mapper/Mapper.{h,cpp}): YAML configuration,
+// input filters, the ICP call, map-update policy, pose / trajectory bookkeeping, optional asynchronous
+// map update.  Same constructor arguments and public methods as the reference class.
+#pragma once
+#include <atomic>
+#include <chrono>
+#include <future>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "IcpSequence.h"
+#include "Map.h"
+#include "MapperModule.h"
+
+namespace nim {
+
+using TimePoint = std::chrono::time_point<std::chrono::steady_clock>;
+
+// Trajectory.{h,cpp}: poses + steady_clock stamps; save() writes the positions as features and the
+// rotation columns as descriptors orientationX/Y/Z (+ times as a scalar descriptor "t")
+class Trajectory {
+public:
+    explicit Trajectory(int dimension = 3) : dimension(dimension) {}
+    void addPose(const Mat4& pose, TimePoint stamp) { poses.push_back(pose); stamps.push_back(stamp); }
+    void clear() { poses.clear(); stamps.clear(); }
+    size_t size() const { return poses.size(); }
+    const Mat4& pose(size_t i) const { return poses[i]; }
+    TimePoint stamp(size_t i) const { return stamps[i]; }
+    void save(const std::string& filename) const;
+private:
+    int dimension;
+    std::vector<Mat4> poses;
+    std::vector<TimePoint> stamps;
+};
+
+class Mapper {
+public:
+    Mapper(const std::string& configFilePath, bool is3D, bool isOnline, bool isMapping, bool saveMapCellsOnHardDrive, int device = 0);
+    ~Mapper();
+
+    void applyInputFilters(DataPoints& inputInSensorFrame);                                   // Mapper.cpp:187-191
+    void processInput(const DataPoints& inputInSensorFrame, const Mat4& estimatedPose, const TimePoint& timeStamp); // :194-238
+    DataPoints getMap() { return map.getGlobalPointCloud(); }
+    void setMap(const DataPoints& newMap);
+    bool getNewLocalMap(DataPoints& mapOut) { return map.getNewLocalPointCloud(mapOut); }
+    Mat4 getPose();
+    bool getIsMapping() const { return isMapping.load(); }
+    void setIsMapping(bool v) { isMapping.store(v); }
+    Trajectory getTrajectory();
+    void setDefaultMapperModule();
+    void loadYamlConfig(const std::string& configFilePath);
+    void loadYamlConfigFromString(const std::string& text);
+    const icpmi_stats& lastIcpStats() const { return icp.stats(); }
+
+private:
+    static constexpr const char* DEFAULT_MAP_UPDATE_CONDITION = "distance"; // Mapper.h:19
+    static constexpr float DEFAULT_MAP_UPDATE_DISTANCE = 1.0f;              // Mapper.h:20
+
+    void fillRegistrar();
+    void validateYamlKeys(const yaml::Node& node, const std::vector<std::string>& validKeys) const;
+    void rebuildRadiusFilter();
+    void setDefaultMapUpdateConfig() { mapUpdateCondition = DEFAULT_MAP_UPDATE_CONDITION; mapUpdateDistance = DEFAULT_MAP_UPDATE_DISTANCE; }
+    void setDefaultMapperConfig() { setDefaultMapUpdateConfig(); setDefaultMapperModule(); }
+    bool shouldUpdateMap(const TimePoint& currentTime, const Mat4& currentPose, float currentOverlap) const; // :240-272
+    void updateMap(const DataPoints& currentInput, const Mat4& currentPose, const TimePoint& currentTimeStamp); // :274-288
+
+    GpuICPSequence icp;                 // first: the filters and modules share its GPU context
+    std::mutex poseLock, trajectoryLock, icpMapLock;
+    DataPointsFilters inputFilters, mapPostFilters;
+    std::string mapUpdateCondition;
+    float mapUpdateOverlap = 0.f, mapUpdateDelay = 0.f, mapUpdateDistance = 0.f;
+    bool is3D, isOnline;
+    std::atomic_bool isMapping;
+    Map map;
+    Mat4 pose = Mat4::identity();
+    Trajectory trajectory;
+    RigidTransformation transformation;
+    std::shared_ptr<DataPointsFilter> radiusFilter;
+    TimePoint lastTimeMapWasUpdated;
+    Mat4 lastPoseWhereMapWasUpdated = Mat4::identity();
+    mutable std::future<void> mapUpdateFuture;
+    MapperModuleRegistrar registrar;
+};
+
+} // namespace nim

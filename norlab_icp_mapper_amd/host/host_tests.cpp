@@ -1,0 +1,219 @@
+// host_tests.cpp -- self-checks of the C++ host shell that need no GPU: YAML subset reader, cloud
+// value semantics, VTK round trip, CPU-side filters, grid arithmetic of the cell window, RAM cell
+// store, 4x4 algebra.  Run by tests/test_host_cpp.py; exits non-zero on the first failure.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
+#include "IcpSequence.h"
+#include "Map.h"
+#include "PointCloud.h"
+#include "Yaml.h"
+
+using namespace nim;
+
+static int failures = 0;
+#define CHECK(cond)                                                                  \
+    do {                                                                             \
+        if (!(cond)) { std::fprintf(stderr, "FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); ++failures; } \
+    } while (0)
+
+static const char* kBundledLikeConfig = R"(
+input:
+  - BoundingBoxDataPointsFilter:
+      xMin: -1.5
+      xMax: 0.5
+      yMin: -1
+      yMax: 1
+      zMin: -1
+      zMax: 0.5
+      removeInside: 1
+
+  - AddDescriptorDataPointsFilter:
+      descriptorName: probabilityDynamic
+      descriptorDimension: 1
+      descriptorValues: [0.6] # initial probability
+
+post:
+    - SurfaceNormalDataPointsFilter:
+        knn: 10
+    - CutAtDescriptorThresholdDataPointsFilter:
+        descName: probabilityDynamic
+        useLargerThan: 1
+        threshold: 0.65
+
+mapper:
+  updateCondition:
+    type: delay
+    value: 0.05
+  mapperModule:
+    - DynamicPointsMapperModule:
+        thresholdDynamic: 0.9
+        alpha: 0.8
+    - OctreeMapperModule:
+        buildParallel: 1
+        maxSizeByNode: 0.15
+        samplingMethod: 1
+  sensorMaxRange: 200
+
+icp:
+  matcher:
+    KDTreeMatcher:
+      knn: 6
+      maxDist: 2.0
+      epsilon: 1
+  errorMinimizer:
+    IdentityErrorMinimizer:
+  transformationCheckers:
+    - CounterTransformationChecker:
+        maxIterationCount: 10
+  inspector: NullInspector
+)";
+
+static void testYaml()
+{
+    const yaml::Node n = yaml::Load(kBundledLikeConfig);
+    CHECK(n.IsMap() && n.map.size() == 4);
+    CHECK(n["input"].IsSequence() && n["input"].seq.size() == 2);
+    const yaml::Node& bb = n["input"].seq[0];
+    CHECK(bb.IsMap() && bb.map.size() == 1 && bb.map[0].first == "BoundingBoxDataPointsFilter");
+    CHECK(bb.map[0].second["xMin"].as<float>() == -1.5f && bb.map[0].second["removeInside"].as<int>() == 1);
+    const yaml::Node& ad = n["input"].seq[1].map[0].second;
+    CHECK(ad["descriptorName"].as<std::string>() == "probabilityDynamic");
+    CHECK(ad["descriptorValues"].IsSequence() && ad["descriptorValues"].seq.size() == 1 && ad["descriptorValues"].seq[0].as<float>() == 0.6f);
+    CHECK(n["post"].seq.size() == 2 && n["post"].seq[1].map[0].second["threshold"].as<float>() == 0.65f);
+    CHECK(n["mapper"]["updateCondition"]["type"].as<std::string>() == "delay");
+    CHECK(n["mapper"]["mapperModule"].seq.size() == 2);
+    CHECK(n["mapper"]["mapperModule"].seq[1].map[0].first == "OctreeMapperModule");
+    CHECK(n["mapper"]["sensorMaxRange"].as<int>() == 200);
+    CHECK(n["icp"]["matcher"]["KDTreeMatcher"]["maxDist"].as<float>() == 2.0f);
+    CHECK(n["icp"]["errorMinimizer"].IsMap() && n["icp"]["errorMinimizer"].map[0].first == "IdentityErrorMinimizer");
+    CHECK(n["icp"]["errorMinimizer"].map[0].second.IsNull());
+    CHECK(n["icp"]["inspector"].as<std::string>() == "NullInspector");
+    CHECK(!n["nothing"] && !n["icp"]["nothing"]["deeper"]);
+    const yaml::Node inl = yaml::Load("a: {x: 1, y: [1, 2, 3], z: inf}\nb: 'quoted # not a comment'\nc:\n- 1\n- 2\n");
+    CHECK(inl["a"]["y"].seq.size() == 3 && inl["a"]["y"].seq[2].as<int>() == 3 && std::isinf(inl["a"]["z"].as<float>()));
+    CHECK(inl["b"].as<std::string>() == "quoted # not a comment");
+    CHECK(inl["c"].IsSequence() && inl["c"].seq.size() == 2);
+    bool threw = false;
+    try { yaml::Load("a: 1\n  b: 2\n"); } catch (const yaml::Exception&) { threw = true; }
+    CHECK(threw);
+    threw = false;
+    try { (void)yaml::Load("a: x").operator[]("a").as<float>(); } catch (const yaml::Exception&) { threw = true; }
+    CHECK(threw);
+}
+
+static DataPoints makeCloud(size_t n)
+{
+    DataPoints c(n);
+    std::vector<float> inten(n), nrm(3 * n);
+    for (size_t i = 0; i < n; ++i) {
+        c.col(i)[0] = (float)i * 0.5f - 3.f; c.col(i)[1] = (float)(i % 7) - 3.f; c.col(i)[2] = (float)(i % 3) * 0.25f;
+        inten[i] = (float)i;
+        nrm[3 * i + 2] = 1.f;
+    }
+    c.addDescriptor("intensity", 1, inten);
+    c.addDescriptor("normals", 3, nrm);
+    return c;
+}
+
+static void testCloud()
+{
+    DataPoints a = makeCloud(10), b = makeCloud(4);
+    CHECK(a.getNbPoints() == 10 && a.descriptorExists("normals") && !a.descriptorExists("nope"));
+    b.removeDescriptor("normals");
+    DataPoints c = a;
+    c.concatenate(b); // descriptors on both sides only
+    CHECK(c.getNbPoints() == 14 && c.descriptorExists("intensity") && !c.descriptorExists("normals"));
+    CHECK(c.getDescriptorByName("intensity").data[10] == 0.f && c.col(13)[3] == 1.f);
+    DataPoints e;
+    e.concatenate(a);
+    CHECK(e.getNbPoints() == 10 && e.descriptorExists("normals"));
+    std::vector<uint8_t> keep(10, 0);
+    keep[2] = keep[7] = 1;
+    a.keepOnly(keep);
+    CHECK(a.getNbPoints() == 2 && a.getDescriptorByName("intensity").data[1] == 7.f && a.col(1)[0] == 0.5f);
+    DataPoints s = e.createSimilarEmpty();
+    s.appendColFrom(e, 3);
+    CHECK(s.getNbPoints() == 1 && s.getDescriptorByName("intensity").data[0] == 3.f && s.getDescriptorByName("normals").data[2] == 1.f);
+    bool threw = false;
+    try { e.getDescriptorByName("missing"); } catch (const InvalidField&) { threw = true; }
+    CHECK(threw);
+    // VTK round trip
+    const std::string path = "/tmp/nim_host_test_cloud.vtk";
+    e.save(path);
+    const DataPoints r = DataPoints::load(path);
+    CHECK(r.getNbPoints() == 10 && r.descriptorExists("intensity") && r.descriptorExists("normals"));
+    CHECK(r.features == e.features && r.getDescriptorByName("intensity").data == e.getDescriptorByName("intensity").data);
+    CHECK(r.getDescriptorByName("normals").span == 3 && r.getDescriptorByName("normals").data == e.getDescriptorByName("normals").data);
+    std::remove(path.c_str());
+}
+
+static void testFilters()
+{
+    DataPoints c = makeCloud(20);
+    auto bb = createDataPointsFilter("BoundingBoxDataPointsFilter", yaml::Load("{xMin: -1, xMax: 1, yMin: -10, yMax: 10, zMin: -1, zMax: 1, removeInside: 1}"), nullptr);
+    bb->inPlaceFilter(c);
+    for (size_t i = 0; i < c.getNbPoints(); ++i) CHECK(!(c.col(i)[0] > -1 && c.col(i)[0] < 1));
+    CHECK(c.getNbPoints() == 17); // x = -0.5, 0, 0.5 are strictly inside; x = -1 and 1 are kept
+    auto dl = createDataPointsFilter("DistanceLimitDataPointsFilter", yaml::Load("{dim: -1, dist: 4, removeInside: 0}"), nullptr);
+    dl->inPlaceFilter(c);
+    for (size_t i = 0; i < c.getNbPoints(); ++i) CHECK(std::sqrt(c.col(i)[0] * c.col(i)[0] + c.col(i)[1] * c.col(i)[1] + c.col(i)[2] * c.col(i)[2]) < 4.f);
+    auto ad = createDataPointsFilter("AddDescriptorDataPointsFilter", yaml::Load("{descriptorName: probabilityDynamic, descriptorDimension: 1, descriptorValues: [0.6]}"), nullptr);
+    ad->inPlaceFilter(c);
+    CHECK(c.getDescriptorByName("probabilityDynamic").data[0] == 0.6f);
+    c.getDescriptorByName("probabilityDynamic").data[1] = 0.7f;
+    const size_t before = c.getNbPoints();
+    auto cut = createDataPointsFilter("CutAtDescriptorThresholdDataPointsFilter", yaml::Load("{descName: probabilityDynamic, useLargerThan: 1, threshold: 0.65}"), nullptr);
+    cut->inPlaceFilter(c);
+    CHECK(c.getNbPoints() == before - 1);
+    DataPoints v = makeCloud(400);
+    auto vox = createDataPointsFilter("OctreeGridDataPointsFilter", yaml::Load("{maxSizeByNode: 4.0, samplingMethod: 0}"), nullptr);
+    vox->inPlaceFilter(v);
+    CHECK(v.getNbPoints() > 0 && v.getNbPoints() < 400);
+    bool threw = false;
+    try { createDataPointsFilter("BoundingBoxDataPointsFilter", yaml::Load("{xMinn: 1}"), nullptr); } catch (const InvalidParameter&) { threw = true; }
+    CHECK(threw);
+    threw = false;
+    try { createDataPointsFilter("NoSuchFilter", yaml::Node(), nullptr); } catch (const InvalidParameter&) { threw = true; }
+    CHECK(threw);
+}
+
+static void testGridAndCells()
+{
+    // Map.cpp:232-235,472-480
+    CHECK(Map::toGridCoordinate(19.99f) == 0 && Map::toGridCoordinate(20.f) == 1 && Map::toGridCoordinate(-0.01f) == -1 && Map::toGridCoordinate(-20.f) == -1);
+    CHECK(Map::toInferiorGridCoordinate(0.86f, 200.f) == -10 && Map::toSuperiorGridCoordinate(0.86f, 200.f) == 10);
+    CHECK(Map::toInferiorGridCoordinate(0.f, 100.f) == -6 && Map::toSuperiorGridCoordinate(0.f, 100.f) == 5);
+    CHECK(Map::cellId(-1, 0, 12) == "-1_0_12");
+    RAMCellManager cm;
+    CHECK(cm.retrieveCell("1_2_3").getNbPoints() == 0 && cm.getAllCellIds().empty());
+    cm.saveCell("1_2_3", makeCloud(5));
+    cm.saveCell("1_2_3", makeCloud(3)); // overwrite
+    CHECK(cm.retrieveCell("1_2_3").getNbPoints() == 3 && cm.getAllCellIds().size() == 1);
+    cm.clearAllCells();
+    CHECK(cm.getAllCellIds().empty());
+}
+
+static void testMat4()
+{
+    Mat4 T = Mat4::identity();
+    const float c = std::cos(0.3f), s = std::sin(0.3f);
+    T(0, 0) = c; T(0, 1) = -s; T(1, 0) = s; T(1, 1) = c; T(0, 3) = 1.f; T(1, 3) = -2.f; T(2, 3) = 0.5f;
+    const Mat4 I = T * T.inverse();
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) CHECK(std::fabs(I(i, j) - (i == j ? 1.f : 0.f)) < 1e-6f);
+    CHECK(T.data()[12] == 1.f && T.data()[1] == s); // column-major storage
+}
+
+int main()
+{
+    testYaml();
+    testCloud();
+    testFilters();
+    testGridAndCells();
+    testMat4();
+    if (failures) { std::fprintf(stderr, "%d check(s) failed\n", failures); return 1; }
+    std::printf("host_tests: all checks passed\n");
+    return 0;
+}
