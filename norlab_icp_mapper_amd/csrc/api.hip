@@ -129,6 +129,7 @@ void icpmi_destroy(icpmi_handle c)
     hipFree(c->d_keys); hipFree(c->d_fill); hipFree(c->d_blocksums); hipFree(c->d_red);
     hipFree(c->d_qsorted); hipFree(c->d_qindex); hipFree(c->d_qkeys); hipFree(c->d_qtile); hipFree(c->d_qitems);
     hipFree(c->d_reading); hipFree(c->d_read_normals); hipFree(c->d_stage_in); hipFree(c->d_stage_n3);
+    hipFree(c->d_match_pt);
     hipFree(c->d_sidx); hipFree(c->d_d2); hipFree(c->d_hard); hipFree(c->d_partials); hipFree(c->d_selhist);
     hipFree(c->d_state);
     if (c->h_state) hipHostFree(c->h_state);
@@ -322,6 +323,7 @@ icpmi_status icpmi_knn(icpmi_handle h, const float* q4, int64_t n, int32_t k, fl
         lc.ring_max = need < 16 ? need : 16;
     } else lc.ring_max = 6;
     h->nn_hist0 = nullptr; // stage call: no quantile selection follows
+    h->nn_match_pt = nullptr;
     h->nn_iter_hint = 0;
     icpmi_status s = nn_launch_k(h, h->d_reading, n, nullptr, lc, allow_self, h->d_sidx, h->d_d2, h->d_state);
     if (s != ICPMI_OK) return s;

@@ -149,6 +149,9 @@ struct icpmi_ctx {
     unsigned* nn_hist0 = nullptr;     // set by the loop when the NN kernel should build the level-0 histogram
     bool nn_builds_hist0 = false;     // set by the NN launcher: true if the launched variant did build it
     int nn_iter_hint = 0;             // iteration index of the launch being enqueued (> 0: seeded by the previous match)
+    float4* d_match_pt = nullptr; size_t cap_match_pt = 0;     // k = 1 loop: matched map point (xyz, original index bits) per query slot
+    float4* nn_match_pt = nullptr;    // set by the loop: keep the loop state (sidx, d2, matched point) in query order
+    bool nn_out_sorted = false;       // set by the NN launcher: true if the launched kernel did so
     IcpState* d_state = nullptr;
     IcpState* h_state = nullptr;                               // pinned mirror
 

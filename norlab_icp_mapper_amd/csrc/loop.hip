@@ -174,11 +174,22 @@ __device__ __forceinline__ void block_find_rank(const unsigned* __restrict__ his
 __global__ __launch_bounds__(256) void fsel_hist0_kernel(const float* __restrict__ d2, int64_t count, const IcpState* __restrict__ st,
                                                          unsigned* __restrict__ hists)
 {
+    // all of a lane's elements are requested up front (one round trip), the flag check and the LDS
+    // clear overlap it
+    constexpr int PF = 8;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float pv[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) pv[u] = i0 + u * stride < count ? d2[i0 + u * stride] : INFINITY;
     if (st->done) return;
     __shared__ unsigned h[ICPMI_FSEL_B0];
     for (int b = threadIdx.x; b < ICPMI_FSEL_B0; b += 256) h[b] = 0;
     __syncthreads();
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+        if (pv[u] != INFINITY && pv[u] > 0.f) atomicAdd(&h[__float_as_uint(pv[u]) >> 21], 1u);
+    for (int64_t i = i0 + PF * stride; i < count; i += stride) {
         const float v = d2[i];
         if (v != INFINITY && v > 0.f) atomicAdd(&h[__float_as_uint(v) >> 21], 1u);
     }
@@ -191,6 +202,13 @@ template <int PASS> // 1: scan level 0, build level 1;  2: scan level 1, build l
 __global__ __launch_bounds__(256) void sel_scan_hist_kernel(const float* __restrict__ d2, int64_t count, IcpState* __restrict__ st,
                                                             unsigned* __restrict__ hists, float quantile)
 {
+    // the lane's first elements are requested before the histogram scan (their round trip overlaps it)
+    constexpr int PF = 2;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float pv[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) pv[u] = i0 + u * stride < count ? d2[i0 + u * stride] : INFINITY;
     if (st->done) return;
     __shared__ unsigned sh[16];
     unsigned bin, rem, total;
@@ -213,13 +231,15 @@ __global__ __launch_bounds__(256) void sel_scan_hist_kernel(const float* __restr
     }
     // Only the elements inside the selected coarser bin contribute and they spread over up to 4096
     // bins: device-scope atomics straight to the level's histogram see little contention.
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
-        const float v = d2[i];
-        if (!(v != INFINITY && v > 0.f)) continue;
+    auto add = [&](float v) {
+        if (!(v != INFINITY && v > 0.f)) return;
         const unsigned bits = __float_as_uint(v);
         if (PASS == 1) { if ((bits >> 21) == prefix) atomicAdd(&hcur[(bits >> 10) & 2047u], 1u); }
         else { if ((bits >> 10) == prefix) atomicAdd(&hcur[bits & 1023u], 1u); }
-    }
+    };
+#pragma unroll
+    for (int u = 0; u < PF; ++u) add(pv[u]);
+    for (int64_t i = i0 + PF * stride; i < count; i += stride) add(d2[i]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -268,8 +288,27 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restric
                                                          const float4* __restrict__ read_normals,
                                                          const int* __restrict__ sidx, const float* __restrict__ d2a,
                                                          double* __restrict__ partials, unsigned* __restrict__ hists,
-                                                         int fused_slot, int is_median, float factor)
+                                                         int fused_slot, int is_median, float factor,
+                                                         const float4* __restrict__ match_pt, const int* __restrict__ qindex)
 {
+    // `reading`, sidx, d2a (and match_pt, the matched map points kept by the NN kernel) share one
+    // order: the caller's, or -- qindex != nullptr -- the tile-sorted query order of the k = 1 loop,
+    // where qindex maps a slot back to the caller's index (needed for reading descriptors only).
+    // The first two elements of every lane are requested before anything else so that their round
+    // trip overlaps the histogram scan below.
+    const int64_t count = (int64_t)n * lc.k;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int64_t e_first = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float pd2[2]; int ps[2]; float4 pr[2], pq[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int64_t e = e_first + u * stride;
+        const bool in = e < count;
+        pd2[u] = in ? d2a[e] : INFINITY;
+        ps[u] = in ? sidx[e] : -1;
+        pr[u] = reading[in ? (int)(e / lc.k) : 0];
+        pq[u] = (match_pt && in) ? match_pt[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if (st->done) return;
     float fused_limit = 0.f;
     if (FUSED) {
@@ -291,19 +330,15 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restric
     for (int i = 0; i < (NVAL > 0 ? NVAL : 1); ++i) acc[i] = 0.0;
     double wsum = 0.0, cnt = 0.0;
     const float* T = st->T_iter;
-    const int64_t count = (int64_t)n * lc.k;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < count; e += (int64_t)gridDim.x * 256) {
-        const float d2 = d2a[e];
-        if (d2 == INFINITY) continue;
-        const int s = sidx[e];
+    auto pair = [&](int64_t e, float d2, int s, float4 r, float4 qkept) {
+        if (d2 == INFINITY) return;
         const int qi = (int)(e / lc.k);
-        const float w = match_weight(lc, st, d2, T, read_normals, qi, normals, s, FUSED ? fused_slot : -1, fused_limit);
-        if (w == 0.f) continue;
+        const float w = match_weight(lc, st, d2, T, read_normals, qindex ? qindex[qi] : qi, normals, s, FUSED ? fused_slot : -1, fused_limit);
+        if (w == 0.f) return;
         wsum += w; cnt += 1.0;
-        if (MIN == ICPMI_MIN_IDENTITY) continue;
-        const float4 r = reading[qi];
+        if (MIN == ICPMI_MIN_IDENTITY) return;
         const float3 p = xf_point(T, r.x, r.y, r.z, r.w);
-        const float4 q = map[s];
+        const float4 q = match_pt ? qkept : map[s];
         if (MIN == ICPMI_MIN_POINT_TO_POINT) {
             const double dw = w;
             acc[0] += dw;
@@ -330,7 +365,11 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restric
                 acc[21 + a] -= wf * dot;
             }
         }
-    }
+    };
+#pragma unroll
+    for (int u = 0; u < 2; ++u) pair(e_first + u * stride, pd2[u], ps[u], pr[u], pq[u]);
+    for (int64_t e = e_first + 2 * stride; e < count; e += stride)
+        pair(e, d2a[e], sidx[e], reading[(int)(e / lc.k)], match_pt ? match_pt[e] : make_float4(0.f, 0.f, 0.f, 0.f));
     // ---- workgroup reduction: wave64 shuffles, then LDS across the 4 waves ----
     // Transposed butterfly: at the step with partner lane ^ m every lane hands over the half of its
     // values the partner keeps, so 32 values x 64 lanes fold with 16+8+4+2+1+1 = 32 exchanges instead
@@ -878,6 +917,7 @@ static icpmi_status ensure_loop_buffers(icpmi_ctx* c, int64_t n, int k)
     if (ensure_cap(c, &c->d_hard, &c->cap_hard, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
     const size_t nb = (cnt + 255) / 256;
     if (ensure_cap(c, &c->d_partials, &c->cap_partials, nb * ICPMI_NV) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (k == 1 && ensure_cap(c, &c->d_match_pt, &c->cap_match_pt, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
     return ICPMI_OK;
 }
 
@@ -934,8 +974,10 @@ static void launch_accumulate(icpmi_ctx* c, int64_t n, const LoopCfg& lc, int nb
     const float4* rn = lc.has_read_normals ? c->d_read_normals : nullptr;
     const int is_med = slot >= 0 && lc.out_type[slot] == ICPMI_OUT_MEDIANDIST;
     const float factor = slot >= 0 ? lc.out_param[slot] : 0.f;
-    hipLaunchKernelGGL((accumulate_kernel<MIN, FUSED>), dim3(nb), dim3(256), 0, c->stream, c->d_reading, (int)n, lc, c->d_state,
-                       c->d_map_sorted, c->d_normals_sorted, rn, c->d_sidx, c->d_d2, c->d_partials, c->d_selhist, slot, is_med, factor);
+    const bool sorted = lc.k == 1 && c->nn_out_sorted; // loop state in query order (see nn1_ml_kernel)
+    hipLaunchKernelGGL((accumulate_kernel<MIN, FUSED>), dim3(nb), dim3(256), 0, c->stream, sorted ? c->d_qsorted : c->d_reading, (int)n, lc, c->d_state,
+                       c->d_map_sorted, c->d_normals_sorted, rn, c->d_sidx, c->d_d2, c->d_partials, c->d_selhist, slot, is_med, factor,
+                       sorted ? c->d_match_pt : (const float4*)nullptr, sorted ? c->d_qindex : (const int*)nullptr);
 }
 
 static void enqueue_accumulate_solve(icpmi_ctx* c, int64_t n, const LoopCfg& lc, float* d_Tstep, double* d_sums)
@@ -963,6 +1005,10 @@ static icpmi_status enqueue_iteration(icpmi_ctx* c, int64_t n, const LoopCfg& lc
     if (nn0) HIP_TRY(c, hipEventRecord(nn0, c->stream));
     c->nn_hist0 = fused_filter_slot(lc) >= 0 ? c->d_selhist + ICPMI_FSEL_OFF0 : nullptr;
     c->nn_builds_hist0 = false;
+    static int keep_pts = -1;
+    if (keep_pts < 0) { const char* e = getenv("ICPMI_SORTED_STATE"); keep_pts = e ? atoi(e) : 1; }
+    c->nn_match_pt = (lc.k == 1 && keep_pts) ? c->d_match_pt : nullptr;
+    c->nn_out_sorted = false;
     icpmi_status s = nn_launch_k(c, c->d_reading, n, c->d_state->T_iter, lc, 1, c->d_sidx, c->d_d2, c->d_state);
     if (s != ICPMI_OK) return s;
     if (nn1) HIP_TRY(c, hipEventRecord(nn1, c->stream));
@@ -1017,7 +1063,8 @@ icpmi_status loop_run(icpmi_ctx* c, int64_t n, const LoopCfg& lc_in, bool fixed,
     if (graph) {
         uint64_t sig = 1469598103934665603ull;
         sig = fnv(&lc, sizeof lc, sig);
-        const void* ptrs[] = {c->d_reading, c->d_read_normals, c->d_sidx, c->d_d2, c->d_hard, c->d_partials, c->d_state,
+        const void* ptrs[] = {c->d_reading, c->d_read_normals, c->d_sidx, c->d_d2, c->d_hard, c->d_partials, c->d_state, c->d_match_pt,
+                              c->d_qsorted, c->d_qindex,
                               c->d_map_sorted, c->d_normals_sorted, c->d_cell_start, c->d_selhist};
         sig = fnv(ptrs, sizeof ptrs, sig);
         sig = fnv(&c->grid, sizeof c->grid, sig);
@@ -1116,6 +1163,8 @@ icpmi_status loop_single_step(icpmi_ctx* c, int64_t n, const LoopCfg& lc, const 
     c->nn_iter_hint = 0;
     c->nn_hist0 = fused_filter_slot(l1) >= 0 ? c->d_selhist + ICPMI_FSEL_OFF0 : nullptr;
     c->nn_builds_hist0 = false;
+    c->nn_match_pt = nullptr;
+    c->nn_out_sorted = false;
     icpmi_status s = nn_launch_k(c, c->d_reading, n, c->d_state->T_iter, l1, 1, c->d_sidx, c->d_d2, c->d_state);
     if (s == ICPMI_OK) {
         enqueue_selection(c, l1, n * l1.k);

@@ -400,16 +400,26 @@ __global__ __launch_bounds__(256) void ids_kernel(const float4* __restrict__ map
 // Queries arrive sorted by super-tile (map_build.hip:sort_queries), so the lanes of a wave touch
 // neighbouring cells and most loads hit the CU's L1 / the XCD's L2.
 // ------------------------------------------------------------------------------------------------
+#ifdef ICPMI_NN_TIMING
+#define NN_TICK(i) do { __builtin_amdgcn_s_waitcnt(0); const long long t_ = clock64(); tacc[i] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define NN_TICK(i) do { } while (0)
+#endif
 template <int G, int NB>
 __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restrict__ queries, const int* __restrict__ qindex, int n,
                                                           const float* __restrict__ Tptr, GridLevels L, float maxr2,
                                                           int allow_self_i, int* __restrict__ out_sidx,
                                                           float* __restrict__ out_d2, IcpState* __restrict__ st,
-                                                          unsigned* __restrict__ hard, unsigned* __restrict__ hist0)
+                                                          unsigned* __restrict__ hard, unsigned* __restrict__ hist0,
+                                                          float4* __restrict__ match_pt)
 {
     static_assert(G == 2 || G == 4 || G == 8 || G == 16, "lanes per query");
     constexpr int NR = (9 + G - 1) / G; // rows owned per lane: row rr belongs to lane rr % G, slot rr / G
     if (st->done) return;
+#ifdef ICPMI_NN_TIMING
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = clock64();
+#endif
     // level-0 histogram of the quantile selection (top 8 bits of the d^2 pattern), per workgroup in LDS
     __shared__ unsigned lh[ICPMI_FSEL_B0];
     if (hist0) {
@@ -427,7 +437,14 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restri
     const int sub = tid % G;
     const bool active = qi < n;
     const float4 r = queries[active ? qi : 0];
-    const int orig = qindex ? qindex[active ? qi : 0] : qi;
+    // Loop mode (match_pt != nullptr): the per-query loop state -- match position, d^2, matched point --
+    // lives in QUERY ORDER (slot qi of the tile-sorted reading), so the seed of this iteration arrives in
+    // the same round trip as the query itself and the results leave as coalesced stores.  Otherwise
+    // (stage calls) results go to the caller's original index.
+    const int orig = match_pt ? qi : (qindex ? qindex[active ? qi : 0] : qi);
+    int sp_kept = -1;
+    float4 qs_kept = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (match_pt) { sp_kept = out_sidx[active ? qi : 0]; qs_kept = match_pt[active ? qi : 0]; }
     float3 p;
     if (Tptr) p = xf_point(Tptr, r.x, r.y, r.z, r.w);
     else p = make_float3(r.x, r.y, r.z);
@@ -435,7 +452,9 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restri
     const int gbase = lane - sub;
 
     Cand best; best.key = ~0ull; best.sidx = -1; // sidx = position in its level | level << 28
+    float bx = 0.f, by = 0.f, bz = 0.f;          // coordinates of the current best candidate
     bool decided = !active;
+    NN_TICK(0);
 
     // Seed (iterations > 0 of one registration): the previous iteration's match of this query is a
     // map point, so its distance under the current transform bounds the nearest-neighbour distance
@@ -445,9 +464,9 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restri
     int lev0 = 0;
     float rub2 = INFINITY; // squared pruning radius (with slack), +inf = no pruning
     if (active && allow_self && st->iter > 0) {
-        const int sp = out_sidx[orig];
+        const int sp = match_pt ? sp_kept : out_sidx[orig];
         if (sp >= 0) {
-            const float4 qs = L.pts[0][sp];
+            const float4 qs = match_pt ? qs_kept : L.pts[0][sp];
             const float ub2 = sqdist3(p.x, p.y, p.z, qs.x, qs.y, qs.z);
             const float ub = sqrtf(ub2);
             for (int lev = 0; lev < L.nlev; ++lev) {
@@ -464,12 +483,14 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restri
                     rub2 = rub * rub;
                     best.key = pack_key(ub2, __float_as_uint(qs.w));
                     best.sidx = sp; // level 0 position
+                    bx = qs.x; by = qs.y; bz = qs.z;
                     break;
                 }
             }
         }
     }
     // lanes of a group must agree on the starting level and radius (they do: same inputs)
+    NN_TICK(1);
 
     for (int lev = lev0; lev < L.nlev && !decided; ++lev) {
         const GridParams g = L.g[lev];
@@ -520,6 +541,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restri
                 rs[sl] = s; rn[sl] = cnt;
             }
         }
+        NN_TICK(2);
         // (2) broadcast, prefix: candidate k of the flat list lives at map[k + off_r], P_r <= k < P_{r+1}
         unsigned Pr[10], Or[9];
         Pr[0] = 0;
@@ -550,16 +572,27 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restri
                 const float d2 = sqdist3(p.x, p.y, p.z, q[u].x, q[u].y, q[u].z);
                 unsigned long long key = pack_key(d2, __float_as_uint(q[u].w));
                 if (!allow_self) key = d2 > 1.1920929e-07f ? key : ~0ull;
-                cand_min(best, key, (int)(gi[u] | ((unsigned)lev << 28)));
+                if (key < best.key) { best.key = key; best.sidx = (int)(gi[u] | ((unsigned)lev << 28)); bx = q[u].x; by = q[u].y; bz = q[u].z; }
             }
         }
+        NN_TICK(3);
         // (3) fold and decide
-        group_reduce<G>(best);
+#pragma unroll
+        for (int off = G / 2; off > 0; off >>= 1) {
+            const unsigned long long ok = __shfl_xor(best.key, off, 64);
+            const int os = __shfl_xor(best.sidx, off, 64);
+            const float ox = __shfl_xor(bx, off, 64), oy = __shfl_xor(by, off, 64), oz = __shfl_xor(bz, off, 64);
+            if (ok < best.key) { best.key = ok; best.sidx = os; bx = ox; by = oy; bz = oz; }
+        }
         const float margin = fmaxf((1.0f + mf) * g.cell - g.slack, 0.f);
         const float m2 = margin * margin;
         const float bd2 = __uint_as_float((unsigned)(best.key >> 32));
         const bool covers = cx - 1 <= 0 && cx + 1 >= g.nx - 1 && cy - 1 <= 0 && cy + 1 >= g.ny - 1 && cz - 1 <= 0 && cz + 1 >= g.nz - 1;
         decided = (best.key != ~0ull && bd2 <= m2) || m2 > maxr2 || covers;
+        NN_TICK(4);
+#ifdef ICPMI_NN_TIMING
+        tacc[6] += 1;
+#endif
     }
 
     if (active && sub == 0) {
@@ -571,10 +604,11 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restri
         } else bd2 = INFINITY;
         out_sidx[orig] = bs;
         out_d2[orig] = bd2;
+        if (match_pt) match_pt[orig] = make_float4(bx, by, bz, __uint_as_float((unsigned)(best.key & 0xffffffffull)));
         if (hist0 && bd2 != INFINITY && bd2 > 0.f) atomicAdd(&lh[__float_as_uint(bd2) >> 21], 1u);
         if (!decided) {
             const unsigned slot = atomicAdd(&st->hard_count, 1u);
-            hard[slot] = (unsigned)orig;
+            hard[slot] = (unsigned)(qindex ? qindex[qi] : qi); // the brute pass works on the caller's order
         }
     }
     if (hist0) {
@@ -582,6 +616,14 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restri
         for (int b = threadIdx.x; b < ICPMI_FSEL_B0; b += NN_BLOCK)
             if (lh[b]) atomicAdd(&hist0[b], lh[b]);
     }
+#ifdef ICPMI_NN_TIMING
+    NN_TICK(5);
+    if (threadIdx.x == 0 && (blockIdx.x % 61) == 0) { // a sample: same-address atomics from every wave would dominate
+        const int base = st->iter > 0 ? 8 : 0; // seeded launches in dbg[8..15], the first one in dbg[0..7]
+        for (int i = 0; i < 7; ++i) atomicAdd(&st->dbg[base + i], (unsigned long long)tacc[i]);
+        atomicAdd(&st->dbg[base + 7], 1ull);
+    }
+#endif
 }
 
 } // namespace
@@ -599,6 +641,7 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
 {
     static int variant = -1;
     if (variant < 0) { const char* e = getenv("ICPMI_NN_VARIANT"); variant = e ? atoi(e) : 0; }
+    c->nn_out_sorted = false;
     if (variant < 100 && c->m < (1 << 28)) {
         // grid pyramid; sorted queries when the caller prepared them for exactly this cloud
         const bool sorted = c->qsorted_n == n && c->qsorted_src == d_reading;
@@ -616,9 +659,13 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
         if (fuse_h0 < 0) { const char* e = getenv("ICPMI_NN_FUSE_HIST0"); fuse_h0 = e ? atoi(e) : 0; }
         unsigned* h0 = (needs_hard || !fuse_h0) ? nullptr : c->nn_hist0;
         c->nn_builds_hist0 = h0 != nullptr;
+        // loop mode keeps the per-query state in query order; the brute-force pass works in the caller's
+        // order, so chains that may need it stay on original indices
+        float4* mp = (needs_hard || !sorted) ? nullptr : c->nn_match_pt;
+        c->nn_out_sorted = mp != nullptr;
 #define LAUNCH_ML(G_, NB_)                                                                                                      \
     hipLaunchKernelGGL((nn1_ml_kernel<G_, NB_>), dim3((int)(((n * G_ + NN_BLOCK - 1) / NN_BLOCK + 7) / 8 * 8)), dim3(NN_BLOCK), 0,  \
-                       c->stream, q, qi, (int)n, d_T, c->levels, lc.maxr2, allow_self, d_sidx, d_d2, d_state, c->d_hard, h0)
+                       c->stream, q, qi, (int)n, d_T, c->levels, lc.maxr2, allow_self, d_sidx, d_d2, d_state, c->d_hard, h0, mp)
         // iterations > 0 are seeded by the previous match (a handful of candidates per query): fewer
         // lanes per query; the unseeded first pass scans whole 27-cell blocks: more lanes per query
         const bool seeded = c->nn_iter_hint > 0 && allow_self;
