@@ -117,6 +117,7 @@ struct icpmi_ctx {
     bool has_normals = false;
     // coarser pyramid levels (level 0 aliases d_map_sorted / d_cell_start)
     GridLevels levels{};
+    uint4* d_lvl_tab = nullptr;       // device copy of `levels` as 4 x uint4 per level (nn.hip reads it into LDS)
     float4* d_lvl_pts[ICPMI_MAXLEV] = {};   size_t cap_lvl_pts[ICPMI_MAXLEV] = {};
     unsigned* d_lvl_cs[ICPMI_MAXLEV] = {};  size_t cap_lvl_cs[ICPMI_MAXLEV] = {};
     unsigned* d_lvl_pos0[ICPMI_MAXLEV] = {}; size_t cap_lvl_pos0[ICPMI_MAXLEV] = {};

@@ -6,6 +6,7 @@
 // HBM traffic per build (M points): read 16 M (stats) + read 16 M / write 4 M (keys) + read 20 M /
 // write 16 M (scatter) (+ 32 M for normals) and two passes over the cell table.
 #include "common.h"
+#include <cstring>
 
 namespace {
 
@@ -174,14 +175,17 @@ __global__ __launch_bounds__(256) void lvl_scatter_kernel(const float4* __restri
     pos0[pos] = (unsigned)i;
 }
 
-// ---- query (reading) sort by super-tile: work list of the tile NN kernel -------------------------
-// super-tile = STX x STY x STZ grid cells (long in x: the cell-sorted map is x-fastest, so a staged
-// region is few long contiguous runs).  Queries outside the grid clamp to the border super-tile.
-// Every super-tile with c queries becomes ceil(c / ICPMI_TQ) work items (start, count); the NN kernel
-// runs one workgroup per item.  Order inside a super-tile is whatever the atomics give; results are
-// written back by ORIGINAL index and all downstream sums run in original order, so nothing
-// observable depends on it.
+// ---- query (reading) sort by super-tile ----------------------------------------------------------
+// super-tile = STX x STY x STZ grid cells (long in x: the cell-sorted map is x-fastest).  Queries
+// outside the grid clamp to the border super-tile.  The k = 1 loop keeps its per-query state and runs
+// its pair sums in this order, so the order must be a function of the input alone: a STABLE LSD
+// radix sort on the super-tile key (6-bit digits, 1024 elements per workgroup, two kernels per pass):
+//   qhist: per-workgroup digit histogram -> count[digit][workgroup], total[digit]
+//   qpass: stable ranks (wave ballots + a 16-entry LDS prefix per digit), workgroup base from
+//          count / total (summed by the workgroup itself: 64 x nwg words), scatter.
+// Equal keys keep ascending original index.  The last pass scatters the points themselves.
 constexpr int STX = 16, STY = 4, STZ = 4;
+constexpr int QS_BITS = 6, QS_BINS = 1 << QS_BITS, QS_EPB = 1024;
 
 __device__ __forceinline__ unsigned st_key(const float4 p, const GridParams& g, int tx, int ty)
 {
@@ -191,62 +195,110 @@ __device__ __forceinline__ unsigned st_key(const float4 p, const GridParams& g, 
     return (unsigned)(((cz / STZ) * ty + (cy / STY)) * tx + (cx / STX));
 }
 
-__global__ __launch_bounds__(256) void qkey_kernel(const float4* __restrict__ pts, int n, GridParams g, int tx, int ty,
-                                                   unsigned* __restrict__ keys, unsigned* __restrict__ count)
+// lanes of the wave (among `valid` ones) holding the same 6-bit digit as this lane
+__device__ __forceinline__ unsigned long long match_digit(unsigned d, bool valid)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const unsigned key = st_key(pts[i], g, tx, ty);
-    keys[i] = key;
-    atomicAdd(&count[key], 1u);
-}
-
-// single workgroup: exclusive scans of the per-super-tile query counts and work-item counts, and the
-// work-item table itself.  count[] is turned into start[] in place; items[0] = number of items.
-__global__ __launch_bounds__(1024) void qtable_kernel(unsigned* __restrict__ count, int nst, uint2* __restrict__ items,
-                                                      unsigned* __restrict__ n_items)
-{
-    __shared__ unsigned sh_a[1024], sh_b[1024];
-    __shared__ unsigned carry_a, carry_b;
-    const int t = threadIdx.x;
-    if (t == 0) { carry_a = 0; carry_b = 0; }
-    __syncthreads();
-    for (int base = 0; base < nst; base += 1024) {
-        const int i = base + t;
-        const unsigned cnt = i < nst ? count[i] : 0u;
-        const unsigned nb = (cnt + ICPMI_TQ - 1) / ICPMI_TQ;
-        sh_a[t] = cnt; sh_b[t] = nb;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            const unsigned aa = t >= off ? sh_a[t - off] : 0u, bb = t >= off ? sh_b[t - off] : 0u;
-            __syncthreads();
-            sh_a[t] += aa; sh_b[t] += bb;
-            __syncthreads();
-        }
-        const unsigned start = carry_a + sh_a[t] - cnt;
-        const unsigned bstart = carry_b + sh_b[t] - nb;
-        if (i < nst) count[i] = start;
-        for (unsigned b = 0; b < nb; ++b) {
-            const unsigned left = cnt - b * ICPMI_TQ;
-            items[bstart + b] = make_uint2(start + b * ICPMI_TQ, left < ICPMI_TQ ? left : (unsigned)ICPMI_TQ);
-        }
-        __syncthreads();
-        if (t == 1023) { carry_a += sh_a[1023]; carry_b += sh_b[1023]; }
-        __syncthreads();
+    unsigned long long m = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < QS_BITS; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const unsigned long long bal = __ballot(bit);
+        m &= bit ? bal : ~bal;
     }
-    if (t == 0) { count[nst] = carry_a; *n_items = carry_b; }
+    return m;
 }
 
-__global__ __launch_bounds__(256) void qscatter_kernel(const float4* __restrict__ pts, int n, const unsigned* __restrict__ keys,
-                                                       const unsigned* __restrict__ start, unsigned* __restrict__ fill,
-                                                       float4* __restrict__ out, int* __restrict__ out_index)
+template <bool FIRST>
+__global__ __launch_bounds__(256) void qhist_kernel(const float4* __restrict__ pts, int n, GridParams g, int tx, int ty,
+                                                    const unsigned* __restrict__ keys_in, unsigned* __restrict__ keys_out, int shift,
+                                                    int nwg, unsigned* __restrict__ count, unsigned* __restrict__ total)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const unsigned key = keys[i];
-    const unsigned pos = start[key] + atomicAdd(&fill[key], 1u);
-    out[pos] = pts[i];
-    out_index[pos] = i;
+    __shared__ unsigned h[QS_BINS];
+    const int t = threadIdx.x, lane = t & 63;
+    if (t < QS_BINS) h[t] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < QS_EPB / 256; ++r) {
+        const int e = blockIdx.x * QS_EPB + r * 256 + t;
+        const bool ok = e < n;
+        unsigned key = 0;
+        if (ok) {
+            key = FIRST ? st_key(pts[e], g, tx, ty) : keys_in[e];
+            if (FIRST) keys_out[e] = key;
+        }
+        const unsigned d = (key >> shift) & (QS_BINS - 1);
+        const unsigned long long m = match_digit(d, ok);
+        if (ok && (m & ((1ull << lane) - 1ull)) == 0ull) atomicAdd(&h[d], (unsigned)__popcll(m));
+    }
+    __syncthreads();
+    if (t < QS_BINS) {
+        count[t * nwg + blockIdx.x] = h[t];
+        if (h[t]) atomicAdd(&total[t], h[t]);
+    }
+}
+
+template <bool FINAL>
+__global__ __launch_bounds__(256) void qpass_kernel(const unsigned* __restrict__ keys_in, const unsigned* __restrict__ vals_in, int n,
+                                                    int shift, int nwg, const unsigned* __restrict__ count,
+                                                    const unsigned* __restrict__ total, unsigned* __restrict__ keys_out,
+                                                    unsigned* __restrict__ vals_out, const float4* __restrict__ pts,
+                                                    float4* __restrict__ out_pts, int* __restrict__ out_index)
+{
+    constexpr int R = QS_EPB / 256;
+    __shared__ unsigned wc[R][4][QS_BINS]; // [round][wave][digit]: count, then exclusive prefix in element order
+    __shared__ unsigned part[4][QS_BINS];
+    __shared__ unsigned base[QS_BINS];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    for (int i = t; i < R * 4 * QS_BINS; i += 256) (&wc[0][0][0])[i] = 0;
+    // this workgroup's base per digit: elements of smaller digits anywhere + same digit in earlier workgroups
+    {
+        const int d = t & (QS_BINS - 1), q = t >> QS_BITS; // 4 lanes-quarters share the sum over earlier workgroups
+        unsigned s = 0;
+        for (int b = q; b < (int)blockIdx.x; b += 4) s += count[d * nwg + b];
+        part[q][d] = s;
+    }
+    unsigned key[R], val[R], rank[R], dig[R];
+    bool ok[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int e = blockIdx.x * QS_EPB + r * 256 + t;
+        ok[r] = e < n;
+        key[r] = ok[r] ? keys_in[e] : 0u;
+        val[r] = ok[r] ? (vals_in ? vals_in[e] : (unsigned)e) : 0u;
+        dig[r] = (key[r] >> shift) & (QS_BINS - 1);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned long long m = match_digit(dig[r], ok[r]);
+        rank[r] = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        if (ok[r] && rank[r] == 0) wc[r][w][dig[r]] = (unsigned)__popcll(m);
+    }
+    __syncthreads();
+    if (t < QS_BINS) {
+        unsigned run = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) { const unsigned cnt = wc[r][ww][t]; wc[r][ww][t] = run; run += cnt; }
+        // exclusive scan of the digit totals over the 64 lanes of wave 0
+        const unsigned tot = total[t];
+        unsigned incl = tot;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        base[t] = incl - tot + part[0][t] + part[1][t] + part[2][t] + part[3][t];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (!ok[r]) continue;
+        const unsigned pos = base[dig[r]] + wc[r][w][dig[r]] + rank[r];
+        if (FINAL) { out_pts[pos] = pts[val[r]]; out_index[pos] = (int)val[r]; }
+        else { keys_out[pos] = key[r]; vals_out[pos] = val[r]; }
+    }
 }
 
 } // namespace
@@ -256,26 +308,41 @@ icpmi_status sort_queries(icpmi_ctx* c, const float4* d_pts, int64_t n)
     const GridParams& g = c->grid;
     const int tx = (g.nx + STX - 1) / STX, ty = (g.ny + STY - 1) / STY, tz = (g.nz + STZ - 1) / STZ;
     const int nst = tx * ty * tz;
-    const int64_t max_items = std::min<int64_t>(n, (n + ICPMI_TQ - 1) / ICPMI_TQ + nst);
+    int bits = 0;
+    while ((1ll << bits) < (long long)nst) ++bits;
+    const int passes = bits <= QS_BITS ? 1 : (bits + QS_BITS - 1) / QS_BITS;
+    const int nwg = (int)((n + QS_EPB - 1) / QS_EPB);
+    if (nwg == 0) return ICPMI_OK;
+    const size_t tab = (size_t)QS_BINS * nwg + QS_BINS; // count[digit][workgroup] + total[digit], per pass
     if (ensure_cap(c, &c->d_qsorted, &c->cap_qsorted, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
     if (ensure_cap(c, &c->d_qindex, &c->cap_qindex, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
-    if (ensure_cap(c, &c->d_qkeys, &c->cap_qkeys, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
-    if (ensure_cap(c, &c->d_qtile, &c->cap_qtile, (size_t)2 * nst + 8) != ICPMI_OK) return ICPMI_ERR_HIP;
-    if (ensure_cap(c, &c->d_qitems, &c->cap_qitems, (size_t)max_items + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
-    HIP_TRY(c, hipMemsetAsync(c->d_qtile, 0, ((size_t)2 * nst + 8) * sizeof(unsigned), c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_qitems, 0, ((size_t)max_items + 1) * sizeof(uint2), c->stream)); // count 0 = no work
-    unsigned* start = c->d_qtile;
-    unsigned* fill = c->d_qtile + nst + 2;
-    unsigned* n_items = c->d_qtile + 2 * nst + 4;
-    const int blocks = (int)((n + 255) / 256);
-    if (blocks == 0) return ICPMI_OK;
-    hipLaunchKernelGGL(qkey_kernel, dim3(blocks), dim3(256), 0, c->stream, d_pts, (int)n, g, tx, ty, c->d_qkeys, start);
-    hipLaunchKernelGGL(qtable_kernel, dim3(1), dim3(1024), 0, c->stream, start, nst, c->d_qitems, n_items);
-    hipLaunchKernelGGL(qscatter_kernel, dim3(blocks), dim3(256), 0, c->stream, d_pts, (int)n, c->d_qkeys, start, fill, c->d_qsorted,
-                       c->d_qindex);
+    if (ensure_cap(c, &c->d_qkeys, &c->cap_qkeys, (size_t)4 * n + 4) != ICPMI_OK) return ICPMI_ERR_HIP; // keys / values, ping-pong
+    if (ensure_cap(c, &c->d_qtile, &c->cap_qtile, tab * passes) != ICPMI_OK) return ICPMI_ERR_HIP;
+    HIP_TRY(c, hipMemsetAsync(c->d_qtile, 0, tab * passes * sizeof(unsigned), c->stream));
+    unsigned* kbuf[2] = {c->d_qkeys, c->d_qkeys + n};
+    unsigned* vbuf[2] = {c->d_qkeys + 2 * n, c->d_qkeys + 3 * n};
+    for (int ps = 0; ps < passes; ++ps) {
+        unsigned* count = c->d_qtile + tab * ps;
+        unsigned* total = count + (size_t)QS_BINS * nwg;
+        const int shift = ps * QS_BITS;
+        const int in = ps & 1, out = in ^ 1;
+        if (ps == 0)
+            hipLaunchKernelGGL(qhist_kernel<true>, dim3(nwg), dim3(256), 0, c->stream, d_pts, (int)n, g, tx, ty, (const unsigned*)nullptr,
+                               kbuf[0], shift, nwg, count, total);
+        else
+            hipLaunchKernelGGL(qhist_kernel<false>, dim3(nwg), dim3(256), 0, c->stream, d_pts, (int)n, g, tx, ty, (const unsigned*)kbuf[in],
+                               (unsigned*)nullptr, shift, nwg, count, total);
+        const unsigned* vin = ps == 0 ? nullptr : vbuf[in];
+        if (ps == passes - 1)
+            hipLaunchKernelGGL(qpass_kernel<true>, dim3(nwg), dim3(256), 0, c->stream, (const unsigned*)kbuf[in], vin, (int)n, shift, nwg,
+                               (const unsigned*)count, (const unsigned*)total, (unsigned*)nullptr, (unsigned*)nullptr, d_pts, c->d_qsorted,
+                               c->d_qindex);
+        else
+            hipLaunchKernelGGL(qpass_kernel<false>, dim3(nwg), dim3(256), 0, c->stream, (const unsigned*)kbuf[in], vin, (int)n, shift, nwg,
+                               (const unsigned*)count, (const unsigned*)total, kbuf[out], vbuf[out], d_pts, (float4*)nullptr, (int*)nullptr);
+    }
     HIP_TRY(c, hipGetLastError());
     c->qsorted_n = n; c->qsorted_src = d_pts;
-    c->q_max_items = (int)max_items; c->d_q_n_items = n_items;
     return ICPMI_OK;
 }
 
@@ -429,6 +496,23 @@ icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float
         HIP_TRY(c, hipGetLastError());
         L.g[l] = gl; L.pts[l] = c->d_lvl_pts[l]; L.cs[l] = c->d_lvl_cs[l]; L.pos0[l] = c->d_lvl_pos0[l];
         L.nlev = l + 1;
+    }
+    // level table for the NN kernels: per level [ox oy oz cell][inv_cell slack nx ny][nz ncells pts][cs pos0]
+    {
+        uint32_t tab[ICPMI_MAXLEV * 16] = {0};
+        auto fbits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+        for (int l = 0; l < L.nlev; ++l) {
+            uint32_t* t = tab + 16 * l;
+            const GridParams& gl = L.g[l];
+            t[0] = fbits(gl.ox); t[1] = fbits(gl.oy); t[2] = fbits(gl.oz); t[3] = fbits(gl.cell);
+            t[4] = fbits(gl.inv_cell); t[5] = fbits(gl.slack); t[6] = (uint32_t)gl.nx; t[7] = (uint32_t)gl.ny;
+            t[8] = (uint32_t)gl.nz; t[9] = (uint32_t)gl.ncells;
+            const uint64_t pp = (uint64_t)(uintptr_t)L.pts[l], pc = (uint64_t)(uintptr_t)L.cs[l], p0 = (uint64_t)(uintptr_t)L.pos0[l];
+            t[10] = (uint32_t)pp; t[11] = (uint32_t)(pp >> 32);
+            t[12] = (uint32_t)pc; t[13] = (uint32_t)(pc >> 32); t[14] = (uint32_t)p0; t[15] = (uint32_t)(p0 >> 32);
+        }
+        if (!c->d_lvl_tab) HIP_TRY(c, hipMalloc((void**)&c->d_lvl_tab, sizeof tab));
+        HIP_TRY(c, hipMemcpyAsync(c->d_lvl_tab, tab, sizeof tab, hipMemcpyHostToDevice, c->stream));
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->m = m;

@@ -411,7 +411,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restri
                                                           int allow_self_i, int* __restrict__ out_sidx,
                                                           float* __restrict__ out_d2, IcpState* __restrict__ st,
                                                           unsigned* __restrict__ hard, unsigned* __restrict__ hist0,
-                                                          float4* __restrict__ match_pt)
+                                                          float4* __restrict__ match_pt, const uint4* __restrict__ ltab_g)
 {
     static_assert(G == 2 || G == 4 || G == 8 || G == 16, "lanes per query");
     constexpr int NR = (9 + G - 1) / G; // rows owned per lane: row rr belongs to lane rr % G, slot rr / G
@@ -420,6 +420,9 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restri
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = clock64();
 #endif
+    // level table -> LDS (4 x 16 bytes per level, layout in map_build.hip:upload_level_table)
+    __shared__ uint4 ltab[ICPMI_MAXLEV * 4];
+    if (threadIdx.x < ICPMI_MAXLEV * 4) ltab[threadIdx.x] = ltab_g[threadIdx.x];
     // level-0 histogram of the quantile selection (top 8 bits of the d^2 pattern), per workgroup in LDS
     __shared__ unsigned lh[ICPMI_FSEL_B0];
     if (hist0) {
@@ -451,6 +454,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restri
     const int lane = threadIdx.x & 63;
     const int gbase = lane - sub;
 
+    __syncthreads(); // ltab visible (its load shared the round trip of the query loads above)
     Cand best; best.key = ~0ull; best.sidx = -1; // sidx = position in its level | level << 28
     float bx = 0.f, by = 0.f, bz = 0.f;          // coordinates of the current best candidate
     bool decided = !active;
@@ -462,40 +466,53 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restri
     // ball, and only visits the rows / cells the ball reaches.  Exactness is untouched: every point
     // within the bound is still scanned and the fold is over the same (d^2, index) keys.
     int lev0 = 0;
-    float rub2 = INFINITY; // squared pruning radius (with slack), +inf = no pruning
-    if (active && allow_self && st->iter > 0) {
-        const int sp = match_pt ? sp_kept : out_sidx[orig];
-        if (sp >= 0) {
-            const float4 qs = match_pt ? qs_kept : L.pts[0][sp];
-            const float ub2 = sqdist3(p.x, p.y, p.z, qs.x, qs.y, qs.z);
-            const float ub = sqrtf(ub2);
-            for (int lev = 0; lev < L.nlev; ++lev) {
-                const GridParams gl = L.g[lev];
-                const float fx = (p.x - gl.ox) * gl.inv_cell, fy = (p.y - gl.oy) * gl.inv_cell, fz = (p.z - gl.oz) * gl.inv_cell;
-                float mfl = fminf(fx - floorf(fx), 1.0f - (fx - floorf(fx)));
-                mfl = fminf(mfl, fminf(fy - floorf(fy), 1.0f - (fy - floorf(fy))));
-                mfl = fminf(mfl, fminf(fz - floorf(fz), 1.0f - (fz - floorf(fz))));
-                if (!(mfl >= 0.f)) mfl = 0.f;
-                const float margin = (1.0f + mfl) * gl.cell - 2.0f * gl.slack;
-                if (ub * 1.000001f <= margin) {
-                    lev0 = lev;
-                    const float rub = ub * 1.000001f + gl.slack;
-                    rub2 = rub * rub;
-                    best.key = pack_key(ub2, __float_as_uint(qs.w));
-                    best.sidx = sp; // level 0 position
-                    bx = qs.x; by = qs.y; bz = qs.z;
-                    break;
-                }
+    // The choice of the starting level runs WAVE-UNIFORMLY (all lanes step through the same `lev`):
+    // the level's grid parameters are then scalar loads into SGPRs.
+    {
+        int sp = -1;
+        float4 qs = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (active && allow_self && st->iter > 0) {
+            sp = match_pt ? sp_kept : out_sidx[orig];
+            if (sp >= 0) qs = match_pt ? qs_kept : L.pts[0][sp];
+        }
+        bool want = sp >= 0;
+        const float ub2 = sqdist3(p.x, p.y, p.z, qs.x, qs.y, qs.z);
+        const float ub = sqrtf(ub2);
+        for (int lev = 0; lev < L.nlev; ++lev) {
+            if (__ballot(want) == 0ull) break;
+            const GridParams gl = L.g[lev];
+            const float fx = (p.x - gl.ox) * gl.inv_cell, fy = (p.y - gl.oy) * gl.inv_cell, fz = (p.z - gl.oz) * gl.inv_cell;
+            float mfl = fminf(fx - floorf(fx), 1.0f - (fx - floorf(fx)));
+            mfl = fminf(mfl, fminf(fy - floorf(fy), 1.0f - (fy - floorf(fy))));
+            mfl = fminf(mfl, fminf(fz - floorf(fz), 1.0f - (fz - floorf(fz))));
+            if (!(mfl >= 0.f)) mfl = 0.f;
+            const float margin = (1.0f + mfl) * gl.cell - 2.0f * gl.slack;
+            if (want && ub * 1.000001f <= margin) {
+                lev0 = lev;
+                best.key = pack_key(ub2, __float_as_uint(qs.w));
+                best.sidx = sp; // level 0 position
+                bx = qs.x; by = qs.y; bz = qs.z;
+                want = false;
             }
         }
     }
-    // lanes of a group must agree on the starting level and radius (they do: same inputs)
+    // lanes of a group agree on the starting level and radius (same inputs)
     NN_TICK(1);
 
+    // The search itself runs with PER-LANE levels (groups of one wave work on different levels in
+    // lockstep); the level's parameters come from the LDS copy of the level table.
     for (int lev = lev0; lev < L.nlev && !decided; ++lev) {
-        const GridParams g = L.g[lev];
-        const float4* __restrict__ map = L.pts[lev];
-        const unsigned* __restrict__ cs = L.cs[lev];
+        GridParams g;
+        const float4* __restrict__ map;
+        const unsigned* __restrict__ cs;
+        {
+            const uint4 a = ltab[4 * lev], b = ltab[4 * lev + 1], c2 = ltab[4 * lev + 2], d = ltab[4 * lev + 3];
+            g.ox = __uint_as_float(a.x); g.oy = __uint_as_float(a.y); g.oz = __uint_as_float(a.z); g.cell = __uint_as_float(a.w);
+            g.inv_cell = __uint_as_float(b.x); g.slack = __uint_as_float(b.y); g.nx = (int)b.z; g.ny = (int)b.w;
+            g.nz = (int)c2.x; g.ncells = (int)c2.y;
+            map = reinterpret_cast<const float4*>(((unsigned long long)c2.w << 32) | c2.z);
+            cs = reinterpret_cast<const unsigned*>(((unsigned long long)d.y << 32) | d.x);
+        }
         const float fx = (p.x - g.ox) * g.inv_cell, fy = (p.y - g.oy) * g.inv_cell, fz = (p.z - g.oz) * g.inv_cell;
         const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
         const int cx = (int)fminf(fmaxf(flx, -1.0e6f), 1.0e6f);
@@ -505,6 +522,44 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restri
         mf = fminf(mf, fminf(fy - fly, 1.0f - (fy - fly)));
         mf = fminf(mf, fminf(fz - flz, 1.0f - (fz - flz)));
         if (!(mf >= 0.f)) mf = 0.f;
+
+        // (0) pruning radius.  Any candidate already held (the seed, or the best of a finer level) bounds
+        //     the answer from above; a query that holds none first scans the x-row through its own cell
+        //     (~1/9 of the block) to get one.  Rows / cells the ball of that radius cannot reach are then
+        //     skipped -- every point within the bound is still scanned, so the block minimum is exact.
+        if (best.key == ~0ull) {
+            unsigned s, e;
+            row_run(g, cs, cx - 1, cx + 1, cy, cz, s, e);
+            for (unsigned i0 = s + (unsigned)sub; i0 < e; i0 += (unsigned)(G * NB)) {
+                float4 q[NB];
+                unsigned gi[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const unsigned k = i0 + (unsigned)(u * G);
+                    gi[u] = k < e ? k : i0;
+                    q[u] = map[gi[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const float d2 = sqdist3(p.x, p.y, p.z, q[u].x, q[u].y, q[u].z);
+                    unsigned long long key = pack_key(d2, __float_as_uint(q[u].w));
+                    if (!allow_self) key = d2 > 1.1920929e-07f ? key : ~0ull;
+                    if (key < best.key) { best.key = key; best.sidx = (int)(gi[u] | ((unsigned)lev << 28)); bx = q[u].x; by = q[u].y; bz = q[u].z; }
+                }
+            }
+#pragma unroll
+            for (int off = G / 2; off > 0; off >>= 1) {
+                const unsigned long long ok = __shfl_xor(best.key, off, 64);
+                const int os = __shfl_xor(best.sidx, off, 64);
+                const float ox = __shfl_xor(bx, off, 64), oy = __shfl_xor(by, off, 64), oz = __shfl_xor(bz, off, 64);
+                if (ok < best.key) { best.key = ok; best.sidx = os; bx = ox; by = oy; bz = oz; }
+            }
+        }
+        float rub2 = INFINITY; // squared pruning radius (with slack), +inf = no pruning
+        if (best.key != ~0ull) {
+            const float rub = sqrtf(__uint_as_float((unsigned)(best.key >> 32))) * 1.000001f + g.slack;
+            rub2 = rub * rub;
+        }
 
         // (1) row lookups: row rr is owned by lane rr % G of the group (slot rr / G); all lookups of a
         //     lane are independent loads
@@ -554,6 +609,13 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restri
             Pr[rr + 1] = Pr[rr] + c;
         }
         const unsigned total = Pr[9];
+#ifdef ICPMI_NN_TIMING
+        tacc[7] += total; // candidates of lane 0's query
+        if (sub == 0 && st->iter > 0 && (qi % 16) == 0) { // distribution over a sample of seeded queries: dbg[18..23]
+            const int bkt = total <= 16 ? 0 : (total <= 32 ? 1 : (total <= 64 ? 2 : (total <= 128 ? 3 : (total <= 256 ? 4 : 5))));
+            atomicAdd(&st->dbg[18 + bkt], 1ull);
+        }
+#endif
         for (unsigned k0 = (unsigned)sub; k0 < total; k0 += (unsigned)(G * NB)) {
             float4 q[NB];
             unsigned gi[NB];
@@ -600,7 +662,11 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restri
         int bs = -1;
         if (best.key != ~0ull && bd2 <= maxr2) {
             const unsigned lv = (unsigned)best.sidx >> 28, pos = (unsigned)best.sidx & 0x0fffffffu;
-            bs = lv == 0 ? (int)pos : (int)L.pos0[lv][pos];
+            if (lv == 0) bs = (int)pos;
+            else {
+                const uint4 d = ltab[4 * lv + 3];
+                bs = (int)reinterpret_cast<const unsigned*>(((unsigned long long)d.w << 32) | d.z)[pos];
+            }
         } else bd2 = INFINITY;
         out_sidx[orig] = bs;
         out_d2[orig] = bd2;
@@ -622,6 +688,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restri
         const int base = st->iter > 0 ? 8 : 0; // seeded launches in dbg[8..15], the first one in dbg[0..7]
         for (int i = 0; i < 7; ++i) atomicAdd(&st->dbg[base + i], (unsigned long long)tacc[i]);
         atomicAdd(&st->dbg[base + 7], 1ull);
+        atomicAdd(&st->dbg[16 + (st->iter > 0 ? 1 : 0)], (unsigned long long)tacc[7]);
     }
 #endif
 }
@@ -665,7 +732,8 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
         c->nn_out_sorted = mp != nullptr;
 #define LAUNCH_ML(G_, NB_)                                                                                                      \
     hipLaunchKernelGGL((nn1_ml_kernel<G_, NB_>), dim3((int)(((n * G_ + NN_BLOCK - 1) / NN_BLOCK + 7) / 8 * 8)), dim3(NN_BLOCK), 0,  \
-                       c->stream, q, qi, (int)n, d_T, c->levels, lc.maxr2, allow_self, d_sidx, d_d2, d_state, c->d_hard, h0, mp)
+                       c->stream, q, qi, (int)n, d_T, c->levels, lc.maxr2, allow_self, d_sidx, d_d2, d_state, c->d_hard, h0, mp,  \
+                       c->d_lvl_tab)
         // iterations > 0 are seeded by the previous match (a handful of candidates per query): fewer
         // lanes per query; the unseeded first pass scans whole 27-cell blocks: more lanes per query
         const bool seeded = c->nn_iter_hint > 0 && allow_self;
@@ -677,7 +745,13 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
             case 4: LAUNCH_ML(16, 4); break;
             case 5: LAUNCH_ML(4, 2); break;
             case 6: LAUNCH_ML(8, 2); break;
-            default: LAUNCH_ML(8, 4); break;
+            case 7: LAUNCH_ML(4, 8); break;
+            case 8: LAUNCH_ML(8, 8); break;
+            case 9: LAUNCH_ML(16, 8); break;
+            default:
+                if (seeded) LAUNCH_ML(8, 4);
+                else LAUNCH_ML(16, 4);
+                break;
         }
 #undef LAUNCH_ML
         const GridParams& top = c->levels.g[c->levels.nlev - 1];
