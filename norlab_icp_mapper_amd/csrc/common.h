@@ -14,12 +14,22 @@
 #define ICPMI_MAX_OUTLIER 8
 #define ICPMI_MAX_SMOOTH 16
 #define ICPMI_SEL_BINS 2048     // legacy 11/11/10 selection (stage entry point, chains with > 1 quantile filter)
-#define ICPMI_FSEL_B0 2048      // fused selection: level 0 = top 11 bits of the d^2 pattern
-#define ICPMI_FSEL_B12 2048     //                  level 1 = next 11 bits, level 2 = last 10 bits
-#define ICPMI_FSEL_OFF0 4096    // word offsets of the fused histograms inside d_selhist
-#define ICPMI_FSEL_OFF1 8192
-#define ICPMI_FSEL_OFF2 12288
-#define ICPMI_SELHIST_WORDS 16384
+// Fused selection (one quantile filter in the chain): two 16-bit radix levels of the d^2 bit pattern,
+// each level a FINE histogram (65536 bins, direct device atomics: the values spread over hundreds of
+// bins) plus a COARSE one over the top 8 bits of the digit (256 bins) that tells a consumer which 256
+// fine bins to read.  Level 0's coarse histogram is hot (2-3 exponent values hold everything), so the
+// NN workgroups aggregate it in LDS and flush into one of ICPMI_S2_COPIES privatised copies.
+#define ICPMI_S2_COPIES 32
+#define ICPMI_S2_C0 4096                                        // word offsets inside d_selhist (legacy bins first)
+#define ICPMI_S2_F0 (ICPMI_S2_C0 + ICPMI_S2_COPIES * 256)
+#define ICPMI_S2_FCOPIES 1                                       // privatised copies of the level-0 FINE histogram
+#define ICPMI_S2_C1 (ICPMI_S2_F0 + ICPMI_S2_FCOPIES * 65536)
+#define ICPMI_S2_F1 (ICPMI_S2_C1 + 256)
+#define ICPMI_SELHIST_WORDS (ICPMI_S2_F1 + 65536)
+// Device atomics serialise per cache line, and neighbouring fine bins are hot together: bin b of a fine
+// histogram lives at word ((b & 255) << 8) | (b >> 8), i.e. consecutive bins are 1 KiB apart.
+#define ICPMI_S2_FIDX(b) ((((b) & 255u) << 8) | ((b) >> 8))
+
 #define ICPMI_NV 32            // doubles per block partial in the minimiser reduction
 #define ICPMI_MAX_K 32
 #define ICPMI_TQ 128           // queries per workgroup of the tile NN kernel (= max work-item size)

@@ -95,41 +95,22 @@ __global__ __launch_bounds__(256) void sel_scan_kernel(IcpState* __restrict__ st
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fused selection (exactly one quantile-type filter in the chain -- the common case): the scan of
-// level L's histogram is redone by EVERY workgroup of the kernel that builds level L + 1 (2048 bins
-// = 8 KB from L2, cheaper than a kernel boundary), so the chain per iteration is
-//   NN -> hist0 -> [scan0 + hist1] -> [scan1 + hist2] -> [scan2 + pair sums] -> solve.
-// Three histogram buffers; each is cleared by block 0 of a later kernel that no longer reads it.
+// Fused selection (exactly one quantile-type filter in the chain -- the common case).  Two 16-bit
+// radix levels (common.h: ICPMI_S2_*), chain per iteration
+//   NN (builds level 0) -> sel2_scan_hist (scans level 0, builds level 1) -> [scan level 1 + pair sums] -> solve.
+// Every workgroup of a consumer kernel redoes the scan of the histogram it needs (256 coarse bins,
+// then the 256 fine bins under the selected coarse one) -- cheaper than a kernel boundary.
+// Clearing: level 0 is cleared by the pair-sum kernel (after its last reader), level 1 by whoever
+// builds level 0 of the next iteration (before its next builder).
 // ---------------------------------------------------------------------------------------------
-// Radix digits of the fused path: 8 / 12 / 12 bits of the IEEE pattern of d^2 (sign bit is 0).  Level 0
-// (256 bins, sign + top exponent bits) is built inside the NN kernel from an LDS histogram per
-// workgroup; levels 1 and 2 (4096 bins) only receive the elements of the selected coarser bin and take
-// device-scope atomics directly.
-//
-// All 256 threads call. Finds the bin of `hist` (256 * EPT entries) holding element `rank`
-// (0-based, ascending); when from_quantile, rank = (unsigned)(float(total) * quantile) like
-// getDistsQuantile. Returns through references (uniform across the block).
-template <int EPT>
-__device__ __forceinline__ void block_find_rank(const unsigned* __restrict__ hist, bool from_quantile, float quantile,
-                                                unsigned rank_in, unsigned* sh /* >= 16 words */, unsigned& bin,
-                                                unsigned& rank_rem, unsigned& total)
+// All 256 threads call with one bin count `v` each (bin = threadIdx.x).  Finds the bin holding element
+// `rank` (0-based, ascending); when from_quantile, rank = (unsigned)(float(total) * quantile) like
+// getDistsQuantile.  Results are uniform across the block.
+__device__ __forceinline__ void block_find_rank256(unsigned v, bool from_quantile, float quantile, unsigned rank_in,
+                                                   unsigned* sh /* >= 16 words */, unsigned& bin, unsigned& rank_rem, unsigned& total)
 {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    unsigned v[EPT];
-    if (EPT >= 4) {
-#pragma unroll
-        for (int e = 0; e < EPT / 4; ++e) {
-            const uint4 a = reinterpret_cast<const uint4*>(hist)[(EPT / 4) * t + e];
-            v[4 * e] = a.x; v[4 * e + 1] = a.y; v[4 * e + 2] = a.z; v[4 * e + 3] = a.w;
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) v[e] = hist[EPT * t + e];
-    }
-    unsigned s = 0;
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) s += v[e];
-    unsigned incl = s;
+    unsigned incl = v;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const unsigned o = __shfl_up(incl, off, 64);
@@ -139,9 +120,8 @@ __device__ __forceinline__ void block_find_rank(const unsigned* __restrict__ his
     __syncthreads();
     const unsigned w0 = sh[0], w1 = sh[1], w2 = sh[2], w3 = sh[3];
     total = w0 + w1 + w2 + w3;
-    const unsigned wbase = wv == 0 ? 0u : (wv == 1 ? w0 : (wv == 2 ? w0 + w1 : w0 + w1 + w2));
-    incl += wbase;
-    const unsigned excl = incl - s;
+    incl += wv == 0 ? 0u : (wv == 1 ? w0 : (wv == 2 ? w0 + w1 : w0 + w1 + w2));
+    const unsigned excl = incl - v;
     unsigned rank = rank_in;
     if (from_quantile) {
         if (total == 0) rank = 0;
@@ -151,31 +131,35 @@ __device__ __forceinline__ void block_find_rank(const unsigned* __restrict__ his
             if (rank > total - 1) rank = total - 1;
         }
     }
-    if (total != 0 && rank >= excl && rank < incl) {
-        unsigned acc = excl, bsel = (unsigned)(EPT - 1);
-        bool found = false;
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            if (!found) {
-                if (rank < acc + v[e]) { bsel = (unsigned)e; found = true; }
-                else acc += v[e];
-            }
-        }
-        sh[8] = (unsigned)t * (unsigned)EPT + bsel;
-        sh[9] = rank - acc; // rank inside the selected bin
-    }
+    if (total != 0 && rank >= excl && rank < incl) { sh[8] = (unsigned)t; sh[9] = rank - excl; }
     __syncthreads();
     bin = sh[8];
     rank_rem = sh[9];
     __syncthreads();
 }
 
-// level-0 histogram as a stand-alone kernel (only for NN variants that do not build it themselves)
-__global__ __launch_bounds__(256) void fsel_hist0_kernel(const float* __restrict__ d2, int64_t count, const IcpState* __restrict__ st,
+// two-tier lookup: coarse bin from `coarse_v` (this thread's coarse count), then the fine bin under it
+template <int FCOPIES>
+__device__ __forceinline__ void block_find_rank_2tier(unsigned coarse_v, const unsigned* __restrict__ fine, bool from_quantile,
+                                                      float quantile, unsigned rank_in, unsigned* sh, unsigned& bin16,
+                                                      unsigned& rank_rem, unsigned& total)
+{
+    unsigned cb, rem, tot2;
+    block_find_rank256(coarse_v, from_quantile, quantile, rank_in, sh, cb, rem, total);
+    if (total == 0) { bin16 = 0; rank_rem = 0; return; }
+    unsigned fv = 0;
+#pragma unroll
+    for (int cpy = 0; cpy < FCOPIES; ++cpy) fv += fine[cpy * 65536 + ICPMI_S2_FIDX(cb * 256 + threadIdx.x)];
+    unsigned fb;
+    block_find_rank256(fv, false, 0.f, rem, sh, fb, rank_rem, tot2);
+    bin16 = (cb << 8) | fb;
+}
+
+// level-0 histograms as a stand-alone kernel (NN variants that do not build them: k > 1, chains that may
+// need the brute-force pass).  Also clears level 1, like the NN kernel does when it is the builder.
+__global__ __launch_bounds__(256) void sel2_hist0_kernel(const float* __restrict__ d2, int64_t count, const IcpState* __restrict__ st,
                                                          unsigned* __restrict__ hists)
 {
-    // all of a lane's elements are requested up front (one round trip), the flag check and the LDS
-    // clear overlap it
     constexpr int PF = 8;
     const int64_t stride = (int64_t)gridDim.x * 256;
     const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -183,59 +167,53 @@ __global__ __launch_bounds__(256) void fsel_hist0_kernel(const float* __restrict
 #pragma unroll
     for (int u = 0; u < PF; ++u) pv[u] = i0 + u * stride < count ? d2[i0 + u * stride] : INFINITY;
     if (st->done) return;
-    __shared__ unsigned h[ICPMI_FSEL_B0];
-    for (int b = threadIdx.x; b < ICPMI_FSEL_B0; b += 256) h[b] = 0;
+    __shared__ unsigned h[256];
+    h[threadIdx.x] = 0;
+    for (int64_t i = i0; i < 256 + 65536; i += stride) hists[ICPMI_S2_C1 + i] = 0;
     __syncthreads();
+    auto add = [&](float v) {
+        if (!(v != INFINITY && v > 0.f)) return;
+        const unsigned bits = __float_as_uint(v);
+        atomicAdd(&h[bits >> 24], 1u);
+        atomicAdd(&hists[ICPMI_S2_F0 + (blockIdx.x % ICPMI_S2_FCOPIES) * 65536 + ICPMI_S2_FIDX(bits >> 16)], 1u);
+    };
 #pragma unroll
-    for (int u = 0; u < PF; ++u)
-        if (pv[u] != INFINITY && pv[u] > 0.f) atomicAdd(&h[__float_as_uint(pv[u]) >> 21], 1u);
-    for (int64_t i = i0 + PF * stride; i < count; i += stride) {
-        const float v = d2[i];
-        if (v != INFINITY && v > 0.f) atomicAdd(&h[__float_as_uint(v) >> 21], 1u);
-    }
+    for (int u = 0; u < PF; ++u) add(pv[u]);
+    for (int64_t i = i0 + PF * stride; i < count; i += stride) add(d2[i]);
     __syncthreads();
-    for (int b = threadIdx.x; b < ICPMI_FSEL_B0; b += 256)
-        if (h[b]) atomicAdd(&hists[ICPMI_FSEL_OFF0 + b], h[b]);
+    if (h[threadIdx.x]) atomicAdd(&hists[ICPMI_S2_C0 + (blockIdx.x % ICPMI_S2_COPIES) * 256 + threadIdx.x], h[threadIdx.x]);
 }
 
-template <int PASS> // 1: scan level 0, build level 1;  2: scan level 1, build level 2
-__global__ __launch_bounds__(256) void sel_scan_hist_kernel(const float* __restrict__ d2, int64_t count, IcpState* __restrict__ st,
-                                                            unsigned* __restrict__ hists, float quantile)
+// scan level 0 (top 16 bits), build level 1 (low 16 bits) from the elements under the selected prefix
+__global__ __launch_bounds__(256) void sel2_scan_hist_kernel(const float* __restrict__ d2, int64_t count, IcpState* __restrict__ st,
+                                                             unsigned* __restrict__ hists, float quantile)
 {
-    // the lane's first elements are requested before the histogram scan (their round trip overlaps it)
+    // the lane's elements and the coarse counts are requested together (one round trip)
     constexpr int PF = 2;
     const int64_t stride = (int64_t)gridDim.x * 256;
     const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
     float pv[PF];
 #pragma unroll
     for (int u = 0; u < PF; ++u) pv[u] = i0 + u * stride < count ? d2[i0 + u * stride] : INFINITY;
+    unsigned cv = 0;
+#pragma unroll
+    for (int cpy = 0; cpy < ICPMI_S2_COPIES; ++cpy) cv += hists[ICPMI_S2_C0 + cpy * 256 + threadIdx.x];
     if (st->done) return;
     __shared__ unsigned sh[16];
-    unsigned bin, rem, total;
-    unsigned* hcur = hists + (PASS == 1 ? ICPMI_FSEL_OFF1 : ICPMI_FSEL_OFF2);
-    if (PASS == 1) block_find_rank<8>(hists + ICPMI_FSEL_OFF0, true, quantile, 0u, sh, bin, rem, total);
-    else block_find_rank<8>(hists + ICPMI_FSEL_OFF1, false, quantile, st->sel_rank_l[0], sh, bin, rem, total);
-    if (PASS == 1 && total == 0) {
+    unsigned prefix, rem, total;
+    block_find_rank_2tier<ICPMI_S2_FCOPIES>(cv, hists + ICPMI_S2_F0, true, quantile, 0u, sh, prefix, rem, total);
+    if (total == 0) {
         if (blockIdx.x == 0 && threadIdx.x == 0) { st->n_valid = 0; st->error = ICPMI_ERR_NO_OUTLIER_TO_FILTER; st->done = 1; }
         return;
     }
-    const unsigned prefix = PASS == 1 ? bin : ((st->sel_prefix_l[0] << 11) | bin);
-    if (blockIdx.x == 0) {
-        if (threadIdx.x == 0) {
-            st->sel_prefix_l[PASS - 1] = prefix;
-            st->sel_rank_l[PASS - 1] = rem;
-            if (PASS == 1) st->n_valid = total;
-        }
-        // level 0 is dead once level 1's builders have run: PASS 2 clears it for the next iteration
-        if (PASS == 2) for (int b = threadIdx.x; b < ICPMI_FSEL_B0; b += 256) hists[ICPMI_FSEL_OFF0 + b] = 0;
-    }
-    // Only the elements inside the selected coarser bin contribute and they spread over up to 4096
-    // bins: device-scope atomics straight to the level's histogram see little contention.
+    if (blockIdx.x == 0 && threadIdx.x == 0) { st->sel_prefix_l[0] = prefix; st->sel_rank_l[0] = rem; st->n_valid = total; }
+    // only the elements under the selected 16-bit prefix contribute (a few hundred): no contention
     auto add = [&](float v) {
         if (!(v != INFINITY && v > 0.f)) return;
         const unsigned bits = __float_as_uint(v);
-        if (PASS == 1) { if ((bits >> 21) == prefix) atomicAdd(&hcur[(bits >> 10) & 2047u], 1u); }
-        else { if ((bits >> 10) == prefix) atomicAdd(&hcur[bits & 1023u], 1u); }
+        if ((bits >> 16) != prefix) return;
+        atomicAdd(&hists[ICPMI_S2_C1 + ((bits >> 8) & 255u)], 1u);
+        atomicAdd(&hists[ICPMI_S2_F1 + ICPMI_S2_FIDX(bits & 0xffffu)], 1u);
     };
 #pragma unroll
     for (int u = 0; u < PF; ++u) add(pv[u]);
@@ -312,17 +290,16 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restric
     if (st->done) return;
     float fused_limit = 0.f;
     if (FUSED) {
-        // scan of the level-2 histogram: the selected element's bit pattern is prefix(22) | bin(10)
+        // scan of level 1: the selected element's bit pattern is prefix(16) | bin(16)
         __shared__ unsigned shsel[16];
+        const unsigned cv = hists[ICPMI_S2_C1 + threadIdx.x];
         unsigned bin, rem, total;
-        block_find_rank<4>(hists + ICPMI_FSEL_OFF2, false, 0.f, st->sel_rank_l[1], shsel, bin, rem, total);
-        const float q = __uint_as_float((st->sel_prefix_l[1] << 10) | bin);
+        block_find_rank_2tier<1>(cv, hists + ICPMI_S2_F1, false, 0.f, st->sel_rank_l[0], shsel, bin, rem, total);
+        const float q = __uint_as_float((st->sel_prefix_l[0] << 16) | bin);
         fused_limit = is_median ? factor * q : q;
-        if (blockIdx.x == 0) {
-            if (threadIdx.x == 0) st->limits[fused_slot] = fused_limit;
-            // level 1 is dead once every level-2 builder has finished (previous kernel)
-            for (int b = threadIdx.x; b < ICPMI_FSEL_B12; b += 256) hists[ICPMI_FSEL_OFF1 + b] = 0;
-        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->limits[fused_slot] = fused_limit;
+        // level 0 is dead (its only reader ran in the previous kernel): clear it for the next iteration
+        for (int64_t i = e_first; i < ICPMI_S2_COPIES * 256 + ICPMI_S2_FCOPIES * 65536; i += stride) hists[ICPMI_S2_C0 + i] = 0;
     }
     constexpr int NVAL = MIN == ICPMI_MIN_POINT_TO_PLANE ? 27 : (MIN == ICPMI_MIN_POINT_TO_POINT ? 16 : 0);
     double acc[NVAL > 0 ? NVAL : 1];
@@ -691,7 +668,7 @@ __global__ __launch_bounds__(256) void solve_kernel(IcpState* __restrict__ st, c
 {
     if (st->done) return;
     // level-2 selection histogram is dead after the accumulation kernel: clear it for the next iteration
-    if (hists) for (int b = threadIdx.x; b < ICPMI_FSEL_B12; b += 256) hists[ICPMI_FSEL_OFF2 + b] = 0;
+    (void)hists;
     // ordered (deterministic) reduction of the block partials: 8 lanes per value, fixed row
     // assignment, fixed combination order
     __shared__ double part[8][ICPMI_NV];
@@ -946,11 +923,10 @@ static void enqueue_selection(icpmi_ctx* c, const LoopCfg& lc, int64_t count, bo
         // fused chain: hist0 -> [scan0 + hist1] -> [scan1 + hist2]; scan2 happens inside the accumulation kernel
         const float quant = lc.out_type[slot] == ICPMI_OUT_MEDIANDIST ? 0.5f : lc.out_param[slot];
         if (!c->nn_builds_hist0)
-            hipLaunchKernelGGL(fsel_hist0_kernel, dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist);
+            hipLaunchKernelGGL(sel2_hist0_kernel, dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist);
         int hb2 = (int)std::min<int64_t>((count + 511) / 512, 512);
         if (hb2 < 1) hb2 = 1;
-        hipLaunchKernelGGL(sel_scan_hist_kernel<1>, dim3(hb2), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist, quant);
-        hipLaunchKernelGGL(sel_scan_hist_kernel<2>, dim3(hb2), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist, quant);
+        hipLaunchKernelGGL(sel2_scan_hist_kernel, dim3(hb2), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist, quant);
         return;
     }
     for (int f = 0; f < lc.n_out; ++f) {
@@ -1003,7 +979,7 @@ static void enqueue_accumulate_solve(icpmi_ctx* c, int64_t n, const LoopCfg& lc,
 static icpmi_status enqueue_iteration(icpmi_ctx* c, int64_t n, const LoopCfg& lc, hipEvent_t nn0, hipEvent_t nn1)
 {
     if (nn0) HIP_TRY(c, hipEventRecord(nn0, c->stream));
-    c->nn_hist0 = fused_filter_slot(lc) >= 0 ? c->d_selhist + ICPMI_FSEL_OFF0 : nullptr;
+    c->nn_hist0 = fused_filter_slot(lc) >= 0 ? c->d_selhist : nullptr;
     c->nn_builds_hist0 = false;
     static int keep_pts = -1;
     if (keep_pts < 0) { const char* e = getenv("ICPMI_SORTED_STATE"); keep_pts = e ? atoi(e) : 1; }
@@ -1161,7 +1137,7 @@ icpmi_status loop_single_step(icpmi_ctx* c, int64_t n, const LoopCfg& lc, const 
     LoopCfg l1 = lc;
     l1.max_iter = 1; l1.use_diff = 0; l1.use_bound = 0;
     c->nn_iter_hint = 0;
-    c->nn_hist0 = fused_filter_slot(l1) >= 0 ? c->d_selhist + ICPMI_FSEL_OFF0 : nullptr;
+    c->nn_hist0 = fused_filter_slot(l1) >= 0 ? c->d_selhist : nullptr;
     c->nn_builds_hist0 = false;
     c->nn_match_pt = nullptr;
     c->nn_out_sorted = false;

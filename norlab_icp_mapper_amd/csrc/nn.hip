@@ -424,10 +424,11 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restri
     __shared__ uint4 ltab[ICPMI_MAXLEV * 4];
     if (threadIdx.x < ICPMI_MAXLEV * 4) ltab[threadIdx.x] = ltab_g[threadIdx.x];
     // level-0 histogram of the quantile selection (top 8 bits of the d^2 pattern), per workgroup in LDS
-    __shared__ unsigned lh[ICPMI_FSEL_B0];
+    __shared__ unsigned lh[256];
     if (hist0) {
-        for (int b = threadIdx.x; b < ICPMI_FSEL_B0; b += NN_BLOCK) lh[b] = 0;
-        __syncthreads();
+        lh[threadIdx.x] = 0; // visible after the barrier below
+        // the builder of level 0 clears level 1 of the previous iteration (loop.hip, fused selection)
+        for (int gt = blockIdx.x * NN_BLOCK + threadIdx.x; gt < 256 + 65536; gt += gridDim.x * NN_BLOCK) hist0[ICPMI_S2_C1 + gt] = 0;
     }
     const bool allow_self = allow_self_i != 0;
     // XCD-aware order: workgroup b runs on XCD b % 8 (observed placement, used for speed only), so
@@ -671,7 +672,11 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restri
         out_sidx[orig] = bs;
         out_d2[orig] = bd2;
         if (match_pt) match_pt[orig] = make_float4(bx, by, bz, __uint_as_float((unsigned)(best.key & 0xffffffffull)));
-        if (hist0 && bd2 != INFINITY && bd2 > 0.f) atomicAdd(&lh[__float_as_uint(bd2) >> 21], 1u);
+        if (hist0 && bd2 != INFINITY && bd2 > 0.f) {
+            const unsigned bits = __float_as_uint(bd2);
+            atomicAdd(&lh[bits >> 24], 1u);
+            atomicAdd(&hist0[ICPMI_S2_F0 + (blockIdx.x % ICPMI_S2_FCOPIES) * 65536 + ICPMI_S2_FIDX(bits >> 16)], 1u);
+        }
         if (!decided) {
             const unsigned slot = atomicAdd(&st->hard_count, 1u);
             hard[slot] = (unsigned)(qindex ? qindex[qi] : qi); // the brute pass works on the caller's order
@@ -679,8 +684,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restri
     }
     if (hist0) {
         __syncthreads();
-        for (int b = threadIdx.x; b < ICPMI_FSEL_B0; b += NN_BLOCK)
-            if (lh[b]) atomicAdd(&hist0[b], lh[b]);
+        if (lh[threadIdx.x]) atomicAdd(&hist0[ICPMI_S2_C0 + (blockIdx.x % ICPMI_S2_COPIES) * 256 + threadIdx.x], lh[threadIdx.x]);
     }
 #ifdef ICPMI_NN_TIMING
     NN_TICK(5);
@@ -719,11 +723,13 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
         // every query is decided on the pyramid
         const GridParams& topg = c->levels.g[c->levels.nlev - 1];
         const bool needs_hard = !std::isfinite(lc.max_dist) || (topg.cell - topg.slack) <= lc.max_dist;
-        // Measured (r1): building the level-0 histogram in this kernel costs +20 us -- 3125 workgroups
-        // flushing ~10 hot bins each serialise on a dozen L2 atomics addresses -- against 4.5 us for the
-        // stand-alone 49-workgroup histogram kernel.  Kept behind an env knob for re-evaluation.
+        // The NN kernel builds level 0 of the fused quantile selection itself (loop.hip): fine bins by
+        // direct atomics, the hot coarse bins through LDS and privatised copies.  (r1 measurement: a
+        // single 2048-bin level-0 histogram flushed by every workgroup cost +20 us in same-address
+        // atomics; the two-tier layout removes that.)  ICPMI_NN_FUSE_HIST0=0 falls back to the
+        // stand-alone builder kernel.
         static int fuse_h0 = -1;
-        if (fuse_h0 < 0) { const char* e = getenv("ICPMI_NN_FUSE_HIST0"); fuse_h0 = e ? atoi(e) : 0; }
+        if (fuse_h0 < 0) { const char* e = getenv("ICPMI_NN_FUSE_HIST0"); fuse_h0 = e ? atoi(e) : 1; }
         unsigned* h0 = (needs_hard || !fuse_h0) ? nullptr : c->nn_hist0;
         c->nn_builds_hist0 = h0 != nullptr;
         // loop mode keeps the per-query state in query order; the brute-force pass works in the caller's
