@@ -158,7 +158,7 @@ def main():
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        out["roofline"] = {"bound": "hbm", "kernel": "nn1_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        out["roofline"] = {"bound": "hbm", "kernel": "nn1_ml_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                            "avg_launch_us": nn_avg_ms * 1e3, "launches_timed": nn_cnt}
         del prof
