@@ -241,9 +241,7 @@ static icpmi_status register_impl(icpmi_handle h, const float* d_scan4, int64_t 
         h->last_error = quant ? "ConvergenceError: no outlier to filter" : "ConvergenceError: ErrorMinimizer: no point to minimize";
         return quant ? ICPMI_ERR_NO_OUTLIER_TO_FILTER : ICPMI_ERR_NO_POINT_TO_MINIMIZE;
     }
-    icpmi_status s = loop_prepare_reading(h, (const float4*)d_scan4, n, needs_rn ? d_n3 : nullptr);
-    if (s != ICPMI_OK) return s;
-    return loop_run(h, n, lc, fixed_iters > 0, T_out, stats);
+    return loop_run(h, (const float4*)d_scan4, needs_rn ? d_n3 : nullptr, n, lc, fixed_iters > 0, T_out, stats);
 }
 
 icpmi_status icpmi_register_dev(icpmi_handle h, const float* d_scan4, int64_t n, const float* d_scan_normals3, float T_out[16],

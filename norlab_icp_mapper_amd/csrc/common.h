@@ -220,6 +220,7 @@ __device__ __forceinline__ unsigned long long pack_key(float d2, unsigned id)
 icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float* d_normals3);
 icpmi_status device_exclusive_scan(icpmi_ctx* c, unsigned* data, int n, unsigned total);
 icpmi_status sort_queries(icpmi_ctx* c, const float4* d_pts, int64_t n);
+icpmi_status sort_queries_reserve(icpmi_ctx* c, int64_t n);
 icpmi_status nn_tile_launch_k1(icpmi_ctx* c, int64_t n, const float* d_T, const LoopCfg& lc, int allow_self, int* d_sidx,
                                float* d_d2, IcpState* d_state);
 icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, const float* d_T, const LoopCfg& lc,
@@ -227,7 +228,8 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
 icpmi_status nn_launch_k(icpmi_ctx* c, const float4* d_reading, int64_t n, const float* d_T, const LoopCfg& lc,
                          int allow_self, int* d_sidx, float* d_d2, IcpState* d_state);
 icpmi_status nn_ids_to_original(icpmi_ctx* c, const int* d_sidx, int64_t count, int* d_ids);
-icpmi_status loop_run(icpmi_ctx* c, int64_t n, const LoopCfg& lc, bool fixed, float T_out[16], icpmi_stats* stats);
+icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals3, int64_t n, const LoopCfg& lc, bool fixed, float T_out[16],
+                      icpmi_stats* stats);
 icpmi_status loop_prepare_reading(icpmi_ctx* c, const float4* d_scan, int64_t n, const float* d_normals3);
 icpmi_status loop_single_step(icpmi_ctx* c, int64_t n, const LoopCfg& lc, const float* T_iter_host, float T_step[16],
                               double sums[32], icpmi_stats* stats);

@@ -1023,23 +1023,43 @@ static void host_mat4_mul(const float* A, const float* B, float* C)
     memcpy(C, R, sizeof R);
 }
 
-icpmi_status loop_run(icpmi_ctx* c, int64_t n, const LoopCfg& lc_in, bool fixed, float T_out[16], icpmi_stats* stats)
+// everything a registration enqueues before its first iteration: centring + tile sort of the reading,
+// loop state, selection histograms
+static icpmi_status enqueue_registration_head(icpmi_ctx* c, const float4* d_scan, const float* d_normals3, int64_t n)
 {
-    LoopCfg lc = lc_in;
-    if (ensure_loop_buffers(c, n, lc.k) != ICPMI_OK) return ICPMI_ERR_HIP;
+    icpmi_status s = loop_prepare_reading(c, d_scan, n, d_normals3);
+    if (s != ICPMI_OK) return s;
     hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(64), 0, c->stream, c->d_state, (const float*)nullptr);
     HIP_TRY(c, hipMemsetAsync(c->d_selhist, 0, ICPMI_SELHIST_WORDS * sizeof(unsigned), c->stream));
     HIP_TRY(c, hipGetLastError());
+    return ICPMI_OK;
+}
+
+icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals3, int64_t n, const LoopCfg& lc_in, bool fixed,
+                      float T_out[16], icpmi_stats* stats)
+{
+    LoopCfg lc = lc_in;
+    // all allocations up front: none may happen while the stream is capturing
+    if (ensure_loop_buffers(c, n, lc.k) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (ensure_cap(c, &c->d_reading, &c->cap_reading, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (d_normals3 && ensure_cap(c, &c->d_read_normals, &c->cap_read_normals, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (c->cfg.knn <= 1 && sort_queries_reserve(c, n) != ICPMI_OK) return ICPMI_ERR_HIP;
 
     const bool profile = c->cfg.profile != 0;
     const bool graph = c->cfg.use_graph != 0 && fixed && !profile;
     float nn_ms_sum = 0.f; int nn_cnt = 0;
 
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    if (!graph) {
+        icpmi_status s = enqueue_registration_head(c, d_scan, d_normals3, n);
+        if (s != ICPMI_OK) return s;
+    }
     if (graph) {
+        // the whole registration -- head and all iterations -- is one graph, replayed while the scan
+        // buffer, the map and the chain stay the same
         uint64_t sig = 1469598103934665603ull;
         sig = fnv(&lc, sizeof lc, sig);
-        const void* ptrs[] = {c->d_reading, c->d_read_normals, c->d_sidx, c->d_d2, c->d_hard, c->d_partials, c->d_state, c->d_match_pt,
+        const void* ptrs[] = {d_scan, d_normals3, c->d_qkeys, c->d_qtile,c->d_reading, c->d_read_normals, c->d_sidx, c->d_d2, c->d_hard, c->d_partials, c->d_state, c->d_match_pt,
                               c->d_qsorted, c->d_qindex,
                               c->d_map_sorted, c->d_normals_sorted, c->d_cell_start, c->d_selhist};
         sig = fnv(ptrs, sizeof ptrs, sig);
@@ -1048,7 +1068,7 @@ icpmi_status loop_run(icpmi_ctx* c, int64_t n, const LoopCfg& lc_in, bool fixed,
             if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
             hipGraph_t g = nullptr;
             HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-            icpmi_status s = ICPMI_OK;
+            icpmi_status s = enqueue_registration_head(c, d_scan, d_normals3, n);
             for (int it = 0; it < lc.max_iter && s == ICPMI_OK; ++it) { c->nn_iter_hint = it; s = enqueue_iteration(c, n, lc, nullptr, nullptr); }
             hipError_t ce = hipStreamEndCapture(c->stream, &g);
             if (s != ICPMI_OK) { if (g) hipGraphDestroy(g); return s; }
@@ -1059,6 +1079,7 @@ icpmi_status loop_run(icpmi_ctx* c, int64_t n, const LoopCfg& lc_in, bool fixed,
             c->graph_n = n; c->graph_iters = lc.max_iter; c->graph_sig = sig;
         }
         HIP_TRY(c, hipGraphLaunch(c->graph_exec, c->stream));
+        if (c->cfg.knn <= 1) { c->qsorted_n = n; c->qsorted_src = c->d_reading; } // what the replayed head leaves in d_qsorted
     } else {
         const int check_every = (lc.use_diff || lc.use_bound) ? 4 : lc.max_iter;
         if (profile && c->nn_events.size() < (size_t)2 * lc.max_iter) {

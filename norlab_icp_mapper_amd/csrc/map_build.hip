@@ -303,6 +303,25 @@ __global__ __launch_bounds__(256) void qpass_kernel(const unsigned* __restrict__
 
 } // namespace
 
+// capacity of everything sort_queries touches (so that the sort itself allocates nothing and can be
+// captured into a graph)
+icpmi_status sort_queries_reserve(icpmi_ctx* c, int64_t n)
+{
+    const GridParams& g = c->grid;
+    const int tx = (g.nx + STX - 1) / STX, ty = (g.ny + STY - 1) / STY, tz = (g.nz + STZ - 1) / STZ;
+    const int nst = tx * ty * tz;
+    int bits = 0;
+    while ((1ll << bits) < (long long)nst) ++bits;
+    const int passes = bits <= QS_BITS ? 1 : (bits + QS_BITS - 1) / QS_BITS;
+    const int nwg = (int)((n + QS_EPB - 1) / QS_EPB);
+    const size_t tab = (size_t)QS_BINS * (nwg > 0 ? nwg : 1) + QS_BINS;
+    if (ensure_cap(c, &c->d_qsorted, &c->cap_qsorted, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (ensure_cap(c, &c->d_qindex, &c->cap_qindex, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (ensure_cap(c, &c->d_qkeys, &c->cap_qkeys, (size_t)4 * n + 4) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (ensure_cap(c, &c->d_qtile, &c->cap_qtile, tab * passes) != ICPMI_OK) return ICPMI_ERR_HIP;
+    return ICPMI_OK;
+}
+
 icpmi_status sort_queries(icpmi_ctx* c, const float4* d_pts, int64_t n)
 {
     const GridParams& g = c->grid;
