@@ -259,6 +259,9 @@ __device__ __forceinline__ float match_weight(const LoopCfg& lc, const IcpState*
 //   point-to-point: [0] sum w, [1..3] sum w p, [4..6] sum w q, [7 + 3c + r] sum w q_r p_c
 //   always:         [27] sum w, [28] number of pairs
 // ---------------------------------------------------------------------------------------------
+__device__ void solve_body(IcpState* __restrict__ st, const double* __restrict__ partials, int nblocks, const LoopCfg& lc,
+                           float* __restrict__ T_step_out, double* __restrict__ sums_out);
+
 template <int MIN, bool FUSED>
 __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restrict__ reading, int n, LoopCfg lc,
                                                          IcpState* __restrict__ st, const float4* __restrict__ map,
@@ -267,7 +270,9 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restric
                                                          const int* __restrict__ sidx, const float* __restrict__ d2a,
                                                          double* __restrict__ partials, unsigned* __restrict__ hists,
                                                          int fused_slot, int is_median, float factor,
-                                                         const float4* __restrict__ match_pt, const int* __restrict__ qindex)
+                                                         const float4* __restrict__ match_pt, const int* __restrict__ qindex,
+                                                         int solve_here, float* __restrict__ T_step_out,
+                                                         double* __restrict__ sums_out)
 {
     // `reading`, sidx, d2a (and match_pt, the matched map points kept by the NN kernel) share one
     // order: the caller's, or -- qindex != nullptr -- the tile-sorted query order of the k = 1 loop,
@@ -381,7 +386,20 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restric
         double v = 0.0;
         if (i < NVAL || i == 27 || i == 28) v = sh[0][i] + sh[1][i] + sh[2][i] + sh[3][i];
         partials[(size_t)blockIdx.x * ICPMI_NV + i] = v;
+        if (solve_here) __threadfence(); // publish: only the lanes that stored a partial pay for the fence
     }
+    if (!solve_here) return;
+    // The last workgroup to publish its partials reduces them (fixed order) and solves: saves a
+    // dependent launch.  Standard ticket pattern: stores -> device fence -> ticket; the winner fences
+    // again before reading the other workgroups' partials.
+    __shared__ unsigned s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&st->ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (threadIdx.x == 0) st->ticket = 0;
+    solve_body(st, partials, (int)gridDim.x, lc, T_step_out, sums_out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -662,13 +680,9 @@ __device__ double quat_angdist(const double* a, const double* b)
 // ---------------------------------------------------------------------------------------------
 // single-wave kernel: ordered reduction of the block partials, solve, compose, checkers
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void solve_kernel(IcpState* __restrict__ st, const double* __restrict__ partials, int nblocks,
-                                                    LoopCfg lc, int n, float* __restrict__ T_step_out, double* __restrict__ sums_out,
-                                                    unsigned* __restrict__ hists)
+__device__ void solve_body(IcpState* __restrict__ st, const double* __restrict__ partials, int nblocks, const LoopCfg& lc,
+                           float* __restrict__ T_step_out, double* __restrict__ sums_out)
 {
-    if (st->done) return;
-    // level-2 selection histogram is dead after the accumulation kernel: clear it for the next iteration
-    (void)hists;
     // ordered (deterministic) reduction of the block partials: 8 lanes per value, fixed row
     // assignment, fixed combination order
     __shared__ double part[8][ICPMI_NV];
@@ -780,6 +794,14 @@ __global__ __launch_bounds__(256) void solve_kernel(IcpState* __restrict__ st, c
     st->dbg[21] += 1;
 }
 
+// stand-alone form (ICPMI_FUSE_SOLVE=0)
+__global__ __launch_bounds__(256) void solve_kernel(IcpState* __restrict__ st, const double* __restrict__ partials, int nblocks,
+                                                    LoopCfg lc, float* __restrict__ T_step_out, double* __restrict__ sums_out)
+{
+    if (st->done) return;
+    solve_body(st, partials, nblocks, lc, T_step_out, sums_out);
+}
+
 __global__ __launch_bounds__(256) void centre_kernel(const float4* __restrict__ scan, int64_t n, float mx, float my, float mz,
                                                      float4* __restrict__ out)
 {
@@ -808,7 +830,7 @@ __global__ void init_state_kernel(IcpState* st, const float* T0)
     st->hist_n = 1;
     st->sel_prefix = 0; st->sel_rank = 0; st->n_valid = 0;
     for (int f = 0; f < ICPMI_MAX_OUTLIER; ++f) st->limits[f] = -1.f;
-    st->pairs = 0; st->wsum = 0; st->hard_count = 0; st->hard_total = 0;
+    st->pairs = 0; st->wsum = 0; st->hard_count = 0; st->hard_total = 0; st->ticket = 0;
     for (int i = 0; i < 24; ++i) st->dbg[i] = 0;
 }
 
@@ -945,7 +967,7 @@ static void enqueue_selection(icpmi_ctx* c, const LoopCfg& lc, int64_t count, bo
 }
 
 template <int MIN, bool FUSED>
-static void launch_accumulate(icpmi_ctx* c, int64_t n, const LoopCfg& lc, int nb, int slot)
+static void launch_accumulate(icpmi_ctx* c, int64_t n, const LoopCfg& lc, int nb, int slot, int solve_here, float* d_Tstep, double* d_sums)
 {
     const float4* rn = lc.has_read_normals ? c->d_read_normals : nullptr;
     const int is_med = slot >= 0 && lc.out_type[slot] == ICPMI_OUT_MEDIANDIST;
@@ -953,7 +975,8 @@ static void launch_accumulate(icpmi_ctx* c, int64_t n, const LoopCfg& lc, int nb
     const bool sorted = lc.k == 1 && c->nn_out_sorted; // loop state in query order (see nn1_ml_kernel)
     hipLaunchKernelGGL((accumulate_kernel<MIN, FUSED>), dim3(nb), dim3(256), 0, c->stream, sorted ? c->d_qsorted : c->d_reading, (int)n, lc, c->d_state,
                        c->d_map_sorted, c->d_normals_sorted, rn, c->d_sidx, c->d_d2, c->d_partials, c->d_selhist, slot, is_med, factor,
-                       sorted ? c->d_match_pt : (const float4*)nullptr, sorted ? c->d_qindex : (const int*)nullptr);
+                       sorted ? c->d_match_pt : (const float4*)nullptr, sorted ? c->d_qindex : (const int*)nullptr, solve_here, d_Tstep,
+                       d_sums);
 }
 
 static void enqueue_accumulate_solve(icpmi_ctx* c, int64_t n, const LoopCfg& lc, float* d_Tstep, double* d_sums)
@@ -962,18 +985,23 @@ static void enqueue_accumulate_solve(icpmi_ctx* c, int64_t n, const LoopCfg& lc,
     const int nb = acc_blocks(count);
     const int slot = fused_filter_slot(lc);
     const bool fused = slot >= 0;
+    static int fuse_solve = -1;
+    // Measured (r1): letting the last pair-sum workgroup solve (ticket + device fences) costs +3.5 us per
+    // iteration against the separate 1-workgroup launch -- the release fences write back the L2 of every
+    // XCD -- so the stand-alone solve launch stays the default.
+    if (fuse_solve < 0) { const char* e = getenv("ICPMI_FUSE_SOLVE"); fuse_solve = e ? atoi(e) : 0; }
     if (lc.minimizer == ICPMI_MIN_POINT_TO_PLANE) {
-        if (fused) launch_accumulate<ICPMI_MIN_POINT_TO_PLANE, true>(c, n, lc, nb, slot);
-        else launch_accumulate<ICPMI_MIN_POINT_TO_PLANE, false>(c, n, lc, nb, slot);
+        if (fused) launch_accumulate<ICPMI_MIN_POINT_TO_PLANE, true>(c, n, lc, nb, slot, fuse_solve, d_Tstep, d_sums);
+        else launch_accumulate<ICPMI_MIN_POINT_TO_PLANE, false>(c, n, lc, nb, slot, fuse_solve, d_Tstep, d_sums);
     } else if (lc.minimizer == ICPMI_MIN_POINT_TO_POINT) {
-        if (fused) launch_accumulate<ICPMI_MIN_POINT_TO_POINT, true>(c, n, lc, nb, slot);
-        else launch_accumulate<ICPMI_MIN_POINT_TO_POINT, false>(c, n, lc, nb, slot);
+        if (fused) launch_accumulate<ICPMI_MIN_POINT_TO_POINT, true>(c, n, lc, nb, slot, fuse_solve, d_Tstep, d_sums);
+        else launch_accumulate<ICPMI_MIN_POINT_TO_POINT, false>(c, n, lc, nb, slot, fuse_solve, d_Tstep, d_sums);
     } else {
-        if (fused) launch_accumulate<ICPMI_MIN_IDENTITY, true>(c, n, lc, nb, slot);
-        else launch_accumulate<ICPMI_MIN_IDENTITY, false>(c, n, lc, nb, slot);
+        if (fused) launch_accumulate<ICPMI_MIN_IDENTITY, true>(c, n, lc, nb, slot, fuse_solve, d_Tstep, d_sums);
+        else launch_accumulate<ICPMI_MIN_IDENTITY, false>(c, n, lc, nb, slot, fuse_solve, d_Tstep, d_sums);
     }
-    hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(256), 0, c->stream, c->d_state, c->d_partials, nb, lc, (int)n, d_Tstep, d_sums,
-                       fused ? c->d_selhist : (unsigned*)nullptr);
+    if (!fuse_solve)
+        hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(256), 0, c->stream, c->d_state, c->d_partials, nb, lc, d_Tstep, d_sums);
 }
 
 static icpmi_status enqueue_iteration(icpmi_ctx* c, int64_t n, const LoopCfg& lc, hipEvent_t nn0, hipEvent_t nn1)
