@@ -186,6 +186,11 @@ icpmi_status icpmi_surface_normals(icpmi_handle h, const float* pts4, int64_t m,
 icpmi_status icpmi_point_distance_keep(icpmi_handle h, const float* map4, int64_t m, const float* in4, int64_t n,
                                        float min_dist, uint8_t* keep);
 
+/* `OctreeMapperModule::inPlaceUpdateMap` decimation (OctreeMapperModule.cpp:35-39 -> OctreeGridDataPointsFilter
+ * {maxSizeByNode: edge, samplingMethod: 0}), as a lattice stand-in: voxel index floor((p - lo) / edge) per axis
+ * with lo the bounding-box minimum; keep[i] = 1 iff i is the smallest index of its voxel. */
+icpmi_status icpmi_voxel_keep_first(icpmi_handle h, const float* in4, int64_t n, float edge, uint8_t* keep);
+
 /* `Map::unloadCells` binning (Map.cpp:206-209,232-235): ijk3[3 i + r] = floor(p_r / cell_size). */
 icpmi_status icpmi_bin_cells(icpmi_handle h, const float* pts4, int64_t n, float cell_size, int32_t* ijk3);
 

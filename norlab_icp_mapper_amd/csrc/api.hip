@@ -384,6 +384,13 @@ icpmi_status icpmi_point_distance_keep(icpmi_handle h, const float* map4, int64_
     return ops_point_distance_keep(h, map4, m, in4, n, min_dist, keep);
 }
 
+icpmi_status icpmi_voxel_keep_first(icpmi_handle h, const float* in4, int64_t n, float edge, uint8_t* keep)
+{
+    CHECK_H(h);
+    if (n < 0 || (n > 0 && (!in4 || !keep)) || !(edge > 0.f)) { h->last_error = "voxel_keep_first: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
+    return ops_voxel_keep_first(h, in4, n, edge, keep);
+}
+
 icpmi_status icpmi_bin_cells(icpmi_handle h, const float* pts4, int64_t n, float cell_size, int32_t* ijk3)
 {
     CHECK_H(h);

@@ -121,6 +121,81 @@ __global__ __launch_bounds__(128) void normals_kernel(const float4* __restrict__
     normals3[3 * i] = nx; normals3[3 * i + 1] = ny; normals3[3 * i + 2] = nz;
 }
 
+// ---- voxel sub-sample (OctreeMapperModule / OctreeGridDataPointsFilter stand-in, samplingMethod 0) ----
+// lattice anchored at the bounding-box minimum; voxel index floor((p - lo) / edge) per axis, 21 bits
+// each; the representative of a voxel is its point of smallest original index (order independent:
+// atomicMin), so the keep mask is a function of the input alone.
+__device__ __forceinline__ unsigned fkey(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float fkey_inv(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+__global__ __launch_bounds__(256) void bbox_min_kernel(const float4* __restrict__ in, int64_t n, unsigned* __restrict__ lo_keys)
+{
+    __shared__ unsigned sh[3][4];
+    unsigned kx = 0xffffffffu, ky = 0xffffffffu, kz = 0xffffffffu;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float4 p = in[i];
+        kx = min(kx, fkey(p.x)); ky = min(ky, fkey(p.y)); kz = min(kz, fkey(p.z));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        kx = min(kx, (unsigned)__shfl_xor((int)kx, off, 64));
+        ky = min(ky, (unsigned)__shfl_xor((int)ky, off, 64));
+        kz = min(kz, (unsigned)__shfl_xor((int)kz, off, 64));
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { sh[0][w] = kx; sh[1][w] = ky; sh[2][w] = kz; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const unsigned v = min(min(sh[threadIdx.x][0], sh[threadIdx.x][1]), min(sh[threadIdx.x][2], sh[threadIdx.x][3]));
+        atomicMin(&lo_keys[threadIdx.x], v);
+    }
+}
+
+__device__ __forceinline__ unsigned long long voxel_key(const float4 p, const unsigned* __restrict__ lo_keys, float edge)
+{
+    const float lo[3] = {fkey_inv(lo_keys[0]), fkey_inv(lo_keys[1]), fkey_inv(lo_keys[2])};
+    const float c[3] = {p.x, p.y, p.z};
+    unsigned long long key = 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float v = fminf(floorf((c[r] - lo[r]) / edge), 2097151.0f);
+        key = key * 2097152ull + (unsigned long long)v;
+    }
+    return key;
+}
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x)
+{
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void voxel_insert_kernel(const float4* __restrict__ in, int64_t n, const unsigned* __restrict__ lo_keys,
+                                                           float edge, unsigned long long* __restrict__ tkeys,
+                                                           unsigned* __restrict__ tvals, unsigned long long mask,
+                                                           unsigned* __restrict__ slot_of)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long key = voxel_key(in[i], lo_keys, edge);
+    unsigned long long slot = mix64(key) & mask;
+    for (;;) {
+        const unsigned long long prev = atomicCAS(&tkeys[slot], ~0ull, key);
+        if (prev == ~0ull || prev == key) break;
+        slot = (slot + 1) & mask;
+    }
+    atomicMin(&tvals[slot], (unsigned)i);
+    slot_of[i] = (unsigned)slot;
+}
+
+__global__ __launch_bounds__(256) void voxel_keep_kernel(int64_t n, const unsigned* __restrict__ tvals, const unsigned* __restrict__ slot_of,
+                                                         uint8_t* __restrict__ keep)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    keep[i] = tvals[slot_of[i]] == (unsigned)i ? 1 : 0;
+}
+
 } // namespace
 
 // helper: a private handle on the same device/stream used to index an arbitrary cloud without
@@ -259,6 +334,39 @@ icpmi_status ops_point_distance_keep(icpmi_ctx* c, const float* map4, int64_t m,
     if (e == hipSuccess) e = hipMemcpyAsync(keep, d_keep, (size_t)n, hipMemcpyDeviceToHost, tc->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(tc->stream);
     hipFree(d_keep);
+    HIP_TRY(c, e);
+    return ICPMI_OK;
+}
+
+icpmi_status ops_voxel_keep_first(icpmi_ctx* c, const float* in4, int64_t n, float edge, uint8_t* keep)
+{
+    if (n == 0) return ICPMI_OK;
+    if (n > 0xfffffff0ll) { c->last_error = "voxel_keep_first: too many points"; return ICPMI_ERR_UNSUPPORTED; }
+    unsigned long long cap = 1024;
+    while (cap < (unsigned long long)n * 2ull) cap <<= 1;
+    float4* d_in = nullptr; unsigned long long* d_keys = nullptr; unsigned* d_vals = nullptr; unsigned* d_slot = nullptr;
+    unsigned* d_lo = nullptr; uint8_t* d_keep = nullptr;
+    hipError_t e = hipMalloc((void**)&d_in, (size_t)n * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_keys, (size_t)cap * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_vals, (size_t)cap * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_slot, (size_t)n * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_lo, 4 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_keep, (size_t)n);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, in4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_keys, 0xff, (size_t)cap * sizeof(unsigned long long), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_vals, 0xff, (size_t)cap * sizeof(unsigned), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_lo, 0xff, 4 * sizeof(unsigned), c->stream);
+    if (e == hipSuccess) {
+        const int blocks = (int)((n + 255) / 256);
+        const int rb = blocks < 1024 ? blocks : 1024;
+        hipLaunchKernelGGL(bbox_min_kernel, dim3(rb), dim3(256), 0, c->stream, d_in, n, d_lo);
+        hipLaunchKernelGGL(voxel_insert_kernel, dim3(blocks), dim3(256), 0, c->stream, d_in, n, d_lo, edge, d_keys, d_vals, cap - 1, d_slot);
+        hipLaunchKernelGGL(voxel_keep_kernel, dim3(blocks), dim3(256), 0, c->stream, n, d_vals, d_slot, d_keep);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(keep, d_keep, (size_t)n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d_in); hipFree(d_keys); hipFree(d_vals); hipFree(d_slot); hipFree(d_lo); hipFree(d_keep);
     HIP_TRY(c, e);
     return ICPMI_OK;
 }

@@ -291,9 +291,16 @@ struct RandomSamplingFilter : DataPointsFilter {
 // (SURVEY.md B.9).  samplingMethod: 0 first point, 1 random point, 2 centroid, 3 medoid.
 struct VoxelGridFilter : DataPointsFilter {
     float maxSize = 0.f; int method = 0; size_t maxPointByNode = 1;
+    icpmi_handle h = nullptr;
     void inPlaceFilter(DataPoints& c) const override {
         const size_t n = c.getNbPoints();
         if (n == 0 || !(maxSize > 0.f)) return;
+        if (method == 0 && h) { // first point per voxel: one hash pass on the GPU (same lattice as below)
+            std::vector<uint8_t> keep(n, 0);
+            GpuICPSequence::check(h, icpmi_voxel_keep_first(h, c.features.data(), (int64_t)n, maxSize, keep.data()));
+            c.keepOnly(keep);
+            return;
+        }
         float lo[3] = {c.col(0)[0], c.col(0)[1], c.col(0)[2]};
         for (size_t i = 1; i < n; ++i) for (int r = 0; r < 3; ++r) lo[r] = std::min(lo[r], c.col(i)[r]);
         struct Cell { size_t first; size_t count; double sum[3]; size_t pick; };
@@ -400,6 +407,7 @@ std::shared_ptr<DataPointsFilter> createDataPointsFilter(const std::string& name
         auto f = std::make_shared<VoxelGridFilter>();
         f->maxSize = getf(p, "maxSizeByNode", 0.f); f->method = geti(p, "samplingMethod", 0);
         f->maxPointByNode = (size_t)geti(p, "maxPointByNode", 1);
+        f->h = ctx;
         return f;
     }
     throw InvalidParameter("unknown DataPointsFilter " + name);

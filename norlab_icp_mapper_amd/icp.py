@@ -330,6 +330,14 @@ class ICPSequence:
         self._check(self._lib.icpmi_point_distance_keep(self._h, m.ctypes.data, m.shape[0], i.ctypes.data, i.shape[0], min_dist, keep.ctypes.data))
         return keep.astype(bool)
 
+    def voxelKeepFirst(self, cloud, edge):
+        """Lattice stand-in of OctreeGridDataPointsFilter{maxSizeByNode: edge, samplingMethod: 0}
+        (OctreeMapperModule.cpp:35-39): mask of the first point of every occupied voxel."""
+        c = _f32c(cloud, 4)
+        keep = np.empty(c.shape[0], dtype=np.uint8)
+        self._check(self._lib.icpmi_voxel_keep_first(self._h, c.ctypes.data, c.shape[0], edge, keep.ctypes.data))
+        return keep.astype(bool)
+
     def binCells(self, cloud, cell_size=20.0):
         c = _f32c(cloud, 4)
         out = np.empty((c.shape[0], 3), dtype=np.int32)

@@ -909,3 +909,36 @@ void orc_cell_ids(const float* pts4, int64_t n, float cell_size, int32_t* ijk3)
     for (int64_t i = 0; i < n; ++i)
         for (int r = 0; r < 3; ++r) ijk3[3 * i + r] = (int32_t)floorf(pts4[4 * i + r] / cell_size);
 }
+
+/* OctreeMapperModule decimation (OctreeMapperModule.cpp:35-39 -> OctreeGridDataPointsFilter, samplingMethod 0)
+ * as a lattice: voxel floor((p - lo) / edge) per axis (21 bits each), lo = bounding-box minimum; the
+ * representative of a voxel is its first point.  Sort-based on purpose (the device side hashes). */
+typedef struct { uint64_t key; int64_t idx; } orc_vox_item;
+static int orc_vox_cmp(const void* a, const void* b)
+{
+    const orc_vox_item* x = (const orc_vox_item*)a; const orc_vox_item* y = (const orc_vox_item*)b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
+}
+void orc_voxel_keep_first(const float* in4, int64_t n, float edge, uint8_t* keep)
+{
+    if (n <= 0) return;
+    float lo[3] = {in4[0], in4[1], in4[2]};
+    for (int64_t i = 1; i < n; ++i)
+        for (int r = 0; r < 3; ++r) if (in4[4 * i + r] < lo[r]) lo[r] = in4[4 * i + r];
+    orc_vox_item* it = (orc_vox_item*)malloc((size_t)n * sizeof(orc_vox_item));
+    for (int64_t i = 0; i < n; ++i) {
+        uint64_t key = 0;
+        for (int r = 0; r < 3; ++r) {
+            float v = floorf((in4[4 * i + r] - lo[r]) / edge);
+            if (v > 2097151.0f) v = 2097151.0f;
+            key = key * 2097152ull + (uint64_t)v;
+        }
+        it[i].key = key; it[i].idx = i;
+        keep[i] = 0;
+    }
+    qsort(it, (size_t)n, sizeof(orc_vox_item), orc_vox_cmp);
+    for (int64_t i = 0; i < n; ++i)
+        if (i == 0 || it[i].key != it[i - 1].key) keep[it[i].idx] = 1;
+    free(it);
+}

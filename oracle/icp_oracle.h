@@ -148,6 +148,9 @@ void orc_point_distance_keep(const float* map4, int64_t m, const float* in4, int
                              uint8_t* keep, int nthreads);
 /* cell index of Map::unloadCells (Map.cpp:206-209,232-235): floor(x / 20.0f) per axis */
 void orc_cell_ids(const float* pts4, int64_t n, float cell_size, int32_t* ijk3);
+/* lattice stand-in of OctreeGridDataPointsFilter{maxSizeByNode: edge, samplingMethod: 0} (OctreeMapperModule.cpp:35-39):
+ * keep[i] = 1 iff i is the first point of its voxel floor((p - bbox_min) / edge) */
+void orc_voxel_keep_first(const float* in4, int64_t n, float edge, uint8_t* keep);
 
 #ifdef __cplusplus
 }

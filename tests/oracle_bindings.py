@@ -70,6 +70,7 @@ def load():
     lib.orc_surface_normals.argtypes = [_P, C.c_int64, C.c_int, _P, C.c_int]
     lib.orc_point_distance_keep.argtypes = [_P, C.c_int64, _P, C.c_int64, C.c_float, _P, C.c_int]
     lib.orc_cell_ids.argtypes = [_P, C.c_int64, C.c_float, _P]
+    lib.orc_voxel_keep_first.argtypes = [_P, C.c_int64, C.c_float, _P]
     _lib = lib
     return lib
 
@@ -209,3 +210,9 @@ def cell_ids(cloud, cell_size=20.0):
     lib = load(); c = _f32(cloud); out = np.empty((c.shape[0], 3), dtype=np.int32)
     lib.orc_cell_ids(c.ctypes.data, c.shape[0], cell_size, out.ctypes.data)
     return out
+
+
+def voxel_keep_first(cloud, edge):
+    lib = load(); c = _f32(cloud); keep = np.zeros(c.shape[0], dtype=np.uint8)
+    lib.orc_voxel_keep_first(c.ctypes.data, c.shape[0], edge, keep.ctypes.data)
+    return keep.astype(bool)

@@ -271,6 +271,27 @@ def _bundled_input_filters(xyz):
     return out
 
 
+def test_voxel_keep_first_exact(amd, oracle, small_scene):
+    icp = amd.ICPSequence(minimizer=0)
+    rng = np.random.default_rng(5)
+    cloud = small_scene["map"].copy()
+    cloud = np.concatenate([cloud, cloud[:500]])          # exact duplicates share a voxel
+    cloud[:, :3] += rng.normal(0, 1e-3, (cloud.shape[0], 3)).astype(np.float32) * (np.arange(cloud.shape[0]) % 2)[:, None]
+    for edge in (0.15, 1.0, 7.5, 1e6):
+        keep = icp.voxelKeepFirst(cloud, edge)
+        ref = oracle.voxel_keep_first(cloud, edge)
+        assert np.array_equal(keep, ref), edge
+        # properties: one survivor per occupied voxel, and it is the first of that voxel
+        lo = cloud[:, :3].min(0)
+        ijk = np.minimum(np.floor((cloud[:, :3] - lo) / np.float32(edge)), 2097151).astype(np.int64)
+        key = (ijk[:, 0] * 2097152 + ijk[:, 1]) * 2097152 + ijk[:, 2]
+        _, first = np.unique(key, return_index=True)
+        assert np.array_equal(np.flatnonzero(keep), np.sort(first))
+    assert icp.voxelKeepFirst(cloud[:0], 0.5).shape == (0,)
+    with pytest.raises(amd.InvalidParameter):
+        icp.voxelKeepFirst(cloud, 0.0)
+
+
 @pytest.fixture(scope="module")
 def bundled():
     import os

@@ -193,3 +193,16 @@ def test_icp_sequence_semantics(oracle, small_scene):
     icp_b.setMap(sc["map"], sc["normals"])
     err, _ = icp_b(sc["scan"])
     assert err == 3
+
+
+def test_voxel_keep_first(oracle):
+    rng = np.random.default_rng(11)
+    c = np.ones((3000, 4), dtype=np.float32)
+    c[:, :3] = rng.uniform(-5, 5, (3000, 3)).astype(np.float32)
+    for edge in (0.5, 2.0):
+        keep = oracle.voxel_keep_first(c, edge)
+        lo = c[:, :3].min(0)
+        ijk = np.floor((c[:, :3] - lo) / np.float32(edge)).astype(np.int64)
+        key = (ijk[:, 0] * 2097152 + ijk[:, 1]) * 2097152 + ijk[:, 2]
+        _, first = np.unique(key, return_index=True)
+        assert np.array_equal(np.flatnonzero(keep), np.sort(first))
