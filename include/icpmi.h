@@ -191,6 +191,23 @@ icpmi_status icpmi_point_distance_keep(icpmi_handle h, const float* map4, int64_
  * with lo the bounding-box minimum; keep[i] = 1 iff i is the smallest index of its voxel. */
 icpmi_status icpmi_voxel_keep_first(icpmi_handle h, const float* in4, int64_t n, float edge, uint8_t* keep);
 
+/* `DynamicPointsMapperModule::inPlaceUpdateMap` (DynamicPointsMapperModule.cpp:34-172; parameters :6-13).
+ * `to_sensor` = pose^-1 (col-major 4x4, :51,57); input4 / map4 in the map frame; map_normals3 = descriptor `normals`
+ * of the map; prob_dynamic (m floats) = descriptor `probabilityDynamic` of the map, updated in place for every
+ * map point within sensor_max_range that has an input beam within 2 * beam_half_angle in (elevation, azimuth). */
+typedef struct icpmi_dynpts_params {
+    float threshold_dynamic; /* 0.6  */
+    float alpha;             /* 0.8  */
+    float beta;              /* 0.99 */
+    float beam_half_angle;   /* 0.01 rad */
+    float epsilon_a;         /* 0.01 */
+    float epsilon_d;         /* 0.01 m */
+    float sensor_max_range;  /* 200 m */
+} icpmi_dynpts_params;
+icpmi_status icpmi_dynamic_points_update(icpmi_handle h, const icpmi_dynpts_params* prm, const float to_sensor[16],
+                                         const float* input4, int64_t n, const float* map4, const float* map_normals3,
+                                         int64_t m, float* prob_dynamic);
+
 /* `Map::unloadCells` binning (Map.cpp:206-209,232-235): ijk3[3 i + r] = floor(p_r / cell_size). */
 icpmi_status icpmi_bin_cells(icpmi_handle h, const float* pts4, int64_t n, float cell_size, int32_t* ijk3);
 

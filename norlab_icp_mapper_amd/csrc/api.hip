@@ -391,6 +391,17 @@ icpmi_status icpmi_voxel_keep_first(icpmi_handle h, const float* in4, int64_t n,
     return ops_voxel_keep_first(h, in4, n, edge, keep);
 }
 
+icpmi_status icpmi_dynamic_points_update(icpmi_handle h, const icpmi_dynpts_params* prm, const float to_sensor[16], const float* in4,
+                                         int64_t n, const float* map4, const float* map_normals3, int64_t m, float* prob_dynamic)
+{
+    CHECK_H(h);
+    if (!prm || !to_sensor || n < 0 || m < 0 || (n > 0 && !in4) || (m > 0 && (!map4 || !map_normals3 || !prob_dynamic))) {
+        h->last_error = "dynamic_points_update: bad arguments"; return ICPMI_ERR_INVALID_ARG;
+    }
+    if (!(prm->beam_half_angle > 0.f)) { h->last_error = "InvalidParameter: beamHalfAngle must be > 0"; return ICPMI_ERR_INVALID_ARG; }
+    return ops_dynamic_points_update(h, prm, to_sensor, in4, n, map4, map_normals3, m, prob_dynamic);
+}
+
 icpmi_status icpmi_bin_cells(icpmi_handle h, const float* pts4, int64_t n, float cell_size, int32_t* ijk3)
 {
     CHECK_H(h);

@@ -241,6 +241,8 @@ LoopCfg make_loop_cfg(const icpmi_ctx* c, int fixed_iterations);
 icpmi_status ops_transform(icpmi_ctx* c, const float T[16], const float* in4, int64_t n, float* out4,
                            const float* in_n3, float* out_n3);
 icpmi_status ops_surface_normals(icpmi_ctx* c, const float* pts4, int64_t m, int knn, float* normals3);
+icpmi_status ops_dynamic_points_update(icpmi_ctx* c, const icpmi_dynpts_params* prm, const float to_sensor[16], const float* in4, int64_t n,
+                                       const float* map4, const float* map_normals3, int64_t m, float* prob);
 icpmi_status ops_voxel_keep_first(icpmi_ctx* c, const float* in4, int64_t n, float edge, uint8_t* keep);
 icpmi_status ops_point_distance_keep(icpmi_ctx* c, const float* map4, int64_t m, const float* in4, int64_t n,
                                      float min_dist, uint8_t* keep);

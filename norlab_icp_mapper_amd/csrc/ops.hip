@@ -196,6 +196,134 @@ __global__ __launch_bounds__(256) void voxel_keep_kernel(int64_t n, const unsign
     keep[i] = tvals[slot_of[i]] == (unsigned)i ? 1 : 0;
 }
 
+// ---- DynamicPointsMapperModule::inPlaceUpdateMap (DynamicPointsMapperModule.cpp:34-172) -------------------
+// Beams = input points in the sensor frame as (elevation, azimuth); every in-range map point looks up
+// its angularly nearest beam within 2 * beamHalfAngle (the reference builds a 2-D kd-tree per call,
+// :75-78; here: a bucket grid of that cell size built by counting sort, 3 x 3 cells per query, ties to
+// the smallest beam index) and updates its probability of being dynamic (:97-148).
+// asin / atan2 go through double and are rounded once (shared with the oracle: libm and the device
+// library then agree bit for bit); everything else is the reference's float arithmetic, with the
+// sub-expressions it writes with a double literal (`1.`) evaluated in double.
+struct DynGrid { float cell; int ne, na; };
+
+__device__ __forceinline__ void to_spherical(float x, float y, float z, float& radius, float& elev, float& azim)
+{
+    radius = sqrtf(x * x + y * y + z * z);
+    elev = (float)asin((double)(z / radius));
+    azim = (float)atan2((double)y, (double)x);
+}
+
+__device__ __forceinline__ int dyn_ecell(const DynGrid& g, float e)
+{
+    const int v = (int)floorf((e + 1.5707963267949f) / g.cell);
+    return v < 0 ? 0 : (v > g.ne - 1 ? g.ne - 1 : v);
+}
+__device__ __forceinline__ int dyn_acell(const DynGrid& g, float a)
+{
+    const int v = (int)floorf((a + 3.14159265358979f) / g.cell);
+    return v < 0 ? 0 : (v > g.na - 1 ? g.na - 1 : v);
+}
+
+// pass 1: beams to the sensor frame + angles + cell counts
+__global__ __launch_bounds__(256) void dyn_beams_kernel(const float4* __restrict__ in, int64_t n, const float* __restrict__ T, DynGrid g,
+                                                        float4* __restrict__ beam_xyzn, float2* __restrict__ beam_ang,
+                                                        unsigned* __restrict__ keys, unsigned* __restrict__ count)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = in[i];
+    const float3 o = xf_point(T, p.x, p.y, p.z, p.w);
+    float radius, elev, azim;
+    to_spherical(o.x, o.y, o.z, radius, elev, azim);
+    beam_xyzn[i] = make_float4(o.x, o.y, o.z, radius);
+    beam_ang[i] = make_float2(elev, azim);
+    const unsigned key = (unsigned)(dyn_ecell(g, elev) * g.na + dyn_acell(g, azim));
+    keys[i] = key;
+    atomicAdd(&count[key], 1u);
+}
+
+__global__ __launch_bounds__(256) void dyn_scatter_kernel(int64_t n, const unsigned* __restrict__ keys, const unsigned* __restrict__ start,
+                                                          unsigned* __restrict__ fill, unsigned* __restrict__ order)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned key = keys[i];
+    order[start[key] + atomicAdd(&fill[key], 1u)] = (unsigned)i;
+}
+
+struct DynPrm { float threshold_dynamic, alpha, beta, beam_half_angle, epsilon_a, epsilon_d, sensor_max_range; };
+
+__global__ __launch_bounds__(256) void dyn_update_kernel(const float4* __restrict__ map, const float* __restrict__ normals3, int64_t m,
+                                                         const float* __restrict__ T, DynGrid g, DynPrm prm,
+                                                         const float4* __restrict__ beam_xyzn, const float2* __restrict__ beam_ang,
+                                                         const unsigned* __restrict__ start, const unsigned* __restrict__ order,
+                                                         float* __restrict__ prob)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const float eps = 0.0001f;
+    const float4 mpt = map[i];
+    const float3 mp = xf_point(T, mpt.x, mpt.y, mpt.z, mpt.w);
+    const float mapNorm = sqrtf(mp.x * mp.x + mp.y * mp.y + mp.z * mp.z);
+    if (!(mapNorm < prm.sensor_max_range)) return; // range cull (:60-69)
+    float radius, qe, qa;
+    to_spherical(mp.x, mp.y, mp.z, radius, qe, qa);
+    const int ce = dyn_ecell(g, qe), ca = dyn_acell(g, qa);
+    const float r2 = g.cell * g.cell;
+    float bd = INFINITY;
+    int best = -1;
+    for (int de = -1; de <= 1; ++de)
+        for (int da = -1; da <= 1; ++da) {
+            const int e = ce + de, a = ca + da;
+            if (e < 0 || e >= g.ne || a < 0 || a >= g.na) continue;
+            const unsigned k = (unsigned)(e * g.na + a);
+            for (unsigned j = start[k]; j < start[k + 1]; ++j) {
+                const int b = (int)order[j];
+                const float2 ang = beam_ang[b];
+                const float d0 = qe - ang.x, d1 = qa - ang.y;
+                const float d = d0 * d0 + d1 * d1;
+                if (d <= r2 && (d < bd || (d == bd && b < best))) { bd = d; best = b; }
+            }
+        }
+    if (best < 0) return; // no beam within 2 * beamHalfAngle
+
+    const float4 ip = beam_xyzn[best];
+    const float inputNorm = ip.w;
+    const float dx = ip.x - mp.x, dy = ip.y - mp.y, dz = ip.z - mp.z;
+    const float delta = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float d_max = prm.epsilon_a * inputNorm;
+    const float n0 = normals3[3 * i], n1 = normals3[3 * i + 1], n2 = normals3[3 * i + 2];
+    const float nx = fmaf(T[8], n2, fmaf(T[4], n1, T[0] * n0));
+    const float ny = fmaf(T[9], n2, fmaf(T[5], n1, T[1] * n0));
+    const float nz = fmaf(T[10], n2, fmaf(T[6], n1, T[2] * n0));
+    const float ndot = (nx * mp.x + ny * mp.y + nz * mp.z) / mapNorm;
+
+    const float w_v = (float)(eps + (1. - eps) * fabs((double)ndot));
+    const float w_d1 = (float)(eps + (1. - eps) * (1. - sqrtf(bd) / (2 * prm.beam_half_angle)));
+    const float offset = delta - prm.epsilon_d;
+    float w_d2 = 1.f;
+    if (delta < prm.epsilon_d || mapNorm > inputNorm) w_d2 = eps;
+    else if (offset < d_max) w_d2 = eps + (1 - eps) * offset / d_max;
+    float w_p2 = eps;
+    if (delta < prm.epsilon_d) w_p2 = 1.f;
+    else if (offset < d_max) w_p2 = (float)(eps + (1. - eps) * (1. - offset / d_max));
+
+    if ((inputNorm + prm.epsilon_d + d_max) >= mapNorm) {
+        const float lastDyn = prob[i];
+        const float c1 = 1 - (w_v * w_d1);
+        const float c2 = w_v * w_d1;
+        float probDynamic, probStatic;
+        if (lastDyn < prm.threshold_dynamic) {
+            probDynamic = c1 * lastDyn + c2 * w_d2 * ((1 - prm.alpha) * (1 - lastDyn) + prm.beta * lastDyn);
+            probStatic = c1 * (1 - lastDyn) + c2 * w_p2 * (prm.alpha * (1 - lastDyn) + (1 - prm.beta) * lastDyn);
+        } else { // latched: once dynamic, always dynamic
+            probDynamic = 1 - eps;
+            probStatic = eps;
+        }
+        prob[i] = probDynamic / (probDynamic + probStatic);
+    }
+}
+
 } // namespace
 
 // helper: a private handle on the same device/stream used to index an arbitrary cloud without
@@ -367,6 +495,57 @@ icpmi_status ops_voxel_keep_first(icpmi_ctx* c, const float* in4, int64_t n, flo
     if (e == hipSuccess) e = hipMemcpyAsync(keep, d_keep, (size_t)n, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     hipFree(d_in); hipFree(d_keys); hipFree(d_vals); hipFree(d_slot); hipFree(d_lo); hipFree(d_keep);
+    HIP_TRY(c, e);
+    return ICPMI_OK;
+}
+
+icpmi_status ops_dynamic_points_update(icpmi_ctx* c, const icpmi_dynpts_params* prm, const float to_sensor[16], const float* in4, int64_t n,
+                                       const float* map4, const float* map_normals3, int64_t m, float* prob)
+{
+    if (n == 0 || m == 0) return ICPMI_OK; // "if (beams.empty()) return"
+    DynGrid g;
+    g.cell = 2 * prm->beam_half_angle;
+    g.ne = (int)floorf(3.14159265358979f / g.cell) + 2;
+    g.na = (int)floorf(6.28318530717959f / g.cell) + 2;
+    const int64_t ncells = (int64_t)g.ne * g.na;
+    if (ncells > (1ll << 28)) { c->last_error = "dynamic_points_update: beamHalfAngle too small for the angular grid"; return ICPMI_ERR_UNSUPPORTED; }
+    DynPrm dp = {prm->threshold_dynamic, prm->alpha, prm->beta, prm->beam_half_angle, prm->epsilon_a, prm->epsilon_d, prm->sensor_max_range};
+    float* d_T = nullptr; float4 *d_in = nullptr, *d_map = nullptr, *d_bx = nullptr; float2* d_ba = nullptr; float *d_nrm = nullptr, *d_prob = nullptr;
+    unsigned *d_keys = nullptr, *d_start = nullptr, *d_fill = nullptr, *d_order = nullptr;
+    hipError_t e = hipMalloc((void**)&d_T, 16 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_in, (size_t)n * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_bx, (size_t)n * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_ba, (size_t)n * sizeof(float2));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_keys, (size_t)n * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_order, (size_t)n * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_start, ((size_t)ncells + 2) * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_fill, (size_t)ncells * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_map, (size_t)m * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_nrm, (size_t)m * 3 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_prob, (size_t)m * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_T, to_sensor, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, in4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_map, map4, (size_t)m * sizeof(float4), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_nrm, map_normals3, (size_t)m * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_prob, prob, (size_t)m * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_start, 0, ((size_t)ncells + 2) * sizeof(unsigned), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_fill, 0, (size_t)ncells * sizeof(unsigned), c->stream);
+    icpmi_status st = ICPMI_OK;
+    if (e == hipSuccess) {
+        const int nb = (int)((n + 255) / 256), mb = (int)((m + 255) / 256);
+        hipLaunchKernelGGL(dyn_beams_kernel, dim3(nb), dim3(256), 0, c->stream, d_in, n, d_T, g, d_bx, d_ba, d_keys, d_start);
+        st = device_exclusive_scan(c, d_start, (int)ncells, (unsigned)n);
+        if (st == ICPMI_OK) {
+            hipLaunchKernelGGL(dyn_scatter_kernel, dim3(nb), dim3(256), 0, c->stream, n, d_keys, d_start, d_fill, d_order);
+            hipLaunchKernelGGL(dyn_update_kernel, dim3(mb), dim3(256), 0, c->stream, d_map, d_nrm, m, d_T, g, dp, d_bx, d_ba, d_start, d_order, d_prob);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpyAsync(prob, d_prob, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+        }
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d_T); hipFree(d_in); hipFree(d_bx); hipFree(d_ba); hipFree(d_keys); hipFree(d_order); hipFree(d_start); hipFree(d_fill);
+    hipFree(d_map); hipFree(d_nrm); hipFree(d_prob);
+    if (st != ICPMI_OK) return st;
     HIP_TRY(c, e);
     return ICPMI_OK;
 }

@@ -60,7 +60,7 @@ public:
     void inPlaceUpdateMap(const DataPoints& input, DataPoints& map, const Mat4& pose) override;
     float thresholdDynamic = 0.6f, alpha = 0.8f, beta = 0.99f, beamHalfAngle = 0.01f, epsilonA = 0.01f, epsilonD = 0.01f, sensorMaxRange = 200.f;
 private:
-    RigidTransformation transformation;
+    icpmi_handle h;
 };
 
 // DEF_REGISTRAR(MapperModule) / ADD_TO_REGISTRAR / createFromYAML (Mapper.h:69, Mapper.cpp:9-13,169)

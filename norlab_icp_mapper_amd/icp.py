@@ -338,6 +338,20 @@ class ICPSequence:
         self._check(self._lib.icpmi_voxel_keep_first(self._h, c.ctypes.data, c.shape[0], edge, keep.ctypes.data))
         return keep.astype(bool)
 
+    def dynamicPointsUpdate(self, to_sensor, input_cloud, map_cloud, map_normals, prob_dynamic, threshold_dynamic=0.6, alpha=0.8,
+                            beta=0.99, beam_half_angle=0.01, epsilon_a=0.01, epsilon_d=0.01, sensor_max_range=200.0):
+        """DynamicPointsMapperModule::inPlaceUpdateMap (DynamicPointsMapperModule.cpp:34-172): returns the
+        updated `probabilityDynamic` of the map.  `to_sensor` = pose^-1 (row-major 4x4 numpy)."""
+        prm = np.array([threshold_dynamic, alpha, beta, beam_half_angle, epsilon_a, epsilon_d, sensor_max_range], dtype=np.float32)
+        T = _T_to_c(to_sensor)
+        i = _f32c(input_cloud, 4); m = _f32c(map_cloud, 4); nn = _f32c(map_normals, 3)
+        out = np.ascontiguousarray(prob_dynamic, dtype=np.float32).copy()
+        if out.shape[0] != m.shape[0] or nn.shape[0] != m.shape[0]:
+            raise InvalidParameter("dynamicPointsUpdate: map, normals and probabilities must have the same length")
+        self._check(self._lib.icpmi_dynamic_points_update(self._h, prm.ctypes.data, T.ctypes.data,
+                                                          i.ctypes.data, i.shape[0], m.ctypes.data, nn.ctypes.data, m.shape[0], out.ctypes.data))
+        return out
+
     def binCells(self, cloud, cell_size=20.0):
         c = _f32c(cloud, 4)
         out = np.empty((c.shape[0], 3), dtype=np.int32)

@@ -942,3 +942,83 @@ void orc_voxel_keep_first(const float* in4, int64_t n, float edge, uint8_t* keep
         if (i == 0 || it[i].key != it[i - 1].key) keep[it[i].idx] = 1;
     free(it);
 }
+
+/* DynamicPointsMapperModule::inPlaceUpdateMap (DynamicPointsMapperModule.cpp:34-172), brute-force angular
+ * nearest beam (the reference: 2-D kd-tree, k = 1, radius 2 * beamHalfAngle, :75-78).  Ties on equal angular
+ * distance go to the smallest beam index; asin / atan2 through double, rounded once (shared with the device). */
+static void orc_xf(const float* T, const float* p, float* o)
+{
+    for (int r = 0; r < 3; ++r) o[r] = fmaf(T[12 + r], p[3], fmaf(T[8 + r], p[2], fmaf(T[4 + r], p[1], T[r] * p[0])));
+}
+void orc_dynamic_points_update(const float prm[7], const float* to_sensor, const float* in4, int64_t n, const float* map4,
+                               const float* map_normals3, int64_t m, float* prob, int nthreads)
+{
+    const float thresholdDynamic = prm[0], alpha = prm[1], beta = prm[2], beamHalfAngle = prm[3], epsilonA = prm[4], epsilonD = prm[5],
+                sensorMaxRange = prm[6];
+    const float eps = 0.0001f;
+    if (n <= 0 || m <= 0) return;
+    float* bx = (float*)malloc((size_t)n * 4 * sizeof(float));
+    float* be = (float*)malloc((size_t)n * sizeof(float));
+    float* ba = (float*)malloc((size_t)n * sizeof(float));
+    for (int64_t i = 0; i < n; ++i) {
+        float o[3];
+        orc_xf(to_sensor, in4 + 4 * i, o);
+        const float radius = sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2]);
+        bx[4 * i] = o[0]; bx[4 * i + 1] = o[1]; bx[4 * i + 2] = o[2]; bx[4 * i + 3] = radius;
+        be[i] = (float)asin((double)(o[2] / radius));
+        ba[i] = (float)atan2((double)o[1], (double)o[0]);
+    }
+    const float cell = 2 * beamHalfAngle;
+    const float r2 = cell * cell;
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static)
+    for (int64_t i = 0; i < m; ++i) {
+        float mp[3];
+        orc_xf(to_sensor, map4 + 4 * i, mp);
+        const float mapNorm = sqrtf(mp[0] * mp[0] + mp[1] * mp[1] + mp[2] * mp[2]);
+        if (!(mapNorm < sensorMaxRange)) continue;
+        const float qe = (float)asin((double)(mp[2] / mapNorm));
+        const float qa = (float)atan2((double)mp[1], (double)mp[0]);
+        float bd = INFINITY;
+        int64_t best = -1;
+        for (int64_t b = 0; b < n; ++b) {
+            const float d0 = qe - be[b], d1 = qa - ba[b];
+            const float d = d0 * d0 + d1 * d1;
+            if (d <= r2 && d < bd) { bd = d; best = b; }
+        }
+        if (best < 0) continue;
+        const float* ip = bx + 4 * best;
+        const float inputNorm = ip[3];
+        const float dx = ip[0] - mp[0], dy = ip[1] - mp[1], dz = ip[2] - mp[2];
+        const float delta = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float d_max = epsilonA * inputNorm;
+        const float* n3 = map_normals3 + 3 * i;
+        const float nx = fmaf(to_sensor[8], n3[2], fmaf(to_sensor[4], n3[1], to_sensor[0] * n3[0]));
+        const float ny = fmaf(to_sensor[9], n3[2], fmaf(to_sensor[5], n3[1], to_sensor[1] * n3[0]));
+        const float nz = fmaf(to_sensor[10], n3[2], fmaf(to_sensor[6], n3[1], to_sensor[2] * n3[0]));
+        const float ndot = (nx * mp[0] + ny * mp[1] + nz * mp[2]) / mapNorm;
+        const float w_v = (float)(eps + (1. - eps) * fabs((double)ndot));
+        const float w_d1 = (float)(eps + (1. - eps) * (1. - sqrtf(bd) / (2 * beamHalfAngle)));
+        const float offset = delta - epsilonD;
+        float w_d2 = 1.f;
+        if (delta < epsilonD || mapNorm > inputNorm) w_d2 = eps;
+        else if (offset < d_max) w_d2 = eps + (1 - eps) * offset / d_max;
+        float w_p2 = eps;
+        if (delta < epsilonD) w_p2 = 1.f;
+        else if (offset < d_max) w_p2 = (float)(eps + (1. - eps) * (1. - offset / d_max));
+        if ((inputNorm + epsilonD + d_max) >= mapNorm) {
+            const float lastDyn = prob[i];
+            const float c1 = 1 - (w_v * w_d1);
+            const float c2 = w_v * w_d1;
+            float probDynamic, probStatic;
+            if (lastDyn < thresholdDynamic) {
+                probDynamic = c1 * lastDyn + c2 * w_d2 * ((1 - alpha) * (1 - lastDyn) + beta * lastDyn);
+                probStatic = c1 * (1 - lastDyn) + c2 * w_p2 * (alpha * (1 - lastDyn) + (1 - beta) * lastDyn);
+            } else {
+                probDynamic = 1 - eps;
+                probStatic = eps;
+            }
+            prob[i] = probDynamic / (probDynamic + probStatic);
+        }
+    }
+    free(bx); free(be); free(ba);
+}

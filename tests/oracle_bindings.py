@@ -71,6 +71,7 @@ def load():
     lib.orc_point_distance_keep.argtypes = [_P, C.c_int64, _P, C.c_int64, C.c_float, _P, C.c_int]
     lib.orc_cell_ids.argtypes = [_P, C.c_int64, C.c_float, _P]
     lib.orc_voxel_keep_first.argtypes = [_P, C.c_int64, C.c_float, _P]
+    lib.orc_dynamic_points_update.argtypes = [_P, _P, _P, C.c_int64, _P, _P, C.c_int64, _P, C.c_int]
     _lib = lib
     return lib
 
@@ -216,3 +217,19 @@ def voxel_keep_first(cloud, edge):
     lib = load(); c = _f32(cloud); keep = np.zeros(c.shape[0], dtype=np.uint8)
     lib.orc_voxel_keep_first(c.ctypes.data, c.shape[0], edge, keep.ctypes.data)
     return keep.astype(bool)
+
+
+DYNPTS_DEFAULTS = dict(threshold_dynamic=0.6, alpha=0.8, beta=0.99, beam_half_angle=0.01, epsilon_a=0.01, epsilon_d=0.01,
+                       sensor_max_range=200.0)
+
+
+def dynamic_points_update(to_sensor, input_cloud, map_cloud, map_normals, prob, nthreads=1, **params):
+    lib = load()
+    prm = dict(DYNPTS_DEFAULTS); prm.update(params)
+    pv = np.array([prm[k] for k in DYNPTS_DEFAULTS], dtype=np.float32)
+    T = np.ascontiguousarray(np.asarray(to_sensor, dtype=np.float32).T)  # col-major
+    i = _f32(input_cloud); m = _f32(map_cloud); nn = np.ascontiguousarray(map_normals, dtype=np.float32)
+    out = np.ascontiguousarray(prob, dtype=np.float32).copy()
+    lib.orc_dynamic_points_update(pv.ctypes.data, T.ctypes.data, i.ctypes.data, i.shape[0], m.ctypes.data, nn.ctypes.data, m.shape[0],
+                                  out.ctypes.data, nthreads)
+    return out

@@ -292,6 +292,34 @@ def test_voxel_keep_first_exact(amd, oracle, small_scene):
         icp.voxelKeepFirst(cloud, 0.0)
 
 
+def test_dynamic_points_update_matches_oracle(amd, oracle, small_scene):
+    """DynamicPointsMapperModule::inPlaceUpdateMap: the device's angular bucket grid against the
+    oracle's brute-force beam search, bit for bit (same float arithmetic, asin/atan2 rounded from double)."""
+    sc = small_scene
+    icp = amd.ICPSequence(minimizer=0)
+    rng = np.random.default_rng(21)
+    pose = amd.synth.make_T((0.02, -0.01, 0.3), (3.0, -2.0, 1.5)).astype(np.float32)
+    to_sensor = np.linalg.inv(pose.astype(np.float64)).astype(np.float32)
+    mp = sc["map"][:15000]
+    nrm = sc["normals"][:15000]
+    scan = sc["scan"]
+    # a moved object: some scan points pulled towards the sensor along their beam => map points behind them turn dynamic
+    sensor = pose[:3, 3]
+    scan = scan.copy()
+    pull = rng.random(scan.shape[0]) < 0.2
+    scan[pull, :3] = sensor + (scan[pull, :3] - sensor) * 0.6
+    prob0 = rng.uniform(0.0, 1.0, mp.shape[0]).astype(np.float32)
+    for kw in (dict(), dict(beam_half_angle=0.03, sensor_max_range=40.0), dict(threshold_dynamic=0.5, alpha=0.6, beta=0.9, epsilon_a=0.05, epsilon_d=0.1)):
+        got = icp.dynamicPointsUpdate(to_sensor, scan, mp, nrm, prob0, **kw)
+        ref = oracle.dynamic_points_update(to_sensor, scan, mp, nrm, prob0, nthreads=8, **kw)
+        changed = ref != prob0
+        assert changed.sum() > 100
+        assert np.array_equal(got, ref), (np.flatnonzero(got != ref)[:10], kw)
+        assert np.isfinite(got).all() and (got >= 0).all() and (got <= 1).all()
+    # no beams / no map: nothing changes
+    assert np.array_equal(icp.dynamicPointsUpdate(to_sensor, scan[:0], mp, nrm, prob0), prob0)
+
+
 @pytest.fixture(scope="module")
 def bundled():
     import os
