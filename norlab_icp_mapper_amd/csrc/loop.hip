@@ -904,7 +904,7 @@ icpmi_status loop_prepare_reading(icpmi_ctx* c, const float4* d_scan, int64_t n,
     }
     HIP_TRY(c, hipGetLastError());
     // tile order of the (centred) reading for the LDS-staged NN kernel
-    if (c->cfg.knn <= 1 && n > 0) return sort_queries(c, c->d_reading, n);
+    if (c->cfg.knn <= 8 && n > 0) return sort_queries(c, c->d_reading, n);
     return ICPMI_OK;
 }
 
@@ -1071,7 +1071,7 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
     if (ensure_loop_buffers(c, n, lc.k) != ICPMI_OK) return ICPMI_ERR_HIP;
     if (ensure_cap(c, &c->d_reading, &c->cap_reading, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
     if (d_normals3 && ensure_cap(c, &c->d_read_normals, &c->cap_read_normals, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
-    if (c->cfg.knn <= 1 && sort_queries_reserve(c, n) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (c->cfg.knn <= 8 && sort_queries_reserve(c, n) != ICPMI_OK) return ICPMI_ERR_HIP;
 
     const bool profile = c->cfg.profile != 0;
     const bool graph = c->cfg.use_graph != 0 && fixed && !profile;
@@ -1107,7 +1107,7 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
             c->graph_n = n; c->graph_iters = lc.max_iter; c->graph_sig = sig;
         }
         HIP_TRY(c, hipGraphLaunch(c->graph_exec, c->stream));
-        if (c->cfg.knn <= 1) { c->qsorted_n = n; c->qsorted_src = c->d_reading; } // what the replayed head leaves in d_qsorted
+        if (c->cfg.knn <= 8) { c->qsorted_n = n; c->qsorted_src = c->d_reading; } // what the replayed head leaves in d_qsorted
     } else {
         const int check_every = (lc.use_diff || lc.use_bound) ? 4 : lc.max_iter;
         if (profile && c->nn_events.size() < (size_t)2 * lc.max_iter) {

@@ -697,6 +697,264 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restri
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// 2 <= k <= 8 over the grid pyramid: the k = 1 scheme with a sorted list per lane.  G lanes serve one
+// query; candidates of a level pass are dealt to the lanes as in nn1_ml_kernel, every lane keeps the
+// KMAX best of ITS candidates; after a pass the group merges by KMAX rounds of "extract the group
+// minimum" (shuffle butterfly) into a list replicated in all lanes, whose k-th key bounds the next
+// pass (rows / cells beyond it are skipped, candidates beyond it dropped, candidates equal to a merged
+// entry -- the same point seen again -- dropped).  Iterations > 0 are seeded with the previous
+// iteration's k matches (lane j fetches match j), which makes the first bound tight.
+// ------------------------------------------------------------------------------------------------
+template <int G, int KMAX>
+__global__ __launch_bounds__(NN_BLOCK) void nnk_ml_kernel(const float4* __restrict__ queries, const int* __restrict__ qindex, int n,
+                                                          const float* __restrict__ Tptr, const uint4* __restrict__ ltab_g, int nlev,
+                                                          int k, float maxr2, int allow_self_i, int seeded, int* __restrict__ out_sidx,
+                                                          float* __restrict__ out_d2, IcpState* __restrict__ st,
+                                                          unsigned* __restrict__ hard)
+{
+    static_assert(G == 8, "lanes per query");
+    constexpr int NB = 4;
+    constexpr int NR = (9 + G - 1) / G;
+    if (st->done) return;
+    __shared__ uint4 ltab[ICPMI_MAXLEV * 4];
+    if (threadIdx.x < ICPMI_MAXLEV * 4) ltab[threadIdx.x] = ltab_g[threadIdx.x];
+    const bool allow_self = allow_self_i != 0;
+    const int chunk = gridDim.x >> 3;
+    const int lb = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    const int tid = lb * NN_BLOCK + threadIdx.x;
+    const int qi = tid / G;
+    const int sub = tid % G;
+    const bool active = qi < n;
+    const float4 r = queries[active ? qi : 0];
+    const int orig = qindex ? qindex[active ? qi : 0] : qi;
+    float3 p;
+    if (Tptr) p = xf_point(Tptr, r.x, r.y, r.z, r.w);
+    else p = make_float3(r.x, r.y, r.z);
+    const int lane = threadIdx.x & 63;
+    const int gbase = lane - sub;
+    __syncthreads();
+
+    // private (per lane) and merged (replicated) lists; sidx = position in its level | level << 28
+    unsigned long long pk[KMAX], mk[KMAX];
+    int ps[KMAX], ms[KMAX];
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i) { pk[i] = ~0ull; ps[i] = -1; mk[i] = ~0ull; ms[i] = -1; }
+    unsigned long long bound = ~0ull; // k-th merged key once k candidates are held
+
+    auto offer = [&](unsigned long long key, int sidx) {
+        if (key > bound || key >= pk[KMAX - 1]) return;
+        bool dup = false;
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) dup |= key == mk[i];
+        if (dup) return;
+#pragma unroll
+        for (int i = KMAX - 1; i >= 0; --i) {
+            const unsigned long long prev = i > 0 ? pk[i - 1] : 0ull;
+            const int prevs = i > 0 ? ps[i - 1] : -1;
+            if (i > 0 && key < prev) { pk[i] = prev; ps[i] = prevs; }
+            else if (key < pk[i]) { pk[i] = key; ps[i] = sidx; }
+        }
+    };
+    // merged <- the KMAX smallest of (merged U all private lists); private lists cleared
+    auto merge = [&]() {
+        if (sub == 0) { // the merged entries re-enter through lane 0 (its private candidates are all > ... not necessarily: insert them)
+#pragma unroll
+            for (int i = 0; i < KMAX; ++i) {
+                const unsigned long long key = mk[i];
+                const int sx = ms[i];
+                if (key != ~0ull && key < pk[KMAX - 1]) {
+#pragma unroll
+                    for (int j = KMAX - 1; j >= 0; --j) {
+                        const unsigned long long prev = j > 0 ? pk[j - 1] : 0ull;
+                        const int prevs = j > 0 ? ps[j - 1] : -1;
+                        if (j > 0 && key < prev) { pk[j] = prev; ps[j] = prevs; }
+                        else if (key < pk[j]) { pk[j] = key; ps[j] = sx; }
+                    }
+                }
+            }
+        }
+        int head = 0;
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) {
+            unsigned long long ck = ~0ull;
+            int cs_ = -1;
+#pragma unroll
+            for (int i = 0; i < KMAX; ++i) if (i == head) { ck = pk[i]; cs_ = ps[i]; }
+            const unsigned long long mine = ck;
+#pragma unroll
+            for (int off = G / 2; off > 0; off >>= 1) {
+                const unsigned long long ok = __shfl_xor(ck, off, 64);
+                const int os = __shfl_xor(cs_, off, 64);
+                if (ok < ck) { ck = ok; cs_ = os; }
+            }
+            mk[j] = ck; ms[j] = cs_;
+            if (mine == ck && mine != ~0ull) ++head; // keys are unique per map point: every holder of the winner advances
+        }
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) { pk[i] = ~0ull; ps[i] = -1; }
+        unsigned long long kth = ~0ull;
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) if (i == k - 1) kth = mk[i];
+        bound = kth;
+    };
+
+    bool decided = !active;
+    int lev = 0;
+    if (seeded && active && allow_self && st->iter > 0) {
+        // lane j < k re-evaluates previous match j under the current transform
+        if (sub < k) {
+            const int sp = out_sidx[(size_t)k * orig + sub];
+            if (sp >= 0) {
+                const float4 q = reinterpret_cast<const float4*>(((unsigned long long)ltab[2].w << 32) | ltab[2].z)[sp];
+                pk[0] = pack_key(sqdist3(p.x, p.y, p.z, q.x, q.y, q.z), __float_as_uint(q.w));
+                ps[0] = sp;
+            }
+        }
+    }
+    if (seeded) {
+        merge();
+        if (bound != ~0ull) { // first level whose block contains the ball of the k-th seed
+            const float ub = sqrtf(__uint_as_float((unsigned)(bound >> 32))) * 1.000001f;
+            for (; lev < nlev - 1; ++lev) {
+                const uint4 a = ltab[4 * lev], b = ltab[4 * lev + 1];
+                const float inv = __uint_as_float(b.x);
+                const float fx = (p.x - __uint_as_float(a.x)) * inv, fy = (p.y - __uint_as_float(a.y)) * inv, fz = (p.z - __uint_as_float(a.z)) * inv;
+                float mfl = fminf(fx - floorf(fx), 1.0f - (fx - floorf(fx)));
+                mfl = fminf(mfl, fminf(fy - floorf(fy), 1.0f - (fy - floorf(fy))));
+                mfl = fminf(mfl, fminf(fz - floorf(fz), 1.0f - (fz - floorf(fz))));
+                if (!(mfl >= 0.f)) mfl = 0.f;
+                if (ub <= (1.0f + mfl) * __uint_as_float(a.w) - 2.0f * __uint_as_float(b.y)) break;
+            }
+        }
+    }
+
+    for (; lev < nlev && !decided; ++lev) {
+        GridParams g;
+        const float4* __restrict__ map;
+        const unsigned* __restrict__ cs;
+        {
+            const uint4 a = ltab[4 * lev], b = ltab[4 * lev + 1], c2 = ltab[4 * lev + 2], d = ltab[4 * lev + 3];
+            g.ox = __uint_as_float(a.x); g.oy = __uint_as_float(a.y); g.oz = __uint_as_float(a.z); g.cell = __uint_as_float(a.w);
+            g.inv_cell = __uint_as_float(b.x); g.slack = __uint_as_float(b.y); g.nx = (int)b.z; g.ny = (int)b.w;
+            g.nz = (int)c2.x; g.ncells = (int)c2.y;
+            map = reinterpret_cast<const float4*>(((unsigned long long)c2.w << 32) | c2.z);
+            cs = reinterpret_cast<const unsigned*>(((unsigned long long)d.y << 32) | d.x);
+        }
+        const float fx = (p.x - g.ox) * g.inv_cell, fy = (p.y - g.oy) * g.inv_cell, fz = (p.z - g.oz) * g.inv_cell;
+        const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
+        const int cx = (int)fminf(fmaxf(flx, -1.0e6f), 1.0e6f);
+        const int cy = (int)fminf(fmaxf(fly, -1.0e6f), 1.0e6f);
+        const int cz = (int)fminf(fmaxf(flz, -1.0e6f), 1.0e6f);
+        float mf = fminf(fx - flx, 1.0f - (fx - flx));
+        mf = fminf(mf, fminf(fy - fly, 1.0f - (fy - fly)));
+        mf = fminf(mf, fminf(fz - flz, 1.0f - (fz - flz)));
+        if (!(mf >= 0.f)) mf = 0.f;
+
+        float rub2 = INFINITY;
+        if (bound != ~0ull) {
+            const float rub = sqrtf(__uint_as_float((unsigned)(bound >> 32))) * 1.000001f + g.slack;
+            rub2 = rub * rub;
+        }
+        unsigned rs[NR], rn[NR];
+        {
+            const float ylo = (fy - fly) * g.cell, yhi = (1.0f - (fy - fly)) * g.cell;
+            const float zlo = (fz - flz) * g.cell, zhi = (1.0f - (fz - flz)) * g.cell;
+#pragma unroll
+            for (int sl = 0; sl < NR; ++sl) {
+                const int rr = sub + sl * G;
+                unsigned s = 0, cnt = 0;
+                if (rr < 9) {
+                    const int dy = (rr % 3) - 1, dz = (rr / 3) - 1;
+                    int xa = cx - 1, xb = cx + 1;
+                    bool reach = true;
+                    if (rub2 != INFINITY) {
+                        const float ddy = dy == 0 ? 0.f : (dy < 0 ? ylo : yhi);
+                        const float ddz = dz == 0 ? 0.f : (dz < 0 ? zlo : zhi);
+                        const float rem2 = rub2 - (ddy * ddy + ddz * ddz);
+                        reach = rem2 >= 0.f;
+                        const float rem = sqrtf(fmaxf(rem2, 0.f));
+                        const int xl = (int)fmaxf(floorf((p.x - rem - g.ox) * g.inv_cell), -1.0e6f);
+                        const int xh = (int)fminf(floorf((p.x + rem - g.ox) * g.inv_cell), 1.0e6f);
+                        xa = xl > xa ? xl : xa;
+                        xb = xh < xb ? xh : xb;
+                    }
+                    if (reach) {
+                        unsigned e;
+                        row_run(g, cs, xa, xb, cy + dy, cz + dz, s, e);
+                        cnt = e - s;
+                    }
+                }
+                rs[sl] = s; rn[sl] = cnt;
+            }
+        }
+        unsigned Pr[10], Or[9];
+        Pr[0] = 0;
+#pragma unroll
+        for (int rr = 0; rr < 9; ++rr) {
+            const int src = gbase + (rr % G);
+            const unsigned s = __shfl(rs[rr / G], src, 64);
+            const unsigned c = __shfl(rn[rr / G], src, 64);
+            Or[rr] = s - Pr[rr];
+            Pr[rr + 1] = Pr[rr] + c;
+        }
+        const unsigned total = Pr[9];
+        for (unsigned k0 = (unsigned)sub; k0 < total; k0 += (unsigned)(G * NB)) {
+            float4 q[NB];
+            unsigned gi[NB];
+            bool ok[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const unsigned kq = k0 + (unsigned)(u * G);
+                ok[u] = kq < total;
+                const unsigned kk = ok[u] ? kq : k0;
+                unsigned off = Or[0];
+#pragma unroll
+                for (int rr = 1; rr < 9; ++rr) off = kk >= Pr[rr] ? Or[rr] : off;
+                gi[u] = kk + off;
+                q[u] = map[gi[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const float d2 = sqdist3(p.x, p.y, p.z, q[u].x, q[u].y, q[u].z);
+                if (ok[u] && (allow_self || d2 > 1.1920929e-07f)) offer(pack_key(d2, __float_as_uint(q[u].w)), (int)(gi[u] | ((unsigned)lev << 28)));
+            }
+        }
+        merge();
+        const float margin = fmaxf((1.0f + mf) * g.cell - g.slack, 0.f);
+        const float m2 = margin * margin;
+        const float kd2 = __uint_as_float((unsigned)(bound >> 32));
+        const bool covers = cx - 1 <= 0 && cx + 1 >= g.nx - 1 && cy - 1 <= 0 && cy + 1 >= g.ny - 1 && cz - 1 <= 0 && cz + 1 >= g.nz - 1;
+        decided = (bound != ~0ull && kd2 <= m2) || m2 > maxr2 || covers;
+    }
+
+    if (active) {
+        // lane j writes result j (static select from the replicated merged list)
+        unsigned long long key = ~0ull;
+        int sx = -1;
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) if (i == sub) { key = mk[i]; sx = ms[i]; }
+        if (sub < k) {
+            float d2 = __uint_as_float((unsigned)(key >> 32));
+            int bs = -1;
+            if (key != ~0ull && d2 <= maxr2) {
+                const unsigned lv = (unsigned)sx >> 28, pos = (unsigned)sx & 0x0fffffffu;
+                if (lv == 0) bs = (int)pos;
+                else {
+                    const uint4 d = ltab[4 * lv + 3];
+                    bs = (int)reinterpret_cast<const unsigned*>(((unsigned long long)d.w << 32) | d.z)[pos];
+                }
+            } else d2 = INFINITY;
+            out_sidx[(size_t)k * orig + sub] = bs;
+            out_d2[(size_t)k * orig + sub] = d2;
+        }
+        if (sub == 0 && !decided) {
+            const unsigned slot = atomicAdd(&st->hard_count, 1u);
+            hard[slot] = (unsigned)orig;
+        }
+    }
+}
+
 } // namespace
 
 void nn_launch_hard_k1(icpmi_ctx* c, const float4* d_reading, const float* d_T, const LoopCfg& lc, int allow_self, int* d_sidx,
@@ -789,6 +1047,28 @@ template <int KMAX>
 static icpmi_status nnk_launch_t(icpmi_ctx* c, const float4* d_reading, int64_t n, const float* d_T, const LoopCfg& lc,
                                  int allow_self, int* d_sidx, float* d_d2, IcpState* d_state)
 {
+    if (KMAX <= 8 && c->m < (1 << 28) && n > 0) {
+        static int use_ml = -1;
+        if (use_ml < 0) { const char* e = getenv("ICPMI_NNK_ML"); use_ml = e ? atoi(e) : 1; }
+        if (use_ml) {
+            constexpr int G = 8;
+            const bool sorted = c->qsorted_n == n && c->qsorted_src == d_reading;
+            const float4* q = sorted ? c->d_qsorted : d_reading;
+            const int* qi = sorted ? c->d_qindex : nullptr;
+            const int seeded = (c->nn_iter_hint > 0 && allow_self) ? 1 : 0;
+            const int grid = (int)(((n * G + NN_BLOCK - 1) / NN_BLOCK + 7) / 8 * 8);
+            hipLaunchKernelGGL((nnk_ml_kernel<G, (KMAX <= 8 ? KMAX : 8)>), dim3(grid), dim3(NN_BLOCK), 0, c->stream, q, qi, (int)n, d_T, c->d_lvl_tab,
+                               c->levels.nlev, lc.k, lc.maxr2, allow_self, seeded, d_sidx, d_d2, d_state, c->d_hard);
+            const GridParams& top = c->levels.g[c->levels.nlev - 1];
+            if (!std::isfinite(lc.max_dist) || (top.cell - top.slack) <= lc.max_dist) {
+                hipLaunchKernelGGL(nnk_hard_kernel<KMAX>, dim3(512), dim3(NN_BLOCK), 0, c->stream, d_reading, d_T, c->d_map_sorted,
+                                   (int)c->m, lc.k, lc.maxr2, allow_self, d_sidx, d_d2, d_state, c->d_hard);
+                hipLaunchKernelGGL(hard_reset_kernel, dim3(1), dim3(64), 0, c->stream, d_state);
+            }
+            HIP_TRY(c, hipGetLastError());
+            return ICPMI_OK;
+        }
+    }
     const int blocks = (int)((n + NN_BLOCK - 1) / NN_BLOCK);
     if (blocks == 0) return ICPMI_OK;
     hipLaunchKernelGGL(nnk_kernel<KMAX>, dim3(blocks), dim3(NN_BLOCK), 0, c->stream, d_reading, (int)n, d_T, c->grid,
