@@ -37,6 +37,8 @@ CHAINS = {
     "p2p": dict(minimizer=1, max_dist=2.0, outliers=[(4, 0.85)]),
     # config 3: point-to-plane (analytic normals on the map)
     "p2plane": dict(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)]),
+    # the documented chain (docs/MapperConfiguration.md:174-189): knn 6, point-to-plane, epsilon 0
+    "docs_knn6": dict(minimizer=2, knn=6, max_dist=2.0, outliers=[(4, 0.85)]),
 }
 
 
@@ -122,7 +124,7 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"single synthetic {args.scan_points}-pt scan vs {args.map_points}-pt map, "
-                        f"{'point-to-point' if args.chain == 'p2p' else 'point-to-plane'} ICP, KDTreeMatcher knn 1 maxDist 2.0 "
+                        f"{'point-to-point' if args.chain == 'p2p' else 'point-to-plane'} ICP, KDTreeMatcher knn {chain.get('knn', 1)} maxDist 2.0 "
                         f"epsilon 0, TrimmedDist 0.85, fixed {ITERS_PER_STEP} iterations per registration",
             "chain": args.chain,
             "iterations_per_step": ITERS_PER_STEP,

@@ -167,21 +167,33 @@ __global__ __launch_bounds__(256) void sel2_hist0_kernel(const float* __restrict
 #pragma unroll
     for (int u = 0; u < PF; ++u) pv[u] = i0 + u * stride < count ? d2[i0 + u * stride] : INFINITY;
     if (st->done) return;
+    // Fine bins go through a direct-mapped LDS table first (slot = bin mod 1024: the occupied bins of
+    // one workgroup are a narrow band of neighbouring exponents/mantissas, so collisions are rare; a
+    // colliding bin falls through to a global atomic).  ~2000 elements per workgroup collapse to a few
+    // hundred global atomics.
     __shared__ unsigned h[256];
+    __shared__ unsigned tkey[1024], tcnt[1024];
     h[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < 1024; i += 256) { tkey[i] = 0xffffffffu; tcnt[i] = 0; }
     for (int64_t i = i0; i < 256 + 65536; i += stride) hists[ICPMI_S2_C1 + i] = 0;
     __syncthreads();
+    unsigned* fine = hists + ICPMI_S2_F0 + (blockIdx.x % ICPMI_S2_FCOPIES) * 65536;
     auto add = [&](float v) {
         if (!(v != INFINITY && v > 0.f)) return;
         const unsigned bits = __float_as_uint(v);
         atomicAdd(&h[bits >> 24], 1u);
-        atomicAdd(&hists[ICPMI_S2_F0 + (blockIdx.x % ICPMI_S2_FCOPIES) * 65536 + ICPMI_S2_FIDX(bits >> 16)], 1u);
+        const unsigned bin = bits >> 16, slot = bin & 1023u;
+        const unsigned old = atomicCAS(&tkey[slot], 0xffffffffu, bin);
+        if (old == 0xffffffffu || old == bin) atomicAdd(&tcnt[slot], 1u);
+        else atomicAdd(&fine[ICPMI_S2_FIDX(bin)], 1u);
     };
 #pragma unroll
     for (int u = 0; u < PF; ++u) add(pv[u]);
     for (int64_t i = i0 + PF * stride; i < count; i += stride) add(d2[i]);
     __syncthreads();
     if (h[threadIdx.x]) atomicAdd(&hists[ICPMI_S2_C0 + (blockIdx.x % ICPMI_S2_COPIES) * 256 + threadIdx.x], h[threadIdx.x]);
+    for (int i = threadIdx.x; i < 1024; i += 256)
+        if (tcnt[i]) atomicAdd(&fine[ICPMI_S2_FIDX(tkey[i])], tcnt[i]);
 }
 
 // scan level 0 (top 16 bits), build level 1 (low 16 bits) from the elements under the selected prefix
