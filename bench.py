@@ -151,7 +151,8 @@ def main():
                 nn_ms += prof.stats.nn_ms_avg * prof.stats.nn_launches
                 nn_cnt += prof.stats.nn_launches
         nn_avg_ms = nn_ms / max(nn_cnt, 1)
-        alg_bytes = args.scan_points * 16 + args.map_points * 16 + args.scan_points * 8
+        kq = chain.get("knn", 1)
+        alg_bytes = args.scan_points * 16 + args.map_points * 16 + args.scan_points * 8 * kq
         achieved = alg_bytes / (nn_avg_ms * 1e-3) / 1e9 if nn_avg_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "nn_traffic.json")
@@ -160,7 +161,7 @@ def main():
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        out["roofline"] = {"bound": "hbm", "kernel": "nn1_ml_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        out["roofline"] = {"bound": "hbm", "kernel": "nn1_ml_kernel" if kq == 1 else "nnk_ml_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                            "avg_launch_us": nn_avg_ms * 1e3, "launches_timed": nn_cnt}
         del prof
@@ -170,7 +171,7 @@ def main():
             import oracle_bindings as ob
             cores = len(os.sched_getaffinity(0))
             nthreads = min(cores, 64)
-            okw = dict(minimizer=chain["minimizer"], max_dist=chain["max_dist"], outliers=chain["outliers"])
+            okw = dict(minimizer=chain["minimizer"], max_dist=chain["max_dist"], outliers=chain["outliers"], knn=chain.get("knn", 1))
             oicp = ob.OracleICP(ob.make_config(max_iterations=ITERS_PER_STEP, nthreads=nthreads, **okw))
             tb = time.perf_counter()
             oicp.setMap(sc["map"], sc["normals"])

@@ -829,7 +829,10 @@ __global__ __launch_bounds__(NN_BLOCK) void nnk_ml_kernel(const float4* __restri
         }
     }
 
-    for (; lev < nlev && !decided; ++lev) {
+    // A query that holds no bound yet first scans only the x-row through its own cell (about 1/9 of
+    // the block); if that yields k candidates the same level is then searched with their bound.
+    bool rowonly = bound == ~0ull;
+    while (lev < nlev && !decided) {
         GridParams g;
         const float4* __restrict__ map;
         const unsigned* __restrict__ cs;
@@ -864,7 +867,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nnk_ml_kernel(const float4* __restri
             for (int sl = 0; sl < NR; ++sl) {
                 const int rr = sub + sl * G;
                 unsigned s = 0, cnt = 0;
-                if (rr < 9) {
+                if (rr < 9 && (!rowonly || rr == 4)) {
                     const int dy = (rr % 3) - 1, dz = (rr / 3) - 1;
                     int xa = cx - 1, xb = cx + 1;
                     bool reach = true;
@@ -921,11 +924,13 @@ __global__ __launch_bounds__(NN_BLOCK) void nnk_ml_kernel(const float4* __restri
             }
         }
         merge();
+        if (rowonly) { rowonly = false; continue; }
         const float margin = fmaxf((1.0f + mf) * g.cell - g.slack, 0.f);
         const float m2 = margin * margin;
         const float kd2 = __uint_as_float((unsigned)(bound >> 32));
         const bool covers = cx - 1 <= 0 && cx + 1 >= g.nx - 1 && cy - 1 <= 0 && cy + 1 >= g.ny - 1 && cz - 1 <= 0 && cz + 1 >= g.nz - 1;
         decided = (bound != ~0ull && kd2 <= m2) || m2 > maxr2 || covers;
+        ++lev;
     }
 
     if (active) {
