@@ -282,15 +282,39 @@ __global__ __launch_bounds__(NN_BLOCK) void nnk_kernel(const float4* __restrict_
     KList<KMAX> L; L.init(k);
     bool decided = false;
     int ring = 0;
+    // distances from the query to the faces of its cell along y and z (for pruning rows of ring 1)
+    const float ylo = (fy - fly) * g.cell, yhi = (1.0f - (fy - fly)) * g.cell;
+    const float zlo = (fz - flz) * g.cell, zhi = (1.0f - (fz - flz)) * g.cell;
     while (!decided && ring < ring_max) {
         ++ring;
         const int side = 2 * ring + 1;
-        for (int rr = 0; rr < side * side; ++rr) {
+        for (int r0 = 0; r0 < side * side; ++r0) {
+            // ring 1 starts with the row through the query's own cell: once k candidates are held, rows and
+            // cells the ball of the k-th distance cannot reach are skipped (every point within it is still seen)
+            const int rr = ring == 1 ? (r0 == 0 ? 4 : (r0 <= 4 ? r0 - 1 : r0)) : r0;
             const int dy = rr % side - ring, dz = rr / side - ring;
             const bool full_row = ring == 1 || (dy == -ring || dy == ring || dz == -ring || dz == ring);
             unsigned s, e;
             if (full_row) {
-                row_run(g, cs, cx - ring, cx + ring, cy + dy, cz + dz, s, e);
+                int xa = cx - ring, xb = cx + ring;
+                if (ring == 1) {
+                    unsigned long long kth = ~0ull;
+#pragma unroll
+                    for (int i = 0; i < KMAX; ++i) if (i == k - 1) kth = L.key[i];
+                    if (kth != ~0ull) {
+                        const float rub = sqrtf(__uint_as_float((unsigned)(kth >> 32))) * 1.000001f + g.slack;
+                        const float ddy = dy == 0 ? 0.f : (dy < 0 ? ylo : yhi);
+                        const float ddz = dz == 0 ? 0.f : (dz < 0 ? zlo : zhi);
+                        const float rem2 = rub * rub - (ddy * ddy + ddz * ddz);
+                        if (rem2 < 0.f) continue;
+                        const float rem = sqrtf(rem2);
+                        const int xl = (int)fmaxf(floorf((p.x - rem - g.ox) * g.inv_cell), -1.0e6f);
+                        const int xh = (int)fminf(floorf((p.x + rem - g.ox) * g.inv_cell), 1.0e6f);
+                        xa = xl > xa ? xl : xa;
+                        xb = xh < xb ? xh : xb;
+                    }
+                }
+                row_run(g, cs, xa, xb, cy + dy, cz + dz, s, e);
                 scan_run_k<KMAX>(map, s, e, p.x, p.y, p.z, allow_self != 0, L);
             } else {
                 if (cx - ring >= 0) {
