@@ -304,12 +304,17 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restric
         pr[u] = reading[in ? (int)(e / lc.k) : 0];
         pq[u] = (match_pt && in) ? match_pt[e] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    const unsigned cv = FUSED ? hists[ICPMI_S2_C1 + threadIdx.x] : 0u; // same round trip as the elements
+    // second round trip, overlapping the fine-histogram read of the selection scan: the matched normals
+    float4 pn[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        pn[u] = (MIN == ICPMI_MIN_POINT_TO_PLANE && ps[u] >= 0) ? normals[ps[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
     if (st->done) return;
     float fused_limit = 0.f;
     if (FUSED) {
         // scan of level 1: the selected element's bit pattern is prefix(16) | bin(16)
         __shared__ unsigned shsel[16];
-        const unsigned cv = hists[ICPMI_S2_C1 + threadIdx.x];
         unsigned bin, rem, total;
         block_find_rank_2tier<1>(cv, hists + ICPMI_S2_F1, false, 0.f, st->sel_rank_l[0], shsel, bin, rem, total);
         const float q = __uint_as_float((st->sel_prefix_l[0] << 16) | bin);
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restric
     for (int i = 0; i < (NVAL > 0 ? NVAL : 1); ++i) acc[i] = 0.0;
     double wsum = 0.0, cnt = 0.0;
     const float* T = st->T_iter;
-    auto pair = [&](int64_t e, float d2, int s, float4 r, float4 qkept) {
+    auto pair = [&](int64_t e, float d2, int s, float4 r, float4 qkept, float4 nkept, bool have_n) {
         if (d2 == INFINITY) return;
         const int qi = (int)(e / lc.k);
         const float w = match_weight(lc, st, d2, T, read_normals, qindex ? qindex[qi] : qi, normals, s, FUSED ? fused_slot : -1, fused_limit);
@@ -345,7 +350,7 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restric
 #pragma unroll
                 for (int rr = 0; rr < 3; ++rr) acc[7 + 3 * c + rr] += wq[rr] * pc[c];
         } else if (MIN == ICPMI_MIN_POINT_TO_PLANE) {
-            const float4 nn = normals[s];
+            const float4 nn = have_n ? nkept : normals[s];
             // per-pair quantities in float exactly as the oracle (and Eigen) form them
             const float F[6] = {p.y * nn.z - p.z * nn.y, p.z * nn.x - p.x * nn.z, p.x * nn.y - p.y * nn.x, nn.x, nn.y, nn.z};
             const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
@@ -361,9 +366,10 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restric
         }
     };
 #pragma unroll
-    for (int u = 0; u < 2; ++u) pair(e_first + u * stride, pd2[u], ps[u], pr[u], pq[u]);
+    for (int u = 0; u < 2; ++u) pair(e_first + u * stride, pd2[u], ps[u], pr[u], pq[u], pn[u], true);
     for (int64_t e = e_first + 2 * stride; e < count; e += stride)
-        pair(e, d2a[e], sidx[e], reading[(int)(e / lc.k)], match_pt ? match_pt[e] : make_float4(0.f, 0.f, 0.f, 0.f));
+        pair(e, d2a[e], sidx[e], reading[(int)(e / lc.k)], match_pt ? match_pt[e] : make_float4(0.f, 0.f, 0.f, 0.f),
+             make_float4(0.f, 0.f, 0.f, 0.f), false);
     // ---- workgroup reduction: wave64 shuffles, then LDS across the 4 waves ----
     // Transposed butterfly: at the step with partner lane ^ m every lane hands over the half of its
     // values the partner keeps, so 32 values x 64 lanes fold with 16+8+4+2+1+1 = 32 exchanges instead
@@ -934,8 +940,10 @@ static icpmi_status ensure_loop_buffers(icpmi_ctx* c, int64_t n, int k)
 
 static int acc_blocks(int64_t count)
 {
+    static int cap = -1;
+    if (cap < 0) { const char* e = getenv("ICPMI_ACC_BLOCKS"); cap = e ? atoi(e) : 256; }
     const int64_t nb = (count + 255) / 256;
-    return (int)(nb < 1 ? 1 : (nb > 256 ? 256 : nb));
+    return (int)(nb < 1 ? 1 : (nb > cap ? cap : nb));
 }
 
 // index of the single quantile-type filter of the chain, or -1 (none) / -2 (more than one)
