@@ -51,7 +51,8 @@ def main():
     ap.add_argument("--map-points", type=int, default=M_MAP)
     ap.add_argument("--scan-points", type=int, default=N_SCAN)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-iters", type=int, default=10)
+    ap.add_argument("--cpu-iters", type=int, default=10, help="iterations of the single-threaded cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work of the multi-threaded cpu_baseline leg")
     args = ap.parse_args()
 
     import numpy as np
@@ -139,7 +140,10 @@ def main():
         out["set_map_ms"] = set_map_ms
         out["grid"] = gi
         gt_t, gt_r = pkg.synth.pose_error(T, sc["T_gt"])
-        out["pose_err_vs_ground_truth"] = {"m": gt_t, "rad": gt_r}
+        out["pose_err_vs_ground_truth"] = {"m": gt_t, "rad": gt_r,
+                                           "note": "after the fixed 20 iterations of throughput mode (Counter checker only); "
+                                                   "the point-to-point chain needs more iterations to converge, the CPU oracle "
+                                                   "lands on the same pose (pose_err_vs_cpu)"}
 
         # ---- roofline of the NN kernel: profile mode = eager launches, HIP events around each NN launch
         prof = pkg.ICPSequence(device=dev, max_iterations=ITERS_PER_STEP, profile=1, **chain)
@@ -176,9 +180,14 @@ def main():
             tb = time.perf_counter()
             oicp.setMap(sc["map"], sc["normals"])
             build_s = time.perf_counter() - tb
-            err, T_cpu = oicp(sc["scan"])
-            mt_its = oicp.stats.iterations / oicp.stats.seconds_total
-            o1 = ob.OracleICP(ob.make_config(max_iterations=max(2, args.cpu_iters // 3), nthreads=1, **okw))
+            # multi-threaded leg: repeat the 20-iteration registration until ~args.cpu_seconds of work
+            mt_iters, mt_secs, mt_regs = 0, 0.0, 0
+            while mt_secs < args.cpu_seconds and mt_regs < 200:
+                err, T_cpu = oicp(sc["scan"])
+                mt_iters += oicp.stats.iterations; mt_secs += oicp.stats.seconds_total; mt_regs += 1
+            mt_its = mt_iters / mt_secs
+            # single-threaded leg (libpointmatcher's own loop is single threaded outside libnabo): a few iterations
+            o1 = ob.OracleICP(ob.make_config(max_iterations=max(2, args.cpu_iters), nthreads=1, **okw))
             o1.setMap(sc["map"], sc["normals"])
             o1(sc["scan"])
             st_its = o1.stats.iterations / o1.stats.seconds_total
@@ -186,8 +195,8 @@ def main():
             out["pose_err_vs_cpu"] = {"m": dt, "rad": dr, "tolerance": {"m": 1e-4, "rad": 1e-4}}
             out["cpu_baseline"] = {
                 "value": max(mt_its, st_its), "unit": "iterations/s", "cores": nthreads if mt_its >= st_its else 1, "kind": "port",
-                "sample": f"oracle (C restatement, gcc -O3, OpenMP over the kNN queries), same map and scan: one "
-                          f"{ITERS_PER_STEP}-iteration registration on {nthreads} threads ({mt_its:.2f} it/s) and "
+                "sample": f"oracle (C restatement, gcc -O3, OpenMP over the kNN queries), same map and scan: {mt_regs} x "
+                          f"{ITERS_PER_STEP}-iteration registrations on {nthreads} threads ({mt_secs:.1f} s, {mt_its:.2f} it/s) and "
                           f"{o1.stats.iterations} iterations on 1 thread ({st_its:.2f} it/s); kd-tree build {build_s:.2f} s excluded",
                 "value_1thread": st_its, "value_multithread": mt_its, "host_cores": cores,
             }
