@@ -75,6 +75,39 @@ def test_knn_far_queries_and_self_match(amd, oracle, small_scene):
     assert (ids[:, 0] != np.arange(2000)).all()
 
 
+@pytest.mark.parametrize("shape", ["single", "identical", "planar", "collinear", "duplicates", "far_offset", "two_clusters"])
+def test_knn_degenerate_maps(amd, oracle, shape):
+    """Degenerate geometry through the grid pyramid: zero extents, ties, k larger than the map, big offsets."""
+    rng = np.random.default_rng(7)
+    def cloud(xyz):
+        c = np.ones((xyz.shape[0], 4), dtype=np.float32); c[:, :3] = xyz.astype(np.float32); return c
+    if shape == "single":
+        m = cloud(np.array([[1.0, 2.0, 3.0]]))
+    elif shape == "identical":
+        m = cloud(np.tile([[0.5, -0.25, 4.0]], (7, 1)))
+    elif shape == "planar":
+        xy = rng.uniform(-3, 3, (500, 2)); m = cloud(np.c_[xy, np.full(500, 1.25)])
+    elif shape == "collinear":
+        t = rng.uniform(-5, 5, 300); m = cloud(np.c_[t, 2 * t, np.zeros(300)])
+    elif shape == "duplicates":
+        base = rng.uniform(-2, 2, (200, 3)); m = cloud(np.r_[base, base, base[:50]])
+    elif shape == "far_offset":
+        m = cloud(rng.uniform(-1, 1, (400, 3)) + np.array([8000.0, -6000.0, 120.0]))
+    else:
+        m = cloud(np.r_[rng.normal(0, 0.05, (150, 3)), rng.normal(0, 0.05, (150, 3)) + 40.0])
+    q = cloud(m[rng.integers(0, m.shape[0], 64), :3] + rng.normal(0, 0.3, (64, 3)))
+    q = np.concatenate([q, m[: min(8, m.shape[0])]])  # exact hits (d2 = 0)
+    for k in (1, 3, 6):
+        for md in (math.inf, 0.5):
+            icp = amd.ICPSequence(minimizer=0, knn=k, max_dist=md if math.isfinite(md) else 2.0)
+            assert icp.setMap(m)
+            mean = icp.getMapMean()
+            ids, d2 = icp.knn(centred(q, mean), k=k, max_dist=md)
+            rids, rd2 = oracle.knn(centred(m, mean), centred(q, mean), k=k, max_dist=md)
+            assert np.array_equal(d2, rd2), (shape, k, md)
+            assert np.array_equal(ids, rids), (shape, k, md)
+
+
 def test_trimmed_limit_and_weights_exact(amd, oracle, small_scene):
     icp = amd.ICPSequence(minimizer=1, max_dist=2.0, outliers=[(4, 0.85)])
     icp.setMap(small_scene["map"])
@@ -222,6 +255,42 @@ def test_error_paths(amd, small_scene):
         icp_b(sc["scan"])
     with pytest.raises(amd.InvalidParameter):
         amd.ICPSequence(knn=0)
+
+
+@pytest.mark.parametrize("minimizer", [1, 2])
+def test_small_and_exact_readings_match_oracle(amd, oracle, small_scene, minimizer):
+    """Ragged / tiny readings and readings that hit map points exactly (d2 = 0 is excluded from the
+    quantile, libpointmatcher's getDistsQuantile): same poses, same iteration counts, same errors."""
+    sc = small_scene
+    rng = np.random.default_rng(3)
+    kw = dict(minimizer=minimizer, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=15, use_differential=0)
+    icp = amd.ICPSequence(**kw)
+    icp.setMap(sc["map"], sc["normals"])
+    oicp = oracle.OracleICP(oracle.make_config(nthreads=4, **kw))
+    oicp.setMap(sc["map"], sc["normals"])
+    exact = sc["map"][rng.integers(0, sc["map"].shape[0], 400)].copy()
+    readings = {
+        "n=7": sc["scan"][:7],
+        "n=64": sc["scan"][:64],
+        "n=257": sc["scan"][100:357],
+        "half_exact": np.concatenate([exact[:200], sc["scan"][:200]]),
+    }
+    for name, rd in readings.items():
+        err, T_ref = oicp(rd)
+        if err != 0:
+            with pytest.raises(amd.ConvergenceError):
+                icp(rd)
+            continue
+        T = icp(rd)
+        assert icp.stats.iterations == oicp.stats.iterations, name
+        assert icp.stats.pairs == oicp.stats.pairs, name
+        dt, dr = amd.synth.pose_error(T, T_ref)
+        assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (name, dt, dr)
+    # every match exact: nothing for the quantile to rank => "no outlier to filter" on both sides
+    err, _ = oicp(exact)
+    assert err != 0
+    with pytest.raises(amd.ConvergenceError):
+        icp(exact)
 
 
 def test_surface_normals_match_oracle(amd, oracle, small_scene):
