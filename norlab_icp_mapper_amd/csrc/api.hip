@@ -127,7 +127,7 @@ void icpmi_destroy(icpmi_handle c)
     for (int l = 0; l < ICPMI_MAXLEV; ++l) { hipFree(c->d_lvl_pts[l]); hipFree(c->d_lvl_cs[l]); hipFree(c->d_lvl_pos0[l]); }
     hipFree(c->d_inv);
     hipFree(c->d_keys); hipFree(c->d_fill); hipFree(c->d_blocksums); hipFree(c->d_red);
-    hipFree(c->d_qsorted); hipFree(c->d_qindex); hipFree(c->d_qkeys); hipFree(c->d_qtile); hipFree(c->d_qitems);
+    hipFree(c->d_qsorted); hipFree(c->d_qindex); hipFree(c->d_qkeys); hipFree(c->d_qtile);
     hipFree(c->d_reading); hipFree(c->d_read_normals); hipFree(c->d_stage_in); hipFree(c->d_stage_n3);
     hipFree(c->d_match_pt); hipFree(c->d_lvl_tab);
     hipFree(c->d_sidx); hipFree(c->d_d2); hipFree(c->d_hard); hipFree(c->d_partials); hipFree(c->d_selhist);
@@ -185,7 +185,7 @@ icpmi_status icpmi_set_map_dev(icpmi_handle h, const float* d_map4, int64_t m, c
     if (accepted) *accepted = 0;
     if (m < 0 || (m > 0 && !d_map4)) { h->last_error = "set_map: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
     if (m == 0) return ICPMI_OK; // upstream: "Ignoring attempt to setMap with an empty map", returns false
-    if (m > 0x7fffffff) { h->last_error = "set_map: more than 2^31-1 points"; return ICPMI_ERR_UNSUPPORTED; }
+    if (m >= (1ll << 28)) { h->last_error = "set_map: more than 2^28-1 points (match positions carry the pyramid level in their top 4 bits)"; return ICPMI_ERR_UNSUPPORTED; }
     if (h->cfg.minimizer == ICPMI_MIN_POINT_TO_PLANE && !d_normals3) {
         // upstream fails later, inside the minimiser, with InvalidField("normals"); keep the map and
         // let icpmi_register report it

@@ -32,7 +32,6 @@
 
 #define ICPMI_NV 32            // doubles per block partial in the minimiser reduction
 #define ICPMI_MAX_K 32
-#define ICPMI_TQ 128           // queries per workgroup of the tile NN kernel (= max work-item size)
 
 // ------------------------------------------------------------------------------------------------
 // NN grid (built by set_map on the centred map).  Dense uniform grid; cells are x-fastest so the
@@ -148,9 +147,6 @@ struct icpmi_ctx {
     unsigned* d_qkeys = nullptr; size_t cap_qkeys = 0;
     unsigned* d_qtile = nullptr; size_t cap_qtile = 0;
     int64_t qsorted_n = -1; const float4* qsorted_src = nullptr; // which reading d_qsorted was built from
-    uint2* d_qitems = nullptr; size_t cap_qitems = 0;          // NN work items (start, count) in d_qsorted
-    unsigned* d_q_n_items = nullptr;                           // device word: number of work items
-    int q_max_items = 0;                                       // host upper bound = NN grid size
     float4* d_stage_in = nullptr; size_t cap_stage_in = 0;     // host->device staging
     float*  d_stage_n3 = nullptr; size_t cap_stage_n3 = 0;
     int*    d_sidx = nullptr; size_t cap_sidx = 0;             // k x n sorted-map index (-1 none)

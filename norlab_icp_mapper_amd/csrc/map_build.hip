@@ -494,7 +494,9 @@ icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float
     } else {
         // trial edge from the bounding volume, then one correction assuming the points sample
         // surfaces (occupied cells ~ area / cell^2): aim at TARGET points per occupied cell.
-        const double TARGET = 8.0;
+        static double target_cfg = -1.0;
+        if (target_cfg < 0) { const char* e = getenv("ICPMI_GRID_TARGET"); target_cfg = e ? atof(e) : 8.0; }
+        const double TARGET = target_cfg;
         double vol = std::max(ext[0], 1e-3) * std::max(ext[1], 1e-3) * std::max(ext[2], 1e-3);
         double cell = cbrt(vol / (double)m) * 1.2;
         g = make_grid(clo, chi, clamp_cell(cell), maxabs);

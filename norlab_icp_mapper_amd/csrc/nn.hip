@@ -7,13 +7,9 @@
 // equal float d2 resolve to the smallest original map index (the deterministic rule shared with the
 // oracle, libnabo's own pick being traversal dependent).
 //
-// Algorithm (k = 1 fast path): G lanes of a wave64 cooperate on one query.  The query's 3x3x3 cell
-// neighbourhood is 9 x-rows, each ONE contiguous run of the cell-sorted float4 array; the 9
-// (start,end) pairs are fetched by different lanes in parallel, then the lanes stride over the
-// candidates with 16-byte loads and fold (d2, index) keys with a butterfly of wave shuffles.  The
-// result is exact when the best distance is within the query's margin to the block boundary;
-// otherwise rings 2..ring_max are searched the same way, and queries still undecided are queued for
-// a brute-force pass over the whole map (only reachable with an unbounded maxDist).
+// Kernels: nn1_ml_kernel (k = 1, the loop's default), nnk_ml_kernel (2 <= k <= 8), nnk_kernel (k <= 32, one
+// lane per query: surface normals), and the brute-force passes for queries the grid cannot decide
+// (only reachable with an unbounded maxDist).  The designs are described above each kernel.
 #include "common.h"
 
 namespace {
@@ -63,113 +59,6 @@ __device__ __forceinline__ void row_run(const GridParams& g, const unsigned* __r
     const int base = (z * g.ny + y) * g.nx;
     s = cs[base + x0];
     e = cs[base + x1 + 1];
-}
-
-template <int G>
-__global__ __launch_bounds__(NN_BLOCK) void nn1_kernel(const float4* __restrict__ reading, int n, const float* __restrict__ Tptr,
-                                                       GridParams g, const float4* __restrict__ map,
-                                                       const unsigned* __restrict__ cs, float maxr2, int ring_max,
-                                                       int allow_self, int* __restrict__ out_sidx, float* __restrict__ out_d2,
-                                                       IcpState* __restrict__ st, unsigned* __restrict__ hard)
-{
-    if (st && st->done) return;
-    const int tid = blockIdx.x * NN_BLOCK + threadIdx.x;
-    const int qi = tid / G;
-    const int sub = tid % G;
-    const bool active = qi < n;
-    const float4 r = reading[active ? qi : 0];
-    float3 p;
-    if (Tptr) p = xf_point(Tptr, r.x, r.y, r.z, r.w);
-    else p = make_float3(r.x, r.y, r.z);
-
-    const float fx = (p.x - g.ox) * g.inv_cell, fy = (p.y - g.oy) * g.inv_cell, fz = (p.z - g.oz) * g.inv_cell;
-    const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
-    // clamp far-away queries so that the integer cell arithmetic cannot overflow
-    const int cx = (int)fminf(fmaxf(flx, -1.0e6f), 1.0e6f);
-    const int cy = (int)fminf(fmaxf(fly, -1.0e6f), 1.0e6f);
-    const int cz = (int)fminf(fmaxf(flz, -1.0e6f), 1.0e6f);
-    // smallest fractional distance to a cell face over the three axes
-    float mf = fminf(fx - flx, 1.0f - (fx - flx));
-    mf = fminf(mf, fminf(fy - fly, 1.0f - (fy - fly)));
-    mf = fminf(mf, fminf(fz - flz, 1.0f - (fz - flz)));
-    if (!(mf >= 0.f)) mf = 0.f;
-
-    Cand best; best.key = ~0ull; best.sidx = -1;
-
-    // ---- ring 1: the 3x3x3 block = 9 x-rows, (start,end) fetched by 9 different lanes ----
-    unsigned s0 = 0, e0 = 0, s1 = 0, e1 = 0;
-    {
-        int rr = sub;
-        if (rr < 9) row_run(g, cs, cx - 1, cx + 1, cy + (rr % 3) - 1, cz + (rr / 3) - 1, s0, e0);
-        rr = sub + G;
-        if (G < 9 && rr < 9) row_run(g, cs, cx - 1, cx + 1, cy + (rr % 3) - 1, cz + (rr / 3) - 1, s1, e1);
-    }
-    const int lane = threadIdx.x & 63;
-    const int gbase = lane - sub;
-#pragma unroll
-    for (int rr = 0; rr < 9; ++rr) {
-        const int src = gbase + (rr % G);
-        const unsigned s = __shfl(rr < G ? s0 : s1, src, 64);
-        const unsigned e = __shfl(rr < G ? e0 : e1, src, 64);
-        scan_run(map, s, e, sub, G, p.x, p.y, p.z, allow_self != 0, best);
-    }
-    group_reduce<G>(best);
-
-    // ---- exactness test / ring expansion ----
-    int ring = 1;
-    bool decided;
-    bool covers;
-    {
-        const float margin = fmaxf(((float)ring + mf) * g.cell - g.slack, 0.f);
-        const float m2 = margin * margin;
-        const float bd2 = __uint_as_float((unsigned)(best.key >> 32));
-        covers = cx - ring <= 0 && cx + ring >= g.nx - 1 && cy - ring <= 0 && cy + ring >= g.ny - 1 && cz - ring <= 0 &&
-                 cz + ring >= g.nz - 1;
-        decided = (best.sidx >= 0 && bd2 <= m2) || m2 > maxr2 || covers;
-    }
-    while (!decided && ring < ring_max) {
-        ++ring;
-        const int side = 2 * ring + 1;
-        const int nrows = side * side;
-        for (int rr = sub; rr < nrows; rr += G) {
-            const int dy = rr % side - ring, dz = rr / side - ring;
-            const bool shell_row = (dy == -ring || dy == ring || dz == -ring || dz == ring);
-            unsigned s, e;
-            if (shell_row) {
-                row_run(g, cs, cx - ring, cx + ring, cy + dy, cz + dz, s, e);
-                scan_run(map, s, e, 0, 1, p.x, p.y, p.z, allow_self != 0, best);
-            } else {
-                if (cx - ring >= 0) {
-                    row_run(g, cs, cx - ring, cx - ring, cy + dy, cz + dz, s, e);
-                    scan_run(map, s, e, 0, 1, p.x, p.y, p.z, allow_self != 0, best);
-                }
-                if (cx + ring <= g.nx - 1) {
-                    row_run(g, cs, cx + ring, cx + ring, cy + dy, cz + dz, s, e);
-                    scan_run(map, s, e, 0, 1, p.x, p.y, p.z, allow_self != 0, best);
-                }
-            }
-        }
-        group_reduce<G>(best);
-        const float margin = fmaxf(((float)ring + mf) * g.cell - g.slack, 0.f);
-        const float m2 = margin * margin;
-        const float bd2 = __uint_as_float((unsigned)(best.key >> 32));
-        covers = cx - ring <= 0 && cx + ring >= g.nx - 1 && cy - ring <= 0 && cy + ring >= g.ny - 1 && cz - ring <= 0 &&
-                 cz + ring >= g.nz - 1;
-        decided = (best.sidx >= 0 && bd2 <= m2) || m2 > maxr2 || covers;
-    }
-
-    if (active && sub == 0) {
-        float bd2 = __uint_as_float((unsigned)(best.key >> 32));
-        int bs = best.sidx;
-        if (bs < 0 || !(bd2 <= maxr2)) { bs = -1; bd2 = INFINITY; }
-        out_sidx[qi] = bs;
-        out_d2[qi] = bd2;
-        if (!decided) {
-            // keep the best found so far as a seed; the brute pass overwrites it
-            const unsigned slot = atomicAdd(&st->hard_count, 1u);
-            hard[slot] = (unsigned)qi;
-        }
-    }
 }
 
 // Brute-force pass for the queued queries (k = 1): one workgroup per query streams the whole map.
@@ -435,7 +324,8 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restri
                                                           int allow_self_i, int* __restrict__ out_sidx,
                                                           float* __restrict__ out_d2, IcpState* __restrict__ st,
                                                           unsigned* __restrict__ hard, unsigned* __restrict__ hist0,
-                                                          float4* __restrict__ match_pt, const uint4* __restrict__ ltab_g)
+                                                          float4* __restrict__ match_pt, const uint4* __restrict__ ltab_g,
+                                                          int unseeded_lev)
 {
     static_assert(G == 2 || G == 4 || G == 8 || G == 16, "lanes per query");
     constexpr int NR = (9 + G - 1) / G; // rows owned per lane: row rr belongs to lane rr % G, slot rr / G
@@ -490,7 +380,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restri
     // from above.  The search starts at the first level whose 3x3x3 block provably contains that
     // ball, and only visits the rows / cells the ball reaches.  Exactness is untouched: every point
     // within the bound is still scanned and the fold is over the same (d^2, index) keys.
-    int lev0 = 0;
+    int lev0 = unseeded_lev; // queries without a usable seed start here (level 0 may be finer than a blind 27-cell search wants)
     // The choice of the starting level runs WAVE-UNIFORMLY (all lanes step through the same `lev`):
     // the level's grid parameters are then scalar loads into SGPRs.
     {
@@ -997,10 +887,8 @@ void nn_launch_hard_k1(icpmi_ctx* c, const float4* d_reading, const float* d_T, 
 icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, const float* d_T, const LoopCfg& lc, int allow_self,
                           int* d_sidx, float* d_d2, IcpState* d_state)
 {
-    static int variant = -1;
-    if (variant < 0) { const char* e = getenv("ICPMI_NN_VARIANT"); variant = e ? atoi(e) : 0; }
     c->nn_out_sorted = false;
-    if (variant < 100 && c->m < (1 << 28)) {
+    {
         // grid pyramid; sorted queries when the caller prepared them for exactly this cloud
         const bool sorted = c->qsorted_n == n && c->qsorted_src == d_reading;
         const float4* q = sorted ? c->d_qsorted : d_reading;
@@ -1015,6 +903,9 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
         // single 2048-bin level-0 histogram flushed by every workgroup cost +20 us in same-address
         // atomics; the two-tier layout removes that.)  ICPMI_NN_FUSE_HIST0=0 falls back to the
         // stand-alone builder kernel.
+        static int unseeded_lev_cfg = -1;
+        if (unseeded_lev_cfg < 0) { const char* e = getenv("ICPMI_NN_UNSEEDED_LEVEL"); unseeded_lev_cfg = e ? atoi(e) : 0; }
+        const int unseeded_lev = unseeded_lev_cfg < c->levels.nlev ? unseeded_lev_cfg : c->levels.nlev - 1;
         static int fuse_h0 = -1;
         if (fuse_h0 < 0) { const char* e = getenv("ICPMI_NN_FUSE_HIST0"); fuse_h0 = e ? atoi(e) : 1; }
         unsigned* h0 = (needs_hard || !fuse_h0) ? nullptr : c->nn_hist0;
@@ -1026,26 +917,12 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
 #define LAUNCH_ML(G_, NB_)                                                                                                      \
     hipLaunchKernelGGL((nn1_ml_kernel<G_, NB_>), dim3((int)(((n * G_ + NN_BLOCK - 1) / NN_BLOCK + 7) / 8 * 8)), dim3(NN_BLOCK), 0,  \
                        c->stream, q, qi, (int)n, d_T, c->levels, lc.maxr2, allow_self, d_sidx, d_d2, d_state, c->d_hard, h0, mp,  \
-                       c->d_lvl_tab)
+                       c->d_lvl_tab, unseeded_lev)
         // iterations > 0 are seeded by the previous match (a handful of candidates per query): fewer
         // lanes per query; the unseeded first pass scans whole 27-cell blocks: more lanes per query
         const bool seeded = c->nn_iter_hint > 0 && allow_self;
-        const int v = seeded ? variant / 10 : variant % 10;
-        switch (v) {
-            case 1: LAUNCH_ML(2, 4); break;
-            case 2: LAUNCH_ML(4, 4); break;
-            case 3: LAUNCH_ML(16, 2); break;
-            case 4: LAUNCH_ML(16, 4); break;
-            case 5: LAUNCH_ML(4, 2); break;
-            case 6: LAUNCH_ML(8, 2); break;
-            case 7: LAUNCH_ML(4, 8); break;
-            case 8: LAUNCH_ML(8, 8); break;
-            case 9: LAUNCH_ML(16, 8); break;
-            default:
-                if (seeded) LAUNCH_ML(8, 4);
-                else LAUNCH_ML(16, 4);
-                break;
-        }
+        if (seeded) LAUNCH_ML(8, 4);
+        else LAUNCH_ML(16, 4);
 #undef LAUNCH_ML
         const GridParams& top = c->levels.g[c->levels.nlev - 1];
         if (!std::isfinite(lc.max_dist) || (top.cell - top.slack) <= lc.max_dist) {
@@ -1056,27 +933,13 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
         HIP_TRY(c, hipGetLastError());
         return ICPMI_OK;
     }
-    c->nn_builds_hist0 = false;
-    constexpr int G = 8;
-    const int64_t threads = n * G;
-    const int blocks = (int)((threads + NN_BLOCK - 1) / NN_BLOCK);
-    if (blocks == 0) return ICPMI_OK;
-    hipLaunchKernelGGL(nn1_kernel<G>, dim3(blocks), dim3(NN_BLOCK), 0, c->stream, d_reading, (int)n, d_T, c->grid, c->d_map_sorted,
-                       c->d_cell_start, lc.maxr2, lc.ring_max, allow_self, d_sidx, d_d2, d_state, c->d_hard);
-    if (!std::isfinite(lc.max_dist) || lc.ring_max < (int)ceilf(lc.max_dist / c->grid.cell) + 1) {
-        hipLaunchKernelGGL(nn1_hard_kernel, dim3(512), dim3(NN_BLOCK), 0, c->stream, d_reading, d_T, c->d_map_sorted, (int)c->m,
-                           lc.maxr2, allow_self, d_sidx, d_d2, d_state, c->d_hard);
-        hipLaunchKernelGGL(hard_reset_kernel, dim3(1), dim3(64), 0, c->stream, d_state);
-    }
-    HIP_TRY(c, hipGetLastError());
-    return ICPMI_OK;
 }
 
 template <int KMAX>
 static icpmi_status nnk_launch_t(icpmi_ctx* c, const float4* d_reading, int64_t n, const float* d_T, const LoopCfg& lc,
                                  int allow_self, int* d_sidx, float* d_d2, IcpState* d_state)
 {
-    if (KMAX <= 8 && c->m < (1 << 28) && n > 0) {
+    if (KMAX <= 8 && n > 0) {
         static int use_ml = -1;
         if (use_ml < 0) { const char* e = getenv("ICPMI_NNK_ML"); use_ml = e ? atoi(e) : 1; }
         if (use_ml) {
