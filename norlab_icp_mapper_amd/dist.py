@@ -77,3 +77,73 @@ class RAMCellManager:
         for cid, pts in bin_cells(points, cell_size).items():
             old = self.retrieveCell(cid)
             self.saveCell(cid, np.concatenate([old, pts], axis=0) if old.shape[0] else pts)
+
+
+class ShardedMapper:
+    """One rank of the scan-sharded mapping loop of SURVEY.md 8(e) / BASELINE config 5.
+
+    Every rank holds a replica of the map and its own scan stream.  One epoch = every rank registers one scan
+    against the shared map (`Mapper::processInput`, Mapper.cpp:194-238, with the prior applied first), keeps the
+    points that are at least `min_dist_new_point` away from the map (`PointDistanceMapperModule`, .cpp:28-50), the
+    accepted points are all-gathered in rank order, de-duplicated across ranks on a `min_dist_new_point` lattice
+    (first point per voxel: deterministic, identical on all ranks), appended, and every rank rebuilds its replica
+    with the identical cloud (`icp.setMap`, Map.cpp:528).  No collective touches the per-iteration path.
+
+    `backend` provides the four operators; by default they are the GPU ones of an `ICPSequence`:
+        register(scan_in_map_frame) -> 4x4 correction, set_map(cloud, normals), keep(map, cloud, min_dist) -> bool mask,
+        normals(cloud, knn) -> (M, 3), dedup(cloud, edge) -> bool mask.
+    """
+
+    def __init__(self, backend, min_dist_new_point=0.15, normals_knn=0, group=None):
+        self.backend = backend
+        self.min_dist = float(min_dist_new_point)
+        self.normals_knn = int(normals_knn)
+        self.group = group
+        self.map = np.zeros((0, 4), dtype=np.float32)
+        self.normals = None
+        self.pose = np.eye(4, dtype=np.float32)
+
+    @staticmethod
+    def gpu_backend(icp):
+        class _B:
+            register = staticmethod(lambda scan: icp(scan))
+            set_map = staticmethod(lambda cloud, normals: icp.setMap(cloud, normals))
+            keep = staticmethod(lambda m, c, d: icp.pointDistanceKeep(m, c, d))
+            normals = staticmethod(lambda cloud, knn: icp.surfaceNormals(cloud, knn))
+            dedup = staticmethod(lambda cloud, edge: icp.voxelKeepFirst(cloud, edge))
+        return _B
+
+    def set_map(self, cloud, normals=None):
+        self.map = np.ascontiguousarray(cloud, dtype=np.float32)
+        if normals is None and self.normals_knn > 0 and self.map.shape[0]:
+            normals = self.backend.normals(self.map, self.normals_knn)
+        self.normals = None if normals is None else np.ascontiguousarray(normals, dtype=np.float32)
+        self.backend.set_map(self.map, self.normals)
+
+    @staticmethod
+    def _apply(T, cloud):
+        T = np.asarray(T, dtype=np.float32)
+        out = cloud.copy()
+        out[:, :3] = cloud[:, :3] @ T[:3, :3].T + T[:3, 3]
+        return out
+
+    def epoch(self, scan, prior):
+        """scan: (n, 4) in the sensor frame; prior: 4x4 estimated pose.  Returns (corrected pose, number of points
+        this rank contributed, number of points appended to the shared map)."""
+        scan = np.ascontiguousarray(scan, dtype=np.float32)
+        in_map = self._apply(prior, scan)                                    # Mapper.cpp:197
+        correction = self.backend.register(in_map) if self.map.shape[0] else np.eye(4, dtype=np.float32)
+        self.pose = (np.asarray(correction, dtype=np.float64) @ np.asarray(prior, dtype=np.float64)).astype(np.float32)  # :215
+        placed = self._apply(self.pose, scan)                                # :221
+        mask = self.backend.keep(self.map, placed, self.min_dist) if self.map.shape[0] else np.ones(placed.shape[0], bool)
+        mine = placed[mask]
+        if dist.is_available() and dist.is_initialized():
+            merged, counts = allgather_points(torch.from_numpy(np.ascontiguousarray(mine)), group=self.group)
+            merged = merged.numpy()
+        else:
+            merged = mine
+        if merged.shape[0]:
+            merged = merged[self.backend.dedup(merged, self.min_dist)]       # points of different ranks closer than min_dist
+            new_map = np.concatenate([self.map, merged], axis=0)
+            self.set_map(new_map, None)
+        return self.pose, int(mine.shape[0]), int(merged.shape[0])

@@ -71,3 +71,54 @@ def test_cell_binning_matches_reference_rule():
     assert np.array_equal(cm.retrieveCell("a"), pts[2:])
     cm.clearAllCells()
     assert cm.getAllCellIds() == []
+
+
+def _mapper_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_bindings as ob
+    from norlab_icp_mapper_amd import synth
+    from norlab_icp_mapper_amd.dist import ShardedMapper
+
+    # CPU backend for the test: the oracle's operators (test infrastructure) behind the same four hooks
+    oicp = ob.OracleICP(ob.make_config(minimizer=1, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=15, nthreads=2))
+
+    class Backend:
+        @staticmethod
+        def register(scan):
+            err, T = oicp(scan)
+            assert err == 0
+            return T
+        set_map = staticmethod(lambda cloud, normals: oicp.setMap(cloud, normals))
+        keep = staticmethod(lambda m, c, d: ob.point_distance_keep(m, c, d, nthreads=2))
+        normals = staticmethod(lambda cloud, knn: ob.surface_normals(cloud, knn))
+        dedup = staticmethod(lambda cloud, edge: ob.voxel_keep_first(cloud, edge))
+
+    sc = synth.make_scene(m=6000, n=1500, seed_scan=43 + 1000 * rank)      # one scan stream per rank, shared map
+    mapper = ShardedMapper(Backend, min_dist_new_point=0.5)
+    mapper.set_map(sc["map"])
+    sizes, poses = [mapper.map.shape[0]], []
+    for epoch in range(2):
+        pose, mine, appended = mapper.epoch(sc["scan"] if epoch == 0 else sc["scan"][::2], np.eye(4))
+        sizes.append(mapper.map.shape[0]); poses.append(pose)
+    np.savez(os.path.join(out_dir, f"mapper{rank}.npz"), map=mapper.map, sizes=np.array(sizes), pose=poses[0], T_gt=sc["T_gt"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_mapper_replicas_stay_identical(tmp_path):
+    """World size 2 over gloo: after every epoch the ranks hold the identical grown map; each rank's pose
+    is its own registration result."""
+    world = 2
+    mp.spawn(_mapper_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(os.path.join(str(tmp_path), f"mapper{k}.npz")) for k in range(world)]
+    assert np.array_equal(r[0]["map"], r[1]["map"])
+    assert np.array_equal(r[0]["sizes"], r[1]["sizes"])
+    assert r[0]["sizes"][1] > r[0]["sizes"][0]                 # the map grew in the first epoch
+    assert r[0]["sizes"][2] - r[0]["sizes"][1] < r[0]["sizes"][1] - r[0]["sizes"][0]  # the second epoch sees mostly known surface
+    # appended points respect the minimum distance among themselves (lattice de-dup) and to the old map (keep mask)
+    for k in range(world):
+        assert np.isfinite(r[k]["pose"]).all()
+    assert not np.array_equal(r[0]["pose"], r[1]["pose"])      # every rank registered its own scan

@@ -389,6 +389,27 @@ def test_dynamic_points_update_matches_oracle(amd, oracle, small_scene):
     assert np.array_equal(icp.dynamicPointsUpdate(to_sensor, scan[:0], mp, nrm, prob0), prob0)
 
 
+def test_sharded_mapper_single_rank(amd, mid_scene):
+    """The map-growth epoch of SURVEY 8(e) with the GPU operators (world size 1: no process group)."""
+    sc = mid_scene
+    icp = amd.ICPSequence(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=30, use_differential=1)
+    from norlab_icp_mapper_amd.dist import ShardedMapper
+    mapper = ShardedMapper(ShardedMapper.gpu_backend(icp), min_dist_new_point=0.3, normals_knn=10)
+    half = sc["map"][::2]
+    mapper.set_map(half)
+    m0 = mapper.map.shape[0]
+    pose, mine, appended = mapper.epoch(sc["scan"], np.eye(4))
+    dt, dr = amd.synth.pose_error(pose, sc["T_gt"])
+    assert dt < 2e-2 and dr < 2e-3, (dt, dr)
+    assert mapper.map.shape[0] == m0 + appended and 0 < appended <= mine   # the lattice de-dup may drop a few
+    # accepted points are at least min_dist from the old map
+    new_pts = mapper.map[m0:]
+    assert icp.pointDistanceKeep(half, new_pts, 0.3).all()
+    # the same scan again contributes (almost) nothing
+    _, mine2, appended2 = mapper.epoch(sc["scan"], np.eye(4))
+    assert appended2 < 0.1 * appended + 5
+
+
 @pytest.fixture(scope="module")
 def bundled():
     import os
