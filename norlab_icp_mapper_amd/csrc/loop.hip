@@ -271,9 +271,6 @@ __device__ __forceinline__ float match_weight(const LoopCfg& lc, const IcpState*
 //   point-to-point: [0] sum w, [1..3] sum w p, [4..6] sum w q, [7 + 3c + r] sum w q_r p_c
 //   always:         [27] sum w, [28] number of pairs
 // ---------------------------------------------------------------------------------------------
-__device__ void solve_body(IcpState* __restrict__ st, const double* __restrict__ partials, int nblocks, const LoopCfg& lc,
-                           float* __restrict__ T_step_out, double* __restrict__ sums_out);
-
 template <int MIN, bool FUSED>
 __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restrict__ reading, int n, LoopCfg lc,
                                                          IcpState* __restrict__ st, const float4* __restrict__ map,
@@ -282,9 +279,7 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restric
                                                          const int* __restrict__ sidx, const float* __restrict__ d2a,
                                                          double* __restrict__ partials, unsigned* __restrict__ hists,
                                                          int fused_slot, int is_median, float factor,
-                                                         const float4* __restrict__ match_pt, const int* __restrict__ qindex,
-                                                         int solve_here, float* __restrict__ T_step_out,
-                                                         double* __restrict__ sums_out)
+                                                         const float4* __restrict__ match_pt, const int* __restrict__ qindex)
 {
     // `reading`, sidx, d2a (and match_pt, the matched map points kept by the NN kernel) share one
     // order: the caller's, or -- qindex != nullptr -- the tile-sorted query order of the k = 1 loop,
@@ -404,20 +399,7 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restric
         double v = 0.0;
         if (i < NVAL || i == 27 || i == 28) v = sh[0][i] + sh[1][i] + sh[2][i] + sh[3][i];
         partials[(size_t)blockIdx.x * ICPMI_NV + i] = v;
-        if (solve_here) __threadfence(); // publish: only the lanes that stored a partial pay for the fence
     }
-    if (!solve_here) return;
-    // The last workgroup to publish its partials reduces them (fixed order) and solves: saves a
-    // dependent launch.  Standard ticket pattern: stores -> device fence -> ticket; the winner fences
-    // again before reading the other workgroups' partials.
-    __shared__ unsigned s_last;
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&st->ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    if (threadIdx.x == 0) st->ticket = 0;
-    solve_body(st, partials, (int)gridDim.x, lc, T_step_out, sums_out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -515,15 +497,27 @@ __device__ void svd3f_dev(const float* H, float* U, float* s, float* V)
         if (off <= 1e-7f) break;
     }
     float sv[3];
+#pragma unroll
     for (int j = 0; j < 3; ++j) sv[j] = sqrtf(a[3 * j] * a[3 * j] + a[3 * j + 1] * a[3 * j + 1] + a[3 * j + 2] * a[3 * j + 2]);
-    int ord[3] = {0, 1, 2};
-    for (int i = 0; i < 2; ++i)
-        for (int j = i + 1; j < 3; ++j)
-            if (sv[ord[j]] > sv[ord[i]]) { const int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
+    // descending order by the exchange sort (0,1) (0,2) (1,2), strict comparisons: columns travel with their
+    // singular value.  Static indices only -- a permutation array would push a, v and sv into scratch.
+#define SVD3_CSWAP(I, J)                                                                      \
+    if (sv[J] > sv[I]) {                                                                      \
+        float t_ = sv[I]; sv[I] = sv[J]; sv[J] = t_;                                          \
+        _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_) {                                    \
+            t_ = a[3 * I + i_]; a[3 * I + i_] = a[3 * J + i_]; a[3 * J + i_] = t_;            \
+            t_ = v[3 * I + i_]; v[3 * I + i_] = v[3 * J + i_]; v[3 * J + i_] = t_;            \
+        }                                                                                     \
+    }
+    SVD3_CSWAP(0, 1)
+    SVD3_CSWAP(0, 2)
+    SVD3_CSWAP(1, 2)
+#undef SVD3_CSWAP
+#pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const int o = ord[j];
-        s[j] = sv[o];
-        for (int i = 0; i < 3; ++i) { V[3 * j + i] = v[3 * o + i]; U[3 * j + i] = a[3 * o + i]; }
+        s[j] = sv[j];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { V[3 * j + i] = v[3 * j + i]; U[3 * j + i] = a[3 * j + i]; }
     }
     const float tiny = s[0] * 1e-6f;
     bool good[3];
@@ -534,8 +528,8 @@ __device__ void svd3f_dev(const float* H, float* U, float* s, float* V)
     if (!good[0]) { for (int i = 0; i < 9; ++i) U[i] = (i % 4 == 0) ? 1.f : 0.f; return; }
     if (!good[1]) {
         const int m = fabsf(U[0]) < fabsf(U[1]) ? (fabsf(U[0]) < fabsf(U[2]) ? 0 : 2) : (fabsf(U[1]) < fabsf(U[2]) ? 1 : 2);
-        float e[3] = {0, 0, 0}; e[m] = 1.f;
-        const float d = U[m];
+        const float e[3] = {m == 0 ? 1.f : 0.f, m == 1 ? 1.f : 0.f, m == 2 ? 1.f : 0.f};
+        const float d = m == 0 ? U[0] : (m == 1 ? U[1] : U[2]);
         const float w[3] = {e[0] - d * U[0], e[1] - d * U[1], e[2] - d * U[2]};
         const float nw = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
         for (int i = 0; i < 3; ++i) U[3 + i] = w[i] / nw;
@@ -812,7 +806,6 @@ __device__ void solve_body(IcpState* __restrict__ st, const double* __restrict__
     st->dbg[21] += 1;
 }
 
-// stand-alone form (ICPMI_FUSE_SOLVE=0)
 __global__ __launch_bounds__(256) void solve_kernel(IcpState* __restrict__ st, const double* __restrict__ partials, int nblocks,
                                                     LoopCfg lc, float* __restrict__ T_step_out, double* __restrict__ sums_out)
 {
@@ -987,7 +980,7 @@ static void enqueue_selection(icpmi_ctx* c, const LoopCfg& lc, int64_t count, bo
 }
 
 template <int MIN, bool FUSED>
-static void launch_accumulate(icpmi_ctx* c, int64_t n, const LoopCfg& lc, int nb, int slot, int solve_here, float* d_Tstep, double* d_sums)
+static void launch_accumulate(icpmi_ctx* c, int64_t n, const LoopCfg& lc, int nb, int slot)
 {
     const float4* rn = lc.has_read_normals ? c->d_read_normals : nullptr;
     const int is_med = slot >= 0 && lc.out_type[slot] == ICPMI_OUT_MEDIANDIST;
@@ -995,8 +988,7 @@ static void launch_accumulate(icpmi_ctx* c, int64_t n, const LoopCfg& lc, int nb
     const bool sorted = lc.k == 1 && c->nn_out_sorted; // loop state in query order (see nn1_ml_kernel)
     hipLaunchKernelGGL((accumulate_kernel<MIN, FUSED>), dim3(nb), dim3(256), 0, c->stream, sorted ? c->d_qsorted : c->d_reading, (int)n, lc, c->d_state,
                        c->d_map_sorted, c->d_normals_sorted, rn, c->d_sidx, c->d_d2, c->d_partials, c->d_selhist, slot, is_med, factor,
-                       sorted ? c->d_match_pt : (const float4*)nullptr, sorted ? c->d_qindex : (const int*)nullptr, solve_here, d_Tstep,
-                       d_sums);
+                       sorted ? c->d_match_pt : (const float4*)nullptr, sorted ? c->d_qindex : (const int*)nullptr);
 }
 
 static void enqueue_accumulate_solve(icpmi_ctx* c, int64_t n, const LoopCfg& lc, float* d_Tstep, double* d_sums)
@@ -1005,23 +997,20 @@ static void enqueue_accumulate_solve(icpmi_ctx* c, int64_t n, const LoopCfg& lc,
     const int nb = acc_blocks(count);
     const int slot = fused_filter_slot(lc);
     const bool fused = slot >= 0;
-    static int fuse_solve = -1;
-    // Measured (r1): letting the last pair-sum workgroup solve (ticket + device fences) costs +3.5 us per
-    // iteration against the separate 1-workgroup launch -- the release fences write back the L2 of every
-    // XCD -- so the stand-alone solve launch stays the default.
-    if (fuse_solve < 0) { const char* e = getenv("ICPMI_FUSE_SOLVE"); fuse_solve = e ? atoi(e) : 0; }
+    // (r1: letting the last pair-sum workgroup solve -- ticket + device fences -- measured +3.5 us per
+    // iteration against this separate 1-workgroup launch, and dragged the solver's registers and scratch
+    // into the pair-sum kernel: removed.)
     if (lc.minimizer == ICPMI_MIN_POINT_TO_PLANE) {
-        if (fused) launch_accumulate<ICPMI_MIN_POINT_TO_PLANE, true>(c, n, lc, nb, slot, fuse_solve, d_Tstep, d_sums);
-        else launch_accumulate<ICPMI_MIN_POINT_TO_PLANE, false>(c, n, lc, nb, slot, fuse_solve, d_Tstep, d_sums);
+        if (fused) launch_accumulate<ICPMI_MIN_POINT_TO_PLANE, true>(c, n, lc, nb, slot);
+        else launch_accumulate<ICPMI_MIN_POINT_TO_PLANE, false>(c, n, lc, nb, slot);
     } else if (lc.minimizer == ICPMI_MIN_POINT_TO_POINT) {
-        if (fused) launch_accumulate<ICPMI_MIN_POINT_TO_POINT, true>(c, n, lc, nb, slot, fuse_solve, d_Tstep, d_sums);
-        else launch_accumulate<ICPMI_MIN_POINT_TO_POINT, false>(c, n, lc, nb, slot, fuse_solve, d_Tstep, d_sums);
+        if (fused) launch_accumulate<ICPMI_MIN_POINT_TO_POINT, true>(c, n, lc, nb, slot);
+        else launch_accumulate<ICPMI_MIN_POINT_TO_POINT, false>(c, n, lc, nb, slot);
     } else {
-        if (fused) launch_accumulate<ICPMI_MIN_IDENTITY, true>(c, n, lc, nb, slot, fuse_solve, d_Tstep, d_sums);
-        else launch_accumulate<ICPMI_MIN_IDENTITY, false>(c, n, lc, nb, slot, fuse_solve, d_Tstep, d_sums);
+        if (fused) launch_accumulate<ICPMI_MIN_IDENTITY, true>(c, n, lc, nb, slot);
+        else launch_accumulate<ICPMI_MIN_IDENTITY, false>(c, n, lc, nb, slot);
     }
-    if (!fuse_solve)
-        hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(256), 0, c->stream, c->d_state, c->d_partials, nb, lc, d_Tstep, d_sums);
+    hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(256), 0, c->stream, c->d_state, c->d_partials, nb, lc, d_Tstep, d_sums);
 }
 
 static icpmi_status enqueue_iteration(icpmi_ctx* c, int64_t n, const LoopCfg& lc, hipEvent_t nn0, hipEvent_t nn1)
