@@ -186,6 +186,21 @@ icpmi_status icpmi_surface_normals(icpmi_handle h, const float* pts4, int64_t m,
 icpmi_status icpmi_point_distance_keep(icpmi_handle h, const float* map4, int64_t m, const float* in4, int64_t n,
                                        float min_dist, uint8_t* keep);
 
+/* `Map::updateLocalPointCloud` for the PointDistance chain, on the resident map (Map.cpp:502-534 with
+ * PointDistanceMapperModule.cpp:28-50 as the only module and, when normals_knn > 0, SurfaceNormalDataPointsFilter{knn}
+ * as the post filter, examples/config.yaml:26-27): scan4 (n x 4, MAP frame) -> keep mask against the handle's current
+ * map (self match excluded, keep iff d2 >= min_dist^2) -> kept points appended in input order -> normals of the whole
+ * grown map recomputed (normals_knn > 0; else the appended points take scan_normals3 or zeros) -> index rebuilt
+ * (`icp.setMap`, Map.cpp:528).  Only the scan crosses PCIe.  On a handle without a map the scan becomes the map
+ * (`PointDistanceMapperModule::createMap`).  The post filter runs in the map frame (the reference rotates the cloud
+ * into the sensor frame and back, Map.cpp:523-525; PCA normals are rotation-equivariant up to rounding). */
+icpmi_status icpmi_map_update_point_distance(icpmi_handle h, const float* scan4, int64_t n, const float* scan_normals3,
+                                             float min_dist, int32_t normals_knn, int64_t* appended, int64_t* new_m);
+
+/* Download of the resident map in the caller's order (what `Map::getLocalPointCloud` returns, Map.cpp:536-540);
+ * out4 / normals3 may be NULL to query *m only. */
+icpmi_status icpmi_get_map(icpmi_handle h, float* out4, float* normals3, int64_t capacity, int64_t* m);
+
 /* `OctreeMapperModule::inPlaceUpdateMap` decimation (OctreeMapperModule.cpp:35-39 -> OctreeGridDataPointsFilter
  * {maxSizeByNode: edge, samplingMethod: 0}), as a lattice stand-in: voxel index floor((p - lo) / edge) per axis
  * with lo the bounding-box minimum; keep[i] = 1 iff i is the smallest index of its voxel. */

@@ -129,7 +129,7 @@ void icpmi_destroy(icpmi_handle c)
     hipFree(c->d_keys); hipFree(c->d_fill); hipFree(c->d_blocksums); hipFree(c->d_red);
     hipFree(c->d_qsorted); hipFree(c->d_qindex); hipFree(c->d_qkeys); hipFree(c->d_qtile);
     hipFree(c->d_reading); hipFree(c->d_read_normals); hipFree(c->d_stage_in); hipFree(c->d_stage_n3);
-    hipFree(c->d_match_pt); hipFree(c->d_lvl_tab);
+    hipFree(c->d_match_pt); hipFree(c->d_lvl_tab); hipFree(c->d_raw); hipFree(c->d_raw_n3);
     hipFree(c->d_sidx); hipFree(c->d_d2); hipFree(c->d_hard); hipFree(c->d_partials); hipFree(c->d_selhist);
     hipFree(c->d_state);
     if (c->h_state) hipHostFree(c->h_state);
@@ -382,6 +382,20 @@ icpmi_status icpmi_point_distance_keep(icpmi_handle h, const float* map4, int64_
     CHECK_H(h);
     if (m < 0 || n < 0 || (m > 0 && !map4) || (n > 0 && (!in4 || !keep))) { h->last_error = "point_distance_keep: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
     return ops_point_distance_keep(h, map4, m, in4, n, min_dist, keep);
+}
+
+icpmi_status icpmi_map_update_point_distance(icpmi_handle h, const float* scan4, int64_t n, const float* scan_normals3, float min_dist,
+                                             int32_t normals_knn, int64_t* appended, int64_t* new_m)
+{
+    CHECK_H(h);
+    if (n < 0 || (n > 0 && !scan4) || !(min_dist >= 0.f)) { h->last_error = "map_update_point_distance: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
+    return ops_map_update_point_distance(h, scan4, n, scan_normals3, min_dist, normals_knn, appended, new_m);
+}
+
+icpmi_status icpmi_get_map(icpmi_handle h, float* out4, float* normals3, int64_t capacity, int64_t* m)
+{
+    CHECK_H(h);
+    return ops_get_map(h, out4, normals3, capacity, m);
 }
 
 icpmi_status icpmi_voxel_keep_first(icpmi_handle h, const float* in4, int64_t n, float edge, uint8_t* keep)

@@ -149,6 +149,11 @@ struct icpmi_ctx {
     int64_t qsorted_n = -1; const float4* qsorted_src = nullptr; // which reading d_qsorted was built from
     float4* d_stage_in = nullptr; size_t cap_stage_in = 0;     // host->device staging
     float*  d_stage_n3 = nullptr; size_t cap_stage_n3 = 0;
+    // resident copy of the map as it was handed to set_map (original frame, caller's order): what the
+    // device-side map update appends to and rebuilds from
+    float4* d_raw = nullptr; size_t cap_raw = 0;
+    float*  d_raw_n3 = nullptr; size_t cap_raw_n3 = 0;
+    int64_t m_raw = 0; bool raw_has_normals = false;
     int*    d_sidx = nullptr; size_t cap_sidx = 0;             // k x n sorted-map index (-1 none)
     float*  d_d2 = nullptr; size_t cap_d2 = 0;                 // k x n
     unsigned* d_hard = nullptr; size_t cap_hard = 0;           // hard query list
@@ -188,6 +193,20 @@ static inline icpmi_status ensure_cap(icpmi_ctx* c, T** p, size_t* cap, size_t n
     size_t want = need + need / 4 + 64;
     HIP_TRY(c, hipMalloc((void**)p, want * sizeof(T)));
     *cap = want;
+    return ICPMI_OK;
+}
+
+// like ensure_cap, but the first `used` entries survive a reallocation
+template <typename T>
+static inline icpmi_status ensure_cap_keep(icpmi_ctx* c, T** p, size_t* cap, size_t need, size_t used)
+{
+    if (need <= *cap && *p) return ICPMI_OK;
+    const size_t want = need + need / 2 + 64;
+    T* q = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&q, want * sizeof(T)));
+    if (*p && used) HIP_TRY(c, hipMemcpyAsync(q, *p, used * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+    if (*p) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipFree(*p)); }
+    *p = q; *cap = want;
     return ICPMI_OK;
 }
 
@@ -239,6 +258,9 @@ icpmi_status ops_transform(icpmi_ctx* c, const float T[16], const float* in4, in
 icpmi_status ops_surface_normals(icpmi_ctx* c, const float* pts4, int64_t m, int knn, float* normals3);
 icpmi_status ops_dynamic_points_update(icpmi_ctx* c, const icpmi_dynpts_params* prm, const float to_sensor[16], const float* in4, int64_t n,
                                        const float* map4, const float* map_normals3, int64_t m, float* prob);
+icpmi_status ops_map_update_point_distance(icpmi_ctx* c, const float* scan4, int64_t n, const float* scan_normals3, float min_dist,
+                                           int normals_knn, int64_t* appended, int64_t* new_m);
+icpmi_status ops_get_map(icpmi_ctx* c, float* out4, float* normals3, int64_t capacity, int64_t* m);
 icpmi_status ops_voxel_keep_first(icpmi_ctx* c, const float* in4, int64_t n, float edge, uint8_t* keep);
 icpmi_status ops_point_distance_keep(icpmi_ctx* c, const float* map4, int64_t m, const float* in4, int64_t n,
                                      float min_dist, uint8_t* keep);

@@ -324,6 +324,29 @@ __global__ __launch_bounds__(256) void dyn_update_kernel(const float4* __restric
     }
 }
 
+__global__ __launch_bounds__(256) void keep_flag_kernel(const float* __restrict__ d2, int64_t n, float lim, unsigned* __restrict__ flag)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    flag[i] = d2[i] >= lim ? 1u : 0u;
+}
+
+// stable compaction: kept input i goes to slot base + pos[i] (pos = exclusive scan of the flags)
+__global__ __launch_bounds__(256) void append_kept_kernel(const float4* __restrict__ in, const float* __restrict__ in_n3, int64_t n,
+                                                          const float* __restrict__ d2, float lim, const unsigned* __restrict__ pos,
+                                                          int64_t base, float4* __restrict__ raw, float* __restrict__ raw_n3)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !(d2[i] >= lim)) return;
+    const int64_t o = base + pos[i];
+    raw[o] = in[i];
+    if (raw_n3) {
+        raw_n3[3 * o] = in_n3 ? in_n3[3 * i] : 0.f;
+        raw_n3[3 * o + 1] = in_n3 ? in_n3[3 * i + 1] : 0.f;
+        raw_n3[3 * o + 2] = in_n3 ? in_n3[3 * i + 2] : 0.f;
+    }
+}
+
 } // namespace
 
 // helper: a private handle on the same device/stream used to index an arbitrary cloud without
@@ -547,5 +570,137 @@ icpmi_status ops_dynamic_points_update(icpmi_ctx* c, const icpmi_dynpts_params* 
     hipFree(d_map); hipFree(d_nrm); hipFree(d_prob);
     if (st != ICPMI_OK) return st;
     HIP_TRY(c, e);
+    return ICPMI_OK;
+}
+
+// SurfaceNormalDataPointsFilter{knn} over a DEVICE cloud into a DEVICE 3 x m array (same kernels as ops_surface_normals)
+static icpmi_status surface_normals_dev(icpmi_ctx* c, const float4* d_pts, int64_t m, int knn, float* d_normals3)
+{
+    TempCtx t;
+    icpmi_status s = make_temp(c, t);
+    if (s != ICPMI_OK) return s;
+    icpmi_ctx* tc = t.h;
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); // d_pts was produced on the caller's stream
+    int32_t acc = 0;
+    s = icpmi_set_map_dev(t.h, (const float*)d_pts, m, nullptr, &acc);
+    if (s != ICPMI_OK) { c->last_error = tc->last_error; return s; }
+    s = loop_prepare_reading(tc, d_pts, m, nullptr);
+    if (s != ICPMI_OK) { c->last_error = tc->last_error; return s; }
+    LoopCfg lc = make_loop_cfg(tc, 1);
+    lc.k = knn; lc.max_dist = INFINITY; lc.maxr2 = INFINITY; lc.ring_max = 6;
+    const size_t cnt = (size_t)m * knn + 1;
+    if (ensure_cap(tc, &tc->d_sidx, &tc->cap_sidx, cnt) != ICPMI_OK || ensure_cap(tc, &tc->d_d2, &tc->cap_d2, cnt) != ICPMI_OK ||
+        ensure_cap(tc, &tc->d_hard, &tc->cap_hard, (size_t)m + 1) != ICPMI_OK) { c->last_error = tc->last_error; return ICPMI_ERR_HIP; }
+    HIP_TRY(c, hipMemsetAsync(tc->d_state, 0, sizeof(IcpState), tc->stream));
+    tc->nn_hist0 = nullptr; tc->nn_iter_hint = 0; tc->nn_match_pt = nullptr;
+    s = nn_launch_k(tc, tc->d_reading, m, nullptr, lc, 1, tc->d_sidx, tc->d_d2, tc->d_state);
+    if (s != ICPMI_OK) { c->last_error = tc->last_error; return s; }
+    // rows of d_sidx follow the query order = the caller's order, so the normals land in place
+    hipLaunchKernelGGL(normals_kernel, dim3((int)((m + 127) / 128)), dim3(128), 0, tc->stream, tc->d_map_sorted, tc->d_sidx, m, knn, d_normals3);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(tc->stream);
+    HIP_TRY(c, e);
+    return ICPMI_OK;
+}
+
+icpmi_status ops_map_update_point_distance(icpmi_ctx* c, const float* scan4, int64_t n, const float* scan_normals3, float min_dist,
+                                           int normals_knn, int64_t* appended, int64_t* new_m)
+{
+    if (appended) *appended = 0;
+    if (new_m) *new_m = c->m_raw;
+    if (n == 0) return ICPMI_OK;
+    if (normals_knn < 0 || normals_knn > ICPMI_MAX_K) { c->last_error = "map_update: normals_knn must be in [0, 32]"; return ICPMI_ERR_INVALID_ARG; }
+    // stage the scan (and its normals)
+    if (ensure_cap(c, &c->d_stage_in, &c->cap_stage_in, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    HIP_TRY(c, hipMemcpyAsync(c->d_stage_in, scan4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    if (scan_normals3) {
+        if (ensure_cap(c, &c->d_stage_n3, &c->cap_stage_n3, (size_t)n * 3) != ICPMI_OK) return ICPMI_ERR_HIP;
+        HIP_TRY(c, hipMemcpyAsync(c->d_stage_n3, scan_normals3, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    }
+    const int64_t m0 = c->m > 0 ? c->m_raw : 0;
+    const float lim = powf(min_dist, 2.f);
+    const int blocks = (int)((n + 255) / 256);
+    unsigned* d_flag = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d_flag, ((size_t)n + 2) * sizeof(unsigned)));
+    icpmi_status s = ICPMI_OK;
+    hipError_t e = hipSuccess;
+    unsigned count = 0;
+    if (m0 > 0) {
+        // PointDistanceMapperModule.cpp:33-42: exact NN of every input point in the map, self match excluded, keep
+        // iff d2 >= minDist^2.  A radius search with maxDist = minDist decides the same predicate.
+        s = loop_prepare_reading(c, c->d_stage_in, n, nullptr);
+        LoopCfg lc = make_loop_cfg(c, 1);
+        lc.k = 1; lc.n_out = 0; lc.max_dist = min_dist; lc.maxr2 = lim;
+        const size_t cnt = (size_t)n + 1;
+        if (s == ICPMI_OK && (ensure_cap(c, &c->d_sidx, &c->cap_sidx, cnt) != ICPMI_OK || ensure_cap(c, &c->d_d2, &c->cap_d2, cnt) != ICPMI_OK ||
+                              ensure_cap(c, &c->d_hard, &c->cap_hard, cnt) != ICPMI_OK)) s = ICPMI_ERR_HIP;
+        if (s == ICPMI_OK) {
+            e = hipMemsetAsync(c->d_state, 0, sizeof(IcpState), c->stream);
+            c->nn_hist0 = nullptr; c->nn_iter_hint = 0; c->nn_match_pt = nullptr;
+            if (e == hipSuccess) s = nn_launch_k(c, c->d_reading, n, nullptr, lc, 0, c->d_sidx, c->d_d2, c->d_state);
+        }
+        if (s == ICPMI_OK && e == hipSuccess) {
+            hipLaunchKernelGGL(keep_flag_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_d2, n, lim, d_flag);
+            s = device_exclusive_scan(c, d_flag, (int)n, 0u);
+        }
+    } else {
+        // PointDistanceMapperModule::createMap: the first scan is the map
+        e = hipMemsetAsync(d_flag, 0, ((size_t)n + 2) * sizeof(unsigned), c->stream);
+    }
+    if (s == ICPMI_OK && e == hipSuccess && m0 > 0) {
+        // count = scan[n-1] + flag[n-1]; the scan overwrote the flags, so recompute the last flag from d2
+        unsigned last_pos = 0; float last_d2 = 0.f;
+        e = hipMemcpyAsync(&last_pos, d_flag + (n - 1), sizeof(unsigned), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&last_d2, c->d_d2 + (n - 1), sizeof(float), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        count = last_pos + (last_d2 >= lim ? 1u : 0u);
+    } else if (m0 == 0) count = (unsigned)n;
+    if (s == ICPMI_OK && e == hipSuccess && count > 0) {
+        const int64_t m1 = m0 + count;
+        const bool want_n = normals_knn > 0 || c->raw_has_normals || scan_normals3 != nullptr;
+        if (m1 >= (1ll << 28)) { c->last_error = "map_update: the map would exceed 2^28-1 points"; s = ICPMI_ERR_UNSUPPORTED; }
+        if (s == ICPMI_OK) s = ensure_cap_keep(c, &c->d_raw, &c->cap_raw, (size_t)m1, (size_t)m0);
+        if (s == ICPMI_OK && want_n) {
+            const bool had = c->raw_has_normals && m0 > 0;
+            s = ensure_cap_keep(c, &c->d_raw_n3, &c->cap_raw_n3, (size_t)m1 * 3, had ? (size_t)m0 * 3 : 0);
+            if (s == ICPMI_OK && !had && m0 > 0) e = hipMemsetAsync(c->d_raw_n3, 0, (size_t)m0 * 3 * sizeof(float), c->stream);
+        }
+        if (s == ICPMI_OK && e == hipSuccess) {
+            if (m0 > 0)
+                hipLaunchKernelGGL(append_kept_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_stage_in,
+                                   scan_normals3 ? c->d_stage_n3 : (const float*)nullptr, n, c->d_d2, lim, d_flag, m0, c->d_raw,
+                                   want_n ? c->d_raw_n3 : (float*)nullptr);
+            else {
+                e = hipMemcpyAsync(c->d_raw, c->d_stage_in, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream);
+                if (e == hipSuccess && want_n) {
+                    if (scan_normals3) e = hipMemcpyAsync(c->d_raw_n3, c->d_stage_n3, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
+                    else e = hipMemsetAsync(c->d_raw_n3, 0, (size_t)n * 3 * sizeof(float), c->stream);
+                }
+            }
+            if (e == hipSuccess) e = hipGetLastError();
+        }
+        // SurfaceNormalDataPointsFilter over the grown map (Map.cpp:524 with examples/config.yaml:26-27)
+        if (s == ICPMI_OK && e == hipSuccess && normals_knn > 0) s = surface_normals_dev(c, c->d_raw, m1, normals_knn, c->d_raw_n3);
+        // icp.setMap(localPointCloud) (Map.cpp:528): rebuild the index from the resident copy
+        if (s == ICPMI_OK && e == hipSuccess) s = map_build(c, c->d_raw, m1, want_n ? c->d_raw_n3 : nullptr);
+        if (s == ICPMI_OK) { if (appended) *appended = count; if (new_m) *new_m = m1; }
+    }
+    hipFree(d_flag);
+    if (s != ICPMI_OK) return s;
+    HIP_TRY(c, e);
+    return ICPMI_OK;
+}
+
+icpmi_status ops_get_map(icpmi_ctx* c, float* out4, float* normals3, int64_t capacity, int64_t* m)
+{
+    if (m) *m = c->m > 0 ? c->m_raw : 0;
+    if (c->m <= 0 || !out4) return ICPMI_OK;
+    if (capacity < c->m_raw) { c->last_error = "get_map: capacity too small"; return ICPMI_ERR_INVALID_ARG; }
+    HIP_TRY(c, hipMemcpyAsync(out4, c->d_raw, (size_t)c->m_raw * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    if (normals3) {
+        if (!c->raw_has_normals) { c->last_error = "InvalidField: the map has no normals"; return ICPMI_ERR_MISSING_NORMALS; }
+        HIP_TRY(c, hipMemcpyAsync(normals3, c->d_raw_n3, (size_t)c->m_raw * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return ICPMI_OK;
 }

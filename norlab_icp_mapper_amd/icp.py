@@ -352,6 +352,26 @@ class ICPSequence:
                                                           i.ctypes.data, i.shape[0], m.ctypes.data, nn.ctypes.data, m.shape[0], out.ctypes.data))
         return out
 
+    def mapUpdatePointDistance(self, scan_in_map_frame, min_dist, normals_knn=0, scan_normals=None):
+        """Map::updateLocalPointCloud for the PointDistance chain on the resident map (Map.cpp:502-534): returns
+        (points appended, points in the map afterwards).  Only the scan is uploaded."""
+        sc = _f32c(scan_in_map_frame, 4)
+        sn = None if scan_normals is None else _f32c(scan_normals, 3)
+        app = C.c_int64(0); m = C.c_int64(0)
+        self._check(self._lib.icpmi_map_update_point_distance(self._h, sc.ctypes.data, sc.shape[0], None if sn is None else sn.ctypes.data,
+                                                              min_dist, normals_knn, C.byref(app), C.byref(m)))
+        return int(app.value), int(m.value)
+
+    def getMap(self, with_normals=False):
+        """The resident map in the caller's order (Map::getLocalPointCloud, Map.cpp:536-540)."""
+        m = C.c_int64(0)
+        self._check(self._lib.icpmi_get_map(self._h, None, None, 0, C.byref(m)))
+        out = np.empty((m.value, 4), dtype=np.float32)
+        nrm = np.empty((m.value, 3), dtype=np.float32) if with_normals else None
+        if m.value:
+            self._check(self._lib.icpmi_get_map(self._h, out.ctypes.data, None if nrm is None else nrm.ctypes.data, m.value, C.byref(m)))
+        return (out, nrm) if with_normals else out
+
     def binCells(self, cloud, cell_size=20.0):
         c = _f32c(cloud, 4)
         out = np.empty((c.shape[0], 3), dtype=np.int32)

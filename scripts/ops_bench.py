@@ -29,3 +29,11 @@ timeit(f"knn k=1 N={n} (stage call)", lambda: icp.knn(q, k=1, max_dist=2.0))
 timeit(f"knn k=6 N={n} (stage call)", lambda: icp.knn(q, k=6, max_dist=2.0))
 timeit(f"binCells M={m}", lambda: icp.binCells(sc["map"]))
 timeit(f"register N={n} (20 it, p2plane)", lambda: icp(sc["scan"]))
+# resident map update: only the scan crosses PCIe
+base = sc["map"][::2]; icp2 = pkg.ICPSequence(minimizer=2, max_dist=2.0)
+for knn in (0, 10):
+    def upd():
+        icp2.setMap(base, sc["normals"][::2])
+        t0 = time.perf_counter(); icp2.mapUpdatePointDistance(sc["scan"], 0.15, normals_knn=knn); return time.perf_counter() - t0
+    upd(); ts = [upd() for _ in range(3)]
+    print(f"{'mapUpdatePointDistance N=%d M=%d normals_knn=%d' % (n, base.shape[0], knn):44s} {min(ts) * 1e3:9.2f} ms")

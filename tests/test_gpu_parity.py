@@ -389,6 +389,49 @@ def test_dynamic_points_update_matches_oracle(amd, oracle, small_scene):
     assert np.array_equal(icp.dynamicPointsUpdate(to_sensor, scan[:0], mp, nrm, prob0), prob0)
 
 
+@pytest.mark.parametrize("normals_knn", [0, 7])
+def test_resident_map_update_equals_composed_path(amd, mid_scene, normals_knn):
+    """icpmi_map_update_point_distance (keep mask vs the resident map, append, normals, rebuild -- all on the
+    device) against the same chain composed from the host-pointer operators: identical map, identical normals,
+    identical registrations afterwards."""
+    sc = mid_scene
+    base = sc["map"][::2]
+    rng = np.random.default_rng(9)
+    scan_map = sc["map"][1::2][rng.permutation(sc["map"].shape[0] // 2)[:20000]].copy()   # unseen half of the surface
+    scan_map[:, :3] += rng.normal(0, 0.02, (scan_map.shape[0], 3)).astype(np.float32)
+    kw = dict(minimizer=2 if normals_knn else 1, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=10, use_differential=0)
+
+    a = amd.ICPSequence(**kw)                                   # composed, host pointers
+    keep = a.pointDistanceKeep(base, scan_map, 0.25)
+    grown = np.concatenate([base, scan_map[keep]])
+    nrm = a.surfaceNormals(grown, knn=normals_knn) if normals_knn else None
+    a.setMap(grown, nrm)
+
+    b = amd.ICPSequence(**kw)                                   # resident
+    b.setMap(base, b.surfaceNormals(base, knn=normals_knn) if normals_knn else None)
+    appended, m = b.mapUpdatePointDistance(scan_map, 0.25, normals_knn=normals_knn)
+    assert appended == int(keep.sum()) and m == grown.shape[0]
+    if normals_knn:
+        got, got_n = b.getMap(with_normals=True)
+        assert np.array_equal(got_n, nrm)
+    else:
+        got = b.getMap()
+    assert np.array_equal(got, grown)
+    Ta, Tb = a(sc["scan"]), b(sc["scan"])
+    assert np.array_equal(Ta, Tb)
+    # a second, shifted scan: same decision as the composed path (exact duplicates count as self matches and are
+    # ignored by the search, PointDistanceMapperModule.cpp:36 passes optionFlags = 0)
+    scan2 = scan_map.copy(); scan2[:, :3] += np.float32(0.1)
+    keep2 = a.pointDistanceKeep(grown, scan2, 0.25)
+    appended2, m2 = b.mapUpdatePointDistance(scan2, 0.25, normals_knn=normals_knn)
+    assert appended2 == int(keep2.sum()) and m2 == m + appended2
+    assert np.array_equal(b.getMap()[m:], scan2[keep2])
+    # a handle without a map: the scan becomes the map (PointDistanceMapperModule::createMap)
+    c = amd.ICPSequence(**kw)
+    app3, m3 = c.mapUpdatePointDistance(scan_map, 0.25, normals_knn=normals_knn)
+    assert app3 == m3 == scan_map.shape[0] and np.array_equal(c.getMap(), scan_map)
+
+
 def test_sharded_mapper_single_rank(amd, mid_scene):
     """The map-growth epoch of SURVEY 8(e) with the GPU operators (world size 1: no process group)."""
     sc = mid_scene
