@@ -92,6 +92,7 @@ int main(int argc, char** argv)
         map.save(dataDir + "/map.vtk");
         if (argc > 3) mapper.getTrajectory().save(argv[3]);
         std::printf("map: %zu points, %zu scans in %.3f s -> %s/map.vtk\n", map.getNbPoints(), scans.size(), secs, dataDir.c_str());
+        std::printf("resident map updates: %ld\n", mapper.residentMapUpdates());
     } catch (const std::exception& e) {
         std::fprintf(stderr, "error: %s\n", e.what());
         return 1;

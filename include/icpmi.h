@@ -191,11 +191,12 @@ icpmi_status icpmi_point_distance_keep(icpmi_handle h, const float* map4, int64_
  * as the post filter, examples/config.yaml:26-27): scan4 (n x 4, MAP frame) -> keep mask against the handle's current
  * map (self match excluded, keep iff d2 >= min_dist^2) -> kept points appended in input order -> normals of the whole
  * grown map recomputed (normals_knn > 0; else the appended points take scan_normals3 or zeros) -> index rebuilt
- * (`icp.setMap`, Map.cpp:528).  Only the scan crosses PCIe.  On a handle without a map the scan becomes the map
+ * (`icp.setMap`, Map.cpp:528).  Only the scan crosses PCIe; keep_out (n bytes, may be NULL) receives the keep mask so
+ * that a host that owns further descriptors of the map can append the kept rows itself.  On a handle without a map the scan becomes the map
  * (`PointDistanceMapperModule::createMap`).  The post filter runs in the map frame (the reference rotates the cloud
  * into the sensor frame and back, Map.cpp:523-525; PCA normals are rotation-equivariant up to rounding). */
 icpmi_status icpmi_map_update_point_distance(icpmi_handle h, const float* scan4, int64_t n, const float* scan_normals3,
-                                             float min_dist, int32_t normals_knn, int64_t* appended, int64_t* new_m);
+                                             float min_dist, int32_t normals_knn, uint8_t* keep_out, int64_t* appended, int64_t* new_m);
 
 /* Download of the resident map in the caller's order (what `Map::getLocalPointCloud` returns, Map.cpp:536-540);
  * out4 / normals3 may be NULL to query *m only. */

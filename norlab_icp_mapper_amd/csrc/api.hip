@@ -385,11 +385,11 @@ icpmi_status icpmi_point_distance_keep(icpmi_handle h, const float* map4, int64_
 }
 
 icpmi_status icpmi_map_update_point_distance(icpmi_handle h, const float* scan4, int64_t n, const float* scan_normals3, float min_dist,
-                                             int32_t normals_knn, int64_t* appended, int64_t* new_m)
+                                             int32_t normals_knn, uint8_t* keep_out, int64_t* appended, int64_t* new_m)
 {
     CHECK_H(h);
     if (n < 0 || (n > 0 && !scan4) || !(min_dist >= 0.f)) { h->last_error = "map_update_point_distance: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
-    return ops_map_update_point_distance(h, scan4, n, scan_normals3, min_dist, normals_knn, appended, new_m);
+    return ops_map_update_point_distance(h, scan4, n, scan_normals3, min_dist, normals_knn, keep_out, appended, new_m);
 }
 
 icpmi_status icpmi_get_map(icpmi_handle h, float* out4, float* normals3, int64_t capacity, int64_t* m)

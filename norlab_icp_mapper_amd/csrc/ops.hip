@@ -604,7 +604,7 @@ static icpmi_status surface_normals_dev(icpmi_ctx* c, const float4* d_pts, int64
 }
 
 icpmi_status ops_map_update_point_distance(icpmi_ctx* c, const float* scan4, int64_t n, const float* scan_normals3, float min_dist,
-                                           int normals_knn, int64_t* appended, int64_t* new_m)
+                                           int normals_knn, uint8_t* keep_out, int64_t* appended, int64_t* new_m)
 {
     if (appended) *appended = 0;
     if (new_m) *new_m = c->m_raw;
@@ -639,6 +639,16 @@ icpmi_status ops_map_update_point_distance(icpmi_ctx* c, const float* scan4, int
             c->nn_hist0 = nullptr; c->nn_iter_hint = 0; c->nn_match_pt = nullptr;
             if (e == hipSuccess) s = nn_launch_k(c, c->d_reading, n, nullptr, lc, 0, c->d_sidx, c->d_d2, c->d_state);
         }
+        if (s == ICPMI_OK && e == hipSuccess && keep_out) {
+            uint8_t* d_keep = nullptr;
+            e = hipMalloc((void**)&d_keep, (size_t)n);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(keep_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_d2, n, lim, d_keep);
+                e = hipMemcpyAsync(keep_out, d_keep, (size_t)n, hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+                hipFree(d_keep);
+            }
+        }
         if (s == ICPMI_OK && e == hipSuccess) {
             hipLaunchKernelGGL(keep_flag_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_d2, n, lim, d_flag);
             s = device_exclusive_scan(c, d_flag, (int)n, 0u);
@@ -646,6 +656,7 @@ icpmi_status ops_map_update_point_distance(icpmi_ctx* c, const float* scan4, int
     } else {
         // PointDistanceMapperModule::createMap: the first scan is the map
         e = hipMemsetAsync(d_flag, 0, ((size_t)n + 2) * sizeof(unsigned), c->stream);
+        if (keep_out) memset(keep_out, 1, (size_t)n);
     }
     if (s == ICPMI_OK && e == hipSuccess && m0 > 0) {
         // count = scan[n-1] + flag[n-1]; the scan overwrote the flags, so recompute the last flag from d2

@@ -170,6 +170,30 @@ bool GpuICPSequence::setMap(const DataPoints& map)
     return accepted != 0;
 }
 
+void GpuICPSequence::mapUpdatePointDistance(const DataPoints& input, float minDist, int normalsKnn, std::vector<uint8_t>& keep, int64_t& appended,
+                                            int64_t& mapSize)
+{
+    const float* normals = nullptr;
+    if (normalsKnn <= 0 && input.descriptorExists("normals") && input.getDescriptorByName("normals").span == 3)
+        normals = input.getDescriptorByName("normals").data.data();
+    keep.assign(input.getNbPoints(), 0);
+    check(h, icpmi_map_update_point_distance(h, input.features.data(), (int64_t)input.getNbPoints(), normals, minDist, normalsKnn, keep.data(),
+                                             &appended, &mapSize));
+}
+
+DataPoints GpuICPSequence::downloadMap() const
+{
+    int64_t m = 0;
+    check(h, icpmi_get_map(h, nullptr, nullptr, 0, &m));
+    DataPoints out((size_t)m);
+    if (m == 0) return out;
+    std::vector<float> nrm(3 * (size_t)m);
+    const icpmi_status s = icpmi_get_map(h, out.features.data(), nrm.data(), m, &m);
+    if (s == ICPMI_ERR_MISSING_NORMALS) check(h, icpmi_get_map(h, out.features.data(), nullptr, m, &m));
+    else { check(h, s); out.addDescriptor("normals", 3, std::move(nrm)); }
+    return out;
+}
+
 Mat4 GpuICPSequence::operator()(const DataPoints& reading)
 {
     Mat4 T = Mat4::identity();
@@ -262,6 +286,7 @@ struct CutAtDescriptorThresholdFilter : DataPointsFilter {
 
 struct SurfaceNormalFilter : DataPointsFilter {
     icpmi_handle h; int knn = 5;
+    int surfaceNormalKnn() const override { return knn; }
     void inPlaceFilter(DataPoints& c) const override {
         const size_t n = c.getNbPoints();
         std::vector<float> normals(3 * n);

@@ -38,6 +38,10 @@ public:
     const ErrorMinimizerView* errorMinimizer = &minimizerView;
 
     icpmi_handle handle() const { return h; }          // for the operators that share the GPU context
+    // Map::updateLocalPointCloud for the PointDistance chain on the resident map (icpmi_map_update_point_distance)
+    void mapUpdatePointDistance(const DataPoints& inputInMapFrame, float minDist, int normalsKnn, std::vector<uint8_t>& keep, int64_t& appended,
+                                int64_t& mapSize);
+    DataPoints downloadMap() const;                    // the resident map (features + `normals` if it has them)
     const icpmi_stats& stats() const { return lastStats; }
     const icpmi_config& config() const { return cfg; }
     static void check(icpmi_handle h, icpmi_status s); // status -> exception mapping
@@ -65,6 +69,8 @@ class DataPointsFilter {
 public:
     virtual ~DataPointsFilter() = default;
     virtual void inPlaceFilter(DataPoints& cloud) const = 0;
+    // > 0 only for SurfaceNormalDataPointsFilter: lets Map run that post filter on the resident map
+    virtual int surfaceNormalKnn() const { return 0; }
 };
 
 class DataPointsFilters {

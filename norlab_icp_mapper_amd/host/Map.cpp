@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
 
 namespace nim {
 
@@ -63,6 +64,7 @@ void Map::loadCells(Box box)
             }
     std::lock_guard<std::mutex> g(localPointCloudLock);
     if (chunk.getNbPoints() > 0) {
+        syncLocalFromDevice();
         localPointCloud.concatenate(chunk);
         {
             std::lock_guard<std::mutex> gi(icpMapLock);
@@ -87,6 +89,7 @@ void Map::unloadCells(Box box)
     DataPoints oldChunk;
     {
         std::lock_guard<std::mutex> g(localPointCloudLock);
+        syncLocalFromDevice();
         const size_t n = localPointCloud.getNbPoints();
         std::vector<uint8_t> leaves(n), stays(n);
         for (size_t i = 0; i < n; ++i) {
@@ -194,13 +197,77 @@ void Map::updatePose(const Mat4& pose)
 DataPoints Map::getLocalPointCloud()
 {
     std::lock_guard<std::mutex> g(localPointCloudLock);
+    syncLocalFromDevice();
     return localPointCloud;
+}
+
+void Map::syncLocalFromDevice()
+{
+    if (!deviceAhead) return;
+    // features and `normals` live on the device; every other descriptor was kept current on the host
+    DataPoints dev;
+    {
+        std::lock_guard<std::mutex> gi(icpMapLock);
+        dev = icp.downloadMap();
+    }
+    localPointCloud.features = std::move(dev.features);
+    localPointCloud.removeDescriptor("normals");
+    if (dev.descriptorExists("normals")) localPointCloud.addDescriptor("normals", 3, std::move(dev.getDescriptorByName("normals").data));
+    deviceAhead = false;
+}
+
+bool Map::tryResidentUpdate(const DataPoints& input, const DataPointsFilters& postFilters)
+{
+    static const bool enabled = [] { const char* e = std::getenv("NIM_RESIDENT_MAP_UPDATE"); return !e || std::atoi(e) != 0; }();
+    if (!enabled || !is3D || mapperModuleVec.size() != 1) return false;
+    const auto* pd = dynamic_cast<const PointDistanceMapperModule*>(mapperModuleVec.front().get());
+    if (!pd) return false;
+    int knn = 0;
+    if (postFilters.size() == 1) knn = postFilters.filters.front()->surfaceNormalKnn();
+    if (postFilters.size() > 1 || (postFilters.size() == 1 && knn <= 0)) return false;
+    // a point-to-plane chain needs normals on every map point: only with the SurfaceNormal post filter
+    if (icp.config().minimizer == ICPMI_MIN_POINT_TO_PLANE && knn <= 0) return false;
+    const bool first = isLocalPointCloudEmpty();
+    if (first && icp.hasMap()) return false; // the ICP map is not the local cloud (cells just unloaded)
+    // without the post filter the map's normals must come with the input (or not exist at all)
+    const bool mapHasNormals = !first && (deviceAhead ? true : localPointCloud.descriptorExists("normals"));
+    if (knn <= 0 && !first && mapHasNormals != input.descriptorExists("normals")) return false;
+
+    std::vector<uint8_t> keep;
+    int64_t appended = 0, m = 0;
+    {
+        std::lock_guard<std::mutex> gi(icpMapLock);
+        icp.mapUpdatePointDistance(input, pd->minDistNewPoint, knn, keep, appended, m);
+    }
+    // descriptors other than `normals` stay on the host, with DataPoints::concatenate's rule (only fields both
+    // clouds have survive); the features / normals of localPointCloud are stale until syncLocalFromDevice()
+    if (first) {
+        localPointCloud = input;                                  // PointDistanceMapperModule::createMap
+    } else {
+        std::vector<Descriptor> kept;
+        for (auto& d : localPointCloud.descriptors) {
+            if (d.name == "normals") continue;
+            if (!input.descriptorExists(d.name) || input.getDescriptorByName(d.name).span != d.span) continue;
+            const Descriptor& in = input.getDescriptorByName(d.name);
+            for (size_t i = 0; i < keep.size(); ++i)
+                if (keep[i]) d.data.insert(d.data.end(), in.data.begin() + (size_t)d.span * i, in.data.begin() + (size_t)d.span * (i + 1));
+            kept.push_back(std::move(d));
+        }
+        localPointCloud.descriptors = std::move(kept);
+    }
+    deviceAhead = true;
+    ++residentUpdates;
+    localPointCloudEmpty.store(m == 0);
+    newLocalPointCloudAvailable = true;
+    return true;
 }
 
 void Map::updateLocalPointCloud(DataPoints input, Mat4 pose, DataPointsFilters postFilters)
 {
     std::lock_guard<std::mutex> g(localPointCloudLock);
     if (mapperModuleVec.empty()) throw InvalidParameter("no mapper module configured");
+    if (tryResidentUpdate(input, postFilters)) return;
+    syncLocalFromDevice();
     if (isLocalPointCloudEmpty()) {
         // the first module creates the map, the others update it with the same scan
         auto it = mapperModuleVec.begin();
@@ -225,6 +292,7 @@ bool Map::getNewLocalPointCloud(DataPoints& out)
 {
     std::lock_guard<std::mutex> g(localPointCloudLock);
     if (!newLocalPointCloudAvailable) return false;
+    syncLocalFromDevice();
     out = localPointCloud;
     newLocalPointCloudAvailable = false;
     return true;
@@ -236,6 +304,7 @@ DataPoints Map::getGlobalPointCloud()
     std::unordered_set<std::string> loaded;
     {
         std::lock_guard<std::mutex> g(localPointCloudLock);
+        syncLocalFromDevice();
         global = localPointCloud;
         loaded = loadedCellIds;
     }
@@ -260,6 +329,7 @@ void Map::setGlobalPointCloud(const DataPoints& cloud)
 {
     std::lock_guard<std::mutex> g(localPointCloudLock);
     localPointCloud = cloud;
+    deviceAhead = false;
     {
         std::lock_guard<std::mutex> gi(icpMapLock);
         icp.setMap(localPointCloud);

@@ -67,6 +67,7 @@ public:
     void addMapperModule(std::shared_ptr<MapperModule> module) { mapperModuleVec.push_back(std::move(module)); }
     void setSensorMaxRange(float r) { sensorMaxRange = r; }
     float getSensorMaxRange() const { return sensorMaxRange; }
+    long residentUpdateCount() const { return residentUpdates.load(); } // map updates that ran on the resident map
 
     // grid arithmetic, public for the unit tests (Map.cpp:130-138,232-235,462-480)
     static int toGridCoordinate(float world) { return (int)std::floor(world / CELL_SIZE); }
@@ -83,6 +84,13 @@ private:
     void scheduleUpdate(const Update& u);
     void loadCells(Box box);
     void unloadCells(Box box);
+    // Resident fast path (icpmi_map_update_point_distance): chain == [PointDistanceMapperModule], post filters
+    // empty or [SurfaceNormalDataPointsFilter], clouds without other descriptors.  The device copy then runs
+    // ahead of localPointCloud, which is refreshed on the next host-side access.
+    bool tryResidentUpdate(const DataPoints& input, const DataPointsFilters& postFilters);
+    void syncLocalFromDevice(); // localPointCloudLock held
+    bool deviceAhead = false;
+    std::atomic<long> residentUpdates{0};
 
     float sensorMaxRange = DEFAULT_SENSOR_MAX_RANGE;
     bool is3D, isOnline;

@@ -42,6 +42,7 @@ public:
     void applyInputFilters(DataPoints& inputInSensorFrame);                                   // Mapper.cpp:187-191
     void processInput(const DataPoints& inputInSensorFrame, const Mat4& estimatedPose, const TimePoint& timeStamp); // :194-238
     DataPoints getMap() { return map.getGlobalPointCloud(); }
+    long residentMapUpdates() const { return map.residentUpdateCount(); }
     void setMap(const DataPoints& newMap);
     bool getNewLocalMap(DataPoints& mapOut) { return map.getNewLocalPointCloud(mapOut); }
     Mat4 getPose();

@@ -352,15 +352,17 @@ class ICPSequence:
                                                           i.ctypes.data, i.shape[0], m.ctypes.data, nn.ctypes.data, m.shape[0], out.ctypes.data))
         return out
 
-    def mapUpdatePointDistance(self, scan_in_map_frame, min_dist, normals_knn=0, scan_normals=None):
+    def mapUpdatePointDistance(self, scan_in_map_frame, min_dist, normals_knn=0, scan_normals=None, return_keep=False):
         """Map::updateLocalPointCloud for the PointDistance chain on the resident map (Map.cpp:502-534): returns
-        (points appended, points in the map afterwards).  Only the scan is uploaded."""
+        (points appended, points in the map afterwards[, keep mask]).  Only the scan is uploaded."""
         sc = _f32c(scan_in_map_frame, 4)
         sn = None if scan_normals is None else _f32c(scan_normals, 3)
         app = C.c_int64(0); m = C.c_int64(0)
+        keep = np.zeros(sc.shape[0], dtype=np.uint8) if return_keep else None
         self._check(self._lib.icpmi_map_update_point_distance(self._h, sc.ctypes.data, sc.shape[0], None if sn is None else sn.ctypes.data,
-                                                              min_dist, normals_knn, C.byref(app), C.byref(m)))
-        return int(app.value), int(m.value)
+                                                              min_dist, normals_knn, None if keep is None else keep.ctypes.data,
+                                                              C.byref(app), C.byref(m)))
+        return (int(app.value), int(m.value), keep.astype(bool)) if return_keep else (int(app.value), int(m.value))
 
     def getMap(self, with_normals=False):
         """The resident map in the caller's order (Map::getLocalPointCloud, Map.cpp:536-540)."""

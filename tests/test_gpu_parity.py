@@ -409,8 +409,8 @@ def test_resident_map_update_equals_composed_path(amd, mid_scene, normals_knn):
 
     b = amd.ICPSequence(**kw)                                   # resident
     b.setMap(base, b.surfaceNormals(base, knn=normals_knn) if normals_knn else None)
-    appended, m = b.mapUpdatePointDistance(scan_map, 0.25, normals_knn=normals_knn)
-    assert appended == int(keep.sum()) and m == grown.shape[0]
+    appended, m, keep_b = b.mapUpdatePointDistance(scan_map, 0.25, normals_knn=normals_knn, return_keep=True)
+    assert appended == int(keep.sum()) and m == grown.shape[0] and np.array_equal(keep_b, keep)
     if normals_knn:
         got, got_n = b.getMap(with_normals=True)
         assert np.array_equal(got_n, nrm)

@@ -191,6 +191,15 @@ def test_example_harness_matches_python_replay(tmp_path):
         assert dt < 0.05 and dr < 4e-3, (dt, dr)          # and the result stays at the ground truth (prior error: 0.037 m / 5.4e-3 rad)
     mp, mdesc = _read_vtk(os.path.join(tmp, "map.vtk"))
     assert "normals" in mdesc and abs(mp.shape[0] - map_pts.shape[0]) <= max(5, map_pts.shape[0] // 500)
+    # this chain (PointDistance + SurfaceNormal post filter, no extra descriptors) runs its map updates on the
+    # resident map; the host path (NIM_RESIDENT_MAP_UPDATE=0) gives the same trajectory up to rounding
+    assert "resident map updates: %d" % len(scans) in out.stdout, out.stdout[-400:]
+    traj2 = os.path.join(tmp, "traj_host.vtk")
+    out2 = subprocess.run([os.path.join(PKG, "build_map_from_scans_and_trajectory"), tmp, cfg, traj2], capture_output=True, text=True,
+                          timeout=600, env=dict(os.environ, NIM_RESIDENT_MAP_UPDATE="0"))
+    assert out2.returncode == 0 and "resident map updates: 0" in out2.stdout
+    pos2, _ = _read_vtk(traj2)
+    assert np.abs(pos2 - pos).max() < 2e-4
 
 
 BUNDLED_LIKE_CONFIG = """
