@@ -519,25 +519,49 @@ __device__ void svd3f_dev(const float* H, float* U, float* s, float* V)
 #pragma unroll
         for (int i = 0; i < 3; ++i) { V[3 * j + i] = v[3 * j + i]; U[3 * j + i] = a[3 * j + i]; }
     }
+    // U = A V S^-1 made orthonormal by construction -- same operations, same order as the oracle (see there)
     const float tiny = s[0] * 1e-6f;
-    bool good[3];
-    for (int j = 0; j < 3; ++j) {
-        good[j] = s[j] > tiny && s[j] > 0.f;
-        if (good[j]) for (int i = 0; i < 3; ++i) U[3 * j + i] /= s[j];
+    if (!(s[0] > 0.f)) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) U[i] = (i % 4 == 0) ? 1.f : 0.f;
+        return;
     }
-    if (!good[0]) { for (int i = 0; i < 9; ++i) U[i] = (i % 4 == 0) ? 1.f : 0.f; return; }
-    if (!good[1]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) U[i] /= s[0];
+    {
+        const float n0 = sqrtf(U[0] * U[0] + U[1] * U[1] + U[2] * U[2]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) U[i] /= n0;
+    }
+    bool have1 = false;
+    if (s[1] > tiny) {
+        float c1[3] = {U[3] / s[1], U[4] / s[1], U[5] / s[1]};
+        const float d = c1[0] * U[0] + c1[1] * U[1] + c1[2] * U[2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) c1[i] = c1[i] - d * U[i];
+        const float n1 = sqrtf(c1[0] * c1[0] + c1[1] * c1[1] + c1[2] * c1[2]);
+        if (n1 > 0.5f) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) U[3 + i] = c1[i] / n1;
+            have1 = true;
+        }
+    }
+    if (!have1) {
         const int m = fabsf(U[0]) < fabsf(U[1]) ? (fabsf(U[0]) < fabsf(U[2]) ? 0 : 2) : (fabsf(U[1]) < fabsf(U[2]) ? 1 : 2);
         const float e[3] = {m == 0 ? 1.f : 0.f, m == 1 ? 1.f : 0.f, m == 2 ? 1.f : 0.f};
         const float d = m == 0 ? U[0] : (m == 1 ? U[1] : U[2]);
         const float w[3] = {e[0] - d * U[0], e[1] - d * U[1], e[2] - d * U[2]};
         const float nw = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+#pragma unroll
         for (int i = 0; i < 3; ++i) U[3 + i] = w[i] / nw;
     }
-    if (!good[2] || !good[1]) {
-        U[6] = U[1] * U[5] - U[2] * U[4];
-        U[7] = U[2] * U[3] - U[0] * U[5];
-        U[8] = U[0] * U[4] - U[1] * U[3];
+    {
+        const float c2[3] = {U[6], U[7], U[8]};
+        const float x[3] = {U[1] * U[5] - U[2] * U[4], U[2] * U[3] - U[0] * U[5], U[0] * U[4] - U[1] * U[3]};
+        const float nx = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+        const float sg = (have1 && s[2] > tiny && (x[0] * c2[0] + x[1] * c2[1] + x[2] * c2[2]) < 0.f) ? -1.f : 1.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) U[6 + i] = sg * (x[i] / nx);
     }
 }
 

@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""Soak test: random maps / readings / chains through the C ABI, looking for hangs, device errors and
+non-finite poses.  Every N-th case is cross-checked against the oracle."""
+import sys, os, time, math
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import norlab_icp_mapper_amd as pkg
+import oracle_bindings as ob
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+only = int(sys.argv[3]) if len(sys.argv) > 3 else -1
+base = pkg.synth.make_scene(m=400_000, n=60_000)
+t0 = time.time(); checked = 0; errors = 0
+for case in range(cases):
+    m = int(rng.choice([1, 7, 300, 5_000, 60_000, 400_000]))
+    n = int(rng.choice([1, 5, 257, 4_000, 60_000]))
+    k = int(rng.choice([1, 1, 1, 3, 6, 10]))
+    minimizer = int(rng.choice([1, 2, 2]))
+    outl = [[], [(4, 0.85)], [(3, 3.0)], [(1, 1.0), (4, 0.7)]][int(rng.integers(0, 4))]
+    md = float(rng.choice([0.5, 2.0, math.inf]))
+    kw = dict(minimizer=minimizer, knn=k, max_dist=md if math.isfinite(md) else 1e30, outliers=outl, max_iterations=int(rng.integers(1, 25)),
+              use_differential=int(rng.integers(0, 2)))
+    if not math.isfinite(md): kw["max_dist"] = math.inf
+    sel = rng.permutation(base["map"].shape[0])[:m]
+    mp, nrm = base["map"][sel], base["normals"][sel]
+    rd = base["scan"][rng.permutation(base["scan"].shape[0])[:n]].copy()
+    rd[:, :3] += rng.normal(0, rng.choice([0.0, 0.01, 0.3]), (n, 3)).astype(np.float32)
+    if only >= 0 and case != only: continue
+    try:
+        icp = pkg.ICPSequence(**kw)
+        icp.setMap(mp, nrm)
+        try:
+            T = icp(rd)
+            assert np.isfinite(T).all(), "non-finite pose"
+            err_gpu = 0
+        except pkg.ConvergenceError:
+            err_gpu = 1
+        if only >= 0:
+            o = ob.OracleICP(ob.make_config(nthreads=16, **kw)); o.setMap(mp, nrm)
+            err, T_ref = o(rd)
+            print("GPU", err_gpu, icp.stats.iterations, icp.stats.pairs, icp.stats.stop_reason, "\n", T if not err_gpu else None)
+            print("CPU", err, o.stats.iterations, o.stats.pairs, o.stats.stop_reason, "\n", T_ref)
+            for it in (1, 2, 3):
+                kw2 = dict(kw); kw2["max_iterations"] = it; kw2["use_differential"] = 0
+                a = pkg.ICPSequence(**kw2); a.setMap(mp, nrm); Ta = a(rd)
+                b = ob.OracleICP(ob.make_config(nthreads=16, **kw2)); b.setMap(mp, nrm); eb, Tb = b(rd)
+                print("iterations", it, "pose diff", pkg.synth.pose_error(Ta, Tb), "pairs", a.stats.pairs, b.stats.pairs)
+        # k >= m pairs every query with every map point: H is identically zero up to rounding, the rotation is noise on
+        # both sides (ill-posed, not comparable)
+        if case % 5 == 0 and m * n <= 400_000 * 4_000 and k < m:
+            o = ob.OracleICP(ob.make_config(nthreads=16, **kw)); o.setMap(mp, nrm)
+            err, T_ref = o(rd)
+            assert (err != 0) == (err_gpu != 0), ("error mismatch", err, err_gpu, kw, m, n)
+            if err == 0:
+                dt, dr = pkg.synth.pose_error(T, T_ref)
+                assert dt <= 1e-3 and dr <= 1e-3, ("pose mismatch", dt, dr, kw, m, n)
+                assert icp.stats.iterations == o.stats.iterations, ("iterations", icp.stats.iterations, o.stats.iterations, kw, m, n)
+            checked += 1
+        icp.close()
+    except AssertionError as e:
+        errors += 1; print("CASE", case, "FAILED:", e)
+print(f"soak: {cases} cases, {checked} cross-checked, {errors} failures, {time.time() - t0:.1f} s")
+sys.exit(1 if errors else 0)
