@@ -154,6 +154,7 @@ struct icpmi_ctx {
     float4* d_raw = nullptr; size_t cap_raw = 0;
     float*  d_raw_n3 = nullptr; size_t cap_raw_n3 = 0;
     int64_t m_raw = 0; bool raw_has_normals = false;
+    bool no_centre = false;           // temp handles of the map-side operators: index raw coordinates (mean = 0)
     int*    d_sidx = nullptr; size_t cap_sidx = 0;             // k x n sorted-map index (-1 none)
     float*  d_d2 = nullptr; size_t cap_d2 = 0;                 // k x n
     unsigned* d_hard = nullptr; size_t cap_hard = 0;           // hard query list

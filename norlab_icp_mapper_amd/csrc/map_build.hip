@@ -460,7 +460,9 @@ icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float
             c->last_error = "set_map: non-finite coordinates in the map cloud";
             return ICPMI_ERR_INVALID_ARG;
         }
-        c->mean[r] = (float)(sum[r] / (double)m);
+        // ICPSequence::setMap centres on the centroid; the map-side operators (libnabo on the raw cloud in the
+        // reference) index the coordinates as they are
+        c->mean[r] = c->no_centre ? 0.f : (float)(sum[r] / (double)m);
     }
     // bbox of the centred cloud: x -> x - mean is monotone in float, so the extrema commute
     float clo[3], chi[3], maxabs = 0.f;

@@ -361,6 +361,7 @@ static icpmi_status make_temp(icpmi_ctx* c, TempCtx& t)
     icpmi_config cfg = c->cfg;
     icpmi_status s = icpmi_create(&cfg, &t.h);
     if (s != ICPMI_OK) { c->last_error = icpmi_last_error(nullptr); return s; }
+    t.h->no_centre = true; // PointDistanceMapperModule.cpp:33 / SurfaceNormalDataPointsFilter build their kd-tree on the raw cloud
     return ICPMI_OK;
 }
 
