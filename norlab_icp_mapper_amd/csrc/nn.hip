@@ -393,9 +393,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restri
         bool want = sp >= 0;
         const float ub2 = sqdist3(p.x, p.y, p.z, qs.x, qs.y, qs.z);
         const float ub = sqrtf(ub2);
-        for (int lev = 0; lev < L.nlev; ++lev) {
-            if (__ballot(want) == 0ull) break;
-            const GridParams gl = L.g[lev];
+        auto try_level = [&](int lev, const GridParams& gl) {
             const float fx = (p.x - gl.ox) * gl.inv_cell, fy = (p.y - gl.oy) * gl.inv_cell, fz = (p.z - gl.oz) * gl.inv_cell;
             float mfl = fminf(fx - floorf(fx), 1.0f - (fx - floorf(fx)));
             mfl = fminf(mfl, fminf(fy - floorf(fy), 1.0f - (fy - floorf(fy))));
@@ -409,6 +407,13 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restri
                 bx = qs.x; by = qs.y; bz = qs.z;
                 want = false;
             }
+        };
+        // level 0 (statically indexed: its parameters arrive with the kernel arguments) decides for nearly every
+        // query of a converging registration; the loop only runs for waves that hold a wider ball
+        try_level(0, L.g[0]);
+        for (int lev = 1; lev < L.nlev; ++lev) {
+            if (__ballot(want) == 0ull) break;
+            try_level(lev, L.g[lev]);
         }
     }
     // lanes of a group agree on the starting level and radius (same inputs)
