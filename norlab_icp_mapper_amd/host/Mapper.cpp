@@ -2,6 +2,8 @@
 #include "Mapper.h"
 
 #include <algorithm>
+#include <cmath>
+#include <iterator>
 #include <fstream>
 #include <iostream>
 #include <sstream>
@@ -59,82 +61,103 @@ void Mapper::rebuildRadiusFilter()
     radiusFilter = createDataPointsFilter("DistanceLimitDataPointsFilter", yaml::Load(y.str()), icp.handle());
 }
 
-void Mapper::validateYamlKeys(const yaml::Node& node, const std::vector<std::string>& validKeys) const
+namespace {
+
+// every key must be one of `allowed`, at most once (the reference's validateYamlKeys messages)
+void requireOnlyKeys(const yaml::Node& node, std::initializer_list<const char*> allowed)
 {
     if (!node.IsMap()) throw yaml::Exception("Expected a YAML Map node.");
     std::unordered_set<std::string> seen;
-    for (const auto& kv : node.map) {
-        if (seen.count(kv.first)) throw yaml::Exception("Duplicated key: " + kv.first);
-        if (std::find(validKeys.begin(), validKeys.end(), kv.first) == validKeys.end()) throw yaml::Exception("Invalid key: " + kv.first);
-        seen.insert(kv.first);
+    for (const auto& entry : node.map) {
+        const std::string& key = entry.first;
+        if (!seen.insert(key).second) throw yaml::Exception("Duplicated key: " + key);
+        const bool known = std::any_of(allowed.begin(), allowed.end(), [&](const char* a) { return key == a; });
+        if (!known) throw yaml::Exception("Invalid key: " + key);
     }
 }
 
-void Mapper::loadYamlConfig(const std::string& configFilePath)
+std::string slurp(const std::string& path)
 {
-    std::ifstream ifs(configFilePath.c_str());
-    if (ifs.fail()) throw std::runtime_error("The input config file " + configFilePath + " does not exist");
-    std::stringstream ss;
-    ss << ifs.rdbuf();
-    loadYamlConfigFromString(ss.str());
+    std::ifstream in(path.c_str());
+    if (!in) throw std::runtime_error("The input config file " + path + " does not exist");
+    return std::string(std::istreambuf_iterator<char>(in), std::istreambuf_iterator<char>());
 }
+
+} // namespace
+
+UpdatePolicy UpdatePolicy::fromYaml(const yaml::Node& uc)
+{
+    requireOnlyKeys(uc, {"type", "value"});
+    for (const char* k : {"type", "value"})
+        if (!uc[k]) throw yaml::Exception(std::string("Missing key: ") + k);
+    // one row per condition: name, tag, admissible range of the value
+    struct Row { const char* name; Kind kind; float lo, hi; };
+    static const Row rows[] = {
+        {"distance", Distance, 0.f, INFINITY},
+        {"overlap", Overlap, 0.f, 1.f},
+        {"delay", Delay, 0.f, INFINITY},
+    };
+    const std::string type = uc["type"].as<std::string>();
+    const float value = uc["value"].as<float>();
+    for (const Row& r : rows) {
+        if (type != r.name) continue;
+        if (!(value >= r.lo && value <= r.hi)) throw yaml::Exception("Invalid map update " + type + ": " + std::to_string(value));
+        UpdatePolicy p; p.kind = r.kind; p.threshold = value;
+        return p;
+    }
+    throw yaml::Exception("Invalid map update condition: " + type);
+}
+
+void Mapper::loadYamlConfig(const std::string& configFilePath) { loadYamlConfigFromString(slurp(configFilePath)); }
 
 void Mapper::loadYamlConfigFromString(const std::string& text)
 {
-    const yaml::Node node = yaml::Load(text);
-    validateYamlKeys(node, {"icp", "input", "post", "mapper"});
+    const yaml::Node root = yaml::Load(text);
+    requireOnlyKeys(root, {"icp", "input", "post", "mapper"});
+    const auto announceMissing = [](const char* what) { std::cout << what << std::endl; };
 
+    // 1. the registration chain; loadFromYamlNode / setDefault re-create the GPU-side chain, so nobody may be using it
     {
-        // the ICP object is recreated by loadFromYamlNode / setDefault: nothing may hold the old context
         std::lock_guard<std::mutex> g(icpMapLock);
-        if (node["icp"]) icp.loadFromYamlNode(node["icp"]);
-        else { std::cout << "icp config not found, using default" << std::endl; icp.setDefault(); }
+        if (const yaml::Node& chain = root["icp"]) icp.loadFromYamlNode(chain);
+        else { announceMissing("icp config not found, using default"); icp.setDefault(); }
     }
-    // filters, modules and transformations share the (new) GPU context
+    // 2. everything that shares the GPU context of that chain
     transformation = RigidTransformation(icp.handle());
-    if (node["input"]) inputFilters = DataPointsFilters(node["input"], icp.handle());
-    else std::cout << "Input config not found, using empty configuration." << std::endl;
-    if (node["post"]) mapPostFilters = DataPointsFilters(node["post"], icp.handle());
-    else std::cout << "Post config not found, using empty configuration." << std::endl;
+    struct FilterSection { const char* key; DataPointsFilters* target; const char* missing; };
+    const FilterSection sections[] = {
+        {"input", &inputFilters, "Input config not found, using empty configuration."},
+        {"post", &mapPostFilters, "Post config not found, using empty configuration."},
+    };
+    for (const FilterSection& sec : sections) {
+        if (const yaml::Node& n = root[sec.key]) *sec.target = DataPointsFilters(n, icp.handle());
+        else announceMissing(sec.missing);
+    }
+    // 3. map growth
+    if (!root["mapper"]) announceMissing("mapper config not found, using default");
+    configureMapperSection(root["mapper"]);
+}
 
-    if (node["mapper"]) {
-        const yaml::Node& mapperNode = node["mapper"];
-        if (mapperNode["updateCondition"]) {
-            const yaml::Node& uc = mapperNode["updateCondition"];
-            validateYamlKeys(uc, {"type", "value"});
-            if (!uc["type"]) throw yaml::Exception("Missing key: type");
-            if (!uc["value"]) throw yaml::Exception("Missing key: value");
-            mapUpdateCondition = uc["type"].as<std::string>();
-            const float value = uc["value"].as<float>();
-            if (mapUpdateCondition == "distance") {
-                if (value < 0) throw yaml::Exception("Invalid map update distance: " + std::to_string(value));
-                mapUpdateDistance = value;
-            } else if (mapUpdateCondition == "overlap") {
-                if (value < 0 || value > 1) throw yaml::Exception("Invalid map update overlap: " + std::to_string(value));
-                mapUpdateOverlap = value;
-            } else if (mapUpdateCondition == "delay") {
-                if (value < 0) throw yaml::Exception("Invalid map update delay: " + std::to_string(value));
-                mapUpdateDelay = value;
-            } else throw yaml::Exception("Invalid map update condition: " + mapUpdateCondition);
-        } else {
-            std::cout << "Mapper update condition not found, using default configuration." << std::endl;
-            setDefaultMapUpdateConfig();
-        }
-        if (mapperNode["sensorMaxRange"]) {
-            const float r = mapperNode["sensorMaxRange"].as<float>();
-            if (r < 0) throw yaml::Exception("Invalid sensor max range: " + std::to_string(r));
-            map.setSensorMaxRange(r);
-        }
-        if (mapperNode["mapperModule"]) {
-            if (!mapperNode["mapperModule"].IsSequence()) throw yaml::Exception("mapperModule must be a sequence");
-            for (const auto& item : mapperNode["mapperModule"].seq) map.addMapperModule(registrar.createFromYAML(item, icp.handle()));
-        } else {
-            std::cout << "mapper module not found, using default" << std::endl;
-            setDefaultMapperModule();
-        }
+void Mapper::configureMapperSection(const yaml::Node& mapperNode)
+{
+    const bool present = (bool)mapperNode;
+    if (present && mapperNode["updateCondition"]) updatePolicy = UpdatePolicy::fromYaml(mapperNode["updateCondition"]);
+    else {
+        if (present) std::cout << "Mapper update condition not found, using default configuration." << std::endl;
+        updatePolicy = UpdatePolicy(); // distance, 1 m
+    }
+    if (present && mapperNode["sensorMaxRange"]) {
+        const float range = mapperNode["sensorMaxRange"].as<float>();
+        if (range < 0) throw yaml::Exception("Invalid sensor max range: " + std::to_string(range));
+        map.setSensorMaxRange(range);
+    }
+    if (present && mapperNode["mapperModule"]) {
+        const yaml::Node& modules = mapperNode["mapperModule"];
+        if (!modules.IsSequence()) throw yaml::Exception("mapperModule must be a sequence");
+        for (const auto& item : modules.seq) map.addMapperModule(registrar.createFromYAML(item, icp.handle()));
     } else {
-        std::cout << "mapper config not found, using default" << std::endl;
-        setDefaultMapperConfig();
+        if (present) std::cout << "mapper module not found, using default" << std::endl;
+        setDefaultMapperModule();
     }
 }
 
@@ -152,54 +175,47 @@ void Mapper::applyInputFilters(DataPoints& inputInSensorFrame)
 
 void Mapper::processInput(const DataPoints& filteredInputInSensorFrame, const Mat4& estimatedPose, const TimePoint& timeStamp)
 {
-    const DataPoints input = transformation.compute(filteredInputInSensorFrame, estimatedPose);
-    Mat4 correctedPose;
-    if (map.isLocalPointCloudEmpty()) {
-        correctedPose = estimatedPose;
-        map.updatePose(correctedPose);
-        updateMap(input, correctedPose, timeStamp);
-    } else {
-        Mat4 correction;
-        {
-            std::lock_guard<std::mutex> g(icpMapLock);
-            correction = icp(input);
-        }
-        correctedPose = correction * estimatedPose;
-        map.updatePose(correctedPose);
-        if (shouldUpdateMap(timeStamp, correctedPose, icp.errorMinimizer->getOverlap()))
-            updateMap(transformation.compute(input, correction), correctedPose, timeStamp);
+    // scan into the map frame by the prior; ICP then returns a correction expressed in the map frame
+    DataPoints scanInMap = transformation.compute(filteredInputInSensorFrame, estimatedPose);
+    const bool bootstrap = map.isLocalPointCloudEmpty(); // nothing to register against: the prior is the pose
+    Mat4 correction = Mat4::identity();
+    if (!bootstrap) {
+        std::lock_guard<std::mutex> g(icpMapLock);
+        correction = icp(scanInMap);
     }
+    const Mat4 correctedPose = bootstrap ? estimatedPose : correction * estimatedPose;
+    map.updatePose(correctedPose);
+    if (bootstrap) growMap(scanInMap, correctedPose, timeStamp);
+    else if (mapUpdateIsDue(timeStamp, correctedPose, icp.errorMinimizer->getOverlap()))
+        growMap(transformation.compute(scanInMap, correction), correctedPose, timeStamp);
+
+    // surface an exception of a finished asynchronous update here, like the reference's future.get()
     if (mapUpdateFuture.valid() && mapUpdateFuture.wait_for(std::chrono::milliseconds(1)) == std::future_status::ready) mapUpdateFuture.get();
-    {
-        std::lock_guard<std::mutex> g(poseLock);
-        pose = correctedPose;
-    }
-    {
-        std::lock_guard<std::mutex> g(trajectoryLock);
-        trajectory.addPose(correctedPose, timeStamp);
-    }
+    { std::lock_guard<std::mutex> g(poseLock); pose = correctedPose; }
+    { std::lock_guard<std::mutex> g(trajectoryLock); trajectory.addPose(correctedPose, timeStamp); }
 }
 
-bool Mapper::shouldUpdateMap(const TimePoint& currentTime, const Mat4& currentPose, float currentOverlap) const
+bool Mapper::mapUpdateIsDue(const TimePoint& now, const Mat4& poseNow, float overlap) const
 {
     if (!isMapping.load()) return false;
-    if (isOnline && mapUpdateFuture.valid() && mapUpdateFuture.wait_for(std::chrono::milliseconds(0)) != std::future_status::ready)
-        return false; // the previous update is still running
-    if (mapUpdateCondition == "overlap") return currentOverlap < mapUpdateOverlap;
-    if (mapUpdateCondition == "delay") return (currentTime - lastTimeMapWasUpdated) > std::chrono::duration<float>(mapUpdateDelay);
-    float d2 = 0.f;
-    for (int r = 0; r < 3; ++r) { const float d = currentPose(r, 3) - lastPoseWhereMapWasUpdated(r, 3); d2 += d * d; }
-    return std::sqrt(d2) > mapUpdateDistance;
+    const bool updateInFlight = isOnline && mapUpdateFuture.valid() && mapUpdateFuture.wait_for(std::chrono::milliseconds(0)) != std::future_status::ready;
+    if (updateInFlight) return false;
+    float travelled2 = 0.f;
+    for (int axis = 0; axis < 3; ++axis) {
+        const float step = poseNow(axis, 3) - lastPoseWhereMapWasUpdated(axis, 3);
+        travelled2 += step * step;
+    }
+    const float seconds = std::chrono::duration<float>(now - lastTimeMapWasUpdated).count();
+    return updatePolicy.due(std::sqrt(travelled2), overlap, seconds);
 }
 
-void Mapper::updateMap(const DataPoints& currentInput, const Mat4& currentPose, const TimePoint& currentTimeStamp)
+void Mapper::growMap(const DataPoints& inputInMapFrame, const Mat4& poseNow, const TimePoint& now)
 {
-    lastTimeMapWasUpdated = currentTimeStamp;
-    lastPoseWhereMapWasUpdated = currentPose;
-    if (isOnline && !map.isLocalPointCloudEmpty())
-        mapUpdateFuture = std::async(std::launch::async, &Map::updateLocalPointCloud, &map, currentInput, currentPose, mapPostFilters);
-    else
-        map.updateLocalPointCloud(currentInput, currentPose, mapPostFilters);
+    lastTimeMapWasUpdated = now;
+    lastPoseWhereMapWasUpdated = poseNow;
+    const bool inBackground = isOnline && !map.isLocalPointCloudEmpty(); // the very first map is built synchronously
+    if (!inBackground) { map.updateLocalPointCloud(inputInMapFrame, poseNow, mapPostFilters); return; }
+    mapUpdateFuture = std::async(std::launch::async, &Map::updateLocalPointCloud, &map, inputInMapFrame, poseNow, mapPostFilters);
 }
 
 void Mapper::setMap(const DataPoints& newMap)

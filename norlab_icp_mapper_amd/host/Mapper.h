@@ -34,6 +34,17 @@ private:
     std::vector<TimePoint> stamps;
 };
 
+// When the map is grown (`mapper: updateCondition:` of the YAML; reference defaults Mapper.h:19-20): parsed once into a
+// tagged value instead of being re-interpreted from its string on every scan.
+struct UpdatePolicy {
+    enum Kind { Distance, Overlap, Delay } kind = Distance;
+    float threshold = 1.0f; // metres travelled / overlap ratio / seconds, by kind
+    static UpdatePolicy fromYaml(const yaml::Node& updateCondition); // throws yaml::Exception with the reference's messages
+    bool due(float metresSinceUpdate, float overlap, float secondsSinceUpdate) const {
+        return kind == Overlap ? overlap < threshold : (kind == Delay ? secondsSinceUpdate > threshold : metresSinceUpdate > threshold);
+    }
+};
+
 class Mapper {
 public:
     Mapper(const std::string& configFilePath, bool is3D, bool isOnline, bool isMapping, bool saveMapCellsOnHardDrive, int device = 0);
@@ -55,22 +66,16 @@ public:
     const icpmi_stats& lastIcpStats() const { return icp.stats(); }
 
 private:
-    static constexpr const char* DEFAULT_MAP_UPDATE_CONDITION = "distance"; // Mapper.h:19
-    static constexpr float DEFAULT_MAP_UPDATE_DISTANCE = 1.0f;              // Mapper.h:20
-
     void fillRegistrar();
-    void validateYamlKeys(const yaml::Node& node, const std::vector<std::string>& validKeys) const;
     void rebuildRadiusFilter();
-    void setDefaultMapUpdateConfig() { mapUpdateCondition = DEFAULT_MAP_UPDATE_CONDITION; mapUpdateDistance = DEFAULT_MAP_UPDATE_DISTANCE; }
-    void setDefaultMapperConfig() { setDefaultMapUpdateConfig(); setDefaultMapperModule(); }
-    bool shouldUpdateMap(const TimePoint& currentTime, const Mat4& currentPose, float currentOverlap) const; // :240-272
-    void updateMap(const DataPoints& currentInput, const Mat4& currentPose, const TimePoint& currentTimeStamp); // :274-288
+    void configureMapperSection(const yaml::Node& mapperNode);                        // the `mapper:` block, or an undefined node
+    bool mapUpdateIsDue(const TimePoint& now, const Mat4& poseNow, float overlap) const; // Mapper.cpp:240-272
+    void growMap(const DataPoints& inputInMapFrame, const Mat4& poseNow, const TimePoint& now); // Mapper.cpp:274-288
 
     GpuICPSequence icp;                 // first: the filters and modules share its GPU context
     std::mutex poseLock, trajectoryLock, icpMapLock;
     DataPointsFilters inputFilters, mapPostFilters;
-    std::string mapUpdateCondition;
-    float mapUpdateOverlap = 0.f, mapUpdateDelay = 0.f, mapUpdateDistance = 0.f;
+    UpdatePolicy updatePolicy;
     bool is3D, isOnline;
     std::atomic_bool isMapping;
     Map map;
