@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--chain", default="p2p", choices=list(CHAINS))
     ap.add_argument("--map-points", type=int, default=M_MAP)
     ap.add_argument("--scan-points", type=int, default=N_SCAN)
+    ap.add_argument("--normals", default="analytic", choices=["analytic", "filter"],
+                    help="map normals of the point-to-plane chains: the scene's analytic ones, or SurfaceNormalDataPointsFilter{knn: 10} "
+                         "run on the map through icpmi_surface_normals (BASELINE config 3)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-iters", type=int, default=10, help="iterations of the single-threaded cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work of the multi-threaded cpu_baseline leg")
@@ -76,6 +79,11 @@ def main():
     sc = pkg.synth.make_scene(m=args.map_points, n=args.scan_points, seed_scan=43 + 1000 * rank)
     chain = dict(CHAINS[args.chain])
     icp = pkg.ICPSequence(device=dev, max_iterations=ITERS_PER_STEP, **chain)
+    normals_ms = None
+    if args.normals == "filter":
+        t0 = time.perf_counter()
+        sc["normals"] = icp.surfaceNormals(sc["map"], knn=10)
+        normals_ms = (time.perf_counter() - t0) * 1e3
     d_map = torch.from_numpy(sc["map"]).cuda()
     d_nrm = torch.from_numpy(sc["normals"]).cuda()
     d_scan = torch.from_numpy(sc["scan"]).cuda()
@@ -138,6 +146,9 @@ def main():
         gi = icp.gridInfo()
         out["device_loop_ms_per_step"] = loop_ms / args.steps
         out["set_map_ms"] = set_map_ms
+        if normals_ms is not None:
+            out["surface_normals_ms"] = normals_ms
+            out["config"]["map_normals"] = "SurfaceNormalDataPointsFilter knn 10 (icpmi_surface_normals, host pointers)"
         out["grid"] = gi
         gt_t, gt_r = pkg.synth.pose_error(T, sc["T_gt"])
         out["pose_err_vs_ground_truth"] = {"m": gt_t, "rad": gt_r,
@@ -171,7 +182,7 @@ def main():
         del prof
 
         # ---- CPU baseline: the oracle on this host, bounded sample of the same workload ----
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:          # reported on rank 0 at N = 1 only
             import oracle_bindings as ob
             cores = len(os.sched_getaffinity(0))
             okw = dict(minimizer=chain["minimizer"], max_dist=chain["max_dist"], outliers=chain["outliers"], knn=chain.get("knn", 1))
