@@ -325,8 +325,8 @@ icpmi_status icpmi_knn(icpmi_handle h, const float* q4, int64_t n, int32_t k, fl
     h->nn_iter_hint = 0;
     icpmi_status s = nn_launch_k(h, h->d_reading, n, nullptr, lc, allow_self, h->d_sidx, h->d_d2, h->d_state);
     if (s != ICPMI_OK) return s;
-    int* d_ids = nullptr;
-    HIP_TRY(h, hipMalloc((void**)&d_ids, (size_t)n * k * sizeof(int)));
+    DevBuf<int> d_ids;
+    HIP_TRY(h, d_ids.alloc((size_t)n * k));
     s = nn_ids_to_original(h, h->d_sidx, n * k, d_ids);
     hipError_t e = hipSuccess;
     if (s == ICPMI_OK) {
@@ -334,7 +334,6 @@ icpmi_status icpmi_knn(icpmi_handle h, const float* q4, int64_t n, int32_t k, fl
         if (e == hipSuccess) e = hipMemcpyAsync(d2, h->d_d2, (size_t)n * k * sizeof(float), hipMemcpyDeviceToHost, h->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     }
-    hipFree(d_ids);
     if (s != ICPMI_OK) return s;
     HIP_TRY(h, e);
     return ICPMI_OK;

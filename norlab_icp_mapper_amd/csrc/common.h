@@ -197,6 +197,18 @@ static inline icpmi_status ensure_cap(icpmi_ctx* c, T** p, size_t* cap, size_t n
     return ICPMI_OK;
 }
 
+// scratch device allocation of one call: freed on every exit path (hipFree waits for work still using it)
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc((void**)&p, (n ? n : 1) * sizeof(T)); }
+    operator T*() const { return p; }
+};
+
 // like ensure_cap, but the first `used` entries survive a reallocation
 template <typename T>
 static inline icpmi_status ensure_cap_keep(icpmi_ctx* c, T** p, size_t* cap, size_t need, size_t used)

@@ -1217,12 +1217,11 @@ icpmi_status loop_single_step(icpmi_ctx* c, int64_t n, const LoopCfg& lc, const 
                               double sums[32], icpmi_stats* stats)
 {
     if (ensure_loop_buffers(c, n, lc.k) != ICPMI_OK) return ICPMI_ERR_HIP;
-    float* d_T0 = nullptr;
-    float* d_Tstep = nullptr;
-    double* d_sums = nullptr;
-    HIP_TRY(c, hipMalloc((void**)&d_Tstep, 16 * sizeof(float) * 2));
-    HIP_TRY(c, hipMalloc((void**)&d_sums, ICPMI_NV * sizeof(double)));
-    d_T0 = d_Tstep + 16;
+    DevBuf<float> d_Tstep; // [0,16): T_step out, [16,32): T_iter in
+    DevBuf<double> d_sums;
+    HIP_TRY(c, d_Tstep.alloc(32));
+    HIP_TRY(c, d_sums.alloc(ICPMI_NV));
+    float* d_T0 = d_Tstep.p + 16;
     if (T_iter_host) HIP_TRY(c, hipMemcpyAsync(d_T0, T_iter_host, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(64), 0, c->stream, c->d_state, T_iter_host ? (const float*)d_T0 : (const float*)nullptr);
     HIP_TRY(c, hipMemsetAsync(c->d_selhist, 0, ICPMI_SELHIST_WORDS * sizeof(unsigned), c->stream));
@@ -1245,7 +1244,6 @@ icpmi_status loop_single_step(icpmi_ctx* c, int64_t n, const LoopCfg& lc, const 
     if (e == hipSuccess) e = hipMemcpyAsync(hT, d_Tstep, sizeof hT, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(hS, d_sums, sizeof hS, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(d_Tstep); hipFree(d_sums);
     if (s != ICPMI_OK) return s;
     HIP_TRY(c, e);
     fill_stats(c, l1, n, stats);
@@ -1274,8 +1272,8 @@ icpmi_status loop_outlier_weights(icpmi_ctx* c, const LoopCfg& lc, const float* 
     HIP_TRY(c, hipMemcpyAsync(c->d_d2, d2, (size_t)count * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_sidx, 0, (size_t)count * sizeof(int), c->stream));
     enqueue_selection(c, l1, count, true);
-    float* d_w = nullptr;
-    HIP_TRY(c, hipMalloc((void**)&d_w, (size_t)(count > 0 ? count : 1) * sizeof(float)));
+    DevBuf<float> d_w;
+    HIP_TRY(c, d_w.alloc((size_t)count));
     const int blocks = (int)((count + 255) / 256);
     if (blocks) hipLaunchKernelGGL(weights_kernel, dim3(blocks), dim3(256), 0, c->stream, count, l1, c->d_state, c->d_normals_sorted,
                                    (const float4*)nullptr, c->d_sidx, c->d_d2, d_w);
@@ -1283,7 +1281,6 @@ icpmi_status loop_outlier_weights(icpmi_ctx* c, const LoopCfg& lc, const float* 
     if (e == hipSuccess) e = hipMemcpyAsync(weights, d_w, (size_t)count * sizeof(float), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(c->h_state, c->d_state, sizeof(IcpState), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(d_w);
     HIP_TRY(c, e);
     if (c->h_state->error) { c->last_error = "ConvergenceError: no outlier to filter"; return (icpmi_status)c->h_state->error; }
     if (limit_out) {

@@ -376,12 +376,11 @@ icpmi_status ops_transform(icpmi_ctx* c, const float T[16], const float* in4, in
         return ICPMI_ERR_INVALID_ARG;
     }
     if (n == 0) return ICPMI_OK;
-    float* d_T = nullptr;
-    float4 *d_in = nullptr, *d_out = nullptr;
-    float *d_n = nullptr, *d_no = nullptr;
-    HIP_TRY(c, hipMalloc((void**)&d_T, 16 * sizeof(float)));
-    HIP_TRY(c, hipMalloc((void**)&d_in, (size_t)n * sizeof(float4)));
-    HIP_TRY(c, hipMalloc((void**)&d_out, (size_t)n * sizeof(float4)));
+    DevBuf<float> d_T, d_n, d_no;
+    DevBuf<float4> d_in, d_out;
+    HIP_TRY(c, d_T.alloc(16));
+    HIP_TRY(c, d_in.alloc((size_t)n));
+    HIP_TRY(c, d_out.alloc((size_t)n));
     hipError_t e = hipMemcpyAsync(d_T, T, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_in, in4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream);
     const int blocks = (int)((n + 255) / 256);
@@ -390,8 +389,8 @@ icpmi_status ops_transform(icpmi_ctx* c, const float T[16], const float* in4, in
         e = hipMemcpyAsync(out4, d_out, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, c->stream);
     }
     if (e == hipSuccess && in_n3 && out_n3) {
-        e = hipMalloc((void**)&d_n, (size_t)n * 3 * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc((void**)&d_no, (size_t)n * 3 * sizeof(float));
+        e = d_n.alloc((size_t)n * 3);
+        if (e == hipSuccess) e = d_no.alloc((size_t)n * 3);
         if (e == hipSuccess) e = hipMemcpyAsync(d_n, in_n3, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(rotate3_kernel, dim3(blocks), dim3(256), 0, c->stream, d_n, n, d_T, d_no);
@@ -399,7 +398,6 @@ icpmi_status ops_transform(icpmi_ctx* c, const float T[16], const float* in4, in
         }
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(d_T); hipFree(d_in); hipFree(d_out); hipFree(d_n); hipFree(d_no);
     HIP_TRY(c, e);
     return ICPMI_OK;
 }
@@ -407,16 +405,15 @@ icpmi_status ops_transform(icpmi_ctx* c, const float T[16], const float* in4, in
 icpmi_status ops_bin_cells(icpmi_ctx* c, const float* pts4, int64_t n, float cell_size, int32_t* ijk3)
 {
     if (n == 0) return ICPMI_OK;
-    float4* d_in = nullptr; int* d_o = nullptr;
-    HIP_TRY(c, hipMalloc((void**)&d_in, (size_t)n * sizeof(float4)));
-    HIP_TRY(c, hipMalloc((void**)&d_o, (size_t)n * 3 * sizeof(int)));
+    DevBuf<float4> d_in; DevBuf<int> d_o;
+    HIP_TRY(c, d_in.alloc((size_t)n));
+    HIP_TRY(c, d_o.alloc((size_t)n * 3));
     hipError_t e = hipMemcpyAsync(d_in, pts4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(bin_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, d_in, n, cell_size, d_o);
         e = hipMemcpyAsync(ijk3, d_o, (size_t)n * 3 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(d_in); hipFree(d_o);
     HIP_TRY(c, e);
     return ICPMI_OK;
 }
@@ -456,13 +453,12 @@ icpmi_status ops_surface_normals(icpmi_ctx* c, const float* pts4, int64_t m, int
     s = temp_knn(c, t, pts4, m, nullptr, m, knn, 1, true);
     if (s != ICPMI_OK) return s;
     icpmi_ctx* tc = t.h;
-    float* d_n = nullptr;
-    HIP_TRY(c, hipMalloc((void**)&d_n, (size_t)m * 3 * sizeof(float)));
+    DevBuf<float> d_n;
+    HIP_TRY(c, d_n.alloc((size_t)m * 3));
     hipLaunchKernelGGL(normals_kernel, dim3((int)((m + 127) / 128)), dim3(128), 0, tc->stream, tc->d_map_sorted, tc->d_sidx, m, knn, d_n);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(normals3, d_n, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost, tc->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(tc->stream);
-    hipFree(d_n);
     HIP_TRY(c, e);
     return ICPMI_OK;
 }
@@ -478,14 +474,13 @@ icpmi_status ops_point_distance_keep(icpmi_ctx* c, const float* map4, int64_t m,
     s = temp_knn(c, t, map4, m, in4, n, 1, 0, false);
     if (s != ICPMI_OK) return s;
     icpmi_ctx* tc = t.h;
-    uint8_t* d_keep = nullptr;
-    HIP_TRY(c, hipMalloc((void**)&d_keep, (size_t)n));
+    DevBuf<uint8_t> d_keep;
+    HIP_TRY(c, d_keep.alloc((size_t)n));
     const float lim = powf(min_dist, 2.f);
     hipLaunchKernelGGL(keep_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, tc->stream, tc->d_d2, n, lim, d_keep);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(keep, d_keep, (size_t)n, hipMemcpyDeviceToHost, tc->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(tc->stream);
-    hipFree(d_keep);
     HIP_TRY(c, e);
     return ICPMI_OK;
 }
