@@ -191,6 +191,31 @@ def test_full_registration_matches_oracle(amd, oracle, mid_scene, name):
         assert np.array_equal(T, np.eye(4, dtype=np.float32))
 
 
+@pytest.mark.parametrize("knn", [1, 3])
+def test_surface_normal_outlier_filter_chain(amd, oracle, mid_scene, knn):
+    """SurfaceNormalOutlierFilter needs the reading's normals (rotated with the cloud, B.7) next to each match: with the
+    loop state kept in tile-sorted query order the descriptor lookup goes through the sort's index."""
+    sc = mid_scene
+    kw = dict(minimizer=2, knn=knn, max_dist=2.0, outliers=[(5, 0.5), (4, 0.9)], max_iterations=12, use_differential=0)
+    icp = amd.ICPSequence(**kw)
+    icp.setMap(sc["map"], sc["normals"])
+    rng = np.random.default_rng(4)
+    sn = sc["scan_normals"].copy()
+    flip = rng.random(sn.shape[0]) < 0.3                     # a third of the reading disagrees with the map's normals
+    sn[flip] = np.roll(sn[flip], 1, axis=1)
+    T = icp(sc["scan"], sn)
+    oicp = oracle.OracleICP(oracle.make_config(nthreads=8, **kw))
+    oicp.setMap(sc["map"], sc["normals"])
+    err, T_ref = oicp(sc["scan"], sn)
+    assert err == 0
+    assert icp.stats.iterations == oicp.stats.iterations and icp.stats.pairs == oicp.stats.pairs
+    assert icp.stats.pairs < 0.8 * sc["scan"].shape[0] * knn   # the filter did reject the flipped normals
+    dt, dr = amd.synth.pose_error(T, T_ref)
+    assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (dt, dr)
+    with pytest.raises(amd.InvalidField):
+        icp(sc["scan"])                                       # reading without normals
+
+
 def test_graph_and_eager_agree(amd, mid_scene):
     import ctypes as C
     sc = mid_scene
