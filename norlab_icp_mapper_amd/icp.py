@@ -207,6 +207,12 @@ class ICPSequence:
     def loadFromYaml(cls, chain, **engine):
         return cls(config_from_yaml_chain(chain, **engine))
 
+    def setConfig(self, cfg=None, **kw):
+        """Swap the chain of the live handle (icpmi_set_config): the map and the handle stay valid."""
+        new = cfg if cfg is not None else default_config(device=self.cfg.device, **kw)
+        self._check(self._lib.icpmi_set_config(self._h, C.byref(new)))
+        self.cfg = new
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.icpmi_destroy(self._h)

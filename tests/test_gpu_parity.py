@@ -191,6 +191,29 @@ def test_full_registration_matches_oracle(amd, oracle, mid_scene, name):
         assert np.array_equal(T, np.eye(4, dtype=np.float32))
 
 
+def test_caller_stream_and_config_swap(amd, mid_scene):
+    """icpmi_set_stream: the handle's work runs on the caller's stream (here a torch stream); icpmi_set_config swaps the
+    chain of a live handle and keeps its map."""
+    import torch
+    sc = mid_scene
+    kw = dict(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=10, use_differential=0)
+    ref = amd.ICPSequence(**kw); ref.setMap(sc["map"], sc["normals"]); T_ref = ref(sc["scan"])
+    icp = amd.ICPSequence(**kw)
+    stream = torch.cuda.Stream()
+    icp.setStream(stream.cuda_stream)
+    icp.setMap(sc["map"], sc["normals"])
+    d = torch.from_numpy(sc["scan"]).cuda()
+    with torch.cuda.stream(stream):
+        d2 = d * 1.0                                            # produced on that stream, consumed by the registration
+    T = icp.registerDev(d2.data_ptr(), d2.shape[0])
+    assert np.array_equal(T, T_ref)
+    # same handle, other chain: point-to-point, median filter; the map stays
+    kw2 = dict(minimizer=1, max_dist=2.0, outliers=[(3, 3.0)], max_iterations=6, use_differential=0)
+    icp.setConfig(**kw2)
+    ref2 = amd.ICPSequence(**kw2); ref2.setMap(sc["map"], sc["normals"])
+    assert np.array_equal(icp(sc["scan"]), ref2(sc["scan"]))
+
+
 @pytest.mark.parametrize("knn", [1, 3])
 def test_surface_normal_outlier_filter_chain(amd, oracle, mid_scene, knn):
     """SurfaceNormalOutlierFilter needs the reading's normals (rotated with the cloud, B.7) next to each match: with the
