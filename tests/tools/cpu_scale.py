@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import norlab_icp_mapper_amd.synth as synth
 import oracle_bindings as ob
 sc = synth.make_scene(m=1_000_000, n=100_000)

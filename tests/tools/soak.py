@@ -2,8 +2,9 @@
 """Soak test: random maps / readings / chains through the C ABI, looking for hangs, device errors and
 non-finite poses.  Every N-th case is cross-checked against the oracle."""
 import sys, os, time, math
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, _ROOT)
+sys.path.insert(0, os.path.join(_ROOT, "tests"))
 import numpy as np
 import norlab_icp_mapper_amd as pkg
 import oracle_bindings as ob

@@ -1,8 +1,9 @@
 #!/usr/bin/env python
 """Soak test of the stage / map-side operators against the oracle (bit-exact where the spec says so)."""
 import sys, os, time, math
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, _ROOT)
+sys.path.insert(0, os.path.join(_ROOT, "tests"))
 import numpy as np
 import norlab_icp_mapper_amd as pkg
 import oracle_bindings as ob
