@@ -120,6 +120,7 @@ icpmi_status icpmi_set_config(icpmi_handle h, const icpmi_config* cfg)
 void icpmi_destroy(icpmi_handle c)
 {
     if (!c) return;
+    if (c->temp) { icpmi_destroy(c->temp); c->temp = nullptr; }
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);

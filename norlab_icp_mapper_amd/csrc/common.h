@@ -154,6 +154,8 @@ struct icpmi_ctx {
     float4* d_raw = nullptr; size_t cap_raw = 0;
     float*  d_raw_n3 = nullptr; size_t cap_raw_n3 = 0;
     int64_t m_raw = 0; bool raw_has_normals = false;
+    icpmi_ctx* temp = nullptr;        // private handle of the map-side operators (indexes arbitrary clouds), created on first use
+    bool single_level = false;        // temp handles of the self k-NN (surface normals): level 0 of the pyramid is all they search
     bool no_centre = false;           // temp handles of the map-side operators: index raw coordinates (mean = 0)
     int*    d_sidx = nullptr; size_t cap_sidx = 0;             // k x n sorted-map index (-1 none)
     float*  d_d2 = nullptr; size_t cap_d2 = 0;                 // k x n
@@ -250,13 +252,12 @@ icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float
 icpmi_status device_exclusive_scan(icpmi_ctx* c, unsigned* data, int n, unsigned total);
 icpmi_status sort_queries(icpmi_ctx* c, const float4* d_pts, int64_t n);
 icpmi_status sort_queries_reserve(icpmi_ctx* c, int64_t n);
-icpmi_status nn_tile_launch_k1(icpmi_ctx* c, int64_t n, const float* d_T, const LoopCfg& lc, int allow_self, int* d_sidx,
-                               float* d_d2, IcpState* d_state);
 icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, const float* d_T, const LoopCfg& lc,
                           int allow_self, int* d_sidx, float* d_d2, IcpState* d_state);
 icpmi_status nn_launch_k(icpmi_ctx* c, const float4* d_reading, int64_t n, const float* d_T, const LoopCfg& lc,
                          int allow_self, int* d_sidx, float* d_d2, IcpState* d_state);
 icpmi_status nn_ids_to_original(icpmi_ctx* c, const int* d_sidx, int64_t count, int* d_ids);
+icpmi_status nn_self_knn(icpmi_ctx* c, const LoopCfg& lc, int* d_sidx, float* d_d2, IcpState* d_state);
 icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals3, int64_t n, const LoopCfg& lc, bool fixed, float T_out[16],
                       icpmi_stats* stats);
 icpmi_status loop_prepare_reading(icpmi_ctx* c, const float4* d_scan, int64_t n, const float* d_normals3);

@@ -544,7 +544,7 @@ icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float
     GridLevels& L = c->levels;
     L.nlev = 1;
     L.g[0] = g; L.pts[0] = c->d_map_sorted; L.cs[0] = c->d_cell_start; L.pos0[0] = nullptr;
-    for (int l = 1; l < ICPMI_MAXLEV; ++l) {
+    for (int l = 1; l < ICPMI_MAXLEV && !c->single_level; ++l) {
         const GridParams& prev = L.g[l - 1];
         const bool reaches = std::isfinite(c->cfg.max_dist) && (prev.cell - prev.slack) > c->cfg.max_dist;
         const bool tiny = prev.nx <= 2 && prev.ny <= 2 && prev.nz <= 2;

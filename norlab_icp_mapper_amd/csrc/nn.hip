@@ -149,11 +149,14 @@ __global__ __launch_bounds__(NN_BLOCK) void nnk_kernel(const float4* __restrict_
                                                        GridParams g, const float4* __restrict__ map,
                                                        const unsigned* __restrict__ cs, int k, float maxr2, int ring_max,
                                                        int allow_self, int* __restrict__ out_sidx, float* __restrict__ out_d2,
-                                                       IcpState* __restrict__ st, unsigned* __restrict__ hard)
+                                                       IcpState* __restrict__ st, unsigned* __restrict__ hard,
+                                                       const unsigned* __restrict__ only, const unsigned* __restrict__ only_count)
 {
     if (st && st->done) return;
-    const int qi = blockIdx.x * NN_BLOCK + threadIdx.x;
-    if (qi >= n) return;
+    // `only` != nullptr: just the listed queries (the left-overs of the tiled self-search below)
+    const int tid = blockIdx.x * NN_BLOCK + threadIdx.x;
+    if (only ? tid >= (int)*only_count : tid >= n) return;
+    const int qi = only ? (int)only[tid] : tid;
     const float4 r = reading[qi];
     float3 p;
     if (Tptr) p = xf_point(Tptr, r.x, r.y, r.z, r.w);
@@ -879,6 +882,117 @@ __global__ __launch_bounds__(NN_BLOCK) void nnk_ml_kernel(const float4* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Self k-NN of the indexed cloud (SurfaceNormalDataPointsFilter: every map point against the map, knn 5..32,
+// self match allowed).  The queries ARE the cell-sorted points, so all queries of a cell share one 3x3x3
+// neighbourhood: a workgroup takes SEG consecutive x-cells of one (y, z) row, stages the 9 x-runs that cover
+// the neighbourhoods of all of them into LDS once (chunks of SELF_CH points) and lets one lane per query scan
+// them from LDS (every lane reads the same address: a broadcast).  Map traffic drops from one gather stream per
+// query to 9 coalesced runs per workgroup.  A query whose k-th distance does not fit its margin to the block
+// boundary is queued and redone by the ring-search kernel.  Results go to row `original index` of out_sidx.
+// ------------------------------------------------------------------------------------------------
+// One wave per workgroup: a 4-cell segment holds ~40 queries, so wider workgroups would idle most of their lanes.
+constexpr int SELF_SEG = 4, SELF_CH = 768, SELF_BLOCK = 64;
+
+template <int KMAX>
+__global__ __launch_bounds__(SELF_BLOCK) void nnk_self_tiled_kernel(GridParams g, const float4* __restrict__ map,
+                                                                  const unsigned* __restrict__ cs, int k, int* __restrict__ out_sidx,
+                                                                  float* __restrict__ out_d2, IcpState* __restrict__ st,
+                                                                  unsigned* __restrict__ queue)
+{
+    const int nsx = (g.nx + SELF_SEG - 1) / SELF_SEG;
+    const int b = blockIdx.x;
+    const int sx = b % nsx, y = (b / nsx) % g.ny, z = b / (nsx * g.ny);
+    const int x0 = sx * SELF_SEG, x1 = min(x0 + SELF_SEG, g.nx); // query cells [x0, x1)
+    const int qbase = (z * g.ny + y) * g.nx;
+    const unsigned qs = cs[qbase + x0], qe = cs[qbase + x1];
+    if (qs == qe) return;
+    // the 9 candidate runs (cells x0-1 .. x1 of the rows (y+dy, z+dz)); workgroup-uniform
+    __shared__ unsigned run_s[9], run_p[10];
+    __shared__ float4 tile[SELF_CH];
+    if (threadIdx.x < 9) {
+        const int dy = (int)threadIdx.x % 3 - 1, dz = (int)threadIdx.x / 3 - 1;
+        unsigned s0 = 0, e0 = 0;
+        row_run(g, cs, x0 - 1, x1, y + dy, z + dz, s0, e0);
+        run_s[threadIdx.x] = s0; run_p[threadIdx.x + 1] = e0 - s0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        run_p[0] = 0;
+        for (int i = 1; i <= 9; ++i) run_p[i] += run_p[i - 1];
+    }
+    __syncthreads();
+    const unsigned ncand = run_p[9];
+    for (unsigned q0 = qs; q0 < qe; q0 += SELF_BLOCK) { // one wave of queries at a time (one pass for all but dense cells)
+        const unsigned qi = q0 + threadIdx.x;
+        const bool active = qi < qe;
+        const float4 me = map[active ? qi : qs];
+        KList<KMAX> L; L.init(k);
+        for (unsigned c0 = 0; c0 < ncand; c0 += SELF_CH) {
+            const unsigned cn = min((unsigned)SELF_CH, ncand - c0);
+            __syncthreads(); // previous chunk fully consumed
+            for (unsigned i = threadIdx.x; i < cn; i += SELF_BLOCK) {
+                const unsigned f = c0 + i; // flat candidate -> run
+                int r = 0;
+#pragma unroll
+                for (int j = 1; j < 9; ++j) r = f >= run_p[j] ? j : r;
+                tile[i] = map[run_s[r] + (f - run_p[r])];
+            }
+            __syncthreads();
+            if (active) {
+                for (unsigned i = 0; i < cn; ++i) {
+                    const float4 q = tile[i];
+                    const float d2 = sqdist3(me.x, me.y, me.z, q.x, q.y, q.z);
+                    L.insert(pack_key(d2, __float_as_uint(q.w)), (int)(c0 + i)); // flat index; turned into a map position below
+                }
+            }
+        }
+        if (!active) continue;
+        // exactness: the staged region contains the query's own 3x3x3 block; points outside the region may be
+        // nearer than the k-th candidate only if that one lies beyond the query's margin to the region
+        const float fx = (me.x - g.ox) * g.inv_cell, fy = (me.y - g.oy) * g.inv_cell, fz = (me.z - g.oz) * g.inv_cell;
+        const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
+        float mf = fminf(fx - flx, 1.0f - (fx - flx));
+        mf = fminf(mf, fminf(fy - fly, 1.0f - (fy - fly)));
+        mf = fminf(mf, fminf(fz - flz, 1.0f - (fz - flz)));
+        if (!(mf >= 0.f)) mf = 0.f;
+        const float margin = fmaxf((1.0f + mf) * g.cell - g.slack, 0.f);
+        unsigned long long kth = ~0ull;
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) if (i == k - 1) kth = L.key[i];
+        const int cx = (int)fminf(fmaxf(flx, -1.0e6f), 1.0e6f);
+        const bool covers = cx - 1 <= 0 && cx + 1 >= g.nx - 1 && y - 1 <= 0 && y + 1 >= g.ny - 1 && z - 1 <= 0 && z + 1 >= g.nz - 1;
+        const bool decided = covers || (kth != ~0ull && __uint_as_float((unsigned)(kth >> 32)) <= margin * margin);
+        const unsigned orig = __float_as_uint(me.w);
+        if (decided) {
+#pragma unroll
+            for (int j = 0; j < KMAX; ++j)
+                if (j < k) {
+                    int pos = -1;
+                    if (L.sidx[j] >= 0) {
+                        const unsigned f = (unsigned)L.sidx[j];
+                        int r = 0;
+#pragma unroll
+                        for (int jj = 1; jj < 9; ++jj) r = f >= run_p[jj] ? jj : r;
+                        pos = (int)(run_s[r] + (f - run_p[r]));
+                    }
+                    out_sidx[(size_t)k * orig + j] = pos;
+                    out_d2[(size_t)k * orig + j] = pos < 0 ? INFINITY : __uint_as_float((unsigned)(L.key[j] >> 32));
+                }
+        } else {
+            const unsigned slot = atomicAdd(&st->hard_count, 1u); // reused as the length of the redo queue
+            queue[slot] = orig;
+        }
+    }
+}
+
+// between the tiled self-search and its redo: queue length -> queue[m + 1] (read by the ring kernel as `only_count`),
+// hard_count reset so that the ring kernel can queue its own left-overs for the brute-force pass
+__global__ void nnk_redo_kernel(IcpState* st, unsigned* len_slot)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) { *len_slot = st->hard_count; st->hard_count = 0; }
+}
+
 } // namespace
 
 void nn_launch_hard_k1(icpmi_ctx* c, const float4* d_reading, const float* d_T, const LoopCfg& lc, int allow_self, int* d_sidx,
@@ -969,7 +1083,8 @@ static icpmi_status nnk_launch_t(icpmi_ctx* c, const float4* d_reading, int64_t 
     const int blocks = (int)((n + NN_BLOCK - 1) / NN_BLOCK);
     if (blocks == 0) return ICPMI_OK;
     hipLaunchKernelGGL(nnk_kernel<KMAX>, dim3(blocks), dim3(NN_BLOCK), 0, c->stream, d_reading, (int)n, d_T, c->grid,
-                       c->d_map_sorted, c->d_cell_start, lc.k, lc.maxr2, lc.ring_max, allow_self, d_sidx, d_d2, d_state, c->d_hard);
+                       c->d_map_sorted, c->d_cell_start, lc.k, lc.maxr2, lc.ring_max, allow_self, d_sidx, d_d2, d_state, c->d_hard,
+                       (const unsigned*)nullptr, (const unsigned*)nullptr);
     if (!std::isfinite(lc.max_dist) || lc.ring_max < (int)ceilf(lc.max_dist / c->grid.cell) + 1) {
         hipLaunchKernelGGL(nnk_hard_kernel<KMAX>, dim3(512), dim3(NN_BLOCK), 0, c->stream, d_reading, d_T, c->d_map_sorted,
                            (int)c->m, lc.k, lc.maxr2, allow_self, d_sidx, d_d2, d_state, c->d_hard);
@@ -987,6 +1102,40 @@ icpmi_status nn_launch_k(icpmi_ctx* c, const float4* d_reading, int64_t n, const
     if (lc.k <= 8) return nnk_launch_t<8>(c, d_reading, n, d_T, lc, allow_self, d_sidx, d_d2, d_state);
     if (lc.k <= 16) return nnk_launch_t<16>(c, d_reading, n, d_T, lc, allow_self, d_sidx, d_d2, d_state);
     if (lc.k <= 32) return nnk_launch_t<32>(c, d_reading, n, d_T, lc, allow_self, d_sidx, d_d2, d_state);
+    c->last_error = "knn > 32 is not supported";
+    return ICPMI_ERR_UNSUPPORTED;
+}
+
+template <int KMAX>
+static icpmi_status nn_self_knn_t(icpmi_ctx* c, const LoopCfg& lc, int* d_sidx, float* d_d2, IcpState* d_state)
+{
+    const GridParams& g = c->grid;
+    const int nsx = (g.nx + SELF_SEG - 1) / SELF_SEG;
+    const long long wgs = (long long)nsx * g.ny * g.nz;
+    if (wgs > 0x7fffffffll) { c->last_error = "self knn: grid too large"; return ICPMI_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(nnk_self_tiled_kernel<KMAX>, dim3((unsigned)wgs), dim3(SELF_BLOCK), 0, c->stream, g, c->d_map_sorted, c->d_cell_start, lc.k,
+                       d_sidx, d_d2, d_state, c->d_hard);
+    // left-overs (k-th neighbour beyond the margin: sparse regions, map border): ring search, then brute force
+    const int blocks = (int)((c->m + NN_BLOCK - 1) / NN_BLOCK);
+    hipLaunchKernelGGL(nnk_redo_kernel, dim3(1), dim3(64), 0, c->stream, d_state, c->d_hard + c->m + 1);
+    hipLaunchKernelGGL(nnk_kernel<KMAX>, dim3(blocks), dim3(NN_BLOCK), 0, c->stream, c->d_reading, (int)c->m, (const float*)nullptr, g,
+                       c->d_map_sorted, c->d_cell_start, lc.k, lc.maxr2, lc.ring_max, 1, d_sidx, d_d2, d_state,
+                       c->d_hard + c->m + 2, (const unsigned*)c->d_hard, (const unsigned*)(c->d_hard + c->m + 1));
+    hipLaunchKernelGGL(nnk_hard_kernel<KMAX>, dim3(512), dim3(NN_BLOCK), 0, c->stream, c->d_reading, (const float*)nullptr, c->d_map_sorted,
+                       (int)c->m, lc.k, lc.maxr2, 1, d_sidx, d_d2, d_state, (const unsigned*)(c->d_hard + c->m + 2));
+    hipLaunchKernelGGL(hard_reset_kernel, dim3(1), dim3(64), 0, c->stream, d_state);
+    HIP_TRY(c, hipGetLastError());
+    return ICPMI_OK;
+}
+
+// self k-NN of the indexed cloud: c->d_reading must hold the cloud in its original order (for the redo passes),
+// c->d_hard at least 2 m + 4 words
+icpmi_status nn_self_knn(icpmi_ctx* c, const LoopCfg& lc, int* d_sidx, float* d_d2, IcpState* d_state)
+{
+    if (lc.k <= 4) return nn_self_knn_t<4>(c, lc, d_sidx, d_d2, d_state);
+    if (lc.k <= 8) return nn_self_knn_t<8>(c, lc, d_sidx, d_d2, d_state);
+    if (lc.k <= 16) return nn_self_knn_t<16>(c, lc, d_sidx, d_d2, d_state);
+    if (lc.k <= 32) return nn_self_knn_t<32>(c, lc, d_sidx, d_d2, d_state);
     c->last_error = "knn > 32 is not supported";
     return ICPMI_ERR_UNSUPPORTED;
 }

@@ -351,17 +351,23 @@ __global__ __launch_bounds__(256) void append_kept_kernel(const float4* __restri
 
 // helper: a private handle on the same device/stream used to index an arbitrary cloud without
 // disturbing the ICP map of the caller's handle
+// The private handle lives as long as its owner (created on first use, destroyed by icpmi_destroy): its buffers are
+// reused from call to call instead of ~20 hipMalloc / hipFree pairs per operator call.
 struct TempCtx {
     icpmi_handle h = nullptr;
-    ~TempCtx() { if (h) icpmi_destroy(h); }
 };
 
 static icpmi_status make_temp(icpmi_ctx* c, TempCtx& t)
 {
-    icpmi_config cfg = c->cfg;
-    icpmi_status s = icpmi_create(&cfg, &t.h);
-    if (s != ICPMI_OK) { c->last_error = icpmi_last_error(nullptr); return s; }
+    if (!c->temp) {
+        icpmi_config cfg = c->cfg;
+        icpmi_status s = icpmi_create(&cfg, &c->temp);
+        if (s != ICPMI_OK) { c->last_error = icpmi_last_error(nullptr); c->temp = nullptr; return s; }
+    }
+    t.h = c->temp;
+    t.h->cfg = c->cfg;
     t.h->no_centre = true; // PointDistanceMapperModule.cpp:33 / SurfaceNormalDataPointsFilter build their kd-tree on the raw cloud
+    t.h->single_level = false;
     return ICPMI_OK;
 }
 
@@ -423,13 +429,22 @@ static icpmi_status temp_knn(icpmi_ctx* c, TempCtx& t, const float* cloud4, int6
                              int allow_self, bool queries_are_cloud)
 {
     icpmi_ctx* tc = t.h;
+    static int tiled = -1;
+    if (tiled < 0) { const char* e = getenv("ICPMI_SELF_KNN_TILED"); tiled = e ? atoi(e) : 1; }
+    const bool self = queries_are_cloud && allow_self && tiled; // SurfaceNormalDataPointsFilter: the cloud against itself
+    tc->single_level = self;
     int32_t acc = 0;
     icpmi_status s = icpmi_set_map(t.h, cloud4, m, nullptr, &acc);
     if (s != ICPMI_OK) { c->last_error = tc->last_error; return s; }
     // queries: stage + centre on the temp map's mean (the index lives in the centred frame)
     if (ensure_cap(tc, &tc->d_stage_in, &tc->cap_stage_in, (size_t)n + 1) != ICPMI_OK) { c->last_error = tc->last_error; return ICPMI_ERR_HIP; }
     HIP_TRY(c, hipMemcpyAsync(tc->d_stage_in, queries_are_cloud ? cloud4 : q4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, tc->stream));
-    s = loop_prepare_reading(tc, tc->d_stage_in, n, nullptr);
+    if (self) { // the redo passes read the cloud in its own order; no tile sort needed
+        if (ensure_cap(tc, &tc->d_reading, &tc->cap_reading, (size_t)n + 1) != ICPMI_OK) { c->last_error = tc->last_error; return ICPMI_ERR_HIP; }
+        HIP_TRY(c, hipMemcpyAsync(tc->d_reading, tc->d_stage_in, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, tc->stream));
+        s = ICPMI_OK;
+    } else
+        s = loop_prepare_reading(tc, tc->d_stage_in, n, nullptr);
     if (s != ICPMI_OK) { c->last_error = tc->last_error; return s; }
     LoopCfg lc = make_loop_cfg(tc, 1);
     lc.k = k; lc.max_dist = INFINITY; lc.maxr2 = INFINITY; lc.ring_max = 6;
@@ -438,7 +453,11 @@ static icpmi_status temp_knn(icpmi_ctx* c, TempCtx& t, const float* cloud4, int6
         ensure_cap(tc, &tc->d_hard, &tc->cap_hard, (size_t)n + 1) != ICPMI_OK) { c->last_error = tc->last_error; return ICPMI_ERR_HIP; }
     HIP_TRY(c, hipMemsetAsync(tc->d_state, 0, sizeof(IcpState), tc->stream));
     tc->nn_hist0 = nullptr; tc->nn_iter_hint = 0; tc->nn_match_pt = nullptr;
-    s = nn_launch_k(tc, tc->d_reading, n, nullptr, lc, allow_self, tc->d_sidx, tc->d_d2, tc->d_state);
+    if (self) {
+        if (ensure_cap(tc, &tc->d_hard, &tc->cap_hard, (size_t)2 * m + 8) != ICPMI_OK) { c->last_error = tc->last_error; return ICPMI_ERR_HIP; }
+        s = nn_self_knn(tc, lc, tc->d_sidx, tc->d_d2, tc->d_state);
+    } else
+        s = nn_launch_k(tc, tc->d_reading, n, nullptr, lc, allow_self, tc->d_sidx, tc->d_d2, tc->d_state);
     if (s != ICPMI_OK) { c->last_error = tc->last_error; return s; }
     return ICPMI_OK;
 }
@@ -577,11 +596,12 @@ static icpmi_status surface_normals_dev(icpmi_ctx* c, const float4* d_pts, int64
     if (s != ICPMI_OK) return s;
     icpmi_ctx* tc = t.h;
     HIP_TRY(c, hipStreamSynchronize(c->stream)); // d_pts was produced on the caller's stream
+    tc->single_level = true;
     int32_t acc = 0;
     s = icpmi_set_map_dev(t.h, (const float*)d_pts, m, nullptr, &acc);
     if (s != ICPMI_OK) { c->last_error = tc->last_error; return s; }
-    s = loop_prepare_reading(tc, d_pts, m, nullptr);
-    if (s != ICPMI_OK) { c->last_error = tc->last_error; return s; }
+    if (ensure_cap(tc, &tc->d_reading, &tc->cap_reading, (size_t)m + 1) != ICPMI_OK) { c->last_error = tc->last_error; return ICPMI_ERR_HIP; }
+    HIP_TRY(c, hipMemcpyAsync(tc->d_reading, d_pts, (size_t)m * sizeof(float4), hipMemcpyDeviceToDevice, tc->stream));
     LoopCfg lc = make_loop_cfg(tc, 1);
     lc.k = knn; lc.max_dist = INFINITY; lc.maxr2 = INFINITY; lc.ring_max = 6;
     const size_t cnt = (size_t)m * knn + 1;
@@ -589,7 +609,8 @@ static icpmi_status surface_normals_dev(icpmi_ctx* c, const float4* d_pts, int64
         ensure_cap(tc, &tc->d_hard, &tc->cap_hard, (size_t)m + 1) != ICPMI_OK) { c->last_error = tc->last_error; return ICPMI_ERR_HIP; }
     HIP_TRY(c, hipMemsetAsync(tc->d_state, 0, sizeof(IcpState), tc->stream));
     tc->nn_hist0 = nullptr; tc->nn_iter_hint = 0; tc->nn_match_pt = nullptr;
-    s = nn_launch_k(tc, tc->d_reading, m, nullptr, lc, 1, tc->d_sidx, tc->d_d2, tc->d_state);
+    if (ensure_cap(tc, &tc->d_hard, &tc->cap_hard, (size_t)2 * m + 8) != ICPMI_OK) { c->last_error = tc->last_error; return ICPMI_ERR_HIP; }
+    s = nn_self_knn(tc, lc, tc->d_sidx, tc->d_d2, tc->d_state);
     if (s != ICPMI_OK) { c->last_error = tc->last_error; return s; }
     // rows of d_sidx follow the query order = the caller's order, so the normals land in place
     hipLaunchKernelGGL(normals_kernel, dim3((int)((m + 127) / 128)), dim3(128), 0, tc->stream, tc->d_map_sorted, tc->d_sidx, m, knn, d_normals3);
