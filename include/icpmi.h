@@ -96,7 +96,7 @@ typedef struct {
     float   max_trans_norm;    /* default 1                                                       */
     /* engine knobs (no reference analogue) */
     float   grid_cell;         /* NN grid cell edge in metres; 0 = choose from the map density     */
-    int32_t use_graph;         /* 1 = replay the iteration as a hipGraph (default), 0 = eager     */
+    int32_t use_graph;         /* 1 = fixed-iteration registrations replay one hipGraph (default) */
     int32_t profile;           /* 1 = eager launches with HIP events around every NN launch        */
     int32_t reserved[8];
 } icpmi_config;
@@ -111,9 +111,9 @@ typedef struct {
     float   weighted_point_used_ratio; /* sum w / (knn N) == getOverlap()                         */
     float   trimmed_limit;             /* last quantile limit on d^2 (Trimmed / Median), else -1  */
     float   loop_ms;                   /* device time of the iteration loop (HIP events)          */
-    float   nn_ms_avg;                 /* profile mode: mean duration of one NN launch            */
+    float   nn_ms_avg;                 /* profile mode: mean NN launch time (event-pair gap removed) */
     int32_t nn_launches;               /* profile mode: number of NN launches averaged            */
-    int64_t hard_queries;              /* NN queries that left the ring search for the brute pass */
+    int64_t hard_queries;              /* NN queries the grid pyramid could not decide (brute pass) */
     int32_t reserved[6];
 } icpmi_stats;
 
