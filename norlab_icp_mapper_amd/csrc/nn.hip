@@ -495,22 +495,28 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restri
             for (int sl = 0; sl < NR; ++sl) {
                 const int rr = sub + sl * G;
                 unsigned s = 0, cnt = 0;
-                if (rr < 9) {
-                    const int dy = (rr % 3) - 1, dz = (rr / 3) - 1;
-                    int xa = cx - 1, xb = cx + 1;
-                    bool reach = true;
-                    if (rub2 != INFINITY) {
-                        const float ddy = dy == 0 ? 0.f : (dy < 0 ? ylo : yhi);
-                        const float ddz = dz == 0 ? 0.f : (dz < 0 ? zlo : zhi);
-                        const float rem2 = rub2 - (ddy * ddy + ddz * ddz);
-                        reach = rem2 >= 0.f; // else the ball does not reach this row
-                        const float rem = sqrtf(fmaxf(rem2, 0.f));
-                        const int xl = (int)fmaxf(floorf((p.x - rem - g.ox) * g.inv_cell), -1.0e6f);
-                        const int xh = (int)fminf(floorf((p.x + rem - g.ox) * g.inv_cell), 1.0e6f);
-                        xa = xl > xa ? xl : xa;
-                        xb = xh < xb ? xh : xb;
-                    }
+                const int dy = (rr % 3) - 1, dz = (rr / 3) - 1;
+                // cheap part first: does the ball reach this row at all?
+                bool reach = rr < 9;
+                float rem2 = INFINITY;
+                if (reach && rub2 != INFINITY) {
+                    const float ddy = dy == 0 ? 0.f : (dy < 0 ? ylo : yhi);
+                    const float ddz = dz == 0 ? 0.f : (dz < 0 ? zlo : zhi);
+                    rem2 = rub2 - (ddy * ddy + ddz * ddz);
+                    reach = rem2 >= 0.f;
+                }
+                // the second slot only holds the corner row of lane 0 of each group: skipped wave-uniformly when no
+                // ball of the wave reaches it (the usual case once the registration converges)
+                if (__ballot(reach) != 0ull) {
                     if (reach) {
+                        int xa = cx - 1, xb = cx + 1;
+                        if (rem2 != INFINITY) {
+                            const float rem = sqrtf(rem2);
+                            const int xl = (int)fmaxf(floorf((p.x - rem - g.ox) * g.inv_cell), -1.0e6f);
+                            const int xh = (int)fminf(floorf((p.x + rem - g.ox) * g.inv_cell), 1.0e6f);
+                            xa = xl > xa ? xl : xa;
+                            xb = xh < xb ? xh : xb;
+                        }
                         unsigned e;
                         row_run(g, cs, xa, xb, cy + dy, cz + dz, s, e);
                         cnt = e - s;
