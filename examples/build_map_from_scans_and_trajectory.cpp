@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <iostream>
 #include <sstream>
@@ -75,7 +76,11 @@ int main(int argc, char** argv)
         const auto scans = listScans(dataDir + "/scans");
         if (trajectory.size() != scans.size()) throw std::runtime_error("trajectory rows and scan files differ in number");
 
-        Mapper mapper(config, /*is3D*/ true, /*isOnline*/ false, /*isMapping*/ true, /*saveMapCellsOnHardDrive*/ false);
+        // NIM_ONLINE=1: online mode (asynchronous map updates and cell paging on their own threads, Mapper.cpp:274-288,
+        // Map.cpp:35-57) -- the reference's example runs offline; the switch exists to exercise those threads
+        const char* onlineEnv = std::getenv("NIM_ONLINE");
+        const bool online = onlineEnv && std::atoi(onlineEnv) != 0;
+        Mapper mapper(config, /*is3D*/ true, /*isOnline*/ online, /*isMapping*/ true, /*saveMapCellsOnHardDrive*/ false);
         const auto t0 = std::chrono::steady_clock::now();
         for (size_t i = 0; i < scans.size(); ++i) {
             const TimePoint stamp{std::chrono::nanoseconds(trajectory[i].ns)};

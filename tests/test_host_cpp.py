@@ -200,6 +200,14 @@ def test_example_harness_matches_python_replay(tmp_path):
     assert out2.returncode == 0 and "resident map updates: 0" in out2.stdout
     pos2, _ = _read_vtk(traj2)
     assert np.abs(pos2 - pos).max() < 2e-4
+    # online mode: map updates on a std::async thread, cell paging on its own thread; a map update may land one scan
+    # later than offline, so only the plumbing is checked (no dead-lock, every scan registered, poses at the truth)
+    traj3 = os.path.join(tmp, "traj_online.vtk")
+    out3 = subprocess.run([os.path.join(PKG, "build_map_from_scans_and_trajectory"), tmp, cfg, traj3], capture_output=True, text=True,
+                          timeout=600, env=dict(os.environ, NIM_ONLINE="1"))
+    assert out3.returncode == 0, out3.stderr + out3.stdout
+    pos3, _ = _read_vtk(traj3)
+    assert pos3.shape == pos.shape and np.abs(pos3 - pos).max() < 0.05
 
 
 BUNDLED_LIKE_CONFIG = """
