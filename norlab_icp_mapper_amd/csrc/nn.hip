@@ -1046,7 +1046,15 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
         // iterations > 0 are seeded by the previous match (a handful of candidates per query): fewer
         // lanes per query; the unseeded first pass scans whole 27-cell blocks: more lanes per query
         const bool seeded = c->nn_iter_hint > 0 && allow_self;
-        if (seeded) LAUNCH_ML(8, 4);
+        static int g_seeded = -1, wide_until = -1;
+        if (g_seeded < 0) { const char* e = getenv("ICPMI_NN_G"); g_seeded = e ? atoi(e) : 8; }
+        if (wide_until < 0) { const char* e = getenv("ICPMI_NN_WIDE_UNTIL"); wide_until = e ? atoi(e) : 1; }
+        // the first solve moves the reading by the whole initial misalignment, so the seeds of iteration 1 bound the
+        // search no better than a fresh own-row scan: it still looks at a few hundred candidates per query and runs
+        // faster 16 lanes wide (r1: 80 us with 8 lanes, measured below)
+        const bool narrow = seeded && c->nn_iter_hint > wide_until;
+        if (narrow && g_seeded == 4) LAUNCH_ML(4, 4);
+        else if (narrow) LAUNCH_ML(8, 4);
         else LAUNCH_ML(16, 4);
 #undef LAUNCH_ML
         const GridParams& top = c->levels.g[c->levels.nlev - 1];
