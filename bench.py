@@ -65,12 +65,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # a launcher (torch.distributed.run) sets RANK / WORLD_SIZE: use the process group then, also for a single rank
+    use_pg = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    dev = local_rank if world > 1 else 0
+    dev = local_rank if use_pg else 0
     torch.cuda.set_device(dev)
 
     import norlab_icp_mapper_amd as pkg
@@ -99,7 +101,7 @@ def main():
         step()
 
     def barrier():
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -111,7 +113,7 @@ def main():
         loop_ms += icp.stats.loop_ms
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_pg:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -221,7 +223,7 @@ def main():
             }
             out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 
