@@ -198,6 +198,17 @@ icpmi_status icpmi_point_distance_keep(icpmi_handle h, const float* map4, int64_
 icpmi_status icpmi_map_update_point_distance(icpmi_handle h, const float* scan4, int64_t n, const float* scan_normals3,
                                              float min_dist, int32_t normals_knn, uint8_t* keep_out, int64_t* appended, int64_t* new_m);
 
+/* `Mapper::processInput` with the scan staged once (Mapper.cpp:194-238): scan4 arrives in the SENSOR frame;
+ * icpmi_register_prior moves it into the map frame by the prior on the device (`transformation->compute(input,
+ * estimatedPose)`, :197), registers it (`icp(input)`, :213) and keeps that cloud in HBM; T_out is the correction.
+ * If the update policy then asks for a map update, icpmi_map_update_staged applies the correction to the kept
+ * cloud (`transformation->compute(input, correction)`, :221) and runs icpmi_map_update_point_distance on it --
+ * the scan crosses PCIe once per processInput instead of five times. */
+icpmi_status icpmi_register_prior(icpmi_handle h, const float* scan4, int64_t n, const float prior[16], float T_out[16],
+                                  icpmi_stats* stats);
+icpmi_status icpmi_map_update_staged(icpmi_handle h, const float correction[16], float min_dist, int32_t normals_knn,
+                                     uint8_t* keep_out, int64_t* appended, int64_t* new_m);
+
 /* Download of the resident map in the caller's order (what `Map::getLocalPointCloud` returns, Map.cpp:536-540);
  * out4 / normals3 may be NULL to query *m only. */
 icpmi_status icpmi_get_map(icpmi_handle h, float* out4, float* normals3, int64_t capacity, int64_t* m);

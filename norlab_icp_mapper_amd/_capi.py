@@ -89,6 +89,8 @@ SYMBOLS = [
     ("icpmi_voxel_keep_first", C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),
     ("icpmi_map_update_point_distance", C.c_int, [_P, _P, C.c_int64, _P, C.c_float, C.c_int32, _P, _P, _P]),
     ("icpmi_get_map", C.c_int, [_P, _P, _P, C.c_int64, _P]),
+    ("icpmi_register_prior", C.c_int, [_P, _P, C.c_int64, _P, _F, C.POINTER(Stats)]),
+    ("icpmi_map_update_staged", C.c_int, [_P, _P, C.c_float, C.c_int32, _P, _P, _P]),
     ("icpmi_dynamic_points_update", C.c_int, [_P, _P, _P, _P, C.c_int64, _P, _P, C.c_int64, _P]),
     ("icpmi_bin_cells", C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),
     ("icpmi_set_stream", C.c_int, [_P, _P]),

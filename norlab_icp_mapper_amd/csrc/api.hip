@@ -130,7 +130,7 @@ void icpmi_destroy(icpmi_handle c)
     hipFree(c->d_keys); hipFree(c->d_fill); hipFree(c->d_blocksums); hipFree(c->d_red);
     hipFree(c->d_qsorted); hipFree(c->d_qindex); hipFree(c->d_qkeys); hipFree(c->d_qtile);
     hipFree(c->d_reading); hipFree(c->d_read_normals); hipFree(c->d_stage_in); hipFree(c->d_stage_n3);
-    hipFree(c->d_match_pt); hipFree(c->d_lvl_tab); hipFree(c->d_raw); hipFree(c->d_raw_n3);
+    hipFree(c->d_match_pt); hipFree(c->d_lvl_tab); hipFree(c->d_raw); hipFree(c->d_raw_n3); hipFree(c->d_scan_map); hipFree(c->d_T16);
     hipFree(c->d_sidx); hipFree(c->d_d2); hipFree(c->d_hard); hipFree(c->d_partials); hipFree(c->d_selhist);
     hipFree(c->d_state);
     if (c->h_state) hipHostFree(c->h_state);
@@ -390,6 +390,35 @@ icpmi_status icpmi_map_update_point_distance(icpmi_handle h, const float* scan4,
     CHECK_H(h);
     if (n < 0 || (n > 0 && !scan4) || !(min_dist >= 0.f)) { h->last_error = "map_update_point_distance: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
     return ops_map_update_point_distance(h, scan4, n, scan_normals3, min_dist, normals_knn, keep_out, appended, new_m);
+}
+
+icpmi_status icpmi_register_prior(icpmi_handle h, const float* scan4, int64_t n, const float prior[16], float T_out[16], icpmi_stats* stats)
+{
+    CHECK_H(h);
+    if (n < 0 || (n > 0 && !scan4) || !prior) { h->last_error = "register_prior: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
+    h->scan_map_n = 0;
+    if (n > 0) {
+        if (ensure_cap(h, &h->d_stage_in, &h->cap_stage_in, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+        if (ensure_cap(h, &h->d_scan_map, &h->cap_scan_map, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+        HIP_TRY(h, hipMemcpyAsync(h->d_stage_in, scan4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+        icpmi_status s = ops_transform_dev(h, prior, h->d_stage_in, n, h->d_scan_map); // Mapper.cpp:197
+        if (s != ICPMI_OK) return s;
+        h->scan_map_n = n;
+    }
+    return register_impl(h, (const float*)h->d_scan_map, n, nullptr, 0, T_out, stats);
+}
+
+icpmi_status icpmi_map_update_staged(icpmi_handle h, const float correction[16], float min_dist, int32_t normals_knn, uint8_t* keep_out,
+                                     int64_t* appended, int64_t* new_m)
+{
+    CHECK_H(h);
+    if (!correction || !(min_dist >= 0.f)) { h->last_error = "map_update_staged: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
+    if (h->scan_map_n <= 0) { h->last_error = "map_update_staged: no scan staged by icpmi_register_prior"; return ICPMI_ERR_INVALID_ARG; }
+    const int64_t n = h->scan_map_n;
+    if (ensure_cap(h, &h->d_stage_in, &h->cap_stage_in, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    icpmi_status s = ops_transform_dev(h, correction, h->d_scan_map, n, h->d_stage_in); // Mapper.cpp:221
+    if (s != ICPMI_OK) return s;
+    return ops_map_update_dev(h, h->d_stage_in, n, nullptr, min_dist, normals_knn, keep_out, appended, new_m);
 }
 
 icpmi_status icpmi_get_map(icpmi_handle h, float* out4, float* normals3, int64_t capacity, int64_t* m)

@@ -154,6 +154,9 @@ struct icpmi_ctx {
     float4* d_raw = nullptr; size_t cap_raw = 0;
     float*  d_raw_n3 = nullptr; size_t cap_raw_n3 = 0;
     int64_t m_raw = 0; bool raw_has_normals = false;
+    // the scan of the last icpmi_register_prior, in the map frame by its prior (what Mapper::processInput calls `input`)
+    float4* d_scan_map = nullptr; size_t cap_scan_map = 0; int64_t scan_map_n = 0;
+    float* d_T16 = nullptr;           // a 4x4 for device-side transforms
     icpmi_ctx* temp = nullptr;        // private handle of the map-side operators (indexes arbitrary clouds), created on first use
     bool single_level = false;        // temp handles of the self k-NN (surface normals): level 0 of the pyramid is all they search
     bool no_centre = false;           // temp handles of the map-side operators: index raw coordinates (mean = 0)
@@ -274,6 +277,9 @@ icpmi_status ops_dynamic_points_update(icpmi_ctx* c, const icpmi_dynpts_params* 
                                        const float* map4, const float* map_normals3, int64_t m, float* prob);
 icpmi_status ops_map_update_point_distance(icpmi_ctx* c, const float* scan4, int64_t n, const float* scan_normals3, float min_dist,
                                            int normals_knn, uint8_t* keep_out, int64_t* appended, int64_t* new_m);
+icpmi_status ops_map_update_dev(icpmi_ctx* c, const float4* d_scan, int64_t n, const float* d_scan_n3, float min_dist, int normals_knn,
+                                uint8_t* keep_out, int64_t* appended, int64_t* new_m);
+icpmi_status ops_transform_dev(icpmi_ctx* c, const float T[16], const float4* d_in, int64_t n, float4* d_out);
 icpmi_status ops_get_map(icpmi_ctx* c, float* out4, float* normals3, int64_t capacity, int64_t* m);
 icpmi_status ops_voxel_keep_first(icpmi_ctx* c, const float* in4, int64_t n, float edge, uint8_t* keep);
 icpmi_status ops_point_distance_keep(icpmi_ctx* c, const float* map4, int64_t m, const float* in4, int64_t n,

@@ -371,16 +371,35 @@ static icpmi_status make_temp(icpmi_ctx* c, TempCtx& t)
     return ICPMI_OK;
 }
 
-icpmi_status ops_transform(icpmi_ctx* c, const float T[16], const float* in4, int64_t n, float* out4, const float* in_n3,
-                           float* out_n3)
+// Transformation::checkParameters: rotation part must be (close to) orthonormal with det +1
+static icpmi_status check_rigid(icpmi_ctx* c, const float T[16])
 {
-    // Transformation::checkParameters: rotation part must be (close to) orthonormal with det +1
     const double det = (double)T[0] * ((double)T[5] * T[10] - (double)T[9] * T[6]) - (double)T[4] * ((double)T[1] * T[10] - (double)T[9] * T[2]) +
                        (double)T[8] * ((double)T[1] * T[6] - (double)T[5] * T[2]);
     if (fabs(1.0 - det) > 1e-3) {
         c->last_error = "TransformationError: RigidTransformation: rotation part is not orthonormal (|1 - det| > 1e-3)";
         return ICPMI_ERR_INVALID_ARG;
     }
+    return ICPMI_OK;
+}
+
+// RigidTransformation::compute on device buffers, on the handle's stream (the 4x4 goes through a small resident buffer)
+icpmi_status ops_transform_dev(icpmi_ctx* c, const float T[16], const float4* d_in, int64_t n, float4* d_out)
+{
+    icpmi_status s = check_rigid(c, T);
+    if (s != ICPMI_OK || n == 0) return s;
+    if (!c->d_T16) HIP_TRY(c, hipMalloc((void**)&c->d_T16, 16 * sizeof(float)));
+    HIP_TRY(c, hipMemcpyAsync(c->d_T16, T, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(transform_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, d_in, n, c->d_T16, d_out);
+    HIP_TRY(c, hipGetLastError());
+    return ICPMI_OK;
+}
+
+icpmi_status ops_transform(icpmi_ctx* c, const float T[16], const float* in4, int64_t n, float* out4, const float* in_n3,
+                           float* out_n3)
+{
+    icpmi_status cs = check_rigid(c, T);
+    if (cs != ICPMI_OK) return cs;
     if (n == 0) return ICPMI_OK;
     DevBuf<float> d_T, d_n, d_no;
     DevBuf<float4> d_in, d_out;
@@ -626,7 +645,6 @@ icpmi_status ops_map_update_point_distance(icpmi_ctx* c, const float* scan4, int
     if (appended) *appended = 0;
     if (new_m) *new_m = c->m_raw;
     if (n == 0) return ICPMI_OK;
-    if (normals_knn < 0 || normals_knn > ICPMI_MAX_K) { c->last_error = "map_update: normals_knn must be in [0, 32]"; return ICPMI_ERR_INVALID_ARG; }
     // stage the scan (and its normals)
     if (ensure_cap(c, &c->d_stage_in, &c->cap_stage_in, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
     HIP_TRY(c, hipMemcpyAsync(c->d_stage_in, scan4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
@@ -634,6 +652,18 @@ icpmi_status ops_map_update_point_distance(icpmi_ctx* c, const float* scan4, int
         if (ensure_cap(c, &c->d_stage_n3, &c->cap_stage_n3, (size_t)n * 3) != ICPMI_OK) return ICPMI_ERR_HIP;
         HIP_TRY(c, hipMemcpyAsync(c->d_stage_n3, scan_normals3, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     }
+    return ops_map_update_dev(c, c->d_stage_in, n, scan_normals3 ? c->d_stage_n3 : nullptr, min_dist, normals_knn, keep_out, appended, new_m);
+}
+
+// the update proper, on a scan that is already in HBM (map frame)
+icpmi_status ops_map_update_dev(icpmi_ctx* c, const float4* d_scan, int64_t n, const float* d_scan_n3, float min_dist, int normals_knn,
+                                uint8_t* keep_out, int64_t* appended, int64_t* new_m)
+{
+    if (appended) *appended = 0;
+    if (new_m) *new_m = c->m_raw;
+    if (n == 0) return ICPMI_OK;
+    if (normals_knn < 0 || normals_knn > ICPMI_MAX_K) { c->last_error = "map_update: normals_knn must be in [0, 32]"; return ICPMI_ERR_INVALID_ARG; }
+    const bool scan_normals3 = d_scan_n3 != nullptr;
     const int64_t m0 = c->m > 0 ? c->m_raw : 0;
     const float lim = powf(min_dist, 2.f);
     const int blocks = (int)((n + 255) / 256);
@@ -645,7 +675,7 @@ icpmi_status ops_map_update_point_distance(icpmi_ctx* c, const float* scan4, int
     if (m0 > 0) {
         // PointDistanceMapperModule.cpp:33-42: exact NN of every input point in the map, self match excluded, keep
         // iff d2 >= minDist^2.  A radius search with maxDist = minDist decides the same predicate.
-        s = loop_prepare_reading(c, c->d_stage_in, n, nullptr);
+        s = loop_prepare_reading(c, d_scan, n, nullptr);
         LoopCfg lc = make_loop_cfg(c, 1);
         lc.k = 1; lc.n_out = 0; lc.max_dist = min_dist; lc.maxr2 = lim;
         const size_t cnt = (size_t)n + 1;
@@ -685,7 +715,7 @@ icpmi_status ops_map_update_point_distance(icpmi_ctx* c, const float* scan4, int
     } else if (m0 == 0) count = (unsigned)n;
     if (s == ICPMI_OK && e == hipSuccess && count > 0) {
         const int64_t m1 = m0 + count;
-        const bool want_n = normals_knn > 0 || c->raw_has_normals || scan_normals3 != nullptr;
+        const bool want_n = normals_knn > 0 || c->raw_has_normals || scan_normals3;
         if (m1 >= (1ll << 28)) { c->last_error = "map_update: the map would exceed 2^28-1 points"; s = ICPMI_ERR_UNSUPPORTED; }
         if (s == ICPMI_OK) s = ensure_cap_keep(c, &c->d_raw, &c->cap_raw, (size_t)m1, (size_t)m0);
         if (s == ICPMI_OK && want_n) {
@@ -695,13 +725,13 @@ icpmi_status ops_map_update_point_distance(icpmi_ctx* c, const float* scan4, int
         }
         if (s == ICPMI_OK && e == hipSuccess) {
             if (m0 > 0)
-                hipLaunchKernelGGL(append_kept_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_stage_in,
-                                   scan_normals3 ? c->d_stage_n3 : (const float*)nullptr, n, c->d_d2, lim, d_flag, m0, c->d_raw,
+                hipLaunchKernelGGL(append_kept_kernel, dim3(blocks), dim3(256), 0, c->stream, d_scan,
+                                   d_scan_n3, n, c->d_d2, lim, d_flag, m0, c->d_raw,
                                    want_n ? c->d_raw_n3 : (float*)nullptr);
             else {
-                e = hipMemcpyAsync(c->d_raw, c->d_stage_in, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream);
+                e = hipMemcpyAsync(c->d_raw, d_scan, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream);
                 if (e == hipSuccess && want_n) {
-                    if (scan_normals3) e = hipMemcpyAsync(c->d_raw_n3, c->d_stage_n3, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
+                    if (scan_normals3) e = hipMemcpyAsync(c->d_raw_n3, d_scan_n3, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
                     else e = hipMemsetAsync(c->d_raw_n3, 0, (size_t)n * 3 * sizeof(float), c->stream);
                 }
             }

@@ -181,6 +181,28 @@ void GpuICPSequence::mapUpdatePointDistance(const DataPoints& input, float minDi
                                              &appended, &mapSize));
 }
 
+Mat4 GpuICPSequence::registerWithPrior(const DataPoints& scan, const Mat4& prior)
+{
+    Mat4 T = Mat4::identity();
+    stagedPoints = scan.getNbPoints();
+    check(h, icpmi_register_prior(h, scan.features.data(), (int64_t)scan.getNbPoints(), prior.data(), T.data(), &lastStats));
+    return T;
+}
+
+void GpuICPSequence::mapUpdateStaged(const Mat4& correction, float minDist, int normalsKnn, std::vector<uint8_t>& keep, int64_t& appended,
+                                     int64_t& mapSize)
+{
+    keep.assign(stagedPoints, 0);
+    check(h, icpmi_map_update_staged(h, correction.data(), minDist, normalsKnn, keep.data(), &appended, &mapSize));
+}
+
+bool GpuICPSequence::chainNeedsReadingNormals() const
+{
+    for (int f = 0; f < cfg.n_outlier; ++f)
+        if (cfg.outlier[f].type == ICPMI_OUT_SURFACENORMAL) return true;
+    return false;
+}
+
 DataPoints GpuICPSequence::downloadMap() const
 {
     int64_t m = 0;

@@ -42,6 +42,10 @@ public:
     void mapUpdatePointDistance(const DataPoints& inputInMapFrame, float minDist, int normalsKnn, std::vector<uint8_t>& keep, int64_t& appended,
                                 int64_t& mapSize);
     DataPoints downloadMap() const;                    // the resident map (features + `normals` if it has them)
+    // Mapper::processInput with the scan staged once on the GPU (icpmi_register_prior / icpmi_map_update_staged)
+    Mat4 registerWithPrior(const DataPoints& scanInSensorFrame, const Mat4& prior);
+    void mapUpdateStaged(const Mat4& correction, float minDist, int normalsKnn, std::vector<uint8_t>& keep, int64_t& appended, int64_t& mapSize);
+    bool chainNeedsReadingNormals() const;             // SurfaceNormalOutlierFilter in the chain
     const icpmi_stats& stats() const { return lastStats; }
     const icpmi_config& config() const { return cfg; }
     static void check(icpmi_handle h, icpmi_status s); // status -> exception mapping
@@ -51,6 +55,7 @@ private:
     icpmi_handle h = nullptr;
     icpmi_config cfg;
     icpmi_stats lastStats{};
+    size_t stagedPoints = 0;                           // size of the scan kept on the GPU by registerWithPrior
     ErrorMinimizerView minimizerView{this};
 };
 

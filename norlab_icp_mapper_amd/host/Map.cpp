@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <stdexcept>
 #include <cstdio>
 
 namespace nim {
@@ -216,13 +217,14 @@ void Map::syncLocalFromDevice()
     deviceAhead = false;
 }
 
-bool Map::tryResidentUpdate(const DataPoints& input, const DataPointsFilters& postFilters)
+bool Map::residentPlan(const DataPoints& input, const DataPointsFilters& postFilters, int& knn, float& minDist) const
 {
     static const bool enabled = [] { const char* e = std::getenv("NIM_RESIDENT_MAP_UPDATE"); return !e || std::atoi(e) != 0; }();
     if (!enabled || !is3D || mapperModuleVec.size() != 1) return false;
     const auto* pd = dynamic_cast<const PointDistanceMapperModule*>(mapperModuleVec.front().get());
     if (!pd) return false;
-    int knn = 0;
+    minDist = pd->minDistNewPoint;
+    knn = 0;
     if (postFilters.size() == 1) knn = postFilters.filters.front()->surfaceNormalKnn();
     if (postFilters.size() > 1 || (postFilters.size() == 1 && knn <= 0)) return false;
     // a point-to-plane chain needs normals on every map point: only with the SurfaceNormal post filter
@@ -232,13 +234,11 @@ bool Map::tryResidentUpdate(const DataPoints& input, const DataPointsFilters& po
     // without the post filter the map's normals must come with the input (or not exist at all)
     const bool mapHasNormals = !first && (deviceAhead ? true : localPointCloud.descriptorExists("normals"));
     if (knn <= 0 && !first && mapHasNormals != input.descriptorExists("normals")) return false;
+    return true;
+}
 
-    std::vector<uint8_t> keep;
-    int64_t appended = 0, m = 0;
-    {
-        std::lock_guard<std::mutex> gi(icpMapLock);
-        icp.mapUpdatePointDistance(input, pd->minDistNewPoint, knn, keep, appended, m);
-    }
+void Map::adoptResidentResult(const DataPoints& input, const std::vector<uint8_t>& keep, int64_t mapSize, bool first)
+{
     // descriptors other than `normals` stay on the host, with DataPoints::concatenate's rule (only fields both
     // clouds have survive); the features / normals of localPointCloud are stale until syncLocalFromDevice()
     if (first) {
@@ -257,9 +257,47 @@ bool Map::tryResidentUpdate(const DataPoints& input, const DataPointsFilters& po
     }
     deviceAhead = true;
     ++residentUpdates;
-    localPointCloudEmpty.store(m == 0);
+    localPointCloudEmpty.store(mapSize == 0);
     newLocalPointCloudAvailable = true;
+}
+
+bool Map::tryResidentUpdate(const DataPoints& input, const DataPointsFilters& postFilters)
+{
+    int knn = 0; float minDist = 0.f;
+    if (!residentPlan(input, postFilters, knn, minDist)) return false;
+    const bool first = isLocalPointCloudEmpty();
+    std::vector<uint8_t> keep;
+    int64_t appended = 0, m = 0;
+    {
+        std::lock_guard<std::mutex> gi(icpMapLock);
+        icp.mapUpdatePointDistance(input, minDist, knn, keep, appended, m);
+    }
+    adoptResidentResult(input, keep, m, first);
     return true;
+}
+
+bool Map::canStageScan(const DataPoints& input, const DataPointsFilters& postFilters)
+{
+    // descriptors that rotate with the cloud would have to be transformed along: host path
+    if (input.descriptorExists("normals") || input.descriptorExists("observationDirections")) return false;
+    std::lock_guard<std::mutex> g(localPointCloudLock);
+    int knn = 0; float minDist = 0.f;
+    return residentPlan(input, postFilters, knn, minDist);
+}
+
+void Map::updateLocalPointCloudStaged(const DataPoints& inputDescriptors, const Mat4& correction, const DataPointsFilters& postFilters)
+{
+    std::lock_guard<std::mutex> g(localPointCloudLock);
+    int knn = 0; float minDist = 0.f;
+    if (!residentPlan(inputDescriptors, postFilters, knn, minDist)) throw std::logic_error("staged map update is not available for this configuration");
+    const bool first = isLocalPointCloudEmpty();
+    std::vector<uint8_t> keep;
+    int64_t appended = 0, m = 0;
+    {
+        std::lock_guard<std::mutex> gi(icpMapLock);
+        icp.mapUpdateStaged(correction, minDist, knn, keep, appended, m);
+    }
+    adoptResidentResult(inputDescriptors, keep, m, first);
 }
 
 void Map::updateLocalPointCloud(DataPoints input, Mat4 pose, DataPointsFilters postFilters)

@@ -61,6 +61,10 @@ public:
     DataPoints getLocalPointCloud();
     void updateLocalPointCloud(DataPoints input, Mat4 pose, DataPointsFilters postFilters); // Map.cpp:502-534
     bool getNewLocalPointCloud(DataPoints& out);
+    // processInput with the scan staged on the GPU: can this input / post-filter combination be updated on the resident map
+    // (see tryResidentUpdate), and the update itself for the scan kept by GpuICPSequence::registerWithPrior
+    bool canStageScan(const DataPoints& inputInSensorFrame, const DataPointsFilters& postFilters);
+    void updateLocalPointCloudStaged(const DataPoints& inputDescriptors, const Mat4& correction, const DataPointsFilters& postFilters);
     DataPoints getGlobalPointCloud();                                                     // Map.cpp:552-573
     void setGlobalPointCloud(const DataPoints& cloud);                                    // Map.cpp:575-588
     bool isLocalPointCloudEmpty() const { return localPointCloudEmpty.load(); }
@@ -88,6 +92,8 @@ private:
     // empty or [SurfaceNormalDataPointsFilter], clouds without other descriptors.  The device copy then runs
     // ahead of localPointCloud, which is refreshed on the next host-side access.
     bool tryResidentUpdate(const DataPoints& input, const DataPointsFilters& postFilters);
+    bool residentPlan(const DataPoints& input, const DataPointsFilters& postFilters, int& knn, float& minDist) const; // lock held
+    void adoptResidentResult(const DataPoints& input, const std::vector<uint8_t>& keep, int64_t mapSize, bool first); // lock held
     void syncLocalFromDevice(); // localPointCloudLock held
     bool deviceAhead = false;
     std::atomic<long> residentUpdates{0};

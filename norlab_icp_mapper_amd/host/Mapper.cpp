@@ -175,6 +175,34 @@ void Mapper::applyInputFilters(DataPoints& inputInSensorFrame)
 
 void Mapper::processInput(const DataPoints& filteredInputInSensorFrame, const Mat4& estimatedPose, const TimePoint& timeStamp)
 {
+    // One upload per scan when the map update can run on the resident map: the scan is moved by the prior, registered and --
+    // if the policy asks for it -- moved by the correction and merged, all on the GPU (icpmi_register_prior /
+    // icpmi_map_update_staged).  Offline only: an asynchronous update would race the next scan for the staged buffer.
+    if (!isOnline && !icp.chainNeedsReadingNormals() && map.canStageScan(filteredInputInSensorFrame, mapPostFilters)) {
+        const bool bootstrap = map.isLocalPointCloudEmpty();
+        Mat4 correction;
+        {
+            std::lock_guard<std::mutex> g(icpMapLock);
+            correction = icp.registerWithPrior(filteredInputInSensorFrame, estimatedPose); // identity while there is no map
+        }
+        const Mat4 correctedPose = bootstrap ? estimatedPose : correction * estimatedPose;
+        map.updatePose(correctedPose);
+        if (bootstrap || mapUpdateIsDue(timeStamp, correctedPose, icp.errorMinimizer->getOverlap())) {
+            lastTimeMapWasUpdated = timeStamp;
+            lastPoseWhereMapWasUpdated = correctedPose;
+            if (map.canStageScan(filteredInputInSensorFrame, mapPostFilters))
+                map.updateLocalPointCloudStaged(filteredInputInSensorFrame, bootstrap ? Mat4::identity() : correction, mapPostFilters);
+            else { // paging in updatePose changed the picture (e.g. the local cloud was emptied): the host path
+                DataPoints inMap = transformation.compute(filteredInputInSensorFrame, estimatedPose);
+                if (!bootstrap) inMap = transformation.compute(inMap, correction);
+                map.updateLocalPointCloud(inMap, correctedPose, mapPostFilters);
+            }
+        }
+        { std::lock_guard<std::mutex> g(poseLock); pose = correctedPose; }
+        { std::lock_guard<std::mutex> g(trajectoryLock); trajectory.addPose(correctedPose, timeStamp); }
+        return;
+    }
+
     // scan into the map frame by the prior; ICP then returns a correction expressed in the map frame
     DataPoints scanInMap = transformation.compute(filteredInputInSensorFrame, estimatedPose);
     const bool bootstrap = map.isLocalPointCloudEmpty(); // nothing to register against: the prior is the pose

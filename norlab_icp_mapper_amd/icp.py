@@ -370,6 +370,30 @@ class ICPSequence:
                                                               C.byref(app), C.byref(m)))
         return (int(app.value), int(m.value), keep.astype(bool)) if return_keep else (int(app.value), int(m.value))
 
+    def registerWithPrior(self, scan_sensor_frame, prior):
+        """Mapper::processInput's first half with the scan staged once (Mapper.cpp:197,213): the scan goes into the map
+        frame by `prior` on the device, is registered, and stays in HBM for mapUpdateStaged.  Returns the correction."""
+        sc = _f32c(scan_sensor_frame, 4)
+        P = _T_to_c(prior)
+        T = (C.c_float * 16)()
+        self._check(self._lib.icpmi_register_prior(self._h, sc.ctypes.data, sc.shape[0], P.ctypes.data, T, C.byref(self.stats)))
+        self._staged_n = sc.shape[0]
+        return _T_from_c(T[:])
+
+    def mapUpdateStaged(self, correction, min_dist, normals_knn=0, return_keep=False):
+        """Second half (Mapper.cpp:221 + Map::updateLocalPointCloud): the staged cloud moved by `correction`, then the
+        PointDistance update on the resident map."""
+        Tc = _T_to_c(correction)
+        app = C.c_int64(0); m = C.c_int64(0)
+        n = C.c_int64(0)
+        keep = None
+        if return_keep:
+            # the staged scan's size is the size of the last registerWithPrior reading
+            keep = np.zeros(self._staged_n, dtype=np.uint8)
+        self._check(self._lib.icpmi_map_update_staged(self._h, Tc.ctypes.data, min_dist, normals_knn, None if keep is None else keep.ctypes.data,
+                                                      C.byref(app), C.byref(m)))
+        return (int(app.value), int(m.value), keep.astype(bool)) if return_keep else (int(app.value), int(m.value))
+
     def getMap(self, with_normals=False):
         """The resident map in the caller's order (Map::getLocalPointCloud, Map.cpp:536-540)."""
         m = C.c_int64(0)

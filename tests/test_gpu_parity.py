@@ -480,6 +480,36 @@ def test_resident_map_update_equals_composed_path(amd, mid_scene, normals_knn):
     assert app3 == m3 == scan_map.shape[0] and np.array_equal(c.getMap(), scan_map)
 
 
+def test_staged_scan_process_input_equals_composed_path(amd, mid_scene):
+    """icpmi_register_prior + icpmi_map_update_staged (one upload per processInput) against transform / register /
+    transform / map update composed from the host-pointer entry points: same correction, same grown map."""
+    sc = mid_scene
+    rng = np.random.default_rng(2)
+    base = sc["map"][::2]
+    prior = amd.synth.make_T((0.004, -0.003, 0.006), (0.05, -0.04, 0.02)).astype(np.float32)
+    # the scan as the sensor sees it: undo the prior on the (already displaced) synthetic scan
+    scan_sensor = sc["scan"].copy()
+    inv = np.linalg.inv(prior.astype(np.float64))
+    scan_sensor[:, :3] = (sc["scan"][:, :3].astype(np.float64) @ inv[:3, :3].T + inv[:3, 3]).astype(np.float32)
+    kw = dict(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=15, use_differential=1)
+
+    a = amd.ICPSequence(**kw); a.setMap(base, a.surfaceNormals(base, knn=10))
+    in_map = a.transform(prior, scan_sensor)
+    corr_a = a(in_map)
+    moved = a.transform(corr_a, in_map)
+    app_a, m_a, keep_a = a.mapUpdatePointDistance(moved, 0.2, normals_knn=10, return_keep=True)
+
+    b = amd.ICPSequence(**kw); b.setMap(base, b.surfaceNormals(base, knn=10))
+    corr_b = b.registerWithPrior(scan_sensor, prior)
+    assert np.array_equal(corr_a, corr_b) and a.stats.iterations == b.stats.iterations
+    app_b, m_b, keep_b = b.mapUpdateStaged(corr_b, 0.2, normals_knn=10, return_keep=True)
+    assert (app_a, m_a) == (app_b, m_b) and np.array_equal(keep_a, keep_b)
+    ma, na = a.getMap(with_normals=True); mb, nb = b.getMap(with_normals=True)
+    assert np.array_equal(ma, mb) and np.array_equal(na, nb)
+    with pytest.raises(amd.InvalidParameter):
+        amd.ICPSequence(**kw).mapUpdateStaged(np.eye(4), 0.2)      # nothing staged
+
+
 def test_sharded_mapper_single_rank(amd, mid_scene):
     """The map-growth epoch of SURVEY 8(e) with the GPU operators (world size 1: no process group)."""
     sc = mid_scene
