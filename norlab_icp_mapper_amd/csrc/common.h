@@ -103,7 +103,7 @@ struct IcpState {
     unsigned hard_count;
     unsigned ticket;             // workgroups of the pair-sum kernel that have published their partials (last one solves)
     unsigned long long hard_total;
-    unsigned long long dbg[24];  // NN diagnostics: [0] ring passes, [1] staged points, [2] work items to global, [3] queries to global, [4] scanned candidates
+    unsigned long long dbg[24];  // diagnostics: NN phase cycles with -DICPMI_NN_TIMING (scripts/nn_phase.py), [20]/[21] serial solve cycles / calls
     // result
     float T_out[16];
 };

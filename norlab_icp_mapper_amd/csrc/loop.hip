@@ -938,7 +938,7 @@ icpmi_status loop_prepare_reading(icpmi_ctx* c, const float4* d_scan, int64_t n,
         if (blocks) hipLaunchKernelGGL(pad_normals_kernel, dim3(blocks), dim3(256), 0, c->stream, d_normals3, n, c->d_read_normals);
     }
     HIP_TRY(c, hipGetLastError());
-    // tile order of the (centred) reading for the LDS-staged NN kernel
+    // tile order of the (centred) reading: wave-local cell coherence for the pyramid NN kernels
     if (c->cfg.knn <= 8 && n > 0) return sort_queries(c, c->d_reading, n);
     return ICPMI_OK;
 }
