@@ -138,8 +138,11 @@ class ShardedMapper:
         mask = self.backend.keep(self.map, placed, self.min_dist) if self.map.shape[0] else np.ones(placed.shape[0], bool)
         mine = placed[mask]
         if dist.is_available() and dist.is_initialized():
-            merged, counts = allgather_points(torch.from_numpy(np.ascontiguousarray(mine)), group=self.group)
-            merged = merged.numpy()
+            t = torch.from_numpy(np.ascontiguousarray(mine))
+            if dist.get_backend(self.group) == "nccl":            # RCCL moves device tensors
+                t = t.cuda()
+            merged, counts = allgather_points(t, group=self.group)
+            merged = merged.cpu().numpy()
         else:
             merged = mine
         if merged.shape[0]:

@@ -613,3 +613,17 @@ def test_full_size_properties(amd):
     # and the registration recovers the ground truth of the scene
     dt, dr = amd.synth.pose_error(T, sc["T_gt"])
     assert dt < 5e-3 and dr < 5e-4
+
+
+def test_sharded_mapping_example_over_rccl(tmp_path):
+    """examples/sharded_mapping.py under torch.distributed.run with one rank: process group over RCCL (backend nccl),
+    device-tensor all-gather of the accepted points, identical rebuild -- the N > 1 code path on the GPU that is here."""
+    import os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "examples", "sharded_mapping.py"), "--map-points", "100000",
+                          "--scan-points", "8000", "--epochs", "2"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "epoch 1:" in out.stdout and "scans/s" in out.stdout
