@@ -19,10 +19,14 @@ for case in range(cases):
     n = int(rng.choice([1, 5, 257, 4_000, 60_000]))
     k = int(rng.choice([1, 1, 1, 3, 6, 10]))
     minimizer = int(rng.choice([1, 2, 2]))
-    outl = [[], [(4, 0.85)], [(3, 3.0)], [(1, 1.0), (4, 0.7)]][int(rng.integers(0, 4))]
+    outl = [[], [(4, 0.85)], [(3, 3.0)], [(1, 1.0), (4, 0.7)], [(2, 0.005), (4, 0.95)], [(5, 0.8), (4, 0.9)], [(4, 1.0)], [(3, 1.0), (1, 0.7)],
+            [(5, 1.2)]][int(rng.integers(0, 9))]
     md = float(rng.choice([0.5, 2.0, math.inf]))
     kw = dict(minimizer=minimizer, knn=k, max_dist=md if math.isfinite(md) else 1e30, outliers=outl, max_iterations=int(rng.integers(1, 25)),
-              use_differential=int(rng.integers(0, 2)))
+              use_differential=int(rng.integers(0, 2)), smooth_length=int(rng.integers(1, 9)), min_diff_rot=float(rng.choice([1e-3, 1e-5, 1e-2])),
+              min_diff_trans=float(rng.choice([1e-3, 1e-5, 1e-2])), use_bound=int(rng.integers(0, 2)), max_rot_norm=float(rng.choice([0.02, 0.8])),
+              max_trans_norm=float(rng.choice([0.05, 5.0])))
+    needs_rn = any(t == 5 for t, _ in outl)
     if not math.isfinite(md): kw["max_dist"] = math.inf
     sel = rng.permutation(base["map"].shape[0])[:m]
     mp, nrm = base["map"][sel], base["normals"][sel]
@@ -32,8 +36,12 @@ for case in range(cases):
     try:
         icp = pkg.ICPSequence(**kw)
         icp.setMap(mp, nrm)
+        rn = None
+        if needs_rn:
+            rn = rng.normal(0, 1, (n, 3)).astype(np.float32); rn /= np.maximum(np.linalg.norm(rn, axis=1, keepdims=True), 1e-6)
+            rn[: n // 2] = nrm[rng.integers(0, m, n // 2)]
         try:
-            T = icp(rd)
+            T = icp(rd, rn)
             assert np.isfinite(T).all(), "non-finite pose"
             err_gpu = 0
         except pkg.ConvergenceError:
@@ -52,7 +60,7 @@ for case in range(cases):
         # both sides (ill-posed, not comparable)
         if case % 5 == 0 and m * n <= 400_000 * 4_000 and k < m:
             o = ob.OracleICP(ob.make_config(nthreads=16, **kw)); o.setMap(mp, nrm)
-            err, T_ref = o(rd)
+            err, T_ref = o(rd, rn)
             assert (err != 0) == (err_gpu != 0), ("error mismatch", err, err_gpu, kw, m, n)
             if err == 0:
                 dt, dr = pkg.synth.pose_error(T, T_ref)
