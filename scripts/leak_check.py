@@ -1,0 +1,23 @@
+#!/usr/bin/env python
+"""Device-memory leak check: handles created, used (map, registration, map-side operators, resident update) and destroyed."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import norlab_icp_mapper_amd as pkg
+sc = pkg.synth.make_scene(m=200_000, n=20_000)
+def free_mb():
+    torch.cuda.synchronize(); f, t = torch.cuda.mem_get_info(); return f / 2**20
+base = None
+for rep in range(6):
+    for i in range(40):
+        icp = pkg.ICPSequence(minimizer=2, knn=1 if i % 2 else 6, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=5)
+        icp.setMap(sc["map"], sc["normals"]); icp(sc["scan"])
+        if i % 4 == 0:
+            icp.surfaceNormals(sc["map"][:50_000], knn=10); icp.pointDistanceKeep(sc["map"], sc["scan"], 0.1); icp.voxelKeepFirst(sc["map"], 0.2)
+            icp.mapUpdatePointDistance(sc["scan"], 0.1, normals_knn=5); icp.registerWithPrior(sc["scan"], np.eye(4)); icp.mapUpdateStaged(np.eye(4), 0.1)
+        icp.close()
+    f = free_mb()
+    if base is None: base = f
+    print(f"round {rep}: free {f:.0f} MiB (delta vs first round {f - base:+.1f})")
+assert abs(free_mb() - base) < 64, "device memory drifts"
+print("leak check ok")
