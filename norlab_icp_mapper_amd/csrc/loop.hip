@@ -727,14 +727,32 @@ __device__ void solve_body(IcpState* __restrict__ st, const double* __restrict__
     {
         const int v = t & (ICPMI_NV - 1), pr = t >> 5;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        int b = pr;
-        for (; b + 24 < nblocks; b += 32) {
-            s0 += partials[(size_t)b * ICPMI_NV + v];
-            s1 += partials[(size_t)(b + 8) * ICPMI_NV + v];
-            s2 += partials[(size_t)(b + 16) * ICPMI_NV + v];
-            s3 += partials[(size_t)(b + 24) * ICPMI_NV + v];
+        if (nblocks <= 256) {
+            // all of this lane's (up to 32) partials are requested at once -- one round trip instead of eight -- and
+            // then added in exactly the order of the streaming loop below
+            double val[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const int bj = pr + 8 * j;
+                val[j] = bj < nblocks ? partials[(size_t)bj * ICPMI_NV + v] : 0.0;
+            }
+            int done = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (pr + 32 * i + 24 < nblocks) { s0 += val[4 * i]; s1 += val[4 * i + 1]; s2 += val[4 * i + 2]; s3 += val[4 * i + 3]; done = 4 * (i + 1); }
+#pragma unroll
+            for (int j = 0; j < 32; ++j)
+                if (j >= done && pr + 8 * j < nblocks) s0 += val[j];
+        } else {
+            int b = pr;
+            for (; b + 24 < nblocks; b += 32) {
+                s0 += partials[(size_t)b * ICPMI_NV + v];
+                s1 += partials[(size_t)(b + 8) * ICPMI_NV + v];
+                s2 += partials[(size_t)(b + 16) * ICPMI_NV + v];
+                s3 += partials[(size_t)(b + 24) * ICPMI_NV + v];
+            }
+            for (; b < nblocks; b += 8) s0 += partials[(size_t)b * ICPMI_NV + v];
         }
-        for (; b < nblocks; b += 8) s0 += partials[(size_t)b * ICPMI_NV + v];
         part[pr][v] = (s0 + s1) + (s2 + s3);
     }
     __syncthreads();
