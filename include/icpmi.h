@@ -235,6 +235,45 @@ icpmi_status icpmi_dynamic_points_update(icpmi_handle h, const icpmi_dynpts_para
                                          const float* input4, int64_t n, const float* map4, const float* map_normals3,
                                          int64_t m, float* prob_dynamic);
 
+/* Same decimation with a choice of representative: method 0 = smallest index of the voxel (icpmi_voxel_keep_first),
+ * method 1 = `samplingMethod: 1` (a random point of the voxel, examples/config.yaml:49) made reproducible: the point
+ * whose index has the smallest 32-bit finaliser hash (fmix32 of MurmurHash3, a bijection) represents its voxel. */
+icpmi_status icpmi_voxel_keep(icpmi_handle h, const float* in4, int64_t n, float edge, int32_t method, uint8_t* keep);
+
+/* `Map::updateLocalPointCloud` (Map.cpp:502-534) for a whole module chain on the RESIDENT map: the mapper modules
+ * (`mapperModuleVec`, Map.cpp:506-521) and then the post filters (Map.cpp:523-525) run as one program on the device copy
+ * of the map; only the scan crosses PCIe.  The device tracks the features, the `normals` and ONE scalar descriptor of
+ * the map (the shipped chain's `probabilityDynamic`); for every other descriptor the host applies `src_out`:
+ * new map point j was point src_out[j] of [old map (m_old points) ; scan (n points)] -- src_out[j] < m_old: an old map
+ * point, else scan point src_out[j] - m_old.
+ *   ICPMI_MOP_POINT_DISTANCE   f[0] = minDistNewPoint                   (PointDistanceMapperModule.cpp:28-50)
+ *   ICPMI_MOP_DYNAMIC_POINTS   f[0..6] = icpmi_dynpts_params in order   (DynamicPointsMapperModule.cpp:34-172; updates the scalar)
+ *   ICPMI_MOP_VOXEL            f[0] = maxSizeByNode, i = samplingMethod 0 | 1 (OctreeMapperModule.cpp:35-39: concatenate, then decimate)
+ *   ICPMI_MOP_SURFACE_NORMALS  i = knn                                  (post filter, examples/config.yaml:26-27)
+ *   ICPMI_MOP_CUT_SCALAR       f[0] = threshold, i = useLargerThan      (CutAtDescriptorThresholdDataPointsFilter, config.yaml:29-32)
+ * The first n_modules entries are mapper modules: on a handle without a map the first one creates the map from the scan
+ * (`createMap`: PointDistance / DynamicPoints take the scan as it is, Voxel decimates it) and the others update it with
+ * the same scan (Map.cpp:508-516).  scan_scalar (n floats) is the scan's value of the tracked scalar, NULL if the chain
+ * has none; scan_normals3 may be NULL (appended points then carry zero normals until a SURFACE_NORMALS step).
+ * to_sensor = pose^-1 (sensor <- map; `pose` is the modules' argument, DynamicPointsMapperModule.cpp:51,57; only
+ * DYNAMIC_POINTS reads it, may be NULL otherwise); post filters run in the map frame.
+ * src_capacity must be >= m_old + 2 n. */
+typedef enum {
+    ICPMI_MOP_POINT_DISTANCE = 0, ICPMI_MOP_DYNAMIC_POINTS = 1, ICPMI_MOP_VOXEL = 2, ICPMI_MOP_SURFACE_NORMALS = 3, ICPMI_MOP_CUT_SCALAR = 4
+} icpmi_map_op_type;
+typedef struct icpmi_map_op { int32_t type; int32_t i; float f[7]; } icpmi_map_op;
+icpmi_status icpmi_map_update_chain(icpmi_handle h, const float* scan4, int64_t n, const float* scan_normals3, const float* scan_scalar,
+                                    const float to_sensor[16], const icpmi_map_op* ops, int32_t n_ops, int32_t n_modules,
+                                    int32_t* src_out, int64_t src_capacity, int64_t* new_m);
+/* The same on the scan staged by icpmi_register_prior, moved by `correction` first (Mapper.cpp:221). */
+icpmi_status icpmi_map_update_chain_staged(icpmi_handle h, const float correction[16], const float* scan_scalar, const float to_sensor[16],
+                                           const icpmi_map_op* ops, int32_t n_ops, int32_t n_modules, int32_t* src_out,
+                                           int64_t src_capacity, int64_t* new_m);
+/* The tracked scalar descriptor of the resident map: upload after a icpmi_set_map (m must equal the map size),
+ * download next to icpmi_get_map. */
+icpmi_status icpmi_set_map_scalar(icpmi_handle h, const float* scalar, int64_t m);
+icpmi_status icpmi_get_map_scalar(icpmi_handle h, float* scalar_out, int64_t capacity);
+
 /* `Map::unloadCells` binning (Map.cpp:206-209,232-235): ijk3[3 i + r] = floor(p_r / cell_size). */
 icpmi_status icpmi_bin_cells(icpmi_handle h, const float* pts4, int64_t n, float cell_size, int32_t* ijk3);
 

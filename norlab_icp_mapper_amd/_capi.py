@@ -63,6 +63,14 @@ class Stats(C.Structure):
     ]
 
 
+class MapOp(C.Structure):
+    """icpmi_map_op: one step of the resident map-update chain."""
+    _fields_ = [("type", C.c_int32), ("i", C.c_int32), ("f", C.c_float * 7)]
+
+
+MOP_POINT_DISTANCE, MOP_DYNAMIC_POINTS, MOP_VOXEL, MOP_SURFACE_NORMALS, MOP_CUT_SCALAR = range(5)
+
+
 # every symbol include/icpmi.h declares: (name, restype, argtypes)
 _P = C.c_void_p
 _F = C.POINTER(C.c_float)
@@ -87,6 +95,11 @@ SYMBOLS = [
     ("icpmi_surface_normals", C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
     ("icpmi_point_distance_keep", C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_float, _P]),
     ("icpmi_voxel_keep_first", C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),
+    ("icpmi_voxel_keep", C.c_int, [_P, _P, C.c_int64, C.c_float, C.c_int32, _P]),
+    ("icpmi_map_update_chain", C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, C.c_int64, _P]),
+    ("icpmi_map_update_chain_staged", C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, C.c_int64, _P]),
+    ("icpmi_set_map_scalar", C.c_int, [_P, _P, C.c_int64]),
+    ("icpmi_get_map_scalar", C.c_int, [_P, _P, C.c_int64]),
     ("icpmi_map_update_point_distance", C.c_int, [_P, _P, C.c_int64, _P, C.c_float, C.c_int32, _P, _P, _P]),
     ("icpmi_get_map", C.c_int, [_P, _P, _P, C.c_int64, _P]),
     ("icpmi_register_prior", C.c_int, [_P, _P, C.c_int64, _P, _F, C.POINTER(Stats)]),

@@ -130,7 +130,8 @@ void icpmi_destroy(icpmi_handle c)
     hipFree(c->d_keys); hipFree(c->d_fill); hipFree(c->d_blocksums); hipFree(c->d_red);
     hipFree(c->d_qsorted); hipFree(c->d_qindex); hipFree(c->d_qkeys); hipFree(c->d_qtile);
     hipFree(c->d_reading); hipFree(c->d_read_normals); hipFree(c->d_stage_in); hipFree(c->d_stage_n3);
-    hipFree(c->d_match_pt); hipFree(c->d_lvl_tab); hipFree(c->d_raw); hipFree(c->d_raw_n3); hipFree(c->d_scan_map); hipFree(c->d_T16);
+    hipFree(c->d_match_pt); hipFree(c->d_lvl_tab); hipFree(c->d_raw); hipFree(c->d_raw_n3); hipFree(c->d_raw_s); hipFree(c->d_src); hipFree(c->d_alt_raw); hipFree(c->d_alt_n3);
+    hipFree(c->d_alt_s); hipFree(c->d_alt_src); hipFree(c->d_stage_s); hipFree(c->d_scan_map); hipFree(c->d_T16);
     hipFree(c->d_sidx); hipFree(c->d_d2); hipFree(c->d_hard); hipFree(c->d_partials); hipFree(c->d_selhist);
     hipFree(c->d_state);
     if (c->h_state) hipHostFree(c->h_state);
@@ -427,11 +428,80 @@ icpmi_status icpmi_get_map(icpmi_handle h, float* out4, float* normals3, int64_t
     return ops_get_map(h, out4, normals3, capacity, m);
 }
 
-icpmi_status icpmi_voxel_keep_first(icpmi_handle h, const float* in4, int64_t n, float edge, uint8_t* keep)
+icpmi_status icpmi_voxel_keep(icpmi_handle h, const float* in4, int64_t n, float edge, int32_t method, uint8_t* keep)
 {
     CHECK_H(h);
-    if (n < 0 || (n > 0 && (!in4 || !keep)) || !(edge > 0.f)) { h->last_error = "voxel_keep_first: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
-    return ops_voxel_keep_first(h, in4, n, edge, keep);
+    if (n < 0 || (n > 0 && (!in4 || !keep)) || !(edge > 0.f) || (method != 0 && method != 1)) { h->last_error = "voxel_keep: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
+    return ops_voxel_keep_first(h, in4, n, edge, method, keep);
+}
+
+icpmi_status icpmi_voxel_keep_first(icpmi_handle h, const float* in4, int64_t n, float edge, uint8_t* keep)
+{
+    return icpmi_voxel_keep(h, in4, n, edge, 0, keep);
+}
+
+static icpmi_status stage_chain_scalar(icpmi_handle h, const float* scan_scalar, int64_t n)
+{
+    if (!scan_scalar || n == 0) return ICPMI_OK;
+    if (ensure_cap(h, &h->d_stage_s, &h->cap_stage_s, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    HIP_TRY(h, hipMemcpyAsync(h->d_stage_s, scan_scalar, (size_t)n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    return ICPMI_OK;
+}
+
+static bool chain_needs_pose(const icpmi_map_op* ops, int32_t n_ops)
+{
+    for (int32_t i = 0; ops && i < n_ops; ++i) if (ops[i].type == ICPMI_MOP_DYNAMIC_POINTS) return true;
+    return false;
+}
+
+icpmi_status icpmi_map_update_chain(icpmi_handle h, const float* scan4, int64_t n, const float* scan_normals3, const float* scan_scalar,
+                                    const float to_sensor[16], const icpmi_map_op* ops, int32_t n_ops, int32_t n_modules,
+                                    int32_t* src_out, int64_t src_capacity, int64_t* new_m)
+{
+    CHECK_H(h);
+    if (n < 0 || (n > 0 && !scan4) || (chain_needs_pose(ops, n_ops) && !to_sensor)) { h->last_error = "map_update_chain: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
+    if (n > 0) {
+        if (ensure_cap(h, &h->d_stage_in, &h->cap_stage_in, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+        HIP_TRY(h, hipMemcpyAsync(h->d_stage_in, scan4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+        if (scan_normals3) {
+            if (ensure_cap(h, &h->d_stage_n3, &h->cap_stage_n3, (size_t)n * 3) != ICPMI_OK) return ICPMI_ERR_HIP;
+            HIP_TRY(h, hipMemcpyAsync(h->d_stage_n3, scan_normals3, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        }
+        icpmi_status s = stage_chain_scalar(h, scan_scalar, n);
+        if (s != ICPMI_OK) return s;
+    }
+    return ops_map_update_chain(h, h->d_stage_in, n, scan_normals3 ? h->d_stage_n3 : nullptr, scan_scalar ? h->d_stage_s : nullptr, to_sensor, ops,
+                                n_ops, n_modules, src_out, src_capacity, new_m);
+}
+
+icpmi_status icpmi_map_update_chain_staged(icpmi_handle h, const float correction[16], const float* scan_scalar, const float to_sensor[16],
+                                           const icpmi_map_op* ops, int32_t n_ops, int32_t n_modules, int32_t* src_out,
+                                           int64_t src_capacity, int64_t* new_m)
+{
+    CHECK_H(h);
+    if (!correction || (chain_needs_pose(ops, n_ops) && !to_sensor)) { h->last_error = "map_update_chain_staged: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
+    if (h->scan_map_n <= 0) { h->last_error = "map_update_chain_staged: no scan staged by icpmi_register_prior"; return ICPMI_ERR_INVALID_ARG; }
+    const int64_t n = h->scan_map_n;
+    if (ensure_cap(h, &h->d_stage_in, &h->cap_stage_in, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    icpmi_status s = ops_transform_dev(h, correction, h->d_scan_map, n, h->d_stage_in); // Mapper.cpp:221
+    if (s == ICPMI_OK) s = stage_chain_scalar(h, scan_scalar, n);
+    if (s != ICPMI_OK) return s;
+    return ops_map_update_chain(h, h->d_stage_in, n, nullptr, scan_scalar ? h->d_stage_s : nullptr, to_sensor, ops, n_ops, n_modules, src_out,
+                                src_capacity, new_m);
+}
+
+icpmi_status icpmi_set_map_scalar(icpmi_handle h, const float* scalar, int64_t m)
+{
+    CHECK_H(h);
+    if (!scalar) { h->last_error = "set_map_scalar: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
+    return ops_map_scalar(h, scalar, nullptr, m);
+}
+
+icpmi_status icpmi_get_map_scalar(icpmi_handle h, float* scalar_out, int64_t capacity)
+{
+    CHECK_H(h);
+    if (!scalar_out || h->m <= 0 || capacity < h->m_raw) { h->last_error = "get_map_scalar: no map, or capacity too small"; return ICPMI_ERR_INVALID_ARG; }
+    return ops_map_scalar(h, nullptr, scalar_out, h->m_raw);
 }
 
 icpmi_status icpmi_dynamic_points_update(icpmi_handle h, const icpmi_dynpts_params* prm, const float to_sensor[16], const float* in4,

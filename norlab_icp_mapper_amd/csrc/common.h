@@ -154,6 +154,15 @@ struct icpmi_ctx {
     float4* d_raw = nullptr; size_t cap_raw = 0;
     float*  d_raw_n3 = nullptr; size_t cap_raw_n3 = 0;
     int64_t m_raw = 0; bool raw_has_normals = false;
+    // one tracked scalar descriptor of the resident map (`probabilityDynamic` for the shipped chain) and the ping-pong
+    // set the map-update chain compacts into (ops.hip: ops_map_update_chain)
+    float*  d_raw_s = nullptr; size_t cap_raw_s = 0; bool raw_has_scalar = false;
+    int*    d_src = nullptr; size_t cap_src = 0;               // provenance of every point of the map being updated
+    float4* d_alt_raw = nullptr; size_t cap_alt_raw = 0;
+    float*  d_alt_n3 = nullptr; size_t cap_alt_n3 = 0;
+    float*  d_alt_s = nullptr; size_t cap_alt_s = 0;
+    int*    d_alt_src = nullptr; size_t cap_alt_src = 0;
+    float*  d_stage_s = nullptr; size_t cap_stage_s = 0;
     // the scan of the last icpmi_register_prior, in the map frame by its prior (what Mapper::processInput calls `input`)
     float4* d_scan_map = nullptr; size_t cap_scan_map = 0; int64_t scan_map_n = 0;
     float* d_T16 = nullptr;           // a 4x4 for device-side transforms
@@ -272,6 +281,10 @@ LoopCfg make_loop_cfg(const icpmi_ctx* c, int fixed_iterations);
 
 icpmi_status ops_transform(icpmi_ctx* c, const float T[16], const float* in4, int64_t n, float* out4,
                            const float* in_n3, float* out_n3);
+icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n, const float* d_scan_n3, const float* d_scan_s,
+                                  const float to_sensor[16], const icpmi_map_op* ops, int n_ops, int n_modules, int32_t* src_out,
+                                  int64_t src_capacity, int64_t* new_m);
+icpmi_status ops_map_scalar(icpmi_ctx* c, const float* set, float* get, int64_t m);
 icpmi_status ops_surface_normals(icpmi_ctx* c, const float* pts4, int64_t m, int knn, float* normals3);
 icpmi_status ops_dynamic_points_update(icpmi_ctx* c, const icpmi_dynpts_params* prm, const float to_sensor[16], const float* in4, int64_t n,
                                        const float* map4, const float* map_normals3, int64_t m, float* prob);
@@ -281,7 +294,7 @@ icpmi_status ops_map_update_dev(icpmi_ctx* c, const float4* d_scan, int64_t n, c
                                 uint8_t* keep_out, int64_t* appended, int64_t* new_m);
 icpmi_status ops_transform_dev(icpmi_ctx* c, const float T[16], const float4* d_in, int64_t n, float4* d_out);
 icpmi_status ops_get_map(icpmi_ctx* c, float* out4, float* normals3, int64_t capacity, int64_t* m);
-icpmi_status ops_voxel_keep_first(icpmi_ctx* c, const float* in4, int64_t n, float edge, uint8_t* keep);
+icpmi_status ops_voxel_keep_first(icpmi_ctx* c, const float* in4, int64_t n, float edge, int method, uint8_t* keep);
 icpmi_status ops_point_distance_keep(icpmi_ctx* c, const float* map4, int64_t m, const float* in4, int64_t n,
                                      float min_dist, uint8_t* keep);
 icpmi_status ops_bin_cells(icpmi_ctx* c, const float* pts4, int64_t n, float cell_size, int32_t* ijk3);

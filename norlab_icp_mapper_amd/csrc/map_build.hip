@@ -526,6 +526,7 @@ icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float
     c->has_normals = d_normals3 != nullptr;
     // resident raw copy (skipped when the caller IS the raw copy: the device-side map update)
     if (d_pts != c->d_raw) {
+        c->raw_has_scalar = false; // a map handed in from outside: its scalar channel comes through icpmi_set_map_scalar
         if (ensure_cap(c, &c->d_raw, &c->cap_raw, (size_t)m) != ICPMI_OK) return ICPMI_ERR_HIP;
         HIP_TRY(c, hipMemcpyAsync(c->d_raw, d_pts, (size_t)m * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
     }

@@ -4,6 +4,7 @@
 //   PointDistanceMapperModule keep mask     (MapperModules/PointDistanceMapperModule.cpp:28-50)
 //   Map::unloadCells cell binning           (Map.cpp:206-209,232-235)
 #include "common.h"
+#include <utility>
 #include <cstring>
 
 namespace {
@@ -170,8 +171,15 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long x)
     return x;
 }
 
+// MurmurHash3's 32-bit finaliser: a bijection of the 32-bit integers, so "smallest hash" names exactly one point
+__device__ __forceinline__ unsigned fmix32(unsigned h)
+{
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+
 __global__ __launch_bounds__(256) void voxel_insert_kernel(const float4* __restrict__ in, int64_t n, const unsigned* __restrict__ lo_keys,
-                                                           float edge, unsigned long long* __restrict__ tkeys,
+                                                           float edge, int method, unsigned long long* __restrict__ tkeys,
                                                            unsigned* __restrict__ tvals, unsigned long long mask,
                                                            unsigned* __restrict__ slot_of)
 {
@@ -184,16 +192,18 @@ __global__ __launch_bounds__(256) void voxel_insert_kernel(const float4* __restr
         if (prev == ~0ull || prev == key) break;
         slot = (slot + 1) & mask;
     }
-    atomicMin(&tvals[slot], (unsigned)i);
+    atomicMin(&tvals[slot], method ? fmix32((unsigned)i) : (unsigned)i);
     slot_of[i] = (unsigned)slot;
 }
 
+// flag[i] = 1 iff i represents its voxel (T = uint8_t for the host mask, unsigned for device compaction)
+template <typename T>
 __global__ __launch_bounds__(256) void voxel_keep_kernel(int64_t n, const unsigned* __restrict__ tvals, const unsigned* __restrict__ slot_of,
-                                                         uint8_t* __restrict__ keep)
+                                                         int method, T* __restrict__ keep)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    keep[i] = tvals[slot_of[i]] == (unsigned)i ? 1 : 0;
+    keep[i] = tvals[slot_of[i]] == (method ? fmix32((unsigned)i) : (unsigned)i) ? 1 : 0;
 }
 
 // ---- DynamicPointsMapperModule::inPlaceUpdateMap (DynamicPointsMapperModule.cpp:34-172) -------------------
@@ -523,41 +533,48 @@ icpmi_status ops_point_distance_keep(icpmi_ctx* c, const float* map4, int64_t m,
     return ICPMI_OK;
 }
 
-icpmi_status ops_voxel_keep_first(icpmi_ctx* c, const float* in4, int64_t n, float edge, uint8_t* keep)
+// decimation flags of a DEVICE cloud (T = uint8_t or unsigned), stream-ordered on c->stream
+template <typename T>
+static icpmi_status voxel_flags_dev(icpmi_ctx* c, const float4* d_in, int64_t n, float edge, int method, T* d_keep)
 {
-    if (n == 0) return ICPMI_OK;
-    if (n > 0xfffffff0ll) { c->last_error = "voxel_keep_first: too many points"; return ICPMI_ERR_UNSUPPORTED; }
+    if (n > 0xfffffff0ll) { c->last_error = "voxel_keep: too many points"; return ICPMI_ERR_UNSUPPORTED; }
     unsigned long long cap = 1024;
     while (cap < (unsigned long long)n * 2ull) cap <<= 1;
-    float4* d_in = nullptr; unsigned long long* d_keys = nullptr; unsigned* d_vals = nullptr; unsigned* d_slot = nullptr;
-    unsigned* d_lo = nullptr; uint8_t* d_keep = nullptr;
-    hipError_t e = hipMalloc((void**)&d_in, (size_t)n * sizeof(float4));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_keys, (size_t)cap * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_vals, (size_t)cap * sizeof(unsigned));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_slot, (size_t)n * sizeof(unsigned));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_lo, 4 * sizeof(unsigned));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_keep, (size_t)n);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_in, in4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_keys, 0xff, (size_t)cap * sizeof(unsigned long long), c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_vals, 0xff, (size_t)cap * sizeof(unsigned), c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_lo, 0xff, 4 * sizeof(unsigned), c->stream);
-    if (e == hipSuccess) {
-        const int blocks = (int)((n + 255) / 256);
-        const int rb = blocks < 1024 ? blocks : 1024;
-        hipLaunchKernelGGL(bbox_min_kernel, dim3(rb), dim3(256), 0, c->stream, d_in, n, d_lo);
-        hipLaunchKernelGGL(voxel_insert_kernel, dim3(blocks), dim3(256), 0, c->stream, d_in, n, d_lo, edge, d_keys, d_vals, cap - 1, d_slot);
-        hipLaunchKernelGGL(voxel_keep_kernel, dim3(blocks), dim3(256), 0, c->stream, n, d_vals, d_slot, d_keep);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(keep, d_keep, (size_t)n, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(d_in); hipFree(d_keys); hipFree(d_vals); hipFree(d_slot); hipFree(d_lo); hipFree(d_keep);
-    HIP_TRY(c, e);
+    DevBuf<unsigned long long> d_keys; DevBuf<unsigned> d_vals, d_slot, d_lo;
+    HIP_TRY(c, d_keys.alloc((size_t)cap));
+    HIP_TRY(c, d_vals.alloc((size_t)cap));
+    HIP_TRY(c, d_slot.alloc((size_t)n));
+    HIP_TRY(c, d_lo.alloc(4));
+    HIP_TRY(c, hipMemsetAsync(d_keys, 0xff, (size_t)cap * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(d_vals, 0xff, (size_t)cap * sizeof(unsigned), c->stream));
+    HIP_TRY(c, hipMemsetAsync(d_lo, 0xff, 4 * sizeof(unsigned), c->stream));
+    const int blocks = (int)((n + 255) / 256);
+    const int rb = blocks < 1024 ? blocks : 1024;
+    hipLaunchKernelGGL(bbox_min_kernel, dim3(rb), dim3(256), 0, c->stream, d_in, n, d_lo);
+    hipLaunchKernelGGL(voxel_insert_kernel, dim3(blocks), dim3(256), 0, c->stream, d_in, n, d_lo, edge, method, d_keys, d_vals, cap - 1, d_slot);
+    hipLaunchKernelGGL(voxel_keep_kernel<T>, dim3(blocks), dim3(256), 0, c->stream, n, d_vals, d_slot, method, d_keep);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); // the scratch tables die with this scope
     return ICPMI_OK;
 }
 
-icpmi_status ops_dynamic_points_update(icpmi_ctx* c, const icpmi_dynpts_params* prm, const float to_sensor[16], const float* in4, int64_t n,
-                                       const float* map4, const float* map_normals3, int64_t m, float* prob)
+icpmi_status ops_voxel_keep_first(icpmi_ctx* c, const float* in4, int64_t n, float edge, int method, uint8_t* keep)
+{
+    if (n == 0) return ICPMI_OK;
+    DevBuf<float4> d_in; DevBuf<uint8_t> d_keep;
+    HIP_TRY(c, d_in.alloc((size_t)n));
+    HIP_TRY(c, d_keep.alloc((size_t)n));
+    HIP_TRY(c, hipMemcpyAsync(d_in, in4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    icpmi_status s = voxel_flags_dev<uint8_t>(c, d_in, n, edge, method, d_keep);
+    if (s != ICPMI_OK) return s;
+    HIP_TRY(c, hipMemcpyAsync(keep, d_keep, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return ICPMI_OK;
+}
+
+// DynamicPointsMapperModule::inPlaceUpdateMap on DEVICE arrays (d_T = pose^-1, 16 floats in HBM); d_prob updated in place
+static icpmi_status dynpts_dev(icpmi_ctx* c, const icpmi_dynpts_params* prm, const float* d_T, const float4* d_in, int64_t n,
+                               const float4* d_map, const float* d_nrm, int64_t m, float* d_prob)
 {
     if (n == 0 || m == 0) return ICPMI_OK; // "if (beams.empty()) return"
     DynGrid g;
@@ -567,43 +584,48 @@ icpmi_status ops_dynamic_points_update(icpmi_ctx* c, const icpmi_dynpts_params* 
     const int64_t ncells = (int64_t)g.ne * g.na;
     if (ncells > (1ll << 28)) { c->last_error = "dynamic_points_update: beamHalfAngle too small for the angular grid"; return ICPMI_ERR_UNSUPPORTED; }
     DynPrm dp = {prm->threshold_dynamic, prm->alpha, prm->beta, prm->beam_half_angle, prm->epsilon_a, prm->epsilon_d, prm->sensor_max_range};
-    float* d_T = nullptr; float4 *d_in = nullptr, *d_map = nullptr, *d_bx = nullptr; float2* d_ba = nullptr; float *d_nrm = nullptr, *d_prob = nullptr;
-    unsigned *d_keys = nullptr, *d_start = nullptr, *d_fill = nullptr, *d_order = nullptr;
-    hipError_t e = hipMalloc((void**)&d_T, 16 * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_in, (size_t)n * sizeof(float4));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_bx, (size_t)n * sizeof(float4));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_ba, (size_t)n * sizeof(float2));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_keys, (size_t)n * sizeof(unsigned));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_order, (size_t)n * sizeof(unsigned));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_start, ((size_t)ncells + 2) * sizeof(unsigned));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_fill, (size_t)ncells * sizeof(unsigned));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_map, (size_t)m * sizeof(float4));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_nrm, (size_t)m * 3 * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_prob, (size_t)m * sizeof(float));
-    if (e == hipSuccess) e = hipMemcpyAsync(d_T, to_sensor, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_in, in4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_map, map4, (size_t)m * sizeof(float4), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_nrm, map_normals3, (size_t)m * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_prob, prob, (size_t)m * sizeof(float), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_start, 0, ((size_t)ncells + 2) * sizeof(unsigned), c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_fill, 0, (size_t)ncells * sizeof(unsigned), c->stream);
-    icpmi_status st = ICPMI_OK;
-    if (e == hipSuccess) {
-        const int nb = (int)((n + 255) / 256), mb = (int)((m + 255) / 256);
-        hipLaunchKernelGGL(dyn_beams_kernel, dim3(nb), dim3(256), 0, c->stream, d_in, n, d_T, g, d_bx, d_ba, d_keys, d_start);
-        st = device_exclusive_scan(c, d_start, (int)ncells, (unsigned)n);
-        if (st == ICPMI_OK) {
-            hipLaunchKernelGGL(dyn_scatter_kernel, dim3(nb), dim3(256), 0, c->stream, n, d_keys, d_start, d_fill, d_order);
-            hipLaunchKernelGGL(dyn_update_kernel, dim3(mb), dim3(256), 0, c->stream, d_map, d_nrm, m, d_T, g, dp, d_bx, d_ba, d_start, d_order, d_prob);
-            e = hipGetLastError();
-            if (e == hipSuccess) e = hipMemcpyAsync(prob, d_prob, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, c->stream);
-        }
+    DevBuf<float4> d_bx; DevBuf<float2> d_ba; DevBuf<unsigned> d_keys, d_start, d_fill, d_order;
+    HIP_TRY(c, d_bx.alloc((size_t)n));
+    HIP_TRY(c, d_ba.alloc((size_t)n));
+    HIP_TRY(c, d_keys.alloc((size_t)n));
+    HIP_TRY(c, d_order.alloc((size_t)n));
+    HIP_TRY(c, d_start.alloc((size_t)ncells + 2));
+    HIP_TRY(c, d_fill.alloc((size_t)ncells));
+    HIP_TRY(c, hipMemsetAsync(d_start, 0, ((size_t)ncells + 2) * sizeof(unsigned), c->stream));
+    HIP_TRY(c, hipMemsetAsync(d_fill, 0, (size_t)ncells * sizeof(unsigned), c->stream));
+    const int nb = (int)((n + 255) / 256), mb = (int)((m + 255) / 256);
+    hipLaunchKernelGGL(dyn_beams_kernel, dim3(nb), dim3(256), 0, c->stream, d_in, n, d_T, g, d_bx, d_ba, d_keys, d_start);
+    icpmi_status st = device_exclusive_scan(c, d_start, (int)ncells, (unsigned)n);
+    if (st == ICPMI_OK) {
+        hipLaunchKernelGGL(dyn_scatter_kernel, dim3(nb), dim3(256), 0, c->stream, n, d_keys, d_start, d_fill, d_order);
+        hipLaunchKernelGGL(dyn_update_kernel, dim3(mb), dim3(256), 0, c->stream, d_map, d_nrm, m, d_T, g, dp, d_bx, d_ba, d_start, d_order, d_prob);
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(d_T); hipFree(d_in); hipFree(d_bx); hipFree(d_ba); hipFree(d_keys); hipFree(d_order); hipFree(d_start); hipFree(d_fill);
-    hipFree(d_map); hipFree(d_nrm); hipFree(d_prob);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream); // the beam tables die with this scope
     if (st != ICPMI_OK) return st;
     HIP_TRY(c, e);
+    return ICPMI_OK;
+}
+
+icpmi_status ops_dynamic_points_update(icpmi_ctx* c, const icpmi_dynpts_params* prm, const float to_sensor[16], const float* in4, int64_t n,
+                                       const float* map4, const float* map_normals3, int64_t m, float* prob)
+{
+    if (n == 0 || m == 0) return ICPMI_OK;
+    DevBuf<float> d_T, d_nrm, d_prob; DevBuf<float4> d_in, d_map;
+    HIP_TRY(c, d_T.alloc(16));
+    HIP_TRY(c, d_in.alloc((size_t)n));
+    HIP_TRY(c, d_map.alloc((size_t)m));
+    HIP_TRY(c, d_nrm.alloc((size_t)m * 3));
+    HIP_TRY(c, d_prob.alloc((size_t)m));
+    HIP_TRY(c, hipMemcpyAsync(d_T, to_sensor, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d_in, in4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d_map, map4, (size_t)m * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d_nrm, map_normals3, (size_t)m * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d_prob, prob, (size_t)m * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    icpmi_status st = dynpts_dev(c, prm, d_T, d_in, n, d_map, d_nrm, m, d_prob);
+    if (st != ICPMI_OK) return st;
+    HIP_TRY(c, hipMemcpyAsync(prob, d_prob, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return ICPMI_OK;
 }
 
@@ -758,6 +780,308 @@ icpmi_status ops_get_map(icpmi_ctx* c, float* out4, float* normals3, int64_t cap
     if (normals3) {
         if (!c->raw_has_normals) { c->last_error = "InvalidField: the map has no normals"; return ICPMI_ERR_MISSING_NORMALS; }
         HIP_TRY(c, hipMemcpyAsync(normals3, c->d_raw_n3, (size_t)c->m_raw * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return ICPMI_OK;
+}
+
+// =================================================================================================================
+// Map::updateLocalPointCloud (Map.cpp:502-534) as one program over the resident map: mapper modules, then post
+// filters.  Working set = the resident arrays themselves (features, normals, one scalar descriptor, provenance);
+// compactions write into the ping-pong set and swap.  Every step is order preserving, so the result is a function
+// of the inputs alone and equals the host chain built from the single operators above.
+// =================================================================================================================
+namespace {
+
+__global__ __launch_bounds__(256) void chain_iota_kernel(int* __restrict__ src, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) src[i] = (int)i;
+}
+
+// scan point i (kept iff flag == nullptr or flag[i]) -> slot base + (pos ? pos[i] : i); provenance src_base + i
+__global__ __launch_bounds__(256) void chain_append_kernel(const float4* __restrict__ in, const float* __restrict__ in_n3,
+                                                           const float* __restrict__ in_s, int64_t n, const unsigned* __restrict__ flag,
+                                                           const unsigned* __restrict__ pos, int64_t base, int src_base,
+                                                           float4* __restrict__ raw, float* __restrict__ raw_n3, float* __restrict__ raw_s,
+                                                           int* __restrict__ src)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || (flag && !flag[i])) return;
+    const int64_t o = base + (pos ? (int64_t)pos[i] : i);
+    raw[o] = in[i];
+    raw_n3[3 * o] = in_n3 ? in_n3[3 * i] : 0.f;
+    raw_n3[3 * o + 1] = in_n3 ? in_n3[3 * i + 1] : 0.f;
+    raw_n3[3 * o + 2] = in_n3 ? in_n3[3 * i + 2] : 0.f;
+    raw_s[o] = in_s ? in_s[i] : 0.f;
+    src[o] = src_base + (int)i;
+}
+
+__global__ __launch_bounds__(256) void chain_compact_kernel(int64_t m, const unsigned* __restrict__ flag, const unsigned* __restrict__ pos,
+                                                            const float4* __restrict__ raw, const float* __restrict__ n3,
+                                                            const float* __restrict__ sc, const int* __restrict__ src,
+                                                            float4* __restrict__ o_raw, float* __restrict__ o_n3, float* __restrict__ o_sc,
+                                                            int* __restrict__ o_src)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m || !flag[i]) return;
+    const int64_t o = pos[i];
+    o_raw[o] = raw[i];
+    o_n3[3 * o] = n3[3 * i]; o_n3[3 * o + 1] = n3[3 * i + 1]; o_n3[3 * o + 2] = n3[3 * i + 2];
+    o_sc[o] = sc[i];
+    o_src[o] = src[i];
+}
+
+// CutAtDescriptorThresholdDataPointsFilter: useLargerThan drops v > threshold, else drops v < threshold
+__global__ __launch_bounds__(256) void chain_cut_flag_kernel(const float* __restrict__ sc, int64_t m, float threshold, int larger,
+                                                             unsigned* __restrict__ flag)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const float v = sc[i];
+    flag[i] = (larger ? !(v > threshold) : !(v < threshold)) ? 1u : 0u;
+}
+
+struct Chain {
+    icpmi_ctx* c;
+    int64_t m = 0;         // points in the working map
+    bool has_n = false;    // its normals mean something
+    bool indexed = false;  // the handle's own search index still describes exactly the working map
+};
+
+// room for `need` points in the main set, the first w.m survive
+icpmi_status chain_reserve(Chain& w, int64_t need)
+{
+    icpmi_ctx* c = w.c;
+    if (need >= (1ll << 28)) { c->last_error = "map_update_chain: the map would exceed 2^28-1 points"; return ICPMI_ERR_UNSUPPORTED; }
+    icpmi_status s = ensure_cap_keep(c, &c->d_raw, &c->cap_raw, (size_t)need, (size_t)w.m);
+    if (s == ICPMI_OK) s = ensure_cap_keep(c, &c->d_raw_n3, &c->cap_raw_n3, (size_t)need * 3, (size_t)w.m * 3);
+    if (s == ICPMI_OK) s = ensure_cap_keep(c, &c->d_raw_s, &c->cap_raw_s, (size_t)need, (size_t)w.m);
+    if (s == ICPMI_OK) s = ensure_cap_keep(c, &c->d_src, &c->cap_src, (size_t)need, (size_t)w.m);
+    return s;
+}
+
+icpmi_status chain_append(Chain& w, const float4* d_scan, const float* d_n3, const float* d_s, int64_t n, const unsigned* flag,
+                          const unsigned* pos, int64_t count, int src_base)
+{
+    icpmi_ctx* c = w.c;
+    if (count == 0) return ICPMI_OK;
+    icpmi_status s = chain_reserve(w, w.m + count);
+    if (s != ICPMI_OK) return s;
+    hipLaunchKernelGGL(chain_append_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, d_scan, d_n3, d_s, n, flag, pos, w.m,
+                       src_base, c->d_raw, c->d_raw_n3, c->d_raw_s, c->d_src);
+    HIP_TRY(c, hipGetLastError());
+    w.m += count;
+    w.indexed = false;
+    return ICPMI_OK;
+}
+
+// flags (0/1) -> stable compaction of the working map; d_pos is scratch of m + 2 words
+icpmi_status chain_compact(Chain& w, unsigned* d_flag, unsigned* d_pos)
+{
+    icpmi_ctx* c = w.c;
+    const int64_t m = w.m;
+    if (m == 0) return ICPMI_OK;
+    HIP_TRY(c, hipMemcpyAsync(d_pos, d_flag, (size_t)m * sizeof(unsigned), hipMemcpyDeviceToDevice, c->stream));
+    icpmi_status s = device_exclusive_scan(c, d_pos, (int)m, 0u);
+    if (s != ICPMI_OK) return s;
+    unsigned last_pos = 0, last_flag = 0;
+    HIP_TRY(c, hipMemcpyAsync(&last_pos, d_pos + (m - 1), sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&last_flag, d_flag + (m - 1), sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const int64_t count = (int64_t)last_pos + last_flag;
+    if (count == m) return ICPMI_OK; // nothing dropped
+    if (ensure_cap(c, &c->d_alt_raw, &c->cap_alt_raw, (size_t)count + 1) != ICPMI_OK || ensure_cap(c, &c->d_alt_n3, &c->cap_alt_n3, (size_t)count * 3 + 1) != ICPMI_OK ||
+        ensure_cap(c, &c->d_alt_s, &c->cap_alt_s, (size_t)count + 1) != ICPMI_OK || ensure_cap(c, &c->d_alt_src, &c->cap_alt_src, (size_t)count + 1) != ICPMI_OK)
+        return ICPMI_ERR_HIP;
+    hipLaunchKernelGGL(chain_compact_kernel, dim3((int)((m + 255) / 256)), dim3(256), 0, c->stream, m, d_flag, d_pos, c->d_raw, c->d_raw_n3,
+                       c->d_raw_s, c->d_src, c->d_alt_raw, c->d_alt_n3, c->d_alt_s, c->d_alt_src);
+    HIP_TRY(c, hipGetLastError());
+    std::swap(c->d_raw, c->d_alt_raw); std::swap(c->cap_raw, c->cap_alt_raw);
+    std::swap(c->d_raw_n3, c->d_alt_n3); std::swap(c->cap_raw_n3, c->cap_alt_n3);
+    std::swap(c->d_raw_s, c->d_alt_s); std::swap(c->cap_raw_s, c->cap_alt_s);
+    std::swap(c->d_src, c->d_alt_src); std::swap(c->cap_src, c->cap_alt_src);
+    w.m = count;
+    w.indexed = false;
+    return ICPMI_OK;
+}
+
+// PointDistanceMapperModule.cpp:33-42 on an indexing handle `ic` (the caller's own handle while its index still
+// describes the working map, the private one otherwise): flag[i] = exact NN of scan i at d2 >= minDist^2
+icpmi_status chain_point_distance_flags(icpmi_ctx* c, icpmi_ctx* ic, const float4* d_scan, int64_t n, float min_dist, unsigned* d_flag)
+{
+    const float lim = powf(min_dist, 2.f);
+    icpmi_status s = loop_prepare_reading(ic, d_scan, n, nullptr);
+    if (s != ICPMI_OK) { c->last_error = ic->last_error; return s; }
+    LoopCfg lc = make_loop_cfg(ic, 1);
+    lc.k = 1; lc.n_out = 0; lc.max_dist = min_dist; lc.maxr2 = lim; // a radius search with maxDist = minDist decides the same predicate
+    const size_t cnt = (size_t)n + 1;
+    if (ensure_cap(ic, &ic->d_sidx, &ic->cap_sidx, cnt) != ICPMI_OK || ensure_cap(ic, &ic->d_d2, &ic->cap_d2, cnt) != ICPMI_OK ||
+        ensure_cap(ic, &ic->d_hard, &ic->cap_hard, cnt) != ICPMI_OK) { c->last_error = ic->last_error; return ICPMI_ERR_HIP; }
+    HIP_TRY(c, hipMemsetAsync(ic->d_state, 0, sizeof(IcpState), ic->stream));
+    ic->nn_hist0 = nullptr; ic->nn_iter_hint = 0; ic->nn_match_pt = nullptr;
+    s = nn_launch_k(ic, ic->d_reading, n, nullptr, lc, 0, ic->d_sidx, ic->d_d2, ic->d_state);
+    if (s != ICPMI_OK) { c->last_error = ic->last_error; return s; }
+    hipLaunchKernelGGL(keep_flag_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, ic->stream, ic->d_d2, n, lim, d_flag);
+    HIP_TRY(c, hipGetLastError());
+    if (ic != c) HIP_TRY(c, hipStreamSynchronize(ic->stream));
+    return ICPMI_OK;
+}
+
+} // namespace
+
+icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n, const float* d_scan_n3, const float* d_scan_s,
+                                  const float to_sensor[16], const icpmi_map_op* ops, int n_ops, int n_modules, int32_t* src_out,
+                                  int64_t src_capacity, int64_t* new_m)
+{
+    const int64_t m0 = c->m > 0 ? c->m_raw : 0;
+    if (new_m) *new_m = m0;
+    if (n_ops < 0 || n_modules < 0 || n_modules > n_ops || (n_ops > 0 && !ops)) { c->last_error = "map_update_chain: bad program"; return ICPMI_ERR_INVALID_ARG; }
+    if (src_out && src_capacity < m0 + 2 * n) { c->last_error = "map_update_chain: src_capacity must be >= m_old + 2 n"; return ICPMI_ERR_INVALID_ARG; }
+    bool uses_scalar = false;
+    for (int i = 0; i < n_ops; ++i) {
+        const icpmi_map_op& op = ops[i];
+        switch (op.type) {
+        case ICPMI_MOP_POINT_DISTANCE: if (!(op.f[0] >= 0.f)) { c->last_error = "InvalidParameter: minDistNewPoint must be >= 0"; return ICPMI_ERR_INVALID_ARG; } break;
+        case ICPMI_MOP_DYNAMIC_POINTS: uses_scalar = true; if (!(op.f[3] > 0.f)) { c->last_error = "InvalidParameter: beamHalfAngle must be > 0"; return ICPMI_ERR_INVALID_ARG; } break;
+        case ICPMI_MOP_VOXEL: if (!(op.f[0] > 0.f) || (op.i != 0 && op.i != 1)) { c->last_error = "map_update_chain: voxel edge must be > 0 and samplingMethod 0 or 1"; return ICPMI_ERR_INVALID_ARG; } break;
+        case ICPMI_MOP_SURFACE_NORMALS: if (op.i < 1 || op.i > ICPMI_MAX_K) { c->last_error = "surface_normals: knn must be in [1, 32]"; return ICPMI_ERR_INVALID_ARG; } break;
+        case ICPMI_MOP_CUT_SCALAR: uses_scalar = true; break;
+        default: c->last_error = "map_update_chain: unknown operator"; return ICPMI_ERR_INVALID_ARG;
+        }
+        if (i >= n_modules && op.type != ICPMI_MOP_SURFACE_NORMALS && op.type != ICPMI_MOP_CUT_SCALAR) { c->last_error = "map_update_chain: a mapper module after the post filters"; return ICPMI_ERR_INVALID_ARG; }
+        if (i < n_modules && (op.type == ICPMI_MOP_SURFACE_NORMALS || op.type == ICPMI_MOP_CUT_SCALAR)) { c->last_error = "map_update_chain: a post filter among the mapper modules"; return ICPMI_ERR_INVALID_ARG; }
+    }
+    if (n_modules == 0) { c->last_error = "InvalidParameter: no mapper module configured"; return ICPMI_ERR_INVALID_ARG; }
+    if (uses_scalar && n > 0 && !d_scan_s) { c->last_error = "InvalidField: the chain needs the tracked scalar descriptor on the input (AddDescriptorDataPointsFilter)"; return ICPMI_ERR_INVALID_ARG; }
+    if (uses_scalar && m0 > 0 && !c->raw_has_scalar) { c->last_error = "InvalidField: the chain needs the tracked scalar descriptor on the map (icpmi_set_map_scalar)"; return ICPMI_ERR_INVALID_ARG; }
+    if (n == 0 && m0 == 0) return ICPMI_OK;
+    for (int i = 0; i < n_modules; ++i)
+        if (ops[i].type == ICPMI_MOP_DYNAMIC_POINTS && m0 > 0 && n > 0 && !c->raw_has_normals) { // before anything is touched
+            c->last_error = "InvalidField: Missing field 'normals' in map point cloud. You can add it with the SurfaceNormalDataPointsFilter in your post filters.";
+            return ICPMI_ERR_MISSING_NORMALS;
+        }
+
+    Chain w;
+    w.c = c; w.m = m0; w.has_n = m0 > 0 && c->raw_has_normals; w.indexed = m0 > 0;
+    // the main set must exist before the first kernel touches it; normals / scalar a map never had read as zeros
+    icpmi_status s = ICPMI_OK;
+    {
+        const bool had_n = w.has_n, had_s = m0 > 0 && c->raw_has_scalar;
+        s = ensure_cap_keep(c, &c->d_raw, &c->cap_raw, (size_t)(m0 + n + 1), (size_t)m0);
+        if (s == ICPMI_OK) s = ensure_cap_keep(c, &c->d_raw_n3, &c->cap_raw_n3, (size_t)(m0 + n + 1) * 3, had_n ? (size_t)m0 * 3 : 0);
+        if (s == ICPMI_OK) s = ensure_cap_keep(c, &c->d_raw_s, &c->cap_raw_s, (size_t)(m0 + n + 1), had_s ? (size_t)m0 : 0);
+        if (s == ICPMI_OK) s = ensure_cap(c, &c->d_src, &c->cap_src, (size_t)(m0 + n + 1));
+        if (s != ICPMI_OK) return s;
+        if (m0 > 0 && !had_n) HIP_TRY(c, hipMemsetAsync(c->d_raw_n3, 0, (size_t)m0 * 3 * sizeof(float), c->stream));
+        if (m0 > 0 && !had_s) HIP_TRY(c, hipMemsetAsync(c->d_raw_s, 0, (size_t)m0 * sizeof(float), c->stream));
+        if (m0 > 0) hipLaunchKernelGGL(chain_iota_kernel, dim3((int)((m0 + 255) / 256)), dim3(256), 0, c->stream, c->d_src, m0);
+    }
+    DevBuf<unsigned> d_flag, d_pos;
+    HIP_TRY(c, d_flag.alloc((size_t)(m0 + 2 * n + 2)));
+    HIP_TRY(c, d_pos.alloc((size_t)(m0 + 2 * n + 2)));
+    const int src_base = (int)m0;
+    bool created = m0 > 0; // false until the first module has created the map from the scan
+
+    for (int i = 0; i < n_ops && s == ICPMI_OK; ++i) {
+        const icpmi_map_op& op = ops[i];
+        switch (op.type) {
+        case ICPMI_MOP_POINT_DISTANCE: {
+            if (n == 0) break;
+            if (!created) { s = chain_append(w, d_scan, d_scan_n3, d_scan_s, n, nullptr, nullptr, n, src_base); w.has_n = d_scan_n3 != nullptr; break; } // createMap: the scan is the map
+            if (w.m == 0) { s = chain_append(w, d_scan, d_scan_n3, d_scan_s, n, nullptr, nullptr, n, src_base); break; } // no neighbour anywhere: d2 = inf
+            icpmi_ctx* ic = c;
+            if (!w.indexed) {
+                TempCtx t;
+                s = make_temp(c, t);
+                if (s != ICPMI_OK) break;
+                ic = t.h;
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                int32_t acc = 0;
+                s = icpmi_set_map_dev(ic, (const float*)c->d_raw, w.m, nullptr, &acc);
+                if (s != ICPMI_OK) { c->last_error = ic->last_error; break; }
+            }
+            s = chain_point_distance_flags(c, ic, d_scan, n, op.f[0], d_flag);
+            if (s != ICPMI_OK) break;
+            HIP_TRY(c, hipMemcpyAsync(d_pos, d_flag, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToDevice, c->stream));
+            s = device_exclusive_scan(c, d_pos, (int)n, 0u);
+            if (s != ICPMI_OK) break;
+            unsigned lp = 0, lf = 0;
+            HIP_TRY(c, hipMemcpyAsync(&lp, d_pos + (n - 1), sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(&lf, d_flag + (n - 1), sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            s = chain_append(w, d_scan, d_scan_n3, d_scan_s, n, d_flag, d_pos, (int64_t)lp + lf, src_base);
+            break;
+        }
+        case ICPMI_MOP_DYNAMIC_POINTS: {
+            if (!created) { s = chain_append(w, d_scan, d_scan_n3, d_scan_s, n, nullptr, nullptr, n, src_base); w.has_n = d_scan_n3 != nullptr; break; } // createMap: no-op on the scan
+            if (n == 0 || w.m == 0) break;
+            if (!w.has_n) { c->last_error = "InvalidField: Missing field 'normals' in map point cloud. You can add it with the SurfaceNormalDataPointsFilter in your post filters."; s = ICPMI_ERR_MISSING_NORMALS; break; }
+            s = check_rigid(c, to_sensor);
+            if (s != ICPMI_OK) break;
+            if (!c->d_T16) HIP_TRY(c, hipMalloc((void**)&c->d_T16, 16 * sizeof(float)));
+            HIP_TRY(c, hipMemcpyAsync(c->d_T16, to_sensor, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream)); // the caller's array may be a temporary
+            icpmi_dynpts_params prm = {op.f[0], op.f[1], op.f[2], op.f[3], op.f[4], op.f[5], op.f[6]};
+            s = dynpts_dev(c, &prm, c->d_T16, d_scan, n, c->d_raw, c->d_raw_n3, w.m, c->d_raw_s);
+            break;
+        }
+        case ICPMI_MOP_VOXEL: {
+            // OctreeMapperModule.cpp:35-39: concatenate, then decimate (createMap: an empty map updated by the scan)
+            s = chain_append(w, d_scan, d_scan_n3, d_scan_s, n, nullptr, nullptr, n, src_base);
+            if (!created) w.has_n = d_scan_n3 != nullptr;
+            if (s != ICPMI_OK || w.m == 0) break;
+            s = voxel_flags_dev<unsigned>(c, c->d_raw, w.m, op.f[0], op.i, d_flag);
+            if (s == ICPMI_OK) s = chain_compact(w, d_flag, d_pos);
+            break;
+        }
+        case ICPMI_MOP_SURFACE_NORMALS: {
+            if (w.m == 0) break;
+            s = surface_normals_dev(c, c->d_raw, w.m, op.i, c->d_raw_n3);
+            w.has_n = true;
+            break;
+        }
+        case ICPMI_MOP_CUT_SCALAR: {
+            if (w.m == 0) break;
+            hipLaunchKernelGGL(chain_cut_flag_kernel, dim3((int)((w.m + 255) / 256)), dim3(256), 0, c->stream, c->d_raw_s, w.m, op.f[0], op.i, d_flag);
+            HIP_TRY(c, hipGetLastError());
+            s = chain_compact(w, d_flag, d_pos);
+            break;
+        }
+        }
+        created = true;
+    }
+    if (s != ICPMI_OK) {
+        // the resident arrays may be half way through the program: drop them, the index of the old map is intact but its
+        // resident copy is not -- force the caller back to icpmi_set_map
+        c->m_raw = 0; c->raw_has_normals = false; c->raw_has_scalar = false; c->m = 0;
+        return s;
+    }
+    if (w.m == 0) { c->last_error = "map_update_chain: the chain removed every point of the map"; c->m_raw = 0; c->m = 0; c->raw_has_scalar = false; return ICPMI_ERR_INVALID_ARG; }
+    if (src_out) {
+        if (src_capacity < w.m) { c->last_error = "map_update_chain: src_capacity too small"; return ICPMI_ERR_INVALID_ARG; }
+        HIP_TRY(c, hipMemcpyAsync(src_out, c->d_src, (size_t)w.m * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    }
+    // icp.setMap(localPointCloud) (Map.cpp:528): rebuild the index from the resident copy
+    s = map_build(c, c->d_raw, w.m, w.has_n ? c->d_raw_n3 : nullptr);
+    if (s != ICPMI_OK) return s;
+    c->raw_has_scalar = (m0 == 0 || c->raw_has_scalar) && (n == 0 || d_scan_s != nullptr); // both parts carried real values
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (new_m) *new_m = w.m;
+    return ICPMI_OK;
+}
+
+icpmi_status ops_map_scalar(icpmi_ctx* c, const float* set, float* get, int64_t m)
+{
+    if (c->m <= 0 || m != c->m_raw) { c->last_error = "map_scalar: size differs from the resident map"; return ICPMI_ERR_INVALID_ARG; }
+    if (set) {
+        if (ensure_cap_keep(c, &c->d_raw_s, &c->cap_raw_s, (size_t)m, 0) != ICPMI_OK) return ICPMI_ERR_HIP;
+        HIP_TRY(c, hipMemcpyAsync(c->d_raw_s, set, (size_t)m * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        c->raw_has_scalar = true;
+    }
+    if (get) {
+        if (!c->raw_has_scalar) { c->last_error = "InvalidField: the map has no tracked scalar descriptor"; return ICPMI_ERR_INVALID_ARG; }
+        HIP_TRY(c, hipMemcpyAsync(get, c->d_raw_s, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return ICPMI_OK;

@@ -344,6 +344,76 @@ class ICPSequence:
         self._check(self._lib.icpmi_voxel_keep_first(self._h, c.ctypes.data, c.shape[0], edge, keep.ctypes.data))
         return keep.astype(bool)
 
+    def voxelKeep(self, cloud, edge, method=0):
+        """Same lattice, representative by `samplingMethod`: 0 first point, 1 pseudo-random point (smallest fmix32 of the index)."""
+        c = _f32c(cloud, 4)
+        keep = np.empty(c.shape[0], dtype=np.uint8)
+        self._check(self._lib.icpmi_voxel_keep(self._h, c.ctypes.data, c.shape[0], edge, method, keep.ctypes.data))
+        return keep.astype(bool)
+
+    @staticmethod
+    def _mapOps(modules, post):
+        """[(name, params...)] -> MapOp array.  Names: 'point_distance' (min_dist), 'dynamic_points' (7 parameters in
+        icpmi_dynpts_params order), 'voxel' (edge, method), 'surface_normals' (knn), 'cut_scalar' (threshold, use_larger_than)."""
+        from . import _capi
+        ops = (_capi.MapOp * (len(modules) + len(post)))()
+        for j, item in enumerate(list(modules) + list(post)):
+            name, args = item[0], item[1:]
+            op = ops[j]
+            if name == "point_distance":
+                op.type = _capi.MOP_POINT_DISTANCE; op.f[0] = args[0]
+            elif name == "dynamic_points":
+                op.type = _capi.MOP_DYNAMIC_POINTS
+                for r in range(7):
+                    op.f[r] = args[r]
+            elif name == "voxel":
+                op.type = _capi.MOP_VOXEL; op.f[0] = args[0]; op.i = int(args[1]) if len(args) > 1 else 0
+            elif name == "surface_normals":
+                op.type = _capi.MOP_SURFACE_NORMALS; op.i = int(args[0])
+            elif name == "cut_scalar":
+                op.type = _capi.MOP_CUT_SCALAR; op.f[0] = args[0]; op.i = int(args[1]) if len(args) > 1 else 1
+            else:
+                raise InvalidParameter("unknown map operator " + name)
+        return ops
+
+    def mapUpdateChain(self, scan_in_map_frame, modules, post=(), scan_scalar=None, scan_normals=None, to_sensor=None, staged_correction=None):
+        """Map::updateLocalPointCloud (Map.cpp:502-534) for a whole module chain + post filters on the resident map.
+        Returns (src, m): new map point j was point src[j] of [old map ; scan].  With staged_correction the scan is the
+        one staged by registerWithPrior (scan_in_map_frame is ignored)."""
+        ops = self._mapOps(modules, post)
+        m_old = C.c_int64(0)
+        self._check(self._lib.icpmi_get_map(self._h, None, None, 0, C.byref(m_old)))
+        ss = None if scan_scalar is None else np.ascontiguousarray(scan_scalar, dtype=np.float32)
+        Ts = None if to_sensor is None else _T_to_c(to_sensor)
+        new_m = C.c_int64(0)
+        if staged_correction is not None:
+            n = self._staged_n
+            src = np.empty(m_old.value + 2 * n + 1, dtype=np.int32)
+            Tc = _T_to_c(staged_correction)
+            self._check(self._lib.icpmi_map_update_chain_staged(self._h, Tc.ctypes.data, None if ss is None else ss.ctypes.data,
+                                                                None if Ts is None else Ts.ctypes.data, ops, len(ops), len(modules),
+                                                                src.ctypes.data, src.shape[0], C.byref(new_m)))
+        else:
+            sc = _f32c(scan_in_map_frame, 4)
+            sn = None if scan_normals is None else _f32c(scan_normals, 3)
+            n = sc.shape[0]
+            src = np.empty(m_old.value + 2 * n + 1, dtype=np.int32)
+            self._check(self._lib.icpmi_map_update_chain(self._h, sc.ctypes.data, n, None if sn is None else sn.ctypes.data,
+                                                         None if ss is None else ss.ctypes.data, None if Ts is None else Ts.ctypes.data,
+                                                         ops, len(ops), len(modules), src.ctypes.data, src.shape[0], C.byref(new_m)))
+        return src[:new_m.value].copy(), int(new_m.value)
+
+    def setMapScalar(self, scalar):
+        s = np.ascontiguousarray(scalar, dtype=np.float32)
+        self._check(self._lib.icpmi_set_map_scalar(self._h, s.ctypes.data, s.shape[0]))
+
+    def getMapScalar(self):
+        m = C.c_int64(0)
+        self._check(self._lib.icpmi_get_map(self._h, None, None, 0, C.byref(m)))
+        out = np.empty(m.value, dtype=np.float32)
+        self._check(self._lib.icpmi_get_map_scalar(self._h, out.ctypes.data, out.shape[0]))
+        return out
+
     def dynamicPointsUpdate(self, to_sensor, input_cloud, map_cloud, map_normals, prob_dynamic, threshold_dynamic=0.6, alpha=0.8,
                             beta=0.99, beam_half_angle=0.01, epsilon_a=0.01, epsilon_d=0.01, sensor_max_range=200.0):
         """DynamicPointsMapperModule::inPlaceUpdateMap (DynamicPointsMapperModule.cpp:34-172): returns the

@@ -928,7 +928,10 @@ static int orc_vox_cmp(const void* a, const void* b)
     if (x->key != y->key) return x->key < y->key ? -1 : 1;
     return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
 }
-void orc_voxel_keep_first(const float* in4, int64_t n, float edge, uint8_t* keep)
+static uint32_t orc_fmix32(uint32_t h) { h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h; }
+/* method 0: the smallest index represents its voxel; method 1 (`samplingMethod: 1`, a random point, made
+ * reproducible): the index with the smallest MurmurHash3 finaliser (a bijection of the 32-bit integers). */
+void orc_voxel_keep(const float* in4, int64_t n, float edge, int method, uint8_t* keep)
 {
     if (n <= 0) return;
     float lo[3] = {in4[0], in4[1], in4[2]};
@@ -942,14 +945,28 @@ void orc_voxel_keep_first(const float* in4, int64_t n, float edge, uint8_t* keep
             if (v > 2097151.0f) v = 2097151.0f;
             key = key * 2097152ull + (uint64_t)v;
         }
-        it[i].key = key; it[i].idx = i;
+        it[i].key = key; it[i].idx = method ? (int64_t)orc_fmix32((uint32_t)i) : i;
         keep[i] = 0;
     }
     qsort(it, (size_t)n, sizeof(orc_vox_item), orc_vox_cmp);
-    for (int64_t i = 0; i < n; ++i)
-        if (i == 0 || it[i].key != it[i - 1].key) keep[it[i].idx] = 1;
+    if (method) { /* undo the bijection: fmix32^-1 is not needed, look the index up again */
+        orc_vox_item* h2 = (orc_vox_item*)malloc((size_t)n * sizeof(orc_vox_item));
+        for (int64_t i = 0; i < n; ++i) { h2[i].key = (uint64_t)orc_fmix32((uint32_t)i); h2[i].idx = i; }
+        qsort(h2, (size_t)n, sizeof(orc_vox_item), orc_vox_cmp);
+        for (int64_t i = 0; i < n; ++i)
+            if (i == 0 || it[i].key != it[i - 1].key) {
+                /* binary search of the hash among the sorted hashes */
+                int64_t lo2 = 0, hi2 = n - 1; const uint64_t want = (uint64_t)it[i].idx;
+                while (lo2 < hi2) { const int64_t mid = (lo2 + hi2) / 2; if (h2[mid].key < want) lo2 = mid + 1; else hi2 = mid; }
+                keep[h2[lo2].idx] = 1;
+            }
+        free(h2);
+    } else
+        for (int64_t i = 0; i < n; ++i)
+            if (i == 0 || it[i].key != it[i - 1].key) keep[it[i].idx] = 1;
     free(it);
 }
+void orc_voxel_keep_first(const float* in4, int64_t n, float edge, uint8_t* keep) { orc_voxel_keep(in4, n, edge, 0, keep); }
 
 /* DynamicPointsMapperModule::inPlaceUpdateMap (DynamicPointsMapperModule.cpp:34-172), brute-force angular
  * nearest beam (the reference: 2-D kd-tree, k = 1, radius 2 * beamHalfAngle, :75-78).  Ties on equal angular

@@ -71,6 +71,7 @@ def load():
     lib.orc_point_distance_keep.argtypes = [_P, C.c_int64, _P, C.c_int64, C.c_float, _P, C.c_int]
     lib.orc_cell_ids.argtypes = [_P, C.c_int64, C.c_float, _P]
     lib.orc_voxel_keep_first.argtypes = [_P, C.c_int64, C.c_float, _P]
+    lib.orc_voxel_keep.argtypes = [_P, C.c_int64, C.c_float, C.c_int, _P]
     lib.orc_dynamic_points_update.argtypes = [_P, _P, _P, C.c_int64, _P, _P, C.c_int64, _P, C.c_int]
     _lib = lib
     return lib
@@ -216,6 +217,12 @@ def cell_ids(cloud, cell_size=20.0):
 def voxel_keep_first(cloud, edge):
     lib = load(); c = _f32(cloud); keep = np.zeros(c.shape[0], dtype=np.uint8)
     lib.orc_voxel_keep_first(c.ctypes.data, c.shape[0], edge, keep.ctypes.data)
+    return keep.astype(bool)
+
+
+def voxel_keep(cloud, edge, method):
+    lib = load(); c = _f32(cloud); keep = np.zeros(c.shape[0], dtype=np.uint8)
+    lib.orc_voxel_keep(c.ctypes.data, c.shape[0], edge, method, keep.ctypes.data)
     return keep.astype(bool)
 
 
