@@ -257,18 +257,21 @@ icpmi_status icpmi_voxel_keep(icpmi_handle h, const float* in4, int64_t n, float
  * has none; scan_normals3 may be NULL (appended points then carry zero normals until a SURFACE_NORMALS step).
  * to_sensor = pose^-1 (sensor <- map; `pose` is the modules' argument, DynamicPointsMapperModule.cpp:51,57; only
  * DYNAMIC_POINTS reads it, may be NULL otherwise); post filters run in the map frame.
- * src_capacity must be >= m_old + 2 n. */
+ * src_capacity must be >= m_old + 2 n.  identity_prefix (may be NULL): when given, receives the length of the head of
+ * the new map that is the untouched head of the old one (src[j] == j for j < *identity_prefix) and src_out is written
+ * from that position on only -- a host that owns further descriptors leaves those rows alone and gathers the rest, and
+ * an append-only chain downloads a few kilobytes instead of the whole vector. */
 typedef enum {
     ICPMI_MOP_POINT_DISTANCE = 0, ICPMI_MOP_DYNAMIC_POINTS = 1, ICPMI_MOP_VOXEL = 2, ICPMI_MOP_SURFACE_NORMALS = 3, ICPMI_MOP_CUT_SCALAR = 4
 } icpmi_map_op_type;
 typedef struct icpmi_map_op { int32_t type; int32_t i; float f[7]; } icpmi_map_op;
 icpmi_status icpmi_map_update_chain(icpmi_handle h, const float* scan4, int64_t n, const float* scan_normals3, const float* scan_scalar,
                                     const float to_sensor[16], const icpmi_map_op* ops, int32_t n_ops, int32_t n_modules,
-                                    int32_t* src_out, int64_t src_capacity, int64_t* new_m);
+                                    int32_t* src_out, int64_t src_capacity, int64_t* identity_prefix, int64_t* new_m);
 /* The same on the scan staged by icpmi_register_prior, moved by `correction` first (Mapper.cpp:221). */
 icpmi_status icpmi_map_update_chain_staged(icpmi_handle h, const float correction[16], const float* scan_scalar, const float to_sensor[16],
                                            const icpmi_map_op* ops, int32_t n_ops, int32_t n_modules, int32_t* src_out,
-                                           int64_t src_capacity, int64_t* new_m);
+                                           int64_t src_capacity, int64_t* identity_prefix, int64_t* new_m);
 /* The tracked scalar descriptor of the resident map: upload after a icpmi_set_map (m must equal the map size),
  * download next to icpmi_get_map. */
 icpmi_status icpmi_set_map_scalar(icpmi_handle h, const float* scalar, int64_t m);

@@ -456,7 +456,7 @@ static bool chain_needs_pose(const icpmi_map_op* ops, int32_t n_ops)
 
 icpmi_status icpmi_map_update_chain(icpmi_handle h, const float* scan4, int64_t n, const float* scan_normals3, const float* scan_scalar,
                                     const float to_sensor[16], const icpmi_map_op* ops, int32_t n_ops, int32_t n_modules,
-                                    int32_t* src_out, int64_t src_capacity, int64_t* new_m)
+                                    int32_t* src_out, int64_t src_capacity, int64_t* identity_prefix, int64_t* new_m)
 {
     CHECK_H(h);
     if (n < 0 || (n > 0 && !scan4) || (chain_needs_pose(ops, n_ops) && !to_sensor)) { h->last_error = "map_update_chain: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
@@ -471,12 +471,12 @@ icpmi_status icpmi_map_update_chain(icpmi_handle h, const float* scan4, int64_t 
         if (s != ICPMI_OK) return s;
     }
     return ops_map_update_chain(h, h->d_stage_in, n, scan_normals3 ? h->d_stage_n3 : nullptr, scan_scalar ? h->d_stage_s : nullptr, to_sensor, ops,
-                                n_ops, n_modules, src_out, src_capacity, new_m);
+                                n_ops, n_modules, src_out, src_capacity, identity_prefix, new_m);
 }
 
 icpmi_status icpmi_map_update_chain_staged(icpmi_handle h, const float correction[16], const float* scan_scalar, const float to_sensor[16],
                                            const icpmi_map_op* ops, int32_t n_ops, int32_t n_modules, int32_t* src_out,
-                                           int64_t src_capacity, int64_t* new_m)
+                                           int64_t src_capacity, int64_t* identity_prefix, int64_t* new_m)
 {
     CHECK_H(h);
     if (!correction || (chain_needs_pose(ops, n_ops) && !to_sensor)) { h->last_error = "map_update_chain_staged: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
@@ -487,7 +487,7 @@ icpmi_status icpmi_map_update_chain_staged(icpmi_handle h, const float correctio
     if (s == ICPMI_OK) s = stage_chain_scalar(h, scan_scalar, n);
     if (s != ICPMI_OK) return s;
     return ops_map_update_chain(h, h->d_stage_in, n, nullptr, scan_scalar ? h->d_stage_s : nullptr, to_sensor, ops, n_ops, n_modules, src_out,
-                                src_capacity, new_m);
+                                src_capacity, identity_prefix, new_m);
 }
 
 icpmi_status icpmi_set_map_scalar(icpmi_handle h, const float* scalar, int64_t m)

@@ -832,6 +832,15 @@ __global__ __launch_bounds__(256) void chain_compact_kernel(int64_t m, const uns
     o_src[o] = src[i];
 }
 
+// first j with src[j] != j (m if none): the untouched head of the map, which the host need not be told about
+__global__ __launch_bounds__(256) void chain_prefix_kernel(const int* __restrict__ src, int64_t m, unsigned* __restrict__ first_moved)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool moved = i < m && src[i] != (int)i;
+    const unsigned long long b = __ballot(moved);
+    if (b && (threadIdx.x & 63) == 0) atomicMin(first_moved, (unsigned)(i + __ffsll((long long)b) - 1));
+}
+
 // CutAtDescriptorThresholdDataPointsFilter: useLargerThan drops v > threshold, else drops v < threshold
 __global__ __launch_bounds__(256) void chain_cut_flag_kernel(const float* __restrict__ sc, int64_t m, float threshold, int larger,
                                                              unsigned* __restrict__ flag)
@@ -932,8 +941,9 @@ icpmi_status chain_point_distance_flags(icpmi_ctx* c, icpmi_ctx* ic, const float
 
 icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n, const float* d_scan_n3, const float* d_scan_s,
                                   const float to_sensor[16], const icpmi_map_op* ops, int n_ops, int n_modules, int32_t* src_out,
-                                  int64_t src_capacity, int64_t* new_m)
+                                  int64_t src_capacity, int64_t* identity_prefix, int64_t* new_m)
 {
+    if (identity_prefix) *identity_prefix = 0;
     const int64_t m0 = c->m > 0 ? c->m_raw : 0;
     if (new_m) *new_m = m0;
     if (n_ops < 0 || n_modules < 0 || n_modules > n_ops || (n_ops > 0 && !ops)) { c->last_error = "map_update_chain: bad program"; return ICPMI_ERR_INVALID_ARG; }
@@ -1060,7 +1070,17 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
     if (w.m == 0) { c->last_error = "map_update_chain: the chain removed every point of the map"; c->m_raw = 0; c->m = 0; c->raw_has_scalar = false; return ICPMI_ERR_INVALID_ARG; }
     if (src_out) {
         if (src_capacity < w.m) { c->last_error = "map_update_chain: src_capacity too small"; return ICPMI_ERR_INVALID_ARG; }
-        HIP_TRY(c, hipMemcpyAsync(src_out, c->d_src, (size_t)w.m * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        int64_t head = 0;
+        if (identity_prefix) {
+            unsigned first_moved = (unsigned)w.m;
+            HIP_TRY(c, hipMemcpyAsync(d_pos, &first_moved, sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(chain_prefix_kernel, dim3((int)((w.m + 255) / 256)), dim3(256), 0, c->stream, c->d_src, w.m, d_pos);
+            HIP_TRY(c, hipMemcpyAsync(&first_moved, d_pos, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            head = first_moved;
+            *identity_prefix = head;
+        }
+        if (w.m > head) HIP_TRY(c, hipMemcpyAsync(src_out + head, c->d_src + head, (size_t)(w.m - head) * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     }
     // icp.setMap(localPointCloud) (Map.cpp:528): rebuild the index from the resident copy
     s = map_build(c, c->d_raw, w.m, w.has_n ? c->d_raw_n3 : nullptr);

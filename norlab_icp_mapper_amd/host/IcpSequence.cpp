@@ -196,6 +196,51 @@ void GpuICPSequence::mapUpdateStaged(const Mat4& correction, float minDist, int 
     check(h, icpmi_map_update_staged(h, correction.data(), minDist, normalsKnn, keep.data(), &appended, &mapSize));
 }
 
+static std::vector<float> scalarRow(const DataPoints& cloud, const std::string& name)
+{
+    const Descriptor& d = cloud.getDescriptorByName(name);
+    const size_t n = cloud.getNbPoints();
+    std::vector<float> out(n);
+    for (size_t i = 0; i < n; ++i) out[i] = d.data[(size_t)d.span * i];
+    return out;
+}
+
+void GpuICPSequence::mapUpdateChain(const DataPoints* input, const Mat4& correction, const std::string& scalarName, const DataPoints& scanDescriptors,
+                                    const Mat4& toSensor, const std::vector<icpmi_map_op>& ops, int nModules, std::vector<int32_t>& src,
+                                    int64_t& prefix, int64_t& mapSize)
+{
+    const size_t n = input ? input->getNbPoints() : stagedPoints;
+    std::vector<float> scalar;
+    if (!scalarName.empty()) scalar = scalarRow(scanDescriptors, scalarName);
+    const float* sp = scalarName.empty() ? nullptr : scalar.data();
+    src.resize((size_t)residentMapSize() + 2 * n + 1);
+    if (input) {
+        const float* normals = nullptr;
+        if (input->descriptorExists("normals") && input->getDescriptorByName("normals").span == 3) normals = input->getDescriptorByName("normals").data.data();
+        check(h, icpmi_map_update_chain(h, input->features.data(), (int64_t)n, normals, sp, toSensor.data(), ops.data(), (int32_t)ops.size(), nModules,
+                                        src.data(), (int64_t)src.size(), &prefix, &mapSize));
+    } else
+        check(h, icpmi_map_update_chain_staged(h, correction.data(), sp, toSensor.data(), ops.data(), (int32_t)ops.size(), nModules, src.data(),
+                                               (int64_t)src.size(), &prefix, &mapSize));
+    src.resize((size_t)mapSize);
+}
+
+void GpuICPSequence::uploadMapScalar(const std::vector<float>& scalar) { check(h, icpmi_set_map_scalar(h, scalar.data(), (int64_t)scalar.size())); }
+
+std::vector<float> GpuICPSequence::downloadMapScalar() const
+{
+    std::vector<float> out((size_t)residentMapSize());
+    if (!out.empty()) check(h, icpmi_get_map_scalar(h, out.data(), (int64_t)out.size()));
+    return out;
+}
+
+int64_t GpuICPSequence::residentMapSize() const
+{
+    int64_t m = 0;
+    check(h, icpmi_get_map(h, nullptr, nullptr, 0, &m));
+    return m;
+}
+
 bool GpuICPSequence::chainNeedsReadingNormals() const
 {
     for (int f = 0; f < cfg.n_outlier; ++f)
@@ -294,6 +339,11 @@ struct AddDescriptorFilter : DataPointsFilter {
 
 struct CutAtDescriptorThresholdFilter : DataPointsFilter {
     std::string name; bool useLargerThan = true; float threshold = 0.f;
+    bool residentOp(icpmi_map_op& op, std::string& scalarName) const override {
+        op = icpmi_map_op{}; op.type = ICPMI_MOP_CUT_SCALAR; op.i = useLargerThan ? 1 : 0; op.f[0] = threshold;
+        scalarName = name;
+        return true;
+    }
     void inPlaceFilter(DataPoints& c) const override {
         const Descriptor& d = c.getDescriptorByName(name);
         const size_t n = c.getNbPoints();
@@ -309,6 +359,10 @@ struct CutAtDescriptorThresholdFilter : DataPointsFilter {
 struct SurfaceNormalFilter : DataPointsFilter {
     icpmi_handle h; int knn = 5;
     int surfaceNormalKnn() const override { return knn; }
+    bool residentOp(icpmi_map_op& op, std::string&) const override {
+        op = icpmi_map_op{}; op.type = ICPMI_MOP_SURFACE_NORMALS; op.i = knn;
+        return knn >= 1 && knn <= 32;
+    }
     void inPlaceFilter(DataPoints& c) const override {
         const size_t n = c.getNbPoints();
         std::vector<float> normals(3 * n);
@@ -339,12 +393,16 @@ struct RandomSamplingFilter : DataPointsFilter {
 struct VoxelGridFilter : DataPointsFilter {
     float maxSize = 0.f; int method = 0; size_t maxPointByNode = 1;
     icpmi_handle h = nullptr;
+    bool residentOp(icpmi_map_op& op, std::string&) const override {
+        op = icpmi_map_op{}; op.type = ICPMI_MOP_VOXEL; op.i = method; op.f[0] = maxSize;
+        return (method == 0 || method == 1) && maxSize > 0.f;
+    }
     void inPlaceFilter(DataPoints& c) const override {
         const size_t n = c.getNbPoints();
         if (n == 0 || !(maxSize > 0.f)) return;
-        if (method == 0 && h) { // first point per voxel: one hash pass on the GPU (same lattice as below)
+        if ((method == 0 || method == 1) && h) { // first / pseudo-random point per voxel: one hash pass on the GPU (same lattice as below)
             std::vector<uint8_t> keep(n, 0);
-            GpuICPSequence::check(h, icpmi_voxel_keep_first(h, c.features.data(), (int64_t)n, maxSize, keep.data()));
+            GpuICPSequence::check(h, icpmi_voxel_keep(h, c.features.data(), (int64_t)n, maxSize, method, keep.data()));
             c.keepOnly(keep);
             return;
         }
@@ -354,7 +412,7 @@ struct VoxelGridFilter : DataPointsFilter {
         std::unordered_map<uint64_t, Cell> cells;
         cells.reserve(n);
         std::vector<uint64_t> keyOf(n);
-        uint64_t rng = 0x2545F4914F6CDD1Dull;
+        auto fmix32 = [](uint32_t v) { v ^= v >> 16; v *= 0x85ebca6bu; v ^= v >> 13; v *= 0xc2b2ae35u; v ^= v >> 16; return v; };
         for (size_t i = 0; i < n; ++i) {
             const float* p = c.col(i);
             uint64_t key = 0;
@@ -366,10 +424,8 @@ struct VoxelGridFilter : DataPointsFilter {
                 Cell& cl = it->second;
                 ++cl.count;
                 for (int r = 0; r < 3; ++r) cl.sum[r] += p[r];
-                if (method == 1) { // reservoir sampling: uniform pick among the cell's points
-                    rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
-                    if (rng % cl.count == 0) cl.pick = i;
-                }
+                // samplingMethod 1 (a random point of the voxel), reproducible: the index with the smallest hash
+                if (method == 1 && fmix32((uint32_t)i) < fmix32((uint32_t)cl.pick)) cl.pick = i;
             }
         }
         if (method == 3) { // medoid: the point closest to the centroid

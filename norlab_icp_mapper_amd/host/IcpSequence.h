@@ -45,6 +45,15 @@ public:
     // Mapper::processInput with the scan staged once on the GPU (icpmi_register_prior / icpmi_map_update_staged)
     Mat4 registerWithPrior(const DataPoints& scanInSensorFrame, const Mat4& prior);
     void mapUpdateStaged(const Mat4& correction, float minDist, int normalsKnn, std::vector<uint8_t>& keep, int64_t& appended, int64_t& mapSize);
+    // Map::updateLocalPointCloud for a whole module chain + post filters on the resident map (icpmi_map_update_chain /
+    // icpmi_map_update_chain_staged when `input` is null: the scan kept by registerWithPrior, moved by `correction`).
+    // src[j] for j >= prefix: provenance of new map point j in [old map ; scan]; the first `prefix` points are untouched.
+    void mapUpdateChain(const DataPoints* inputInMapFrame, const Mat4& correction, const std::string& scalarName, const DataPoints& scanDescriptors,
+                        const Mat4& toSensor, const std::vector<icpmi_map_op>& ops, int nModules, std::vector<int32_t>& src, int64_t& prefix,
+                        int64_t& mapSize);
+    void uploadMapScalar(const std::vector<float>& scalar);   // the tracked scalar descriptor of the resident map
+    std::vector<float> downloadMapScalar() const;
+    int64_t residentMapSize() const;
     bool chainNeedsReadingNormals() const;             // SurfaceNormalOutlierFilter in the chain
     const icpmi_stats& stats() const { return lastStats; }
     const icpmi_config& config() const { return cfg; }
@@ -76,6 +85,9 @@ public:
     virtual void inPlaceFilter(DataPoints& cloud) const = 0;
     // > 0 only for SurfaceNormalDataPointsFilter: lets Map run that post filter on the resident map
     virtual int surfaceNormalKnn() const { return 0; }
+    // true when the filter can run as a step of icpmi_map_update_chain on the resident map: fills `op` and names the
+    // scalar descriptor it reads (empty: none)
+    virtual bool residentOp(icpmi_map_op& op, std::string& scalarName) const { (void)op; (void)scalarName; return false; }
 };
 
 class DataPointsFilters {

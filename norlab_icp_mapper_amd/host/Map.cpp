@@ -205,74 +205,130 @@ DataPoints Map::getLocalPointCloud()
 void Map::syncLocalFromDevice()
 {
     if (!deviceAhead) return;
-    // features and `normals` live on the device; every other descriptor was kept current on the host
+    // features, `normals` and the tracked scalar descriptor live on the device; every other descriptor was kept current on the host
     DataPoints dev;
+    std::vector<float> scalar;
     {
         std::lock_guard<std::mutex> gi(icpMapLock);
         dev = icp.downloadMap();
+        if (!residentScalar.empty()) scalar = icp.downloadMapScalar();
     }
     localPointCloud.features = std::move(dev.features);
     localPointCloud.removeDescriptor("normals");
-    if (dev.descriptorExists("normals")) localPointCloud.addDescriptor("normals", 3, std::move(dev.getDescriptorByName("normals").data));
+    if (residentNormals && dev.descriptorExists("normals")) localPointCloud.addDescriptor("normals", 3, std::move(dev.getDescriptorByName("normals").data));
+    if (!residentScalar.empty()) localPointCloud.addDescriptor(residentScalar, 1, std::move(scalar));
     deviceAhead = false;
 }
 
-bool Map::residentPlan(const DataPoints& input, const DataPointsFilters& postFilters, int& knn, float& minDist) const
+bool Map::residentPlan(const DataPoints& input, const DataPointsFilters& postFilters, ResidentProgram& prog) const
 {
     static const bool enabled = [] { const char* e = std::getenv("NIM_RESIDENT_MAP_UPDATE"); return !e || std::atoi(e) != 0; }();
-    if (!enabled || !is3D || mapperModuleVec.size() != 1) return false;
-    const auto* pd = dynamic_cast<const PointDistanceMapperModule*>(mapperModuleVec.front().get());
-    if (!pd) return false;
-    minDist = pd->minDistNewPoint;
-    knn = 0;
-    if (postFilters.size() == 1) knn = postFilters.filters.front()->surfaceNormalKnn();
-    if (postFilters.size() > 1 || (postFilters.size() == 1 && knn <= 0)) return false;
+    if (!enabled || !is3D || mapperModuleVec.empty()) return false;
+    prog = ResidentProgram{};
+    auto adopt = [&](bool ok, const icpmi_map_op& op, const std::string& name) {
+        if (!ok) return false;
+        if (!name.empty()) {
+            if (!prog.scalarName.empty() && prog.scalarName != name) return false; // the device tracks one scalar descriptor
+            prog.scalarName = name;
+        }
+        prog.ops.push_back(op);
+        return true;
+    };
+    int dynamicAt = -1;
+    for (const auto& module : mapperModuleVec) {
+        icpmi_map_op op{}; std::string name;
+        if (!adopt(module->residentOp(op, name), op, name)) return false;
+        if (op.type == ICPMI_MOP_DYNAMIC_POINTS && dynamicAt < 0) dynamicAt = (int)prog.ops.size() - 1;
+    }
+    prog.nModules = (int)prog.ops.size();
+    for (const auto& filter : postFilters.filters) {
+        icpmi_map_op op{}; std::string name;
+        if (!adopt(filter->residentOp(op, name), op, name)) return false;
+        prog.computesNormals |= op.type == ICPMI_MOP_SURFACE_NORMALS;
+    }
     // a point-to-plane chain needs normals on every map point: only with the SurfaceNormal post filter
-    if (icp.config().minimizer == ICPMI_MIN_POINT_TO_PLANE && knn <= 0) return false;
+    if (icp.config().minimizer == ICPMI_MIN_POINT_TO_PLANE && !prog.computesNormals) return false;
     const bool first = isLocalPointCloudEmpty();
     if (first && icp.hasMap()) return false; // the ICP map is not the local cloud (cells just unloaded)
-    // without the post filter the map's normals must come with the input (or not exist at all)
-    const bool mapHasNormals = !first && (deviceAhead ? true : localPointCloud.descriptorExists("normals"));
-    if (knn <= 0 && !first && mapHasNormals != input.descriptorExists("normals")) return false;
+    const bool inputNormals = input.descriptorExists("normals") && input.getDescriptorByName("normals").span == 3;
+    const bool mapNormals = !first && (deviceAhead ? residentNormals : localPointCloud.descriptorExists("normals"));
+    // without the post filter the map's normals must come with the input (or not exist at all): DataPoints::concatenate's rule
+    if (!prog.computesNormals && !first && mapNormals != inputNormals) return false;
+    // DynamicPointsMapperModule.cpp:38-41 throws on a map without normals: let the host path raise the reference's error
+    if (dynamicAt >= 0 && ((!first && !mapNormals) || (first && dynamicAt > 0 && !inputNormals))) return false;
+    if (!prog.scalarName.empty()) {
+        if (!input.descriptorExists(prog.scalarName) || input.getDescriptorByName(prog.scalarName).span != 1) return false;
+        if (!first) {
+            if (deviceAhead ? residentScalar != prog.scalarName
+                            : (!localPointCloud.descriptorExists(prog.scalarName) || localPointCloud.getDescriptorByName(prog.scalarName).span != 1))
+                return false;
+        }
+    }
     return true;
 }
 
-void Map::adoptResidentResult(const DataPoints& input, const std::vector<uint8_t>& keep, int64_t mapSize, bool first)
+void Map::prepareResidentScalar(const ResidentProgram& prog, bool first)
 {
-    // descriptors other than `normals` stay on the host, with DataPoints::concatenate's rule (only fields both
-    // clouds have survive); the features / normals of localPointCloud are stale until syncLocalFromDevice()
-    if (first) {
-        localPointCloud = input;                                  // PointDistanceMapperModule::createMap
-    } else {
-        std::vector<Descriptor> kept;
-        for (auto& d : localPointCloud.descriptors) {
-            if (d.name == "normals") continue;
-            if (!input.descriptorExists(d.name) || input.getDescriptorByName(d.name).span != d.span) continue;
-            const Descriptor& in = input.getDescriptorByName(d.name);
-            for (size_t i = 0; i < keep.size(); ++i)
-                if (keep[i]) d.data.insert(d.data.end(), in.data.begin() + (size_t)d.span * i, in.data.begin() + (size_t)d.span * (i + 1));
-            kept.push_back(std::move(d));
+    // the host copy is the authority whenever the device does not run ahead: hand it the tracked scalar (icp.setMap carries
+    // features and normals only)
+    if (first || prog.scalarName.empty() || deviceAhead) return;
+    const Descriptor& d = localPointCloud.getDescriptorByName(prog.scalarName);
+    std::vector<float> row(localPointCloud.getNbPoints());
+    for (size_t i = 0; i < row.size(); ++i) row[i] = d.data[(size_t)d.span * i];
+    std::lock_guard<std::mutex> gi(icpMapLock);
+    icp.uploadMapScalar(row);
+}
+
+void Map::adoptResidentResult(const DataPoints& input, const ResidentProgram& prog, const std::vector<int32_t>& src, int64_t prefix,
+                              int64_t mapSize, bool first)
+{
+    // `normals` and the tracked scalar live on the device; every other descriptor follows the provenance vector with
+    // DataPoints::concatenate's rule (only fields both clouds have survive; the first scan brings its own set).  Features,
+    // normals and the scalar of localPointCloud are stale until syncLocalFromDevice().
+    const size_t m0 = first ? 0 : (size_t)residentCount;
+    const bool hadNormals = !first && (deviceAhead ? residentNormals : localPointCloud.descriptorExists("normals"));
+    const bool inputNormals = input.descriptorExists("normals") && input.getDescriptorByName("normals").span == 3;
+    std::vector<Descriptor> next;
+    const std::vector<Descriptor>& fields = first ? input.descriptors : localPointCloud.descriptors;
+    for (const Descriptor& old : fields) {
+        if (old.name == "normals" || old.name == prog.scalarName) continue;
+        if (!input.descriptorExists(old.name) || input.getDescriptorByName(old.name).span != old.span) continue;
+        const Descriptor& in = input.getDescriptorByName(old.name);
+        const size_t span = (size_t)old.span;
+        Descriptor d; d.name = old.name; d.span = old.span;
+        d.data.resize(span * (size_t)mapSize);
+        if (!first && prefix > 0) std::copy(old.data.begin(), old.data.begin() + span * (size_t)prefix, d.data.begin());
+        for (size_t j = first ? 0 : (size_t)prefix; j < (size_t)mapSize; ++j) {
+            const size_t from = (size_t)src[j];
+            const float* row = from < m0 ? &old.data[span * from] : &in.data[span * (from - m0)];
+            std::copy(row, row + span, d.data.begin() + span * j);
         }
-        localPointCloud.descriptors = std::move(kept);
+        next.push_back(std::move(d));
     }
+    localPointCloud.descriptors = std::move(next);
+    residentNormals = prog.computesNormals || (first ? inputNormals : (hadNormals && inputNormals));
+    residentScalar = prog.scalarName;
+    residentCount = mapSize;
     deviceAhead = true;
     ++residentUpdates;
     localPointCloudEmpty.store(mapSize == 0);
     newLocalPointCloudAvailable = true;
 }
 
-bool Map::tryResidentUpdate(const DataPoints& input, const DataPointsFilters& postFilters)
+bool Map::tryResidentUpdate(const DataPoints& input, const Mat4& pose, const DataPointsFilters& postFilters)
 {
-    int knn = 0; float minDist = 0.f;
-    if (!residentPlan(input, postFilters, knn, minDist)) return false;
+    ResidentProgram prog;
+    if (!residentPlan(input, postFilters, prog)) return false;
     const bool first = isLocalPointCloudEmpty();
-    std::vector<uint8_t> keep;
-    int64_t appended = 0, m = 0;
+    if (!deviceAhead) residentCount = (int64_t)localPointCloud.getNbPoints();
+    prepareResidentScalar(prog, first);
+    std::vector<int32_t> src;
+    int64_t prefix = 0, m = 0;
     {
         std::lock_guard<std::mutex> gi(icpMapLock);
-        icp.mapUpdatePointDistance(input, minDist, knn, keep, appended, m);
+        icp.mapUpdateChain(&input, Mat4::identity(), prog.scalarName, input, pose.inverse(), prog.ops, prog.nModules, src, prefix, m);
     }
-    adoptResidentResult(input, keep, m, first);
+    adoptResidentResult(input, prog, src, prefix, m, first);
     return true;
 }
 
@@ -281,30 +337,32 @@ bool Map::canStageScan(const DataPoints& input, const DataPointsFilters& postFil
     // descriptors that rotate with the cloud would have to be transformed along: host path
     if (input.descriptorExists("normals") || input.descriptorExists("observationDirections")) return false;
     std::lock_guard<std::mutex> g(localPointCloudLock);
-    int knn = 0; float minDist = 0.f;
-    return residentPlan(input, postFilters, knn, minDist);
+    ResidentProgram prog;
+    return residentPlan(input, postFilters, prog);
 }
 
-void Map::updateLocalPointCloudStaged(const DataPoints& inputDescriptors, const Mat4& correction, const DataPointsFilters& postFilters)
+void Map::updateLocalPointCloudStaged(const DataPoints& inputDescriptors, const Mat4& correction, const Mat4& pose, const DataPointsFilters& postFilters)
 {
     std::lock_guard<std::mutex> g(localPointCloudLock);
-    int knn = 0; float minDist = 0.f;
-    if (!residentPlan(inputDescriptors, postFilters, knn, minDist)) throw std::logic_error("staged map update is not available for this configuration");
+    ResidentProgram prog;
+    if (!residentPlan(inputDescriptors, postFilters, prog)) throw std::logic_error("staged map update is not available for this configuration");
     const bool first = isLocalPointCloudEmpty();
-    std::vector<uint8_t> keep;
-    int64_t appended = 0, m = 0;
+    if (!deviceAhead) residentCount = (int64_t)localPointCloud.getNbPoints();
+    prepareResidentScalar(prog, first);
+    std::vector<int32_t> src;
+    int64_t prefix = 0, m = 0;
     {
         std::lock_guard<std::mutex> gi(icpMapLock);
-        icp.mapUpdateStaged(correction, minDist, knn, keep, appended, m);
+        icp.mapUpdateChain(nullptr, correction, prog.scalarName, inputDescriptors, pose.inverse(), prog.ops, prog.nModules, src, prefix, m);
     }
-    adoptResidentResult(inputDescriptors, keep, m, first);
+    adoptResidentResult(inputDescriptors, prog, src, prefix, m, first);
 }
 
 void Map::updateLocalPointCloud(DataPoints input, Mat4 pose, DataPointsFilters postFilters)
 {
     std::lock_guard<std::mutex> g(localPointCloudLock);
     if (mapperModuleVec.empty()) throw InvalidParameter("no mapper module configured");
-    if (tryResidentUpdate(input, postFilters)) return;
+    if (tryResidentUpdate(input, pose, postFilters)) return;
     syncLocalFromDevice();
     if (isLocalPointCloudEmpty()) {
         // the first module creates the map, the others update it with the same scan

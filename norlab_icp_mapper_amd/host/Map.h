@@ -64,7 +64,7 @@ public:
     // processInput with the scan staged on the GPU: can this input / post-filter combination be updated on the resident map
     // (see tryResidentUpdate), and the update itself for the scan kept by GpuICPSequence::registerWithPrior
     bool canStageScan(const DataPoints& inputInSensorFrame, const DataPointsFilters& postFilters);
-    void updateLocalPointCloudStaged(const DataPoints& inputDescriptors, const Mat4& correction, const DataPointsFilters& postFilters);
+    void updateLocalPointCloudStaged(const DataPoints& inputDescriptors, const Mat4& correction, const Mat4& pose, const DataPointsFilters& postFilters);
     DataPoints getGlobalPointCloud();                                                     // Map.cpp:552-573
     void setGlobalPointCloud(const DataPoints& cloud);                                    // Map.cpp:575-588
     bool isLocalPointCloudEmpty() const { return localPointCloudEmpty.load(); }
@@ -88,14 +88,21 @@ private:
     void scheduleUpdate(const Update& u);
     void loadCells(Box box);
     void unloadCells(Box box);
-    // Resident fast path (icpmi_map_update_point_distance): chain == [PointDistanceMapperModule], post filters
-    // empty or [SurfaceNormalDataPointsFilter], clouds without other descriptors.  The device copy then runs
-    // ahead of localPointCloud, which is refreshed on the next host-side access.
-    bool tryResidentUpdate(const DataPoints& input, const DataPointsFilters& postFilters);
-    bool residentPlan(const DataPoints& input, const DataPointsFilters& postFilters, int& knn, float& minDist) const; // lock held
-    void adoptResidentResult(const DataPoints& input, const std::vector<uint8_t>& keep, int64_t mapSize, bool first); // lock held
+    // Resident path (icpmi_map_update_chain): every mapper module and every post filter describes itself as a device
+    // step (MapperModule::residentOp / DataPointsFilter::residentOp) -- the three built-in modules, SurfaceNormal and
+    // CutAtDescriptorThreshold do; a plugin that does not sends the update down the host path.  The device copy then
+    // runs ahead of localPointCloud, which is refreshed on the next host-side access.
+    struct ResidentProgram { std::vector<icpmi_map_op> ops; int nModules = 0; std::string scalarName; bool computesNormals = false; };
+    bool tryResidentUpdate(const DataPoints& input, const Mat4& pose, const DataPointsFilters& postFilters);
+    bool residentPlan(const DataPoints& input, const DataPointsFilters& postFilters, ResidentProgram& prog) const; // lock held
+    void prepareResidentScalar(const ResidentProgram& prog, bool first);                                         // lock held
+    void adoptResidentResult(const DataPoints& input, const ResidentProgram& prog, const std::vector<int32_t>& src, int64_t prefix,
+                             int64_t mapSize, bool first);                                                        // lock held
     void syncLocalFromDevice(); // localPointCloudLock held
     bool deviceAhead = false;
+    bool residentNormals = false;      // while deviceAhead: the device map carries `normals`
+    std::string residentScalar;        // ... and this scalar descriptor (empty: none)
+    int64_t residentCount = 0;         // ... and this many points
     std::atomic<long> residentUpdates{0};
 
     float sensorMaxRange = DEFAULT_SENSOR_MAX_RANGE;

@@ -191,7 +191,7 @@ void Mapper::processInput(const DataPoints& filteredInputInSensorFrame, const Ma
             lastTimeMapWasUpdated = timeStamp;
             lastPoseWhereMapWasUpdated = correctedPose;
             if (map.canStageScan(filteredInputInSensorFrame, mapPostFilters))
-                map.updateLocalPointCloudStaged(filteredInputInSensorFrame, bootstrap ? Mat4::identity() : correction, mapPostFilters);
+                map.updateLocalPointCloudStaged(filteredInputInSensorFrame, bootstrap ? Mat4::identity() : correction, correctedPose, mapPostFilters);
             else { // paging in updatePose changed the picture (e.g. the local cloud was emptied): the host path
                 DataPoints inMap = transformation.compute(filteredInputInSensorFrame, estimatedPose);
                 if (!bootstrap) inMap = transformation.compute(inMap, correction);

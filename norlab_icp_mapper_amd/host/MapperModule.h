@@ -22,6 +22,9 @@ public:
     virtual void inPlaceCreateMap(DataPoints& input, const Mat4& pose) = 0;
     virtual DataPoints updateMap(const DataPoints& input, const DataPoints& map, const Mat4& pose) { DataPoints out(map); inPlaceUpdateMap(input, out, pose); return out; }
     virtual void inPlaceUpdateMap(const DataPoints& input, DataPoints& map, const Mat4& pose) = 0;
+    // true when the module can run as a step of icpmi_map_update_chain on the resident map (Map::residentPlan): fills
+    // `op` and names the scalar descriptor it reads / writes (empty: none).  Plugins that keep the default stay on the host path.
+    virtual bool residentOp(icpmi_map_op& op, std::string& scalarName) const { (void)op; (void)scalarName; return false; }
 };
 
 // Keeps the input points whose exact nearest map neighbour (self-match excluded, no radius) is at
@@ -33,6 +36,7 @@ public:
     static std::string description() { return "Create a new map from the first scan. Update the map by adding the scan points that are farther than minDistNewPoint from every map point."; }
     void inPlaceCreateMap(DataPoints&, const Mat4&) override {} // the first scan is the map
     void inPlaceUpdateMap(const DataPoints& input, DataPoints& map, const Mat4& pose) override;
+    bool residentOp(icpmi_map_op& op, std::string&) const override { op = icpmi_map_op{}; op.type = ICPMI_MOP_POINT_DISTANCE; op.f[0] = minDistNewPoint; return true; }
     float minDistNewPoint = 0.03f; // availableParameters default (PointDistanceMapperModule.h:24)
 private:
     icpmi_handle h;
@@ -45,6 +49,7 @@ public:
     static std::string description() { return "Concatenate the scan to the map, then keep one point per octree leaf."; }
     void inPlaceCreateMap(DataPoints& input, const Mat4& pose) override { DataPoints empty = input.createSimilarEmpty(); inPlaceUpdateMap(empty, input, pose); }
     void inPlaceUpdateMap(const DataPoints& input, DataPoints& map, const Mat4& pose) override;
+    bool residentOp(icpmi_map_op& op, std::string& scalarName) const override { return octreeFilter->residentOp(op, scalarName); }
 private:
     std::shared_ptr<DataPointsFilter> octreeFilter;
 };
@@ -58,6 +63,13 @@ public:
     static std::string description() { return "Update the probability of map points to be dynamic from the beams of the scan that see them."; }
     void inPlaceCreateMap(DataPoints&, const Mat4&) override {}
     void inPlaceUpdateMap(const DataPoints& input, DataPoints& map, const Mat4& pose) override;
+    bool residentOp(icpmi_map_op& op, std::string& scalarName) const override {
+        op = icpmi_map_op{}; op.type = ICPMI_MOP_DYNAMIC_POINTS;
+        const float prm[7] = {thresholdDynamic, alpha, beta, beamHalfAngle, epsilonA, epsilonD, sensorMaxRange};
+        for (int r = 0; r < 7; ++r) op.f[r] = prm[r];
+        scalarName = "probabilityDynamic";
+        return true;
+    }
     float thresholdDynamic = 0.6f, alpha = 0.8f, beta = 0.99f, beamHalfAngle = 0.01f, epsilonA = 0.01f, epsilonD = 0.01f, sensorMaxRange = 200.f;
 private:
     icpmi_handle h;

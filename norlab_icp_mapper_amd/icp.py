@@ -376,7 +376,8 @@ class ICPSequence:
                 raise InvalidParameter("unknown map operator " + name)
         return ops
 
-    def mapUpdateChain(self, scan_in_map_frame, modules, post=(), scan_scalar=None, scan_normals=None, to_sensor=None, staged_correction=None):
+    def mapUpdateChain(self, scan_in_map_frame, modules, post=(), scan_scalar=None, scan_normals=None, to_sensor=None, staged_correction=None,
+                       with_prefix=False):
         """Map::updateLocalPointCloud (Map.cpp:502-534) for a whole module chain + post filters on the resident map.
         Returns (src, m): new map point j was point src[j] of [old map ; scan].  With staged_correction the scan is the
         one staged by registerWithPrior (scan_in_map_frame is ignored)."""
@@ -386,13 +387,15 @@ class ICPSequence:
         ss = None if scan_scalar is None else np.ascontiguousarray(scan_scalar, dtype=np.float32)
         Ts = None if to_sensor is None else _T_to_c(to_sensor)
         new_m = C.c_int64(0)
+        head = C.c_int64(0)
+        hp = C.byref(head) if with_prefix else None
         if staged_correction is not None:
             n = self._staged_n
             src = np.empty(m_old.value + 2 * n + 1, dtype=np.int32)
             Tc = _T_to_c(staged_correction)
             self._check(self._lib.icpmi_map_update_chain_staged(self._h, Tc.ctypes.data, None if ss is None else ss.ctypes.data,
                                                                 None if Ts is None else Ts.ctypes.data, ops, len(ops), len(modules),
-                                                                src.ctypes.data, src.shape[0], C.byref(new_m)))
+                                                                src.ctypes.data, src.shape[0], hp, C.byref(new_m)))
         else:
             sc = _f32c(scan_in_map_frame, 4)
             sn = None if scan_normals is None else _f32c(scan_normals, 3)
@@ -400,7 +403,10 @@ class ICPSequence:
             src = np.empty(m_old.value + 2 * n + 1, dtype=np.int32)
             self._check(self._lib.icpmi_map_update_chain(self._h, sc.ctypes.data, n, None if sn is None else sn.ctypes.data,
                                                          None if ss is None else ss.ctypes.data, None if Ts is None else Ts.ctypes.data,
-                                                         ops, len(ops), len(modules), src.ctypes.data, src.shape[0], C.byref(new_m)))
+                                                         ops, len(ops), len(modules), src.ctypes.data, src.shape[0], hp, C.byref(new_m)))
+        if with_prefix:  # the head was not written by the library: it is the identity
+            src[:head.value] = np.arange(head.value, dtype=np.int32)
+            return src[:new_m.value].copy(), int(new_m.value), int(head.value)
         return src[:new_m.value].copy(), int(new_m.value)
 
     def setMapScalar(self, scalar):

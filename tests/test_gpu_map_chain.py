@@ -95,8 +95,12 @@ def test_chain_equals_host_composition(amd, oracle, chain):
     icp = amd.ICPSequence(minimizer=1, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=5, use_differential=0)
     icp.setMap(base, base_n)
     icp.setMapScalar(base_s)
-    src, m = icp.mapUpdateChain(scan, modules, post, scan_scalar=scan_s, to_sensor=to_sensor)
+    src, m, head = icp.mapUpdateChain(scan, modules, post, scan_scalar=scan_s, to_sensor=to_sensor, with_prefix=True)
     pts, nrm, sc, ref_src = host_chain(oracle, base, base_n, base_s, scan, scan_s, to_sensor, modules, post)
+    moved = np.nonzero(ref_src != np.arange(ref_src.shape[0]))[0]
+    assert head == (moved[0] if moved.size else ref_src.shape[0])
+    if chain.startswith("point_distance"):
+        assert head == base.shape[0]            # append-only chain: only the tail is reported
 
     assert m == pts.shape[0]
     assert np.array_equal(src, ref_src)

@@ -285,3 +285,22 @@ def test_bundled_configuration_known_answer(tmp_path):
     assert {"normals", "probabilityDynamic"} <= set(mdesc)
     assert 1000 < mp.shape[0] < 12000
     assert (mdesc["probabilityDynamic"] <= 0.65 + 1e-6).all()
+    # the whole shipped chain (DynamicPoints + Octree modules, normals + probability cut) runs on the resident map
+    # (icpmi_map_update_chain): every scan is one resident update, and the host path (NIM_RESIDENT_MAP_UPDATE=0) builds the
+    # same map -- same points (the decimation and the cut are index / threshold decisions on identical inputs; the
+    # post-filter normals differ in rounding because the host path rotates the map into the sensor frame and back)
+    assert "resident map updates: 3" in out.stdout, out.stdout[-300:]
+    for f in ("map.vtk",):
+        os.replace(os.path.join(tmp, f), os.path.join(tmp, "resident_" + f))
+    out2 = subprocess.run([os.path.join(PKG, "build_map_from_scans_and_trajectory"), tmp, cfg, traj_out], capture_output=True, text=True,
+                          timeout=600, env=dict(os.environ, NIM_RESIDENT_MAP_UPDATE="0"))
+    assert out2.returncode == 0 and "resident map updates: 0" in out2.stdout, out2.stderr + out2.stdout[-300:]
+    hp, hdesc = _read_vtk(os.path.join(tmp, "map.vtk"))
+    assert abs(hp.shape[0] - mp.shape[0]) <= max(3, mp.shape[0] // 200), (hp.shape, mp.shape)
+    if hp.shape[0] == mp.shape[0]:
+        same = np.all(np.abs(hp - mp) < 1e-5, axis=1)
+        assert same.mean() > 0.99
+        dots = np.abs(np.einsum("ij,ij->i", hdesc["normals"][same], mdesc["normals"][same]))
+        assert (dots > 1 - 1e-3).mean() > 0.99
+        assert np.abs(hdesc["probabilityDynamic"][same] - mdesc["probabilityDynamic"][same]).max() < 1e-4
+        assert np.array_equal(hdesc["intensity"][same], mdesc["intensity"][same])    # a host-side descriptor followed the provenance vector
