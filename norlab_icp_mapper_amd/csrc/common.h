@@ -163,6 +163,10 @@ struct icpmi_ctx {
     float*  d_alt_s = nullptr; size_t cap_alt_s = 0;
     int*    d_alt_src = nullptr; size_t cap_alt_src = 0;
     float*  d_stage_s = nullptr; size_t cap_stage_s = 0;
+    // scratch of the map-side operators (hash tables, beam buckets, flags): kept between calls -- a hipMalloc / hipFree
+    // pair costs more than most of the kernels that use them
+    void* scratch[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // the scan of the last icpmi_register_prior, in the map frame by its prior (what Mapper::processInput calls `input`)
     float4* d_scan_map = nullptr; size_t cap_scan_map = 0; int64_t scan_map_n = 0;
     float* d_T16 = nullptr;           // a 4x4 for device-side transforms
@@ -222,6 +226,20 @@ struct DevBuf {
     hipError_t alloc(size_t n) { return hipMalloc((void**)&p, (n ? n : 1) * sizeof(T)); }
     operator T*() const { return p; }
 };
+
+// slot `k` of the operator scratch, at least `count` entries of T (contents undefined)
+template <typename T>
+static inline T* scratch_get(icpmi_ctx* c, int k, size_t count)
+{
+    const size_t need = (count ? count : 1) * sizeof(T);
+    if (need > c->scratch_bytes[k] || !c->scratch[k]) {
+        if (c->scratch[k]) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->scratch[k]); c->scratch[k] = nullptr; c->scratch_bytes[k] = 0; }
+        const size_t want = need + need / 4 + 256;
+        if (hipMalloc(&c->scratch[k], want) != hipSuccess) { c->scratch[k] = nullptr; c->last_error = "out of device memory (operator scratch)"; return nullptr; }
+        c->scratch_bytes[k] = want;
+    }
+    return (T*)c->scratch[k];
+}
 
 // like ensure_cap, but the first `used` entries survive a reallocation
 template <typename T>

@@ -252,20 +252,24 @@ __global__ __launch_bounds__(256) void dyn_beams_kernel(const float4* __restrict
     atomicAdd(&count[key], 1u);
 }
 
+// pass 2: counting-sort scatter; the angles travel with the beam so that a bucket is one contiguous read
 __global__ __launch_bounds__(256) void dyn_scatter_kernel(int64_t n, const unsigned* __restrict__ keys, const unsigned* __restrict__ start,
-                                                          unsigned* __restrict__ fill, unsigned* __restrict__ order)
+                                                          const float2* __restrict__ beam_ang, unsigned* __restrict__ fill,
+                                                          unsigned* __restrict__ order, float2* __restrict__ sorted_ang)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const unsigned key = keys[i];
-    order[start[key] + atomicAdd(&fill[key], 1u)] = (unsigned)i;
+    const unsigned pos = start[key] + atomicAdd(&fill[key], 1u);
+    order[pos] = (unsigned)i;
+    sorted_ang[pos] = beam_ang[i];
 }
 
 struct DynPrm { float threshold_dynamic, alpha, beta, beam_half_angle, epsilon_a, epsilon_d, sensor_max_range; };
 
 __global__ __launch_bounds__(256) void dyn_update_kernel(const float4* __restrict__ map, const float* __restrict__ normals3, int64_t m,
                                                          const float* __restrict__ T, DynGrid g, DynPrm prm,
-                                                         const float4* __restrict__ beam_xyzn, const float2* __restrict__ beam_ang,
+                                                         const float4* __restrict__ beam_xyzn, const float2* __restrict__ sorted_ang,
                                                          const unsigned* __restrict__ start, const unsigned* __restrict__ order,
                                                          float* __restrict__ prob)
 {
@@ -288,11 +292,13 @@ __global__ __launch_bounds__(256) void dyn_update_kernel(const float4* __restric
             if (e < 0 || e >= g.ne || a < 0 || a >= g.na) continue;
             const unsigned k = (unsigned)(e * g.na + a);
             for (unsigned j = start[k]; j < start[k + 1]; ++j) {
-                const int b = (int)order[j];
-                const float2 ang = beam_ang[b];
+                const float2 ang = sorted_ang[j];
                 const float d0 = qe - ang.x, d1 = qa - ang.y;
                 const float d = d0 * d0 + d1 * d1;
-                if (d <= r2 && (d < bd || (d == bd && b < best))) { bd = d; best = b; }
+                if (d <= r2 && d <= bd) { // ties on the angular distance go to the smallest beam index (the bucket order is arbitrary)
+                    const int b = (int)order[j];
+                    if (d < bd || b < best) { bd = d; best = b; }
+                }
             }
         }
     if (best < 0) return; // no beam within 2 * beamHalfAngle
@@ -540,11 +546,11 @@ static icpmi_status voxel_flags_dev(icpmi_ctx* c, const float4* d_in, int64_t n,
     if (n > 0xfffffff0ll) { c->last_error = "voxel_keep: too many points"; return ICPMI_ERR_UNSUPPORTED; }
     unsigned long long cap = 1024;
     while (cap < (unsigned long long)n * 2ull) cap <<= 1;
-    DevBuf<unsigned long long> d_keys; DevBuf<unsigned> d_vals, d_slot, d_lo;
-    HIP_TRY(c, d_keys.alloc((size_t)cap));
-    HIP_TRY(c, d_vals.alloc((size_t)cap));
-    HIP_TRY(c, d_slot.alloc((size_t)n));
-    HIP_TRY(c, d_lo.alloc(4));
+    unsigned long long* d_keys = scratch_get<unsigned long long>(c, 0, (size_t)cap);
+    unsigned* d_vals = scratch_get<unsigned>(c, 1, (size_t)cap);
+    unsigned* d_slot = scratch_get<unsigned>(c, 2, (size_t)n);
+    unsigned* d_lo = scratch_get<unsigned>(c, 3, 4);
+    if (!d_keys || !d_vals || !d_slot || !d_lo) return ICPMI_ERR_HIP;
     HIP_TRY(c, hipMemsetAsync(d_keys, 0xff, (size_t)cap * sizeof(unsigned long long), c->stream));
     HIP_TRY(c, hipMemsetAsync(d_vals, 0xff, (size_t)cap * sizeof(unsigned), c->stream));
     HIP_TRY(c, hipMemsetAsync(d_lo, 0xff, 4 * sizeof(unsigned), c->stream));
@@ -554,7 +560,6 @@ static icpmi_status voxel_flags_dev(icpmi_ctx* c, const float4* d_in, int64_t n,
     hipLaunchKernelGGL(voxel_insert_kernel, dim3(blocks), dim3(256), 0, c->stream, d_in, n, d_lo, edge, method, d_keys, d_vals, cap - 1, d_slot);
     hipLaunchKernelGGL(voxel_keep_kernel<T>, dim3(blocks), dim3(256), 0, c->stream, n, d_vals, d_slot, method, d_keep);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipStreamSynchronize(c->stream)); // the scratch tables die with this scope
     return ICPMI_OK;
 }
 
@@ -584,26 +589,25 @@ static icpmi_status dynpts_dev(icpmi_ctx* c, const icpmi_dynpts_params* prm, con
     const int64_t ncells = (int64_t)g.ne * g.na;
     if (ncells > (1ll << 28)) { c->last_error = "dynamic_points_update: beamHalfAngle too small for the angular grid"; return ICPMI_ERR_UNSUPPORTED; }
     DynPrm dp = {prm->threshold_dynamic, prm->alpha, prm->beta, prm->beam_half_angle, prm->epsilon_a, prm->epsilon_d, prm->sensor_max_range};
-    DevBuf<float4> d_bx; DevBuf<float2> d_ba; DevBuf<unsigned> d_keys, d_start, d_fill, d_order;
-    HIP_TRY(c, d_bx.alloc((size_t)n));
-    HIP_TRY(c, d_ba.alloc((size_t)n));
-    HIP_TRY(c, d_keys.alloc((size_t)n));
-    HIP_TRY(c, d_order.alloc((size_t)n));
-    HIP_TRY(c, d_start.alloc((size_t)ncells + 2));
-    HIP_TRY(c, d_fill.alloc((size_t)ncells));
+    float4* d_bx = scratch_get<float4>(c, 0, (size_t)n);
+    float2* d_ba = scratch_get<float2>(c, 1, (size_t)n);
+    unsigned* d_keys = scratch_get<unsigned>(c, 2, (size_t)n);
+    unsigned* d_order = scratch_get<unsigned>(c, 3, (size_t)n);
+    unsigned* d_start = scratch_get<unsigned>(c, 4, (size_t)ncells + 2);
+    unsigned* d_fill = scratch_get<unsigned>(c, 5, (size_t)ncells);
+    float2* d_sa = scratch_get<float2>(c, 8, (size_t)n);
+    if (!d_bx || !d_ba || !d_keys || !d_order || !d_start || !d_fill || !d_sa) return ICPMI_ERR_HIP;
     HIP_TRY(c, hipMemsetAsync(d_start, 0, ((size_t)ncells + 2) * sizeof(unsigned), c->stream));
     HIP_TRY(c, hipMemsetAsync(d_fill, 0, (size_t)ncells * sizeof(unsigned), c->stream));
     const int nb = (int)((n + 255) / 256), mb = (int)((m + 255) / 256);
     hipLaunchKernelGGL(dyn_beams_kernel, dim3(nb), dim3(256), 0, c->stream, d_in, n, d_T, g, d_bx, d_ba, d_keys, d_start);
     icpmi_status st = device_exclusive_scan(c, d_start, (int)ncells, (unsigned)n);
     if (st == ICPMI_OK) {
-        hipLaunchKernelGGL(dyn_scatter_kernel, dim3(nb), dim3(256), 0, c->stream, n, d_keys, d_start, d_fill, d_order);
-        hipLaunchKernelGGL(dyn_update_kernel, dim3(mb), dim3(256), 0, c->stream, d_map, d_nrm, m, d_T, g, dp, d_bx, d_ba, d_start, d_order, d_prob);
+        hipLaunchKernelGGL(dyn_scatter_kernel, dim3(nb), dim3(256), 0, c->stream, n, d_keys, d_start, d_ba, d_fill, d_order, d_sa);
+        hipLaunchKernelGGL(dyn_update_kernel, dim3(mb), dim3(256), 0, c->stream, d_map, d_nrm, m, d_T, g, dp, d_bx, d_sa, d_start, d_order, d_prob);
     }
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream); // the beam tables die with this scope
     if (st != ICPMI_OK) return st;
-    HIP_TRY(c, e);
+    HIP_TRY(c, hipGetLastError());
     return ICPMI_OK;
 }
 
@@ -838,7 +842,10 @@ __global__ __launch_bounds__(256) void chain_prefix_kernel(const int* __restrict
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool moved = i < m && src[i] != (int)i;
     const unsigned long long b = __ballot(moved);
-    if (b && (threadIdx.x & 63) == 0) atomicMin(first_moved, (unsigned)(i + __ffsll((long long)b) - 1));
+    if (b && (threadIdx.x & 63) == 0) {
+        const unsigned cand = (unsigned)(i + __ffsll((long long)b) - 1);
+        if (cand < __hip_atomic_load(first_moved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(first_moved, cand);
+    }
 }
 
 // CutAtDescriptorThresholdDataPointsFilter: useLargerThan drops v > threshold, else drops v < threshold
@@ -987,9 +994,9 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
         if (m0 > 0 && !had_s) HIP_TRY(c, hipMemsetAsync(c->d_raw_s, 0, (size_t)m0 * sizeof(float), c->stream));
         if (m0 > 0) hipLaunchKernelGGL(chain_iota_kernel, dim3((int)((m0 + 255) / 256)), dim3(256), 0, c->stream, c->d_src, m0);
     }
-    DevBuf<unsigned> d_flag, d_pos;
-    HIP_TRY(c, d_flag.alloc((size_t)(m0 + 2 * n + 2)));
-    HIP_TRY(c, d_pos.alloc((size_t)(m0 + 2 * n + 2)));
+    unsigned* d_flag = scratch_get<unsigned>(c, 6, (size_t)(m0 + 2 * n + 2));
+    unsigned* d_pos = scratch_get<unsigned>(c, 7, (size_t)(m0 + 2 * n + 2));
+    if (!d_flag || !d_pos) return ICPMI_ERR_HIP;
     const int src_base = (int)m0;
     bool created = m0 > 0; // false until the first module has created the map from the scan
 
@@ -1030,8 +1037,7 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
             s = check_rigid(c, to_sensor);
             if (s != ICPMI_OK) break;
             if (!c->d_T16) HIP_TRY(c, hipMalloc((void**)&c->d_T16, 16 * sizeof(float)));
-            HIP_TRY(c, hipMemcpyAsync(c->d_T16, to_sensor, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream)); // the caller's array may be a temporary
+            HIP_TRY(c, hipMemcpyAsync(c->d_T16, to_sensor, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream)); // pageable source: staged before the call returns
             icpmi_dynpts_params prm = {op.f[0], op.f[1], op.f[2], op.f[3], op.f[4], op.f[5], op.f[6]};
             s = dynpts_dev(c, &prm, c->d_T16, d_scan, n, c->d_raw, c->d_raw_n3, w.m, c->d_raw_s);
             break;
