@@ -257,7 +257,7 @@ icpmi_status icpmi_voxel_keep(icpmi_handle h, const float* in4, int64_t n, float
  * has none; scan_normals3 may be NULL (appended points then carry zero normals until a SURFACE_NORMALS step).
  * to_sensor = pose^-1 (sensor <- map; `pose` is the modules' argument, DynamicPointsMapperModule.cpp:51,57; only
  * DYNAMIC_POINTS reads it, may be NULL otherwise); post filters run in the map frame.
- * src_capacity must be >= m_old + 2 n.  identity_prefix (may be NULL): when given, receives the length of the head of
+ * src_capacity must be >= m_old + n_modules * n (every module appends at most the whole scan).  identity_prefix (may be NULL): when given, receives the length of the head of
  * the new map that is the untouched head of the old one (src[j] == j for j < *identity_prefix) and src_out is written
  * from that position on only -- a host that owns further descriptors leaves those rows alone and gathers the rest, and
  * an append-only chain downloads a few kilobytes instead of the whole vector. */

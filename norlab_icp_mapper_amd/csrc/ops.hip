@@ -954,7 +954,7 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
     const int64_t m0 = c->m > 0 ? c->m_raw : 0;
     if (new_m) *new_m = m0;
     if (n_ops < 0 || n_modules < 0 || n_modules > n_ops || (n_ops > 0 && !ops)) { c->last_error = "map_update_chain: bad program"; return ICPMI_ERR_INVALID_ARG; }
-    if (src_out && src_capacity < m0 + 2 * n) { c->last_error = "map_update_chain: src_capacity must be >= m_old + 2 n"; return ICPMI_ERR_INVALID_ARG; }
+    if (src_out && src_capacity < m0 + (int64_t)n_modules * n) { c->last_error = "map_update_chain: src_capacity must be >= m_old + n_modules * n"; return ICPMI_ERR_INVALID_ARG; }
     bool uses_scalar = false;
     for (int i = 0; i < n_ops; ++i) {
         const icpmi_map_op& op = ops[i];
@@ -994,8 +994,9 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
         if (m0 > 0 && !had_s) HIP_TRY(c, hipMemsetAsync(c->d_raw_s, 0, (size_t)m0 * sizeof(float), c->stream));
         if (m0 > 0) hipLaunchKernelGGL(chain_iota_kernel, dim3((int)((m0 + 255) / 256)), dim3(256), 0, c->stream, c->d_src, m0);
     }
-    unsigned* d_flag = scratch_get<unsigned>(c, 6, (size_t)(m0 + 2 * n + 2));
-    unsigned* d_pos = scratch_get<unsigned>(c, 7, (size_t)(m0 + 2 * n + 2));
+    // every module appends at most the whole scan
+    unsigned* d_flag = scratch_get<unsigned>(c, 6, (size_t)(m0 + (int64_t)n_modules * n + 2));
+    unsigned* d_pos = scratch_get<unsigned>(c, 7, (size_t)(m0 + (int64_t)n_modules * n + 2));
     if (!d_flag || !d_pos) return ICPMI_ERR_HIP;
     const int src_base = (int)m0;
     bool created = m0 > 0; // false until the first module has created the map from the scan

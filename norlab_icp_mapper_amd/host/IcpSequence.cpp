@@ -213,7 +213,7 @@ void GpuICPSequence::mapUpdateChain(const DataPoints* input, const Mat4& correct
     std::vector<float> scalar;
     if (!scalarName.empty()) scalar = scalarRow(scanDescriptors, scalarName);
     const float* sp = scalarName.empty() ? nullptr : scalar.data();
-    src.resize((size_t)residentMapSize() + 2 * n + 1);
+    src.resize((size_t)residentMapSize() + (size_t)(nModules > 0 ? nModules : 1) * n + 1);
     if (input) {
         const float* normals = nullptr;
         if (input->descriptorExists("normals") && input->getDescriptorByName("normals").span == 3) normals = input->getDescriptorByName("normals").data.data();

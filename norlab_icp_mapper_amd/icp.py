@@ -391,7 +391,7 @@ class ICPSequence:
         hp = C.byref(head) if with_prefix else None
         if staged_correction is not None:
             n = self._staged_n
-            src = np.empty(m_old.value + 2 * n + 1, dtype=np.int32)
+            src = np.empty(m_old.value + max(1, len(modules)) * n + 1, dtype=np.int32)
             Tc = _T_to_c(staged_correction)
             self._check(self._lib.icpmi_map_update_chain_staged(self._h, Tc.ctypes.data, None if ss is None else ss.ctypes.data,
                                                                 None if Ts is None else Ts.ctypes.data, ops, len(ops), len(modules),
@@ -400,7 +400,7 @@ class ICPSequence:
             sc = _f32c(scan_in_map_frame, 4)
             sn = None if scan_normals is None else _f32c(scan_normals, 3)
             n = sc.shape[0]
-            src = np.empty(m_old.value + 2 * n + 1, dtype=np.int32)
+            src = np.empty(m_old.value + max(1, len(modules)) * n + 1, dtype=np.int32)
             self._check(self._lib.icpmi_map_update_chain(self._h, sc.ctypes.data, n, None if sn is None else sn.ctypes.data,
                                                          None if ss is None else ss.ctypes.data, None if Ts is None else Ts.ctypes.data,
                                                          ops, len(ops), len(modules), src.ctypes.data, src.shape[0], hp, C.byref(new_m)))

@@ -73,6 +73,7 @@ def normals_close(a, b):
 
 
 CHAINS = {
+    "three_appends": ([("voxel", 0.05, 0), ("point_distance", 0.0), ("voxel", 0.02, 1)], []),   # the working map outgrows m + 2 n
     "point_distance": ([("point_distance", 0.25)], []),
     "point_distance+normals": ([("point_distance", 0.25)], [("surface_normals", 8)]),
     "shipped": ([("dynamic_points",) + DYN, ("voxel", 0.3, 1)], [("surface_normals", 10), ("cut_scalar", 0.65, 1)]),
