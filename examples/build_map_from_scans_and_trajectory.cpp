@@ -94,7 +94,8 @@ int main(int argc, char** argv)
         }
         const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         DataPoints map = mapper.getMap();
-        map.save(dataDir + "/map.vtk");
+        const char* binaryEnv = std::getenv("NIM_BINARY_VTK"); // BINARY legacy VTK (big-endian), as libpointmatcher's `binary` save option
+        map.save(dataDir + "/map.vtk", binaryEnv && std::atoi(binaryEnv) != 0);
         if (argc > 3) mapper.getTrajectory().save(argv[3]);
         std::printf("map: %zu points, %zu scans in %.3f s -> %s/map.vtk\n", map.getNbPoints(), scans.size(), secs, dataDir.c_str());
         std::printf("resident map updates: %ld\n", mapper.residentMapUpdates());

@@ -161,7 +161,7 @@ public:
     // ASCII VTK POLYDATA in libpointmatcher's dialect: POINTS / VERTICES / POINT_DATA
     // with SCALARS, VECTORS and NORMALS blocks mapped to descriptors by name
     static DataPoints load(const std::string& path);
-    void save(const std::string& path) const;
+    void save(const std::string& path, bool binary = false) const; // VTK legacy, ASCII (default, as the reference's examples) or BINARY
 };
 
 } // namespace nim

@@ -1,90 +1,203 @@
-// PointCloudIO.cpp -- ASCII VTK reader / writer for the dialect libpointmatcher writes and the
+// PointCloudIO.cpp -- VTK legacy reader / writer for the dialect libpointmatcher writes and the
 // reference's example data uses (examples/data/scans/*.vtk):
-//   # vtk DataFile Version 3.0 / <title> / ASCII / DATASET POLYDATA
-//   POINTS n float, VERTICES n 2n, POINT_DATA n, then SCALARS <name> float [+ LOOKUP_TABLE default],
+//   # vtk DataFile Version 3.0 / <title> / ASCII | BINARY / DATASET POLYDATA
+//   POINTS n float, VERTICES n 2n, POINT_DATA n, then SCALARS <name> float [numComp] [+ LOOKUP_TABLE default],
 //   VECTORS <name> float, NORMALS <name> float.
+// The file is read in one piece and tokenised in place (strtof on a 2.6 MB scan is ~10x faster than the
+// iostream extractors the replay harness used to spend most of its wall time in); BINARY files carry
+// big-endian values, as the format prescribes and libpointmatcher's `binary` save option writes.
 #include "PointCloud.h"
 
+#include <cstdint>
 #include <cstdio>
-#include <fstream>
-#include <sstream>
+#include <cstdlib>
+#include <cstring>
 
 namespace nim {
 
+namespace {
+
+struct Cursor {
+    const char* p; const char* end; const std::string& path;
+    void skipSpace() { while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) ++p; }
+    bool atEnd() { skipSpace(); return p >= end; }
+    std::string word() {
+        skipSpace();
+        const char* b = p;
+        while (p < end && !(*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) ++p;
+        return std::string(b, p);
+    }
+    std::string restOfLine() {
+        const char* b = p;
+        while (p < end && *p != '\n') ++p;
+        std::string s(b, p);
+        if (p < end) ++p;
+        return s;
+    }
+    double number() {
+        skipSpace();
+        if (p >= end) throw std::runtime_error("Unexpected end of file in " + path);
+        char* after = nullptr;
+        const double v = std::strtod(p, &after); // the buffer is NUL terminated
+        if (after == p) throw std::runtime_error("Malformed number in " + path);
+        p = after;
+        return v;
+    }
+    size_t count() { const double v = number(); if (v < 0) throw std::runtime_error("Negative count in " + path); return (size_t)v; }
+    // BINARY payload: exactly one newline separates the header line from the bytes
+    void toPayload() { while (p < end && *p != '\n') ++p; if (p < end) ++p; }
+    const unsigned char* bytes(size_t n) {
+        if ((size_t)(end - p) < n) throw std::runtime_error("Truncated binary section in " + path);
+        const unsigned char* b = (const unsigned char*)p;
+        p += n;
+        return b;
+    }
+};
+
+size_t typeSize(const std::string& t, const std::string& path)
+{
+    if (t == "float" || t == "int" || t == "unsigned_int") return 4;
+    if (t == "double" || t == "long" || t == "unsigned_long" || t == "vtktypeint64") return 8;
+    if (t == "short" || t == "unsigned_short") return 2;
+    if (t == "char" || t == "unsigned_char") return 1;
+    throw std::runtime_error("Unsupported VTK data type " + t + " in " + path);
+}
+
+// one big-endian value of `type` as float
+float beValue(const unsigned char* b, const std::string& type)
+{
+    if (type == "float") { uint32_t u = ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | b[3]; float f; std::memcpy(&f, &u, 4); return f; }
+    if (type == "double") { uint64_t u = 0; for (int i = 0; i < 8; ++i) u = (u << 8) | b[i]; double d; std::memcpy(&d, &u, 8); return (float)d; }
+    if (type == "int") { uint32_t u = ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | b[3]; return (float)(int32_t)u; }
+    if (type == "unsigned_int") { uint32_t u = ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | b[3]; return (float)u; }
+    if (type == "short") return (float)(int16_t)(((uint16_t)b[0] << 8) | b[1]);
+    if (type == "unsigned_short") return (float)(uint16_t)(((uint16_t)b[0] << 8) | b[1]);
+    if (type == "char") return (float)(signed char)b[0];
+    if (type == "unsigned_char") return (float)b[0];
+    uint64_t u = 0; for (int i = 0; i < 8; ++i) u = (u << 8) | b[i];
+    return type == "unsigned_long" ? (float)u : (float)(int64_t)u;
+}
+
+void readValues(Cursor& c, bool binary, const std::string& type, size_t count, float* out, size_t stride, size_t width)
+{
+    // `count` tuples of `width` values; tuple i lands at out + stride * i.  BINARY: the cursor sits on the first payload byte
+    if (binary) {
+        const size_t ts = typeSize(type, c.path);
+        const unsigned char* b = c.bytes(ts * count * width);
+        for (size_t i = 0; i < count; ++i)
+            for (size_t r = 0; r < width; ++r) out[stride * i + r] = beValue(b + ts * (width * i + r), type);
+    } else {
+        for (size_t i = 0; i < count; ++i)
+            for (size_t r = 0; r < width; ++r) out[stride * i + r] = (float)c.number();
+    }
+}
+
+void putBE32(std::vector<unsigned char>& buf, uint32_t u) { buf.push_back(u >> 24); buf.push_back(u >> 16); buf.push_back(u >> 8); buf.push_back(u); }
+void putBEf(std::vector<unsigned char>& buf, float f) { uint32_t u; std::memcpy(&u, &f, 4); putBE32(buf, u); }
+
+} // namespace
+
 DataPoints DataPoints::load(const std::string& path)
 {
-    std::ifstream in(path);
-    if (!in) throw std::runtime_error("Cannot open file " + path);
-    std::string line, word;
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("Cannot open file " + path);
+    std::string text;
+    {
+        std::fseek(f, 0, SEEK_END);
+        const long size = std::ftell(f);
+        std::fseek(f, 0, SEEK_SET);
+        text.resize(size > 0 ? (size_t)size : 0);
+        const size_t got = text.empty() ? 0 : std::fread(&text[0], 1, text.size(), f);
+        std::fclose(f);
+        if (got != text.size()) throw std::runtime_error("Cannot read file " + path);
+    }
+    Cursor c{text.c_str(), text.c_str() + text.size(), path};
+    // header: "# vtk DataFile Version x.y" / title / ASCII | BINARY
+    if (c.restOfLine().compare(0, 5, "# vtk") != 0) throw std::runtime_error("Not a VTK legacy file: " + path);
+    c.restOfLine();
+    const std::string format = c.word();
+    if (format != "ASCII" && format != "BINARY") throw std::runtime_error("VTK format must be ASCII or BINARY in " + path);
+    const bool binary = format == "BINARY";
+
     DataPoints cloud;
     size_t n = 0;
     bool seenPoints = false;
-    while (in >> word) {
-        if (word == "#") { std::getline(in, line); continue; }
-        if (word == "POINTS") {
-            std::string type;
-            in >> n >> type;
+    while (!c.atEnd()) {
+        const std::string word = c.word();
+        if (word == "DATASET") {
+            const std::string kind = c.word();
+            if (kind != "POLYDATA" && kind != "UNSTRUCTURED_GRID") throw std::runtime_error("Unsupported VTK dataset " + kind + " in " + path);
+        } else if (word == "POINTS") {
+            n = c.count();
+            const std::string type = c.word();
             cloud = DataPoints(n);
-            for (size_t i = 0; i < n; ++i) in >> cloud.features[4 * i] >> cloud.features[4 * i + 1] >> cloud.features[4 * i + 2];
+            if (binary) c.toPayload();
+            readValues(c, binary, type, n, cloud.features.data(), 4, 3);
             seenPoints = true;
-        } else if (word == "VERTICES" || word == "LINES" || word == "POLYGONS") {
-            size_t cnt, total;
-            in >> cnt >> total;
-            long long skip;
-            for (size_t i = 0; i < total; ++i) in >> skip;
+        } else if (word == "VERTICES" || word == "LINES" || word == "POLYGONS" || word == "CELLS") {
+            c.count();
+            const size_t total = c.count();
+            if (binary) { c.toPayload(); c.bytes(4 * total); }
+            else for (size_t i = 0; i < total; ++i) c.number();
+        } else if (word == "CELL_TYPES") {
+            const size_t total = c.count();
+            if (binary) { c.toPayload(); c.bytes(4 * total); }
+            else for (size_t i = 0; i < total; ++i) c.number();
         } else if (word == "POINT_DATA") {
-            size_t cnt;
-            in >> cnt;
-            if (cnt != n) throw std::runtime_error("POINT_DATA size mismatch in " + path);
+            if (c.count() != n) throw std::runtime_error("POINT_DATA size mismatch in " + path);
         } else if (word == "SCALARS") {
-            std::string name, type;
-            in >> name >> type;
-            std::getline(in, line); // optional numComp on the same line
+            const std::string name = c.word(), type = c.word();
             int span = 1;
-            { std::istringstream ls(line); int c; if (ls >> c) span = c; }
-            std::streampos pos = in.tellg();
-            in >> word;
-            if (word == "LOOKUP_TABLE") in >> word; else in.seekg(pos);
+            { const std::string rest = c.restOfLine(); const int v = std::atoi(rest.c_str()); if (v > 0) span = v; } // optional numComp
+            // the header line is consumed; an optional "LOOKUP_TABLE <name>" line follows, then the values
+            const char* mark = c.p;
+            if (c.word() == "LOOKUP_TABLE") { c.word(); if (binary) c.toPayload(); } else c.p = mark;
             std::vector<float> data((size_t)span * n);
-            for (auto& v : data) in >> v;
+            readValues(c, binary, type, n, data.data(), (size_t)span, (size_t)span);
             cloud.addDescriptor(name, span, std::move(data));
         } else if (word == "VECTORS" || word == "NORMALS") {
-            std::string name, type;
-            in >> name >> type;
+            const std::string name = c.word(), type = c.word();
             std::vector<float> data(3 * n);
-            for (auto& v : data) in >> v;
+            if (binary) c.toPayload();
+            readValues(c, binary, type, n, data.data(), 3, 3);
             cloud.addDescriptor(name, 3, std::move(data));
-        } else if (word == "vtk" || word == "ASCII" || word == "DATASET" || word == "POLYDATA") {
-            if (word == "vtk") std::getline(in, line);
         } else {
-            // title line and anything else: skip to end of line
-            std::getline(in, line);
+            c.restOfLine(); // anything else (FIELD blocks, comments): skip the line
         }
     }
     if (!seenPoints) throw std::runtime_error("No POINTS section in " + path);
     return cloud;
 }
 
-void DataPoints::save(const std::string& path) const
+void DataPoints::save(const std::string& path, bool binary) const
 {
-    FILE* f = std::fopen(path.c_str(), "w");
+    FILE* f = std::fopen(path.c_str(), "wb");
     if (!f) throw std::runtime_error("Cannot open file " + path + " for writing");
     const size_t n = getNbPoints();
-    std::fprintf(f, "# vtk DataFile Version 3.0\nFile created by norlab_icp_mapper_amd\nASCII\nDATASET POLYDATA\n");
+    std::fprintf(f, "# vtk DataFile Version 3.0\nFile created by norlab_icp_mapper_amd\n%s\nDATASET POLYDATA\n", binary ? "BINARY" : "ASCII");
+    std::vector<unsigned char> buf;
+    auto flush = [&] { if (!buf.empty()) std::fwrite(buf.data(), 1, buf.size(), f); buf.clear(); std::fputc('\n', f); };
     std::fprintf(f, "POINTS %zu float\n", n);
-    for (size_t i = 0; i < n; ++i) std::fprintf(f, "%.9g %.9g %.9g\n", features[4 * i], features[4 * i + 1], features[4 * i + 2]);
+    if (binary) { buf.reserve(12 * n); for (size_t i = 0; i < n; ++i) for (int r = 0; r < 3; ++r) putBEf(buf, features[4 * i + r]); flush(); }
+    else for (size_t i = 0; i < n; ++i) std::fprintf(f, "%.9g %.9g %.9g\n", features[4 * i], features[4 * i + 1], features[4 * i + 2]);
     std::fprintf(f, "VERTICES %zu %zu\n", n, 2 * n);
-    for (size_t i = 0; i < n; ++i) std::fprintf(f, "1 %zu\n", i);
+    if (binary) { buf.reserve(8 * n); for (size_t i = 0; i < n; ++i) { putBE32(buf, 1u); putBE32(buf, (uint32_t)i); } flush(); }
+    else for (size_t i = 0; i < n; ++i) std::fprintf(f, "1 %zu\n", i);
     std::fprintf(f, "POINT_DATA %zu\n", n);
     for (const auto& d : descriptors) {
         if (d.name == "normals" && d.span == 3) std::fprintf(f, "NORMALS %s float\n", d.name.c_str());
         else if (d.span == 3) std::fprintf(f, "VECTORS %s float\n", d.name.c_str());
         else if (d.span == 1) std::fprintf(f, "SCALARS %s float\nLOOKUP_TABLE default\n", d.name.c_str());
         else std::fprintf(f, "SCALARS %s float %d\nLOOKUP_TABLE default\n", d.name.c_str(), d.span);
-        for (size_t i = 0; i < n; ++i) {
-            for (int r = 0; r < d.span; ++r) std::fprintf(f, r ? " %.9g" : "%.9g", d.data[(size_t)d.span * i + r]);
-            std::fprintf(f, "\n");
-        }
+        if (binary) {
+            buf.reserve(4 * d.data.size());
+            for (float v : d.data) putBEf(buf, v);
+            flush();
+        } else
+            for (size_t i = 0; i < n; ++i) {
+                for (int r = 0; r < d.span; ++r) std::fprintf(f, r ? " %.9g" : "%.9g", d.data[(size_t)d.span * i + r]);
+                std::fprintf(f, "\n");
+            }
     }
     std::fclose(f);
 }

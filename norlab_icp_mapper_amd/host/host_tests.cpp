@@ -3,6 +3,7 @@
 // store, 4x4 algebra.  Run by tests/test_host_cpp.py; exits non-zero on the first failure.
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <string>
 
@@ -147,6 +148,28 @@ static void testCloud()
     CHECK(r.getNbPoints() == 10 && r.descriptorExists("intensity") && r.descriptorExists("normals"));
     CHECK(r.features == e.features && r.getDescriptorByName("intensity").data == e.getDescriptorByName("intensity").data);
     CHECK(r.getDescriptorByName("normals").span == 3 && r.getDescriptorByName("normals").data == e.getDescriptorByName("normals").data);
+    // BINARY (big-endian payloads, what libpointmatcher writes with its `binary` save option): bit-exact round trip,
+    // also for a payload that happens to contain newline / space bytes
+    DataPoints bc = e;
+    bc.features[4 * 3 + 0] = 2.3509887e-38f;          // 0x01000000: bytes 01 00 00 00
+    bc.features[4 * 4 + 1] = 6.7272636e-10f;          // contains 0x0a / 0x20 bytes in its pattern
+    { float f; const uint32_t u = 0x0a200a0du; std::memcpy(&f, &u, 4); bc.features[4 * 5 + 2] = f; }
+    std::vector<float> multi(2 * 10);
+    for (size_t i = 0; i < multi.size(); ++i) multi[i] = 0.25f * (float)i;
+    bc.addDescriptor("pair", 2, multi);
+    bc.save(path, /*binary*/ true);
+    const DataPoints rb = DataPoints::load(path);
+    CHECK(rb.getNbPoints() == 10 && rb.features == bc.features);
+    CHECK(rb.getDescriptorByName("intensity").data == bc.getDescriptorByName("intensity").data);
+    CHECK(rb.getDescriptorByName("normals").data == bc.getDescriptorByName("normals").data);
+    CHECK(rb.getDescriptorByName("pair").span == 2 && rb.getDescriptorByName("pair").data == multi);
+    bc.save(path);                                     // and the multi-component scalar through ASCII
+    const DataPoints ra = DataPoints::load(path);
+    CHECK(ra.getDescriptorByName("pair").span == 2 && ra.getDescriptorByName("pair").data == multi && ra.features == bc.features);
+    bool bad = false;
+    { FILE* f = std::fopen(path.c_str(), "wb"); std::fputs("# vtk DataFile Version 3.0\nt\nBINARY\nDATASET POLYDATA\nPOINTS 4 float\nxx", f); std::fclose(f); }
+    try { DataPoints::load(path); } catch (const std::runtime_error&) { bad = true; }
+    CHECK(bad);                                       // truncated payload is an error, not a short read
     std::remove(path.c_str());
 }
 
