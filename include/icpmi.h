@@ -277,6 +277,19 @@ icpmi_status icpmi_map_update_chain_staged(icpmi_handle h, const float correctio
 icpmi_status icpmi_set_map_scalar(icpmi_handle h, const float* scalar, int64_t m);
 icpmi_status icpmi_get_map_scalar(icpmi_handle h, float* scalar_out, int64_t capacity);
 
+/* Input-side filters as ONE pass (`Mapper::applyInputFilters`, Mapper.cpp:187-191: the DistanceLimit radius filter of
+ * Mapper.cpp:27-31 followed by the `input:` chain, e.g. the two BoundingBox filters of examples/config.yaml:2-18): every
+ * filter of these two kinds is a per-point predicate, so a run of them is one fused kernel and one compaction instead
+ * of one pass + one copy of every descriptor per filter.  keep[i] = 1 iff point i passes ALL filters.
+ *   ICPMI_FILT_DISTANCE_LIMIT  i = dim (-1: radial distance, 0..2: |coordinate|), f[0] = dist, f[1] = removeInside (0 | 1):
+ *                              v = dim < 0 ? sqrt(x^2 + y^2 + z^2) : |p[dim]|; kept iff removeInside ? v > |dist| : v < |dist|
+ *   ICPMI_FILT_BOUNDING_BOX    f[0..2] = xMin, yMin, zMin, f[3..5] = xMax, yMax, zMax, i = removeInside:
+ *                              inside iff min < p < max on all three axes; kept iff removeInside ? !inside : inside */
+typedef enum { ICPMI_FILT_DISTANCE_LIMIT = 0, ICPMI_FILT_BOUNDING_BOX = 1 } icpmi_point_filter_type;
+typedef struct icpmi_point_filter { int32_t type; int32_t i; float f[6]; } icpmi_point_filter;
+icpmi_status icpmi_filter_points(icpmi_handle h, const float* in4, int64_t n, const icpmi_point_filter* filters, int32_t n_filters,
+                                 uint8_t* keep);
+
 /* `Map::unloadCells` binning (Map.cpp:206-209,232-235): ijk3[3 i + r] = floor(p_r / cell_size). */
 icpmi_status icpmi_bin_cells(icpmi_handle h, const float* pts4, int64_t n, float cell_size, int32_t* ijk3);
 

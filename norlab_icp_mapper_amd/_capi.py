@@ -68,6 +68,11 @@ class MapOp(C.Structure):
     _fields_ = [("type", C.c_int32), ("i", C.c_int32), ("f", C.c_float * 7)]
 
 
+class PointFilter(C.Structure):
+    """icpmi_point_filter: one DistanceLimit / BoundingBox predicate of the fused input-filter pass."""
+    _fields_ = [("type", C.c_int32), ("i", C.c_int32), ("f", C.c_float * 6)]
+
+
 MOP_POINT_DISTANCE, MOP_DYNAMIC_POINTS, MOP_VOXEL, MOP_SURFACE_NORMALS, MOP_CUT_SCALAR = range(5)
 
 
@@ -95,6 +100,7 @@ SYMBOLS = [
     ("icpmi_surface_normals", C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
     ("icpmi_point_distance_keep", C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_float, _P]),
     ("icpmi_voxel_keep_first", C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),
+    ("icpmi_filter_points", C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, _P]),
     ("icpmi_voxel_keep", C.c_int, [_P, _P, C.c_int64, C.c_float, C.c_int32, _P]),
     ("icpmi_map_update_chain", C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, C.c_int64, _P, _P]),
     ("icpmi_map_update_chain_staged", C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, C.c_int64, _P, _P]),

@@ -516,6 +516,21 @@ icpmi_status icpmi_dynamic_points_update(icpmi_handle h, const icpmi_dynpts_para
     return ops_dynamic_points_update(h, prm, to_sensor, in4, n, map4, map_normals3, m, prob_dynamic);
 }
 
+icpmi_status icpmi_filter_points(icpmi_handle h, const float* in4, int64_t n, const icpmi_point_filter* filters, int32_t n_filters, uint8_t* keep)
+{
+    CHECK_H(h);
+    if (n < 0 || n_filters < 0 || n_filters > ICPMI_MAX_POINT_FILTERS || (n_filters > 0 && !filters) || (n > 0 && (!in4 || !keep))) {
+        h->last_error = "filter_points: bad arguments (at most 16 filters per call)"; return ICPMI_ERR_INVALID_ARG;
+    }
+    for (int32_t k = 0; k < n_filters; ++k) {
+        const icpmi_point_filter& f = filters[k];
+        if ((f.type != ICPMI_FILT_DISTANCE_LIMIT && f.type != ICPMI_FILT_BOUNDING_BOX) || (f.type == ICPMI_FILT_DISTANCE_LIMIT && (f.i < -1 || f.i > 2))) {
+            h->last_error = "InvalidParameter: filter_points: unknown filter or dim outside [-1, 2]"; return ICPMI_ERR_INVALID_ARG;
+        }
+    }
+    return ops_filter_points(h, in4, n, filters, n_filters, keep);
+}
+
 icpmi_status icpmi_bin_cells(icpmi_handle h, const float* pts4, int64_t n, float cell_size, int32_t* ijk3)
 {
     CHECK_H(h);

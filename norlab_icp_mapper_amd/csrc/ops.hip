@@ -122,6 +122,30 @@ __global__ __launch_bounds__(128) void normals_kernel(const float4* __restrict__
     normals3[3 * i] = nx; normals3[3 * i + 1] = ny; normals3[3 * i + 2] = nz;
 }
 
+// ---- fused input filters (Mapper::applyInputFilters): one predicate pass for a run of DistanceLimit / BoundingBox filters ----
+struct FilterPack { icpmi_point_filter f[ICPMI_MAX_POINT_FILTERS]; int n; };
+
+__global__ __launch_bounds__(256) void filter_points_kernel(const float4* __restrict__ in, int64_t n, FilterPack fp, uint8_t* __restrict__ keep)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = in[i];
+    bool ok = true;
+    for (int k = 0; k < fp.n; ++k) {
+        const icpmi_point_filter& f = fp.f[k];
+        if (f.type == ICPMI_FILT_DISTANCE_LIMIT) {
+            // sqrtf of the sum in the oracle's order (no contraction: -ffp-contract=off on both sides)
+            const float v = f.i < 0 ? sqrtf(p.x * p.x + p.y * p.y + p.z * p.z) : fabsf(f.i == 0 ? p.x : (f.i == 1 ? p.y : p.z));
+            const float ad = fabsf(f.f[0]);
+            ok &= f.f[1] != 0.f ? v > ad : v < ad;
+        } else {
+            const bool inside = p.x > f.f[0] && p.x < f.f[3] && p.y > f.f[1] && p.y < f.f[4] && p.z > f.f[2] && p.z < f.f[5];
+            ok &= f.i ? !inside : inside;
+        }
+    }
+    keep[i] = ok ? 1 : 0;
+}
+
 // ---- voxel sub-sample (OctreeMapperModule / OctreeGridDataPointsFilter stand-in, samplingMethod 0) ----
 // lattice anchored at the bounding-box minimum; voxel index floor((p - lo) / edge) per axis, 21 bits
 // each; the representative of a voxel is its point of smallest original index (order independent:
@@ -560,6 +584,23 @@ static icpmi_status voxel_flags_dev(icpmi_ctx* c, const float4* d_in, int64_t n,
     hipLaunchKernelGGL(voxel_insert_kernel, dim3(blocks), dim3(256), 0, c->stream, d_in, n, d_lo, edge, method, d_keys, d_vals, cap - 1, d_slot);
     hipLaunchKernelGGL(voxel_keep_kernel<T>, dim3(blocks), dim3(256), 0, c->stream, n, d_vals, d_slot, method, d_keep);
     HIP_TRY(c, hipGetLastError());
+    return ICPMI_OK;
+}
+
+icpmi_status ops_filter_points(icpmi_ctx* c, const float* in4, int64_t n, const icpmi_point_filter* filters, int n_filters, uint8_t* keep)
+{
+    if (n == 0) return ICPMI_OK;
+    FilterPack fp;
+    fp.n = n_filters;
+    for (int k = 0; k < n_filters; ++k) fp.f[k] = filters[k];
+    if (ensure_cap(c, &c->d_stage_in, &c->cap_stage_in, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    uint8_t* d_keep = scratch_get<uint8_t>(c, 9, (size_t)n);
+    if (!d_keep) return ICPMI_ERR_HIP;
+    HIP_TRY(c, hipMemcpyAsync(c->d_stage_in, in4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(filter_points_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_stage_in, n, fp, d_keep);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(keep, d_keep, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return ICPMI_OK;
 }
 

@@ -1,6 +1,8 @@
 // IcpSequence.cpp -- see IcpSequence.h.
 #include "IcpSequence.h"
 
+#include <cstdlib>
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -299,6 +301,10 @@ namespace {
 
 struct DistanceLimitFilter : DataPointsFilter {
     int dim = -1; float dist = 1.f; bool removeInside = true;
+    bool pointFilter(icpmi_point_filter& f) const override {
+        f = icpmi_point_filter{}; f.type = ICPMI_FILT_DISTANCE_LIMIT; f.i = dim; f.f[0] = dist; f.f[1] = removeInside ? 1.f : 0.f;
+        return dim >= -1 && dim <= 2;
+    }
     void inPlaceFilter(DataPoints& c) const override {
         const size_t n = c.getNbPoints();
         std::vector<uint8_t> keep(n);
@@ -314,6 +320,11 @@ struct DistanceLimitFilter : DataPointsFilter {
 
 struct BoundingBoxFilter : DataPointsFilter {
     float lo[3] = {-1, -1, -1}, hi[3] = {1, 1, 1}; bool removeInside = true;
+    bool pointFilter(icpmi_point_filter& f) const override {
+        f = icpmi_point_filter{}; f.type = ICPMI_FILT_BOUNDING_BOX; f.i = removeInside ? 1 : 0;
+        for (int r = 0; r < 3; ++r) { f.f[r] = lo[r]; f.f[3 + r] = hi[r]; }
+        return true;
+    }
     void inPlaceFilter(DataPoints& c) const override {
         const size_t n = c.getNbPoints();
         std::vector<uint8_t> keep(n);
@@ -516,8 +527,32 @@ std::shared_ptr<DataPointsFilter> createDataPointsFilter(const std::string& name
     throw InvalidParameter("unknown DataPointsFilter " + name);
 }
 
-DataPointsFilters::DataPointsFilters(const yaml::Node& seq, icpmi_handle ctx)
+void DataPointsFilters::apply(DataPoints& cloud, const DataPointsFilter* leading) const
 {
+    static const bool fuse = [] { const char* e = std::getenv("NIM_FUSED_INPUT_FILTERS"); return !e || std::atoi(e) != 0; }();
+    std::vector<const DataPointsFilter*> chain;
+    if (leading) chain.push_back(leading);
+    for (const auto& f : filters) chain.push_back(f.get());
+    size_t i = 0;
+    while (i < chain.size()) {
+        std::vector<icpmi_point_filter> run;
+        icpmi_point_filter pf;
+        while (fuse && ctx && i + run.size() < chain.size() && run.size() < 16 && chain[i + run.size()]->pointFilter(pf)) run.push_back(pf);
+        if (run.size() >= 2 && cloud.getNbPoints() > 0) {
+            std::vector<uint8_t> keep(cloud.getNbPoints());
+            GpuICPSequence::check(ctx, icpmi_filter_points(ctx, cloud.features.data(), (int64_t)cloud.getNbPoints(), run.data(), (int32_t)run.size(), keep.data()));
+            cloud.keepOnly(keep);
+            i += run.size();
+        } else {
+            chain[i]->inPlaceFilter(cloud);
+            ++i;
+        }
+    }
+}
+
+DataPointsFilters::DataPointsFilters(const yaml::Node& seq, icpmi_handle ctx_) : ctx(ctx_)
+{
+    icpmi_handle ctx = ctx_;
     if (!seq) return;
     if (!seq.IsSequence()) throw yaml::Exception("expected a sequence of filters");
     for (const auto& item : seq.seq) {

@@ -88,6 +88,8 @@ public:
     // true when the filter can run as a step of icpmi_map_update_chain on the resident map: fills `op` and names the
     // scalar descriptor it reads (empty: none)
     virtual bool residentOp(icpmi_map_op& op, std::string& scalarName) const { (void)op; (void)scalarName; return false; }
+    // true for per-point predicates (DistanceLimit, BoundingBox): a run of them is one icpmi_filter_points pass
+    virtual bool pointFilter(icpmi_point_filter& f) const { (void)f; return false; }
 };
 
 class DataPointsFilters {
@@ -95,9 +97,12 @@ public:
     DataPointsFilters() = default;
     // a YAML sequence of single-key maps, e.g. the `input:` and `post:` sections (Mapper.cpp:82,92)
     DataPointsFilters(const yaml::Node& seq, icpmi_handle ctx);
-    void apply(DataPoints& cloud) const { for (const auto& f : filters) f->inPlaceFilter(cloud); }
+    // the chain in order; runs of per-point predicates (optionally starting with `leading`, the mapper's radius filter,
+    // Mapper.cpp:187-191) go through one fused GPU pass and one compaction
+    void apply(DataPoints& cloud, const DataPointsFilter* leading = nullptr) const;
     size_t size() const { return filters.size(); }
     std::vector<std::shared_ptr<DataPointsFilter>> filters;
+    icpmi_handle ctx = nullptr;
 };
 
 std::shared_ptr<DataPointsFilter> createDataPointsFilter(const std::string& name, const yaml::Node& params, icpmi_handle ctx);

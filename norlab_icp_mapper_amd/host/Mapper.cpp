@@ -169,8 +169,7 @@ void Mapper::setDefaultMapperModule()
 
 void Mapper::applyInputFilters(DataPoints& inputInSensorFrame)
 {
-    radiusFilter->inPlaceFilter(inputInSensorFrame);
-    inputFilters.apply(inputInSensorFrame);
+    inputFilters.apply(inputInSensorFrame, radiusFilter.get()); // radius filter first, then the `input:` chain
 }
 
 void Mapper::processInput(const DataPoints& filteredInputInSensorFrame, const Mat4& estimatedPose, const TimePoint& timeStamp)

@@ -344,6 +344,25 @@ class ICPSequence:
         self._check(self._lib.icpmi_voxel_keep_first(self._h, c.ctypes.data, c.shape[0], edge, keep.ctypes.data))
         return keep.astype(bool)
 
+    def filterPoints(self, cloud, filters):
+        """Mapper::applyInputFilters as one pass: filters = [("distance_limit", dim, dist, remove_inside) |
+        ("bounding_box", (xmin, ymin, zmin), (xmax, ymax, zmax), remove_inside)]; returns the keep mask."""
+        from . import _capi
+        c = _f32c(cloud, 4)
+        arr = (_capi.PointFilter * max(1, len(filters)))()
+        for k, flt in enumerate(filters):
+            if flt[0] == "distance_limit":
+                arr[k].type = 0; arr[k].i = int(flt[1]); arr[k].f[0] = flt[2]; arr[k].f[1] = 1.0 if flt[3] else 0.0
+            elif flt[0] == "bounding_box":
+                arr[k].type = 1; arr[k].i = 1 if flt[3] else 0
+                for r in range(3):
+                    arr[k].f[r] = flt[1][r]; arr[k].f[3 + r] = flt[2][r]
+            else:
+                raise InvalidParameter("unknown point filter " + str(flt[0]))
+        keep = np.empty(c.shape[0], dtype=np.uint8)
+        self._check(self._lib.icpmi_filter_points(self._h, c.ctypes.data, c.shape[0], arr, len(filters), keep.ctypes.data))
+        return keep.astype(bool)
+
     def voxelKeep(self, cloud, edge, method=0):
         """Same lattice, representative by `samplingMethod`: 0 first point, 1 pseudo-random point (smallest fmix32 of the index)."""
         c = _f32c(cloud, 4)

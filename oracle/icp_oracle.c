@@ -1047,3 +1047,27 @@ void orc_dynamic_points_update(const float prm[7], const float* to_sensor, const
     }
     free(bx); free(be); free(ba);
 }
+
+/* Mapper::applyInputFilters for DistanceLimit / BoundingBox filters (Mapper.cpp:27-31, examples/config.yaml:2-18):
+ * filters = n_filters rows of 8 floats {type, i, f0..f5} (type 0 distance limit: i = dim, f0 = dist, f1 = removeInside;
+ * type 1 bounding box: f0..2 = min, f3..5 = max, i = removeInside). keep[i] = 1 iff every filter keeps point i. */
+void orc_filter_points(const float* in4, int64_t n, const float* filters, int n_filters, uint8_t* keep)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        const float* p = in4 + 4 * i;
+        int ok = 1;
+        for (int k = 0; k < n_filters; ++k) {
+            const float* f = filters + 8 * k;
+            if ((int)f[0] == 0) {
+                const int dim = (int)f[1];
+                const float v = dim < 0 ? sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) : fabsf(p[dim]);
+                const float ad = fabsf(f[2]);
+                ok &= f[3] != 0.f ? v > ad : v < ad;
+            } else {
+                const int inside = p[0] > f[2] && p[0] < f[5] && p[1] > f[3] && p[1] < f[6] && p[2] > f[4] && p[2] < f[7];
+                ok &= (int)f[1] ? !inside : inside;
+            }
+        }
+        keep[i] = (uint8_t)ok;
+    }
+}

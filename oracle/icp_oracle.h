@@ -151,6 +151,7 @@ void orc_cell_ids(const float* pts4, int64_t n, float cell_size, int32_t* ijk3);
 /* lattice stand-in of OctreeGridDataPointsFilter{maxSizeByNode: edge, samplingMethod: 0} (OctreeMapperModule.cpp:35-39):
  * keep[i] = 1 iff i is the first point of its voxel floor((p - bbox_min) / edge) */
 void orc_voxel_keep_first(const float* in4, int64_t n, float edge, uint8_t* keep);
+void orc_filter_points(const float* in4, int64_t n, const float* filters, int n_filters, uint8_t* keep);
 void orc_voxel_keep(const float* in4, int64_t n, float edge, int method, uint8_t* keep);
 /* DynamicPointsMapperModule::inPlaceUpdateMap (DynamicPointsMapperModule.cpp:34-172).  prm = {thresholdDynamic, alpha,
  * beta, beamHalfAngle, epsilonA, epsilonD, sensorMaxRange}; to_sensor = pose^-1 (col-major); prob updated in place. */

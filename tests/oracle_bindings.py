@@ -71,6 +71,7 @@ def load():
     lib.orc_point_distance_keep.argtypes = [_P, C.c_int64, _P, C.c_int64, C.c_float, _P, C.c_int]
     lib.orc_cell_ids.argtypes = [_P, C.c_int64, C.c_float, _P]
     lib.orc_voxel_keep_first.argtypes = [_P, C.c_int64, C.c_float, _P]
+    lib.orc_filter_points.argtypes = [_P, C.c_int64, _P, C.c_int, _P]
     lib.orc_voxel_keep.argtypes = [_P, C.c_int64, C.c_float, C.c_int, _P]
     lib.orc_dynamic_points_update.argtypes = [_P, _P, _P, C.c_int64, _P, _P, C.c_int64, _P, C.c_int]
     _lib = lib
@@ -217,6 +218,19 @@ def cell_ids(cloud, cell_size=20.0):
 def voxel_keep_first(cloud, edge):
     lib = load(); c = _f32(cloud); keep = np.zeros(c.shape[0], dtype=np.uint8)
     lib.orc_voxel_keep_first(c.ctypes.data, c.shape[0], edge, keep.ctypes.data)
+    return keep.astype(bool)
+
+
+def filter_points(cloud, filters):
+    """filters as ICPSequence.filterPoints takes them"""
+    lib = load(); c = _f32(cloud); keep = np.zeros(c.shape[0], dtype=np.uint8)
+    rows = np.zeros((max(1, len(filters)), 8), dtype=np.float32)
+    for k, f in enumerate(filters):
+        if f[0] == "distance_limit":
+            rows[k] = [0, f[1], f[2], 1.0 if f[3] else 0.0, 0, 0, 0, 0]
+        else:
+            rows[k] = [1, 1.0 if f[3] else 0.0, *f[1], *f[2]]
+    lib.orc_filter_points(c.ctypes.data, c.shape[0], rows.ctypes.data, len(filters), keep.ctypes.data)
     return keep.astype(bool)
 
 

@@ -627,3 +627,24 @@ def test_sharded_mapping_example_over_rccl(tmp_path):
                           "--scan-points", "8000", "--epochs", "2"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "epoch 1:" in out.stdout and "scans/s" in out.stdout
+
+
+def test_fused_input_filters_bit_exact(amd, oracle, mid_scene):
+    """icpmi_filter_points (Mapper::applyInputFilters as one pass) against the oracle's predicates, same keep mask."""
+    rng = np.random.default_rng(21)
+    c = mid_scene["scan"].copy()
+    c[:200, :3] = rng.uniform(-2, 2, (200, 3)).astype(np.float32)           # points inside the robot-body boxes
+    c[200, :3] = (0.5, 0.0, 0.0)                                            # on a face
+    c[201, :3] = np.nan                                                     # NaN fails every comparison alike
+    icp = amd.ICPSequence(minimizer=0)
+    shipped = [("distance_limit", -1, 40.0, False), ("bounding_box", (-1.5, -1, -1), (0.5, 1, 0.5), True),
+               ("bounding_box", (-6, -2.5, -1), (-1.5, 2.5, 1), True)]
+    for filters in (shipped, [("distance_limit", 1, 12.5, True)], [("bounding_box", (-30, -30, 0.5), (30, 30, 9), False)] * 16, []):
+        got = icp.filterPoints(c, filters)
+        assert np.array_equal(got, oracle.filter_points(c, filters))
+    assert 0 < icp.filterPoints(c, shipped).sum() < c.shape[0]
+    assert icp.filterPoints(c[:0], shipped).shape == (0,)
+    with pytest.raises(amd.InvalidParameter):
+        icp.filterPoints(c, [("distance_limit", 3, 1.0, False)])
+    with pytest.raises(amd.InvalidParameter):
+        icp.filterPoints(c, [("distance_limit", -1, 1.0, False)] * 17)

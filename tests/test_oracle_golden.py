@@ -206,3 +206,45 @@ def test_voxel_keep_first(oracle):
         key = (ijk[:, 0] * 2097152 + ijk[:, 1]) * 2097152 + ijk[:, 2]
         _, first = np.unique(key, return_index=True)
         assert np.array_equal(np.flatnonzero(keep), np.sort(first))
+
+
+def test_voxel_keep_pseudo_random_representative(oracle):
+    """samplingMethod 1 made reproducible: the point whose index has the smallest fmix32 represents its voxel."""
+    rng = np.random.default_rng(12)
+    c = np.ones((4000, 4), dtype=np.float32)
+    c[:, :3] = rng.uniform(-3, 3, (4000, 3)).astype(np.float32)
+
+    def fmix32(h):
+        h = np.asarray(h, dtype=np.uint64)
+        h ^= h >> np.uint64(16); h = (h * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)
+        h ^= h >> np.uint64(13); h = (h * np.uint64(0xC2B2AE35)) & np.uint64(0xFFFFFFFF)
+        h ^= h >> np.uint64(16)
+        return h
+    keep = oracle.voxel_keep(c, 0.75, 1)
+    lo = c[:, :3].min(0)
+    ijk = np.floor((c[:, :3] - lo) / np.float32(0.75)).astype(np.int64)
+    key = (ijk[:, 0] * 2097152 + ijk[:, 1]) * 2097152 + ijk[:, 2]
+    h = fmix32(np.arange(4000))
+    order = np.lexsort((h, key))
+    first = order[np.r_[True, key[order][1:] != key[order][:-1]]]
+    assert np.array_equal(np.flatnonzero(keep), np.sort(first))
+    assert keep.sum() == oracle.voxel_keep(c, 0.75, 0).sum()        # same voxels, other representatives
+
+
+def test_filter_points_against_numpy(oracle):
+    """DistanceLimit / BoundingBox predicates (Mapper.cpp:27-31, examples/config.yaml:2-18)."""
+    rng = np.random.default_rng(13)
+    c = np.ones((5000, 4), dtype=np.float32)
+    c[:, :3] = rng.uniform(-8, 8, (5000, 3)).astype(np.float32)
+    c[0, :3] = (0.5, 0.0, 0.0); c[1, :3] = (-1.5, 0.2, 0.1)          # exactly on a box face: strict comparisons keep them outside
+    filters = [("distance_limit", -1, 7.5, False), ("bounding_box", (-1.5, -1, -1), (0.5, 1, 0.5), True),
+               ("bounding_box", (-6, -2.5, -1), (-1.5, 2.5, 1), True), ("distance_limit", 2, -6.0, False)]
+    keep = oracle.filter_points(c, filters)
+    x, y, z = c[:, 0], c[:, 1], c[:, 2]
+    r = np.sqrt(x * x + y * y + z * z, dtype=np.float32)
+    in1 = (x > -1.5) & (x < 0.5) & (y > -1) & (y < 1) & (z > -1) & (z < 0.5)
+    in2 = (x > -6) & (x < -1.5) & (y > -2.5) & (y < 2.5) & (z > -1) & (z < 1)
+    ref = (r < 7.5) & ~in1 & ~in2 & (np.abs(z) < 6.0)
+    assert np.array_equal(keep, ref) and keep[0] and keep[1]
+    assert np.array_equal(oracle.filter_points(c, [("distance_limit", 0, 3.0, True)]), np.abs(x) > 3.0)
+    assert oracle.filter_points(c, []).all()
