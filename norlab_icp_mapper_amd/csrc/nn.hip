@@ -898,10 +898,10 @@ __global__ __launch_bounds__(NN_BLOCK) void nnk_ml_kernel(const float4* __restri
 // boundary is queued and redone by the ring-search kernel.  Results go to row `original index` of out_sidx.
 // ------------------------------------------------------------------------------------------------
 // One wave per workgroup: a 4-cell segment holds ~40 queries, so wider workgroups would idle most of their lanes.
-constexpr int SELF_SEG = 4, SELF_CH = 768, SELF_BLOCK = 64;
+constexpr int SELF_SEG = 4, SELF_CH = 384, SELF_BLOCK = 64;
 
 template <int KMAX>
-__global__ __launch_bounds__(SELF_BLOCK) void nnk_self_tiled_kernel(GridParams g, const float4* __restrict__ map,
+__global__ __launch_bounds__(SELF_BLOCK) __attribute__((amdgpu_waves_per_eu(KMAX <= 10 ? 5 : 1))) void nnk_self_tiled_kernel(GridParams g, const float4* __restrict__ map,
                                                                   const unsigned* __restrict__ cs, int k, int* __restrict__ out_sidx,
                                                                   float* __restrict__ out_d2, IcpState* __restrict__ st,
                                                                   unsigned* __restrict__ queue)
@@ -928,11 +928,30 @@ __global__ __launch_bounds__(SELF_BLOCK) void nnk_self_tiled_kernel(GridParams g
         for (int i = 1; i <= 9; ++i) run_p[i] += run_p[i - 1];
     }
     __syncthreads();
+    // a query only needs the cells x-1 .. x+1 of every run (its own 3x3x3 block): flat offsets of the cell boundaries of
+    // every run, and the boundaries of the query cells themselves
+    __shared__ unsigned cell_off[9][SELF_SEG + 3], qb[SELF_SEG + 1];
+    if (threadIdx.x < 9 * (SELF_SEG + 3)) {
+        const int r = (int)threadIdx.x / (SELF_SEG + 3), j = (int)threadIdx.x % (SELF_SEG + 3);
+        const int yy = y + r % 3 - 1, zz = z + r / 3 - 1;
+        unsigned off = run_p[r];
+        if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
+            const int lo = max(x0 - 1, 0), hi = min(x1, g.nx - 1) + 1; // the run's own extent, as row_run clipped it
+            const int xx = min(max(x0 - 1 + j, lo), hi);
+            off = run_p[r] + (cs[(zz * g.ny + yy) * g.nx + xx] - run_s[r]);
+        }
+        cell_off[r][j] = off;
+    }
+    if (threadIdx.x <= SELF_SEG) qb[threadIdx.x] = cs[qbase + min(x0 + (int)threadIdx.x, x1)];
+    __syncthreads();
     const unsigned ncand = run_p[9];
     for (unsigned q0 = qs; q0 < qe; q0 += SELF_BLOCK) { // one wave of queries at a time (one pass for all but dense cells)
         const unsigned qi = q0 + threadIdx.x;
         const bool active = qi < qe;
         const float4 me = map[active ? qi : qs];
+        int cxl = 0; // the query's cell within the segment
+#pragma unroll
+        for (int j = 1; j < SELF_SEG; ++j) cxl += qi >= qb[j] ? 1 : 0;
         KList<KMAX> L; L.init(k);
         for (unsigned c0 = 0; c0 < ncand; c0 += SELF_CH) {
             const unsigned cn = min((unsigned)SELF_CH, ncand - c0);
@@ -946,10 +965,13 @@ __global__ __launch_bounds__(SELF_BLOCK) void nnk_self_tiled_kernel(GridParams g
             }
             __syncthreads();
             if (active) {
-                for (unsigned i = 0; i < cn; ++i) {
-                    const float4 q = tile[i];
-                    const float d2 = sqdist3(me.x, me.y, me.z, q.x, q.y, q.z);
-                    L.insert(pack_key(d2, __float_as_uint(q.w)), (int)(c0 + i)); // flat index; turned into a map position below
+                for (int r = 0; r < 9; ++r) {
+                    const unsigned lo = max(cell_off[r][cxl], c0), hi = min(cell_off[r][cxl + 3], c0 + cn);
+                    for (unsigned i = lo; i < hi; ++i) {
+                        const float4 q = tile[i - c0];
+                        const float d2 = sqdist3(me.x, me.y, me.z, q.x, q.y, q.z);
+                        L.insert(pack_key(d2, __float_as_uint(q.w)), (int)i); // flat index; turned into a map position below
+                    }
                 }
             }
         }
@@ -1148,6 +1170,8 @@ icpmi_status nn_self_knn(icpmi_ctx* c, const LoopCfg& lc, int* d_sidx, float* d_
 {
     if (lc.k <= 4) return nn_self_knn_t<4>(c, lc, d_sidx, d_d2, d_state);
     if (lc.k <= 8) return nn_self_knn_t<8>(c, lc, d_sidx, d_d2, d_state);
+    // knn 10 is the shipped post filter (examples/config.yaml:26-27): a list of exactly 10 inserts less often and cheaper than one of 16
+    if (lc.k <= 10) return nn_self_knn_t<10>(c, lc, d_sidx, d_d2, d_state);
     if (lc.k <= 16) return nn_self_knn_t<16>(c, lc, d_sidx, d_d2, d_state);
     if (lc.k <= 32) return nn_self_knn_t<32>(c, lc, d_sidx, d_d2, d_state);
     c->last_error = "knn > 32 is not supported";
