@@ -1135,6 +1135,7 @@ icpmi_status nn_launch_k(icpmi_ctx* c, const float4* d_reading, int64_t n, const
 {
     if (lc.k == 1) return nn_launch_k1(c, d_reading, n, d_T, lc, allow_self, d_sidx, d_d2, d_state);
     if (lc.k <= 4) return nnk_launch_t<4>(c, d_reading, n, d_T, lc, allow_self, d_sidx, d_d2, d_state);
+    if (lc.k <= 6) return nnk_launch_t<6>(c, d_reading, n, d_T, lc, allow_self, d_sidx, d_d2, d_state); // knn 6: the documented chain
     if (lc.k <= 8) return nnk_launch_t<8>(c, d_reading, n, d_T, lc, allow_self, d_sidx, d_d2, d_state);
     if (lc.k <= 16) return nnk_launch_t<16>(c, d_reading, n, d_T, lc, allow_self, d_sidx, d_d2, d_state);
     if (lc.k <= 32) return nnk_launch_t<32>(c, d_reading, n, d_T, lc, allow_self, d_sidx, d_d2, d_state);
