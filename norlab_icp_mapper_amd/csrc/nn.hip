@@ -15,6 +15,10 @@
 namespace {
 
 constexpr int NN_BLOCK = 256;
+#ifndef ICPMI_NN1_BLOCK
+#define ICPMI_NN1_BLOCK 128
+#endif
+constexpr int NN1_BLOCK = ICPMI_NN1_BLOCK; // workgroup of the k = 1 pyramid kernel
 
 struct Cand {
     unsigned long long key; // (d2 bits << 32) | original index
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(256) void ids_kernel(const float4* __restrict__ map
 #define NN_TICK(i) do { } while (0)
 #endif
 template <int G, int NB>
-__global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restrict__ queries, const int* __restrict__ qindex, int n,
+__global__ __launch_bounds__(NN1_BLOCK) void nn1_ml_kernel(const float4* __restrict__ queries, const int* __restrict__ qindex, int n,
                                                           const float* __restrict__ Tptr, GridLevels L, float maxr2,
                                                           int allow_self_i, int* __restrict__ out_sidx,
                                                           float* __restrict__ out_d2, IcpState* __restrict__ st,
@@ -343,9 +347,9 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restri
     // level-0 histogram of the quantile selection (top 8 bits of the d^2 pattern), per workgroup in LDS
     __shared__ unsigned lh[256];
     if (hist0) {
-        lh[threadIdx.x] = 0; // visible after the barrier below
+        for (int t = threadIdx.x; t < 256; t += NN1_BLOCK) lh[t] = 0; // visible after the barrier below
         // the builder of level 0 clears level 1 of the previous iteration (loop.hip, fused selection)
-        for (int gt = blockIdx.x * NN_BLOCK + threadIdx.x; gt < 256 + 65536; gt += gridDim.x * NN_BLOCK) hist0[ICPMI_S2_C1 + gt] = 0;
+        for (int gt = blockIdx.x * NN1_BLOCK + threadIdx.x; gt < 256 + 65536; gt += gridDim.x * NN1_BLOCK) hist0[ICPMI_S2_C1 + gt] = 0;
     }
     const bool allow_self = allow_self_i != 0;
     // XCD-aware order: workgroup b runs on XCD b % 8 (observed placement, used for speed only), so
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restri
     // (~1/8 of the cells) resident in that XCD's private 4 MiB L2.  The grid is padded to 8 * chunk.
     const int chunk = gridDim.x >> 3;
     const int lb = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    const int tid = lb * NN_BLOCK + threadIdx.x;
+    const int tid = lb * NN1_BLOCK + threadIdx.x;
     const int qi = tid / G;
     const int sub = tid % G;
     const bool active = qi < n;
@@ -612,7 +616,8 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_ml_kernel(const float4* __restri
     }
     if (hist0) {
         __syncthreads();
-        if (lh[threadIdx.x]) atomicAdd(&hist0[ICPMI_S2_C0 + (blockIdx.x % ICPMI_S2_COPIES) * 256 + threadIdx.x], lh[threadIdx.x]);
+        for (int t = threadIdx.x; t < 256; t += NN1_BLOCK)
+            if (lh[t]) atomicAdd(&hist0[ICPMI_S2_C0 + (blockIdx.x % ICPMI_S2_COPIES) * 256 + t], lh[t]);
     }
 #ifdef ICPMI_NN_TIMING
     NN_TICK(5);
@@ -1062,7 +1067,7 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
         float4* mp = (needs_hard || !sorted) ? nullptr : c->nn_match_pt;
         c->nn_out_sorted = mp != nullptr;
 #define LAUNCH_ML(G_, NB_)                                                                                                      \
-    hipLaunchKernelGGL((nn1_ml_kernel<G_, NB_>), dim3((int)(((n * G_ + NN_BLOCK - 1) / NN_BLOCK + 7) / 8 * 8)), dim3(NN_BLOCK), 0,  \
+    hipLaunchKernelGGL((nn1_ml_kernel<G_, NB_>), dim3((int)(((n * G_ + NN1_BLOCK - 1) / NN1_BLOCK + 7) / 8 * 8)), dim3(NN1_BLOCK), 0,  \
                        c->stream, q, qi, (int)n, d_T, c->levels, lc.maxr2, allow_self, d_sidx, d_d2, d_state, c->d_hard, h0, mp,  \
                        c->d_lvl_tab, unseeded_lev)
         // iterations > 0 are seeded by the previous match (a handful of candidates per query): fewer
