@@ -15,6 +15,12 @@ for rep in range(6):
         if i % 4 == 0:
             icp.surfaceNormals(sc["map"][:50_000], knn=10); icp.pointDistanceKeep(sc["map"], sc["scan"], 0.1); icp.voxelKeepFirst(sc["map"], 0.2)
             icp.mapUpdatePointDistance(sc["scan"], 0.1, normals_knn=5); icp.registerWithPrior(sc["scan"], np.eye(4)); icp.mapUpdateStaged(np.eye(4), 0.1)
+        if i % 8 == 0:   # the resident chain (scratch arena, ping-pong set, scalar channel) and the fused input filters
+            prob = np.full(sc["scan"].shape[0], 0.6, np.float32)
+            icp.setMapScalar(np.full(icp.getMap().shape[0], 0.6, np.float32))
+            icp.mapUpdateChain(sc["scan"], [("dynamic_points", 0.9, 0.8, 0.99, 0.01, 0.01, 0.01, 200.0), ("voxel", 0.15, 1)],
+                               [("surface_normals", 10), ("cut_scalar", 0.65, 1)], scan_scalar=prob, to_sensor=np.eye(4))
+            icp.filterPoints(sc["scan"], [("distance_limit", -1, 40.0, False), ("bounding_box", (-1, -1, -1), (1, 1, 1), True)])
         icp.close()
     f = free_mb()
     if base is None: base = f
