@@ -332,7 +332,7 @@ __global__ __launch_bounds__(NN1_BLOCK) void nn1_ml_kernel(const float4* __restr
                                                           float* __restrict__ out_d2, IcpState* __restrict__ st,
                                                           unsigned* __restrict__ hard, unsigned* __restrict__ hist0,
                                                           float4* __restrict__ match_pt, const uint4* __restrict__ ltab_g,
-                                                          int unseeded_lev)
+                                                          int unseeded_lev, int seed_pre)
 {
     static_assert(G == 2 || G == 4 || G == 8 || G == 16, "lanes per query");
     constexpr int NR = (9 + G - 1) / G; // rows owned per lane: row rr belongs to lane rr % G, slot rr / G
@@ -424,6 +424,11 @@ __global__ __launch_bounds__(NN1_BLOCK) void nn1_ml_kernel(const float4* __restr
         }
     }
     // lanes of a group agree on the starting level and radius (same inputs)
+    // A seed too wide for level 0 (the first solve moved the reading by the whole initial misalignment): the query
+    // itself is usually close to the surface by now, so start at level 0 after all and let the own-row scan tighten
+    // the bound first; the seed still bounds whatever that scan finds.
+    bool widepre = false;
+    if (seed_pre && lev0 > 0 && best.key != ~0ull) { widepre = true; lev0 = 0; }
     NN_TICK(1);
 
     // The search itself runs with PER-LANE levels (groups of one wave work on different levels in
@@ -454,7 +459,7 @@ __global__ __launch_bounds__(NN1_BLOCK) void nn1_ml_kernel(const float4* __restr
         //     the answer from above; a query that holds none first scans the x-row through its own cell
         //     (~1/9 of the block) to get one.  Rows / cells the ball of that radius cannot reach are then
         //     skipped -- every point within the bound is still scanned, so the block minimum is exact.
-        if (best.key == ~0ull) {
+        if (best.key == ~0ull || (widepre && lev == 0)) {
             unsigned s, e;
             row_run(g, cs, cx - 1, cx + 1, cy, cz, s, e);
             for (unsigned i0 = s + (unsigned)sub; i0 < e; i0 += (unsigned)(G * NB)) {
@@ -1066,10 +1071,12 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
         // order, so chains that may need it stay on original indices
         float4* mp = (needs_hard || !sorted) ? nullptr : c->nn_match_pt;
         c->nn_out_sorted = mp != nullptr;
+        static int seed_pre_cfg = -1;
+        if (seed_pre_cfg < 0) { const char* e = getenv("ICPMI_NN_SEED_PRE"); seed_pre_cfg = e ? atoi(e) : 2; }
 #define LAUNCH_ML(G_, NB_)                                                                                                      \
     hipLaunchKernelGGL((nn1_ml_kernel<G_, NB_>), dim3((int)(((n * G_ + NN1_BLOCK - 1) / NN1_BLOCK + 7) / 8 * 8)), dim3(NN1_BLOCK), 0,  \
                        c->stream, q, qi, (int)n, d_T, c->levels, lc.maxr2, allow_self, d_sidx, d_d2, d_state, c->d_hard, h0, mp,  \
-                       c->d_lvl_tab, unseeded_lev)
+                       c->d_lvl_tab, unseeded_lev, seed_pre)
         // iterations > 0 are seeded by the previous match (a handful of candidates per query): fewer
         // lanes per query; the unseeded first pass scans whole 27-cell blocks: more lanes per query
         const bool seeded = c->nn_iter_hint > 0 && allow_self;
@@ -1080,6 +1087,7 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
         // search no better than a fresh own-row scan: it still looks at a few hundred candidates per query and runs
         // faster 16 lanes wide (r1: 80 us with 8 lanes, measured below)
         const bool narrow = seeded && c->nn_iter_hint > wide_until;
+        const int seed_pre = seed_pre_cfg == 2 ? (narrow ? 0 : 1) : seed_pre_cfg; // 2: only on the wide launch after the first solve
         if (narrow && g_seeded == 4) LAUNCH_ML(4, 4);
         else if (narrow) LAUNCH_ML(8, 4);
         else LAUNCH_ML(16, 4);
