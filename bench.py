@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--chain", default="p2p", choices=list(CHAINS))
     ap.add_argument("--map-points", type=int, default=M_MAP)
     ap.add_argument("--scan-points", type=int, default=N_SCAN)
+    ap.add_argument("--scale", type=float, default=1.0,
+                    help="scene extent factor (SURVEY.md 8d, config 5: --map-points 10000000 --scale 3.16 keeps the point density of config 2)")
     ap.add_argument("--normals", default="analytic", choices=["analytic", "filter"],
                     help="map normals of the point-to-plane chains: the scene's analytic ones, or SurfaceNormalDataPointsFilter{knn: 10} "
                          "run on the map through icpmi_surface_normals (BASELINE config 3)")
@@ -78,7 +80,7 @@ def main():
     import norlab_icp_mapper_amd as pkg
 
     # ---- workload: replicated map, one scan stream per rank ----
-    sc = pkg.synth.make_scene(m=args.map_points, n=args.scan_points, seed_scan=43 + 1000 * rank)
+    sc = pkg.synth.make_scene(m=args.map_points, n=args.scan_points, seed_scan=43 + 1000 * rank, scale=args.scale)
     chain = dict(CHAINS[args.chain])
     icp = pkg.ICPSequence(device=dev, max_iterations=ITERS_PER_STEP, **chain)
     normals_ms = None
