@@ -181,3 +181,22 @@ def test_chain_errors(amd):
     assert np.array_equal(icp.getMap(), base)
     src, m = icp.mapUpdateChain(scan, [("voxel", 0.3, 0)], [])
     assert m == src.shape[0] and (np.diff(src) > 0).all()
+
+
+def test_chain_with_an_empty_scan_still_runs_the_program(amd, oracle):
+    """n = 0: the modules have nothing to add, the decimation and the post filters still run over the map."""
+    base, _ = make_clouds(amd, 10, m=8000, n=10)
+    sc0 = np.linspace(0.0, 1.0, base.shape[0]).astype(np.float32)
+    icp = amd.ICPSequence(minimizer=1, max_dist=2.0, max_iterations=5)
+    icp.setMap(base); icp.setMapScalar(sc0)
+    empty = np.zeros((0, 4), np.float32)
+    modules, post = [("point_distance", 0.1), ("voxel", 0.5, 0)], [("cut_scalar", 0.8, 1)]
+    src, m = icp.mapUpdateChain(empty, modules, post, scan_scalar=np.zeros(0, np.float32))
+    pts, _, sc, ref_src = host_chain(oracle, base, np.zeros((base.shape[0], 3), np.float32), sc0, empty, np.zeros(0, np.float32),
+                                     np.eye(4, dtype=np.float32), modules, post)
+    assert m == pts.shape[0] and np.array_equal(src, ref_src)
+    assert np.array_equal(icp.getMap(), pts) and np.array_equal(icp.getMapScalar(), sc)
+    # nothing at all: no map, no scan
+    fresh = amd.ICPSequence(minimizer=1, max_dist=2.0, max_iterations=5)
+    src0, m0 = fresh.mapUpdateChain(empty, modules, [])
+    assert m0 == 0 and src0.shape == (0,)
