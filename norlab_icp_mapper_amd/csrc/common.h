@@ -81,6 +81,7 @@ struct LoopCfg {
 // lives here so that the loop never synchronises with the host.
 struct IcpState {
     float T_iter[16];
+    float T_prev[16];       // T_iter of the previous iteration (what the queries of the previous NN launch were moved by)
     int   iter;
     int   done;
     int   error;           // icpmi_status (0 = ok)
@@ -182,6 +183,8 @@ struct icpmi_ctx {
     bool nn_builds_hist0 = false;     // set by the NN launcher: true if the launched variant did build it
     int nn_iter_hint = 0;             // iteration index of the launch being enqueued (> 0: seeded by the previous match)
     float4* d_match_pt = nullptr; size_t cap_match_pt = 0;     // k = 1 loop: matched map point (xyz, original index bits) per query slot
+    float*  d_lb = nullptr; size_t cap_lb = 0;                 // ... and a lower bound on the distance to every OTHER map point (match-survival test)
+    float*  nn_lb = nullptr;
     float4* nn_match_pt = nullptr;    // set by the loop: keep the loop state (sidx, d2, matched point) in query order
     bool nn_out_sorted = false;       // set by the NN launcher: true if the launched kernel did so
     IcpState* d_state = nullptr;

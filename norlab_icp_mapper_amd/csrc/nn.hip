@@ -325,14 +325,14 @@ __global__ __launch_bounds__(256) void ids_kernel(const float4* __restrict__ map
 #else
 #define NN_TICK(i) do { } while (0)
 #endif
-template <int G, int NB>
+template <int G, int NB, bool SURV>
 __global__ __launch_bounds__(NN1_BLOCK) void nn1_ml_kernel(const float4* __restrict__ queries, const int* __restrict__ qindex, int n,
                                                           const float* __restrict__ Tptr, GridLevels L, float maxr2,
                                                           int allow_self_i, int* __restrict__ out_sidx,
                                                           float* __restrict__ out_d2, IcpState* __restrict__ st,
                                                           unsigned* __restrict__ hard, unsigned* __restrict__ hist0,
                                                           float4* __restrict__ match_pt, const uint4* __restrict__ ltab_g,
-                                                          int unseeded_lev, int seed_pre)
+                                                          int unseeded_lev, int seed_pre, float* __restrict__ lbarr)
 {
     static_assert(G == 2 || G == 4 || G == 8 || G == 16, "lanes per query");
     constexpr int NR = (9 + G - 1) / G; // rows owned per lane: row rr belongs to lane rr % G, slot rr / G
@@ -370,6 +370,7 @@ __global__ __launch_bounds__(NN1_BLOCK) void nn1_ml_kernel(const float4* __restr
     int sp_kept = -1;
     float4 qs_kept = make_float4(0.f, 0.f, 0.f, 0.f);
     if (match_pt) { sp_kept = out_sidx[active ? qi : 0]; qs_kept = match_pt[active ? qi : 0]; }
+    const float lb_kept = SURV ? lbarr[active ? qi : 0] : 0.f;
     float3 p;
     if (Tptr) p = xf_point(Tptr, r.x, r.y, r.z, r.w);
     else p = make_float3(r.x, r.y, r.z);
@@ -380,20 +381,59 @@ __global__ __launch_bounds__(NN1_BLOCK) void nn1_ml_kernel(const float4* __restr
     Cand best; best.key = ~0ull; best.sidx = -1; // sidx = position in its level | level << 28
     float bx = 0.f, by = 0.f, bz = 0.f;          // coordinates of the current best candidate
     bool decided = !active;
+    float sec2 = INFINITY;   // smallest d^2 seen for a point other than the best one
+    float delta = 0.f;       // how far this query moved since the previous launch
+    bool survived = false;
     NN_TICK(0);
+
+    // Match survival (loop mode, iterations > 0).  The previous launch left, per query, a lower bound lb on the distance
+    // from the query (as it stood then) to every map point OTHER than its match.  The query has moved by delta since, so
+    // every other point is still at least lb - delta away: if the old match is strictly closer than that, it is the
+    // unique nearest neighbour again and the search is skipped.  Margins cover the rounding of the float distances
+    // (relative 1e-5) and of coordinate differences (em); the fold over (d^2, index) keys of a full search would
+    // pick the same point, and d^2 is recomputed from the same two points by the same expression.
+    if (SURV && allow_self && st->iter > 0) {
+        const float* Tp = st->T_prev;
+        const float3 pp = xf_point(Tp, r.x, r.y, r.z, r.w);
+        const float em = 1e-6f * (fabsf(p.x) + fabsf(p.y) + fabsf(p.z)) + 1e-7f;
+        delta = sqrtf(sqdist3(p.x, p.y, p.z, pp.x, pp.y, pp.z)) * 1.00001f + em;
+        if (active && sp_kept >= 0) {
+            const float ub2s = sqdist3(p.x, p.y, p.z, qs_kept.x, qs_kept.y, qs_kept.z);
+            const float ds = sqrtf(ub2s) * 1.00001f + em;
+            if (ds + delta < lb_kept) {
+                survived = true; decided = true;
+                sec2 = lb_kept - delta; // for a surviving lane sec2 carries the new bound itself (a distance)
+                best.key = pack_key(ub2s, __float_as_uint(qs_kept.w));
+                best.sidx = sp_kept;
+                bx = qs_kept.x; by = qs_kept.y; bz = qs_kept.z;
+            }
+        }
+    }
+    // from here on `delta` is the shell searched beyond the bound: a few steps of this query, never less than the rounding
+    // margins of the test above (a converged registration moves its queries by less than those)
+    if (SURV) delta = fmaxf(4.0f * delta, 16e-6f * (fabsf(p.x) + fabsf(p.y) + fabsf(p.z)) + 4e-6f);
+    const bool wave_survived = SURV && __ballot(!(survived || !active)) == 0ull; // nothing to search for in this wave
+#ifdef ICPMI_SURV_STATS
+    if (SURV && st->iter >= 10) {
+        const unsigned long long bs_ = __ballot(survived && sub == 0), ba_ = __ballot(active && sub == 0);
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&st->dbg[22], (unsigned long long)__popcll(bs_)); atomicAdd(&st->dbg[23], (unsigned long long)__popcll(ba_));
+            atomicAdd(&st->dbg[19], wave_survived ? 1ull : 0ull); atomicAdd(&st->dbg[18], 1ull); }
+    }
+#endif
 
     // Seed (iterations > 0 of one registration): the previous iteration's match of this query is a
     // map point, so its distance under the current transform bounds the nearest-neighbour distance
     // from above.  The search starts at the first level whose 3x3x3 block provably contains that
     // ball, and only visits the rows / cells the ball reaches.  Exactness is untouched: every point
     // within the bound is still scanned and the fold is over the same (d^2, index) keys.
+    if (!wave_survived) {
     int lev0 = unseeded_lev; // queries without a usable seed start here (level 0 may be finer than a blind 27-cell search wants)
     // The choice of the starting level runs WAVE-UNIFORMLY (all lanes step through the same `lev`):
     // the level's grid parameters are then scalar loads into SGPRs.
     {
         int sp = -1;
         float4 qs = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (active && allow_self && st->iter > 0) {
+        if (active && !survived && allow_self && st->iter > 0) {
             sp = match_pt ? sp_kept : out_sidx[orig];
             if (sp >= 0) qs = match_pt ? qs_kept : L.pts[0][sp];
         }
@@ -476,6 +516,10 @@ __global__ __launch_bounds__(NN1_BLOCK) void nn1_ml_kernel(const float4* __restr
                     const float d2 = sqdist3(p.x, p.y, p.z, q[u].x, q[u].y, q[u].z);
                     unsigned long long key = pack_key(d2, __float_as_uint(q[u].w));
                     if (!allow_self) key = d2 > 1.1920929e-07f ? key : ~0ull;
+                    if (SURV) { // runner-up: the old best when it is beaten, else any other point
+                        if (key < best.key) { if (best.key != ~0ull) sec2 = fminf(sec2, __uint_as_float((unsigned)(best.key >> 32))); }
+                        else if (key != best.key) sec2 = fminf(sec2, d2);
+                    }
                     if (key < best.key) { best.key = key; best.sidx = (int)(gi[u] | ((unsigned)lev << 28)); bx = q[u].x; by = q[u].y; bz = q[u].z; }
                 }
             }
@@ -484,13 +528,26 @@ __global__ __launch_bounds__(NN1_BLOCK) void nn1_ml_kernel(const float4* __restr
                 const unsigned long long ok = __shfl_xor(best.key, off, 64);
                 const int os = __shfl_xor(best.sidx, off, 64);
                 const float ox = __shfl_xor(bx, off, 64), oy = __shfl_xor(by, off, 64), oz = __shfl_xor(bz, off, 64);
+                if (SURV) {
+                    const float osec = __shfl_xor(sec2, off, 64);
+                    if (ok < best.key) { if (best.key != ~0ull) sec2 = fminf(sec2, __uint_as_float((unsigned)(best.key >> 32))); }
+                    else if (ok != best.key && ok != ~0ull) sec2 = fminf(sec2, __uint_as_float((unsigned)(ok >> 32)));
+                    sec2 = fminf(sec2, osec);
+                }
                 if (ok < best.key) { best.key = ok; best.sidx = os; bx = ox; by = oy; bz = oz; }
             }
         }
         float rub2 = INFINITY; // squared pruning radius (with slack), +inf = no pruning
+        float rc_lev = INFINITY; // every point within this radius gets scanned at this level (block margin aside)
         if (best.key != ~0ull) {
-            const float rub = sqrtf(__uint_as_float((unsigned)(best.key >> 32))) * 1.000001f + g.slack;
+            // loop mode searches a thin shell beyond the bound (a few times the query's last step, at most a tenth of a
+            // cell) so that the next launch can tell from the runner-up distance whether the match survives.  With no
+            // step recorded yet (iteration 0) the shell is the rounding floor: harmless.
+            const float shell = SURV ? fminf(delta, 0.1f * g.cell) : 0.f;
+            const float bd = sqrtf(__uint_as_float((unsigned)(best.key >> 32)));
+            const float rub = bd * 1.000001f + g.slack + shell;
             rub2 = rub * rub;
+            rc_lev = bd + shell;
         }
 
         // (1) row lookups: row rr is owned by lane rr % G of the group (slot rr / G); all lookups of a
@@ -572,6 +629,10 @@ __global__ __launch_bounds__(NN1_BLOCK) void nn1_ml_kernel(const float4* __restr
                 const float d2 = sqdist3(p.x, p.y, p.z, q[u].x, q[u].y, q[u].z);
                 unsigned long long key = pack_key(d2, __float_as_uint(q[u].w));
                 if (!allow_self) key = d2 > 1.1920929e-07f ? key : ~0ull;
+                if (SURV) { // runner-up: the old best when it is beaten, else any other point
+                    if (key < best.key) { if (best.key != ~0ull) sec2 = fminf(sec2, __uint_as_float((unsigned)(best.key >> 32))); }
+                    else if (key != best.key) sec2 = fminf(sec2, d2);
+                }
                 if (key < best.key) { best.key = key; best.sidx = (int)(gi[u] | ((unsigned)lev << 28)); bx = q[u].x; by = q[u].y; bz = q[u].z; }
             }
         }
@@ -582,6 +643,12 @@ __global__ __launch_bounds__(NN1_BLOCK) void nn1_ml_kernel(const float4* __restr
             const unsigned long long ok = __shfl_xor(best.key, off, 64);
             const int os = __shfl_xor(best.sidx, off, 64);
             const float ox = __shfl_xor(bx, off, 64), oy = __shfl_xor(by, off, 64), oz = __shfl_xor(bz, off, 64);
+            if (SURV) {
+                const float osec = __shfl_xor(sec2, off, 64);
+                if (ok < best.key) { if (best.key != ~0ull) sec2 = fminf(sec2, __uint_as_float((unsigned)(best.key >> 32))); }
+                else if (ok != best.key && ok != ~0ull) sec2 = fminf(sec2, __uint_as_float((unsigned)(ok >> 32)));
+                sec2 = fminf(sec2, osec);
+            }
             if (ok < best.key) { best.key = ok; best.sidx = os; bx = ox; by = oy; bz = oz; }
         }
         const float margin = fmaxf((1.0f + mf) * g.cell - g.slack, 0.f);
@@ -589,11 +656,17 @@ __global__ __launch_bounds__(NN1_BLOCK) void nn1_ml_kernel(const float4* __restr
         const float bd2 = __uint_as_float((unsigned)(best.key >> 32));
         const bool covers = cx - 1 <= 0 && cx + 1 >= g.nx - 1 && cy - 1 <= 0 && cy + 1 >= g.ny - 1 && cz - 1 <= 0 && cz + 1 >= g.nz - 1;
         decided = (best.key != ~0ull && bd2 <= m2) || m2 > maxr2 || covers;
+        if (SURV && decided) { // points outside the block are at least `margin` away
+            const float rcl = covers ? rc_lev : fminf(rc_lev, margin);
+            sec2 = fminf(sec2, rcl * rcl);
+        }
         NN_TICK(4);
 #ifdef ICPMI_NN_TIMING
         tacc[6] += 1;
 #endif
     }
+
+    } // !wave_survived
 
     if (active && sub == 0) {
         float bd2 = __uint_as_float((unsigned)(best.key >> 32));
@@ -609,6 +682,13 @@ __global__ __launch_bounds__(NN1_BLOCK) void nn1_ml_kernel(const float4* __restr
         out_sidx[orig] = bs;
         out_d2[orig] = bd2;
         if (match_pt) match_pt[orig] = make_float4(bx, by, bz, __uint_as_float((unsigned)(best.key & 0xffffffffull)));
+        if (SURV) {
+            const float em = 1e-6f * (fabsf(p.x) + fabsf(p.y) + fabsf(p.z)) + 1e-7f;
+            float lbn = 0.f; // nothing known (no match, or the search was handed to the brute-force pass)
+            if (survived) lbn = sec2;
+            else if (decided && bs >= 0) lbn = sqrtf(sec2) * 0.99999f - em; // runner-up distance or completeness radius, whichever is smaller
+            lbarr[orig] = lbn;
+        }
         if (hist0 && bd2 != INFINITY && bd2 > 0.f) {
             const unsigned bits = __float_as_uint(bd2);
             atomicAdd(&lh[bits >> 24], 1u);
@@ -1071,12 +1151,15 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
         // order, so chains that may need it stay on original indices
         float4* mp = (needs_hard || !sorted) ? nullptr : c->nn_match_pt;
         c->nn_out_sorted = mp != nullptr;
+        float* lbp = mp ? c->nn_lb : nullptr; // match-survival bounds (loop mode only)
         static int seed_pre_cfg = -1;
         if (seed_pre_cfg < 0) { const char* e = getenv("ICPMI_NN_SEED_PRE"); seed_pre_cfg = e ? atoi(e) : 2; }
 #define LAUNCH_ML(G_, NB_)                                                                                                      \
-    hipLaunchKernelGGL((nn1_ml_kernel<G_, NB_>), dim3((int)(((n * G_ + NN1_BLOCK - 1) / NN1_BLOCK + 7) / 8 * 8)), dim3(NN1_BLOCK), 0,  \
+    do { if (lbp) LAUNCH_ML2(G_, NB_, true); else LAUNCH_ML2(G_, NB_, false); } while (0)
+#define LAUNCH_ML2(G_, NB_, S_)                                                                                                      \
+    hipLaunchKernelGGL((nn1_ml_kernel<G_, NB_, S_>), dim3((int)(((n * G_ + NN1_BLOCK - 1) / NN1_BLOCK + 7) / 8 * 8)), dim3(NN1_BLOCK), 0,  \
                        c->stream, q, qi, (int)n, d_T, c->levels, lc.maxr2, allow_self, d_sidx, d_d2, d_state, c->d_hard, h0, mp,  \
-                       c->d_lvl_tab, unseeded_lev, seed_pre)
+                       c->d_lvl_tab, unseeded_lev, seed_pre, lbp)
         // iterations > 0 are seeded by the previous match (a handful of candidates per query): fewer
         // lanes per query; the unseeded first pass scans whole 27-cell blocks: more lanes per query
         const bool seeded = c->nn_iter_hint > 0 && allow_self;
@@ -1092,6 +1175,7 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
         else if (narrow) LAUNCH_ML(8, 4);
         else LAUNCH_ML(16, 4);
 #undef LAUNCH_ML
+#undef LAUNCH_ML2
         const GridParams& top = c->levels.g[c->levels.nlev - 1];
         if (!std::isfinite(lc.max_dist) || (top.cell - top.slack) <= lc.max_dist) {
             hipLaunchKernelGGL(nn1_hard_kernel, dim3(512), dim3(NN_BLOCK), 0, c->stream, d_reading, d_T, c->d_map_sorted, (int)c->m,
