@@ -102,6 +102,7 @@ struct IcpState {
     long long pairs;
     double wsum;
     unsigned hard_count;
+    unsigned nfail;              // queries queued by nn1_survive_kernel for the search launch that follows (reset by the solve)
     unsigned ticket;             // workgroups of the pair-sum kernel that have published their partials (last one solves)
     unsigned long long hard_total;
     unsigned long long dbg[24];  // diagnostics: NN phase cycles with -DICPMI_NN_TIMING (scripts/nn_phase.py), [20]/[21] serial solve cycles / calls
@@ -184,7 +185,8 @@ struct icpmi_ctx {
     int nn_iter_hint = 0;             // iteration index of the launch being enqueued (> 0: seeded by the previous match)
     float4* d_match_pt = nullptr; size_t cap_match_pt = 0;     // k = 1 loop: matched map point (xyz, original index bits) per query slot
     float*  d_lb = nullptr; size_t cap_lb = 0;                 // ... and a lower bound on the distance to every OTHER map point (match-survival test)
-    float*  nn_lb = nullptr;
+    int*    d_faillist = nullptr; size_t cap_faillist = 0;     // queue of the queries whose match did not survive
+    float*  nn_lb = nullptr; bool nn_lb_written = false;       // the previous NN launch of this registration left the bounds
     float4* nn_match_pt = nullptr;    // set by the loop: keep the loop state (sidx, d2, matched point) in query order
     bool nn_out_sorted = false;       // set by the NN launcher: true if the launched kernel did so
     IcpState* d_state = nullptr;

@@ -767,6 +767,7 @@ __device__ void solve_body(IcpState* __restrict__ st, const double* __restrict__
     if (t != 0) return;
     const long long tsolve0 = clock64();
 
+    st->nfail = 0; // the survival queue of this iteration has been consumed
     const double wsum = tot[27];
     const long long P = (long long)(tot[28] + 0.5);
     st->pairs = P;
@@ -883,7 +884,7 @@ __global__ void init_state_kernel(IcpState* st, const float* T0)
     st->hist_n = 1;
     st->sel_prefix = 0; st->sel_rank = 0; st->n_valid = 0;
     for (int f = 0; f < ICPMI_MAX_OUTLIER; ++f) st->limits[f] = -1.f;
-    st->pairs = 0; st->wsum = 0; st->hard_count = 0; st->hard_total = 0; st->ticket = 0;
+    st->pairs = 0; st->wsum = 0; st->hard_count = 0; st->hard_total = 0; st->ticket = 0; st->nfail = 0;
     for (int i = 0; i < 24; ++i) st->dbg[i] = 0;
 }
 
@@ -971,6 +972,7 @@ static icpmi_status ensure_loop_buffers(icpmi_ctx* c, int64_t n, int k)
     if (ensure_cap(c, &c->d_partials, &c->cap_partials, nb * ICPMI_NV) != ICPMI_OK) return ICPMI_ERR_HIP;
     if (k == 1 && ensure_cap(c, &c->d_match_pt, &c->cap_match_pt, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
     if (k == 1 && ensure_cap(c, &c->d_lb, &c->cap_lb, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (k == 1 && ensure_cap(c, &c->d_faillist, &c->cap_faillist, (size_t)n + 512 + (size_t)n / 256 + 8) != ICPMI_OK) return ICPMI_ERR_HIP;
     return ICPMI_OK;
 }
 
@@ -1142,7 +1144,7 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
         // buffer, the map and the chain stay the same
         uint64_t sig = 1469598103934665603ull;
         sig = fnv(&lc, sizeof lc, sig);
-        const void* ptrs[] = {d_scan, d_normals3, c->d_qkeys, c->d_qtile,c->d_reading, c->d_read_normals, c->d_sidx, c->d_d2, c->d_hard, c->d_partials, c->d_state, c->d_match_pt, c->d_lb,
+        const void* ptrs[] = {d_scan, d_normals3, c->d_qkeys, c->d_qtile,c->d_reading, c->d_read_normals, c->d_sidx, c->d_d2, c->d_hard, c->d_partials, c->d_state, c->d_match_pt, c->d_lb, c->d_faillist,
                               c->d_qsorted, c->d_qindex,
                               c->d_map_sorted, c->d_normals_sorted, c->d_cell_start, c->d_selhist};
         sig = fnv(ptrs, sizeof ptrs, sig);
