@@ -130,7 +130,7 @@ void icpmi_destroy(icpmi_handle c)
     hipFree(c->d_keys); hipFree(c->d_fill); hipFree(c->d_blocksums); hipFree(c->d_red);
     hipFree(c->d_qsorted); hipFree(c->d_qindex); hipFree(c->d_qkeys); hipFree(c->d_qtile);
     hipFree(c->d_reading); hipFree(c->d_read_normals); hipFree(c->d_stage_in); hipFree(c->d_stage_n3);
-    hipFree(c->d_match_pt); hipFree(c->d_lb); hipFree(c->d_faillist); hipFree(c->d_lvl_tab); hipFree(c->d_raw); hipFree(c->d_raw_n3); hipFree(c->d_raw_s); hipFree(c->d_src); hipFree(c->d_alt_raw); hipFree(c->d_alt_n3);
+    hipFree(c->d_match_pt); hipFree(c->d_lvl_tab); hipFree(c->d_raw); hipFree(c->d_raw_n3); hipFree(c->d_raw_s); hipFree(c->d_src); hipFree(c->d_alt_raw); hipFree(c->d_alt_n3);
     hipFree(c->d_alt_s); hipFree(c->d_alt_src); hipFree(c->d_stage_s);
     for (int k = 0; k < 10; ++k) hipFree(c->scratch[k]); hipFree(c->d_scan_map); hipFree(c->d_T16);
     hipFree(c->d_sidx); hipFree(c->d_d2); hipFree(c->d_hard); hipFree(c->d_partials); hipFree(c->d_selhist);

@@ -81,7 +81,6 @@ struct LoopCfg {
 // lives here so that the loop never synchronises with the host.
 struct IcpState {
     float T_iter[16];
-    float T_prev[16];       // T_iter of the previous iteration (what the queries of the previous NN launch were moved by)
     int   iter;
     int   done;
     int   error;           // icpmi_status (0 = ok)
@@ -102,7 +101,6 @@ struct IcpState {
     long long pairs;
     double wsum;
     unsigned hard_count;
-    unsigned nfail;              // queries queued by nn1_survive_kernel for the search launch that follows (reset by the solve)
     unsigned ticket;             // workgroups of the pair-sum kernel that have published their partials (last one solves)
     unsigned long long hard_total;
     unsigned long long dbg[24];  // diagnostics: NN phase cycles with -DICPMI_NN_TIMING (scripts/nn_phase.py), [20]/[21] serial solve cycles / calls
@@ -184,9 +182,6 @@ struct icpmi_ctx {
     bool nn_builds_hist0 = false;     // set by the NN launcher: true if the launched variant did build it
     int nn_iter_hint = 0;             // iteration index of the launch being enqueued (> 0: seeded by the previous match)
     float4* d_match_pt = nullptr; size_t cap_match_pt = 0;     // k = 1 loop: matched map point (xyz, original index bits) per query slot
-    float*  d_lb = nullptr; size_t cap_lb = 0;                 // ... and a lower bound on the distance to every OTHER map point (match-survival test)
-    int*    d_faillist = nullptr; size_t cap_faillist = 0;     // queue of the queries whose match did not survive
-    float*  nn_lb = nullptr; bool nn_lb_written = false;       // the previous NN launch of this registration left the bounds
     float4* nn_match_pt = nullptr;    // set by the loop: keep the loop state (sidx, d2, matched point) in query order
     bool nn_out_sorted = false;       // set by the NN launcher: true if the launched kernel did so
     IcpState* d_state = nullptr;

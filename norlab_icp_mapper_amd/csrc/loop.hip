@@ -767,7 +767,6 @@ __device__ void solve_body(IcpState* __restrict__ st, const double* __restrict__
     if (t != 0) return;
     const long long tsolve0 = clock64();
 
-    st->nfail = 0; // the survival queue of this iteration has been consumed
     const double wsum = tot[27];
     const long long P = (long long)(tot[28] + 0.5);
     st->pairs = P;
@@ -804,7 +803,7 @@ __device__ void solve_body(IcpState* __restrict__ st, const double* __restrict__
 
     float Ti[16];
     mat4_mul_dev(Ts, st->T_iter, Ti);
-    for (int i = 0; i < 16; ++i) { st->T_prev[i] = st->T_iter[i]; st->T_iter[i] = Ti[i]; }
+    for (int i = 0; i < 16; ++i) st->T_iter[i] = Ti[i];
     st->iter += 1;
 
     // ---- TransformationCheckers ----
@@ -876,7 +875,7 @@ __global__ __launch_bounds__(256) void pad_normals_kernel(const float* __restric
 __global__ void init_state_kernel(IcpState* st, const float* T0)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    for (int i = 0; i < 16; ++i) st->T_prev[i] = st->T_iter[i] = T0 ? T0[i] : ((i % 5 == 0) ? 1.f : 0.f);
+    for (int i = 0; i < 16; ++i) st->T_iter[i] = T0 ? T0[i] : ((i % 5 == 0) ? 1.f : 0.f);
     st->iter = 0; st->done = 0; st->error = 0; st->stop_reason = 0; st->counter = 0;
     quat_from_T(st->T_iter, st->hq);
     for (int r = 0; r < 3; ++r) st->ht[r] = st->T_iter[12 + r];
@@ -884,7 +883,7 @@ __global__ void init_state_kernel(IcpState* st, const float* T0)
     st->hist_n = 1;
     st->sel_prefix = 0; st->sel_rank = 0; st->n_valid = 0;
     for (int f = 0; f < ICPMI_MAX_OUTLIER; ++f) st->limits[f] = -1.f;
-    st->pairs = 0; st->wsum = 0; st->hard_count = 0; st->hard_total = 0; st->ticket = 0; st->nfail = 0;
+    st->pairs = 0; st->wsum = 0; st->hard_count = 0; st->hard_total = 0; st->ticket = 0;
     for (int i = 0; i < 24; ++i) st->dbg[i] = 0;
 }
 
@@ -971,8 +970,6 @@ static icpmi_status ensure_loop_buffers(icpmi_ctx* c, int64_t n, int k)
     const size_t nb = (cnt + 255) / 256;
     if (ensure_cap(c, &c->d_partials, &c->cap_partials, nb * ICPMI_NV) != ICPMI_OK) return ICPMI_ERR_HIP;
     if (k == 1 && ensure_cap(c, &c->d_match_pt, &c->cap_match_pt, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
-    if (k == 1 && ensure_cap(c, &c->d_lb, &c->cap_lb, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
-    if (k == 1 && ensure_cap(c, &c->d_faillist, &c->cap_faillist, (size_t)n + 512 + (size_t)n / 256 + 8) != ICPMI_OK) return ICPMI_ERR_HIP;
     return ICPMI_OK;
 }
 
@@ -1066,9 +1063,6 @@ static icpmi_status enqueue_iteration(icpmi_ctx* c, int64_t n, const LoopCfg& lc
     static int keep_pts = -1;
     if (keep_pts < 0) { const char* e = getenv("ICPMI_SORTED_STATE"); keep_pts = e ? atoi(e) : 1; }
     c->nn_match_pt = (lc.k == 1 && keep_pts) ? c->d_match_pt : nullptr;
-    static int survive = -1;
-    if (survive < 0) { const char* e = getenv("ICPMI_NN_SURVIVE"); survive = e ? atoi(e) : 0; }
-    c->nn_lb = (c->nn_match_pt && survive) ? c->d_lb : nullptr;
     c->nn_out_sorted = false;
     icpmi_status s = nn_launch_k(c, c->d_reading, n, c->d_state->T_iter, lc, 1, c->d_sidx, c->d_d2, c->d_state);
     if (s != ICPMI_OK) return s;
@@ -1144,7 +1138,7 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
         // buffer, the map and the chain stay the same
         uint64_t sig = 1469598103934665603ull;
         sig = fnv(&lc, sizeof lc, sig);
-        const void* ptrs[] = {d_scan, d_normals3, c->d_qkeys, c->d_qtile,c->d_reading, c->d_read_normals, c->d_sidx, c->d_d2, c->d_hard, c->d_partials, c->d_state, c->d_match_pt, c->d_lb, c->d_faillist,
+        const void* ptrs[] = {d_scan, d_normals3, c->d_qkeys, c->d_qtile,c->d_reading, c->d_read_normals, c->d_sidx, c->d_d2, c->d_hard, c->d_partials, c->d_state, c->d_match_pt,
                               c->d_qsorted, c->d_qindex,
                               c->d_map_sorted, c->d_normals_sorted, c->d_cell_start, c->d_selhist};
         sig = fnv(ptrs, sizeof ptrs, sig);

@@ -325,108 +325,18 @@ __global__ __launch_bounds__(256) void ids_kernel(const float4* __restrict__ map
 #else
 #define NN_TICK(i) do { } while (0)
 #endif
-// Match survival, one lane per query (loop mode, from the second narrow launch on): see the test inside nn1_ml_kernel.
-// Queries whose match survives are finished here (same outputs as the tail of a full search that ends on that point);
-// the others are queued for nn1_ml_kernel<.., LIST = true>.  The queue order depends on wave timing, the results do not.
-__global__ __launch_bounds__(256) void nn1_survive_kernel(const float4* __restrict__ queries, int n, const float* __restrict__ Tptr, float maxr2,
-                                                          int* __restrict__ out_sidx, float* __restrict__ out_d2, IcpState* __restrict__ st,
-                                                          unsigned* __restrict__ hist0, const float4* __restrict__ match_pt,
-                                                          float* __restrict__ lbarr, int* __restrict__ faillist, int* __restrict__ failcnt)
-{
-    // every load of the query state is issued before anything waits: this kernel is one round trip long, and with
-    // ~1.5 waves per SIMD nothing else hides a second one
-    const int q1 = blockIdx.x * 256 + threadIdx.x;
-    const bool in = q1 < n;
-    const int qc = in ? q1 : 0;
-    const float4 r1 = queries[qc];
-    const int sp1 = out_sidx[qc];
-    const float4 qs1 = match_pt[qc];
-    const float lb1 = lbarr[qc];
-    const int done = st->done;
-    __shared__ unsigned lh[256];
-    if (hist0) {
-        lh[threadIdx.x] = 0;
-        for (int gt = blockIdx.x * 256 + threadIdx.x; gt < 256 + 65536; gt += gridDim.x * 256) hist0[ICPMI_S2_C1 + gt] = 0; // as nn1_ml_kernel does
-        __syncthreads();
-    }
-    const float3 p1 = xf_point(Tptr, r1.x, r1.y, r1.z, r1.w);
-    const float3 pp1 = xf_point(st->T_prev, r1.x, r1.y, r1.z, r1.w);
-    const float em1 = 1e-6f * (fabsf(p1.x) + fabsf(p1.y) + fabsf(p1.z)) + 1e-7f;
-    const float delta1 = sqrtf(sqdist3(p1.x, p1.y, p1.z, pp1.x, pp1.y, pp1.z)) * 1.00001f + em1;
-    const float ub2s = sqdist3(p1.x, p1.y, p1.z, qs1.x, qs1.y, qs1.z);
-    const float ds1 = sqrtf(ub2s) * 1.00001f + em1;
-    const bool live = in & (done == 0);
-    const bool pass = live & (sp1 >= 0) & (ds1 + delta1 < lb1); // no short circuit: the loads above must not sink into a branch
-    const bool fail = live & !pass;
-    unsigned hbits = 0u; // d^2 pattern to be counted (0: nothing)
-    if (pass) {
-        // the match survives: same outputs as the tail of a full search that ends on this point
-        float bd2 = ub2s;
-        if (!(bd2 <= maxr2)) { out_sidx[q1] = -1; bd2 = INFINITY; }
-        out_d2[q1] = bd2;
-        lbarr[q1] = lb1 - delta1;
-        if (hist0 && bd2 != INFINITY && bd2 > 0.f) hbits = __float_as_uint(bd2);
-    }
-    if (hist0) {
-        // level 0 of the quantile selection: the coarse digit has two or three hot values, so the wave counts each
-        // distinct value once (ballots) instead of 64 same-address LDS atomics
-        const bool has = hbits != 0u;
-        const unsigned coarse = hbits >> 24;
-        unsigned long long todo_m = __ballot(has);
-        while (todo_m) {
-            const int leader = __ffsll((long long)todo_m) - 1;
-            const unsigned v = (unsigned)__shfl((int)coarse, leader, 64);
-            const unsigned long long same = __ballot(has && coarse == v);
-            if ((int)(threadIdx.x & 63) == leader) atomicAdd(&lh[v], (unsigned)__popcll(same));
-            todo_m &= ~same;
-        }
-        if (has) atomicAdd(&hist0[ICPMI_S2_F0 + (blockIdx.x % ICPMI_S2_FCOPIES) * 65536 + ICPMI_S2_FIDX(hbits >> 16)], 1u);
-    }
-    // The queue is segmented: this workgroup's 256 queries own entries [256 b, 256 b + count_b) and word b of the counts
-    // behind the list (a single global counter would serialise ~1500 same-address atomics: 10 us).  Wave w of the
-    // workgroup writes behind the waves before it: stable, so the queue is a function of the inputs.
-    __shared__ unsigned wcnt[4];
-    const unsigned long long fm = __ballot(fail);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) wcnt[wv] = (unsigned)__popcll(fm);
-    __syncthreads();
-    unsigned base = 0;
-    for (int w = 0; w < wv; ++w) base += wcnt[w];
-    if (fail) faillist[blockIdx.x * 256 + base + (unsigned)__popcll(fm & ((1ull << lane) - 1ull))] = q1;
-    if (threadIdx.x == 0) failcnt[blockIdx.x] = (int)(wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3]);
-    if (hist0 && lh[threadIdx.x]) atomicAdd(&hist0[ICPMI_S2_C0 + (blockIdx.x % ICPMI_S2_COPIES) * 256 + threadIdx.x], lh[threadIdx.x]);
-}
-
-static int wide_until_cfg()
-{
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("ICPMI_NN_WIDE_UNTIL"); v = e ? atoi(e) : 1; }
-    return v;
-}
-
-template <int G, int NB, bool SURV, bool LIST>
+template <int G, int NB>
 __global__ __launch_bounds__(NN1_BLOCK) void nn1_ml_kernel(const float4* __restrict__ queries, const int* __restrict__ qindex, int n,
                                                           const float* __restrict__ Tptr, GridLevels L, float maxr2,
                                                           int allow_self_i, int* __restrict__ out_sidx,
                                                           float* __restrict__ out_d2, IcpState* __restrict__ st,
                                                           unsigned* __restrict__ hard, unsigned* __restrict__ hist0,
                                                           float4* __restrict__ match_pt, const uint4* __restrict__ ltab_g,
-                                                          int unseeded_lev, int seed_pre, float* __restrict__ lbarr, int surv_test, const int* __restrict__ faillist, const int* __restrict__ failcnt)
+                                                          int unseeded_lev, int seed_pre)
 {
     static_assert(G == 2 || G == 4 || G == 8 || G == 16, "lanes per query");
     constexpr int NR = (9 + G - 1) / G; // rows owned per lane: row rr belongs to lane rr % G, slot rr / G
     if (st->done) return;
-    // list mode: 256 / GPW consecutive workgroups serve the queue segment of one nn1_survive_kernel workgroup
-    int seg_cnt = 0, seg_first = 0;
-    if (LIST) {
-        constexpr int WPS = 256 / (NN1_BLOCK / G); // workgroups per segment
-        const int lbq = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-        const int seg = lbq / WPS;
-        if (seg * 256 >= n) return;
-        seg_cnt = failcnt[seg];
-        seg_first = (lbq % WPS) * (NN1_BLOCK / G);
-        if (seg_first >= seg_cnt) return; // nothing queued for this workgroup
-    }
 #ifdef ICPMI_NN_TIMING
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = clock64();
@@ -447,281 +357,118 @@ __global__ __launch_bounds__(NN1_BLOCK) void nn1_ml_kernel(const float4* __restr
     // (~1/8 of the cells) resident in that XCD's private 4 MiB L2.  The grid is padded to 8 * chunk.
     const int chunk = gridDim.x >> 3;
     const int lb = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    constexpr int GPW = NN1_BLOCK / G; // query groups per workgroup
-    const int sub = threadIdx.x % G;
-    // List mode (loop mode once the runner-up bounds exist): nn1_survive_kernel has finished every query whose match
-    // survives and queued the others; group g of this launch searches entry g of that queue.
-    int qi; bool active;
-    if (LIST) {
-        const int slot = seg_first + (int)threadIdx.x / G;
-        active = slot < seg_cnt;
-        qi = active ? faillist[(lb / (256 / GPW)) * 256 + slot] : 0;
-    } else {
-        qi = (lb * NN1_BLOCK + (int)threadIdx.x) / G;
-        active = qi < n;
-    }
-    {
+    const int tid = lb * NN1_BLOCK + threadIdx.x;
+    const int qi = tid / G;
+    const int sub = tid % G;
+    const bool active = qi < n;
     const float4 r = queries[active ? qi : 0];
-        // Loop mode (match_pt != nullptr): the per-query loop state -- match position, d^2, matched point --
-        // lives in QUERY ORDER (slot qi of the tile-sorted reading), so the seed of this iteration arrives in
-        // the same round trip as the query itself and the results leave as coalesced stores.  Otherwise
-        // (stage calls) results go to the caller's original index.
-        const int orig = match_pt ? qi : (qindex ? qindex[active ? qi : 0] : qi);
-        int sp_kept = -1;
-        float4 qs_kept = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (match_pt) { sp_kept = out_sidx[active ? qi : 0]; qs_kept = match_pt[active ? qi : 0]; }
-        const float lb_kept = SURV ? lbarr[active ? qi : 0] : 0.f;
-        float3 p;
-        if (Tptr) p = xf_point(Tptr, r.x, r.y, r.z, r.w);
-        else p = make_float3(r.x, r.y, r.z);
-        const int lane = threadIdx.x & 63;
-        const int gbase = lane - sub;
+    // Loop mode (match_pt != nullptr): the per-query loop state -- match position, d^2, matched point --
+    // lives in QUERY ORDER (slot qi of the tile-sorted reading), so the seed of this iteration arrives in
+    // the same round trip as the query itself and the results leave as coalesced stores.  Otherwise
+    // (stage calls) results go to the caller's original index.
+    const int orig = match_pt ? qi : (qindex ? qindex[active ? qi : 0] : qi);
+    int sp_kept = -1;
+    float4 qs_kept = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (match_pt) { sp_kept = out_sidx[active ? qi : 0]; qs_kept = match_pt[active ? qi : 0]; }
+    float3 p;
+    if (Tptr) p = xf_point(Tptr, r.x, r.y, r.z, r.w);
+    else p = make_float3(r.x, r.y, r.z);
+    const int lane = threadIdx.x & 63;
+    const int gbase = lane - sub;
 
-        __syncthreads(); // ltab visible (its load shared the round trip of the query loads above)
-        Cand best; best.key = ~0ull; best.sidx = -1; // sidx = position in its level | level << 28
-        float bx = 0.f, by = 0.f, bz = 0.f;          // coordinates of the current best candidate
-        bool decided = !active;
-        float sec2 = INFINITY;   // smallest d^2 seen for a point other than the best one
-        float delta = 0.f;       // how far this query moved since the previous launch
-        bool survived = false;
-        NN_TICK(0);
+    __syncthreads(); // ltab visible (its load shared the round trip of the query loads above)
+    Cand best; best.key = ~0ull; best.sidx = -1; // sidx = position in its level | level << 28
+    float bx = 0.f, by = 0.f, bz = 0.f;          // coordinates of the current best candidate
+    bool decided = !active;
+    NN_TICK(0);
 
-        // Match survival (loop mode, iterations > 0).  The previous launch left, per query, a lower bound lb on the distance
-        // from the query (as it stood then) to every map point OTHER than its match.  The query has moved by delta since, so
-        // every other point is still at least lb - delta away: if the old match is strictly closer than that, it is the
-        // unique nearest neighbour again and the search is skipped.  Margins cover the rounding of the float distances
-        // (relative 1e-5) and of coordinate differences (em); the fold over (d^2, index) keys of a full search would
-        // pick the same point, and d^2 is recomputed from the same two points by the same expression.
-        if (SURV && allow_self && st->iter > 0) {
-            const float* Tp = st->T_prev;
-            const float3 pp = xf_point(Tp, r.x, r.y, r.z, r.w);
-            const float em = 1e-6f * (fabsf(p.x) + fabsf(p.y) + fabsf(p.z)) + 1e-7f;
-            delta = sqrtf(sqdist3(p.x, p.y, p.z, pp.x, pp.y, pp.z)) * 1.00001f + em;
-            if (!LIST && surv_test && active && sp_kept >= 0) { // (list mode: nn1_survive_kernel ran this test with one lane per query)
-                const float ub2s = sqdist3(p.x, p.y, p.z, qs_kept.x, qs_kept.y, qs_kept.z);
-                const float ds = sqrtf(ub2s) * 1.00001f + em;
-                if (ds + delta < lb_kept) {
-                    survived = true; decided = true;
-                    sec2 = lb_kept - delta; // for a surviving lane sec2 carries the new bound itself (a distance)
-                    best.key = pack_key(ub2s, __float_as_uint(qs_kept.w));
-                    best.sidx = sp_kept;
-                    bx = qs_kept.x; by = qs_kept.y; bz = qs_kept.z;
-                }
+    // Seed (iterations > 0 of one registration): the previous iteration's match of this query is a
+    // map point, so its distance under the current transform bounds the nearest-neighbour distance
+    // from above.  The search starts at the first level whose 3x3x3 block provably contains that
+    // ball, and only visits the rows / cells the ball reaches.  Exactness is untouched: every point
+    // within the bound is still scanned and the fold is over the same (d^2, index) keys.
+    int lev0 = unseeded_lev; // queries without a usable seed start here (level 0 may be finer than a blind 27-cell search wants)
+    // The choice of the starting level runs WAVE-UNIFORMLY (all lanes step through the same `lev`):
+    // the level's grid parameters are then scalar loads into SGPRs.
+    {
+        int sp = -1;
+        float4 qs = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (active && allow_self && st->iter > 0) {
+            sp = match_pt ? sp_kept : out_sidx[orig];
+            if (sp >= 0) qs = match_pt ? qs_kept : L.pts[0][sp];
+        }
+        bool want = sp >= 0;
+        const float ub2 = sqdist3(p.x, p.y, p.z, qs.x, qs.y, qs.z);
+        const float ub = sqrtf(ub2);
+        auto try_level = [&](int lev, const GridParams& gl) {
+            const float fx = (p.x - gl.ox) * gl.inv_cell, fy = (p.y - gl.oy) * gl.inv_cell, fz = (p.z - gl.oz) * gl.inv_cell;
+            float mfl = fminf(fx - floorf(fx), 1.0f - (fx - floorf(fx)));
+            mfl = fminf(mfl, fminf(fy - floorf(fy), 1.0f - (fy - floorf(fy))));
+            mfl = fminf(mfl, fminf(fz - floorf(fz), 1.0f - (fz - floorf(fz))));
+            if (!(mfl >= 0.f)) mfl = 0.f;
+            const float margin = (1.0f + mfl) * gl.cell - 2.0f * gl.slack;
+            if (want && ub * 1.000001f <= margin) {
+                lev0 = lev;
+                best.key = pack_key(ub2, __float_as_uint(qs.w));
+                best.sidx = sp; // level 0 position
+                bx = qs.x; by = qs.y; bz = qs.z;
+                want = false;
             }
+        };
+        // level 0 (statically indexed: its parameters arrive with the kernel arguments) decides for nearly every
+        // query of a converging registration; the loop only runs for waves that hold a wider ball
+        try_level(0, L.g[0]);
+        for (int lev = 1; lev < L.nlev; ++lev) {
+            if (__ballot(want) == 0ull) break;
+            try_level(lev, L.g[lev]);
         }
-        // from here on `delta` is the shell searched beyond the bound: a few steps of this query, never less than the rounding
-        // margins of the test above (a converged registration moves its queries by less than those)
-        if (SURV) delta = fmaxf(4.0f * delta, 16e-6f * (fabsf(p.x) + fabsf(p.y) + fabsf(p.z)) + 4e-6f);
-        const bool wave_survived = SURV && __ballot(!(survived || !active)) == 0ull; // nothing to search for in this wave
-#ifdef ICPMI_SURV_STATS
-        if (SURV && st->iter >= 10) {
-            const unsigned long long bs_ = __ballot(survived && sub == 0), ba_ = __ballot(active && sub == 0);
-            if ((threadIdx.x & 63) == 0) { atomicAdd(&st->dbg[22], (unsigned long long)__popcll(bs_)); atomicAdd(&st->dbg[23], (unsigned long long)__popcll(ba_));
-                atomicAdd(&st->dbg[19], wave_survived ? 1ull : 0ull); atomicAdd(&st->dbg[18], 1ull); }
-        }
-#endif
+    }
+    // lanes of a group agree on the starting level and radius (same inputs)
+    // A seed too wide for level 0 (the first solve moved the reading by the whole initial misalignment): the query
+    // itself is usually close to the surface by now, so start at level 0 after all and let the own-row scan tighten
+    // the bound first; the seed still bounds whatever that scan finds.
+    bool widepre = false;
+    if (seed_pre && lev0 > 0 && best.key != ~0ull) { widepre = true; lev0 = 0; }
+    NN_TICK(1);
 
-        // Seed (iterations > 0 of one registration): the previous iteration's match of this query is a
-        // map point, so its distance under the current transform bounds the nearest-neighbour distance
-        // from above.  The search starts at the first level whose 3x3x3 block provably contains that
-        // ball, and only visits the rows / cells the ball reaches.  Exactness is untouched: every point
-        // within the bound is still scanned and the fold is over the same (d^2, index) keys.
-        if (!wave_survived) {
-        int lev0 = unseeded_lev; // queries without a usable seed start here (level 0 may be finer than a blind 27-cell search wants)
-        // The choice of the starting level runs WAVE-UNIFORMLY (all lanes step through the same `lev`):
-        // the level's grid parameters are then scalar loads into SGPRs.
+    // The search itself runs with PER-LANE levels (groups of one wave work on different levels in
+    // lockstep); the level's parameters come from the LDS copy of the level table.
+    for (int lev = lev0; lev < L.nlev && !decided; ++lev) {
+        GridParams g;
+        const float4* __restrict__ map;
+        const unsigned* __restrict__ cs;
         {
-            int sp = -1;
-            float4 qs = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (active && !survived && allow_self && st->iter > 0) {
-                sp = match_pt ? sp_kept : out_sidx[orig];
-                if (sp >= 0) qs = match_pt ? qs_kept : L.pts[0][sp];
-            }
-            bool want = sp >= 0;
-            const float ub2 = sqdist3(p.x, p.y, p.z, qs.x, qs.y, qs.z);
-            const float ub = sqrtf(ub2);
-            auto try_level = [&](int lev, const GridParams& gl) {
-                const float fx = (p.x - gl.ox) * gl.inv_cell, fy = (p.y - gl.oy) * gl.inv_cell, fz = (p.z - gl.oz) * gl.inv_cell;
-                float mfl = fminf(fx - floorf(fx), 1.0f - (fx - floorf(fx)));
-                mfl = fminf(mfl, fminf(fy - floorf(fy), 1.0f - (fy - floorf(fy))));
-                mfl = fminf(mfl, fminf(fz - floorf(fz), 1.0f - (fz - floorf(fz))));
-                if (!(mfl >= 0.f)) mfl = 0.f;
-                const float margin = (1.0f + mfl) * gl.cell - 2.0f * gl.slack;
-                if (want && ub * 1.000001f <= margin) {
-                    lev0 = lev;
-                    best.key = pack_key(ub2, __float_as_uint(qs.w));
-                    best.sidx = sp; // level 0 position
-                    bx = qs.x; by = qs.y; bz = qs.z;
-                    want = false;
-                }
-            };
-            // level 0 (statically indexed: its parameters arrive with the kernel arguments) decides for nearly every
-            // query of a converging registration; the loop only runs for waves that hold a wider ball
-            try_level(0, L.g[0]);
-            for (int lev = 1; lev < L.nlev; ++lev) {
-                if (__ballot(want) == 0ull) break;
-                try_level(lev, L.g[lev]);
-            }
+            const uint4 a = ltab[4 * lev], b = ltab[4 * lev + 1], c2 = ltab[4 * lev + 2], d = ltab[4 * lev + 3];
+            g.ox = __uint_as_float(a.x); g.oy = __uint_as_float(a.y); g.oz = __uint_as_float(a.z); g.cell = __uint_as_float(a.w);
+            g.inv_cell = __uint_as_float(b.x); g.slack = __uint_as_float(b.y); g.nx = (int)b.z; g.ny = (int)b.w;
+            g.nz = (int)c2.x; g.ncells = (int)c2.y;
+            map = reinterpret_cast<const float4*>(((unsigned long long)c2.w << 32) | c2.z);
+            cs = reinterpret_cast<const unsigned*>(((unsigned long long)d.y << 32) | d.x);
         }
-        // lanes of a group agree on the starting level and radius (same inputs)
-        // A seed too wide for level 0 (the first solve moved the reading by the whole initial misalignment): the query
-        // itself is usually close to the surface by now, so start at level 0 after all and let the own-row scan tighten
-        // the bound first; the seed still bounds whatever that scan finds.
-        bool widepre = false;
-        if (seed_pre && lev0 > 0 && best.key != ~0ull) { widepre = true; lev0 = 0; }
-        NN_TICK(1);
+        const float fx = (p.x - g.ox) * g.inv_cell, fy = (p.y - g.oy) * g.inv_cell, fz = (p.z - g.oz) * g.inv_cell;
+        const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
+        const int cx = (int)fminf(fmaxf(flx, -1.0e6f), 1.0e6f);
+        const int cy = (int)fminf(fmaxf(fly, -1.0e6f), 1.0e6f);
+        const int cz = (int)fminf(fmaxf(flz, -1.0e6f), 1.0e6f);
+        float mf = fminf(fx - flx, 1.0f - (fx - flx));
+        mf = fminf(mf, fminf(fy - fly, 1.0f - (fy - fly)));
+        mf = fminf(mf, fminf(fz - flz, 1.0f - (fz - flz)));
+        if (!(mf >= 0.f)) mf = 0.f;
 
-        // The search itself runs with PER-LANE levels (groups of one wave work on different levels in
-        // lockstep); the level's parameters come from the LDS copy of the level table.
-        for (int lev = lev0; lev < L.nlev && !decided; ++lev) {
-            GridParams g;
-            const float4* __restrict__ map;
-            const unsigned* __restrict__ cs;
-            {
-                const uint4 a = ltab[4 * lev], b = ltab[4 * lev + 1], c2 = ltab[4 * lev + 2], d = ltab[4 * lev + 3];
-                g.ox = __uint_as_float(a.x); g.oy = __uint_as_float(a.y); g.oz = __uint_as_float(a.z); g.cell = __uint_as_float(a.w);
-                g.inv_cell = __uint_as_float(b.x); g.slack = __uint_as_float(b.y); g.nx = (int)b.z; g.ny = (int)b.w;
-                g.nz = (int)c2.x; g.ncells = (int)c2.y;
-                map = reinterpret_cast<const float4*>(((unsigned long long)c2.w << 32) | c2.z);
-                cs = reinterpret_cast<const unsigned*>(((unsigned long long)d.y << 32) | d.x);
-            }
-            const float fx = (p.x - g.ox) * g.inv_cell, fy = (p.y - g.oy) * g.inv_cell, fz = (p.z - g.oz) * g.inv_cell;
-            const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
-            const int cx = (int)fminf(fmaxf(flx, -1.0e6f), 1.0e6f);
-            const int cy = (int)fminf(fmaxf(fly, -1.0e6f), 1.0e6f);
-            const int cz = (int)fminf(fmaxf(flz, -1.0e6f), 1.0e6f);
-            float mf = fminf(fx - flx, 1.0f - (fx - flx));
-            mf = fminf(mf, fminf(fy - fly, 1.0f - (fy - fly)));
-            mf = fminf(mf, fminf(fz - flz, 1.0f - (fz - flz)));
-            if (!(mf >= 0.f)) mf = 0.f;
-
-            // (0) pruning radius.  Any candidate already held (the seed, or the best of a finer level) bounds
-            //     the answer from above; a query that holds none first scans the x-row through its own cell
-            //     (~1/9 of the block) to get one.  Rows / cells the ball of that radius cannot reach are then
-            //     skipped -- every point within the bound is still scanned, so the block minimum is exact.
-            if (best.key == ~0ull || (widepre && lev == 0)) {
-                unsigned s, e;
-                row_run(g, cs, cx - 1, cx + 1, cy, cz, s, e);
-                for (unsigned i0 = s + (unsigned)sub; i0 < e; i0 += (unsigned)(G * NB)) {
-                    float4 q[NB];
-                    unsigned gi[NB];
-#pragma unroll
-                    for (int u = 0; u < NB; ++u) {
-                        const unsigned k = i0 + (unsigned)(u * G);
-                        gi[u] = k < e ? k : i0;
-                        q[u] = map[gi[u]];
-                    }
-#pragma unroll
-                    for (int u = 0; u < NB; ++u) {
-                        const float d2 = sqdist3(p.x, p.y, p.z, q[u].x, q[u].y, q[u].z);
-                        unsigned long long key = pack_key(d2, __float_as_uint(q[u].w));
-                        if (!allow_self) key = d2 > 1.1920929e-07f ? key : ~0ull;
-                        if (SURV) { // runner-up: the old best when it is beaten, else any other point
-                            if (key < best.key) { if (best.key != ~0ull) sec2 = fminf(sec2, __uint_as_float((unsigned)(best.key >> 32))); }
-                            else if (key != best.key) sec2 = fminf(sec2, d2);
-                        }
-                        if (key < best.key) { best.key = key; best.sidx = (int)(gi[u] | ((unsigned)lev << 28)); bx = q[u].x; by = q[u].y; bz = q[u].z; }
-                    }
-                }
-#pragma unroll
-                for (int off = G / 2; off > 0; off >>= 1) {
-                    const unsigned long long ok = __shfl_xor(best.key, off, 64);
-                    const int os = __shfl_xor(best.sidx, off, 64);
-                    const float ox = __shfl_xor(bx, off, 64), oy = __shfl_xor(by, off, 64), oz = __shfl_xor(bz, off, 64);
-                    if (SURV) {
-                        const float osec = __shfl_xor(sec2, off, 64);
-                        if (ok < best.key) { if (best.key != ~0ull) sec2 = fminf(sec2, __uint_as_float((unsigned)(best.key >> 32))); }
-                        else if (ok != best.key && ok != ~0ull) sec2 = fminf(sec2, __uint_as_float((unsigned)(ok >> 32)));
-                        sec2 = fminf(sec2, osec);
-                    }
-                    if (ok < best.key) { best.key = ok; best.sidx = os; bx = ox; by = oy; bz = oz; }
-                }
-            }
-            float rub2 = INFINITY; // squared pruning radius (with slack), +inf = no pruning
-            float rc_lev = INFINITY; // every point within this radius gets scanned at this level (block margin aside)
-            if (best.key != ~0ull) {
-                // loop mode searches a thin shell beyond the bound (a few times the query's last step, at most a tenth of a
-                // cell) so that the next launch can tell from the runner-up distance whether the match survives.  With no
-                // step recorded yet (iteration 0) the shell is the rounding floor: harmless.
-                const float shell = SURV ? fminf(delta, 0.1f * g.cell) : 0.f;
-                const float bd = sqrtf(__uint_as_float((unsigned)(best.key >> 32)));
-                const float rub = bd * 1.000001f + g.slack + shell;
-                rub2 = rub * rub;
-                rc_lev = bd + shell;
-            }
-
-            // (1) row lookups: row rr is owned by lane rr % G of the group (slot rr / G); all lookups of a
-            //     lane are independent loads
-            unsigned rs[NR], rn[NR];
-            {
-                // distances from the query to the lower / upper faces of its cell along y and z
-                const float ylo = (fy - fly) * g.cell, yhi = (1.0f - (fy - fly)) * g.cell;
-                const float zlo = (fz - flz) * g.cell, zhi = (1.0f - (fz - flz)) * g.cell;
-#pragma unroll
-                for (int sl = 0; sl < NR; ++sl) {
-                    const int rr = sub + sl * G;
-                    unsigned s = 0, cnt = 0;
-                    const int dy = (rr % 3) - 1, dz = (rr / 3) - 1;
-                    // cheap part first: does the ball reach this row at all?
-                    bool reach = rr < 9;
-                    float rem2 = INFINITY;
-                    if (reach && rub2 != INFINITY) {
-                        const float ddy = dy == 0 ? 0.f : (dy < 0 ? ylo : yhi);
-                        const float ddz = dz == 0 ? 0.f : (dz < 0 ? zlo : zhi);
-                        rem2 = rub2 - (ddy * ddy + ddz * ddz);
-                        reach = rem2 >= 0.f;
-                    }
-                    // the second slot only holds the corner row of lane 0 of each group: skipped wave-uniformly when no
-                    // ball of the wave reaches it (the usual case once the registration converges)
-                    if (__ballot(reach) != 0ull) {
-                        if (reach) {
-                            int xa = cx - 1, xb = cx + 1;
-                            if (rem2 != INFINITY) {
-                                const float rem = sqrtf(rem2);
-                                const int xl = (int)fmaxf(floorf((p.x - rem - g.ox) * g.inv_cell), -1.0e6f);
-                                const int xh = (int)fminf(floorf((p.x + rem - g.ox) * g.inv_cell), 1.0e6f);
-                                xa = xl > xa ? xl : xa;
-                                xb = xh < xb ? xh : xb;
-                            }
-                            unsigned e;
-                            row_run(g, cs, xa, xb, cy + dy, cz + dz, s, e);
-                            cnt = e - s;
-                        }
-                    }
-                    rs[sl] = s; rn[sl] = cnt;
-                }
-            }
-            NN_TICK(2);
-            // (2) broadcast, prefix: candidate k of the flat list lives at map[k + off_r], P_r <= k < P_{r+1}
-            unsigned Pr[10], Or[9];
-            Pr[0] = 0;
-#pragma unroll
-            for (int rr = 0; rr < 9; ++rr) {
-                const int src = gbase + (rr % G);
-                const unsigned s = __shfl(rs[rr / G], src, 64);
-                const unsigned c = __shfl(rn[rr / G], src, 64);
-                Or[rr] = s - Pr[rr];
-                Pr[rr + 1] = Pr[rr] + c;
-            }
-            const unsigned total = Pr[9];
-#ifdef ICPMI_NN_TIMING
-            tacc[7] += total; // candidates of lane 0's query
-            if (sub == 0 && st->iter > 0 && (qi % 16) == 0) { // distribution over a sample of seeded queries: dbg[18..23]
-                const int bkt = total <= 16 ? 0 : (total <= 32 ? 1 : (total <= 64 ? 2 : (total <= 128 ? 3 : (total <= 256 ? 4 : 5))));
-                atomicAdd(&st->dbg[18 + bkt], 1ull);
-            }
-#endif
-            for (unsigned k0 = (unsigned)sub; k0 < total; k0 += (unsigned)(G * NB)) {
+        // (0) pruning radius.  Any candidate already held (the seed, or the best of a finer level) bounds
+        //     the answer from above; a query that holds none first scans the x-row through its own cell
+        //     (~1/9 of the block) to get one.  Rows / cells the ball of that radius cannot reach are then
+        //     skipped -- every point within the bound is still scanned, so the block minimum is exact.
+        if (best.key == ~0ull || (widepre && lev == 0)) {
+            unsigned s, e;
+            row_run(g, cs, cx - 1, cx + 1, cy, cz, s, e);
+            for (unsigned i0 = s + (unsigned)sub; i0 < e; i0 += (unsigned)(G * NB)) {
                 float4 q[NB];
                 unsigned gi[NB];
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
-                    const unsigned k = k0 + (unsigned)(u * G);
-                    const unsigned kk = k < total ? k : k0; // clamped duplicates of k0 are harmless
-                    unsigned off = Or[0];
-#pragma unroll
-                    for (int rr = 1; rr < 9; ++rr) off = kk >= Pr[rr] ? Or[rr] : off;
-                    gi[u] = kk + off;
+                    const unsigned k = i0 + (unsigned)(u * G);
+                    gi[u] = k < e ? k : i0;
                     q[u] = map[gi[u]];
                 }
 #pragma unroll
@@ -729,75 +476,147 @@ __global__ __launch_bounds__(NN1_BLOCK) void nn1_ml_kernel(const float4* __restr
                     const float d2 = sqdist3(p.x, p.y, p.z, q[u].x, q[u].y, q[u].z);
                     unsigned long long key = pack_key(d2, __float_as_uint(q[u].w));
                     if (!allow_self) key = d2 > 1.1920929e-07f ? key : ~0ull;
-                    if (SURV) { // runner-up: the old best when it is beaten, else any other point
-                        if (key < best.key) { if (best.key != ~0ull) sec2 = fminf(sec2, __uint_as_float((unsigned)(best.key >> 32))); }
-                        else if (key != best.key) sec2 = fminf(sec2, d2);
-                    }
                     if (key < best.key) { best.key = key; best.sidx = (int)(gi[u] | ((unsigned)lev << 28)); bx = q[u].x; by = q[u].y; bz = q[u].z; }
                 }
             }
-            NN_TICK(3);
-            // (3) fold and decide
 #pragma unroll
             for (int off = G / 2; off > 0; off >>= 1) {
                 const unsigned long long ok = __shfl_xor(best.key, off, 64);
                 const int os = __shfl_xor(best.sidx, off, 64);
                 const float ox = __shfl_xor(bx, off, 64), oy = __shfl_xor(by, off, 64), oz = __shfl_xor(bz, off, 64);
-                if (SURV) {
-                    const float osec = __shfl_xor(sec2, off, 64);
-                    if (ok < best.key) { if (best.key != ~0ull) sec2 = fminf(sec2, __uint_as_float((unsigned)(best.key >> 32))); }
-                    else if (ok != best.key && ok != ~0ull) sec2 = fminf(sec2, __uint_as_float((unsigned)(ok >> 32)));
-                    sec2 = fminf(sec2, osec);
-                }
                 if (ok < best.key) { best.key = ok; best.sidx = os; bx = ox; by = oy; bz = oz; }
             }
-            const float margin = fmaxf((1.0f + mf) * g.cell - g.slack, 0.f);
-            const float m2 = margin * margin;
-            const float bd2 = __uint_as_float((unsigned)(best.key >> 32));
-            const bool covers = cx - 1 <= 0 && cx + 1 >= g.nx - 1 && cy - 1 <= 0 && cy + 1 >= g.ny - 1 && cz - 1 <= 0 && cz + 1 >= g.nz - 1;
-            decided = (best.key != ~0ull && bd2 <= m2) || m2 > maxr2 || covers;
-            if (SURV && decided) { // points outside the block are at least `margin` away
-                const float rcl = covers ? rc_lev : fminf(rc_lev, margin);
-                sec2 = fminf(sec2, rcl * rcl);
-            }
-            NN_TICK(4);
-#ifdef ICPMI_NN_TIMING
-            tacc[6] += 1;
-#endif
+        }
+        float rub2 = INFINITY; // squared pruning radius (with slack), +inf = no pruning
+        if (best.key != ~0ull) {
+            const float rub = sqrtf(__uint_as_float((unsigned)(best.key >> 32))) * 1.000001f + g.slack;
+            rub2 = rub * rub;
         }
 
-        } // !wave_survived
-
-        if (active && sub == 0) {
-            float bd2 = __uint_as_float((unsigned)(best.key >> 32));
-            int bs = -1;
-            if (best.key != ~0ull && bd2 <= maxr2) {
-                const unsigned lv = (unsigned)best.sidx >> 28, pos = (unsigned)best.sidx & 0x0fffffffu;
-                if (lv == 0) bs = (int)pos;
-                else {
-                    const uint4 d = ltab[4 * lv + 3];
-                    bs = (int)reinterpret_cast<const unsigned*>(((unsigned long long)d.w << 32) | d.z)[pos];
+        // (1) row lookups: row rr is owned by lane rr % G of the group (slot rr / G); all lookups of a
+        //     lane are independent loads
+        unsigned rs[NR], rn[NR];
+        {
+            // distances from the query to the lower / upper faces of its cell along y and z
+            const float ylo = (fy - fly) * g.cell, yhi = (1.0f - (fy - fly)) * g.cell;
+            const float zlo = (fz - flz) * g.cell, zhi = (1.0f - (fz - flz)) * g.cell;
+#pragma unroll
+            for (int sl = 0; sl < NR; ++sl) {
+                const int rr = sub + sl * G;
+                unsigned s = 0, cnt = 0;
+                const int dy = (rr % 3) - 1, dz = (rr / 3) - 1;
+                // cheap part first: does the ball reach this row at all?
+                bool reach = rr < 9;
+                float rem2 = INFINITY;
+                if (reach && rub2 != INFINITY) {
+                    const float ddy = dy == 0 ? 0.f : (dy < 0 ? ylo : yhi);
+                    const float ddz = dz == 0 ? 0.f : (dz < 0 ? zlo : zhi);
+                    rem2 = rub2 - (ddy * ddy + ddz * ddz);
+                    reach = rem2 >= 0.f;
                 }
-            } else bd2 = INFINITY;
-            out_sidx[orig] = bs;
-            out_d2[orig] = bd2;
-            if (match_pt) match_pt[orig] = make_float4(bx, by, bz, __uint_as_float((unsigned)(best.key & 0xffffffffull)));
-            if (SURV) {
-                const float em = 1e-6f * (fabsf(p.x) + fabsf(p.y) + fabsf(p.z)) + 1e-7f;
-                float lbn = 0.f; // nothing known (no match, or the search was handed to the brute-force pass)
-                if (survived) lbn = sec2;
-                else if (decided && bs >= 0) lbn = sqrtf(sec2) * 0.99999f - em; // runner-up distance or completeness radius, whichever is smaller
-                lbarr[orig] = lbn;
+                // the second slot only holds the corner row of lane 0 of each group: skipped wave-uniformly when no
+                // ball of the wave reaches it (the usual case once the registration converges)
+                if (__ballot(reach) != 0ull) {
+                    if (reach) {
+                        int xa = cx - 1, xb = cx + 1;
+                        if (rem2 != INFINITY) {
+                            const float rem = sqrtf(rem2);
+                            const int xl = (int)fmaxf(floorf((p.x - rem - g.ox) * g.inv_cell), -1.0e6f);
+                            const int xh = (int)fminf(floorf((p.x + rem - g.ox) * g.inv_cell), 1.0e6f);
+                            xa = xl > xa ? xl : xa;
+                            xb = xh < xb ? xh : xb;
+                        }
+                        unsigned e;
+                        row_run(g, cs, xa, xb, cy + dy, cz + dz, s, e);
+                        cnt = e - s;
+                    }
+                }
+                rs[sl] = s; rn[sl] = cnt;
             }
-            if (hist0 && bd2 != INFINITY && bd2 > 0.f) {
-                const unsigned bits = __float_as_uint(bd2);
-                atomicAdd(&lh[bits >> 24], 1u);
-                atomicAdd(&hist0[ICPMI_S2_F0 + (blockIdx.x % ICPMI_S2_FCOPIES) * 65536 + ICPMI_S2_FIDX(bits >> 16)], 1u);
+        }
+        NN_TICK(2);
+        // (2) broadcast, prefix: candidate k of the flat list lives at map[k + off_r], P_r <= k < P_{r+1}
+        unsigned Pr[10], Or[9];
+        Pr[0] = 0;
+#pragma unroll
+        for (int rr = 0; rr < 9; ++rr) {
+            const int src = gbase + (rr % G);
+            const unsigned s = __shfl(rs[rr / G], src, 64);
+            const unsigned c = __shfl(rn[rr / G], src, 64);
+            Or[rr] = s - Pr[rr];
+            Pr[rr + 1] = Pr[rr] + c;
+        }
+        const unsigned total = Pr[9];
+#ifdef ICPMI_NN_TIMING
+        tacc[7] += total; // candidates of lane 0's query
+        if (sub == 0 && st->iter > 0 && (qi % 16) == 0) { // distribution over a sample of seeded queries: dbg[18..23]
+            const int bkt = total <= 16 ? 0 : (total <= 32 ? 1 : (total <= 64 ? 2 : (total <= 128 ? 3 : (total <= 256 ? 4 : 5))));
+            atomicAdd(&st->dbg[18 + bkt], 1ull);
+        }
+#endif
+        for (unsigned k0 = (unsigned)sub; k0 < total; k0 += (unsigned)(G * NB)) {
+            float4 q[NB];
+            unsigned gi[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const unsigned k = k0 + (unsigned)(u * G);
+                const unsigned kk = k < total ? k : k0; // clamped duplicates of k0 are harmless
+                unsigned off = Or[0];
+#pragma unroll
+                for (int rr = 1; rr < 9; ++rr) off = kk >= Pr[rr] ? Or[rr] : off;
+                gi[u] = kk + off;
+                q[u] = map[gi[u]];
             }
-            if (!decided) {
-                const unsigned slot = atomicAdd(&st->hard_count, 1u);
-                hard[slot] = (unsigned)(qindex ? qindex[qi] : qi); // the brute pass works on the caller's order
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const float d2 = sqdist3(p.x, p.y, p.z, q[u].x, q[u].y, q[u].z);
+                unsigned long long key = pack_key(d2, __float_as_uint(q[u].w));
+                if (!allow_self) key = d2 > 1.1920929e-07f ? key : ~0ull;
+                if (key < best.key) { best.key = key; best.sidx = (int)(gi[u] | ((unsigned)lev << 28)); bx = q[u].x; by = q[u].y; bz = q[u].z; }
             }
+        }
+        NN_TICK(3);
+        // (3) fold and decide
+#pragma unroll
+        for (int off = G / 2; off > 0; off >>= 1) {
+            const unsigned long long ok = __shfl_xor(best.key, off, 64);
+            const int os = __shfl_xor(best.sidx, off, 64);
+            const float ox = __shfl_xor(bx, off, 64), oy = __shfl_xor(by, off, 64), oz = __shfl_xor(bz, off, 64);
+            if (ok < best.key) { best.key = ok; best.sidx = os; bx = ox; by = oy; bz = oz; }
+        }
+        const float margin = fmaxf((1.0f + mf) * g.cell - g.slack, 0.f);
+        const float m2 = margin * margin;
+        const float bd2 = __uint_as_float((unsigned)(best.key >> 32));
+        const bool covers = cx - 1 <= 0 && cx + 1 >= g.nx - 1 && cy - 1 <= 0 && cy + 1 >= g.ny - 1 && cz - 1 <= 0 && cz + 1 >= g.nz - 1;
+        decided = (best.key != ~0ull && bd2 <= m2) || m2 > maxr2 || covers;
+        NN_TICK(4);
+#ifdef ICPMI_NN_TIMING
+        tacc[6] += 1;
+#endif
+    }
+
+    if (active && sub == 0) {
+        float bd2 = __uint_as_float((unsigned)(best.key >> 32));
+        int bs = -1;
+        if (best.key != ~0ull && bd2 <= maxr2) {
+            const unsigned lv = (unsigned)best.sidx >> 28, pos = (unsigned)best.sidx & 0x0fffffffu;
+            if (lv == 0) bs = (int)pos;
+            else {
+                const uint4 d = ltab[4 * lv + 3];
+                bs = (int)reinterpret_cast<const unsigned*>(((unsigned long long)d.w << 32) | d.z)[pos];
+            }
+        } else bd2 = INFINITY;
+        out_sidx[orig] = bs;
+        out_d2[orig] = bd2;
+        if (match_pt) match_pt[orig] = make_float4(bx, by, bz, __uint_as_float((unsigned)(best.key & 0xffffffffull)));
+        if (hist0 && bd2 != INFINITY && bd2 > 0.f) {
+            const unsigned bits = __float_as_uint(bd2);
+            atomicAdd(&lh[bits >> 24], 1u);
+            atomicAdd(&hist0[ICPMI_S2_F0 + (blockIdx.x % ICPMI_S2_FCOPIES) * 65536 + ICPMI_S2_FIDX(bits >> 16)], 1u);
+        }
+        if (!decided) {
+            const unsigned slot = atomicAdd(&st->hard_count, 1u);
+            hard[slot] = (unsigned)(qindex ? qindex[qi] : qi); // the brute pass works on the caller's order
         }
     }
     if (hist0) {
@@ -1252,20 +1071,12 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
         // order, so chains that may need it stay on original indices
         float4* mp = (needs_hard || !sorted) ? nullptr : c->nn_match_pt;
         c->nn_out_sorted = mp != nullptr;
-        // match-survival bounds (loop mode): written by the narrow launches, tested from the launch after the first
-        // of them on, there with one lane per query (two-phase kernel)
-        const bool narrow_now = c->nn_iter_hint > 0 && allow_self && c->nn_iter_hint > wide_until_cfg();
-        float* lbp = (mp && narrow_now) ? c->nn_lb : nullptr;
-        if (c->nn_iter_hint == 0) c->nn_lb_written = false;
-        const int surv_test = (lbp && c->nn_lb_written) ? 1 : 0;
         static int seed_pre_cfg = -1;
         if (seed_pre_cfg < 0) { const char* e = getenv("ICPMI_NN_SEED_PRE"); seed_pre_cfg = e ? atoi(e) : 2; }
 #define LAUNCH_ML(G_, NB_)                                                                                                      \
-    do { if (lbp) LAUNCH_ML2(G_, NB_, true, false); else LAUNCH_ML2(G_, NB_, false, false); } while (0)
-#define LAUNCH_ML2(G_, NB_, S_, L_)                                                                                             \
-    hipLaunchKernelGGL((nn1_ml_kernel<G_, NB_, S_, L_>), dim3((int)(((n * G_ + NN1_BLOCK - 1) / NN1_BLOCK + 7) / 8 * 8)), dim3(NN1_BLOCK), 0,  \
+    hipLaunchKernelGGL((nn1_ml_kernel<G_, NB_>), dim3((int)(((n * G_ + NN1_BLOCK - 1) / NN1_BLOCK + 7) / 8 * 8)), dim3(NN1_BLOCK), 0,  \
                        c->stream, q, qi, (int)n, d_T, c->levels, lc.maxr2, allow_self, d_sidx, d_d2, d_state, c->d_hard, h0, mp,  \
-                       c->d_lvl_tab, unseeded_lev, seed_pre, lbp, surv_test, (const int*)c->d_faillist, (const int*)(c->d_faillist + ((n + 255) / 256) * 256))
+                       c->d_lvl_tab, unseeded_lev, seed_pre)
         // iterations > 0 are seeded by the previous match (a handful of candidates per query): fewer
         // lanes per query; the unseeded first pass scans whole 27-cell blocks: more lanes per query
         const bool seeded = c->nn_iter_hint > 0 && allow_self;
@@ -1278,23 +1089,9 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
         const bool narrow = seeded && c->nn_iter_hint > wide_until;
         const int seed_pre = seed_pre_cfg == 2 ? (narrow ? 0 : 1) : seed_pre_cfg; // 2: only on the wide launch after the first solve
         if (narrow && g_seeded == 4) LAUNCH_ML(4, 4);
-        else if (narrow && surv_test) {
-            // survivors first (one lane per query), then the search over the queue they left
-            static int dbg_nohist = -1;
-            if (dbg_nohist < 0) { const char* e = getenv("ICPMI_SURV_NOHIST"); dbg_nohist = e ? atoi(e) : 0; }
-            hipLaunchKernelGGL(nn1_survive_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, q, (int)n, d_T, lc.maxr2, d_sidx, d_d2, d_state,
-                               dbg_nohist ? (unsigned*)nullptr : h0, (const float4*)mp, lbp, c->d_faillist, c->d_faillist + ((n + 255) / 256) * 256);
-            // 256 / (NN1_BLOCK / 8) search workgroups per 256-query segment of the queue
-            hipLaunchKernelGGL((nn1_ml_kernel<8, 4, true, true>), dim3((int)(((n + 255) / 256) * (256 / (NN1_BLOCK / 8)))), dim3(NN1_BLOCK), 0,
-                               c->stream, q, qi, (int)n, d_T, c->levels, lc.maxr2, allow_self, d_sidx, d_d2, d_state, c->d_hard, h0, mp,
-                               c->d_lvl_tab, unseeded_lev, seed_pre, lbp, surv_test, (const int*)c->d_faillist,
-                               (const int*)(c->d_faillist + ((n + 255) / 256) * 256));
-        }
         else if (narrow) LAUNCH_ML(8, 4);
         else LAUNCH_ML(16, 4);
 #undef LAUNCH_ML
-#undef LAUNCH_ML2
-        c->nn_lb_written = lbp != nullptr;
         const GridParams& top = c->levels.g[c->levels.nlev - 1];
         if (!std::isfinite(lc.max_dist) || (top.cell - top.slack) <= lc.max_dist) {
             hipLaunchKernelGGL(nn1_hard_kernel, dim3(512), dim3(NN_BLOCK), 0, c->stream, d_reading, d_T, c->d_map_sorted, (int)c->m,
