@@ -734,8 +734,8 @@ icpmi_status ops_map_update_dev(icpmi_ctx* c, const float4* d_scan, int64_t n, c
     const int64_t m0 = c->m > 0 ? c->m_raw : 0;
     const float lim = powf(min_dist, 2.f);
     const int blocks = (int)((n + 255) / 256);
-    unsigned* d_flag = nullptr;
-    HIP_TRY(c, hipMalloc((void**)&d_flag, ((size_t)n + 2) * sizeof(unsigned)));
+    unsigned* d_flag = scratch_get<unsigned>(c, 6, (size_t)n + 2); // kept between calls
+    if (!d_flag) return ICPMI_ERR_HIP;
     icpmi_status s = ICPMI_OK;
     hipError_t e = hipSuccess;
     unsigned count = 0;
@@ -754,13 +754,12 @@ icpmi_status ops_map_update_dev(icpmi_ctx* c, const float4* d_scan, int64_t n, c
             if (e == hipSuccess) s = nn_launch_k(c, c->d_reading, n, nullptr, lc, 0, c->d_sidx, c->d_d2, c->d_state);
         }
         if (s == ICPMI_OK && e == hipSuccess && keep_out) {
-            uint8_t* d_keep = nullptr;
-            e = hipMalloc((void**)&d_keep, (size_t)n);
+            uint8_t* d_keep = scratch_get<uint8_t>(c, 9, (size_t)n);
+            if (!d_keep) e = hipErrorOutOfMemory;
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(keep_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_d2, n, lim, d_keep);
                 e = hipMemcpyAsync(keep_out, d_keep, (size_t)n, hipMemcpyDeviceToHost, c->stream);
                 if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-                hipFree(d_keep);
             }
         }
         if (s == ICPMI_OK && e == hipSuccess) {
@@ -810,7 +809,6 @@ icpmi_status ops_map_update_dev(icpmi_ctx* c, const float4* d_scan, int64_t n, c
         if (s == ICPMI_OK && e == hipSuccess) s = map_build(c, c->d_raw, m1, want_n ? c->d_raw_n3 : nullptr);
         if (s == ICPMI_OK) { if (appended) *appended = count; if (new_m) *new_m = m1; }
     }
-    hipFree(d_flag);
     if (s != ICPMI_OK) return s;
     HIP_TRY(c, e);
     return ICPMI_OK;
