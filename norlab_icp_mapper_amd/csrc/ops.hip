@@ -310,10 +310,22 @@ __global__ __launch_bounds__(256) void dyn_update_kernel(const float4* __restric
     const float r2 = g.cell * g.cell;
     float bd = INFINITY;
     int best = -1;
-    for (int de = -1; de <= 1; ++de)
-        for (int da = -1; da <= 1; ++da) {
+    // own cell first: where the beams are dense (the horizon band of a ground scan) the nearest one is a fraction of a
+    // cell away, and a neighbouring cell whose nearest edge is farther than the best so far cannot hold a closer beam
+    // (nor an equally close one: the test is strict and leaves a margin for the rounding of the cell assignment)
+    const float elo = (float)ce * g.cell - 1.5707963267949f, alo = (float)ca * g.cell - 3.14159265358979f;
+    const float gapE[3] = {qe - elo, 0.f, elo + g.cell - qe}, gapA[3] = {qa - alo, 0.f, alo + g.cell - qa};
+#pragma unroll
+    for (int c9 = 0; c9 < 9; ++c9) {
+        {
+            // visiting order: centre, then the eight neighbours
+            const int idx9 = c9 == 0 ? 4 : (c9 <= 4 ? c9 - 1 : c9);
+            const int de = idx9 / 3 - 1, da = idx9 % 3 - 1;
             const int e = ce + de, a = ca + da;
             if (e < 0 || e >= g.ne || a < 0 || a >= g.na) continue;
+            const float ge = fmaxf(gapE[de + 1] - 1e-5f, 0.f), ga = fmaxf(gapA[da + 1] - 1e-5f, 0.f);
+            const float dmin = ge * ge + ga * ga;
+            if (dmin > r2 || dmin > bd) continue;
             const unsigned k = (unsigned)(e * g.na + a);
             for (unsigned j = start[k]; j < start[k + 1]; ++j) {
                 const float2 ang = sorted_ang[j];
@@ -325,6 +337,7 @@ __global__ __launch_bounds__(256) void dyn_update_kernel(const float4* __restric
                 }
             }
         }
+    }
     if (best < 0) return; // no beam within 2 * beamHalfAngle
 
     const float4 ip = beam_xyzn[best];
