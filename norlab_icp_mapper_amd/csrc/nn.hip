@@ -1024,6 +1024,111 @@ __global__ __launch_bounds__(SELF_BLOCK) __attribute__((amdgpu_waves_per_eu(KMAX
     }
 }
 
+// Redo of the tiled self-search's left-overs (k-th neighbour beyond the staged block: sparse regions, map border), one
+// WAVE per query: the rows of ring R are dealt to the lanes, every lane keeps the KMAX best of its rows, and after each
+// ring the wave merges them (KMAX rounds of "extract the wave minimum") into a list replicated in all lanes.  Same
+// rings, same decision rule and same (d^2, index) order as nnk_kernel -- which ran these queries one lane each, and
+// whose slowest lane (a few thousand candidates, serially) set the duration of the whole pass.
+template <int KMAX>
+__global__ __launch_bounds__(64) void nnk_wave_kernel(const float4* __restrict__ reading, GridParams g, const float4* __restrict__ map,
+                                                      const unsigned* __restrict__ cs, int k, float maxr2, int ring_max, int allow_self,
+                                                      int* __restrict__ out_sidx, float* __restrict__ out_d2, IcpState* __restrict__ st,
+                                                      unsigned* __restrict__ hard, const unsigned* __restrict__ only,
+                                                      const unsigned* __restrict__ only_count)
+{
+    if (st && st->done) return;
+    const int lane = threadIdx.x;
+    const int count = (int)*only_count;
+    for (int w = blockIdx.x; w < count; w += gridDim.x) {
+        const int qi = (int)only[w];
+        const float4 r = reading[qi];
+        const float3 p = make_float3(r.x, r.y, r.z);
+        const float fx = (p.x - g.ox) * g.inv_cell, fy = (p.y - g.oy) * g.inv_cell, fz = (p.z - g.oz) * g.inv_cell;
+        const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
+        const int cx = (int)fminf(fmaxf(flx, -1.0e6f), 1.0e6f);
+        const int cy = (int)fminf(fmaxf(fly, -1.0e6f), 1.0e6f);
+        const int cz = (int)fminf(fmaxf(flz, -1.0e6f), 1.0e6f);
+        float mf = fminf(fx - flx, 1.0f - (fx - flx));
+        mf = fminf(mf, fminf(fy - fly, 1.0f - (fy - fly)));
+        mf = fminf(mf, fminf(fz - flz, 1.0f - (fz - flz)));
+        if (!(mf >= 0.f)) mf = 0.f;
+
+        KList<KMAX> Gl; Gl.init(k); // the k best so far, replicated in every lane
+        bool decided = false;
+        int ring = 0;
+        while (!decided && ring < ring_max) {
+            ++ring;
+            const int side = 2 * ring + 1;
+            KList<KMAX> Lc; Lc.init(k); // this lane's share of the ring
+            for (int r0 = lane; r0 < side * side; r0 += 64) {
+                const int dy = r0 % side - ring, dz = r0 / side - ring;
+                const bool full_row = ring == 1 || (dy == -ring || dy == ring || dz == -ring || dz == ring);
+                unsigned s, e;
+                if (full_row) {
+                    row_run(g, cs, cx - ring, cx + ring, cy + dy, cz + dz, s, e);
+                    scan_run_k<KMAX>(map, s, e, p.x, p.y, p.z, allow_self != 0, Lc);
+                } else {
+                    if (cx - ring >= 0) {
+                        row_run(g, cs, cx - ring, cx - ring, cy + dy, cz + dz, s, e);
+                        scan_run_k<KMAX>(map, s, e, p.x, p.y, p.z, allow_self != 0, Lc);
+                    }
+                    if (cx + ring <= g.nx - 1) {
+                        row_run(g, cs, cx + ring, cx + ring, cy + dy, cz + dz, s, e);
+                        scan_run_k<KMAX>(map, s, e, p.x, p.y, p.z, allow_self != 0, Lc);
+                    }
+                }
+            }
+            // merge: lane 0 also holds what the earlier rings found (shells are disjoint: no point is seen twice)
+            if (lane == 0) {
+#pragma unroll
+                for (int j = 0; j < KMAX; ++j) Lc.insert(Gl.key[j], Gl.sidx[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < KMAX; ++j) {
+                const unsigned long long head = Lc.key[0];
+                unsigned long long mk = head;
+                int ms = Lc.sidx[0];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const unsigned long long ok = __shfl_xor(mk, off, 64);
+                    const int os = __shfl_xor(ms, off, 64);
+                    if (ok < mk) { mk = ok; ms = os; }
+                }
+                Gl.key[j] = mk; Gl.sidx[j] = ms;
+                if (head == mk && mk != ~0ull) { // keys are unique: exactly one lane gives up its head
+#pragma unroll
+                    for (int i = 0; i + 1 < KMAX; ++i) { Lc.key[i] = Lc.key[i + 1]; Lc.sidx[i] = Lc.sidx[i + 1]; }
+                    Lc.key[KMAX - 1] = ~0ull; Lc.sidx[KMAX - 1] = -1;
+                }
+            }
+            const float margin = fmaxf(((float)ring + mf) * g.cell - g.slack, 0.f);
+            const float m2 = margin * margin;
+            unsigned long long kth = ~0ull;
+#pragma unroll
+            for (int i = 0; i < KMAX; ++i) if (i == k - 1) kth = Gl.key[i];
+            const float kd2 = __uint_as_float((unsigned)(kth >> 32));
+            const bool covers = cx - ring <= 0 && cx + ring >= g.nx - 1 && cy - ring <= 0 && cy + ring >= g.ny - 1 &&
+                                cz - ring <= 0 && cz + ring >= g.nz - 1;
+            decided = (kth != ~0ull && kd2 <= m2) || m2 > maxr2 || covers;
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < KMAX; ++j)
+                if (j < k) {
+                    float d2 = __uint_as_float((unsigned)(Gl.key[j] >> 32));
+                    int sx = Gl.sidx[j];
+                    if (sx < 0 || !(d2 <= maxr2)) { sx = -1; d2 = INFINITY; }
+                    out_sidx[(size_t)k * qi + j] = sx;
+                    out_d2[(size_t)k * qi + j] = d2;
+                }
+            if (!decided) {
+                const unsigned slot = atomicAdd(&st->hard_count, 1u);
+                hard[slot] = (unsigned)qi;
+            }
+        }
+    }
+}
+
 // between the tiled self-search and its redo: queue length -> queue[m + 1] (read by the ring kernel as `only_count`),
 // hard_count reset so that the ring kernel can queue its own left-overs for the brute-force pass
 __global__ void nnk_redo_kernel(IcpState* st, unsigned* len_slot)
@@ -1168,9 +1273,16 @@ static icpmi_status nn_self_knn_t(icpmi_ctx* c, const LoopCfg& lc, int* d_sidx, 
     // left-overs (k-th neighbour beyond the margin: sparse regions, map border): ring search, then brute force
     const int blocks = (int)((c->m + NN_BLOCK - 1) / NN_BLOCK);
     hipLaunchKernelGGL(nnk_redo_kernel, dim3(1), dim3(64), 0, c->stream, d_state, c->d_hard + c->m + 1);
-    hipLaunchKernelGGL(nnk_kernel<KMAX>, dim3(blocks), dim3(NN_BLOCK), 0, c->stream, c->d_reading, (int)c->m, (const float*)nullptr, g,
-                       c->d_map_sorted, c->d_cell_start, lc.k, lc.maxr2, lc.ring_max, 1, d_sidx, d_d2, d_state,
-                       c->d_hard + c->m + 2, (const unsigned*)c->d_hard, (const unsigned*)(c->d_hard + c->m + 1));
+    static int wave_redo = -1;
+    if (wave_redo < 0) { const char* e = getenv("ICPMI_SELF_REDO_WAVE"); wave_redo = e ? atoi(e) : 1; }
+    if (wave_redo)
+        hipLaunchKernelGGL(nnk_wave_kernel<KMAX>, dim3(4096), dim3(64), 0, c->stream, c->d_reading, g, c->d_map_sorted, c->d_cell_start, lc.k,
+                           lc.maxr2, lc.ring_max, 1, d_sidx, d_d2, d_state, c->d_hard + c->m + 2, (const unsigned*)c->d_hard,
+                           (const unsigned*)(c->d_hard + c->m + 1));
+    else
+        hipLaunchKernelGGL(nnk_kernel<KMAX>, dim3(blocks), dim3(NN_BLOCK), 0, c->stream, c->d_reading, (int)c->m, (const float*)nullptr, g,
+                           c->d_map_sorted, c->d_cell_start, lc.k, lc.maxr2, lc.ring_max, 1, d_sidx, d_d2, d_state,
+                           c->d_hard + c->m + 2, (const unsigned*)c->d_hard, (const unsigned*)(c->d_hard + c->m + 1));
     hipLaunchKernelGGL(nnk_hard_kernel<KMAX>, dim3(512), dim3(NN_BLOCK), 0, c->stream, c->d_reading, (const float*)nullptr, c->d_map_sorted,
                        (int)c->m, lc.k, lc.maxr2, 1, d_sidx, d_d2, d_state, (const unsigned*)(c->d_hard + c->m + 2));
     hipLaunchKernelGGL(hard_reset_kernel, dim3(1), dim3(64), 0, c->stream, d_state);
