@@ -209,22 +209,25 @@ static std::vector<float> scalarRow(const DataPoints& cloud, const std::string& 
 
 void GpuICPSequence::mapUpdateChain(const DataPoints* input, const Mat4& correction, const std::string& scalarName, const DataPoints& scanDescriptors,
                                     const Mat4& toSensor, const std::vector<icpmi_map_op>& ops, int nModules, std::vector<int32_t>& src,
-                                    int64_t& prefix, int64_t& mapSize)
+                                    int64_t& prefix, int64_t& mapSize, bool wantSrc)
 {
     const size_t n = input ? input->getNbPoints() : stagedPoints;
     std::vector<float> scalar;
     if (!scalarName.empty()) scalar = scalarRow(scanDescriptors, scalarName);
     const float* sp = scalarName.empty() ? nullptr : scalar.data();
-    src.resize((size_t)residentMapSize() + (size_t)(nModules > 0 ? nModules : 1) * n + 1);
+    src.resize(wantSrc ? (size_t)residentMapSize() + (size_t)(nModules > 0 ? nModules : 1) * n + 1 : 0);
+    int32_t* srcp = wantSrc ? src.data() : nullptr;
+    int64_t* prefp = wantSrc ? &prefix : nullptr;
+    prefix = 0;
     if (input) {
         const float* normals = nullptr;
         if (input->descriptorExists("normals") && input->getDescriptorByName("normals").span == 3) normals = input->getDescriptorByName("normals").data.data();
         check(h, icpmi_map_update_chain(h, input->features.data(), (int64_t)n, normals, sp, toSensor.data(), ops.data(), (int32_t)ops.size(), nModules,
-                                        src.data(), (int64_t)src.size(), &prefix, &mapSize));
+                                        srcp, (int64_t)src.size(), prefp, &mapSize));
     } else
-        check(h, icpmi_map_update_chain_staged(h, correction.data(), sp, toSensor.data(), ops.data(), (int32_t)ops.size(), nModules, src.data(),
-                                               (int64_t)src.size(), &prefix, &mapSize));
-    src.resize((size_t)mapSize);
+        check(h, icpmi_map_update_chain_staged(h, correction.data(), sp, toSensor.data(), ops.data(), (int32_t)ops.size(), nModules, srcp,
+                                               (int64_t)src.size(), prefp, &mapSize));
+    if (wantSrc) src.resize((size_t)mapSize);
 }
 
 void GpuICPSequence::uploadMapScalar(const std::vector<float>& scalar) { check(h, icpmi_set_map_scalar(h, scalar.data(), (int64_t)scalar.size())); }

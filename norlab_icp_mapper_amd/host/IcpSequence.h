@@ -50,7 +50,7 @@ public:
     // src[j] for j >= prefix: provenance of new map point j in [old map ; scan]; the first `prefix` points are untouched.
     void mapUpdateChain(const DataPoints* inputInMapFrame, const Mat4& correction, const std::string& scalarName, const DataPoints& scanDescriptors,
                         const Mat4& toSensor, const std::vector<icpmi_map_op>& ops, int nModules, std::vector<int32_t>& src, int64_t& prefix,
-                        int64_t& mapSize);
+                        int64_t& mapSize, bool wantSrc = true); // wantSrc = false: no host-side descriptor needs the provenance vector
     void uploadMapScalar(const std::vector<float>& scalar);   // the tracked scalar descriptor of the resident map
     std::vector<float> downloadMapScalar() const;
     int64_t residentMapSize() const;

@@ -267,6 +267,16 @@ bool Map::residentPlan(const DataPoints& input, const DataPointsFilters& postFil
     return true;
 }
 
+bool Map::hostDescriptorsFollow(const DataPoints& input, const ResidentProgram& prog, bool first) const
+{
+    const std::vector<Descriptor>& fields = first ? input.descriptors : localPointCloud.descriptors;
+    for (const Descriptor& d : fields) {
+        if (d.name == "normals" || d.name == prog.scalarName) continue;
+        if (input.descriptorExists(d.name) && input.getDescriptorByName(d.name).span == d.span) return true;
+    }
+    return false;
+}
+
 void Map::prepareResidentScalar(const ResidentProgram& prog, bool first)
 {
     // the host copy is the authority whenever the device does not run ahead: hand it the tracked scalar (icp.setMap carries
@@ -326,7 +336,8 @@ bool Map::tryResidentUpdate(const DataPoints& input, const Mat4& pose, const Dat
     int64_t prefix = 0, m = 0;
     {
         std::lock_guard<std::mutex> gi(icpMapLock);
-        icp.mapUpdateChain(&input, Mat4::identity(), prog.scalarName, input, pose.inverse(), prog.ops, prog.nModules, src, prefix, m);
+        icp.mapUpdateChain(&input, Mat4::identity(), prog.scalarName, input, pose.inverse(), prog.ops, prog.nModules, src, prefix, m,
+                           hostDescriptorsFollow(input, prog, first));
     }
     adoptResidentResult(input, prog, src, prefix, m, first);
     return true;
@@ -353,7 +364,8 @@ void Map::updateLocalPointCloudStaged(const DataPoints& inputDescriptors, const 
     int64_t prefix = 0, m = 0;
     {
         std::lock_guard<std::mutex> gi(icpMapLock);
-        icp.mapUpdateChain(nullptr, correction, prog.scalarName, inputDescriptors, pose.inverse(), prog.ops, prog.nModules, src, prefix, m);
+        icp.mapUpdateChain(nullptr, correction, prog.scalarName, inputDescriptors, pose.inverse(), prog.ops, prog.nModules, src, prefix, m,
+                           hostDescriptorsFollow(inputDescriptors, prog, first));
     }
     adoptResidentResult(inputDescriptors, prog, src, prefix, m, first);
 }

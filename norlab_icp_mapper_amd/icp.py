@@ -396,7 +396,7 @@ class ICPSequence:
         return ops
 
     def mapUpdateChain(self, scan_in_map_frame, modules, post=(), scan_scalar=None, scan_normals=None, to_sensor=None, staged_correction=None,
-                       with_prefix=False):
+                       with_prefix=False, want_src=True):
         """Map::updateLocalPointCloud (Map.cpp:502-534) for a whole module chain + post filters on the resident map.
         Returns (src, m): new map point j was point src[j] of [old map ; scan].  With staged_correction the scan is the
         one staged by registerWithPrior (scan_in_map_frame is ignored)."""
@@ -408,6 +408,19 @@ class ICPSequence:
         new_m = C.c_int64(0)
         head = C.c_int64(0)
         hp = C.byref(head) if with_prefix else None
+        if not want_src:   # a caller without further descriptors does not need the provenance vector (3 MB per update at 800 k points)
+            Tc = None if staged_correction is None else _T_to_c(staged_correction)
+            if staged_correction is not None:
+                self._check(self._lib.icpmi_map_update_chain_staged(self._h, Tc.ctypes.data, None if ss is None else ss.ctypes.data,
+                                                                    None if Ts is None else Ts.ctypes.data, ops, len(ops), len(modules),
+                                                                    None, 0, None, C.byref(new_m)))
+            else:
+                sc = _f32c(scan_in_map_frame, 4)
+                sn = None if scan_normals is None else _f32c(scan_normals, 3)
+                self._check(self._lib.icpmi_map_update_chain(self._h, sc.ctypes.data, sc.shape[0], None if sn is None else sn.ctypes.data,
+                                                             None if ss is None else ss.ctypes.data, None if Ts is None else Ts.ctypes.data,
+                                                             ops, len(ops), len(modules), None, 0, None, C.byref(new_m)))
+            return None, int(new_m.value)
         if staged_correction is not None:
             n = self._staged_n
             src = np.empty(m_old.value + max(1, len(modules)) * n + 1, dtype=np.int32)
