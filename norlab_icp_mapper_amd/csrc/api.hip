@@ -96,6 +96,7 @@ icpmi_status icpmi_create(const icpmi_config* cfg, icpmi_handle* out)
     CR(hipMalloc((void**)&c->d_selhist, ICPMI_SELHIST_WORDS * sizeof(unsigned)));
     CR(hipMemset(c->d_selhist, 0, ICPMI_SELHIST_WORDS * sizeof(unsigned)));
     CR(hipHostMalloc((void**)&c->h_state, sizeof(IcpState), hipHostMallocDefault));
+    CR(hipHostMalloc((void**)&c->h_pin, ICPMI_PIN_BYTES, hipHostMallocDefault));
     CR(hipEventCreate(&c->ev0));
     CR(hipEventCreate(&c->ev1));
 #undef CR
@@ -136,6 +137,7 @@ void icpmi_destroy(icpmi_handle c)
     hipFree(c->d_sidx); hipFree(c->d_d2); hipFree(c->d_hard); hipFree(c->d_partials); hipFree(c->d_selhist);
     hipFree(c->d_state);
     if (c->h_state) hipHostFree(c->h_state);
+    if (c->h_pin) hipHostFree(c->h_pin);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     for (hipEvent_t e : c->nn_events) hipEventDestroy(e);

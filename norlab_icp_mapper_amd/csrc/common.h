@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <cstring>
 #include <string>
 #include <vector>
 #include <unordered_map>
@@ -186,6 +187,7 @@ struct icpmi_ctx {
     bool nn_out_sorted = false;       // set by the NN launcher: true if the launched kernel did so
     IcpState* d_state = nullptr;
     IcpState* h_state = nullptr;                               // pinned mirror
+    unsigned char* h_pin = nullptr;                            // pinned page for small read-backs (counts, statistics)
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> nn_events;
@@ -226,6 +228,26 @@ struct DevBuf {
     hipError_t alloc(size_t n) { return hipMalloc((void**)&p, (n ? n : 1) * sizeof(T)); }
     operator T*() const { return p; }
 };
+
+// Small device -> host read through the pinned page: a copy into pageable memory is staged and blocks for tens of
+// microseconds, and a map update makes a dozen of them (counts after every compaction, grid statistics).
+#define ICPMI_PIN_BYTES (128 * 1024)
+static inline icpmi_status read_back2(icpmi_ctx* c, void* dst0, const void* src0, size_t b0, void* dst1, const void* src1, size_t b1)
+{
+    if (!c->h_pin || b0 + b1 > ICPMI_PIN_BYTES) {
+        HIP_TRY(c, hipMemcpyAsync(dst0, src0, b0, hipMemcpyDeviceToHost, c->stream));
+        if (b1) HIP_TRY(c, hipMemcpyAsync(dst1, src1, b1, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return ICPMI_OK;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->h_pin, src0, b0, hipMemcpyDeviceToHost, c->stream));
+    if (b1) HIP_TRY(c, hipMemcpyAsync(c->h_pin + b0, src1, b1, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    memcpy(dst0, c->h_pin, b0);
+    if (b1) memcpy(dst1, c->h_pin + b0, b1);
+    return ICPMI_OK;
+}
+static inline icpmi_status read_back(icpmi_ctx* c, void* dst, const void* src, size_t bytes) { return read_back2(c, dst, src, bytes, nullptr, nullptr, 0); }
 
 // slot `k` of the operator scratch, at least `count` entries of T (contents undefined)
 template <typename T>

@@ -419,8 +419,7 @@ static icpmi_status grid_count(icpmi_ctx* c, const float4* d_pts, int64_t m, con
     hipLaunchKernelGGL(key_kernel, dim3(blocks), dim3(256), 0, c->stream, d_pts, m, c->mean[0], c->mean[1], c->mean[2], g,
                        c->d_keys, c->d_cell_start, d_nocc);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(h_nocc, d_nocc, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (read_back(c, h_nocc, d_nocc, sizeof(unsigned)) != ICPMI_OK) return ICPMI_ERR_HIP;
     return ICPMI_OK;
 }
 
@@ -445,8 +444,7 @@ icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float
     hipLaunchKernelGGL(stats_kernel, dim3(rblocks), dim3(RB), 0, c->stream, d_pts, m, c->d_red);
     HIP_TRY(c, hipGetLastError());
     std::vector<double> part((size_t)rblocks * 9);
-    HIP_TRY(c, hipMemcpyAsync(part.data(), c->d_red, part.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (read_back(c, part.data(), c->d_red, part.size() * sizeof(double)) != ICPMI_OK) return ICPMI_ERR_HIP;
     double sum[3] = {0, 0, 0};
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int b = 0; b < rblocks; ++b)

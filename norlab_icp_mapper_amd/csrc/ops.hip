@@ -787,9 +787,7 @@ icpmi_status ops_map_update_dev(icpmi_ctx* c, const float4* d_scan, int64_t n, c
     if (s == ICPMI_OK && e == hipSuccess && m0 > 0) {
         // count = scan[n-1] + flag[n-1]; the scan overwrote the flags, so recompute the last flag from d2
         unsigned last_pos = 0; float last_d2 = 0.f;
-        e = hipMemcpyAsync(&last_pos, d_flag + (n - 1), sizeof(unsigned), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(&last_d2, c->d_d2 + (n - 1), sizeof(float), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (read_back2(c, &last_pos, d_flag + (n - 1), sizeof(unsigned), &last_d2, c->d_d2 + (n - 1), sizeof(float)) != ICPMI_OK) e = hipErrorUnknown;
         count = last_pos + (last_d2 >= lim ? 1u : 0u);
     } else if (m0 == 0) count = (unsigned)n;
     if (s == ICPMI_OK && e == hipSuccess && count > 0) {
@@ -954,9 +952,7 @@ icpmi_status chain_compact(Chain& w, unsigned* d_flag, unsigned* d_pos)
     icpmi_status s = device_exclusive_scan(c, d_pos, (int)m, 0u);
     if (s != ICPMI_OK) return s;
     unsigned last_pos = 0, last_flag = 0;
-    HIP_TRY(c, hipMemcpyAsync(&last_pos, d_pos + (m - 1), sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(&last_flag, d_flag + (m - 1), sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (read_back2(c, &last_pos, d_pos + (m - 1), sizeof(unsigned), &last_flag, d_flag + (m - 1), sizeof(unsigned)) != ICPMI_OK) return ICPMI_ERR_HIP;
     const int64_t count = (int64_t)last_pos + last_flag;
     if (count == m) return ICPMI_OK; // nothing dropped
     if (ensure_cap(c, &c->d_alt_raw, &c->cap_alt_raw, (size_t)count + 1) != ICPMI_OK || ensure_cap(c, &c->d_alt_n3, &c->cap_alt_n3, (size_t)count * 3 + 1) != ICPMI_OK ||
@@ -1077,9 +1073,7 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
             s = device_exclusive_scan(c, d_pos, (int)n, 0u);
             if (s != ICPMI_OK) break;
             unsigned lp = 0, lf = 0;
-            HIP_TRY(c, hipMemcpyAsync(&lp, d_pos + (n - 1), sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, hipMemcpyAsync(&lf, d_flag + (n - 1), sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (read_back2(c, &lp, d_pos + (n - 1), sizeof(unsigned), &lf, d_flag + (n - 1), sizeof(unsigned)) != ICPMI_OK) return ICPMI_ERR_HIP;
             s = chain_append(w, d_scan, d_scan_n3, d_scan_s, n, d_flag, d_pos, (int64_t)lp + lf, src_base);
             break;
         }
@@ -1134,8 +1128,7 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
             unsigned first_moved = (unsigned)w.m;
             HIP_TRY(c, hipMemcpyAsync(d_pos, &first_moved, sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
             hipLaunchKernelGGL(chain_prefix_kernel, dim3((int)((w.m + 255) / 256)), dim3(256), 0, c->stream, c->d_src, w.m, d_pos);
-            HIP_TRY(c, hipMemcpyAsync(&first_moved, d_pos, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (read_back(c, &first_moved, d_pos, sizeof(unsigned)) != ICPMI_OK) return ICPMI_ERR_HIP;
             head = first_moved;
             *identity_prefix = head;
         }
