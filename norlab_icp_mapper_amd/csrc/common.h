@@ -173,6 +173,7 @@ struct icpmi_ctx {
     float* d_T16 = nullptr;           // a 4x4 for device-side transforms
     icpmi_ctx* temp = nullptr;        // private handle of the map-side operators (indexes arbitrary clouds), created on first use
     bool single_level = false;        // temp handles of the self k-NN (surface normals): level 0 of the pyramid is all they search
+    bool keep_raw = true;             // temp handles index clouds they do not own: no resident copy of the input
     bool no_centre = false;           // temp handles of the map-side operators: index raw coordinates (mean = 0)
     int*    d_sidx = nullptr; size_t cap_sidx = 0;             // k x n sorted-map index (-1 none)
     float*  d_d2 = nullptr; size_t cap_d2 = 0;                 // k x n

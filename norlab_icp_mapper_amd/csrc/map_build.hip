@@ -523,16 +523,16 @@ icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float
     if (d_normals3 && ensure_cap(c, &c->d_normals_sorted, &c->cap_normals, (size_t)m) != ICPMI_OK) return ICPMI_ERR_HIP;
     c->has_normals = d_normals3 != nullptr;
     // resident raw copy (skipped when the caller IS the raw copy: the device-side map update)
-    if (d_pts != c->d_raw) {
+    if (d_pts != c->d_raw && c->keep_raw) {
         c->raw_has_scalar = false; // a map handed in from outside: its scalar channel comes through icpmi_set_map_scalar
         if (ensure_cap(c, &c->d_raw, &c->cap_raw, (size_t)m) != ICPMI_OK) return ICPMI_ERR_HIP;
         HIP_TRY(c, hipMemcpyAsync(c->d_raw, d_pts, (size_t)m * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
     }
-    if (d_normals3 && d_normals3 != c->d_raw_n3) {
+    if (d_normals3 && d_normals3 != c->d_raw_n3 && c->keep_raw) {
         if (ensure_cap(c, &c->d_raw_n3, &c->cap_raw_n3, (size_t)m * 3) != ICPMI_OK) return ICPMI_ERR_HIP;
         HIP_TRY(c, hipMemcpyAsync(c->d_raw_n3, d_normals3, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     }
-    c->m_raw = m; c->raw_has_normals = d_normals3 != nullptr;
+    c->m_raw = c->keep_raw ? m : 0; c->raw_has_normals = c->keep_raw && d_normals3 != nullptr;
     const int blocks = (int)((m + 255) / 256);
     hipLaunchKernelGGL(scatter_kernel, dim3(blocks), dim3(256), 0, c->stream, d_pts, d_normals3, m, c->mean[0], c->mean[1], c->mean[2],
                        c->d_keys, c->d_cell_start, c->d_fill, c->d_map_sorted, d_normals3 ? c->d_normals_sorted : nullptr);

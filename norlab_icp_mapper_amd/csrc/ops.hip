@@ -419,6 +419,7 @@ static icpmi_status make_temp(icpmi_ctx* c, TempCtx& t)
     }
     t.h = c->temp;
     t.h->cfg = c->cfg;
+    t.h->keep_raw = false;
     t.h->no_centre = true; // PointDistanceMapperModule.cpp:33 / SurfaceNormalDataPointsFilter build their kd-tree on the raw cloud
     t.h->single_level = false;
     return ICPMI_OK;
