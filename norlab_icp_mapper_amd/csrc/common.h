@@ -310,7 +310,7 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
 icpmi_status nn_launch_k(icpmi_ctx* c, const float4* d_reading, int64_t n, const float* d_T, const LoopCfg& lc,
                          int allow_self, int* d_sidx, float* d_d2, IcpState* d_state);
 icpmi_status nn_ids_to_original(icpmi_ctx* c, const int* d_sidx, int64_t count, int* d_ids);
-icpmi_status nn_self_knn(icpmi_ctx* c, const LoopCfg& lc, int* d_sidx, float* d_d2, IcpState* d_state);
+icpmi_status nn_self_knn(icpmi_ctx* c, const float4* d_cloud, const LoopCfg& lc, int* d_sidx, float* d_d2, IcpState* d_state);
 icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals3, int64_t n, const LoopCfg& lc, bool fixed, float T_out[16],
                       icpmi_stats* stats);
 icpmi_status loop_prepare_reading(icpmi_ctx* c, const float4* d_scan, int64_t n, const float* d_normals3);

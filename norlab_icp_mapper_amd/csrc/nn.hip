@@ -1262,7 +1262,7 @@ icpmi_status nn_launch_k(icpmi_ctx* c, const float4* d_reading, int64_t n, const
 }
 
 template <int KMAX>
-static icpmi_status nn_self_knn_t(icpmi_ctx* c, const LoopCfg& lc, int* d_sidx, float* d_d2, IcpState* d_state)
+static icpmi_status nn_self_knn_t(icpmi_ctx* c, const float4* d_cloud, const LoopCfg& lc, int* d_sidx, float* d_d2, IcpState* d_state)
 {
     const GridParams& g = c->grid;
     const int nsx = (g.nx + SELF_SEG - 1) / SELF_SEG;
@@ -1276,30 +1276,30 @@ static icpmi_status nn_self_knn_t(icpmi_ctx* c, const LoopCfg& lc, int* d_sidx, 
     static int wave_redo = -1;
     if (wave_redo < 0) { const char* e = getenv("ICPMI_SELF_REDO_WAVE"); wave_redo = e ? atoi(e) : 1; }
     if (wave_redo)
-        hipLaunchKernelGGL(nnk_wave_kernel<KMAX>, dim3(4096), dim3(64), 0, c->stream, c->d_reading, g, c->d_map_sorted, c->d_cell_start, lc.k,
+        hipLaunchKernelGGL(nnk_wave_kernel<KMAX>, dim3(4096), dim3(64), 0, c->stream, d_cloud, g, c->d_map_sorted, c->d_cell_start, lc.k,
                            lc.maxr2, lc.ring_max, 1, d_sidx, d_d2, d_state, c->d_hard + c->m + 2, (const unsigned*)c->d_hard,
                            (const unsigned*)(c->d_hard + c->m + 1));
     else
-        hipLaunchKernelGGL(nnk_kernel<KMAX>, dim3(blocks), dim3(NN_BLOCK), 0, c->stream, c->d_reading, (int)c->m, (const float*)nullptr, g,
+        hipLaunchKernelGGL(nnk_kernel<KMAX>, dim3(blocks), dim3(NN_BLOCK), 0, c->stream, d_cloud, (int)c->m, (const float*)nullptr, g,
                            c->d_map_sorted, c->d_cell_start, lc.k, lc.maxr2, lc.ring_max, 1, d_sidx, d_d2, d_state,
                            c->d_hard + c->m + 2, (const unsigned*)c->d_hard, (const unsigned*)(c->d_hard + c->m + 1));
-    hipLaunchKernelGGL(nnk_hard_kernel<KMAX>, dim3(512), dim3(NN_BLOCK), 0, c->stream, c->d_reading, (const float*)nullptr, c->d_map_sorted,
+    hipLaunchKernelGGL(nnk_hard_kernel<KMAX>, dim3(512), dim3(NN_BLOCK), 0, c->stream, d_cloud, (const float*)nullptr, c->d_map_sorted,
                        (int)c->m, lc.k, lc.maxr2, 1, d_sidx, d_d2, d_state, (const unsigned*)(c->d_hard + c->m + 2));
     hipLaunchKernelGGL(hard_reset_kernel, dim3(1), dim3(64), 0, c->stream, d_state);
     HIP_TRY(c, hipGetLastError());
     return ICPMI_OK;
 }
 
-// self k-NN of the indexed cloud: c->d_reading must hold the cloud in its original order (for the redo passes),
+// self k-NN of the indexed cloud: d_cloud is that cloud in its original order and in the frame of the index (for the redo passes),
 // c->d_hard at least 2 m + 4 words
-icpmi_status nn_self_knn(icpmi_ctx* c, const LoopCfg& lc, int* d_sidx, float* d_d2, IcpState* d_state)
+icpmi_status nn_self_knn(icpmi_ctx* c, const float4* d_cloud, const LoopCfg& lc, int* d_sidx, float* d_d2, IcpState* d_state)
 {
-    if (lc.k <= 4) return nn_self_knn_t<4>(c, lc, d_sidx, d_d2, d_state);
-    if (lc.k <= 8) return nn_self_knn_t<8>(c, lc, d_sidx, d_d2, d_state);
+    if (lc.k <= 4) return nn_self_knn_t<4>(c, d_cloud, lc, d_sidx, d_d2, d_state);
+    if (lc.k <= 8) return nn_self_knn_t<8>(c, d_cloud, lc, d_sidx, d_d2, d_state);
     // knn 10 is the shipped post filter (examples/config.yaml:26-27): a list of exactly 10 inserts less often and cheaper than one of 16
-    if (lc.k <= 10) return nn_self_knn_t<10>(c, lc, d_sidx, d_d2, d_state);
-    if (lc.k <= 16) return nn_self_knn_t<16>(c, lc, d_sidx, d_d2, d_state);
-    if (lc.k <= 32) return nn_self_knn_t<32>(c, lc, d_sidx, d_d2, d_state);
+    if (lc.k <= 10) return nn_self_knn_t<10>(c, d_cloud, lc, d_sidx, d_d2, d_state);
+    if (lc.k <= 16) return nn_self_knn_t<16>(c, d_cloud, lc, d_sidx, d_d2, d_state);
+    if (lc.k <= 32) return nn_self_knn_t<32>(c, d_cloud, lc, d_sidx, d_d2, d_state);
     c->last_error = "knn > 32 is not supported";
     return ICPMI_ERR_UNSUPPORTED;
 }

@@ -510,13 +510,14 @@ static icpmi_status temp_knn(icpmi_ctx* c, TempCtx& t, const float* cloud4, int6
     icpmi_status s = icpmi_set_map(t.h, cloud4, m, nullptr, &acc);
     if (s != ICPMI_OK) { c->last_error = tc->last_error; return s; }
     // queries: stage + centre on the temp map's mean (the index lives in the centred frame)
-    if (ensure_cap(tc, &tc->d_stage_in, &tc->cap_stage_in, (size_t)n + 1) != ICPMI_OK) { c->last_error = tc->last_error; return ICPMI_ERR_HIP; }
-    HIP_TRY(c, hipMemcpyAsync(tc->d_stage_in, queries_are_cloud ? cloud4 : q4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, tc->stream));
-    if (self) { // the redo passes read the cloud in its own order; no tile sort needed
-        if (ensure_cap(tc, &tc->d_reading, &tc->cap_reading, (size_t)n + 1) != ICPMI_OK) { c->last_error = tc->last_error; return ICPMI_ERR_HIP; }
-        HIP_TRY(c, hipMemcpyAsync(tc->d_reading, tc->d_stage_in, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, tc->stream));
-        s = ICPMI_OK;
-    } else
+    // (the cloud itself is already there: icpmi_set_map staged it in d_stage_in -- no second upload, and no re-sizing
+    // of that buffer, which would drop it)
+    if (!queries_are_cloud) {
+        if (ensure_cap(tc, &tc->d_stage_in, &tc->cap_stage_in, (size_t)n + 1) != ICPMI_OK) { c->last_error = tc->last_error; return ICPMI_ERR_HIP; }
+        HIP_TRY(c, hipMemcpyAsync(tc->d_stage_in, q4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, tc->stream));
+    }
+    if (self) s = ICPMI_OK; // the redo passes read the staged cloud in its own order; no tile sort, no copy
+    else
         s = loop_prepare_reading(tc, tc->d_stage_in, n, nullptr);
     if (s != ICPMI_OK) { c->last_error = tc->last_error; return s; }
     LoopCfg lc = make_loop_cfg(tc, 1);
@@ -528,7 +529,7 @@ static icpmi_status temp_knn(icpmi_ctx* c, TempCtx& t, const float* cloud4, int6
     tc->nn_hist0 = nullptr; tc->nn_iter_hint = 0; tc->nn_match_pt = nullptr;
     if (self) {
         if (ensure_cap(tc, &tc->d_hard, &tc->cap_hard, (size_t)2 * m + 8) != ICPMI_OK) { c->last_error = tc->last_error; return ICPMI_ERR_HIP; }
-        s = nn_self_knn(tc, lc, tc->d_sidx, tc->d_d2, tc->d_state);
+        s = nn_self_knn(tc, tc->d_stage_in, lc, tc->d_sidx, tc->d_d2, tc->d_state);
     } else
         s = nn_launch_k(tc, tc->d_reading, n, nullptr, lc, allow_self, tc->d_sidx, tc->d_d2, tc->d_state);
     if (s != ICPMI_OK) { c->last_error = tc->last_error; return s; }
@@ -700,8 +701,6 @@ static icpmi_status surface_normals_dev(icpmi_ctx* c, const float4* d_pts, int64
     int32_t acc = 0;
     s = icpmi_set_map_dev(t.h, (const float*)d_pts, m, nullptr, &acc);
     if (s != ICPMI_OK) { c->last_error = tc->last_error; return s; }
-    if (ensure_cap(tc, &tc->d_reading, &tc->cap_reading, (size_t)m + 1) != ICPMI_OK) { c->last_error = tc->last_error; return ICPMI_ERR_HIP; }
-    HIP_TRY(c, hipMemcpyAsync(tc->d_reading, d_pts, (size_t)m * sizeof(float4), hipMemcpyDeviceToDevice, tc->stream));
     LoopCfg lc = make_loop_cfg(tc, 1);
     lc.k = knn; lc.max_dist = INFINITY; lc.maxr2 = INFINITY; lc.ring_max = 6;
     const size_t cnt = (size_t)m * knn + 1;
@@ -710,7 +709,7 @@ static icpmi_status surface_normals_dev(icpmi_ctx* c, const float4* d_pts, int64
     HIP_TRY(c, hipMemsetAsync(tc->d_state, 0, sizeof(IcpState), tc->stream));
     tc->nn_hist0 = nullptr; tc->nn_iter_hint = 0; tc->nn_match_pt = nullptr;
     if (ensure_cap(tc, &tc->d_hard, &tc->cap_hard, (size_t)2 * m + 8) != ICPMI_OK) { c->last_error = tc->last_error; return ICPMI_ERR_HIP; }
-    s = nn_self_knn(tc, lc, tc->d_sidx, tc->d_d2, tc->d_state);
+    s = nn_self_knn(tc, d_pts, lc, tc->d_sidx, tc->d_d2, tc->d_state);
     if (s != ICPMI_OK) { c->last_error = tc->last_error; return s; }
     // rows of d_sidx follow the query order = the caller's order, so the normals land in place
     hipLaunchKernelGGL(normals_kernel, dim3((int)((m + 127) / 128)), dim3(128), 0, tc->stream, tc->d_map_sorted, tc->d_sidx, m, knn, d_normals3);
