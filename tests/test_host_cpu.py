@@ -45,6 +45,23 @@ def test_config_defaults_and_struct_layout():
     assert C.sizeof(_capi.Config) == 5 * 4 + 8 * 8 + 12 * 4 + 8 * 4
 
 
+def test_operator_structs_match_the_header(tmp_path):
+    """icpmi_map_op / icpmi_point_filter / icpmi_dynpts_params as gcc lays them out from include/icpmi.h
+    against the ctypes mirrors the tests and the bench bind."""
+    import subprocess
+    from norlab_icp_mapper_amd import _capi
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "icpmi.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu\\n", '
+                   'sizeof(icpmi_map_op), offsetof(icpmi_map_op, f), sizeof(icpmi_point_filter), offsetof(icpmi_point_filter, f), '
+                   'sizeof(icpmi_dynpts_params), sizeof(icpmi_stats)); return 0; }\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert got[0] == C.sizeof(_capi.MapOp) and got[1] == _capi.MapOp.f.offset
+    assert got[2] == C.sizeof(_capi.PointFilter) and got[3] == _capi.PointFilter.f.offset
+    assert got[4] == 7 * 4 and got[5] == C.sizeof(_capi.Stats)
+
+
 def test_create_without_gpu_fails_loudly():
     import torch
     if torch.cuda.is_available():
