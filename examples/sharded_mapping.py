@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--scan-points", type=int, default=100_000)
     ap.add_argument("--epochs", type=int, default=6)
     ap.add_argument("--min-dist", type=float, default=0.15)
+    ap.add_argument("--backend", default="resident", choices=["resident", "host"],
+                    help="resident: the map stays in HBM, only scans and accepted points cross PCIe; host: every operator takes host arrays")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     use_pg = "RANK" in os.environ and "MASTER_PORT" in os.environ
@@ -30,7 +32,8 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
     scene = pkg.synth.make_scene(m=args.map_points, n=8)
     icp = pkg.ICPSequence(device=local, minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=40, use_differential=1)
-    mapper = ShardedMapper(ShardedMapper.gpu_backend(icp), min_dist_new_point=args.min_dist, normals_knn=10)
+    backend = ShardedMapper.resident_backend(icp) if args.backend == "resident" else ShardedMapper.gpu_backend(icp)
+    mapper = ShardedMapper(backend, min_dist_new_point=args.min_dist, normals_knn=10)
     mapper.set_map(scene["map"][::2])                        # start from half of the surface samples: the streams fill it in
     scans = [pkg.synth.make_scene(m=8, n=args.scan_points, seed_scan=100 + 1000 * rank + e) for e in range(args.epochs)]
     if use_pg: dist.barrier()
@@ -40,11 +43,11 @@ def main():
         dt, dr = pkg.synth.pose_error(pose, sc["T_gt"])
         if rank == 0:
             print(f"epoch {e}: rank 0 pose error {dt:.4f} m / {dr:.5f} rad, {mine} points offered by rank 0, {appended} appended by all ranks, "
-                  f"map {mapper.map.shape[0]}")
+                  f"map {mapper._resident_points if args.backend == 'resident' else mapper.map.shape[0]}")
     if use_pg: dist.barrier()
     torch.cuda.synchronize(); secs = time.perf_counter() - t0
     if rank == 0:
-        print(f"{world} stream(s) x {args.epochs} epochs in {secs:.2f} s = {world * args.epochs / secs:.1f} scans/s (host-array map exchange)")
+        print(f"{world} stream(s) x {args.epochs} epochs in {secs:.2f} s = {world * args.epochs / secs:.1f} scans/s ({args.backend} map)")
     if use_pg: dist.destroy_process_group()
 
 

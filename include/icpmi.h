@@ -209,6 +209,14 @@ icpmi_status icpmi_register_prior(icpmi_handle h, const float* scan4, int64_t n,
 icpmi_status icpmi_map_update_staged(icpmi_handle h, const float correction[16], float min_dist, int32_t normals_knn,
                                      uint8_t* keep_out, int64_t* appended, int64_t* new_m);
 
+/* `PointDistanceMapperModule` keep mask of the scan staged by icpmi_register_prior against the RESIDENT map, without
+ * touching the map (scan-sharded mapping, SURVEY.md 8e: every rank decides which of its points are new, the accepted
+ * points of all ranks are exchanged, and only then does every replica append the same set): the staged cloud is moved by
+ * `correction` (Mapper.cpp:221); keep_out[i] = 1 iff its exact nearest map neighbour is at least min_dist away
+ * (PointDistanceMapperModule.cpp:33-42); placed_out4 (n x 4, may be NULL) receives the moved cloud. */
+icpmi_status icpmi_staged_point_distance_keep(icpmi_handle h, const float correction[16], float min_dist, uint8_t* keep_out,
+                                              float* placed_out4);
+
 /* Download of the resident map in the caller's order (what `Map::getLocalPointCloud` returns, Map.cpp:536-540);
  * out4 / normals3 may be NULL to query *m only. */
 icpmi_status icpmi_get_map(icpmi_handle h, float* out4, float* normals3, int64_t capacity, int64_t* m);

@@ -425,6 +425,14 @@ icpmi_status icpmi_map_update_staged(icpmi_handle h, const float correction[16],
     return ops_map_update_dev(h, h->d_stage_in, n, nullptr, min_dist, normals_knn, keep_out, appended, new_m);
 }
 
+icpmi_status icpmi_staged_point_distance_keep(icpmi_handle h, const float correction[16], float min_dist, uint8_t* keep_out, float* placed_out4)
+{
+    CHECK_H(h);
+    if (!correction || !keep_out || !(min_dist >= 0.f)) { h->last_error = "staged_point_distance_keep: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
+    if (h->scan_map_n <= 0) { h->last_error = "staged_point_distance_keep: no scan staged by icpmi_register_prior"; return ICPMI_ERR_INVALID_ARG; }
+    return ops_staged_keep(h, correction, min_dist, keep_out, placed_out4);
+}
+
 icpmi_status icpmi_get_map(icpmi_handle h, float* out4, float* normals3, int64_t capacity, int64_t* m)
 {
     CHECK_H(h);

@@ -327,6 +327,7 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
                                   int64_t src_capacity, int64_t* identity_prefix, int64_t* new_m);
 #define ICPMI_MAX_POINT_FILTERS 16
 icpmi_status ops_filter_points(icpmi_ctx* c, const float* in4, int64_t n, const icpmi_point_filter* filters, int n_filters, uint8_t* keep);
+icpmi_status ops_staged_keep(icpmi_ctx* c, const float correction[16], float min_dist, uint8_t* keep_out, float* placed_out4);
 icpmi_status ops_map_scalar(icpmi_ctx* c, const float* set, float* get, int64_t m);
 icpmi_status ops_surface_normals(icpmi_ctx* c, const float* pts4, int64_t m, int knn, float* normals3);
 icpmi_status ops_dynamic_points_update(icpmi_ctx* c, const icpmi_dynpts_params* prm, const float to_sensor[16], const float* in4, int64_t n,

@@ -1143,6 +1143,30 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
     return ICPMI_OK;
 }
 
+icpmi_status ops_staged_keep(icpmi_ctx* c, const float correction[16], float min_dist, uint8_t* keep_out, float* placed_out4)
+{
+    const int64_t n = c->scan_map_n;
+    if (ensure_cap(c, &c->d_stage_in, &c->cap_stage_in, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    icpmi_status s = ops_transform_dev(c, correction, c->d_scan_map, n, c->d_stage_in); // Mapper.cpp:221
+    if (s != ICPMI_OK) return s;
+    if (placed_out4) HIP_TRY(c, hipMemcpyAsync(placed_out4, c->d_stage_in, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    if (c->m <= 0) { // no map yet: every point is new
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        memset(keep_out, 1, (size_t)n);
+        return ICPMI_OK;
+    }
+    unsigned* d_flag = scratch_get<unsigned>(c, 6, (size_t)n + 2);
+    uint8_t* d_keep = scratch_get<uint8_t>(c, 9, (size_t)n);
+    if (!d_flag || !d_keep) return ICPMI_ERR_HIP;
+    s = chain_point_distance_flags(c, c, c->d_stage_in, n, min_dist, d_flag);
+    if (s != ICPMI_OK) return s;
+    hipLaunchKernelGGL(keep_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_d2, n, powf(min_dist, 2.f), d_keep);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(keep_out, d_keep, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return ICPMI_OK;
+}
+
 icpmi_status ops_map_scalar(icpmi_ctx* c, const float* set, float* get, int64_t m)
 {
     if (c->m <= 0 || m != c->m_raw) { c->last_error = "map_scalar: size differs from the resident map"; return ICPMI_ERR_INVALID_ARG; }

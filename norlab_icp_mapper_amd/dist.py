@@ -102,6 +102,7 @@ class ShardedMapper:
         self.map = np.zeros((0, 4), dtype=np.float32)
         self.normals = None
         self.pose = np.eye(4, dtype=np.float32)
+        self._resident_points = 0
 
     @staticmethod
     def gpu_backend(icp):
@@ -113,7 +114,49 @@ class ShardedMapper:
             dedup = staticmethod(lambda cloud, edge: icp.voxelKeepFirst(cloud, edge))
         return _B
 
+    @staticmethod
+    def resident_backend(icp):
+        """The same epoch with the map resident in HBM (`ICPSequence` over the C ABI): the scan is uploaded once
+        (`icpmi_register_prior`), the keep mask is decided against the resident map without touching it
+        (`icpmi_staged_point_distance_keep`), and what all ranks accepted is appended on the device
+        (`icpmi_map_update_point_distance` with min_dist 0 keeps every point) -- per epoch only the scan and the accepted
+        points cross PCIe, not the map (160 MB at 10 M points)."""
+        class _R:
+            resident = True
+            register_prior = staticmethod(lambda scan, prior: icp.registerWithPrior(scan, prior))
+            staged_keep = staticmethod(lambda correction, d: icp.stagedPointDistanceKeep(correction, d))
+            append = staticmethod(lambda pts, knn: icp.mapUpdatePointDistance(pts, 0.0, normals_knn=knn))
+            set_map = staticmethod(lambda cloud, normals: icp.setMap(cloud, normals))
+            normals = staticmethod(lambda cloud, knn: icp.surfaceNormals(cloud, knn))
+            dedup = staticmethod(lambda cloud, edge: icp.voxelKeepFirst(cloud, edge))
+            get_map = staticmethod(lambda: icp.getMap())
+        return _R
+
+    def get_map(self):
+        """The replica's map (downloaded from the device in resident mode)."""
+        return self.backend.get_map() if getattr(self.backend, "resident", False) else self.map
+
+    def _epoch_resident(self, scan, prior):
+        correction = self.backend.register_prior(scan, prior)               # identity while there is no map; stages the scan
+        self.pose = (np.asarray(correction, dtype=np.float64) @ np.asarray(prior, dtype=np.float64)).astype(np.float32)
+        mask, placed = self.backend.staged_keep(correction, self.min_dist)
+        mine = placed[mask]
+        if dist.is_available() and dist.is_initialized():
+            t = torch.from_numpy(np.ascontiguousarray(mine))
+            if dist.get_backend(self.group) == "nccl":
+                t = t.cuda()
+            merged, _ = allgather_points(t, group=self.group)
+            merged = merged.cpu().numpy()
+        else:
+            merged = mine
+        if merged.shape[0]:
+            merged = merged[self.backend.dedup(merged, self.min_dist)]
+            self.backend.append(np.ascontiguousarray(merged), self.normals_knn)
+            self._resident_points += int(merged.shape[0])
+        return self.pose, int(mine.shape[0]), int(merged.shape[0])
+
     def set_map(self, cloud, normals=None):
+        self._resident_points = int(np.asarray(cloud).shape[0])
         self.map = np.ascontiguousarray(cloud, dtype=np.float32)
         if normals is None and self.normals_knn > 0 and self.map.shape[0]:
             normals = self.backend.normals(self.map, self.normals_knn)
@@ -131,6 +174,8 @@ class ShardedMapper:
         """scan: (n, 4) in the sensor frame; prior: 4x4 estimated pose.  Returns (corrected pose, number of points
         this rank contributed, number of points appended to the shared map)."""
         scan = np.ascontiguousarray(scan, dtype=np.float32)
+        if getattr(self.backend, "resident", False):
+            return self._epoch_resident(scan, np.asarray(prior, dtype=np.float32))
         in_map = self._apply(prior, scan)                                    # Mapper.cpp:197
         correction = self.backend.register(in_map) if self.map.shape[0] else np.eye(4, dtype=np.float32)
         self.pose = (np.asarray(correction, dtype=np.float64) @ np.asarray(prior, dtype=np.float64)).astype(np.float32)  # :215
@@ -149,4 +194,5 @@ class ShardedMapper:
             merged = merged[self.backend.dedup(merged, self.min_dist)]       # points of different ranks closer than min_dist
             new_map = np.concatenate([self.map, merged], axis=0)
             self.set_map(new_map, None)
+        self._resident_points = int(self.map.shape[0])
         return self.pose, int(mine.shape[0]), int(merged.shape[0])

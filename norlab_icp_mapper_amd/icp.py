@@ -502,6 +502,15 @@ class ICPSequence:
                                                       C.byref(app), C.byref(m)))
         return (int(app.value), int(m.value), keep.astype(bool)) if return_keep else (int(app.value), int(m.value))
 
+    def stagedPointDistanceKeep(self, correction, min_dist):
+        """Keep mask of the staged scan (moved by `correction`) against the resident map, map untouched; returns
+        (mask, moved cloud).  The scan-sharded loop exchanges the accepted points before any replica appends them."""
+        Tc = _T_to_c(correction)
+        keep = np.zeros(self._staged_n, dtype=np.uint8)
+        placed = np.empty((self._staged_n, 4), dtype=np.float32)
+        self._check(self._lib.icpmi_staged_point_distance_keep(self._h, Tc.ctypes.data, min_dist, keep.ctypes.data, placed.ctypes.data))
+        return keep.astype(bool), placed
+
     def getMap(self, with_normals=False):
         """The resident map in the caller's order (Map::getLocalPointCloud, Map.cpp:536-540)."""
         m = C.c_int64(0)

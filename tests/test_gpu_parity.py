@@ -531,6 +531,36 @@ def test_sharded_mapper_single_rank(amd, mid_scene):
     assert appended2 < 0.1 * appended + 5
 
 
+def test_sharded_mapper_resident_backend_matches_host_backend(amd, mid_scene):
+    """The same epochs with the map resident in HBM (register_prior / staged keep / device-side append): same poses, same
+    accepted sets as the host-pointer backend up to the rounding of how the scan is placed (one 4x4 in numpy there, prior
+    then correction on the device here), and the replica downloaded from the device is the concatenation the host keeps."""
+    from norlab_icp_mapper_amd.dist import ShardedMapper
+    sc = mid_scene
+    kw = dict(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=30, use_differential=1)
+    half = sc["map"][::2]
+    host = ShardedMapper(ShardedMapper.gpu_backend(amd.ICPSequence(**kw)), min_dist_new_point=0.3, normals_knn=10)
+    ricp = amd.ICPSequence(**kw)
+    res = ShardedMapper(ShardedMapper.resident_backend(ricp), min_dist_new_point=0.3, normals_knn=10)
+    host.set_map(half); res.set_map(half)
+    scans = [sc["scan"], amd.synth.make_scene(m=8, n=20000, seed_scan=77)["scan"]]
+    for scan in scans:
+        ph, mine_h, app_h = host.epoch(scan, np.eye(4))
+        pr, mine_r, app_r = res.epoch(scan, np.eye(4))
+        dt, dr = amd.synth.pose_error(ph, pr)
+        assert dt < 1e-4 and dr < 1e-4, (dt, dr)
+        assert abs(mine_h - mine_r) <= max(3, mine_h // 200) and abs(app_h - app_r) <= max(3, app_h // 200), (mine_h, mine_r, app_h, app_r)
+    got = res.get_map()
+    assert got.shape[0] == res._resident_points and np.array_equal(got[: half.shape[0]], half)
+    assert abs(got.shape[0] - host.map.shape[0]) <= max(6, host.map.shape[0] // 1000)
+    # the keep decision itself, against the composed operator on the same placed cloud: identical masks
+    corr = ricp.registerWithPrior(scans[0], np.eye(4))
+    mask, placed = ricp.stagedPointDistanceKeep(corr, 0.3)
+    ref = ricp.pointDistanceKeep(got, placed, 0.3)
+    assert (mask != ref).sum() <= 2          # centred index here, raw coordinates there: a tie on the threshold may flip
+    assert np.array_equal(ricp.getMap(), got)                                   # and the map was not touched
+
+
 @pytest.fixture(scope="module")
 def bundled():
     import os
