@@ -122,3 +122,78 @@ def test_sharded_mapper_replicas_stay_identical(tmp_path):
     for k in range(world):
         assert np.isfinite(r[k]["pose"]).all()
     assert not np.array_equal(r[0]["pose"], r[1]["pose"])      # every rank registered its own scan
+
+
+def _resident_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_bindings as ob
+    from norlab_icp_mapper_amd import synth
+    from norlab_icp_mapper_amd.dist import ShardedMapper
+
+    # CPU stand-in of the RESIDENT backend (ShardedMapper.resident_backend): the replica lives behind the backend, the
+    # mapper only sees scans, masks and accepted points -- same hooks, the oracle's operators behind them
+    oicp = ob.OracleICP(ob.make_config(minimizer=1, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=15, nthreads=2))
+
+    class Resident:
+        resident = True
+        cloud = np.zeros((0, 4), np.float32)
+        staged = None
+
+        @classmethod
+        def set_map(cls, cloud, normals):
+            cls.cloud = np.ascontiguousarray(cloud, dtype=np.float32)
+            oicp.setMap(cls.cloud, normals)
+
+        @classmethod
+        def register_prior(cls, scan, prior):
+            cls.staged = ob.transform(prior, scan)
+            if cls.cloud.shape[0] == 0:
+                return np.eye(4, dtype=np.float32)
+            err, T = oicp(cls.staged)
+            assert err == 0
+            return T
+
+        @classmethod
+        def staged_keep(cls, correction, d):
+            placed = ob.transform(correction, cls.staged)
+            if cls.cloud.shape[0] == 0:
+                return np.ones(placed.shape[0], bool), placed
+            return ob.point_distance_keep(cls.cloud, placed, d, nthreads=2), placed
+
+        @classmethod
+        def append(cls, pts, knn):
+            cls.set_map(np.concatenate([cls.cloud, pts]), None)
+
+        normals = staticmethod(lambda cloud, knn: ob.surface_normals(cloud, knn))
+        dedup = staticmethod(lambda cloud, edge: ob.voxel_keep_first(cloud, edge))
+        get_map = classmethod(lambda cls: cls.cloud)
+
+    sc = synth.make_scene(m=6000, n=1500, seed_scan=43 + 1000 * rank)
+    mapper = ShardedMapper(Resident, min_dist_new_point=0.5)
+    mapper.set_map(sc["map"])
+    sizes = [mapper.get_map().shape[0]]
+    for epoch in range(2):
+        pose, mine, appended = mapper.epoch(sc["scan"] if epoch == 0 else sc["scan"][::2], np.eye(4))
+        sizes.append(mapper.get_map().shape[0])
+        assert mapper._resident_points == sizes[-1]
+    np.savez(os.path.join(out_dir, f"resident{rank}.npz"), map=mapper.get_map(), sizes=np.array(sizes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_mapper_resident_flow_replicas_stay_identical(tmp_path):
+    """The resident flow of the epoch (register_prior -> staged keep -> exchange -> append) over gloo with two ranks and
+    a CPU stand-in behind the resident hooks: identical replicas, and the same growth as the host-array flow above."""
+    world = 2
+    port = _free_port()
+    mp.spawn(_resident_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_mapper_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(os.path.join(str(tmp_path), f"resident{k}.npz")) for k in range(world)]
+    h = np.load(os.path.join(str(tmp_path), "mapper0.npz"))
+    assert np.array_equal(r[0]["map"], r[1]["map"]) and np.array_equal(r[0]["sizes"], r[1]["sizes"])
+    assert r[0]["sizes"][1] > r[0]["sizes"][0]
+    # same decisions as the host-array flow (the scan is placed by two exact float transforms here, by one numpy product there)
+    assert abs(int(r[0]["sizes"][2]) - int(h["sizes"][2])) <= 3
