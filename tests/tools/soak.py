@@ -58,7 +58,9 @@ for case in range(cases):
                 print("iterations", it, "pose diff", pkg.synth.pose_error(Ta, Tb), "pairs", a.stats.pairs, b.stats.pairs)
         # k >= m pairs every query with every map point: H is identically zero up to rounding, the rotation is noise on
         # both sides (ill-posed, not comparable)
-        if case % 5 == 0 and m * n <= 400_000 * 4_000 and k < m:
+        # likewise point-to-point with ONE reading point: all pairs share p, so H = sum w q p^T - (sum w q)(sum w p)^T / sum w
+        # cancels to the rounding noise of two different summation orders
+        if case % 5 == 0 and m * n <= 400_000 * 4_000 and k < m and not (minimizer == 1 and n == 1):
             o = ob.OracleICP(ob.make_config(nthreads=16, **kw)); o.setMap(mp, nrm)
             err, T_ref = o(rd, rn)
             assert (err != 0) == (err_gpu != 0), ("error mismatch", err, err_gpu, kw, m, n)
