@@ -19,9 +19,13 @@
  *   - every function returns an icpmi_status; icpmi_last_error(h) gives the message.  The reference
  *     reports the same conditions as C++ exceptions (PM::ConvergenceError, ...); the mapping is
  *     given next to each status code;
- *   - one HIP stream per handle; calls on one handle must be serialised by the caller (the reference
- *     serialises icp() and icp.setMap() with icpMapLock, Mapper.cpp:212, Map.cpp:527-529);
- *     different handles are independent (one per GPU).
+ *   - one HIP stream per handle; every entry point locks its handle for the duration of the call, so
+ *     calls on one handle from several threads are safe and run one after the other (the reference
+ *     serialises icp() and icp.setMap() with icpMapLock, Mapper.cpp:212, Map.cpp:527-529, but its
+ *     modules and filters -- each with a private kd-tree -- run outside that lock: online mode reaches
+ *     one handle from the caller's thread, the std::async update thread and the paging thread);
+ *     pairs of calls that hand state to each other (icpmi_register_prior -> icpmi_map_update_*_staged)
+ *     still belong to one logical owner; different handles are independent (one per GPU).
  */
 #ifndef ICPMI_H
 #define ICPMI_H

@@ -6,9 +6,11 @@
 
 static std::string g_create_error;
 
+// locks the handle for the rest of the calling function (see icpmi_ctx::mu) and makes its device current
 #define CHECK_H(h)                                                           \
+    if (!(h)) return ICPMI_ERR_INVALID_ARG;                                  \
+    std::lock_guard<std::recursive_mutex> _handle_lock((h)->mu);             \
     do {                                                                     \
-        if (!(h)) return ICPMI_ERR_INVALID_ARG;                              \
         hipError_t _e = hipSetDevice((h)->device);                           \
         if (_e != hipSuccess) {                                              \
             (h)->last_error = std::string("hipSetDevice: ") + hipGetErrorString(_e); \

@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 #include <unordered_map>
+#include <mutex>
 
 #include "../../include/icpmi.h"
 
@@ -115,6 +116,11 @@ struct icpmi_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string last_error;
+    // Every public entry point holds this for its whole duration: the handle's stream, staging buffers, operator scratch and
+    // `temp` handle are shared by all calls, and the reference's callers reach one handle from several threads (online mode:
+    // input filters on the caller's thread, the map update on a std::async thread, cell paging on Map::updateThread --
+    // Mapper.cpp:274-288, Map.cpp:35-57).  Recursive: entry points call each other.
+    std::recursive_mutex mu;
 
     // map
     int64_t m = 0;

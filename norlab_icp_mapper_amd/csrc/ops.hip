@@ -9,6 +9,12 @@
 
 namespace {
 
+// `dists(i) >= std::pow(minDistNewPoint, 2)` (PointDistanceMapperModule.cpp:42): std::pow(float, int) is evaluated in
+// double and the float distance is promoted for the comparison.  The product of two floats is exact in double.
+inline double pd_limit(float min_dist) { return (double)min_dist * (double)min_dist; }
+// squared search radius that is guaranteed to return every neighbour with d2 < limit (the smallest float >= limit)
+inline float pd_radius2(double lim) { float r = (float)lim; if ((double)r < lim) r = nextafterf(r, INFINITY); return r; }
+
 __global__ __launch_bounds__(256) void transform_kernel(const float4* __restrict__ in, int64_t n, const float* __restrict__ T,
                                                         float4* __restrict__ out)
 {
@@ -41,11 +47,11 @@ __global__ __launch_bounds__(256) void bin_kernel(const float4* __restrict__ in,
     ijk[3 * i + 2] = (int)floorf(p.z / cell);
 }
 
-__global__ __launch_bounds__(256) void keep_kernel(const float* __restrict__ d2, int64_t n, float lim, uint8_t* __restrict__ keep)
+__global__ __launch_bounds__(256) void keep_kernel(const float* __restrict__ d2, int64_t n, double lim, uint8_t* __restrict__ keep)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    keep[i] = d2[i] >= lim ? 1 : 0;
+    keep[i] = (double)d2[i] >= lim ? 1 : 0; // `dists(i) >= std::pow(minDistNewPoint, 2)`: a double comparison (PointDistanceMapperModule.cpp:42)
 }
 
 // one lane per point: mean + covariance of the kNN set in double, smallest eigenvector by Jacobi
@@ -377,7 +383,7 @@ __global__ __launch_bounds__(256) void dyn_update_kernel(const float4* __restric
     }
 }
 
-__global__ __launch_bounds__(256) void keep_flag_kernel(const float* __restrict__ d2, int64_t n, float lim, unsigned* __restrict__ flag)
+__global__ __launch_bounds__(256) void keep_flag_kernel(const float* __restrict__ d2, int64_t n, double lim, unsigned* __restrict__ flag)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -386,11 +392,11 @@ __global__ __launch_bounds__(256) void keep_flag_kernel(const float* __restrict_
 
 // stable compaction: kept input i goes to slot base + pos[i] (pos = exclusive scan of the flags)
 __global__ __launch_bounds__(256) void append_kept_kernel(const float4* __restrict__ in, const float* __restrict__ in_n3, int64_t n,
-                                                          const float* __restrict__ d2, float lim, const unsigned* __restrict__ pos,
+                                                          const float* __restrict__ d2, double lim, const unsigned* __restrict__ pos,
                                                           int64_t base, float4* __restrict__ raw, float* __restrict__ raw_n3)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n || !(d2[i] >= lim)) return;
+    if (i >= n || !((double)d2[i] >= lim)) return;
     const int64_t o = base + pos[i];
     raw[o] = in[i];
     if (raw_n3) {
@@ -569,7 +575,7 @@ icpmi_status ops_point_distance_keep(icpmi_ctx* c, const float* map4, int64_t m,
     icpmi_ctx* tc = t.h;
     DevBuf<uint8_t> d_keep;
     HIP_TRY(c, d_keep.alloc((size_t)n));
-    const float lim = powf(min_dist, 2.f);
+    const double lim = pd_limit(min_dist);
     hipLaunchKernelGGL(keep_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, tc->stream, tc->d_d2, n, lim, d_keep);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(keep, d_keep, (size_t)n, hipMemcpyDeviceToHost, tc->stream);
@@ -745,7 +751,7 @@ icpmi_status ops_map_update_dev(icpmi_ctx* c, const float4* d_scan, int64_t n, c
     if (normals_knn < 0 || normals_knn > ICPMI_MAX_K) { c->last_error = "map_update: normals_knn must be in [0, 32]"; return ICPMI_ERR_INVALID_ARG; }
     const bool scan_normals3 = d_scan_n3 != nullptr;
     const int64_t m0 = c->m > 0 ? c->m_raw : 0;
-    const float lim = powf(min_dist, 2.f);
+    const double lim = pd_limit(min_dist);
     const int blocks = (int)((n + 255) / 256);
     unsigned* d_flag = scratch_get<unsigned>(c, 6, (size_t)n + 2); // kept between calls
     if (!d_flag) return ICPMI_ERR_HIP;
@@ -757,7 +763,7 @@ icpmi_status ops_map_update_dev(icpmi_ctx* c, const float4* d_scan, int64_t n, c
         // iff d2 >= minDist^2.  A radius search with maxDist = minDist decides the same predicate.
         s = loop_prepare_reading(c, d_scan, n, nullptr);
         LoopCfg lc = make_loop_cfg(c, 1);
-        lc.k = 1; lc.n_out = 0; lc.max_dist = min_dist; lc.maxr2 = lim;
+        lc.k = 1; lc.n_out = 0; lc.max_dist = min_dist; lc.maxr2 = pd_radius2(lim);
         const size_t cnt = (size_t)n + 1;
         if (s == ICPMI_OK && (ensure_cap(c, &c->d_sidx, &c->cap_sidx, cnt) != ICPMI_OK || ensure_cap(c, &c->d_d2, &c->cap_d2, cnt) != ICPMI_OK ||
                               ensure_cap(c, &c->d_hard, &c->cap_hard, cnt) != ICPMI_OK)) s = ICPMI_ERR_HIP;
@@ -974,11 +980,11 @@ icpmi_status chain_compact(Chain& w, unsigned* d_flag, unsigned* d_pos)
 // describes the working map, the private one otherwise): flag[i] = exact NN of scan i at d2 >= minDist^2
 icpmi_status chain_point_distance_flags(icpmi_ctx* c, icpmi_ctx* ic, const float4* d_scan, int64_t n, float min_dist, unsigned* d_flag)
 {
-    const float lim = powf(min_dist, 2.f);
+    const double lim = pd_limit(min_dist);
     icpmi_status s = loop_prepare_reading(ic, d_scan, n, nullptr);
     if (s != ICPMI_OK) { c->last_error = ic->last_error; return s; }
     LoopCfg lc = make_loop_cfg(ic, 1);
-    lc.k = 1; lc.n_out = 0; lc.max_dist = min_dist; lc.maxr2 = lim; // a radius search with maxDist = minDist decides the same predicate
+    lc.k = 1; lc.n_out = 0; lc.max_dist = min_dist; lc.maxr2 = pd_radius2(lim); // a radius search with maxDist = minDist decides the same predicate
     const size_t cnt = (size_t)n + 1;
     if (ensure_cap(ic, &ic->d_sidx, &ic->cap_sidx, cnt) != ICPMI_OK || ensure_cap(ic, &ic->d_d2, &ic->cap_d2, cnt) != ICPMI_OK ||
         ensure_cap(ic, &ic->d_hard, &ic->cap_hard, cnt) != ICPMI_OK) { c->last_error = ic->last_error; return ICPMI_ERR_HIP; }
@@ -1160,7 +1166,7 @@ icpmi_status ops_staged_keep(icpmi_ctx* c, const float correction[16], float min
     if (!d_flag || !d_keep) return ICPMI_ERR_HIP;
     s = chain_point_distance_flags(c, c, c->d_stage_in, n, min_dist, d_flag);
     if (s != ICPMI_OK) return s;
-    hipLaunchKernelGGL(keep_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_d2, n, powf(min_dist, 2.f), d_keep);
+    hipLaunchKernelGGL(keep_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_d2, n, pd_limit(min_dist), d_keep);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(keep_out, d_keep, (size_t)n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -906,8 +906,8 @@ void orc_point_distance_keep(const float* map4, int64_t m, const float* in4, int
     int32_t* ids = (int32_t*)malloc((size_t)(n > 0 ? n : 1) * sizeof(int32_t));
     float* d2 = (float*)malloc((size_t)(n > 0 ? n : 1) * sizeof(float));
     orc_kdtree_knn(t, in4, n, 1, INFINITY, 0, ids, d2, nthreads);
-    const float lim = powf(min_dist, 2.f);
-    for (int64_t i = 0; i < n; ++i) keep[i] = d2[i] >= lim;
+    const double lim = pow((double)min_dist, 2.0); /* std::pow(float, int) promotes to double; dists(i) is promoted for the comparison (PointDistanceMapperModule.cpp:42) */
+    for (int64_t i = 0; i < n; ++i) keep[i] = (double)d2[i] >= lim;
     free(ids); free(d2); orc_kdtree_free(t);
 }
 

@@ -178,6 +178,27 @@ def bundled():
     print("wrote bundled_scans.npz", out["scan0_xyz"].shape, out["scan1_xyz"].shape, out["trajectory"].shape)
 
 
+def bundled_all():
+    """All 14 scans of the reference's example (xyz as float32, the example's lexicographic file order, cpp:191) and the
+    14 trajectory rows: the input of BASELINE config 4 (full trajectory replay).  ~5 MB compressed."""
+    ref = "/root/reference/examples/data"
+    if not os.path.isdir(ref):
+        print("reference not mounted: skipping bundled_scans_all.npz")
+        return
+    scans = sorted(glob.glob(os.path.join(ref, "scans", "*.vtk")))
+    out = {"scan_names": np.array([os.path.basename(s) for s in scans])}
+    for k, path in enumerate(scans):
+        pts, _ = read_vtk_points(path)
+        out[f"scan{k}_xyz"] = pts
+    out["trajectory"] = np.load(os.path.join(HERE, "bundled_scans.npz"))["trajectory"]
+    np.savez_compressed(os.path.join(HERE, "bundled_scans_all.npz"), **out)
+    print("wrote bundled_scans_all.npz", [out[f"scan{k}_xyz"].shape[0] for k in range(len(scans))])
+
+
 if __name__ == "__main__":
-    numpy_vectors()
-    bundled()
+    if len(sys.argv) > 1 and sys.argv[1] == "bundled_all":
+        bundled_all()
+    else:
+        numpy_vectors()
+        bundled()
+        bundled_all()
