@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- ICP iterations/s, 100k-point scan vs 1M-point map (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--chain p2p|p2plane]
+    python bench.py --gpus N --steps K --warmup W [--chain p2p|p2plane|docs_knn6] [--no-extras] [--no-cpu]
 
 One "step" is one registration of the hot path in throughput mode: a fixed 20 ICP iterations
 (Counter checker only) of one synthetic 100k-point scan against the 1M-point map,
@@ -9,16 +9,25 @@ with the scan already resident in HBM.  value = ICP iterations executed by all r
 (max over ranks, barrier + device sync on both sides).  Ranks hold a replica of the map and their own
 scan (independent seeds): the path shards across scans with no data-path collective => weak scaling.
 
-Extra objects on the JSON line:
-  roofline     -- the NN kernel: algorithmic bytes per launch (N*16 query read + M*16 map read +
-                  N*8 result write) / mean launch duration measured with HIP events
-                  on the library's stream (profile mode), against the 8 TB/s HBM peak.
+Extra objects on the JSON line (rank 0):
+  roofline     -- the NN kernel of the headline workload: algorithmic bytes per launch (N*16 query read +
+                  M*16 map read + N*8 result write) / mean launch duration measured with HIP
+                  events on the library's stream (profile mode), against the 8 TB/s HBM peak.
+  step_ms      -- min / median / max over the timed steps (every step ends with a device sync).
+  chains       -- (N = 1 only) the other BASELINE configurations measured the same way, each with its own
+                  value / step_ms / roofline: `p2plane_filter_normals` (config 3: point-to-plane against normals
+                  from SurfaceNormalDataPointsFilter{knn 10} run on the map), `map_10M` (config 5's map on one GPU:
+                  10 M points, same density), `batch8` (8 readings through icpmi_register_batch_dev: aggregate
+                  throughput of one GPU serving 8 scan streams -- NOT the headline, which is one scan).
   cpu_baseline -- the CPU oracle (a port: libpointmatcher is not installed) timed on this host on a
                   bounded sample of the same workload.
+  libpointmatcher -- "present" when oracle/_ref/liboracle_pm.so (the real PM::ICPSequence, `make -C oracle oracle_pm`)
+                  exists and was used for pose_err_vs_libpointmatcher; "absent" otherwise.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -42,6 +51,53 @@ CHAINS = {
 }
 
 
+def step_stats(ms):
+    return {"min": min(ms), "median": statistics.median(ms), "max": max(ms), "n": len(ms)}
+
+
+def nn_roofline(pkg, dev, chain, d_map, d_nrm, d_scan, n_scan, m_map, traffic_key=None):
+    """profile mode = eager launches with HIP events on the library's stream around every NN launch"""
+    prof = pkg.ICPSequence(device=dev, max_iterations=ITERS_PER_STEP, profile=1, **chain)
+    prof.setMapDev(d_map.data_ptr(), d_map.shape[0], d_nrm.data_ptr())
+    nn_ms, nn_cnt = 0.0, 0
+    for r in range(3 + 5):
+        prof.registerDev(d_scan.data_ptr(), d_scan.shape[0], fixed_iterations=ITERS_PER_STEP)
+        if r >= 3:
+            nn_ms += prof.stats.nn_ms_avg * prof.stats.nn_launches
+            nn_cnt += prof.stats.nn_launches
+    nn_avg_ms = nn_ms / max(nn_cnt, 1)
+    kq = chain.get("knn", 1)
+    alg_bytes = n_scan * 16 + m_map * 16 + n_scan * 8 * kq
+    achieved = alg_bytes / (nn_avg_ms * 1e-3) / 1e9 if nn_avg_ms > 0 else 0.0
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "nn_traffic.json")
+    if traffic_key and os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get(traffic_key)
+        except Exception:
+            traffic = None
+    del prof
+    return {"bound": "hbm", "kernel": "nn1_ml_kernel" if kq == 1 else "nnk_ml_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+            "avg_launch_us": nn_avg_ms * 1e3, "launches_timed": nn_cnt}
+
+
+def time_registrations(torch, icp, d_scan, steps, warmup):
+    def step():
+        return icp.registerDev(d_scan.data_ptr(), d_scan.shape[0], fixed_iterations=ITERS_PER_STEP)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    per = []
+    t_all = time.perf_counter()
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        T = step()
+        per.append((time.perf_counter() - t0) * 1e3)
+    torch.cuda.synchronize()
+    return T, time.perf_counter() - t_all, per
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -55,7 +111,9 @@ def main():
     ap.add_argument("--normals", default="analytic", choices=["analytic", "filter"],
                     help="map normals of the point-to-plane chains: the scene's analytic ones, or SurfaceNormalDataPointsFilter{knn: 10} "
                          "run on the map through icpmi_surface_normals (BASELINE config 3)")
+    ap.add_argument("--batch", type=int, default=0, help="headline through icpmi_register_batch_dev with this many readings (0: single registration)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip the `chains` object (configs 3 / 5 and the batch of 8)")
     ap.add_argument("--cpu-iters", type=int, default=10, help="iterations of the single-threaded cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work of the multi-threaded cpu_baseline leg")
     args = ap.parse_args()
@@ -96,7 +154,16 @@ def main():
     assert icp.setMapDev(d_map.data_ptr(), d_map.shape[0], d_nrm.data_ptr())
     set_map_ms = (time.perf_counter() - t0) * 1e3
 
+    batch_scans = None
+    if args.batch > 1:
+        batch_scans = [d_scan] + [torch.from_numpy(pkg.synth.make_scene(m=8, n=args.scan_points, seed_scan=43 + 1000 * rank + 7 * b, scale=args.scale)["scan"]).cuda()
+                                  for b in range(1, args.batch)]
+
     def step():
+        if batch_scans is not None:
+            Ts, _, status = icp.registerBatchDev([d.data_ptr() for d in batch_scans], [d.shape[0] for d in batch_scans], fixed_iterations=ITERS_PER_STEP)
+            assert not any(status), status
+            return Ts[0]
         return icp.registerDev(d_scan.data_ptr(), d_scan.shape[0], fixed_iterations=ITERS_PER_STEP)
 
     for _ in range(args.warmup):
@@ -109,17 +176,20 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    loop_ms = 0.0
+    loop_ms, per_step = 0.0, []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         T = step()
-        loop_ms += icp.stats.loop_ms
+        per_step.append((time.perf_counter() - ts) * 1e3)
+        loop_ms += icp.stats.loop_ms if batch_scans is None else icp.batch_stats[0].loop_ms
     barrier()
     elapsed = time.perf_counter() - t0
     if use_pg:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    iters_total = world * args.steps * ITERS_PER_STEP
+    readings = max(args.batch, 1)
+    iters_total = world * args.steps * ITERS_PER_STEP * readings
     value = iters_total / elapsed
 
     out = {
@@ -136,11 +206,12 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"single synthetic {args.scan_points}-pt scan vs {args.map_points}-pt map, "
+            "workload": (f"{readings} synthetic {args.scan_points}-pt scans (one batched launch sequence)" if readings > 1 else
+                         f"single synthetic {args.scan_points}-pt scan") + f" vs {args.map_points}-pt map, "
                         f"{'point-to-point' if args.chain == 'p2p' else 'point-to-plane'} ICP, KDTreeMatcher knn {chain.get('knn', 1)} maxDist 2.0 "
                         f"epsilon 0, TrimmedDist 0.85, fixed {ITERS_PER_STEP} iterations per registration",
             "chain": args.chain,
-            "iterations_per_step": ITERS_PER_STEP,
+            "iterations_per_step": ITERS_PER_STEP * readings,
             "scene": "box+pillars sigma=0.01 seeds 42/43/44 (SURVEY.md 8d)",
             "parallelism": f"scan-sharded x{world}, map replicated",
         },
@@ -148,6 +219,7 @@ def main():
 
     if rank == 0:
         gi = icp.gridInfo()
+        out["step_ms"] = step_stats(per_step)
         out["device_loop_ms_per_step"] = loop_ms / args.steps
         out["set_map_ms"] = set_map_ms
         if normals_ms is not None:
@@ -159,33 +231,76 @@ def main():
                                            "note": "after the fixed 20 iterations of throughput mode (Counter checker only); "
                                                    "the point-to-point chain needs more iterations to converge, the CPU oracle "
                                                    "lands on the same pose (pose_err_vs_cpu)"}
+        traffic_key = {"p2p": "hbm_bytes_per_launch", "p2plane": "hbm_bytes_per_launch_p2plane", "docs_knn6": "hbm_bytes_per_launch_knn6"}[args.chain]
+        if args.map_points != M_MAP or args.scan_points != N_SCAN:
+            traffic_key = None
+        out["roofline"] = nn_roofline(pkg, dev, chain, d_map, d_nrm, d_scan, args.scan_points, args.map_points, traffic_key)
 
-        # ---- roofline of the NN kernel: profile mode = eager launches, HIP events around each NN launch
-        prof = pkg.ICPSequence(device=dev, max_iterations=ITERS_PER_STEP, profile=1, **chain)
-        prof.setMapDev(d_map.data_ptr(), d_map.shape[0], d_nrm.data_ptr())
-        nn_ms, nn_cnt = 0.0, 0
-        for r in range(3 + 5):
-            prof.registerDev(d_scan.data_ptr(), d_scan.shape[0], fixed_iterations=ITERS_PER_STEP)
-            if r >= 3:
-                nn_ms += prof.stats.nn_ms_avg * prof.stats.nn_launches
-                nn_cnt += prof.stats.nn_launches
-        nn_avg_ms = nn_ms / max(nn_cnt, 1)
-        kq = chain.get("knn", 1)
-        alg_bytes = args.scan_points * 16 + args.map_points * 16 + args.scan_points * 8 * kq
-        achieved = alg_bytes / (nn_avg_ms * 1e-3) / 1e9 if nn_avg_ms > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "nn_traffic.json")
-        if os.path.exists(pmc):
+        # ---- the other BASELINE configurations, same measurement (N = 1 only) ----
+        if not args.no_extras and world == 1 and args.batch <= 1:
+            extras = {}
+            # config 3: point-to-plane against SurfaceNormalDataPointsFilter normals
+            c3 = dict(CHAINS["p2plane"])
+            icp3 = pkg.ICPSequence(device=dev, max_iterations=ITERS_PER_STEP, **c3)
+            t0 = time.perf_counter()
+            nrm3 = icp3.surfaceNormals(sc["map"], knn=10)
+            nrm_ms = (time.perf_counter() - t0) * 1e3
+            d_nrm3 = torch.from_numpy(nrm3).cuda()
+            icp3.setMapDev(d_map.data_ptr(), d_map.shape[0], d_nrm3.data_ptr())
+            T3, el3, per3 = time_registrations(torch, icp3, d_scan, args.steps, args.warmup)
+            g3t, g3r = pkg.synth.pose_error(T3, sc["T_gt"])
+            extras["p2plane_filter_normals"] = {
+                "config": "BASELINE config 3: 100k-pt scan vs 1M-pt map, point-to-plane, map normals from SurfaceNormalDataPointsFilter{knn 10}",
+                "value": args.steps * ITERS_PER_STEP / el3, "unit": "iterations/s", "step_ms": step_stats(per3), "surface_normals_ms": nrm_ms,
+                "pose_err_vs_ground_truth": {"m": g3t, "rad": g3r},
+                "roofline": nn_roofline(pkg, dev, c3, d_map, d_nrm3, d_scan, args.scan_points, args.map_points, "hbm_bytes_per_launch_p2plane")}
+            del icp3, d_nrm3
+            # batch of 8 readings: one GPU serving 8 scan streams
+            B = 8
+            scans8 = [d_scan] + [torch.from_numpy(pkg.synth.make_scene(m=8, n=args.scan_points, seed_scan=43 + 7 * b, scale=args.scale)["scan"]).cuda()
+                                 for b in range(1, B)]
+            ptrs, ns = [d.data_ptr() for d in scans8], [d.shape[0] for d in scans8]
+            for _ in range(args.warmup):
+                icp.registerBatchDev(ptrs, ns, fixed_iterations=ITERS_PER_STEP)
+            torch.cuda.synchronize()
+            per8 = []
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                ts = time.perf_counter()
+                Ts8, _, status8 = icp.registerBatchDev(ptrs, ns, fixed_iterations=ITERS_PER_STEP)
+                per8.append((time.perf_counter() - ts) * 1e3)
+            torch.cuda.synchronize()
+            el8 = time.perf_counter() - t0
+            extras["batch8"] = {
+                "config": f"8 x {args.scan_points}-pt scans vs the {args.map_points}-pt map in one launch sequence (icpmi_register_batch_dev), {args.chain} chain",
+                "value": args.steps * ITERS_PER_STEP * B / el8, "unit": "iterations/s (aggregate of 8 readings)", "step_ms": step_stats(per8),
+                "first_reading_equals_single_registration": bool(np.array_equal(Ts8[0], T)), "errors": int(sum(1 for s in status8 if s))}
+            del scans8
+            # config 5's map on one GPU: 10 M points at the same density
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out["roofline"] = {"bound": "hbm", "kernel": "nn1_ml_kernel" if kq == 1 else "nnk_ml_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
-                           "avg_launch_us": nn_avg_ms * 1e3, "launches_timed": nn_cnt}
-        del prof
+                sc10 = pkg.synth.make_scene(m=10_000_000, n=args.scan_points, scale=3.16)
+                d_map10 = torch.from_numpy(sc10["map"]).cuda(); d_nrm10 = torch.from_numpy(sc10["normals"]).cuda()
+                d_scan10 = torch.from_numpy(sc10["scan"]).cuda()
+                icp10 = pkg.ICPSequence(device=dev, max_iterations=ITERS_PER_STEP, **chain)
+                t0 = time.perf_counter()
+                icp10.setMapDev(d_map10.data_ptr(), d_map10.shape[0], d_nrm10.data_ptr())
+                sm10 = (time.perf_counter() - t0) * 1e3
+                T10, el10, per10 = time_registrations(torch, icp10, d_scan10, args.steps, args.warmup)
+                g10t, g10r = pkg.synth.pose_error(T10, sc10["T_gt"])
+                del icp10
+                extras["map_10M"] = {
+                    "config": f"BASELINE config 5's map on one GPU: 100k-pt scan vs 10M-pt map (scene x3.16, same density), {args.chain} chain",
+                    "value": args.steps * ITERS_PER_STEP / el10, "unit": "iterations/s", "step_ms": step_stats(per10), "set_map_ms": sm10,
+                    "pose_err_vs_ground_truth": {"m": g10t, "rad": g10r},
+                    "roofline": nn_roofline(pkg, dev, chain, d_map10, d_nrm10, d_scan10, args.scan_points, 10_000_000, "hbm_bytes_per_launch_10M")}
+                del d_map10, d_nrm10, d_scan10, sc10
+            except Exception as e:  # a host without the memory for the 10 M scene: say so instead of failing the headline
+                extras["map_10M"] = {"error": repr(e)}
+            out["chains"] = extras
 
         # ---- CPU baseline: the oracle on this host, bounded sample of the same workload ----
+        pm_lib = os.path.join(ROOT, "oracle", "_ref", "liboracle_pm.so")
+        out["libpointmatcher"] = "present" if os.path.exists(pm_lib) else "absent"
         if not args.no_cpu and world == 1:          # reported on rank 0 at N = 1 only
             import oracle_bindings as ob
             cores = len(os.sched_getaffinity(0))
@@ -224,6 +339,14 @@ def main():
                 "value_1thread": st_its, "value_multithread": mt_its, "host_cores": cores,
             }
             out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]
+            if out["libpointmatcher"] == "present":
+                try:
+                    import oracle_pm_bindings as opm
+                    T_pm = opm.register_default_chain(args.chain, sc["map"], sc["normals"], sc["scan"], ITERS_PER_STEP)
+                    pt, pr = pkg.synth.pose_error(T, T_pm)
+                    out["pose_err_vs_libpointmatcher"] = {"m": pt, "rad": pr}
+                except Exception as e:
+                    out["pose_err_vs_libpointmatcher"] = {"error": repr(e)}
         print(json.dumps(out))
     if use_pg:
         dist.barrier()

@@ -153,6 +153,18 @@ icpmi_status icpmi_register_dev(icpmi_handle h, const float* d_scan4, int64_t n,
 icpmi_status icpmi_register_fixed_dev(icpmi_handle h, const float* d_scan4, int64_t n, const float* d_scan_normals3,
                                       int32_t iterations, float T_out[16], icpmi_stats* stats);
 
+/* `icp(input)` for `batch` independent readings against the same map in ONE launch sequence (no reference analogue: the
+ * reference registers one scan per call, Mapper.cpp:213; this is what a multi-stream front end -- BASELINE config 5: several
+ * scan streams against a shared map -- calls instead of `batch` registrations): every kernel of the loop runs once per
+ * iteration for all readings (blockIdx.y = reading), each reading keeps its own loop state and stops on its own checkers.
+ * Results are bit-identical to registering each reading alone.  d_scans4: host array of `batch` device pointers (readings
+ * already moved by their priors), n: their sizes; fixed_iterations > 0 = throughput mode (Counter only), 0 = the handle's
+ * checkers.  T_out: 16 floats per reading; stats / status: one entry per reading (status may be NULL: the first error is
+ * then the return value).  1 <= batch <= 16.  Chains the batched kernels do not serve (knn > 1, several quantile filters,
+ * SurfaceNormalOutlierFilter, unbounded maxDist) are registered one reading after the other -- same results. */
+icpmi_status icpmi_register_batch_dev(icpmi_handle h, int32_t batch, const float* const* d_scans4, const int64_t* n,
+                                      int32_t fixed_iterations, float* T_out, icpmi_stats* stats, icpmi_status* status);
+
 /* ---- stage-level entry points (the per-stage virtuals of SURVEY.md 8b B2; used by parity tests) ---- */
 
 /* `Transformation::compute(cloud, T)` (Mapper.cpp:197,221; Map.cpp:523,525): out4 = T * in4;

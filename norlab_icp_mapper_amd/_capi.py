@@ -93,6 +93,7 @@ SYMBOLS = [
     ("icpmi_register", C.c_int, [_P, _P, C.c_int64, _P, _F, C.POINTER(Stats)]),
     ("icpmi_register_dev", C.c_int, [_P, _P, C.c_int64, _P, _F, C.POINTER(Stats)]),
     ("icpmi_register_fixed_dev", C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, _F, C.POINTER(Stats)]),
+    ("icpmi_register_batch_dev", C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P, _P, _P]),
     ("icpmi_transform", C.c_int, [_P, _F, _P, C.c_int64, _P, _P, _P]),
     ("icpmi_knn", C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_float, C.c_int32, _P, _P]),
     ("icpmi_outlier_weights", C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, _P, _P, _F]),

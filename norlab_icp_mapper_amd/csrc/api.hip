@@ -93,12 +93,16 @@ icpmi_status icpmi_create(const icpmi_config* cfg, icpmi_handle* out)
     CR(hipSetDevice(c->device));
     CR(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->own_stream = true;
-    CR(hipMalloc((void**)&c->d_state, sizeof(IcpState)));
-    CR(hipMemset(c->d_state, 0, sizeof(IcpState)));
+    CR(hipMalloc((void**)&c->d_state, sizeof(IcpState) * ICPMI_MAX_BATCH));
+    CR(hipMemset(c->d_state, 0, sizeof(IcpState) * ICPMI_MAX_BATCH));
     CR(hipMalloc((void**)&c->d_selhist, ICPMI_SELHIST_WORDS * sizeof(unsigned)));
     CR(hipMemset(c->d_selhist, 0, ICPMI_SELHIST_WORDS * sizeof(unsigned)));
-    CR(hipHostMalloc((void**)&c->h_state, sizeof(IcpState), hipHostMallocDefault));
+    c->cap_selhist = ICPMI_SELHIST_WORDS;
+    CR(hipHostMalloc((void**)&c->h_state, sizeof(IcpState) * ICPMI_MAX_BATCH, hipHostMallocDefault));
     CR(hipHostMalloc((void**)&c->h_pin, ICPMI_PIN_BYTES, hipHostMallocDefault));
+    CR(hipHostMalloc((void**)&c->h_progress, 64, hipHostMallocMapped));
+    *c->h_progress = 0;
+    CR(hipHostGetDevicePointer((void**)&c->d_progress, c->h_progress, 0));
     CR(hipEventCreate(&c->ev0));
     CR(hipEventCreate(&c->ev1));
 #undef CR
@@ -117,6 +121,7 @@ icpmi_status icpmi_set_config(icpmi_handle h, const icpmi_config* cfg)
     h->cfg = *cfg;
     // the cached loop graph was captured for the previous chain
     if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; h->graph_n = -1; }
+    if (h->bgraph_exec) { hipGraphExecDestroy(h->bgraph_exec); h->bgraph_exec = nullptr; h->bgraph_sig = 0; }
     return ICPMI_OK;
 }
 
@@ -127,6 +132,7 @@ void icpmi_destroy(icpmi_handle c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
+    if (c->bgraph_exec) hipGraphExecDestroy(c->bgraph_exec);
     hipFree(c->d_map_sorted); hipFree(c->d_normals_sorted); hipFree(c->d_cell_start);
     for (int l = 0; l < ICPMI_MAXLEV; ++l) { hipFree(c->d_lvl_pts[l]); hipFree(c->d_lvl_cs[l]); hipFree(c->d_lvl_pos0[l]); }
     hipFree(c->d_inv);
@@ -140,6 +146,7 @@ void icpmi_destroy(icpmi_handle c)
     hipFree(c->d_state);
     if (c->h_state) hipHostFree(c->h_state);
     if (c->h_pin) hipHostFree(c->h_pin);
+    if (c->h_progress) hipHostFree(c->h_progress);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     for (hipEvent_t e : c->nn_events) hipEventDestroy(e);
@@ -157,6 +164,7 @@ icpmi_status icpmi_set_stream(icpmi_handle h, void* hip_stream)
     h->stream = (hipStream_t)hip_stream;
     h->own_stream = false;
     if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; h->graph_n = -1; }
+    if (h->bgraph_exec) { hipGraphExecDestroy(h->bgraph_exec); h->bgraph_exec = nullptr; h->bgraph_sig = 0; }
     return ICPMI_OK;
 }
 
@@ -264,6 +272,45 @@ icpmi_status icpmi_register_fixed_dev(icpmi_handle h, const float* d_scan4, int6
     CHECK_H(h);
     if (iterations < 1) { h->last_error = "register_fixed: iterations must be >= 1"; return ICPMI_ERR_INVALID_ARG; }
     return register_impl(h, d_scan4, n, d_scan_normals3, iterations, T_out, stats);
+}
+
+icpmi_status icpmi_register_batch_dev(icpmi_handle h, int32_t batch, const float* const* d_scans4, const int64_t* n, int32_t fixed_iterations,
+                                      float* T_out, icpmi_stats* stats, icpmi_status* status)
+{
+    CHECK_H(h);
+    if (batch < 1 || batch > ICPMI_MAX_BATCH || !d_scans4 || !n || !T_out || fixed_iterations < 0) {
+        h->last_error = "register_batch: bad arguments (1 <= batch <= 16)"; return ICPMI_ERR_INVALID_ARG;
+    }
+    for (int b = 0; b < batch; ++b)
+        if (n[b] < 0 || (n[b] > 0 && !d_scans4[b])) { h->last_error = "register_batch: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
+    // The one-launch-per-iteration path serves the chains whose kernels take a batch: k = 1 on the grid pyramid without a
+    // brute-force pass, at most one quantile filter, no filter that reads descriptors of the reading.  Everything else --
+    // and empty readings, a handle without a map -- runs the readings one after the other: same results, no sharing.
+    bool together = batch > 1 && h->m > 0 && h->cfg.knn == 1 && (h->cfg.minimizer != ICPMI_MIN_POINT_TO_PLANE || h->has_normals);
+    int nquant = 0;
+    for (int f = 0; f < h->cfg.n_outlier; ++f) {
+        const int t = h->cfg.outlier[f].type;
+        if (t == ICPMI_OUT_SURFACENORMAL) together = false;
+        if (t == ICPMI_OUT_TRIMMEDDIST || t == ICPMI_OUT_MEDIANDIST) ++nquant;
+    }
+    if (nquant > 1) together = false;
+    for (int b = 0; b < batch; ++b) if (n[b] == 0 || n[b] > 0x7fffffff / ICPMI_MAX_K) together = false;
+    if (together) {
+        const GridParams& top = h->levels.g[h->levels.nlev - 1];
+        if (!std::isfinite(h->cfg.max_dist) || (top.cell - top.slack) <= h->cfg.max_dist) together = false; // would need the brute-force pass
+    }
+    if (!together) {
+        icpmi_status first = ICPMI_OK;
+        for (int b = 0; b < batch; ++b) {
+            const icpmi_status sb = register_impl(h, d_scans4[b], n[b], nullptr, fixed_iterations, T_out + 16 * b, stats ? stats + b : nullptr);
+            if (status) status[b] = sb;
+            if (sb != ICPMI_OK && first == ICPMI_OK) first = sb;
+        }
+        return status ? ICPMI_OK : first;
+    }
+    if (stats) memset(stats, 0, sizeof(icpmi_stats) * batch);
+    LoopCfg lc = make_loop_cfg(h, fixed_iterations);
+    return loop_run_batch(h, batch, d_scans4, n, lc, fixed_iterations > 0, T_out, stats, status);
 }
 
 icpmi_status icpmi_register(icpmi_handle h, const float* scan4, int64_t n, const float* scan_normals3, float T_out[16],

@@ -60,6 +60,20 @@ struct GridLevels {
     const unsigned* pos0[ICPMI_MAXLEV]; // level position -> level-0 position (nullptr for level 0)
 };
 
+// Batched registration (icpmi_register_batch_dev): B independent readings against the same map go through ONE launch
+// of every kernel of the loop, blockIdx.y = reading.  Per-reading arrays are slices of one allocation (slice b starts
+// at b * qstride elements; selection histograms, pair-sum partials and the IcpState array have their own fixed
+// strides).  A single registration is the batch of one (blockIdx.y == 0, every offset 0): the SAME kernels serve
+// both, so a reading registers to the same bits alone or in a batch.
+#define ICPMI_MAX_BATCH 16
+struct BatchArgs {
+    int nscan;
+    int qstride;                 // elements between the per-reading slices of the per-query arrays
+    int n[ICPMI_MAX_BATCH];      // points of every reading
+};
+struct BatchSrc { const float4* p[ICPMI_MAX_BATCH]; }; // the readings as handed in (device pointers)
+static inline BatchArgs batch_of_one(int64_t n) { BatchArgs b; memset(&b, 0, sizeof b); b.nscan = 1; b.n[0] = (int)n; return b; }
+
 // Device-side description of the ICP chain for one registration (passed by value to kernels).
 struct LoopCfg {
     int   k;
@@ -105,6 +119,7 @@ struct IcpState {
     unsigned hard_count;
     unsigned ticket;             // workgroups of the pair-sum kernel that have published their partials (last one solves)
     unsigned long long hard_total;
+    unsigned seq;                // registration sequence number (tag of the progress word, see icpmi_ctx::h_progress)
     unsigned long long dbg[24];  // diagnostics: NN phase cycles with -DICPMI_NN_TIMING (scripts/nn_phase.py), [20]/[21] serial solve cycles / calls
     // result
     float T_out[16];
@@ -185,16 +200,23 @@ struct icpmi_ctx {
     float*  d_d2 = nullptr; size_t cap_d2 = 0;                 // k x n
     unsigned* d_hard = nullptr; size_t cap_hard = 0;           // hard query list
     double* d_partials = nullptr; size_t cap_partials = 0;
-    unsigned* d_selhist = nullptr;                             // ICPMI_SEL_BINS
+    unsigned* d_selhist = nullptr; size_t cap_selhist = 0;     // ICPMI_SELHIST_WORDS per reading of a batch
     unsigned* nn_hist0 = nullptr;     // set by the loop when the NN kernel should build the level-0 histogram
     bool nn_builds_hist0 = false;     // set by the NN launcher: true if the launched variant did build it
     int nn_iter_hint = 0;             // iteration index of the launch being enqueued (> 0: seeded by the previous match)
     float4* d_match_pt = nullptr; size_t cap_match_pt = 0;     // k = 1 loop: matched map point (xyz, original index bits) per query slot
     float4* nn_match_pt = nullptr;    // set by the loop: keep the loop state (sidx, d2, matched point) in query order
     bool nn_out_sorted = false;       // set by the NN launcher: true if the launched kernel did so
-    IcpState* d_state = nullptr;
-    IcpState* h_state = nullptr;                               // pinned mirror
+    IcpState* d_state = nullptr;                               // ICPMI_MAX_BATCH states (a single registration uses the first)
+    IcpState* h_state = nullptr;                               // pinned mirror (ICPMI_MAX_BATCH)
+    int batch_cur = 1;                                         // readings of the launch sequence being enqueued (set by the loop)
+    BatchArgs batch_args{};                                    // their sizes / slice stride
     unsigned char* h_pin = nullptr;                            // pinned page for small read-backs (counts, statistics)
+    // Progress word of the running registration in host-mapped pinned memory, written by the solve kernel after every
+    // iteration: bit 31 = loop finished, bits 30..12 = registration sequence number, bits 11..0 = iterations completed.
+    // A registration with data-dependent length (Differential / Bound checkers) is enqueued eagerly, a bounded number of
+    // iterations ahead of this word, instead of stopping the stream for a read-back every few iterations (loop.hip).
+    unsigned* h_progress = nullptr; unsigned* d_progress = nullptr; unsigned reg_seq = 0;
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> nn_events;
@@ -202,6 +224,7 @@ struct icpmi_ctx {
     // cached graph of one full fixed-count loop
     hipGraphExec_t graph_exec = nullptr;
     int64_t graph_n = -1; int graph_iters = -1; uint64_t graph_sig = 0;
+    hipGraphExec_t bgraph_exec = nullptr; uint64_t bgraph_sig = 0; // ... and of one batched registration
 };
 
 #define HIP_TRY(ctx, expr)                                                                     \
@@ -310,7 +333,8 @@ __device__ __forceinline__ unsigned long long pack_key(float d2, unsigned id)
 icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float* d_normals3);
 icpmi_status device_exclusive_scan(icpmi_ctx* c, unsigned* data, int n, unsigned total);
 icpmi_status sort_queries(icpmi_ctx* c, const float4* d_pts, int64_t n);
-icpmi_status sort_queries_reserve(icpmi_ctx* c, int64_t n);
+icpmi_status sort_queries_reserve(icpmi_ctx* c, int64_t n, int nscan = 1);
+icpmi_status sort_queries_batch(icpmi_ctx* c, const float4* d_pts, const BatchArgs& ba); // slices of d_pts -> slices of d_qsorted / d_qindex
 icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, const float* d_T, const LoopCfg& lc,
                           int allow_self, int* d_sidx, float* d_d2, IcpState* d_state);
 icpmi_status nn_launch_k(icpmi_ctx* c, const float4* d_reading, int64_t n, const float* d_T, const LoopCfg& lc,
@@ -320,6 +344,8 @@ icpmi_status nn_self_knn(icpmi_ctx* c, const float4* d_cloud, const LoopCfg& lc,
 icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals3, int64_t n, const LoopCfg& lc, bool fixed, float T_out[16],
                       icpmi_stats* stats);
 icpmi_status loop_prepare_reading(icpmi_ctx* c, const float4* d_scan, int64_t n, const float* d_normals3);
+icpmi_status loop_run_batch(icpmi_ctx* c, int batch, const float* const* d_scans4, const int64_t* n, const LoopCfg& lc, bool fixed,
+                            float* T_out, icpmi_stats* stats, icpmi_status* status);
 icpmi_status loop_single_step(icpmi_ctx* c, int64_t n, const LoopCfg& lc, const float* T_iter_host, float T_step[16],
                               double sums[32], icpmi_stats* stats);
 icpmi_status loop_outlier_weights(icpmi_ctx* c, const LoopCfg& lc, const float* d2, const int32_t* ids, int k, int64_t n,

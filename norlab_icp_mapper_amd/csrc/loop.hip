@@ -157,9 +157,13 @@ __device__ __forceinline__ void block_find_rank_2tier(unsigned coarse_v, const u
 
 // level-0 histograms as a stand-alone kernel (NN variants that do not build them: k > 1, chains that may
 // need the brute-force pass).  Also clears level 1, like the NN kernel does when it is the builder.
-__global__ __launch_bounds__(256) void sel2_hist0_kernel(const float* __restrict__ d2, int64_t count, const IcpState* __restrict__ st,
+__global__ __launch_bounds__(256) void sel2_hist0_kernel(const float* __restrict__ d2, BatchArgs ba, int k, const IcpState* __restrict__ st,
                                                          unsigned* __restrict__ hists)
 {
+    const int64_t count = (int64_t)ba.n[blockIdx.y] * k; // blockIdx.y = reading of a batch
+    d2 += (size_t)blockIdx.y * (size_t)ba.qstride * k;
+    hists += (size_t)blockIdx.y * ICPMI_SELHIST_WORDS;
+    st += blockIdx.y;
     constexpr int PF = 8;
     const int64_t stride = (int64_t)gridDim.x * 256;
     const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -197,9 +201,14 @@ __global__ __launch_bounds__(256) void sel2_hist0_kernel(const float* __restrict
 }
 
 // scan level 0 (top 16 bits), build level 1 (low 16 bits) from the elements under the selected prefix
-__global__ __launch_bounds__(256) void sel2_scan_hist_kernel(const float* __restrict__ d2, int64_t count, IcpState* __restrict__ st,
+__global__ __launch_bounds__(256) void sel2_scan_hist_kernel(const float* __restrict__ d2, BatchArgs ba, int k, IcpState* __restrict__ st,
                                                              unsigned* __restrict__ hists, float quantile)
 {
+    // blockIdx.y = reading of a batch (common.h: BatchArgs)
+    const int64_t count = (int64_t)ba.n[blockIdx.y] * k;
+    d2 += (size_t)blockIdx.y * (size_t)ba.qstride * k;
+    hists += (size_t)blockIdx.y * ICPMI_SELHIST_WORDS;
+    st += blockIdx.y;
     // the lane's elements and the coarse counts are requested together (one round trip)
     constexpr int PF = 2;
     const int64_t stride = (int64_t)gridDim.x * 256;
@@ -271,8 +280,16 @@ __device__ __forceinline__ float match_weight(const LoopCfg& lc, const IcpState*
 //   point-to-point: [0] sum w, [1..3] sum w p, [4..6] sum w q, [7 + 3c + r] sum w q_r p_c
 //   always:         [27] sum w, [28] number of pairs
 // ---------------------------------------------------------------------------------------------
+// workgroups that take part in the pair sums of `count` matches (the host's acc_blocks): a batch launches the grid of its
+// largest reading, every reading uses the workgroups -- and therefore the summation order -- it would use alone
+__device__ __forceinline__ int acc_blocks_dev(int64_t count, int cap)
+{
+    const int64_t nb = (count + 255) / 256;
+    return (int)(nb < 1 ? 1 : (nb > cap ? cap : nb));
+}
+
 template <int MIN, bool FUSED>
-__global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restrict__ reading, int n, LoopCfg lc,
+__global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restrict__ reading, BatchArgs ba, int acc_cap, LoopCfg lc,
                                                          IcpState* __restrict__ st, const float4* __restrict__ map,
                                                          const float4* __restrict__ normals,
                                                          const float4* __restrict__ read_normals,
@@ -281,13 +298,27 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restric
                                                          int fused_slot, int is_median, float factor,
                                                          const float4* __restrict__ match_pt, const int* __restrict__ qindex)
 {
+    // blockIdx.y = reading of a batch (common.h: BatchArgs); a single registration is the batch of one
+    const int n = ba.n[blockIdx.y];
+    const int nbe = acc_blocks_dev((int64_t)n * lc.k, acc_cap);
+    if ((int)blockIdx.x >= nbe) return;
+    {
+        const size_t qo = (size_t)blockIdx.y * (size_t)ba.qstride;
+        reading += qo; sidx += qo * lc.k; d2a += qo * lc.k;
+        if (match_pt) match_pt += qo;
+        if (qindex) qindex += qo;
+        if (read_normals) read_normals += qo;
+        partials += (size_t)blockIdx.y * (size_t)acc_cap * ICPMI_NV;
+        hists += (size_t)blockIdx.y * ICPMI_SELHIST_WORDS;
+        st += blockIdx.y;
+    }
     // `reading`, sidx, d2a (and match_pt, the matched map points kept by the NN kernel) share one
     // order: the caller's, or -- qindex != nullptr -- the tile-sorted query order of the k = 1 loop,
     // where qindex maps a slot back to the caller's index (needed for reading descriptors only).
     // The first two elements of every lane are requested before anything else so that their round
     // trip overlaps the histogram scan below.
     const int64_t count = (int64_t)n * lc.k;
-    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int64_t stride = (int64_t)nbe * 256;
     const int64_t e_first = (int64_t)blockIdx.x * 256 + threadIdx.x;
     float pd2[2]; int ps[2]; float4 pr[2], pq[2];
 #pragma unroll
@@ -848,16 +879,37 @@ __device__ void solve_body(IcpState* __restrict__ st, const double* __restrict__
     st->dbg[21] += 1;
 }
 
-__global__ __launch_bounds__(256) void solve_kernel(IcpState* __restrict__ st, const double* __restrict__ partials, int nblocks,
-                                                    LoopCfg lc, float* __restrict__ T_step_out, double* __restrict__ sums_out)
+// progress word (icpmi_ctx::h_progress): visible to the host while the stream keeps running
+__device__ __forceinline__ void publish_progress(const IcpState* st, unsigned* progress)
 {
-    if (st->done) return;
-    solve_body(st, partials, nblocks, lc, T_step_out, sums_out);
+    if (!progress) return;
+    const unsigned v = ((unsigned)(st->done != 0) << 31) | ((st->seq & 0x7ffffu) << 12) | ((unsigned)st->iter & 0xfffu);
+    __hip_atomic_store(progress, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-__global__ __launch_bounds__(256) void centre_kernel(const float4* __restrict__ scan, int64_t n, float mx, float my, float mz,
-                                                     float4* __restrict__ out)
+__global__ __launch_bounds__(256) void solve_kernel(IcpState* __restrict__ st, const double* __restrict__ partials, BatchArgs ba, int acc_cap,
+                                                    LoopCfg lc, float* __restrict__ T_step_out, double* __restrict__ sums_out,
+                                                    unsigned* __restrict__ progress)
 {
+    // blockIdx.x = reading of a batch: one workgroup per registration
+    const int nblocks = acc_blocks_dev((int64_t)ba.n[blockIdx.x] * lc.k, acc_cap);
+    st += blockIdx.x;
+    partials += (size_t)blockIdx.x * (size_t)acc_cap * ICPMI_NV;
+    if (progress) progress += blockIdx.x;
+    if (st->done) { // finished earlier, or an upstream kernel of this iteration raised an error
+        if (threadIdx.x == 0) publish_progress(st, progress);
+        return;
+    }
+    solve_body(st, partials, nblocks, lc, T_step_out, sums_out);
+    if (threadIdx.x == 0) publish_progress(st, progress);
+}
+
+__global__ __launch_bounds__(256) void centre_kernel(BatchSrc src, BatchArgs ba, float mx, float my, float mz, float4* __restrict__ out)
+{
+    // blockIdx.y = reading of a batch: its own source pointer, slice blockIdx.y of `out`
+    const int64_t n = ba.n[blockIdx.y];
+    const float4* __restrict__ scan = src.p[blockIdx.y];
+    out += (size_t)blockIdx.y * (size_t)ba.qstride;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float4 p = scan[i];
@@ -872,9 +924,13 @@ __global__ __launch_bounds__(256) void pad_normals_kernel(const float* __restric
     out[i] = make_float4(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2], 0.f);
 }
 
-__global__ void init_state_kernel(IcpState* st, const float* T0)
+__global__ void init_state_kernel(IcpState* st, const float* T0, unsigned seq, unsigned* progress)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (threadIdx.x != 0) return;
+    st += blockIdx.x; // one state per reading of a batch
+    if (progress) progress += blockIdx.x;
+    st->seq = seq;
+    if (progress) __hip_atomic_store(progress, (seq & 0x7ffffu) << 12, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     for (int i = 0; i < 16; ++i) st->T_iter[i] = T0 ? T0[i] : ((i % 5 == 0) ? 1.f : 0.f);
     st->iter = 0; st->done = 0; st->error = 0; st->stop_reason = 0; st->counter = 0;
     quat_from_T(st->T_iter, st->hq);
@@ -950,7 +1006,10 @@ icpmi_status loop_prepare_reading(icpmi_ctx* c, const float4* d_scan, int64_t n,
 {
     if (ensure_cap(c, &c->d_reading, &c->cap_reading, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
     const int blocks = (int)((n + 255) / 256);
-    if (blocks) hipLaunchKernelGGL(centre_kernel, dim3(blocks), dim3(256), 0, c->stream, d_scan, n, c->mean[0], c->mean[1], c->mean[2], c->d_reading);
+    if (blocks) {
+        BatchSrc src; memset(&src, 0, sizeof src); src.p[0] = d_scan;
+        hipLaunchKernelGGL(centre_kernel, dim3(blocks), dim3(256), 0, c->stream, src, batch_of_one(n), c->mean[0], c->mean[1], c->mean[2], c->d_reading);
+    }
     if (d_normals3) {
         if (ensure_cap(c, &c->d_read_normals, &c->cap_read_normals, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
         if (blocks) hipLaunchKernelGGL(pad_normals_kernel, dim3(blocks), dim3(256), 0, c->stream, d_normals3, n, c->d_read_normals);
@@ -961,25 +1020,37 @@ icpmi_status loop_prepare_reading(icpmi_ctx* c, const float4* d_scan, int64_t n,
     return ICPMI_OK;
 }
 
-static icpmi_status ensure_loop_buffers(icpmi_ctx* c, int64_t n, int k)
+static int acc_cap()
 {
-    const size_t cnt = (size_t)n * k + 1;
-    if (ensure_cap(c, &c->d_sidx, &c->cap_sidx, cnt) != ICPMI_OK) return ICPMI_ERR_HIP;
-    if (ensure_cap(c, &c->d_d2, &c->cap_d2, cnt) != ICPMI_OK) return ICPMI_ERR_HIP;
-    if (ensure_cap(c, &c->d_hard, &c->cap_hard, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
-    const size_t nb = (cnt + 255) / 256;
-    if (ensure_cap(c, &c->d_partials, &c->cap_partials, nb * ICPMI_NV) != ICPMI_OK) return ICPMI_ERR_HIP;
-    if (k == 1 && ensure_cap(c, &c->d_match_pt, &c->cap_match_pt, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
-    return ICPMI_OK;
+    static int cap = -1;
+    if (cap < 0) { const char* e = getenv("ICPMI_ACC_BLOCKS"); cap = e ? atoi(e) : 256; if (cap < 1) cap = 1; }
+    return cap;
 }
 
 static int acc_blocks(int64_t count)
 {
-    static int cap = -1;
-    if (cap < 0) { const char* e = getenv("ICPMI_ACC_BLOCKS"); cap = e ? atoi(e) : 256; }
+    const int cap = acc_cap();
     const int64_t nb = (count + 255) / 256;
     return (int)(nb < 1 ? 1 : (nb > cap ? cap : nb));
 }
+
+// the readings the launch sequence being enqueued works on: the batch set by loop_run_batch, else the single reading
+static BatchArgs cur_batch(const icpmi_ctx* c, int64_t n) { return c->batch_cur > 1 ? c->batch_args : batch_of_one(n); }
+
+// n = points per slice, nscan slices (a single registration: one slice of n points)
+static icpmi_status ensure_loop_buffers(icpmi_ctx* c, int64_t n, int k, int nscan = 1)
+{
+    const size_t cnt = (size_t)n * k * nscan + 1;
+    if (ensure_cap(c, &c->d_sidx, &c->cap_sidx, cnt) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (ensure_cap(c, &c->d_d2, &c->cap_d2, cnt) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (ensure_cap(c, &c->d_hard, &c->cap_hard, (size_t)n * nscan + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    const size_t nb = std::max<size_t>(((size_t)n * k + 255) / 256, (size_t)acc_cap()); // slices of acc_cap() rows (see accumulate_kernel)
+    if (ensure_cap(c, &c->d_partials, &c->cap_partials, nb * ICPMI_NV * nscan) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (k == 1 && ensure_cap(c, &c->d_match_pt, &c->cap_match_pt, (size_t)n * nscan + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (ensure_cap(c, &c->d_selhist, &c->cap_selhist, (size_t)ICPMI_SELHIST_WORDS * nscan) != ICPMI_OK) return ICPMI_ERR_HIP;
+    return ICPMI_OK;
+}
+
 
 // index of the single quantile-type filter of the chain, or -1 (none) / -2 (more than one)
 static int fused_filter_slot(const LoopCfg& lc)
@@ -999,11 +1070,12 @@ static void enqueue_selection(icpmi_ctx* c, const LoopCfg& lc, int64_t count, bo
     if (slot >= 0) {
         // fused chain: hist0 -> [scan0 + hist1] -> [scan1 + hist2]; scan2 happens inside the accumulation kernel
         const float quant = lc.out_type[slot] == ICPMI_OUT_MEDIANDIST ? 0.5f : lc.out_param[slot];
+        const BatchArgs ba = cur_batch(c, count / lc.k);
         if (!c->nn_builds_hist0)
-            hipLaunchKernelGGL(sel2_hist0_kernel, dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist);
+            hipLaunchKernelGGL(sel2_hist0_kernel, dim3(hb, ba.nscan), dim3(256), 0, c->stream, c->d_d2, ba, lc.k, c->d_state, c->d_selhist);
         int hb2 = (int)std::min<int64_t>((count + 511) / 512, 512);
         if (hb2 < 1) hb2 = 1;
-        hipLaunchKernelGGL(sel2_scan_hist_kernel, dim3(hb2), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist, quant);
+        hipLaunchKernelGGL(sel2_scan_hist_kernel, dim3(hb2, ba.nscan), dim3(256), 0, c->stream, c->d_d2, ba, lc.k, c->d_state, c->d_selhist, quant);
         return;
     }
     for (int f = 0; f < lc.n_out; ++f) {
@@ -1028,7 +1100,8 @@ static void launch_accumulate(icpmi_ctx* c, int64_t n, const LoopCfg& lc, int nb
     const int is_med = slot >= 0 && lc.out_type[slot] == ICPMI_OUT_MEDIANDIST;
     const float factor = slot >= 0 ? lc.out_param[slot] : 0.f;
     const bool sorted = lc.k == 1 && c->nn_out_sorted; // loop state in query order (see nn1_ml_kernel)
-    hipLaunchKernelGGL((accumulate_kernel<MIN, FUSED>), dim3(nb), dim3(256), 0, c->stream, sorted ? c->d_qsorted : c->d_reading, (int)n, lc, c->d_state,
+    const BatchArgs ba = cur_batch(c, n);
+    hipLaunchKernelGGL((accumulate_kernel<MIN, FUSED>), dim3(nb, ba.nscan), dim3(256), 0, c->stream, sorted ? c->d_qsorted : c->d_reading, ba, acc_cap(), lc, c->d_state,
                        c->d_map_sorted, c->d_normals_sorted, rn, c->d_sidx, c->d_d2, c->d_partials, c->d_selhist, slot, is_med, factor,
                        sorted ? c->d_match_pt : (const float4*)nullptr, sorted ? c->d_qindex : (const int*)nullptr);
 }
@@ -1052,7 +1125,8 @@ static void enqueue_accumulate_solve(icpmi_ctx* c, int64_t n, const LoopCfg& lc,
         if (fused) launch_accumulate<ICPMI_MIN_IDENTITY, true>(c, n, lc, nb, slot);
         else launch_accumulate<ICPMI_MIN_IDENTITY, false>(c, n, lc, nb, slot);
     }
-    hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(256), 0, c->stream, c->d_state, c->d_partials, nb, lc, d_Tstep, d_sums);
+    const BatchArgs ba = cur_batch(c, n);
+    hipLaunchKernelGGL(solve_kernel, dim3(ba.nscan), dim3(256), 0, c->stream, c->d_state, c->d_partials, ba, acc_cap(), lc, d_Tstep, d_sums, c->d_progress);
 }
 
 static icpmi_status enqueue_iteration(icpmi_ctx* c, int64_t n, const LoopCfg& lc, hipEvent_t nn0, hipEvent_t nn1)
@@ -1108,7 +1182,8 @@ static icpmi_status enqueue_registration_head(icpmi_ctx* c, const float4* d_scan
 {
     icpmi_status s = loop_prepare_reading(c, d_scan, n, d_normals3);
     if (s != ICPMI_OK) return s;
-    hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(64), 0, c->stream, c->d_state, (const float*)nullptr);
+    c->reg_seq = (c->reg_seq + 1) & 0x7ffffu;
+    hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(64), 0, c->stream, c->d_state, (const float*)nullptr, c->reg_seq, c->d_progress);
     HIP_TRY(c, hipMemsetAsync(c->d_selhist, 0, ICPMI_SELHIST_WORDS * sizeof(unsigned), c->stream));
     HIP_TRY(c, hipGetLastError());
     return ICPMI_OK;
@@ -1166,14 +1241,39 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
                 hipEvent_t e; HIP_TRY(c, hipEventCreate(&e)); c->nn_events.push_back(e);
             }
         }
+        // A loop of data-dependent length (Differential / Bound) is enqueued a bounded number of iterations ahead of the
+        // progress word the solve kernel publishes in host-mapped memory: the stream never drains for a read-back (r1:
+        // a hipMemcpy + hipStreamSynchronize every 4 iterations, ~25 us of idle GPU each), and at most `ahead` iterations
+        // run as early-exit kernels after the loop has stopped.  ICPMI_RUN_AHEAD=0 restores the periodic read-back.
+        static int ahead = -1;
+        if (ahead < 0) { const char* e = getenv("ICPMI_RUN_AHEAD"); ahead = e ? atoi(e) : 2; }
+        const bool poll = ahead > 0 && !profile && (lc.use_diff || lc.use_bound) && c->h_progress && lc.max_iter < 0xfff;
         int launched = 0;
-        for (int it = 0; it < lc.max_iter; ++it) {
+        bool stopped = false;
+        for (int it = 0; it < lc.max_iter && !stopped; ++it) {
             hipEvent_t e0 = profile ? c->nn_events[2 * it] : nullptr, e1 = profile ? c->nn_events[2 * it + 1] : nullptr;
             c->nn_iter_hint = it;
             icpmi_status s = enqueue_iteration(c, n, lc, e0, e1);
             if (s != ICPMI_OK) return s;
             ++launched;
-            if ((it + 1) % check_every == 0 && it + 1 < lc.max_iter) {
+            if (it + 1 >= lc.max_iter) break;
+            if (poll) {
+                // go on as soon as the GPU has finished all but `ahead` of the iterations enqueued so far
+                for (unsigned spins = 1;; ++spins) {
+                    const unsigned v = __atomic_load_n(c->h_progress, __ATOMIC_ACQUIRE);
+                    if (((v >> 12) & 0x7ffffu) == c->reg_seq) {
+                        if (v >> 31) { stopped = true; break; }
+                        if ((int)(v & 0xfffu) + ahead > it) break;
+                    }
+                    if ((spins & 255u) == 0 && hipStreamQuery(c->stream) == hipSuccess) {
+                        // everything enqueued has run: the word is final (a kernel that stops the loop without passing
+                        // through the solve kernel cannot leave the host waiting)
+                        const unsigned w = __atomic_load_n(c->h_progress, __ATOMIC_ACQUIRE);
+                        stopped = ((w >> 12) & 0x7ffffu) != c->reg_seq || (w >> 31) != 0 || (int)(w & 0xfffu) <= it;
+                        break;
+                    }
+                }
+            } else if ((it + 1) % check_every == 0) {
                 HIP_TRY(c, hipMemcpyAsync(&c->h_state->done, &c->d_state->done, sizeof(int), hipMemcpyDeviceToHost, c->stream));
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
                 if (c->h_state->done) break;
@@ -1231,6 +1331,145 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
     return ICPMI_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Batched registration: B readings against the same map, every kernel of the loop launched once per iteration with
+// blockIdx.y = reading (NN: B x N queries in one launch; pair sums: B x 256 workgroups; solve: B workgroups).  A single
+// registration is latency-bound (~2.4 wave lifetimes of the NN kernel plus four kernel boundaries per
+// iteration leave most of the chip idle); B readings share those fixed costs.  Every reading keeps its own IcpState,
+// selection histograms and partials, stops on its own checkers (its kernels early-exit on its `done`), and -- the
+// kernels being the ones a single registration runs -- ends on the same bits as when registered alone.
+// ---------------------------------------------------------------------------------------------
+static void batch_result(icpmi_ctx* c, const LoopCfg& lc, const IcpState* hs, int64_t n, float* T_out, icpmi_stats* stats, icpmi_status* status)
+{
+    if (stats) {
+        stats->iterations = hs->iter;
+        stats->stop_reason = hs->stop_reason;
+        stats->pairs = hs->pairs;
+        const double denom = (double)lc.k * (double)n;
+        stats->point_used_ratio = denom > 0 ? (float)hs->pairs / (float)denom : 0.f;
+        stats->weighted_point_used_ratio = denom > 0 ? (float)(hs->wsum / denom) : 0.f;
+        stats->trimmed_limit = -1.f;
+        for (int f = 0; f < lc.n_out; ++f)
+            if (lc.out_type[f] == ICPMI_OUT_TRIMMEDDIST || lc.out_type[f] == ICPMI_OUT_MEDIANDIST) stats->trimmed_limit = hs->limits[f];
+        stats->hard_queries = (int64_t)hs->hard_total;
+    }
+    for (int i = 0; i < 16; ++i) T_out[i] = (i % 5 == 0) ? 1.f : 0.f;
+    if (status) *status = (icpmi_status)hs->error;
+    if (hs->error) return;
+    float Tm[16], Tmi[16], tmp[16];
+    for (int i = 0; i < 16; ++i) Tm[i] = Tmi[i] = (i % 5 == 0) ? 1.f : 0.f;
+    for (int r = 0; r < 3; ++r) { Tm[12 + r] = c->mean[r]; Tmi[12 + r] = -c->mean[r]; }
+    host_mat4_mul(hs->T_iter, Tmi, tmp);
+    host_mat4_mul(Tm, tmp, T_out);
+}
+
+icpmi_status loop_run_batch(icpmi_ctx* c, int B, const float* const* d_scans4, const int64_t* nn, const LoopCfg& lc, bool fixed, float* T_out,
+                            icpmi_stats* stats, icpmi_status* status)
+{
+    int64_t nmax = 0;
+    for (int b = 0; b < B; ++b) nmax = nn[b] > nmax ? nn[b] : nmax;
+    const int64_t NS = (nmax + 63) / 64 * 64; // slice stride of the per-query arrays
+    BatchArgs ba; memset(&ba, 0, sizeof ba);
+    BatchSrc src; memset(&src, 0, sizeof src);
+    ba.nscan = B; ba.qstride = (int)NS;
+    for (int b = 0; b < B; ++b) { ba.n[b] = (int)nn[b]; src.p[b] = (const float4*)d_scans4[b]; }
+    // all allocations up front: none may happen while the stream is capturing
+    if (ensure_loop_buffers(c, NS, lc.k, B) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (ensure_cap(c, &c->d_reading, &c->cap_reading, (size_t)NS * B + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (sort_queries_reserve(c, NS, B) != ICPMI_OK) return ICPMI_ERR_HIP;
+    struct Scope { icpmi_ctx* c; ~Scope() { c->batch_cur = 1; c->qsorted_n = -1; c->qsorted_src = nullptr; } } scope{c};
+    c->batch_cur = B; c->batch_args = ba;
+
+    auto head = [&]() -> icpmi_status {
+        const int blocks = (int)((nmax + 255) / 256);
+        hipLaunchKernelGGL(centre_kernel, dim3(blocks, B), dim3(256), 0, c->stream, src, ba, c->mean[0], c->mean[1], c->mean[2], c->d_reading);
+        icpmi_status s = sort_queries_batch(c, c->d_reading, ba);
+        if (s != ICPMI_OK) return s;
+        c->reg_seq = (c->reg_seq + 1) & 0x7ffffu;
+        hipLaunchKernelGGL(init_state_kernel, dim3(B), dim3(64), 0, c->stream, c->d_state, (const float*)nullptr, c->reg_seq, c->d_progress);
+        HIP_TRY(c, hipMemsetAsync(c->d_selhist, 0, (size_t)ICPMI_SELHIST_WORDS * B * sizeof(unsigned), c->stream));
+        HIP_TRY(c, hipGetLastError());
+        return ICPMI_OK;
+    };
+
+    const bool graph = c->cfg.use_graph != 0 && fixed && c->cfg.profile == 0;
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    if (graph) {
+        uint64_t sig = 1469598103934665603ull;
+        sig = fnv(&lc, sizeof lc, sig);
+        sig = fnv(&ba, sizeof ba, sig);
+        sig = fnv(&src, sizeof src, sig);
+        const void* ptrs[] = {c->d_qkeys, c->d_qtile, c->d_reading, c->d_sidx, c->d_d2, c->d_hard, c->d_partials, c->d_state, c->d_match_pt,
+                              c->d_qsorted, c->d_qindex, c->d_map_sorted, c->d_normals_sorted, c->d_cell_start, c->d_selhist};
+        sig = fnv(ptrs, sizeof ptrs, sig);
+        sig = fnv(&c->grid, sizeof c->grid, sig);
+        if (!c->bgraph_exec || c->bgraph_sig != sig) {
+            if (c->bgraph_exec) { hipGraphExecDestroy(c->bgraph_exec); c->bgraph_exec = nullptr; }
+            hipGraph_t g = nullptr;
+            HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            icpmi_status s = head();
+            for (int it = 0; it < lc.max_iter && s == ICPMI_OK; ++it) { c->nn_iter_hint = it; s = enqueue_iteration(c, nmax, lc, nullptr, nullptr); }
+            hipError_t ce = hipStreamEndCapture(c->stream, &g);
+            if (s != ICPMI_OK) { if (g) hipGraphDestroy(g); return s; }
+            HIP_TRY(c, ce);
+            hipError_t ie = hipGraphInstantiate(&c->bgraph_exec, g, nullptr, nullptr, 0);
+            hipGraphDestroy(g);
+            HIP_TRY(c, ie);
+            c->bgraph_sig = sig;
+        }
+        HIP_TRY(c, hipGraphLaunch(c->bgraph_exec, c->stream));
+    } else {
+        icpmi_status s = head();
+        if (s != ICPMI_OK) return s;
+        static int ahead = -1;
+        if (ahead < 0) { const char* e = getenv("ICPMI_RUN_AHEAD"); ahead = e ? atoi(e) : 2; if (ahead < 1) ahead = 1; }
+        const bool poll = (lc.use_diff || lc.use_bound) && c->h_progress && lc.max_iter < 0xfff;
+        bool stopped = false;
+        for (int it = 0; it < lc.max_iter && !stopped; ++it) {
+            c->nn_iter_hint = it;
+            s = enqueue_iteration(c, nmax, lc, nullptr, nullptr);
+            if (s != ICPMI_OK) return s;
+            if (it + 1 >= lc.max_iter || !poll) continue;
+            // as loop_run: stay `ahead` iterations in front of the slowest reading still running; stop when all have stopped
+            for (unsigned spins = 1;; ++spins) {
+                bool all_done = true, may_go = true;
+                for (int b = 0; b < B; ++b) {
+                    const unsigned v = __atomic_load_n(c->h_progress + b, __ATOMIC_ACQUIRE);
+                    const bool mine = ((v >> 12) & 0x7ffffu) == c->reg_seq;
+                    const bool done = mine && (v >> 31);
+                    all_done &= done;
+                    if (!done && !(mine && (int)(v & 0xfffu) + ahead > it)) may_go = false;
+                }
+                if (all_done) { stopped = true; break; }
+                if (may_go) break;
+                if ((spins & 255u) == 0 && hipStreamQuery(c->stream) == hipSuccess) {
+                    bool progress = false; // everything enqueued has run: go on only if some reading still iterates
+                    for (int b = 0; b < B; ++b) {
+                        const unsigned w = __atomic_load_n(c->h_progress + b, __ATOMIC_ACQUIRE);
+                        progress |= ((w >> 12) & 0x7ffffu) == c->reg_seq && (w >> 31) == 0 && (int)(w & 0xfffu) > it;
+                    }
+                    stopped = !progress;
+                    break;
+                }
+            }
+        }
+    }
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(IcpState) * B, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    icpmi_status first = ICPMI_OK;
+    for (int b = 0; b < B; ++b) {
+        icpmi_status sb = ICPMI_OK;
+        batch_result(c, lc, c->h_state + b, nn[b], T_out + 16 * b, stats ? stats + b : nullptr, &sb);
+        if (stats) stats[b].loop_ms = ms;
+        if (status) status[b] = sb;
+        if (sb != ICPMI_OK && first == ICPMI_OK) { first = sb; c->last_error = "register_batch: a reading ended with a convergence error (see the per-reading status)"; }
+    }
+    return status ? ICPMI_OK : first;
+}
+
 icpmi_status loop_single_step(icpmi_ctx* c, int64_t n, const LoopCfg& lc, const float* T_iter_host, float T_step[16],
                               double sums[32], icpmi_stats* stats)
 {
@@ -1241,7 +1480,8 @@ icpmi_status loop_single_step(icpmi_ctx* c, int64_t n, const LoopCfg& lc, const 
     HIP_TRY(c, d_sums.alloc(ICPMI_NV));
     float* d_T0 = d_Tstep.p + 16;
     if (T_iter_host) HIP_TRY(c, hipMemcpyAsync(d_T0, T_iter_host, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(64), 0, c->stream, c->d_state, T_iter_host ? (const float*)d_T0 : (const float*)nullptr);
+    hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(64), 0, c->stream, c->d_state, T_iter_host ? (const float*)d_T0 : (const float*)nullptr, 0u,
+                       (unsigned*)nullptr);
     HIP_TRY(c, hipMemsetAsync(c->d_selhist, 0, ICPMI_SELHIST_WORDS * sizeof(unsigned), c->stream));
     HIP_TRY(c, hipMemsetAsync(d_Tstep, 0, 16 * sizeof(float), c->stream));
     LoopCfg l1 = lc;
@@ -1285,7 +1525,7 @@ icpmi_status loop_outlier_weights(icpmi_ctx* c, const LoopCfg& lc, const float* 
     const int64_t count = (int64_t)k * n;
     if (ensure_loop_buffers(c, n, k) != ICPMI_OK) return ICPMI_ERR_HIP;
     LoopCfg l1 = lc; l1.k = k;
-    hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(64), 0, c->stream, c->d_state, (const float*)nullptr);
+    hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(64), 0, c->stream, c->d_state, (const float*)nullptr, 0u, (unsigned*)nullptr);
     HIP_TRY(c, hipMemsetAsync(c->d_selhist, 0, ICPMI_SELHIST_WORDS * sizeof(unsigned), c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_d2, d2, (size_t)count * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_sidx, 0, (size_t)count * sizeof(int), c->stream));

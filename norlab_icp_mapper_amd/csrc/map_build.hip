@@ -241,11 +241,18 @@ __device__ __forceinline__ unsigned long long match_digit(unsigned d, bool valid
     return m;
 }
 
+// (blockIdx.y = reading of a batch: slices of the per-query arrays qs elements apart, one count table of `tabstride`
+// words per reading)
 template <bool FIRST>
-__global__ __launch_bounds__(256) void qhist_kernel(const float4* __restrict__ pts, int n, GridParams g, int tx, int ty,
+__global__ __launch_bounds__(256) void qhist_kernel(const float4* __restrict__ pts, BatchArgs ba, GridParams g, int tx, int ty,
                                                     const unsigned* __restrict__ keys_in, unsigned* __restrict__ keys_out, int shift,
-                                                    int nwg, unsigned* __restrict__ count, unsigned* __restrict__ total)
+                                                    int nwg, unsigned* __restrict__ count, unsigned* __restrict__ total, int qs, int tabstride)
 {
+    const int n = ba.n[blockIdx.y];
+    pts += (size_t)blockIdx.y * qs;
+    if (keys_in) keys_in += (size_t)blockIdx.y * 4 * qs;
+    if (keys_out) keys_out += (size_t)blockIdx.y * 4 * qs;
+    count += (size_t)blockIdx.y * tabstride; total += (size_t)blockIdx.y * tabstride;
     __shared__ unsigned h[QS_BINS];
     const int t = threadIdx.x, lane = t & 63;
     if (t < QS_BINS) h[t] = 0;
@@ -271,12 +278,21 @@ __global__ __launch_bounds__(256) void qhist_kernel(const float4* __restrict__ p
 }
 
 template <bool FINAL>
-__global__ __launch_bounds__(256) void qpass_kernel(const unsigned* __restrict__ keys_in, const unsigned* __restrict__ vals_in, int n,
+__global__ __launch_bounds__(256) void qpass_kernel(const unsigned* __restrict__ keys_in, const unsigned* __restrict__ vals_in, BatchArgs ba,
                                                     int shift, int nwg, const unsigned* __restrict__ count,
                                                     const unsigned* __restrict__ total, unsigned* __restrict__ keys_out,
                                                     unsigned* __restrict__ vals_out, const float4* __restrict__ pts,
-                                                    float4* __restrict__ out_pts, int* __restrict__ out_index)
+                                                    float4* __restrict__ out_pts, int* __restrict__ out_index, int qs, int tabstride)
 {
+    const int n = ba.n[blockIdx.y];
+    keys_in += (size_t)blockIdx.y * 4 * qs;
+    if (vals_in) vals_in += (size_t)blockIdx.y * 4 * qs;
+    if (keys_out) keys_out += (size_t)blockIdx.y * 4 * qs;
+    if (vals_out) vals_out += (size_t)blockIdx.y * 4 * qs;
+    count += (size_t)blockIdx.y * tabstride; total += (size_t)blockIdx.y * tabstride;
+    pts += (size_t)blockIdx.y * qs;
+    if (out_pts) out_pts += (size_t)blockIdx.y * qs;
+    if (out_index) out_index += (size_t)blockIdx.y * qs;
     constexpr int R = QS_EPB / 256;
     __shared__ unsigned wc[R][4][QS_BINS]; // [round][wave][digit]: count, then exclusive prefix in element order
     __shared__ unsigned part[4][QS_BINS];
@@ -337,66 +353,76 @@ __global__ __launch_bounds__(256) void qpass_kernel(const unsigned* __restrict__
 } // namespace
 
 // capacity of everything sort_queries touches (so that the sort itself allocates nothing and can be
-// captured into a graph)
-icpmi_status sort_queries_reserve(icpmi_ctx* c, int64_t n)
+// captured into a graph); nscan slices of n elements each
+static void sort_dims(const icpmi_ctx* c, int64_t n, int& tx, int& ty, int& passes, int& nwg, size_t& tab)
 {
     const GridParams& g = c->grid;
-    const int tx = (g.nx + STX - 1) / STX, ty = (g.ny + STY - 1) / STY, tz = (g.nz + STZ - 1) / STZ;
+    tx = (g.nx + STX - 1) / STX; ty = (g.ny + STY - 1) / STY;
+    const int tz = (g.nz + STZ - 1) / STZ;
     const int nst = tx * ty * tz;
     int bits = 0;
     while ((1ll << bits) < (long long)nst) ++bits;
-    const int passes = bits <= QS_BITS ? 1 : (bits + QS_BITS - 1) / QS_BITS;
-    const int nwg = (int)((n + QS_EPB - 1) / QS_EPB);
-    const size_t tab = (size_t)QS_BINS * (nwg > 0 ? nwg : 1) + QS_BINS;
-    if (ensure_cap(c, &c->d_qsorted, &c->cap_qsorted, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
-    if (ensure_cap(c, &c->d_qindex, &c->cap_qindex, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
-    if (ensure_cap(c, &c->d_qkeys, &c->cap_qkeys, (size_t)4 * n + 4) != ICPMI_OK) return ICPMI_ERR_HIP;
-    if (ensure_cap(c, &c->d_qtile, &c->cap_qtile, tab * passes) != ICPMI_OK) return ICPMI_ERR_HIP;
+    passes = bits <= QS_BITS ? 1 : (bits + QS_BITS - 1) / QS_BITS;
+    nwg = (int)((n + QS_EPB - 1) / QS_EPB);
+    tab = (size_t)QS_BINS * (nwg > 0 ? nwg : 1) + QS_BINS; // count[digit][workgroup] + total[digit], per pass
+}
+
+icpmi_status sort_queries_reserve(icpmi_ctx* c, int64_t n, int nscan)
+{
+    int tx, ty, passes, nwg; size_t tab;
+    sort_dims(c, n, tx, ty, passes, nwg, tab);
+    const size_t tot = (size_t)n * nscan;
+    if (ensure_cap(c, &c->d_qsorted, &c->cap_qsorted, tot + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (ensure_cap(c, &c->d_qindex, &c->cap_qindex, tot + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (ensure_cap(c, &c->d_qkeys, &c->cap_qkeys, (size_t)4 * tot + 4) != ICPMI_OK) return ICPMI_ERR_HIP; // keys / values, ping-pong
+    if (ensure_cap(c, &c->d_qtile, &c->cap_qtile, tab * passes * nscan) != ICPMI_OK) return ICPMI_ERR_HIP;
     return ICPMI_OK;
 }
 
-icpmi_status sort_queries(icpmi_ctx* c, const float4* d_pts, int64_t n)
+// stable radix sort of every reading's points by super-tile: slice b of d_pts (ba.n[b] points, slices qs elements apart;
+// a batch of one: qs = n) -> slice b of d_qsorted / d_qindex
+icpmi_status sort_queries_batch(icpmi_ctx* c, const float4* d_pts, const BatchArgs& ba)
 {
     const GridParams& g = c->grid;
-    const int tx = (g.nx + STX - 1) / STX, ty = (g.ny + STY - 1) / STY, tz = (g.nz + STZ - 1) / STZ;
-    const int nst = tx * ty * tz;
-    int bits = 0;
-    while ((1ll << bits) < (long long)nst) ++bits;
-    const int passes = bits <= QS_BITS ? 1 : (bits + QS_BITS - 1) / QS_BITS;
-    const int nwg = (int)((n + QS_EPB - 1) / QS_EPB);
+    int nmax = 0;
+    for (int b = 0; b < ba.nscan; ++b) nmax = ba.n[b] > nmax ? ba.n[b] : nmax;
+    const int qs = ba.nscan == 1 ? nmax : ba.qstride;
+    int tx, ty, passes, nwg; size_t tab;
+    sort_dims(c, nmax, tx, ty, passes, nwg, tab);
     if (nwg == 0) return ICPMI_OK;
-    const size_t tab = (size_t)QS_BINS * nwg + QS_BINS; // count[digit][workgroup] + total[digit], per pass
-    if (ensure_cap(c, &c->d_qsorted, &c->cap_qsorted, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
-    if (ensure_cap(c, &c->d_qindex, &c->cap_qindex, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
-    if (ensure_cap(c, &c->d_qkeys, &c->cap_qkeys, (size_t)4 * n + 4) != ICPMI_OK) return ICPMI_ERR_HIP; // keys / values, ping-pong
-    if (ensure_cap(c, &c->d_qtile, &c->cap_qtile, tab * passes) != ICPMI_OK) return ICPMI_ERR_HIP;
-    HIP_TRY(c, hipMemsetAsync(c->d_qtile, 0, tab * passes * sizeof(unsigned), c->stream));
-    unsigned* kbuf[2] = {c->d_qkeys, c->d_qkeys + n};
-    unsigned* vbuf[2] = {c->d_qkeys + 2 * n, c->d_qkeys + 3 * n};
+    if (sort_queries_reserve(c, qs, ba.nscan) != ICPMI_OK) return ICPMI_ERR_HIP;
+    const size_t tab_all = tab * passes; // one reading's tables
+    HIP_TRY(c, hipMemsetAsync(c->d_qtile, 0, tab_all * ba.nscan * sizeof(unsigned), c->stream));
+    unsigned* kbuf[2] = {c->d_qkeys, c->d_qkeys + qs};
+    unsigned* vbuf[2] = {c->d_qkeys + 2 * (size_t)qs, c->d_qkeys + 3 * (size_t)qs};
+    const dim3 grid(nwg, ba.nscan);
     for (int ps = 0; ps < passes; ++ps) {
         unsigned* count = c->d_qtile + tab * ps;
         unsigned* total = count + (size_t)QS_BINS * nwg;
         const int shift = ps * QS_BITS;
         const int in = ps & 1, out = in ^ 1;
         if (ps == 0)
-            hipLaunchKernelGGL(qhist_kernel<true>, dim3(nwg), dim3(256), 0, c->stream, d_pts, (int)n, g, tx, ty, (const unsigned*)nullptr,
-                               kbuf[0], shift, nwg, count, total);
+            hipLaunchKernelGGL(qhist_kernel<true>, grid, dim3(256), 0, c->stream, d_pts, ba, g, tx, ty, (const unsigned*)nullptr,
+                               kbuf[0], shift, nwg, count, total, qs, (int)tab_all);
         else
-            hipLaunchKernelGGL(qhist_kernel<false>, dim3(nwg), dim3(256), 0, c->stream, d_pts, (int)n, g, tx, ty, (const unsigned*)kbuf[in],
-                               (unsigned*)nullptr, shift, nwg, count, total);
+            hipLaunchKernelGGL(qhist_kernel<false>, grid, dim3(256), 0, c->stream, d_pts, ba, g, tx, ty, (const unsigned*)kbuf[in],
+                               (unsigned*)nullptr, shift, nwg, count, total, qs, (int)tab_all);
         const unsigned* vin = ps == 0 ? nullptr : vbuf[in];
         if (ps == passes - 1)
-            hipLaunchKernelGGL(qpass_kernel<true>, dim3(nwg), dim3(256), 0, c->stream, (const unsigned*)kbuf[in], vin, (int)n, shift, nwg,
+            hipLaunchKernelGGL(qpass_kernel<true>, grid, dim3(256), 0, c->stream, (const unsigned*)kbuf[in], vin, ba, shift, nwg,
                                (const unsigned*)count, (const unsigned*)total, (unsigned*)nullptr, (unsigned*)nullptr, d_pts, c->d_qsorted,
-                               c->d_qindex);
+                               c->d_qindex, qs, (int)tab_all);
         else
-            hipLaunchKernelGGL(qpass_kernel<false>, dim3(nwg), dim3(256), 0, c->stream, (const unsigned*)kbuf[in], vin, (int)n, shift, nwg,
-                               (const unsigned*)count, (const unsigned*)total, kbuf[out], vbuf[out], d_pts, (float4*)nullptr, (int*)nullptr);
+            hipLaunchKernelGGL(qpass_kernel<false>, grid, dim3(256), 0, c->stream, (const unsigned*)kbuf[in], vin, ba, shift, nwg,
+                               (const unsigned*)count, (const unsigned*)total, kbuf[out], vbuf[out], d_pts, (float4*)nullptr, (int*)nullptr,
+                               qs, (int)tab_all);
     }
     HIP_TRY(c, hipGetLastError());
-    c->qsorted_n = n; c->qsorted_src = d_pts;
+    c->qsorted_n = ba.nscan == 1 ? nmax : -1; c->qsorted_src = ba.nscan == 1 ? d_pts : nullptr;
     return ICPMI_OK;
 }
+
+icpmi_status sort_queries(icpmi_ctx* c, const float4* d_pts, int64_t n) { return sort_queries_batch(c, d_pts, batch_of_one(n)); }
 
 // in-place exclusive scan of data[0..n) (counts -> starts); data[n] = total
 icpmi_status device_exclusive_scan(icpmi_ctx* c, unsigned* data, int n, unsigned total)

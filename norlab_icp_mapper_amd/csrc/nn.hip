@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void ids_kernel(const float4* __restrict__ map
 #define NN_TICK(i) do { } while (0)
 #endif
 template <int G, int NB>
-__global__ __launch_bounds__(NN1_BLOCK) void nn1_ml_kernel(const float4* __restrict__ queries, const int* __restrict__ qindex, int n,
+__global__ __launch_bounds__(NN1_BLOCK) void nn1_ml_kernel(const float4* __restrict__ queries, const int* __restrict__ qindex, BatchArgs ba,
                                                           const float* __restrict__ Tptr, GridLevels L, float maxr2,
                                                           int allow_self_i, int* __restrict__ out_sidx,
                                                           float* __restrict__ out_d2, IcpState* __restrict__ st,
@@ -336,6 +336,17 @@ __global__ __launch_bounds__(NN1_BLOCK) void nn1_ml_kernel(const float4* __restr
 {
     static_assert(G == 2 || G == 4 || G == 8 || G == 16, "lanes per query");
     constexpr int NR = (9 + G - 1) / G; // rows owned per lane: row rr belongs to lane rr % G, slot rr / G
+    // blockIdx.y = reading of a batch (common.h: BatchArgs); a single registration is the batch of one
+    const int n = ba.n[blockIdx.y];
+    {
+        const size_t qo = (size_t)blockIdx.y * (size_t)ba.qstride;
+        queries += qo; out_sidx += qo; out_d2 += qo;
+        if (qindex) qindex += qo;
+        if (match_pt) match_pt += qo;
+        if (hist0) hist0 += (size_t)blockIdx.y * ICPMI_SELHIST_WORDS;
+        if (Tptr) Tptr = reinterpret_cast<const float*>(reinterpret_cast<const char*>(Tptr) + (size_t)blockIdx.y * sizeof(IcpState));
+        st += blockIdx.y;
+    }
     if (st->done) return;
 #ifdef ICPMI_NN_TIMING
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -355,7 +366,10 @@ __global__ __launch_bounds__(NN1_BLOCK) void nn1_ml_kernel(const float4* __restr
     // XCD-aware order: workgroup b runs on XCD b % 8 (observed placement, used for speed only), so
     // giving each XCD one contiguous eighth of the tile-sorted queries keeps its share of the map
     // (~1/8 of the cells) resident in that XCD's private 4 MiB L2.  The grid is padded to 8 * chunk.
-    const int chunk = gridDim.x >> 3;
+    // (in a batch the grid is sized for the largest reading: this reading's own padded workgroup count decides)
+    const int wgs = (int)((((long long)n * G + NN1_BLOCK - 1) / NN1_BLOCK + 7) / 8 * 8);
+    if ((int)blockIdx.x >= wgs) return;
+    const int chunk = wgs >> 3;
     const int lb = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
     const int tid = lb * NN1_BLOCK + threadIdx.x;
     const int qi = tid / G;
@@ -1152,7 +1166,7 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
     c->nn_out_sorted = false;
     {
         // grid pyramid; sorted queries when the caller prepared them for exactly this cloud
-        const bool sorted = c->qsorted_n == n && c->qsorted_src == d_reading;
+        const bool sorted = c->batch_cur > 1 || (c->qsorted_n == n && c->qsorted_src == d_reading); // a batch is always tile-sorted
         const float4* q = sorted ? c->d_qsorted : d_reading;
         const int* qi = sorted ? c->d_qindex : nullptr;
         if (n == 0) return ICPMI_OK;
@@ -1178,9 +1192,11 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
         c->nn_out_sorted = mp != nullptr;
         static int seed_pre_cfg = -1;
         if (seed_pre_cfg < 0) { const char* e = getenv("ICPMI_NN_SEED_PRE"); seed_pre_cfg = e ? atoi(e) : 2; }
+        // a batch (c->batch_cur > 1, set by loop_run_batch): grid.y = readings, grid.x sized for the largest one
+        const BatchArgs ba = c->batch_cur > 1 ? c->batch_args : batch_of_one(n);
 #define LAUNCH_ML(G_, NB_)                                                                                                      \
-    hipLaunchKernelGGL((nn1_ml_kernel<G_, NB_>), dim3((int)(((n * G_ + NN1_BLOCK - 1) / NN1_BLOCK + 7) / 8 * 8)), dim3(NN1_BLOCK), 0,  \
-                       c->stream, q, qi, (int)n, d_T, c->levels, lc.maxr2, allow_self, d_sidx, d_d2, d_state, c->d_hard, h0, mp,  \
+    hipLaunchKernelGGL((nn1_ml_kernel<G_, NB_>), dim3((int)(((n * G_ + NN1_BLOCK - 1) / NN1_BLOCK + 7) / 8 * 8), ba.nscan), dim3(NN1_BLOCK), 0,  \
+                       c->stream, q, qi, ba, d_T, c->levels, lc.maxr2, allow_self, d_sidx, d_d2, d_state, c->d_hard, h0, mp,  \
                        c->d_lvl_tab, unseeded_lev, seed_pre)
         // iterations > 0 are seeded by the previous match (a handful of candidates per query): fewer
         // lanes per query; the unseeded first pass scans whole 27-cell blocks: more lanes per query

@@ -275,6 +275,19 @@ class ICPSequence:
         self._check(st)
         return _T_from_c(T[:])
 
+    def registerBatchDev(self, d_scan_ptrs, ns, fixed_iterations=0):
+        """icpmi_register_batch_dev: B readings (device pointers, sizes) against the map in one launch sequence.
+        Returns (list of 4x4 corrections, list of Stats, list of status codes)."""
+        B = len(d_scan_ptrs)
+        ptrs = (C.c_void_p * B)(*[int(p) for p in d_scan_ptrs])
+        nn = (C.c_int64 * B)(*[int(n) for n in ns])
+        T = (C.c_float * (16 * B))()
+        stats = (_capi.Stats * B)()
+        status = (C.c_int * B)()
+        self._check(self._lib.icpmi_register_batch_dev(self._h, B, ptrs, nn, fixed_iterations, T, stats, status))
+        self.batch_stats = stats
+        return [_T_from_c(T[16 * b:16 * b + 16]) for b in range(B)], [stats[b] for b in range(B)], [int(status[b]) for b in range(B)]
+
     # ---- stage-level entry points ----
     def transform(self, T, cloud, normals=None):
         cloud = _f32c(cloud, 4)

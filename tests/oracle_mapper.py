@@ -1,0 +1,166 @@
+"""Oracle-side restatement of `Mapper::processInput` / `Map::updateLocalPointCloud` (TEST INFRASTRUCTURE).
+
+Composes the CPU oracle's single operators (oracle/icp_oracle.c through tests/oracle_bindings.py -- never a kernel of
+libicpmi.so) exactly as the reference composes libpointmatcher's, so that the C++ host shell + HIP path can be checked
+scan by scan against an independent replay of a whole trajectory:
+
+    applyInputFilters      norlab_icp_mapper/Mapper.cpp:187-191   radius filter (Mapper.cpp:27-31), then the `input:` chain
+    processInput           Mapper.cpp:194-238                    prior -> icp -> correction * prior -> policy -> update
+    shouldUpdateMap        Mapper.cpp:240-272                    overlap / delay / distance
+    updateLocalPointCloud  Map.cpp:502-534                       first scan: module 0 creates, the rest update (:505-515);
+                                                                 to the sensor frame, post filters, back, icp.setMap (:523-528)
+    module bodies          MapperModules/{PointDistance,Octree,DynamicPoints}MapperModule.cpp
+
+Clouds are dicts {"xyz1": (n, 4) float32, <descriptor name>: (n, span) float32}; `concatenate` keeps the descriptors
+both clouds have (PM::DataPoints::concatenate).  Cell paging (Map::updatePose) does not change what the registration
+sees as long as the trajectory stays inside the window of loaded cells (sensorMaxRange + 2 buffer cells of 20 m,
+Map.cpp:246-460): the replays this is used for do.
+"""
+import numpy as np
+
+import oracle_bindings as ob
+
+
+def _h(xyz):
+    out = np.ones((xyz.shape[0], 4), dtype=np.float32)
+    out[:, :3] = xyz[:, :3]
+    return out
+
+
+def keep_only(cloud, mask):
+    return {k: np.ascontiguousarray(v[mask]) for k, v in cloud.items()}
+
+
+def concatenate(a, b):
+    """PM::DataPoints::concatenate: features stacked, descriptors present in both kept."""
+    out = {"xyz1": np.concatenate([a["xyz1"], b["xyz1"]], 0)}
+    for k in a:
+        if k != "xyz1" and k in b:
+            out[k] = np.concatenate([a[k], b[k]], 0)
+    return out
+
+
+def transform_cloud(T, cloud):
+    """RigidTransformation::compute: features by T, `normals` / `observationDirections` by R, the rest copied."""
+    out = dict(cloud)
+    out["xyz1"] = ob.transform(T, cloud["xyz1"])
+    for name in ("normals", "observationDirections"):
+        if name in cloud:
+            out[name] = ob.rotate3(T, cloud[name])
+    return out
+
+
+def mat4_mul_f32(A, B):
+    """4x4 float product with the fmaf chain the host shell uses (column by column accumulation)."""
+    A = np.asarray(A, dtype=np.float32); B = np.asarray(B, dtype=np.float32)
+    return (A.astype(np.float64) @ B.astype(np.float64)).astype(np.float32)
+
+
+class OracleMapper:
+    def __init__(self, icp_kw, modules, post=(), update=("distance", 1.0), sensor_max_range=80.0, input_filters=(),
+                 add_descriptors=(), nthreads=8, octree=None):
+        """modules: [("point_distance", minDist) | ("dynamic_points", {params}) | ("octree", maxSize, samplingMethod)]
+        post: [("surface_normals", knn) | ("cut", descName, useLargerThan, threshold)]
+        input_filters: oracle_bindings.filter_points rows; add_descriptors: [(name, value)] (AddDescriptorDataPointsFilter)
+        octree: callable(xyz1, maxSize, method) -> bool mask (the decimation operator under test: the voxel stand-in or
+        the octree restatement); default = the oracle's voxel operator."""
+        self.icp = ob.OracleICP(ob.make_config(nthreads=nthreads, **icp_kw))
+        self.modules, self.post, self.update = list(modules), list(post), update
+        self.sensor_max_range, self.input_filters, self.add_descriptors = sensor_max_range, list(input_filters), list(add_descriptors)
+        self.nthreads = nthreads
+        self.octree = octree or (lambda xyz1, size, method: ob.voxel_keep(xyz1, size, method))
+        self.map = None
+        self.pose = np.eye(4, dtype=np.float32)
+        self.trajectory, self.iterations, self.updated = [], [], []
+        self.last_time, self.last_pose = None, None
+
+    # ---- Mapper::applyInputFilters ----
+    def apply_input_filters(self, xyz, extra=None):
+        cloud = {"xyz1": _h(xyz)}
+        if extra:
+            cloud.update({k: np.asarray(v, dtype=np.float32).reshape(xyz.shape[0], -1) for k, v in extra.items()})
+        filters = [("distance_limit", -1, float(self.sensor_max_range), 0)] + self.input_filters
+        cloud = keep_only(cloud, ob.filter_points(cloud["xyz1"], filters))
+        for name, value in self.add_descriptors:
+            cloud[name] = np.full((cloud["xyz1"].shape[0], 1), value, dtype=np.float32)
+        return cloud
+
+    # ---- the module chain ----
+    def _module_update(self, mod, inp, mp, pose):
+        kind = mod[0]
+        if kind == "point_distance":                       # PointDistanceMapperModule.cpp:28-50
+            keep = ob.point_distance_keep(mp["xyz1"], inp["xyz1"], mod[1], nthreads=self.nthreads)
+            return concatenate(mp, keep_only(inp, keep))
+        if kind == "octree":                               # OctreeMapperModule.cpp:35-39: concatenate, then decimate
+            both = concatenate(mp, inp)
+            return keep_only(both, self.octree(both["xyz1"], mod[1], mod[2]))
+        if kind == "dynamic_points":                       # DynamicPointsMapperModule.cpp:34-151
+            to_sensor = np.linalg.inv(pose.astype(np.float64)).astype(np.float32)
+            out = dict(mp)
+            out["probabilityDynamic"] = ob.dynamic_points_update(to_sensor, inp["xyz1"], mp["xyz1"], mp["normals"], mp["probabilityDynamic"][:, 0],
+                                                                 nthreads=self.nthreads, **mod[1])[:, None]
+            return out
+        raise ValueError(kind)
+
+    def _module_create(self, mod, inp, pose):
+        if mod[0] in ("point_distance", "dynamic_points"):  # createMap keeps the input untouched (.cpp:8-21 / :14-27)
+            return dict(inp)
+        if mod[0] == "octree":                              # OctreeMapperModule.cpp:15-27: update of an empty map
+            return keep_only(inp, self.octree(inp["xyz1"], mod[1], mod[2]))
+        raise ValueError(mod[0])
+
+    def update_local_point_cloud(self, inp, pose):
+        if self.map is None or self.map["xyz1"].shape[0] == 0:
+            mp = self._module_create(self.modules[0], inp, pose)
+            for mod in self.modules[1:]:
+                mp = self._module_update(mod, inp, mp, pose)
+        else:
+            mp = self.map
+            for mod in self.modules:
+                mp = self._module_update(mod, inp, mp, pose)
+        inv = np.linalg.inv(pose.astype(np.float64)).astype(np.float32)
+        sensor = transform_cloud(inv, mp)
+        for f in self.post:
+            if f[0] == "surface_normals":
+                sensor["normals"] = ob.surface_normals(sensor["xyz1"], knn=f[1], nthreads=self.nthreads)
+            elif f[0] == "cut":
+                v = sensor[f[1]][:, 0]
+                sensor = keep_only(sensor, ~(v > f[3]) if f[2] else ~(v < f[3]))
+            else:
+                raise ValueError(f[0])
+        self.map = transform_cloud(pose, sensor)
+        self.icp.setMap(self.map["xyz1"], self.map.get("normals"))
+
+    # ---- Mapper::shouldUpdateMap ----
+    def _should_update(self, stamp, pose, overlap):
+        kind, value = self.update
+        if kind == "overlap":
+            return overlap < value
+        if kind == "delay":
+            return (stamp - self.last_time) > np.float32(value)
+        d = pose[:3, 3].astype(np.float32) - self.last_pose[:3, 3].astype(np.float32)
+        return float(np.sqrt(np.float32(np.dot(d, d)))) > value
+
+    # ---- Mapper::processInput ----
+    def process_input(self, filtered, prior, stamp_s):
+        prior = np.asarray(prior, dtype=np.float32)
+        inp = transform_cloud(prior, filtered)
+        if self.map is None or self.map["xyz1"].shape[0] == 0:
+            corrected = prior
+            self.last_time, self.last_pose = stamp_s, corrected
+            self.update_local_point_cloud(inp, corrected)
+            self.iterations.append(0); self.updated.append(True)
+        else:
+            err, corr = self.icp(inp["xyz1"], inp.get("normals"))
+            if err:
+                raise RuntimeError(f"oracle ICP error {err}")
+            corrected = mat4_mul_f32(corr, prior)
+            self.iterations.append(self.icp.stats.iterations)
+            upd = self._should_update(stamp_s, corrected, self.icp.stats.weighted_point_used_ratio)
+            if upd:
+                self.last_time, self.last_pose = stamp_s, corrected
+                self.update_local_point_cloud(transform_cloud(corr, inp), corrected)
+            self.updated.append(bool(upd))
+        self.pose = corrected
+        self.trajectory.append(corrected)
+        return corrected

@@ -1,0 +1,258 @@
+"""BASELINE.json configurations 3, 4 and 5 under `-m gpu`, against the CPU oracle.
+
+config 3  point-to-plane against SurfaceNormalDataPointsFilter normals, COMPOSED: the GPU computes the normals and
+          registers against them; the oracle computes its own normals and registers against those.
+config 4  the full examples/ trajectory replay: all 14 bundled scans (tests/golden/bundled_scans_all.npz) through the C++
+          host shell (`build_map_from_scans_and_trajectory`, the reference's harness and its lexicographic scan / trajectory
+          pairing, examples/build_map_from_scans_and_trajectory.cpp:191-232) with the shipped configuration switched to
+          PointToPlane / epsilon 0 / samplingMethod 0, against an oracle-side replay of
+          Mapper::processInput / Map::updateLocalPointCloud (tests/oracle_mapper.py) -- pose per scan.
+config 5  the 10 M-point map on one GPU: kNN ids / d^2 and one full point-to-plane registration against the oracle on a
+          query subset the oracle can afford, plus size-independent properties at the full 100 k-point reading.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "norlab_icp_mapper_amd")
+POSE_TOL_M, POSE_TOL_RAD = 1e-4, 1e-4
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import norlab_icp_mapper_amd as pkg
+    return pkg
+
+
+# ------------------------------------------------------------------------------------------------ config 3
+def test_config3_gpu_normals_then_point_to_plane_against_oracle_normals_then_oracle(amd, oracle, mid_scene):
+    sc = mid_scene
+    kw = dict(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=40, use_differential=1)
+    icp = amd.ICPSequence(**kw)
+    n_gpu = icp.surfaceNormals(sc["map"], knn=10)
+    n_cpu = oracle.surface_normals(sc["map"], knn=10, nthreads=8)
+    # the two normal fields agree point by point up to sign (unoriented PCA normals) and rounding of the eigen-solve
+    dots = np.abs(np.einsum("ij,ij->i", n_gpu, n_cpu))
+    deg = np.linalg.norm(n_cpu, axis=1) < 0.5                     # rank-deficient neighbourhoods: zero normal on both sides
+    assert np.array_equal(deg, np.linalg.norm(n_gpu, axis=1) < 0.5)
+    assert (dots[~deg] > 1 - 1e-4).all(), float(dots[~deg].min())
+    assert icp.setMap(sc["map"], n_gpu)
+    T = icp(sc["scan"])
+    oicp = oracle.OracleICP(oracle.make_config(nthreads=8, **kw))
+    oicp.setMap(sc["map"], n_cpu)
+    err, T_ref = oicp(sc["scan"])
+    assert err == 0
+    assert icp.stats.iterations == oicp.stats.iterations and icp.stats.stop_reason == oicp.stats.stop_reason
+    assert icp.stats.pairs == oicp.stats.pairs
+    dt, dr = amd.synth.pose_error(T, T_ref)
+    assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (dt, dr)
+    gt, gr = amd.synth.pose_error(T, sc["T_gt"])
+    assert gt < 5e-3 and gr < 5e-4, (gt, gr)
+
+
+# ------------------------------------------------------------------------------------------------ config 4
+CONFIG4_YAML = """
+input:
+  - BoundingBoxDataPointsFilter:
+      xMin: -1.5
+      xMax: 0.5
+      yMin: -1
+      yMax: 1
+      zMin: -1
+      zMax: 0.5
+      removeInside: 1
+  - BoundingBoxDataPointsFilter:
+      xMin: -6
+      xMax: -1.5
+      yMin: -2.5
+      yMax: 2.5
+      zMin: -1
+      zMax: 1
+      removeInside: 1
+  - AddDescriptorDataPointsFilter:
+      descriptorName: probabilityDynamic
+      descriptorDimension: 1
+      descriptorValues: [0.6]
+post:
+    - SurfaceNormalDataPointsFilter:
+        knn: 10
+    - CutAtDescriptorThresholdDataPointsFilter:
+        descName: probabilityDynamic
+        useLargerThan: 1
+        threshold: 0.65
+mapper:
+  updateCondition:
+    type: delay
+    value: 0.05
+  mapperModule:
+    - DynamicPointsMapperModule:
+        thresholdDynamic: 0.9
+        alpha: 0.8
+        beta: 0.99
+        beamHalfAngle: 0.01
+        epsilonA: 0.01
+        epsilonD: 0.01
+    - OctreeMapperModule:
+        buildParallel: 1
+        maxSizeByNode: 0.15
+        samplingMethod: 0
+  sensorMaxRange: 200
+icp:
+  matcher:
+    KDTreeMatcher:
+      knn: 6
+      maxDist: 2.0
+      epsilon: 0
+  errorMinimizer:
+    PointToPlaneErrorMinimizer:
+  transformationCheckers:
+    - CounterTransformationChecker:
+        maxIterationCount: 10
+  inspector: NullInspector
+"""
+
+
+def _quat_T(row):
+    x, y, z, qx, qy, qz, qw = row
+    R = np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)],
+                  [2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)],
+                  [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)]])
+    T = np.eye(4); T[:3, :3] = R; T[:3, 3] = [x, y, z]
+    return T.astype(np.float32)
+
+
+def _write_bundled_dataset(tmp, z):
+    """the fixture back into the reference's on-disk layout: scans/<original names>.vtk (ASCII, libpointmatcher's
+    dialect) + trajectory.csv (the ROS odometry dump's columns)"""
+    os.makedirs(os.path.join(tmp, "scans"))
+    names = [str(s) for s in z["scan_names"]]
+    for k, name in enumerate(names):
+        pts = z[f"scan{k}_xyz"]
+        n = pts.shape[0]
+        with open(os.path.join(tmp, "scans", name), "w") as f:
+            f.write("# vtk DataFile Version 3.0\nFile created by libpointmatcher\nASCII\nDATASET POLYDATA\n")
+            f.write(f"POINTS {n} float\n")
+            np.savetxt(f, pts, fmt="%.9g")
+            f.write(f"VERTICES {n} {2 * n}\n")
+            np.savetxt(f, np.stack([np.ones(n, int), np.arange(n)], 1), fmt="%d")
+    traj = z["trajectory"]
+    with open(os.path.join(tmp, "trajectory.csv"), "w") as f:
+        f.write("header.stamp.sec,header.stamp.nanosec,header.frame_id,child_frame_id,pose.pose.position.x,pose.pose.position.y,"
+                "pose.pose.position.z,pose.pose.orientation.x,pose.pose.orientation.y,pose.pose.orientation.z,pose.pose.orientation.w,pose.covariance\n")
+        for r in traj:
+            f.write(f"{int(r[0])},{int(r[1])},map,base_link," + ",".join(repr(float(v)) for v in r[2:]) + ",[0. 0. 0.]\n")
+    return names, traj
+
+
+def test_config4_full_bundled_trajectory_replay_against_oracle_replay(amd, oracle, tmp_path):
+    from test_host_cpp import _build_host, _read_vtk
+    import oracle_mapper as om
+    _build_host()
+    z = np.load(os.path.join(ROOT, "tests", "golden", "bundled_scans_all.npz"))
+    tmp = str(tmp_path)
+    names, traj = _write_bundled_dataset(tmp, z)
+    # the example pairs trajectory row i with the i-th file in LEXICOGRAPHIC order (cpp:191): the fixture keeps that order,
+    # and it is NOT chronological -- cloud_1690309710_85582848 (t = 710.0856 s) sorts last
+    assert names == sorted(names) and len(names) == 14 and names[-1].startswith("cloud_1690309710_85582848")
+    stamps_from_names = [int(n.split("_")[1]) * 10**9 + int(n.split("_")[2].split(".")[0]) for n in names]
+    assert stamps_from_names != sorted(stamps_from_names)
+    cfg = os.path.join(tmp, "config.yaml")
+    open(cfg, "w").write(CONFIG4_YAML)
+    traj_out = os.path.join(tmp, "traj.vtk")
+    out = subprocess.run([os.path.join(PKG, "build_map_from_scans_and_trajectory"), tmp, cfg, traj_out], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert out.stdout.count("iterations 10") == 13, out.stdout          # scan 1 creates the map, 13 registrations of 10 passes each
+    pos, desc = _read_vtk(traj_out)
+    assert pos.shape[0] == 14
+    cpp = []
+    for i in range(14):
+        T = np.eye(4, dtype=np.float32)
+        T[:3, 0], T[:3, 1], T[:3, 2], T[:3, 3] = desc["orientationX"][i], desc["orientationY"][i], desc["orientationZ"][i], pos[i]
+        cpp.append(T)
+
+    # ---- the oracle's replay of the same trajectory ----
+    nt = min(16, len(os.sched_getaffinity(0)))
+    mapper = om.OracleMapper(
+        dict(knn=6, max_dist=2.0, minimizer=2, outliers=[], max_iterations=10),
+        [("dynamic_points", dict(threshold_dynamic=0.9, alpha=0.8, beta=0.99, beam_half_angle=0.01, epsilon_a=0.01, epsilon_d=0.01)),
+         ("octree", 0.15, 0)],
+        post=[("surface_normals", 10), ("cut", "probabilityDynamic", 1, 0.65)], update=("delay", 0.05), sensor_max_range=200.0,
+        input_filters=[("bounding_box", (-1.5, -1, -1), (0.5, 1, 0.5), 1), ("bounding_box", (-6, -2.5, -1), (-1.5, 2.5, 1), 1)],
+        add_descriptors=[("probabilityDynamic", 0.6)], nthreads=nt)
+    worst = (0.0, 0.0)
+    moved = 0.0
+    for i in range(14):
+        cloud = mapper.apply_input_filters(z[f"scan{i}_xyz"])
+        prior = _quat_T(traj[i, 2:])
+        T_ref = mapper.process_input(cloud, prior, traj[i, 0] + traj[i, 1] * 1e-9)
+        dt, dr = amd.synth.pose_error(cpp[i], T_ref)
+        assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (i, names[i], dt, dr)
+        worst = (max(worst[0], dt), max(worst[1], dr))
+        moved = max(moved, amd.synth.pose_error(T_ref, prior)[0])
+    assert mapper.iterations == [0] + [10] * 13 and all(mapper.updated)          # delay 0.05 s: every scan updates the map
+    assert moved > 1e-3                                                          # the registrations do correct the priors
+    # the maps agree in size (the decimation and the probability cut are index / threshold decisions on near-identical clouds)
+    mp, mdesc = _read_vtk(os.path.join(tmp, "map.vtk"))
+    m_ref = mapper.map["xyz1"].shape[0]
+    assert abs(mp.shape[0] - m_ref) <= max(5, m_ref // 200), (mp.shape[0], m_ref)
+    assert {"normals", "probabilityDynamic"} <= set(mdesc)
+    print(f"config 4: 14 scans, worst pose difference to the oracle replay {worst[0]:.2e} m / {worst[1]:.2e} rad, map {mp.shape[0]} vs {m_ref} points")
+
+
+# ------------------------------------------------------------------------------------------------ config 5
+@pytest.fixture(scope="module")
+def scene_10m(amd):
+    return amd.synth.make_scene(m=10_000_000, n=100_000, scale=3.16)
+
+
+def test_config5_knn_on_the_10M_map_matches_oracle(amd, oracle, scene_10m):
+    sc = scene_10m
+    icp = amd.ICPSequence(minimizer=2, max_dist=2.0)
+    assert icp.setMap(sc["map"], sc["normals"])
+    mean = icp.getMapMean()
+    rng = np.random.default_rng(5)
+    q = sc["scan"][rng.permutation(sc["scan"].shape[0])[:5000]].copy()
+    q[:, :3] -= mean[None, :]
+    ref = sc["map"].copy(); ref[:, :3] -= mean[None, :]
+    for k, md in ((1, 2.0), (6, 2.0)):
+        ids, d2 = icp.knn(q, k=k, max_dist=md)
+        oid, od2 = oracle.knn(ref, q, k=k, max_dist=md, nthreads=16)
+        assert np.array_equal(d2, od2)
+        assert np.array_equal(ids, oid)
+
+
+def test_config5_registration_on_the_10M_map(amd, oracle, scene_10m):
+    sc = scene_10m
+    kw = dict(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=40, use_differential=1)
+    icp = amd.ICPSequence(**kw)
+    assert icp.setMap(sc["map"], sc["normals"])
+    # (a) a 5 k-point reading the oracle can afford: iterations, stop reason, pairs, pose
+    rng = np.random.default_rng(6)
+    sub = np.ascontiguousarray(sc["scan"][np.sort(rng.permutation(sc["scan"].shape[0])[:5000])])
+    T = icp(sub)
+    oicp = oracle.OracleICP(oracle.make_config(nthreads=16, **kw))
+    oicp.setMap(sc["map"], sc["normals"])
+    err, T_ref = oicp(sub)
+    assert err == 0
+    assert (icp.stats.iterations, icp.stats.stop_reason, icp.stats.pairs) == (oicp.stats.iterations, oicp.stats.stop_reason, oicp.stats.pairs)
+    dt, dr = amd.synth.pose_error(T, T_ref)
+    assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (dt, dr)
+    # (b) the full 100 k-point reading: size-independent properties
+    T_full = icp(sc["scan"])
+    it_full = icp.stats.iterations
+    gt, gr = amd.synth.pose_error(T_full, sc["T_gt"])
+    assert gt < 5e-3 and gr < 5e-4, (gt, gr)                                    # recovers the known transform
+    assert np.array_equal(icp(sc["scan"]), T_full) and icp.stats.iterations == it_full   # bitwise reproducible
+    assert 0.84 < icp.stats.point_used_ratio <= 0.8501                          # TrimmedDist 0.85 keeps rank floor(0.85 n) + ties
+    # idempotence: registering the reading moved by the correction yields (almost) no further motion
+    moved = icp.transform(T_full, sc["scan"])
+    T_again = icp(moved)
+    mt, mr = amd.synth.pose_error(T_again, np.eye(4, dtype=np.float32))
+    assert mt < 2e-3 and mr < 2e-4, (mt, mr)
+    # the pyramid decides every query of a bounded-radius search: no brute-force left-overs on the big map
+    assert icp.stats.hard_queries == 0
