@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define ICPMI_VERSION 1
+#define ICPMI_VERSION 2
 
 typedef struct icpmi_ctx* icpmi_handle;
 
@@ -279,8 +279,13 @@ icpmi_status icpmi_voxel_keep(icpmi_handle h, const float* in4, int64_t n, float
  * (`createMap`: PointDistance / DynamicPoints take the scan as it is, Voxel decimates it) and the others update it with
  * the same scan (Map.cpp:508-516).  scan_scalar (n floats) is the scan's value of the tracked scalar, NULL if the chain
  * has none; scan_normals3 may be NULL (appended points then carry zero normals until a SURFACE_NORMALS step).
- * to_sensor = pose^-1 (sensor <- map; `pose` is the modules' argument, DynamicPointsMapperModule.cpp:51,57; only
- * DYNAMIC_POINTS reads it, may be NULL otherwise); post filters run in the map frame.
+ * to_sensor = pose^-1 (sensor <- map; `pose` is the modules' argument, DynamicPointsMapperModule.cpp:51,57), from_sensor = pose.
+ * With from_sensor given the post filters run exactly where the reference runs them: the whole working map is moved into the
+ * sensor frame by to_sensor, filtered, and moved back by from_sensor (Map.cpp:523-525) -- every map point picks up the
+ * rounding of that round trip on every update, as in the reference (two transform kernels over the map: microseconds).
+ * from_sensor == NULL: post filters in the map frame, coordinates of old map points untouched (not what the reference
+ * does: a replay of the bundled trajectory then leaves the reference's poses by up to 0.4 mm); to_sensor may be NULL when
+ * from_sensor is and the chain has no DYNAMIC_POINTS.
  * src_capacity must be >= m_old + n_modules * n (every module appends at most the whole scan).  identity_prefix (may be NULL): when given, receives the length of the head of
  * the new map that is the untouched head of the old one (src[j] == j for j < *identity_prefix) and src_out is written
  * from that position on only -- a host that owns further descriptors leaves those rows alone and gathers the rest, and
@@ -290,12 +295,12 @@ typedef enum {
 } icpmi_map_op_type;
 typedef struct icpmi_map_op { int32_t type; int32_t i; float f[7]; } icpmi_map_op;
 icpmi_status icpmi_map_update_chain(icpmi_handle h, const float* scan4, int64_t n, const float* scan_normals3, const float* scan_scalar,
-                                    const float to_sensor[16], const icpmi_map_op* ops, int32_t n_ops, int32_t n_modules,
-                                    int32_t* src_out, int64_t src_capacity, int64_t* identity_prefix, int64_t* new_m);
+                                    const float to_sensor[16], const float from_sensor[16], const icpmi_map_op* ops, int32_t n_ops,
+                                    int32_t n_modules, int32_t* src_out, int64_t src_capacity, int64_t* identity_prefix, int64_t* new_m);
 /* The same on the scan staged by icpmi_register_prior, moved by `correction` first (Mapper.cpp:221). */
 icpmi_status icpmi_map_update_chain_staged(icpmi_handle h, const float correction[16], const float* scan_scalar, const float to_sensor[16],
-                                           const icpmi_map_op* ops, int32_t n_ops, int32_t n_modules, int32_t* src_out,
-                                           int64_t src_capacity, int64_t* identity_prefix, int64_t* new_m);
+                                           const float from_sensor[16], const icpmi_map_op* ops, int32_t n_ops, int32_t n_modules,
+                                           int32_t* src_out, int64_t src_capacity, int64_t* identity_prefix, int64_t* new_m);
 /* The tracked scalar descriptor of the resident map: upload after a icpmi_set_map (m must equal the map size),
  * download next to icpmi_get_map. */
 icpmi_status icpmi_set_map_scalar(icpmi_handle h, const float* scalar, int64_t m);

@@ -515,11 +515,11 @@ static bool chain_needs_pose(const icpmi_map_op* ops, int32_t n_ops)
 }
 
 icpmi_status icpmi_map_update_chain(icpmi_handle h, const float* scan4, int64_t n, const float* scan_normals3, const float* scan_scalar,
-                                    const float to_sensor[16], const icpmi_map_op* ops, int32_t n_ops, int32_t n_modules,
-                                    int32_t* src_out, int64_t src_capacity, int64_t* identity_prefix, int64_t* new_m)
+                                    const float to_sensor[16], const float from_sensor[16], const icpmi_map_op* ops, int32_t n_ops,
+                                    int32_t n_modules, int32_t* src_out, int64_t src_capacity, int64_t* identity_prefix, int64_t* new_m)
 {
     CHECK_H(h);
-    if (n < 0 || (n > 0 && !scan4) || (chain_needs_pose(ops, n_ops) && !to_sensor)) { h->last_error = "map_update_chain: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
+    if (n < 0 || (n > 0 && !scan4) || (chain_needs_pose(ops, n_ops) && !to_sensor) || (from_sensor && !to_sensor)) { h->last_error = "map_update_chain: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
     if (n > 0) {
         if (ensure_cap(h, &h->d_stage_in, &h->cap_stage_in, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
         HIP_TRY(h, hipMemcpyAsync(h->d_stage_in, scan4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, h->stream));
@@ -530,24 +530,24 @@ icpmi_status icpmi_map_update_chain(icpmi_handle h, const float* scan4, int64_t 
         icpmi_status s = stage_chain_scalar(h, scan_scalar, n);
         if (s != ICPMI_OK) return s;
     }
-    return ops_map_update_chain(h, h->d_stage_in, n, scan_normals3 ? h->d_stage_n3 : nullptr, scan_scalar ? h->d_stage_s : nullptr, to_sensor, ops,
-                                n_ops, n_modules, src_out, src_capacity, identity_prefix, new_m);
+    return ops_map_update_chain(h, h->d_stage_in, n, scan_normals3 ? h->d_stage_n3 : nullptr, scan_scalar ? h->d_stage_s : nullptr, to_sensor,
+                                from_sensor, ops, n_ops, n_modules, src_out, src_capacity, identity_prefix, new_m);
 }
 
 icpmi_status icpmi_map_update_chain_staged(icpmi_handle h, const float correction[16], const float* scan_scalar, const float to_sensor[16],
-                                           const icpmi_map_op* ops, int32_t n_ops, int32_t n_modules, int32_t* src_out,
-                                           int64_t src_capacity, int64_t* identity_prefix, int64_t* new_m)
+                                           const float from_sensor[16], const icpmi_map_op* ops, int32_t n_ops, int32_t n_modules,
+                                           int32_t* src_out, int64_t src_capacity, int64_t* identity_prefix, int64_t* new_m)
 {
     CHECK_H(h);
-    if (!correction || (chain_needs_pose(ops, n_ops) && !to_sensor)) { h->last_error = "map_update_chain_staged: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
+    if (!correction || (chain_needs_pose(ops, n_ops) && !to_sensor) || (from_sensor && !to_sensor)) { h->last_error = "map_update_chain_staged: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
     if (h->scan_map_n <= 0) { h->last_error = "map_update_chain_staged: no scan staged by icpmi_register_prior"; return ICPMI_ERR_INVALID_ARG; }
     const int64_t n = h->scan_map_n;
     if (ensure_cap(h, &h->d_stage_in, &h->cap_stage_in, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
     icpmi_status s = ops_transform_dev(h, correction, h->d_scan_map, n, h->d_stage_in); // Mapper.cpp:221
     if (s == ICPMI_OK) s = stage_chain_scalar(h, scan_scalar, n);
     if (s != ICPMI_OK) return s;
-    return ops_map_update_chain(h, h->d_stage_in, n, nullptr, scan_scalar ? h->d_stage_s : nullptr, to_sensor, ops, n_ops, n_modules, src_out,
-                                src_capacity, identity_prefix, new_m);
+    return ops_map_update_chain(h, h->d_stage_in, n, nullptr, scan_scalar ? h->d_stage_s : nullptr, to_sensor, from_sensor, ops, n_ops, n_modules,
+                                src_out, src_capacity, identity_prefix, new_m);
 }
 
 icpmi_status icpmi_set_map_scalar(icpmi_handle h, const float* scalar, int64_t m)

@@ -355,8 +355,8 @@ LoopCfg make_loop_cfg(const icpmi_ctx* c, int fixed_iterations);
 icpmi_status ops_transform(icpmi_ctx* c, const float T[16], const float* in4, int64_t n, float* out4,
                            const float* in_n3, float* out_n3);
 icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n, const float* d_scan_n3, const float* d_scan_s,
-                                  const float to_sensor[16], const icpmi_map_op* ops, int n_ops, int n_modules, int32_t* src_out,
-                                  int64_t src_capacity, int64_t* identity_prefix, int64_t* new_m);
+                                  const float to_sensor[16], const float from_sensor[16], const icpmi_map_op* ops, int n_ops, int n_modules,
+                                  int32_t* src_out, int64_t src_capacity, int64_t* identity_prefix, int64_t* new_m);
 #define ICPMI_MAX_POINT_FILTERS 16
 icpmi_status ops_filter_points(icpmi_ctx* c, const float* in4, int64_t n, const icpmi_point_filter* filters, int n_filters, uint8_t* keep);
 icpmi_status ops_staged_keep(icpmi_ctx* c, const float correction[16], float min_dist, uint8_t* keep_out, float* placed_out4);

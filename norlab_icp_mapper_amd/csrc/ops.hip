@@ -1000,9 +1000,21 @@ icpmi_status chain_point_distance_flags(icpmi_ctx* c, icpmi_ctx* ic, const float
 
 } // namespace
 
+// the working map moved by T in place: features by T, normals by its rotation (RigidTransformation::compute on the whole map,
+// Map.cpp:523 / :525)
+static icpmi_status chain_move(icpmi_ctx* c, const float T[16], int64_t m, bool has_n)
+{
+    if (m == 0) return ICPMI_OK;
+    icpmi_status s = ops_transform_dev(c, T, c->d_raw, m, c->d_raw); // uploads T into d_T16
+    if (s != ICPMI_OK) return s;
+    if (has_n) hipLaunchKernelGGL(rotate3_kernel, dim3((int)((m + 255) / 256)), dim3(256), 0, c->stream, (const float*)c->d_raw_n3, m, (const float*)c->d_T16, c->d_raw_n3);
+    HIP_TRY(c, hipGetLastError());
+    return ICPMI_OK;
+}
+
 icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n, const float* d_scan_n3, const float* d_scan_s,
-                                  const float to_sensor[16], const icpmi_map_op* ops, int n_ops, int n_modules, int32_t* src_out,
-                                  int64_t src_capacity, int64_t* identity_prefix, int64_t* new_m)
+                                  const float to_sensor[16], const float from_sensor[16], const icpmi_map_op* ops, int n_ops, int n_modules,
+                                  int32_t* src_out, int64_t src_capacity, int64_t* identity_prefix, int64_t* new_m)
 {
     if (identity_prefix) *identity_prefix = 0;
     const int64_t m0 = c->m > 0 ? c->m_raw : 0;
@@ -1055,8 +1067,15 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
     const int src_base = (int)m0;
     bool created = m0 > 0; // false until the first module has created the map from the scan
 
+    // Map.cpp:523-525: the post filters see the map in the SENSOR frame -- the whole map is moved by pose^-1, filtered, and
+    // moved back by pose, on every update; the coordinates of every map point pick up that rounding each time, and so must
+    // the resident copy (a replay of the bundled trajectory leaves the reference's by up to 0.4 mm otherwise: which point
+    // survives a decimation or a threshold can hinge on the last bit).  from_sensor == NULL: filters in the map frame.
+    const bool round_trip = from_sensor != nullptr && to_sensor != nullptr;
+    bool in_sensor = false;
     for (int i = 0; i < n_ops && s == ICPMI_OK; ++i) {
         const icpmi_map_op& op = ops[i];
+        if (i == n_modules && round_trip) { s = chain_move(c, to_sensor, w.m, w.has_n); in_sensor = true; if (s != ICPMI_OK) break; }
         switch (op.type) {
         case ICPMI_MOP_POINT_DISTANCE: {
             if (n == 0) break;
@@ -1119,6 +1138,10 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
         }
         }
         created = true;
+    }
+    if (s == ICPMI_OK && round_trip) {
+        if (!in_sensor) s = chain_move(c, to_sensor, w.m, w.has_n); // no post filter at all: the reference still makes the trip
+        if (s == ICPMI_OK) s = chain_move(c, from_sensor, w.m, w.has_n);
     }
     if (s != ICPMI_OK) {
         // the resident arrays may be half way through the program: drop them, the index of the old map is intact but its

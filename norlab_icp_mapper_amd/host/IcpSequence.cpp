@@ -208,9 +208,10 @@ static std::vector<float> scalarRow(const DataPoints& cloud, const std::string& 
 }
 
 void GpuICPSequence::mapUpdateChain(const DataPoints* input, const Mat4& correction, const std::string& scalarName, const DataPoints& scanDescriptors,
-                                    const Mat4& toSensor, const std::vector<icpmi_map_op>& ops, int nModules, std::vector<int32_t>& src,
+                                    const Mat4& pose, const std::vector<icpmi_map_op>& ops, int nModules, std::vector<int32_t>& src,
                                     int64_t& prefix, int64_t& mapSize, bool wantSrc)
 {
+    const Mat4 toSensor = pose.inverse();
     const size_t n = input ? input->getNbPoints() : stagedPoints;
     std::vector<float> scalar;
     if (!scalarName.empty()) scalar = scalarRow(scanDescriptors, scalarName);
@@ -222,10 +223,10 @@ void GpuICPSequence::mapUpdateChain(const DataPoints* input, const Mat4& correct
     if (input) {
         const float* normals = nullptr;
         if (input->descriptorExists("normals") && input->getDescriptorByName("normals").span == 3) normals = input->getDescriptorByName("normals").data.data();
-        check(h, icpmi_map_update_chain(h, input->features.data(), (int64_t)n, normals, sp, toSensor.data(), ops.data(), (int32_t)ops.size(), nModules,
+        check(h, icpmi_map_update_chain(h, input->features.data(), (int64_t)n, normals, sp, toSensor.data(), pose.data(), ops.data(), (int32_t)ops.size(), nModules,
                                         srcp, (int64_t)src.size(), prefp, &mapSize));
     } else
-        check(h, icpmi_map_update_chain_staged(h, correction.data(), sp, toSensor.data(), ops.data(), (int32_t)ops.size(), nModules, srcp,
+        check(h, icpmi_map_update_chain_staged(h, correction.data(), sp, toSensor.data(), pose.data(), ops.data(), (int32_t)ops.size(), nModules, srcp,
                                                (int64_t)src.size(), prefp, &mapSize));
     if (wantSrc) src.resize((size_t)mapSize);
 }

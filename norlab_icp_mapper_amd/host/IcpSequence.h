@@ -48,8 +48,9 @@ public:
     // Map::updateLocalPointCloud for a whole module chain + post filters on the resident map (icpmi_map_update_chain /
     // icpmi_map_update_chain_staged when `input` is null: the scan kept by registerWithPrior, moved by `correction`).
     // src[j] for j >= prefix: provenance of new map point j in [old map ; scan]; the first `prefix` points are untouched.
+    // pose: the post filters run in the sensor frame (the map is moved by pose^-1 and back by pose, Map.cpp:523-525), on the device.
     void mapUpdateChain(const DataPoints* inputInMapFrame, const Mat4& correction, const std::string& scalarName, const DataPoints& scanDescriptors,
-                        const Mat4& toSensor, const std::vector<icpmi_map_op>& ops, int nModules, std::vector<int32_t>& src, int64_t& prefix,
+                        const Mat4& pose, const std::vector<icpmi_map_op>& ops, int nModules, std::vector<int32_t>& src, int64_t& prefix,
                         int64_t& mapSize, bool wantSrc = true); // wantSrc = false: no host-side descriptor needs the provenance vector
     void uploadMapScalar(const std::vector<float>& scalar);   // the tracked scalar descriptor of the resident map
     std::vector<float> downloadMapScalar() const;

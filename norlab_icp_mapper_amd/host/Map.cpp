@@ -336,7 +336,7 @@ bool Map::tryResidentUpdate(const DataPoints& input, const Mat4& pose, const Dat
     int64_t prefix = 0, m = 0;
     {
         std::lock_guard<std::mutex> gi(icpMapLock);
-        icp.mapUpdateChain(&input, Mat4::identity(), prog.scalarName, input, pose.inverse(), prog.ops, prog.nModules, src, prefix, m,
+        icp.mapUpdateChain(&input, Mat4::identity(), prog.scalarName, input, pose, prog.ops, prog.nModules, src, prefix, m,
                            hostDescriptorsFollow(input, prog, first));
     }
     adoptResidentResult(input, prog, src, prefix, m, first);
@@ -364,7 +364,7 @@ void Map::updateLocalPointCloudStaged(const DataPoints& inputDescriptors, const 
     int64_t prefix = 0, m = 0;
     {
         std::lock_guard<std::mutex> gi(icpMapLock);
-        icp.mapUpdateChain(nullptr, correction, prog.scalarName, inputDescriptors, pose.inverse(), prog.ops, prog.nModules, src, prefix, m,
+        icp.mapUpdateChain(nullptr, correction, prog.scalarName, inputDescriptors, pose, prog.ops, prog.nModules, src, prefix, m,
                            hostDescriptorsFollow(inputDescriptors, prog, first));
     }
     adoptResidentResult(inputDescriptors, prog, src, prefix, m, first);

@@ -409,7 +409,7 @@ class ICPSequence:
         return ops
 
     def mapUpdateChain(self, scan_in_map_frame, modules, post=(), scan_scalar=None, scan_normals=None, to_sensor=None, staged_correction=None,
-                       with_prefix=False, want_src=True):
+                       with_prefix=False, want_src=True, from_sensor=None):
         """Map::updateLocalPointCloud (Map.cpp:502-534) for a whole module chain + post filters on the resident map.
         Returns (src, m): new map point j was point src[j] of [old map ; scan].  With staged_correction the scan is the
         one staged by registerWithPrior (scan_in_map_frame is ignored)."""
@@ -418,6 +418,8 @@ class ICPSequence:
         self._check(self._lib.icpmi_get_map(self._h, None, None, 0, C.byref(m_old)))
         ss = None if scan_scalar is None else np.ascontiguousarray(scan_scalar, dtype=np.float32)
         Ts = None if to_sensor is None else _T_to_c(to_sensor)
+        Tf = None if from_sensor is None else _T_to_c(from_sensor)   # pose: the post filters then run in the sensor frame (Map.cpp:523-525)
+        Tfp = None if Tf is None else Tf.ctypes.data
         new_m = C.c_int64(0)
         head = C.c_int64(0)
         hp = C.byref(head) if with_prefix else None
@@ -425,13 +427,13 @@ class ICPSequence:
             Tc = None if staged_correction is None else _T_to_c(staged_correction)
             if staged_correction is not None:
                 self._check(self._lib.icpmi_map_update_chain_staged(self._h, Tc.ctypes.data, None if ss is None else ss.ctypes.data,
-                                                                    None if Ts is None else Ts.ctypes.data, ops, len(ops), len(modules),
+                                                                    None if Ts is None else Ts.ctypes.data, Tfp, ops, len(ops), len(modules),
                                                                     None, 0, None, C.byref(new_m)))
             else:
                 sc = _f32c(scan_in_map_frame, 4)
                 sn = None if scan_normals is None else _f32c(scan_normals, 3)
                 self._check(self._lib.icpmi_map_update_chain(self._h, sc.ctypes.data, sc.shape[0], None if sn is None else sn.ctypes.data,
-                                                             None if ss is None else ss.ctypes.data, None if Ts is None else Ts.ctypes.data,
+                                                             None if ss is None else ss.ctypes.data, None if Ts is None else Ts.ctypes.data, Tfp,
                                                              ops, len(ops), len(modules), None, 0, None, C.byref(new_m)))
             return None, int(new_m.value)
         if staged_correction is not None:
@@ -439,7 +441,7 @@ class ICPSequence:
             src = np.empty(m_old.value + max(1, len(modules)) * n + 1, dtype=np.int32)
             Tc = _T_to_c(staged_correction)
             self._check(self._lib.icpmi_map_update_chain_staged(self._h, Tc.ctypes.data, None if ss is None else ss.ctypes.data,
-                                                                None if Ts is None else Ts.ctypes.data, ops, len(ops), len(modules),
+                                                                None if Ts is None else Ts.ctypes.data, Tfp, ops, len(ops), len(modules),
                                                                 src.ctypes.data, src.shape[0], hp, C.byref(new_m)))
         else:
             sc = _f32c(scan_in_map_frame, 4)
@@ -447,7 +449,7 @@ class ICPSequence:
             n = sc.shape[0]
             src = np.empty(m_old.value + max(1, len(modules)) * n + 1, dtype=np.int32)
             self._check(self._lib.icpmi_map_update_chain(self._h, sc.ctypes.data, n, None if sn is None else sn.ctypes.data,
-                                                         None if ss is None else ss.ctypes.data, None if Ts is None else Ts.ctypes.data,
+                                                         None if ss is None else ss.ctypes.data, None if Ts is None else Ts.ctypes.data, Tfp,
                                                          ops, len(ops), len(modules), src.ctypes.data, src.shape[0], hp, C.byref(new_m)))
         if with_prefix:  # the head was not written by the library: it is the identity
             src[:head.value] = np.arange(head.value, dtype=np.int32)

