@@ -264,6 +264,15 @@ icpmi_status icpmi_dynamic_points_update(icpmi_handle h, const icpmi_dynpts_para
  * whose index has the smallest 32-bit finaliser hash (fmix32 of MurmurHash3, a bijection) represents its voxel. */
 icpmi_status icpmi_voxel_keep(icpmi_handle h, const float* in4, int64_t n, float edge, int32_t method, uint8_t* keep);
 
+/* `OctreeGridDataPointsFilter{maxSizeByNode, maxPointByNode, samplingMethod}` (created at OctreeMapperModule.cpp:12, applied at :38):
+ * octree over the bounding cube of the cloud, split until the node edge is <= max_size or the node holds <= max_points points
+ * (depth capped at 21), one representative per leaf: method 0 = the first point of the leaf (smallest index), 1 = a random
+ * point made reproducible (smallest fmix32(index)).  order_out (capacity n) = indices of the kept points in the order upstream
+ * leaves the cloud in (depth-first leaf order); leaf_of_out (n entries, may be NULL) = leaf ordinal of every input point (for
+ * callers that build centroids / medoids, samplingMethod 2 / 3, themselves). */
+icpmi_status icpmi_octree_sample(icpmi_handle h, const float* in4, int64_t n, float max_size, int32_t max_points, int32_t method,
+                                 int32_t* order_out, int32_t* leaf_of_out, int64_t* n_out);
+
 /* `Map::updateLocalPointCloud` (Map.cpp:502-534) for a whole module chain on the RESIDENT map: the mapper modules
  * (`mapperModuleVec`, Map.cpp:506-521) and then the post filters (Map.cpp:523-525) run as one program on the device copy
  * of the map; only the scan crosses PCIe.  The device tracks the features, the `normals` and ONE scalar descriptor of
@@ -273,6 +282,10 @@ icpmi_status icpmi_voxel_keep(icpmi_handle h, const float* in4, int64_t n, float
  *   ICPMI_MOP_POINT_DISTANCE   f[0] = minDistNewPoint                   (PointDistanceMapperModule.cpp:28-50)
  *   ICPMI_MOP_DYNAMIC_POINTS   f[0..6] = icpmi_dynpts_params in order   (DynamicPointsMapperModule.cpp:34-172; updates the scalar)
  *   ICPMI_MOP_VOXEL            f[0] = maxSizeByNode, i = samplingMethod 0 | 1 (OctreeMapperModule.cpp:35-39: concatenate, then decimate)
+ *   ICPMI_MOP_OCTREE           f[0] = maxSizeByNode, f[1] = maxPointByNode (0 = 1), i = samplingMethod 0 | 1: the octree itself
+ *                              (OctreeMapperModule.cpp:8-12,35-39 -> OctreeGridDataPointsFilter: bounding-cube root, split until the
+ *                              edge is <= maxSizeByNode or the node holds <= maxPointByNode points, one point per leaf, the map left
+ *                              in leaf-visiting order); ICPMI_MOP_VOXEL is the fixed-lattice decimation kept for callers that want it
  *   ICPMI_MOP_SURFACE_NORMALS  i = knn                                  (post filter, examples/config.yaml:26-27)
  *   ICPMI_MOP_CUT_SCALAR       f[0] = threshold, i = useLargerThan      (CutAtDescriptorThresholdDataPointsFilter, config.yaml:29-32)
  * The first n_modules entries are mapper modules: on a handle without a map the first one creates the map from the scan
@@ -291,7 +304,8 @@ icpmi_status icpmi_voxel_keep(icpmi_handle h, const float* in4, int64_t n, float
  * from that position on only -- a host that owns further descriptors leaves those rows alone and gathers the rest, and
  * an append-only chain downloads a few kilobytes instead of the whole vector. */
 typedef enum {
-    ICPMI_MOP_POINT_DISTANCE = 0, ICPMI_MOP_DYNAMIC_POINTS = 1, ICPMI_MOP_VOXEL = 2, ICPMI_MOP_SURFACE_NORMALS = 3, ICPMI_MOP_CUT_SCALAR = 4
+    ICPMI_MOP_POINT_DISTANCE = 0, ICPMI_MOP_DYNAMIC_POINTS = 1, ICPMI_MOP_VOXEL = 2, ICPMI_MOP_SURFACE_NORMALS = 3, ICPMI_MOP_CUT_SCALAR = 4,
+    ICPMI_MOP_OCTREE = 5
 } icpmi_map_op_type;
 typedef struct icpmi_map_op { int32_t type; int32_t i; float f[7]; } icpmi_map_op;
 icpmi_status icpmi_map_update_chain(icpmi_handle h, const float* scan4, int64_t n, const float* scan_normals3, const float* scan_scalar,

@@ -73,7 +73,7 @@ class PointFilter(C.Structure):
     _fields_ = [("type", C.c_int32), ("i", C.c_int32), ("f", C.c_float * 6)]
 
 
-MOP_POINT_DISTANCE, MOP_DYNAMIC_POINTS, MOP_VOXEL, MOP_SURFACE_NORMALS, MOP_CUT_SCALAR = range(5)
+MOP_POINT_DISTANCE, MOP_DYNAMIC_POINTS, MOP_VOXEL, MOP_SURFACE_NORMALS, MOP_CUT_SCALAR, MOP_OCTREE = range(6)
 
 
 # every symbol include/icpmi.h declares: (name, restype, argtypes)
@@ -103,6 +103,7 @@ SYMBOLS = [
     ("icpmi_voxel_keep_first", C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),
     ("icpmi_filter_points", C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, _P]),
     ("icpmi_voxel_keep", C.c_int, [_P, _P, C.c_int64, C.c_float, C.c_int32, _P]),
+    ("icpmi_octree_sample", C.c_int, [_P, _P, C.c_int64, C.c_float, C.c_int32, C.c_int32, _P, _P, _P]),
     ("icpmi_map_update_chain", C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, C.c_int64, _P, _P]),
     ("icpmi_map_update_chain_staged", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, C.c_int64, _P, _P]),
     ("icpmi_set_map_scalar", C.c_int, [_P, _P, C.c_int64]),

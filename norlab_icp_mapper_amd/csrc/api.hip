@@ -495,6 +495,14 @@ icpmi_status icpmi_voxel_keep(icpmi_handle h, const float* in4, int64_t n, float
     return ops_voxel_keep_first(h, in4, n, edge, method, keep);
 }
 
+icpmi_status icpmi_octree_sample(icpmi_handle h, const float* in4, int64_t n, float max_size, int32_t max_points, int32_t method,
+                                 int32_t* order_out, int32_t* leaf_of_out, int64_t* n_out)
+{
+    CHECK_H(h);
+    if (n < 0 || (n > 0 && !in4) || !(max_size >= 0.f) || max_points < 0 || (method != 0 && method != 1)) { h->last_error = "octree_sample: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
+    return ops_octree_sample(h, in4, n, max_size, max_points, method, order_out, leaf_of_out, n_out);
+}
+
 icpmi_status icpmi_voxel_keep_first(icpmi_handle h, const float* in4, int64_t n, float edge, uint8_t* keep)
 {
     return icpmi_voxel_keep(h, in4, n, edge, 0, keep);

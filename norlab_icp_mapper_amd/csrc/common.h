@@ -374,3 +374,7 @@ icpmi_status ops_voxel_keep_first(icpmi_ctx* c, const float* in4, int64_t n, flo
 icpmi_status ops_point_distance_keep(icpmi_ctx* c, const float* map4, int64_t m, const float* in4, int64_t n,
                                      float min_dist, uint8_t* keep);
 icpmi_status ops_bin_cells(icpmi_ctx* c, const float* pts4, int64_t n, float cell_size, int32_t* ijk3);
+icpmi_status octree_sample_dev(icpmi_ctx* c, const float4* d_in, int64_t n, float max_size, int max_pts, int method, int* d_order, int* d_leaf_of,
+                               int64_t* n_out);
+icpmi_status ops_octree_sample(icpmi_ctx* c, const float* in4, int64_t n, float max_size, int max_pts, int method, int32_t* order_out,
+                               int32_t* leaf_of_out, int64_t* n_out);

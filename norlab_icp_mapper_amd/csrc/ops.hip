@@ -976,6 +976,40 @@ icpmi_status chain_compact(Chain& w, unsigned* d_flag, unsigned* d_pos)
     return ICPMI_OK;
 }
 
+// the working map re-ordered / decimated by an index list: new point j = old point order[j] (OctreeGridDataPointsFilter
+// leaves the cloud in leaf-visiting order)
+__global__ __launch_bounds__(256) void chain_gather_kernel(int64_t count, const int* __restrict__ order, const float4* __restrict__ raw,
+                                                           const float* __restrict__ n3, const float* __restrict__ sc, const int* __restrict__ src,
+                                                           float4* __restrict__ o_raw, float* __restrict__ o_n3, float* __restrict__ o_sc,
+                                                           int* __restrict__ o_src)
+{
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= count) return;
+    const int64_t i = order[o];
+    o_raw[o] = raw[i];
+    o_n3[3 * o] = n3[3 * i]; o_n3[3 * o + 1] = n3[3 * i + 1]; o_n3[3 * o + 2] = n3[3 * i + 2];
+    o_sc[o] = sc[i];
+    o_src[o] = src[i];
+}
+
+icpmi_status chain_gather(Chain& w, const int* d_order, int64_t count)
+{
+    icpmi_ctx* c = w.c;
+    if (ensure_cap(c, &c->d_alt_raw, &c->cap_alt_raw, (size_t)count + 1) != ICPMI_OK || ensure_cap(c, &c->d_alt_n3, &c->cap_alt_n3, (size_t)count * 3 + 1) != ICPMI_OK ||
+        ensure_cap(c, &c->d_alt_s, &c->cap_alt_s, (size_t)count + 1) != ICPMI_OK || ensure_cap(c, &c->d_alt_src, &c->cap_alt_src, (size_t)count + 1) != ICPMI_OK)
+        return ICPMI_ERR_HIP;
+    if (count) hipLaunchKernelGGL(chain_gather_kernel, dim3((int)((count + 255) / 256)), dim3(256), 0, c->stream, count, d_order, c->d_raw, c->d_raw_n3,
+                                  c->d_raw_s, c->d_src, c->d_alt_raw, c->d_alt_n3, c->d_alt_s, c->d_alt_src);
+    HIP_TRY(c, hipGetLastError());
+    std::swap(c->d_raw, c->d_alt_raw); std::swap(c->cap_raw, c->cap_alt_raw);
+    std::swap(c->d_raw_n3, c->d_alt_n3); std::swap(c->cap_raw_n3, c->cap_alt_n3);
+    std::swap(c->d_raw_s, c->d_alt_s); std::swap(c->cap_raw_s, c->cap_alt_s);
+    std::swap(c->d_src, c->d_alt_src); std::swap(c->cap_src, c->cap_alt_src);
+    w.m = count;
+    w.indexed = false;
+    return ICPMI_OK;
+}
+
 // PointDistanceMapperModule.cpp:33-42 on an indexing handle `ic` (the caller's own handle while its index still
 // describes the working map, the private one otherwise): flag[i] = exact NN of scan i at d2 >= minDist^2
 icpmi_status chain_point_distance_flags(icpmi_ctx* c, icpmi_ctx* ic, const float4* d_scan, int64_t n, float min_dist, unsigned* d_flag)
@@ -1030,6 +1064,11 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
         case ICPMI_MOP_VOXEL: if (!(op.f[0] > 0.f) || (op.i != 0 && op.i != 1)) { c->last_error = "map_update_chain: voxel edge must be > 0 and samplingMethod 0 or 1"; return ICPMI_ERR_INVALID_ARG; } break;
         case ICPMI_MOP_SURFACE_NORMALS: if (op.i < 1 || op.i > ICPMI_MAX_K) { c->last_error = "surface_normals: knn must be in [1, 32]"; return ICPMI_ERR_INVALID_ARG; } break;
         case ICPMI_MOP_CUT_SCALAR: uses_scalar = true; break;
+        case ICPMI_MOP_OCTREE:
+            if (!(op.f[0] >= 0.f) || (op.i != 0 && op.i != 1) || !(op.f[1] >= 0.f) || op.f[1] > 64.f) {
+                c->last_error = "map_update_chain: octree needs maxSizeByNode >= 0, samplingMethod 0 or 1, maxPointByNode <= 64"; return ICPMI_ERR_INVALID_ARG;
+            }
+            break;
         default: c->last_error = "map_update_chain: unknown operator"; return ICPMI_ERR_INVALID_ARG;
         }
         if (i >= n_modules && op.type != ICPMI_MOP_SURFACE_NORMALS && op.type != ICPMI_MOP_CUT_SCALAR) { c->last_error = "map_update_chain: a mapper module after the post filters"; return ICPMI_ERR_INVALID_ARG; }
@@ -1121,6 +1160,16 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
             if (s != ICPMI_OK || w.m == 0) break;
             s = voxel_flags_dev<unsigned>(c, c->d_raw, w.m, op.f[0], op.i, d_flag);
             if (s == ICPMI_OK) s = chain_compact(w, d_flag, d_pos);
+            break;
+        }
+        case ICPMI_MOP_OCTREE: {
+            // OctreeMapperModule.cpp:35-39: concatenate, then the octree filter; the cloud comes out in leaf-visiting order
+            s = chain_append(w, d_scan, d_scan_n3, d_scan_s, n, nullptr, nullptr, n, src_base);
+            if (!created) w.has_n = d_scan_n3 != nullptr;
+            if (s != ICPMI_OK || w.m == 0) break;
+            int64_t kept = 0;
+            s = octree_sample_dev(c, c->d_raw, w.m, op.f[0], (int)op.f[1], op.i, (int*)d_pos, nullptr, &kept);
+            if (s == ICPMI_OK) s = chain_gather(w, (const int*)d_pos, kept);
             break;
         }
         case ICPMI_MOP_SURFACE_NORMALS: {

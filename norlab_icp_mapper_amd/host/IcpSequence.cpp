@@ -401,66 +401,76 @@ struct RandomSamplingFilter : DataPointsFilter {
     }
 };
 
-// OctreeGridDataPointsFilter stand-in: one point per occupied voxel of edge maxSizeByNode on a
-// lattice anchored at the cloud's bounding-box corner.  Upstream builds an octree over the bounding
-// CUBE, so its leaves are not lattice aligned; the two agree statistically, not point for point
-// (SURVEY.md B.9).  samplingMethod: 0 first point, 1 random point, 2 centroid, 3 medoid.
-struct VoxelGridFilter : DataPointsFilter {
-    float maxSize = 0.f; int method = 0; size_t maxPointByNode = 1;
+// OctreeGridDataPointsFilter (created at OctreeMapperModule.cpp:12, applied at :38): octree over the bounding
+// cube of the cloud, split until the node edge is <= maxSizeByNode or the node holds <= maxPointByNode points, one point per
+// leaf, the cloud left in leaf-visiting order.  The tree lives on the device (icpmi_octree_sample / ICPMI_MOP_OCTREE):
+// samplingMethod 0 (first point of the leaf) and 1 (random point, made reproducible) pick there; 2 (centroid: features and
+// descriptors averaged over the leaf) and 3 (medoid: the point with the smallest summed distance to the others of its leaf)
+// are formed here from the device's leaf assignment.
+struct OctreeGridFilter : DataPointsFilter {
+    float maxSize = 0.f; int method = 0; int maxPointByNode = 1;
     icpmi_handle h = nullptr;
     bool residentOp(icpmi_map_op& op, std::string&) const override {
-        op = icpmi_map_op{}; op.type = ICPMI_MOP_VOXEL; op.i = method; op.f[0] = maxSize;
-        return (method == 0 || method == 1) && maxSize > 0.f;
+        op = icpmi_map_op{}; op.type = ICPMI_MOP_OCTREE; op.i = method; op.f[0] = maxSize; op.f[1] = (float)maxPointByNode;
+        return (method == 0 || method == 1) && maxSize >= 0.f && maxPointByNode <= 64;
+    }
+    static DataPoints gather(const DataPoints& c, const std::vector<int32_t>& order) {
+        DataPoints out = c.createSimilarEmpty(order.size());
+        out.features.resize(4 * order.size());
+        for (auto& d : out.descriptors) d.data.resize((size_t)d.span * order.size());
+        for (size_t j = 0; j < order.size(); ++j) {
+            const size_t i = (size_t)order[j];
+            std::copy(c.col(i), c.col(i) + 4, out.features.begin() + 4 * j);
+            for (size_t k = 0; k < c.descriptors.size(); ++k) {
+                const Descriptor& s = c.descriptors[k];
+                std::copy(s.data.begin() + (size_t)s.span * i, s.data.begin() + (size_t)s.span * (i + 1), out.descriptors[k].data.begin() + (size_t)s.span * j);
+            }
+        }
+        return out;
     }
     void inPlaceFilter(DataPoints& c) const override {
         const size_t n = c.getNbPoints();
-        if (n == 0 || !(maxSize > 0.f)) return;
-        if ((method == 0 || method == 1) && h) { // first / pseudo-random point per voxel: one hash pass on the GPU (same lattice as below)
-            std::vector<uint8_t> keep(n, 0);
-            GpuICPSequence::check(h, icpmi_voxel_keep(h, c.features.data(), (int64_t)n, maxSize, method, keep.data()));
-            c.keepOnly(keep);
+        if (n == 0) return;
+        if (!h) throw std::logic_error("OctreeGridDataPointsFilter needs a GPU context");
+        std::vector<int32_t> order(n), leaf;
+        if (method >= 2) leaf.resize(n);
+        int64_t m = 0;
+        GpuICPSequence::check(h, icpmi_octree_sample(h, c.features.data(), (int64_t)n, maxSize, maxPointByNode, method == 1 ? 1 : 0, order.data(),
+                                                     method >= 2 ? leaf.data() : nullptr, &m));
+        order.resize((size_t)m);
+        if (method <= 1) { c = gather(c, order); return; }
+        // members of every leaf, in list order
+        std::vector<std::vector<int32_t>> members((size_t)m);
+        for (size_t i = 0; i < n; ++i) members[(size_t)leaf[i]].push_back((int32_t)i);
+        if (method == 3) { // medoid
+            for (size_t l = 0; l < (size_t)m; ++l) {
+                const auto& mem = members[l];
+                double best = INFINITY; int32_t pick = mem[0];
+                for (int32_t a : mem) {
+                    double sum = 0;
+                    for (int32_t b : mem) {
+                        double d2 = 0;
+                        for (int r = 0; r < 3; ++r) { const double e = (double)c.col((size_t)a)[r] - c.col((size_t)b)[r]; d2 += e * e; }
+                        sum += std::sqrt(d2);
+                    }
+                    if (sum < best) { best = sum; pick = a; }
+                }
+                order[l] = pick;
+            }
+            c = gather(c, order);
             return;
         }
-        float lo[3] = {c.col(0)[0], c.col(0)[1], c.col(0)[2]};
-        for (size_t i = 1; i < n; ++i) for (int r = 0; r < 3; ++r) lo[r] = std::min(lo[r], c.col(i)[r]);
-        struct Cell { size_t first; size_t count; double sum[3]; size_t pick; };
-        std::unordered_map<uint64_t, Cell> cells;
-        cells.reserve(n);
-        std::vector<uint64_t> keyOf(n);
-        auto fmix32 = [](uint32_t v) { v ^= v >> 16; v *= 0x85ebca6bu; v ^= v >> 13; v *= 0xc2b2ae35u; v ^= v >> 16; return v; };
-        for (size_t i = 0; i < n; ++i) {
-            const float* p = c.col(i);
-            uint64_t key = 0;
-            for (int r = 0; r < 3; ++r) key = key * 2097152ull + (uint64_t)std::min<double>(2097151.0, std::floor((p[r] - lo[r]) / maxSize));
-            keyOf[i] = key;
-            auto it = cells.find(key);
-            if (it == cells.end()) cells.emplace(key, Cell{i, 1, {p[0], p[1], p[2]}, i});
-            else {
-                Cell& cl = it->second;
-                ++cl.count;
-                for (int r = 0; r < 3; ++r) cl.sum[r] += p[r];
-                // samplingMethod 1 (a random point of the voxel), reproducible: the index with the smallest hash
-                if (method == 1 && fmix32((uint32_t)i) < fmix32((uint32_t)cl.pick)) cl.pick = i;
+        DataPoints out = gather(c, order); // centroid: the representative's slot receives the leaf's averages
+        for (size_t l = 0; l < (size_t)m; ++l) {
+            const auto& mem = members[l];
+            const double inv = 1.0 / (double)mem.size();
+            for (int r = 0; r < 3; ++r) { double s2 = 0; for (int32_t i : mem) s2 += c.col((size_t)i)[r]; out.col(l)[r] = (float)(s2 * inv); }
+            for (size_t k = 0; k < c.descriptors.size(); ++k) {
+                const Descriptor& d = c.descriptors[k];
+                for (int r = 0; r < d.span; ++r) { double s2 = 0; for (int32_t i : mem) s2 += d.data[(size_t)d.span * i + r]; out.descriptors[k].data[(size_t)d.span * l + r] = (float)(s2 * inv); }
             }
         }
-        if (method == 3) { // medoid: the point closest to the centroid
-            std::unordered_map<uint64_t, double> bestd;
-            for (size_t i = 0; i < n; ++i) {
-                Cell& cl = cells[keyOf[i]];
-                double d = 0;
-                for (int r = 0; r < 3; ++r) { const double e = c.col(i)[r] - cl.sum[r] / cl.count; d += e * e; }
-                auto it = bestd.find(keyOf[i]);
-                if (it == bestd.end() || d < it->second) { bestd[keyOf[i]] = d; cl.pick = i; }
-            }
-        }
-        std::vector<uint8_t> keep(n, 0);
-        for (auto& kv : cells) {
-            Cell& cl = kv.second;
-            const size_t rep = (method == 0 || method == 2) ? cl.first : cl.pick;
-            keep[rep] = 1;
-            if (method == 2) for (int r = 0; r < 3; ++r) c.col(rep)[r] = (float)(cl.sum[r] / cl.count);
-        }
-        c.keepOnly(keep);
+        c = std::move(out);
     }
 };
 
@@ -522,9 +532,10 @@ std::shared_ptr<DataPointsFilter> createDataPointsFilter(const std::string& name
     }
     if (name == "OctreeGridDataPointsFilter") {
         requireKnown(p, {"buildParallel", "maxPointByNode", "maxSizeByNode", "samplingMethod"}, name);
-        auto f = std::make_shared<VoxelGridFilter>();
+        auto f = std::make_shared<OctreeGridFilter>();
         f->maxSize = getf(p, "maxSizeByNode", 0.f); f->method = geti(p, "samplingMethod", 0);
-        f->maxPointByNode = (size_t)geti(p, "maxPointByNode", 1);
+        f->maxPointByNode = geti(p, "maxPointByNode", 1);
+        if (f->maxSize < 0.f || f->maxPointByNode < 1 || f->method < 0 || f->method > 3) throw InvalidParameter(name + ": parameter out of range");
         f->h = ctx;
         return f;
     }

@@ -376,6 +376,16 @@ class ICPSequence:
         self._check(self._lib.icpmi_filter_points(self._h, c.ctypes.data, c.shape[0], arr, len(filters), keep.ctypes.data))
         return keep.astype(bool)
 
+    def octreeSample(self, cloud, max_size, max_points=1, method=0, with_leaves=False):
+        """OctreeGridDataPointsFilter: indices of the kept points in leaf-visiting order (+ the leaf ordinal of every point)"""
+        c = _f32c(cloud, 4)
+        order = np.empty(c.shape[0], dtype=np.int32)
+        leaf = np.empty(c.shape[0], dtype=np.int32) if with_leaves else None
+        m = C.c_int64(0)
+        self._check(self._lib.icpmi_octree_sample(self._h, c.ctypes.data, c.shape[0], max_size, max_points, method, order.ctypes.data,
+                                                  None if leaf is None else leaf.ctypes.data, C.byref(m)))
+        return (order[:m.value].copy(), leaf) if with_leaves else order[:m.value].copy()
+
     def voxelKeep(self, cloud, edge, method=0):
         """Same lattice, representative by `samplingMethod`: 0 first point, 1 pseudo-random point (smallest fmix32 of the index)."""
         c = _f32c(cloud, 4)
@@ -400,6 +410,9 @@ class ICPSequence:
                     op.f[r] = args[r]
             elif name == "voxel":
                 op.type = _capi.MOP_VOXEL; op.f[0] = args[0]; op.i = int(args[1]) if len(args) > 1 else 0
+            elif name == "octree":      # (maxSizeByNode, samplingMethod = 0, maxPointByNode = 1)
+                op.type = _capi.MOP_OCTREE; op.f[0] = args[0]; op.i = int(args[1]) if len(args) > 1 else 0
+                op.f[1] = float(args[2]) if len(args) > 2 else 1.0
             elif name == "surface_normals":
                 op.type = _capi.MOP_SURFACE_NORMALS; op.i = int(args[0])
             elif name == "cut_scalar":

@@ -968,6 +968,69 @@ void orc_voxel_keep(const float* in4, int64_t n, float edge, int method, uint8_t
 }
 void orc_voxel_keep_first(const float* in4, int64_t n, float edge, uint8_t* keep) { orc_voxel_keep(in4, n, edge, 0, keep); }
 
+/* ------------------------------------------------------------------------------------------------
+ * OctreeGridDataPointsFilter behind OctreeMapperModule (OctreeMapperModule.cpp:8-12,35-39) -- the octree
+ * itself, restated RECURSIVELY like upstream's Octree_<T,3>::build (libpointmatcher 1.4.x octree.hpp, as recalled):
+ *   root    = the bounding CUBE of the cloud: centre = (min + max) / 2 per axis, radius = max over the axes of (max - centre);
+ *   build   : a node is a leaf iff 2 * radius <= maxSizeByNode or it holds <= maxPointByNode points (or depth 21 is reached:
+ *             the device side packs the path into 63 bits); otherwise its points go to 8 children, child index bit r set iff
+ *             p_r > centre_r, child centre = centre +- radius / 2 (float adds), child radius = radius / 2; every child list
+ *             keeps the order of the parent's list (so "first" is the smallest original index);
+ *   sample  : leaves are visited depth first, children in index order 0..7; every non-empty leaf yields ONE point:
+ *             samplingMethod 0 the first of its list, 1 a random one -- made reproducible: the smallest fmix32(original index);
+ *   output  : the representatives in visiting order (upstream compacts the cloud in that order: the map comes out
+ *             Morton-ordered, which decides who is "first" the next time two old points share a leaf).
+ * order_out receives the original indices of the output points; returns their number.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { const float* p; float max_size; int64_t max_pts; int method; int32_t* out; int64_t n_out; } orc_oct_ctx;
+static void orc_oct_build(orc_oct_ctx* c, int32_t* idx, int64_t cnt, float cx, float cy, float cz, float radius, int depth)
+{
+    if (cnt == 0) return;
+    if (radius * 2.f <= c->max_size || cnt <= c->max_pts || depth >= 21) {
+        int32_t rep = idx[0];
+        if (c->method == 1)
+            for (int64_t i = 1; i < cnt; ++i) if (orc_fmix32((uint32_t)idx[i]) < orc_fmix32((uint32_t)rep)) rep = idx[i];
+        c->out[c->n_out++] = rep;
+        return;
+    }
+    int64_t n8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint8_t* oct = (uint8_t*)malloc((size_t)cnt);
+    for (int64_t i = 0; i < cnt; ++i) {
+        const float* q = c->p + 4 * (int64_t)idx[i];
+        const int o = (q[0] > cx ? 1 : 0) | (q[1] > cy ? 2 : 0) | (q[2] > cz ? 4 : 0);
+        oct[i] = (uint8_t)o; ++n8[o];
+    }
+    int32_t* buf = (int32_t*)malloc((size_t)cnt * sizeof(int32_t));
+    int64_t start[8], fill[8], acc = 0;
+    for (int o = 0; o < 8; ++o) { start[o] = fill[o] = acc; acc += n8[o]; }
+    for (int64_t i = 0; i < cnt; ++i) buf[fill[oct[i]]++] = idx[i]; /* stable: parent order kept */
+    free(oct);
+    const float half = radius * 0.5f;
+    for (int o = 0; o < 8; ++o)
+        orc_oct_build(c, buf + start[o], n8[o], cx + ((o & 1) ? half : -half), cy + ((o & 2) ? half : -half), cz + ((o & 4) ? half : -half),
+                      half, depth + 1);
+    free(buf);
+}
+int64_t orc_octree_sample(const float* in4, int64_t n, float max_size, int64_t max_pts, int method, int32_t* order_out)
+{
+    if (n <= 0) return 0;
+    float lo[3] = {in4[0], in4[1], in4[2]}, hi[3] = {in4[0], in4[1], in4[2]};
+    for (int64_t i = 1; i < n; ++i)
+        for (int r = 0; r < 3; ++r) {
+            const float v = in4[4 * i + r];
+            if (v < lo[r]) lo[r] = v;
+            if (v > hi[r]) hi[r] = v;
+        }
+    float c[3], radius = 0.f;
+    for (int r = 0; r < 3; ++r) { c[r] = (lo[r] + hi[r]) / 2.f; const float rr = hi[r] - c[r]; if (rr > radius) radius = rr; }
+    int32_t* idx = (int32_t*)malloc((size_t)n * sizeof(int32_t));
+    for (int64_t i = 0; i < n; ++i) idx[i] = (int32_t)i;
+    orc_oct_ctx ctx = {in4, max_size, max_pts < 1 ? 1 : max_pts, method, order_out, 0};
+    orc_oct_build(&ctx, idx, n, c[0], c[1], c[2], radius, 0);
+    free(idx);
+    return ctx.n_out;
+}
+
 /* DynamicPointsMapperModule::inPlaceUpdateMap (DynamicPointsMapperModule.cpp:34-172), brute-force angular
  * nearest beam (the reference: 2-D kd-tree, k = 1, radius 2 * beamHalfAngle, :75-78).  Ties on equal angular
  * distance go to the smallest beam index; asin / atan2 through double, rounded once (shared with the device). */

@@ -153,6 +153,9 @@ void orc_cell_ids(const float* pts4, int64_t n, float cell_size, int32_t* ijk3);
 void orc_voxel_keep_first(const float* in4, int64_t n, float edge, uint8_t* keep);
 void orc_filter_points(const float* in4, int64_t n, const float* filters, int n_filters, uint8_t* keep);
 void orc_voxel_keep(const float* in4, int64_t n, float edge, int method, uint8_t* keep);
+/* OctreeGridDataPointsFilter{maxSizeByNode, maxPointByNode, samplingMethod 0 | 1}: the real octree (bounding cube, recursive
+ * split); order_out (capacity n) = original indices of the kept points in leaf-visiting (Morton) order; returns their number */
+int64_t orc_octree_sample(const float* in4, int64_t n, float max_size, int64_t max_pts, int method, int32_t* order_out);
 /* DynamicPointsMapperModule::inPlaceUpdateMap (DynamicPointsMapperModule.cpp:34-172).  prm = {thresholdDynamic, alpha,
  * beta, beamHalfAngle, epsilonA, epsilonD, sensorMaxRange}; to_sensor = pose^-1 (col-major); prob updated in place. */
 void orc_dynamic_points_update(const float prm[7], const float* to_sensor, const float* in4, int64_t n, const float* map4,

@@ -39,7 +39,7 @@ for i in range(14):
         corr = icp(inp); Tg = om.mat4_mul_f32(corr, prior)
     moved = icp.transform(corr, inp)
     to_sensor = np.linalg.inv(Tg.astype(np.float64)).astype(np.float32)
-    icp.mapUpdateChain(moved, [("dynamic_points",) + dyn7, ("voxel", 0.15, 0)], [("surface_normals", 10), ("cut_scalar", 0.65, 1)],
+    icp.mapUpdateChain(moved, [("dynamic_points",) + dyn7, ("octree", 0.15, 0, 1)], [("surface_normals", 10), ("cut_scalar", 0.65, 1)],
                        scan_scalar=np.full(moved.shape[0], 0.6, np.float32), to_sensor=to_sensor, from_sensor=Tg, want_src=False)
     gm = icp.getMap()
     def setdiff(a, b):

@@ -73,6 +73,8 @@ def load():
     lib.orc_voxel_keep_first.argtypes = [_P, C.c_int64, C.c_float, _P]
     lib.orc_filter_points.argtypes = [_P, C.c_int64, _P, C.c_int, _P]
     lib.orc_voxel_keep.argtypes = [_P, C.c_int64, C.c_float, C.c_int, _P]
+    lib.orc_octree_sample.restype = C.c_int64
+    lib.orc_octree_sample.argtypes = [_P, C.c_int64, C.c_float, C.c_int64, C.c_int, _P]
     lib.orc_dynamic_points_update.argtypes = [_P, _P, _P, C.c_int64, _P, _P, C.c_int64, _P, C.c_int]
     _lib = lib
     return lib
@@ -238,6 +240,13 @@ def voxel_keep(cloud, edge, method):
     lib = load(); c = _f32(cloud); keep = np.zeros(c.shape[0], dtype=np.uint8)
     lib.orc_voxel_keep(c.ctypes.data, c.shape[0], edge, method, keep.ctypes.data)
     return keep.astype(bool)
+
+
+def octree_sample(cloud, max_size, max_pts=1, method=0):
+    """OctreeGridDataPointsFilter: original indices of the kept points, in leaf-visiting order"""
+    lib = load(); c = _f32(cloud); order = np.empty(c.shape[0], dtype=np.int32)
+    m = lib.orc_octree_sample(c.ctypes.data, c.shape[0], max_size, max_pts, method, order.ctypes.data)
+    return order[:m].copy()
 
 
 DYNPTS_DEFAULTS = dict(threshold_dynamic=0.6, alpha=0.8, beta=0.99, beam_half_angle=0.01, epsilon_a=0.01, epsilon_d=0.01,

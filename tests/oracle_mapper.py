@@ -31,6 +31,11 @@ def keep_only(cloud, mask):
     return {k: np.ascontiguousarray(v[mask]) for k, v in cloud.items()}
 
 
+def gather(cloud, order):
+    """the cloud re-ordered / decimated by an index list (OctreeGridDataPointsFilter leaves it in leaf-visiting order)"""
+    return {k: np.ascontiguousarray(v[order]) for k, v in cloud.items()}
+
+
 def concatenate(a, b):
     """PM::DataPoints::concatenate: features stacked, descriptors present in both kept."""
     out = {"xyz1": np.concatenate([a["xyz1"], b["xyz1"]], 0)}
@@ -67,12 +72,10 @@ def mat4_mul_f32(A, B):
 
 class OracleMapper:
     def __init__(self, icp_kw, modules, post=(), update=("distance", 1.0), sensor_max_range=80.0, input_filters=(),
-                 add_descriptors=(), nthreads=8, octree=None, post_in_map_frame=False):
-        """modules: [("point_distance", minDist) | ("dynamic_points", {params}) | ("octree", maxSize, samplingMethod)]
+                 add_descriptors=(), nthreads=8, post_in_map_frame=False):
+        """modules: [("point_distance", minDist) | ("dynamic_points", {params}) | ("octree", maxSize, samplingMethod[, maxPointByNode])]
         post: [("surface_normals", knn) | ("cut", descName, useLargerThan, threshold)]
-        input_filters: oracle_bindings.filter_points rows; add_descriptors: [(name, value)] (AddDescriptorDataPointsFilter)
-        octree: callable(xyz1, maxSize, method) -> bool mask (the decimation operator under test: the voxel stand-in or
-        the octree restatement); default = the oracle's voxel operator."""
+        input_filters: oracle_bindings.filter_points rows; add_descriptors: [(name, value)] (AddDescriptorDataPointsFilter)"""
         self.icp = ob.OracleICP(ob.make_config(nthreads=nthreads, **icp_kw))
         self.modules, self.post, self.update = list(modules), list(post), update
         self.sensor_max_range, self.input_filters, self.add_descriptors = sensor_max_range, list(input_filters), list(add_descriptors)
@@ -80,7 +83,6 @@ class OracleMapper:
         # True: the post filters see the cloud in the map frame (what the resident device path does: no rotation of the whole
         # map into the sensor frame and back on every update); False: the reference's Map.cpp:523-525
         self.post_in_map_frame = post_in_map_frame
-        self.octree = octree or (lambda xyz1, size, method: ob.voxel_keep(xyz1, size, method))
         self.map = None
         self.pose = np.eye(4, dtype=np.float32)
         self.trajectory, self.iterations, self.updated = [], [], []
@@ -105,7 +107,7 @@ class OracleMapper:
             return concatenate(mp, keep_only(inp, keep))
         if kind == "octree":                               # OctreeMapperModule.cpp:35-39: concatenate, then decimate
             both = concatenate(mp, inp)
-            return keep_only(both, self.octree(both["xyz1"], mod[1], mod[2]))
+            return gather(both, ob.octree_sample(both["xyz1"], mod[1], mod[3] if len(mod) > 3 else 1, mod[2]))
         if kind == "dynamic_points":                       # DynamicPointsMapperModule.cpp:34-151
             to_sensor = np.linalg.inv(pose.astype(np.float64)).astype(np.float32)
             out = dict(mp)
@@ -118,7 +120,7 @@ class OracleMapper:
         if mod[0] in ("point_distance", "dynamic_points"):  # createMap keeps the input untouched (.cpp:8-21 / :14-27)
             return dict(inp)
         if mod[0] == "octree":                              # OctreeMapperModule.cpp:15-27: update of an empty map
-            return keep_only(inp, self.octree(inp["xyz1"], mod[1], mod[2]))
+            return gather(inp, ob.octree_sample(inp["xyz1"], mod[1], mod[3] if len(mod) > 3 else 1, mod[2]))
         raise ValueError(mod[0])
 
     def update_local_point_cloud(self, inp, pose):
