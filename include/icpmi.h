@@ -196,6 +196,9 @@ icpmi_status icpmi_minimize_step(icpmi_handle h, const float* reading4, int64_t 
 
 /* `SurfaceNormalDataPointsFilter{knn}` (Map.cpp:524 via examples/config.yaml:26-27). */
 icpmi_status icpmi_surface_normals(icpmi_handle h, const float* pts4, int64_t m, int32_t knn, float* normals3);
+/* ... with `keepDensities: 1`: densities (m floats, may be NULL) = knn / (4/3 pi r^3), r = the largest distance of a neighbour
+ * from the centroid of the neighbourhood (the descriptor MaxDensityDataPointsFilter reads). */
+icpmi_status icpmi_surface_normals_ex(icpmi_handle h, const float* pts4, int64_t m, int32_t knn, float* normals3, float* densities);
 
 /* `PointDistanceMapperModule::inPlaceUpdateMap` keep mask (PointDistanceMapperModule.cpp:28-50):
  * keep[i] = 1 iff the exact NN of input i in map (self match excluded) has d2 >= min_dist^2. */

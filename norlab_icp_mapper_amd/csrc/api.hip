@@ -429,6 +429,13 @@ icpmi_status icpmi_surface_normals(icpmi_handle h, const float* pts4, int64_t m,
     return ops_surface_normals(h, pts4, m, knn, normals3);
 }
 
+icpmi_status icpmi_surface_normals_ex(icpmi_handle h, const float* pts4, int64_t m, int32_t knn, float* normals3, float* densities)
+{
+    CHECK_H(h);
+    if (m < 0 || (m > 0 && (!pts4 || !normals3))) { h->last_error = "surface_normals: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
+    return ops_surface_normals(h, pts4, m, knn, normals3, densities);
+}
+
 icpmi_status icpmi_point_distance_keep(icpmi_handle h, const float* map4, int64_t m, const float* in4, int64_t n, float min_dist,
                                        uint8_t* keep)
 {

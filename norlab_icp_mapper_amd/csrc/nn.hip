@@ -1209,8 +1209,19 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
         // faster 16 lanes wide (r1: 80 us with 8 lanes, measured below)
         const bool narrow = seeded && c->nn_iter_hint > wide_until;
         const int seed_pre = seed_pre_cfg == 2 ? (narrow ? 0 : 1) : seed_pre_cfg; // 2: only on the wide launch after the first solve
-        if (narrow && g_seeded == 4) LAUNCH_ML(4, 4);
+        // One registration is latency-bound and runs best 8 lanes wide; a launch with several hundred thousand queries (a
+        // batch, a very large reading) is throughput-bound, where the work every lane of a group repeats (cell coordinates,
+        // pruning radius, row bounds) is what counts: 4 lanes per query (r2, batch of 8 x 100 k: +10 % point-to-point,
+        // +20 % point-to-plane; a single 100 k reading: -10 % / +4 %).  ICPMI_NN_G forces a width, ICPMI_NN_G4_FROM the switch.
+        static long long g4_from = -1;
+        if (g4_from < 0) { const char* e = getenv("ICPMI_NN_G4_FROM"); g4_from = e ? atoll(e) : 300000; }
+        long long total_q = 0;
+        for (int b = 0; b < ba.nscan; ++b) total_q += ba.n[b];
+        const int g_narrow = getenv("ICPMI_NN_G") ? g_seeded : (total_q >= g4_from ? 4 : 8);
+        if (narrow && g_narrow == 2) LAUNCH_ML(2, 4);
+        else if (narrow && g_narrow == 4) LAUNCH_ML(4, 4);
         else if (narrow) LAUNCH_ML(8, 4);
+        else if (total_q >= g4_from && !getenv("ICPMI_NN_WIDE16")) LAUNCH_ML(8, 4); // the wide first launches, likewise one step narrower
         else LAUNCH_ML(16, 4);
 #undef LAUNCH_ML
         const GridParams& top = c->levels.g[c->levels.nlev - 1];

@@ -55,8 +55,10 @@ __global__ __launch_bounds__(256) void keep_kernel(const float* __restrict__ d2,
 }
 
 // one lane per point: mean + covariance of the kNN set in double, smallest eigenvector by Jacobi
+// densities (may be null): `keepDensities` of the filter -- points per volume of the sphere that holds the neighbourhood around
+// its centroid: k / (4/3 pi r^3), r = the largest distance of a neighbour from the centroid (computeDensity)
 __global__ __launch_bounds__(128) void normals_kernel(const float4* __restrict__ map, const int* __restrict__ sidx, int64_t m, int k,
-                                                      float* __restrict__ normals3)
+                                                      float* __restrict__ normals3, float* __restrict__ densities)
 {
     const int64_t i = (int64_t)blockIdx.x * 128 + threadIdx.x;
     if (i >= m) return;
@@ -70,13 +72,19 @@ __global__ __launch_bounds__(128) void normals_kernel(const float4* __restrict__
     }
     const double inv = 1.0 / (real > 0 ? real : 1);
     mean[0] *= inv; mean[1] *= inv; mean[2] *= inv;
-    double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
+    double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0, rmax2 = 0;
     for (int j = 0; j < k; ++j) {
         const int s = sidx[(size_t)k * i + j];
         if (s < 0) continue;
         const float4 q = map[s];
         const double x = q.x - mean[0], y = q.y - mean[1], z = q.z - mean[2];
         c00 += x * x; c01 += x * y; c02 += x * z; c11 += y * y; c12 += y * z; c22 += z * z;
+        const double r2 = x * x + y * y + z * z;
+        rmax2 = r2 > rmax2 ? r2 : rmax2;
+    }
+    if (densities) {
+        const double r = sqrt(rmax2);
+        densities[i] = (float)((double)real / ((4.0 / 3.0) * 3.14159265358979323846 * (r * r * r)));
     }
     // cyclic Jacobi on the symmetric 3x3
     double A[3][3] = {{c00, c01, c02}, {c01, c11, c12}, {c02, c12, c22}};
@@ -542,7 +550,7 @@ static icpmi_status temp_knn(icpmi_ctx* c, TempCtx& t, const float* cloud4, int6
     return ICPMI_OK;
 }
 
-icpmi_status ops_surface_normals(icpmi_ctx* c, const float* pts4, int64_t m, int knn, float* normals3)
+icpmi_status ops_surface_normals(icpmi_ctx* c, const float* pts4, int64_t m, int knn, float* normals3, float* densities)
 {
     if (m == 0) return ICPMI_OK;
     if (knn < 1 || knn > ICPMI_MAX_K) { c->last_error = "surface_normals: knn must be in [1, 32]"; return ICPMI_ERR_INVALID_ARG; }
@@ -552,11 +560,14 @@ icpmi_status ops_surface_normals(icpmi_ctx* c, const float* pts4, int64_t m, int
     s = temp_knn(c, t, pts4, m, nullptr, m, knn, 1, true);
     if (s != ICPMI_OK) return s;
     icpmi_ctx* tc = t.h;
-    DevBuf<float> d_n;
+    DevBuf<float> d_n, d_dens;
     HIP_TRY(c, d_n.alloc((size_t)m * 3));
-    hipLaunchKernelGGL(normals_kernel, dim3((int)((m + 127) / 128)), dim3(128), 0, tc->stream, tc->d_map_sorted, tc->d_sidx, m, knn, d_n);
+    if (densities) HIP_TRY(c, d_dens.alloc((size_t)m));
+    hipLaunchKernelGGL(normals_kernel, dim3((int)((m + 127) / 128)), dim3(128), 0, tc->stream, tc->d_map_sorted, tc->d_sidx, m, knn, d_n,
+                       densities ? d_dens.p : (float*)nullptr);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(normals3, d_n, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost, tc->stream);
+    if (e == hipSuccess && densities) e = hipMemcpyAsync(densities, d_dens, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, tc->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(tc->stream);
     HIP_TRY(c, e);
     return ICPMI_OK;
@@ -718,7 +729,8 @@ static icpmi_status surface_normals_dev(icpmi_ctx* c, const float4* d_pts, int64
     s = nn_self_knn(tc, d_pts, lc, tc->d_sidx, tc->d_d2, tc->d_state);
     if (s != ICPMI_OK) { c->last_error = tc->last_error; return s; }
     // rows of d_sidx follow the query order = the caller's order, so the normals land in place
-    hipLaunchKernelGGL(normals_kernel, dim3((int)((m + 127) / 128)), dim3(128), 0, tc->stream, tc->d_map_sorted, tc->d_sidx, m, knn, d_normals3);
+    hipLaunchKernelGGL(normals_kernel, dim3((int)((m + 127) / 128)), dim3(128), 0, tc->stream, tc->d_map_sorted, tc->d_sidx, m, knn, d_normals3,
+                       (float*)nullptr);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(tc->stream);
     HIP_TRY(c, e);

@@ -4,6 +4,7 @@
 #include <cstdlib>
 
 #include <algorithm>
+#include <random>
 #include <cmath>
 #include <cstring>
 #include <unordered_map>
@@ -44,10 +45,9 @@ void GpuICPSequence::recreate()
 
 void GpuICPSequence::setDefault()
 {
-    // libpointmatcher's default chain: KDTreeMatcher knn 1, TrimmedDist 0.85, PointToPlane,
-    // Counter 40 + Differential(1e-3, 1e-3, 3).  Its RandomSampling reading filter and
-    // SamplingSurfaceNormal reference filter are not on the accelerated path: the reading is used
-    // whole and map normals, when the map carries none, come from the surface-normal operator.
+    // libpointmatcher's default chain (PM::ICPChainBase::setDefault, called at Mapper.cpp:77 when the configuration has no
+    // `icp:` key): RandomSampling(0.75) on the reading, SamplingSurfaceNormal on the reference,
+    // KDTreeMatcher knn 1, TrimmedDist 0.85, PointToPlane, Counter 40 + Differential(1e-3, 1e-3, 3).
     const int dev = cfg.device;
     icpmi_config_default(&cfg);
     cfg.device = dev;
@@ -57,6 +57,13 @@ void GpuICPSequence::setDefault()
     cfg.minimizer = ICPMI_MIN_POINT_TO_PLANE;
     cfg.use_differential = 1;
     recreate();
+    readingDataPointsFilters = std::make_shared<DataPointsFilters>();
+    readingDataPointsFilters->ctx = h;
+    readingDataPointsFilters->filters.push_back(createDataPointsFilter("RandomSamplingDataPointsFilter", yaml::Node(), h));
+    referenceDataPointsFilters = std::make_shared<DataPointsFilters>();
+    referenceDataPointsFilters->ctx = h;
+    referenceDataPointsFilters->filters.push_back(createDataPointsFilter("SamplingSurfaceNormalDataPointsFilter", yaml::Node(), h));
+    readingStepDataPointsFilters.reset();
 }
 
 static void requireKnown(const yaml::Node& params, std::initializer_list<const char*> known, const std::string& who)
@@ -89,9 +96,6 @@ void GpuICPSequence::loadFromYamlNode(const yaml::Node& icp)
             for (const char* v : valid) ok |= kv.first == v;
             if (!ok) throw InvalidParameter("unknown ICP chain key: " + kv.first);
         }
-    for (const char* key : {"readingDataPointsFilters", "referenceDataPointsFilters", "readingStepDataPointsFilters"})
-        if (icp[key] && icp[key].IsSequence() && !icp[key].seq.empty())
-            throw InvalidParameter(std::string(key) + " inside the ICP chain are not on the accelerated path; apply them as input filters");
 
     if (icp["matcher"]) {
         auto e = singleEntry(icp["matcher"], "matcher");
@@ -149,25 +153,73 @@ void GpuICPSequence::loadFromYamlNode(const yaml::Node& icp)
             } else throw InvalidParameter("unknown transformation checker " + e.first);
         }
     recreate();
+    auto chain = [&](const char* key) -> std::shared_ptr<DataPointsFilters> {
+        if (!icp[key] || !icp[key].IsSequence() || icp[key].seq.empty()) return nullptr;
+        return std::make_shared<DataPointsFilters>(icp[key], h);
+    };
+    readingDataPointsFilters = chain("readingDataPointsFilters");
+    referenceDataPointsFilters = chain("referenceDataPointsFilters");
+    readingStepDataPointsFilters = chain("readingStepDataPointsFilters");
+    if (readingStepDataPointsFilters)
+        for (const auto& f : readingStepDataPointsFilters->filters)
+            if (!f->repeatable())
+                throw InvalidParameter("readingStepDataPointsFilters: a filter whose result changes from call to call (RandomSampling with seed -1) "
+                                       "cannot run inside the device-resident loop; give it a seed, or apply it as a readingDataPointsFilter");
 }
 
 bool GpuICPSequence::hasMap() const { return h && icpmi_has_map(h); }
 
-bool GpuICPSequence::setMap(const DataPoints& map)
+bool GpuICPSequence::hasReadingFilters() const
+{
+    return (readingDataPointsFilters && readingDataPointsFilters->size()) || (readingStepDataPointsFilters && readingStepDataPointsFilters->size());
+}
+
+DataPoints GpuICPSequence::filteredReading(const DataPoints& reading) const
+{
+    DataPoints r = reading;
+    if (readingDataPointsFilters) readingDataPointsFilters->apply(r);
+    if (readingStepDataPointsFilters) readingStepDataPointsFilters->apply(r);
+    return r;
+}
+
+bool GpuICPSequence::setMap(const DataPoints& mapIn)
 {
     int32_t accepted = 0;
+    if (mapIn.getNbPoints() == 0) return false; // "Ignoring attempt to setMap with an empty map"
+    DataPoints filtered;
+    const DataPoints* mapp = &mapIn;
+    if (referenceDataPointsFilters && referenceDataPointsFilters->size()) {
+        // upstream filters the CENTRED copy of the map (mean subtracted first): filters that look at coordinates
+        // (BoundingBox, DistanceLimit) mean them relative to the centroid.  The original coordinates ride along as a descriptor
+        // and are put back afterwards, so that the core centres the very points the caller handed in.
+        filtered = mapIn;
+        const size_t n = filtered.getNbPoints();
+        double mean[3] = {0, 0, 0};
+        for (size_t i = 0; i < n; ++i) for (int r = 0; r < 3; ++r) mean[r] += filtered.col(i)[r];
+        std::vector<float> orig(3 * n);
+        for (size_t i = 0; i < n; ++i)
+            for (int r = 0; r < 3; ++r) { orig[3 * i + r] = filtered.col(i)[r]; filtered.col(i)[r] = (float)(filtered.col(i)[r] - mean[r] / (double)n); }
+        filtered.addDescriptor("__icpmi_original_xyz", 3, std::move(orig));
+        referenceDataPointsFilters->apply(filtered);
+        const size_t m = filtered.getNbPoints();
+        if (filtered.descriptorExists("__icpmi_original_xyz")) {
+            const Descriptor& o = filtered.getDescriptorByName("__icpmi_original_xyz");
+            for (size_t i = 0; i < m; ++i) for (int r = 0; r < 3; ++r) filtered.col(i)[r] = o.data[3 * i + r];
+            filtered.removeDescriptor("__icpmi_original_xyz");
+        } else
+            for (size_t i = 0; i < m; ++i) for (int r = 0; r < 3; ++r) filtered.col(i)[r] = (float)(filtered.col(i)[r] + mean[r] / (double)n);
+        if (m == 0) return false;
+        mapp = &filtered;
+    }
+    const DataPoints& map = *mapp;
     const float* normals = nullptr;
-    std::vector<float> computed;
     if (map.descriptorExists("normals")) {
         const Descriptor& d = map.getDescriptorByName("normals");
         if (d.span != 3) throw InvalidField("descriptor normals must have 3 rows");
         normals = d.data.data();
-    } else if (cfg.minimizer == ICPMI_MIN_POINT_TO_PLANE && map.getNbPoints() > 0) {
-        // stand-in for the reference filters of the default chain (see setDefault)
-        computed.resize(3 * map.getNbPoints());
-        check(h, icpmi_surface_normals(h, map.features.data(), (int64_t)map.getNbPoints(), 7, computed.data()));
-        normals = computed.data();
     }
+    // a point-to-plane chain against a map without `normals`: the map is accepted (upstream's setMap does not look) and the
+    // registration raises InvalidField("normals"), as upstream's minimiser does
     check(h, icpmi_set_map(h, map.features.data(), (int64_t)map.getNbPoints(), normals, &accepted));
     return accepted != 0;
 }
@@ -267,9 +319,12 @@ DataPoints GpuICPSequence::downloadMap() const
     return out;
 }
 
-Mat4 GpuICPSequence::operator()(const DataPoints& reading)
+Mat4 GpuICPSequence::operator()(const DataPoints& readingIn)
 {
     Mat4 T = Mat4::identity();
+    DataPoints owned;
+    if (hasReadingFilters()) owned = filteredReading(readingIn);
+    const DataPoints& reading = hasReadingFilters() ? owned : readingIn;
     const float* normals = nullptr;
     if (reading.descriptorExists("normals") && reading.getDescriptorByName("normals").span == 3)
         normals = reading.getDescriptorByName("normals").data.data();
@@ -372,32 +427,191 @@ struct CutAtDescriptorThresholdFilter : DataPointsFilter {
 };
 
 struct SurfaceNormalFilter : DataPointsFilter {
-    icpmi_handle h; int knn = 5;
+    icpmi_handle h; int knn = 5; bool keepDensities = false;
     int surfaceNormalKnn() const override { return knn; }
     bool residentOp(icpmi_map_op& op, std::string&) const override {
         op = icpmi_map_op{}; op.type = ICPMI_MOP_SURFACE_NORMALS; op.i = knn;
-        return knn >= 1 && knn <= 32;
+        return knn >= 1 && knn <= 32 && !keepDensities; // the resident map does not track `densities`
     }
     void inPlaceFilter(DataPoints& c) const override {
         const size_t n = c.getNbPoints();
-        std::vector<float> normals(3 * n);
-        GpuICPSequence::check(h, icpmi_surface_normals(h, c.features.data(), (int64_t)n, knn, normals.data()));
+        std::vector<float> normals(3 * n), dens(keepDensities ? n : 0);
+        GpuICPSequence::check(h, icpmi_surface_normals_ex(h, c.features.data(), (int64_t)n, knn, normals.data(), keepDensities ? dens.data() : nullptr));
         c.addDescriptor("normals", 3, std::move(normals));
+        if (keepDensities) c.addDescriptor("densities", 1, std::move(dens));
     }
 };
 
+// std::minstd_rand (x <- 48271 x mod 2^31 - 1: fully specified by the C++ standard, so the oracle restates it) and the two ways
+// upstream turns it into [0, 1): randomSamplingMethod 0 "direct" = x / float(max - min), 1 "uniform" =
+// std::uniform_real_distribution<float> = (x - min) / float(max - min + 1) capped below 1 (libstdc++'s generate_canonical).
+struct MinStd {
+    uint32_t x;
+    explicit MinStd(uint32_t seed) : x(seed % 2147483647u) { if (x == 0) x = 1; }
+    uint32_t next() { x = (uint32_t)(((uint64_t)x * 48271ull) % 2147483647ull); return x; }
+    float unit(int method) {
+        const uint32_t v = next();
+        if (method == 1) { const float r = (float)(v - 1u) / 2147483646.0f; return r < 1.0f ? r : std::nextafter(1.0f, 0.0f); }
+        return (float)v / 2147483645.0f; // max() - min() = 2147483646 - 1
+    }
+};
+
+// RandomSamplingDataPointsFilter{prob 0.75, randomSamplingMethod 0, seed -1} [UPSTREAM 1.4.x, as recalled]: a fresh
+// std::minstd_rand per call (seed -1: std::random_device), one number per point, point kept iff number < prob, never more
+// than floor(n * prob) + 1 points.
 struct RandomSamplingFilter : DataPointsFilter {
-    float prob = 0.75f;
+    float prob = 0.75f; int method = 0; int seed = -1;
+    bool repeatable() const override { return seed != -1; }
+    void inPlaceFilter(DataPoints& c) const override {
+        const size_t n = c.getNbPoints();
+        const size_t nOut = (size_t)((float)n * prob);
+        MinStd rng(seed == -1 ? (uint32_t)std::random_device()() : (uint32_t)seed);
+        std::vector<uint8_t> keep(n, 0);
+        size_t j = 0;
+        for (size_t i = 0; i < n && j <= nOut; ++i)
+            if (rng.unit(method) < prob) { keep[i] = 1; ++j; }
+        c.keepOnly(keep);
+    }
+};
+
+// MaxDensityDataPointsFilter{maxDensity 10} [UPSTREAM]: needs `densities` (SurfaceNormalDataPointsFilter{keepDensities: 1});
+// a point in a region denser than maxDensity survives with probability maxDensity / density.
+struct MaxDensityFilter : DataPointsFilter {
+    float maxDensity = 10.f; int seed = 1;
+    void inPlaceFilter(DataPoints& c) const override {
+        if (!c.descriptorExists("densities")) throw InvalidField("MaxDensityDataPointsFilter: Error, no densities found in descriptors.");
+        const Descriptor& d = c.getDescriptorByName("densities");
+        const size_t n = c.getNbPoints();
+        MinStd rng((uint32_t)seed);
+        std::vector<uint8_t> keep(n, 1);
+        for (size_t i = 0; i < n; ++i) {
+            const float density = d.data[(size_t)d.span * i];
+            if (density > maxDensity) keep[i] = rng.unit(0) < maxDensity / density;
+        }
+        c.keepOnly(keep);
+    }
+};
+
+struct IdentityFilter : DataPointsFilter { void inPlaceFilter(DataPoints&) const override {} };
+
+struct RemoveNaNFilter : DataPointsFilter {
     void inPlaceFilter(DataPoints& c) const override {
         const size_t n = c.getNbPoints();
         std::vector<uint8_t> keep(n);
-        uint64_t s = 0x9E3779B97F4A7C15ull; // fixed seed: deterministic replays
-        for (size_t i = 0; i < n; ++i) {
-            s += 0x9E3779B97F4A7C15ull;
-            uint64_t z = s; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
-            keep[i] = (double)(z >> 11) * (1.0 / 9007199254740992.0) < prob;
-        }
+        for (size_t i = 0; i < n; ++i) { const float* p = c.col(i); keep[i] = !(std::isnan(p[0]) || std::isnan(p[1]) || std::isnan(p[2])); }
         c.keepOnly(keep);
+    }
+};
+
+// symmetric 3x3 eigen-decomposition (cyclic Jacobi, double): eigenvalues w, eigenvectors in the columns of Q
+static void jacobi3(const double C[9], double w[3], double Q[9])
+{
+    double A[3][3] = {{C[0], C[3], C[6]}, {C[1], C[4], C[7]}, {C[2], C[5], C[8]}};
+    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+        const double dg = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
+        if (off <= 1e-32 * dg || off < 1e-300) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (A[p][q] == 0.0) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
+                for (int k = 0; k < 3; ++k) { const double a = A[k][p], b = A[k][q]; A[k][p] = cs * a - sn * b; A[k][q] = sn * a + cs * b; }
+                for (int k = 0; k < 3; ++k) { const double a = A[p][k], b = A[q][k]; A[p][k] = cs * a - sn * b; A[q][k] = sn * a + cs * b; }
+                for (int k = 0; k < 3; ++k) { const double a = V[k][p], b = V[k][q]; V[k][p] = cs * a - sn * b; V[k][q] = sn * a + cs * b; }
+            }
+    }
+    for (int e = 0; e < 3; ++e) { w[e] = A[e][e]; for (int r = 0; r < 3; ++r) Q[3 * e + r] = V[r][e]; }
+}
+
+// SamplingSurfaceNormalDataPointsFilter{ratio 0.5, knn 7, samplingMethod 0, maxBoxDim inf, averageExistingDescriptors 1,
+// keepNormals 1} [UPSTREAM, as recalled] -- the reference filter of PM::ICPSequence::setDefault (Mapper.cpp:77): the cloud is
+// split at the median of its widest dimension until a box holds at most knn points; every box gets ONE normal (smallest
+// eigenvector of the covariance of its points; boxes of rank < 2 or wider than maxBoxDim are dropped), and its points are kept
+// with probability `ratio` (samplingMethod 0) or replaced by their mean (1).  Output in box order.  Deterministic here: the
+// median split orders by (coordinate, index), points inside a box by index, the random numbers are MinStd(seed) (upstream:
+// std::nth_element's permutation and std::rand).  Host code: a recursive median split is what the reference runs on the CPU
+// too; it runs once per setMap.
+struct SamplingSurfaceNormalFilter : DataPointsFilter {
+    float ratio = 0.5f; int knn = 7; int method = 0; float maxBoxDim = INFINITY; bool averageDescriptors = true; bool keepNormals = true; int seed = 1;
+    struct Work {
+        const DataPoints* in; DataPoints out; std::vector<float> normals; MinStd rng; const SamplingSurfaceNormalFilter* f;
+        Work(const DataPoints* c, const SamplingSurfaceNormalFilter* ff) : in(c), out(c->createSimilarEmpty()), rng((uint32_t)ff->seed), f(ff) {}
+    };
+    void fuse(Work& w, std::vector<int32_t>& idx, size_t first, size_t last) const {
+        const size_t cnt = last - first;
+        std::sort(idx.begin() + first, idx.begin() + last);
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        double mean[3] = {0, 0, 0};
+        for (size_t k = first; k < last; ++k) {
+            const float* p = w.in->col((size_t)idx[k]);
+            for (int r = 0; r < 3; ++r) { lo[r] = std::min(lo[r], p[r]); hi[r] = std::max(hi[r], p[r]); mean[r] += p[r]; }
+        }
+        if (std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2])) > maxBoxDim) return;
+        for (int r = 0; r < 3; ++r) mean[r] /= (double)cnt;
+        double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (size_t k = first; k < last; ++k) {
+            const float* p = w.in->col((size_t)idx[k]);
+            const double v[3] = {p[0] - mean[0], p[1] - mean[1], p[2] - mean[2]};
+            for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) C[3 * c + r] += v[r] * v[c];
+        }
+        double ev[3], Q[9];
+        jacobi3(C, ev, Q);
+        const double wmax = std::max(std::fabs(ev[0]), std::max(std::fabs(ev[1]), std::fabs(ev[2])));
+        int rank = 0;
+        for (int e = 0; e < 3; ++e) if (wmax > 0 && std::fabs(ev[e]) > 3.0 * 1.1920928955078125e-07 * wmax) ++rank;
+        if (rank < 2) return; // the points of the box are "unfit"
+        int e = 0;
+        if (ev[1] < ev[e]) e = 1;
+        if (ev[2] < ev[e]) e = 2;
+        const float nrm[3] = {(float)Q[3 * e], (float)Q[3 * e + 1], (float)Q[3 * e + 2]};
+        if (method == 1) {
+            w.out.appendColFrom(*w.in, (size_t)idx[first]);
+            const size_t j = w.out.getNbPoints() - 1;
+            for (int r = 0; r < 3; ++r) w.out.col(j)[r] = (float)mean[r];
+            if (averageDescriptors)
+                for (size_t d = 0; d < w.in->descriptors.size(); ++d) {
+                    const Descriptor& src = w.in->descriptors[d];
+                    for (int r = 0; r < src.span; ++r) {
+                        double s2 = 0;
+                        for (size_t k = first; k < last; ++k) s2 += src.data[(size_t)src.span * idx[k] + r];
+                        w.out.descriptors[d].data[(size_t)src.span * j + r] = (float)(s2 / (double)cnt);
+                    }
+                }
+            w.normals.insert(w.normals.end(), nrm, nrm + 3);
+            return;
+        }
+        for (size_t k = first; k < last; ++k)
+            if (w.rng.unit(0) < ratio) { w.out.appendColFrom(*w.in, (size_t)idx[k]); w.normals.insert(w.normals.end(), nrm, nrm + 3); }
+    }
+    void build(Work& w, std::vector<int32_t>& idx, size_t first, size_t last, const float lo[3], const float hi[3]) const {
+        const size_t cnt = last - first;
+        if (cnt == 0) return;
+        if (cnt <= (size_t)knn) { fuse(w, idx, first, last); return; }
+        int dim = 0;
+        for (int r = 1; r < 3; ++r) if (hi[r] - lo[r] > hi[dim] - lo[dim]) dim = r;
+        const size_t right = cnt / 2, left = cnt - right;
+        const DataPoints* in = w.in;
+        auto less = [in, dim](int32_t a, int32_t b) { const float x = in->col((size_t)a)[dim], y = in->col((size_t)b)[dim]; return x < y || (x == y && a < b); };
+        std::nth_element(idx.begin() + first, idx.begin() + first + left, idx.begin() + last, less);
+        const float cut = in->col((size_t)idx[first + left])[dim];
+        float lhi[3] = {hi[0], hi[1], hi[2]}, rlo[3] = {lo[0], lo[1], lo[2]};
+        lhi[dim] = cut; rlo[dim] = cut;
+        build(w, idx, first, first + left, lo, lhi);
+        build(w, idx, first + left, last, rlo, hi);
+    }
+    void inPlaceFilter(DataPoints& c) const override {
+        const size_t n = c.getNbPoints();
+        if (n == 0) return;
+        std::vector<int32_t> idx(n);
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (size_t i = 0; i < n; ++i) { idx[i] = (int32_t)i; for (int r = 0; r < 3; ++r) { lo[r] = std::min(lo[r], c.col(i)[r]); hi[r] = std::max(hi[r], c.col(i)[r]); } }
+        Work w(&c, this);
+        build(w, idx, 0, n, lo, hi);
+        if (keepNormals) w.out.addDescriptor("normals", 3, std::move(w.normals));
+        c = std::move(w.out);
     }
 };
 
@@ -518,18 +732,41 @@ std::shared_ptr<DataPointsFilter> createDataPointsFilter(const std::string& name
     if (name == "SurfaceNormalDataPointsFilter") {
         requireKnown(p, {"knn", "maxDist", "epsilon", "keepNormals", "keepDensities", "keepEigenValues", "keepEigenVectors",
                          "keepMatchedIds", "keepMeanDist", "sortEigen", "smoothNormals"}, name);
-        for (const char* k : {"keepDensities", "keepEigenValues", "keepEigenVectors", "keepMatchedIds", "keepMeanDist", "smoothNormals"})
+        for (const char* k : {"keepEigenValues", "keepEigenVectors", "keepMatchedIds", "keepMeanDist", "smoothNormals"})
             if (geti(p, k, 0) != 0) throw InvalidParameter(name + ": " + k + " is not on the accelerated path");
         auto f = std::make_shared<SurfaceNormalFilter>();
-        f->h = ctx; f->knn = geti(p, "knn", 5);
+        f->h = ctx; f->knn = geti(p, "knn", 5); f->keepDensities = geti(p, "keepDensities", 0) != 0;
         return f;
     }
     if (name == "RandomSamplingDataPointsFilter") {
         requireKnown(p, {"prob", "randomSamplingMethod", "seed"}, name);
         auto f = std::make_shared<RandomSamplingFilter>();
-        f->prob = getf(p, "prob", 0.75f);
+        f->prob = getf(p, "prob", 0.75f); f->method = geti(p, "randomSamplingMethod", 0); f->seed = geti(p, "seed", -1);
+        if (!(f->prob >= 0.f && f->prob <= 1.f) || f->method < 0 || f->method > 1 || f->seed < -1) throw InvalidParameter(name + ": parameter out of range");
         return f;
     }
+    if (name == "SamplingSurfaceNormalDataPointsFilter") {
+        requireKnown(p, {"ratio", "knn", "samplingMethod", "maxBoxDim", "averageExistingDescriptors", "keepNormals", "keepDensities", "keepEigenValues",
+                         "keepEigenVectors", "seed"}, name);
+        for (const char* k : {"keepDensities", "keepEigenValues", "keepEigenVectors"})
+            if (geti(p, k, 0) != 0) throw InvalidParameter(name + ": " + k + " is not supported");
+        auto f = std::make_shared<SamplingSurfaceNormalFilter>();
+        f->ratio = getf(p, "ratio", 0.5f); f->knn = geti(p, "knn", 7); f->method = geti(p, "samplingMethod", 0);
+        f->maxBoxDim = p["maxBoxDim"] ? p["maxBoxDim"].as<float>() : INFINITY;
+        f->averageDescriptors = geti(p, "averageExistingDescriptors", 1) != 0; f->keepNormals = geti(p, "keepNormals", 1) != 0;
+        f->seed = geti(p, "seed", 1);
+        if (!(f->ratio > 0.f && f->ratio <= 1.f) || f->knn < 3 || f->method < 0 || f->method > 1) throw InvalidParameter(name + ": parameter out of range");
+        return f;
+    }
+    if (name == "MaxDensityDataPointsFilter") {
+        requireKnown(p, {"maxDensity", "seed"}, name);
+        auto f = std::make_shared<MaxDensityFilter>();
+        f->maxDensity = getf(p, "maxDensity", 10.f); f->seed = geti(p, "seed", 1);
+        if (!(f->maxDensity > 0.f)) throw InvalidParameter(name + ": maxDensity must be > 0");
+        return f;
+    }
+    if (name == "IdentityDataPointsFilter") return std::make_shared<IdentityFilter>();
+    if (name == "RemoveNaNDataPointsFilter") return std::make_shared<RemoveNaNFilter>();
     if (name == "OctreeGridDataPointsFilter") {
         requireKnown(p, {"buildParallel", "maxPointByNode", "maxSizeByNode", "samplingMethod"}, name);
         auto f = std::make_shared<OctreeGridFilter>();

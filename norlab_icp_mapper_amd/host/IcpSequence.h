@@ -17,6 +17,8 @@
 
 namespace nim {
 
+class DataPointsFilters;
+
 class GpuICPSequence {
 public:
     struct ErrorMinimizerView {
@@ -56,12 +58,25 @@ public:
     std::vector<float> downloadMapScalar() const;
     int64_t residentMapSize() const;
     bool chainNeedsReadingNormals() const;             // SurfaceNormalOutlierFilter in the chain
+    // true when the chain filters the reading inside operator() (readingDataPointsFilters / readingStepDataPointsFilters):
+    // the staged-scan path of Mapper::processInput hands the unfiltered scan to the GPU and must not be taken then
+    bool hasReadingFilters() const;
+    // referenceDataPointsFilters present: every map must pass through setMap (the resident map update rebuilds the index
+    // from the device copy and would skip them)
+    bool hasReferenceFilters() const { return referenceDataPointsFilters != nullptr; }
     const icpmi_stats& stats() const { return lastStats; }
     const icpmi_config& config() const { return cfg; }
     static void check(icpmi_handle h, icpmi_status s); // status -> exception mapping
 
+    // The DataPointsFilters chains INSIDE the ICP object (PM::ICPChainBase: `readingDataPointsFilters`, applied to a copy of
+    // the reading in its incoming frame at the top of operator(); `readingStepDataPointsFilters`, applied to a copy of the
+    // reading at the top of every iteration -- every filter here gives the same result on the same input, so once;
+    // `referenceDataPointsFilters`, applied to the centred copy of the map inside setMap).
+    std::shared_ptr<DataPointsFilters> readingDataPointsFilters, readingStepDataPointsFilters, referenceDataPointsFilters;
+
 private:
     void recreate();
+    DataPoints filteredReading(const DataPoints& reading) const;
     icpmi_handle h = nullptr;
     icpmi_config cfg;
     icpmi_stats lastStats{};
@@ -91,6 +106,9 @@ public:
     virtual bool residentOp(icpmi_map_op& op, std::string& scalarName) const { (void)op; (void)scalarName; return false; }
     // true for per-point predicates (DistanceLimit, BoundingBox): a run of them is one icpmi_filter_points pass
     virtual bool pointFilter(icpmi_point_filter& f) const { (void)f; return false; }
+    // false when two calls on the same cloud may differ (RandomSampling seeded from std::random_device): such a filter cannot
+    // serve as a readingStepDataPointsFilter, which the accelerated loop applies once instead of once per iteration
+    virtual bool repeatable() const { return true; }
 };
 
 class DataPointsFilters {

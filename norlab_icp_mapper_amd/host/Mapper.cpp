@@ -177,7 +177,7 @@ void Mapper::processInput(const DataPoints& filteredInputInSensorFrame, const Ma
     // One upload per scan when the map update can run on the resident map: the scan is moved by the prior, registered and --
     // if the policy asks for it -- moved by the correction and merged, all on the GPU (icpmi_register_prior /
     // icpmi_map_update_staged).  Offline only: an asynchronous update would race the next scan for the staged buffer.
-    if (!isOnline && !icp.chainNeedsReadingNormals() && map.canStageScan(filteredInputInSensorFrame, mapPostFilters)) {
+    if (!isOnline && !icp.chainNeedsReadingNormals() && !icp.hasReadingFilters() && map.canStageScan(filteredInputInSensorFrame, mapPostFilters)) {
         const bool bootstrap = map.isLocalPointCloudEmpty();
         Mat4 correction;
         {

@@ -191,11 +191,31 @@ static void testFilters()
     auto cut = createDataPointsFilter("CutAtDescriptorThresholdDataPointsFilter", yaml::Load("{descName: probabilityDynamic, useLargerThan: 1, threshold: 0.65}"), nullptr);
     cut->inPlaceFilter(c);
     CHECK(c.getNbPoints() == before - 1);
-    DataPoints v = makeCloud(400);
-    auto vox = createDataPointsFilter("OctreeGridDataPointsFilter", yaml::Load("{maxSizeByNode: 4.0, samplingMethod: 0}"), nullptr);
-    vox->inPlaceFilter(v);
-    CHECK(v.getNbPoints() > 0 && v.getNbPoints() < 400);
+    // host-side filters of the ICP chains: RandomSampling is std::minstd_rand with the configured seed -- same seed, same subset
+    {
+        DataPoints r1 = makeCloud(1000), r2 = makeCloud(1000);
+        auto rs = createDataPointsFilter("RandomSamplingDataPointsFilter", yaml::Load("{prob: 0.5, seed: 7}"), nullptr);
+        rs->inPlaceFilter(r1); rs->inPlaceFilter(r2);
+        CHECK(r1.getNbPoints() == r2.getNbPoints() && r1.getNbPoints() > 400 && r1.getNbPoints() < 600 && r1.features == r2.features);
+        CHECK(rs->repeatable() && !createDataPointsFilter("RandomSamplingDataPointsFilter", yaml::Node(), nullptr)->repeatable());
+        DataPoints s1 = makeCloud(2000);
+        auto ssn = createDataPointsFilter("SamplingSurfaceNormalDataPointsFilter", yaml::Load("{ratio: 0.5, knn: 7}"), nullptr);
+        ssn->inPlaceFilter(s1);
+        CHECK(s1.getNbPoints() > 600 && s1.getNbPoints() < 1400 && s1.descriptorExists("normals"));
+        const Descriptor& nn = s1.getDescriptorByName("normals");
+        for (size_t i = 0; i < s1.getNbPoints(); ++i) {
+            const float l = nn.data[3 * i] * nn.data[3 * i] + nn.data[3 * i + 1] * nn.data[3 * i + 1] + nn.data[3 * i + 2] * nn.data[3 * i + 2];
+            CHECK(std::fabs(l - 1.f) < 1e-4f);
+        }
+    }
+    // the octree lives on the device: without a GPU context the filter refuses instead of falling back
     bool threw = false;
+    try {
+        DataPoints v = makeCloud(400);
+        createDataPointsFilter("OctreeGridDataPointsFilter", yaml::Load("{maxSizeByNode: 4.0, samplingMethod: 0}"), nullptr)->inPlaceFilter(v);
+    } catch (const std::logic_error&) { threw = true; }
+    CHECK(threw);
+    threw = false;
     try { createDataPointsFilter("BoundingBoxDataPointsFilter", yaml::Load("{xMinn: 1}"), nullptr); } catch (const InvalidParameter&) { threw = true; }
     CHECK(threw);
     threw = false;

@@ -336,11 +336,15 @@ class ICPSequence:
         self._check(self._lib.icpmi_minimize_step(self._h, r.ctypes.data, r.shape[0], tptr, T, sums, C.byref(self.stats)))
         return _T_from_c(T[:]), np.array(sums[:])
 
-    def surfaceNormals(self, cloud, knn=5):
-        cloud = _f32c(cloud, 4)
-        out = np.empty((cloud.shape[0], 3), dtype=np.float32)
-        self._check(self._lib.icpmi_surface_normals(self._h, cloud.ctypes.data, cloud.shape[0], knn, out.ctypes.data))
-        return out
+    def surfaceNormals(self, cloud, knn=5, with_densities=False):
+        c = _f32c(cloud, 4)
+        out = np.empty((c.shape[0], 3), dtype=np.float32)
+        if not with_densities:
+            self._check(self._lib.icpmi_surface_normals(self._h, c.ctypes.data, c.shape[0], knn, out.ctypes.data))
+            return out
+        dens = np.empty(c.shape[0], dtype=np.float32)
+        self._check(self._lib.icpmi_surface_normals_ex(self._h, c.ctypes.data, c.shape[0], knn, out.ctypes.data, dens.ctypes.data))
+        return out, dens
 
     def pointDistanceKeep(self, map_cloud, input_cloud, min_dist):
         m = _f32c(map_cloud, 4)

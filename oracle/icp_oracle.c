@@ -857,7 +857,10 @@ int orc_icp_register(orc_icp* s, const float* scan4, int64_t n, const float* sca
 /* ------------------------------------------------------------------------------------------------
  * SurfaceNormalDataPointsFilter (applied at Map.cpp:524 from examples/config.yaml:26)
  * ---------------------------------------------------------------------------------------------- */
-void orc_surface_normals(const float* pts4, int64_t m, int knn, float* normals3, int nthreads)
+void orc_surface_normals(const float* pts4, int64_t m, int knn, float* normals3, int nthreads) { orc_surface_normals_ex(pts4, m, knn, normals3, NULL, nthreads); }
+/* densities (may be NULL): keepDensities -- knn / (4/3 pi r^3), r = the largest distance of a neighbour from the centroid of the
+ * neighbourhood (SurfaceNormalDataPointsFilter::computeDensity: NN.colwise().norm().maxCoeff() on the centred neighbours) */
+void orc_surface_normals_ex(const float* pts4, int64_t m, int knn, float* normals3, float* densities, int nthreads)
 {
     orc_kdtree* t = orc_kdtree_build(pts4, m, 3, knn > 1 ? knn : 8);
     int32_t* ids = (int32_t*)malloc((size_t)m * knn * sizeof(int32_t));
@@ -874,13 +877,17 @@ void orc_surface_normals(const float* pts4, int64_t m, int knn, float* normals3,
         }
         double C[9] = { 0 };
         for (int r = 0; r < 3; ++r) mean[r] /= (real > 0 ? real : 1);
+        double rmax2 = 0;
         for (int j = 0; j < knn; ++j) {
             const int32_t id = ids[(int64_t)knn * i + j];
             if (id < 0) continue;
             double v[3];
             for (int r = 0; r < 3; ++r) v[r] = (double)pts4[4 * (int64_t)id + r] - mean[r];
             for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) C[3 * c + r] += v[r] * v[c];
+            const double r2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+            if (r2 > rmax2) rmax2 = r2;
         }
+        if (densities) { const double rr = sqrt(rmax2); densities[i] = (float)((double)real / ((4.0 / 3.0) * 3.14159265358979323846 * (rr * rr * rr))); }
         double w[3], Q[9];
         jacobi_eig_sym(3, C, w, Q);
         /* rank test of upstream: needs rank >= 2, otherwise eigenvalues 0 / eigenvectors identity */
@@ -1109,6 +1116,126 @@ void orc_dynamic_points_update(const float prm[7], const float* to_sensor, const
         }
     }
     free(bx); free(be); free(ba);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * The DataPointsFilters of PM::ICPSequence::setDefault (Mapper.cpp:77) and MaxDensity [UPSTREAM 1.4.x, as
+ * recalled].  Random numbers: std::minstd_rand (x <- 48271 x mod 2^31 - 1, defined by the C++ standard); "direct" = x / float
+ * (max - min), "uniform" = std::uniform_real_distribution<float> as libstdc++ evaluates it.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { uint32_t x; } orc_minstd;
+static void orc_minstd_seed(orc_minstd* g, uint32_t seed) { g->x = seed % 2147483647u; if (g->x == 0) g->x = 1; }
+static float orc_minstd_unit(orc_minstd* g, int method)
+{
+    g->x = (uint32_t)(((uint64_t)g->x * 48271ull) % 2147483647ull);
+    if (method == 1) { const float r = (float)(g->x - 1u) / 2147483646.0f; return r < 1.0f ? r : nextafterf(1.0f, 0.0f); }
+    return (float)g->x / 2147483645.0f;
+}
+/* RandomSamplingDataPointsFilter{prob, randomSamplingMethod, seed >= 0}: a fresh generator per call, one number per point, kept
+ * iff number < prob, never more than floor(n prob) + 1 points */
+void orc_random_sampling_keep(int64_t n, float prob, int method, int seed, uint8_t* keep)
+{
+    orc_minstd g; orc_minstd_seed(&g, (uint32_t)seed);
+    const int64_t n_out = (int64_t)((float)n * prob);
+    int64_t j = 0;
+    for (int64_t i = 0; i < n; ++i) keep[i] = 0;
+    for (int64_t i = 0; i < n && j <= n_out; ++i)
+        if (orc_minstd_unit(&g, method) < prob) { keep[i] = 1; ++j; }
+}
+/* MaxDensityDataPointsFilter{maxDensity, seed}: a point in a region denser than maxDensity survives with probability maxDensity / density */
+void orc_max_density_keep(const float* densities, int64_t n, float max_density, int seed, uint8_t* keep)
+{
+    orc_minstd g; orc_minstd_seed(&g, (uint32_t)seed);
+    for (int64_t i = 0; i < n; ++i) {
+        keep[i] = 1;
+        if (densities[i] > max_density) keep[i] = orc_minstd_unit(&g, 0) < max_density / densities[i];
+    }
+}
+/* SamplingSurfaceNormalDataPointsFilter{ratio, knn, samplingMethod 0, maxBoxDim, seed}: median splits of the widest dimension
+ * (ties by index) until a box holds <= knn points; one normal per box (rank >= 2, else the box is dropped), its points --
+ * in index order -- kept with probability ratio.  order_out / normals_out (capacity n / 3 n) = kept indices and their
+ * normals in box order; returns the number kept.  The split is a full sort per node (the host shell uses nth_element: the
+ * two halves are the same sets). */
+typedef struct { const float* p; int dim; } orc_ssn_cmp_ctx;
+static orc_ssn_cmp_ctx g_ssn_cmp; /* qsort has no context argument; the oracle is single threaded here */
+static int orc_ssn_cmp(const void* a, const void* b)
+{
+    const int32_t ia = *(const int32_t*)a, ib = *(const int32_t*)b;
+    const float x = g_ssn_cmp.p[4 * (int64_t)ia + g_ssn_cmp.dim], y = g_ssn_cmp.p[4 * (int64_t)ib + g_ssn_cmp.dim];
+    if (x != y) return x < y ? -1 : 1;
+    return ia < ib ? -1 : (ia > ib ? 1 : 0);
+}
+static int orc_i32_cmp(const void* a, const void* b) { const int32_t x = *(const int32_t*)a, y = *(const int32_t*)b; return x < y ? -1 : (x > y ? 1 : 0); }
+typedef struct { const float* p; float ratio; int knn; float max_box; orc_minstd g; int32_t* order; float* normals; int64_t n_out; } orc_ssn_ctx;
+static void orc_ssn_fuse(orc_ssn_ctx* c, int32_t* idx, int64_t cnt)
+{
+    qsort(idx, (size_t)cnt, sizeof(int32_t), orc_i32_cmp);
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    double mean[3] = {0, 0, 0};
+    for (int64_t k = 0; k < cnt; ++k)
+        for (int r = 0; r < 3; ++r) {
+            const float v = c->p[4 * (int64_t)idx[k] + r];
+            if (v < lo[r]) lo[r] = v;
+            if (v > hi[r]) hi[r] = v;
+            mean[r] += v;
+        }
+    float box = hi[0] - lo[0];
+    if (hi[1] - lo[1] > box) box = hi[1] - lo[1];
+    if (hi[2] - lo[2] > box) box = hi[2] - lo[2];
+    if (box > c->max_box) return;
+    for (int r = 0; r < 3; ++r) mean[r] /= (double)cnt;
+    double C[9] = {0};
+    for (int64_t k = 0; k < cnt; ++k) {
+        double v[3];
+        for (int r = 0; r < 3; ++r) v[r] = (double)c->p[4 * (int64_t)idx[k] + r] - mean[r];
+        for (int cc = 0; cc < 3; ++cc) for (int r = 0; r < 3; ++r) C[3 * cc + r] += v[r] * v[cc];
+    }
+    double w[3], Q[9];
+    jacobi_eig_sym(3, C, w, Q);
+    const double wmax = fmax(fabs(w[0]), fmax(fabs(w[1]), fabs(w[2])));
+    int rank = 0;
+    for (int e = 0; e < 3; ++e) if (wmax > 0 && fabs(w[e]) > 3.0 * FLT_EPSILON * wmax) ++rank;
+    if (rank < 2) return;
+    int e = 0;
+    if (w[1] < w[e]) e = 1;
+    if (w[2] < w[e]) e = 2;
+    for (int64_t k = 0; k < cnt; ++k)
+        if (orc_minstd_unit(&c->g, 0) < c->ratio) {
+            c->order[c->n_out] = idx[k];
+            for (int r = 0; r < 3; ++r) c->normals[3 * c->n_out + r] = (float)Q[3 * e + r];
+            ++c->n_out;
+        }
+}
+static void orc_ssn_build(orc_ssn_ctx* c, int32_t* idx, int64_t cnt, const float* lo, const float* hi)
+{
+    if (cnt == 0) return;
+    if (cnt <= c->knn) { orc_ssn_fuse(c, idx, cnt); return; }
+    int dim = 0;
+    for (int r = 1; r < 3; ++r) if (hi[r] - lo[r] > hi[dim] - lo[dim]) dim = r;
+    const int64_t right = cnt / 2, left = cnt - right;
+    g_ssn_cmp.p = c->p; g_ssn_cmp.dim = dim;
+    qsort(idx, (size_t)cnt, sizeof(int32_t), orc_ssn_cmp);
+    const float cut = c->p[4 * (int64_t)idx[left] + dim];
+    float lhi[3] = {hi[0], hi[1], hi[2]}, rlo[3] = {lo[0], lo[1], lo[2]};
+    lhi[dim] = cut; rlo[dim] = cut;
+    orc_ssn_build(c, idx, left, lo, lhi);
+    orc_ssn_build(c, idx + left, right, rlo, hi);
+}
+int64_t orc_sampling_surface_normal(const float* pts4, int64_t n, float ratio, int knn, float max_box_dim, int seed, int32_t* order_out,
+                                    float* normals_out)
+{
+    if (n <= 0) return 0;
+    int32_t* idx = (int32_t*)malloc((size_t)n * sizeof(int32_t));
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = 0; i < n; ++i) {
+        idx[i] = (int32_t)i;
+        for (int r = 0; r < 3; ++r) { const float v = pts4[4 * i + r]; if (v < lo[r]) lo[r] = v; if (v > hi[r]) hi[r] = v; }
+    }
+    orc_ssn_ctx c; c.p = pts4; c.ratio = ratio; c.knn = knn; c.max_box = max_box_dim; c.order = order_out; c.normals = normals_out; c.n_out = 0;
+    orc_minstd_seed(&c.g, (uint32_t)seed);
+    orc_ssn_build(&c, idx, n, lo, hi);
+    free(idx);
+    return c.n_out;
 }
 
 /* Mapper::applyInputFilters for DistanceLimit / BoundingBox filters (Mapper.cpp:27-31, examples/config.yaml:2-18):

@@ -142,6 +142,7 @@ int orc_icp_register(orc_icp* s, const float* scan4, int64_t n, const float* sca
 /* ---- map-side operators on the path ---- */
 /* SurfaceNormalDataPointsFilter: kNN (self included) + smallest-eigenvector normal */
 void orc_surface_normals(const float* pts4, int64_t m, int knn, float* normals3, int nthreads);
+void orc_surface_normals_ex(const float* pts4, int64_t m, int knn, float* normals3, float* densities, int nthreads);
 /* PointDistanceMapperModule::inPlaceUpdateMap keep-mask (PointDistanceMapperModule.cpp:28-50):
  * keep[i] = 1 iff exact NN (self match NOT allowed, no radius) has d2 >= minDist^2 */
 void orc_point_distance_keep(const float* map4, int64_t m, const float* in4, int64_t n, float min_dist,
@@ -155,6 +156,11 @@ void orc_filter_points(const float* in4, int64_t n, const float* filters, int n_
 void orc_voxel_keep(const float* in4, int64_t n, float edge, int method, uint8_t* keep);
 /* OctreeGridDataPointsFilter{maxSizeByNode, maxPointByNode, samplingMethod 0 | 1}: the real octree (bounding cube, recursive
  * split); order_out (capacity n) = original indices of the kept points in leaf-visiting (Morton) order; returns their number */
+/* DataPointsFilters of the default ICP chain (PM::ICPSequence::setDefault) and MaxDensity; std::minstd_rand random numbers */
+void orc_random_sampling_keep(int64_t n, float prob, int method, int seed, uint8_t* keep);
+void orc_max_density_keep(const float* densities, int64_t n, float max_density, int seed, uint8_t* keep);
+int64_t orc_sampling_surface_normal(const float* pts4, int64_t n, float ratio, int knn, float max_box_dim, int seed, int32_t* order_out,
+                                    float* normals_out);
 int64_t orc_octree_sample(const float* in4, int64_t n, float max_size, int64_t max_pts, int method, int32_t* order_out);
 /* DynamicPointsMapperModule::inPlaceUpdateMap (DynamicPointsMapperModule.cpp:34-172).  prm = {thresholdDynamic, alpha,
  * beta, beamHalfAngle, epsilonA, epsilonD, sensorMaxRange}; to_sensor = pose^-1 (col-major); prob updated in place. */

@@ -68,11 +68,16 @@ def load():
     lib.orc_icp_get_mean.argtypes = [_P, _P]
     lib.orc_icp_register.argtypes = [_P, _P, C.c_int64, _P, _P, C.POINTER(Stats)]
     lib.orc_surface_normals.argtypes = [_P, C.c_int64, C.c_int, _P, C.c_int]
+    lib.orc_surface_normals_ex.argtypes = [_P, C.c_int64, C.c_int, _P, _P, C.c_int]
     lib.orc_point_distance_keep.argtypes = [_P, C.c_int64, _P, C.c_int64, C.c_float, _P, C.c_int]
     lib.orc_cell_ids.argtypes = [_P, C.c_int64, C.c_float, _P]
     lib.orc_voxel_keep_first.argtypes = [_P, C.c_int64, C.c_float, _P]
     lib.orc_filter_points.argtypes = [_P, C.c_int64, _P, C.c_int, _P]
     lib.orc_voxel_keep.argtypes = [_P, C.c_int64, C.c_float, C.c_int, _P]
+    lib.orc_random_sampling_keep.argtypes = [C.c_int64, C.c_float, C.c_int, C.c_int, _P]
+    lib.orc_max_density_keep.argtypes = [_P, C.c_int64, C.c_float, C.c_int, _P]
+    lib.orc_sampling_surface_normal.restype = C.c_int64
+    lib.orc_sampling_surface_normal.argtypes = [_P, C.c_int64, C.c_float, C.c_int, C.c_float, C.c_int, _P, _P]
     lib.orc_octree_sample.restype = C.c_int64
     lib.orc_octree_sample.argtypes = [_P, C.c_int64, C.c_float, C.c_int64, C.c_int, _P]
     lib.orc_dynamic_points_update.argtypes = [_P, _P, _P, C.c_int64, _P, _P, C.c_int64, _P, C.c_int]
@@ -199,10 +204,14 @@ class OracleICP:
         return err, T_from_c(T)
 
 
-def surface_normals(cloud, knn=5, nthreads=1):
+def surface_normals(cloud, knn=5, nthreads=1, with_densities=False):
     lib = load(); cloud = _f32(cloud); out = np.empty((cloud.shape[0], 3), dtype=np.float32)
-    lib.orc_surface_normals(cloud.ctypes.data, cloud.shape[0], knn, out.ctypes.data, nthreads)
-    return out
+    if not with_densities:
+        lib.orc_surface_normals(cloud.ctypes.data, cloud.shape[0], knn, out.ctypes.data, nthreads)
+        return out
+    dens = np.empty(cloud.shape[0], dtype=np.float32)
+    lib.orc_surface_normals_ex(cloud.ctypes.data, cloud.shape[0], knn, out.ctypes.data, dens.ctypes.data, nthreads)
+    return out, dens
 
 
 def point_distance_keep(map_cloud, in_cloud, min_dist, nthreads=1):
@@ -240,6 +249,25 @@ def voxel_keep(cloud, edge, method):
     lib = load(); c = _f32(cloud); keep = np.zeros(c.shape[0], dtype=np.uint8)
     lib.orc_voxel_keep(c.ctypes.data, c.shape[0], edge, method, keep.ctypes.data)
     return keep.astype(bool)
+
+
+def random_sampling_keep(n, prob=0.75, method=0, seed=1):
+    lib = load(); keep = np.zeros(n, dtype=np.uint8)
+    lib.orc_random_sampling_keep(n, prob, method, seed, keep.ctypes.data)
+    return keep.astype(bool)
+
+
+def max_density_keep(densities, max_density=10.0, seed=1):
+    lib = load(); d = _f32(densities); keep = np.zeros(d.shape[0], dtype=np.uint8)
+    lib.orc_max_density_keep(d.ctypes.data, d.shape[0], max_density, seed, keep.ctypes.data)
+    return keep.astype(bool)
+
+
+def sampling_surface_normal(cloud, ratio=0.5, knn=7, max_box_dim=math.inf, seed=1):
+    """(kept indices in box order, their normals)"""
+    lib = load(); c = _f32(cloud); order = np.empty(c.shape[0], dtype=np.int32); nrm = np.empty((c.shape[0], 3), dtype=np.float32)
+    m = lib.orc_sampling_surface_normal(c.ctypes.data, c.shape[0], ratio, knn, max_box_dim, seed, order.ctypes.data, nrm.ctypes.data)
+    return order[:m].copy(), nrm[:m].copy()
 
 
 def octree_sample(cloud, max_size, max_pts=1, method=0):

@@ -1,0 +1,104 @@
+"""DataPointsFilters of the C++ host shell that the ICP chains use (PM::ICPSequence::setDefault: RandomSampling on the reading,
+SamplingSurfaceNormal on the reference; MaxDensity) against the oracle's restatements -- same std::minstd_rand streams, so the
+kept sets are identical.  CPU part: the host-only filters.  GPU part: densities from the device, the default chain end to end."""
+import os
+
+import numpy as np
+import pytest
+
+
+def _cloud(n, seed):
+    rng = np.random.default_rng(seed)
+    c = np.ones((n, 4), np.float32)
+    c[:, :3] = (rng.uniform(-1, 1, (n, 3)) * [20.0, 12.0, 0.4]).astype(np.float32)
+    c[: n // 3, 2] = 0.0                      # a flat patch: rank-2 boxes
+    return c
+
+
+@pytest.fixture(scope="module")
+def host():
+    import subprocess
+    import host_bindings as hb
+    if not os.path.exists(hb.LIB):
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "norlab_icp_mapper_amd", "csrc"), "-j8"])
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "norlab_icp_mapper_amd", "host"), "-j8"])
+    return hb
+
+
+@pytest.mark.parametrize("method", [0, 1])
+@pytest.mark.parametrize("prob,seed", [(0.75, 1), (0.2, 12345), (1.0, 3), (0.0, 9)])
+def test_random_sampling_equals_oracle(host, oracle, prob, seed, method):
+    c = _cloud(5000, 1)
+    out, _, _ = host.filter_chain(f"- RandomSamplingDataPointsFilter: {{prob: {prob}, randomSamplingMethod: {method}, seed: {seed}}}", c)
+    keep = oracle.random_sampling_keep(c.shape[0], prob, method, seed)
+    assert np.array_equal(out, c[keep])
+    assert out.shape[0] <= int(np.float32(c.shape[0]) * np.float32(prob)) + 1
+
+
+def test_sampling_surface_normal_equals_oracle(host, oracle):
+    for n, knn, ratio, seed in ((6000, 7, 0.5, 1), (3001, 12, 0.9, 5), (50, 7, 1.0, 2), (5, 7, 0.5, 1)):
+        c = _cloud(n, n)
+        out, nrm, _ = host.filter_chain(f"- SamplingSurfaceNormalDataPointsFilter: {{ratio: {ratio}, knn: {knn}, seed: {seed}}}", c)
+        order, onrm = oracle.sampling_surface_normal(c, ratio, knn, seed=seed)
+        assert np.array_equal(out, c[order]), (n, knn)
+        if order.shape[0]:
+            assert nrm is not None
+            dots = np.abs(np.einsum("ij,ij->i", nrm, onrm))
+            assert (dots > 1 - 1e-5).all()
+            assert np.allclose(np.linalg.norm(nrm, axis=1), 1.0, atol=1e-5)
+
+
+def test_max_density_equals_oracle(host, oracle):
+    c = _cloud(4000, 7)
+    rng = np.random.default_rng(2)
+    dens = rng.uniform(0.0, 40.0, c.shape[0]).astype(np.float32)
+    out, _, d = host.filter_chain("- MaxDensityDataPointsFilter: {maxDensity: 10, seed: 4}", c, desc_name="densities", desc=dens)
+    keep = oracle.max_density_keep(dens, 10.0, 4)
+    assert np.array_equal(out, c[keep]) and np.array_equal(d, dens[keep])
+    with pytest.raises(RuntimeError):
+        host.filter_chain("- MaxDensityDataPointsFilter: {maxDensity: 10}", c)          # no `densities`: InvalidField
+
+
+@pytest.mark.gpu
+def test_densities_and_max_density_chain_on_gpu(host, oracle):
+    import norlab_icp_mapper_amd as amd
+    sc = amd.synth.make_scene(m=60_000, n=10)
+    icp = amd.ICPSequence()
+    n_gpu, d_gpu = icp.surfaceNormals(sc["map"], knn=10, with_densities=True)
+    n_cpu, d_cpu = oracle.surface_normals(sc["map"], knn=10, nthreads=8, with_densities=True)
+    assert np.array_equal(d_gpu, d_cpu)                                                   # same neighbours, same double formula
+    out, nrm, _ = host.filter_chain("- SurfaceNormalDataPointsFilter: {knn: 10, keepDensities: 1}\n- MaxDensityDataPointsFilter: {maxDensity: 30, seed: 2}",
+                                    sc["map"], handle=icp._h.value if hasattr(icp._h, "value") else icp._h)
+    keep = oracle.max_density_keep(d_cpu, 30.0, 2)
+    assert np.array_equal(out, sc["map"][keep]) and 0 < keep.sum() < keep.shape[0]
+
+
+@pytest.mark.gpu
+def test_default_chain_reading_and_reference_filters(host, oracle, mid_scene, tmp_path):
+    """A configuration without an `icp:` key (Mapper.cpp:74-78): PM::ICPSequence::setDefault -- RandomSampling(0.75) on the reading,
+    SamplingSurfaceNormal on the map.  The C++ host shell registers what the oracle registers when it is given the oracle-filtered
+    clouds (the host's filters draw from std::random_device for seed -1, so the reading filter is pinned with a seed here)."""
+    import subprocess
+    import norlab_icp_mapper_amd as amd
+    sc = mid_scene
+    # the reference filter of the default chain on the map: host == oracle (kept set and normals)
+    icp = amd.ICPSequence()
+    href = icp._h.value if hasattr(icp._h, "value") else icp._h
+    m_out, m_nrm, _ = host.filter_chain("- SamplingSurfaceNormalDataPointsFilter", sc["map"], handle=href)
+    order, onrm = oracle.sampling_surface_normal(sc["map"], 0.5, 7, seed=1)
+    assert np.array_equal(m_out, sc["map"][order])
+    r_out, _, _ = host.filter_chain("- RandomSamplingDataPointsFilter: {prob: 0.75, seed: 11}", sc["scan"])
+    keep = oracle.random_sampling_keep(sc["scan"].shape[0], 0.75, 0, 11)
+    assert np.array_equal(r_out, sc["scan"][keep])
+    # the default chain on those clouds: GPU vs oracle
+    kw = dict(minimizer=2, outliers=[(4, 0.85)], max_iterations=40, use_differential=1)        # knn 1, maxDist inf
+    g = amd.ICPSequence(**kw); g.setMap(m_out, m_nrm)
+    T = g(r_out)
+    o = oracle.OracleICP(oracle.make_config(nthreads=8, **kw)); o.setMap(m_out, onrm)
+    err, T_ref = o(r_out)
+    assert err == 0 and g.stats.iterations == o.stats.iterations
+    dt, dr = amd.synth.pose_error(T, T_ref)
+    assert dt <= 1e-4 and dr <= 1e-4, (dt, dr)
+    gt, gr = amd.synth.pose_error(T, sc["T_gt"])
+    assert gt < 1e-2 and gr < 1e-3, (gt, gr)
