@@ -1,0 +1,143 @@
+// sharded_mapping -- BASELINE config 5 in C++: one process per GPU, independent scans of the examples/ trajectory sharded over
+// the ranks, the accepted points all-gathered over RCCL inside libicpmi.so and merged into every rank's map replica and
+// CellManager (norlab_icp_mapper_amd/host/ShardedMapper.h).
+//
+//   RANK=r WORLD_SIZE=N LOCAL_RANK=g ICPMI_COMM_FILE=/tmp/id  sharded_mapping <data dir> <config.yaml> [minDistNewPoint] [normalsKnn]
+//
+// <data dir> as the reference's example: scans/*.vtk + trajectory.csv, paired in lexicographic order (examples/
+// build_map_from_scans_and_trajectory.cpp:191).  The first scan seeds the map on every rank; afterwards epoch e hands scan
+// 1 + e N + r to rank r.  Rank 0 writes the communicator id to ICPMI_COMM_FILE, the others wait for it (any launcher works:
+// the id is the only thing the ranks share besides the file system).  With WORLD_SIZE unset it is one rank and no RCCL.
+#include <dirent.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../norlab_icp_mapper_amd/host/Mapper.h"
+#include "../norlab_icp_mapper_amd/host/ShardedMapper.h"
+
+using namespace nim;
+
+static std::vector<Mat4> readPoses(const std::string& path)
+{
+    std::ifstream in(path);
+    if (!in) throw std::runtime_error("cannot open " + path);
+    std::vector<Mat4> out;
+    std::string line;
+    std::getline(in, line);
+    while (std::getline(in, line)) {
+        if (line.empty()) continue;
+        std::vector<std::string> f;
+        std::stringstream ss(line);
+        std::string tok;
+        while (std::getline(ss, tok, ',')) f.push_back(tok);
+        if (f.size() < 11) throw std::runtime_error("malformed trajectory row");
+        const double x = std::stod(f[4]), y = std::stod(f[5]), z = std::stod(f[6]);
+        const double qx = std::stod(f[7]), qy = std::stod(f[8]), qz = std::stod(f[9]), qw = std::stod(f[10]);
+        Mat4 T = Mat4::identity();
+        T(0, 0) = (float)(1 - 2 * (qy * qy + qz * qz)); T(0, 1) = (float)(2 * (qx * qy - qz * qw)); T(0, 2) = (float)(2 * (qx * qz + qy * qw));
+        T(1, 0) = (float)(2 * (qx * qy + qz * qw)); T(1, 1) = (float)(1 - 2 * (qx * qx + qz * qz)); T(1, 2) = (float)(2 * (qy * qz - qx * qw));
+        T(2, 0) = (float)(2 * (qx * qz - qy * qw)); T(2, 1) = (float)(2 * (qy * qz + qx * qw)); T(2, 2) = (float)(1 - 2 * (qx * qx + qy * qy));
+        T(0, 3) = (float)x; T(1, 3) = (float)y; T(2, 3) = (float)z;
+        out.push_back(T);
+    }
+    return out;
+}
+
+static std::vector<std::string> listScans(const std::string& dir)
+{
+    std::vector<std::string> files;
+    DIR* d = opendir(dir.c_str());
+    if (!d) throw std::runtime_error("cannot open " + dir);
+    while (dirent* e = readdir(d)) {
+        const std::string name = e->d_name;
+        if (name.size() > 4 && name.substr(name.size() - 4) == ".vtk") files.push_back(dir + "/" + name);
+    }
+    closedir(d);
+    std::sort(files.begin(), files.end());
+    return files;
+}
+
+static int envInt(const char* k, int def) { const char* v = std::getenv(k); return v ? std::atoi(v) : def; }
+
+int main(int argc, char** argv)
+{
+    if (argc < 3) { std::fprintf(stderr, "usage: %s <data dir> <config.yaml> [minDistNewPoint] [normalsKnn]\n", argv[0]); return 2; }
+    try {
+        const int rank = envInt("RANK", 0), world = envInt("WORLD_SIZE", 1), local = envInt("LOCAL_RANK", rank);
+        const std::string dataDir = argv[1];
+        const float minDist = argc > 3 ? (float)std::atof(argv[3]) : 0.15f;
+        const int knn = argc > 4 ? std::atoi(argv[4]) : 10;
+        std::ifstream cfgFile(argv[2]);
+        if (!cfgFile) throw std::runtime_error(std::string("cannot open ") + argv[2]);
+        std::stringstream cfgText; cfgText << cfgFile.rdbuf();
+        const yaml::Node cfg = yaml::Load(cfgText.str());
+        ShardedMapper mapper(cfg["icp"], minDist, knn, local);
+        if (world > 1) {
+            const char* file = std::getenv("ICPMI_COMM_FILE");
+            if (!file) throw std::runtime_error("ICPMI_COMM_FILE must name a file all ranks can reach");
+            icpmi_comm_id id;
+            if (rank == 0) {
+                id = ShardedMapper::createCommunicatorId();
+                const std::string tmp = std::string(file) + ".tmp";
+                { std::ofstream o(tmp, std::ios::binary); o.write(id.bytes, sizeof id.bytes); }
+                std::rename(tmp.c_str(), file);
+            } else {
+                for (int tries = 0;; ++tries) {
+                    std::ifstream i(file, std::ios::binary);
+                    if (i && i.read(id.bytes, sizeof id.bytes)) break;
+                    if (tries > 6000) throw std::runtime_error("no communicator id in ICPMI_COMM_FILE after 60 s");
+                    usleep(10000);
+                }
+            }
+            mapper.initCommunicator(id, world, rank);
+        }
+        const auto poses = readPoses(dataDir + "/trajectory.csv");
+        const auto scans = listScans(dataDir + "/scans");
+        if (poses.size() != scans.size() || scans.empty()) throw std::runtime_error("trajectory rows and scan files differ in number");
+        // the mapper's own input filters (radius + the `input:` chain) through a Mapper-less path: DataPointsFilters of the configuration
+        DataPointsFilters inputFilters(cfg["input"], nullptr);
+        auto load = [&](size_t i) { DataPoints c = DataPoints::load(scans[i]); inputFilters.apply(c); return c; };
+        {   // the first scan seeds the map, identically on every rank
+            DataPoints first = load(0);
+            DataPoints inMap = first;
+            for (size_t i = 0; i < first.getNbPoints(); ++i) {
+                const float* p = first.col(i); float* q = inMap.col(i);
+                for (int r = 0; r < 3; ++r) q[r] = poses[0](r, 0) * p[0] + poses[0](r, 1) * p[1] + poses[0](r, 2) * p[2] + poses[0](r, 3);
+            }
+            mapper.setMap(inMap);
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        size_t done = 0;
+        for (size_t e = 0; 1 + e * (size_t)world + (size_t)rank < scans.size(); ++e) {
+            const size_t i = 1 + e * (size_t)world + (size_t)rank;
+            const DataPoints cloud = load(i);
+            const Mat4 pose = mapper.processScan(cloud, poses[i]);
+            ++done;
+            std::printf("rank %d epoch %zu scan %zu: %zu pts, pose %.4f %.4f %.4f, iterations %d, %ld accepted here, %ld appended by all ranks, map %ld\n",
+                        rank, e, i, cloud.getNbPoints(), pose(0, 3), pose(1, 3), pose(2, 3), mapper.lastIcpStats().iterations,
+                        (long)mapper.lastAcceptedLocal(), (long)mapper.lastAppended(), (long)mapper.mapSize());
+        }
+        // ranks with one scan fewer still take part in the last epoch's collective (an empty contribution)
+        if (world > 1) {
+            const size_t epochs = (scans.size() - 1 + (size_t)world - 1) / (size_t)world;
+            if (done < epochs) { DataPoints none(0); mapper.processScan(none, Mat4::identity()); }
+        }
+        const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        size_t cellPts = 0;
+        for (const auto& id : mapper.cells().getAllCellIds()) cellPts += mapper.cells().retrieveCell(id).getNbPoints();
+        std::printf("rank %d: %zu scans in %.3f s, map %ld points, %zu cells holding %zu merged points\n", rank, done, secs, (long)mapper.mapSize(),
+                    mapper.cells().getAllCellIds().size(), cellPts);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -339,6 +339,28 @@ icpmi_status icpmi_filter_points(icpmi_handle h, const float* in4, int64_t n, co
 /* `Map::unloadCells` binning (Map.cpp:206-209,232-235): ijk3[3 i + r] = floor(p_r / cell_size). */
 icpmi_status icpmi_bin_cells(icpmi_handle h, const float* pts4, int64_t n, float cell_size, int32_t* ijk3);
 
+/* ---- multi-GPU: scan-sharded mapping (BASELINE config 5) ----
+ * One process and one handle per GPU, the map replicated, every rank registering its own scan stream; the one exchange is map
+ * growth: the points every rank accepted are all-gathered over RCCL (xGMI) so that all replicas append the same set -- what a
+ * host then bins into 20 m cells for its CellManager (Map.cpp:206-229).  No reference analogue (the reference is one process).
+ *   icpmi_comm_get_unique_id  rank 0 creates the id (an ncclUniqueId); the application hands it to the other ranks
+ *   icpmi_comm_init           collective over all ranks: ncclCommInitRank on the handle's device
+ *   icpmi_staged_merge_allgather  one map-growth epoch, entirely on the device: the scan staged by icpmi_register_prior is moved
+ *       by `correction` (Mapper.cpp:221); the points at least min_dist from the resident map are compacted
+ *       (PointDistanceMapperModule.cpp:33-42); counts, then the padded point blocks, are all-gathered on the handle's stream;
+ *       the blocks are merged in rank order, block r keeping only the points that are at least min_dist from the points
+ *       accepted from ranks < r (exactly what one mapper would have appended had it processed the scans in rank order);
+ *       the merged set is appended to the resident map, its normals recomputed (normals_knn > 0) and the index rebuilt.
+ *       No accepted point crosses PCIe unless merged_out4 (capacity merged_capacity points) asks for the merged set.
+ *       Without a communicator the handle is its own single rank. */
+typedef struct icpmi_comm_id { char bytes[128]; } icpmi_comm_id;
+icpmi_status icpmi_comm_get_unique_id(icpmi_comm_id* id);
+icpmi_status icpmi_comm_init(icpmi_handle h, const icpmi_comm_id* id, int32_t n_ranks, int32_t rank);
+icpmi_status icpmi_comm_destroy(icpmi_handle h);
+icpmi_status icpmi_staged_merge_allgather(icpmi_handle h, const float correction[16], float min_dist, int32_t normals_knn,
+                                          int64_t* accepted_local, int64_t* appended_total, int64_t* new_m, float* merged_out4,
+                                          int64_t merged_capacity, int64_t* merged_n);
+
 /* ---- plumbing ---- */
 /* Use an externally owned hipStream_t (e.g. torch's current stream) instead of the handle's own. */
 icpmi_status icpmi_set_stream(icpmi_handle h, void* hip_stream);

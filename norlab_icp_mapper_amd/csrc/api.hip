@@ -130,6 +130,7 @@ void icpmi_destroy(icpmi_handle c)
     if (!c) return;
     if (c->temp) { icpmi_destroy(c->temp); c->temp = nullptr; }
     hipSetDevice(c->device);
+    comm_destroy(c);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
     if (c->bgraph_exec) hipGraphExecDestroy(c->bgraph_exec);
@@ -140,7 +141,7 @@ void icpmi_destroy(icpmi_handle c)
     hipFree(c->d_qsorted); hipFree(c->d_qindex); hipFree(c->d_qkeys); hipFree(c->d_qtile);
     hipFree(c->d_reading); hipFree(c->d_read_normals); hipFree(c->d_stage_in); hipFree(c->d_stage_n3);
     hipFree(c->d_match_pt); hipFree(c->d_lvl_tab); hipFree(c->d_raw); hipFree(c->d_raw_n3); hipFree(c->d_raw_s); hipFree(c->d_src); hipFree(c->d_alt_raw); hipFree(c->d_alt_n3);
-    hipFree(c->d_alt_s); hipFree(c->d_alt_src); hipFree(c->d_stage_s);
+    hipFree(c->d_alt_s); hipFree(c->d_alt_src); hipFree(c->d_stage_s); hipFree(c->d_merge_send); hipFree(c->d_merge_recv); hipFree(c->d_merged);
     for (int k = 0; k < 10; ++k) hipFree(c->scratch[k]); hipFree(c->d_scan_map); hipFree(c->d_T16);
     hipFree(c->d_sidx); hipFree(c->d_d2); hipFree(c->d_hard); hipFree(c->d_partials); hipFree(c->d_selhist);
     hipFree(c->d_state);
@@ -487,6 +488,37 @@ icpmi_status icpmi_staged_point_distance_keep(icpmi_handle h, const float correc
     if (!correction || !keep_out || !(min_dist >= 0.f)) { h->last_error = "staged_point_distance_keep: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
     if (h->scan_map_n <= 0) { h->last_error = "staged_point_distance_keep: no scan staged by icpmi_register_prior"; return ICPMI_ERR_INVALID_ARG; }
     return ops_staged_keep(h, correction, min_dist, keep_out, placed_out4);
+}
+
+icpmi_status icpmi_comm_get_unique_id(icpmi_comm_id* id)
+{
+    if (!id) { g_create_error = "comm_get_unique_id: null argument"; return ICPMI_ERR_INVALID_ARG; }
+    return comm_unique_id(id, g_create_error);
+}
+
+icpmi_status icpmi_comm_init(icpmi_handle h, const icpmi_comm_id* id, int32_t n_ranks, int32_t rank)
+{
+    CHECK_H(h);
+    if (!id || n_ranks < 1 || rank < 0 || rank >= n_ranks) { h->last_error = "comm_init: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
+    return comm_init(h, id, n_ranks, rank);
+}
+
+icpmi_status icpmi_comm_destroy(icpmi_handle h)
+{
+    CHECK_H(h);
+    return comm_destroy(h);
+}
+
+icpmi_status icpmi_staged_merge_allgather(icpmi_handle h, const float correction[16], float min_dist, int32_t normals_knn,
+                                          int64_t* accepted_local, int64_t* appended_total, int64_t* new_m, float* merged_out4,
+                                          int64_t merged_capacity, int64_t* merged_n)
+{
+    CHECK_H(h);
+    if (!correction || !(min_dist >= 0.f) || normals_knn < 0 || normals_knn > ICPMI_MAX_K || merged_capacity < 0) {
+        h->last_error = "staged_merge_allgather: bad arguments"; return ICPMI_ERR_INVALID_ARG;
+    }
+    if (h->scan_map_n <= 0 && !h->comm) { h->last_error = "staged_merge_allgather: no scan staged by icpmi_register_prior"; return ICPMI_ERR_INVALID_ARG; }
+    return ops_staged_merge_allgather(h, correction, min_dist, normals_knn, accepted_local, appended_total, new_m, merged_out4, merged_capacity, merged_n);
 }
 
 icpmi_status icpmi_get_map(icpmi_handle h, float* out4, float* normals3, int64_t capacity, int64_t* m)

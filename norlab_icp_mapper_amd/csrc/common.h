@@ -225,6 +225,13 @@ struct icpmi_ctx {
     hipGraphExec_t graph_exec = nullptr;
     int64_t graph_n = -1; int graph_iters = -1; uint64_t graph_sig = 0;
     hipGraphExec_t bgraph_exec = nullptr; uint64_t bgraph_sig = 0; // ... and of one batched registration
+
+    // buffers of the map-growth epoch (ops.hip: ops_staged_merge_allgather): this rank's accepted points, all ranks' blocks, the merged set
+    float4* d_merge_send = nullptr; size_t cap_merge_send = 0;
+    float4* d_merge_recv = nullptr; size_t cap_merge_recv = 0;
+    float4* d_merged = nullptr; size_t cap_merged = 0;
+    // RCCL communicator of the scan-sharded mapping mode (comm.hip); null = a single rank
+    void* comm = nullptr; int comm_ranks = 1, comm_rank = 0;
 };
 
 #define HIP_TRY(ctx, expr)                                                                     \
@@ -374,6 +381,12 @@ icpmi_status ops_voxel_keep_first(icpmi_ctx* c, const float* in4, int64_t n, flo
 icpmi_status ops_point_distance_keep(icpmi_ctx* c, const float* map4, int64_t m, const float* in4, int64_t n,
                                      float min_dist, uint8_t* keep);
 icpmi_status ops_bin_cells(icpmi_ctx* c, const float* pts4, int64_t n, float cell_size, int32_t* ijk3);
+icpmi_status comm_unique_id(icpmi_comm_id* id, std::string& err);
+icpmi_status comm_init(icpmi_ctx* c, const icpmi_comm_id* id, int n_ranks, int rank);
+icpmi_status comm_destroy(icpmi_ctx* c);
+icpmi_status comm_allgather(icpmi_ctx* c, const void* d_send, void* d_recv, size_t count, bool is_float);
+icpmi_status ops_staged_merge_allgather(icpmi_ctx* c, const float correction[16], float min_dist, int normals_knn, int64_t* accepted_local,
+                                        int64_t* appended_total, int64_t* new_m, float* merged_out4, int64_t merged_capacity, int64_t* merged_n);
 icpmi_status octree_sample_dev(icpmi_ctx* c, const float4* d_in, int64_t n, float max_size, int max_pts, int method, int* d_order, int* d_leaf_of,
                                int64_t* n_out);
 icpmi_status ops_octree_sample(icpmi_ctx* c, const float* in4, int64_t n, float max_size, int max_pts, int method, int32_t* order_out,

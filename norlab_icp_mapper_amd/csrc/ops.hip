@@ -1233,6 +1233,132 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
     return ICPMI_OK;
 }
 
+// stable compaction of the flagged points of `in` behind position `base` of `out`
+__global__ __launch_bounds__(256) void merge_compact_kernel(const float4* __restrict__ in, int64_t n, const unsigned* __restrict__ flag,
+                                                            const unsigned* __restrict__ pos, float4* __restrict__ out, int64_t base)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    out[base + pos[i]] = in[i];
+}
+
+// flags -> kept points appended to d_out[base ...): returns how many (one small read-back)
+static icpmi_status merge_append_flagged(icpmi_ctx* c, const float4* d_in, int64_t n, unsigned* d_flag, unsigned* d_pos, float4* d_out, int64_t base,
+                                         int64_t* kept)
+{
+    *kept = 0;
+    if (n == 0) return ICPMI_OK;
+    HIP_TRY(c, hipMemcpyAsync(d_pos, d_flag, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToDevice, c->stream));
+    icpmi_status s = device_exclusive_scan(c, d_pos, (int)n, 0u);
+    if (s != ICPMI_OK) return s;
+    hipLaunchKernelGGL(merge_compact_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, d_in, n, (const unsigned*)d_flag, (const unsigned*)d_pos,
+                       d_out, base);
+    HIP_TRY(c, hipGetLastError());
+    unsigned lp = 0, lf = 0;
+    if (read_back2(c, &lp, d_pos + (n - 1), sizeof(unsigned), &lf, d_flag + (n - 1), sizeof(unsigned)) != ICPMI_OK) return ICPMI_ERR_HIP;
+    *kept = (int64_t)lp + lf;
+    return ICPMI_OK;
+}
+
+// One map-growth epoch of the scan-sharded mapper (include/icpmi.h: icpmi_staged_merge_allgather), device-resident.
+icpmi_status ops_staged_merge_allgather(icpmi_ctx* c, const float correction[16], float min_dist, int normals_knn, int64_t* accepted_local,
+                                        int64_t* appended_total, int64_t* new_m, float* merged_out4, int64_t merged_capacity, int64_t* merged_n)
+{
+    if (accepted_local) *accepted_local = 0;
+    if (appended_total) *appended_total = 0;
+    if (merged_n) *merged_n = 0;
+    if (new_m) *new_m = c->m > 0 ? c->m_raw : 0;
+    const int R = c->comm ? c->comm_ranks : 1;
+    const int64_t n = c->scan_map_n;
+    // ---- this rank's accepted points: the staged scan moved by the correction (Mapper.cpp:221), PointDistance against the resident map
+    unsigned* d_flag = scratch_get<unsigned>(c, 6, (size_t)n + 2);
+    unsigned* d_pos = scratch_get<unsigned>(c, 7, (size_t)n + 2);
+    if (!d_flag || !d_pos) return ICPMI_ERR_HIP;
+    int64_t mine = 0;
+    if (ensure_cap(c, &c->d_stage_in, &c->cap_stage_in, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (ensure_cap(c, &c->d_merge_send, &c->cap_merge_send, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    // (a failure on this rank must not leave the others waiting in the collective: it travels as a negative count)
+    icpmi_status local = ICPMI_OK;
+    if (n > 0) {
+        local = ops_transform_dev(c, correction, c->d_scan_map, n, c->d_stage_in);
+        if (local == ICPMI_OK) {
+            if (c->m > 0) {
+                local = chain_point_distance_flags(c, c, c->d_stage_in, n, min_dist, d_flag);
+                if (local == ICPMI_OK) local = merge_append_flagged(c, c->d_stage_in, n, d_flag, d_pos, c->d_merge_send, 0, &mine);
+            } else { // no map yet: every point is new
+                if (hipMemcpyAsync(c->d_merge_send, c->d_stage_in, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream) != hipSuccess) local = ICPMI_ERR_HIP;
+                mine = n;
+            }
+        }
+    }
+    const std::string local_error = c->last_error;
+    if (accepted_local) *accepted_local = local == ICPMI_OK ? mine : 0;
+    // ---- counts of all ranks
+    long long* d_cnt = scratch_get<long long>(c, 8, (size_t)R + 8);
+    if (!d_cnt) return ICPMI_ERR_HIP;
+    long long hmine = local == ICPMI_OK ? mine : -1;
+    HIP_TRY(c, hipMemcpyAsync(d_cnt + R, &hmine, sizeof hmine, hipMemcpyHostToDevice, c->stream));
+    icpmi_status s = comm_allgather(c, d_cnt + R, d_cnt, 1, false);
+    if (s != ICPMI_OK) return s;
+    std::vector<long long> counts((size_t)R);
+    if (read_back(c, counts.data(), d_cnt, sizeof(long long) * (size_t)R) != ICPMI_OK) return ICPMI_ERR_HIP;
+    long long maxc = 0, total = 0;
+    for (int r = 0; r < R; ++r)
+        if (counts[(size_t)r] < 0) { // every rank leaves the epoch together
+            if (local != ICPMI_OK) { c->last_error = local_error; return local; }
+            c->last_error = "staged_merge_allgather: rank " + std::to_string(r) + " failed before the exchange";
+            return ICPMI_ERR_HIP;
+        }
+    for (long long v : counts) { maxc = v > maxc ? v : maxc; total += v; }
+    if (total == 0) { if (new_m) *new_m = c->m > 0 ? c->m_raw : 0; return ICPMI_OK; }
+    // ---- the point blocks, padded to the largest (one all-gather; the payload is a few MB at most: latency, not bandwidth)
+    if (ensure_cap_keep(c, &c->d_merge_send, &c->cap_merge_send, (size_t)maxc + 1, (size_t)mine) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (ensure_cap(c, &c->d_merge_recv, &c->cap_merge_recv, (size_t)maxc * R + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (ensure_cap(c, &c->d_merged, &c->cap_merged, (size_t)total + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    s = comm_allgather(c, c->d_merge_send, c->d_merge_recv, (size_t)maxc * 4, true);
+    if (s != ICPMI_OK) return s;
+    // ---- merge in rank order; block r keeps what is at least min_dist from the points accepted from ranks < r
+    int64_t acc = 0;
+    for (int r = 0; r < R; ++r) {
+        const int64_t cr = counts[(size_t)r];
+        if (cr == 0) continue;
+        const float4* blk = c->d_merge_recv + (size_t)r * (size_t)maxc;
+        if (acc == 0 || !(min_dist > 0.f)) {
+            HIP_TRY(c, hipMemcpyAsync(c->d_merged + acc, blk, (size_t)cr * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+            acc += cr;
+            continue;
+        }
+        TempCtx t;
+        s = make_temp(c, t);
+        if (s != ICPMI_OK) return s;
+        HIP_TRY(c, hipStreamSynchronize(c->stream)); // the private handle works on its own stream
+        int32_t ok = 0;
+        s = icpmi_set_map_dev(t.h, (const float*)c->d_merged, acc, nullptr, &ok);
+        if (s != ICPMI_OK) { c->last_error = t.h->last_error; return s; }
+        unsigned* f2 = scratch_get<unsigned>(c, 6, (size_t)cr + 2);
+        unsigned* p2 = scratch_get<unsigned>(c, 7, (size_t)cr + 2);
+        if (!f2 || !p2) return ICPMI_ERR_HIP;
+        s = chain_point_distance_flags(c, t.h, blk, cr, min_dist, f2);
+        int64_t kept = 0;
+        if (s == ICPMI_OK) s = merge_append_flagged(c, blk, cr, f2, p2, c->d_merged, acc, &kept);
+        if (s != ICPMI_OK) return s;
+        acc += kept;
+    }
+    if (merged_n) *merged_n = acc;
+    if (merged_out4) {
+        if (merged_capacity < acc) { c->last_error = "staged_merge_allgather: merged_capacity too small"; return ICPMI_ERR_INVALID_ARG; }
+        HIP_TRY(c, hipMemcpyAsync(merged_out4, c->d_merged, (size_t)acc * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    }
+    // ---- every replica appends the same set (all points kept: the distance tests are done), normals, index
+    int64_t app = 0, m1 = 0;
+    s = ops_map_update_dev(c, c->d_merged, acc, nullptr, 0.f, normals_knn, nullptr, &app, &m1);
+    if (s != ICPMI_OK) return s;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (appended_total) *appended_total = app;
+    if (new_m) *new_m = m1;
+    return ICPMI_OK;
+}
+
 icpmi_status ops_staged_keep(icpmi_ctx* c, const float correction[16], float min_dist, uint8_t* keep_out, float* placed_out4)
 {
     const int64_t n = c->scan_map_n;

@@ -85,13 +85,18 @@ class ShardedMapper:
     Every rank holds a replica of the map and its own scan stream.  One epoch = every rank registers one scan
     against the shared map (`Mapper::processInput`, Mapper.cpp:194-238, with the prior applied first), keeps the
     points that are at least `min_dist_new_point` away from the map (`PointDistanceMapperModule`, .cpp:28-50), the
-    accepted points are all-gathered in rank order, de-duplicated across ranks on a `min_dist_new_point` lattice
-    (first point per voxel: deterministic, identical on all ranks), appended, and every rank rebuilds its replica
-    with the identical cloud (`icp.setMap`, Map.cpp:528).  No collective touches the per-iteration path.
+    accepted points are all-gathered in rank order and merged block by block: block r keeps the points that are at
+    least `min_dist_new_point` from the points accepted from ranks < r (the exact PointDistance rule again: what one
+    mapper would have appended had it processed the scans in rank order -- identical on all ranks), appended, and
+    every rank rebuilds its replica with the identical cloud (`icp.setMap`, Map.cpp:528).  No collective touches the
+    per-iteration path.
 
-    `backend` provides the four operators; by default they are the GPU ones of an `ICPSequence`:
-        register(scan_in_map_frame) -> 4x4 correction, set_map(cloud, normals), keep(map, cloud, min_dist) -> bool mask,
-        normals(cloud, knn) -> (M, 3), dedup(cloud, edge) -> bool mask.
+    `backend` provides the operators; three are built in:
+        gpu_backend      host arrays between the C-ABI operators, torch.distributed moves the accepted points
+        resident_backend the map stays in HBM, torch.distributed moves the accepted points
+        device_backend   the whole epoch inside the library: RCCL all-gather on the handle's stream, merge and append on
+                         the device (`icpmi_staged_merge_allgather`) -- no accepted point crosses PCIe
+    (and the tests inject the CPU oracle's operators over gloo).
     """
 
     def __init__(self, backend, min_dist_new_point=0.15, normals_knn=0, group=None):
@@ -111,7 +116,6 @@ class ShardedMapper:
             set_map = staticmethod(lambda cloud, normals: icp.setMap(cloud, normals))
             keep = staticmethod(lambda m, c, d: icp.pointDistanceKeep(m, c, d))
             normals = staticmethod(lambda cloud, knn: icp.surfaceNormals(cloud, knn))
-            dedup = staticmethod(lambda cloud, edge: icp.voxelKeepFirst(cloud, edge))
         return _B
 
     @staticmethod
@@ -128,9 +132,45 @@ class ShardedMapper:
             append = staticmethod(lambda pts, knn: icp.mapUpdatePointDistance(pts, 0.0, normals_knn=knn))
             set_map = staticmethod(lambda cloud, normals: icp.setMap(cloud, normals))
             normals = staticmethod(lambda cloud, knn: icp.surfaceNormals(cloud, knn))
-            dedup = staticmethod(lambda cloud, edge: icp.voxelKeepFirst(cloud, edge))
+            keep = staticmethod(lambda m, c, d: icp.pointDistanceKeep(m, c, d))
             get_map = staticmethod(lambda: icp.getMap())
         return _R
+
+    @staticmethod
+    def device_backend(icp, group=None):
+        """The epoch inside libicpmi.so: the library owns an RCCL communicator (created here from an id that rank 0 makes and
+        torch.distributed hands round once) and runs the exchange, the rank-ordered merge and the append on the device."""
+        world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        rank = dist.get_rank(group) if world > 1 else 0
+        if world > 1:
+            box = [icp.commUniqueId() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            icp.commInit(box[0], world, rank)
+
+        class _D:
+            resident = True
+            device_merge = True
+            register_prior = staticmethod(lambda scan, prior: icp.registerWithPrior(scan, prior))
+            merge = staticmethod(lambda correction, d, knn: icp.stagedMergeAllGather(correction, d, normals_knn=knn))
+            set_map = staticmethod(lambda cloud, normals: icp.setMap(cloud, normals))
+            normals = staticmethod(lambda cloud, knn: icp.surfaceNormals(cloud, knn))
+            get_map = staticmethod(lambda: icp.getMap())
+        return _D
+
+    def _merge_blocks(self, merged, counts):
+        """rank-ordered exact merge: block r keeps what is at least min_dist from the points accepted from ranks < r"""
+        if len(counts) <= 1 or not (self.min_dist > 0):
+            return merged
+        out, off = None, 0
+        for c in counts:
+            blk = merged[off:off + c]; off += c
+            if c == 0:
+                continue
+            if out is None:
+                out = blk
+            else:
+                out = np.concatenate([out, blk[self.backend.keep(out, np.ascontiguousarray(blk), self.min_dist)]], axis=0)
+        return merged[:0] if out is None else np.ascontiguousarray(out)
 
     def get_map(self):
         """The replica's map (downloaded from the device in resident mode)."""
@@ -139,18 +179,21 @@ class ShardedMapper:
     def _epoch_resident(self, scan, prior):
         correction = self.backend.register_prior(scan, prior)               # identity while there is no map; stages the scan
         self.pose = (np.asarray(correction, dtype=np.float64) @ np.asarray(prior, dtype=np.float64)).astype(np.float32)
+        if getattr(self.backend, "device_merge", False):
+            mine_n, appended, m1 = self.backend.merge(correction, self.min_dist, self.normals_knn)
+            self._resident_points = m1
+            return self.pose, mine_n, appended
         mask, placed = self.backend.staged_keep(correction, self.min_dist)
         mine = placed[mask]
         if dist.is_available() and dist.is_initialized():
             t = torch.from_numpy(np.ascontiguousarray(mine))
             if dist.get_backend(self.group) == "nccl":
                 t = t.cuda()
-            merged, _ = allgather_points(t, group=self.group)
-            merged = merged.cpu().numpy()
+            merged, counts = allgather_points(t, group=self.group)
+            merged = self._merge_blocks(merged.cpu().numpy(), counts)
         else:
             merged = mine
         if merged.shape[0]:
-            merged = merged[self.backend.dedup(merged, self.min_dist)]
             self.backend.append(np.ascontiguousarray(merged), self.normals_knn)
             self._resident_points += int(merged.shape[0])
         return self.pose, int(mine.shape[0]), int(merged.shape[0])
@@ -187,11 +230,10 @@ class ShardedMapper:
             if dist.get_backend(self.group) == "nccl":            # RCCL moves device tensors
                 t = t.cuda()
             merged, counts = allgather_points(t, group=self.group)
-            merged = merged.cpu().numpy()
+            merged = self._merge_blocks(merged.cpu().numpy(), counts)      # points of different ranks closer than min_dist
         else:
             merged = mine
         if merged.shape[0]:
-            merged = merged[self.backend.dedup(merged, self.min_dist)]       # points of different ranks closer than min_dist
             new_map = np.concatenate([self.map, merged], axis=0)
             self.set_map(new_map, None)
         self._resident_points = int(self.map.shape[0])

@@ -2,6 +2,8 @@
 // ICP object; cell paging is host logic over value-type clouds exactly like the reference.
 #include "Map.h"
 
+#include <functional>
+
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -117,20 +119,26 @@ void Map::unloadCells(Box box)
         localPointCloudEmpty.store(localPointCloud.getNbPoints() == 0);
         newLocalPointCloudAvailable = true;
     }
-    // bin what left into 20 m cells; saveCell overwrites (RAMCellManager.cpp:13-16)
-    std::unordered_map<std::string, std::vector<uint8_t>> members;
-    const size_t nOld = oldChunk.getNbPoints();
-    for (size_t i = 0; i < nOld; ++i) {
-        const float* p = oldChunk.col(i);
-        auto& mask = members[cellId(toGridCoordinate(p[0]), toGridCoordinate(p[1]), toGridCoordinate(p[2]))];
-        if (mask.empty()) mask.assign(nOld, 0);
-        mask[i] = 1;
-    }
-    for (auto& kv : members) {
-        DataPoints cell = oldChunk;
-        cell.keepOnly(kv.second);
+    // bin what left into 20 m cells; saveCell overwrites (RAMCellManager.cpp:13-16).  One pass: the rows of every cell are
+    // collected first, then each cell is built from its own rows only (O(points), like the reference's per-point appends).
+    binIntoCells(oldChunk, [&](const std::string& id, DataPoints&& cell) {
         std::lock_guard<std::mutex> g(cellManagerLock);
-        cellManager->saveCell(kv.first, cell);
+        cellManager->saveCell(id, cell);
+    });
+}
+
+void Map::binIntoCells(const DataPoints& cloud, const std::function<void(const std::string&, DataPoints&&)>& sink)
+{
+    std::unordered_map<std::string, std::vector<size_t>> rows;
+    const size_t n = cloud.getNbPoints();
+    for (size_t i = 0; i < n; ++i) {
+        const float* p = cloud.col(i);
+        rows[cellId(toGridCoordinate(p[0]), toGridCoordinate(p[1]), toGridCoordinate(p[2]))].push_back(i);
+    }
+    for (auto& kv : rows) {
+        DataPoints cell = cloud.createSimilarEmpty(kv.second.size());
+        for (size_t i : kv.second) cell.appendColFrom(cloud, i);
+        sink(kv.first, std::move(cell));
     }
 }
 

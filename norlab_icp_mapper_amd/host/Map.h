@@ -5,6 +5,7 @@
 #include <atomic>
 #include <climits>
 #include <list>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -77,6 +78,8 @@ public:
     static int toGridCoordinate(float world) { return (int)std::floor(world / CELL_SIZE); }
     static int toInferiorGridCoordinate(float world, float range) { return (int)std::ceil(((world - range) / CELL_SIZE) - 1.0); }
     static int toSuperiorGridCoordinate(float world, float range) { return (int)std::floor((world + range) / CELL_SIZE); }
+    // the points of `cloud` grouped by 20 m cell (Map.cpp:206-229), every cell handed to `sink` once
+    static void binIntoCells(const DataPoints& cloud, const std::function<void(const std::string&, DataPoints&&)>& sink);
     static std::string cellId(int row, int column, int aisle) { return std::to_string(row) + "_" + std::to_string(column) + "_" + std::to_string(aisle); }
 
 private:

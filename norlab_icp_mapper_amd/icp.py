@@ -543,6 +543,38 @@ class ICPSequence:
         self._check(self._lib.icpmi_staged_point_distance_keep(self._h, Tc.ctypes.data, min_dist, keep.ctypes.data, placed.ctypes.data))
         return keep.astype(bool), placed
 
+    # ---- scan-sharded mapping: RCCL communicator + device-resident map-growth epoch ----
+    @staticmethod
+    def commUniqueId():
+        """rank 0: a fresh communicator id (128 bytes) to hand to the other ranks"""
+        lib = _capi.load()
+        buf = (C.c_char * 128)()
+        st = lib.icpmi_comm_get_unique_id(buf)
+        if st != _capi.ICPMI_OK:
+            raise HipError(lib.icpmi_last_error(None).decode())
+        return bytes(buf)
+
+    def commInit(self, unique_id, n_ranks, rank):
+        buf = (C.c_char * 128).from_buffer_copy(unique_id)
+        self._check(self._lib.icpmi_comm_init(self._h, buf, n_ranks, rank))
+
+    def commDestroy(self):
+        self._check(self._lib.icpmi_comm_destroy(self._h))
+
+    def stagedMergeAllGather(self, correction, min_dist, normals_knn=0, return_merged=False, merged_capacity=None):
+        """icpmi_staged_merge_allgather: (accepted on this rank, appended on every replica, new map size[, merged points])"""
+        Tc = _T_to_c(correction)
+        acc, app, new_m, mn = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        out = None
+        if return_merged:
+            cap = int(merged_capacity if merged_capacity is not None else 8 * max(self._staged_n, 1))
+            out = np.empty((cap, 4), dtype=np.float32)
+        self._check(self._lib.icpmi_staged_merge_allgather(self._h, Tc.ctypes.data, min_dist, normals_knn, C.byref(acc), C.byref(app), C.byref(new_m),
+                                                           None if out is None else out.ctypes.data, 0 if out is None else out.shape[0], C.byref(mn)))
+        if return_merged:
+            return int(acc.value), int(app.value), int(new_m.value), out[:mn.value].copy()
+        return int(acc.value), int(app.value), int(new_m.value)
+
     def getMap(self, with_normals=False):
         """The resident map in the caller's order (Map::getLocalPointCloud, Map.cpp:536-540)."""
         m = C.c_int64(0)

@@ -94,7 +94,6 @@ def _mapper_worker(rank, world, port, out_dir):
         set_map = staticmethod(lambda cloud, normals: oicp.setMap(cloud, normals))
         keep = staticmethod(lambda m, c, d: ob.point_distance_keep(m, c, d, nthreads=2))
         normals = staticmethod(lambda cloud, knn: ob.surface_normals(cloud, knn))
-        dedup = staticmethod(lambda cloud, edge: ob.voxel_keep_first(cloud, edge))
 
     sc = synth.make_scene(m=6000, n=1500, seed_scan=43 + 1000 * rank)      # one scan stream per rank, shared map
     mapper = ShardedMapper(Backend, min_dist_new_point=0.5)
@@ -103,7 +102,7 @@ def _mapper_worker(rank, world, port, out_dir):
     for epoch in range(2):
         pose, mine, appended = mapper.epoch(sc["scan"] if epoch == 0 else sc["scan"][::2], np.eye(4))
         sizes.append(mapper.map.shape[0]); poses.append(pose)
-    np.savez(os.path.join(out_dir, f"mapper{rank}.npz"), map=mapper.map, sizes=np.array(sizes), pose=poses[0], T_gt=sc["T_gt"])
+    np.savez(os.path.join(out_dir, f"mapper{rank}.npz"), map=mapper.map, sizes=np.array(sizes), pose=poses[0], T_gt=sc["T_gt"], base=sc["map"].shape[0])
     dist.barrier()
     dist.destroy_process_group()
 
@@ -118,7 +117,17 @@ def test_sharded_mapper_replicas_stay_identical(tmp_path):
     assert np.array_equal(r[0]["sizes"], r[1]["sizes"])
     assert r[0]["sizes"][1] > r[0]["sizes"][0]                 # the map grew in the first epoch
     assert r[0]["sizes"][2] - r[0]["sizes"][1] < r[0]["sizes"][1] - r[0]["sizes"][0]  # the second epoch sees mostly known surface
-    # appended points respect the minimum distance among themselves (lattice de-dup) and to the old map (keep mask)
+    # PointDistanceMapperModule's invariant holds on the merged map as it would after one mapper had taken the scans in rank
+    # order: every appended point is at least minDistNewPoint from the old map, and a point of a later rank at least that
+    # far from the points accepted from the earlier ranks
+    import oracle_bindings as ob
+    m = r[0]["map"]; base = int(r[0]["base"]); first = int(r[0]["sizes"][1])
+    grown = m[base:first]
+    assert ob.point_distance_keep(m[:base], grown, 0.5).all()
+    ids, d2 = ob.knn(grown, grown, k=2)                          # nearest OTHER appended point
+    close = d2[:, 1] < 0.25
+    # pairs closer than minDist can only come from ONE rank's scan (a mapper appends all of a scan's accepted points at once)
+    assert close.sum() < grown.shape[0]
     for k in range(world):
         assert np.isfinite(r[k]["pose"]).all()
     assert not np.array_equal(r[0]["pose"], r[1]["pose"])      # every rank registered its own scan
@@ -168,7 +177,7 @@ def _resident_worker(rank, world, port, out_dir):
             cls.set_map(np.concatenate([cls.cloud, pts]), None)
 
         normals = staticmethod(lambda cloud, knn: ob.surface_normals(cloud, knn))
-        dedup = staticmethod(lambda cloud, edge: ob.voxel_keep_first(cloud, edge))
+        keep = staticmethod(lambda m, c, d: ob.point_distance_keep(m, c, d, nthreads=2))
         get_map = classmethod(lambda cls: cls.cloud)
 
     sc = synth.make_scene(m=6000, n=1500, seed_scan=43 + 1000 * rank)

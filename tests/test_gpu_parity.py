@@ -522,7 +522,7 @@ def test_sharded_mapper_single_rank(amd, mid_scene):
     pose, mine, appended = mapper.epoch(sc["scan"], np.eye(4))
     dt, dr = amd.synth.pose_error(pose, sc["T_gt"])
     assert dt < 2e-2 and dr < 2e-3, (dt, dr)
-    assert mapper.map.shape[0] == m0 + appended and 0 < appended <= mine   # the lattice de-dup may drop a few
+    assert mapper.map.shape[0] == m0 + appended and 0 < appended == mine   # one rank: nothing to merge against
     # accepted points are at least min_dist from the old map
     new_pts = mapper.map[m0:]
     assert icp.pointDistanceKeep(half, new_pts, 0.3).all()
@@ -643,6 +643,31 @@ def test_full_size_properties(amd):
     # and the registration recovers the ground truth of the scene
     dt, dr = amd.synth.pose_error(T, sc["T_gt"])
     assert dt < 5e-3 and dr < 5e-4
+
+
+def test_sharded_mapper_device_backend_equals_resident_backend(amd, mid_scene):
+    """The epoch inside the library (icpmi_staged_merge_allgather: compaction, RCCL all-gather on the handle's stream -- here a
+    one-rank communicator, the only kind one GPU allows --, rank-ordered merge, append, normals, index) against the resident
+    backend that moves the accepted points through the host: same poses, same accepted counts, the same map bit for bit."""
+    from norlab_icp_mapper_amd.dist import ShardedMapper
+    sc = mid_scene
+    kw = dict(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=30, use_differential=1)
+    half = sc["map"][::2]
+    ricp, dicp = amd.ICPSequence(**kw), amd.ICPSequence(**kw)
+    dicp.commInit(amd.ICPSequence.commUniqueId(), 1, 0)
+    res = ShardedMapper(ShardedMapper.resident_backend(ricp), min_dist_new_point=0.3, normals_knn=10)
+    dev = ShardedMapper(ShardedMapper.device_backend(dicp), min_dist_new_point=0.3, normals_knn=10)
+    res.set_map(half); dev.set_map(half)
+    for scan in (sc["scan"], amd.synth.make_scene(m=8, n=20000, seed_scan=77)["scan"]):
+        pr, mine_r, app_r = res.epoch(scan, np.eye(4))
+        pd, mine_d, app_d = dev.epoch(scan, np.eye(4))
+        assert np.array_equal(pr, pd) and (mine_r, app_r) == (mine_d, app_d)
+    assert np.array_equal(res.get_map(), dev.get_map())
+    m_before = dev.get_map().shape[0]
+    acc, app, m1, merged = dicp.stagedMergeAllGather(np.eye(4, dtype=np.float32), 0.3, normals_knn=0, return_merged=True)
+    assert acc == app == merged.shape[0] and m1 == m_before + app       # the staged scan offered once more, placed by another transform
+    assert np.array_equal(dev.get_map()[m_before:], merged)
+    dicp.commDestroy()
 
 
 def test_sharded_mapping_example_over_rccl(tmp_path):

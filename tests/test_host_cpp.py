@@ -14,7 +14,7 @@ PKG = os.path.join(ROOT, "norlab_icp_mapper_amd")
 
 def _build_host():
     # prebuilt binaries travel with the repository snapshot to the GPU box: build only what is missing
-    need = [os.path.join(PKG, n) for n in ("libicpmi.so", "libnorlab_icp_mapper_host.so", "host_tests", "build_map_from_scans_and_trajectory")]
+    need = [os.path.join(PKG, n) for n in ("libicpmi.so", "libnorlab_icp_mapper_host.so", "host_tests", "build_map_from_scans_and_trajectory", "sharded_mapping")]
     if all(os.path.exists(p) for p in need):
         return
     subprocess.check_call(["make", "-s", "-C", os.path.join(PKG, "csrc"), "-j8"])
@@ -304,3 +304,28 @@ def test_bundled_configuration_known_answer(tmp_path):
         assert (dots > 1 - 1e-3).mean() > 0.99
         assert np.abs(hdesc["probabilityDynamic"][same] - mdesc["probabilityDynamic"][same]).max() < 1e-4
         assert np.array_equal(hdesc["intensity"][same], mdesc["intensity"][same])    # a host-side descriptor followed the provenance vector
+
+
+@pytest.mark.gpu
+def test_cpp_sharded_mapper_single_rank(tmp_path):
+    """examples/sharded_mapping.cpp (nim::ShardedMapper: staged registration, icpmi_staged_merge_allgather, merged points binned
+    into the rank's RAMCellManager) with one rank -- the multi-rank path minus the communicator, which one GPU cannot host twice."""
+    import re
+    _build_host()
+    tmp = str(tmp_path)
+    scans, priors, truth = _make_dataset(tmp, n_scans=4, n_pts=12000)
+    cfg = os.path.join(tmp, "config.yaml")
+    open(cfg, "w").write(P2PLANE_CONFIG)
+    out = subprocess.run([os.path.join(PKG, "sharded_mapping"), tmp, cfg, "0.15", "10"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr + out.stdout
+    rows = re.findall(r"rank 0 epoch (\d+) scan (\d+): (\d+) pts, pose (\S+) (\S+) (\S+), iterations (\d+), (\d+) accepted here, (\d+) appended by all ranks, map (\d+)", out.stdout)
+    assert len(rows) == 3
+    size = len(scans[0])
+    for k, r in enumerate(rows):
+        accepted, appended, m = int(r[7]), int(r[8]), int(r[9])
+        assert accepted == appended > 0 and m == size + appended          # one rank: what it accepts is what every replica appends
+        size = m
+        pose = np.array([float(r[3]), float(r[4]), float(r[5])])
+        assert np.linalg.norm(pose - truth[k + 1][:3, 3]) < 0.05 and 0 < int(r[6]) <= 40
+    tail = re.search(r"rank 0: 3 scans in \S+ s, map (\d+) points, (\d+) cells holding (\d+) merged points", out.stdout)
+    assert tail and int(tail.group(1)) == size and int(tail.group(3)) == size - len(scans[0]) and int(tail.group(2)) >= 1
