@@ -192,6 +192,36 @@ def main():
     iters_total = world * args.steps * ITERS_PER_STEP * readings
     value = iters_total / elapsed
 
+    # ---- the one exchange of the multi-GPU path, outside the timed region: a map-growth epoch through the library's own RCCL
+    # communicator (icpmi_staged_merge_allgather: accepted points compacted, all-gathered on the handle's stream, merged in rank
+    # order and appended on the device).  Every rank must take the same decisions, or the collective would hang: agree first.
+    merge = None
+    if use_pg:
+        try:
+            ok = 1
+            try:
+                box = [icp.commUniqueId() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                icp.commInit(box[0], world, rank)
+            except Exception as e:  # noqa: BLE001
+                ok, merge = 0, {"error": repr(e)}
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                corr = icp.registerWithPrior(sc["scan"], np.eye(4, dtype=np.float32))
+                barrier()
+                tm = time.perf_counter()
+                mine_n, appended, new_m = icp.stagedMergeAllGather(corr, 0.15, normals_knn=0)
+                barrier()
+                tms = torch.tensor([time.perf_counter() - tm], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tms, op=dist.ReduceOp.MAX)
+                merge = {"ms": float(tms.item()) * 1e3, "accepted_rank0": mine_n, "appended_all_ranks": appended, "map_points_after": new_m,
+                         "what": "PointDistance(0.15 m) accept of one 100k-pt scan per rank + RCCL all-gather + rank-ordered exact merge + append + index rebuild"}
+            elif merge is None:
+                merge = {"error": "another rank could not create its communicator"}
+        except Exception as e:  # noqa: BLE001
+            merge = {"error": repr(e)}
+
     out = {
         "metric": "ICP iterations/sec, 100k-pt scan vs 1M-pt map",
         "value": value,
@@ -219,6 +249,8 @@ def main():
 
     if rank == 0:
         gi = icp.gridInfo()
+        if merge is not None:
+            out["merge_epoch"] = merge
         out["step_ms"] = step_stats(per_step)
         out["device_loop_ms_per_step"] = loop_ms / args.steps
         out["set_map_ms"] = set_map_ms

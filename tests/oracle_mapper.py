@@ -11,10 +11,13 @@ scan by scan against an independent replay of a whole trajectory:
                                                                  to the sensor frame, post filters, back, icp.setMap (:523-528)
     module bodies          MapperModules/{PointDistance,Octree,DynamicPoints}MapperModule.cpp
 
+    updatePose             Map.cpp:246-460                       the sliding window of loaded 20 m cells (`paging=True`): window
+                                                                 edges ceil((p - R)/20 - 1) / floor((p + R)/20) (:472-480), moved when
+                                                                 an edge is 2 cells off (:278...), BUFFER_SIZE 2; loadCells :71-128,
+                                                                 unloadCells :140-230, RAMCellManager.cpp:3-31; getMap :552-573
+
 Clouds are dicts {"xyz1": (n, 4) float32, <descriptor name>: (n, span) float32}; `concatenate` keeps the descriptors
-both clouds have (PM::DataPoints::concatenate).  Cell paging (Map::updatePose) does not change what the registration
-sees as long as the trajectory stays inside the window of loaded cells (sensorMaxRange + 2 buffer cells of 20 m,
-Map.cpp:246-460): the replays this is used for do.
+both clouds have (PM::DataPoints::concatenate).
 """
 import numpy as np
 
@@ -72,7 +75,7 @@ def mat4_mul_f32(A, B):
 
 class OracleMapper:
     def __init__(self, icp_kw, modules, post=(), update=("distance", 1.0), sensor_max_range=80.0, input_filters=(),
-                 add_descriptors=(), nthreads=8, post_in_map_frame=False):
+                 add_descriptors=(), nthreads=8, post_in_map_frame=False, paging=False):
         """modules: [("point_distance", minDist) | ("dynamic_points", {params}) | ("octree", maxSize, samplingMethod[, maxPointByNode])]
         post: [("surface_normals", knn) | ("cut", descName, useLargerThan, threshold)]
         input_filters: oracle_bindings.filter_points rows; add_descriptors: [(name, value)] (AddDescriptorDataPointsFilter)"""
@@ -84,6 +87,10 @@ class OracleMapper:
         # map into the sensor frame and back on every update); False: the reference's Map.cpp:523-525
         self.post_in_map_frame = post_in_map_frame
         self.map = None
+        self.paging = paging
+        self.cells, self.loaded, self.first_pose_update = {}, set(), True      # RAMCellManager, loadedCellIds, firstPoseUpdate
+        self.win = None                                                        # [inferior, superior] LastUpdateIndex per axis
+        self.page_events = []
         self.pose = np.eye(4, dtype=np.float32)
         self.trajectory, self.iterations, self.updated = [], [], []
         self.last_time, self.last_pose = None, None
@@ -145,6 +152,107 @@ class OracleMapper:
         self.map = sensor if self.post_in_map_frame else transform_cloud(pose, sensor)
         self.icp.setMap(self.map["xyz1"], self.map.get("normals"))
 
+    # ---- Map::updatePose and the cell manager ----
+    CELL, BUF = np.float32(20.0), 2
+
+    def _inf(self, w):
+        return int(np.ceil(np.float32(np.float32(np.float32(w) - np.float32(self.sensor_max_range)) / self.CELL) - 1.0))
+
+    def _sup(self, w):
+        return int(np.floor(np.float32(np.float32(w) + np.float32(self.sensor_max_range)) / self.CELL))
+
+    def _set_icp_map(self):
+        if self.map is not None and self.map["xyz1"].shape[0]:
+            self.icp.setMap(self.map["xyz1"], self.map.get("normals"))            # an empty cloud is ignored (setMap returns false)
+
+    def _unload(self, lo, hi):
+        """Map.cpp:140-230: points inside the half-open box of the cell range leave the local cloud and are saved per cell"""
+        if self.map is not None and self.map["xyz1"].shape[0]:
+            p = self.map["xyz1"][:, :3]
+            inside = np.ones(p.shape[0], bool)
+            for a in range(3):
+                start = -np.inf if lo[a] is None else np.float32(lo[a]) * self.CELL
+                end = np.inf if hi[a] is None else np.float32(hi[a] + 1) * self.CELL
+                inside &= (p[:, a] >= start) & (p[:, a] < end)
+            old = keep_only(self.map, inside)
+            self.map = keep_only(self.map, ~inside)
+            self._set_icp_map()
+            ijk = np.floor(old["xyz1"][:, :3] / self.CELL).astype(np.int64)
+            ids = [f"{i}_{j}_{k}" for i, j, k in ijk]
+            order = {}
+            for row, cid in enumerate(ids):
+                order.setdefault(cid, []).append(row)
+            for cid, rows in order.items():
+                self.cells[cid] = gather(old, np.array(rows))                  # saveCell overwrites
+        if lo[0] is None:
+            self.loaded.clear()
+        else:
+            for i in range(lo[0], hi[0] + 1):
+                for j in range(lo[1], hi[1] + 1):
+                    for k in range(lo[2], hi[2] + 1):
+                        self.loaded.discard(f"{i}_{j}_{k}")
+
+    def _load(self, lo, hi):
+        """Map.cpp:71-128"""
+        chunk = None
+        for i in range(lo[0], hi[0] + 1):
+            for j in range(lo[1], hi[1] + 1):
+                for k in range(lo[2], hi[2] + 1):
+                    cell = self.cells.get(f"{i}_{j}_{k}")
+                    if cell is not None and cell["xyz1"].shape[0]:
+                        chunk = cell if chunk is None else concatenate(chunk, cell)
+                    self.loaded.add(f"{i}_{j}_{k}")
+        if chunk is not None:
+            self.map = chunk if self.map is None or self.map["xyz1"].shape[0] == 0 and not self.map_has_fields() else concatenate(self.map, chunk)
+            self._set_icp_map()
+
+    def map_has_fields(self):
+        return self.map is not None and len(self.map) > 1
+
+    def update_pose(self, pose):
+        if not self.paging:
+            return
+        pos = [float(pose[a, 3]) for a in range(3)]
+        B = self.BUF
+        if self.first_pose_update:
+            self.win = [[self._inf(pos[a]), self._sup(pos[a])] for a in range(3)]
+            self.cells.clear(); self.loaded.clear()
+            self._unload([None] * 3, [None] * 3)
+            self._load([self.win[a][0] - B for a in range(3)], [self.win[a][1] + B for a in range(3)])
+            self.first_pose_update = False
+            return
+        for a in range(3):                                                      # rows, columns, aisles -- in that order (Map.cpp:276-457)
+            def box(start, end):
+                lo = [self.win[b][0] - B for b in range(3)]; hi = [self.win[b][1] + B for b in range(3)]
+                lo[a], hi[a] = start, end
+                return lo, hi
+            inf_now, sup_now = self._inf(pos[a]), self._sup(pos[a])
+            inf_last, sup_last = self.win[a]
+            if abs(inf_now - inf_last) >= 2:                                    # the trailing edge
+                if inf_now < inf_last:
+                    n = inf_last - inf_now
+                    lo, hi = box(inf_now - B, inf_now - B + n - 1); self._load(lo, hi); self.page_events.append(("load", a, lo[a], hi[a]))
+                if inf_now > inf_last:
+                    n = inf_now - inf_last
+                    lo, hi = box(inf_last - B, inf_last - B + n - 1); self._unload(lo, hi); self.page_events.append(("unload", a, lo[a], hi[a]))
+                self.win[a][0] = inf_now
+            if abs(sup_now - sup_last) >= 2:                                    # the leading edge
+                if sup_now < sup_last:
+                    n = sup_last - sup_now
+                    lo, hi = box(sup_last + B - n + 1, sup_last + B); self._unload(lo, hi); self.page_events.append(("unload", a, lo[a], hi[a]))
+                if sup_now > sup_last:
+                    n = sup_now - sup_last
+                    lo, hi = box(sup_now + B - n + 1, sup_now + B); self._load(lo, hi); self.page_events.append(("load", a, lo[a], hi[a]))
+                self.win[a][1] = sup_now
+
+    def get_map(self):
+        """Mapper::getMap (Map.cpp:552-573): the local cloud plus every saved cell that is not loaded"""
+        out = self.map
+        for cid, cell in self.cells.items():
+            if cid not in self.loaded:
+                out = cell if out is None else concatenate(out, cell)
+        return out
+
     # ---- Mapper::shouldUpdateMap ----
     def _should_update(self, stamp, pose, overlap):
         kind, value = self.update
@@ -161,6 +269,7 @@ class OracleMapper:
         inp = transform_cloud(prior, filtered)
         if self.map is None or self.map["xyz1"].shape[0] == 0:
             corrected = prior
+            self.update_pose(corrected)
             self.last_time, self.last_pose = stamp_s, corrected
             self.update_local_point_cloud(inp, corrected)
             self.iterations.append(0); self.updated.append(True)
@@ -170,6 +279,7 @@ class OracleMapper:
                 raise RuntimeError(f"oracle ICP error {err}")
             corrected = mat4_mul_f32(corr, prior)
             self.iterations.append(self.icp.stats.iterations)
+            self.update_pose(corrected)
             upd = self._should_update(stamp_s, corrected, self.icp.stats.weighted_point_used_ratio)
             if upd:
                 self.last_time, self.last_pose = stamp_s, corrected
