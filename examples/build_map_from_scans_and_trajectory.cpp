@@ -80,6 +80,8 @@ int main(int argc, char** argv)
         // Map.cpp:35-57) -- the reference's example runs offline; the switch exists to exercise those threads
         const char* onlineEnv = std::getenv("NIM_ONLINE");
         const bool online = onlineEnv && std::atoi(onlineEnv) != 0;
+        const char* drainEnv = std::getenv("NIM_ONLINE_DRAIN"); // with NIM_ONLINE: wait for the update / paging threads after every scan
+        const bool drain = drainEnv && std::atoi(drainEnv) != 0;
         Mapper mapper(config, /*is3D*/ true, /*isOnline*/ online, /*isMapping*/ true, /*saveMapCellsOnHardDrive*/ false);
         const auto t0 = std::chrono::steady_clock::now();
         for (size_t i = 0; i < scans.size(); ++i) {
@@ -87,10 +89,11 @@ int main(int argc, char** argv)
             DataPoints cloud = DataPoints::load(scans[i]);
             mapper.applyInputFilters(cloud);
             mapper.processInput(cloud, trajectory[i].pose, stamp);
+            if (drain) mapper.waitForPendingWork();
             const Mat4 p = mapper.getPose();
-            std::printf("scan %zu/%zu  %zu pts  pose %.4f %.4f %.4f  iterations %d  overlap %.3f\n", i + 1, scans.size(),
+            std::printf("scan %zu/%zu  %zu pts  pose %.4f %.4f %.4f  iterations %d  overlap %.3f  local map %zu\n", i + 1, scans.size(),
                         cloud.getNbPoints(), p(0, 3), p(1, 3), p(2, 3), mapper.lastIcpStats().iterations,
-                        mapper.lastIcpStats().weighted_point_used_ratio);
+                        mapper.lastIcpStats().weighted_point_used_ratio, mapper.localMapSize());
         }
         const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         DataPoints map = mapper.getMap();

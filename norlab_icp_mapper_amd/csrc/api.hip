@@ -129,6 +129,7 @@ void icpmi_destroy(icpmi_handle c)
 {
     if (!c) return;
     if (c->temp) { icpmi_destroy(c->temp); c->temp = nullptr; }
+    if (c->temp_raw) { icpmi_destroy(c->temp_raw); c->temp_raw = nullptr; }
     hipSetDevice(c->device);
     comm_destroy(c);
     if (c->stream) hipStreamSynchronize(c->stream);

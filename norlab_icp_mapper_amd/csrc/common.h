@@ -193,6 +193,12 @@ struct icpmi_ctx {
     float4* d_scan_map = nullptr; size_t cap_scan_map = 0; int64_t scan_map_n = 0;
     float* d_T16 = nullptr;           // a 4x4 for device-side transforms
     icpmi_ctx* temp = nullptr;        // private handle of the map-side operators (indexes arbitrary clouds), created on first use
+    // PointDistanceMapperModule builds its kd-tree on the map AS IT IS (PointDistanceMapperModule.cpp:32-36), the ICP matcher on the
+    // map minus its centroid: squared distances in the two frames differ by rounding, and a keep decision at d2 ~ minDist^2 with
+    // them.  The resident map-update paths therefore decide against this second index of the resident map in its own frame, rebuilt
+    // when the map changed (map_version) -- not against the registration index.
+    icpmi_ctx* temp_raw = nullptr; uint64_t temp_raw_version = 0;
+    uint64_t map_version = 0;         // bumped by every map_build of this handle
     bool single_level = false;        // temp handles of the self k-NN (surface normals): level 0 of the pyramid is all they search
     bool keep_raw = true;             // temp handles index clouds they do not own: no resident copy of the input
     bool no_centre = false;           // temp handles of the map-side operators: index raw coordinates (mean = 0)

@@ -464,6 +464,7 @@ static GridParams make_grid(const float lo[3], const float hi[3], float cell, fl
 
 icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float* d_normals3)
 {
+    ++c->map_version;
     // ---- stats ----
     const int rblocks = (int)std::min<int64_t>((m + RB - 1) / RB, 1024);
     if (ensure_cap(c, &c->d_red, &c->cap_red, (size_t)rblocks * 9) != ICPMI_OK) return ICPMI_ERR_HIP;

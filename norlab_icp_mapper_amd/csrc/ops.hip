@@ -398,6 +398,28 @@ __global__ __launch_bounds__(256) void keep_flag_kernel(const float* __restrict_
     flag[i] = d2[i] >= lim ? 1u : 0u;
 }
 
+__global__ __launch_bounds__(256) void flag_to_keep_kernel(const unsigned* __restrict__ flag, int64_t n, uint8_t* __restrict__ keep)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) keep[i] = flag[i] ? 1 : 0;
+}
+
+// stable compaction by flags: kept input i goes to slot base + pos[i] (pos = exclusive scan of the flags)
+__global__ __launch_bounds__(256) void append_flagged_kernel(const float4* __restrict__ in, const float* __restrict__ in_n3, int64_t n,
+                                                             const unsigned* __restrict__ flag, const unsigned* __restrict__ pos, int64_t base,
+                                                             float4* __restrict__ raw, float* __restrict__ raw_n3)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    const int64_t o = base + pos[i];
+    raw[o] = in[i];
+    if (raw_n3) {
+        raw_n3[3 * o] = in_n3 ? in_n3[3 * i] : 0.f;
+        raw_n3[3 * o + 1] = in_n3 ? in_n3[3 * i + 1] : 0.f;
+        raw_n3[3 * o + 2] = in_n3 ? in_n3[3 * i + 2] : 0.f;
+    }
+}
+
 // stable compaction: kept input i goes to slot base + pos[i] (pos = exclusive scan of the flags)
 __global__ __launch_bounds__(256) void append_kept_kernel(const float4* __restrict__ in, const float* __restrict__ in_n3, int64_t n,
                                                           const float* __restrict__ d2, double lim, const unsigned* __restrict__ pos,
@@ -436,6 +458,30 @@ static icpmi_status make_temp(icpmi_ctx* c, TempCtx& t)
     t.h->keep_raw = false;
     t.h->no_centre = true; // PointDistanceMapperModule.cpp:33 / SurfaceNormalDataPointsFilter build their kd-tree on the raw cloud
     t.h->single_level = false;
+    return ICPMI_OK;
+}
+
+namespace { icpmi_status chain_point_distance_flags(icpmi_ctx* c, icpmi_ctx* ic, const float4* d_scan, int64_t n, float min_dist, unsigned* d_flag); }
+
+// the index PointDistanceMapperModule searches: the resident map in its own frame (common.h: temp_raw)
+static icpmi_status raw_index(icpmi_ctx* c, icpmi_ctx** out)
+{
+    if (!c->temp_raw) {
+        icpmi_config cfg = c->cfg;
+        icpmi_status s = icpmi_create(&cfg, &c->temp_raw);
+        if (s != ICPMI_OK) { c->last_error = icpmi_last_error(nullptr); c->temp_raw = nullptr; return s; }
+        c->temp_raw_version = 0;
+    }
+    icpmi_ctx* t = c->temp_raw;
+    t->cfg = c->cfg; t->keep_raw = false; t->no_centre = true; t->single_level = false;
+    if (c->temp_raw_version != c->map_version || t->m != c->m_raw) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream)); // the resident copy was produced on the caller's stream
+        int32_t ok = 0;
+        icpmi_status s = icpmi_set_map_dev(t, (const float*)c->d_raw, c->m_raw, nullptr, &ok);
+        if (s != ICPMI_OK) { c->last_error = t->last_error; return s; }
+        c->temp_raw_version = c->map_version;
+    }
+    *out = t;
     return ICPMI_OK;
 }
 
@@ -766,48 +812,40 @@ icpmi_status ops_map_update_dev(icpmi_ctx* c, const float4* d_scan, int64_t n, c
     const double lim = pd_limit(min_dist);
     const int blocks = (int)((n + 255) / 256);
     unsigned* d_flag = scratch_get<unsigned>(c, 6, (size_t)n + 2); // kept between calls
-    if (!d_flag) return ICPMI_ERR_HIP;
+    unsigned* d_pos = scratch_get<unsigned>(c, 7, (size_t)n + 2);
+    if (!d_flag || !d_pos) return ICPMI_ERR_HIP;
     icpmi_status s = ICPMI_OK;
     hipError_t e = hipSuccess;
     unsigned count = 0;
     if (m0 > 0) {
-        // PointDistanceMapperModule.cpp:33-42: exact NN of every input point in the map, self match excluded, keep
-        // iff d2 >= minDist^2.  A radius search with maxDist = minDist decides the same predicate.
-        s = loop_prepare_reading(c, d_scan, n, nullptr);
-        LoopCfg lc = make_loop_cfg(c, 1);
-        lc.k = 1; lc.n_out = 0; lc.max_dist = min_dist; lc.maxr2 = pd_radius2(lim);
-        const size_t cnt = (size_t)n + 1;
-        if (s == ICPMI_OK && (ensure_cap(c, &c->d_sidx, &c->cap_sidx, cnt) != ICPMI_OK || ensure_cap(c, &c->d_d2, &c->cap_d2, cnt) != ICPMI_OK ||
-                              ensure_cap(c, &c->d_hard, &c->cap_hard, cnt) != ICPMI_OK)) s = ICPMI_ERR_HIP;
-        if (s == ICPMI_OK) {
-            e = hipMemsetAsync(c->d_state, 0, sizeof(IcpState), c->stream);
-            c->nn_hist0 = nullptr; c->nn_iter_hint = 0; c->nn_match_pt = nullptr;
-            if (e == hipSuccess) s = nn_launch_k(c, c->d_reading, n, nullptr, lc, 0, c->d_sidx, c->d_d2, c->d_state);
-        }
-        if (s == ICPMI_OK && e == hipSuccess && keep_out) {
+        // PointDistanceMapperModule.cpp:33-42: exact NN of every input point in the map AS IT IS (raw_index: not the centred
+        // registration index), self match excluded, keep iff d2 >= minDist^2
+        icpmi_ctx* ri = nullptr;
+        s = raw_index(c, &ri);
+        if (s == ICPMI_OK) s = chain_point_distance_flags(c, ri, d_scan, n, min_dist, d_flag);
+        if (s == ICPMI_OK && keep_out) {
             uint8_t* d_keep = scratch_get<uint8_t>(c, 9, (size_t)n);
             if (!d_keep) e = hipErrorOutOfMemory;
             if (e == hipSuccess) {
-                hipLaunchKernelGGL(keep_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_d2, n, lim, d_keep);
+                hipLaunchKernelGGL(flag_to_keep_kernel, dim3(blocks), dim3(256), 0, c->stream, (const unsigned*)d_flag, n, d_keep);
                 e = hipMemcpyAsync(keep_out, d_keep, (size_t)n, hipMemcpyDeviceToHost, c->stream);
                 if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
             }
         }
         if (s == ICPMI_OK && e == hipSuccess) {
-            hipLaunchKernelGGL(keep_flag_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_d2, n, lim, d_flag);
-            s = device_exclusive_scan(c, d_flag, (int)n, 0u);
+            e = hipMemcpyAsync(d_pos, d_flag, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToDevice, c->stream);
+            if (e == hipSuccess) s = device_exclusive_scan(c, d_pos, (int)n, 0u);
+        }
+        if (s == ICPMI_OK && e == hipSuccess) {
+            unsigned lp = 0, lf = 0;
+            if (read_back2(c, &lp, d_pos + (n - 1), sizeof(unsigned), &lf, d_flag + (n - 1), sizeof(unsigned)) != ICPMI_OK) e = hipErrorUnknown;
+            count = lp + lf;
         }
     } else {
         // PointDistanceMapperModule::createMap: the first scan is the map
-        e = hipMemsetAsync(d_flag, 0, ((size_t)n + 2) * sizeof(unsigned), c->stream);
         if (keep_out) memset(keep_out, 1, (size_t)n);
+        count = (unsigned)n;
     }
-    if (s == ICPMI_OK && e == hipSuccess && m0 > 0) {
-        // count = scan[n-1] + flag[n-1]; the scan overwrote the flags, so recompute the last flag from d2
-        unsigned last_pos = 0; float last_d2 = 0.f;
-        if (read_back2(c, &last_pos, d_flag + (n - 1), sizeof(unsigned), &last_d2, c->d_d2 + (n - 1), sizeof(float)) != ICPMI_OK) e = hipErrorUnknown;
-        count = last_pos + (last_d2 >= lim ? 1u : 0u);
-    } else if (m0 == 0) count = (unsigned)n;
     if (s == ICPMI_OK && e == hipSuccess && count > 0) {
         const int64_t m1 = m0 + count;
         const bool want_n = normals_knn > 0 || c->raw_has_normals || scan_normals3;
@@ -820,9 +858,8 @@ icpmi_status ops_map_update_dev(icpmi_ctx* c, const float4* d_scan, int64_t n, c
         }
         if (s == ICPMI_OK && e == hipSuccess) {
             if (m0 > 0)
-                hipLaunchKernelGGL(append_kept_kernel, dim3(blocks), dim3(256), 0, c->stream, d_scan,
-                                   d_scan_n3, n, c->d_d2, lim, d_flag, m0, c->d_raw,
-                                   want_n ? c->d_raw_n3 : (float*)nullptr);
+                hipLaunchKernelGGL(append_flagged_kernel, dim3(blocks), dim3(256), 0, c->stream, d_scan, d_scan_n3, n, (const unsigned*)d_flag,
+                                   (const unsigned*)d_pos, m0, c->d_raw, want_n ? c->d_raw_n3 : (float*)nullptr);
             else {
                 e = hipMemcpyAsync(c->d_raw, d_scan, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream);
                 if (e == hipSuccess && want_n) {
@@ -1132,8 +1169,9 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
             if (n == 0) break;
             if (!created) { s = chain_append(w, d_scan, d_scan_n3, d_scan_s, n, nullptr, nullptr, n, src_base); w.has_n = d_scan_n3 != nullptr; break; } // createMap: the scan is the map
             if (w.m == 0) { s = chain_append(w, d_scan, d_scan_n3, d_scan_s, n, nullptr, nullptr, n, src_base); break; } // no neighbour anywhere: d2 = inf
-            icpmi_ctx* ic = c;
-            if (!w.indexed) {
+            icpmi_ctx* ic = nullptr;
+            if (w.indexed) { s = raw_index(c, &ic); if (s != ICPMI_OK) break; } // the resident map, in its own frame
+            else {
                 TempCtx t;
                 s = make_temp(c, t);
                 if (s != ICPMI_OK) break;
@@ -1283,7 +1321,9 @@ icpmi_status ops_staged_merge_allgather(icpmi_ctx* c, const float correction[16]
         local = ops_transform_dev(c, correction, c->d_scan_map, n, c->d_stage_in);
         if (local == ICPMI_OK) {
             if (c->m > 0) {
-                local = chain_point_distance_flags(c, c, c->d_stage_in, n, min_dist, d_flag);
+                icpmi_ctx* ri = nullptr;
+                local = raw_index(c, &ri);
+                if (local == ICPMI_OK) local = chain_point_distance_flags(c, ri, c->d_stage_in, n, min_dist, d_flag);
                 if (local == ICPMI_OK) local = merge_append_flagged(c, c->d_stage_in, n, d_flag, d_pos, c->d_merge_send, 0, &mine);
             } else { // no map yet: every point is new
                 if (hipMemcpyAsync(c->d_merge_send, c->d_stage_in, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream) != hipSuccess) local = ICPMI_ERR_HIP;
@@ -1374,9 +1414,11 @@ icpmi_status ops_staged_keep(icpmi_ctx* c, const float correction[16], float min
     unsigned* d_flag = scratch_get<unsigned>(c, 6, (size_t)n + 2);
     uint8_t* d_keep = scratch_get<uint8_t>(c, 9, (size_t)n);
     if (!d_flag || !d_keep) return ICPMI_ERR_HIP;
-    s = chain_point_distance_flags(c, c, c->d_stage_in, n, min_dist, d_flag);
+    icpmi_ctx* ri = nullptr;
+    s = raw_index(c, &ri);
+    if (s == ICPMI_OK) s = chain_point_distance_flags(c, ri, c->d_stage_in, n, min_dist, d_flag);
     if (s != ICPMI_OK) return s;
-    hipLaunchKernelGGL(keep_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_d2, n, pd_limit(min_dist), d_keep);
+    hipLaunchKernelGGL(flag_to_keep_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, (const unsigned*)d_flag, n, d_keep);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(keep_out, d_keep, (size_t)n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -38,15 +38,21 @@ void Map::updateThreadFunction()
             std::lock_guard<std::mutex> g(updateListLock);
             if (!updateList.empty()) { u = updateList.front(); updateList.pop_front(); have = true; }
         }
-        if (have) applyUpdate(u);
+        if (have) { applyUpdate(u); updatesInFlight.fetch_sub(1); }
         else std::this_thread::sleep_for(std::chrono::milliseconds(10));
     }
+}
+
+void Map::waitForPaging()
+{
+    while (isOnline && updatesInFlight.load() > 0) std::this_thread::sleep_for(std::chrono::milliseconds(1));
 }
 
 void Map::scheduleUpdate(const Update& u)
 {
     if (isOnline) {
         std::lock_guard<std::mutex> g(updateListLock);
+        updatesInFlight.fetch_add(1);
         updateList.push_back(u);
     } else applyUpdate(u);
 }

@@ -89,6 +89,14 @@ private:
     void updateThreadFunction();
     void applyUpdate(const Update& u) { if (u.load) loadCells(u.box); else unloadCells(u.box); }
     void scheduleUpdate(const Update& u);
+public:
+    // points of the local cloud (the resident copy when the device runs ahead of the host copy)
+    size_t localSize() { std::lock_guard<std::mutex> g(localPointCloudLock); return deviceAhead ? (size_t)residentCount : localPointCloud.getNbPoints(); }
+    // online mode: blocks until the paging thread has applied every scheduled load / unload (no reference analogue: used by
+    // replays that want the asynchronous pipeline drained between scans, so that an online run reproduces the offline one)
+    void waitForPaging();
+private:
+    std::atomic_int updatesInFlight{0};
     void loadCells(Box box);
     void unloadCells(Box box);
     // Resident path (icpmi_map_update_chain): every mapper module and every post filter describes itself as a device

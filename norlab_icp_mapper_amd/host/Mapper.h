@@ -54,6 +54,11 @@ public:
     void processInput(const DataPoints& inputInSensorFrame, const Mat4& estimatedPose, const TimePoint& timeStamp); // :194-238
     DataPoints getMap() { return map.getGlobalPointCloud(); }
     long residentMapUpdates() const { return map.residentUpdateCount(); }
+    size_t localMapSize() { return map.localSize(); }
+    // online mode: blocks until the asynchronous map update in flight (Mapper.cpp:282) and every scheduled cell load / unload
+    // (Map.cpp:35-57) are done.  No reference analogue; a replay that calls it after every processInput makes the online
+    // pipeline reproduce the offline trajectory (the reference's online results depend on thread timing).
+    void waitForPendingWork() { if (mapUpdateFuture.valid()) mapUpdateFuture.wait(); map.waitForPaging(); }
     void setMap(const DataPoints& newMap);
     bool getNewLocalMap(DataPoints& mapOut) { return map.getNewLocalPointCloud(mapOut); }
     Mat4 getPose();

@@ -90,7 +90,7 @@ class OracleMapper:
         self.paging = paging
         self.cells, self.loaded, self.first_pose_update = {}, set(), True      # RAMCellManager, loadedCellIds, firstPoseUpdate
         self.win = None                                                        # [inferior, superior] LastUpdateIndex per axis
-        self.page_events = []
+        self.page_events, self.reloaded_points = [], 0
         self.pose = np.eye(4, dtype=np.float32)
         self.trajectory, self.iterations, self.updated = [], [], []
         self.last_time, self.last_pose = None, None
@@ -203,6 +203,7 @@ class OracleMapper:
                         chunk = cell if chunk is None else concatenate(chunk, cell)
                     self.loaded.add(f"{i}_{j}_{k}")
         if chunk is not None:
+            self.reloaded_points += int(chunk["xyz1"].shape[0])
             self.map = chunk if self.map is None or self.map["xyz1"].shape[0] == 0 and not self.map_has_fields() else concatenate(self.map, chunk)
             self._set_icp_map()
 
@@ -231,18 +232,18 @@ class OracleMapper:
             if abs(inf_now - inf_last) >= 2:                                    # the trailing edge
                 if inf_now < inf_last:
                     n = inf_last - inf_now
-                    lo, hi = box(inf_now - B, inf_now - B + n - 1); self._load(lo, hi); self.page_events.append(("load", a, lo[a], hi[a]))
+                    lo, hi = box(inf_now - B, inf_now - B + n - 1); self._load(lo, hi); self.page_events.append(("load", a, lo[a], hi[a], len(self.trajectory)))
                 if inf_now > inf_last:
                     n = inf_now - inf_last
-                    lo, hi = box(inf_last - B, inf_last - B + n - 1); self._unload(lo, hi); self.page_events.append(("unload", a, lo[a], hi[a]))
+                    lo, hi = box(inf_last - B, inf_last - B + n - 1); self._unload(lo, hi); self.page_events.append(("unload", a, lo[a], hi[a], len(self.trajectory)))
                 self.win[a][0] = inf_now
             if abs(sup_now - sup_last) >= 2:                                    # the leading edge
                 if sup_now < sup_last:
                     n = sup_last - sup_now
-                    lo, hi = box(sup_last + B - n + 1, sup_last + B); self._unload(lo, hi); self.page_events.append(("unload", a, lo[a], hi[a]))
+                    lo, hi = box(sup_last + B - n + 1, sup_last + B); self._unload(lo, hi); self.page_events.append(("unload", a, lo[a], hi[a], len(self.trajectory)))
                 if sup_now > sup_last:
                     n = sup_now - sup_last
-                    lo, hi = box(sup_now + B - n + 1, sup_now + B); self._load(lo, hi); self.page_events.append(("load", a, lo[a], hi[a]))
+                    lo, hi = box(sup_now + B - n + 1, sup_now + B); self._load(lo, hi); self.page_events.append(("load", a, lo[a], hi[a], len(self.trajectory)))
                 self.win[a][1] = sup_now
 
     def get_map(self):

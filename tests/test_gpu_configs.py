@@ -270,3 +270,122 @@ def test_config5_registration_on_the_10M_map(amd, oracle, scene_10m):
     T_again = icp(icp.transform(T_full, sc["scan"]))
     mt, mr = amd.synth.pose_error(T_again, np.eye(4, dtype=np.float32))
     assert mt < 3e-3 and mr < 3e-3, (mt, mr)
+
+
+# ------------------------------------------------------------------------------------------------ cell paging (a12 / f4)
+PAGING_CONFIG = """
+post:
+  - SurfaceNormalDataPointsFilter:
+      knn: 10
+mapper:
+  updateCondition:
+    type: distance
+    value: 2.0
+  mapperModule:
+    - PointDistanceMapperModule:
+        minDistNewPoint: 0.3
+  sensorMaxRange: 25
+icp:
+  matcher:
+    KDTreeMatcher:
+      knn: 1
+      maxDist: 2.0
+      epsilon: 0
+  outlierFilters:
+    - TrimmedDistOutlierFilter:
+        ratio: 0.85
+  errorMinimizer:
+    PointToPlaneErrorMinimizer:
+  transformationCheckers:
+    - CounterTransformationChecker:
+        maxIterationCount: 30
+    - DifferentialTransformationChecker:
+        minDiffRotErr: 0.001
+        minDiffTransErr: 0.001
+        smoothLength: 3
+  inspector: NullInspector
+"""
+
+
+def _make_corridor_dataset(tmp, amd, out_steps=26, back_steps=18, step=5.0, n_pts=5000, scale=2.4):
+    """a sensor driving 125 m along x through the (scaled) synthetic hall and 90 m back, seeing 25 m: with 20 m cells, a window of
+    sensorMaxRange + 2 buffer cells and a hysteresis of 2 cells the map pages cells out behind it on the way out and loads
+    them again -- points included -- on the way back (Map.cpp:246-460)"""
+    from test_host_cpp import _write_vtk, _quat
+    os.makedirs(os.path.join(tmp, "scans"))
+    rows, scans, priors = [], [], []
+    x0 = -82.0
+    along = list(range(out_steps)) + list(range(out_steps - 2, out_steps - 2 - back_steps, -1))
+    for s, k in enumerate(along):
+        T_true = amd.synth.make_T((0.0, 0.0, 0.01 * k), (x0 + step * k, 1.0 + 0.05 * k + (0.4 if s >= out_steps else 0.0), 0.0))
+        pts, _ = amd.synth.sample_surfaces(60 * n_pts, seed=700 + s, scale=scale)
+        sensor = T_true[:3, 3] + np.array([0.0, 0.0, 1.5])
+        pts = pts[np.linalg.norm(pts - sensor, axis=1) < 24.0][:n_pts]
+        pts = pts + np.stack([amd.synth.gaussian(1100 + s, 2 * r, len(pts)) for r in range(3)], 1) * 0.01
+        Ti = np.linalg.inv(T_true)
+        local = (pts @ Ti[:3, :3].T + Ti[:3, 3]).astype(np.float32)
+        T_prior = amd.synth.make_T((0.002, -0.002, 0.001), (0.02, -0.015, 0.01)) @ T_true if s else T_true
+        q = _quat(T_prior[:3, :3])
+        rows.append([1700000000, 100000000 * s, *T_prior[:3, 3], *q])
+        _write_vtk(os.path.join(tmp, "scans", f"cloud_{s:03d}.vtk"), local)
+        scans.append(local)
+    with open(os.path.join(tmp, "trajectory.csv"), "w") as f:
+        f.write("header.stamp.sec,header.stamp.nanosec,header.frame_id,child_frame_id,pose.pose.position.x,pose.pose.position.y,"
+                "pose.pose.position.z,pose.pose.orientation.x,pose.pose.orientation.y,pose.pose.orientation.z,pose.pose.orientation.w,pose.covariance\n")
+        for r in rows:
+            f.write(f"{r[0]},{r[1]},map,base_link," + ",".join(repr(float(v)) for v in r[2:]) + ",[0. 0. 0.]\n")
+    for r in rows:
+        priors.append(_quat_T(np.array(r[2:], dtype=np.float64)))
+    return scans, priors, [r[0] + r[1] * 1e-9 for r in rows]
+
+
+def test_cell_paging_replay_against_oracle_replay(amd, oracle, tmp_path):
+    """Map::updatePose / loadCells / unloadCells / RAMCellManager under the GPU-backed host shell: a drive long enough to page
+    cells out (and, on the way back in the second half of the list, in again), scan by scan against the oracle-side replay with
+    the reference's paging restated (tests/oracle_mapper.py: update_pose) -- poses, and the global map (local cloud + saved
+    cells, Mapper::getMap) as a point set."""
+    from test_host_cpp import _build_host, _read_vtk
+    import oracle_mapper as om
+    _build_host()
+    tmp = str(tmp_path)
+    scans, priors, stamps = _make_corridor_dataset(tmp, amd)
+    cfg = os.path.join(tmp, "config.yaml")
+    open(cfg, "w").write(PAGING_CONFIG)
+    traj_out = os.path.join(tmp, "traj.vtk")
+    out = subprocess.run([os.path.join(PKG, "build_map_from_scans_and_trajectory"), tmp, cfg, traj_out], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr + out.stdout
+    pos, desc = _read_vtk(traj_out)
+    mapper = om.OracleMapper(dict(knn=1, max_dist=2.0, minimizer=2, outliers=[(4, 0.85)], max_iterations=30, use_differential=1),
+                             [("point_distance", 0.3)], post=[("surface_normals", 10)], update=("distance", 2.0), sensor_max_range=25.0,
+                             nthreads=min(16, len(os.sched_getaffinity(0))), paging=True)
+    worst = 0.0
+    sizes = []
+    for i, (scan, prior, stamp) in enumerate(zip(scans, priors, stamps)):
+        cloud = mapper.apply_input_filters(scan)
+        T_ref = mapper.process_input(cloud, prior, stamp)
+        sizes.append(mapper.map["xyz1"].shape[0])
+        T = np.eye(4, dtype=np.float32)
+        T[:3, 0], T[:3, 1], T[:3, 2], T[:3, 3] = desc["orientationX"][i], desc["orientationY"][i], desc["orientationZ"][i], pos[i]
+        dt, dr = amd.synth.pose_error(T, T_ref)
+        if not (dt <= POSE_TOL_M and dr <= POSE_TOL_RAD):
+            import re
+            its = re.findall(r"iterations (\d+)  overlap \S+  local map (\d+)", out.stdout)
+            raise AssertionError((i, dt, dr, "harness (iterations, local map)", its[max(0, i - 8):i + 1], "oracle local map", sizes[max(0, i - 8):i + 1],
+                                  "oracle iterations", mapper.iterations[max(0, i - 8):i + 1], "page events", mapper.page_events))
+        worst = max(worst, dt)
+    unloads = [e for e in mapper.page_events if e[0] == "unload"]
+    loads = [e for e in mapper.page_events if e[0] == "load"]
+    assert len(unloads) >= 4 and len(loads) >= 4, mapper.page_events            # the window moved out and back
+    assert mapper.reloaded_points > 0                                            # and points saved on the way out came back into the local map
+    assert any(c["xyz1"].shape[0] > 0 for cid, c in mapper.cells.items() if cid not in mapper.loaded)   # and cells hold points that left the local map
+    # Mapper::getMap(): local cloud + saved cells not loaded -- the same point set on both sides
+    mp, mdesc = _read_vtk(os.path.join(tmp, "map.vtk"))
+    ref = mapper.get_map()["xyz1"][:, :3]
+    assert mp.shape[0] == ref.shape[0], (mp.shape, ref.shape)
+    a = np.sort(np.ascontiguousarray(mp).view([("x", "f4"), ("y", "f4"), ("z", "f4")]).ravel())
+    b = np.sort(np.ascontiguousarray(ref).view([("x", "f4"), ("y", "f4"), ("z", "f4")]).ravel())
+    same = np.mean(a == b)
+    assert same > 0.999, same        # (ASCII VTK keeps 9 significant digits: exact round trip of float32)
+    local_n = mapper.map["xyz1"].shape[0]
+    assert local_n < ref.shape[0]                                                # part of the map lives in the cell manager
+    print(f"paging: {len(scans)} scans, {len(unloads)} unloads / {len(loads)} loads, local {local_n} of {ref.shape[0]} points, worst pose difference {worst:.2e} m")
