@@ -51,20 +51,48 @@ __device__ __forceinline__ int cell_of(float v, float o, float inv, int n)
     return c < 0 ? 0 : (c >= n ? n - 1 : c);
 }
 
+// ---- runs of equal keys inside a wave become ONE atomic per run --------------------------------
+// The coarser pyramid levels are built from the cell-sorted level-0 array (10^3..10^6 points per coarse cell: one atomic per
+// point serialises at ~6.5 ns each on the same address -- 11 ms per kernel at 1 M points), and the cloud handed to set_map is
+// often spatially ordered too (the octree filter leaves the map in Morton order; a lidar scan is ordered along its beams):
+// level 0 uses the same trick (r2: 98 -> 4x fewer device atomics on an octree-ordered 0.9 M-point map).
+struct WaveRun { bool head; int rank; int len; int head_lane; };
+__device__ __forceinline__ WaveRun wave_run(unsigned key, bool valid)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned prev = (unsigned)__shfl_up((int)key, 1, 64);
+    const bool pvalid = __shfl_up((int)valid, 1, 64) != 0;
+    const bool head = valid && (lane == 0 || !pvalid || prev != key);
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long valids = __ballot(valid);
+    WaveRun r;
+    r.head = head;
+    const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+    r.head_lane = below ? 63 - __clzll((long long)below) : lane;
+    r.rank = lane - r.head_lane;
+    const unsigned long long above = (lane == 63) ? 0ull : (heads & ~((2ull << lane) - 1ull));
+    const int nvalid = __popcll(valids); // valid lanes are a prefix of the wave
+    const int end = above ? (__ffsll((long long)above) - 1) : nvalid;
+    r.len = end - r.head_lane;
+    return r;
+}
+
 // ---- pass 2: keys + per-cell histogram -------------------------------------------------------
 __global__ __launch_bounds__(256) void key_kernel(const float4* __restrict__ pts, int64_t m, float mx, float my, float mz,
                                                   GridParams g, unsigned* __restrict__ keys, unsigned* __restrict__ count,
-                                                  unsigned* __restrict__ n_occ)
+                                                  unsigned* __restrict__ n_occ, int run_atomics)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= m) return;
-    const float4 p = pts[i];
+    const bool valid = i < m;
+    const float4 p = pts[valid ? i : 0];
     const int cx = cell_of(p.x - mx, g.ox, g.inv_cell, g.nx);
     const int cy = cell_of(p.y - my, g.oy, g.inv_cell, g.ny);
     const int cz = cell_of(p.z - mz, g.oz, g.inv_cell, g.nz);
     const unsigned key = (unsigned)((cz * g.ny + cy) * g.nx + cx);
-    keys[i] = key;
-    if (atomicAdd(&count[key], 1u) == 0u) atomicAdd(n_occ, 1u);
+    if (valid) keys[i] = key;
+    if (!run_atomics) { if (valid && atomicAdd(&count[key], 1u) == 0u) atomicAdd(n_occ, 1u); return; }
+    const WaveRun r = wave_run(key, valid);
+    if (r.head && atomicAdd(&count[key], (unsigned)r.len) == 0u) atomicAdd(n_occ, 1u);
 }
 
 // ---- exclusive scan of the cell histogram (3 kernels) ----------------------------------------
@@ -137,40 +165,24 @@ __global__ __launch_bounds__(SCAN_T) void scan_final_kernel(unsigned* __restrict
 __global__ __launch_bounds__(256) void scatter_kernel(const float4* __restrict__ pts, const float* __restrict__ normals3, int64_t m,
                                                       float mx, float my, float mz, const unsigned* __restrict__ keys,
                                                       const unsigned* __restrict__ start, unsigned* __restrict__ fill,
-                                                      float4* __restrict__ out, float4* __restrict__ out_n)
+                                                      float4* __restrict__ out, float4* __restrict__ out_n, int run_atomics)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= m) return;
-    const float4 p = pts[i];
-    const unsigned key = keys[i];
-    const unsigned pos = start[key] + atomicAdd(&fill[key], 1u);
+    const bool valid = i < m;
+    const float4 p = pts[valid ? i : 0];
+    const unsigned key = keys[valid ? i : 0];
+    unsigned pos;
+    if (!run_atomics) { if (!valid) return; pos = start[key] + atomicAdd(&fill[key], 1u); }
+    else {
+        const WaveRun r = wave_run(key, valid);
+        unsigned base = 0;
+        if (r.head) base = atomicAdd(&fill[key], (unsigned)r.len);
+        base = (unsigned)__shfl((int)base, r.head_lane, 64);
+        if (!valid) return;
+        pos = start[key] + base + (unsigned)r.rank;
+    }
     out[pos] = make_float4(p.x - mx, p.y - my, p.z - mz, __uint_as_float((unsigned)i));
     if (out_n) out_n[pos] = make_float4(normals3[3 * i], normals3[3 * i + 1], normals3[3 * i + 2], 0.f);
-}
-
-// ---- coarser pyramid levels are built from the level-0 (already centred, cell-sorted) array ----
-// The level-0 array is cell sorted, so consecutive points mostly share their coarser cell: each wave
-// turns its runs of equal keys into ONE atomic per run (coarse levels hold 10^3..10^6 points per cell;
-// one atomic per point serialises at ~6.5 ns each on the same address -- 11 ms per kernel at 1 M points).
-struct WaveRun { bool head; int rank; int len; int head_lane; };
-__device__ __forceinline__ WaveRun wave_run(unsigned key, bool valid)
-{
-    const int lane = threadIdx.x & 63;
-    const unsigned prev = (unsigned)__shfl_up((int)key, 1, 64);
-    const bool pvalid = __shfl_up((int)valid, 1, 64) != 0;
-    const bool head = valid && (lane == 0 || !pvalid || prev != key);
-    const unsigned long long heads = __ballot(head);
-    const unsigned long long valids = __ballot(valid);
-    WaveRun r;
-    r.head = head;
-    const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
-    r.head_lane = below ? 63 - __clzll((long long)below) : lane;
-    r.rank = lane - r.head_lane;
-    const unsigned long long above = (lane == 63) ? 0ull : (heads & ~((2ull << lane) - 1ull));
-    const int nvalid = __popcll(valids); // valid lanes are a prefix of the wave
-    const int end = above ? (__ffsll((long long)above) - 1) : nvalid;
-    r.len = end - r.head_lane;
-    return r;
 }
 
 __global__ __launch_bounds__(256) void lvl_key_kernel(const float4* __restrict__ pts0, int64_t m, GridParams g,
@@ -424,6 +436,13 @@ icpmi_status sort_queries_batch(icpmi_ctx* c, const float4* d_pts, const BatchAr
 
 icpmi_status sort_queries(icpmi_ctx* c, const float4* d_pts, int64_t n) { return sort_queries_batch(c, d_pts, batch_of_one(n)); }
 
+static int run_atomics_cfg()
+{
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("ICPMI_RUN_ATOMICS"); v = e ? atoi(e) : 1; }
+    return v;
+}
+
 // in-place exclusive scan of data[0..n) (counts -> starts); data[n] = total
 icpmi_status device_exclusive_scan(icpmi_ctx* c, unsigned* data, int n, unsigned total)
 {
@@ -443,7 +462,7 @@ static icpmi_status grid_count(icpmi_ctx* c, const float4* d_pts, int64_t m, con
     unsigned* d_nocc = c->d_cell_start + g.ncells + 1; // spare word after start[ncells]
     const int blocks = (int)((m + 255) / 256);
     hipLaunchKernelGGL(key_kernel, dim3(blocks), dim3(256), 0, c->stream, d_pts, m, c->mean[0], c->mean[1], c->mean[2], g,
-                       c->d_keys, c->d_cell_start, d_nocc);
+                       c->d_keys, c->d_cell_start, d_nocc, run_atomics_cfg());
     HIP_TRY(c, hipGetLastError());
     if (read_back(c, h_nocc, d_nocc, sizeof(unsigned)) != ICPMI_OK) return ICPMI_ERR_HIP;
     return ICPMI_OK;
@@ -562,7 +581,7 @@ icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float
     c->m_raw = c->keep_raw ? m : 0; c->raw_has_normals = c->keep_raw && d_normals3 != nullptr;
     const int blocks = (int)((m + 255) / 256);
     hipLaunchKernelGGL(scatter_kernel, dim3(blocks), dim3(256), 0, c->stream, d_pts, d_normals3, m, c->mean[0], c->mean[1], c->mean[2],
-                       c->d_keys, c->d_cell_start, c->d_fill, c->d_map_sorted, d_normals3 ? c->d_normals_sorted : nullptr);
+                       c->d_keys, c->d_cell_start, c->d_fill, c->d_map_sorted, d_normals3 ? c->d_normals_sorted : nullptr, run_atomics_cfg());
     HIP_TRY(c, hipGetLastError());
 
     // ---- coarser pyramid levels: cell edge doubles until one 3x3x3 block reaches past maxDist (or

@@ -446,6 +446,19 @@ struct TempCtx {
     icpmi_handle h = nullptr;
 };
 
+// private handles enqueue on the owner's stream: what they read was produced there and what they produce is consumed there,
+// so stream order replaces the hipStreamSynchronize pairs an own stream needs (r2: two per surface-normal step of a map update)
+static void share_stream(icpmi_ctx* c, icpmi_ctx* t)
+{
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("ICPMI_SHARE_STREAM"); on = e ? atoi(e) : 1; }
+    if (!on || t->stream == c->stream) return;
+    if (t->stream) (void)hipStreamSynchronize(t->stream);
+    if (t->own_stream && t->stream) (void)hipStreamDestroy(t->stream);
+    t->stream = c->stream; t->own_stream = false;
+    if (t->graph_exec) { hipGraphExecDestroy(t->graph_exec); t->graph_exec = nullptr; t->graph_n = -1; }
+}
+
 static icpmi_status make_temp(icpmi_ctx* c, TempCtx& t)
 {
     if (!c->temp) {
@@ -454,6 +467,7 @@ static icpmi_status make_temp(icpmi_ctx* c, TempCtx& t)
         if (s != ICPMI_OK) { c->last_error = icpmi_last_error(nullptr); c->temp = nullptr; return s; }
     }
     t.h = c->temp;
+    share_stream(c, t.h);
     t.h->cfg = c->cfg;
     t.h->keep_raw = false;
     t.h->no_centre = true; // PointDistanceMapperModule.cpp:33 / SurfaceNormalDataPointsFilter build their kd-tree on the raw cloud
@@ -473,9 +487,10 @@ static icpmi_status raw_index(icpmi_ctx* c, icpmi_ctx** out)
         c->temp_raw_version = 0;
     }
     icpmi_ctx* t = c->temp_raw;
+    share_stream(c, t);
     t->cfg = c->cfg; t->keep_raw = false; t->no_centre = true; t->single_level = false;
     if (c->temp_raw_version != c->map_version || t->m != c->m_raw) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream)); // the resident copy was produced on the caller's stream
+        if (t->stream != c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream)); // the resident copy was produced on the caller's stream
         int32_t ok = 0;
         icpmi_status s = icpmi_set_map_dev(t, (const float*)c->d_raw, c->m_raw, nullptr, &ok);
         if (s != ICPMI_OK) { c->last_error = t->last_error; return s; }
@@ -759,7 +774,7 @@ static icpmi_status surface_normals_dev(icpmi_ctx* c, const float4* d_pts, int64
     icpmi_status s = make_temp(c, t);
     if (s != ICPMI_OK) return s;
     icpmi_ctx* tc = t.h;
-    HIP_TRY(c, hipStreamSynchronize(c->stream)); // d_pts was produced on the caller's stream
+    if (tc->stream != c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream)); // d_pts was produced on the caller's stream
     tc->single_level = true;
     int32_t acc = 0;
     s = icpmi_set_map_dev(t.h, (const float*)d_pts, m, nullptr, &acc);
@@ -777,9 +792,8 @@ static icpmi_status surface_normals_dev(icpmi_ctx* c, const float4* d_pts, int64
     // rows of d_sidx follow the query order = the caller's order, so the normals land in place
     hipLaunchKernelGGL(normals_kernel, dim3((int)((m + 127) / 128)), dim3(128), 0, tc->stream, tc->d_map_sorted, tc->d_sidx, m, knn, d_normals3,
                        (float*)nullptr);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(tc->stream);
-    HIP_TRY(c, e);
+    HIP_TRY(c, hipGetLastError());
+    if (tc->stream != c->stream) HIP_TRY(c, hipStreamSynchronize(tc->stream));
     return ICPMI_OK;
 }
 
@@ -1077,7 +1091,7 @@ icpmi_status chain_point_distance_flags(icpmi_ctx* c, icpmi_ctx* ic, const float
     if (s != ICPMI_OK) { c->last_error = ic->last_error; return s; }
     hipLaunchKernelGGL(keep_flag_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, ic->stream, ic->d_d2, n, lim, d_flag);
     HIP_TRY(c, hipGetLastError());
-    if (ic != c) HIP_TRY(c, hipStreamSynchronize(ic->stream));
+    if (ic->stream != c->stream) HIP_TRY(c, hipStreamSynchronize(ic->stream));
     return ICPMI_OK;
 }
 
@@ -1176,7 +1190,7 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
                 s = make_temp(c, t);
                 if (s != ICPMI_OK) break;
                 ic = t.h;
-                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                if (ic->stream != c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
                 int32_t acc = 0;
                 s = icpmi_set_map_dev(ic, (const float*)c->d_raw, w.m, nullptr, &acc);
                 if (s != ICPMI_OK) { c->last_error = ic->last_error; break; }
@@ -1371,7 +1385,7 @@ icpmi_status ops_staged_merge_allgather(icpmi_ctx* c, const float correction[16]
         TempCtx t;
         s = make_temp(c, t);
         if (s != ICPMI_OK) return s;
-        HIP_TRY(c, hipStreamSynchronize(c->stream)); // the private handle works on its own stream
+        if (t.h->stream != c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
         int32_t ok = 0;
         s = icpmi_set_map_dev(t.h, (const float*)c->d_merged, acc, nullptr, &ok);
         if (s != ICPMI_OK) { c->last_error = t.h->last_error; return s; }

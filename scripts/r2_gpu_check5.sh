@@ -1,0 +1,6 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"; O=gpurun_out/r2c5; mkdir -p $O
+python scripts/r2_chain_bench.py 2>&1 | tee $O/chain_bench.txt
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_chain -- python $GRAFT_REPO_ROOT/scripts/r2_chain_bench.py 1000000 100000 12 "round trip" > /dev/null 2>&1
+python $GRAFT_REPO_ROOT/scripts/kstats.py $GRAFT_REPO_ROOT/$O/prof_chain | head -45
