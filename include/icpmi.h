@@ -65,12 +65,27 @@ typedef enum {
     ICPMI_OUT_MINDIST = 2,      /* MinDistOutlierFilter{minDist}        w = d2 >= minDist^2          */
     ICPMI_OUT_MEDIANDIST = 3,   /* MedianDistOutlierFilter{factor}      w = d2 <= factor*median(d2)  */
     ICPMI_OUT_TRIMMEDDIST = 4,  /* TrimmedDistOutlierFilter{ratio}      w = d2 <= quantile(d2,ratio) */
-    ICPMI_OUT_SURFACENORMAL = 5 /* SurfaceNormalOutlierFilter{maxAngle} w = n_read.n_ref > cos(maxAngle) */
+    ICPMI_OUT_SURFACENORMAL = 5,/* SurfaceNormalOutlierFilter{maxAngle} w = n_read.n_ref > cos(maxAngle) */
+    /* GenericDescriptorOutlierFilter{source: reference, descName, useSoftThreshold, useLargerThan, threshold}: the 1-row descriptor
+     * of the matched map point -- the tracked scalar channel, icpmi_set_map_scalar -- decides.  param = threshold, iparam = flags.
+     * hard: w = desc > threshold (useLargerThan) or desc < threshold; soft: w = desc.  source: reading is UNSUPPORTED. */
+    ICPMI_OUT_GENERICDESCRIPTOR = 6,
+    /* RobustOutlierFilter{robustFct, tuning, scaleEstimator: none | mad, nbIterationForScale, distanceType}: M-estimator weight of
+     * e2 = residual / scale^2.  param = tuning, param2 = nbIterationForScale, iparam = robustFct | scaleEstimator << 4 |
+     * distanceType << 8.  berg / std scale estimators and a finite `approximation` are UNSUPPORTED. */
+    ICPMI_OUT_ROBUST = 7
 } icpmi_outlier_type;
+enum { ICPMI_GEN_SOURCE_READING = 1, ICPMI_GEN_SOFT = 2, ICPMI_GEN_LARGER = 4 };
+enum { ICPMI_ROB_CAUCHY = 0, ICPMI_ROB_WELSCH = 1, ICPMI_ROB_SC = 2, ICPMI_ROB_GM = 3, ICPMI_ROB_TUKEY = 4, ICPMI_ROB_HUBER = 5,
+       ICPMI_ROB_L1 = 6, ICPMI_ROB_STUDENT = 7 };
+enum { ICPMI_SCALE_NONE = 0, ICPMI_SCALE_MAD = 1 };
+enum { ICPMI_DIST_POINT2POINT = 0, ICPMI_DIST_POINT2PLANE = 1 };
 
 typedef struct {
     int32_t type; /* icpmi_outlier_type */
     float   param;
+    int32_t iparam; /* flags / enums of GenericDescriptor and Robust, 0 otherwise */
+    float   param2; /* Robust: nbIterationForScale                                 */
 } icpmi_outlier;
 
 typedef enum { ICPMI_STOP_NONE = 0, ICPMI_STOP_COUNTER = 1, ICPMI_STOP_DIFFERENTIAL = 2 } icpmi_stop_reason;
@@ -89,6 +104,7 @@ typedef struct {
     icpmi_outlier outlier[8];
     /* error minimiser */
     int32_t minimizer;         /* icpmi_minimizer                                                 */
+    int32_t force_4dof;        /* PointToPlaneErrorMinimizer.force4DOF: yaw + translation only     */
     /* transformation checkers */
     int32_t max_iterations;    /* CounterTransformationChecker.maxIterationCount, default 40      */
     int32_t use_differential;  /* DifferentialTransformationChecker present                       */

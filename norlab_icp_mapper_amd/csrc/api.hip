@@ -53,7 +53,19 @@ static icpmi_status validate_config(const icpmi_config* cfg, std::string& err)
     for (int f = 0; f < cfg->n_outlier; ++f) {
         const int t = cfg->outlier[f].type;
         const float p = cfg->outlier[f].param;
-        if (t < ICPMI_OUT_MAXDIST || t > ICPMI_OUT_SURFACENORMAL) { err = "InvalidParameter: unknown outlier filter type"; return ICPMI_ERR_INVALID_ARG; }
+        if (t < ICPMI_OUT_MAXDIST || t > ICPMI_OUT_ROBUST) { err = "InvalidParameter: unknown outlier filter type"; return ICPMI_ERR_INVALID_ARG; }
+        if (t == ICPMI_OUT_GENERICDESCRIPTOR) {
+            const int ip = cfg->outlier[f].iparam;
+            if (ip & ~7) { err = "InvalidParameter: GenericDescriptorOutlierFilter: unknown flag"; return ICPMI_ERR_INVALID_ARG; }
+            if (ip & ICPMI_GEN_SOURCE_READING) { err = "GenericDescriptorOutlierFilter{source: reading} is not supported (the boundary carries no reading descriptor)"; return ICPMI_ERR_UNSUPPORTED; }
+        }
+        if (t == ICPMI_OUT_ROBUST) {
+            const int ip = cfg->outlier[f].iparam;
+            if ((ip & 15) > ICPMI_ROB_STUDENT || ((ip >> 4) & 15) > ICPMI_SCALE_MAD || ((ip >> 8) & 15) > ICPMI_DIST_POINT2PLANE || (ip >> 12)) {
+                err = "InvalidParameter: RobustOutlierFilter: unknown robustFct / scaleEstimator / distanceType"; return ICPMI_ERR_INVALID_ARG;
+            }
+            if (!(cfg->outlier[f].param2 >= 0.f)) { err = "InvalidParameter: RobustOutlierFilter: nbIterationForScale must be >= 0"; return ICPMI_ERR_INVALID_ARG; }
+        }
         if (t == ICPMI_OUT_TRIMMEDDIST && !(p >= 0.f && p <= 1.f)) { err = "InvalidParameter: TrimmedDist ratio must be in [0, 1]"; return ICPMI_ERR_INVALID_ARG; }
         if ((t == ICPMI_OUT_MAXDIST || t == ICPMI_OUT_MINDIST || t == ICPMI_OUT_MEDIANDIST) && !(p >= 0.f)) { err = "InvalidParameter: negative outlier filter parameter"; return ICPMI_ERR_INVALID_ARG; }
     }
@@ -230,6 +242,23 @@ icpmi_status icpmi_set_map(icpmi_handle h, const float* map4, int64_t m, const f
 
 static void identity16(float* T) { for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.f : 0.f; }
 
+// fields the GenericDescriptor / Robust filters of the chain read on the map
+static icpmi_status check_ext_filters(icpmi_ctx* h)
+{
+    for (int f = 0; f < h->cfg.n_outlier; ++f) {
+        const icpmi_outlier& o = h->cfg.outlier[f];
+        if (o.type == ICPMI_OUT_GENERICDESCRIPTOR && !(h->raw_has_scalar && h->m_raw == h->m)) {
+            h->last_error = "InvalidField: GenericDescriptorOutlierFilter needs the tracked scalar descriptor on the map (icpmi_set_map_scalar)";
+            return ICPMI_ERR_INVALID_ARG;
+        }
+        if (o.type == ICPMI_OUT_ROBUST && ((o.iparam >> 8) & 15) == ICPMI_DIST_POINT2PLANE && !h->has_normals) {
+            h->last_error = "InvalidField: RobustOutlierFilter{distanceType: point2plane} needs the descriptor 'normals' on the map";
+            return ICPMI_ERR_MISSING_NORMALS;
+        }
+    }
+    return ICPMI_OK;
+}
+
 static icpmi_status register_impl(icpmi_handle h, const float* d_scan4, int64_t n, const float* d_n3, int fixed_iters,
                                   float T_out[16], icpmi_stats* stats)
 {
@@ -249,6 +278,7 @@ static icpmi_status register_impl(icpmi_handle h, const float* d_scan4, int64_t 
         h->last_error = "InvalidField: SurfaceNormalOutlierFilter needs 'normals' on both reading and map";
         return ICPMI_ERR_MISSING_NORMALS;
     }
+    { const icpmi_status es = check_ext_filters(h); if (es != ICPMI_OK) return es; }
     LoopCfg lc = make_loop_cfg(h, fixed_iters);
     lc.has_read_normals = needs_rn ? 1 : 0;
     if (n == 0) {
@@ -292,7 +322,7 @@ icpmi_status icpmi_register_batch_dev(icpmi_handle h, int32_t batch, const float
     int nquant = 0;
     for (int f = 0; f < h->cfg.n_outlier; ++f) {
         const int t = h->cfg.outlier[f].type;
-        if (t == ICPMI_OUT_SURFACENORMAL) together = false;
+        if (t == ICPMI_OUT_SURFACENORMAL || t == ICPMI_OUT_GENERICDESCRIPTOR || t == ICPMI_OUT_ROBUST) together = false;
         if (t == ICPMI_OUT_TRIMMEDDIST || t == ICPMI_OUT_MEDIANDIST) ++nquant;
     }
     if (nquant > 1) together = false;
@@ -410,6 +440,7 @@ icpmi_status icpmi_minimize_step(icpmi_handle h, const float* reading4, int64_t 
 {
     CHECK_H(h);
     if (n <= 0 || !reading4) { h->last_error = "minimize_step: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
+    { const icpmi_status es = check_ext_filters(h); if (es != ICPMI_OK) return es; }
     if (h->m <= 0) { h->last_error = "minimize_step: no map"; return ICPMI_ERR_INVALID_ARG; }
     if (h->cfg.minimizer == ICPMI_MIN_POINT_TO_PLANE && !h->has_normals) {
         h->last_error = "InvalidField: PointToPlaneErrorMinimizer needs the descriptor 'normals' on the map";

@@ -84,6 +84,10 @@ struct LoopCfg {
     int   n_out;
     int   out_type[ICPMI_MAX_OUTLIER];
     float out_param[ICPMI_MAX_OUTLIER];
+    int   out_iparam[ICPMI_MAX_OUTLIER];
+    float out_param2[ICPMI_MAX_OUTLIER];
+    int   ext;             // GenericDescriptor / Robust in the chain: the pair-sum kernel's EXT variant
+    int   force_4dof;
     int   max_iter;
     int   use_diff;
     float min_rot, min_trans;
@@ -113,6 +117,8 @@ struct IcpState {
     unsigned sel_prefix_l[3];  // fused selection: one slot per radix level (written by level L,
     unsigned sel_rank_l[3];    // read by level L + 1 -- never both in one kernel)
     float limits[ICPMI_MAX_OUTLIER];
+    float robust_med;      // RobustOutlierFilter{mad}: median of the finite d2 of this iteration
+    float robust_scale;    // RobustOutlierFilter::scale, kept between iterations (nbIterationForScale)
     // statistics of the last iteration
     long long pairs;
     double wsum;

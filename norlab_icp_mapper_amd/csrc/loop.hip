@@ -16,18 +16,27 @@ namespace {
 // and > 0, element of rank (size_t)(count * quantile) [float product], quantile == 1 -> max.
 // d2 >= 0 so the IEEE bit pattern orders like an unsigned integer: 3 radix passes 11/11/10 bits.
 // ---------------------------------------------------------------------------------------------
-template <int PASS>
+// MODE 0: the quantile of the finite positive d2 (getDistsQuantile).  MODE 1 / 2: RobustOutlierFilter{scaleEstimator: mad} --
+// Matches::getMedianAbsDeviation takes every finite d2 (zeros included): 1 = the values themselves, 2 = |d2 - median|;
+// nb_scale: the estimate is only refreshed while iteration <= nbIterationForScale (0 = always).
+template <int PASS, int MODE = 0>
 __global__ __launch_bounds__(256) void sel_hist_kernel(const float* __restrict__ d2, int64_t count,
-                                                       const IcpState* __restrict__ st, unsigned* __restrict__ ghist)
+                                                       const IcpState* __restrict__ st, unsigned* __restrict__ ghist, int nb_scale = 0)
 {
     if (st->done) return;
+    if (MODE != 0 && nb_scale != 0 && st->iter + 1 > nb_scale) return;
     __shared__ unsigned h[ICPMI_SEL_BINS];
     for (int b = threadIdx.x; b < ICPMI_SEL_BINS; b += 256) h[b] = 0;
     __syncthreads();
     const unsigned prefix = st->sel_prefix;
+    const float med = MODE == 2 ? st->robust_med : 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
-        const float v = d2[i];
-        if (!(v != INFINITY && v > 0.f)) continue;
+        float v = d2[i];
+        if (MODE == 0) { if (!(v != INFINITY && v > 0.f)) continue; }
+        else {
+            if (v == INFINITY) continue;
+            if (MODE == 2) v = fabsf(v - med);
+        }
         const unsigned bits = __float_as_uint(v);
         if (PASS == 0) atomicAdd(&h[bits >> 21], 1u);
         else if (PASS == 1) { if ((bits >> 21) == prefix) atomicAdd(&h[(bits >> 10) & 2047u], 1u); }
@@ -41,9 +50,11 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(const float* __restrict__
 // single workgroup: locate the bin holding the wanted rank, narrow prefix / rank, clear the histogram
 template <int PASS>
 __global__ __launch_bounds__(256) void sel_scan_kernel(IcpState* __restrict__ st, unsigned* __restrict__ ghist, float quantile,
-                                                       int filter_slot, int is_median, float factor)
+                                                       int filter_slot, int is_median, float factor, int dest = 0, int nb_scale = 0)
 {
+    // dest 0: limits[filter_slot] (quantile filters); 1: robust_med, 2: robust_scale = sqrt(mad) -- rank size / 2 (quantile < 0)
     if (st->done) return;
+    if (dest != 0 && nb_scale != 0 && st->iter + 1 > nb_scale) return;
     __shared__ unsigned sh[256];
     __shared__ unsigned s_rank;
     const int t = threadIdx.x;
@@ -64,7 +75,8 @@ __global__ __launch_bounds__(256) void sel_scan_kernel(IcpState* __restrict__ st
             if (total == 0) { st->error = ICPMI_ERR_NO_OUTLIER_TO_FILTER; st->done = 1; s_rank = 0; }
             else {
                 unsigned r;
-                if (quantile == 1.0f) r = total - 1;
+                if (quantile < 0.f) r = total / 2;
+                else if (quantile == 1.0f) r = total - 1;
                 else {
                     r = (unsigned)((float)total * quantile);
                     if (r > total - 1) r = total - 1;
@@ -89,7 +101,9 @@ __global__ __launch_bounds__(256) void sel_scan_kernel(IcpState* __restrict__ st
         st->sel_rank = rank - acc;
         if (PASS == 2) {
             const float q = __uint_as_float(np);
-            st->limits[filter_slot] = is_median ? factor * q : q;
+            if (dest == 1) st->robust_med = q;
+            else if (dest == 2) st->robust_scale = sqrtf(q);
+            else st->limits[filter_slot] = is_median ? factor * q : q;
         }
     }
 }
@@ -244,10 +258,36 @@ __global__ __launch_bounds__(256) void sel2_scan_hist_kernel(const float* __rest
 // ---------------------------------------------------------------------------------------------
 // outlier weight of one match (OutlierFilters::compute; weights multiply)
 // ---------------------------------------------------------------------------------------------
+// M-estimator weight of RobustOutlierFilter for the scaled squared residual e2 (tuning k); exp / pow through double so that
+// host libm and device ocml round to the same float
+__device__ __forceinline__ float robust_weight(int fct, float e2, float kk)
+{
+    const float k2 = kk * kk;
+    float w;
+    switch (fct) {
+    case ICPMI_ROB_CAUCHY: w = 1.f / (1.f + e2 / k2); break;
+    case ICPMI_ROB_WELSCH: w = (float)exp((double)(-e2 / k2)); break;
+    case ICPMI_ROB_SC: { const float t = kk + e2; w = e2 >= kk ? 4.f * k2 * (1.f / (t * t)) : 1.f; break; }
+    case ICPMI_ROB_GM: { const float t = kk + e2; w = k2 * (1.f / (t * t)); break; }
+    case ICPMI_ROB_TUKEY: { const float t = 1.f - e2 / k2; w = e2 >= k2 ? 0.f : t * t; break; }
+    case ICPMI_ROB_HUBER: w = e2 >= k2 ? kk * (1.f / sqrtf(e2)) : 1.f; break;
+    case ICPMI_ROB_L1: w = 1.f / sqrtf(e2); break;
+    default: {
+        const float pw = (float)pow((double)(1.f + e2 / kk), (double)(-(kk + 3.f) / 2.f));
+        w = pw * (kk + 3.f) * (1.f / (kk + e2));
+        break; }
+    }
+    return w <= 0.f ? 0.f : w;
+}
+
+// EXT: chains with GenericDescriptor / Robust filters -- ref_scalar (per ORIGINAL map index `orig`) and the squared
+// point-to-plane distance of the pair (plane2) come from the caller
+template <bool EXT = false>
 __device__ __forceinline__ float match_weight(const LoopCfg& lc, const IcpState* __restrict__ st, float d2,
                                               const float* __restrict__ T, const float4* __restrict__ read_normals, int qi,
                                               const float4* __restrict__ ref_normals, int sidx, int fused_slot = -1,
-                                              float fused_limit = 0.f)
+                                              float fused_limit = 0.f, const float* __restrict__ ref_scalar = nullptr, int orig = 0,
+                                              float plane2 = 0.f)
 {
     float w = 1.f;
     for (int f = 0; f < lc.n_out; ++f) {
@@ -268,6 +308,15 @@ __device__ __forceinline__ float match_weight(const LoopCfg& lc, const IcpState*
             const float4 b = ref_normals[sidx];
             const float dot = fmaf(az, b.z, fmaf(ay, b.y, ax * b.x));
             w *= (dot > cosf(prm)) ? 1.f : 0.f;
+        } else if (EXT && type == ICPMI_OUT_GENERICDESCRIPTOR) {
+            const int ip = lc.out_iparam[f];
+            const float v = ref_scalar[orig];
+            w *= (ip & ICPMI_GEN_SOFT) ? v : ((ip & ICPMI_GEN_LARGER) ? (v > prm ? 1.f : 0.f) : (v < prm ? 1.f : 0.f));
+        } else if (EXT && type == ICPMI_OUT_ROBUST) {
+            const int ip = lc.out_iparam[f];
+            const float sc = ((ip >> 4) & 15) == ICPMI_SCALE_MAD ? st->robust_scale : 1.f;
+            const float res = ((ip >> 8) & 15) == ICPMI_DIST_POINT2PLANE ? plane2 : d2;
+            w *= robust_weight(ip & 15, res / (sc * sc), prm);
         }
     }
     return w;
@@ -288,7 +337,7 @@ __device__ __forceinline__ int acc_blocks_dev(int64_t count, int cap)
     return (int)(nb < 1 ? 1 : (nb > cap ? cap : nb));
 }
 
-template <int MIN, bool FUSED>
+template <int MIN, bool FUSED, bool EXT>
 __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restrict__ reading, BatchArgs ba, int acc_cap, LoopCfg lc,
                                                          IcpState* __restrict__ st, const float4* __restrict__ map,
                                                          const float4* __restrict__ normals,
@@ -296,7 +345,8 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restric
                                                          const int* __restrict__ sidx, const float* __restrict__ d2a,
                                                          double* __restrict__ partials, unsigned* __restrict__ hists,
                                                          int fused_slot, int is_median, float factor,
-                                                         const float4* __restrict__ match_pt, const int* __restrict__ qindex)
+                                                         const float4* __restrict__ match_pt, const int* __restrict__ qindex,
+                                                         const float* __restrict__ ref_scalar)
 {
     // blockIdx.y = reading of a batch (common.h: BatchArgs); a single registration is the batch of one
     const int n = ba.n[blockIdx.y];
@@ -358,7 +408,21 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restric
     auto pair = [&](int64_t e, float d2, int s, float4 r, float4 qkept, float4 nkept, bool have_n) {
         if (d2 == INFINITY) return;
         const int qi = (int)(e / lc.k);
-        const float w = match_weight(lc, st, d2, T, read_normals, qindex ? qindex[qi] : qi, normals, s, FUSED ? fused_slot : -1, fused_limit);
+        float w;
+        if (EXT) {
+            // the filters that read the pair itself: original index of the matched point (its .w), point-to-plane residual
+            const float3 pe = xf_point(T, r.x, r.y, r.z, r.w);
+            const float4 qe = match_pt ? qkept : map[s];
+            float plane2 = 0.f;
+            if (normals) {
+                const float4 ne = have_n && MIN == ICPMI_MIN_POINT_TO_PLANE ? nkept : normals[s];
+                const float dx = pe.x - qe.x, dy = pe.y - qe.y, dz = pe.z - qe.z;
+                const float dot = dx * ne.x + dy * ne.y + dz * ne.z;
+                plane2 = dot * dot;
+            }
+            w = match_weight<true>(lc, st, d2, T, read_normals, qindex ? qindex[qi] : qi, normals, s, FUSED ? fused_slot : -1, fused_limit,
+                                   ref_scalar, __float_as_int(qe.w), plane2);
+        } else w = match_weight(lc, st, d2, T, read_normals, qindex ? qindex[qi] : qi, normals, s, FUSED ? fused_slot : -1, fused_limit);
         if (w == 0.f) return;
         wsum += w; cnt += 1.0;
         if (MIN == ICPMI_MIN_IDENTITY) return;
@@ -618,78 +682,79 @@ __device__ void rotation_from_H(const float* H, float* R)
 }
 
 // solvePossiblyUnderdeterminedLinearSystem: float LLT when A is invertible, else
-// the minimum-norm solution (double symmetric pseudo-inverse) -- same rule as the oracle.
-// minimum-norm branch of solve6 (rank-deficient A): rare, kept out of line so that its scratch-resident
+// the minimum-norm solution (double symmetric pseudo-inverse) -- same rule as the oracle.  N = 6, or 4 (force4DOF).
+// minimum-norm branch (rank-deficient A): rare, kept out of line so that its scratch-resident
 // arrays do not burden the common path
-__device__ __noinline__ void solve6_min_norm(const float* A, const float* b, float* x);
+__device__ __noinline__ void solve_min_norm(int n, const float* A, const float* b, float* x);
 
-__device__ void solve6(const float* A, const float* b, float* x)
+template <int N>
+__device__ void solve_spd(const float* A, const float* b, float* x)
 {
-    // invertibility rule shared with the oracle: every float Cholesky pivot > 6 eps_f max_j A_jj.
+    // invertibility rule shared with the oracle: every float Cholesky pivot > N eps_f max_j A_jj.
     // Every loop has compile-time bounds and is fully unrolled: L, y live in registers (a rolled
     // triangular loop would put them in scratch memory, ~10 us of dependent scratch traffic).
     float dmax = 0.f;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) dmax = A[6 * j + j] > dmax ? A[6 * j + j] : dmax;
-    const float pthr = 6.0f * 1.1920928955078125e-07f * dmax;
-    float L[36];
+    for (int j = 0; j < N; ++j) dmax = A[N * j + j] > dmax ? A[N * j + j] : dmax;
+    const float pthr = (float)N * 1.1920928955078125e-07f * dmax;
+    float L[N * N];
     bool ok = true;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        float d = A[6 * j + j];
+    for (int j = 0; j < N; ++j) {
+        float d = A[N * j + j];
 #pragma unroll
-        for (int kk = 0; kk < 6; ++kk) if (kk < j) d -= L[6 * kk + j] * L[6 * kk + j];
+        for (int kk = 0; kk < N; ++kk) if (kk < j) d -= L[N * kk + j] * L[N * kk + j];
         ok = ok && (d > pthr);
         const float ljj = sqrtf(d);
-        L[6 * j + j] = ljj;
+        L[N * j + j] = ljj;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < N; ++i) {
             if (i > j) {
-                float s = A[6 * j + i];
+                float s = A[N * j + i];
 #pragma unroll
-                for (int kk = 0; kk < 6; ++kk) if (kk < j) s -= L[6 * kk + i] * L[6 * kk + j];
-                L[6 * j + i] = s / ljj;
+                for (int kk = 0; kk < N; ++kk) if (kk < j) s -= L[N * kk + i] * L[N * kk + j];
+                L[N * j + i] = s / ljj;
             }
         }
     }
     if (ok) {
-        float y[6];
+        float y[N];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < N; ++i) {
             float s = b[i];
 #pragma unroll
-            for (int kk = 0; kk < 6; ++kk) if (kk < i) s -= L[6 * kk + i] * y[kk];
-            y[i] = s / L[6 * i + i];
+            for (int kk = 0; kk < N; ++kk) if (kk < i) s -= L[N * kk + i] * y[kk];
+            y[i] = s / L[N * i + i];
         }
 #pragma unroll
-        for (int i = 5; i >= 0; --i) {
+        for (int i = N - 1; i >= 0; --i) {
             float s = y[i];
 #pragma unroll
-            for (int kk = 0; kk < 6; ++kk) if (kk > i) s -= L[6 * i + kk] * x[kk];
-            x[i] = s / L[6 * i + i];
+            for (int kk = 0; kk < N; ++kk) if (kk > i) s -= L[N * i + kk] * x[kk];
+            x[i] = s / L[N * i + i];
         }
         return;
     }
-    solve6_min_norm(A, b, x);
+    solve_min_norm(N, A, b, x);
 }
 
-__device__ __noinline__ void solve6_min_norm(const float* A, const float* b, float* x)
+__device__ __noinline__ void solve_min_norm(int n, const float* A, const float* b, float* x)
 {
     double Ad[36], w[6], Q[36];
-    for (int i = 0; i < 36; ++i) Ad[i] = A[i];
-    jacobi_eig(6, Ad, w, Q);
+    for (int i = 0; i < n * n; ++i) Ad[i] = A[i];
+    jacobi_eig(n, Ad, w, Q);
     double wmax = 0;
-    for (int i = 0; i < 6; ++i) if (fabs(w[i]) > wmax) wmax = fabs(w[i]);
-    const double thr = 6.0 * 1.1920928955078125e-07 * wmax;
+    for (int i = 0; i < n; ++i) if (fabs(w[i]) > wmax) wmax = fabs(w[i]);
+    const double thr = (double)n * 1.1920928955078125e-07 * wmax;
     double xd[6] = {0, 0, 0, 0, 0, 0};
-    for (int e = 0; e < 6; ++e) {
+    for (int e = 0; e < n; ++e) {
         if (!(w[e] > thr)) continue;
         double proj = 0;
-        for (int i = 0; i < 6; ++i) proj += Q[6 * e + i] * (double)b[i];
+        for (int i = 0; i < n; ++i) proj += Q[n * e + i] * (double)b[i];
         proj /= w[e];
-        for (int i = 0; i < 6; ++i) xd[i] += proj * Q[6 * e + i];
+        for (int i = 0; i < n; ++i) xd[i] += proj * Q[n * e + i];
     }
-    for (int i = 0; i < 6; ++i) x[i] = (float)xd[i];
+    for (int i = 0; i < n; ++i) x[i] = (float)xd[i];
 }
 
 __device__ void angle_axis_T(const float* x3, float* T)
@@ -824,7 +889,13 @@ __device__ void solve_body(IcpState* __restrict__ st, const double* __restrict__
         for (int a = 0; a < 6; ++a)
             for (int bb = a; bb < 6; ++bb) { const float v = (float)tot[idx++]; A[6 * a + bb] = v; A[6 * bb + a] = v; }
         for (int a = 0; a < 6; ++a) b[a] = (float)tot[21 + a];
-        solve6(A, b, x);
+        if (lc.force_4dof) {
+            // force4DOF: F = [cross_z; n] -- the {2,3,4,5} sub-system of the 6-DOF sums; x = (yaw, t)
+            float A4[16], b4[4], x4[4];
+            for (int c = 0; c < 4; ++c) { b4[c] = b[2 + c]; for (int r = 0; r < 4; ++r) A4[4 * c + r] = A[6 * (2 + c) + (2 + r)]; }
+            solve_spd<4>(A4, b4, x4);
+            x[0] = 0.f; x[1] = 0.f; x[2] = x4[0]; x[3] = x4[1]; x[4] = x4[2]; x[5] = x4[3];
+        } else solve_spd<6>(A, b, x);
         angle_axis_T(x, Ts);
         Ts[12] = x[3]; Ts[13] = x[4]; Ts[14] = x[5];
     }
@@ -939,6 +1010,7 @@ __global__ void init_state_kernel(IcpState* st, const float* T0, unsigned seq, u
     st->hist_n = 1;
     st->sel_prefix = 0; st->sel_rank = 0; st->n_valid = 0;
     for (int f = 0; f < ICPMI_MAX_OUTLIER; ++f) st->limits[f] = -1.f;
+    st->robust_med = 0.f; st->robust_scale = 1.f;
     st->pairs = 0; st->wsum = 0; st->hard_count = 0; st->hard_total = 0; st->ticket = 0;
     for (int i = 0; i < 24; ++i) st->dbg[i] = 0;
 }
@@ -946,17 +1018,19 @@ __global__ void init_state_kernel(IcpState* st, const float* T0, unsigned seq, u
 __global__ __launch_bounds__(256) void weights_kernel(int64_t count, LoopCfg lc, const IcpState* __restrict__ st,
                                                       const float4* __restrict__ normals, const float4* __restrict__ read_normals,
                                                       const int* __restrict__ sidx, const float* __restrict__ d2a,
-                                                      float* __restrict__ w)
+                                                      float* __restrict__ w, const float* __restrict__ ref_scalar)
 {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= count) return;
     const int s = sidx[e];
     float wt = 1.f;
     // the chain is evaluated on every entry like upstream (an invalid match has d2 = +inf and fails
-    // every "<= limit" test; SurfaceNormal needs a valid id)
+    // every "<= limit" test; SurfaceNormal / GenericDescriptor need a valid id, Robust gives an unmatched entry weight 0).
+    // This stage entry point gets ORIGINAL ids: the scalar channel is indexed by them directly.
     bool needs_id = false;
-    for (int f = 0; f < lc.n_out; ++f) needs_id |= lc.out_type[f] == ICPMI_OUT_SURFACENORMAL;
-    if (needs_id && s < 0) wt = 0.f;
+    for (int f = 0; f < lc.n_out; ++f) needs_id |= lc.out_type[f] == ICPMI_OUT_SURFACENORMAL || lc.out_type[f] == ICPMI_OUT_GENERICDESCRIPTOR || lc.out_type[f] == ICPMI_OUT_ROBUST;
+    if (needs_id && (s < 0 || (lc.ext && d2a[e] == INFINITY))) wt = 0.f;
+    else if (lc.ext) wt = match_weight<true>(lc, st, d2a[e], nullptr, read_normals, (int)(e / lc.k), normals, s < 0 ? 0 : s, -1, 0.f, ref_scalar, s < 0 ? 0 : s, 0.f);
     else wt = match_weight(lc, st, d2a[e], nullptr, read_normals, (int)(e / lc.k), normals, s < 0 ? 0 : s);
     w[e] = wt;
 }
@@ -989,7 +1063,11 @@ LoopCfg make_loop_cfg(const icpmi_ctx* c, int fixed_iterations)
     for (int f = 0; f < cfg.n_outlier && f < ICPMI_MAX_OUTLIER; ++f) {
         lc.out_type[f] = cfg.outlier[f].type;
         lc.out_param[f] = cfg.outlier[f].param;
+        lc.out_iparam[f] = cfg.outlier[f].iparam;
+        lc.out_param2[f] = cfg.outlier[f].param2;
+        if (lc.out_type[f] == ICPMI_OUT_GENERICDESCRIPTOR || lc.out_type[f] == ICPMI_OUT_ROBUST) lc.ext = 1;
     }
+    lc.force_4dof = cfg.force_4dof != 0 && cfg.minimizer == ICPMI_MIN_POINT_TO_PLANE;
     if (fixed_iterations > 0) {
         lc.max_iter = fixed_iterations; lc.use_diff = 0; lc.use_bound = 0;
     } else {
@@ -1067,6 +1145,20 @@ static void enqueue_selection(icpmi_ctx* c, const LoopCfg& lc, int64_t count, bo
     const int slot = legacy ? -2 : fused_filter_slot(lc);
     int hb = (int)std::min<int64_t>((count + 2047) / 2048, 256);
     if (hb < 1) hb = 1;
+    // RobustOutlierFilter{scaleEstimator: mad}: scale = sqrt(median |d2 - median(d2)|) -- two more selections on the legacy bins
+    // (disjoint from the fused levels), on the single-registration path only (a batch with such a chain runs reading by reading)
+    for (int f = 0; f < lc.n_out; ++f) {
+        if (lc.out_type[f] != ICPMI_OUT_ROBUST || ((lc.out_iparam[f] >> 4) & 15) != ICPMI_SCALE_MAD) continue;
+        const int nb = (int)lc.out_param2[f];
+        for (int dest = 1; dest <= 2; ++dest) {
+#define MAD_PASS(P) \
+            if (dest == 1) hipLaunchKernelGGL((sel_hist_kernel<P, 1>), dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist, nb); \
+            else hipLaunchKernelGGL((sel_hist_kernel<P, 2>), dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist, nb); \
+            hipLaunchKernelGGL(sel_scan_kernel<P>, dim3(1), dim3(256), 0, c->stream, c->d_state, c->d_selhist, -1.f, f, 0, 0.f, dest, nb);
+            MAD_PASS(0) MAD_PASS(1) MAD_PASS(2)
+#undef MAD_PASS
+        }
+    }
     if (slot >= 0) {
         // fused chain: hist0 -> [scan0 + hist1] -> [scan1 + hist2]; scan2 happens inside the accumulation kernel
         const float quant = lc.out_type[slot] == ICPMI_OUT_MEDIANDIST ? 0.5f : lc.out_param[slot];
@@ -1084,26 +1176,38 @@ static void enqueue_selection(icpmi_ctx* c, const LoopCfg& lc, int64_t count, bo
         const int is_med = type == ICPMI_OUT_MEDIANDIST;
         const float quant = is_med ? 0.5f : lc.out_param[f];
         const float factor = lc.out_param[f];
-        hipLaunchKernelGGL(sel_hist_kernel<0>, dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist);
-        hipLaunchKernelGGL(sel_scan_kernel<0>, dim3(1), dim3(256), 0, c->stream, c->d_state, c->d_selhist, quant, f, is_med, factor);
-        hipLaunchKernelGGL(sel_hist_kernel<1>, dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist);
-        hipLaunchKernelGGL(sel_scan_kernel<1>, dim3(1), dim3(256), 0, c->stream, c->d_state, c->d_selhist, quant, f, is_med, factor);
-        hipLaunchKernelGGL(sel_hist_kernel<2>, dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist);
-        hipLaunchKernelGGL(sel_scan_kernel<2>, dim3(1), dim3(256), 0, c->stream, c->d_state, c->d_selhist, quant, f, is_med, factor);
+        hipLaunchKernelGGL((sel_hist_kernel<0, 0>), dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist, 0);
+        hipLaunchKernelGGL(sel_scan_kernel<0>, dim3(1), dim3(256), 0, c->stream, c->d_state, c->d_selhist, quant, f, is_med, factor, 0, 0);
+        hipLaunchKernelGGL((sel_hist_kernel<1, 0>), dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist, 0);
+        hipLaunchKernelGGL(sel_scan_kernel<1>, dim3(1), dim3(256), 0, c->stream, c->d_state, c->d_selhist, quant, f, is_med, factor, 0, 0);
+        hipLaunchKernelGGL((sel_hist_kernel<2, 0>), dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist, 0);
+        hipLaunchKernelGGL(sel_scan_kernel<2>, dim3(1), dim3(256), 0, c->stream, c->d_state, c->d_selhist, quant, f, is_med, factor, 0, 0);
     }
 }
 
+template <int MIN, bool FUSED, bool EXT>
+static void launch_accumulate_ext(icpmi_ctx* c, int64_t n, const LoopCfg& lc, int nb, int slot);
+
 template <int MIN, bool FUSED>
 static void launch_accumulate(icpmi_ctx* c, int64_t n, const LoopCfg& lc, int nb, int slot)
+{
+    // EXT: the chain holds a GenericDescriptor / Robust filter (rare): its own instantiation keeps the common kernels as they were
+    if (lc.ext) launch_accumulate_ext<MIN, FUSED, true>(c, n, lc, nb, slot);
+    else launch_accumulate_ext<MIN, FUSED, false>(c, n, lc, nb, slot);
+}
+
+template <int MIN, bool FUSED, bool EXT>
+static void launch_accumulate_ext(icpmi_ctx* c, int64_t n, const LoopCfg& lc, int nb, int slot)
 {
     const float4* rn = lc.has_read_normals ? c->d_read_normals : nullptr;
     const int is_med = slot >= 0 && lc.out_type[slot] == ICPMI_OUT_MEDIANDIST;
     const float factor = slot >= 0 ? lc.out_param[slot] : 0.f;
     const bool sorted = lc.k == 1 && c->nn_out_sorted; // loop state in query order (see nn1_ml_kernel)
     const BatchArgs ba = cur_batch(c, n);
-    hipLaunchKernelGGL((accumulate_kernel<MIN, FUSED>), dim3(nb, ba.nscan), dim3(256), 0, c->stream, sorted ? c->d_qsorted : c->d_reading, ba, acc_cap(), lc, c->d_state,
-                       c->d_map_sorted, c->d_normals_sorted, rn, c->d_sidx, c->d_d2, c->d_partials, c->d_selhist, slot, is_med, factor,
-                       sorted ? c->d_match_pt : (const float4*)nullptr, sorted ? c->d_qindex : (const int*)nullptr);
+    hipLaunchKernelGGL((accumulate_kernel<MIN, FUSED, EXT>), dim3(nb, ba.nscan), dim3(256), 0, c->stream, sorted ? c->d_qsorted : c->d_reading, ba, acc_cap(), lc, c->d_state,
+                       c->d_map_sorted, c->has_normals ? c->d_normals_sorted : (const float4*)nullptr, rn, c->d_sidx, c->d_d2, c->d_partials, c->d_selhist, slot, is_med, factor,
+                       sorted ? c->d_match_pt : (const float4*)nullptr, sorted ? c->d_qindex : (const int*)nullptr,
+                       (EXT && c->raw_has_scalar) ? c->d_raw_s : (const float*)nullptr);
 }
 
 static void enqueue_accumulate_solve(icpmi_ctx* c, int64_t n, const LoopCfg& lc, float* d_Tstep, double* d_sums)
@@ -1521,20 +1625,34 @@ icpmi_status loop_outlier_weights(icpmi_ctx* c, const LoopCfg& lc, const float* 
             c->last_error = "icpmi_outlier_weights: SurfaceNormalOutlierFilter is only available inside icpmi_register";
             return ICPMI_ERR_UNSUPPORTED;
         }
-    (void)ids; (void)read_normals3;
+    (void)read_normals3;
+    bool needs_ids = false;
+    for (int f = 0; f < lc.n_out; ++f) {
+        if (lc.out_type[f] == ICPMI_OUT_ROBUST && ((lc.out_iparam[f] >> 8) & 15) == ICPMI_DIST_POINT2PLANE) {
+            c->last_error = "icpmi_outlier_weights: RobustOutlierFilter{distanceType: point2plane} is only available inside icpmi_register";
+            return ICPMI_ERR_UNSUPPORTED;
+        }
+        if (lc.out_type[f] == ICPMI_OUT_GENERICDESCRIPTOR) {
+            if (!ids || !c->raw_has_scalar) { c->last_error = "InvalidField: GenericDescriptorOutlierFilter needs ids and the tracked scalar descriptor on the map"; return ICPMI_ERR_INVALID_ARG; }
+            for (int64_t e = 0; e < (int64_t)k * n; ++e)
+                if (ids[e] >= c->m_raw) { c->last_error = "outlier_weights: id outside the map"; return ICPMI_ERR_INVALID_ARG; }
+        }
+        needs_ids |= lc.out_type[f] == ICPMI_OUT_GENERICDESCRIPTOR || lc.out_type[f] == ICPMI_OUT_ROBUST;
+    }
     const int64_t count = (int64_t)k * n;
     if (ensure_loop_buffers(c, n, k) != ICPMI_OK) return ICPMI_ERR_HIP;
     LoopCfg l1 = lc; l1.k = k;
     hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(64), 0, c->stream, c->d_state, (const float*)nullptr, 0u, (unsigned*)nullptr);
     HIP_TRY(c, hipMemsetAsync(c->d_selhist, 0, ICPMI_SELHIST_WORDS * sizeof(unsigned), c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_d2, d2, (size_t)count * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_sidx, 0, (size_t)count * sizeof(int), c->stream));
+    if (needs_ids && ids) HIP_TRY(c, hipMemcpyAsync(c->d_sidx, ids, (size_t)count * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    else HIP_TRY(c, hipMemsetAsync(c->d_sidx, 0, (size_t)count * sizeof(int), c->stream));
     enqueue_selection(c, l1, count, true);
     DevBuf<float> d_w;
     HIP_TRY(c, d_w.alloc((size_t)count));
     const int blocks = (int)((count + 255) / 256);
     if (blocks) hipLaunchKernelGGL(weights_kernel, dim3(blocks), dim3(256), 0, c->stream, count, l1, c->d_state, c->d_normals_sorted,
-                                   (const float4*)nullptr, c->d_sidx, c->d_d2, d_w);
+                                   (const float4*)nullptr, c->d_sidx, c->d_d2, d_w, c->raw_has_scalar ? c->d_raw_s : (const float*)nullptr);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(weights, d_w, (size_t)count * sizeof(float), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(c->h_state, c->d_state, sizeof(IcpState), hipMemcpyDeviceToHost, c->stream);
@@ -1545,6 +1663,7 @@ icpmi_status loop_outlier_weights(icpmi_ctx* c, const LoopCfg& lc, const float* 
         *limit_out = -1.f;
         for (int f = 0; f < l1.n_out; ++f)
             if (l1.out_type[f] == ICPMI_OUT_TRIMMEDDIST || l1.out_type[f] == ICPMI_OUT_MEDIANDIST) *limit_out = c->h_state->limits[f];
+            else if (l1.out_type[f] == ICPMI_OUT_ROBUST && ((l1.out_iparam[f] >> 4) & 15) == ICPMI_SCALE_MAD) *limit_out = c->h_state->robust_scale;
     }
     return ICPMI_OK;
 }

@@ -1262,7 +1262,15 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
         c->m_raw = 0; c->raw_has_normals = false; c->raw_has_scalar = false; c->m = 0;
         return s;
     }
-    if (w.m == 0) { c->last_error = "map_update_chain: the chain removed every point of the map"; c->m_raw = 0; c->m = 0; c->raw_has_scalar = false; return ICPMI_ERR_INVALID_ARG; }
+    if (w.m == 0) {
+        // the chain removed every point (e.g. CutAtDescriptorThreshold cut the whole map): the reference goes on with an empty local
+        // cloud -- `icp.setMap` ignores an empty cloud and keeps its previous map (Map.cpp:528), the next scan
+        // creates the map anew (Map.cpp:505-515).  Same here: the resident copy is empty, the registration index stays.
+        c->m_raw = 0; c->raw_has_normals = false; c->raw_has_scalar = false;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (new_m) *new_m = 0;
+        return ICPMI_OK;
+    }
     if (src_out) {
         if (src_capacity < w.m) { c->last_error = "map_update_chain: src_capacity too small"; return ICPMI_ERR_INVALID_ARG; }
         int64_t head = 0;

@@ -51,6 +51,7 @@ void GpuICPSequence::setDefault()
     const int dev = cfg.device;
     icpmi_config_default(&cfg);
     cfg.device = dev;
+    genericDescName.clear();
     cfg.n_outlier = 1;
     cfg.outlier[0].type = ICPMI_OUT_TRIMMEDDIST;
     cfg.outlier[0].param = 0.85f;
@@ -106,6 +107,7 @@ void GpuICPSequence::loadFromYamlNode(const yaml::Node& icp)
         if (e.second["maxDist"]) cfg.max_dist = e.second["maxDist"].as<float>();
     }
     cfg.n_outlier = 0;
+    genericDescName.clear();
     if (icp["outlierFilters"].IsSequence())
         for (const auto& item : icp["outlierFilters"].seq) {
             auto e = singleEntry(item, "outlier filter");
@@ -119,6 +121,44 @@ void GpuICPSequence::loadFromYamlNode(const yaml::Node& icp)
             else if (e.first == "MinDistOutlierFilter") { o.type = ICPMI_OUT_MINDIST; o.param = param("minDist", 1.f); }
             else if (e.first == "MedianDistOutlierFilter") { o.type = ICPMI_OUT_MEDIANDIST; o.param = param("factor", 3.f); }
             else if (e.first == "SurfaceNormalOutlierFilter") { o.type = ICPMI_OUT_SURFACENORMAL; o.param = param("maxAngle", 1.57f); }
+            else if (e.first == "GenericDescriptorOutlierFilter") {
+                // defaults of upstream's registrar: source reference, descName none, useSoftThreshold 0, useLargerThan 1, threshold 0.1
+                const yaml::Node& p = e.second;
+                requireKnown(p, {"source", "descName", "useSoftThreshold", "useLargerThan", "threshold"}, e.first);
+                const std::string source = p["source"] ? p["source"].str() : "reference";
+                if (source != "reference" && source != "reading") throw InvalidParameter("GenericDescriptorOutlierFilter: source must be reference or reading");
+                if (source == "reading") throw InvalidParameter("GenericDescriptorOutlierFilter{source: reading} is not on the accelerated path");
+                const std::string name = p["descName"] ? p["descName"].str() : "none";
+                if (!genericDescName.empty() && genericDescName != name) throw InvalidParameter("GenericDescriptorOutlierFilter: the device tracks one scalar descriptor of the map");
+                genericDescName = name;
+                o.type = ICPMI_OUT_GENERICDESCRIPTOR;
+                o.param = p["threshold"] ? p["threshold"].as<float>() : 0.1f;
+                o.iparam = ((p["useSoftThreshold"] && p["useSoftThreshold"].as<int>()) ? ICPMI_GEN_SOFT : 0) |
+                           ((!p["useLargerThan"] || p["useLargerThan"].as<int>()) ? ICPMI_GEN_LARGER : 0);
+            } else if (e.first == "RobustOutlierFilter") {
+                // defaults: robustFct cauchy, tuning 1, scaleEstimator mad, nbIterationForScale 0, distanceType point2point, approximation inf
+                const yaml::Node& p = e.second;
+                requireKnown(p, {"robustFct", "tuning", "scaleEstimator", "nbIterationForScale", "distanceType", "approximation"}, e.first);
+                static const char* fcts[] = {"cauchy", "welsch", "sc", "gm", "tukey", "huber", "L1", "student"};
+                const std::string fct = p["robustFct"] ? p["robustFct"].str() : "cauchy";
+                int fid = -1;
+                for (int i = 0; i < 8; ++i) if (fct == fcts[i]) fid = i;
+                if (fid < 0) throw InvalidParameter("RobustOutlierFilter: unknown robustFct " + fct);
+                const std::string sc = p["scaleEstimator"] ? p["scaleEstimator"].str() : "mad";
+                int sid;
+                if (sc == "none") sid = ICPMI_SCALE_NONE; else if (sc == "mad") sid = ICPMI_SCALE_MAD;
+                else if (sc == "berg" || sc == "std") throw InvalidParameter("RobustOutlierFilter{scaleEstimator: " + sc + "} is not on the accelerated path");
+                else throw InvalidParameter("RobustOutlierFilter: unknown scaleEstimator " + sc);
+                const std::string dt = p["distanceType"] ? p["distanceType"].str() : "point2point";
+                int did;
+                if (dt == "point2point") did = ICPMI_DIST_POINT2POINT; else if (dt == "point2plane") did = ICPMI_DIST_POINT2PLANE;
+                else throw InvalidParameter("RobustOutlierFilter: unknown distanceType " + dt);
+                if (p["approximation"] && std::isfinite(p["approximation"].as<float>())) throw InvalidParameter("RobustOutlierFilter{approximation} is not on the accelerated path");
+                o.type = ICPMI_OUT_ROBUST;
+                o.param = p["tuning"] ? p["tuning"].as<float>() : 1.f;
+                o.param2 = p["nbIterationForScale"] ? (float)p["nbIterationForScale"].as<int>() : 0.f;
+                o.iparam = fid | (sid << 4) | (did << 8);
+            }
             else throw InvalidParameter("unknown outlier filter " + e.first);
             if (cfg.n_outlier >= 8) throw InvalidParameter("at most 8 outlier filters");
             cfg.outlier[cfg.n_outlier++] = o;
@@ -129,8 +169,8 @@ void GpuICPSequence::loadFromYamlNode(const yaml::Node& icp)
         else if (e.first == "PointToPointErrorMinimizer") cfg.minimizer = ICPMI_MIN_POINT_TO_POINT;
         else if (e.first == "PointToPlaneErrorMinimizer") {
             cfg.minimizer = ICPMI_MIN_POINT_TO_PLANE;
-            for (const char* k : {"force2D", "force4DOF"})
-                if (e.second[k] && e.second[k].as<int>() != 0) throw InvalidParameter(std::string(k) + " is not on the accelerated path");
+            cfg.force_4dof = (e.second["force4DOF"] && e.second["force4DOF"].as<int>() != 0) ? 1 : 0;
+            if (e.second["force2D"] && e.second["force2D"].as<int>() != 0) throw InvalidParameter("force2D is not on the accelerated path");
         } else throw InvalidParameter("unknown error minimizer " + e.first);
     }
     if (icp["transformationCheckers"].IsSequence())
@@ -221,6 +261,12 @@ bool GpuICPSequence::setMap(const DataPoints& mapIn)
     // a point-to-plane chain against a map without `normals`: the map is accepted (upstream's setMap does not look) and the
     // registration raises InvalidField("normals"), as upstream's minimiser does
     check(h, icpmi_set_map(h, map.features.data(), (int64_t)map.getNbPoints(), normals, &accepted));
+    if (accepted && !genericDescName.empty()) {
+        // GenericDescriptorOutlierFilter{source: reference}: the descriptor it reads travels as the map's tracked scalar channel
+        if (!map.descriptorExists(genericDescName) || map.getDescriptorByName(genericDescName).span != 1)
+            throw InvalidField("GenericDescriptorOutlierFilter: the reference has no 1-row descriptor " + genericDescName);
+        uploadMapScalar(map.getDescriptorByName(genericDescName).data);
+    }
     return accepted != 0;
 }
 

@@ -57,6 +57,7 @@ public:
     void uploadMapScalar(const std::vector<float>& scalar);   // the tracked scalar descriptor of the resident map
     std::vector<float> downloadMapScalar() const;
     int64_t residentMapSize() const;
+    const std::string& genericDescriptorName() const { return genericDescName; } // GenericDescriptorOutlierFilter.descName, or empty
     bool chainNeedsReadingNormals() const;             // SurfaceNormalOutlierFilter in the chain
     // true when the chain filters the reading inside operator() (readingDataPointsFilters / readingStepDataPointsFilters):
     // the staged-scan path of Mapper::processInput hands the unfiltered scan to the GPU and must not be taken then
@@ -81,6 +82,7 @@ private:
     icpmi_config cfg;
     icpmi_stats lastStats{};
     size_t stagedPoints = 0;                           // size of the scan kept on the GPU by registerWithPrior
+    std::string genericDescName;                       // GenericDescriptorOutlierFilter.descName (empty: no such filter)
     ErrorMinimizerView minimizerView{this};
 };
 

@@ -237,7 +237,8 @@ void Map::syncLocalFromDevice()
 bool Map::residentPlan(const DataPoints& input, const DataPointsFilters& postFilters, ResidentProgram& prog) const
 {
     static const bool enabled = [] { const char* e = std::getenv("NIM_RESIDENT_MAP_UPDATE"); return !e || std::atoi(e) != 0; }();
-    if (!enabled || !is3D || mapperModuleVec.empty() || icp.hasReferenceFilters()) return false;
+    // (a GenericDescriptorOutlierFilter reads a descriptor of the host cloud handed to setMap: host path)
+    if (!enabled || !is3D || mapperModuleVec.empty() || icp.hasReferenceFilters() || !icp.genericDescriptorName().empty()) return false;
     prog = ResidentProgram{};
     auto adopt = [&](bool ok, const icpmi_map_op& op, const std::string& name) {
         if (!ok) return false;

@@ -92,9 +92,11 @@ def default_config(**kw):
         setattr(cfg, k, v)
     if outliers is not None:
         cfg.n_outlier = len(outliers)
-        for i, (t, p) in enumerate(outliers):
-            cfg.outlier[i].type = t
-            cfg.outlier[i].param = p
+        for i, o in enumerate(outliers):  # (type, param[, iparam[, param2]])
+            cfg.outlier[i].type = o[0]
+            cfg.outlier[i].param = o[1]
+            cfg.outlier[i].iparam = o[2] if len(o) > 2 else 0
+            cfg.outlier[i].param2 = o[3] if len(o) > 3 else 0.0
     return cfg
 
 
@@ -138,6 +140,30 @@ def config_from_yaml_chain(chain, **engine):
     outs = []
     for node in chain.get("outlierFilters", []) or []:
         name, p = single(node, "outlier filter")
+        if name == "GenericDescriptorOutlierFilter":
+            # upstream defaults: source reference, descName none, useSoftThreshold 0, useLargerThan 1, threshold 0.1
+            for key in p:
+                if key not in ("source", "descName", "useSoftThreshold", "useLargerThan", "threshold"):
+                    raise InvalidParameter(f"{name}: unknown parameter {key}")
+            if p.get("source", "reference") != "reference":
+                raise NotImplementedError("GenericDescriptorOutlierFilter{source: reading} is not on the accelerated path")
+            kw["generic_desc_name"] = str(p.get("descName", "none"))
+            flags = (_capi.GEN_SOFT if int(p.get("useSoftThreshold", 0)) else 0) | (_capi.GEN_LARGER if int(p.get("useLargerThan", 1)) else 0)
+            outs.append((_capi.OUT_GENERICDESCRIPTOR, float(p.get("threshold", 0.1)), flags, 0.0))
+            continue
+        if name == "RobustOutlierFilter":
+            # upstream defaults: robustFct cauchy, tuning 1, scaleEstimator mad, nbIterationForScale 0, distanceType point2point
+            for key in p:
+                if key not in ("robustFct", "tuning", "scaleEstimator", "nbIterationForScale", "distanceType", "approximation"):
+                    raise InvalidParameter(f"{name}: unknown parameter {key}")
+            fct, sc, dt = str(p.get("robustFct", "cauchy")), str(p.get("scaleEstimator", "mad")), str(p.get("distanceType", "point2point"))
+            if fct not in _capi.ROBUST_FCT or dt not in _capi.ROBUST_DIST or sc not in ("none", "mad", "berg", "std"):
+                raise InvalidParameter(f"{name}: unknown robustFct / scaleEstimator / distanceType")
+            if sc not in _capi.ROBUST_SCALE or math.isfinite(float(str(p.get("approximation", "inf")).replace(".inf", "inf"))):
+                raise NotImplementedError("RobustOutlierFilter: berg / std scale estimators and `approximation` are not on the accelerated path")
+            outs.append((_capi.OUT_ROBUST, float(p.get("tuning", 1.0)),
+                         _capi.ROBUST_FCT[fct] | (_capi.ROBUST_SCALE[sc] << 4) | (_capi.ROBUST_DIST[dt] << 8), float(int(p.get("nbIterationForScale", 0)))))
+            continue
         if name not in _OUTLIER_NAMES:
             raise InvalidParameter(f"unknown outlier filter {name}")
         t, pname, default = _OUTLIER_NAMES[name]
@@ -150,9 +176,10 @@ def config_from_yaml_chain(chain, **engine):
     name, p = single(chain.get("errorMinimizer", "PointToPlaneErrorMinimizer"), "errorMinimizer")
     if name not in _MINIMIZERS:
         raise InvalidParameter(f"unknown error minimizer {name}")
-    if any(int(p.get(k, 0)) for k in ("force2D", "force4DOF")):
-        raise NotImplementedError("force2D / force4DOF are not on the accelerated path")
+    if int(p.get("force2D", 0)):
+        raise NotImplementedError("force2D is not on the accelerated path")
     kw["minimizer"] = _MINIMIZERS[name]
+    kw["force_4dof"] = 1 if (name == "PointToPlaneErrorMinimizer" and int(p.get("force4DOF", 0))) else 0
 
     kw["max_iterations"] = 40
     for node in chain.get("transformationCheckers", [{"CounterTransformationChecker": {}}]) or []:
@@ -171,6 +198,7 @@ def config_from_yaml_chain(chain, **engine):
         else:
             raise InvalidParameter(f"unknown transformation checker {name}")
     kw.update(engine)
+    kw.pop("generic_desc_name", None)  # the caller hands the descriptor over with ICPSequence.setMapScalar
     return default_config(**kw)
 
 

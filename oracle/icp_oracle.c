@@ -309,6 +309,26 @@ int orc_outlier_weights(const orc_config* cfg, const float* d2, const int32_t* i
                         const float* read_normals3, const float* ref_normals3, float* weights,
                         float* limit_out)
 {
+    float scale = 1.f;
+    return orc_outlier_weights_ex(cfg, d2, ids, k, n, read_normals3, ref_normals3, NULL, NULL, NULL, 1, &scale, weights, limit_out);
+}
+
+/* rank size/2 of the finite entries (Matches::getMedianAbsDeviation's two nth_element calls) */
+static float orc_median_finite(const float* v, int64_t cnt, int* empty)
+{
+    float* tmp = (float*)malloc((size_t)(cnt > 0 ? cnt : 1) * sizeof(float));
+    int64_t m = 0;
+    for (int64_t i = 0; i < cnt; ++i) if (v[i] != INFINITY && v[i] == v[i]) tmp[m++] = v[i];
+    *empty = m == 0;
+    const float r = m ? select_rank(tmp, m, m / 2) : 0.f;
+    free(tmp);
+    return r;
+}
+
+int orc_outlier_weights_ex(const orc_config* cfg, const float* d2, const int32_t* ids, int k, int64_t n, const float* read_normals3,
+                           const float* ref_normals3, const float* ref_scalar, const float* step4, const float* ref4, int iteration,
+                           float* robust_scale, float* weights, float* limit_out)
+{
     const int64_t cnt = (int64_t)k * n;
     for (int64_t i = 0; i < cnt; ++i) weights[i] = 1.0f;
     if (limit_out) *limit_out = -1.f;
@@ -344,6 +364,78 @@ int orc_outlier_weights(const orc_config* cfg, const float* d2, const int32_t* i
                     const float* b = ref_normals3 + 3 * (int64_t)id;
                     const float dot = fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0]));
                     weights[(int64_t)k * i + j] *= (dot > cosmax) ? 1.f : 0.f;
+                }
+        } else if (type == ORC_OUT_GENERICDESCRIPTOR) {
+            /* GenericDescriptorOutlierFilter{source, descName, useSoftThreshold, useLargerThan, threshold} [UPSTREAM]: the 1-row
+             * descriptor of the matched reference point (source: reference) decides: hard -> (desc > threshold) or (desc <
+             * threshold); soft -> the weight IS the descriptor value */
+            const int ip = cfg->outlier[f].iparam;
+            if ((ip & ORC_GEN_SOURCE_READING) || !ref_scalar) return ORC_ERR_ARG;
+            for (int64_t e = 0; e < cnt; ++e) {
+                const int32_t id = ids[e];
+                if (id < 0) { weights[e] = 0.f; continue; }
+                const float v = ref_scalar[id];
+                float w;
+                if (ip & ORC_GEN_SOFT) w = v;
+                else w = (ip & ORC_GEN_LARGER) ? (v > prm ? 1.f : 0.f) : (v < prm ? 1.f : 0.f);
+                weights[e] *= w;
+            }
+        } else if (type == ORC_OUT_ROBUST) {
+            /* RobustOutlierFilter{robustFct, tuning, scaleEstimator none | mad, nbIterationForScale, distanceType} [UPSTREAM:
+             * OutlierFiltersImpl.cpp robustFiltering]: while iteration <= nbIterationForScale (always when that is 0) the scale is
+             * re-estimated -- mad: sqrt(Matches::getMedianAbsDeviation()), the rank size/2 of |d2 - median(d2)| over the finite
+             * SQUARED MATCH distances (whatever distanceType says); none: 1.  e2 = residual / scale^2 with residual = the squared
+             * match distance (point2point) or the squared point-to-plane distance; w = the M-estimator's weight of e2 with
+             * tuning k; negative weights clamp to 0 (ARBITRARY_SMALL_VALUE underflows to 0 in float).  `approximation` stays at
+             * its default (+inf).  expf / powf go through double so that host libm and device ocml round to the same float. */
+            const int ip = cfg->outlier[f].iparam;
+            const int fct = ip & 15, sc = (ip >> 4) & 15, dt = (ip >> 8) & 15;
+            const int nb_scale = (int)cfg->outlier[f].param2;
+            if (nb_scale == 0 || iteration <= nb_scale) {
+                if (sc == ORC_SCALE_MAD) {
+                    int empty = 0;
+                    const float med = orc_median_finite(d2, cnt, &empty);
+                    if (empty) return ORC_ERR_NO_OUTLIER_TO_FILTER;
+                    float* dev = (float*)malloc((size_t)cnt * sizeof(float));
+                    for (int64_t e = 0; e < cnt; ++e) dev[e] = d2[e] == INFINITY ? INFINITY : fabsf(d2[e] - med);
+                    const float mad = orc_median_finite(dev, cnt, &empty);
+                    free(dev);
+                    *robust_scale = sqrtf(mad);
+                } else *robust_scale = 1.f;
+            }
+            const float s2 = *robust_scale * *robust_scale;
+            const float kk = prm, k2 = prm * prm;
+            if (limit_out && sc == ORC_SCALE_MAD) *limit_out = *robust_scale;
+            for (int64_t i = 0; i < n; ++i)
+                for (int j = 0; j < k; ++j) {
+                    const int64_t e = (int64_t)k * i + j;
+                    const int32_t id = ids[e];
+                    if (id < 0 || d2[e] == INFINITY) { weights[e] = 0.f; continue; }
+                    float res = d2[e];
+                    if (dt == ORC_DIST_POINT2PLANE) {
+                        if (!step4 || !ref4 || !ref_normals3) return ORC_ERR_ARG;
+                        const float* p = step4 + 4 * i; const float* q = ref4 + 4 * (int64_t)id; const float* nn = ref_normals3 + 3 * (int64_t)id;
+                        const float dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
+                        const float dot = dx * nn[0] + dy * nn[1] + dz * nn[2];
+                        res = dot * dot;
+                    }
+                    const float e2 = res / s2;
+                    float w;
+                    switch (fct) {
+                    case ORC_ROB_CAUCHY: w = 1.f / (1.f + e2 / k2); break;
+                    case ORC_ROB_WELSCH: w = (float)exp((double)(-e2 / k2)); break;
+                    case ORC_ROB_SC: { const float t = kk + e2; w = e2 >= kk ? 4.f * k2 * (1.f / (t * t)) : 1.f; break; }
+                    case ORC_ROB_GM: { const float t = kk + e2; w = k2 * (1.f / (t * t)); break; }
+                    case ORC_ROB_TUKEY: { const float t = 1.f - e2 / k2; w = e2 >= k2 ? 0.f : t * t; break; }
+                    case ORC_ROB_HUBER: w = e2 >= k2 ? kk * (1.f / sqrtf(e2)) : 1.f; break;
+                    case ORC_ROB_L1: w = 1.f / sqrtf(e2); break;
+                    default: { /* Student, d = 3 */
+                        const float pw = (float)pow((double)(1.f + e2 / kk), (double)(-(kk + 3.f) / 2.f));
+                        w = pw * (kk + 3.f) * (1.f / (kk + e2));
+                        break; }
+                    }
+                    if (w <= 0.f) w = 0.f;
+                    weights[e] *= w;
                 }
         } else {
             return ORC_ERR_ARG;
@@ -515,59 +607,60 @@ static void jacobi_eig_sym(int n, const double* Ain, double* w, double* Q)
  * pivots (every pivot > 6 eps_f max_j A_jj) instead of the full-pivot QR rank, and the degenerate
  * branch uses a double-precision symmetric pseudo-inverse; both give upstream's minimum-norm answer
  * up to rounding. */
-void orc_solve6(const float* A, const float* b, float* x)
+void orc_solve_n(int n, const float* A, const float* b, float* x)
 {
     float dmax = 0.f;
-    for (int j = 0; j < 6; ++j) if (A[6 * j + j] > dmax) dmax = A[6 * j + j];
-    const float pthr = 6.0f * FLT_EPSILON * dmax;
+    for (int j = 0; j < n; ++j) if (A[n * j + j] > dmax) dmax = A[n * j + j];
+    const float pthr = (float)n * FLT_EPSILON * dmax;
     {
         /* float Cholesky A = L L^T, forward / backward substitution */
         float L[36]; memset(L, 0, sizeof L);
         int ok = 1;
-        for (int j = 0; j < 6 && ok; ++j) {
-            float d = A[6 * j + j];
-            for (int kk = 0; kk < j; ++kk) d -= L[6 * kk + j] * L[6 * kk + j];
+        for (int j = 0; j < n && ok; ++j) {
+            float d = A[n * j + j];
+            for (int kk = 0; kk < j; ++kk) d -= L[n * kk + j] * L[n * kk + j];
             if (!(d > pthr)) { ok = 0; break; }
             const float ljj = sqrtf(d);
-            L[6 * j + j] = ljj;
-            for (int i = j + 1; i < 6; ++i) {
-                float s = A[6 * j + i];
-                for (int kk = 0; kk < j; ++kk) s -= L[6 * kk + i] * L[6 * kk + j];
-                L[6 * j + i] = s / ljj;
+            L[n * j + j] = ljj;
+            for (int i = j + 1; i < n; ++i) {
+                float s = A[n * j + i];
+                for (int kk = 0; kk < j; ++kk) s -= L[n * kk + i] * L[n * kk + j];
+                L[n * j + i] = s / ljj;
             }
         }
         if (ok) {
             float y[6];
-            for (int i = 0; i < 6; ++i) {
+            for (int i = 0; i < n; ++i) {
                 float s = b[i];
-                for (int kk = 0; kk < i; ++kk) s -= L[6 * kk + i] * y[kk];
-                y[i] = s / L[6 * i + i];
+                for (int kk = 0; kk < i; ++kk) s -= L[n * kk + i] * y[kk];
+                y[i] = s / L[n * i + i];
             }
-            for (int i = 5; i >= 0; --i) {
+            for (int i = n - 1; i >= 0; --i) {
                 float s = y[i];
-                for (int kk = i + 1; kk < 6; ++kk) s -= L[6 * i + kk] * x[kk];
-                x[i] = s / L[6 * i + i];
+                for (int kk = i + 1; kk < n; ++kk) s -= L[n * i + kk] * x[kk];
+                x[i] = s / L[n * i + i];
             }
             return;
         }
     }
     /* minimum-norm least squares through the eigen-decomposition */
     double Ad[36], w[6], Q[36];
-    for (int i = 0; i < 36; ++i) Ad[i] = A[i];
-    jacobi_eig_sym(6, Ad, w, Q);
+    for (int i = 0; i < n * n; ++i) Ad[i] = A[i];
+    jacobi_eig_sym(n, Ad, w, Q);
     double wmax = 0;
-    for (int i = 0; i < 6; ++i) if (fabs(w[i]) > wmax) wmax = fabs(w[i]);
-    const double thr = 6.0 * (double)FLT_EPSILON * wmax;
+    for (int i = 0; i < n; ++i) if (fabs(w[i]) > wmax) wmax = fabs(w[i]);
+    const double thr = (double)n * (double)FLT_EPSILON * wmax;
     double xd[6] = { 0, 0, 0, 0, 0, 0 };
-    for (int e = 0; e < 6; ++e) {
+    for (int e = 0; e < n; ++e) {
         if (!(w[e] > thr)) continue;
         double proj = 0;
-        for (int i = 0; i < 6; ++i) proj += Q[6 * e + i] * (double)b[i];
+        for (int i = 0; i < n; ++i) proj += Q[n * e + i] * (double)b[i];
         proj /= w[e];
-        for (int i = 0; i < 6; ++i) xd[i] += proj * Q[6 * e + i];
+        for (int i = 0; i < n; ++i) xd[i] += proj * Q[n * e + i];
     }
-    for (int i = 0; i < 6; ++i) x[i] = (float)xd[i];
+    for (int i = 0; i < n; ++i) x[i] = (float)xd[i];
 }
+void orc_solve6(const float* A, const float* b, float* x) { orc_solve_n(6, A, b, x); }
 
 /* Eigen::AngleAxis(angle, axis).toRotationMatrix() in float */
 static void angle_axis_to_R(const float* x3, float* T)
@@ -595,6 +688,16 @@ static void angle_axis_to_R(const float* x3, float* T)
 int orc_minimize(int minimizer, const float* reading4, int64_t n, const float* ref4,
                  const float* ref_normals3, const int32_t* ids, const float* d2, const float* w, int k,
                  float* T_out, double* A_out, double* b_out, float* x_out, orc_stats* st)
+{
+    return orc_minimize_ex(minimizer, 0, reading4, n, ref4, ref_normals3, ids, d2, w, k, T_out, A_out, b_out, x_out, st);
+}
+
+/* force_4dof: PointToPlaneErrorMinimizer{force4DOF: 1} [UPSTREAM PointToPlane.cpp compute_in_place]: the cross product is
+ * reduced to its z component, F = [cross_z; n] (4 rows), x = (yaw, t); the step is AngleAxis(x0, unitZ) + t.  F's rows are rows
+ * 2..5 of the 6-DOF F, so A and b are the {2,3,4,5} sub-system of the 6-DOF sums. */
+int orc_minimize_ex(int minimizer, int force_4dof, const float* reading4, int64_t n, const float* ref4,
+                    const float* ref_normals3, const int32_t* ids, const float* d2, const float* w, int k,
+                    float* T_out, double* A_out, double* b_out, float* x_out, orc_stats* st)
 {
     int64_t P = 0;
     double wsum = 0;
@@ -655,7 +758,12 @@ int orc_minimize(int minimizer, const float* reading4, int64_t n, const float* r
     for (int i = 0; i < 6; ++i) bf[i] = (float)b[i];
     if (A_out) memcpy(A_out, A, sizeof A);
     if (b_out) memcpy(b_out, b, sizeof b);
-    orc_solve6(Af, bf, x);
+    if (force_4dof) {
+        float A4[16], b4[4], x4[4];
+        for (int c = 0; c < 4; ++c) { b4[c] = bf[2 + c]; for (int r = 0; r < 4; ++r) A4[4 * c + r] = Af[6 * (2 + c) + (2 + r)]; }
+        orc_solve_n(4, A4, b4, x4);
+        x[0] = 0.f; x[1] = 0.f; x[2] = x4[0]; x[3] = x4[1]; x[4] = x4[2]; x[5] = x4[3];
+    } else orc_solve6(Af, bf, x);
     if (x_out) memcpy(x_out, x, sizeof x);
     angle_axis_to_R(x, T_out);
     T_out[12] = x[3]; T_out[13] = x[4]; T_out[14] = x[5];
@@ -713,6 +821,7 @@ struct orc_icp {
     float mean[3];
     float* map4;       /* centred map                                       */
     float* normals3;   /* or NULL                                           */
+    float* scalar;     /* or NULL: the descriptor GenericDescriptorOutlierFilter reads */
     orc_kdtree* tree;
 };
 
@@ -728,7 +837,15 @@ orc_icp* orc_icp_create(const orc_config* cfg)
 void orc_icp_destroy(orc_icp* s)
 {
     if (!s) return;
-    free(s->map4); free(s->normals3); orc_kdtree_free(s->tree); free(s);
+    free(s->map4); free(s->normals3); free(s->scalar); orc_kdtree_free(s->tree); free(s);
+}
+
+void orc_icp_set_map_scalar(orc_icp* s, const float* scalar)
+{
+    free(s->scalar); s->scalar = NULL;
+    if (!scalar || s->m <= 0) return;
+    s->scalar = (float*)malloc((size_t)s->m * sizeof(float));
+    memcpy(s->scalar, scalar, (size_t)s->m * sizeof(float));
 }
 
 int orc_icp_has_map(const orc_icp* s) { return s->m > 0; }
@@ -737,8 +854,8 @@ void orc_icp_get_mean(const orc_icp* s, float* mean3) { memcpy(mean3, s->mean, 3
 int orc_icp_set_map(orc_icp* s, const float* map4, int64_t m, const float* normals3)
 {
     if (m <= 0) return 0; /* ICPSequence::setMap rejects an empty cloud, state unchanged */
-    free(s->map4); free(s->normals3); orc_kdtree_free(s->tree);
-    s->normals3 = NULL;
+    free(s->map4); free(s->normals3); free(s->scalar); orc_kdtree_free(s->tree);
+    s->normals3 = NULL; s->scalar = NULL;
     s->m = m;
     double sum[3] = { 0, 0, 0 };
     for (int64_t i = 0; i < m; ++i) for (int r = 0; r < 3; ++r) sum[r] += map4[4 * i + r];
@@ -792,6 +909,7 @@ int orc_icp_register(orc_icp* s, const float* scan4, int64_t n, const float* sca
     float init_t[3] = { 0, 0, 0 }; double init_q[4]; memcpy(init_q, hq, sizeof init_q);
 
     int err = ORC_OK, iterate = 1;
+    float robust_scale = 1.f; /* RobustOutlierFilter::scale, kept between iterations */
     const double t0 = now_s();
     while (iterate) {
         orc_transform(T_iter, reading, step, n);
@@ -799,10 +917,11 @@ int orc_icp_register(orc_icp* s, const float* scan4, int64_t n, const float* sca
         const double tk = now_s();
         orc_kdtree_knn(s->tree, step, n, k, cfg->max_dist, 1, ids, d2, cfg->nthreads);
         st->seconds_knn += now_s() - tk;
-        err = orc_outlier_weights(cfg, d2, ids, k, n, step_normals, s->normals3, w, &st->trimmed_limit);
+        err = orc_outlier_weights_ex(cfg, d2, ids, k, n, step_normals, s->normals3, s->scalar, step, s->map4, st->iterations + 1,
+                                     &robust_scale, w, &st->trimmed_limit);
         if (err) break;
         float T_step[16];
-        err = orc_minimize(cfg->minimizer, step, n, s->map4, s->normals3, ids, d2, w, k, T_step, NULL, NULL, NULL, st);
+        err = orc_minimize_ex(cfg->minimizer, cfg->force_4dof, step, n, s->map4, s->normals3, ids, d2, w, k, T_step, NULL, NULL, NULL, st);
         if (err) break;
         mat4_mul(T_step, T_iter, T_iter);
         ++st->iterations;

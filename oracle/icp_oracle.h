@@ -44,7 +44,12 @@ extern "C" {
 /* ---- configuration: mirrors include/icpmi.h (kept textually independent) ---- */
 enum { ORC_MIN_IDENTITY = 0, ORC_MIN_POINT_TO_POINT = 1, ORC_MIN_POINT_TO_PLANE = 2 };
 enum { ORC_OUT_MAXDIST = 1, ORC_OUT_MINDIST = 2, ORC_OUT_MEDIANDIST = 3, ORC_OUT_TRIMMEDDIST = 4,
-       ORC_OUT_SURFACENORMAL = 5 };
+       ORC_OUT_SURFACENORMAL = 5, ORC_OUT_GENERICDESCRIPTOR = 6, ORC_OUT_ROBUST = 7 };
+/* GenericDescriptorOutlierFilter iparam bits; RobustOutlierFilter iparam = fct | scale << 4 | distance << 8 */
+enum { ORC_GEN_SOURCE_READING = 1, ORC_GEN_SOFT = 2, ORC_GEN_LARGER = 4 };
+enum { ORC_ROB_CAUCHY = 0, ORC_ROB_WELSCH = 1, ORC_ROB_SC = 2, ORC_ROB_GM = 3, ORC_ROB_TUKEY = 4, ORC_ROB_HUBER = 5, ORC_ROB_L1 = 6, ORC_ROB_STUDENT = 7 };
+enum { ORC_SCALE_NONE = 0, ORC_SCALE_MAD = 1 };
+enum { ORC_DIST_POINT2POINT = 0, ORC_DIST_POINT2PLANE = 1 };
 enum { ORC_OK = 0, ORC_ERR_NO_POINT_TO_MINIMIZE = 1, ORC_ERR_NO_OUTLIER_TO_FILTER = 2,
        ORC_ERR_BOUND = 3, ORC_ERR_NAN = 4, ORC_ERR_ARG = 5 };
 enum { ORC_STOP_NONE = 0, ORC_STOP_COUNTER = 1, ORC_STOP_DIFFERENTIAL = 2 };
@@ -52,6 +57,8 @@ enum { ORC_STOP_NONE = 0, ORC_STOP_COUNTER = 1, ORC_STOP_DIFFERENTIAL = 2 };
 typedef struct {
     int   type;
     float param;
+    int   iparam;            /* flags / enums of GenericDescriptor and Robust                 */
+    float param2;            /* Robust: nbIterationForScale                                   */
 } orc_outlier;
 
 typedef struct {
@@ -69,6 +76,7 @@ typedef struct {
     float max_rot_norm;
     float max_trans_norm;
     int   nthreads;          /* OpenMP threads for the kNN query loop (>=1)       */
+    int   force_4dof;        /* PointToPlaneErrorMinimizer.force4DOF               */
 } orc_config;
 
 typedef struct {
@@ -118,12 +126,21 @@ int orc_outlier_weights(const orc_config* cfg, const float* d2, const int32_t* i
 int orc_minimize(int minimizer, const float* reading4, int64_t n, const float* ref4,
                  const float* ref_normals3, const int32_t* ids, const float* d2, const float* w, int k,
                  float* T_out, double* A_out, double* b_out, float* x_out, orc_stats* st);
+int orc_minimize_ex(int minimizer, int force_4dof, const float* reading4, int64_t n, const float* ref4,
+                 const float* ref_normals3, const int32_t* ids, const float* d2, const float* w, int k,
+                 float* T_out, double* A_out, double* b_out, float* x_out, orc_stats* st);
 
 /* 3x3 SVD-based rotation (PointToPointErrorMinimizer) from a float 3x3 H (col-major): R = U V^T with
  * the reflection fix. Exposed for unit tests. */
 void orc_rotation_from_H(const float* H, float* R);
 /* solvePossiblyUnderdeterminedLinearSystem restatement, A 6x6 col-major float. */
 void orc_solve6(const float* A, const float* b, float* x);
+void orc_solve_n(int n, const float* A, const float* b, float* x); /* n <= 6; the same rule for any size */
+/* every filter of the chain, including the ones that need more than the matches: ref_scalar (GenericDescriptor, per map point),
+ * step4 / ref4 (Robust point2plane residuals), *robust_scale (kept between iterations: nbIterationForScale), iteration (1-based) */
+int orc_outlier_weights_ex(const orc_config* cfg, const float* d2, const int32_t* ids, int k, int64_t n, const float* read_normals3,
+                           const float* ref_normals3, const float* ref_scalar, const float* step4, const float* ref4, int iteration,
+                           float* robust_scale, float* weights, float* limit_out);
 
 /* ---- ICPSequence ---- */
 typedef struct orc_icp orc_icp;
@@ -132,6 +149,8 @@ void orc_icp_destroy(orc_icp* s);
 /* returns 1 on success, 0 if the cloud is empty (state unchanged) */
 int orc_icp_set_map(orc_icp* s, const float* map4, int64_t m, const float* normals3);
 int orc_icp_has_map(const orc_icp* s);
+/* the 1-row descriptor of the map GenericDescriptorOutlierFilter{source: reference} reads (m floats, copied) */
+void orc_icp_set_map_scalar(orc_icp* s, const float* scalar);
 /* mean used for centring (3 floats) */
 void orc_icp_get_mean(const orc_icp* s, float* mean3);
 /* icp(cloudIn): T_out 4x4 col-major correction in the map frame. If fixed_iterations > 0 only the

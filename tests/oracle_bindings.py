@@ -11,11 +11,12 @@ _LIB = os.path.join(_ROOT, "oracle", "liboracle.so")
 
 MIN_IDENTITY, MIN_POINT_TO_POINT, MIN_POINT_TO_PLANE = 0, 1, 2
 OUT_MAXDIST, OUT_MINDIST, OUT_MEDIANDIST, OUT_TRIMMEDDIST, OUT_SURFACENORMAL = 1, 2, 3, 4, 5
+OUT_GENERICDESCRIPTOR, OUT_ROBUST = 6, 7
 STOP_COUNTER, STOP_DIFFERENTIAL = 1, 2
 
 
 class Outlier(C.Structure):
-    _fields_ = [("type", C.c_int), ("param", C.c_float)]
+    _fields_ = [("type", C.c_int), ("param", C.c_float), ("iparam", C.c_int), ("param2", C.c_float)]
 
 
 class Config(C.Structure):
@@ -23,7 +24,7 @@ class Config(C.Structure):
                 ("outlier", Outlier * 8), ("max_iterations", C.c_int), ("use_differential", C.c_int),
                 ("min_diff_rot", C.c_float), ("min_diff_trans", C.c_float), ("smooth_length", C.c_int),
                 ("use_bound", C.c_int), ("max_rot_norm", C.c_float), ("max_trans_norm", C.c_float),
-                ("nthreads", C.c_int)]
+                ("nthreads", C.c_int), ("force_4dof", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -57,7 +58,14 @@ def load():
     lib.orc_dists_quantile.restype = C.c_float
     lib.orc_dists_quantile.argtypes = [_P, C.c_int64, C.c_float]
     lib.orc_outlier_weights.argtypes = [C.POINTER(Config), _P, _P, C.c_int, C.c_int64, _P, _P, _P, C.POINTER(C.c_float)]
+    lib.orc_outlier_weights_ex.argtypes = [C.POINTER(Config), _P, _P, C.c_int, C.c_int64, _P, _P, _P, _P, _P, C.c_int, C.POINTER(C.c_float),
+                                           _P, C.POINTER(C.c_float)]
+    lib.orc_icp_set_map_scalar.argtypes = [_P, _P]
+    lib.orc_icp_set_map_scalar.restype = None
+    lib.orc_solve_n.argtypes = [C.c_int, _P, _P, _P]
+    lib.orc_solve_n.restype = None
     lib.orc_minimize.argtypes = [C.c_int, _P, C.c_int64, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, C.POINTER(Stats)]
+    lib.orc_minimize_ex.argtypes = [C.c_int, C.c_int, _P, C.c_int64, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, C.POINTER(Stats)]
     lib.orc_rotation_from_H.argtypes = [_P, _P]
     lib.orc_solve6.argtypes = [_P, _P, _P]
     lib.orc_icp_create.restype = _P
@@ -87,16 +95,19 @@ def load():
 
 def make_config(knn=1, max_dist=math.inf, minimizer=MIN_POINT_TO_PLANE, outliers=(), max_iterations=40,
                 use_differential=0, min_diff_rot=1e-3, min_diff_trans=1e-3, smooth_length=3, use_bound=0,
-                max_rot_norm=1.0, max_trans_norm=1.0, nthreads=1):
+                max_rot_norm=1.0, max_trans_norm=1.0, nthreads=1, force_4dof=0):
     cfg = Config()
     cfg.knn, cfg.max_dist, cfg.minimizer = knn, max_dist, minimizer
     cfg.n_outlier = len(outliers)
-    for i, (t, p) in enumerate(outliers):
-        cfg.outlier[i].type, cfg.outlier[i].param = t, p
+    for i, o in enumerate(outliers):  # (type, param[, iparam[, param2]])
+        cfg.outlier[i].type, cfg.outlier[i].param = o[0], o[1]
+        cfg.outlier[i].iparam = o[2] if len(o) > 2 else 0
+        cfg.outlier[i].param2 = o[3] if len(o) > 3 else 0.0
     cfg.max_iterations, cfg.use_differential = max_iterations, use_differential
     cfg.min_diff_rot, cfg.min_diff_trans, cfg.smooth_length = min_diff_rot, min_diff_trans, smooth_length
     cfg.use_bound, cfg.max_rot_norm, cfg.max_trans_norm = use_bound, max_rot_norm, max_trans_norm
     cfg.nthreads = nthreads
+    cfg.force_4dof = force_4dof
     return cfg
 
 
@@ -142,24 +153,36 @@ def dists_quantile(d2, q):
     return float(lib.orc_dists_quantile(d2.ctypes.data, d2.size, q))
 
 
-def outlier_weights(cfg, d2, ids, read_normals=None, ref_normals=None):
+def outlier_weights(cfg, d2, ids, read_normals=None, ref_normals=None, ref_scalar=None, step=None, ref=None, iteration=1, scale=1.0):
+    """OutlierFilters::compute of the chain; the keyword extras feed GenericDescriptor (ref_scalar) and Robust (step, ref,
+    iteration, the scale kept from the previous iteration).  Returns (err, weights, limit) -- with Robust{mad} limit = scale."""
     lib = load(); d2 = _f32(d2); ids = np.ascontiguousarray(ids, dtype=np.int32)
     n, k = d2.shape
-    w = np.empty_like(d2); lim = C.c_float(-1)
-    rn = _f32(read_normals).ctypes.data if read_normals is not None else None
-    fn = _f32(ref_normals).ctypes.data if ref_normals is not None else None
-    err = lib.orc_outlier_weights(C.byref(cfg), d2.ctypes.data, ids.ctypes.data, k, n, rn, fn, w.ctypes.data, C.byref(lim))
+    w = np.empty_like(d2); lim = C.c_float(-1); sc = C.c_float(scale)
+    ptr = lambda a: _f32(a).ctypes.data if a is not None else None
+    keep = [_f32(a) if a is not None else None for a in (read_normals, ref_normals, ref_scalar, step, ref)]
+    args = [a.ctypes.data if a is not None else None for a in keep]
+    err = lib.orc_outlier_weights_ex(C.byref(cfg), d2.ctypes.data, ids.ctypes.data, k, n, args[0], args[1], args[2], args[3], args[4],
+                                     int(iteration), C.byref(sc), w.ctypes.data, C.byref(lim))
     return err, w, float(lim.value)
 
 
-def minimize(minimizer, reading, ref, ref_normals, ids, d2, w):
+def solve_n(A, b):
+    """solvePossiblyUnderdeterminedLinearSystem at any size <= 6 (column-major == row-major: A is symmetric)"""
+    lib = load(); A = _f32(A); b = _f32(b); n = b.size
+    x = np.zeros(n, dtype=np.float32)
+    lib.orc_solve_n(n, A.ctypes.data, b.ctypes.data, x.ctypes.data)
+    return x
+
+
+def minimize(minimizer, reading, ref, ref_normals, ids, d2, w, force_4dof=0):
     lib = load(); reading = _f32(reading); ref = _f32(ref)
     ids = np.ascontiguousarray(ids, dtype=np.int32); d2 = _f32(d2); w = _f32(w)
     n, k = d2.shape
     T = np.zeros(16, dtype=np.float32); A = np.zeros(36); b = np.zeros(6); x = np.zeros(6, dtype=np.float32)
     st = Stats()
     nr = _f32(ref_normals) if ref_normals is not None else None
-    err = lib.orc_minimize(minimizer, reading.ctypes.data, n, ref.ctypes.data, nr.ctypes.data if nr is not None else None,
+    err = lib.orc_minimize_ex(minimizer, int(force_4dof), reading.ctypes.data, n, ref.ctypes.data, nr.ctypes.data if nr is not None else None,
                            ids.ctypes.data, d2.ctypes.data, w.ctypes.data, k, T.ctypes.data, A.ctypes.data, b.ctypes.data,
                            x.ctypes.data, C.byref(st))
     return err, T_from_c(T), A.reshape(6, 6).T.copy(), b, x, st
@@ -192,6 +215,10 @@ class OracleICP:
     def setMap(self, cloud, normals=None):
         cloud = _f32(cloud); n = _f32(normals) if normals is not None else None
         return bool(self.lib.orc_icp_set_map(self.h, cloud.ctypes.data, cloud.shape[0], n.ctypes.data if n is not None else None))
+
+    def setMapScalar(self, scalar):
+        """the 1-row descriptor GenericDescriptorOutlierFilter{source: reference} reads"""
+        s = _f32(scalar).ravel(); self.lib.orc_icp_set_map_scalar(self.h, s.ctypes.data)
 
     def getMapMean(self):
         m = np.zeros(3, dtype=np.float32); self.lib.orc_icp_get_mean(self.h, m.ctypes.data); return m

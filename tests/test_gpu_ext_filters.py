@@ -1,0 +1,176 @@
+"""GenericDescriptorOutlierFilter, RobustOutlierFilter and PointToPlaneErrorMinimizer{force4DOF} on the HIP path against the
+oracle (the chain elements upstream's registrar offers beyond the bundled configurations).  Weights are
+compared bit for bit (identically specified float arithmetic; exp / pow go through double on both sides), poses within the
+1e-4 m / 1e-4 rad of BASELINE.json's north_star."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL_M = 1e-4
+POSE_TOL_RAD = 1e-4
+
+GEN, ROB = 6, 7
+SOFT, LARGER = 2, 4
+FCT = {"cauchy": 0, "welsch": 1, "sc": 2, "gm": 3, "tukey": 4, "huber": 5, "L1": 6, "student": 7}
+
+
+def rob(fct, tuning, scale="none", nb=0, dist="point2point"):
+    return (ROB, float(tuning), FCT[fct] | ({"none": 0, "mad": 1}[scale] << 4) | ({"point2point": 0, "point2plane": 1}[dist] << 8), float(nb))
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import norlab_icp_mapper_amd as pkg
+    return pkg
+
+
+def centred(cloud, mean):
+    out = cloud.copy()
+    out[:, :3] = cloud[:, :3] - mean[None, :]
+    return out
+
+
+def scalar_of(sc):
+    # a per-point descriptor with structure and ties at the thresholds used below
+    rng = np.random.default_rng(5)
+    s = rng.random(sc["map"].shape[0]).astype(np.float32)
+    s[::7] = 0.5
+    return s
+
+
+@pytest.mark.parametrize("flags,thr", [(LARGER, 0.5), (0, 0.5), (SOFT, 0.0), (SOFT | LARGER, 0.3)])
+def test_generic_descriptor_weights_exact(amd, oracle, small_scene, flags, thr):
+    sc = small_scene
+    chain = [(GEN, thr, flags, 0.0), (4, 0.9)]
+    icp = amd.ICPSequence(minimizer=1, max_dist=2.0, outliers=chain)
+    icp.setMap(sc["map"])
+    s = scalar_of(sc)
+    icp.setMapScalar(s)
+    mean = icp.getMapMean()
+    ids, d2 = icp.knn(centred(sc["scan"], mean), k=3, max_dist=0.6)  # leaves unmatched slots (id -1)
+    assert (ids < 0).any()
+    w, lim = icp.outlierWeights(d2, ids)
+    err, rw, rlim = oracle.outlier_weights(oracle.make_config(outliers=chain), d2, ids, ref_scalar=s)
+    assert err == 0 and lim == rlim
+    assert np.array_equal(w, rw)
+    assert 0 < np.count_nonzero(w) < w.size
+
+
+def test_generic_descriptor_needs_the_scalar(amd, small_scene):
+    sc = small_scene
+    icp = amd.ICPSequence(minimizer=1, max_dist=2.0, outliers=[(GEN, 0.5, LARGER, 0.0)])
+    icp.setMap(sc["map"])
+    with pytest.raises(Exception, match="InvalidField|scalar"):
+        icp(sc["scan"])
+    with pytest.raises(Exception):  # source: reading
+        amd.ICPSequence(minimizer=1, outliers=[(GEN, 0.5, 1, 0.0)])
+
+
+@pytest.mark.parametrize("fct", list(FCT))
+@pytest.mark.parametrize("scale", ["none", "mad"])
+def test_robust_weights_exact(amd, oracle, small_scene, fct, scale):
+    sc = small_scene
+    tuning = {"sc": 0.02, "gm": 0.05, "student": 1.5}.get(fct, 0.1 if scale == "none" else 1.2)
+    chain = [rob(fct, tuning, scale)]
+    icp = amd.ICPSequence(minimizer=1, max_dist=2.0, outliers=chain)
+    icp.setMap(sc["map"])
+    mean = icp.getMapMean()
+    ids, d2 = icp.knn(centred(sc["scan"], mean), k=2, max_dist=0.8)
+    w, lim = icp.outlierWeights(d2, ids)
+    err, rw, rlim = oracle.outlier_weights(oracle.make_config(outliers=chain), d2, ids)
+    assert err == 0
+    if scale == "mad":
+        assert lim == rlim and lim > 0  # the scale estimate itself
+    assert np.array_equal(w, rw), (fct, scale, np.abs(w - rw).max())
+    assert np.isfinite(w).all() and w.max() > 0
+    # every M-estimator down-weights the far matches (L1 / Huber / ... are monotone in e2)
+    fin = np.isfinite(d2)
+    near, far = w[fin & (d2 < np.quantile(d2[fin], 0.2))].mean(), w[fin & (d2 > np.quantile(d2[fin], 0.8))].mean()
+    assert near >= far
+    assert np.all(w[~fin] == 0)
+
+
+CHAINS = {
+    "p2plane_cauchy_mad": dict(minimizer=2, max_dist=2.0, outliers=[rob("cauchy", 1.0, "mad")], max_iterations=25, use_differential=1),
+    "p2plane_huber_mad_nb3_plane": dict(minimizer=2, max_dist=2.0, outliers=[rob("huber", 1.5, "mad", 3, "point2plane")], max_iterations=12),
+    "p2p_welsch_none_trim": dict(minimizer=1, max_dist=2.0, outliers=[(4, 0.9), rob("welsch", 0.3)], max_iterations=15),
+    "p2plane_tukey_plane": dict(minimizer=2, max_dist=1.0, outliers=[rob("tukey", 0.5, "none", 0, "point2plane")], max_iterations=12),
+    "p2plane_generic_trim": dict(minimizer=2, max_dist=2.0, outliers=[(GEN, 0.25, LARGER, 0.0), (4, 0.85)], max_iterations=20, use_differential=1),
+    "p2plane_generic_soft": dict(minimizer=2, max_dist=2.0, outliers=[(GEN, 0.0, SOFT, 0.0)], max_iterations=10),
+    "p2plane_4dof": dict(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=30, use_differential=1, force_4dof=1),
+}
+
+
+@pytest.mark.parametrize("name", list(CHAINS))
+def test_registration_matches_oracle(amd, oracle, mid_scene, name):
+    sc = mid_scene
+    kw = dict(CHAINS[name])
+    icp = amd.ICPSequence(**kw)
+    assert icp.setMap(sc["map"], sc["normals"])
+    s = scalar_of(sc)
+    if "generic" in name:
+        icp.setMapScalar(s)
+    T = icp(sc["scan"])
+    okw = dict(kw); okw["nthreads"] = 8
+    oicp = oracle.OracleICP(oracle.make_config(**okw))
+    oicp.setMap(sc["map"], sc["normals"])
+    if "generic" in name:
+        oicp.setMapScalar(s)
+    err, T_ref = oicp(sc["scan"])
+    assert err == 0
+    assert icp.stats.iterations == oicp.stats.iterations
+    assert icp.stats.stop_reason == oicp.stats.stop_reason
+    assert icp.stats.pairs == oicp.stats.pairs
+    dt, dr = amd.synth.pose_error(T, T_ref)
+    assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (dt, dr)
+    assert abs(icp.errorMinimizer.getOverlap() - oicp.stats.weighted_point_used_ratio) < 2e-6
+    if name == "p2plane_4dof":
+        # yaw + translation only: the z axis stays the z axis in every step, hence in the product
+        assert np.allclose(T[2, :3], [0, 0, 1], atol=1e-6) and np.allclose(T[:3, 2], [0, 0, 1], atol=1e-6)
+        # fixed launch sequence (hipGraph) == checked loop
+        import torch
+        d = torch.from_numpy(np.ascontiguousarray(sc["scan"], dtype=np.float32)).cuda()
+        its = icp.stats.iterations
+        assert np.array_equal(icp.registerDev(d.data_ptr(), d.shape[0], fixed_iterations=its), T)
+
+
+def test_force_4dof_single_step_matches_oracle(amd, oracle, small_scene):
+    sc = small_scene
+    icp = amd.ICPSequence(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], force_4dof=1)
+    icp.setMap(sc["map"], sc["normals"])
+    mean = icp.getMapMean()
+    mapc = centred(sc["map"], mean)
+    q = centred(sc["scan"], mean)
+    T_iter = amd.synth.make_T((0.0, 0.0, 0.01), (0.02, 0.01, -0.01)).astype(np.float32)
+    T_step, sums = icp.minimizeStep(q, T_iter)
+    step = oracle.transform(T_iter, q)
+    ids, d2 = oracle.knn(mapc, step, k=1, max_dist=2.0)
+    err, w, lim = oracle.outlier_weights(oracle.make_config(max_dist=2.0, outliers=[(4, 0.85)]), d2, ids)
+    err, T_ref, A, b, x, st = oracle.minimize(2, step, mapc, sc["normals"], ids, d2, w, force_4dof=1)
+    assert err == 0 and x[0] == 0 and x[1] == 0
+    # the 4 x 4 system is the {2..5} block of the 6-DOF sums
+    x4 = oracle.solve_n(A[2:, 2:].astype(np.float32), b[2:].astype(np.float32))
+    assert np.array_equal(x4, x[2:])
+    np.testing.assert_allclose(np.linalg.solve(A[2:, 2:], b[2:]), x4, rtol=2e-3, atol=1e-6)
+    dt, dr = amd.synth.pose_error(T_step, T_ref)
+    assert dt < 1e-5 and dr < 1e-5
+    assert np.allclose(T_step[2, :3], [0, 0, 1], atol=1e-7)
+
+
+def test_batch_with_ext_chain_equals_single_registrations(amd, mid_scene):
+    # a batch whose chain holds a Robust filter runs reading by reading: same results as the calls one after the other
+    sc = mid_scene
+    kw = dict(CHAINS["p2plane_cauchy_mad"])
+    icp = amd.ICPSequence(**kw)
+    icp.setMap(sc["map"], sc["normals"])
+    import torch
+    scans = [sc["scan"], sc["scan"][::2].copy(), sc["scan"][1::3].copy()]
+    dev = [torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda() for x in scans]
+    singles = [icp.registerDev(d.data_ptr(), d.shape[0]).copy() for d in dev]
+    Ts, stats, status = icp.registerBatchDev([d.data_ptr() for d in dev], [d.shape[0] for d in dev])
+    for b in range(3):
+        assert status[b] == 0
+        assert np.array_equal(Ts[b], singles[b])

@@ -200,3 +200,19 @@ def test_chain_with_an_empty_scan_still_runs_the_program(amd, oracle):
     fresh = amd.ICPSequence(minimizer=1, max_dist=2.0, max_iterations=5)
     src0, m0 = fresh.mapUpdateChain(empty, modules, [])
     assert m0 == 0 and src0.shape == (0,)
+
+
+def test_chain_that_removes_every_point_leaves_an_empty_map(amd):
+    """CutAtDescriptorThreshold cutting the whole map: the reference goes on with an empty local cloud (`icp.setMap` ignores an
+    empty cloud and keeps its previous map, Map.cpp:528) and the next scan creates the map anew (Map.cpp:505-515)."""
+    base, scan = make_clouds(amd, 12, m=6000, n=1500)
+    icp = amd.ICPSequence(minimizer=1, max_dist=2.0, max_iterations=5)
+    icp.setMap(base); icp.setMapScalar(np.full(base.shape[0], 0.9, np.float32))
+    src, m = icp.mapUpdateChain(scan, [("point_distance", 0.2)], [("cut_scalar", 0.5, 1)], scan_scalar=np.full(scan.shape[0], 0.9, np.float32))
+    assert m == 0 and src.shape == (0,) and icp.getMap().shape[0] == 0
+    assert icp.hasMap()                                   # the registration index is the previous map
+    T = icp(scan)                                         # and still registers
+    assert np.isfinite(T).all()
+    # the next scan creates the map: first-scan semantics of the chain
+    src, m = icp.mapUpdateChain(scan, [("point_distance", 0.2)], [("cut_scalar", 0.95, 1)], scan_scalar=np.full(scan.shape[0], 0.9, np.float32))
+    assert m == scan.shape[0] and np.array_equal(icp.getMap(), scan) and np.array_equal(src, np.arange(scan.shape[0]))

@@ -42,7 +42,8 @@ def test_config_defaults_and_struct_layout():
     assert cfg.min_diff_rot == pytest.approx(1e-3) and cfg.smooth_length == 3 and cfg.use_graph == 1
     # the ctypes mirrors must have the C layout: 8-byte aligned int64 members, trailing reserved block
     assert C.sizeof(_capi.Stats) == 72
-    assert C.sizeof(_capi.Config) == 5 * 4 + 8 * 8 + 12 * 4 + 8 * 4
+    assert C.sizeof(_capi.Config) == 5 * 4 + 8 * 16 + 13 * 4 + 8 * 4
+    assert cfg.force_4dof == 0
 
 
 def test_operator_structs_match_the_header(tmp_path):
@@ -60,6 +61,13 @@ def test_operator_structs_match_the_header(tmp_path):
     assert got[0] == C.sizeof(_capi.MapOp) and got[1] == _capi.MapOp.f.offset
     assert got[2] == C.sizeof(_capi.PointFilter) and got[3] == _capi.PointFilter.f.offset
     assert got[4] == 7 * 4 and got[5] == C.sizeof(_capi.Stats)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "icpmi.h"\nint main(void) { printf("%zu %zu %zu %zu %zu\\n", '
+                   'sizeof(icpmi_config), sizeof(icpmi_outlier), offsetof(icpmi_config, outlier), offsetof(icpmi_config, force_4dof), '
+                   'offsetof(icpmi_config, reserved)); return 0; }\n')
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert got == [C.sizeof(_capi.Config), C.sizeof(_capi.Outlier), _capi.Config.outlier.offset, _capi.Config.force_4dof.offset,
+                   _capi.Config.reserved.offset]
 
 
 def test_create_without_gpu_fails_loudly():
@@ -128,6 +136,26 @@ inspector: NullInspector
             pkg.config_from_yaml_chain(bad)
     with pytest.raises(NotImplementedError):
         pkg.config_from_yaml_chain({"errorMinimizer": {"PointToPlaneErrorMinimizer": {"force2D": 1}}})
+    # the chain elements beyond the bundled configurations
+    cfg = pkg.config_from_yaml_chain({
+        "outlierFilters": [{"RobustOutlierFilter": {"robustFct": "huber", "tuning": 1.5, "scaleEstimator": "mad", "nbIterationForScale": 4,
+                                                    "distanceType": "point2plane"}},
+                           {"GenericDescriptorOutlierFilter": {"descName": "probabilityDynamic", "useLargerThan": 0, "threshold": 0.6}},
+                           "RobustOutlierFilter"],
+        "errorMinimizer": {"PointToPlaneErrorMinimizer": {"force4DOF": 1}}})
+    assert cfg.force_4dof == 1 and cfg.n_outlier == 3
+    o = cfg.outlier
+    assert (o[0].type, o[0].param, o[0].iparam, o[0].param2) == (_capi.OUT_ROBUST, 1.5, 5 | (1 << 4) | (1 << 8), 4.0)
+    assert (o[1].type, o[1].iparam) == (_capi.OUT_GENERICDESCRIPTOR, 0) and o[1].param == pytest.approx(0.6)
+    assert (o[2].type, o[2].param, o[2].iparam, o[2].param2) == (_capi.OUT_ROBUST, 1.0, 0 | (1 << 4), 0.0)  # upstream's defaults
+    assert pkg.config_from_yaml_chain({"errorMinimizer": {"PointToPointErrorMinimizer": {}}}).force_4dof == 0
+    for bad in ({"RobustOutlierFilter": {"robustFct": "foo"}}, {"RobustOutlierFilter": {"nope": 1}}, {"GenericDescriptorOutlierFilter": {"nope": 1}}):
+        with pytest.raises(pkg.InvalidParameter):
+            pkg.config_from_yaml_chain({"outlierFilters": [bad]})
+    for unsupported in ({"RobustOutlierFilter": {"scaleEstimator": "berg"}}, {"RobustOutlierFilter": {"approximation": 2.0}},
+                        {"GenericDescriptorOutlierFilter": {"source": "reading"}}):
+        with pytest.raises(NotImplementedError):
+            pkg.config_from_yaml_chain({"outlierFilters": [unsupported]})
 
 
 def test_synthetic_scene_is_deterministic_and_well_formed():

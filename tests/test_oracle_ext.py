@@ -1,0 +1,113 @@
+"""CPU checks of the oracle's restatement of RobustOutlierFilter / GenericDescriptorOutlierFilter / force4DOF against hand-computed
+values (the formulas of upstream's OutlierFiltersImpl.cpp robustFiltering and PointToPlane.cpp, as recalled: libpointmatcher is
+absent, parity unpinned)."""
+import math
+
+import numpy as np
+import pytest
+
+GEN, ROB = 6, 7
+FCT = {"cauchy": 0, "welsch": 1, "sc": 2, "gm": 3, "tukey": 4, "huber": 5, "L1": 6, "student": 7}
+
+
+def rob(fct, tuning, scale="none", nb=0, dist="point2point"):
+    return (ROB, float(tuning), FCT[fct] | ({"none": 0, "mad": 1}[scale] << 4) | ({"point2point": 0, "point2plane": 1}[dist] << 8), float(nb))
+
+
+def test_robust_known_answers(oracle):
+    # hand-computed weights (the formulas of upstream's robustFiltering) on three residuals, scale none
+    d2 = np.array([[0.01], [0.04], [1.0]], dtype=np.float32)
+    ids = np.zeros((3, 1), dtype=np.int32)
+    k = np.float32(0.2); k2 = k * k
+    want = {
+        "cauchy": 1 / (1 + d2 / k2),
+        "welsch": np.exp(-(d2 / k2).astype(np.float64)).astype(np.float32),
+        "sc": np.where(d2 >= k, 4 * k2 / (k + d2) ** 2, 1),
+        "gm": k2 / (k + d2) ** 2,
+        "tukey": np.where(d2 >= k2, 0, (1 - d2 / k2) ** 2),
+        "huber": np.where(d2 >= k2, k / np.sqrt(d2), 1),
+        "L1": 1 / np.sqrt(d2),
+        "student": (1 + d2 / k) ** (-(k + 3) / 2) * (k + 3) / (k + d2),
+    }
+    for fct, ref in want.items():
+        err, w, _ = oracle.outlier_weights(oracle.make_config(outliers=[rob(fct, 0.2)]), d2, ids)
+        assert err == 0
+        np.testing.assert_allclose(w, ref.astype(np.float32), rtol=3e-6, err_msg=fct)
+    # mad: median of {0.01, 0.04, 1.0} at rank 3 / 2 = 1 -> 0.04; |d2 - 0.04| = {0.03, 0, 0.96} -> rank 1 -> 0.03
+    err, w, scale = oracle.outlier_weights(oracle.make_config(outliers=[rob("cauchy", 1.0, "mad")]), d2, ids)
+    assert err == 0
+    assert scale == pytest.approx(math.sqrt(0.03), rel=1e-6)
+    np.testing.assert_allclose(w[:, 0], 1 / (1 + d2[:, 0] / np.float32(0.03)), rtol=1e-5)
+
+
+def test_robust_scale_is_kept_after_nb_iterations(oracle):
+    d2 = np.array([[0.01], [0.04], [1.0]], dtype=np.float32)
+    ids = np.zeros((3, 1), dtype=np.int32)
+    cfg = oracle.make_config(outliers=[rob("cauchy", 1.0, "mad", nb=2)])
+    # iteration 3 > nbIterationForScale: the scale handed in stays
+    err, w, scale = oracle.outlier_weights(cfg, d2, ids, iteration=3, scale=0.5)
+    assert err == 0 and scale == 0.5
+    np.testing.assert_allclose(w[:, 0], 1 / (1 + d2[:, 0] / np.float32(0.25)), rtol=1e-6)
+    err, w, scale = oracle.outlier_weights(cfg, d2, ids, iteration=2, scale=0.5)
+    assert scale == pytest.approx(math.sqrt(0.03), rel=1e-6)
+    # no finite match at all: "no outlier to filter"
+    err, _, _ = oracle.outlier_weights(cfg, np.full((3, 1), np.inf, dtype=np.float32), -np.ones((3, 1), dtype=np.int32))
+    assert err != 0
+
+
+def test_robust_point2plane_residual(oracle):
+    # one pair: p = (0, 0, 1), q = origin, n = (0, 0.6, 0.8): plane distance 0.8, squared 0.64 (the match distance is 1)
+    step = np.array([[0, 0, 1, 1]], dtype=np.float32); ref = np.array([[0, 0, 0, 1]], dtype=np.float32)
+    nn = np.array([[0, 0.6, 0.8]], dtype=np.float32)
+    d2 = np.array([[1.0]], dtype=np.float32); ids = np.zeros((1, 1), dtype=np.int32)
+    err, w, _ = oracle.outlier_weights(oracle.make_config(outliers=[rob("cauchy", 1.0, dist="point2plane")]), d2, ids, ref_normals=nn, step=step, ref=ref)
+    assert err == 0
+    assert w[0, 0] == pytest.approx(1 / (1 + 0.64), rel=1e-6)
+    err, w, _ = oracle.outlier_weights(oracle.make_config(outliers=[rob("cauchy", 1.0)]), d2, ids)
+    assert w[0, 0] == pytest.approx(0.5, rel=1e-6)
+
+
+def test_generic_descriptor_known_answers(oracle):
+    d2 = np.full((4, 1), 0.1, dtype=np.float32)
+    ids = np.array([[0], [1], [2], [-1]], dtype=np.int32)
+    s = np.array([0.2, 0.5, 0.9], dtype=np.float32)
+    for flags, want in ((4, [0, 0, 1, 0]), (0, [1, 0, 0, 0]), (2, [0.2, 0.5, 0.9, 0]), (6, [0.2, 0.5, 0.9, 0])):
+        err, w, _ = oracle.outlier_weights(oracle.make_config(outliers=[(GEN, 0.5, flags, 0.0)]), d2, ids, ref_scalar=s)
+        assert err == 0
+        np.testing.assert_array_equal(w[:, 0], np.array(want, dtype=np.float32))
+    err, _, _ = oracle.outlier_weights(oracle.make_config(outliers=[(GEN, 0.5, 1, 0.0)]), d2, ids, ref_scalar=s)
+    assert err != 0  # source: reading
+
+
+def test_force_4dof_recovers_a_yaw_and_ignores_tilt(oracle):
+    rng = np.random.default_rng(3)
+    n = 4000
+    ref = np.c_[rng.uniform(-5, 5, (n, 3)), np.ones(n)].astype(np.float32)
+    nn = rng.normal(size=(n, 3)); nn /= np.linalg.norm(nn, axis=1, keepdims=True); nn = nn.astype(np.float32)
+    yaw, t = 0.01, np.array([0.02, -0.01, 0.03])
+    c, s = math.cos(-yaw), math.sin(-yaw)
+    Rinv = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
+    reading = ref.copy(); reading[:, :3] = ((ref[:, :3] - t) @ Rinv.T).astype(np.float32)
+    ids = np.arange(n, dtype=np.int32)[:, None]; d2 = np.ones((n, 1), dtype=np.float32); w = np.ones((n, 1), dtype=np.float32)
+    err, T, A, b, x, st = oracle.minimize(2, reading, ref, nn, ids, d2, w, force_4dof=1)
+    assert err == 0 and x[0] == 0 and x[1] == 0
+    assert x[2] == pytest.approx(yaw, abs=2e-4)
+    np.testing.assert_allclose(T[:3, 3], t, atol=3e-4)
+    np.testing.assert_allclose(T[2, :3], [0, 0, 1], atol=1e-7)
+    # the 6-DOF solve of a tilted reading finds the tilt, the 4-DOF one cannot (x0 = x1 = 0 by construction)
+    tilt = np.array([[1, 0, 0], [0, math.cos(0.01), -math.sin(0.01)], [0, math.sin(0.01), math.cos(0.01)]])
+    reading2 = ref.copy(); reading2[:, :3] = (ref[:, :3] @ tilt).astype(np.float32)
+    _, _, _, _, x6, _ = oracle.minimize(2, reading2, ref, nn, ids, d2, w)
+    _, T4, _, _, x4, _ = oracle.minimize(2, reading2, ref, nn, ids, d2, w, force_4dof=1)
+    assert abs(x6[0]) > 5e-3 and x4[0] == 0
+    np.testing.assert_allclose(T4[2, :3], [0, 0, 1], atol=1e-7)
+
+
+def test_solve_n_matches_numpy_and_handles_rank_deficiency(oracle):
+    rng = np.random.default_rng(0)
+    for n in (4, 6):
+        M = rng.normal(size=(n + 3, n)); A = (M.T @ M).astype(np.float32); b = rng.normal(size=n).astype(np.float32)
+        np.testing.assert_allclose(oracle.solve_n(A, b), np.linalg.solve(A.astype(np.float64), b), rtol=2e-3, atol=1e-5)
+        v = rng.normal(size=(n, 2)); A = (v @ v.T).astype(np.float32)   # rank 2: the minimum-norm solution
+        b = (A @ rng.normal(size=n)).astype(np.float32)
+        np.testing.assert_allclose(oracle.solve_n(A, b), np.linalg.pinv(A.astype(np.float64), rcond=1e-6) @ b, rtol=1e-3, atol=1e-4)
