@@ -109,6 +109,8 @@ struct IcpState {
     int   hist_n;          // number of poses pushed to the differential checker
     double hq[(ICPMI_MAX_SMOOTH + 1) * 4];
     double ht[(ICPMI_MAX_SMOOTH + 1) * 3];
+    double hrot[ICPMI_MAX_SMOOTH + 1];   // |angular distance| and translation distance between pose slot i and the pose before it
+    double htr[ICPMI_MAX_SMOOTH + 1];
     double init_q[4];
     // quantile selection
     unsigned sel_prefix;

@@ -665,7 +665,9 @@ __device__ float det3f(const float* R)
     return R[0] * (R[4] * R[8] - R[7] * R[5]) - R[3] * (R[1] * R[8] - R[7] * R[2]) + R[6] * (R[1] * R[5] - R[4] * R[2]);
 }
 
-__device__ void rotation_from_H(const float* H, float* R)
+// the route through the SVD: singular or reflecting H only (see rotation_from_H) -- out of line, its registers and its
+// thirty-sweep loop stay off the common path
+__device__ __noinline__ void rotation_from_H_svd(const float* H, float* R)
 {
     float U[9], s[3], V[9];
     svd3f_dev(H, U, s, V);
@@ -679,6 +681,62 @@ __device__ void rotation_from_H(const float* H, float* R)
         if (pass == 0 && det3f(R) < 0.f) { for (int i = 0; i < 3; ++i) V[6 + i] = -V[6 + i]; }
         else break;
     }
+}
+
+// U V^T of H = U S V^T is the orthogonal polar factor of H whenever det H > 0, and the Newton iteration X <- (X + X^-T) / 2
+// reaches it without U, S, V: ~4 iterations of ~60 instructions against ~18 Jacobi rotations of ~140 (the single-lane
+// solve went from ~12 k to ~2.5 k clocks).  Same operations, same order as the oracle (polar_newton3f there).
+__device__ bool polar_newton3f(const float* H, float* R)
+{
+    float n2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) n2 = fmaf(H[i], H[i], n2);
+    if (!(n2 > 0.f) || n2 == INFINITY) return false;
+    const float inv = 1.f / sqrtf(n2);
+    float X[9], C[9], Y[9], Xn[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) X[i] = H[i] * inv;
+    for (int it = 0; it < 20; ++it) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int a = (i + 1) % 3, b = (i + 2) % 3, c = (j + 1) % 3, d = (j + 2) % 3;
+                const float t = X[3 * d + a] * X[3 * c + b];
+                C[3 * j + i] = fmaf(X[3 * c + a], X[3 * d + b], -t);
+            }
+        float det = X[0] * C[0];
+        det = fmaf(X[3], C[3], det);
+        det = fmaf(X[6], C[6], det);
+        if (it == 0 && !(det > 1e-6f)) return false;
+        const float invdet = 1.f / det;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Y[i] = C[i] * invdet;
+        if (it < 2) {
+            float nx = 0.f, ny = 0.f;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) { nx = fmaf(X[i], X[i], nx); ny = fmaf(Y[i], Y[i], ny); }
+            const float mu = sqrtf(sqrtf(ny / nx)), imu = 1.f / mu;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Xn[i] = 0.5f * fmaf(mu, X[i], Y[i] * imu);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Xn[i] = 0.5f * (X[i] + Y[i]);
+        }
+        float dmax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { const float dd = fabsf(Xn[i] - X[i]); if (dd > dmax) dmax = dd; X[i] = Xn[i]; }
+        if (!(dmax == dmax)) return false;
+        if (it >= 2 && dmax <= 3e-4f) break;
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = X[i];
+    return true;
+}
+
+__device__ void rotation_from_H(const float* H, float* R)
+{
+    if (!polar_newton3f(H, R)) rotation_from_H_svd(H, R);
 }
 
 // solvePossiblyUnderdeterminedLinearSystem: float LLT when A is invertible, else
@@ -697,7 +755,7 @@ __device__ void solve_spd(const float* A, const float* b, float* x)
 #pragma unroll
     for (int j = 0; j < N; ++j) dmax = A[N * j + j] > dmax ? A[N * j + j] : dmax;
     const float pthr = (float)N * 1.1920928955078125e-07f * dmax;
-    float L[N * N];
+    float L[N * N], iL[N];
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
@@ -707,13 +765,15 @@ __device__ void solve_spd(const float* A, const float* b, float* x)
         ok = ok && (d > pthr);
         const float ljj = sqrtf(d);
         L[N * j + j] = ljj;
+        const float ilj = 1.f / ljj; // one reciprocal per pivot, multiplied through (column and both substitutions)
+        iL[j] = ilj;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             if (i > j) {
                 float s = A[N * j + i];
 #pragma unroll
                 for (int kk = 0; kk < N; ++kk) if (kk < j) s -= L[N * kk + i] * L[N * kk + j];
-                L[N * j + i] = s / ljj;
+                L[N * j + i] = s * ilj;
             }
         }
     }
@@ -724,14 +784,14 @@ __device__ void solve_spd(const float* A, const float* b, float* x)
             float s = b[i];
 #pragma unroll
             for (int kk = 0; kk < N; ++kk) if (kk < i) s -= L[N * kk + i] * y[kk];
-            y[i] = s / L[N * i + i];
+            y[i] = s * iL[i];
         }
 #pragma unroll
         for (int i = N - 1; i >= 0; --i) {
             float s = y[i];
 #pragma unroll
             for (int kk = 0; kk < N; ++kk) if (kk > i) s -= L[N * i + kk] * x[kk];
-            x[i] = s / L[N * i + i];
+            x[i] = s * iL[i];
         }
         return;
     }
@@ -763,8 +823,21 @@ __device__ void angle_axis_T(const float* x3, float* T)
     const float nrm = sqrtf(x3[0] * x3[0] + x3[1] * x3[1] + x3[2] * x3[2]);
     if (!(nrm > 0.f)) return;
     const float ax = x3[0] / nrm, ay = x3[1] / nrm, az = x3[2] / nrm;
-    // sin / cos through double so that host libm and device ocml round to the same float
-    const float s = (float)sin((double)nrm), c = (float)cos((double)nrm);
+    // the oracle's orc_sincos_f, operation by operation: Taylor / Horner with fmaf below 0.5 rad (a double sin + cos is ~2000
+    // clocks of the single lane), through double above -- where host libm and device ocml round to the same float
+    float s, c;
+    if (nrm < 0.5f) {
+        const float z = nrm * nrm;
+        float ps = fmaf(z, 2.75573192e-06f, -1.98412698e-04f);
+        ps = fmaf(z, ps, 8.33333333e-03f);
+        ps = fmaf(z, ps, -1.66666667e-01f);
+        s = fmaf(nrm * z, ps, nrm);
+        float pc = fmaf(z, -2.75573192e-07f, 2.48015873e-05f);
+        pc = fmaf(z, pc, -1.38888889e-03f);
+        pc = fmaf(z, pc, 4.16666667e-02f);
+        pc = fmaf(z, pc, -0.5f);
+        c = fmaf(z, pc, 1.f);
+    } else { s = (float)sin((double)nrm); c = (float)cos((double)nrm); }
     const float sx = s * ax, sy = s * ay, sz = s * az;
     const float cx = (1.f - c) * ax, cy = (1.f - c) * ay, cz = (1.f - c) * az;
     float tmp;
@@ -874,13 +947,15 @@ __device__ void solve_body(IcpState* __restrict__ st, const double* __restrict__
     if (lc.minimizer == ICPMI_MIN_POINT_TO_POINT) {
         // H = sum w q p^T - (sum w q)(sum w p)^T / sum w, rounded to float like the reference's
         // float matrices, then R = U V^T; t = mean_q - R mean_p
+        const double iw = 1.0 / wsum; // one reciprocal, multiplied through (a double division is ~30 instructions of a single lane)
+        const double mpd[3] = {tot[1] * iw, tot[2] * iw, tot[3] * iw}, mqd[3] = {tot[4] * iw, tot[5] * iw, tot[6] * iw};
         float H[9];
         for (int c = 0; c < 3; ++c)
-            for (int r = 0; r < 3; ++r) H[3 * c + r] = (float)(tot[7 + 3 * c + r] - tot[4 + r] * tot[1 + c] / wsum);
+            for (int r = 0; r < 3; ++r) H[3 * c + r] = (float)(tot[7 + 3 * c + r] - mqd[r] * tot[1 + c]);
         float R[9];
         rotation_from_H(H, R);
-        const float mp[3] = {(float)(tot[1] / wsum), (float)(tot[2] / wsum), (float)(tot[3] / wsum)};
-        const float mq[3] = {(float)(tot[4] / wsum), (float)(tot[5] / wsum), (float)(tot[6] / wsum)};
+        const float mp[3] = {(float)mpd[0], (float)mpd[1], (float)mpd[2]};
+        const float mq[3] = {(float)mqd[0], (float)mqd[1], (float)mqd[2]};
         for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) Ts[4 * c + r] = R[3 * c + r];
         for (int r = 0; r < 3; ++r) Ts[12 + r] = mq[r] - (R[r] * mp[0] + R[3 + r] * mp[1] + R[6 + r] * mp[2]);
     } else if (lc.minimizer == ICPMI_MIN_POINT_TO_PLANE) {
@@ -899,6 +974,7 @@ __device__ void solve_body(IcpState* __restrict__ st, const double* __restrict__
         angle_axis_T(x, Ts);
         Ts[12] = x[3]; Ts[13] = x[4]; Ts[14] = x[5];
     }
+    const long long tsolve1 = clock64();
     for (int i = 0; i < 16; ++i)
         if (Ts[i] != Ts[i]) { st->error = ICPMI_ERR_NAN; st->done = 1; return; }
     if (T_step_out) for (int i = 0; i < 16; ++i) T_step_out[i] = Ts[i];
@@ -908,6 +984,7 @@ __device__ void solve_body(IcpState* __restrict__ st, const double* __restrict__
     for (int i = 0; i < 16; ++i) st->T_iter[i] = Ti[i];
     st->iter += 1;
 
+    const long long tsolve2 = clock64();
     // ---- TransformationCheckers ----
     bool iterate = true;
     int reason = ICPMI_STOP_NONE;
@@ -921,15 +998,18 @@ __device__ void solve_body(IcpState* __restrict__ st, const double* __restrict__
         for (int r = 0; r < 3; ++r) st->ht[3 * slot + r] = Ti[12 + r];
         st->hist_n += 1;
         const int hn = st->hist_n;
+        {
+            // the step between pose hn - 1 (just pushed) and pose hn - 2: computed once, read SL times (the older steps of the
+            // window were stored by the iterations that pushed them -- same values, same summation order as recomputing)
+            const int a = (hn - 1) % RING, bq = (hn - 2) % RING;
+            st->hrot[a] = fabs(quat_angdist(st->hq + 4 * a, st->hq + 4 * bq));
+            const double dx = st->ht[3 * a] - st->ht[3 * bq], dy = st->ht[3 * a + 1] - st->ht[3 * bq + 1],
+                         dz = st->ht[3 * a + 2] - st->ht[3 * bq + 2];
+            st->htr[a] = sqrt(dx * dx + dy * dy + dz * dz);
+        }
         if (hn > SL) {
             double rot = 0, tr = 0;
-            for (int i = hn - 1; i >= hn - SL; --i) {
-                const int a = i % RING, bq = (i - 1) % RING;
-                rot += fabs(quat_angdist(st->hq + 4 * a, st->hq + 4 * bq));
-                const double dx = st->ht[3 * a] - st->ht[3 * bq], dy = st->ht[3 * a + 1] - st->ht[3 * bq + 1],
-                             dz = st->ht[3 * a + 2] - st->ht[3 * bq + 2];
-                tr += sqrt(dx * dx + dy * dy + dz * dz);
-            }
+            for (int i = hn - 1; i >= hn - SL; --i) { rot += st->hrot[i % RING]; tr += st->htr[i % RING]; }
             rot /= SL; tr /= SL;
             if (rot != rot || tr != tr) { st->error = ICPMI_ERR_NAN; st->done = 1; return; }
             if (rot < (double)lc.min_rot && tr < (double)lc.min_trans) {
@@ -946,8 +1026,11 @@ __device__ void solve_body(IcpState* __restrict__ st, const double* __restrict__
         if (rot > (double)lc.max_rot || nt > (double)lc.max_trans) { st->error = ICPMI_ERR_BOUND; st->done = 1; return; }
     }
     if (!iterate) { st->done = 1; st->stop_reason = reason; }
-    st->dbg[20] += (unsigned long long)(clock64() - tsolve0); // serial part of the solve (diagnostic)
+    const long long tsolve3 = clock64();
+    st->dbg[20] += (unsigned long long)(tsolve3 - tsolve0); // serial part of the solve (diagnostic)
     st->dbg[21] += 1;
+    st->dbg[22] += (unsigned long long)(tsolve1 - tsolve0); // ... of which the minimiser,
+    st->dbg[23] += (unsigned long long)(tsolve3 - tsolve2); // ... and the checkers
 }
 
 // progress word (icpmi_ctx::h_progress): visible to the host while the stream keeps running

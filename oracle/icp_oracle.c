@@ -549,8 +549,8 @@ static float det3(const float* R)
 }
 
 /* PointToPointErrorMinimizer::compute tail: R = U V^T, reflection -> negate the last
- * row of V^T */
-void orc_rotation_from_H(const float* H, float* R)
+ * row of V^T.  This is the route through the SVD itself; orc_rotation_from_H takes it for the matrices its fast path declines. */
+void orc_rotation_from_H_svd(const float* H, float* R)
 {
     float U[9], s[3], V[9];
     svd3f(H, U, s, V);
@@ -564,6 +564,54 @@ void orc_rotation_from_H(const float* H, float* R)
         if (pass == 0 && det3(R) < 0.f) { for (int i = 0; i < 3; ++i) V[6 + i] = -V[6 + i]; }
         else break;
     }
+}
+
+/* U V^T of H = U S V^T is the orthogonal polar factor of H whenever det H > 0 -- no reflection to repair -- and the Newton
+ * iteration X <- (X + X^-T) / 2 reaches it without forming U, S or V (Higham 1986; Frobenius-scaled for the first two steps,
+ * quadratic afterwards: the step that moves X by d leaves an error ~ d^2 / 2).  Shared numeric spec with the device: every
+ * product-sum below is the explicit fmaf / rounding sequence written here.  Returns 0 -- R untouched -- when H is (close to)
+ * singular or a reflection: det of the Frobenius-normalised H <= 1e-6. */
+static int polar_newton3f(const float* H, float* R)
+{
+    float n2 = 0.f;
+    for (int i = 0; i < 9; ++i) n2 = fmaf(H[i], H[i], n2);
+    if (!(n2 > 0.f) || n2 == INFINITY) return 0;
+    const float inv = 1.f / sqrtf(n2);
+    float X[9], C[9], Y[9], Xn[9];
+    for (int i = 0; i < 9; ++i) X[i] = H[i] * inv;
+    for (int it = 0; it < 20; ++it) {
+        /* cofactors, element (i, j) stored at [3 j + i]; X^-T = C / det */
+        for (int j = 0; j < 3; ++j)
+            for (int i = 0; i < 3; ++i) {
+                const int a = (i + 1) % 3, b = (i + 2) % 3, c = (j + 1) % 3, d = (j + 2) % 3;
+                const float t = X[3 * d + a] * X[3 * c + b];
+                C[3 * j + i] = fmaf(X[3 * c + a], X[3 * d + b], -t);
+            }
+        float det = X[0] * C[0];
+        det = fmaf(X[3], C[3], det);
+        det = fmaf(X[6], C[6], det);
+        if (it == 0 && !(det > 1e-6f)) return 0;
+        const float invdet = 1.f / det;
+        for (int i = 0; i < 9; ++i) Y[i] = C[i] * invdet;
+        if (it < 2) {
+            float nx = 0.f, ny = 0.f;
+            for (int i = 0; i < 9; ++i) { nx = fmaf(X[i], X[i], nx); ny = fmaf(Y[i], Y[i], ny); }
+            const float mu = sqrtf(sqrtf(ny / nx)), imu = 1.f / mu;
+            for (int i = 0; i < 9; ++i) Xn[i] = 0.5f * fmaf(mu, X[i], Y[i] * imu);
+        } else
+            for (int i = 0; i < 9; ++i) Xn[i] = 0.5f * (X[i] + Y[i]);
+        float dmax = 0.f;
+        for (int i = 0; i < 9; ++i) { const float dd = fabsf(Xn[i] - X[i]); if (dd > dmax) dmax = dd; X[i] = Xn[i]; }
+        if (!(dmax == dmax)) return 0;
+        if (it >= 2 && dmax <= 3e-4f) break;
+    }
+    for (int i = 0; i < 9; ++i) R[i] = X[i];
+    return 1;
+}
+
+void orc_rotation_from_H(const float* H, float* R)
+{
+    if (!polar_newton3f(H, R)) orc_rotation_from_H_svd(H, R);
 }
 
 /* symmetric Jacobi eigen-decomposition in double (n <= 6): A = Q diag(w) Q^T */
@@ -614,7 +662,7 @@ void orc_solve_n(int n, const float* A, const float* b, float* x)
     const float pthr = (float)n * FLT_EPSILON * dmax;
     {
         /* float Cholesky A = L L^T, forward / backward substitution */
-        float L[36]; memset(L, 0, sizeof L);
+        float L[36], iL[6]; memset(L, 0, sizeof L);
         int ok = 1;
         for (int j = 0; j < n && ok; ++j) {
             float d = A[n * j + j];
@@ -622,10 +670,12 @@ void orc_solve_n(int n, const float* A, const float* b, float* x)
             if (!(d > pthr)) { ok = 0; break; }
             const float ljj = sqrtf(d);
             L[n * j + j] = ljj;
+            const float ilj = 1.f / ljj; /* one reciprocal per pivot, multiplied through (column and both substitutions) */
+            iL[j] = ilj;
             for (int i = j + 1; i < n; ++i) {
                 float s = A[n * j + i];
                 for (int kk = 0; kk < j; ++kk) s -= L[n * kk + i] * L[n * kk + j];
-                L[n * j + i] = s / ljj;
+                L[n * j + i] = s * ilj;
             }
         }
         if (ok) {
@@ -633,12 +683,12 @@ void orc_solve_n(int n, const float* A, const float* b, float* x)
             for (int i = 0; i < n; ++i) {
                 float s = b[i];
                 for (int kk = 0; kk < i; ++kk) s -= L[n * kk + i] * y[kk];
-                y[i] = s / L[n * i + i];
+                y[i] = s * iL[i];
             }
             for (int i = n - 1; i >= 0; --i) {
                 float s = y[i];
                 for (int kk = i + 1; kk < n; ++kk) s -= L[n * i + kk] * x[kk];
-                x[i] = s / L[n * i + i];
+                x[i] = s * iL[i];
             }
             return;
         }
@@ -662,6 +712,26 @@ void orc_solve_n(int n, const float* A, const float* b, float* x)
 }
 void orc_solve6(const float* A, const float* b, float* x) { orc_solve_n(6, A, b, x); }
 
+/* sin / cos of the step angle in float, specified operation by operation so that host and device produce the same bits
+ * (libm's sinf and ocml's are each within an ulp, but not of each other): below 0.5 rad -- every ICP step but a wild first
+ * one -- the Taylor polynomials in Horner form with fmaf (truncation < 2e-8 relative, i.e. below half an ulp; the result is
+ * within ~1 ulp of the true value); above, through double, where both libraries round to the same float. */
+void orc_sincos_f(float x, float* s, float* c)
+{
+    if (x < 0.5f) {
+        const float z = x * x;
+        float ps = fmaf(z, 2.75573192e-06f, -1.98412698e-04f);   /* 1/9!, -1/7! */
+        ps = fmaf(z, ps, 8.33333333e-03f);                       /* 1/5! */
+        ps = fmaf(z, ps, -1.66666667e-01f);                      /* -1/3! */
+        *s = fmaf(x * z, ps, x);
+        float pc = fmaf(z, -2.75573192e-07f, 2.48015873e-05f);   /* -1/10!, 1/8! */
+        pc = fmaf(z, pc, -1.38888889e-03f);                      /* -1/6! */
+        pc = fmaf(z, pc, 4.16666667e-02f);                       /* 1/4! */
+        pc = fmaf(z, pc, -0.5f);
+        *c = fmaf(z, pc, 1.f);
+    } else { *s = (float)sin((double)x); *c = (float)cos((double)x); }
+}
+
 /* Eigen::AngleAxis(angle, axis).toRotationMatrix() in float */
 static void angle_axis_to_R(const float* x3, float* T)
 {
@@ -669,8 +739,8 @@ static void angle_axis_to_R(const float* x3, float* T)
     mat4_identity(T);
     if (!(nrm > 0.f)) return; /* degenerate: upstream replaces the NaN rotation by identity */
     const float ax = x3[0] / nrm, ay = x3[1] / nrm, az = x3[2] / nrm;
-    /* sin / cos through double so that host libm and device ocml round to the same float */
-    const float s = (float)sin((double)nrm), c = (float)cos((double)nrm);
+    float s, c;
+    orc_sincos_f(nrm, &s, &c);
     const float sx = s * ax, sy = s * ay, sz = s * az;
     const float cx = (1.f - c) * ax, cy = (1.f - c) * ay, cz = (1.f - c) * az;
     float tmp;
@@ -742,8 +812,9 @@ int orc_minimize_ex(int minimizer, int force_4dof, const float* reading4, int64_
         /* H = sum w (q - mq)(p - mp)^T = sum w q p^T - (sum w q)(sum w p)^T / sum w */
         float H[9], R[9];
         double mp[3], mq[3];
-        for (int r = 0; r < 3; ++r) { mp[r] = sp[r] / wsum; mq[r] = sq[r] / wsum; }
-        for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) H[3 * c + r] = (float)(Hs[3 * c + r] - sq[r] * sp[c] / wsum);
+        const double iw = 1.0 / wsum; /* one reciprocal, multiplied through */
+        for (int r = 0; r < 3; ++r) { mp[r] = sp[r] * iw; mq[r] = sq[r] * iw; }
+        for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) H[3 * c + r] = (float)(Hs[3 * c + r] - mq[r] * sp[c]);
         if (A_out) for (int i = 0; i < 9; ++i) A_out[i] = H[i];
         orc_rotation_from_H(H, R);
         const float mpf[3] = { (float)mp[0], (float)mp[1], (float)mp[2] };

@@ -132,7 +132,9 @@ int orc_minimize_ex(int minimizer, int force_4dof, const float* reading4, int64_
 
 /* 3x3 SVD-based rotation (PointToPointErrorMinimizer) from a float 3x3 H (col-major): R = U V^T with
  * the reflection fix. Exposed for unit tests. */
+void orc_sincos_f(float x, float* s, float* c); /* x >= 0: the step angle of the point-to-plane minimiser */
 void orc_rotation_from_H(const float* H, float* R);
+void orc_rotation_from_H_svd(const float* H, float* R); /* the route through the SVD (fallback of the above) */
 /* solvePossiblyUnderdeterminedLinearSystem restatement, A 6x6 col-major float. */
 void orc_solve6(const float* A, const float* b, float* x);
 void orc_solve_n(int n, const float* A, const float* b, float* x); /* n <= 6; the same rule for any size */

@@ -67,6 +67,9 @@ def load():
     lib.orc_minimize.argtypes = [C.c_int, _P, C.c_int64, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, C.POINTER(Stats)]
     lib.orc_minimize_ex.argtypes = [C.c_int, C.c_int, _P, C.c_int64, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, C.POINTER(Stats)]
     lib.orc_rotation_from_H.argtypes = [_P, _P]
+    lib.orc_rotation_from_H_svd.argtypes = [_P, _P]
+    lib.orc_sincos_f.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.orc_sincos_f.restype = None
     lib.orc_solve6.argtypes = [_P, _P, _P]
     lib.orc_icp_create.restype = _P
     lib.orc_icp_create.argtypes = [C.POINTER(Config)]
@@ -188,9 +191,16 @@ def minimize(minimizer, reading, ref, ref_normals, ids, d2, w, force_4dof=0):
     return err, T_from_c(T), A.reshape(6, 6).T.copy(), b, x, st
 
 
-def rotation_from_H(H):
+def sincos_f(x):
+    lib = load(); s = C.c_float(); c = C.c_float()
+    lib.orc_sincos_f(float(x), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def rotation_from_H(H, svd=False):
+    """R = U V^T of H (reflection repaired); svd=True: the route through the SVD itself instead of the polar iteration"""
     lib = load(); Hc = np.ascontiguousarray(np.asarray(H, dtype=np.float32).T).ravel(); R = np.zeros(9, dtype=np.float32)
-    lib.orc_rotation_from_H(Hc.ctypes.data, R.ctypes.data)
+    (lib.orc_rotation_from_H_svd if svd else lib.orc_rotation_from_H)(Hc.ctypes.data, R.ctypes.data)
     return R.reshape(3, 3).T.copy()
 
 

@@ -111,3 +111,41 @@ def test_solve_n_matches_numpy_and_handles_rank_deficiency(oracle):
         v = rng.normal(size=(n, 2)); A = (v @ v.T).astype(np.float32)   # rank 2: the minimum-norm solution
         b = (A @ rng.normal(size=n)).astype(np.float32)
         np.testing.assert_allclose(oracle.solve_n(A, b), np.linalg.pinv(A.astype(np.float64), rcond=1e-6) @ b, rtol=1e-3, atol=1e-4)
+
+
+def test_rotation_from_H_polar_route_equals_the_svd_route(oracle):
+    """the Newton polar iteration and the Jacobi SVD reach the same U V^T; singular and reflecting H take the SVD route"""
+    rng = np.random.default_rng(11)
+    def rot():
+        Q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        if np.linalg.det(Q) < 0: Q[:, 0] *= -1
+        return Q
+    for kappa, tol in ((1, 3e-7), (30, 6e-7), (1e3, 2e-6), (1e4, 5e-6)):
+        for _ in range(100):
+            U, V = rot(), rot()
+            S = np.array([1.0, rng.uniform(1 / kappa, 1), 1 / kappa]) * 10.0 ** rng.uniform(-3, 9)
+            H = ((U * S) @ V.T).astype(np.float32)
+            Ud, _, Vtd = np.linalg.svd(H.astype(np.float64))
+            want = Ud @ Vtd
+            R = oracle.rotation_from_H(H)
+            assert np.abs(R - want).max() < tol, (kappa, np.abs(R - want).max())
+            assert np.abs(oracle.rotation_from_H(H, svd=True) - want).max() < 4 * tol
+            assert np.abs(R.astype(np.float64) @ R.T - np.eye(3)).max() < 1e-6
+    # reflection (det H < 0), rank 2, rank 1, zero: the SVD route, bit for bit
+    U, V = rot(), rot()
+    for S in ([3, 2, -1], [3, 2, 0], [3, 0, 0], [0, 0, 0], [1, 1, 1e-8]):
+        H = ((U * np.array(S, dtype=np.float64)) @ V.T).astype(np.float32)
+        assert np.array_equal(oracle.rotation_from_H(H), oracle.rotation_from_H(H, svd=True))
+        R = oracle.rotation_from_H(H)
+        assert np.linalg.det(R.astype(np.float64)) > 0.999
+
+
+def test_step_angle_sincos_within_an_ulp(oracle):
+    """the operation-by-operation sin / cos of the point-to-plane step angle (shared bit for bit with the device)"""
+    xs = np.concatenate([np.linspace(0, 0.5, 20001)[:-1], [1e-8, 1e-5, 0.49999997, 0.5, 0.7, 1.5, 3.0]]).astype(np.float32)
+    for x in xs:
+        s, c = oracle.sincos_f(x)
+        ts, tc = math.sin(float(x)), math.cos(float(x))
+        assert abs(s - ts) <= 0.75 * np.spacing(np.float32(abs(ts))) + 1e-45
+        assert abs(c - tc) <= 0.75 * np.spacing(np.float32(abs(tc)))
+    assert oracle.sincos_f(0.0) == (0.0, 1.0)
