@@ -90,9 +90,22 @@ __global__ __launch_bounds__(256) void key_kernel(const float4* __restrict__ pts
     const int cz = cell_of(p.z - mz, g.oz, g.inv_cell, g.nz);
     const unsigned key = (unsigned)((cz * g.ny + cy) * g.nx + cx);
     if (valid) keys[i] = key;
-    if (!run_atomics) { if (valid && atomicAdd(&count[key], 1u) == 0u) atomicAdd(n_occ, 1u); return; }
-    const WaveRun r = wave_run(key, valid);
-    if (r.head && atomicAdd(&count[key], (unsigned)r.len) == 0u) atomicAdd(n_occ, 1u);
+    // number of occupied cells = lanes that found their cell's counter at zero.  One same-address device atomic per such lane
+    // serialises at ~1.3 ns each (115 k occupied cells: 150 us of a kernel that otherwise takes 25): counted per wave by
+    // ballot, per workgroup in LDS, one global atomic per workgroup.
+    bool first;
+    if (!run_atomics) first = valid && atomicAdd(&count[key], 1u) == 0u;
+    else {
+        const WaveRun r = wave_run(key, valid);
+        first = r.head && atomicAdd(&count[key], (unsigned)r.len) == 0u;
+    }
+    __shared__ unsigned occ;
+    if (threadIdx.x == 0) occ = 0;
+    __syncthreads();
+    const unsigned long long firsts = __ballot(first);
+    if ((threadIdx.x & 63) == 0 && firsts) atomicAdd(&occ, (unsigned)__popcll(firsts));
+    __syncthreads();
+    if (threadIdx.x == 0 && occ) atomicAdd(n_occ, occ);
 }
 
 // ---- exclusive scan of the cell histogram (3 kernels) ----------------------------------------
@@ -545,6 +558,9 @@ icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float
         const double TARGET = target_cfg;
         double vol = std::max(ext[0], 1e-3) * std::max(ext[1], 1e-3) * std::max(ext[2], 1e-3);
         double cell = cbrt(vol / (double)m) * 1.2;
+        // a handle that indexed a cloud of about this size before (the map of the previous update, the private handle of a
+        // map-side operator) starts from that edge: the trial count is then usually the only one
+        if (c->grid.cell > 0.f && c->m > 0 && (double)m > 0.7 * (double)c->m && (double)m < 1.4 * (double)c->m) cell = c->grid.cell;
         g = make_grid(clo, chi, clamp_cell(cell), maxabs);
         if (grid_count(c, d_pts, m, g, &n_occ) != ICPMI_OK) return ICPMI_ERR_HIP;
         for (int it = 0; it < 2; ++it) {

@@ -4,6 +4,7 @@
 //   PointDistanceMapperModule keep mask     (MapperModules/PointDistanceMapperModule.cpp:28-50)
 //   Map::unloadCells cell binning           (Map.cpp:206-209,232-235)
 #include "common.h"
+#include <chrono>
 #include <utility>
 #include <cstring>
 
@@ -1175,9 +1176,20 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
     // survives a decimation or a threshold can hinge on the last bit).  from_sensor == NULL: filters in the map frame.
     const bool round_trip = from_sensor != nullptr && to_sensor != nullptr;
     bool in_sensor = false;
+    // ICPMI_CHAIN_TIMING=1: wall time of every step with a stream sync behind it, on stderr (diagnostic; perturbs the overlap)
+    static const bool timing = [] { const char* e = getenv("ICPMI_CHAIN_TIMING"); return e && atoi(e) != 0; }();
+    auto tick = [&](const char* what, int type) {
+        static thread_local std::chrono::steady_clock::time_point t0;
+        if (!timing) return;
+        (void)hipStreamSynchronize(c->stream);
+        const auto t1 = std::chrono::steady_clock::now();
+        if (what) fprintf(stderr, "[icpmi chain] %-14s type %d  m %lld  %8.1f us\n", what, type, (long long)w.m, std::chrono::duration<double, std::micro>(t1 - t0).count());
+        t0 = std::chrono::steady_clock::now();
+    };
+    tick(nullptr, 0);
     for (int i = 0; i < n_ops && s == ICPMI_OK; ++i) {
         const icpmi_map_op& op = ops[i];
-        if (i == n_modules && round_trip) { s = chain_move(c, to_sensor, w.m, w.has_n); in_sensor = true; if (s != ICPMI_OK) break; }
+        if (i == n_modules && round_trip) { s = chain_move(c, to_sensor, w.m, w.has_n); in_sensor = true; if (s != ICPMI_OK) break; tick("to_sensor", -1); }
         switch (op.type) {
         case ICPMI_MOP_POINT_DISTANCE: {
             if (n == 0) break;
@@ -1251,10 +1263,12 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
         }
         }
         created = true;
+        tick("op", op.type);
     }
     if (s == ICPMI_OK && round_trip) {
         if (!in_sensor) s = chain_move(c, to_sensor, w.m, w.has_n); // no post filter at all: the reference still makes the trip
         if (s == ICPMI_OK) s = chain_move(c, from_sensor, w.m, w.has_n);
+        tick("from_sensor", -2);
     }
     if (s != ICPMI_OK) {
         // the resident arrays may be half way through the program: drop them, the index of the old map is intact but its
@@ -1284,11 +1298,13 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
         }
         if (w.m > head) HIP_TRY(c, hipMemcpyAsync(src_out + head, c->d_src + head, (size_t)(w.m - head) * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     }
+    tick("src", -3);
     // icp.setMap(localPointCloud) (Map.cpp:528): rebuild the index from the resident copy
     s = map_build(c, c->d_raw, w.m, w.has_n ? c->d_raw_n3 : nullptr);
     if (s != ICPMI_OK) return s;
     c->raw_has_scalar = (m0 == 0 || c->raw_has_scalar) && (n == 0 || d_scan_s != nullptr); // both parts carried real values
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    tick("map_build", -4);
     if (new_m) *new_m = w.m;
     return ICPMI_OK;
 }
