@@ -3,11 +3,42 @@
 #include "common.h"
 #include <cstring>
 #include <new>
+#include <dlfcn.h>
 
 static std::string g_create_error;
 
+// ICPMI_ROCTX=1: every entry point that takes a handle runs inside a roctx range named after it (rocprofv3 --marker-trace
+// then shows registrations, map updates and merges as ranges above their kernels).  The marker library is looked up at run
+// time: nothing links against it, and without the variable the cost is one predictable branch per call.
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        const char* e = getenv("ICPMI_ROCTX");
+        if (!e || !atoi(e)) return;
+        for (const char* name : {"libroctx64.so.4", "libroctx64.so", "librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so"}) {
+            void* lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (!lib) continue;
+            push = (int (*)(const char*))dlsym(lib, "roctxRangePushA");
+            pop = (int (*)())dlsym(lib, "roctxRangePop");
+            if (push && pop) return;
+            push = nullptr; pop = nullptr;
+        }
+    }
+};
+Roctx& roctx() { static Roctx r; return r; }
+struct RoctxRange {
+    bool on;
+    explicit RoctxRange(const char* name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+    ~RoctxRange() { if (on) roctx().pop(); }
+};
+} // namespace
+
 // locks the handle for the rest of the calling function (see icpmi_ctx::mu) and makes its device current
 #define CHECK_H(h)                                                           \
+    RoctxRange _roctx_range(__func__);                                       \
     if (!(h)) return ICPMI_ERR_INVALID_ARG;                                  \
     std::lock_guard<std::recursive_mutex> _handle_lock((h)->mu);             \
     do {                                                                     \

@@ -328,3 +328,21 @@ def dynamic_points_update(to_sensor, input_cloud, map_cloud, map_normals, prob, 
     lib.orc_dynamic_points_update(pv.ctypes.data, T.ctypes.data, i.ctypes.data, i.shape[0], m.ctypes.data, nn.ctypes.data, m.shape[0],
                                   out.ctypes.data, nthreads)
     return out
+
+
+def check_normals_are_smallest_eigenvectors(pts, ids, normals, what):
+    """EVERY normal must be a smallest-eigenvalue direction of the covariance of its exact neighbour set, to float
+    precision: Rayleigh quotient within 2e-5 of the largest eigenvalue above the smallest one (float64 reference).  Where the
+    two smallest eigenvalues coincide the direction is free inside that eigenspace -- and only there."""
+    P = pts[:, :3].astype(np.float64)
+    nb = P[ids]                                   # n x k x 3
+    d = nb - nb.mean(axis=1, keepdims=True)
+    C = np.einsum("nki,nkj->nij", d, d)
+    lam = np.linalg.eigvalsh(C)                   # ascending
+    nn = normals.astype(np.float64)
+    np.testing.assert_allclose(np.linalg.norm(nn, axis=1), 1.0, atol=2e-6, err_msg=what)
+    ray = np.einsum("ni,nij,nj->n", nn, C, nn)
+    rank2 = lam[:, 1] > 3 * np.finfo(np.float32).eps * lam[:, 2]   # upstream's rank test; below it the normal is the fallback
+    excess = (ray - lam[:, 0]) / np.maximum(lam[:, 2], 1e-300)
+    assert np.all(excess[rank2] <= 2e-5), (what, float(excess[rank2].max()), int(np.argmax(excess)))
+    return rank2

@@ -82,6 +82,15 @@ def test_create_without_gpu_fails_loudly():
         pkg.ICPSequence(knn=0)
 
 
+def test_roctx_ranges_are_optional_and_harmless():
+    """ICPMI_ROCTX=1 looks the marker library up at run time; entry points behave the same with and without it"""
+    import subprocess, sys
+    code = ("import ctypes as C; lib = C.CDLL(%r); T = (C.c_float * 16)(); "
+            "print(lib.icpmi_register(None, None, 0, None, T, None), lib.icpmi_has_map(None))" % os.path.join(ROOT, "norlab_icp_mapper_amd", "libicpmi.so"))
+    outs = [subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, ICPMI_ROCTX=v)).split() for v in ("0", "1")]
+    assert outs[0] == outs[1] and int(outs[0][0]) != 0
+
+
 def test_yaml_chain_translation():
     import yaml
     import norlab_icp_mapper_amd as pkg
