@@ -73,7 +73,11 @@ typedef enum {
     /* RobustOutlierFilter{robustFct, tuning, scaleEstimator: none | mad, nbIterationForScale, distanceType}: M-estimator weight of
      * e2 = residual / scale^2.  param = tuning, param2 = nbIterationForScale, iparam = robustFct | scaleEstimator << 4 |
      * distanceType << 8.  berg / std scale estimators and a finite `approximation` are UNSUPPORTED. */
-    ICPMI_OUT_ROBUST = 7
+    ICPMI_OUT_ROBUST = 7,
+    /* VarTrimmedDistOutlierFilter{minRatio, maxRatio, lambda} (Phillips et al. 2007): TrimmedDist at the ratio that minimises
+     * FRMS(i) = (sum of the i + 1 smallest d2) / ((i + 1) ((i + 1) / N)^(2 lambda)) over floor(minRatio N) <= i < floor(maxRatio N).
+     * param = minRatio, param2 = maxRatio, param3 = lambda. */
+    ICPMI_OUT_VARTRIMMEDDIST = 8
 } icpmi_outlier_type;
 enum { ICPMI_GEN_SOURCE_READING = 1, ICPMI_GEN_SOFT = 2, ICPMI_GEN_LARGER = 4 };
 enum { ICPMI_ROB_CAUCHY = 0, ICPMI_ROB_WELSCH = 1, ICPMI_ROB_SC = 2, ICPMI_ROB_GM = 3, ICPMI_ROB_TUKEY = 4, ICPMI_ROB_HUBER = 5,
@@ -85,7 +89,8 @@ typedef struct {
     int32_t type; /* icpmi_outlier_type */
     float   param;
     int32_t iparam; /* flags / enums of GenericDescriptor and Robust, 0 otherwise */
-    float   param2; /* Robust: nbIterationForScale                                 */
+    float   param2; /* Robust: nbIterationForScale; VarTrimmedDist: maxRatio        */
+    float   param3; /* VarTrimmedDist: lambda                                       */
 } icpmi_outlier;
 
 typedef enum { ICPMI_STOP_NONE = 0, ICPMI_STOP_COUNTER = 1, ICPMI_STOP_DIFFERENTIAL = 2 } icpmi_stop_reason;

@@ -16,7 +16,7 @@ ERR_INVALID_ARG, ERR_HIP, ERR_NO_POINT_TO_MINIMIZE, ERR_NO_OUTLIER_TO_FILTER = 1
 ERR_BOUND, ERR_NAN, ERR_MISSING_NORMALS, ERR_UNSUPPORTED = 5, 6, 7, 8
 MIN_IDENTITY, MIN_POINT_TO_POINT, MIN_POINT_TO_PLANE = 0, 1, 2
 OUT_MAXDIST, OUT_MINDIST, OUT_MEDIANDIST, OUT_TRIMMEDDIST, OUT_SURFACENORMAL = 1, 2, 3, 4, 5
-OUT_GENERICDESCRIPTOR, OUT_ROBUST = 6, 7
+OUT_GENERICDESCRIPTOR, OUT_ROBUST, OUT_VARTRIMMEDDIST = 6, 7, 8
 GEN_SOURCE_READING, GEN_SOFT, GEN_LARGER = 1, 2, 4
 ROBUST_FCT = {"cauchy": 0, "welsch": 1, "sc": 2, "gm": 3, "tukey": 4, "huber": 5, "L1": 6, "student": 7}
 ROBUST_SCALE = {"none": 0, "mad": 1}
@@ -25,7 +25,7 @@ STOP_NONE, STOP_COUNTER, STOP_DIFFERENTIAL = 0, 1, 2
 
 
 class Outlier(C.Structure):
-    _fields_ = [("type", C.c_int32), ("param", C.c_float), ("iparam", C.c_int32), ("param2", C.c_float)]
+    _fields_ = [("type", C.c_int32), ("param", C.c_float), ("iparam", C.c_int32), ("param2", C.c_float), ("param3", C.c_float)]
 
 
 class Config(C.Structure):

@@ -84,7 +84,13 @@ static icpmi_status validate_config(const icpmi_config* cfg, std::string& err)
     for (int f = 0; f < cfg->n_outlier; ++f) {
         const int t = cfg->outlier[f].type;
         const float p = cfg->outlier[f].param;
-        if (t < ICPMI_OUT_MAXDIST || t > ICPMI_OUT_ROBUST) { err = "InvalidParameter: unknown outlier filter type"; return ICPMI_ERR_INVALID_ARG; }
+        if (t < ICPMI_OUT_MAXDIST || t > ICPMI_OUT_VARTRIMMEDDIST) { err = "InvalidParameter: unknown outlier filter type"; return ICPMI_ERR_INVALID_ARG; }
+        if (t == ICPMI_OUT_VARTRIMMEDDIST) {
+            const float lo = cfg->outlier[f].param, hi = cfg->outlier[f].param2, lam = cfg->outlier[f].param3;
+            if (!(lo > 0.f && lo < 1.f) || !(hi > 0.f && hi < 1.f) || !(lo <= hi) || !(lam >= 0.f)) { // upstream: ratios in ]0, 1[, lambda >= 0
+                err = "InvalidParameter: VarTrimmedDist needs 0 < minRatio <= maxRatio < 1 and lambda >= 0"; return ICPMI_ERR_INVALID_ARG;
+            }
+        }
         if (t == ICPMI_OUT_GENERICDESCRIPTOR) {
             const int ip = cfg->outlier[f].iparam;
             if (ip & ~7) { err = "InvalidParameter: GenericDescriptorOutlierFilter: unknown flag"; return ICPMI_ERR_INVALID_ARG; }
@@ -315,7 +321,7 @@ static icpmi_status register_impl(icpmi_handle h, const float* d_scan4, int64_t 
     if (n == 0) {
         // upstream: Trimmed/Median throw "no outlier to filter", otherwise "no point to minimize"
         bool quant = false;
-        for (int f = 0; f < lc.n_out; ++f) quant |= lc.out_type[f] == ICPMI_OUT_TRIMMEDDIST || lc.out_type[f] == ICPMI_OUT_MEDIANDIST;
+        for (int f = 0; f < lc.n_out; ++f) quant |= lc.out_type[f] == ICPMI_OUT_TRIMMEDDIST || lc.out_type[f] == ICPMI_OUT_MEDIANDIST || lc.out_type[f] == ICPMI_OUT_VARTRIMMEDDIST;
         h->last_error = quant ? "ConvergenceError: no outlier to filter" : "ConvergenceError: ErrorMinimizer: no point to minimize";
         return quant ? ICPMI_ERR_NO_OUTLIER_TO_FILTER : ICPMI_ERR_NO_POINT_TO_MINIMIZE;
     }
@@ -353,7 +359,7 @@ icpmi_status icpmi_register_batch_dev(icpmi_handle h, int32_t batch, const float
     int nquant = 0;
     for (int f = 0; f < h->cfg.n_outlier; ++f) {
         const int t = h->cfg.outlier[f].type;
-        if (t == ICPMI_OUT_SURFACENORMAL || t == ICPMI_OUT_GENERICDESCRIPTOR || t == ICPMI_OUT_ROBUST) together = false;
+        if (t == ICPMI_OUT_SURFACENORMAL || t == ICPMI_OUT_GENERICDESCRIPTOR || t == ICPMI_OUT_ROBUST || t == ICPMI_OUT_VARTRIMMEDDIST) together = false;
         if (t == ICPMI_OUT_TRIMMEDDIST || t == ICPMI_OUT_MEDIANDIST) ++nquant;
     }
     if (nquant > 1) together = false;

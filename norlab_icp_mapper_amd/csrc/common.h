@@ -86,6 +86,7 @@ struct LoopCfg {
     float out_param[ICPMI_MAX_OUTLIER];
     int   out_iparam[ICPMI_MAX_OUTLIER];
     float out_param2[ICPMI_MAX_OUTLIER];
+    float out_param3[ICPMI_MAX_OUTLIER];
     int   ext;             // GenericDescriptor / Robust in the chain: the pair-sum kernel's EXT variant
     int   force_4dof;
     int   max_iter;
@@ -119,6 +120,8 @@ struct IcpState {
     unsigned sel_prefix_l[3];  // fused selection: one slot per radix level (written by level L,
     unsigned sel_rank_l[3];    // read by level L + 1 -- never both in one kernel)
     float limits[ICPMI_MAX_OUTLIER];
+    unsigned vt_valid;     // VarTrimmedDist: number of valid matches of this iteration (counted by vt_keys_kernel, cleared by vt_pick_kernel)
+    float vt_ratio;        // ... and the ratio optimizeInlierRatio picked (diagnostic)
     float robust_med;      // RobustOutlierFilter{mad}: median of the finite d2 of this iteration
     float robust_scale;    // RobustOutlierFilter::scale, kept between iterations (nbIterationForScale)
     // statistics of the last iteration
@@ -401,6 +404,8 @@ icpmi_status comm_destroy(icpmi_ctx* c);
 icpmi_status comm_allgather(icpmi_ctx* c, const void* d_send, void* d_recv, size_t count, bool is_float);
 icpmi_status ops_staged_merge_allgather(icpmi_ctx* c, const float correction[16], float min_dist, int normals_knn, int64_t* accepted_local,
                                         int64_t* appended_total, int64_t* new_m, float* merged_out4, int64_t merged_capacity, int64_t* merged_n);
+size_t radix_sort_tab_words(int64_t n, int bits);
+icpmi_status radix_sort_pairs(icpmi_ctx* c, unsigned long long* d_keys2, unsigned* d_vals2, int64_t n, int bits, unsigned* d_tab, int* result_half);
 icpmi_status octree_sample_dev(icpmi_ctx* c, const float4* d_in, int64_t n, float max_size, int max_pts, int method, int* d_order, int* d_leaf_of,
                                int64_t* n_out);
 icpmi_status ops_octree_sample(icpmi_ctx* c, const float* in4, int64_t n, float max_size, int max_pts, int method, int32_t* order_out,

@@ -256,6 +256,155 @@ __global__ __launch_bounds__(256) void sel2_scan_hist_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// VarTrimmedDistOutlierFilter (optimizeInlierRatio, Phillips et al. 2007): the valid d2 sorted (radix sort of the bit
+// patterns, octree.hip), their running sum in double, FRMS(i) = cum(i) / ((i + 1) ((i + 1) / N)^(2 lambda)) minimised over
+// minEl <= i < min(maxEl, V); the limit is then the quantile at i_min / N read straight from the sorted array.
+//   vt_keys -> radix_sort_pairs -> vt_chunk_sums -> vt_chunk_offsets -> vt_frms -> vt_pick        (a rare chain: not batched)
+// ---------------------------------------------------------------------------------------------
+constexpr int VT_CHUNK = 2048; // elements per workgroup of the scan (256 threads x 8)
+
+__global__ __launch_bounds__(256) void vt_keys_kernel(const float* __restrict__ d2, int64_t count, IcpState* __restrict__ st,
+                                                      unsigned long long* __restrict__ keys, unsigned* __restrict__ vals)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const float v = i < count ? d2[i] : INFINITY;
+    const bool valid = v != INFINITY && v > 0.f;
+    if (i < count) { keys[i] = valid ? (unsigned long long)__float_as_uint(v) : 0xffffffffull; vals[i] = 0u; } // invalid entries sort to the end
+    __shared__ unsigned cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    const unsigned long long b = __ballot(valid);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&cnt, (unsigned)__popcll(b));
+    __syncthreads();
+    if (threadIdx.x == 0 && cnt) atomicAdd(&st->vt_valid, cnt);
+}
+
+__device__ __forceinline__ double vt_value(const unsigned long long* __restrict__ sorted, int64_t i, int64_t V)
+{
+    return i < V ? (double)__uint_as_float((unsigned)sorted[i]) : 0.0;
+}
+
+__global__ __launch_bounds__(256) void vt_chunk_sums_kernel(const unsigned long long* __restrict__ sorted, const IcpState* __restrict__ st,
+                                                            double* __restrict__ sums)
+{
+    const int64_t V = st->vt_valid;
+    const int64_t base = (int64_t)blockIdx.x * VT_CHUNK + threadIdx.x * 8;
+    double s = 0.0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += vt_value(sorted, base + e, V);
+    __shared__ double sh[256];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[blockIdx.x] = sh[0];
+}
+
+// one workgroup: sums[b] -> sum of the chunks before b, in chunk order (tiles of 1024 through LDS; lane 0 adds them up in order)
+__global__ __launch_bounds__(256) void vt_chunk_offsets_kernel(double* __restrict__ sums, int nchunks)
+{
+    __shared__ double sh[1024];
+    __shared__ double carry;
+    if (threadIdx.x == 0) carry = 0.0;
+    for (int base = 0; base < nchunks; base += 1024) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 1024; i += 256) sh[i] = base + i < nchunks ? sums[base + i] : 0.0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double run = carry;
+            const int lim = nchunks - base < 1024 ? nchunks - base : 1024;
+            for (int i = 0; i < lim; ++i) { const double v = sh[i]; sh[i] = run; run += v; }
+            carry = run;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 1024; i += 256) if (base + i < nchunks) sums[base + i] = sh[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void vt_frms_kernel(const unsigned long long* __restrict__ sorted, int64_t count, const IcpState* __restrict__ st,
+                                                      const double* __restrict__ offsets, long long min_el, long long max_el, float lambda,
+                                                      double* __restrict__ best_val, long long* __restrict__ best_idx)
+{
+    const int64_t V = st->vt_valid;
+    const int64_t hi = max_el < V ? max_el : V;
+    const int64_t base = (int64_t)blockIdx.x * VT_CHUNK + threadIdx.x * 8;
+    double v[8], s = 0.0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { v[e] = vt_value(sorted, base + e, V); s += v[e]; }
+    __shared__ double sh[256];
+    __shared__ long long shi[256];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) { // inclusive scan of the thread totals
+        const double add = threadIdx.x >= off ? sh[threadIdx.x - off] : 0.0;
+        __syncthreads();
+        sh[threadIdx.x] += add;
+        __syncthreads();
+    }
+    double cum = offsets[blockIdx.x] + (sh[threadIdx.x] - s);
+    __syncthreads();
+    double bv = INFINITY; long long bi = -1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int64_t i = base + e;
+        cum += v[e];
+        if (i >= min_el && i < hi) {
+            const double ids = (double)(i + 1), ratio = ids / (double)count;
+            const double frms = cum / (ids * pow(ratio, 2.0 * (double)lambda));
+            if (bi < 0 || frms < bv) { bv = frms; bi = i; }
+        }
+    }
+    sh[threadIdx.x] = bv; shi[threadIdx.x] = bi;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) { // first minimum: smaller value, or the same value at a smaller rank
+        if (threadIdx.x < off) {
+            const double ov = sh[threadIdx.x + off]; const long long oi = shi[threadIdx.x + off];
+            const long long mi = shi[threadIdx.x];
+            if (oi >= 0 && (mi < 0 || ov < sh[threadIdx.x] || (ov == sh[threadIdx.x] && oi < mi))) { sh[threadIdx.x] = ov; shi[threadIdx.x] = oi; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { best_val[blockIdx.x] = sh[0]; best_idx[blockIdx.x] = shi[0]; }
+}
+
+__global__ __launch_bounds__(256) void vt_pick_kernel(const unsigned long long* __restrict__ sorted, int64_t count, IcpState* __restrict__ st,
+                                                      const double* __restrict__ best_val, const long long* __restrict__ best_idx, int nchunks,
+                                                      long long min_el, int filter_slot)
+{
+    __shared__ double sh[256];
+    __shared__ long long shi[256];
+    double bv = INFINITY; long long bi = -1;
+    for (int b = threadIdx.x; b < nchunks; b += 256) {
+        const double ov = best_val[b]; const long long oi = best_idx[b];
+        if (oi >= 0 && (bi < 0 || ov < bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+    }
+    sh[threadIdx.x] = bv; shi[threadIdx.x] = bi;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) {
+            const double ov = sh[threadIdx.x + off]; const long long oi = shi[threadIdx.x + off];
+            const long long mi = shi[threadIdx.x];
+            if (oi >= 0 && (mi < 0 || ov < sh[threadIdx.x] || (ov == sh[threadIdx.x] && oi < mi))) { sh[threadIdx.x] = ov; shi[threadIdx.x] = oi; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    const unsigned V = st->vt_valid;
+    st->vt_valid = 0; // for the next iteration's count
+    if (st->done) return;
+    if (V == 0) { st->error = ICPMI_ERR_NO_OUTLIER_TO_FILTER; st->done = 1; return; }
+    long long best = shi[0] >= 0 ? shi[0] : min_el;
+    const float ratio = (float)best / (float)count;
+    st->vt_ratio = ratio;
+    unsigned r; // getDistsQuantile(ratio) over the V valid entries
+    if (ratio == 1.0f) r = V - 1;
+    else { r = (unsigned)((float)V * ratio); if (r > V - 1) r = V - 1; }
+    st->limits[filter_slot] = __uint_as_float((unsigned)sorted[r]);
+}
+
+// ---------------------------------------------------------------------------------------------
 // outlier weight of one match (OutlierFilters::compute; weights multiply)
 // ---------------------------------------------------------------------------------------------
 // M-estimator weight of RobustOutlierFilter for the scaled squared residual e2 (tuning k); exp / pow through double so that
@@ -295,7 +444,8 @@ __device__ __forceinline__ float match_weight(const LoopCfg& lc, const IcpState*
         const float prm = lc.out_param[f];
         if (type == ICPMI_OUT_MAXDIST) w *= (d2 <= prm * prm) ? 1.f : 0.f;
         else if (type == ICPMI_OUT_MINDIST) w *= (d2 >= prm * prm) ? 1.f : 0.f;
-        else if (type == ICPMI_OUT_MEDIANDIST || type == ICPMI_OUT_TRIMMEDDIST) w *= (d2 <= (f == fused_slot ? fused_limit : st->limits[f])) ? 1.f : 0.f;
+        else if (type == ICPMI_OUT_MEDIANDIST || type == ICPMI_OUT_TRIMMEDDIST || type == ICPMI_OUT_VARTRIMMEDDIST)
+            w *= (d2 <= (f == fused_slot ? fused_limit : st->limits[f])) ? 1.f : 0.f;
         else if (type == ICPMI_OUT_SURFACENORMAL) {
             const float4 a = read_normals[qi];
             float ax = a.x, ay = a.y, az = a.z;
@@ -1093,7 +1243,7 @@ __global__ void init_state_kernel(IcpState* st, const float* T0, unsigned seq, u
     st->hist_n = 1;
     st->sel_prefix = 0; st->sel_rank = 0; st->n_valid = 0;
     for (int f = 0; f < ICPMI_MAX_OUTLIER; ++f) st->limits[f] = -1.f;
-    st->robust_med = 0.f; st->robust_scale = 1.f;
+    st->robust_med = 0.f; st->robust_scale = 1.f; st->vt_valid = 0; st->vt_ratio = -1.f;
     st->pairs = 0; st->wsum = 0; st->hard_count = 0; st->hard_total = 0; st->ticket = 0;
     for (int i = 0; i < 24; ++i) st->dbg[i] = 0;
 }
@@ -1148,6 +1298,7 @@ LoopCfg make_loop_cfg(const icpmi_ctx* c, int fixed_iterations)
         lc.out_param[f] = cfg.outlier[f].param;
         lc.out_iparam[f] = cfg.outlier[f].iparam;
         lc.out_param2[f] = cfg.outlier[f].param2;
+        lc.out_param3[f] = cfg.outlier[f].param3;
         if (lc.out_type[f] == ICPMI_OUT_GENERICDESCRIPTOR || lc.out_type[f] == ICPMI_OUT_ROBUST) lc.ext = 1;
     }
     lc.force_4dof = cfg.force_4dof != 0 && cfg.minimizer == ICPMI_MIN_POINT_TO_PLANE;
@@ -1213,6 +1364,27 @@ static icpmi_status ensure_loop_buffers(icpmi_ctx* c, int64_t n, int k, int nsca
 }
 
 
+// scratch of the VarTrimmedDist passes (operator scratch slots 0..4, shared with the map-side operators: never live at the
+// same time on one handle); reserved before a capture starts, looked up again -- same pointers -- when the passes are enqueued
+struct VtBuffers { unsigned long long* keys; unsigned* vals; unsigned* tab; double* sums; double* best_val; long long* best_idx; int nchunks; };
+static bool chain_has_vartrimmed(const LoopCfg& lc)
+{
+    for (int f = 0; f < lc.n_out; ++f) if (lc.out_type[f] == ICPMI_OUT_VARTRIMMEDDIST) return true;
+    return false;
+}
+static icpmi_status vt_buffers(icpmi_ctx* c, int64_t count, VtBuffers* b)
+{
+    b->nchunks = (int)((count + VT_CHUNK - 1) / VT_CHUNK);
+    b->keys = scratch_get<unsigned long long>(c, 0, (size_t)2 * count + 2);
+    b->vals = scratch_get<unsigned>(c, 1, (size_t)2 * count + 2);
+    b->tab = scratch_get<unsigned>(c, 2, radix_sort_tab_words(count, 32));
+    b->sums = scratch_get<double>(c, 3, (size_t)2 * b->nchunks + 2);
+    b->best_idx = scratch_get<long long>(c, 4, (size_t)b->nchunks + 1);
+    if (!b->keys || !b->vals || !b->tab || !b->sums || !b->best_idx) return ICPMI_ERR_HIP;
+    b->best_val = b->sums + b->nchunks + 1;
+    return ICPMI_OK;
+}
+
 // index of the single quantile-type filter of the chain, or -1 (none) / -2 (more than one)
 static int fused_filter_slot(const LoopCfg& lc)
 {
@@ -1241,6 +1413,22 @@ static void enqueue_selection(icpmi_ctx* c, const LoopCfg& lc, int64_t count, bo
             MAD_PASS(0) MAD_PASS(1) MAD_PASS(2)
 #undef MAD_PASS
         }
+    }
+    for (int f = 0; f < lc.n_out; ++f) {
+        if (lc.out_type[f] != ICPMI_OUT_VARTRIMMEDDIST) continue;
+        VtBuffers vb;
+        if (vt_buffers(c, count, &vb) != ICPMI_OK) return; // reserved by the caller: cannot fail here
+        const long long min_el = (long long)floorf(lc.out_param[f] * (float)count), max_el = (long long)floorf(lc.out_param2[f] * (float)count);
+        hipLaunchKernelGGL(vt_keys_kernel, dim3((int)((count + 255) / 256)), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, vb.keys, vb.vals);
+        int half = 0;
+        if (radix_sort_pairs(c, vb.keys, vb.vals, count, 32, vb.tab, &half) != ICPMI_OK) return;
+        const unsigned long long* sorted = vb.keys + (half ? count : 0);
+        hipLaunchKernelGGL(vt_chunk_sums_kernel, dim3(vb.nchunks), dim3(256), 0, c->stream, sorted, c->d_state, vb.sums);
+        hipLaunchKernelGGL(vt_chunk_offsets_kernel, dim3(1), dim3(256), 0, c->stream, vb.sums, vb.nchunks);
+        hipLaunchKernelGGL(vt_frms_kernel, dim3(vb.nchunks), dim3(256), 0, c->stream, sorted, count, c->d_state, (const double*)vb.sums, min_el, max_el,
+                           lc.out_param3[f], vb.best_val, vb.best_idx);
+        hipLaunchKernelGGL(vt_pick_kernel, dim3(1), dim3(256), 0, c->stream, sorted, count, c->d_state, (const double*)vb.best_val,
+                           (const long long*)vb.best_idx, vb.nchunks, min_el, f);
     }
     if (slot >= 0) {
         // fused chain: hist0 -> [scan0 + hist1] -> [scan1 + hist2]; scan2 happens inside the accumulation kernel
@@ -1346,7 +1534,7 @@ static void fill_stats(icpmi_ctx* c, const LoopCfg& lc, int64_t n, icpmi_stats* 
     stats->weighted_point_used_ratio = denom > 0 ? (float)(hs->wsum / denom) : 0.f;
     stats->trimmed_limit = -1.f;
     for (int f = 0; f < lc.n_out; ++f)
-        if (lc.out_type[f] == ICPMI_OUT_TRIMMEDDIST || lc.out_type[f] == ICPMI_OUT_MEDIANDIST) stats->trimmed_limit = hs->limits[f];
+        if (lc.out_type[f] == ICPMI_OUT_TRIMMEDDIST || lc.out_type[f] == ICPMI_OUT_MEDIANDIST || lc.out_type[f] == ICPMI_OUT_VARTRIMMEDDIST) stats->trimmed_limit = hs->limits[f];
     stats->hard_queries = (int64_t)hs->hard_total;
     for (int i = 0; i < 3; ++i) { stats->reserved[2 * i] = (int32_t)(hs->dbg[i] & 0xffffffffu); stats->reserved[2 * i + 1] = (int32_t)(hs->dbg[i] >> 32); }
 }
@@ -1382,6 +1570,7 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
     LoopCfg lc = lc_in;
     // all allocations up front: none may happen while the stream is capturing
     if (ensure_loop_buffers(c, n, lc.k) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (chain_has_vartrimmed(lc)) { VtBuffers vb; if (vt_buffers(c, n * lc.k, &vb) != ICPMI_OK) return ICPMI_ERR_HIP; }
     if (ensure_cap(c, &c->d_reading, &c->cap_reading, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
     if (d_normals3 && ensure_cap(c, &c->d_read_normals, &c->cap_read_normals, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
     if (c->cfg.knn <= 8 && sort_queries_reserve(c, n) != ICPMI_OK) return ICPMI_ERR_HIP;
@@ -1402,7 +1591,8 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
         sig = fnv(&lc, sizeof lc, sig);
         const void* ptrs[] = {d_scan, d_normals3, c->d_qkeys, c->d_qtile,c->d_reading, c->d_read_normals, c->d_sidx, c->d_d2, c->d_hard, c->d_partials, c->d_state, c->d_match_pt,
                               c->d_qsorted, c->d_qindex,
-                              c->d_map_sorted, c->d_normals_sorted, c->d_cell_start, c->d_selhist};
+                              c->d_map_sorted, c->d_normals_sorted, c->d_cell_start, c->d_selhist,
+                              c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3], c->scratch[4]}; // (VarTrimmedDist passes)
         sig = fnv(ptrs, sizeof ptrs, sig);
         sig = fnv(&c->grid, sizeof c->grid, sig);
         if (!c->graph_exec || c->graph_n != n || c->graph_iters != lc.max_iter || c->graph_sig != sig) {
@@ -1745,7 +1935,7 @@ icpmi_status loop_outlier_weights(icpmi_ctx* c, const LoopCfg& lc, const float* 
     if (limit_out) {
         *limit_out = -1.f;
         for (int f = 0; f < l1.n_out; ++f)
-            if (l1.out_type[f] == ICPMI_OUT_TRIMMEDDIST || l1.out_type[f] == ICPMI_OUT_MEDIANDIST) *limit_out = c->h_state->limits[f];
+            if (l1.out_type[f] == ICPMI_OUT_TRIMMEDDIST || l1.out_type[f] == ICPMI_OUT_MEDIANDIST || l1.out_type[f] == ICPMI_OUT_VARTRIMMEDDIST) *limit_out = c->h_state->limits[f];
             else if (l1.out_type[f] == ICPMI_OUT_ROBUST && ((l1.out_iparam[f] >> 4) & 15) == ICPMI_SCALE_MAD) *limit_out = c->h_state->robust_scale;
     }
     return ICPMI_OK;

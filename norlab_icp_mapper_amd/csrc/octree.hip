@@ -247,6 +247,37 @@ __global__ __launch_bounds__(256) void oct_best_kernel(const unsigned long long*
 // Leaves of the octree over the n points of d_in, one representative each: d_order[0 .. *n_out) = their original indices in
 // leaf-visiting order (device array of at least n ints); d_leaf_of (may be null) = leaf ordinal of every input point.
 // Uses operator scratch slots 0-4; stream-ordered on c->stream except for two small read-backs (depth, leaf count).
+// Stable LSD radix sort of (u64 key, u32 value) pairs on the low `bits` bits of the key, 6 bits per pass.  d_keys2 / d_vals2
+// hold 2 n elements (two ping-pong halves, the input in the first); d_tab holds radix_sort_tab_words(n, bits) words.
+// *result_half tells which half holds the sorted pairs.  Everything is enqueued on c->stream, nothing is read back.
+size_t radix_sort_tab_words(int64_t n, int bits)
+{
+    const int nwg = (int)((n + RS_EPB - 1) / RS_EPB);
+    return ((size_t)RS_BINS * nwg + RS_BINS) * (size_t)((bits + RS_BITS - 1) / RS_BITS) + 16;
+}
+
+icpmi_status radix_sort_pairs(icpmi_ctx* c, unsigned long long* d_keys2, unsigned* d_vals2, int64_t n, int bits, unsigned* d_tab, int* result_half)
+{
+    const int nwg = (int)((n + RS_EPB - 1) / RS_EPB);
+    const size_t tab = (size_t)RS_BINS * nwg + RS_BINS;
+    const int passes = (bits + RS_BITS - 1) / RS_BITS;
+    unsigned long long* kb[2] = {d_keys2, d_keys2 + n};
+    unsigned* vb[2] = {d_vals2, d_vals2 + n};
+    if (passes > 0) HIP_TRY(c, hipMemsetAsync(d_tab, 0, tab * passes * sizeof(unsigned), c->stream));
+    int cur = 0;
+    for (int ps = 0; ps < passes; ++ps) {
+        unsigned* count = d_tab + tab * ps;
+        unsigned* total = count + (size_t)RS_BINS * nwg;
+        hipLaunchKernelGGL(rs_hist_kernel, dim3(nwg), dim3(256), 0, c->stream, (const unsigned long long*)kb[cur], n, ps * RS_BITS, nwg, count, total);
+        hipLaunchKernelGGL(rs_scatter_kernel, dim3(nwg), dim3(256), 0, c->stream, (const unsigned long long*)kb[cur], (const unsigned*)vb[cur], n,
+                           ps * RS_BITS, nwg, (const unsigned*)count, (const unsigned*)total, kb[cur ^ 1], vb[cur ^ 1]);
+        cur ^= 1;
+    }
+    HIP_TRY(c, hipGetLastError());
+    *result_half = cur;
+    return ICPMI_OK;
+}
+
 icpmi_status octree_sample_dev(icpmi_ctx* c, const float4* d_in, int64_t n, float max_size, int max_pts, int method, int* d_order, int* d_leaf_of,
                                int64_t* n_out)
 {
@@ -274,18 +305,12 @@ icpmi_status octree_sample_dev(icpmi_ctx* c, const float4* d_in, int64_t n, floa
     OctRoot root;
     if (read_back(c, &root, d_root, sizeof root) != ICPMI_OK) return ICPMI_ERR_HIP;
     const int bits = 3 * root.depth;
-    const int passes = (bits + RS_BITS - 1) / RS_BITS;
     unsigned long long* kb[2] = {d_keys, d_keys + n};
     unsigned* vb[2] = {d_vals, d_vals + n};
-    if (passes > 0) HIP_TRY(c, hipMemsetAsync(d_tab, 0, tab * passes * sizeof(unsigned), c->stream));
     int cur = 0;
-    for (int ps = 0; ps < passes; ++ps) {
-        unsigned* count = d_tab + tab * ps;
-        unsigned* total = count + (size_t)RS_BINS * nwg;
-        hipLaunchKernelGGL(rs_hist_kernel, dim3(nwg), dim3(256), 0, c->stream, (const unsigned long long*)kb[cur], n, ps * RS_BITS, nwg, count, total);
-        hipLaunchKernelGGL(rs_scatter_kernel, dim3(nwg), dim3(256), 0, c->stream, (const unsigned long long*)kb[cur], (const unsigned*)vb[cur], n,
-                           ps * RS_BITS, nwg, (const unsigned*)count, (const unsigned*)total, kb[cur ^ 1], vb[cur ^ 1]);
-        cur ^= 1;
+    {
+        const icpmi_status ss = radix_sort_pairs(c, d_keys, d_vals, n, bits, d_tab, &cur);
+        if (ss != ICPMI_OK) return ss;
     }
     unsigned* d_ord = d_flag + n + 2; // exclusive scan of the leaf-start flags
     hipLaunchKernelGGL(oct_leaf_kernel, dim3(blocks), dim3(256), 0, c->stream, (const unsigned long long*)kb[cur], n, (const OctRoot*)d_root, max_pts,

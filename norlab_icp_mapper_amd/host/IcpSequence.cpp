@@ -121,6 +121,15 @@ void GpuICPSequence::loadFromYamlNode(const yaml::Node& icp)
             else if (e.first == "MinDistOutlierFilter") { o.type = ICPMI_OUT_MINDIST; o.param = param("minDist", 1.f); }
             else if (e.first == "MedianDistOutlierFilter") { o.type = ICPMI_OUT_MEDIANDIST; o.param = param("factor", 3.f); }
             else if (e.first == "SurfaceNormalOutlierFilter") { o.type = ICPMI_OUT_SURFACENORMAL; o.param = param("maxAngle", 1.57f); }
+            else if (e.first == "VarTrimmedDistOutlierFilter") {
+                // defaults of upstream's registrar: minRatio 0.05, maxRatio 0.99, lambda 0.95
+                const yaml::Node& p = e.second;
+                requireKnown(p, {"minRatio", "maxRatio", "lambda"}, e.first);
+                o.type = ICPMI_OUT_VARTRIMMEDDIST;
+                o.param = p["minRatio"] ? p["minRatio"].as<float>() : 0.05f;
+                o.param2 = p["maxRatio"] ? p["maxRatio"].as<float>() : 0.99f;
+                o.param3 = p["lambda"] ? p["lambda"].as<float>() : 0.95f;
+            }
             else if (e.first == "GenericDescriptorOutlierFilter") {
                 // defaults of upstream's registrar: source reference, descName none, useSoftThreshold 0, useLargerThan 1, threshold 0.1
                 const yaml::Node& p = e.second;

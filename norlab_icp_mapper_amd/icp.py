@@ -97,6 +97,7 @@ def default_config(**kw):
             cfg.outlier[i].param = o[1]
             cfg.outlier[i].iparam = o[2] if len(o) > 2 else 0
             cfg.outlier[i].param2 = o[3] if len(o) > 3 else 0.0
+            cfg.outlier[i].param3 = o[4] if len(o) > 4 else 0.0
     return cfg
 
 
@@ -150,6 +151,13 @@ def config_from_yaml_chain(chain, **engine):
             kw["generic_desc_name"] = str(p.get("descName", "none"))
             flags = (_capi.GEN_SOFT if int(p.get("useSoftThreshold", 0)) else 0) | (_capi.GEN_LARGER if int(p.get("useLargerThan", 1)) else 0)
             outs.append((_capi.OUT_GENERICDESCRIPTOR, float(p.get("threshold", 0.1)), flags, 0.0))
+            continue
+        if name == "VarTrimmedDistOutlierFilter":
+            # upstream defaults: minRatio 0.05, maxRatio 0.99, lambda 0.95
+            for key in p:
+                if key not in ("minRatio", "maxRatio", "lambda"):
+                    raise InvalidParameter(f"{name}: unknown parameter {key}")
+            outs.append((_capi.OUT_VARTRIMMEDDIST, float(p.get("minRatio", 0.05)), 0, float(p.get("maxRatio", 0.99)), float(p.get("lambda", 0.95))))
             continue
         if name == "RobustOutlierFilter":
             # upstream defaults: robustFct cauchy, tuning 1, scaleEstimator mad, nbIterationForScale 0, distanceType point2point

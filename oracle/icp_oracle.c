@@ -302,6 +302,38 @@ float orc_dists_quantile(const float* d2, int64_t count, float quantile)
     return r;
 }
 
+/* VarTrimmedDistOutlierFilter::optimizeInlierRatio [UPSTREAM OutlierFiltersImpl.cpp; Phillips et al. 2007, FRMSD]: the valid
+ * squared distances sorted ascending, their running sum, and over the ranks minEl = floor(minRatio N) .. maxEl = floor(maxRatio N)
+ * (N = ALL entries, valid or not -- upstream's points_nbr) the minimiser of
+ *     FRMS(i) = (sum of the i + 1 smallest) / ((i + 1) ((i + 1) / N)^(2 lambda));          optRatio = i_min / N  (float)
+ * Restated deviations: the running sum and FRMS are formed in double (upstream: float partial_sum and Eigen float arrays, whose
+ * rounding no other summation order reproduces); ranks at or beyond the number of valid entries -- where upstream's Eigen::Map
+ * reads the unwritten tail of a reserved vector -- are not candidates; no candidate at all => optRatio = minEl / N. */
+static int orc_cmp_float(const void* a, const void* b) { const float x = *(const float*)a, y = *(const float*)b; return x < y ? -1 : (x > y ? 1 : 0); }
+float orc_var_trimmed_ratio(const float* d2, int64_t count, float min_ratio, float max_ratio, float lambda)
+{
+    float* vals = (float*)malloc((size_t)(count > 0 ? count : 1) * sizeof(float));
+    int64_t V = 0;
+    for (int64_t i = 0; i < count; ++i)
+        if (d2[i] != INFINITY && d2[i] > 0.f) vals[V++] = d2[i];
+    if (V == 0) { free(vals); return -1.f; }
+    qsort(vals, (size_t)V, sizeof(float), orc_cmp_float);
+    const int64_t min_el = (int64_t)floorf(min_ratio * (float)count), max_el = (int64_t)floorf(max_ratio * (float)count);
+    const int64_t hi = max_el < V ? max_el : V;
+    double cum = 0.0, best = 0.0;
+    int64_t best_i = -1;
+    for (int64_t i = 0; i < hi; ++i) {
+        cum += (double)vals[i];
+        if (i < min_el) continue;
+        const double ids = (double)(i + 1), ratio = ids / (double)count;
+        const double frms = cum / (ids * pow(ratio, 2.0 * (double)lambda));
+        if (best_i < 0 || frms < best) { best = frms; best_i = i; }
+    }
+    free(vals);
+    if (best_i < 0) best_i = min_el;
+    return (float)best_i / (float)count;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * OutlierFilters::compute. Empty chain => all ones; filters multiply.
  * ---------------------------------------------------------------------------------------------- */
@@ -351,6 +383,14 @@ int orc_outlier_weights_ex(const orc_config* cfg, const float* d2, const int32_t
                 lim = orc_dists_quantile(d2, cnt, prm);
                 if (lim < 0.f) return ORC_ERR_NO_OUTLIER_TO_FILTER;
             }
+            if (limit_out) *limit_out = lim;
+            for (int64_t i = 0; i < cnt; ++i) weights[i] *= (d2[i] <= lim) ? 1.f : 0.f;
+        } else if (type == ORC_OUT_VARTRIMMEDDIST) {
+            /* VarTrimmedDistOutlierFilter{minRatio, maxRatio, lambda}: TrimmedDist at the ratio optimizeInlierRatio picks */
+            const float ratio = orc_var_trimmed_ratio(d2, cnt, prm, cfg->outlier[f].param2, cfg->outlier[f].param3);
+            if (ratio < 0.f) return ORC_ERR_NO_OUTLIER_TO_FILTER;
+            const float lim = orc_dists_quantile(d2, cnt, ratio);
+            if (lim < 0.f) return ORC_ERR_NO_OUTLIER_TO_FILTER;
             if (limit_out) *limit_out = lim;
             for (int64_t i = 0; i < cnt; ++i) weights[i] *= (d2[i] <= lim) ? 1.f : 0.f;
         } else if (type == ORC_OUT_SURFACENORMAL) {

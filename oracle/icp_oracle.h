@@ -44,7 +44,7 @@ extern "C" {
 /* ---- configuration: mirrors include/icpmi.h (kept textually independent) ---- */
 enum { ORC_MIN_IDENTITY = 0, ORC_MIN_POINT_TO_POINT = 1, ORC_MIN_POINT_TO_PLANE = 2 };
 enum { ORC_OUT_MAXDIST = 1, ORC_OUT_MINDIST = 2, ORC_OUT_MEDIANDIST = 3, ORC_OUT_TRIMMEDDIST = 4,
-       ORC_OUT_SURFACENORMAL = 5, ORC_OUT_GENERICDESCRIPTOR = 6, ORC_OUT_ROBUST = 7 };
+       ORC_OUT_SURFACENORMAL = 5, ORC_OUT_GENERICDESCRIPTOR = 6, ORC_OUT_ROBUST = 7, ORC_OUT_VARTRIMMEDDIST = 8 };
 /* GenericDescriptorOutlierFilter iparam bits; RobustOutlierFilter iparam = fct | scale << 4 | distance << 8 */
 enum { ORC_GEN_SOURCE_READING = 1, ORC_GEN_SOFT = 2, ORC_GEN_LARGER = 4 };
 enum { ORC_ROB_CAUCHY = 0, ORC_ROB_WELSCH = 1, ORC_ROB_SC = 2, ORC_ROB_GM = 3, ORC_ROB_TUKEY = 4, ORC_ROB_HUBER = 5, ORC_ROB_L1 = 6, ORC_ROB_STUDENT = 7 };
@@ -58,7 +58,8 @@ typedef struct {
     int   type;
     float param;
     int   iparam;            /* flags / enums of GenericDescriptor and Robust                 */
-    float param2;            /* Robust: nbIterationForScale                                   */
+    float param2;            /* Robust: nbIterationForScale; VarTrimmedDist: maxRatio          */
+    float param3;            /* VarTrimmedDist: lambda                                         */
 } orc_outlier;
 
 typedef struct {
@@ -113,6 +114,8 @@ void orc_bruteforce_knn(const float* pts4, int64_t m, int dim, const float* q4, 
 
 /* Matches::getDistsQuantile: quantile over finite, >0 entries. returns <0 if none */
 float orc_dists_quantile(const float* d2, int64_t count, float quantile);
+/* VarTrimmedDistOutlierFilter::optimizeInlierRatio; < 0: no valid match */
+float orc_var_trimmed_ratio(const float* d2, int64_t count, float min_ratio, float max_ratio, float lambda);
 
 /* OutlierFilters::compute for the configured chain. ref_normals/read_normals (3 x .) may be NULL
  * unless a SurfaceNormal filter is configured. weights is k x n. */

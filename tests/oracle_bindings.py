@@ -11,12 +11,12 @@ _LIB = os.path.join(_ROOT, "oracle", "liboracle.so")
 
 MIN_IDENTITY, MIN_POINT_TO_POINT, MIN_POINT_TO_PLANE = 0, 1, 2
 OUT_MAXDIST, OUT_MINDIST, OUT_MEDIANDIST, OUT_TRIMMEDDIST, OUT_SURFACENORMAL = 1, 2, 3, 4, 5
-OUT_GENERICDESCRIPTOR, OUT_ROBUST = 6, 7
+OUT_GENERICDESCRIPTOR, OUT_ROBUST, OUT_VARTRIMMEDDIST = 6, 7, 8
 STOP_COUNTER, STOP_DIFFERENTIAL = 1, 2
 
 
 class Outlier(C.Structure):
-    _fields_ = [("type", C.c_int), ("param", C.c_float), ("iparam", C.c_int), ("param2", C.c_float)]
+    _fields_ = [("type", C.c_int), ("param", C.c_float), ("iparam", C.c_int), ("param2", C.c_float), ("param3", C.c_float)]
 
 
 class Config(C.Structure):
@@ -60,6 +60,8 @@ def load():
     lib.orc_outlier_weights.argtypes = [C.POINTER(Config), _P, _P, C.c_int, C.c_int64, _P, _P, _P, C.POINTER(C.c_float)]
     lib.orc_outlier_weights_ex.argtypes = [C.POINTER(Config), _P, _P, C.c_int, C.c_int64, _P, _P, _P, _P, _P, C.c_int, C.POINTER(C.c_float),
                                            _P, C.POINTER(C.c_float)]
+    lib.orc_var_trimmed_ratio.argtypes = [_P, C.c_int64, C.c_float, C.c_float, C.c_float]
+    lib.orc_var_trimmed_ratio.restype = C.c_float
     lib.orc_icp_set_map_scalar.argtypes = [_P, _P]
     lib.orc_icp_set_map_scalar.restype = None
     lib.orc_solve_n.argtypes = [C.c_int, _P, _P, _P]
@@ -106,6 +108,7 @@ def make_config(knn=1, max_dist=math.inf, minimizer=MIN_POINT_TO_PLANE, outliers
         cfg.outlier[i].type, cfg.outlier[i].param = o[0], o[1]
         cfg.outlier[i].iparam = o[2] if len(o) > 2 else 0
         cfg.outlier[i].param2 = o[3] if len(o) > 3 else 0.0
+        cfg.outlier[i].param3 = o[4] if len(o) > 4 else 0.0
     cfg.max_iterations, cfg.use_differential = max_iterations, use_differential
     cfg.min_diff_rot, cfg.min_diff_trans, cfg.smooth_length = min_diff_rot, min_diff_trans, smooth_length
     cfg.use_bound, cfg.max_rot_norm, cfg.max_trans_norm = use_bound, max_rot_norm, max_trans_norm
@@ -154,6 +157,11 @@ def knn(cloud, queries, k=1, max_dist=math.inf, allow_self=True, bucket=8, nthre
 def dists_quantile(d2, q):
     lib = load(); d2 = _f32(d2).ravel()
     return float(lib.orc_dists_quantile(d2.ctypes.data, d2.size, q))
+
+
+def var_trimmed_ratio(d2, min_ratio=0.05, max_ratio=0.99, lam=0.95):
+    lib = load(); d2 = _f32(d2).ravel()
+    return float(lib.orc_var_trimmed_ratio(d2.ctypes.data, d2.size, min_ratio, max_ratio, lam))
 
 
 def outlier_weights(cfg, d2, ids, read_normals=None, ref_normals=None, ref_scalar=None, step=None, ref=None, iteration=1, scale=1.0):

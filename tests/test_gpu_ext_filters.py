@@ -93,6 +93,40 @@ def test_robust_weights_exact(amd, oracle, small_scene, fct, scale):
     assert np.all(w[~fin] == 0)
 
 
+VT = 8
+
+
+@pytest.mark.parametrize("params", [(0.05, 0.99, 0.95), (0.3, 0.6, 0.95), (0.05, 0.99, 2.5), (0.7, 0.99, 0.2)])
+@pytest.mark.parametrize("k,max_dist", [(1, 2.0), (3, 0.6)])
+def test_var_trimmed_weights_exact(amd, oracle, small_scene, params, k, max_dist):
+    sc = small_scene
+    chain = [(VT, params[0], 0, params[1], params[2])]
+    icp = amd.ICPSequence(minimizer=1, max_dist=2.0, outliers=chain)
+    icp.setMap(sc["map"])
+    mean = icp.getMapMean()
+    # a reading with outliers: a fifth of the points pushed off the surfaces
+    q = centred(sc["scan"], mean)
+    q[::5, :3] += np.random.default_rng(8).normal(0, 0.4, (q[::5].shape[0], 3)).astype(np.float32)
+    ids, d2 = icp.knn(q, k=k, max_dist=max_dist)
+    w, lim = icp.outlierWeights(d2, ids)
+    err, rw, rlim = oracle.outlier_weights(oracle.make_config(outliers=chain), d2, ids)
+    assert err == 0
+    assert lim == rlim, (lim, rlim, oracle.var_trimmed_ratio(d2, *params))
+    assert np.array_equal(w, rw)
+    assert 0 < np.count_nonzero(w) < w.size
+
+
+def test_var_trimmed_no_valid_match_raises(amd, small_scene):
+    sc = small_scene
+    icp = amd.ICPSequence(minimizer=1, max_dist=2.0, outliers=[(VT, 0.05, 0, 0.99, 0.95)])
+    icp.setMap(sc["map"])
+    far = sc["scan"].copy(); far[:, :3] += 500.0
+    with pytest.raises(amd.ConvergenceError):
+        icp(far)
+    with pytest.raises(Exception):
+        amd.ICPSequence(minimizer=1, outliers=[(VT, 0.9, 0, 0.5, 0.95)])  # minRatio > maxRatio
+
+
 CHAINS = {
     "p2plane_cauchy_mad": dict(minimizer=2, max_dist=2.0, outliers=[rob("cauchy", 1.0, "mad")], max_iterations=25, use_differential=1),
     "p2plane_huber_mad_nb3_plane": dict(minimizer=2, max_dist=2.0, outliers=[rob("huber", 1.5, "mad", 3, "point2plane")], max_iterations=12),
@@ -100,6 +134,8 @@ CHAINS = {
     "p2plane_tukey_plane": dict(minimizer=2, max_dist=1.0, outliers=[rob("tukey", 0.5, "none", 0, "point2plane")], max_iterations=12),
     "p2plane_generic_trim": dict(minimizer=2, max_dist=2.0, outliers=[(GEN, 0.25, LARGER, 0.0), (4, 0.85)], max_iterations=20, use_differential=1),
     "p2plane_generic_soft": dict(minimizer=2, max_dist=2.0, outliers=[(GEN, 0.0, SOFT, 0.0)], max_iterations=10),
+    "p2plane_vartrimmed": dict(minimizer=2, max_dist=2.0, outliers=[(VT, 0.05, 0, 0.99, 0.95)], max_iterations=25, use_differential=1),
+    "p2p_vartrimmed_knn3_maxdist": dict(minimizer=1, knn=3, max_dist=1.0, outliers=[(1, 0.8), (VT, 0.2, 0, 0.9, 1.5)], max_iterations=8),
     "p2plane_4dof": dict(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=30, use_differential=1, force_4dof=1),
 }
 
@@ -127,14 +163,17 @@ def test_registration_matches_oracle(amd, oracle, mid_scene, name):
     dt, dr = amd.synth.pose_error(T, T_ref)
     assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (dt, dr)
     assert abs(icp.errorMinimizer.getOverlap() - oicp.stats.weighted_point_used_ratio) < 2e-6
-    if name == "p2plane_4dof":
-        # yaw + translation only: the z axis stays the z axis in every step, hence in the product
-        assert np.allclose(T[2, :3], [0, 0, 1], atol=1e-6) and np.allclose(T[:3, 2], [0, 0, 1], atol=1e-6)
+    if "vartrimmed" in name:
+        assert icp.stats.trimmed_limit == oicp.stats.trimmed_limit
+    if name in ("p2plane_4dof", "p2plane_vartrimmed"):
         # fixed launch sequence (hipGraph) == checked loop
         import torch
         d = torch.from_numpy(np.ascontiguousarray(sc["scan"], dtype=np.float32)).cuda()
         its = icp.stats.iterations
         assert np.array_equal(icp.registerDev(d.data_ptr(), d.shape[0], fixed_iterations=its), T)
+    if name == "p2plane_4dof":
+        # yaw + translation only: the z axis stays the z axis in every step, hence in the product
+        assert np.allclose(T[2, :3], [0, 0, 1], atol=1e-6) and np.allclose(T[:3, 2], [0, 0, 1], atol=1e-6)
 
 
 def test_force_4dof_single_step_matches_oracle(amd, oracle, small_scene):

@@ -42,7 +42,7 @@ def test_config_defaults_and_struct_layout():
     assert cfg.min_diff_rot == pytest.approx(1e-3) and cfg.smooth_length == 3 and cfg.use_graph == 1
     # the ctypes mirrors must have the C layout: 8-byte aligned int64 members, trailing reserved block
     assert C.sizeof(_capi.Stats) == 72
-    assert C.sizeof(_capi.Config) == 5 * 4 + 8 * 16 + 13 * 4 + 8 * 4
+    assert C.sizeof(_capi.Config) == 5 * 4 + 8 * 20 + 13 * 4 + 8 * 4
     assert cfg.force_4dof == 0
 
 
@@ -150,9 +150,11 @@ inspector: NullInspector
         "outlierFilters": [{"RobustOutlierFilter": {"robustFct": "huber", "tuning": 1.5, "scaleEstimator": "mad", "nbIterationForScale": 4,
                                                     "distanceType": "point2plane"}},
                            {"GenericDescriptorOutlierFilter": {"descName": "probabilityDynamic", "useLargerThan": 0, "threshold": 0.6}},
-                           "RobustOutlierFilter"],
+                           "RobustOutlierFilter", {"VarTrimmedDistOutlierFilter": {"minRatio": 0.1, "lambda": 2.0}}],
         "errorMinimizer": {"PointToPlaneErrorMinimizer": {"force4DOF": 1}}})
-    assert cfg.force_4dof == 1 and cfg.n_outlier == 3
+    assert cfg.force_4dof == 1 and cfg.n_outlier == 4
+    assert (cfg.outlier[3].type, cfg.outlier[3].param3) == (_capi.OUT_VARTRIMMEDDIST, 2.0)
+    assert cfg.outlier[3].param == pytest.approx(0.1) and cfg.outlier[3].param2 == pytest.approx(0.99)
     o = cfg.outlier
     assert (o[0].type, o[0].param, o[0].iparam, o[0].param2) == (_capi.OUT_ROBUST, 1.5, 5 | (1 << 4) | (1 << 8), 4.0)
     assert (o[1].type, o[1].iparam) == (_capi.OUT_GENERICDESCRIPTOR, 0) and o[1].param == pytest.approx(0.6)

@@ -158,3 +158,39 @@ def test_oracle_normals_are_smallest_eigenvectors_everywhere(oracle):
     ids, _ = oracle.knn(pts, pts, k=10, nthreads=4)
     ok = oracle.check_normals_are_smallest_eigenvectors(pts, ids, rn, "oracle")
     assert ok.mean() > 0.999
+
+
+def test_var_trimmed_ratio_known_answers(oracle):
+    """optimizeInlierRatio against a direct numpy evaluation of FRMS over the candidate ranks"""
+    rng = np.random.default_rng(21)
+    def ref(d2, lo, hi, lam):
+        N = d2.size
+        v = np.sort(d2[np.isfinite(d2) & (d2 > 0)].astype(np.float64))
+        cum = np.cumsum(v)
+        a, b = int(math.floor(np.float32(lo) * np.float32(N))), min(int(math.floor(np.float32(hi) * np.float32(N))), v.size)
+        if b <= a:
+            return np.float32(a) / np.float32(N)
+        i = np.arange(a, b)
+        frms = cum[a:b] / ((i + 1) * ((i + 1) / N) ** (2 * lam))
+        return np.float32(a + int(np.argmin(frms))) / np.float32(N)
+    # inliers ~ small residuals, 30 % outliers far away: with lambda above 1 the FRMS minimum sits at the inlier fraction (the
+    # mean of the smallest fraction f of Gaussian squared residuals grows like f^2, so lambda <= 1 favours the smallest f)
+    d2 = np.concatenate([rng.normal(0, 0.02, 7000) ** 2, rng.uniform(0.5, 4.0, 3000)]).astype(np.float32)
+    rng.shuffle(d2)
+    r = oracle.var_trimmed_ratio(d2, 0.05, 0.99, 0.95)
+    assert r == ref(d2, 0.05, 0.99, 0.95)
+    r13 = oracle.var_trimmed_ratio(d2, 0.05, 0.99, 1.3)
+    assert r13 == ref(d2, 0.05, 0.99, 1.3) and 0.4 < r13 <= 0.7001      # never past the inlier fraction
+    r3 = oracle.var_trimmed_ratio(d2, 0.05, 0.99, 3.0)
+    assert r3 == ref(d2, 0.05, 0.99, 3.0) and 0.69 < r3 <= 0.7001
+    # unmatched entries count in N but are no candidates; all-invalid -> -1
+    d2b = d2.copy(); d2b[::5] = np.inf; d2b[1::50] = 0.0
+    assert oracle.var_trimmed_ratio(d2b, 0.05, 0.99, 0.95) == ref(d2b, 0.05, 0.99, 0.95)
+    assert oracle.var_trimmed_ratio(np.full(10, np.inf, np.float32)) < 0
+    for lo, hi, lam in ((0.3, 0.5, 0.95), (0.9, 0.99, 0.1), (0.05, 0.99, 3.0), (0.999, 0.9995, 1.0)):
+        assert oracle.var_trimmed_ratio(d2b, lo, hi, lam) == ref(d2b, lo, hi, lam), (lo, hi, lam)
+    # the filter = TrimmedDist at that ratio
+    ids = np.zeros((d2.size, 1), dtype=np.int32)
+    err, w, lim = oracle.outlier_weights(oracle.make_config(outliers=[(8, 0.05, 0, 0.99, 0.95)]), d2.reshape(-1, 1), ids)
+    assert err == 0 and lim == oracle.dists_quantile(d2, r)
+    np.testing.assert_array_equal(w[:, 0], (d2 <= lim).astype(np.float32))
