@@ -61,8 +61,12 @@ __global__ __launch_bounds__(256) void keep_kernel(const float* __restrict__ d2,
 __global__ __launch_bounds__(128) void normals_kernel(const float4* __restrict__ map, const int* __restrict__ sidx, int64_t m, int k,
                                                       float* __restrict__ normals3, float* __restrict__ densities)
 {
-    const int64_t i = (int64_t)blockIdx.x * 128 + threadIdx.x;
-    if (i >= m) return;
+    // lane <-> point in CELL-SORTED order (its original index rides in .w): the ten neighbours of adjacent lanes are then
+    // adjacent in `map` -- gathers that hit the same lines -- whatever order the caller's cloud is in (an append-ordered map
+    // made them ten random 64-byte sectors per point: 213 us for 0.64 M points, against 108 us for 0.92 M octree-ordered ones)
+    const int64_t si = (int64_t)blockIdx.x * 128 + threadIdx.x;
+    if (si >= m) return;
+    const int64_t i = (int64_t)__float_as_uint(map[si].w);
     double mean[3] = {0, 0, 0};
     int real = 0;
     for (int j = 0; j < k; ++j) {
@@ -479,7 +483,10 @@ static icpmi_status make_temp(icpmi_ctx* c, TempCtx& t)
 namespace { icpmi_status chain_point_distance_flags(icpmi_ctx* c, icpmi_ctx* ic, const float4* d_scan, int64_t n, float min_dist, unsigned* d_flag); }
 
 // the index PointDistanceMapperModule searches: the resident map in its own frame (common.h: temp_raw)
-static icpmi_status raw_index(icpmi_ctx* c, icpmi_ctx** out)
+// `reach`: the radius the caller will search with (minDistNewPoint): the pyramid of this index only needs the levels whose
+// blocks reach that far -- level 0 alone for the usual 0.1 m against ~0.5 m cells, instead of the three levels the
+// registration radius asks for
+static icpmi_status raw_index(icpmi_ctx* c, icpmi_ctx** out, float reach)
 {
     if (!c->temp_raw) {
         icpmi_config cfg = c->cfg;
@@ -489,8 +496,12 @@ static icpmi_status raw_index(icpmi_ctx* c, icpmi_ctx** out)
     }
     icpmi_ctx* t = c->temp_raw;
     share_stream(c, t);
+    const float built_reach = t->cfg.max_dist;
     t->cfg = c->cfg; t->keep_raw = false; t->no_centre = true; t->single_level = false;
-    if (c->temp_raw_version != c->map_version || t->m != c->m_raw) {
+    const float want = reach > 1e-3f ? reach : 1e-3f;
+    const bool current = c->temp_raw_version == c->map_version && t->m == c->m_raw && t->m > 0;
+    t->cfg.max_dist = current && built_reach >= want ? built_reach : want;
+    if (!current || built_reach < want) {
         if (t->stream != c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream)); // the resident copy was produced on the caller's stream
         int32_t ok = 0;
         icpmi_status s = icpmi_set_map_dev(t, (const float*)c->d_raw, c->m_raw, nullptr, &ok);
@@ -836,7 +847,7 @@ icpmi_status ops_map_update_dev(icpmi_ctx* c, const float4* d_scan, int64_t n, c
         // PointDistanceMapperModule.cpp:33-42: exact NN of every input point in the map AS IT IS (raw_index: not the centred
         // registration index), self match excluded, keep iff d2 >= minDist^2
         icpmi_ctx* ri = nullptr;
-        s = raw_index(c, &ri);
+        s = raw_index(c, &ri, min_dist);
         if (s == ICPMI_OK) s = chain_point_distance_flags(c, ri, d_scan, n, min_dist, d_flag);
         if (s == ICPMI_OK && keep_out) {
             uint8_t* d_keep = scratch_get<uint8_t>(c, 9, (size_t)n);
@@ -1196,7 +1207,7 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
             if (!created) { s = chain_append(w, d_scan, d_scan_n3, d_scan_s, n, nullptr, nullptr, n, src_base); w.has_n = d_scan_n3 != nullptr; break; } // createMap: the scan is the map
             if (w.m == 0) { s = chain_append(w, d_scan, d_scan_n3, d_scan_s, n, nullptr, nullptr, n, src_base); break; } // no neighbour anywhere: d2 = inf
             icpmi_ctx* ic = nullptr;
-            if (w.indexed) { s = raw_index(c, &ic); if (s != ICPMI_OK) break; } // the resident map, in its own frame
+            if (w.indexed) { s = raw_index(c, &ic, op.f[0]); if (s != ICPMI_OK) break; } // the resident map, in its own frame
             else {
                 TempCtx t;
                 s = make_temp(c, t);
@@ -1204,6 +1215,7 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
                 ic = t.h;
                 if (ic->stream != c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
                 int32_t acc = 0;
+                ic->cfg.max_dist = op.f[0] > 1e-3f ? op.f[0] : 1e-3f; // the levels this radius needs (see raw_index)
                 s = icpmi_set_map_dev(ic, (const float*)c->d_raw, w.m, nullptr, &acc);
                 if (s != ICPMI_OK) { c->last_error = ic->last_error; break; }
             }
@@ -1360,7 +1372,7 @@ icpmi_status ops_staged_merge_allgather(icpmi_ctx* c, const float correction[16]
         if (local == ICPMI_OK) {
             if (c->m > 0) {
                 icpmi_ctx* ri = nullptr;
-                local = raw_index(c, &ri);
+                local = raw_index(c, &ri, min_dist);
                 if (local == ICPMI_OK) local = chain_point_distance_flags(c, ri, c->d_stage_in, n, min_dist, d_flag);
                 if (local == ICPMI_OK) local = merge_append_flagged(c, c->d_stage_in, n, d_flag, d_pos, c->d_merge_send, 0, &mine);
             } else { // no map yet: every point is new
@@ -1453,7 +1465,7 @@ icpmi_status ops_staged_keep(icpmi_ctx* c, const float correction[16], float min
     uint8_t* d_keep = scratch_get<uint8_t>(c, 9, (size_t)n);
     if (!d_flag || !d_keep) return ICPMI_ERR_HIP;
     icpmi_ctx* ri = nullptr;
-    s = raw_index(c, &ri);
+    s = raw_index(c, &ri, min_dist);
     if (s == ICPMI_OK) s = chain_point_distance_flags(c, ri, c->d_stage_in, n, min_dist, d_flag);
     if (s != ICPMI_OK) return s;
     hipLaunchKernelGGL(flag_to_keep_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, (const unsigned*)d_flag, n, d_keep);
