@@ -18,7 +18,9 @@ struct Roctx {
     {
         const char* e = getenv("ICPMI_ROCTX");
         if (!e || !atoi(e)) return;
-        for (const char* name : {"libroctx64.so.4", "libroctx64.so", "librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so"}) {
+        // rocprofv3 --marker-trace follows the SDK's marker library; the roctracer one is the fall-back for older tools
+        for (const char* name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so.1",
+                                 "libroctx64.so.4", "libroctx64.so", "/opt/rocm/lib/libroctx64.so.4"}) {
             void* lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (!lib) continue;
             push = (int (*)(const char*))dlsym(lib, "roctxRangePushA");
