@@ -340,6 +340,18 @@ void Map::adoptResidentResult(const DataPoints& input, const ResidentProgram& pr
     newLocalPointCloudAvailable = true;
 }
 
+// A chain that fails half way (out of device memory, a HIP error) has dropped the resident arrays (ops_map_update_chain): the host
+// copy is stale by every update since the last sync and cannot be refreshed any more.  Leave a CONSISTENT empty local cloud -- the
+// next scan creates the map anew, the registration index of the old map stays in the ICP object -- and let the error travel on.
+void Map::dropLocalCloudAfterFailedUpdate()
+{
+    if (icp.residentMapSize() > 0) return; // validation errors leave the device state alone
+    localPointCloud = DataPoints();
+    deviceAhead = false; residentCount = 0; residentNormals = false; residentScalar.clear();
+    localPointCloudEmpty.store(true);
+    newLocalPointCloudAvailable = true;
+}
+
 bool Map::tryResidentUpdate(const DataPoints& input, const Mat4& pose, const DataPointsFilters& postFilters)
 {
     ResidentProgram prog;
@@ -351,8 +363,10 @@ bool Map::tryResidentUpdate(const DataPoints& input, const Mat4& pose, const Dat
     int64_t prefix = 0, m = 0;
     {
         std::lock_guard<std::mutex> gi(icpMapLock);
-        icp.mapUpdateChain(&input, Mat4::identity(), prog.scalarName, input, pose, prog.ops, prog.nModules, src, prefix, m,
-                           hostDescriptorsFollow(input, prog, first));
+        try {
+            icp.mapUpdateChain(&input, Mat4::identity(), prog.scalarName, input, pose, prog.ops, prog.nModules, src, prefix, m,
+                               hostDescriptorsFollow(input, prog, first));
+        } catch (...) { dropLocalCloudAfterFailedUpdate(); throw; }
     }
     adoptResidentResult(input, prog, src, prefix, m, first);
     return true;
@@ -379,8 +393,10 @@ void Map::updateLocalPointCloudStaged(const DataPoints& inputDescriptors, const 
     int64_t prefix = 0, m = 0;
     {
         std::lock_guard<std::mutex> gi(icpMapLock);
-        icp.mapUpdateChain(nullptr, correction, prog.scalarName, inputDescriptors, pose, prog.ops, prog.nModules, src, prefix, m,
-                           hostDescriptorsFollow(inputDescriptors, prog, first));
+        try {
+            icp.mapUpdateChain(nullptr, correction, prog.scalarName, inputDescriptors, pose, prog.ops, prog.nModules, src, prefix, m,
+                               hostDescriptorsFollow(inputDescriptors, prog, first));
+        } catch (...) { dropLocalCloudAfterFailedUpdate(); throw; }
     }
     adoptResidentResult(inputDescriptors, prog, src, prefix, m, first);
 }

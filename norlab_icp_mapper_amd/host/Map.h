@@ -107,6 +107,7 @@ private:
     bool tryResidentUpdate(const DataPoints& input, const Mat4& pose, const DataPointsFilters& postFilters);
     bool residentPlan(const DataPoints& input, const DataPointsFilters& postFilters, ResidentProgram& prog) const; // lock held
     bool hostDescriptorsFollow(const DataPoints& input, const ResidentProgram& prog, bool first) const;          // lock held
+    void dropLocalCloudAfterFailedUpdate();                                                                      // lock held
     void prepareResidentScalar(const ResidentProgram& prog, bool first);                                         // lock held
     void adoptResidentResult(const DataPoints& input, const ResidentProgram& prog, const std::vector<int32_t>& src, int64_t prefix,
                              int64_t mapSize, bool first);                                                        // lock held
