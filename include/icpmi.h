@@ -110,6 +110,8 @@ typedef struct {
     /* error minimiser */
     int32_t minimizer;         /* icpmi_minimizer                                                 */
     int32_t force_4dof;        /* PointToPlaneErrorMinimizer.force4DOF: yaw + translation only     */
+    int32_t force_2d;          /* PointToPlaneErrorMinimizer.force2D on 3-D clouds: yaw + (tx, ty), */
+                               /* residual = the 2-D dot with the top two rows of the normals       */
     /* transformation checkers */
     int32_t max_iterations;    /* CounterTransformationChecker.maxIterationCount, default 40      */
     int32_t use_differential;  /* DifferentialTransformationChecker present                       */

@@ -109,6 +109,7 @@ static icpmi_status validate_config(const icpmi_config* cfg, std::string& err)
         if ((t == ICPMI_OUT_MAXDIST || t == ICPMI_OUT_MINDIST || t == ICPMI_OUT_MEDIANDIST) && !(p >= 0.f)) { err = "InvalidParameter: negative outlier filter parameter"; return ICPMI_ERR_INVALID_ARG; }
     }
     if (cfg->minimizer < ICPMI_MIN_IDENTITY || cfg->minimizer > ICPMI_MIN_POINT_TO_PLANE) { err = "InvalidParameter: unknown error minimizer"; return ICPMI_ERR_INVALID_ARG; }
+    if (cfg->force_4dof && cfg->force_2d) { err = "InvalidParameter: force2D and force4DOF exclude each other"; return ICPMI_ERR_INVALID_ARG; }
     if (cfg->max_iterations < 1) { err = "InvalidParameter: maxIterationCount must be >= 1"; return ICPMI_ERR_INVALID_ARG; }
     if (cfg->use_differential && (cfg->smooth_length < 1 || cfg->smooth_length > ICPMI_MAX_SMOOTH)) { err = "InvalidParameter: smoothLength must be in [1, 16]"; return ICPMI_ERR_INVALID_ARG; }
     if (cfg->grid_cell < 0.f) { err = "InvalidParameter: grid_cell must be >= 0"; return ICPMI_ERR_INVALID_ARG; }

@@ -89,6 +89,7 @@ struct LoopCfg {
     float out_param3[ICPMI_MAX_OUTLIER];
     int   ext;             // GenericDescriptor / Robust in the chain: the pair-sum kernel's EXT variant
     int   force_4dof;
+    int   force_2d;        // (routes the pair sums through the EXT variant: three more sums, b of the 2-D residual)
     int   max_iter;
     int   use_diff;
     float min_rot, min_trans;

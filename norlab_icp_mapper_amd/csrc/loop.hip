@@ -554,6 +554,7 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restric
 #pragma unroll
     for (int i = 0; i < (NVAL > 0 ? NVAL : 1); ++i) acc[i] = 0.0;
     double wsum = 0.0, cnt = 0.0;
+    double b2d[3] = {0.0, 0.0, 0.0}; // force2D: b of the 2-D residual (EXT variant only)
     const float* T = st->T_iter;
     auto pair = [&](int64_t e, float d2, int s, float4 r, float4 qkept, float4 nkept, bool have_n) {
         if (d2 == INFINITY) return;
@@ -603,6 +604,11 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restric
                 for (int b = a; b < 6; ++b) acc[idx++] += wf * F[b];
                 acc[21 + a] -= wf * dot;
             }
+            if (EXT && lc.force_2d) {
+                const float dot2 = dx * nn.x + dy * nn.y; // upstream drops the z row of the features and of the normals
+#pragma unroll
+                for (int a = 0; a < 3; ++a) b2d[a] -= ((double)w * F[2 + a]) * dot2;
+            }
         }
     };
 #pragma unroll
@@ -621,6 +627,7 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restric
 #pragma unroll
     for (int i = 0; i < ICPMI_NV; ++i) val[i] = i < NVAL ? acc[i < NVAL ? i : 0] : 0.0;
     val[27] = wsum; val[28] = cnt;
+    if (EXT) { val[29] = b2d[0]; val[30] = b2d[1]; val[31] = b2d[2]; }
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
         const int m = 1 << s;
@@ -642,7 +649,7 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restric
     if (threadIdx.x < ICPMI_NV) {
         const int i = threadIdx.x;
         double v = 0.0;
-        if (i < NVAL || i == 27 || i == 28) v = sh[0][i] + sh[1][i] + sh[2][i] + sh[3][i];
+        if (i < NVAL || i == 27 || i == 28 || (EXT && i > 28)) v = sh[0][i] + sh[1][i] + sh[2][i] + sh[3][i];
         partials[(size_t)blockIdx.x * ICPMI_NV + i] = v;
     }
 }
@@ -1114,7 +1121,13 @@ __device__ void solve_body(IcpState* __restrict__ st, const double* __restrict__
         for (int a = 0; a < 6; ++a)
             for (int bb = a; bb < 6; ++bb) { const float v = (float)tot[idx++]; A[6 * a + bb] = v; A[6 * bb + a] = v; }
         for (int a = 0; a < 6; ++a) b[a] = (float)tot[21 + a];
-        if (lc.force_4dof) {
+        if (lc.force_2d) {
+            // force2D: F = [x ny - y nx; nx; ny] -- rows 2..4 of the 6-DOF F --, b from the 2-D residual (tot[29..31]); x = (yaw, tx, ty)
+            float A3[9], b3[3], x3[3];
+            for (int c = 0; c < 3; ++c) { b3[c] = (float)tot[29 + c]; for (int r = 0; r < 3; ++r) A3[3 * c + r] = A[6 * (2 + c) + (2 + r)]; }
+            solve_spd<3>(A3, b3, x3);
+            x[0] = 0.f; x[1] = 0.f; x[2] = x3[0]; x[3] = x3[1]; x[4] = x3[2]; x[5] = 0.f;
+        } else if (lc.force_4dof) {
             // force4DOF: F = [cross_z; n] -- the {2,3,4,5} sub-system of the 6-DOF sums; x = (yaw, t)
             float A4[16], b4[4], x4[4];
             for (int c = 0; c < 4; ++c) { b4[c] = b[2 + c]; for (int r = 0; r < 4; ++r) A4[4 * c + r] = A[6 * (2 + c) + (2 + r)]; }
@@ -1302,6 +1315,8 @@ LoopCfg make_loop_cfg(const icpmi_ctx* c, int fixed_iterations)
         if (lc.out_type[f] == ICPMI_OUT_GENERICDESCRIPTOR || lc.out_type[f] == ICPMI_OUT_ROBUST) lc.ext = 1;
     }
     lc.force_4dof = cfg.force_4dof != 0 && cfg.minimizer == ICPMI_MIN_POINT_TO_PLANE;
+    lc.force_2d = cfg.force_2d != 0 && cfg.minimizer == ICPMI_MIN_POINT_TO_PLANE;
+    if (lc.force_2d) lc.ext = 1;
     if (fixed_iterations > 0) {
         lc.max_iter = fixed_iterations; lc.use_diff = 0; lc.use_bound = 0;
     } else {

@@ -179,7 +179,8 @@ void GpuICPSequence::loadFromYamlNode(const yaml::Node& icp)
         else if (e.first == "PointToPlaneErrorMinimizer") {
             cfg.minimizer = ICPMI_MIN_POINT_TO_PLANE;
             cfg.force_4dof = (e.second["force4DOF"] && e.second["force4DOF"].as<int>() != 0) ? 1 : 0;
-            if (e.second["force2D"] && e.second["force2D"].as<int>() != 0) throw InvalidParameter("force2D is not on the accelerated path");
+            cfg.force_2d = (e.second["force2D"] && e.second["force2D"].as<int>() != 0) ? 1 : 0;
+            if (cfg.force_4dof && cfg.force_2d) throw InvalidParameter("PointToPlaneErrorMinimizer: force2D and force4DOF exclude each other");
         } else throw InvalidParameter("unknown error minimizer " + e.first);
     }
     if (icp["transformationCheckers"].IsSequence())

@@ -184,10 +184,11 @@ def config_from_yaml_chain(chain, **engine):
     name, p = single(chain.get("errorMinimizer", "PointToPlaneErrorMinimizer"), "errorMinimizer")
     if name not in _MINIMIZERS:
         raise InvalidParameter(f"unknown error minimizer {name}")
-    if int(p.get("force2D", 0)):
-        raise NotImplementedError("force2D is not on the accelerated path")
     kw["minimizer"] = _MINIMIZERS[name]
     kw["force_4dof"] = 1 if (name == "PointToPlaneErrorMinimizer" and int(p.get("force4DOF", 0))) else 0
+    kw["force_2d"] = 1 if (name == "PointToPlaneErrorMinimizer" and int(p.get("force2D", 0))) else 0
+    if kw["force_4dof"] and kw["force_2d"]:
+        raise InvalidParameter("PointToPlaneErrorMinimizer: force2D and force4DOF exclude each other")
 
     kw["max_iterations"] = 40
     for node in chain.get("transformationCheckers", [{"CounterTransformationChecker": {}}]) or []:

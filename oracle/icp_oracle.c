@@ -802,9 +802,12 @@ int orc_minimize(int minimizer, const float* reading4, int64_t n, const float* r
     return orc_minimize_ex(minimizer, 0, reading4, n, ref4, ref_normals3, ids, d2, w, k, T_out, A_out, b_out, x_out, st);
 }
 
-/* force_4dof: PointToPlaneErrorMinimizer{force4DOF: 1} [UPSTREAM PointToPlane.cpp compute_in_place]: the cross product is
+/* force_4dof == 1: PointToPlaneErrorMinimizer{force4DOF: 1} [UPSTREAM PointToPlane.cpp compute_in_place]: the cross product is
  * reduced to its z component, F = [cross_z; n] (4 rows), x = (yaw, t); the step is AngleAxis(x0, unitZ) + t.  F's rows are rows
- * 2..5 of the 6-DOF F, so A and b are the {2,3,4,5} sub-system of the 6-DOF sums. */
+ * 2..5 of the 6-DOF F, so A and b are the {2,3,4,5} sub-system of the 6-DOF sums.
+ * force_4dof == 2: {force2D: 1} on 3-D clouds: upstream drops the z row of the features and takes the top two rows of the normals
+ * (not renormalised): F = [x ny - y nx; nx; ny] -- rows 2..4 of the 6-DOF F --, the residual is the 2-D dot (dx nx + dy ny),
+ * x = (yaw, tx, ty), the step is Rotation2D(x0) + (tx, ty) embedded in the 4 x 4 identity. */
 int orc_minimize_ex(int minimizer, int force_4dof, const float* reading4, int64_t n, const float* ref4,
                     const float* ref_normals3, const int32_t* ids, const float* d2, const float* w, int k,
                     float* T_out, double* A_out, double* b_out, float* x_out, orc_stats* st)
@@ -812,7 +815,7 @@ int orc_minimize_ex(int minimizer, int force_4dof, const float* reading4, int64_
     int64_t P = 0;
     double wsum = 0;
     double sp[3] = { 0, 0, 0 }, sq[3] = { 0, 0, 0 }, Hs[9] = { 0 };
-    double A[36] = { 0 }, b[6] = { 0 };
+    double A[36] = { 0 }, b[6] = { 0 }, b2d[3] = { 0, 0, 0 };
     for (int64_t i = 0; i < n; ++i)
         for (int j = 0; j < k; ++j) {
             const int64_t e = (int64_t)k * i + j;
@@ -837,6 +840,10 @@ int orc_minimize_ex(int minimizer, int force_4dof, const float* reading4, int64_
                     const double wf = (double)we * F[c];
                     for (int r = 0; r < 6; ++r) A[6 * c + r] += wf * F[r];
                     b[c] -= wf * dot;
+                }
+                if (force_4dof == 2) {
+                    const float dot2 = dx * nn[0] + dy * nn[1];
+                    for (int c = 0; c < 3; ++c) b2d[c] -= ((double)we * F[2 + c]) * dot2;
                 }
             }
         }
@@ -869,7 +876,12 @@ int orc_minimize_ex(int minimizer, int force_4dof, const float* reading4, int64_
     for (int i = 0; i < 6; ++i) bf[i] = (float)b[i];
     if (A_out) memcpy(A_out, A, sizeof A);
     if (b_out) memcpy(b_out, b, sizeof b);
-    if (force_4dof) {
+    if (force_4dof == 2) {
+        float A3[9], b3[3], x3[3];
+        for (int c = 0; c < 3; ++c) { b3[c] = (float)b2d[c]; for (int r = 0; r < 3; ++r) A3[3 * c + r] = Af[6 * (2 + c) + (2 + r)]; }
+        orc_solve_n(3, A3, b3, x3);
+        x[0] = 0.f; x[1] = 0.f; x[2] = x3[0]; x[3] = x3[1]; x[4] = x3[2]; x[5] = 0.f;
+    } else if (force_4dof) {
         float A4[16], b4[4], x4[4];
         for (int c = 0; c < 4; ++c) { b4[c] = bf[2 + c]; for (int r = 0; r < 4; ++r) A4[4 * c + r] = Af[6 * (2 + c) + (2 + r)]; }
         orc_solve_n(4, A4, b4, x4);
@@ -1032,7 +1044,7 @@ int orc_icp_register(orc_icp* s, const float* scan4, int64_t n, const float* sca
                                      &robust_scale, w, &st->trimmed_limit);
         if (err) break;
         float T_step[16];
-        err = orc_minimize_ex(cfg->minimizer, cfg->force_4dof, step, n, s->map4, s->normals3, ids, d2, w, k, T_step, NULL, NULL, NULL, st);
+        err = orc_minimize_ex(cfg->minimizer, cfg->force_2d ? 2 : (cfg->force_4dof ? 1 : 0), step, n, s->map4, s->normals3, ids, d2, w, k, T_step, NULL, NULL, NULL, st);
         if (err) break;
         mat4_mul(T_step, T_iter, T_iter);
         ++st->iterations;

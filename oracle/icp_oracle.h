@@ -78,6 +78,7 @@ typedef struct {
     float max_trans_norm;
     int   nthreads;          /* OpenMP threads for the kNN query loop (>=1)       */
     int   force_4dof;        /* PointToPlaneErrorMinimizer.force4DOF               */
+    int   force_2d;          /* PointToPlaneErrorMinimizer.force2D                 */
 } orc_config;
 
 typedef struct {

@@ -24,7 +24,7 @@ class Config(C.Structure):
                 ("outlier", Outlier * 8), ("max_iterations", C.c_int), ("use_differential", C.c_int),
                 ("min_diff_rot", C.c_float), ("min_diff_trans", C.c_float), ("smooth_length", C.c_int),
                 ("use_bound", C.c_int), ("max_rot_norm", C.c_float), ("max_trans_norm", C.c_float),
-                ("nthreads", C.c_int), ("force_4dof", C.c_int)]
+                ("nthreads", C.c_int), ("force_4dof", C.c_int), ("force_2d", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -100,7 +100,7 @@ def load():
 
 def make_config(knn=1, max_dist=math.inf, minimizer=MIN_POINT_TO_PLANE, outliers=(), max_iterations=40,
                 use_differential=0, min_diff_rot=1e-3, min_diff_trans=1e-3, smooth_length=3, use_bound=0,
-                max_rot_norm=1.0, max_trans_norm=1.0, nthreads=1, force_4dof=0):
+                max_rot_norm=1.0, max_trans_norm=1.0, nthreads=1, force_4dof=0, force_2d=0):
     cfg = Config()
     cfg.knn, cfg.max_dist, cfg.minimizer = knn, max_dist, minimizer
     cfg.n_outlier = len(outliers)
@@ -114,6 +114,7 @@ def make_config(knn=1, max_dist=math.inf, minimizer=MIN_POINT_TO_PLANE, outliers
     cfg.use_bound, cfg.max_rot_norm, cfg.max_trans_norm = use_bound, max_rot_norm, max_trans_norm
     cfg.nthreads = nthreads
     cfg.force_4dof = force_4dof
+    cfg.force_2d = force_2d
     return cfg
 
 

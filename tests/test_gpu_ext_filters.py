@@ -136,6 +136,7 @@ CHAINS = {
     "p2plane_generic_soft": dict(minimizer=2, max_dist=2.0, outliers=[(GEN, 0.0, SOFT, 0.0)], max_iterations=10),
     "p2plane_vartrimmed": dict(minimizer=2, max_dist=2.0, outliers=[(VT, 0.05, 0, 0.99, 0.95)], max_iterations=25, use_differential=1),
     "p2p_vartrimmed_knn3_maxdist": dict(minimizer=1, knn=3, max_dist=1.0, outliers=[(1, 0.8), (VT, 0.2, 0, 0.9, 1.5)], max_iterations=8),
+    "p2plane_2d": dict(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=30, use_differential=1, force_2d=1),
     "p2plane_4dof": dict(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=30, use_differential=1, force_4dof=1),
 }
 
@@ -165,7 +166,10 @@ def test_registration_matches_oracle(amd, oracle, mid_scene, name):
     assert abs(icp.errorMinimizer.getOverlap() - oicp.stats.weighted_point_used_ratio) < 2e-6
     if "vartrimmed" in name:
         assert icp.stats.trimmed_limit == oicp.stats.trimmed_limit
-    if name in ("p2plane_4dof", "p2plane_vartrimmed"):
+    if name == "p2plane_2d":
+        # yaw + (tx, ty): no motion along z, z axis kept
+        assert T[2, 3] == 0 and np.allclose(T[2, :3], [0, 0, 1], atol=1e-6) and np.allclose(T[:3, 2], [0, 0, 1], atol=1e-6)
+    if name in ("p2plane_4dof", "p2plane_vartrimmed", "p2plane_2d"):
         # fixed launch sequence (hipGraph) == checked loop
         import torch
         d = torch.from_numpy(np.ascontiguousarray(sc["scan"], dtype=np.float32)).cuda()
@@ -197,6 +201,27 @@ def test_force_4dof_single_step_matches_oracle(amd, oracle, small_scene):
     dt, dr = amd.synth.pose_error(T_step, T_ref)
     assert dt < 1e-5 and dr < 1e-5
     assert np.allclose(T_step[2, :3], [0, 0, 1], atol=1e-7)
+
+
+def test_force_2d_single_step_matches_oracle(amd, oracle, small_scene):
+    sc = small_scene
+    icp = amd.ICPSequence(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], force_2d=1)
+    icp.setMap(sc["map"], sc["normals"])
+    mean = icp.getMapMean()
+    mapc = centred(sc["map"], mean)
+    q = centred(sc["scan"], mean)
+    T_iter = amd.synth.make_T((0.0, 0.0, 0.01), (0.02, 0.01, 0.0)).astype(np.float32)
+    T_step, sums = icp.minimizeStep(q, T_iter)
+    step = oracle.transform(T_iter, q)
+    ids, d2 = oracle.knn(mapc, step, k=1, max_dist=2.0)
+    err, w, lim = oracle.outlier_weights(oracle.make_config(max_dist=2.0, outliers=[(4, 0.85)]), d2, ids)
+    err, T_ref, A, b, x, st = oracle.minimize(2, step, mapc, sc["normals"], ids, d2, w, force_4dof=2)
+    assert err == 0
+    dt, dr = amd.synth.pose_error(T_step, T_ref)
+    assert dt < 1e-5 and dr < 1e-5
+    assert T_step[2, 3] == 0 and np.allclose(T_step[2, :3], [0, 0, 1], atol=1e-7)
+    with pytest.raises(Exception):
+        amd.ICPSequence(minimizer=2, force_2d=1, force_4dof=1)
 
 
 def test_batch_with_ext_chain_equals_single_registrations(amd, mid_scene):

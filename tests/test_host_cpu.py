@@ -42,7 +42,7 @@ def test_config_defaults_and_struct_layout():
     assert cfg.min_diff_rot == pytest.approx(1e-3) and cfg.smooth_length == 3 and cfg.use_graph == 1
     # the ctypes mirrors must have the C layout: 8-byte aligned int64 members, trailing reserved block
     assert C.sizeof(_capi.Stats) == 72
-    assert C.sizeof(_capi.Config) == 5 * 4 + 8 * 20 + 13 * 4 + 8 * 4
+    assert C.sizeof(_capi.Config) == 5 * 4 + 8 * 20 + 14 * 4 + 8 * 4
     assert cfg.force_4dof == 0
 
 
@@ -143,8 +143,9 @@ inspector: NullInspector
                 {"transformationCheckers": [{"FooChecker": {}}]}, {"icp": {}}):
         with pytest.raises(pkg.InvalidParameter):
             pkg.config_from_yaml_chain(bad)
-    with pytest.raises(NotImplementedError):
-        pkg.config_from_yaml_chain({"errorMinimizer": {"PointToPlaneErrorMinimizer": {"force2D": 1}}})
+    assert pkg.config_from_yaml_chain({"errorMinimizer": {"PointToPlaneErrorMinimizer": {"force2D": 1}}}).force_2d == 1
+    with pytest.raises(pkg.InvalidParameter):
+        pkg.config_from_yaml_chain({"errorMinimizer": {"PointToPlaneErrorMinimizer": {"force2D": 1, "force4DOF": 1}}})
     # the chain elements beyond the bundled configurations
     cfg = pkg.config_from_yaml_chain({
         "outlierFilters": [{"RobustOutlierFilter": {"robustFct": "huber", "tuning": 1.5, "scaleEstimator": "mad", "nbIterationForScale": 4,

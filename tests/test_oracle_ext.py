@@ -194,3 +194,28 @@ def test_var_trimmed_ratio_known_answers(oracle):
     err, w, lim = oracle.outlier_weights(oracle.make_config(outliers=[(8, 0.05, 0, 0.99, 0.95)]), d2.reshape(-1, 1), ids)
     assert err == 0 and lim == oracle.dists_quantile(d2, r)
     np.testing.assert_array_equal(w[:, 0], (d2 <= lim).astype(np.float32))
+
+
+def test_force_2d_is_the_planar_system_of_upstream(oracle):
+    """force2D on 3-D clouds: F = [x ny - y nx; nx; ny], residual (dx nx + dy ny), x = (yaw, tx, ty) -- against numpy"""
+    rng = np.random.default_rng(4)
+    n = 3000
+    ref = np.c_[rng.uniform(-5, 5, (n, 3)), np.ones(n)].astype(np.float32)
+    nn = rng.normal(size=(n, 3)); nn /= np.linalg.norm(nn, axis=1, keepdims=True); nn = nn.astype(np.float32)
+    yaw, t = 0.012, np.array([0.03, -0.02, 0.5])          # a z offset the planar solve must not see
+    c, s = math.cos(-yaw), math.sin(-yaw)
+    Rinv = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
+    reading = ref.copy(); reading[:, :3] = ((ref[:, :3] - t) @ Rinv.T).astype(np.float32)
+    ids = np.arange(n, dtype=np.int32)[:, None]; d2 = np.ones((n, 1), dtype=np.float32)
+    w = rng.uniform(0.2, 1.0, (n, 1)).astype(np.float32)
+    err, T, A, b, x, st = oracle.minimize(2, reading, ref, nn, ids, d2, w, force_4dof=2)
+    assert err == 0 and x[0] == 0 and x[1] == 0 and x[5] == 0
+    p, q, m = reading[:, :3].astype(np.float64), ref[:, :3].astype(np.float64), nn.astype(np.float64)
+    F = np.c_[p[:, 0] * m[:, 1] - p[:, 1] * m[:, 0], m[:, 0], m[:, 1]]
+    dot2 = (p[:, 0] - q[:, 0]) * m[:, 0] + (p[:, 1] - q[:, 1]) * m[:, 1]
+    A3 = (F * w.astype(np.float64)).T @ F
+    b3 = -(F * w.astype(np.float64)).T @ dot2
+    np.testing.assert_allclose(x[2:5], np.linalg.solve(A3, b3), rtol=2e-4, atol=2e-6)
+    assert x[2] == pytest.approx(yaw, abs=3e-4)
+    np.testing.assert_allclose(T[:2, 3], t[:2], atol=5e-4)
+    assert T[2, 3] == 0 and np.allclose(T[2, :3], [0, 0, 1], atol=1e-7) and np.allclose(T[:3, 2], [0, 0, 1], atol=1e-7)
