@@ -196,31 +196,52 @@ def main():
     # communicator (icpmi_staged_merge_allgather: accepted points compacted, all-gathered on the handle's stream, merged in rank
     # order and appended on the device).  Every rank must take the same decisions, or the collective would hang: agree first.
     merge = None
+    merge_hung = False
     if use_pg:
-        try:
-            ok = 1
+        # On a watchdog: a collective that never completes (a rank lost, an RCCL transport problem between two GPUs) must not
+        # take the headline measured above with it -- after MERGE_TIMEOUT_S the line is printed without the epoch and every
+        # rank leaves through os._exit.
+        import threading
+        box_out = {}
+
+        def merge_epoch():
+            torch.cuda.set_device(local_rank)
+            m = None
             try:
-                box = [icp.commUniqueId() if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                icp.commInit(box[0], world, rank)
-            except Exception as e:  # noqa: BLE001
-                ok, merge = 0, {"error": repr(e)}
-            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 1:
-                corr = icp.registerWithPrior(sc["scan"], np.eye(4, dtype=np.float32))
-                barrier()
-                tm = time.perf_counter()
-                mine_n, appended, new_m = icp.stagedMergeAllGather(corr, 0.15, normals_knn=0)
-                barrier()
-                tms = torch.tensor([time.perf_counter() - tm], dtype=torch.float64, device="cuda")
-                dist.all_reduce(tms, op=dist.ReduceOp.MAX)
-                merge = {"ms": float(tms.item()) * 1e3, "accepted_rank0": mine_n, "appended_all_ranks": appended, "map_points_after": new_m,
+                ok = 1
+                try:
+                    box = [icp.commUniqueId() if rank == 0 else None]
+                    dist.broadcast_object_list(box, src=0)
+                    icp.commInit(box[0], world, rank)
+                except Exception as e:  # noqa: BLE001
+                    ok, m = 0, {"error": repr(e)}
+                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 1:
+                    corr = icp.registerWithPrior(sc["scan"], np.eye(4, dtype=np.float32))
+                    barrier()
+                    tm = time.perf_counter()
+                    mine_n, appended, new_m = icp.stagedMergeAllGather(corr, 0.15, normals_knn=0)
+                    barrier()
+                    tms = torch.tensor([time.perf_counter() - tm], dtype=torch.float64, device="cuda")
+                    dist.all_reduce(tms, op=dist.ReduceOp.MAX)
+                    m = {"ms": float(tms.item()) * 1e3, "accepted_rank0": mine_n, "appended_all_ranks": appended, "map_points_after": new_m,
                          "what": "PointDistance(0.15 m) accept of one 100k-pt scan per rank + RCCL all-gather + rank-ordered exact merge + append + index rebuild"}
-            elif merge is None:
-                merge = {"error": "another rank could not create its communicator"}
-        except Exception as e:  # noqa: BLE001
-            merge = {"error": repr(e)}
+                elif m is None:
+                    m = {"error": "another rank could not create its communicator"}
+            except Exception as e:  # noqa: BLE001
+                m = {"error": repr(e)}
+            box_out["merge"] = m
+
+        MERGE_TIMEOUT_S = 90.0
+        th = threading.Thread(target=merge_epoch, daemon=True)
+        th.start()
+        th.join(MERGE_TIMEOUT_S)
+        if th.is_alive():
+            merge_hung = True
+            merge = {"error": f"no result within {MERGE_TIMEOUT_S:.0f} s (collective did not complete); headline unaffected"}
+        else:
+            merge = box_out.get("merge")
 
     out = {
         "metric": "ICP iterations/sec, 100k-pt scan vs 1M-pt map",
@@ -379,8 +400,11 @@ def main():
                     out["pose_err_vs_libpointmatcher"] = {"m": pt, "rad": pr}
                 except Exception as e:
                     out["pose_err_vs_libpointmatcher"] = {"error": repr(e)}
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if use_pg:
+        if merge_hung:
+            sys.stdout.flush()
+            os._exit(0)
         dist.barrier()
         dist.destroy_process_group()
 
