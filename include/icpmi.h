@@ -342,7 +342,7 @@ icpmi_status icpmi_map_update_chain_staged(icpmi_handle h, const float correctio
                                            const float from_sensor[16], const icpmi_map_op* ops, int32_t n_ops, int32_t n_modules,
                                            int32_t* src_out, int64_t src_capacity, int64_t* identity_prefix, int64_t* new_m);
 /* The tracked scalar descriptor of the resident map: upload after a icpmi_set_map (m must equal the map size),
- * download next to icpmi_get_map. */
+ * download next to icpmi_get_map (no map, or an empty resident map: ICPMI_OK and nothing written, like icpmi_get_map's 0 points). */
 icpmi_status icpmi_set_map_scalar(icpmi_handle h, const float* scalar, int64_t m);
 icpmi_status icpmi_get_map_scalar(icpmi_handle h, float* scalar_out, int64_t capacity);
 

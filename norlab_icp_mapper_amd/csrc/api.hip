@@ -679,7 +679,9 @@ icpmi_status icpmi_set_map_scalar(icpmi_handle h, const float* scalar, int64_t m
 icpmi_status icpmi_get_map_scalar(icpmi_handle h, float* scalar_out, int64_t capacity)
 {
     CHECK_H(h);
-    if (!scalar_out || h->m <= 0 || capacity < h->m_raw) { h->last_error = "get_map_scalar: no map, or capacity too small"; return ICPMI_ERR_INVALID_ARG; }
+    if (h->m <= 0 || h->m_raw == 0) return ICPMI_OK; // no map, or an empty resident map (a chain removed every point): nothing to
+                                                     // hand out -- like icpmi_get_map, which reports 0 points
+    if (!scalar_out || capacity < h->m_raw) { h->last_error = "get_map_scalar: no map, or capacity too small"; return ICPMI_ERR_INVALID_ARG; }
     return ops_map_scalar(h, nullptr, scalar_out, h->m_raw);
 }
 
