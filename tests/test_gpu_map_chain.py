@@ -48,6 +48,11 @@ def host_chain(ob, map_pts, map_n, map_s, scan, scan_s, to_sensor, modules, post
             append()
             keep = ob.voxel_keep(pts, op[1], op[2])
             pts, nrm, sc, src = pts[keep], nrm[keep], sc[keep], src[keep]
+        elif name == "octree":      # ("octree", maxSizeByNode, samplingMethod, maxPointByNode): the cloud comes out in leaf order
+            append()
+            if pts.shape[0]:
+                order = ob.octree_sample(pts, op[1], op[3] if len(op) > 3 else 1, op[2] if len(op) > 2 else 0)
+                pts, nrm, sc, src = pts[order], nrm[order], sc[order], src[order]
         created = True
     for op in post:
         if op[0] == "surface_normals":

@@ -28,12 +28,14 @@ def cloud(n, src):
 def program():
     mods = []
     for _ in range(int(rng.integers(1, 4))):
-        t = rng.choice(["pd", "dyn", "vox"])
+        t = rng.choice(["pd", "dyn", "vox", "oct"])
         if t == "pd":
             mods.append(("point_distance", float(rng.choice([0.0, 0.05, 0.3, 1.0]))))
         elif t == "dyn":
             mods.append(("dynamic_points", float(rng.choice([0.3, 0.6, 0.9])), 0.8, 0.99, float(rng.choice([0.005, 0.01, 0.05])),
                          float(rng.choice([0.001, 0.01, 0.1])), float(rng.choice([0.001, 0.01, 0.3])), float(rng.choice([30.0, 200.0]))))
+        elif t == "oct":   # the real OctreeGridDataPointsFilter: (maxSizeByNode, samplingMethod 0 = first point, maxPointByNode)
+            mods.append(("octree", float(rng.choice([0.05, 0.3, 2.0, 0.0])), 0, int(rng.choice([1, 1, 4, 16]))))
         else:
             mods.append(("voxel", float(rng.choice([0.05, 0.3, 2.0, 500.0])), int(rng.integers(0, 2))))
     post = []
