@@ -924,7 +924,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nnk_ml_kernel(const float4* __restri
 // One wave per workgroup: a 4-cell segment holds ~40 queries, so wider workgroups would idle most of their lanes.
 constexpr int SELF_SEG = 4, SELF_CH = 384, SELF_BLOCK = 64;
 
-template <int KMAX>
+template <int KMAX, int SELF_Q>
 __global__ __launch_bounds__(SELF_BLOCK) __attribute__((amdgpu_waves_per_eu(KMAX <= 10 ? 5 : 1))) void nnk_self_tiled_kernel(GridParams g, const float4* __restrict__ map,
                                                                   const unsigned* __restrict__ cs, int k, int* __restrict__ out_sidx,
                                                                   float* __restrict__ out_d2, IcpState* __restrict__ st,
@@ -940,6 +940,7 @@ __global__ __launch_bounds__(SELF_BLOCK) __attribute__((amdgpu_waves_per_eu(KMAX
     // the 9 candidate runs (cells x0-1 .. x1 of the rows (y+dy, z+dz)); workgroup-uniform
     __shared__ unsigned run_s[9], run_p[10];
     __shared__ float4 tile[SELF_CH];
+    __shared__ unsigned short qslot[SELF_Q][SELF_BLOCK]; // per-lane queue of candidates awaiting insertion (tile slots)
     if (threadIdx.x < 9) {
         const int dy = (int)threadIdx.x % 3 - 1, dz = (int)threadIdx.x / 3 - 1;
         unsigned s0 = 0, e0 = 0;
@@ -989,14 +990,33 @@ __global__ __launch_bounds__(SELF_BLOCK) __attribute__((amdgpu_waves_per_eu(KMAX
             }
             __syncthreads();
             if (active) {
+                // A candidate that beats the lane's k-th best is only QUEUED (its tile slot, 2 bytes in LDS); the sorted insertion --
+                // ~70 instructions the whole wave pays whenever any one lane inserts, which is at nearly every candidate -- runs
+                // for all lanes together when some lane's queue is full and at the end of the chunk.  The bound is a little stale
+                // while a queue fills (a few more candidates get queued); the k best of the same candidate set come out.
+                int qn = 0;
+                auto drain = [&]() {
+                    for (int t = 0; t < SELF_Q; ++t) {
+                        if (__ballot(t < qn) == 0ull) break;
+                        if (t < qn) {
+                            const unsigned ti = qslot[t][threadIdx.x];
+                            const float4 q = tile[ti];
+                            const float d2 = sqdist3(me.x, me.y, me.z, q.x, q.y, q.z);
+                            L.insert(pack_key(d2, __float_as_uint(q.w)), (int)(c0 + ti)); // flat index; turned into a map position below
+                        }
+                    }
+                    qn = 0;
+                };
                 for (int r = 0; r < 9; ++r) {
                     const unsigned lo = max(cell_off[r][cxl], c0), hi = min(cell_off[r][cxl + 3], c0 + cn);
                     for (unsigned i = lo; i < hi; ++i) {
                         const float4 q = tile[i - c0];
                         const float d2 = sqdist3(me.x, me.y, me.z, q.x, q.y, q.z);
-                        L.insert(pack_key(d2, __float_as_uint(q.w)), (int)i); // flat index; turned into a map position below
+                        if (pack_key(d2, __float_as_uint(q.w)) < L.worst()) { qslot[qn][threadIdx.x] = (unsigned short)(i - c0); ++qn; }
+                        if (__ballot(qn == SELF_Q) != 0ull) drain();
                     }
                 }
+                drain();
             }
         }
         if (!active) continue;
@@ -1295,8 +1315,12 @@ static icpmi_status nn_self_knn_t(icpmi_ctx* c, const float4* d_cloud, const Loo
     const int nsx = (g.nx + SELF_SEG - 1) / SELF_SEG;
     const long long wgs = (long long)nsx * g.ny * g.nz;
     if (wgs > 0x7fffffffll) { c->last_error = "self knn: grid too large"; return ICPMI_ERR_UNSUPPORTED; }
-    hipLaunchKernelGGL(nnk_self_tiled_kernel<KMAX>, dim3((unsigned)wgs), dim3(SELF_BLOCK), 0, c->stream, g, c->d_map_sorted, c->d_cell_start, lc.k,
-                       d_sidx, d_d2, d_state, c->d_hard);
+    static int self_q = -1; // candidates a lane queues before the wave inserts them (nnk_self_tiled_kernel)
+    if (self_q < 0) { const char* e = getenv("ICPMI_SELF_Q"); self_q = e ? atoi(e) : 8; }
+#define LAUNCH_SELF(Q_) hipLaunchKernelGGL((nnk_self_tiled_kernel<KMAX, Q_>), dim3((unsigned)wgs), dim3(SELF_BLOCK), 0, c->stream, g, c->d_map_sorted, \
+                                           c->d_cell_start, lc.k, d_sidx, d_d2, d_state, c->d_hard)
+    if (self_q <= 1) LAUNCH_SELF(1); else if (self_q <= 4) LAUNCH_SELF(4); else if (self_q <= 8) LAUNCH_SELF(8); else LAUNCH_SELF(16);
+#undef LAUNCH_SELF
     // left-overs (k-th neighbour beyond the margin: sparse regions, map border): ring search, then brute force
     const int blocks = (int)((c->m + NN_BLOCK - 1) / NN_BLOCK);
     hipLaunchKernelGGL(nnk_redo_kernel, dim3(1), dim3(64), 0, c->stream, d_state, c->d_hard + c->m + 1);
