@@ -834,7 +834,6 @@ icpmi_status ops_map_update_dev(icpmi_ctx* c, const float4* d_scan, int64_t n, c
     if (normals_knn < 0 || normals_knn > ICPMI_MAX_K) { c->last_error = "map_update: normals_knn must be in [0, 32]"; return ICPMI_ERR_INVALID_ARG; }
     const bool scan_normals3 = d_scan_n3 != nullptr;
     const int64_t m0 = c->m > 0 ? c->m_raw : 0;
-    const double lim = pd_limit(min_dist);
     const int blocks = (int)((n + 255) / 256);
     unsigned* d_flag = scratch_get<unsigned>(c, 6, (size_t)n + 2); // kept between calls
     unsigned* d_pos = scratch_get<unsigned>(c, 7, (size_t)n + 2);
