@@ -21,6 +21,15 @@ for rep in range(6):
             icp.mapUpdateChain(sc["scan"], [("dynamic_points", 0.9, 0.8, 0.99, 0.01, 0.01, 0.01, 200.0), ("voxel", 0.15, 1)],
                                [("surface_normals", 10), ("cut_scalar", 0.65, 1)], scan_scalar=prob, to_sensor=np.eye(4))
             icp.filterPoints(sc["scan"], [("distance_limit", -1, 40.0, False), ("bounding_box", (-1, -1, -1), (1, 1, 1), True)])
+            # r2: octree operator, batch, the library's RCCL epoch (1-rank communicator), the raw-frame index, VarTrimmed / Robust scratch
+            icp.octreeSample(sc["map"][:80_000], 0.2, 4)
+            icp.mapUpdateChain(sc["scan"], [("octree", 0.15, 0, 1)], [("surface_normals", 10)], scan_scalar=prob, to_sensor=np.eye(4), from_sensor=np.eye(4))
+            d = [torch.from_numpy(sc["scan"]).cuda(), torch.from_numpy(sc["scan"][::2].copy()).cuda()]
+            icp.registerBatchDev([t.data_ptr() for t in d], [t.shape[0] for t in d])
+            icp.commInit(icp.commUniqueId(), 1, 0)
+            corr = icp.registerWithPrior(sc["scan"], np.eye(4)); icp.stagedMergeAllGather(corr, 0.1, normals_knn=5); icp.commDestroy()
+            e = pkg.ICPSequence(minimizer=2, max_dist=2.0, outliers=[(8, 0.05, 0, 0.99, 0.95), (7, 1.0, 0 | (1 << 4), 0.0)], max_iterations=4)
+            e.setMap(sc["map"], sc["normals"]); e(sc["scan"]); e.close()
         icp.close()
     f = free_mb()
     if base is None: base = f
