@@ -65,8 +65,27 @@ icpmi_status comm_unique_id(icpmi_comm_id* id, std::string& err)
     return ICPMI_OK;
 }
 
+// Loopback communicator (ICPMI_COMM_LOOPBACK=R at the time of icpmi_comm_init): R ranks simulated on ONE GPU -- every "rank"
+// contributes this rank's own block, rank r's points moved by r * ICPMI_COMM_LOOPBACK_SHIFT metres along x.  It exists so that
+// the rank-ordered merge of icpmi_staged_merge_allgather (counts, padding, block offsets, rejection against the blocks of the
+// lower ranks) can be checked against the oracle on a single-GPU box; RCCL is not touched.
+__global__ __launch_bounds__(256) void loop_shift_kernel(float4* __restrict__ p, size_t n, float dx)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i].x += dx;
+}
+
 icpmi_status comm_init(icpmi_ctx* c, const icpmi_comm_id* id, int n_ranks, int rank)
 {
+    if (const char* lb = getenv("ICPMI_COMM_LOOPBACK")) {
+        const int R = atoi(lb);
+        if (R > 1) {
+            if (c->comm) (void)comm_destroy(c);
+            const char* sh = getenv("ICPMI_COMM_LOOPBACK_SHIFT");
+            c->comm = nullptr; c->comm_ranks = R; c->comm_rank = 0; c->comm_loop_shift = sh ? (float)atof(sh) : 0.f;
+            return ICPMI_OK;
+        }
+    }
     Rccl& r = rccl();
     if (!r.lib) { c->last_error = r.error; return ICPMI_ERR_HIP; }
     if (c->comm) { RCCL_TRY(c, r.CommDestroy((ncclComm_t)c->comm)); c->comm = nullptr; }
@@ -80,7 +99,7 @@ icpmi_status comm_init(icpmi_ctx* c, const icpmi_comm_id* id, int n_ranks, int r
 
 icpmi_status comm_destroy(icpmi_ctx* c)
 {
-    if (!c->comm) return ICPMI_OK;
+    if (!c->comm) { c->comm_ranks = 1; c->comm_rank = 0; c->comm_loop_shift = 0.f; return ICPMI_OK; }
     Rccl& r = rccl();
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (r.lib) (void)r.CommDestroy((ncclComm_t)c->comm);
@@ -93,7 +112,14 @@ icpmi_status comm_allgather(icpmi_ctx* c, const void* d_send, void* d_recv, size
 {
     if (!c->comm) {
         const size_t bytes = count * (is_float ? sizeof(float) : sizeof(long long));
-        if (d_send != d_recv) HIP_TRY(c, hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, c->stream));
+        for (int r = 0; r < c->comm_ranks; ++r) { // one rank, or the loopback communicator's R copies
+            char* dst = (char*)d_recv + (size_t)r * bytes;
+            if (dst != (const char*)d_send) HIP_TRY(c, hipMemcpyAsync(dst, d_send, bytes, hipMemcpyDeviceToDevice, c->stream));
+            if (is_float && r > 0 && c->comm_loop_shift != 0.f && count >= 4)
+                hipLaunchKernelGGL(loop_shift_kernel, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, c->stream, (float4*)dst, count / 4,
+                                   (float)r * c->comm_loop_shift);
+        }
+        HIP_TRY(c, hipGetLastError());
         return ICPMI_OK;
     }
     RCCL_TRY(c, rccl().AllGather(d_send, d_recv, count, is_float ? ncclFloat : ncclInt64, (ncclComm_t)c->comm, c->stream));

@@ -250,6 +250,7 @@ struct icpmi_ctx {
     float4* d_merged = nullptr; size_t cap_merged = 0;
     // RCCL communicator of the scan-sharded mapping mode (comm.hip); null = a single rank
     void* comm = nullptr; int comm_ranks = 1, comm_rank = 0;
+    float comm_loop_shift = 0.f;      // loopback communicator (comm.hip): rank r's block = this rank's, moved r * shift along x
 };
 
 #define HIP_TRY(ctx, expr)                                                                     \

@@ -1354,7 +1354,7 @@ icpmi_status ops_staged_merge_allgather(icpmi_ctx* c, const float correction[16]
     if (appended_total) *appended_total = 0;
     if (merged_n) *merged_n = 0;
     if (new_m) *new_m = c->m > 0 ? c->m_raw : 0;
-    const int R = c->comm ? c->comm_ranks : 1;
+    const int R = c->comm_ranks; // 1 without a communicator (or the loopback communicator's simulated ranks, comm.hip)
     const int64_t n = c->scan_map_n;
     // ---- this rank's accepted points: the staged scan moved by the correction (Mapper.cpp:221), PointDistance against the resident map
     unsigned* d_flag = scratch_get<unsigned>(c, 6, (size_t)n + 2);

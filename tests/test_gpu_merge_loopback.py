@@ -1,0 +1,60 @@
+"""The rank-ordered merge of icpmi_staged_merge_allgather with MORE THAN ONE rank, on one GPU: the loopback communicator
+(ICPMI_COMM_LOOPBACK=R, csrc/comm.hip) makes every simulated rank contribute this rank's accepted block, rank r's moved by
+r * shift along x.  What the library appends must be exactly what the oracle's PointDistance rule leaves when the blocks are
+merged in rank order (block r keeps the points at least minDistNewPoint from the points kept from ranks < r) -- the rule the
+scan-sharded mapper applies over RCCL, where a one-GPU box can only ever run one rank."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MIN_DIST = 0.3
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import norlab_icp_mapper_amd as pkg
+    return pkg
+
+
+@pytest.mark.parametrize("ranks,shift", [(2, 0.0), (3, 0.12), (4, 0.2), (5, 0.45)])
+def test_rank_ordered_merge_matches_the_oracle(amd, oracle, mid_scene, ranks, shift, monkeypatch):
+    sc = mid_scene
+    monkeypatch.setenv("ICPMI_COMM_LOOPBACK", str(ranks))
+    monkeypatch.setenv("ICPMI_COMM_LOOPBACK_SHIFT", repr(shift))
+    icp = amd.ICPSequence(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=30, use_differential=1)
+    half, half_n = sc["map"][::2].copy(), sc["normals"][::2].copy()
+    assert icp.setMap(half, half_n)
+    icp.commInit(icp.commUniqueId(), 1, 0)  # the loopback communicator ignores the id and simulates `ranks` ranks
+    corr = icp.registerWithPrior(sc["scan"], np.eye(4, dtype=np.float32))
+    keep, placed = icp.stagedPointDistanceKeep(corr, MIN_DIST)
+    # oracle: this rank's accepted block, then the blocks of the simulated ranks in rank order
+    assert np.array_equal(keep, oracle.point_distance_keep(half, placed, MIN_DIST, nthreads=8))
+    block0 = placed[keep]
+    merged = block0.copy()
+    for r in range(1, ranks):
+        blk = block0.copy()
+        blk[:, 0] = blk[:, 0] + np.float32(np.float32(r) * np.float32(shift))
+        k = oracle.point_distance_keep(merged, blk, MIN_DIST, nthreads=8)
+        merged = np.concatenate([merged, blk[k]])
+    mine, appended, new_m, got_merged = icp.stagedMergeAllGather(corr, MIN_DIST, normals_knn=0, return_merged=True,
+                                                                 merged_capacity=ranks * block0.shape[0] + 8)
+    assert mine == block0.shape[0]
+    assert appended == merged.shape[0] and new_m == half.shape[0] + merged.shape[0]
+    assert np.array_equal(got_merged, merged)
+    assert np.array_equal(icp.getMap(), np.concatenate([half, merged]))
+    # (shift 0: the higher ranks hand in exact duplicates -- which the reference's search, run without self matches, does not
+    # see at distance 0: a duplicate is judged by its nearest OTHER point, PointDistanceMapperModule.cpp:33-42; the oracle
+    # above applies the same rule)
+    if shift >= MIN_DIST * 1.5:
+        assert appended > mine                       # far enough apart: the higher ranks contribute points
+    icp.commDestroy()
+    # without the variable the communicator is a real one again (one rank here)
+    monkeypatch.delenv("ICPMI_COMM_LOOPBACK")
+    icp.commInit(icp.commUniqueId(), 1, 0)
+    corr = icp.registerWithPrior(sc["scan"], np.eye(4, dtype=np.float32))
+    mine2, appended2, _ = icp.stagedMergeAllGather(corr, MIN_DIST)
+    assert appended2 == mine2
+    icp.commDestroy()
