@@ -4,6 +4,8 @@
 #include <cstring>
 #include <new>
 #include <dlfcn.h>
+#include <mutex>
+#include <cstdio>
 
 static std::string g_create_error;
 
@@ -282,6 +284,25 @@ icpmi_status icpmi_set_map(icpmi_handle h, const float* map4, int64_t m, const f
 
 static void identity16(float* T) { for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.f : 0.f; }
 
+// ICPMI_STATS_JSON=<path>: one JSON line per registration with the names libpointmatcher's inspector records for an ICP call
+// (IterationsCount, OverlapRatio, ConvergenceDuration) plus the loop's own statistics.  Opened once, appended.
+static FILE* stats_json()
+{
+    static FILE* f = [] { const char* p = getenv("ICPMI_STATS_JSON"); return (p && *p) ? fopen(p, "a") : (FILE*)nullptr; }();
+    return f;
+}
+
+static void write_stats_json(const icpmi_stats& st, int64_t n, icpmi_status rs)
+{
+    static std::mutex mu;
+    std::lock_guard<std::mutex> g(mu);
+    fprintf(stats_json(), "{\"IterationsCount\": %d, \"OverlapRatio\": %.9g, \"ConvergenceDuration\": %.9g, \"PointUsedRatio\": %.9g, "
+                          "\"PairsUsed\": %lld, \"ReadingPoints\": %lld, \"StopReason\": %d, \"TrimmedLimit\": %.9g, \"Status\": %d}\n",
+            st.iterations, (double)st.weighted_point_used_ratio, (double)st.loop_ms * 1e-3, (double)st.point_used_ratio, (long long)st.pairs,
+            (long long)n, st.stop_reason, (double)st.trimmed_limit, (int)rs);
+    fflush(stats_json());
+}
+
 // fields the GenericDescriptor / Robust filters of the chain read on the map
 static icpmi_status check_ext_filters(icpmi_ctx* h)
 {
@@ -328,7 +349,11 @@ static icpmi_status register_impl(icpmi_handle h, const float* d_scan4, int64_t 
         h->last_error = quant ? "ConvergenceError: no outlier to filter" : "ConvergenceError: ErrorMinimizer: no point to minimize";
         return quant ? ICPMI_ERR_NO_OUTLIER_TO_FILTER : ICPMI_ERR_NO_POINT_TO_MINIMIZE;
     }
-    return loop_run(h, (const float4*)d_scan4, needs_rn ? d_n3 : nullptr, n, lc, fixed_iters > 0, T_out, stats);
+    icpmi_stats local;
+    if (!stats && stats_json()) stats = &local;
+    const icpmi_status rs = loop_run(h, (const float4*)d_scan4, needs_rn ? d_n3 : nullptr, n, lc, fixed_iters > 0, T_out, stats);
+    if (stats_json() && stats) write_stats_json(*stats, n, rs);
+    return rs;
 }
 
 icpmi_status icpmi_register_dev(icpmi_handle h, const float* d_scan4, int64_t n, const float* d_scan_normals3, float T_out[16],

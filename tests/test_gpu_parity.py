@@ -712,3 +712,23 @@ def test_fused_input_filters_bit_exact(amd, oracle, mid_scene):
         icp.filterPoints(c, [("distance_limit", 3, 1.0, False)])
     with pytest.raises(amd.InvalidParameter):
         icp.filterPoints(c, [("distance_limit", -1, 1.0, False)] * 17)
+
+
+def test_inspector_style_json_stats(amd, mid_scene, tmp_path):
+    """ICPMI_STATS_JSON: one line per registration with libpointmatcher's inspector names (read once per process: subprocess)"""
+    import json, os, subprocess, sys
+    path = tmp_path / "stats.jsonl"
+    code = ("import norlab_icp_mapper_amd as pkg\n"
+            "sc = pkg.synth.make_scene(m=50000, n=5000)\n"
+            "icp = pkg.ICPSequence(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=40, use_differential=1)\n"
+            "icp.setMap(sc['map'], sc['normals'])\n"
+            "for _ in range(3): icp(sc['scan'])\n"
+            "print(icp.stats.iterations, icp.stats.pairs)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, ICPMI_STATS_JSON=str(path), PYTHONPATH=root), text=True)
+    its, pairs = (int(v) for v in out.split()[-2:])
+    lines = [json.loads(l) for l in open(path)]
+    assert len(lines) == 3
+    for rec in lines:
+        assert rec["IterationsCount"] == its and rec["PairsUsed"] == pairs and rec["ReadingPoints"] == 5000 and rec["Status"] == 0
+        assert 0 < rec["OverlapRatio"] <= 1 and rec["ConvergenceDuration"] > 0 and rec["StopReason"] in (1, 2)
