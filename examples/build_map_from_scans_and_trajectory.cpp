@@ -82,7 +82,10 @@ int main(int argc, char** argv)
         const bool online = onlineEnv && std::atoi(onlineEnv) != 0;
         const char* drainEnv = std::getenv("NIM_ONLINE_DRAIN"); // with NIM_ONLINE: wait for the update / paging threads after every scan
         const bool drain = drainEnv && std::atoi(drainEnv) != 0;
-        Mapper mapper(config, /*is3D*/ true, /*isOnline*/ online, /*isMapping*/ true, /*saveMapCellsOnHardDrive*/ false);
+        // NIM_2D=1: planar clouds (the constructor's is3D == false, Mapper.h:53): every scan has z == 0, poses move in the plane
+        const char* planarEnv = std::getenv("NIM_2D");
+        const bool is3D = !(planarEnv && std::atoi(planarEnv) != 0);
+        Mapper mapper(config, is3D, /*isOnline*/ online, /*isMapping*/ true, /*saveMapCellsOnHardDrive*/ false);
         const auto t0 = std::chrono::steady_clock::now();
         for (size_t i = 0; i < scans.size(); ++i) {
             const TimePoint stamp{std::chrono::nanoseconds(trajectory[i].ns)};

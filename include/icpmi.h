@@ -112,6 +112,9 @@ typedef struct {
     int32_t force_4dof;        /* PointToPlaneErrorMinimizer.force4DOF: yaw + translation only     */
     int32_t force_2d;          /* PointToPlaneErrorMinimizer.force2D on 3-D clouds: yaw + (tx, ty), */
                                /* residual = the 2-D dot with the top two rows of the normals       */
+    int32_t is_2d;             /* planar clouds (the mapper's is3D == false, Mapper.h:53): every    */
+                               /* point has z == 0; point-to-point solves the 2-D rotation,         */
+                               /* point-to-plane the force2D system, SurfaceNormal the 2 x 2 problem */
     /* transformation checkers */
     int32_t max_iterations;    /* CounterTransformationChecker.maxIterationCount, default 40      */
     int32_t use_differential;  /* DifferentialTransformationChecker present                       */

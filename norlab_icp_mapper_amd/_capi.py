@@ -39,6 +39,7 @@ class Config(C.Structure):
         ("minimizer", C.c_int32),
         ("force_4dof", C.c_int32),
         ("force_2d", C.c_int32),
+        ("is_2d", C.c_int32),
         ("max_iterations", C.c_int32),
         ("use_differential", C.c_int32),
         ("min_diff_rot", C.c_float),

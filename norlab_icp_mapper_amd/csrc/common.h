@@ -90,6 +90,7 @@ struct LoopCfg {
     int   ext;             // GenericDescriptor / Robust in the chain: the pair-sum kernel's EXT variant
     int   force_4dof;
     int   force_2d;        // (routes the pair sums through the EXT variant: three more sums, b of the 2-D residual)
+    int   is_2d;           // planar clouds: point-to-point solves the in-plane rotation in closed form
     int   max_iter;
     int   use_diff;
     float min_rot, min_trans;

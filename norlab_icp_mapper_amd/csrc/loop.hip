@@ -1110,7 +1110,16 @@ __device__ void solve_body(IcpState* __restrict__ st, const double* __restrict__
         for (int c = 0; c < 3; ++c)
             for (int r = 0; r < 3; ++r) H[3 * c + r] = (float)(tot[7 + 3 * c + r] - mqd[r] * tot[1 + c]);
         float R[9];
-        rotation_from_H(H, R);
+        if (lc.is_2d) {
+            // planar clouds: the proper in-plane rotation that maximises tr(R^T H), theta = atan2(H10 - H01, H00 + H11) (what the
+            // 2 x 2 SVD with its reflection repair returns), same operations as the oracle
+            const float a = H[0] + H[4], b2 = H[1] - H[3];
+            const float r = sqrtf(a * a + b2 * b2);
+            float cs = 1.f, sn = 0.f;
+            if (r > 0.f) { cs = a / r; sn = b2 / r; }
+            for (int i = 0; i < 9; ++i) R[i] = 0.f;
+            R[0] = cs; R[1] = sn; R[3] = -sn; R[4] = cs; R[8] = 1.f;
+        } else rotation_from_H(H, R);
         const float mp[3] = {(float)mpd[0], (float)mpd[1], (float)mpd[2]};
         const float mq[3] = {(float)mqd[0], (float)mqd[1], (float)mqd[2]};
         for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) Ts[4 * c + r] = R[3 * c + r];
@@ -1315,7 +1324,8 @@ LoopCfg make_loop_cfg(const icpmi_ctx* c, int fixed_iterations)
         if (lc.out_type[f] == ICPMI_OUT_GENERICDESCRIPTOR || lc.out_type[f] == ICPMI_OUT_ROBUST) lc.ext = 1;
     }
     lc.force_4dof = cfg.force_4dof != 0 && cfg.minimizer == ICPMI_MIN_POINT_TO_PLANE;
-    lc.force_2d = cfg.force_2d != 0 && cfg.minimizer == ICPMI_MIN_POINT_TO_PLANE;
+    lc.is_2d = cfg.is_2d != 0;
+    lc.force_2d = (cfg.force_2d != 0 || cfg.is_2d != 0) && cfg.minimizer == ICPMI_MIN_POINT_TO_PLANE;
     if (lc.force_2d) lc.ext = 1;
     if (fixed_iterations > 0) {
         lc.max_iter = fixed_iterations; lc.use_diff = 0; lc.use_bound = 0;

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void keep_kernel(const float* __restrict__ d2,
 // densities (may be null): `keepDensities` of the filter -- points per volume of the sphere that holds the neighbourhood around
 // its centroid: k / (4/3 pi r^3), r = the largest distance of a neighbour from the centroid (computeDensity)
 __global__ __launch_bounds__(128) void normals_kernel(const float4* __restrict__ map, const int* __restrict__ sidx, int64_t m, int k,
-                                                      float* __restrict__ normals3, float* __restrict__ densities)
+                                                      float* __restrict__ normals3, float* __restrict__ densities, int dim2)
 {
     const int64_t i = (int64_t)blockIdx.x * 128 + threadIdx.x;
     if (i >= m) return;
@@ -128,7 +128,19 @@ __global__ __launch_bounds__(128) void normals_kernel(const float4* __restrict__
     const double thr = 3.0 * 1.1920928955078125e-07 * wmax;
     const int rank = (wmax > 0) ? ((fabs(w0) > thr) + (fabs(w1) > thr) + (fabs(w2) > thr)) : 0;
     float nx = 1.f, ny = 0.f, nz = 0.f; // upstream's degenerate answer: eigenvectors = identity
-    if (rank >= 2) {
+    if (dim2) {
+        // planar cloud (z == 0: the rotations with the z axis saw zero off-diagonals): the smaller eigenvector of the plane's pair;
+        // upstream needs rank + 1 >= featDim - 1 = 2 there, i.e. rank >= 1
+        const double wm2 = fmax(fabs(w0), fabs(w1));
+        const double thr2 = 2.0 * 1.1920928955078125e-07 * wm2;
+        const int rank2 = (wm2 > 0) ? ((fabs(w0) > thr2) + (fabs(w1) > thr2)) : 0;
+        if (rank2 >= 1) {
+            const int e2 = w1 < w0 ? 1 : 0;
+            nx = (float)(e2 == 0 ? Q[0][0] : Q[0][1]);
+            ny = (float)(e2 == 0 ? Q[1][0] : Q[1][1]);
+            nz = 0.f;
+        }
+    } else if (rank >= 2) {
         int e = 0;
         double wm = w0;
         if (w1 < wm) { wm = w1; e = 1; }
@@ -636,7 +648,7 @@ icpmi_status ops_surface_normals(icpmi_ctx* c, const float* pts4, int64_t m, int
     HIP_TRY(c, d_n.alloc((size_t)m * 3));
     if (densities) HIP_TRY(c, d_dens.alloc((size_t)m));
     hipLaunchKernelGGL(normals_kernel, dim3((int)((m + 127) / 128)), dim3(128), 0, tc->stream, tc->d_map_sorted, tc->d_sidx, m, knn, d_n,
-                       densities ? d_dens.p : (float*)nullptr);
+                       densities ? d_dens.p : (float*)nullptr, c->cfg.is_2d);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(normals3, d_n, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost, tc->stream);
     if (e == hipSuccess && densities) e = hipMemcpyAsync(densities, d_dens, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, tc->stream);
@@ -802,7 +814,7 @@ static icpmi_status surface_normals_dev(icpmi_ctx* c, const float4* d_pts, int64
     if (s != ICPMI_OK) { c->last_error = tc->last_error; return s; }
     // rows of d_sidx follow the query order = the caller's order, so the normals land in place
     hipLaunchKernelGGL(normals_kernel, dim3((int)((m + 127) / 128)), dim3(128), 0, tc->stream, tc->d_map_sorted, tc->d_sidx, m, knn, d_normals3,
-                       (float*)nullptr);
+                       (float*)nullptr, c->cfg.is_2d);
     HIP_TRY(c, hipGetLastError());
     if (tc->stream != c->stream) HIP_TRY(c, hipStreamSynchronize(tc->stream));
     return ICPMI_OK;

@@ -35,6 +35,14 @@ GpuICPSequence::GpuICPSequence(int device)
 
 GpuICPSequence::~GpuICPSequence() { icpmi_destroy(h); }
 
+// the mapper's is3D == false (Mapper.h:53): every cloud is planar (z == 0); kept across loadFromYamlNode / setDefault
+void GpuICPSequence::setPlanar(bool on)
+{
+    planar = on;
+    cfg.is_2d = on ? 1 : 0;
+    recreate();
+}
+
 void GpuICPSequence::recreate()
 {
     // the handle is created once and re-configured afterwards: filters, modules and transformations
@@ -51,6 +59,7 @@ void GpuICPSequence::setDefault()
     const int dev = cfg.device;
     icpmi_config_default(&cfg);
     cfg.device = dev;
+    cfg.is_2d = planar ? 1 : 0;
     genericDescName.clear();
     cfg.n_outlier = 1;
     cfg.outlier[0].type = ICPMI_OUT_TRIMMEDDIST;
@@ -89,6 +98,7 @@ void GpuICPSequence::loadFromYamlNode(const yaml::Node& icp)
     const int dev = cfg.device;
     icpmi_config_default(&cfg);
     cfg.device = dev;
+    cfg.is_2d = planar ? 1 : 0;
     if (icp.IsMap())
         for (const auto& kv : icp.map) {
             static const char* valid[] = {"matcher", "outlierFilters", "errorMinimizer", "transformationCheckers", "inspector", "logger",

@@ -57,6 +57,8 @@ public:
     void uploadMapScalar(const std::vector<float>& scalar);   // the tracked scalar descriptor of the resident map
     std::vector<float> downloadMapScalar() const;
     int64_t residentMapSize() const;
+    void setPlanar(bool on);                           // 2-D clouds (z == 0): planar minimisers and normals
+    bool isPlanar() const { return planar; }
     const std::string& genericDescriptorName() const { return genericDescName; } // GenericDescriptorOutlierFilter.descName, or empty
     bool chainNeedsReadingNormals() const;             // SurfaceNormalOutlierFilter in the chain
     // true when the chain filters the reading inside operator() (readingDataPointsFilters / readingStepDataPointsFilters):
@@ -83,6 +85,7 @@ private:
     icpmi_stats lastStats{};
     size_t stagedPoints = 0;                           // size of the scan kept on the GPU by registerWithPrior
     std::string genericDescName;                       // GenericDescriptorOutlierFilter.descName (empty: no such filter)
+    bool planar = false;                               // 2-D mapping (is3D == false): icpmi_config::is_2d
     ErrorMinimizerView minimizerView{this};
 };
 

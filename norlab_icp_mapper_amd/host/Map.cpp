@@ -15,7 +15,9 @@ namespace nim {
 Map::Map(bool is3D_, bool isOnline_, bool saveCellsOnHardDrive, GpuICPSequence& icp_, std::mutex& icpMapLock_)
     : is3D(is3D_), isOnline(isOnline_), icp(icp_), icpMapLock(icpMapLock_), transformation(icp_.handle())
 {
-    if (!is3D) throw InvalidParameter("the GPU path is 3-D only (is3D must be true)");
+    // is3D == false: clouds are planar (z == 0 in the 4 x N layout this host keeps for both cases); cells are binned over
+    // two axes (below), the registration core switches to its planar minimisers and normals (icpmi_config::is_2d)
+    if (!is3D) icp.setPlanar(true);
     if (saveCellsOnHardDrive) throw InvalidParameter("HardDriveCellManager is out of scope (DESIGN.md section 8); use RAM cells");
     cellManager.reset(new RAMCellManager());
     if (isOnline) updateThread = std::thread(&Map::updateThreadFunction, this);

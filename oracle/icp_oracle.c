@@ -841,7 +841,7 @@ int orc_minimize_ex(int minimizer, int force_4dof, const float* reading4, int64_
                     for (int r = 0; r < 6; ++r) A[6 * c + r] += wf * F[r];
                     b[c] -= wf * dot;
                 }
-                if (force_4dof == 2) {
+                if ((force_4dof & 3) == 2) {
                     const float dot2 = dx * nn[0] + dy * nn[1];
                     for (int c = 0; c < 3; ++c) b2d[c] -= ((double)we * F[2 + c]) * dot2;
                 }
@@ -863,6 +863,16 @@ int orc_minimize_ex(int minimizer, int force_4dof, const float* reading4, int64_
         for (int r = 0; r < 3; ++r) { mp[r] = sp[r] * iw; mq[r] = sq[r] * iw; }
         for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) H[3 * c + r] = (float)(Hs[3 * c + r] - mq[r] * sp[c]);
         if (A_out) for (int i = 0; i < 9; ++i) A_out[i] = H[i];
+        if (force_4dof & 4) {
+            /* planar clouds: the proper rotation that maximises tr(R^T H2) over the plane, R(theta) with
+             * theta = atan2(H10 - H01, H00 + H11) -- what the 2 x 2 SVD with its reflection repair returns -- in closed form */
+            const float a = H[0] + H[4], b2 = H[1] - H[3]; /* H(1,0) = H[3*0+1], H(0,1) = H[3*1+0] */
+            const float r = sqrtf(a * a + b2 * b2);
+            float cs = 1.f, sn = 0.f;
+            if (r > 0.f) { cs = a / r; sn = b2 / r; }
+            for (int i = 0; i < 9; ++i) R[i] = 0.f;
+            R[0] = cs; R[1] = sn; R[3] = -sn; R[4] = cs; R[8] = 1.f;
+        } else
         orc_rotation_from_H(H, R);
         const float mpf[3] = { (float)mp[0], (float)mp[1], (float)mp[2] };
         const float mqf[3] = { (float)mq[0], (float)mq[1], (float)mq[2] };
@@ -876,12 +886,12 @@ int orc_minimize_ex(int minimizer, int force_4dof, const float* reading4, int64_
     for (int i = 0; i < 6; ++i) bf[i] = (float)b[i];
     if (A_out) memcpy(A_out, A, sizeof A);
     if (b_out) memcpy(b_out, b, sizeof b);
-    if (force_4dof == 2) {
+    if ((force_4dof & 3) == 2) {
         float A3[9], b3[3], x3[3];
         for (int c = 0; c < 3; ++c) { b3[c] = (float)b2d[c]; for (int r = 0; r < 3; ++r) A3[3 * c + r] = Af[6 * (2 + c) + (2 + r)]; }
         orc_solve_n(3, A3, b3, x3);
         x[0] = 0.f; x[1] = 0.f; x[2] = x3[0]; x[3] = x3[1]; x[4] = x3[2]; x[5] = 0.f;
-    } else if (force_4dof) {
+    } else if ((force_4dof & 3) == 1) {
         float A4[16], b4[4], x4[4];
         for (int c = 0; c < 4; ++c) { b4[c] = bf[2 + c]; for (int r = 0; r < 4; ++r) A4[4 * c + r] = Af[6 * (2 + c) + (2 + r)]; }
         orc_solve_n(4, A4, b4, x4);
@@ -1044,7 +1054,7 @@ int orc_icp_register(orc_icp* s, const float* scan4, int64_t n, const float* sca
                                      &robust_scale, w, &st->trimmed_limit);
         if (err) break;
         float T_step[16];
-        err = orc_minimize_ex(cfg->minimizer, cfg->force_2d ? 2 : (cfg->force_4dof ? 1 : 0), step, n, s->map4, s->normals3, ids, d2, w, k, T_step, NULL, NULL, NULL, st);
+        err = orc_minimize_ex(cfg->minimizer, cfg->is_2d ? (2 | 4) : (cfg->force_2d ? 2 : (cfg->force_4dof ? 1 : 0)), step, n, s->map4, s->normals3, ids, d2, w, k, T_step, NULL, NULL, NULL, st);
         if (err) break;
         mat4_mul(T_step, T_iter, T_iter);
         ++st->iterations;
@@ -1102,7 +1112,18 @@ int orc_icp_register(orc_icp* s, const float* scan4, int64_t n, const float* sca
 void orc_surface_normals(const float* pts4, int64_t m, int knn, float* normals3, int nthreads) { orc_surface_normals_ex(pts4, m, knn, normals3, NULL, nthreads); }
 /* densities (may be NULL): keepDensities -- knn / (4/3 pi r^3), r = the largest distance of a neighbour from the centroid of the
  * neighbourhood (SurfaceNormalDataPointsFilter::computeDensity: NN.colwise().norm().maxCoeff() on the centred neighbours) */
+static void orc_surface_normals_impl(const float* pts4, int64_t m, int knn, float* normals3, float* densities, int nthreads, int dim2);
 void orc_surface_normals_ex(const float* pts4, int64_t m, int knn, float* normals3, float* densities, int nthreads)
+{
+    orc_surface_normals_impl(pts4, m, knn, normals3, densities, nthreads, 0);
+}
+/* 2-D clouds (features 3 x N upstream; here z == 0): SurfaceNormalDataPointsFilter diagonalises the 2 x 2 covariance; needs
+ * rank + 1 >= featDim - 1 = 2, i.e. rank >= 1; the normal is the eigenvector of the smaller eigenvalue, in the plane */
+void orc_surface_normals_2d(const float* pts4, int64_t m, int knn, float* normals3, int nthreads)
+{
+    orc_surface_normals_impl(pts4, m, knn, normals3, NULL, nthreads, 1);
+}
+static void orc_surface_normals_impl(const float* pts4, int64_t m, int knn, float* normals3, float* densities, int nthreads, int dim2)
 {
     orc_kdtree* t = orc_kdtree_build(pts4, m, 3, knn > 1 ? knn : 8);
     int32_t* ids = (int32_t*)malloc((size_t)m * knn * sizeof(int32_t));
@@ -1132,6 +1153,16 @@ void orc_surface_normals_ex(const float* pts4, int64_t m, int knn, float* normal
         if (densities) { const double rr = sqrt(rmax2); densities[i] = (float)((double)real / ((4.0 / 3.0) * 3.14159265358979323846 * (rr * rr * rr))); }
         double w[3], Q[9];
         jacobi_eig_sym(3, C, w, Q);
+        if (dim2) {
+            /* z == 0: the (0,2) and (1,2) rotations of the Jacobi sweep see zero off-diagonals, w[0], w[1] are the plane's pair */
+            const double wm2 = fmax(fabs(w[0]), fabs(w[1]));
+            int rank2 = 0;
+            for (int e = 0; e < 2; ++e) if (fabs(w[e]) > 2.0 * FLT_EPSILON * wm2 && wm2 > 0) ++rank2;
+            if (rank2 < 1) { normals3[3 * i] = 1.f; normals3[3 * i + 1] = 0.f; normals3[3 * i + 2] = 0.f; continue; }
+            const int e2 = w[1] < w[0] ? 1 : 0;
+            normals3[3 * i] = (float)Q[3 * e2]; normals3[3 * i + 1] = (float)Q[3 * e2 + 1]; normals3[3 * i + 2] = 0.f;
+            continue;
+        }
         /* rank test of upstream: needs rank >= 2, otherwise eigenvalues 0 / eigenvectors identity */
         double wmax = fmax(fabs(w[0]), fmax(fabs(w[1]), fabs(w[2])));
         int rank = 0;

@@ -79,6 +79,7 @@ typedef struct {
     int   nthreads;          /* OpenMP threads for the kNN query loop (>=1)       */
     int   force_4dof;        /* PointToPlaneErrorMinimizer.force4DOF               */
     int   force_2d;          /* PointToPlaneErrorMinimizer.force2D                 */
+    int   is_2d;             /* planar clouds (z == 0 everywhere; the mapper's is3D == false): 2-D minimisers          */
 } orc_config;
 
 typedef struct {
@@ -168,6 +169,8 @@ int orc_icp_register(orc_icp* s, const float* scan4, int64_t n, const float* sca
 /* SurfaceNormalDataPointsFilter: kNN (self included) + smallest-eigenvector normal */
 void orc_surface_normals(const float* pts4, int64_t m, int knn, float* normals3, int nthreads);
 void orc_surface_normals_ex(const float* pts4, int64_t m, int knn, float* normals3, float* densities, int nthreads);
+/* planar clouds: the normal is the smaller eigenvector of the 2 x 2 covariance of (x, y), z component 0 */
+void orc_surface_normals_2d(const float* pts4, int64_t m, int knn, float* normals3, int nthreads);
 /* PointDistanceMapperModule::inPlaceUpdateMap keep-mask (PointDistanceMapperModule.cpp:28-50):
  * keep[i] = 1 iff exact NN (self match NOT allowed, no radius) has d2 >= minDist^2 */
 void orc_point_distance_keep(const float* map4, int64_t m, const float* in4, int64_t n, float min_dist,

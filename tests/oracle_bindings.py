@@ -24,7 +24,7 @@ class Config(C.Structure):
                 ("outlier", Outlier * 8), ("max_iterations", C.c_int), ("use_differential", C.c_int),
                 ("min_diff_rot", C.c_float), ("min_diff_trans", C.c_float), ("smooth_length", C.c_int),
                 ("use_bound", C.c_int), ("max_rot_norm", C.c_float), ("max_trans_norm", C.c_float),
-                ("nthreads", C.c_int), ("force_4dof", C.c_int), ("force_2d", C.c_int)]
+                ("nthreads", C.c_int), ("force_4dof", C.c_int), ("force_2d", C.c_int), ("is_2d", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -82,6 +82,7 @@ def load():
     lib.orc_icp_register.argtypes = [_P, _P, C.c_int64, _P, _P, C.POINTER(Stats)]
     lib.orc_surface_normals.argtypes = [_P, C.c_int64, C.c_int, _P, C.c_int]
     lib.orc_surface_normals_ex.argtypes = [_P, C.c_int64, C.c_int, _P, _P, C.c_int]
+    lib.orc_surface_normals_2d.argtypes = [_P, C.c_int64, C.c_int, _P, C.c_int]
     lib.orc_point_distance_keep.argtypes = [_P, C.c_int64, _P, C.c_int64, C.c_float, _P, C.c_int]
     lib.orc_cell_ids.argtypes = [_P, C.c_int64, C.c_float, _P]
     lib.orc_voxel_keep_first.argtypes = [_P, C.c_int64, C.c_float, _P]
@@ -100,7 +101,7 @@ def load():
 
 def make_config(knn=1, max_dist=math.inf, minimizer=MIN_POINT_TO_PLANE, outliers=(), max_iterations=40,
                 use_differential=0, min_diff_rot=1e-3, min_diff_trans=1e-3, smooth_length=3, use_bound=0,
-                max_rot_norm=1.0, max_trans_norm=1.0, nthreads=1, force_4dof=0, force_2d=0):
+                max_rot_norm=1.0, max_trans_norm=1.0, nthreads=1, force_4dof=0, force_2d=0, is_2d=0):
     cfg = Config()
     cfg.knn, cfg.max_dist, cfg.minimizer = knn, max_dist, minimizer
     cfg.n_outlier = len(outliers)
@@ -115,6 +116,7 @@ def make_config(knn=1, max_dist=math.inf, minimizer=MIN_POINT_TO_PLANE, outliers
     cfg.nthreads = nthreads
     cfg.force_4dof = force_4dof
     cfg.force_2d = force_2d
+    cfg.is_2d = is_2d
     return cfg
 
 
@@ -250,8 +252,11 @@ class OracleICP:
         return err, T_from_c(T)
 
 
-def surface_normals(cloud, knn=5, nthreads=1, with_densities=False):
+def surface_normals(cloud, knn=5, nthreads=1, with_densities=False, planar=False):
     lib = load(); cloud = _f32(cloud); out = np.empty((cloud.shape[0], 3), dtype=np.float32)
+    if planar:  # 2-D clouds (z == 0): the smaller eigenvector of the 2 x 2 covariance
+        lib.orc_surface_normals_2d(cloud.ctypes.data, cloud.shape[0], knn, out.ctypes.data, nthreads)
+        return out
     if not with_densities:
         lib.orc_surface_normals(cloud.ctypes.data, cloud.shape[0], knn, out.ctypes.data, nthreads)
         return out

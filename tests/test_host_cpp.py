@@ -2,6 +2,7 @@
 over the C ABI).  CPU part: the self-test executable.  GPU part: the example harness replayed against
 an independent Python restatement of Mapper::processInput on the same library, and the known answer
 of the bundled configuration (Identity minimiser => trajectory unchanged)."""
+import math
 import os
 import subprocess
 
@@ -219,6 +220,90 @@ def test_example_harness_matches_python_replay(tmp_path):
     assert pos4.shape == pos.shape
     for i, t in enumerate(truth):
         assert np.linalg.norm(pos4[i] - t[:3, 3]) < 0.05, (i, pos4[i], t[:3, 3])
+
+
+@pytest.mark.gpu
+def test_planar_mapping_harness(tmp_path):
+    """is3D == false (Mapper.h:53): planar scans through the C++ Mapper (NIM_2D=1) -- 2-D normals from the post filter, the planar
+    point-to-plane system, two-axis cell paging -- against a replay of the same steps through the C ABI in planar mode, and
+    against the ground truth."""
+    import norlab_icp_mapper_amd as amd
+    from test_oracle_ext import _planar_scene
+    _build_host()
+    tmp = str(tmp_path)
+    os.makedirs(os.path.join(tmp, "scans"))
+    full, _, _ = _planar_scene(n_map=40000, n_scan=10, seed=31)
+    rng = np.random.default_rng(5)
+    rows, scans, truth = [], [], []
+    for s in range(5):
+        yaw, t = 0.02 * s, np.array([0.3 * s, 0.1 * s])
+        c, sn = math.cos(yaw), math.sin(yaw)
+        T_true = np.eye(4); T_true[:2, :2] = [[c, -sn], [sn, c]]; T_true[:2, 3] = t
+        idx = rng.permutation(full.shape[0])[:9000]
+        pts = full[idx, :2].astype(np.float64) + rng.normal(0, 0.005, (9000, 2))
+        local = (pts - t) @ T_true[:2, :2]                                  # R^T (p - t)
+        local = np.c_[local, np.zeros(len(local))].astype(np.float32)
+        e = np.eye(4)
+        if s:
+            ey, et = 0.004, np.array([0.02, -0.015])
+            e[:2, :2] = [[math.cos(ey), -math.sin(ey)], [math.sin(ey), math.cos(ey)]]; e[:2, 3] = et
+        T_prior = e @ T_true
+        rows.append([1700000000, 100000000 * s, *T_prior[:3, 3], *_quat(T_prior[:3, :3])])
+        _write_vtk(os.path.join(tmp, "scans", f"cloud_{s:03d}.vtk"), local)
+        scans.append(local); truth.append(T_true)
+    with open(os.path.join(tmp, "trajectory.csv"), "w") as f:
+        f.write("header.stamp.sec,header.stamp.nanosec,header.frame_id,child_frame_id,pose.pose.position.x,pose.pose.position.y,"
+                "pose.pose.position.z,pose.pose.orientation.x,pose.pose.orientation.y,pose.pose.orientation.z,pose.pose.orientation.w,pose.covariance\n")
+        for r in rows:
+            f.write(f"{r[0]},{r[1]},map,base_link," + ",".join(repr(float(v)) for v in r[2:]) + ",[0. 0. 0.]\n")
+    priors = [_quat_T(np.array(r[2:], dtype=np.float64)) for r in rows]
+    cfg = os.path.join(tmp, "config.yaml")
+    open(cfg, "w").write(P2PLANE_CONFIG.replace("maxDist: 2.0", "maxDist: 1.0").replace("minDistNewPoint: 0.15", "minDistNewPoint: 0.05"))
+    traj_out = os.path.join(tmp, "traj.vtk")
+    out = subprocess.run([os.path.join(PKG, "build_map_from_scans_and_trajectory"), tmp, cfg, traj_out], capture_output=True, text=True,
+                         timeout=600, env=dict(os.environ, NIM_2D="1"))
+    assert out.returncode == 0, out.stderr + out.stdout
+    pos, desc = _read_vtk(traj_out)
+    assert pos.shape[0] == len(scans) and np.all(pos[:, 2] == 0)
+    # the same steps through the C ABI, planar mode
+    icp = amd.ICPSequence(minimizer=2, max_dist=1.0, outliers=[(4, 0.85)], max_iterations=40, use_differential=1, is_2d=1)
+
+    def h4(p):
+        o = np.ones((p.shape[0], 4), dtype=np.float32); o[:, :3] = p; return o
+
+    def post_and_set(map_pts, pose):
+        inv = np.linalg.inv(pose.astype(np.float64)).astype(np.float32)
+        sensor = icp.transform(inv, map_pts)
+        sensor[:, 2] = 0                                             # exact by construction: planar poses keep z
+        normals_s = icp.surfaceNormals(sensor, knn=10)
+        back, normals = icp.transform(pose, sensor, normals_s)
+        icp.setMap(back, normals)
+        return back
+
+    map_pts = None
+    for i, (s, prior) in enumerate(zip(scans, priors)):
+        inp = icp.transform(prior, h4(s))
+        if map_pts is None:
+            corrected = prior
+            map_pts = post_and_set(inp, corrected)
+        else:
+            corr = icp(inp)
+            corrected = (corr.astype(np.float32) @ prior).astype(np.float32)
+            moved = icp.transform(corr, inp)
+            keep = icp.pointDistanceKeep(map_pts, moved, 0.05)
+            map_pts = post_and_set(np.concatenate([map_pts, moved[keep]], 0), corrected)
+        T = np.eye(4, dtype=np.float32)                              # a 2-D trajectory stores the two in-plane axes
+        ox, oy = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        ox[:len(desc["orientationX"][i])] = desc["orientationX"][i]; oy[:len(desc["orientationY"][i])] = desc["orientationY"][i]
+        assert "orientationZ" not in desc and ox[2] == 0 and oy[2] == 0
+        T[:3, 0], T[:3, 1], T[:3, 3] = ox, oy, pos[i]
+        dt, dr = amd.synth.pose_error(T, corrected)
+        assert dt < 2e-4 and dr < 2e-4, (i, dt, dr)
+        dt, dr = amd.synth.pose_error(T, truth[i])
+        assert dt < 1e-2 and dr < 3e-3, (i, dt, dr)                  # priors are off by 2.5 cm / 4e-3 rad
+        assert np.allclose(T[2, :3], [0, 0, 1], atol=1e-6) and np.allclose(T[:3, 2], [0, 0, 1], atol=1e-6)
+    mp, mdesc = _read_vtk(os.path.join(tmp, "map.vtk"))
+    assert np.all(mp[:, 2] == 0) and "normals" in mdesc and np.all(mdesc["normals"][:, 2] == 0)
 
 
 BUNDLED_LIKE_CONFIG = """

@@ -42,7 +42,7 @@ def test_config_defaults_and_struct_layout():
     assert cfg.min_diff_rot == pytest.approx(1e-3) and cfg.smooth_length == 3 and cfg.use_graph == 1
     # the ctypes mirrors must have the C layout: 8-byte aligned int64 members, trailing reserved block
     assert C.sizeof(_capi.Stats) == 72
-    assert C.sizeof(_capi.Config) == 5 * 4 + 8 * 20 + 14 * 4 + 8 * 4
+    assert C.sizeof(_capi.Config) == 5 * 4 + 8 * 20 + 15 * 4 + 8 * 4
     assert cfg.force_4dof == 0
 
 

@@ -219,3 +219,45 @@ def test_force_2d_is_the_planar_system_of_upstream(oracle):
     assert x[2] == pytest.approx(yaw, abs=3e-4)
     np.testing.assert_allclose(T[:2, 3], t[:2], atol=5e-4)
     assert T[2, 3] == 0 and np.allclose(T[2, :3], [0, 0, 1], atol=1e-7) and np.allclose(T[:3, 2], [0, 0, 1], atol=1e-7)
+
+
+def _planar_scene(n_map=4000, n_scan=1500, seed=9):
+    """a room outline with two round pillars, z = 0; the scan is the same outline seen from a moved pose, with noise"""
+    rng = np.random.default_rng(seed)
+    def outline(n):
+        t = rng.random(n)
+        side = rng.integers(0, 6, n)
+        x = np.where(side == 0, -6 + 12 * t, np.where(side == 1, 6.0, np.where(side == 2, 6 - 12 * t, np.where(side == 3, -6.0, 0.0))))
+        y = np.where(side == 0, -4.0, np.where(side == 1, -4 + 8 * t, np.where(side == 2, 4.0, np.where(side == 3, 4 - 8 * t, 0.0))))
+        a = 2 * np.pi * t
+        x = np.where(side == 4, 2.0 + 0.4 * np.cos(a), np.where(side == 5, -3.0 + 0.6 * np.cos(a), x))
+        y = np.where(side == 4, 1.0 + 0.4 * np.sin(a), np.where(side == 5, -1.5 + 0.6 * np.sin(a), y))
+        return np.c_[x, y]
+    mp = outline(n_map) + rng.normal(0, 0.005, (n_map, 2))
+    yaw, t = 0.03, np.array([0.08, -0.05])
+    c, s = math.cos(yaw), math.sin(yaw)
+    R = np.array([[c, -s], [s, c]])
+    sc = (outline(n_scan) + rng.normal(0, 0.005, (n_scan, 2)) - t) @ R          # = R^T (p - t): the scan in the moved sensor frame
+    to4 = lambda p: np.c_[p, np.zeros(len(p)), np.ones(len(p))].astype(np.float32)
+    T = np.eye(4); T[:2, :2] = R; T[:2, 3] = t
+    return to4(mp), to4(sc), T
+
+
+def test_planar_mode_normals_and_registration(oracle):
+    from norlab_icp_mapper_amd import synth
+    mp, sc, T_gt = _planar_scene()
+    nrm = oracle.surface_normals(mp, knn=8, nthreads=4, planar=True)
+    assert np.all(nrm[:, 2] == 0) and np.allclose(np.linalg.norm(nrm, axis=1), 1, atol=1e-6)
+    wall = (np.abs(mp[:, 1] + 4) < 0.02) & (np.abs(mp[:, 0]) < 5)                      # the y = -4 wall: normal along y
+    assert np.median(np.abs(nrm[wall, 1])) > 0.995 and np.quantile(np.abs(nrm[wall, 1]), 0.05) > 0.9     # 5 mm noise over ~4 cm neighbourhoods
+    # the 3-D filter on the same cloud can only answer z (the zero eigenvalue): that is why planar clouds need their own
+    assert np.abs(oracle.surface_normals(mp, knn=8, nthreads=4)[wall, 2]).min() > 0.99
+    for minimizer in (1, 2):
+        o = oracle.OracleICP(oracle.make_config(minimizer=minimizer, max_dist=1.0, outliers=[(4, 0.9)], max_iterations=40, use_differential=1,
+                                                nthreads=4, is_2d=1))
+        o.setMap(mp, nrm)
+        err, T = o(sc)
+        assert err == 0
+        dt, dr = synth.pose_error(T, T_gt)
+        assert dt < (1e-2 if minimizer == 1 else 5e-3) and dr < (6e-3 if minimizer == 1 else 2e-3), (minimizer, dt, dr)
+        assert T[2, 3] == 0 and np.allclose(T[2, :3], [0, 0, 1], atol=1e-7) and np.allclose(T[:3, 2], [0, 0, 1], atol=1e-7)
