@@ -116,6 +116,7 @@ class ShardedMapper:
             set_map = staticmethod(lambda cloud, normals: icp.setMap(cloud, normals))
             keep = staticmethod(lambda m, c, d: icp.pointDistanceKeep(m, c, d))
             normals = staticmethod(lambda cloud, knn: icp.surfaceNormals(cloud, knn))
+            transform = staticmethod(lambda T, cloud: icp.transform(T, cloud))
         return _B
 
     @staticmethod
@@ -219,10 +220,14 @@ class ShardedMapper:
         scan = np.ascontiguousarray(scan, dtype=np.float32)
         if getattr(self.backend, "resident", False):
             return self._epoch_resident(scan, np.asarray(prior, dtype=np.float32))
-        in_map = self._apply(prior, scan)                                    # Mapper.cpp:197
+        # RigidTransformation::compute of the backend when it has one (the device's fmaf chain, bit for bit what the resident path
+        # applies), numpy otherwise.  The reference moves the scan TWICE -- by the prior (Mapper.cpp:197), then the registered
+        # cloud by the correction (:221) -- not once by their product: the same two steps here.
+        move = getattr(self.backend, "transform", None) or self._apply
+        in_map = move(np.asarray(prior, dtype=np.float32), scan)             # Mapper.cpp:197
         correction = self.backend.register(in_map) if self.map.shape[0] else np.eye(4, dtype=np.float32)
         self.pose = (np.asarray(correction, dtype=np.float64) @ np.asarray(prior, dtype=np.float64)).astype(np.float32)  # :215
-        placed = self._apply(self.pose, scan)                                # :221
+        placed = move(np.asarray(correction, dtype=np.float32), in_map)      # :221
         mask = self.backend.keep(self.map, placed, self.min_dist) if self.map.shape[0] else np.ones(placed.shape[0], bool)
         mine = placed[mask]
         if dist.is_available() and dist.is_initialized():

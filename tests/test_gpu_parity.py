@@ -557,11 +557,13 @@ def test_sharded_mapper_resident_backend_matches_host_backend(amd, mid_scene):
         ph, mine_h, app_h = host.epoch(scan, np.eye(4))
         pr, mine_r, app_r = res.epoch(scan, np.eye(4))
         dt, dr = amd.synth.pose_error(ph, pr)
-        assert dt < 1e-4 and dr < 1e-4, (dt, dr)
-        assert abs(mine_h - mine_r) <= max(3, mine_h // 200) and abs(app_h - app_r) <= max(3, app_h // 200), (mine_h, mine_r, app_h, app_r)
+        assert dt < 1e-6 and dr < 1e-6, (dt, dr)
+        # both backends place the scan by the same two device transforms (prior, then correction: Mapper.cpp:197, :221) and
+        # decide against the same map: the accepted sets are identical -- no allowance
+        assert mine_h == mine_r and app_h == app_r, (mine_h, mine_r, app_h, app_r)
     got = res.get_map()
     assert got.shape[0] == res._resident_points and np.array_equal(got[: half.shape[0]], half)
-    assert abs(got.shape[0] - host.map.shape[0]) <= max(6, host.map.shape[0] // 1000)
+    assert np.array_equal(got, host.map)
     # the keep decision itself, against the composed operator on the same placed cloud: identical masks
     corr = ricp.registerWithPrior(scans[0], np.eye(4))
     mask, placed = ricp.stagedPointDistanceKeep(corr, 0.3)
