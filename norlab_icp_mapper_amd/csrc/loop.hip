@@ -1876,6 +1876,7 @@ icpmi_status loop_single_step(icpmi_ctx* c, int64_t n, const LoopCfg& lc, const 
                               double sums[32], icpmi_stats* stats)
 {
     if (ensure_loop_buffers(c, n, lc.k) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (chain_has_vartrimmed(lc)) { VtBuffers vb; if (vt_buffers(c, n * lc.k, &vb) != ICPMI_OK) return ICPMI_ERR_HIP; } // reserved here: enqueue_selection cannot fail
     DevBuf<float> d_Tstep; // [0,16): T_step out, [16,32): T_iter in
     DevBuf<double> d_sums;
     HIP_TRY(c, d_Tstep.alloc(32));
@@ -1939,6 +1940,7 @@ icpmi_status loop_outlier_weights(icpmi_ctx* c, const LoopCfg& lc, const float* 
     }
     const int64_t count = (int64_t)k * n;
     if (ensure_loop_buffers(c, n, k) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (chain_has_vartrimmed(lc)) { VtBuffers vb; if (vt_buffers(c, (int64_t)k * n, &vb) != ICPMI_OK) return ICPMI_ERR_HIP; }
     LoopCfg l1 = lc; l1.k = k;
     hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(64), 0, c->stream, c->d_state, (const float*)nullptr, 0u, (unsigned*)nullptr);
     HIP_TRY(c, hipMemsetAsync(c->d_selhist, 0, ICPMI_SELHIST_WORDS * sizeof(unsigned), c->stream));
