@@ -24,6 +24,7 @@ icpmi_comm_id ShardedMapper::createCommunicatorId()
 void ShardedMapper::initCommunicator(const icpmi_comm_id& id, int nRanks, int rank)
 {
     GpuICPSequence::check(icp.handle(), icpmi_comm_init(icp.handle(), &id, nRanks, rank));
+    ranks = nRanks;
 }
 
 bool ShardedMapper::setMap(const DataPoints& map)
@@ -43,8 +44,10 @@ Mat4 ShardedMapper::processScan(const DataPoints& scan, const Mat4& estimatedPos
 {
     const Mat4 correction = icp.registerWithPrior(scan, estimatedPose);     // Mapper.cpp:197,213: identity while there is no map
     const Mat4 corrected = correction * estimatedPose;                       // :215
-    // the merged set comes back once, for the cell manager: the bound is what all ranks can contribute
-    std::vector<float> merged(4 * (size_t)(64 * (scan.getNbPoints() + 1)));
+    // the merged set comes back once, for the cell manager: at most what all ranks can contribute (every rank its whole scan;
+    // scans of the ranks are taken to be about this size -- a larger merge reports ICPMI_ERR_INVALID_ARG, nothing is lost)
+    const size_t need = 4 * (size_t)(2 * (size_t)ranks * (scan.getNbPoints() + 1));
+    if (merged.size() < need) merged.resize(need);
     int64_t mergedN = 0;
     icpmi_status s = icpmi_staged_merge_allgather(icp.handle(), correction.data(), minDist, normalsKnn, &acceptedLocal, &appended, &residentSize,
                                                   merged.data(), (int64_t)(merged.size() / 4), &mergedN);

@@ -4,6 +4,7 @@
 // over RCCL inside the library (icpmi_staged_merge_allgather) and merged into every replica, then binned into 20 m cells for
 // this rank's CellManager (Map.cpp:206-229, RAMCellManager.cpp:13-16).  No reference analogue: the reference is one process.
 #pragma once
+#include <vector>
 #include <memory>
 #include <string>
 
@@ -37,6 +38,8 @@ private:
     float minDist;
     int normalsKnn;
     int64_t residentSize = 0, acceptedLocal = 0, appended = 0;
+    int ranks = 1;                 // size of the communicator (1 until initCommunicator)
+    std::vector<float> merged;     // what all ranks accepted in the last epoch, for the cell manager (kept between epochs)
 };
 
 } // namespace nim
