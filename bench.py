@@ -101,8 +101,8 @@ def time_registrations(torch, icp, d_scan, steps, warmup):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)  # 0.2 s of timed region at ~1 ms per registration: long enough for an outside sampler to see
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--chain", default="p2p", choices=list(CHAINS))
     ap.add_argument("--map-points", type=int, default=M_MAP)
     ap.add_argument("--scan-points", type=int, default=N_SCAN)
