@@ -708,25 +708,16 @@ __global__ __launch_bounds__(NN_BLOCK) void nnk_ml_kernel(const float4* __restri
             else if (key < pk[i]) { pk[i] = key; ps[i] = sidx; }
         }
     };
-    // merged <- the KMAX smallest of (merged U all private lists); private lists cleared
+    // merged <- the KMAX smallest of (merged U all private lists); private lists cleared.  A (G + 1)-way merge: every round takes
+    // the smaller of the group minimum of the private heads (shuffle butterfly) and the head of the OLD merged list, which all
+    // lanes hold (r1 pushed the old merged entries back through lane 0's private list first: KMAX sorted insertions that the
+    // whole wave executed).  Private lists never hold a merged point (offer() drops those), so the two sources are disjoint.
     auto merge = [&]() {
-        if (sub == 0) { // the merged entries re-enter through lane 0 (its private candidates are all > ... not necessarily: insert them)
+        unsigned long long omk[KMAX];
+        int oms[KMAX];
 #pragma unroll
-            for (int i = 0; i < KMAX; ++i) {
-                const unsigned long long key = mk[i];
-                const int sx = ms[i];
-                if (key != ~0ull && key < pk[KMAX - 1]) {
-#pragma unroll
-                    for (int j = KMAX - 1; j >= 0; --j) {
-                        const unsigned long long prev = j > 0 ? pk[j - 1] : 0ull;
-                        const int prevs = j > 0 ? ps[j - 1] : -1;
-                        if (j > 0 && key < prev) { pk[j] = prev; ps[j] = prevs; }
-                        else if (key < pk[j]) { pk[j] = key; ps[j] = sx; }
-                    }
-                }
-            }
-        }
-        int head = 0;
+        for (int i = 0; i < KMAX; ++i) { omk[i] = mk[i]; oms[i] = ms[i]; }
+        int head = 0, hm = 0;
 #pragma unroll
         for (int j = 0; j < KMAX; ++j) {
             unsigned long long ck = ~0ull;
@@ -740,8 +731,15 @@ __global__ __launch_bounds__(NN_BLOCK) void nnk_ml_kernel(const float4* __restri
                 const int os = __shfl_xor(cs_, off, 64);
                 if (ok < ck) { ck = ok; cs_ = os; }
             }
-            mk[j] = ck; ms[j] = cs_;
-            if (mine == ck && mine != ~0ull) ++head; // keys are unique per map point: every holder of the winner advances
+            unsigned long long ok2 = ~0ull;
+            int os2 = -1;
+#pragma unroll
+            for (int i = 0; i < KMAX; ++i) if (i == hm) { ok2 = omk[i]; os2 = oms[i]; }
+            if (ok2 < ck) { mk[j] = ok2; ms[j] = os2; ++hm; }
+            else {
+                mk[j] = ck; ms[j] = cs_;
+                if (mine == ck && mine != ~0ull) ++head; // keys are unique per map point: every holder of the winner advances
+            }
         }
 #pragma unroll
         for (int i = 0; i < KMAX; ++i) { pk[i] = ~0ull; ps[i] = -1; }
