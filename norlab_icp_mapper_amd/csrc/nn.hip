@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void ids_kernel(const float4* __restrict__ map
 #else
 #define NN_TICK(i) do { } while (0)
 #endif
-template <int G, int NB>
+template <int G, int NB, bool SELF> // SELF: self matches allowed (the registration loop) -- compile-time, it sits in the innermost loop
 __global__ __launch_bounds__(NN1_BLOCK) void nn1_ml_kernel(const float4* __restrict__ queries, const int* __restrict__ qindex, BatchArgs ba,
                                                           const float* __restrict__ Tptr, GridLevels L, float maxr2,
                                                           int allow_self_i, int* __restrict__ out_sidx,
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(NN1_BLOCK) void nn1_ml_kernel(const float4* __restr
         // the builder of level 0 clears level 1 of the previous iteration (loop.hip, fused selection)
         for (int gt = blockIdx.x * NN1_BLOCK + threadIdx.x; gt < 256 + 65536; gt += gridDim.x * NN1_BLOCK) hist0[ICPMI_S2_C1 + gt] = 0;
     }
-    const bool allow_self = allow_self_i != 0;
+    const bool allow_self = SELF; (void)allow_self_i;
     // XCD-aware order: workgroup b runs on XCD b % 8 (observed placement, used for speed only), so
     // giving each XCD one contiguous eighth of the tile-sorted queries keeps its share of the map
     // (~1/8 of the cells) resident in that XCD's private 4 MiB L2.  The grid is padded to 8 * chunk.
@@ -1212,8 +1212,9 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
         if (seed_pre_cfg < 0) { const char* e = getenv("ICPMI_NN_SEED_PRE"); seed_pre_cfg = e ? atoi(e) : 2; }
         // a batch (c->batch_cur > 1, set by loop_run_batch): grid.y = readings, grid.x sized for the largest one
         const BatchArgs ba = c->batch_cur > 1 ? c->batch_args : batch_of_one(n);
-#define LAUNCH_ML(G_, NB_)                                                                                                      \
-    hipLaunchKernelGGL((nn1_ml_kernel<G_, NB_>), dim3((int)(((n * G_ + NN1_BLOCK - 1) / NN1_BLOCK + 7) / 8 * 8), ba.nscan), dim3(NN1_BLOCK), 0,  \
+#define LAUNCH_ML(G_, NB_) do { if (allow_self) LAUNCH_ML2(G_, NB_, true); else LAUNCH_ML2(G_, NB_, false); } while (0)
+#define LAUNCH_ML2(G_, NB_, S_)                                                                                                 \
+    hipLaunchKernelGGL((nn1_ml_kernel<G_, NB_, S_>), dim3((int)(((n * G_ + NN1_BLOCK - 1) / NN1_BLOCK + 7) / 8 * 8), ba.nscan), dim3(NN1_BLOCK), 0,  \
                        c->stream, q, qi, ba, d_T, c->levels, lc.maxr2, allow_self, d_sidx, d_d2, d_state, c->d_hard, h0, mp,  \
                        c->d_lvl_tab, unseeded_lev, seed_pre)
         // iterations > 0 are seeded by the previous match (a handful of candidates per query): fewer
@@ -1242,6 +1243,7 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
         else if (total_q >= g4_from && !getenv("ICPMI_NN_WIDE16")) LAUNCH_ML(8, 4); // the wide first launches, likewise one step narrower
         else LAUNCH_ML(16, 4);
 #undef LAUNCH_ML
+#undef LAUNCH_ML2
         const GridParams& top = c->levels.g[c->levels.nlev - 1];
         if (!std::isfinite(lc.max_dist) || (top.cell - top.slack) <= lc.max_dist) {
             hipLaunchKernelGGL(nn1_hard_kernel, dim3(512), dim3(NN_BLOCK), 0, c->stream, d_reading, d_T, c->d_map_sorted, (int)c->m,
