@@ -560,6 +560,39 @@ struct MaxDensityFilter : DataPointsFilter {
 
 struct IdentityFilter : DataPointsFilter { void inPlaceFilter(DataPoints&) const override {} };
 
+// ObservationDirectionDataPointsFilter{x 0, y 0, z 0} [UPSTREAM]: descriptor `observationDirections` = sensor position - point
+// (3 rows; it rotates with the cloud like `normals`, RigidTransformation::compute)
+struct ObservationDirectionFilter : DataPointsFilter {
+    float c[3] = {0, 0, 0};
+    void inPlaceFilter(DataPoints& cl) const override {
+        const size_t n = cl.getNbPoints();
+        std::vector<float> d(3 * n);
+        for (size_t i = 0; i < n; ++i) { const float* p = cl.col(i); for (int r = 0; r < 3; ++r) d[3 * i + r] = c[r] - p[r]; }
+        if (cl.descriptorExists("observationDirections")) cl.removeDescriptor("observationDirections");
+        cl.addDescriptor("observationDirections", 3, std::move(d));
+    }
+};
+
+// OrientNormalsDataPointsFilter{towardCenter 1} [UPSTREAM]: a normal whose scalar product with the observation direction is
+// negative (towardCenter) / positive (away) is flipped; needs `normals` and `observationDirections`
+struct OrientNormalsFilter : DataPointsFilter {
+    bool towardCenter = true;
+    void inPlaceFilter(DataPoints& cl) const override {
+        if (!cl.descriptorExists("normals")) throw InvalidField("OrientNormalsDataPointsFilter: Error, cannot find normals in descriptors.");
+        if (!cl.descriptorExists("observationDirections")) throw InvalidField("OrientNormalsDataPointsFilter: Error, cannot find observation directions in descriptors.");
+        Descriptor nrm = cl.getDescriptorByName("normals");
+        const Descriptor& od = cl.getDescriptorByName("observationDirections");
+        if (nrm.span != 3 || od.span != 3) throw InvalidField("OrientNormalsDataPointsFilter: normals and observationDirections must have 3 rows");
+        const size_t n = cl.getNbPoints();
+        for (size_t i = 0; i < n; ++i) {
+            const float dot = nrm.data[3 * i] * od.data[3 * i] + nrm.data[3 * i + 1] * od.data[3 * i + 1] + nrm.data[3 * i + 2] * od.data[3 * i + 2];
+            if (towardCenter ? dot < 0.f : dot > 0.f) for (int r = 0; r < 3; ++r) nrm.data[3 * i + r] = -nrm.data[3 * i + r];
+        }
+        cl.removeDescriptor("normals");
+        cl.addDescriptor("normals", 3, std::move(nrm.data));
+    }
+};
+
 struct RemoveNaNFilter : DataPointsFilter {
     void inPlaceFilter(DataPoints& c) const override {
         const size_t n = c.getNbPoints();
@@ -832,6 +865,27 @@ std::shared_ptr<DataPointsFilter> createDataPointsFilter(const std::string& name
         return f;
     }
     if (name == "IdentityDataPointsFilter") return std::make_shared<IdentityFilter>();
+    if (name == "ObservationDirectionDataPointsFilter") {
+        requireKnown(p, {"x", "y", "z"}, name);
+        auto f = std::make_shared<ObservationDirectionFilter>();
+        f->c[0] = getf(p, "x", 0.f); f->c[1] = getf(p, "y", 0.f); f->c[2] = getf(p, "z", 0.f);
+        return f;
+    }
+    if (name == "OrientNormalsDataPointsFilter") {
+        requireKnown(p, {"towardCenter"}, name);
+        auto f = std::make_shared<OrientNormalsFilter>();
+        f->towardCenter = geti(p, "towardCenter", 1) != 0;
+        return f;
+    }
+    if (name == "MinDistDataPointsFilter" || name == "MaxDistDataPointsFilter") {
+        // the older names of DistanceLimitDataPointsFilter: MinDist{dim -1, minDist 1} keeps what lies beyond, MaxDist{dim -1, maxDist 1} within
+        const bool isMin = name == "MinDistDataPointsFilter";
+        requireKnown(p, {"dim", isMin ? "minDist" : "maxDist"}, name);
+        auto f = std::make_shared<DistanceLimitFilter>();
+        f->dim = geti(p, "dim", -1); f->dist = getf(p, isMin ? "minDist" : "maxDist", 1.f); f->removeInside = isMin;
+        if (f->dim < -1 || f->dim > 2) throw InvalidParameter(name + ": dim must be in [-1, 2]");
+        return f;
+    }
     if (name == "RemoveNaNDataPointsFilter") return std::make_shared<RemoveNaNFilter>();
     if (name == "OctreeGridDataPointsFilter") {
         requireKnown(p, {"buildParallel", "maxPointByNode", "maxSizeByNode", "samplingMethod"}, name);

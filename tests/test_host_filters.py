@@ -26,6 +26,34 @@ def host():
     return hb
 
 
+def test_observation_direction_orient_normals_and_the_old_distance_names(host):
+    """ObservationDirection / OrientNormals (they sit beside SurfaceNormal in most mapper configurations) and the MinDist / MaxDist
+    names of DistanceLimit, against numpy"""
+    c = _cloud(5000, 3)
+    rng = np.random.default_rng(4)
+    nrm = rng.normal(size=(5000, 3)).astype(np.float32); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    sensor = np.float32([1.5, -2.0, 0.75])
+    out, _, od = host.filter_chain("[{ObservationDirectionDataPointsFilter: {x: 1.5, y: -2.0, z: 0.75}}]", c,
+                                   desc_name="observationDirections", desc=np.zeros((5000, 3), np.float32))
+    assert np.array_equal(out, c) and np.array_equal(od, sensor[None, :] - c[:, :3])
+    for toward in (1, 0):
+        chain = "[{ObservationDirectionDataPointsFilter: {x: 1.5, y: -2.0, z: 0.75}}, {OrientNormalsDataPointsFilter: {towardCenter: %d}}]" % toward
+        _, got, _ = host.filter_chain(chain, c, desc_name="normals", desc=nrm)
+        dots = (nrm * (sensor[None, :] - c[:, :3])).sum(1, dtype=np.float32)
+        flip = dots < 0 if toward else dots > 0
+        want = np.where(flip[:, None], -nrm, nrm)
+        assert np.array_equal(got, want) and 0.3 < flip.mean() < 0.7
+    with pytest.raises(RuntimeError, match="observation directions"):
+        host.filter_chain("[OrientNormalsDataPointsFilter]", c, desc_name="normals", desc=nrm)
+    r = np.sqrt((c[:, :3].astype(np.float32) ** 2).sum(1, dtype=np.float32))
+    far, _, _ = host.filter_chain("[{MinDistDataPointsFilter: {minDist: 8.0}}]", c)
+    near, _, _ = host.filter_chain("[{MaxDistDataPointsFilter: {maxDist: 8.0}}]", c)
+    assert far.shape[0] + near.shape[0] <= 5000 and far.shape[0] > 0 and near.shape[0] > 0
+    assert np.array_equal(far, c[r > 8.0]) and np.array_equal(near, c[r < 8.0])
+    ax, _, _ = host.filter_chain("[{MaxDistDataPointsFilter: {dim: 1, maxDist: 3.0}}]", c)
+    assert np.array_equal(ax, c[np.abs(c[:, 1]) < 3.0])
+
+
 @pytest.mark.parametrize("method", [0, 1])
 @pytest.mark.parametrize("prob,seed", [(0.75, 1), (0.2, 12345), (1.0, 3), (0.0, 9)])
 def test_random_sampling_equals_oracle(host, oracle, prob, seed, method):
