@@ -98,6 +98,30 @@ def time_registrations(torch, icp, d_scan, steps, warmup):
     return T, time.perf_counter() - t_all, per
 
 
+def dry_launch(args):
+    """The launcher path without GPUs (tests/test_bench_launch.py): every rank joins a gloo group, the ranks are counted by an
+    all-reduce and rank 0 prints the one JSON line."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    seen = 1
+    if "RANK" in os.environ:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+        t = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(t)
+        seen = int(t.item())
+        ranks = [None] * world
+        dist.all_gather_object(ranks, {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "pid": os.getpid()})
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        ranks = [{"rank": 0, "local_rank": 0, "pid": os.getpid()}]
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "ranks_seen": seen, "ranks": ranks, "requested_gpus": args.gpus}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,7 +140,31 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the `chains` object (configs 3 / 5 and the batch of 8)")
     ap.add_argument("--cpu-iters", type=int, default=10, help="iterations of the single-threaded cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work of the multi-threaded cpu_baseline leg")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launcher check without GPUs: start the ranks (gloo), count them with an all-reduce, print one JSON line from rank 0")
     args = ap.parse_args()
+
+    # ---- `python bench.py --gpus N` on its own starts the N ranks (one process per GPU) ------------------------------------
+    # Under a launcher (torch.distributed.run sets RANK / WORLD_SIZE) this process IS one of the ranks.  Started bare with
+    # --gpus N > 1 it re-executes itself under torch.distributed.run on 127.0.0.1 with a free port, so that the command the
+    # driver uses for N = 1 also produces the N > 1 line (the flag used to be parsed and ignored).
+    if args.gpus > 1 and "RANK" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "8")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks; reporting the launcher's count",
+              file=sys.stderr)
+    if args.dry_launch:
+        return dry_launch(args)
 
     import numpy as np
     import torch
@@ -184,8 +232,12 @@ def main():
         loop_ms += icp.stats.loop_ms if batch_scans is None else icp.batch_stats[0].loop_ms
     barrier()
     elapsed = time.perf_counter() - t0
+    per_rank_value = [args.steps * ITERS_PER_STEP * max(args.batch, 1) / elapsed]
     if use_pg:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        each = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(each, tt)
+        per_rank_value = [args.steps * ITERS_PER_STEP * max(args.batch, 1) / float(e.item()) for e in each]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     readings = max(args.batch, 1)
@@ -225,7 +277,9 @@ def main():
                     barrier()
                     tms = torch.tensor([time.perf_counter() - tm], dtype=torch.float64, device="cuda")
                     dist.all_reduce(tms, op=dist.ReduceOp.MAX)
-                    m = {"ms": float(tms.item()) * 1e3, "accepted_rank0": mine_n, "appended_all_ranks": appended, "map_points_after": new_m,
+                    cr, cme, ckind = icp.commInfo()
+                    m = {"ms": float(tms.item()) * 1e3, "rccl_ranks": cr, "rccl_rank": cme, "communicator": {0: "none", 1: "rccl", 2: "loopback"}[ckind],
+                         "accepted_rank0": mine_n, "appended_all_ranks": appended, "map_points_after": new_m,
                          "what": "PointDistance(0.15 m) accept of one 100k-pt scan per rank + RCCL all-gather + rank-ordered exact merge + append + index rebuild"}
                 elif m is None:
                     m = {"error": "another rank could not create its communicator"}
@@ -270,6 +324,7 @@ def main():
 
     if rank == 0:
         gi = icp.gridInfo()
+        out["per_rank_value"] = per_rank_value
         if merge is not None:
             out["merge_epoch"] = merge
         out["step_ms"] = step_stats(per_step)

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define ICPMI_VERSION 2
+#define ICPMI_VERSION 3
 
 typedef struct icpmi_ctx* icpmi_handle;
 
@@ -378,14 +378,29 @@ icpmi_status icpmi_bin_cells(icpmi_handle h, const float* pts4, int64_t n, float
  *       accepted from ranks < r (exactly what one mapper would have appended had it processed the scans in rank order);
  *       the merged set is appended to the resident map, its normals recomputed (normals_knn > 0) and the index rebuilt.
  *       No accepted point crosses PCIe unless merged_out4 (capacity merged_capacity points) asks for the merged set.
- *       Without a communicator the handle is its own single rank. */
+ *       Without a communicator the handle is its own single rank.
+ *       Collective discipline (v3): the call is a collective -- EVERY rank of the communicator must make it once per epoch, also a
+ *       rank that has nothing to add: `correction == NULL` (or nothing staged, see icpmi_stage_discard) contributes zero points and
+ *       still receives and appends what the others accepted.  A rank whose local part fails reports count -1 and ALL ranks return an
+ *       error together without appending; buffers are grown to the gathered sizes behind a second one-word exchange, so no rank can
+ *       leave between two collectives.  The merged set is always appended: when merged_capacity is smaller than the merged set,
+ *       merged_out4 receives the first merged_capacity points, *merged_n the full count, the status stays ICPMI_OK and
+ *       icpmi_staged_merged_points returns the whole set -- replicas never diverge over a host buffer.
+ *   icpmi_staged_merged_points  the merged set of the last epoch (out4 == NULL: only *n), kept on the device until the next epoch
+ *   icpmi_stage_discard          drops the scan staged by icpmi_register_prior (e.g. after its registration failed: the rank then
+ *                                takes part in the epoch empty-handed and reports its own error afterwards) */
 typedef struct icpmi_comm_id { char bytes[128]; } icpmi_comm_id;
 icpmi_status icpmi_comm_get_unique_id(icpmi_comm_id* id);
 icpmi_status icpmi_comm_init(icpmi_handle h, const icpmi_comm_id* id, int32_t n_ranks, int32_t rank);
 icpmi_status icpmi_comm_destroy(icpmi_handle h);
+/* What the handle's communicator reports about itself (RCCL: ncclCommCount / ncclCommUserRank); kind 0 = none (the handle is its own
+ * single rank), 1 = RCCL, 2 = the loopback test communicator.  Any pointer may be NULL. */
+icpmi_status icpmi_comm_info(icpmi_handle h, int32_t* n_ranks, int32_t* rank, int32_t* kind);
 icpmi_status icpmi_staged_merge_allgather(icpmi_handle h, const float correction[16], float min_dist, int32_t normals_knn,
                                           int64_t* accepted_local, int64_t* appended_total, int64_t* new_m, float* merged_out4,
                                           int64_t merged_capacity, int64_t* merged_n);
+icpmi_status icpmi_staged_merged_points(icpmi_handle h, float* out4, int64_t capacity, int64_t* n);
+icpmi_status icpmi_stage_discard(icpmi_handle h);
 
 /* ---- plumbing ---- */
 /* Use an externally owned hipStream_t (e.g. torch's current stream) instead of the handle's own. */

@@ -123,7 +123,10 @@ SYMBOLS = [
     ("icpmi_comm_get_unique_id", C.c_int, [_P]),
     ("icpmi_comm_init", C.c_int, [_P, _P, C.c_int32, C.c_int32]),
     ("icpmi_comm_destroy", C.c_int, [_P]),
+    ("icpmi_comm_info", C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("icpmi_staged_merge_allgather", C.c_int, [_P, _P, C.c_float, C.c_int32, _P, _P, _P, _P, C.c_int64, _P]),
+    ("icpmi_staged_merged_points", C.c_int, [_P, _P, C.c_int64, _P]),
+    ("icpmi_stage_discard", C.c_int, [_P]),
     ("icpmi_register_prior", C.c_int, [_P, _P, C.c_int64, _P, _F, C.POINTER(Stats)]),
     ("icpmi_map_update_staged", C.c_int, [_P, _P, C.c_float, C.c_int32, _P, _P, _P]),
     ("icpmi_dynamic_points_update", C.c_int, [_P, _P, _P, _P, C.c_int64, _P, _P, C.c_int64, _P]),

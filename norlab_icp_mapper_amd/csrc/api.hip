@@ -196,7 +196,7 @@ void icpmi_destroy(icpmi_handle c)
     hipFree(c->d_qsorted); hipFree(c->d_qindex); hipFree(c->d_qkeys); hipFree(c->d_qtile);
     hipFree(c->d_reading); hipFree(c->d_read_normals); hipFree(c->d_stage_in); hipFree(c->d_stage_n3);
     hipFree(c->d_match_pt); hipFree(c->d_lvl_tab); hipFree(c->d_raw); hipFree(c->d_raw_n3); hipFree(c->d_raw_s); hipFree(c->d_src); hipFree(c->d_alt_raw); hipFree(c->d_alt_n3);
-    hipFree(c->d_alt_s); hipFree(c->d_alt_src); hipFree(c->d_stage_s); hipFree(c->d_merge_send); hipFree(c->d_merge_recv); hipFree(c->d_merged);
+    hipFree(c->d_alt_s); hipFree(c->d_alt_src); hipFree(c->d_stage_s); hipFree(c->d_merge_send); hipFree(c->d_merge_recv); hipFree(c->d_merged); hipFree(c->d_comm_cnt);
     for (int k = 0; k < 10; ++k) hipFree(c->scratch[k]); hipFree(c->d_scan_map); hipFree(c->d_T16);
     hipFree(c->d_sidx); hipFree(c->d_d2); hipFree(c->d_hard); hipFree(c->d_partials); hipFree(c->d_selhist);
     hipFree(c->d_state);
@@ -600,6 +600,17 @@ icpmi_status icpmi_comm_init(icpmi_handle h, const icpmi_comm_id* id, int32_t n_
     return comm_init(h, id, n_ranks, rank);
 }
 
+icpmi_status icpmi_comm_info(icpmi_handle h, int32_t* n_ranks, int32_t* rank, int32_t* kind)
+{
+    CHECK_H(h);
+    int a = 1, b = 0, k = 0;
+    const icpmi_status s = comm_info(h, &a, &b, &k);
+    if (n_ranks) *n_ranks = a;
+    if (rank) *rank = b;
+    if (kind) *kind = k;
+    return s;
+}
+
 icpmi_status icpmi_comm_destroy(icpmi_handle h)
 {
     CHECK_H(h);
@@ -611,11 +622,27 @@ icpmi_status icpmi_staged_merge_allgather(icpmi_handle h, const float correction
                                           int64_t merged_capacity, int64_t* merged_n)
 {
     CHECK_H(h);
-    if (!correction || !(min_dist >= 0.f) || normals_knn < 0 || normals_knn > ICPMI_MAX_K || merged_capacity < 0) {
+    // (argument errors are local by construction: every rank passes the same min_dist / normals_knn, and a rank that hands in
+    // garbage here has a bug no protocol can paper over)
+    if (!(min_dist >= 0.f) || normals_knn < 0 || normals_knn > ICPMI_MAX_K || merged_capacity < 0) {
         h->last_error = "staged_merge_allgather: bad arguments"; return ICPMI_ERR_INVALID_ARG;
     }
-    if (h->scan_map_n <= 0 && !h->comm) { h->last_error = "staged_merge_allgather: no scan staged by icpmi_register_prior"; return ICPMI_ERR_INVALID_ARG; }
+    // correction == NULL or nothing staged: this rank contributes no points and still takes part in the exchange
     return ops_staged_merge_allgather(h, correction, min_dist, normals_knn, accepted_local, appended_total, new_m, merged_out4, merged_capacity, merged_n);
+}
+
+icpmi_status icpmi_staged_merged_points(icpmi_handle h, float* out4, int64_t capacity, int64_t* n)
+{
+    CHECK_H(h);
+    if (capacity < 0) { h->last_error = "staged_merged_points: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
+    return ops_staged_merged_points(h, out4, capacity, n);
+}
+
+icpmi_status icpmi_stage_discard(icpmi_handle h)
+{
+    CHECK_H(h);
+    h->scan_map_n = 0;
+    return ICPMI_OK;
 }
 
 icpmi_status icpmi_get_map(icpmi_handle h, float* out4, float* normals3, int64_t capacity, int64_t* m)

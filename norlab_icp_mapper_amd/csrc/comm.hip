@@ -4,6 +4,7 @@
 // need librccl.so at all, and the library binds to whichever copy the process already holds (PyTorch ships one).
 #include "common.h"
 
+#include <cstdio>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -16,6 +17,8 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     std::string error;
 };
 
@@ -35,6 +38,8 @@ Rccl& rccl()
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
     r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+    r.CommCount = (decltype(r.CommCount))dlsym(r.lib, "ncclCommCount");       // optional: only icpmi_comm_info asks
+    r.CommUserRank = (decltype(r.CommUserRank))dlsym(r.lib, "ncclCommUserRank");
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString) {
         r.error = "librccl.so lacks an expected symbol";
         dlclose(r.lib); r.lib = nullptr;
@@ -65,14 +70,30 @@ icpmi_status comm_unique_id(icpmi_comm_id* id, std::string& err)
     return ICPMI_OK;
 }
 
-// Loopback communicator (ICPMI_COMM_LOOPBACK=R at the time of icpmi_comm_init): R ranks simulated on ONE GPU -- every "rank"
-// contributes this rank's own block, rank r's points moved by r * ICPMI_COMM_LOOPBACK_SHIFT metres along x.  It exists so that
-// the rank-ordered merge of icpmi_staged_merge_allgather (counts, padding, block offsets, rejection against the blocks of the
-// lower ranks) can be checked against the oracle on a single-GPU box; RCCL is not touched.
+// Loopback communicator (test hook; ICPMI_COMM_LOOPBACK=R in the environment AND icpmi_comm_init(..., n_ranks = 1, rank = 0)):
+// R ranks simulated on ONE GPU -- every "rank" contributes this rank's own block, rank r's points moved by
+// r * ICPMI_COMM_LOOPBACK_SHIFT metres along x; with ICPMI_COMM_LOOPBACK_RAGGED=1 simulated rank r hands in only the first
+// floor(count * w[r % 5]) points of it, w = {1/2, 1, 1/4, 3/4, 0} (unequal and empty blocks; rank 0, "this" rank, is one of the
+// small ones).  It exists so that the rank-ordered merge of icpmi_staged_merge_allgather (counts, padding, block offsets,
+// rejection against the blocks of the lower ranks) can be checked against the oracle on a single-GPU box; RCCL is not touched.
+// A real multi-rank job (n_ranks > 1) with the variable left set is refused: it would silently merge copies of its own block.
 __global__ __launch_bounds__(256) void loop_shift_kernel(float4* __restrict__ p, size_t n, float dx)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i].x += dx;
+}
+
+__global__ void loop_counts_kernel(const long long* __restrict__ mine, long long* __restrict__ all, int R, int ragged)
+{
+    const int r = threadIdx.x;
+    if (r >= R) return;
+    long long v = *mine;
+    if (ragged && v > 0) {
+        const int w = r % 5; // quarters: 2, 4, 1, 3, 0
+        const long long q = w == 0 ? 2 : (w == 1 ? 4 : (w == 2 ? 1 : (w == 3 ? 3 : 0)));
+        v = v * q / 4;
+    }
+    all[r] = v;
 }
 
 icpmi_status comm_init(icpmi_ctx* c, const icpmi_comm_id* id, int n_ranks, int rank)
@@ -80,30 +101,54 @@ icpmi_status comm_init(icpmi_ctx* c, const icpmi_comm_id* id, int n_ranks, int r
     if (const char* lb = getenv("ICPMI_COMM_LOOPBACK")) {
         const int R = atoi(lb);
         if (R > 1) {
+            if (n_ranks != 1) {
+                c->last_error = "comm_init: ICPMI_COMM_LOOPBACK (a single-process test hook) is set in a job of more than one rank";
+                return ICPMI_ERR_INVALID_ARG;
+            }
+            if (R > 256) { c->last_error = "comm_init: ICPMI_COMM_LOOPBACK > 256"; return ICPMI_ERR_INVALID_ARG; }
             if (c->comm) (void)comm_destroy(c);
             const char* sh = getenv("ICPMI_COMM_LOOPBACK_SHIFT");
+            const char* rg = getenv("ICPMI_COMM_LOOPBACK_RAGGED");
             c->comm = nullptr; c->comm_ranks = R; c->comm_rank = 0; c->comm_loop_shift = sh ? (float)atof(sh) : 0.f;
-            return ICPMI_OK;
+            c->comm_loop_ragged = rg && atoi(rg) != 0;
+            fprintf(stderr, "[icpmi] loopback communicator active: %d simulated ranks on one GPU, no RCCL (ICPMI_COMM_LOOPBACK)\n", R);
+            return ensure_cap(c, &c->d_comm_cnt, &c->cap_comm_cnt, (size_t)2 * R + 16);
         }
     }
     Rccl& r = rccl();
     if (!r.lib) { c->last_error = r.error; return ICPMI_ERR_HIP; }
     if (c->comm) { RCCL_TRY(c, r.CommDestroy((ncclComm_t)c->comm)); c->comm = nullptr; }
+    // the words of the epoch's count / ready exchanges: allocated here so that no allocation can fail between two collectives
+    if (ensure_cap(c, &c->d_comm_cnt, &c->cap_comm_cnt, (size_t)2 * n_ranks + 16) != ICPMI_OK) return ICPMI_ERR_HIP;
     ncclUniqueId u;
     memcpy(&u, id, sizeof u);
     ncclComm_t comm = nullptr;
     RCCL_TRY(c, r.CommInitRank(&comm, n_ranks, u, rank));
-    c->comm = comm; c->comm_ranks = n_ranks; c->comm_rank = rank;
+    c->comm = comm; c->comm_ranks = n_ranks; c->comm_rank = rank; c->comm_loop_shift = 0.f; c->comm_loop_ragged = false;
     return ICPMI_OK;
 }
 
 icpmi_status comm_destroy(icpmi_ctx* c)
 {
-    if (!c->comm) { c->comm_ranks = 1; c->comm_rank = 0; c->comm_loop_shift = 0.f; return ICPMI_OK; }
+    if (!c->comm) { c->comm_ranks = 1; c->comm_rank = 0; c->comm_loop_shift = 0.f; c->comm_loop_ragged = false; return ICPMI_OK; }
     Rccl& r = rccl();
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (r.lib) (void)r.CommDestroy((ncclComm_t)c->comm);
     c->comm = nullptr; c->comm_ranks = 1; c->comm_rank = 0;
+    return ICPMI_OK;
+}
+
+// what the communicator itself reports (RCCL: ncclCommCount / ncclCommUserRank); kind: 0 none (single rank), 1 RCCL, 2 loopback
+icpmi_status comm_info(icpmi_ctx* c, int* n_ranks, int* rank, int* kind)
+{
+    *n_ranks = c->comm_ranks; *rank = c->comm_rank; *kind = c->comm ? 1 : (c->comm_ranks > 1 ? 2 : 0);
+    if (c->comm) {
+        Rccl& r = rccl();
+        if (r.CommCount && r.CommUserRank) {
+            RCCL_TRY(c, r.CommCount((ncclComm_t)c->comm, n_ranks));
+            RCCL_TRY(c, r.CommUserRank((ncclComm_t)c->comm, rank));
+        }
+    }
     return ICPMI_OK;
 }
 
@@ -112,6 +157,12 @@ icpmi_status comm_allgather(icpmi_ctx* c, const void* d_send, void* d_recv, size
 {
     if (!c->comm) {
         const size_t bytes = count * (is_float ? sizeof(float) : sizeof(long long));
+        if (!is_float && count == 1 && c->comm_ranks > 1) { // the loopback communicator's count exchange (possibly ragged)
+            hipLaunchKernelGGL(loop_counts_kernel, dim3(1), dim3(256), 0, c->stream, (const long long*)d_send, (long long*)d_recv, c->comm_ranks,
+                               c->comm_loop_ragged ? 1 : 0);
+            HIP_TRY(c, hipGetLastError());
+            return ICPMI_OK;
+        }
         for (int r = 0; r < c->comm_ranks; ++r) { // one rank, or the loopback communicator's R copies
             char* dst = (char*)d_recv + (size_t)r * bytes;
             if (dst != (const char*)d_send) HIP_TRY(c, hipMemcpyAsync(dst, d_send, bytes, hipMemcpyDeviceToDevice, c->stream));

@@ -252,6 +252,9 @@ struct icpmi_ctx {
     // RCCL communicator of the scan-sharded mapping mode (comm.hip); null = a single rank
     void* comm = nullptr; int comm_ranks = 1, comm_rank = 0;
     float comm_loop_shift = 0.f;      // loopback communicator (comm.hip): rank r's block = this rank's, moved r * shift along x
+    bool comm_loop_ragged = false;    // ... and cut to unequal sizes (comm.hip: loop_counts_kernel)
+    long long* d_comm_cnt = nullptr; size_t cap_comm_cnt = 0; // words of the epoch's count / ready exchanges (allocated by comm_init)
+    int64_t merged_last_n = 0;        // points of the last epoch's merged set, still in d_merged (icpmi_staged_merged_points)
 };
 
 #define HIP_TRY(ctx, expr)                                                                     \
@@ -404,9 +407,11 @@ icpmi_status ops_bin_cells(icpmi_ctx* c, const float* pts4, int64_t n, float cel
 icpmi_status comm_unique_id(icpmi_comm_id* id, std::string& err);
 icpmi_status comm_init(icpmi_ctx* c, const icpmi_comm_id* id, int n_ranks, int rank);
 icpmi_status comm_destroy(icpmi_ctx* c);
+icpmi_status comm_info(icpmi_ctx* c, int* n_ranks, int* rank, int* kind);
 icpmi_status comm_allgather(icpmi_ctx* c, const void* d_send, void* d_recv, size_t count, bool is_float);
 icpmi_status ops_staged_merge_allgather(icpmi_ctx* c, const float correction[16], float min_dist, int normals_knn, int64_t* accepted_local,
                                         int64_t* appended_total, int64_t* new_m, float* merged_out4, int64_t merged_capacity, int64_t* merged_n);
+icpmi_status ops_staged_merged_points(icpmi_ctx* c, float* out4, int64_t capacity, int64_t* n);
 size_t radix_sort_tab_words(int64_t n, int bits);
 icpmi_status radix_sort_pairs(icpmi_ctx* c, unsigned long long* d_keys2, unsigned* d_vals2, int64_t n, int bits, unsigned* d_tab, int* result_half);
 icpmi_status octree_sample_dev(icpmi_ctx* c, const float4* d_in, int64_t n, float max_size, int max_pts, int method, int* d_order, int* d_leaf_of,

@@ -1673,7 +1673,10 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
                         if (v >> 31) { stopped = true; break; }
                         if ((int)(v & 0xfffu) + ahead > it) break;
                     }
-                    if ((spins & 255u) == 0 && hipStreamQuery(c->stream) == hipSuccess) {
+                    if ((spins & 255u) != 0) continue;
+                    const hipError_t qe = hipStreamQuery(c->stream);
+                    if (qe != hipSuccess && qe != hipErrorNotReady) HIP_TRY(c, qe); // stream in an error state: nothing will ever advance the word
+                    if (qe == hipSuccess) {
                         // everything enqueued has run: the word is final (a kernel that stops the loop without passing
                         // through the solve kernel cannot leave the host waiting)
                         const unsigned w = __atomic_load_n(c->h_progress, __ATOMIC_ACQUIRE);
@@ -1850,7 +1853,10 @@ icpmi_status loop_run_batch(icpmi_ctx* c, int B, const float* const* d_scans4, c
                 }
                 if (all_done) { stopped = true; break; }
                 if (may_go) break;
-                if ((spins & 255u) == 0 && hipStreamQuery(c->stream) == hipSuccess) {
+                if ((spins & 255u) != 0) continue;
+                const hipError_t qe = hipStreamQuery(c->stream);
+                if (qe != hipSuccess && qe != hipErrorNotReady) HIP_TRY(c, qe); // stream in an error state: terminal
+                if (qe == hipSuccess) {
                     bool progress = false; // everything enqueued has run: go on only if some reading still iterates
                     for (int b = 0; b < B; ++b) {
                         const unsigned w = __atomic_load_n(c->h_progress + b, __ATOMIC_ACQUIRE);

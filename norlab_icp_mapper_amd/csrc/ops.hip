@@ -1359,6 +1359,13 @@ static icpmi_status merge_append_flagged(icpmi_ctx* c, const float4* d_in, int64
 }
 
 // One map-growth epoch of the scan-sharded mapper (include/icpmi.h: icpmi_staged_merge_allgather), device-resident.
+// Collective discipline: a rank must never leave between two collectives its peers are going to enter.
+//   * every failure before the count exchange travels as count -1 (all ranks then leave together, nobody appends);
+//   * what can fail between the count exchange and the point exchange (growing the buffers to the gathered sizes) is reported in a
+//     second one-word exchange (`ready`), so a rank that cannot allocate does not leave its peers in the point all-gather;
+//   * after the point exchange every rank holds the same blocks and runs the same deterministic merge + append; the merged set is
+//     ALWAYS appended -- a caller's copy-out buffer that is too small gets what fits and learns the full size from *merged_n
+//     (fetch the rest with icpmi_staged_merged_points): the replicas cannot diverge over a host buffer.
 icpmi_status ops_staged_merge_allgather(icpmi_ctx* c, const float correction[16], float min_dist, int normals_knn, int64_t* accepted_local,
                                         int64_t* appended_total, int64_t* new_m, float* merged_out4, int64_t merged_capacity, int64_t* merged_n)
 {
@@ -1366,19 +1373,25 @@ icpmi_status ops_staged_merge_allgather(icpmi_ctx* c, const float correction[16]
     if (appended_total) *appended_total = 0;
     if (merged_n) *merged_n = 0;
     if (new_m) *new_m = c->m > 0 ? c->m_raw : 0;
+    c->merged_last_n = 0;
     const int R = c->comm_ranks; // 1 without a communicator (or the loopback communicator's simulated ranks, comm.hip)
-    const int64_t n = c->scan_map_n;
+    const int64_t n = correction ? c->scan_map_n : 0; // no correction = nothing to contribute (empty scan / failed registration)
+    // the exchange words: allocated by comm_init; a handle that is its own single rank gets them here (no peer can be left waiting)
+    if (!c->d_comm_cnt || c->cap_comm_cnt < (size_t)2 * R + 16) {
+        if (c->comm) { c->last_error = "staged_merge_allgather: communicator without exchange words"; return ICPMI_ERR_HIP; }
+        if (ensure_cap(c, &c->d_comm_cnt, &c->cap_comm_cnt, (size_t)2 * R + 16) != ICPMI_OK) return ICPMI_ERR_HIP;
+    }
     // ---- this rank's accepted points: the staged scan moved by the correction (Mapper.cpp:221), PointDistance against the resident map
-    unsigned* d_flag = scratch_get<unsigned>(c, 6, (size_t)n + 2);
-    unsigned* d_pos = scratch_get<unsigned>(c, 7, (size_t)n + 2);
-    if (!d_flag || !d_pos) return ICPMI_ERR_HIP;
-    int64_t mine = 0;
-    if (ensure_cap(c, &c->d_stage_in, &c->cap_stage_in, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
-    if (ensure_cap(c, &c->d_merge_send, &c->cap_merge_send, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
-    // (a failure on this rank must not leave the others waiting in the collective: it travels as a negative count)
     icpmi_status local = ICPMI_OK;
+    int64_t mine = 0;
+    unsigned* d_flag = nullptr; unsigned* d_pos = nullptr;
     if (n > 0) {
-        local = ops_transform_dev(c, correction, c->d_scan_map, n, c->d_stage_in);
+        d_flag = scratch_get<unsigned>(c, 6, (size_t)n + 2);
+        d_pos = scratch_get<unsigned>(c, 7, (size_t)n + 2);
+        if (!d_flag || !d_pos) local = ICPMI_ERR_HIP;
+        if (local == ICPMI_OK) local = ensure_cap(c, &c->d_stage_in, &c->cap_stage_in, (size_t)n + 1);
+        if (local == ICPMI_OK) local = ensure_cap(c, &c->d_merge_send, &c->cap_merge_send, (size_t)n + 1);
+        if (local == ICPMI_OK) local = ops_transform_dev(c, correction, c->d_scan_map, n, c->d_stage_in);
         if (local == ICPMI_OK) {
             if (c->m > 0) {
                 icpmi_ctx* ri = nullptr;
@@ -1393,9 +1406,8 @@ icpmi_status ops_staged_merge_allgather(icpmi_ctx* c, const float correction[16]
     }
     const std::string local_error = c->last_error;
     if (accepted_local) *accepted_local = local == ICPMI_OK ? mine : 0;
-    // ---- counts of all ranks
-    long long* d_cnt = scratch_get<long long>(c, 8, (size_t)R + 8);
-    if (!d_cnt) return ICPMI_ERR_HIP;
+    // ---- counts of all ranks (collective 1)
+    long long* d_cnt = c->d_comm_cnt;
     long long hmine = local == ICPMI_OK ? mine : -1;
     HIP_TRY(c, hipMemcpyAsync(d_cnt + R, &hmine, sizeof hmine, hipMemcpyHostToDevice, c->stream));
     icpmi_status s = comm_allgather(c, d_cnt + R, d_cnt, 1, false);
@@ -1411,10 +1423,26 @@ icpmi_status ops_staged_merge_allgather(icpmi_ctx* c, const float correction[16]
         }
     for (long long v : counts) { maxc = v > maxc ? v : maxc; total += v; }
     if (total == 0) { if (new_m) *new_m = c->m > 0 ? c->m_raw : 0; return ICPMI_OK; }
-    // ---- the point blocks, padded to the largest (one all-gather; the payload is a few MB at most: latency, not bandwidth)
-    if (ensure_cap_keep(c, &c->d_merge_send, &c->cap_merge_send, (size_t)maxc + 1, (size_t)mine) != ICPMI_OK) return ICPMI_ERR_HIP;
-    if (ensure_cap(c, &c->d_merge_recv, &c->cap_merge_recv, (size_t)maxc * R + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
-    if (ensure_cap(c, &c->d_merged, &c->cap_merged, (size_t)total + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    // ---- buffers at the gathered sizes; `ready` exchange (collective 2, only when there are peers)
+    icpmi_status grow = ensure_cap_keep(c, &c->d_merge_send, &c->cap_merge_send, (size_t)maxc + 1, (size_t)mine);
+    if (grow == ICPMI_OK) grow = ensure_cap(c, &c->d_merge_recv, &c->cap_merge_recv, (size_t)maxc * R + 1);
+    if (grow == ICPMI_OK) grow = ensure_cap(c, &c->d_merged, &c->cap_merged, (size_t)total + 1);
+    const std::string grow_error = c->last_error;
+    if (c->comm) {
+        long long hready = grow == ICPMI_OK ? 1 : -1;
+        HIP_TRY(c, hipMemcpyAsync(d_cnt + R, &hready, sizeof hready, hipMemcpyHostToDevice, c->stream));
+        s = comm_allgather(c, d_cnt + R, d_cnt, 1, false);
+        if (s != ICPMI_OK) return s;
+        std::vector<long long> ready((size_t)R);
+        if (read_back(c, ready.data(), d_cnt, sizeof(long long) * (size_t)R) != ICPMI_OK) return ICPMI_ERR_HIP;
+        for (int r = 0; r < R; ++r)
+            if (ready[(size_t)r] < 0) {
+                if (grow != ICPMI_OK) { c->last_error = grow_error; return grow; }
+                c->last_error = "staged_merge_allgather: rank " + std::to_string(r) + " could not size its exchange buffers";
+                return ICPMI_ERR_HIP;
+            }
+    } else if (grow != ICPMI_OK) return grow;
+    // ---- the point blocks, padded to the largest (collective 3; the payload is a few MB at most: latency, not bandwidth)
     s = comm_allgather(c, c->d_merge_send, c->d_merge_recv, (size_t)maxc * 4, true);
     if (s != ICPMI_OK) return s;
     // ---- merge in rank order; block r keeps what is at least min_dist from the points accepted from ranks < r
@@ -1444,18 +1472,31 @@ icpmi_status ops_staged_merge_allgather(icpmi_ctx* c, const float correction[16]
         if (s != ICPMI_OK) return s;
         acc += kept;
     }
-    if (merged_n) *merged_n = acc;
-    if (merged_out4) {
-        if (merged_capacity < acc) { c->last_error = "staged_merge_allgather: merged_capacity too small"; return ICPMI_ERR_INVALID_ARG; }
-        HIP_TRY(c, hipMemcpyAsync(merged_out4, c->d_merged, (size_t)acc * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
-    }
     // ---- every replica appends the same set (all points kept: the distance tests are done), normals, index
     int64_t app = 0, m1 = 0;
     s = ops_map_update_dev(c, c->d_merged, acc, nullptr, 0.f, normals_knn, nullptr, &app, &m1);
     if (s != ICPMI_OK) return s;
+    c->merged_last_n = acc;
+    if (merged_n) *merged_n = acc;
+    if (merged_out4 && merged_capacity > 0) { // what fits; *merged_n says how much there is
+        const int64_t cp = acc < merged_capacity ? acc : merged_capacity;
+        if (cp > 0) HIP_TRY(c, hipMemcpyAsync(merged_out4, c->d_merged, (size_t)cp * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (appended_total) *appended_total = app;
     if (new_m) *new_m = m1;
+    return ICPMI_OK;
+}
+
+// the merged set of the last epoch (still in d_merged): out4 may be NULL to query *n only
+icpmi_status ops_staged_merged_points(icpmi_ctx* c, float* out4, int64_t capacity, int64_t* n)
+{
+    const int64_t have = c->merged_last_n;
+    if (n) *n = have;
+    if (!out4 || have == 0) return ICPMI_OK;
+    if (capacity < have) { c->last_error = "staged_merged_points: capacity too small"; return ICPMI_ERR_INVALID_ARG; }
+    HIP_TRY(c, hipMemcpyAsync(out4, c->d_merged, (size_t)have * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return ICPMI_OK;
 }
 

@@ -178,14 +178,28 @@ class ShardedMapper:
         return self.backend.get_map() if getattr(self.backend, "resident", False) else self.map
 
     def _epoch_resident(self, scan, prior):
-        correction = self.backend.register_prior(scan, prior)               # identity while there is no map; stages the scan
-        self.pose = (np.asarray(correction, dtype=np.float64) @ np.asarray(prior, dtype=np.float64)).astype(np.float32)
+        # The epoch is a collective: a rank with no scan left, or whose registration fails (an ordinary ICP ConvergenceError), must
+        # still take part in the exchange -- empty-handed -- or its peers wait in the all-gather forever.  Its own error is raised
+        # once every rank is through the epoch.
+        failure, correction = None, None
+        if scan.shape[0] > 0:
+            try:
+                correction = self.backend.register_prior(scan, prior)       # identity while there is no map; stages the scan
+            except Exception as e:  # noqa: BLE001 -- re-raised below, after the collective
+                failure = e
+        if correction is not None:
+            self.pose = (np.asarray(correction, dtype=np.float64) @ np.asarray(prior, dtype=np.float64)).astype(np.float32)
         if getattr(self.backend, "device_merge", False):
-            mine_n, appended, m1 = self.backend.merge(correction, self.min_dist, self.normals_knn)
+            mine_n, appended, m1 = self.backend.merge(correction, self.min_dist, self.normals_knn)   # None: contributes nothing
             self._resident_points = m1
+            if failure is not None:
+                raise failure
             return self.pose, mine_n, appended
-        mask, placed = self.backend.staged_keep(correction, self.min_dist)
-        mine = placed[mask]
+        if correction is not None:
+            mask, placed = self.backend.staged_keep(correction, self.min_dist)
+            mine = placed[mask]
+        else:
+            mine = np.zeros((0, 4), dtype=np.float32)
         if dist.is_available() and dist.is_initialized():
             t = torch.from_numpy(np.ascontiguousarray(mine))
             if dist.get_backend(self.group) == "nccl":
@@ -197,6 +211,8 @@ class ShardedMapper:
         if merged.shape[0]:
             self.backend.append(np.ascontiguousarray(merged), self.normals_knn)
             self._resident_points += int(merged.shape[0])
+        if failure is not None:
+            raise failure
         return self.pose, int(mine.shape[0]), int(merged.shape[0])
 
     def set_map(self, cloud, normals=None):
@@ -224,12 +240,18 @@ class ShardedMapper:
         # applies), numpy otherwise.  The reference moves the scan TWICE -- by the prior (Mapper.cpp:197), then the registered
         # cloud by the correction (:221) -- not once by their product: the same two steps here.
         move = getattr(self.backend, "transform", None) or self._apply
-        in_map = move(np.asarray(prior, dtype=np.float32), scan)             # Mapper.cpp:197
-        correction = self.backend.register(in_map) if self.map.shape[0] else np.eye(4, dtype=np.float32)
-        self.pose = (np.asarray(correction, dtype=np.float64) @ np.asarray(prior, dtype=np.float64)).astype(np.float32)  # :215
-        placed = move(np.asarray(correction, dtype=np.float32), in_map)      # :221
-        mask = self.backend.keep(self.map, placed, self.min_dist) if self.map.shape[0] else np.ones(placed.shape[0], bool)
-        mine = placed[mask]
+        failure = None
+        mine = np.zeros((0, 4), dtype=np.float32)                              # an empty scan / a failed registration contributes nothing
+        if scan.shape[0] > 0:
+            try:
+                in_map = move(np.asarray(prior, dtype=np.float32), scan)             # Mapper.cpp:197
+                correction = self.backend.register(in_map) if self.map.shape[0] else np.eye(4, dtype=np.float32)
+                self.pose = (np.asarray(correction, dtype=np.float64) @ np.asarray(prior, dtype=np.float64)).astype(np.float32)  # :215
+                placed = move(np.asarray(correction, dtype=np.float32), in_map)      # :221
+                mask = self.backend.keep(self.map, placed, self.min_dist) if self.map.shape[0] else np.ones(placed.shape[0], bool)
+                mine = placed[mask]
+            except Exception as e:  # noqa: BLE001 -- the exchange below is a collective: take part, then re-raise
+                failure = e
         if dist.is_available() and dist.is_initialized():
             t = torch.from_numpy(np.ascontiguousarray(mine))
             if dist.get_backend(self.group) == "nccl":            # RCCL moves device tensors
@@ -242,4 +264,6 @@ class ShardedMapper:
             new_map = np.concatenate([self.map, merged], axis=0)
             self.set_map(new_map, None)
         self._resident_points = int(self.map.shape[0])
+        if failure is not None:
+            raise failure
         return self.pose, int(mine.shape[0]), int(merged.shape[0])

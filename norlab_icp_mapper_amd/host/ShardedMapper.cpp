@@ -1,6 +1,7 @@
 // ShardedMapper.cpp -- see ShardedMapper.h.
 #include "ShardedMapper.h"
 
+#include <exception>
 #include <vector>
 
 namespace nim {
@@ -42,23 +43,41 @@ bool ShardedMapper::setMap(const DataPoints& map)
 
 Mat4 ShardedMapper::processScan(const DataPoints& scan, const Mat4& estimatedPose)
 {
-    const Mat4 correction = icp.registerWithPrior(scan, estimatedPose);     // Mapper.cpp:197,213: identity while there is no map
+    // The epoch below is a collective: EVERY rank must enter it once, also a rank that has run out of scans (an empty cloud)
+    // and a rank whose registration throws (an ordinary PM::ConvergenceError) -- otherwise its peers wait in the all-gather
+    // forever.  Such a rank contributes nothing, still appends what the others accepted, and reports its own
+    // error once the epoch is through.
+    Mat4 correction = Mat4::identity();
+    std::exception_ptr failure;
+    bool contribute = scan.getNbPoints() > 0;
+    if (contribute) {
+        try {
+            correction = icp.registerWithPrior(scan, estimatedPose);        // Mapper.cpp:197,213: identity while there is no map
+        } catch (...) {
+            failure = std::current_exception();
+            contribute = false;
+        }
+    }
+    if (!contribute) (void)icpmi_stage_discard(icp.handle());               // nothing staged: count 0 in the exchange
     const Mat4 corrected = correction * estimatedPose;                       // :215
-    // the merged set comes back once, for the cell manager: at most what all ranks can contribute (every rank its whole scan;
-    // scans of the ranks are taken to be about this size -- a larger merge reports ICPMI_ERR_INVALID_ARG, nothing is lost)
-    const size_t need = 4 * (size_t)(2 * (size_t)ranks * (scan.getNbPoints() + 1));
-    if (merged.size() < need) merged.resize(need);
     int64_t mergedN = 0;
-    icpmi_status s = icpmi_staged_merge_allgather(icp.handle(), correction.data(), minDist, normalsKnn, &acceptedLocal, &appended, &residentSize,
-                                                  merged.data(), (int64_t)(merged.size() / 4), &mergedN);
+    // the merged set stays on the device; its size is only known after the exchange, so it is fetched in a second call (a
+    // host buffer sized from this rank's scan alone was too small next to larger ranks and let replicas diverge)
+    icpmi_status s = icpmi_staged_merge_allgather(icp.handle(), contribute ? correction.data() : nullptr, minDist, normalsKnn, &acceptedLocal,
+                                                  &appended, &residentSize, nullptr, 0, &mergedN);
     GpuICPSequence::check(icp.handle(), s);
-    DataPoints grown((size_t)mergedN);
-    std::copy(merged.begin(), merged.begin() + 4 * (size_t)mergedN, grown.features.begin());
-    Map::binIntoCells(grown, [&](const std::string& id, DataPoints&& cell) {
-        DataPoints old = cellManager->retrieveCell(id);
-        if (old.getNbPoints() == 0) cellManager->saveCell(id, cell);
-        else { old.concatenate(cell); cellManager->saveCell(id, old); }
-    });
+    if (mergedN > 0) {
+        if (merged.size() < 4 * (size_t)mergedN) merged.resize(4 * (size_t)mergedN);
+        GpuICPSequence::check(icp.handle(), icpmi_staged_merged_points(icp.handle(), merged.data(), mergedN, &mergedN));
+        DataPoints grown((size_t)mergedN);
+        std::copy(merged.begin(), merged.begin() + 4 * (size_t)mergedN, grown.features.begin());
+        Map::binIntoCells(grown, [&](const std::string& id, DataPoints&& cell) {
+            DataPoints old = cellManager->retrieveCell(id);
+            if (old.getNbPoints() == 0) cellManager->saveCell(id, cell);
+            else { old.concatenate(cell); cellManager->saveCell(id, old); }
+        });
+    }
+    if (failure) std::rethrow_exception(failure);
     return corrected;
 }
 

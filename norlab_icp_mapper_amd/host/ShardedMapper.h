@@ -22,7 +22,8 @@ public:
     void initCommunicator(const icpmi_comm_id& id, int nRanks, int rank); // collective
 
     bool setMap(const DataPoints& map);                                   // the same cloud on every rank
-    // one epoch (collective when a communicator is set): returns the corrected pose of THIS rank's scan
+    // one epoch (collective when a communicator is set: every rank calls it once per epoch, with an EMPTY cloud when it has no
+    // scan left): returns the corrected pose of THIS rank's scan.  A registration error is thrown after the exchange.
     Mat4 processScan(const DataPoints& scanInSensorFrame, const Mat4& estimatedPose);
 
     int64_t mapSize() const { return residentSize; }

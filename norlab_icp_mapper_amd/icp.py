@@ -595,22 +595,47 @@ class ICPSequence:
         buf = (C.c_char * 128).from_buffer_copy(unique_id)
         self._check(self._lib.icpmi_comm_init(self._h, buf, n_ranks, rank))
 
+    def commInfo(self):
+        """icpmi_comm_info: (ranks, rank, kind) as the communicator itself reports them; kind 0 none / 1 RCCL / 2 loopback."""
+        a, b, k = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        self._check(self._lib.icpmi_comm_info(self._h, C.byref(a), C.byref(b), C.byref(k)))
+        return int(a.value), int(b.value), int(k.value)
+
     def commDestroy(self):
         self._check(self._lib.icpmi_comm_destroy(self._h))
 
     def stagedMergeAllGather(self, correction, min_dist, normals_knn=0, return_merged=False, merged_capacity=None):
-        """icpmi_staged_merge_allgather: (accepted on this rank, appended on every replica, new map size[, merged points])"""
-        Tc = _T_to_c(correction)
+        """icpmi_staged_merge_allgather: (accepted on this rank, appended on every replica, new map size[, merged points]).
+        correction None: this rank contributes nothing (empty scan / failed registration) and still takes part in the exchange.
+        The merged set is fetched with icpmi_staged_merged_points once its size is known (merged_capacity only sizes the
+        optional in-call copy, which may be smaller than the set)."""
+        Tc = None if correction is None else _T_to_c(correction)
         acc, app, new_m, mn = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
         out = None
+        if return_merged and merged_capacity is not None:
+            out = np.empty((int(merged_capacity), 4), dtype=np.float32)
+        self._check(self._lib.icpmi_staged_merge_allgather(self._h, None if Tc is None else Tc.ctypes.data, min_dist, normals_knn, C.byref(acc),
+                                                           C.byref(app), C.byref(new_m), None if out is None else out.ctypes.data,
+                                                           0 if out is None else out.shape[0], C.byref(mn)))
         if return_merged:
-            cap = int(merged_capacity if merged_capacity is not None else 8 * max(self._staged_n, 1))
-            out = np.empty((cap, 4), dtype=np.float32)
-        self._check(self._lib.icpmi_staged_merge_allgather(self._h, Tc.ctypes.data, min_dist, normals_knn, C.byref(acc), C.byref(app), C.byref(new_m),
-                                                           None if out is None else out.ctypes.data, 0 if out is None else out.shape[0], C.byref(mn)))
-        if return_merged:
+            if out is None or mn.value > out.shape[0]:
+                out = self.stagedMergedPoints()
             return int(acc.value), int(app.value), int(new_m.value), out[:mn.value].copy()
         return int(acc.value), int(app.value), int(new_m.value)
+
+    def stagedMergedPoints(self):
+        """icpmi_staged_merged_points: the merged set of the last epoch."""
+        n = C.c_int64(0)
+        self._check(self._lib.icpmi_staged_merged_points(self._h, None, 0, C.byref(n)))
+        out = np.empty((n.value, 4), dtype=np.float32)
+        if n.value:
+            self._check(self._lib.icpmi_staged_merged_points(self._h, out.ctypes.data, n.value, C.byref(n)))
+        return out
+
+    def stageDiscard(self):
+        """icpmi_stage_discard: drop the scan staged by registerWithPrior."""
+        self._check(self._lib.icpmi_stage_discard(self._h))
+        self._staged_n = 0
 
     def getMap(self, with_normals=False):
         """The resident map in the caller's order (Map::getLocalPointCloud, Map.cpp:536-540)."""

@@ -206,3 +206,61 @@ def test_sharded_mapper_resident_flow_replicas_stay_identical(tmp_path):
     assert r[0]["sizes"][1] > r[0]["sizes"][0]
     # same decisions as the host-array flow (the scan is placed by two exact float transforms here, by one numpy product there)
     assert abs(int(r[0]["sizes"][2]) - int(h["sizes"][2])) <= 3
+
+
+def _uneven_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=60))
+    import oracle_bindings as ob
+    from norlab_icp_mapper_amd import synth
+    from norlab_icp_mapper_amd.dist import ShardedMapper
+
+    oicp = ob.OracleICP(ob.make_config(minimizer=1, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=10, nthreads=2))
+    fail_next = {"on": False}
+
+    class Backend:
+        @staticmethod
+        def register(scan):
+            if fail_next["on"]:
+                raise RuntimeError("ConvergenceError: no point to minimize")   # what an ordinary failed registration raises
+            err, T = oicp(scan)
+            assert err == 0
+            return T
+        set_map = staticmethod(lambda cloud, normals: oicp.setMap(cloud, normals))
+        keep = staticmethod(lambda m, c, d: ob.point_distance_keep(m, c, d, nthreads=2))
+        normals = staticmethod(lambda cloud, knn: ob.surface_normals(cloud, knn))
+
+    sc = synth.make_scene(m=5000, n=1200, seed_scan=43 + 1000 * rank)
+    mapper = ShardedMapper(Backend, min_dist_new_point=0.5)
+    mapper.set_map(sc["map"])
+    sizes, raised = [mapper.map.shape[0]], []
+    empty = np.zeros((0, 4), dtype=np.float32)
+    # epoch 0: both ranks have a scan; epoch 1: rank 1 has run out of scans (14 scans over 2, 4 or 8 ranks leave such a tail);
+    # epoch 2: rank 0's registration fails; epoch 3: both fine again -- nobody may hang, replicas must stay identical
+    plan = [(sc["scan"], sc["scan"]), (sc["scan"][::2], empty), (sc["scan"][1::2], sc["scan"][::3]), (sc["scan"][::5], sc["scan"][1::3])]
+    for e, scans in enumerate(plan):
+        fail_next["on"] = (e == 2 and rank == 0)
+        try:
+            mapper.epoch(scans[rank], np.eye(4))
+            raised.append(0)
+        except RuntimeError as ex:
+            assert "no point to minimize" in str(ex)
+            raised.append(1)
+        sizes.append(mapper.map.shape[0])
+    np.savez(os.path.join(out_dir, f"uneven{rank}.npz"), map=mapper.map, sizes=np.array(sizes), raised=np.array(raised))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_mapper_uneven_scan_counts_and_failed_registration(tmp_path):
+    """ADVICE r2 (high): a rank with no scan left, or whose registration throws, must still take part in the epoch's exchange;
+    its own error surfaces afterwards and the replicas stay identical."""
+    world = 2
+    mp.spawn(_uneven_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(os.path.join(str(tmp_path), f"uneven{k}.npz")) for k in range(world)]
+    assert np.array_equal(r[0]["map"], r[1]["map"])
+    assert np.array_equal(r[0]["sizes"], r[1]["sizes"])
+    assert list(r[0]["raised"]) == [0, 0, 1, 0] and list(r[1]["raised"]) == [0, 0, 0, 0]
+    assert r[0]["sizes"][2] > r[0]["sizes"][1] or r[0]["sizes"][1] > r[0]["sizes"][0]

@@ -425,3 +425,32 @@ def test_cpp_sharded_mapper_single_rank(tmp_path):
         assert np.linalg.norm(pose - truth[k + 1][:3, 3]) < 0.05 and 0 < int(r[6]) <= 40
     tail = re.search(r"rank 0: 3 scans in \S+ s, map (\d+) points, (\d+) cells holding (\d+) merged points", out.stdout)
     assert tail and int(tail.group(1)) == size and int(tail.group(3)) == size - len(scans[0]) and int(tail.group(2)) >= 1
+
+
+@pytest.mark.gpu
+def test_cpp_sharded_mapper_unequal_ranks_through_loopback(tmp_path):
+    """nim::ShardedMapper::processScan with ranks that contribute unequal blocks (loopback communicator, ragged): the merged set
+    is fetched at its gathered size (a host buffer sized from the local scan diverged the replicas), so the
+    resident map, the appended count and the points binned into the cell manager must agree epoch after epoch."""
+    import re
+    _build_host()
+    tmp = str(tmp_path)
+    scans, priors, truth = _make_dataset(tmp, n_scans=4, n_pts=12000)
+    cfg = os.path.join(tmp, "config.yaml")
+    open(cfg, "w").write(P2PLANE_CONFIG)
+    env = dict(os.environ, ICPMI_COMM_LOOPBACK="4", ICPMI_COMM_LOOPBACK_SHIFT="0.4", ICPMI_COMM_LOOPBACK_RAGGED="1")
+    out = subprocess.run([os.path.join(PKG, "sharded_mapping"), tmp, cfg, "0.15", "0"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert "loopback communicator active" in out.stderr
+    rows = re.findall(r"rank 0 epoch (\d+) scan (\d+): (\d+) pts, pose (\S+) (\S+) (\S+), iterations (\d+), (\d+) accepted here, (\d+) appended by all ranks, map (\d+)", out.stdout)
+    assert len(rows) == 3
+    size = len(scans[0])
+    more = 0
+    for r in rows:
+        accepted, appended, m = int(r[7]), int(r[8]), int(r[9])
+        assert m == size + appended
+        more += appended > accepted          # simulated ranks 1 and 3 hand in larger blocks than this rank's half
+        size = m
+    assert more >= 1
+    tail = re.search(r"rank 0: 3 scans in \S+ s, map (\d+) points, (\d+) cells holding (\d+) merged points", out.stdout)
+    assert tail and int(tail.group(1)) == size and int(tail.group(3)) == size - len(scans[0])
