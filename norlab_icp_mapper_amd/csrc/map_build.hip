@@ -581,7 +581,7 @@ icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float
     // ---- scatter ----
     if (ensure_cap(c, &c->d_fill, &c->cap_fill, (size_t)g.ncells) != ICPMI_OK) return ICPMI_ERR_HIP;
     HIP_TRY(c, hipMemsetAsync(c->d_fill, 0, (size_t)g.ncells * sizeof(unsigned), c->stream));
-    if (ensure_cap(c, &c->d_map_sorted, &c->cap_map, (size_t)m) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (ensure_cap(c, &c->d_map_sorted, &c->cap_map, (size_t)m + 16) != ICPMI_OK) return ICPMI_ERR_HIP;
     if (d_normals3 && ensure_cap(c, &c->d_normals_sorted, &c->cap_normals, (size_t)m) != ICPMI_OK) return ICPMI_ERR_HIP;
     c->has_normals = d_normals3 != nullptr;
     // resident raw copy (skipped when the caller IS the raw copy: the device-side map update)
@@ -612,7 +612,7 @@ icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float
         if (reaches || tiny) break;
         GridParams gl = make_grid(clo, chi, prev.cell * 2.0f, maxabs);
         if (ensure_cap(c, &c->d_lvl_cs[l], &c->cap_lvl_cs[l], (size_t)gl.ncells + 2) != ICPMI_OK) return ICPMI_ERR_HIP;
-        if (ensure_cap(c, &c->d_lvl_pts[l], &c->cap_lvl_pts[l], (size_t)m) != ICPMI_OK) return ICPMI_ERR_HIP;
+        if (ensure_cap(c, &c->d_lvl_pts[l], &c->cap_lvl_pts[l], (size_t)m + 16) != ICPMI_OK) return ICPMI_ERR_HIP;
         if (ensure_cap(c, &c->d_lvl_pos0[l], &c->cap_lvl_pos0[l], (size_t)m) != ICPMI_OK) return ICPMI_ERR_HIP;
         HIP_TRY(c, hipMemsetAsync(c->d_lvl_cs[l], 0, ((size_t)gl.ncells + 2) * sizeof(unsigned), c->stream));
         HIP_TRY(c, hipMemsetAsync(c->d_fill, 0, (size_t)gl.ncells * sizeof(unsigned), c->stream)); // ncells shrinks with l

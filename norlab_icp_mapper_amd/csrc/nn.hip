@@ -20,6 +20,14 @@ constexpr int NN_BLOCK = 256;
 #endif
 constexpr int NN1_BLOCK = ICPMI_NN1_BLOCK; // workgroup of the k = 1 pyramid kernel
 
+typedef __attribute__((address_space(1))) unsigned gunsigned;
+// sqrt for pruning radii and level choices: one v_sqrt_f32 (1 ulp) instead of the IEEE-exact sequence (~12 instructions, and the
+// kernels take it per row), nudged UP by 2^-21 relative so that it never under-estimates -- a bound that is a hair too wide only
+// ever adds candidates, it cannot change the exact minimum
+__device__ __forceinline__ float sqrt_up(float x) { return __builtin_amdgcn_sqrtf(x) * 1.0000005f; }
+typedef float vf4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) vf4 gfloat4; // 16 bytes in global memory (global_load, not flat_load)
+
 struct Cand {
     unsigned long long key; // (d2 bits << 32) | original index
     int sidx;               // position in the sorted map
@@ -650,6 +658,720 @@ __global__ __launch_bounds__(NN1_BLOCK) void nn1_ml_kernel(const float4* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// k = 1 over the grid pyramid, WAVE-QUEUE variant (r3; the loop's default).  Same search, same exactness rules, same
+// (d^2, index) keys as nn1_ml_kernel -- hence the same bits -- but the work of a wave is split differently:
+//
+//   nn1_ml_kernel gives G = 8 lanes to one query for the whole search, so every lane of a group repeats the query's
+//   set-up (transform, seed test, level choice, cell coordinates, pruning radius), the group pays 18 shuffles to flatten
+//   its nine rows into one candidate list, and every candidate load walks an 8-deep select chain to find its row:
+//   ~750 VALU instructions per wave for 8 queries, ~6 % of the lane-slots doing distance tests.
+//
+//   Here a one-wave workgroup owns Q = 64 / LPQ queries and alternates between two roles:
+//   (1) LANE PER QUERY (LPQ lanes share a query's nine rows): set-up once per query, row ranges looked up, and every
+//       non-empty row cut into PIECES of <= 8 consecutive candidates that go into an LDS work list {start, count, query};
+//   (2) LANE PER PIECE: lane i takes pieces i, i + 64, ... whatever query they belong to -- eight independent 16-byte
+//       loads in flight from ONE address register (immediate offsets; loads past the run's end are masked, the level
+//       arrays are padded), the piece's best key goes into the query's LDS slot by a 64-bit ds_min; the lane whose key IS
+//       the slot's value afterwards records its position (keys are unique per map point, and LDS operations of one wave
+//       complete in order: no race, no returned atomic);
+//   (3) lane per query again: read the slot, apply the level's exactness rule; undecided queries repeat at the next
+//       level (or, for a query that held no bound yet, with the bound its own row just gave it).
+//   The candidates of all Q queries are thus spread evenly over the 64 lanes however unevenly they are spread over the
+//   queries, and the per-query set-up is paid once (LPQ = 1) instead of eight times.
+// ------------------------------------------------------------------------------------------------
+// inclusive prefix sum over the 64 lanes of a wave in registers (DPP: shifts within rows of 16 lanes, then the row totals
+// broadcast into the following rows); every lane must be active
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned v)
+{
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); // row_shr:1
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); // row_shr:2
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); // row_shr:4
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); // row_shr:8
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1, 3
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+template <int LPQ, bool SELF>
+__global__ __launch_bounds__(64) void nn1_wq_kernel(const float4* __restrict__ queries, const int* __restrict__ qindex, BatchArgs ba,
+                                                    const float* __restrict__ Tptr, GridLevels L, float maxr2, int* __restrict__ out_sidx,
+                                                    float* __restrict__ out_d2, IcpState* __restrict__ st, unsigned* __restrict__ hard,
+                                                    unsigned* __restrict__ hist0, float4* __restrict__ match_pt,
+                                                    const uint4* __restrict__ ltab_g, int unseeded_lev, int seed_pre)
+{
+    static_assert(LPQ == 1 || LPQ == 2 || LPQ == 3 || LPQ == 4, "lanes per query in the set-up role");
+    constexpr int Q = 64 / LPQ;            // queries per wave
+    constexpr int NR = (9 + LPQ - 1) / LPQ; // rows per lane: row rr belongs to lane rr % LPQ of the query, slot rr / LPQ
+    constexpr int CAP = 16 * Q;            // pieces per pass (>= 9 Q: one piece per row always fits)
+    constexpr int PLB = 3;                 // log2 of the base piece length: 8 loads in flight per lane and piece
+    const int n = ba.n[blockIdx.y];
+    {
+        const size_t qo = (size_t)blockIdx.y * (size_t)ba.qstride;
+        queries += qo; out_sidx += qo; out_d2 += qo;
+        if (qindex) qindex += qo;
+        if (match_pt) match_pt += qo;
+        if (hist0) hist0 += (size_t)blockIdx.y * ICPMI_SELHIST_WORDS;
+        if (Tptr) Tptr = reinterpret_cast<const float*>(reinterpret_cast<const char*>(Tptr) + (size_t)blockIdx.y * sizeof(IcpState));
+        st += blockIdx.y;
+    }
+#ifdef ICPMI_NN_TIMING
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = clock64();
+#endif
+    __shared__ uint4 ltab[ICPMI_MAXLEV * 4];
+    __shared__ unsigned lh[256];
+    __shared__ uint4 pieces[CAP];            // {address of the first candidate (lo, hi), count << 8 | query slot, its position in the level array}
+    __shared__ float4 qrec[Q];               // transformed query, w = bits of its current level
+    __shared__ unsigned long long qkey[Q];   // best (d^2, index) key of the query so far
+    __shared__ unsigned qwin[Q];             // ... where that point sits: position | level << 28
+    __shared__ float4 qpt[Q];                // ... and the point itself (what the loop keeps as the next iteration's seed)
+    const int lane = threadIdx.x;
+    // XCD-aware order, as nn1_ml_kernel: workgroup b runs on XCD b % 8; each XCD gets one contiguous eighth of the queries
+    const int wgs = (int)((((long long)n + Q - 1) / Q + 7) / 8 * 8);
+    if ((int)blockIdx.x >= wgs) return;
+    const int chunk = wgs >> 3;
+    const int lb = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    const bool lane_ok = lane < Q * LPQ; // LPQ = 3: 21 queries, lane 63 idles in the set-up role
+    const int slot = lane_ok ? lane / LPQ : 0;
+    const int sub = lane_ok ? lane % LPQ : 0;
+    const int qi = lb * Q + slot;
+    const bool active = lane_ok && qi < n;
+    // ---- everything the wave needs from memory before it can start leaves in ONE round trip: stop flag, iteration, T, level
+    //      table, query, seed (a wave lives for a handful of dependent trips; each one saved is ~10 % of its life)
+    const int st_done = st->done, st_iter = st->iter;
+    uint4 ltab_mine = make_uint4(0u, 0u, 0u, 0u);
+    if (lane < ICPMI_MAXLEV * 4) ltab_mine = ltab_g[lane];
+    const float4 r = queries[active ? qi : 0];
+    const int orig = match_pt ? qi : (qindex ? qindex[active ? qi : 0] : qi);
+    int sp_kept = -1;
+    float4 qs_kept = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (match_pt) { sp_kept = out_sidx[active ? qi : 0]; qs_kept = match_pt[active ? qi : 0]; }
+    float3 p;
+    if (Tptr) p = xf_point(Tptr, r.x, r.y, r.z, r.w);
+    else p = make_float3(r.x, r.y, r.z);
+    if (st_done) return;
+    if (lane < ICPMI_MAXLEV * 4) ltab[lane] = ltab_mine;
+    if (hist0) {
+        for (int t = lane; t < 256; t += 64) lh[t] = 0;
+        // the builder of level 0 clears level 1 of the previous iteration (loop.hip, fused selection)
+        for (int gt = blockIdx.x * 64 + lane; gt < 256 + 65536; gt += wgs * 64) hist0[ICPMI_S2_C1 + gt] = 0; // (the workgroups of THIS reading: a batch launches the grid of its largest)
+    }
+    const bool allow_self = SELF;
+    __syncthreads(); // ltab / lh visible
+
+    Cand best; best.key = ~0ull; best.sidx = -1; // sidx = position in its level | level << 28
+    float4 seed_pt = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool best_is_seed = false;
+    bool decided = !active;
+    int lev0 = unseeded_lev;
+    {   // seed: see nn1_ml_kernel -- the previous match bounds the answer; start at the first level whose block holds that ball
+        int sp = -1;
+        float4 qs = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (active && allow_self && st_iter > 0) {
+            sp = match_pt ? sp_kept : out_sidx[orig];
+            if (sp >= 0) qs = match_pt ? qs_kept : L.pts[0][sp];
+        }
+        bool want = sp >= 0;
+        const float ub2 = sqdist3(p.x, p.y, p.z, qs.x, qs.y, qs.z);
+        const float ub = sqrt_up(ub2);
+        auto try_level = [&](int lev, const GridParams& gl) {
+            const float fx = (p.x - gl.ox) * gl.inv_cell, fy = (p.y - gl.oy) * gl.inv_cell, fz = (p.z - gl.oz) * gl.inv_cell;
+            float mfl = fminf(fx - floorf(fx), 1.0f - (fx - floorf(fx)));
+            mfl = fminf(mfl, fminf(fy - floorf(fy), 1.0f - (fy - floorf(fy))));
+            mfl = fminf(mfl, fminf(fz - floorf(fz), 1.0f - (fz - floorf(fz))));
+            if (!(mfl >= 0.f)) mfl = 0.f;
+            const float margin = (1.0f + mfl) * gl.cell - 2.0f * gl.slack;
+            if (want && ub * 1.000001f <= margin) {
+                lev0 = lev;
+                best.key = pack_key(ub2, __float_as_uint(qs.w));
+                best.sidx = sp; // level 0 position
+                seed_pt = qs; best_is_seed = true;
+                want = false;
+            }
+        };
+        try_level(0, L.g[0]);
+        for (int lev = 1; lev < L.nlev; ++lev) {
+            if (__ballot(want) == 0ull) break;
+            try_level(lev, L.g[lev]);
+        }
+    }
+    bool widepre = false;
+    if (seed_pre && lev0 > 0 && best.key != ~0ull) { widepre = true; lev0 = 0; }
+
+    int lev = lev0;
+    bool did_pre = false; // this level's own-row pass has run
+    NN_TICK(0);
+    for (;;) {
+        const bool run = !decided && lev < L.nlev;
+        if (__ballot(run) == 0ull) break;
+        const int lv = run ? lev : 0;
+        GridParams g;
+        const gunsigned* __restrict__ cs; // (global address space: rebuilt from integers, it would be read through the flat path)
+        unsigned long long lvl_pts;
+        {
+            const uint4 a = ltab[4 * lv], b = ltab[4 * lv + 1], c2 = ltab[4 * lv + 2], d = ltab[4 * lv + 3];
+            lvl_pts = ((unsigned long long)c2.w << 32) | c2.z;
+            g.ox = __uint_as_float(a.x); g.oy = __uint_as_float(a.y); g.oz = __uint_as_float(a.z); g.cell = __uint_as_float(a.w);
+            g.inv_cell = __uint_as_float(b.x); g.slack = __uint_as_float(b.y); g.nx = (int)b.z; g.ny = (int)b.w;
+            g.nz = (int)c2.x; g.ncells = (int)c2.y;
+            cs = reinterpret_cast<const gunsigned*>(((unsigned long long)d.y << 32) | d.x);
+        }
+        const float fx = (p.x - g.ox) * g.inv_cell, fy = (p.y - g.oy) * g.inv_cell, fz = (p.z - g.oz) * g.inv_cell;
+        const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
+        const int cx = (int)fminf(fmaxf(flx, -1.0e6f), 1.0e6f);
+        const int cy = (int)fminf(fmaxf(fly, -1.0e6f), 1.0e6f);
+        const int cz = (int)fminf(fmaxf(flz, -1.0e6f), 1.0e6f);
+        float mf = fminf(fx - flx, 1.0f - (fx - flx));
+        mf = fminf(mf, fminf(fy - fly, 1.0f - (fy - fly)));
+        mf = fminf(mf, fminf(fz - flz, 1.0f - (fz - flz)));
+        if (!(mf >= 0.f)) mf = 0.f;
+        // a query that holds no bound yet (or a seed too wide for level 0, see seed_pre) first looks at the x-row through its
+        // own cell only; the pass after that prunes with what it found
+        const bool prescan = run && !did_pre && (best.key == ~0ull || (widepre && lev == 0));
+        float rub2 = INFINITY; // squared pruning radius (with slack), +inf = no pruning
+        if (!prescan && best.key != ~0ull) {
+            const float rub = sqrt_up(__uint_as_float((unsigned)(best.key >> 32))) * 1.000001f + g.slack;
+            rub2 = rub * rub;
+        }
+        // ---- role 1: row ranges.  Branch-free on purpose: with the lookups behind `if (reach)` the compiler waits for one
+        //      row's pair of loads before it issues the next row's (NR dependent round trips); unreached rows read cs[0]
+        //      twice instead and all 2 NR loads of a lane leave together.
+        unsigned rs[NR], rn[NR];
+        {
+            const float ylo = (fy - fly) * g.cell, yhi = (1.0f - (fy - fly)) * g.cell;
+            const float zlo = (fz - flz) * g.cell, zhi = (1.0f - (fz - flz)) * g.cell;
+            unsigned ia[NR], ib[NR];
+#pragma unroll
+            for (int sl = 0; sl < NR; ++sl) {
+                const int rr = sub + sl * LPQ;
+                const int dy = (rr % 3) - 1, dz = (rr / 3) - 1;
+                bool reach = run && rr < 9 && (!prescan || rr == 4);
+                const float ddy = dy == 0 ? 0.f : (dy < 0 ? ylo : yhi);
+                const float ddz = dz == 0 ? 0.f : (dz < 0 ? zlo : zhi);
+                const float rem2 = rub2 - (ddy * ddy + ddz * ddz); // +inf without a bound
+                reach = reach && rem2 >= 0.f;
+                int xa = cx - 1, xb = cx + 1;
+                if (rem2 != INFINITY) {
+                    const float rem = sqrt_up(fmaxf(rem2, 0.f));
+                    const int xl = (int)fmaxf(floorf((p.x - rem - g.ox) * g.inv_cell), -1.0e6f);
+                    const int xh = (int)fminf(floorf((p.x + rem - g.ox) * g.inv_cell), 1.0e6f);
+                    xa = xl > xa ? xl : xa;
+                    xb = xh < xb ? xh : xb;
+                }
+                const int y = cy + dy, z = cz + dz;
+                xa = xa < 0 ? 0 : xa;
+                xb = xb > g.nx - 1 ? g.nx - 1 : xb;
+                reach = reach && y >= 0 && y < g.ny && z >= 0 && z < g.nz && xa <= xb;
+                const int rowbase = (z * g.ny + y) * g.nx;
+                ia[sl] = reach ? (unsigned)(rowbase + xa) : 0u;
+                ib[sl] = reach ? (unsigned)(rowbase + xb + 1) : 0u;
+            }
+#pragma unroll
+            for (int sl = 0; sl < NR; ++sl) { rs[sl] = cs[ia[sl]]; rn[sl] = cs[ib[sl]]; }
+#pragma unroll
+            for (int sl = 0; sl < NR; ++sl) rn[sl] -= rs[sl]; // 0 for unreached rows (both loads hit cs[0])
+        }
+        NN_TICK(1);
+        if (sub == 0 && lane_ok) {
+            qrec[slot] = make_float4(p.x, p.y, p.z, __int_as_float(lv));
+            qkey[slot] = best.key;
+            qwin[slot] = (unsigned)best.sidx;
+        }
+        // ---- pieces: piece length 8, doubled until the wave's pieces fit the list (dense cells, degenerate maps); a lane's
+        //      pieces start at the exclusive prefix sum of the counts (DPP scan in registers)
+        int plb = PLB;
+        unsigned base = 0, total = 0;
+        for (;;) {
+            unsigned np = 0;
+#pragma unroll
+            for (int sl = 0; sl < NR; ++sl) np += (rn[sl] + ((1u << plb) - 1u)) >> plb;
+            const unsigned incl = wave_incl_scan(np);
+            total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+            base = incl - np;
+            if (total <= (unsigned)CAP) break;
+            ++plb;
+        }
+#pragma unroll
+        for (int sl = 0; sl < NR; ++sl) {
+            unsigned s = rs[sl], c = rn[sl];
+            while (c) {
+                const unsigned t = c < (1u << plb) ? c : (1u << plb);
+                const unsigned long long ad = lvl_pts + (unsigned long long)s * 16ull;
+                pieces[base++] = make_uint4((unsigned)ad, (unsigned)(ad >> 32), (t << 8) | (unsigned)slot, s);
+                s += t; c -= t;
+            }
+        }
+        __syncthreads();
+        NN_TICK(2);
+#ifdef ICPMI_NN_TIMING
+        tacc[6] += 1; tacc[7] += total;
+#endif
+        // ---- role 2: lane per piece -- eight independent 16-byte loads from ONE address register (immediate offsets)
+        for (unsigned i = (unsigned)lane; i < total; i += 64u) {
+            const uint4 e = pieces[i];
+            const unsigned qsl = e.z & 255u, cnt = e.z >> 8;
+            const float4 qr = qrec[qsl];
+            // (global address space: a pointer rebuilt from integers would otherwise be loaded through the flat path)
+            const gfloat4* mp = reinterpret_cast<const gfloat4*>(((unsigned long long)e.y << 32) | e.x);
+            unsigned long long kb = ~0ull;
+            unsigned pb = 0;
+            for (unsigned c0 = 0; c0 < cnt; c0 += 8u) { // one round unless a dense cell forced pieces longer than 8
+                vf4 q[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) q[u] = mp[c0 + u]; // past the run's end: masked below (the level arrays are padded)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float d2 = sqdist3(qr.x, qr.y, qr.z, q[u].x, q[u].y, q[u].z);
+                    const unsigned long long key = pack_key(d2, __float_as_uint(q[u].w));
+                    bool ok = c0 + (unsigned)u < cnt;
+                    if (!allow_self) ok = ok && d2 > 1.1920929e-07f;
+                    if (ok && key < kb) { kb = key; pb = c0 + (unsigned)u; }
+                }
+            }
+            if (kb != ~0ull) {
+                atomicMin(&qkey[qsl], kb);
+                // LDS operations of one wave complete in order: this load sees the minima of every lane of this step; keys are
+                // unique per map point, so at most one lane finds its own key there
+                if (__atomic_load_n(&qkey[qsl], __ATOMIC_RELAXED) == kb) {
+                    const vf4 w = mp[pb]; // (an L1 hit: this lane loaded it a moment ago)
+                    qwin[qsl] = (e.w + pb) | (__float_as_uint(qr.w) << 28);
+                    qpt[qsl] = make_float4(w.x, w.y, w.z, w.w);
+                }
+            }
+        }
+        __syncthreads();
+        NN_TICK(3);
+        // ---- role 3: decide
+        if (run) {
+            const unsigned long long k2 = qkey[slot];
+            if (k2 != best.key) { best.key = k2; best.sidx = (int)qwin[slot]; best_is_seed = false; }
+            if (prescan) did_pre = true;
+            else {
+                const float margin = fmaxf((1.0f + mf) * g.cell - g.slack, 0.f);
+                const float m2 = margin * margin;
+                const float bd2 = __uint_as_float((unsigned)(best.key >> 32));
+                const bool covers = cx - 1 <= 0 && cx + 1 >= g.nx - 1 && cy - 1 <= 0 && cy + 1 >= g.ny - 1 && cz - 1 <= 0 && cz + 1 >= g.nz - 1;
+                decided = (best.key != ~0ull && bd2 <= m2) || m2 > maxr2 || covers;
+                if (!decided) { ++lev; did_pre = false; }
+            }
+        }
+        if (__ballot(!decided && lev < L.nlev) != 0ull) __syncthreads(); // slots are rewritten by the next pass
+        NN_TICK(4);
+    }
+
+    float bd2 = __uint_as_float((unsigned)(best.key >> 32));
+    const bool found = best.key != ~0ull && bd2 <= maxr2;
+    if (!found) bd2 = INFINITY;
+    const bool writer = active && sub == 0;
+    if (hist0) { // coarse level-0 histogram through LDS first: its barrier must not sit behind the global stores below
+        if (writer && bd2 != INFINITY && bd2 > 0.f) atomicAdd(&lh[__float_as_uint(bd2) >> 24], 1u);
+        __syncthreads();
+        for (int t = lane; t < 256; t += 64)
+            if (lh[t]) atomicAdd(&hist0[ICPMI_S2_C0 + (blockIdx.x % ICPMI_S2_COPIES) * 256 + t], lh[t]);
+    }
+    if (writer) {
+        int bs = -1;
+        float4 mpt = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (found) {
+            const unsigned lvb = (unsigned)best.sidx >> 28, pos = (unsigned)best.sidx & 0x0fffffffu;
+            if (lvb == 0) bs = (int)pos;
+            else {
+                const uint4 d = ltab[4 * lvb + 3];
+                bs = (int)reinterpret_cast<const unsigned*>(((unsigned long long)d.w << 32) | d.z)[pos];
+            }
+            mpt = best_is_seed ? seed_pt : qpt[slot];
+        }
+        out_sidx[orig] = bs;
+        out_d2[orig] = bd2;
+        if (match_pt) match_pt[orig] = make_float4(mpt.x, mpt.y, mpt.z, __uint_as_float((unsigned)(best.key & 0xffffffffull)));
+        if (hist0 && bd2 != INFINITY && bd2 > 0.f) {
+            const unsigned bits = __float_as_uint(bd2);
+            atomicAdd(&hist0[ICPMI_S2_F0 + (blockIdx.x % ICPMI_S2_FCOPIES) * 65536 + ICPMI_S2_FIDX(bits >> 16)], 1u);
+        }
+        if (!decided) {
+            const unsigned hslot = atomicAdd(&st->hard_count, 1u);
+            hard[hslot] = (unsigned)(qindex ? qindex[qi] : qi); // the brute pass works on the caller's order
+        }
+    }
+#ifdef ICPMI_NN_TIMING
+    NN_TICK(5);
+    if (threadIdx.x == 0 && (blockIdx.x % 61) == 0) { // a sample: same-address atomics from every wave would dominate
+        const int tb = st_iter > 1 ? 8 : 0; // steady launches in dbg[8..15], the first two in dbg[0..7]
+        for (int i = 0; i < 6; ++i) atomicAdd(&st->dbg[tb + i], (unsigned long long)tacc[i]);
+        atomicAdd(&st->dbg[tb + 6], (unsigned long long)tacc[6]);
+        atomicAdd(&st->dbg[tb + 7], 1ull);
+        atomicAdd(&st->dbg[16 + (st_iter > 1 ? 1 : 0)], (unsigned long long)tacc[7]);
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// nn1_wg_kernel: the wave-queue scheme with the roles given to DIFFERENT NUMBERS OF WAVES.  The per-query set-up is cheapest
+// with one lane per query (every instruction of it then serves 64 queries; with LPQ lanes per query it is paid LPQ times), but
+// one wave that also looks up the nine rows and works off the ~330 pieces of its 64 queries lives for ten dependent steps --
+// and at 100 k queries there are only 1.5 such waves per SIMD to hide that behind.  Here a workgroup of four waves owns 64
+// queries:
+//   (1a) wave 0, lane per query: transform, seed, level, pruning radius -> LDS record (the other waves are parked at the
+//        barrier and issue nothing);
+//   (1b) all four waves, lane = query, WAVE = ROW GROUP (rows w, w + 4, w + 8 of the 3 x 3 block): row ranges, pieces;
+//   (2)  all four waves, lane per piece (one or two steps for 64 queries);
+//   (3)  wave 0 decides and stores.
+// Same keys, same exactness rules, same bits as nn1_ml_kernel / nn1_wq_kernel.
+// ------------------------------------------------------------------------------------------------
+template <int NW, bool SELF>
+__global__ __launch_bounds__(64 * NW) void nn1_wg_kernel(const float4* __restrict__ queries, const int* __restrict__ qindex, BatchArgs ba,
+                                                     const float* __restrict__ Tptr, GridLevels L, float maxr2, int* __restrict__ out_sidx,
+                                                     float* __restrict__ out_d2, IcpState* __restrict__ st, unsigned* __restrict__ hard,
+                                                     unsigned* __restrict__ hist0, float4* __restrict__ match_pt,
+                                                     const uint4* __restrict__ ltab_g, int unseeded_lev, int seed_pre)
+{
+    static_assert(NW == 3 || NW == 4, "waves per workgroup");
+    constexpr int NT = 64 * NW, Q = 64;
+    constexpr int NR = 3;                  // rows per lane in role 1b: rr = wave + NW sl
+    constexpr int CAP = 16 * Q;            // pieces per pass (>= 9 Q: one piece per row always fits)
+    constexpr int PLB = 3;                 // log2 of the base piece length: 8 loads in flight per lane and piece
+    const int n = ba.n[blockIdx.y];
+    {
+        const size_t qo = (size_t)blockIdx.y * (size_t)ba.qstride;
+        queries += qo; out_sidx += qo; out_d2 += qo;
+        if (qindex) qindex += qo;
+        if (match_pt) match_pt += qo;
+        if (hist0) hist0 += (size_t)blockIdx.y * ICPMI_SELHIST_WORDS;
+        if (Tptr) Tptr = reinterpret_cast<const float*>(reinterpret_cast<const char*>(Tptr) + (size_t)blockIdx.y * sizeof(IcpState));
+        st += blockIdx.y;
+    }
+#ifdef ICPMI_NN_TIMING
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = clock64();
+    const long long t_c0 = tlast, t_w0 = wall_clock64();
+#endif
+    __shared__ uint4 ltab[ICPMI_MAXLEV * 4];
+    __shared__ unsigned lh[256];
+    __shared__ uint4 pieces[CAP];            // {address of the first candidate (lo, hi), count << 8 | query slot, its position in the level array}
+    __shared__ float4 qrec[Q];               // transformed query, w = bits of its current level
+    __shared__ float2 qaux[Q];               // squared pruning radius (+inf: none), flags: 1 = searching, 2 = own row only
+    __shared__ unsigned long long qkey[Q];   // best (d^2, index) key of the query so far
+    __shared__ unsigned qwin[Q];             // ... where that point sits: position | level << 28
+    __shared__ float4 qpt[Q];                // ... and the point itself (what the loop keeps as the next iteration's seed)
+    __shared__ unsigned s_any, s_total[2];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const bool w0 = wave == 0;
+    // XCD-aware order, as nn1_ml_kernel: workgroup b runs on XCD b % 8; each XCD gets one contiguous eighth of the queries
+    const int wgs = (int)((((long long)n + Q - 1) / Q + 7) / 8 * 8);
+    if ((int)blockIdx.x >= wgs) return;
+    const int chunk = wgs >> 3;
+    const int lb = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    const int slot = lane;
+    const int qi = lb * Q + slot;
+    const bool active = w0 && qi < n; // only wave 0 owns queries
+    const int st_done = st->done, st_iter = st->iter;
+    uint4 ltab_mine = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < ICPMI_MAXLEV * 4) ltab_mine = ltab_g[tid];
+    float4 r = make_float4(0.f, 0.f, 0.f, 1.f);
+    int orig = 0, sp_kept = -1;
+    float4 qs_kept = make_float4(0.f, 0.f, 0.f, 0.f);
+    float3 p = make_float3(0.f, 0.f, 0.f);
+    if (w0) { // (a wave-uniform branch: the other waves go straight to the barrier)
+        r = queries[active ? qi : 0];
+        orig = match_pt ? qi : (qindex ? qindex[active ? qi : 0] : qi);
+        if (match_pt) { sp_kept = out_sidx[active ? qi : 0]; qs_kept = match_pt[active ? qi : 0]; }
+        if (Tptr) p = xf_point(Tptr, r.x, r.y, r.z, r.w);
+        else p = make_float3(r.x, r.y, r.z);
+    }
+    if (st_done) return;
+    if (tid < ICPMI_MAXLEV * 4) ltab[tid] = ltab_mine;
+    if (hist0) {
+        for (int t = tid; t < 256; t += NT) lh[t] = 0;
+        // the builder of level 0 clears level 1 of the previous iteration (loop.hip, fused selection)
+        for (int gt = blockIdx.x * NT + tid; gt < 256 + 65536; gt += wgs * NT) hist0[ICPMI_S2_C1 + gt] = 0; // (the workgroups of THIS reading: a batch launches the grid of its largest)
+    }
+    const bool allow_self = SELF;
+
+    Cand best; best.key = ~0ull; best.sidx = -1; // sidx = position in its level | level << 28
+    float4 seed_pt = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool best_is_seed = false;
+    bool decided = !active;
+    int lev0 = unseeded_lev;
+    if (w0) {   // seed: see nn1_ml_kernel -- the previous match bounds the answer; start at the first level whose block holds that ball
+        int sp = -1;
+        float4 qs = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (active && allow_self && st_iter > 0) {
+            sp = match_pt ? sp_kept : out_sidx[orig];
+            if (sp >= 0) qs = match_pt ? qs_kept : L.pts[0][sp];
+        }
+        bool want = sp >= 0;
+        const float ub2 = sqdist3(p.x, p.y, p.z, qs.x, qs.y, qs.z);
+        const float ub = sqrt_up(ub2);
+        auto try_level = [&](int lev, const GridParams& gl) {
+            const float fx = (p.x - gl.ox) * gl.inv_cell, fy = (p.y - gl.oy) * gl.inv_cell, fz = (p.z - gl.oz) * gl.inv_cell;
+            float mfl = fminf(fx - floorf(fx), 1.0f - (fx - floorf(fx)));
+            mfl = fminf(mfl, fminf(fy - floorf(fy), 1.0f - (fy - floorf(fy))));
+            mfl = fminf(mfl, fminf(fz - floorf(fz), 1.0f - (fz - floorf(fz))));
+            if (!(mfl >= 0.f)) mfl = 0.f;
+            const float margin = (1.0f + mfl) * gl.cell - 2.0f * gl.slack;
+            if (want && ub * 1.000001f <= margin) {
+                lev0 = lev;
+                best.key = pack_key(ub2, __float_as_uint(qs.w));
+                best.sidx = sp; // level 0 position
+                seed_pt = qs; best_is_seed = true;
+                want = false;
+            }
+        };
+        try_level(0, L.g[0]);
+        for (int lev = 1; lev < L.nlev; ++lev) {
+            if (__ballot(want) == 0ull) break;
+            try_level(lev, L.g[lev]);
+        }
+    }
+    bool widepre = false;
+    if (seed_pre && lev0 > 0 && best.key != ~0ull) { widepre = true; lev0 = 0; }
+
+    int lev = lev0;
+    bool did_pre = false; // this level's own-row pass has run
+    NN_TICK(0);
+    __syncthreads(); // ltab / lh visible
+    for (;;) {
+        // ---- (1a) wave 0, lane per query: what the row lookups need goes into the query's record
+        bool run = false, prescan = false;
+        if (w0) {
+            run = !decided && lev < L.nlev;
+            const bool any = __ballot(run) != 0ull;
+            if (lane == 0) { s_any = any ? 1u : 0u; s_total[0] = 0u; s_total[1] = 0u; }
+            if (any) {
+                const int lv = run ? lev : 0;
+                // a query that holds no bound yet (or a seed too wide for level 0, see seed_pre) first looks at the x-row through
+                // its own cell only; the pass after that prunes with what it found
+                prescan = run && !did_pre && (best.key == ~0ull || (widepre && lev == 0));
+                float rub2 = INFINITY; // squared pruning radius (with slack), +inf = no pruning
+                if (!prescan && best.key != ~0ull) {
+                    const float slack = __uint_as_float(ltab[4 * lv + 1].y);
+                    const float rub = sqrt_up(__uint_as_float((unsigned)(best.key >> 32))) * 1.000001f + slack;
+                    rub2 = rub * rub;
+                }
+                qrec[slot] = make_float4(p.x, p.y, p.z, __int_as_float(lv));
+                qaux[slot] = make_float2(rub2, __int_as_float((run ? 1 : 0) | (prescan ? 2 : 0)));
+                qkey[slot] = best.key;
+                qwin[slot] = (unsigned)best.sidx;
+            }
+        }
+        __syncthreads();
+        if (!s_any) break;
+        NN_TICK(1);
+        // ---- (1b) all waves: lane = query, wave = row group
+        float mf, g_cell, g_slack;
+        bool covers;
+        {
+            const float4 qr = qrec[slot];
+            const float2 qa = qaux[slot];
+            const int lv = __float_as_int(qr.w);
+            const int fl = __float_as_int(qa.y);
+            const bool qrun = (fl & 1) != 0, qpre = (fl & 2) != 0;
+            const float rub2 = qa.x;
+            GridParams g;
+            const gunsigned* __restrict__ cs; // (global address space: rebuilt from integers, it would be read through the flat path)
+            unsigned long long lvl_pts;
+            {
+                const uint4 a = ltab[4 * lv], b = ltab[4 * lv + 1], c2 = ltab[4 * lv + 2], d = ltab[4 * lv + 3];
+                lvl_pts = ((unsigned long long)c2.w << 32) | c2.z;
+                g.ox = __uint_as_float(a.x); g.oy = __uint_as_float(a.y); g.oz = __uint_as_float(a.z); g.cell = __uint_as_float(a.w);
+                g.inv_cell = __uint_as_float(b.x); g.slack = __uint_as_float(b.y); g.nx = (int)b.z; g.ny = (int)b.w;
+                g.nz = (int)c2.x; g.ncells = (int)c2.y;
+                cs = reinterpret_cast<const gunsigned*>(((unsigned long long)d.y << 32) | d.x);
+            }
+            const float fx = (qr.x - g.ox) * g.inv_cell, fy = (qr.y - g.oy) * g.inv_cell, fz = (qr.z - g.oz) * g.inv_cell;
+            const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
+            const int cx = (int)fminf(fmaxf(flx, -1.0e6f), 1.0e6f);
+            const int cy = (int)fminf(fmaxf(fly, -1.0e6f), 1.0e6f);
+            const int cz = (int)fminf(fmaxf(flz, -1.0e6f), 1.0e6f);
+            mf = fminf(fx - flx, 1.0f - (fx - flx));
+            mf = fminf(mf, fminf(fy - fly, 1.0f - (fy - fly)));
+            mf = fminf(mf, fminf(fz - flz, 1.0f - (fz - flz)));
+            if (!(mf >= 0.f)) mf = 0.f;
+            g_cell = g.cell; g_slack = g.slack;
+            covers = cx - 1 <= 0 && cx + 1 >= g.nx - 1 && cy - 1 <= 0 && cy + 1 >= g.ny - 1 && cz - 1 <= 0 && cz + 1 >= g.nz - 1;
+            // row ranges: branch-free so that all 2 NR loads of a lane leave together (unreached rows read cs[0] twice)
+            unsigned rs[NR], rn[NR];
+            {
+                const float ylo = (fy - fly) * g.cell, yhi = (1.0f - (fy - fly)) * g.cell;
+                const float zlo = (fz - flz) * g.cell, zhi = (1.0f - (fz - flz)) * g.cell;
+                unsigned ia[NR], ib[NR];
+#pragma unroll
+                for (int sl = 0; sl < NR; ++sl) {
+                    const int rr = wave + sl * NW; // wave-uniform
+                    const int dy = (rr % 3) - 1, dz = (rr / 3) - 1;
+                    bool reach = qrun && rr < 9 && (!qpre || rr == 4);
+                    const float ddy = dy == 0 ? 0.f : (dy < 0 ? ylo : yhi);
+                    const float ddz = dz == 0 ? 0.f : (dz < 0 ? zlo : zhi);
+                    const float rem2 = rub2 - (ddy * ddy + ddz * ddz); // +inf without a bound
+                    reach = reach && rem2 >= 0.f;
+                    int xa = cx - 1, xb = cx + 1;
+                    if (rem2 != INFINITY) {
+                        const float rem = sqrt_up(fmaxf(rem2, 0.f));
+                        const int xl = (int)fmaxf(floorf((qr.x - rem - g.ox) * g.inv_cell), -1.0e6f);
+                        const int xh = (int)fminf(floorf((qr.x + rem - g.ox) * g.inv_cell), 1.0e6f);
+                        xa = xl > xa ? xl : xa;
+                        xb = xh < xb ? xh : xb;
+                    }
+                    const int y = cy + dy, z = cz + dz;
+                    xa = xa < 0 ? 0 : xa;
+                    xb = xb > g.nx - 1 ? g.nx - 1 : xb;
+                    reach = reach && y >= 0 && y < g.ny && z >= 0 && z < g.nz && xa <= xb;
+                    const int rowbase = (z * g.ny + y) * g.nx;
+                    ia[sl] = reach ? (unsigned)(rowbase + xa) : 0u;
+                    ib[sl] = reach ? (unsigned)(rowbase + xb + 1) : 0u;
+                }
+#pragma unroll
+                for (int sl = 0; sl < NR; ++sl) { rs[sl] = cs[ia[sl]]; rn[sl] = cs[ib[sl]]; }
+#pragma unroll
+                for (int sl = 0; sl < NR; ++sl) rn[sl] -= rs[sl]; // 0 for unreached rows (both loads hit cs[0])
+            }
+            // pieces: length 8; a lane's pieces start at the wave's exclusive prefix (DPP scan) behind the wave's share of the list
+            // (one LDS atomic per wave).  If the workgroup's pieces overflow the list (dense cells, degenerate maps), everybody
+            // repeats the count with pieces long enough to fit.
+            int plb = PLB;
+            unsigned base = 0;
+            for (int round = 0; round < 2; ++round) {
+                unsigned np = 0;
+#pragma unroll
+                for (int sl = 0; sl < NR; ++sl) np += (rn[sl] + ((1u << plb) - 1u)) >> plb;
+                const unsigned incl = wave_incl_scan(np);
+                const unsigned wtot = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+                unsigned wb = 0;
+                if (lane == 63 && wtot) wb = atomicAdd(&s_total[round], wtot);
+                wb = (unsigned)__builtin_amdgcn_readlane((int)wb, 63);
+                base = wb + incl - np;
+                __syncthreads();
+                const unsigned tot = s_total[round];
+                if (tot <= (unsigned)CAP) break;
+                // sum over rows of ceil(c / 2^(plb + k)) <= tot / 2^k + (number of rows <= 9 Q)
+                int k = 1;
+                while ((tot >> k) > (unsigned)(CAP - 9 * Q)) ++k;
+                plb += k;
+            }
+#pragma unroll
+            for (int sl = 0; sl < NR; ++sl) {
+                unsigned s = rs[sl], c = rn[sl];
+                while (c) {
+                    const unsigned t = c < (1u << plb) ? c : (1u << plb);
+                    const unsigned long long ad = lvl_pts + (unsigned long long)s * 16ull;
+                    pieces[base++] = make_uint4((unsigned)ad, (unsigned)(ad >> 32), (t << 8) | (unsigned)slot, s);
+                    s += t; c -= t;
+                }
+            }
+        }
+        __syncthreads();
+        const unsigned total = s_total[1] ? s_total[1] : s_total[0];
+        NN_TICK(2);
+#ifdef ICPMI_NN_TIMING
+        tacc[6] += 1; tacc[7] += total;
+#endif
+        // ---- (2) all waves, lane per piece: eight independent 16-byte loads from ONE address register (immediate offsets).
+        //      The atomics of a step and the look at their outcome are separated by a workgroup barrier.
+        for (unsigned i0 = 0; i0 < total; i0 += (unsigned)NT) {
+            const unsigned i = i0 + (unsigned)tid;
+            const bool has = i < total;
+            const uint4 e = pieces[has ? i : 0u];
+            const unsigned qsl = e.z & 255u, cnt = has ? e.z >> 8 : 0u;
+            const float4 qr = qrec[qsl];
+            // (global address space: a pointer rebuilt from integers would otherwise be loaded through the flat path)
+            const gfloat4* mp = reinterpret_cast<const gfloat4*>(((unsigned long long)e.y << 32) | e.x);
+            unsigned long long kb = ~0ull;
+            unsigned pb = 0;
+            float bx = 0.f, by = 0.f, bz = 0.f; // the best candidate's coordinates ride along (a reload would be one more trip)
+            for (unsigned c0 = 0; c0 < cnt; c0 += 8u) { // one round unless a dense cell forced pieces longer than 8
+                vf4 q[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) q[u] = mp[c0 + u]; // past the run's end: masked below (the level arrays are padded)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float d2 = sqdist3(qr.x, qr.y, qr.z, q[u].x, q[u].y, q[u].z);
+                    const unsigned long long key = pack_key(d2, __float_as_uint(q[u].w));
+                    bool ok = c0 + (unsigned)u < cnt;
+                    if (!allow_self) ok = ok && d2 > 1.1920929e-07f;
+                    if (ok && key < kb) { kb = key; pb = c0 + (unsigned)u; bx = q[u].x; by = q[u].y; bz = q[u].z; }
+                }
+            }
+            if (kb != ~0ull) atomicMin(&qkey[qsl], kb);
+            __syncthreads();
+            // keys are unique per map point: at most one lane of the workgroup finds its own key in the slot
+            if (kb != ~0ull && __atomic_load_n(&qkey[qsl], __ATOMIC_RELAXED) == kb) {
+                qwin[qsl] = (e.w + pb) | (__float_as_uint(qr.w) << 28);
+                qpt[qsl] = make_float4(bx, by, bz, __uint_as_float((unsigned)(kb & 0xffffffffull)));
+            }
+        }
+        __syncthreads();
+        NN_TICK(3);
+        // ---- (3) wave 0 decides
+        if (w0 && run) {
+            const unsigned long long k2 = qkey[slot];
+            if (k2 != best.key) { best.key = k2; best.sidx = (int)qwin[slot]; best_is_seed = false; }
+            if (prescan) did_pre = true;
+            else {
+                const float margin = fmaxf((1.0f + mf) * g_cell - g_slack, 0.f);
+                const float m2 = margin * margin;
+                const float bd2 = __uint_as_float((unsigned)(best.key >> 32));
+                decided = (best.key != ~0ull && bd2 <= m2) || m2 > maxr2 || covers;
+                if (!decided) { ++lev; did_pre = false; }
+            }
+        }
+        NN_TICK(4);
+    }
+
+    float bd2 = __uint_as_float((unsigned)(best.key >> 32));
+    const bool found = best.key != ~0ull && bd2 <= maxr2;
+    if (!found) bd2 = INFINITY;
+    const bool writer = active;
+    if (hist0) { // coarse level-0 histogram through LDS first: its barrier must not sit behind the global stores below
+        if (writer && bd2 != INFINITY && bd2 > 0.f) atomicAdd(&lh[__float_as_uint(bd2) >> 24], 1u);
+        __syncthreads();
+        for (int t = tid; t < 256; t += NT)
+            if (lh[t]) atomicAdd(&hist0[ICPMI_S2_C0 + (blockIdx.x % ICPMI_S2_COPIES) * 256 + t], lh[t]);
+    }
+    if (writer) {
+        int bs = -1;
+        float4 mpt = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (found) {
+            const unsigned lvb = (unsigned)best.sidx >> 28, pos = (unsigned)best.sidx & 0x0fffffffu;
+            if (lvb == 0) bs = (int)pos;
+            else {
+                const uint4 d = ltab[4 * lvb + 3];
+                bs = (int)reinterpret_cast<const unsigned*>(((unsigned long long)d.w << 32) | d.z)[pos];
+            }
+            mpt = best_is_seed ? seed_pt : qpt[slot];
+        }
+        out_sidx[orig] = bs;
+        out_d2[orig] = bd2;
+        if (match_pt) match_pt[orig] = make_float4(mpt.x, mpt.y, mpt.z, __uint_as_float((unsigned)(best.key & 0xffffffffull)));
+        if (hist0 && bd2 != INFINITY && bd2 > 0.f) {
+            const unsigned bits = __float_as_uint(bd2);
+            atomicAdd(&hist0[ICPMI_S2_F0 + (blockIdx.x % ICPMI_S2_FCOPIES) * 65536 + ICPMI_S2_FIDX(bits >> 16)], 1u);
+        }
+        if (!decided) {
+            const unsigned hslot = atomicAdd(&st->hard_count, 1u);
+            hard[hslot] = (unsigned)(qindex ? qindex[qi] : qi); // the brute pass works on the caller's order
+        }
+    }
+#ifdef ICPMI_NN_TIMING
+    NN_TICK(5);
+    if (threadIdx.x == 0 && st_iter > 1) { // the heaviest workgroup of the steady launches: its life and its pieces
+        atomicMax(&st->dbg[20], (unsigned long long)(clock64() - t_c0));
+        atomicMax(&st->dbg[21], (unsigned long long)tacc[7]);
+    }
+    if (threadIdx.x == 0 && (blockIdx.x % 61) == 0) { // a sample: same-address atomics from every wave would dominate
+        const int tb = st_iter > 1 ? 8 : 0; // steady launches in dbg[8..15], the first two in dbg[0..7]
+        for (int i = 0; i < 6; ++i) atomicAdd(&st->dbg[tb + i], (unsigned long long)tacc[i]);
+        atomicAdd(&st->dbg[tb + 6], (unsigned long long)tacc[6]);
+        atomicAdd(&st->dbg[tb + 7], 1ull);
+        atomicAdd(&st->dbg[16 + (st_iter > 1 ? 1 : 0)], (unsigned long long)tacc[7]);
+        atomicAdd(&st->dbg[22], (unsigned long long)(clock64() - t_c0));       // shader clock ticks of this workgroup's life
+        atomicAdd(&st->dbg[23], (unsigned long long)(wall_clock64() - t_w0));  // ... and 100 MHz constant-clock ticks of the same
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
 // 2 <= k <= 8 over the grid pyramid: the k = 1 scheme with a sorted list per lane.  G lanes serve one
 // query; candidates of a level pass are dealt to the lanes as in nn1_ml_kernel, every lane keeps the
 // KMAX best of ITS candidates; after a pass the group merges by KMAX rounds of "extract the group
@@ -1237,13 +1959,36 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
         long long total_q = 0;
         for (int b = 0; b < ba.nscan; ++b) total_q += ba.n[b];
         const int g_narrow = getenv("ICPMI_NN_G") ? g_seeded : (total_q >= g4_from ? 4 : 8);
-        if (narrow && g_narrow == 2) LAUNCH_ML(2, 4);
+        // r3: the wave-queue kernel (nn1_wq_kernel) is the default; ICPMI_NN_WQ=0 brings nn1_ml_kernel back for A/B runs
+        static int use_wq = -1, wq_lpq = -1;
+        if (use_wq < 0) { const char* e = getenv("ICPMI_NN_WQ"); use_wq = e ? atoi(e) : 1; }
+        if (wq_lpq < 0) { const char* e = getenv("ICPMI_NN_WQ_LPQ"); wq_lpq = e ? atoi(e) : 2; }
+#define LAUNCH_WQ2(LPQ_, S_)                                                                                                    \
+    hipLaunchKernelGGL((nn1_wq_kernel<LPQ_, S_>), dim3((int)(((n + (64 / LPQ_) - 1) / (64 / LPQ_) + 7) / 8 * 8), ba.nscan), dim3(64), 0, c->stream,   \
+                       q, qi, ba, d_T, c->levels, lc.maxr2, d_sidx, d_d2, d_state, c->d_hard, h0, mp, c->d_lvl_tab, unseeded_lev, seed_pre)
+#define LAUNCH_WQ(LPQ_) do { if (allow_self) LAUNCH_WQ2(LPQ_, true); else LAUNCH_WQ2(LPQ_, false); } while (0)
+        static int wg_nw = -1;
+        if (wg_nw < 0) { const char* e = getenv("ICPMI_NN_WG"); wg_nw = e ? atoi(e) : 4; }
+#define LAUNCH_WG2(NW_, S_)                                                                                                     \
+    hipLaunchKernelGGL((nn1_wg_kernel<NW_, S_>), dim3((int)(((n + 63) / 64 + 7) / 8 * 8), ba.nscan), dim3(64 * NW_), 0, c->stream,  \
+                       q, qi, ba, d_T, c->levels, lc.maxr2, d_sidx, d_d2, d_state, c->d_hard, h0, mp, c->d_lvl_tab, unseeded_lev, seed_pre)
+        if (use_wq && wg_nw == 4) { if (allow_self) LAUNCH_WG2(4, true); else LAUNCH_WG2(4, false); }
+        else if (use_wq && wg_nw > 0) { if (allow_self) LAUNCH_WG2(3, true); else LAUNCH_WG2(3, false); }
+        else if (use_wq) {
+            if (wq_lpq == 1) LAUNCH_WQ(1);
+            else if (wq_lpq == 3) LAUNCH_WQ(3);
+            else if (wq_lpq == 4) LAUNCH_WQ(4);
+            else LAUNCH_WQ(2);
+        }
+        else if (narrow && g_narrow == 2) LAUNCH_ML(2, 4);
         else if (narrow && g_narrow == 4) LAUNCH_ML(4, 4);
         else if (narrow) LAUNCH_ML(8, 4);
         else if (total_q >= g4_from && !getenv("ICPMI_NN_WIDE16")) LAUNCH_ML(8, 4); // the wide first launches, likewise one step narrower
         else LAUNCH_ML(16, 4);
 #undef LAUNCH_ML
 #undef LAUNCH_ML2
+#undef LAUNCH_WQ
+#undef LAUNCH_WQ2
         const GridParams& top = c->levels.g[c->levels.nlev - 1];
         if (!std::isfinite(lc.max_dist) || (top.cell - top.slack) <= lc.max_dist) {
             hipLaunchKernelGGL(nn1_hard_kernel, dim3(512), dim3(NN_BLOCK), 0, c->stream, d_reading, d_T, c->d_map_sorted, (int)c->m,

@@ -439,7 +439,7 @@ def test_cpp_sharded_mapper_unequal_ranks_through_loopback(tmp_path):
     cfg = os.path.join(tmp, "config.yaml")
     open(cfg, "w").write(P2PLANE_CONFIG)
     env = dict(os.environ, ICPMI_COMM_LOOPBACK="4", ICPMI_COMM_LOOPBACK_SHIFT="0.4", ICPMI_COMM_LOOPBACK_RAGGED="1")
-    out = subprocess.run([os.path.join(PKG, "sharded_mapping"), tmp, cfg, "0.15", "0"], capture_output=True, text=True, timeout=600, env=env)
+    out = subprocess.run([os.path.join(PKG, "sharded_mapping"), tmp, cfg, "0.15", "10"], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr + out.stdout
     assert "loopback communicator active" in out.stderr
     rows = re.findall(r"rank 0 epoch (\d+) scan (\d+): (\d+) pts, pose (\S+) (\S+) (\S+), iterations (\d+), (\d+) accepted here, (\d+) appended by all ranks, map (\d+)", out.stdout)
