@@ -51,6 +51,16 @@ CHAINS = {
 }
 
 
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def step_stats(ms):
     return {"min": min(ms), "median": statistics.median(ms), "max": max(ms), "n": len(ms)}
 
@@ -77,7 +87,8 @@ def nn_roofline(pkg, dev, chain, d_map, d_nrm, d_scan, n_scan, m_map, traffic_ke
         except Exception:
             traffic = None
     del prof
-    return {"bound": "hbm", "kernel": "nn1_ml_kernel" if kq == 1 else "nnk_ml_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+    nn1 = "nn1_ml_kernel" if os.environ.get("ICPMI_NN_WQ", "1") == "0" else ("nn1_wq_kernel" if os.environ.get("ICPMI_NN_WG", "4") == "0" else "nn1_wg_kernel")
+    return {"bound": "hbm", "kernel": nn1 if kq == 1 else "nnk_ml_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
             "avg_launch_us": nn_avg_ms * 1e3, "launches_timed": nn_cnt}
 
@@ -200,7 +211,14 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     assert icp.setMapDev(d_map.data_ptr(), d_map.shape[0], d_nrm.data_ptr())
-    set_map_ms = (time.perf_counter() - t0) * 1e3
+    set_map_ms = (time.perf_counter() - t0) * 1e3          # first call on this handle: includes every allocation
+    warm = []
+    for _ in range(5):                                      # what Map::updateLocalPointCloud pays from the second update on
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        assert icp.setMapDev(d_map.data_ptr(), d_map.shape[0], d_nrm.data_ptr())
+        warm.append((time.perf_counter() - t0) * 1e3)
+    set_map_warm_ms = statistics.median(warm)
 
     batch_scans = None
     if args.batch > 1:
@@ -330,6 +348,7 @@ def main():
         out["step_ms"] = step_stats(per_step)
         out["device_loop_ms_per_step"] = loop_ms / args.steps
         out["set_map_ms"] = set_map_ms
+        out["set_map_warm_ms"] = set_map_warm_ms
         if normals_ms is not None:
             out["surface_normals_ms"] = normals_ms
             out["config"]["map_normals"] = "SurfaceNormalDataPointsFilter knn 10 (icpmi_surface_normals, host pointers)"
@@ -363,6 +382,27 @@ def main():
                 "pose_err_vs_ground_truth": {"m": g3t, "rad": g3r},
                 "roofline": nn_roofline(pkg, dev, c3, d_map, d_nrm3, d_scan, args.scan_points, args.map_points, "hbm_bytes_per_launch_p2plane")}
             del icp3, d_nrm3
+            # the documented chain (docs/MapperConfiguration.md:174-189): knn 6, point-to-plane, epsilon 0
+            c6 = dict(CHAINS["docs_knn6"])
+            icp6 = pkg.ICPSequence(device=dev, max_iterations=ITERS_PER_STEP, **c6)
+            icp6.setMapDev(d_map.data_ptr(), d_map.shape[0], d_nrm.data_ptr())
+            T6, el6, per6 = time_registrations(torch, icp6, d_scan, max(args.steps // 2, 5), args.warmup)
+            g6t, g6r = pkg.synth.pose_error(T6, sc["T_gt"])
+            extras["docs_knn6"] = {
+                "config": "docs/MapperConfiguration.md:174-189: KDTreeMatcher knn 6 maxDist 2.0 epsilon 0, TrimmedDist 0.85, PointToPlane; 100k-pt scan vs 1M-pt map",
+                "value": max(args.steps // 2, 5) * ITERS_PER_STEP / el6, "unit": "iterations/s", "step_ms": step_stats(per6),
+                "pose_err_vs_ground_truth": {"m": g6t, "rad": g6r},
+                "roofline": nn_roofline(pkg, dev, c6, d_map, d_nrm, d_scan, args.scan_points, args.map_points, "hbm_bytes_per_launch_knn6")}
+            if not args.no_cpu:
+                import oracle_bindings as ob6
+                o6 = ob6.OracleICP(ob6.make_config(max_iterations=ITERS_PER_STEP, nthreads=min(32, len(os.sched_getaffinity(0))), minimizer=2, knn=6, max_dist=2.0,
+                                                    outliers=[(4, 0.85)]))
+                o6.setMap(sc["map"], sc["normals"])
+                _, T6c = o6(sc["scan"])
+                e6t, e6r = pkg.synth.pose_error(T6, T6c)
+                extras["docs_knn6"]["pose_err_vs_cpu"] = {"m": e6t, "rad": e6r}
+                extras["docs_knn6"]["cpu_iterations_per_s"] = o6.stats.iterations / o6.stats.seconds_total
+            del icp6
             # batch of 8 readings: one GPU serving 8 scan streams
             B = 8
             scans8 = [d_scan] + [torch.from_numpy(pkg.synth.make_scene(m=8, n=args.scan_points, seed_scan=43 + 7 * b, scale=args.scale)["scan"]).cuda()
@@ -445,6 +485,7 @@ def main():
                           f"{ITERS_PER_STEP}-iteration registrations on {nthreads} threads ({mt_secs:.1f} s, {mt_its:.2f} it/s) and "
                           f"{o1.stats.iterations} iterations on 1 thread ({st_its:.2f} it/s); kd-tree build {build_s:.2f} s excluded",
                 "value_1thread": st_its, "value_multithread": mt_its, "host_cores": cores,
+                "cpu_model": cpu_model(), "compiler_flags": "gcc -O3 -march=x86-64-v3 -mfma -ffp-contract=off -fopenmp (oracle/Makefile)",
             }
             out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]
             if out["libpointmatcher"] == "present":

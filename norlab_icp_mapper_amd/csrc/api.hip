@@ -514,6 +514,9 @@ icpmi_status icpmi_minimize_step(icpmi_handle h, const float* reading4, int64_t 
     if (stats) memset(stats, 0, sizeof *stats);
     if (ensure_cap(h, &h->d_reading, &h->cap_reading, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
     HIP_TRY(h, hipMemcpyAsync(h->d_reading, reading4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+    // d_reading has new contents: a tile-sorted copy of what was there before (an icpmi_knn with the same n) must not be searched in
+    // its place (r3: tests/test_gpu_golden.py found the step computed on the previous call's queries)
+    h->qsorted_n = -1; h->qsorted_src = nullptr;
     LoopCfg lc = make_loop_cfg(h, 1);
     for (int f = 0; f < lc.n_out; ++f)
         if (lc.out_type[f] == ICPMI_OUT_SURFACENORMAL) { h->last_error = "minimize_step: SurfaceNormal filter needs icpmi_register"; return ICPMI_ERR_UNSUPPORTED; }

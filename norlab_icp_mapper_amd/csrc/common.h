@@ -226,6 +226,7 @@ struct icpmi_ctx {
     float4* d_match_pt = nullptr; size_t cap_match_pt = 0;     // k = 1 loop: matched map point (xyz, original index bits) per query slot
     float4* nn_match_pt = nullptr;    // set by the loop: keep the loop state (sidx, d2, matched point) in query order
     bool nn_out_sorted = false;       // set by the NN launcher: true if the launched kernel did so
+    bool nn_sorted_k = false;         // set by the loop for k > 1: keep the k matches of a query at its slot of the tile-sorted order
     IcpState* d_state = nullptr;                               // ICPMI_MAX_BATCH states (a single registration uses the first)
     IcpState* h_state = nullptr;                               // pinned mirror (ICPMI_MAX_BATCH)
     int batch_cur = 1;                                         // readings of the launch sequence being enqueued (set by the loop)

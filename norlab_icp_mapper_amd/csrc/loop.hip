@@ -1504,11 +1504,11 @@ static void launch_accumulate_ext(icpmi_ctx* c, int64_t n, const LoopCfg& lc, in
     const float4* rn = lc.has_read_normals ? c->d_read_normals : nullptr;
     const int is_med = slot >= 0 && lc.out_type[slot] == ICPMI_OUT_MEDIANDIST;
     const float factor = slot >= 0 ? lc.out_param[slot] : 0.f;
-    const bool sorted = lc.k == 1 && c->nn_out_sorted; // loop state in query order (see nn1_ml_kernel)
+    const bool sorted = c->nn_out_sorted; // loop state in query order (k = 1: with the matched points, see nn1_wg_kernel; k > 1: ids and d2)
     const BatchArgs ba = cur_batch(c, n);
     hipLaunchKernelGGL((accumulate_kernel<MIN, FUSED, EXT>), dim3(nb, ba.nscan), dim3(256), 0, c->stream, sorted ? c->d_qsorted : c->d_reading, ba, acc_cap(), lc, c->d_state,
                        c->d_map_sorted, c->has_normals ? c->d_normals_sorted : (const float4*)nullptr, rn, c->d_sidx, c->d_d2, c->d_partials, c->d_selhist, slot, is_med, factor,
-                       sorted ? c->d_match_pt : (const float4*)nullptr, sorted ? c->d_qindex : (const int*)nullptr,
+                       (sorted && lc.k == 1) ? c->d_match_pt : (const float4*)nullptr, sorted ? c->d_qindex : (const int*)nullptr,
                        (EXT && c->raw_has_scalar) ? c->d_raw_s : (const float*)nullptr);
 }
 
@@ -1543,8 +1543,10 @@ static icpmi_status enqueue_iteration(icpmi_ctx* c, int64_t n, const LoopCfg& lc
     static int keep_pts = -1;
     if (keep_pts < 0) { const char* e = getenv("ICPMI_SORTED_STATE"); keep_pts = e ? atoi(e) : 1; }
     c->nn_match_pt = (lc.k == 1 && keep_pts) ? c->d_match_pt : nullptr;
+    c->nn_sorted_k = lc.k > 1 && keep_pts;
     c->nn_out_sorted = false;
     icpmi_status s = nn_launch_k(c, c->d_reading, n, c->d_state->T_iter, lc, 1, c->d_sidx, c->d_d2, c->d_state);
+    c->nn_sorted_k = false; // (only this launch: stage calls on the same handle answer in the caller's order)
     if (s != ICPMI_OK) return s;
     if (nn1) HIP_TRY(c, hipEventRecord(nn1, c->stream));
     enqueue_selection(c, lc, n * lc.k);
@@ -1905,6 +1907,7 @@ icpmi_status loop_single_step(icpmi_ctx* c, int64_t n, const LoopCfg& lc, const 
     c->nn_hist0 = fused_filter_slot(l1) >= 0 ? c->d_selhist : nullptr;
     c->nn_builds_hist0 = false;
     c->nn_match_pt = nullptr;
+    c->nn_sorted_k = false;
     c->nn_out_sorted = false;
     icpmi_status s = nn_launch_k(c, c->d_reading, n, c->d_state->T_iter, l1, 1, c->d_sidx, c->d_d2, c->d_state);
     if (s == ICPMI_OK) {

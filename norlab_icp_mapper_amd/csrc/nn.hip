@@ -1385,7 +1385,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nnk_ml_kernel(const float4* __restri
                                                           const float* __restrict__ Tptr, const uint4* __restrict__ ltab_g, int nlev,
                                                           int k, float maxr2, int allow_self_i, int seeded, int* __restrict__ out_sidx,
                                                           float* __restrict__ out_d2, IcpState* __restrict__ st,
-                                                          unsigned* __restrict__ hard)
+                                                          unsigned* __restrict__ hard, int out_sorted)
 {
     static_assert(G == 8, "lanes per query");
     constexpr int NB = 4;
@@ -1401,7 +1401,9 @@ __global__ __launch_bounds__(NN_BLOCK) void nnk_ml_kernel(const float4* __restri
     const int sub = tid % G;
     const bool active = qi < n;
     const float4 r = queries[active ? qi : 0];
-    const int orig = qindex ? qindex[active ? qi : 0] : qi;
+    // out_sorted (the loop, r3): the k matches of a query live at its slot of the TILE-SORTED order -- seeds and results are
+    // coalesced, and the pair sums then walk spatially coherent matches (their gathers share cache lines)
+    const int orig = (qindex && !out_sorted) ? qindex[active ? qi : 0] : qi;
     float3 p;
     if (Tptr) p = xf_point(Tptr, r.x, r.y, r.z, r.w);
     else p = make_float3(r.x, r.y, r.z);
@@ -1627,7 +1629,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nnk_ml_kernel(const float4* __restri
         }
         if (sub == 0 && !decided) {
             const unsigned slot = atomicAdd(&st->hard_count, 1u);
-            hard[slot] = (unsigned)orig;
+            hard[slot] = (unsigned)(qindex ? qindex[qi] : qi); // the brute pass works on the caller's order
         }
     }
 }
@@ -2014,9 +2016,13 @@ static icpmi_status nnk_launch_t(icpmi_ctx* c, const float4* d_reading, int64_t 
             const int* qi = sorted ? c->d_qindex : nullptr;
             const int seeded = (c->nn_iter_hint > 0 && allow_self) ? 1 : 0;
             const int grid = (int)(((n * G + NN_BLOCK - 1) / NN_BLOCK + 7) / 8 * 8);
-            hipLaunchKernelGGL((nnk_ml_kernel<G, (KMAX <= 8 ? KMAX : 8)>), dim3(grid), dim3(NN_BLOCK), 0, c->stream, q, qi, (int)n, d_T, c->d_lvl_tab,
-                               c->levels.nlev, lc.k, lc.maxr2, allow_self, seeded, d_sidx, d_d2, d_state, c->d_hard);
             const GridParams& top = c->levels.g[c->levels.nlev - 1];
+            const bool needs_hard = !std::isfinite(lc.max_dist) || (top.cell - top.slack) <= lc.max_dist;
+            // loop mode: results in query order (the brute-force pass works in the caller's order: chains that may need it stay there)
+            const int out_sorted = (c->nn_sorted_k && sorted && !needs_hard) ? 1 : 0;
+            c->nn_out_sorted = out_sorted != 0;
+            hipLaunchKernelGGL((nnk_ml_kernel<G, (KMAX <= 8 ? KMAX : 8)>), dim3(grid), dim3(NN_BLOCK), 0, c->stream, q, qi, (int)n, d_T, c->d_lvl_tab,
+                               c->levels.nlev, lc.k, lc.maxr2, allow_self, seeded, d_sidx, d_d2, d_state, c->d_hard, out_sorted);
             if (!std::isfinite(lc.max_dist) || (top.cell - top.slack) <= lc.max_dist) {
                 hipLaunchKernelGGL(nnk_hard_kernel<KMAX>, dim3(512), dim3(NN_BLOCK), 0, c->stream, d_reading, d_T, c->d_map_sorted,
                                    (int)c->m, lc.k, lc.maxr2, allow_self, d_sidx, d_d2, d_state, c->d_hard);

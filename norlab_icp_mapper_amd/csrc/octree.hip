@@ -62,7 +62,8 @@ __global__ __launch_bounds__(OB) void oct_root_kernel(const float* __restrict__ 
     }
     if (t == 0) {
         float c[3], radius = 0.f;
-        for (int r = 0; r < 3; ++r) { c[r] = (sl[r][0] + sh[r][0]) / 2.f; const float rr = sh[r][0] - c[r]; if (rr > radius) radius = rr; }
+        // upstream's Octree_::build: radii = max - min; centre = min + radii * 0.5; maxRadius = max(radii) * 0.5 (the oracle's rule, r3)
+        for (int r = 0; r < 3; ++r) { const float ext = sh[r][0] - sl[r][0]; c[r] = sl[r][0] + ext * 0.5f; const float rr = ext * 0.5f; if (rr > radius) radius = rr; }
         int d = 0;
         float rad = radius;
         while (d < 21 && !(rad * 2.f <= max_size)) { rad *= 0.5f; ++d; } // the first depth whose edge is <= maxSizeByNode

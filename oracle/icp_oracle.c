@@ -1302,7 +1302,9 @@ int64_t orc_octree_sample(const float* in4, int64_t n, float max_size, int64_t m
             if (v > hi[r]) hi[r] = v;
         }
     float c[3], radius = 0.f;
-    for (int r = 0; r < 3; ++r) { c[r] = (lo[r] + hi[r]) / 2.f; const float rr = hi[r] - c[r]; if (rr > radius) radius = rr; }
+    /* upstream's Octree_::build: radii = max - min; centre = min + radii * 0.5; maxRadius = max(radii) * 0.5 -- NOT (min + max) / 2
+     * and max(max - centre), which can differ in the last bit and flip a `p > centre` decision */
+    for (int r = 0; r < 3; ++r) { const float ext = hi[r] - lo[r]; c[r] = lo[r] + ext * 0.5f; const float rr = ext * 0.5f; if (rr > radius) radius = rr; }
     int32_t* idx = (int32_t*)malloc((size_t)n * sizeof(int32_t));
     for (int64_t i = 0; i < n; ++i) idx[i] = (int32_t)i;
     orc_oct_ctx ctx = {in4, max_size, max_pts < 1 ? 1 : max_pts, method, order_out, 0};
