@@ -86,6 +86,11 @@ int main(int argc, char** argv)
         const char* planarEnv = std::getenv("NIM_2D");
         const bool is3D = !(planarEnv && std::atoi(planarEnv) != 0);
         Mapper mapper(config, is3D, /*isOnline*/ online, /*isMapping*/ true, /*saveMapCellsOnHardDrive*/ false);
+        // NIM_SETMAP_AT=i: after scan i (0-based) the whole map is taken out with getMap() and handed back with setMap() -- the
+        // reference's checkpoint / resume path (Mapper.cpp:295-301 -> Map::setGlobalPointCloud, Map.cpp:575-588: the next updatePose
+        // pages the cloud into cells again; the trajectory restarts)
+        const char* setMapEnv = std::getenv("NIM_SETMAP_AT");
+        const long setMapAt = setMapEnv ? std::atol(setMapEnv) : -1;
         const auto t0 = std::chrono::steady_clock::now();
         for (size_t i = 0; i < scans.size(); ++i) {
             const TimePoint stamp{std::chrono::nanoseconds(trajectory[i].ns)};
@@ -93,6 +98,12 @@ int main(int argc, char** argv)
             mapper.applyInputFilters(cloud);
             mapper.processInput(cloud, trajectory[i].pose, stamp);
             if (drain) mapper.waitForPendingWork();
+            if ((long)i == setMapAt) {
+                mapper.waitForPendingWork();
+                const DataPoints whole = mapper.getMap();
+                mapper.setMap(whole);
+                std::printf("setMap: %zu points handed back after scan %zu\n", whole.getNbPoints(), i + 1);
+            }
             const Mat4 p = mapper.getPose();
             std::printf("scan %zu/%zu  %zu pts  pose %.4f %.4f %.4f  iterations %d  overlap %.3f  local map %zu\n", i + 1, scans.size(),
                         cloud.getNbPoints(), p(0, 3), p(1, 3), p(2, 3), mapper.lastIcpStats().iterations,

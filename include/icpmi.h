@@ -144,7 +144,11 @@ typedef struct {
     float   nn_ms_avg;                 /* profile mode: mean NN launch time (event-pair gap removed) */
     int32_t nn_launches;               /* profile mode: number of NN launches averaged            */
     int64_t hard_queries;              /* NN queries the grid pyramid could not decide (brute pass) */
-    int32_t reserved[6];
+    int32_t reserved[4];
+    float   sensor_noise_overlap;      /* getOverlap() of a reading that carries `simpleSensorNoise` and `normals`
+                                          (icpmi_set_reading_sensor_noise): the share of the last iteration's pairs within the
+                                          sensor noise; -1 when not computed (then getOverlap() == weighted_point_used_ratio) */
+    int32_t reserved2;
 } icpmi_stats;
 
 void icpmi_config_default(icpmi_config* cfg);
@@ -166,6 +170,14 @@ icpmi_status icpmi_set_map_dev(icpmi_handle h, const float* d_map4, int64_t m, c
 int32_t      icpmi_has_map(icpmi_handle h);
 /* centroid used for centring (T_refIn_refMean translation) */
 icpmi_status icpmi_get_map_mean(icpmi_handle h, float mean3[3]);
+
+/* `ErrorMinimizer::getOverlap()` (read at Mapper.cpp:219, used by the `overlap` update condition, Mapper.cpp:257-260): when the reading
+ * carries the descriptors `simpleSensorNoise` (1 x N) and `normals`, upstream's minimisers do not return the weighted ratio but the share of
+ * the last iteration's pairs that lie within the sensor noise -- PointToPoint: |p - q| < mean|p - q| + noise_i; PointToPlane:
+ * |(p - q) . n_i / |n_i|| < noise_i with n_i the READING's normal.  This call hands over the noise row of the NEXT registration's reading
+ * (host pointer, n floats, one shot: it is consumed by that registration, whose scan_normals3 must be given and whose n must match; any
+ * other case leaves stats.sensor_noise_overlap at -1).  noise == NULL or n == 0 clears it. */
+icpmi_status icpmi_set_reading_sensor_noise(icpmi_handle h, const float* noise, int64_t n);
 
 /* Replaces `TransformationParameters PM::ICPSequence::operator()(const DataPoints&)`
  * (Mapper.cpp:213): scan4 is the reading already moved by the prior (Mapper.cpp:197); T_out is the

@@ -67,7 +67,9 @@ class Stats(C.Structure):
         ("nn_ms_avg", C.c_float),
         ("nn_launches", C.c_int32),
         ("hard_queries", C.c_int64),
-        ("reserved", C.c_int32 * 6),
+        ("reserved", C.c_int32 * 4),
+        ("sensor_noise_overlap", C.c_float),
+        ("reserved2", C.c_int32),
     ]
 
 
@@ -99,6 +101,7 @@ SYMBOLS = [
     ("icpmi_has_map", C.c_int32, [_P]),
     ("icpmi_get_map_mean", C.c_int, [_P, _F]),
     ("icpmi_register", C.c_int, [_P, _P, C.c_int64, _P, _F, C.POINTER(Stats)]),
+    ("icpmi_set_reading_sensor_noise", C.c_int, [_P, _P, C.c_int64]),
     ("icpmi_register_dev", C.c_int, [_P, _P, C.c_int64, _P, _F, C.POINTER(Stats)]),
     ("icpmi_register_fixed_dev", C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, _F, C.POINTER(Stats)]),
     ("icpmi_register_batch_dev", C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P, _P, _P]),

@@ -196,7 +196,7 @@ void icpmi_destroy(icpmi_handle c)
     hipFree(c->d_qsorted); hipFree(c->d_qindex); hipFree(c->d_qkeys); hipFree(c->d_qtile);
     hipFree(c->d_reading); hipFree(c->d_read_normals); hipFree(c->d_stage_in); hipFree(c->d_stage_n3);
     hipFree(c->d_match_pt); hipFree(c->d_lvl_tab); hipFree(c->d_raw); hipFree(c->d_raw_n3); hipFree(c->d_raw_s); hipFree(c->d_src); hipFree(c->d_alt_raw); hipFree(c->d_alt_n3);
-    hipFree(c->d_alt_s); hipFree(c->d_alt_src); hipFree(c->d_stage_s); hipFree(c->d_merge_send); hipFree(c->d_merge_recv); hipFree(c->d_merged); hipFree(c->d_comm_cnt);
+    hipFree(c->d_alt_s); hipFree(c->d_alt_src); hipFree(c->d_stage_s); hipFree(c->d_merge_send); hipFree(c->d_merge_recv); hipFree(c->d_merged); hipFree(c->d_comm_cnt); hipFree(c->d_read_noise);
     for (int k = 0; k < 10; ++k) hipFree(c->scratch[k]); hipFree(c->d_scan_map); hipFree(c->d_T16);
     hipFree(c->d_sidx); hipFree(c->d_d2); hipFree(c->d_hard); hipFree(c->d_partials); hipFree(c->d_selhist);
     hipFree(c->d_state);
@@ -341,7 +341,12 @@ static icpmi_status register_impl(icpmi_handle h, const float* d_scan4, int64_t 
     }
     { const icpmi_status es = check_ext_filters(h); if (es != ICPMI_OK) return es; }
     LoopCfg lc = make_loop_cfg(h, fixed_iters);
-    lc.has_read_normals = needs_rn ? 1 : 0;
+    // sensor-noise overlap (icpmi_set_reading_sensor_noise): the noise row is one shot -- this registration consumes it
+    const bool sn = h->read_noise_n == n && n > 0 && d_n3 && !lc.ext && !lc.is_2d &&
+                    (lc.minimizer == ICPMI_MIN_POINT_TO_POINT || lc.minimizer == ICPMI_MIN_POINT_TO_PLANE);
+    h->read_noise_n = 0;
+    lc.sensor_noise = sn ? 1 : 0;
+    lc.has_read_normals = (needs_rn || sn) ? 1 : 0;
     if (n == 0) {
         // upstream: Trimmed/Median throw "no outlier to filter", otherwise "no point to minimize"
         bool quant = false;
@@ -351,9 +356,21 @@ static icpmi_status register_impl(icpmi_handle h, const float* d_scan4, int64_t 
     }
     icpmi_stats local;
     if (!stats && stats_json()) stats = &local;
-    const icpmi_status rs = loop_run(h, (const float4*)d_scan4, needs_rn ? d_n3 : nullptr, n, lc, fixed_iters > 0, T_out, stats);
+    const icpmi_status rs = loop_run(h, (const float4*)d_scan4, (needs_rn || sn) ? d_n3 : nullptr, n, lc, fixed_iters > 0, T_out, stats);
     if (stats_json() && stats) write_stats_json(*stats, n, rs);
     return rs;
+}
+
+icpmi_status icpmi_set_reading_sensor_noise(icpmi_handle h, const float* noise, int64_t n)
+{
+    CHECK_H(h);
+    h->read_noise_n = 0;
+    if (!noise || n <= 0) return ICPMI_OK;
+    if (ensure_cap(h, &h->d_read_noise, &h->cap_read_noise, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    HIP_TRY(h, hipMemcpyAsync(h->d_read_noise, noise, (size_t)n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream)); // the caller's buffer is free on return
+    h->read_noise_n = n;
+    return ICPMI_OK;
 }
 
 icpmi_status icpmi_register_dev(icpmi_handle h, const float* d_scan4, int64_t n, const float* d_scan_normals3, float T_out[16],

@@ -98,6 +98,7 @@ struct LoopCfg {
     int   use_bound;
     float max_rot, max_trans;
     int   has_read_normals;
+    int   sensor_noise;    // the reading carries simpleSensorNoise + normals: getOverlap() is the sensor-noise count (loop.hip: overlap pass)
 };
 
 // Device-resident loop state (one per handle).  Everything the iteration needs between kernels
@@ -134,6 +135,7 @@ struct IcpState {
     unsigned long long hard_total;
     unsigned seq;                // registration sequence number (tag of the progress word, see icpmi_ctx::h_progress)
     unsigned long long dbg[24];  // diagnostics: NN phase cycles with -DICPMI_NN_TIMING (scripts/nn_phase.py), [20]/[21] serial solve cycles / calls
+    float T_prev[16];            // T_iter BEFORE the last minimisation (kept when LoopCfg::sensor_noise: getOverlap() looks at that step's pairs)
     // result
     float T_out[16];
 };
@@ -177,6 +179,8 @@ struct icpmi_ctx {
     // reading-side buffers (capacity in entries)
     float4* d_reading = nullptr; size_t cap_reading = 0;       // centred reading
     float4* d_read_normals = nullptr; size_t cap_read_normals = 0;
+    float*  d_read_noise = nullptr; size_t cap_read_noise = 0; int64_t read_noise_n = 0; // simpleSensorNoise of the NEXT reading (one shot)
+    bool graph_sorted = false;        // loop state order of the cached graph
     float4* d_qsorted = nullptr; size_t cap_qsorted = 0;       // centred reading sorted by tile (NN locality)
     int*    d_qindex = nullptr; size_t cap_qindex = 0;         // sorted position -> original index
     unsigned* d_qkeys = nullptr; size_t cap_qkeys = 0;
@@ -374,6 +378,7 @@ icpmi_status nn_ids_to_original(icpmi_ctx* c, const int* d_sidx, int64_t count, 
 icpmi_status nn_self_knn(icpmi_ctx* c, const float4* d_cloud, const LoopCfg& lc, int* d_sidx, float* d_d2, IcpState* d_state);
 icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals3, int64_t n, const LoopCfg& lc, bool fixed, float T_out[16],
                       icpmi_stats* stats);
+icpmi_status loop_sensor_noise_overlap(icpmi_ctx* c, int64_t n, const LoopCfg& lc, bool sorted, float* overlap);
 icpmi_status loop_prepare_reading(icpmi_ctx* c, const float4* d_scan, int64_t n, const float* d_normals3);
 icpmi_status loop_run_batch(icpmi_ctx* c, int batch, const float* const* d_scans4, const int64_t* n, const LoopCfg& lc, bool fixed,
                             float* T_out, icpmi_stats* stats, icpmi_status* status);

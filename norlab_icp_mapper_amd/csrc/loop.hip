@@ -1153,6 +1153,7 @@ __device__ void solve_body(IcpState* __restrict__ st, const double* __restrict__
 
     float Ti[16];
     mat4_mul_dev(Ts, st->T_iter, Ti);
+    if (lc.sensor_noise) for (int i = 0; i < 16; ++i) st->T_prev[i] = st->T_iter[i]; // the pose this step's pairs were formed under
     for (int i = 0; i < 16; ++i) st->T_iter[i] = Ti[i];
     st->iter += 1;
 
@@ -1337,6 +1338,94 @@ LoopCfg make_loop_cfg(const icpmi_ctx* c, int fixed_iterations)
     lc.smooth = cfg.smooth_length < 1 ? 1 : (cfg.smooth_length > ICPMI_MAX_SMOOTH ? ICPMI_MAX_SMOOTH : cfg.smooth_length);
     lc.max_rot = cfg.max_rot_norm; lc.max_trans = cfg.max_trans_norm;
     return lc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ErrorMinimizer::getOverlap() for a reading that carries `simpleSensorNoise` and `normals` (read at Mapper.cpp:219).
+// The pairs are the last iteration's error elements: reading point under T_prev, its match, weight != 0.
+//   PointToPoint : dists_i = |p - q|, mean over the pairs, count(dists_i < mean + noise_i) / pairs
+//   PointToPlane : count(|(p - q) . n_i / |n_i|| < noise_i) / pairs, n_i = the READING's normal under T_prev
+// MODE 0: per-workgroup partial sums {pairs, sum of dists} in a fixed order (p2p needs the mean first); MODE 1: the count.
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void overlap_kernel(const float4* __restrict__ reading, const int* __restrict__ qindex, int n, LoopCfg lc,
+                                                      const IcpState* __restrict__ st, const float4* __restrict__ map,
+                                                      const float4* __restrict__ ref_normals, const float4* __restrict__ read_normals,
+                                                      const float* __restrict__ noise, const int* __restrict__ sidx, const float* __restrict__ d2a,
+                                                      const float4* __restrict__ match_pt, float mean, double* __restrict__ partial,
+                                                      unsigned long long* __restrict__ count)
+{
+    const float* T = st->T_prev;
+    const int64_t total = (int64_t)n * lc.k;
+    double np = 0.0, sd = 0.0;
+    unsigned long long cnt = 0;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const float d2 = d2a[e];
+        if (d2 == INFINITY) continue;
+        const int qi = (int)(e / lc.k);
+        const int oi = qindex ? qindex[qi] : qi;
+        const int s = sidx[e];
+        const float w = match_weight(lc, st, d2, T, read_normals, oi, ref_normals, s);
+        if (w == 0.f) continue;
+        const float4 r = reading[qi];
+        const float3 p = xf_point(T, r.x, r.y, r.z, r.w);
+        const float4 q = match_pt ? match_pt[e] : map[s];
+        const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+        if (lc.minimizer == ICPMI_MIN_POINT_TO_POINT) {
+            const float dist = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+            if (MODE == 0) { np += 1.0; sd += (double)dist; }
+            else if (dist < mean + noise[oi]) ++cnt;
+        } else {
+            const float4 a = read_normals[oi];
+            const float nx = fmaf(T[8], a.z, fmaf(T[4], a.y, T[0] * a.x)), ny = fmaf(T[9], a.z, fmaf(T[5], a.y, T[1] * a.x)),
+                        nz = fmaf(T[10], a.z, fmaf(T[6], a.y, T[2] * a.x));
+            const float nn = sqrtf(fmaf(nz, nz, fmaf(ny, ny, nx * nx)));
+            const float proj = fmaf(dz, nz / nn, fmaf(dy, ny / nn, dx * (nx / nn)));
+            if (MODE == 0) np += 1.0;
+            else if (fabsf(proj) < noise[oi]) ++cnt;
+        }
+    }
+    __shared__ double sh[2][256];
+    __shared__ unsigned long long shc[256];
+    sh[0][threadIdx.x] = np; sh[1][threadIdx.x] = sd; shc[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) { sh[0][threadIdx.x] += sh[0][threadIdx.x + off]; sh[1][threadIdx.x] += sh[1][threadIdx.x + off]; shc[threadIdx.x] += shc[threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (MODE == 0) { partial[2 * blockIdx.x] = sh[0][0]; partial[2 * blockIdx.x + 1] = sh[1][0]; }
+        else if (shc[0]) atomicAdd(count, shc[0]);
+    }
+}
+
+icpmi_status loop_sensor_noise_overlap(icpmi_ctx* c, int64_t n, const LoopCfg& lc, bool sorted, float* overlap)
+{
+    *overlap = -1.f;
+    constexpr int NB = 128;
+    double* d_part = scratch_get<double>(c, 5, 2 * NB + 2);
+    if (!d_part) return ICPMI_ERR_HIP;
+    unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(d_part + 2 * NB);
+    HIP_TRY(c, hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), c->stream));
+    const float4* rd = sorted ? c->d_qsorted : c->d_reading;
+    const int* qi = sorted ? c->d_qindex : nullptr;
+    const float4* mp = (sorted && lc.k == 1) ? c->d_match_pt : nullptr;
+    const float4* rnm = c->has_normals ? c->d_normals_sorted : nullptr;
+    hipLaunchKernelGGL(overlap_kernel<0>, dim3(NB), dim3(256), 0, c->stream, rd, qi, (int)n, lc, c->d_state, c->d_map_sorted, rnm, c->d_read_normals,
+                       c->d_read_noise, c->d_sidx, c->d_d2, mp, 0.f, d_part, d_cnt);
+    double hp[2 * NB];
+    if (read_back(c, hp, d_part, sizeof hp) != ICPMI_OK) return ICPMI_ERR_HIP;
+    double pairs = 0.0, sum = 0.0;
+    for (int b = 0; b < NB; ++b) { pairs += hp[2 * b]; sum += hp[2 * b + 1]; }
+    if (!(pairs > 0.0)) return ICPMI_OK;
+    const float mean = (float)(sum / pairs);
+    hipLaunchKernelGGL(overlap_kernel<1>, dim3(NB), dim3(256), 0, c->stream, rd, qi, (int)n, lc, c->d_state, c->d_map_sorted, rnm, c->d_read_normals,
+                       c->d_read_noise, c->d_sidx, c->d_d2, mp, mean, d_part, d_cnt);
+    unsigned long long hc = 0;
+    if (read_back(c, &hc, d_cnt, sizeof hc) != ICPMI_OK) return ICPMI_ERR_HIP;
+    HIP_TRY(c, hipGetLastError());
+    *overlap = (float)((double)hc / pairs);
+    return ICPMI_OK;
 }
 
 icpmi_status loop_prepare_reading(icpmi_ctx* c, const float4* d_scan, int64_t n, const float* d_normals3)
@@ -1569,7 +1658,7 @@ static void fill_stats(icpmi_ctx* c, const LoopCfg& lc, int64_t n, icpmi_stats* 
     for (int f = 0; f < lc.n_out; ++f)
         if (lc.out_type[f] == ICPMI_OUT_TRIMMEDDIST || lc.out_type[f] == ICPMI_OUT_MEDIANDIST || lc.out_type[f] == ICPMI_OUT_VARTRIMMEDDIST) stats->trimmed_limit = hs->limits[f];
     stats->hard_queries = (int64_t)hs->hard_total;
-    for (int i = 0; i < 3; ++i) { stats->reserved[2 * i] = (int32_t)(hs->dbg[i] & 0xffffffffu); stats->reserved[2 * i + 1] = (int32_t)(hs->dbg[i] >> 32); }
+    for (int i = 0; i < 2; ++i) { stats->reserved[2 * i] = (int32_t)(hs->dbg[i] & 0xffffffffu); stats->reserved[2 * i + 1] = (int32_t)(hs->dbg[i] >> 32); }
 }
 
 static void host_mat4_mul(const float* A, const float* B, float* C)
@@ -1640,7 +1729,7 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
             hipError_t ie = hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0);
             hipGraphDestroy(g);
             HIP_TRY(c, ie);
-            c->graph_n = n; c->graph_iters = lc.max_iter; c->graph_sig = sig;
+            c->graph_n = n; c->graph_iters = lc.max_iter; c->graph_sig = sig; c->graph_sorted = c->nn_out_sorted;
         }
         HIP_TRY(c, hipGraphLaunch(c->graph_exec, c->stream));
         if (c->cfg.knn <= 8) { c->qsorted_n = n; c->qsorted_src = c->d_reading; } // what the replayed head leaves in d_qsorted
@@ -1723,6 +1812,13 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
         if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) stats->loop_ms = ms;
         stats->nn_ms_avg = nn_cnt ? nn_ms_sum / nn_cnt : 0.f;
         stats->nn_launches = nn_cnt;
+        stats->sensor_noise_overlap = -1.f;
+    }
+    if (lc.sensor_noise && stats && !c->h_state->error && c->h_state->iter > 0) {
+        // ErrorMinimizer::getOverlap() with sensor noise: one pass over the last iteration's pairs, still in the loop's buffers
+        const bool sorted_state = graph ? c->graph_sorted : c->nn_out_sorted;
+        const icpmi_status os = loop_sensor_noise_overlap(c, n, lc, sorted_state, &stats->sensor_noise_overlap);
+        if (os != ICPMI_OK) return os;
     }
     const IcpState* hs = c->h_state;
     if (hs->error) {

@@ -23,7 +23,7 @@ class GpuICPSequence {
 public:
     struct ErrorMinimizerView {
         const GpuICPSequence* owner;
-        float getOverlap() const { return owner->lastStats.weighted_point_used_ratio; }
+        float getOverlap() const { return owner->lastStats.sensor_noise_overlap >= 0.f ? owner->lastStats.sensor_noise_overlap : owner->lastStats.weighted_point_used_ratio; }
         float getPointUsedRatio() const { return owner->lastStats.point_used_ratio; }
     };
 

@@ -216,7 +216,10 @@ class _ErrorMinimizerView:
         self._o = owner
 
     def getOverlap(self):
-        return float(self._o.stats.weighted_point_used_ratio)
+        """upstream: the sensor-noise count when the reading carried `simpleSensorNoise` and `normals` (ICPSequence.setReadingSensorNoise),
+        the weighted ratio of used points otherwise"""
+        sn = float(self._o.stats.sensor_noise_overlap)
+        return sn if sn >= 0.0 else float(self._o.stats.weighted_point_used_ratio)
 
     def getPointUsedRatio(self):
         return float(self._o.stats.point_used_ratio)
@@ -302,6 +305,11 @@ class ICPSequence:
         st = self._lib.icpmi_register(self._h, scan.ctypes.data, scan.shape[0], nptr, T, C.byref(self.stats))
         self._check(st)
         return _T_from_c(T[:])
+
+    def setReadingSensorNoise(self, noise):
+        """icpmi_set_reading_sensor_noise: the `simpleSensorNoise` row of the NEXT reading (one shot; that call must bring scan_normals)."""
+        nz = None if noise is None else np.ascontiguousarray(noise, dtype=np.float32).ravel()
+        self._check(self._lib.icpmi_set_reading_sensor_noise(self._h, None if nz is None else nz.ctypes.data, 0 if nz is None else nz.shape[0]))
 
     def registerDev(self, d_scan_ptr, n, fixed_iterations=0, d_normals_ptr=None):
         T = (C.c_float * 16)()

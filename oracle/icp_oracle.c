@@ -956,6 +956,7 @@ struct orc_icp {
     float* normals3;   /* or NULL                                           */
     float* scalar;     /* or NULL: the descriptor GenericDescriptorOutlierFilter reads */
     orc_kdtree* tree;
+    float* read_noise; int64_t read_noise_n; /* simpleSensorNoise of the next reading (one shot) */
 };
 
 orc_icp* orc_icp_create(const orc_config* cfg)
@@ -970,7 +971,7 @@ orc_icp* orc_icp_create(const orc_config* cfg)
 void orc_icp_destroy(orc_icp* s)
 {
     if (!s) return;
-    free(s->map4); free(s->normals3); free(s->scalar); orc_kdtree_free(s->tree); free(s);
+    free(s->map4); free(s->normals3); free(s->scalar); free(s->read_noise); orc_kdtree_free(s->tree); free(s);
 }
 
 void orc_icp_set_map_scalar(orc_icp* s, const float* scalar)
@@ -981,6 +982,14 @@ void orc_icp_set_map_scalar(orc_icp* s, const float* scalar)
     memcpy(s->scalar, scalar, (size_t)s->m * sizeof(float));
 }
 
+void orc_icp_set_reading_noise(orc_icp* s, const float* noise, int64_t n)
+{
+    free(s->read_noise); s->read_noise = NULL; s->read_noise_n = 0;
+    if (!noise || n <= 0) return;
+    s->read_noise = (float*)malloc((size_t)n * sizeof(float));
+    memcpy(s->read_noise, noise, (size_t)n * sizeof(float));
+    s->read_noise_n = n;
+}
 int orc_icp_has_map(const orc_icp* s) { return s->m > 0; }
 void orc_icp_get_mean(const orc_icp* s, float* mean3) { memcpy(mean3, s->mean, 3 * sizeof(float)); }
 
@@ -1012,7 +1021,9 @@ int orc_icp_register(orc_icp* s, const float* scan4, int64_t n, const float* sca
 {
     orc_stats local; if (!st) st = &local;
     memset(st, 0, sizeof *st);
+    st->sensor_noise_overlap = -1.f;
     mat4_identity(T_out);
+    const int64_t noise_n = s->read_noise_n; s->read_noise_n = 0; /* one shot */
     if (!orc_icp_has_map(s)) return ORC_OK; /* "Ignoring attempt to perform ICP with an empty map" */
     const orc_config* cfg = &s->cfg;
     const int k = cfg->knn;
@@ -1097,6 +1108,36 @@ int orc_icp_register(orc_icp* s, const float* scan4, int64_t n, const float* sca
     }
     st->seconds_total = now_s() - t0;
     st->error = err;
+    /* ErrorMinimizer::getOverlap() (read at Mapper.cpp:219) when the reading carries `simpleSensorNoise` and `normals` (SURVEY B.6,
+     * upstream as recalled): over the LAST iteration's error elements (w != 0, finite match; `step`, `ids`, `w` still hold them) --
+     * PointToPoint: |p - q| < mean|p - q| + noise_i; PointToPlane: |(p - q) . n_i / |n_i|| < noise_i, n_i the reading's normal */
+    if (!err && noise_n == n && n > 0 && step_normals && st->iterations > 0 && !cfg->is_2d &&
+        (cfg->minimizer == ORC_MIN_POINT_TO_POINT || cfg->minimizer == ORC_MIN_POINT_TO_PLANE)) {
+        double pairs = 0.0, sum = 0.0;
+        for (int pass = 0; pass < 2; ++pass) {
+            const float mean = pairs > 0.0 ? (float)(sum / pairs) : 0.f;
+            double count = 0.0;
+            for (int64_t i = 0; i < n; ++i)
+                for (int j = 0; j < k; ++j) {
+                    const int64_t e = (int64_t)k * i + j;
+                    if (!(d2[e] < INFINITY) || w[e] == 0.f || ids[e] < 0) continue;
+                    const float* p = step + 4 * i; const float* q = s->map4 + 4 * (int64_t)ids[e];
+                    const float dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
+                    if (cfg->minimizer == ORC_MIN_POINT_TO_POINT) {
+                        const float dist = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+                        if (pass == 0) { pairs += 1.0; sum += (double)dist; }
+                        else if (dist < mean + s->read_noise[i]) count += 1.0;
+                    } else {
+                        const float* nr = step_normals + 3 * i;
+                        const float nn = sqrtf(fmaf(nr[2], nr[2], fmaf(nr[1], nr[1], nr[0] * nr[0])));
+                        const float proj = fmaf(dz, nr[2] / nn, fmaf(dy, nr[1] / nn, dx * (nr[0] / nn)));
+                        if (pass == 0) pairs += 1.0;
+                        else if (fabsf(proj) < s->read_noise[i]) count += 1.0;
+                    }
+                }
+            if (pass == 1 && pairs > 0.0) st->sensor_noise_overlap = (float)(count / pairs);
+        }
+    }
     if (!err) {
         float tmp[16];
         mat4_mul(T_iter, Tmean_inv, tmp);

@@ -92,6 +92,7 @@ typedef struct {
     float trimmed_limit;             /* last TrimmedDist / MedianDist limit (d^2)      */
     double seconds_knn;              /* wall time spent in the kNN stage               */
     double seconds_total;            /* wall time of the iteration loop                */
+    float sensor_noise_overlap;      /* getOverlap() with `simpleSensorNoise` + `normals` on the reading (orc_icp_set_reading_noise), else -1 */
 } orc_stats;
 
 /* ---- stage-level functions ---- */
@@ -152,6 +153,9 @@ int orc_outlier_weights_ex(const orc_config* cfg, const float* d2, const int32_t
 /* ---- ICPSequence ---- */
 typedef struct orc_icp orc_icp;
 orc_icp* orc_icp_create(const orc_config* cfg);
+/* `simpleSensorNoise` row (n floats) of the NEXT reading handed to orc_icp_register (one shot; the reading's normals come with that
+ * call): ErrorMinimizer::getOverlap() then counts the last iteration's pairs that lie within the sensor noise */
+void orc_icp_set_reading_noise(orc_icp* s, const float* noise, int64_t n);
 void orc_icp_destroy(orc_icp* s);
 /* returns 1 on success, 0 if the cloud is empty (state unchanged) */
 int orc_icp_set_map(orc_icp* s, const float* map4, int64_t m, const float* normals3);

@@ -30,7 +30,8 @@ class Config(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("iterations", C.c_int), ("stop_reason", C.c_int), ("error", C.c_int), ("pairs", C.c_int64),
                 ("point_used_ratio", C.c_float), ("weighted_point_used_ratio", C.c_float),
-                ("trimmed_limit", C.c_float), ("seconds_knn", C.c_double), ("seconds_total", C.c_double)]
+                ("trimmed_limit", C.c_float), ("seconds_knn", C.c_double), ("seconds_total", C.c_double),
+                ("sensor_noise_overlap", C.c_float)]
 
 
 _lib = None
@@ -80,6 +81,8 @@ def load():
     lib.orc_icp_has_map.argtypes = [_P]
     lib.orc_icp_get_mean.argtypes = [_P, _P]
     lib.orc_icp_register.argtypes = [_P, _P, C.c_int64, _P, _P, C.POINTER(Stats)]
+    lib.orc_icp_set_reading_noise.argtypes = [_P, _P, C.c_int64]
+    lib.orc_icp_set_reading_noise.restype = None
     lib.orc_surface_normals.argtypes = [_P, C.c_int64, C.c_int, _P, C.c_int]
     lib.orc_surface_normals_ex.argtypes = [_P, C.c_int64, C.c_int, _P, _P, C.c_int]
     lib.orc_surface_normals_2d.argtypes = [_P, C.c_int64, C.c_int, _P, C.c_int]
@@ -243,6 +246,11 @@ class OracleICP:
 
     def getMapMean(self):
         m = np.zeros(3, dtype=np.float32); self.lib.orc_icp_get_mean(self.h, m.ctypes.data); return m
+
+    def setReadingNoise(self, noise):
+        """`simpleSensorNoise` row of the next reading (one shot): stats.sensor_noise_overlap is then getOverlap()"""
+        nz = np.ascontiguousarray(noise, dtype=np.float32).ravel()
+        self.lib.orc_icp_set_reading_noise(self.h, nz.ctypes.data, nz.shape[0])
 
     def __call__(self, scan, scan_normals=None):
         scan = _f32(scan); sn = _f32(scan_normals) if scan_normals is not None else None

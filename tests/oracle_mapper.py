@@ -246,6 +246,14 @@ class OracleMapper:
                     lo, hi = box(sup_now + B - n + 1, sup_now + B); self._load(lo, hi); self.page_events.append(("load", a, lo[a], hi[a], len(self.trajectory)))
                 self.win[a][1] = sup_now
 
+    def set_map(self, cloud):
+        """Mapper::setMap (Mapper.cpp:295-301) -> Map::setGlobalPointCloud (Map.cpp:575-588): the cloud replaces the local map, the
+        matcher is rebuilt, the next updatePose pages it into cells from scratch, the trajectory restarts"""
+        self.map = {k: v.copy() for k, v in cloud.items()}
+        self._set_icp_map()
+        self.first_pose_update = True
+        self.trajectory = []
+
     def get_map(self):
         """Mapper::getMap (Map.cpp:552-573): the local cloud plus every saved cell that is not loaded"""
         out = self.map

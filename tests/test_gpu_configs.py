@@ -389,3 +389,54 @@ def test_cell_paging_replay_against_oracle_replay(amd, oracle, tmp_path):
     local_n = mapper.map["xyz1"].shape[0]
     assert local_n < ref.shape[0]                                                # part of the map lives in the cell manager
     print(f"paging: {len(scans)} scans, {len(unloads)} unloads / {len(loads)} loads, local {local_n} of {ref.shape[0]} points, worst pose difference {worst:.2e} m")
+
+
+def test_set_map_repages_the_global_cloud(amd, oracle, tmp_path):
+    """Mapper::setMap -> Map::setGlobalPointCloud (Mapper.cpp:295-301, Map.cpp:575-588; SURVEY section 5 'checkpoint / resume', 8f rank 4):
+    in the middle of the paging drive the whole map (local cloud + saved cells, Mapper::getMap) is taken out and handed back; the next
+    updatePose must page it into cells again and the drive must go on as the oracle-side replay of the same sequence does -- poses
+    scan by scan, cell traffic, and the final global map as a point set (VERDICT r2 missing 4: this path had no test)."""
+    from test_host_cpp import _build_host, _read_vtk
+    import oracle_mapper as om
+    _build_host()
+    tmp = str(tmp_path)
+    scans, priors, stamps = _make_corridor_dataset(tmp, amd, out_steps=22, back_steps=12)
+    cfg = os.path.join(tmp, "config.yaml")
+    open(cfg, "w").write(PAGING_CONFIG)
+    traj_out = os.path.join(tmp, "traj.vtk")
+    AT = 17
+    env = dict(os.environ, NIM_SETMAP_AT=str(AT))
+    out = subprocess.run([os.path.join(PKG, "build_map_from_scans_and_trajectory"), tmp, cfg, traj_out], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert f"handed back after scan {AT + 1}" in out.stdout
+    pos, desc = _read_vtk(traj_out)
+    assert pos.shape[0] == len(scans) - (AT + 1)                              # Mapper::setMap clears the trajectory
+    mapper = om.OracleMapper(dict(knn=1, max_dist=2.0, minimizer=2, outliers=[(4, 0.85)], max_iterations=30, use_differential=1),
+                             [("point_distance", 0.3)], post=[("surface_normals", 10)], update=("distance", 2.0), sensor_max_range=25.0,
+                             nthreads=min(16, len(os.sched_getaffinity(0))), paging=True)
+    worst, handed = 0.0, None
+    for i, (scan, prior, stamp) in enumerate(zip(scans, priors, stamps)):
+        T_ref = mapper.process_input(mapper.apply_input_filters(scan), prior, stamp)
+        if i == AT:
+            handed = mapper.get_map()
+            events_before = len(mapper.page_events)
+            mapper.set_map(handed)
+            assert mapper.first_pose_update
+        if i > AT:
+            r = i - (AT + 1)
+            T = np.eye(4, dtype=np.float32)
+            T[:3, 0], T[:3, 1], T[:3, 2], T[:3, 3] = desc["orientationX"][r], desc["orientationY"][r], desc["orientationZ"][r], pos[r]
+            dt, dr = amd.synth.pose_error(T, T_ref)
+            assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (i, dt, dr)
+            worst = max(worst, dt)
+    assert f"setMap: {handed['xyz1'].shape[0]} points" in out.stdout            # the same number of points went through getMap / setMap
+    assert not mapper.first_pose_update                                        # the first updatePose after setMap re-paged the cloud
+    assert len(mapper.page_events) > events_before                             # ... and the window kept moving afterwards
+    assert any(c["xyz1"].shape[0] > 0 for cid, c in mapper.cells.items() if cid not in mapper.loaded)
+    mp, _ = _read_vtk(os.path.join(tmp, "map.vtk"))
+    ref = mapper.get_map()["xyz1"][:, :3]
+    assert mp.shape[0] == ref.shape[0], (mp.shape, ref.shape)
+    a = np.sort(np.ascontiguousarray(mp).view([("x", "f4"), ("y", "f4"), ("z", "f4")]).ravel())
+    b = np.sort(np.ascontiguousarray(ref).view([("x", "f4"), ("y", "f4"), ("z", "f4")]).ravel())
+    assert np.mean(a == b) > 0.999
+    print(f"setMap re-paging: {len(scans)} scans, handed back {handed['xyz1'].shape[0]} points after scan {AT + 1}, worst pose difference {worst:.2e} m")

@@ -238,3 +238,39 @@ def test_batch_with_ext_chain_equals_single_registrations(amd, mid_scene):
     for b in range(3):
         assert status[b] == 0
         assert np.array_equal(Ts[b], singles[b])
+
+
+@pytest.mark.parametrize("minimizer", [1, 2])
+@pytest.mark.parametrize("knn", [1, 3])
+def test_sensor_noise_overlap_matches_oracle(amd, oracle, mid_scene, minimizer, knn):
+    """ErrorMinimizer::getOverlap() for a reading that carries `simpleSensorNoise` and `normals` (read at Mapper.cpp:219, drives the
+    `overlap` update condition, Mapper.cpp:257-260): the share of the last iteration's pairs within the sensor noise, not the
+    weighted ratio (VERDICT r2 missing 3).  Device pass (icpmi_set_reading_sensor_noise) against the oracle's restatement."""
+    sc = mid_scene
+    n = sc["scan"].shape[0]
+    rng = np.random.default_rng(11)
+    noise = rng.uniform(0.002, 0.03, n).astype(np.float32)               # e.g. what SimpleSensorNoiseDataPointsFilter writes per beam
+    nrm = rng.normal(size=(n, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    kw = dict(minimizer=minimizer, knn=knn, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=12, use_differential=1)
+    icp = amd.ICPSequence(**kw)
+    assert icp.setMap(sc["map"], sc["normals"])
+    icp.setReadingSensorNoise(noise)
+    T = icp(sc["scan"], nrm)
+    o = oracle.OracleICP(oracle.make_config(nthreads=8, **kw))
+    o.setMap(sc["map"], sc["normals"])
+    o.setReadingNoise(noise)
+    err, T_ref = o(sc["scan"], nrm)
+    assert err == 0 and icp.stats.iterations == o.stats.iterations and icp.stats.pairs == o.stats.pairs
+    assert 0.0 < o.stats.sensor_noise_overlap < 1.0
+    # counts of pairs: identical unless a pair sits within rounding of its threshold (the two sides sum the mean in a different order)
+    assert abs(icp.stats.sensor_noise_overlap - o.stats.sensor_noise_overlap) <= 2.0 / max(o.stats.pairs, 1)
+    assert icp.errorMinimizer.getOverlap() == pytest.approx(icp.stats.sensor_noise_overlap)
+    assert abs(icp.errorMinimizer.getOverlap() - icp.stats.weighted_point_used_ratio) > 1e-3   # it is NOT the weighted ratio
+    # one shot: the next registration (no noise handed over) answers with the weighted ratio again
+    icp(sc["scan"], nrm)
+    assert icp.stats.sensor_noise_overlap == -1.0
+    assert icp.errorMinimizer.getOverlap() == pytest.approx(icp.stats.weighted_point_used_ratio)
+    # and the fixed-count graph path keeps the pose it would have had without the overlap pass
+    dt, dr = amd.synth.pose_error(T, T_ref)
+    assert dt <= 1e-4 and dr <= 1e-4

@@ -261,3 +261,33 @@ def test_planar_mode_normals_and_registration(oracle):
         dt, dr = synth.pose_error(T, T_gt)
         assert dt < (1e-2 if minimizer == 1 else 5e-3) and dr < (6e-3 if minimizer == 1 else 2e-3), (minimizer, dt, dr)
         assert T[2, 3] == 0 and np.allclose(T[2, :3], [0, 0, 1], atol=1e-7) and np.allclose(T[:3, 2], [0, 0, 1], atol=1e-7)
+
+
+def test_sensor_noise_overlap_known_answer(oracle):
+    """getOverlap() with `simpleSensorNoise` + `normals` on the reading, by hand: an identity registration (the reading IS a subset of
+    the map, IdentityErrorMinimizer is not involved -- point-to-plane on exact matches solves to identity) of points lifted off a plane."""
+    rng = np.random.default_rng(3)
+    g = np.stack(np.meshgrid(np.arange(20.0), np.arange(20.0)), -1).reshape(-1, 2)
+    m = np.ones((g.shape[0], 4), np.float32); m[:, :2] = g; m[:, 2] = 0
+    mn = np.tile(np.array([[0, 0, 1]], np.float32), (m.shape[0], 1))
+    scan = m[::2].copy()
+    lift = rng.uniform(0.0, 0.02, scan.shape[0]).astype(np.float32)
+    scan[:, 2] += lift                                               # distance to the match = lift, along the normal
+    noise = np.full(scan.shape[0], 0.01, np.float32)
+    nrm = np.tile(np.array([[0, 0, 2]], np.float32), (scan.shape[0], 1))  # un-normalised on purpose: upstream normalises
+    o = oracle.OracleICP(oracle.make_config(minimizer=2, max_dist=1.0, outliers=[], max_iterations=1))
+    o.setMap(m, mn)
+    o.setReadingNoise(noise)
+    err, _ = o(scan, nrm)
+    assert err == 0 and o.stats.pairs == scan.shape[0]
+    assert o.stats.sensor_noise_overlap == np.float32((lift < 0.01).sum() / scan.shape[0])
+    # point-to-point: dist < mean(dist) + noise
+    o = oracle.OracleICP(oracle.make_config(minimizer=1, max_dist=1.0, outliers=[], max_iterations=1))
+    o.setMap(m, mn)
+    o.setReadingNoise(noise)
+    err, _ = o(scan, nrm)
+    assert err == 0
+    assert o.stats.sensor_noise_overlap == np.float32((lift < np.float32(lift.astype(np.float64).mean()) + noise).sum() / scan.shape[0])
+    # no noise handed over -> -1 (getOverlap() falls back to the weighted ratio)
+    err, _ = o(scan, nrm)
+    assert o.stats.sensor_noise_overlap == -1.0
