@@ -154,8 +154,8 @@ icpmi_status icpmi_create(const icpmi_config* cfg, icpmi_handle* out)
     c->cap_selhist = ICPMI_SELHIST_WORDS;
     CR(hipHostMalloc((void**)&c->h_state, sizeof(IcpState) * ICPMI_MAX_BATCH, hipHostMallocDefault));
     CR(hipHostMalloc((void**)&c->h_pin, ICPMI_PIN_BYTES, hipHostMallocDefault));
-    CR(hipHostMalloc((void**)&c->h_progress, 64, hipHostMallocMapped));
-    *c->h_progress = 0;
+    CR(hipHostMalloc((void**)&c->h_progress, 256, hipHostMallocMapped)); // words 0..15: progress per reading of a batch; word 32: sequence number of the registration being launched
+    memset(c->h_progress, 0, 256);
     CR(hipHostGetDevicePointer((void**)&c->d_progress, c->h_progress, 0));
     CR(hipEventCreate(&c->ev0));
     CR(hipEventCreate(&c->ev1));
@@ -176,6 +176,8 @@ icpmi_status icpmi_set_config(icpmi_handle h, const icpmi_config* cfg)
     // the cached loop graph was captured for the previous chain
     if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; h->graph_n = -1; }
     if (h->bgraph_exec) { hipGraphExecDestroy(h->bgraph_exec); h->bgraph_exec = nullptr; h->bgraph_sig = 0; }
+    for (int g = 0; g < 2; ++g) if (h->seg_exec[g]) { hipGraphExecDestroy(h->seg_exec[g]); h->seg_exec[g] = nullptr; }
+    h->seg_sig = 0; h->seg_n = -1;
     return ICPMI_OK;
 }
 
@@ -189,6 +191,7 @@ void icpmi_destroy(icpmi_handle c)
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
     if (c->bgraph_exec) hipGraphExecDestroy(c->bgraph_exec);
+    for (int g = 0; g < 2; ++g) if (c->seg_exec[g]) hipGraphExecDestroy(c->seg_exec[g]);
     hipFree(c->d_map_sorted); hipFree(c->d_normals_sorted); hipFree(c->d_cell_start);
     for (int l = 0; l < ICPMI_MAXLEV; ++l) { hipFree(c->d_lvl_pts[l]); hipFree(c->d_lvl_cs[l]); hipFree(c->d_lvl_pos0[l]); }
     hipFree(c->d_inv);
@@ -221,6 +224,8 @@ icpmi_status icpmi_set_stream(icpmi_handle h, void* hip_stream)
     h->own_stream = false;
     if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; h->graph_n = -1; }
     if (h->bgraph_exec) { hipGraphExecDestroy(h->bgraph_exec); h->bgraph_exec = nullptr; h->bgraph_sig = 0; }
+    for (int g = 0; g < 2; ++g) if (h->seg_exec[g]) { hipGraphExecDestroy(h->seg_exec[g]); h->seg_exec[g] = nullptr; }
+    h->seg_sig = 0; h->seg_n = -1;
     return ICPMI_OK;
 }
 

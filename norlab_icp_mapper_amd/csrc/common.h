@@ -249,6 +249,9 @@ struct icpmi_ctx {
     hipGraphExec_t graph_exec = nullptr;
     int64_t graph_n = -1; int graph_iters = -1; uint64_t graph_sig = 0;
     hipGraphExec_t bgraph_exec = nullptr; uint64_t bgraph_sig = 0; // ... and of one batched registration
+    // checked loops (Counter + Differential / Bound: what Mapper::processInput runs) as SEGMENT graphs: [0] = head + the first
+    // seg_len iterations, [1] = seg_len further iterations, replayed while the progress word says the loop is still running
+    hipGraphExec_t seg_exec[2] = {nullptr, nullptr}; uint64_t seg_sig = 0; int64_t seg_n = -1; int seg_len = 0; bool seg_sorted = false;
 
     // buffers of the map-growth epoch (ops.hip: ops_staged_merge_allgather): this rank's accepted points, all ranks' blocks, the merged set
     float4* d_merge_send = nullptr; size_t cap_merge_send = 0;

@@ -1251,9 +1251,12 @@ __global__ __launch_bounds__(256) void pad_normals_kernel(const float* __restric
     out[i] = make_float4(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2], 0.f);
 }
 
-__global__ void init_state_kernel(IcpState* st, const float* T0, unsigned seq, unsigned* progress)
+__global__ void init_state_kernel(IcpState* st, const float* T0, unsigned seq, unsigned* progress, const unsigned* seq_src = nullptr)
 {
     if (threadIdx.x != 0) return;
+    // seq_src: the sequence number is read from host-mapped memory at RUN time -- a captured graph must not freeze the number of the
+    // registration it was captured for (the host matches the progress word against the number of the registration it is waiting on)
+    if (seq_src) seq = __hip_atomic_load(seq_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     st += blockIdx.x; // one state per reading of a batch
     if (progress) progress += blockIdx.x;
     st->seq = seq;
@@ -1679,8 +1682,9 @@ static icpmi_status enqueue_registration_head(icpmi_ctx* c, const float4* d_scan
 {
     icpmi_status s = loop_prepare_reading(c, d_scan, n, d_normals3);
     if (s != ICPMI_OK) return s;
-    c->reg_seq = (c->reg_seq + 1) & 0x7ffffu;
-    hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(64), 0, c->stream, c->d_state, (const float*)nullptr, c->reg_seq, c->d_progress);
+    // (the registration's sequence number: loop_run stores it in h_progress[32] before it launches anything)
+    hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(64), 0, c->stream, c->d_state, (const float*)nullptr, c->reg_seq, c->d_progress,
+                       c->d_progress ? (const unsigned*)(c->d_progress + 32) : (const unsigned*)nullptr);
     HIP_TRY(c, hipMemsetAsync(c->d_selhist, 0, ICPMI_SELHIST_WORDS * sizeof(unsigned), c->stream));
     HIP_TRY(c, hipGetLastError());
     return ICPMI_OK;
@@ -1701,12 +1705,74 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
     const bool graph = c->cfg.use_graph != 0 && fixed && !profile;
     float nn_ms_sum = 0.f; int nn_cnt = 0;
 
+    c->reg_seq = (c->reg_seq + 1) & 0x7ffffu;
+    if (c->h_progress) __atomic_store_n(c->h_progress + 32, c->reg_seq, __ATOMIC_RELEASE);
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    if (!graph) {
+    // A checked loop (Counter + Differential / Bound: what Mapper::processInput runs) as SEGMENT graphs (r3):
+    // head + the first S iterations are one graph, S further iterations another; a segment is launched when the progress word
+    // says the loop is still running and within S / 2 iterations of the end of what is enqueued.  Iterations past the stop are
+    // early-exit kernels (every kernel of the loop returns on st->done): at most S - 1 of them, against eager launches -- and
+    // their wider kernel-to-kernel gaps -- for every real iteration.  ICPMI_SEG=0 restores the eager run-ahead loop.
+    static int seg_cfg = -1;
+    if (seg_cfg < 0) { const char* e = getenv("ICPMI_SEG"); seg_cfg = e ? atoi(e) : 4; }
+    const bool segmented = !graph && !profile && c->cfg.use_graph != 0 && seg_cfg > 0 && (lc.use_diff || lc.use_bound) && c->h_progress &&
+                           lc.max_iter < 0xfff && lc.max_iter > 1;
+    if (!graph && !segmented) {
         icpmi_status s = enqueue_registration_head(c, d_scan, d_normals3, n);
         if (s != ICPMI_OK) return s;
     }
-    if (graph) {
+    if (segmented) {
+        const int S = seg_cfg < lc.max_iter ? seg_cfg : lc.max_iter;
+        uint64_t sig = 1469598103934665603ull;
+        sig = fnv(&lc, sizeof lc, sig);
+        const void* ptrs[] = {d_scan, d_normals3, c->d_qkeys, c->d_qtile,c->d_reading, c->d_read_normals, c->d_sidx, c->d_d2, c->d_hard, c->d_partials, c->d_state, c->d_match_pt,
+                              c->d_qsorted, c->d_qindex, c->d_map_sorted, c->d_normals_sorted, c->d_cell_start, c->d_selhist,
+                              c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3], c->scratch[4]};
+        sig = fnv(ptrs, sizeof ptrs, sig);
+        sig = fnv(&c->grid, sizeof c->grid, sig);
+        if (!c->seg_exec[0] || !c->seg_exec[1] || c->seg_n != n || c->seg_len != S || c->seg_sig != sig) {
+            for (int g = 0; g < 2; ++g) if (c->seg_exec[g]) { hipGraphExecDestroy(c->seg_exec[g]); c->seg_exec[g] = nullptr; }
+            for (int g = 0; g < 2; ++g) {
+                hipGraph_t gr = nullptr;
+                HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+                icpmi_status s = g == 0 ? enqueue_registration_head(c, d_scan, d_normals3, n) : ICPMI_OK;
+                // (later segments: every iteration is seeded and past the wide first launches -- one graph serves them all)
+                for (int it = 0; it < S && s == ICPMI_OK; ++it) { c->nn_iter_hint = g == 0 ? it : S + it; s = enqueue_iteration(c, n, lc, nullptr, nullptr); }
+                hipError_t ce = hipStreamEndCapture(c->stream, &gr);
+                if (s != ICPMI_OK) { if (gr) hipGraphDestroy(gr); return s; }
+                HIP_TRY(c, ce);
+                hipError_t ie = hipGraphInstantiate(&c->seg_exec[g], gr, nullptr, nullptr, 0);
+                hipGraphDestroy(gr);
+                HIP_TRY(c, ie);
+            }
+            c->seg_n = n; c->seg_len = S; c->seg_sig = sig; c->seg_sorted = c->nn_out_sorted;
+        }
+        HIP_TRY(c, hipGraphLaunch(c->seg_exec[0], c->stream));
+        if (c->cfg.knn <= 8) { c->qsorted_n = n; c->qsorted_src = c->d_reading; } // what the replayed head leaves in d_qsorted
+        int launched = S;
+        const int lead = S > 1 ? S / 2 : 1;
+        bool stopped = false;
+        while (launched < lc.max_iter && !stopped) {
+            for (unsigned spins = 1;; ++spins) {
+                const unsigned v = __atomic_load_n(c->h_progress, __ATOMIC_ACQUIRE);
+                if (((v >> 12) & 0x7ffffu) == c->reg_seq) {
+                    if (v >> 31) { stopped = true; break; }
+                    if ((int)(v & 0xfffu) + lead >= launched) break;
+                }
+                if ((spins & 255u) != 0) continue;
+                const hipError_t qe = hipStreamQuery(c->stream);
+                if (qe != hipSuccess && qe != hipErrorNotReady) HIP_TRY(c, qe);
+                if (qe == hipSuccess) { // everything enqueued has run: the word is final
+                    const unsigned w = __atomic_load_n(c->h_progress, __ATOMIC_ACQUIRE);
+                    stopped = ((w >> 12) & 0x7ffffu) != c->reg_seq || (w >> 31) != 0 || (int)(w & 0xfffu) < launched;
+                    break;
+                }
+            }
+            if (stopped) break;
+            HIP_TRY(c, hipGraphLaunch(c->seg_exec[1], c->stream));
+            launched += S;
+        }
+    } else if (graph) {
         // the whole registration -- head and all iterations -- is one graph, replayed while the scan
         // buffer, the map and the chain stay the same
         uint64_t sig = 1469598103934665603ull;
@@ -1816,7 +1882,7 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
     }
     if (lc.sensor_noise && stats && !c->h_state->error && c->h_state->iter > 0) {
         // ErrorMinimizer::getOverlap() with sensor noise: one pass over the last iteration's pairs, still in the loop's buffers
-        const bool sorted_state = graph ? c->graph_sorted : c->nn_out_sorted;
+        const bool sorted_state = graph ? c->graph_sorted : (segmented ? c->seg_sorted : c->nn_out_sorted);
         const icpmi_status os = loop_sensor_noise_overlap(c, n, lc, sorted_state, &stats->sensor_noise_overlap);
         if (os != ICPMI_OK) return os;
     }
