@@ -153,7 +153,7 @@ icpmi_status icpmi_create(const icpmi_config* cfg, icpmi_handle* out)
     CR(hipMemset(c->d_selhist, 0, ICPMI_SELHIST_WORDS * sizeof(unsigned)));
     c->cap_selhist = ICPMI_SELHIST_WORDS;
     CR(hipHostMalloc((void**)&c->h_state, sizeof(IcpState) * ICPMI_MAX_BATCH, hipHostMallocDefault));
-    CR(hipHostMalloc((void**)&c->h_pin, ICPMI_PIN_BYTES, hipHostMallocDefault));
+    CR(hipHostMalloc((void**)&c->h_pin, ICPMI_PIN_BYTES + ICPMI_UP_SLOT * ICPMI_UP_SLOTS, hipHostMallocDefault));
     CR(hipHostMalloc((void**)&c->h_progress, 256, hipHostMallocMapped)); // words 0..15: progress per reading of a batch; word 32: sequence number of the registration being launched
     memset(c->h_progress, 0, 256);
     CR(hipHostGetDevicePointer((void**)&c->d_progress, c->h_progress, 0));

@@ -235,7 +235,8 @@ struct icpmi_ctx {
     IcpState* h_state = nullptr;                               // pinned mirror (ICPMI_MAX_BATCH)
     int batch_cur = 1;                                         // readings of the launch sequence being enqueued (set by the loop)
     BatchArgs batch_args{};                                    // their sizes / slice stride
-    unsigned char* h_pin = nullptr;                            // pinned page for small read-backs (counts, statistics)
+    unsigned char* h_pin = nullptr;                            // pinned page: [0, ICPMI_PIN_BYTES) small read-backs, behind it the ring of upload_small
+    unsigned up_next = 0;
     // Progress word of the running registration in host-mapped pinned memory, written by the solve kernel after every
     // iteration: bit 31 = loop finished, bits 30..12 = registration sequence number, bits 11..0 = iterations completed.
     // A registration with data-dependent length (Differential / Bound checkers) is enqueued eagerly, a bounded number of
@@ -279,7 +280,9 @@ static inline icpmi_status ensure_cap(icpmi_ctx* c, T** p, size_t* cap, size_t n
 {
     if (need <= *cap && *p) return ICPMI_OK;
     if (*p) { HIP_TRY(c, hipFree(*p)); *p = nullptr; *cap = 0; }
-    size_t want = need + need / 4 + 64;
+    // doubling: a map that grows by a scan's worth of points per update would otherwise reallocate a few of its ~20 arrays on every
+    // update, and a hipFree is a device-wide synchronisation (~0.2 ms each, r3 HIP trace: 1 ms per map update); HBM is not the constraint
+    size_t want = 2 * need + 64;
     HIP_TRY(c, hipMalloc((void**)p, want * sizeof(T)));
     *cap = want;
     return ICPMI_OK;
@@ -317,6 +320,24 @@ static inline icpmi_status read_back2(icpmi_ctx* c, void* dst0, const void* src0
 }
 static inline icpmi_status read_back(icpmi_ctx* c, void* dst, const void* src, size_t bytes) { return read_back2(c, dst, src, bytes, nullptr, nullptr, 0); }
 
+// Small host -> device upload (a 4x4, a level table, a counter) through a ring of slots in the pinned page: a copy from PAGEABLE memory is
+// staged by the runtime and costs ~40 us of host time each (r3 HIP trace: ~20 of them per map update); from pinned memory it is an async
+// DMA of a few microseconds.  The ring lives in the upper half of the page (read-backs use the lower half); 64 slots of 1 KiB: a slot is
+// reused only 64 uploads later, and every entry point synchronises its stream long before that.
+#define ICPMI_UP_SLOT 1024
+#define ICPMI_UP_SLOTS 64
+static inline icpmi_status upload_small(icpmi_ctx* c, void* d_dst, const void* h_src, size_t bytes)
+{
+    if (!c->h_pin || bytes > ICPMI_UP_SLOT) {
+        HIP_TRY(c, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
+        return ICPMI_OK;
+    }
+    unsigned char* slot = c->h_pin + ICPMI_PIN_BYTES + (size_t)(c->up_next++ % ICPMI_UP_SLOTS) * ICPMI_UP_SLOT;
+    memcpy(slot, h_src, bytes);
+    HIP_TRY(c, hipMemcpyAsync(d_dst, slot, bytes, hipMemcpyHostToDevice, c->stream));
+    return ICPMI_OK;
+}
+
 // slot `k` of the operator scratch, at least `count` entries of T (contents undefined)
 template <typename T>
 static inline T* scratch_get(icpmi_ctx* c, int k, size_t count)
@@ -324,7 +345,7 @@ static inline T* scratch_get(icpmi_ctx* c, int k, size_t count)
     const size_t need = (count ? count : 1) * sizeof(T);
     if (need > c->scratch_bytes[k] || !c->scratch[k]) {
         if (c->scratch[k]) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->scratch[k]); c->scratch[k] = nullptr; c->scratch_bytes[k] = 0; }
-        const size_t want = need + need / 4 + 256;
+        const size_t want = 2 * need + 256;
         if (hipMalloc(&c->scratch[k], want) != hipSuccess) { c->scratch[k] = nullptr; c->last_error = "out of device memory (operator scratch)"; return nullptr; }
         c->scratch_bytes[k] = want;
     }
@@ -336,7 +357,7 @@ template <typename T>
 static inline icpmi_status ensure_cap_keep(icpmi_ctx* c, T** p, size_t* cap, size_t need, size_t used)
 {
     if (need <= *cap && *p) return ICPMI_OK;
-    const size_t want = need + need / 2 + 64;
+    const size_t want = 2 * need + 64;
     T* q = nullptr;
     HIP_TRY(c, hipMalloc((void**)&q, want * sizeof(T)));
     if (*p && used) HIP_TRY(c, hipMemcpyAsync(q, *p, used * sizeof(T), hipMemcpyDeviceToDevice, c->stream));

@@ -639,7 +639,7 @@ icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float
             t[12] = (uint32_t)pc; t[13] = (uint32_t)(pc >> 32); t[14] = (uint32_t)p0; t[15] = (uint32_t)(p0 >> 32);
         }
         if (!c->d_lvl_tab) HIP_TRY(c, hipMalloc((void**)&c->d_lvl_tab, sizeof tab));
-        HIP_TRY(c, hipMemcpyAsync(c->d_lvl_tab, tab, sizeof tab, hipMemcpyHostToDevice, c->stream));
+        { const icpmi_status us = upload_small(c, c->d_lvl_tab, tab, sizeof tab); if (us != ICPMI_OK) return us; }
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->m = m;

@@ -541,7 +541,7 @@ icpmi_status ops_transform_dev(icpmi_ctx* c, const float T[16], const float4* d_
     icpmi_status s = check_rigid(c, T);
     if (s != ICPMI_OK || n == 0) return s;
     if (!c->d_T16) HIP_TRY(c, hipMalloc((void**)&c->d_T16, 16 * sizeof(float)));
-    HIP_TRY(c, hipMemcpyAsync(c->d_T16, T, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    { const icpmi_status us = upload_small(c, c->d_T16, T, 16 * sizeof(float)); if (us != ICPMI_OK) return us; }
     hipLaunchKernelGGL(transform_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, d_in, n, c->d_T16, d_out);
     HIP_TRY(c, hipGetLastError());
     return ICPMI_OK;
@@ -1246,7 +1246,7 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
             s = check_rigid(c, to_sensor);
             if (s != ICPMI_OK) break;
             if (!c->d_T16) HIP_TRY(c, hipMalloc((void**)&c->d_T16, 16 * sizeof(float)));
-            HIP_TRY(c, hipMemcpyAsync(c->d_T16, to_sensor, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream)); // pageable source: staged before the call returns
+            { const icpmi_status us = upload_small(c, c->d_T16, to_sensor, 16 * sizeof(float)); if (us != ICPMI_OK) return us; }
             icpmi_dynpts_params prm = {op.f[0], op.f[1], op.f[2], op.f[3], op.f[4], op.f[5], op.f[6]};
             s = dynpts_dev(c, &prm, c->d_T16, d_scan, n, c->d_raw, c->d_raw_n3, w.m, c->d_raw_s);
             break;
@@ -1312,7 +1312,7 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
         int64_t head = 0;
         if (identity_prefix) {
             unsigned first_moved = (unsigned)w.m;
-            HIP_TRY(c, hipMemcpyAsync(d_pos, &first_moved, sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+            { const icpmi_status us = upload_small(c, d_pos, &first_moved, sizeof(unsigned)); if (us != ICPMI_OK) return us; }
             hipLaunchKernelGGL(chain_prefix_kernel, dim3((int)((w.m + 255) / 256)), dim3(256), 0, c->stream, c->d_src, w.m, d_pos);
             if (read_back(c, &first_moved, d_pos, sizeof(unsigned)) != ICPMI_OK) return ICPMI_ERR_HIP;
             head = first_moved;
@@ -1409,7 +1409,7 @@ icpmi_status ops_staged_merge_allgather(icpmi_ctx* c, const float correction[16]
     // ---- counts of all ranks (collective 1)
     long long* d_cnt = c->d_comm_cnt;
     long long hmine = local == ICPMI_OK ? mine : -1;
-    HIP_TRY(c, hipMemcpyAsync(d_cnt + R, &hmine, sizeof hmine, hipMemcpyHostToDevice, c->stream));
+    { const icpmi_status us = upload_small(c, d_cnt + R, &hmine, sizeof hmine); if (us != ICPMI_OK) return us; }
     icpmi_status s = comm_allgather(c, d_cnt + R, d_cnt, 1, false);
     if (s != ICPMI_OK) return s;
     std::vector<long long> counts((size_t)R);
@@ -1430,7 +1430,7 @@ icpmi_status ops_staged_merge_allgather(icpmi_ctx* c, const float correction[16]
     const std::string grow_error = c->last_error;
     if (c->comm) {
         long long hready = grow == ICPMI_OK ? 1 : -1;
-        HIP_TRY(c, hipMemcpyAsync(d_cnt + R, &hready, sizeof hready, hipMemcpyHostToDevice, c->stream));
+        { const icpmi_status us = upload_small(c, d_cnt + R, &hready, sizeof hready); if (us != ICPMI_OK) return us; }
         s = comm_allgather(c, d_cnt + R, d_cnt, 1, false);
         if (s != ICPMI_OK) return s;
         std::vector<long long> ready((size_t)R);
