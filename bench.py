@@ -403,6 +403,39 @@ def main():
                 extras["docs_knn6"]["pose_err_vs_cpu"] = {"m": e6t, "rad": e6r}
                 extras["docs_knn6"]["cpu_iterations_per_s"] = o6.stats.iterations / o6.stats.seconds_total
             del icp6
+            # PM::ICPSequence::setDefault() -- the chain of a configuration without an `icp:` key (Mapper.cpp:74-78): SamplingSurfaceNormal
+            # on the reference at every setMap (device: icpmi_sampling_surface_normal), RandomSampling(0.75) on the reading, KDTree knn 1,
+            # TrimmedDist 0.85, PointToPlane, Counter 40 + Differential
+            try:
+                icpd = pkg.ICPSequence(device=dev, minimizer=2, max_dist=float("inf"), outliers=[(4, 0.85)], max_iterations=40, use_differential=1)
+                icpd.samplingSurfaceNormal(sc["map"])                                  # warm-up (allocations)
+                t0 = time.perf_counter()
+                order, nrm_ssn = icpd.samplingSurfaceNormal(sc["map"])
+                ssn_ms = (time.perf_counter() - t0) * 1e3
+                ref = np.ascontiguousarray(sc["map"][order])
+                t0 = time.perf_counter()
+                icpd.setMap(ref, nrm_ssn)
+                sm_ms = (time.perf_counter() - t0) * 1e3
+                keep = np.random.default_rng(7).random(sc["scan"].shape[0]) < 0.75       # (a stand-in of the same size for the seeded minstd stream)
+                d_read = torch.from_numpy(np.ascontiguousarray(sc["scan"][keep])).cuda()
+                for _ in range(3):
+                    Td = icpd.registerDev(d_read.data_ptr(), d_read.shape[0])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter(); reps = 20; its = 0
+                for _ in range(reps):
+                    Td = icpd.registerDev(d_read.data_ptr(), d_read.shape[0]); its += icpd.stats.iterations
+                torch.cuda.synchronize()
+                eld = time.perf_counter() - t0
+                gdt, gdr = pkg.synth.pose_error(Td, sc["T_gt"])
+                extras["default_chain"] = {
+                    "config": "PM::ICPSequence::setDefault(): SamplingSurfaceNormal{ratio 0.5, knn 7} on the 1M-pt reference (host pointers in, kept indices + "
+                              "normals out), RandomSampling 0.75 on the 100k-pt reading, KDTree knn 1, TrimmedDist 0.85, PointToPlane, Counter 40 + Differential",
+                    "sampling_surface_normal_ms": ssn_ms, "reference_points_kept": int(order.shape[0]), "set_map_ms": sm_ms,
+                    "ms_per_registration": eld / reps * 1e3, "iterations_per_registration": its / reps, "value": its / eld, "unit": "iterations/s",
+                    "pose_err_vs_ground_truth": {"m": gdt, "rad": gdr}}
+                del icpd, d_read
+            except Exception as e:  # noqa: BLE001
+                extras["default_chain"] = {"error": repr(e)}
             # batch of 8 readings: one GPU serving 8 scan streams
             B = 8
             scans8 = [d_scan] + [torch.from_numpy(pkg.synth.make_scene(m=8, n=args.scan_points, seed_scan=43 + 7 * b, scale=args.scale)["scan"]).cuda()

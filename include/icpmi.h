@@ -305,6 +305,15 @@ icpmi_status icpmi_dynamic_points_update(icpmi_handle h, const icpmi_dynpts_para
  * whose index has the smallest 32-bit finaliser hash (fmix32 of MurmurHash3, a bijection) represents its voxel. */
 icpmi_status icpmi_voxel_keep(icpmi_handle h, const float* in4, int64_t n, float edge, int32_t method, uint8_t* keep);
 
+/* `SamplingSurfaceNormalDataPointsFilter{ratio, knn, samplingMethod: 0, maxBoxDim, seed}` -- the REFERENCE filter of
+ * `PM::ICPSequence::setDefault()` (a configuration without an `icp:` key, Mapper.cpp:74-78), run at every `icp.setMap` (Map.cpp:111,178,528,581):
+ * median splits of the widest box dimension (ties by index) until a box holds <= knn points, one PCA normal per box (boxes of rank < 2 or
+ * wider than maxBoxDim are dropped), the points of a box -- in index order -- kept with probability ratio (std::minstd_rand seeded with
+ * `seed`, one number per point of a surviving box, boxes in depth-first order).  order_out (capacity n) receives the kept indices in box
+ * order, normals3_out (capacity 3 n) their normals; *n_out the number kept.  Entirely on the device (csrc/ssn.hip). */
+icpmi_status icpmi_sampling_surface_normal(icpmi_handle h, const float* in4, int64_t n, float ratio, int32_t knn, float max_box_dim, int32_t seed,
+                                           int32_t* order_out, float* normals3_out, int64_t* n_out);
+
 /* `OctreeGridDataPointsFilter{maxSizeByNode, maxPointByNode, samplingMethod}` (created at OctreeMapperModule.cpp:12, applied at :38):
  * octree over the bounding cube of the cloud, split until the node edge is <= max_size or the node holds <= max_points points
  * (depth capped at 21), one representative per leaf: method 0 = the first point of the leaf (smallest index), 1 = a random

@@ -442,6 +442,10 @@ icpmi_status comm_allgather(icpmi_ctx* c, const void* d_send, void* d_recv, size
 icpmi_status ops_staged_merge_allgather(icpmi_ctx* c, const float correction[16], float min_dist, int normals_knn, int64_t* accepted_local,
                                         int64_t* appended_total, int64_t* new_m, float* merged_out4, int64_t merged_capacity, int64_t* merged_n);
 icpmi_status ops_staged_merged_points(icpmi_ctx* c, float* out4, int64_t capacity, int64_t* n);
+icpmi_status ssn_sample_dev(icpmi_ctx* c, const float4* d_in, int64_t n, float ratio, int knn, float max_box, unsigned seed, int* d_order_out,
+                            float* d_normals_out, int64_t* n_out);
+icpmi_status ops_sampling_surface_normal(icpmi_ctx* c, const float* in4, int64_t n, float ratio, int knn, float max_box, int seed, int32_t* order_out,
+                                         float* normals3_out, int64_t* n_out);
 size_t radix_sort_tab_words(int64_t n, int bits);
 icpmi_status radix_sort_pairs(icpmi_ctx* c, unsigned long long* d_keys2, unsigned* d_vals2, int64_t n, int bits, unsigned* d_tab, int* result_half);
 icpmi_status octree_sample_dev(icpmi_ctx* c, const float4* d_in, int64_t n, float max_size, int max_pts, int method, int* d_order, int* d_leaf_of,

@@ -638,6 +638,7 @@ static void jacobi3(const double C[9], double w[3], double Q[9])
 // std::nth_element's permutation and std::rand).  Host code: a recursive median split is what the reference runs on the CPU
 // too; it runs once per setMap.
 struct SamplingSurfaceNormalFilter : DataPointsFilter {
+    icpmi_handle h = nullptr; // GPU context (createDataPointsFilter): the device path of inPlaceFilter
     float ratio = 0.5f; int knn = 7; int method = 0; float maxBoxDim = INFINITY; bool averageDescriptors = true; bool keepNormals = true; int seed = 1;
     struct Work {
         const DataPoints* in; DataPoints out; std::vector<float> normals; MinStd rng; const SamplingSurfaceNormalFilter* f;
@@ -708,6 +709,21 @@ struct SamplingSurfaceNormalFilter : DataPointsFilter {
     void inPlaceFilter(DataPoints& c) const override {
         const size_t n = c.getNbPoints();
         if (n == 0) return;
+        if (h && method == 0 && knn >= 3 && seed >= 0) {
+            // r3: the partition, the box normals and the sampling run on the device (csrc/ssn.hip: one radix sort per tree level) -- the
+            // filter sits on the REFERENCE of the default chain, i.e. on the whole map at every icp.setMap; the host recursion below
+            // (one thread) stays for samplingMethod 1 and for a shell without a GPU context
+            std::vector<int32_t> order(n);
+            std::vector<float> nrm(3 * n);
+            int64_t kept = 0;
+            GpuICPSequence::check(h, icpmi_sampling_surface_normal(h, c.features.data(), (int64_t)n, ratio, knn, maxBoxDim, seed, order.data(), nrm.data(), &kept));
+            DataPoints out = c.createSimilarEmpty();
+            for (int64_t k = 0; k < kept; ++k) out.appendColFrom(c, (size_t)order[(size_t)k]);
+            nrm.resize(3 * (size_t)kept);
+            if (keepNormals) out.addDescriptor("normals", 3, std::move(nrm));
+            c = std::move(out);
+            return;
+        }
         std::vector<int32_t> idx(n);
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (size_t i = 0; i < n; ++i) { idx[i] = (int32_t)i; for (int r = 0; r < 3; ++r) { lo[r] = std::min(lo[r], c.col(i)[r]); hi[r] = std::max(hi[r], c.col(i)[r]); } }
@@ -854,6 +870,7 @@ std::shared_ptr<DataPointsFilter> createDataPointsFilter(const std::string& name
         for (const char* k : {"keepDensities", "keepEigenValues", "keepEigenVectors"})
             if (geti(p, k, 0) != 0) throw InvalidParameter(name + ": " + k + " is not supported");
         auto f = std::make_shared<SamplingSurfaceNormalFilter>();
+        f->h = ctx;
         f->ratio = getf(p, "ratio", 0.5f); f->knn = geti(p, "knn", 7); f->method = geti(p, "samplingMethod", 0);
         f->maxBoxDim = p["maxBoxDim"] ? p["maxBoxDim"].as<float>() : INFINITY;
         f->averageDescriptors = geti(p, "averageExistingDescriptors", 1) != 0; f->keepNormals = geti(p, "keepNormals", 1) != 0;

@@ -425,6 +425,16 @@ class ICPSequence:
         self._check(self._lib.icpmi_filter_points(self._h, c.ctypes.data, c.shape[0], arr, len(filters), keep.ctypes.data))
         return keep.astype(bool)
 
+    def samplingSurfaceNormal(self, cloud, ratio=0.5, knn=7, max_box_dim=math.inf, seed=1):
+        """icpmi_sampling_surface_normal: (kept indices in box order, their normals) -- SamplingSurfaceNormalDataPointsFilter, samplingMethod 0."""
+        c = _f32c(cloud, 4)
+        order = np.empty(c.shape[0], dtype=np.int32)
+        nrm = np.empty((c.shape[0], 3), dtype=np.float32)
+        n_out = C.c_int64(0)
+        self._check(self._lib.icpmi_sampling_surface_normal(self._h, c.ctypes.data, c.shape[0], ratio, knn, max_box_dim, seed, order.ctypes.data,
+                                                            nrm.ctypes.data, C.byref(n_out)))
+        return order[:n_out.value].copy(), nrm[:n_out.value].copy()
+
     def octreeSample(self, cloud, max_size, max_points=1, method=0, with_leaves=False):
         """OctreeGridDataPointsFilter: indices of the kept points in leaf-visiting order (+ the leaf ordinal of every point)"""
         c = _f32c(cloud, 4)

@@ -83,3 +83,26 @@ def test_octree_chain_equals_oracle_composition(amd, oracle):
     both = np.concatenate([sc["map"], scan])
     # provenance: new map point j is point src[j] of [old map ; scan] -- before the sensor-frame round trip moved it by rounding
     assert np.abs(both[src, :3] - got[:, :3]).max() < 5e-5
+
+
+@pytest.mark.parametrize("n,knn,ratio,seed,max_box", [(6000, 7, 0.5, 1, np.inf), (3001, 12, 0.9, 5, np.inf), (50, 7, 1.0, 2, np.inf), (5, 7, 0.5, 1, np.inf),
+                                                      (40000, 7, 0.5, 1, np.inf), (20000, 9, 0.7, 3, 1.5), (9, 3, 0.5, 1, np.inf)])
+def test_sampling_surface_normal_on_device_equals_oracle(amd, oracle, n, knn, ratio, seed, max_box):
+    """icpmi_sampling_surface_normal (csrc/ssn.hip: one radix sort per tree level, PCA per box, minstd by skip-ahead) against the oracle's
+    recursion (orc_sampling_surface_normal): the kept indices in box order must be IDENTICAL, the normals agree to rounding.
+    SamplingSurfaceNormalDataPointsFilter is the reference filter of PM::ICPSequence::setDefault (Mapper.cpp:74-78)."""
+    rng = np.random.default_rng(n + knn)
+    c = np.ones((n, 4), np.float32)
+    c[:, :3] = (rng.uniform(-1, 1, (n, 3)) * [20.0, 12.0, 0.4]).astype(np.float32)
+    c[: n // 3, 2] = 0.0                                    # a flat patch: rank-2 boxes, and many equal z coordinates (ties by index)
+    if n >= 3000:
+        c[100:160] = c[100]                                 # duplicates: rank-0 boxes are dropped, ties everywhere
+        c[200:400, 0] = np.float32(-0.0); c[400:600, 0] = np.float32(0.0)   # signed zeros compare equal
+    icp = amd.ICPSequence()
+    order, nrm = icp.samplingSurfaceNormal(c, ratio=ratio, knn=knn, max_box_dim=max_box, seed=seed)
+    o_order, o_nrm = oracle.sampling_surface_normal(c, ratio, knn, seed=seed, max_box_dim=max_box)
+    assert np.array_equal(order, o_order), (n, knn, order.shape, o_order.shape)
+    if order.shape[0]:
+        dots = np.abs(np.einsum("ij,ij->i", nrm, o_nrm))
+        assert (dots > 1 - 1e-5).all()
+        assert np.allclose(np.linalg.norm(nrm, axis=1), 1.0, atol=1e-5)
