@@ -199,7 +199,7 @@ void icpmi_destroy(icpmi_handle c)
     hipFree(c->d_qsorted); hipFree(c->d_qindex); hipFree(c->d_qkeys); hipFree(c->d_qtile);
     hipFree(c->d_reading); hipFree(c->d_read_normals); hipFree(c->d_stage_in); hipFree(c->d_stage_n3);
     hipFree(c->d_match_pt); hipFree(c->d_lvl_tab); hipFree(c->d_raw); hipFree(c->d_raw_n3); hipFree(c->d_raw_s); hipFree(c->d_src); hipFree(c->d_alt_raw); hipFree(c->d_alt_n3);
-    hipFree(c->d_alt_s); hipFree(c->d_alt_src); hipFree(c->d_stage_s); hipFree(c->d_merge_send); hipFree(c->d_merge_recv); hipFree(c->d_merged); hipFree(c->d_comm_cnt); hipFree(c->d_read_noise);
+    hipFree(c->d_alt_s); hipFree(c->d_alt_src); hipFree(c->d_stage_s); hipFree(c->d_merge_send); hipFree(c->d_merge_recv); hipFree(c->d_merged); hipFree(c->d_comm_cnt); hipFree(c->d_read_noise); hipFree(c->d_map_pn);
     for (int k = 0; k < 10; ++k) hipFree(c->scratch[k]); hipFree(c->d_scan_map); hipFree(c->d_T16);
     hipFree(c->d_sidx); hipFree(c->d_d2); hipFree(c->d_hard); hipFree(c->d_partials); hipFree(c->d_selhist);
     hipFree(c->d_state);

@@ -159,6 +159,9 @@ struct icpmi_ctx {
     int64_t n_occupied = 0;
     float4* d_map_sorted = nullptr;     // xyz centred, w = bits of the original index
     float4* d_normals_sorted = nullptr; // xyz normal, w unused; nullptr if the map has no normals
+    // point and normal of level-0 position s side by side (pn[2 s], pn[2 s + 1]: one 64-byte sector): what the pair sums of a k > 1
+    // chain gather at random -- two separate 16-byte gathers fetch two sectors (r3: 76.5 MB per launch for 33.6 MB of payload)
+    float4* d_map_pn = nullptr; size_t cap_map_pn = 0;
     unsigned* d_cell_start = nullptr;   // ncells + 1
     size_t cap_map = 0, cap_cells = 0, cap_normals = 0;
     bool has_normals = false;

@@ -162,8 +162,10 @@ __device__ __forceinline__ void block_find_rank_2tier(unsigned coarse_v, const u
     block_find_rank256(coarse_v, from_quantile, quantile, rank_in, sh, cb, rem, total);
     if (total == 0) { bin16 = 0; rank_rem = 0; return; }
     unsigned fv = 0;
+    if (threadIdx.x < 256) { // (workgroups wider than 256 threads: the extra waves carry empty bins through the scan)
 #pragma unroll
-    for (int cpy = 0; cpy < FCOPIES; ++cpy) fv += fine[cpy * 65536 + ICPMI_S2_FIDX(cb * 256 + threadIdx.x)];
+        for (int cpy = 0; cpy < FCOPIES; ++cpy) fv += fine[cpy * 65536 + ICPMI_S2_FIDX(cb * 256 + threadIdx.x)];
+    }
     unsigned fb;
     block_find_rank256(fv, false, 0.f, rem, sh, fb, rank_rem, tot2);
     bin16 = (cb << 8) | fb;
@@ -481,14 +483,18 @@ __device__ __forceinline__ float match_weight(const LoopCfg& lc, const IcpState*
 // ---------------------------------------------------------------------------------------------
 // workgroups that take part in the pair sums of `count` matches (the host's acc_blocks): a batch launches the grid of its
 // largest reading, every reading uses the workgroups -- and therefore the summation order -- it would use alone
-__device__ __forceinline__ int acc_blocks_dev(int64_t count, int cap)
+// threads per pair-sum workgroup: k = 1 gives every lane one or two pairs; with k matches per query a 256-thread workgroup left every lane
+// ~9 pairs to walk one dependent gather after the other with ONE wave per SIMD to hide it (knn 6: 20 us) -- 1024 threads per workgroup
+// keep the number of partials (and the solve's ordered reduction) and give every lane at most three
+__host__ __device__ __forceinline__ int acc_threads(int k) { return k > 1 ? 1024 : 256; }
+__host__ __device__ __forceinline__ int acc_blocks_dev(int64_t count, int cap, int bt = 256)
 {
-    const int64_t nb = (count + 255) / 256;
+    const int64_t nb = (count + bt - 1) / bt;
     return (int)(nb < 1 ? 1 : (nb > cap ? cap : nb));
 }
 
-template <int MIN, bool FUSED, bool EXT>
-__global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restrict__ reading, BatchArgs ba, int acc_cap, LoopCfg lc,
+template <int MIN, bool FUSED, bool EXT, int BT = 256>
+__global__ __launch_bounds__(BT) void accumulate_kernel(const float4* __restrict__ reading, BatchArgs ba, int acc_cap, LoopCfg lc,
                                                          IcpState* __restrict__ st, const float4* __restrict__ map,
                                                          const float4* __restrict__ normals,
                                                          const float4* __restrict__ read_normals,
@@ -496,11 +502,12 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restric
                                                          double* __restrict__ partials, unsigned* __restrict__ hists,
                                                          int fused_slot, int is_median, float factor,
                                                          const float4* __restrict__ match_pt, const int* __restrict__ qindex,
-                                                         const float* __restrict__ ref_scalar)
+                                                         const float* __restrict__ ref_scalar, const float4* __restrict__ pnm)
 {
+    // pnm != nullptr (k > 1, point-to-plane): matched point and its normal sit side by side -- one gather, one 64-byte sector
     // blockIdx.y = reading of a batch (common.h: BatchArgs); a single registration is the batch of one
     const int n = ba.n[blockIdx.y];
-    const int nbe = acc_blocks_dev((int64_t)n * lc.k, acc_cap);
+    const int nbe = acc_blocks_dev((int64_t)n * lc.k, acc_cap, BT);
     if ((int)blockIdx.x >= nbe) return;
     {
         const size_t qo = (size_t)blockIdx.y * (size_t)ba.qstride;
@@ -518,8 +525,8 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restric
     // The first two elements of every lane are requested before anything else so that their round
     // trip overlaps the histogram scan below.
     const int64_t count = (int64_t)n * lc.k;
-    const int64_t stride = (int64_t)nbe * 256;
-    const int64_t e_first = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t stride = (int64_t)nbe * BT;
+    const int64_t e_first = (int64_t)blockIdx.x * BT + threadIdx.x;
     float pd2[2]; int ps[2]; float4 pr[2], pq[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -528,14 +535,14 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restric
         pd2[u] = in ? d2a[e] : INFINITY;
         ps[u] = in ? sidx[e] : -1;
         pr[u] = reading[in ? (int)(e / lc.k) : 0];
-        pq[u] = (match_pt && in) ? match_pt[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        pq[u] = (match_pt && in) ? match_pt[e] : ((pnm && ps[u] >= 0) ? pnm[2 * (size_t)ps[u]] : make_float4(0.f, 0.f, 0.f, 0.f));
     }
-    const unsigned cv = FUSED ? hists[ICPMI_S2_C1 + threadIdx.x] : 0u; // same round trip as the elements
+    const unsigned cv = (FUSED && threadIdx.x < 256) ? hists[ICPMI_S2_C1 + threadIdx.x] : 0u; // same round trip as the elements
     // second round trip, overlapping the fine-histogram read of the selection scan: the matched normals
     float4 pn[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
-        pn[u] = (MIN == ICPMI_MIN_POINT_TO_PLANE && ps[u] >= 0) ? normals[ps[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+        pn[u] = (MIN == ICPMI_MIN_POINT_TO_PLANE && ps[u] >= 0) ? (pnm ? pnm[2 * (size_t)ps[u] + 1] : normals[ps[u]]) : make_float4(0.f, 0.f, 0.f, 0.f);
     if (st->done) return;
     float fused_limit = 0.f;
     if (FUSED) {
@@ -563,10 +570,10 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restric
         if (EXT) {
             // the filters that read the pair itself: original index of the matched point (its .w), point-to-plane residual
             const float3 pe = xf_point(T, r.x, r.y, r.z, r.w);
-            const float4 qe = match_pt ? qkept : map[s];
+            const float4 qe = (match_pt || (pnm && have_n)) ? qkept : (pnm ? pnm[2 * (size_t)s] : map[s]);
             float plane2 = 0.f;
             if (normals) {
-                const float4 ne = have_n && MIN == ICPMI_MIN_POINT_TO_PLANE ? nkept : normals[s];
+                const float4 ne = have_n && MIN == ICPMI_MIN_POINT_TO_PLANE ? nkept : (pnm ? pnm[2 * (size_t)s + 1] : normals[s]);
                 const float dx = pe.x - qe.x, dy = pe.y - qe.y, dz = pe.z - qe.z;
                 const float dot = dx * ne.x + dy * ne.y + dz * ne.z;
                 plane2 = dot * dot;
@@ -578,7 +585,7 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restric
         wsum += w; cnt += 1.0;
         if (MIN == ICPMI_MIN_IDENTITY) return;
         const float3 p = xf_point(T, r.x, r.y, r.z, r.w);
-        const float4 q = match_pt ? qkept : map[s];
+        const float4 q = (match_pt || (pnm && have_n)) ? qkept : (pnm ? pnm[2 * (size_t)s] : map[s]);
         if (MIN == ICPMI_MIN_POINT_TO_POINT) {
             const double dw = w;
             acc[0] += dw;
@@ -591,7 +598,7 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restric
 #pragma unroll
                 for (int rr = 0; rr < 3; ++rr) acc[7 + 3 * c + rr] += wq[rr] * pc[c];
         } else if (MIN == ICPMI_MIN_POINT_TO_PLANE) {
-            const float4 nn = have_n ? nkept : normals[s];
+            const float4 nn = have_n ? nkept : (pnm ? pnm[2 * (size_t)s + 1] : normals[s]);
             // per-pair quantities in float exactly as the oracle (and Eigen) form them
             const float F[6] = {p.y * nn.z - p.z * nn.y, p.z * nn.x - p.x * nn.z, p.x * nn.y - p.y * nn.x, nn.x, nn.y, nn.z};
             const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
@@ -621,7 +628,7 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restric
     // values the partner keeps, so 32 values x 64 lanes fold with 16+8+4+2+1+1 = 32 exchanges instead
     // of 32 x 6.  After the five halving steps lane l holds value bitrev5(l & 31) summed over its
     // 32-lane half; the last exchange joins the halves.  Fixed pattern => deterministic sums.
-    __shared__ double sh[4][ICPMI_NV];
+    __shared__ double sh[BT / 64][ICPMI_NV];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double val[ICPMI_NV];
 #pragma unroll
@@ -649,7 +656,11 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restric
     if (threadIdx.x < ICPMI_NV) {
         const int i = threadIdx.x;
         double v = 0.0;
-        if (i < NVAL || i == 27 || i == 28 || (EXT && i > 28)) v = sh[0][i] + sh[1][i] + sh[2][i] + sh[3][i];
+        if (i < NVAL || i == 27 || i == 28 || (EXT && i > 28)) {
+            v = sh[0][i] + sh[1][i] + sh[2][i] + sh[3][i];
+#pragma unroll
+            for (int w2 = 4; w2 < BT / 64; ++w2) v += sh[w2][i]; // fixed order
+        }
         partials[(size_t)blockIdx.x * ICPMI_NV + i] = v;
     }
 }
@@ -1219,7 +1230,7 @@ __global__ __launch_bounds__(256) void solve_kernel(IcpState* __restrict__ st, c
                                                     unsigned* __restrict__ progress)
 {
     // blockIdx.x = reading of a batch: one workgroup per registration
-    const int nblocks = acc_blocks_dev((int64_t)ba.n[blockIdx.x] * lc.k, acc_cap);
+    const int nblocks = acc_blocks_dev((int64_t)ba.n[blockIdx.x] * lc.k, acc_cap, acc_threads(lc.k));
     st += blockIdx.x;
     partials += (size_t)blockIdx.x * (size_t)acc_cap * ICPMI_NV;
     if (progress) progress += blockIdx.x;
@@ -1456,10 +1467,10 @@ static int acc_cap()
     return cap;
 }
 
-static int acc_blocks(int64_t count)
+static int acc_blocks(int64_t count, int bt = 256)
 {
     const int cap = acc_cap();
-    const int64_t nb = (count + 255) / 256;
+    const int64_t nb = (count + bt - 1) / bt;
     return (int)(nb < 1 ? 1 : (nb > cap ? cap : nb));
 }
 
@@ -1581,6 +1592,7 @@ static void enqueue_selection(icpmi_ctx* c, const LoopCfg& lc, int64_t count, bo
 
 template <int MIN, bool FUSED, bool EXT>
 static void launch_accumulate_ext(icpmi_ctx* c, int64_t n, const LoopCfg& lc, int nb, int slot);
+static bool pn_enabled() { static int v = -1; if (v < 0) { const char* e = getenv("ICPMI_ACC_PN"); v = e ? atoi(e) : 1; } return v != 0; }
 
 template <int MIN, bool FUSED>
 static void launch_accumulate(icpmi_ctx* c, int64_t n, const LoopCfg& lc, int nb, int slot)
@@ -1598,16 +1610,24 @@ static void launch_accumulate_ext(icpmi_ctx* c, int64_t n, const LoopCfg& lc, in
     const float factor = slot >= 0 ? lc.out_param[slot] : 0.f;
     const bool sorted = c->nn_out_sorted; // loop state in query order (k = 1: with the matched points, see nn1_wg_kernel; k > 1: ids and d2)
     const BatchArgs ba = cur_batch(c, n);
+    if (lc.k > 1) {
+        hipLaunchKernelGGL((accumulate_kernel<MIN, FUSED, EXT, 1024>), dim3(nb, ba.nscan), dim3(1024), 0, c->stream, sorted ? c->d_qsorted : c->d_reading, ba, acc_cap(), lc, c->d_state,
+                           c->d_map_sorted, c->has_normals ? c->d_normals_sorted : (const float4*)nullptr, rn, c->d_sidx, c->d_d2, c->d_partials, c->d_selhist, slot, is_med, factor,
+                           (const float4*)nullptr, sorted ? c->d_qindex : (const int*)nullptr, (EXT && c->raw_has_scalar) ? c->d_raw_s : (const float*)nullptr,
+                           (MIN == ICPMI_MIN_POINT_TO_PLANE && c->has_normals && c->d_map_pn && pn_enabled()) ? c->d_map_pn : (const float4*)nullptr);
+        return;
+    }
     hipLaunchKernelGGL((accumulate_kernel<MIN, FUSED, EXT>), dim3(nb, ba.nscan), dim3(256), 0, c->stream, sorted ? c->d_qsorted : c->d_reading, ba, acc_cap(), lc, c->d_state,
                        c->d_map_sorted, c->has_normals ? c->d_normals_sorted : (const float4*)nullptr, rn, c->d_sidx, c->d_d2, c->d_partials, c->d_selhist, slot, is_med, factor,
                        (sorted && lc.k == 1) ? c->d_match_pt : (const float4*)nullptr, sorted ? c->d_qindex : (const int*)nullptr,
-                       (EXT && c->raw_has_scalar) ? c->d_raw_s : (const float*)nullptr);
+                       (EXT && c->raw_has_scalar) ? c->d_raw_s : (const float*)nullptr,
+                       (lc.k > 1 && MIN == ICPMI_MIN_POINT_TO_PLANE && c->has_normals && c->d_map_pn && pn_enabled()) ? c->d_map_pn : (const float4*)nullptr);
 }
 
 static void enqueue_accumulate_solve(icpmi_ctx* c, int64_t n, const LoopCfg& lc, float* d_Tstep, double* d_sums)
 {
     const int64_t count = n * lc.k;
-    const int nb = acc_blocks(count);
+    const int nb = acc_blocks(count, acc_threads(lc.k));
     const int slot = fused_filter_slot(lc);
     const bool fused = slot >= 0;
     // (r1: letting the last pair-sum workgroup solve -- ticket + device fences -- measured +3.5 us per

@@ -216,6 +216,15 @@ __global__ __launch_bounds__(256) void lvl_key_kernel(const float4* __restrict__
     if (r.head) atomicAdd(&count[key], (unsigned)r.len);
 }
 
+// point and normal of every level-0 position side by side (common.h: d_map_pn)
+__global__ __launch_bounds__(256) void pn_kernel(const float4* __restrict__ pts, const float4* __restrict__ nrm, int64_t m, float4* __restrict__ pn)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    pn[2 * i] = pts[i];
+    pn[2 * i + 1] = nrm[i];
+}
+
 __global__ __launch_bounds__(256) void lvl_scatter_kernel(const float4* __restrict__ pts0, int64_t m, const unsigned* __restrict__ keys,
                                                           const unsigned* __restrict__ start, unsigned* __restrict__ fill,
                                                           float4* __restrict__ out, unsigned* __restrict__ pos0)
@@ -599,6 +608,11 @@ icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float
     hipLaunchKernelGGL(scatter_kernel, dim3(blocks), dim3(256), 0, c->stream, d_pts, d_normals3, m, c->mean[0], c->mean[1], c->mean[2],
                        c->d_keys, c->d_cell_start, c->d_fill, c->d_map_sorted, d_normals3 ? c->d_normals_sorted : nullptr, run_atomics_cfg());
     HIP_TRY(c, hipGetLastError());
+    if (d_normals3 && !c->single_level && c->keep_raw) { // (the handles of the map-side operators never run pair sums)
+        if (ensure_cap(c, &c->d_map_pn, &c->cap_map_pn, 2 * (size_t)m + 2) != ICPMI_OK) return ICPMI_ERR_HIP;
+        hipLaunchKernelGGL(pn_kernel, dim3(blocks), dim3(256), 0, c->stream, (const float4*)c->d_map_sorted, (const float4*)c->d_normals_sorted, m, c->d_map_pn);
+        HIP_TRY(c, hipGetLastError());
+    }
 
     // ---- coarser pyramid levels: cell edge doubles until one 3x3x3 block reaches past maxDist (or
     //      the grid is at most 2 cells wide, where a block always covers it) ----

@@ -1355,7 +1355,7 @@ __global__ __launch_bounds__(64 * NW) void nn1_wg_kernel(const float4* __restric
     }
 #ifdef ICPMI_NN_TIMING
     NN_TICK(5);
-    if (threadIdx.x == 0 && st_iter > 1) { // the heaviest workgroup of the steady launches: its life and its pieces
+    if (threadIdx.x == 0 && st_iter > 1 && (blockIdx.x % 7) == 0) { // the heaviest of a sample of the steady launches' workgroups: its life and its pieces
         atomicMax(&st->dbg[20], (unsigned long long)(clock64() - t_c0));
         atomicMax(&st->dbg[21], (unsigned long long)tacc[7]);
     }

@@ -9,6 +9,7 @@ B="python $GRAFT_REPO_ROOT/bench.py --no-cpu --no-extras --steps 3 --warmup 1"
 pmc calib/fetch FETCH_SIZE -- $GRAFT_REPO_ROOT/scripts/pmc_calib.bin
 pmc calib/write WRITE_SIZE -- $GRAFT_REPO_ROOT/scripts/pmc_calib.bin
 for wl in "p2p:--chain p2p" "p2plane:--chain p2plane" "knn6:--chain docs_knn6" "map10M:--chain p2p --map-points 10000000 --scale 3.16" "batch8:--chain p2p --batch 8"; do
+  if [ -n "$WL" ] && [ "${wl%%:*}" != "$WL" ]; then continue; fi
   name=${wl%%:*}; args=${wl#*:}
   pmc $name/fetch FETCH_SIZE -- $B $args
   pmc $name/write WRITE_SIZE -- $B $args
