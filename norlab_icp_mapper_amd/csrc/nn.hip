@@ -1635,6 +1635,408 @@ __global__ __launch_bounds__(NN_BLOCK) void nnk_ml_kernel(const float4* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// nnk_wg_kernel: 2 <= k <= 8 in the loop (seeded launches), with the roles of nn1_wg_kernel.  A workgroup of four waves owns 64
+// queries:
+//   (1a) wave 0, lane per query: keeps the query's sorted k-list in registers (seeded with the previous iteration's k matches
+//        under the current transform), publishes the level, the pruning radius and the ACCEPT BOUND (k-th key held, else the
+//        key of maxr2);
+//   (1b) all waves, lane = query, wave = row group: row ranges -> pieces of 8 candidates;
+//   (2)  all waves, lane per piece: candidates with key <= bound go to the query's list in LDS (one LDS atomic per piece);
+//   (3)  wave 0 merges its query's list into the k-list (the same point seen again is dropped by its key) and decides.
+// A list that overflows (CAPQ entries) is not lost work: the k-list of what DID arrive tightens the bound, and the pass is
+// repeated -- of the candidates under the old bound at least CAPQ - k lie above the new one, so this terminates.  Keys, the
+// exactness rule per level and the output are those of nnk_ml_kernel: the same k points in the same order.
+// Measured (r3, knn 6, 100 k queries, 1 M points): steady launches 37.3 -> 25 us.  NOT for wide bounds: a launch whose seeds
+// moved far (iteration 1) overflows the lists and repeats passes (172 us here, as nnk_ml_kernel), the unseeded launch takes
+// 270 us against 115 us -- the launcher keeps nnk_ml_kernel for iterations 0 and 1.  Level 0 of the fused quantile selection
+// from this kernel's tail (k atomics per query on the fine bins) made a launch 55 us; the stand-alone builder (12.5 us), which
+// combines 4096 matches in LDS before it touches memory, stays.
+// ------------------------------------------------------------------------------------------------
+#ifndef NNK_WG_WAVES
+#define NNK_WG_WAVES 5
+#endif
+template <int KMAX>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NNK_WG_WAVES))) void nnk_wg_kernel(const float4* __restrict__ queries, const int* __restrict__ qindex, int n,
+                                                     const float* __restrict__ Tptr, const uint4* __restrict__ ltab_g, int nlev,
+                                                     int k, float maxr2, int* __restrict__ out_sidx, float* __restrict__ out_d2,
+                                                     IcpState* __restrict__ st, unsigned* __restrict__ hard, int out_sorted, int seed_pre)
+{
+    constexpr int NW = 4, NT = 64 * NW, Q = 64, NR = 3;
+    constexpr int CAP = 14 * Q;   // pieces per pass (> 9 Q: one piece per row always fits)
+    constexpr int PLB = 3;
+    constexpr int CAPQ = 24;      // list entries per query and pass (> KMAX).  (48, at three waves per SIMD, for the wide first launches: slower)
+    static_assert(CAPQ > KMAX, "a repeated pass must make progress");
+    __shared__ uint4 ltab[ICPMI_MAXLEV * 4];
+    __shared__ uint2 pieces[CAP];                 // {position of the first candidate in its level array, count << 8 | query slot}
+    __shared__ float4 qrec[Q];                    // transformed query, w = bits of its current level
+    __shared__ float2 qaux[Q];                    // squared pruning radius (+inf: none), flags: 1 = searching, 2 = own row only
+    __shared__ unsigned long long qbound[Q];      // candidates with a key above this are dropped
+    __shared__ unsigned qcnt[Q];                  // candidates offered to the list this pass (may exceed CAPQ)
+    __shared__ unsigned long long qlk[CAPQ * Q];  // [entry][query]
+    __shared__ unsigned qlp[CAPQ * Q];
+    __shared__ unsigned s_any, s_total[2];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const bool w0 = wave == 0;
+    const int wgs = (int)((((long long)n + Q - 1) / Q + 7) / 8 * 8);
+    if ((int)blockIdx.x >= wgs) return;
+    const int chunk = wgs >> 3;
+    const int lb = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    const int slot = lane;
+    const int qi = lb * Q + slot;
+    const bool active = w0 && qi < n;
+    if (st->done) return;
+#ifdef ICPMI_NN_TIMING
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = clock64();
+    const long long t_c0 = tlast;
+    unsigned long long t_ovf = 0, t_off = 0;
+    const int st_iter = st->iter;
+#endif
+    if (tid < ICPMI_MAXLEV * 4) ltab[tid] = ltab_g[tid];
+    int orig = 0;
+    float3 p = make_float3(0.f, 0.f, 0.f);
+    unsigned long long mk[KMAX];
+    int ms[KMAX];
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i) { mk[i] = ~0ull; ms[i] = -1; }
+    auto insert = [&](unsigned long long key, int sidx, bool check_dup) {
+        if (key >= mk[KMAX - 1]) return;
+        if (check_dup) {
+            bool dup = false;
+#pragma unroll
+            for (int i = 0; i < KMAX; ++i) dup |= key == mk[i];
+            if (dup) return;
+        }
+#pragma unroll
+        for (int i = KMAX - 1; i >= 0; --i) {
+            const unsigned long long prev = i > 0 ? mk[i - 1] : 0ull;
+            const int prevs = i > 0 ? ms[i - 1] : -1;
+            if (i > 0 && key < prev) { mk[i] = prev; ms[i] = prevs; }
+            else if (key < mk[i]) { mk[i] = key; ms[i] = sidx; }
+        }
+    };
+    auto kth = [&]() {
+        unsigned long long v = ~0ull;
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) if (i == k - 1) v = mk[i];
+        return v;
+    };
+    const unsigned long long maxkey = pack_key(maxr2, 0xffffffffu);
+    // first level >= from whose 3 x 3 x 3 block contains the ball of this key's distance around the query
+    auto level_for = [&](unsigned long long b, int from) {
+        const float ub = sqrtf(__uint_as_float((unsigned)(b >> 32))) * 1.000001f;
+        int l = from;
+        for (; l < nlev - 1; ++l) {
+            const uint4 a = ltab_g[4 * l], bb = ltab_g[4 * l + 1];
+            const float inv = __uint_as_float(bb.x);
+            const float fx = (p.x - __uint_as_float(a.x)) * inv, fy = (p.y - __uint_as_float(a.y)) * inv, fz = (p.z - __uint_as_float(a.z)) * inv;
+            float mfl = fminf(fx - floorf(fx), 1.0f - (fx - floorf(fx)));
+            mfl = fminf(mfl, fminf(fy - floorf(fy), 1.0f - (fy - floorf(fy))));
+            mfl = fminf(mfl, fminf(fz - floorf(fz), 1.0f - (fz - floorf(fz))));
+            if (!(mfl >= 0.f)) mfl = 0.f;
+            if (ub <= (1.0f + mfl) * __uint_as_float(a.w) - 2.0f * __uint_as_float(bb.y)) break;
+        }
+        return l;
+    };
+    bool widepre = false;
+    int lev = 0;
+    unsigned long long seedb = ~0ull; // key of the farthest previous match (all k valid), an upper bound of the k-th key
+    if (w0) {
+        const float4 r = queries[active ? qi : 0];
+        orig = (qindex && !out_sorted) ? qindex[active ? qi : 0] : qi;
+        if (Tptr) p = xf_point(Tptr, r.x, r.y, r.z, r.w);
+        else p = make_float3(r.x, r.y, r.z);
+        if (active && st->iter > 0) { // the previous k matches under the current transform (all loads first, then the insertions)
+            const gfloat4* l0 = reinterpret_cast<const gfloat4*>(((unsigned long long)ltab_g[2].w << 32) | ltab_g[2].z);
+            int sp[KMAX];
+            vf4 sq[KMAX];
+#pragma unroll
+            for (int j = 0; j < KMAX; ++j) sp[j] = j < k ? out_sidx[(size_t)k * orig + j] : -1;
+#pragma unroll
+            for (int j = 0; j < KMAX; ++j) sq[j] = l0[sp[j] >= 0 ? sp[j] : 0];
+            unsigned long long sb = 0ull; // the bound is the farthest of the k; the points themselves are met again in the pass
+            bool allv = true;
+#pragma unroll
+            for (int j = 0; j < KMAX; ++j) {
+                const unsigned long long key = pack_key(sqdist3(p.x, p.y, p.z, sq[j].x, sq[j].y, sq[j].z), __float_as_uint(sq[j].w));
+                if (j < k) { sb = key > sb ? key : sb; allv = allv && sp[j] >= 0; }
+            }
+            if (allv) seedb = sb;
+        }
+        if (seedb != ~0ull) {
+            lev = level_for(seedb, 0);
+            // seeds too wide for level 0 (the first iterations): the x-row through the query's own cell of level 0 first -- the k-th
+            // of what it holds under the seed bound is usually much tighter, and the level is chosen again from that
+            if (seed_pre && lev > 0) { widepre = true; lev = 0; }
+        }
+    }
+    bool decided = !active;
+    bool did_pre = false;
+#ifdef ICPMI_NNK_DIAG
+    int diag_pass = 0;
+#endif
+    NN_TICK(0);
+    __syncthreads(); // ltab visible
+    for (;;) {
+        // ---- (1a)
+        bool run = false, prescan = false;
+        if (w0) {
+            run = !decided && lev < nlev;
+            const bool any = __ballot(run) != 0ull;
+            if (lane == 0) { s_any = any ? 1u : 0u; s_total[0] = 0u; s_total[1] = 0u; }
+            if (any) {
+                const int lv = run ? lev : 0;
+                unsigned long long b = kth();
+                b = seedb < b ? seedb : b;
+                prescan = run && !did_pre && (b == ~0ull || widepre);
+                const unsigned long long acc = b < maxkey ? b : maxkey;
+                float rub2 = INFINITY;
+                if (!prescan && acc < 0x7f80000000000000ull) { // (a finite radius: the k-th held, or the matcher's maxDist)
+                    const float slack = __uint_as_float(ltab[4 * lv + 1].y);
+                    const float rub = sqrt_up(__uint_as_float((unsigned)(acc >> 32))) * 1.000001f + slack;
+                    rub2 = rub * rub;
+                }
+                qrec[slot] = make_float4(p.x, p.y, p.z, __int_as_float(lv));
+                qaux[slot] = make_float2(rub2, __int_as_float((run ? 1 : 0) | (prescan ? 2 : 0)));
+                qbound[slot] = acc;
+                qcnt[slot] = 0u;
+            }
+        }
+        __syncthreads();
+        if (!s_any) break;
+        NN_TICK(1);
+        // ---- (1b) all waves: lane = query, wave = row group (as nn1_wg_kernel)
+        float mf, g_cell, g_slack;
+        bool covers;
+        {
+            const float4 qr = qrec[slot];
+            const float2 qa = qaux[slot];
+            const int lv = __float_as_int(qr.w);
+            const int fl = __float_as_int(qa.y);
+            const bool qrun = (fl & 1) != 0, qpre = (fl & 2) != 0;
+            const float rub2 = qa.x;
+            GridParams g;
+            const gunsigned* __restrict__ cs;
+            {
+                const uint4 a = ltab[4 * lv], b = ltab[4 * lv + 1], c2 = ltab[4 * lv + 2], d = ltab[4 * lv + 3];
+                g.ox = __uint_as_float(a.x); g.oy = __uint_as_float(a.y); g.oz = __uint_as_float(a.z); g.cell = __uint_as_float(a.w);
+                g.inv_cell = __uint_as_float(b.x); g.slack = __uint_as_float(b.y); g.nx = (int)b.z; g.ny = (int)b.w;
+                g.nz = (int)c2.x; g.ncells = (int)c2.y;
+                cs = reinterpret_cast<const gunsigned*>(((unsigned long long)d.y << 32) | d.x);
+            }
+            const float fx = (qr.x - g.ox) * g.inv_cell, fy = (qr.y - g.oy) * g.inv_cell, fz = (qr.z - g.oz) * g.inv_cell;
+            const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
+            const int cx = (int)fminf(fmaxf(flx, -1.0e6f), 1.0e6f);
+            const int cy = (int)fminf(fmaxf(fly, -1.0e6f), 1.0e6f);
+            const int cz = (int)fminf(fmaxf(flz, -1.0e6f), 1.0e6f);
+            mf = fminf(fx - flx, 1.0f - (fx - flx));
+            mf = fminf(mf, fminf(fy - fly, 1.0f - (fy - fly)));
+            mf = fminf(mf, fminf(fz - flz, 1.0f - (fz - flz)));
+            if (!(mf >= 0.f)) mf = 0.f;
+            g_cell = g.cell; g_slack = g.slack;
+            covers = cx - 1 <= 0 && cx + 1 >= g.nx - 1 && cy - 1 <= 0 && cy + 1 >= g.ny - 1 && cz - 1 <= 0 && cz + 1 >= g.nz - 1;
+            unsigned rs[NR], rn[NR];
+            {
+                const float ylo = (fy - fly) * g.cell, yhi = (1.0f - (fy - fly)) * g.cell;
+                const float zlo = (fz - flz) * g.cell, zhi = (1.0f - (fz - flz)) * g.cell;
+                unsigned ia[NR], ib[NR];
+#pragma unroll
+                for (int sl = 0; sl < NR; ++sl) {
+                    const int rr = wave + sl * NW;
+                    const int dy = (rr % 3) - 1, dz = (rr / 3) - 1;
+                    bool reach = qrun && rr < 9 && (!qpre || rr == 4);
+                    const float ddy = dy == 0 ? 0.f : (dy < 0 ? ylo : yhi);
+                    const float ddz = dz == 0 ? 0.f : (dz < 0 ? zlo : zhi);
+                    const float rem2 = rub2 - (ddy * ddy + ddz * ddz);
+                    reach = reach && rem2 >= 0.f;
+                    int xa = cx - 1, xb = cx + 1;
+                    if (rem2 != INFINITY) {
+                        const float rem = sqrt_up(fmaxf(rem2, 0.f));
+                        const int xl = (int)fmaxf(floorf((qr.x - rem - g.ox) * g.inv_cell), -1.0e6f);
+                        const int xh = (int)fminf(floorf((qr.x + rem - g.ox) * g.inv_cell), 1.0e6f);
+                        xa = xl > xa ? xl : xa;
+                        xb = xh < xb ? xh : xb;
+                    }
+                    const int y = cy + dy, z = cz + dz;
+                    xa = xa < 0 ? 0 : xa;
+                    xb = xb > g.nx - 1 ? g.nx - 1 : xb;
+                    reach = reach && y >= 0 && y < g.ny && z >= 0 && z < g.nz && xa <= xb;
+                    const int rowbase = (z * g.ny + y) * g.nx;
+                    ia[sl] = reach ? (unsigned)(rowbase + xa) : 0u;
+                    ib[sl] = reach ? (unsigned)(rowbase + xb + 1) : 0u;
+                }
+#pragma unroll
+                for (int sl = 0; sl < NR; ++sl) { rs[sl] = cs[ia[sl]]; rn[sl] = cs[ib[sl]]; }
+#pragma unroll
+                for (int sl = 0; sl < NR; ++sl) rn[sl] -= rs[sl];
+            }
+            int plb = PLB;
+            unsigned base = 0;
+            for (int round = 0; round < 2; ++round) {
+                unsigned np = 0;
+#pragma unroll
+                for (int sl = 0; sl < NR; ++sl) np += (rn[sl] + ((1u << plb) - 1u)) >> plb;
+                const unsigned incl = wave_incl_scan(np);
+                const unsigned wtot = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+                unsigned wb = 0;
+                if (lane == 63 && wtot) wb = atomicAdd(&s_total[round], wtot);
+                wb = (unsigned)__builtin_amdgcn_readlane((int)wb, 63);
+                base = wb + incl - np;
+                __syncthreads();
+                const unsigned tot = s_total[round];
+                if (tot <= (unsigned)CAP) break;
+                int kk = 1;
+                while ((tot >> kk) > (unsigned)(CAP - 9 * Q)) ++kk;
+                plb += kk;
+            }
+#pragma unroll
+            for (int sl = 0; sl < NR; ++sl) {
+                unsigned s = rs[sl], c = rn[sl];
+                while (c) {
+                    const unsigned t = c < (1u << plb) ? c : (1u << plb);
+                    pieces[base++] = make_uint2(s, (t << 8) | (unsigned)slot);
+                    s += t; c -= t;
+                }
+            }
+        }
+        __syncthreads();
+        const unsigned total = s_total[1] ? s_total[1] : s_total[0];
+        NN_TICK(2);
+#ifdef ICPMI_NN_TIMING
+        tacc[6] += 1; tacc[7] += total;
+#endif
+        // ---- (2) all waves, lane per piece: survivors of the bound go to the query's list
+        for (unsigned i0 = 0; i0 < total; i0 += (unsigned)NT) {
+            const unsigned i = i0 + (unsigned)tid;
+            const bool has = i < total;
+            const uint2 e = pieces[has ? i : 0u];
+            const unsigned qsl = e.y & 255u, cnt = has ? e.y >> 8 : 0u;
+            const float4 qr = qrec[qsl];
+            const unsigned long long bnd = qbound[qsl];
+            const unsigned bh = (unsigned)(bnd >> 32), bl = (unsigned)bnd;
+            const unsigned lvbits = __float_as_uint(qr.w) << 28;
+            const uint4 lt2 = ltab[4 * __float_as_int(qr.w) + 2];
+            const gfloat4* mp = reinterpret_cast<const gfloat4*>((((unsigned long long)lt2.w << 32) | lt2.z) + (unsigned long long)e.x * 16ull);
+            for (unsigned c0 = 0; c0 < cnt; c0 += 8u) {
+                vf4 q[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) q[u] = mp[c0 + u];
+                unsigned d2b[8]; // (key = d2 bits << 32 | index bits: compared in halves, packed only when stored)
+                unsigned okm = 0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    d2b[u] = (unsigned)(pack_key(sqdist3(qr.x, qr.y, qr.z, q[u].x, q[u].y, q[u].z), 0u) >> 32);
+                    const unsigned wb = __float_as_uint(q[u].w);
+                    if (c0 + (unsigned)u < cnt && (d2b[u] < bh || (d2b[u] == bh && wb <= bl))) okm |= 1u << u;
+                }
+                if (okm) {
+                    unsigned at = atomicAdd(&qcnt[qsl], (unsigned)__popc(okm));
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (okm & (1u << u)) {
+                            if (at < (unsigned)CAPQ) {
+                                qlk[at * Q + qsl] = ((unsigned long long)d2b[u] << 32) | __float_as_uint(q[u].w);
+                                qlp[at * Q + qsl] = (e.x + c0 + (unsigned)u) | lvbits;
+                            }
+                            ++at;
+                        }
+                }
+            }
+        }
+        __syncthreads();
+        NN_TICK(3);
+        // ---- (3) wave 0: list -> k-list, decide
+        if (w0) {
+            const unsigned offered = run ? qcnt[slot] : 0u;
+#ifdef ICPMI_NN_TIMING
+            t_off += offered; t_ovf += offered > (unsigned)CAPQ ? 1 : 0;
+#endif
+            const unsigned nq = offered < (unsigned)CAPQ ? offered : (unsigned)CAPQ;
+            // (a pass over an empty k-list cannot meet a point twice: the usual case, one pass per launch)
+            if (__ballot(mk[0] != ~0ull) == 0ull)
+                for (unsigned e = 0; __ballot(e < nq) != 0ull; ++e) {
+                    const unsigned long long key = qlk[e * Q + slot];
+                    const unsigned pos = qlp[e * Q + slot];
+                    if (e < nq) insert(key, (int)pos, false);
+                }
+            else
+                for (unsigned e = 0; __ballot(e < nq) != 0ull; ++e) {
+                    const unsigned long long key = qlk[e * Q + slot];
+                    const unsigned pos = qlp[e * Q + slot];
+                    if (e < nq) insert(key, (int)pos, true);
+                }
+#ifdef ICPMI_NNK_DIAG
+            if (run && st->iter == ICPMI_NNK_DIAG) { // per pass of the launch of that iteration: queries, candidates offered, levels, overflows
+                const int ps = diag_pass < 5 ? diag_pass : 5;
+                atomicAdd(&st->dbg[ps], 1ull); atomicAdd(&st->dbg[6 + ps], (unsigned long long)offered);
+                atomicAdd(&st->dbg[12 + ps], (unsigned long long)lev); atomicAdd(&st->dbg[18 + ps], offered > (unsigned)CAPQ ? 1ull : 0ull);
+            }
+            ++diag_pass;
+#endif
+            if (run) {
+                if (prescan) { // (whether or not its list overflowed: the full pass follows, at the level its bound asks for)
+                    did_pre = true; widepre = false;
+                    unsigned long long b = kth();
+                    b = seedb < b ? seedb : b;
+                    if (b != ~0ull) lev = level_for(b, lev);
+                } else if (offered > (unsigned)CAPQ) { } // tighter bound, same level again
+                else {
+                    const unsigned long long b = kth();
+                    const float margin = fmaxf((1.0f + mf) * g_cell - g_slack, 0.f);
+                    const float m2 = margin * margin;
+                    const float kd2 = __uint_as_float((unsigned)(b >> 32));
+                    decided = (b != ~0ull && kd2 <= m2) || m2 > maxr2 || covers;
+                    if (!decided) { ++lev; did_pre = false; }
+                }
+            }
+        }
+        NN_TICK(4);
+    }
+    if (active) {
+        int bs[KMAX];
+        float bd[KMAX];
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) {
+            float d2 = __uint_as_float((unsigned)(mk[j] >> 32));
+            int b = -1;
+            if (mk[j] != ~0ull && d2 <= maxr2) {
+                const unsigned lv = (unsigned)ms[j] >> 28, pos = (unsigned)ms[j] & 0x0fffffffu;
+                if (lv == 0) b = (int)pos;
+                else {
+                    const uint4 d = ltab[4 * lv + 3];
+                    b = (int)reinterpret_cast<const unsigned*>(((unsigned long long)d.w << 32) | d.z)[pos];
+                }
+            } else d2 = INFINITY;
+            bs[j] = b; bd[j] = d2;
+        }
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j)
+            if (j < k) { out_sidx[(size_t)k * orig + j] = bs[j]; out_d2[(size_t)k * orig + j] = bd[j]; }
+        if (!decided) {
+            const unsigned hslot = atomicAdd(&st->hard_count, 1u);
+            hard[hslot] = (unsigned)(qindex ? qindex[qi] : qi);
+        }
+    }
+#ifdef ICPMI_NN_TIMING
+    NN_TICK(5);
+    if (w0 && st_iter > 1 && (blockIdx.x % 61) == 0) { atomicAdd(&st->dbg[18], t_ovf); atomicAdd(&st->dbg[19], t_off); }
+    if (threadIdx.x == 0 && st_iter > 1 && (blockIdx.x % 7) == 0) {
+        atomicMax(&st->dbg[20], (unsigned long long)(clock64() - t_c0));
+        atomicMax(&st->dbg[21], (unsigned long long)tacc[7]);
+    }
+    if (threadIdx.x == 0 && (blockIdx.x % 61) == 0) {
+        const int tb = st_iter > 1 ? 8 : 0;
+        for (int i = 0; i < 6; ++i) atomicAdd(&st->dbg[tb + i], (unsigned long long)tacc[i]);
+        atomicAdd(&st->dbg[tb + 6], (unsigned long long)tacc[6]);
+        atomicAdd(&st->dbg[tb + 7], 1ull);
+        atomicAdd(&st->dbg[16 + (st_iter > 1 ? 1 : 0)], (unsigned long long)tacc[7]);
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
 // Self k-NN of the indexed cloud (SurfaceNormalDataPointsFilter: every map point against the map, knn 5..32,
 // self match allowed).  The queries ARE the cell-sorted points, so all queries of a cell share one 3x3x3
 // neighbourhood: a workgroup takes SEG consecutive x-cells of one (y, z) row, stages the 9 x-runs that cover
@@ -2021,6 +2423,15 @@ static icpmi_status nnk_launch_t(icpmi_ctx* c, const float4* d_reading, int64_t 
             // loop mode: results in query order (the brute-force pass works in the caller's order: chains that may need it stay there)
             const int out_sorted = (c->nn_sorted_k && sorted && !needs_hard) ? 1 : 0;
             c->nn_out_sorted = out_sorted != 0;
+            // the loop's seeded launches from iteration ICPMI_NNK_WG_FROM on: nnk_wg_kernel (a negative value: nnk_ml_kernel everywhere)
+            static int wg_from = -2, wg_pre = -1;
+            if (wg_from == -2) { const char* e = getenv("ICPMI_NNK_WG_FROM"); wg_from = e ? atoi(e) : 2; }
+            if (wg_pre < 0) { const char* e = getenv("ICPMI_NNK_SEED_PRE"); wg_pre = e ? atoi(e) : 1; }
+            const bool use_wg = wg_from >= 0 && allow_self && c->nn_iter_hint >= wg_from && c->batch_cur <= 1;
+            if (use_wg)
+                hipLaunchKernelGGL((nnk_wg_kernel<(KMAX <= 8 ? KMAX : 8)>), dim3((int)(((n + 63) / 64 + 7) / 8 * 8)), dim3(256), 0, c->stream, q, qi,
+                                   (int)n, d_T, c->d_lvl_tab, c->levels.nlev, lc.k, lc.maxr2, d_sidx, d_d2, d_state, c->d_hard, out_sorted, wg_pre);
+            else
             hipLaunchKernelGGL((nnk_ml_kernel<G, (KMAX <= 8 ? KMAX : 8)>), dim3(grid), dim3(NN_BLOCK), 0, c->stream, q, qi, (int)n, d_T, c->d_lvl_tab,
                                c->levels.nlev, lc.k, lc.maxr2, allow_self, seeded, d_sidx, d_d2, d_state, c->d_hard, out_sorted);
             if (!std::isfinite(lc.max_dist) || (top.cell - top.slack) <= lc.max_dist) {
