@@ -24,7 +24,9 @@
 #define ICPMI_S2_COPIES 32
 #define ICPMI_S2_C0 4096                                        // word offsets inside d_selhist (legacy bins first)
 #define ICPMI_S2_F0 (ICPMI_S2_C0 + ICPMI_S2_COPIES * 256)
+#ifndef ICPMI_S2_FCOPIES
 #define ICPMI_S2_FCOPIES 1                                       // privatised copies of the level-0 FINE histogram
+#endif
 #define ICPMI_S2_C1 (ICPMI_S2_F0 + ICPMI_S2_FCOPIES * 65536)
 #define ICPMI_S2_F1 (ICPMI_S2_C1 + 256)
 #define ICPMI_SELHIST_WORDS (ICPMI_S2_F1 + 65536)

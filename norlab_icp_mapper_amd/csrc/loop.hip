@@ -180,40 +180,57 @@ __global__ __launch_bounds__(256) void sel2_hist0_kernel(const float* __restrict
     d2 += (size_t)blockIdx.y * (size_t)ba.qstride * k;
     hists += (size_t)blockIdx.y * ICPMI_SELHIST_WORDS;
     st += blockIdx.y;
-    constexpr int PF = 8;
+#ifndef ICPMI_H0_PF
+#define ICPMI_H0_PF 16
+#endif
+    constexpr int PF = ICPMI_H0_PF; // all of a thread's matches in flight before the first LDS atomic (4096 per workgroup: 16 per thread)
     const int64_t stride = (int64_t)gridDim.x * 256;
     const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
     float pv[PF];
 #pragma unroll
     for (int u = 0; u < PF; ++u) pv[u] = i0 + u * stride < count ? d2[i0 + u * stride] : INFINITY;
     if (st->done) return;
-    // Fine bins go through a direct-mapped LDS table first (slot = bin mod 1024: the occupied bins of
-    // one workgroup are a narrow band of neighbouring exponents/mantissas, so collisions are rare; a
-    // colliding bin falls through to a global atomic).  ~2000 elements per workgroup collapse to a few
-    // hundred global atomics.
+    // Fine bins (top 16 bits of d^2) are counted in LDS first, in a direct-mapped window of 4096 bins = 32 octaves that ends
+    // just above the largest value of the workgroup's FIRST batch of matches (the matches of a launch span a few octaves below
+    // the matcher's radius; whatever falls outside goes to memory directly): ONE LDS atomic per match -- r2 used a 1024-slot hash
+    // (compare-and-swap, then the count) plus the coarse bin, three dependent LDS atomics on addresses that most lanes of a
+    // wave share.  The coarse bins are summed from the window when it is flushed.
+    constexpr int WIN = 4096;
     __shared__ unsigned h[256];
-    __shared__ unsigned tkey[1024], tcnt[1024];
+    __shared__ unsigned win[WIN];
+    __shared__ unsigned s_top;
     h[threadIdx.x] = 0;
-    for (int i = threadIdx.x; i < 1024; i += 256) { tkey[i] = 0xffffffffu; tcnt[i] = 0; }
+    for (int i = threadIdx.x; i < WIN; i += 256) win[i] = 0;
+    if (threadIdx.x == 0) s_top = 0u;
     for (int64_t i = i0; i < 256 + 65536; i += stride) hists[ICPMI_S2_C1 + i] = 0;
     __syncthreads();
+    {
+        unsigned mx = 0;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) if (pv[u] != INFINITY && pv[u] > 0.f) mx = max(mx, __float_as_uint(pv[u]) >> 16);
+        for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off, 64));
+        if ((threadIdx.x & 63) == 0 && mx) atomicMax(&s_top, mx);
+    }
+    __syncthreads();
+    const unsigned top = s_top + 1u, lo = top > (unsigned)WIN ? top - (unsigned)WIN : 0u;
     unsigned* fine = hists + ICPMI_S2_F0 + (blockIdx.x % ICPMI_S2_FCOPIES) * 65536;
     auto add = [&](float v) {
         if (!(v != INFINITY && v > 0.f)) return;
         const unsigned bits = __float_as_uint(v);
-        atomicAdd(&h[bits >> 24], 1u);
-        const unsigned bin = bits >> 16, slot = bin & 1023u;
-        const unsigned old = atomicCAS(&tkey[slot], 0xffffffffu, bin);
-        if (old == 0xffffffffu || old == bin) atomicAdd(&tcnt[slot], 1u);
-        else atomicAdd(&fine[ICPMI_S2_FIDX(bin)], 1u);
+        const unsigned bin = bits >> 16, rel = bin - lo;
+        if (rel < (unsigned)WIN) atomicAdd(&win[rel], 1u);
+        else { atomicAdd(&h[bits >> 24], 1u); atomicAdd(&fine[ICPMI_S2_FIDX(bin)], 1u); }
     };
 #pragma unroll
     for (int u = 0; u < PF; ++u) add(pv[u]);
     for (int64_t i = i0 + PF * stride; i < count; i += stride) add(d2[i]);
     __syncthreads();
+    for (int i = threadIdx.x; i < WIN; i += 256) {
+        const unsigned cnt = win[i];
+        if (cnt) { const unsigned bin = lo + (unsigned)i; atomicAdd(&h[bin >> 8], cnt); atomicAdd(&fine[ICPMI_S2_FIDX(bin)], cnt); }
+    }
+    __syncthreads();
     if (h[threadIdx.x]) atomicAdd(&hists[ICPMI_S2_C0 + (blockIdx.x % ICPMI_S2_COPIES) * 256 + threadIdx.x], h[threadIdx.x]);
-    for (int i = threadIdx.x; i < 1024; i += 256)
-        if (tcnt[i]) atomicAdd(&fine[ICPMI_S2_FIDX(tkey[i])], tcnt[i]);
 }
 
 // scan level 0 (top 16 bits), build level 1 (low 16 bits) from the elements under the selected prefix

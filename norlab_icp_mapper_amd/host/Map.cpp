@@ -240,7 +240,10 @@ bool Map::residentPlan(const DataPoints& input, const DataPointsFilters& postFil
 {
     static const bool enabled = [] { const char* e = std::getenv("NIM_RESIDENT_MAP_UPDATE"); return !e || std::atoi(e) != 0; }();
     // (a GenericDescriptorOutlierFilter reads a descriptor of the host cloud handed to setMap: host path)
-    if (!enabled || !is3D || mapperModuleVec.empty() || icp.hasReferenceFilters() || !icp.genericDescriptorName().empty()) return false;
+    // (planar maps too, r3: the clouds keep z == 0 in the 4 x N layout and a planar pose maps z = 0 to z = 0 exactly, so the chain's
+    //  kernels see what the host-pointer operators see -- spherical coordinates with elevation asin(0 / r) = 0, the reference's
+    //  is3D == false branch of DynamicPointsMapperModule.cpp:156-172; normals through the planar eigen-solve, icpmi_config::is_2d)
+    if (!enabled || mapperModuleVec.empty() || icp.hasReferenceFilters() || !icp.genericDescriptorName().empty()) return false;
     prog = ResidentProgram{};
     auto adopt = [&](bool ok, const icpmi_map_op& op, const std::string& name) {
         if (!ok) return false;

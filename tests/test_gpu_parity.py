@@ -446,6 +446,41 @@ def test_dynamic_points_update_matches_oracle(amd, oracle, small_scene):
     assert np.array_equal(icp.dynamicPointsUpdate(to_sensor, scan[:0], mp, nrm, prob0), prob0)
 
 
+def test_dynamic_points_update_planar_matches_oracle(amd, oracle):
+    """The is3D == false branch (DynamicPointsMapperModule.cpp:156-172): elevation 0 for every point, azimuth atan2(y, x), radii
+    over the two axes.  Planar clouds keep z == 0 in the 4 x N layout, where the 3-D formulas give exactly that -- asin(0 / r) = 0,
+    sqrt(x^2 + y^2 + 0) -- so the device kernel and the oracle's restatement serve both cases; a dynamic object (scan points
+    pulled towards the sensor) must raise the probability of the wall points behind it, bit for bit as the oracle does."""
+    from test_oracle_ext import _planar_scene
+    mp, scan, T = _planar_scene(n_map=12000, n_scan=3000, seed=4)
+    icp = amd.ICPSequence(minimizer=0, is_2d=1)
+    nrm = icp.surfaceNormals(mp, knn=8)
+    assert np.all(nrm[:, 2] == 0)
+    pose = T.astype(np.float32)                                    # planar pose: the scan is given in this sensor frame
+    to_sensor = np.linalg.inv(pose.astype(np.float64)).astype(np.float32)
+    scan_map = icp.transform(pose, scan)
+    assert np.all(scan_map[:, 2] == 0)
+    rng = np.random.default_rng(3)
+    sensor = pose[:3, 3]
+    pull = rng.random(scan_map.shape[0]) < 0.25
+    scan_map[pull, :3] = sensor + (scan_map[pull, :3] - sensor) * 0.5
+    prob0 = rng.uniform(0.0, 1.0, mp.shape[0]).astype(np.float32)
+    for kw in (dict(beam_half_angle=0.01), dict(beam_half_angle=0.03, sensor_max_range=5.0), dict(threshold_dynamic=0.5, alpha=0.6, beta=0.9, epsilon_a=0.05, epsilon_d=0.1)):
+        got = icp.dynamicPointsUpdate(to_sensor, scan_map, mp, nrm, prob0, **kw)
+        ref = oracle.dynamic_points_update(to_sensor, scan_map, mp, nrm, prob0, nthreads=8, **kw)
+        assert (ref != prob0).sum() > 100
+        assert np.array_equal(got, ref), (np.flatnonzero(got != ref)[:10], kw)
+    # and through the resident chain in planar mode: the same update as one operator of icpmi_map_update_chain
+    icp.setMap(mp, nrm)
+    icp.setMapScalar(prob0)
+    dyn = ("dynamic_points", 0.6, 0.8, 0.99, 0.01, 0.01, 0.01, 200.0)
+    icp.mapUpdateChain(scan_map, [dyn], [], scan_scalar=np.full(scan_map.shape[0], 0.6, np.float32), scan_normals=icp.surfaceNormals(scan_map, knn=8),
+                       to_sensor=to_sensor)
+    ref = oracle.dynamic_points_update(to_sensor, scan_map, mp, nrm, prob0, nthreads=8)
+    got = icp.getMapScalar()
+    assert np.array_equal(got, ref)                                # (the module alone updates the map's descriptor: it adds no point)
+
+
 @pytest.mark.parametrize("normals_knn", [0, 7])
 def test_resident_map_update_equals_composed_path(amd, mid_scene, normals_knn):
     """icpmi_map_update_point_distance (keep mask vs the resident map, append, normals, rebuild -- all on the

@@ -304,6 +304,73 @@ def test_planar_mapping_harness(tmp_path):
         assert np.allclose(T[2, :3], [0, 0, 1], atol=1e-6) and np.allclose(T[:3, 2], [0, 0, 1], atol=1e-6)
     mp, mdesc = _read_vtk(os.path.join(tmp, "map.vtk"))
     assert np.all(mp[:, 2] == 0) and "normals" in mdesc and np.all(mdesc["normals"][:, 2] == 0)
+    # r3: planar maps update on the resident map too (Map::residentPlan no longer asks for is3D); the host path gives the same
+    # trajectory and the same map up to the rounding of the host path's trip through the sensor frame
+    assert "resident map updates: %d" % len(scans) in out.stdout, out.stdout[-400:]
+    os.replace(os.path.join(tmp, "map.vtk"), os.path.join(tmp, "resident_map.vtk"))
+    traj2 = os.path.join(tmp, "traj_host.vtk")
+    out2 = subprocess.run([os.path.join(PKG, "build_map_from_scans_and_trajectory"), tmp, cfg, traj2], capture_output=True, text=True,
+                          timeout=600, env=dict(os.environ, NIM_2D="1", NIM_RESIDENT_MAP_UPDATE="0"))
+    assert out2.returncode == 0 and "resident map updates: 0" in out2.stdout, out2.stderr + out2.stdout[-300:]
+    pos2, _ = _read_vtk(traj2)
+    assert np.abs(pos2 - pos).max() < 2e-4
+    hp, _ = _read_vtk(os.path.join(tmp, "map.vtk"))
+    assert np.all(hp[:, 2] == 0) and abs(hp.shape[0] - mp.shape[0]) <= max(5, mp.shape[0] // 500)
+
+
+@pytest.mark.gpu
+def test_planar_bundled_chain_resident_matches_host(tmp_path):
+    """The shipped module chain on a PLANAR map (DynamicPointsMapperModule.cpp:156-172 with is3D == false: elevation 0, azimuth
+    atan2(y, x), radii over the two axes; the quadtree of OctreeMapperModule; 2-D normals; the probability cut) as ONE resident
+    update per scan against the host path that calls the same operators through host pointers."""
+    from test_oracle_ext import _planar_scene
+    _build_host()
+    tmp = str(tmp_path)
+    os.makedirs(os.path.join(tmp, "scans"))
+    full, _, _ = _planar_scene(n_map=30000, n_scan=10, seed=77)
+    rng = np.random.default_rng(9)
+    rows = []
+    for s in range(4):
+        yaw, t = 0.03 * s, np.array([0.25 * s, -0.1 * s])
+        c, sn = math.cos(yaw), math.sin(yaw)
+        T = np.eye(4); T[:2, :2] = [[c, -sn], [sn, c]]; T[:2, 3] = t
+        idx = rng.permutation(full.shape[0])[:6000]
+        pts = full[idx, :2].astype(np.float64) + rng.normal(0, 0.004, (6000, 2))
+        if s >= 2:                                                    # something that was not there before: points in front of the wall
+            blob = rng.normal(0, 0.15, (300, 2)) + t + np.array([1.5, 0.5])
+            pts = np.concatenate([pts, blob])
+        local = (pts - t) @ T[:2, :2]
+        local = np.c_[local, np.zeros(len(local))].astype(np.float32)
+        rows.append([1700000000, 100000000 * s, *T[:3, 3], *_quat(T[:3, :3])])
+        _write_vtk(os.path.join(tmp, "scans", f"cloud_{s:03d}.vtk"), local)
+    with open(os.path.join(tmp, "trajectory.csv"), "w") as f:
+        f.write("header.stamp.sec,header.stamp.nanosec,header.frame_id,child_frame_id,pose.pose.position.x,pose.pose.position.y,"
+                "pose.pose.position.z,pose.pose.orientation.x,pose.pose.orientation.y,pose.pose.orientation.z,pose.pose.orientation.w,pose.covariance\n")
+        for r in rows:
+            f.write(f"{r[0]},{r[1]},map,base_link," + ",".join(repr(float(v)) for v in r[2:]) + ",[0. 0. 0.]\n")
+    cfg = os.path.join(tmp, "config.yaml")
+    open(cfg, "w").write(BUNDLED_LIKE_CONFIG.replace("zMin: -1", "zMin: -0.5").replace("maxSizeByNode: 0.15", "maxSizeByNode: 0.05"))
+    traj_out = os.path.join(tmp, "traj.vtk")
+    out = subprocess.run([os.path.join(PKG, "build_map_from_scans_and_trajectory"), tmp, cfg, traj_out], capture_output=True, text=True,
+                         timeout=600, env=dict(os.environ, NIM_2D="1"))
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert "resident map updates: 4" in out.stdout, out.stdout[-300:]
+    mp, mdesc = _read_vtk(os.path.join(tmp, "map.vtk"))
+    assert np.all(mp[:, 2] == 0) and {"normals", "probabilityDynamic"} <= set(mdesc) and np.all(mdesc["normals"][:, 2] == 0)
+    assert (mdesc["probabilityDynamic"] <= 0.65 + 1e-6).all() and mp.shape[0] > 1000
+    assert (mdesc["probabilityDynamic"] != np.float32(0.6)).mean() > 0.2          # the Bayesian update did run on the planar map
+    os.replace(os.path.join(tmp, "map.vtk"), os.path.join(tmp, "resident_map.vtk"))
+    out2 = subprocess.run([os.path.join(PKG, "build_map_from_scans_and_trajectory"), tmp, cfg, traj_out], capture_output=True, text=True,
+                          timeout=600, env=dict(os.environ, NIM_2D="1", NIM_RESIDENT_MAP_UPDATE="0"))
+    assert out2.returncode == 0 and "resident map updates: 0" in out2.stdout, out2.stderr + out2.stdout[-300:]
+    hp, hdesc = _read_vtk(os.path.join(tmp, "map.vtk"))
+    assert abs(hp.shape[0] - mp.shape[0]) <= max(3, mp.shape[0] // 200), (hp.shape, mp.shape)
+    if hp.shape[0] == mp.shape[0]:
+        same = np.all(np.abs(hp - mp) < 1e-5, axis=1)
+        assert same.mean() > 0.99
+        dots = np.abs(np.einsum("ij,ij->i", hdesc["normals"][same], mdesc["normals"][same]))
+        assert (dots > 1 - 1e-3).mean() > 0.99
+        assert np.abs(hdesc["probabilityDynamic"][same] - mdesc["probabilityDynamic"][same]).max() < 1e-4
 
 
 BUNDLED_LIKE_CONFIG = """
