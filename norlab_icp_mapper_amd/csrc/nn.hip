@@ -1476,13 +1476,23 @@ __global__ __launch_bounds__(NN_BLOCK) void nnk_ml_kernel(const float4* __restri
     bool decided = !active;
     int lev = 0;
     if (seeded && active && allow_self && st->iter > 0) {
-        // lane j < k re-evaluates previous match j under the current transform
-        if (sub < k) {
-            const int sp = out_sidx[(size_t)k * orig + sub];
-            if (sp >= 0) {
-                const float4 q = reinterpret_cast<const float4*>(((unsigned long long)ltab[2].w << 32) | ltab[2].z)[sp];
-                pk[0] = pack_key(sqdist3(p.x, p.y, p.z, q.x, q.y, q.z), __float_as_uint(q.w));
-                ps[0] = sp;
+        // lane j re-evaluates previous matches j, j + G, ... under the current transform
+        if (KMAX <= G) {
+            if (sub < k) {
+                const int sp = out_sidx[(size_t)k * orig + sub];
+                if (sp >= 0) {
+                    const float4 q = reinterpret_cast<const float4*>(((unsigned long long)ltab[2].w << 32) | ltab[2].z)[sp];
+                    pk[0] = pack_key(sqdist3(p.x, p.y, p.z, q.x, q.y, q.z), __float_as_uint(q.w));
+                    ps[0] = sp;
+                }
+            }
+        } else {
+            for (int j = sub; j < k; j += G) {
+                const int sp = out_sidx[(size_t)k * orig + j];
+                if (sp >= 0) {
+                    const float4 q = reinterpret_cast<const float4*>(((unsigned long long)ltab[2].w << 32) | ltab[2].z)[sp];
+                    offer(pack_key(sqdist3(p.x, p.y, p.z, q.x, q.y, q.z), __float_as_uint(q.w)), sp);
+                }
             }
         }
     }
@@ -1608,12 +1618,13 @@ __global__ __launch_bounds__(NN_BLOCK) void nnk_ml_kernel(const float4* __restri
     }
 
     if (active) {
-        // lane j writes result j (static select from the replicated merged list)
+        // lane j writes results j, j + G, ... (static select from the replicated merged list)
+        for (int jj = sub; jj < k; jj += G) {
         unsigned long long key = ~0ull;
         int sx = -1;
 #pragma unroll
-        for (int i = 0; i < KMAX; ++i) if (i == sub) { key = mk[i]; sx = ms[i]; }
-        if (sub < k) {
+        for (int i = 0; i < KMAX; ++i) if (i == jj) { key = mk[i]; sx = ms[i]; }
+        {
             float d2 = __uint_as_float((unsigned)(key >> 32));
             int bs = -1;
             if (key != ~0ull && d2 <= maxr2) {
@@ -1624,8 +1635,9 @@ __global__ __launch_bounds__(NN_BLOCK) void nnk_ml_kernel(const float4* __restri
                     bs = (int)reinterpret_cast<const unsigned*>(((unsigned long long)d.w << 32) | d.z)[pos];
                 }
             } else d2 = INFINITY;
-            out_sidx[(size_t)k * orig + sub] = bs;
-            out_d2[(size_t)k * orig + sub] = d2;
+            out_sidx[(size_t)k * orig + jj] = bs;
+            out_d2[(size_t)k * orig + jj] = d2;
+        }
         }
         if (sub == 0 && !decided) {
             const unsigned slot = atomicAdd(&st->hard_count, 1u);
@@ -1656,7 +1668,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nnk_ml_kernel(const float4* __restri
 #define NNK_WG_WAVES 5
 #endif
 template <int KMAX>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NNK_WG_WAVES))) void nnk_wg_kernel(const float4* __restrict__ queries, const int* __restrict__ qindex, int n,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KMAX <= 8 ? NNK_WG_WAVES : 3))) void nnk_wg_kernel(const float4* __restrict__ queries, const int* __restrict__ qindex, int n,
                                                      const float* __restrict__ Tptr, const uint4* __restrict__ ltab_g, int nlev,
                                                      int k, float maxr2, int* __restrict__ out_sidx, float* __restrict__ out_d2,
                                                      IcpState* __restrict__ st, unsigned* __restrict__ hard, int out_sorted, int seed_pre)
@@ -2408,7 +2420,8 @@ template <int KMAX>
 static icpmi_status nnk_launch_t(icpmi_ctx* c, const float4* d_reading, int64_t n, const float* d_T, const LoopCfg& lc,
                                  int allow_self, int* d_sidx, float* d_d2, IcpState* d_state)
 {
-    if (KMAX <= 8 && n > 0) {
+    if constexpr (KMAX <= 16) if (n > 0) {
+        constexpr int KM = KMAX; // (k <= 16: the cooperative kernels; r2 stopped at 8 and left knn 10 on the one-lane kernel, 5 x slower)
         static int use_ml = -1;
         if (use_ml < 0) { const char* e = getenv("ICPMI_NNK_ML"); use_ml = e ? atoi(e) : 1; }
         if (use_ml) {
@@ -2429,10 +2442,10 @@ static icpmi_status nnk_launch_t(icpmi_ctx* c, const float4* d_reading, int64_t 
             if (wg_pre < 0) { const char* e = getenv("ICPMI_NNK_SEED_PRE"); wg_pre = e ? atoi(e) : 1; }
             const bool use_wg = wg_from >= 0 && allow_self && c->nn_iter_hint >= wg_from && c->batch_cur <= 1;
             if (use_wg)
-                hipLaunchKernelGGL((nnk_wg_kernel<(KMAX <= 8 ? KMAX : 8)>), dim3((int)(((n + 63) / 64 + 7) / 8 * 8)), dim3(256), 0, c->stream, q, qi,
+                hipLaunchKernelGGL((nnk_wg_kernel<KM>), dim3((int)(((n + 63) / 64 + 7) / 8 * 8)), dim3(256), 0, c->stream, q, qi,
                                    (int)n, d_T, c->d_lvl_tab, c->levels.nlev, lc.k, lc.maxr2, d_sidx, d_d2, d_state, c->d_hard, out_sorted, wg_pre);
             else
-            hipLaunchKernelGGL((nnk_ml_kernel<G, (KMAX <= 8 ? KMAX : 8)>), dim3(grid), dim3(NN_BLOCK), 0, c->stream, q, qi, (int)n, d_T, c->d_lvl_tab,
+            hipLaunchKernelGGL((nnk_ml_kernel<G, KM>), dim3(grid), dim3(NN_BLOCK), 0, c->stream, q, qi, (int)n, d_T, c->d_lvl_tab,
                                c->levels.nlev, lc.k, lc.maxr2, allow_self, seeded, d_sidx, d_d2, d_state, c->d_hard, out_sorted);
             if (!std::isfinite(lc.max_dist) || (top.cell - top.slack) <= lc.max_dist) {
                 hipLaunchKernelGGL(nnk_hard_kernel<KMAX>, dim3(512), dim3(NN_BLOCK), 0, c->stream, d_reading, d_T, c->d_map_sorted,

@@ -39,7 +39,7 @@ def run_variant(frm, k, m, n, graph):
     return json.loads(line[len("RESULT "):])
 
 
-@pytest.mark.parametrize("k,m,n,graph", [(6, 400_000, 50_000, 0), (6, 400_000, 50_000, 1), (3, 150_000, 20_011, 0), (8, 60_000, 5_000, 0)])
+@pytest.mark.parametrize("k,m,n,graph", [(6, 400_000, 50_000, 0), (6, 400_000, 50_000, 1), (3, 150_000, 20_011, 0), (8, 60_000, 5_000, 0), (10, 200_000, 20_000, 0), (16, 100_000, 10_000, 1)])
 def test_wg_matcher_lands_on_the_same_bits(k, m, n, graph):
     ref = run_variant(-1, k, m, n, graph)
     assert ref[0]["it"] > 3, "the registration must run seeded iterations"

@@ -38,7 +38,7 @@ def test_transform_bit_exact(amd, oracle, small_scene):
         icp.transform(bad, small_scene["scan"])
 
 
-@pytest.mark.parametrize("k,max_dist", [(1, 2.0), (1, math.inf), (1, 0.05), (6, 2.0), (10, math.inf)])
+@pytest.mark.parametrize("k,max_dist", [(1, 2.0), (1, math.inf), (1, 0.05), (6, 2.0), (10, math.inf), (12, 2.0), (16, math.inf), (16, 0.1), (20, 2.0)])
 def test_knn_matches_oracle_exactly(amd, oracle, small_scene, k, max_dist):
     icp = amd.ICPSequence(minimizer=0, knn=min(k, 32))
     assert icp.setMap(small_scene["map"])
@@ -97,7 +97,7 @@ def test_knn_degenerate_maps(amd, oracle, shape):
         m = cloud(np.r_[rng.normal(0, 0.05, (150, 3)), rng.normal(0, 0.05, (150, 3)) + 40.0])
     q = cloud(m[rng.integers(0, m.shape[0], 64), :3] + rng.normal(0, 0.3, (64, 3)))
     q = np.concatenate([q, m[: min(8, m.shape[0])]])  # exact hits (d2 = 0)
-    for k in (1, 3, 6):
+    for k in (1, 3, 6, 10, 16):               # (9..16: the cooperative kernels since r3; k may exceed the map)
         for md in (math.inf, 0.5):
             icp = amd.ICPSequence(minimizer=0, knn=k, max_dist=md if math.isfinite(md) else 2.0)
             assert icp.setMap(m)
