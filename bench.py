@@ -88,7 +88,9 @@ def nn_roofline(pkg, dev, chain, d_map, d_nrm, d_scan, n_scan, m_map, traffic_ke
             traffic = None
     del prof
     nn1 = "nn1_ml_kernel" if os.environ.get("ICPMI_NN_WQ", "1") == "0" else ("nn1_wq_kernel" if os.environ.get("ICPMI_NN_WG", "4") == "0" else "nn1_wg_kernel")
-    return {"bound": "hbm", "kernel": nn1 if kq == 1 else "nnk_ml_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+    # knn > 1: nnk_ml_kernel serves iterations 0 and 1, nnk_wg_kernel the seeded ones (18 of a step's 20 launches); the average is over all
+    nnk = "nnk_ml_kernel" if os.environ.get("ICPMI_NNK_WG_FROM", "2").startswith("-") else "nnk_wg_kernel (+ nnk_ml_kernel, iterations 0-1)"
+    return {"bound": "hbm", "kernel": nn1 if kq == 1 else nnk, "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
             "avg_launch_us": nn_avg_ms * 1e3, "launches_timed": nn_cnt}
 

@@ -41,7 +41,7 @@ for wl in sorted(os.listdir(root)):
     for p in sorted(os.listdir(os.path.join(root, wl))):
         for k, v in counters(os.path.join(root, wl, p)).items():
             merged[k].update(v)
-    keep = {k: v for k, v in merged.items() if any(t in k for t in ("nn1_", "nnk_ml", "accumulate", "solve", "sel2"))}
+    keep = {k: v for k, v in merged.items() if any(t in k for t in ("nn1_", "nnk_ml", "nnk_wg", "accumulate", "solve", "sel2"))}
     for k, v in keep.items():
         if "FETCH_SIZE" in v or "WRITE_SIZE" in v:
             v["hbm_bytes_calibrated"] = v.get("FETCH_SIZE", 0) * 1024 * f_read + v.get("WRITE_SIZE", 0) * 1024 * f_w4

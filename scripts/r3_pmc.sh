@@ -25,16 +25,22 @@ import json
 d = json.load(open("gpurun_out/r3pmc/summary.json"))
 out = {"source": "profiles/r3_pmc_summary.json (scripts/r3_pmc.sh: rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE, TCC, TCP and SQ sets, each in its own pass, no trace domains; `python bench.py --no-cpu --no-extras --steps 3 --warmup 1` per workload)",
        "calibration": d.get("factors_used"),
-       "per_launch": "average over the 20 NN launches of a registration (nn1_wg_kernel for k = 1, nnk_ml_kernel for knn 6); the bench's roofline.avg_launch_us is the same average",
+       "per_launch": "average over the 20 NN launches of a registration (nn1_wg_kernel for k = 1; knn 6: nnk_wg_kernel, 18 of the 20 launches -- the two nnk_ml_kernel launches of iterations 0 and 1 are NOT in this figure); the bench's roofline.avg_launch_us is the same average",
        "l2_hit_rate": {}, "wave": {}}
 keys = {"p2p": "hbm_bytes_per_launch", "p2plane": "hbm_bytes_per_launch_p2plane", "knn6": "hbm_bytes_per_launch_knn6", "map10M": "hbm_bytes_per_launch_10M", "batch8": "hbm_bytes_per_launch_batch8"}
 for wl, key in keys.items():
     ks = d.get(wl, {})
-    nn = [(k, v) for k, v in ks.items() if k.startswith("nn1_") or k.startswith("nnk_ml")]
+    nn = [(k, v) for k, v in ks.items() if k.startswith("nn1_") or k.startswith("nnk_ml") or k.startswith("nnk_wg")]
     if not nn: continue
     # the dominant NN instantiation of the workload: the one with the most waves x launches is what the average is made of
     k, v = max(nn, key=lambda kv: kv[1].get("SQ_WAVES", 0))
     if "hbm_bytes_calibrated" in v: out[key] = int(v["hbm_bytes_calibrated"])
+    if wl == "knn6": # the bench's average is over the step's 20 launches: 2 x nnk_ml_kernel (iterations 0 and 1) + 18 x nnk_wg_kernel
+        wg = [v2 for k2, v2 in nn if k2.startswith("nnk_wg") and "hbm_bytes_calibrated" in v2]
+        ml = [v2 for k2, v2 in nn if k2.startswith("nnk_ml") and "hbm_bytes_calibrated" in v2]
+        if wg and ml:
+            out[key] = int((18 * wg[0]["hbm_bytes_calibrated"] + 2 * ml[0]["hbm_bytes_calibrated"]) / 20)
+            out["knn6_split"] = {"nnk_wg_kernel": int(wg[0]["hbm_bytes_calibrated"]), "nnk_ml_kernel": int(ml[0]["hbm_bytes_calibrated"]), "weights": [18, 2]}
     if "l2_hit_rate" in v: out["l2_hit_rate"][wl] = round(v["l2_hit_rate"], 3)
     out["wave"][wl] = {"kernel": k, "waves": v.get("SQ_WAVES"), "lifetime_quad_cycles": round(v.get("wave_lifetime_quad_cycles", 0)),
                        "wait_any_frac": round(v.get("wait_any_frac", 0), 3),
