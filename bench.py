@@ -179,6 +179,12 @@ def main():
     if args.dry_launch:
         return dry_launch(args)
 
+    # stdout carries ONE JSON line: libraries that write banners to fd 1 (RCCL prints its version block at the first communicator
+    # init) are sent to stderr for the length of the run, the line goes to the saved descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -531,7 +537,8 @@ def main():
                     out["pose_err_vs_libpointmatcher"] = {"m": pt, "rad": pr}
                 except Exception as e:
                     out["pose_err_vs_libpointmatcher"] = {"error": repr(e)}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if use_pg:
         if merge_hung:
             sys.stdout.flush()
