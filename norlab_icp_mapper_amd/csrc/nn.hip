@@ -1475,7 +1475,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nnk_ml_kernel(const float4* __restri
 
     bool decided = !active;
     int lev = 0;
-    if (seeded && active && allow_self && st->iter > 0) {
+    if ((seeded & 1) && active && allow_self && st->iter > 0) {
         // lane j re-evaluates previous matches j, j + G, ... under the current transform
         if (KMAX <= G) {
             if (sub < k) {
@@ -1496,7 +1496,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nnk_ml_kernel(const float4* __restri
             }
         }
     }
-    if (seeded) {
+    if (seeded & 1) {
         merge();
         if (bound != ~0ull) { // first level whose block contains the ball of the k-th seed
             const float ub = sqrtf(__uint_as_float((unsigned)(bound >> 32))) * 1.000001f;
@@ -1516,6 +1516,11 @@ __global__ __launch_bounds__(NN_BLOCK) void nnk_ml_kernel(const float4* __restri
     // A query that holds no bound yet first scans only the x-row through its own cell (about 1/9 of
     // the block); if that yields k candidates the same level is then searched with their bound.
     bool rowonly = bound == ~0ull;
+    // Seeds too wide for level 0 (iteration 1: the first solve moved the reading a long way): the same own-row pass at level 0
+    // first, pruned by the seed bound -- the k-th of the row is usually far tighter, and the coarse levels, whose blocks hold 8 / 64
+    // times the candidates, are then rarely needed (r3: 172 -> see DESIGN 11.6; without this the seeded launch was SLOWER than the
+    // unseeded one)
+    if ((seeded & 2) && lev > 0) { lev = 0; rowonly = true; }
     while (lev < nlev && !decided) {
         GridParams g;
         const float4* __restrict__ map;
@@ -2429,7 +2434,9 @@ static icpmi_status nnk_launch_t(icpmi_ctx* c, const float4* d_reading, int64_t 
             const bool sorted = c->qsorted_n == n && c->qsorted_src == d_reading;
             const float4* q = sorted ? c->d_qsorted : d_reading;
             const int* qi = sorted ? c->d_qindex : nullptr;
-            const int seeded = (c->nn_iter_hint > 0 && allow_self) ? 1 : 0;
+            static int ml_pre = -1; // bit 1 of `seeded`: wide seeds start with the own-row pass at level 0 (nnk_ml_kernel)
+            if (ml_pre < 0) { const char* e = getenv("ICPMI_NNK_ML_SEED_PRE"); ml_pre = e ? atoi(e) : 1; }
+            const int seeded = (c->nn_iter_hint > 0 && allow_self) ? (1 | (ml_pre ? 2 : 0)) : 0;
             const int grid = (int)(((n * G + NN_BLOCK - 1) / NN_BLOCK + 7) / 8 * 8);
             const GridParams& top = c->levels.g[c->levels.nlev - 1];
             const bool needs_hard = !std::isfinite(lc.max_dist) || (top.cell - top.slack) <= lc.max_dist;
