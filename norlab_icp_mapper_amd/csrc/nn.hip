@@ -1518,8 +1518,8 @@ __global__ __launch_bounds__(NN_BLOCK) void nnk_ml_kernel(const float4* __restri
     bool rowonly = bound == ~0ull;
     // Seeds too wide for level 0 (iteration 1: the first solve moved the reading a long way): the same own-row pass at level 0
     // first, pruned by the seed bound -- the k-th of the row is usually far tighter, and the coarse levels, whose blocks hold 8 / 64
-    // times the candidates, are then rarely needed (r3: 172 -> see DESIGN 11.6; without this the seeded launch was SLOWER than the
-    // unseeded one)
+    // times the candidates, are then rarely needed (r3, knn 6: iteration 1 172 -> 75 us; without this the seeded launch was SLOWER than
+    // the unseeded one, 115 us)
     if ((seeded & 2) && lev > 0) { lev = 0; rowonly = true; }
     while (lev < nlev && !decided) {
         GridParams g;
@@ -1664,8 +1664,8 @@ __global__ __launch_bounds__(NN_BLOCK) void nnk_ml_kernel(const float4* __restri
 // repeated -- of the candidates under the old bound at least CAPQ - k lie above the new one, so this terminates.  Keys, the
 // exactness rule per level and the output are those of nnk_ml_kernel: the same k points in the same order.
 // Measured (r3, knn 6, 100 k queries, 1 M points): steady launches 37.3 -> 25 us.  NOT for wide bounds: a launch whose seeds
-// moved far (iteration 1) overflows the lists and repeats passes (172 us here, as nnk_ml_kernel), the unseeded launch takes
-// 270 us against 115 us -- the launcher keeps nnk_ml_kernel for iterations 0 and 1.  Level 0 of the fused quantile selection
+// moved far (iteration 1) overflows the lists and repeats passes (172 us here; nnk_ml_kernel with its own-row pass first: 75 us),
+// the unseeded launch takes 270 us against 115 us -- the launcher keeps nnk_ml_kernel for iterations 0 and 1.  Level 0 of the fused quantile selection
 // from this kernel's tail (k atomics per query on the fine bins) made a launch 55 us; the stand-alone builder (12.5 us), which
 // combines 4096 matches in LDS before it touches memory, stays.
 // ------------------------------------------------------------------------------------------------
