@@ -105,9 +105,10 @@ int main(int argc, char** argv)
                 std::printf("setMap: %zu points handed back after scan %zu\n", whole.getNbPoints(), i + 1);
             }
             const Mat4 p = mapper.getPose();
-            std::printf("scan %zu/%zu  %zu pts  pose %.4f %.4f %.4f  iterations %d  overlap %.3f  local map %zu\n", i + 1, scans.size(),
-                        cloud.getNbPoints(), p(0, 3), p(1, 3), p(2, 3), mapper.lastIcpStats().iterations,
-                        mapper.lastIcpStats().weighted_point_used_ratio, mapper.localMapSize());
+            std::printf("scan %zu/%zu  %zu pts  pose %.4f %.4f %.4f  iterations %d  overlap %.3f  local map %zu  map_version %ld  update %d\n", i + 1,
+                        scans.size(), cloud.getNbPoints(), p(0, 3), p(1, 3), p(2, 3), mapper.lastIcpStats().iterations,
+                        mapper.lastIcpStats().weighted_point_used_ratio, mapper.localMapSize(), mapper.lastRegistrationMapVersion(),
+                        mapper.lastScanStartedMapUpdate() ? 1 : 0);
         }
         const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         DataPoints map = mapper.getMap();

@@ -371,6 +371,7 @@ bool Map::tryResidentUpdate(const DataPoints& input, const Mat4& pose, const Dat
         try {
             icp.mapUpdateChain(&input, Mat4::identity(), prog.scalarName, input, pose, prog.ops, prog.nModules, src, prefix, m,
                                hostDescriptorsFollow(input, prog, first));
+        ++icpMapVersions;
         } catch (...) { dropLocalCloudAfterFailedUpdate(); throw; }
     }
     adoptResidentResult(input, prog, src, prefix, m, first);
@@ -401,6 +402,7 @@ void Map::updateLocalPointCloudStaged(const DataPoints& inputDescriptors, const 
         try {
             icp.mapUpdateChain(nullptr, correction, prog.scalarName, inputDescriptors, pose, prog.ops, prog.nModules, src, prefix, m,
                                hostDescriptorsFollow(inputDescriptors, prog, first));
+        ++icpMapVersions;
         } catch (...) { dropLocalCloudAfterFailedUpdate(); throw; }
     }
     adoptResidentResult(inputDescriptors, prog, src, prefix, m, first);
@@ -427,6 +429,7 @@ void Map::updateLocalPointCloud(DataPoints input, Mat4 pose, DataPointsFilters p
     {
         std::lock_guard<std::mutex> gi(icpMapLock);
         icp.setMap(localPointCloud);
+        ++icpMapVersions;
     }
     localPointCloudEmpty.store(localPointCloud.getNbPoints() == 0);
     newLocalPointCloudAvailable = true;

@@ -73,6 +73,10 @@ public:
     void setSensorMaxRange(float r) { sensorMaxRange = r; }
     float getSensorMaxRange() const { return sensorMaxRange; }
     long residentUpdateCount() const { return residentUpdates.load(); } // map updates that ran on the resident map
+    // how many map UPDATES the registration map has taken (bumped under icpMapLock by updateLocalPointCloud{,Staged}; cell paging
+    // and setGlobalPointCloud hand the map over too but are not counted): a registration that reads it under the same lock knows
+    // which map it ran against (free-running online mode, tests)
+    long icpMapVersion() const { return icpMapVersions.load(); }
 
     // grid arithmetic, public for the unit tests (Map.cpp:130-138,232-235,462-480)
     static int toGridCoordinate(float world) { return (int)std::floor(world / CELL_SIZE); }
@@ -117,6 +121,7 @@ private:
     std::string residentScalar;        // ... and this scalar descriptor (empty: none)
     int64_t residentCount = 0;         // ... and this many points
     std::atomic<long> residentUpdates{0};
+    std::atomic<long> icpMapVersions{0};
 
     float sensorMaxRange = DEFAULT_SENSOR_MAX_RANGE;
     bool is3D, isOnline;

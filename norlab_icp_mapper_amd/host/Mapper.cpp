@@ -1,5 +1,6 @@
 // Mapper.cpp -- see Mapper.h.
 #include "Mapper.h"
+#include <thread>
 
 #include <algorithm>
 #include <cmath>
@@ -180,8 +181,10 @@ void Mapper::processInput(const DataPoints& filteredInputInSensorFrame, const Ma
     if (!isOnline && !icp.chainNeedsReadingNormals() && !icp.hasReadingFilters() && map.canStageScan(filteredInputInSensorFrame, mapPostFilters)) {
         const bool bootstrap = map.isLocalPointCloudEmpty();
         Mat4 correction;
+        lastScanGrewMap = false;
         {
             std::lock_guard<std::mutex> g(icpMapLock);
+            lastSeenMapVersion = map.icpMapVersion();
             correction = icp.registerWithPrior(filteredInputInSensorFrame, estimatedPose); // identity while there is no map
         }
         const Mat4 correctedPose = bootstrap ? estimatedPose : correction * estimatedPose;
@@ -189,6 +192,7 @@ void Mapper::processInput(const DataPoints& filteredInputInSensorFrame, const Ma
         if (bootstrap || mapUpdateIsDue(timeStamp, correctedPose, icp.errorMinimizer->getOverlap())) {
             lastTimeMapWasUpdated = timeStamp;
             lastPoseWhereMapWasUpdated = correctedPose;
+            lastScanGrewMap = true;
             if (map.canStageScan(filteredInputInSensorFrame, mapPostFilters))
                 map.updateLocalPointCloudStaged(filteredInputInSensorFrame, bootstrap ? Mat4::identity() : correction, correctedPose, mapPostFilters);
             else { // paging in updatePose changed the picture (e.g. the local cloud was emptied): the host path
@@ -206,15 +210,19 @@ void Mapper::processInput(const DataPoints& filteredInputInSensorFrame, const Ma
     DataPoints scanInMap = transformation.compute(filteredInputInSensorFrame, estimatedPose);
     const bool bootstrap = map.isLocalPointCloudEmpty(); // nothing to register against: the prior is the pose
     Mat4 correction = Mat4::identity();
+    lastScanGrewMap = false;
     if (!bootstrap) {
         std::lock_guard<std::mutex> g(icpMapLock);
+        lastSeenMapVersion = map.icpMapVersion();
         correction = icp(scanInMap);
     }
     const Mat4 correctedPose = bootstrap ? estimatedPose : correction * estimatedPose;
     map.updatePose(correctedPose);
-    if (bootstrap) growMap(scanInMap, correctedPose, timeStamp);
-    else if (mapUpdateIsDue(timeStamp, correctedPose, icp.errorMinimizer->getOverlap()))
+    if (bootstrap) { growMap(scanInMap, correctedPose, timeStamp); lastScanGrewMap = true; }
+    else if (mapUpdateIsDue(timeStamp, correctedPose, icp.errorMinimizer->getOverlap())) {
         growMap(transformation.compute(scanInMap, correction), correctedPose, timeStamp);
+        lastScanGrewMap = true;
+    }
 
     // surface an exception of a finished asynchronous update here, like the reference's future.get()
     if (mapUpdateFuture.valid() && mapUpdateFuture.wait_for(std::chrono::milliseconds(1)) == std::future_status::ready) mapUpdateFuture.get();
@@ -242,7 +250,13 @@ void Mapper::growMap(const DataPoints& inputInMapFrame, const Mat4& poseNow, con
     lastPoseWhereMapWasUpdated = poseNow;
     const bool inBackground = isOnline && !map.isLocalPointCloudEmpty(); // the very first map is built synchronously
     if (!inBackground) { map.updateLocalPointCloud(inputInMapFrame, poseNow, mapPostFilters); return; }
-    mapUpdateFuture = std::async(std::launch::async, &Map::updateLocalPointCloud, &map, inputInMapFrame, poseNow, mapPostFilters);
+    // NIM_TEST_UPDATE_DELAY_MS (tests): the background update starts late, so that the next scans find it in flight -- they are
+    // registered against the older map and start no update of their own (Mapper.cpp:257-260)
+    static const int delayMs = [] { const char* e = std::getenv("NIM_TEST_UPDATE_DELAY_MS"); return e ? std::atoi(e) : 0; }();
+    mapUpdateFuture = std::async(std::launch::async, [this, inputInMapFrame, poseNow] {
+        if (delayMs > 0) std::this_thread::sleep_for(std::chrono::milliseconds(delayMs));
+        map.updateLocalPointCloud(inputInMapFrame, poseNow, mapPostFilters);
+    });
 }
 
 void Mapper::setMap(const DataPoints& newMap)

@@ -69,6 +69,10 @@ public:
     void loadYamlConfig(const std::string& configFilePath);
     void loadYamlConfigFromString(const std::string& text);
     const icpmi_stats& lastIcpStats() const { return icp.stats(); }
+    // the last processInput: version of the registration map it ran against (Map::icpMapVersion, read under the ICP lock) and
+    // whether it started a map update -- what a replay needs to reproduce a free-running online run scan by scan
+    long lastRegistrationMapVersion() const { return lastSeenMapVersion; }
+    bool lastScanStartedMapUpdate() const { return lastScanGrewMap; }
 
 private:
     void fillRegistrar();
@@ -82,6 +86,8 @@ private:
     DataPointsFilters inputFilters, mapPostFilters;
     UpdatePolicy updatePolicy;
     bool is3D, isOnline;
+    long lastSeenMapVersion = 0;
+    bool lastScanGrewMap = false;
     std::atomic_bool isMapping;
     Map map;
     Mat4 pose = Mat4::identity();

@@ -214,12 +214,54 @@ def test_example_harness_matches_python_replay(tmp_path):
     # i - 2 -- every pose must still be the registration result against one of those maps, i.e. stay at the ground truth
     traj4 = os.path.join(tmp, "traj_online_free.vtk")
     out4 = subprocess.run([os.path.join(PKG, "build_map_from_scans_and_trajectory"), tmp, cfg, traj4], capture_output=True, text=True,
-                          timeout=600, env=dict(os.environ, NIM_ONLINE="1"))
+                          timeout=600, env=dict(os.environ, NIM_ONLINE="1", NIM_TEST_UPDATE_DELAY_MS="25"))
     assert out4.returncode == 0, out4.stderr + out4.stdout
-    pos4, _ = _read_vtk(traj4)
+    pos4, desc4 = _read_vtk(traj4)
     assert pos4.shape == pos.shape
     for i, t in enumerate(truth):
         assert np.linalg.norm(pos4[i] - t[:3, 3]) < 0.05, (i, pos4[i], t[:3, 3])
+    # r3: ... and exactly that, scan by scan.  The harness prints which version of the registration map every scan ran against
+    # (Map::icpMapVersion, read under the ICP lock) and whether it started an update (a scan that finds one in flight does not,
+    # Mapper.cpp:257-260); replaying THAT schedule through the C ABI must give the free-running poses to rounding.
+    import re
+    sched = [(int(m.group(1)), int(m.group(2))) for m in re.finditer(r"map_version (\d+)  update (\d)", out4.stdout)]
+    assert len(sched) == len(scans) and sched[0][1] == 1
+    assert sum(u for _, u in sched) >= 2
+    started_before = np.cumsum([0] + [u for _, u in sched])[:-1]
+    # (the background update is held back 25 ms: at least one scan must have run against an older map than the newest started)
+    assert any(v < b for (v, _), b in zip(sched[1:], started_before[1:])) or any(u == 0 for _, u in sched[1:]), sched
+
+    def build_version(map_pts, pose):
+        inv = np.linalg.inv(pose.astype(np.float64)).astype(np.float32)
+        sensor = icp.transform(inv, map_pts)
+        normals_s = icp.surfaceNormals(sensor, knn=10)
+        back, normals = icp.transform(pose, sensor, normals_s)
+        return back, normals
+
+    versions = []
+    for i, (s_, prior) in enumerate(zip(scans, priors)):
+        cloud = h4(s_)
+        cloud = cloud[np.linalg.norm(cloud[:, :3], axis=1) < 100.0]
+        inp = icp.transform(prior, cloud)
+        seen, started = sched[i]
+        if i == 0:
+            corrected = prior
+            versions.append(build_version(inp, corrected))
+        else:
+            assert 1 <= seen <= len(versions), (i, seen, len(versions))     # only updates started by earlier scans can have landed
+            icp.setMap(*versions[seen - 1])
+            corr = icp(inp)
+            corrected = (corr.astype(np.float32) @ prior).astype(np.float32)
+            if started:                                                      # no update was in flight: it builds on the newest map
+                base = versions[-1][0]
+                moved = icp.transform(corr, inp)
+                keep = icp.pointDistanceKeep(base, moved, 0.15)
+                versions.append(build_version(np.concatenate([base, moved[keep]], 0), corrected))
+        T4 = np.eye(4, dtype=np.float32)
+        T4[:3, 0], T4[:3, 1], T4[:3, 2], T4[:3, 3] = desc4["orientationX"][i], desc4["orientationY"][i], desc4["orientationZ"][i], pos4[i]
+        dt, dr = amd.synth.pose_error(T4, corrected)
+        assert dt < 2e-4 and dr < 2e-4, (i, sched, dt, dr)
+    assert len(versions) == sum(u for _, u in sched)
 
 
 @pytest.mark.gpu
