@@ -18,7 +18,7 @@ for case in range(cases):
     rng = np.random.default_rng([seed, case])  # one stream per case: `only` replays exactly the case a full run reported
     m = int(rng.choice([1, 7, 300, 5_000, 60_000, 400_000]))
     n = int(rng.choice([1, 5, 257, 4_000, 60_000]))
-    k = int(rng.choice([1, 1, 1, 3, 6, 10]))
+    k = int(rng.choice([1, 1, 1, 3, 6, 10, 8, 16, 12]))   # (r3: the cooperative kernels serve k <= 16)
     minimizer = int(rng.choice([1, 2, 2]))
     # (type, param[, iparam, param2, param3]): 6 GenericDescriptor, 7 Robust (fct | scale << 4 | dist << 8), 8 VarTrimmedDist
     rob = lambda fct, tun, sc=0, nb=0, dist=0: (7, tun, fct | (sc << 4) | (dist << 8), float(nb))
