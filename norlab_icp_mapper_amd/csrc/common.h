@@ -393,12 +393,74 @@ __device__ __forceinline__ unsigned long long pack_key(float d2, unsigned id)
     return ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)id;
 }
 
+__device__ inline void quat_from_T(const float* T, double* q)
+{
+    const double m00 = T[0], m11 = T[5], m22 = T[10];
+    double t = m00 + m11 + m22;
+    if (t > 0) {
+        t = sqrt(t + 1.0);
+        q[0] = 0.5 * t; t = 0.5 / t;
+        q[1] = ((double)T[4 * 1 + 2] - (double)T[4 * 2 + 1]) * t;
+        q[2] = ((double)T[4 * 2 + 0] - (double)T[4 * 0 + 2]) * t;
+        q[3] = ((double)T[4 * 0 + 1] - (double)T[4 * 1 + 0]) * t;
+    } else {
+        int i = 0;
+        if (m11 > m00) i = 1;
+        if (m22 > (i == 0 ? m00 : m11)) i = 2;
+        const int j = (i + 1) % 3, kk = (j + 1) % 3;
+        auto M = [&](int r, int c) { return (double)T[4 * c + r]; };
+        t = sqrt(M(i, i) - M(j, j) - M(kk, kk) + 1.0);
+        double v[3];
+        v[i] = 0.5 * t; t = 0.5 / t;
+        q[0] = (M(kk, j) - M(j, kk)) * t;
+        v[j] = (M(j, i) + M(i, j)) * t;
+        v[kk] = (M(kk, i) + M(i, kk)) * t;
+        q[1] = v[0]; q[2] = v[1]; q[3] = v[2];
+    }
+}
+
+
+// start of a registration: the loop state of one reading (init_state_kernel; the last kernel of the query sort when the head is fused)
+__device__ inline void init_state_dev(IcpState* st, const float* T0, unsigned seq, unsigned* progress, const unsigned* seq_src)
+{
+    // seq_src: the sequence number is read from host-mapped memory at RUN time -- a captured graph must not freeze the number of the
+    // registration it was captured for (the host matches the progress word against the number of the registration it is waiting on)
+    if (seq_src) seq = __hip_atomic_load(seq_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    st->seq = seq;
+    if (progress) __hip_atomic_store(progress, (seq & 0x7ffffu) << 12, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int i = 0; i < 16; ++i) st->T_iter[i] = T0 ? T0[i] : ((i % 5 == 0) ? 1.f : 0.f);
+    st->iter = 0; st->done = 0; st->error = 0; st->stop_reason = 0; st->counter = 0;
+    quat_from_T(st->T_iter, st->hq);
+    for (int r = 0; r < 3; ++r) st->ht[r] = st->T_iter[12 + r];
+    for (int r = 0; r < 4; ++r) st->init_q[r] = st->hq[r];
+    st->hist_n = 1;
+    st->sel_prefix = 0; st->sel_rank = 0; st->n_valid = 0;
+    for (int f = 0; f < ICPMI_MAX_OUTLIER; ++f) st->limits[f] = -1.f;
+    st->robust_med = 0.f; st->robust_scale = 1.f; st->vt_valid = 0; st->vt_ratio = -1.f;
+    st->pairs = 0; st->wsum = 0; st->hard_count = 0; st->hard_total = 0; st->ticket = 0;
+    for (int i = 0; i < 24; ++i) st->dbg[i] = 0;
+}
+
+// The head of a registration folded into the kernels of the query sort (r3: 8 graph nodes -> 3): the first kernel centres the raw
+// readings (Mapper.cpp:213's T_refMean_dataIn) while it computes their tile keys, the last one initialises the loop state and clears
+// the selection histograms while it scatters.
+struct SortHead {
+    BatchSrc raw;                 // the readings as handed in; centred into the sort's input array
+    float mean[3];
+    IcpState* st = nullptr;       // loop state(s) to initialise (one per reading), or nullptr
+    unsigned seq = 0;
+    unsigned* progress = nullptr;
+    const unsigned* seq_src = nullptr;
+    unsigned* selhist = nullptr;  // ICPMI_SELHIST_WORDS words per reading to clear, or nullptr
+};
+
 // ---- cross-TU host entry points ---------------------------------------------------------------
 icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float* d_normals3);
 icpmi_status device_exclusive_scan(icpmi_ctx* c, unsigned* data, int n, unsigned total);
 icpmi_status sort_queries(icpmi_ctx* c, const float4* d_pts, int64_t n);
 icpmi_status sort_queries_reserve(icpmi_ctx* c, int64_t n, int nscan = 1);
-icpmi_status sort_queries_batch(icpmi_ctx* c, const float4* d_pts, const BatchArgs& ba); // slices of d_pts -> slices of d_qsorted / d_qindex
+icpmi_status sort_queries_batch(icpmi_ctx* c, const float4* d_pts, const BatchArgs& ba, const SortHead* head = nullptr); // slices of d_pts -> slices of d_qsorted / d_qindex
+                                                                                 // (head: d_pts is WRITTEN first, from head->raw minus the mean)
 icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, const float* d_T, const LoopCfg& lc,
                           int allow_self, int* d_sidx, float* d_d2, IcpState* d_state);
 icpmi_status nn_launch_k(icpmi_ctx* c, const float4* d_reading, int64_t n, const float* d_T, const LoopCfg& lc,
@@ -408,7 +470,7 @@ icpmi_status nn_self_knn(icpmi_ctx* c, const float4* d_cloud, const LoopCfg& lc,
 icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals3, int64_t n, const LoopCfg& lc, bool fixed, float T_out[16],
                       icpmi_stats* stats);
 icpmi_status loop_sensor_noise_overlap(icpmi_ctx* c, int64_t n, const LoopCfg& lc, bool sorted, float* overlap);
-icpmi_status loop_prepare_reading(icpmi_ctx* c, const float4* d_scan, int64_t n, const float* d_normals3);
+icpmi_status loop_prepare_reading(icpmi_ctx* c, const float4* d_scan, int64_t n, const float* d_normals3, bool* head_done = nullptr);
 icpmi_status loop_run_batch(icpmi_ctx* c, int batch, const float* const* d_scans4, const int64_t* n, const LoopCfg& lc, bool fixed,
                             float* T_out, icpmi_stats* stats, icpmi_status* status);
 icpmi_status loop_single_step(icpmi_ctx* c, int64_t n, const LoopCfg& lc, const float* T_iter_host, float T_step[16],

@@ -1032,32 +1032,6 @@ __device__ void angle_axis_T(const float* x3, float* T)
     T[0] = cx * ax + c; T[5] = cy * ay + c; T[10] = cz * az + c;
 }
 
-__device__ void quat_from_T(const float* T, double* q)
-{
-    const double m00 = T[0], m11 = T[5], m22 = T[10];
-    double t = m00 + m11 + m22;
-    if (t > 0) {
-        t = sqrt(t + 1.0);
-        q[0] = 0.5 * t; t = 0.5 / t;
-        q[1] = ((double)T[4 * 1 + 2] - (double)T[4 * 2 + 1]) * t;
-        q[2] = ((double)T[4 * 2 + 0] - (double)T[4 * 0 + 2]) * t;
-        q[3] = ((double)T[4 * 0 + 1] - (double)T[4 * 1 + 0]) * t;
-    } else {
-        int i = 0;
-        if (m11 > m00) i = 1;
-        if (m22 > (i == 0 ? m00 : m11)) i = 2;
-        const int j = (i + 1) % 3, kk = (j + 1) % 3;
-        auto M = [&](int r, int c) { return (double)T[4 * c + r]; };
-        t = sqrt(M(i, i) - M(j, j) - M(kk, kk) + 1.0);
-        double v[3];
-        v[i] = 0.5 * t; t = 0.5 / t;
-        q[0] = (M(kk, j) - M(j, kk)) * t;
-        v[j] = (M(j, i) + M(i, j)) * t;
-        v[kk] = (M(kk, i) + M(i, kk)) * t;
-        q[1] = v[0]; q[2] = v[1]; q[3] = v[2];
-    }
-}
-
 __device__ double quat_angdist(const double* a, const double* b)
 {
     const double w = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
@@ -1282,24 +1256,7 @@ __global__ __launch_bounds__(256) void pad_normals_kernel(const float* __restric
 __global__ void init_state_kernel(IcpState* st, const float* T0, unsigned seq, unsigned* progress, const unsigned* seq_src = nullptr)
 {
     if (threadIdx.x != 0) return;
-    // seq_src: the sequence number is read from host-mapped memory at RUN time -- a captured graph must not freeze the number of the
-    // registration it was captured for (the host matches the progress word against the number of the registration it is waiting on)
-    if (seq_src) seq = __hip_atomic_load(seq_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    st += blockIdx.x; // one state per reading of a batch
-    if (progress) progress += blockIdx.x;
-    st->seq = seq;
-    if (progress) __hip_atomic_store(progress, (seq & 0x7ffffu) << 12, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    for (int i = 0; i < 16; ++i) st->T_iter[i] = T0 ? T0[i] : ((i % 5 == 0) ? 1.f : 0.f);
-    st->iter = 0; st->done = 0; st->error = 0; st->stop_reason = 0; st->counter = 0;
-    quat_from_T(st->T_iter, st->hq);
-    for (int r = 0; r < 3; ++r) st->ht[r] = st->T_iter[12 + r];
-    for (int r = 0; r < 4; ++r) st->init_q[r] = st->hq[r];
-    st->hist_n = 1;
-    st->sel_prefix = 0; st->sel_rank = 0; st->n_valid = 0;
-    for (int f = 0; f < ICPMI_MAX_OUTLIER; ++f) st->limits[f] = -1.f;
-    st->robust_med = 0.f; st->robust_scale = 1.f; st->vt_valid = 0; st->vt_ratio = -1.f;
-    st->pairs = 0; st->wsum = 0; st->hard_count = 0; st->hard_total = 0; st->ticket = 0;
-    for (int i = 0; i < 24; ++i) st->dbg[i] = 0;
+    init_state_dev(st + blockIdx.x, T0, seq, progress ? progress + blockIdx.x : nullptr, seq_src); // one state per reading of a batch
 }
 
 __global__ __launch_bounds__(256) void weights_kernel(int64_t count, LoopCfg lc, const IcpState* __restrict__ st,
@@ -1459,11 +1416,18 @@ icpmi_status loop_sensor_noise_overlap(icpmi_ctx* c, int64_t n, const LoopCfg& l
     return ICPMI_OK;
 }
 
-icpmi_status loop_prepare_reading(icpmi_ctx* c, const float4* d_scan, int64_t n, const float* d_normals3)
+// ICPMI_FUSE_HEAD (default 1): centring, loop-state initialisation and the clearing of the selection histograms ride in the kernels of
+// the query sort (SortHead) -- the head of a registration is 3 graph nodes instead of 8
+static bool fuse_head() { static int v = -1; if (v < 0) { const char* e = getenv("ICPMI_FUSE_HEAD"); v = e ? atoi(e) : 1; } return v != 0; }
+
+// head_done: the caller wants the loop state initialised too (enqueue_registration_head); set when the sort's kernels did it
+icpmi_status loop_prepare_reading(icpmi_ctx* c, const float4* d_scan, int64_t n, const float* d_normals3, bool* head_done)
 {
     if (ensure_cap(c, &c->d_reading, &c->cap_reading, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
     const int blocks = (int)((n + 255) / 256);
-    if (blocks) {
+    const bool fused = head_done && fuse_head() && c->cfg.knn <= 8 && n > 0;
+    if (head_done) *head_done = fused;
+    if (blocks && !fused) {
         BatchSrc src; memset(&src, 0, sizeof src); src.p[0] = d_scan;
         hipLaunchKernelGGL(centre_kernel, dim3(blocks), dim3(256), 0, c->stream, src, batch_of_one(n), c->mean[0], c->mean[1], c->mean[2], c->d_reading);
     }
@@ -1473,6 +1437,14 @@ icpmi_status loop_prepare_reading(icpmi_ctx* c, const float4* d_scan, int64_t n,
     }
     HIP_TRY(c, hipGetLastError());
     // tile order of the (centred) reading: wave-local cell coherence for the pyramid NN kernels
+    if (fused) {
+        SortHead h; memset(&h.raw, 0, sizeof h.raw);
+        h.raw.p[0] = d_scan; h.mean[0] = c->mean[0]; h.mean[1] = c->mean[1]; h.mean[2] = c->mean[2];
+        h.st = c->d_state; h.seq = c->reg_seq; h.progress = c->d_progress;
+        h.seq_src = c->d_progress ? (const unsigned*)(c->d_progress + 32) : (const unsigned*)nullptr;
+        h.selhist = c->d_selhist;
+        return sort_queries_batch(c, c->d_reading, batch_of_one(n), &h);
+    }
     if (c->cfg.knn <= 8 && n > 0) return sort_queries(c, c->d_reading, n);
     return ICPMI_OK;
 }
@@ -1717,8 +1689,10 @@ static void host_mat4_mul(const float* A, const float* B, float* C)
 // loop state, selection histograms
 static icpmi_status enqueue_registration_head(icpmi_ctx* c, const float4* d_scan, const float* d_normals3, int64_t n)
 {
-    icpmi_status s = loop_prepare_reading(c, d_scan, n, d_normals3);
+    bool head_done = false;
+    icpmi_status s = loop_prepare_reading(c, d_scan, n, d_normals3, &head_done);
     if (s != ICPMI_OK) return s;
+    if (head_done) return ICPMI_OK;
     // (the registration's sequence number: loop_run stores it in h_progress[32] before it launches anything)
     hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(64), 0, c->stream, c->d_state, (const float*)nullptr, c->reg_seq, c->d_progress,
                        c->d_progress ? (const unsigned*)(c->d_progress + 32) : (const unsigned*)nullptr);
@@ -1994,6 +1968,12 @@ icpmi_status loop_run_batch(icpmi_ctx* c, int B, const float* const* d_scans4, c
 
     auto head = [&]() -> icpmi_status {
         const int blocks = (int)((nmax + 255) / 256);
+        if (fuse_head() && nmax > 0) {
+            c->reg_seq = (c->reg_seq + 1) & 0x7ffffu;
+            SortHead h; h.raw = src; h.mean[0] = c->mean[0]; h.mean[1] = c->mean[1]; h.mean[2] = c->mean[2];
+            h.st = c->d_state; h.seq = c->reg_seq; h.progress = c->d_progress; h.seq_src = nullptr; h.selhist = c->d_selhist;
+            return sort_queries_batch(c, c->d_reading, ba, &h);
+        }
         hipLaunchKernelGGL(centre_kernel, dim3(blocks, B), dim3(256), 0, c->stream, src, ba, c->mean[0], c->mean[1], c->mean[2], c->d_reading);
         icpmi_status s = sort_queries_batch(c, c->d_reading, ba);
         if (s != ICPMI_OK) return s;

@@ -277,19 +277,25 @@ __device__ __forceinline__ unsigned long long match_digit(unsigned d, bool valid
 
 // (blockIdx.y = reading of a batch: slices of the per-query arrays qs elements apart, one count table of `tabstride`
 // words per reading)
-template <bool FIRST>
-__global__ __launch_bounds__(256) void qhist_kernel(const float4* __restrict__ pts, BatchArgs ba, GridParams g, int tx, int ty,
-                                                    const unsigned* __restrict__ keys_in, unsigned* __restrict__ keys_out, int shift,
-                                                    int nwg, unsigned* __restrict__ count, unsigned* __restrict__ total, int qs, int tabstride)
+// First kernel of the sort: tile keys and the digit counts of pass 0, per workgroup.  CENTRE (the registration head, r3): the points
+// are read from the readings as handed in and moved by -mean through the fmaf chain of a transform (what centre_kernel did in a
+// launch of its own) into `pts`, the sort's input.  It also clears the count tables of the later passes, which the scatter kernels
+// fill with atomics.  r2 cleared a `total` table with a memset node and ran a histogram kernel per pass.
+template <bool CENTRE>
+__global__ __launch_bounds__(256) void qfirst_kernel(BatchSrc raw, float mx, float my, float mz, float4* __restrict__ pts, BatchArgs ba, GridParams g,
+                                                     int tx, int ty, unsigned* __restrict__ keys_out, int nwg, unsigned* __restrict__ tables,
+                                                     int later_words, int tab, int qs, int tabstride)
 {
     const int n = ba.n[blockIdx.y];
+    const float4* __restrict__ src = CENTRE ? raw.p[blockIdx.y] : nullptr;
     pts += (size_t)blockIdx.y * qs;
-    if (keys_in) keys_in += (size_t)blockIdx.y * 4 * qs;
-    if (keys_out) keys_out += (size_t)blockIdx.y * 4 * qs;
-    count += (size_t)blockIdx.y * tabstride; total += (size_t)blockIdx.y * tabstride;
+    keys_out += (size_t)blockIdx.y * 4 * qs;
+    tables += (size_t)blockIdx.y * tabstride;
+    unsigned* count = tables;
     __shared__ unsigned h[QS_BINS];
     const int t = threadIdx.x, lane = t & 63;
     if (t < QS_BINS) h[t] = 0;
+    for (int i = blockIdx.x * 256 + t; i < later_words; i += nwg * 256) tables[tab + i] = 0;
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < QS_EPB / 256; ++r) {
@@ -297,48 +303,64 @@ __global__ __launch_bounds__(256) void qhist_kernel(const float4* __restrict__ p
         const bool ok = e < n;
         unsigned key = 0;
         if (ok) {
-            key = FIRST ? st_key(pts[e], g, tx, ty) : keys_in[e];
-            if (FIRST) keys_out[e] = key;
+            float4 p;
+            if (CENTRE) {
+                const float4 q = src[e];
+                p = make_float4(fmaf(-mx, q.w, q.x), fmaf(-my, q.w, q.y), fmaf(-mz, q.w, q.z), q.w);
+                pts[e] = p;
+            } else p = pts[e];
+            key = st_key(p, g, tx, ty);
+            keys_out[e] = key;
         }
-        const unsigned d = (key >> shift) & (QS_BINS - 1);
+        const unsigned d = key & (QS_BINS - 1);
         const unsigned long long m = match_digit(d, ok);
         if (ok && (m & ((1ull << lane) - 1ull)) == 0ull) atomicAdd(&h[d], (unsigned)__popcll(m));
     }
     __syncthreads();
-    if (t < QS_BINS) {
-        count[t * nwg + blockIdx.x] = h[t];
-        if (h[t]) atomicAdd(&total[t], h[t]);
-    }
+    if (t < QS_BINS) count[t * nwg + blockIdx.x] = h[t];
 }
 
+// One pass: stable scatter by the 6-bit digit at `shift`.  A workgroup's base per digit comes from the per-workgroup counts (elements
+// of smaller digits anywhere + the same digit in earlier workgroups -- the digit totals are summed from the same table, no atomics).
+// Not FINAL: the counts of the NEXT pass are built here, one atomic per element on count_next[digit'][destination workgroup].
+// FINAL: points and original indices land in the sorted arrays; with a head, workgroup 0 of every reading also initialises that
+// reading's loop state and all workgroups clear its selection histograms (init_state_kernel and a memset node in r2).
 template <bool FINAL>
 __global__ __launch_bounds__(256) void qpass_kernel(const unsigned* __restrict__ keys_in, const unsigned* __restrict__ vals_in, BatchArgs ba,
-                                                    int shift, int nwg, const unsigned* __restrict__ count,
-                                                    const unsigned* __restrict__ total, unsigned* __restrict__ keys_out,
-                                                    unsigned* __restrict__ vals_out, const float4* __restrict__ pts,
-                                                    float4* __restrict__ out_pts, int* __restrict__ out_index, int qs, int tabstride)
+                                                    int shift, int nwg, const unsigned* __restrict__ count, unsigned* __restrict__ count_next,
+                                                    unsigned* __restrict__ keys_out, unsigned* __restrict__ vals_out,
+                                                    const float4* __restrict__ pts, float4* __restrict__ out_pts, int* __restrict__ out_index,
+                                                    int qs, int tabstride, IcpState* st_init, unsigned seq, unsigned* progress,
+                                                    const unsigned* seq_src, unsigned* __restrict__ selhist)
 {
     const int n = ba.n[blockIdx.y];
     keys_in += (size_t)blockIdx.y * 4 * qs;
     if (vals_in) vals_in += (size_t)blockIdx.y * 4 * qs;
     if (keys_out) keys_out += (size_t)blockIdx.y * 4 * qs;
     if (vals_out) vals_out += (size_t)blockIdx.y * 4 * qs;
-    count += (size_t)blockIdx.y * tabstride; total += (size_t)blockIdx.y * tabstride;
+    count += (size_t)blockIdx.y * tabstride;
+    if (count_next) count_next += (size_t)blockIdx.y * tabstride;
     pts += (size_t)blockIdx.y * qs;
     if (out_pts) out_pts += (size_t)blockIdx.y * qs;
     if (out_index) out_index += (size_t)blockIdx.y * qs;
     constexpr int R = QS_EPB / 256;
     __shared__ unsigned wc[R][4][QS_BINS]; // [round][wave][digit]: count, then exclusive prefix in element order
-    __shared__ unsigned part[4][QS_BINS];
+    __shared__ unsigned part[4][QS_BINS], whole[4][QS_BINS];
     __shared__ unsigned base[QS_BINS];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (FINAL) {
+        if (st_init && blockIdx.x == 0 && t == 0) init_state_dev(st_init + blockIdx.y, nullptr, seq, progress ? progress + blockIdx.y : nullptr, seq_src);
+        if (selhist) {
+            unsigned* hs = selhist + (size_t)blockIdx.y * ICPMI_SELHIST_WORDS;
+            for (int i = blockIdx.x * 256 + t; i < ICPMI_SELHIST_WORDS; i += nwg * 256) hs[i] = 0;
+        }
+    }
     for (int i = t; i < R * 4 * QS_BINS; i += 256) (&wc[0][0][0])[i] = 0;
-    // this workgroup's base per digit: elements of smaller digits anywhere + same digit in earlier workgroups
     {
-        const int d = t & (QS_BINS - 1), q = t >> QS_BITS; // 4 lanes-quarters share the sum over earlier workgroups
-        unsigned s = 0;
-        for (int b = q; b < (int)blockIdx.x; b += 4) s += count[d * nwg + b];
-        part[q][d] = s;
+        const int d = t & (QS_BINS - 1), q = t >> QS_BITS; // 4 lane-quarters share the sums over the workgroups
+        unsigned before = 0, all = 0;
+        for (int b = q; b < nwg; b += 4) { const unsigned v = count[d * nwg + b]; all += v; before += b < (int)blockIdx.x ? v : 0u; }
+        part[q][d] = before; whole[q][d] = all;
     }
     unsigned key[R], val[R], rank[R], dig[R];
     bool ok[R];
@@ -365,7 +387,7 @@ __global__ __launch_bounds__(256) void qpass_kernel(const unsigned* __restrict__
 #pragma unroll
             for (int ww = 0; ww < 4; ++ww) { const unsigned cnt = wc[r][ww][t]; wc[r][ww][t] = run; run += cnt; }
         // exclusive scan of the digit totals over the 64 lanes of wave 0
-        const unsigned tot = total[t];
+        const unsigned tot = whole[0][t] + whole[1][t] + whole[2][t] + whole[3][t];
         unsigned incl = tot;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -380,7 +402,10 @@ __global__ __launch_bounds__(256) void qpass_kernel(const unsigned* __restrict__
         if (!ok[r]) continue;
         const unsigned pos = base[dig[r]] + wc[r][w][dig[r]] + rank[r];
         if (FINAL) { out_pts[pos] = pts[val[r]]; out_index[pos] = (int)val[r]; }
-        else { keys_out[pos] = key[r]; vals_out[pos] = val[r]; }
+        else {
+            keys_out[pos] = key[r]; vals_out[pos] = val[r];
+            atomicAdd(&count_next[((key[r] >> (shift + QS_BITS)) & (QS_BINS - 1)) * nwg + pos / QS_EPB], 1u);
+        }
     }
 }
 
@@ -414,8 +439,8 @@ icpmi_status sort_queries_reserve(icpmi_ctx* c, int64_t n, int nscan)
 }
 
 // stable radix sort of every reading's points by super-tile: slice b of d_pts (ba.n[b] points, slices qs elements apart;
-// a batch of one: qs = n) -> slice b of d_qsorted / d_qindex
-icpmi_status sort_queries_batch(icpmi_ctx* c, const float4* d_pts, const BatchArgs& ba)
+// a batch of one: qs = n) -> slice b of d_qsorted / d_qindex.  passes + 1 kernels, no memset node.  head != nullptr: see SortHead.
+icpmi_status sort_queries_batch(icpmi_ctx* c, const float4* d_pts, const BatchArgs& ba, const SortHead* head)
 {
     const GridParams& g = c->grid;
     int nmax = 0;
@@ -423,33 +448,36 @@ icpmi_status sort_queries_batch(icpmi_ctx* c, const float4* d_pts, const BatchAr
     const int qs = ba.nscan == 1 ? nmax : ba.qstride;
     int tx, ty, passes, nwg; size_t tab;
     sort_dims(c, nmax, tx, ty, passes, nwg, tab);
-    if (nwg == 0) return ICPMI_OK;
+    if (nwg == 0) { if (head) { c->last_error = "sort_queries: a fused head needs points"; return ICPMI_ERR_INVALID_ARG; } return ICPMI_OK; }
     if (sort_queries_reserve(c, qs, ba.nscan) != ICPMI_OK) return ICPMI_ERR_HIP;
     const size_t tab_all = tab * passes; // one reading's tables
-    HIP_TRY(c, hipMemsetAsync(c->d_qtile, 0, tab_all * ba.nscan * sizeof(unsigned), c->stream));
     unsigned* kbuf[2] = {c->d_qkeys, c->d_qkeys + qs};
     unsigned* vbuf[2] = {c->d_qkeys + 2 * (size_t)qs, c->d_qkeys + 3 * (size_t)qs};
     const dim3 grid(nwg, ba.nscan);
+    const int later = (int)(tab * (passes - 1));
+    if (head)
+        hipLaunchKernelGGL(qfirst_kernel<true>, grid, dim3(256), 0, c->stream, head->raw, head->mean[0], head->mean[1], head->mean[2],
+                           const_cast<float4*>(d_pts), ba, g, tx, ty, kbuf[0], nwg, c->d_qtile, later, (int)tab, qs, (int)tab_all);
+    else {
+        BatchSrc none; memset(&none, 0, sizeof none);
+        hipLaunchKernelGGL(qfirst_kernel<false>, grid, dim3(256), 0, c->stream, none, 0.f, 0.f, 0.f, const_cast<float4*>(d_pts), ba, g, tx, ty,
+                           kbuf[0], nwg, c->d_qtile, later, (int)tab, qs, (int)tab_all);
+    }
     for (int ps = 0; ps < passes; ++ps) {
         unsigned* count = c->d_qtile + tab * ps;
-        unsigned* total = count + (size_t)QS_BINS * nwg;
         const int shift = ps * QS_BITS;
         const int in = ps & 1, out = in ^ 1;
-        if (ps == 0)
-            hipLaunchKernelGGL(qhist_kernel<true>, grid, dim3(256), 0, c->stream, d_pts, ba, g, tx, ty, (const unsigned*)nullptr,
-                               kbuf[0], shift, nwg, count, total, qs, (int)tab_all);
-        else
-            hipLaunchKernelGGL(qhist_kernel<false>, grid, dim3(256), 0, c->stream, d_pts, ba, g, tx, ty, (const unsigned*)kbuf[in],
-                               (unsigned*)nullptr, shift, nwg, count, total, qs, (int)tab_all);
         const unsigned* vin = ps == 0 ? nullptr : vbuf[in];
         if (ps == passes - 1)
             hipLaunchKernelGGL(qpass_kernel<true>, grid, dim3(256), 0, c->stream, (const unsigned*)kbuf[in], vin, ba, shift, nwg,
-                               (const unsigned*)count, (const unsigned*)total, (unsigned*)nullptr, (unsigned*)nullptr, d_pts, c->d_qsorted,
-                               c->d_qindex, qs, (int)tab_all);
+                               (const unsigned*)count, (unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr, d_pts, c->d_qsorted,
+                               c->d_qindex, qs, (int)tab_all, head ? head->st : (IcpState*)nullptr, head ? head->seq : 0u,
+                               head ? head->progress : (unsigned*)nullptr, head ? head->seq_src : (const unsigned*)nullptr,
+                               head ? head->selhist : (unsigned*)nullptr);
         else
             hipLaunchKernelGGL(qpass_kernel<false>, grid, dim3(256), 0, c->stream, (const unsigned*)kbuf[in], vin, ba, shift, nwg,
-                               (const unsigned*)count, (const unsigned*)total, kbuf[out], vbuf[out], d_pts, (float4*)nullptr, (int*)nullptr,
-                               qs, (int)tab_all);
+                               (const unsigned*)count, count + tab, kbuf[out], vbuf[out], d_pts, (float4*)nullptr, (int*)nullptr,
+                               qs, (int)tab_all, (IcpState*)nullptr, 0u, (unsigned*)nullptr, (const unsigned*)nullptr, (unsigned*)nullptr);
     }
     HIP_TRY(c, hipGetLastError());
     c->qsorted_n = ba.nscan == 1 ? nmax : -1; c->qsorted_src = ba.nscan == 1 ? d_pts : nullptr;
