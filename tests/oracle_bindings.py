@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_LIB = os.path.join(_ROOT, "oracle", "liboracle.so")
+_LIB = os.environ.get("ICP_ORACLE_LIB") or os.path.join(_ROOT, "oracle", "liboracle.so")  # (override: the sanitizer build, tests/tools/oracle_sanitize.sh)
 
 MIN_IDENTITY, MIN_POINT_TO_POINT, MIN_POINT_TO_PLANE = 0, 1, 2
 OUT_MAXDIST, OUT_MINDIST, OUT_MEDIANDIST, OUT_TRIMMEDDIST, OUT_SURFACENORMAL = 1, 2, 3, 4, 5
