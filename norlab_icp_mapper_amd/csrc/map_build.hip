@@ -320,9 +320,34 @@ __global__ __launch_bounds__(256) void qfirst_kernel(BatchSrc raw, float mx, flo
     if (t < QS_BINS) count[t * nwg + blockIdx.x] = h[t];
 }
 
+// digit counts of a later pass, per workgroup, from the keys as the previous pass left them (every entry of the table is written:
+// nothing to clear)
+__global__ __launch_bounds__(256) void qcount_kernel(const unsigned* __restrict__ keys_in, BatchArgs ba, int shift, int nwg,
+                                                     unsigned* __restrict__ count, int qs, int tabstride)
+{
+    const int n = ba.n[blockIdx.y];
+    keys_in += (size_t)blockIdx.y * 4 * qs;
+    count += (size_t)blockIdx.y * tabstride;
+    __shared__ unsigned h[QS_BINS];
+    const int t = threadIdx.x, lane = t & 63;
+    if (t < QS_BINS) h[t] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < QS_EPB / 256; ++r) {
+        const int e = blockIdx.x * QS_EPB + r * 256 + t;
+        const bool ok = e < n;
+        const unsigned d = ((ok ? keys_in[e] : 0u) >> shift) & (QS_BINS - 1);
+        const unsigned long long m = match_digit(d, ok);
+        if (ok && (m & ((1ull << lane) - 1ull)) == 0ull) atomicAdd(&h[d], (unsigned)__popcll(m));
+    }
+    __syncthreads();
+    if (t < QS_BINS) count[t * nwg + blockIdx.x] = h[t];
+}
+
 // One pass: stable scatter by the 6-bit digit at `shift`.  A workgroup's base per digit comes from the per-workgroup counts (elements
 // of smaller digits anywhere + the same digit in earlier workgroups -- the digit totals are summed from the same table, no atomics).
-// Not FINAL: the counts of the NEXT pass are built here, one atomic per element on count_next[digit'][destination workgroup].
+// (Building the NEXT pass's counts here, one global atomic per element on count_next[digit'][destination workgroup], was tried: the
+// scatter went 7.4 -> 21 us, 76 us with the 10 M map's three passes -- qcount_kernel does it from LDS in 5 us.)
 // FINAL: points and original indices land in the sorted arrays; with a head, workgroup 0 of every reading also initialises that
 // reading's loop state and all workgroups clear its selection histograms (init_state_kernel and a memset node in r2).
 template <bool FINAL>
@@ -404,7 +429,6 @@ __global__ __launch_bounds__(256) void qpass_kernel(const unsigned* __restrict__
         if (FINAL) { out_pts[pos] = pts[val[r]]; out_index[pos] = (int)val[r]; }
         else {
             keys_out[pos] = key[r]; vals_out[pos] = val[r];
-            atomicAdd(&count_next[((key[r] >> (shift + QS_BITS)) & (QS_BINS - 1)) * nwg + pos / QS_EPB], 1u);
         }
     }
 }
@@ -439,7 +463,7 @@ icpmi_status sort_queries_reserve(icpmi_ctx* c, int64_t n, int nscan)
 }
 
 // stable radix sort of every reading's points by super-tile: slice b of d_pts (ba.n[b] points, slices qs elements apart;
-// a batch of one: qs = n) -> slice b of d_qsorted / d_qindex.  passes + 1 kernels, no memset node.  head != nullptr: see SortHead.
+// a batch of one: qs = n) -> slice b of d_qsorted / d_qindex.  2 passes kernels (first pass: keys + counts in one), no memset node.  head != nullptr: see SortHead.
 icpmi_status sort_queries_batch(icpmi_ctx* c, const float4* d_pts, const BatchArgs& ba, const SortHead* head)
 {
     const GridParams& g = c->grid;
@@ -454,7 +478,7 @@ icpmi_status sort_queries_batch(icpmi_ctx* c, const float4* d_pts, const BatchAr
     unsigned* kbuf[2] = {c->d_qkeys, c->d_qkeys + qs};
     unsigned* vbuf[2] = {c->d_qkeys + 2 * (size_t)qs, c->d_qkeys + 3 * (size_t)qs};
     const dim3 grid(nwg, ba.nscan);
-    const int later = (int)(tab * (passes - 1));
+    const int later = 0; // (the tables of the later passes are written in full by qcount_kernel)
     if (head)
         hipLaunchKernelGGL(qfirst_kernel<true>, grid, dim3(256), 0, c->stream, head->raw, head->mean[0], head->mean[1], head->mean[2],
                            const_cast<float4*>(d_pts), ba, g, tx, ty, kbuf[0], nwg, c->d_qtile, later, (int)tab, qs, (int)tab_all);
@@ -468,6 +492,7 @@ icpmi_status sort_queries_batch(icpmi_ctx* c, const float4* d_pts, const BatchAr
         const int shift = ps * QS_BITS;
         const int in = ps & 1, out = in ^ 1;
         const unsigned* vin = ps == 0 ? nullptr : vbuf[in];
+        if (ps > 0) hipLaunchKernelGGL(qcount_kernel, grid, dim3(256), 0, c->stream, (const unsigned*)kbuf[in], ba, shift, nwg, count, qs, (int)tab_all);
         if (ps == passes - 1)
             hipLaunchKernelGGL(qpass_kernel<true>, grid, dim3(256), 0, c->stream, (const unsigned*)kbuf[in], vin, ba, shift, nwg,
                                (const unsigned*)count, (unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr, d_pts, c->d_qsorted,
