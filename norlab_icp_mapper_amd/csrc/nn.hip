@@ -1047,7 +1047,8 @@ __global__ __launch_bounds__(64 * NW) void nn1_wg_kernel(const float4* __restric
 #endif
     __shared__ uint4 ltab[ICPMI_MAXLEV * 4];
     __shared__ unsigned lh[256];
-    __shared__ uint4 pieces[CAP];            // {address of the first candidate (lo, hi), count << 8 | query slot, its position in the level array}
+    __shared__ uint2 pieces[CAP];            // {position of the first candidate in its level array, count << 8 | query slot} (the address comes from the level table)
+    __shared__ float2 qdec[Q];               // what the decision of a pass needs from its row phase: squared margin, block covers the grid
     __shared__ float4 qrec[Q];               // transformed query, w = bits of its current level
     __shared__ float2 qaux[Q];               // squared pruning radius (+inf: none), flags: 1 = searching, 2 = own row only
     __shared__ unsigned long long qkey[Q];   // best (d^2, index) key of the query so far
@@ -1090,8 +1091,6 @@ __global__ __launch_bounds__(64 * NW) void nn1_wg_kernel(const float4* __restric
     const bool allow_self = SELF;
 
     Cand best; best.key = ~0ull; best.sidx = -1; // sidx = position in its level | level << 28
-    float4 seed_pt = make_float4(0.f, 0.f, 0.f, 0.f);
-    bool best_is_seed = false;
     bool decided = !active;
     int lev0 = unseeded_lev;
     if (w0) {   // seed: see nn1_ml_kernel -- the previous match bounds the answer; start at the first level whose block holds that ball
@@ -1115,7 +1114,7 @@ __global__ __launch_bounds__(64 * NW) void nn1_wg_kernel(const float4* __restric
                 lev0 = lev;
                 best.key = pack_key(ub2, __float_as_uint(qs.w));
                 best.sidx = sp; // level 0 position
-                seed_pt = qs; best_is_seed = true;
+                qpt[slot] = qs; // (the seed is the best so far: a winner of a later pass overwrites it -- after the barrier below)
                 want = false;
             }
         };
@@ -1160,9 +1159,9 @@ __global__ __launch_bounds__(64 * NW) void nn1_wg_kernel(const float4* __restric
         if (!s_any) break;
         NN_TICK(1);
         // ---- (1b) all waves: lane = query, wave = row group
-        float mf, g_cell, g_slack;
-        bool covers;
         {
+            float mf, g_cell, g_slack;
+            bool covers;
             const float4 qr = qrec[slot];
             const float2 qa = qaux[slot];
             const int lv = __float_as_int(qr.w);
@@ -1171,10 +1170,8 @@ __global__ __launch_bounds__(64 * NW) void nn1_wg_kernel(const float4* __restric
             const float rub2 = qa.x;
             GridParams g;
             const gunsigned* __restrict__ cs; // (global address space: rebuilt from integers, it would be read through the flat path)
-            unsigned long long lvl_pts;
             {
                 const uint4 a = ltab[4 * lv], b = ltab[4 * lv + 1], c2 = ltab[4 * lv + 2], d = ltab[4 * lv + 3];
-                lvl_pts = ((unsigned long long)c2.w << 32) | c2.z;
                 g.ox = __uint_as_float(a.x); g.oy = __uint_as_float(a.y); g.oz = __uint_as_float(a.z); g.cell = __uint_as_float(a.w);
                 g.inv_cell = __uint_as_float(b.x); g.slack = __uint_as_float(b.y); g.nx = (int)b.z; g.ny = (int)b.w;
                 g.nz = (int)c2.x; g.ncells = (int)c2.y;
@@ -1191,6 +1188,7 @@ __global__ __launch_bounds__(64 * NW) void nn1_wg_kernel(const float4* __restric
             if (!(mf >= 0.f)) mf = 0.f;
             g_cell = g.cell; g_slack = g.slack;
             covers = cx - 1 <= 0 && cx + 1 >= g.nx - 1 && cy - 1 <= 0 && cy + 1 >= g.ny - 1 && cz - 1 <= 0 && cz + 1 >= g.nz - 1;
+            if (w0) { const float margin = fmaxf((1.0f + mf) * g_cell - g_slack, 0.f); qdec[slot] = make_float2(margin * margin, covers ? 1.f : 0.f); } // (not carried in registers across the piece steps)
             // row ranges: branch-free so that all 2 NR loads of a lane leave together (unreached rows read cs[0] twice)
             unsigned rs[NR], rn[NR];
             {
@@ -1255,8 +1253,7 @@ __global__ __launch_bounds__(64 * NW) void nn1_wg_kernel(const float4* __restric
                 unsigned s = rs[sl], c = rn[sl];
                 while (c) {
                     const unsigned t = c < (1u << plb) ? c : (1u << plb);
-                    const unsigned long long ad = lvl_pts + (unsigned long long)s * 16ull;
-                    pieces[base++] = make_uint4((unsigned)ad, (unsigned)(ad >> 32), (t << 8) | (unsigned)slot, s);
+                    pieces[base++] = make_uint2(s, (t << 8) | (unsigned)slot);
                     s += t; c -= t;
                 }
             }
@@ -1272,11 +1269,12 @@ __global__ __launch_bounds__(64 * NW) void nn1_wg_kernel(const float4* __restric
         for (unsigned i0 = 0; i0 < total; i0 += (unsigned)NT) {
             const unsigned i = i0 + (unsigned)tid;
             const bool has = i < total;
-            const uint4 e = pieces[has ? i : 0u];
-            const unsigned qsl = e.z & 255u, cnt = has ? e.z >> 8 : 0u;
+            const uint2 e = pieces[has ? i : 0u];
+            const unsigned qsl = e.y & 255u, cnt = has ? e.y >> 8 : 0u;
             const float4 qr = qrec[qsl];
             // (global address space: a pointer rebuilt from integers would otherwise be loaded through the flat path)
-            const gfloat4* mp = reinterpret_cast<const gfloat4*>(((unsigned long long)e.y << 32) | e.x);
+            const uint4 lt2 = ltab[4 * __float_as_int(qr.w) + 2];
+            const gfloat4* mp = reinterpret_cast<const gfloat4*>((((unsigned long long)lt2.w << 32) | lt2.z) + (unsigned long long)e.x * 16ull);
             unsigned long long kb = ~0ull;
             unsigned pb = 0;
             float bx = 0.f, by = 0.f, bz = 0.f; // the best candidate's coordinates ride along (a reload would be one more trip)
@@ -1297,7 +1295,7 @@ __global__ __launch_bounds__(64 * NW) void nn1_wg_kernel(const float4* __restric
             __syncthreads();
             // keys are unique per map point: at most one lane of the workgroup finds its own key in the slot
             if (kb != ~0ull && __atomic_load_n(&qkey[qsl], __ATOMIC_RELAXED) == kb) {
-                qwin[qsl] = (e.w + pb) | (__float_as_uint(qr.w) << 28);
+                qwin[qsl] = (e.x + pb) | (__float_as_uint(qr.w) << 28);
                 qpt[qsl] = make_float4(bx, by, bz, __uint_as_float((unsigned)(kb & 0xffffffffull)));
             }
         }
@@ -1306,11 +1304,12 @@ __global__ __launch_bounds__(64 * NW) void nn1_wg_kernel(const float4* __restric
         // ---- (3) wave 0 decides
         if (w0 && run) {
             const unsigned long long k2 = qkey[slot];
-            if (k2 != best.key) { best.key = k2; best.sidx = (int)qwin[slot]; best_is_seed = false; }
+            if (k2 != best.key) { best.key = k2; best.sidx = (int)qwin[slot]; }
             if (prescan) did_pre = true;
             else {
-                const float margin = fmaxf((1.0f + mf) * g_cell - g_slack, 0.f);
-                const float m2 = margin * margin;
+                const float2 dq = qdec[slot];
+                const float m2 = dq.x;
+                const bool covers = dq.y != 0.f;
                 const float bd2 = __uint_as_float((unsigned)(best.key >> 32));
                 decided = (best.key != ~0ull && bd2 <= m2) || m2 > maxr2 || covers;
                 if (!decided) { ++lev; did_pre = false; }
@@ -1339,7 +1338,7 @@ __global__ __launch_bounds__(64 * NW) void nn1_wg_kernel(const float4* __restric
                 const uint4 d = ltab[4 * lvb + 3];
                 bs = (int)reinterpret_cast<const unsigned*>(((unsigned long long)d.w << 32) | d.z)[pos];
             }
-            mpt = best_is_seed ? seed_pt : qpt[slot];
+            mpt = qpt[slot];
         }
         out_sidx[orig] = bs;
         out_d2[orig] = bd2;
