@@ -21,7 +21,9 @@
 // bins) plus a COARSE one over the top 8 bits of the digit (256 bins) that tells a consumer which 256
 // fine bins to read.  Level 0's coarse histogram is hot (2-3 exponent values hold everything), so the
 // NN workgroups aggregate it in LDS and flush into one of ICPMI_S2_COPIES privatised copies.
-#define ICPMI_S2_COPIES 32
+#ifndef ICPMI_S2_COPIES
+#define ICPMI_S2_COPIES 8   // (r3: 32 -> 8: the level-0 scan of every selection workgroup sums the copies; +1 % on the k = 1 chains, 2 copies -3 %)
+#endif
 #define ICPMI_S2_C0 4096                                        // word offsets inside d_selhist (legacy bins first)
 #define ICPMI_S2_F0 (ICPMI_S2_C0 + ICPMI_S2_COPIES * 256)
 #ifndef ICPMI_S2_FCOPIES
