@@ -154,6 +154,8 @@ icpmi_status icpmi_create(const icpmi_config* cfg, icpmi_handle* out)
     c->cap_selhist = ICPMI_SELHIST_WORDS;
     CR(hipHostMalloc((void**)&c->h_state, sizeof(IcpState) * ICPMI_MAX_BATCH, hipHostMallocDefault));
     CR(hipHostMalloc((void**)&c->h_pin, ICPMI_PIN_BYTES + ICPMI_UP_SLOT * ICPMI_UP_SLOTS, hipHostMallocDefault));
+    CR(hipHostMalloc((void**)&c->h_nocc, 64, hipHostMallocDefault));
+    *c->h_nocc = 0;
     CR(hipHostMalloc((void**)&c->h_progress, 256, hipHostMallocMapped)); // words 0..15: progress per reading of a batch; word 32: sequence number of the registration being launched
     memset(c->h_progress, 0, 256);
     CR(hipHostGetDevicePointer((void**)&c->d_progress, c->h_progress, 0));
@@ -205,6 +207,7 @@ void icpmi_destroy(icpmi_handle c)
     hipFree(c->d_state);
     if (c->h_state) hipHostFree(c->h_state);
     if (c->h_pin) hipHostFree(c->h_pin);
+    if (c->h_nocc) hipHostFree(c->h_nocc);
     if (c->h_progress) hipHostFree(c->h_progress);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);

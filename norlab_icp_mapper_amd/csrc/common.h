@@ -242,6 +242,7 @@ struct icpmi_ctx {
     IcpState* h_state = nullptr;                               // pinned mirror (ICPMI_MAX_BATCH)
     int batch_cur = 1;                                         // readings of the launch sequence being enqueued (set by the loop)
     BatchArgs batch_args{};                                    // their sizes / slice stride
+    unsigned* h_nocc = nullptr; int64_t nocc_m = 0;            // pinned word: occupied cells of the last index build, and that build's point count (map_build)
     unsigned char* h_pin = nullptr;                            // pinned page: [0, ICPMI_PIN_BYTES) small read-backs, behind it the ring of upload_small
     unsigned up_next = 0;
     // Progress word of the running registration in host-mapped pinned memory, written by the solve kernel after every

@@ -530,6 +530,8 @@ icpmi_status device_exclusive_scan(icpmi_ctx* c, unsigned* data, int n, unsigned
     return ICPMI_OK;
 }
 
+// h_nocc == nullptr: the occupied-cell count is not waited for -- it is copied to the handle's pinned word behind the kernel and read
+// at the NEXT build (whose bounding-box read-back has synchronised the stream by then)
 static icpmi_status grid_count(icpmi_ctx* c, const float4* d_pts, int64_t m, const GridParams& g, unsigned* h_nocc)
 {
     if (ensure_cap(c, &c->d_cell_start, &c->cap_cells, (size_t)g.ncells + 2) != ICPMI_OK) return ICPMI_ERR_HIP;
@@ -539,6 +541,7 @@ static icpmi_status grid_count(icpmi_ctx* c, const float4* d_pts, int64_t m, con
     hipLaunchKernelGGL(key_kernel, dim3(blocks), dim3(256), 0, c->stream, d_pts, m, c->mean[0], c->mean[1], c->mean[2], g,
                        c->d_keys, c->d_cell_start, d_nocc, run_atomics_cfg());
     HIP_TRY(c, hipGetLastError());
+    if (!h_nocc) { HIP_TRY(c, hipMemcpyAsync(c->h_nocc, d_nocc, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream)); return ICPMI_OK; }
     if (read_back(c, h_nocc, d_nocc, sizeof(unsigned)) != ICPMI_OK) return ICPMI_ERR_HIP;
     return ICPMI_OK;
 }
@@ -618,6 +621,21 @@ icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float
         static double target_cfg = -1.0;
         if (target_cfg < 0) { const char* e = getenv("ICPMI_GRID_TARGET"); target_cfg = e ? atof(e) : 8.0; }
         const double TARGET = target_cfg;
+        // A handle that rebuilds the index of a slowly growing map (every map update, twice) does not wait for the occupancy of THIS
+        // build: it corrects the edge with the count of the previous one, which arrived in pinned memory long ago (r3: one stream
+        // synchronisation less per build; ICPMI_GRID_DEFER=0 restores the read-back).  The edge only steers speed: the search is exact.
+        static int defer = -1;
+        if (defer < 0) { const char* e = getenv("ICPMI_GRID_DEFER"); defer = e ? atoi(e) : 1; }
+        if (defer && c->h_nocc && c->nocc_m > 0 && c->grid.cell > 0.f && c->m > 0 && (double)m > 0.7 * (double)c->m && (double)m < 1.4 * (double)c->m) {
+            const double occ = (double)c->nocc_m / (double)std::max(1u, *c->h_nocc);
+            double cell = c->grid.cell;
+            if (!(occ > TARGET * 0.6 && occ < TARGET * 1.6)) cell = cell * sqrt(TARGET / occ);
+            g = make_grid(clo, chi, clamp_cell(cell), maxabs);
+            n_occ = *c->h_nocc;
+            if (grid_count(c, d_pts, m, g, nullptr) != ICPMI_OK) return ICPMI_ERR_HIP;
+            c->nocc_m = m;
+            goto grid_chosen;
+        }
         double vol = std::max(ext[0], 1e-3) * std::max(ext[1], 1e-3) * std::max(ext[2], 1e-3);
         double cell = cbrt(vol / (double)m) * 1.2;
         // a handle that indexed a cloud of about this size before (the map of the previous update, the private handle of a
@@ -634,6 +652,8 @@ icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float
             if (grid_count(c, d_pts, m, g, &n_occ) != ICPMI_OK) return ICPMI_ERR_HIP;
         }
     }
+    if (c->h_nocc) { *c->h_nocc = n_occ; c->nocc_m = m; }
+grid_chosen:
     c->grid = g;
     c->n_occupied = n_occ;
 
