@@ -65,7 +65,33 @@ def step_stats(ms):
     return {"min": min(ms), "median": statistics.median(ms), "max": max(ms), "n": len(ms)}
 
 
-def nn_roofline(pkg, dev, chain, d_map, d_nrm, d_scan, n_scan, m_map, traffic_key=None):
+def kernel_sources_sha():
+    """Stamp of the kernel sources a counter measurement belongs to: profiles/nn_traffic.json carries the stamp of the tree its PMC
+    passes ran on, and `roofline.traffic` is printed only while that stamp is the one of the sources in this tree (a
+    constant loaded from a file goes stale silently the next time a kernel changes)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "norlab_icp_mapper_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def map_points_in_reach(np, map4, scan4, max_dist):
+    """Map points the search can touch at all: inside the reading's bounding box grown by maxDist.  SURVEY 8d charges `M * 16` for
+    "read the map once"; for a map the reading covers (configs 2 / 3: the box is the whole room) this IS M, for the 10 M-point map
+    of config 5 it is the part of the map a 100 k-point scan can reach -- charging all 160 MB there printed frac > 1 in r3."""
+    lo = scan4[:, :3].min(axis=0) - max_dist
+    hi = scan4[:, :3].max(axis=0) + max_dist
+    inside = np.ones(map4.shape[0], dtype=bool)
+    for a in range(3):
+        inside &= (map4[:, a] >= lo[a]) & (map4[:, a] <= hi[a])
+    return int(np.count_nonzero(inside))
+
+
+def nn_roofline(pkg, dev, chain, d_map, d_nrm, d_scan, n_scan, m_map, traffic_key=None, m_reach=None):
     """profile mode = eager launches with HIP events on the library's stream around every NN launch"""
     prof = pkg.ICPSequence(device=dev, max_iterations=ITERS_PER_STEP, profile=1, **chain)
     prof.setMapDev(d_map.data_ptr(), d_map.shape[0], d_nrm.data_ptr())
@@ -77,13 +103,18 @@ def nn_roofline(pkg, dev, chain, d_map, d_nrm, d_scan, n_scan, m_map, traffic_ke
             nn_cnt += prof.stats.nn_launches
     nn_avg_ms = nn_ms / max(nn_cnt, 1)
     kq = chain.get("knn", 1)
-    alg_bytes = n_scan * 16 + m_map * 16 + n_scan * 8 * kq
+    m_alg = m_map if m_reach is None else min(m_map, m_reach)
+    alg_bytes = n_scan * 16 + m_alg * 16 + n_scan * 8 * kq
     achieved = alg_bytes / (nn_avg_ms * 1e-3) / 1e9 if nn_avg_ms > 0 else 0.0
-    traffic = None
+    traffic, traffic_note = None, None
     pmc = os.path.join(ROOT, "profiles", "nn_traffic.json")
     if traffic_key and os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get(traffic_key)
+            rec = json.load(open(pmc))
+            if rec.get("kernel_sources_sha") == kernel_sources_sha():
+                traffic = rec.get(traffic_key)
+            else:
+                traffic_note = "profiles/nn_traffic.json was measured on other kernel sources (stamp mismatch): not reported"
         except Exception:
             traffic = None
     del prof
@@ -92,7 +123,9 @@ def nn_roofline(pkg, dev, chain, d_map, d_nrm, d_scan, n_scan, m_map, traffic_ke
     nnk = "nnk_ml_kernel" if os.environ.get("ICPMI_NNK_WG_FROM", "2").startswith("-") else "nnk_wg_kernel (+ nnk_ml_kernel, iterations 0-1)"
     return {"bound": "hbm", "kernel": nn1 if kq == 1 else nnk, "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
-            "avg_launch_us": nn_avg_ms * 1e3, "launches_timed": nn_cnt}
+            "map_points_charged": m_alg, "avg_launch_us": nn_avg_ms * 1e3, "launches_timed": nn_cnt,
+            **({"traffic_frac": traffic / (nn_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS} if traffic and nn_avg_ms > 0 else {}),
+            **({"traffic_note": traffic_note} if traffic_note else {})}
 
 
 def time_registrations(torch, icp, d_scan, steps, warmup):
@@ -369,7 +402,8 @@ def main():
         traffic_key = {"p2p": "hbm_bytes_per_launch", "p2plane": "hbm_bytes_per_launch_p2plane", "docs_knn6": "hbm_bytes_per_launch_knn6"}[args.chain]
         if args.map_points != M_MAP or args.scan_points != N_SCAN:
             traffic_key = None
-        out["roofline"] = nn_roofline(pkg, dev, chain, d_map, d_nrm, d_scan, args.scan_points, args.map_points, traffic_key)
+        out["roofline"] = nn_roofline(pkg, dev, chain, d_map, d_nrm, d_scan, args.scan_points, args.map_points, traffic_key,
+                                      m_reach=map_points_in_reach(np, sc["map"], sc["scan"], chain["max_dist"]))
 
         # ---- the other BASELINE configurations, same measurement (N = 1 only) ----
         if not args.no_extras and world == 1 and args.batch <= 1:
@@ -481,7 +515,8 @@ def main():
                     "config": f"BASELINE config 5's map on one GPU: 100k-pt scan vs 10M-pt map (scene x3.16, same density), {args.chain} chain",
                     "value": args.steps * ITERS_PER_STEP / el10, "unit": "iterations/s", "step_ms": step_stats(per10), "set_map_ms": sm10,
                     "pose_err_vs_ground_truth": {"m": g10t, "rad": g10r},
-                    "roofline": nn_roofline(pkg, dev, chain, d_map10, d_nrm10, d_scan10, args.scan_points, 10_000_000, "hbm_bytes_per_launch_10M")}
+                    "roofline": nn_roofline(pkg, dev, chain, d_map10, d_nrm10, d_scan10, args.scan_points, 10_000_000, "hbm_bytes_per_launch_10M",
+                                            m_reach=map_points_in_reach(np, sc10["map"], sc10["scan"], chain["max_dist"]))}
                 del d_map10, d_nrm10, d_scan10, sc10
             except Exception as e:  # a host without the memory for the 10 M scene: say so instead of failing the headline
                 extras["map_10M"] = {"error": repr(e)}

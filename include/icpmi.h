@@ -218,7 +218,9 @@ icpmi_status icpmi_transform(icpmi_handle h, const float T[16], const float* in4
 icpmi_status icpmi_knn(icpmi_handle h, const float* q4, int64_t n, int32_t k, float max_dist, int32_t allow_self,
                        int32_t* ids, float* d2);
 
-/* `OutlierFilters::compute` for the handle's chain on given matches (host arrays, k x n). */
+/* `OutlierFilters::compute` for the handle's chain on given matches (host arrays, k x n; ids = ORIGINAL map indices, needed by
+ * SurfaceNormal / GenericDescriptor / Robust; read_normals3 = the reading's `normals`, 3 x n, needed by SurfaceNormalOutlierFilter,
+ * whose map side comes from the normals handed to icpmi_set_map). */
 icpmi_status icpmi_outlier_weights(icpmi_handle h, const float* d2, const int32_t* ids, int32_t k, int64_t n,
                                    const float* read_normals3, float* weights, float* limit_out);
 

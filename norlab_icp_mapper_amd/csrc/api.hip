@@ -176,10 +176,7 @@ icpmi_status icpmi_set_config(icpmi_handle h, const icpmi_config* cfg)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->cfg = *cfg;
     // the cached loop graph was captured for the previous chain
-    if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; h->graph_n = -1; }
-    if (h->bgraph_exec) { hipGraphExecDestroy(h->bgraph_exec); h->bgraph_exec = nullptr; h->bgraph_sig = 0; }
-    for (int g = 0; g < 2; ++g) if (h->seg_exec[g]) { hipGraphExecDestroy(h->seg_exec[g]); h->seg_exec[g] = nullptr; }
-    h->seg_sig = 0; h->seg_n = -1;
+    drop_loop_graphs(h);
     return ICPMI_OK;
 }
 
@@ -225,10 +222,7 @@ icpmi_status icpmi_set_stream(icpmi_handle h, void* hip_stream)
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     h->stream = (hipStream_t)hip_stream;
     h->own_stream = false;
-    if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; h->graph_n = -1; }
-    if (h->bgraph_exec) { hipGraphExecDestroy(h->bgraph_exec); h->bgraph_exec = nullptr; h->bgraph_sig = 0; }
-    for (int g = 0; g < 2; ++g) if (h->seg_exec[g]) { hipGraphExecDestroy(h->seg_exec[g]); h->seg_exec[g] = nullptr; }
-    h->seg_sig = 0; h->seg_n = -1;
+    drop_loop_graphs(h);
     return ICPMI_OK;
 }
 
@@ -332,7 +326,7 @@ static icpmi_status register_impl(icpmi_handle h, const float* d_scan4, int64_t 
                                   float T_out[16], icpmi_stats* stats)
 {
     if (!T_out) { h->last_error = "register: T_out is null"; return ICPMI_ERR_INVALID_ARG; }
-    if (stats) memset(stats, 0, sizeof *stats);
+    if (stats) { memset(stats, 0, sizeof *stats); stats->sensor_noise_overlap = -1.f; } // -1 = "not computed" on EVERY path
     identity16(T_out);
     if (n < 0 || (n > 0 && !d_scan4)) { h->last_error = "register: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
     if (h->m <= 0) return ICPMI_OK; // "Ignoring attempt to perform ICP with an empty map" -> identity
@@ -350,11 +344,13 @@ static icpmi_status register_impl(icpmi_handle h, const float* d_scan4, int64_t 
     { const icpmi_status es = check_ext_filters(h); if (es != ICPMI_OK) return es; }
     LoopCfg lc = make_loop_cfg(h, fixed_iters);
     // sensor-noise overlap (icpmi_set_reading_sensor_noise): the noise row is one shot -- this registration consumes it
-    const bool sn = h->read_noise_n == n && n > 0 && d_n3 && !lc.ext && !lc.is_2d &&
-                    (lc.minimizer == ICPMI_MIN_POINT_TO_POINT || lc.minimizer == ICPMI_MIN_POINT_TO_PLANE);
+    // (PointToPointErrorMinimizer::getOverlap() needs `simpleSensorNoise` alone; only the point-to-plane variant also reads the reading's
+    // `normals` -- ADVICE r3)
+    const bool sn = h->read_noise_n == n && n > 0 && !lc.ext && !lc.is_2d &&
+                    (lc.minimizer == ICPMI_MIN_POINT_TO_POINT || (lc.minimizer == ICPMI_MIN_POINT_TO_PLANE && d_n3));
     h->read_noise_n = 0;
     lc.sensor_noise = sn ? 1 : 0;
-    lc.has_read_normals = (needs_rn || sn) ? 1 : 0;
+    lc.has_read_normals = (needs_rn || (sn && d_n3)) ? 1 : 0;
     if (n == 0) {
         // upstream: Trimmed/Median throw "no outlier to filter", otherwise "no point to minimize"
         bool quant = false;
@@ -430,7 +426,7 @@ icpmi_status icpmi_register_batch_dev(icpmi_handle h, int32_t batch, const float
         }
         return status ? ICPMI_OK : first;
     }
-    if (stats) memset(stats, 0, sizeof(icpmi_stats) * batch);
+    if (stats) { memset(stats, 0, sizeof(icpmi_stats) * batch); for (int b = 0; b < batch; ++b) stats[b].sensor_noise_overlap = -1.f; }
     LoopCfg lc = make_loop_cfg(h, fixed_iterations);
     return loop_run_batch(h, batch, d_scans4, n, lc, fixed_iterations > 0, T_out, stats, status);
 }
@@ -536,7 +532,7 @@ icpmi_status icpmi_minimize_step(icpmi_handle h, const float* reading4, int64_t 
         h->last_error = "InvalidField: PointToPlaneErrorMinimizer needs the descriptor 'normals' on the map";
         return ICPMI_ERR_MISSING_NORMALS;
     }
-    if (stats) memset(stats, 0, sizeof *stats);
+    if (stats) { memset(stats, 0, sizeof *stats); stats->sensor_noise_overlap = -1.f; }
     if (ensure_cap(h, &h->d_reading, &h->cap_reading, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
     HIP_TRY(h, hipMemcpyAsync(h->d_reading, reading4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, h->stream));
     // d_reading has new contents: a tile-sorted copy of what was there before (an icpmi_knn with the same n) must not be searched in

@@ -296,6 +296,19 @@ static inline icpmi_status ensure_cap(icpmi_ctx* c, T** p, size_t* cap, size_t n
     return ICPMI_OK;
 }
 
+// Every cached loop graph (fixed-count, batched, the two segment graphs of a checked loop) holds pointers, grid parameters, the map's mean
+// and its normals flag as they were at capture time: a rebuilt index or a changed stream invalidates all of them (only graph_exec
+// was dropped, and the signature of the segment graphs does not cover mean / m / has_normals / d_map_pn / the level arrays).
+static inline void drop_loop_graphs(icpmi_ctx* c)
+{
+    if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+    c->graph_n = -1; c->graph_sig = 0;
+    if (c->bgraph_exec) { hipGraphExecDestroy(c->bgraph_exec); c->bgraph_exec = nullptr; }
+    c->bgraph_sig = 0;
+    for (int g = 0; g < 2; ++g) if (c->seg_exec[g]) { hipGraphExecDestroy(c->seg_exec[g]); c->seg_exec[g] = nullptr; }
+    c->seg_sig = 0; c->seg_n = -1;
+}
+
 // scratch device allocation of one call: freed on every exit path (hipFree waits for work still using it)
 template <typename T>
 struct DevBuf {

@@ -1670,6 +1670,7 @@ static void fill_stats(icpmi_ctx* c, const LoopCfg& lc, int64_t n, icpmi_stats* 
     for (int f = 0; f < lc.n_out; ++f)
         if (lc.out_type[f] == ICPMI_OUT_TRIMMEDDIST || lc.out_type[f] == ICPMI_OUT_MEDIANDIST || lc.out_type[f] == ICPMI_OUT_VARTRIMMEDDIST) stats->trimmed_limit = hs->limits[f];
     stats->hard_queries = (int64_t)hs->hard_total;
+    stats->sensor_noise_overlap = -1.f; // "not computed" unless loop_run's sensor-noise pass overwrites it
     for (int i = 0; i < 2; ++i) { stats->reserved[2 * i] = (int32_t)(hs->dbg[i] & 0xffffffffu); stats->reserved[2 * i + 1] = (int32_t)(hs->dbg[i] >> 32); }
 }
 
@@ -1938,6 +1939,7 @@ static void batch_result(icpmi_ctx* c, const LoopCfg& lc, const IcpState* hs, in
         for (int f = 0; f < lc.n_out; ++f)
             if (lc.out_type[f] == ICPMI_OUT_TRIMMEDDIST || lc.out_type[f] == ICPMI_OUT_MEDIANDIST) stats->trimmed_limit = hs->limits[f];
         stats->hard_queries = (int64_t)hs->hard_total;
+        stats->sensor_noise_overlap = -1.f; // the batch path never runs the sensor-noise pass
     }
     for (int i = 0; i < 16; ++i) T_out[i] = (i % 5 == 0) ? 1.f : 0.f;
     if (status) *status = (icpmi_status)hs->error;
@@ -2111,14 +2113,28 @@ icpmi_status loop_single_step(icpmi_ctx* c, int64_t n, const LoopCfg& lc, const 
 icpmi_status loop_outlier_weights(icpmi_ctx* c, const LoopCfg& lc, const float* d2, const int32_t* ids, int k, int64_t n,
                                   const float* read_normals3, float* weights, float* limit_out)
 {
-    // matches arrive with ORIGINAL ids; the device tables are in sorted order, so SurfaceNormal
-    // filtering through this stage entry point needs the inverse permutation -- not offered here.
-    for (int f = 0; f < lc.n_out; ++f)
-        if (lc.out_type[f] == ICPMI_OUT_SURFACENORMAL) {
-            c->last_error = "icpmi_outlier_weights: SurfaceNormalOutlierFilter is only available inside icpmi_register";
-            return ICPMI_ERR_UNSUPPORTED;
+    // matches arrive with ORIGINAL ids; the device's normals table is in sorted order.  SurfaceNormalOutlierFilter (r4) reads the map's
+    // normals from the resident copy instead, which IS in the caller's order (d_raw_n3, padded to float4 for the kernel).
+    bool needs_sn = false;
+    for (int f = 0; f < lc.n_out; ++f) needs_sn |= lc.out_type[f] == ICPMI_OUT_SURFACENORMAL;
+    float4* d_ref_n4 = nullptr;
+    float* d_rn3 = nullptr;
+    if (needs_sn) {
+        if (!ids || !read_normals3 || !c->raw_has_normals || c->m_raw <= 0) {
+            c->last_error = "InvalidField: SurfaceNormalOutlierFilter needs ids, 'normals' on the reading and 'normals' on the map";
+            return ICPMI_ERR_MISSING_NORMALS;
         }
-    (void)read_normals3;
+        for (int64_t e = 0; e < (int64_t)k * n; ++e)
+            if (ids[e] >= c->m_raw) { c->last_error = "outlier_weights: id outside the map"; return ICPMI_ERR_INVALID_ARG; }
+        d_ref_n4 = scratch_get<float4>(c, 8, (size_t)c->m_raw + 1);
+        d_rn3 = scratch_get<float>(c, 9, (size_t)3 * n + 3);
+        if (!d_ref_n4 || !d_rn3) return ICPMI_ERR_HIP;
+        if (ensure_cap(c, &c->d_read_normals, &c->cap_read_normals, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+        HIP_TRY(c, hipMemcpyAsync(d_rn3, read_normals3, (size_t)3 * n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(pad_normals_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, (const float*)d_rn3, n, c->d_read_normals);
+        hipLaunchKernelGGL(pad_normals_kernel, dim3((int)((c->m_raw + 255) / 256)), dim3(256), 0, c->stream, (const float*)c->d_raw_n3, c->m_raw, d_ref_n4);
+        HIP_TRY(c, hipGetLastError());
+    }
     bool needs_ids = false;
     for (int f = 0; f < lc.n_out; ++f) {
         if (lc.out_type[f] == ICPMI_OUT_ROBUST && ((lc.out_iparam[f] >> 8) & 15) == ICPMI_DIST_POINT2PLANE) {
@@ -2130,7 +2146,7 @@ icpmi_status loop_outlier_weights(icpmi_ctx* c, const LoopCfg& lc, const float* 
             for (int64_t e = 0; e < (int64_t)k * n; ++e)
                 if (ids[e] >= c->m_raw) { c->last_error = "outlier_weights: id outside the map"; return ICPMI_ERR_INVALID_ARG; }
         }
-        needs_ids |= lc.out_type[f] == ICPMI_OUT_GENERICDESCRIPTOR || lc.out_type[f] == ICPMI_OUT_ROBUST;
+        needs_ids |= lc.out_type[f] == ICPMI_OUT_GENERICDESCRIPTOR || lc.out_type[f] == ICPMI_OUT_ROBUST || lc.out_type[f] == ICPMI_OUT_SURFACENORMAL;
     }
     const int64_t count = (int64_t)k * n;
     if (ensure_loop_buffers(c, n, k) != ICPMI_OK) return ICPMI_ERR_HIP;
@@ -2145,8 +2161,10 @@ icpmi_status loop_outlier_weights(icpmi_ctx* c, const LoopCfg& lc, const float* 
     DevBuf<float> d_w;
     HIP_TRY(c, d_w.alloc((size_t)count));
     const int blocks = (int)((count + 255) / 256);
-    if (blocks) hipLaunchKernelGGL(weights_kernel, dim3(blocks), dim3(256), 0, c->stream, count, l1, c->d_state, c->d_normals_sorted,
-                                   (const float4*)nullptr, c->d_sidx, c->d_d2, d_w, c->raw_has_scalar ? c->d_raw_s : (const float*)nullptr);
+    if (blocks) hipLaunchKernelGGL(weights_kernel, dim3(blocks), dim3(256), 0, c->stream, count, l1, c->d_state,
+                                   needs_sn ? (const float4*)d_ref_n4 : (const float4*)c->d_normals_sorted,
+                                   needs_sn ? (const float4*)c->d_read_normals : (const float4*)nullptr, c->d_sidx, c->d_d2, d_w,
+                                   c->raw_has_scalar ? c->d_raw_s : (const float*)nullptr);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(weights, d_w, (size_t)count * sizeof(float), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(c->h_state, c->d_state, sizeof(IcpState), hipMemcpyDeviceToHost, c->stream);

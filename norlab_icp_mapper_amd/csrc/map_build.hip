@@ -729,9 +729,12 @@ grid_chosen:
         { const icpmi_status us = upload_small(c, c->d_lvl_tab, tab, sizeof tab); if (us != ICPMI_OK) return us; }
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // (a deferred build steered its edge with the PREVIOUS build's occupancy; its own count has arrived in the pinned word by now:
+    //  icpmi_get_grid_info reports the grid it describes -- ADVICE r3)
+    if (c->h_nocc && c->nocc_m == m) c->n_occupied = *c->h_nocc;
     c->m = m;
     c->qsorted_n = -1; c->qsorted_src = nullptr; // tiles are defined on the grid of the map
     // any cached loop graph captured pointers / grid parameters of the previous map
-    if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; c->graph_n = -1; }
+    drop_loop_graphs(c);
     return ICPMI_OK;
 }

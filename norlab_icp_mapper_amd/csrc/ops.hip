@@ -472,7 +472,7 @@ static void share_stream(icpmi_ctx* c, icpmi_ctx* t)
     if (t->stream) (void)hipStreamSynchronize(t->stream);
     if (t->own_stream && t->stream) (void)hipStreamDestroy(t->stream);
     t->stream = c->stream; t->own_stream = false;
-    if (t->graph_exec) { hipGraphExecDestroy(t->graph_exec); t->graph_exec = nullptr; t->graph_n = -1; }
+    drop_loop_graphs(t);
 }
 
 static icpmi_status make_temp(icpmi_ctx* c, TempCtx& t)

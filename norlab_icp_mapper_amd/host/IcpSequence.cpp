@@ -396,7 +396,9 @@ Mat4 GpuICPSequence::operator()(const DataPoints& readingIn)
         normals = reading.getDescriptorByName("normals").data.data();
     // ErrorMinimizer::getOverlap() (Mapper.cpp:219): a reading that carries `simpleSensorNoise` (and normals) gets upstream's
     // sensor-noise count instead of the weighted ratio; the row rides to the device ahead of the registration (one shot)
-    if (normals && reading.descriptorExists("simpleSensorNoise") && reading.getDescriptorByName("simpleSensorNoise").span == 1)
+    // (PointToPointErrorMinimizer::getOverlap() needs the noise row alone, only PointToPlane also the reading's normals)
+    if ((normals || cfg.minimizer == ICPMI_MIN_POINT_TO_POINT) && reading.descriptorExists("simpleSensorNoise") &&
+        reading.getDescriptorByName("simpleSensorNoise").span == 1)
         check(h, icpmi_set_reading_sensor_noise(h, reading.getDescriptorByName("simpleSensorNoise").data.data(), (int64_t)reading.getNbPoints()));
     check(h, icpmi_register(h, reading.features.data(), (int64_t)reading.getNbPoints(), normals, T.data(), &lastStats));
     return T;

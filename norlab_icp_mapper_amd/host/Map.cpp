@@ -236,6 +236,20 @@ void Map::syncLocalFromDevice()
     deviceAhead = false;
 }
 
+// The resident chain serves planar maps (is3D == false) because a planar pose maps z = 0 to z = 0 exactly and the kernels then see what the
+// reference's 2-D branch computes.  That argument needs every input point at z == 0 and a pose whose row / column 2 is exactly identity:
+// checked here, anything else takes the host-pointer path.
+static bool planarPose(const Mat4& T)
+{
+    return T(2, 0) == 0.f && T(2, 1) == 0.f && T(0, 2) == 0.f && T(1, 2) == 0.f && T(2, 2) == 1.f && T(2, 3) == 0.f;
+}
+static bool planarCloud(const DataPoints& c)
+{
+    const size_t n = c.getNbPoints();
+    for (size_t i = 0; i < n; ++i) if (c.features[4 * i + 2] != 0.f) return false;
+    return true;
+}
+
 bool Map::residentPlan(const DataPoints& input, const DataPointsFilters& postFilters, ResidentProgram& prog) const
 {
     static const bool enabled = [] { const char* e = std::getenv("NIM_RESIDENT_MAP_UPDATE"); return !e || std::atoi(e) != 0; }();
@@ -244,6 +258,7 @@ bool Map::residentPlan(const DataPoints& input, const DataPointsFilters& postFil
     //  kernels see what the host-pointer operators see -- spherical coordinates with elevation asin(0 / r) = 0, the reference's
     //  is3D == false branch of DynamicPointsMapperModule.cpp:156-172; normals through the planar eigen-solve, icpmi_config::is_2d)
     if (!enabled || mapperModuleVec.empty() || icp.hasReferenceFilters() || !icp.genericDescriptorName().empty()) return false;
+    if (!is3D && !planarCloud(input)) return false;
     prog = ResidentProgram{};
     auto adopt = [&](bool ok, const icpmi_map_op& op, const std::string& name) {
         if (!ok) return false;
@@ -360,6 +375,7 @@ void Map::dropLocalCloudAfterFailedUpdate()
 bool Map::tryResidentUpdate(const DataPoints& input, const Mat4& pose, const DataPointsFilters& postFilters)
 {
     ResidentProgram prog;
+    if (!is3D && !planarPose(pose)) return false;
     if (!residentPlan(input, postFilters, prog)) return false;
     const bool first = isLocalPointCloudEmpty();
     if (!deviceAhead) residentCount = (int64_t)localPointCloud.getNbPoints();
@@ -378,8 +394,9 @@ bool Map::tryResidentUpdate(const DataPoints& input, const Mat4& pose, const Dat
     return true;
 }
 
-bool Map::canStageScan(const DataPoints& input, const DataPointsFilters& postFilters)
+bool Map::canStageScan(const DataPoints& input, const DataPointsFilters& postFilters, const Mat4* pose)
 {
+    if (!is3D && pose && !planarPose(*pose)) return false;
     // descriptors that rotate with the cloud would have to be transformed along: host path
     if (input.descriptorExists("normals") || input.descriptorExists("observationDirections")) return false;
     std::lock_guard<std::mutex> g(localPointCloudLock);

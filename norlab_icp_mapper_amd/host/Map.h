@@ -64,7 +64,8 @@ public:
     bool getNewLocalPointCloud(DataPoints& out);
     // processInput with the scan staged on the GPU: can this input / post-filter combination be updated on the resident map
     // (see tryResidentUpdate), and the update itself for the scan kept by GpuICPSequence::registerWithPrior
-    bool canStageScan(const DataPoints& inputInSensorFrame, const DataPointsFilters& postFilters);
+    // (pose: a planar map takes the resident chain only under an exactly planar pose, see planarInputs in Map.cpp)
+    bool canStageScan(const DataPoints& inputInSensorFrame, const DataPointsFilters& postFilters, const Mat4* pose = nullptr);
     void updateLocalPointCloudStaged(const DataPoints& inputDescriptors, const Mat4& correction, const Mat4& pose, const DataPointsFilters& postFilters);
     DataPoints getGlobalPointCloud();                                                     // Map.cpp:552-573
     void setGlobalPointCloud(const DataPoints& cloud);                                    // Map.cpp:575-588

@@ -178,7 +178,10 @@ void Mapper::processInput(const DataPoints& filteredInputInSensorFrame, const Ma
     // One upload per scan when the map update can run on the resident map: the scan is moved by the prior, registered and --
     // if the policy asks for it -- moved by the correction and merged, all on the GPU (icpmi_register_prior /
     // icpmi_map_update_staged).  Offline only: an asynchronous update would race the next scan for the staged buffer.
-    if (!isOnline && !icp.chainNeedsReadingNormals() && !icp.hasReadingFilters() && map.canStageScan(filteredInputInSensorFrame, mapPostFilters)) {
+    // (a reading with `simpleSensorNoise` takes the host-pointer path below: icpmi_register_prior does not carry the noise row that
+    // ErrorMinimizer::getOverlap() then needs, Mapper.cpp:219)
+    if (!isOnline && !icp.chainNeedsReadingNormals() && !icp.hasReadingFilters() && !filteredInputInSensorFrame.descriptorExists("simpleSensorNoise") &&
+        map.canStageScan(filteredInputInSensorFrame, mapPostFilters, &estimatedPose)) {
         const bool bootstrap = map.isLocalPointCloudEmpty();
         Mat4 correction;
         lastScanGrewMap = false;
@@ -193,7 +196,7 @@ void Mapper::processInput(const DataPoints& filteredInputInSensorFrame, const Ma
             lastTimeMapWasUpdated = timeStamp;
             lastPoseWhereMapWasUpdated = correctedPose;
             lastScanGrewMap = true;
-            if (map.canStageScan(filteredInputInSensorFrame, mapPostFilters))
+            if (map.canStageScan(filteredInputInSensorFrame, mapPostFilters, &correctedPose))
                 map.updateLocalPointCloudStaged(filteredInputInSensorFrame, bootstrap ? Mat4::identity() : correction, correctedPose, mapPostFilters);
             else { // paging in updatePose changed the picture (e.g. the local cloud was emptied): the host path
                 DataPoints inMap = transformation.compute(filteredInputInSensorFrame, estimatedPose);

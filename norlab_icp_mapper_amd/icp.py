@@ -358,7 +358,7 @@ class ICPSequence:
         self._check(self._lib.icpmi_knn(self._h, q.ctypes.data, q.shape[0], k, max_dist, int(allow_self), ids.ctypes.data, d2.ctypes.data))
         return ids, d2
 
-    def outlierWeights(self, d2, ids=None):
+    def outlierWeights(self, d2, ids=None, read_normals=None):
         d2 = np.ascontiguousarray(d2, dtype=np.float32)
         n, k = d2.shape
         w = np.empty_like(d2)
@@ -367,7 +367,11 @@ class ICPSequence:
         if ids is not None:
             ids = np.ascontiguousarray(ids, dtype=np.int32)
             idp = ids.ctypes.data
-        self._check(self._lib.icpmi_outlier_weights(self._h, d2.ctypes.data, idp, k, n, None, w.ctypes.data, C.byref(lim)))
+        rnp = None
+        if read_normals is not None:
+            read_normals = _f32c(read_normals, 3)
+            rnp = read_normals.ctypes.data
+        self._check(self._lib.icpmi_outlier_weights(self._h, d2.ctypes.data, idp, k, n, rnp, w.ctypes.data, C.byref(lim)))
         return w, float(lim.value)
 
     def minimizeStep(self, reading_centred, T_iter=None):

@@ -1111,8 +1111,9 @@ int orc_icp_register(orc_icp* s, const float* scan4, int64_t n, const float* sca
     /* ErrorMinimizer::getOverlap() (read at Mapper.cpp:219) when the reading carries `simpleSensorNoise` and `normals` (SURVEY B.6,
      * upstream as recalled): over the LAST iteration's error elements (w != 0, finite match; `step`, `ids`, `w` still hold them) --
      * PointToPoint: |p - q| < mean|p - q| + noise_i; PointToPlane: |(p - q) . n_i / |n_i|| < noise_i, n_i the reading's normal */
-    if (!err && noise_n == n && n > 0 && step_normals && st->iterations > 0 && !cfg->is_2d &&
-        (cfg->minimizer == ORC_MIN_POINT_TO_POINT || cfg->minimizer == ORC_MIN_POINT_TO_PLANE)) {
+    /* (PointToPointErrorMinimizer::getOverlap() asks for `simpleSensorNoise` alone; only the point-to-plane variant also for `normals`) */
+    if (!err && noise_n == n && n > 0 && st->iterations > 0 && !cfg->is_2d &&
+        (cfg->minimizer == ORC_MIN_POINT_TO_POINT || (cfg->minimizer == ORC_MIN_POINT_TO_PLANE && step_normals))) {
         double pairs = 0.0, sum = 0.0;
         for (int pass = 0; pass < 2; ++pass) {
             const float mean = pairs > 0.0 ? (float)(sum / pairs) : 0.f;

@@ -55,6 +55,49 @@ def test_config3_gpu_normals_then_point_to_plane_against_oracle_normals_then_ora
     assert gt < 5e-3 and gr < 5e-4, (gt, gr)
 
 
+# ------------------------------------------------------------------------------------------------ configs 2 / 3 at the BASELINE size
+@pytest.fixture(scope="module")
+def full_scene():
+    from norlab_icp_mapper_amd import synth
+    return synth.make_scene(m=1_000_000, n=100_000)       # BASELINE.json configs 2 / 3: 100 k-point scan vs 1 M-point map
+
+
+@pytest.mark.parametrize("name,minimizer,normals", [("config2_p2p", 1, "analytic"), ("config3_p2plane", 2, "analytic"), ("config3_p2plane_filter", 2, "filter")])
+def test_full_size_checked_registration_matches_oracle(amd, oracle, full_scene, name, minimizer, normals):
+    """The production-shape chain (Counter 40 + Differential, SURVEY.md 8d chains A / B) at the FULL BASELINE size against the oracle:
+    iterations, stop reason, pairs of the last iteration, trimmed limit and pose (VERDICT r3 missing 4: until r4 this comparison
+    existed at full size only inside bench.py).  The oracle registers in ~1 s on 16 threads; its kd-tree build is the long part."""
+    sc = full_scene
+    kw = dict(minimizer=minimizer, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=40, use_differential=1)
+    icp = amd.ICPSequence(**kw)
+    nrm = sc["normals"]
+    if normals == "filter":                                   # config 3 (ii): SurfaceNormalDataPointsFilter{knn: 10} run on the map
+        nrm = icp.surfaceNormals(sc["map"], knn=10)
+    assert icp.setMap(sc["map"], nrm)
+    T = icp(sc["scan"])
+    o = oracle.OracleICP(oracle.make_config(nthreads=min(16, len(os.sched_getaffinity(0))), **kw))
+    o.setMap(sc["map"], nrm)
+    err, T_ref = o(sc["scan"])
+    assert err == 0
+    assert icp.stats.iterations == o.stats.iterations and icp.stats.stop_reason == o.stats.stop_reason, (icp.stats.iterations, o.stats.iterations)
+    assert icp.stats.pairs == o.stats.pairs
+    assert icp.stats.trimmed_limit == o.stats.trimmed_limit
+    dt, dr = amd.synth.pose_error(T, T_ref)
+    assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (name, dt, dr)
+    gt, gr = amd.synth.pose_error(T, sc["T_gt"])
+    assert gt < 5e-3 and gr < 5e-4, (gt, gr)
+    # ... and throughput mode (what bench.py times: Counter only, fixed 20 iterations) lands where the oracle lands
+    import torch
+    d = torch.from_numpy(sc["scan"]).cuda()
+    T20 = icp.registerDev(d.data_ptr(), d.shape[0], fixed_iterations=20)
+    o20 = oracle.OracleICP(oracle.make_config(nthreads=min(16, len(os.sched_getaffinity(0))), **dict(kw, max_iterations=20, use_differential=0)))
+    o20.setMap(sc["map"], nrm)
+    err, T20_ref = o20(sc["scan"])
+    assert err == 0 and icp.stats.iterations == 20 == o20.stats.iterations
+    dt, dr = amd.synth.pose_error(T20, T20_ref)
+    assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (name, "fixed 20", dt, dr)
+
+
 # ------------------------------------------------------------------------------------------------ config 4
 CONFIG4_YAML = """
 input:

@@ -274,3 +274,69 @@ def test_sensor_noise_overlap_matches_oracle(amd, oracle, mid_scene, minimizer, 
     # and the fixed-count graph path keeps the pose it would have had without the overlap pass
     dt, dr = amd.synth.pose_error(T, T_ref)
     assert dt <= 1e-4 and dr <= 1e-4
+
+
+def test_sensor_noise_overlap_p2p_needs_no_reading_normals(amd, oracle, mid_scene):
+    """PointToPointErrorMinimizer::getOverlap() needs `simpleSensorNoise` alone (ADVICE r3): a reading without normals still gets the
+    sensor-noise count; the point-to-plane variant without reading normals falls back to the weighted ratio (-1)."""
+    sc = mid_scene
+    n = sc["scan"].shape[0]
+    noise = np.random.default_rng(12).uniform(0.002, 0.03, n).astype(np.float32)
+    kw = dict(minimizer=1, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=12, use_differential=1)
+    icp = amd.ICPSequence(**kw)
+    assert icp.setMap(sc["map"], sc["normals"])
+    icp.setReadingSensorNoise(noise)
+    icp(sc["scan"])
+    o = oracle.OracleICP(oracle.make_config(nthreads=8, **kw))
+    o.setMap(sc["map"], sc["normals"])
+    o.setReadingNoise(noise)
+    err, _ = o(sc["scan"])
+    assert err == 0 and icp.stats.iterations == o.stats.iterations and icp.stats.pairs == o.stats.pairs
+    assert 0.0 < o.stats.sensor_noise_overlap < 1.0
+    assert abs(icp.stats.sensor_noise_overlap - o.stats.sensor_noise_overlap) <= 2.0 / max(o.stats.pairs, 1)
+    kw2 = dict(kw, minimizer=2)
+    icp2 = amd.ICPSequence(**kw2)
+    assert icp2.setMap(sc["map"], sc["normals"])
+    icp2.setReadingSensorNoise(noise)
+    icp2(sc["scan"])
+    assert icp2.stats.sensor_noise_overlap == -1.0
+    assert icp2.errorMinimizer.getOverlap() == pytest.approx(icp2.stats.weighted_point_used_ratio)
+
+
+def test_sensor_noise_sentinel_on_every_stats_path(amd, mid_scene):
+    """stats.sensor_noise_overlap is -1 ("not computed") on every path that fills stats -- minimizeStep, the batch entry, a handle
+    without a map -- so that getOverlap() falls back to the weighted ratio and never reads a zeroed field."""
+    import torch
+    sc = mid_scene
+    icp = amd.ICPSequence(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=6)
+    icp(sc["scan"])                                        # no map: identity
+    assert icp.stats.sensor_noise_overlap == -1.0
+    assert icp.setMap(sc["map"], sc["normals"])
+    icp.minimizeStep(sc["scan"] - np.r_[icp.getMapMean(), 0].astype(np.float32))
+    assert icp.stats.sensor_noise_overlap == -1.0
+    assert icp.errorMinimizer.getOverlap() == pytest.approx(icp.stats.weighted_point_used_ratio) and icp.errorMinimizer.getOverlap() > 0.1
+    dev = [torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda() for x in (sc["scan"], sc["scan"][::2].copy())]
+    _, stats, status = icp.registerBatchDev([d.data_ptr() for d in dev], [d.shape[0] for d in dev])
+    assert not any(status) and all(s.sensor_noise_overlap == -1.0 for s in stats)
+
+
+def test_set_map_with_then_without_normals_drops_segment_graphs(amd, oracle, mid_scene):
+    """A checked loop replays segment graphs; a rebuild of the index -- same cloud, same grid, but normals gone, or another cloud of the
+    same size -- must not replay a graph captured for the previous map (only the fixed-count graph was dropped)."""
+    sc = mid_scene
+    kw = dict(minimizer=1, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=40, use_differential=1)
+    icp = amd.ICPSequence(**kw)
+    o = oracle.OracleICP(oracle.make_config(nthreads=8, **kw))
+    assert icp.setMap(sc["map"], sc["normals"])
+    T0 = icp(sc["scan"])
+    assert icp.setMap(sc["map"], None)                     # same points, same grid: normals gone
+    T1 = icp(sc["scan"])
+    assert np.array_equal(T0, T1)
+    shifted = sc["map"].copy(); shifted[:, 0] += np.float32(0.25)   # same size, same extent up to a shift: the mean moves
+    assert icp.setMap(shifted, None)
+    T2 = icp(sc["scan"])
+    o.setMap(shifted, None)
+    err, T2_ref = o(sc["scan"])
+    assert err == 0 and icp.stats.iterations == o.stats.iterations
+    dt, dr = amd.synth.pose_error(T2, T2_ref)
+    assert dt <= 1e-4 and dr <= 1e-4
