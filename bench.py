@@ -144,6 +144,80 @@ def time_registrations(torch, icp, d_scan, steps, warmup):
     return T, time.perf_counter() - t_all, per
 
 
+def minstd_random_sampling_keep(np, n, prob=0.75, seed=1):
+    """RandomSamplingDataPointsFilter{prob, randomSamplingMethod 0, seed} as host/IcpSequence.cpp evaluates it (the filter of
+    PM::ICPSequence::setDefault()): std::minstd_rand (x <- 48271 x mod 2^31 - 1), one number float(x) / 2147483645.0f per point, kept iff
+    number < prob, never more than floor(n prob) + 1 points.  (r3 fed the default chain a numpy default_rng stand-in of the same size.)"""
+    x = seed % 2147483647 or 1
+    xs = np.empty(n, dtype=np.float32)
+    for i in range(n):
+        x = (x * 48271) % 2147483647
+        xs[i] = x
+    keep = (xs / np.float32(2147483645.0)) < np.float32(prob)
+    n_out = int(np.float32(n) * np.float32(prob))
+    over = np.nonzero(np.cumsum(keep) > n_out + 1)[0]
+    if over.size:
+        keep[over[0]:] = False
+    return keep
+
+
+def circle_scans(pkg, n_scans, n_points, scale, rank, radius=20.0):
+    """BASELINE config 5's streams: scan s of rank r is seeded 100 + 1000 r + s and taken from a sensor on a circle of
+    radius 20 m; each is an independent sample of the scene's surfaces within 60 m of its sensor, moved by T_gt^-1 (identity prior)."""
+    import math as _m
+    out = []
+    for sidx in range(n_scans):
+        th = 2.0 * _m.pi * (sidx + 0.37 * rank) / max(n_scans, 1)
+        sc = pkg.synth.make_scene(m=8, n=n_points, scale=scale, seed_scan=100 + 1000 * rank + sidx,
+                                  sensor=(radius * _m.cos(th), radius * _m.sin(th), 1.5))
+        out.append(sc["scan"])
+    return out
+
+
+def config5_stream(np, torch, pkg, dev, d_map, d_nrm, d_scans, chain, min_dist, comm, barrier):
+    """One rank's part of BASELINE config 5: every scan is registered against the shared map (Counter 40 + Differential: what
+    Mapper::processInput runs) and followed by ONE map-growth epoch (icpmi_staged_merge_allgather: PointDistance accept against the
+    resident map, all-gather of the accepted points, rank-ordered merge, append, index rebuild on every replica) -- registration AND
+    epoch inside the timed region.  comm: None (single rank), ("rccl", id, world, rank) or ("loopback", R, shift)."""
+    import os as _os
+    icp = pkg.ICPSequence(device=dev, max_iterations=40, use_differential=1, **chain)
+    assert icp.setMapDev(d_map.data_ptr(), d_map.shape[0], d_nrm.data_ptr() if d_nrm is not None else None)
+    if comm is not None and comm[0] == "loopback":
+        _os.environ["ICPMI_COMM_LOOPBACK"] = str(comm[1]); _os.environ["ICPMI_COMM_LOOPBACK_SHIFT"] = repr(comm[2])
+        try:
+            icp.commInit(bytes(128), 1, 0)
+        finally:
+            del _os.environ["ICPMI_COMM_LOOPBACK"]; del _os.environ["ICPMI_COMM_LOOPBACK_SHIFT"]
+    elif comm is not None and comm[0] == "rccl":
+        icp.commInit(comm[1], comm[2], comm[3])
+    eye = np.eye(4, dtype=np.float32)
+    # warm-up: one scan's registration + epoch on a throw-away handle state would grow the map; instead the first scan is registered once
+    # untimed (graphs, allocations) and its epoch is left to the timed loop
+    icp.registerWithPriorDev(d_scans[0].data_ptr(), d_scans[0].shape[0], eye)
+    icp.stageDiscard()
+    barrier()
+    reg_ms, ep_ms, its, accepted, appended = [], [], 0, [], []
+    t0 = time.perf_counter()
+    for d in d_scans:
+        ta = time.perf_counter()
+        corr = icp.registerWithPriorDev(d.data_ptr(), d.shape[0], eye)
+        its += icp.stats.iterations
+        tb = time.perf_counter()
+        mine, app, new_m = icp.stagedMergeAllGather(corr, min_dist, normals_knn=0)
+        tc = time.perf_counter()
+        reg_ms.append((tb - ta) * 1e3); ep_ms.append((tc - tb) * 1e3); accepted.append(mine); appended.append(app)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    cr, cme, ckind = icp.commInfo()
+    res = {"scans": len(d_scans), "elapsed_s": elapsed, "iterations": its, "register_ms": step_stats(reg_ms), "merge_epoch_ms": step_stats(ep_ms),
+           "accepted_per_scan_this_rank": accepted, "appended_per_epoch_all_ranks": appended, "map_points_after": new_m,
+           "rccl_ranks": cr, "rccl_rank": cme, "communicator": {0: "none", 1: "rccl", 2: "loopback"}[ckind]}
+    if comm is not None:
+        icp.commDestroy()
+    del icp
+    return res
+
+
 def dry_launch(args):
     """The launcher path without GPUs (tests/test_bench_launch.py): every rank joins a gloo group, the ranks are counted by an
     all-reduce and rank 0 prints the one JSON line."""
@@ -186,6 +260,10 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the `chains` object (configs 3 / 5 and the batch of 8)")
     ap.add_argument("--cpu-iters", type=int, default=10, help="iterations of the single-threaded cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work of the multi-threaded cpu_baseline leg")
+    ap.add_argument("--workload", default="registration", choices=["registration", "config5"],
+                    help="registration (default, the north-star headline): independent 20-iteration registrations; config5: BASELINE config 5 -- "
+                         "every rank streams --scans scans against the shared 10 M-point map, one RCCL merge epoch per scan INSIDE the timed region")
+    ap.add_argument("--scans", type=int, default=8, help="scans per rank of --workload config5")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launcher check without GPUs: start the ranks (gloo), count them with an all-reduce, print one JSON line from rank 0")
     args = ap.parse_args()
@@ -237,6 +315,51 @@ def main():
 
     import norlab_icp_mapper_amd as pkg
 
+    def barrier():
+        if use_pg:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- --workload config5: scan streams against the shared 10 M-point map, one merge epoch per scan in the timed region ----
+    if args.workload == "config5":
+        m5 = args.map_points if args.map_points != M_MAP else 10_000_000
+        scale5 = args.scale if args.scale != 1.0 else 3.16
+        chain = dict(CHAINS[args.chain])
+        sc5 = pkg.synth.make_scene(m=m5, n=8, scale=scale5)
+        d_map = torch.from_numpy(sc5["map"]).cuda()
+        d_nrm = torch.from_numpy(sc5["normals"]).cuda() if chain["minimizer"] == 2 else None
+        d_scans = [torch.from_numpy(x).cuda() for x in circle_scans(pkg, args.scans, args.scan_points, scale5, rank)]
+        comm = None
+        if use_pg:
+            box = [pkg.ICPSequence.commUniqueId() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            comm = ("rccl", box[0], world, rank)
+        res = config5_stream(np, torch, pkg, dev, d_map, d_nrm, d_scans, chain, 0.15, comm, barrier)
+        el = torch.tensor([res["elapsed_s"], float(res["iterations"])], dtype=torch.float64, device="cuda")
+        each = [torch.zeros_like(el) for _ in range(world)]
+        if use_pg:
+            dist.all_gather(each, el)
+        else:
+            each = [el]
+        elapsed = max(float(e[0].item()) for e in each)
+        its_all = sum(float(e[1].item()) for e in each)
+        out = {"metric": "ICP iterations/sec, 100k-pt scan vs 1M-pt map", "value": its_all / elapsed, "unit": "iterations/s", "n_gpus": world,
+               "steps": args.scans, "warmup": 1, "ms_per_step": elapsed / args.scans * 1e3, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"BASELINE config 5: {world} scan stream(s) x {args.scans} synthetic {args.scan_points}-pt scans vs the shared "
+                                      f"{m5}-pt map (scene x{scale5}), {args.chain} chain, Counter 40 + Differential, one map-growth epoch per scan "
+                                      f"(PointDistance 0.15 m accept + RCCL all-gather + rank-ordered merge + append + index rebuild) inside the timed region",
+                          "chain": args.chain, "parallelism": f"scan-sharded x{world}, map replicated, RCCL all-gather of accepted points per scan"},
+               "scans_per_s": world * args.scans / elapsed, "per_rank_elapsed_s": [float(e[0].item()) for e in each],
+               "per_rank_iterations": [float(e[1].item()) for e in each], "rank0": res}
+        if rank == 0:
+            sys.stdout.flush()
+            os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        if use_pg:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     # ---- workload: replicated map, one scan stream per rank ----
     sc = pkg.synth.make_scene(m=args.map_points, n=args.scan_points, seed_scan=43 + 1000 * rank, scale=args.scale)
     chain = dict(CHAINS[args.chain])
@@ -275,11 +398,6 @@ def main():
 
     for _ in range(args.warmup):
         step()
-
-    def barrier():
-        if use_pg:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     barrier()
     t0 = time.perf_counter()
@@ -445,6 +563,26 @@ def main():
                 extras["docs_knn6"]["pose_err_vs_cpu"] = {"m": e6t, "rad": e6r}
                 extras["docs_knn6"]["cpu_iterations_per_s"] = o6.stats.iterations / o6.stats.seconds_total
             del icp6
+            # what Mapper::processInput runs (Mapper.cpp:213): Counter 40 + Differential -- a registration of data-dependent length, segment graphs
+            icpc = pkg.ICPSequence(device=dev, minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=40, use_differential=1)
+            icpc.setMapDev(d_map.data_ptr(), d_map.shape[0], d_nrm.data_ptr())
+            for _ in range(5):
+                Tc = icpc.registerDev(d_scan.data_ptr(), d_scan.shape[0])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter(); repsc, itsc, perc = 50, 0, []
+            for _ in range(repsc):
+                ts = time.perf_counter()
+                Tc = icpc.registerDev(d_scan.data_ptr(), d_scan.shape[0]); itsc += icpc.stats.iterations
+                perc.append((time.perf_counter() - ts) * 1e3)
+            torch.cuda.synchronize()
+            elc = time.perf_counter() - t0
+            gct, gcr = pkg.synth.pose_error(Tc, sc["T_gt"])
+            extras["checked_p2plane"] = {
+                "config": "production shape (Mapper.cpp:213): 100k-pt scan vs 1M-pt map, point-to-plane, TrimmedDist 0.85, Counter 40 + Differential(1e-3, 1e-3, 3)",
+                "ms_per_registration": elc / repsc * 1e3, "iterations_per_registration": itsc / repsc, "us_per_iteration": elc / max(itsc, 1) * 1e6,
+                "value": itsc / elc, "unit": "iterations/s", "step_ms": step_stats(perc), "stop_reason": int(icpc.stats.stop_reason),
+                "pose_err_vs_ground_truth": {"m": gct, "rad": gcr}}
+            del icpc
             # PM::ICPSequence::setDefault() -- the chain of a configuration without an `icp:` key (Mapper.cpp:74-78): SamplingSurfaceNormal
             # on the reference at every setMap (device: icpmi_sampling_surface_normal), RandomSampling(0.75) on the reading, KDTree knn 1,
             # TrimmedDist 0.85, PointToPlane, Counter 40 + Differential
@@ -458,7 +596,7 @@ def main():
                 t0 = time.perf_counter()
                 icpd.setMap(ref, nrm_ssn)
                 sm_ms = (time.perf_counter() - t0) * 1e3
-                keep = np.random.default_rng(7).random(sc["scan"].shape[0]) < 0.75       # (a stand-in of the same size for the seeded minstd stream)
+                keep = minstd_random_sampling_keep(np, sc["scan"].shape[0], 0.75, seed=1)   # the seeded minstd stream of the host filter
                 d_read = torch.from_numpy(np.ascontiguousarray(sc["scan"][keep])).cuda()
                 for _ in range(3):
                     Td = icpd.registerDev(d_read.data_ptr(), d_read.shape[0])
@@ -517,9 +655,39 @@ def main():
                     "pose_err_vs_ground_truth": {"m": g10t, "rad": g10r},
                     "roofline": nn_roofline(pkg, dev, chain, d_map10, d_nrm10, d_scan10, args.scan_points, 10_000_000, "hbm_bytes_per_launch_10M",
                                             m_reach=map_points_in_reach(np, sc10["map"], sc10["scan"], chain["max_dist"]))}
+                # BASELINE config 5 as far as one GPU goes: a stream of scans against the 10 M-point map, one map-growth epoch per scan
+                # (single rank: the epoch is accept + compaction + append + index rebuild, no exchange)
+                try:
+                    c5scans = [torch.from_numpy(x).cuda() for x in circle_scans(pkg, 6, args.scan_points, 3.16, 0)]
+                    r5 = config5_stream(np, torch, pkg, dev, d_map10, None if chain["minimizer"] != 2 else d_nrm10, c5scans, chain, 0.15, None, barrier)
+                    extras["config5_stream_1gpu"] = {
+                        "config": "BASELINE config 5 on one GPU: 6 x 100k-pt scans (sensors on a 20 m circle, seeds 100 + s) vs the 10M-pt map, Counter 40 + "
+                                  "Differential, one PointDistance(0.15 m) map-growth epoch per scan inside the timed region",
+                        "scans_per_s": r5["scans"] / r5["elapsed_s"], "value": r5["iterations"] / r5["elapsed_s"], "unit": "iterations/s", **r5}
+                    del c5scans
+                except Exception as e:  # noqa: BLE001
+                    extras["config5_stream_1gpu"] = {"error": repr(e)}
                 del d_map10, d_nrm10, d_scan10, sc10
             except Exception as e:  # a host without the memory for the 10 M scene: say so instead of failing the headline
                 extras["map_10M"] = {"error": repr(e)}
+            # the replicated work of the merge as the rank count grows, on ONE GPU through the loopback communicator (csrc/comm.hip: every
+            # simulated rank hands in this rank's accepted block, rank r's moved r x 0.4 m along x): R = 1, 2, 4, 8
+            try:
+                lb = {}
+                lscans = [torch.from_numpy(x).cuda() for x in circle_scans(pkg, 5, args.scan_points, args.scale, 0)]
+                for R in (1, 2, 4, 8):
+                    rr = config5_stream(np, torch, pkg, dev, d_map, None if chain["minimizer"] != 2 else d_nrm, lscans, chain, 0.15,
+                                        None if R == 1 else ("loopback", R, 0.4), barrier)
+                    lb[f"R{R}"] = {"merge_epoch_ms": rr["merge_epoch_ms"], "appended_per_epoch_all_ranks": rr["appended_per_epoch_all_ranks"],
+                                   "accepted_per_scan_this_rank": rr["accepted_per_scan_this_rank"], "scans_per_s": rr["scans"] / rr["elapsed_s"],
+                                   "communicator": rr["communicator"], "ranks": rr["rccl_ranks"]}
+                lb["epoch_ms_R8_over_R1"] = lb["R8"]["merge_epoch_ms"]["median"] / lb["R1"]["merge_epoch_ms"]["median"]
+                extras["merge_loopback"] = {
+                    "config": f"map-growth epoch vs simulated rank count on one GPU (ICPMI_COMM_LOOPBACK): 5 x {args.scan_points}-pt scans vs the "
+                              f"{args.map_points}-pt map, PointDistance 0.15 m, blocks of rank r shifted r x 0.4 m", **lb}
+                del lscans
+            except Exception as e:  # noqa: BLE001
+                extras["merge_loopback"] = {"error": repr(e)}
             out["chains"] = extras
 
         # ---- CPU baseline: the oracle on this host, bounded sample of the same workload ----

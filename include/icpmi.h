@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define ICPMI_VERSION 3
+#define ICPMI_VERSION 4
 
 typedef struct icpmi_ctx* icpmi_handle;
 
@@ -265,6 +265,9 @@ icpmi_status icpmi_map_update_point_distance(icpmi_handle h, const float* scan4,
  * the scan crosses PCIe once per processInput instead of five times. */
 icpmi_status icpmi_register_prior(icpmi_handle h, const float* scan4, int64_t n, const float prior[16], float T_out[16],
                                   icpmi_stats* stats);
+/* (v4) the same with the sensor-frame scan already in HBM on the handle's GPU: no PCIe crossing at all */
+icpmi_status icpmi_register_prior_dev(icpmi_handle h, const float* d_scan4, int64_t n, const float prior[16], float T_out[16],
+                                      icpmi_stats* stats);
 icpmi_status icpmi_map_update_staged(icpmi_handle h, const float correction[16], float min_dist, int32_t normals_knn,
                                      uint8_t* keep_out, int64_t* appended, int64_t* new_m);
 

@@ -590,6 +590,22 @@ icpmi_status icpmi_register_prior(icpmi_handle h, const float* scan4, int64_t n,
     return register_impl(h, (const float*)h->d_scan_map, n, nullptr, 0, T_out, stats);
 }
 
+// ... with the scan already in HBM (sensor frame): what a scan stream that lives on the device -- or a benchmark that must not time
+// PCIe -- hands over; everything else as icpmi_register_prior
+icpmi_status icpmi_register_prior_dev(icpmi_handle h, const float* d_scan4, int64_t n, const float prior[16], float T_out[16], icpmi_stats* stats)
+{
+    CHECK_H(h);
+    if (n < 0 || (n > 0 && !d_scan4) || !prior) { h->last_error = "register_prior_dev: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
+    h->scan_map_n = 0;
+    if (n > 0) {
+        if (ensure_cap(h, &h->d_scan_map, &h->cap_scan_map, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+        icpmi_status s = ops_transform_dev(h, prior, (const float4*)d_scan4, n, h->d_scan_map); // Mapper.cpp:197
+        if (s != ICPMI_OK) return s;
+        h->scan_map_n = n;
+    }
+    return register_impl(h, (const float*)h->d_scan_map, n, nullptr, 0, T_out, stats);
+}
+
 icpmi_status icpmi_map_update_staged(icpmi_handle h, const float correction[16], float min_dist, int32_t normals_knn, uint8_t* keep_out,
                                      int64_t* appended, int64_t* new_m)
 {

@@ -853,7 +853,8 @@ icpmi_status ops_map_update_dev(icpmi_ctx* c, const float4* d_scan, int64_t n, c
     icpmi_status s = ICPMI_OK;
     hipError_t e = hipSuccess;
     unsigned count = 0;
-    if (m0 > 0) {
+    const bool keep_all = !(min_dist > 0.f); // d2 >= 0 holds for every match and for none: nothing to search (the merge epoch's append, r4)
+    if (m0 > 0 && !keep_all) {
         // PointDistanceMapperModule.cpp:33-42: exact NN of every input point in the map AS IT IS (raw_index: not the centred
         // registration index), self match excluded, keep iff d2 >= minDist^2
         icpmi_ctx* ri = nullptr;
@@ -893,14 +894,14 @@ icpmi_status ops_map_update_dev(icpmi_ctx* c, const float4* d_scan, int64_t n, c
             if (s == ICPMI_OK && !had && m0 > 0) e = hipMemsetAsync(c->d_raw_n3, 0, (size_t)m0 * 3 * sizeof(float), c->stream);
         }
         if (s == ICPMI_OK && e == hipSuccess) {
-            if (m0 > 0)
+            if (m0 > 0 && !keep_all)
                 hipLaunchKernelGGL(append_flagged_kernel, dim3(blocks), dim3(256), 0, c->stream, d_scan, d_scan_n3, n, (const unsigned*)d_flag,
                                    (const unsigned*)d_pos, m0, c->d_raw, want_n ? c->d_raw_n3 : (float*)nullptr);
-            else {
-                e = hipMemcpyAsync(c->d_raw, d_scan, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream);
+            else { // the first scan IS the map, or every point is kept: a plain append behind the m0 points there are
+                e = hipMemcpyAsync(c->d_raw + m0, d_scan, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream);
                 if (e == hipSuccess && want_n) {
-                    if (scan_normals3) e = hipMemcpyAsync(c->d_raw_n3, d_scan_n3, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
-                    else e = hipMemsetAsync(c->d_raw_n3, 0, (size_t)n * 3 * sizeof(float), c->stream);
+                    if (scan_normals3) e = hipMemcpyAsync(c->d_raw_n3 + 3 * m0, d_scan_n3, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
+                    else e = hipMemsetAsync(c->d_raw_n3 + 3 * m0, 0, (size_t)n * 3 * sizeof(float), c->stream);
                 }
             }
             if (e == hipSuccess) e = hipGetLastError();
@@ -1358,6 +1359,159 @@ static icpmi_status merge_append_flagged(icpmi_ctx* c, const float4* d_in, int64
     return ICPMI_OK;
 }
 
+// ---- rank-ordered greedy merge of the gathered blocks (r4) -------------------------------------------------------------------------
+// The rule (what one mapper would have appended had it taken the scans in rank order, PointDistanceMapperModule.cpp:33-42 block by block):
+// a point of block r is dropped iff some KEPT point q of a block < r has FLT_EPSILON < d2(p, q) and (double)d2 < minDist^2, d2 the float
+// fmaf chain of the NN kernels on the raw coordinates (sqdist3) -- exactly the predicate the per-block temporary index of r2 / r3 decided
+// through its nearest neighbour.  All gathered points go into one spatial hash (cell edge a little above minDist: every such q lies in
+// the 3 x 3 x 3 cells around p), then blocks 1 .. R - 1 are flagged one after the other (block r needs the flags of the blocks below it).
+// Order inside a cell comes from atomics and is not reproducible; the predicate is an "exists", so the flags are.
+struct MergeBlocks { long long cnt[256]; };  // (never more than 256 ranks: comm.hip)
+
+__device__ __forceinline__ unsigned long long merge_cell_key(int ix, int iy, int iz)
+{
+    // 21 bits per axis; cells whose indices alias under the mask share a bucket -- more candidates, never fewer (distances decide)
+    return ((unsigned long long)((unsigned)ix & 0x1fffffu)) | ((unsigned long long)((unsigned)iy & 0x1fffffu) << 21) |
+           ((unsigned long long)((unsigned)iz & 0x1fffffu) << 42);
+}
+__device__ __forceinline__ int merge_cell_of(float v, float inv_h) { return (int)floorf(v * inv_h); }
+
+__global__ __launch_bounds__(256) void merge_hash_insert_kernel(const float4* __restrict__ recv, long long maxc, int R, MergeBlocks mb, float inv_h,
+                                                                unsigned long long* __restrict__ tkeys, unsigned* __restrict__ tcnt,
+                                                                unsigned long long mask, unsigned* __restrict__ slot_of, unsigned* __restrict__ rank_of)
+{
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= maxc * R) return;
+    const int r = (int)(g / maxc);
+    if (g - (long long)r * maxc >= mb.cnt[r]) return;
+    const float4 p = recv[g];
+    const unsigned long long key = merge_cell_key(merge_cell_of(p.x, inv_h), merge_cell_of(p.y, inv_h), merge_cell_of(p.z, inv_h));
+    unsigned long long slot = mix64(key) & mask;
+    for (;;) {
+        const unsigned long long prev = atomicCAS(&tkeys[slot], ~0ull, key);
+        if (prev == ~0ull || prev == key) break;
+        slot = (slot + 1) & mask;
+    }
+    slot_of[g] = (unsigned)slot;
+    rank_of[g] = atomicAdd(&tcnt[slot], 1u);
+}
+
+__global__ __launch_bounds__(256) void merge_hash_scatter_kernel(long long maxc, int R, MergeBlocks mb, const unsigned* __restrict__ tstart,
+                                                                 const unsigned* __restrict__ slot_of, const unsigned* __restrict__ rank_of,
+                                                                 unsigned* __restrict__ cell_pts)
+{
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= maxc * R) return;
+    const int r = (int)(g / maxc);
+    if (g - (long long)r * maxc >= mb.cnt[r]) return;
+    cell_pts[tstart[slot_of[g]] + rank_of[g]] = (unsigned)g;
+}
+
+// flags of block r (first = the lowest non-empty block: everything kept)
+__global__ __launch_bounds__(256) void merge_flag_kernel(const float4* __restrict__ recv, long long maxc, int r, long long cnt_r, int first, float inv_h,
+                                                         double lim, const unsigned long long* __restrict__ tkeys, const unsigned* __restrict__ tstart,
+                                                         unsigned long long mask, const unsigned* __restrict__ cell_pts, unsigned* __restrict__ kept)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= cnt_r) return;
+    const long long g = (long long)r * maxc + i;
+    if (first) { kept[g] = 1u; return; }
+    const float4 p = recv[g];
+    const int cx = merge_cell_of(p.x, inv_h), cy = merge_cell_of(p.y, inv_h), cz = merge_cell_of(p.z, inv_h);
+    const long long lower_end = (long long)r * maxc; // global indices below this belong to lower blocks
+    bool drop = false;
+    for (int dz = -1; dz <= 1 && !drop; ++dz)
+        for (int dy = -1; dy <= 1 && !drop; ++dy)
+            for (int dx = -1; dx <= 1 && !drop; ++dx) {
+                const unsigned long long key = merge_cell_key(cx + dx, cy + dy, cz + dz);
+                unsigned long long slot = mix64(key) & mask;
+                bool found = false;
+                for (;;) {
+                    const unsigned long long k = tkeys[slot];
+                    if (k == key) { found = true; break; }
+                    if (k == ~0ull) break;
+                    slot = (slot + 1) & mask;
+                }
+                if (!found) continue;
+                const unsigned b = tstart[slot], e = tstart[slot + 1];
+                for (unsigned j = b; j < e; ++j) {
+                    const unsigned q = cell_pts[j];
+                    if ((long long)q >= lower_end || !kept[q]) continue;
+                    const float4 o = recv[q];
+                    const float d2 = sqdist3(p.x, p.y, p.z, o.x, o.y, o.z);
+                    if (d2 > 1.1920929e-07f && (double)d2 < lim) { drop = true; break; }
+                }
+            }
+    kept[g] = drop ? 0u : 1u;
+}
+
+static icpmi_status merge_greedy(icpmi_ctx* c, const std::vector<long long>& counts, long long maxc, float min_dist, int64_t* merged_n)
+{
+    const int R = (int)counts.size();
+    *merged_n = 0;
+    const long long span = maxc * R; // padded layout of d_merge_recv: global index g = r * maxc + i
+    if (span <= 0) return ICPMI_OK;
+    if (span >= (1ll << 31)) { c->last_error = "staged_merge_allgather: gathered set too large"; return ICPMI_ERR_UNSUPPORTED; }
+    int first_block = -1, nonempty = 0;
+    for (int r = 0; r < R; ++r) if (counts[(size_t)r] > 0) { if (first_block < 0) first_block = r; ++nonempty; }
+    if (first_block < 0) return ICPMI_OK;
+    // kept flags over the padded layout (padding stays 0), their scan, and the compaction into d_merged
+    unsigned* kept = scratch_get<unsigned>(c, 6, (size_t)span + 2);
+    unsigned* pos = scratch_get<unsigned>(c, 7, (size_t)span + 2);
+    if (!kept || !pos) return ICPMI_ERR_HIP;
+    HIP_TRY(c, hipMemsetAsync(kept, 0, ((size_t)span + 2) * sizeof(unsigned), c->stream));
+    MergeBlocks mb; memset(&mb, 0, sizeof mb);
+    if (R > 256) { c->last_error = "staged_merge_allgather: more than 256 ranks"; return ICPMI_ERR_UNSUPPORTED; }
+    for (int r = 0; r < R; ++r) mb.cnt[r] = counts[(size_t)r];
+    const bool greedy = nonempty > 1 && min_dist > 0.f;
+    const int gblocks = (int)((span + 255) / 256);
+    if (!greedy) { // one block, or no distance rule: everything handed in is kept
+        for (int r = 0; r < R; ++r)
+            if (counts[(size_t)r] > 0)
+                hipLaunchKernelGGL(merge_flag_kernel, dim3((int)((counts[(size_t)r] + 255) / 256)), dim3(256), 0, c->stream, (const float4*)c->d_merge_recv, maxc, r,
+                                   counts[(size_t)r], 1, 0.f, 0.0, (const unsigned long long*)nullptr, (const unsigned*)nullptr, 0ull, (const unsigned*)nullptr, kept);
+    } else {
+        long long total = 0;
+        for (long long v : counts) total += v;
+        unsigned long long cap = 1024;
+        while (cap < 2ull * (unsigned long long)total) cap <<= 1;
+        // table: keys (u64) | counts -> starts (u32, cap + 1) ; per point: slot, rank ; cell-ordered point list
+        unsigned long long* tkeys = scratch_get<unsigned long long>(c, 0, (size_t)cap);
+        unsigned* tcnt = scratch_get<unsigned>(c, 1, (size_t)cap + 2);
+        unsigned* slot_of = scratch_get<unsigned>(c, 2, (size_t)span + 1);
+        unsigned* rank_of = scratch_get<unsigned>(c, 3, (size_t)span + 1);
+        unsigned* cell_pts = scratch_get<unsigned>(c, 4, (size_t)total + 1);
+        if (!tkeys || !tcnt || !slot_of || !rank_of || !cell_pts) return ICPMI_ERR_HIP;
+        HIP_TRY(c, hipMemsetAsync(tkeys, 0xff, (size_t)cap * sizeof(unsigned long long), c->stream));
+        HIP_TRY(c, hipMemsetAsync(tcnt, 0, ((size_t)cap + 2) * sizeof(unsigned), c->stream));
+        // cell edge: a little above minDist (a relative 1e-3 dwarfs the rounding of v * inv_h for coordinates up to ~10^4 cells from the origin;
+        // beyond that the margin grows with the coordinate's ulp)
+        const float h = min_dist * 1.001f + 1e-6f;
+        const float inv_h = 1.0f / h;
+        hipLaunchKernelGGL(merge_hash_insert_kernel, dim3(gblocks), dim3(256), 0, c->stream, (const float4*)c->d_merge_recv, maxc, R, mb, inv_h, tkeys, tcnt,
+                           cap - 1, slot_of, rank_of);
+        HIP_TRY(c, hipGetLastError());
+        icpmi_status s = device_exclusive_scan(c, tcnt, (int)cap, (unsigned)total);
+        if (s != ICPMI_OK) return s;
+        hipLaunchKernelGGL(merge_hash_scatter_kernel, dim3(gblocks), dim3(256), 0, c->stream, maxc, R, mb, (const unsigned*)tcnt, (const unsigned*)slot_of,
+                           (const unsigned*)rank_of, cell_pts);
+        const double lim = pd_limit(min_dist);
+        for (int r = first_block; r < R; ++r) {
+            if (counts[(size_t)r] == 0) continue;
+            hipLaunchKernelGGL(merge_flag_kernel, dim3((int)((counts[(size_t)r] + 255) / 256)), dim3(256), 0, c->stream, (const float4*)c->d_merge_recv, maxc, r,
+                               counts[(size_t)r], r == first_block ? 1 : 0, inv_h, lim, (const unsigned long long*)tkeys, (const unsigned*)tcnt, cap - 1,
+                               (const unsigned*)cell_pts, kept);
+        }
+        HIP_TRY(c, hipGetLastError());
+    }
+    // stable compaction in global order = rank order, then input order inside a block (what the per-block appends of r3 produced)
+    int64_t n_kept = 0;
+    icpmi_status s = merge_append_flagged(c, c->d_merge_recv, span, kept, pos, c->d_merged, 0, &n_kept);
+    if (s != ICPMI_OK) return s;
+    *merged_n = n_kept;
+    return ICPMI_OK;
+}
+
 // One map-growth epoch of the scan-sharded mapper (include/icpmi.h: icpmi_staged_merge_allgather), device-resident.
 // Collective discipline: a rank must never leave between two collectives its peers are going to enter.
 //   * every failure before the count exchange travels as count -1 (all ranks then leave together, nobody appends);
@@ -1446,32 +1600,11 @@ icpmi_status ops_staged_merge_allgather(icpmi_ctx* c, const float correction[16]
     s = comm_allgather(c, c->d_merge_send, c->d_merge_recv, (size_t)maxc * 4, true);
     if (s != ICPMI_OK) return s;
     // ---- merge in rank order; block r keeps what is at least min_dist from the points accepted from ranks < r
+    // r4: ONE spatial hash over all gathered blocks and R - 1 flag passes in rank order instead of one temporary index (a dozen launches and
+    // two read-backs) per block -- the same greedy rule, the same candidates' float distances, the same kept set (merge_greedy).
     int64_t acc = 0;
-    for (int r = 0; r < R; ++r) {
-        const int64_t cr = counts[(size_t)r];
-        if (cr == 0) continue;
-        const float4* blk = c->d_merge_recv + (size_t)r * (size_t)maxc;
-        if (acc == 0 || !(min_dist > 0.f)) {
-            HIP_TRY(c, hipMemcpyAsync(c->d_merged + acc, blk, (size_t)cr * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
-            acc += cr;
-            continue;
-        }
-        TempCtx t;
-        s = make_temp(c, t);
-        if (s != ICPMI_OK) return s;
-        if (t.h->stream != c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
-        int32_t ok = 0;
-        s = icpmi_set_map_dev(t.h, (const float*)c->d_merged, acc, nullptr, &ok);
-        if (s != ICPMI_OK) { c->last_error = t.h->last_error; return s; }
-        unsigned* f2 = scratch_get<unsigned>(c, 6, (size_t)cr + 2);
-        unsigned* p2 = scratch_get<unsigned>(c, 7, (size_t)cr + 2);
-        if (!f2 || !p2) return ICPMI_ERR_HIP;
-        s = chain_point_distance_flags(c, t.h, blk, cr, min_dist, f2);
-        int64_t kept = 0;
-        if (s == ICPMI_OK) s = merge_append_flagged(c, blk, cr, f2, p2, c->d_merged, acc, &kept);
-        if (s != ICPMI_OK) return s;
-        acc += kept;
-    }
+    s = merge_greedy(c, counts, maxc, min_dist, &acc);
+    if (s != ICPMI_OK) return s;
     // ---- every replica appends the same set (all points kept: the distance tests are done), normals, index
     int64_t app = 0, m1 = 0;
     s = ops_map_update_dev(c, c->d_merged, acc, nullptr, 0.f, normals_knn, nullptr, &app, &m1);

@@ -579,6 +579,14 @@ class ICPSequence:
         self._staged_n = sc.shape[0]
         return _T_from_c(T[:])
 
+    def registerWithPriorDev(self, d_scan_ptr, n, prior):
+        """icpmi_register_prior_dev: registerWithPrior for a sensor-frame scan that is already in HBM."""
+        P = _T_to_c(prior)
+        T = (C.c_float * 16)()
+        self._check(self._lib.icpmi_register_prior_dev(self._h, d_scan_ptr, n, P.ctypes.data, T, C.byref(self.stats)))
+        self._staged_n = n
+        return _T_from_c(T[:])
+
     def mapUpdateStaged(self, correction, min_dist, normals_knn=0, return_keep=False):
         """Second half (Mapper.cpp:221 + Map::updateLocalPointCloud): the staged cloud moved by `correction`, then the
         PointDistance update on the resident map."""

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in icpmi.h but not exported"
         assert name in bound, f"{name} declared in icpmi.h but missing from the ctypes table"
-    assert lib.icpmi_version() == 3
+    assert lib.icpmi_version() == 4
 
 
 def test_config_defaults_and_struct_layout():
