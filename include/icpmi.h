@@ -128,7 +128,10 @@ typedef struct {
     float   grid_cell;         /* NN grid cell edge in metres; 0 = choose from the map density     */
     int32_t use_graph;         /* 1 = fixed-iteration registrations replay one hipGraph (default) */
     int32_t profile;           /* 1 = eager launches with HIP events around every NN launch        */
-    int32_t reserved[8];
+    int32_t fuse_solve;        /* (v4) three launches per iteration: the solve of iteration i rides in the prologue of every       */
+                               /* workgroup of iteration i + 1's NN launch.  0 (default) = off, 1 = wherever the chain allows,      */
+                               /* 2 = only for fixed-count point-to-point registrations (where it measured faster)      */
+    int32_t reserved[7];
 } icpmi_config;
 
 /* What PM::ICPSequence exposes after a call: errorMinimizer->getOverlap() (Mapper.cpp:219) is

@@ -51,7 +51,8 @@ class Config(C.Structure):
         ("grid_cell", C.c_float),
         ("use_graph", C.c_int32),
         ("profile", C.c_int32),
-        ("reserved", C.c_int32 * 8),
+        ("fuse_solve", C.c_int32),
+        ("reserved", C.c_int32 * 7),
     ]
 
 

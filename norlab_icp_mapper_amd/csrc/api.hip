@@ -147,8 +147,9 @@ icpmi_status icpmi_create(const icpmi_config* cfg, icpmi_handle* out)
     CR(hipSetDevice(c->device));
     CR(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->own_stream = true;
-    CR(hipMalloc((void**)&c->d_state, sizeof(IcpState) * ICPMI_MAX_BATCH));
-    CR(hipMemset(c->d_state, 0, sizeof(IcpState) * ICPMI_MAX_BATCH));
+    CR(hipMalloc((void**)&c->d_state, sizeof(IcpState) * 2 * ICPMI_MAX_BATCH));
+    CR(hipMemset(c->d_state, 0, sizeof(IcpState) * 2 * ICPMI_MAX_BATCH));
+    c->st_cur = c->d_state;
     CR(hipMalloc((void**)&c->d_selhist, ICPMI_SELHIST_WORDS * sizeof(unsigned)));
     CR(hipMemset(c->d_selhist, 0, ICPMI_SELHIST_WORDS * sizeof(unsigned)));
     c->cap_selhist = ICPMI_SELHIST_WORDS;
@@ -200,7 +201,7 @@ void icpmi_destroy(icpmi_handle c)
     hipFree(c->d_match_pt); hipFree(c->d_lvl_tab); hipFree(c->d_raw); hipFree(c->d_raw_n3); hipFree(c->d_raw_s); hipFree(c->d_src); hipFree(c->d_alt_raw); hipFree(c->d_alt_n3);
     hipFree(c->d_alt_s); hipFree(c->d_alt_src); hipFree(c->d_stage_s); hipFree(c->d_merge_send); hipFree(c->d_merge_recv); hipFree(c->d_merged); hipFree(c->d_comm_cnt); hipFree(c->d_read_noise); hipFree(c->d_map_pn);
     for (int k = 0; k < 10; ++k) hipFree(c->scratch[k]); hipFree(c->d_scan_map); hipFree(c->d_T16);
-    hipFree(c->d_sidx); hipFree(c->d_d2); hipFree(c->d_hard); hipFree(c->d_partials); hipFree(c->d_selhist);
+    hipFree(c->d_sidx); hipFree(c->d_d2); hipFree(c->d_hard); hipFree(c->d_selhist);
     hipFree(c->d_state);
     if (c->h_state) hipHostFree(c->h_state);
     if (c->h_pin) hipHostFree(c->h_pin);

@@ -13,6 +13,7 @@
 
 #include "../../include/icpmi.h"
 
+#define ICPMI_NV 32            // values of the minimiser's pair sums (27 of A / b or 16 of the point-to-point sums, sum w, pair count, force2D's b)
 #define ICPMI_MAX_OUTLIER 8
 #define ICPMI_MAX_SMOOTH 16
 #define ICPMI_SEL_BINS 2048     // legacy 11/11/10 selection (stage entry point, chains with > 1 quantile filter)
@@ -31,12 +32,25 @@
 #endif
 #define ICPMI_S2_C1 (ICPMI_S2_F0 + ICPMI_S2_FCOPIES * 65536)
 #define ICPMI_S2_F1 (ICPMI_S2_C1 + 256)
-#define ICPMI_SELHIST_WORDS (ICPMI_S2_F1 + 65536)
+// Pair-sum accumulators (r4), behind the histograms so that everything that clears the one clears the other: the ICPMI_NV sums of a
+// registration's iteration as signed 64-bit FIXED-POINT device atomics -- integer additions commute, so the total does not depend on the
+// order in which the pair-sum workgroups arrive, and what the solver reads is 32 values, not 64 KB of per-workgroup partials to be
+// reduced in a fixed order.  A value v is held as two limbs, hi = rint(v 2^-16) and lo = rint((v - hi 2^16) 2^40): together 2^-40
+// absolute resolution over +-2^78 with no range analysis (every limb sum stays far inside 64 bits), no carries between the limbs
+// (they are summed independently and joined in double).  ICPMI_ACC_COPIES privatised copies (workgroup b adds to copy b % COPIES),
+// every (copy, value, limb) on its own 128-byte line: device atomics serialise per line.  Two parities: the pair sums of
+// iteration i go to parity i & 1 (nn.hip: the next NN launch reads them while this iteration's successor already accumulates).
+#define ICPMI_ACC_COPIES 2   // (8 copies made every reader fetch 64 KB of padded lines -- 100 MB per NN launch once every workgroup reads them; 2: 128 atomics per line)
+#define ICPMI_ACC_PAD 16                                               // u64 per slot = one 128-byte line
+#define ICPMI_ACC_U64 (ICPMI_ACC_COPIES * ICPMI_NV * 2 * ICPMI_ACC_PAD)   // per parity: 8192 u64 = 64 KiB
+#define ICPMI_ACC_IDX(copy, i, limb) ((((copy) * ICPMI_NV + (i)) * 2 + (limb)) * ICPMI_ACC_PAD)
+#define ICPMI_ACC_FLAG (ICPMI_ACC_IDX(0, 0, 0) + 8)                    // a non-finite partial was met (NaN must reach the solver: ICPMI_ERR_NAN)
+#define ICPMI_S2_ACC (ICPMI_S2_F1 + 65536)                             // u32 word offset of parity 0 (128-byte aligned)
+#define ICPMI_SELHIST_WORDS (ICPMI_S2_ACC + 2 * 2 * ICPMI_ACC_U64)
 // Device atomics serialise per cache line, and neighbouring fine bins are hot together: bin b of a fine
 // histogram lives at word ((b & 255) << 8) | (b >> 8), i.e. consecutive bins are 1 KiB apart.
 #define ICPMI_S2_FIDX(b) ((((b) & 255u) << 8) | ((b) >> 8))
 
-#define ICPMI_NV 32            // doubles per block partial in the minimiser reduction
 #define ICPMI_MAX_K 32
 
 // ------------------------------------------------------------------------------------------------
@@ -229,7 +243,6 @@ struct icpmi_ctx {
     int*    d_sidx = nullptr; size_t cap_sidx = 0;             // k x n sorted-map index (-1 none)
     float*  d_d2 = nullptr; size_t cap_d2 = 0;                 // k x n
     unsigned* d_hard = nullptr; size_t cap_hard = 0;           // hard query list
-    double* d_partials = nullptr; size_t cap_partials = 0;
     unsigned* d_selhist = nullptr; size_t cap_selhist = 0;     // ICPMI_SELHIST_WORDS per reading of a batch
     unsigned* nn_hist0 = nullptr;     // set by the loop when the NN kernel should build the level-0 histogram
     bool nn_builds_hist0 = false;     // set by the NN launcher: true if the launched variant did build it
@@ -238,7 +251,20 @@ struct icpmi_ctx {
     float4* nn_match_pt = nullptr;    // set by the loop: keep the loop state (sidx, d2, matched point) in query order
     bool nn_out_sorted = false;       // set by the NN launcher: true if the launched kernel did so
     bool nn_sorted_k = false;         // set by the loop for k > 1: keep the k matches of a query at its slot of the tile-sorted order
-    IcpState* d_state = nullptr;                               // ICPMI_MAX_BATCH states (a single registration uses the first)
+    IcpState* d_state = nullptr;                               // 2 x ICPMI_MAX_BATCH states (a single registration uses the first; the second set is
+                                                               // the other parity of the fused solve, see nn_fs_* below)
+    // r4: the solve of iteration L - 1 runs in the prologue of EVERY workgroup of the NN launch of iteration L (nn1_wg_kernel<.., FSOLVE>):
+    // the pair sums are 32 fixed-point accumulators (ICPMI_ACC_*), the algebra is ~2 us of one lane, and redoing it 1 568 times costs less
+    // than a one-workgroup launch and its kernel boundary.  The loop state ping-pongs: NN launch L reads state[(L - 1) & 1] and the
+    // accumulators of parity (L - 1) & 1, workgroup 0 writes state[L & 1], the other kernels of iteration L work on state[L & 1].
+    IcpState* st_cur = nullptr;                                // the state the kernels of the iteration being enqueued use (loop.hip)
+    int acc_parity_cur = 0;                                    // ... and the parity of the accumulators its pair sums go to (| 2: zero the other)
+    bool fsolve_cur = false;                                   // the registration being enqueued runs with the fused solve
+    bool nn_fsolve = false;                                    // set by the loop for the next NN launch: fused solve
+    int nn_fs_pending = 0;                                     // ... there IS a previous iteration whose sums wait (L > 0)
+    IcpState* nn_fs_prev = nullptr;                            // ... its state
+    int nn_fs_acc_parity = 0;                                  // ... parity of its accumulators
+    LoopCfg nn_fs_lc{};                                        // ... the chain
     IcpState* h_state = nullptr;                               // pinned mirror (ICPMI_MAX_BATCH)
     int batch_cur = 1;                                         // readings of the launch sequence being enqueued (set by the loop)
     BatchArgs batch_args{};                                    // their sizes / slice stride
@@ -426,7 +452,7 @@ __device__ inline void quat_from_T(const float* T, double* q)
         const int j = (i + 1) % 3, kk = (j + 1) % 3;
         auto M = [&](int r, int c) { return (double)T[4 * c + r]; };
         t = sqrt(M(i, i) - M(j, j) - M(kk, kk) + 1.0);
-        double v[3];
+        __shared__ double v[3]; // (run-time index: LDS instead of scratch memory; one lane per workgroup ever gets here)
         v[i] = 0.5 * t; t = 0.5 / t;
         q[0] = (M(kk, j) - M(j, kk)) * t;
         v[j] = (M(j, i) + M(i, j)) * t;

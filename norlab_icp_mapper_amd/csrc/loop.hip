@@ -7,6 +7,7 @@
 // kernel and one single-wave solve kernel.  All decisions (convergence, errors) stay on the device
 // in IcpState; kernels of a finished loop exit on st->done.
 #include "common.h"
+#include "solve.h"
 #include <cstring>
 
 namespace {
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(BT) void accumulate_kernel(const float4* __restrict
                                                          const float4* __restrict__ normals,
                                                          const float4* __restrict__ read_normals,
                                                          const int* __restrict__ sidx, const float* __restrict__ d2a,
-                                                         double* __restrict__ partials, unsigned* __restrict__ hists,
+                                                         int acc_parity /* | 2: also zero the OTHER parity (fused solve) */, unsigned* __restrict__ hists,
                                                          int fused_slot, int is_median, float factor,
                                                          const float4* __restrict__ match_pt, const int* __restrict__ qindex,
                                                          const float* __restrict__ ref_scalar, const float4* __restrict__ pnm)
@@ -532,7 +533,6 @@ __global__ __launch_bounds__(BT) void accumulate_kernel(const float4* __restrict
         if (match_pt) match_pt += qo;
         if (qindex) qindex += qo;
         if (read_normals) read_normals += qo;
-        partials += (size_t)blockIdx.y * (size_t)acc_cap * ICPMI_NV;
         hists += (size_t)blockIdx.y * ICPMI_SELHIST_WORDS;
         st += blockIdx.y;
     }
@@ -561,6 +561,12 @@ __global__ __launch_bounds__(BT) void accumulate_kernel(const float4* __restrict
     for (int u = 0; u < 2; ++u)
         pn[u] = (MIN == ICPMI_MIN_POINT_TO_PLANE && ps[u] >= 0) ? (pnm ? pnm[2 * (size_t)ps[u] + 1] : normals[ps[u]]) : make_float4(0.f, 0.f, 0.f, 0.f);
     if (st->done) return;
+    if (acc_parity & 2) {
+        // fused solve (nn.hip): the accumulators of the other parity were read by every workgroup of this iteration's NN launch -- the
+        // last readers -- and take the pair sums of the NEXT iteration: zeroed here
+        unsigned long long* other = reinterpret_cast<unsigned long long*>(hists + ICPMI_S2_ACC) + (size_t)((acc_parity & 1) ^ 1) * ICPMI_ACC_U64;
+        for (int64_t i = (int64_t)blockIdx.x * BT + threadIdx.x; i < ICPMI_ACC_U64; i += (int64_t)nbe * BT) other[i] = 0ull;
+    }
     float fused_limit = 0.f;
     if (FUSED) {
         // scan of level 1: the selected element's bit pattern is prefix(16) | bin(16)
@@ -678,558 +684,45 @@ __global__ __launch_bounds__(BT) void accumulate_kernel(const float4* __restrict
 #pragma unroll
             for (int w2 = 4; w2 < BT / 64; ++w2) v += sh[w2][i]; // fixed order
         }
-        partials[(size_t)blockIdx.x * ICPMI_NV + i] = v;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// small dense algebra for the single-lane solve
-// ---------------------------------------------------------------------------------------------
-__device__ void mat4_mul_dev(const float* A, const float* B, float* C)
-{
-    float R[16];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float s = A[i] * B[4 * j];
-#pragma unroll
-            for (int kk = 1; kk < 4; ++kk) s = fmaf(A[4 * kk + i], B[4 * j + kk], s);
-            R[4 * j + i] = s;
-        }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) C[i] = R[i];
-}
-
-// symmetric Jacobi eigen-decomposition (double), n <= 6, col-major
-__device__ void jacobi_eig(int n, const double* Ain, double* w, double* Q)
-{
-    double A[36];
-    for (int i = 0; i < n * n; ++i) A[i] = Ain[i];
-    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) Q[n * j + i] = (i == j) ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        double off = 0;
-        for (int p = 0; p < n; ++p) for (int q = p + 1; q < n; ++q) off += A[n * q + p] * A[n * q + p];
-        double dg = 0;
-        for (int p = 0; p < n; ++p) dg += A[n * p + p] * A[n * p + p];
-        if (off <= 1e-32 * dg || off < 1e-300) break;
-        for (int p = 0; p < n - 1; ++p)
-            for (int q = p + 1; q < n; ++q) {
-                const double apq = A[n * q + p];
-                if (apq == 0.0) continue;
-                const double theta = (A[n * q + q] - A[n * p + p]) / (2.0 * apq);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-                for (int kk = 0; kk < n; ++kk) {
-                    const double akp = A[n * p + kk], akq = A[n * q + kk];
-                    A[n * p + kk] = c * akp - s * akq; A[n * q + kk] = s * akp + c * akq;
-                }
-                for (int kk = 0; kk < n; ++kk) {
-                    const double apk = A[n * kk + p], aqk = A[n * kk + q];
-                    A[n * kk + p] = c * apk - s * aqk; A[n * kk + q] = s * apk + c * aqk;
-                }
-                for (int kk = 0; kk < n; ++kk) {
-                    const double qkp = Q[n * p + kk], qkq = Q[n * q + kk];
-                    Q[n * p + kk] = c * qkp - s * qkq; Q[n * q + kk] = s * qkp + c * qkq;
-                }
-            }
-    }
-    for (int i = 0; i < n; ++i) w[i] = A[n * i + i];
-}
-
-// Rotation of the point-to-point minimiser: R = U V^T of the float 3x3 H = U S V^T,
-// with the last row of V^T negated when det(R) < 0.  The SVD is a one-sided (Hestenes) Jacobi in
-// float -- the numeric spec shared with the oracle: cyclic (0,1),(0,2),(1,2) sweeps on the columns,
-// rotation skipped below 1e-9 relative off-diagonal, stop at 1e-7, singular values sorted
-// descending, columns of U belonging to (near) zero singular values completed by cross products.
-__device__ void svd3f_dev(const float* H, float* U, float* s, float* V)
-{
-    float a[9], v[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    for (int i = 0; i < 9; ++i) a[i] = H[i];
-    for (int sweep = 0; sweep < 30; ++sweep) {
-        float off = 0.f;
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-#pragma unroll
-            for (int q = p + 1; q < 3; ++q) {
-                float alpha = 0, beta = 0, gamma = 0;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    alpha += a[3 * p + i] * a[3 * p + i];
-                    beta += a[3 * q + i] * a[3 * q + i];
-                    gamma += a[3 * p + i] * a[3 * q + i];
-                }
-                if (gamma == 0.f) continue;
-                const float lim = fabsf(gamma) / sqrtf(fmaxf(alpha * beta, 1.17549435e-38f));
-                if (lim > off) off = lim;
-                if (lim <= 1e-9f) continue;
-                const float zeta = (beta - alpha) / (2.f * gamma);
-                const float tt = (zeta >= 0.f ? 1.f : -1.f) / (fabsf(zeta) + sqrtf(1.f + zeta * zeta));
-                const float c = 1.f / sqrtf(1.f + tt * tt), sn = c * tt;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const float ap = a[3 * p + i], aq = a[3 * q + i];
-                    a[3 * p + i] = c * ap - sn * aq; a[3 * q + i] = sn * ap + c * aq;
-                    const float vp = v[3 * p + i], vq = v[3 * q + i];
-                    v[3 * p + i] = c * vp - sn * vq; v[3 * q + i] = sn * vp + c * vq;
-                }
-            }
-        if (off <= 1e-7f) break;
-    }
-    float sv[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) sv[j] = sqrtf(a[3 * j] * a[3 * j] + a[3 * j + 1] * a[3 * j + 1] + a[3 * j + 2] * a[3 * j + 2]);
-    // descending order by the exchange sort (0,1) (0,2) (1,2), strict comparisons: columns travel with their
-    // singular value.  Static indices only -- a permutation array would push a, v and sv into scratch.
-#define SVD3_CSWAP(I, J)                                                                      \
-    if (sv[J] > sv[I]) {                                                                      \
-        float t_ = sv[I]; sv[I] = sv[J]; sv[J] = t_;                                          \
-        _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_) {                                    \
-            t_ = a[3 * I + i_]; a[3 * I + i_] = a[3 * J + i_]; a[3 * J + i_] = t_;            \
-            t_ = v[3 * I + i_]; v[3 * I + i_] = v[3 * J + i_]; v[3 * J + i_] = t_;            \
-        }                                                                                     \
-    }
-    SVD3_CSWAP(0, 1)
-    SVD3_CSWAP(0, 2)
-    SVD3_CSWAP(1, 2)
-#undef SVD3_CSWAP
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        s[j] = sv[j];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { V[3 * j + i] = v[3 * j + i]; U[3 * j + i] = a[3 * j + i]; }
-    }
-    // U = A V S^-1 made orthonormal by construction -- same operations, same order as the oracle (see there)
-    const float tiny = s[0] * 1e-6f;
-    if (!(s[0] > 0.f)) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) U[i] = (i % 4 == 0) ? 1.f : 0.f;
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) U[i] /= s[0];
-    {
-        const float n0 = sqrtf(U[0] * U[0] + U[1] * U[1] + U[2] * U[2]);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) U[i] /= n0;
-    }
-    bool have1 = false;
-    if (s[1] > tiny) {
-        float c1[3] = {U[3] / s[1], U[4] / s[1], U[5] / s[1]};
-        const float d = c1[0] * U[0] + c1[1] * U[1] + c1[2] * U[2];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) c1[i] = c1[i] - d * U[i];
-        const float n1 = sqrtf(c1[0] * c1[0] + c1[1] * c1[1] + c1[2] * c1[2]);
-        if (n1 > 0.5f) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) U[3 + i] = c1[i] / n1;
-            have1 = true;
-        }
-    }
-    if (!have1) {
-        const int m = fabsf(U[0]) < fabsf(U[1]) ? (fabsf(U[0]) < fabsf(U[2]) ? 0 : 2) : (fabsf(U[1]) < fabsf(U[2]) ? 1 : 2);
-        const float e[3] = {m == 0 ? 1.f : 0.f, m == 1 ? 1.f : 0.f, m == 2 ? 1.f : 0.f};
-        const float d = m == 0 ? U[0] : (m == 1 ? U[1] : U[2]);
-        const float w[3] = {e[0] - d * U[0], e[1] - d * U[1], e[2] - d * U[2]};
-        const float nw = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) U[3 + i] = w[i] / nw;
-    }
-    {
-        const float c2[3] = {U[6], U[7], U[8]};
-        const float x[3] = {U[1] * U[5] - U[2] * U[4], U[2] * U[3] - U[0] * U[5], U[0] * U[4] - U[1] * U[3]};
-        const float nx = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
-        const float sg = (have1 && s[2] > tiny && (x[0] * c2[0] + x[1] * c2[1] + x[2] * c2[2]) < 0.f) ? -1.f : 1.f;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) U[6 + i] = sg * (x[i] / nx);
-    }
-}
-
-__device__ float det3f(const float* R)
-{
-    return R[0] * (R[4] * R[8] - R[7] * R[5]) - R[3] * (R[1] * R[8] - R[7] * R[2]) + R[6] * (R[1] * R[5] - R[4] * R[2]);
-}
-
-// the route through the SVD: singular or reflecting H only (see rotation_from_H) -- out of line, its registers and its
-// thirty-sweep loop stay off the common path
-__device__ __noinline__ void rotation_from_H_svd(const float* H, float* R)
-{
-    float U[9], s[3], V[9];
-    svd3f_dev(H, U, s, V);
-    for (int pass = 0; pass < 2; ++pass) {
-        for (int j = 0; j < 3; ++j)
-            for (int i = 0; i < 3; ++i) {
-                float acc = 0.f;
-                for (int kk = 0; kk < 3; ++kk) acc += U[3 * kk + i] * V[3 * kk + j];
-                R[3 * j + i] = acc;
-            }
-        if (pass == 0 && det3f(R) < 0.f) { for (int i = 0; i < 3; ++i) V[6 + i] = -V[6 + i]; }
-        else break;
-    }
-}
-
-// U V^T of H = U S V^T is the orthogonal polar factor of H whenever det H > 0, and the Newton iteration X <- (X + X^-T) / 2
-// reaches it without U, S, V: ~4 iterations of ~60 instructions against ~18 Jacobi rotations of ~140 (the single-lane
-// solve went from ~12 k to ~2.5 k clocks).  Same operations, same order as the oracle (polar_newton3f there).
-__device__ bool polar_newton3f(const float* H, float* R)
-{
-    float n2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) n2 = fmaf(H[i], H[i], n2);
-    if (!(n2 > 0.f) || n2 == INFINITY) return false;
-    const float inv = 1.f / sqrtf(n2);
-    float X[9], C[9], Y[9], Xn[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) X[i] = H[i] * inv;
-    for (int it = 0; it < 20; ++it) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int a = (i + 1) % 3, b = (i + 2) % 3, c = (j + 1) % 3, d = (j + 2) % 3;
-                const float t = X[3 * d + a] * X[3 * c + b];
-                C[3 * j + i] = fmaf(X[3 * c + a], X[3 * d + b], -t);
-            }
-        float det = X[0] * C[0];
-        det = fmaf(X[3], C[3], det);
-        det = fmaf(X[6], C[6], det);
-        if (it == 0 && !(det > 1e-6f)) return false;
-        const float invdet = 1.f / det;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) Y[i] = C[i] * invdet;
-        if (it < 2) {
-            float nx = 0.f, ny = 0.f;
-#pragma unroll
-            for (int i = 0; i < 9; ++i) { nx = fmaf(X[i], X[i], nx); ny = fmaf(Y[i], Y[i], ny); }
-            const float mu = sqrtf(sqrtf(ny / nx)), imu = 1.f / mu;
-#pragma unroll
-            for (int i = 0; i < 9; ++i) Xn[i] = 0.5f * fmaf(mu, X[i], Y[i] * imu);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) Xn[i] = 0.5f * (X[i] + Y[i]);
-        }
-        float dmax = 0.f;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) { const float dd = fabsf(Xn[i] - X[i]); if (dd > dmax) dmax = dd; X[i] = Xn[i]; }
-        if (!(dmax == dmax)) return false;
-        if (it >= 2 && dmax <= 3e-4f) break;
-    }
-#pragma unroll
-    for (int i = 0; i < 9; ++i) R[i] = X[i];
-    return true;
-}
-
-__device__ void rotation_from_H(const float* H, float* R)
-{
-    if (!polar_newton3f(H, R)) rotation_from_H_svd(H, R);
-}
-
-// solvePossiblyUnderdeterminedLinearSystem: float LLT when A is invertible, else
-// the minimum-norm solution (double symmetric pseudo-inverse) -- same rule as the oracle.  N = 6, or 4 (force4DOF).
-// minimum-norm branch (rank-deficient A): rare, kept out of line so that its scratch-resident
-// arrays do not burden the common path
-__device__ __noinline__ void solve_min_norm(int n, const float* A, const float* b, float* x);
-
-template <int N>
-__device__ void solve_spd(const float* A, const float* b, float* x)
-{
-    // invertibility rule shared with the oracle: every float Cholesky pivot > N eps_f max_j A_jj.
-    // Every loop has compile-time bounds and is fully unrolled: L, y live in registers (a rolled
-    // triangular loop would put them in scratch memory, ~10 us of dependent scratch traffic).
-    float dmax = 0.f;
-#pragma unroll
-    for (int j = 0; j < N; ++j) dmax = A[N * j + j] > dmax ? A[N * j + j] : dmax;
-    const float pthr = (float)N * 1.1920928955078125e-07f * dmax;
-    float L[N * N], iL[N];
-    bool ok = true;
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-        float d = A[N * j + j];
-#pragma unroll
-        for (int kk = 0; kk < N; ++kk) if (kk < j) d -= L[N * kk + j] * L[N * kk + j];
-        ok = ok && (d > pthr);
-        const float ljj = sqrtf(d);
-        L[N * j + j] = ljj;
-        const float ilj = 1.f / ljj; // one reciprocal per pivot, multiplied through (column and both substitutions)
-        iL[j] = ilj;
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            if (i > j) {
-                float s = A[N * j + i];
-#pragma unroll
-                for (int kk = 0; kk < N; ++kk) if (kk < j) s -= L[N * kk + i] * L[N * kk + j];
-                L[N * j + i] = s * ilj;
+        // the workgroup's sum joins the iteration's accumulator as two fixed-point limbs (common.h: ICPMI_ACC_*): integer atomics,
+        // so the total is the same whatever order the workgroups arrive in
+        unsigned long long* acc = reinterpret_cast<unsigned long long*>(hists + ICPMI_S2_ACC) + (size_t)(acc_parity & 1) * ICPMI_ACC_U64;
+        if (v != 0.0) {
+            if (!(fabs(v) < 0x1p77)) atomicOr(reinterpret_cast<unsigned*>(acc + ICPMI_ACC_FLAG), 1u);
+            else {
+                const double hi = rint(v * 0x1p-16);
+                const double lo = v - hi * 65536.0;                 // exact: a multiple of ulp(v) below 2^15
+                const long long H = (long long)hi, Lq = __double2ll_rn(lo * 0x1p40);
+                const int cp = blockIdx.x & (ICPMI_ACC_COPIES - 1);
+                if (H) atomicAdd(acc + ICPMI_ACC_IDX(cp, i, 0), (unsigned long long)H);
+                if (Lq) atomicAdd(acc + ICPMI_ACC_IDX(cp, i, 1), (unsigned long long)Lq);
             }
         }
     }
-    if (ok) {
-        float y[N];
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            float s = b[i];
-#pragma unroll
-            for (int kk = 0; kk < N; ++kk) if (kk < i) s -= L[N * kk + i] * y[kk];
-            y[i] = s * iL[i];
-        }
-#pragma unroll
-        for (int i = N - 1; i >= 0; --i) {
-            float s = y[i];
-#pragma unroll
-            for (int kk = 0; kk < N; ++kk) if (kk > i) s -= L[N * i + kk] * x[kk];
-            x[i] = s * iL[i];
-        }
-        return;
-    }
-    solve_min_norm(N, A, b, x);
 }
 
-__device__ __noinline__ void solve_min_norm(int n, const float* A, const float* b, float* x)
-{
-    double Ad[36], w[6], Q[36];
-    for (int i = 0; i < n * n; ++i) Ad[i] = A[i];
-    jacobi_eig(n, Ad, w, Q);
-    double wmax = 0;
-    for (int i = 0; i < n; ++i) if (fabs(w[i]) > wmax) wmax = fabs(w[i]);
-    const double thr = (double)n * 1.1920928955078125e-07 * wmax;
-    double xd[6] = {0, 0, 0, 0, 0, 0};
-    for (int e = 0; e < n; ++e) {
-        if (!(w[e] > thr)) continue;
-        double proj = 0;
-        for (int i = 0; i < n; ++i) proj += Q[n * e + i] * (double)b[i];
-        proj /= w[e];
-        for (int i = 0; i < n; ++i) xd[i] += proj * Q[n * e + i];
-    }
-    for (int i = 0; i < n; ++i) x[i] = (float)xd[i];
-}
-
-__device__ void angle_axis_T(const float* x3, float* T)
-{
-    for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.f : 0.f;
-    const float nrm = sqrtf(x3[0] * x3[0] + x3[1] * x3[1] + x3[2] * x3[2]);
-    if (!(nrm > 0.f)) return;
-    const float ax = x3[0] / nrm, ay = x3[1] / nrm, az = x3[2] / nrm;
-    // the oracle's orc_sincos_f, operation by operation: Taylor / Horner with fmaf below 0.5 rad (a double sin + cos is ~2000
-    // clocks of the single lane), through double above -- where host libm and device ocml round to the same float
-    float s, c;
-    if (nrm < 0.5f) {
-        const float z = nrm * nrm;
-        float ps = fmaf(z, 2.75573192e-06f, -1.98412698e-04f);
-        ps = fmaf(z, ps, 8.33333333e-03f);
-        ps = fmaf(z, ps, -1.66666667e-01f);
-        s = fmaf(nrm * z, ps, nrm);
-        float pc = fmaf(z, -2.75573192e-07f, 2.48015873e-05f);
-        pc = fmaf(z, pc, -1.38888889e-03f);
-        pc = fmaf(z, pc, 4.16666667e-02f);
-        pc = fmaf(z, pc, -0.5f);
-        c = fmaf(z, pc, 1.f);
-    } else { s = (float)sin((double)nrm); c = (float)cos((double)nrm); }
-    const float sx = s * ax, sy = s * ay, sz = s * az;
-    const float cx = (1.f - c) * ax, cy = (1.f - c) * ay, cz = (1.f - c) * az;
-    float tmp;
-    tmp = cx * ay; T[4 * 1 + 0] = tmp - sz; T[4 * 0 + 1] = tmp + sz;
-    tmp = cx * az; T[4 * 2 + 0] = tmp + sy; T[4 * 0 + 2] = tmp - sy;
-    tmp = cy * az; T[4 * 2 + 1] = tmp - sx; T[4 * 1 + 2] = tmp + sx;
-    T[0] = cx * ax + c; T[5] = cy * ay + c; T[10] = cz * az + c;
-}
-
-__device__ double quat_angdist(const double* a, const double* b)
-{
-    const double w = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
-    const double x = -a[0] * b[1] + a[1] * b[0] - a[2] * b[3] + a[3] * b[2];
-    const double y = -a[0] * b[2] + a[1] * b[3] + a[2] * b[0] - a[3] * b[1];
-    const double z = -a[0] * b[3] - a[1] * b[2] + a[2] * b[1] + a[3] * b[0];
-    return 2.0 * atan2(sqrt(x * x + y * y + z * z), fabs(w));
-}
-
-// ---------------------------------------------------------------------------------------------
-// single-wave kernel: ordered reduction of the block partials, solve, compose, checkers
-// ---------------------------------------------------------------------------------------------
-__device__ void solve_body(IcpState* __restrict__ st, const double* __restrict__ partials, int nblocks, const LoopCfg& lc,
-                           float* __restrict__ T_step_out, double* __restrict__ sums_out)
-{
-    // ordered (deterministic) reduction of the block partials: 8 lanes per value, fixed row
-    // assignment, fixed combination order
-    __shared__ double part[8][ICPMI_NV];
-    __shared__ double tot[ICPMI_NV];
-    const int t = threadIdx.x;
-    {
-        const int v = t & (ICPMI_NV - 1), pr = t >> 5;
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        if (nblocks <= 256) {
-            // all of this lane's (up to 32) partials are requested at once -- one round trip instead of eight -- and
-            // then added in exactly the order of the streaming loop below
-            double val[32];
-#pragma unroll
-            for (int j = 0; j < 32; ++j) {
-                const int bj = pr + 8 * j;
-                val[j] = bj < nblocks ? partials[(size_t)bj * ICPMI_NV + v] : 0.0;
-            }
-            int done = 0;
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (pr + 32 * i + 24 < nblocks) { s0 += val[4 * i]; s1 += val[4 * i + 1]; s2 += val[4 * i + 2]; s3 += val[4 * i + 3]; done = 4 * (i + 1); }
-#pragma unroll
-            for (int j = 0; j < 32; ++j)
-                if (j >= done && pr + 8 * j < nblocks) s0 += val[j];
-        } else {
-            int b = pr;
-            for (; b + 24 < nblocks; b += 32) {
-                s0 += partials[(size_t)b * ICPMI_NV + v];
-                s1 += partials[(size_t)(b + 8) * ICPMI_NV + v];
-                s2 += partials[(size_t)(b + 16) * ICPMI_NV + v];
-                s3 += partials[(size_t)(b + 24) * ICPMI_NV + v];
-            }
-            for (; b < nblocks; b += 8) s0 += partials[(size_t)b * ICPMI_NV + v];
-        }
-        part[pr][v] = (s0 + s1) + (s2 + s3);
-    }
-    __syncthreads();
-    if (t < ICPMI_NV) {
-        double s = 0.0;
-#pragma unroll
-        for (int pr = 0; pr < 8; ++pr) s += part[pr][t];
-        tot[t] = s;
-        if (sums_out) sums_out[t] = s;
-    }
-    __syncthreads();
-    if (t != 0) return;
-    const long long tsolve0 = clock64();
-
-    const double wsum = tot[27];
-    const long long P = (long long)(tot[28] + 0.5);
-    st->pairs = P;
-    st->wsum = wsum;
-    if (P == 0) { st->error = ICPMI_ERR_NO_POINT_TO_MINIMIZE; st->done = 1; return; }
-
-    float Ts[16];
-    for (int i = 0; i < 16; ++i) Ts[i] = (i % 5 == 0) ? 1.f : 0.f;
-    if (lc.minimizer == ICPMI_MIN_POINT_TO_POINT) {
-        // H = sum w q p^T - (sum w q)(sum w p)^T / sum w, rounded to float like the reference's
-        // float matrices, then R = U V^T; t = mean_q - R mean_p
-        const double iw = 1.0 / wsum; // one reciprocal, multiplied through (a double division is ~30 instructions of a single lane)
-        const double mpd[3] = {tot[1] * iw, tot[2] * iw, tot[3] * iw}, mqd[3] = {tot[4] * iw, tot[5] * iw, tot[6] * iw};
-        float H[9];
-        for (int c = 0; c < 3; ++c)
-            for (int r = 0; r < 3; ++r) H[3 * c + r] = (float)(tot[7 + 3 * c + r] - mqd[r] * tot[1 + c]);
-        float R[9];
-        if (lc.is_2d) {
-            // planar clouds: the proper in-plane rotation that maximises tr(R^T H), theta = atan2(H10 - H01, H00 + H11) (what the
-            // 2 x 2 SVD with its reflection repair returns), same operations as the oracle
-            const float a = H[0] + H[4], b2 = H[1] - H[3];
-            const float r = sqrtf(a * a + b2 * b2);
-            float cs = 1.f, sn = 0.f;
-            if (r > 0.f) { cs = a / r; sn = b2 / r; }
-            for (int i = 0; i < 9; ++i) R[i] = 0.f;
-            R[0] = cs; R[1] = sn; R[3] = -sn; R[4] = cs; R[8] = 1.f;
-        } else rotation_from_H(H, R);
-        const float mp[3] = {(float)mpd[0], (float)mpd[1], (float)mpd[2]};
-        const float mq[3] = {(float)mqd[0], (float)mqd[1], (float)mqd[2]};
-        for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) Ts[4 * c + r] = R[3 * c + r];
-        for (int r = 0; r < 3; ++r) Ts[12 + r] = mq[r] - (R[r] * mp[0] + R[3 + r] * mp[1] + R[6 + r] * mp[2]);
-    } else if (lc.minimizer == ICPMI_MIN_POINT_TO_PLANE) {
-        float A[36], b[6], x[6];
-        int idx = 0;
-        for (int a = 0; a < 6; ++a)
-            for (int bb = a; bb < 6; ++bb) { const float v = (float)tot[idx++]; A[6 * a + bb] = v; A[6 * bb + a] = v; }
-        for (int a = 0; a < 6; ++a) b[a] = (float)tot[21 + a];
-        if (lc.force_2d) {
-            // force2D: F = [x ny - y nx; nx; ny] -- rows 2..4 of the 6-DOF F --, b from the 2-D residual (tot[29..31]); x = (yaw, tx, ty)
-            float A3[9], b3[3], x3[3];
-            for (int c = 0; c < 3; ++c) { b3[c] = (float)tot[29 + c]; for (int r = 0; r < 3; ++r) A3[3 * c + r] = A[6 * (2 + c) + (2 + r)]; }
-            solve_spd<3>(A3, b3, x3);
-            x[0] = 0.f; x[1] = 0.f; x[2] = x3[0]; x[3] = x3[1]; x[4] = x3[2]; x[5] = 0.f;
-        } else if (lc.force_4dof) {
-            // force4DOF: F = [cross_z; n] -- the {2,3,4,5} sub-system of the 6-DOF sums; x = (yaw, t)
-            float A4[16], b4[4], x4[4];
-            for (int c = 0; c < 4; ++c) { b4[c] = b[2 + c]; for (int r = 0; r < 4; ++r) A4[4 * c + r] = A[6 * (2 + c) + (2 + r)]; }
-            solve_spd<4>(A4, b4, x4);
-            x[0] = 0.f; x[1] = 0.f; x[2] = x4[0]; x[3] = x4[1]; x[4] = x4[2]; x[5] = x4[3];
-        } else solve_spd<6>(A, b, x);
-        angle_axis_T(x, Ts);
-        Ts[12] = x[3]; Ts[13] = x[4]; Ts[14] = x[5];
-    }
-    const long long tsolve1 = clock64();
-    for (int i = 0; i < 16; ++i)
-        if (Ts[i] != Ts[i]) { st->error = ICPMI_ERR_NAN; st->done = 1; return; }
-    if (T_step_out) for (int i = 0; i < 16; ++i) T_step_out[i] = Ts[i];
-
-    float Ti[16];
-    mat4_mul_dev(Ts, st->T_iter, Ti);
-    if (lc.sensor_noise) for (int i = 0; i < 16; ++i) st->T_prev[i] = st->T_iter[i]; // the pose this step's pairs were formed under
-    for (int i = 0; i < 16; ++i) st->T_iter[i] = Ti[i];
-    st->iter += 1;
-
-    const long long tsolve2 = clock64();
-    // ---- TransformationCheckers ----
-    bool iterate = true;
-    int reason = ICPMI_STOP_NONE;
-    st->counter += 1;
-    if (st->counter >= lc.max_iter) { iterate = false; reason = ICPMI_STOP_COUNTER; }
-    if (lc.use_diff) {
-        const int SL = lc.smooth;
-        const int RING = ICPMI_MAX_SMOOTH + 1;
-        const int slot = st->hist_n % RING;
-        quat_from_T(Ti, st->hq + 4 * slot);
-        for (int r = 0; r < 3; ++r) st->ht[3 * slot + r] = Ti[12 + r];
-        st->hist_n += 1;
-        const int hn = st->hist_n;
-        {
-            // the step between pose hn - 1 (just pushed) and pose hn - 2: computed once, read SL times (the older steps of the
-            // window were stored by the iterations that pushed them -- same values, same summation order as recomputing)
-            const int a = (hn - 1) % RING, bq = (hn - 2) % RING;
-            st->hrot[a] = fabs(quat_angdist(st->hq + 4 * a, st->hq + 4 * bq));
-            const double dx = st->ht[3 * a] - st->ht[3 * bq], dy = st->ht[3 * a + 1] - st->ht[3 * bq + 1],
-                         dz = st->ht[3 * a + 2] - st->ht[3 * bq + 2];
-            st->htr[a] = sqrt(dx * dx + dy * dy + dz * dz);
-        }
-        if (hn > SL) {
-            double rot = 0, tr = 0;
-            for (int i = hn - 1; i >= hn - SL; --i) { rot += st->hrot[i % RING]; tr += st->htr[i % RING]; }
-            rot /= SL; tr /= SL;
-            if (rot != rot || tr != tr) { st->error = ICPMI_ERR_NAN; st->done = 1; return; }
-            if (rot < (double)lc.min_rot && tr < (double)lc.min_trans) {
-                if (iterate) reason = ICPMI_STOP_DIFFERENTIAL;
-                iterate = false;
-            }
-        }
-    }
-    if (lc.use_bound) {
-        double q[4];
-        quat_from_T(Ti, q);
-        const double rot = fabs(quat_angdist(q, st->init_q));
-        const double nt = sqrt((double)Ti[12] * Ti[12] + (double)Ti[13] * Ti[13] + (double)Ti[14] * Ti[14]);
-        if (rot > (double)lc.max_rot || nt > (double)lc.max_trans) { st->error = ICPMI_ERR_BOUND; st->done = 1; return; }
-    }
-    if (!iterate) { st->done = 1; st->stop_reason = reason; }
-    const long long tsolve3 = clock64();
-    st->dbg[20] += (unsigned long long)(tsolve3 - tsolve0); // serial part of the solve (diagnostic)
-    st->dbg[21] += 1;
-    st->dbg[22] += (unsigned long long)(tsolve1 - tsolve0); // ... of which the minimiser,
-    st->dbg[23] += (unsigned long long)(tsolve3 - tsolve2); // ... and the checkers
-}
-
-// progress word (icpmi_ctx::h_progress): visible to the host while the stream keeps running
-__device__ __forceinline__ void publish_progress(const IcpState* st, unsigned* progress)
-{
-    if (!progress) return;
-    const unsigned v = ((unsigned)(st->done != 0) << 31) | ((st->seq & 0x7ffffu) << 12) | ((unsigned)st->iter & 0xfffu);
-    __hip_atomic_store(progress, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-__global__ __launch_bounds__(256) void solve_kernel(IcpState* __restrict__ st, const double* __restrict__ partials, BatchArgs ba, int acc_cap,
-                                                    LoopCfg lc, float* __restrict__ T_step_out, double* __restrict__ sums_out,
+__global__ __launch_bounds__(256) void solve_kernel(IcpState* __restrict__ st, const IcpState* __restrict__ st_in, unsigned* __restrict__ hists,
+                                                    int acc_parity, int clear, LoopCfg lc, float* __restrict__ T_step_out, double* __restrict__ sums_out,
                                                     unsigned* __restrict__ progress)
 {
     // blockIdx.x = reading of a batch: one workgroup per registration
-    const int nblocks = acc_blocks_dev((int64_t)ba.n[blockIdx.x] * lc.k, acc_cap, acc_threads(lc.k));
     st += blockIdx.x;
-    partials += (size_t)blockIdx.x * (size_t)acc_cap * ICPMI_NV;
+    if (st_in && st_in != st) {
+        // the closing solve of a fused-solve sequence (see enqueue_iteration): the pending sums were formed under st_in, the result goes
+        // to the other parity -- exactly what the prologue of a following NN launch would compute (and will recompute, identically, if
+        // another segment follows: the accumulators are not cleared here)
+        const unsigned* g = reinterpret_cast<const unsigned*>(st_in + blockIdx.x);
+        unsigned* o = reinterpret_cast<unsigned*>(st);
+        for (int i = threadIdx.x; i < (int)(sizeof(IcpState) / sizeof(unsigned)); i += 256) o[i] = g[i];
+        __syncthreads();
+    }
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(hists + (size_t)blockIdx.x * ICPMI_SELHIST_WORDS + ICPMI_S2_ACC) + (size_t)acc_parity * ICPMI_ACC_U64;
     if (progress) progress += blockIdx.x;
     if (st->done) { // finished earlier, or an upstream kernel of this iteration raised an error
         if (threadIdx.x == 0) publish_progress(st, progress);
         return;
     }
-    solve_body(st, partials, nblocks, lc, T_step_out, sums_out);
+    solve_body(st, acc, clear != 0, lc, T_step_out, sums_out);
     if (threadIdx.x == 0) publish_progress(st, progress);
 }
 
@@ -1473,8 +966,6 @@ static icpmi_status ensure_loop_buffers(icpmi_ctx* c, int64_t n, int k, int nsca
     if (ensure_cap(c, &c->d_sidx, &c->cap_sidx, cnt) != ICPMI_OK) return ICPMI_ERR_HIP;
     if (ensure_cap(c, &c->d_d2, &c->cap_d2, cnt) != ICPMI_OK) return ICPMI_ERR_HIP;
     if (ensure_cap(c, &c->d_hard, &c->cap_hard, (size_t)n * nscan + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
-    const size_t nb = std::max<size_t>(((size_t)n * k + 255) / 256, (size_t)acc_cap()); // slices of acc_cap() rows (see accumulate_kernel)
-    if (ensure_cap(c, &c->d_partials, &c->cap_partials, nb * ICPMI_NV * nscan) != ICPMI_OK) return ICPMI_ERR_HIP;
     if (k == 1 && ensure_cap(c, &c->d_match_pt, &c->cap_match_pt, (size_t)n * nscan + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
     if (ensure_cap(c, &c->d_selhist, &c->cap_selhist, (size_t)ICPMI_SELHIST_WORDS * nscan) != ICPMI_OK) return ICPMI_ERR_HIP;
     return ICPMI_OK;
@@ -1524,9 +1015,9 @@ static void enqueue_selection(icpmi_ctx* c, const LoopCfg& lc, int64_t count, bo
         const int nb = (int)lc.out_param2[f];
         for (int dest = 1; dest <= 2; ++dest) {
 #define MAD_PASS(P) \
-            if (dest == 1) hipLaunchKernelGGL((sel_hist_kernel<P, 1>), dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist, nb); \
-            else hipLaunchKernelGGL((sel_hist_kernel<P, 2>), dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist, nb); \
-            hipLaunchKernelGGL(sel_scan_kernel<P>, dim3(1), dim3(256), 0, c->stream, c->d_state, c->d_selhist, -1.f, f, 0, 0.f, dest, nb);
+            if (dest == 1) hipLaunchKernelGGL((sel_hist_kernel<P, 1>), dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->st_cur, c->d_selhist, nb); \
+            else hipLaunchKernelGGL((sel_hist_kernel<P, 2>), dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->st_cur, c->d_selhist, nb); \
+            hipLaunchKernelGGL(sel_scan_kernel<P>, dim3(1), dim3(256), 0, c->stream, c->st_cur, c->d_selhist, -1.f, f, 0, 0.f, dest, nb);
             MAD_PASS(0) MAD_PASS(1) MAD_PASS(2)
 #undef MAD_PASS
         }
@@ -1536,15 +1027,15 @@ static void enqueue_selection(icpmi_ctx* c, const LoopCfg& lc, int64_t count, bo
         VtBuffers vb;
         if (vt_buffers(c, count, &vb) != ICPMI_OK) return; // reserved by the caller: cannot fail here
         const long long min_el = (long long)floorf(lc.out_param[f] * (float)count), max_el = (long long)floorf(lc.out_param2[f] * (float)count);
-        hipLaunchKernelGGL(vt_keys_kernel, dim3((int)((count + 255) / 256)), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, vb.keys, vb.vals);
+        hipLaunchKernelGGL(vt_keys_kernel, dim3((int)((count + 255) / 256)), dim3(256), 0, c->stream, c->d_d2, count, c->st_cur, vb.keys, vb.vals);
         int half = 0;
         if (radix_sort_pairs(c, vb.keys, vb.vals, count, 32, vb.tab, &half) != ICPMI_OK) return;
         const unsigned long long* sorted = vb.keys + (half ? count : 0);
-        hipLaunchKernelGGL(vt_chunk_sums_kernel, dim3(vb.nchunks), dim3(256), 0, c->stream, sorted, c->d_state, vb.sums);
+        hipLaunchKernelGGL(vt_chunk_sums_kernel, dim3(vb.nchunks), dim3(256), 0, c->stream, sorted, c->st_cur, vb.sums);
         hipLaunchKernelGGL(vt_chunk_offsets_kernel, dim3(1), dim3(256), 0, c->stream, vb.sums, vb.nchunks);
-        hipLaunchKernelGGL(vt_frms_kernel, dim3(vb.nchunks), dim3(256), 0, c->stream, sorted, count, c->d_state, (const double*)vb.sums, min_el, max_el,
+        hipLaunchKernelGGL(vt_frms_kernel, dim3(vb.nchunks), dim3(256), 0, c->stream, sorted, count, c->st_cur, (const double*)vb.sums, min_el, max_el,
                            lc.out_param3[f], vb.best_val, vb.best_idx);
-        hipLaunchKernelGGL(vt_pick_kernel, dim3(1), dim3(256), 0, c->stream, sorted, count, c->d_state, (const double*)vb.best_val,
+        hipLaunchKernelGGL(vt_pick_kernel, dim3(1), dim3(256), 0, c->stream, sorted, count, c->st_cur, (const double*)vb.best_val,
                            (const long long*)vb.best_idx, vb.nchunks, min_el, f);
     }
     if (slot >= 0) {
@@ -1557,11 +1048,11 @@ static void enqueue_selection(icpmi_ctx* c, const LoopCfg& lc, int64_t count, bo
             // matches: 1024 per workgroup -6 %, 2048 baseline, 4096 +0.8 %, 8192 -4 %)
             int hb0 = (int)std::min<int64_t>((count + 4095) / 4096, 256);
             if (hb0 < 1) hb0 = 1;
-            hipLaunchKernelGGL(sel2_hist0_kernel, dim3(hb0, ba.nscan), dim3(256), 0, c->stream, c->d_d2, ba, lc.k, c->d_state, c->d_selhist);
+            hipLaunchKernelGGL(sel2_hist0_kernel, dim3(hb0, ba.nscan), dim3(256), 0, c->stream, c->d_d2, ba, lc.k, c->st_cur, c->d_selhist);
         }
         int hb2 = (int)std::min<int64_t>((count + 511) / 512, 512);
         if (hb2 < 1) hb2 = 1;
-        hipLaunchKernelGGL(sel2_scan_hist_kernel, dim3(hb2, ba.nscan), dim3(256), 0, c->stream, c->d_d2, ba, lc.k, c->d_state, c->d_selhist, quant);
+        hipLaunchKernelGGL(sel2_scan_hist_kernel, dim3(hb2, ba.nscan), dim3(256), 0, c->stream, c->d_d2, ba, lc.k, c->st_cur, c->d_selhist, quant);
         return;
     }
     for (int f = 0; f < lc.n_out; ++f) {
@@ -1570,12 +1061,12 @@ static void enqueue_selection(icpmi_ctx* c, const LoopCfg& lc, int64_t count, bo
         const int is_med = type == ICPMI_OUT_MEDIANDIST;
         const float quant = is_med ? 0.5f : lc.out_param[f];
         const float factor = lc.out_param[f];
-        hipLaunchKernelGGL((sel_hist_kernel<0, 0>), dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist, 0);
-        hipLaunchKernelGGL(sel_scan_kernel<0>, dim3(1), dim3(256), 0, c->stream, c->d_state, c->d_selhist, quant, f, is_med, factor, 0, 0);
-        hipLaunchKernelGGL((sel_hist_kernel<1, 0>), dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist, 0);
-        hipLaunchKernelGGL(sel_scan_kernel<1>, dim3(1), dim3(256), 0, c->stream, c->d_state, c->d_selhist, quant, f, is_med, factor, 0, 0);
-        hipLaunchKernelGGL((sel_hist_kernel<2, 0>), dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist, 0);
-        hipLaunchKernelGGL(sel_scan_kernel<2>, dim3(1), dim3(256), 0, c->stream, c->d_state, c->d_selhist, quant, f, is_med, factor, 0, 0);
+        hipLaunchKernelGGL((sel_hist_kernel<0, 0>), dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->st_cur, c->d_selhist, 0);
+        hipLaunchKernelGGL(sel_scan_kernel<0>, dim3(1), dim3(256), 0, c->stream, c->st_cur, c->d_selhist, quant, f, is_med, factor, 0, 0);
+        hipLaunchKernelGGL((sel_hist_kernel<1, 0>), dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->st_cur, c->d_selhist, 0);
+        hipLaunchKernelGGL(sel_scan_kernel<1>, dim3(1), dim3(256), 0, c->stream, c->st_cur, c->d_selhist, quant, f, is_med, factor, 0, 0);
+        hipLaunchKernelGGL((sel_hist_kernel<2, 0>), dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->st_cur, c->d_selhist, 0);
+        hipLaunchKernelGGL(sel_scan_kernel<2>, dim3(1), dim3(256), 0, c->stream, c->st_cur, c->d_selhist, quant, f, is_med, factor, 0, 0);
     }
 }
 
@@ -1600,14 +1091,14 @@ static void launch_accumulate_ext(icpmi_ctx* c, int64_t n, const LoopCfg& lc, in
     const bool sorted = c->nn_out_sorted; // loop state in query order (k = 1: with the matched points, see nn1_wg_kernel; k > 1: ids and d2)
     const BatchArgs ba = cur_batch(c, n);
     if (lc.k > 1) {
-        hipLaunchKernelGGL((accumulate_kernel<MIN, FUSED, EXT, 1024>), dim3(nb, ba.nscan), dim3(1024), 0, c->stream, sorted ? c->d_qsorted : c->d_reading, ba, acc_cap(), lc, c->d_state,
-                           c->d_map_sorted, c->has_normals ? c->d_normals_sorted : (const float4*)nullptr, rn, c->d_sidx, c->d_d2, c->d_partials, c->d_selhist, slot, is_med, factor,
+        hipLaunchKernelGGL((accumulate_kernel<MIN, FUSED, EXT, 1024>), dim3(nb, ba.nscan), dim3(1024), 0, c->stream, sorted ? c->d_qsorted : c->d_reading, ba, acc_cap(), lc, c->st_cur,
+                           c->d_map_sorted, c->has_normals ? c->d_normals_sorted : (const float4*)nullptr, rn, c->d_sidx, c->d_d2, c->acc_parity_cur, c->d_selhist, slot, is_med, factor,
                            (const float4*)nullptr, sorted ? c->d_qindex : (const int*)nullptr, (EXT && c->raw_has_scalar) ? c->d_raw_s : (const float*)nullptr,
                            (MIN == ICPMI_MIN_POINT_TO_PLANE && c->has_normals && c->d_map_pn && pn_enabled()) ? c->d_map_pn : (const float4*)nullptr);
         return;
     }
-    hipLaunchKernelGGL((accumulate_kernel<MIN, FUSED, EXT>), dim3(nb, ba.nscan), dim3(256), 0, c->stream, sorted ? c->d_qsorted : c->d_reading, ba, acc_cap(), lc, c->d_state,
-                       c->d_map_sorted, c->has_normals ? c->d_normals_sorted : (const float4*)nullptr, rn, c->d_sidx, c->d_d2, c->d_partials, c->d_selhist, slot, is_med, factor,
+    hipLaunchKernelGGL((accumulate_kernel<MIN, FUSED, EXT>), dim3(nb, ba.nscan), dim3(256), 0, c->stream, sorted ? c->d_qsorted : c->d_reading, ba, acc_cap(), lc, c->st_cur,
+                       c->d_map_sorted, c->has_normals ? c->d_normals_sorted : (const float4*)nullptr, rn, c->d_sidx, c->d_d2, c->acc_parity_cur, c->d_selhist, slot, is_med, factor,
                        (sorted && lc.k == 1) ? c->d_match_pt : (const float4*)nullptr, sorted ? c->d_qindex : (const int*)nullptr,
                        (EXT && c->raw_has_scalar) ? c->d_raw_s : (const float*)nullptr,
                        (lc.k > 1 && MIN == ICPMI_MIN_POINT_TO_PLANE && c->has_normals && c->d_map_pn && pn_enabled()) ? c->d_map_pn : (const float4*)nullptr);
@@ -1633,12 +1124,67 @@ static void enqueue_accumulate_solve(icpmi_ctx* c, int64_t n, const LoopCfg& lc,
         else launch_accumulate<ICPMI_MIN_IDENTITY, false>(c, n, lc, nb, slot);
     }
     const BatchArgs ba = cur_batch(c, n);
-    hipLaunchKernelGGL(solve_kernel, dim3(ba.nscan), dim3(256), 0, c->stream, c->d_state, c->d_partials, ba, acc_cap(), lc, d_Tstep, d_sums, c->d_progress);
+    if (c->fsolve_cur) return; // the next NN launch (or enqueue_finish) solves
+    hipLaunchKernelGGL(solve_kernel, dim3(ba.nscan), dim3(256), 0, c->stream, c->d_state, (const IcpState*)nullptr, c->d_selhist, 0, 1, lc, d_Tstep, d_sums,
+                       c->d_progress);
+}
+
+// r4: may the solve ride in the NN launches of this registration (common.h: nn_fs_*)?  Only where that launch is nn1_wg_kernel<4, true> on
+// the query-ordered state (k = 1, no brute pass, tile-sorted reading) and the chain's other kernels keep nothing in IcpState across
+// iterations that workgroup 0's copy could race with (no EXT filters, no VarTrimmed, at most one quantile filter, no sensor-noise pass).
+static bool fsolve_eligible(const icpmi_ctx* c, const LoopCfg& lc, int64_t n)
+{
+    static int wq = -1, wg = -1, keep = -1, seg = -1;
+    const int on = 1;
+    if (wq < 0) {
+        const char* e = getenv("ICPMI_NN_WQ"); wq = e ? atoi(e) : 1;
+        e = getenv("ICPMI_NN_WG"); wg = e ? atoi(e) : 4;
+        e = getenv("ICPMI_SORTED_STATE"); keep = e ? atoi(e) : 1;
+        e = getenv("ICPMI_SEG"); seg = e ? atoi(e) : 4;
+    }
+    if (!on || !wq || wg != 4 || !keep || (seg & 1)) return false;
+    if (lc.k != 1 || lc.ext || lc.sensor_noise || chain_has_vartrimmed(lc) || c->batch_cur > 1 || c->cfg.knn > 8 || n <= 0) return false;
+    int nq = 0;
+    for (int f = 0; f < lc.n_out; ++f) nq += lc.out_type[f] == ICPMI_OUT_TRIMMEDDIST || lc.out_type[f] == ICPMI_OUT_MEDIANDIST;
+    if (nq > 1) return false;
+    const GridParams& top = c->levels.g[c->levels.nlev - 1];
+    return std::isfinite(lc.max_dist) && (top.cell - top.slack) > lc.max_dist; // (else the launch is followed by the brute pass)
+}
+
+// the solve that closes a fused-solve sequence of `done_iters` iterations: state[(done_iters - 1) & 1] + its accumulators -> state[done_iters & 1]
+static void enqueue_finish(icpmi_ctx* c, const LoopCfg& lc, int done_iters)
+{
+    if (done_iters <= 0) return;
+    IcpState* in = c->d_state + ((done_iters - 1) & 1) * ICPMI_MAX_BATCH;
+    IcpState* out = c->d_state + (done_iters & 1) * ICPMI_MAX_BATCH;
+    hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(256), 0, c->stream, out, (const IcpState*)in, c->d_selhist, (done_iters - 1) & 1, 0, lc, (float*)nullptr,
+                       (double*)nullptr, c->d_progress);
 }
 
 static icpmi_status enqueue_iteration(icpmi_ctx* c, int64_t n, const LoopCfg& lc, hipEvent_t nn0, hipEvent_t nn1)
 {
     if (nn0) HIP_TRY(c, hipEventRecord(nn0, c->stream));
+    if (c->fsolve_cur) {
+        // iteration L = c->nn_iter_hint: its NN launch solves iteration L - 1 (state and accumulators of parity (L - 1) & 1) and writes
+        // state[L & 1], which the selection and the pair sums of iteration L then work on; the pair sums go to parity L & 1
+        const int L = c->nn_iter_hint;
+        IcpState* cur = c->d_state + (L & 1) * ICPMI_MAX_BATCH;
+        c->nn_fsolve = true; c->nn_fs_pending = L > 0; c->nn_fs_prev = c->d_state + ((L - 1) & 1) * ICPMI_MAX_BATCH;
+        c->nn_fs_acc_parity = (L - 1) & 1; c->nn_fs_lc = lc;
+        c->nn_hist0 = fused_filter_slot(lc) >= 0 ? c->d_selhist : nullptr;
+        c->nn_builds_hist0 = false;
+        c->nn_match_pt = c->d_match_pt; c->nn_sorted_k = false; c->nn_out_sorted = false;
+        icpmi_status s = nn_launch_k(c, c->d_reading, n, cur->T_iter, lc, 1, c->d_sidx, c->d_d2, cur);
+        c->nn_fsolve = false;
+        if (s != ICPMI_OK) return s;
+        if (nn1) HIP_TRY(c, hipEventRecord(nn1, c->stream));
+        c->st_cur = cur; c->acc_parity_cur = (L & 1) | (L > 0 ? 2 : 0);
+        enqueue_selection(c, lc, n * lc.k);
+        enqueue_accumulate_solve(c, n, lc, nullptr, nullptr);
+        c->st_cur = c->d_state; c->acc_parity_cur = 0;
+        HIP_TRY(c, hipGetLastError());
+        return ICPMI_OK;
+    }
     c->nn_hist0 = fused_filter_slot(lc) >= 0 ? c->d_selhist : nullptr;
     c->nn_builds_hist0 = false;
     static int keep_pts = -1;
@@ -1716,6 +1262,20 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
     const bool profile = c->cfg.profile != 0;
     const bool graph = c->cfg.use_graph != 0 && fixed && !profile;
     float nn_ms_sum = 0.f; int nn_cnt = 0;
+    // r4: three launches per iteration -- the solve rides in the next NN launch (common.h: nn_fs_*; nn.hip: FusedSolve)
+    struct FsGuard { icpmi_ctx* c; ~FsGuard() { c->fsolve_cur = false; c->st_cur = c->d_state; c->acc_parity_cur = 0; } } fs_guard{c};
+    // Measured (r4, 100 k x 1 M, A/B in one call): fixed-count point-to-point 23.0 k -> 23.75 k it/s (the NN launch grows by 3.9 us, a 5.6 us
+    // launch and a boundary go); fixed-count point-to-plane 24.9 k -> 24.4 k (its solve costs 6 us in the prologue); checked loops 0.382 ->
+    // 0.392 ms per 6-iteration registration (every segment ends on a closing solve, the Differential checker runs in every workgroup).
+    // Off unless asked for: icpmi_config::fuse_solve (1: wherever eligible, 2: fixed-count point-to-point only) or ICPMI_FUSE_SOLVE.
+    {
+        static int env_mode = -2;
+        if (env_mode == -2) { const char* e = getenv("ICPMI_FUSE_SOLVE"); env_mode = e ? atoi(e) : -1; }
+        const int mode = env_mode >= 0 ? env_mode : c->cfg.fuse_solve;
+        c->fsolve_cur = mode > 0 && fsolve_eligible(c, lc, n) &&
+                        (mode == 1 || (fixed && lc.minimizer == ICPMI_MIN_POINT_TO_POINT && !lc.use_diff && !lc.use_bound));
+    }
+    int fin_parity = 0; // which of the two states holds the result (fused solve: the parity of the number of iterations enqueued)
 
     c->reg_seq = (c->reg_seq + 1) & 0x7ffffu;
     if (c->h_progress) __atomic_store_n(c->h_progress + 32, c->reg_seq, __ATOMIC_RELEASE);
@@ -1737,7 +1297,7 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
         const int S = seg_cfg < lc.max_iter ? seg_cfg : lc.max_iter;
         uint64_t sig = 1469598103934665603ull;
         sig = fnv(&lc, sizeof lc, sig);
-        const void* ptrs[] = {d_scan, d_normals3, c->d_qkeys, c->d_qtile,c->d_reading, c->d_read_normals, c->d_sidx, c->d_d2, c->d_hard, c->d_partials, c->d_state, c->d_match_pt,
+        const void* ptrs[] = {d_scan, d_normals3, c->d_qkeys, c->d_qtile,c->d_reading, c->d_read_normals, c->d_sidx, c->d_d2, c->d_hard, c->d_state, c->d_match_pt,
                               c->d_qsorted, c->d_qindex, c->d_map_sorted, c->d_normals_sorted, c->d_cell_start, c->d_selhist,
                               c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3], c->scratch[4]};
         sig = fnv(ptrs, sizeof ptrs, sig);
@@ -1750,6 +1310,9 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
                 icpmi_status s = g == 0 ? enqueue_registration_head(c, d_scan, d_normals3, n) : ICPMI_OK;
                 // (later segments: every iteration is seeded and past the wide first launches -- one graph serves them all)
                 for (int it = 0; it < S && s == ICPMI_OK; ++it) { c->nn_iter_hint = g == 0 ? it : S + it; s = enqueue_iteration(c, n, lc, nullptr, nullptr); }
+                // (fused solve: the segment ends with the solve of its last iteration -- the next segment's first NN launch redoes it,
+                // identically, from the same state and accumulators; S is even, so both kinds of segment start on parity 0)
+                if (s == ICPMI_OK && c->fsolve_cur) enqueue_finish(c, lc, g == 0 ? S : 2 * S);
                 hipError_t ce = hipStreamEndCapture(c->stream, &gr);
                 if (s != ICPMI_OK) { if (gr) hipGraphDestroy(gr); return s; }
                 HIP_TRY(c, ce);
@@ -1784,12 +1347,13 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
             HIP_TRY(c, hipGraphLaunch(c->seg_exec[1], c->stream));
             launched += S;
         }
+        fin_parity = c->fsolve_cur ? (launched & 1) : 0;
     } else if (graph) {
         // the whole registration -- head and all iterations -- is one graph, replayed while the scan
         // buffer, the map and the chain stay the same
         uint64_t sig = 1469598103934665603ull;
         sig = fnv(&lc, sizeof lc, sig);
-        const void* ptrs[] = {d_scan, d_normals3, c->d_qkeys, c->d_qtile,c->d_reading, c->d_read_normals, c->d_sidx, c->d_d2, c->d_hard, c->d_partials, c->d_state, c->d_match_pt,
+        const void* ptrs[] = {d_scan, d_normals3, c->d_qkeys, c->d_qtile,c->d_reading, c->d_read_normals, c->d_sidx, c->d_d2, c->d_hard, c->d_state, c->d_match_pt,
                               c->d_qsorted, c->d_qindex,
                               c->d_map_sorted, c->d_normals_sorted, c->d_cell_start, c->d_selhist,
                               c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3], c->scratch[4]}; // (VarTrimmedDist passes)
@@ -1801,6 +1365,7 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
             HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
             icpmi_status s = enqueue_registration_head(c, d_scan, d_normals3, n);
             for (int it = 0; it < lc.max_iter && s == ICPMI_OK; ++it) { c->nn_iter_hint = it; s = enqueue_iteration(c, n, lc, nullptr, nullptr); }
+            if (s == ICPMI_OK && c->fsolve_cur) enqueue_finish(c, lc, lc.max_iter);
             hipError_t ce = hipStreamEndCapture(c->stream, &g);
             if (s != ICPMI_OK) { if (g) hipGraphDestroy(g); return s; }
             HIP_TRY(c, ce);
@@ -1811,6 +1376,7 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
         }
         HIP_TRY(c, hipGraphLaunch(c->graph_exec, c->stream));
         if (c->cfg.knn <= 8) { c->qsorted_n = n; c->qsorted_src = c->d_reading; } // what the replayed head leaves in d_qsorted
+        fin_parity = c->fsolve_cur ? (lc.max_iter & 1) : 0;
     } else {
         const int check_every = (lc.use_diff || lc.use_bound) ? 4 : lc.max_iter;
         if (profile && c->nn_events.size() < (size_t)2 * lc.max_iter) {
@@ -1849,16 +1415,22 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
                         // everything enqueued has run: the word is final (a kernel that stops the loop without passing
                         // through the solve kernel cannot leave the host waiting)
                         const unsigned w = __atomic_load_n(c->h_progress, __ATOMIC_ACQUIRE);
-                        stopped = ((w >> 12) & 0x7ffffu) != c->reg_seq || (w >> 31) != 0 || (int)(w & 0xfffu) <= it;
+                        // (fused solve: iteration `it` is acknowledged by the NEXT NN launch -- an idle stream at `it` means "go on")
+                        stopped = ((w >> 12) & 0x7ffffu) != c->reg_seq || (w >> 31) != 0 || (int)(w & 0xfffu) + (c->fsolve_cur ? 1 : 0) <= it;
                         break;
                     }
                 }
             } else if ((it + 1) % check_every == 0) {
-                HIP_TRY(c, hipMemcpyAsync(&c->h_state->done, &c->d_state->done, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                // (fused solve: the stop decision of iteration `it` is taken by the NEXT NN launch; asked for now, it takes the closing
+                // solve -- which that launch then repeats, identically)
+                if (c->fsolve_cur) enqueue_finish(c, lc, it + 1);
+                const IcpState* sd = c->d_state + (c->fsolve_cur ? ((it + 1) & 1) * ICPMI_MAX_BATCH : 0);
+                HIP_TRY(c, hipMemcpyAsync(&c->h_state->done, &sd->done, sizeof(int), hipMemcpyDeviceToHost, c->stream));
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
                 if (c->h_state->done) break;
             }
         }
+        if (c->fsolve_cur) { enqueue_finish(c, lc, launched); fin_parity = launched & 1; }
         if (profile) {
             // back-to-back event pair: what two records cost with nothing in between (subtracted below)
             if (c->nn_events.size() < (size_t)2 * lc.max_iter + 2) {
@@ -1867,7 +1439,7 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
             HIP_TRY(c, hipEventRecord(c->nn_events[2 * lc.max_iter], c->stream));
             HIP_TRY(c, hipEventRecord(c->nn_events[2 * lc.max_iter + 1], c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
-            HIP_TRY(c, hipMemcpy(c->h_state, c->d_state, sizeof(IcpState), hipMemcpyDeviceToHost));
+            HIP_TRY(c, hipMemcpy(c->h_state, c->d_state + fin_parity * ICPMI_MAX_BATCH, sizeof(IcpState), hipMemcpyDeviceToHost));
             const int iters_done = c->h_state->iter < launched ? c->h_state->iter : launched;
             for (int it = 0; it < iters_done; ++it) {
                 float ms = 0.f;
@@ -1881,7 +1453,7 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
         }
     }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(IcpState), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_state, c->d_state + fin_parity * ICPMI_MAX_BATCH, sizeof(IcpState), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
 
     fill_stats(c, lc, n, stats);
@@ -1993,7 +1565,7 @@ icpmi_status loop_run_batch(icpmi_ctx* c, int B, const float* const* d_scans4, c
         sig = fnv(&lc, sizeof lc, sig);
         sig = fnv(&ba, sizeof ba, sig);
         sig = fnv(&src, sizeof src, sig);
-        const void* ptrs[] = {c->d_qkeys, c->d_qtile, c->d_reading, c->d_sidx, c->d_d2, c->d_hard, c->d_partials, c->d_state, c->d_match_pt,
+        const void* ptrs[] = {c->d_qkeys, c->d_qtile, c->d_reading, c->d_sidx, c->d_d2, c->d_hard, c->d_state, c->d_match_pt,
                               c->d_qsorted, c->d_qindex, c->d_map_sorted, c->d_normals_sorted, c->d_cell_start, c->d_selhist};
         sig = fnv(ptrs, sizeof ptrs, sig);
         sig = fnv(&c->grid, sizeof c->grid, sig);
