@@ -195,6 +195,8 @@ void icpmi_destroy(icpmi_handle c)
     hipFree(c->d_map_sorted); hipFree(c->d_normals_sorted); hipFree(c->d_cell_start);
     for (int l = 0; l < ICPMI_MAXLEV; ++l) { hipFree(c->d_lvl_pts[l]); hipFree(c->d_lvl_cs[l]); hipFree(c->d_lvl_pos0[l]); }
     hipFree(c->d_inv);
+    for (int l = 0; l < ICPMI_MAXLEV; ++l) { hipFree(c->d_lvl_key[l]); hipFree(c->d_alt_pts[l]); hipFree(c->d_alt_cs[l]); hipFree(c->d_alt_pos0[l]); hipFree(c->d_alt_key[l]); }
+    hipFree(c->d_alt_nsorted); hipFree(c->d_alt_pn); hipFree(c->d_ins_key); hipFree(c->d_ins_rank);
     hipFree(c->d_keys); hipFree(c->d_fill); hipFree(c->d_blocksums); hipFree(c->d_red);
     hipFree(c->d_qsorted); hipFree(c->d_qindex); hipFree(c->d_qkeys); hipFree(c->d_qtile);
     hipFree(c->d_reading); hipFree(c->d_read_normals); hipFree(c->d_stage_in); hipFree(c->d_stage_n3);
@@ -240,6 +242,10 @@ icpmi_status icpmi_debug_counters(icpmi_handle h, uint64_t out[24])
 {
     if (!h || !out) return ICPMI_ERR_INVALID_ARG;
     for (int i = 0; i < 24; ++i) out[i] = h->h_state->dbg[i];
+    // [18] / [19]: index builds served by the incremental insert / from scratch (low word: this handle's registration index; high
+    // word: its private raw-frame index, ops.hip: raw_index)
+    out[18] = (uint64_t)(uint32_t)h->ins_count | ((uint64_t)(uint32_t)(h->temp_raw ? h->temp_raw->ins_count : 0) << 32);
+    out[19] = (uint64_t)(uint32_t)h->full_count | ((uint64_t)(uint32_t)(h->temp_raw ? h->temp_raw->full_count : 0) << 32);
     return ICPMI_OK;
 }
 

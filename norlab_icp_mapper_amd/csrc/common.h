@@ -189,7 +189,28 @@ struct icpmi_ctx {
     float4* d_lvl_pts[ICPMI_MAXLEV] = {};   size_t cap_lvl_pts[ICPMI_MAXLEV] = {};
     unsigned* d_lvl_cs[ICPMI_MAXLEV] = {};  size_t cap_lvl_cs[ICPMI_MAXLEV] = {};
     unsigned* d_lvl_pos0[ICPMI_MAXLEV] = {}; size_t cap_lvl_pos0[ICPMI_MAXLEV] = {};
-    unsigned* d_inv = nullptr; size_t cap_inv = 0; // original index -> level-0 position
+    unsigned* d_inv = nullptr; size_t cap_inv = 0; // original index -> level-0 position (kept for the incremental insert, map_build.hip: map_insert)
+    // r4: incremental index insert.  A map that grew by an APPEND (Map::updateLocalPointCloud with PointDistanceMapperModule, the merge epoch
+    // of the scan-sharded mapper) keeps its grid; its new index is the old one with the delta merged into the cell-sorted arrays of every
+    // level -- one streaming pass per level instead of keys + histogram + scan + atomic scatter over all points.  The result is what a
+    // full build on the same grid produces up to the order inside a cell (which nothing downstream sees): centred coordinates are
+    // recomputed from the raw points with the NEW centroid, bit for bit what map_build writes.
+    unsigned* d_lvl_key[ICPMI_MAXLEV] = {}; size_t cap_lvl_key[ICPMI_MAXLEV] = {};   // cell of every sorted position, per level
+    float4* d_alt_pts[ICPMI_MAXLEV] = {};   size_t cap_alt_pts[ICPMI_MAXLEV] = {};   // ping-pong set the merge writes into
+    unsigned* d_alt_cs[ICPMI_MAXLEV] = {};  size_t cap_alt_cs[ICPMI_MAXLEV] = {};
+    unsigned* d_alt_pos0[ICPMI_MAXLEV] = {}; size_t cap_alt_pos0[ICPMI_MAXLEV] = {};
+    unsigned* d_alt_key[ICPMI_MAXLEV] = {}; size_t cap_alt_key[ICPMI_MAXLEV] = {};
+    float4* d_alt_nsorted = nullptr; size_t cap_alt_nsorted = 0;
+    float4* d_alt_pn = nullptr; size_t cap_alt_pn = 0;
+    unsigned* d_ins_key = nullptr; size_t cap_ins_key = 0;   // delta: cell key and rank inside the cell, per level
+    unsigned* d_ins_rank = nullptr; size_t cap_ins_rank = 0;
+    bool ins_ready = false;            // the current index carries the key / inverse arrays the insert needs
+    double sum_raw[3] = {0, 0, 0};     // sum of the raw coordinates of the indexed cloud (the centroid of the grown cloud without a pass over it)
+    float lo_raw[3] = {0, 0, 0}, hi_raw[3] = {0, 0, 0}; // its bounding box
+    float cell0 = 0.f;                 // level-0 cell edge as chosen by the last full build (the insert keeps it)
+    uint64_t raw_epoch = 0;            // bumped whenever d_raw is rewritten other than by an append (private raw index: ops.hip)
+    uint64_t temp_raw_epoch = 0; int64_t temp_raw_m = 0;
+    int64_t ins_count = 0, full_count = 0; // builds served by the insert / by the full path (diagnostics)
 
     // scratch for set_map
     unsigned* d_keys = nullptr; size_t cap_keys = 0;
@@ -240,6 +261,7 @@ struct icpmi_ctx {
     bool single_level = false;        // temp handles of the self k-NN (surface normals): level 0 of the pyramid is all they search
     bool keep_raw = true;             // temp handles index clouds they do not own: no resident copy of the input
     bool no_centre = false;           // temp handles of the map-side operators: index raw coordinates (mean = 0)
+    bool is_raw_index = false;        // the private raw-frame index of a resident map (ops.hip: raw_index): grows by appends with its owner
     int*    d_sidx = nullptr; size_t cap_sidx = 0;             // k x n sorted-map index (-1 none)
     float*  d_d2 = nullptr; size_t cap_d2 = 0;                 // k x n
     unsigned* d_hard = nullptr; size_t cap_hard = 0;           // hard query list
@@ -497,7 +519,8 @@ struct SortHead {
 };
 
 // ---- cross-TU host entry points ---------------------------------------------------------------
-icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float* d_normals3);
+// keep_prefix: the first keep_prefix points of d_pts are the cloud of the previous build, unchanged and in the same order (an append)
+icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float* d_normals3, int64_t keep_prefix = 0);
 icpmi_status device_exclusive_scan(icpmi_ctx* c, unsigned* data, int n, unsigned total);
 icpmi_status sort_queries(icpmi_ctx* c, const float4* d_pts, int64_t n);
 icpmi_status sort_queries_reserve(icpmi_ctx* c, int64_t n, int nscan = 1);

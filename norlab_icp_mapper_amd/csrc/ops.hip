@@ -508,16 +508,19 @@ static icpmi_status raw_index(icpmi_ctx* c, icpmi_ctx** out, float reach)
     icpmi_ctx* t = c->temp_raw;
     share_stream(c, t);
     const float built_reach = t->cfg.max_dist;
-    t->cfg = c->cfg; t->keep_raw = false; t->no_centre = true; t->single_level = false;
+    t->cfg = c->cfg; t->keep_raw = false; t->no_centre = true; t->single_level = false; t->is_raw_index = true;
     const float want = reach > 1e-3f ? reach : 1e-3f;
     const bool current = c->temp_raw_version == c->map_version && t->m == c->m_raw && t->m > 0;
     t->cfg.max_dist = current && built_reach >= want ? built_reach : want;
     if (!current || built_reach < want) {
         if (t->stream != c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream)); // the resident copy was produced on the caller's stream
-        int32_t ok = 0;
-        icpmi_status s = icpmi_set_map_dev(t, (const float*)c->d_raw, c->m_raw, nullptr, &ok);
+        if (c->m_raw <= 0) { c->last_error = "raw_index: no resident map"; return ICPMI_ERR_INVALID_ARG; }
+        // r4: the resident map grew by an append since this index was built (same raw_epoch: nobody rewrote d_raw) -- the delta is
+        // merged into the cell-sorted arrays (map_build.hip: map_insert; raw coordinates, centroid 0: nothing is even recentred)
+        const bool grown = t->m > 0 && t->m < c->m_raw && c->temp_raw_epoch == c->raw_epoch && c->temp_raw_m == t->m && built_reach >= want;
+        icpmi_status s = map_build(t, c->d_raw, c->m_raw, nullptr, grown ? t->m : 0);
         if (s != ICPMI_OK) { c->last_error = t->last_error; return s; }
-        c->temp_raw_version = c->map_version;
+        c->temp_raw_version = c->map_version; c->temp_raw_epoch = c->raw_epoch; c->temp_raw_m = c->m_raw;
     }
     *out = t;
     return ICPMI_OK;
@@ -909,7 +912,8 @@ icpmi_status ops_map_update_dev(icpmi_ctx* c, const float4* d_scan, int64_t n, c
         // SurfaceNormalDataPointsFilter over the grown map (Map.cpp:524 with examples/config.yaml:26-27)
         if (s == ICPMI_OK && e == hipSuccess && normals_knn > 0) s = surface_normals_dev(c, c->d_raw, m1, normals_knn, c->d_raw_n3);
         // icp.setMap(localPointCloud) (Map.cpp:528): rebuild the index from the resident copy
-        if (s == ICPMI_OK && e == hipSuccess) s = map_build(c, c->d_raw, m1, want_n ? c->d_raw_n3 : nullptr);
+        // (an append: the first m0 resident points are the cloud the index was built from -- map_insert where it applies)
+        if (s == ICPMI_OK && e == hipSuccess) s = map_build(c, c->d_raw, m1, want_n ? c->d_raw_n3 : nullptr, (m0 > 0 && c->m == m0) ? m0 : 0);
         if (s == ICPMI_OK) { if (appended) *appended = count; if (new_m) *new_m = m1; }
     }
     if (s != ICPMI_OK) return s;
@@ -1139,6 +1143,7 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
     if (identity_prefix) *identity_prefix = 0;
     const int64_t m0 = c->m > 0 ? c->m_raw : 0;
     if (new_m) *new_m = m0;
+    ++c->raw_epoch; // the program may move, compact or reorder the resident points: the private raw-frame index is rebuilt, not appended to
     if (n_ops < 0 || n_modules < 0 || n_modules > n_ops || (n_ops > 0 && !ops)) { c->last_error = "map_update_chain: bad program"; return ICPMI_ERR_INVALID_ARG; }
     if (src_out && src_capacity < m0 + (int64_t)n_modules * n) { c->last_error = "map_update_chain: src_capacity must be >= m_old + n_modules * n"; return ICPMI_ERR_INVALID_ARG; }
     bool uses_scalar = false;

@@ -9,6 +9,11 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# the incremental index insert (csrc/map_build.hip: map_insert) is meant for maps of several million points; the tests want it on every
+# append, at their sizes (read once per process by the library)
+os.environ.setdefault("ICPMI_INSERT_MIN", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
