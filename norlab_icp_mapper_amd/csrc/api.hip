@@ -196,6 +196,7 @@ void icpmi_destroy(icpmi_handle c)
     for (int l = 0; l < ICPMI_MAXLEV; ++l) { hipFree(c->d_lvl_pts[l]); hipFree(c->d_lvl_cs[l]); hipFree(c->d_lvl_pos0[l]); }
     hipFree(c->d_inv);
     for (int l = 0; l < ICPMI_MAXLEV; ++l) { hipFree(c->d_lvl_key[l]); hipFree(c->d_alt_pts[l]); hipFree(c->d_alt_cs[l]); hipFree(c->d_alt_pos0[l]); hipFree(c->d_alt_key[l]); }
+    hipFree(c->d_raw0); hipFree(c->d_alt_raw0); hipFree(c->d_ins_dstart0);
     hipFree(c->d_alt_nsorted); hipFree(c->d_alt_pn); hipFree(c->d_ins_key); hipFree(c->d_ins_rank);
     hipFree(c->d_keys); hipFree(c->d_fill); hipFree(c->d_blocksums); hipFree(c->d_red);
     hipFree(c->d_qsorted); hipFree(c->d_qindex); hipFree(c->d_qkeys); hipFree(c->d_qtile);

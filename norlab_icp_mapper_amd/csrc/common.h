@@ -200,11 +200,15 @@ struct icpmi_ctx {
     unsigned* d_alt_cs[ICPMI_MAXLEV] = {};  size_t cap_alt_cs[ICPMI_MAXLEV] = {};
     unsigned* d_alt_pos0[ICPMI_MAXLEV] = {}; size_t cap_alt_pos0[ICPMI_MAXLEV] = {};
     unsigned* d_alt_key[ICPMI_MAXLEV] = {}; size_t cap_alt_key[ICPMI_MAXLEV] = {};
+    float4* d_raw0 = nullptr; size_t cap_raw0 = 0;           // level-0 twin: the RAW points (w = original index) in level-0 sorted order (centred handles)
+    float4* d_alt_raw0 = nullptr; size_t cap_alt_raw0 = 0;
+    unsigned* d_ins_dstart0 = nullptr; size_t cap_ins_dstart0 = 0; // level 0's delta prefix, kept while the upper levels are merged
     float4* d_alt_nsorted = nullptr; size_t cap_alt_nsorted = 0;
     float4* d_alt_pn = nullptr; size_t cap_alt_pn = 0;
     unsigned* d_ins_key = nullptr; size_t cap_ins_key = 0;   // delta: cell key and rank inside the cell, per level
     unsigned* d_ins_rank = nullptr; size_t cap_ins_rank = 0;
-    bool ins_ready = false;            // the current index carries the key / inverse arrays the insert needs
+    bool ins_ready = false;            // the current index carries the key / twin arrays the insert needs
+    bool ins_normals_changed = false;  // set by a caller that recomputed the normals of the WHOLE cloud before an append-build (ops.hip)
     double sum_raw[3] = {0, 0, 0};     // sum of the raw coordinates of the indexed cloud (the centroid of the grown cloud without a pass over it)
     float lo_raw[3] = {0, 0, 0}, hi_raw[3] = {0, 0, 0}; // its bounding box
     float cell0 = 0.f;                 // level-0 cell edge as chosen by the last full build (the insert keeps it)

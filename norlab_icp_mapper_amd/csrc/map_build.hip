@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(const float4* __restrict__
                                                       float mx, float my, float mz, const unsigned* __restrict__ keys,
                                                       const unsigned* __restrict__ start, unsigned* __restrict__ fill,
                                                       float4* __restrict__ out, float4* __restrict__ out_n, int run_atomics,
-                                                      unsigned* __restrict__ okey, unsigned* __restrict__ inv)
+                                                      unsigned* __restrict__ okey, float4* __restrict__ twin)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool valid = i < m;
@@ -197,7 +197,8 @@ __global__ __launch_bounds__(256) void scatter_kernel(const float4* __restrict__
     }
     out[pos] = make_float4(p.x - mx, p.y - my, p.z - mz, __uint_as_float((unsigned)i));
     if (out_n) out_n[pos] = make_float4(normals3[3 * i], normals3[3 * i + 1], normals3[3 * i + 2], 0.f);
-    if (okey) { okey[pos] = key; inv[i] = pos; } // (what an incremental insert of the next append needs, map_insert)
+    if (okey) okey[pos] = key;                                                   // (what an incremental insert of the next append needs,
+    if (twin) twin[pos] = make_float4(p.x, p.y, p.z, __uint_as_float((unsigned)i)); //  map_insert: the cell of every position, the raw points in sorted order)
 }
 
 __global__ __launch_bounds__(256) void lvl_key_kernel(const float4* __restrict__ pts0, int64_t m, GridParams g,
@@ -262,31 +263,55 @@ __global__ __launch_bounds__(256) void ins_key_kernel(const float4* __restrict__
     drank[j] = atomicAdd(&dcount[key], 1u);
 }
 
-// old sorted position s of this level -> s + (delta points in cells before its cell); coordinates recentred from the raw point
-__global__ __launch_bounds__(256) void ins_move_kernel(const float4* __restrict__ pts_old, const unsigned* __restrict__ key_old, int64_t m0,
-                                                       const unsigned* __restrict__ dstart, const float4* __restrict__ raw, float mx, float my, float mz,
-                                                       int recentre, float4* __restrict__ pts_new, unsigned* __restrict__ key_new,
-                                                       unsigned* __restrict__ inv /* level 0: written; level > 0: read */, unsigned* __restrict__ pos0_new,
-                                                       const float* __restrict__ normals3, float4* __restrict__ nrm_new, float4* __restrict__ pn_new)
+// Level 0: old sorted position s -> s + (delta points in cells before its cell).  The centred coordinates are recomputed from the RAW
+// point with the new centroid (exactly scatter_kernel's arithmetic); the raw points travel in a twin array in the same order
+// (d_raw0: streamed, not gathered by original index -- a random 16-byte gather per point was 370 us of this kernel at 10 M points).
+// Handles that index raw coordinates (centroid 0) have no twin: their points are copied.
+__global__ __launch_bounds__(256) void ins_move0_kernel(const float4* __restrict__ pts_old, const float4* __restrict__ twin_old,
+                                                        const unsigned* __restrict__ key_old, int64_t m0, const unsigned* __restrict__ dstart,
+                                                        float mx, float my, float mz, float4* __restrict__ pts_new, float4* __restrict__ twin_new,
+                                                        unsigned* __restrict__ key_new, const float* __restrict__ normals3,
+                                                        const float4* __restrict__ nrm_old, float4* __restrict__ nrm_new, float4* __restrict__ pn_new)
 {
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (s >= m0) return;
-    float4 p = pts_old[s];
     const unsigned c = key_old[s];
-    const unsigned o = __float_as_uint(p.w);
     const unsigned np = (unsigned)s + dstart[c];
-    if (recentre) { const float4 r = raw[o]; p.x = r.x - mx; p.y = r.y - my; p.z = r.z - mz; } // exactly scatter_kernel's arithmetic
+    float4 p;
+    if (twin_old) {
+        const float4 r = twin_old[s];
+        twin_new[np] = r;
+        p = make_float4(r.x - mx, r.y - my, r.z - mz, r.w);
+    } else p = pts_old[s];
     pts_new[np] = p;
     key_new[np] = c;
-    if (pos0_new) pos0_new[np] = inv[o];
-    else {
-        inv[o] = np;
-        if (nrm_new) {
-            const float4 nn = make_float4(normals3[3 * (size_t)o], normals3[3 * (size_t)o + 1], normals3[3 * (size_t)o + 2], 0.f);
-            nrm_new[np] = nn;
-            if (pn_new) { pn_new[2 * (size_t)np] = p; pn_new[2 * (size_t)np + 1] = nn; }
-        }
+    if (nrm_new) {
+        // (normals3 != nullptr: the caller recomputed the whole field -- gathered by original index; else the old sorted normals move along)
+        float4 nn;
+        if (normals3) { const unsigned o = __float_as_uint(p.w); nn = make_float4(normals3[3 * (size_t)o], normals3[3 * (size_t)o + 1], normals3[3 * (size_t)o + 2], 0.f); }
+        else nn = nrm_old[s];
+        nrm_new[np] = nn;
+        if (pn_new) { pn_new[2 * (size_t)np] = p; pn_new[2 * (size_t)np + 1] = nn; }
     }
+}
+
+// Level l > 0: the entry moves by the delta points in cells before its cell OF THIS LEVEL; its level-0 position moves by the delta
+// points before its level-0 cell, and its coordinates are read from the NEW level-0 array at that position (both orders are spatial:
+// the gathers stay inside a few contiguous runs) -- what lvl_scatter_kernel copies in a full build.
+__global__ __launch_bounds__(256) void ins_movel_kernel(const unsigned* __restrict__ key_old, const unsigned* __restrict__ pos0_old, int64_t m0,
+                                                        const unsigned* __restrict__ dstart, const unsigned* __restrict__ key0_old,
+                                                        const unsigned* __restrict__ dstart0, const float4* __restrict__ pts0_new,
+                                                        float4* __restrict__ pts_new, unsigned* __restrict__ key_new, unsigned* __restrict__ pos0_new)
+{
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= m0) return;
+    const unsigned c = key_old[s];
+    const unsigned np = (unsigned)s + dstart[c];
+    const unsigned p0 = pos0_old[s];
+    const unsigned p0n = p0 + dstart0[key0_old[p0]];
+    pts_new[np] = pts0_new[p0n];
+    key_new[np] = c;
+    pos0_new[np] = p0n;
 }
 
 // delta point j goes behind the old points of its cell
@@ -295,7 +320,7 @@ __global__ __launch_bounds__(256) void ins_delta_kernel(const float4* __restrict
                                                         const unsigned* __restrict__ cs_old, const unsigned* __restrict__ dstart,
                                                         float4* __restrict__ pts_new, unsigned* __restrict__ key_new, unsigned* __restrict__ inv,
                                                         unsigned* __restrict__ pos0_new, const float* __restrict__ normals3, float4* __restrict__ nrm_new,
-                                                        float4* __restrict__ pn_new)
+                                                        float4* __restrict__ pn_new, float4* __restrict__ twin_new)
 {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
@@ -306,9 +331,10 @@ __global__ __launch_bounds__(256) void ins_delta_kernel(const float4* __restrict
     const float4 p = make_float4(r.x - mx, r.y - my, r.z - mz, __uint_as_float(o));
     pts_new[np] = p;
     key_new[np] = c;
-    if (pos0_new) pos0_new[np] = inv[o];
+    if (twin_new) twin_new[np] = make_float4(r.x, r.y, r.z, __uint_as_float(o));
+    if (pos0_new) pos0_new[np] = inv[j]; // (inv: level-0 position of delta point j, written by this kernel's level-0 launch)
     else {
-        inv[o] = np;
+        inv[j] = np;
         if (nrm_new) {
             const float4 nn = make_float4(normals3[3 * (size_t)o], normals3[3 * (size_t)o + 1], normals3[3 * (size_t)o + 2], 0.f);
             nrm_new[np] = nn;
@@ -664,7 +690,7 @@ static icpmi_status upload_level_table(icpmi_ctx* c)
 // The index of [previous cloud ; delta] from the index of the previous cloud (common.h: "incremental index insert").  *done = false:
 // not applicable (the delta leaves the bounding box, the grid would change, the arrays of the previous build lack the keys ...) -- the
 // caller builds from scratch.
-static icpmi_status map_insert(icpmi_ctx* c, const float4* d_pts, int64_t m0, int64_t m1, const float* d_normals3, bool* done)
+static icpmi_status map_insert(icpmi_ctx* c, const float4* d_pts, int64_t m0, int64_t m1, const float* d_normals3, bool normals_changed, bool* done)
 {
     *done = false;
     static int on = -1, min_m = -1;
@@ -706,13 +732,16 @@ static icpmi_status map_insert(icpmi_ctx* c, const float4* d_pts, int64_t m0, in
         gnew[l] = make_grid(clo, chi, L.g[l].cell, maxabs);
         if (gnew[l].nx != L.g[l].nx || gnew[l].ny != L.g[l].ny || gnew[l].nz != L.g[l].nz) return ICPMI_OK; // (the box's extent rounds differently under the new centroid)
     }
-    const bool recentre = mean[0] != c->mean[0] || mean[1] != c->mean[1] || mean[2] != c->mean[2];
     // ---- buffers (all allocations before anything is written)
     const bool with_n = d_normals3 != nullptr;
     const bool with_pn = with_n && c->d_map_pn != nullptr && !c->single_level && c->keep_raw;
     if (ensure_cap(c, &c->d_ins_key, &c->cap_ins_key, (size_t)n + 1) != ICPMI_OK || ensure_cap(c, &c->d_ins_rank, &c->cap_ins_rank, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
-    if (ensure_cap_keep(c, &c->d_inv, &c->cap_inv, (size_t)m1 + 1, (size_t)m0) != ICPMI_OK) return ICPMI_ERR_HIP;
+    const bool twin = !c->no_centre; // (centroid 0: the sorted points ARE the raw points)
+    if (twin && !c->d_raw0) return ICPMI_OK;
+    if (ensure_cap(c, &c->d_inv, &c->cap_inv, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP; // level-0 position of every delta point
     if (ensure_cap(c, &c->d_fill, &c->cap_fill, (size_t)L.g[0].ncells + 2) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (ensure_cap(c, &c->d_ins_dstart0, &c->cap_ins_dstart0, (size_t)L.g[0].ncells + 2) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (twin && ensure_cap(c, &c->d_alt_raw0, &c->cap_alt_raw0, (size_t)m1 + 16) != ICPMI_OK) return ICPMI_ERR_HIP;
     for (int l = 0; l < L.nlev; ++l) {
         if (ensure_cap(c, &c->d_alt_pts[l], &c->cap_alt_pts[l], (size_t)m1 + 16) != ICPMI_OK) return ICPMI_ERR_HIP;
         if (ensure_cap(c, &c->d_alt_key[l], &c->cap_alt_key[l], (size_t)m1 + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
@@ -728,17 +757,23 @@ static icpmi_status map_insert(icpmi_ctx* c, const float4* d_pts, int64_t m0, in
         float4* pts_old = l == 0 ? c->d_map_sorted : c->d_lvl_pts[l];
         unsigned* cs_old = l == 0 ? c->d_cell_start : c->d_lvl_cs[l];
         unsigned* key_old = c->d_lvl_key[l];
-        unsigned* dstart = c->d_fill;
+        unsigned* dstart = l == 0 ? c->d_ins_dstart0 : c->d_fill;
         HIP_TRY(c, hipMemsetAsync(dstart, 0, ((size_t)g.ncells + 2) * sizeof(unsigned), c->stream));
         hipLaunchKernelGGL(ins_key_kernel, dim3(gbn), dim3(256), 0, c->stream, d_pts, m0, n, mean[0], mean[1], mean[2], g, c->d_ins_key, c->d_ins_rank, dstart);
         if (device_exclusive_scan(c, dstart, g.ncells, (unsigned)n) != ICPMI_OK) return ICPMI_ERR_HIP;
-        hipLaunchKernelGGL(ins_move_kernel, dim3(gb0), dim3(256), 0, c->stream, (const float4*)pts_old, (const unsigned*)key_old, m0, (const unsigned*)dstart, d_pts,
-                           mean[0], mean[1], mean[2], recentre ? 1 : 0, c->d_alt_pts[l], c->d_alt_key[l], c->d_inv, l == 0 ? (unsigned*)nullptr : c->d_alt_pos0[l],
-                           d_normals3, (l == 0 && with_n) ? c->d_alt_nsorted : (float4*)nullptr, (l == 0 && with_pn) ? c->d_alt_pn : (float4*)nullptr);
+        if (l == 0)
+            hipLaunchKernelGGL(ins_move0_kernel, dim3(gb0), dim3(256), 0, c->stream, (const float4*)pts_old, twin ? (const float4*)c->d_raw0 : (const float4*)nullptr,
+                               (const unsigned*)key_old, m0, (const unsigned*)dstart, mean[0], mean[1], mean[2], c->d_alt_pts[0],
+                               twin ? c->d_alt_raw0 : (float4*)nullptr, c->d_alt_key[0], normals_changed ? d_normals3 : (const float*)nullptr,
+                               (const float4*)c->d_normals_sorted, with_n ? c->d_alt_nsorted : (float4*)nullptr, with_pn ? c->d_alt_pn : (float4*)nullptr);
+        else
+            hipLaunchKernelGGL(ins_movel_kernel, dim3(gb0), dim3(256), 0, c->stream, (const unsigned*)key_old, (const unsigned*)c->d_lvl_pos0[l], m0,
+                               (const unsigned*)dstart, (const unsigned*)c->d_lvl_key[0], (const unsigned*)c->d_ins_dstart0, (const float4*)c->d_alt_pts[0],
+                               c->d_alt_pts[l], c->d_alt_key[l], c->d_alt_pos0[l]);
         hipLaunchKernelGGL(ins_delta_kernel, dim3(gbn), dim3(256), 0, c->stream, d_pts, m0, n, mean[0], mean[1], mean[2], (const unsigned*)c->d_ins_key,
                            (const unsigned*)c->d_ins_rank, (const unsigned*)cs_old, (const unsigned*)dstart, c->d_alt_pts[l], c->d_alt_key[l], c->d_inv,
                            l == 0 ? (unsigned*)nullptr : c->d_alt_pos0[l], d_normals3, (l == 0 && with_n) ? c->d_alt_nsorted : (float4*)nullptr,
-                           (l == 0 && with_pn) ? c->d_alt_pn : (float4*)nullptr);
+                           (l == 0 && with_pn) ? c->d_alt_pn : (float4*)nullptr, (l == 0 && twin) ? c->d_alt_raw0 : (float4*)nullptr);
         hipLaunchKernelGGL(ins_cs_kernel, dim3((g.ncells + 1 + 255) / 256), dim3(256), 0, c->stream, (const unsigned*)cs_old, (const unsigned*)dstart, g.ncells + 1, c->d_alt_cs[l]);
         HIP_TRY(c, hipGetLastError());
     }
@@ -751,6 +786,7 @@ static icpmi_status map_insert(icpmi_ctx* c, const float4* d_pts, int64_t m0, in
         std::swap(c->d_lvl_cs[l], c->d_alt_cs[l]); std::swap(c->cap_lvl_cs[l], c->cap_alt_cs[l]);
         std::swap(c->d_lvl_pos0[l], c->d_alt_pos0[l]); std::swap(c->cap_lvl_pos0[l], c->cap_alt_pos0[l]);
     }
+    if (twin) { std::swap(c->d_raw0, c->d_alt_raw0); std::swap(c->cap_raw0, c->cap_alt_raw0); }
     if (with_n) { std::swap(c->d_normals_sorted, c->d_alt_nsorted); std::swap(c->cap_normals, c->cap_alt_nsorted); }
     if (with_pn) { std::swap(c->d_map_pn, c->d_alt_pn); std::swap(c->cap_map_pn, c->cap_alt_pn); }
     for (int l = 0; l < L.nlev; ++l) {
@@ -777,7 +813,8 @@ icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float
     ++c->map_version;
     if (keep_prefix > 0 && keep_prefix < m) {
         bool done = false;
-        const icpmi_status is = map_insert(c, d_pts, keep_prefix, m, d_normals3, &done);
+        // (normals of the kept prefix: unchanged unless the caller says otherwise through c->ins_normals_changed -- a recomputed field)
+        const icpmi_status is = map_insert(c, d_pts, keep_prefix, m, d_normals3, c->ins_normals_changed, &done);
         if (is != ICPMI_OK || done) return is;
     }
     ++c->full_count;
@@ -902,14 +939,15 @@ grid_chosen:
     // handles whose cloud grows by appends (the owner of a resident map, its private raw-frame index) keep what map_insert needs: the
     // cell of every sorted position per level and original index -> level-0 position (+4 bytes per point and level written here)
     const bool want_ins = (c->keep_raw || c->is_raw_index) && !c->single_level && !(c->cfg.grid_cell > 0.f);
+    const bool want_twin = want_ins && !c->no_centre;
     if (want_ins) {
         if (ensure_cap(c, &c->d_lvl_key[0], &c->cap_lvl_key[0], (size_t)m + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
-        if (ensure_cap(c, &c->d_inv, &c->cap_inv, (size_t)m + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+        if (want_twin && ensure_cap(c, &c->d_raw0, &c->cap_raw0, (size_t)m + 16) != ICPMI_OK) return ICPMI_ERR_HIP;
     }
     c->ins_ready = false;
     hipLaunchKernelGGL(scatter_kernel, dim3(blocks), dim3(256), 0, c->stream, d_pts, d_normals3, m, c->mean[0], c->mean[1], c->mean[2],
                        c->d_keys, c->d_cell_start, c->d_fill, c->d_map_sorted, d_normals3 ? c->d_normals_sorted : nullptr, run_atomics_cfg(),
-                       want_ins ? c->d_lvl_key[0] : (unsigned*)nullptr, want_ins ? c->d_inv : (unsigned*)nullptr);
+                       want_ins ? c->d_lvl_key[0] : (unsigned*)nullptr, want_twin ? c->d_raw0 : (float4*)nullptr);
     HIP_TRY(c, hipGetLastError());
     if (d_normals3 && !c->single_level && c->keep_raw) { // (the handles of the map-side operators never run pair sums)
         if (ensure_cap(c, &c->d_map_pn, &c->cap_map_pn, 2 * (size_t)m + 2) != ICPMI_OK) return ICPMI_ERR_HIP;

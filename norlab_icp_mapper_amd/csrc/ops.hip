@@ -913,7 +913,9 @@ icpmi_status ops_map_update_dev(icpmi_ctx* c, const float4* d_scan, int64_t n, c
         if (s == ICPMI_OK && e == hipSuccess && normals_knn > 0) s = surface_normals_dev(c, c->d_raw, m1, normals_knn, c->d_raw_n3);
         // icp.setMap(localPointCloud) (Map.cpp:528): rebuild the index from the resident copy
         // (an append: the first m0 resident points are the cloud the index was built from -- map_insert where it applies)
+        c->ins_normals_changed = normals_knn > 0 || !c->has_normals; // (the whole field was recomputed above / had no sorted copy)
         if (s == ICPMI_OK && e == hipSuccess) s = map_build(c, c->d_raw, m1, want_n ? c->d_raw_n3 : nullptr, (m0 > 0 && c->m == m0) ? m0 : 0);
+        c->ins_normals_changed = false;
         if (s == ICPMI_OK) { if (appended) *appended = count; if (new_m) *new_m = m1; }
     }
     if (s != ICPMI_OK) return s;
