@@ -694,9 +694,9 @@ static icpmi_status map_insert(icpmi_ctx* c, const float4* d_pts, int64_t m0, in
 {
     *done = false;
     static int on = -1, min_m = -1;
-    if (on < 0) { const char* e = getenv("ICPMI_INSERT"); on = e ? atoi(e) : 1; e = getenv("ICPMI_INSERT_MIN"); min_m = e ? atoi(e) : 3000000; }
-    // (below a few million points the ~8 launches per level cost what the full build's four passes cost: measured at 1 M, two indices per
-    //  map update: 0.62 ms from scratch, 0.74 ms by insert; at 10 M: 3.65 ms against 2.03 ms.  The GPU tests set the threshold to 0.)
+    if (on < 0) { const char* e = getenv("ICPMI_INSERT"); on = e ? atoi(e) : 1; e = getenv("ICPMI_INSERT_MIN"); min_m = e ? atoi(e) : 0; }
+    // (measured, one map-growth epoch = two index updates, A/B in one call: 1 M points 0.72 -> 0.56 ms, 10 M points 3.65 -> 0.97 ms; the first
+    //  version -- raw points gathered by original index -- lost at 1 M: 0.74 ms.  ICPMI_INSERT_MIN: smallest cloud the insert serves.)
     const int64_t n = m1 - m0;
     GridLevels& L = c->levels;
     if (!on || !c->ins_ready || m0 != c->m || m0 <= 0 || n <= 0 || n > m0 / 2 || m1 < min_m || (d_normals3 != nullptr) != c->has_normals || c->cfg.grid_cell > 0.f) return ICPMI_OK;
