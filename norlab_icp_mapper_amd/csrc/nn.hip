@@ -1074,6 +1074,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(FSOLVE 
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const bool w0 = wave == 0;
+#ifndef ICPMI_NN_NO_HOIST
+    // r4: every kernel argument the prologue reads (pointers, the level-0 grid) is requested from the kernarg segment in ONE batch here;
+    // left to itself the compiler loads each one behind the branch that first uses it -- a dozen dependent scalar round trips in front
+    // of the first barrier (ISA of r3's kernel).  The empty asm only pins the values into SGPRs at this point.
+    {
+        const GridParams g0 = L.g[0];
+        asm volatile("" ::"s"(queries), "s"(qindex), "s"(out_sidx), "s"(out_d2), "s"(match_pt), "s"(ltab_g), "s"(Tptr), "s"(st), "s"(hist0), "s"(hard));
+        asm volatile("" ::"s"(g0.ox), "s"(g0.oy), "s"(g0.oz), "s"(g0.cell), "s"(g0.inv_cell), "s"(g0.slack), "s"(L.nlev), "s"(maxr2), "s"(unseeded_lev), "s"(seed_pre));
+    }
+#endif
     // XCD-aware order, as nn1_ml_kernel: workgroup b runs on XCD b % 8; each XCD gets one contiguous eighth of the queries
     const int wgs = (int)((((long long)n + Q - 1) / Q + 7) / 8 * 8);
     if ((int)blockIdx.x >= wgs) return;

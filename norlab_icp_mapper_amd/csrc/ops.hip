@@ -1374,6 +1374,7 @@ static icpmi_status merge_append_flagged(icpmi_ctx* c, const float4* d_in, int64
 // the 3 x 3 x 3 cells around p), then blocks 1 .. R - 1 are flagged one after the other (block r needs the flags of the blocks below it).
 // Order inside a cell comes from atomics and is not reproducible; the predicate is an "exists", so the flags are.
 struct MergeBlocks { long long cnt[256]; };  // (never more than 256 ranks: comm.hip)
+#define MERGE_FILTER_WORDS (1u << 19)        // 2^24 bits: one per 24-bit hash of an occupied cell (a few 10^5 cells: < 2 % false positives)
 
 __device__ __forceinline__ unsigned long long merge_cell_key(int ix, int iy, int iz)
 {
@@ -1385,7 +1386,8 @@ __device__ __forceinline__ int merge_cell_of(float v, float inv_h) { return (int
 
 __global__ __launch_bounds__(256) void merge_hash_insert_kernel(const float4* __restrict__ recv, long long maxc, int R, MergeBlocks mb, float inv_h,
                                                                 unsigned long long* __restrict__ tkeys, unsigned* __restrict__ tcnt,
-                                                                unsigned long long mask, unsigned* __restrict__ slot_of, unsigned* __restrict__ rank_of)
+                                                                unsigned long long mask, unsigned* __restrict__ slot_of, unsigned* __restrict__ rank_of,
+                                                                unsigned* __restrict__ bits)
 {
     const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
     if (g >= maxc * R) return;
@@ -1393,7 +1395,8 @@ __global__ __launch_bounds__(256) void merge_hash_insert_kernel(const float4* __
     if (g - (long long)r * maxc >= mb.cnt[r]) return;
     const float4 p = recv[g];
     const unsigned long long key = merge_cell_key(merge_cell_of(p.x, inv_h), merge_cell_of(p.y, inv_h), merge_cell_of(p.z, inv_h));
-    unsigned long long slot = mix64(key) & mask;
+    const unsigned long long hk = mix64(key);
+    unsigned long long slot = hk & mask;
     for (;;) {
         const unsigned long long prev = atomicCAS(&tkeys[slot], ~0ull, key);
         if (prev == ~0ull || prev == key) break;
@@ -1401,23 +1404,29 @@ __global__ __launch_bounds__(256) void merge_hash_insert_kernel(const float4* __
     }
     slot_of[g] = (unsigned)slot;
     rank_of[g] = atomicAdd(&tcnt[slot], 1u);
+    const unsigned hb = (unsigned)(hk >> 40); // 24 bits of the hash: the occupied-cell filter (MERGE_FILTER_BITS)
+    atomicOr(&bits[hb >> 5], 1u << (hb & 31u));
 }
 
 __global__ __launch_bounds__(256) void merge_hash_scatter_kernel(long long maxc, int R, MergeBlocks mb, const unsigned* __restrict__ tstart,
                                                                  const unsigned* __restrict__ slot_of, const unsigned* __restrict__ rank_of,
-                                                                 unsigned* __restrict__ cell_pts)
+                                                                 const float4* __restrict__ recv, float4* __restrict__ cell_pts)
 {
     const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
     if (g >= maxc * R) return;
     const int r = (int)(g / maxc);
     if (g - (long long)r * maxc >= mb.cnt[r]) return;
-    cell_pts[tstart[slot_of[g]] + rank_of[g]] = (unsigned)g;
+    // the point itself rides in the cell-ordered list (w = its global index): a candidate is ONE contiguous 16-byte load, not an
+    // index -> flag -> point chain of three dependent ones
+    const float4 p = recv[g];
+    cell_pts[tstart[slot_of[g]] + rank_of[g]] = make_float4(p.x, p.y, p.z, __uint_as_float((unsigned)g));
 }
 
 // flags of block r (first = the lowest non-empty block: everything kept)
 __global__ __launch_bounds__(256) void merge_flag_kernel(const float4* __restrict__ recv, long long maxc, int r, long long cnt_r, int first, float inv_h,
                                                          double lim, const unsigned long long* __restrict__ tkeys, const unsigned* __restrict__ tstart,
-                                                         unsigned long long mask, const unsigned* __restrict__ cell_pts, unsigned* __restrict__ kept)
+                                                         unsigned long long mask, const float4* __restrict__ cell_pts, unsigned* __restrict__ kept,
+                                                         const unsigned* __restrict__ bits)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= cnt_r) return;
@@ -1426,29 +1435,44 @@ __global__ __launch_bounds__(256) void merge_flag_kernel(const float4* __restric
     const float4 p = recv[g];
     const int cx = merge_cell_of(p.x, inv_h), cy = merge_cell_of(p.y, inv_h), cz = merge_cell_of(p.z, inv_h);
     const long long lower_end = (long long)r * maxc; // global indices below this belong to lower blocks
+    // Most of the 27 cells around a point are empty, and an empty cell costs a hash table its longest search (probe until a free slot,
+    // one dependent round trip per step: 27 of those chains in a row were 50 - 70 us per launch).  A 2^24-bit filter of the occupied
+    // cells' hashes answers "empty" for them with ONE load, all 27 in flight together; only the few cells the filter lets through
+    // (occupied, or one of its < 2 % false positives) go to the table.
+    unsigned cand = 0u;
+    {
+        unsigned w[27];
+#pragma unroll
+        for (int q = 0; q < 27; ++q) {
+            const unsigned hb = (unsigned)(mix64(merge_cell_key(cx + (q % 3) - 1, cy + ((q / 3) % 3) - 1, cz + (q / 9) - 1)) >> 40);
+            w[q] = bits[hb >> 5] >> (hb & 31u);
+        }
+#pragma unroll
+        for (int q = 0; q < 27; ++q) cand |= (w[q] & 1u) << q;
+    }
     bool drop = false;
-    for (int dz = -1; dz <= 1 && !drop; ++dz)
-        for (int dy = -1; dy <= 1 && !drop; ++dy)
-            for (int dx = -1; dx <= 1 && !drop; ++dx) {
-                const unsigned long long key = merge_cell_key(cx + dx, cy + dy, cz + dz);
-                unsigned long long slot = mix64(key) & mask;
-                bool found = false;
-                for (;;) {
-                    const unsigned long long k = tkeys[slot];
-                    if (k == key) { found = true; break; }
-                    if (k == ~0ull) break;
-                    slot = (slot + 1) & mask;
-                }
-                if (!found) continue;
-                const unsigned b = tstart[slot], e = tstart[slot + 1];
-                for (unsigned j = b; j < e; ++j) {
-                    const unsigned q = cell_pts[j];
-                    if ((long long)q >= lower_end || !kept[q]) continue;
-                    const float4 o = recv[q];
-                    const float d2 = sqdist3(p.x, p.y, p.z, o.x, o.y, o.z);
-                    if (d2 > 1.1920929e-07f && (double)d2 < lim) { drop = true; break; }
-                }
+    while (cand && !drop) {
+        const int q = __ffs((int)cand) - 1;
+        cand &= cand - 1u;
+        const unsigned long long key = merge_cell_key(cx + (q % 3) - 1, cy + ((q / 3) % 3) - 1, cz + (q / 9) - 1);
+        unsigned long long sl = mix64(key) & mask, k = tkeys[sl];
+        while (k != key && k != ~0ull) { sl = (sl + 1) & mask; k = tkeys[sl]; }
+        if (k != key) continue; // a false positive of the filter
+        const unsigned rbq = tstart[sl], req = tstart[sl + 1];
+        for (unsigned j = rbq; j < req && !drop; j += 4u) {
+            float4 o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) o[u] = cell_pts[j + u < req ? j + u : j]; // four candidates in flight
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (j + u >= req) continue;
+                const unsigned o_i = __float_as_uint(o[u].w);
+                if ((long long)o_i >= lower_end) continue;
+                const float d2 = sqdist3(p.x, p.y, p.z, o[u].x, o[u].y, o[u].z);
+                if (d2 > 1.1920929e-07f && (double)d2 < lim && kept[o_i]) drop = true; // (the flag only for a candidate that is near: rare)
             }
+        }
+    }
     kept[g] = drop ? 0u : 1u;
 }
 
@@ -1476,7 +1500,7 @@ static icpmi_status merge_greedy(icpmi_ctx* c, const std::vector<long long>& cou
         for (int r = 0; r < R; ++r)
             if (counts[(size_t)r] > 0)
                 hipLaunchKernelGGL(merge_flag_kernel, dim3((int)((counts[(size_t)r] + 255) / 256)), dim3(256), 0, c->stream, (const float4*)c->d_merge_recv, maxc, r,
-                                   counts[(size_t)r], 1, 0.f, 0.0, (const unsigned long long*)nullptr, (const unsigned*)nullptr, 0ull, (const unsigned*)nullptr, kept);
+                                   counts[(size_t)r], 1, 0.f, 0.0, (const unsigned long long*)nullptr, (const unsigned*)nullptr, 0ull, (const float4*)nullptr, kept, (const unsigned*)nullptr);
     } else {
         long long total = 0;
         for (long long v : counts) total += v;
@@ -1487,8 +1511,11 @@ static icpmi_status merge_greedy(icpmi_ctx* c, const std::vector<long long>& cou
         unsigned* tcnt = scratch_get<unsigned>(c, 1, (size_t)cap + 2);
         unsigned* slot_of = scratch_get<unsigned>(c, 2, (size_t)span + 1);
         unsigned* rank_of = scratch_get<unsigned>(c, 3, (size_t)span + 1);
-        unsigned* cell_pts = scratch_get<unsigned>(c, 4, (size_t)total + 1);
+        float4* cell_pts = scratch_get<float4>(c, 4, (size_t)total + 1);
         if (!tkeys || !tcnt || !slot_of || !rank_of || !cell_pts) return ICPMI_ERR_HIP;
+        unsigned* bits = scratch_get<unsigned>(c, 5, (size_t)MERGE_FILTER_WORDS);
+        if (!bits) return ICPMI_ERR_HIP;
+        HIP_TRY(c, hipMemsetAsync(bits, 0, (size_t)MERGE_FILTER_WORDS * sizeof(unsigned), c->stream));
         HIP_TRY(c, hipMemsetAsync(tkeys, 0xff, (size_t)cap * sizeof(unsigned long long), c->stream));
         HIP_TRY(c, hipMemsetAsync(tcnt, 0, ((size_t)cap + 2) * sizeof(unsigned), c->stream));
         // cell edge: a little above minDist (a relative 1e-3 dwarfs the rounding of v * inv_h for coordinates up to ~10^4 cells from the origin;
@@ -1496,18 +1523,18 @@ static icpmi_status merge_greedy(icpmi_ctx* c, const std::vector<long long>& cou
         const float h = min_dist * 1.001f + 1e-6f;
         const float inv_h = 1.0f / h;
         hipLaunchKernelGGL(merge_hash_insert_kernel, dim3(gblocks), dim3(256), 0, c->stream, (const float4*)c->d_merge_recv, maxc, R, mb, inv_h, tkeys, tcnt,
-                           cap - 1, slot_of, rank_of);
+                           cap - 1, slot_of, rank_of, bits);
         HIP_TRY(c, hipGetLastError());
         icpmi_status s = device_exclusive_scan(c, tcnt, (int)cap, (unsigned)total);
         if (s != ICPMI_OK) return s;
         hipLaunchKernelGGL(merge_hash_scatter_kernel, dim3(gblocks), dim3(256), 0, c->stream, maxc, R, mb, (const unsigned*)tcnt, (const unsigned*)slot_of,
-                           (const unsigned*)rank_of, cell_pts);
+                           (const unsigned*)rank_of, (const float4*)c->d_merge_recv, cell_pts);
         const double lim = pd_limit(min_dist);
         for (int r = first_block; r < R; ++r) {
             if (counts[(size_t)r] == 0) continue;
             hipLaunchKernelGGL(merge_flag_kernel, dim3((int)((counts[(size_t)r] + 255) / 256)), dim3(256), 0, c->stream, (const float4*)c->d_merge_recv, maxc, r,
                                counts[(size_t)r], r == first_block ? 1 : 0, inv_h, lim, (const unsigned long long*)tkeys, (const unsigned*)tcnt, cap - 1,
-                               (const unsigned*)cell_pts, kept);
+                               (const float4*)cell_pts, kept, (const unsigned*)bits);
         }
         HIP_TRY(c, hipGetLastError());
     }
