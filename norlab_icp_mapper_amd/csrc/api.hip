@@ -245,6 +245,7 @@ icpmi_status icpmi_debug_counters(icpmi_handle h, uint64_t out[24])
     for (int i = 0; i < 24; ++i) out[i] = h->h_state->dbg[i];
     // [18] / [19]: index builds served by the incremental insert / from scratch (low word: this handle's registration index; high
     // word: its private raw-frame index, ops.hip: raw_index)
+    out[17] = (uint64_t)h->raw_view_count; // PointDistance searches served by the raw-frame view of the registration index (no second index)
     out[18] = (uint64_t)(uint32_t)h->ins_count | ((uint64_t)(uint32_t)(h->temp_raw ? h->temp_raw->ins_count : 0) << 32);
     out[19] = (uint64_t)(uint32_t)h->full_count | ((uint64_t)(uint32_t)(h->temp_raw ? h->temp_raw->full_count : 0) << 32);
     return ICPMI_OK;

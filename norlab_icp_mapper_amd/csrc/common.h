@@ -214,6 +214,8 @@ struct icpmi_ctx {
     float cell0 = 0.f;                 // level-0 cell edge as chosen by the last full build (the insert keeps it)
     uint64_t raw_epoch = 0;            // bumped whenever d_raw is rewritten other than by an append (private raw index: ops.hip)
     uint64_t temp_raw_epoch = 0; int64_t temp_raw_m = 0;
+    uint64_t raw_view_version = 0;     // map_version the raw-frame VIEW of the registration index was set up for (ops.hip: raw_index)
+    int64_t raw_view_count = 0;        // PointDistance searches served by the view (diagnostics)
     int64_t ins_count = 0, full_count = 0; // builds served by the insert / by the full path (diagnostics)
 
     // scratch for set_map
@@ -525,6 +527,7 @@ struct SortHead {
 // ---- cross-TU host entry points ---------------------------------------------------------------
 // keep_prefix: the first keep_prefix points of d_pts are the cloud of the previous build, unchanged and in the same order (an append)
 icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float* d_normals3, int64_t keep_prefix = 0);
+icpmi_status upload_level_table(icpmi_ctx* c); // c->levels -> c->d_lvl_tab (the table the NN kernels copy to LDS)
 icpmi_status device_exclusive_scan(icpmi_ctx* c, unsigned* data, int n, unsigned total);
 icpmi_status sort_queries(icpmi_ctx* c, const float4* d_pts, int64_t n);
 icpmi_status sort_queries_reserve(icpmi_ctx* c, int64_t n, int nscan = 1);

@@ -667,7 +667,7 @@ static GridParams make_grid(const float lo[3], const float hi[3], float cell, fl
     return g;
 }
 
-static icpmi_status upload_level_table(icpmi_ctx* c)
+icpmi_status upload_level_table(icpmi_ctx* c)
 {
     // level table for the NN kernels: per level [ox oy oz cell][inv_cell slack nx ny][nz ncells pts][cs pos0]
     GridLevels& L = c->levels;

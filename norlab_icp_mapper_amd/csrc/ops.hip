@@ -507,9 +507,44 @@ static icpmi_status raw_index(icpmi_ctx* c, icpmi_ctx** out, float reach)
     }
     icpmi_ctx* t = c->temp_raw;
     share_stream(c, t);
+    const float want = reach > 1e-3f ? reach : 1e-3f;
+    // r4: no second index at all where the registration index carries the raw twin of its level 0 (map_build.hip: d_raw0 -- the resident
+    // points, raw coordinates, in level-0 sorted order) and one 3 x 3 x 3 block of level 0 holds the search ball: the private handle
+    // becomes a VIEW -- the owner's cell starts, the twin as the point array, the grid laid over the raw bounding box, centroid 0.  The
+    // search is exact whatever grid it walks, so ids and d^2 are those of an index built on the raw cloud (tests: every map-update and
+    // merge test compares the keep masks with the oracle's search of the raw map).  A point's cell was assigned from its centred
+    // coordinates; a query's cell comes from raw ones: the two agree up to rounding far below the grid's slack.
+    {
+        static int view_on = -1;
+        if (view_on < 0) { const char* e = getenv("ICPMI_RAW_VIEW"); view_on = e ? atoi(e) : 1; }
+        const GridParams& g0 = c->levels.g[0];
+        if (view_on && c->ins_ready && c->d_raw0 && !c->no_centre && c->m > 0 && c->m == c->m_raw && (g0.cell - 2.f * g0.slack) > want * 1.001f) {
+            if (c->raw_view_version != c->map_version || t->m != c->m) {
+                float maxabs = 0.f;
+                for (int r = 0; r < 3; ++r) maxabs = fmaxf(maxabs, fmaxf(fabsf(c->lo_raw[r]), fabsf(c->hi_raw[r])));
+                GridParams g = g0;
+                g.ox = c->lo_raw[0]; g.oy = c->lo_raw[1]; g.oz = c->lo_raw[2];
+                g.slack = g.cell * 1e-3f + maxabs * 2e-6f;
+                if (!((g.cell - 2.f * g.slack) > want * 1.001f)) goto no_view; // (a map far from the origin: its raw coordinates round coarser)
+                t->cfg = c->cfg; t->cfg.max_dist = want; t->keep_raw = false; t->no_centre = true; t->single_level = true; t->is_raw_index = false;
+                t->levels = GridLevels{};
+                t->levels.nlev = 1; t->levels.g[0] = g; t->levels.pts[0] = c->d_raw0; t->levels.cs[0] = c->d_cell_start; t->levels.pos0[0] = nullptr;
+                t->grid = g; t->m = c->m; t->mean[0] = t->mean[1] = t->mean[2] = 0.f; t->has_normals = false; t->ins_ready = false;
+                t->qsorted_n = -1; t->qsorted_src = nullptr;
+                drop_loop_graphs(t);
+                { const icpmi_status us = upload_level_table(t); if (us != ICPMI_OK) { c->last_error = t->last_error; return us; } }
+                c->raw_view_version = c->map_version;
+                c->temp_raw_version = 0; // (the handle's own arrays no longer describe anything)
+            }
+            ++c->raw_view_count;
+            *out = t;
+            return ICPMI_OK;
+        }
+    }
+no_view:
+    c->raw_view_version = 0;
     const float built_reach = t->cfg.max_dist;
     t->cfg = c->cfg; t->keep_raw = false; t->no_centre = true; t->single_level = false; t->is_raw_index = true;
-    const float want = reach > 1e-3f ? reach : 1e-3f;
     const bool current = c->temp_raw_version == c->map_version && t->m == c->m_raw && t->m > 0;
     t->cfg.max_dist = current && built_reach >= want ? built_reach : want;
     if (!current || built_reach < want) {

@@ -17,7 +17,7 @@ def amd():
 
 def builds(icp):
     c = icp.debugCounters()
-    return {"ins": c[18] & 0xffffffff, "full": c[19] & 0xffffffff, "raw_ins": c[18] >> 32, "raw_full": c[19] >> 32}
+    return {"ins": c[18] & 0xffffffff, "full": c[19] & 0xffffffff, "raw_ins": c[18] >> 32, "raw_full": c[19] >> 32, "raw_view": c[17]}
 
 
 def queries(rng, cloud, n):
@@ -76,9 +76,9 @@ def test_delta_outside_the_box_rebuilds(amd, small_scene):
 
 
 def test_point_distance_updates_use_the_grown_raw_index(amd, oracle, mid_scene):
-    """Map::updateLocalPointCloud with PointDistanceMapperModule, twice: the keep decisions of the second update are taken against the
-    private raw-frame index after ITS insert (PointDistanceMapperModule.cpp:33-42 searches the map as it is) -- same mask as the oracle's
-    search of the grown map."""
+    """Map::updateLocalPointCloud with PointDistanceMapperModule, three times: the keep decisions are taken in the map's own frame
+    (PointDistanceMapperModule.cpp:33-42 searches the map as it is) -- on the raw twin of the grown registration index -- and must be
+    the oracle's search of the grown raw map, mask for mask."""
     sc = mid_scene
     half = sc["map"][::2].copy()
     icp = amd.ICPSequence(minimizer=1, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=8)
@@ -94,4 +94,5 @@ def test_point_distance_updates_use_the_grown_raw_index(amd, oracle, mid_scene):
         cur = np.concatenate([cur, scan[keep]])
         assert new_m == cur.shape[0]
     b = builds(icp)
-    assert b["ins"] >= 2 and b["raw_ins"] >= 1, b
+    # the registration index grew by inserts; the raw-frame searches ran on its raw twin (a view: no second index was built at all)
+    assert b["ins"] >= 2 and b["raw_view"] >= 3 and b["raw_full"] == 0, b
