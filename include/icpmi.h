@@ -68,7 +68,8 @@ typedef enum {
     ICPMI_OUT_SURFACENORMAL = 5,/* SurfaceNormalOutlierFilter{maxAngle} w = n_read.n_ref > cos(maxAngle) */
     /* GenericDescriptorOutlierFilter{source: reference, descName, useSoftThreshold, useLargerThan, threshold}: the 1-row descriptor
      * of the matched map point -- the tracked scalar channel, icpmi_set_map_scalar -- decides.  param = threshold, iparam = flags.
-     * hard: w = desc > threshold (useLargerThan) or desc < threshold; soft: w = desc.  source: reading is UNSUPPORTED. */
+     * hard: w = desc > threshold (useLargerThan) or desc < threshold; soft: w = desc.  source: reading (iparam | ICPMI_GEN_SOURCE_READING,
+     * v4): the descriptor of the READING point decides -- its row is handed over with icpmi_set_reading_scalar before every registration. */
     ICPMI_OUT_GENERICDESCRIPTOR = 6,
     /* RobustOutlierFilter{robustFct, tuning, scaleEstimator: none | mad, nbIterationForScale, distanceType}: M-estimator weight of
      * e2 = residual / scale^2.  param = tuning, param2 = nbIterationForScale, iparam = robustFct | scaleEstimator << 4 |
@@ -181,6 +182,11 @@ icpmi_status icpmi_get_map_mean(icpmi_handle h, float mean3[3]);
  * (host pointer, n floats, one shot: it is consumed by that registration, whose scan_normals3 must be given and whose n must match; any
  * other case leaves stats.sensor_noise_overlap at -1).  noise == NULL or n == 0 clears it. */
 icpmi_status icpmi_set_reading_sensor_noise(icpmi_handle h, const float* noise, int64_t n);
+
+/* (v4) GenericDescriptorOutlierFilter{source: reading}: the 1-row descriptor `descName` of the NEXT registration's reading (host pointer, n
+ * floats, one shot: consumed by that registration, whose n must match -- else it fails with InvalidField like upstream's missing descriptor).
+ * scalar == NULL or n == 0 clears it.  Registrations of a batch with such a chain are not served (every reading needs its own row). */
+icpmi_status icpmi_set_reading_scalar(icpmi_handle h, const float* scalar, int64_t n);
 
 /* Replaces `TransformationParameters PM::ICPSequence::operator()(const DataPoints&)`
  * (Mapper.cpp:213): scan4 is the reading already moved by the prior (Mapper.cpp:197); T_out is the

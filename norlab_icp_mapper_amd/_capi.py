@@ -133,6 +133,7 @@ SYMBOLS = [
     ("icpmi_staged_merged_points", C.c_int, [_P, _P, C.c_int64, _P]),
     ("icpmi_stage_discard", C.c_int, [_P]),
     ("icpmi_register_prior", C.c_int, [_P, _P, C.c_int64, _P, _F, C.POINTER(Stats)]),
+    ("icpmi_set_reading_scalar", C.c_int, [_P, _P, C.c_int64]),
     ("icpmi_register_prior_dev", C.c_int, [_P, _P, C.c_int64, _P, _F, C.POINTER(Stats)]),
     ("icpmi_map_update_staged", C.c_int, [_P, _P, C.c_float, C.c_int32, _P, _P, _P]),
     ("icpmi_dynamic_points_update", C.c_int, [_P, _P, _P, _P, C.c_int64, _P, _P, C.c_int64, _P]),

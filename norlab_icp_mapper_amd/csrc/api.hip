@@ -98,7 +98,6 @@ static icpmi_status validate_config(const icpmi_config* cfg, std::string& err)
         if (t == ICPMI_OUT_GENERICDESCRIPTOR) {
             const int ip = cfg->outlier[f].iparam;
             if (ip & ~7) { err = "InvalidParameter: GenericDescriptorOutlierFilter: unknown flag"; return ICPMI_ERR_INVALID_ARG; }
-            if (ip & ICPMI_GEN_SOURCE_READING) { err = "GenericDescriptorOutlierFilter{source: reading} is not supported (the boundary carries no reading descriptor)"; return ICPMI_ERR_UNSUPPORTED; }
         }
         if (t == ICPMI_OUT_ROBUST) {
             const int ip = cfg->outlier[f].iparam;
@@ -202,7 +201,7 @@ void icpmi_destroy(icpmi_handle c)
     hipFree(c->d_qsorted); hipFree(c->d_qindex); hipFree(c->d_qkeys); hipFree(c->d_qtile);
     hipFree(c->d_reading); hipFree(c->d_read_normals); hipFree(c->d_stage_in); hipFree(c->d_stage_n3);
     hipFree(c->d_match_pt); hipFree(c->d_lvl_tab); hipFree(c->d_raw); hipFree(c->d_raw_n3); hipFree(c->d_raw_s); hipFree(c->d_src); hipFree(c->d_alt_raw); hipFree(c->d_alt_n3);
-    hipFree(c->d_alt_s); hipFree(c->d_alt_src); hipFree(c->d_stage_s); hipFree(c->d_merge_send); hipFree(c->d_merge_recv); hipFree(c->d_merged); hipFree(c->d_comm_cnt); hipFree(c->d_read_noise); hipFree(c->d_map_pn);
+    hipFree(c->d_alt_s); hipFree(c->d_alt_src); hipFree(c->d_stage_s); hipFree(c->d_merge_send); hipFree(c->d_merge_recv); hipFree(c->d_merged); hipFree(c->d_comm_cnt); hipFree(c->d_read_noise); hipFree(c->d_read_scalar); hipFree(c->d_map_pn);
     for (int k = 0; k < 10; ++k) hipFree(c->scratch[k]); hipFree(c->d_scan_map); hipFree(c->d_T16);
     hipFree(c->d_sidx); hipFree(c->d_d2); hipFree(c->d_hard); hipFree(c->d_selhist);
     hipFree(c->d_state);
@@ -319,7 +318,7 @@ static icpmi_status check_ext_filters(icpmi_ctx* h)
 {
     for (int f = 0; f < h->cfg.n_outlier; ++f) {
         const icpmi_outlier& o = h->cfg.outlier[f];
-        if (o.type == ICPMI_OUT_GENERICDESCRIPTOR && !(h->raw_has_scalar && h->m_raw == h->m)) {
+        if (o.type == ICPMI_OUT_GENERICDESCRIPTOR && !(o.iparam & ICPMI_GEN_SOURCE_READING) && !(h->raw_has_scalar && h->m_raw == h->m)) {
             h->last_error = "InvalidField: GenericDescriptorOutlierFilter needs the tracked scalar descriptor on the map (icpmi_set_map_scalar)";
             return ICPMI_ERR_INVALID_ARG;
         }
@@ -328,6 +327,17 @@ static icpmi_status check_ext_filters(icpmi_ctx* h)
             return ICPMI_ERR_MISSING_NORMALS;
         }
     }
+    return ICPMI_OK;
+}
+
+// the stage entry points carry no reading descriptor: a chain with GenericDescriptorOutlierFilter{source: reading} is served by icpmi_register only
+static icpmi_status reject_reading_source(icpmi_ctx* h, const char* who)
+{
+    for (int f = 0; f < h->cfg.n_outlier; ++f)
+        if (h->cfg.outlier[f].type == ICPMI_OUT_GENERICDESCRIPTOR && (h->cfg.outlier[f].iparam & ICPMI_GEN_SOURCE_READING)) {
+            h->last_error = std::string(who) + ": GenericDescriptorOutlierFilter{source: reading} is only available inside icpmi_register";
+            return ICPMI_ERR_UNSUPPORTED;
+        }
     return ICPMI_OK;
 }
 
@@ -352,6 +362,16 @@ static icpmi_status register_impl(icpmi_handle h, const float* d_scan4, int64_t 
     }
     { const icpmi_status es = check_ext_filters(h); if (es != ICPMI_OK) return es; }
     LoopCfg lc = make_loop_cfg(h, fixed_iters);
+    {   // GenericDescriptorOutlierFilter{source: reading}: the row handed over for THIS reading (one shot)
+        bool wants = false;
+        for (int f = 0; f < h->cfg.n_outlier; ++f) wants |= h->cfg.outlier[f].type == ICPMI_OUT_GENERICDESCRIPTOR && (h->cfg.outlier[f].iparam & ICPMI_GEN_SOURCE_READING);
+        const int64_t have = h->read_scalar_n; h->read_scalar_n = 0;
+        if (wants && n > 0 && have != n) {
+            h->last_error = "InvalidField: GenericDescriptorOutlierFilter{source: reading} needs the reading's descriptor (icpmi_set_reading_scalar, one row per point)";
+            return ICPMI_ERR_INVALID_ARG;
+        }
+        lc.read_scalar = wants ? h->d_read_scalar : nullptr;
+    }
     // sensor-noise overlap (icpmi_set_reading_sensor_noise): the noise row is one shot -- this registration consumes it
     // (PointToPointErrorMinimizer::getOverlap() needs `simpleSensorNoise` alone; only the point-to-plane variant also reads the reading's
     // `normals` -- ADVICE r3)
@@ -383,6 +403,18 @@ icpmi_status icpmi_set_reading_sensor_noise(icpmi_handle h, const float* noise, 
     HIP_TRY(h, hipMemcpyAsync(h->d_read_noise, noise, (size_t)n * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream)); // the caller's buffer is free on return
     h->read_noise_n = n;
+    return ICPMI_OK;
+}
+
+icpmi_status icpmi_set_reading_scalar(icpmi_handle h, const float* scalar, int64_t n)
+{
+    CHECK_H(h);
+    h->read_scalar_n = 0;
+    if (!scalar || n <= 0) return ICPMI_OK;
+    if (ensure_cap(h, &h->d_read_scalar, &h->cap_read_scalar, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    HIP_TRY(h, hipMemcpyAsync(h->d_read_scalar, scalar, (size_t)n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream)); // the caller's buffer is free on return
+    h->read_scalar_n = n;
     return ICPMI_OK;
 }
 
@@ -526,6 +558,7 @@ icpmi_status icpmi_outlier_weights(icpmi_handle h, const float* d2, const int32_
     CHECK_H(h);
     if (k < 1 || n < 0 || (n > 0 && (!d2 || !weights))) { h->last_error = "outlier_weights: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
     if (n == 0) return ICPMI_OK;
+    { const icpmi_status rs = reject_reading_source(h, "outlier_weights"); if (rs != ICPMI_OK) return rs; }
     LoopCfg lc = make_loop_cfg(h, 1);
     return loop_outlier_weights(h, lc, d2, ids, k, n, read_normals3, weights, limit_out);
 }
@@ -536,6 +569,7 @@ icpmi_status icpmi_minimize_step(icpmi_handle h, const float* reading4, int64_t 
     CHECK_H(h);
     if (n <= 0 || !reading4) { h->last_error = "minimize_step: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
     { const icpmi_status es = check_ext_filters(h); if (es != ICPMI_OK) return es; }
+    { const icpmi_status rs = reject_reading_source(h, "minimize_step"); if (rs != ICPMI_OK) return rs; }
     if (h->m <= 0) { h->last_error = "minimize_step: no map"; return ICPMI_ERR_INVALID_ARG; }
     if (h->cfg.minimizer == ICPMI_MIN_POINT_TO_PLANE && !h->has_normals) {
         h->last_error = "InvalidField: PointToPlaneErrorMinimizer needs the descriptor 'normals' on the map";

@@ -117,6 +117,7 @@ struct LoopCfg {
     float max_rot, max_trans;
     int   has_read_normals;
     int   sensor_noise;    // the reading carries simpleSensorNoise + normals: getOverlap() is the sensor-noise count (loop.hip: overlap pass)
+    const float* read_scalar; // GenericDescriptorOutlierFilter{source: reading}: that descriptor of the reading, caller's order (device)
 };
 
 // Device-resident loop state (one per handle).  Everything the iteration needs between kernels
@@ -228,6 +229,7 @@ struct icpmi_ctx {
     float4* d_reading = nullptr; size_t cap_reading = 0;       // centred reading
     float4* d_read_normals = nullptr; size_t cap_read_normals = 0;
     float*  d_read_noise = nullptr; size_t cap_read_noise = 0; int64_t read_noise_n = 0; // simpleSensorNoise of the NEXT reading (one shot)
+    float*  d_read_scalar = nullptr; size_t cap_read_scalar = 0; int64_t read_scalar_n = 0; // GenericDescriptor{source: reading} row of the NEXT reading
     bool graph_sorted = false;        // loop state order of the cached graph
     float4* d_qsorted = nullptr; size_t cap_qsorted = 0;       // centred reading sorted by tile (NN locality)
     int*    d_qindex = nullptr; size_t cap_qindex = 0;         // sorted position -> original index

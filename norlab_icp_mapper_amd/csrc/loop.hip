@@ -480,7 +480,7 @@ __device__ __forceinline__ float match_weight(const LoopCfg& lc, const IcpState*
             w *= (dot > cosf(prm)) ? 1.f : 0.f;
         } else if (EXT && type == ICPMI_OUT_GENERICDESCRIPTOR) {
             const int ip = lc.out_iparam[f];
-            const float v = ref_scalar[orig];
+            const float v = (ip & ICPMI_GEN_SOURCE_READING) ? lc.read_scalar[qi] : ref_scalar[orig];
             w *= (ip & ICPMI_GEN_SOFT) ? v : ((ip & ICPMI_GEN_LARGER) ? (v > prm ? 1.f : 0.f) : (v < prm ? 1.f : 0.f));
         } else if (EXT && type == ICPMI_OUT_ROBUST) {
             const int ip = lc.out_iparam[f];

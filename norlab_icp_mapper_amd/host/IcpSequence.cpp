@@ -60,7 +60,7 @@ void GpuICPSequence::setDefault()
     icpmi_config_default(&cfg);
     cfg.device = dev;
     cfg.is_2d = planar ? 1 : 0;
-    genericDescName.clear();
+    genericDescName.clear(); genericReadDescName.clear();
     cfg.n_outlier = 1;
     cfg.outlier[0].type = ICPMI_OUT_TRIMMEDDIST;
     cfg.outlier[0].param = 0.85f;
@@ -117,7 +117,7 @@ void GpuICPSequence::loadFromYamlNode(const yaml::Node& icp)
         if (e.second["maxDist"]) cfg.max_dist = e.second["maxDist"].as<float>();
     }
     cfg.n_outlier = 0;
-    genericDescName.clear();
+    genericDescName.clear(); genericReadDescName.clear();
     if (icp["outlierFilters"].IsSequence())
         for (const auto& item : icp["outlierFilters"].seq) {
             auto e = singleEntry(item, "outlier filter");
@@ -146,14 +146,19 @@ void GpuICPSequence::loadFromYamlNode(const yaml::Node& icp)
                 requireKnown(p, {"source", "descName", "useSoftThreshold", "useLargerThan", "threshold"}, e.first);
                 const std::string source = p["source"] ? p["source"].str() : "reference";
                 if (source != "reference" && source != "reading") throw InvalidParameter("GenericDescriptorOutlierFilter: source must be reference or reading");
-                if (source == "reading") throw InvalidParameter("GenericDescriptorOutlierFilter{source: reading} is not on the accelerated path");
                 const std::string name = p["descName"] ? p["descName"].str() : "none";
-                if (!genericDescName.empty() && genericDescName != name) throw InvalidParameter("GenericDescriptorOutlierFilter: the device tracks one scalar descriptor of the map");
-                genericDescName = name;
+                if (source == "reading") {
+                    // (r4) the descriptor of the READING point decides: its row rides to the device ahead of every registration (operator())
+                    if (!genericReadDescName.empty() && genericReadDescName != name) throw InvalidParameter("GenericDescriptorOutlierFilter: one reading descriptor per chain");
+                    genericReadDescName = name;
+                } else {
+                    if (!genericDescName.empty() && genericDescName != name) throw InvalidParameter("GenericDescriptorOutlierFilter: the device tracks one scalar descriptor of the map");
+                    genericDescName = name;
+                }
                 o.type = ICPMI_OUT_GENERICDESCRIPTOR;
                 o.param = p["threshold"] ? p["threshold"].as<float>() : 0.1f;
                 o.iparam = ((p["useSoftThreshold"] && p["useSoftThreshold"].as<int>()) ? ICPMI_GEN_SOFT : 0) |
-                           ((!p["useLargerThan"] || p["useLargerThan"].as<int>()) ? ICPMI_GEN_LARGER : 0);
+                           ((!p["useLargerThan"] || p["useLargerThan"].as<int>()) ? ICPMI_GEN_LARGER : 0) | (source == "reading" ? ICPMI_GEN_SOURCE_READING : 0);
             } else if (e.first == "RobustOutlierFilter") {
                 // defaults: robustFct cauchy, tuning 1, scaleEstimator mad, nbIterationForScale 0, distanceType point2point, approximation inf
                 const yaml::Node& p = e.second;
@@ -396,6 +401,11 @@ Mat4 GpuICPSequence::operator()(const DataPoints& readingIn)
         normals = reading.getDescriptorByName("normals").data.data();
     // ErrorMinimizer::getOverlap() (Mapper.cpp:219): a reading that carries `simpleSensorNoise` (and normals) gets upstream's
     // sensor-noise count instead of the weighted ratio; the row rides to the device ahead of the registration (one shot)
+    if (!genericReadDescName.empty()) { // GenericDescriptorOutlierFilter{source: reading}
+        if (!reading.descriptorExists(genericReadDescName) || reading.getDescriptorByName(genericReadDescName).span != 1)
+            throw InvalidField("GenericDescriptorOutlierFilter: the reading has no 1-row descriptor " + genericReadDescName);
+        check(h, icpmi_set_reading_scalar(h, reading.getDescriptorByName(genericReadDescName).data.data(), (int64_t)reading.getNbPoints()));
+    }
     // (PointToPointErrorMinimizer::getOverlap() needs the noise row alone, only PointToPlane also the reading's normals)
     if ((normals || cfg.minimizer == ICPMI_MIN_POINT_TO_POINT) && reading.descriptorExists("simpleSensorNoise") &&
         reading.getDescriptorByName("simpleSensorNoise").span == 1)

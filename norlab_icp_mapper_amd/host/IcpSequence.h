@@ -85,6 +85,10 @@ private:
     icpmi_stats lastStats{};
     size_t stagedPoints = 0;                           // size of the scan kept on the GPU by registerWithPrior
     std::string genericDescName;                       // GenericDescriptorOutlierFilter.descName (empty: no such filter)
+    std::string genericReadDescName;                   // ... of a filter with source: reading (the row goes to the device with every reading)
+  public:
+    bool readsReadingDescriptor() const { return !genericReadDescName.empty(); }
+  private:
     bool planar = false;                               // 2-D mapping (is3D == false): icpmi_config::is_2d
     ErrorMinimizerView minimizerView{this};
 };

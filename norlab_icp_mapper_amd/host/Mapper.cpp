@@ -180,7 +180,8 @@ void Mapper::processInput(const DataPoints& filteredInputInSensorFrame, const Ma
     // icpmi_map_update_staged).  Offline only: an asynchronous update would race the next scan for the staged buffer.
     // (a reading with `simpleSensorNoise` takes the host-pointer path below: icpmi_register_prior does not carry the noise row that
     // ErrorMinimizer::getOverlap() then needs, Mapper.cpp:219)
-    if (!isOnline && !icp.chainNeedsReadingNormals() && !icp.hasReadingFilters() && !filteredInputInSensorFrame.descriptorExists("simpleSensorNoise") &&
+    if (!isOnline && !icp.chainNeedsReadingNormals() && !icp.hasReadingFilters() && !icp.readsReadingDescriptor() &&
+        !filteredInputInSensorFrame.descriptorExists("simpleSensorNoise") &&
         map.canStageScan(filteredInputInSensorFrame, mapPostFilters, &estimatedPose)) {
         const bool bootstrap = map.isLocalPointCloudEmpty();
         Mat4 correction;

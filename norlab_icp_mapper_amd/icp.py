@@ -146,10 +146,13 @@ def config_from_yaml_chain(chain, **engine):
             for key in p:
                 if key not in ("source", "descName", "useSoftThreshold", "useLargerThan", "threshold"):
                     raise InvalidParameter(f"{name}: unknown parameter {key}")
-            if p.get("source", "reference") != "reference":
-                raise NotImplementedError("GenericDescriptorOutlierFilter{source: reading} is not on the accelerated path")
-            kw["generic_desc_name"] = str(p.get("descName", "none"))
-            flags = (_capi.GEN_SOFT if int(p.get("useSoftThreshold", 0)) else 0) | (_capi.GEN_LARGER if int(p.get("useLargerThan", 1)) else 0)
+            source = p.get("source", "reference")
+            if source not in ("reference", "reading"):
+                raise InvalidParameter(f"{name}: source must be reference or reading")
+            # (source: reading -- r4: the reading's row goes to the device with ICPSequence.setReadingScalar before every registration)
+            kw["generic_read_desc_name" if source == "reading" else "generic_desc_name"] = str(p.get("descName", "none"))
+            flags = (_capi.GEN_SOFT if int(p.get("useSoftThreshold", 0)) else 0) | (_capi.GEN_LARGER if int(p.get("useLargerThan", 1)) else 0) | \
+                    (_capi.GEN_SOURCE_READING if source == "reading" else 0)
             outs.append((_capi.OUT_GENERICDESCRIPTOR, float(p.get("threshold", 0.1)), flags, 0.0))
             continue
         if name == "VarTrimmedDistOutlierFilter":
@@ -208,6 +211,7 @@ def config_from_yaml_chain(chain, **engine):
             raise InvalidParameter(f"unknown transformation checker {name}")
     kw.update(engine)
     kw.pop("generic_desc_name", None)  # the caller hands the descriptor over with ICPSequence.setMapScalar
+    kw.pop("generic_read_desc_name", None)  # ... and the reading's with ICPSequence.setReadingScalar
     return default_config(**kw)
 
 
@@ -310,6 +314,11 @@ class ICPSequence:
         """icpmi_set_reading_sensor_noise: the `simpleSensorNoise` row of the NEXT reading (one shot; that call must bring scan_normals)."""
         nz = None if noise is None else np.ascontiguousarray(noise, dtype=np.float32).ravel()
         self._check(self._lib.icpmi_set_reading_sensor_noise(self._h, None if nz is None else nz.ctypes.data, 0 if nz is None else nz.shape[0]))
+
+    def setReadingScalar(self, scalar):
+        """icpmi_set_reading_scalar: the descriptor row GenericDescriptorOutlierFilter{source: reading} reads, for the NEXT reading (one shot)."""
+        sc = None if scalar is None else np.ascontiguousarray(scalar, dtype=np.float32).ravel()
+        self._check(self._lib.icpmi_set_reading_scalar(self._h, None if sc is None else sc.ctypes.data, 0 if sc is None else sc.shape[0]))
 
     def registerDev(self, d_scan_ptr, n, fixed_iterations=0, d_normals_ptr=None):
         T = (C.c_float * 16)()

@@ -357,6 +357,12 @@ static float orc_median_finite(const float* v, int64_t cnt, int* empty)
     return r;
 }
 
+/* GenericDescriptorOutlierFilter{source: reading}: the 1-row descriptor of the READING point decides (same rule as source: reference,
+ * OutlierFiltersImpl.cpp as recalled).  The row is handed over out of band (the checker is single threaded): orc_set_reading_scalar for the
+ * stage call, orc_icp_set_reading_scalar for a registration. */
+static const float* g_read_scalar = NULL;
+void orc_set_reading_scalar(const float* scalar) { g_read_scalar = scalar; }
+
 int orc_outlier_weights_ex(const orc_config* cfg, const float* d2, const int32_t* ids, int k, int64_t n, const float* read_normals3,
                            const float* ref_normals3, const float* ref_scalar, const float* step4, const float* ref4, int iteration,
                            float* robust_scale, float* weights, float* limit_out)
@@ -410,11 +416,12 @@ int orc_outlier_weights_ex(const orc_config* cfg, const float* d2, const int32_t
              * descriptor of the matched reference point (source: reference) decides: hard -> (desc > threshold) or (desc <
              * threshold); soft -> the weight IS the descriptor value */
             const int ip = cfg->outlier[f].iparam;
-            if ((ip & ORC_GEN_SOURCE_READING) || !ref_scalar) return ORC_ERR_ARG;
+            const int from_reading = (ip & ORC_GEN_SOURCE_READING) != 0;
+            if (from_reading ? !g_read_scalar : !ref_scalar) return ORC_ERR_ARG;
             for (int64_t e = 0; e < cnt; ++e) {
                 const int32_t id = ids[e];
                 if (id < 0) { weights[e] = 0.f; continue; }
-                const float v = ref_scalar[id];
+                const float v = from_reading ? g_read_scalar[e / k] : ref_scalar[id];
                 float w;
                 if (ip & ORC_GEN_SOFT) w = v;
                 else w = (ip & ORC_GEN_LARGER) ? (v > prm ? 1.f : 0.f) : (v < prm ? 1.f : 0.f);
@@ -957,6 +964,7 @@ struct orc_icp {
     float* scalar;     /* or NULL: the descriptor GenericDescriptorOutlierFilter reads */
     orc_kdtree* tree;
     float* read_noise; int64_t read_noise_n; /* simpleSensorNoise of the next reading (one shot) */
+    float* read_scalar; int64_t read_scalar_n; /* GenericDescriptorOutlierFilter{source: reading}: that descriptor of the next reading (one shot) */
 };
 
 orc_icp* orc_icp_create(const orc_config* cfg)
@@ -971,7 +979,7 @@ orc_icp* orc_icp_create(const orc_config* cfg)
 void orc_icp_destroy(orc_icp* s)
 {
     if (!s) return;
-    free(s->map4); free(s->normals3); free(s->scalar); free(s->read_noise); orc_kdtree_free(s->tree); free(s);
+    free(s->map4); free(s->normals3); free(s->scalar); free(s->read_noise); free(s->read_scalar); orc_kdtree_free(s->tree); free(s);
 }
 
 void orc_icp_set_map_scalar(orc_icp* s, const float* scalar)
@@ -980,6 +988,15 @@ void orc_icp_set_map_scalar(orc_icp* s, const float* scalar)
     if (!scalar || s->m <= 0) return;
     s->scalar = (float*)malloc((size_t)s->m * sizeof(float));
     memcpy(s->scalar, scalar, (size_t)s->m * sizeof(float));
+}
+
+void orc_icp_set_reading_scalar(orc_icp* s, const float* scalar, int64_t n)
+{
+    free(s->read_scalar); s->read_scalar = NULL; s->read_scalar_n = 0;
+    if (!scalar || n <= 0) return;
+    s->read_scalar = (float*)malloc((size_t)n * sizeof(float));
+    memcpy(s->read_scalar, scalar, (size_t)n * sizeof(float));
+    s->read_scalar_n = n;
 }
 
 void orc_icp_set_reading_noise(orc_icp* s, const float* noise, int64_t n)
@@ -1024,6 +1041,8 @@ int orc_icp_register(orc_icp* s, const float* scan4, int64_t n, const float* sca
     st->sensor_noise_overlap = -1.f;
     mat4_identity(T_out);
     const int64_t noise_n = s->read_noise_n; s->read_noise_n = 0; /* one shot */
+    const int64_t rscalar_n = s->read_scalar_n; s->read_scalar_n = 0;
+    g_read_scalar = rscalar_n == n ? s->read_scalar : NULL;
     if (!orc_icp_has_map(s)) return ORC_OK; /* "Ignoring attempt to perform ICP with an empty map" */
     const orc_config* cfg = &s->cfg;
     const int k = cfg->knn;

@@ -146,6 +146,7 @@ void orc_solve6(const float* A, const float* b, float* x);
 void orc_solve_n(int n, const float* A, const float* b, float* x); /* n <= 6; the same rule for any size */
 /* every filter of the chain, including the ones that need more than the matches: ref_scalar (GenericDescriptor, per map point),
  * step4 / ref4 (Robust point2plane residuals), *robust_scale (kept between iterations: nbIterationForScale), iteration (1-based) */
+void orc_set_reading_scalar(const float* scalar); /* GenericDescriptor{source: reading}: the reading's row for the next orc_outlier_weights_ex */
 int orc_outlier_weights_ex(const orc_config* cfg, const float* d2, const int32_t* ids, int k, int64_t n, const float* read_normals3,
                            const float* ref_normals3, const float* ref_scalar, const float* step4, const float* ref4, int iteration,
                            float* robust_scale, float* weights, float* limit_out);
@@ -156,6 +157,7 @@ orc_icp* orc_icp_create(const orc_config* cfg);
 /* `simpleSensorNoise` row (n floats) of the NEXT reading handed to orc_icp_register (one shot; the reading's normals come with that
  * call): ErrorMinimizer::getOverlap() then counts the last iteration's pairs that lie within the sensor noise */
 void orc_icp_set_reading_noise(orc_icp* s, const float* noise, int64_t n);
+void orc_icp_set_reading_scalar(orc_icp* s, const float* scalar, int64_t n); /* GenericDescriptor{source: reading}, one shot */
 void orc_icp_destroy(orc_icp* s);
 /* returns 1 on success, 0 if the cloud is empty (state unchanged) */
 int orc_icp_set_map(orc_icp* s, const float* map4, int64_t m, const float* normals3);

@@ -83,6 +83,10 @@ def load():
     lib.orc_icp_register.argtypes = [_P, _P, C.c_int64, _P, _P, C.POINTER(Stats)]
     lib.orc_icp_set_reading_noise.argtypes = [_P, _P, C.c_int64]
     lib.orc_icp_set_reading_noise.restype = None
+    lib.orc_icp_set_reading_scalar.argtypes = [_P, _P, C.c_int64]
+    lib.orc_icp_set_reading_scalar.restype = None
+    lib.orc_set_reading_scalar.argtypes = [_P]
+    lib.orc_set_reading_scalar.restype = None
     lib.orc_surface_normals.argtypes = [_P, C.c_int64, C.c_int, _P, C.c_int]
     lib.orc_surface_normals_ex.argtypes = [_P, C.c_int64, C.c_int, _P, _P, C.c_int]
     lib.orc_surface_normals_2d.argtypes = [_P, C.c_int64, C.c_int, _P, C.c_int]
@@ -170,7 +174,7 @@ def var_trimmed_ratio(d2, min_ratio=0.05, max_ratio=0.99, lam=0.95):
     return float(lib.orc_var_trimmed_ratio(d2.ctypes.data, d2.size, min_ratio, max_ratio, lam))
 
 
-def outlier_weights(cfg, d2, ids, read_normals=None, ref_normals=None, ref_scalar=None, step=None, ref=None, iteration=1, scale=1.0):
+def outlier_weights(cfg, d2, ids, read_normals=None, ref_normals=None, ref_scalar=None, step=None, ref=None, iteration=1, scale=1.0, read_scalar=None):
     """OutlierFilters::compute of the chain; the keyword extras feed GenericDescriptor (ref_scalar) and Robust (step, ref,
     iteration, the scale kept from the previous iteration).  Returns (err, weights, limit) -- with Robust{mad} limit = scale."""
     lib = load(); d2 = _f32(d2); ids = np.ascontiguousarray(ids, dtype=np.int32)
@@ -179,8 +183,11 @@ def outlier_weights(cfg, d2, ids, read_normals=None, ref_normals=None, ref_scala
     ptr = lambda a: _f32(a).ctypes.data if a is not None else None
     keep = [_f32(a) if a is not None else None for a in (read_normals, ref_normals, ref_scalar, step, ref)]
     args = [a.ctypes.data if a is not None else None for a in keep]
+    rs = _f32(read_scalar).ravel() if read_scalar is not None else None
+    lib.orc_set_reading_scalar(rs.ctypes.data if rs is not None else None)
     err = lib.orc_outlier_weights_ex(C.byref(cfg), d2.ctypes.data, ids.ctypes.data, k, n, args[0], args[1], args[2], args[3], args[4],
                                      int(iteration), C.byref(sc), w.ctypes.data, C.byref(lim))
+    lib.orc_set_reading_scalar(None)
     return err, w, float(lim.value)
 
 
@@ -251,6 +258,11 @@ class OracleICP:
         """`simpleSensorNoise` row of the next reading (one shot): stats.sensor_noise_overlap is then getOverlap()"""
         nz = np.ascontiguousarray(noise, dtype=np.float32).ravel()
         self.lib.orc_icp_set_reading_noise(self.h, nz.ctypes.data, nz.shape[0])
+
+    def setReadingScalar(self, scalar):
+        """GenericDescriptorOutlierFilter{source: reading}: that 1-row descriptor of the next reading (one shot)"""
+        s = np.ascontiguousarray(scalar, dtype=np.float32).ravel()
+        self.lib.orc_icp_set_reading_scalar(self.h, s.ctypes.data, s.shape[0])
 
     def __call__(self, scan, scan_normals=None):
         scan = _f32(scan); sn = _f32(scan_normals) if scan_normals is not None else None

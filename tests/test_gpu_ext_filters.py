@@ -65,8 +65,6 @@ def test_generic_descriptor_needs_the_scalar(amd, small_scene):
     icp.setMap(sc["map"])
     with pytest.raises(Exception, match="InvalidField|scalar"):
         icp(sc["scan"])
-    with pytest.raises(Exception):  # source: reading
-        amd.ICPSequence(minimizer=1, outliers=[(GEN, 0.5, 1, 0.0)])
 
 
 @pytest.mark.parametrize("fct", list(FCT))
@@ -340,3 +338,38 @@ def test_set_map_with_then_without_normals_drops_segment_graphs(amd, oracle, mid
     assert err == 0 and icp.stats.iterations == o.stats.iterations
     dt, dr = amd.synth.pose_error(T2, T2_ref)
     assert dt <= 1e-4 and dr <= 1e-4
+
+
+def test_generic_descriptor_source_reading(amd, oracle, mid_scene):
+    """GenericDescriptorOutlierFilter{source: reading} (r4, icpmi_set_reading_scalar): the descriptor of the READING point decides.  Known
+    answer by numpy (Identity minimiser, one iteration: the pairs are the matched reading points whose descriptor passes), then a full
+    point-to-plane registration against the oracle, hard and soft."""
+    sc = mid_scene
+    n = sc["scan"].shape[0]
+    rng = np.random.default_rng(21)
+    desc = rng.random(n).astype(np.float32)
+    desc[::9] = 0.5
+    READ = 1
+    icp = amd.ICPSequence(minimizer=0, max_dist=50.0, outliers=[(GEN, 0.5, READ | LARGER, 0.0)], max_iterations=1)
+    assert icp.setMap(sc["map"], sc["normals"])
+    icp.setReadingScalar(desc)
+    icp(sc["scan"])
+    assert icp.stats.pairs == int((desc > np.float32(0.5)).sum())
+    with pytest.raises(Exception, match="InvalidField|descriptor"):      # one shot: the next reading came without its row
+        icp(sc["scan"])
+    with pytest.raises(Exception):                                       # the stage entry points carry no reading descriptor
+        icp.outlierWeights(np.ones((4, 1), np.float32), np.zeros((4, 1), np.int32))
+    for flags in (READ | LARGER, READ, READ | SOFT):
+        kw = dict(minimizer=2, max_dist=2.0, outliers=[(GEN, 0.4, flags, 0.0), (4, 0.9)], max_iterations=25, use_differential=1)
+        icp = amd.ICPSequence(**kw)
+        assert icp.setMap(sc["map"], sc["normals"])
+        icp.setReadingScalar(desc)
+        T = icp(sc["scan"])
+        o = oracle.OracleICP(oracle.make_config(nthreads=8, **kw))
+        o.setMap(sc["map"], sc["normals"])
+        o.setReadingScalar(desc)
+        err, T_ref = o(sc["scan"])
+        assert err == 0 and icp.stats.iterations == o.stats.iterations and icp.stats.pairs == o.stats.pairs, (flags, icp.stats.pairs, o.stats.pairs)
+        assert icp.stats.weighted_point_used_ratio == pytest.approx(o.stats.weighted_point_used_ratio, rel=1e-6)
+        dt, dr = amd.synth.pose_error(T, T_ref)
+        assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (flags, dt, dr)

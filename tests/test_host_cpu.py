@@ -164,8 +164,9 @@ inspector: NullInspector
     for bad in ({"RobustOutlierFilter": {"robustFct": "foo"}}, {"RobustOutlierFilter": {"nope": 1}}, {"GenericDescriptorOutlierFilter": {"nope": 1}}):
         with pytest.raises(pkg.InvalidParameter):
             pkg.config_from_yaml_chain({"outlierFilters": [bad]})
-    for unsupported in ({"RobustOutlierFilter": {"scaleEstimator": "berg"}}, {"RobustOutlierFilter": {"approximation": 2.0}},
-                        {"GenericDescriptorOutlierFilter": {"source": "reading"}}):
+    rd = pkg.config_from_yaml_chain({"outlierFilters": [{"GenericDescriptorOutlierFilter": {"source": "reading", "descName": "intensity", "threshold": 0.3}}]})
+    assert rd.outlier[0].iparam == _capi.GEN_SOURCE_READING | _capi.GEN_LARGER      # r4: served (icpmi_set_reading_scalar)
+    for unsupported in ({"RobustOutlierFilter": {"scaleEstimator": "berg"}}, {"RobustOutlierFilter": {"approximation": 2.0}}):
         with pytest.raises(NotImplementedError):
             pkg.config_from_yaml_chain({"outlierFilters": [unsupported]})
 

@@ -76,7 +76,12 @@ def test_generic_descriptor_known_answers(oracle):
         assert err == 0
         np.testing.assert_array_equal(w[:, 0], np.array(want, dtype=np.float32))
     err, _, _ = oracle.outlier_weights(oracle.make_config(outliers=[(GEN, 0.5, 1, 0.0)]), d2, ids, ref_scalar=s)
-    assert err != 0  # source: reading
+    assert err != 0  # source: reading without the reading's row
+    rs = np.array([0.9, 0.1, 0.6, 0.7], dtype=np.float32)   # ... with it: the READING point's descriptor decides (entry 3 is unmatched)
+    for flags, want in ((1 | 4, [1, 0, 1, 0]), (1, [0, 1, 0, 0]), (1 | 2, [0.9, 0.1, 0.6, 0])):
+        err, w, _ = oracle.outlier_weights(oracle.make_config(outliers=[(GEN, 0.5, flags, 0.0)]), d2, ids, read_scalar=rs)
+        assert err == 0
+        np.testing.assert_array_equal(w[:, 0], np.array(want, dtype=np.float32))
 
 
 def test_force_4dof_recovers_a_yaw_and_ignores_tilt(oracle):
