@@ -248,6 +248,10 @@ icpmi_status icpmi_surface_normals(icpmi_handle h, const float* pts4, int64_t m,
 /* ... with `keepDensities: 1`: densities (m floats, may be NULL) = knn / (4/3 pi r^3), r = the largest distance of a neighbour
  * from the centroid of the neighbourhood (the descriptor MaxDensityDataPointsFilter reads). */
 icpmi_status icpmi_surface_normals_ex(icpmi_handle h, const float* pts4, int64_t m, int32_t knn, float* normals3, float* densities);
+/* (v4) ... with `keepMatchedIds: 1` / `keepMeanDist: 1`: matched_ids (knn x m int32, column i = the neighbours of point i by ascending
+ * (d2, index), the point itself first; may be NULL) and mean_dist (m floats: distance from the point to the mean of its neighbours; may be NULL). */
+icpmi_status icpmi_surface_normals_ex2(icpmi_handle h, const float* pts4, int64_t m, int32_t knn, float* normals3, float* densities,
+                                       int32_t* matched_ids, float* mean_dist);
 
 /* `PointDistanceMapperModule::inPlaceUpdateMap` keep mask (PointDistanceMapperModule.cpp:28-50):
  * keep[i] = 1 iff the exact NN of input i in map (self match excluded) has d2 >= min_dist^2. */

@@ -58,8 +58,11 @@ __global__ __launch_bounds__(256) void keep_kernel(const float* __restrict__ d2,
 // one lane per point: mean + covariance of the kNN set in double, smallest eigenvector by Jacobi
 // densities (may be null): `keepDensities` of the filter -- points per volume of the sphere that holds the neighbourhood around
 // its centroid: k / (4/3 pi r^3), r = the largest distance of a neighbour from the centroid (computeDensity)
+// mean_dist (may be null): `keepMeanDist` -- distance from the point to the mean of its neighbours.  The point is read as its own first
+// neighbour (d2 = 0 sorts first; a duplicate that wins the index tie has the same coordinates), which keeps it in the index's centred frame.
 __global__ __launch_bounds__(128) void normals_kernel(const float4* __restrict__ map, const int* __restrict__ sidx, int64_t m, int k,
-                                                      float* __restrict__ normals3, float* __restrict__ densities, int dim2)
+                                                      float* __restrict__ normals3, float* __restrict__ densities, int dim2,
+                                                      float* __restrict__ mean_dist = nullptr)
 {
     const int64_t i = (int64_t)blockIdx.x * 128 + threadIdx.x;
     if (i >= m) return;
@@ -89,6 +92,12 @@ __global__ __launch_bounds__(128) void normals_kernel(const float4* __restrict__
     if (densities) {
         const double r = sqrt(rmax2);
         densities[i] = (float)((double)real / ((4.0 / 3.0) * 3.14159265358979323846 * (r * r * r)));
+    }
+    if (mean_dist) {
+        const int s0 = sidx[(size_t)k * i];
+        const float4 p = map[s0 < 0 ? 0 : s0];
+        const double x = p.x - mean[0], y = p.y - mean[1], z = p.z - mean[2];
+        mean_dist[i] = (float)sqrt(x * x + y * y + z * z);
     }
     // cyclic Jacobi on the symmetric 3x3
     double A[3][3] = {{c00, c01, c02}, {c01, c11, c12}, {c02, c12, c22}};
@@ -672,7 +681,8 @@ static icpmi_status temp_knn(icpmi_ctx* c, TempCtx& t, const float* cloud4, int6
     return ICPMI_OK;
 }
 
-icpmi_status ops_surface_normals(icpmi_ctx* c, const float* pts4, int64_t m, int knn, float* normals3, float* densities)
+icpmi_status ops_surface_normals(icpmi_ctx* c, const float* pts4, int64_t m, int knn, float* normals3, float* densities, int32_t* matched_ids,
+                                 float* mean_dist)
 {
     if (m == 0) return ICPMI_OK;
     if (knn < 1 || knn > ICPMI_MAX_K) { c->last_error = "surface_normals: knn must be in [1, 32]"; return ICPMI_ERR_INVALID_ARG; }
@@ -682,12 +692,20 @@ icpmi_status ops_surface_normals(icpmi_ctx* c, const float* pts4, int64_t m, int
     s = temp_knn(c, t, pts4, m, nullptr, m, knn, 1, true);
     if (s != ICPMI_OK) return s;
     icpmi_ctx* tc = t.h;
-    DevBuf<float> d_n, d_dens;
+    DevBuf<float> d_n, d_dens, d_md;
+    DevBuf<int> d_ids;
     HIP_TRY(c, d_n.alloc((size_t)m * 3));
     if (densities) HIP_TRY(c, d_dens.alloc((size_t)m));
+    if (mean_dist) HIP_TRY(c, d_md.alloc((size_t)m));
     hipLaunchKernelGGL(normals_kernel, dim3((int)((m + 127) / 128)), dim3(128), 0, tc->stream, tc->d_map_sorted, tc->d_sidx, m, knn, d_n,
-                       densities ? d_dens.p : (float*)nullptr, c->cfg.is_2d);
+                       densities ? d_dens.p : (float*)nullptr, c->cfg.is_2d, mean_dist ? d_md.p : (float*)nullptr);
     hipError_t e = hipGetLastError();
+    if (e == hipSuccess && matched_ids) { // keepMatchedIds: sorted positions -> the caller's indices
+        e = d_ids.alloc((size_t)m * knn);
+        if (e == hipSuccess && nn_ids_to_original(tc, tc->d_sidx, m * knn, d_ids) != ICPMI_OK) { c->last_error = tc->last_error; return ICPMI_ERR_HIP; }
+        if (e == hipSuccess) e = hipMemcpyAsync(matched_ids, d_ids, (size_t)m * knn * sizeof(int), hipMemcpyDeviceToHost, tc->stream);
+    }
+    if (e == hipSuccess && mean_dist) e = hipMemcpyAsync(mean_dist, d_md, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, tc->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(normals3, d_n, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost, tc->stream);
     if (e == hipSuccess && densities) e = hipMemcpyAsync(densities, d_dens, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, tc->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(tc->stream);

@@ -509,18 +509,27 @@ struct CutAtDescriptorThresholdFilter : DataPointsFilter {
 };
 
 struct SurfaceNormalFilter : DataPointsFilter {
-    icpmi_handle h; int knn = 5; bool keepDensities = false;
+    icpmi_handle h; int knn = 5; bool keepDensities = false, keepMatchedIds = false, keepMeanDist = false;
     int surfaceNormalKnn() const override { return knn; }
     bool residentOp(icpmi_map_op& op, std::string&) const override {
         op = icpmi_map_op{}; op.type = ICPMI_MOP_SURFACE_NORMALS; op.i = knn;
-        return knn >= 1 && knn <= 32 && !keepDensities; // the resident map does not track `densities`
+        // the resident map does not track `densities`, `matchedIds` or `meanDist`
+        return knn >= 1 && knn <= 32 && !keepDensities && !keepMatchedIds && !keepMeanDist;
     }
     void inPlaceFilter(DataPoints& c) const override {
         const size_t n = c.getNbPoints();
-        std::vector<float> normals(3 * n), dens(keepDensities ? n : 0);
-        GpuICPSequence::check(h, icpmi_surface_normals_ex(h, c.features.data(), (int64_t)n, knn, normals.data(), keepDensities ? dens.data() : nullptr));
+        std::vector<float> normals(3 * n), dens(keepDensities ? n : 0), md(keepMeanDist ? n : 0);
+        std::vector<int32_t> ids(keepMatchedIds ? n * (size_t)knn : 0);
+        GpuICPSequence::check(h, icpmi_surface_normals_ex2(h, c.features.data(), (int64_t)n, knn, normals.data(), keepDensities ? dens.data() : nullptr,
+                                                           keepMatchedIds ? ids.data() : nullptr, keepMeanDist ? md.data() : nullptr));
         c.addDescriptor("normals", 3, std::move(normals));
         if (keepDensities) c.addDescriptor("densities", 1, std::move(dens));
+        if (keepMatchedIds) { // upstream stores the ids as descriptor rows of the cloud's scalar type
+            std::vector<float> f(ids.size());
+            for (size_t i = 0; i < ids.size(); ++i) f[i] = (float)ids[i];
+            c.addDescriptor("matchedIds", knn, std::move(f));
+        }
+        if (keepMeanDist) c.addDescriptor("meanDist", 1, std::move(md));
     }
 };
 
@@ -863,10 +872,11 @@ std::shared_ptr<DataPointsFilter> createDataPointsFilter(const std::string& name
     if (name == "SurfaceNormalDataPointsFilter") {
         requireKnown(p, {"knn", "maxDist", "epsilon", "keepNormals", "keepDensities", "keepEigenValues", "keepEigenVectors",
                          "keepMatchedIds", "keepMeanDist", "sortEigen", "smoothNormals"}, name);
-        for (const char* k : {"keepEigenValues", "keepEigenVectors", "keepMatchedIds", "keepMeanDist", "smoothNormals"})
+        for (const char* k : {"keepEigenValues", "keepEigenVectors", "smoothNormals"})
             if (geti(p, k, 0) != 0) throw InvalidParameter(name + ": " + k + " is not on the accelerated path");
         auto f = std::make_shared<SurfaceNormalFilter>();
         f->h = ctx; f->knn = geti(p, "knn", 5); f->keepDensities = geti(p, "keepDensities", 0) != 0;
+        f->keepMatchedIds = geti(p, "keepMatchedIds", 0) != 0; f->keepMeanDist = geti(p, "keepMeanDist", 0) != 0;
         return f;
     }
     if (name == "RandomSamplingDataPointsFilter") {

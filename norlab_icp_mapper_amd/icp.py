@@ -394,9 +394,19 @@ class ICPSequence:
         self._check(self._lib.icpmi_minimize_step(self._h, r.ctypes.data, r.shape[0], tptr, T, sums, C.byref(self.stats)))
         return _T_from_c(T[:]), np.array(sums[:])
 
-    def surfaceNormals(self, cloud, knn=5, with_densities=False):
+    def surfaceNormals(self, cloud, knn=5, with_densities=False, with_matched_ids=False, with_mean_dist=False):
+        """normals [, densities] [, matched ids (m, knn) int32] [, mean distance (m,)] -- SurfaceNormalDataPointsFilter with
+        keepDensities / keepMatchedIds / keepMeanDist."""
         c = _f32c(cloud, 4)
         out = np.empty((c.shape[0], 3), dtype=np.float32)
+        if with_matched_ids or with_mean_dist:
+            m = c.shape[0]
+            dens = np.empty(m, dtype=np.float32) if with_densities else None
+            ids = np.empty((m, knn), dtype=np.int32) if with_matched_ids else None
+            md = np.empty(m, dtype=np.float32) if with_mean_dist else None
+            ptr = lambda a: a.ctypes.data if a is not None else None
+            self._check(self._lib.icpmi_surface_normals_ex2(self._h, c.ctypes.data, m, knn, out.ctypes.data, ptr(dens), ptr(ids), ptr(md)))
+            return tuple(x for x in (out, dens, ids, md) if x is not None)
         if not with_densities:
             self._check(self._lib.icpmi_surface_normals(self._h, c.ctypes.data, c.shape[0], knn, out.ctypes.data))
             return out

@@ -1174,6 +1174,10 @@ void orc_surface_normals(const float* pts4, int64_t m, int knn, float* normals3,
 /* densities (may be NULL): keepDensities -- knn / (4/3 pi r^3), r = the largest distance of a neighbour from the centroid of the
  * neighbourhood (SurfaceNormalDataPointsFilter::computeDensity: NN.colwise().norm().maxCoeff() on the centred neighbours) */
 static void orc_surface_normals_impl(const float* pts4, int64_t m, int knn, float* normals3, float* densities, int nthreads, int dim2);
+/* keepMatchedIds / keepMeanDist of the filter (SurfaceNormal.cpp as recalled): the ids of the knn neighbours of every point (self included,
+ * ascending distance), and the distance from the point to the mean of its neighbours.  Set before a call, consumed by it. */
+static int32_t* g_sn_ids_out = NULL; static float* g_sn_meandist_out = NULL;
+void orc_surface_normals_extras(int32_t* matched_ids, float* mean_dist) { g_sn_ids_out = matched_ids; g_sn_meandist_out = mean_dist; }
 void orc_surface_normals_ex(const float* pts4, int64_t m, int knn, float* normals3, float* densities, int nthreads)
 {
     orc_surface_normals_impl(pts4, m, knn, normals3, densities, nthreads, 0);
@@ -1212,6 +1216,12 @@ static void orc_surface_normals_impl(const float* pts4, int64_t m, int knn, floa
             if (r2 > rmax2) rmax2 = r2;
         }
         if (densities) { const double rr = sqrt(rmax2); densities[i] = (float)((double)real / ((4.0 / 3.0) * 3.14159265358979323846 * (rr * rr * rr))); }
+        if (g_sn_ids_out) for (int j = 0; j < knn; ++j) g_sn_ids_out[(int64_t)knn * i + j] = ids[(int64_t)knn * i + j];
+        if (g_sn_meandist_out) {
+            double dd = 0;
+            for (int r = 0; r < 3; ++r) { const double v = (double)pts4[4 * i + r] - mean[r]; dd += v * v; }
+            g_sn_meandist_out[i] = (float)sqrt(dd);
+        }
         double w[3], Q[9];
         jacobi_eig_sym(3, C, w, Q);
         if (dim2) {
@@ -1235,6 +1245,7 @@ static void orc_surface_normals_impl(const float* pts4, int64_t m, int knn, floa
         for (int r = 0; r < 3; ++r) normals3[3 * i + r] = (float)Q[3 * e + r];
     }
     free(ids); free(d2); orc_kdtree_free(t);
+    g_sn_ids_out = NULL; g_sn_meandist_out = NULL;
 }
 
 /* PointDistanceMapperModule::inPlaceUpdateMap keep mask (PointDistanceMapperModule.cpp:28-50):

@@ -272,6 +272,16 @@ class OracleICP:
         return err, T_from_c(T)
 
 
+def surface_normals_extras(cloud, knn=5, nthreads=1):
+    """(normals, matched ids (m, knn), mean distance (m,)): keepMatchedIds / keepMeanDist of the filter"""
+    lib = load(); cloud = _f32(cloud); m = cloud.shape[0]
+    out = np.empty((m, 3), dtype=np.float32); ids = np.empty((m, knn), dtype=np.int32); md = np.empty(m, dtype=np.float32)
+    lib.orc_surface_normals_extras.argtypes = [_P, _P]; lib.orc_surface_normals_extras.restype = None
+    lib.orc_surface_normals_extras(ids.ctypes.data, md.ctypes.data)
+    lib.orc_surface_normals(cloud.ctypes.data, m, knn, out.ctypes.data, nthreads)
+    return out, ids, md
+
+
 def surface_normals(cloud, knn=5, nthreads=1, with_densities=False, planar=False):
     lib = load(); cloud = _f32(cloud); out = np.empty((cloud.shape[0], 3), dtype=np.float32)
     if planar:  # 2-D clouds (z == 0): the smaller eigenvector of the 2 x 2 covariance

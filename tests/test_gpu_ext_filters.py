@@ -373,3 +373,30 @@ def test_generic_descriptor_source_reading(amd, oracle, mid_scene):
         assert icp.stats.weighted_point_used_ratio == pytest.approx(o.stats.weighted_point_used_ratio, rel=1e-6)
         dt, dr = amd.synth.pose_error(T, T_ref)
         assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (flags, dt, dr)
+
+
+def test_surface_normal_keep_matched_ids_and_mean_dist(amd, oracle):
+    """icpmi_surface_normals_ex2: keepMatchedIds / keepMeanDist against the oracle (ids bit-equal, distances to float rounding: the
+    index works in a centred frame) and against scipy directly."""
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(5)
+    pts = np.ones((20000, 4), dtype=np.float32)
+    pts[:, :3] = rng.uniform(-30, 30, (20000, 3)).astype(np.float32)
+    pts[:, 2] *= 0.1
+    k = 9
+    icp = amd.ICPSequence(minimizer=0)
+    n, dens, ids, md = icp.surfaceNormals(pts, knn=k, with_densities=True, with_matched_ids=True, with_mean_dist=True)
+    rn, rids, rmd = oracle.surface_normals_extras(pts, knn=k, nthreads=8)
+    assert ids.dtype == np.int32 and ids.shape == (20000, k)
+    assert np.array_equal(ids, rids)
+    np.testing.assert_allclose(md, rmd, rtol=2e-4, atol=2e-5)
+    P = pts[:, :3].astype(np.float64)
+    _, ref = cKDTree(P).query(P, k=k)
+    assert np.array_equal(np.sort(ids, axis=1), np.sort(ref, axis=1))
+    # the plain entries give the same normals / densities
+    n0, d0 = icp.surfaceNormals(pts, knn=k, with_densities=True)
+    assert np.array_equal(n, n0) and np.array_equal(dens, d0)
+    # either output alone
+    (n1, ids1) = icp.surfaceNormals(pts, knn=k, with_matched_ids=True)
+    (n2, md2) = icp.surfaceNormals(pts, knn=k, with_mean_dist=True)
+    assert np.array_equal(ids1, ids) and np.array_equal(md2, md) and np.array_equal(n1, n) and np.array_equal(n2, n)

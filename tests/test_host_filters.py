@@ -130,3 +130,23 @@ def test_default_chain_reading_and_reference_filters(host, oracle, mid_scene, tm
     assert dt <= 1e-4 and dr <= 1e-4, (dt, dr)
     gt, gr = amd.synth.pose_error(T, sc["T_gt"])
     assert gt < 1e-2 and gr < 1e-3, (gt, gr)
+
+
+@pytest.mark.gpu
+def test_surface_normal_keep_matched_ids_and_mean_dist_descriptors(host, oracle):
+    """SurfaceNormalDataPointsFilter{keepMatchedIds: 1, keepMeanDist: 1} of the host shell: descriptors `matchedIds` (knn rows, ids as
+    the cloud's scalar type) and `meanDist` (1 row), equal to the oracle's."""
+    import norlab_icp_mapper_amd as amd
+    sc = amd.synth.make_scene(m=20_000, n=10)
+    icp = amd.ICPSequence()
+    h = icp._h.value if hasattr(icp._h, "value") else icp._h
+    k = 6
+    _, ids, md = oracle.surface_normals_extras(sc["map"], knn=k, nthreads=8)
+    n = sc["map"].shape[0]
+    yaml = f"- SurfaceNormalDataPointsFilter: {{knn: {k}, keepMatchedIds: 1, keepMeanDist: 1}}"
+    # (the test hook reads back the descriptor it was given by name: the filter replaces it)
+    out, nrm, got_ids = host.filter_chain(yaml, sc["map"], handle=h, desc_name="matchedIds", desc=np.zeros((n, k), np.float32))
+    assert nrm is not None and np.array_equal(out, sc["map"])
+    assert np.array_equal(got_ids, ids.astype(np.float32))
+    _, _, got_md = host.filter_chain(yaml, sc["map"], handle=h, desc_name="meanDist", desc=np.zeros(n, np.float32))
+    np.testing.assert_allclose(got_md.reshape(-1), md, rtol=2e-4, atol=2e-5)

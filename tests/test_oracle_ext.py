@@ -296,3 +296,23 @@ def test_sensor_noise_overlap_known_answer(oracle):
     # no noise handed over -> -1 (getOverlap() falls back to the weighted ratio)
     err, _ = o(scan, nrm)
     assert o.stats.sensor_noise_overlap == -1.0
+
+
+def test_surface_normal_matched_ids_and_mean_dist_match_ckdtree(oracle):
+    """keepMatchedIds / keepMeanDist (SurfaceNormalDataPointsFilter as recalled): the ids are the point's own kNN set (self first),
+    the mean distance is |p - mean(neighbours)| -- pinned against scipy's cKDTree, independent of the oracle's own k-d tree."""
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(77)
+    pts = np.ones((4000, 4), dtype=np.float32)
+    pts[:, :3] = rng.uniform(-10, 10, (4000, 3)).astype(np.float32)
+    k = 7
+    n, ids, md = oracle.surface_normals_extras(pts, knn=k)
+    P = pts[:, :3].astype(np.float64)
+    _, ref = cKDTree(P).query(P, k=k)
+    assert np.array_equal(ids[:, 0], np.arange(4000))
+    assert np.array_equal(np.sort(ids, axis=1), np.sort(ref, axis=1))
+    want = np.linalg.norm(P - P[ref].mean(axis=1), axis=1)
+    np.testing.assert_allclose(md, want, rtol=1e-5, atol=1e-6)
+    # the extras do not disturb the normals, and they are one-shot (the next call runs without them)
+    n2 = oracle.surface_normals(pts, knn=k)
+    assert np.array_equal(n, n2)
