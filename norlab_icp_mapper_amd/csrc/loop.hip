@@ -542,13 +542,29 @@ __global__ __launch_bounds__(BT) void accumulate_kernel(const float4* __restrict
     // The first two elements of every lane are requested before anything else so that their round
     // trip overlaps the histogram scan below.
     const int64_t count = (int64_t)n * lc.k;
-    const int64_t stride = (int64_t)nbe * BT;
-    const int64_t e_first = (int64_t)blockIdx.x * BT + threadIdx.x;
-    float pd2[2]; int ps[2]; float4 pr[2], pq[2];
+    const int64_t stride = (int64_t)nbe * BT;                                // (of the clears below: every thread of the reading's grid)
+    const int64_t gtid = (int64_t)blockIdx.x * BT + threadIdx.x;
+    // r4: a workgroup takes a CONTIGUOUS run of pairs, and the runs go to the XCDs the way the NN kernel hands out its queries
+    // (workgroup b runs on XCD b % 8; XCD x gets the x-th eighth of the tile-sorted pairs): the gathers of an XCD -- matched points,
+    // normals -- fall into one eighth of the map instead of all of it, inside a 4 MB L2.  ICPMI_ACC_STRIDED: the r1-r3 strided sweeps.
+#ifdef ICPMI_ACC_STRIDED
+    const int64_t estep = stride;
+    const int64_t e_first = gtid, e_end = count;
+#else
+    const int64_t estep = BT;
+    const int wgc = (nbe & 7) == 0 ? (int)(blockIdx.x & 7) * (nbe >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int64_t per_wg = (count + nbe - 1) / nbe;
+    const int64_t e_first = (int64_t)wgc * per_wg + threadIdx.x;
+    const int64_t e_end = ((int64_t)wgc + 1) * per_wg < count ? ((int64_t)wgc + 1) * per_wg : count;
+#endif
+    // (k > 1: 1024-thread workgroups, one per CU, up to 600 k pairs at knn 6 -- three pairs per lane; a third pair walked AFTER the first two
+    // is two more dependent round trips, so all three are requested up front)
+    constexpr int PF = BT > 256 ? 3 : 2;
+    float pd2[PF]; int ps[PF]; float4 pr[PF], pq[PF];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int64_t e = e_first + u * stride;
-        const bool in = e < count;
+    for (int u = 0; u < PF; ++u) {
+        const int64_t e = e_first + u * estep;
+        const bool in = e < e_end;
         pd2[u] = in ? d2a[e] : INFINITY;
         ps[u] = in ? sidx[e] : -1;
         pr[u] = reading[in ? (int)(e / lc.k) : 0];
@@ -556,9 +572,9 @@ __global__ __launch_bounds__(BT) void accumulate_kernel(const float4* __restrict
     }
     const unsigned cv = (FUSED && threadIdx.x < 256) ? hists[ICPMI_S2_C1 + threadIdx.x] : 0u; // same round trip as the elements
     // second round trip, overlapping the fine-histogram read of the selection scan: the matched normals
-    float4 pn[2];
+    float4 pn[PF];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < PF; ++u)
         pn[u] = (MIN == ICPMI_MIN_POINT_TO_PLANE && ps[u] >= 0) ? (pnm ? pnm[2 * (size_t)ps[u] + 1] : normals[ps[u]]) : make_float4(0.f, 0.f, 0.f, 0.f);
     if (st->done) return;
     if (acc_parity & 2) {
@@ -577,7 +593,7 @@ __global__ __launch_bounds__(BT) void accumulate_kernel(const float4* __restrict
         fused_limit = is_median ? factor * q : q;
         if (blockIdx.x == 0 && threadIdx.x == 0) st->limits[fused_slot] = fused_limit;
         // level 0 is dead (its only reader ran in the previous kernel): clear it for the next iteration
-        for (int64_t i = e_first; i < ICPMI_S2_COPIES * 256 + ICPMI_S2_FCOPIES * 65536; i += stride) hists[ICPMI_S2_C0 + i] = 0;
+        for (int64_t i = gtid; i < ICPMI_S2_COPIES * 256 + ICPMI_S2_FCOPIES * 65536; i += stride) hists[ICPMI_S2_C0 + i] = 0;
     }
     constexpr int NVAL = MIN == ICPMI_MIN_POINT_TO_PLANE ? 27 : (MIN == ICPMI_MIN_POINT_TO_POINT ? 16 : 0);
     double acc[NVAL > 0 ? NVAL : 1];
@@ -642,8 +658,8 @@ __global__ __launch_bounds__(BT) void accumulate_kernel(const float4* __restrict
         }
     };
 #pragma unroll
-    for (int u = 0; u < 2; ++u) pair(e_first + u * stride, pd2[u], ps[u], pr[u], pq[u], pn[u], true);
-    for (int64_t e = e_first + 2 * stride; e < count; e += stride)
+    for (int u = 0; u < PF; ++u) pair(e_first + u * estep, pd2[u], ps[u], pr[u], pq[u], pn[u], true);
+    for (int64_t e = e_first + PF * estep; e < e_end; e += estep)
         pair(e, d2a[e], sidx[e], reading[(int)(e / lc.k)], match_pt ? match_pt[e] : make_float4(0.f, 0.f, 0.f, 0.f),
              make_float4(0.f, 0.f, 0.f, 0.f), false);
     // ---- workgroup reduction: wave64 shuffles, then LDS across the 4 waves ----

@@ -1,0 +1,8 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"; R=$GRAFT_REPO_ROOT; O=gpurun_out/${1:-knn6q}; mkdir -p $O
+python -m pytest tests/test_gpu_knn_wg.py tests/test_gpu_parity.py tests/test_gpu_fused_solve.py -m gpu -q -x 2>&1 | tail -2
+for rep in 1 2; do python $R/bench.py --no-cpu --no-extras --chain docs_knn6 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('docs_knn6', round(d['value']), d['ms_per_step'])"; done
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -o t -- python $R/bench.py --no-cpu --no-extras --chain docs_knn6 > /dev/null 2>&1
+f=$(find $R/$O/prof -name "*kernel_stats.csv" | head -1); python $R/scripts/kstats.py $f 2>/dev/null | head -8
+find $R/$O -name "*kernel_trace.csv" -delete; find $R/$O -name "*agent_info.csv" -delete
