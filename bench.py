@@ -177,7 +177,7 @@ def circle_scans(pkg, n_scans, n_points, scale, rank, radius=20.0):
 def config5_stream(np, torch, pkg, dev, d_map, d_nrm, d_scans, chain, min_dist, comm, barrier):
     """One rank's part of BASELINE config 5: every scan is registered against the shared map (Counter 40 + Differential: what
     Mapper::processInput runs) and followed by ONE map-growth epoch (icpmi_staged_merge_allgather: PointDistance accept against the
-    resident map, all-gather of the accepted points, rank-ordered merge, append, index rebuild on every replica) -- registration AND
+    resident map, all-gather of the accepted points, rank-ordered merge, append, incremental index insert on every replica) -- registration AND
     epoch inside the timed region.  comm: None (single rank), ("rccl", id, world, rank) or ("loopback", R, shift)."""
     import os as _os
     icp = pkg.ICPSequence(device=dev, max_iterations=40, use_differential=1, **chain)
@@ -348,7 +348,7 @@ def main():
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"BASELINE config 5: {world} scan stream(s) x {args.scans} synthetic {args.scan_points}-pt scans vs the shared "
                                       f"{m5}-pt map (scene x{scale5}), {args.chain} chain, Counter 40 + Differential, one map-growth epoch per scan "
-                                      f"(PointDistance 0.15 m accept + RCCL all-gather + rank-ordered merge + append + index rebuild) inside the timed region",
+                                      f"(PointDistance 0.15 m accept + RCCL all-gather + rank-ordered merge + append + incremental index insert) inside the timed region",
                           "chain": args.chain, "parallelism": f"scan-sharded x{world}, map replicated, RCCL all-gather of accepted points per scan"},
                "scans_per_s": world * args.scans / elapsed, "per_rank_elapsed_s": [float(e[0].item()) for e in each],
                "per_rank_iterations": [float(e[1].item()) for e in each], "rank0": res}
@@ -457,7 +457,7 @@ def main():
                     cr, cme, ckind = icp.commInfo()
                     m = {"ms": float(tms.item()) * 1e3, "rccl_ranks": cr, "rccl_rank": cme, "communicator": {0: "none", 1: "rccl", 2: "loopback"}[ckind],
                          "accepted_rank0": mine_n, "appended_all_ranks": appended, "map_points_after": new_m,
-                         "what": "PointDistance(0.15 m) accept of one 100k-pt scan per rank + RCCL all-gather + rank-ordered exact merge + append + index rebuild"}
+                         "what": "PointDistance(0.15 m) accept of one 100k-pt scan per rank + RCCL all-gather + rank-ordered exact merge + append + incremental index insert"}
                 elif m is None:
                     m = {"error": "another rank could not create its communicator"}
             except Exception as e:  # noqa: BLE001
@@ -670,7 +670,7 @@ def main():
                     "roofline": nn_roofline(pkg, dev, chain, d_map10, d_nrm10, d_scan10, args.scan_points, 10_000_000, "hbm_bytes_per_launch_10M",
                                             m_reach=map_points_in_reach(np, sc10["map"], sc10["scan"], chain["max_dist"]))}
                 # BASELINE config 5 as far as one GPU goes: a stream of scans against the 10 M-point map, one map-growth epoch per scan
-                # (single rank: the epoch is accept + compaction + append + index rebuild, no exchange)
+                # (single rank: the epoch is accept + compaction + append + index insert, no exchange)
                 try:
                     c5scans = [torch.from_numpy(x).cuda() for x in circle_scans(pkg, 6, args.scan_points, 3.16, 0)]
                     r5 = config5_stream(np, torch, pkg, dev, d_map10, None if chain["minimizer"] != 2 else d_nrm10, c5scans, chain, 0.15, None, barrier)

@@ -861,6 +861,18 @@ int orc_minimize_ex(int minimizer, int force_4dof, const float* reading4, int64_
     }
     if (P == 0) return ORC_ERR_NO_POINT_TO_MINIMIZE;
     mat4_identity(T_out);
+    /* A weight that is not a number the sums can hold (RobustOutlierFilter L1 / Huber on a residual of exactly zero: 1 / sqrt(0)) makes
+     * the system meaningless: upstream's float LLT would return NaN or garbage depending on where the inf lands.  Both sides of this
+     * repository agree on the outcome instead -- "transformation is not a number" (the HIP path's fixed-point accumulators refuse a
+     * partial beyond +-2^77, csrc/loop.hip: accumulate_kernel). */
+    {
+        int bad = !(fabs(wsum) < 0x1p77);
+        for (int r = 0; r < 3; ++r) bad |= !(fabs(sp[r]) < 0x1p77) || !(fabs(sq[r]) < 0x1p77) || !(fabs(b2d[r]) < 0x1p77);
+        for (int r = 0; r < 9; ++r) bad |= !(fabs(Hs[r]) < 0x1p77);
+        for (int r = 0; r < 36; ++r) bad |= !(fabs(A[r]) < 0x1p77);
+        for (int r = 0; r < 6; ++r) bad |= !(fabs(b[r]) < 0x1p77);
+        if (bad) return ORC_ERR_NAN;
+    }
     if (minimizer == ORC_MIN_IDENTITY) return ORC_OK;
     if (minimizer == ORC_MIN_POINT_TO_POINT) {
         /* H = sum w (q - mq)(p - mp)^T = sum w q p^T - (sum w q)(sum w p)^T / sum w */
