@@ -107,3 +107,59 @@ def test_random_chain_matches_oracle(amd, oracle, i):
     Tf = icp.registerDev(d.data_ptr(), d.shape[0], fixed_iterations=icp.stats.iterations, d_normals_ptr=dn.data_ptr() if need_rn else None)
     dt, dr = amd.synth.pose_error(Tf, T)
     assert dt <= 1e-6 and dr <= 1e-6, (dt, dr, what)
+
+
+def draw_map_chain(rng):
+    """a mapper-module chain + post filters (Map::updateLocalPointCloud, Map.cpp:502-534) and the clouds of three successive updates"""
+    modules = []
+    for t in rng.choice(["point_distance", "dynamic_points", "voxel", "octree"], size=int(rng.integers(1, 4)), replace=True):
+        if t == "point_distance": modules.append(("point_distance", float(rng.choice([0.0, 0.05, 0.15, 0.3]))))
+        elif t == "dynamic_points":
+            modules.append(("dynamic_points", float(rng.uniform(0.6, 0.95)), float(rng.uniform(0.5, 0.9)), float(rng.uniform(0.9, 0.999)),
+                            float(rng.uniform(0.005, 0.03)), float(rng.uniform(0.005, 0.03)), float(rng.uniform(0.005, 0.03)), float(rng.choice([30.0, 200.0]))))
+        elif t == "voxel": modules.append(("voxel", float(rng.uniform(0.03, 0.5)), int(rng.integers(0, 2))))
+        else: modules.append(("octree", float(rng.uniform(0.1, 1.0)), 0, int(rng.choice([1, 2, 6]))))
+    post = []
+    if rng.integers(0, 2): post.append(("surface_normals", int(rng.integers(5, 13))))
+    if rng.integers(0, 3) == 0: post.append(("cut_scalar", float(rng.uniform(0.3, 0.9)), int(rng.integers(0, 2))))
+    return modules, post
+
+
+@pytest.mark.parametrize("i", range(max(N_DRAWS // 2, 1)))
+def test_random_map_update_chain_matches_oracle(amd, oracle, i):
+    """Three successive updates of a resident map by a random module chain (the second and third run on the state the first left:
+    the incremental index insert, the raw-frame view, regrown buffers) against the same chain composed from the oracle's operators."""
+    from test_gpu_map_chain import host_chain, normals_close
+    rng = np.random.default_rng(50_000 + 1000 * SEED0 + i)
+    modules, post = draw_map_chain(rng)
+    m, n = int(rng.integers(8_000, 40_000)), int(rng.integers(1_000, 7_000))
+    sc = amd.synth.make_scene(m=m, n=8, scale=0.25, seed_map=int(rng.integers(1, 1 << 20)))
+    base = sc["map"].copy()
+    base_n = oracle.surface_normals(base, knn=8, nthreads=8)
+    base_s = rng.uniform(0.0, 1.0, m).astype(np.float32)
+    icp = amd.ICPSequence(minimizer=1, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=5, use_differential=0)
+    icp.setMap(base, base_n); icp.setMapScalar(base_s)
+    pts, nrm, scal = base, base_n, base_s
+    what = (i, modules, post, m, n)
+    for u in range(3):
+        pick = rng.permutation(pts.shape[0])[:min(n, pts.shape[0])]
+        scan = pts[pick].copy()
+        scan[:, :3] += rng.normal(0, float(rng.choice([0.02, 0.1, 0.4])), (scan.shape[0], 3)).astype(np.float32)
+        scan_s = np.full(scan.shape[0], float(rng.uniform(0.3, 0.8)), np.float32)
+        pose = amd.synth.make_T(tuple(rng.uniform(-0.05, 0.05, 3)), tuple(rng.uniform(-3.0, 3.0, 3))).astype(np.float32)
+        to_sensor = np.linalg.inv(pose.astype(np.float64)).astype(np.float32)
+        src, m_new, _ = icp.mapUpdateChain(scan, modules, post, scan_scalar=scan_s, to_sensor=to_sensor, with_prefix=True)
+        pts, nrm, scal, ref_src = host_chain(oracle, pts, nrm, scal, scan, scan_s, to_sensor, modules, post)
+        assert m_new == pts.shape[0], (u, what)
+        assert np.array_equal(src, ref_src), (u, what)
+        got, got_n = icp.getMap(with_normals=True)
+        assert np.array_equal(got, pts), (u, what)
+        assert np.array_equal(icp.getMapScalar(), scal), (u, what)
+        if any(p[0] == "surface_normals" for p in post):
+            if pts.shape[0] > 12:
+                assert normals_close(got_n, nrm) > 0.995, (u, what)
+            nrm = got_n            # both sides go on from the same normals (PCA signs / eigen-solver round-off must not compound)
+        else:
+            assert np.array_equal(got_n, nrm), (u, what)
+        if pts.shape[0] == 0:
+            break
