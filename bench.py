@@ -351,7 +351,10 @@ def main():
                                       f"(PointDistance 0.15 m accept + RCCL all-gather + rank-ordered merge + append + incremental index insert) inside the timed region",
                           "chain": args.chain, "parallelism": f"scan-sharded x{world}, map replicated, RCCL all-gather of accepted points per scan"},
                "scans_per_s": world * args.scans / elapsed, "per_rank_elapsed_s": [float(e[0].item()) for e in each],
-               "per_rank_iterations": [float(e[1].item()) for e in each], "rank0": res}
+               "per_rank_iterations": [float(e[1].item()) for e in each],
+               "merge_epoch": {"ms": res["merge_epoch_ms"]["median"], "min_ms": res["merge_epoch_ms"]["min"], "max_ms": res["merge_epoch_ms"]["max"],
+                               "n": res["merge_epoch_ms"]["n"], "inside_timed_region": True},
+               "rccl_ranks": res.get("rccl_ranks"), "communicator": res.get("communicator"), "rank0": res}
         if rank == 0:
             sys.stdout.flush()
             os.write(real_stdout, (json.dumps(out) + "\n").encode())
