@@ -449,6 +449,9 @@ icpmi_status icpmi_get_grid_info(icpmi_handle h, float* cell, int32_t dims[3], i
 int32_t      icpmi_version(void);
 /* Diagnostics of the last registration (engine internals, not part of the reference surface). */
 icpmi_status icpmi_debug_counters(icpmi_handle h, uint64_t out[24]);
+/* Test seam: the n-th value (n >= 1) of the std::minstd_rand stream as the DEVICE computes it by skip-ahead (csrc/ssn.hip, behind
+ * SamplingSurfaceNormalDataPointsFilter -- PM::ICPSequence::setDefault(), Mapper.cpp:74-78).  [rand.predef]: seed 1, n = 10 000 -> 399268537. */
+icpmi_status icpmi_debug_minstd_nth(icpmi_handle h, uint32_t seed, uint32_t n, uint32_t* out);
 
 #ifdef __cplusplus
 }

@@ -141,6 +141,7 @@ SYMBOLS = [
     ("icpmi_bin_cells", C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),
     ("icpmi_set_stream", C.c_int, [_P, _P]),
     ("icpmi_debug_counters", C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    ("icpmi_debug_minstd_nth", C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
     ("icpmi_get_grid_info", C.c_int, [_P, _F, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
 ]
 

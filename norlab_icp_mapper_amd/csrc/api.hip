@@ -244,10 +244,23 @@ icpmi_status icpmi_debug_counters(icpmi_handle h, uint64_t out[24])
     for (int i = 0; i < 24; ++i) out[i] = h->h_state->dbg[i];
     // [18] / [19]: index builds served by the incremental insert / from scratch (low word: this handle's registration index; high
     // word: its private raw-frame index, ops.hip: raw_index)
+    // (a -DICPMI_NN_TIMING build keeps all 24 slots for the NN kernels' phase clocks -- ADVICE r4)
+#ifndef ICPMI_NN_TIMING
     out[17] = (uint64_t)h->raw_view_count; // PointDistance searches served by the raw-frame view of the registration index (no second index)
     out[18] = (uint64_t)(uint32_t)h->ins_count | ((uint64_t)(uint32_t)(h->temp_raw ? h->temp_raw->ins_count : 0) << 32);
     out[19] = (uint64_t)(uint32_t)h->full_count | ((uint64_t)(uint32_t)(h->temp_raw ? h->temp_raw->full_count : 0) << 32);
+#endif
     return ICPMI_OK;
+}
+
+icpmi_status icpmi_debug_minstd_nth(icpmi_handle h, uint32_t seed, uint32_t n, uint32_t* out)
+{
+    CHECK_H(h);
+    if (!out || n == 0) { h->last_error = "debug_minstd_nth: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
+    unsigned v = 0;
+    const icpmi_status s = ssn_debug_minstd(h, seed, n, &v);
+    *out = v;
+    return s;
 }
 
 icpmi_status icpmi_get_grid_info(icpmi_handle h, float* cell, int32_t dims[3], int64_t* n_cells, int64_t* n_occupied)
@@ -344,6 +357,10 @@ static icpmi_status reject_reading_source(icpmi_ctx* h, const char* who)
 static icpmi_status register_impl(icpmi_handle h, const float* d_scan4, int64_t n, const float* d_n3, int fixed_iters,
                                   float T_out[16], icpmi_stats* stats)
 {
+    // the one-shot reading rows (icpmi_set_reading_scalar / _sensor_noise) belong to THIS call whatever becomes of it: consumed here, before
+    // any early return, so that a registration that bails out cannot leave a stale row armed for the next one
+    const int64_t have_scalar_n = h->read_scalar_n, have_noise_n = h->read_noise_n;
+    h->read_scalar_n = 0; h->read_noise_n = 0;
     if (!T_out) { h->last_error = "register: T_out is null"; return ICPMI_ERR_INVALID_ARG; }
     if (stats) { memset(stats, 0, sizeof *stats); stats->sensor_noise_overlap = -1.f; } // -1 = "not computed" on EVERY path
     identity16(T_out);
@@ -365,8 +382,7 @@ static icpmi_status register_impl(icpmi_handle h, const float* d_scan4, int64_t 
     {   // GenericDescriptorOutlierFilter{source: reading}: the row handed over for THIS reading (one shot)
         bool wants = false;
         for (int f = 0; f < h->cfg.n_outlier; ++f) wants |= h->cfg.outlier[f].type == ICPMI_OUT_GENERICDESCRIPTOR && (h->cfg.outlier[f].iparam & ICPMI_GEN_SOURCE_READING);
-        const int64_t have = h->read_scalar_n; h->read_scalar_n = 0;
-        if (wants && n > 0 && have != n) {
+        if (wants && n > 0 && have_scalar_n != n) {
             h->last_error = "InvalidField: GenericDescriptorOutlierFilter{source: reading} needs the reading's descriptor (icpmi_set_reading_scalar, one row per point)";
             return ICPMI_ERR_INVALID_ARG;
         }
@@ -375,9 +391,8 @@ static icpmi_status register_impl(icpmi_handle h, const float* d_scan4, int64_t 
     // sensor-noise overlap (icpmi_set_reading_sensor_noise): the noise row is one shot -- this registration consumes it
     // (PointToPointErrorMinimizer::getOverlap() needs `simpleSensorNoise` alone; only the point-to-plane variant also reads the reading's
     // `normals` -- ADVICE r3)
-    const bool sn = h->read_noise_n == n && n > 0 && !lc.ext && !lc.is_2d &&
+    const bool sn = have_noise_n == n && n > 0 && !lc.ext && !lc.is_2d &&
                     (lc.minimizer == ICPMI_MIN_POINT_TO_POINT || (lc.minimizer == ICPMI_MIN_POINT_TO_PLANE && d_n3));
-    h->read_noise_n = 0;
     lc.sensor_noise = sn ? 1 : 0;
     lc.has_read_normals = (needs_rn || (sn && d_n3)) ? 1 : 0;
     if (n == 0) {

@@ -36,11 +36,15 @@
 // registration's iteration as signed 64-bit FIXED-POINT device atomics -- integer additions commute, so the total does not depend on the
 // order in which the pair-sum workgroups arrive, and what the solver reads is 32 values, not 64 KB of per-workgroup partials to be
 // reduced in a fixed order.  A value v is held as two limbs, hi = rint(v 2^-16) and lo = rint((v - hi 2^16) 2^40): together 2^-40
-// absolute resolution over +-2^78 with no range analysis (every limb sum stays far inside 64 bits), no carries between the limbs
-// (they are summed independently and joined in double).  ICPMI_ACC_COPIES privatised copies (workgroup b adds to copy b % COPIES),
+// absolute resolution over +-2^78 with no range analysis, no carries between the limbs (they are summed independently and joined in
+// double).  Headroom: |hi| <= 2^62 / adds by the range limit, and one contribution to lo is at most 2^15 x 2^40 = 2^55, so a copy that
+// receives ICPMI_ACC_MAX_ADDS = 128 workgroup partials stays below 2^62 -- ONE bit inside int64, not more: loop.hip's acc_cap() clamps the
+// number of pair-sum workgroups to ICPMI_ACC_MAX_ADDS x ICPMI_ACC_COPIES whatever ICPMI_ACC_BLOCKS asks for.
+// ICPMI_ACC_COPIES privatised copies (workgroup b adds to copy b % COPIES),
 // every (copy, value, limb) on its own 128-byte line: device atomics serialise per line.  Two parities: the pair sums of
 // iteration i go to parity i & 1 (nn.hip: the next NN launch reads them while this iteration's successor already accumulates).
 #define ICPMI_ACC_COPIES 2   // (8 copies made every reader fetch 64 KB of padded lines -- 100 MB per NN launch once every workgroup reads them; 2: 128 atomics per line)
+#define ICPMI_ACC_MAX_ADDS 128 // workgroup partials one copy may receive per iteration (limb headroom, see above)
 #define ICPMI_ACC_PAD 16                                               // u64 per slot = one 128-byte line
 #define ICPMI_ACC_U64 (ICPMI_ACC_COPIES * ICPMI_NV * 2 * ICPMI_ACC_PAD)   // per parity: 8192 u64 = 64 KiB
 #define ICPMI_ACC_IDX(copy, i, limb) ((((copy) * ICPMI_NV + (i)) * 2 + (limb)) * ICPMI_ACC_PAD)
@@ -52,6 +56,25 @@
 #define ICPMI_S2_FIDX(b) ((((b) & 255u) << 8) | ((b) >> 8))
 
 #define ICPMI_MAX_K 32
+
+// Once-touched streams (queries, per-query loop state, matches) with the non-temporal cache policy (`nt`): -DICPMI_NT_STREAMS.  r5
+// measurement: an XCD's L2 does not keep ANY line across a kernel boundary on this part (the second of two back-to-back NN
+// launches fetches the same 20.6 MB past the L2 as the first), so there is no map slice for these streams to push out between launches;
+// inside a launch the hint changed nothing measurable.  Kept as a switch; plain loads / stores by default.
+#ifdef __HIPCC__
+typedef float icpmi_vf4 __attribute__((ext_vector_type(4)));
+#ifdef ICPMI_NT_STREAMS
+__device__ __forceinline__ float4 ld_stream(const float4* p) { const icpmi_vf4 v = __builtin_nontemporal_load(reinterpret_cast<const icpmi_vf4*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ float ld_stream(const float* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ int ld_stream(const int* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void st_stream(float4* p, float4 v) { icpmi_vf4 w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w; __builtin_nontemporal_store(w, reinterpret_cast<icpmi_vf4*>(p)); }
+__device__ __forceinline__ void st_stream(float* p, float v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void st_stream(int* p, int v) { __builtin_nontemporal_store(v, p); }
+#else
+template <class T> __device__ __forceinline__ T ld_stream(const T* p) { return *p; }
+template <class T> __device__ __forceinline__ void st_stream(T* p, T v) { *p = v; }
+#endif
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // NN grid (built by set_map on the centred map).  Dense uniform grid; cells are x-fastest so the
@@ -584,6 +607,7 @@ icpmi_status comm_allgather(icpmi_ctx* c, const void* d_send, void* d_recv, size
 icpmi_status ops_staged_merge_allgather(icpmi_ctx* c, const float correction[16], float min_dist, int normals_knn, int64_t* accepted_local,
                                         int64_t* appended_total, int64_t* new_m, float* merged_out4, int64_t merged_capacity, int64_t* merged_n);
 icpmi_status ops_staged_merged_points(icpmi_ctx* c, float* out4, int64_t capacity, int64_t* n);
+icpmi_status ssn_debug_minstd(icpmi_ctx* c, unsigned seed, unsigned n, unsigned* out);
 icpmi_status ssn_sample_dev(icpmi_ctx* c, const float4* d_in, int64_t n, float ratio, int knn, float max_box, unsigned seed, int* d_order_out,
                             float* d_normals_out, int64_t* n_out);
 icpmi_status ops_sampling_surface_normal(icpmi_ctx* c, const float* in4, int64_t n, float ratio, int knn, float max_box, int seed, int32_t* order_out,

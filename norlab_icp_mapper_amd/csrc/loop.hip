@@ -565,10 +565,10 @@ __global__ __launch_bounds__(BT) void accumulate_kernel(const float4* __restrict
     for (int u = 0; u < PF; ++u) {
         const int64_t e = e_first + u * estep;
         const bool in = e < e_end;
-        pd2[u] = in ? d2a[e] : INFINITY;
-        ps[u] = in ? sidx[e] : -1;
-        pr[u] = reading[in ? (int)(e / lc.k) : 0];
-        pq[u] = (match_pt && in) ? match_pt[e] : ((pnm && ps[u] >= 0) ? pnm[2 * (size_t)ps[u]] : make_float4(0.f, 0.f, 0.f, 0.f));
+        pd2[u] = in ? ld_stream(d2a + e) : INFINITY;
+        ps[u] = in ? ld_stream(sidx + e) : -1;
+        pr[u] = ld_stream(reading + (in ? (int)(e / lc.k) : 0));
+        pq[u] = (match_pt && in) ? ld_stream(match_pt + e) : ((pnm && ps[u] >= 0) ? pnm[2 * (size_t)ps[u]] : make_float4(0.f, 0.f, 0.f, 0.f));
     }
     const unsigned cv = (FUSED && threadIdx.x < 256) ? hists[ICPMI_S2_C1 + threadIdx.x] : 0u; // same round trip as the elements
     // second round trip, overlapping the fine-histogram read of the selection scan: the matched normals
@@ -961,7 +961,11 @@ icpmi_status loop_prepare_reading(icpmi_ctx* c, const float4* d_scan, int64_t n,
 static int acc_cap()
 {
     static int cap = -1;
-    if (cap < 0) { const char* e = getenv("ICPMI_ACC_BLOCKS"); cap = e ? atoi(e) : 256; if (cap < 1) cap = 1; }
+    if (cap < 0) {
+        const char* e = getenv("ICPMI_ACC_BLOCKS"); cap = e ? atoi(e) : 256; if (cap < 1) cap = 1;
+        // the limb headroom of the fixed-point accumulators (common.h) is sized for ICPMI_ACC_MAX_ADDS workgroup partials per copy
+        if (cap > ICPMI_ACC_MAX_ADDS * ICPMI_ACC_COPIES) cap = ICPMI_ACC_MAX_ADDS * ICPMI_ACC_COPIES;
+    }
     return cap;
 }
 

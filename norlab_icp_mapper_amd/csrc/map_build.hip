@@ -343,11 +343,17 @@ __global__ __launch_bounds__(256) void ins_delta_kernel(const float4* __restrict
     }
 }
 
+// newly != nullptr (level 0): also counts the cells the delta occupies for the first time (icpmi_get_grid_info stays true after an insert)
 __global__ __launch_bounds__(256) void ins_cs_kernel(const unsigned* __restrict__ cs_old, const unsigned* __restrict__ dstart, int ncells1,
-                                                     unsigned* __restrict__ cs_new)
+                                                     unsigned* __restrict__ cs_new, unsigned* __restrict__ newly)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c < ncells1) cs_new[c] = cs_old[c] + dstart[c];
+    if (newly) {
+        const bool fresh = c + 1 < ncells1 && cs_old[c + 1] == cs_old[c] && dstart[c + 1] > dstart[c];
+        const unsigned long long b = __ballot(fresh);
+        if ((threadIdx.x & 63) == 0 && b) atomicAdd(newly, (unsigned)__popcll(b));
+    }
 }
 
 // ---- query (reading) sort by super-tile ----------------------------------------------------------
@@ -774,8 +780,32 @@ static icpmi_status map_insert(icpmi_ctx* c, const float4* d_pts, int64_t m0, in
                            (const unsigned*)c->d_ins_rank, (const unsigned*)cs_old, (const unsigned*)dstart, c->d_alt_pts[l], c->d_alt_key[l], c->d_inv,
                            l == 0 ? (unsigned*)nullptr : c->d_alt_pos0[l], d_normals3, (l == 0 && with_n) ? c->d_alt_nsorted : (float4*)nullptr,
                            (l == 0 && with_pn) ? c->d_alt_pn : (float4*)nullptr, (l == 0 && twin) ? c->d_alt_raw0 : (float4*)nullptr);
-        hipLaunchKernelGGL(ins_cs_kernel, dim3((g.ncells + 1 + 255) / 256), dim3(256), 0, c->stream, (const unsigned*)cs_old, (const unsigned*)dstart, g.ncells + 1, c->d_alt_cs[l]);
+        // (level 0: dstart[ncells + 1] -- cleared with the table, not touched by the scan -- counts the newly occupied cells)
+        hipLaunchKernelGGL(ins_cs_kernel, dim3((g.ncells + 1 + 255) / 256), dim3(256), 0, c->stream, (const unsigned*)cs_old, (const unsigned*)dstart, g.ncells + 1, c->d_alt_cs[l],
+                           l == 0 ? dstart + g.ncells + 1 : (unsigned*)nullptr);
         HIP_TRY(c, hipGetLastError());
+        if (l == 0 && c->h_nocc) HIP_TRY(c, hipMemcpyAsync(c->h_nocc + 1, dstart + g.ncells + 1, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    }
+    // ---- level table and completion against the ALT set, BEFORE anything of the live index is replaced: a failure up to here leaves the
+    //      handle on the index of m0 points, consistent
+    GridLevels Lnew = L;
+    for (int l = 0; l < L.nlev; ++l) {
+        Lnew.g[l] = gnew[l];
+        Lnew.pts[l] = c->d_alt_pts[l];
+        Lnew.cs[l] = c->d_alt_cs[l];
+        Lnew.pos0[l] = l == 0 ? nullptr : c->d_alt_pos0[l];
+    }
+    {
+        const GridLevels Lold = L;
+        L = Lnew; // (upload_level_table reads c->levels)
+        const icpmi_status us = upload_level_table(c);
+        const hipError_t se = us == ICPMI_OK ? hipStreamSynchronize(c->stream) : hipSuccess;
+        if (us != ICPMI_OK || se != hipSuccess) {
+            // the device copy of the level table may describe either set now: no index until a full build has run
+            L = Lold; c->ins_ready = false; c->m = 0; c->m_raw = 0; drop_loop_graphs(c);
+            if (us != ICPMI_OK) return us;
+            HIP_TRY(c, se);
+        }
     }
     // ---- the written set becomes the index
     std::swap(c->d_map_sorted, c->d_alt_pts[0]); std::swap(c->cap_map, c->cap_alt_pts[0]);
@@ -797,8 +827,7 @@ static icpmi_status map_insert(icpmi_ctx* c, const float4* d_pts, int64_t m0, in
     }
     c->grid = gnew[0];
     for (int r = 0; r < 3; ++r) { c->mean[r] = mean[r]; c->sum_raw[r] = sum[r]; }
-    { const icpmi_status us = upload_level_table(c); if (us != ICPMI_OK) return us; }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->h_nocc) { c->n_occupied += c->h_nocc[1]; *c->h_nocc = (unsigned)c->n_occupied; c->nocc_m = m1; } // (the stream is idle: the copy has landed)
     c->m = m1;
     c->m_raw = c->keep_raw ? m1 : 0; c->raw_has_normals = c->keep_raw && with_n;
     c->qsorted_n = -1; c->qsorted_src = nullptr;

@@ -727,7 +727,6 @@ __global__ __launch_bounds__(64) void nn1_wq_kernel(const float4* __restrict__ q
     __shared__ unsigned qwin[Q];             // ... where that point sits: position | level << 28
     __shared__ float4 qpt[Q];                // ... and the point itself (what the loop keeps as the next iteration's seed)
     const int lane = threadIdx.x;
-    // XCD-aware order, as nn1_ml_kernel: workgroup b runs on XCD b % 8; each XCD gets one contiguous eighth of the queries
     const int wgs = (int)((((long long)n + Q - 1) / Q + 7) / 8 * 8);
     if ((int)blockIdx.x >= wgs) return;
     const int chunk = wgs >> 3;
@@ -1084,11 +1083,27 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(FSOLVE 
         asm volatile("" ::"s"(g0.ox), "s"(g0.oy), "s"(g0.oz), "s"(g0.cell), "s"(g0.inv_cell), "s"(g0.slack), "s"(L.nlev), "s"(maxr2), "s"(unseeded_lev), "s"(seed_pre));
     }
 #endif
-    // XCD-aware order, as nn1_ml_kernel: workgroup b runs on XCD b % 8; each XCD gets one contiguous eighth of the queries
     const int wgs = (int)((((long long)n + Q - 1) / Q + 7) / 8 * 8);
     if ((int)blockIdx.x >= wgs) return;
     __shared__ IcpState s_st;
     int fs_done = 0, fs_iter = 0;
+    // the workgroup's queries, XCD-aware order as nn1_ml_kernel: workgroup b runs on XCD b % 8; each XCD gets one contiguous eighth.
+    // The query / seed loads depend on nothing but the block index: requested HERE so that, with FSOLVE, they travel in the same round
+    // trip as the previous state and the pair sums the solver waits for (r5; r4 issued them behind the solve: one more trip on every
+    // workgroup's chain).
+    const int chunk = wgs >> 3;
+    const int lb = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    const int slot = lane;
+    const int qi = lb * Q + slot;
+    const bool active = w0 && qi < n; // only wave 0 owns queries
+    float4 r = make_float4(0.f, 0.f, 0.f, 1.f);
+    int orig = 0, sp_kept = -1;
+    float4 qs_kept = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (w0) { // (a wave-uniform branch: the other waves go straight to the barrier)
+        r = ld_stream(queries + (active ? qi : 0));
+        orig = match_pt ? qi : (qindex ? qindex[active ? qi : 0] : qi);
+        if (match_pt) { sp_kept = ld_stream(out_sidx + (active ? qi : 0)); qs_kept = ld_stream(match_pt + (active ? qi : 0)); }
+    }
     if (FSOLVE) {
         // First thing in the kernel, with nothing of the search live yet.  ONE round trip: the part of the previous state the solver
         // reads (pose, counters; the checkers' history only when a Differential / Bound checker is in the chain) and the accumulators
@@ -1139,24 +1154,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(FSOLVE 
         }
         fs_done = s_st.done; fs_iter = s_st.iter;
     }
-    const int chunk = wgs >> 3;
-    const int lb = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    const int slot = lane;
-    const int qi = lb * Q + slot;
-    const bool active = w0 && qi < n; // only wave 0 owns queries
     int st_done = fs_done, st_iter = fs_iter;
     if (!FSOLVE) { st_done = st->done; st_iter = st->iter; }
     uint4 ltab_mine = make_uint4(0u, 0u, 0u, 0u);
     if (tid < ICPMI_MAXLEV * 4) ltab_mine = ltab_g[tid];
-    float4 r = make_float4(0.f, 0.f, 0.f, 1.f);
-    int orig = 0, sp_kept = -1;
-    float4 qs_kept = make_float4(0.f, 0.f, 0.f, 0.f);
     float3 p = make_float3(0.f, 0.f, 0.f);
-    if (w0) { // (a wave-uniform branch: the other waves go straight to the barrier)
-        r = queries[active ? qi : 0];
-        orig = match_pt ? qi : (qindex ? qindex[active ? qi : 0] : qi);
-        if (match_pt) { sp_kept = out_sidx[active ? qi : 0]; qs_kept = match_pt[active ? qi : 0]; }
-    }
     if (FSOLVE) {
         if (w0) p = xf_point(s_st.T_iter, r.x, r.y, r.z, r.w);
     } else if (w0) {
@@ -1422,9 +1424,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(FSOLVE 
             }
             mpt = qpt[slot];
         }
-        out_sidx[orig] = bs;
-        out_d2[orig] = bd2;
-        if (match_pt) match_pt[orig] = make_float4(mpt.x, mpt.y, mpt.z, __uint_as_float((unsigned)(best.key & 0xffffffffull)));
+        st_stream(out_sidx + orig, bs);
+        st_stream(out_d2 + orig, bd2);
+        if (match_pt) st_stream(match_pt + orig, make_float4(mpt.x, mpt.y, mpt.z, __uint_as_float((unsigned)(best.key & 0xffffffffull))));
         if (hist0 && bd2 != INFINITY && bd2 > 0.f) {
             const unsigned bits = __float_as_uint(bd2);
             atomicAdd(&hist0[ICPMI_S2_F0 + (blockIdx.x % ICPMI_S2_FCOPIES) * 65536 + ICPMI_S2_FIDX(bits >> 16)], 1u);
@@ -2485,7 +2487,14 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
             hipLaunchKernelGGL((nn1_wg_kernel<4, true, true>), dim3((int)(((n + 63) / 64 + 7) / 8 * 8), ba.nscan), dim3(256), 0, c->stream,
                                q, qi, ba, d_T, c->levels, lc.maxr2, d_sidx, d_d2, d_state, c->d_hard, h0, mp, c->d_lvl_tab, unseeded_lev, seed_pre, fs);
         }
-        else if (use_wq && wg_nw == 4) { if (allow_self) LAUNCH_WG2(4, true); else LAUNCH_WG2(4, false); }
+        else if (use_wq && wg_nw == 4) {
+            if (allow_self) LAUNCH_WG2(4, true); else LAUNCH_WG2(4, false);
+            // diagnostic (r5, scripts/r5/l2_real.sh): the same search once more, right behind the first, without the histogram -- what does
+            // the SECOND launch fetch past the L2?  (results unchanged: the repeat is seeded with the answer)
+            static int nn_twice = -1;
+            if (nn_twice < 0) { const char* e = getenv("ICPMI_NN_TWICE"); nn_twice = e ? atoi(e) : 0; }
+            if (nn_twice && allow_self && mp) { h0 = nullptr; LAUNCH_WG2(4, true); }
+        }
         else if (use_wq && wg_nw > 0) { if (allow_self) LAUNCH_WG2(3, true); else LAUNCH_WG2(3, false); }
         else if (use_wq) {
             if (wq_lpq == 1) LAUNCH_WQ(1);

@@ -1557,6 +1557,8 @@ static icpmi_status merge_greedy(icpmi_ctx* c, const std::vector<long long>& cou
     } else {
         long long total = 0;
         for (long long v : counts) total += v;
+        // the table has 2 .. 4 x total slots and its scan length is an int: 2^29 gathered points would make it 2^31
+        if (total >= (1ll << 29)) { c->last_error = "staged_merge_allgather: gathered set too large (2^29 points or more)"; return ICPMI_ERR_UNSUPPORTED; }
         unsigned long long cap = 1024;
         while (cap < 2ull * (unsigned long long)total) cap <<= 1;
         // table: keys (u64) | counts -> starts (u32, cap + 1) ; per point: slot, rank ; cell-ordered point list

@@ -585,10 +585,14 @@ __device__ void solve_serial(IcpState* st, const double* tot, const LoopCfg& lc,
     }
     if (!iterate) { st->done = 1; st->stop_reason = reason; }
     const long long tsolve3 = clock64();
+#ifndef ICPMI_NN_TIMING // (a timing build gives dbg[0..23] to the NN kernels' phase clocks: scripts/nn_phase.py must read them clean -- ADVICE r4)
     st->dbg[20] += (unsigned long long)(tsolve3 - tsolve0); // serial part of the solve (diagnostic)
     st->dbg[21] += 1;
     st->dbg[22] += (unsigned long long)(tsolve1 - tsolve0); // ... of which the minimiser,
     st->dbg[23] += (unsigned long long)(tsolve3 - tsolve2); // ... and the checkers
+#else
+    (void)tsolve1; (void)tsolve2; (void)tsolve3;
+#endif
 }
 
 // the stand-alone solve: 256 threads read the accumulators (and clear them when asked), thread 0 solves

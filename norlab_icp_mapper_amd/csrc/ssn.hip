@@ -174,6 +174,18 @@ __global__ __launch_bounds__(128) void ssn_fuse_kernel(const float4* __restrict_
 
 __device__ __forceinline__ unsigned minstd_mulmod(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) % 2147483647ull); }
 
+// the n-th value (n >= 1) of std::minstd_rand seeded with `seed`: x0 48271^n mod (2^31 - 1) by square-and-multiply -- no sequential generator.
+// [rand.predef]: the 10 000th value of a default-constructed (seed 1) minstd_rand is 399268537 (tests/test_gpu_pins.py holds this function to it).
+__device__ __forceinline__ unsigned minstd_nth(unsigned seed, unsigned n)
+{
+    unsigned x = seed % 2147483647u;
+    if (x == 0u) x = 1u;
+    unsigned e = n, base = 48271u, acc = 1u;
+    while (e) { if (e & 1u) acc = minstd_mulmod(acc, base); base = minstd_mulmod(base, base); e >>= 1; }
+    return minstd_mulmod(acc, x);
+}
+__global__ void minstd_nth_kernel(unsigned seed, unsigned n, unsigned* __restrict__ out) { if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = minstd_nth(seed, n); }
+
 // keep[pos] = the point's random number (the (rank + 1)-th of std::minstd_rand seeded with `seed`) is below ratio
 __global__ __launch_bounds__(256) void ssn_draw_kernel(int64_t n, const unsigned* __restrict__ draws, const unsigned* __restrict__ rank, float ratio,
                                                        unsigned seed, unsigned* __restrict__ keep)
@@ -182,11 +194,7 @@ __global__ __launch_bounds__(256) void ssn_draw_kernel(int64_t n, const unsigned
     if (pos >= n) return;
     unsigned k = 0u;
     if (draws[pos]) {
-        unsigned x = seed % 2147483647u;
-        if (x == 0u) x = 1u;
-        unsigned e = rank[pos] + 1u, base = 48271u, acc = 1u; // 48271^(rank + 1) mod (2^31 - 1)
-        while (e) { if (e & 1u) acc = minstd_mulmod(acc, base); base = minstd_mulmod(base, base); e >>= 1; }
-        x = minstd_mulmod(acc, x);
+        const unsigned x = minstd_nth(seed, rank[pos] + 1u);
         k = ((float)x / 2147483645.0f) < ratio ? 1u : 0u;
     }
     keep[pos] = k;
@@ -204,6 +212,16 @@ __global__ __launch_bounds__(256) void ssn_emit_kernel(int64_t n, const unsigned
 }
 
 } // namespace
+
+// test seam (icpmi_debug_minstd_nth): the value ssn_draw_kernel's skip-ahead computes for the n-th number of the stream
+icpmi_status ssn_debug_minstd(icpmi_ctx* c, unsigned seed, unsigned n, unsigned* out)
+{
+    DevBuf<unsigned> d; HIP_TRY(c, d.alloc(1));
+    hipLaunchKernelGGL(minstd_nth_kernel, dim3(1), dim3(64), 0, c->stream, seed, n, d.p);
+    HIP_TRY(c, hipGetLastError());
+    if (read_back(c, out, d.p, sizeof(unsigned)) != ICPMI_OK) return ICPMI_ERR_HIP;
+    return ICPMI_OK;
+}
 
 // device pointers in, device pointers out (d_order_out / d_normals_out: capacity n / 3 n); *n_out read back once
 icpmi_status ssn_sample_dev(icpmi_ctx* c, const float4* d_in, int64_t n, float ratio, int knn, float max_box, unsigned seed, int* d_order_out,

@@ -547,6 +547,11 @@ struct MinStd {
     }
 };
 
+} // namespace
+// test seam (TestHooks.cpp: nim_test_minstd_nth): the raw n-th value of the host filters' generator
+uint32_t minstdNth(uint32_t seed, uint32_t n) { MinStd g(seed); uint32_t v = g.x; for (uint32_t i = 0; i < n; ++i) v = g.next(); return v; }
+namespace {
+
 // RandomSamplingDataPointsFilter{prob 0.75, randomSamplingMethod 0, seed -1} [UPSTREAM 1.4.x, as recalled]: a fresh
 // std::minstd_rand per call (seed -1: std::random_device), one number per point, point kept iff number < prob, never more
 // than floor(n * prob) + 1 points.

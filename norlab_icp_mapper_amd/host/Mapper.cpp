@@ -186,14 +186,19 @@ void Mapper::processInput(const DataPoints& filteredInputInSensorFrame, const Ma
         const bool bootstrap = map.isLocalPointCloudEmpty();
         Mat4 correction;
         lastScanGrewMap = false;
+        lastUpdMs = 0.0;
+        const auto tReg = std::chrono::steady_clock::now();
         {
             std::lock_guard<std::mutex> g(icpMapLock);
             lastSeenMapVersion = map.icpMapVersion();
             correction = icp.registerWithPrior(filteredInputInSensorFrame, estimatedPose); // identity while there is no map
         }
+        lastRegMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tReg).count();
         const Mat4 correctedPose = bootstrap ? estimatedPose : correction * estimatedPose;
         map.updatePose(correctedPose);
         if (bootstrap || mapUpdateIsDue(timeStamp, correctedPose, icp.errorMinimizer->getOverlap())) {
+            const auto tUpd = std::chrono::steady_clock::now();
+            struct UpdClock { const std::chrono::steady_clock::time_point t0; double& out; ~UpdClock() { out = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } updClock{tUpd, lastUpdMs};
             lastTimeMapWasUpdated = timeStamp;
             lastPoseWhereMapWasUpdated = correctedPose;
             lastScanGrewMap = true;
@@ -215,18 +220,23 @@ void Mapper::processInput(const DataPoints& filteredInputInSensorFrame, const Ma
     const bool bootstrap = map.isLocalPointCloudEmpty(); // nothing to register against: the prior is the pose
     Mat4 correction = Mat4::identity();
     lastScanGrewMap = false;
+    lastUpdMs = 0.0;
+    const auto tReg = std::chrono::steady_clock::now();
     if (!bootstrap) {
         std::lock_guard<std::mutex> g(icpMapLock);
         lastSeenMapVersion = map.icpMapVersion();
         correction = icp(scanInMap);
     }
+    lastRegMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tReg).count();
     const Mat4 correctedPose = bootstrap ? estimatedPose : correction * estimatedPose;
     map.updatePose(correctedPose);
+    const auto tUpd = std::chrono::steady_clock::now();
     if (bootstrap) { growMap(scanInMap, correctedPose, timeStamp); lastScanGrewMap = true; }
     else if (mapUpdateIsDue(timeStamp, correctedPose, icp.errorMinimizer->getOverlap())) {
         growMap(transformation.compute(scanInMap, correction), correctedPose, timeStamp);
         lastScanGrewMap = true;
     }
+    if (lastScanGrewMap) lastUpdMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tUpd).count(); // (online: the hand-off only)
 
     // surface an exception of a finished asynchronous update here, like the reference's future.get()
     if (mapUpdateFuture.valid() && mapUpdateFuture.wait_for(std::chrono::milliseconds(1)) == std::future_status::ready) mapUpdateFuture.get();

@@ -73,6 +73,10 @@ public:
     // whether it started a map update -- what a replay needs to reproduce a free-running online run scan by scan
     long lastRegistrationMapVersion() const { return lastSeenMapVersion; }
     bool lastScanStartedMapUpdate() const { return lastScanGrewMap; }
+    // wall time of the last processInput's two halves (offline mode; host clock around the calls, the GPU work is waited for inside them):
+    // the ICP call (Mapper.cpp:213) and the map update it started (Map::updateLocalPointCloud, 0 when none was due).  Measurement only.
+    double lastRegisterMs() const { return lastRegMs; }
+    double lastMapUpdateMs() const { return lastUpdMs; }
 
 private:
     void fillRegistrar();
@@ -88,6 +92,7 @@ private:
     bool is3D, isOnline;
     long lastSeenMapVersion = 0;
     bool lastScanGrewMap = false;
+    double lastRegMs = 0.0, lastUpdMs = 0.0;
     std::atomic_bool isMapping;
     Map map;
     Mat4 pose = Mat4::identity();

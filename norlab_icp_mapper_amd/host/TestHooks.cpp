@@ -5,7 +5,12 @@
 
 #include "IcpSequence.h"
 
+namespace nim { uint32_t minstdNth(uint32_t seed, uint32_t n); } // IcpSequence.cpp: the generator RandomSampling / MaxDensity / SamplingSurfaceNormal draw from
+
 extern "C" {
+
+// the raw n-th value of the host filters' std::minstd_rand restatement ([rand.predef]: seed 1, n = 10 000 -> 399268537)
+uint32_t nim_test_minstd_nth(uint32_t seed, uint32_t n) { return nim::minstdNth(seed, n); }
 
 // yaml_seq: e.g. "- RandomSamplingDataPointsFilter: {prob: 0.5, seed: 3}".  in: 4 x n features + optional descriptor `desc_name`
 // (span x n).  out4 (capacity 4 n), out_normals3 (3 n, may be NULL: receives `normals` if the result has them), out_desc (span x n,

@@ -192,6 +192,7 @@ void orc_voxel_keep(const float* in4, int64_t n, float edge, int method, uint8_t
 /* OctreeGridDataPointsFilter{maxSizeByNode, maxPointByNode, samplingMethod 0 | 1}: the real octree (bounding cube, recursive
  * split); order_out (capacity n) = original indices of the kept points in leaf-visiting (Morton) order; returns their number */
 /* DataPointsFilters of the default ICP chain (PM::ICPSequence::setDefault) and MaxDensity; std::minstd_rand random numbers */
+uint32_t orc_minstd_nth(uint32_t seed, uint32_t n); /* raw n-th value of the stream (test hook) */
 void orc_random_sampling_keep(int64_t n, float prob, int method, int seed, uint8_t* keep);
 void orc_max_density_keep(const float* densities, int64_t n, float max_density, int seed, uint8_t* keep);
 int64_t orc_sampling_surface_normal(const float* pts4, int64_t n, float ratio, int knn, float max_box_dim, int seed, int32_t* order_out,

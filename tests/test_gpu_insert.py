@@ -96,3 +96,56 @@ def test_point_distance_updates_use_the_grown_raw_index(amd, oracle, mid_scene):
     b = builds(icp)
     # the registration index grew by inserts; the raw-frame searches ran on its raw twin (a view: no second index was built at all)
     assert b["ins"] >= 2 and b["raw_view"] >= 3 and b["raw_full"] == 0, b
+
+
+def test_two_hundred_appends_stay_bit_equal_to_a_fresh_build(amd, mid_scene):
+    """VERDICT r4 (weak 11): the incremental centroid is `(sum_raw + sum(delta)) / m1` carried in double from insert to insert, a fresh build
+    sums per-block partials in another order, and the level-0 cell edge stays tuned to the density of the FIRST build.  200 small appends in a
+    row, all served by the insert; after appends 1, 10, 50 and 200 the index must still answer like a fresh build of the concatenated cloud:
+    same centroid float, kNN ids / d^2 bit for bit (k = 1 and 6, radius and unbounded), same registration.  The occupied-cell count of
+    icpmi_get_grid_info follows the growth and agrees with a recount of the resident cloud on the handle's own grid."""
+    sc = mid_scene
+    rng = np.random.default_rng(21)
+    m = sc["map"].shape[0]
+    nbase = m * 6 // 10
+    kw = dict(minimizer=1, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=10)
+    grow = amd.ICPSequence(**kw)
+    assert grow.setMap(sc["map"][:nbase].copy())
+    occ0 = grow.gridInfo()["n_occupied"]
+    rest = sc["map"][nbase:]
+    per = rest.shape[0] // 200
+    cur = [sc["map"][:nbase]]
+    last_occ = occ0
+    for step in range(1, 201):
+        delta = rest[(step - 1) * per: step * per].copy()
+        app, new_m = grow.mapUpdatePointDistance(delta, 0.0, normals_knn=0)
+        cur.append(delta)
+        assert app == per and new_m == nbase + step * per
+        b = builds(grow)
+        assert b["ins"] == step and b["full"] == 1, (step, b)          # every append went through the insert
+        gi = grow.gridInfo()
+        assert last_occ <= gi["n_occupied"] <= gi["n_cells"]
+        last_occ = gi["n_occupied"]
+        if step in (1, 10, 50, 200):
+            cloud = np.concatenate(cur)
+            fresh = amd.ICPSequence(**kw)
+            assert fresh.setMap(cloud)
+            assert np.array_equal(grow.getMapMean(), fresh.getMapMean()), step
+            q = queries(rng, cloud, 3000)
+            q[:, :3] -= fresh.getMapMean()
+            for k, r in ((1, 2.0), (1, np.inf), (6, np.inf), (6, 0.7)):
+                ia, da = grow.knn(q, k=k, max_dist=r)
+                ib, db = fresh.knn(q, k=k, max_dist=r)
+                assert np.array_equal(ia, ib) and np.array_equal(da, db), (step, k, r)
+            assert np.array_equal(grow(sc["scan"]), fresh(sc["scan"])), step
+    assert last_occ > occ0                                             # 80 k new points do occupy new cells
+    # recount on the handle's own grid (box of the first build, moved with the centroid; overhanging points clamp into border cells); the
+    # arithmetic at cell walls is the kernel's, not numpy's: 1 % tolerance
+    gi = grow.gridInfo()
+    mean = grow.getMapMean().astype(np.float32)
+    cloud = np.concatenate(cur)[:, :3]
+    o = sc["map"][:nbase, :3].min(0) - mean
+    idx = np.floor((cloud - mean - o) / np.float32(gi["cell"])).astype(np.int64)
+    idx = np.clip(idx, 0, np.array(gi["dims"]) - 1)
+    recount = np.unique(idx[:, 0] + gi["dims"][0] * (idx[:, 1] + gi["dims"][1] * idx[:, 2])).shape[0]
+    assert abs(recount - gi["n_occupied"]) <= 0.01 * recount, (recount, gi)
