@@ -246,6 +246,7 @@ icpmi_status icpmi_debug_counters(icpmi_handle h, uint64_t out[24])
     // word: its private raw-frame index, ops.hip: raw_index)
     // (a -DICPMI_NN_TIMING build keeps all 24 slots for the NN kernels' phase clocks -- ADVICE r4)
 #ifndef ICPMI_NN_TIMING
+    out[16] = (uint64_t)h->oct_respeculated; // octree filter calls whose speculated depth was too shallow (sorted twice; octree.hip)
     out[17] = (uint64_t)h->raw_view_count; // PointDistance searches served by the raw-frame view of the registration index (no second index)
     out[18] = (uint64_t)(uint32_t)h->ins_count | ((uint64_t)(uint32_t)(h->temp_raw ? h->temp_raw->ins_count : 0) << 32);
     out[19] = (uint64_t)(uint32_t)h->full_count | ((uint64_t)(uint32_t)(h->temp_raw ? h->temp_raw->full_count : 0) << 32);

@@ -244,7 +244,8 @@ struct icpmi_ctx {
 
     // scratch for set_map
     unsigned* d_keys = nullptr; size_t cap_keys = 0;
-    unsigned* d_fill = nullptr; size_t cap_fill = 0;
+    int oct_depth_hint = 0; long oct_respeculated = 0; // octree.hip: tree depth of the previous call on this handle (the sort runs ahead of the depth's arrival), wrong guesses
+    unsigned* d_fill = nullptr; size_t cap_fill = 0; bool fill_clean = false; // the count table of the grid builds: zero between builds while fill_clean (map_build.hip: counts_begin)
     unsigned* d_blocksums = nullptr; size_t cap_blocksums = 0;
     double* d_red = nullptr; size_t cap_red = 0;
 
@@ -403,6 +404,8 @@ struct DevBuf {
 // Small device -> host read through the pinned page: a copy into pageable memory is staged and blocks for tens of
 // microseconds, and a map update makes a dozen of them (counts after every compaction, grid statistics).
 #define ICPMI_PIN_BYTES (128 * 1024)
+#define ICPMI_PROGRESS_OCT_WORD 48  // ... and 8 words for the octree's root cube (octree.hip)
+#define ICPMI_PROGRESS_SCAN_WORD 40 // word of the host-mapped progress page (api.hip: h_progress, 64 words) that device_scan_flags_count reports into
 static inline icpmi_status read_back2(icpmi_ctx* c, void* dst0, const void* src0, size_t b0, void* dst1, const void* src1, size_t b1)
 {
     if (!c->h_pin || b0 + b1 > ICPMI_PIN_BYTES) {
@@ -554,6 +557,11 @@ struct SortHead {
 icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float* d_normals3, int64_t keep_prefix = 0);
 icpmi_status upload_level_table(icpmi_ctx* c); // c->levels -> c->d_lvl_tab (the table the NN kernels copy to LDS)
 icpmi_status device_exclusive_scan(icpmi_ctx* c, unsigned* data, int n, unsigned total);
+icpmi_status device_exclusive_scan_io(icpmi_ctx* c, const unsigned* in, unsigned* out, int n, unsigned total); // in == out allowed
+// counts[0..n) -> starts in CURSOR layout (starts[0] = 0, starts[i + 1] = start of cell i, starts[n + 1] = total; n + 2 words): a scatter takes
+// its slots with atomicAdd(&starts[key + 1], len) and leaves the plain exclusive scan behind.  zero_counts: counts[0 .. n + 1] end up zero.
+icpmi_status device_scan_flags_count(icpmi_ctx* c, const unsigned* flag, unsigned* pos, int n, int64_t* count); // pos = exclusive scan of the 0 / 1 flags, *count = how many are set (one stream wait, no copy)
+icpmi_status device_exclusive_scan_cursor(icpmi_ctx* c, unsigned* counts, unsigned* starts, int n, unsigned total, bool zero_counts);
 icpmi_status sort_queries(icpmi_ctx* c, const float4* d_pts, int64_t n);
 icpmi_status sort_queries_reserve(icpmi_ctx* c, int64_t n, int nscan = 1);
 icpmi_status sort_queries_batch(icpmi_ctx* c, const float4* d_pts, const BatchArgs& ba, const SortHead* head = nullptr); // slices of d_pts -> slices of d_qsorted / d_qindex

@@ -1181,8 +1181,32 @@ static void enqueue_finish(icpmi_ctx* c, const LoopCfg& lc, int done_iters)
                        (double*)nullptr, c->d_progress);
 }
 
+// diagnostic (r5, scripts/r5/l2_real2.sh): 64 MB of other lines through every XCD's L2 in front of an NN launch -- whatever the L2 still held
+// of the map from the previous iteration is gone; the launch's events (profile mode) do not include this kernel
+__global__ __launch_bounds__(256) void l2_thrash_kernel(const uint4* __restrict__ buf, size_t n_u4, unsigned* __restrict__ sink)
+{
+    unsigned acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_u4; i += (size_t)gridDim.x * 256) { const uint4 v = buf[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
+    if (acc == 0x12345u) sink[0] = 1;
+}
+
+// (allocated by the first loop_run, outside any stream capture; nullptr unless ICPMI_NN_FLUSH_L2 is set)
+static uint4* g_l2_thrash = nullptr;
+static const uint4* l2_thrash_buffer() { return g_l2_thrash; }
+static void l2_thrash_prepare()
+{
+    static int thrash = -1;
+    if (thrash >= 0) return;
+    const char* e = getenv("ICPMI_NN_FLUSH_L2"); thrash = e ? atoi(e) : 0;
+    if (!thrash) return;
+    const size_t bytes = (64u << 20) + 64;
+    if (hipMalloc((void**)&g_l2_thrash, bytes) != hipSuccess || hipMemset(g_l2_thrash, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) g_l2_thrash = nullptr;
+}
+
 static icpmi_status enqueue_iteration(icpmi_ctx* c, int64_t n, const LoopCfg& lc, hipEvent_t nn0, hipEvent_t nn1)
 {
+    if (const uint4* buf = l2_thrash_buffer())
+        hipLaunchKernelGGL(l2_thrash_kernel, dim3(2048), dim3(256), 0, c->stream, buf, (size_t)(64u << 20) / 16, reinterpret_cast<unsigned*>(const_cast<uint4*>(buf) + (size_t)(64u << 20) / 16));
     if (nn0) HIP_TRY(c, hipEventRecord(nn0, c->stream));
     if (c->fsolve_cur) {
         // iteration L = c->nn_iter_hint: its NN launch solves iteration L - 1 (state and accumulators of parity (L - 1) & 1) and writes
@@ -1271,6 +1295,7 @@ static icpmi_status enqueue_registration_head(icpmi_ctx* c, const float4* d_scan
 icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals3, int64_t n, const LoopCfg& lc_in, bool fixed,
                       float T_out[16], icpmi_stats* stats)
 {
+    l2_thrash_prepare();
     LoopCfg lc = lc_in;
     // all allocations up front: none may happen while the stream is capturing
     if (ensure_loop_buffers(c, n, lc.k) != ICPMI_OK) return ICPMI_ERR_HIP;

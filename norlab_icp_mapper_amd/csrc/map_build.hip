@@ -172,12 +172,80 @@ __global__ __launch_bounds__(SCAN_T) void scan_final_kernel(unsigned* __restrict
     if (blockIdx.x == 0 && threadIdx.x == 0) data[n] = total;
 }
 
+// ---- r5: the same scan in TWO kernels (n <= SCAN2_MAX_NB chunks).  The offset of a chunk is the sum of the totals of the chunks before it;
+// every workgroup of the second kernel adds those up itself (at most 8 192 words that sit in the L2) instead of waiting for a one-workgroup
+// launch that scans them: one launch (~4.5 us behind a 3 us kernel) less for each of the ~7 scans of a map update, and `in` may differ from
+// `out` (the flag -> position scans of the compactions copied their input first).  Integer sums: the result is the three-kernel scan's.
+constexpr int SCAN2_MAX_NB = 8192;
+
+__device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned t = (unsigned)__shfl_up((int)v, o, 64); if (lane >= o) v += t; }
+    return v;
+}
+// exclusive scan over the SCAN_T threads of a workgroup; sh: SCAN_T / 64 words; *total (optional): the workgroup's sum
+__device__ __forceinline__ unsigned block_exclusive_scan_fast(unsigned v, unsigned* sh, unsigned* total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned incl = wave_incl_scan_u32(v);
+    if (lane == 63) sh[wave] = incl;
+    __syncthreads();
+    unsigned base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_T / 64; ++w) { const unsigned t = sh[w]; if (w < wave) base += t; tot += t; }
+    if (total) *total = tot;
+    __syncthreads();
+    return base + incl - v;
+}
+
+__global__ __launch_bounds__(SCAN_T) void scan2_sums_kernel(const unsigned* __restrict__ in, int n, unsigned* __restrict__ sums)
+{
+    __shared__ unsigned sh[SCAN_T / 64];
+    const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_E;
+    unsigned s = 0;
+#pragma unroll
+    for (int e = 0; e < SCAN_E; ++e) if (base + e < n) s += in[base + e];
+    unsigned tot;
+    block_exclusive_scan_fast(s, sh, &tot);
+    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+// shift = 1: out[0] = 0, out[i + 1] = exclusive sum of in[0..i), out[n + 1] = total -- the layout the cursor scatters below turn into the
+// plain starts.  zero_in: in[0 .. n + 1] is left zero (the count table cleans itself for its next user: no memset in front of a build).
+// shift / zero_in need in != out.
+__global__ __launch_bounds__(SCAN_T) void scan2_final_kernel(const unsigned* __restrict__ in, unsigned* __restrict__ out, int n,
+                                                             const unsigned* __restrict__ sums, unsigned total, int shift, unsigned* __restrict__ zero_in,
+                                                             unsigned* __restrict__ sum_out = nullptr /* the sum of in[0..n): e.g. a word of host-mapped memory */)
+{
+    __shared__ unsigned sh[SCAN_T / 64];
+    const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_E;
+    unsigned v[SCAN_E], s = 0;
+#pragma unroll
+    for (int e = 0; e < SCAN_E; ++e) { v[e] = base + e < n ? in[base + e] : 0u; s += v[e]; }
+    unsigned part = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += SCAN_T) part += sums[b];
+    unsigned off;
+    block_exclusive_scan_fast(part, sh, &off);
+    unsigned wg_tot;
+    unsigned ex = block_exclusive_scan_fast(s, sh, &wg_tot) + off;
+    if (sum_out && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *sum_out = off + wg_tot;
+#pragma unroll
+    for (int e = 0; e < SCAN_E; ++e) { if (base + e < n) { out[base + e + shift] = ex; if (zero_in && v[e]) zero_in[base + e] = 0u; } ex += v[e]; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out[n + shift] = total;
+        if (shift) out[0] = 0u;
+        if (zero_in) { zero_in[n] = 0u; zero_in[n + 1] = 0u; }
+    }
+}
+
 // ---- pass 3: scatter into cell order ---------------------------------------------------------
 // Order inside a cell is whatever the atomics give; nothing downstream depends on it because every
 // nearest-neighbour comparison is on the pair (d^2, original index).
 __global__ __launch_bounds__(256) void scatter_kernel(const float4* __restrict__ pts, const float* __restrict__ normals3, int64_t m,
                                                       float mx, float my, float mz, const unsigned* __restrict__ keys,
-                                                      const unsigned* __restrict__ start, unsigned* __restrict__ fill,
+                                                      unsigned* __restrict__ cursor /* = starts + 1: cursor[key] = next free slot of cell `key` */,
                                                       float4* __restrict__ out, float4* __restrict__ out_n, int run_atomics,
                                                       unsigned* __restrict__ okey, float4* __restrict__ twin)
 {
@@ -186,14 +254,14 @@ __global__ __launch_bounds__(256) void scatter_kernel(const float4* __restrict__
     const float4 p = pts[valid ? i : 0];
     const unsigned key = keys[valid ? i : 0];
     unsigned pos;
-    if (!run_atomics) { if (!valid) return; pos = start[key] + atomicAdd(&fill[key], 1u); }
+    if (!run_atomics) { if (!valid) return; pos = atomicAdd(&cursor[key], 1u); }
     else {
         const WaveRun r = wave_run(key, valid);
         unsigned base = 0;
-        if (r.head) base = atomicAdd(&fill[key], (unsigned)r.len);
+        if (r.head) base = atomicAdd(&cursor[key], (unsigned)r.len);
         base = (unsigned)__shfl((int)base, r.head_lane, 64);
         if (!valid) return;
-        pos = start[key] + base + (unsigned)r.rank;
+        pos = base + (unsigned)r.rank;
     }
     out[pos] = make_float4(p.x - mx, p.y - my, p.z - mz, __uint_as_float((unsigned)i));
     if (out_n) out_n[pos] = make_float4(normals3[3 * i], normals3[3 * i + 1], normals3[3 * i + 2], 0.f);
@@ -229,7 +297,7 @@ __global__ __launch_bounds__(256) void pn_kernel(const float4* __restrict__ pts,
 }
 
 __global__ __launch_bounds__(256) void lvl_scatter_kernel(const float4* __restrict__ pts0, int64_t m, const unsigned* __restrict__ keys,
-                                                          const unsigned* __restrict__ start, unsigned* __restrict__ fill,
+                                                          unsigned* __restrict__ cursor /* = starts + 1 */,
                                                           float4* __restrict__ out, unsigned* __restrict__ pos0, unsigned* __restrict__ okey)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -237,7 +305,7 @@ __global__ __launch_bounds__(256) void lvl_scatter_kernel(const float4* __restri
     const unsigned key = valid ? keys[i] : 0xffffffffu;
     const WaveRun r = wave_run(key, valid);
     unsigned base = 0;
-    if (r.head) base = start[key] + atomicAdd(&fill[key], (unsigned)r.len);
+    if (r.head) base = atomicAdd(&cursor[key], (unsigned)r.len);
     base = (unsigned)__shfl((int)base, r.head_lane, 64);
     if (!valid) return;
     const unsigned pos = base + (unsigned)r.rank;
@@ -633,10 +701,96 @@ static int run_atomics_cfg()
 }
 
 // in-place exclusive scan of data[0..n) (counts -> starts); data[n] = total
-icpmi_status device_exclusive_scan(icpmi_ctx* c, unsigned* data, int n, unsigned total)
+icpmi_status device_exclusive_scan(icpmi_ctx* c, unsigned* data, int n, unsigned total) { return device_exclusive_scan_io(c, data, data, n, total); }
+
+static int scan2_enabled()
+{
+    static int two = -1;
+    if (two < 0) { const char* e = getenv("ICPMI_SCAN2"); two = e ? atoi(e) : 1; }
+    return two;
+}
+
+// The count table of a grid build -> the cell starts, in the layout a CURSOR scatter wants (r5): counts[0..n) (+ the occupancy word at
+// counts[n + 1]) -> starts[0] = 0, starts[i + 1] = start of cell i, starts[n + 1] = total.  A scatter then takes its slots with
+// atomicAdd(&starts[key + 1], len): when every point is placed, starts[i + 1] has grown to the start of cell i + 1 -- the array IS the plain
+// exclusive scan, with no second table of fill cursors to clear (r4: two memsets per grid, three to four launches).  The counts are left
+// ZERO (c->fill_clean): the next build counts into them as they are.  starts needs n + 2 words.
+icpmi_status device_exclusive_scan_cursor(icpmi_ctx* c, unsigned* counts, unsigned* starts, int n, unsigned total, bool zero_counts)
 {
     const int nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
     if (ensure_cap(c, &c->d_blocksums, &c->cap_blocksums, (size_t)nb + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (scan2_enabled() && nb <= SCAN2_MAX_NB) {
+        hipLaunchKernelGGL(scan2_sums_kernel, dim3(nb > 0 ? nb : 1), dim3(SCAN_T), 0, c->stream, (const unsigned*)counts, n, c->d_blocksums);
+        hipLaunchKernelGGL(scan2_final_kernel, dim3(nb > 0 ? nb : 1), dim3(SCAN_T), 0, c->stream, (const unsigned*)counts, starts, n, (const unsigned*)c->d_blocksums, total, 1,
+                           zero_counts ? counts : (unsigned*)nullptr);
+        HIP_TRY(c, hipGetLastError());
+        return ICPMI_OK;
+    }
+    // very large tables: the three-kernel scan on a copy, the zero word in front, the counts cleared by a memset
+    HIP_TRY(c, hipMemcpyAsync(starts + 1, counts, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(starts, 0, sizeof(unsigned), c->stream));
+    const icpmi_status s = device_exclusive_scan_io(c, starts + 1, starts + 1, n, total);
+    if (s != ICPMI_OK) return s;
+    if (zero_counts) HIP_TRY(c, hipMemsetAsync(counts, 0, ((size_t)n + 2) * sizeof(unsigned), c->stream));
+    return ICPMI_OK;
+}
+
+static icpmi_status device_scan_counts_to_cursors(icpmi_ctx* c, unsigned* counts, unsigned* starts, int n, unsigned total)
+{
+    const icpmi_status s = device_exclusive_scan_cursor(c, counts, starts, n, total, true);
+    if (s == ICPMI_OK) c->fill_clean = true;
+    return s;
+}
+
+// the handle's count table (c->d_fill), `words` zero words: cleared only when a previous user left it dirty or it was reallocated
+static icpmi_status counts_begin(icpmi_ctx* c, size_t words)
+{
+    const size_t cap_before = c->cap_fill;
+    if (ensure_cap(c, &c->d_fill, &c->cap_fill, words) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (c->cap_fill != cap_before) c->fill_clean = false; // a fresh allocation (the allocator may hand back the same address)
+    if (!c->fill_clean) HIP_TRY(c, hipMemsetAsync(c->d_fill, 0, c->cap_fill * sizeof(unsigned), c->stream));
+    c->fill_clean = false; // (about to be counted into; device_scan_counts_to_cursors hands it back clean)
+    return ICPMI_OK;
+}
+
+// out[0..n) = exclusive scan of flag[0..n) (out[n] = 0) and the NUMBER of set flags on the host: the last workgroup of the scan writes the sum
+// into host-mapped memory, the caller's wait for the stream is the read-back (r4: two copy launches into the pinned page and the same wait)
+icpmi_status device_scan_flags_count(icpmi_ctx* c, const unsigned* flag, unsigned* pos, int n, int64_t* count)
+{
+    *count = 0;
+    if (n <= 0) return ICPMI_OK;
+    const int nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    if (c->d_progress && c->h_progress && scan2_enabled() && nb <= SCAN2_MAX_NB) {
+        if (ensure_cap(c, &c->d_blocksums, &c->cap_blocksums, (size_t)nb + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+        unsigned* d_word = c->d_progress + ICPMI_PROGRESS_SCAN_WORD;
+        volatile unsigned* h_word = c->h_progress + ICPMI_PROGRESS_SCAN_WORD;
+        hipLaunchKernelGGL(scan2_sums_kernel, dim3(nb), dim3(SCAN_T), 0, c->stream, flag, n, c->d_blocksums);
+        hipLaunchKernelGGL(scan2_final_kernel, dim3(nb), dim3(SCAN_T), 0, c->stream, flag, pos, n, (const unsigned*)c->d_blocksums, 0u, 0, (unsigned*)nullptr, d_word);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        *count = (int64_t)*h_word;
+        return ICPMI_OK;
+    }
+    const icpmi_status s = device_exclusive_scan_io(c, flag, pos, n, 0u);
+    if (s != ICPMI_OK) return s;
+    unsigned lp = 0, lf = 0;
+    if (read_back2(c, &lp, pos + (n - 1), sizeof(unsigned), &lf, flag + (n - 1), sizeof(unsigned)) != ICPMI_OK) return ICPMI_ERR_HIP;
+    *count = (int64_t)lp + lf;
+    return ICPMI_OK;
+}
+
+// out[0..n) = exclusive scan of in[0..n), out[n] = total; in == out allowed
+icpmi_status device_exclusive_scan_io(icpmi_ctx* c, const unsigned* in, unsigned* data, int n, unsigned total)
+{
+    const int nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    if (ensure_cap(c, &c->d_blocksums, &c->cap_blocksums, (size_t)nb + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (scan2_enabled() && nb <= SCAN2_MAX_NB) {
+        hipLaunchKernelGGL(scan2_sums_kernel, dim3(nb > 0 ? nb : 1), dim3(SCAN_T), 0, c->stream, in, n, c->d_blocksums);
+        hipLaunchKernelGGL(scan2_final_kernel, dim3(nb > 0 ? nb : 1), dim3(SCAN_T), 0, c->stream, in, data, n, (const unsigned*)c->d_blocksums, total, 0, (unsigned*)nullptr);
+        HIP_TRY(c, hipGetLastError());
+        return ICPMI_OK;
+    }
+    if (in != data) HIP_TRY(c, hipMemcpyAsync(data, in, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToDevice, c->stream));
     hipLaunchKernelGGL(scan_sums_kernel, dim3(nb), dim3(SCAN_T), 0, c->stream, data, n, c->d_blocksums);
     hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_T), 0, c->stream, c->d_blocksums, nb);
     hipLaunchKernelGGL(scan_final_kernel, dim3(nb), dim3(SCAN_T), 0, c->stream, data, n, c->d_blocksums, total);
@@ -649,11 +803,12 @@ icpmi_status device_exclusive_scan(icpmi_ctx* c, unsigned* data, int n, unsigned
 static icpmi_status grid_count(icpmi_ctx* c, const float4* d_pts, int64_t m, const GridParams& g, unsigned* h_nocc)
 {
     if (ensure_cap(c, &c->d_cell_start, &c->cap_cells, (size_t)g.ncells + 2) != ICPMI_OK) return ICPMI_ERR_HIP;
-    HIP_TRY(c, hipMemsetAsync(c->d_cell_start, 0, ((size_t)g.ncells + 2) * sizeof(unsigned), c->stream));
-    unsigned* d_nocc = c->d_cell_start + g.ncells + 1; // spare word after start[ncells]
+    // r5: the counts go to the handle's self-cleaning count table (c->d_fill), the starts are written in full by the scan: no memset of either
+    if (counts_begin(c, (size_t)g.ncells + 2) != ICPMI_OK) return ICPMI_ERR_HIP;
+    unsigned* d_nocc = c->d_fill + g.ncells + 1; // spare word behind the counts (cleared with them)
     const int blocks = (int)((m + 255) / 256);
     hipLaunchKernelGGL(key_kernel, dim3(blocks), dim3(256), 0, c->stream, d_pts, m, c->mean[0], c->mean[1], c->mean[2], g,
-                       c->d_keys, c->d_cell_start, d_nocc, run_atomics_cfg());
+                       c->d_keys, c->d_fill, d_nocc, run_atomics_cfg());
     HIP_TRY(c, hipGetLastError());
     if (!h_nocc) { HIP_TRY(c, hipMemcpyAsync(c->h_nocc, d_nocc, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream)); return ICPMI_OK; }
     if (read_back(c, h_nocc, d_nocc, sizeof(unsigned)) != ICPMI_OK) return ICPMI_ERR_HIP;
@@ -746,6 +901,7 @@ static icpmi_status map_insert(icpmi_ctx* c, const float4* d_pts, int64_t m0, in
     if (twin && !c->d_raw0) return ICPMI_OK;
     if (ensure_cap(c, &c->d_inv, &c->cap_inv, (size_t)n + 1) != ICPMI_OK) return ICPMI_ERR_HIP; // level-0 position of every delta point
     if (ensure_cap(c, &c->d_fill, &c->cap_fill, (size_t)L.g[0].ncells + 2) != ICPMI_OK) return ICPMI_ERR_HIP;
+    c->fill_clean = false; // (used below as the delta's cell starts of the coarser levels: a full build clears it first)
     if (ensure_cap(c, &c->d_ins_dstart0, &c->cap_ins_dstart0, (size_t)L.g[0].ncells + 2) != ICPMI_OK) return ICPMI_ERR_HIP;
     if (twin && ensure_cap(c, &c->d_alt_raw0, &c->cap_alt_raw0, (size_t)m1 + 16) != ICPMI_OK) return ICPMI_ERR_HIP;
     for (int l = 0; l < L.nlev; ++l) {
@@ -943,12 +1099,10 @@ grid_chosen:
     c->grid = g;
     c->n_occupied = n_occ;
 
-    // ---- exclusive scan of the histogram ----
-    if (device_exclusive_scan(c, c->d_cell_start, g.ncells, (unsigned)m) != ICPMI_OK) return ICPMI_ERR_HIP;
+    // ---- exclusive scan of the histogram: counts (c->d_fill, left zero) -> cell starts in cursor layout ----
+    if (device_scan_counts_to_cursors(c, c->d_fill, c->d_cell_start, g.ncells, (unsigned)m) != ICPMI_OK) return ICPMI_ERR_HIP;
 
     // ---- scatter ----
-    if (ensure_cap(c, &c->d_fill, &c->cap_fill, (size_t)g.ncells) != ICPMI_OK) return ICPMI_ERR_HIP;
-    HIP_TRY(c, hipMemsetAsync(c->d_fill, 0, (size_t)g.ncells * sizeof(unsigned), c->stream));
     if (ensure_cap(c, &c->d_map_sorted, &c->cap_map, (size_t)m + 16) != ICPMI_OK) return ICPMI_ERR_HIP;
     if (d_normals3 && ensure_cap(c, &c->d_normals_sorted, &c->cap_normals, (size_t)m) != ICPMI_OK) return ICPMI_ERR_HIP;
     c->has_normals = d_normals3 != nullptr;
@@ -975,7 +1129,7 @@ grid_chosen:
     }
     c->ins_ready = false;
     hipLaunchKernelGGL(scatter_kernel, dim3(blocks), dim3(256), 0, c->stream, d_pts, d_normals3, m, c->mean[0], c->mean[1], c->mean[2],
-                       c->d_keys, c->d_cell_start, c->d_fill, c->d_map_sorted, d_normals3 ? c->d_normals_sorted : nullptr, run_atomics_cfg(),
+                       c->d_keys, c->d_cell_start + 1, c->d_map_sorted, d_normals3 ? c->d_normals_sorted : nullptr, run_atomics_cfg(),
                        want_ins ? c->d_lvl_key[0] : (unsigned*)nullptr, want_twin ? c->d_raw0 : (float4*)nullptr);
     HIP_TRY(c, hipGetLastError());
     if (d_normals3 && !c->single_level && c->keep_raw) { // (the handles of the map-side operators never run pair sums)
@@ -998,13 +1152,12 @@ grid_chosen:
         if (ensure_cap(c, &c->d_lvl_cs[l], &c->cap_lvl_cs[l], (size_t)gl.ncells + 2) != ICPMI_OK) return ICPMI_ERR_HIP;
         if (ensure_cap(c, &c->d_lvl_pts[l], &c->cap_lvl_pts[l], (size_t)m + 16) != ICPMI_OK) return ICPMI_ERR_HIP;
         if (ensure_cap(c, &c->d_lvl_pos0[l], &c->cap_lvl_pos0[l], (size_t)m) != ICPMI_OK) return ICPMI_ERR_HIP;
-        HIP_TRY(c, hipMemsetAsync(c->d_lvl_cs[l], 0, ((size_t)gl.ncells + 2) * sizeof(unsigned), c->stream));
-        HIP_TRY(c, hipMemsetAsync(c->d_fill, 0, (size_t)gl.ncells * sizeof(unsigned), c->stream)); // ncells shrinks with l
-        hipLaunchKernelGGL(lvl_key_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_map_sorted, m, gl, c->d_keys, c->d_lvl_cs[l]);
-        if (device_exclusive_scan(c, c->d_lvl_cs[l], gl.ncells, (unsigned)m) != ICPMI_OK) return ICPMI_ERR_HIP;
+        if (counts_begin(c, (size_t)gl.ncells + 2) != ICPMI_OK) return ICPMI_ERR_HIP; // (the scan of the level below left the table zero)
+        hipLaunchKernelGGL(lvl_key_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_map_sorted, m, gl, c->d_keys, c->d_fill);
+        if (device_scan_counts_to_cursors(c, c->d_fill, c->d_lvl_cs[l], gl.ncells, (unsigned)m) != ICPMI_OK) return ICPMI_ERR_HIP;
         if (want_ins && ensure_cap(c, &c->d_lvl_key[l], &c->cap_lvl_key[l], (size_t)m + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
-        hipLaunchKernelGGL(lvl_scatter_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_map_sorted, m, c->d_keys, c->d_lvl_cs[l],
-                           c->d_fill, c->d_lvl_pts[l], c->d_lvl_pos0[l], want_ins ? c->d_lvl_key[l] : (unsigned*)nullptr);
+        hipLaunchKernelGGL(lvl_scatter_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_map_sorted, m, c->d_keys, c->d_lvl_cs[l] + 1,
+                           c->d_lvl_pts[l], c->d_lvl_pos0[l], want_ins ? c->d_lvl_key[l] : (unsigned*)nullptr);
         HIP_TRY(c, hipGetLastError());
         L.g[l] = gl; L.pts[l] = c->d_lvl_pts[l]; L.cs[l] = c->d_lvl_cs[l]; L.pos0[l] = c->d_lvl_pos0[l];
         L.nlev = l + 1;

@@ -46,7 +46,8 @@ __global__ __launch_bounds__(OB) void oct_bbox_kernel(const float4* __restrict__
     if (t == 0) for (int r = 0; r < 3; ++r) { part[6 * blockIdx.x + r] = sl[r][0]; part[6 * blockIdx.x + 3 + r] = sh[r][0]; }
 }
 
-__global__ __launch_bounds__(OB) void oct_root_kernel(const float* __restrict__ part, int nb, float max_size, OctRoot* __restrict__ root)
+__global__ __launch_bounds__(OB) void oct_root_kernel(const float* __restrict__ part, int nb, float max_size, OctRoot* __restrict__ root,
+                                                      OctRoot* __restrict__ root_host /* host-mapped copy, may be null */)
 {
     __shared__ float sl[3][OB], sh[3][OB];
     const int t = threadIdx.x;
@@ -68,6 +69,7 @@ __global__ __launch_bounds__(OB) void oct_root_kernel(const float* __restrict__ 
         float rad = radius;
         while (d < 21 && !(rad * 2.f <= max_size)) { rad *= 0.5f; ++d; } // the first depth whose edge is <= maxSizeByNode
         root->cx = c[0]; root->cy = c[1]; root->cz = c[2]; root->radius = radius; root->depth = d;
+        if (root_host) { root_host->cx = c[0]; root_host->cy = c[1]; root_host->cz = c[2]; root_host->radius = radius; root_host->depth = d; }
     }
 }
 
@@ -299,29 +301,45 @@ icpmi_status octree_sample_dev(icpmi_ctx* c, const float4* d_in, int64_t n, floa
     unsigned* d_flag = scratch_get<unsigned>(c, 4, (size_t)2 * n + 4);
     if (!d_keys || !d_vals || !d_tab || !d_part || !d_flag) return ICPMI_ERR_HIP;
     OctRoot* d_root = reinterpret_cast<OctRoot*>(d_part + 6 * rb);
+    // The depth of the tree (= the number of sort passes) is a function of the bounding cube, which the host does not know.  r4 waited for
+    // it; r5 sorts with the depth of the handle's PREVIOUS call (a map that grows by a scan keeps its cube to within a factor of two
+    // almost always) and checks the real one when it waits for the leaf count anyway -- the root travels through host-mapped memory, no
+    // copy launch.  A wrong guess repeats paths + sort with the right depth (tests/test_gpu_octree.py forces one).
+    OctRoot* d_root_host = c->d_progress ? reinterpret_cast<OctRoot*>(c->d_progress + ICPMI_PROGRESS_OCT_WORD) : nullptr;
+    const volatile OctRoot* h_root = c->h_progress ? reinterpret_cast<const volatile OctRoot*>(c->h_progress + ICPMI_PROGRESS_OCT_WORD) : nullptr;
     hipLaunchKernelGGL(oct_bbox_kernel, dim3(rb), dim3(OB), 0, c->stream, d_in, n, d_part);
-    hipLaunchKernelGGL(oct_root_kernel, dim3(1), dim3(OB), 0, c->stream, (const float*)d_part, rb, max_size, d_root);
-    hipLaunchKernelGGL(oct_path_kernel, dim3(blocks), dim3(256), 0, c->stream, d_in, n, (const OctRoot*)d_root, d_keys, d_vals);
+    hipLaunchKernelGGL(oct_root_kernel, dim3(1), dim3(OB), 0, c->stream, (const float*)d_part, rb, max_size, d_root, d_root_host);
     HIP_TRY(c, hipGetLastError());
-    OctRoot root;
-    if (read_back(c, &root, d_root, sizeof root) != ICPMI_OK) return ICPMI_ERR_HIP;
-    const int bits = 3 * root.depth;
+    static int speculate = -1;
+    if (speculate < 0) { const char* e = getenv("ICPMI_OCT_SPECULATE"); speculate = e ? atoi(e) : 1; }
+    int depth = (speculate && h_root && c->oct_depth_hint > 0) ? c->oct_depth_hint : -1;
+    if (depth < 0) {
+        OctRoot root;
+        if (read_back(c, &root, d_root, sizeof root) != ICPMI_OK) return ICPMI_ERR_HIP;
+        depth = root.depth;
+    }
     unsigned long long* kb[2] = {d_keys, d_keys + n};
     unsigned* vb[2] = {d_vals, d_vals + n};
-    int cur = 0;
-    {
-        const icpmi_status ss = radix_sort_pairs(c, d_keys, d_vals, n, bits, d_tab, &cur);
-        if (ss != ICPMI_OK) return ss;
-    }
     unsigned* d_ord = d_flag + n + 2; // exclusive scan of the leaf-start flags
-    hipLaunchKernelGGL(oct_leaf_kernel, dim3(blocks), dim3(256), 0, c->stream, (const unsigned long long*)kb[cur], n, (const OctRoot*)d_root, max_pts,
-                       d_flag);
-    HIP_TRY(c, hipMemcpyAsync(d_ord, d_flag, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToDevice, c->stream));
-    icpmi_status s = device_exclusive_scan(c, d_ord, (int)n, 0u);
-    if (s != ICPMI_OK) return s;
-    unsigned last_ord = 0, last_flag = 0;
-    if (read_back2(c, &last_ord, d_ord + (n - 1), sizeof(unsigned), &last_flag, d_flag + (n - 1), sizeof(unsigned)) != ICPMI_OK) return ICPMI_ERR_HIP;
-    const int64_t leaves = (int64_t)last_ord + last_flag;
+    int cur = 0;
+    int64_t leaves = 0;
+    for (int attempt = 0;; ++attempt) {
+        hipLaunchKernelGGL(oct_path_kernel, dim3(blocks), dim3(256), 0, c->stream, d_in, n, (const OctRoot*)d_root, d_keys, d_vals);
+        HIP_TRY(c, hipGetLastError());
+        {
+            const icpmi_status ss = radix_sort_pairs(c, d_keys, d_vals, n, 3 * depth, d_tab, &cur);
+            if (ss != ICPMI_OK) return ss;
+        }
+        hipLaunchKernelGGL(oct_leaf_kernel, dim3(blocks), dim3(256), 0, c->stream, (const unsigned long long*)kb[cur], n, (const OctRoot*)d_root, max_pts,
+                           d_flag);
+        const icpmi_status s = device_scan_flags_count(c, d_flag, d_ord, (int)n, &leaves); // (waits for the stream: the root has landed too)
+        if (s != ICPMI_OK) return s;
+        const int real_depth = h_root ? h_root->depth : depth;
+        c->oct_depth_hint = real_depth;
+        if (real_depth <= depth || attempt > 0) break; // (a guess that was too deep sorted on a few zero bits more: still the order of the paths)
+        depth = real_depth; // the guess was too shallow: once more with the cube's own depth
+        ++c->oct_respeculated;
+    }
     unsigned long long* d_best = kb[cur ^ 1]; // the other key buffer is free now
     HIP_TRY(c, hipMemsetAsync(d_best, 0xff, (size_t)leaves * sizeof(unsigned long long), c->stream));
     hipLaunchKernelGGL(oct_pick_kernel, dim3(blocks), dim3(256), 0, c->stream, (const unsigned*)vb[cur], (const unsigned*)d_flag, (const unsigned*)d_ord, n,

@@ -16,26 +16,50 @@ inline double pd_limit(float min_dist) { return (double)min_dist * (double)min_d
 // squared search radius that is guaranteed to return every neighbour with d2 < limit (the smallest float >= limit)
 inline float pd_radius2(double lim) { float r = (float)lim; if ((double)r < lim) r = nextafterf(r, INFINITY); return r; }
 
-__global__ __launch_bounds__(256) void transform_kernel(const float4* __restrict__ in, int64_t n, const float* __restrict__ T,
-                                                        float4* __restrict__ out)
+// A 4 x 4 (col-major) as a kernel ARGUMENT: the matrix rides in the kernarg segment (scalar loads), no device copy of it and no upload
+// launch in front of the kernel that reads it (r5: the map-update chain uploaded four matrices per update, one copy kernel each).
+struct Mat16 { float v[16]; };
+static inline Mat16 mat16(const float T[16]) { Mat16 m; memcpy(m.v, T, sizeof m.v); return m; }
+
+__global__ __launch_bounds__(256) void transform_kernel(const float4* __restrict__ in, int64_t n, Mat16 M, float4* __restrict__ out)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    const float* T = M.v;
     const float4 p = in[i];
     const float3 o = xf_point(T, p.x, p.y, p.z, p.w);
     const float w = fmaf(T[15], p.w, fmaf(T[11], p.z, fmaf(T[7], p.y, T[3] * p.x)));
     out[i] = make_float4(o.x, o.y, o.z, w);
 }
 
-__global__ __launch_bounds__(256) void rotate3_kernel(const float* __restrict__ in3, int64_t n, const float* __restrict__ T,
-                                                      float* __restrict__ out3)
+__global__ __launch_bounds__(256) void rotate3_kernel(const float* __restrict__ in3, int64_t n, Mat16 M, float* __restrict__ out3)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    const float* T = M.v;
     const float x = in3[3 * i], y = in3[3 * i + 1], z = in3[3 * i + 2];
     out3[3 * i] = fmaf(T[8], z, fmaf(T[4], y, T[0] * x));
     out3[3 * i + 1] = fmaf(T[9], z, fmaf(T[5], y, T[1] * x));
     out3[3 * i + 2] = fmaf(T[10], z, fmaf(T[6], y, T[2] * x));
+}
+
+// RigidTransformation::compute on a whole resident cloud, in place: features by T and -- n3 != nullptr -- normals by its rotation, one
+// launch (the arithmetic of transform_kernel and rotate3_kernel, element for element)
+__global__ __launch_bounds__(256) void move_kernel(float4* __restrict__ pts, float* __restrict__ n3, int64_t n, Mat16 M)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* T = M.v;
+    const float4 p = pts[i];
+    const float3 o = xf_point(T, p.x, p.y, p.z, p.w);
+    const float w = fmaf(T[15], p.w, fmaf(T[11], p.z, fmaf(T[7], p.y, T[3] * p.x)));
+    pts[i] = make_float4(o.x, o.y, o.z, w);
+    if (n3) {
+        const float x = n3[3 * i], y = n3[3 * i + 1], z = n3[3 * i + 2];
+        n3[3 * i] = fmaf(T[8], z, fmaf(T[4], y, T[0] * x));
+        n3[3 * i + 1] = fmaf(T[9], z, fmaf(T[5], y, T[1] * x));
+        n3[3 * i + 2] = fmaf(T[10], z, fmaf(T[6], y, T[2] * x));
+    }
 }
 
 __global__ __launch_bounds__(256) void bin_kernel(const float4* __restrict__ in, int64_t n, float cell, int* __restrict__ ijk)
@@ -298,14 +322,14 @@ __device__ __forceinline__ int dyn_acell(const DynGrid& g, float a)
 }
 
 // pass 1: beams to the sensor frame + angles + cell counts
-__global__ __launch_bounds__(256) void dyn_beams_kernel(const float4* __restrict__ in, int64_t n, const float* __restrict__ T, DynGrid g,
+__global__ __launch_bounds__(256) void dyn_beams_kernel(const float4* __restrict__ in, int64_t n, Mat16 M, DynGrid g,
                                                         float4* __restrict__ beam_xyzn, float2* __restrict__ beam_ang,
                                                         unsigned* __restrict__ keys, unsigned* __restrict__ count)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float4 p = in[i];
-    const float3 o = xf_point(T, p.x, p.y, p.z, p.w);
+    const float3 o = xf_point(M.v, p.x, p.y, p.z, p.w);
     float radius, elev, azim;
     to_spherical(o.x, o.y, o.z, radius, elev, azim);
     beam_xyzn[i] = make_float4(o.x, o.y, o.z, radius);
@@ -315,29 +339,29 @@ __global__ __launch_bounds__(256) void dyn_beams_kernel(const float4* __restrict
     atomicAdd(&count[key], 1u);
 }
 
-// pass 2: counting-sort scatter; the angles travel with the beam so that a bucket is one contiguous read
-__global__ __launch_bounds__(256) void dyn_scatter_kernel(int64_t n, const unsigned* __restrict__ keys, const unsigned* __restrict__ start,
-                                                          const float2* __restrict__ beam_ang, unsigned* __restrict__ fill,
-                                                          unsigned* __restrict__ order, float2* __restrict__ sorted_ang)
+// pass 2: counting-sort scatter; a bucket entry is ONE 16-byte record {elevation, azimuth, beam index} (r5: the index used to sit in a second
+// array -- a dependent load per accepted candidate); the buckets of one elevation row are contiguous, so a row of the 3 x 3 block is one run
+__global__ __launch_bounds__(256) void dyn_scatter_kernel(int64_t n, const unsigned* __restrict__ keys, unsigned* __restrict__ cursor /* = starts + 1 */,
+                                                          const float2* __restrict__ beam_ang, float4* __restrict__ sorted_rec)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const unsigned key = keys[i];
-    const unsigned pos = start[key] + atomicAdd(&fill[key], 1u);
-    order[pos] = (unsigned)i;
-    sorted_ang[pos] = beam_ang[i];
+    const unsigned pos = atomicAdd(&cursor[key], 1u);
+    const float2 a = beam_ang[i];
+    sorted_rec[pos] = make_float4(a.x, a.y, __uint_as_float((unsigned)i), 0.f);
 }
 
 struct DynPrm { float threshold_dynamic, alpha, beta, beam_half_angle, epsilon_a, epsilon_d, sensor_max_range; };
 
 __global__ __launch_bounds__(256) void dyn_update_kernel(const float4* __restrict__ map, const float* __restrict__ normals3, int64_t m,
-                                                         const float* __restrict__ T, DynGrid g, DynPrm prm,
-                                                         const float4* __restrict__ beam_xyzn, const float2* __restrict__ sorted_ang,
-                                                         const unsigned* __restrict__ start, const unsigned* __restrict__ order,
-                                                         float* __restrict__ prob)
+                                                         Mat16 M, DynGrid g, DynPrm prm,
+                                                         const float4* __restrict__ beam_xyzn, const float4* __restrict__ sorted_rec,
+                                                         const unsigned* __restrict__ start, float* __restrict__ prob)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= m) return;
+    const float* T = M.v;
     const float eps = 0.0001f;
     const float4 mpt = map[i];
     const float3 mp = xf_point(T, mpt.x, mpt.y, mpt.z, mpt.w);
@@ -349,31 +373,45 @@ __global__ __launch_bounds__(256) void dyn_update_kernel(const float4* __restric
     const float r2 = g.cell * g.cell;
     float bd = INFINITY;
     int best = -1;
-    // own cell first: where the beams are dense (the horizon band of a ground scan) the nearest one is a fraction of a
-    // cell away, and a neighbouring cell whose nearest edge is farther than the best so far cannot hold a closer beam
-    // (nor an equally close one: the test is strict and leaves a margin for the rounding of the cell assignment)
+    // The nearest beam within 2 * beamHalfAngle = one bucket edge: it lies in the 3 x 3 block of buckets around the point's own.  The
+    // buckets (e, a - 1 .. a + 1) of one elevation row are consecutive keys: the four bounds of a row's three buckets are four consecutive
+    // words, and all twelve are requested together before anything depends on them (r4 fetched the two bounds of a bucket when it got
+    // there: nine dependent round trips before the ninth bucket's records).  Own bucket first: where the beams are dense the nearest one
+    // is a fraction of a bucket away, and a neighbour whose nearest edge is farther than the best so far cannot hold a closer beam (nor
+    // an equally close one: the test is strict and leaves a margin for the rounding of the cell assignment).  The winner is the minimum
+    // of (angular distance, beam index): independent of the visiting order.  (Scanning whole rows without the per-bucket test -- fewer
+    // branches -- looked at 3 - 5 x the records and was slower: 253 vs 225 us.)
     const float elo = (float)ce * g.cell - 1.5707963267949f, alo = (float)ca * g.cell - 3.14159265358979f;
     const float gapE[3] = {qe - elo, 0.f, elo + g.cell - qe}, gapA[3] = {qa - alo, 0.f, alo + g.cell - qa};
+    unsigned sb[3][4];
+#pragma unroll
+    for (int de = 0; de < 3; ++de) {
+        const int e = ce + de - 1;
+        const bool row = e >= 0 && e < g.ne;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            int a = ca - 1 + x;                       // bound x = start of bucket (e, ca - 1 + x)
+            a = a < 0 ? 0 : (a > g.na ? g.na : a);    // (a == na: the start of the next row's first bucket = the end of this row's last)
+            sb[de][x] = start[row ? (unsigned)(e * g.na + a) : 0u];
+        }
+    }
 #pragma unroll
     for (int c9 = 0; c9 < 9; ++c9) {
-        {
-            // visiting order: centre, then the eight neighbours
-            const int idx9 = c9 == 0 ? 4 : (c9 <= 4 ? c9 - 1 : c9);
-            const int de = idx9 / 3 - 1, da = idx9 % 3 - 1;
-            const int e = ce + de, a = ca + da;
-            if (e < 0 || e >= g.ne || a < 0 || a >= g.na) continue;
-            const float ge = fmaxf(gapE[de + 1] - 1e-5f, 0.f), ga = fmaxf(gapA[da + 1] - 1e-5f, 0.f);
-            const float dmin = ge * ge + ga * ga;
-            if (dmin > r2 || dmin > bd) continue;
-            const unsigned k = (unsigned)(e * g.na + a);
-            for (unsigned j = start[k]; j < start[k + 1]; ++j) {
-                const float2 ang = sorted_ang[j];
-                const float d0 = qe - ang.x, d1 = qa - ang.y;
-                const float d = d0 * d0 + d1 * d1;
-                if (d <= r2 && d <= bd) { // ties on the angular distance go to the smallest beam index (the bucket order is arbitrary)
-                    const int b = (int)order[j];
-                    if (d < bd || b < best) { bd = d; best = b; }
-                }
+        // visiting order: centre, then the eight neighbours
+        const int idx9 = c9 == 0 ? 4 : (c9 <= 4 ? c9 - 1 : c9);
+        const int de = idx9 / 3, da = idx9 % 3;
+        const int e = ce + de - 1, a = ca + da - 1;
+        if (e < 0 || e >= g.ne || a < 0 || a >= g.na) continue;
+        const float ge = fmaxf(gapE[de] - 1e-5f, 0.f), ga = fmaxf(gapA[da] - 1e-5f, 0.f);
+        const float dmin = ge * ge + ga * ga;
+        if (dmin > r2 || dmin > bd) continue;
+        for (unsigned j = sb[de][da]; j < sb[de][da + 1]; ++j) {
+            const float4 rec = sorted_rec[j];
+            const float d0 = qe - rec.x, d1 = qa - rec.y;
+            const float d = d0 * d0 + d1 * d1;
+            if (d <= r2 && d <= bd) { // ties on the angular distance go to the smallest beam index (the bucket order is arbitrary)
+                const int b = (int)__float_as_uint(rec.z);
+                if (d < bd || b < best) { bd = d; best = b; }
             }
         }
     }
@@ -587,9 +625,7 @@ icpmi_status ops_transform_dev(icpmi_ctx* c, const float T[16], const float4* d_
 {
     icpmi_status s = check_rigid(c, T);
     if (s != ICPMI_OK || n == 0) return s;
-    if (!c->d_T16) HIP_TRY(c, hipMalloc((void**)&c->d_T16, 16 * sizeof(float)));
-    { const icpmi_status us = upload_small(c, c->d_T16, T, 16 * sizeof(float)); if (us != ICPMI_OK) return us; }
-    hipLaunchKernelGGL(transform_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, d_in, n, c->d_T16, d_out);
+    hipLaunchKernelGGL(transform_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, d_in, n, mat16(T), d_out);
     HIP_TRY(c, hipGetLastError());
     return ICPMI_OK;
 }
@@ -600,16 +636,14 @@ icpmi_status ops_transform(icpmi_ctx* c, const float T[16], const float* in4, in
     icpmi_status cs = check_rigid(c, T);
     if (cs != ICPMI_OK) return cs;
     if (n == 0) return ICPMI_OK;
-    DevBuf<float> d_T, d_n, d_no;
+    DevBuf<float> d_n, d_no;
     DevBuf<float4> d_in, d_out;
-    HIP_TRY(c, d_T.alloc(16));
     HIP_TRY(c, d_in.alloc((size_t)n));
     HIP_TRY(c, d_out.alloc((size_t)n));
-    hipError_t e = hipMemcpyAsync(d_T, T, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_in, in4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream);
+    hipError_t e = hipMemcpyAsync(d_in, in4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream);
     const int blocks = (int)((n + 255) / 256);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(transform_kernel, dim3(blocks), dim3(256), 0, c->stream, d_in, n, d_T, d_out);
+        hipLaunchKernelGGL(transform_kernel, dim3(blocks), dim3(256), 0, c->stream, d_in, n, mat16(T), d_out);
         e = hipMemcpyAsync(out4, d_out, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, c->stream);
     }
     if (e == hipSuccess && in_n3 && out_n3) {
@@ -617,7 +651,7 @@ icpmi_status ops_transform(icpmi_ctx* c, const float T[16], const float* in4, in
         if (e == hipSuccess) e = d_no.alloc((size_t)n * 3);
         if (e == hipSuccess) e = hipMemcpyAsync(d_n, in_n3, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(rotate3_kernel, dim3(blocks), dim3(256), 0, c->stream, d_n, n, d_T, d_no);
+            hipLaunchKernelGGL(rotate3_kernel, dim3(blocks), dim3(256), 0, c->stream, d_n, n, mat16(T), d_no);
             e = hipMemcpyAsync(out_n3, d_no, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
         }
     }
@@ -791,7 +825,7 @@ icpmi_status ops_voxel_keep_first(icpmi_ctx* c, const float* in4, int64_t n, flo
 }
 
 // DynamicPointsMapperModule::inPlaceUpdateMap on DEVICE arrays (d_T = pose^-1, 16 floats in HBM); d_prob updated in place
-static icpmi_status dynpts_dev(icpmi_ctx* c, const icpmi_dynpts_params* prm, const float* d_T, const float4* d_in, int64_t n,
+static icpmi_status dynpts_dev(icpmi_ctx* c, const icpmi_dynpts_params* prm, const float T[16], const float4* d_in, int64_t n,
                                const float4* d_map, const float* d_nrm, int64_t m, float* d_prob)
 {
     if (n == 0 || m == 0) return ICPMI_OK; // "if (beams.empty()) return"
@@ -805,19 +839,19 @@ static icpmi_status dynpts_dev(icpmi_ctx* c, const icpmi_dynpts_params* prm, con
     float4* d_bx = scratch_get<float4>(c, 0, (size_t)n);
     float2* d_ba = scratch_get<float2>(c, 1, (size_t)n);
     unsigned* d_keys = scratch_get<unsigned>(c, 2, (size_t)n);
-    unsigned* d_order = scratch_get<unsigned>(c, 3, (size_t)n);
     unsigned* d_start = scratch_get<unsigned>(c, 4, (size_t)ncells + 2);
-    unsigned* d_fill = scratch_get<unsigned>(c, 5, (size_t)ncells);
-    float2* d_sa = scratch_get<float2>(c, 8, (size_t)n);
-    if (!d_bx || !d_ba || !d_keys || !d_order || !d_start || !d_fill || !d_sa) return ICPMI_ERR_HIP;
-    HIP_TRY(c, hipMemsetAsync(d_start, 0, ((size_t)ncells + 2) * sizeof(unsigned), c->stream));
-    HIP_TRY(c, hipMemsetAsync(d_fill, 0, (size_t)ncells * sizeof(unsigned), c->stream));
+    unsigned* d_cnt = scratch_get<unsigned>(c, 5, (size_t)ncells + 2);
+    float4* d_rec = scratch_get<float4>(c, 8, (size_t)n);
+    if (!d_bx || !d_ba || !d_keys || !d_start || !d_cnt || !d_rec) return ICPMI_ERR_HIP;
+    const Mat16 M = mat16(T);
+    // counts -> starts in cursor layout (map_build.hip): one table to clear, the starts are written in full by the scan
+    HIP_TRY(c, hipMemsetAsync(d_cnt, 0, ((size_t)ncells + 2) * sizeof(unsigned), c->stream));
     const int nb = (int)((n + 255) / 256), mb = (int)((m + 255) / 256);
-    hipLaunchKernelGGL(dyn_beams_kernel, dim3(nb), dim3(256), 0, c->stream, d_in, n, d_T, g, d_bx, d_ba, d_keys, d_start);
-    icpmi_status st = device_exclusive_scan(c, d_start, (int)ncells, (unsigned)n);
+    hipLaunchKernelGGL(dyn_beams_kernel, dim3(nb), dim3(256), 0, c->stream, d_in, n, M, g, d_bx, d_ba, d_keys, d_cnt);
+    icpmi_status st = device_exclusive_scan_cursor(c, d_cnt, d_start, (int)ncells, (unsigned)n, false);
     if (st == ICPMI_OK) {
-        hipLaunchKernelGGL(dyn_scatter_kernel, dim3(nb), dim3(256), 0, c->stream, n, d_keys, d_start, d_ba, d_fill, d_order, d_sa);
-        hipLaunchKernelGGL(dyn_update_kernel, dim3(mb), dim3(256), 0, c->stream, d_map, d_nrm, m, d_T, g, dp, d_bx, d_sa, d_start, d_order, d_prob);
+        hipLaunchKernelGGL(dyn_scatter_kernel, dim3(nb), dim3(256), 0, c->stream, n, d_keys, d_start + 1, d_ba, d_rec);
+        hipLaunchKernelGGL(dyn_update_kernel, dim3(mb), dim3(256), 0, c->stream, d_map, d_nrm, m, M, g, dp, (const float4*)d_bx, (const float4*)d_rec, (const unsigned*)d_start, d_prob);
     }
     if (st != ICPMI_OK) return st;
     HIP_TRY(c, hipGetLastError());
@@ -828,18 +862,16 @@ icpmi_status ops_dynamic_points_update(icpmi_ctx* c, const icpmi_dynpts_params* 
                                        const float* map4, const float* map_normals3, int64_t m, float* prob)
 {
     if (n == 0 || m == 0) return ICPMI_OK;
-    DevBuf<float> d_T, d_nrm, d_prob; DevBuf<float4> d_in, d_map;
-    HIP_TRY(c, d_T.alloc(16));
+    DevBuf<float> d_nrm, d_prob; DevBuf<float4> d_in, d_map;
     HIP_TRY(c, d_in.alloc((size_t)n));
     HIP_TRY(c, d_map.alloc((size_t)m));
     HIP_TRY(c, d_nrm.alloc((size_t)m * 3));
     HIP_TRY(c, d_prob.alloc((size_t)m));
-    HIP_TRY(c, hipMemcpyAsync(d_T, to_sensor, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(d_in, in4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(d_map, map4, (size_t)m * sizeof(float4), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(d_nrm, map_normals3, (size_t)m * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(d_prob, prob, (size_t)m * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    icpmi_status st = dynpts_dev(c, prm, d_T, d_in, n, d_map, d_nrm, m, d_prob);
+    icpmi_status st = dynpts_dev(c, prm, to_sensor, d_in, n, d_map, d_nrm, m, d_prob);
     if (st != ICPMI_OK) return st;
     HIP_TRY(c, hipMemcpyAsync(prob, d_prob, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -926,8 +958,7 @@ icpmi_status ops_map_update_dev(icpmi_ctx* c, const float4* d_scan, int64_t n, c
             }
         }
         if (s == ICPMI_OK && e == hipSuccess) {
-            e = hipMemcpyAsync(d_pos, d_flag, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToDevice, c->stream);
-            if (e == hipSuccess) s = device_exclusive_scan(c, d_pos, (int)n, 0u);
+            s = device_exclusive_scan_io(c, d_flag, d_pos, (int)n, 0u);
         }
         if (s == ICPMI_OK && e == hipSuccess) {
             unsigned lp = 0, lf = 0;
@@ -1099,12 +1130,9 @@ icpmi_status chain_compact(Chain& w, unsigned* d_flag, unsigned* d_pos)
     icpmi_ctx* c = w.c;
     const int64_t m = w.m;
     if (m == 0) return ICPMI_OK;
-    HIP_TRY(c, hipMemcpyAsync(d_pos, d_flag, (size_t)m * sizeof(unsigned), hipMemcpyDeviceToDevice, c->stream));
-    icpmi_status s = device_exclusive_scan(c, d_pos, (int)m, 0u);
+    int64_t count = 0;
+    icpmi_status s = device_scan_flags_count(c, d_flag, d_pos, (int)m, &count);
     if (s != ICPMI_OK) return s;
-    unsigned last_pos = 0, last_flag = 0;
-    if (read_back2(c, &last_pos, d_pos + (m - 1), sizeof(unsigned), &last_flag, d_flag + (m - 1), sizeof(unsigned)) != ICPMI_OK) return ICPMI_ERR_HIP;
-    const int64_t count = (int64_t)last_pos + last_flag;
     if (count == m) return ICPMI_OK; // nothing dropped
     if (ensure_cap(c, &c->d_alt_raw, &c->cap_alt_raw, (size_t)count + 1) != ICPMI_OK || ensure_cap(c, &c->d_alt_n3, &c->cap_alt_n3, (size_t)count * 3 + 1) != ICPMI_OK ||
         ensure_cap(c, &c->d_alt_s, &c->cap_alt_s, (size_t)count + 1) != ICPMI_OK || ensure_cap(c, &c->d_alt_src, &c->cap_alt_src, (size_t)count + 1) != ICPMI_OK)
@@ -1184,9 +1212,9 @@ icpmi_status chain_point_distance_flags(icpmi_ctx* c, icpmi_ctx* ic, const float
 static icpmi_status chain_move(icpmi_ctx* c, const float T[16], int64_t m, bool has_n)
 {
     if (m == 0) return ICPMI_OK;
-    icpmi_status s = ops_transform_dev(c, T, c->d_raw, m, c->d_raw); // uploads T into d_T16
+    const icpmi_status s = check_rigid(c, T);
     if (s != ICPMI_OK) return s;
-    if (has_n) hipLaunchKernelGGL(rotate3_kernel, dim3((int)((m + 255) / 256)), dim3(256), 0, c->stream, (const float*)c->d_raw_n3, m, (const float*)c->d_T16, c->d_raw_n3);
+    hipLaunchKernelGGL(move_kernel, dim3((int)((m + 255) / 256)), dim3(256), 0, c->stream, c->d_raw, has_n ? c->d_raw_n3 : (float*)nullptr, m, mat16(T));
     HIP_TRY(c, hipGetLastError());
     return ICPMI_OK;
 }
@@ -1292,12 +1320,10 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
             }
             s = chain_point_distance_flags(c, ic, d_scan, n, op.f[0], d_flag);
             if (s != ICPMI_OK) break;
-            HIP_TRY(c, hipMemcpyAsync(d_pos, d_flag, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToDevice, c->stream));
-            s = device_exclusive_scan(c, d_pos, (int)n, 0u);
+            int64_t accepted = 0;
+            s = device_scan_flags_count(c, d_flag, d_pos, (int)n, &accepted);
             if (s != ICPMI_OK) break;
-            unsigned lp = 0, lf = 0;
-            if (read_back2(c, &lp, d_pos + (n - 1), sizeof(unsigned), &lf, d_flag + (n - 1), sizeof(unsigned)) != ICPMI_OK) return ICPMI_ERR_HIP;
-            s = chain_append(w, d_scan, d_scan_n3, d_scan_s, n, d_flag, d_pos, (int64_t)lp + lf, src_base);
+            s = chain_append(w, d_scan, d_scan_n3, d_scan_s, n, d_flag, d_pos, accepted, src_base);
             break;
         }
         case ICPMI_MOP_DYNAMIC_POINTS: {
@@ -1306,10 +1332,8 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
             if (!w.has_n) { c->last_error = "InvalidField: Missing field 'normals' in map point cloud. You can add it with the SurfaceNormalDataPointsFilter in your post filters."; s = ICPMI_ERR_MISSING_NORMALS; break; }
             s = check_rigid(c, to_sensor);
             if (s != ICPMI_OK) break;
-            if (!c->d_T16) HIP_TRY(c, hipMalloc((void**)&c->d_T16, 16 * sizeof(float)));
-            { const icpmi_status us = upload_small(c, c->d_T16, to_sensor, 16 * sizeof(float)); if (us != ICPMI_OK) return us; }
             icpmi_dynpts_params prm = {op.f[0], op.f[1], op.f[2], op.f[3], op.f[4], op.f[5], op.f[6]};
-            s = dynpts_dev(c, &prm, c->d_T16, d_scan, n, c->d_raw, c->d_raw_n3, w.m, c->d_raw_s);
+            s = dynpts_dev(c, &prm, to_sensor, d_scan, n, c->d_raw, c->d_raw_n3, w.m, c->d_raw_s);
             break;
         }
         case ICPMI_MOP_VOXEL: {
@@ -1407,8 +1431,7 @@ static icpmi_status merge_append_flagged(icpmi_ctx* c, const float4* d_in, int64
 {
     *kept = 0;
     if (n == 0) return ICPMI_OK;
-    HIP_TRY(c, hipMemcpyAsync(d_pos, d_flag, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToDevice, c->stream));
-    icpmi_status s = device_exclusive_scan(c, d_pos, (int)n, 0u);
+    icpmi_status s = device_exclusive_scan_io(c, d_flag, d_pos, (int)n, 0u);
     if (s != ICPMI_OK) return s;
     hipLaunchKernelGGL(merge_compact_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, d_in, n, (const unsigned*)d_flag, (const unsigned*)d_pos,
                        d_out, base);

@@ -272,12 +272,10 @@ icpmi_status ssn_sample_dev(icpmi_ctx* c, const float4* d_in, int64_t n, float r
     const unsigned* d_order = d_vals.p + (half ? n : 0);
     hipLaunchKernelGGL(ssn_fuse_kernel, dim3((int)((n + 127) / 128)), dim3(128), 0, c->stream, d_in, n, d_order, (const unsigned*)d_nstart.p, (const unsigned*)d_ncnt.p,
                        max_box, d_bnrm.p, d_draws.p);
-    HIP_TRY(c, hipMemcpyAsync(d_rank.p, d_draws.p, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToDevice, c->stream));
-    icpmi_status s = device_exclusive_scan(c, d_rank.p, (int)n, 0u);
+    icpmi_status s = device_exclusive_scan_io(c, d_draws.p, d_rank.p, (int)n, 0u);
     if (s != ICPMI_OK) return s;
     hipLaunchKernelGGL(ssn_draw_kernel, dim3(blocks), dim3(256), 0, c->stream, n, (const unsigned*)d_draws.p, (const unsigned*)d_rank.p, ratio, seed, d_keep.p);
-    HIP_TRY(c, hipMemcpyAsync(d_outpos.p, d_keep.p, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToDevice, c->stream));
-    s = device_exclusive_scan(c, d_outpos.p, (int)n, 0u);
+    s = device_exclusive_scan_io(c, d_keep.p, d_outpos.p, (int)n, 0u);
     if (s != ICPMI_OK) return s;
     unsigned lp = 0, lk = 0;
     if (read_back2(c, &lp, d_outpos.p + (n - 1), sizeof(unsigned), &lk, d_keep.p + (n - 1), sizeof(unsigned)) != ICPMI_OK) return ICPMI_ERR_HIP;

@@ -37,6 +37,29 @@ __global__ __launch_bounds__(256) void warm(const uint4* __restrict__ buf, unsig
     if (acc == 0x12345u) sink[0] = 1;
 }
 
+// `warm` that also WRITES: 1.5 MB per XCD of stores to another buffer + one atomic per thread (what an NN launch leaves behind: matches, histogram)
+__global__ __launch_bounds__(256) void warm_write(const uint4* __restrict__ buf, uint4* __restrict__ other, unsigned* __restrict__ hist, unsigned* __restrict__ sink)
+{
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, G = gridDim.x >> 3;
+    const uint4* s = buf + (size_t)xcd * SLICE_U4;
+    unsigned acc = 0;
+    for (size_t i = (size_t)j * 256 + threadIdx.x; i < SLICE_U4; i += (size_t)G * 256) { const uint4 v = s[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
+    constexpr size_t WU4 = (3u << 19) / 16; // 1.5 MB per XCD
+    uint4* o = other + (size_t)xcd * WU4;
+    for (size_t i = (size_t)j * 256 + threadIdx.x; i < WU4; i += (size_t)G * 256) o[i] = make_uint4((unsigned)i, acc, 2u, 3u);
+    atomicAdd(&hist[(blockIdx.x * 256 + threadIdx.x) & 65535], 1u);
+    if (acc == 0x12345u) sink[0] = 1;
+}
+// a one-workgroup launch (the solve of an iteration): does it shift the round-robin of the NEXT launch's workgroups over the XCDs?
+__global__ void one_wg(unsigned* __restrict__ sink) { if (threadIdx.x == 999) sink[1] = 1; }
+// which XCC does a workgroup run on?  (HW_REG_XCC_ID, low 4 bits)
+__global__ void xcc_of(unsigned* __restrict__ out)
+{
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    if (threadIdx.x == 0) out[blockIdx.x] = v & 15u;
+}
+
 template <bool NT>
 __global__ __launch_bounds__(256) void stream(const uint4* __restrict__ buf, size_t n_u4, unsigned* __restrict__ sink)
 {
@@ -93,8 +116,8 @@ static double median_of(unsigned long long* d_out, int n)
 int main()
 {
     const int PW = 64, STEPS = 64; // 64 probing waves (8 per XCD), 64 dependent steps each
-    uint4 *map, *other, *big; unsigned* sink; unsigned long long* out;
-    CK(hipMalloc(&map, 8 * SLICE_BYTES)); CK(hipMalloc(&other, 12u << 20)); CK(hipMalloc(&big, 1u << 30)); CK(hipMalloc(&sink, 64)); CK(hipMalloc(&out, 4096 * 8));
+    uint4 *map, *other, *big; unsigned *sink, *hist; unsigned long long* out;
+    CK(hipMalloc(&map, 8 * SLICE_BYTES)); CK(hipMalloc(&other, 12u << 20)); CK(hipMalloc(&big, 1u << 30)); CK(hipMalloc(&sink, 64)); CK(hipMalloc(&hist, 65536 * 4)); CK(hipMemset(hist, 0, 65536 * 4)); CK(hipMalloc(&out, 4096 * 8));
     CK(hipMemset(map, 0, 8 * SLICE_BYTES)); CK(hipMemset(other, 0, 12u << 20)); CK(hipMemset(big, 0, 1u << 30));
     hipStream_t s; CK(hipStreamCreate(&s));
     const unsigned* mw = reinterpret_cast<const unsigned*>(map);
@@ -117,6 +140,27 @@ int main()
         printf("12 MB streamed in between (nt)      : %6.0f\n", median_of(out, PW));
         W(); CK(hipStreamSynchronize(s)); flush(); P(0); CK(hipStreamSynchronize(s));
         printf("after 1 GiB of other traffic (HBM)  : %6.0f\n", median_of(out, PW));
+        flush(); hipLaunchKernelGGL(warm_write, dim3(8 * 64), dim3(256), 0, s, map, other, hist, sink); P(0); CK(hipStreamSynchronize(s));
+        printf("warm launch also stores 1.5 MB/XCD + atomics : %6.0f\n", median_of(out, PW));
+        flush(); W(); hipLaunchKernelGGL(one_wg, dim3(1), dim3(64), 0, s, sink); P(0); CK(hipStreamSynchronize(s));
+        printf("a one-workgroup launch in between   : %6.0f\n", median_of(out, PW));
+        flush(); W(); hipLaunchKernelGGL(one_wg, dim3(3), dim3(64), 0, s, sink); P(0); CK(hipStreamSynchronize(s));
+        printf("a three-workgroup launch in between : %6.0f\n", median_of(out, PW));
+        {
+            unsigned h[48];
+            hipLaunchKernelGGL(xcc_of, dim3(16), dim3(64), 0, s, hist); CK(hipStreamSynchronize(s));
+            CK(hipMemcpy(h, hist, 16 * 4, hipMemcpyDeviceToHost));
+            hipLaunchKernelGGL(one_wg, dim3(1), dim3(64), 0, s, sink);
+            hipLaunchKernelGGL(xcc_of, dim3(16), dim3(64), 0, s, hist + 16); CK(hipStreamSynchronize(s));
+            CK(hipMemcpy(h + 16, hist + 16, 16 * 4, hipMemcpyDeviceToHost));
+            hipLaunchKernelGGL(one_wg, dim3(3), dim3(64), 0, s, sink);
+            hipLaunchKernelGGL(xcc_of, dim3(16), dim3(64), 0, s, hist + 32); CK(hipStreamSynchronize(s));
+            CK(hipMemcpy(h + 32, hist + 32, 16 * 4, hipMemcpyDeviceToHost));
+            printf("XCC of workgroups 0..15: plain"); for (int i = 0; i < 16; ++i) printf(" %u", h[i]);
+            printf(" | behind a 1-workgroup launch"); for (int i = 0; i < 16; ++i) printf(" %u", h[16 + i]);
+            printf(" | behind a 3-workgroup launch"); for (int i = 0; i < 16; ++i) printf(" %u", h[32 + i]);
+            printf("\n");
+        }
         // the same pair as a graph
         hipGraph_t g; hipGraphExec_t ge;
         flush(); CK(hipStreamSynchronize(s));

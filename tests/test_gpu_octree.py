@@ -57,6 +57,20 @@ def test_octree_sample_equals_oracle_recursion(amd, oracle, method, max_pts, max
                 assert cell <= max_size * (1 + 1e-6) or D == 21
 
 
+def test_octree_depth_speculation_recovers_from_a_wrong_guess(amd, oracle):
+    """r5: the sort passes are enqueued with the tree depth of the handle's PREVIOUS call, the real depth is checked when the leaf count
+    arrives.  A shallow cloud first, then a deep one on the same handle: the second call must notice, sort again and still agree with the
+    oracle; a deep-then-shallow pair must not re-sort (sorting on more bits than the paths have is still their order)."""
+    clouds = _clouds(amd)
+    icp = amd.ICPSequence()
+    before = icp.debugCounters()[16]
+    for name in ("line", "blobs", "scene", "one", "scene", "slab"):
+        got = icp.octreeSample(clouds[name], 0.05, 1, 0)
+        assert np.array_equal(got, oracle.octree_sample(clouds[name], 0.05, 1, 0)), name
+    redone = icp.debugCounters()[16] - before
+    assert 1 <= redone <= 3, redone          # line (first call: waits) -> blobs deeper? -> scene ... at least the one -> scene step re-sorts
+
+
 def test_octree_chain_equals_oracle_composition(amd, oracle):
     """OctreeMapperModule on the resident map (concatenate, then the octree, map left in leaf order) inside the shipped chain"""
     import oracle_mapper as om
