@@ -273,9 +273,17 @@ def config5_stream(np, torch, pkg, dev, d_map, d_nrm, d_scans, chain, min_dist, 
     barrier()
     elapsed = time.perf_counter() - t0
     cr, cme, ckind = icp.commInfo()
+    dbg = icp.debugCounters()
+    fast_ep, slow_ep = int(dbg[14]), int(dbg[15])
     res = {"scans": len(d_scans), "elapsed_s": elapsed, "iterations": its, "register_ms": step_stats(reg_ms), "merge_epoch_ms": step_stats(ep_ms),
            "accepted_per_scan_this_rank": accepted, "appended_per_epoch_all_ranks": appended, "map_points_after": new_m,
-           "rccl_ranks": cr, "rccl_rank": cme, "communicator": {0: "none", 1: "rccl", 2: "loopback"}[ckind]}
+           "rccl_ranks": cr, "rccl_rank": cme, "communicator": {0: "none", 1: "rccl", 2: "loopback"}[ckind],
+           # r5: what one epoch costs in exchanges (csrc/ops.hip: merge_epoch_one_collective)
+           "epochs_one_collective": fast_ep, "epochs_three_collectives": slow_ep,
+           "collectives_per_epoch": (fast_ep * 1 + slow_ep * 3) / max(fast_ep + slow_ep, 1),
+           "host_waits_before_the_merge_per_epoch": (fast_ep * 1 + slow_ep * 3) / max(fast_ep + slow_ep, 1),
+           "epoch_exchange": "one ncclAllGather of fixed-size blocks {count header, <= 32768 accepted points} per scan; the R counts reach the host "
+                             "through host-mapped memory behind it (one stream wait); a block overflow falls back to count + ready + points"}
     if comm is not None:
         icp.commDestroy()
     del icp
@@ -407,7 +415,8 @@ def main():
             each = [el]
         elapsed = max(float(e[0].item()) for e in each)
         its_all = sum(float(e[1].item()) for e in each)
-        out = {"metric": "ICP iterations/sec, 100k-pt scan vs 1M-pt map", "value": its_all / elapsed, "unit": "iterations/s", "n_gpus": world,
+        out = {"metric": f"ICP iterations/sec, {world} stream(s) of {args.scan_points}-pt scans vs shared {m5}-pt map, one map-growth epoch per scan (BASELINE config 5)",
+               "value": its_all / elapsed, "unit": "iterations/s", "n_gpus": world,
                "steps": args.scans, "warmup": 1, "ms_per_step": elapsed / args.scans * 1e3, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"BASELINE config 5: {world} scan stream(s) x {args.scans} synthetic {args.scan_points}-pt scans vs the shared "

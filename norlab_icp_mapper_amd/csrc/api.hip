@@ -156,8 +156,8 @@ icpmi_status icpmi_create(const icpmi_config* cfg, icpmi_handle* out)
     CR(hipHostMalloc((void**)&c->h_pin, ICPMI_PIN_BYTES + ICPMI_UP_SLOT * ICPMI_UP_SLOTS, hipHostMallocDefault));
     CR(hipHostMalloc((void**)&c->h_nocc, 64, hipHostMallocDefault));
     *c->h_nocc = 0;
-    CR(hipHostMalloc((void**)&c->h_progress, 256, hipHostMallocMapped)); // words 0..15: progress per reading of a batch; word 32: sequence number of the registration being launched
-    memset(c->h_progress, 0, 256);
+    CR(hipHostMalloc((void**)&c->h_progress, ICPMI_PROGRESS_WORDS * sizeof(unsigned), hipHostMallocMapped)); // words 0..15: progress per reading of a batch; word 32: sequence number of the registration being launched
+    memset(c->h_progress, 0, ICPMI_PROGRESS_WORDS * sizeof(unsigned));
     CR(hipHostGetDevicePointer((void**)&c->d_progress, c->h_progress, 0));
     CR(hipEventCreate(&c->ev0));
     CR(hipEventCreate(&c->ev1));
@@ -246,6 +246,8 @@ icpmi_status icpmi_debug_counters(icpmi_handle h, uint64_t out[24])
     // word: its private raw-frame index, ops.hip: raw_index)
     // (a -DICPMI_NN_TIMING build keeps all 24 slots for the NN kernels' phase clocks -- ADVICE r4)
 #ifndef ICPMI_NN_TIMING
+    out[14] = (uint64_t)h->merge_fast_epochs; // map-growth epochs served with ONE collective / with the count + ready + points exchanges (ops.hip)
+    out[15] = (uint64_t)h->merge_slow_epochs;
     out[16] = (uint64_t)h->oct_respeculated; // octree filter calls whose speculated depth was too shallow (sorted twice; octree.hip)
     out[17] = (uint64_t)h->raw_view_count; // PointDistance searches served by the raw-frame view of the registration index (no second index)
     out[18] = (uint64_t)(uint32_t)h->ins_count | ((uint64_t)(uint32_t)(h->temp_raw ? h->temp_raw->ins_count : 0) << 32);

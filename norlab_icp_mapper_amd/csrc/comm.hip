@@ -108,6 +108,45 @@ __global__ void loop_counts_kernel(const long long* __restrict__ mine, long long
     all[r] = v;
 }
 
+// the loopback communicator's ONE-collective exchange: block r = this rank's block with the header's count cut as loop_counts_kernel cuts
+// it (ragged) and the points moved r * shift along x
+__global__ __launch_bounds__(256) void loop_gather_blocks_kernel(const float4* __restrict__ send, float4* __restrict__ recv, size_t block4, int R, float shift, int ragged)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= block4 * (size_t)R) return;
+    const size_t r = i / block4, e = i - r * block4;
+    const float4 hdr = send[0];
+    long long cnt = (long long)(int)__float_as_uint(hdr.x);
+    if (ragged && cnt > 0) {
+        const int w = (int)(r % 5); // quarters: 2, 4, 1, 3, 0 (loop_counts_kernel)
+        const long long q = w == 0 ? 2 : (w == 1 ? 4 : (w == 2 ? 1 : (w == 3 ? 3 : 0)));
+        cnt = cnt * q / 4;
+    }
+    if (e == 0) { recv[i] = make_float4(__uint_as_float((unsigned)(int)cnt), hdr.y, hdr.z, hdr.w); return; }
+    if ((long long)e > cnt) return; // (padding: never read)
+    float4 p = send[e];
+    if (r) p.x += (float)r * shift;
+    recv[i] = p;
+}
+
+// The exchange buffers of the one-collective epoch, sized for the communicator: send = 1 block, recv = n_ranks blocks, merged = n_ranks x
+// merge_block points.  Called where no peer can be left waiting (comm_init; a single-rank handle: the first epoch).  ICPMI_MERGE_BLOCK:
+// points per block (default 32 768; 0: the three-collective epoch).
+icpmi_status merge_blocks_reserve(icpmi_ctx* c, int n_ranks)
+{
+    long long block_cfg = 32768; // (read per communicator, not once per process: the tests run both epochs in one process)
+    { const char* e = getenv("ICPMI_MERGE_BLOCK"); if (e) block_cfg = atoll(e); if (block_cfg < 0) block_cfg = 0; }
+    c->merge_block = 0;
+    if (block_cfg == 0) return ICPMI_OK;
+    const size_t b4 = (size_t)block_cfg + 1;
+    if (b4 * (size_t)n_ranks >= (1ull << 31)) return ICPMI_OK; // (the merge indexes the gathered span with 31 bits: such a job keeps the old epoch)
+    if (ensure_cap(c, &c->d_merge_send, &c->cap_merge_send, b4 + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (ensure_cap(c, &c->d_merge_recv, &c->cap_merge_recv, b4 * (size_t)n_ranks + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (ensure_cap(c, &c->d_merged, &c->cap_merged, (size_t)block_cfg * (size_t)n_ranks + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+    c->merge_block = block_cfg;
+    return ICPMI_OK;
+}
+
 icpmi_status comm_init(icpmi_ctx* c, const icpmi_comm_id* id, int n_ranks, int rank)
 {
     if (const char* lb = getenv("ICPMI_COMM_LOOPBACK")) {
@@ -124,7 +163,8 @@ icpmi_status comm_init(icpmi_ctx* c, const icpmi_comm_id* id, int n_ranks, int r
             c->comm = nullptr; c->comm_ranks = R; c->comm_rank = 0; c->comm_loop_shift = sh ? (float)atof(sh) : 0.f;
             c->comm_loop_ragged = rg && atoi(rg) != 0;
             fprintf(stderr, "[icpmi] loopback communicator active: %d simulated ranks on one GPU, no RCCL (ICPMI_COMM_LOOPBACK)\n", R);
-            return ensure_cap(c, &c->d_comm_cnt, &c->cap_comm_cnt, (size_t)2 * R + 16);
+            if (ensure_cap(c, &c->d_comm_cnt, &c->cap_comm_cnt, (size_t)2 * R + 16) != ICPMI_OK) return ICPMI_ERR_HIP;
+            return merge_blocks_reserve(c, R);
         }
     }
     Rccl& r = rccl();
@@ -132,6 +172,7 @@ icpmi_status comm_init(icpmi_ctx* c, const icpmi_comm_id* id, int n_ranks, int r
     if (c->comm) { RCCL_TRY(c, r.CommDestroy((ncclComm_t)c->comm)); c->comm = nullptr; }
     // the words of the epoch's count / ready exchanges: allocated here so that no allocation can fail between two collectives
     if (ensure_cap(c, &c->d_comm_cnt, &c->cap_comm_cnt, (size_t)2 * n_ranks + 16) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (merge_blocks_reserve(c, n_ranks) != ICPMI_OK) return ICPMI_ERR_HIP; // (a failure here is reported before any collective exists)
     ncclUniqueId u;
     memcpy(&u, id, sizeof u);
     ncclComm_t comm = nullptr;
@@ -142,6 +183,7 @@ icpmi_status comm_init(icpmi_ctx* c, const icpmi_comm_id* id, int n_ranks, int r
 
 icpmi_status comm_destroy(icpmi_ctx* c)
 {
+    c->merge_block = 0; // (sized per communicator: the next one, or the single-rank handle's first epoch, reserves again)
     if (!c->comm) { c->comm_ranks = 1; c->comm_rank = 0; c->comm_loop_shift = 0.f; c->comm_loop_ragged = false; return ICPMI_OK; }
     Rccl& r = rccl();
     if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -193,5 +235,22 @@ icpmi_status comm_allgather(icpmi_ctx* c, const void* d_send, void* d_recv, size
         return ICPMI_OK;
     }
     RCCL_TRY(c, rccl().AllGather(d_send, d_recv, count, is_float ? ncclFloat : ncclInt64, (ncclComm_t)c->comm, c->stream));
+    return ICPMI_OK;
+}
+
+icpmi_status comm_allgather_blocks(icpmi_ctx* c, const float4* d_send, float4* d_recv, size_t block4)
+{
+    if (c->comm) {
+        RCCL_TRY(c, rccl().AllGather(d_send, d_recv, block4 * 4, ncclFloat, (ncclComm_t)c->comm, c->stream));
+        return ICPMI_OK;
+    }
+    if (c->comm_ranks > 1) { // loopback
+        hipLaunchKernelGGL(loop_gather_blocks_kernel, dim3((unsigned)((block4 * c->comm_ranks + 255) / 256)), dim3(256), 0, c->stream, d_send, d_recv, block4,
+                           c->comm_ranks, c->comm_loop_shift, c->comm_loop_ragged ? 1 : 0);
+        HIP_TRY(c, hipGetLastError());
+        return ICPMI_OK;
+    }
+    // one rank: its own block is the gathered set (header + the points handed in: the padding is never read)
+    HIP_TRY(c, hipMemcpyAsync(d_recv, d_send, block4 * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
     return ICPMI_OK;
 }

@@ -351,6 +351,11 @@ struct icpmi_ctx {
     float comm_loop_shift = 0.f;      // loopback communicator (comm.hip): rank r's block = this rank's, moved r * shift along x
     bool comm_loop_ragged = false;    // ... and cut to unequal sizes (comm.hip: loop_counts_kernel)
     long long* d_comm_cnt = nullptr; size_t cap_comm_cnt = 0; // words of the epoch's count / ready exchanges (allocated by comm_init)
+    // r5: the ONE-collective epoch (ops.hip: ops_staged_merge_allgather).  Every rank hands in a block of merge_block + 1 float4: a header
+    // {bits(count) | -1, magic} and up to merge_block accepted points; the blocks are sized when the communicator is created (no allocation,
+    // hence no `ready` exchange, between the local accept and the collective).  0: the three-collective epoch of r4.
+    int64_t merge_block = 0;
+    long merge_fast_epochs = 0, merge_slow_epochs = 0; // epochs served by the one-collective path / by the count + ready + points path
     int64_t merged_last_n = 0;        // points of the last epoch's merged set, still in d_merged (icpmi_staged_merged_points)
 };
 
@@ -404,6 +409,9 @@ struct DevBuf {
 // Small device -> host read through the pinned page: a copy into pageable memory is staged and blocks for tens of
 // microseconds, and a map update makes a dozen of them (counts after every compaction, grid statistics).
 #define ICPMI_PIN_BYTES (128 * 1024)
+#define ICPMI_PROGRESS_WORDS 512      // size of the host-mapped page in words
+#define ICPMI_PROGRESS_HDR_WORD 64    // ... 256 words: the block headers (counts) of a one-collective epoch, one per rank (ops.hip)
+#define ICPMI_MERGE_MAGIC 0x49435035u // 'ICP5' in the header's y
 #define ICPMI_PROGRESS_OCT_WORD 48  // ... and 8 words for the octree's root cube (octree.hip)
 #define ICPMI_PROGRESS_SCAN_WORD 40 // word of the host-mapped progress page (api.hip: h_progress, 64 words) that device_scan_flags_count reports into
 static inline icpmi_status read_back2(icpmi_ctx* c, void* dst0, const void* src0, size_t b0, void* dst1, const void* src1, size_t b1)
@@ -561,6 +569,7 @@ icpmi_status device_exclusive_scan_io(icpmi_ctx* c, const unsigned* in, unsigned
 // counts[0..n) -> starts in CURSOR layout (starts[0] = 0, starts[i + 1] = start of cell i, starts[n + 1] = total; n + 2 words): a scatter takes
 // its slots with atomicAdd(&starts[key + 1], len) and leaves the plain exclusive scan behind.  zero_counts: counts[0 .. n + 1] end up zero.
 icpmi_status device_scan_flags_count(icpmi_ctx* c, const unsigned* flag, unsigned* pos, int n, int64_t* count); // pos = exclusive scan of the 0 / 1 flags, *count = how many are set (one stream wait, no copy)
+icpmi_status device_exclusive_scan_sum(icpmi_ctx* c, const unsigned* flag, unsigned* pos, int n, unsigned* d_sum); // ... the count stays on the device
 icpmi_status device_exclusive_scan_cursor(icpmi_ctx* c, unsigned* counts, unsigned* starts, int n, unsigned total, bool zero_counts);
 icpmi_status sort_queries(icpmi_ctx* c, const float4* d_pts, int64_t n);
 icpmi_status sort_queries_reserve(icpmi_ctx* c, int64_t n, int nscan = 1);
@@ -612,6 +621,10 @@ icpmi_status comm_init(icpmi_ctx* c, const icpmi_comm_id* id, int n_ranks, int r
 icpmi_status comm_destroy(icpmi_ctx* c);
 icpmi_status comm_info(icpmi_ctx* c, int* n_ranks, int* rank, int* kind);
 icpmi_status comm_allgather(icpmi_ctx* c, const void* d_send, void* d_recv, size_t count, bool is_float);
+// all-gather of one fixed-size block of `block4` float4 per rank (element 0 = header: x = bits(count) or bits(-1)); the loopback
+// communicator builds its simulated ranks' blocks (shifted points, ragged counts) in one launch.  No communicator: d_recv = a copy of d_send.
+icpmi_status comm_allgather_blocks(icpmi_ctx* c, const float4* d_send, float4* d_recv, size_t block4);
+icpmi_status merge_blocks_reserve(icpmi_ctx* c, int n_ranks); // the exchange buffers of the one-collective epoch (called by comm_init)
 icpmi_status ops_staged_merge_allgather(icpmi_ctx* c, const float correction[16], float min_dist, int normals_knn, int64_t* accepted_local,
                                         int64_t* appended_total, int64_t* new_m, float* merged_out4, int64_t merged_capacity, int64_t* merged_n);
 icpmi_status ops_staged_merged_points(icpmi_ctx* c, float* out4, int64_t capacity, int64_t* n);

@@ -779,6 +779,28 @@ icpmi_status device_scan_flags_count(icpmi_ctx* c, const unsigned* flag, unsigne
     return ICPMI_OK;
 }
 
+__global__ void scan_tail_sum_kernel(const unsigned* __restrict__ pos, const unsigned* __restrict__ flag, int n, unsigned* __restrict__ out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) *out = n > 0 ? pos[n - 1] + flag[n - 1] : 0u;
+}
+
+// pos = exclusive scan of flag[0..n) (pos[n] = 0) and the number of set flags in the DEVICE word *d_sum -- nothing waits, nothing is read back
+icpmi_status device_exclusive_scan_sum(icpmi_ctx* c, const unsigned* flag, unsigned* pos, int n, unsigned* d_sum)
+{
+    const int nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    if (n > 0 && scan2_enabled() && nb <= SCAN2_MAX_NB) {
+        if (ensure_cap(c, &c->d_blocksums, &c->cap_blocksums, (size_t)nb + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
+        hipLaunchKernelGGL(scan2_sums_kernel, dim3(nb), dim3(SCAN_T), 0, c->stream, flag, n, c->d_blocksums);
+        hipLaunchKernelGGL(scan2_final_kernel, dim3(nb), dim3(SCAN_T), 0, c->stream, flag, pos, n, (const unsigned*)c->d_blocksums, 0u, 0, (unsigned*)nullptr, d_sum);
+        HIP_TRY(c, hipGetLastError());
+        return ICPMI_OK;
+    }
+    if (n > 0) { const icpmi_status s = device_exclusive_scan_io(c, flag, pos, n, 0u); if (s != ICPMI_OK) return s; }
+    hipLaunchKernelGGL(scan_tail_sum_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned*)pos, flag, n, d_sum);
+    HIP_TRY(c, hipGetLastError());
+    return ICPMI_OK;
+}
+
 // out[0..n) = exclusive scan of in[0..n), out[n] = total; in == out allowed
 icpmi_status device_exclusive_scan_io(icpmi_ctx* c, const unsigned* in, unsigned* data, int n, unsigned total)
 {

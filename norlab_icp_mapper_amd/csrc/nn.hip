@@ -2621,6 +2621,15 @@ static icpmi_status nn_self_knn_t(icpmi_ctx* c, const float4* d_cloud, const Loo
                        (int)c->m, lc.k, lc.maxr2, 1, d_sidx, d_d2, d_state, (const unsigned*)(c->d_hard + c->m + 2));
     hipLaunchKernelGGL(hard_reset_kernel, dim3(1), dim3(64), 0, c->stream, d_state);
     HIP_TRY(c, hipGetLastError());
+    {
+        static int diag = -1; // ICPMI_SELF_DIAG=1: how many queries the tiled pass left to the ring kernel (a read-back: diagnostic only)
+        if (diag < 0) { const char* e = getenv("ICPMI_SELF_DIAG"); diag = e ? atoi(e) : 0; }
+        if (diag) {
+            unsigned left = 0;
+            if (read_back(c, &left, c->d_hard + c->m + 1, sizeof(unsigned)) == ICPMI_OK)
+                fprintf(stderr, "[icpmi self-knn] m %lld k %d: %u queries (%.2f %%) redone by the ring kernel\n", (long long)c->m, lc.k, left, 100.0 * left / (double)c->m);
+        }
+    }
     return ICPMI_OK;
 }
 

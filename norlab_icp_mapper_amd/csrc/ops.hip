@@ -1552,7 +1552,8 @@ __global__ __launch_bounds__(256) void merge_flag_kernel(const float4* __restric
     kept[g] = drop ? 0u : 1u;
 }
 
-static icpmi_status merge_greedy(icpmi_ctx* c, const std::vector<long long>& counts, long long maxc, float min_dist, int64_t* merged_n)
+// recv: block r = recv[r * maxc .. r * maxc + counts[r]) (maxc = the stride of the padded layout)
+static icpmi_status merge_greedy(icpmi_ctx* c, const float4* recv, const std::vector<long long>& counts, long long maxc, float min_dist, int64_t* merged_n)
 {
     const int R = (int)counts.size();
     *merged_n = 0;
@@ -1575,7 +1576,7 @@ static icpmi_status merge_greedy(icpmi_ctx* c, const std::vector<long long>& cou
     if (!greedy) { // one block, or no distance rule: everything handed in is kept
         for (int r = 0; r < R; ++r)
             if (counts[(size_t)r] > 0)
-                hipLaunchKernelGGL(merge_flag_kernel, dim3((int)((counts[(size_t)r] + 255) / 256)), dim3(256), 0, c->stream, (const float4*)c->d_merge_recv, maxc, r,
+                hipLaunchKernelGGL(merge_flag_kernel, dim3((int)((counts[(size_t)r] + 255) / 256)), dim3(256), 0, c->stream, recv, maxc, r,
                                    counts[(size_t)r], 1, 0.f, 0.0, (const unsigned long long*)nullptr, (const unsigned*)nullptr, 0ull, (const float4*)nullptr, kept, (const unsigned*)nullptr);
     } else {
         long long total = 0;
@@ -1600,17 +1601,17 @@ static icpmi_status merge_greedy(icpmi_ctx* c, const std::vector<long long>& cou
         // beyond that the margin grows with the coordinate's ulp)
         const float h = min_dist * 1.001f + 1e-6f;
         const float inv_h = 1.0f / h;
-        hipLaunchKernelGGL(merge_hash_insert_kernel, dim3(gblocks), dim3(256), 0, c->stream, (const float4*)c->d_merge_recv, maxc, R, mb, inv_h, tkeys, tcnt,
+        hipLaunchKernelGGL(merge_hash_insert_kernel, dim3(gblocks), dim3(256), 0, c->stream, recv, maxc, R, mb, inv_h, tkeys, tcnt,
                            cap - 1, slot_of, rank_of, bits);
         HIP_TRY(c, hipGetLastError());
         icpmi_status s = device_exclusive_scan(c, tcnt, (int)cap, (unsigned)total);
         if (s != ICPMI_OK) return s;
         hipLaunchKernelGGL(merge_hash_scatter_kernel, dim3(gblocks), dim3(256), 0, c->stream, maxc, R, mb, (const unsigned*)tcnt, (const unsigned*)slot_of,
-                           (const unsigned*)rank_of, (const float4*)c->d_merge_recv, cell_pts);
+                           (const unsigned*)rank_of, recv, cell_pts);
         const double lim = pd_limit(min_dist);
         for (int r = first_block; r < R; ++r) {
             if (counts[(size_t)r] == 0) continue;
-            hipLaunchKernelGGL(merge_flag_kernel, dim3((int)((counts[(size_t)r] + 255) / 256)), dim3(256), 0, c->stream, (const float4*)c->d_merge_recv, maxc, r,
+            hipLaunchKernelGGL(merge_flag_kernel, dim3((int)((counts[(size_t)r] + 255) / 256)), dim3(256), 0, c->stream, recv, maxc, r,
                                counts[(size_t)r], r == first_block ? 1 : 0, inv_h, lim, (const unsigned long long*)tkeys, (const unsigned*)tcnt, cap - 1,
                                (const float4*)cell_pts, kept, (const unsigned*)bits);
         }
@@ -1618,9 +1619,111 @@ static icpmi_status merge_greedy(icpmi_ctx* c, const std::vector<long long>& cou
     }
     // stable compaction in global order = rank order, then input order inside a block (what the per-block appends of r3 produced)
     int64_t n_kept = 0;
-    icpmi_status s = merge_append_flagged(c, c->d_merge_recv, span, kept, pos, c->d_merged, 0, &n_kept);
+    icpmi_status s = merge_append_flagged(c, recv, span, kept, pos, c->d_merged, 0, &n_kept);
     if (s != ICPMI_OK) return s;
     *merged_n = n_kept;
+    return ICPMI_OK;
+}
+
+// ---- r5: the one-collective epoch ------------------------------------------------------------------------------------------------------
+// like merge_compact_kernel, but never past `cap` points (a block has a fixed size; the header carries the true count, an overflow sends
+// every rank to the three-collective epoch)
+__global__ __launch_bounds__(256) void merge_compact_cap_kernel(const float4* __restrict__ in, int64_t n, const unsigned* __restrict__ flag,
+                                                                const unsigned* __restrict__ pos, float4* __restrict__ out, unsigned cap)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    const unsigned p = pos[i];
+    if (p < cap) out[p] = in[i];
+}
+// header of this rank's block: {bits(count) | bits(-1): this rank failed before the exchange, magic}
+__global__ void merge_header_kernel(float4* __restrict__ hdr, const unsigned* __restrict__ count_word, int ok, unsigned fixed_count, int use_fixed)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const unsigned cnt = ok ? (use_fixed ? fixed_count : *count_word) : 0xffffffffu;
+        *hdr = make_float4(__uint_as_float(cnt), __uint_as_float(ICPMI_MERGE_MAGIC), 0.f, 0.f);
+    }
+}
+// the R headers of the gathered blocks -> host-mapped words (count, or 0xfffffffe for a header without the magic)
+__global__ void merge_headers_out_kernel(const float4* __restrict__ recv, size_t block4, int R, unsigned* __restrict__ out)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    const float4 h = recv[(size_t)r * block4];
+    out[r] = __float_as_uint(h.y) == ICPMI_MERGE_MAGIC ? __float_as_uint(h.x) : 0xfffffffeu;
+}
+
+// One collective per epoch: every rank hands in ONE fixed-size block {header, <= merge_block points}.  No host read-back in front of the
+// collective (the accept count goes from the scan straight into the header), none between collectives (there is only one), one stream wait
+// behind it (the R counts arrive in host-mapped memory).  Everything a rank can fail at before the exchange travels as count -1; buffers
+// were sized with the communicator.  *fall_back: some rank accepted more points than a block holds -- every rank sees the same headers
+// and takes the three-collective epoch for this scan (nothing has been appended yet).
+static icpmi_status merge_epoch_one_collective(icpmi_ctx* c, const float correction[16], float min_dist, int64_t n, std::vector<long long>& counts,
+                                               const float4** gathered, long long* stride, bool* fall_back, int64_t* mine_out)
+{
+    *fall_back = false; *mine_out = 0;
+    const int R = c->comm_ranks;
+    const int64_t cap = c->merge_block;
+    const size_t block4 = (size_t)cap + 1;
+    float4* send = c->d_merge_send;
+    unsigned* d_count = reinterpret_cast<unsigned*>(c->d_comm_cnt); // (one word: the scan's sum)
+    icpmi_status local = ICPMI_OK;
+    bool fixed = true; unsigned fixed_count = 0;
+    if (n > 0) {
+        unsigned* d_flag = scratch_get<unsigned>(c, 6, (size_t)n + 2);
+        unsigned* d_pos = scratch_get<unsigned>(c, 7, (size_t)n + 2);
+        if (!d_flag || !d_pos) local = ICPMI_ERR_HIP;
+        if (local == ICPMI_OK) local = ensure_cap(c, &c->d_stage_in, &c->cap_stage_in, (size_t)n + 1);
+        if (local == ICPMI_OK) local = ops_transform_dev(c, correction, c->d_scan_map, n, c->d_stage_in);
+        if (local == ICPMI_OK) {
+            if (c->m > 0) {
+                icpmi_ctx* ri = nullptr;
+                local = raw_index(c, &ri, min_dist);
+                if (local == ICPMI_OK) local = chain_point_distance_flags(c, ri, c->d_stage_in, n, min_dist, d_flag);
+                if (local == ICPMI_OK) local = device_exclusive_scan_sum(c, d_flag, d_pos, (int)n, d_count);
+                if (local == ICPMI_OK) {
+                    hipLaunchKernelGGL(merge_compact_cap_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, c->stream, (const float4*)c->d_stage_in, n,
+                                       (const unsigned*)d_flag, (const unsigned*)d_pos, send + 1, (unsigned)cap);
+                    fixed = false;
+                }
+            } else { // no map yet: every point is new
+                const int64_t cp = n < cap ? n : cap;
+                if (hipMemcpyAsync(send + 1, c->d_stage_in, (size_t)cp * sizeof(float4), hipMemcpyDeviceToDevice, c->stream) != hipSuccess) local = ICPMI_ERR_HIP;
+                fixed_count = (unsigned)n;
+            }
+        }
+    }
+    const std::string local_error = c->last_error;
+    hipLaunchKernelGGL(merge_header_kernel, dim3(1), dim3(64), 0, c->stream, send, (const unsigned*)d_count, local == ICPMI_OK ? 1 : 0, fixed_count, fixed ? 1 : 0);
+    HIP_TRY(c, hipGetLastError());
+    // ---- THE collective (a single rank without a communicator: its block is the gathered set)
+    const float4* recv = send;
+    if (c->comm || R > 1) {
+        const icpmi_status s = comm_allgather_blocks(c, send, c->d_merge_recv, block4);
+        if (s != ICPMI_OK) return s;
+        recv = c->d_merge_recv;
+    }
+    // ---- the R counts: host-mapped words, one wait
+    unsigned* d_hdr = c->d_progress + ICPMI_PROGRESS_HDR_WORD;
+    volatile unsigned* h_hdr = c->h_progress + ICPMI_PROGRESS_HDR_WORD;
+    hipLaunchKernelGGL(merge_headers_out_kernel, dim3((R + 255) / 256), dim3(256), 0, c->stream, recv, block4, R, d_hdr);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    counts.assign((size_t)R, 0);
+    bool over = false;
+    for (int r = 0; r < R; ++r) {
+        const unsigned v = h_hdr[r];
+        if (v == 0xffffffffu || v == 0xfffffffeu) { // every rank leaves the epoch together
+            if (local != ICPMI_OK) { c->last_error = local_error; return local; }
+            c->last_error = "staged_merge_allgather: rank " + std::to_string(r) + (v == 0xffffffffu ? " failed before the exchange" : " sent a block without the header");
+            return ICPMI_ERR_HIP;
+        }
+        counts[(size_t)r] = (long long)v;
+        over |= (int64_t)v > cap;
+    }
+    *mine_out = counts[(size_t)c->comm_rank];
+    if (over) { *fall_back = true; return ICPMI_OK; }
+    *gathered = recv + 1; *stride = (long long)block4;
     return ICPMI_OK;
 }
 
@@ -1647,6 +1750,28 @@ icpmi_status ops_staged_merge_allgather(icpmi_ctx* c, const float correction[16]
         if (c->comm) { c->last_error = "staged_merge_allgather: communicator without exchange words"; return ICPMI_ERR_HIP; }
         if (ensure_cap(c, &c->d_comm_cnt, &c->cap_comm_cnt, (size_t)2 * R + 16) != ICPMI_OK) return ICPMI_ERR_HIP;
     }
+    // ---- r5: ONE collective (fixed-size blocks with a count header); the three-collective epoch below stays as the fall-back
+    if (c->merge_block == 0 && !c->comm && R == 1) { const icpmi_status rs = merge_blocks_reserve(c, 1); if (rs != ICPMI_OK) return rs; } // (its own single rank: no peer to strand)
+    int64_t acc = 0;
+    bool served = false;
+    if (c->merge_block > 0) {
+        std::vector<long long> counts;
+        const float4* gathered = nullptr; long long stride = 0; bool fall_back = false; int64_t mine1 = 0;
+        icpmi_status s1 = merge_epoch_one_collective(c, correction, min_dist, n, counts, &gathered, &stride, &fall_back, &mine1);
+        if (s1 != ICPMI_OK) return s1;
+        if (!fall_back) {
+            if (accepted_local) *accepted_local = mine1;
+            long long total = 0;
+            for (long long v : counts) total += v;
+            ++c->merge_fast_epochs;
+            if (total == 0) { if (new_m) *new_m = c->m > 0 ? c->m_raw : 0; return ICPMI_OK; }
+            s1 = merge_greedy(c, gathered, counts, stride, min_dist, &acc);
+            if (s1 != ICPMI_OK) return s1;
+            served = true;
+        }
+    }
+    if (!served) {
+    ++c->merge_slow_epochs;
     // ---- this rank's accepted points: the staged scan moved by the correction (Mapper.cpp:221), PointDistance against the resident map
     icpmi_status local = ICPMI_OK;
     int64_t mine = 0;
@@ -1714,20 +1839,22 @@ icpmi_status ops_staged_merge_allgather(icpmi_ctx* c, const float correction[16]
     // ---- merge in rank order; block r keeps what is at least min_dist from the points accepted from ranks < r
     // r4: ONE spatial hash over all gathered blocks and R - 1 flag passes in rank order instead of one temporary index (a dozen launches and
     // two read-backs) per block -- the same greedy rule, the same candidates' float distances, the same kept set (merge_greedy).
-    int64_t acc = 0;
-    s = merge_greedy(c, counts, maxc, min_dist, &acc);
+    s = merge_greedy(c, c->d_merge_recv, counts, maxc, min_dist, &acc);
     if (s != ICPMI_OK) return s;
+    }
     // ---- every replica appends the same set (all points kept: the distance tests are done), normals, index
     int64_t app = 0, m1 = 0;
-    s = ops_map_update_dev(c, c->d_merged, acc, nullptr, 0.f, normals_knn, nullptr, &app, &m1);
+    icpmi_status s = ops_map_update_dev(c, c->d_merged, acc, nullptr, 0.f, normals_knn, nullptr, &app, &m1);
     if (s != ICPMI_OK) return s;
     c->merged_last_n = acc;
     if (merged_n) *merged_n = acc;
     if (merged_out4 && merged_capacity > 0) { // what fits; *merged_n says how much there is
         const int64_t cp = acc < merged_capacity ? acc : merged_capacity;
-        if (cp > 0) HIP_TRY(c, hipMemcpyAsync(merged_out4, c->d_merged, (size_t)cp * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+        if (cp > 0) {
+            HIP_TRY(c, hipMemcpyAsync(merged_out4, c->d_merged, (size_t)cp * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream)); // (only the copy-out needs the wait: the index update above has synchronised already)
+        }
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (appended_total) *appended_total = app;
     if (new_m) *new_m = m1;
     return ICPMI_OK;
