@@ -639,20 +639,6 @@ def main():
                 extras["docs_knn6"]["pose_err_vs_cpu"] = {"m": e6t, "rad": e6r}
                 extras["docs_knn6"]["cpu_iterations_per_s"] = o6.stats.iterations / o6.stats.seconds_total
             del icp6
-            # icpmi_config::fuse_solve: three launches per iteration (the solve rides in the next NN launch's prologue) -- same bits, measured
-            # here against the headline's four; off by default because only this fixed-count point-to-point shape gains
-            try:
-                icpf = pkg.ICPSequence(device=dev, max_iterations=ITERS_PER_STEP, fuse_solve=1, **chain)
-                icpf.setMapDev(d_map.data_ptr(), d_map.shape[0], d_nrm.data_ptr())
-                Tf, elf, perf = time_registrations(torch, icpf, d_scan, args.steps, args.warmup)
-                extras["fused_solve"] = {
-                    "config": f"the headline workload ({args.chain}) with icpmi_config::fuse_solve = 1: NN (+ the previous iteration's solve in every workgroup's "
-                              "prologue), selection, pair sums -- three launches per iteration, one closing solve per registration",
-                    "value": args.steps * ITERS_PER_STEP / elf, "unit": "iterations/s", "step_ms": step_stats(perf),
-                    "same_bits_as_headline": bool(np.array_equal(Tf, T))}
-                del icpf
-            except Exception as e:  # noqa: BLE001
-                extras["fused_solve"] = {"error": repr(e)}
             # what Mapper::processInput runs (Mapper.cpp:213): Counter 40 + Differential -- a registration of data-dependent length, segment graphs
             icpc = pkg.ICPSequence(device=dev, minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=40, use_differential=1)
             icpc.setMapDev(d_map.data_ptr(), d_map.shape[0], d_nrm.data_ptr())

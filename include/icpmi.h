@@ -129,9 +129,9 @@ typedef struct {
     float   grid_cell;         /* NN grid cell edge in metres; 0 = choose from the map density     */
     int32_t use_graph;         /* 1 = fixed-iteration registrations replay one hipGraph (default) */
     int32_t profile;           /* 1 = eager launches with HIP events around every NN launch        */
-    int32_t fuse_solve;        /* (v4) three launches per iteration: the solve of iteration i rides in the prologue of every       */
-                               /* workgroup of iteration i + 1's NN launch.  0 (default) = off, 1 = wherever the chain allows,      */
-                               /* 2 = only for fixed-count point-to-point registrations (where it measured faster)      */
+    int32_t fuse_solve;        /* (v4) asked for the solve inside the next NN launch (three launches per iteration).  The path lost  */
+                               /* on two of three shapes and was REMOVED in r5: the field keeps the struct's layout    */
+                               /* and is ignored (every value runs the four-launch iteration, bit-identical results as before).     */
     int32_t reserved[7];
 } icpmi_config;
 

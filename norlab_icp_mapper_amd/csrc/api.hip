@@ -146,9 +146,8 @@ icpmi_status icpmi_create(const icpmi_config* cfg, icpmi_handle* out)
     CR(hipSetDevice(c->device));
     CR(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->own_stream = true;
-    CR(hipMalloc((void**)&c->d_state, sizeof(IcpState) * 2 * ICPMI_MAX_BATCH));
-    CR(hipMemset(c->d_state, 0, sizeof(IcpState) * 2 * ICPMI_MAX_BATCH));
-    c->st_cur = c->d_state;
+    CR(hipMalloc((void**)&c->d_state, sizeof(IcpState) * ICPMI_MAX_BATCH));
+    CR(hipMemset(c->d_state, 0, sizeof(IcpState) * ICPMI_MAX_BATCH));
     CR(hipMalloc((void**)&c->d_selhist, ICPMI_SELHIST_WORDS * sizeof(unsigned)));
     CR(hipMemset(c->d_selhist, 0, ICPMI_SELHIST_WORDS * sizeof(unsigned)));
     c->cap_selhist = ICPMI_SELHIST_WORDS;

@@ -41,16 +41,16 @@
 // receives ICPMI_ACC_MAX_ADDS = 128 workgroup partials stays below 2^62 -- ONE bit inside int64, not more: loop.hip's acc_cap() clamps the
 // number of pair-sum workgroups to ICPMI_ACC_MAX_ADDS x ICPMI_ACC_COPIES whatever ICPMI_ACC_BLOCKS asks for.
 // ICPMI_ACC_COPIES privatised copies (workgroup b adds to copy b % COPIES),
-// every (copy, value, limb) on its own 128-byte line: device atomics serialise per line.  Two parities: the pair sums of
-// iteration i go to parity i & 1 (nn.hip: the next NN launch reads them while this iteration's successor already accumulates).
+// every (copy, value, limb) on its own 128-byte line: device atomics serialise per line.  (r4 kept two parities of them for the solve
+// fused into the next NN launch; that path was removed in r5 -- DESIGN 13.3 -- and one set is left.)
 #define ICPMI_ACC_COPIES 2   // (8 copies made every reader fetch 64 KB of padded lines -- 100 MB per NN launch once every workgroup reads them; 2: 128 atomics per line)
 #define ICPMI_ACC_MAX_ADDS 128 // workgroup partials one copy may receive per iteration (limb headroom, see above)
 #define ICPMI_ACC_PAD 16                                               // u64 per slot = one 128-byte line
-#define ICPMI_ACC_U64 (ICPMI_ACC_COPIES * ICPMI_NV * 2 * ICPMI_ACC_PAD)   // per parity: 8192 u64 = 64 KiB
+#define ICPMI_ACC_U64 (ICPMI_ACC_COPIES * ICPMI_NV * 2 * ICPMI_ACC_PAD)   // 2048 u64 = 16 KiB
 #define ICPMI_ACC_IDX(copy, i, limb) ((((copy) * ICPMI_NV + (i)) * 2 + (limb)) * ICPMI_ACC_PAD)
 #define ICPMI_ACC_FLAG (ICPMI_ACC_IDX(0, 0, 0) + 8)                    // a non-finite partial was met (NaN must reach the solver: ICPMI_ERR_NAN)
-#define ICPMI_S2_ACC (ICPMI_S2_F1 + 65536)                             // u32 word offset of parity 0 (128-byte aligned)
-#define ICPMI_SELHIST_WORDS (ICPMI_S2_ACC + 2 * 2 * ICPMI_ACC_U64)
+#define ICPMI_S2_ACC (ICPMI_S2_F1 + 65536)                             // u32 word offset of the accumulators (128-byte aligned)
+#define ICPMI_SELHIST_WORDS (ICPMI_S2_ACC + 2 * ICPMI_ACC_U64)
 // Device atomics serialise per cache line, and neighbouring fine bins are hot together: bin b of a fine
 // histogram lives at word ((b & 255) << 8) | (b >> 8), i.e. consecutive bins are 1 KiB apart.
 #define ICPMI_S2_FIDX(b) ((((b) & 255u) << 8) | ((b) >> 8))
@@ -305,20 +305,7 @@ struct icpmi_ctx {
     float4* nn_match_pt = nullptr;    // set by the loop: keep the loop state (sidx, d2, matched point) in query order
     bool nn_out_sorted = false;       // set by the NN launcher: true if the launched kernel did so
     bool nn_sorted_k = false;         // set by the loop for k > 1: keep the k matches of a query at its slot of the tile-sorted order
-    IcpState* d_state = nullptr;                               // 2 x ICPMI_MAX_BATCH states (a single registration uses the first; the second set is
-                                                               // the other parity of the fused solve, see nn_fs_* below)
-    // r4: the solve of iteration L - 1 runs in the prologue of EVERY workgroup of the NN launch of iteration L (nn1_wg_kernel<.., FSOLVE>):
-    // the pair sums are 32 fixed-point accumulators (ICPMI_ACC_*), the algebra is ~2 us of one lane, and redoing it 1 568 times costs less
-    // than a one-workgroup launch and its kernel boundary.  The loop state ping-pongs: NN launch L reads state[(L - 1) & 1] and the
-    // accumulators of parity (L - 1) & 1, workgroup 0 writes state[L & 1], the other kernels of iteration L work on state[L & 1].
-    IcpState* st_cur = nullptr;                                // the state the kernels of the iteration being enqueued use (loop.hip)
-    int acc_parity_cur = 0;                                    // ... and the parity of the accumulators its pair sums go to (| 2: zero the other)
-    bool fsolve_cur = false;                                   // the registration being enqueued runs with the fused solve
-    bool nn_fsolve = false;                                    // set by the loop for the next NN launch: fused solve
-    int nn_fs_pending = 0;                                     // ... there IS a previous iteration whose sums wait (L > 0)
-    IcpState* nn_fs_prev = nullptr;                            // ... its state
-    int nn_fs_acc_parity = 0;                                  // ... parity of its accumulators
-    LoopCfg nn_fs_lc{};                                        // ... the chain
+    IcpState* d_state = nullptr;                               // ICPMI_MAX_BATCH states (a single registration uses the first)
     IcpState* h_state = nullptr;                               // pinned mirror (ICPMI_MAX_BATCH)
     int batch_cur = 1;                                         // readings of the launch sequence being enqueued (set by the loop)
     BatchArgs batch_args{};                                    // their sizes / slice stride

@@ -517,7 +517,7 @@ __global__ __launch_bounds__(BT) void accumulate_kernel(const float4* __restrict
                                                          const float4* __restrict__ normals,
                                                          const float4* __restrict__ read_normals,
                                                          const int* __restrict__ sidx, const float* __restrict__ d2a,
-                                                         int acc_parity /* | 2: also zero the OTHER parity (fused solve) */, unsigned* __restrict__ hists,
+                                                         unsigned* __restrict__ hists,
                                                          int fused_slot, int is_median, float factor,
                                                          const float4* __restrict__ match_pt, const int* __restrict__ qindex,
                                                          const float* __restrict__ ref_scalar, const float4* __restrict__ pnm)
@@ -577,12 +577,6 @@ __global__ __launch_bounds__(BT) void accumulate_kernel(const float4* __restrict
     for (int u = 0; u < PF; ++u)
         pn[u] = (MIN == ICPMI_MIN_POINT_TO_PLANE && ps[u] >= 0) ? (pnm ? pnm[2 * (size_t)ps[u] + 1] : normals[ps[u]]) : make_float4(0.f, 0.f, 0.f, 0.f);
     if (st->done) return;
-    if (acc_parity & 2) {
-        // fused solve (nn.hip): the accumulators of the other parity were read by every workgroup of this iteration's NN launch -- the
-        // last readers -- and take the pair sums of the NEXT iteration: zeroed here
-        unsigned long long* other = reinterpret_cast<unsigned long long*>(hists + ICPMI_S2_ACC) + (size_t)((acc_parity & 1) ^ 1) * ICPMI_ACC_U64;
-        for (int64_t i = (int64_t)blockIdx.x * BT + threadIdx.x; i < ICPMI_ACC_U64; i += (int64_t)nbe * BT) other[i] = 0ull;
-    }
     float fused_limit = 0.f;
     if (FUSED) {
         // scan of level 1: the selected element's bit pattern is prefix(16) | bin(16)
@@ -702,7 +696,7 @@ __global__ __launch_bounds__(BT) void accumulate_kernel(const float4* __restrict
         }
         // the workgroup's sum joins the iteration's accumulator as two fixed-point limbs (common.h: ICPMI_ACC_*): integer atomics,
         // so the total is the same whatever order the workgroups arrive in
-        unsigned long long* acc = reinterpret_cast<unsigned long long*>(hists + ICPMI_S2_ACC) + (size_t)(acc_parity & 1) * ICPMI_ACC_U64;
+        unsigned long long* acc = reinterpret_cast<unsigned long long*>(hists + ICPMI_S2_ACC);
         if (v != 0.0) {
             if (!(fabs(v) < 0x1p77)) atomicOr(reinterpret_cast<unsigned*>(acc + ICPMI_ACC_FLAG), 1u);
             else {
@@ -717,22 +711,12 @@ __global__ __launch_bounds__(BT) void accumulate_kernel(const float4* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void solve_kernel(IcpState* __restrict__ st, const IcpState* __restrict__ st_in, unsigned* __restrict__ hists,
-                                                    int acc_parity, int clear, LoopCfg lc, float* __restrict__ T_step_out, double* __restrict__ sums_out,
-                                                    unsigned* __restrict__ progress)
+__global__ __launch_bounds__(256) void solve_kernel(IcpState* __restrict__ st, unsigned* __restrict__ hists, int clear, LoopCfg lc,
+                                                    float* __restrict__ T_step_out, double* __restrict__ sums_out, unsigned* __restrict__ progress)
 {
     // blockIdx.x = reading of a batch: one workgroup per registration
     st += blockIdx.x;
-    if (st_in && st_in != st) {
-        // the closing solve of a fused-solve sequence (see enqueue_iteration): the pending sums were formed under st_in, the result goes
-        // to the other parity -- exactly what the prologue of a following NN launch would compute (and will recompute, identically, if
-        // another segment follows: the accumulators are not cleared here)
-        const unsigned* g = reinterpret_cast<const unsigned*>(st_in + blockIdx.x);
-        unsigned* o = reinterpret_cast<unsigned*>(st);
-        for (int i = threadIdx.x; i < (int)(sizeof(IcpState) / sizeof(unsigned)); i += 256) o[i] = g[i];
-        __syncthreads();
-    }
-    unsigned long long* acc = reinterpret_cast<unsigned long long*>(hists + (size_t)blockIdx.x * ICPMI_SELHIST_WORDS + ICPMI_S2_ACC) + (size_t)acc_parity * ICPMI_ACC_U64;
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(hists + (size_t)blockIdx.x * ICPMI_SELHIST_WORDS + ICPMI_S2_ACC);
     if (progress) progress += blockIdx.x;
     if (st->done) { // finished earlier, or an upstream kernel of this iteration raised an error
         if (threadIdx.x == 0) publish_progress(st, progress);
@@ -1035,9 +1019,9 @@ static void enqueue_selection(icpmi_ctx* c, const LoopCfg& lc, int64_t count, bo
         const int nb = (int)lc.out_param2[f];
         for (int dest = 1; dest <= 2; ++dest) {
 #define MAD_PASS(P) \
-            if (dest == 1) hipLaunchKernelGGL((sel_hist_kernel<P, 1>), dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->st_cur, c->d_selhist, nb); \
-            else hipLaunchKernelGGL((sel_hist_kernel<P, 2>), dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->st_cur, c->d_selhist, nb); \
-            hipLaunchKernelGGL(sel_scan_kernel<P>, dim3(1), dim3(256), 0, c->stream, c->st_cur, c->d_selhist, -1.f, f, 0, 0.f, dest, nb);
+            if (dest == 1) hipLaunchKernelGGL((sel_hist_kernel<P, 1>), dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist, nb); \
+            else hipLaunchKernelGGL((sel_hist_kernel<P, 2>), dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist, nb); \
+            hipLaunchKernelGGL(sel_scan_kernel<P>, dim3(1), dim3(256), 0, c->stream, c->d_state, c->d_selhist, -1.f, f, 0, 0.f, dest, nb);
             MAD_PASS(0) MAD_PASS(1) MAD_PASS(2)
 #undef MAD_PASS
         }
@@ -1047,15 +1031,15 @@ static void enqueue_selection(icpmi_ctx* c, const LoopCfg& lc, int64_t count, bo
         VtBuffers vb;
         if (vt_buffers(c, count, &vb) != ICPMI_OK) return; // reserved by the caller: cannot fail here
         const long long min_el = (long long)floorf(lc.out_param[f] * (float)count), max_el = (long long)floorf(lc.out_param2[f] * (float)count);
-        hipLaunchKernelGGL(vt_keys_kernel, dim3((int)((count + 255) / 256)), dim3(256), 0, c->stream, c->d_d2, count, c->st_cur, vb.keys, vb.vals);
+        hipLaunchKernelGGL(vt_keys_kernel, dim3((int)((count + 255) / 256)), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, vb.keys, vb.vals);
         int half = 0;
         if (radix_sort_pairs(c, vb.keys, vb.vals, count, 32, vb.tab, &half) != ICPMI_OK) return;
         const unsigned long long* sorted = vb.keys + (half ? count : 0);
-        hipLaunchKernelGGL(vt_chunk_sums_kernel, dim3(vb.nchunks), dim3(256), 0, c->stream, sorted, c->st_cur, vb.sums);
+        hipLaunchKernelGGL(vt_chunk_sums_kernel, dim3(vb.nchunks), dim3(256), 0, c->stream, sorted, c->d_state, vb.sums);
         hipLaunchKernelGGL(vt_chunk_offsets_kernel, dim3(1), dim3(256), 0, c->stream, vb.sums, vb.nchunks);
-        hipLaunchKernelGGL(vt_frms_kernel, dim3(vb.nchunks), dim3(256), 0, c->stream, sorted, count, c->st_cur, (const double*)vb.sums, min_el, max_el,
+        hipLaunchKernelGGL(vt_frms_kernel, dim3(vb.nchunks), dim3(256), 0, c->stream, sorted, count, c->d_state, (const double*)vb.sums, min_el, max_el,
                            lc.out_param3[f], vb.best_val, vb.best_idx);
-        hipLaunchKernelGGL(vt_pick_kernel, dim3(1), dim3(256), 0, c->stream, sorted, count, c->st_cur, (const double*)vb.best_val,
+        hipLaunchKernelGGL(vt_pick_kernel, dim3(1), dim3(256), 0, c->stream, sorted, count, c->d_state, (const double*)vb.best_val,
                            (const long long*)vb.best_idx, vb.nchunks, min_el, f);
     }
     if (slot >= 0) {
@@ -1068,11 +1052,11 @@ static void enqueue_selection(icpmi_ctx* c, const LoopCfg& lc, int64_t count, bo
             // matches: 1024 per workgroup -6 %, 2048 baseline, 4096 +0.8 %, 8192 -4 %)
             int hb0 = (int)std::min<int64_t>((count + 4095) / 4096, 256);
             if (hb0 < 1) hb0 = 1;
-            hipLaunchKernelGGL(sel2_hist0_kernel, dim3(hb0, ba.nscan), dim3(256), 0, c->stream, c->d_d2, ba, lc.k, c->st_cur, c->d_selhist);
+            hipLaunchKernelGGL(sel2_hist0_kernel, dim3(hb0, ba.nscan), dim3(256), 0, c->stream, c->d_d2, ba, lc.k, c->d_state, c->d_selhist);
         }
         int hb2 = (int)std::min<int64_t>((count + 511) / 512, 512);
         if (hb2 < 1) hb2 = 1;
-        hipLaunchKernelGGL(sel2_scan_hist_kernel, dim3(hb2, ba.nscan), dim3(256), 0, c->stream, c->d_d2, ba, lc.k, c->st_cur, c->d_selhist, quant);
+        hipLaunchKernelGGL(sel2_scan_hist_kernel, dim3(hb2, ba.nscan), dim3(256), 0, c->stream, c->d_d2, ba, lc.k, c->d_state, c->d_selhist, quant);
         return;
     }
     for (int f = 0; f < lc.n_out; ++f) {
@@ -1081,12 +1065,12 @@ static void enqueue_selection(icpmi_ctx* c, const LoopCfg& lc, int64_t count, bo
         const int is_med = type == ICPMI_OUT_MEDIANDIST;
         const float quant = is_med ? 0.5f : lc.out_param[f];
         const float factor = lc.out_param[f];
-        hipLaunchKernelGGL((sel_hist_kernel<0, 0>), dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->st_cur, c->d_selhist, 0);
-        hipLaunchKernelGGL(sel_scan_kernel<0>, dim3(1), dim3(256), 0, c->stream, c->st_cur, c->d_selhist, quant, f, is_med, factor, 0, 0);
-        hipLaunchKernelGGL((sel_hist_kernel<1, 0>), dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->st_cur, c->d_selhist, 0);
-        hipLaunchKernelGGL(sel_scan_kernel<1>, dim3(1), dim3(256), 0, c->stream, c->st_cur, c->d_selhist, quant, f, is_med, factor, 0, 0);
-        hipLaunchKernelGGL((sel_hist_kernel<2, 0>), dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->st_cur, c->d_selhist, 0);
-        hipLaunchKernelGGL(sel_scan_kernel<2>, dim3(1), dim3(256), 0, c->stream, c->st_cur, c->d_selhist, quant, f, is_med, factor, 0, 0);
+        hipLaunchKernelGGL((sel_hist_kernel<0, 0>), dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist, 0);
+        hipLaunchKernelGGL(sel_scan_kernel<0>, dim3(1), dim3(256), 0, c->stream, c->d_state, c->d_selhist, quant, f, is_med, factor, 0, 0);
+        hipLaunchKernelGGL((sel_hist_kernel<1, 0>), dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist, 0);
+        hipLaunchKernelGGL(sel_scan_kernel<1>, dim3(1), dim3(256), 0, c->stream, c->d_state, c->d_selhist, quant, f, is_med, factor, 0, 0);
+        hipLaunchKernelGGL((sel_hist_kernel<2, 0>), dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist, 0);
+        hipLaunchKernelGGL(sel_scan_kernel<2>, dim3(1), dim3(256), 0, c->stream, c->d_state, c->d_selhist, quant, f, is_med, factor, 0, 0);
     }
 }
 
@@ -1111,14 +1095,14 @@ static void launch_accumulate_ext(icpmi_ctx* c, int64_t n, const LoopCfg& lc, in
     const bool sorted = c->nn_out_sorted; // loop state in query order (k = 1: with the matched points, see nn1_wg_kernel; k > 1: ids and d2)
     const BatchArgs ba = cur_batch(c, n);
     if (lc.k > 1) {
-        hipLaunchKernelGGL((accumulate_kernel<MIN, FUSED, EXT, 1024>), dim3(nb, ba.nscan), dim3(1024), 0, c->stream, sorted ? c->d_qsorted : c->d_reading, ba, acc_cap(), lc, c->st_cur,
-                           c->d_map_sorted, c->has_normals ? c->d_normals_sorted : (const float4*)nullptr, rn, c->d_sidx, c->d_d2, c->acc_parity_cur, c->d_selhist, slot, is_med, factor,
+        hipLaunchKernelGGL((accumulate_kernel<MIN, FUSED, EXT, 1024>), dim3(nb, ba.nscan), dim3(1024), 0, c->stream, sorted ? c->d_qsorted : c->d_reading, ba, acc_cap(), lc, c->d_state,
+                           c->d_map_sorted, c->has_normals ? c->d_normals_sorted : (const float4*)nullptr, rn, c->d_sidx, c->d_d2, c->d_selhist, slot, is_med, factor,
                            (const float4*)nullptr, sorted ? c->d_qindex : (const int*)nullptr, (EXT && c->raw_has_scalar) ? c->d_raw_s : (const float*)nullptr,
                            (MIN == ICPMI_MIN_POINT_TO_PLANE && c->has_normals && c->d_map_pn && pn_enabled()) ? c->d_map_pn : (const float4*)nullptr);
         return;
     }
-    hipLaunchKernelGGL((accumulate_kernel<MIN, FUSED, EXT>), dim3(nb, ba.nscan), dim3(256), 0, c->stream, sorted ? c->d_qsorted : c->d_reading, ba, acc_cap(), lc, c->st_cur,
-                       c->d_map_sorted, c->has_normals ? c->d_normals_sorted : (const float4*)nullptr, rn, c->d_sidx, c->d_d2, c->acc_parity_cur, c->d_selhist, slot, is_med, factor,
+    hipLaunchKernelGGL((accumulate_kernel<MIN, FUSED, EXT>), dim3(nb, ba.nscan), dim3(256), 0, c->stream, sorted ? c->d_qsorted : c->d_reading, ba, acc_cap(), lc, c->d_state,
+                       c->d_map_sorted, c->has_normals ? c->d_normals_sorted : (const float4*)nullptr, rn, c->d_sidx, c->d_d2, c->d_selhist, slot, is_med, factor,
                        (sorted && lc.k == 1) ? c->d_match_pt : (const float4*)nullptr, sorted ? c->d_qindex : (const int*)nullptr,
                        (EXT && c->raw_has_scalar) ? c->d_raw_s : (const float*)nullptr,
                        (lc.k > 1 && MIN == ICPMI_MIN_POINT_TO_PLANE && c->has_normals && c->d_map_pn && pn_enabled()) ? c->d_map_pn : (const float4*)nullptr);
@@ -1144,41 +1128,8 @@ static void enqueue_accumulate_solve(icpmi_ctx* c, int64_t n, const LoopCfg& lc,
         else launch_accumulate<ICPMI_MIN_IDENTITY, false>(c, n, lc, nb, slot);
     }
     const BatchArgs ba = cur_batch(c, n);
-    if (c->fsolve_cur) return; // the next NN launch (or enqueue_finish) solves
-    hipLaunchKernelGGL(solve_kernel, dim3(ba.nscan), dim3(256), 0, c->stream, c->d_state, (const IcpState*)nullptr, c->d_selhist, 0, 1, lc, d_Tstep, d_sums,
+    hipLaunchKernelGGL(solve_kernel, dim3(ba.nscan), dim3(256), 0, c->stream, c->d_state, c->d_selhist, 1, lc, d_Tstep, d_sums,
                        c->d_progress);
-}
-
-// r4: may the solve ride in the NN launches of this registration (common.h: nn_fs_*)?  Only where that launch is nn1_wg_kernel<4, true> on
-// the query-ordered state (k = 1, no brute pass, tile-sorted reading) and the chain's other kernels keep nothing in IcpState across
-// iterations that workgroup 0's copy could race with (no EXT filters, no VarTrimmed, at most one quantile filter, no sensor-noise pass).
-static bool fsolve_eligible(const icpmi_ctx* c, const LoopCfg& lc, int64_t n)
-{
-    static int wq = -1, wg = -1, keep = -1, seg = -1;
-    const int on = 1;
-    if (wq < 0) {
-        const char* e = getenv("ICPMI_NN_WQ"); wq = e ? atoi(e) : 1;
-        e = getenv("ICPMI_NN_WG"); wg = e ? atoi(e) : 4;
-        e = getenv("ICPMI_SORTED_STATE"); keep = e ? atoi(e) : 1;
-        e = getenv("ICPMI_SEG"); seg = e ? atoi(e) : 4;
-    }
-    if (!on || !wq || wg != 4 || !keep || (seg & 1)) return false;
-    if (lc.k != 1 || lc.ext || lc.sensor_noise || chain_has_vartrimmed(lc) || c->batch_cur > 1 || c->cfg.knn > 8 || n <= 0) return false;
-    int nq = 0;
-    for (int f = 0; f < lc.n_out; ++f) nq += lc.out_type[f] == ICPMI_OUT_TRIMMEDDIST || lc.out_type[f] == ICPMI_OUT_MEDIANDIST;
-    if (nq > 1) return false;
-    const GridParams& top = c->levels.g[c->levels.nlev - 1];
-    return std::isfinite(lc.max_dist) && (top.cell - top.slack) > lc.max_dist; // (else the launch is followed by the brute pass)
-}
-
-// the solve that closes a fused-solve sequence of `done_iters` iterations: state[(done_iters - 1) & 1] + its accumulators -> state[done_iters & 1]
-static void enqueue_finish(icpmi_ctx* c, const LoopCfg& lc, int done_iters)
-{
-    if (done_iters <= 0) return;
-    IcpState* in = c->d_state + ((done_iters - 1) & 1) * ICPMI_MAX_BATCH;
-    IcpState* out = c->d_state + (done_iters & 1) * ICPMI_MAX_BATCH;
-    hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(256), 0, c->stream, out, (const IcpState*)in, c->d_selhist, (done_iters - 1) & 1, 0, lc, (float*)nullptr,
-                       (double*)nullptr, c->d_progress);
 }
 
 // diagnostic (r5, scripts/r5/l2_real2.sh): 64 MB of other lines through every XCD's L2 in front of an NN launch -- whatever the L2 still held
@@ -1208,27 +1159,6 @@ static icpmi_status enqueue_iteration(icpmi_ctx* c, int64_t n, const LoopCfg& lc
     if (const uint4* buf = l2_thrash_buffer())
         hipLaunchKernelGGL(l2_thrash_kernel, dim3(2048), dim3(256), 0, c->stream, buf, (size_t)(64u << 20) / 16, reinterpret_cast<unsigned*>(const_cast<uint4*>(buf) + (size_t)(64u << 20) / 16));
     if (nn0) HIP_TRY(c, hipEventRecord(nn0, c->stream));
-    if (c->fsolve_cur) {
-        // iteration L = c->nn_iter_hint: its NN launch solves iteration L - 1 (state and accumulators of parity (L - 1) & 1) and writes
-        // state[L & 1], which the selection and the pair sums of iteration L then work on; the pair sums go to parity L & 1
-        const int L = c->nn_iter_hint;
-        IcpState* cur = c->d_state + (L & 1) * ICPMI_MAX_BATCH;
-        c->nn_fsolve = true; c->nn_fs_pending = L > 0; c->nn_fs_prev = c->d_state + ((L - 1) & 1) * ICPMI_MAX_BATCH;
-        c->nn_fs_acc_parity = (L - 1) & 1; c->nn_fs_lc = lc;
-        c->nn_hist0 = fused_filter_slot(lc) >= 0 ? c->d_selhist : nullptr;
-        c->nn_builds_hist0 = false;
-        c->nn_match_pt = c->d_match_pt; c->nn_sorted_k = false; c->nn_out_sorted = false;
-        icpmi_status s = nn_launch_k(c, c->d_reading, n, cur->T_iter, lc, 1, c->d_sidx, c->d_d2, cur);
-        c->nn_fsolve = false;
-        if (s != ICPMI_OK) return s;
-        if (nn1) HIP_TRY(c, hipEventRecord(nn1, c->stream));
-        c->st_cur = cur; c->acc_parity_cur = (L & 1) | (L > 0 ? 2 : 0);
-        enqueue_selection(c, lc, n * lc.k);
-        enqueue_accumulate_solve(c, n, lc, nullptr, nullptr);
-        c->st_cur = c->d_state; c->acc_parity_cur = 0;
-        HIP_TRY(c, hipGetLastError());
-        return ICPMI_OK;
-    }
     c->nn_hist0 = fused_filter_slot(lc) >= 0 ? c->d_selhist : nullptr;
     c->nn_builds_hist0 = false;
     static int keep_pts = -1;
@@ -1307,21 +1237,6 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
     const bool profile = c->cfg.profile != 0;
     const bool graph = c->cfg.use_graph != 0 && fixed && !profile;
     float nn_ms_sum = 0.f; int nn_cnt = 0;
-    // r4: three launches per iteration -- the solve rides in the next NN launch (common.h: nn_fs_*; nn.hip: FusedSolve)
-    struct FsGuard { icpmi_ctx* c; ~FsGuard() { c->fsolve_cur = false; c->st_cur = c->d_state; c->acc_parity_cur = 0; } } fs_guard{c};
-    // Measured (r4, 100 k x 1 M, A/B in one call): fixed-count point-to-point 23.0 k -> 23.75 k it/s (the NN launch grows by 3.9 us, a 5.6 us
-    // launch and a boundary go); fixed-count point-to-plane 24.9 k -> 24.4 k (its solve costs 6 us in the prologue); checked loops 0.382 ->
-    // 0.392 ms per 6-iteration registration (every segment ends on a closing solve, the Differential checker runs in every workgroup).
-    // Off unless asked for: icpmi_config::fuse_solve (1: wherever eligible, 2: fixed-count point-to-point only) or ICPMI_FUSE_SOLVE.
-    {
-        static int env_mode = -2;
-        if (env_mode == -2) { const char* e = getenv("ICPMI_FUSE_SOLVE"); env_mode = e ? atoi(e) : -1; }
-        const int mode = env_mode >= 0 ? env_mode : c->cfg.fuse_solve;
-        c->fsolve_cur = mode > 0 && fsolve_eligible(c, lc, n) &&
-                        (mode == 1 || (fixed && lc.minimizer == ICPMI_MIN_POINT_TO_POINT && !lc.use_diff && !lc.use_bound));
-    }
-    int fin_parity = 0; // which of the two states holds the result (fused solve: the parity of the number of iterations enqueued)
-
     c->reg_seq = (c->reg_seq + 1) & 0x7ffffu;
     if (c->h_progress) __atomic_store_n(c->h_progress + 32, c->reg_seq, __ATOMIC_RELEASE);
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
@@ -1355,9 +1270,6 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
                 icpmi_status s = g == 0 ? enqueue_registration_head(c, d_scan, d_normals3, n) : ICPMI_OK;
                 // (later segments: every iteration is seeded and past the wide first launches -- one graph serves them all)
                 for (int it = 0; it < S && s == ICPMI_OK; ++it) { c->nn_iter_hint = g == 0 ? it : S + it; s = enqueue_iteration(c, n, lc, nullptr, nullptr); }
-                // (fused solve: the segment ends with the solve of its last iteration -- the next segment's first NN launch redoes it,
-                // identically, from the same state and accumulators; S is even, so both kinds of segment start on parity 0)
-                if (s == ICPMI_OK && c->fsolve_cur) enqueue_finish(c, lc, g == 0 ? S : 2 * S);
                 hipError_t ce = hipStreamEndCapture(c->stream, &gr);
                 if (s != ICPMI_OK) { if (gr) hipGraphDestroy(gr); return s; }
                 HIP_TRY(c, ce);
@@ -1392,7 +1304,6 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
             HIP_TRY(c, hipGraphLaunch(c->seg_exec[1], c->stream));
             launched += S;
         }
-        fin_parity = c->fsolve_cur ? (launched & 1) : 0;
     } else if (graph) {
         // the whole registration -- head and all iterations -- is one graph, replayed while the scan
         // buffer, the map and the chain stay the same
@@ -1410,7 +1321,6 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
             HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
             icpmi_status s = enqueue_registration_head(c, d_scan, d_normals3, n);
             for (int it = 0; it < lc.max_iter && s == ICPMI_OK; ++it) { c->nn_iter_hint = it; s = enqueue_iteration(c, n, lc, nullptr, nullptr); }
-            if (s == ICPMI_OK && c->fsolve_cur) enqueue_finish(c, lc, lc.max_iter);
             hipError_t ce = hipStreamEndCapture(c->stream, &g);
             if (s != ICPMI_OK) { if (g) hipGraphDestroy(g); return s; }
             HIP_TRY(c, ce);
@@ -1421,7 +1331,6 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
         }
         HIP_TRY(c, hipGraphLaunch(c->graph_exec, c->stream));
         if (c->cfg.knn <= 8) { c->qsorted_n = n; c->qsorted_src = c->d_reading; } // what the replayed head leaves in d_qsorted
-        fin_parity = c->fsolve_cur ? (lc.max_iter & 1) : 0;
     } else {
         const int check_every = (lc.use_diff || lc.use_bound) ? 4 : lc.max_iter;
         if (profile && c->nn_events.size() < (size_t)2 * lc.max_iter) {
@@ -1460,22 +1369,17 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
                         // everything enqueued has run: the word is final (a kernel that stops the loop without passing
                         // through the solve kernel cannot leave the host waiting)
                         const unsigned w = __atomic_load_n(c->h_progress, __ATOMIC_ACQUIRE);
-                        // (fused solve: iteration `it` is acknowledged by the NEXT NN launch -- an idle stream at `it` means "go on")
-                        stopped = ((w >> 12) & 0x7ffffu) != c->reg_seq || (w >> 31) != 0 || (int)(w & 0xfffu) + (c->fsolve_cur ? 1 : 0) <= it;
+                        stopped = ((w >> 12) & 0x7ffffu) != c->reg_seq || (w >> 31) != 0 || (int)(w & 0xfffu) <= it;
                         break;
                     }
                 }
             } else if ((it + 1) % check_every == 0) {
-                // (fused solve: the stop decision of iteration `it` is taken by the NEXT NN launch; asked for now, it takes the closing
-                // solve -- which that launch then repeats, identically)
-                if (c->fsolve_cur) enqueue_finish(c, lc, it + 1);
-                const IcpState* sd = c->d_state + (c->fsolve_cur ? ((it + 1) & 1) * ICPMI_MAX_BATCH : 0);
+                const IcpState* sd = c->d_state;
                 HIP_TRY(c, hipMemcpyAsync(&c->h_state->done, &sd->done, sizeof(int), hipMemcpyDeviceToHost, c->stream));
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
                 if (c->h_state->done) break;
             }
         }
-        if (c->fsolve_cur) { enqueue_finish(c, lc, launched); fin_parity = launched & 1; }
         if (profile) {
             // back-to-back event pair: what two records cost with nothing in between (subtracted below)
             if (c->nn_events.size() < (size_t)2 * lc.max_iter + 2) {
@@ -1484,7 +1388,7 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
             HIP_TRY(c, hipEventRecord(c->nn_events[2 * lc.max_iter], c->stream));
             HIP_TRY(c, hipEventRecord(c->nn_events[2 * lc.max_iter + 1], c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
-            HIP_TRY(c, hipMemcpy(c->h_state, c->d_state + fin_parity * ICPMI_MAX_BATCH, sizeof(IcpState), hipMemcpyDeviceToHost));
+            HIP_TRY(c, hipMemcpy(c->h_state, c->d_state, sizeof(IcpState), hipMemcpyDeviceToHost));
             const int iters_done = c->h_state->iter < launched ? c->h_state->iter : launched;
             for (int it = 0; it < iters_done; ++it) {
                 float ms = 0.f;
@@ -1498,7 +1402,7 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
         }
     }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->h_state, c->d_state + fin_parity * ICPMI_MAX_BATCH, sizeof(IcpState), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(IcpState), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
 
     fill_stats(c, lc, n, stats);

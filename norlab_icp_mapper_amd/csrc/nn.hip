@@ -11,7 +11,6 @@
 // lane per query: surface normals), and the brute-force passes for queries the grid cannot decide
 // (only reachable with an unbounded maxDist).  The designs are described above each kernel.
 #include "common.h"
-#include "solve.h"
 
 namespace {
 
@@ -1006,7 +1005,10 @@ __global__ __launch_bounds__(64) void nn1_wq_kernel(const float4* __restrict__ q
 }
 
 // ------------------------------------------------------------------------------------------------
-// nn1_wg_kernel: the wave-queue scheme with the roles given to DIFFERENT NUMBERS OF WAVES.  The per-query set-up is cheapest
+// nn1_wg_kernel: the wave-queue scheme with the roles given to DIFFERENT NUMBERS OF WAVES.
+// (r4 carried an FSOLVE variant -- the previous iteration's solve in every workgroup's prologue, three launches per iteration.  r5 moved its
+//  loads into the query round trip and measured again: fixed-count point-to-point +1.8 %, point-to-plane -1.8 %, checked 6-iteration
+//  registrations -4 ... -6 %; the kernel needed scratch memory for the solver's cold paths.  Removed: DESIGN 13.3.)  The per-query set-up is cheapest
 // with one lane per query (every instruction of it then serves 64 queries; with LPQ lanes per query it is paid LPQ times), but
 // one wave that also looks up the nine rows and works off the ~330 pieces of its 64 queries lives for ten dependent steps --
 // and at 100 k queries there are only 1.5 such waves per SIMD to hide that behind.  Here a workgroup of four waves owns 64
@@ -1018,28 +1020,14 @@ __global__ __launch_bounds__(64) void nn1_wq_kernel(const float4* __restrict__ q
 //   (3)  wave 0 decides and stores.
 // Same keys, same exactness rules, same bits as nn1_ml_kernel / nn1_wq_kernel.
 // ------------------------------------------------------------------------------------------------
-// FSOLVE (r4): the solve of the PREVIOUS iteration in the prologue of every workgroup.  The pair-sum kernel of iteration L - 1 left 32
-// fixed-point sums (common.h: ICPMI_ACC_*); every workgroup of this launch reads them and the previous loop state (fs.prev) into LDS,
-// one lane runs the minimiser + compose + checkers there (solve.h: solve_serial -- the code of solve_kernel), and the workgroup goes on
-// with the T_iter it computed itself: no polling, no fence -- the kernel boundary behind the pair sums gives visibility -- and no
-// one-workgroup launch between two iterations.  Workgroup 0 alone writes the new state (`st`: the other parity) and the progress word.
-struct FusedSolve {
-    const IcpState* prev;        // state the pending sums were formed under (nullptr: nothing pending, `st` holds the state to use)
-    unsigned* selhist;           // d_selhist (the accumulators sit behind the histograms)
-    int acc_parity;
-    unsigned* progress;
-    LoopCfg lc;
-};
-
-template <int NW, bool SELF, bool FSOLVE = false>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(FSOLVE ? 6 : 1))) void nn1_wg_kernel(const float4* __restrict__ queries, const int* __restrict__ qindex, BatchArgs ba,
+template <int NW, bool SELF>
+__global__ __launch_bounds__(64 * NW) void nn1_wg_kernel(const float4* __restrict__ queries, const int* __restrict__ qindex, BatchArgs ba,
                                                      const float* __restrict__ Tptr, GridLevels L, float maxr2, int* __restrict__ out_sidx,
                                                      float* __restrict__ out_d2, IcpState* __restrict__ st, unsigned* __restrict__ hard,
                                                      unsigned* __restrict__ hist0, float4* __restrict__ match_pt,
-                                                     const uint4* __restrict__ ltab_g, int unseeded_lev, int seed_pre, FusedSolve fs)
+                                                     const uint4* __restrict__ ltab_g, int unseeded_lev, int seed_pre)
 {
     static_assert(NW == 3 || NW == 4, "waves per workgroup");
-    static_assert(!FSOLVE || NW == 4, "the fused solve reads the accumulators with 256 threads");
     constexpr int NT = 64 * NW, Q = 64;
     constexpr int NR = 3;                  // rows per lane in role 1b: rr = wave + NW sl
     constexpr int CAP = 16 * Q;            // pieces per pass (>= 9 Q: one piece per row always fits)
@@ -1085,12 +1073,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(FSOLVE 
 #endif
     const int wgs = (int)((((long long)n + Q - 1) / Q + 7) / 8 * 8);
     if ((int)blockIdx.x >= wgs) return;
-    __shared__ IcpState s_st;
-    int fs_done = 0, fs_iter = 0;
     // the workgroup's queries, XCD-aware order as nn1_ml_kernel: workgroup b runs on XCD b % 8; each XCD gets one contiguous eighth.
-    // The query / seed loads depend on nothing but the block index: requested HERE so that, with FSOLVE, they travel in the same round
-    // trip as the previous state and the pair sums the solver waits for (r5; r4 issued them behind the solve: one more trip on every
-    // workgroup's chain).
     const int chunk = wgs >> 3;
     const int lb = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
     const int slot = lane;
@@ -1104,64 +1087,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(FSOLVE 
         orig = match_pt ? qi : (qindex ? qindex[active ? qi : 0] : qi);
         if (match_pt) { sp_kept = ld_stream(out_sidx + (active ? qi : 0)); qs_kept = ld_stream(match_pt + (active ? qi : 0)); }
     }
-    if (FSOLVE) {
-        // First thing in the kernel, with nothing of the search live yet.  ONE round trip: the part of the previous state the solver
-        // reads (pose, counters; the checkers' history only when a Differential / Bound checker is in the chain) and the accumulators
-        // in use, every value's copies and limbs by the lane that owns the value -- no staging, one barrier.  Workgroup 0, the one
-        // writer of the new state, takes the whole struct.
-        __shared__ double s_tot[ICPMI_NV];
-        __shared__ unsigned s_nonfinite;
-        const bool pending = fs.prev != nullptr;
-        const IcpState* src = pending ? fs.prev + blockIdx.y : st;
-        {
-            const int words = (blockIdx.x == 0) ? (int)(sizeof(IcpState) / sizeof(unsigned))
-                                                : (int)(((fs.lc.use_diff || fs.lc.use_bound) ? offsetof(IcpState, sel_prefix) : offsetof(IcpState, hq)) / sizeof(unsigned));
-            const unsigned* g = reinterpret_cast<const unsigned*>(src);
-            unsigned* l = reinterpret_cast<unsigned*>(&s_st);
-            for (int i = tid; i < words; i += NT) l[i] = g[i];
-        }
-        if (pending) {
-            const unsigned long long* acc = reinterpret_cast<const unsigned long long*>(fs.selhist + (size_t)blockIdx.y * ICPMI_SELHIST_WORDS + ICPMI_S2_ACC) +
-                                            (size_t)fs.acc_parity * ICPMI_ACC_U64;
-            // wave 1 reads (wave 0's lanes are the serial solver's and the queries'): lane i < 32 owns value i
-            if (tid >= 64 && tid < 64 + ICPMI_NV) {
-                const int i = tid - 64;
-                long long H = 0, Lq = 0;
-                if ((pair_sum_mask(fs.lc) >> i) & 1u) {
-                    unsigned long long v[2 * ICPMI_ACC_COPIES];
-#pragma unroll
-                    for (int cp = 0; cp < ICPMI_ACC_COPIES; ++cp) { v[2 * cp] = acc[ICPMI_ACC_IDX(cp, i, 0)]; v[2 * cp + 1] = acc[ICPMI_ACC_IDX(cp, i, 1)]; }
-#pragma unroll
-                    for (int cp = 0; cp < ICPMI_ACC_COPIES; ++cp) { H += (long long)v[2 * cp]; Lq += (long long)v[2 * cp + 1]; }
-                }
-                s_tot[i] = (double)H * 65536.0 + (double)Lq * 0x1p-40;
-            }
-            if (tid == 64 + ICPMI_NV) s_nonfinite = *reinterpret_cast<const unsigned*>(acc + ICPMI_ACC_FLAG);
-        }
-        __syncthreads();
-        if (pending && !s_st.done) {
-            if (tid == 0) {
-                if (s_nonfinite) { s_st.error = ICPMI_ERR_NAN; s_st.done = 1; }
-                else solve_serial(&s_st, s_tot, fs.lc, nullptr);
-            }
-            __syncthreads();
-        }
-        if (pending && blockIdx.x == 0) { // the one writer of the new state (the other parity) and of the progress word
-            unsigned* g = reinterpret_cast<unsigned*>(st);
-            const unsigned* l = reinterpret_cast<const unsigned*>(&s_st);
-            for (int i = tid; i < (int)(sizeof(IcpState) / sizeof(unsigned)); i += NT) g[i] = l[i];
-            if (tid == 0) publish_progress(&s_st, fs.progress ? fs.progress + blockIdx.y : nullptr);
-        }
-        fs_done = s_st.done; fs_iter = s_st.iter;
-    }
-    int st_done = fs_done, st_iter = fs_iter;
-    if (!FSOLVE) { st_done = st->done; st_iter = st->iter; }
+    const int st_done = st->done, st_iter = st->iter;
     uint4 ltab_mine = make_uint4(0u, 0u, 0u, 0u);
     if (tid < ICPMI_MAXLEV * 4) ltab_mine = ltab_g[tid];
     float3 p = make_float3(0.f, 0.f, 0.f);
-    if (FSOLVE) {
-        if (w0) p = xf_point(s_st.T_iter, r.x, r.y, r.z, r.w);
-    } else if (w0) {
+    if (w0) {
         if (Tptr) p = xf_point(Tptr, r.x, r.y, r.z, r.w);
         else p = make_float3(r.x, r.y, r.z);
     }
@@ -2473,21 +2403,10 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
 #define LAUNCH_WQ(LPQ_) do { if (allow_self) LAUNCH_WQ2(LPQ_, true); else LAUNCH_WQ2(LPQ_, false); } while (0)
         static int wg_nw = -1;
         if (wg_nw < 0) { const char* e = getenv("ICPMI_NN_WG"); wg_nw = e ? atoi(e) : 4; }
-        FusedSolve fs; memset(&fs, 0, sizeof fs);
 #define LAUNCH_WG2(NW_, S_)                                                                                                     \
     hipLaunchKernelGGL((nn1_wg_kernel<NW_, S_>), dim3((int)(((n + 63) / 64 + 7) / 8 * 8), ba.nscan), dim3(64 * NW_), 0, c->stream,  \
-                       q, qi, ba, d_T, c->levels, lc.maxr2, d_sidx, d_d2, d_state, c->d_hard, h0, mp, c->d_lvl_tab, unseeded_lev, seed_pre, fs)
-        // the loop asked for the fused solve (loop.hip: enqueue_iteration; it checked that this launch IS the four-wave kernel on the
-        // sorted state without a brute pass): the solve of the previous iteration rides in this launch's prologue
-        const bool fsolve = c->nn_fsolve && use_wq && wg_nw == 4 && allow_self && mp != nullptr && !needs_hard;
-        if (c->nn_fsolve && !fsolve) { c->last_error = "internal: fused solve requested for a launch that cannot carry it"; return ICPMI_ERR_UNSUPPORTED; }
-        if (fsolve) {
-            fs.prev = c->nn_fs_pending ? c->nn_fs_prev : nullptr; fs.selhist = c->d_selhist; fs.acc_parity = c->nn_fs_acc_parity;
-            fs.progress = c->d_progress; fs.lc = c->nn_fs_lc;
-            hipLaunchKernelGGL((nn1_wg_kernel<4, true, true>), dim3((int)(((n + 63) / 64 + 7) / 8 * 8), ba.nscan), dim3(256), 0, c->stream,
-                               q, qi, ba, d_T, c->levels, lc.maxr2, d_sidx, d_d2, d_state, c->d_hard, h0, mp, c->d_lvl_tab, unseeded_lev, seed_pre, fs);
-        }
-        else if (use_wq && wg_nw == 4) {
+                       q, qi, ba, d_T, c->levels, lc.maxr2, d_sidx, d_d2, d_state, c->d_hard, h0, mp, c->d_lvl_tab, unseeded_lev, seed_pre)
+        if (use_wq && wg_nw == 4) {
             if (allow_self) LAUNCH_WG2(4, true); else LAUNCH_WG2(4, false);
             // diagnostic (r5, scripts/r5/l2_real.sh): the same search once more, right behind the first, without the histogram -- what does
             // the SECOND launch fetch past the L2?  (results unchanged: the repeat is seeded with the answer)

@@ -1,7 +1,6 @@
 // solve.h -- the single-lane part of an ICP iteration (ErrorMinimizer::compute's algebra, T_iter = T_step T_iter, TransformationCheckers;
-// SURVEY.md B.5 - B.8) and the reader of the fixed-point pair-sum accumulators.  A header because TWO translation units run it: loop.hip's
-// stand-alone solve_kernel and, r4, nn.hip's nn1_wg_kernel, whose every workgroup redoes the solve of the previous iteration in its
-// prologue instead of waiting for a one-workgroup launch (no relocatable device code in this build: each unit gets its own copy).
+// SURVEY.md B.5 - B.8) and the reader of the fixed-point pair-sum accumulators.  Included by loop.hip (solve_kernel).  (A header since r4,
+// when nn.hip's nn1_wg_kernel also ran it in every workgroup's prologue; that variant was measured again and removed in r5)
 #pragma once
 #include "common.h"
 
