@@ -1552,6 +1552,86 @@ __global__ __launch_bounds__(256) void merge_flag_kernel(const float4* __restric
     kept[g] = drop ? 0u : 1u;
 }
 
+__global__ __launch_bounds__(256) void merge_flag_all_kernel(const float4* __restrict__ recv, long long maxc, int R, MergeBlocks mb, int first_block, float inv_h,
+                                                         double lim, const unsigned long long* __restrict__ tkeys, const unsigned* __restrict__ tstart,
+                                                         unsigned long long mask, const float4* __restrict__ cell_pts, unsigned* __restrict__ kept,
+                                                         const unsigned* __restrict__ bits, unsigned* __restrict__ status)
+{
+    // r5: ALL blocks in one launch.  The greedy rule is a recursion over the rank order -- a point is dropped iff a KEPT point of a lower
+    // block is near -- and r4 ran it as R - 1 launches (block r after block r - 1: ~17 us each, the R-dependent part of the epoch).  Here a
+    // point that finds a near candidate of a lower block WAITS for that candidate's verdict (status: 0 undecided, 1 dropped, 2 kept;
+    // agent-scope atomics) and goes on.  The dependencies point strictly downwards in the global index, workgroups are dispatched in
+    // index order, and nothing a workgroup waits for lives in a later workgroup: the recursion always makes progress.  The verdicts are a
+    // function of the lower blocks' verdicts alone, so they are the R - 1 launches' verdicts, whatever the timing.
+    // (a WAVE never holds points of two blocks -- thread t serves point t % tpb of block t / tpb, tpb = maxc rounded up to 64: a lane that
+    //  waits for a lane of its own wave would wait for ever, the other lane's verdict is stored behind the loop both of them are in)
+    // EIGHT lanes per point, lane `sub` looks at cells sub, sub + 8, sub + 16, sub + 24 of the 27: a cell costs three to four dependent round
+    // trips (probe, bucket bounds, candidates), one lane walking its five to eight occupied cells one after the other was a chain of ~25
+    // (111 us for 113 k points at R = 8); the group's verdict is the OR of its lanes' (ballot).
+    const long long t = ((long long)blockIdx.x * 256 + threadIdx.x) >> 3;
+    const int sub = threadIdx.x & 7;
+    const long long tpb = (maxc + 63) & ~63ll;
+    const int r = (int)(t / tpb);
+    const long long i = t - (long long)r * tpb;
+    const bool live = r < R && i < mb.cnt[r < R ? r : 0];
+    const long long g = live ? (long long)r * maxc + i : 0;
+    bool drop = false;
+    if (live && r > first_block) {
+        const float4 p = recv[g];
+        const int cx = merge_cell_of(p.x, inv_h), cy = merge_cell_of(p.y, inv_h), cz = merge_cell_of(p.z, inv_h);
+        const long long lower_end = (long long)r * maxc; // global indices below this belong to lower blocks
+        // Most of the 27 cells around a point are empty, and an empty cell costs a hash table its longest search (probe until a free slot).
+        // A 2^24-bit filter of the occupied cells' hashes answers "empty" for them with ONE load, all of a lane's in flight together; only
+        // the few cells the filter lets through (occupied, or one of its < 2 % false positives) go to the table.
+        unsigned cand = 0u;
+        {
+            unsigned w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = sub + 8 * j;
+                const int qq = q < 27 ? q : 0;
+                const unsigned hb = (unsigned)(mix64(merge_cell_key(cx + (qq % 3) - 1, cy + ((qq / 3) % 3) - 1, cz + (qq / 9) - 1)) >> 40);
+                w[j] = q < 27 ? bits[hb >> 5] >> (hb & 31u) : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cand |= (w[j] & 1u) << j;
+        }
+        while (cand && !drop) {
+            const int j4 = __ffs((int)cand) - 1;
+            cand &= cand - 1u;
+            const int q = sub + 8 * j4;
+            const unsigned long long key = merge_cell_key(cx + (q % 3) - 1, cy + ((q / 3) % 3) - 1, cz + (q / 9) - 1);
+            unsigned long long sl = mix64(key) & mask, k = tkeys[sl];
+            while (k != key && k != ~0ull) { sl = (sl + 1) & mask; k = tkeys[sl]; }
+            if (k != key) continue; // a false positive of the filter
+            const unsigned rbq = tstart[sl], req = tstart[sl + 1];
+            for (unsigned j = rbq; j < req && !drop; j += 4u) {
+                float4 o[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) o[u] = cell_pts[j + u < req ? j + u : j]; // four candidates in flight
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (j + u >= req) continue;
+                    const unsigned o_i = __float_as_uint(o[u].w);
+                    if ((long long)o_i >= lower_end) continue;
+                    const float d2 = sqdist3(p.x, p.y, p.z, o[u].x, o[u].y, o[u].z);
+                    if (d2 > 1.1920929e-07f && (double)d2 < lim) { // a near candidate of a lower block: its verdict decides (rare)
+                        unsigned v;
+                        while ((v = __hip_atomic_load(&status[o_i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) __builtin_amdgcn_s_sleep(2);
+                        if (v == 2u) drop = true;
+                    }
+                }
+            }
+        }
+    }
+    const unsigned long long dropped = __ballot(drop);
+    if (!live || sub != 0) return;
+    const bool any = ((dropped >> (threadIdx.x & 56)) & 0xffull) != 0ull;
+    kept[g] = any ? 0u : 1u;
+    __hip_atomic_store(&status[g], any ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+
 // recv: block r = recv[r * maxc .. r * maxc + counts[r]) (maxc = the stride of the padded layout)
 static icpmi_status merge_greedy(icpmi_ctx* c, const float4* recv, const std::vector<long long>& counts, long long maxc, float min_dist, int64_t* merged_n)
 {
@@ -1609,6 +1689,16 @@ static icpmi_status merge_greedy(icpmi_ctx* c, const float4* recv, const std::ve
         hipLaunchKernelGGL(merge_hash_scatter_kernel, dim3(gblocks), dim3(256), 0, c->stream, maxc, R, mb, (const unsigned*)tcnt, (const unsigned*)slot_of,
                            (const unsigned*)rank_of, recv, cell_pts);
         const double lim = pd_limit(min_dist);
+        static int one_launch = -1; // ICPMI_MERGE_FLAG_ALL=0: the R - 1 launches of r4 (A/B, and the fall-back for sets too large to trust co-dispatch)
+        if (one_launch < 0) { const char* e = getenv("ICPMI_MERGE_FLAG_ALL"); one_launch = e ? atoi(e) : 1; }
+        if (one_launch && span <= (1ll << 22)) {
+            unsigned* status = scratch_get<unsigned>(c, 8, (size_t)span + 2);
+            if (!status) return ICPMI_ERR_HIP;
+            HIP_TRY(c, hipMemsetAsync(status, 0, ((size_t)span + 2) * sizeof(unsigned), c->stream));
+            const long long tpb = (maxc + 63) & ~63ll;
+            hipLaunchKernelGGL(merge_flag_all_kernel, dim3((unsigned)((tpb * R * 8 + 255) / 256)), dim3(256), 0, c->stream, recv, maxc, R, mb, first_block, inv_h, lim, (const unsigned long long*)tkeys,
+                               (const unsigned*)tcnt, cap - 1, (const float4*)cell_pts, kept, (const unsigned*)bits, status);
+        } else
         for (int r = first_block; r < R; ++r) {
             if (counts[(size_t)r] == 0) continue;
             hipLaunchKernelGGL(merge_flag_kernel, dim3((int)((counts[(size_t)r] + 255) / 256)), dim3(256), 0, c->stream, recv, maxc, r,
@@ -1743,6 +1833,17 @@ icpmi_status ops_staged_merge_allgather(icpmi_ctx* c, const float correction[16]
     if (merged_n) *merged_n = 0;
     if (new_m) *new_m = c->m > 0 ? c->m_raw : 0;
     c->merged_last_n = 0;
+    // ICPMI_EPOCH_TIMING=1: wall time of the epoch's stages with a stream wait behind each, on stderr (diagnostic; perturbs the overlap)
+    static const bool ep_timing = [] { const char* e = getenv("ICPMI_EPOCH_TIMING"); return e && atoi(e) != 0; }();
+    auto ep_tick = [&](const char* what) {
+        static thread_local std::chrono::steady_clock::time_point t0;
+        if (!ep_timing) return;
+        (void)hipStreamSynchronize(c->stream);
+        const auto t1 = std::chrono::steady_clock::now();
+        if (what) fprintf(stderr, "[icpmi epoch] %-22s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t1 - t0).count());
+        t0 = std::chrono::steady_clock::now();
+    };
+    ep_tick(nullptr);
     const int R = c->comm_ranks; // 1 without a communicator (or the loopback communicator's simulated ranks, comm.hip)
     const int64_t n = correction ? c->scan_map_n : 0; // no correction = nothing to contribute (empty scan / failed registration)
     // the exchange words: allocated by comm_init; a handle that is its own single rank gets them here (no peer can be left waiting)
@@ -1759,6 +1860,7 @@ icpmi_status ops_staged_merge_allgather(icpmi_ctx* c, const float correction[16]
         const float4* gathered = nullptr; long long stride = 0; bool fall_back = false; int64_t mine1 = 0;
         icpmi_status s1 = merge_epoch_one_collective(c, correction, min_dist, n, counts, &gathered, &stride, &fall_back, &mine1);
         if (s1 != ICPMI_OK) return s1;
+        ep_tick("accept + collective");
         if (!fall_back) {
             if (accepted_local) *accepted_local = mine1;
             long long total = 0;
@@ -1767,6 +1869,7 @@ icpmi_status ops_staged_merge_allgather(icpmi_ctx* c, const float correction[16]
             if (total == 0) { if (new_m) *new_m = c->m > 0 ? c->m_raw : 0; return ICPMI_OK; }
             s1 = merge_greedy(c, gathered, counts, stride, min_dist, &acc);
             if (s1 != ICPMI_OK) return s1;
+            ep_tick("rank-ordered merge");
             served = true;
         }
     }
@@ -1846,6 +1949,7 @@ icpmi_status ops_staged_merge_allgather(icpmi_ctx* c, const float correction[16]
     int64_t app = 0, m1 = 0;
     icpmi_status s = ops_map_update_dev(c, c->d_merged, acc, nullptr, 0.f, normals_knn, nullptr, &app, &m1);
     if (s != ICPMI_OK) return s;
+    ep_tick("append + index insert");
     c->merged_last_n = acc;
     if (merged_n) *merged_n = acc;
     if (merged_out4 && merged_capacity > 0) { // what fits; *merged_n says how much there is
