@@ -113,6 +113,9 @@ def nn_roofline(pkg, dev, chain, d_map, d_nrm, d_scan, n_scan, m_map, traffic_ke
             rec = json.load(open(pmc))
             if rec.get("kernel_sources_sha") == kernel_sources_sha():
                 traffic = rec.get(traffic_key)
+                # (per-dispatch counter collection does not preserve the L2 from one dispatch to the next, so this is the launch
+                #  on cold caches -- an upper bound for the production run, where an XCD's map slice survives the kernel boundary)
+                traffic_note = "rocprofv3 --pmc per dispatch: caches cold at every launch (upper bound for the graph-replayed loop, DESIGN 13.1)"
             else:
                 traffic_note = "profiles/nn_traffic.json was measured on other kernel sources (stamp mismatch): not reported"
         except Exception:
