@@ -252,6 +252,13 @@ icpmi_status icpmi_surface_normals_ex(icpmi_handle h, const float* pts4, int64_t
  * (d2, index), the point itself first; may be NULL) and mean_dist (m floats: distance from the point to the mean of its neighbours; may be NULL). */
 icpmi_status icpmi_surface_normals_ex2(icpmi_handle h, const float* pts4, int64_t m, int32_t knn, float* normals3, float* densities,
                                        int32_t* matched_ids, float* mean_dist);
+/* (r5) ... with `keepEigenValues: 1` / `keepEigenVectors: 1` and `sortEigen: 1`: eig_values3 (3 x m, may be NULL) = the eigenvalues of the
+ * neighbourhood's scatter matrix NN NN^T in ascending order; eig_vectors9 (9 x m, may be NULL) = upstream's serializeEigVec of the
+ * eigenvector matrix in that column order (entry 3 k + j of a point = component k of eigenvector j).  Rank < 2: zeros / identity, as upstream.
+ * The sign of an eigenvector is the solver's.  Upstream's UNSORTED order (sortEigen: 0) is whatever Eigen::EigenSolver returns and is not
+ * reproduced: the host filter serves the two descriptors only together with sortEigen: 1. */
+icpmi_status icpmi_surface_normals_ex3(icpmi_handle h, const float* pts4, int64_t m, int32_t knn, float* normals3, float* densities,
+                                       int32_t* matched_ids, float* mean_dist, float* eig_values3, float* eig_vectors9);
 
 /* `PointDistanceMapperModule::inPlaceUpdateMap` keep mask (PointDistanceMapperModule.cpp:28-50):
  * keep[i] = 1 iff the exact NN of input i in map (self match excluded) has d2 >= min_dist^2. */

@@ -113,6 +113,7 @@ SYMBOLS = [
     ("icpmi_surface_normals", C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
     ("icpmi_surface_normals_ex", C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P]),
     ("icpmi_surface_normals_ex2", C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P]),
+    ("icpmi_surface_normals_ex3", C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P, _P, _P]),
     ("icpmi_point_distance_keep", C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_float, _P]),
     ("icpmi_voxel_keep_first", C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),
     ("icpmi_filter_points", C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, _P]),

@@ -626,6 +626,14 @@ icpmi_status icpmi_surface_normals_ex2(icpmi_handle h, const float* pts4, int64_
     return ops_surface_normals(h, pts4, m, knn, normals3, densities, matched_ids, mean_dist);
 }
 
+icpmi_status icpmi_surface_normals_ex3(icpmi_handle h, const float* pts4, int64_t m, int32_t knn, float* normals3, float* densities,
+                                       int32_t* matched_ids, float* mean_dist, float* eig_values3, float* eig_vectors9)
+{
+    CHECK_H(h);
+    if (m < 0 || (m > 0 && (!pts4 || !normals3))) { h->last_error = "surface_normals: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
+    return ops_surface_normals(h, pts4, m, knn, normals3, densities, matched_ids, mean_dist, eig_values3, eig_vectors9);
+}
+
 icpmi_status icpmi_point_distance_keep(icpmi_handle h, const float* map4, int64_t m, const float* in4, int64_t n, float min_dist,
                                        uint8_t* keep)
 {

@@ -590,7 +590,7 @@ icpmi_status ops_filter_points(icpmi_ctx* c, const float* in4, int64_t n, const 
 icpmi_status ops_staged_keep(icpmi_ctx* c, const float correction[16], float min_dist, uint8_t* keep_out, float* placed_out4);
 icpmi_status ops_map_scalar(icpmi_ctx* c, const float* set, float* get, int64_t m);
 icpmi_status ops_surface_normals(icpmi_ctx* c, const float* pts4, int64_t m, int knn, float* normals3, float* densities = nullptr,
-                                 int32_t* matched_ids = nullptr, float* mean_dist = nullptr);
+                                 int32_t* matched_ids = nullptr, float* mean_dist = nullptr, float* eig_values = nullptr, float* eig_vectors = nullptr);
 icpmi_status ops_dynamic_points_update(icpmi_ctx* c, const icpmi_dynpts_params* prm, const float to_sensor[16], const float* in4, int64_t n,
                                        const float* map4, const float* map_normals3, int64_t m, float* prob);
 icpmi_status ops_map_update_point_distance(icpmi_ctx* c, const float* scan4, int64_t n, const float* scan_normals3, float min_dist,

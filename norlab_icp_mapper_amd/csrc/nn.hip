@@ -149,10 +149,18 @@ template <int KMAX>
 __device__ __forceinline__ void scan_run_k(const float4* __restrict__ map, unsigned s, unsigned e, float px, float py, float pz,
                                            bool allow_self, KList<KMAX>& L)
 {
-    for (unsigned i = s; i < e; ++i) {
-        const float4 q = map[i];
-        const float d2 = sqdist3(px, py, pz, q.x, q.y, q.z);
-        if (allow_self || d2 > 1.1920929e-07f) L.insert(pack_key(d2, __float_as_uint(q.w)), (int)i);
+    // four points in flight (r5): one point per trip made a run of c points a chain of c memory latencies -- the ring kernel that redoes the
+    // tiled self-search's few left-over queries took 57 - 62 us for a few hundred of them.  Same insertion order, same lists.
+    for (unsigned i = s; i < e; i += 4u) {
+        float4 q[4];
+#pragma unroll
+        for (unsigned u = 0; u < 4u; ++u) q[u] = map[i + u < e ? i + u : i];
+#pragma unroll
+        for (unsigned u = 0; u < 4u; ++u) {
+            if (i + u >= e) continue;
+            const float d2 = sqdist3(px, py, pz, q[u].x, q[u].y, q[u].z);
+            if (allow_self || d2 > 1.1920929e-07f) L.insert(pack_key(d2, __float_as_uint(q[u].w)), (int)(i + u));
+        }
     }
 }
 

@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256) void keep_kernel(const float* __restrict__ d2,
 // neighbour (d2 = 0 sorts first; a duplicate that wins the index tie has the same coordinates), which keeps it in the index's centred frame.
 __global__ __launch_bounds__(128) void normals_kernel(const float4* __restrict__ map, const int* __restrict__ sidx, int64_t m, int k,
                                                       float* __restrict__ normals3, float* __restrict__ densities, int dim2,
-                                                      float* __restrict__ mean_dist = nullptr)
+                                                      float* __restrict__ mean_dist = nullptr, float* __restrict__ eig_values = nullptr,
+                                                      float* __restrict__ eig_vectors = nullptr)
 {
     const int64_t i = (int64_t)blockIdx.x * 128 + threadIdx.x;
     if (i >= m) return;
@@ -160,6 +161,31 @@ __global__ __launch_bounds__(128) void normals_kernel(const float4* __restrict__
     const double wmax = fmax(fabs(w0), fmax(fabs(w1), fabs(w2)));
     const double thr = 3.0 * 1.1920928955078125e-07 * wmax;
     const int rank = (wmax > 0) ? ((fabs(w0) > thr) + (fabs(w1) > thr) + (fabs(w2) > thr)) : 0;
+    if ((eig_values || eig_vectors) && !dim2) {
+        // keepEigenValues / keepEigenVectors with sortEigen: 1 (r5): eigenvalues of the scatter matrix ascending (the exchange sort (0,1) (0,2)
+        // (1,2), strict), serializeEigVec of the eigenvector matrix in that column order -- entry 3 k + j = component k of eigenvector j;
+        // rank < 2: upstream's degenerate answer (zeros, identity).  Static indices only (no scratch).
+        double e0 = w0, e1 = w1, e2 = w2;
+        int o0 = 0, o1 = 1, o2 = 2;
+        if (rank >= 2) {
+            if (e1 < e0) { const double t = e0; e0 = e1; e1 = t; const int u = o0; o0 = o1; o1 = u; }
+            if (e2 < e0) { const double t = e0; e0 = e2; e2 = t; const int u = o0; o0 = o2; o2 = u; }
+            if (e2 < e1) { const double t = e1; e1 = e2; e2 = t; const int u = o1; o1 = o2; o2 = u; }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int oj = j == 0 ? o0 : (j == 1 ? o1 : o2);
+            const double wj = j == 0 ? e0 : (j == 1 ? e1 : e2);
+            if (eig_values) eig_values[3 * i + j] = rank >= 2 ? (float)wj : 0.f;
+            if (eig_vectors) {
+#pragma unroll
+                for (int kk = 0; kk < 3; ++kk) {
+                    const double q = oj == 0 ? Q[kk][0] : (oj == 1 ? Q[kk][1] : Q[kk][2]);
+                    eig_vectors[9 * i + 3 * kk + j] = rank >= 2 ? (float)q : (kk == j ? 1.f : 0.f);
+                }
+            }
+        }
+    }
     float nx = 1.f, ny = 0.f, nz = 0.f; // upstream's degenerate answer: eigenvectors = identity
     if (dim2) {
         // planar cloud (z == 0: the rotations with the z axis saw zero off-diagonals): the smaller eigenvector of the plane's pair;
@@ -716,7 +742,7 @@ static icpmi_status temp_knn(icpmi_ctx* c, TempCtx& t, const float* cloud4, int6
 }
 
 icpmi_status ops_surface_normals(icpmi_ctx* c, const float* pts4, int64_t m, int knn, float* normals3, float* densities, int32_t* matched_ids,
-                                 float* mean_dist)
+                                 float* mean_dist, float* eig_values, float* eig_vectors)
 {
     if (m == 0) return ICPMI_OK;
     if (knn < 1 || knn > ICPMI_MAX_K) { c->last_error = "surface_normals: knn must be in [1, 32]"; return ICPMI_ERR_INVALID_ARG; }
@@ -726,14 +752,20 @@ icpmi_status ops_surface_normals(icpmi_ctx* c, const float* pts4, int64_t m, int
     s = temp_knn(c, t, pts4, m, nullptr, m, knn, 1, true);
     if (s != ICPMI_OK) return s;
     icpmi_ctx* tc = t.h;
-    DevBuf<float> d_n, d_dens, d_md;
+    if ((eig_values || eig_vectors) && c->cfg.is_2d) { c->last_error = "surface_normals: keepEigenValues / keepEigenVectors are not served for planar clouds"; return ICPMI_ERR_UNSUPPORTED; }
+    DevBuf<float> d_n, d_dens, d_md, d_ev, d_evec;
     DevBuf<int> d_ids;
     HIP_TRY(c, d_n.alloc((size_t)m * 3));
     if (densities) HIP_TRY(c, d_dens.alloc((size_t)m));
     if (mean_dist) HIP_TRY(c, d_md.alloc((size_t)m));
+    if (eig_values) HIP_TRY(c, d_ev.alloc((size_t)m * 3));
+    if (eig_vectors) HIP_TRY(c, d_evec.alloc((size_t)m * 9));
     hipLaunchKernelGGL(normals_kernel, dim3((int)((m + 127) / 128)), dim3(128), 0, tc->stream, tc->d_map_sorted, tc->d_sidx, m, knn, d_n,
-                       densities ? d_dens.p : (float*)nullptr, c->cfg.is_2d, mean_dist ? d_md.p : (float*)nullptr);
+                       densities ? d_dens.p : (float*)nullptr, c->cfg.is_2d, mean_dist ? d_md.p : (float*)nullptr,
+                       eig_values ? d_ev.p : (float*)nullptr, eig_vectors ? d_evec.p : (float*)nullptr);
     hipError_t e = hipGetLastError();
+    if (e == hipSuccess && eig_values) e = hipMemcpyAsync(eig_values, d_ev, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost, tc->stream);
+    if (e == hipSuccess && eig_vectors) e = hipMemcpyAsync(eig_vectors, d_evec, (size_t)m * 9 * sizeof(float), hipMemcpyDeviceToHost, tc->stream);
     if (e == hipSuccess && matched_ids) { // keepMatchedIds: sorted positions -> the caller's indices
         e = d_ids.alloc((size_t)m * knn);
         if (e == hipSuccess && nn_ids_to_original(tc, tc->d_sidx, m * knn, d_ids) != ICPMI_OK) { c->last_error = tc->last_error; return ICPMI_ERR_HIP; }

@@ -509,20 +509,24 @@ struct CutAtDescriptorThresholdFilter : DataPointsFilter {
 };
 
 struct SurfaceNormalFilter : DataPointsFilter {
-    icpmi_handle h; int knn = 5; bool keepDensities = false, keepMatchedIds = false, keepMeanDist = false;
+    icpmi_handle h; int knn = 5; bool keepDensities = false, keepMatchedIds = false, keepMeanDist = false, keepEigenValues = false, keepEigenVectors = false;
     int surfaceNormalKnn() const override { return knn; }
     bool residentOp(icpmi_map_op& op, std::string&) const override {
         op = icpmi_map_op{}; op.type = ICPMI_MOP_SURFACE_NORMALS; op.i = knn;
         // the resident map does not track `densities`, `matchedIds` or `meanDist`
-        return knn >= 1 && knn <= 32 && !keepDensities && !keepMatchedIds && !keepMeanDist;
+        return knn >= 1 && knn <= 32 && !keepDensities && !keepMatchedIds && !keepMeanDist && !keepEigenValues && !keepEigenVectors;
     }
     void inPlaceFilter(DataPoints& c) const override {
         const size_t n = c.getNbPoints();
         std::vector<float> normals(3 * n), dens(keepDensities ? n : 0), md(keepMeanDist ? n : 0);
         std::vector<int32_t> ids(keepMatchedIds ? n * (size_t)knn : 0);
-        GpuICPSequence::check(h, icpmi_surface_normals_ex2(h, c.features.data(), (int64_t)n, knn, normals.data(), keepDensities ? dens.data() : nullptr,
-                                                           keepMatchedIds ? ids.data() : nullptr, keepMeanDist ? md.data() : nullptr));
+        std::vector<float> eva(keepEigenValues ? 3 * n : 0), eve(keepEigenVectors ? 9 * n : 0);
+        GpuICPSequence::check(h, icpmi_surface_normals_ex3(h, c.features.data(), (int64_t)n, knn, normals.data(), keepDensities ? dens.data() : nullptr,
+                                                           keepMatchedIds ? ids.data() : nullptr, keepMeanDist ? md.data() : nullptr,
+                                                           keepEigenValues ? eva.data() : nullptr, keepEigenVectors ? eve.data() : nullptr));
         c.addDescriptor("normals", 3, std::move(normals));
+        if (keepEigenValues) c.addDescriptor("eigValues", 3, std::move(eva));     // (upstream's descriptor names)
+        if (keepEigenVectors) c.addDescriptor("eigVectors", 9, std::move(eve));
         if (keepDensities) c.addDescriptor("densities", 1, std::move(dens));
         if (keepMatchedIds) { // upstream stores the ids as descriptor rows of the cloud's scalar type
             std::vector<float> f(ids.size());
@@ -877,10 +881,14 @@ std::shared_ptr<DataPointsFilter> createDataPointsFilter(const std::string& name
     if (name == "SurfaceNormalDataPointsFilter") {
         requireKnown(p, {"knn", "maxDist", "epsilon", "keepNormals", "keepDensities", "keepEigenValues", "keepEigenVectors",
                          "keepMatchedIds", "keepMeanDist", "sortEigen", "smoothNormals"}, name);
-        for (const char* k : {"keepEigenValues", "keepEigenVectors", "smoothNormals"})
-            if (geti(p, k, 0) != 0) throw InvalidParameter(name + ": " + k + " is not on the accelerated path");
+        if (geti(p, "smoothNormals", 0) != 0) throw InvalidParameter(name + ": smoothNormals is not on the accelerated path");
+        // r5: keepEigenValues / keepEigenVectors are served in ASCENDING eigenvalue order, i.e. together with sortEigen: 1; upstream's unsorted
+        // order is whatever Eigen::EigenSolver returns for the matrix at hand and is not reproduced
+        if ((geti(p, "keepEigenValues", 0) != 0 || geti(p, "keepEigenVectors", 0) != 0) && geti(p, "sortEigen", 0) == 0)
+            throw InvalidParameter(name + ": keepEigenValues / keepEigenVectors are served with sortEigen: 1 only (the unsorted order is the eigen-solver's)");
         auto f = std::make_shared<SurfaceNormalFilter>();
         f->h = ctx; f->knn = geti(p, "knn", 5); f->keepDensities = geti(p, "keepDensities", 0) != 0;
+        f->keepEigenValues = geti(p, "keepEigenValues", 0) != 0; f->keepEigenVectors = geti(p, "keepEigenVectors", 0) != 0;
         f->keepMatchedIds = geti(p, "keepMatchedIds", 0) != 0; f->keepMeanDist = geti(p, "keepMeanDist", 0) != 0;
         return f;
     }

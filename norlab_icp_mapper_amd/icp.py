@@ -414,6 +414,14 @@ class ICPSequence:
         self._check(self._lib.icpmi_surface_normals_ex(self._h, c.ctypes.data, c.shape[0], knn, out.ctypes.data, dens.ctypes.data))
         return out, dens
 
+    def surfaceNormalsEigen(self, cloud, knn=5):
+        """(normals, eigenvalues (m, 3) ascending, eigenvectors (m, 9): entry 3 k + j = component k of eigenvector j) --
+        SurfaceNormalDataPointsFilter with keepEigenValues / keepEigenVectors and sortEigen: 1 (icpmi_surface_normals_ex3)."""
+        c = _f32c(cloud, 4); m = c.shape[0]
+        out = np.empty((m, 3), dtype=np.float32); ev = np.empty((m, 3), dtype=np.float32); evec = np.empty((m, 9), dtype=np.float32)
+        self._check(self._lib.icpmi_surface_normals_ex3(self._h, c.ctypes.data, m, knn, out.ctypes.data, None, None, None, ev.ctypes.data, evec.ctypes.data))
+        return out, ev, evec
+
     def pointDistanceKeep(self, map_cloud, input_cloud, min_dist):
         m = _f32c(map_cloud, 4)
         i = _f32c(input_cloud, 4)

@@ -1190,6 +1190,27 @@ static void orc_surface_normals_impl(const float* pts4, int64_t m, int knn, floa
  * ascending distance), and the distance from the point to the mean of its neighbours.  Set before a call, consumed by it. */
 static int32_t* g_sn_ids_out = NULL; static float* g_sn_meandist_out = NULL;
 void orc_surface_normals_extras(int32_t* matched_ids, float* mean_dist) { g_sn_ids_out = matched_ids; g_sn_meandist_out = mean_dist; }
+/* keepEigenValues / keepEigenVectors with sortEigen: 1 (SurfaceNormal.cpp as recalled): the eigenvalues of C = NN NN^T (the centred
+ * neighbours' scatter matrix, NOT divided by the count) in ascending order, and serializeEigVec of the eigenvector matrix whose columns
+ * follow that order: entry 3 k + j = component k of eigenvector j.  A neighbourhood of rank < 2 gets upstream's degenerate answer
+ * (eigenvalues 0, eigenvectors identity).  The sign of an eigenvector is the Jacobi iteration's (upstream: Eigen's) -- compare up to sign.
+ * Set before a call, consumed by it. */
+static float* g_sn_eigval_out = NULL; static float* g_sn_eigvec_out = NULL;
+void orc_surface_normals_eigen(float* eig_values3, float* eig_vectors9) { g_sn_eigval_out = eig_values3; g_sn_eigvec_out = eig_vectors9; }
+static void orc_sn_store_eigen(int64_t i, const double* w, const double* Q, int degenerate)
+{
+    int o[3] = { 0, 1, 2 };
+    if (!degenerate) { /* ascending, stable: the exchange sort (0,1) (0,2) (1,2) with strict comparisons */
+        int t;
+        if (w[o[1]] < w[o[0]]) { t = o[0]; o[0] = o[1]; o[1] = t; }
+        if (w[o[2]] < w[o[0]]) { t = o[0]; o[0] = o[2]; o[2] = t; }
+        if (w[o[2]] < w[o[1]]) { t = o[1]; o[1] = o[2]; o[2] = t; }
+    }
+    for (int j = 0; j < 3; ++j) {
+        if (g_sn_eigval_out) g_sn_eigval_out[3 * i + j] = degenerate ? 0.f : (float)w[o[j]];
+        if (g_sn_eigvec_out) for (int k = 0; k < 3; ++k) g_sn_eigvec_out[9 * i + 3 * k + j] = degenerate ? (k == j ? 1.f : 0.f) : (float)Q[3 * o[j] + k];
+    }
+}
 void orc_surface_normals_ex(const float* pts4, int64_t m, int knn, float* normals3, float* densities, int nthreads)
 {
     orc_surface_normals_impl(pts4, m, knn, normals3, densities, nthreads, 0);
@@ -1250,6 +1271,7 @@ static void orc_surface_normals_impl(const float* pts4, int64_t m, int knn, floa
         double wmax = fmax(fabs(w[0]), fmax(fabs(w[1]), fabs(w[2])));
         int rank = 0;
         for (int e = 0; e < 3; ++e) if (fabs(w[e]) > 3.0 * FLT_EPSILON * wmax && wmax > 0) ++rank;
+        if (g_sn_eigval_out || g_sn_eigvec_out) orc_sn_store_eigen(i, w, Q, rank < 2);
         if (rank < 2) { normals3[3 * i] = 1.f; normals3[3 * i + 1] = 0.f; normals3[3 * i + 2] = 0.f; continue; }
         int e = 0;
         if (w[1] < w[e]) e = 1;
@@ -1257,7 +1279,7 @@ static void orc_surface_normals_impl(const float* pts4, int64_t m, int knn, floa
         for (int r = 0; r < 3; ++r) normals3[3 * i + r] = (float)Q[3 * e + r];
     }
     free(ids); free(d2); orc_kdtree_free(t);
-    g_sn_ids_out = NULL; g_sn_meandist_out = NULL;
+    g_sn_ids_out = NULL; g_sn_meandist_out = NULL; g_sn_eigval_out = NULL; g_sn_eigvec_out = NULL;
 }
 
 /* PointDistanceMapperModule::inPlaceUpdateMap keep mask (PointDistanceMapperModule.cpp:28-50):

@@ -175,6 +175,7 @@ int orc_icp_register(orc_icp* s, const float* scan4, int64_t n, const float* sca
 /* SurfaceNormalDataPointsFilter: kNN (self included) + smallest-eigenvector normal */
 void orc_surface_normals(const float* pts4, int64_t m, int knn, float* normals3, int nthreads);
 void orc_surface_normals_extras(int32_t* matched_ids /* knn x m */, float* mean_dist /* m */); /* outputs of the NEXT orc_surface_normals* call */
+void orc_surface_normals_eigen(float* eig_values3, float* eig_vectors9); /* keepEigenValues / keepEigenVectors, sortEigen 1: consumed by the next call */
 void orc_surface_normals_ex(const float* pts4, int64_t m, int knn, float* normals3, float* densities, int nthreads);
 /* planar clouds: the normal is the smaller eigenvector of the 2 x 2 covariance of (x, y), z component 0 */
 void orc_surface_normals_2d(const float* pts4, int64_t m, int knn, float* normals3, int nthreads);

@@ -282,6 +282,16 @@ def surface_normals_extras(cloud, knn=5, nthreads=1):
     return out, ids, md
 
 
+def surface_normals_eigen(cloud, knn=5, nthreads=1):
+    """(normals, eigenvalues (m, 3) ascending, serialised eigenvectors (m, 9)): keepEigenValues / keepEigenVectors with sortEigen 1"""
+    lib = load(); cloud = _f32(cloud); m = cloud.shape[0]
+    out = np.empty((m, 3), dtype=np.float32); ev = np.empty((m, 3), dtype=np.float32); evec = np.empty((m, 9), dtype=np.float32)
+    lib.orc_surface_normals_eigen.argtypes = [_P, _P]; lib.orc_surface_normals_eigen.restype = None
+    lib.orc_surface_normals_eigen(ev.ctypes.data, evec.ctypes.data)
+    lib.orc_surface_normals(cloud.ctypes.data, m, knn, out.ctypes.data, nthreads)
+    return out, ev, evec
+
+
 def surface_normals(cloud, knn=5, nthreads=1, with_densities=False, planar=False):
     lib = load(); cloud = _f32(cloud); out = np.empty((cloud.shape[0], 3), dtype=np.float32)
     if planar:  # 2-D clouds (z == 0): the smaller eigenvector of the 2 x 2 covariance

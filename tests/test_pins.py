@@ -91,3 +91,73 @@ def test_max_density_numpy_vector(oracle, max_density, seed):
         c = np.ones((dens.shape[0], 4), np.float32); c[:, 0] = np.arange(dens.shape[0], dtype=np.float32)
         out, _, _ = hb.filter_chain("[{MaxDensityDataPointsFilter: {maxDensity: %r, seed: %d}}]" % (max_density, seed), c, desc_name="densities", desc=dens)
         assert np.array_equal(out[:, 0].astype(np.int64), np.nonzero(want)[0])
+
+
+# ---- SurfaceNormalDataPointsFilter{keepEigenValues, keepEigenVectors, sortEigen: 1} (r5) -------------------------------------------------
+def _eigh_reference(cloud, knn):
+    """numpy / scipy restatement: scatter matrix NN NN^T of the knn neighbours (self included) about their mean, numpy.linalg.eigh (ascending)"""
+    from scipy.spatial import cKDTree
+    xyz = cloud[:, :3].astype(np.float64)
+    _, ids = cKDTree(xyz).query(xyz, k=knn)
+    nb = xyz[ids]                                            # (m, knn, 3)
+    c = nb - nb.mean(axis=1, keepdims=True)
+    S = np.einsum("mki,mkj->mij", c, c)
+    w, v = np.linalg.eigh(S)                                 # ascending, columns = eigenvectors
+    return w, v
+
+
+def _check_eigen_against_numpy(ev, evec, normals, cloud, knn):
+    w, v = _eigh_reference(cloud, knn)
+    scale = np.abs(w).max(axis=1, keepdims=True) + 1e-30
+    assert np.all(np.diff(ev, axis=1) >= 0)                                         # ascending
+    assert np.max(np.abs(ev - w) / scale) < 2e-5
+    V = evec.reshape(-1, 3, 3)                                                      # V[i, k, j] = component k of eigenvector j
+    gap_ok = (np.diff(w, axis=1).min(axis=1) > 1e-3 * scale[:, 0])                  # an eigenvector is defined up to sign where its value is simple
+    dots = np.abs(np.einsum("mkj,mkj->mj", V.astype(np.float64), v))
+    assert gap_ok.mean() > 0.9 and np.all(dots[gap_ok] > 1 - 1e-4)
+    assert np.array_equal(V[gap_ok][:, :, 0], normals[gap_ok])                      # the normal IS the first (smallest) eigenvector
+
+
+def test_oracle_surface_normal_eigen_outputs_match_numpy_eigh(oracle):
+    rng = np.random.default_rng(5)
+    cloud = np.ones((3000, 4), np.float32)
+    cloud[:, :3] = (rng.uniform(-1, 1, (3000, 3)) * [6.0, 4.0, 0.3]).astype(np.float32)
+    nrm, ev, evec = oracle.surface_normals_eigen(cloud, knn=9, nthreads=4)
+    assert np.array_equal(nrm, oracle.surface_normals(cloud, knn=9, nthreads=4))   # asking for the eigen outputs changes nothing else
+    _check_eigen_against_numpy(ev, evec, nrm, cloud, 9)
+    # a rank-1 neighbourhood (points on a line): upstream's degenerate answer -- eigenvalues 0, eigenvectors identity, normal (1, 0, 0)
+    line = np.ones((50, 4), np.float32); line[:, 0] = np.arange(50, dtype=np.float32) * 0.1; line[:, 1:3] = 0
+    nrm, ev, evec = oracle.surface_normals_eigen(line, knn=5)
+    assert np.all(ev == 0) and np.array_equal(evec, np.tile(np.eye(3, dtype=np.float32).reshape(-1), (50, 1))) and np.all(nrm == [1, 0, 0])
+
+
+@pytest.mark.gpu
+def test_device_surface_normal_eigen_outputs_match_oracle_and_numpy(oracle):
+    import norlab_icp_mapper_amd as pkg
+    rng = np.random.default_rng(6)
+    cloud = np.ones((20000, 4), np.float32)
+    cloud[:, :3] = (rng.uniform(-1, 1, (20000, 3)) * [20.0, 12.0, 0.5]).astype(np.float32)
+    cloud[:5000, 2] = 0.0                                    # a flat patch: the smallest eigenvalue is exactly 0 there
+    icp = pkg.ICPSequence()
+    nrm, ev, evec = icp.surfaceNormalsEigen(cloud, knn=10)
+    o_nrm, o_ev, o_evec = oracle.surface_normals_eigen(cloud, knn=10, nthreads=8)
+    assert np.array_equal(nrm, icp.surfaceNormals(cloud, knn=10))
+    flip = np.sign((nrm * o_nrm).sum(1)); flip[flip == 0] = 1   # (the suite compares normals up to sign)
+    assert np.allclose(nrm * flip[:, None], o_nrm, atol=1e-6)
+    assert np.allclose(ev, o_ev, rtol=1e-6, atol=1e-9)
+    assert np.allclose(np.abs(evec), np.abs(o_evec), atol=2e-5) or np.mean(np.abs(np.abs(evec) - np.abs(o_evec)) < 2e-5) > 0.999
+    _check_eigen_against_numpy(ev, evec, nrm, cloud, 10)
+    line = np.ones((64, 4), np.float32); line[:, 0] = np.arange(64, dtype=np.float32) * 0.1; line[:, 1:3] = 0
+    nrm, ev, evec = icp.surfaceNormalsEigen(line, knn=5)
+    assert np.all(ev == 0) and np.array_equal(evec, np.tile(np.eye(3, dtype=np.float32).reshape(-1), (64, 1)))
+
+
+def test_host_filter_serves_eigen_descriptors_only_sorted():
+    import host_bindings as hb
+    if not os.path.exists(hb.LIB):
+        pytest.skip("host shell not built")
+    c = np.ones((10, 4), np.float32)
+    with pytest.raises(RuntimeError, match="sortEigen"):
+        hb.filter_chain("[{SurfaceNormalDataPointsFilter: {knn: 5, keepEigenValues: 1}}]", c)
+    with pytest.raises(RuntimeError, match="smoothNormals"):
+        hb.filter_chain("[{SurfaceNormalDataPointsFilter: {knn: 5, smoothNormals: 1}}]", c)
