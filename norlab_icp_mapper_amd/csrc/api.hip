@@ -155,6 +155,7 @@ icpmi_status icpmi_create(const icpmi_config* cfg, icpmi_handle* out)
     CR(hipHostMalloc((void**)&c->h_pin, ICPMI_PIN_BYTES + ICPMI_UP_SLOT * ICPMI_UP_SLOTS, hipHostMallocDefault));
     CR(hipHostMalloc((void**)&c->h_nocc, 64, hipHostMallocDefault));
     *c->h_nocc = 0;
+    if (hipHostGetDevicePointer((void**)&c->d_nocc_host, c->h_nocc, 0) != hipSuccess) c->d_nocc_host = nullptr; // (then the copy launch stays)
     CR(hipHostMalloc((void**)&c->h_progress, ICPMI_PROGRESS_WORDS * sizeof(unsigned), hipHostMallocMapped)); // words 0..15: progress per reading of a batch; word 32: sequence number of the registration being launched
     memset(c->h_progress, 0, ICPMI_PROGRESS_WORDS * sizeof(unsigned));
     CR(hipHostGetDevicePointer((void**)&c->d_progress, c->h_progress, 0));

@@ -309,6 +309,7 @@ struct icpmi_ctx {
     IcpState* h_state = nullptr;                               // pinned mirror (ICPMI_MAX_BATCH)
     int batch_cur = 1;                                         // readings of the launch sequence being enqueued (set by the loop)
     BatchArgs batch_args{};                                    // their sizes / slice stride
+    unsigned* d_nocc_host = nullptr; bool nocc_by_scan = false; // device address of h_nocc; the pending occupancy word is delivered by the build's scan
     unsigned* h_nocc = nullptr; int64_t nocc_m = 0;            // pinned word: occupied cells of the last index build, and that build's point count (map_build)
     unsigned char* h_pin = nullptr;                            // pinned page: [0, ICPMI_PIN_BYTES) small read-backs, behind it the ring of upload_small
     unsigned up_next = 0;
@@ -557,7 +558,7 @@ icpmi_status device_exclusive_scan_io(icpmi_ctx* c, const unsigned* in, unsigned
 // its slots with atomicAdd(&starts[key + 1], len) and leaves the plain exclusive scan behind.  zero_counts: counts[0 .. n + 1] end up zero.
 icpmi_status device_scan_flags_count(icpmi_ctx* c, const unsigned* flag, unsigned* pos, int n, int64_t* count); // pos = exclusive scan of the 0 / 1 flags, *count = how many are set (one stream wait, no copy)
 icpmi_status device_exclusive_scan_sum(icpmi_ctx* c, const unsigned* flag, unsigned* pos, int n, unsigned* d_sum); // ... the count stays on the device
-icpmi_status device_exclusive_scan_cursor(icpmi_ctx* c, unsigned* counts, unsigned* starts, int n, unsigned total, bool zero_counts);
+icpmi_status device_exclusive_scan_cursor(icpmi_ctx* c, unsigned* counts, unsigned* starts, int n, unsigned total, bool zero_counts, unsigned* tail_out = nullptr); // tail_out: receives counts[n + 1]
 icpmi_status sort_queries(icpmi_ctx* c, const float4* d_pts, int64_t n);
 icpmi_status sort_queries_reserve(icpmi_ctx* c, int64_t n, int nscan = 1);
 icpmi_status sort_queries_batch(icpmi_ctx* c, const float4* d_pts, const BatchArgs& ba, const SortHead* head = nullptr); // slices of d_pts -> slices of d_qsorted / d_qindex

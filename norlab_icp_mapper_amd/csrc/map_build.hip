@@ -217,7 +217,8 @@ __global__ __launch_bounds__(SCAN_T) void scan2_sums_kernel(const unsigned* __re
 // shift / zero_in need in != out.
 __global__ __launch_bounds__(SCAN_T) void scan2_final_kernel(const unsigned* __restrict__ in, unsigned* __restrict__ out, int n,
                                                              const unsigned* __restrict__ sums, unsigned total, int shift, unsigned* __restrict__ zero_in,
-                                                             unsigned* __restrict__ sum_out = nullptr /* the sum of in[0..n): e.g. a word of host-mapped memory */)
+                                                             unsigned* __restrict__ sum_out = nullptr /* the sum of in[0..n): e.g. a word of host-mapped memory */,
+                                                             unsigned* __restrict__ tail_out = nullptr /* receives in[n + 1] (a grid build's occupancy word) before it is zeroed */)
 {
     __shared__ unsigned sh[SCAN_T / 64];
     const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_E;
@@ -236,6 +237,7 @@ __global__ __launch_bounds__(SCAN_T) void scan2_final_kernel(const unsigned* __r
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         out[n + shift] = total;
         if (shift) out[0] = 0u;
+        if (tail_out) *tail_out = in[n + 1];
         if (zero_in) { zero_in[n] = 0u; zero_in[n + 1] = 0u; }
     }
 }
@@ -715,18 +717,19 @@ static int scan2_enabled()
 // atomicAdd(&starts[key + 1], len): when every point is placed, starts[i + 1] has grown to the start of cell i + 1 -- the array IS the plain
 // exclusive scan, with no second table of fill cursors to clear (r4: two memsets per grid, three to four launches).  The counts are left
 // ZERO (c->fill_clean): the next build counts into them as they are.  starts needs n + 2 words.
-icpmi_status device_exclusive_scan_cursor(icpmi_ctx* c, unsigned* counts, unsigned* starts, int n, unsigned total, bool zero_counts)
+icpmi_status device_exclusive_scan_cursor(icpmi_ctx* c, unsigned* counts, unsigned* starts, int n, unsigned total, bool zero_counts, unsigned* tail_out)
 {
     const int nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
     if (ensure_cap(c, &c->d_blocksums, &c->cap_blocksums, (size_t)nb + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
     if (scan2_enabled() && nb <= SCAN2_MAX_NB) {
         hipLaunchKernelGGL(scan2_sums_kernel, dim3(nb > 0 ? nb : 1), dim3(SCAN_T), 0, c->stream, (const unsigned*)counts, n, c->d_blocksums);
         hipLaunchKernelGGL(scan2_final_kernel, dim3(nb > 0 ? nb : 1), dim3(SCAN_T), 0, c->stream, (const unsigned*)counts, starts, n, (const unsigned*)c->d_blocksums, total, 1,
-                           zero_counts ? counts : (unsigned*)nullptr);
+                           zero_counts ? counts : (unsigned*)nullptr, (unsigned*)nullptr, tail_out);
         HIP_TRY(c, hipGetLastError());
         return ICPMI_OK;
     }
     // very large tables: the three-kernel scan on a copy, the zero word in front, the counts cleared by a memset
+    if (tail_out) HIP_TRY(c, hipMemcpyAsync(tail_out, counts + n + 1, sizeof(unsigned), hipMemcpyDefault, c->stream));
     HIP_TRY(c, hipMemcpyAsync(starts + 1, counts, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(starts, 0, sizeof(unsigned), c->stream));
     const icpmi_status s = device_exclusive_scan_io(c, starts + 1, starts + 1, n, total);
@@ -735,9 +738,9 @@ icpmi_status device_exclusive_scan_cursor(icpmi_ctx* c, unsigned* counts, unsign
     return ICPMI_OK;
 }
 
-static icpmi_status device_scan_counts_to_cursors(icpmi_ctx* c, unsigned* counts, unsigned* starts, int n, unsigned total)
+static icpmi_status device_scan_counts_to_cursors(icpmi_ctx* c, unsigned* counts, unsigned* starts, int n, unsigned total, unsigned* tail_out = nullptr)
 {
-    const icpmi_status s = device_exclusive_scan_cursor(c, counts, starts, n, total, true);
+    const icpmi_status s = device_exclusive_scan_cursor(c, counts, starts, n, total, true, tail_out);
     if (s == ICPMI_OK) c->fill_clean = true;
     return s;
 }
@@ -832,7 +835,11 @@ static icpmi_status grid_count(icpmi_ctx* c, const float4* d_pts, int64_t m, con
     hipLaunchKernelGGL(key_kernel, dim3(blocks), dim3(256), 0, c->stream, d_pts, m, c->mean[0], c->mean[1], c->mean[2], g,
                        c->d_keys, c->d_fill, d_nocc, run_atomics_cfg());
     HIP_TRY(c, hipGetLastError());
-    if (!h_nocc) { HIP_TRY(c, hipMemcpyAsync(c->h_nocc, d_nocc, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream)); return ICPMI_OK; }
+    if (!h_nocc) { // not waited for: the scan that turns these counts into starts writes the word to the pinned page (no copy launch)
+        if (c->d_nocc_host) c->nocc_by_scan = true;
+        else HIP_TRY(c, hipMemcpyAsync(c->h_nocc, d_nocc, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        return ICPMI_OK;
+    }
     if (read_back(c, h_nocc, d_nocc, sizeof(unsigned)) != ICPMI_OK) return ICPMI_ERR_HIP;
     return ICPMI_OK;
 }
@@ -1122,7 +1129,8 @@ grid_chosen:
     c->n_occupied = n_occ;
 
     // ---- exclusive scan of the histogram: counts (c->d_fill, left zero) -> cell starts in cursor layout ----
-    if (device_scan_counts_to_cursors(c, c->d_fill, c->d_cell_start, g.ncells, (unsigned)m) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (device_scan_counts_to_cursors(c, c->d_fill, c->d_cell_start, g.ncells, (unsigned)m, (c->nocc_by_scan && c->d_nocc_host) ? c->d_nocc_host : nullptr) != ICPMI_OK) return ICPMI_ERR_HIP;
+    c->nocc_by_scan = false;
 
     // ---- scatter ----
     if (ensure_cap(c, &c->d_map_sorted, &c->cap_map, (size_t)m + 16) != ICPMI_OK) return ICPMI_ERR_HIP;
