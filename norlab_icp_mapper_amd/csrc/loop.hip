@@ -718,6 +718,9 @@ __global__ __launch_bounds__(256) void solve_kernel(IcpState* __restrict__ st, u
     st += blockIdx.x;
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(hists + (size_t)blockIdx.x * ICPMI_SELHIST_WORDS + ICPMI_S2_ACC);
     if (progress) progress += blockIdx.x;
+    // (r5: the brute pass's queue is emptied here instead of by a one-thread launch of its own behind every NN launch of a chain with an
+    //  unbounded maxDist -- the next NN launch starts behind this kernel)
+    if (threadIdx.x == 0 && st->hard_count) { st->hard_total += st->hard_count; st->hard_count = 0; }
     if (st->done) { // finished earlier, or an upstream kernel of this iteration raised an error
         if (threadIdx.x == 0) publish_progress(st, progress);
         return;

@@ -74,10 +74,14 @@ __device__ __forceinline__ void row_run(const GridParams& g, const unsigned* __r
 }
 
 // Brute-force pass for the queued queries (k = 1): one workgroup per query streams the whole map.
+// match_pt != nullptr (r5): the loop state is kept in QUERY order (`reading` = the tile-sorted queries, the queue holds query slots): the
+// matched point goes next to the match, and -- hist0 != nullptr -- the match joins the level-0 selection histogram the NN kernel built for
+// the queries it decided itself (csrc/loop.hip, fused selection; copy 0 of the privatised tables).
 __global__ __launch_bounds__(NN_BLOCK) void nn1_hard_kernel(const float4* __restrict__ reading, const float* __restrict__ Tptr,
                                                             const float4* __restrict__ map, int m, float maxr2, int allow_self,
                                                             int* __restrict__ out_sidx, float* __restrict__ out_d2,
-                                                            IcpState* __restrict__ st, const unsigned* __restrict__ hard)
+                                                            IcpState* __restrict__ st, const unsigned* __restrict__ hard,
+                                                            float4* __restrict__ match_pt = nullptr, unsigned* __restrict__ hist0 = nullptr)
 {
     if (st->done) return;
     const unsigned nh = st->hard_count;
@@ -102,6 +106,12 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_hard_kernel(const float4* __rest
             if (bs < 0 || !(bd2 <= maxr2)) { bs = -1; bd2 = INFINITY; }
             out_sidx[qi] = bs;
             out_d2[qi] = bd2;
+            if (match_pt) match_pt[qi] = bs >= 0 ? map[bs] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (hist0 && bd2 != INFINITY && bd2 > 0.f) {
+                const unsigned bits = __float_as_uint(bd2);
+                atomicAdd(&hist0[ICPMI_S2_C0 + (bits >> 24)], 1u);
+                atomicAdd(&hist0[ICPMI_S2_F0 + ICPMI_S2_FIDX(bits >> 16)], 1u);
+            }
         }
         __syncthreads();
     }
@@ -1345,7 +1355,7 @@ __global__ __launch_bounds__(64 * NW) void nn1_wg_kernel(const float4* __restric
     if (!found) bd2 = INFINITY;
     const bool writer = active;
     if (hist0) { // coarse level-0 histogram through LDS first: its barrier must not sit behind the global stores below
-        if (writer && bd2 != INFINITY && bd2 > 0.f) atomicAdd(&lh[__float_as_uint(bd2) >> 24], 1u);
+        if (writer && decided && bd2 != INFINITY && bd2 > 0.f) atomicAdd(&lh[__float_as_uint(bd2) >> 24], 1u); // (a queued query joins the histogram in the brute pass)
         __syncthreads();
         for (int t = tid; t < 256; t += NT)
             if (lh[t]) atomicAdd(&hist0[ICPMI_S2_C0 + (blockIdx.x % ICPMI_S2_COPIES) * 256 + t], lh[t]);
@@ -1365,13 +1375,13 @@ __global__ __launch_bounds__(64 * NW) void nn1_wg_kernel(const float4* __restric
         st_stream(out_sidx + orig, bs);
         st_stream(out_d2 + orig, bd2);
         if (match_pt) st_stream(match_pt + orig, make_float4(mpt.x, mpt.y, mpt.z, __uint_as_float((unsigned)(best.key & 0xffffffffull))));
-        if (hist0 && bd2 != INFINITY && bd2 > 0.f) {
+        if (hist0 && decided && bd2 != INFINITY && bd2 > 0.f) {
             const unsigned bits = __float_as_uint(bd2);
             atomicAdd(&hist0[ICPMI_S2_F0 + (blockIdx.x % ICPMI_S2_FCOPIES) * 65536 + ICPMI_S2_FIDX(bits >> 16)], 1u);
         }
         if (!decided) {
             const unsigned hslot = atomicAdd(&st->hard_count, 1u);
-            hard[hslot] = (unsigned)(qindex ? qindex[qi] : qi); // the brute pass works on the caller's order
+            hard[hslot] = (unsigned)(match_pt ? qi : (qindex ? qindex[qi] : qi)); // the brute pass works on the order the state is kept in
         }
     }
 #ifdef ICPMI_NN_TIMING
@@ -2366,11 +2376,20 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
         const int unseeded_lev = unseeded_lev_cfg < c->levels.nlev ? unseeded_lev_cfg : c->levels.nlev - 1;
         static int fuse_h0 = -1;
         if (fuse_h0 < 0) { const char* e = getenv("ICPMI_NN_FUSE_HIST0"); fuse_h0 = e ? atoi(e) : 1; }
-        unsigned* h0 = (needs_hard || !fuse_h0) ? nullptr : c->nn_hist0;
+        // r5: a chain that may need the brute pass (unbounded maxDist -- PM::ICPSequence::setDefault() --, or a maxDist beyond the top level's
+        // block) used to fall off the fast path altogether: state in the caller's order, no fused histogram, no matched points.  With the
+        // four-wave kernel the queue now holds query slots and the brute pass writes the same state (point, histogram) for what it decides.
+        static int hard_sorted_cfg = -1;
+        if (hard_sorted_cfg < 0) {
+            const char* e = getenv("ICPMI_HARD_SORTED"); hard_sorted_cfg = e ? atoi(e) : 1;
+            const char* wq = getenv("ICPMI_NN_WQ"); const char* wg = getenv("ICPMI_NN_WG");
+            if ((wq && atoi(wq) == 0) || (wg && atoi(wg) != 4)) hard_sorted_cfg = 0; // (only nn1_wg_kernel<4, ..> queues slots)
+        }
+        const bool hard_sorted = needs_hard && hard_sorted_cfg && allow_self && sorted && c->batch_cur <= 1;
+        unsigned* h0 = ((needs_hard && !hard_sorted) || !fuse_h0) ? nullptr : c->nn_hist0;
         c->nn_builds_hist0 = h0 != nullptr;
-        // loop mode keeps the per-query state in query order; the brute-force pass works in the caller's
-        // order, so chains that may need it stay on original indices
-        float4* mp = (needs_hard || !sorted) ? nullptr : c->nn_match_pt;
+        // loop mode keeps the per-query state in query order
+        float4* mp = ((needs_hard && !hard_sorted) || !sorted) ? nullptr : c->nn_match_pt;
         c->nn_out_sorted = mp != nullptr;
         static int seed_pre_cfg = -1;
         if (seed_pre_cfg < 0) { const char* e = getenv("ICPMI_NN_SEED_PRE"); seed_pre_cfg = e ? atoi(e) : 2; }
@@ -2440,9 +2459,14 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
 #undef LAUNCH_WQ2
         const GridParams& top = c->levels.g[c->levels.nlev - 1];
         if (!std::isfinite(lc.max_dist) || (top.cell - top.slack) <= lc.max_dist) {
+            if (hard_sorted && mp)
+                hipLaunchKernelGGL(nn1_hard_kernel, dim3(512), dim3(NN_BLOCK), 0, c->stream, q, d_T, c->d_map_sorted, (int)c->m,
+                                   lc.maxr2, allow_self, d_sidx, d_d2, d_state, c->d_hard, mp, c->nn_builds_hist0 ? c->nn_hist0 : (unsigned*)nullptr);
+            else
             hipLaunchKernelGGL(nn1_hard_kernel, dim3(512), dim3(NN_BLOCK), 0, c->stream, d_reading, d_T, c->d_map_sorted, (int)c->m,
                                lc.maxr2, allow_self, d_sidx, d_d2, d_state, c->d_hard);
-            hipLaunchKernelGGL(hard_reset_kernel, dim3(1), dim3(64), 0, c->stream, d_state);
+            // (the loop's solve_kernel empties the queue; a stage call -- icpmi_knn -- has no solve behind it)
+            if (!(hard_sorted && mp)) hipLaunchKernelGGL(hard_reset_kernel, dim3(1), dim3(64), 0, c->stream, d_state);
         }
         HIP_TRY(c, hipGetLastError());
         return ICPMI_OK;
