@@ -191,6 +191,7 @@ void icpmi_destroy(icpmi_handle c)
     if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
     if (c->bgraph_exec) hipGraphExecDestroy(c->bgraph_exec);
     for (int g = 0; g < 2; ++g) if (c->seg_exec[g]) hipGraphExecDestroy(c->seg_exec[g]);
+    for (auto& hd : c->seg_heads) if (hd.exec) hipGraphExecDestroy(hd.exec);
     hipFree(c->d_map_sorted); hipFree(c->d_normals_sorted); hipFree(c->d_cell_start);
     for (int l = 0; l < ICPMI_MAXLEV; ++l) { hipFree(c->d_lvl_pts[l]); hipFree(c->d_lvl_cs[l]); hipFree(c->d_lvl_pos0[l]); }
     hipFree(c->d_inv);

@@ -329,6 +329,10 @@ struct icpmi_ctx {
     // checked loops (Counter + Differential / Bound: what Mapper::processInput runs) as SEGMENT graphs: [0] = head + the first
     // seg_len iterations, [1] = seg_len further iterations, replayed while the progress word says the loop is still running
     hipGraphExec_t seg_exec[2] = {nullptr, nullptr}; uint64_t seg_sig = 0; int64_t seg_n = -1; int seg_len = 0; bool seg_sorted = false;
+    // r5: head graphs of OTHER lengths (head + L iterations, L = the iteration count of the handle's previous checked registration): a mapper's
+    // registrations stop after about the same number of iterations scan after scan, and a head graph of exactly that length has no dead iterations
+    struct SegHead { int len = 0; hipGraphExec_t exec = nullptr; unsigned long used = 0; } seg_heads[4];
+    int seg_prev_iters = 0, seg_last_iters = 0; unsigned long seg_clock = 0;
 
     // buffers of the map-growth epoch (ops.hip: ops_staged_merge_allgather): this rank's accepted points, all ranks' blocks, the merged set
     float4* d_merge_send = nullptr; size_t cap_merge_send = 0;
@@ -379,6 +383,7 @@ static inline void drop_loop_graphs(icpmi_ctx* c)
     if (c->bgraph_exec) { hipGraphExecDestroy(c->bgraph_exec); c->bgraph_exec = nullptr; }
     c->bgraph_sig = 0;
     for (int g = 0; g < 2; ++g) if (c->seg_exec[g]) { hipGraphExecDestroy(c->seg_exec[g]); c->seg_exec[g] = nullptr; }
+    for (auto& hd : c->seg_heads) { if (hd.exec) hipGraphExecDestroy(hd.exec); hd.exec = nullptr; hd.len = 0; }
     c->seg_sig = 0; c->seg_n = -1;
 }
 

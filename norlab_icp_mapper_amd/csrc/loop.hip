@@ -1267,6 +1267,7 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
         sig = fnv(&c->grid, sizeof c->grid, sig);
         if (!c->seg_exec[0] || !c->seg_exec[1] || c->seg_n != n || c->seg_len != S || c->seg_sig != sig) {
             for (int g = 0; g < 2; ++g) if (c->seg_exec[g]) { hipGraphExecDestroy(c->seg_exec[g]); c->seg_exec[g] = nullptr; }
+            for (auto& hd : c->seg_heads) { if (hd.exec) hipGraphExecDestroy(hd.exec); hd.exec = nullptr; hd.len = 0; } // (captured the same pointers)
             for (int g = 0; g < 2; ++g) {
                 hipGraph_t gr = nullptr;
                 HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
@@ -1282,12 +1283,45 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
             }
             c->seg_n = n; c->seg_len = S; c->seg_sig = sig; c->seg_sorted = c->nn_out_sorted;
         }
-        HIP_TRY(c, hipGraphLaunch(c->seg_exec[0], c->stream));
+        // r5: the head graph's length follows the handle's previous checked registration.  A mapper registers scan after scan against almost
+        // the same map from almost the same prior: the loop stops after the same few iterations every time (6 in the benchmark scene), and
+        // head + 4 followed by a segment of 4 ran two dead iterations (eight early-exit launches, ~24 us of a 0.37 ms registration) behind the
+        // stop.  With a head of exactly the previous count the host waits for that head to finish (no look-ahead: the prediction says the loop
+        // is over) and goes on with ordinary segments only if it is not.  ICPMI_SEG_ADAPT=0: always head + S.
+        static int adapt_cfg = -1;
+        if (adapt_cfg < 0) { const char* e = getenv("ICPMI_SEG_ADAPT"); adapt_cfg = e ? atoi(e) : 1; }
+        hipGraphExec_t head_exec = c->seg_exec[0];
+        int head_len = S;
+        if (adapt_cfg && c->seg_prev_iters >= 2 && c->seg_prev_iters != S && c->seg_prev_iters <= 24 && c->seg_prev_iters < lc.max_iter) {
+            const int L = c->seg_prev_iters;
+            icpmi_ctx::SegHead* slot = nullptr;
+            for (auto& hd : c->seg_heads) if (hd.exec && hd.len == L) slot = &hd;
+            if (!slot) {
+                slot = &c->seg_heads[0];
+                for (auto& hd : c->seg_heads) if (!hd.exec) { slot = &hd; break; } else if (hd.used < slot->used) slot = &hd;
+                if (slot->exec) { hipGraphExecDestroy(slot->exec); slot->exec = nullptr; slot->len = 0; }
+                hipGraph_t gr = nullptr;
+                HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+                icpmi_status hs = enqueue_registration_head(c, d_scan, d_normals3, n);
+                for (int it = 0; it < L && hs == ICPMI_OK; ++it) { c->nn_iter_hint = it; hs = enqueue_iteration(c, n, lc, nullptr, nullptr); }
+                hipError_t ce = hipStreamEndCapture(c->stream, &gr);
+                if (hs != ICPMI_OK) { if (gr) hipGraphDestroy(gr); return hs; }
+                HIP_TRY(c, ce);
+                hipError_t ie = hipGraphInstantiate(&slot->exec, gr, nullptr, nullptr, 0);
+                hipGraphDestroy(gr);
+                HIP_TRY(c, ie);
+                slot->len = L;
+            }
+            slot->used = ++c->seg_clock;
+            head_exec = slot->exec; head_len = L;
+        }
+        HIP_TRY(c, hipGraphLaunch(head_exec, c->stream));
         if (c->cfg.knn <= 8) { c->qsorted_n = n; c->qsorted_src = c->d_reading; } // what the replayed head leaves in d_qsorted
-        int launched = S;
-        const int lead = S > 1 ? S / 2 : 1;
+        int launched = head_len;
         bool stopped = false;
         while (launched < lc.max_iter && !stopped) {
+            // (behind a predicted head: no look-ahead -- the next segment goes out only once the head has run and the loop is still going)
+            const int lead = (launched == head_len && head_len != S) ? 0 : (S > 1 ? S / 2 : 1);
             for (unsigned spins = 1;; ++spins) {
                 const unsigned v = __atomic_load_n(c->h_progress, __ATOMIC_ACQUIRE);
                 if (((v >> 12) & 0x7ffffu) == c->reg_seq) {
@@ -1409,6 +1443,12 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
     HIP_TRY(c, hipStreamSynchronize(c->stream));
 
     fill_stats(c, lc, n, stats);
+    if (segmented) { // what the next checked registration's head graph is cut to (the larger of the last two counts: one dead iteration costs
+                     // less than a head that ends one iteration early and a segment behind it)
+        const int it_now = c->h_state->error ? 0 : c->h_state->iter;
+        c->seg_prev_iters = it_now > c->seg_last_iters ? it_now : c->seg_last_iters;
+        c->seg_last_iters = it_now;
+    }
     if (stats) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) stats->loop_ms = ms;

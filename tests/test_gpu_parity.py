@@ -256,6 +256,42 @@ def test_graph_and_eager_agree(amd, mid_scene):
     assert np.array_equal(out[0], out[1])
 
 
+def test_checked_loop_head_graph_follows_the_previous_iteration_count(amd, oracle, mid_scene):
+    """r5: the head graph of a checked registration (Counter + Differential: what Mapper::processInput runs) is cut to the iteration count of
+    the handle's previous registrations; a scan that needs more iterations than predicted goes on with ordinary segments, one that needs
+    fewer runs dead iterations.  Scans of different difficulty in turn on ONE handle: every result must be the oracle's (iterations, stop
+    reason, pose bit for bit with the eager loop of a fresh handle)."""
+    sc = mid_scene
+    kw = dict(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=40, use_differential=1)
+    rng = np.random.default_rng(3)
+    scans = [sc["scan"]]
+    for shift, yaw in ((0.02, 0.0), (1.2, 0.0), (0.0, 0.12), (0.5, -0.06)):   # closer to / farther from the map: fewer / more iterations
+        cy, sy = np.float32(np.cos(yaw)), np.float32(np.sin(yaw))
+        s2 = sc["scan"].copy()
+        s2[:, 0], s2[:, 1] = cy * s2[:, 0] - sy * s2[:, 1] + np.float32(shift), sy * sc["scan"][:, 0] + cy * s2[:, 1] - np.float32(shift / 2)
+        scans.append(s2)
+    scans.append(sc["scan"][rng.permutation(sc["scan"].shape[0])[:7000]].copy())   # another size: the graphs are rebuilt
+    icp = amd.ICPSequence(**kw)
+    icp.setMap(sc["map"], sc["normals"])
+    ref = amd.ICPSequence(use_graph=0, **kw)
+    ref.setMap(sc["map"], sc["normals"])
+    counts = []
+    for rep in range(2):
+        for s in scans + scans[::-1]:
+            T = icp(s); it, why = icp.stats.iterations, icp.stats.stop_reason
+            Tr = ref(s)
+            assert (it, why) == (ref.stats.iterations, ref.stats.stop_reason)
+            assert np.array_equal(T, Tr)
+            counts.append(it)
+    assert len(set(counts)) >= 3, counts              # the sequence really alternates between different loop lengths
+    o = oracle.OracleICP(oracle.make_config(nthreads=8, **kw)); o.setMap(sc["map"], sc["normals"])
+    for s in scans[:3]:
+        _, To = o(s); T = icp(s)
+        assert icp.stats.iterations == o.stats.iterations
+        dt, dr = amd.synth.pose_error(T, To)
+        assert dt <= 1e-4 and dr <= 1e-4
+
+
 @pytest.mark.parametrize("minimizer", [1, 2])
 def test_registration_is_bitwise_reproducible(amd, mid_scene, minimizer):
     """The loop keeps its state and runs its pair sums in tile-sorted query order; that order comes
