@@ -71,9 +71,12 @@ typedef enum {
      * hard: w = desc > threshold (useLargerThan) or desc < threshold; soft: w = desc.  source: reading (iparam | ICPMI_GEN_SOURCE_READING,
      * v4): the descriptor of the READING point decides -- its row is handed over with icpmi_set_reading_scalar before every registration. */
     ICPMI_OUT_GENERICDESCRIPTOR = 6,
-    /* RobustOutlierFilter{robustFct, tuning, scaleEstimator: none | mad, nbIterationForScale, distanceType}: M-estimator weight of
-     * e2 = residual / scale^2.  param = tuning, param2 = nbIterationForScale, iparam = robustFct | scaleEstimator << 4 |
-     * distanceType << 8.  berg / std scale estimators and a finite `approximation` are UNSUPPORTED. */
+    /* RobustOutlierFilter{robustFct, tuning, scaleEstimator: none | mad | berg | std, nbIterationForScale, distanceType,
+     * approximation}: M-estimator weight of e2 = residual / scale^2.  param = tuning, param2 = nbIterationForScale, param3 =
+     * approximation (0 or +inf: none; e2 >= approximation^2 forces the weight to 0), iparam = robustFct | scaleEstimator << 4 |
+     * distanceType << 8.  berg (r5): scale 1.9 sqrt(median d2) at iteration 1, then 0.85 (scale - tuning) + tuning, with Bergstrom's
+     * constants as the M-estimator's tuning (cauchy 4.3040, tukey 7.0589, huber 2.0138).  std (r5): sqrt of the standard deviation of
+     * EVERY entry of the distance matrix (an infinite entry makes the registration end with ICPMI_ERR_NAN, as it poisons upstream's). */
     ICPMI_OUT_ROBUST = 7,
     /* VarTrimmedDistOutlierFilter{minRatio, maxRatio, lambda} (Phillips et al. 2007): TrimmedDist at the ratio that minimises
      * FRMS(i) = (sum of the i + 1 smallest d2) / ((i + 1) ((i + 1) / N)^(2 lambda)) over floor(minRatio N) <= i < floor(maxRatio N).
@@ -83,7 +86,7 @@ typedef enum {
 enum { ICPMI_GEN_SOURCE_READING = 1, ICPMI_GEN_SOFT = 2, ICPMI_GEN_LARGER = 4 };
 enum { ICPMI_ROB_CAUCHY = 0, ICPMI_ROB_WELSCH = 1, ICPMI_ROB_SC = 2, ICPMI_ROB_GM = 3, ICPMI_ROB_TUKEY = 4, ICPMI_ROB_HUBER = 5,
        ICPMI_ROB_L1 = 6, ICPMI_ROB_STUDENT = 7 };
-enum { ICPMI_SCALE_NONE = 0, ICPMI_SCALE_MAD = 1 };
+enum { ICPMI_SCALE_NONE = 0, ICPMI_SCALE_MAD = 1, ICPMI_SCALE_BERG = 2, ICPMI_SCALE_STD = 3 };
 enum { ICPMI_DIST_POINT2POINT = 0, ICPMI_DIST_POINT2PLANE = 1 };
 
 typedef struct {
@@ -91,7 +94,7 @@ typedef struct {
     float   param;
     int32_t iparam; /* flags / enums of GenericDescriptor and Robust, 0 otherwise */
     float   param2; /* Robust: nbIterationForScale; VarTrimmedDist: maxRatio        */
-    float   param3; /* VarTrimmedDist: lambda                                       */
+    float   param3; /* VarTrimmedDist: lambda; Robust: approximation (0 / +inf: none)  */
 } icpmi_outlier;
 
 typedef enum { ICPMI_STOP_NONE = 0, ICPMI_STOP_COUNTER = 1, ICPMI_STOP_DIFFERENTIAL = 2 } icpmi_stop_reason;

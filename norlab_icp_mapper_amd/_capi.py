@@ -19,7 +19,7 @@ OUT_MAXDIST, OUT_MINDIST, OUT_MEDIANDIST, OUT_TRIMMEDDIST, OUT_SURFACENORMAL = 1
 OUT_GENERICDESCRIPTOR, OUT_ROBUST, OUT_VARTRIMMEDDIST = 6, 7, 8
 GEN_SOURCE_READING, GEN_SOFT, GEN_LARGER = 1, 2, 4
 ROBUST_FCT = {"cauchy": 0, "welsch": 1, "sc": 2, "gm": 3, "tukey": 4, "huber": 5, "L1": 6, "student": 7}
-ROBUST_SCALE = {"none": 0, "mad": 1}
+ROBUST_SCALE = {"none": 0, "mad": 1, "berg": 2, "std": 3}
 ROBUST_DIST = {"point2point": 0, "point2plane": 1}
 STOP_NONE, STOP_COUNTER, STOP_DIFFERENTIAL = 0, 1, 2
 

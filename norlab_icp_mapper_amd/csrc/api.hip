@@ -101,10 +101,11 @@ static icpmi_status validate_config(const icpmi_config* cfg, std::string& err)
         }
         if (t == ICPMI_OUT_ROBUST) {
             const int ip = cfg->outlier[f].iparam;
-            if ((ip & 15) > ICPMI_ROB_STUDENT || ((ip >> 4) & 15) > ICPMI_SCALE_MAD || ((ip >> 8) & 15) > ICPMI_DIST_POINT2PLANE || (ip >> 12)) {
+            if ((ip & 15) > ICPMI_ROB_STUDENT || ((ip >> 4) & 15) > ICPMI_SCALE_STD || ((ip >> 8) & 15) > ICPMI_DIST_POINT2PLANE || (ip >> 12)) {
                 err = "InvalidParameter: RobustOutlierFilter: unknown robustFct / scaleEstimator / distanceType"; return ICPMI_ERR_INVALID_ARG;
             }
             if (!(cfg->outlier[f].param2 >= 0.f)) { err = "InvalidParameter: RobustOutlierFilter: nbIterationForScale must be >= 0"; return ICPMI_ERR_INVALID_ARG; }
+            if (!(cfg->outlier[f].param3 >= 0.f)) { err = "InvalidParameter: RobustOutlierFilter: approximation must be >= 0 (0 or +inf: none)"; return ICPMI_ERR_INVALID_ARG; }
         }
         if (t == ICPMI_OUT_TRIMMEDDIST && !(p >= 0.f && p <= 1.f)) { err = "InvalidParameter: TrimmedDist ratio must be in [0, 1]"; return ICPMI_ERR_INVALID_ARG; }
         if ((t == ICPMI_OUT_MAXDIST || t == ICPMI_OUT_MINDIST || t == ICPMI_OUT_MEDIANDIST) && !(p >= 0.f)) { err = "InvalidParameter: negative outlier filter parameter"; return ICPMI_ERR_INVALID_ARG; }

@@ -17,7 +17,8 @@ namespace {
 // and > 0, element of rank (size_t)(count * quantile) [float product], quantile == 1 -> max.
 // d2 >= 0 so the IEEE bit pattern orders like an unsigned integer: 3 radix passes 11/11/10 bits.
 // ---------------------------------------------------------------------------------------------
-// MODE 0: the quantile of the finite positive d2 (getDistsQuantile).  MODE 1 / 2: RobustOutlierFilter{scaleEstimator: mad} --
+// MODE 0: the quantile of the finite positive d2 (getDistsQuantile); MODE 3: the same values, at iteration 1 only
+// (RobustOutlierFilter{scaleEstimator: berg}).  MODE 1 / 2: RobustOutlierFilter{scaleEstimator: mad} --
 // Matches::getMedianAbsDeviation takes every finite d2 (zeros included): 1 = the values themselves, 2 = |d2 - median|;
 // nb_scale: the estimate is only refreshed while iteration <= nbIterationForScale (0 = always).
 template <int PASS, int MODE = 0>
@@ -26,6 +27,7 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(const float* __restrict__
 {
     if (st->done) return;
     if (MODE != 0 && nb_scale != 0 && st->iter + 1 > nb_scale) return;
+    if (MODE == 3 && st->iter != 0) return; // berg: the median is taken at iteration 1 only
     __shared__ unsigned h[ICPMI_SEL_BINS];
     for (int b = threadIdx.x; b < ICPMI_SEL_BINS; b += 256) h[b] = 0;
     __syncthreads();
@@ -33,7 +35,7 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(const float* __restrict__
     const float med = MODE == 2 ? st->robust_med : 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
         float v = d2[i];
-        if (MODE == 0) { if (!(v != INFINITY && v > 0.f)) continue; }
+        if (MODE == 0 || MODE == 3) { if (!(v != INFINITY && v > 0.f)) continue; }
         else {
             if (v == INFINITY) continue;
             if (MODE == 2) v = fabsf(v - med);
@@ -48,14 +50,64 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(const float* __restrict__
         if (h[b]) atomicAdd(&ghist[b], h[b]);
 }
 
+// RobustOutlierFilter{scaleEstimator: std}: Matches::getStandardDeviation over EVERY entry of the distance matrix.  Two rounds
+// (PASS 0: sum d -> mean, kept in robust_med; PASS 1: sum (d - mean)^2 -> robust_scale = sqrt(sqrt(sum / (size - 1)))), each a
+// fixed grid of fixed-order partial sums in double (`part`, one per workgroup) and a one-workgroup tail: same bits every run.
+template <int PASS>
+__global__ __launch_bounds__(256) void std_part_kernel(const float* __restrict__ d2, int64_t count, const IcpState* __restrict__ st,
+                                                       double* __restrict__ part, int nb_scale)
+{
+    if (st->done) return;
+    if (nb_scale != 0 && st->iter + 1 > nb_scale) return;
+    __shared__ double sh[256];
+    const float mean = PASS == 1 ? st->robust_med : 0.f;
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+        const float v = d2[i];
+        if (PASS == 0) s += (double)v;
+        else { const float dv = __fsub_rn(v, mean); s += (double)__fmul_rn(dv, dv); }
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void std_tail_kernel(IcpState* __restrict__ st, const double* __restrict__ part, int nparts, int64_t count,
+                                                       int nb_scale)
+{
+    if (st->done) return;
+    if (nb_scale != 0 && st->iter + 1 > nb_scale) return;
+    __shared__ double sh[256];
+    sh[threadIdx.x] = (int)threadIdx.x < nparts ? part[threadIdx.x] : 0.0;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (PASS == 0) st->robust_med = (float)(sh[0] / (double)count);
+        else st->robust_scale = sqrtf(sqrtf((float)sh[0] / (float)(count - 1)));
+    }
+}
+
 // single workgroup: locate the bin holding the wanted rank, narrow prefix / rank, clear the histogram
 template <int PASS>
 __global__ __launch_bounds__(256) void sel_scan_kernel(IcpState* __restrict__ st, unsigned* __restrict__ ghist, float quantile,
                                                        int filter_slot, int is_median, float factor, int dest = 0, int nb_scale = 0)
 {
-    // dest 0: limits[filter_slot] (quantile filters); 1: robust_med, 2: robust_scale = sqrt(mad) -- rank size / 2 (quantile < 0)
+    // dest 0: limits[filter_slot] (quantile filters); 1: robust_med, 2: robust_scale = sqrt(mad) -- rank size / 2 (quantile < 0);
+    // 3: berg -- robust_scale = 1.9 sqrt(quantile) at iteration 1, 0.85 (scale - target) + target afterwards (factor = target)
     if (st->done) return;
     if (dest != 0 && nb_scale != 0 && st->iter + 1 > nb_scale) return;
+    if (dest == 3 && st->iter != 0) {
+        if (PASS == 2 && threadIdx.x == 0) st->robust_scale = __fadd_rn(__fmul_rn(0.85f, __fsub_rn(st->robust_scale, factor)), factor);
+        return;
+    }
     __shared__ unsigned sh[256];
     __shared__ unsigned s_rank;
     const int t = threadIdx.x;
@@ -104,6 +156,7 @@ __global__ __launch_bounds__(256) void sel_scan_kernel(IcpState* __restrict__ st
             const float q = __uint_as_float(np);
             if (dest == 1) st->robust_med = q;
             else if (dest == 2) st->robust_scale = sqrtf(q);
+            else if (dest == 3) st->robust_scale = (float)(1.9 * (double)sqrtf(q));
             else st->limits[filter_slot] = is_median ? factor * q : q;
         }
     }
@@ -484,9 +537,16 @@ __device__ __forceinline__ float match_weight(const LoopCfg& lc, const IcpState*
             w *= (ip & ICPMI_GEN_SOFT) ? v : ((ip & ICPMI_GEN_LARGER) ? (v > prm ? 1.f : 0.f) : (v < prm ? 1.f : 0.f));
         } else if (EXT && type == ICPMI_OUT_ROBUST) {
             const int ip = lc.out_iparam[f];
-            const float sc = ((ip >> 4) & 15) == ICPMI_SCALE_MAD ? st->robust_scale : 1.f;
+            const int se = (ip >> 4) & 15, fct = ip & 15;
+            const float sc = se != ICPMI_SCALE_NONE ? st->robust_scale : 1.f;
             const float res = ((ip >> 8) & 15) == ICPMI_DIST_POINT2PLANE ? plane2 : d2;
-            w *= robust_weight(ip & 15, res / (sc * sc), prm);
+            // berg: `tuning` is the scale the estimate converges to; the M-estimator runs on Bergstrom's constants
+            const float kk = se != ICPMI_SCALE_BERG ? prm : (fct == ICPMI_ROB_CAUCHY ? 4.3040f : fct == ICPMI_ROB_TUKEY ? 7.0589f : fct == ICPMI_ROB_HUBER ? 2.0138f : prm);
+            const float e2 = res / (sc * sc);
+            const float apx = lc.out_param3[f];
+            float rw = robust_weight(fct, e2, kk);
+            if (apx > 0.f && apx != INFINITY && e2 >= apx * apx) rw = 0.f;
+            w *= rw;
         }
     }
     return w;
@@ -1018,15 +1078,32 @@ static void enqueue_selection(icpmi_ctx* c, const LoopCfg& lc, int64_t count, bo
     // RobustOutlierFilter{scaleEstimator: mad}: scale = sqrt(median |d2 - median(d2)|) -- two more selections on the legacy bins
     // (disjoint from the fused levels), on the single-registration path only (a batch with such a chain runs reading by reading)
     for (int f = 0; f < lc.n_out; ++f) {
-        if (lc.out_type[f] != ICPMI_OUT_ROBUST || ((lc.out_iparam[f] >> 4) & 15) != ICPMI_SCALE_MAD) continue;
+        if (lc.out_type[f] != ICPMI_OUT_ROBUST) continue;
+        const int se = (lc.out_iparam[f] >> 4) & 15;
         const int nb = (int)lc.out_param2[f];
-        for (int dest = 1; dest <= 2; ++dest) {
+        if (se == ICPMI_SCALE_MAD) {
+            for (int dest = 1; dest <= 2; ++dest) {
 #define MAD_PASS(P) \
-            if (dest == 1) hipLaunchKernelGGL((sel_hist_kernel<P, 1>), dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist, nb); \
-            else hipLaunchKernelGGL((sel_hist_kernel<P, 2>), dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist, nb); \
-            hipLaunchKernelGGL(sel_scan_kernel<P>, dim3(1), dim3(256), 0, c->stream, c->d_state, c->d_selhist, -1.f, f, 0, 0.f, dest, nb);
-            MAD_PASS(0) MAD_PASS(1) MAD_PASS(2)
+                if (dest == 1) hipLaunchKernelGGL((sel_hist_kernel<P, 1>), dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist, nb); \
+                else hipLaunchKernelGGL((sel_hist_kernel<P, 2>), dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist, nb); \
+                hipLaunchKernelGGL(sel_scan_kernel<P>, dim3(1), dim3(256), 0, c->stream, c->d_state, c->d_selhist, -1.f, f, 0, 0.f, dest, nb);
+                MAD_PASS(0) MAD_PASS(1) MAD_PASS(2)
 #undef MAD_PASS
+            }
+        } else if (se == ICPMI_SCALE_BERG) {
+            // iteration 1: the median of the finite positive d2 on the legacy bins; later iterations: the last scan kernel alone does the recurrence
+#define BERG_PASS(P) \
+            hipLaunchKernelGGL((sel_hist_kernel<P, 3>), dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, c->d_selhist, nb); \
+            hipLaunchKernelGGL(sel_scan_kernel<P>, dim3(1), dim3(256), 0, c->stream, c->d_state, c->d_selhist, 0.5f, f, 0, lc.out_param[f], 3, nb);
+            BERG_PASS(0) BERG_PASS(1) BERG_PASS(2)
+#undef BERG_PASS
+        } else if (se == ICPMI_SCALE_STD) {
+            double* part = reinterpret_cast<double*>(c->d_selhist + ICPMI_SEL_BINS); // 256 doubles between the legacy bins and the fused levels
+            static_assert(ICPMI_SEL_BINS + 512 <= ICPMI_S2_C0, "partials of the std estimator fit in front of the fused histograms");
+            hipLaunchKernelGGL(std_part_kernel<0>, dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, part, nb);
+            hipLaunchKernelGGL(std_tail_kernel<0>, dim3(1), dim3(256), 0, c->stream, c->d_state, part, hb, count, nb);
+            hipLaunchKernelGGL(std_part_kernel<1>, dim3(hb), dim3(256), 0, c->stream, c->d_d2, count, c->d_state, part, nb);
+            hipLaunchKernelGGL(std_tail_kernel<1>, dim3(1), dim3(256), 0, c->stream, c->d_state, part, hb, count, nb);
         }
     }
     for (int f = 0; f < lc.n_out; ++f) {
@@ -1739,7 +1816,7 @@ icpmi_status loop_outlier_weights(icpmi_ctx* c, const LoopCfg& lc, const float* 
         *limit_out = -1.f;
         for (int f = 0; f < l1.n_out; ++f)
             if (l1.out_type[f] == ICPMI_OUT_TRIMMEDDIST || l1.out_type[f] == ICPMI_OUT_MEDIANDIST || l1.out_type[f] == ICPMI_OUT_VARTRIMMEDDIST) *limit_out = c->h_state->limits[f];
-            else if (l1.out_type[f] == ICPMI_OUT_ROBUST && ((l1.out_iparam[f] >> 4) & 15) == ICPMI_SCALE_MAD) *limit_out = c->h_state->robust_scale;
+            else if (l1.out_type[f] == ICPMI_OUT_ROBUST && ((l1.out_iparam[f] >> 4) & 15) != ICPMI_SCALE_NONE) *limit_out = c->h_state->robust_scale;
     }
     return ICPMI_OK;
 }

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <random>
 #include <cmath>
+#include <limits>
 #include <cstring>
 #include <unordered_map>
 
@@ -171,16 +172,18 @@ void GpuICPSequence::loadFromYamlNode(const yaml::Node& icp)
                 const std::string sc = p["scaleEstimator"] ? p["scaleEstimator"].str() : "mad";
                 int sid;
                 if (sc == "none") sid = ICPMI_SCALE_NONE; else if (sc == "mad") sid = ICPMI_SCALE_MAD;
-                else if (sc == "berg" || sc == "std") throw InvalidParameter("RobustOutlierFilter{scaleEstimator: " + sc + "} is not on the accelerated path");
+                else if (sc == "berg") sid = ICPMI_SCALE_BERG; else if (sc == "std") sid = ICPMI_SCALE_STD;
                 else throw InvalidParameter("RobustOutlierFilter: unknown scaleEstimator " + sc);
                 const std::string dt = p["distanceType"] ? p["distanceType"].str() : "point2point";
                 int did;
                 if (dt == "point2point") did = ICPMI_DIST_POINT2POINT; else if (dt == "point2plane") did = ICPMI_DIST_POINT2PLANE;
                 else throw InvalidParameter("RobustOutlierFilter: unknown distanceType " + dt);
-                if (p["approximation"] && std::isfinite(p["approximation"].as<float>())) throw InvalidParameter("RobustOutlierFilter{approximation} is not on the accelerated path");
+                const float apx = p["approximation"] ? p["approximation"].as<float>() : std::numeric_limits<float>::infinity();
+                if (!(apx > 0.f)) throw InvalidParameter("RobustOutlierFilter: approximation must be > 0");   // (upstream's range: min 0, max inf; 0 would drop every match)
                 o.type = ICPMI_OUT_ROBUST;
                 o.param = p["tuning"] ? p["tuning"].as<float>() : 1.f;
                 o.param2 = p["nbIterationForScale"] ? (float)p["nbIterationForScale"].as<int>() : 0.f;
+                o.param3 = apx;
                 o.iparam = fid | (sid << 4) | (did << 8);
             }
             else throw InvalidParameter("unknown outlier filter " + e.first);

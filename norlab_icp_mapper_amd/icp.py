@@ -170,10 +170,11 @@ def config_from_yaml_chain(chain, **engine):
             fct, sc, dt = str(p.get("robustFct", "cauchy")), str(p.get("scaleEstimator", "mad")), str(p.get("distanceType", "point2point"))
             if fct not in _capi.ROBUST_FCT or dt not in _capi.ROBUST_DIST or sc not in ("none", "mad", "berg", "std"):
                 raise InvalidParameter(f"{name}: unknown robustFct / scaleEstimator / distanceType")
-            if sc not in _capi.ROBUST_SCALE or math.isfinite(float(str(p.get("approximation", "inf")).replace(".inf", "inf"))):
-                raise NotImplementedError("RobustOutlierFilter: berg / std scale estimators and `approximation` are not on the accelerated path")
+            apx = float(str(p.get("approximation", "inf")).replace(".inf", "inf"))
+            if not apx > 0.0:
+                raise InvalidParameter(f"{name}: approximation must be > 0")
             outs.append((_capi.OUT_ROBUST, float(p.get("tuning", 1.0)),
-                         _capi.ROBUST_FCT[fct] | (_capi.ROBUST_SCALE[sc] << 4) | (_capi.ROBUST_DIST[dt] << 8), float(int(p.get("nbIterationForScale", 0)))))
+                         _capi.ROBUST_FCT[fct] | (_capi.ROBUST_SCALE[sc] << 4) | (_capi.ROBUST_DIST[dt] << 8), float(int(p.get("nbIterationForScale", 0))), apx))
             continue
         if name not in _OUTLIER_NAMES:
             raise InvalidParameter(f"unknown outlier filter {name}")

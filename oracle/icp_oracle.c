@@ -428,16 +428,29 @@ int orc_outlier_weights_ex(const orc_config* cfg, const float* d2, const int32_t
                 weights[e] *= w;
             }
         } else if (type == ORC_OUT_ROBUST) {
-            /* RobustOutlierFilter{robustFct, tuning, scaleEstimator none | mad, nbIterationForScale, distanceType} [UPSTREAM:
-             * OutlierFiltersImpl.cpp robustFiltering]: while iteration <= nbIterationForScale (always when that is 0) the scale is
-             * re-estimated -- mad: sqrt(Matches::getMedianAbsDeviation()), the rank size/2 of |d2 - median(d2)| over the finite
-             * SQUARED MATCH distances (whatever distanceType says); none: 1.  e2 = residual / scale^2 with residual = the squared
-             * match distance (point2point) or the squared point-to-plane distance; w = the M-estimator's weight of e2 with
-             * tuning k; negative weights clamp to 0 (ARBITRARY_SMALL_VALUE underflows to 0 in float).  `approximation` stays at
-             * its default (+inf).  expf / powf go through double so that host libm and device ocml round to the same float. */
+            /* RobustOutlierFilter{robustFct, tuning, scaleEstimator none | mad | berg | std, nbIterationForScale, distanceType,
+             * approximation} [UPSTREAM: OutlierFiltersImpl.cpp RobustOutlierFilter / robustFiltering, libpointmatcher 1.4.x as recalled --
+             * the library is not in this image]: while iteration <= nbIterationForScale (always when that is 0) the scale is
+             * re-estimated --
+             *   mad : sqrt(Matches::getMedianAbsDeviation()), the rank size/2 of |d2 - median(d2)| over the finite SQUARED MATCH
+             *         distances (whatever distanceType says);
+             *   std : sqrt(Matches::getStandardDeviation()) = sqrt(sqrt(sum (d - mean(d))^2 / (size - 1))) over EVERY entry of the
+             *         distance matrix (an infinite entry -- maxDist, fewer than k matches -- makes it NaN upstream too; the registration
+             *         then ends with "not a number" like every non-finite weight, see the minimizer);
+             *   berg: iteration 1: 1.9 * sqrt(getDistsQuantile(0.5)), later scale = 0.85 (scale - target) + target, where target is the
+             *         configured `tuning` and the M-estimator's tuning constant becomes Bergstrom's 4.3040 (cauchy), 7.0589 (tukey),
+             *         2.0138 (huber); the other functions keep `tuning` for both;
+             *   none: 1.
+             * e2 = residual / scale^2 with residual = the squared match distance (point2point) or the squared point-to-plane distance;
+             * w = the M-estimator's weight of e2 with tuning k; negative weights clamp to 0 (ARBITRARY_SMALL_VALUE underflows to 0 in
+             * float); e2 >= approximation^2 forces the weight to 0.  The reductions of `std` run in double and round to float where
+             * Eigen would hold a float (mean, sum of squares): Eigen's packet order is not knowable here, the double sum is within half
+             * an ulp of any of them.  expf / powf go through double so that host libm and device ocml round to the same float. */
             const int ip = cfg->outlier[f].iparam;
             const int fct = ip & 15, sc = (ip >> 4) & 15, dt = (ip >> 8) & 15;
             const int nb_scale = (int)cfg->outlier[f].param2;
+            float tuning = prm;
+            if (sc == ORC_SCALE_BERG) tuning = fct == ORC_ROB_CAUCHY ? 4.3040f : fct == ORC_ROB_TUKEY ? 7.0589f : fct == ORC_ROB_HUBER ? 2.0138f : prm;
             if (nb_scale == 0 || iteration <= nb_scale) {
                 if (sc == ORC_SCALE_MAD) {
                     int empty = 0;
@@ -448,11 +461,32 @@ int orc_outlier_weights_ex(const orc_config* cfg, const float* d2, const int32_t
                     const float mad = orc_median_finite(dev, cnt, &empty);
                     free(dev);
                     *robust_scale = sqrtf(mad);
+                } else if (sc == ORC_SCALE_STD) {
+                    double s = 0.0;
+                    for (int64_t e = 0; e < cnt; ++e) s += (double)d2[e];
+                    const float mean = (float)(s / (double)cnt);
+                    double ss = 0.0;
+                    for (int64_t e = 0; e < cnt; ++e) { const float dv = d2[e] - mean; ss += (double)(dv * dv); }
+                    const float var = (float)ss / (float)(cnt - 1);
+                    *robust_scale = sqrtf(sqrtf(var));
+                } else if (sc == ORC_SCALE_BERG) {
+                    if (iteration == 1) {
+                        const float med = orc_dists_quantile(d2, cnt, 0.5f);
+                        if (med < 0.f) return ORC_ERR_NO_OUTLIER_TO_FILTER;
+                        *robust_scale = (float)(1.9 * (double)sqrtf(med));
+                    } else {
+                        const float rate = 0.85f;
+                        const float t = rate * (*robust_scale - prm);
+                        *robust_scale = t + prm;
+                    }
                 } else *robust_scale = 1.f;
             }
             const float s2 = *robust_scale * *robust_scale;
-            const float kk = prm, k2 = prm * prm;
-            if (limit_out && sc == ORC_SCALE_MAD) *limit_out = *robust_scale;
+            const float kk = tuning, k2 = tuning * tuning;
+            const float apx = cfg->outlier[f].param3;
+            const int has_apx = apx > 0.f && apx != INFINITY;
+            const float apx2 = apx * apx;
+            if (limit_out && sc != ORC_SCALE_NONE) *limit_out = *robust_scale;
             for (int64_t i = 0; i < n; ++i)
                 for (int j = 0; j < k; ++j) {
                     const int64_t e = (int64_t)k * i + j;
@@ -482,6 +516,7 @@ int orc_outlier_weights_ex(const orc_config* cfg, const float* d2, const int32_t
                         break; }
                     }
                     if (w <= 0.f) w = 0.f;
+                    if (has_apx && e2 >= apx2) w = 0.f;
                     weights[e] *= w;
                 }
         } else {

@@ -48,7 +48,7 @@ enum { ORC_OUT_MAXDIST = 1, ORC_OUT_MINDIST = 2, ORC_OUT_MEDIANDIST = 3, ORC_OUT
 /* GenericDescriptorOutlierFilter iparam bits; RobustOutlierFilter iparam = fct | scale << 4 | distance << 8 */
 enum { ORC_GEN_SOURCE_READING = 1, ORC_GEN_SOFT = 2, ORC_GEN_LARGER = 4 };
 enum { ORC_ROB_CAUCHY = 0, ORC_ROB_WELSCH = 1, ORC_ROB_SC = 2, ORC_ROB_GM = 3, ORC_ROB_TUKEY = 4, ORC_ROB_HUBER = 5, ORC_ROB_L1 = 6, ORC_ROB_STUDENT = 7 };
-enum { ORC_SCALE_NONE = 0, ORC_SCALE_MAD = 1 };
+enum { ORC_SCALE_NONE = 0, ORC_SCALE_MAD = 1, ORC_SCALE_BERG = 2, ORC_SCALE_STD = 3 };
 enum { ORC_DIST_POINT2POINT = 0, ORC_DIST_POINT2PLANE = 1 };
 enum { ORC_OK = 0, ORC_ERR_NO_POINT_TO_MINIMIZE = 1, ORC_ERR_NO_OUTLIER_TO_FILTER = 2,
        ORC_ERR_BOUND = 3, ORC_ERR_NAN = 4, ORC_ERR_ARG = 5 };
@@ -59,7 +59,7 @@ typedef struct {
     float param;
     int   iparam;            /* flags / enums of GenericDescriptor and Robust                 */
     float param2;            /* Robust: nbIterationForScale; VarTrimmedDist: maxRatio          */
-    float param3;            /* VarTrimmedDist: lambda                                         */
+    float param3;            /* VarTrimmedDist: lambda; Robust: approximation (0 or +inf: none) */
 } orc_outlier;
 
 typedef struct {

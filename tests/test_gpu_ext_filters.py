@@ -17,8 +17,9 @@ SOFT, LARGER = 2, 4
 FCT = {"cauchy": 0, "welsch": 1, "sc": 2, "gm": 3, "tukey": 4, "huber": 5, "L1": 6, "student": 7}
 
 
-def rob(fct, tuning, scale="none", nb=0, dist="point2point"):
-    return (ROB, float(tuning), FCT[fct] | ({"none": 0, "mad": 1}[scale] << 4) | ({"point2point": 0, "point2plane": 1}[dist] << 8), float(nb))
+def rob(fct, tuning, scale="none", nb=0, dist="point2point", approximation=0.0):
+    return (ROB, float(tuning), FCT[fct] | ({"none": 0, "mad": 1, "berg": 2, "std": 3}[scale] << 4) | ({"point2point": 0, "point2plane": 1}[dist] << 8),
+            float(nb), float(approximation))
 
 
 @pytest.fixture(scope="module")
@@ -91,6 +92,52 @@ def test_robust_weights_exact(amd, oracle, small_scene, fct, scale):
     assert np.all(w[~fin] == 0)
 
 
+@pytest.mark.parametrize("fct", ["cauchy", "tukey", "huber", "welsch"])
+@pytest.mark.parametrize("scale,approximation", [("berg", 0.0), ("std", 0.0), ("mad", 1.5), ("berg", 0.8), ("none", 0.3)])
+def test_robust_berg_std_approximation_weights_exact(amd, oracle, small_scene, fct, scale, approximation):
+    """r5: the scale estimators berg / std and `approximation` (rejected until r4).  Stage call = iteration 1: berg's scale is
+    1.9 sqrt(median d2), std's the square root of the standard deviation of every entry (all finite here: the search radius holds
+    every query's k neighbours)."""
+    sc = small_scene
+    tuning = 0.05 if scale == "berg" else (0.1 if scale == "none" else 1.2)      # berg: the scale the estimate converges to
+    chain = [rob(fct, tuning, scale, approximation=approximation)]
+    icp = amd.ICPSequence(minimizer=1, max_dist=2.0, outliers=chain)
+    icp.setMap(sc["map"])
+    mean = icp.getMapMean()
+    ids, d2 = icp.knn(centred(sc["scan"], mean), k=2, max_dist=50.0)
+    assert np.isfinite(d2).all()
+    w, lim = icp.outlierWeights(d2, ids)
+    err, rw, rlim = oracle.outlier_weights(oracle.make_config(outliers=chain), d2, ids)
+    assert err == 0
+    if scale == "berg":
+        pos = np.sort(d2[d2 > 0]); med = pos[int(np.float32(pos.size) * np.float32(0.5))]
+        assert lim == np.float32(1.9 * float(np.sqrt(np.float32(med))))
+    if scale == "std":
+        assert lim == pytest.approx(np.sqrt(np.std(d2.astype(np.float64), ddof=1)), rel=2e-6)
+    if scale != "none":
+        assert lim == rlim and lim > 0
+    assert np.array_equal(w, rw), (fct, scale, np.abs(w - rw).max())
+    assert np.isfinite(w).all() and w.max() > 0
+    if approximation:
+        e2 = d2 / np.float32(lim if scale != "none" else 1.0) ** 2
+        cut = e2 >= np.float32(approximation) ** 2
+        assert 0 < cut.sum() < cut.size and np.all(w[cut] == 0) and np.any(w[~cut] > 0)   # (tukey / welsch reach 0 on their own too)
+
+
+def test_robust_std_with_an_unmatched_entry_is_not_a_number(amd, oracle, small_scene):
+    """Matches::getStandardDeviation runs over EVERY entry of the distance matrix: one infinite entry (maxDist) makes the scale NaN
+    upstream; both sides of this repository end the registration with "not a number" then."""
+    sc = small_scene
+    kw = dict(minimizer=1, max_dist=0.3, knn=3, outliers=[rob("cauchy", 1.0, "std")], max_iterations=5)
+    icp = amd.ICPSequence(**kw)
+    icp.setMap(sc["map"], sc["normals"])
+    with pytest.raises(amd.ConvergenceError, match="not a number|NaN|nan"):
+        icp(sc["scan"])
+    o = oracle.OracleICP(oracle.make_config(**kw)); o.setMap(sc["map"], sc["normals"])
+    err, _ = o(sc["scan"])
+    assert err == 4   # ORC_ERR_NAN
+
+
 VT = 8
 
 
@@ -130,6 +177,11 @@ CHAINS = {
     "p2plane_huber_mad_nb3_plane": dict(minimizer=2, max_dist=2.0, outliers=[rob("huber", 1.5, "mad", 3, "point2plane")], max_iterations=12),
     "p2p_welsch_none_trim": dict(minimizer=1, max_dist=2.0, outliers=[(4, 0.9), rob("welsch", 0.3)], max_iterations=15),
     "p2plane_tukey_plane": dict(minimizer=2, max_dist=1.0, outliers=[rob("tukey", 0.5, "none", 0, "point2plane")], max_iterations=12),
+    "p2plane_cauchy_berg": dict(minimizer=2, max_dist=50.0, outliers=[rob("cauchy", 0.05, "berg")], max_iterations=25, use_differential=1),
+    "p2p_tukey_berg_nb4_apx": dict(minimizer=1, max_dist=50.0, outliers=[rob("tukey", 0.1, "berg", 4, approximation=5.0)], max_iterations=12),
+    "p2plane_huber_std_plane": dict(minimizer=2, max_dist=50.0, outliers=[rob("huber", 1.0, "std", 0, "point2plane")], max_iterations=12),
+    "p2plane_welsch_std_nb2_trim": dict(minimizer=2, max_dist=50.0, knn=2, outliers=[(4, 0.9), rob("welsch", 2.0, "std", 2)], max_iterations=10),
+    "p2plane_cauchy_mad_apx": dict(minimizer=2, max_dist=2.0, outliers=[rob("cauchy", 1.0, "mad", approximation=2.0)], max_iterations=25, use_differential=1),
     "p2plane_generic_trim": dict(minimizer=2, max_dist=2.0, outliers=[(GEN, 0.25, LARGER, 0.0), (4, 0.85)], max_iterations=20, use_differential=1),
     "p2plane_generic_soft": dict(minimizer=2, max_dist=2.0, outliers=[(GEN, 0.0, SOFT, 0.0)], max_iterations=10),
     "p2plane_vartrimmed": dict(minimizer=2, max_dist=2.0, outliers=[(VT, 0.05, 0, 0.99, 0.95)], max_iterations=25, use_differential=1),

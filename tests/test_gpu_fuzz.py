@@ -43,7 +43,13 @@ def draw(rng):
         elif t == SNO: outliers.append((SNO, float(rng.uniform(0.6, 1.4)))); need_rn = True
         elif t == ROB:
             fct = int(rng.integers(0, 8)); scale = int(rng.integers(0, 2)); dist = int(rng.integers(0, 2)) if minimizer == 2 else 0
-            outliers.append((ROB, float(rng.uniform(0.3, 2.0)), fct | (scale << 4) | (dist << 8), float(rng.choice([0, 0, 3]))))
+            tuning, nb = float(rng.uniform(0.3, 2.0)), float(rng.choice([0, 0, 3]))
+            # r5: berg / std / approximation, derived from the tuning's digits so that the draws of the earlier rounds keep their streams
+            x = int(tuning * 1e6) % 10
+            if x in (0, 1): scale, tuning = 2, tuning * 0.1      # berg: `tuning` is the scale the estimate converges to
+            elif x == 2: scale = 3                                # std (a finite maxDist makes it "not a number" on both sides)
+            apx = [0.0, 0.0, 0.0, 1.5, 3.0][int(tuning * 1e5) % 5]
+            outliers.append((ROB, tuning, fct | (scale << 4) | (dist << 8), nb, apx))
         elif t == GEN:
             gen = str(rng.choice(["reference", "reading"]))
             flags = int(rng.choice([0, 4, 2])) | (1 if gen == "reading" else 0)   # include/icpmi.h: 1 source reading, 2 soft, 4 useLargerThan

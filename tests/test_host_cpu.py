@@ -166,9 +166,14 @@ inspector: NullInspector
             pkg.config_from_yaml_chain({"outlierFilters": [bad]})
     rd = pkg.config_from_yaml_chain({"outlierFilters": [{"GenericDescriptorOutlierFilter": {"source": "reading", "descName": "intensity", "threshold": 0.3}}]})
     assert rd.outlier[0].iparam == _capi.GEN_SOURCE_READING | _capi.GEN_LARGER      # r4: served (icpmi_set_reading_scalar)
-    for unsupported in ({"RobustOutlierFilter": {"scaleEstimator": "berg"}}, {"RobustOutlierFilter": {"approximation": 2.0}}):
-        with pytest.raises(NotImplementedError):
-            pkg.config_from_yaml_chain({"outlierFilters": [unsupported]})
+    # r5: berg / std scale estimators and `approximation` are served
+    rb = pkg.config_from_yaml_chain({"outlierFilters": [{"RobustOutlierFilter": {"scaleEstimator": "berg", "tuning": 0.05, "approximation": 2.0}},
+                                                        {"RobustOutlierFilter": {"scaleEstimator": "std", "robustFct": "tukey"}}]})
+    assert (rb.outlier[0].iparam, rb.outlier[0].param3, rb.outlier[0].param) == (0 | (2 << 4), 2.0, pytest.approx(0.05))
+    assert rb.outlier[1].iparam == 4 | (3 << 4) and math.isinf(rb.outlier[1].param3)
+    for bad in ({"RobustOutlierFilter": {"scaleEstimator": "foo"}}, {"RobustOutlierFilter": {"approximation": 0.0}}, {"RobustOutlierFilter": {"approximation": -1.0}}):
+        with pytest.raises(pkg.InvalidParameter):
+            pkg.config_from_yaml_chain({"outlierFilters": [bad]})
 
 
 def test_synthetic_scene_is_deterministic_and_well_formed():

@@ -10,8 +10,9 @@ GEN, ROB = 6, 7
 FCT = {"cauchy": 0, "welsch": 1, "sc": 2, "gm": 3, "tukey": 4, "huber": 5, "L1": 6, "student": 7}
 
 
-def rob(fct, tuning, scale="none", nb=0, dist="point2point"):
-    return (ROB, float(tuning), FCT[fct] | ({"none": 0, "mad": 1}[scale] << 4) | ({"point2point": 0, "point2plane": 1}[dist] << 8), float(nb))
+def rob(fct, tuning, scale="none", nb=0, dist="point2point", approximation=0.0):
+    return (ROB, float(tuning), FCT[fct] | ({"none": 0, "mad": 1, "berg": 2, "std": 3}[scale] << 4) | ({"point2point": 0, "point2plane": 1}[dist] << 8),
+            float(nb), float(approximation))
 
 
 def test_robust_known_answers(oracle):
@@ -53,6 +54,43 @@ def test_robust_scale_is_kept_after_nb_iterations(oracle):
     # no finite match at all: "no outlier to filter"
     err, _, _ = oracle.outlier_weights(cfg, np.full((3, 1), np.inf, dtype=np.float32), -np.ones((3, 1), dtype=np.int32))
     assert err != 0
+
+
+def test_robust_berg_std_approximation_known_answers(oracle):
+    """r5: hand-computed scales of the berg / std estimators and the `approximation` cut (upstream's robustFiltering as recalled)."""
+    d2 = np.array([[0.01], [0.04], [0.09], [1.0], [0.0]], dtype=np.float32)
+    ids = np.zeros((5, 1), dtype=np.int32)
+    # berg, iteration 1: getDistsQuantile(0.5) over the positive finite {0.01, 0.04, 0.09, 1.0} -> index 4 * 0.5 = 2 -> 0.09; scale = 1.9 * 0.3
+    cfg = oracle.make_config(outliers=[rob("cauchy", 0.05, "berg")])
+    err, w, scale = oracle.outlier_weights(cfg, d2, ids)
+    assert err == 0 and scale == pytest.approx(0.57, rel=1e-6)
+    k2 = np.float32(4.3040) ** 2                                   # Bergstrom's constant, not `tuning`
+    np.testing.assert_allclose(w[:, 0], 1 / (1 + (d2[:, 0] / np.float32(scale) ** 2) / k2), rtol=1e-6)
+    # later iterations: scale -> 0.85 (scale - tuning) + tuning, no matter what the distances are
+    err, w, s2 = oracle.outlier_weights(cfg, d2, ids, iteration=2, scale=scale)
+    assert s2 == pytest.approx(0.85 * (0.57 - 0.05) + 0.05, rel=1e-6)
+    err, w, s3 = oracle.outlier_weights(oracle.make_config(outliers=[rob("cauchy", 0.05, "berg", nb=2)]), d2, ids, iteration=3, scale=s2)
+    assert s3 == s2                                                 # iteration > nbIterationForScale: kept
+    # tukey / huber take their own constants, welsch keeps `tuning` for both roles
+    for fct, kk in (("tukey", 7.0589), ("huber", 2.0138), ("welsch", 0.05)):
+        err, w, scale = oracle.outlier_weights(oracle.make_config(outliers=[rob(fct, 0.05, "berg")]), d2, ids)
+        e2 = d2[:, 0].astype(np.float64) / 0.57 ** 2
+        ref = {"tukey": np.where(e2 >= kk * kk, 0, (1 - e2 / kk ** 2) ** 2), "huber": np.where(e2 >= kk * kk, kk / np.sqrt(np.maximum(e2, 1e-30)), 1),
+               "welsch": np.exp(-e2 / kk ** 2)}[fct]
+        np.testing.assert_allclose(w[:, 0], ref, rtol=2e-5, atol=1e-30, err_msg=fct)
+    # std: sqrt of the sample standard deviation (ddof 1) of every entry, zeros included
+    err, w, scale = oracle.outlier_weights(oracle.make_config(outliers=[rob("cauchy", 1.0, "std")]), d2, ids)
+    sd = np.std(d2.astype(np.float64), ddof=1)
+    assert err == 0 and scale == pytest.approx(math.sqrt(sd), rel=1e-6)
+    np.testing.assert_allclose(w[:, 0], 1 / (1 + d2[:, 0] / sd), rtol=1e-5)
+    # ... and an infinite entry poisons it, as it does upstream
+    d2i = d2.copy(); d2i[3, 0] = np.inf
+    err, w, scale = oracle.outlier_weights(oracle.make_config(outliers=[rob("cauchy", 1.0, "std")]), d2i, ids)
+    assert math.isnan(scale)
+    # approximation: e2 >= approximation^2 -> 0 (e2 = d2 here: scale none)
+    err, w, _ = oracle.outlier_weights(oracle.make_config(outliers=[rob("cauchy", 1.0, approximation=0.3)]), d2, ids)
+    assert list(w[:, 0] == 0) == [False, False, True, True, False]
+    np.testing.assert_allclose(w[:2, 0], 1 / (1 + d2[:2, 0]), rtol=1e-6)
 
 
 def test_robust_point2plane_residual(oracle):
