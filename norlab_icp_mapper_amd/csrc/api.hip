@@ -204,7 +204,7 @@ void icpmi_destroy(icpmi_handle c)
     hipFree(c->d_reading); hipFree(c->d_read_normals); hipFree(c->d_stage_in); hipFree(c->d_stage_n3);
     hipFree(c->d_match_pt); hipFree(c->d_lvl_tab); hipFree(c->d_raw); hipFree(c->d_raw_n3); hipFree(c->d_raw_s); hipFree(c->d_src); hipFree(c->d_alt_raw); hipFree(c->d_alt_n3);
     hipFree(c->d_alt_s); hipFree(c->d_alt_src); hipFree(c->d_stage_s); hipFree(c->d_merge_send); hipFree(c->d_merge_recv); hipFree(c->d_merged); hipFree(c->d_comm_cnt); hipFree(c->d_read_noise); hipFree(c->d_read_scalar); hipFree(c->d_map_pn);
-    for (int k = 0; k < 10; ++k) hipFree(c->scratch[k]); hipFree(c->d_scan_map); hipFree(c->d_T16);
+    for (int k = 0; k < ICPMI_SCRATCH_SLOTS; ++k) hipFree(c->scratch[k]); hipFree(c->d_scan_map); hipFree(c->d_T16);
     hipFree(c->d_sidx); hipFree(c->d_d2); hipFree(c->d_hard); hipFree(c->d_selhist);
     hipFree(c->d_state);
     if (c->h_state) hipHostFree(c->h_state);
@@ -214,6 +214,9 @@ void icpmi_destroy(icpmi_handle c)
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     for (hipEvent_t e : c->nn_events) hipEventDestroy(e);
+    if (c->side_fork) hipEventDestroy(c->side_fork);
+    if (c->side_join) hipEventDestroy(c->side_join);
+    if (c->side) hipStreamDestroy(c->side);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     delete c;
 }

@@ -74,6 +74,28 @@ __device__ __forceinline__ void st_stream(int* p, int v) { __builtin_nontemporal
 template <class T> __device__ __forceinline__ T ld_stream(const T* p) { return *p; }
 template <class T> __device__ __forceinline__ void st_stream(T* p, T v) { *p = v; }
 #endif
+
+// ---- runs of equal keys inside a wave become ONE atomic per run (counting sorts: map_build.hip, the DynamicPoints bucket grid) ----
+struct WaveRun { bool head; int rank; int len; int head_lane; };
+__device__ __forceinline__ WaveRun wave_run(unsigned key, bool valid)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned prev = (unsigned)__shfl_up((int)key, 1, 64);
+    const bool pvalid = __shfl_up((int)valid, 1, 64) != 0;
+    const bool head = valid && (lane == 0 || !pvalid || prev != key);
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long valids = __ballot(valid);
+    WaveRun r;
+    r.head = head;
+    const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+    r.head_lane = below ? 63 - __clzll((long long)below) : lane;
+    r.rank = lane - r.head_lane;
+    const unsigned long long above = (lane == 63) ? 0ull : (heads & ~((2ull << lane) - 1ull));
+    const int nvalid = __popcll(valids); // valid lanes are a prefix of the wave
+    const int end = above ? (__ffsll((long long)above) - 1) : nvalid;
+    r.len = end - r.head_lane;
+    return r;
+}
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -182,6 +204,7 @@ struct IcpState {
     float T_out[16];
 };
 
+#define ICPMI_SCRATCH_SLOTS 20
 struct icpmi_ctx {
     icpmi_config cfg;
     int device = 0;
@@ -278,8 +301,10 @@ struct icpmi_ctx {
     float*  d_stage_s = nullptr; size_t cap_stage_s = 0;
     // scratch of the map-side operators (hash tables, beam buckets, flags): kept between calls -- a hipMalloc / hipFree
     // pair costs more than most of the kernels that use them
-    void* scratch[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t scratch_bytes[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    void* scratch[ICPMI_SCRATCH_SLOTS] = {};                  // slots 0..9: operators on the handle's stream; 10..19: the DynamicPoints module (may run on `side`)
+    size_t scratch_bytes[ICPMI_SCRATCH_SLOTS] = {};
+    hipStream_t side = nullptr;                              // map-update chain: DynamicPoints next to the decimation that follows it (ops.hip)
+    hipEvent_t side_fork = nullptr, side_join = nullptr;
     // the scan of the last icpmi_register_prior, in the map frame by its prior (what Mapper::processInput calls `input`)
     float4* d_scan_map = nullptr; size_t cap_scan_map = 0; int64_t scan_map_n = 0;
     float* d_T16 = nullptr;           // a 4x4 for device-side transforms
@@ -564,6 +589,11 @@ icpmi_status device_exclusive_scan_io(icpmi_ctx* c, const unsigned* in, unsigned
 icpmi_status device_scan_flags_count(icpmi_ctx* c, const unsigned* flag, unsigned* pos, int n, int64_t* count); // pos = exclusive scan of the 0 / 1 flags, *count = how many are set (one stream wait, no copy)
 icpmi_status device_exclusive_scan_sum(icpmi_ctx* c, const unsigned* flag, unsigned* pos, int n, unsigned* d_sum); // ... the count stays on the device
 icpmi_status device_exclusive_scan_cursor(icpmi_ctx* c, unsigned* counts, unsigned* starts, int n, unsigned total, bool zero_counts, unsigned* tail_out = nullptr); // tail_out: receives counts[n + 1]
+// the same scan on another stream with the caller's own chunk-total words (device_scan_side_words(n) of them); false from
+// device_scan_side_ok(n): the table is too large for the two-kernel scan -- stay on the handle's stream
+bool device_scan_side_ok(int n);
+size_t device_scan_side_words(int n);
+icpmi_status device_exclusive_scan_cursor_side(icpmi_ctx* c, hipStream_t stream, unsigned* sums, unsigned* counts, unsigned* starts, int n, unsigned total);
 icpmi_status sort_queries(icpmi_ctx* c, const float4* d_pts, int64_t n);
 icpmi_status sort_queries_reserve(icpmi_ctx* c, int64_t n, int nscan = 1);
 icpmi_status sort_queries_batch(icpmi_ctx* c, const float4* d_pts, const BatchArgs& ba, const SortHead* head = nullptr); // slices of d_pts -> slices of d_qsorted / d_qindex

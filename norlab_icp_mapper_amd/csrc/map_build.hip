@@ -56,26 +56,7 @@ __device__ __forceinline__ int cell_of(float v, float o, float inv, int n)
 // point serialises at ~6.5 ns each on the same address -- 11 ms per kernel at 1 M points), and the cloud handed to set_map is
 // often spatially ordered too (the octree filter leaves the map in Morton order; a lidar scan is ordered along its beams):
 // level 0 uses the same trick (r2: 98 -> 4x fewer device atomics on an octree-ordered 0.9 M-point map).
-struct WaveRun { bool head; int rank; int len; int head_lane; };
-__device__ __forceinline__ WaveRun wave_run(unsigned key, bool valid)
-{
-    const int lane = threadIdx.x & 63;
-    const unsigned prev = (unsigned)__shfl_up((int)key, 1, 64);
-    const bool pvalid = __shfl_up((int)valid, 1, 64) != 0;
-    const bool head = valid && (lane == 0 || !pvalid || prev != key);
-    const unsigned long long heads = __ballot(head);
-    const unsigned long long valids = __ballot(valid);
-    WaveRun r;
-    r.head = head;
-    const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
-    r.head_lane = below ? 63 - __clzll((long long)below) : lane;
-    r.rank = lane - r.head_lane;
-    const unsigned long long above = (lane == 63) ? 0ull : (heads & ~((2ull << lane) - 1ull));
-    const int nvalid = __popcll(valids); // valid lanes are a prefix of the wave
-    const int end = above ? (__ffsll((long long)above) - 1) : nvalid;
-    r.len = end - r.head_lane;
-    return r;
-}
+// (WaveRun / wave_run: common.h -- the bucket grid of the DynamicPoints module uses them too)
 
 // ---- pass 2: keys + per-cell histogram -------------------------------------------------------
 __global__ __launch_bounds__(256) void key_kernel(const float4* __restrict__ pts, int64_t m, float mx, float my, float mz,
@@ -735,6 +716,19 @@ icpmi_status device_exclusive_scan_cursor(icpmi_ctx* c, unsigned* counts, unsign
     const icpmi_status s = device_exclusive_scan_io(c, starts + 1, starts + 1, n, total);
     if (s != ICPMI_OK) return s;
     if (zero_counts) HIP_TRY(c, hipMemsetAsync(counts, 0, ((size_t)n + 2) * sizeof(unsigned), c->stream));
+    return ICPMI_OK;
+}
+
+bool device_scan_side_ok(int n) { return scan2_enabled() && (n + SCAN_CHUNK - 1) / SCAN_CHUNK <= SCAN2_MAX_NB; }
+size_t device_scan_side_words(int n) { return (size_t)(n + SCAN_CHUNK - 1) / SCAN_CHUNK + 1; }
+icpmi_status device_exclusive_scan_cursor_side(icpmi_ctx* c, hipStream_t stream, unsigned* sums, unsigned* counts, unsigned* starts, int n, unsigned total)
+{
+    if (!device_scan_side_ok(n)) return ICPMI_ERR_UNSUPPORTED;
+    const int nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    hipLaunchKernelGGL(scan2_sums_kernel, dim3(nb > 0 ? nb : 1), dim3(SCAN_T), 0, stream, (const unsigned*)counts, n, sums);
+    hipLaunchKernelGGL(scan2_final_kernel, dim3(nb > 0 ? nb : 1), dim3(SCAN_T), 0, stream, (const unsigned*)counts, starts, n, (const unsigned*)sums, total, 1,
+                       (unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr);
+    HIP_TRY(c, hipGetLastError());
     return ICPMI_OK;
 }
 

@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void voxel_keep_kernel(int64_t n, const unsign
 // asin / atan2 go through double and are rounded once (shared with the oracle: libm and the device
 // library then agree bit for bit); everything else is the reference's float arithmetic, with the
 // sub-expressions it writes with a double literal (`1.`) evaluated in double.
-struct DynGrid { float cell; int ne, na; };
+struct DynGrid { float cell; int ne, na; float r2; };   // r2 = (2 beamHalfAngle)^2: the search radius, DYN_RINGS cells wide
 
 __device__ __forceinline__ void to_spherical(float x, float y, float z, float& radius, float& elev, float& azim)
 {
@@ -353,16 +353,20 @@ __global__ __launch_bounds__(256) void dyn_beams_kernel(const float4* __restrict
                                                         unsigned* __restrict__ keys, unsigned* __restrict__ count)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float4 p = in[i];
+    const bool valid = i < n;
+    const float4 p = in[valid ? i : 0];
     const float3 o = xf_point(M.v, p.x, p.y, p.z, p.w);
     float radius, elev, azim;
     to_spherical(o.x, o.y, o.z, radius, elev, azim);
+    const unsigned key = (unsigned)(dyn_ecell(g, elev) * g.na + dyn_acell(g, azim));
+    // a lidar scan is ordered along its beams: neighbours in the array fall into the same bucket, and same-address device atomics
+    // serialise -- one atomic per run of equal keys in the wave (r5; map_build.hip's counting sorts do the same)
+    const WaveRun r = wave_run(key, valid);
+    if (r.head) atomicAdd(&count[key], (unsigned)r.len);
+    if (!valid) return;
     beam_xyzn[i] = make_float4(o.x, o.y, o.z, radius);
     beam_ang[i] = make_float2(elev, azim);
-    const unsigned key = (unsigned)(dyn_ecell(g, elev) * g.na + dyn_acell(g, azim));
     keys[i] = key;
-    atomicAdd(&count[key], 1u);
 }
 
 // pass 2: counting-sort scatter; a bucket entry is ONE 16-byte record {elevation, azimuth, beam index} (r5: the index used to sit in a second
@@ -371,13 +375,23 @@ __global__ __launch_bounds__(256) void dyn_scatter_kernel(int64_t n, const unsig
                                                           const float2* __restrict__ beam_ang, float4* __restrict__ sorted_rec)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const unsigned key = keys[i];
-    const unsigned pos = atomicAdd(&cursor[key], 1u);
-    const float2 a = beam_ang[i];
-    sorted_rec[pos] = make_float4(a.x, a.y, __uint_as_float((unsigned)i), 0.f);
+    const bool valid = i < n;
+    const unsigned key = keys[valid ? i : 0];
+    const float2 a = beam_ang[valid ? i : 0];
+    const WaveRun r = wave_run(key, valid);
+    unsigned base = 0;
+    if (r.head) base = atomicAdd(&cursor[key], (unsigned)r.len);
+    base = (unsigned)__shfl((int)base, r.head_lane, 64);
+    if (!valid) return;
+    sorted_rec[base + (unsigned)r.rank] = make_float4(a.x, a.y, __uint_as_float((unsigned)i), 0.f);
 }
 
+#ifndef DYN_INFLIGHT
+#define DYN_INFLIGHT 4
+#endif
+#ifndef DYN_RINGS
+#define DYN_RINGS 2   // buckets per search radius (1: 3 x 3 block of one-radius buckets, the layout until r4)
+#endif
 struct DynPrm { float threshold_dynamic, alpha, beta, beam_half_angle, epsilon_a, epsilon_d, sensor_max_range; };
 
 __global__ __launch_bounds__(256) void dyn_update_kernel(const float4* __restrict__ map, const float* __restrict__ normals3, int64_t m,
@@ -396,48 +410,70 @@ __global__ __launch_bounds__(256) void dyn_update_kernel(const float4* __restric
     float radius, qe, qa;
     to_spherical(mp.x, mp.y, mp.z, radius, qe, qa);
     const int ce = dyn_ecell(g, qe), ca = dyn_acell(g, qa);
-    const float r2 = g.cell * g.cell;
+    const float r2 = g.r2;
     float bd = INFINITY;
     int best = -1;
-    // The nearest beam within 2 * beamHalfAngle = one bucket edge: it lies in the 3 x 3 block of buckets around the point's own.  The
-    // buckets (e, a - 1 .. a + 1) of one elevation row are consecutive keys: the four bounds of a row's three buckets are four consecutive
-    // words, and all twelve are requested together before anything depends on them (r4 fetched the two bounds of a bucket when it got
-    // there: nine dependent round trips before the ninth bucket's records).  Own bucket first: where the beams are dense the nearest one
-    // is a fraction of a bucket away, and a neighbour whose nearest edge is farther than the best so far cannot hold a closer beam (nor
-    // an equally close one: the test is strict and leaves a margin for the rounding of the cell assignment).  The winner is the minimum
-    // of (angular distance, beam index): independent of the visiting order.  (Scanning whole rows without the per-bucket test -- fewer
-    // branches -- looked at 3 - 5 x the records and was slower: 253 vs 225 us.)
+    // The nearest beam within 2 * beamHalfAngle = DYN_RINGS bucket edges: it lies in the (2 R + 1)^2 block of buckets around the point's
+    // own.  The buckets (e, a - R .. a + R) of one elevation row are consecutive keys: the bounds of a row's buckets are 2 R + 2 consecutive
+    // words, and all of them are requested together before anything depends on them (r4 fetched the two bounds of a bucket when it got
+    // there: nine dependent round trips before the ninth bucket's records).  Own bucket first, then ring by ring: where the beams are
+    // dense the nearest one is a fraction of a bucket away, and a bucket whose nearest edge is farther than the best so far cannot hold a
+    // closer beam (nor an equally close one: the test is strict and leaves a margin for the rounding of the cell assignment).  The winner
+    // is the minimum of (angular distance, beam index): independent of the visiting order.
+    // r5: buckets of HALF the radius (R = 2, 5 x 5 block).  With one-radius buckets a point paid for every record of its own bucket before
+    // the pruning could start -- 150 records where a surface is seen at a grazing angle (the synthetic scenes; a spinning lidar's own
+    // returns are uniform in angle); a quarter bucket first, and the ring behind it mostly pruned: search 136 -> see DESIGN 13.2b.
+    // (Scanning whole rows without the per-bucket test -- fewer branches -- looked at 3 - 5 x the records and was slower: 253 vs 225 us.)
+    constexpr int R = DYN_RINGS, W = 2 * R + 1;
     const float elo = (float)ce * g.cell - 1.5707963267949f, alo = (float)ca * g.cell - 3.14159265358979f;
-    const float gapE[3] = {qe - elo, 0.f, elo + g.cell - qe}, gapA[3] = {qa - alo, 0.f, alo + g.cell - qa};
-    unsigned sb[3][4];
+    float gapE[W], gapA[W];
 #pragma unroll
-    for (int de = 0; de < 3; ++de) {
-        const int e = ce + de - 1;
+    for (int d = 0; d < W; ++d) {
+        // distance from the query to the nearest edge of the bucket d - R cells away (0 for its own)
+        gapE[d] = d < R ? (qe - elo) + (float)(R - 1 - d) * g.cell : (d == R ? 0.f : (elo + g.cell - qe) + (float)(d - R - 1) * g.cell);
+        gapA[d] = d < R ? (qa - alo) + (float)(R - 1 - d) * g.cell : (d == R ? 0.f : (alo + g.cell - qa) + (float)(d - R - 1) * g.cell);
+    }
+    unsigned sb[W][W + 1];
+#pragma unroll
+    for (int de = 0; de < W; ++de) {
+        const int e = ce + de - R;
         const bool row = e >= 0 && e < g.ne;
 #pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            int a = ca - 1 + x;                       // bound x = start of bucket (e, ca - 1 + x)
+        for (int x = 0; x <= W; ++x) {
+            int a = ca - R + x;                       // bound x = start of bucket (e, ca - R + x)
             a = a < 0 ? 0 : (a > g.na ? g.na : a);    // (a == na: the start of the next row's first bucket = the end of this row's last)
             sb[de][x] = start[row ? (unsigned)(e * g.na + a) : 0u];
         }
     }
 #pragma unroll
-    for (int c9 = 0; c9 < 9; ++c9) {
-        // visiting order: centre, then the eight neighbours
-        const int idx9 = c9 == 0 ? 4 : (c9 <= 4 ? c9 - 1 : c9);
-        const int de = idx9 / 3, da = idx9 % 3;
-        const int e = ce + de - 1, a = ca + da - 1;
-        if (e < 0 || e >= g.ne || a < 0 || a >= g.na) continue;
-        const float ge = fmaxf(gapE[de] - 1e-5f, 0.f), ga = fmaxf(gapA[da] - 1e-5f, 0.f);
-        const float dmin = ge * ge + ga * ga;
-        if (dmin > r2 || dmin > bd) continue;
-        for (unsigned j = sb[de][da]; j < sb[de][da + 1]; ++j) {
-            const float4 rec = sorted_rec[j];
-            const float d0 = qe - rec.x, d1 = qa - rec.y;
-            const float d = d0 * d0 + d1 * d1;
-            if (d <= r2 && d <= bd) { // ties on the angular distance go to the smallest beam index (the bucket order is arbitrary)
-                const int b = (int)__float_as_uint(rec.z);
-                if (d < bd || b < best) { bd = d; best = b; }
+    for (int ring = 0; ring <= R; ++ring) {
+#pragma unroll
+        for (int de = 0; de < W; ++de) {
+#pragma unroll
+            for (int da = 0; da < W; ++da) {
+                const int re = de > R ? de - R : R - de, ra = da > R ? da - R : R - da;
+                if ((re > ra ? re : ra) != ring) continue;   // (compile time)
+                const int e = ce + de - R, a = ca + da - R;
+                if (e < 0 || e >= g.ne || a < 0 || a >= g.na) continue;
+                const float ge = fmaxf(gapE[de] - 1e-5f, 0.f), ga = fmaxf(gapA[da] - 1e-5f, 0.f);
+                const float dmin = ge * ge + ga * ga;
+                if (dmin > r2 || dmin > bd) continue;
+                // DYN_INFLIGHT records requested together (r5: one per trip made every record a full memory round trip of the wave's slowest lane)
+                const unsigned jend = sb[de][da + 1];
+                for (unsigned j = sb[de][da]; j < jend; j += DYN_INFLIGHT) {
+                    float4 rec[DYN_INFLIGHT];
+#pragma unroll
+                    for (int u = 0; u < DYN_INFLIGHT; ++u) rec[u] = sorted_rec[j + u < jend ? j + u : jend - 1];
+#pragma unroll
+                    for (int u = 0; u < DYN_INFLIGHT; ++u) {
+                        const float d0 = qe - rec[u].x, d1 = qa - rec[u].y;
+                        const float d = d0 * d0 + d1 * d1;
+                        if (d <= r2 && d <= bd) { // ties on the angular distance go to the smallest beam index (the bucket order is arbitrary; a clamped repeat changes nothing)
+                            const int b = (int)__float_as_uint(rec[u].z);
+                            if (d < bd || b < best) { bd = d; best = b; }
+                        }
+                    }
+                }
             }
         }
     }
@@ -856,38 +892,52 @@ icpmi_status ops_voxel_keep_first(icpmi_ctx* c, const float* in4, int64_t n, flo
     return ICPMI_OK;
 }
 
-// DynamicPointsMapperModule::inPlaceUpdateMap on DEVICE arrays (d_T = pose^-1, 16 floats in HBM); d_prob updated in place
+// DynamicPointsMapperModule::inPlaceUpdateMap on DEVICE arrays (T = pose^-1 as a kernel argument); d_prob updated in place.  Its scratch is
+// its own (slots 10..19) and `stream` may be the handle's side stream: the module only touches the probabilities of the OLD map points, so
+// the map-update chain runs it next to the decimation that follows (ops_map_update_chain).
 static icpmi_status dynpts_dev(icpmi_ctx* c, const icpmi_dynpts_params* prm, const float T[16], const float4* d_in, int64_t n,
-                               const float4* d_map, const float* d_nrm, int64_t m, float* d_prob)
+                               const float4* d_map, const float* d_nrm, int64_t m, float* d_prob, hipStream_t stream)
 {
     if (n == 0 || m == 0) return ICPMI_OK; // "if (beams.empty()) return"
     DynGrid g;
-    g.cell = 2 * prm->beam_half_angle;
+    const float reach = 2 * prm->beam_half_angle;
+    g.r2 = reach * reach;
+    g.cell = reach / (float)DYN_RINGS;
     g.ne = (int)floorf(3.14159265358979f / g.cell) + 2;
     g.na = (int)floorf(6.28318530717959f / g.cell) + 2;
     const int64_t ncells = (int64_t)g.ne * g.na;
     if (ncells > (1ll << 28)) { c->last_error = "dynamic_points_update: beamHalfAngle too small for the angular grid"; return ICPMI_ERR_UNSUPPORTED; }
     DynPrm dp = {prm->threshold_dynamic, prm->alpha, prm->beta, prm->beam_half_angle, prm->epsilon_a, prm->epsilon_d, prm->sensor_max_range};
-    float4* d_bx = scratch_get<float4>(c, 0, (size_t)n);
-    float2* d_ba = scratch_get<float2>(c, 1, (size_t)n);
-    unsigned* d_keys = scratch_get<unsigned>(c, 2, (size_t)n);
-    unsigned* d_start = scratch_get<unsigned>(c, 4, (size_t)ncells + 2);
-    unsigned* d_cnt = scratch_get<unsigned>(c, 5, (size_t)ncells + 2);
-    float4* d_rec = scratch_get<float4>(c, 8, (size_t)n);
-    if (!d_bx || !d_ba || !d_keys || !d_start || !d_cnt || !d_rec) return ICPMI_ERR_HIP;
+    float4* d_bx = scratch_get<float4>(c, 10, (size_t)n);
+    float2* d_ba = scratch_get<float2>(c, 11, (size_t)n);
+    unsigned* d_keys = scratch_get<unsigned>(c, 12, (size_t)n);
+    unsigned* d_start = scratch_get<unsigned>(c, 13, (size_t)ncells + 2);
+    unsigned* d_cnt = scratch_get<unsigned>(c, 14, (size_t)ncells + 2);
+    float4* d_rec = scratch_get<float4>(c, 15, (size_t)n);
+    const bool side_scan = device_scan_side_ok((int)ncells);
+    unsigned* d_sums = side_scan ? scratch_get<unsigned>(c, 16, device_scan_side_words((int)ncells)) : nullptr;
+    if (!d_bx || !d_ba || !d_keys || !d_start || !d_cnt || !d_rec || (side_scan && !d_sums)) return ICPMI_ERR_HIP;
+    if (!side_scan && stream != c->stream) { c->last_error = "dynamic_points_update: internal -- side stream with a table the two-kernel scan cannot take"; return ICPMI_ERR_UNSUPPORTED; }
     const Mat16 M = mat16(T);
     // counts -> starts in cursor layout (map_build.hip): one table to clear, the starts are written in full by the scan
-    HIP_TRY(c, hipMemsetAsync(d_cnt, 0, ((size_t)ncells + 2) * sizeof(unsigned), c->stream));
+    HIP_TRY(c, hipMemsetAsync(d_cnt, 0, ((size_t)ncells + 2) * sizeof(unsigned), stream));
     const int nb = (int)((n + 255) / 256), mb = (int)((m + 255) / 256);
-    hipLaunchKernelGGL(dyn_beams_kernel, dim3(nb), dim3(256), 0, c->stream, d_in, n, M, g, d_bx, d_ba, d_keys, d_cnt);
-    icpmi_status st = device_exclusive_scan_cursor(c, d_cnt, d_start, (int)ncells, (unsigned)n, false);
-    if (st == ICPMI_OK) {
-        hipLaunchKernelGGL(dyn_scatter_kernel, dim3(nb), dim3(256), 0, c->stream, n, d_keys, d_start + 1, d_ba, d_rec);
-        hipLaunchKernelGGL(dyn_update_kernel, dim3(mb), dim3(256), 0, c->stream, d_map, d_nrm, m, M, g, dp, (const float4*)d_bx, (const float4*)d_rec, (const unsigned*)d_start, d_prob);
-    }
+    hipLaunchKernelGGL(dyn_beams_kernel, dim3(nb), dim3(256), 0, stream, d_in, n, M, g, d_bx, d_ba, d_keys, d_cnt);
+    icpmi_status st = side_scan ? device_exclusive_scan_cursor_side(c, stream, d_sums, d_cnt, d_start, (int)ncells, (unsigned)n)
+                                : device_exclusive_scan_cursor(c, d_cnt, d_start, (int)ncells, (unsigned)n, false);
     if (st != ICPMI_OK) return st;
+    hipLaunchKernelGGL(dyn_scatter_kernel, dim3(nb), dim3(256), 0, stream, n, d_keys, d_start + 1, d_ba, d_rec);
+    hipLaunchKernelGGL(dyn_update_kernel, dim3(mb), dim3(256), 0, stream, d_map, d_nrm, m, M, g, dp, (const float4*)d_bx, (const float4*)d_rec, (const unsigned*)d_start, d_prob);
     HIP_TRY(c, hipGetLastError());
     return ICPMI_OK;
+}
+
+// whether the side scan of dynpts_dev is available for these parameters (the chain asks before it forks)
+static bool dynpts_side_ok(const icpmi_dynpts_params* prm)
+{
+    const float cell = 2 * prm->beam_half_angle / (float)DYN_RINGS;
+    const int64_t ncells = ((int64_t)floorf(3.14159265358979f / cell) + 2) * ((int64_t)floorf(6.28318530717959f / cell) + 2);
+    return ncells <= (1ll << 28) && device_scan_side_ok((int)ncells);
 }
 
 icpmi_status ops_dynamic_points_update(icpmi_ctx* c, const icpmi_dynpts_params* prm, const float to_sensor[16], const float* in4, int64_t n,
@@ -903,7 +953,7 @@ icpmi_status ops_dynamic_points_update(icpmi_ctx* c, const icpmi_dynpts_params* 
     HIP_TRY(c, hipMemcpyAsync(d_map, map4, (size_t)m * sizeof(float4), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(d_nrm, map_normals3, (size_t)m * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(d_prob, prob, (size_t)m * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    icpmi_status st = dynpts_dev(c, prm, to_sensor, d_in, n, d_map, d_nrm, m, d_prob);
+    icpmi_status st = dynpts_dev(c, prm, to_sensor, d_in, n, d_map, d_nrm, m, d_prob, c->stream);
     if (st != ICPMI_OK) return st;
     HIP_TRY(c, hipMemcpyAsync(prob, d_prob, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1239,6 +1289,16 @@ icpmi_status chain_point_distance_flags(icpmi_ctx* c, icpmi_ctx* ic, const float
 
 } // namespace
 
+// the side stream of the map-update chain and its two events, created on first use
+static bool chain_side_ready(icpmi_ctx* c)
+{
+    if (c->side && c->side_fork && c->side_join) return true;
+    if (!c->side && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { c->side = nullptr; return false; }
+    if (!c->side_fork && hipEventCreateWithFlags(&c->side_fork, hipEventDisableTiming) != hipSuccess) { c->side_fork = nullptr; return false; }
+    if (!c->side_join && hipEventCreateWithFlags(&c->side_join, hipEventDisableTiming) != hipSuccess) { c->side_join = nullptr; return false; }
+    return true;
+}
+
 // the working map moved by T in place: features by T, normals by its rotation (RigidTransformation::compute on the whole map,
 // Map.cpp:523 / :525)
 static icpmi_status chain_move(icpmi_ctx* c, const float T[16], int64_t m, bool has_n)
@@ -1329,8 +1389,17 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
         t0 = std::chrono::steady_clock::now();
     };
     tick(nullptr, 0);
+    static const bool overlap = [] { const char* e = getenv("ICPMI_CHAIN_OVERLAP"); return !e || atoi(e) != 0; }();
+    bool forked = false;
+    auto join = [&]() -> icpmi_status { // the handle's stream waits for the module on the side stream
+        if (!forked) return ICPMI_OK;
+        forked = false;
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->side_join, 0));
+        return ICPMI_OK;
+    };
     for (int i = 0; i < n_ops && s == ICPMI_OK; ++i) {
         const icpmi_map_op& op = ops[i];
+        if (forked && op.type != ICPMI_MOP_OCTREE && op.type != ICPMI_MOP_VOXEL) { s = join(); if (s != ICPMI_OK) break; } // (cannot happen: the fork looks at the next module)
         if (i == n_modules && round_trip) { s = chain_move(c, to_sensor, w.m, w.has_n); in_sensor = true; if (s != ICPMI_OK) break; tick("to_sensor", -1); }
         switch (op.type) {
         case ICPMI_MOP_POINT_DISTANCE: {
@@ -1365,7 +1434,23 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
             s = check_rigid(c, to_sensor);
             if (s != ICPMI_OK) break;
             icpmi_dynpts_params prm = {op.f[0], op.f[1], op.f[2], op.f[3], op.f[4], op.f[5], op.f[6]};
-            s = dynpts_dev(c, &prm, to_sensor, d_scan, n, c->d_raw, c->d_raw_n3, w.m, c->d_raw_s);
+            // r5: the module reads the old map's points and normals and rewrites the probabilities of THOSE points; the decimation that
+            // follows in the shipped chain (OctreeMapperModule: append the scan, sort / hash POSITIONS) does not look at a probability
+            // until it moves the survivors.  Fork: the module on the side stream, the decimation on the handle's, joined in front of the
+            // kernel that moves the descriptors (chain_gather / chain_compact).  The append may not move the arrays under the side
+            // stream: their room is reserved first.
+            const bool decimates_next = i + 1 < n_modules && (ops[i + 1].type == ICPMI_MOP_OCTREE || ops[i + 1].type == ICPMI_MOP_VOXEL);
+            if (overlap && !timing && decimates_next && dynpts_side_ok(&prm) && chain_side_ready(c)) {
+                s = chain_reserve(w, w.m + n);
+                if (s != ICPMI_OK) break;
+                HIP_TRY(c, hipEventRecord(c->side_fork, c->stream));
+                HIP_TRY(c, hipStreamWaitEvent(c->side, c->side_fork, 0));
+                s = dynpts_dev(c, &prm, to_sensor, d_scan, n, c->d_raw, c->d_raw_n3, w.m, c->d_raw_s, c->side);
+                forked = true; // (also after an error: the side stream may hold half of the module)
+                if (s == ICPMI_OK) HIP_TRY(c, hipEventRecord(c->side_join, c->side));
+                break;
+            }
+            s = dynpts_dev(c, &prm, to_sensor, d_scan, n, c->d_raw, c->d_raw_n3, w.m, c->d_raw_s, c->stream);
             break;
         }
         case ICPMI_MOP_VOXEL: {
@@ -1374,6 +1459,7 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
             if (!created) w.has_n = d_scan_n3 != nullptr;
             if (s != ICPMI_OK || w.m == 0) break;
             s = voxel_flags_dev<unsigned>(c, c->d_raw, w.m, op.f[0], op.i, d_flag);
+            if (s == ICPMI_OK) s = join();
             if (s == ICPMI_OK) s = chain_compact(w, d_flag, d_pos);
             break;
         }
@@ -1384,6 +1470,7 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
             if (s != ICPMI_OK || w.m == 0) break;
             int64_t kept = 0;
             s = octree_sample_dev(c, c->d_raw, w.m, op.f[0], (int)op.f[1], op.i, (int*)d_pos, nullptr, &kept);
+            if (s == ICPMI_OK) s = join();
             if (s == ICPMI_OK) s = chain_gather(w, (const int*)d_pos, kept);
             break;
         }
@@ -1403,6 +1490,10 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
         }
         created = true;
         tick("op", op.type);
+    }
+    if (forked) { // an error between fork and join: nothing may be left running on the side stream when the arrays are dropped
+        (void)hipStreamSynchronize(c->side);
+        forked = false;
     }
     if (s == ICPMI_OK && round_trip) {
         if (!in_sensor) s = chain_move(c, to_sensor, w.m, w.has_n); // no post filter at all: the reference still makes the trip
