@@ -354,6 +354,7 @@ struct icpmi_ctx {
     // checked loops (Counter + Differential / Bound: what Mapper::processInput runs) as SEGMENT graphs: [0] = head + the first
     // seg_len iterations, [1] = seg_len further iterations, replayed while the progress word says the loop is still running
     hipGraphExec_t seg_exec[2] = {nullptr, nullptr}; uint64_t seg_sig = 0; int64_t seg_n = -1; int seg_len = 0; bool seg_sorted = false;
+    int seg_uses = 0, seg_wasted = 0; uint64_t eager_sig = 0, map_epoch = 0; int64_t eager_n = -1;   // see drop_loop_graphs (map_epoch: one tick per invalidation)
     // r5: head graphs of OTHER lengths (head + L iterations, L = the iteration count of the handle's previous checked registration): a mapper's
     // registrations stop after about the same number of iterations scan after scan, and a head graph of exactly that length has no dead iterations
     struct SegHead { int len = 0; hipGraphExec_t exec = nullptr; unsigned long used = 0; } seg_heads[4];
@@ -407,6 +408,10 @@ static inline void drop_loop_graphs(icpmi_ctx* c)
     c->graph_n = -1; c->graph_sig = 0;
     if (c->bgraph_exec) { hipGraphExecDestroy(c->bgraph_exec); c->bgraph_exec = nullptr; }
     c->bgraph_sig = 0;
+    // (r5) segment graphs that served a single registration before the map under them changed were not worth their capture: two such
+    // sets in a row and loop_run goes eager until a signature repeats (a mapper rebuilds its map behind every scan)
+    if (c->seg_exec[0]) { if (c->seg_uses <= 1) ++c->seg_wasted; else c->seg_wasted = 0; }
+    c->seg_uses = 0; ++c->map_epoch;
     for (int g = 0; g < 2; ++g) if (c->seg_exec[g]) { hipGraphExecDestroy(c->seg_exec[g]); c->seg_exec[g] = nullptr; }
     for (auto& hd : c->seg_heads) { if (hd.exec) hipGraphExecDestroy(hd.exec); hd.exec = nullptr; hd.len = 0; }
     c->seg_sig = 0; c->seg_n = -1;

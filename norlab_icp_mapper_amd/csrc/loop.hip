@@ -1327,21 +1327,35 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
     // their wider kernel-to-kernel gaps -- for every real iteration.  ICPMI_SEG=0 restores the eager run-ahead loop.
     static int seg_cfg = -1;
     if (seg_cfg < 0) { const char* e = getenv("ICPMI_SEG"); seg_cfg = e ? atoi(e) : 4; }
-    const bool segmented = !graph && !profile && c->cfg.use_graph != 0 && seg_cfg > 0 && (lc.use_diff || lc.use_bound) && c->h_progress &&
-                           lc.max_iter < 0xfff && lc.max_iter > 1;
-    if (!graph && !segmented) {
-        icpmi_status s = enqueue_registration_head(c, d_scan, d_normals3, n);
-        if (s != ICPMI_OK) return s;
-    }
+    bool segmented = !graph && !profile && c->cfg.use_graph != 0 && seg_cfg > 0 && (lc.use_diff || lc.use_bound) && c->h_progress &&
+                     lc.max_iter < 0xfff && lc.max_iter > 1;
+    const int S = seg_cfg > 0 && seg_cfg < lc.max_iter ? seg_cfg : lc.max_iter;
+    uint64_t sig = 1469598103934665603ull;
     if (segmented) {
-        const int S = seg_cfg < lc.max_iter ? seg_cfg : lc.max_iter;
-        uint64_t sig = 1469598103934665603ull;
         sig = fnv(&lc, sizeof lc, sig);
         const void* ptrs[] = {d_scan, d_normals3, c->d_qkeys, c->d_qtile,c->d_reading, c->d_read_normals, c->d_sidx, c->d_d2, c->d_hard, c->d_state, c->d_match_pt,
                               c->d_qsorted, c->d_qindex, c->d_map_sorted, c->d_normals_sorted, c->d_cell_start, c->d_selhist,
                               c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3], c->scratch[4]};
         sig = fnv(ptrs, sizeof ptrs, sig);
         sig = fnv(&c->grid, sizeof c->grid, sig);
+        sig = fnv(&c->map_epoch, sizeof c->map_epoch, sig);
+        // r5: a mapper rebuilds its map behind every scan (Map::updateLocalPointCloud -> icp.setMap), and every rebuild drops the graphs:
+        // capture + instantiate + destroy per scan cost more than they saved (chain bench: register 0.58 -> 0.455 ms, update 1.53 -> 1.45 ms
+        // with no graph at all).  After two sets in a row that served one registration each the handle runs its checked loops eagerly,
+        // until the same map and scan size come back twice (localisation against a fixed map, the benchmark's repeats): then a graph pays again.
+        static const int adapt = [] { const char* e = getenv("ICPMI_GRAPH_ADAPT"); return e ? atoi(e) : 1; }();
+        const bool cached = c->seg_exec[0] && c->seg_exec[1] && c->seg_n == n && c->seg_len == S && c->seg_sig == sig;
+        if (adapt && !cached && c->seg_wasted >= 2) {
+            if (c->eager_sig == sig && c->eager_n == n) c->seg_wasted = 0;
+            else { c->eager_sig = sig; c->eager_n = n; segmented = false; }
+        }
+    }
+    if (!graph && !segmented) {
+        icpmi_status s = enqueue_registration_head(c, d_scan, d_normals3, n);
+        if (s != ICPMI_OK) return s;
+    }
+    if (segmented) {
+        ++c->seg_uses;
         if (!c->seg_exec[0] || !c->seg_exec[1] || c->seg_n != n || c->seg_len != S || c->seg_sig != sig) {
             for (int g = 0; g < 2; ++g) if (c->seg_exec[g]) { hipGraphExecDestroy(c->seg_exec[g]); c->seg_exec[g] = nullptr; }
             for (auto& hd : c->seg_heads) { if (hd.exec) hipGraphExecDestroy(hd.exec); hd.exec = nullptr; hd.len = 0; } // (captured the same pointers)
@@ -1358,7 +1372,7 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
                 hipGraphDestroy(gr);
                 HIP_TRY(c, ie);
             }
-            c->seg_n = n; c->seg_len = S; c->seg_sig = sig; c->seg_sorted = c->nn_out_sorted;
+            c->seg_n = n; c->seg_len = S; c->seg_sig = sig; c->seg_sorted = c->nn_out_sorted; c->seg_uses = 1;
         }
         // r5: the head graph's length follows the handle's previous checked registration.  A mapper registers scan after scan against almost
         // the same map from almost the same prior: the loop stops after the same few iterations every time (6 in the benchmark scene), and

@@ -2266,31 +2266,66 @@ __global__ __launch_bounds__(64) void nnk_wave_kernel(const float4* __restrict__
             ++ring;
             const int side = 2 * ring + 1;
             KList<KMAX> Lc; Lc.init(k); // this lane's share of the ring
-            for (int r0 = lane; r0 < side * side; r0 += 64) {
-                const int dy = r0 % side - ring, dz = r0 / side - ring;
-                const bool full_row = ring == 1 || (dy == -ring || dy == ring || dz == -ring || dz == ring);
-                unsigned s, e;
-                if (full_row) {
-                    row_run(g, cs, cx - ring, cx + ring, cy + dy, cz + dz, s, e);
-                    scan_run_k<KMAX>(map, s, e, p.x, p.y, p.z, allow_self != 0, Lc);
-                } else {
-                    if (cx - ring >= 0) {
-                        row_run(g, cs, cx - ring, cx - ring, cy + dy, cz + dz, s, e);
-                        scan_run_k<KMAX>(map, s, e, p.x, p.y, p.z, allow_self != 0, Lc);
+            // r5: rows to the lanes for their BOUNDS only (one trip for 64 rows); the candidates of the non-empty runs are then dealt to
+            // the lanes 64 at a time, four runs in flight.  (Until r5 a lane scanned its whole row: in ring 1 nine lanes walked ~40 points
+            // each, four per trip, while 55 idled -- 50 us for the ~200 queries the tiled pass leaves.)  Same candidates; a k-list does
+            // not depend on the order they arrive in, nor on the lane that holds them before the merge.
+            for (int base = 0; base < side * side; base += 64) {
+                unsigned rs[2] = {0u, 0u}, re[2] = {0u, 0u};
+                const int r0 = base + lane;
+                if (r0 < side * side) {
+                    const int dy = r0 % side - ring, dz = r0 / side - ring;
+                    const bool full_row = ring == 1 || (dy == -ring || dy == ring || dz == -ring || dz == ring);
+                    if (full_row) row_run(g, cs, cx - ring, cx + ring, cy + dy, cz + dz, rs[0], re[0]);
+                    else {
+                        if (cx - ring >= 0) row_run(g, cs, cx - ring, cx - ring, cy + dy, cz + dz, rs[0], re[0]);
+                        if (cx + ring <= g.nx - 1) row_run(g, cs, cx + ring, cx + ring, cy + dy, cz + dz, rs[1], re[1]);
                     }
-                    if (cx + ring <= g.nx - 1) {
-                        row_run(g, cs, cx + ring, cx + ring, cy + dy, cz + dz, s, e);
-                        scan_run_k<KMAX>(map, s, e, p.x, p.y, p.z, allow_self != 0, Lc);
+                }
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    unsigned long long mask = __ballot(re[half] > rs[half]);
+                    while (mask) {
+                        unsigned bs[4], be[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            bs[u] = be[u] = 0u;
+                            if (mask) {
+                                const int l = __ffsll((long long)mask) - 1;
+                                mask &= mask - 1ull;
+                                bs[u] = (unsigned)__shfl((int)rs[half], l, 64);
+                                be[u] = (unsigned)__shfl((int)re[half], l, 64);
+                            }
+                        }
+                        bool more = true;
+                        for (unsigned off = 0; more; off += 64u) { // (uniform)
+                            float4 q[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) { const unsigned i = bs[u] + off + (unsigned)lane; q[u] = map[i < be[u] ? i : bs[u]]; }
+                            more = false;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const unsigned i = bs[u] + off + (unsigned)lane;
+                                if (i < be[u]) {
+                                    const float d2 = sqdist3(p.x, p.y, p.z, q[u].x, q[u].y, q[u].z);
+                                    if (allow_self || d2 > 1.1920929e-07f) Lc.insert(pack_key(d2, __float_as_uint(q[u].w)), (int)i);
+                                }
+                                more |= bs[u] + off + 64u < be[u];
+                            }
+                        }
                     }
                 }
             }
-            // merge: lane 0 also holds what the earlier rings found (shells are disjoint: no point is seen twice)
-            if (lane == 0) {
+            // merge: lane 0 also holds what the earlier rings found (shells are disjoint: no point is seen twice).  A ring in which no
+            // lane found a candidate leaves the list as it is.
+            const bool ring_empty = __ballot(Lc.key[0] != ~0ull) == 0ull;
+            if (lane == 0 && !ring_empty) {
 #pragma unroll
                 for (int j = 0; j < KMAX; ++j) Lc.insert(Gl.key[j], Gl.sidx[j]);
             }
 #pragma unroll
             for (int j = 0; j < KMAX; ++j) {
+                if (ring_empty) break;
                 const unsigned long long head = Lc.key[0];
                 unsigned long long mk = head;
                 int ms = Lc.sidx[0];

@@ -16,7 +16,7 @@ scans = [pkg.synth.make_scene(m=8, n=n, seed_scan=500 + s)["scan"] for s in rang
 prior = np.eye(4, dtype=np.float32)
 DYN = (0.9, 0.8, 0.99, 0.01, 0.01, 0.01, 200.0)
 post = [("surface_normals", 10), ("cut_scalar", 0.65, 1)]
-kw = dict(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=40, use_differential=1)
+kw = dict(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=40, use_differential=1, use_graph=int(os.environ.get("CHAIN_USE_GRAPH", "1")))
 map0, nrm0 = base["map"][::2], base["normals"][::2]
 prob0 = np.full(map0.shape[0], 0.6, np.float32)
 for name, dec, trip in (("voxel, map frame", ("voxel", 0.15, 1), False), ("octree, map frame", ("octree", 0.15, 1, 1), False),
