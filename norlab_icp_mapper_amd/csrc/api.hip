@@ -145,11 +145,11 @@ icpmi_status icpmi_create(const icpmi_config* cfg, icpmi_handle* out)
         }                                                                                             \
     } while (0)
     CR(hipSetDevice(c->device));
-    CR(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CR(stream_acquire(&c->stream));
     c->own_stream = true;
-    CR(hipMalloc((void**)&c->d_state, sizeof(IcpState) * ICPMI_MAX_BATCH));
+    CR(dev_malloc((void**)&c->d_state, sizeof(IcpState) * ICPMI_MAX_BATCH));
     CR(hipMemset(c->d_state, 0, sizeof(IcpState) * ICPMI_MAX_BATCH));
-    CR(hipMalloc((void**)&c->d_selhist, ICPMI_SELHIST_WORDS * sizeof(unsigned)));
+    CR(dev_malloc((void**)&c->d_selhist, ICPMI_SELHIST_WORDS * sizeof(unsigned)));
     CR(hipMemset(c->d_selhist, 0, ICPMI_SELHIST_WORDS * sizeof(unsigned)));
     c->cap_selhist = ICPMI_SELHIST_WORDS;
     CR(hipHostMalloc((void**)&c->h_state, sizeof(IcpState) * ICPMI_MAX_BATCH, hipHostMallocDefault));
@@ -193,20 +193,20 @@ void icpmi_destroy(icpmi_handle c)
     if (c->bgraph_exec) hipGraphExecDestroy(c->bgraph_exec);
     for (int g = 0; g < 2; ++g) if (c->seg_exec[g]) hipGraphExecDestroy(c->seg_exec[g]);
     for (auto& hd : c->seg_heads) if (hd.exec) hipGraphExecDestroy(hd.exec);
-    hipFree(c->d_map_sorted); hipFree(c->d_normals_sorted); hipFree(c->d_cell_start);
-    for (int l = 0; l < ICPMI_MAXLEV; ++l) { hipFree(c->d_lvl_pts[l]); hipFree(c->d_lvl_cs[l]); hipFree(c->d_lvl_pos0[l]); }
-    hipFree(c->d_inv);
-    for (int l = 0; l < ICPMI_MAXLEV; ++l) { hipFree(c->d_lvl_key[l]); hipFree(c->d_alt_pts[l]); hipFree(c->d_alt_cs[l]); hipFree(c->d_alt_pos0[l]); hipFree(c->d_alt_key[l]); }
-    hipFree(c->d_raw0); hipFree(c->d_alt_raw0); hipFree(c->d_ins_dstart0);
-    hipFree(c->d_alt_nsorted); hipFree(c->d_alt_pn); hipFree(c->d_ins_key); hipFree(c->d_ins_rank);
-    hipFree(c->d_keys); hipFree(c->d_fill); hipFree(c->d_blocksums); hipFree(c->d_red);
-    hipFree(c->d_qsorted); hipFree(c->d_qindex); hipFree(c->d_qkeys); hipFree(c->d_qtile);
-    hipFree(c->d_reading); hipFree(c->d_read_normals); hipFree(c->d_stage_in); hipFree(c->d_stage_n3);
-    hipFree(c->d_match_pt); hipFree(c->d_lvl_tab); hipFree(c->d_raw); hipFree(c->d_raw_n3); hipFree(c->d_raw_s); hipFree(c->d_src); hipFree(c->d_alt_raw); hipFree(c->d_alt_n3);
-    hipFree(c->d_alt_s); hipFree(c->d_alt_src); hipFree(c->d_stage_s); hipFree(c->d_merge_send); hipFree(c->d_merge_recv); hipFree(c->d_merged); hipFree(c->d_comm_cnt); hipFree(c->d_read_noise); hipFree(c->d_read_scalar); hipFree(c->d_map_pn);
-    for (int k = 0; k < ICPMI_SCRATCH_SLOTS; ++k) hipFree(c->scratch[k]); hipFree(c->d_scan_map); hipFree(c->d_T16);
-    hipFree(c->d_sidx); hipFree(c->d_d2); hipFree(c->d_hard); hipFree(c->d_selhist);
-    hipFree(c->d_state);
+    dev_free(c->d_map_sorted); dev_free(c->d_normals_sorted); dev_free(c->d_cell_start);
+    for (int l = 0; l < ICPMI_MAXLEV; ++l) { dev_free(c->d_lvl_pts[l]); dev_free(c->d_lvl_cs[l]); dev_free(c->d_lvl_pos0[l]); }
+    dev_free(c->d_inv);
+    for (int l = 0; l < ICPMI_MAXLEV; ++l) { dev_free(c->d_lvl_key[l]); dev_free(c->d_alt_pts[l]); dev_free(c->d_alt_cs[l]); dev_free(c->d_alt_pos0[l]); dev_free(c->d_alt_key[l]); }
+    dev_free(c->d_raw0); dev_free(c->d_alt_raw0); dev_free(c->d_ins_dstart0);
+    dev_free(c->d_alt_nsorted); dev_free(c->d_alt_pn); dev_free(c->d_ins_key); dev_free(c->d_ins_rank);
+    dev_free(c->d_keys); dev_free(c->d_fill); dev_free(c->d_blocksums); dev_free(c->d_red);
+    dev_free(c->d_qsorted); dev_free(c->d_qindex); dev_free(c->d_qkeys); dev_free(c->d_qtile);
+    dev_free(c->d_reading); dev_free(c->d_read_normals); dev_free(c->d_stage_in); dev_free(c->d_stage_n3);
+    dev_free(c->d_match_pt); dev_free(c->d_lvl_tab); dev_free(c->d_raw); dev_free(c->d_raw_n3); dev_free(c->d_raw_s); dev_free(c->d_src); dev_free(c->d_alt_raw); dev_free(c->d_alt_n3);
+    dev_free(c->d_alt_s); dev_free(c->d_alt_src); dev_free(c->d_stage_s); dev_free(c->d_merge_send); dev_free(c->d_merge_recv); dev_free(c->d_merged); dev_free(c->d_comm_cnt); dev_free(c->d_read_noise); dev_free(c->d_read_scalar); dev_free(c->d_map_pn);
+    for (int k = 0; k < ICPMI_SCRATCH_SLOTS; ++k) dev_free(c->scratch[k]); dev_free(c->d_scan_map); dev_free(c->d_T16);
+    dev_free(c->d_sidx); dev_free(c->d_d2); dev_free(c->d_hard); dev_free(c->d_selhist);
+    dev_free(c->d_state); dev_free(c->d_selfsq);
     if (c->h_state) hipHostFree(c->h_state);
     if (c->h_pin) hipHostFree(c->h_pin);
     if (c->h_nocc) hipHostFree(c->h_nocc);
@@ -216,8 +216,8 @@ void icpmi_destroy(icpmi_handle c)
     for (hipEvent_t e : c->nn_events) hipEventDestroy(e);
     if (c->side_fork) hipEventDestroy(c->side_fork);
     if (c->side_join) hipEventDestroy(c->side_join);
-    if (c->side) hipStreamDestroy(c->side);
-    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    if (c->side) stream_release(c->side);
+    if (c->own_stream && c->stream) stream_release(c->stream);
     delete c;
 }
 
@@ -227,7 +227,7 @@ icpmi_status icpmi_set_stream(icpmi_handle h, void* hip_stream)
 {
     CHECK_H(h);
     if (h->stream) hipStreamSynchronize(h->stream);
-    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    if (h->own_stream && h->stream) stream_release(h->stream);
     h->stream = (hipStream_t)hip_stream;
     h->own_stream = false;
     drop_loop_graphs(h);

@@ -10,6 +10,8 @@
 #include <vector>
 #include <unordered_map>
 #include <mutex>
+#include <map>
+#include <cstdlib>
 
 #include "../../include/icpmi.h"
 
@@ -204,6 +206,114 @@ struct IcpState {
     float T_out[16];
 };
 
+
+// ------------------------------------------------------------------------------------------------
+// Device memory through a process-wide block cache (r5).  hipFree unmaps the block behind a device-wide synchronisation and hipMalloc
+// maps a new one (~0.1 - 0.3 ms a pair at the sizes of a map's arrays); a mapper grows ~20 arrays by doubling while its map grows, every
+// operator call holds a few temporaries, and a replay that builds a fresh mapper pays all of it again (BASELINE config 4: the first two of
+// 14 scans were 14 of 37 ms).  dev_free keeps the block (after the same device-wide synchronisation hipFree implies: nothing in flight
+// can still touch it), dev_malloc hands out the smallest cached block of at least the size asked for and at most twice that + 1 MiB.
+// ICPMI_ALLOC_CACHE_MB (default 4096; 0: plain hipMalloc / hipFree) bounds what is kept; the largest blocks go first.
+// ------------------------------------------------------------------------------------------------
+struct DevBlockCache {
+    std::mutex mu;
+    std::unordered_map<void*, size_t> live;      // every block handed out -> its true size
+    std::multimap<size_t, void*> idle;           // cached blocks by size
+    size_t idle_bytes = 0, limit = 0;
+    bool on = true;
+    DevBlockCache()
+    {
+        const char* e = getenv("ICPMI_ALLOC_CACHE_MB");
+        const long mb = e ? atol(e) : 4096;
+        on = mb > 0; limit = on ? (size_t)mb << 20 : 0;
+    }
+};
+inline DevBlockCache& dev_block_cache() { static DevBlockCache* c = new DevBlockCache; return *c; } // (never destroyed: the runtime may be gone first)
+
+inline hipError_t dev_malloc(void** p, size_t bytes)
+{
+    DevBlockCache& bc = dev_block_cache();
+    if (!bc.on) return hipMalloc(p, bytes);
+    if (bytes == 0) bytes = 1;
+    bytes = (bytes + 255) & ~(size_t)255;
+    {
+        std::lock_guard<std::mutex> lk(bc.mu);
+        auto it = bc.idle.lower_bound(bytes);
+        if (it != bc.idle.end() && it->first <= 2 * bytes + ((size_t)1 << 20)) {
+            *p = it->second; bc.live[*p] = it->first; bc.idle_bytes -= it->first; bc.idle.erase(it);
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) { // out of memory: give the cache back and try once more
+        std::lock_guard<std::mutex> lk(bc.mu);
+        (void)hipGetLastError();
+        for (auto& kv : bc.idle) (void)hipFree(kv.second);
+        bc.idle.clear(); bc.idle_bytes = 0;
+        e = hipMalloc(p, bytes);
+        if (e != hipSuccess) return e;
+    }
+    std::lock_guard<std::mutex> lk(bc.mu);
+    bc.live[*p] = bytes;
+    return hipSuccess;
+}
+
+inline hipError_t dev_free(void* p)
+{
+    if (!p) return hipSuccess;
+    DevBlockCache& bc = dev_block_cache();
+    if (!bc.on) return hipFree(p);
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> lk(bc.mu);
+        auto it = bc.live.find(p);
+        if (it == bc.live.end()) return hipFree(p); // not ours (allocated before the cache was switched on)
+        bytes = it->second; bc.live.erase(it);
+    }
+    const hipError_t e = hipDeviceSynchronize(); // what hipFree would have waited for
+    std::lock_guard<std::mutex> lk(bc.mu);
+    bc.idle.emplace(bytes, p); bc.idle_bytes += bytes;
+    while (bc.idle_bytes > bc.limit && !bc.idle.empty()) {
+        auto last = std::prev(bc.idle.end());
+        (void)hipFree(last->second); bc.idle_bytes -= last->first; bc.idle.erase(last);
+    }
+    return e;
+}
+
+
+// Streams through a process-wide pool (r5): hipStreamCreateWithFlags takes 1.7 - 23 ms on this runtime and hipStreamDestroy 2 - 3.5 ms
+// (rocprofv3 --hip-runtime-trace on the BASELINE config 4 replay: 10 creations = 50 ms of a run whose 42 scans take 130 ms) -- a mapper
+// that is built, fed a trajectory and dropped paid for its handle's stream, the private handle of its map-side operators and the side
+// stream of its chain with its first two scans.  A released stream is drained and kept (at most 16).
+struct StreamPool { std::mutex mu; std::map<int, std::vector<hipStream_t>> idle_of; }; // per device
+inline StreamPool& stream_pool() { static StreamPool* p = new StreamPool; return *p; }
+inline hipError_t stream_acquire(hipStream_t* s)
+{
+    StreamPool& sp = stream_pool();
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lk(sp.mu);
+        auto& idle = sp.idle_of[dev];
+        if (!idle.empty()) { *s = idle.back(); idle.pop_back(); return hipSuccess; }
+    }
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+inline void stream_release(hipStream_t s)
+{
+    if (!s) return;
+    (void)hipStreamSynchronize(s);
+    StreamPool& sp = stream_pool();
+    int dev = 0;
+    (void)hipGetDevice(&dev); // (a handle is created, used and destroyed with its device current: icpmi_create / CHECK_H set it)
+    {
+        std::lock_guard<std::mutex> lk(sp.mu);
+        auto& idle = sp.idle_of[dev];
+        if (idle.size() < 16) { idle.push_back(s); return; }
+    }
+    (void)hipStreamDestroy(s);
+}
+
 #define ICPMI_SCRATCH_SLOTS 20
 struct icpmi_ctx {
     icpmi_config cfg;
@@ -354,7 +464,9 @@ struct icpmi_ctx {
     // checked loops (Counter + Differential / Bound: what Mapper::processInput runs) as SEGMENT graphs: [0] = head + the first
     // seg_len iterations, [1] = seg_len further iterations, replayed while the progress word says the loop is still running
     hipGraphExec_t seg_exec[2] = {nullptr, nullptr}; uint64_t seg_sig = 0; int64_t seg_n = -1; int seg_len = 0; bool seg_sorted = false;
-    int seg_uses = 0, seg_wasted = 0; uint64_t eager_sig = 0, map_epoch = 0; int64_t eager_n = -1;   // see drop_loop_graphs (map_epoch: one tick per invalidation)
+    int64_t self_sq_m = 0;   // point count of the self search whose sum of squared cell counts sits in the mapped page (ICPMI_PROGRESS_SELF_WORD)
+    unsigned long long* d_selfsq = nullptr; int64_t selfsq_m = 0; bool selfsq_dirty = false; // ... and the device word the build of a single-level index leaves that sum in
+    int seg_uses = 0, seg_wasted = 0, graph_uses = 0, graph_wasted = 0; uint64_t eager_sig = 0, map_epoch = 0; int64_t eager_n = -1;   // see drop_loop_graphs (map_epoch: one tick per invalidation)
     // r5: head graphs of OTHER lengths (head + L iterations, L = the iteration count of the handle's previous checked registration): a mapper's
     // registrations stop after about the same number of iterations scan after scan, and a head graph of exactly that length has no dead iterations
     struct SegHead { int len = 0; hipGraphExec_t exec = nullptr; unsigned long used = 0; } seg_heads[4];
@@ -390,11 +502,11 @@ template <typename T>
 static inline icpmi_status ensure_cap(icpmi_ctx* c, T** p, size_t* cap, size_t need)
 {
     if (need <= *cap && *p) return ICPMI_OK;
-    if (*p) { HIP_TRY(c, hipFree(*p)); *p = nullptr; *cap = 0; }
+    if (*p) { HIP_TRY(c, dev_free(*p)); *p = nullptr; *cap = 0; }
     // doubling: a map that grows by a scan's worth of points per update would otherwise reallocate a few of its ~20 arrays on every
     // update, and a hipFree is a device-wide synchronisation (~0.2 ms each, r3 HIP trace: 1 ms per map update); HBM is not the constraint
     size_t want = 2 * need + 64;
-    HIP_TRY(c, hipMalloc((void**)p, want * sizeof(T)));
+    HIP_TRY(c, dev_malloc((void**)p, want * sizeof(T)));
     *cap = want;
     return ICPMI_OK;
 }
@@ -404,8 +516,8 @@ static inline icpmi_status ensure_cap(icpmi_ctx* c, T** p, size_t* cap, size_t n
 // was dropped, and the signature of the segment graphs does not cover mean / m / has_normals / d_map_pn / the level arrays).
 static inline void drop_loop_graphs(icpmi_ctx* c)
 {
-    if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
-    c->graph_n = -1; c->graph_sig = 0;
+    if (c->graph_exec) { if (c->graph_uses <= 1) ++c->graph_wasted; else c->graph_wasted = 0; hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+    c->graph_n = -1; c->graph_sig = 0; c->graph_uses = 0;
     if (c->bgraph_exec) { hipGraphExecDestroy(c->bgraph_exec); c->bgraph_exec = nullptr; }
     c->bgraph_sig = 0;
     // (r5) segment graphs that served a single registration before the map under them changed were not worth their capture: two such
@@ -424,8 +536,8 @@ struct DevBuf {
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    ~DevBuf() { if (p) hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc((void**)&p, (n ? n : 1) * sizeof(T)); }
+    ~DevBuf() { if (p) dev_free(p); }
+    hipError_t alloc(size_t n) { return dev_malloc((void**)&p, (n ? n : 1) * sizeof(T)); }
     operator T*() const { return p; }
 };
 
@@ -436,6 +548,7 @@ struct DevBuf {
 #define ICPMI_PROGRESS_HDR_WORD 64    // ... 256 words: the block headers (counts) of a one-collective epoch, one per rank (ops.hip)
 #define ICPMI_MERGE_MAGIC 0x49435035u // 'ICP5' in the header's y
 #define ICPMI_PROGRESS_OCT_WORD 48  // ... and 8 words for the octree's root cube (octree.hip)
+#define ICPMI_PROGRESS_SELF_WORD 56 // ... two words: sum over the cells of (points in the cell)^2 of the last tiled self search (nn.hip -> map_build.hip)
 #define ICPMI_PROGRESS_SCAN_WORD 40 // word of the host-mapped progress page (api.hip: h_progress, 64 words) that device_scan_flags_count reports into
 static inline icpmi_status read_back2(icpmi_ctx* c, void* dst0, const void* src0, size_t b0, void* dst1, const void* src1, size_t b1)
 {
@@ -478,9 +591,9 @@ static inline T* scratch_get(icpmi_ctx* c, int k, size_t count)
 {
     const size_t need = (count ? count : 1) * sizeof(T);
     if (need > c->scratch_bytes[k] || !c->scratch[k]) {
-        if (c->scratch[k]) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->scratch[k]); c->scratch[k] = nullptr; c->scratch_bytes[k] = 0; }
+        if (c->scratch[k]) { (void)hipStreamSynchronize(c->stream); (void)dev_free(c->scratch[k]); c->scratch[k] = nullptr; c->scratch_bytes[k] = 0; }
         const size_t want = 2 * need + 256;
-        if (hipMalloc(&c->scratch[k], want) != hipSuccess) { c->scratch[k] = nullptr; c->last_error = "out of device memory (operator scratch)"; return nullptr; }
+        if (dev_malloc(&c->scratch[k], want) != hipSuccess) { c->scratch[k] = nullptr; c->last_error = "out of device memory (operator scratch)"; return nullptr; }
         c->scratch_bytes[k] = want;
     }
     return (T*)c->scratch[k];
@@ -493,9 +606,9 @@ static inline icpmi_status ensure_cap_keep(icpmi_ctx* c, T** p, size_t* cap, siz
     if (need <= *cap && *p) return ICPMI_OK;
     const size_t want = 2 * need + 64;
     T* q = nullptr;
-    HIP_TRY(c, hipMalloc((void**)&q, want * sizeof(T)));
+    HIP_TRY(c, dev_malloc((void**)&q, want * sizeof(T)));
     if (*p && used) HIP_TRY(c, hipMemcpyAsync(q, *p, used * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
-    if (*p) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipFree(*p)); }
+    if (*p) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, dev_free(*p)); }
     *p = q; *cap = want;
     return ICPMI_OK;
 }

@@ -1315,7 +1315,7 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
     if (c->cfg.knn <= 8 && sort_queries_reserve(c, n) != ICPMI_OK) return ICPMI_ERR_HIP;
 
     const bool profile = c->cfg.profile != 0;
-    const bool graph = c->cfg.use_graph != 0 && fixed && !profile;
+    bool graph = c->cfg.use_graph != 0 && fixed && !profile;
     float nn_ms_sum = 0.f; int nn_cnt = 0;
     c->reg_seq = (c->reg_seq + 1) & 0x7ffffu;
     if (c->h_progress) __atomic_store_n(c->h_progress + 32, c->reg_seq, __ATOMIC_RELEASE);
@@ -1348,6 +1348,24 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
         if (adapt && !cached && c->seg_wasted >= 2) {
             if (c->eager_sig == sig && c->eager_n == n) c->seg_wasted = 0;
             else { c->eager_sig = sig; c->eager_n = n; segmented = false; }
+        }
+    }
+    uint64_t fsig = 1469598103934665603ull;
+    if (graph) {
+        fsig = fnv(&lc, sizeof lc, fsig);
+        const void* ptrs[] = {d_scan, d_normals3, c->d_qkeys, c->d_qtile,c->d_reading, c->d_read_normals, c->d_sidx, c->d_d2, c->d_hard, c->d_state, c->d_match_pt,
+                              c->d_qsorted, c->d_qindex,
+                              c->d_map_sorted, c->d_normals_sorted, c->d_cell_start, c->d_selhist,
+                              c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3], c->scratch[4]}; // (VarTrimmedDist passes)
+        fsig = fnv(ptrs, sizeof ptrs, fsig);
+        fsig = fnv(&c->grid, sizeof c->grid, fsig);
+        fsig = fnv(&c->map_epoch, sizeof c->map_epoch, fsig);
+        // the same rule for the one-graph registration of a Counter-only chain (the shipped configuration: examples/config.yaml:54-57)
+        static const int adapt = [] { const char* e = getenv("ICPMI_GRAPH_ADAPT"); return e ? atoi(e) : 1; }();
+        const bool cached = c->graph_exec && c->graph_n == n && c->graph_iters == lc.max_iter && c->graph_sig == fsig;
+        if (adapt && !cached && c->graph_wasted >= 2) {
+            if (c->eager_sig == fsig && c->eager_n == n) c->graph_wasted = 0;
+            else { c->eager_sig = fsig; c->eager_n = n; graph = false; }
         }
     }
     if (!graph && !segmented) {
@@ -1435,14 +1453,8 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
     } else if (graph) {
         // the whole registration -- head and all iterations -- is one graph, replayed while the scan
         // buffer, the map and the chain stay the same
-        uint64_t sig = 1469598103934665603ull;
-        sig = fnv(&lc, sizeof lc, sig);
-        const void* ptrs[] = {d_scan, d_normals3, c->d_qkeys, c->d_qtile,c->d_reading, c->d_read_normals, c->d_sidx, c->d_d2, c->d_hard, c->d_state, c->d_match_pt,
-                              c->d_qsorted, c->d_qindex,
-                              c->d_map_sorted, c->d_normals_sorted, c->d_cell_start, c->d_selhist,
-                              c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3], c->scratch[4]}; // (VarTrimmedDist passes)
-        sig = fnv(ptrs, sizeof ptrs, sig);
-        sig = fnv(&c->grid, sizeof c->grid, sig);
+        const uint64_t sig = fsig;
+        ++c->graph_uses;
         if (!c->graph_exec || c->graph_n != n || c->graph_iters != lc.max_iter || c->graph_sig != sig) {
             if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
             hipGraph_t g = nullptr;
@@ -1455,7 +1467,7 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
             hipError_t ie = hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0);
             hipGraphDestroy(g);
             HIP_TRY(c, ie);
-            c->graph_n = n; c->graph_iters = lc.max_iter; c->graph_sig = sig; c->graph_sorted = c->nn_out_sorted;
+            c->graph_n = n; c->graph_iters = lc.max_iter; c->graph_sig = sig; c->graph_sorted = c->nn_out_sorted; c->graph_uses = 1;
         }
         HIP_TRY(c, hipGraphLaunch(c->graph_exec, c->stream));
         if (c->cfg.knn <= 8) { c->qsorted_n = n; c->qsorted_src = c->d_reading; } // what the replayed head leaves in d_qsorted

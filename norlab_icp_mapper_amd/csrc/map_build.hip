@@ -58,6 +58,9 @@ __device__ __forceinline__ int cell_of(float v, float o, float inv, int n)
 // level 0 uses the same trick (r2: 98 -> 4x fewer device atomics on an octree-ordered 0.9 M-point map).
 // (WaveRun / wave_run: common.h -- the bucket grid of the DynamicPoints module uses them too)
 
+#ifndef ICPMI_SELF_TARGET_DEFAULT
+#define ICPMI_SELF_TARGET_DEFAULT 8.0
+#endif
 // ---- pass 2: keys + per-cell histogram -------------------------------------------------------
 __global__ __launch_bounds__(256) void key_kernel(const float4* __restrict__ pts, int64_t m, float mx, float my, float mz,
                                                   GridParams g, unsigned* __restrict__ keys, unsigned* __restrict__ count,
@@ -838,6 +841,17 @@ static icpmi_status grid_count(icpmi_ctx* c, const float4* d_pts, int64_t m, con
     return ICPMI_OK;
 }
 
+// sum over the cells of (points in the cell)^2 -- divided by the point count, the occupancy of the cell an average POINT sits in.
+// The single-level grid of the tiled self search is tuned with it: the mean over occupied cells says 12 where a lidar map's points
+// see 26 (dense near the trajectory, sparse far out), and the search pays for what the points see.
+__global__ __launch_bounds__(256) void sq_counts_kernel(const unsigned* __restrict__ counts, int n, unsigned long long* __restrict__ out)
+{
+    unsigned long long s = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) { const unsigned long long v = counts[i]; s += v * v; }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+}
+
 static GridParams make_grid(const float lo[3], const float hi[3], float cell, float maxabs)
 {
     GridParams g;
@@ -867,7 +881,7 @@ icpmi_status upload_level_table(icpmi_ctx* c)
         t[10] = (uint32_t)pp; t[11] = (uint32_t)(pp >> 32);
         t[12] = (uint32_t)pc; t[13] = (uint32_t)(pc >> 32); t[14] = (uint32_t)p0; t[15] = (uint32_t)(p0 >> 32);
     }
-    if (!c->d_lvl_tab) HIP_TRY(c, hipMalloc((void**)&c->d_lvl_tab, sizeof tab));
+    if (!c->d_lvl_tab) HIP_TRY(c, dev_malloc((void**)&c->d_lvl_tab, sizeof tab));
     return upload_small(c, c->d_lvl_tab, tab, sizeof tab);
 }
 
@@ -1085,7 +1099,11 @@ icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float
         // surfaces (occupied cells ~ area / cell^2): aim at TARGET points per occupied cell.
         static double target_cfg = -1.0;
         if (target_cfg < 0) { const char* e = getenv("ICPMI_GRID_TARGET"); target_cfg = e ? atof(e) : 8.0; }
-        const double TARGET = target_cfg;
+        static double self_target = -1.0; // the single-level grid of the tiled self search (SurfaceNormal): its own optimum (ICPMI_SELF_TARGET)
+        if (self_target < 0) { const char* e = getenv("ICPMI_SELF_TARGET"); self_target = e ? atof(e) : ICPMI_SELF_TARGET_DEFAULT; }
+        const double TARGET = c->single_level ? self_target : target_cfg;
+        static double self_sb_target = -1.0; // ICPMI_SELF_SB_TARGET: size-biased occupancy the self-search grid aims at (0: the mean-occupancy rule only)
+        if (self_sb_target < 0) { const char* e = getenv("ICPMI_SELF_SB_TARGET"); self_sb_target = e ? atof(e) : 11.0; }
         // A handle that rebuilds the index of a slowly growing map (every map update, twice) does not wait for the occupancy of THIS
         // build: it corrects the edge with the count of the previous one, which arrived in pinned memory long ago (r3: one stream
         // synchronisation less per build; ICPMI_GRID_DEFER=0 restores the read-back).  The edge only steers speed: the search is exact.
@@ -1094,10 +1112,25 @@ icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float
         if (defer && c->h_nocc && c->nocc_m > 0 && c->grid.cell > 0.f && c->m > 0 && (double)m > 0.7 * (double)c->m && (double)m < 1.4 * (double)c->m) {
             const double occ = (double)c->nocc_m / (double)std::max(1u, *c->h_nocc);
             double cell = c->grid.cell;
+            const unsigned long long sq_prev = c->single_level && c->h_progress && c->self_sq_m > 0 && self_sb_target > 0.0
+                ? *reinterpret_cast<volatile unsigned long long*>(c->h_progress + ICPMI_PROGRESS_SELF_WORD) : 0ull;
+            // the self-search index: by what its last search's points saw (written by that search, long arrived) -- where that differs
+            // from the mean over occupied cells, i.e. where the density has a heavy tail (a lidar map: dense along the trajectory);
+            // evenly sampled surfaces keep the occupancy rule they were tuned with
+            const double sb_prev = sq_prev ? (double)sq_prev / (double)c->self_sq_m : 0.0;
+            if (sb_prev > 1.6 * occ) {
+                if (!(sb_prev > self_sb_target * 0.88 && sb_prev < self_sb_target * 1.12)) cell = cell * sqrt(self_sb_target / sb_prev);
+            } else
             if (!(occ > TARGET * 0.6 && occ < TARGET * 1.6)) cell = cell * sqrt(TARGET / occ);
             g = make_grid(clo, chi, clamp_cell(cell), maxabs);
             n_occ = *c->h_nocc;
             if (grid_count(c, d_pts, m, g, nullptr) != ICPMI_OK) return ICPMI_ERR_HIP;
+            if (c->single_level && self_sb_target > 0.0) { // what the points of THIS build see, for the build after it (nn.hip: nnk_redo_kernel delivers it)
+                if (!c->d_selfsq) { HIP_TRY(c, dev_malloc((void**)&c->d_selfsq, sizeof(unsigned long long))); HIP_TRY(c, hipMemsetAsync(c->d_selfsq, 0, sizeof(unsigned long long), c->stream)); }
+                else if (c->selfsq_dirty) HIP_TRY(c, hipMemsetAsync(c->d_selfsq, 0, sizeof(unsigned long long), c->stream)); // (a build no search followed)
+                hipLaunchKernelGGL(sq_counts_kernel, dim3(std::min((g.ncells + 255) / 256, 2048)), dim3(256), 0, c->stream, (const unsigned*)c->d_fill, g.ncells, c->d_selfsq);
+                c->selfsq_m = m; c->selfsq_dirty = true;
+            }
             c->nocc_m = m;
             goto grid_chosen;
         }
@@ -1108,6 +1141,32 @@ icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float
         if (c->grid.cell > 0.f && c->m > 0 && (double)m > 0.7 * (double)c->m && (double)m < 1.4 * (double)c->m) cell = c->grid.cell;
         g = make_grid(clo, chi, clamp_cell(cell), maxabs);
         if (grid_count(c, d_pts, m, g, &n_occ) != ICPMI_OK) return ICPMI_ERR_HIP;
+        if (c->single_level && self_sb_target > 0.0) {
+            // first builds of the self-search index (nothing deferred to go by): correct the edge with the size-biased occupancy, read back
+            for (int it = 0; it < 3; ++it) {
+                unsigned long long* d_sq = reinterpret_cast<unsigned long long*>(c->d_blocksums); // (free between builds' scans)
+                unsigned long long sq = 0;
+                if (ensure_cap(c, &c->d_blocksums, &c->cap_blocksums, 4) != ICPMI_OK) return ICPMI_ERR_HIP;
+                d_sq = reinterpret_cast<unsigned long long*>(c->d_blocksums);
+                HIP_TRY(c, hipMemsetAsync(d_sq, 0, sizeof sq, c->stream));
+                hipLaunchKernelGGL(sq_counts_kernel, dim3(std::min((g.ncells + 255) / 256, 2048)), dim3(256), 0, c->stream, (const unsigned*)c->d_fill, g.ncells, d_sq);
+                if (read_back(c, &sq, d_sq, sizeof sq) != ICPMI_OK) return ICPMI_ERR_HIP;
+                const double sb = (double)sq / (double)m, occ_now = (double)m / (double)std::max(1u, n_occ);
+                if (!(sb > 1.6 * occ_now)) { // evenly sampled: the occupancy rule
+                    if (occ_now > TARGET * 0.6 && occ_now < TARGET * 1.6) break;
+                    const float c3 = clamp_cell(g.cell * sqrt(TARGET / occ_now));
+                    if (fabsf(c3 - g.cell) < 0.05f * g.cell) break;
+                    g = make_grid(clo, chi, c3, maxabs);
+                    if (grid_count(c, d_pts, m, g, &n_occ) != ICPMI_OK) return ICPMI_ERR_HIP;
+                    continue;
+                }
+                if (sb > self_sb_target * 0.88 && sb < self_sb_target * 1.12) break;
+                const float c2 = clamp_cell(g.cell * sqrt(self_sb_target / sb));
+                if (fabsf(c2 - g.cell) < 0.05f * g.cell) break;
+                g = make_grid(clo, chi, c2, maxabs);
+                if (grid_count(c, d_pts, m, g, &n_occ) != ICPMI_OK) return ICPMI_ERR_HIP;
+            }
+        } else
         for (int it = 0; it < 2; ++it) {
             const double occ = (double)m / (double)std::max(1u, n_occ);
             if (occ > TARGET * 0.6 && occ < TARGET * 1.6) break;

@@ -2096,14 +2096,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KMAX <= 8 ?
 // One wave per workgroup: a 4-cell segment holds ~40 queries, so wider workgroups would idle most of their lanes.
 constexpr int SELF_SEG = 4, SELF_CH = 384, SELF_BLOCK = 64;
 
+// one segment (SELF_SEG x-cells of one (y, z) row) by one wave
 template <int KMAX, int SELF_Q>
-__global__ __launch_bounds__(SELF_BLOCK) __attribute__((amdgpu_waves_per_eu(KMAX <= 10 ? 5 : 1))) void nnk_self_tiled_kernel(GridParams g, const float4* __restrict__ map,
-                                                                  const unsigned* __restrict__ cs, int k, int* __restrict__ out_sidx,
-                                                                  float* __restrict__ out_d2, IcpState* __restrict__ st,
-                                                                  unsigned* __restrict__ queue)
+__device__ __forceinline__ void self_tiled_segment(const int b, const GridParams& g, const float4* __restrict__ map,
+                                                   const unsigned* __restrict__ cs, int k, int* __restrict__ out_sidx,
+                                                   float* __restrict__ out_d2, IcpState* __restrict__ st,
+                                                   unsigned* __restrict__ queue)
 {
     const int nsx = (g.nx + SELF_SEG - 1) / SELF_SEG;
-    const int b = blockIdx.x;
     const int sx = b % nsx, y = (b / nsx) % g.ny, z = b / (nsx * g.ny);
     const int x0 = sx * SELF_SEG, x1 = min(x0 + SELF_SEG, g.nx); // query cells [x0, x1)
     const int qbase = (z * g.ny + y) * g.nx;
@@ -2141,7 +2141,11 @@ __global__ __launch_bounds__(SELF_BLOCK) __attribute__((amdgpu_waves_per_eu(KMAX
     }
     if (threadIdx.x <= SELF_SEG) qb[threadIdx.x] = cs[qbase + min(x0 + (int)threadIdx.x, x1)];
     __syncthreads();
+
     const unsigned ncand = run_p[9];
+#ifdef ICPMI_SELF_WORK_DIAG
+    if (threadIdx.x == 0) atomicAdd(&st->dbg[23], (unsigned long long)(qe - qs) * (unsigned long long)ncand); // (one address: costs 0.2 ms on 30 k segments)
+#endif
     for (unsigned q0 = qs; q0 < qe; q0 += SELF_BLOCK) { // one wave of queries at a time (one pass for all but dense cells)
         const unsigned qi = q0 + threadIdx.x;
         const bool active = qi < qe;
@@ -2226,6 +2230,43 @@ __global__ __launch_bounds__(SELF_BLOCK) __attribute__((amdgpu_waves_per_eu(KMAX
         } else {
             const unsigned slot = atomicAdd(&st->hard_count, 1u); // reused as the length of the redo queue
             queue[slot] = orig;
+        }
+    }
+}
+
+// The launch.  PERSIST = false: workgroup b takes segment b (a grid that is mostly occupied: the synthetic scenes, an indoor map).
+// PERSIST = true (r5): a fixed number of workgroups take batches of SELF_BATCH consecutive segments in turn, look at the batch's cell
+// starts with one lane each and work through the occupied ones -- the map of a vehicle's trajectory fills 0.3 % of its bounding grid
+// (BASELINE config 4: 5 000 of 377 000 segments), and a workgroup per segment spent 0.4 ms of the launch on starting and ending empty
+// workgroups.  (Batches drawn from a counter instead: every draw is an atomic on ONE address, 47 000 of them -- slower than what it
+// replaced.)  st->dbg[23] collects queries x staged candidates, a cost figure for diagnostics (the state is cleared in front of every self search).
+constexpr int SELF_BATCH = 64;
+template <int KMAX, int SELF_Q, bool PERSIST>
+__global__ __launch_bounds__(SELF_BLOCK) __attribute__((amdgpu_waves_per_eu(KMAX <= 10 ? 5 : 1))) void nnk_self_tiled_kernel(GridParams g, const float4* __restrict__ map,
+                                                                  const unsigned* __restrict__ cs, int k, int* __restrict__ out_sidx,
+                                                                  float* __restrict__ out_d2, IcpState* __restrict__ st,
+                                                                  unsigned* __restrict__ queue, unsigned nseg)
+{
+    if (!PERSIST) { self_tiled_segment<KMAX, SELF_Q>((int)blockIdx.x, g, map, cs, k, out_sidx, out_d2, st, queue); return; }
+    const int nsx = (g.nx + SELF_SEG - 1) / SELF_SEG;
+    // workgroup w owns the segments b = w (mod gridDim.x): neighbours along x -- occupied together where the map is -- go to
+    // different workgroups (64 CONSECUTIVE segments per workgroup put a wall's whole row on one wave: 2.5 x slower than no list at all)
+    for (unsigned i0 = 0; (unsigned long long)i0 * gridDim.x + blockIdx.x < nseg; i0 += SELF_BATCH) {
+        const unsigned long long bl = (unsigned long long)(i0 + threadIdx.x) * gridDim.x + blockIdx.x;
+        bool occupied = false;
+        if (bl < nseg) {
+            const int b = (int)bl;
+            const int sx = b % nsx, y = (b / nsx) % g.ny, z = b / (nsx * g.ny);
+            const int x0 = sx * SELF_SEG, x1 = min(x0 + SELF_SEG, g.nx);
+            const int qbase = (z * g.ny + y) * g.nx;
+            occupied = cs[qbase + x1] > cs[qbase + x0];
+        }
+        unsigned long long mask = __ballot(occupied);
+        while (mask) {
+            const int l = __ffsll((long long)mask) - 1;
+            mask &= mask - 1ull;
+            self_tiled_segment<KMAX, SELF_Q>((int)((i0 + (unsigned)l) * gridDim.x + blockIdx.x), g, map, cs, k, out_sidx, out_d2, st, queue);
+            __syncthreads();
         }
     }
 }
@@ -2372,9 +2413,14 @@ __global__ __launch_bounds__(64) void nnk_wave_kernel(const float4* __restrict__
 
 // between the tiled self-search and its redo: queue length -> queue[m + 1] (read by the ring kernel as `only_count`),
 // hard_count reset so that the ring kernel can queue its own left-overs for the brute-force pass
-__global__ void nnk_redo_kernel(IcpState* st, unsigned* len_slot)
+__global__ void nnk_redo_kernel(IcpState* st, unsigned* len_slot, unsigned long long* sq_dev, unsigned long long* sq_mapped)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) { *len_slot = st->hard_count; st->hard_count = 0; }
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        *len_slot = st->hard_count; st->hard_count = 0;
+        // sum of squared cell counts of this index (sq_counts_kernel at its build): to the host-mapped page, where the NEXT build of the
+        // index reads it (map_build.hip); the device word is handed back clean
+        if (sq_dev && sq_mapped) { *sq_mapped = *sq_dev; *sq_dev = 0ull; }
+    }
 }
 
 } // namespace
@@ -2586,13 +2632,26 @@ static icpmi_status nn_self_knn_t(icpmi_ctx* c, const float4* d_cloud, const Loo
     if (wgs > 0x7fffffffll) { c->last_error = "self knn: grid too large"; return ICPMI_ERR_UNSUPPORTED; }
     static int self_q = -1; // candidates a lane queues before the wave inserts them (nnk_self_tiled_kernel)
     if (self_q < 0) { const char* e = getenv("ICPMI_SELF_Q"); self_q = e ? atoi(e) : 8; }
-#define LAUNCH_SELF(Q_) hipLaunchKernelGGL((nnk_self_tiled_kernel<KMAX, Q_>), dim3((unsigned)wgs), dim3(SELF_BLOCK), 0, c->stream, g, c->d_map_sorted, \
-                                           c->d_cell_start, lc.k, d_sidx, d_d2, d_state, c->d_hard)
+    // a grid whose segments are mostly empty is worked through by a fixed number of workgroups (see the kernel); the occupancy is the
+    // one this index was built with (h_nocc: written by the build's scan, long arrived)
+    static int persist_cfg = -1; // ICPMI_SELF_PERSIST: 0 never, 1 always, default: by occupancy
+    if (persist_cfg < 0) { const char* e = getenv("ICPMI_SELF_PERSIST"); persist_cfg = e ? atoi(e) : 2; }
+    const double occupied_cells = c->h_nocc && *c->h_nocc ? (double)*c->h_nocc : (double)g.ncells;
+    const bool persist = persist_cfg == 1 || (persist_cfg == 2 && occupied_cells * 32.0 < (double)g.ncells);
+    const unsigned pgrid = (unsigned)std::min<long long>(wgs, 8192);
+#define LAUNCH_SELF(Q_) do { \
+        if (persist) hipLaunchKernelGGL((nnk_self_tiled_kernel<KMAX, Q_, true>), dim3(pgrid), dim3(SELF_BLOCK), 0, c->stream, g, c->d_map_sorted, \
+                                        c->d_cell_start, lc.k, d_sidx, d_d2, d_state, c->d_hard, (unsigned)wgs); \
+        else hipLaunchKernelGGL((nnk_self_tiled_kernel<KMAX, Q_, false>), dim3((unsigned)wgs), dim3(SELF_BLOCK), 0, c->stream, g, c->d_map_sorted, \
+                                c->d_cell_start, lc.k, d_sidx, d_d2, d_state, c->d_hard, (unsigned)wgs); } while (0)
     if (self_q <= 1) LAUNCH_SELF(1); else if (self_q <= 4) LAUNCH_SELF(4); else if (self_q <= 8) LAUNCH_SELF(8); else LAUNCH_SELF(16);
 #undef LAUNCH_SELF
     // left-overs (k-th neighbour beyond the margin: sparse regions, map border): ring search, then brute force
     const int blocks = (int)((c->m + NN_BLOCK - 1) / NN_BLOCK);
-    hipLaunchKernelGGL(nnk_redo_kernel, dim3(1), dim3(64), 0, c->stream, d_state, c->d_hard + c->m + 1);
+    const bool sq_ready = c->d_progress && c->d_selfsq && c->selfsq_m == c->m; // (the build of THIS index left its sum in d_selfsq)
+    hipLaunchKernelGGL(nnk_redo_kernel, dim3(1), dim3(64), 0, c->stream, d_state, c->d_hard + c->m + 1, sq_ready ? c->d_selfsq : (unsigned long long*)nullptr,
+                       sq_ready ? reinterpret_cast<unsigned long long*>(c->d_progress + ICPMI_PROGRESS_SELF_WORD) : (unsigned long long*)nullptr);
+    if (sq_ready) { c->self_sq_m = c->m; c->selfsq_dirty = false; }
     static int wave_redo = -1;
     if (wave_redo < 0) { const char* e = getenv("ICPMI_SELF_REDO_WAVE"); wave_redo = e ? atoi(e) : 1; }
     if (wave_redo)
@@ -2614,6 +2673,26 @@ static icpmi_status nn_self_knn_t(icpmi_ctx* c, const float4* d_cloud, const Loo
             unsigned left = 0;
             if (read_back(c, &left, c->d_hard + c->m + 1, sizeof(unsigned)) == ICPMI_OK)
                 fprintf(stderr, "[icpmi self-knn] m %lld k %d: %u queries (%.2f %%) redone by the ring kernel\n", (long long)c->m, lc.k, left, 100.0 * left / (double)c->m);
+#ifdef ICPMI_SELF_WORK_DIAG
+            {
+                unsigned long long work = 0;
+                if (hipMemcpy(&work, &d_state->dbg[23], sizeof work, hipMemcpyDeviceToHost) == hipSuccess)
+                    fprintf(stderr, "[icpmi self-knn] staged candidates per query: %.1f\n", (double)work / (double)c->m);
+            }
+#endif
+            if (diag > 1) { // the shape of the grid the tiled pass was launched over
+                std::vector<unsigned> cs((size_t)g.ncells + 1);
+                if (hipMemcpy(cs.data(), c->d_cell_start, cs.size() * sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess) {
+                    unsigned occ = 0, mx = 0, seg_occ = 0, seg_mx = 0; unsigned long long sq = 0;
+                    for (int i = 0; i < g.ncells; ++i) { const unsigned n1 = cs[i + 1] - cs[i]; occ += n1 > 0; mx = n1 > mx ? n1 : mx; sq += (unsigned long long)n1 * n1; }
+                    for (int z = 0; z < g.nz; ++z) for (int y = 0; y < g.ny; ++y) for (int x = 0; x < g.nx; x += SELF_SEG) {
+                        const int b = (z * g.ny + y) * g.nx; const int x1 = x + SELF_SEG < g.nx ? x + SELF_SEG : g.nx;
+                        const unsigned n1 = cs[b + x1] - cs[b + x]; seg_occ += n1 > 0; seg_mx = n1 > seg_mx ? n1 : seg_mx;
+                    }
+                    fprintf(stderr, "[icpmi self-knn] grid %d x %d x %d = %d cells (edge %.3f), %u occupied, max %u per cell, size-biased mean %.1f; %lld segments, %u occupied, max %u\n",
+                            g.nx, g.ny, g.nz, g.ncells, g.cell, occ, mx, (double)sq / (double)c->m, (long long)wgs, seg_occ, seg_mx);
+                }
+            }
         }
     }
     return ICPMI_OK;

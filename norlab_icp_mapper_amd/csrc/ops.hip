@@ -579,7 +579,7 @@ static void share_stream(icpmi_ctx* c, icpmi_ctx* t)
     if (on < 0) { const char* e = getenv("ICPMI_SHARE_STREAM"); on = e ? atoi(e) : 1; }
     if (!on || t->stream == c->stream) return;
     if (t->stream) (void)hipStreamSynchronize(t->stream);
-    if (t->own_stream && t->stream) (void)hipStreamDestroy(t->stream);
+    if (t->own_stream && t->stream) stream_release(t->stream);
     t->stream = c->stream; t->own_stream = false;
     drop_loop_graphs(t);
 }
@@ -1293,7 +1293,7 @@ icpmi_status chain_point_distance_flags(icpmi_ctx* c, icpmi_ctx* ic, const float
 static bool chain_side_ready(icpmi_ctx* c)
 {
     if (c->side && c->side_fork && c->side_join) return true;
-    if (!c->side && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { c->side = nullptr; return false; }
+    if (!c->side && stream_acquire(&c->side) != hipSuccess) { c->side = nullptr; return false; }
     if (!c->side_fork && hipEventCreateWithFlags(&c->side_fork, hipEventDisableTiming) != hipSuccess) { c->side_fork = nullptr; return false; }
     if (!c->side_join && hipEventCreateWithFlags(&c->side_join, hipEventDisableTiming) != hipSuccess) { c->side_join = nullptr; return false; }
     return true;
