@@ -1,0 +1,187 @@
+"""The runtime around the kernels: loops that leave their graphs when the map changes behind every scan and come
+back to them, the process-wide stream pool and device block cache under handle churn and two threads, the library with both switched
+off, the self-search grid that follows what the points see.  None of it may change a bit of any result: every check is bitwise
+against a handle that runs eagerly, against the same computation done first, or against the oracle.
+
+Reference: the registrations stand behind Mapper::processInput (Mapper.cpp:213), the rebuild behind Map::updateLocalPointCloud ->
+icp.setMap (Map.cpp:528), the normals behind the post filters (Map.cpp:523-525)."""
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import norlab_icp_mapper_amd as pkg
+    return pkg
+
+
+def _bits(T):
+    return np.asarray(T, dtype=np.float32).view(np.uint32).copy()
+
+
+@pytest.mark.parametrize("checked", [1, 0])
+def test_mapper_mode_leaves_its_graphs_and_comes_back_with_the_same_bits(amd, small_scene, checked):
+    """A mapper replaces its map behind every scan: after two graph sets that served one registration each the handle runs its loops
+    eagerly (ICPMI_GRAPH_ADAPT), and returns to graphs when a map is registered against twice.  Checked loops (Counter + Differential:
+    segment graphs) and the Counter-only chain of the shipped configuration (one graph): every pose equals, bit for bit, the pose of a
+    handle that never used a graph."""
+    sc = small_scene
+    kw = dict(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=40 if checked else 10, use_differential=checked)
+    icp = amd.ICPSequence(**kw)
+    ref = amd.ICPSequence(use_graph=0, **kw)
+    rng = np.random.default_rng(11)
+    m = sc["map"].shape[0]
+    its = []
+    for j in range(7):                      # seven different maps, one registration each: graphs are dropped every time
+        keep = np.sort(rng.permutation(m)[: m - 500 * (j + 1)])
+        for h in (icp, ref):
+            h.setMap(sc["map"][keep], sc["normals"][keep])
+        T, Tr = icp(sc["scan"]), ref(sc["scan"])
+        assert icp.stats.iterations == ref.stats.iterations and icp.stats.stop_reason == ref.stats.stop_reason
+        assert np.array_equal(_bits(T), _bits(Tr)), j
+        its.append(icp.stats.iterations)
+    first = None
+    for rep in range(5):                    # ... then localisation against the last map: the same signature comes back, graphs pay again
+        T, Tr = icp(sc["scan"]), ref(sc["scan"])
+        assert np.array_equal(_bits(T), _bits(Tr)), rep
+        first = _bits(T) if first is None else first
+        assert np.array_equal(_bits(T), first)
+    scan2 = sc["scan"][::2].copy()          # another reading size in between
+    assert np.array_equal(_bits(icp(scan2)), _bits(ref(scan2)))
+    assert np.array_equal(_bits(icp(sc["scan"])), first)
+    assert min(its) >= 2
+
+
+def test_handle_churn_through_the_block_cache_and_the_stream_pool(amd, small_scene):
+    """Handles created and destroyed in turn, with maps of different sizes: released streams and device blocks are handed to the next
+    handle (common.h: stream_acquire / dev_malloc).  A block that is larger than asked for, or that held another handle's map, must not
+    show: every registration equals the first one made with that map size."""
+    sc = small_scene
+    kw = dict(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=8, use_differential=0)
+    sizes = [60000, 20000, 45000, 60000, 9000, 45000, 20000, 60000, 9000, 30000, 45000, 60000]
+    seen = {}
+    for k, msz in enumerate(sizes):
+        icp = amd.ICPSequence(**kw)
+        icp.setMap(sc["map"][:msz], sc["normals"][:msz])
+        T = _bits(icp(sc["scan"]))
+        nrm = icp.surfaceNormals(sc["map"][: msz // 3], knn=7)
+        if msz in seen:
+            assert np.array_equal(T, seen[msz][0]), (k, msz)
+            assert np.array_equal(nrm.view(np.uint32), seen[msz][1].view(np.uint32)), (k, msz)
+        else:
+            seen[msz] = (T, nrm.copy())
+        if k % 3 != 2:
+            icp.close()                     # (every third handle is left to the garbage collector)
+    many = [amd.ICPSequence(**kw) for _ in range(20)]   # more streams than the pool keeps
+    for h in many:
+        h.close()
+    icp = amd.ICPSequence(**kw)
+    icp.setMap(sc["map"][:45000], sc["normals"][:45000])
+    assert np.array_equal(_bits(icp(sc["scan"])), seen[45000][0])
+
+
+def test_two_threads_two_handles(amd, small_scene):
+    """One handle per thread (the contract of include/icpmi.h), both allocating and releasing through the shared cache and pool while
+    the other registers: same bits as the serial runs."""
+    sc = small_scene
+    kw = dict(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=40, use_differential=1)
+    maps = [(sc["map"][:50000], sc["normals"][:50000]), (sc["map"][10000:], sc["normals"][10000:])]
+    serial = []
+    for mp, nr in maps:
+        icp = amd.ICPSequence(**kw); icp.setMap(mp, nr); serial.append(_bits(icp(sc["scan"]))); icp.close()
+    out = [[], []]
+    errs = []
+
+    def work(t):
+        try:
+            for rep in range(6):
+                icp = amd.ICPSequence(**kw)
+                icp.setMap(*maps[t])
+                out[t].append(_bits(icp(sc["scan"])))
+                out[t].append(_bits(icp(sc["scan"])))
+                icp.close()
+        except Exception as e:  # noqa: BLE001 -- reported below, in the main thread
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in (0, 1)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for t in (0, 1):
+        assert len(out[t]) == 12
+        for T in out[t]:
+            assert np.array_equal(T, serial[t])
+
+
+_CHILD = r"""
+import sys, hashlib
+import numpy as np
+sys.path.insert(0, %r)
+import norlab_icp_mapper_amd as pkg
+sc = pkg.synth.make_scene(m=60000, n=6000)
+h = hashlib.sha256()
+icp = pkg.ICPSequence(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=40, use_differential=1)
+icp.setMap(sc["map"][::2], sc["normals"][::2])
+icp.setMapScalar(np.full(sc["map"][::2].shape[0], 0.6, np.float32))
+prior = np.eye(4, dtype=np.float32)
+for k in range(4):
+    scan = pkg.synth.make_scene(m=8, n=6000, seed_scan=900 + k)["scan"]
+    corr = icp.registerWithPrior(scan, prior)
+    pose = (corr @ prior).astype(np.float32)
+    src, m = icp.mapUpdateChain(None, [("dynamic_points", 0.9, 0.8, 0.99, 0.01, 0.01, 0.01, 200.0), ("octree", 0.15, 1, 1)],
+                                [("surface_normals", 10), ("cut_scalar", 0.65, 1)], scan_scalar=np.full(6000, 0.6, np.float32),
+                                to_sensor=np.linalg.inv(pose), from_sensor=pose, staged_correction=corr)
+    h.update(np.asarray(corr, np.float32).tobytes()); h.update(src.tobytes()); h.update(icp.getMapScalar().tobytes())
+print("DIGEST", h.hexdigest(), m)
+"""
+
+
+def test_switches_off_same_bits():
+    """The same four scans through registration + the shipped map-update chain in three fresh processes: defaults; no block cache, no
+    graph adaptation, no chain overlap, no octree speculation; and the self-search grid on the mean-occupancy rule only.  One digest over
+    every correction, every provenance vector and the surviving probabilities."""
+    def run(extra):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-c", _CHILD % ROOT], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("DIGEST")]
+        assert line, r.stdout[-500:] + r.stderr[-500:]
+        return line[0]
+    a = run({})
+    b = run({"ICPMI_ALLOC_CACHE_MB": "0", "ICPMI_GRAPH_ADAPT": "0", "ICPMI_CHAIN_OVERLAP": "0", "ICPMI_OCT_SPECULATE": "0", "ICPMI_SEG_ADAPT": "0"})
+    c = run({"ICPMI_SELF_SB_TARGET": "0", "ICPMI_SCAN2": "0"})
+    assert a == b == c
+
+
+def test_self_search_grid_follows_the_density_and_the_neighbours_do_not(amd, oracle):
+    """A cloud with a heavy-tailed density (a dense patch along a 'trajectory', sparse far field): the single-level grid of the tiled self
+    search is re-tuned from what the points of the previous search saw (sum of squared cell counts).  The search is exact whatever the
+    grid: neighbour ids, normals and mean distances of the first, second and third call on ONE handle are identical, and the ids are the
+    oracle's."""
+    rng = np.random.default_rng(5)
+    dense = np.c_[rng.uniform(-3, 3, 60000), rng.uniform(-3, 3, 60000), 0.02 * rng.standard_normal(60000)]
+    ring = rng.uniform(0, 2 * np.pi, 25000); rad = rng.uniform(20, 120, 25000)
+    far = np.c_[rad * np.cos(ring), rad * np.sin(ring), 0.5 * rng.standard_normal(25000) + 0.01 * rad]
+    wall = np.c_[rng.uniform(-40, 40, 15000), np.full(15000, 35.0) + 0.03 * rng.standard_normal(15000), rng.uniform(0, 6, 15000)]
+    pts = np.concatenate([dense, far, wall]).astype(np.float32)
+    cloud = np.c_[pts, np.ones(len(pts), np.float32)].astype(np.float32)
+    cloud = cloud[rng.permutation(len(cloud))]
+    icp = amd.ICPSequence(minimizer=2)
+    runs = [icp.surfaceNormals(cloud, knn=10, with_matched_ids=True, with_mean_dist=True) for _ in range(3)]
+    for r in runs[1:]:
+        for x, y in zip(r, runs[0]):
+            assert np.array_equal(np.ascontiguousarray(x).view(np.uint32), np.ascontiguousarray(y).view(np.uint32))
+    _, ids_o, md_o = oracle.surface_normals_extras(cloud, knn=10, nthreads=8)
+    assert np.array_equal(runs[0][1], ids_o)
+    assert np.array_equal(runs[0][2].view(np.uint32), md_o.view(np.uint32))
