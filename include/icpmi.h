@@ -341,6 +341,15 @@ icpmi_status icpmi_voxel_keep(icpmi_handle h, const float* in4, int64_t n, float
  * order, normals3_out (capacity 3 n) their normals; *n_out the number kept.  Entirely on the device (csrc/ssn.hip). */
 icpmi_status icpmi_sampling_surface_normal(icpmi_handle h, const float* in4, int64_t n, float ratio, int32_t knn, float max_box_dim, int32_t seed,
                                            int32_t* order_out, float* normals3_out, int64_t* n_out);
+/* ... with `samplingMethod` (upstream's fuseRange, as recalled): 0 = the call above (the extra outputs are not touched); 1 = every surviving box
+ * is replaced by ONE point: order_out[j] = the smallest index of box j (the column the caller keeps), mean3_out[3 j ..] its new position -- the
+ * mean of the box, accumulated in double in index order --, normals3_out[3 j ..] the box normal, and members_out[member_start_out[j] ..
+ * + member_count_out[j]) the members of the box in index order: what `averageExistingDescriptors` averages over (descriptor rows live with
+ * the caller).  No random number is drawn; boxes in depth-first order; *n_out = number of boxes.  Capacities n (3 n for mean3_out); any
+ * of the four extra outputs may be NULL.  Entirely on the device. */
+icpmi_status icpmi_sampling_surface_normal_ex(icpmi_handle h, const float* in4, int64_t n, float ratio, int32_t knn, float max_box_dim, int32_t seed,
+                                              int32_t method, int32_t* order_out, float* normals3_out, int64_t* n_out, float* mean3_out,
+                                              int32_t* member_start_out, int32_t* member_count_out, int32_t* members_out);
 
 /* `OctreeGridDataPointsFilter{maxSizeByNode, maxPointByNode, samplingMethod}` (created at OctreeMapperModule.cpp:12, applied at :38):
  * octree over the bounding cube of the cloud, split until the node edge is <= max_size or the node holds <= max_points points

@@ -119,6 +119,7 @@ SYMBOLS = [
     ("icpmi_filter_points", C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, _P]),
     ("icpmi_voxel_keep", C.c_int, [_P, _P, C.c_int64, C.c_float, C.c_int32, _P]),
     ("icpmi_sampling_surface_normal", C.c_int, [_P, _P, C.c_int64, C.c_float, C.c_int32, C.c_float, C.c_int32, _P, _P, _P]),
+    ("icpmi_sampling_surface_normal_ex", C.c_int, [_P, _P, C.c_int64, C.c_float, C.c_int32, C.c_float, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
     ("icpmi_octree_sample", C.c_int, [_P, _P, C.c_int64, C.c_float, C.c_int32, C.c_int32, _P, _P, _P]),
     ("icpmi_map_update_chain", C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, C.c_int64, _P, _P]),
     ("icpmi_map_update_chain_staged", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, C.c_int64, _P, _P]),

@@ -790,6 +790,18 @@ icpmi_status icpmi_sampling_surface_normal(icpmi_handle h, const float* in4, int
     return ops_sampling_surface_normal(h, in4, n, ratio, knn, max_box_dim, seed, order_out, normals3_out, n_out);
 }
 
+icpmi_status icpmi_sampling_surface_normal_ex(icpmi_handle h, const float* in4, int64_t n, float ratio, int32_t knn, float max_box_dim, int32_t seed,
+                                              int32_t method, int32_t* order_out, float* normals3_out, int64_t* n_out, float* mean3_out,
+                                              int32_t* member_start_out, int32_t* member_count_out, int32_t* members_out)
+{
+    CHECK_H(h);
+    if (n < 0 || (n > 0 && !in4) || !(ratio > 0.f) || !(ratio <= 1.f) || knn < 3 || !(max_box_dim > 0.f) || seed < 0 || (method != 0 && method != 1)) {
+        h->last_error = "sampling_surface_normal: bad arguments (0 < ratio <= 1, knn >= 3, maxBoxDim > 0, seed >= 0, samplingMethod 0 or 1)"; return ICPMI_ERR_INVALID_ARG;
+    }
+    return ops_sampling_surface_normal_ex(h, in4, n, ratio, knn, max_box_dim, seed, method, order_out, normals3_out, n_out, mean3_out, member_start_out,
+                                          member_count_out, members_out);
+}
+
 icpmi_status icpmi_octree_sample(icpmi_handle h, const float* in4, int64_t n, float max_size, int32_t max_points, int32_t method,
                                  int32_t* order_out, int32_t* leaf_of_out, int64_t* n_out)
 {

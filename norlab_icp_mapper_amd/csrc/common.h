@@ -771,7 +771,11 @@ icpmi_status ops_staged_merge_allgather(icpmi_ctx* c, const float correction[16]
 icpmi_status ops_staged_merged_points(icpmi_ctx* c, float* out4, int64_t capacity, int64_t* n);
 icpmi_status ssn_debug_minstd(icpmi_ctx* c, unsigned seed, unsigned n, unsigned* out);
 icpmi_status ssn_sample_dev(icpmi_ctx* c, const float4* d_in, int64_t n, float ratio, int knn, float max_box, unsigned seed, int* d_order_out,
-                            float* d_normals_out, int64_t* n_out);
+                            float* d_normals_out, int64_t* n_out, int method = 0, float* d_mean_out = nullptr, int* d_mstart_out = nullptr,
+                            int* d_mcount_out = nullptr, int* d_members_out = nullptr, int64_t* n_members_out = nullptr);
+icpmi_status ops_sampling_surface_normal_ex(icpmi_ctx* c, const float* in4, int64_t n, float ratio, int knn, float max_box, int seed, int method,
+                                            int32_t* order_out, float* normals3_out, int64_t* n_out, float* mean3_out, int32_t* mstart_out,
+                                            int32_t* mcount_out, int32_t* members_out);
 icpmi_status ops_sampling_surface_normal(icpmi_ctx* c, const float* in4, int64_t n, float ratio, int knn, float max_box, int seed, int32_t* order_out,
                                          float* normals3_out, int64_t* n_out);
 size_t radix_sort_tab_words(int64_t n, int bits);

@@ -133,7 +133,7 @@ __device__ void ssn_jacobi3(double* A, double* w, double* Q) // the oracle's cyc
 // boxes wider than maxBoxDim or of rank < 2 are dropped.  draws[pos] = 1 for every point of a surviving box (it consumes one random number).
 __global__ __launch_bounds__(128) void ssn_fuse_kernel(const float4* __restrict__ p, int64_t n, const unsigned* __restrict__ order,
                                                        const unsigned* __restrict__ nstart, const unsigned* __restrict__ ncnt, float max_box,
-                                                       float* __restrict__ box_normal, unsigned* __restrict__ draws)
+                                                       float* __restrict__ box_normal, unsigned* __restrict__ draws, float* __restrict__ box_mean)
 {
     const int64_t pos = (int64_t)blockIdx.x * 128 + threadIdx.x;
     if (pos >= n) return;
@@ -169,6 +169,7 @@ __global__ __launch_bounds__(128) void ssn_fuse_kernel(const float4* __restrict_
         for (int r = 0; r < 3; ++r) nrm[r] = (float)Q[3 * e + r];
     }
     for (int r = 0; r < 3; ++r) box_normal[3 * pos + r] = nrm[r];
+    if (box_mean) for (int r = 0; r < 3; ++r) box_mean[3 * pos + r] = (float)mean[r]; // (samplingMethod 1: the box's new point; divided above when the box survives)
     for (unsigned k = 0; k < cnt; ++k) draws[pos + k] = ok ? 1u : 0u;
 }
 
@@ -211,6 +212,37 @@ __global__ __launch_bounds__(256) void ssn_emit_kernel(int64_t n, const unsigned
     for (int r = 0; r < 3; ++r) normals_out[3 * (size_t)o + r] = box_normal[3 * (size_t)s + r];
 }
 
+// samplingMethod 1: one output per surviving box.  first[pos] = pos is the first position of a surviving box
+__global__ __launch_bounds__(256) void ssn_first_kernel(int64_t n, const unsigned* __restrict__ order, const unsigned* __restrict__ nstart,
+                                                        const unsigned* __restrict__ draws, unsigned* __restrict__ first)
+{
+    const int64_t pos = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (pos >= n) return;
+    first[pos] = (draws[pos] && nstart[order[pos]] == (unsigned)pos) ? 1u : 0u;
+}
+
+// ... box j (= outpos of its first position): smallest member index (the box is in index order), normal, mean, its run in the member list;
+// every point of a surviving box goes to the member list at its rank among such points
+__global__ __launch_bounds__(256) void ssn_emit_box_kernel(int64_t n, const unsigned* __restrict__ order, const unsigned* __restrict__ ncnt,
+                                                           const unsigned* __restrict__ draws, const unsigned* __restrict__ rank,
+                                                           const unsigned* __restrict__ first, const unsigned* __restrict__ outpos,
+                                                           const float* __restrict__ box_normal, const float* __restrict__ box_mean,
+                                                           int* __restrict__ order_out, float* __restrict__ normals_out, float* __restrict__ mean_out,
+                                                           int* __restrict__ mstart_out, int* __restrict__ mcount_out, int* __restrict__ members_out)
+{
+    const int64_t pos = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (pos >= n || !draws[pos]) return;
+    const unsigned i = order[pos];
+    if (members_out) members_out[rank[pos]] = (int)i;
+    if (!first[pos]) return;
+    const unsigned o = outpos[pos];
+    order_out[o] = (int)i;
+    for (int r = 0; r < 3; ++r) normals_out[3 * (size_t)o + r] = box_normal[3 * (size_t)pos + r];
+    if (mean_out) for (int r = 0; r < 3; ++r) mean_out[3 * (size_t)o + r] = box_mean[3 * (size_t)pos + r];
+    if (mstart_out) mstart_out[o] = (int)rank[pos];
+    if (mcount_out) mcount_out[o] = (int)ncnt[i];
+}
+
 } // namespace
 
 // test seam (icpmi_debug_minstd_nth): the value ssn_draw_kernel's skip-ahead computes for the n-th number of the stream
@@ -224,10 +256,14 @@ icpmi_status ssn_debug_minstd(icpmi_ctx* c, unsigned seed, unsigned n, unsigned*
 }
 
 // device pointers in, device pointers out (d_order_out / d_normals_out: capacity n / 3 n); *n_out read back once
+// method 1 (samplingMethod 1): one output per surviving box -- its smallest index, its normal, d_mean_out (3 per box) its new position,
+// d_members_out[d_mstart_out[j] .. + d_mcount_out[j]) its members in index order (*n_members_out of them in all); the extras may be null.
 icpmi_status ssn_sample_dev(icpmi_ctx* c, const float4* d_in, int64_t n, float ratio, int knn, float max_box, unsigned seed, int* d_order_out,
-                            float* d_normals_out, int64_t* n_out)
+                            float* d_normals_out, int64_t* n_out, int method, float* d_mean_out, int* d_mstart_out, int* d_mcount_out,
+                            int* d_members_out, int64_t* n_members_out)
 {
     *n_out = 0;
+    if (n_members_out) *n_members_out = 0;
     if (n == 0) return ICPMI_OK;
     if (n > 0x7ffffff0ll) { c->last_error = "SamplingSurfaceNormal: too many points"; return ICPMI_ERR_UNSUPPORTED; }
     if (knn < 3) { c->last_error = "InvalidParameter: SamplingSurfaceNormalDataPointsFilter knn must be >= 3"; return ICPMI_ERR_INVALID_ARG; }
@@ -236,13 +272,14 @@ icpmi_status ssn_sample_dev(icpmi_ctx* c, const float4* d_in, int64_t n, float r
     while ((1ll << nbits) <= n) ++nbits;
     const int bits = 32 + nbits;
     DevBuf<unsigned long long> d_keys; DevBuf<unsigned> d_vals, d_nstart, d_ncnt, d_tab, d_draws, d_rank, d_keep, d_outpos;
-    DevBuf<SsnBox> d_box[2]; DevBuf<float> d_part, d_bnrm;
+    DevBuf<SsnBox> d_box[2]; DevBuf<float> d_part, d_bnrm, d_bmean;
     HIP_TRY(c, d_keys.alloc(2 * (size_t)n)); HIP_TRY(c, d_vals.alloc(2 * (size_t)n));
     HIP_TRY(c, d_nstart.alloc((size_t)n)); HIP_TRY(c, d_ncnt.alloc((size_t)n));
     HIP_TRY(c, d_tab.alloc(radix_sort_tab_words(n, bits)));
     HIP_TRY(c, d_box[0].alloc((size_t)n + 1)); HIP_TRY(c, d_box[1].alloc((size_t)n + 1));
     HIP_TRY(c, d_draws.alloc((size_t)n + 2)); HIP_TRY(c, d_rank.alloc((size_t)n + 2)); HIP_TRY(c, d_keep.alloc((size_t)n + 2)); HIP_TRY(c, d_outpos.alloc((size_t)n + 2));
     HIP_TRY(c, d_bnrm.alloc(3 * (size_t)n));
+    if (method == 1) HIP_TRY(c, d_bmean.alloc(3 * (size_t)n));
     constexpr int RB = 64;
     HIP_TRY(c, d_part.alloc(6 * RB));
     // root box
@@ -271,9 +308,25 @@ icpmi_status ssn_sample_dev(icpmi_ctx* c, const float4* d_in, int64_t n, float r
     }
     const unsigned* d_order = d_vals.p + (half ? n : 0);
     hipLaunchKernelGGL(ssn_fuse_kernel, dim3((int)((n + 127) / 128)), dim3(128), 0, c->stream, d_in, n, d_order, (const unsigned*)d_nstart.p, (const unsigned*)d_ncnt.p,
-                       max_box, d_bnrm.p, d_draws.p);
+                       max_box, d_bnrm.p, d_draws.p, method == 1 ? d_bmean.p : nullptr);
     icpmi_status s = device_exclusive_scan_io(c, d_draws.p, d_rank.p, (int)n, 0u);
     if (s != ICPMI_OK) return s;
+    if (method == 1) { // no random number: every surviving box gives one point
+        hipLaunchKernelGGL(ssn_first_kernel, dim3(blocks), dim3(256), 0, c->stream, n, d_order, (const unsigned*)d_nstart.p, (const unsigned*)d_draws.p, d_keep.p);
+        s = device_exclusive_scan_io(c, d_keep.p, d_outpos.p, (int)n, 0u);
+        if (s != ICPMI_OK) return s;
+        unsigned lp = 0, lk = 0, lr = 0, ld = 0;
+        if (read_back2(c, &lp, d_outpos.p + (n - 1), sizeof(unsigned), &lk, d_keep.p + (n - 1), sizeof(unsigned)) != ICPMI_OK) return ICPMI_ERR_HIP;
+        if (read_back2(c, &lr, d_rank.p + (n - 1), sizeof(unsigned), &ld, d_draws.p + (n - 1), sizeof(unsigned)) != ICPMI_OK) return ICPMI_ERR_HIP;
+        hipLaunchKernelGGL(ssn_emit_box_kernel, dim3(blocks), dim3(256), 0, c->stream, n, d_order, (const unsigned*)d_ncnt.p, (const unsigned*)d_draws.p,
+                           (const unsigned*)d_rank.p, (const unsigned*)d_keep.p, (const unsigned*)d_outpos.p, (const float*)d_bnrm.p, (const float*)d_bmean.p,
+                           d_order_out, d_normals_out, d_mean_out, d_mstart_out, d_mcount_out, d_members_out);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipStreamSynchronize(c->stream)); // the scratch of this call is freed on return
+        *n_out = (int64_t)lp + lk;
+        if (n_members_out) *n_members_out = (int64_t)lr + ld;
+        return ICPMI_OK;
+    }
     hipLaunchKernelGGL(ssn_draw_kernel, dim3(blocks), dim3(256), 0, c->stream, n, (const unsigned*)d_draws.p, (const unsigned*)d_rank.p, ratio, seed, d_keep.p);
     s = device_exclusive_scan_io(c, d_keep.p, d_outpos.p, (int)n, 0u);
     if (s != ICPMI_OK) return s;
@@ -287,23 +340,37 @@ icpmi_status ssn_sample_dev(icpmi_ctx* c, const float4* d_in, int64_t n, float r
     return ICPMI_OK;
 }
 
-// host-pointer entry (icpmi_sampling_surface_normal)
-icpmi_status ops_sampling_surface_normal(icpmi_ctx* c, const float* in4, int64_t n, float ratio, int knn, float max_box, int seed, int32_t* order_out,
-                                         float* normals3_out, int64_t* n_out)
+// host-pointer entries (icpmi_sampling_surface_normal, icpmi_sampling_surface_normal_ex)
+icpmi_status ops_sampling_surface_normal_ex(icpmi_ctx* c, const float* in4, int64_t n, float ratio, int knn, float max_box, int seed, int method,
+                                            int32_t* order_out, float* normals3_out, int64_t* n_out, float* mean3_out, int32_t* mstart_out,
+                                            int32_t* mcount_out, int32_t* members_out)
 {
     if (n_out) *n_out = 0;
     if (n == 0) return ICPMI_OK;
-    DevBuf<float4> d_in; DevBuf<int> d_order; DevBuf<float> d_nrm;
+    DevBuf<float4> d_in; DevBuf<int> d_order, d_ms, d_mc, d_mem; DevBuf<float> d_nrm, d_mean;
     HIP_TRY(c, d_in.alloc((size_t)n)); HIP_TRY(c, d_order.alloc((size_t)n)); HIP_TRY(c, d_nrm.alloc(3 * (size_t)n));
+    if (method == 1) { HIP_TRY(c, d_mean.alloc(3 * (size_t)n)); HIP_TRY(c, d_ms.alloc((size_t)n)); HIP_TRY(c, d_mc.alloc((size_t)n)); HIP_TRY(c, d_mem.alloc((size_t)n)); }
     HIP_TRY(c, hipMemcpyAsync(d_in.p, in4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-    int64_t kept = 0;
-    const icpmi_status s = ssn_sample_dev(c, d_in.p, n, ratio, knn, max_box, (unsigned)seed, d_order.p, d_nrm.p, &kept);
+    int64_t kept = 0, members = 0;
+    const icpmi_status s = ssn_sample_dev(c, d_in.p, n, ratio, knn, max_box, (unsigned)seed, d_order.p, d_nrm.p, &kept, method, d_mean.p, d_ms.p, d_mc.p, d_mem.p, &members);
     if (s != ICPMI_OK) return s;
     if (kept > 0) {
         if (order_out) HIP_TRY(c, hipMemcpyAsync(order_out, d_order.p, (size_t)kept * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         if (normals3_out) HIP_TRY(c, hipMemcpyAsync(normals3_out, d_nrm.p, 3 * (size_t)kept * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        if (method == 1) {
+            if (mean3_out) HIP_TRY(c, hipMemcpyAsync(mean3_out, d_mean.p, 3 * (size_t)kept * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+            if (mstart_out) HIP_TRY(c, hipMemcpyAsync(mstart_out, d_ms.p, (size_t)kept * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            if (mcount_out) HIP_TRY(c, hipMemcpyAsync(mcount_out, d_mc.p, (size_t)kept * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            if (members_out && members > 0) HIP_TRY(c, hipMemcpyAsync(members_out, d_mem.p, (size_t)members * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        }
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     if (n_out) *n_out = kept;
     return ICPMI_OK;
+}
+
+icpmi_status ops_sampling_surface_normal(icpmi_ctx* c, const float* in4, int64_t n, float ratio, int knn, float max_box, int seed, int32_t* order_out,
+                                         float* normals3_out, int64_t* n_out)
+{
+    return ops_sampling_surface_normal_ex(c, in4, n, ratio, knn, max_box, seed, 0, order_out, normals3_out, n_out, nullptr, nullptr, nullptr, nullptr);
 }

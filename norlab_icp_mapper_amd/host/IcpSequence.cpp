@@ -745,7 +745,7 @@ struct SamplingSurfaceNormalFilter : DataPointsFilter {
         if (h && method == 0 && knn >= 3 && seed >= 0) {
             // r3: the partition, the box normals and the sampling run on the device (csrc/ssn.hip: one radix sort per tree level) -- the
             // filter sits on the REFERENCE of the default chain, i.e. on the whole map at every icp.setMap; the host recursion below
-            // (one thread) stays for samplingMethod 1 and for a shell without a GPU context
+            // (one thread) is what a shell WITHOUT a GPU context runs (the CPU-only unit tests of the host classes)
             std::vector<int32_t> order(n);
             std::vector<float> nrm(3 * n);
             int64_t kept = 0;
@@ -753,6 +753,35 @@ struct SamplingSurfaceNormalFilter : DataPointsFilter {
             DataPoints out = c.createSimilarEmpty();
             for (int64_t k = 0; k < kept; ++k) out.appendColFrom(c, (size_t)order[(size_t)k]);
             nrm.resize(3 * (size_t)kept);
+            if (keepNormals) out.addDescriptor("normals", 3, std::move(nrm));
+            c = std::move(out);
+            return;
+        }
+        if (h && method == 1 && knn >= 3) {
+            // r5: samplingMethod 1 on the device too -- partition, box normals and box means by csrc/ssn.hip; what stays here is the
+            // bookkeeping of the container: the kept column per box and, with averageExistingDescriptors, the mean of every descriptor
+            // row over the members the device lists (descriptor rows live in this container, not on the device)
+            std::vector<int32_t> order(n), ms(n), mc(n), mem(n);
+            std::vector<float> nrm(3 * n), mean(3 * n);
+            int64_t boxes = 0;
+            GpuICPSequence::check(h, icpmi_sampling_surface_normal_ex(h, c.features.data(), (int64_t)n, 1.0f, knn, maxBoxDim, seed < 0 ? 1 : seed, 1, order.data(),
+                                                                      nrm.data(), &boxes, mean.data(), ms.data(), mc.data(), mem.data()));
+            DataPoints out = c.createSimilarEmpty();
+            for (int64_t b = 0; b < boxes; ++b) {
+                out.appendColFrom(c, (size_t)order[(size_t)b]);
+                const size_t j = out.getNbPoints() - 1;
+                for (int r = 0; r < 3; ++r) out.col(j)[r] = mean[3 * (size_t)b + r];
+                if (averageDescriptors)
+                    for (size_t d = 0; d < c.descriptors.size(); ++d) {
+                        const Descriptor& src = c.descriptors[d];
+                        for (int r = 0; r < src.span; ++r) {
+                            double s2 = 0;
+                            for (int32_t k = 0; k < mc[(size_t)b]; ++k) s2 += src.data[(size_t)src.span * mem[(size_t)ms[(size_t)b] + k] + r];
+                            out.descriptors[d].data[(size_t)src.span * j + r] = (float)(s2 / (double)mc[(size_t)b]);
+                        }
+                    }
+            }
+            nrm.resize(3 * (size_t)boxes);
             if (keepNormals) out.addDescriptor("normals", 3, std::move(nrm));
             c = std::move(out);
             return;

@@ -467,6 +467,19 @@ class ICPSequence:
                                                             nrm.ctypes.data, C.byref(n_out)))
         return order[:n_out.value].copy(), nrm[:n_out.value].copy()
 
+    def samplingSurfaceNormalBoxes(self, cloud, knn=7, max_box_dim=math.inf):
+        """icpmi_sampling_surface_normal_ex with samplingMethod 1: one point per surviving box -- (first member index, normal, mean of the box,
+        member start, member count, members in index order)."""
+        c = _f32c(cloud, 4); n = c.shape[0]
+        order = np.empty(n, dtype=np.int32); nrm = np.empty((n, 3), dtype=np.float32); mean = np.empty((n, 3), dtype=np.float32)
+        ms = np.empty(n, dtype=np.int32); mc = np.empty(n, dtype=np.int32); mem = np.empty(n, dtype=np.int32)
+        n_out = C.c_int64(0)
+        self._check(self._lib.icpmi_sampling_surface_normal_ex(self._h, c.ctypes.data, n, 1.0, knn, max_box_dim, 1, 1, order.ctypes.data, nrm.ctypes.data,
+                                                               C.byref(n_out), mean.ctypes.data, ms.ctypes.data, mc.ctypes.data, mem.ctypes.data))
+        k = n_out.value
+        tot = int(ms[k - 1] + mc[k - 1]) if k else 0
+        return order[:k].copy(), nrm[:k].copy(), mean[:k].copy(), ms[:k].copy(), mc[:k].copy(), mem[:tot].copy()
+
     def octreeSample(self, cloud, max_size, max_points=1, method=0, with_leaves=False):
         """OctreeGridDataPointsFilter: indices of the kept points in leaf-visiting order (+ the leaf ordinal of every point)"""
         c = _f32c(cloud, 4)

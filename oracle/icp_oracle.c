@@ -1589,7 +1589,9 @@ static int orc_ssn_cmp(const void* a, const void* b)
     return ia < ib ? -1 : (ia > ib ? 1 : 0);
 }
 static int orc_i32_cmp(const void* a, const void* b) { const int32_t x = *(const int32_t*)a, y = *(const int32_t*)b; return x < y ? -1 : (x > y ? 1 : 0); }
-typedef struct { const float* p; float ratio; int knn; float max_box; orc_minstd g; int32_t* order; float* normals; int64_t n_out; } orc_ssn_ctx;
+typedef struct { const float* p; float ratio; int knn; float max_box; orc_minstd g; int32_t* order; float* normals; int64_t n_out;
+                 /* samplingMethod 1 (orc_sampling_surface_normal_ex): one output per surviving box */
+                 int method; float* mean; int32_t* mstart; int32_t* mcount; int32_t* members; int64_t n_members; } orc_ssn_ctx;
 static void orc_ssn_fuse(orc_ssn_ctx* c, int32_t* idx, int64_t cnt)
 {
     qsort(idx, (size_t)cnt, sizeof(int32_t), orc_i32_cmp);
@@ -1622,6 +1624,20 @@ static void orc_ssn_fuse(orc_ssn_ctx* c, int32_t* idx, int64_t cnt)
     int e = 0;
     if (w[1] < w[e]) e = 1;
     if (w[2] < w[e]) e = 2;
+    if (c->method == 1) {
+        /* samplingMethod 1 [UPSTREAM, as recalled: fuseRange's second branch]: the box is replaced by ONE point -- the first of its list
+         * (here: its smallest index) moved to the mean of the box; existing descriptors are averaged over the members by the caller
+         * (averageExistingDescriptors), who gets the member list for it.  No random number is drawn. */
+        const int64_t o = c->n_out;
+        c->order[o] = idx[0];
+        for (int r = 0; r < 3; ++r) { c->normals[3 * o + r] = (float)Q[3 * e + r]; if (c->mean) c->mean[3 * o + r] = (float)mean[r]; }
+        if (c->mstart) c->mstart[o] = (int32_t)c->n_members;
+        if (c->mcount) c->mcount[o] = (int32_t)cnt;
+        if (c->members) for (int64_t k = 0; k < cnt; ++k) c->members[c->n_members + k] = idx[k];
+        c->n_members += cnt;
+        ++c->n_out;
+        return;
+    }
     for (int64_t k = 0; k < cnt; ++k)
         if (orc_minstd_unit(&c->g, 0) < c->ratio) {
             c->order[c->n_out] = idx[k];
@@ -1655,6 +1671,29 @@ int64_t orc_sampling_surface_normal(const float* pts4, int64_t n, float ratio, i
         for (int r = 0; r < 3; ++r) { const float v = pts4[4 * i + r]; if (v < lo[r]) lo[r] = v; if (v > hi[r]) hi[r] = v; }
     }
     orc_ssn_ctx c; c.p = pts4; c.ratio = ratio; c.knn = knn; c.max_box = max_box_dim; c.order = order_out; c.normals = normals_out; c.n_out = 0;
+    c.method = 0; c.mean = NULL; c.mstart = NULL; c.mcount = NULL; c.members = NULL; c.n_members = 0;
+    orc_minstd_seed(&c.g, (uint32_t)seed);
+    orc_ssn_build(&c, idx, n, lo, hi);
+    free(idx);
+    return c.n_out;
+}
+/* ... with `samplingMethod`: 0 as above (the extra outputs are not touched); 1 = one point per surviving box: order_out[j] = the smallest
+ * index of box j, mean3_out[3 j ..] its new position (the mean of the box, accumulated in double in index order), normals_out its normal,
+ * members_out[mstart_out[j] .. + mcount_out[j]) the members in index order (what a caller averages the descriptors over).  Boxes in
+ * depth-first order.  Any of mean3_out / mstart_out / mcount_out / members_out (capacity 3 n / n / n / n) may be NULL. */
+int64_t orc_sampling_surface_normal_ex(const float* pts4, int64_t n, float ratio, int knn, float max_box_dim, int seed, int method,
+                                       int32_t* order_out, float* normals_out, float* mean3_out, int32_t* mstart_out, int32_t* mcount_out,
+                                       int32_t* members_out)
+{
+    if (n <= 0) return 0;
+    int32_t* idx = (int32_t*)malloc((size_t)n * sizeof(int32_t));
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = 0; i < n; ++i) {
+        idx[i] = (int32_t)i;
+        for (int r = 0; r < 3; ++r) { const float v = pts4[4 * i + r]; if (v < lo[r]) lo[r] = v; if (v > hi[r]) hi[r] = v; }
+    }
+    orc_ssn_ctx c; c.p = pts4; c.ratio = ratio; c.knn = knn; c.max_box = max_box_dim; c.order = order_out; c.normals = normals_out; c.n_out = 0;
+    c.method = method == 1 ? 1 : 0; c.mean = mean3_out; c.mstart = mstart_out; c.mcount = mcount_out; c.members = members_out; c.n_members = 0;
     orc_minstd_seed(&c.g, (uint32_t)seed);
     orc_ssn_build(&c, idx, n, lo, hi);
     free(idx);

@@ -198,6 +198,10 @@ void orc_random_sampling_keep(int64_t n, float prob, int method, int seed, uint8
 void orc_max_density_keep(const float* densities, int64_t n, float max_density, int seed, uint8_t* keep);
 int64_t orc_sampling_surface_normal(const float* pts4, int64_t n, float ratio, int knn, float max_box_dim, int seed, int32_t* order_out,
                                     float* normals_out);
+/* ... with samplingMethod 0 | 1 (1: one point per surviving box at the mean of the box; see icp_oracle.c) */
+int64_t orc_sampling_surface_normal_ex(const float* pts4, int64_t n, float ratio, int knn, float max_box_dim, int seed, int method,
+                                       int32_t* order_out, float* normals_out, float* mean3_out, int32_t* mstart_out, int32_t* mcount_out,
+                                       int32_t* members_out);
 int64_t orc_octree_sample(const float* in4, int64_t n, float max_size, int64_t max_pts, int method, int32_t* order_out);
 /* DynamicPointsMapperModule::inPlaceUpdateMap (DynamicPointsMapperModule.cpp:34-172).  prm = {thresholdDynamic, alpha,
  * beta, beamHalfAngle, epsilonA, epsilonD, sensorMaxRange}; to_sensor = pose^-1 (col-major); prob updated in place. */

@@ -361,6 +361,19 @@ def sampling_surface_normal(cloud, ratio=0.5, knn=7, max_box_dim=math.inf, seed=
     return order[:m].copy(), nrm[:m].copy()
 
 
+def sampling_surface_normal_boxes(cloud, knn=7, max_box_dim=math.inf):
+    """samplingMethod 1: (first member index, normal, mean, member start, member count, members) per surviving box"""
+    lib = load(); c = _f32(cloud); n = c.shape[0]
+    order = np.empty(n, dtype=np.int32); nrm = np.empty((n, 3), dtype=np.float32); mean = np.empty((n, 3), dtype=np.float32)
+    ms = np.empty(n, dtype=np.int32); mc = np.empty(n, dtype=np.int32); mem = np.empty(n, dtype=np.int32)
+    lib.orc_sampling_surface_normal_ex.restype = C.c_int64
+    lib.orc_sampling_surface_normal_ex.argtypes = [_P, C.c_int64, C.c_float, C.c_int, C.c_float, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]
+    k = lib.orc_sampling_surface_normal_ex(c.ctypes.data, n, 1.0, knn, max_box_dim, 1, 1, order.ctypes.data, nrm.ctypes.data, mean.ctypes.data,
+                                           ms.ctypes.data, mc.ctypes.data, mem.ctypes.data)
+    tot = int(ms[k - 1] + mc[k - 1]) if k else 0
+    return order[:k].copy(), nrm[:k].copy(), mean[:k].copy(), ms[:k].copy(), mc[:k].copy(), mem[:tot].copy()
+
+
 def octree_sample(cloud, max_size, max_pts=1, method=0):
     """OctreeGridDataPointsFilter: original indices of the kept points, in leaf-visiting order"""
     lib = load(); c = _f32(cloud); order = np.empty(c.shape[0], dtype=np.int32)

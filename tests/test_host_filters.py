@@ -150,3 +150,66 @@ def test_surface_normal_keep_matched_ids_and_mean_dist_descriptors(host, oracle)
     assert np.array_equal(got_ids, ids.astype(np.float32))
     _, _, got_md = host.filter_chain(yaml, sc["map"], handle=h, desc_name="meanDist", desc=np.zeros(n, np.float32))
     np.testing.assert_allclose(got_md.reshape(-1), md, rtol=2e-4, atol=2e-5)
+
+
+def _ssn_boxes_from_method0(oracle, c, knn):
+    """samplingMethod 1 restated on top of samplingMethod 0 at ratio 1 (every point of a surviving box is kept, in box order, with its box's
+    normal): a box is a maximal run of kept points with the same normal whose length fits the partition; rather than guess the cuts, take
+    the member runs from the oracle's method-1 output and check them against this stream -- then means and firsts follow in numpy."""
+    order0, nrm0 = oracle.sampling_surface_normal(c, 1.0, knn, seed=1)
+    first, nrm, mean, ms, mc, mem = oracle.sampling_surface_normal_boxes(c, knn)
+    assert np.array_equal(mem, order0)                                   # same boxes, same depth-first order, index order inside
+    assert ms[0] == 0 and np.array_equal(ms[1:], np.cumsum(mc)[:-1]) and ms[-1] + mc[-1] == mem.shape[0]
+    assert (mc >= 1).all() and (mc <= knn).all()
+    for j in range(first.shape[0]):
+        run = mem[ms[j]:ms[j] + mc[j]]
+        assert (np.diff(run) > 0).all() and first[j] == run[0]
+        assert np.array_equal(nrm0[ms[j]:ms[j] + mc[j]], np.repeat(nrm[j][None], mc[j], 0))
+        acc = np.zeros(3, np.float64)
+        for i in run:                                                    # the same left-to-right double sum
+            acc += c[i, :3].astype(np.float64)
+        assert np.array_equal((acc / float(mc[j])).astype(np.float32), mean[j])
+    return first, nrm, mean, ms, mc, mem
+
+
+def test_sampling_surface_normal_method1_oracle_and_host(host, oracle):
+    """samplingMethod 1 (one point per box, at the mean; descriptors averaged): the oracle against its own method 0 + numpy, and the host
+    shell WITHOUT a GPU context (the recursion a CPU-only unit test runs) against the oracle -- positions, normals and the averaged row."""
+    for n, knn in ((3000, 7), (1201, 12), (40, 7)):
+        c = _cloud(n, 100 + n)
+        first, nrm, mean, ms, mc, mem = _ssn_boxes_from_method0(oracle, c, knn)
+        rng = np.random.default_rng(n)
+        d = rng.uniform(0, 1, n).astype(np.float32)
+        out, hn, dout = host.filter_chain(f"- SamplingSurfaceNormalDataPointsFilter: {{samplingMethod: 1, knn: {knn}}}", c, desc_name="intensity", desc=d)
+        assert out.shape[0] == first.shape[0]
+        assert np.array_equal(out[:, :3], mean) and np.array_equal(out[:, 3], c[first, 3])
+        dots = np.abs(np.einsum("ij,ij->i", hn, nrm))
+        assert (dots > 1 - 1e-5).all()
+        want = np.array([np.float32(sum(float(d[i]) for i in mem[ms[j]:ms[j] + mc[j]]) / float(mc[j])) for j in range(first.shape[0])], np.float32)
+        assert np.array_equal(dout, want)
+
+
+@pytest.mark.gpu
+def test_sampling_surface_normal_method1_on_the_device(host, oracle):
+    """icpmi_sampling_surface_normal_ex(method 1) against the oracle -- boxes, firsts, member lists and means bit for bit, normals to the
+    rounding of the two Jacobi sweeps -- and the host filter WITH a GPU context against the host filter without one."""
+    import norlab_icp_mapper_amd as amd
+    icp = amd.ICPSequence()
+    href = icp._h.value if hasattr(icp._h, "value") else icp._h
+    sc = amd.synth.make_scene(m=150_000, n=10)
+    for c, knn, box in ((sc["map"], 7, np.inf), (_cloud(5003, 9), 12, np.inf), (_cloud(800, 3), 7, 0.9), (_cloud(5, 1), 7, np.inf)):
+        got = icp.samplingSurfaceNormalBoxes(c, knn=knn, max_box_dim=box)
+        want = oracle.sampling_surface_normal_boxes(c, knn=knn, max_box_dim=box)
+        assert got[0].shape == want[0].shape
+        for k in (0, 3, 4, 5):
+            assert np.array_equal(got[k], want[k]), k
+        assert np.array_equal(got[2].view(np.uint32), want[2].view(np.uint32))
+        if want[0].shape[0]:
+            assert (np.abs(np.einsum("ij,ij->i", got[1], want[1])) > 1 - 1e-5).all()
+    c = sc["map"][:40_000]
+    d = np.random.default_rng(4).uniform(0, 1, c.shape[0]).astype(np.float32)
+    y = "- SamplingSurfaceNormalDataPointsFilter: {samplingMethod: 1, knn: 9}"
+    a = host.filter_chain(y, c, handle=href, desc_name="intensity", desc=d)
+    b = host.filter_chain(y, c, desc_name="intensity", desc=d)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2])
+    assert (np.abs(np.einsum("ij,ij->i", a[1], b[1])) > 1 - 1e-5).all()
