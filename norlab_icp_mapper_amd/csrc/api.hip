@@ -148,9 +148,9 @@ icpmi_status icpmi_create(const icpmi_config* cfg, icpmi_handle* out)
     CR(stream_acquire(&c->stream));
     c->own_stream = true;
     CR(dev_malloc((void**)&c->d_state, sizeof(IcpState) * ICPMI_MAX_BATCH));
-    CR(hipMemset(c->d_state, 0, sizeof(IcpState) * ICPMI_MAX_BATCH));
+    CR(hipMemsetAsync(c->d_state, 0, sizeof(IcpState) * ICPMI_MAX_BATCH, c->stream)); // (not the legacy stream: a synchronous hipMemset breaks another thread's capture)
     CR(dev_malloc((void**)&c->d_selhist, ICPMI_SELHIST_WORDS * sizeof(unsigned)));
-    CR(hipMemset(c->d_selhist, 0, ICPMI_SELHIST_WORDS * sizeof(unsigned)));
+    CR(hipMemsetAsync(c->d_selhist, 0, ICPMI_SELHIST_WORDS * sizeof(unsigned), c->stream));
     c->cap_selhist = ICPMI_SELHIST_WORDS;
     CR(hipHostMalloc((void**)&c->h_state, sizeof(IcpState) * ICPMI_MAX_BATCH, hipHostMallocDefault));
     CR(hipHostMalloc((void**)&c->h_pin, ICPMI_PIN_BYTES + ICPMI_UP_SLOT * ICPMI_UP_SLOTS, hipHostMallocDefault));

@@ -12,6 +12,7 @@
 #include <mutex>
 #include <map>
 #include <cstdlib>
+#include <shared_mutex>
 
 #include "../../include/icpmi.h"
 
@@ -215,6 +216,20 @@ struct IcpState {
 // can still touch it), dev_malloc hands out the smallest cached block of at least the size asked for and at most twice that + 1 MiB.
 // ICPMI_ALLOC_CACHE_MB (default 4096; 0: plain hipMalloc / hipFree) bounds what is kept; the largest blocks go first.
 // ------------------------------------------------------------------------------------------------
+// A device-wide synchronisation and a stream capture in ANOTHER thread do not mix on this runtime (scripts/r5/capture_threads.hip, ROCm 7:
+// hipDeviceSynchronize fails with "operation not permitted when stream is capturing" AND invalidates the other thread's thread-local capture;
+// so does a synchronous hipMemcpy / hipMemset on the legacy stream; hipMalloc / hipFree / hipStreamCreate / hipHostMalloc / launches do not).
+// One handle per thread is the contract of icpmi.h -- a mapper's update thread next to its registration thread (Mapper.cpp:274-288) is exactly
+// that -- so: a thread that captures holds this gate shared from BeginCapture to EndCapture (host-side work only), dev_free takes it exclusive
+// around its hipDeviceSynchronize, and the library makes no synchronous legacy-stream call outside diagnostics.
+inline std::shared_mutex& capture_gate() { static std::shared_mutex* m = new std::shared_mutex; return *m; } // (never destroyed: see dev_block_cache)
+struct CaptureGate {
+    CaptureGate() { capture_gate().lock_shared(); }
+    ~CaptureGate() { capture_gate().unlock_shared(); }
+    CaptureGate(const CaptureGate&) = delete;
+    CaptureGate& operator=(const CaptureGate&) = delete;
+};
+
 struct DevBlockCache {
     std::mutex mu;
     std::unordered_map<void*, size_t> live;      // every block handed out -> its true size
@@ -270,7 +285,8 @@ inline hipError_t dev_free(void* p)
         if (it == bc.live.end()) return hipFree(p); // not ours (allocated before the cache was switched on)
         bytes = it->second; bc.live.erase(it);
     }
-    const hipError_t e = hipDeviceSynchronize(); // what hipFree would have waited for
+    hipError_t e;
+    { std::unique_lock<std::shared_mutex> gate(capture_gate()); e = hipDeviceSynchronize(); } // what hipFree would have waited for; not while another thread captures
     std::lock_guard<std::mutex> lk(bc.mu);
     bc.idle.emplace(bytes, p); bc.idle_bytes += bytes;
     while (bc.idle_bytes > bc.limit && !bc.idle.empty()) {
@@ -706,7 +722,8 @@ icpmi_status device_exclusive_scan_io(icpmi_ctx* c, const unsigned* in, unsigned
 // its slots with atomicAdd(&starts[key + 1], len) and leaves the plain exclusive scan behind.  zero_counts: counts[0 .. n + 1] end up zero.
 icpmi_status device_scan_flags_count(icpmi_ctx* c, const unsigned* flag, unsigned* pos, int n, int64_t* count); // pos = exclusive scan of the 0 / 1 flags, *count = how many are set (one stream wait, no copy)
 icpmi_status device_exclusive_scan_sum(icpmi_ctx* c, const unsigned* flag, unsigned* pos, int n, unsigned* d_sum); // ... the count stays on the device
-icpmi_status device_exclusive_scan_cursor(icpmi_ctx* c, unsigned* counts, unsigned* starts, int n, unsigned total, bool zero_counts, unsigned* tail_out = nullptr); // tail_out: receives counts[n + 1]
+icpmi_status device_exclusive_scan_cursor(icpmi_ctx* c, unsigned* counts, unsigned* starts, int n, unsigned total, bool zero_counts, unsigned* tail_out = nullptr,
+                                          unsigned long long* sq_out = nullptr); // tail_out: receives counts[n + 1]
 // the same scan on another stream with the caller's own chunk-total words (device_scan_side_words(n) of them); false from
 // device_scan_side_ok(n): the table is too large for the two-kernel scan -- stay on the handle's stream
 bool device_scan_side_ok(int n);

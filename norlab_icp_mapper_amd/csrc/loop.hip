@@ -1379,6 +1379,7 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
             for (auto& hd : c->seg_heads) { if (hd.exec) hipGraphExecDestroy(hd.exec); hd.exec = nullptr; hd.len = 0; } // (captured the same pointers)
             for (int g = 0; g < 2; ++g) {
                 hipGraph_t gr = nullptr;
+                CaptureGate capture_scope; // (common.h: no device-wide synchronisation of another thread while this one captures)
                 HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
                 icpmi_status s = g == 0 ? enqueue_registration_head(c, d_scan, d_normals3, n) : ICPMI_OK;
                 // (later segments: every iteration is seeded and past the wide first launches -- one graph serves them all)
@@ -1410,6 +1411,7 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
                 for (auto& hd : c->seg_heads) if (!hd.exec) { slot = &hd; break; } else if (hd.used < slot->used) slot = &hd;
                 if (slot->exec) { hipGraphExecDestroy(slot->exec); slot->exec = nullptr; slot->len = 0; }
                 hipGraph_t gr = nullptr;
+                CaptureGate capture_scope; // (common.h: no device-wide synchronisation of another thread while this one captures)
                 HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
                 icpmi_status hs = enqueue_registration_head(c, d_scan, d_normals3, n);
                 for (int it = 0; it < L && hs == ICPMI_OK; ++it) { c->nn_iter_hint = it; hs = enqueue_iteration(c, n, lc, nullptr, nullptr); }
@@ -1458,7 +1460,8 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
         if (!c->graph_exec || c->graph_n != n || c->graph_iters != lc.max_iter || c->graph_sig != sig) {
             if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
             hipGraph_t g = nullptr;
-            HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            CaptureGate capture_scope; // (common.h: no device-wide synchronisation of another thread while this one captures)
+                HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
             icpmi_status s = enqueue_registration_head(c, d_scan, d_normals3, n);
             for (int it = 0; it < lc.max_iter && s == ICPMI_OK; ++it) { c->nn_iter_hint = it; s = enqueue_iteration(c, n, lc, nullptr, nullptr); }
             hipError_t ce = hipStreamEndCapture(c->stream, &g);
@@ -1667,7 +1670,8 @@ icpmi_status loop_run_batch(icpmi_ctx* c, int B, const float* const* d_scans4, c
         if (!c->bgraph_exec || c->bgraph_sig != sig) {
             if (c->bgraph_exec) { hipGraphExecDestroy(c->bgraph_exec); c->bgraph_exec = nullptr; }
             hipGraph_t g = nullptr;
-            HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            CaptureGate capture_scope; // (common.h: no device-wide synchronisation of another thread while this one captures)
+                HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
             icpmi_status s = head();
             for (int it = 0; it < lc.max_iter && s == ICPMI_OK; ++it) { c->nn_iter_hint = it; s = enqueue_iteration(c, nmax, lc, nullptr, nullptr); }
             hipError_t ce = hipStreamEndCapture(c->stream, &g);

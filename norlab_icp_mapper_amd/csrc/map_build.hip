@@ -184,13 +184,20 @@ __device__ __forceinline__ unsigned block_exclusive_scan_fast(unsigned v, unsign
     return base + incl - v;
 }
 
-__global__ __launch_bounds__(SCAN_T) void scan2_sums_kernel(const unsigned* __restrict__ in, int n, unsigned* __restrict__ sums)
+// sq_out (may be null): += the sum of in[i]^2 -- a grid build's "occupancy an average point sees" (map_build), from the read this kernel makes anyway
+__global__ __launch_bounds__(SCAN_T) void scan2_sums_kernel(const unsigned* __restrict__ in, int n, unsigned* __restrict__ sums,
+                                                            unsigned long long* __restrict__ sq_out = nullptr)
 {
     __shared__ unsigned sh[SCAN_T / 64];
     const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_E;
     unsigned s = 0;
+    unsigned long long q = 0;
 #pragma unroll
-    for (int e = 0; e < SCAN_E; ++e) if (base + e < n) s += in[base + e];
+    for (int e = 0; e < SCAN_E; ++e) if (base + e < n) { const unsigned v = in[base + e]; s += v; q += (unsigned long long)v * v; }
+    if (sq_out) { // (kernel-uniform)
+        for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+        if ((threadIdx.x & 63) == 0 && q) atomicAdd(sq_out, q);
+    }
     unsigned tot;
     block_exclusive_scan_fast(s, sh, &tot);
     if (threadIdx.x == 0) sums[blockIdx.x] = tot;
@@ -552,7 +559,14 @@ __global__ __launch_bounds__(256) void qpass_kernel(const unsigned* __restrict__
     {
         const int d = t & (QS_BINS - 1), q = t >> QS_BITS; // 4 lane-quarters share the sums over the workgroups
         unsigned before = 0, all = 0;
-        for (int b = q; b < nwg; b += 4) { const unsigned v = count[d * nwg + b]; all += v; before += b < (int)blockIdx.x ? v : 0u; }
+        const unsigned* __restrict__ cp = count + (size_t)d * nwg;
+        for (int b = q; b < nwg; b += 64) { // (r5) sixteen counts per trip (100 k queries: 49 workgroups -- one trip instead of twelve dependent ones)
+            unsigned v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int bb = b + 4 * u; v[u] = bb < nwg ? cp[bb] : 0u; }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { all += v[u]; before += b + 4 * u < (int)blockIdx.x ? v[u] : 0u; }
+        }
         part[q][d] = before; whole[q][d] = all;
     }
     unsigned key[R], val[R], rank[R], dig[R];
@@ -696,23 +710,36 @@ static int scan2_enabled()
     return two;
 }
 
+// sum over the cells of (points in the cell)^2 -- divided by the point count, the occupancy of the cell an average POINT sits in.
+// The single-level grid of the tiled self search is tuned with it: the mean over occupied cells says 12 where a lidar map's points
+// see 26 (dense near the trajectory, sparse far out), and the search pays for what the points see.
+__global__ __launch_bounds__(256) void sq_counts_kernel(const unsigned* __restrict__ counts, int n, unsigned long long* __restrict__ out)
+{
+    unsigned long long s = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) { const unsigned long long v = counts[i]; s += v * v; }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+}
+
 // The count table of a grid build -> the cell starts, in the layout a CURSOR scatter wants (r5): counts[0..n) (+ the occupancy word at
 // counts[n + 1]) -> starts[0] = 0, starts[i + 1] = start of cell i, starts[n + 1] = total.  A scatter then takes its slots with
 // atomicAdd(&starts[key + 1], len): when every point is placed, starts[i + 1] has grown to the start of cell i + 1 -- the array IS the plain
 // exclusive scan, with no second table of fill cursors to clear (r4: two memsets per grid, three to four launches).  The counts are left
 // ZERO (c->fill_clean): the next build counts into them as they are.  starts needs n + 2 words.
-icpmi_status device_exclusive_scan_cursor(icpmi_ctx* c, unsigned* counts, unsigned* starts, int n, unsigned total, bool zero_counts, unsigned* tail_out)
+icpmi_status device_exclusive_scan_cursor(icpmi_ctx* c, unsigned* counts, unsigned* starts, int n, unsigned total, bool zero_counts, unsigned* tail_out,
+                                          unsigned long long* sq_out)
 {
     const int nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
     if (ensure_cap(c, &c->d_blocksums, &c->cap_blocksums, (size_t)nb + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
     if (scan2_enabled() && nb <= SCAN2_MAX_NB) {
-        hipLaunchKernelGGL(scan2_sums_kernel, dim3(nb > 0 ? nb : 1), dim3(SCAN_T), 0, c->stream, (const unsigned*)counts, n, c->d_blocksums);
+        hipLaunchKernelGGL(scan2_sums_kernel, dim3(nb > 0 ? nb : 1), dim3(SCAN_T), 0, c->stream, (const unsigned*)counts, n, c->d_blocksums, sq_out);
         hipLaunchKernelGGL(scan2_final_kernel, dim3(nb > 0 ? nb : 1), dim3(SCAN_T), 0, c->stream, (const unsigned*)counts, starts, n, (const unsigned*)c->d_blocksums, total, 1,
                            zero_counts ? counts : (unsigned*)nullptr, (unsigned*)nullptr, tail_out);
         HIP_TRY(c, hipGetLastError());
         return ICPMI_OK;
     }
     // very large tables: the three-kernel scan on a copy, the zero word in front, the counts cleared by a memset
+    if (sq_out) hipLaunchKernelGGL(sq_counts_kernel, dim3(std::min((n + 255) / 256, 2048)), dim3(256), 0, c->stream, (const unsigned*)counts, n, sq_out);
     if (tail_out) HIP_TRY(c, hipMemcpyAsync(tail_out, counts + n + 1, sizeof(unsigned), hipMemcpyDefault, c->stream));
     HIP_TRY(c, hipMemcpyAsync(starts + 1, counts, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(starts, 0, sizeof(unsigned), c->stream));
@@ -735,9 +762,10 @@ icpmi_status device_exclusive_scan_cursor_side(icpmi_ctx* c, hipStream_t stream,
     return ICPMI_OK;
 }
 
-static icpmi_status device_scan_counts_to_cursors(icpmi_ctx* c, unsigned* counts, unsigned* starts, int n, unsigned total, unsigned* tail_out = nullptr)
+static icpmi_status device_scan_counts_to_cursors(icpmi_ctx* c, unsigned* counts, unsigned* starts, int n, unsigned total, unsigned* tail_out = nullptr,
+                                                  unsigned long long* sq_out = nullptr)
 {
-    const icpmi_status s = device_exclusive_scan_cursor(c, counts, starts, n, total, true, tail_out);
+    const icpmi_status s = device_exclusive_scan_cursor(c, counts, starts, n, total, true, tail_out, sq_out);
     if (s == ICPMI_OK) c->fill_clean = true;
     return s;
 }
@@ -841,16 +869,6 @@ static icpmi_status grid_count(icpmi_ctx* c, const float4* d_pts, int64_t m, con
     return ICPMI_OK;
 }
 
-// sum over the cells of (points in the cell)^2 -- divided by the point count, the occupancy of the cell an average POINT sits in.
-// The single-level grid of the tiled self search is tuned with it: the mean over occupied cells says 12 where a lidar map's points
-// see 26 (dense near the trajectory, sparse far out), and the search pays for what the points see.
-__global__ __launch_bounds__(256) void sq_counts_kernel(const unsigned* __restrict__ counts, int n, unsigned long long* __restrict__ out)
-{
-    unsigned long long s = 0;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) { const unsigned long long v = counts[i]; s += v * v; }
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
-}
 
 static GridParams make_grid(const float lo[3], const float hi[3], float cell, float maxabs)
 {
@@ -1091,6 +1109,7 @@ icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float
     };
     GridParams g;
     unsigned n_occ = 0;
+    unsigned long long* sq_pending = nullptr;
     if (c->cfg.grid_cell > 0.f) {
         g = make_grid(clo, chi, clamp_cell(c->cfg.grid_cell), maxabs);
         if (grid_count(c, d_pts, m, g, &n_occ) != ICPMI_OK) return ICPMI_ERR_HIP;
@@ -1128,7 +1147,7 @@ icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float
             if (c->single_level && self_sb_target > 0.0) { // what the points of THIS build see, for the build after it (nn.hip: nnk_redo_kernel delivers it)
                 if (!c->d_selfsq) { HIP_TRY(c, dev_malloc((void**)&c->d_selfsq, sizeof(unsigned long long))); HIP_TRY(c, hipMemsetAsync(c->d_selfsq, 0, sizeof(unsigned long long), c->stream)); }
                 else if (c->selfsq_dirty) HIP_TRY(c, hipMemsetAsync(c->d_selfsq, 0, sizeof(unsigned long long), c->stream)); // (a build no search followed)
-                hipLaunchKernelGGL(sq_counts_kernel, dim3(std::min((g.ncells + 255) / 256, 2048)), dim3(256), 0, c->stream, (const unsigned*)c->d_fill, g.ncells, c->d_selfsq);
+                sq_pending = c->d_selfsq; // (r5: summed by the scan of these counts below -- a kernel of its own read the whole sparse table once more: 52 us per update)
                 c->selfsq_m = m; c->selfsq_dirty = true;
             }
             c->nocc_m = m;
@@ -1182,7 +1201,7 @@ grid_chosen:
     c->n_occupied = n_occ;
 
     // ---- exclusive scan of the histogram: counts (c->d_fill, left zero) -> cell starts in cursor layout ----
-    if (device_scan_counts_to_cursors(c, c->d_fill, c->d_cell_start, g.ncells, (unsigned)m, (c->nocc_by_scan && c->d_nocc_host) ? c->d_nocc_host : nullptr) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (device_scan_counts_to_cursors(c, c->d_fill, c->d_cell_start, g.ncells, (unsigned)m, (c->nocc_by_scan && c->d_nocc_host) ? c->d_nocc_host : nullptr, sq_pending) != ICPMI_OK) return ICPMI_ERR_HIP;
     c->nocc_by_scan = false;
 
     // ---- scatter ----

@@ -95,7 +95,10 @@ __global__ __launch_bounds__(256) void oct_path_kernel(const float4* __restrict_
 }
 
 // ---- stable LSD radix sort of (u64 key, u32 value), 6-bit digits: histogram per workgroup, then ranked scatter ----
-constexpr int RS_BITS = 6, RS_BINS = 64, RS_EPB = 2048; // elements per workgroup
+#ifndef ICPMI_RS_EPB
+#define ICPMI_RS_EPB 2048
+#endif
+constexpr int RS_BITS = 6, RS_BINS = 64, RS_EPB = ICPMI_RS_EPB; // elements per workgroup
 
 __device__ __forceinline__ unsigned long long match6(unsigned d, bool valid)
 {
@@ -144,8 +147,17 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const unsigned long lon
     for (int i = t; i < R * 4 * RS_BINS; i += 256) (&wc[0][0][0])[i] = 0;
     {
         const int d = t & (RS_BINS - 1), q = t >> RS_BITS; // 4 quarters share the sum over the earlier workgroups
+        // (r5) sixteen counts requested per trip: the loop over the earlier workgroups was one dependent load after the other -- 110 round
+        // trips for the last workgroup of a 0.9 M-element pass, most of the kernel's 27 us
         unsigned s = 0;
-        for (int b = q; b < (int)blockIdx.x; b += 4) s += count[d * nwg + b];
+        const unsigned* __restrict__ cp = count + (size_t)d * nwg;
+        for (int b = q; b < (int)blockIdx.x; b += 64) {
+            unsigned v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int bb = b + 4 * u; v[u] = bb < (int)blockIdx.x ? cp[bb] : 0u; }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += v[u];
+        }
         part[q][d] = s;
     }
     unsigned long long key[R];

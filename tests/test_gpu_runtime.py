@@ -91,7 +91,9 @@ def test_handle_churn_through_the_block_cache_and_the_stream_pool(amd, small_sce
 
 def test_two_threads_two_handles(amd, small_scene):
     """One handle per thread (the contract of include/icpmi.h), both allocating and releasing through the shared cache and pool while
-    the other registers: same bits as the serial runs."""
+    the other registers and CAPTURES its loop graphs: same bits as the serial runs.  (On this runtime a hipDeviceSynchronize or a
+    synchronous legacy-stream copy in one thread invalidates a thread-local stream capture in another -- scripts/r5/capture_threads.hip;
+    the first version of this test caught dev_free doing exactly that: common.h capture_gate.)"""
     sc = small_scene
     kw = dict(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=40, use_differential=1)
     maps = [(sc["map"][:50000], sc["normals"][:50000]), (sc["map"][10000:], sc["normals"][10000:])]
@@ -122,6 +124,60 @@ def test_two_threads_two_handles(amd, small_scene):
         assert len(out[t]) == 12
         for T in out[t]:
             assert np.array_equal(T, serial[t])
+
+
+def test_a_thread_that_churns_handles_next_to_one_that_recaptures_its_graphs(amd, small_scene):
+    """The mapper's two threads (Mapper.cpp:274-288: registration goes on while the map update runs): thread 0 replaces its map before
+    every other registration, so its segment graphs are captured again and again; thread 1 creates handles, builds maps, computes normals
+    and destroys them -- allocations, frees (device-wide synchronisations), fresh streams.  No capture may break, every pose of thread 0
+    equals the serial pose for its map."""
+    sc = small_scene
+    kw = dict(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=40, use_differential=1)
+    m = sc["map"].shape[0]
+    keeps = [np.arange(m - 700 * j) for j in range(4)]
+    serial = []
+    for keep in keeps:
+        icp = amd.ICPSequence(**kw); icp.setMap(sc["map"][keep], sc["normals"][keep]); serial.append(_bits(icp(sc["scan"]))); icp.close()
+    errs, got = [], []
+    done = threading.Event()
+
+    def registrar():
+        try:
+            icp = amd.ICPSequence(**kw)
+            for rep in range(40):
+                j = rep % 4
+                if rep % 2 == 0:
+                    icp.setMap(sc["map"][keeps[j]], sc["normals"][keeps[j]])
+                    cur = j
+                got.append((cur, _bits(icp(sc["scan"]))))
+            icp.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append("registrar: " + repr(e))
+        finally:
+            done.set()
+
+    def churner():
+        try:
+            k = 0
+            while not done.is_set() and k < 400:
+                h = amd.ICPSequence(**kw)
+                sz = 8000 + 3000 * (k % 7)
+                h.setMap(sc["map"][:sz], sc["normals"][:sz])
+                h.surfaceNormals(sc["map"][:sz], knn=6)
+                h.close()
+                k += 1
+        except Exception as e:  # noqa: BLE001
+            errs.append("churner: " + repr(e))
+
+    th = [threading.Thread(target=registrar), threading.Thread(target=churner)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    assert len(got) == 40
+    for j, T in got:
+        assert np.array_equal(T, serial[j])
 
 
 _CHILD = r"""
