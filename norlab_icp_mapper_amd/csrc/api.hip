@@ -152,7 +152,9 @@ icpmi_status icpmi_create(const icpmi_config* cfg, icpmi_handle* out)
     CR(dev_malloc((void**)&c->d_selhist, ICPMI_SELHIST_WORDS * sizeof(unsigned)));
     CR(hipMemsetAsync(c->d_selhist, 0, ICPMI_SELHIST_WORDS * sizeof(unsigned), c->stream));
     c->cap_selhist = ICPMI_SELHIST_WORDS;
-    CR(hipHostMalloc((void**)&c->h_state, sizeof(IcpState) * ICPMI_MAX_BATCH, hipHostMallocDefault));
+    CR(hipHostMalloc((void**)&c->h_state, sizeof(IcpState) * ICPMI_MAX_BATCH, hipHostMallocMapped));
+    memset(c->h_state, 0, sizeof(IcpState) * ICPMI_MAX_BATCH);
+    if (hipHostGetDevicePointer((void**)&c->d_state_mirror, c->h_state, 0) != hipSuccess) { c->d_state_mirror = nullptr; (void)hipGetLastError(); } // (then loop_run copies)
     CR(hipHostMalloc((void**)&c->h_pin, ICPMI_PIN_BYTES + ICPMI_UP_SLOT * ICPMI_UP_SLOTS, hipHostMallocDefault));
     CR(hipHostMalloc((void**)&c->h_nocc, 64, hipHostMallocDefault));
     *c->h_nocc = 0;

@@ -205,6 +205,9 @@ struct IcpState {
     float T_prev[16];            // T_iter BEFORE the last minimisation (kept when LoopCfg::sensor_noise: getOverlap() looks at that step's pairs)
     // result
     float T_out[16];
+    // r5: device clocks (wall_clock64, 100 MHz) of the first kernel of the registration's head and of the solve that stopped the loop:
+    // stats->loop_ms without a HIP event to wait for (loop_run's fast finish).  t_done == 0: the loop was not stopped by a solve.
+    unsigned long long t_start, t_done;
 };
 
 
@@ -458,6 +461,7 @@ struct icpmi_ctx {
     bool nn_sorted_k = false;         // set by the loop for k > 1: keep the k matches of a query at its slot of the tile-sorted order
     IcpState* d_state = nullptr;                               // ICPMI_MAX_BATCH states (a single registration uses the first)
     IcpState* h_state = nullptr;                               // pinned mirror (ICPMI_MAX_BATCH)
+    IcpState* d_state_mirror = nullptr;                        // ... and its device address: the solve kernel of a single registration writes the finished state there itself (r5)
     int batch_cur = 1;                                         // readings of the launch sequence being enqueued (set by the loop)
     BatchArgs batch_args{};                                    // their sizes / slice stride
     unsigned* d_nocc_host = nullptr; bool nocc_by_scan = false; // device address of h_nocc; the pending occupancy word is delivered by the build's scan
@@ -697,6 +701,7 @@ __device__ inline void init_state_dev(IcpState* st, const float* T0, unsigned se
     st->robust_med = 0.f; st->robust_scale = 1.f; st->vt_valid = 0; st->vt_ratio = -1.f;
     st->pairs = 0; st->wsum = 0; st->hard_count = 0; st->hard_total = 0; st->ticket = 0;
     for (int i = 0; i < 24; ++i) st->dbg[i] = 0;
+    st->t_done = 0; // (t_start belongs to the first kernel of the head, which runs BEFORE this when the head is folded into the query sort)
 }
 
 // The head of a registration folded into the kernels of the query sort (r3: 8 graph nodes -> 3): the first kernel centres the raw

@@ -771,8 +771,22 @@ __global__ __launch_bounds__(BT) void accumulate_kernel(const float4* __restrict
     }
 }
 
+// (r5) the state of a FINISHED registration goes to the host by itself: the first wave of the solve copies IcpState into the handle's pinned
+// host block (`mirror` = device address of icpmi_ctx::h_state; null for batches and operators) in front of the progress word that says
+// "done" -- loop_run then returns on that word instead of enqueueing a copy and draining the stream (21 - 26 us per registration between
+// the flag and the state on the host, `-DICPMI_TAIL_DIAG`).  Loads past the L1 (thread 0 wrote the state a moment ago), plain stores, and
+// the word's system-scope release behind them: one wave, one instruction stream.
+__device__ __forceinline__ void mirror_state(const IcpState* st, IcpState* mirror)
+{
+    const unsigned* src = reinterpret_cast<const unsigned*>(st);
+    unsigned* dst = reinterpret_cast<unsigned*>(mirror);
+    constexpr int W = (int)(sizeof(IcpState) / sizeof(unsigned));
+    for (int i = threadIdx.x; i < W; i += 64) dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __global__ __launch_bounds__(256) void solve_kernel(IcpState* __restrict__ st, unsigned* __restrict__ hists, int clear, LoopCfg lc,
-                                                    float* __restrict__ T_step_out, double* __restrict__ sums_out, unsigned* __restrict__ progress)
+                                                    float* __restrict__ T_step_out, double* __restrict__ sums_out, unsigned* __restrict__ progress,
+                                                    IcpState* __restrict__ mirror)
 {
     // blockIdx.x = reading of a batch: one workgroup per registration
     st += blockIdx.x;
@@ -782,10 +796,16 @@ __global__ __launch_bounds__(256) void solve_kernel(IcpState* __restrict__ st, u
     //  unbounded maxDist -- the next NN launch starts behind this kernel)
     if (threadIdx.x == 0 && st->hard_count) { st->hard_total += st->hard_count; st->hard_count = 0; }
     if (st->done) { // finished earlier, or an upstream kernel of this iteration raised an error
+        if (mirror && threadIdx.x < 64) mirror_state(st, mirror + blockIdx.x); // (the same words again after the first time: harmless)
         if (threadIdx.x == 0) publish_progress(st, progress);
         return;
     }
     solve_body(st, acc, clear != 0, lc, T_step_out, sums_out);
+    if (threadIdx.x == 0 && st->done) st->t_done = (unsigned long long)wall_clock64();
+    if (mirror) {
+        __syncthreads(); // thread 0's stores to the state are issued
+        if (threadIdx.x < 64 && __hip_atomic_load(&st->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) mirror_state(st, mirror + blockIdx.x);
+    }
     if (threadIdx.x == 0) publish_progress(st, progress);
 }
 
@@ -812,6 +832,7 @@ __global__ __launch_bounds__(256) void pad_normals_kernel(const float* __restric
 __global__ void init_state_kernel(IcpState* st, const float* T0, unsigned seq, unsigned* progress, const unsigned* seq_src = nullptr)
 {
     if (threadIdx.x != 0) return;
+    st[blockIdx.x].t_start = (unsigned long long)wall_clock64(); // (a head that is not folded into the query sort: this kernel stands for its start)
     init_state_dev(st + blockIdx.x, T0, seq, progress ? progress + blockIdx.x : nullptr, seq_src); // one state per reading of a batch
 }
 
@@ -1209,7 +1230,7 @@ static void enqueue_accumulate_solve(icpmi_ctx* c, int64_t n, const LoopCfg& lc,
     }
     const BatchArgs ba = cur_batch(c, n);
     hipLaunchKernelGGL(solve_kernel, dim3(ba.nscan), dim3(256), 0, c->stream, c->d_state, c->d_selhist, 1, lc, d_Tstep, d_sums,
-                       c->d_progress);
+                       c->d_progress, ba.nscan == 1 ? c->d_state_mirror : (IcpState*)nullptr);
 }
 
 // diagnostic (r5, scripts/r5/l2_real2.sh): 64 MB of other lines through every XCD's L2 in front of an NN launch -- whatever the L2 still held
@@ -1319,7 +1340,11 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
     float nn_ms_sum = 0.f; int nn_cnt = 0;
     c->reg_seq = (c->reg_seq + 1) & 0x7ffffu;
     if (c->h_progress) __atomic_store_n(c->h_progress + 32, c->reg_seq, __ATOMIC_RELEASE);
-    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    // r5 (fast finish, see the end of this function): the finished state reaches the host by itself and carries the device clocks of its
+    // start and stop -- no event pair, no copy, no drain
+    static const int fast_cfg = [] { const char* e = getenv("ICPMI_FAST_FINISH"); return e ? atoi(e) : 1; }();
+    const bool fast_ok = fast_cfg && !profile && c->d_state_mirror && c->h_progress && lc.max_iter < 0xfff;
+    if (!fast_ok) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     // A checked loop (Counter + Differential / Bound: what Mapper::processInput runs) as SEGMENT graphs (r3):
     // head + the first S iterations are one graph, S further iterations another; a segment is launched when the progress word
     // says the loop is still running and within S / 2 iterations of the end of what is enqueued.  Iterations past the stop are
@@ -1544,9 +1569,37 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
             }
         }
     }
-    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(IcpState), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // r5: the final state is already in c->h_state when the progress word says "done" (solve_kernel: mirror_state), with the device clocks
+    // of the head's first kernel and of the solve that stopped the loop in it.  Returning on that word instead of behind an event or a
+    // drained stream takes the end-of-graph release and the completion signal (21 - 26 us between the flag and the drained stream,
+    // -DICPMI_TAIL_DIAG) off the caller's clock: the next registration is enqueued while they happen.  Whatever this registration still has
+    // in the stream (dead iterations behind a stop) touches the handle's own buffers only and stays in stream order with everything the
+    // handle enqueues next.  The copy + drain below remains for loops that end without the flag (no Counter in the chain and the host's
+    // bound reached, a stream in an error state), for the profiling loop and for ICPMI_FAST_FINISH=0.
+    bool have_state = false;
+    if (fast_ok) {
+        for (unsigned spins = 1;; ++spins) {
+            const unsigned v = __atomic_load_n(c->h_progress, __ATOMIC_ACQUIRE);
+            if (((v >> 12) & 0x7ffffu) == (c->reg_seq & 0x7ffffu) && (v >> 31)) { have_state = true; break; }
+            if ((spins & 255u) != 0) continue;
+            const hipError_t qe = hipStreamQuery(c->stream);
+            if (qe != hipSuccess && qe != hipErrorNotReady) HIP_TRY(c, qe);
+            if (qe == hipSuccess) { // everything has run: the word is final
+                const unsigned w = __atomic_load_n(c->h_progress, __ATOMIC_ACQUIRE);
+                have_state = ((w >> 12) & 0x7ffffu) == (c->reg_seq & 0x7ffffu) && (w >> 31);
+                break;
+            }
+        }
+        if (have_state) {
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            const volatile IcpState* hv = c->h_state;
+            have_state = hv->done != 0 && hv->seq == c->reg_seq; // (belt and braces: the block belongs to THIS registration)
+        }
+    } else HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    if (!have_state) {
+        HIP_TRY(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(IcpState), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
 
     fill_stats(c, lc, n, stats);
     if (segmented) { // what the next checked registration's head graph is cut to (the larger of the last two counts: one dead iteration costs
@@ -1557,7 +1610,10 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
     }
     if (stats) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) stats->loop_ms = ms;
+        if (fast_ok) { // device clocks, 100 MHz: head's first kernel -> the solve that stopped the loop (0 when no solve stopped it)
+            const unsigned long long t0 = c->h_state->t_start, t1 = c->h_state->t_done;
+            stats->loop_ms = (t1 > t0) ? (float)((double)(t1 - t0) * 1e-5) : 0.f;
+        } else if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) stats->loop_ms = ms;
         stats->nn_ms_avg = nn_cnt ? nn_ms_sum / nn_cnt : 0.f;
         stats->nn_launches = nn_cnt;
         stats->sensor_noise_overlap = -1.f;

@@ -459,8 +459,9 @@ __device__ __forceinline__ unsigned long long match_digit(unsigned d, bool valid
 template <bool CENTRE>
 __global__ __launch_bounds__(256) void qfirst_kernel(BatchSrc raw, float mx, float my, float mz, float4* __restrict__ pts, BatchArgs ba, GridParams g,
                                                      int tx, int ty, unsigned* __restrict__ keys_out, int nwg, unsigned* __restrict__ tables,
-                                                     int later_words, int tab, int qs, int tabstride)
+                                                     int later_words, int tab, int qs, int tabstride, IcpState* __restrict__ st_stamp)
 {
+    if (st_stamp && blockIdx.x == 0 && threadIdx.x == 0) st_stamp[blockIdx.y].t_start = (unsigned long long)wall_clock64(); // the registration's first kernel
     const int n = ba.n[blockIdx.y];
     const float4* __restrict__ src = CENTRE ? raw.p[blockIdx.y] : nullptr;
     pts += (size_t)blockIdx.y * qs;
@@ -663,11 +664,11 @@ icpmi_status sort_queries_batch(icpmi_ctx* c, const float4* d_pts, const BatchAr
     const int later = 0; // (the tables of the later passes are written in full by qcount_kernel)
     if (head)
         hipLaunchKernelGGL(qfirst_kernel<true>, grid, dim3(256), 0, c->stream, head->raw, head->mean[0], head->mean[1], head->mean[2],
-                           const_cast<float4*>(d_pts), ba, g, tx, ty, kbuf[0], nwg, c->d_qtile, later, (int)tab, qs, (int)tab_all);
+                           const_cast<float4*>(d_pts), ba, g, tx, ty, kbuf[0], nwg, c->d_qtile, later, (int)tab, qs, (int)tab_all, head->st);
     else {
         BatchSrc none; memset(&none, 0, sizeof none);
         hipLaunchKernelGGL(qfirst_kernel<false>, grid, dim3(256), 0, c->stream, none, 0.f, 0.f, 0.f, const_cast<float4*>(d_pts), ba, g, tx, ty,
-                           kbuf[0], nwg, c->d_qtile, later, (int)tab, qs, (int)tab_all);
+                           kbuf[0], nwg, c->d_qtile, later, (int)tab, qs, (int)tab_all, (IcpState*)nullptr);
     }
     for (int ps = 0; ps < passes; ++ps) {
         unsigned* count = c->d_qtile + tab * ps;

@@ -215,7 +215,8 @@ def test_switches_off_same_bits():
         assert line, r.stdout[-500:] + r.stderr[-500:]
         return line[0]
     a = run({})
-    b = run({"ICPMI_ALLOC_CACHE_MB": "0", "ICPMI_GRAPH_ADAPT": "0", "ICPMI_CHAIN_OVERLAP": "0", "ICPMI_OCT_SPECULATE": "0", "ICPMI_SEG_ADAPT": "0"})
+    b = run({"ICPMI_ALLOC_CACHE_MB": "0", "ICPMI_GRAPH_ADAPT": "0", "ICPMI_CHAIN_OVERLAP": "0", "ICPMI_OCT_SPECULATE": "0", "ICPMI_SEG_ADAPT": "0",
+             "ICPMI_FAST_FINISH": "0"})
     c = run({"ICPMI_SELF_SB_TARGET": "0", "ICPMI_SCAN2": "0"})
     assert a == b == c
 
@@ -241,3 +242,35 @@ def test_self_search_grid_follows_the_density_and_the_neighbours_do_not(amd, ora
     _, ids_o, md_o = oracle.surface_normals_extras(cloud, knn=10, nthreads=8)
     assert np.array_equal(runs[0][1], ids_o)
     assert np.array_equal(runs[0][2].view(np.uint32), md_o.view(np.uint32))
+
+
+@pytest.mark.parametrize("checked", [1, 0])
+def test_finished_state_reaches_the_host_by_itself(amd, small_scene, checked):
+    """r5 fast finish: the solve that stops the loop mirrors the state into the handle's pinned block in front of the "done" word and
+    loop_run returns on that word -- no copy, no drained stream, no event pair; stats.loop_ms comes from the device clocks the state
+    carries.  Back-to-back registrations (the next one is enqueued while the previous graph's tail still runs), alternating scans and
+    sizes: pose, iterations, stop reason, pair count, trim limit of every call equal the eager handle's, and the device time of the loop
+    is positive and not longer than the call."""
+    import time
+    sc = small_scene
+    kw = dict(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=40 if checked else 12, use_differential=checked)
+    icp = amd.ICPSequence(**kw); icp.setMap(sc["map"], sc["normals"])
+    ref = amd.ICPSequence(use_graph=0, **kw); ref.setMap(sc["map"], sc["normals"])
+    scans = [sc["scan"], sc["scan"][::2].copy(), sc["scan"][: 3000].copy()]
+    for rep in range(12):
+        s = scans[rep % 3]
+        t0 = time.perf_counter(); T = icp(s); wall = (time.perf_counter() - t0) * 1e3
+        a = (icp.stats.iterations, icp.stats.stop_reason, icp.stats.pairs, icp.stats.trimmed_limit, icp.stats.weighted_point_used_ratio)
+        lm = icp.stats.loop_ms
+        Tr = ref(s)
+        b = (ref.stats.iterations, ref.stats.stop_reason, ref.stats.pairs, ref.stats.trimmed_limit, ref.stats.weighted_point_used_ratio)
+        assert a == b, rep
+        assert np.array_equal(_bits(T), _bits(Tr)), rep
+        assert 0.0 < lm <= wall * 1.05 + 0.05, (rep, lm, wall)
+    # an error raised on the device travels the same way (no point within reach: "no point to minimize" / "no outlier to filter")
+    far = sc["scan"].copy(); far[:, :3] += np.float32(500.0)
+    for h in (icp, ref):
+        with pytest.raises(Exception) as ei:
+            h(far)
+        assert "ConvergenceError" in str(ei.value)
+    assert np.array_equal(_bits(icp(sc["scan"])), _bits(ref(sc["scan"])))   # ... and the handle goes on
