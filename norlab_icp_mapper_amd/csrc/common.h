@@ -461,6 +461,7 @@ struct icpmi_ctx {
     bool nn_sorted_k = false;         // set by the loop for k > 1: keep the k matches of a query at its slot of the tile-sorted order
     IcpState* d_state = nullptr;                               // ICPMI_MAX_BATCH states (a single registration uses the first)
     IcpState* h_state = nullptr;                               // pinned mirror (ICPMI_MAX_BATCH)
+    unsigned scan_tag = 0;                                     // call number of device_scan_flags_count: the tag its count comes back with (map_build.hip)
     IcpState* d_state_mirror = nullptr;                        // ... and its device address: the solve kernel of a single registration writes the finished state there itself (r5)
     int batch_cur = 1;                                         // readings of the launch sequence being enqueued (set by the loop)
     BatchArgs batch_args{};                                    // their sizes / slice stride

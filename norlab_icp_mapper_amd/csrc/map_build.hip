@@ -209,7 +209,8 @@ __global__ __launch_bounds__(SCAN_T) void scan2_sums_kernel(const unsigned* __re
 __global__ __launch_bounds__(SCAN_T) void scan2_final_kernel(const unsigned* __restrict__ in, unsigned* __restrict__ out, int n,
                                                              const unsigned* __restrict__ sums, unsigned total, int shift, unsigned* __restrict__ zero_in,
                                                              unsigned* __restrict__ sum_out = nullptr /* the sum of in[0..n): e.g. a word of host-mapped memory */,
-                                                             unsigned* __restrict__ tail_out = nullptr /* receives in[n + 1] (a grid build's occupancy word) before it is zeroed */)
+                                                             unsigned* __restrict__ tail_out = nullptr /* receives in[n + 1] (a grid build's occupancy word) before it is zeroed */,
+                                                             unsigned sum_tag = 0u /* != 0: sum_out is a 64-bit slot of host-mapped memory and receives tag << 32 | sum with a system-scope release (a host that spins on the tag) */)
 {
     __shared__ unsigned sh[SCAN_T / 64];
     const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_E;
@@ -222,7 +223,10 @@ __global__ __launch_bounds__(SCAN_T) void scan2_final_kernel(const unsigned* __r
     block_exclusive_scan_fast(part, sh, &off);
     unsigned wg_tot;
     unsigned ex = block_exclusive_scan_fast(s, sh, &wg_tot) + off;
-    if (sum_out && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *sum_out = off + wg_tot;
+    if (sum_out && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        if (sum_tag) __hip_atomic_store(reinterpret_cast<unsigned long long*>(sum_out), ((unsigned long long)sum_tag << 32) | (unsigned long long)(off + wg_tot), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        else *sum_out = off + wg_tot;
+    }
 #pragma unroll
     for (int e = 0; e < SCAN_E; ++e) { if (base + e < n) { out[base + e + shift] = ex; if (zero_in && v[e]) zero_in[base + e] = 0u; } ex += v[e]; }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -793,9 +797,30 @@ icpmi_status device_scan_flags_count(icpmi_ctx* c, const unsigned* flag, unsigne
         if (ensure_cap(c, &c->d_blocksums, &c->cap_blocksums, (size_t)nb + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
         unsigned* d_word = c->d_progress + ICPMI_PROGRESS_SCAN_WORD;
         volatile unsigned* h_word = c->h_progress + ICPMI_PROGRESS_SCAN_WORD;
-        hipLaunchKernelGGL(scan2_sums_kernel, dim3(nb), dim3(SCAN_T), 0, c->stream, flag, n, c->d_blocksums);
-        hipLaunchKernelGGL(scan2_final_kernel, dim3(nb), dim3(SCAN_T), 0, c->stream, flag, pos, n, (const unsigned*)c->d_blocksums, 0u, 0, (unsigned*)nullptr, d_word);
+        // r5: the count arrives TAGGED (words 40 / 41 as one 64-bit slot: call number << 32 | count, system-scope release) and the host spins on
+        // the tag instead of draining the stream: a drained stream costs the completion signal and the restart of an empty queue (~20 us,
+        // DESIGN 13.6e) -- five to seven times per map update --, the word is here ~2 us after the kernel's last workgroup wrote it, and what the
+        // caller enqueues next queues up behind a GPU that never went idle.  ICPMI_SPIN_COUNTS=0: drain as before.
+        static const int spin_cfg = [] { const char* e = getenv("ICPMI_SPIN_COUNTS"); return e ? atoi(e) : 1; }();
+        const unsigned tag = spin_cfg ? (++c->scan_tag ? c->scan_tag : ++c->scan_tag) : 0u;
+        hipLaunchKernelGGL(scan2_sums_kernel, dim3(nb), dim3(SCAN_T), 0, c->stream, flag, n, c->d_blocksums, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL(scan2_final_kernel, dim3(nb), dim3(SCAN_T), 0, c->stream, flag, pos, n, (const unsigned*)c->d_blocksums, 0u, 0, (unsigned*)nullptr, d_word,
+                           (unsigned*)nullptr, tag);
         HIP_TRY(c, hipGetLastError());
+        if (tag) {
+            const volatile unsigned long long* h64 = reinterpret_cast<const volatile unsigned long long*>(c->h_progress + ICPMI_PROGRESS_SCAN_WORD);
+            for (unsigned spins = 1;; ++spins) {
+                const unsigned long long v = __atomic_load_n(h64, __ATOMIC_ACQUIRE);
+                if ((unsigned)(v >> 32) == tag) { *count = (int64_t)(unsigned)(v & 0xffffffffull); return ICPMI_OK; }
+                if ((spins & 1023u) != 0) continue;
+                const hipError_t qe = hipStreamQuery(c->stream);
+                if (qe == hipErrorNotReady) continue;
+                HIP_TRY(c, qe); // (a stream in an error state: nothing will ever write the word)
+                const unsigned long long w = __atomic_load_n(h64, __ATOMIC_ACQUIRE);
+                if ((unsigned)(w >> 32) == tag) { *count = (int64_t)(unsigned)(w & 0xffffffffull); return ICPMI_OK; }
+                c->last_error = "device_scan_flags_count: the count never arrived"; return ICPMI_ERR_HIP;
+            }
+        }
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         *count = (int64_t)*h_word;
         return ICPMI_OK;
