@@ -51,6 +51,7 @@ struct RoctxRange {
             (h)->last_error = std::string("hipSetDevice: ") + hipGetErrorString(_e); \
             return ICPMI_ERR_HIP;                                            \
         }                                                                    \
+        if ((h)->zero_pending && zero_state_if_pending(h) != ICPMI_OK) return ICPMI_ERR_HIP; \
     } while (0)
 
 extern "C" {
@@ -148,9 +149,8 @@ icpmi_status icpmi_create(const icpmi_config* cfg, icpmi_handle* out)
     CR(stream_acquire(&c->stream));
     c->own_stream = true;
     CR(dev_malloc((void**)&c->d_state, sizeof(IcpState) * ICPMI_MAX_BATCH));
-    CR(hipMemsetAsync(c->d_state, 0, sizeof(IcpState) * ICPMI_MAX_BATCH, c->stream)); // (not the legacy stream: a synchronous hipMemset breaks another thread's capture)
+    c->zero_pending = true; // (common.h: zero_state_if_pending -- neither the legacy stream, which breaks another thread's capture, nor a stream this handle may never use)
     CR(dev_malloc((void**)&c->d_selhist, ICPMI_SELHIST_WORDS * sizeof(unsigned)));
-    CR(hipMemsetAsync(c->d_selhist, 0, ICPMI_SELHIST_WORDS * sizeof(unsigned), c->stream));
     c->cap_selhist = ICPMI_SELHIST_WORDS;
     CR(hipHostMalloc((void**)&c->h_state, sizeof(IcpState) * ICPMI_MAX_BATCH, hipHostMallocMapped));
     memset(c->h_state, 0, sizeof(IcpState) * ICPMI_MAX_BATCH);

@@ -461,6 +461,7 @@ struct icpmi_ctx {
     bool nn_sorted_k = false;         // set by the loop for k > 1: keep the k matches of a query at its slot of the tile-sorted order
     IcpState* d_state = nullptr;                               // ICPMI_MAX_BATCH states (a single registration uses the first)
     IcpState* h_state = nullptr;                               // pinned mirror (ICPMI_MAX_BATCH)
+    bool zero_pending = false;                                 // d_state / d_selhist still to be cleared: on the stream the handle really uses, at its first call (zero_state_if_pending)
     unsigned scan_tag = 0;                                     // call number of device_scan_flags_count: the tag its count comes back with (map_build.hip)
     IcpState* d_state_mirror = nullptr;                        // ... and its device address: the solve kernel of a single registration writes the finished state there itself (r5)
     int batch_cur = 1;                                         // readings of the launch sequence being enqueued (set by the loop)
@@ -535,6 +536,19 @@ static inline icpmi_status ensure_cap(icpmi_ctx* c, T** p, size_t* cap, size_t n
 // Every cached loop graph (fixed-count, batched, the two segment graphs of a checked loop) holds pointers, grid parameters, the map's mean
 // and its normals flag as they were at capture time: a rebuilt index or a changed stream invalidates all of them (only graph_exec
 // was dropped, and the signature of the segment graphs does not cover mean / m / has_normals / d_map_pn / the level arrays).
+// The loop state and the selection histograms of a new handle are cleared at its FIRST call, on the stream it then has: a private handle adopts its
+// owner's stream right after its creation and never touches its own -- clearing there at creation (r5, after the synchronous hipMemset on the
+// legacy stream had to go: it breaks another thread's capture) made the runtime build a hardware queue for every such stream, milliseconds
+// of the first scans of a mapper.
+static inline icpmi_status zero_state_if_pending(icpmi_ctx* c)
+{
+    if (!c->zero_pending) return ICPMI_OK;
+    HIP_TRY(c, hipMemsetAsync(c->d_state, 0, sizeof(IcpState) * ICPMI_MAX_BATCH, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_selhist, 0, ICPMI_SELHIST_WORDS * sizeof(unsigned), c->stream));
+    c->zero_pending = false;
+    return ICPMI_OK;
+}
+
 static inline void drop_loop_graphs(icpmi_ctx* c)
 {
     if (c->graph_exec) { if (c->graph_uses <= 1) ++c->graph_wasted; else c->graph_wasted = 0; hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }

@@ -582,6 +582,7 @@ static void share_stream(icpmi_ctx* c, icpmi_ctx* t)
     if (t->own_stream && t->stream) stream_release(t->stream);
     t->stream = c->stream; t->own_stream = false;
     drop_loop_graphs(t);
+    (void)zero_state_if_pending(t); // (on the owner's stream; an error surfaces at the handle's next call)
 }
 
 static icpmi_status make_temp(icpmi_ctx* c, TempCtx& t)
