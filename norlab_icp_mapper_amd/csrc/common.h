@@ -53,7 +53,22 @@
 #define ICPMI_ACC_IDX(copy, i, limb) ((((copy) * ICPMI_NV + (i)) * 2 + (limb)) * ICPMI_ACC_PAD)
 #define ICPMI_ACC_FLAG (ICPMI_ACC_IDX(0, 0, 0) + 8)                    // a non-finite partial was met (NaN must reach the solver: ICPMI_ERR_NAN)
 #define ICPMI_S2_ACC (ICPMI_S2_F1 + 65536)                             // u32 word offset of the accumulators (128-byte aligned)
-#define ICPMI_SELHIST_WORDS (ICPMI_S2_ACC + 2 * ICPMI_ACC_U64)
+// (r5) Speculative level 0 for the k > 1 loop (nnk_wg_kernel builds it, loop.hip: win_lookup reads it).  The 16-bit prefix the selection
+// picks moves by a fraction of a bin from one iteration to the next once the registration settles, and the stand-alone level-0 builder
+// costs 10.7 us per iteration at knn 6 (116 k device atomics: DESIGN 11.6, 12.8).  So the NN kernel counts its own k x 64 distances into
+// ICPMI_WIN_BINS bins around the PREVIOUS iteration's prefix plus "below" and "above" -- nine counts, reduced inside the wave, three
+// 64-bit atomics per workgroup (three 21-bit fields each: the host enables the window only below 2^21 matches, so no field can carry) --
+// and when the selected rank falls inside the window the builder launch has nothing to do.  A miss (the first iterations, a limit that
+// jumps) is the full histogram as before; the counts are exact either way, so the selected element is the same bit pattern.
+// Every (copy, word) on its own 128-byte line; the header word holds (lowest window prefix + 1), 0 = no window this iteration.
+#define ICPMI_WIN_BINS 7
+#define ICPMI_WIN_COPIES 8
+#define ICPMI_WIN_PAD 16                                                  // u64 per slot = one 128-byte line
+#define ICPMI_WIN_HDR (ICPMI_WIN_COPIES * 3 * ICPMI_WIN_PAD)              // u64 index of the header
+#define ICPMI_WIN_U64 (ICPMI_WIN_HDR + ICPMI_WIN_PAD)
+#define ICPMI_WIN_MAX_COUNT (1ll << 21)
+#define ICPMI_S2_WIN (ICPMI_S2_ACC + 2 * ICPMI_ACC_U64)                   // u32 word offset of the window (128-byte aligned)
+#define ICPMI_SELHIST_WORDS (ICPMI_S2_WIN + 2 * ICPMI_WIN_U64)
 // Device atomics serialise per cache line, and neighbouring fine bins are hot together: bin b of a fine
 // histogram lives at word ((b & 255) << 8) | (b >> 8), i.e. consecutive bins are 1 KiB apart.
 #define ICPMI_S2_FIDX(b) ((((b) & 255u) << 8) | ((b) >> 8))
@@ -454,6 +469,7 @@ struct icpmi_ctx {
     unsigned* d_selhist = nullptr; size_t cap_selhist = 0;     // ICPMI_SELHIST_WORDS per reading of a batch
     unsigned* nn_hist0 = nullptr;     // set by the loop when the NN kernel should build the level-0 histogram
     bool nn_builds_hist0 = false;     // set by the NN launcher: true if the launched variant did build it
+    bool nn_builds_win = false;       // ... true if it counted the speculative window (ICPMI_S2_WIN: nnk_wg_kernel in a fused-selection loop)
     int nn_iter_hint = 0;             // iteration index of the launch being enqueued (> 0: seeded by the previous match)
     float4* d_match_pt = nullptr; size_t cap_match_pt = 0;     // k = 1 loop: matched map point (xyz, original index bits) per query slot
     float4* nn_match_pt = nullptr;    // set by the loop: keep the loop state (sidx, d2, matched point) in query order

@@ -225,15 +225,75 @@ __device__ __forceinline__ void block_find_rank_2tier(unsigned coarse_v, const u
     bin16 = (cb << 8) | fb;
 }
 
+// (r5) The speculative window of the k > 1 loop (common.h: ICPMI_S2_WIN; counted by nnk_wg_kernel around the previous iteration's prefix).
+// All 256 threads call; true = the selected rank lies in one of the window's bins: `prefix` is that bin, `rank_rem` the rank inside it,
+// `total` the number of finite positive distances -- what block_find_rank_2tier would return from a full level 0, without one.
+// false = no window this iteration, or the rank falls below / above it (the caller goes on with the full histogram).
+__device__ __forceinline__ bool win_lookup(const unsigned* __restrict__ hists, float quantile, unsigned* sh /* >= 16 words */,
+                                           unsigned& prefix, unsigned& rank_rem, unsigned& total)
+{
+    const unsigned long long* __restrict__ W = reinterpret_cast<const unsigned long long*>(hists + ICPMI_S2_WIN);
+    const int t = threadIdx.x;
+    unsigned long long v = 0ull;
+    if (t < ICPMI_WIN_COPIES * 3) v = W[(size_t)t * ICPMI_WIN_PAD];       // (copy, word) = (t / 3, t % 3)
+    else if (t == ICPMI_WIN_COPIES * 3) v = W[ICPMI_WIN_HDR];
+    if (t < 16) sh[t] = 0u;
+    __syncthreads();
+    if (t < ICPMI_WIN_COPIES * 3) {
+        const int w = t % 3;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const unsigned f = (unsigned)(v >> (21 * j)) & 0x1fffffu;
+            if (f) atomicAdd(&sh[3 * w + j], f);
+        }
+    } else if (t == ICPMI_WIN_COPIES * 3) sh[9] = (unsigned)v;
+    __syncthreads();
+    if (t == 0) {
+        const unsigned lo1 = sh[9], below = sh[0], above = sh[ICPMI_WIN_BINS + 1];
+        unsigned inwin = 0u;
+        for (int b = 0; b < ICPMI_WIN_BINS; ++b) inwin += sh[1 + b];
+        const unsigned tot = below + inwin + above;
+        unsigned hit = 0u, pf = 0u, rr = 0u;
+        if (lo1 != 0u && tot != 0u) {
+            unsigned rank; // getDistsQuantile's index, as block_find_rank256 forms it
+            if (quantile == 1.0f) rank = tot - 1;
+            else {
+                rank = (unsigned)((float)tot * quantile);
+                if (rank > tot - 1) rank = tot - 1;
+            }
+            if (rank >= below && rank - below < inwin) {
+                unsigned r = rank - below;
+                for (int b = 0; b < ICPMI_WIN_BINS; ++b) {
+                    const unsigned cb = sh[1 + b];
+                    if (r < cb) { pf = lo1 - 1u + (unsigned)b; rr = r; hit = 1u; break; }
+                    r -= cb;
+                }
+            }
+        }
+        sh[10] = hit; sh[11] = pf; sh[12] = rr; sh[13] = tot;
+    }
+    __syncthreads();
+    const bool hit = sh[10] != 0u;
+    prefix = sh[11]; rank_rem = sh[12]; total = sh[13];
+    __syncthreads();
+    return hit;
+}
+
 // level-0 histograms as a stand-alone kernel (NN variants that do not build them: k > 1, chains that may
 // need the brute-force pass).  Also clears level 1, like the NN kernel does when it is the builder.
 __global__ __launch_bounds__(256) void sel2_hist0_kernel(const float* __restrict__ d2, BatchArgs ba, int k, const IcpState* __restrict__ st,
-                                                         unsigned* __restrict__ hists)
+                                                         unsigned* __restrict__ hists, float quantile, int use_win)
 {
     const int64_t count = (int64_t)ba.n[blockIdx.y] * k; // blockIdx.y = reading of a batch
     d2 += (size_t)blockIdx.y * (size_t)ba.qstride * k;
     hists += (size_t)blockIdx.y * ICPMI_SELHIST_WORDS;
     st += blockIdx.y;
+    if (use_win) { // (r5) the NN kernel's window holds the selected element (and that kernel cleared level 1): nothing to do in this launch
+        if (st->done) return;
+        __shared__ unsigned shw[16];
+        unsigned pf, rr, tot;
+        if (win_lookup(hists, quantile, shw, pf, rr, tot)) return;
+    }
 #ifndef ICPMI_H0_PF
 #define ICPMI_H0_PF 16
 #endif
@@ -289,7 +349,7 @@ __global__ __launch_bounds__(256) void sel2_hist0_kernel(const float* __restrict
 
 // scan level 0 (top 16 bits), build level 1 (low 16 bits) from the elements under the selected prefix
 __global__ __launch_bounds__(256) void sel2_scan_hist_kernel(const float* __restrict__ d2, BatchArgs ba, int k, IcpState* __restrict__ st,
-                                                             unsigned* __restrict__ hists, float quantile)
+                                                             unsigned* __restrict__ hists, float quantile, int use_win)
 {
     // blockIdx.y = reading of a batch (common.h: BatchArgs)
     const int64_t count = (int64_t)ba.n[blockIdx.y] * k;
@@ -309,7 +369,12 @@ __global__ __launch_bounds__(256) void sel2_scan_hist_kernel(const float* __rest
     if (st->done) return;
     __shared__ unsigned sh[16];
     unsigned prefix, rem, total;
-    block_find_rank_2tier<ICPMI_S2_FCOPIES>(cv, hists + ICPMI_S2_F0, true, quantile, 0u, sh, prefix, rem, total);
+    // (r5) k > 1: the NN kernel's window around the previous prefix first (the stand-alone builder took the same decision from the same words)
+    const bool win_hit = use_win && win_lookup(hists, quantile, sh, prefix, rem, total);
+    if (!win_hit) block_find_rank_2tier<ICPMI_S2_FCOPIES>(cv, hists + ICPMI_S2_F0, true, quantile, 0u, sh, prefix, rem, total);
+#ifndef ICPMI_NN_TIMING
+    if (use_win && blockIdx.x == 0 && threadIdx.x == 0) st->dbg[win_hit ? 12 : 13] += 1ull; // diagnostics: iterations served by the window / by the full level 0
+#endif
     if (total == 0) {
         if (blockIdx.x == 0 && threadIdx.x == 0) { st->n_valid = 0; st->error = ICPMI_ERR_NO_OUTLIER_TO_FILTER; st->done = 1; }
         return;
@@ -648,6 +713,8 @@ __global__ __launch_bounds__(BT) void accumulate_kernel(const float4* __restrict
         if (blockIdx.x == 0 && threadIdx.x == 0) st->limits[fused_slot] = fused_limit;
         // level 0 is dead (its only reader ran in the previous kernel): clear it for the next iteration
         for (int64_t i = gtid; i < ICPMI_S2_COPIES * 256 + ICPMI_S2_FCOPIES * 65536; i += stride) hists[ICPMI_S2_C0 + i] = 0;
+        // ... and so is the speculative window of the k > 1 loop (its readers ran in the two kernels before this one)
+        if (lc.k > 1) for (int64_t i = gtid; i < 2 * ICPMI_WIN_U64; i += stride) hists[ICPMI_S2_WIN + i] = 0;
     }
     constexpr int NVAL = MIN == ICPMI_MIN_POINT_TO_PLANE ? 27 : (MIN == ICPMI_MIN_POINT_TO_POINT ? 16 : 0);
     double acc[NVAL > 0 ? NVAL : 1];
@@ -1153,11 +1220,13 @@ static void enqueue_selection(icpmi_ctx* c, const LoopCfg& lc, int64_t count, bo
             // matches: 1024 per workgroup -6 %, 2048 baseline, 4096 +0.8 %, 8192 -4 %)
             int hb0 = (int)std::min<int64_t>((count + 4095) / 4096, 256);
             if (hb0 < 1) hb0 = 1;
-            hipLaunchKernelGGL(sel2_hist0_kernel, dim3(hb0, ba.nscan), dim3(256), 0, c->stream, c->d_d2, ba, lc.k, c->d_state, c->d_selhist);
+            hipLaunchKernelGGL(sel2_hist0_kernel, dim3(hb0, ba.nscan), dim3(256), 0, c->stream, c->d_d2, ba, lc.k, c->d_state, c->d_selhist, quant,
+                               c->nn_builds_win ? 1 : 0);
         }
         int hb2 = (int)std::min<int64_t>((count + 511) / 512, 512);
         if (hb2 < 1) hb2 = 1;
-        hipLaunchKernelGGL(sel2_scan_hist_kernel, dim3(hb2, ba.nscan), dim3(256), 0, c->stream, c->d_d2, ba, lc.k, c->d_state, c->d_selhist, quant);
+        hipLaunchKernelGGL(sel2_scan_hist_kernel, dim3(hb2, ba.nscan), dim3(256), 0, c->stream, c->d_d2, ba, lc.k, c->d_state, c->d_selhist, quant,
+                           (c->nn_builds_win && !c->nn_builds_hist0) ? 1 : 0);
         return;
     }
     for (int f = 0; f < lc.n_out; ++f) {
@@ -1262,6 +1331,7 @@ static icpmi_status enqueue_iteration(icpmi_ctx* c, int64_t n, const LoopCfg& lc
     if (nn0) HIP_TRY(c, hipEventRecord(nn0, c->stream));
     c->nn_hist0 = fused_filter_slot(lc) >= 0 ? c->d_selhist : nullptr;
     c->nn_builds_hist0 = false;
+    c->nn_builds_win = false;
     static int keep_pts = -1;
     if (keep_pts < 0) { const char* e = getenv("ICPMI_SORTED_STATE"); keep_pts = e ? atoi(e) : 1; }
     c->nn_match_pt = (lc.k == 1 && keep_pts) ? c->d_match_pt : nullptr;
@@ -1814,6 +1884,7 @@ icpmi_status loop_single_step(icpmi_ctx* c, int64_t n, const LoopCfg& lc, const 
     c->nn_iter_hint = 0;
     c->nn_hist0 = fused_filter_slot(l1) >= 0 ? c->d_selhist : nullptr;
     c->nn_builds_hist0 = false;
+    c->nn_builds_win = false;
     c->nn_match_pt = nullptr;
     c->nn_sorted_k = false;
     c->nn_out_sorted = false;

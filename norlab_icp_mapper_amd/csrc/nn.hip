@@ -1707,7 +1707,8 @@ template <int KMAX>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KMAX <= 8 ? NNK_WG_WAVES : 3))) void nnk_wg_kernel(const float4* __restrict__ queries, const int* __restrict__ qindex, int n,
                                                      const float* __restrict__ Tptr, const uint4* __restrict__ ltab_g, int nlev,
                                                      int k, float maxr2, int* __restrict__ out_sidx, float* __restrict__ out_d2,
-                                                     IcpState* __restrict__ st, unsigned* __restrict__ hard, int out_sorted, int seed_pre)
+                                                     IcpState* __restrict__ st, unsigned* __restrict__ hard, int out_sorted, int seed_pre,
+                                                     unsigned long long* __restrict__ win /* speculative level 0 of the fused selection (common.h: ICPMI_S2_WIN), or nullptr */)
 {
     constexpr int NW = 4, NT = 64 * NW, Q = 64, NR = 3;
     constexpr int CAP = 14 * Q;   // pieces per pass (> 9 Q: one piece per row always fits)
@@ -1735,6 +1736,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KMAX <= 8 ?
     const int qi = lb * Q + slot;
     const bool active = w0 && qi < n;
     if (st->done) return;
+    // the window sits around the prefix the PREVIOUS iteration's selection picked (sel2_scan_hist_kernel ran before this launch)
+    const bool use_win = win != nullptr && st->iter > 0;
+    const unsigned win_c = st->sel_prefix_l[0];
+    const unsigned win_lo = win_c > (unsigned)(ICPMI_WIN_BINS / 2) ? win_c - (unsigned)(ICPMI_WIN_BINS / 2) : 0u;
+    if (use_win) { // level 1 of the selection is cleared by whoever builds level 0 (here: the window; its last reader was the previous pair-sum kernel)
+        unsigned* __restrict__ l1 = reinterpret_cast<unsigned*>(win) - ICPMI_S2_WIN + ICPMI_S2_C1;
+        for (int i = (int)blockIdx.x * NT + tid; i < 256 + 65536; i += wgs * NT) l1[i] = 0u;
+    }
 #ifdef ICPMI_NN_TIMING
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = clock64();
@@ -2042,6 +2051,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KMAX <= 8 ?
         }
         NN_TICK(4);
     }
+    unsigned long long wcnt0 = 0ull, wcnt1 = 0ull;
     if (active) {
         int bs[KMAX];
         float bd[KMAX];
@@ -2066,6 +2076,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KMAX <= 8 ?
             const unsigned hslot = atomicAdd(&st->hard_count, 1u);
             hard[hslot] = (unsigned)(qindex ? qindex[qi] : qi);
         }
+        // the nine counts of the speculative window: field 0 = below, 1 .. BINS = the bins from win_lo on, BINS + 1 = above; twelve bits
+        // per field and lane-sum (<= 64 x 16), five fields per 64-bit word.  Same predicate as sel2_hist0_kernel: finite and positive.
+        if (use_win) {
+#pragma unroll
+            for (int j = 0; j < KMAX; ++j)
+                if (j < k && bd[j] != INFINITY && bd[j] > 0.f) {
+                    const unsigned bin = __float_as_uint(bd[j]) >> 16;
+                    const unsigned f = bin < win_lo ? 0u : (bin - win_lo < (unsigned)ICPMI_WIN_BINS ? bin - win_lo + 1u : (unsigned)ICPMI_WIN_BINS + 1u);
+                    if (f < 5u) wcnt0 += 1ull << (12u * f); else wcnt1 += 1ull << (12u * (f - 5u));
+                }
+        }
+    }
+    if (w0 && use_win) { // (whole wave: lanes without a query carry zeros)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            wcnt0 += (unsigned long long)__shfl_xor((long long)wcnt0, off, 64);
+            wcnt1 += (unsigned long long)__shfl_xor((long long)wcnt1, off, 64);
+        }
+        if (lane < 3) {
+            unsigned long long w = 0ull;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int f = 3 * lane + j;
+                const unsigned long long v = f < 5 ? (wcnt0 >> (12 * f)) & 0xfffull : (wcnt1 >> (12 * (f - 5))) & 0xfffull;
+                w |= v << (21 * j);
+            }
+            if (w) atomicAdd(&win[(size_t)((blockIdx.x & (ICPMI_WIN_COPIES - 1)) * 3 + lane) * ICPMI_WIN_PAD], w);
+        }
+        if (blockIdx.x == 0 && lane == 0) win[ICPMI_WIN_HDR] = (unsigned long long)win_lo + 1ull;
     }
 #ifdef ICPMI_NN_TIMING
     NN_TICK(5);
@@ -2581,9 +2620,15 @@ static icpmi_status nnk_launch_t(icpmi_ctx* c, const float4* d_reading, int64_t 
             if (wg_from == -2) { const char* e = getenv("ICPMI_NNK_WG_FROM"); wg_from = e ? atoi(e) : 2; }
             if (wg_pre < 0) { const char* e = getenv("ICPMI_NNK_SEED_PRE"); wg_pre = e ? atoi(e) : 1; }
             const bool use_wg = wg_from >= 0 && allow_self && c->nn_iter_hint >= wg_from && c->batch_cur <= 1;
+            // (r5) the speculative window of the fused selection (common.h: ICPMI_S2_WIN): loops with one quantile filter whose every query is
+            // decided on the pyramid (the brute pass rewrites d2 afterwards), below 2^21 matches (the packed counts cannot carry); ICPMI_SEL_WIN=0: off
+            static int sel_win = -1;
+            if (sel_win < 0) { const char* e = getenv("ICPMI_SEL_WIN"); sel_win = e ? atoi(e) : 1; }
+            c->nn_builds_win = use_wg && sel_win && c->nn_hist0 != nullptr && d_d2 == c->d_d2 && !needs_hard && n * (int64_t)lc.k < ICPMI_WIN_MAX_COUNT;
             if (use_wg)
                 hipLaunchKernelGGL((nnk_wg_kernel<KM>), dim3((int)(((n + 63) / 64 + 7) / 8 * 8)), dim3(256), 0, c->stream, q, qi,
-                                   (int)n, d_T, c->d_lvl_tab, c->levels.nlev, lc.k, lc.maxr2, d_sidx, d_d2, d_state, c->d_hard, out_sorted, wg_pre);
+                                   (int)n, d_T, c->d_lvl_tab, c->levels.nlev, lc.k, lc.maxr2, d_sidx, d_d2, d_state, c->d_hard, out_sorted, wg_pre,
+                                   c->nn_builds_win ? reinterpret_cast<unsigned long long*>(c->nn_hist0 + ICPMI_S2_WIN) : (unsigned long long*)nullptr);
             else
             hipLaunchKernelGGL((nnk_ml_kernel<G, KM>), dim3(grid), dim3(NN_BLOCK), 0, c->stream, q, qi, (int)n, d_T, c->d_lvl_tab,
                                c->levels.nlev, lc.k, lc.maxr2, allow_self, seeded, d_sidx, d_d2, d_state, c->d_hard, out_sorted);
