@@ -62,7 +62,9 @@
 // jumps) is the full histogram as before; the counts are exact either way, so the selected element is the same bit pattern.
 // Every (copy, word) on its own 128-byte line; the header word holds (lowest window prefix + 1), 0 = no window this iteration.
 #define ICPMI_WIN_BINS 7
+#ifndef ICPMI_WIN_COPIES
 #define ICPMI_WIN_COPIES 8
+#endif
 #define ICPMI_WIN_PAD 16                                                  // u64 per slot = one 128-byte line
 #define ICPMI_WIN_HDR (ICPMI_WIN_COPIES * 3 * ICPMI_WIN_PAD)              // u64 index of the header
 #define ICPMI_WIN_U64 (ICPMI_WIN_HDR + ICPMI_WIN_PAD)

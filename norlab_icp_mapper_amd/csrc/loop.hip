@@ -233,20 +233,20 @@ __device__ __forceinline__ bool win_lookup(const unsigned* __restrict__ hists, f
                                            unsigned& prefix, unsigned& rank_rem, unsigned& total)
 {
     const unsigned long long* __restrict__ W = reinterpret_cast<const unsigned long long*>(hists + ICPMI_S2_WIN);
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, w = t >> 6, l = t & 63;
+    // wave w < 3 sums word w over the copies (the packed fields cannot carry: every field's total is below 2^21), wave 3 fetches the header
+    static_assert(ICPMI_WIN_COPIES <= 64, "one lane per copy");
     unsigned long long v = 0ull;
-    if (t < ICPMI_WIN_COPIES * 3) v = W[(size_t)t * ICPMI_WIN_PAD];       // (copy, word) = (t / 3, t % 3)
-    else if (t == ICPMI_WIN_COPIES * 3) v = W[ICPMI_WIN_HDR];
-    if (t < 16) sh[t] = 0u;
-    __syncthreads();
-    if (t < ICPMI_WIN_COPIES * 3) {
-        const int w = t % 3;
+    if (w < 3) { if (l < ICPMI_WIN_COPIES) v = W[(size_t)(l * 3 + w) * ICPMI_WIN_PAD]; }
+    else if (l == 0) v = W[ICPMI_WIN_HDR];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const unsigned f = (unsigned)(v >> (21 * j)) & 0x1fffffu;
-            if (f) atomicAdd(&sh[3 * w + j], f);
-        }
-    } else if (t == ICPMI_WIN_COPIES * 3) sh[9] = (unsigned)v;
+    for (int off = 32; off > 0; off >>= 1) v += (unsigned long long)__shfl_xor((long long)v, off, 64);
+    if (l == 0) {
+        if (w < 3) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) sh[3 * w + j] = (unsigned)(v >> (21 * j)) & 0x1fffffu;
+        } else sh[9] = (unsigned)v;
+    }
     __syncthreads();
     if (t == 0) {
         const unsigned lo1 = sh[9], below = sh[0], above = sh[ICPMI_WIN_BINS + 1];

@@ -2051,7 +2051,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KMAX <= 8 ?
         }
         NN_TICK(4);
     }
-    unsigned long long wcnt0 = 0ull, wcnt1 = 0ull;
+    unsigned long long wcnt = 0ull;
     if (active) {
         int bs[KMAX];
         float bd[KMAX];
@@ -2076,33 +2076,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KMAX <= 8 ?
             const unsigned hslot = atomicAdd(&st->hard_count, 1u);
             hard[hslot] = (unsigned)(qindex ? qindex[qi] : qi);
         }
-        // the nine counts of the speculative window: field 0 = below, 1 .. BINS = the bins from win_lo on, BINS + 1 = above; twelve bits
-        // per field and lane-sum (<= 64 x 16), five fields per 64-bit word.  Same predicate as sel2_hist0_kernel: finite and positive.
+        // the nine counts of the speculative window: field 0 = below, 1 .. BINS = the bins from win_lo on, BINS + 1 = above; seven bits per
+        // field and lane (<= 16 distances).  Same predicate as sel2_hist0_kernel: finite and positive.
         if (use_win) {
 #pragma unroll
             for (int j = 0; j < KMAX; ++j)
                 if (j < k && bd[j] != INFINITY && bd[j] > 0.f) {
                     const unsigned bin = __float_as_uint(bd[j]) >> 16;
                     const unsigned f = bin < win_lo ? 0u : (bin - win_lo < (unsigned)ICPMI_WIN_BINS ? bin - win_lo + 1u : (unsigned)ICPMI_WIN_BINS + 1u);
-                    if (f < 5u) wcnt0 += 1ull << (12u * f); else wcnt1 += 1ull << (12u * (f - 5u));
+                    wcnt += 1ull << (7u * f);
                 }
         }
     }
-    if (w0 && use_win) { // (whole wave: lanes without a query carry zeros)
+    if (w0 && use_win) { // (the whole wave: lanes without a query carry zeros)
+        // wave totals in registers: two 16-bit fields per word (<= 64 x 16 per field), DPP prefix sums, the totals read from lane 63
+        static_assert(ICPMI_WIN_BINS + 2 == 9, "nine fields: five words of two, three packed atomics of three");
+        unsigned tot[5];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            wcnt0 += (unsigned long long)__shfl_xor((long long)wcnt0, off, 64);
-            wcnt1 += (unsigned long long)__shfl_xor((long long)wcnt1, off, 64);
+        for (int i = 0; i < 5; ++i) {
+            const unsigned lo = (unsigned)(wcnt >> (14 * i)) & 127u, hi = i < 4 ? (unsigned)(wcnt >> (14 * i + 7)) & 127u : 0u;
+            tot[i] = (unsigned)__builtin_amdgcn_readlane((int)wave_incl_scan(lo | (hi << 16)), 63);
         }
         if (lane < 3) {
             unsigned long long w = 0ull;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int f = 3 * lane + j;
-                const unsigned long long v = f < 5 ? (wcnt0 >> (12 * f)) & 0xfffull : (wcnt1 >> (12 * (f - 5))) & 0xfffull;
-                w |= v << (21 * j);
+                unsigned v = 0u;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) if (i == (f >> 1)) v = (f & 1) ? tot[i] >> 16 : tot[i] & 0xffffu;
+                w |= (unsigned long long)v << (21 * j);
             }
+#ifndef ICPMI_WIN_DIAG_NOATOM
             if (w) atomicAdd(&win[(size_t)((blockIdx.x & (ICPMI_WIN_COPIES - 1)) * 3 + lane) * ICPMI_WIN_PAD], w);
+#endif
         }
         if (blockIdx.x == 0 && lane == 0) win[ICPMI_WIN_HDR] = (unsigned long long)win_lo + 1ull;
     }

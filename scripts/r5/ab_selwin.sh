@@ -1,5 +1,5 @@
 #!/bin/bash
-# DESIGN 13.9: the speculative level 0 of the k > 1 loop (ICPMI_SEL_WIN) and the pair sums' skipped gathers (ICPMI_ACC_SKIP: built for this A/B, no gain, removed afterwards -- the switch is a no-op in the tree), one call
+# DESIGN 13.7b: the speculative level 0 of the k > 1 loop (ICPMI_SEL_WIN) and the pair sums' skipped gathers (ICPMI_ACC_SKIP: built for this A/B, no gain, removed afterwards -- the switch is a no-op in the tree), one call
 cd "$GRAFT_REPO_ROOT"
 one() { env "$@" python bench.py --no-cpu --no-extras --chain "$CH" 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('   $CH', round(d['value']), 'it/s  ms_per_step', round(d['ms_per_step'],4))"; }
 run() { echo "== $1"; shift; for CH in docs_knn6 p2plane; do one "$@"; done; }

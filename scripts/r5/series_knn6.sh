@@ -1,5 +1,5 @@
 #!/bin/bash
-# per-launch kernel durations of one knn-6 registration with and without the speculative window (DESIGN 13.9)
+# per-launch kernel durations of one knn-6 registration with and without the speculative window (DESIGN 13.7b)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r5series6; mkdir -p $O
 for W in 1 0; do
