@@ -640,7 +640,10 @@ def main():
             icp6.setMapDev(d_map.data_ptr(), d_map.shape[0], d_nrm.data_ptr())
             T6, el6, per6 = time_registrations(torch, icp6, d_scan, max(args.steps // 2, 5), args.warmup)
             g6t, g6r = pkg.synth.pose_error(T6, sc["T_gt"])
+            dbg6 = icp6.debugCounters()  # (r5) iterations of the last registration whose level 0 came from the NN kernel's window / from the full histogram
             extras["docs_knn6"] = {
+                "selection_window": {"iterations_served": int(dbg6[12]), "iterations_missed": int(dbg6[13]), "of": ITERS_PER_STEP,
+                                     "note": "speculative level 0 of the quantile selection counted by nnk_wg_kernel (iterations 2..); ICPMI_SEL_WIN=0 switches it off"},
                 "config": "docs/MapperConfiguration.md:174-189: KDTreeMatcher knn 6 maxDist 2.0 epsilon 0, TrimmedDist 0.85, PointToPlane; 100k-pt scan vs 1M-pt map",
                 "value": max(args.steps // 2, 5) * ITERS_PER_STEP / el6, "unit": "iterations/s", "step_ms": step_stats(per6),
                 "pose_err_vs_ground_truth": {"m": g6t, "rad": g6r},
