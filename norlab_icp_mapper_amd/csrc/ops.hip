@@ -84,6 +84,10 @@ __global__ __launch_bounds__(256) void keep_kernel(const float* __restrict__ d2,
 // its centroid: k / (4/3 pi r^3), r = the largest distance of a neighbour from the centroid (computeDensity)
 // mean_dist (may be null): `keepMeanDist` -- distance from the point to the mean of its neighbours.  The point is read as its own first
 // neighbour (d2 = 0 sorts first; a duplicate that wins the index tie has the same coordinates), which keeps it in the index's centred frame.
+// KMAX > 0 (k <= KMAX; r5): the row of neighbour ids and the k neighbours are requested up front -- two round trips -- and both passes (mean,
+// scatter matrix) run from registers in the same order; the generic variant (KMAX = 0: any k) walks them one dependent load after the other,
+// twice.  Same sums in the same order: same bits.
+template <int KMAX>
 __global__ __launch_bounds__(128) void normals_kernel(const float4* __restrict__ map, const int* __restrict__ sidx, int64_t m, int k,
                                                       float* __restrict__ normals3, float* __restrict__ densities, int dim2,
                                                       float* __restrict__ mean_dist = nullptr, float* __restrict__ eig_values = nullptr,
@@ -96,32 +100,55 @@ __global__ __launch_bounds__(128) void normals_kernel(const float4* __restrict__
     // in the caller's order)
     double mean[3] = {0, 0, 0};
     int real = 0;
-    for (int j = 0; j < k; ++j) {
-        const int s = sidx[(size_t)k * i + j];
-        if (s < 0) continue;
-        const float4 q = map[s];
-        mean[0] += q.x; mean[1] += q.y; mean[2] += q.z; ++real;
-    }
-    const double inv = 1.0 / (real > 0 ? real : 1);
-    mean[0] *= inv; mean[1] *= inv; mean[2] *= inv;
     double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0, rmax2 = 0;
-    for (int j = 0; j < k; ++j) {
-        const int s = sidx[(size_t)k * i + j];
-        if (s < 0) continue;
-        const float4 q = map[s];
-        const double x = q.x - mean[0], y = q.y - mean[1], z = q.z - mean[2];
-        c00 += x * x; c01 += x * y; c02 += x * z; c11 += y * y; c12 += y * z; c22 += z * z;
-        const double r2 = x * x + y * y + z * z;
-        rmax2 = r2 > rmax2 ? r2 : rmax2;
+    float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f); // the point itself (its own first neighbour), or map[0] where the row starts with "none"
+    if constexpr (KMAX > 0) {
+        int sv[KMAX];
+        float4 qv[KMAX];
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) sv[j] = j < k ? sidx[(size_t)k * i + j] : -1;
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) qv[j] = map[sv[j] < 0 ? 0 : sv[j]];
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j)
+            if (sv[j] >= 0) { mean[0] += qv[j].x; mean[1] += qv[j].y; mean[2] += qv[j].z; ++real; }
+        const double inv = 1.0 / (real > 0 ? real : 1);
+        mean[0] *= inv; mean[1] *= inv; mean[2] *= inv;
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j)
+            if (sv[j] >= 0) {
+                const double x = qv[j].x - mean[0], y = qv[j].y - mean[1], z = qv[j].z - mean[2];
+                c00 += x * x; c01 += x * y; c02 += x * z; c11 += y * y; c12 += y * z; c22 += z * z;
+                const double r2 = x * x + y * y + z * z;
+                rmax2 = r2 > rmax2 ? r2 : rmax2;
+            }
+        p0 = qv[0];
+    } else {
+        for (int j = 0; j < k; ++j) {
+            const int s = sidx[(size_t)k * i + j];
+            if (s < 0) continue;
+            const float4 q = map[s];
+            mean[0] += q.x; mean[1] += q.y; mean[2] += q.z; ++real;
+        }
+        const double inv = 1.0 / (real > 0 ? real : 1);
+        mean[0] *= inv; mean[1] *= inv; mean[2] *= inv;
+        for (int j = 0; j < k; ++j) {
+            const int s = sidx[(size_t)k * i + j];
+            if (s < 0) continue;
+            const float4 q = map[s];
+            const double x = q.x - mean[0], y = q.y - mean[1], z = q.z - mean[2];
+            c00 += x * x; c01 += x * y; c02 += x * z; c11 += y * y; c12 += y * z; c22 += z * z;
+            const double r2 = x * x + y * y + z * z;
+            rmax2 = r2 > rmax2 ? r2 : rmax2;
+        }
+        if (mean_dist) { const int s0 = sidx[(size_t)k * i]; p0 = map[s0 < 0 ? 0 : s0]; }
     }
     if (densities) {
         const double r = sqrt(rmax2);
         densities[i] = (float)((double)real / ((4.0 / 3.0) * 3.14159265358979323846 * (r * r * r)));
     }
     if (mean_dist) {
-        const int s0 = sidx[(size_t)k * i];
-        const float4 p = map[s0 < 0 ? 0 : s0];
-        const double x = p.x - mean[0], y = p.y - mean[1], z = p.z - mean[2];
+        const double x = p0.x - mean[0], y = p0.y - mean[1], z = p0.z - mean[2];
         mean_dist[i] = (float)sqrt(x * x + y * y + z * z);
     }
     // cyclic Jacobi on the symmetric 3x3
@@ -209,6 +236,18 @@ __global__ __launch_bounds__(128) void normals_kernel(const float4* __restrict__
         nz = (float)(e == 0 ? Q[2][0] : (e == 1 ? Q[2][1] : Q[2][2]));
     }
     normals3[3 * i] = nx; normals3[3 * i + 1] = ny; normals3[3 * i + 2] = nz;
+}
+
+// k <= 10 (the shipped SurfaceNormalDataPointsFilter{knn: 10}) and k <= 16 keep the neighbourhood in registers; ICPMI_NORMALS_REG=0: the generic walk
+static void launch_normals(hipStream_t stream, const float4* map, const int* sidx, int64_t m, int k, float* normals3, float* densities, int dim2,
+                           float* mean_dist = nullptr, float* eig_values = nullptr, float* eig_vectors = nullptr)
+{
+    static int reg = -1;
+    if (reg < 0) { const char* e = getenv("ICPMI_NORMALS_REG"); reg = e ? atoi(e) : 1; }
+    const dim3 grid((int)((m + 127) / 128)), block(128);
+    if (reg && k <= 10) hipLaunchKernelGGL(normals_kernel<10>, grid, block, 0, stream, map, sidx, m, k, normals3, densities, dim2, mean_dist, eig_values, eig_vectors);
+    else if (reg && k <= 16) hipLaunchKernelGGL(normals_kernel<16>, grid, block, 0, stream, map, sidx, m, k, normals3, densities, dim2, mean_dist, eig_values, eig_vectors);
+    else hipLaunchKernelGGL(normals_kernel<0>, grid, block, 0, stream, map, sidx, m, k, normals3, densities, dim2, mean_dist, eig_values, eig_vectors);
 }
 
 // ---- fused input filters (Mapper::applyInputFilters): one predicate pass for a run of DistanceLimit / BoundingBox filters ----
@@ -797,9 +836,8 @@ icpmi_status ops_surface_normals(icpmi_ctx* c, const float* pts4, int64_t m, int
     if (mean_dist) HIP_TRY(c, d_md.alloc((size_t)m));
     if (eig_values) HIP_TRY(c, d_ev.alloc((size_t)m * 3));
     if (eig_vectors) HIP_TRY(c, d_evec.alloc((size_t)m * 9));
-    hipLaunchKernelGGL(normals_kernel, dim3((int)((m + 127) / 128)), dim3(128), 0, tc->stream, tc->d_map_sorted, tc->d_sidx, m, knn, d_n,
-                       densities ? d_dens.p : (float*)nullptr, c->cfg.is_2d, mean_dist ? d_md.p : (float*)nullptr,
-                       eig_values ? d_ev.p : (float*)nullptr, eig_vectors ? d_evec.p : (float*)nullptr);
+    launch_normals(tc->stream, tc->d_map_sorted, tc->d_sidx, m, knn, d_n, densities ? d_dens.p : (float*)nullptr, c->cfg.is_2d,
+                   mean_dist ? d_md.p : (float*)nullptr, eig_values ? d_ev.p : (float*)nullptr, eig_vectors ? d_evec.p : (float*)nullptr);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && eig_values) e = hipMemcpyAsync(eig_values, d_ev, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost, tc->stream);
     if (e == hipSuccess && eig_vectors) e = hipMemcpyAsync(eig_vectors, d_evec, (size_t)m * 9 * sizeof(float), hipMemcpyDeviceToHost, tc->stream);
@@ -984,8 +1022,7 @@ static icpmi_status surface_normals_dev(icpmi_ctx* c, const float4* d_pts, int64
     s = nn_self_knn(tc, d_pts, lc, tc->d_sidx, tc->d_d2, tc->d_state);
     if (s != ICPMI_OK) { c->last_error = tc->last_error; return s; }
     // rows of d_sidx follow the query order = the caller's order, so the normals land in place
-    hipLaunchKernelGGL(normals_kernel, dim3((int)((m + 127) / 128)), dim3(128), 0, tc->stream, tc->d_map_sorted, tc->d_sidx, m, knn, d_normals3,
-                       (float*)nullptr, c->cfg.is_2d);
+    launch_normals(tc->stream, tc->d_map_sorted, tc->d_sidx, m, knn, d_normals3, (float*)nullptr, c->cfg.is_2d);
     HIP_TRY(c, hipGetLastError());
     if (tc->stream != c->stream) HIP_TRY(c, hipStreamSynchronize(tc->stream));
     return ICPMI_OK;
