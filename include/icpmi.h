@@ -466,7 +466,8 @@ icpmi_status icpmi_set_stream(icpmi_handle h, void* hip_stream);
 /* Grid parameters chosen by the last set_map: cell edge, dims[3], number of cells (for DESIGN/bench). */
 icpmi_status icpmi_get_grid_info(icpmi_handle h, float* cell, int32_t dims[3], int64_t* n_cells, int64_t* n_occupied);
 int32_t      icpmi_version(void);
-/* Diagnostics of the last registration (engine internals, not part of the reference surface). */
+/* Diagnostics of the last registration (engine internals, not part of the reference surface).  Slots 12 / 13 (r5): iterations of a k > 1 loop whose
+   quantile selection took its level 0 from the NN kernel's window / from the full histogram behind a window that missed. */
 icpmi_status icpmi_debug_counters(icpmi_handle h, uint64_t out[24]);
 /* Test seam: the n-th value (n >= 1) of the std::minstd_rand stream as the DEVICE computes it by skip-ahead (csrc/ssn.hip, behind
  * SamplingSurfaceNormalDataPointsFilter -- PM::ICPSequence::setDefault(), Mapper.cpp:74-78).  [rand.predef]: seed 1, n = 10 000 -> 399268537. */
