@@ -153,6 +153,8 @@ def config4_replay(np, pkg, with_cpu, passes=3):
         run = subprocess.run([exe, tmp, cfg], capture_output=True, text=True, timeout=600, env=dict(os.environ, NIM_TIMING=str(passes)))
         if run.returncode != 0:
             return {"error": (run.stderr + run.stdout)[-400:]}
+        if os.environ.get("ICPMI_SELF_DIAG"):  # (diagnostic lines of the library's self search travel on the harness's stderr)
+            sys.stderr.write("".join(l + "\n" for l in run.stderr.splitlines() if "icpmi" in l)[-4000:])
     num = r"([-+0-9.eE]+)"
     reps = [dict(zip(("pass", "scans", "process_ms", "register_ms", "update_ms", "iterations", "scans_per_s"), map(float, m)))
             for m in re.findall(rf"replay: pass {num} scans {num} process_ms {num} register_ms {num} update_ms {num} iterations {num} scans_per_s {num}", run.stdout)]

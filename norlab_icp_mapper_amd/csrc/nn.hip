@@ -292,10 +292,28 @@ __global__ __launch_bounds__(NN_BLOCK) void nnk_hard_kernel(const float4* __rest
         if (Tptr) p = xf_point(Tptr, r.x, r.y, r.z, r.w);
         else p = make_float3(r.x, r.y, r.z);
         KList<KMAX> L; L.init(k);
-        for (unsigned i = threadIdx.x; i < (unsigned)m; i += NN_BLOCK) {
-            const float4 q = map[i];
-            const float d2 = sqdist3(p.x, p.y, p.z, q.x, q.y, q.z);
-            if (allow_self || d2 > 1.1920929e-07f) L.insert(pack_key(d2, __float_as_uint(q.w)), (int)i);
+        // (r5) Every kernel that queues a query here has written the k candidates it did find to the query's row first (nnk_kernel, nnk_ml_kernel,
+        // nnk_wg_kernel, nnk_wave_kernel: rows and queue entries share one index): when that list is full its k-th key bounds the answer, and a
+        // candidate above it never touches a lane's list.  Without the bound some lane of a wave inserts at nearly every candidate (a lane's list
+        // changes ~50 times over its 390 candidates of a 0.1 M-point map) and the whole wave pays the 64-bit insertion each time: ~200 us per
+        // QUERY -- and a lidar map's sparse periphery sends 400 - 500 points of every self search here (BASELINE config 4).  Same k points:
+        // the k smallest keys are all <= the k-th key of any k valid candidates.
+        const float kb = out_d2[(size_t)k * qi + (k - 1)];
+        const unsigned long long bound = kb != INFINITY ? pack_key(kb, 0xffffffffu) : ~0ull;
+        // ... and eight candidates are requested per trip (one load, one test, the next load was a memory round trip per candidate: what
+        // was left of the kernel once the insertions were gone).  Same candidates in the same order.
+        constexpr int HU = 8;
+        for (unsigned i0 = threadIdx.x; i0 < (unsigned)m; i0 += NN_BLOCK * HU) {
+            float4 q[HU];
+#pragma unroll
+            for (int u = 0; u < HU; ++u) { const unsigned i = i0 + (unsigned)u * NN_BLOCK; q[u] = map[i < (unsigned)m ? i : i0]; }
+#pragma unroll
+            for (int u = 0; u < HU; ++u) {
+                const unsigned i = i0 + (unsigned)u * NN_BLOCK;
+                const float d2 = sqdist3(p.x, p.y, p.z, q[u].x, q[u].y, q[u].z);
+                const unsigned long long key = pack_key(d2, __float_as_uint(q[u].w));
+                if (i < (unsigned)m && (allow_self || d2 > 1.1920929e-07f) && key <= bound) L.insert(key, (int)i);
+            }
         }
         int head = 0;
         for (int j = 0; j < k; ++j) {
@@ -2353,6 +2371,9 @@ __global__ __launch_bounds__(64) void nnk_wave_kernel(const float4* __restrict__
             ++ring;
             const int side = 2 * ring + 1;
             KList<KMAX> Lc; Lc.init(k); // this lane's share of the ring
+            unsigned long long gkth = ~0ull; // the k-th key of the rings before this one (all lanes hold the same list)
+#pragma unroll
+            for (int i = 0; i < KMAX; ++i) if (i == k - 1) gkth = Gl.key[i];
             // r5: rows to the lanes for their BOUNDS only (one trip for 64 rows); the candidates of the non-empty runs are then dealt to
             // the lanes 64 at a time, four runs in flight.  (Until r5 a lane scanned its whole row: in ring 1 nine lanes walked ~40 points
             // each, four per trip, while 55 idled -- 50 us for the ~200 queries the tiled pass leaves.)  Same candidates; a k-list does
@@ -2395,7 +2416,10 @@ __global__ __launch_bounds__(64) void nnk_wave_kernel(const float4* __restrict__
                                 const unsigned i = bs[u] + off + (unsigned)lane;
                                 if (i < be[u]) {
                                     const float d2 = sqdist3(p.x, p.y, p.z, q[u].x, q[u].y, q[u].z);
-                                    if (allow_self || d2 > 1.1920929e-07f) Lc.insert(pack_key(d2, __float_as_uint(q[u].w)), (int)i);
+                                    // (r5) a candidate that does not beat the k-th of the rings before it never reaches the answer: it stays out
+                                    // of the lane's list, and a ring that adds nothing skips its merge (ring_empty below)
+                                    const unsigned long long key = pack_key(d2, __float_as_uint(q[u].w));
+                                    if ((allow_self || d2 > 1.1920929e-07f) && key < gkth) Lc.insert(key, (int)i);
                                 }
                                 more |= bs[u] + off + 64u < be[u];
                             }
@@ -2714,17 +2738,23 @@ static icpmi_status nn_self_knn_t(icpmi_ctx* c, const float4* d_cloud, const Loo
         hipLaunchKernelGGL(nnk_kernel<KMAX>, dim3(blocks), dim3(NN_BLOCK), 0, c->stream, d_cloud, (int)c->m, (const float*)nullptr, g,
                            c->d_map_sorted, c->d_cell_start, lc.k, lc.maxr2, lc.ring_max, 1, d_sidx, d_d2, d_state,
                            c->d_hard + c->m + 2, (const unsigned*)c->d_hard, (const unsigned*)(c->d_hard + c->m + 1));
-    hipLaunchKernelGGL(nnk_hard_kernel<KMAX>, dim3(512), dim3(NN_BLOCK), 0, c->stream, d_cloud, (const float*)nullptr, c->d_map_sorted,
+    static int diag = -1; // ICPMI_SELF_DIAG=1: how many queries the tiled pass left to the ring kernel, and that one to the brute pass (read-backs: diagnostic only)
+    if (diag < 0) { const char* e = getenv("ICPMI_SELF_DIAG"); diag = e ? atoi(e) : 0; }
+    unsigned diag_brute = 0;
+    if (diag) read_back(c, &diag_brute, &d_state->hard_count, sizeof(unsigned));
+    // the brute pass of what the rings left undecided: one workgroup per query streams the map (BASELINE config 4, a lidar map's sparse
+    // periphery: 6 - 8 % of the points go to the ring kernel, 400 - 500 of 100 k on to here; ICPMI_SELF_HARD_GRID: no effect measured)
+    static int hard_grid = -1;
+    if (hard_grid < 0) { const char* e = getenv("ICPMI_SELF_HARD_GRID"); hard_grid = e ? atoi(e) : 512; if (hard_grid < 1) hard_grid = 512; }
+    hipLaunchKernelGGL(nnk_hard_kernel<KMAX>, dim3(hard_grid), dim3(NN_BLOCK), 0, c->stream, d_cloud, (const float*)nullptr, c->d_map_sorted,
                        (int)c->m, lc.k, lc.maxr2, 1, d_sidx, d_d2, d_state, (const unsigned*)(c->d_hard + c->m + 2));
     hipLaunchKernelGGL(hard_reset_kernel, dim3(1), dim3(64), 0, c->stream, d_state);
     HIP_TRY(c, hipGetLastError());
     {
-        static int diag = -1; // ICPMI_SELF_DIAG=1: how many queries the tiled pass left to the ring kernel (a read-back: diagnostic only)
-        if (diag < 0) { const char* e = getenv("ICPMI_SELF_DIAG"); diag = e ? atoi(e) : 0; }
         if (diag) {
             unsigned left = 0;
             if (read_back(c, &left, c->d_hard + c->m + 1, sizeof(unsigned)) == ICPMI_OK)
-                fprintf(stderr, "[icpmi self-knn] m %lld k %d: %u queries (%.2f %%) redone by the ring kernel\n", (long long)c->m, lc.k, left, 100.0 * left / (double)c->m);
+                fprintf(stderr, "[icpmi self-knn] m %lld k %d: %u queries (%.2f %%) redone by the ring kernel, %u by the brute pass (ring_max %d, cell %.3f)\n", (long long)c->m, lc.k, left, 100.0 * left / (double)c->m, diag_brute, lc.ring_max, (double)g.cell);
 #ifdef ICPMI_SELF_WORK_DIAG
             {
                 unsigned long long work = 0;

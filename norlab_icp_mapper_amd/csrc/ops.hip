@@ -1013,6 +1013,7 @@ static icpmi_status surface_normals_dev(icpmi_ctx* c, const float4* d_pts, int64
     if (s != ICPMI_OK) { c->last_error = tc->last_error; return s; }
     LoopCfg lc = make_loop_cfg(tc, 1);
     lc.k = knn; lc.max_dist = INFINITY; lc.maxr2 = INFINITY; lc.ring_max = 6;
+    { static int rm = -1; if (rm < 0) { const char* e = getenv("ICPMI_SELF_RING_MAX"); rm = e ? atoi(e) : 6; if (rm < 1) rm = 6; } lc.ring_max = rm; }
     const size_t cnt = (size_t)m * knn + 1;
     if (ensure_cap(tc, &tc->d_sidx, &tc->cap_sidx, cnt) != ICPMI_OK || ensure_cap(tc, &tc->d_d2, &tc->cap_d2, cnt) != ICPMI_OK ||
         ensure_cap(tc, &tc->d_hard, &tc->cap_hard, (size_t)m + 1) != ICPMI_OK) { c->last_error = tc->last_error; return ICPMI_ERR_HIP; }
