@@ -274,3 +274,27 @@ def test_finished_state_reaches_the_host_by_itself(amd, small_scene, checked):
             h(far)
         assert "ConvergenceError" in str(ei.value)
     assert np.array_equal(_bits(icp(sc["scan"])), _bits(ref(sc["scan"])))   # ... and the handle goes on
+
+
+@pytest.mark.parametrize("knn", [10, 5, 12])
+def test_self_search_leftovers_of_a_sparse_periphery(amd, oracle, knn):
+    """What a lidar map does to the self search: a dense patch and a few hundred isolated points scattered over hundreds of
+    metres.  The isolated points' neighbours lie dozens of cells away: the tiled pass leaves them to the ring kernel (pruned by the k-th key
+    of the rings before), six rings decide nothing, and the brute pass (bounded by the k-th key the ring kernel left in the row, eight
+    candidates per trip) finds them.  Neighbour ids and mean distances are the oracle's, bit for bit; a second call on the same handle too."""
+    rng = np.random.default_rng(31 + knn)
+    dense = np.c_[rng.uniform(-4, 4, 40000), rng.uniform(-4, 4, 40000), 0.05 * rng.standard_normal(40000)]
+    lone = rng.uniform(-300, 300, (400, 3)) * np.array([1.0, 1.0, 0.05])
+    pairs = lone[:120] + rng.normal(0, 0.4, (120, 3))          # some of them in loose pairs: short lists that fill late
+    line = np.c_[np.linspace(20, 250, 600), 0.2 * rng.standard_normal(600), 0.2 * rng.standard_normal(600)]   # a thin row of posts: neighbours along one axis only
+    pts = np.concatenate([dense, lone, pairs, line]).astype(np.float32)
+    cloud = np.c_[pts, np.ones(len(pts), np.float32)].astype(np.float32)
+    cloud = cloud[rng.permutation(len(cloud))]
+    icp = amd.ICPSequence(minimizer=2)
+    first = icp.surfaceNormals(cloud, knn=knn, with_matched_ids=True, with_mean_dist=True)
+    again = icp.surfaceNormals(cloud, knn=knn, with_matched_ids=True, with_mean_dist=True)
+    _, ids_o, md_o = oracle.surface_normals_extras(cloud, knn=knn, nthreads=8)
+    assert np.array_equal(first[1], ids_o)
+    assert np.array_equal(first[2].view(np.uint32), md_o.view(np.uint32))
+    for x, y in zip(first, again):
+        assert np.array_equal(np.ascontiguousarray(x).view(np.uint32), np.ascontiguousarray(y).view(np.uint32))
