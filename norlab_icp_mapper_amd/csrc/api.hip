@@ -119,7 +119,10 @@ static icpmi_status validate_config(const icpmi_config* cfg, std::string& err)
     return ICPMI_OK;
 }
 
-icpmi_status icpmi_create(const icpmi_config* cfg, icpmi_handle* out)
+} // extern "C"
+
+// a handle without the allocation cache's handle count: what icpmi_create wraps, and what the private handles of the map-side operators are made of
+icpmi_status create_handle(const icpmi_config* cfg, icpmi_handle* out)
 {
     if (!cfg || !out) { g_create_error = "icpmi_create: null argument"; return ICPMI_ERR_INVALID_ARG; }
     *out = nullptr;
@@ -169,6 +172,21 @@ icpmi_status icpmi_create(const icpmi_config* cfg, icpmi_handle* out)
     return ICPMI_OK;
 }
 
+extern "C" {
+
+// handles the CALLER creates count towards the allocation cache's lifetime (private handles are created through create_handle directly)
+icpmi_status icpmi_create(const icpmi_config* cfg, icpmi_handle* out)
+{
+    const icpmi_status s = create_handle(cfg, out);
+    if (s == ICPMI_OK) {
+        (*out)->counted = true;
+        DevBlockCache& bc = dev_block_cache();
+        std::lock_guard<std::mutex> lk(bc.mu);
+        ++bc.handles;
+    }
+    return s;
+}
+
 icpmi_status icpmi_set_config(icpmi_handle h, const icpmi_config* cfg)
 {
     CHECK_H(h);
@@ -189,12 +207,17 @@ void icpmi_destroy(icpmi_handle c)
     if (c->temp) { icpmi_destroy(c->temp); c->temp = nullptr; }
     if (c->temp_raw) { icpmi_destroy(c->temp_raw); c->temp_raw = nullptr; }
     hipSetDevice(c->device);
+    selfgrid_destroy(c);
     comm_destroy(c);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
     if (c->bgraph_exec) hipGraphExecDestroy(c->bgraph_exec);
     for (int g = 0; g < 2; ++g) if (c->seg_exec[g]) hipGraphExecDestroy(c->seg_exec[g]);
     for (auto& hd : c->seg_heads) if (hd.exec) hipGraphExecDestroy(hd.exec);
+    // ONE device-wide wait for all of the handle's blocks (one per block, each under the exclusive capture gate, stalled every
+    // other thread's registration on this GPU ~80 times in a row)
+    (void)dev_sync_for_free();
+#define dev_free(p) dev_free((p), true)
     dev_free(c->d_map_sorted); dev_free(c->d_normals_sorted); dev_free(c->d_cell_start);
     for (int l = 0; l < ICPMI_MAXLEV; ++l) { dev_free(c->d_lvl_pts[l]); dev_free(c->d_lvl_cs[l]); dev_free(c->d_lvl_pos0[l]); }
     dev_free(c->d_inv);
@@ -209,6 +232,7 @@ void icpmi_destroy(icpmi_handle c)
     for (int k = 0; k < ICPMI_SCRATCH_SLOTS; ++k) dev_free(c->scratch[k]); dev_free(c->d_scan_map); dev_free(c->d_T16);
     dev_free(c->d_sidx); dev_free(c->d_d2); dev_free(c->d_hard); dev_free(c->d_selhist);
     dev_free(c->d_state); dev_free(c->d_selfsq);
+#undef dev_free
     if (c->h_state) hipHostFree(c->h_state);
     if (c->h_pin) hipHostFree(c->h_pin);
     if (c->h_nocc) hipHostFree(c->h_nocc);
@@ -220,8 +244,22 @@ void icpmi_destroy(icpmi_handle c)
     if (c->side_join) hipEventDestroy(c->side_join);
     if (c->side) stream_release(c->side);
     if (c->own_stream && c->stream) stream_release(c->stream);
+    const bool counted = c->counted;
     delete c;
+    if (counted) { // the process's last top-level handle: cached blocks go back to the runtime (a co-resident allocator sees them as used memory)
+        DevBlockCache& bc = dev_block_cache();
+        std::lock_guard<std::mutex> lk(bc.mu);
+        if (--bc.handles <= 0) { bc.handles = 0; dev_cache_release_locked(bc); }
+    }
 }
+
+// every device block the library's allocation cache holds back to the runtime (common.h: DevBlockCache); handles stay valid
+icpmi_status icpmi_trim_cache(void)
+{
+    dev_cache_trim();
+    return ICPMI_OK;
+}
+
 
 const char* icpmi_last_error(icpmi_handle h) { return h ? h->last_error.c_str() : g_create_error.c_str(); }
 

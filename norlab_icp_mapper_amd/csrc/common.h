@@ -234,7 +234,8 @@ struct IcpState {
 // operator call holds a few temporaries, and a replay that builds a fresh mapper pays all of it again (BASELINE config 4: the first two of
 // 14 scans were 14 of 37 ms).  dev_free keeps the block (after the same device-wide synchronisation hipFree implies: nothing in flight
 // can still touch it), dev_malloc hands out the smallest cached block of at least the size asked for and at most twice that + 1 MiB.
-// ICPMI_ALLOC_CACHE_MB (default 4096; 0: plain hipMalloc / hipFree) bounds what is kept; the largest blocks go first.
+// ICPMI_ALLOC_CACHE_MB (default 1024; 0: plain hipMalloc / hipFree) bounds what is kept; the largest blocks go first.  Blocks are cached per
+// device; the cache is emptied when the process's last handle is destroyed and by icpmi_trim_cache().
 // ------------------------------------------------------------------------------------------------
 // A device-wide synchronisation and a stream capture in ANOTHER thread do not mix on this runtime (scripts/r5/capture_threads.hip, ROCm 7:
 // hipDeviceSynchronize fails with "operation not permitted when stream is capturing" AND invalidates the other thread's thread-local capture;
@@ -251,19 +252,35 @@ struct CaptureGate {
 };
 
 struct DevBlockCache {
+    struct Live { size_t bytes; int dev; };
     std::mutex mu;
-    std::unordered_map<void*, size_t> live;      // every block handed out -> its true size
-    std::multimap<size_t, void*> idle;           // cached blocks by size
+    std::unordered_map<void*, Live> live;                  // every block handed out -> its true size and the device it was mapped on
+    std::map<int, std::multimap<size_t, void*>> idle_of;   // cached blocks by size, PER DEVICE (r6, ADVICE r5: icpmi_config::device puts several GPUs in one process)
     size_t idle_bytes = 0, limit = 0;
+    long handles = 0;                                      // live top-level handles (icpmi_create / icpmi_destroy): the cache is trimmed when the last one goes
     bool on = true;
     DevBlockCache()
     {
         const char* e = getenv("ICPMI_ALLOC_CACHE_MB");
-        const long mb = e ? atol(e) : 4096;
+        const long mb = e ? atol(e) : 1024;                // r6: 1 GiB (r5: 4 GiB -- a co-resident allocator sees cached blocks as used memory)
         on = mb > 0; limit = on ? (size_t)mb << 20 : 0;
     }
 };
 inline DevBlockCache& dev_block_cache() { static DevBlockCache* c = new DevBlockCache; return *c; } // (never destroyed: the runtime may be gone first)
+
+// every cached block of every device back to the runtime (icpmi_trim_cache; the out-of-memory path; the last handle's destruction).
+// Caller holds bc.mu.  hipFree synchronises the device it runs on; the blocks are idle, so any device will do.
+inline void dev_cache_release_locked(DevBlockCache& bc)
+{
+    for (auto& dv : bc.idle_of) for (auto& kv : dv.second) (void)hipFree(kv.second);
+    bc.idle_of.clear(); bc.idle_bytes = 0;
+}
+inline void dev_cache_trim()
+{
+    DevBlockCache& bc = dev_block_cache();
+    std::lock_guard<std::mutex> lk(bc.mu);
+    dev_cache_release_locked(bc);
+}
 
 inline hipError_t dev_malloc(void** p, size_t bytes)
 {
@@ -271,11 +288,14 @@ inline hipError_t dev_malloc(void** p, size_t bytes)
     if (!bc.on) return hipMalloc(p, bytes);
     if (bytes == 0) bytes = 1;
     bytes = (bytes + 255) & ~(size_t)255;
+    int dev = 0;
+    (void)hipGetDevice(&dev); // (a handle is created, used and destroyed with its device current: icpmi_create / CHECK_H set it)
     {
         std::lock_guard<std::mutex> lk(bc.mu);
-        auto it = bc.idle.lower_bound(bytes);
-        if (it != bc.idle.end() && it->first <= 2 * bytes + ((size_t)1 << 20)) {
-            *p = it->second; bc.live[*p] = it->first; bc.idle_bytes -= it->first; bc.idle.erase(it);
+        auto& idle = bc.idle_of[dev];
+        auto it = idle.lower_bound(bytes);
+        if (it != idle.end() && it->first <= 2 * bytes + ((size_t)1 << 20)) {
+            *p = it->second; bc.live[*p] = {it->first, dev}; bc.idle_bytes -= it->first; idle.erase(it);
             return hipSuccess;
         }
     }
@@ -283,37 +303,54 @@ inline hipError_t dev_malloc(void** p, size_t bytes)
     if (e != hipSuccess) { // out of memory: give the cache back and try once more
         std::lock_guard<std::mutex> lk(bc.mu);
         (void)hipGetLastError();
-        for (auto& kv : bc.idle) (void)hipFree(kv.second);
-        bc.idle.clear(); bc.idle_bytes = 0;
+        dev_cache_release_locked(bc);
         e = hipMalloc(p, bytes);
         if (e != hipSuccess) return e;
     }
     std::lock_guard<std::mutex> lk(bc.mu);
-    bc.live[*p] = bytes;
+    bc.live[*p] = {bytes, dev};
     return hipSuccess;
 }
 
-inline hipError_t dev_free(void* p)
+// synced == true: the caller has just synchronised the block's device itself (icpmi_destroy: ONE device-wide wait for its ~80 blocks instead of
+// one per block, each under the exclusive capture gate -- ADVICE r5)
+inline hipError_t dev_free(void* p, bool synced = false)
 {
     if (!p) return hipSuccess;
     DevBlockCache& bc = dev_block_cache();
     if (!bc.on) return hipFree(p);
-    size_t bytes = 0;
+    DevBlockCache::Live lv{0, 0};
     {
         std::lock_guard<std::mutex> lk(bc.mu);
         auto it = bc.live.find(p);
         if (it == bc.live.end()) return hipFree(p); // not ours (allocated before the cache was switched on)
-        bytes = it->second; bc.live.erase(it);
+        lv = it->second; bc.live.erase(it);
     }
-    hipError_t e;
-    { std::unique_lock<std::shared_mutex> gate(capture_gate()); e = hipDeviceSynchronize(); } // what hipFree would have waited for; not while another thread captures
+    hipError_t e = hipSuccess;
+    if (!synced) {
+        // what hipFree would have waited for -- on the device the block lives on; not while another thread captures
+        std::unique_lock<std::shared_mutex> gate(capture_gate());
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        if (cur != lv.dev) (void)hipSetDevice(lv.dev);
+        e = hipDeviceSynchronize();
+        if (cur != lv.dev) (void)hipSetDevice(cur);
+    }
     std::lock_guard<std::mutex> lk(bc.mu);
-    bc.idle.emplace(bytes, p); bc.idle_bytes += bytes;
-    while (bc.idle_bytes > bc.limit && !bc.idle.empty()) {
-        auto last = std::prev(bc.idle.end());
-        (void)hipFree(last->second); bc.idle_bytes -= last->first; bc.idle.erase(last);
+    bc.idle_of[lv.dev].emplace(lv.bytes, p); bc.idle_bytes += lv.bytes;
+    while (bc.idle_bytes > bc.limit) { // the largest block of the fullest device goes first
+        std::multimap<size_t, void*>* big = nullptr;
+        for (auto& dv : bc.idle_of) if (!dv.second.empty() && (!big || std::prev(dv.second.end())->first > std::prev(big->end())->first)) big = &dv.second;
+        if (!big) break;
+        auto last = std::prev(big->end());
+        (void)hipFree(last->second); bc.idle_bytes -= last->first; big->erase(last);
     }
     return e;
+}
+inline hipError_t dev_sync_for_free() // one device-wide wait under the capture gate, for a run of dev_free(p, true)
+{
+    std::unique_lock<std::shared_mutex> gate(capture_gate());
+    return hipDeviceSynchronize();
 }
 
 
@@ -527,6 +564,8 @@ struct icpmi_ctx {
     int64_t merge_block = 0;
     long merge_fast_epochs = 0, merge_slow_epochs = 0; // epochs served by the one-collective path / by the count + ready + points path
     int64_t merged_last_n = 0;        // points of the last epoch's merged set, still in d_merged (icpmi_staged_merged_points)
+    struct SelfGridCtx* sg = nullptr; // sparse block grid of the self k-NN (selfgrid.hip): tables, work lists and the tuning state of the handle's previous build
+    bool counted = false;             // created through icpmi_create (not a private handle): counts towards the allocation cache's lifetime (api.hip)
 };
 
 #define HIP_TRY(ctx, expr)                                                                     \
@@ -688,6 +727,35 @@ __device__ __forceinline__ unsigned long long pack_key(float d2, unsigned id)
     return ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)id;
 }
 
+// bounded sorted list of (key = d2 bits << 32 | original index, sorted position): the k best of a k-NN search, in registers
+template <int KMAX>
+struct KList {
+    unsigned long long key[KMAX];
+    int sidx[KMAX];
+    int k, filled;
+    __device__ __forceinline__ void init(int kk)
+    {
+        k = kk; filled = 0;
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) { key[i] = ~0ull; sidx[i] = -1; }
+    }
+    __device__ __forceinline__ unsigned long long worst() const { return key[KMAX - 1]; }
+    // keeps the KMAX smallest; callers read the first k (k <= KMAX), so the list may hold more than
+    // k entries -- harmless, and it keeps all indexing static (registers, no scratch).
+    __device__ __forceinline__ void insert(unsigned long long kk, int s)
+    {
+        if (kk >= key[KMAX - 1]) return;
+#pragma unroll
+        for (int i = KMAX - 1; i >= 0; --i) {
+            const unsigned long long prev = i > 0 ? key[i - 1] : 0ull;
+            const int prevs = i > 0 ? sidx[i - 1] : -1;
+            if (i > 0 && kk < prev) { key[i] = prev; sidx[i] = prevs; }
+            else if (kk < key[i]) { key[i] = kk; sidx[i] = s; }
+        }
+        if (filled < KMAX) ++filled;
+    }
+};
+
 __device__ inline void quat_from_T(const float* T, double* q)
 {
     const double m00 = T[0], m11 = T[5], m22 = T[10];
@@ -777,6 +845,11 @@ icpmi_status nn_launch_k(icpmi_ctx* c, const float4* d_reading, int64_t n, const
                          int allow_self, int* d_sidx, float* d_d2, IcpState* d_state);
 icpmi_status nn_ids_to_original(icpmi_ctx* c, const int* d_sidx, int64_t count, int* d_ids);
 icpmi_status nn_self_knn(icpmi_ctx* c, const float4* d_cloud, const LoopCfg& lc, int* d_sidx, float* d_d2, IcpState* d_state);
+// self k-NN of a device cloud through a sparse block grid built for the call (selfgrid.hip): rows of d_sidx / d_d2 in the cloud's order, entries =
+// positions in c->d_map_sorted (w = original index bits), which the call leaves behind for launch_normals / nn_ids_to_original
+icpmi_status selfgrid_knn(icpmi_ctx* c, const float4* d_pts, int64_t m, int k, int* d_sidx, float* d_d2);
+void selfgrid_destroy(icpmi_ctx* c);
+icpmi_status create_handle(const icpmi_config* cfg, icpmi_handle* out); // icpmi_create without the cache's handle count (private handles)
 icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals3, int64_t n, const LoopCfg& lc, bool fixed, float T_out[16],
                       icpmi_stats* stats);
 icpmi_status loop_sensor_noise_overlap(icpmi_ctx* c, int64_t n, const LoopCfg& lc, bool sorted, float* overlap);

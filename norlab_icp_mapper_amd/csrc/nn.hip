@@ -127,34 +127,7 @@ __global__ void hard_reset_kernel(IcpState* st)
 // search.  Used by knn > 1 matchers (docs/MapperConfiguration.md:174-189 uses knn 6) and by the
 // surface-normal operator (knn 10 on the map itself).
 // ------------------------------------------------------------------------------------------------
-template <int KMAX>
-struct KList {
-    unsigned long long key[KMAX];
-    int sidx[KMAX];
-    int k, filled;
-    __device__ __forceinline__ void init(int kk)
-    {
-        k = kk; filled = 0;
-#pragma unroll
-        for (int i = 0; i < KMAX; ++i) { key[i] = ~0ull; sidx[i] = -1; }
-    }
-    __device__ __forceinline__ unsigned long long worst() const { return key[KMAX - 1]; }
-    // keeps the KMAX smallest; callers read the first k (k <= KMAX), so the list may hold more than
-    // k entries -- harmless, and it keeps all indexing static (registers, no scratch).
-    __device__ __forceinline__ void insert(unsigned long long kk, int s)
-    {
-        if (kk >= key[KMAX - 1]) return;
-#pragma unroll
-        for (int i = KMAX - 1; i >= 0; --i) {
-            const unsigned long long prev = i > 0 ? key[i - 1] : 0ull;
-            const int prevs = i > 0 ? sidx[i - 1] : -1;
-            if (i > 0 && kk < prev) { key[i] = prev; sidx[i] = prevs; }
-            else if (kk < key[i]) { key[i] = kk; sidx[i] = s; }
-        }
-        if (filled < KMAX) ++filled;
-    }
-};
-
+// (KList<KMAX>: common.h -- the block-grid self search of selfgrid.hip keeps the same lists)
 template <int KMAX>
 __device__ __forceinline__ void scan_run_k(const float4* __restrict__ map, unsigned s, unsigned e, float px, float py, float pz,
                                            bool allow_self, KList<KMAX>& L)

@@ -624,11 +624,17 @@ static void share_stream(icpmi_ctx* c, icpmi_ctx* t)
     (void)zero_state_if_pending(t); // (on the owner's stream; an error surfaces at the handle's next call)
 }
 
+static bool self_grid_on()
+{
+    static const int on = [] { const char* e = getenv("ICPMI_SELF_GRID"); return e ? atoi(e) : 1; }();
+    return on != 0;
+}
+
 static icpmi_status make_temp(icpmi_ctx* c, TempCtx& t)
 {
     if (!c->temp) {
         icpmi_config cfg = c->cfg;
-        icpmi_status s = icpmi_create(&cfg, &c->temp);
+        icpmi_status s = create_handle(&cfg, &c->temp);
         if (s != ICPMI_OK) { c->last_error = icpmi_last_error(nullptr); c->temp = nullptr; return s; }
     }
     t.h = c->temp;
@@ -650,7 +656,7 @@ static icpmi_status raw_index(icpmi_ctx* c, icpmi_ctx** out, float reach)
 {
     if (!c->temp_raw) {
         icpmi_config cfg = c->cfg;
-        icpmi_status s = icpmi_create(&cfg, &c->temp_raw);
+        icpmi_status s = create_handle(&cfg, &c->temp_raw);
         if (s != ICPMI_OK) { c->last_error = icpmi_last_error(nullptr); c->temp_raw = nullptr; return s; }
         c->temp_raw_version = 0;
     }
@@ -786,6 +792,16 @@ static icpmi_status temp_knn(icpmi_ctx* c, TempCtx& t, const float* cloud4, int6
     static int tiled = -1;
     if (tiled < 0) { const char* e = getenv("ICPMI_SELF_KNN_TILED"); tiled = e ? atoi(e) : 1; }
     const bool self = queries_are_cloud && allow_self && tiled; // SurfaceNormalDataPointsFilter: the cloud against itself
+    if (self && self_grid_on()) { // r6: the sparse block grid (selfgrid.hip)
+        if (m <= 0 || !cloud4) { c->last_error = "set_map: empty cloud"; return ICPMI_ERR_INVALID_ARG; }
+        const size_t cnt = (size_t)m * k + 1;
+        if (ensure_cap(tc, &tc->d_stage_in, &tc->cap_stage_in, (size_t)m + 1) != ICPMI_OK || ensure_cap(tc, &tc->d_sidx, &tc->cap_sidx, cnt) != ICPMI_OK ||
+            ensure_cap(tc, &tc->d_d2, &tc->cap_d2, cnt) != ICPMI_OK) { c->last_error = tc->last_error; return ICPMI_ERR_HIP; }
+        HIP_TRY(c, hipMemcpyAsync(tc->d_stage_in, cloud4, (size_t)m * sizeof(float4), hipMemcpyHostToDevice, tc->stream));
+        const icpmi_status gs = selfgrid_knn(tc, tc->d_stage_in, m, k, tc->d_sidx, tc->d_d2);
+        if (gs != ICPMI_OK) c->last_error = tc->last_error;
+        return gs;
+    }
     tc->single_level = self;
     int32_t acc = 0;
     icpmi_status s = icpmi_set_map(t.h, cloud4, m, nullptr, &acc);
@@ -1007,6 +1023,16 @@ static icpmi_status surface_normals_dev(icpmi_ctx* c, const float4* d_pts, int64
     if (s != ICPMI_OK) return s;
     icpmi_ctx* tc = t.h;
     if (tc->stream != c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream)); // d_pts was produced on the caller's stream
+    if (self_grid_on()) { // r6: the sparse block grid (selfgrid.hip) -- index and search in one call
+        const size_t cnt = (size_t)m * knn + 1;
+        if (ensure_cap(tc, &tc->d_sidx, &tc->cap_sidx, cnt) != ICPMI_OK || ensure_cap(tc, &tc->d_d2, &tc->cap_d2, cnt) != ICPMI_OK) { c->last_error = tc->last_error; return ICPMI_ERR_HIP; }
+        s = selfgrid_knn(tc, d_pts, m, knn, tc->d_sidx, tc->d_d2);
+        if (s != ICPMI_OK) { c->last_error = tc->last_error; return s; }
+        launch_normals(tc->stream, tc->d_map_sorted, tc->d_sidx, m, knn, d_normals3, (float*)nullptr, c->cfg.is_2d);
+        HIP_TRY(c, hipGetLastError());
+        if (tc->stream != c->stream) HIP_TRY(c, hipStreamSynchronize(tc->stream));
+        return ICPMI_OK;
+    }
     tc->single_level = true;
     int32_t acc = 0;
     s = icpmi_set_map_dev(t.h, (const float*)d_pts, m, nullptr, &acc);
