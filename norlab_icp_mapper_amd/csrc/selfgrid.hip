@@ -15,11 +15,11 @@
 //     exists where points are.
 //   * the points are sorted by (Morton index of the block, Morton index of the A-cell inside it): EVERY level of the octree over the A-cells
 //     -- cells of edge cell * 2^l -- is one contiguous run of the sorted array, found with two look-ups (l <= 2: in F, l > 2: in T).
-// Search (2 launches):
-//   * sg_tiled_kernel: one wave per occupied block stages the 6 x 6 x 6 A-cells around it into LDS (216 look-ups, then coalesced runs) and
-//     every point of the block scans its own 3 x 3 x 3 cells from there.  Decided when the k-th distance fits the margin to the block
-//     boundary (faces on the border of the grid do not count: nothing lies beyond them).  Blocks with fewer than `tau` points skip this pass.
-//   * sg_wave_kernel: the rest (config 4: ~15 %), one wave per query, level after level (edge x 2): the 3 x 3 x 3 block of level l is visited
+// Search (2 launches; selection ACROSS the lanes of a wave -- see the kernels):
+//   * sg_cell_kernel: one wave per 16 consecutive sorted points.  Per A-cell: its 27 neighbours looked up (one lane each), their points into
+//     registers; per query: distances, one 64-key bitonic sort, further batches merged only when they can matter.  Decided when the k-th
+//     distance fits the margin to the border of the 3 x 3 x 3 cells (faces on the border of the grid do not count: nothing lies beyond them).
+//   * sg_level_kernel: the rest (config 4: ~12 %), one wave per query, level after level (edge x 2): the 3 x 3 x 3 block of level l is visited
 //     as its 216 cells of level l - 1, those farther than the k-th distance found one level down are not looked up at all, the candidates of
 //     the others are dealt to the lanes 64 at a time.  The top level covers the grid: every query ends here, there is no brute pass.
 // Exactness: both kernels return the k smallest keys (d^2 bits << 32 | original index) over candidate sets that contain every point within the
@@ -39,6 +39,7 @@ struct SelfGridCtx {
     unsigned* d_f = nullptr; size_t cap_f = 0;                                // SG_F words per block
     float4* d_coarse = nullptr; size_t cap_coarse = 0;                        // the points sorted by block (before the sort inside the blocks)
     uint2* d_queue = nullptr; size_t cap_queue = 0;                           // {sorted position, bits of the bound on the k-th d^2} of the queries the tiled pass left
+    unsigned* d_inv = nullptr; size_t cap_inv = 0;                            // original index -> sorted position
     float* d_part = nullptr; size_t cap_part = 0;                             // bounding-box partials
     struct SgState* d_state = nullptr;
     // tuning state: the edge of the previous build and what its points saw (size-biased A-cell occupancy, delivered through the mapped page)
@@ -48,18 +49,16 @@ struct SelfGridCtx {
 
 struct SgState {
     unsigned nblk;   // occupied blocks (claimed by the key kernel)
-    unsigned qcount; // queries queued for the wave kernel
     unsigned bad;    // non-finite coordinates seen by the bounding-box pass
-    unsigned pad;
-    unsigned long long sq; // sum over the A-cells of (points in the cell)^2
-    unsigned long long levels; // diagnostics: sum of the levels at which the wave kernel's queries ended
-    unsigned long long tick[16]; // -DSG_TIMING: phase clocks of the search kernels (sampled workgroups)
+    unsigned long long sq;     // sum over the A-cells of (points in the cell)^2 (summed from sqpart by the cell kernel)
+    unsigned long long levels; // diagnostics: sum of the levels at which the level kernel's queries ended
+    unsigned qcount[64];       // queries queued for the level kernel, per sub-queue
+    unsigned long long sqpart[64]; // partial sums of sq, by workgroup % 64 (thousands of atomics on ONE address serialise at 10 - 25 ns each)
 };
 
 namespace {
 
 constexpr int SG_F = 65;   // words of a block's row of F
-constexpr int SG_CH = 384; // candidates staged per chunk (LDS tile)
 
 struct SgGrid {
     float ox, oy, oz, cell, inv_cell, maxabs;
@@ -147,12 +146,20 @@ __device__ __forceinline__ float sg_margin2(const SgGrid& g, int l, const int a[
     return margin * margin;
 }
 
+// a square root that never under-estimates (one v_sqrt_f32, 1 ulp, nudged up)
+__device__ __forceinline__ float sqrt_up_sg(float x) { return __builtin_amdgcn_sqrtf(x) * 1.0000005f; }
+
+// inclusive scan over the 64 lanes: four DPP row shifts inside the rows of 16, two row broadcasts across them
 __device__ __forceinline__ unsigned sg_wave_incl_scan(unsigned v)
 {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const unsigned t = (unsigned)__shfl_up((int)v, o, 64); if (lane >= o) v += t; }
-    return v;
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true); // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true); // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true); // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true); // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, true); // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, true); // row_bcast:31 -> rows 2, 3
+    return (unsigned)x;
 }
 
 // ---- build ------------------------------------------------------------------------------------------------------------------------------
@@ -182,7 +189,10 @@ __global__ __launch_bounds__(SG_RB) void sg_bbox_kernel(const float4* __restrict
 
 __global__ void sg_reset_kernel(SgState* st)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) { st->nblk = 0; st->qcount = 0; st->bad = 0; st->pad = 0; st->sq = 0ull; st->levels = 0ull; for (int i = 0; i < 16; ++i) st->tick[i] = 0ull; }
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) { st->nblk = 0; st->bad = 0; st->sq = 0ull; st->levels = 0ull; }
+        if (threadIdx.x < 64) { st->qcount[threadIdx.x] = 0; st->sqpart[threadIdx.x] = 0ull; }
+    }
 }
 
 // per point: key = Morton index of its block << 6 | Morton index of its A-cell in the block; points per block counted (one atomic per run of
@@ -241,7 +251,7 @@ __global__ __launch_bounds__(256) void sg_scatter_kernel(const float4* __restric
 // the atomics give -- every comparison downstream is on (d^2, original index)), its row of F, its share of the sum of squared cell counts
 __global__ __launch_bounds__(64) void sg_block_sort_kernel(const float4* __restrict__ in, float4* __restrict__ out, SgGrid g,
                                                            const unsigned* __restrict__ tstart, const uint4* __restrict__ blist,
-                                                           unsigned* __restrict__ f, SgState* __restrict__ st)
+                                                           unsigned* __restrict__ f, unsigned* __restrict__ inv, SgState* __restrict__ st)
 {
     __shared__ unsigned cnt[64], cur[64];
     const int lane = threadIdx.x;
@@ -279,304 +289,381 @@ __global__ __launch_bounds__(64) void sg_block_sort_kernel(const float4* __restr
             }
             const unsigned r = atomicAdd(&cur[sub], 1u);
             out[s0 + r] = p;
+            inv[__float_as_uint(p.w)] = s0 + r;
         }
         __syncthreads();
     }
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
-    if (lane == 0 && sq) atomicAdd(&st->sq, sq);
+    if (lane == 0 && sq) atomicAdd(&st->sqpart[blockIdx.x & 63], sq);
 }
 
 // ---- search -----------------------------------------------------------------------------------------------------------------------------
-// A query is its sorted position; what leaves the tiled pass undecided is queued with the k-th distance it did find (a bound on the answer)
-__device__ __forceinline__ void sg_queue_push(SgState* st, uint2* __restrict__ queue, unsigned pos, unsigned bound_bits, bool push)
+// Both kernels select ACROSS the lanes of a wave: every lane holds the key of one candidate -- d^2 bits << 32 | payload, payload ordered by the
+// original index --, a bitonic network sorts the 64 keys (21 compare-exchange steps, each two lane permutes and a 64-bit compare), and further
+// batches of 64 are sorted and merged only when one of their keys beats the k-th so far.  No per-lane lists: r2 - r5 (and this file's first
+// version) kept a sorted list of k keys per QUERY lane, ~120 instructions per insertion paid by the whole wave whenever one lane inserted, and
+// ran at 2.5 - 5 ns per query on a lidar map; here a query costs one sort (~130 instructions) whatever its neighbours do.
+constexpr int SGQ = 16; // consecutive sorted queries per wave of the cell kernel (they share cells: the candidates stay in registers)
+constexpr int SG_R = 4; // candidate registers per lane: neighbourhoods of up to 256 points are kept across the queries of a cell
+
+__device__ const signed char SG_ORD[27][3] = { // the 27 cells of a neighbourhood, nearest first: centre, faces, edges, corners
+    {0, 0, 0},
+    {-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1},
+    {-1, -1, 0}, {1, -1, 0}, {-1, 1, 0}, {1, 1, 0}, {-1, 0, -1}, {1, 0, -1}, {-1, 0, 1}, {1, 0, 1}, {0, -1, -1}, {0, 1, -1}, {0, -1, 1}, {0, 1, 1},
+    {-1, -1, -1}, {1, -1, -1}, {-1, 1, -1}, {1, 1, -1}, {-1, -1, 1}, {1, -1, 1}, {-1, 1, 1}, {1, 1, 1}};
+
+// value of lane (lane ^ J), without the LDS crossbar: DPP quad permutes / row shifts / row rotate inside a row of 16 lanes, gfx950's
+// v_permlane16_swap / v_permlane32_swap across rows (a sort written with __shfl_xor is 42 ds_bpermute_b32 round trips, one behind the other)
+template <int J>
+__device__ __forceinline__ unsigned sg_lane_xor(unsigned v)
 {
-    const unsigned long long who = __ballot(push);
-    if (!who) return;
-    const int lane = threadIdx.x & 63;
-    unsigned base = 0;
-    if (lane == __ffsll((long long)who) - 1) base = atomicAdd(&st->qcount, (unsigned)__popcll(who));
-    base = (unsigned)__shfl((int)base, __ffsll((long long)who) - 1, 64);
-    if (push) queue[base + (unsigned)__popcll(who & ((1ull << lane) - 1ull))] = make_uint2(pos, bound_bits);
+    const int x = (int)v;
+    if constexpr (J == 1) return (unsigned)__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false);      // quad_perm [1, 0, 3, 2]
+    else if constexpr (J == 2) return (unsigned)__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false); // quad_perm [2, 3, 0, 1]
+    else if constexpr (J == 4) {
+        const int t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);                            // row_shl:4 into banks 0, 2
+        return (unsigned)__builtin_amdgcn_update_dpp(t, x, 0x114, 0xF, 0xA, false);                         // row_shr:4 into banks 1, 3
+    } else if constexpr (J == 8) return (unsigned)__builtin_amdgcn_update_dpp(x, x, 0x128, 0xF, 0xF, false); // row_ror:8
+    else if constexpr (J == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); // r[0]: odd rows <- even rows; r[1]: even rows <- odd rows
+        return (threadIdx.x & 16) ? r[0] : r[1];
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+        return (threadIdx.x & 32) ? r[0] : r[1];
+    }
+}
+template <int J>
+__device__ __forceinline__ unsigned long long sg_lane_xor64(unsigned long long v)
+{
+    return ((unsigned long long)sg_lane_xor<J>((unsigned)(v >> 32)) << 32) | (unsigned long long)sg_lane_xor<J>((unsigned)v);
+}
+__device__ __forceinline__ unsigned long long sg_readlane64(unsigned long long v, int l /* uniform */)
+{
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l) << 32) |
+           (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
 }
 
-template <int KMAX, int SELF_Q>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KMAX <= 10 ? 4 : 1))) void sg_tiled_kernel(
-    SgGrid g, const float4* __restrict__ map, const unsigned* __restrict__ tstart, const unsigned* __restrict__ tbid, const unsigned* __restrict__ f,
-    const uint4* __restrict__ blist, SgState* __restrict__ st, int k, unsigned tau, int* __restrict__ out_sidx, float* __restrict__ out_d2,
-    uint2* __restrict__ queue, unsigned long long* __restrict__ sq_mapped)
+// bitonic sort across the 64 lanes (keys are unique, or ~0 = nothing): ascending, or DESC: descending.  n (uniform): only lanes [0, n) hold
+// real keys -- the phases that merge halves of nothing are skipped (n <= 16: 10 steps, n <= 32: 15, else 21)
+#define SG_CE(K2, J) { const unsigned long long other = sg_lane_xor64<J>(key); \
+                       const bool take_min = ((((K2) >= 64) || (lane & (K2)) == 0) == ((lane & (J)) == 0)) != DESC; \
+                       key = (take_min == (other < key)) ? other : key; }
+template <bool DESC>
+__device__ __forceinline__ void sg_sort64(unsigned long long& key, unsigned n = 64u)
 {
-    __shared__ int nb_bid[27];
-    __shared__ unsigned cstart[216], coff[217];
-    __shared__ float4 tile[SG_CH];
-    __shared__ unsigned short qslot[SELF_Q][64];
+    const int lane = threadIdx.x & 63;
+    SG_CE(2, 1)
+    SG_CE(4, 2) SG_CE(4, 1)
+    SG_CE(8, 4) SG_CE(8, 2) SG_CE(8, 1)
+    SG_CE(16, 8) SG_CE(16, 4) SG_CE(16, 2) SG_CE(16, 1)
+    if (DESC || n > 16u) { SG_CE(32, 16) SG_CE(32, 8) SG_CE(32, 4) SG_CE(32, 2) SG_CE(32, 1) }
+    if (DESC || n > 32u) { SG_CE(64, 32) SG_CE(64, 16) SG_CE(64, 8) SG_CE(64, 4) SG_CE(64, 2) SG_CE(64, 1) }
+}
+// best: ascending over the lanes, b: DESCENDING -> best = the 64 smallest of both, ascending
+__device__ __forceinline__ void sg_merge64(unsigned long long& best, unsigned long long b)
+{
+    const int lane = threadIdx.x & 63;
+    constexpr bool DESC = false;
+    unsigned long long key = b < best ? b : best; // bitonic: the low half of the merge
+    SG_CE(64, 32) SG_CE(64, 16) SG_CE(64, 8) SG_CE(64, 4) SG_CE(64, 2) SG_CE(64, 1)
+    best = key;
+}
+#undef SG_CE
+// one key (uniform) into `best` (ascending over the lanes): the lanes holding larger keys take their left neighbour's, the first of them x
+__device__ __forceinline__ void sg_insert64(unsigned long long& best, unsigned long long x)
+{
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(best >> 32), 0x138, 0xF, 0xF, true); // wave_shr:1 (lane 0 reads 0)
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)best, 0x138, 0xF, 0xF, true);
+    const unsigned long long left = ((unsigned long long)hi << 32) | lo;
+    best = best > x ? (left > x ? left : x) : best;
+}
+// a further batch of keys (one per lane, ~0 = nothing) into `best`: nothing when none beats the k-th so far, the few that do one by one,
+// a sort and a merge when they are many
+__device__ __forceinline__ void sg_absorb(unsigned long long& best, unsigned long long key, int k)
+{
+    unsigned long long kth = sg_readlane64(best, k - 1);
+    unsigned long long mask = __ballot(key < kth);
+    if (!mask) return;
+    if (__popcll(mask) > 12) { sg_sort64<true>(key); sg_merge64(best, key); return; }
+    while (mask) {
+        const int l = __ffsll((long long)mask) - 1;
+        mask &= mask - 1ull;
+        const unsigned long long x = sg_readlane64(key, l);
+        if (x < kth) { sg_insert64(best, x); kth = sg_readlane64(best, k - 1); }
+    }
+}
+
+constexpr int SG_NQ = 64; // sub-queues between the two search kernels (a wave appends to queue blockIdx % SG_NQ: ~100 atomics per counter
+                          // instead of thousands on one address -- same-address device atomics serialise at 10 - 25 ns each)
+
+// One wave per SGQ consecutive points of the sorted array (= a few A-cells).  Per cell: 27 look-ups (one lane each, nearest cells first), the
+// neighbourhood's points into registers (lane j holds candidates j, j + 64, ...); per query: distances, one sort of the first 64, the rest
+// absorbed.  A query is decided when its k-th distance fits the margin to the border of its 3 x 3 x 3 cells; the others are queued for the
+// level kernel with the k-th distance they did find.  packed_ok (cloud below 2^24 points): the payload is original index << 8 | candidate
+// slot, and the slot finds the sorted position in LDS; otherwise (and for neighbourhoods beyond 256 points) the payload is the original
+// index and `inv` maps it back.
+__global__ __launch_bounds__(64) void sg_cell_kernel(SgGrid g, const float4* __restrict__ map, const unsigned* __restrict__ tstart,
+                                                     const unsigned* __restrict__ tbid, const unsigned* __restrict__ f,
+                                                     const unsigned* __restrict__ inv, SgState* __restrict__ st, int k, unsigned m, int packed_ok,
+                                                     int* __restrict__ out_sidx, float* __restrict__ out_d2, uint2* __restrict__ queue, unsigned qcap,
+                                                     unsigned long long* __restrict__ sq_mapped)
+{
+    __shared__ unsigned pre[28], cst[27], cpos[64 * SG_R];
+    __shared__ uint2 undq[SGQ];
     const int lane = threadIdx.x;
-    const unsigned nblk = st->nblk;
     // what the points of this build see (the block sort is done): to the host-mapped page, where the NEXT build of this handle reads it
-    if (blockIdx.x == 0 && lane == 0 && sq_mapped) *sq_mapped = st->sq;
+    if (blockIdx.x == 0 && sq_mapped) {
+        unsigned long long sq = st->sqpart[lane];
+        for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+        if (lane == 0) { *sq_mapped = sq; st->sq = sq; }
+    }
     const unsigned INF_BITS = 0x7f800000u;
-#ifdef SG_TIMING
-    long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = clock64();
-#define SG_TICK(i) do { const long long t_now = clock64(); tk[i] += t_now - t_prev; t_prev = t_now; } while (0)
-#else
-#define SG_TICK(i) do { } while (0)
-#endif
-    for (unsigned b = blockIdx.x; b < nblk; b += gridDim.x) {
-        __syncthreads(); // (LDS of the previous block fully consumed)
-        SG_TICK(7);
-        const uint4 bi = blist[b];
-        const int bx = (int)bi.y, by = (int)bi.z, bz = (int)bi.w;
-        const unsigned qs = tstart[bi.x], qe = tstart[bi.x + 1];
-        if (qe - qs < tau) { // a sparse block: its points are not decided by cells this small -- straight to the levels
-            for (unsigned q0 = qs; q0 < qe; q0 += 64) sg_queue_push(st, queue, q0 + lane, INF_BITS, q0 + lane < qe);
-            continue;
-        }
-        if (lane < 27) {
-            const int nx = bx + lane % 3 - 1, ny = by + (lane / 3) % 3 - 1, nz = bz + lane / 9 - 1;
-            int bid = -1;
-            if (nx >= 0 && ny >= 0 && nz >= 0 && nx < (1 << g.nbits[0]) && ny < (1 << g.nbits[1]) && nz < (1 << g.nbits[2])) {
-                const unsigned hb = sg_hb(g, nx, ny, nz);
-                const unsigned t0 = tstart[hb], t1 = tstart[hb + 1];
-                const unsigned v = tbid[hb];
-                if (t1 > t0) bid = (int)v;
-            }
-            nb_bid[lane] = bid;
-        }
-        __syncthreads();
-        // the 6 x 6 x 6 A-cells around the block, x fastest: start and count of each, then the flat offsets
-        unsigned total = 0;
+    const unsigned q0 = blockIdx.x * SGQ, q1 = min(q0 + (unsigned)SGQ, m);
+    // the wave's queries, one trip; what a query needs besides its coordinates is computed by its lane and read with v_readlane below
+    const float4 mine = map[min(q0 + (unsigned)lane, m - 1)];
+    const float mfx = (mine.x - g.ox) * g.inv_cell, mfy = (mine.y - g.oy) * g.inv_cell, mfz = (mine.z - g.oz) * g.inv_cell;
+    const int ma3[3] = {sg_cell_of(mine.x, g.ox, g.inv_cell, g.na[0]), sg_cell_of(mine.y, g.oy, g.inv_cell, g.na[1]), sg_cell_of(mine.z, g.oz, g.inv_cell, g.na[2])};
+    const float mfa[3] = {fminf(fmaxf(mfx - (float)ma3[0], 0.f), 1.f), fminf(fmaxf(mfy - (float)ma3[1], 0.f), 1.f), fminf(fmaxf(mfz - (float)ma3[2], 0.f), 1.f)};
+    const float mm2 = sg_margin2(g, 0, ma3, mfa);
+    int pa0 = -1, pa1 = -1, pa2 = -1;
+    unsigned N = 0, nund = 0;
+    bool big = false;
+    float4 cand[SG_R];
+    unsigned cpay[SG_R];
+    bool cval[SG_R];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int idx = lane + 64 * j;
-            unsigned cn = 0, cs0 = 0;
-            if (idx < 216) {
-                const int lx = idx % 6, ly = (idx / 6) % 6, lz = idx / 36;
-                const int bidn = nb_bid[((lx + 3) >> 2) + 3 * ((ly + 3) >> 2) + 9 * ((lz + 3) >> 2)];
-                if (bidn >= 0) {
-                    const unsigned sub = sg_sub((4 * bx - 1 + lx) & 3, (4 * by - 1 + ly) & 3, (4 * bz - 1 + lz) & 3);
-                    const unsigned* row = f + (size_t)bidn * SG_F;
-                    cs0 = row[sub]; cn = row[sub + 1] - cs0;
+    for (int r = 0; r < SG_R; ++r) { cand[r] = make_float4(0.f, 0.f, 0.f, 0.f); cpay[r] = 0; cval[r] = false; }
+    for (unsigned qi = q0; qi < q1; ++qi) {
+        const int src = (int)(qi - q0);
+        const float mex = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.x), src)), mey = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.y), src)),
+                    mez = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.z), src));
+        const unsigned orig_q = (unsigned)__builtin_amdgcn_readlane(__float_as_int(mine.w), src);
+        const int a0 = __builtin_amdgcn_readlane(ma3[0], src), a1 = __builtin_amdgcn_readlane(ma3[1], src), a2 = __builtin_amdgcn_readlane(ma3[2], src);
+        const float m2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mm2), src));
+        if (a0 != pa0 || a1 != pa1 || a2 != pa2) { // (wave-uniform) a new cell: its neighbourhood
+            pa0 = a0; pa1 = a1; pa2 = a2;
+            __syncthreads();
+            unsigned s = 0, e = 0;
+            if (lane < 27) sg_cell_range(g, tstart, tbid, f, 0, a0 + SG_ORD[lane][0], a1 + SG_ORD[lane][1], a2 + SG_ORD[lane][2], s, e);
+            const unsigned incl = sg_wave_incl_scan(e - s);
+            if (lane < 27) { pre[lane + 1] = incl; cst[lane] = s; }
+            if (lane == 0) pre[0] = 0;
+            N = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+            __syncthreads();
+            big = !packed_ok || N > (unsigned)(64 * SG_R);
+#pragma unroll
+            for (int r = 0; r < SG_R; ++r) {
+                const unsigned fl = (unsigned)(lane + 64 * r);
+                unsigned pos = ~0u;
+                if (fl < N) {
+                    int lo = 0, hi = 27; // the cell of flat candidate fl: the last offset <= fl
+#pragma unroll
+                    for (int it = 0; it < 5; ++it) { const int mid = (lo + hi) >> 1; if (pre[mid] <= fl) lo = mid; else hi = mid; }
+                    pos = cst[lo] + (fl - pre[lo]);
                 }
+                cval[r] = pos != ~0u;
+                cand[r] = map[cval[r] ? pos : qi];
+                cpos[fl] = pos;
+                const unsigned orig = __float_as_uint(cand[r].w);
+                cpay[r] = big ? orig : ((orig << 8) | fl);
             }
-            const unsigned incl = sg_wave_incl_scan(cn);
-            if (idx < 216) { cstart[idx] = cs0; coff[idx + 1] = total + incl; }
-            total += (unsigned)__shfl((int)incl, 63, 64);
+            __syncthreads();
         }
-        if (lane == 0) coff[0] = 0;
-        __syncthreads();
-        SG_TICK(0);
-        const unsigned ncand = total;
-        if (ncand < (unsigned)k) { // fewer than k points in the whole neighbourhood
-            for (unsigned q0 = qs; q0 < qe; q0 += 64) sg_queue_push(st, queue, q0 + lane, INF_BITS, q0 + lane < qe);
-            continue;
-        }
-        auto stage = [&](unsigned c0, unsigned cn) {
-            for (unsigned i = lane; i < cn; i += 64) {
-                const unsigned fl = c0 + i;
-                int lo = 0, hi = 216; // the cell of flat candidate fl: the last offset <= fl
+        unsigned long long best = ~0ull;
+        if (N >= (unsigned)k || m2 == INFINITY) { // (fewer than k points around it: the levels decide)
 #pragma unroll
-                for (int it = 0; it < 8; ++it) { const int mid = (lo + hi) >> 1; if (coff[mid] <= fl) lo = mid; else hi = mid; }
-                tile[i] = map[cstart[lo] + (fl - coff[lo])];
+            for (int r = 0; r < SG_R; ++r) {
+                if ((unsigned)(64 * r) >= N) break; // (uniform)
+                const float d2 = sqdist3(mex, mey, mez, cand[r].x, cand[r].y, cand[r].z);
+                const unsigned long long key = cval[r] ? pack_key(d2, cpay[r]) : ~0ull;
+                if (r == 0) { best = key; sg_sort64<false>(best, N); }
+                else sg_absorb(best, key, k);
             }
-        };
-        const bool single = ncand <= (unsigned)SG_CH;
-        if (single) { stage(0u, ncand); __syncthreads(); }
-        SG_TICK(1);
-        for (unsigned q0 = qs; q0 < qe; q0 += 64) {
-            const unsigned qi = q0 + lane;
-            const bool active = qi < qe;
-            const float4 me = map[active ? qi : qs];
-            const float fx = (me.x - g.ox) * g.inv_cell, fy = (me.y - g.oy) * g.inv_cell, fz = (me.z - g.oz) * g.inv_cell;
-            const int a3[3] = {sg_cell_of(me.x, g.ox, g.inv_cell, g.na[0]), sg_cell_of(me.y, g.oy, g.inv_cell, g.na[1]), sg_cell_of(me.z, g.oz, g.inv_cell, g.na[2])};
-            const float fa[3] = {fminf(fmaxf(fx - (float)a3[0], 0.f), 1.f), fminf(fmaxf(fy - (float)a3[1], 0.f), 1.f), fminf(fmaxf(fz - (float)a3[2], 0.f), 1.f)};
-            const int lx = a3[0] - (4 * bx - 1), ly = a3[1] - (4 * by - 1), lz = a3[2] - (4 * bz - 1); // 1 .. 4
-            KList<KMAX> L; L.init(k);
-            for (unsigned c0 = 0; c0 < ncand; c0 += SG_CH) {
-                const unsigned cn = min((unsigned)SG_CH, ncand - c0);
-                if (!single) { __syncthreads(); stage(c0, cn); __syncthreads(); SG_TICK(1); }
-                if (active) {
-                    // a candidate that beats the lane's k-th best is only QUEUED (its tile slot); the sorted insertion -- ~70 instructions the
-                    // whole wave pays whenever one lane inserts -- runs for all lanes together when a queue is full and at the end of the chunk
-                    int qn = 0;
-                    auto drain = [&]() {
-                        for (int t = 0; t < SELF_Q; ++t) {
-                            if (__ballot(t < qn) == 0ull) break;
-#ifdef SG_TIMING
-                            ++tk[4];
-#endif
-                            if (t < qn) {
-                                const unsigned ti = qslot[t][lane];
-                                const float4 q = tile[ti];
-                                const float d2 = sqdist3(me.x, me.y, me.z, q.x, q.y, q.z);
-                                L.insert(pack_key(d2, __float_as_uint(q.w)), (int)(c0 + ti)); // flat index; a map position below
-                            }
-                        }
-                        qn = 0;
-                    };
-#pragma unroll 1
-                    for (int r = 0; r < 9; ++r) {
-                        const int rb = ((lz + r / 3 - 1) * 6 + (ly + r % 3 - 1)) * 6 + (lx - 1);
-                        const unsigned lo = max(coff[rb], c0), hi = min(coff[rb + 3], c0 + cn);
-                        for (unsigned i = lo; i < hi; ++i) {
-#ifdef SG_TIMING
-                            ++tk[5];
-#endif
-                            const float4 q = tile[i - c0];
-                            const float d2 = sqdist3(me.x, me.y, me.z, q.x, q.y, q.z);
-                            if (pack_key(d2, __float_as_uint(q.w)) < L.worst()) { qslot[qn][lane] = (unsigned short)(i - c0); ++qn; }
-                            if (__ballot(qn == SELF_Q) != 0ull) drain();
-                        }
-                    }
-                    drain();
+            for (unsigned c0 = 64u * SG_R; c0 < N; c0 += 64u) { // a neighbourhood beyond the registers (big mode): fetched per query
+                const unsigned fl = c0 + (unsigned)lane;
+                unsigned long long key = ~0ull;
+                if (fl < N) {
+                    int lo = 0, hi = 27;
+#pragma unroll
+                    for (int it = 0; it < 5; ++it) { const int mid = (lo + hi) >> 1; if (pre[mid] <= fl) lo = mid; else hi = mid; }
+                    const float4 q = map[cst[lo] + (fl - pre[lo])];
+                    key = pack_key(sqdist3(mex, mey, mez, q.x, q.y, q.z), __float_as_uint(q.w));
                 }
-                SG_TICK(2);
+                sg_absorb(best, key, k);
             }
-            // exactness: every point within the margin of the query lies in its 3 x 3 x 3 cells
-            const float m2 = sg_margin2(g, 0, a3, fa);
-            unsigned long long kth = ~0ull;
-#pragma unroll
-            for (int i = 0; i < KMAX; ++i) if (i == k - 1) kth = L.key[i];
-            const float kd2 = __uint_as_float((unsigned)(kth >> 32));
-            const bool decided = active && (m2 == INFINITY || (kth != ~0ull && kd2 <= m2));
-            if (decided) {
-                const unsigned orig = __float_as_uint(me.w);
-#pragma unroll
-                for (int j = 0; j < KMAX; ++j)
-                    if (j < k) {
-                        int pos = -1;
-                        if (L.sidx[j] >= 0) {
-                            const unsigned fl = (unsigned)L.sidx[j];
-                            int lo = 0, hi = 216;
-#pragma unroll
-                            for (int it = 0; it < 8; ++it) { const int mid = (lo + hi) >> 1; if (coff[mid] <= fl) lo = mid; else hi = mid; }
-                            pos = (int)(cstart[lo] + (fl - coff[lo]));
-                        }
-                        out_sidx[(size_t)k * orig + j] = pos;
-                        out_d2[(size_t)k * orig + j] = pos < 0 ? INFINITY : __uint_as_float((unsigned)(L.key[j] >> 32));
-                    }
+        }
+        const unsigned long long kth = sg_readlane64(best, k - 1);
+        const float kd2 = __uint_as_float((unsigned)(kth >> 32));
+        const bool decided = m2 == INFINITY || (kth != ~0ull && kd2 <= m2);
+        if (decided) {
+            if (lane < k) {
+                const bool valid = best != ~0ull;
+                int pos = -1;
+                if (valid) pos = big ? (int)inv[(unsigned)best] : (int)cpos[(unsigned)best & 0xffu];
+                out_sidx[(size_t)k * orig_q + lane] = pos;
+                out_d2[(size_t)k * orig_q + lane] = valid ? __uint_as_float((unsigned)(best >> 32)) : INFINITY;
             }
-            sg_queue_push(st, queue, qi, kth != ~0ull ? (unsigned)(kth >> 32) : INF_BITS, active && !decided);
-            SG_TICK(3);
+        } else {
+            if (lane == 0) undq[nund] = make_uint2(qi, kth != ~0ull ? (unsigned)(kth >> 32) : INF_BITS);
+            ++nund;
         }
     }
-#ifdef SG_TIMING
-    if (lane == 0 && (blockIdx.x % 16) == 0) { for (int i = 0; i < 8; ++i) atomicAdd(&st->tick[i], (unsigned long long)tk[i]); }
-#endif
-#undef SG_TICK
+    if (nund) { // (uniform) one atomic per wave, on one of SG_NQ counters
+        __syncthreads();
+        const unsigned qn = blockIdx.x % SG_NQ;
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(&st->qcount[qn], nund);
+        base = (unsigned)__builtin_amdgcn_readlane((int)base, 0);
+        if ((unsigned)lane < nund) queue[(size_t)qn * qcap + base + lane] = undq[lane];
+    }
 }
 
-// One wave per queued query, level after level.  At level l the 3 x 3 x 3 block of cells of edge cell * 2^l around the query is visited as
-// its 6 x 6 x 6 cells of level l - 1: the lanes take four of them each, drop those farther than the bound (the k-th distance one level down,
-// or the tiled pass's), look the others up, and the candidates of all runs are dealt to the lanes 64 at a time (a flat index over the runs'
-// prefix sums, in LDS).  Every lane keeps the KMAX best of its share; k rounds of "extract the wave minimum" merge them.  The list starts
-// over at every level (no point is seen twice inside one) and only admits d^2 <= bound.
-template <int KMAX>
-__global__ __launch_bounds__(64) void sg_wave_kernel(SgGrid g, const float4* __restrict__ map, const unsigned* __restrict__ tstart,
-                                                     const unsigned* __restrict__ tbid, const unsigned* __restrict__ f, SgState* __restrict__ st,
-                                                     int k, int* __restrict__ out_sidx, float* __restrict__ out_d2, const uint2* __restrict__ queue)
+// One wave per queued query.  Phase A (only while fewer than k points have been seen -- a query the cell kernel found k candidates for skips
+// it): level after level (edge x 2), the 27 cells around the query, each one contiguous run of the sorted array, until k points are in hand
+// or the block is the whole grid.  Their k-th distance b bounds the answer, so phase B is ONE ball query: the cells of the level whose edge is
+// at least b / 2 that the box [p - b, p + b] touches (at most 6 per axis, 216 in all: four per lane), those whose box is farther than b
+// dropped, the points of the others dealt to the lanes 64 at a time (a flat index over the runs' prefix sums, in LDS), four batches
+// requested before any is looked at; keys beyond b are dropped at once, the first batch that holds anything is sorted, the rest absorbed.
+// Every point within b of the query lies in those cells (a point's cell index is monotone in its coordinate), k of them exist: exact, and
+// done -- r6's first version climbed the levels to the end and a query in the sparse periphery of a lidar map streamed the thousands of
+// points of a 50 m block past one wave.
+__device__ __forceinline__ void sg_flat_locate(const unsigned* __restrict__ rp, const unsigned* __restrict__ rs, int n_runs_pow2_steps, int n_runs,
+                                               unsigned fl, unsigned& pos)
+{
+    int lo = 0, hi = n_runs; // the run of flat candidate fl: the last offset <= fl
+    for (int it = 0; it < n_runs_pow2_steps; ++it) { const int mid = (lo + hi) >> 1; if (rp[mid] <= fl) lo = mid; else hi = mid; }
+    pos = rs[lo] + (fl - rp[lo]);
+}
+
+__global__ __launch_bounds__(64) void sg_level_kernel(SgGrid g, const float4* __restrict__ map, const unsigned* __restrict__ tstart,
+                                                      const unsigned* __restrict__ tbid, const unsigned* __restrict__ f,
+                                                      const unsigned* __restrict__ inv, SgState* __restrict__ st, int k,
+                                                      int* __restrict__ out_sidx, float* __restrict__ out_d2, const uint2* __restrict__ queue, unsigned qcap,
+                                                      int diag)
 {
     __shared__ unsigned rs[256], rp[257];
     const int lane = threadIdx.x;
-    const unsigned count = st->qcount;
+    const unsigned qn = blockIdx.x % SG_NQ, stride = gridDim.x / SG_NQ; // (the grid is a multiple of SG_NQ)
+    const unsigned count = st->qcount[qn];
     unsigned long long lev_sum = 0;
-    for (unsigned w = blockIdx.x; w < count; w += gridDim.x) {
-        const uint2 qe = queue[w];
+    for (unsigned w = blockIdx.x / SG_NQ; w < count; w += stride) {
+        const uint2 qe = queue[(size_t)qn * qcap + w];
         const float4 me = map[qe.x];
         float bound = __uint_as_float(qe.y);
         const float fx = (me.x - g.ox) * g.inv_cell, fy = (me.y - g.oy) * g.inv_cell, fz = (me.z - g.oz) * g.inv_cell;
         const int a3[3] = {sg_cell_of(me.x, g.ox, g.inv_cell, g.na[0]), sg_cell_of(me.y, g.oy, g.inv_cell, g.na[1]), sg_cell_of(me.z, g.oz, g.inv_cell, g.na[2])};
         const float fa[3] = {fminf(fmaxf(fx - (float)a3[0], 0.f), 1.f), fminf(fmaxf(fy - (float)a3[1], 0.f), 1.f), fminf(fmaxf(fz - (float)a3[2], 0.f), 1.f)};
-        KList<KMAX> Gl; Gl.init(k);
-        int l = 1;
-        for (;; ++l) {
+        unsigned long long best = ~0ull;
+        bool done = false;
+        int l = 0;
+        // ---- phase A: any k points ----
+        while (bound == INFINITY) {
+            ++l;
             const float m2 = sg_margin2(g, l, a3, fa);
-            const float cs = g.cell * (float)(1u << (l - 1));      // edge of the cells looked up at this level
-            const float slack = cs * 2e-3f + g.maxabs * 2e-6f;
-            const int s0x = ((a3[0] >> l) - 1) * 2, s0y = ((a3[1] >> l) - 1) * 2, s0z = ((a3[2] >> l) - 1) * 2;
             __syncthreads(); // (rs / rp of the previous level consumed)
+            unsigned s = 0, e = 0;
+            if (lane < 27) sg_cell_range(g, tstart, tbid, f, l, (a3[0] >> l) + SG_ORD[lane][0], (a3[1] >> l) + SG_ORD[lane][1], (a3[2] >> l) + SG_ORD[lane][2], s, e);
+            const unsigned incl = sg_wave_incl_scan(e - s);
+            if (lane < 27) { rp[lane + 1] = incl; rs[lane] = s; }
+            if (lane == 0) rp[0] = 0;
+            const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+            __syncthreads();
+            best = ~0ull;
+            bool first = true;
+            for (unsigned base = 0; base < total; base += 256u) {
+                float4 q[4];
+                bool val[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned fl = base + 64u * u + (unsigned)lane;
+                    unsigned pos = qe.x;
+                    val[u] = fl < total;
+                    if (val[u]) sg_flat_locate(rp, rs, 5, 27, fl, pos);
+                    q[u] = map[pos];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (base + 64u * u >= total) break; // (uniform)
+                    const unsigned long long key = val[u] ? pack_key(sqdist3(me.x, me.y, me.z, q[u].x, q[u].y, q[u].z), __float_as_uint(q[u].w)) : ~0ull;
+                    if (first) { best = key; sg_sort64<false>(best, total); first = false; }
+                    else sg_absorb(best, key, k);
+                }
+            }
+            const unsigned long long kth = sg_readlane64(best, k - 1);
+            const float kd2 = __uint_as_float((unsigned)(kth >> 32));
+            if (m2 == INFINITY || (kth != ~0ull && kd2 <= m2) || l >= 31) { done = true; break; } // the block holds every point that matters
+            if (kth != ~0ull) bound = kd2; // k real points within kd2: the answer's k-th is no farther
+        }
+        // ---- phase B: the ball of the bound ----
+        if (!done) {
+            const float b = sqrt_up_sg(bound);
+            int sl = 0;
+            while (sl < 30 && g.cell * (float)(1u << sl) < 0.5f * b) ++sl;
+            const float reach = b * 1.00001f + (g.cell * (float)(1u << sl) * 1e-3f + g.maxabs * 4e-6f);
+            int c0[3], nc[3];
+            const float pme[3] = {me.x, me.y, me.z}, org[3] = {g.ox, g.oy, g.oz};
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                const int lo_c = sg_cell_of(pme[ax] - reach, org[ax], g.inv_cell, g.na[ax]) >> sl, hi_c = sg_cell_of(pme[ax] + reach, org[ax], g.inv_cell, g.na[ax]) >> sl;
+                c0[ax] = lo_c; nc[ax] = min(hi_c - lo_c + 1, 6); // (at most 6 by the choice of sl; the clamp only guards the arithmetic)
+            }
+            const float cs = g.cell * (float)(1u << sl);
+            const float slack = cs * 2e-3f + g.maxabs * 2e-6f;
+            __syncthreads();
             unsigned total = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int idx = lane + 64 * j;
                 unsigned s = 0, e = 0;
-                if (idx < 216) {
-                    const int sx = s0x + idx % 6, sy = s0y + (idx / 6) % 6, sz = s0z + idx / 36;
+                const int ix = idx % 6, iy = (idx / 6) % 6, iz = idx / 36;
+                if (idx < 216 && ix < nc[0] && iy < nc[1] && iz < nc[2]) {
+                    const int sx = c0[0] + ix, sy = c0[1] + iy, sz = c0[2] + iz;
                     // distance from the query to the cell's box, every gap shortened by the slack (a point may sit a rounding outside its cell)
                     const float lox = g.ox + (float)sx * cs, loy = g.oy + (float)sy * cs, loz = g.oz + (float)sz * cs;
                     const float gx = fmaxf(fmaxf(lox - me.x, me.x - (lox + cs)) - slack, 0.f);
                     const float gy = fmaxf(fmaxf(loy - me.y, me.y - (loy + cs)) - slack, 0.f);
                     const float gz = fmaxf(fmaxf(loz - me.z, me.z - (loz + cs)) - slack, 0.f);
-                    if (!(fmaf(gz, gz, fmaf(gy, gy, gx * gx)) > bound)) sg_cell_range(g, tstart, tbid, f, l - 1, sx, sy, sz, s, e);
+                    if (!(fmaf(gz, gz, fmaf(gy, gy, gx * gx)) > bound)) sg_cell_range(g, tstart, tbid, f, sl, sx, sy, sz, s, e);
                 }
-                const unsigned len = e - s;
-                const unsigned incl = sg_wave_incl_scan(len);
+                const unsigned incl = sg_wave_incl_scan(e - s);
                 if (idx < 216) { rs[idx] = s; rp[idx + 1] = total + incl; }
-                total += (unsigned)__shfl((int)incl, 63, 64);
+                total += (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
             }
             if (lane == 0) rp[0] = 0;
             __syncthreads();
-            KList<KMAX> Lc; Lc.init(k);
-            for (unsigned base = 0; base < total; base += 128u) {
-                float4 q[2];
-                unsigned pos[2];
+            best = ~0ull;
+            bool first = true;
+            for (unsigned base = 0; base < total; base += 256u) {
+                float4 q[4];
+                bool val[4];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < 4; ++u) {
                     const unsigned fl = base + 64u * u + (unsigned)lane;
-                    pos[u] = ~0u;
-                    if (fl < total) {
-                        int lo = 0, hi = 216;
-#pragma unroll
-                        for (int it = 0; it < 8; ++it) { const int mid = (lo + hi) >> 1; if (rp[mid] <= fl) lo = mid; else hi = mid; }
-                        pos[u] = rs[lo] + (fl - rp[lo]);
-                    }
-                    q[u] = map[pos[u] != ~0u ? pos[u] : qe.x];
+                    unsigned pos = qe.x;
+                    val[u] = fl < total;
+                    if (val[u]) sg_flat_locate(rp, rs, 8, 216, fl, pos);
+                    q[u] = map[pos];
                 }
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    if (pos[u] != ~0u) {
-                        const float d2 = sqdist3(me.x, me.y, me.z, q[u].x, q[u].y, q[u].z);
-                        if (d2 <= bound) Lc.insert(pack_key(d2, __float_as_uint(q[u].w)), (int)pos[u]);
-                    }
-            }
-            // merge: k rounds of the wave minimum over the heads of the lanes' lists (keys are unique: one lane gives up its head per round)
-            Gl.init(k);
-#pragma unroll
-            for (int j = 0; j < KMAX; ++j) {
-                const unsigned long long head = Lc.key[0];
-                unsigned long long mk = head;
-                int ms = Lc.sidx[0];
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    const unsigned long long ok = __shfl_xor(mk, off, 64);
-                    const int os = __shfl_xor(ms, off, 64);
-                    if (ok < mk) { mk = ok; ms = os; }
-                }
-                if (j < k) { Gl.key[j] = mk; Gl.sidx[j] = mk != ~0ull ? ms : -1; }
-                if (head == mk && mk != ~0ull) {
-#pragma unroll
-                    for (int i = 0; i + 1 < KMAX; ++i) { Lc.key[i] = Lc.key[i + 1]; Lc.sidx[i] = Lc.sidx[i + 1]; }
-                    Lc.key[KMAX - 1] = ~0ull; Lc.sidx[KMAX - 1] = -1;
+                for (int u = 0; u < 4; ++u) {
+                    if (base + 64u * u >= total) break; // (uniform)
+                    const float d2 = sqdist3(me.x, me.y, me.z, q[u].x, q[u].y, q[u].z);
+                    const unsigned long long key = (val[u] && d2 <= bound) ? pack_key(d2, __float_as_uint(q[u].w)) : ~0ull;
+                    if (first) {
+                        if (__ballot(key != ~0ull) != 0ull) { best = key; sg_sort64<false>(best); first = false; }
+                    } else sg_absorb(best, key, k);
                 }
             }
-            unsigned long long kth = ~0ull;
-#pragma unroll
-            for (int i = 0; i < KMAX; ++i) if (i == k - 1) kth = Gl.key[i];
-            const float kd2 = __uint_as_float((unsigned)(kth >> 32));
-            if (m2 == INFINITY || (kth != ~0ull && kd2 <= m2) || l >= 31) break;
-            if (kth != ~0ull) bound = kd2; // k real points within kd2: the answer's k-th is no farther
         }
         lev_sum += (unsigned long long)l;
-        if (lane == 0) {
+        if (lane < k) {
+            const bool valid = best != ~0ull;
             const unsigned orig = __float_as_uint(me.w);
-#pragma unroll
-            for (int j = 0; j < KMAX; ++j)
-                if (j < k) {
-                    const int sx = Gl.sidx[j];
-                    out_sidx[(size_t)k * orig + j] = sx;
-                    out_d2[(size_t)k * orig + j] = sx < 0 ? INFINITY : __uint_as_float((unsigned)(Gl.key[j] >> 32));
-                }
+            out_sidx[(size_t)k * orig + lane] = valid ? (int)inv[(unsigned)best] : -1;
+            out_d2[(size_t)k * orig + lane] = valid ? __uint_as_float((unsigned)(best >> 32)) : INFINITY;
         }
     }
-    if (lane == 0 && lev_sum) atomicAdd(&st->levels, lev_sum);
+    if (diag && lane == 0 && lev_sum) atomicAdd(&st->levels, lev_sum); // (ICPMI_SELF_DIAG only: thousands of atomics on one address)
 }
 
 template <typename T>
@@ -591,16 +678,17 @@ icpmi_status sg_cap(icpmi_ctx* c, T** p, size_t* cap, size_t need, bool* fresh =
     return ICPMI_OK;
 }
 
-template <int KMAX>
-void sg_launch_search(icpmi_ctx* c, SelfGridCtx* sg, const SgGrid& g, int k, unsigned tau, unsigned blocks_max, int* d_sidx, float* d_d2,
-                      unsigned long long* sq_mapped)
+unsigned sg_queue_cap(int64_t m) { const int64_t waves = (m + SGQ - 1) / SGQ; return (unsigned)(((waves + SG_NQ - 1) / SG_NQ) * SGQ); }
+
+void sg_launch_search(icpmi_ctx* c, SelfGridCtx* sg, const SgGrid& g, int k, int64_t m, int* d_sidx, float* d_d2, unsigned long long* sq_mapped, int diag)
 {
-    const unsigned g1 = std::max(1u, std::min(blocks_max, 16384u));
-    hipLaunchKernelGGL((sg_tiled_kernel<KMAX, 8>), dim3(g1), dim3(64), 0, c->stream, g, (const float4*)c->d_map_sorted, (const unsigned*)sg->d_tstart,
-                       (const unsigned*)sg->d_tbid, (const unsigned*)sg->d_f, (const uint4*)sg->d_blist, sg->d_state, k, tau, d_sidx, d_d2, sg->d_queue,
-                       sq_mapped);
-    hipLaunchKernelGGL(sg_wave_kernel<KMAX>, dim3(4096), dim3(64), 0, c->stream, g, (const float4*)c->d_map_sorted, (const unsigned*)sg->d_tstart,
-                       (const unsigned*)sg->d_tbid, (const unsigned*)sg->d_f, sg->d_state, k, d_sidx, d_d2, (const uint2*)sg->d_queue);
+    const unsigned g1 = (unsigned)((m + SGQ - 1) / SGQ), qcap = sg_queue_cap(m);
+    hipLaunchKernelGGL(sg_cell_kernel, dim3(g1), dim3(64), 0, c->stream, g, (const float4*)c->d_map_sorted, (const unsigned*)sg->d_tstart,
+                       (const unsigned*)sg->d_tbid, (const unsigned*)sg->d_f, (const unsigned*)sg->d_inv, sg->d_state, k, (unsigned)m,
+                       m < (1ll << 24) ? 1 : 0, d_sidx, d_d2, sg->d_queue, qcap, sq_mapped);
+    hipLaunchKernelGGL(sg_level_kernel, dim3(8192), dim3(64), 0, c->stream, g, (const float4*)c->d_map_sorted, (const unsigned*)sg->d_tstart,
+                       (const unsigned*)sg->d_tbid, (const unsigned*)sg->d_f, (const unsigned*)sg->d_inv, sg->d_state, k, d_sidx, d_d2,
+                       (const uint2*)sg->d_queue, qcap, diag);
 }
 
 } // namespace
@@ -611,7 +699,7 @@ void selfgrid_destroy(icpmi_ctx* c)
     if (!sg) return;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dev_free(sg->d_tcnt); dev_free(sg->d_tstart); dev_free(sg->d_tbid); dev_free(sg->d_blist); dev_free(sg->d_f); dev_free(sg->d_coarse);
-    dev_free(sg->d_queue); dev_free(sg->d_part); dev_free(sg->d_state);
+    dev_free(sg->d_queue); dev_free(sg->d_inv); dev_free(sg->d_part); dev_free(sg->d_state);
     delete sg;
     c->sg = nullptr;
 }
@@ -683,7 +771,6 @@ icpmi_status selfgrid_knn(icpmi_ctx* c, const float4* d_pts, int64_t m, int k, i
         trials = 5; // a cloud this handle has not seen the like of: build, look at the occupancy, correct
     }
     static const int diag = [] { const char* e = getenv("ICPMI_SELF_DIAG"); return e ? atoi(e) : 0; }();
-    static const unsigned tau = [] { const char* e = getenv("ICPMI_SG_TAU"); return e ? (unsigned)atoi(e) : 8u; }();
     const int blocks256 = (int)((m + 255) / 256);
     SgGrid g{};
     unsigned blocks_max = 0;
@@ -696,7 +783,7 @@ icpmi_status selfgrid_knn(icpmi_ctx* c, const float4* d_pts, int64_t m, int k, i
         sg->tcnt_clean = false;
         if (sg_cap(c, &sg->d_tstart, &sg->cap_tstart, (size_t)g.tsize + 2) != ICPMI_OK || sg_cap(c, &sg->d_tbid, &sg->cap_tbid, (size_t)g.tsize + 1) != ICPMI_OK ||
             sg_cap(c, &sg->d_blist, &sg->cap_blist, (size_t)blocks_max + 1) != ICPMI_OK || sg_cap(c, &sg->d_f, &sg->cap_f, (size_t)blocks_max * SG_F + 1) != ICPMI_OK ||
-            sg_cap(c, &sg->d_coarse, &sg->cap_coarse, (size_t)m + 16) != ICPMI_OK || sg_cap(c, &sg->d_queue, &sg->cap_queue, (size_t)m + 1) != ICPMI_OK ||
+            sg_cap(c, &sg->d_coarse, &sg->cap_coarse, (size_t)m + 16) != ICPMI_OK || sg_cap(c, &sg->d_queue, &sg->cap_queue, (size_t)sg_queue_cap(m) * SG_NQ + 1) != ICPMI_OK || sg_cap(c, &sg->d_inv, &sg->cap_inv, (size_t)m + 1) != ICPMI_OK ||
             ensure_cap(c, &c->d_keys, &c->cap_keys, (size_t)m) != ICPMI_OK || ensure_cap(c, &c->d_map_sorted, &c->cap_map, (size_t)m + 16) != ICPMI_OK)
             return ICPMI_ERR_HIP;
         if (trial > 0) hipLaunchKernelGGL(sg_reset_kernel, dim3(1), dim3(64), 0, c->stream, sg->d_state);
@@ -706,11 +793,12 @@ icpmi_status selfgrid_knn(icpmi_ctx* c, const float4* d_pts, int64_t m, int k, i
         sg->tcnt_clean = true;
         hipLaunchKernelGGL(sg_scatter_kernel, dim3(blocks256), dim3(256), 0, c->stream, d_pts, m, (const unsigned*)c->d_keys, sg->d_tstart + 1, sg->d_coarse);
         hipLaunchKernelGGL(sg_block_sort_kernel, dim3(std::max(1u, std::min(blocks_max, 8192u))), dim3(64), 0, c->stream, (const float4*)sg->d_coarse,
-                           c->d_map_sorted, g, (const unsigned*)sg->d_tstart, (const uint4*)sg->d_blist, sg->d_f, sg->d_state);
+                           c->d_map_sorted, g, (const unsigned*)sg->d_tstart, (const uint4*)sg->d_blist, sg->d_f, sg->d_inv, sg->d_state);
         HIP_TRY(c, hipGetLastError());
         if (trial + 1 >= trials) break;
-        unsigned long long sq = 0;
-        if (read_back(c, &sq, &sg->d_state->sq, sizeof sq) != ICPMI_OK) return ICPMI_ERR_HIP;
+        unsigned long long sqp[64], sq = 0;
+        if (read_back(c, sqp, sg->d_state->sqpart, sizeof sqp) != ICPMI_OK) return ICPMI_ERR_HIP;
+        for (int i = 0; i < 64; ++i) sq += sqp[i];
         const double sb = (double)sq / (double)m;
         if (sb > 0.85 * target && sb < 1.18 * target) break;
         const double next = (double)g.cell * std::min(4.0, std::max(0.25, sqrt(target / sb)));
@@ -720,23 +808,17 @@ icpmi_status selfgrid_knn(icpmi_ctx* c, const float4* d_pts, int64_t m, int k, i
     sg->cell = g.cell; sg->m = m; sg->k = k; ++sg->seq;
 
     // ---- search ----
-    if (k <= 4) sg_launch_search<4>(c, sg, g, k, tau, blocks_max, d_sidx, d_d2, d_sq);
-    else if (k <= 8) sg_launch_search<8>(c, sg, g, k, tau, blocks_max, d_sidx, d_d2, d_sq);
-    else if (k <= 10) sg_launch_search<10>(c, sg, g, k, tau, blocks_max, d_sidx, d_d2, d_sq); // the shipped post filter (examples/config.yaml:26-27)
-    else if (k <= 16) sg_launch_search<16>(c, sg, g, k, tau, blocks_max, d_sidx, d_d2, d_sq);
-    else sg_launch_search<32>(c, sg, g, k, tau, blocks_max, d_sidx, d_d2, d_sq);
+    sg_launch_search(c, sg, g, k, m, d_sidx, d_d2, d_sq, diag);
     HIP_TRY(c, hipGetLastError());
     if (diag) {
         SgState hs{};
-        if (read_back(c, &hs, sg->d_state, sizeof hs) == ICPMI_OK)
+        unsigned qtot = 0;
+        if (read_back(c, &hs, sg->d_state, sizeof hs) == ICPMI_OK) for (int i = 0; i < 64; ++i) qtot += hs.qcount[i];
+        if (qtot || hs.nblk)
             fprintf(stderr, "[icpmi self-knn] m %lld k %d: A-cell %.3f (%d x %d x %d), T %d entries, %u blocks, size-biased occupancy %.1f (target %.1f); "
                             "%u queries (%.2f %%) through the levels, mean end level %.2f\n",
-                    (long long)m, k, (double)g.cell, g.na[0], g.na[1], g.na[2], g.tsize, hs.nblk, (double)hs.sq / (double)m, target, hs.qcount,
-                    100.0 * hs.qcount / (double)m, hs.qcount ? (double)hs.levels / (double)hs.qcount : 0.0);
-#ifdef SG_TIMING
-        fprintf(stderr, "[icpmi self-knn] tiled kernel, sampled workgroups (cycles x 1e3): setup %.0f  stage %.0f  scan+insert %.0f  decide+write %.0f  loop-top %.0f | drain rounds %llu  scan iterations %llu\n",
-                hs.tick[0] * 1e-3, hs.tick[1] * 1e-3, hs.tick[2] * 1e-3, hs.tick[3] * 1e-3, hs.tick[7] * 1e-3, hs.tick[4], hs.tick[5]);
-#endif
+                    (long long)m, k, (double)g.cell, g.na[0], g.na[1], g.na[2], g.tsize, hs.nblk, (double)hs.sq / (double)m, target, qtot,
+                    100.0 * qtot / (double)m, qtot ? (double)hs.levels / (double)qtot : 0.0);
     }
     return ICPMI_OK;
 }
