@@ -466,6 +466,13 @@ icpmi_status icpmi_set_stream(icpmi_handle h, void* hip_stream);
 /* Grid parameters chosen by the last set_map: cell edge, dims[3], number of cells (for DESIGN/bench). */
 icpmi_status icpmi_get_grid_info(icpmi_handle h, float* cell, int32_t dims[3], int64_t* n_cells, int64_t* n_occupied);
 int32_t      icpmi_version(void);
+/* "icpmi <version> src:<stamp>": <stamp> = the first 16 hex digits of the SHA-256 over the library's sources (csrc Makefile: sorted *.hip, common.h,
+ * solve.h, include/icpmi.h) as they were when this binary was linked -- tests/conftest.py recomputes it from the tree and refuses to run GPU
+ * tests against a binary built from other sources. */
+const char*  icpmi_build_info(void);
+/* The library caches freed device blocks per device (at most ICPMI_ALLOC_CACHE_MB, default 1024; emptied when the process's last handle is
+ * destroyed).  This hands every cached block back to the runtime now; live handles stay valid. */
+icpmi_status icpmi_trim_cache(void);
 /* Diagnostics of the last registration (engine internals, not part of the reference surface).  Slots 12 / 13 (r5): iterations of a k > 1 loop whose
    quantile selection took its level 0 from the NN kernel's window / from the full histogram behind a window that missed. */
 icpmi_status icpmi_debug_counters(icpmi_handle h, uint64_t out[24]);

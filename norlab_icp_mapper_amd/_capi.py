@@ -92,6 +92,8 @@ _P = C.c_void_p
 _F = C.POINTER(C.c_float)
 SYMBOLS = [
     ("icpmi_version", C.c_int32, []),
+    ("icpmi_build_info", C.c_char_p, []),
+    ("icpmi_trim_cache", C.c_int, []),
     ("icpmi_config_default", None, [C.POINTER(Config)]),
     ("icpmi_create", C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
     ("icpmi_set_config", C.c_int, [_P, C.POINTER(Config)]),

@@ -57,6 +57,12 @@ struct RoctxRange {
 extern "C" {
 
 int32_t icpmi_version(void) { return ICPMI_VERSION; }
+#ifndef ICPMI_SRC_STAMP
+#define ICPMI_SRC_STAMP "unstamped"
+#endif
+#define ICPMI_STR2(x) #x
+#define ICPMI_STR(x) ICPMI_STR2(x)
+const char* icpmi_build_info(void) { return "icpmi " ICPMI_STR(ICPMI_VERSION) " src:" ICPMI_SRC_STAMP; }
 
 void icpmi_config_default(icpmi_config* cfg)
 {
@@ -231,7 +237,7 @@ void icpmi_destroy(icpmi_handle c)
     dev_free(c->d_alt_s); dev_free(c->d_alt_src); dev_free(c->d_stage_s); dev_free(c->d_merge_send); dev_free(c->d_merge_recv); dev_free(c->d_merged); dev_free(c->d_comm_cnt); dev_free(c->d_read_noise); dev_free(c->d_read_scalar); dev_free(c->d_map_pn);
     for (int k = 0; k < ICPMI_SCRATCH_SLOTS; ++k) dev_free(c->scratch[k]); dev_free(c->d_scan_map); dev_free(c->d_T16);
     dev_free(c->d_sidx); dev_free(c->d_d2); dev_free(c->d_hard); dev_free(c->d_selhist);
-    dev_free(c->d_state); dev_free(c->d_selfsq);
+    dev_free(c->d_state);
 #undef dev_free
     if (c->h_state) hipHostFree(c->h_state);
     if (c->h_pin) hipHostFree(c->h_pin);

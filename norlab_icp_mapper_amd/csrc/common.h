@@ -498,7 +498,7 @@ struct icpmi_ctx {
     // when the map changed (map_version) -- not against the registration index.
     icpmi_ctx* temp_raw = nullptr; uint64_t temp_raw_version = 0;
     uint64_t map_version = 0;         // bumped by every map_build of this handle
-    bool single_level = false;        // temp handles of the self k-NN (surface normals): level 0 of the pyramid is all they search
+    bool single_level = false;        // the raw-frame VIEW of a registration index (ops.hip: raw_index): level 0 of the pyramid is all it searches
     bool keep_raw = true;             // temp handles index clouds they do not own: no resident copy of the input
     bool no_centre = false;           // temp handles of the map-side operators: index raw coordinates (mean = 0)
     bool is_raw_index = false;        // the private raw-frame index of a resident map (ops.hip: raw_index): grows by appends with its owner
@@ -541,8 +541,6 @@ struct icpmi_ctx {
     // checked loops (Counter + Differential / Bound: what Mapper::processInput runs) as SEGMENT graphs: [0] = head + the first
     // seg_len iterations, [1] = seg_len further iterations, replayed while the progress word says the loop is still running
     hipGraphExec_t seg_exec[2] = {nullptr, nullptr}; uint64_t seg_sig = 0; int64_t seg_n = -1; int seg_len = 0; bool seg_sorted = false;
-    int64_t self_sq_m = 0;   // point count of the self search whose sum of squared cell counts sits in the mapped page (ICPMI_PROGRESS_SELF_WORD)
-    unsigned long long* d_selfsq = nullptr; int64_t selfsq_m = 0; bool selfsq_dirty = false; // ... and the device word the build of a single-level index leaves that sum in
     int seg_uses = 0, seg_wasted = 0, graph_uses = 0, graph_wasted = 0; uint64_t eager_sig = 0, map_epoch = 0; int64_t eager_n = -1;   // see drop_loop_graphs (map_epoch: one tick per invalidation)
     // r5: head graphs of OTHER lengths (head + L iterations, L = the iteration count of the handle's previous checked registration): a mapper's
     // registrations stop after about the same number of iterations scan after scan, and a head graph of exactly that length has no dead iterations
@@ -640,7 +638,7 @@ struct DevBuf {
 #define ICPMI_PROGRESS_HDR_WORD 64    // ... 256 words: the block headers (counts) of a one-collective epoch, one per rank (ops.hip)
 #define ICPMI_MERGE_MAGIC 0x49435035u // 'ICP5' in the header's y
 #define ICPMI_PROGRESS_OCT_WORD 48  // ... and 8 words for the octree's root cube (octree.hip)
-#define ICPMI_PROGRESS_SELF_WORD 56 // ... two words: sum over the cells of (points in the cell)^2 of the last tiled self search (nn.hip -> map_build.hip)
+#define ICPMI_PROGRESS_SELF_WORD 56 // ... two words: sum over the A-cells of (points in the cell)^2 of the handle's last self search (selfgrid.hip: the next build tunes its edge with it)
 #define ICPMI_PROGRESS_SCAN_WORD 40 // word of the host-mapped progress page (api.hip: h_progress, 64 words) that device_scan_flags_count reports into
 static inline icpmi_status read_back2(icpmi_ctx* c, void* dst0, const void* src0, size_t b0, void* dst1, const void* src1, size_t b1)
 {
@@ -828,8 +826,7 @@ icpmi_status device_exclusive_scan_io(icpmi_ctx* c, const unsigned* in, unsigned
 // its slots with atomicAdd(&starts[key + 1], len) and leaves the plain exclusive scan behind.  zero_counts: counts[0 .. n + 1] end up zero.
 icpmi_status device_scan_flags_count(icpmi_ctx* c, const unsigned* flag, unsigned* pos, int n, int64_t* count); // pos = exclusive scan of the 0 / 1 flags, *count = how many are set (one stream wait, no copy)
 icpmi_status device_exclusive_scan_sum(icpmi_ctx* c, const unsigned* flag, unsigned* pos, int n, unsigned* d_sum); // ... the count stays on the device
-icpmi_status device_exclusive_scan_cursor(icpmi_ctx* c, unsigned* counts, unsigned* starts, int n, unsigned total, bool zero_counts, unsigned* tail_out = nullptr,
-                                          unsigned long long* sq_out = nullptr); // tail_out: receives counts[n + 1]
+icpmi_status device_exclusive_scan_cursor(icpmi_ctx* c, unsigned* counts, unsigned* starts, int n, unsigned total, bool zero_counts, unsigned* tail_out = nullptr); // tail_out: receives counts[n + 1]
 // the same scan on another stream with the caller's own chunk-total words (device_scan_side_words(n) of them); false from
 // device_scan_side_ok(n): the table is too large for the two-kernel scan -- stay on the handle's stream
 bool device_scan_side_ok(int n);
@@ -844,7 +841,6 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
 icpmi_status nn_launch_k(icpmi_ctx* c, const float4* d_reading, int64_t n, const float* d_T, const LoopCfg& lc,
                          int allow_self, int* d_sidx, float* d_d2, IcpState* d_state);
 icpmi_status nn_ids_to_original(icpmi_ctx* c, const int* d_sidx, int64_t count, int* d_ids);
-icpmi_status nn_self_knn(icpmi_ctx* c, const float4* d_cloud, const LoopCfg& lc, int* d_sidx, float* d_d2, IcpState* d_state);
 // self k-NN of a device cloud through a sparse block grid built for the call (selfgrid.hip): rows of d_sidx / d_d2 in the cloud's order, entries =
 // positions in c->d_map_sorted (w = original index bits), which the call leaves behind for launch_normals / nn_ids_to_original
 icpmi_status selfgrid_knn(icpmi_ctx* c, const float4* d_pts, int64_t m, int k, int* d_sidx, float* d_d2);

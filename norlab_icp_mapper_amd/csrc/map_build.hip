@@ -58,9 +58,6 @@ __device__ __forceinline__ int cell_of(float v, float o, float inv, int n)
 // level 0 uses the same trick (r2: 98 -> 4x fewer device atomics on an octree-ordered 0.9 M-point map).
 // (WaveRun / wave_run: common.h -- the bucket grid of the DynamicPoints module uses them too)
 
-#ifndef ICPMI_SELF_TARGET_DEFAULT
-#define ICPMI_SELF_TARGET_DEFAULT 8.0
-#endif
 // ---- pass 2: keys + per-cell histogram -------------------------------------------------------
 __global__ __launch_bounds__(256) void key_kernel(const float4* __restrict__ pts, int64_t m, float mx, float my, float mz,
                                                   GridParams g, unsigned* __restrict__ keys, unsigned* __restrict__ count,
@@ -184,20 +181,13 @@ __device__ __forceinline__ unsigned block_exclusive_scan_fast(unsigned v, unsign
     return base + incl - v;
 }
 
-// sq_out (may be null): += the sum of in[i]^2 -- a grid build's "occupancy an average point sees" (map_build), from the read this kernel makes anyway
-__global__ __launch_bounds__(SCAN_T) void scan2_sums_kernel(const unsigned* __restrict__ in, int n, unsigned* __restrict__ sums,
-                                                            unsigned long long* __restrict__ sq_out = nullptr)
+__global__ __launch_bounds__(SCAN_T) void scan2_sums_kernel(const unsigned* __restrict__ in, int n, unsigned* __restrict__ sums)
 {
     __shared__ unsigned sh[SCAN_T / 64];
     const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_E;
     unsigned s = 0;
-    unsigned long long q = 0;
 #pragma unroll
-    for (int e = 0; e < SCAN_E; ++e) if (base + e < n) { const unsigned v = in[base + e]; s += v; q += (unsigned long long)v * v; }
-    if (sq_out) { // (kernel-uniform)
-        for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
-        if ((threadIdx.x & 63) == 0 && q) atomicAdd(sq_out, q);
-    }
+    for (int e = 0; e < SCAN_E; ++e) if (base + e < n) s += in[base + e];
     unsigned tot;
     block_exclusive_scan_fast(s, sh, &tot);
     if (threadIdx.x == 0) sums[blockIdx.x] = tot;
@@ -715,36 +705,23 @@ static int scan2_enabled()
     return two;
 }
 
-// sum over the cells of (points in the cell)^2 -- divided by the point count, the occupancy of the cell an average POINT sits in.
-// The single-level grid of the tiled self search is tuned with it: the mean over occupied cells says 12 where a lidar map's points
-// see 26 (dense near the trajectory, sparse far out), and the search pays for what the points see.
-__global__ __launch_bounds__(256) void sq_counts_kernel(const unsigned* __restrict__ counts, int n, unsigned long long* __restrict__ out)
-{
-    unsigned long long s = 0;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) { const unsigned long long v = counts[i]; s += v * v; }
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
-}
-
 // The count table of a grid build -> the cell starts, in the layout a CURSOR scatter wants (r5): counts[0..n) (+ the occupancy word at
 // counts[n + 1]) -> starts[0] = 0, starts[i + 1] = start of cell i, starts[n + 1] = total.  A scatter then takes its slots with
 // atomicAdd(&starts[key + 1], len): when every point is placed, starts[i + 1] has grown to the start of cell i + 1 -- the array IS the plain
 // exclusive scan, with no second table of fill cursors to clear (r4: two memsets per grid, three to four launches).  The counts are left
 // ZERO (c->fill_clean): the next build counts into them as they are.  starts needs n + 2 words.
-icpmi_status device_exclusive_scan_cursor(icpmi_ctx* c, unsigned* counts, unsigned* starts, int n, unsigned total, bool zero_counts, unsigned* tail_out,
-                                          unsigned long long* sq_out)
+icpmi_status device_exclusive_scan_cursor(icpmi_ctx* c, unsigned* counts, unsigned* starts, int n, unsigned total, bool zero_counts, unsigned* tail_out)
 {
     const int nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
     if (ensure_cap(c, &c->d_blocksums, &c->cap_blocksums, (size_t)nb + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
     if (scan2_enabled() && nb <= SCAN2_MAX_NB) {
-        hipLaunchKernelGGL(scan2_sums_kernel, dim3(nb > 0 ? nb : 1), dim3(SCAN_T), 0, c->stream, (const unsigned*)counts, n, c->d_blocksums, sq_out);
+        hipLaunchKernelGGL(scan2_sums_kernel, dim3(nb > 0 ? nb : 1), dim3(SCAN_T), 0, c->stream, (const unsigned*)counts, n, c->d_blocksums);
         hipLaunchKernelGGL(scan2_final_kernel, dim3(nb > 0 ? nb : 1), dim3(SCAN_T), 0, c->stream, (const unsigned*)counts, starts, n, (const unsigned*)c->d_blocksums, total, 1,
                            zero_counts ? counts : (unsigned*)nullptr, (unsigned*)nullptr, tail_out);
         HIP_TRY(c, hipGetLastError());
         return ICPMI_OK;
     }
     // very large tables: the three-kernel scan on a copy, the zero word in front, the counts cleared by a memset
-    if (sq_out) hipLaunchKernelGGL(sq_counts_kernel, dim3(std::min((n + 255) / 256, 2048)), dim3(256), 0, c->stream, (const unsigned*)counts, n, sq_out);
     if (tail_out) HIP_TRY(c, hipMemcpyAsync(tail_out, counts + n + 1, sizeof(unsigned), hipMemcpyDefault, c->stream));
     HIP_TRY(c, hipMemcpyAsync(starts + 1, counts, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(starts, 0, sizeof(unsigned), c->stream));
@@ -767,10 +744,9 @@ icpmi_status device_exclusive_scan_cursor_side(icpmi_ctx* c, hipStream_t stream,
     return ICPMI_OK;
 }
 
-static icpmi_status device_scan_counts_to_cursors(icpmi_ctx* c, unsigned* counts, unsigned* starts, int n, unsigned total, unsigned* tail_out = nullptr,
-                                                  unsigned long long* sq_out = nullptr)
+static icpmi_status device_scan_counts_to_cursors(icpmi_ctx* c, unsigned* counts, unsigned* starts, int n, unsigned total, unsigned* tail_out = nullptr)
 {
-    const icpmi_status s = device_exclusive_scan_cursor(c, counts, starts, n, total, true, tail_out, sq_out);
+    const icpmi_status s = device_exclusive_scan_cursor(c, counts, starts, n, total, true, tail_out);
     if (s == ICPMI_OK) c->fill_clean = true;
     return s;
 }
@@ -803,7 +779,7 @@ icpmi_status device_scan_flags_count(icpmi_ctx* c, const unsigned* flag, unsigne
         // caller enqueues next queues up behind a GPU that never went idle.  ICPMI_SPIN_COUNTS=0: drain as before.
         static const int spin_cfg = [] { const char* e = getenv("ICPMI_SPIN_COUNTS"); return e ? atoi(e) : 1; }();
         const unsigned tag = spin_cfg ? (++c->scan_tag ? c->scan_tag : ++c->scan_tag) : 0u;
-        hipLaunchKernelGGL(scan2_sums_kernel, dim3(nb), dim3(SCAN_T), 0, c->stream, flag, n, c->d_blocksums, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL(scan2_sums_kernel, dim3(nb), dim3(SCAN_T), 0, c->stream, flag, n, c->d_blocksums);
         hipLaunchKernelGGL(scan2_final_kernel, dim3(nb), dim3(SCAN_T), 0, c->stream, flag, pos, n, (const unsigned*)c->d_blocksums, 0u, 0, (unsigned*)nullptr, d_word,
                            (unsigned*)nullptr, tag);
         HIP_TRY(c, hipGetLastError());
@@ -1135,7 +1111,6 @@ icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float
     };
     GridParams g;
     unsigned n_occ = 0;
-    unsigned long long* sq_pending = nullptr;
     if (c->cfg.grid_cell > 0.f) {
         g = make_grid(clo, chi, clamp_cell(c->cfg.grid_cell), maxabs);
         if (grid_count(c, d_pts, m, g, &n_occ) != ICPMI_OK) return ICPMI_ERR_HIP;
@@ -1144,11 +1119,7 @@ icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float
         // surfaces (occupied cells ~ area / cell^2): aim at TARGET points per occupied cell.
         static double target_cfg = -1.0;
         if (target_cfg < 0) { const char* e = getenv("ICPMI_GRID_TARGET"); target_cfg = e ? atof(e) : 8.0; }
-        static double self_target = -1.0; // the single-level grid of the tiled self search (SurfaceNormal): its own optimum (ICPMI_SELF_TARGET)
-        if (self_target < 0) { const char* e = getenv("ICPMI_SELF_TARGET"); self_target = e ? atof(e) : ICPMI_SELF_TARGET_DEFAULT; }
-        const double TARGET = c->single_level ? self_target : target_cfg;
-        static double self_sb_target = -1.0; // ICPMI_SELF_SB_TARGET: size-biased occupancy the self-search grid aims at (0: the mean-occupancy rule only)
-        if (self_sb_target < 0) { const char* e = getenv("ICPMI_SELF_SB_TARGET"); self_sb_target = e ? atof(e) : 11.0; }
+        const double TARGET = target_cfg;
         // A handle that rebuilds the index of a slowly growing map (every map update, twice) does not wait for the occupancy of THIS
         // build: it corrects the edge with the count of the previous one, which arrived in pinned memory long ago (r3: one stream
         // synchronisation less per build; ICPMI_GRID_DEFER=0 restores the read-back).  The edge only steers speed: the search is exact.
@@ -1157,25 +1128,10 @@ icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float
         if (defer && c->h_nocc && c->nocc_m > 0 && c->grid.cell > 0.f && c->m > 0 && (double)m > 0.7 * (double)c->m && (double)m < 1.4 * (double)c->m) {
             const double occ = (double)c->nocc_m / (double)std::max(1u, *c->h_nocc);
             double cell = c->grid.cell;
-            const unsigned long long sq_prev = c->single_level && c->h_progress && c->self_sq_m > 0 && self_sb_target > 0.0
-                ? *reinterpret_cast<volatile unsigned long long*>(c->h_progress + ICPMI_PROGRESS_SELF_WORD) : 0ull;
-            // the self-search index: by what its last search's points saw (written by that search, long arrived) -- where that differs
-            // from the mean over occupied cells, i.e. where the density has a heavy tail (a lidar map: dense along the trajectory);
-            // evenly sampled surfaces keep the occupancy rule they were tuned with
-            const double sb_prev = sq_prev ? (double)sq_prev / (double)c->self_sq_m : 0.0;
-            if (sb_prev > 1.6 * occ) {
-                if (!(sb_prev > self_sb_target * 0.88 && sb_prev < self_sb_target * 1.12)) cell = cell * sqrt(self_sb_target / sb_prev);
-            } else
             if (!(occ > TARGET * 0.6 && occ < TARGET * 1.6)) cell = cell * sqrt(TARGET / occ);
             g = make_grid(clo, chi, clamp_cell(cell), maxabs);
             n_occ = *c->h_nocc;
             if (grid_count(c, d_pts, m, g, nullptr) != ICPMI_OK) return ICPMI_ERR_HIP;
-            if (c->single_level && self_sb_target > 0.0) { // what the points of THIS build see, for the build after it (nn.hip: nnk_redo_kernel delivers it)
-                if (!c->d_selfsq) { HIP_TRY(c, dev_malloc((void**)&c->d_selfsq, sizeof(unsigned long long))); HIP_TRY(c, hipMemsetAsync(c->d_selfsq, 0, sizeof(unsigned long long), c->stream)); }
-                else if (c->selfsq_dirty) HIP_TRY(c, hipMemsetAsync(c->d_selfsq, 0, sizeof(unsigned long long), c->stream)); // (a build no search followed)
-                sq_pending = c->d_selfsq; // (r5: summed by the scan of these counts below -- a kernel of its own read the whole sparse table once more: 52 us per update)
-                c->selfsq_m = m; c->selfsq_dirty = true;
-            }
             c->nocc_m = m;
             goto grid_chosen;
         }
@@ -1186,32 +1142,6 @@ icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float
         if (c->grid.cell > 0.f && c->m > 0 && (double)m > 0.7 * (double)c->m && (double)m < 1.4 * (double)c->m) cell = c->grid.cell;
         g = make_grid(clo, chi, clamp_cell(cell), maxabs);
         if (grid_count(c, d_pts, m, g, &n_occ) != ICPMI_OK) return ICPMI_ERR_HIP;
-        if (c->single_level && self_sb_target > 0.0) {
-            // first builds of the self-search index (nothing deferred to go by): correct the edge with the size-biased occupancy, read back
-            for (int it = 0; it < 3; ++it) {
-                unsigned long long* d_sq = reinterpret_cast<unsigned long long*>(c->d_blocksums); // (free between builds' scans)
-                unsigned long long sq = 0;
-                if (ensure_cap(c, &c->d_blocksums, &c->cap_blocksums, 4) != ICPMI_OK) return ICPMI_ERR_HIP;
-                d_sq = reinterpret_cast<unsigned long long*>(c->d_blocksums);
-                HIP_TRY(c, hipMemsetAsync(d_sq, 0, sizeof sq, c->stream));
-                hipLaunchKernelGGL(sq_counts_kernel, dim3(std::min((g.ncells + 255) / 256, 2048)), dim3(256), 0, c->stream, (const unsigned*)c->d_fill, g.ncells, d_sq);
-                if (read_back(c, &sq, d_sq, sizeof sq) != ICPMI_OK) return ICPMI_ERR_HIP;
-                const double sb = (double)sq / (double)m, occ_now = (double)m / (double)std::max(1u, n_occ);
-                if (!(sb > 1.6 * occ_now)) { // evenly sampled: the occupancy rule
-                    if (occ_now > TARGET * 0.6 && occ_now < TARGET * 1.6) break;
-                    const float c3 = clamp_cell(g.cell * sqrt(TARGET / occ_now));
-                    if (fabsf(c3 - g.cell) < 0.05f * g.cell) break;
-                    g = make_grid(clo, chi, c3, maxabs);
-                    if (grid_count(c, d_pts, m, g, &n_occ) != ICPMI_OK) return ICPMI_ERR_HIP;
-                    continue;
-                }
-                if (sb > self_sb_target * 0.88 && sb < self_sb_target * 1.12) break;
-                const float c2 = clamp_cell(g.cell * sqrt(self_sb_target / sb));
-                if (fabsf(c2 - g.cell) < 0.05f * g.cell) break;
-                g = make_grid(clo, chi, c2, maxabs);
-                if (grid_count(c, d_pts, m, g, &n_occ) != ICPMI_OK) return ICPMI_ERR_HIP;
-            }
-        } else
         for (int it = 0; it < 2; ++it) {
             const double occ = (double)m / (double)std::max(1u, n_occ);
             if (occ > TARGET * 0.6 && occ < TARGET * 1.6) break;
@@ -1227,7 +1157,7 @@ grid_chosen:
     c->n_occupied = n_occ;
 
     // ---- exclusive scan of the histogram: counts (c->d_fill, left zero) -> cell starts in cursor layout ----
-    if (device_scan_counts_to_cursors(c, c->d_fill, c->d_cell_start, g.ncells, (unsigned)m, (c->nocc_by_scan && c->d_nocc_host) ? c->d_nocc_host : nullptr, sq_pending) != ICPMI_OK) return ICPMI_ERR_HIP;
+    if (device_scan_counts_to_cursors(c, c->d_fill, c->d_cell_start, g.ncells, (unsigned)m, (c->nocc_by_scan && c->d_nocc_host) ? c->d_nocc_host : nullptr) != ICPMI_OK) return ICPMI_ERR_HIP;
     c->nocc_by_scan = false;
 
     // ---- scatter ----

@@ -2121,351 +2121,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KMAX <= 8 ?
 #endif
 }
 
-// ------------------------------------------------------------------------------------------------
-// Self k-NN of the indexed cloud (SurfaceNormalDataPointsFilter: every map point against the map, knn 5..32,
-// self match allowed).  The queries ARE the cell-sorted points, so all queries of a cell share one 3x3x3
-// neighbourhood: a workgroup takes SEG consecutive x-cells of one (y, z) row, stages the 9 x-runs that cover
-// the neighbourhoods of all of them into LDS once (chunks of SELF_CH points) and lets one lane per query scan
-// them from LDS (every lane reads the same address: a broadcast).  Map traffic drops from one gather stream per
-// query to 9 coalesced runs per workgroup.  A query whose k-th distance does not fit its margin to the block
-// boundary is queued and redone by the ring-search kernel.  Results go to row `original index` of out_sidx.
-// ------------------------------------------------------------------------------------------------
-// One wave per workgroup: a 4-cell segment holds ~40 queries, so wider workgroups would idle most of their lanes.
-constexpr int SELF_SEG = 4, SELF_CH = 384, SELF_BLOCK = 64;
-
-// one segment (SELF_SEG x-cells of one (y, z) row) by one wave
-template <int KMAX, int SELF_Q>
-__device__ __forceinline__ void self_tiled_segment(const int b, const GridParams& g, const float4* __restrict__ map,
-                                                   const unsigned* __restrict__ cs, int k, int* __restrict__ out_sidx,
-                                                   float* __restrict__ out_d2, IcpState* __restrict__ st,
-                                                   unsigned* __restrict__ queue)
-{
-    const int nsx = (g.nx + SELF_SEG - 1) / SELF_SEG;
-    const int sx = b % nsx, y = (b / nsx) % g.ny, z = b / (nsx * g.ny);
-    const int x0 = sx * SELF_SEG, x1 = min(x0 + SELF_SEG, g.nx); // query cells [x0, x1)
-    const int qbase = (z * g.ny + y) * g.nx;
-    const unsigned qs = cs[qbase + x0], qe = cs[qbase + x1];
-    if (qs == qe) return;
-    // the 9 candidate runs (cells x0-1 .. x1 of the rows (y+dy, z+dz)); workgroup-uniform
-    __shared__ unsigned run_s[9], run_p[10];
-    __shared__ float4 tile[SELF_CH];
-    __shared__ unsigned short qslot[SELF_Q][SELF_BLOCK]; // per-lane queue of candidates awaiting insertion (tile slots)
-    if (threadIdx.x < 9) {
-        const int dy = (int)threadIdx.x % 3 - 1, dz = (int)threadIdx.x / 3 - 1;
-        unsigned s0 = 0, e0 = 0;
-        row_run(g, cs, x0 - 1, x1, y + dy, z + dz, s0, e0);
-        run_s[threadIdx.x] = s0; run_p[threadIdx.x + 1] = e0 - s0;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        run_p[0] = 0;
-        for (int i = 1; i <= 9; ++i) run_p[i] += run_p[i - 1];
-    }
-    __syncthreads();
-    // a query only needs the cells x-1 .. x+1 of every run (its own 3x3x3 block): flat offsets of the cell boundaries of
-    // every run, and the boundaries of the query cells themselves
-    __shared__ unsigned cell_off[9][SELF_SEG + 3], qb[SELF_SEG + 1];
-    if (threadIdx.x < 9 * (SELF_SEG + 3)) {
-        const int r = (int)threadIdx.x / (SELF_SEG + 3), j = (int)threadIdx.x % (SELF_SEG + 3);
-        const int yy = y + r % 3 - 1, zz = z + r / 3 - 1;
-        unsigned off = run_p[r];
-        if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
-            const int lo = max(x0 - 1, 0), hi = min(x1, g.nx - 1) + 1; // the run's own extent, as row_run clipped it
-            const int xx = min(max(x0 - 1 + j, lo), hi);
-            off = run_p[r] + (cs[(zz * g.ny + yy) * g.nx + xx] - run_s[r]);
-        }
-        cell_off[r][j] = off;
-    }
-    if (threadIdx.x <= SELF_SEG) qb[threadIdx.x] = cs[qbase + min(x0 + (int)threadIdx.x, x1)];
-    __syncthreads();
-
-    const unsigned ncand = run_p[9];
-#ifdef ICPMI_SELF_WORK_DIAG
-    if (threadIdx.x == 0) atomicAdd(&st->dbg[23], (unsigned long long)(qe - qs) * (unsigned long long)ncand); // (one address: costs 0.2 ms on 30 k segments)
-#endif
-    for (unsigned q0 = qs; q0 < qe; q0 += SELF_BLOCK) { // one wave of queries at a time (one pass for all but dense cells)
-        const unsigned qi = q0 + threadIdx.x;
-        const bool active = qi < qe;
-        const float4 me = map[active ? qi : qs];
-        int cxl = 0; // the query's cell within the segment
-#pragma unroll
-        for (int j = 1; j < SELF_SEG; ++j) cxl += qi >= qb[j] ? 1 : 0;
-        KList<KMAX> L; L.init(k);
-        for (unsigned c0 = 0; c0 < ncand; c0 += SELF_CH) {
-            const unsigned cn = min((unsigned)SELF_CH, ncand - c0);
-            __syncthreads(); // previous chunk fully consumed
-            for (unsigned i = threadIdx.x; i < cn; i += SELF_BLOCK) {
-                const unsigned f = c0 + i; // flat candidate -> run
-                int r = 0;
-#pragma unroll
-                for (int j = 1; j < 9; ++j) r = f >= run_p[j] ? j : r;
-                tile[i] = map[run_s[r] + (f - run_p[r])];
-            }
-            __syncthreads();
-            if (active) {
-                // A candidate that beats the lane's k-th best is only QUEUED (its tile slot, 2 bytes in LDS); the sorted insertion --
-                // ~70 instructions the whole wave pays whenever any one lane inserts, which is at nearly every candidate -- runs
-                // for all lanes together when some lane's queue is full and at the end of the chunk.  The bound is a little stale
-                // while a queue fills (a few more candidates get queued); the k best of the same candidate set come out.
-                int qn = 0;
-                auto drain = [&]() {
-                    for (int t = 0; t < SELF_Q; ++t) {
-                        if (__ballot(t < qn) == 0ull) break;
-                        if (t < qn) {
-                            const unsigned ti = qslot[t][threadIdx.x];
-                            const float4 q = tile[ti];
-                            const float d2 = sqdist3(me.x, me.y, me.z, q.x, q.y, q.z);
-                            L.insert(pack_key(d2, __float_as_uint(q.w)), (int)(c0 + ti)); // flat index; turned into a map position below
-                        }
-                    }
-                    qn = 0;
-                };
-                for (int r = 0; r < 9; ++r) {
-                    const unsigned lo = max(cell_off[r][cxl], c0), hi = min(cell_off[r][cxl + 3], c0 + cn);
-                    for (unsigned i = lo; i < hi; ++i) {
-                        const float4 q = tile[i - c0];
-                        const float d2 = sqdist3(me.x, me.y, me.z, q.x, q.y, q.z);
-                        if (pack_key(d2, __float_as_uint(q.w)) < L.worst()) { qslot[qn][threadIdx.x] = (unsigned short)(i - c0); ++qn; }
-                        if (__ballot(qn == SELF_Q) != 0ull) drain();
-                    }
-                }
-                drain();
-            }
-        }
-        if (!active) continue;
-        // exactness: the staged region contains the query's own 3x3x3 block; points outside the region may be
-        // nearer than the k-th candidate only if that one lies beyond the query's margin to the region
-        const float fx = (me.x - g.ox) * g.inv_cell, fy = (me.y - g.oy) * g.inv_cell, fz = (me.z - g.oz) * g.inv_cell;
-        const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
-        float mf = fminf(fx - flx, 1.0f - (fx - flx));
-        mf = fminf(mf, fminf(fy - fly, 1.0f - (fy - fly)));
-        mf = fminf(mf, fminf(fz - flz, 1.0f - (fz - flz)));
-        if (!(mf >= 0.f)) mf = 0.f;
-        const float margin = fmaxf((1.0f + mf) * g.cell - g.slack, 0.f);
-        unsigned long long kth = ~0ull;
-#pragma unroll
-        for (int i = 0; i < KMAX; ++i) if (i == k - 1) kth = L.key[i];
-        const int cx = (int)fminf(fmaxf(flx, -1.0e6f), 1.0e6f);
-        const bool covers = cx - 1 <= 0 && cx + 1 >= g.nx - 1 && y - 1 <= 0 && y + 1 >= g.ny - 1 && z - 1 <= 0 && z + 1 >= g.nz - 1;
-        const bool decided = covers || (kth != ~0ull && __uint_as_float((unsigned)(kth >> 32)) <= margin * margin);
-        const unsigned orig = __float_as_uint(me.w);
-        if (decided) {
-#pragma unroll
-            for (int j = 0; j < KMAX; ++j)
-                if (j < k) {
-                    int pos = -1;
-                    if (L.sidx[j] >= 0) {
-                        const unsigned f = (unsigned)L.sidx[j];
-                        int r = 0;
-#pragma unroll
-                        for (int jj = 1; jj < 9; ++jj) r = f >= run_p[jj] ? jj : r;
-                        pos = (int)(run_s[r] + (f - run_p[r]));
-                    }
-                    out_sidx[(size_t)k * orig + j] = pos;
-                    out_d2[(size_t)k * orig + j] = pos < 0 ? INFINITY : __uint_as_float((unsigned)(L.key[j] >> 32));
-                }
-        } else {
-            const unsigned slot = atomicAdd(&st->hard_count, 1u); // reused as the length of the redo queue
-            queue[slot] = orig;
-        }
-    }
-}
-
-// The launch.  PERSIST = false: workgroup b takes segment b (a grid that is mostly occupied: the synthetic scenes, an indoor map).
-// PERSIST = true (r5): a fixed number of workgroups take batches of SELF_BATCH consecutive segments in turn, look at the batch's cell
-// starts with one lane each and work through the occupied ones -- the map of a vehicle's trajectory fills 0.3 % of its bounding grid
-// (BASELINE config 4: 5 000 of 377 000 segments), and a workgroup per segment spent 0.4 ms of the launch on starting and ending empty
-// workgroups.  (Batches drawn from a counter instead: every draw is an atomic on ONE address, 47 000 of them -- slower than what it
-// replaced.)  st->dbg[23] collects queries x staged candidates, a cost figure for diagnostics (the state is cleared in front of every self search).
-constexpr int SELF_BATCH = 64;
-template <int KMAX, int SELF_Q, bool PERSIST>
-__global__ __launch_bounds__(SELF_BLOCK) __attribute__((amdgpu_waves_per_eu(KMAX <= 10 ? 5 : 1))) void nnk_self_tiled_kernel(GridParams g, const float4* __restrict__ map,
-                                                                  const unsigned* __restrict__ cs, int k, int* __restrict__ out_sidx,
-                                                                  float* __restrict__ out_d2, IcpState* __restrict__ st,
-                                                                  unsigned* __restrict__ queue, unsigned nseg)
-{
-    if (!PERSIST) { self_tiled_segment<KMAX, SELF_Q>((int)blockIdx.x, g, map, cs, k, out_sidx, out_d2, st, queue); return; }
-    const int nsx = (g.nx + SELF_SEG - 1) / SELF_SEG;
-    // workgroup w owns the segments b = w (mod gridDim.x): neighbours along x -- occupied together where the map is -- go to
-    // different workgroups (64 CONSECUTIVE segments per workgroup put a wall's whole row on one wave: 2.5 x slower than no list at all)
-    for (unsigned i0 = 0; (unsigned long long)i0 * gridDim.x + blockIdx.x < nseg; i0 += SELF_BATCH) {
-        const unsigned long long bl = (unsigned long long)(i0 + threadIdx.x) * gridDim.x + blockIdx.x;
-        bool occupied = false;
-        if (bl < nseg) {
-            const int b = (int)bl;
-            const int sx = b % nsx, y = (b / nsx) % g.ny, z = b / (nsx * g.ny);
-            const int x0 = sx * SELF_SEG, x1 = min(x0 + SELF_SEG, g.nx);
-            const int qbase = (z * g.ny + y) * g.nx;
-            occupied = cs[qbase + x1] > cs[qbase + x0];
-        }
-        unsigned long long mask = __ballot(occupied);
-        while (mask) {
-            const int l = __ffsll((long long)mask) - 1;
-            mask &= mask - 1ull;
-            self_tiled_segment<KMAX, SELF_Q>((int)((i0 + (unsigned)l) * gridDim.x + blockIdx.x), g, map, cs, k, out_sidx, out_d2, st, queue);
-            __syncthreads();
-        }
-    }
-}
-
-// Redo of the tiled self-search's left-overs (k-th neighbour beyond the staged block: sparse regions, map border), one
-// WAVE per query: the rows of ring R are dealt to the lanes, every lane keeps the KMAX best of its rows, and after each
-// ring the wave merges them (KMAX rounds of "extract the wave minimum") into a list replicated in all lanes.  Same
-// rings, same decision rule and same (d^2, index) order as nnk_kernel -- which ran these queries one lane each, and
-// whose slowest lane (a few thousand candidates, serially) set the duration of the whole pass.
-template <int KMAX>
-__global__ __launch_bounds__(64) void nnk_wave_kernel(const float4* __restrict__ reading, GridParams g, const float4* __restrict__ map,
-                                                      const unsigned* __restrict__ cs, int k, float maxr2, int ring_max, int allow_self,
-                                                      int* __restrict__ out_sidx, float* __restrict__ out_d2, IcpState* __restrict__ st,
-                                                      unsigned* __restrict__ hard, const unsigned* __restrict__ only,
-                                                      const unsigned* __restrict__ only_count)
-{
-    if (st && st->done) return;
-    const int lane = threadIdx.x;
-    const int count = (int)*only_count;
-    for (int w = blockIdx.x; w < count; w += gridDim.x) {
-        const int qi = (int)only[w];
-        const float4 r = reading[qi];
-        const float3 p = make_float3(r.x, r.y, r.z);
-        const float fx = (p.x - g.ox) * g.inv_cell, fy = (p.y - g.oy) * g.inv_cell, fz = (p.z - g.oz) * g.inv_cell;
-        const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
-        const int cx = (int)fminf(fmaxf(flx, -1.0e6f), 1.0e6f);
-        const int cy = (int)fminf(fmaxf(fly, -1.0e6f), 1.0e6f);
-        const int cz = (int)fminf(fmaxf(flz, -1.0e6f), 1.0e6f);
-        float mf = fminf(fx - flx, 1.0f - (fx - flx));
-        mf = fminf(mf, fminf(fy - fly, 1.0f - (fy - fly)));
-        mf = fminf(mf, fminf(fz - flz, 1.0f - (fz - flz)));
-        if (!(mf >= 0.f)) mf = 0.f;
-
-        KList<KMAX> Gl; Gl.init(k); // the k best so far, replicated in every lane
-        bool decided = false;
-        int ring = 0;
-        while (!decided && ring < ring_max) {
-            ++ring;
-            const int side = 2 * ring + 1;
-            KList<KMAX> Lc; Lc.init(k); // this lane's share of the ring
-            unsigned long long gkth = ~0ull; // the k-th key of the rings before this one (all lanes hold the same list)
-#pragma unroll
-            for (int i = 0; i < KMAX; ++i) if (i == k - 1) gkth = Gl.key[i];
-            // r5: rows to the lanes for their BOUNDS only (one trip for 64 rows); the candidates of the non-empty runs are then dealt to
-            // the lanes 64 at a time, four runs in flight.  (Until r5 a lane scanned its whole row: in ring 1 nine lanes walked ~40 points
-            // each, four per trip, while 55 idled -- 50 us for the ~200 queries the tiled pass leaves.)  Same candidates; a k-list does
-            // not depend on the order they arrive in, nor on the lane that holds them before the merge.
-            for (int base = 0; base < side * side; base += 64) {
-                unsigned rs[2] = {0u, 0u}, re[2] = {0u, 0u};
-                const int r0 = base + lane;
-                if (r0 < side * side) {
-                    const int dy = r0 % side - ring, dz = r0 / side - ring;
-                    const bool full_row = ring == 1 || (dy == -ring || dy == ring || dz == -ring || dz == ring);
-                    if (full_row) row_run(g, cs, cx - ring, cx + ring, cy + dy, cz + dz, rs[0], re[0]);
-                    else {
-                        if (cx - ring >= 0) row_run(g, cs, cx - ring, cx - ring, cy + dy, cz + dz, rs[0], re[0]);
-                        if (cx + ring <= g.nx - 1) row_run(g, cs, cx + ring, cx + ring, cy + dy, cz + dz, rs[1], re[1]);
-                    }
-                }
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    unsigned long long mask = __ballot(re[half] > rs[half]);
-                    while (mask) {
-                        unsigned bs[4], be[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            bs[u] = be[u] = 0u;
-                            if (mask) {
-                                const int l = __ffsll((long long)mask) - 1;
-                                mask &= mask - 1ull;
-                                bs[u] = (unsigned)__shfl((int)rs[half], l, 64);
-                                be[u] = (unsigned)__shfl((int)re[half], l, 64);
-                            }
-                        }
-                        bool more = true;
-                        for (unsigned off = 0; more; off += 64u) { // (uniform)
-                            float4 q[4];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) { const unsigned i = bs[u] + off + (unsigned)lane; q[u] = map[i < be[u] ? i : bs[u]]; }
-                            more = false;
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const unsigned i = bs[u] + off + (unsigned)lane;
-                                if (i < be[u]) {
-                                    const float d2 = sqdist3(p.x, p.y, p.z, q[u].x, q[u].y, q[u].z);
-                                    // (r5) a candidate that does not beat the k-th of the rings before it never reaches the answer: it stays out
-                                    // of the lane's list, and a ring that adds nothing skips its merge (ring_empty below)
-                                    const unsigned long long key = pack_key(d2, __float_as_uint(q[u].w));
-                                    if ((allow_self || d2 > 1.1920929e-07f) && key < gkth) Lc.insert(key, (int)i);
-                                }
-                                more |= bs[u] + off + 64u < be[u];
-                            }
-                        }
-                    }
-                }
-            }
-            // merge: lane 0 also holds what the earlier rings found (shells are disjoint: no point is seen twice).  A ring in which no
-            // lane found a candidate leaves the list as it is.
-            const bool ring_empty = __ballot(Lc.key[0] != ~0ull) == 0ull;
-            if (lane == 0 && !ring_empty) {
-#pragma unroll
-                for (int j = 0; j < KMAX; ++j) Lc.insert(Gl.key[j], Gl.sidx[j]);
-            }
-#pragma unroll
-            for (int j = 0; j < KMAX; ++j) {
-                if (ring_empty) break;
-                const unsigned long long head = Lc.key[0];
-                unsigned long long mk = head;
-                int ms = Lc.sidx[0];
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    const unsigned long long ok = __shfl_xor(mk, off, 64);
-                    const int os = __shfl_xor(ms, off, 64);
-                    if (ok < mk) { mk = ok; ms = os; }
-                }
-                Gl.key[j] = mk; Gl.sidx[j] = ms;
-                if (head == mk && mk != ~0ull) { // keys are unique: exactly one lane gives up its head
-#pragma unroll
-                    for (int i = 0; i + 1 < KMAX; ++i) { Lc.key[i] = Lc.key[i + 1]; Lc.sidx[i] = Lc.sidx[i + 1]; }
-                    Lc.key[KMAX - 1] = ~0ull; Lc.sidx[KMAX - 1] = -1;
-                }
-            }
-            const float margin = fmaxf(((float)ring + mf) * g.cell - g.slack, 0.f);
-            const float m2 = margin * margin;
-            unsigned long long kth = ~0ull;
-#pragma unroll
-            for (int i = 0; i < KMAX; ++i) if (i == k - 1) kth = Gl.key[i];
-            const float kd2 = __uint_as_float((unsigned)(kth >> 32));
-            const bool covers = cx - ring <= 0 && cx + ring >= g.nx - 1 && cy - ring <= 0 && cy + ring >= g.ny - 1 &&
-                                cz - ring <= 0 && cz + ring >= g.nz - 1;
-            decided = (kth != ~0ull && kd2 <= m2) || m2 > maxr2 || covers;
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int j = 0; j < KMAX; ++j)
-                if (j < k) {
-                    float d2 = __uint_as_float((unsigned)(Gl.key[j] >> 32));
-                    int sx = Gl.sidx[j];
-                    if (sx < 0 || !(d2 <= maxr2)) { sx = -1; d2 = INFINITY; }
-                    out_sidx[(size_t)k * qi + j] = sx;
-                    out_d2[(size_t)k * qi + j] = d2;
-                }
-            if (!decided) {
-                const unsigned slot = atomicAdd(&st->hard_count, 1u);
-                hard[slot] = (unsigned)qi;
-            }
-        }
-    }
-}
-
-// between the tiled self-search and its redo: queue length -> queue[m + 1] (read by the ring kernel as `only_count`),
-// hard_count reset so that the ring kernel can queue its own left-overs for the brute-force pass
-__global__ void nnk_redo_kernel(IcpState* st, unsigned* len_slot, unsigned long long* sq_dev, unsigned long long* sq_mapped)
-{
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        *len_slot = st->hard_count; st->hard_count = 0;
-        // sum of squared cell counts of this index (sq_counts_kernel at its build): to the host-mapped page, where the NEXT build of the
-        // index reads it (map_build.hip); the device word is handed back clean
-        if (sq_dev && sq_mapped) { *sq_mapped = *sq_dev; *sq_dev = 0ull; }
-    }
-}
-
 } // namespace
 
 void nn_launch_hard_k1(icpmi_ctx* c, const float4* d_reading, const float* d_T, const LoopCfg& lc, int allow_self, int* d_sidx,
@@ -2668,101 +2323,6 @@ icpmi_status nn_launch_k(icpmi_ctx* c, const float4* d_reading, int64_t n, const
     if (lc.k <= 8) return nnk_launch_t<8>(c, d_reading, n, d_T, lc, allow_self, d_sidx, d_d2, d_state);
     if (lc.k <= 16) return nnk_launch_t<16>(c, d_reading, n, d_T, lc, allow_self, d_sidx, d_d2, d_state);
     if (lc.k <= 32) return nnk_launch_t<32>(c, d_reading, n, d_T, lc, allow_self, d_sidx, d_d2, d_state);
-    c->last_error = "knn > 32 is not supported";
-    return ICPMI_ERR_UNSUPPORTED;
-}
-
-template <int KMAX>
-static icpmi_status nn_self_knn_t(icpmi_ctx* c, const float4* d_cloud, const LoopCfg& lc, int* d_sidx, float* d_d2, IcpState* d_state)
-{
-    const GridParams& g = c->grid;
-    const int nsx = (g.nx + SELF_SEG - 1) / SELF_SEG;
-    const long long wgs = (long long)nsx * g.ny * g.nz;
-    if (wgs > 0x7fffffffll) { c->last_error = "self knn: grid too large"; return ICPMI_ERR_UNSUPPORTED; }
-    static int self_q = -1; // candidates a lane queues before the wave inserts them (nnk_self_tiled_kernel)
-    if (self_q < 0) { const char* e = getenv("ICPMI_SELF_Q"); self_q = e ? atoi(e) : 8; }
-    // a grid whose segments are mostly empty is worked through by a fixed number of workgroups (see the kernel); the occupancy is the
-    // one this index was built with (h_nocc: written by the build's scan, long arrived)
-    static int persist_cfg = -1; // ICPMI_SELF_PERSIST: 0 never, 1 always, default: by occupancy
-    if (persist_cfg < 0) { const char* e = getenv("ICPMI_SELF_PERSIST"); persist_cfg = e ? atoi(e) : 2; }
-    const double occupied_cells = c->h_nocc && *c->h_nocc ? (double)*c->h_nocc : (double)g.ncells;
-    const bool persist = persist_cfg == 1 || (persist_cfg == 2 && occupied_cells * 32.0 < (double)g.ncells);
-    const unsigned pgrid = (unsigned)std::min<long long>(wgs, 8192);
-#define LAUNCH_SELF(Q_) do { \
-        if (persist) hipLaunchKernelGGL((nnk_self_tiled_kernel<KMAX, Q_, true>), dim3(pgrid), dim3(SELF_BLOCK), 0, c->stream, g, c->d_map_sorted, \
-                                        c->d_cell_start, lc.k, d_sidx, d_d2, d_state, c->d_hard, (unsigned)wgs); \
-        else hipLaunchKernelGGL((nnk_self_tiled_kernel<KMAX, Q_, false>), dim3((unsigned)wgs), dim3(SELF_BLOCK), 0, c->stream, g, c->d_map_sorted, \
-                                c->d_cell_start, lc.k, d_sidx, d_d2, d_state, c->d_hard, (unsigned)wgs); } while (0)
-    if (self_q <= 1) LAUNCH_SELF(1); else if (self_q <= 4) LAUNCH_SELF(4); else if (self_q <= 8) LAUNCH_SELF(8); else LAUNCH_SELF(16);
-#undef LAUNCH_SELF
-    // left-overs (k-th neighbour beyond the margin: sparse regions, map border): ring search, then brute force
-    const int blocks = (int)((c->m + NN_BLOCK - 1) / NN_BLOCK);
-    const bool sq_ready = c->d_progress && c->d_selfsq && c->selfsq_m == c->m; // (the build of THIS index left its sum in d_selfsq)
-    hipLaunchKernelGGL(nnk_redo_kernel, dim3(1), dim3(64), 0, c->stream, d_state, c->d_hard + c->m + 1, sq_ready ? c->d_selfsq : (unsigned long long*)nullptr,
-                       sq_ready ? reinterpret_cast<unsigned long long*>(c->d_progress + ICPMI_PROGRESS_SELF_WORD) : (unsigned long long*)nullptr);
-    if (sq_ready) { c->self_sq_m = c->m; c->selfsq_dirty = false; }
-    static int wave_redo = -1;
-    if (wave_redo < 0) { const char* e = getenv("ICPMI_SELF_REDO_WAVE"); wave_redo = e ? atoi(e) : 1; }
-    if (wave_redo)
-        hipLaunchKernelGGL(nnk_wave_kernel<KMAX>, dim3(4096), dim3(64), 0, c->stream, d_cloud, g, c->d_map_sorted, c->d_cell_start, lc.k,
-                           lc.maxr2, lc.ring_max, 1, d_sidx, d_d2, d_state, c->d_hard + c->m + 2, (const unsigned*)c->d_hard,
-                           (const unsigned*)(c->d_hard + c->m + 1));
-    else
-        hipLaunchKernelGGL(nnk_kernel<KMAX>, dim3(blocks), dim3(NN_BLOCK), 0, c->stream, d_cloud, (int)c->m, (const float*)nullptr, g,
-                           c->d_map_sorted, c->d_cell_start, lc.k, lc.maxr2, lc.ring_max, 1, d_sidx, d_d2, d_state,
-                           c->d_hard + c->m + 2, (const unsigned*)c->d_hard, (const unsigned*)(c->d_hard + c->m + 1));
-    static int diag = -1; // ICPMI_SELF_DIAG=1: how many queries the tiled pass left to the ring kernel, and that one to the brute pass (read-backs: diagnostic only)
-    if (diag < 0) { const char* e = getenv("ICPMI_SELF_DIAG"); diag = e ? atoi(e) : 0; }
-    unsigned diag_brute = 0;
-    if (diag) read_back(c, &diag_brute, &d_state->hard_count, sizeof(unsigned));
-    // the brute pass of what the rings left undecided: one workgroup per query streams the map (BASELINE config 4, a lidar map's sparse
-    // periphery: 6 - 8 % of the points go to the ring kernel, 400 - 500 of 100 k on to here; ICPMI_SELF_HARD_GRID: no effect measured)
-    static int hard_grid = -1;
-    if (hard_grid < 0) { const char* e = getenv("ICPMI_SELF_HARD_GRID"); hard_grid = e ? atoi(e) : 512; if (hard_grid < 1) hard_grid = 512; }
-    hipLaunchKernelGGL(nnk_hard_kernel<KMAX>, dim3(hard_grid), dim3(NN_BLOCK), 0, c->stream, d_cloud, (const float*)nullptr, c->d_map_sorted,
-                       (int)c->m, lc.k, lc.maxr2, 1, d_sidx, d_d2, d_state, (const unsigned*)(c->d_hard + c->m + 2));
-    hipLaunchKernelGGL(hard_reset_kernel, dim3(1), dim3(64), 0, c->stream, d_state);
-    HIP_TRY(c, hipGetLastError());
-    {
-        if (diag) {
-            unsigned left = 0;
-            if (read_back(c, &left, c->d_hard + c->m + 1, sizeof(unsigned)) == ICPMI_OK)
-                fprintf(stderr, "[icpmi self-knn] m %lld k %d: %u queries (%.2f %%) redone by the ring kernel, %u by the brute pass (ring_max %d, cell %.3f)\n", (long long)c->m, lc.k, left, 100.0 * left / (double)c->m, diag_brute, lc.ring_max, (double)g.cell);
-#ifdef ICPMI_SELF_WORK_DIAG
-            {
-                unsigned long long work = 0;
-                if (hipMemcpy(&work, &d_state->dbg[23], sizeof work, hipMemcpyDeviceToHost) == hipSuccess)
-                    fprintf(stderr, "[icpmi self-knn] staged candidates per query: %.1f\n", (double)work / (double)c->m);
-            }
-#endif
-            if (diag > 1) { // the shape of the grid the tiled pass was launched over
-                std::vector<unsigned> cs((size_t)g.ncells + 1);
-                if (hipMemcpy(cs.data(), c->d_cell_start, cs.size() * sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess) {
-                    unsigned occ = 0, mx = 0, seg_occ = 0, seg_mx = 0; unsigned long long sq = 0;
-                    for (int i = 0; i < g.ncells; ++i) { const unsigned n1 = cs[i + 1] - cs[i]; occ += n1 > 0; mx = n1 > mx ? n1 : mx; sq += (unsigned long long)n1 * n1; }
-                    for (int z = 0; z < g.nz; ++z) for (int y = 0; y < g.ny; ++y) for (int x = 0; x < g.nx; x += SELF_SEG) {
-                        const int b = (z * g.ny + y) * g.nx; const int x1 = x + SELF_SEG < g.nx ? x + SELF_SEG : g.nx;
-                        const unsigned n1 = cs[b + x1] - cs[b + x]; seg_occ += n1 > 0; seg_mx = n1 > seg_mx ? n1 : seg_mx;
-                    }
-                    fprintf(stderr, "[icpmi self-knn] grid %d x %d x %d = %d cells (edge %.3f), %u occupied, max %u per cell, size-biased mean %.1f; %lld segments, %u occupied, max %u\n",
-                            g.nx, g.ny, g.nz, g.ncells, g.cell, occ, mx, (double)sq / (double)c->m, (long long)wgs, seg_occ, seg_mx);
-                }
-            }
-        }
-    }
-    return ICPMI_OK;
-}
-
-// self k-NN of the indexed cloud: d_cloud is that cloud in its original order and in the frame of the index (for the redo passes),
-// c->d_hard at least 2 m + 4 words
-icpmi_status nn_self_knn(icpmi_ctx* c, const float4* d_cloud, const LoopCfg& lc, int* d_sidx, float* d_d2, IcpState* d_state)
-{
-    if (lc.k <= 4) return nn_self_knn_t<4>(c, d_cloud, lc, d_sidx, d_d2, d_state);
-    if (lc.k <= 8) return nn_self_knn_t<8>(c, d_cloud, lc, d_sidx, d_d2, d_state);
-    // knn 10 is the shipped post filter (examples/config.yaml:26-27): a list of exactly 10 inserts less often and cheaper than one of 16
-    if (lc.k <= 10) return nn_self_knn_t<10>(c, d_cloud, lc, d_sidx, d_d2, d_state);
-    if (lc.k <= 16) return nn_self_knn_t<16>(c, d_cloud, lc, d_sidx, d_d2, d_state);
-    if (lc.k <= 32) return nn_self_knn_t<32>(c, d_cloud, lc, d_sidx, d_d2, d_state);
     c->last_error = "knn > 32 is not supported";
     return ICPMI_ERR_UNSUPPORTED;
 }

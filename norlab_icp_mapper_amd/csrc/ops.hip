@@ -624,12 +624,6 @@ static void share_stream(icpmi_ctx* c, icpmi_ctx* t)
     (void)zero_state_if_pending(t); // (on the owner's stream; an error surfaces at the handle's next call)
 }
 
-static bool self_grid_on()
-{
-    static const int on = [] { const char* e = getenv("ICPMI_SELF_GRID"); return e ? atoi(e) : 1; }();
-    return on != 0;
-}
-
 static icpmi_status make_temp(icpmi_ctx* c, TempCtx& t)
 {
     if (!c->temp) {
@@ -789,10 +783,8 @@ static icpmi_status temp_knn(icpmi_ctx* c, TempCtx& t, const float* cloud4, int6
                              int allow_self, bool queries_are_cloud)
 {
     icpmi_ctx* tc = t.h;
-    static int tiled = -1;
-    if (tiled < 0) { const char* e = getenv("ICPMI_SELF_KNN_TILED"); tiled = e ? atoi(e) : 1; }
-    const bool self = queries_are_cloud && allow_self && tiled; // SurfaceNormalDataPointsFilter: the cloud against itself
-    if (self && self_grid_on()) { // r6: the sparse block grid (selfgrid.hip)
+    const bool self = queries_are_cloud && allow_self; // SurfaceNormalDataPointsFilter: the cloud against itself -- the sparse block grid (selfgrid.hip)
+    if (self) {
         if (m <= 0 || !cloud4) { c->last_error = "set_map: empty cloud"; return ICPMI_ERR_INVALID_ARG; }
         const size_t cnt = (size_t)m * k + 1;
         if (ensure_cap(tc, &tc->d_stage_in, &tc->cap_stage_in, (size_t)m + 1) != ICPMI_OK || ensure_cap(tc, &tc->d_sidx, &tc->cap_sidx, cnt) != ICPMI_OK ||
@@ -802,7 +794,7 @@ static icpmi_status temp_knn(icpmi_ctx* c, TempCtx& t, const float* cloud4, int6
         if (gs != ICPMI_OK) c->last_error = tc->last_error;
         return gs;
     }
-    tc->single_level = self;
+    tc->single_level = false;
     int32_t acc = 0;
     icpmi_status s = icpmi_set_map(t.h, cloud4, m, nullptr, &acc);
     if (s != ICPMI_OK) { c->last_error = tc->last_error; return s; }
@@ -813,9 +805,7 @@ static icpmi_status temp_knn(icpmi_ctx* c, TempCtx& t, const float* cloud4, int6
         if (ensure_cap(tc, &tc->d_stage_in, &tc->cap_stage_in, (size_t)n + 1) != ICPMI_OK) { c->last_error = tc->last_error; return ICPMI_ERR_HIP; }
         HIP_TRY(c, hipMemcpyAsync(tc->d_stage_in, q4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, tc->stream));
     }
-    if (self) s = ICPMI_OK; // the redo passes read the staged cloud in its own order; no tile sort, no copy
-    else
-        s = loop_prepare_reading(tc, tc->d_stage_in, n, nullptr);
+    s = loop_prepare_reading(tc, tc->d_stage_in, n, nullptr);
     if (s != ICPMI_OK) { c->last_error = tc->last_error; return s; }
     LoopCfg lc = make_loop_cfg(tc, 1);
     lc.k = k; lc.max_dist = INFINITY; lc.maxr2 = INFINITY; lc.ring_max = 6;
@@ -824,11 +814,7 @@ static icpmi_status temp_knn(icpmi_ctx* c, TempCtx& t, const float* cloud4, int6
         ensure_cap(tc, &tc->d_hard, &tc->cap_hard, (size_t)n + 1) != ICPMI_OK) { c->last_error = tc->last_error; return ICPMI_ERR_HIP; }
     HIP_TRY(c, hipMemsetAsync(tc->d_state, 0, sizeof(IcpState), tc->stream));
     tc->nn_hist0 = nullptr; tc->nn_iter_hint = 0; tc->nn_match_pt = nullptr;
-    if (self) {
-        if (ensure_cap(tc, &tc->d_hard, &tc->cap_hard, (size_t)2 * m + 8) != ICPMI_OK) { c->last_error = tc->last_error; return ICPMI_ERR_HIP; }
-        s = nn_self_knn(tc, tc->d_stage_in, lc, tc->d_sidx, tc->d_d2, tc->d_state);
-    } else
-        s = nn_launch_k(tc, tc->d_reading, n, nullptr, lc, allow_self, tc->d_sidx, tc->d_d2, tc->d_state);
+    s = nn_launch_k(tc, tc->d_reading, n, nullptr, lc, allow_self, tc->d_sidx, tc->d_d2, tc->d_state);
     if (s != ICPMI_OK) { c->last_error = tc->last_error; return s; }
     return ICPMI_OK;
 }
@@ -1023,30 +1009,10 @@ static icpmi_status surface_normals_dev(icpmi_ctx* c, const float4* d_pts, int64
     if (s != ICPMI_OK) return s;
     icpmi_ctx* tc = t.h;
     if (tc->stream != c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream)); // d_pts was produced on the caller's stream
-    if (self_grid_on()) { // r6: the sparse block grid (selfgrid.hip) -- index and search in one call
-        const size_t cnt = (size_t)m * knn + 1;
-        if (ensure_cap(tc, &tc->d_sidx, &tc->cap_sidx, cnt) != ICPMI_OK || ensure_cap(tc, &tc->d_d2, &tc->cap_d2, cnt) != ICPMI_OK) { c->last_error = tc->last_error; return ICPMI_ERR_HIP; }
-        s = selfgrid_knn(tc, d_pts, m, knn, tc->d_sidx, tc->d_d2);
-        if (s != ICPMI_OK) { c->last_error = tc->last_error; return s; }
-        launch_normals(tc->stream, tc->d_map_sorted, tc->d_sidx, m, knn, d_normals3, (float*)nullptr, c->cfg.is_2d);
-        HIP_TRY(c, hipGetLastError());
-        if (tc->stream != c->stream) HIP_TRY(c, hipStreamSynchronize(tc->stream));
-        return ICPMI_OK;
-    }
-    tc->single_level = true;
-    int32_t acc = 0;
-    s = icpmi_set_map_dev(t.h, (const float*)d_pts, m, nullptr, &acc);
-    if (s != ICPMI_OK) { c->last_error = tc->last_error; return s; }
-    LoopCfg lc = make_loop_cfg(tc, 1);
-    lc.k = knn; lc.max_dist = INFINITY; lc.maxr2 = INFINITY; lc.ring_max = 6;
-    { static int rm = -1; if (rm < 0) { const char* e = getenv("ICPMI_SELF_RING_MAX"); rm = e ? atoi(e) : 6; if (rm < 1) rm = 6; } lc.ring_max = rm; }
+    // r6: the sparse block grid (selfgrid.hip) -- index and search in one call
     const size_t cnt = (size_t)m * knn + 1;
-    if (ensure_cap(tc, &tc->d_sidx, &tc->cap_sidx, cnt) != ICPMI_OK || ensure_cap(tc, &tc->d_d2, &tc->cap_d2, cnt) != ICPMI_OK ||
-        ensure_cap(tc, &tc->d_hard, &tc->cap_hard, (size_t)m + 1) != ICPMI_OK) { c->last_error = tc->last_error; return ICPMI_ERR_HIP; }
-    HIP_TRY(c, hipMemsetAsync(tc->d_state, 0, sizeof(IcpState), tc->stream));
-    tc->nn_hist0 = nullptr; tc->nn_iter_hint = 0; tc->nn_match_pt = nullptr;
-    if (ensure_cap(tc, &tc->d_hard, &tc->cap_hard, (size_t)2 * m + 8) != ICPMI_OK) { c->last_error = tc->last_error; return ICPMI_ERR_HIP; }
-    s = nn_self_knn(tc, d_pts, lc, tc->d_sidx, tc->d_d2, tc->d_state);
+    if (ensure_cap(tc, &tc->d_sidx, &tc->cap_sidx, cnt) != ICPMI_OK || ensure_cap(tc, &tc->d_d2, &tc->cap_d2, cnt) != ICPMI_OK) { c->last_error = tc->last_error; return ICPMI_ERR_HIP; }
+    s = selfgrid_knn(tc, d_pts, m, knn, tc->d_sidx, tc->d_d2);
     if (s != ICPMI_OK) { c->last_error = tc->last_error; return s; }
     // rows of d_sidx follow the query order = the caller's order, so the normals land in place
     launch_normals(tc->stream, tc->d_map_sorted, tc->d_sidx, m, knn, d_normals3, (float*)nullptr, c->cfg.is_2d);
