@@ -4,6 +4,8 @@
 // need librccl.so at all, and the library binds to whichever copy the process already holds (PyTorch ships one).
 #include "common.h"
 
+#include <vector>
+
 #include <cstdio>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -138,6 +140,7 @@ icpmi_status merge_blocks_reserve(icpmi_ctx* c, int n_ranks)
     { const char* e = getenv("ICPMI_MERGE_BLOCK"); if (e) block_cfg = atoll(e); if (block_cfg < 0) block_cfg = 0; }
     c->merge_block = 0;
     if (block_cfg == 0) return ICPMI_OK;
+    if (n_ranks > 256) return ICPMI_OK; // (the R block headers arrive in 256 words of the host-mapped page, common.h: ICPMI_PROGRESS_HDR_WORD -- larger jobs keep the three-collective epoch)
     const size_t b4 = (size_t)block_cfg + 1;
     if (b4 * (size_t)n_ranks >= (1ull << 31)) return ICPMI_OK; // (the merge indexes the gathered span with 31 bits: such a job keeps the old epoch)
     if (ensure_cap(c, &c->d_merge_send, &c->cap_merge_send, b4 + 1) != ICPMI_OK) return ICPMI_ERR_HIP;
@@ -178,6 +181,18 @@ icpmi_status comm_init(icpmi_ctx* c, const icpmi_comm_id* id, int n_ranks, int r
     ncclComm_t comm = nullptr;
     RCCL_TRY(c, r.CommInitRank(&comm, n_ranks, u, rank));
     c->comm = comm; c->comm_ranks = n_ranks; c->comm_rank = rank; c->comm_loop_shift = 0.f; c->comm_loop_ragged = false;
+    // The block size of the one-collective epoch must be the same on every rank (ICPMI_MERGE_BLOCK is read per rank; an all-gather of blocks of
+    // different sizes is undefined): gathered once, here, where every rank is inside comm_init anyway.  "All equal" is the same verdict on
+    // every rank; otherwise every rank keeps the three-collective epoch.
+    if (n_ranks > 1) {
+        long long mine = (long long)c->merge_block;
+        { const icpmi_status us = upload_small(c, c->d_comm_cnt, &mine, sizeof mine); if (us != ICPMI_OK) return us; }
+        const icpmi_status gs = comm_allgather(c, c->d_comm_cnt, c->d_comm_cnt + 8, 1, false);
+        if (gs != ICPMI_OK) return gs;
+        std::vector<long long> all((size_t)n_ranks);
+        if (read_back(c, all.data(), c->d_comm_cnt + 8, all.size() * sizeof(long long)) != ICPMI_OK) return ICPMI_ERR_HIP;
+        for (long long v : all) if (v != mine) { c->merge_block = 0; break; }
+    }
     return ICPMI_OK;
 }
 

@@ -450,7 +450,7 @@ struct icpmi_ctx {
 
     // scratch for set_map
     unsigned* d_keys = nullptr; size_t cap_keys = 0;
-    int oct_depth_hint = 0; long oct_respeculated = 0; // octree.hip: tree depth of the previous call on this handle (the sort runs ahead of the depth's arrival), wrong guesses
+    int oct_depth_hint = 0, oct_tag = 0; long oct_respeculated = 0; // octree.hip: tree depth of the previous call on this handle (the sort runs ahead of the depth's arrival), wrong guesses
     unsigned* d_fill = nullptr; size_t cap_fill = 0; bool fill_clean = false; // the count table of the grid builds: zero between builds while fill_clean (map_build.hip: counts_begin)
     unsigned* d_blocksums = nullptr; size_t cap_blocksums = 0;
     double* d_red = nullptr; size_t cap_red = 0;

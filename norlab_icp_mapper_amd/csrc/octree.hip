@@ -47,7 +47,7 @@ __global__ __launch_bounds__(OB) void oct_bbox_kernel(const float4* __restrict__
 }
 
 __global__ __launch_bounds__(OB) void oct_root_kernel(const float* __restrict__ part, int nb, float max_size, OctRoot* __restrict__ root,
-                                                      OctRoot* __restrict__ root_host /* host-mapped copy, may be null */)
+                                                      OctRoot* __restrict__ root_host /* host-mapped copy, may be null */, int tag)
 {
     __shared__ float sl[3][OB], sh[3][OB];
     const int t = threadIdx.x;
@@ -69,7 +69,12 @@ __global__ __launch_bounds__(OB) void oct_root_kernel(const float* __restrict__ 
         float rad = radius;
         while (d < 21 && !(rad * 2.f <= max_size)) { rad *= 0.5f; ++d; } // the first depth whose edge is <= maxSizeByNode
         root->cx = c[0]; root->cy = c[1]; root->cz = c[2]; root->radius = radius; root->depth = d;
-        if (root_host) { root_host->cx = c[0]; root_host->cy = c[1]; root_host->cz = c[2]; root_host->radius = radius; root_host->depth = d; }
+        if (root_host) {
+            // the host reads the depth WITHOUT draining the stream (it spins on the count of a later scan): published with the call's tag behind a
+            // system-scope release, checked on the host (r6, ADVICE r5: a plain store was visible in practice, not by contract)
+            root_host->cx = c[0]; root_host->cy = c[1]; root_host->cz = c[2]; root_host->radius = radius; root_host->depth = d;
+            __hip_atomic_store(&root_host->pad[0], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -320,7 +325,8 @@ icpmi_status octree_sample_dev(icpmi_ctx* c, const float4* d_in, int64_t n, floa
     OctRoot* d_root_host = c->d_progress ? reinterpret_cast<OctRoot*>(c->d_progress + ICPMI_PROGRESS_OCT_WORD) : nullptr;
     const volatile OctRoot* h_root = c->h_progress ? reinterpret_cast<const volatile OctRoot*>(c->h_progress + ICPMI_PROGRESS_OCT_WORD) : nullptr;
     hipLaunchKernelGGL(oct_bbox_kernel, dim3(rb), dim3(OB), 0, c->stream, d_in, n, d_part);
-    hipLaunchKernelGGL(oct_root_kernel, dim3(1), dim3(OB), 0, c->stream, (const float*)d_part, rb, max_size, d_root, d_root_host);
+    const int root_tag = ++c->oct_tag ? c->oct_tag : ++c->oct_tag;
+    hipLaunchKernelGGL(oct_root_kernel, dim3(1), dim3(OB), 0, c->stream, (const float*)d_part, rb, max_size, d_root, d_root_host, root_tag);
     HIP_TRY(c, hipGetLastError());
     static int speculate = -1;
     if (speculate < 0) { const char* e = getenv("ICPMI_OCT_SPECULATE"); speculate = e ? atoi(e) : 1; }
@@ -344,9 +350,16 @@ icpmi_status octree_sample_dev(icpmi_ctx* c, const float4* d_in, int64_t n, floa
         }
         hipLaunchKernelGGL(oct_leaf_kernel, dim3(blocks), dim3(256), 0, c->stream, (const unsigned long long*)kb[cur], n, (const OctRoot*)d_root, max_pts,
                            d_flag);
-        const icpmi_status s = device_scan_flags_count(c, d_flag, d_ord, (int)n, &leaves); // (waits for the stream: the root has landed too)
+        const icpmi_status s = device_scan_flags_count(c, d_flag, d_ord, (int)n, &leaves); // (spins on the count's tag; the stream is NOT drained)
         if (s != ICPMI_OK) return s;
-        const int real_depth = h_root ? h_root->depth : depth;
+        int real_depth = depth;
+        if (h_root) {
+            // the root kernel ran long before the scan whose count just arrived; its tag says that its stores are visible here
+            bool seen = false;
+            for (int spins = 0; spins < (1 << 20) && !seen; ++spins) seen = __atomic_load_n(const_cast<const int*>(&h_root->pad[0]), __ATOMIC_ACQUIRE) == root_tag;
+            if (seen) real_depth = h_root->depth;
+            else { OctRoot root; if (read_back(c, &root, d_root, sizeof root) != ICPMI_OK) return ICPMI_ERR_HIP; real_depth = root.depth; }
+        }
         c->oct_depth_hint = real_depth;
         if (real_depth <= depth || attempt > 0) break; // (a guess that was too deep sorted on a few zero bits more: still the order of the paths)
         depth = real_depth; // the guess was too shallow: once more with the cube's own depth

@@ -616,7 +616,7 @@ static void share_stream(icpmi_ctx* c, icpmi_ctx* t)
 {
     static int on = -1;
     if (on < 0) { const char* e = getenv("ICPMI_SHARE_STREAM"); on = e ? atoi(e) : 1; }
-    if (!on || t->stream == c->stream) return;
+    if (!on || t->stream == c->stream) { (void)zero_state_if_pending(t); return; } // (a handle that keeps its own stream still starts from a cleared state: ADVICE r5)
     if (t->stream) (void)hipStreamSynchronize(t->stream);
     if (t->own_stream && t->stream) stream_release(t->stream);
     t->stream = c->stream; t->own_stream = false;
@@ -1422,6 +1422,9 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
     tick(nullptr, 0);
     static const bool overlap = [] { const char* e = getenv("ICPMI_CHAIN_OVERLAP"); return !e || atoi(e) != 0; }();
     bool forked = false;
+    // whatever path leaves this function between a fork and its join (an error return inside the operator loop): nothing may still be
+    // running on the side stream when the caller drops or reuses the arrays it works on
+    struct SideGuard { icpmi_ctx* c; bool* forked; ~SideGuard() { if (*forked && c->side) (void)hipStreamSynchronize(c->side); } } side_guard{c, &forked};
     auto join = [&]() -> icpmi_status { // the handle's stream waits for the module on the side stream
         if (!forked) return ICPMI_OK;
         forked = false;
@@ -1939,7 +1942,9 @@ static icpmi_status merge_epoch_one_collective(icpmi_ctx* c, const float correct
     }
     const std::string local_error = c->last_error;
     hipLaunchKernelGGL(merge_header_kernel, dim3(1), dim3(64), 0, c->stream, send, (const unsigned*)d_count, local == ICPMI_OK ? 1 : 0, fixed_count, fixed ? 1 : 0);
-    HIP_TRY(c, hipGetLastError());
+    // (collective discipline: nothing returns between here and the exchange -- a rank that left now would strand its peers inside the all-gather;
+    //  a launch that failed is reported after the collective, whose own error every rank sees)
+    const hipError_t header_launch = hipGetLastError();
     // ---- THE collective (a single rank without a communicator: its block is the gathered set)
     const float4* recv = send;
     if (c->comm || R > 1) {
@@ -1947,6 +1952,7 @@ static icpmi_status merge_epoch_one_collective(icpmi_ctx* c, const float correct
         if (s != ICPMI_OK) return s;
         recv = c->d_merge_recv;
     }
+    HIP_TRY(c, header_launch);
     // ---- the R counts: host-mapped words, one wait
     unsigned* d_hdr = c->d_progress + ICPMI_PROGRESS_HDR_WORD;
     volatile unsigned* h_hdr = c->h_progress + ICPMI_PROGRESS_HDR_WORD;
