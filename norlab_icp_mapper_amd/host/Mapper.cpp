@@ -14,22 +14,23 @@ namespace nim {
 
 void Trajectory::save(const std::string& filename) const
 {
-    // positions as features, rotation columns as orientationX/Y/Z, stamps as "t" (Trajectory.cpp:17-51;
-    // upstream stores the stamps in DataPoints::times, this cloud type carries them as a descriptor)
+    // positions as features, rotation columns as orientationX/Y/Z, stamps as the int64 time row "t" holding
+    // `time_since_epoch().count()` (Trajectory.cpp:15-53: DataPoints(features, labels, descriptors, labels, times, timeLabels))
     const size_t n = poses.size();
     DataPoints cloud(n);
-    std::vector<float> ox(3 * n), oy(3 * n), oz(3 * n), t(n);
+    std::vector<float> ox(3 * n), oy(3 * n), oz(3 * n);
+    std::vector<std::int64_t> t(n);
     for (size_t i = 0; i < n; ++i) {
         for (int r = 0; r < 3; ++r) {
             cloud.col(i)[r] = poses[i](r, 3);
             ox[3 * i + r] = poses[i](r, 0); oy[3 * i + r] = poses[i](r, 1); oz[3 * i + r] = poses[i](r, 2);
         }
-        t[i] = (float)std::chrono::duration<double>(stamps[i].time_since_epoch()).count();
+        t[i] = (std::int64_t)stamps[i].time_since_epoch().count();
     }
     cloud.addDescriptor("orientationX", 3, std::move(ox));
     cloud.addDescriptor("orientationY", 3, std::move(oy));
     if (dimension == 3) cloud.addDescriptor("orientationZ", 3, std::move(oz));
-    cloud.addDescriptor("t", 1, std::move(t));
+    cloud.addTime("t", 1, std::move(t));
     cloud.save(filename);
 }
 

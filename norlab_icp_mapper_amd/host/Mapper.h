@@ -18,7 +18,7 @@ namespace nim {
 using TimePoint = std::chrono::time_point<std::chrono::steady_clock>;
 
 // Trajectory.{h,cpp}: poses + steady_clock stamps; save() writes the positions as features and the
-// rotation columns as descriptors orientationX/Y/Z (+ times as a scalar descriptor "t")
+// rotation columns as descriptors orientationX/Y/Z, the stamps as the int64 time row "t" (Trajectory.cpp:35-47)
 class Trajectory {
 public:
     explicit Trajectory(int dimension = 3) : dimension(dimension) {}

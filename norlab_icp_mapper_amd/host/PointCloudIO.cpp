@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 
 namespace nim {
 
@@ -92,6 +93,12 @@ void readValues(Cursor& c, bool binary, const std::string& type, size_t count, f
     }
 }
 
+// int64 time rows as two unsigned_int scalars per row group (see PointCloud.h)
+const char* const kSplitHigh = "_splitTime_high32";
+const char* const kSplitLow = "_splitTime_low32";
+bool endsWith(const std::string& s, const char* suffix) { const size_t k = std::strlen(suffix); return s.size() > k && s.compare(s.size() - k, k, suffix) == 0; }
+struct SplitTime { int span = 1; std::vector<uint32_t> high, low; };
+
 void putBE32(std::vector<unsigned char>& buf, uint32_t u) { buf.push_back(u >> 24); buf.push_back(u >> 16); buf.push_back(u >> 8); buf.push_back(u); }
 void putBEf(std::vector<unsigned char>& buf, float f) { uint32_t u; std::memcpy(&u, &f, 4); putBE32(buf, u); }
 
@@ -122,6 +129,7 @@ DataPoints DataPoints::load(const std::string& path)
     DataPoints cloud;
     size_t n = 0;
     bool seenPoints = false;
+    std::map<std::string, SplitTime> splitHalves;
     while (!c.atEnd()) {
         const std::string word = c.word();
         if (word == "DATASET") {
@@ -152,6 +160,21 @@ DataPoints DataPoints::load(const std::string& path)
             // the header line is consumed; an optional "LOOKUP_TABLE <name>" line follows, then the values
             const char* mark = c.p;
             if (c.word() == "LOOKUP_TABLE") { c.word(); if (binary) c.toPayload(); } else c.p = mark;
+            // one half of a time row group: exact 32-bit words, joined below
+            const bool hi = endsWith(name, kSplitHigh), lo = endsWith(name, kSplitLow);
+            if ((hi || lo) && (type == "unsigned_int" || type == "int")) {
+                std::vector<uint32_t> words((size_t)span * n);
+                if (binary) {
+                    const unsigned char* b = c.bytes(4 * words.size());
+                    for (size_t i = 0; i < words.size(); ++i) words[i] = ((uint32_t)b[4 * i] << 24) | ((uint32_t)b[4 * i + 1] << 16) | ((uint32_t)b[4 * i + 2] << 8) | b[4 * i + 3];
+                } else
+                    for (size_t i = 0; i < words.size(); ++i) words[i] = (uint32_t)std::strtoull(c.word().c_str(), nullptr, 10);
+                const std::string base = name.substr(0, name.size() - std::strlen(hi ? kSplitHigh : kSplitLow));
+                auto& half = splitHalves[base];
+                half.span = span;
+                (hi ? half.high : half.low) = std::move(words);
+                continue;
+            }
             std::vector<float> data((size_t)span * n);
             readValues(c, binary, type, n, data.data(), (size_t)span, (size_t)span);
             cloud.addDescriptor(name, span, std::move(data));
@@ -166,6 +189,13 @@ DataPoints DataPoints::load(const std::string& path)
         }
     }
     if (!seenPoints) throw std::runtime_error("No POINTS section in " + path);
+    for (auto& kv : splitHalves) {
+        SplitTime& h = kv.second;
+        if (h.high.size() != h.low.size() || h.high.size() != (size_t)h.span * n) throw std::runtime_error("Incomplete split time field " + kv.first + " in " + path);
+        std::vector<std::int64_t> t(h.high.size());
+        for (size_t i = 0; i < t.size(); ++i) t[i] = (std::int64_t)(((uint64_t)h.high[i] << 32) | (uint64_t)h.low[i]);
+        cloud.addTime(kv.first, h.span, std::move(t));
+    }
     return cloud;
 }
 
@@ -199,6 +229,21 @@ void DataPoints::save(const std::string& path, bool binary) const
                 std::fprintf(f, "\n");
             }
     }
+    for (const auto& t : times)
+        for (int half = 0; half < 2; ++half) {
+            if (t.span == 1) std::fprintf(f, "SCALARS %s%s unsigned_int\nLOOKUP_TABLE default\n", t.name.c_str(), half == 0 ? kSplitHigh : kSplitLow);
+            else std::fprintf(f, "SCALARS %s%s unsigned_int %d\nLOOKUP_TABLE default\n", t.name.c_str(), half == 0 ? kSplitHigh : kSplitLow, t.span);
+            auto word = [&](std::int64_t v) { return (uint32_t)(half == 0 ? ((uint64_t)v >> 32) : ((uint64_t)v & 0xffffffffull)); };
+            if (binary) {
+                buf.reserve(4 * t.data.size());
+                for (std::int64_t v : t.data) putBE32(buf, word(v));
+                flush();
+            } else
+                for (size_t i = 0; i < n; ++i) {
+                    for (int r = 0; r < t.span; ++r) std::fprintf(f, r ? " %u" : "%u", word(t.data[(size_t)t.span * i + r]));
+                    std::fprintf(f, "\n");
+                }
+        }
     std::fclose(f);
 }
 

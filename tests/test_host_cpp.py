@@ -54,7 +54,8 @@ def _read_vtk(path):
         if parts and parts[0] in ("SCALARS", "VECTORS", "NORMALS"):
             name = parts[1]
             j += 2 if parts[0] == "SCALARS" else 1
-            desc[name] = np.array([[float(v) for v in lines[j + r].split()] for r in range(n)], dtype=np.float32)
+            kind = np.uint32 if len(parts) > 2 and parts[2] == "unsigned_int" else np.float32
+            desc[name] = np.array([[(int(v) if kind is np.uint32 else float(v)) for v in lines[j + r].split()] for r in range(n)], dtype=kind)
             j += n
         else:
             j += 1
@@ -93,11 +94,19 @@ def _make_dataset(tmp, n_scans=4, n_pts=15000):
         rows.append([1700000000, 100000000 * s, *T_prior[:3, 3], *q])
         _write_vtk(os.path.join(tmp, "scans", f"cloud_{s:03d}.vtk"), local.astype(np.float32))
         scans.append(local.astype(np.float32)); truth.append(T_true)
+    # the harness finds its columns by NAME (reference examples/build_map_from_scans_and_trajectory.cpp:38-90): this dump carries them in another
+    # order than the bundled one (tests/config4_data.py writes that), with extra columns in between
+    names = ["child_frame_id", "pose.pose.orientation.w", "pose.pose.orientation.x", "pose.pose.orientation.y", "pose.pose.orientation.z", "twist.twist.linear.x",
+             "pose.pose.position.z", "pose.pose.position.y", "pose.pose.position.x", "header.frame_id", "header.stamp.nanosec", "header.stamp.sec"]
     with open(os.path.join(tmp, "trajectory.csv"), "w") as f:
-        f.write("header.stamp.sec,header.stamp.nanosec,header.frame_id,child_frame_id,pose.pose.position.x,pose.pose.position.y,"
-                "pose.pose.position.z,pose.pose.orientation.x,pose.pose.orientation.y,pose.pose.orientation.z,pose.pose.orientation.w,pose.covariance\n")
+        f.write(",".join(names) + "\n")
         for r in rows:
-            f.write(f"{r[0]},{r[1]},map,base_link," + ",".join(repr(float(v)) for v in r[2:]) + ",[0. 0. 0.]\n")
+            sec, nsec, x, y, z, qx, qy, qz, qw = r
+            val = {"child_frame_id": "base_link", "header.frame_id": "map", "twist.twist.linear.x": "0.0", "header.stamp.sec": str(sec), "header.stamp.nanosec": str(nsec),
+                   "pose.pose.position.x": repr(float(x)), "pose.pose.position.y": repr(float(y)), "pose.pose.position.z": repr(float(z)),
+                   "pose.pose.orientation.x": repr(float(qx)), "pose.pose.orientation.y": repr(float(qy)), "pose.pose.orientation.z": repr(float(qz)),
+                   "pose.pose.orientation.w": repr(float(qw))}
+            f.write(",".join(val[n] for n in names) + "\n")
     priors = [_quat_T(np.array(r[2:], dtype=np.float64)) for r in rows]
     return scans, priors, truth
 
@@ -137,6 +146,21 @@ icp:
 
 
 @pytest.mark.gpu
+def test_example_harness_needs_its_columns_by_name(tmp_path):
+    """a trajectory dump whose header lacks one of the nine columns the reference looks up is the reference's error, whatever the positions"""
+    _build_host()
+    tmp = str(tmp_path)
+    _make_dataset(tmp, n_scans=2, n_pts=2000)
+    path = os.path.join(tmp, "trajectory.csv")
+    text = open(path).read().replace("pose.pose.orientation.w", "pose.pose.orientation.W")
+    open(path, "w").write(text)
+    cfg = os.path.join(tmp, "config.yaml")
+    open(cfg, "w").write(P2PLANE_CONFIG)
+    out = subprocess.run([os.path.join(PKG, "build_map_from_scans_and_trajectory"), tmp, cfg], capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0 and "Required columns not found in the header" in (out.stderr + out.stdout)
+
+
+@pytest.mark.gpu
 def test_example_harness_matches_python_replay(tmp_path):
     import norlab_icp_mapper_amd as amd
     _build_host()
@@ -149,6 +173,10 @@ def test_example_harness_matches_python_replay(tmp_path):
     assert out.returncode == 0, out.stderr + out.stdout
     pos, desc = _read_vtk(traj_out)
     assert pos.shape[0] == len(scans)
+    # Trajectory::save (Trajectory.cpp:35-47): the stamps as int64 `times` -- libpointmatcher's VTK writer splits them into two unsigned_int
+    # scalars; the dataset's stamps are 100 ms apart at epoch scale and must come back exactly
+    t = (desc["t_splitTime_high32"][:, 0].astype(np.uint64) << np.uint64(32)) | desc["t_splitTime_low32"][:, 0].astype(np.uint64)
+    assert [int(v) for v in t] == [1700000000 * 10**9 + 10**8 * i for i in range(len(scans))], t
     cpp_poses = []
     for i in range(len(scans)):
         T = np.eye(4, dtype=np.float32)
