@@ -121,9 +121,9 @@ def nn_roofline(pkg, dev, chain, d_map, d_nrm, d_scan, n_scan, m_map, traffic_ke
         except Exception:
             traffic = None
     del prof
-    nn1 = "nn1_ml_kernel" if os.environ.get("ICPMI_NN_WQ", "1") == "0" else ("nn1_wq_kernel" if os.environ.get("ICPMI_NN_WG", "4") == "0" else "nn1_wg_kernel")
+    nn1 = "nn1_wg_kernel"
     # knn > 1: nnk_ml_kernel serves iterations 0 and 1, nnk_wg_kernel the seeded ones (18 of a step's 20 launches); the average is over all
-    nnk = "nnk_ml_kernel" if os.environ.get("ICPMI_NNK_WG_FROM", "2").startswith("-") else "nnk_wg_kernel (+ nnk_ml_kernel, iterations 0-1)"
+    nnk = "nnk_wg_kernel (+ nnk_ml_kernel, iterations 0-1)"
     return {"bound": "hbm", "kernel": nn1 if kq == 1 else nnk, "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
             "map_points_charged": m_alg, "avg_launch_us": nn_avg_ms * 1e3, "launches_timed": nn_cnt,
@@ -645,7 +645,7 @@ def main():
             dbg6 = icp6.debugCounters()  # (r5) iterations of the last registration whose level 0 came from the NN kernel's window / from the full histogram
             extras["docs_knn6"] = {
                 "selection_window": {"iterations_served": int(dbg6[12]), "iterations_missed": int(dbg6[13]), "of": ITERS_PER_STEP,
-                                     "note": "speculative level 0 of the quantile selection counted by nnk_wg_kernel (iterations 2..); ICPMI_SEL_WIN=0 switches it off"},
+                                     "note": "speculative level 0 of the quantile selection counted by nnk_wg_kernel (iterations 2..); icpmi_config::sel_window_off switches it off"},
                 "config": "docs/MapperConfiguration.md:174-189: KDTreeMatcher knn 6 maxDist 2.0 epsilon 0, TrimmedDist 0.85, PointToPlane; 100k-pt scan vs 1M-pt map",
                 "value": max(args.steps // 2, 5) * ITERS_PER_STEP / el6, "unit": "iterations/s", "step_ms": step_stats(per6),
                 "pose_err_vs_ground_truth": {"m": g6t, "rad": g6r},

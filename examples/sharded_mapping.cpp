@@ -31,16 +31,29 @@ static std::vector<Mat4> readPoses(const std::string& path)
     if (!in) throw std::runtime_error("cannot open " + path);
     std::vector<Mat4> out;
     std::string line;
-    std::getline(in, line);
+    // columns by NAME, as the reference's harness finds them (examples/build_map_from_scans_and_trajectory.cpp:38-90)
+    if (!std::getline(in, line)) throw std::runtime_error("empty trajectory file " + path);
+    const char* wanted[7] = {"pose.pose.position.x", "pose.pose.position.y", "pose.pose.position.z",
+                             "pose.pose.orientation.x", "pose.pose.orientation.y", "pose.pose.orientation.z", "pose.pose.orientation.w"};
+    int col[7] = {-1, -1, -1, -1, -1, -1, -1};
+    size_t need = 0;
+    {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        std::stringstream hs(line);
+        std::string name;
+        for (int i = 0; std::getline(hs, name, ','); ++i)
+            for (int k = 0; k < 7; ++k) if (name == wanted[k]) { col[k] = i; if ((size_t)i + 1 > need) need = (size_t)i + 1; }
+        for (int k = 0; k < 7; ++k) if (col[k] < 0) throw std::runtime_error("Error: Required columns not found in the header.");
+    }
     while (std::getline(in, line)) {
         if (line.empty()) continue;
         std::vector<std::string> f;
         std::stringstream ss(line);
         std::string tok;
         while (std::getline(ss, tok, ',')) f.push_back(tok);
-        if (f.size() < 11) throw std::runtime_error("malformed trajectory row");
-        const double x = std::stod(f[4]), y = std::stod(f[5]), z = std::stod(f[6]);
-        const double qx = std::stod(f[7]), qy = std::stod(f[8]), qz = std::stod(f[9]), qw = std::stod(f[10]);
+        if (f.size() < need) throw std::runtime_error("malformed trajectory row");
+        const double x = std::stod(f[col[0]]), y = std::stod(f[col[1]]), z = std::stod(f[col[2]]);
+        const double qx = std::stod(f[col[3]]), qy = std::stod(f[col[4]]), qz = std::stod(f[col[5]]), qw = std::stod(f[col[6]]);
         Mat4 T = Mat4::identity();
         T(0, 0) = (float)(1 - 2 * (qy * qy + qz * qz)); T(0, 1) = (float)(2 * (qx * qy - qz * qw)); T(0, 2) = (float)(2 * (qx * qz + qy * qw));
         T(1, 0) = (float)(2 * (qx * qy + qz * qw)); T(1, 1) = (float)(1 - 2 * (qx * qx + qz * qz)); T(1, 2) = (float)(2 * (qy * qz - qx * qw));

@@ -135,7 +135,13 @@ typedef struct {
     int32_t fuse_solve;        /* (v4) asked for the solve inside the next NN launch (three launches per iteration).  The path lost  */
                                /* on two of three shapes and was REMOVED in r5: the field keeps the struct's layout    */
                                /* and is ignored (every value runs the four-launch iteration, bit-identical results as before).     */
-    int32_t reserved[7];
+    /* r6: the two switches of the k > 1 matcher that tests still need were environment variables through r5 (read once per process); they are
+       per-handle fields now.  Zero = the default, so a zeroed tail keeps every old caller's behaviour.                                        */
+    int32_t knn_wg_from;       /* which iterations of a k > 1 loop nnk_wg_kernel serves: 0 = from iteration 2 (default), n > 0 = from          */
+                               /* iteration n - 1, < 0 = none (nnk_ml_kernel everywhere).  Same bits either way (tests/test_gpu_knn_wg.py).    */
+    int32_t sel_window_off;    /* 1 = the quantile selection of a k > 1 loop always builds its full level-0 histogram (no speculative window, */
+                               /* DESIGN_history.md 13.7b).  Same bits either way (tests/test_gpu_sel_window.py).                              */
+    int32_t reserved[5];
 } icpmi_config;
 
 /* What PM::ICPSequence exposes after a call: errorMinimizer->getOverlap() (Mapper.cpp:219) is
@@ -470,8 +476,9 @@ int32_t      icpmi_version(void);
  * solve.h, include/icpmi.h) as they were when this binary was linked -- tests/conftest.py recomputes it from the tree and refuses to run GPU
  * tests against a binary built from other sources. */
 const char*  icpmi_build_info(void);
-/* The library caches freed device blocks per device (at most ICPMI_ALLOC_CACHE_MB, default 1024; emptied when the process's last handle is
- * destroyed).  This hands every cached block back to the runtime now; live handles stay valid. */
+/* The library caches freed device blocks per device (at most ICPMI_ALLOC_CACHE_MB, default 1024) so that a mapper that is dropped and rebuilt
+ * finds its ~300 arrays again.  A host that shares the GPU with another allocator calls this when it is done with a mapper: every cached
+ * block goes back to the runtime now; live handles stay valid. */
 icpmi_status icpmi_trim_cache(void);
 /* Diagnostics of the last registration (engine internals, not part of the reference surface).  Slots 12 / 13 (r5): iterations of a k > 1 loop whose
    quantile selection took its level 0 from the NN kernel's window / from the full histogram behind a window that missed. */

@@ -52,7 +52,9 @@ class Config(C.Structure):
         ("use_graph", C.c_int32),
         ("profile", C.c_int32),
         ("fuse_solve", C.c_int32),
-        ("reserved", C.c_int32 * 7),
+        ("knn_wg_from", C.c_int32),
+        ("sel_window_off", C.c_int32),
+        ("reserved", C.c_int32 * 5),
     ]
 
 

@@ -235,7 +235,7 @@ struct IcpState {
 // 14 scans were 14 of 37 ms).  dev_free keeps the block (after the same device-wide synchronisation hipFree implies: nothing in flight
 // can still touch it), dev_malloc hands out the smallest cached block of at least the size asked for and at most twice that + 1 MiB.
 // ICPMI_ALLOC_CACHE_MB (default 1024; 0: plain hipMalloc / hipFree) bounds what is kept; the largest blocks go first.  Blocks are cached per
-// device; the cache is emptied when the process's last handle is destroyed and by icpmi_trim_cache().
+// device; icpmi_trim_cache() empties it.
 // ------------------------------------------------------------------------------------------------
 // A device-wide synchronisation and a stream capture in ANOTHER thread do not mix on this runtime (scripts/r5/capture_threads.hip, ROCm 7:
 // hipDeviceSynchronize fails with "operation not permitted when stream is capturing" AND invalidates the other thread's thread-local capture;
@@ -257,7 +257,7 @@ struct DevBlockCache {
     std::unordered_map<void*, Live> live;                  // every block handed out -> its true size and the device it was mapped on
     std::map<int, std::multimap<size_t, void*>> idle_of;   // cached blocks by size, PER DEVICE (r6, ADVICE r5: icpmi_config::device puts several GPUs in one process)
     size_t idle_bytes = 0, limit = 0;
-    long handles = 0;                                      // live top-level handles (icpmi_create / icpmi_destroy): the cache is trimmed when the last one goes
+    long handles = 0;                                      // live top-level handles (icpmi_create / icpmi_destroy; bookkeeping)
     bool on = true;
     DevBlockCache()
     {

@@ -1060,9 +1060,9 @@ icpmi_status loop_sensor_noise_overlap(icpmi_ctx* c, int64_t n, const LoopCfg& l
     return ICPMI_OK;
 }
 
-// ICPMI_FUSE_HEAD (default 1): centring, loop-state initialisation and the clearing of the selection histograms ride in the kernels of
-// the query sort (SortHead) -- the head of a registration is 3 graph nodes instead of 8
-static bool fuse_head() { static int v = -1; if (v < 0) { const char* e = getenv("ICPMI_FUSE_HEAD"); v = e ? atoi(e) : 1; } return v != 0; }
+// centring, loop-state initialisation and the clearing of the selection histograms ride in the kernels of the query sort (SortHead) -- the
+// head of a registration is 3 graph nodes instead of 8
+static bool fuse_head() { return true; }
 
 // head_done: the caller wants the loop state initialised too (enqueue_registration_head); set when the sort's kernels did it
 icpmi_status loop_prepare_reading(icpmi_ctx* c, const float4* d_scan, int64_t n, const float* d_normals3, bool* head_done)
@@ -1097,7 +1097,7 @@ static int acc_cap()
 {
     static int cap = -1;
     if (cap < 0) {
-        const char* e = getenv("ICPMI_ACC_BLOCKS"); cap = e ? atoi(e) : 256; if (cap < 1) cap = 1;
+        cap = 256; // (r4 sweep 256 / 300 / 400 / 600: one 1 024-thread workgroup per CU wins)
         // the limb headroom of the fixed-point accumulators (common.h) is sized for ICPMI_ACC_MAX_ADDS workgroup partials per copy
         if (cap > ICPMI_ACC_MAX_ADDS * ICPMI_ACC_COPIES) cap = ICPMI_ACC_MAX_ADDS * ICPMI_ACC_COPIES;
     }
@@ -1246,7 +1246,7 @@ static void enqueue_selection(icpmi_ctx* c, const LoopCfg& lc, int64_t count, bo
 
 template <int MIN, bool FUSED, bool EXT>
 static void launch_accumulate_ext(icpmi_ctx* c, int64_t n, const LoopCfg& lc, int nb, int slot);
-static bool pn_enabled() { static int v = -1; if (v < 0) { const char* e = getenv("ICPMI_ACC_PN"); v = e ? atoi(e) : 1; } return v != 0; }
+static bool pn_enabled() { return true; }
 
 template <int MIN, bool FUSED>
 static void launch_accumulate(icpmi_ctx* c, int64_t n, const LoopCfg& lc, int nb, int slot)
@@ -1318,7 +1318,10 @@ static void l2_thrash_prepare()
 {
     static int thrash = -1;
     if (thrash >= 0) return;
-    const char* e = getenv("ICPMI_NN_FLUSH_L2"); thrash = e ? atoi(e) : 0;
+    thrash = 0; // (r5 diagnostic, DESIGN_history.md 13.1: 64 MB pushed through every L2 in front of every NN launch; compile with -DICPMI_NN_FLUSH_L2 to get it back)
+#ifdef ICPMI_NN_FLUSH_L2
+    thrash = 1;
+#endif
     if (!thrash) return;
     const size_t bytes = (64u << 20) + 64;
     if (hipMalloc((void**)&g_l2_thrash, bytes) != hipSuccess || hipMemset(g_l2_thrash, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) g_l2_thrash = nullptr;
@@ -1332,8 +1335,7 @@ static icpmi_status enqueue_iteration(icpmi_ctx* c, int64_t n, const LoopCfg& lc
     c->nn_hist0 = fused_filter_slot(lc) >= 0 ? c->d_selhist : nullptr;
     c->nn_builds_hist0 = false;
     c->nn_builds_win = false;
-    static int keep_pts = -1;
-    if (keep_pts < 0) { const char* e = getenv("ICPMI_SORTED_STATE"); keep_pts = e ? atoi(e) : 1; }
+    constexpr int keep_pts = 1;
     c->nn_match_pt = (lc.k == 1 && keep_pts) ? c->d_match_pt : nullptr;
     c->nn_sorted_k = lc.k > 1 && keep_pts;
     c->nn_out_sorted = false;
@@ -1412,16 +1414,14 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
     if (c->h_progress) __atomic_store_n(c->h_progress + 32, c->reg_seq, __ATOMIC_RELEASE);
     // r5 (fast finish, see the end of this function): the finished state reaches the host by itself and carries the device clocks of its
     // start and stop -- no event pair, no copy, no drain
-    static const int fast_cfg = [] { const char* e = getenv("ICPMI_FAST_FINISH"); return e ? atoi(e) : 1; }();
-    const bool fast_ok = fast_cfg && !profile && c->d_state_mirror && c->h_progress && lc.max_iter < 0xfff;
+    const bool fast_ok = !profile && c->d_state_mirror && c->h_progress && lc.max_iter < 0xfff;
     if (!fast_ok) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     // A checked loop (Counter + Differential / Bound: what Mapper::processInput runs) as SEGMENT graphs (r3):
     // head + the first S iterations are one graph, S further iterations another; a segment is launched when the progress word
     // says the loop is still running and within S / 2 iterations of the end of what is enqueued.  Iterations past the stop are
     // early-exit kernels (every kernel of the loop returns on st->done): at most S - 1 of them, against eager launches -- and
-    // their wider kernel-to-kernel gaps -- for every real iteration.  ICPMI_SEG=0 restores the eager run-ahead loop.
-    static int seg_cfg = -1;
-    if (seg_cfg < 0) { const char* e = getenv("ICPMI_SEG"); seg_cfg = e ? atoi(e) : 4; }
+    // their wider kernel-to-kernel gaps -- for every real iteration.
+    constexpr int seg_cfg = 4;
     bool segmented = !graph && !profile && c->cfg.use_graph != 0 && seg_cfg > 0 && (lc.use_diff || lc.use_bound) && c->h_progress &&
                      lc.max_iter < 0xfff && lc.max_iter > 1;
     const int S = seg_cfg > 0 && seg_cfg < lc.max_iter ? seg_cfg : lc.max_iter;
@@ -1438,7 +1438,7 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
         // capture + instantiate + destroy per scan cost more than they saved (chain bench: register 0.58 -> 0.455 ms, update 1.53 -> 1.45 ms
         // with no graph at all).  After two sets in a row that served one registration each the handle runs its checked loops eagerly,
         // until the same map and scan size come back twice (localisation against a fixed map, the benchmark's repeats): then a graph pays again.
-        static const int adapt = [] { const char* e = getenv("ICPMI_GRAPH_ADAPT"); return e ? atoi(e) : 1; }();
+        constexpr int adapt = 1;
         const bool cached = c->seg_exec[0] && c->seg_exec[1] && c->seg_n == n && c->seg_len == S && c->seg_sig == sig;
         if (adapt && !cached && c->seg_wasted >= 2) {
             if (c->eager_sig == sig && c->eager_n == n) c->seg_wasted = 0;
@@ -1456,7 +1456,7 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
         fsig = fnv(&c->grid, sizeof c->grid, fsig);
         fsig = fnv(&c->map_epoch, sizeof c->map_epoch, fsig);
         // the same rule for the one-graph registration of a Counter-only chain (the shipped configuration: examples/config.yaml:54-57)
-        static const int adapt = [] { const char* e = getenv("ICPMI_GRAPH_ADAPT"); return e ? atoi(e) : 1; }();
+        constexpr int adapt = 1;
         const bool cached = c->graph_exec && c->graph_n == n && c->graph_iters == lc.max_iter && c->graph_sig == fsig;
         if (adapt && !cached && c->graph_wasted >= 2) {
             if (c->eager_sig == fsig && c->eager_n == n) c->graph_wasted = 0;
@@ -1492,9 +1492,8 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
         // the same map from almost the same prior: the loop stops after the same few iterations every time (6 in the benchmark scene), and
         // head + 4 followed by a segment of 4 ran two dead iterations (eight early-exit launches, ~24 us of a 0.37 ms registration) behind the
         // stop.  With a head of exactly the previous count the host waits for that head to finish (no look-ahead: the prediction says the loop
-        // is over) and goes on with ordinary segments only if it is not.  ICPMI_SEG_ADAPT=0: always head + S.
-        static int adapt_cfg = -1;
-        if (adapt_cfg < 0) { const char* e = getenv("ICPMI_SEG_ADAPT"); adapt_cfg = e ? atoi(e) : 1; }
+        // is over) and goes on with ordinary segments only if it is not.
+        constexpr int adapt_cfg = 1;
         hipGraphExec_t head_exec = c->seg_exec[0];
         int head_len = S;
         if (adapt_cfg && c->seg_prev_iters >= 2 && c->seg_prev_iters != S && c->seg_prev_iters <= 24 && c->seg_prev_iters < lc.max_iter) {
@@ -1579,9 +1578,8 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
         // A loop of data-dependent length (Differential / Bound) is enqueued a bounded number of iterations ahead of the
         // progress word the solve kernel publishes in host-mapped memory: the stream never drains for a read-back (r1:
         // a hipMemcpy + hipStreamSynchronize every 4 iterations, ~25 us of idle GPU each), and at most `ahead` iterations
-        // run as early-exit kernels after the loop has stopped.  ICPMI_RUN_AHEAD=0 restores the periodic read-back.
-        static int ahead = -1;
-        if (ahead < 0) { const char* e = getenv("ICPMI_RUN_AHEAD"); ahead = e ? atoi(e) : 2; }
+        // run as early-exit kernels after the loop has stopped.
+        constexpr int ahead = 2;
         const bool poll = ahead > 0 && !profile && (lc.use_diff || lc.use_bound) && c->h_progress && lc.max_iter < 0xfff;
         int launched = 0;
         bool stopped = false;
@@ -1812,8 +1810,7 @@ icpmi_status loop_run_batch(icpmi_ctx* c, int B, const float* const* d_scans4, c
     } else {
         icpmi_status s = head();
         if (s != ICPMI_OK) return s;
-        static int ahead = -1;
-        if (ahead < 0) { const char* e = getenv("ICPMI_RUN_AHEAD"); ahead = e ? atoi(e) : 2; if (ahead < 1) ahead = 1; }
+        constexpr int ahead = 2;
         const bool poll = (lc.use_diff || lc.use_bound) && c->h_progress && lc.max_iter < 0xfff;
         bool stopped = false;
         for (int it = 0; it < lc.max_iter && !stopped; ++it) {

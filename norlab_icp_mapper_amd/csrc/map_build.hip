@@ -690,9 +690,7 @@ icpmi_status sort_queries(icpmi_ctx* c, const float4* d_pts, int64_t n) { return
 
 static int run_atomics_cfg()
 {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("ICPMI_RUN_ATOMICS"); v = e ? atoi(e) : 1; }
-    return v;
+    return 1; // (one atomic per run of equal keys in a wave: r2; the per-point variant stays in the kernels for reference)
 }
 
 // in-place exclusive scan of data[0..n) (counts -> starts); data[n] = total
@@ -700,9 +698,7 @@ icpmi_status device_exclusive_scan(icpmi_ctx* c, unsigned* data, int n, unsigned
 
 static int scan2_enabled()
 {
-    static int two = -1;
-    if (two < 0) { const char* e = getenv("ICPMI_SCAN2"); two = e ? atoi(e) : 1; }
-    return two;
+    return 1; // (the two-kernel scan, r5; tables beyond SCAN2_MAX_NB chunks take the three-kernel one)
 }
 
 // The count table of a grid build -> the cell starts, in the layout a CURSOR scatter wants (r5): counts[0..n) (+ the occupancy word at
@@ -776,9 +772,8 @@ icpmi_status device_scan_flags_count(icpmi_ctx* c, const unsigned* flag, unsigne
         // r5: the count arrives TAGGED (words 40 / 41 as one 64-bit slot: call number << 32 | count, system-scope release) and the host spins on
         // the tag instead of draining the stream: a drained stream costs the completion signal and the restart of an empty queue (~20 us,
         // DESIGN 13.6e) -- five to seven times per map update --, the word is here ~2 us after the kernel's last workgroup wrote it, and what the
-        // caller enqueues next queues up behind a GPU that never went idle.  ICPMI_SPIN_COUNTS=0: drain as before.
-        static const int spin_cfg = [] { const char* e = getenv("ICPMI_SPIN_COUNTS"); return e ? atoi(e) : 1; }();
-        const unsigned tag = spin_cfg ? (++c->scan_tag ? c->scan_tag : ++c->scan_tag) : 0u;
+        // caller enqueues next queues up behind a GPU that never went idle.
+        const unsigned tag = ++c->scan_tag ? c->scan_tag : ++c->scan_tag;
         hipLaunchKernelGGL(scan2_sums_kernel, dim3(nb), dim3(SCAN_T), 0, c->stream, flag, n, c->d_blocksums);
         hipLaunchKernelGGL(scan2_final_kernel, dim3(nb), dim3(SCAN_T), 0, c->stream, flag, pos, n, (const unsigned*)c->d_blocksums, 0u, 0, (unsigned*)nullptr, d_word,
                            (unsigned*)nullptr, tag);
@@ -912,7 +907,7 @@ static icpmi_status map_insert(icpmi_ctx* c, const float4* d_pts, int64_t m0, in
 {
     *done = false;
     static int on = -1, min_m = -1;
-    if (on < 0) { const char* e = getenv("ICPMI_INSERT"); on = e ? atoi(e) : 1; e = getenv("ICPMI_INSERT_MIN"); min_m = e ? atoi(e) : 0; }
+    if (on < 0) { on = 1; const char* e = getenv("ICPMI_INSERT_MIN"); min_m = e ? atoi(e) : 0; }
     // (measured, one map-growth epoch = two index updates, A/B in one call: 1 M points 0.72 -> 0.56 ms, 10 M points 3.65 -> 0.97 ms; the first
     //  version -- raw points gathered by original index -- lost at 1 M: 0.74 ms.  ICPMI_INSERT_MIN: smallest cloud the insert serves.)
     const int64_t n = m1 - m0;
@@ -1117,15 +1112,11 @@ icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float
     } else {
         // trial edge from the bounding volume, then one correction assuming the points sample
         // surfaces (occupied cells ~ area / cell^2): aim at TARGET points per occupied cell.
-        static double target_cfg = -1.0;
-        if (target_cfg < 0) { const char* e = getenv("ICPMI_GRID_TARGET"); target_cfg = e ? atof(e) : 8.0; }
-        const double TARGET = target_cfg;
+        const double TARGET = 8.0;
         // A handle that rebuilds the index of a slowly growing map (every map update, twice) does not wait for the occupancy of THIS
         // build: it corrects the edge with the count of the previous one, which arrived in pinned memory long ago (r3: one stream
-        // synchronisation less per build; ICPMI_GRID_DEFER=0 restores the read-back).  The edge only steers speed: the search is exact.
-        static int defer = -1;
-        if (defer < 0) { const char* e = getenv("ICPMI_GRID_DEFER"); defer = e ? atoi(e) : 1; }
-        if (defer && c->h_nocc && c->nocc_m > 0 && c->grid.cell > 0.f && c->m > 0 && (double)m > 0.7 * (double)c->m && (double)m < 1.4 * (double)c->m) {
+        // synchronisation less per build).  The edge only steers speed: the search is exact.
+        if (c->h_nocc && c->nocc_m > 0 && c->grid.cell > 0.f && c->m > 0 && (double)m > 0.7 * (double)c->m && (double)m < 1.4 * (double)c->m) {
             const double occ = (double)c->nocc_m / (double)std::max(1u, *c->h_nocc);
             double cell = c->grid.cell;
             if (!(occ > TARGET * 0.6 && occ < TARGET * 1.6)) cell = cell * sqrt(TARGET / occ);

@@ -7,7 +7,7 @@
 // equal float d2 resolve to the smallest original map index (the deterministic rule shared with the
 // oracle, libnabo's own pick being traversal dependent).
 //
-// Kernels: nn1_ml_kernel (k = 1, the loop's default), nnk_ml_kernel (2 <= k <= 8), nnk_kernel (k <= 32, one
+// Kernels: nn1_wg_kernel (k = 1), nnk_ml_kernel / nnk_wg_kernel (2 <= k <= 16), nnk_kernel (17 <= k <= 32, one
 // lane per query: surface normals), and the brute-force passes for queries the grid cannot decide
 // (only reachable with an unbounded maxDist).  The designs are described above each kernel.
 #include "common.h"
@@ -15,10 +15,6 @@
 namespace {
 
 constexpr int NN_BLOCK = 256;
-#ifndef ICPMI_NN1_BLOCK
-#define ICPMI_NN1_BLOCK 128
-#endif
-constexpr int NN1_BLOCK = ICPMI_NN1_BLOCK; // workgroup of the k = 1 pyramid kernel
 
 typedef __attribute__((address_space(1))) unsigned gunsigned;
 // sqrt for pruning radii and level choices: one v_sqrt_f32 (1 ulp) instead of the IEEE-exact sequence (~12 instructions, and the
@@ -326,367 +322,26 @@ __global__ __launch_bounds__(256) void ids_kernel(const float4* __restrict__ map
 }
 
 // ------------------------------------------------------------------------------------------------
-// k = 1 over the grid pyramid (the default path).  G lanes per query; per level:
-//   (1) the 9 x-rows of the 3x3x3 block are looked up by 9 different lanes -- one round trip;
-//   (2) their (start, count) pairs are broadcast with wave shuffles and prefix-summed, which turns
-//       the 27 cells into ONE flat candidate list; lane `sub` takes candidates sub, sub + G, ... and
-//       keeps NB independent 16-byte loads in flight -- the map side of the search is a handful of
-//       coalesced streams per query, no dependent chain longer than two round trips per level;
-//   (3) (d^2, index) keys are folded with a shuffle butterfly and the level's exactness rule is
-//       applied; an undecided query repeats the same code one level up (cell edge x2).
-// Queries arrive sorted by super-tile (map_build.hip:sort_queries), so the lanes of a wave touch
-// neighbouring cells and most loads hit the CU's L1 / the XCD's L2.
+// k = 1 over the grid pyramid.  (r1 - r2: nn1_ml_kernel, G lanes per query; r3: nn1_wq_kernel, a one-wave workgroup alternating
+// between lane-per-query and lane-per-piece; both were kept selectable through r5 and were removed in r6 -- git history has them,
+// DESIGN_history.md sections 5 / 11.2 their measurements.  What runs is nn1_wg_kernel below.)
 // ------------------------------------------------------------------------------------------------
 #ifdef ICPMI_NN_TIMING
 #define NN_TICK(i) do { __builtin_amdgcn_s_waitcnt(0); const long long t_ = clock64(); tacc[i] += t_ - tlast; tlast = t_; } while (0)
 #else
 #define NN_TICK(i) do { } while (0)
 #endif
-template <int G, int NB, bool SELF> // SELF: self matches allowed (the registration loop) -- compile-time, it sits in the innermost loop
-__global__ __launch_bounds__(NN1_BLOCK) void nn1_ml_kernel(const float4* __restrict__ queries, const int* __restrict__ qindex, BatchArgs ba,
-                                                          const float* __restrict__ Tptr, GridLevels L, float maxr2,
-                                                          int allow_self_i, int* __restrict__ out_sidx,
-                                                          float* __restrict__ out_d2, IcpState* __restrict__ st,
-                                                          unsigned* __restrict__ hard, unsigned* __restrict__ hist0,
-                                                          float4* __restrict__ match_pt, const uint4* __restrict__ ltab_g,
-                                                          int unseeded_lev, int seed_pre)
-{
-    static_assert(G == 2 || G == 4 || G == 8 || G == 16, "lanes per query");
-    constexpr int NR = (9 + G - 1) / G; // rows owned per lane: row rr belongs to lane rr % G, slot rr / G
-    // blockIdx.y = reading of a batch (common.h: BatchArgs); a single registration is the batch of one
-    const int n = ba.n[blockIdx.y];
-    {
-        const size_t qo = (size_t)blockIdx.y * (size_t)ba.qstride;
-        queries += qo; out_sidx += qo; out_d2 += qo;
-        if (qindex) qindex += qo;
-        if (match_pt) match_pt += qo;
-        if (hist0) hist0 += (size_t)blockIdx.y * ICPMI_SELHIST_WORDS;
-        if (Tptr) Tptr = reinterpret_cast<const float*>(reinterpret_cast<const char*>(Tptr) + (size_t)blockIdx.y * sizeof(IcpState));
-        st += blockIdx.y;
-    }
-    if (st->done) return;
-#ifdef ICPMI_NN_TIMING
-    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long tlast = clock64();
-#endif
-    // level table -> LDS (4 x 16 bytes per level, layout in map_build.hip:upload_level_table)
-    __shared__ uint4 ltab[ICPMI_MAXLEV * 4];
-    if (threadIdx.x < ICPMI_MAXLEV * 4) ltab[threadIdx.x] = ltab_g[threadIdx.x];
-    // level-0 histogram of the quantile selection (top 8 bits of the d^2 pattern), per workgroup in LDS
-    __shared__ unsigned lh[256];
-    if (hist0) {
-        for (int t = threadIdx.x; t < 256; t += NN1_BLOCK) lh[t] = 0; // visible after the barrier below
-        // the builder of level 0 clears level 1 of the previous iteration (loop.hip, fused selection)
-        for (int gt = blockIdx.x * NN1_BLOCK + threadIdx.x; gt < 256 + 65536; gt += gridDim.x * NN1_BLOCK) hist0[ICPMI_S2_C1 + gt] = 0;
-    }
-    const bool allow_self = SELF; (void)allow_self_i;
-    // XCD-aware order: workgroup b runs on XCD b % 8 (observed placement, used for speed only), so
-    // giving each XCD one contiguous eighth of the tile-sorted queries keeps its share of the map
-    // (~1/8 of the cells) resident in that XCD's private 4 MiB L2.  The grid is padded to 8 * chunk.
-    // (in a batch the grid is sized for the largest reading: this reading's own padded workgroup count decides)
-    const int wgs = (int)((((long long)n * G + NN1_BLOCK - 1) / NN1_BLOCK + 7) / 8 * 8);
-    if ((int)blockIdx.x >= wgs) return;
-    const int chunk = wgs >> 3;
-    const int lb = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    const int tid = lb * NN1_BLOCK + threadIdx.x;
-    const int qi = tid / G;
-    const int sub = tid % G;
-    const bool active = qi < n;
-    const float4 r = queries[active ? qi : 0];
-    // Loop mode (match_pt != nullptr): the per-query loop state -- match position, d^2, matched point --
-    // lives in QUERY ORDER (slot qi of the tile-sorted reading), so the seed of this iteration arrives in
-    // the same round trip as the query itself and the results leave as coalesced stores.  Otherwise
-    // (stage calls) results go to the caller's original index.
-    const int orig = match_pt ? qi : (qindex ? qindex[active ? qi : 0] : qi);
-    int sp_kept = -1;
-    float4 qs_kept = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (match_pt) { sp_kept = out_sidx[active ? qi : 0]; qs_kept = match_pt[active ? qi : 0]; }
-    float3 p;
-    if (Tptr) p = xf_point(Tptr, r.x, r.y, r.z, r.w);
-    else p = make_float3(r.x, r.y, r.z);
-    const int lane = threadIdx.x & 63;
-    const int gbase = lane - sub;
-
-    __syncthreads(); // ltab visible (its load shared the round trip of the query loads above)
-    Cand best; best.key = ~0ull; best.sidx = -1; // sidx = position in its level | level << 28
-    float bx = 0.f, by = 0.f, bz = 0.f;          // coordinates of the current best candidate
-    bool decided = !active;
-    NN_TICK(0);
-
-    // Seed (iterations > 0 of one registration): the previous iteration's match of this query is a
-    // map point, so its distance under the current transform bounds the nearest-neighbour distance
-    // from above.  The search starts at the first level whose 3x3x3 block provably contains that
-    // ball, and only visits the rows / cells the ball reaches.  Exactness is untouched: every point
-    // within the bound is still scanned and the fold is over the same (d^2, index) keys.
-    int lev0 = unseeded_lev; // queries without a usable seed start here (level 0 may be finer than a blind 27-cell search wants)
-    // The choice of the starting level runs WAVE-UNIFORMLY (all lanes step through the same `lev`):
-    // the level's grid parameters are then scalar loads into SGPRs.
-    {
-        int sp = -1;
-        float4 qs = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (active && allow_self && st->iter > 0) {
-            sp = match_pt ? sp_kept : out_sidx[orig];
-            if (sp >= 0) qs = match_pt ? qs_kept : L.pts[0][sp];
-        }
-        bool want = sp >= 0;
-        const float ub2 = sqdist3(p.x, p.y, p.z, qs.x, qs.y, qs.z);
-        const float ub = sqrtf(ub2);
-        auto try_level = [&](int lev, const GridParams& gl) {
-            const float fx = (p.x - gl.ox) * gl.inv_cell, fy = (p.y - gl.oy) * gl.inv_cell, fz = (p.z - gl.oz) * gl.inv_cell;
-            float mfl = fminf(fx - floorf(fx), 1.0f - (fx - floorf(fx)));
-            mfl = fminf(mfl, fminf(fy - floorf(fy), 1.0f - (fy - floorf(fy))));
-            mfl = fminf(mfl, fminf(fz - floorf(fz), 1.0f - (fz - floorf(fz))));
-            if (!(mfl >= 0.f)) mfl = 0.f;
-            const float margin = (1.0f + mfl) * gl.cell - 2.0f * gl.slack;
-            if (want && ub * 1.000001f <= margin) {
-                lev0 = lev;
-                best.key = pack_key(ub2, __float_as_uint(qs.w));
-                best.sidx = sp; // level 0 position
-                bx = qs.x; by = qs.y; bz = qs.z;
-                want = false;
-            }
-        };
-        // level 0 (statically indexed: its parameters arrive with the kernel arguments) decides for nearly every
-        // query of a converging registration; the loop only runs for waves that hold a wider ball
-        try_level(0, L.g[0]);
-        for (int lev = 1; lev < L.nlev; ++lev) {
-            if (__ballot(want) == 0ull) break;
-            try_level(lev, L.g[lev]);
-        }
-    }
-    // lanes of a group agree on the starting level and radius (same inputs)
-    // A seed too wide for level 0 (the first solve moved the reading by the whole initial misalignment): the query
-    // itself is usually close to the surface by now, so start at level 0 after all and let the own-row scan tighten
-    // the bound first; the seed still bounds whatever that scan finds.
-    bool widepre = false;
-    if (seed_pre && lev0 > 0 && best.key != ~0ull) { widepre = true; lev0 = 0; }
-    NN_TICK(1);
-
-    // The search itself runs with PER-LANE levels (groups of one wave work on different levels in
-    // lockstep); the level's parameters come from the LDS copy of the level table.
-    for (int lev = lev0; lev < L.nlev && !decided; ++lev) {
-        GridParams g;
-        const float4* __restrict__ map;
-        const unsigned* __restrict__ cs;
-        {
-            const uint4 a = ltab[4 * lev], b = ltab[4 * lev + 1], c2 = ltab[4 * lev + 2], d = ltab[4 * lev + 3];
-            g.ox = __uint_as_float(a.x); g.oy = __uint_as_float(a.y); g.oz = __uint_as_float(a.z); g.cell = __uint_as_float(a.w);
-            g.inv_cell = __uint_as_float(b.x); g.slack = __uint_as_float(b.y); g.nx = (int)b.z; g.ny = (int)b.w;
-            g.nz = (int)c2.x; g.ncells = (int)c2.y;
-            map = reinterpret_cast<const float4*>(((unsigned long long)c2.w << 32) | c2.z);
-            cs = reinterpret_cast<const unsigned*>(((unsigned long long)d.y << 32) | d.x);
-        }
-        const float fx = (p.x - g.ox) * g.inv_cell, fy = (p.y - g.oy) * g.inv_cell, fz = (p.z - g.oz) * g.inv_cell;
-        const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
-        const int cx = (int)fminf(fmaxf(flx, -1.0e6f), 1.0e6f);
-        const int cy = (int)fminf(fmaxf(fly, -1.0e6f), 1.0e6f);
-        const int cz = (int)fminf(fmaxf(flz, -1.0e6f), 1.0e6f);
-        float mf = fminf(fx - flx, 1.0f - (fx - flx));
-        mf = fminf(mf, fminf(fy - fly, 1.0f - (fy - fly)));
-        mf = fminf(mf, fminf(fz - flz, 1.0f - (fz - flz)));
-        if (!(mf >= 0.f)) mf = 0.f;
-
-        // (0) pruning radius.  Any candidate already held (the seed, or the best of a finer level) bounds
-        //     the answer from above; a query that holds none first scans the x-row through its own cell
-        //     (~1/9 of the block) to get one.  Rows / cells the ball of that radius cannot reach are then
-        //     skipped -- every point within the bound is still scanned, so the block minimum is exact.
-        if (best.key == ~0ull || (widepre && lev == 0)) {
-            unsigned s, e;
-            row_run(g, cs, cx - 1, cx + 1, cy, cz, s, e);
-            for (unsigned i0 = s + (unsigned)sub; i0 < e; i0 += (unsigned)(G * NB)) {
-                float4 q[NB];
-                unsigned gi[NB];
-#pragma unroll
-                for (int u = 0; u < NB; ++u) {
-                    const unsigned k = i0 + (unsigned)(u * G);
-                    gi[u] = k < e ? k : i0;
-                    q[u] = map[gi[u]];
-                }
-#pragma unroll
-                for (int u = 0; u < NB; ++u) {
-                    const float d2 = sqdist3(p.x, p.y, p.z, q[u].x, q[u].y, q[u].z);
-                    unsigned long long key = pack_key(d2, __float_as_uint(q[u].w));
-                    if (!allow_self) key = d2 > 1.1920929e-07f ? key : ~0ull;
-                    if (key < best.key) { best.key = key; best.sidx = (int)(gi[u] | ((unsigned)lev << 28)); bx = q[u].x; by = q[u].y; bz = q[u].z; }
-                }
-            }
-#pragma unroll
-            for (int off = G / 2; off > 0; off >>= 1) {
-                const unsigned long long ok = __shfl_xor(best.key, off, 64);
-                const int os = __shfl_xor(best.sidx, off, 64);
-                const float ox = __shfl_xor(bx, off, 64), oy = __shfl_xor(by, off, 64), oz = __shfl_xor(bz, off, 64);
-                if (ok < best.key) { best.key = ok; best.sidx = os; bx = ox; by = oy; bz = oz; }
-            }
-        }
-        float rub2 = INFINITY; // squared pruning radius (with slack), +inf = no pruning
-        if (best.key != ~0ull) {
-            const float rub = sqrtf(__uint_as_float((unsigned)(best.key >> 32))) * 1.000001f + g.slack;
-            rub2 = rub * rub;
-        }
-
-        // (1) row lookups: row rr is owned by lane rr % G of the group (slot rr / G); all lookups of a
-        //     lane are independent loads
-        unsigned rs[NR], rn[NR];
-        {
-            // distances from the query to the lower / upper faces of its cell along y and z
-            const float ylo = (fy - fly) * g.cell, yhi = (1.0f - (fy - fly)) * g.cell;
-            const float zlo = (fz - flz) * g.cell, zhi = (1.0f - (fz - flz)) * g.cell;
-#pragma unroll
-            for (int sl = 0; sl < NR; ++sl) {
-                const int rr = sub + sl * G;
-                unsigned s = 0, cnt = 0;
-                const int dy = (rr % 3) - 1, dz = (rr / 3) - 1;
-                // cheap part first: does the ball reach this row at all?
-                bool reach = rr < 9;
-                float rem2 = INFINITY;
-                if (reach && rub2 != INFINITY) {
-                    const float ddy = dy == 0 ? 0.f : (dy < 0 ? ylo : yhi);
-                    const float ddz = dz == 0 ? 0.f : (dz < 0 ? zlo : zhi);
-                    rem2 = rub2 - (ddy * ddy + ddz * ddz);
-                    reach = rem2 >= 0.f;
-                }
-                // the second slot only holds the corner row of lane 0 of each group: skipped wave-uniformly when no
-                // ball of the wave reaches it (the usual case once the registration converges)
-                if (__ballot(reach) != 0ull) {
-                    if (reach) {
-                        int xa = cx - 1, xb = cx + 1;
-                        if (rem2 != INFINITY) {
-                            const float rem = sqrtf(rem2);
-                            const int xl = (int)fmaxf(floorf((p.x - rem - g.ox) * g.inv_cell), -1.0e6f);
-                            const int xh = (int)fminf(floorf((p.x + rem - g.ox) * g.inv_cell), 1.0e6f);
-                            xa = xl > xa ? xl : xa;
-                            xb = xh < xb ? xh : xb;
-                        }
-                        unsigned e;
-                        row_run(g, cs, xa, xb, cy + dy, cz + dz, s, e);
-                        cnt = e - s;
-                    }
-                }
-                rs[sl] = s; rn[sl] = cnt;
-            }
-        }
-        NN_TICK(2);
-        // (2) broadcast, prefix: candidate k of the flat list lives at map[k + off_r], P_r <= k < P_{r+1}
-        unsigned Pr[10], Or[9];
-        Pr[0] = 0;
-#pragma unroll
-        for (int rr = 0; rr < 9; ++rr) {
-            const int src = gbase + (rr % G);
-            const unsigned s = __shfl(rs[rr / G], src, 64);
-            const unsigned c = __shfl(rn[rr / G], src, 64);
-            Or[rr] = s - Pr[rr];
-            Pr[rr + 1] = Pr[rr] + c;
-        }
-        const unsigned total = Pr[9];
-#ifdef ICPMI_NN_TIMING
-        tacc[7] += total; // candidates of lane 0's query
-        if (sub == 0 && st->iter > 0 && (qi % 16) == 0) { // distribution over a sample of seeded queries: dbg[18..23]
-            const int bkt = total <= 16 ? 0 : (total <= 32 ? 1 : (total <= 64 ? 2 : (total <= 128 ? 3 : (total <= 256 ? 4 : 5))));
-            atomicAdd(&st->dbg[18 + bkt], 1ull);
-        }
-#endif
-        for (unsigned k0 = (unsigned)sub; k0 < total; k0 += (unsigned)(G * NB)) {
-            float4 q[NB];
-            unsigned gi[NB];
-#pragma unroll
-            for (int u = 0; u < NB; ++u) {
-                const unsigned k = k0 + (unsigned)(u * G);
-                const unsigned kk = k < total ? k : k0; // clamped duplicates of k0 are harmless
-                unsigned off = Or[0];
-#pragma unroll
-                for (int rr = 1; rr < 9; ++rr) off = kk >= Pr[rr] ? Or[rr] : off;
-                gi[u] = kk + off;
-                q[u] = map[gi[u]];
-            }
-#pragma unroll
-            for (int u = 0; u < NB; ++u) {
-                const float d2 = sqdist3(p.x, p.y, p.z, q[u].x, q[u].y, q[u].z);
-                unsigned long long key = pack_key(d2, __float_as_uint(q[u].w));
-                if (!allow_self) key = d2 > 1.1920929e-07f ? key : ~0ull;
-                if (key < best.key) { best.key = key; best.sidx = (int)(gi[u] | ((unsigned)lev << 28)); bx = q[u].x; by = q[u].y; bz = q[u].z; }
-            }
-        }
-        NN_TICK(3);
-        // (3) fold and decide
-#pragma unroll
-        for (int off = G / 2; off > 0; off >>= 1) {
-            const unsigned long long ok = __shfl_xor(best.key, off, 64);
-            const int os = __shfl_xor(best.sidx, off, 64);
-            const float ox = __shfl_xor(bx, off, 64), oy = __shfl_xor(by, off, 64), oz = __shfl_xor(bz, off, 64);
-            if (ok < best.key) { best.key = ok; best.sidx = os; bx = ox; by = oy; bz = oz; }
-        }
-        const float margin = fmaxf((1.0f + mf) * g.cell - g.slack, 0.f);
-        const float m2 = margin * margin;
-        const float bd2 = __uint_as_float((unsigned)(best.key >> 32));
-        const bool covers = cx - 1 <= 0 && cx + 1 >= g.nx - 1 && cy - 1 <= 0 && cy + 1 >= g.ny - 1 && cz - 1 <= 0 && cz + 1 >= g.nz - 1;
-        decided = (best.key != ~0ull && bd2 <= m2) || m2 > maxr2 || covers;
-        NN_TICK(4);
-#ifdef ICPMI_NN_TIMING
-        tacc[6] += 1;
-#endif
-    }
-
-    if (active && sub == 0) {
-        float bd2 = __uint_as_float((unsigned)(best.key >> 32));
-        int bs = -1;
-        if (best.key != ~0ull && bd2 <= maxr2) {
-            const unsigned lv = (unsigned)best.sidx >> 28, pos = (unsigned)best.sidx & 0x0fffffffu;
-            if (lv == 0) bs = (int)pos;
-            else {
-                const uint4 d = ltab[4 * lv + 3];
-                bs = (int)reinterpret_cast<const unsigned*>(((unsigned long long)d.w << 32) | d.z)[pos];
-            }
-        } else bd2 = INFINITY;
-        out_sidx[orig] = bs;
-        out_d2[orig] = bd2;
-        if (match_pt) match_pt[orig] = make_float4(bx, by, bz, __uint_as_float((unsigned)(best.key & 0xffffffffull)));
-        if (hist0 && bd2 != INFINITY && bd2 > 0.f) {
-            const unsigned bits = __float_as_uint(bd2);
-            atomicAdd(&lh[bits >> 24], 1u);
-            atomicAdd(&hist0[ICPMI_S2_F0 + (blockIdx.x % ICPMI_S2_FCOPIES) * 65536 + ICPMI_S2_FIDX(bits >> 16)], 1u);
-        }
-        if (!decided) {
-            const unsigned slot = atomicAdd(&st->hard_count, 1u);
-            hard[slot] = (unsigned)(qindex ? qindex[qi] : qi); // the brute pass works on the caller's order
-        }
-    }
-    if (hist0) {
-        __syncthreads();
-        for (int t = threadIdx.x; t < 256; t += NN1_BLOCK)
-            if (lh[t]) atomicAdd(&hist0[ICPMI_S2_C0 + (blockIdx.x % ICPMI_S2_COPIES) * 256 + t], lh[t]);
-    }
-#ifdef ICPMI_NN_TIMING
-    NN_TICK(5);
-    if (threadIdx.x == 0 && (blockIdx.x % 61) == 0) { // a sample: same-address atomics from every wave would dominate
-        const int base = st->iter > 0 ? 8 : 0; // seeded launches in dbg[8..15], the first one in dbg[0..7]
-        for (int i = 0; i < 7; ++i) atomicAdd(&st->dbg[base + i], (unsigned long long)tacc[i]);
-        atomicAdd(&st->dbg[base + 7], 1ull);
-        atomicAdd(&st->dbg[16 + (st->iter > 0 ? 1 : 0)], (unsigned long long)tacc[7]);
-    }
-#endif
-}
-
 // ------------------------------------------------------------------------------------------------
-// k = 1 over the grid pyramid, WAVE-QUEUE variant (r3; the loop's default).  Same search, same exactness rules, same
-// (d^2, index) keys as nn1_ml_kernel -- hence the same bits -- but the work of a wave is split differently:
-//
-//   nn1_ml_kernel gives G = 8 lanes to one query for the whole search, so every lane of a group repeats the query's
-//   set-up (transform, seed test, level choice, cell coordinates, pruning radius), the group pays 18 shuffles to flatten
-//   its nine rows into one candidate list, and every candidate load walks an 8-deep select chain to find its row:
-//   ~750 VALU instructions per wave for 8 queries, ~6 % of the lane-slots doing distance tests.
-//
-//   Here a one-wave workgroup owns Q = 64 / LPQ queries and alternates between two roles:
-//   (1) LANE PER QUERY (LPQ lanes share a query's nine rows): set-up once per query, row ranges looked up, and every
-//       non-empty row cut into PIECES of <= 8 consecutive candidates that go into an LDS work list {start, count, query};
-//   (2) LANE PER PIECE: lane i takes pieces i, i + 64, ... whatever query they belong to -- eight independent 16-byte
-//       loads in flight from ONE address register (immediate offsets; loads past the run's end are masked, the level
-//       arrays are padded), the piece's best key goes into the query's LDS slot by a 64-bit ds_min; the lane whose key IS
-//       the slot's value afterwards records its position (keys are unique per map point, and LDS operations of one wave
-//       complete in order: no race, no returned atomic);
-//   (3) lane per query again: read the slot, apply the level's exactness rule; undecided queries repeat at the next
-//       level (or, for a query that held no bound yet, with the bound its own row just gave it).
-//   The candidates of all Q queries are thus spread evenly over the 64 lanes however unevenly they are spread over the
-//   queries, and the per-query set-up is paid once (LPQ = 1) instead of eight times.
+// The wave-queue scheme (r3) the kernel below inherits: a workgroup owns Q = 64 queries and alternates between two roles:
+//   (1) LANE PER QUERY: set-up once per query, row ranges looked up, and every non-empty row cut into PIECES of <= 8 consecutive
+//       candidates that go into an LDS work list {start, count, query};
+//   (2) LANE PER PIECE: lane i takes pieces i, i + 64, ... whatever query they belong to -- eight independent 16-byte loads in flight
+//       from ONE address register (immediate offsets; loads past the run's end are masked, the level arrays are padded), the piece's
+//       best key goes into the query's LDS slot by a 64-bit ds_min; the lane whose key IS the slot's value afterwards records its
+//       position (keys are unique per map point, and LDS operations of one wave complete in order: no race, no returned atomic);
+//   (3) lane per query again: read the slot, apply the level's exactness rule; undecided queries repeat at the next level (or, for a
+//       query that held no bound yet, with the bound its own row just gave it).
+//   The candidates of all Q queries are thus spread evenly over the lanes however unevenly they are spread over the queries.
 // ------------------------------------------------------------------------------------------------
 // inclusive prefix sum over the 64 lanes of a wave in registers (DPP: shifts within rows of 16 lanes, then the row totals
 // broadcast into the following rows); every lane must be active
@@ -699,318 +354,6 @@ __device__ __forceinline__ unsigned wave_incl_scan(unsigned v)
     v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1, 3
     v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2, 3
     return v;
-}
-
-template <int LPQ, bool SELF>
-__global__ __launch_bounds__(64) void nn1_wq_kernel(const float4* __restrict__ queries, const int* __restrict__ qindex, BatchArgs ba,
-                                                    const float* __restrict__ Tptr, GridLevels L, float maxr2, int* __restrict__ out_sidx,
-                                                    float* __restrict__ out_d2, IcpState* __restrict__ st, unsigned* __restrict__ hard,
-                                                    unsigned* __restrict__ hist0, float4* __restrict__ match_pt,
-                                                    const uint4* __restrict__ ltab_g, int unseeded_lev, int seed_pre)
-{
-    static_assert(LPQ == 1 || LPQ == 2 || LPQ == 3 || LPQ == 4, "lanes per query in the set-up role");
-    constexpr int Q = 64 / LPQ;            // queries per wave
-    constexpr int NR = (9 + LPQ - 1) / LPQ; // rows per lane: row rr belongs to lane rr % LPQ of the query, slot rr / LPQ
-    constexpr int CAP = 16 * Q;            // pieces per pass (>= 9 Q: one piece per row always fits)
-    constexpr int PLB = 3;                 // log2 of the base piece length: 8 loads in flight per lane and piece
-    const int n = ba.n[blockIdx.y];
-    {
-        const size_t qo = (size_t)blockIdx.y * (size_t)ba.qstride;
-        queries += qo; out_sidx += qo; out_d2 += qo;
-        if (qindex) qindex += qo;
-        if (match_pt) match_pt += qo;
-        if (hist0) hist0 += (size_t)blockIdx.y * ICPMI_SELHIST_WORDS;
-        if (Tptr) Tptr = reinterpret_cast<const float*>(reinterpret_cast<const char*>(Tptr) + (size_t)blockIdx.y * sizeof(IcpState));
-        st += blockIdx.y;
-    }
-#ifdef ICPMI_NN_TIMING
-    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long tlast = clock64();
-#endif
-    __shared__ uint4 ltab[ICPMI_MAXLEV * 4];
-    __shared__ unsigned lh[256];
-    __shared__ uint4 pieces[CAP];            // {address of the first candidate (lo, hi), count << 8 | query slot, its position in the level array}
-    __shared__ float4 qrec[Q];               // transformed query, w = bits of its current level
-    __shared__ unsigned long long qkey[Q];   // best (d^2, index) key of the query so far
-    __shared__ unsigned qwin[Q];             // ... where that point sits: position | level << 28
-    __shared__ float4 qpt[Q];                // ... and the point itself (what the loop keeps as the next iteration's seed)
-    const int lane = threadIdx.x;
-    const int wgs = (int)((((long long)n + Q - 1) / Q + 7) / 8 * 8);
-    if ((int)blockIdx.x >= wgs) return;
-    const int chunk = wgs >> 3;
-    const int lb = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    const bool lane_ok = lane < Q * LPQ; // LPQ = 3: 21 queries, lane 63 idles in the set-up role
-    const int slot = lane_ok ? lane / LPQ : 0;
-    const int sub = lane_ok ? lane % LPQ : 0;
-    const int qi = lb * Q + slot;
-    const bool active = lane_ok && qi < n;
-    // ---- everything the wave needs from memory before it can start leaves in ONE round trip: stop flag, iteration, T, level
-    //      table, query, seed (a wave lives for a handful of dependent trips; each one saved is ~10 % of its life)
-    const int st_done = st->done, st_iter = st->iter;
-    uint4 ltab_mine = make_uint4(0u, 0u, 0u, 0u);
-    if (lane < ICPMI_MAXLEV * 4) ltab_mine = ltab_g[lane];
-    const float4 r = queries[active ? qi : 0];
-    const int orig = match_pt ? qi : (qindex ? qindex[active ? qi : 0] : qi);
-    int sp_kept = -1;
-    float4 qs_kept = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (match_pt) { sp_kept = out_sidx[active ? qi : 0]; qs_kept = match_pt[active ? qi : 0]; }
-    float3 p;
-    if (Tptr) p = xf_point(Tptr, r.x, r.y, r.z, r.w);
-    else p = make_float3(r.x, r.y, r.z);
-    if (st_done) return;
-    if (lane < ICPMI_MAXLEV * 4) ltab[lane] = ltab_mine;
-    if (hist0) {
-        for (int t = lane; t < 256; t += 64) lh[t] = 0;
-        // the builder of level 0 clears level 1 of the previous iteration (loop.hip, fused selection)
-        for (int gt = blockIdx.x * 64 + lane; gt < 256 + 65536; gt += wgs * 64) hist0[ICPMI_S2_C1 + gt] = 0; // (the workgroups of THIS reading: a batch launches the grid of its largest)
-    }
-    const bool allow_self = SELF;
-    __syncthreads(); // ltab / lh visible
-
-    Cand best; best.key = ~0ull; best.sidx = -1; // sidx = position in its level | level << 28
-    float4 seed_pt = make_float4(0.f, 0.f, 0.f, 0.f);
-    bool best_is_seed = false;
-    bool decided = !active;
-    int lev0 = unseeded_lev;
-    {   // seed: see nn1_ml_kernel -- the previous match bounds the answer; start at the first level whose block holds that ball
-        int sp = -1;
-        float4 qs = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (active && allow_self && st_iter > 0) {
-            sp = match_pt ? sp_kept : out_sidx[orig];
-            if (sp >= 0) qs = match_pt ? qs_kept : L.pts[0][sp];
-        }
-        bool want = sp >= 0;
-        const float ub2 = sqdist3(p.x, p.y, p.z, qs.x, qs.y, qs.z);
-        const float ub = sqrt_up(ub2);
-        auto try_level = [&](int lev, const GridParams& gl) {
-            const float fx = (p.x - gl.ox) * gl.inv_cell, fy = (p.y - gl.oy) * gl.inv_cell, fz = (p.z - gl.oz) * gl.inv_cell;
-            float mfl = fminf(fx - floorf(fx), 1.0f - (fx - floorf(fx)));
-            mfl = fminf(mfl, fminf(fy - floorf(fy), 1.0f - (fy - floorf(fy))));
-            mfl = fminf(mfl, fminf(fz - floorf(fz), 1.0f - (fz - floorf(fz))));
-            if (!(mfl >= 0.f)) mfl = 0.f;
-            const float margin = (1.0f + mfl) * gl.cell - 2.0f * gl.slack;
-            if (want && ub * 1.000001f <= margin) {
-                lev0 = lev;
-                best.key = pack_key(ub2, __float_as_uint(qs.w));
-                best.sidx = sp; // level 0 position
-                seed_pt = qs; best_is_seed = true;
-                want = false;
-            }
-        };
-        try_level(0, L.g[0]);
-        for (int lev = 1; lev < L.nlev; ++lev) {
-            if (__ballot(want) == 0ull) break;
-            try_level(lev, L.g[lev]);
-        }
-    }
-    bool widepre = false;
-    if (seed_pre && lev0 > 0 && best.key != ~0ull) { widepre = true; lev0 = 0; }
-
-    int lev = lev0;
-    bool did_pre = false; // this level's own-row pass has run
-    NN_TICK(0);
-    for (;;) {
-        const bool run = !decided && lev < L.nlev;
-        if (__ballot(run) == 0ull) break;
-        const int lv = run ? lev : 0;
-        GridParams g;
-        const gunsigned* __restrict__ cs; // (global address space: rebuilt from integers, it would be read through the flat path)
-        unsigned long long lvl_pts;
-        {
-            const uint4 a = ltab[4 * lv], b = ltab[4 * lv + 1], c2 = ltab[4 * lv + 2], d = ltab[4 * lv + 3];
-            lvl_pts = ((unsigned long long)c2.w << 32) | c2.z;
-            g.ox = __uint_as_float(a.x); g.oy = __uint_as_float(a.y); g.oz = __uint_as_float(a.z); g.cell = __uint_as_float(a.w);
-            g.inv_cell = __uint_as_float(b.x); g.slack = __uint_as_float(b.y); g.nx = (int)b.z; g.ny = (int)b.w;
-            g.nz = (int)c2.x; g.ncells = (int)c2.y;
-            cs = reinterpret_cast<const gunsigned*>(((unsigned long long)d.y << 32) | d.x);
-        }
-        const float fx = (p.x - g.ox) * g.inv_cell, fy = (p.y - g.oy) * g.inv_cell, fz = (p.z - g.oz) * g.inv_cell;
-        const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
-        const int cx = (int)fminf(fmaxf(flx, -1.0e6f), 1.0e6f);
-        const int cy = (int)fminf(fmaxf(fly, -1.0e6f), 1.0e6f);
-        const int cz = (int)fminf(fmaxf(flz, -1.0e6f), 1.0e6f);
-        float mf = fminf(fx - flx, 1.0f - (fx - flx));
-        mf = fminf(mf, fminf(fy - fly, 1.0f - (fy - fly)));
-        mf = fminf(mf, fminf(fz - flz, 1.0f - (fz - flz)));
-        if (!(mf >= 0.f)) mf = 0.f;
-        // a query that holds no bound yet (or a seed too wide for level 0, see seed_pre) first looks at the x-row through its
-        // own cell only; the pass after that prunes with what it found
-        const bool prescan = run && !did_pre && (best.key == ~0ull || (widepre && lev == 0));
-        float rub2 = INFINITY; // squared pruning radius (with slack), +inf = no pruning
-        if (!prescan && best.key != ~0ull) {
-            const float rub = sqrt_up(__uint_as_float((unsigned)(best.key >> 32))) * 1.000001f + g.slack;
-            rub2 = rub * rub;
-        }
-        // ---- role 1: row ranges.  Branch-free on purpose: with the lookups behind `if (reach)` the compiler waits for one
-        //      row's pair of loads before it issues the next row's (NR dependent round trips); unreached rows read cs[0]
-        //      twice instead and all 2 NR loads of a lane leave together.
-        unsigned rs[NR], rn[NR];
-        {
-            const float ylo = (fy - fly) * g.cell, yhi = (1.0f - (fy - fly)) * g.cell;
-            const float zlo = (fz - flz) * g.cell, zhi = (1.0f - (fz - flz)) * g.cell;
-            unsigned ia[NR], ib[NR];
-#pragma unroll
-            for (int sl = 0; sl < NR; ++sl) {
-                const int rr = sub + sl * LPQ;
-                const int dy = (rr % 3) - 1, dz = (rr / 3) - 1;
-                bool reach = run && rr < 9 && (!prescan || rr == 4);
-                const float ddy = dy == 0 ? 0.f : (dy < 0 ? ylo : yhi);
-                const float ddz = dz == 0 ? 0.f : (dz < 0 ? zlo : zhi);
-                const float rem2 = rub2 - (ddy * ddy + ddz * ddz); // +inf without a bound
-                reach = reach && rem2 >= 0.f;
-                int xa = cx - 1, xb = cx + 1;
-                if (rem2 != INFINITY) {
-                    const float rem = sqrt_up(fmaxf(rem2, 0.f));
-                    const int xl = (int)fmaxf(floorf((p.x - rem - g.ox) * g.inv_cell), -1.0e6f);
-                    const int xh = (int)fminf(floorf((p.x + rem - g.ox) * g.inv_cell), 1.0e6f);
-                    xa = xl > xa ? xl : xa;
-                    xb = xh < xb ? xh : xb;
-                }
-                const int y = cy + dy, z = cz + dz;
-                xa = xa < 0 ? 0 : xa;
-                xb = xb > g.nx - 1 ? g.nx - 1 : xb;
-                reach = reach && y >= 0 && y < g.ny && z >= 0 && z < g.nz && xa <= xb;
-                const int rowbase = (z * g.ny + y) * g.nx;
-                ia[sl] = reach ? (unsigned)(rowbase + xa) : 0u;
-                ib[sl] = reach ? (unsigned)(rowbase + xb + 1) : 0u;
-            }
-#pragma unroll
-            for (int sl = 0; sl < NR; ++sl) { rs[sl] = cs[ia[sl]]; rn[sl] = cs[ib[sl]]; }
-#pragma unroll
-            for (int sl = 0; sl < NR; ++sl) rn[sl] -= rs[sl]; // 0 for unreached rows (both loads hit cs[0])
-        }
-        NN_TICK(1);
-        if (sub == 0 && lane_ok) {
-            qrec[slot] = make_float4(p.x, p.y, p.z, __int_as_float(lv));
-            qkey[slot] = best.key;
-            qwin[slot] = (unsigned)best.sidx;
-        }
-        // ---- pieces: piece length 8, doubled until the wave's pieces fit the list (dense cells, degenerate maps); a lane's
-        //      pieces start at the exclusive prefix sum of the counts (DPP scan in registers)
-        int plb = PLB;
-        unsigned base = 0, total = 0;
-        for (;;) {
-            unsigned np = 0;
-#pragma unroll
-            for (int sl = 0; sl < NR; ++sl) np += (rn[sl] + ((1u << plb) - 1u)) >> plb;
-            const unsigned incl = wave_incl_scan(np);
-            total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
-            base = incl - np;
-            if (total <= (unsigned)CAP) break;
-            ++plb;
-        }
-#pragma unroll
-        for (int sl = 0; sl < NR; ++sl) {
-            unsigned s = rs[sl], c = rn[sl];
-            while (c) {
-                const unsigned t = c < (1u << plb) ? c : (1u << plb);
-                const unsigned long long ad = lvl_pts + (unsigned long long)s * 16ull;
-                pieces[base++] = make_uint4((unsigned)ad, (unsigned)(ad >> 32), (t << 8) | (unsigned)slot, s);
-                s += t; c -= t;
-            }
-        }
-        __syncthreads();
-        NN_TICK(2);
-#ifdef ICPMI_NN_TIMING
-        tacc[6] += 1; tacc[7] += total;
-#endif
-        // ---- role 2: lane per piece -- eight independent 16-byte loads from ONE address register (immediate offsets)
-        for (unsigned i = (unsigned)lane; i < total; i += 64u) {
-            const uint4 e = pieces[i];
-            const unsigned qsl = e.z & 255u, cnt = e.z >> 8;
-            const float4 qr = qrec[qsl];
-            // (global address space: a pointer rebuilt from integers would otherwise be loaded through the flat path)
-            const gfloat4* mp = reinterpret_cast<const gfloat4*>(((unsigned long long)e.y << 32) | e.x);
-            unsigned long long kb = ~0ull;
-            unsigned pb = 0;
-            for (unsigned c0 = 0; c0 < cnt; c0 += 8u) { // one round unless a dense cell forced pieces longer than 8
-                vf4 q[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) q[u] = mp[c0 + u]; // past the run's end: masked below (the level arrays are padded)
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const float d2 = sqdist3(qr.x, qr.y, qr.z, q[u].x, q[u].y, q[u].z);
-                    const unsigned long long key = pack_key(d2, __float_as_uint(q[u].w));
-                    bool ok = c0 + (unsigned)u < cnt;
-                    if (!allow_self) ok = ok && d2 > 1.1920929e-07f;
-                    if (ok && key < kb) { kb = key; pb = c0 + (unsigned)u; }
-                }
-            }
-            if (kb != ~0ull) {
-                atomicMin(&qkey[qsl], kb);
-                // LDS operations of one wave complete in order: this load sees the minima of every lane of this step; keys are
-                // unique per map point, so at most one lane finds its own key there
-                if (__atomic_load_n(&qkey[qsl], __ATOMIC_RELAXED) == kb) {
-                    const vf4 w = mp[pb]; // (an L1 hit: this lane loaded it a moment ago)
-                    qwin[qsl] = (e.w + pb) | (__float_as_uint(qr.w) << 28);
-                    qpt[qsl] = make_float4(w.x, w.y, w.z, w.w);
-                }
-            }
-        }
-        __syncthreads();
-        NN_TICK(3);
-        // ---- role 3: decide
-        if (run) {
-            const unsigned long long k2 = qkey[slot];
-            if (k2 != best.key) { best.key = k2; best.sidx = (int)qwin[slot]; best_is_seed = false; }
-            if (prescan) did_pre = true;
-            else {
-                const float margin = fmaxf((1.0f + mf) * g.cell - g.slack, 0.f);
-                const float m2 = margin * margin;
-                const float bd2 = __uint_as_float((unsigned)(best.key >> 32));
-                const bool covers = cx - 1 <= 0 && cx + 1 >= g.nx - 1 && cy - 1 <= 0 && cy + 1 >= g.ny - 1 && cz - 1 <= 0 && cz + 1 >= g.nz - 1;
-                decided = (best.key != ~0ull && bd2 <= m2) || m2 > maxr2 || covers;
-                if (!decided) { ++lev; did_pre = false; }
-            }
-        }
-        if (__ballot(!decided && lev < L.nlev) != 0ull) __syncthreads(); // slots are rewritten by the next pass
-        NN_TICK(4);
-    }
-
-    float bd2 = __uint_as_float((unsigned)(best.key >> 32));
-    const bool found = best.key != ~0ull && bd2 <= maxr2;
-    if (!found) bd2 = INFINITY;
-    const bool writer = active && sub == 0;
-    if (hist0) { // coarse level-0 histogram through LDS first: its barrier must not sit behind the global stores below
-        if (writer && bd2 != INFINITY && bd2 > 0.f) atomicAdd(&lh[__float_as_uint(bd2) >> 24], 1u);
-        __syncthreads();
-        for (int t = lane; t < 256; t += 64)
-            if (lh[t]) atomicAdd(&hist0[ICPMI_S2_C0 + (blockIdx.x % ICPMI_S2_COPIES) * 256 + t], lh[t]);
-    }
-    if (writer) {
-        int bs = -1;
-        float4 mpt = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (found) {
-            const unsigned lvb = (unsigned)best.sidx >> 28, pos = (unsigned)best.sidx & 0x0fffffffu;
-            if (lvb == 0) bs = (int)pos;
-            else {
-                const uint4 d = ltab[4 * lvb + 3];
-                bs = (int)reinterpret_cast<const unsigned*>(((unsigned long long)d.w << 32) | d.z)[pos];
-            }
-            mpt = best_is_seed ? seed_pt : qpt[slot];
-        }
-        out_sidx[orig] = bs;
-        out_d2[orig] = bd2;
-        if (match_pt) match_pt[orig] = make_float4(mpt.x, mpt.y, mpt.z, __uint_as_float((unsigned)(best.key & 0xffffffffull)));
-        if (hist0 && bd2 != INFINITY && bd2 > 0.f) {
-            const unsigned bits = __float_as_uint(bd2);
-            atomicAdd(&hist0[ICPMI_S2_F0 + (blockIdx.x % ICPMI_S2_FCOPIES) * 65536 + ICPMI_S2_FIDX(bits >> 16)], 1u);
-        }
-        if (!decided) {
-            const unsigned hslot = atomicAdd(&st->hard_count, 1u);
-            hard[hslot] = (unsigned)(qindex ? qindex[qi] : qi); // the brute pass works on the caller's order
-        }
-    }
-#ifdef ICPMI_NN_TIMING
-    NN_TICK(5);
-    if (threadIdx.x == 0 && (blockIdx.x % 61) == 0) { // a sample: same-address atomics from every wave would dominate
-        const int tb = st_iter > 1 ? 8 : 0; // steady launches in dbg[8..15], the first two in dbg[0..7]
-        for (int i = 0; i < 6; ++i) atomicAdd(&st->dbg[tb + i], (unsigned long long)tacc[i]);
-        atomicAdd(&st->dbg[tb + 6], (unsigned long long)tacc[6]);
-        atomicAdd(&st->dbg[tb + 7], 1ull);
-        atomicAdd(&st->dbg[16 + (st_iter > 1 ? 1 : 0)], (unsigned long long)tacc[7]);
-    }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1027,7 +370,7 @@ __global__ __launch_bounds__(64) void nn1_wq_kernel(const float4* __restrict__ q
 //   (1b) all four waves, lane = query, WAVE = ROW GROUP (rows w, w + 4, w + 8 of the 3 x 3 block): row ranges, pieces;
 //   (2)  all four waves, lane per piece (one or two steps for 64 queries);
 //   (3)  wave 0 decides and stores.
-// Same keys, same exactness rules, same bits as nn1_ml_kernel / nn1_wq_kernel.
+// Same keys and exactness rules as the r1 - r3 kernels it replaced: same bits.
 // ------------------------------------------------------------------------------------------------
 template <int NW, bool SELF>
 __global__ __launch_bounds__(64 * NW) void nn1_wg_kernel(const float4* __restrict__ queries, const int* __restrict__ qindex, BatchArgs ba,
@@ -2150,92 +1493,26 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
         // single 2048-bin level-0 histogram flushed by every workgroup cost +20 us in same-address
         // atomics; the two-tier layout removes that.)  ICPMI_NN_FUSE_HIST0=0 falls back to the
         // stand-alone builder kernel.
-        static int unseeded_lev_cfg = -1;
-        if (unseeded_lev_cfg < 0) { const char* e = getenv("ICPMI_NN_UNSEEDED_LEVEL"); unseeded_lev_cfg = e ? atoi(e) : 0; }
-        const int unseeded_lev = unseeded_lev_cfg < c->levels.nlev ? unseeded_lev_cfg : c->levels.nlev - 1;
-        static int fuse_h0 = -1;
-        if (fuse_h0 < 0) { const char* e = getenv("ICPMI_NN_FUSE_HIST0"); fuse_h0 = e ? atoi(e) : 1; }
+        const int unseeded_lev = 0;
         // r5: a chain that may need the brute pass (unbounded maxDist -- PM::ICPSequence::setDefault() --, or a maxDist beyond the top level's
-        // block) used to fall off the fast path altogether: state in the caller's order, no fused histogram, no matched points.  With the
-        // four-wave kernel the queue now holds query slots and the brute pass writes the same state (point, histogram) for what it decides.
-        static int hard_sorted_cfg = -1;
-        if (hard_sorted_cfg < 0) {
-            const char* e = getenv("ICPMI_HARD_SORTED"); hard_sorted_cfg = e ? atoi(e) : 1;
-            const char* wq = getenv("ICPMI_NN_WQ"); const char* wg = getenv("ICPMI_NN_WG");
-            if ((wq && atoi(wq) == 0) || (wg && atoi(wg) != 4)) hard_sorted_cfg = 0; // (only nn1_wg_kernel<4, ..> queues slots)
-        }
-        const bool hard_sorted = needs_hard && hard_sorted_cfg && allow_self && sorted && c->batch_cur <= 1;
-        unsigned* h0 = ((needs_hard && !hard_sorted) || !fuse_h0) ? nullptr : c->nn_hist0;
+        // block) keeps the fast path: the queue holds query slots and the brute pass writes the same state (point, histogram) for what it decides.
+        const bool hard_sorted = needs_hard && allow_self && sorted && c->batch_cur <= 1;
+        unsigned* h0 = (needs_hard && !hard_sorted) ? nullptr : c->nn_hist0;
         c->nn_builds_hist0 = h0 != nullptr;
         // loop mode keeps the per-query state in query order
         float4* mp = ((needs_hard && !hard_sorted) || !sorted) ? nullptr : c->nn_match_pt;
         c->nn_out_sorted = mp != nullptr;
-        static int seed_pre_cfg = -1;
-        if (seed_pre_cfg < 0) { const char* e = getenv("ICPMI_NN_SEED_PRE"); seed_pre_cfg = e ? atoi(e) : 2; }
         // a batch (c->batch_cur > 1, set by loop_run_batch): grid.y = readings, grid.x sized for the largest one
         const BatchArgs ba = c->batch_cur > 1 ? c->batch_args : batch_of_one(n);
-#define LAUNCH_ML(G_, NB_) do { if (allow_self) LAUNCH_ML2(G_, NB_, true); else LAUNCH_ML2(G_, NB_, false); } while (0)
-#define LAUNCH_ML2(G_, NB_, S_)                                                                                                 \
-    hipLaunchKernelGGL((nn1_ml_kernel<G_, NB_, S_>), dim3((int)(((n * G_ + NN1_BLOCK - 1) / NN1_BLOCK + 7) / 8 * 8), ba.nscan), dim3(NN1_BLOCK), 0,  \
-                       c->stream, q, qi, ba, d_T, c->levels, lc.maxr2, allow_self, d_sidx, d_d2, d_state, c->d_hard, h0, mp,  \
-                       c->d_lvl_tab, unseeded_lev, seed_pre)
-        // iterations > 0 are seeded by the previous match (a handful of candidates per query): fewer
-        // lanes per query; the unseeded first pass scans whole 27-cell blocks: more lanes per query
+        // the first solve moves the reading by the whole initial misalignment, so the seeds of iteration 1 bound the search no better than a
+        // fresh own-row scan: that launch starts with the own-row pass at level 0 (seed_pre), the later ones go straight to their seed
         const bool seeded = c->nn_iter_hint > 0 && allow_self;
-        static int g_seeded = -1, wide_until = -1;
-        if (g_seeded < 0) { const char* e = getenv("ICPMI_NN_G"); g_seeded = e ? atoi(e) : 8; }
-        if (wide_until < 0) { const char* e = getenv("ICPMI_NN_WIDE_UNTIL"); wide_until = e ? atoi(e) : 1; }
-        // the first solve moves the reading by the whole initial misalignment, so the seeds of iteration 1 bound the
-        // search no better than a fresh own-row scan: it still looks at a few hundred candidates per query and runs
-        // faster 16 lanes wide (r1: 80 us with 8 lanes, measured below)
-        const bool narrow = seeded && c->nn_iter_hint > wide_until;
-        const int seed_pre = seed_pre_cfg == 2 ? (narrow ? 0 : 1) : seed_pre_cfg; // 2: only on the wide launch after the first solve
-        // One registration is latency-bound and runs best 8 lanes wide; a launch with several hundred thousand queries (a
-        // batch, a very large reading) is throughput-bound, where the work every lane of a group repeats (cell coordinates,
-        // pruning radius, row bounds) is what counts: 4 lanes per query (r2, batch of 8 x 100 k: +10 % point-to-point,
-        // +20 % point-to-plane; a single 100 k reading: -10 % / +4 %).  ICPMI_NN_G forces a width, ICPMI_NN_G4_FROM the switch.
-        static long long g4_from = -1;
-        if (g4_from < 0) { const char* e = getenv("ICPMI_NN_G4_FROM"); g4_from = e ? atoll(e) : 300000; }
-        long long total_q = 0;
-        for (int b = 0; b < ba.nscan; ++b) total_q += ba.n[b];
-        const int g_narrow = getenv("ICPMI_NN_G") ? g_seeded : (total_q >= g4_from ? 4 : 8);
-        // r3: the wave-queue kernel (nn1_wq_kernel) is the default; ICPMI_NN_WQ=0 brings nn1_ml_kernel back for A/B runs
-        static int use_wq = -1, wq_lpq = -1;
-        if (use_wq < 0) { const char* e = getenv("ICPMI_NN_WQ"); use_wq = e ? atoi(e) : 1; }
-        if (wq_lpq < 0) { const char* e = getenv("ICPMI_NN_WQ_LPQ"); wq_lpq = e ? atoi(e) : 2; }
-#define LAUNCH_WQ2(LPQ_, S_)                                                                                                    \
-    hipLaunchKernelGGL((nn1_wq_kernel<LPQ_, S_>), dim3((int)(((n + (64 / LPQ_) - 1) / (64 / LPQ_) + 7) / 8 * 8), ba.nscan), dim3(64), 0, c->stream,   \
+        const int seed_pre = (seeded && c->nn_iter_hint > 1) ? 0 : 1;
+#define LAUNCH_WG(S_)                                                                                                           \
+    hipLaunchKernelGGL((nn1_wg_kernel<4, S_>), dim3((int)(((n + 63) / 64 + 7) / 8 * 8), ba.nscan), dim3(256), 0, c->stream,    \
                        q, qi, ba, d_T, c->levels, lc.maxr2, d_sidx, d_d2, d_state, c->d_hard, h0, mp, c->d_lvl_tab, unseeded_lev, seed_pre)
-#define LAUNCH_WQ(LPQ_) do { if (allow_self) LAUNCH_WQ2(LPQ_, true); else LAUNCH_WQ2(LPQ_, false); } while (0)
-        static int wg_nw = -1;
-        if (wg_nw < 0) { const char* e = getenv("ICPMI_NN_WG"); wg_nw = e ? atoi(e) : 4; }
-#define LAUNCH_WG2(NW_, S_)                                                                                                     \
-    hipLaunchKernelGGL((nn1_wg_kernel<NW_, S_>), dim3((int)(((n + 63) / 64 + 7) / 8 * 8), ba.nscan), dim3(64 * NW_), 0, c->stream,  \
-                       q, qi, ba, d_T, c->levels, lc.maxr2, d_sidx, d_d2, d_state, c->d_hard, h0, mp, c->d_lvl_tab, unseeded_lev, seed_pre)
-        if (use_wq && wg_nw == 4) {
-            if (allow_self) LAUNCH_WG2(4, true); else LAUNCH_WG2(4, false);
-            // diagnostic (r5, scripts/r5/l2_real.sh): the same search once more, right behind the first, without the histogram -- what does
-            // the SECOND launch fetch past the L2?  (results unchanged: the repeat is seeded with the answer)
-            static int nn_twice = -1;
-            if (nn_twice < 0) { const char* e = getenv("ICPMI_NN_TWICE"); nn_twice = e ? atoi(e) : 0; }
-            if (nn_twice && allow_self && mp) { h0 = nullptr; LAUNCH_WG2(4, true); }
-        }
-        else if (use_wq && wg_nw > 0) { if (allow_self) LAUNCH_WG2(3, true); else LAUNCH_WG2(3, false); }
-        else if (use_wq) {
-            if (wq_lpq == 1) LAUNCH_WQ(1);
-            else if (wq_lpq == 3) LAUNCH_WQ(3);
-            else if (wq_lpq == 4) LAUNCH_WQ(4);
-            else LAUNCH_WQ(2);
-        }
-        else if (narrow && g_narrow == 2) LAUNCH_ML(2, 4);
-        else if (narrow && g_narrow == 4) LAUNCH_ML(4, 4);
-        else if (narrow) LAUNCH_ML(8, 4);
-        else if (total_q >= g4_from && !getenv("ICPMI_NN_WIDE16")) LAUNCH_ML(8, 4); // the wide first launches, likewise one step narrower
-        else LAUNCH_ML(16, 4);
-#undef LAUNCH_ML
-#undef LAUNCH_ML2
-#undef LAUNCH_WQ
-#undef LAUNCH_WQ2
+        if (allow_self) LAUNCH_WG(true); else LAUNCH_WG(false);
+#undef LAUNCH_WG
         const GridParams& top = c->levels.g[c->levels.nlev - 1];
         if (!std::isfinite(lc.max_dist) || (top.cell - top.slack) <= lc.max_dist) {
             if (hard_sorted && mp)
@@ -2258,31 +1535,26 @@ static icpmi_status nnk_launch_t(icpmi_ctx* c, const float4* d_reading, int64_t 
 {
     if constexpr (KMAX <= 16) if (n > 0) {
         constexpr int KM = KMAX; // (k <= 16: the cooperative kernels; r2 stopped at 8 and left knn 10 on the one-lane kernel, 5 x slower)
-        static int use_ml = -1;
-        if (use_ml < 0) { const char* e = getenv("ICPMI_NNK_ML"); use_ml = e ? atoi(e) : 1; }
-        if (use_ml) {
+        {
             constexpr int G = 8;
             const bool sorted = c->qsorted_n == n && c->qsorted_src == d_reading;
             const float4* q = sorted ? c->d_qsorted : d_reading;
             const int* qi = sorted ? c->d_qindex : nullptr;
-            static int ml_pre = -1; // bit 1 of `seeded`: wide seeds start with the own-row pass at level 0 (nnk_ml_kernel)
-            if (ml_pre < 0) { const char* e = getenv("ICPMI_NNK_ML_SEED_PRE"); ml_pre = e ? atoi(e) : 1; }
-            const int seeded = (c->nn_iter_hint > 0 && allow_self) ? (1 | (ml_pre ? 2 : 0)) : 0;
+            const int seeded = (c->nn_iter_hint > 0 && allow_self) ? 3 : 0; // bit 1: wide seeds start with the own-row pass at level 0 (nnk_ml_kernel)
             const int grid = (int)(((n * G + NN_BLOCK - 1) / NN_BLOCK + 7) / 8 * 8);
             const GridParams& top = c->levels.g[c->levels.nlev - 1];
             const bool needs_hard = !std::isfinite(lc.max_dist) || (top.cell - top.slack) <= lc.max_dist;
             // loop mode: results in query order (the brute-force pass works in the caller's order: chains that may need it stay there)
             const int out_sorted = (c->nn_sorted_k && sorted && !needs_hard) ? 1 : 0;
             c->nn_out_sorted = out_sorted != 0;
-            // the loop's seeded launches from iteration ICPMI_NNK_WG_FROM on: nnk_wg_kernel (a negative value: nnk_ml_kernel everywhere)
-            static int wg_from = -2, wg_pre = -1;
-            if (wg_from == -2) { const char* e = getenv("ICPMI_NNK_WG_FROM"); wg_from = e ? atoi(e) : 2; }
-            if (wg_pre < 0) { const char* e = getenv("ICPMI_NNK_SEED_PRE"); wg_pre = e ? atoi(e) : 1; }
+            // the loop's seeded launches from iteration 2 on: nnk_wg_kernel; iterations 0 / 1 (no seed / seeds the first solve moved far), batches and
+            // stage calls: nnk_ml_kernel.  (icpmi_config::knn_wg_from, a test seam: -1 = nnk_ml_kernel everywhere, 0 / 1 = nnk_wg_kernel earlier.)
+            const int wg_from = c->cfg.knn_wg_from == 0 ? 2 : (c->cfg.knn_wg_from < 0 ? -1 : c->cfg.knn_wg_from - 1);
+            const int wg_pre = 1;
             const bool use_wg = wg_from >= 0 && allow_self && c->nn_iter_hint >= wg_from && c->batch_cur <= 1;
             // (r5) the speculative window of the fused selection (common.h: ICPMI_S2_WIN): loops with one quantile filter whose every query is
-            // decided on the pyramid (the brute pass rewrites d2 afterwards), below 2^21 matches (the packed counts cannot carry); ICPMI_SEL_WIN=0: off
-            static int sel_win = -1;
-            if (sel_win < 0) { const char* e = getenv("ICPMI_SEL_WIN"); sel_win = e ? atoi(e) : 1; }
+            // decided on the pyramid (the brute pass rewrites d2 afterwards), below 2^21 matches (the packed counts cannot carry); icpmi_config::sel_window_off: off
+            const int sel_win = c->cfg.sel_window_off ? 0 : 1;
             c->nn_builds_win = use_wg && sel_win && c->nn_hist0 != nullptr && d_d2 == c->d_d2 && !needs_hard && n * (int64_t)lc.k < ICPMI_WIN_MAX_COUNT;
             if (use_wg)
                 hipLaunchKernelGGL((nnk_wg_kernel<KM>), dim3((int)(((n + 63) / 64 + 7) / 8 * 8)), dim3(256), 0, c->stream, q, qi,
@@ -2300,17 +1572,20 @@ static icpmi_status nnk_launch_t(icpmi_ctx* c, const float4* d_reading, int64_t 
             return ICPMI_OK;
         }
     }
-    const int blocks = (int)((n + NN_BLOCK - 1) / NN_BLOCK);
-    if (blocks == 0) return ICPMI_OK;
-    hipLaunchKernelGGL(nnk_kernel<KMAX>, dim3(blocks), dim3(NN_BLOCK), 0, c->stream, d_reading, (int)n, d_T, c->grid,
-                       c->d_map_sorted, c->d_cell_start, lc.k, lc.maxr2, lc.ring_max, allow_self, d_sidx, d_d2, d_state, c->d_hard,
-                       (const unsigned*)nullptr, (const unsigned*)nullptr);
-    if (!std::isfinite(lc.max_dist) || lc.ring_max < (int)ceilf(lc.max_dist / c->grid.cell) + 1) {
-        hipLaunchKernelGGL(nnk_hard_kernel<KMAX>, dim3(512), dim3(NN_BLOCK), 0, c->stream, d_reading, d_T, c->d_map_sorted,
-                           (int)c->m, lc.k, lc.maxr2, allow_self, d_sidx, d_d2, d_state, c->d_hard);
-        hipLaunchKernelGGL(hard_reset_kernel, dim3(1), dim3(64), 0, c->stream, d_state);
+    // k = 17 .. 32: one lane per query, ring search (the cooperative kernels keep their lists in registers up to k = 16)
+    if constexpr (KMAX > 16) {
+        const int blocks = (int)((n + NN_BLOCK - 1) / NN_BLOCK);
+        if (blocks == 0) return ICPMI_OK;
+        hipLaunchKernelGGL(nnk_kernel<KMAX>, dim3(blocks), dim3(NN_BLOCK), 0, c->stream, d_reading, (int)n, d_T, c->grid,
+                           c->d_map_sorted, c->d_cell_start, lc.k, lc.maxr2, lc.ring_max, allow_self, d_sidx, d_d2, d_state, c->d_hard,
+                           (const unsigned*)nullptr, (const unsigned*)nullptr);
+        if (!std::isfinite(lc.max_dist) || lc.ring_max < (int)ceilf(lc.max_dist / c->grid.cell) + 1) {
+            hipLaunchKernelGGL(nnk_hard_kernel<KMAX>, dim3(512), dim3(NN_BLOCK), 0, c->stream, d_reading, d_T, c->d_map_sorted,
+                               (int)c->m, lc.k, lc.maxr2, allow_self, d_sidx, d_d2, d_state, c->d_hard);
+            hipLaunchKernelGGL(hard_reset_kernel, dim3(1), dim3(64), 0, c->stream, d_state);
+        }
+        HIP_TRY(c, hipGetLastError());
     }
-    HIP_TRY(c, hipGetLastError());
     return ICPMI_OK;
 }
 

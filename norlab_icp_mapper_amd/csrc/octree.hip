@@ -328,9 +328,7 @@ icpmi_status octree_sample_dev(icpmi_ctx* c, const float4* d_in, int64_t n, floa
     const int root_tag = ++c->oct_tag ? c->oct_tag : ++c->oct_tag;
     hipLaunchKernelGGL(oct_root_kernel, dim3(1), dim3(OB), 0, c->stream, (const float*)d_part, rb, max_size, d_root, d_root_host, root_tag);
     HIP_TRY(c, hipGetLastError());
-    static int speculate = -1;
-    if (speculate < 0) { const char* e = getenv("ICPMI_OCT_SPECULATE"); speculate = e ? atoi(e) : 1; }
-    int depth = (speculate && h_root && c->oct_depth_hint > 0) ? c->oct_depth_hint : -1;
+    int depth = (h_root && c->oct_depth_hint > 0) ? c->oct_depth_hint : -1;
     if (depth < 0) {
         OctRoot root;
         if (read_back(c, &root, d_root, sizeof root) != ICPMI_OK) return ICPMI_ERR_HIP;

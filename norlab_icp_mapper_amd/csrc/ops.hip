@@ -242,8 +242,7 @@ __global__ __launch_bounds__(128) void normals_kernel(const float4* __restrict__
 static void launch_normals(hipStream_t stream, const float4* map, const int* sidx, int64_t m, int k, float* normals3, float* densities, int dim2,
                            float* mean_dist = nullptr, float* eig_values = nullptr, float* eig_vectors = nullptr)
 {
-    static int reg = -1;
-    if (reg < 0) { const char* e = getenv("ICPMI_NORMALS_REG"); reg = e ? atoi(e) : 1; }
+    constexpr int reg = 1;
     const dim3 grid((int)((m + 127) / 128)), block(128);
     if (reg && k <= 10) hipLaunchKernelGGL(normals_kernel<10>, grid, block, 0, stream, map, sidx, m, k, normals3, densities, dim2, mean_dist, eig_values, eig_vectors);
     else if (reg && k <= 16) hipLaunchKernelGGL(normals_kernel<16>, grid, block, 0, stream, map, sidx, m, k, normals3, densities, dim2, mean_dist, eig_values, eig_vectors);
@@ -614,9 +613,7 @@ struct TempCtx {
 // so stream order replaces the hipStreamSynchronize pairs an own stream needs (r2: two per surface-normal step of a map update)
 static void share_stream(icpmi_ctx* c, icpmi_ctx* t)
 {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("ICPMI_SHARE_STREAM"); on = e ? atoi(e) : 1; }
-    if (!on || t->stream == c->stream) { (void)zero_state_if_pending(t); return; } // (a handle that keeps its own stream still starts from a cleared state: ADVICE r5)
+    if (t->stream == c->stream) { (void)zero_state_if_pending(t); return; } // (a handle that keeps its own stream still starts from a cleared state: ADVICE r5)
     if (t->stream) (void)hipStreamSynchronize(t->stream);
     if (t->own_stream && t->stream) stream_release(t->stream);
     t->stream = c->stream; t->own_stream = false;
@@ -664,10 +661,8 @@ static icpmi_status raw_index(icpmi_ctx* c, icpmi_ctx** out, float reach)
     // merge test compares the keep masks with the oracle's search of the raw map).  A point's cell was assigned from its centred
     // coordinates; a query's cell comes from raw ones: the two agree up to rounding far below the grid's slack.
     {
-        static int view_on = -1;
-        if (view_on < 0) { const char* e = getenv("ICPMI_RAW_VIEW"); view_on = e ? atoi(e) : 1; }
         const GridParams& g0 = c->levels.g[0];
-        if (view_on && c->ins_ready && c->d_raw0 && !c->no_centre && c->m > 0 && c->m == c->m_raw && (g0.cell - 2.f * g0.slack) > want * 1.001f) {
+        if (c->ins_ready && c->d_raw0 && !c->no_centre && c->m > 0 && c->m == c->m_raw && (g0.cell - 2.f * g0.slack) > want * 1.001f) {
             if (c->raw_view_version != c->map_version || t->m != c->m) {
                 float maxabs = 0.f;
                 for (int r = 0; r < 3; ++r) maxabs = fmaxf(maxabs, fmaxf(fabsf(c->lo_raw[r]), fabsf(c->hi_raw[r])));
@@ -1420,7 +1415,7 @@ icpmi_status ops_map_update_chain(icpmi_ctx* c, const float4* d_scan, int64_t n,
         t0 = std::chrono::steady_clock::now();
     };
     tick(nullptr, 0);
-    static const bool overlap = [] { const char* e = getenv("ICPMI_CHAIN_OVERLAP"); return !e || atoi(e) != 0; }();
+    constexpr bool overlap = true;
     bool forked = false;
     // whatever path leaves this function between a fork and its join (an error return inside the operator loop): nothing may still be
     // running on the side stream when the caller drops or reuses the arrays it works on
@@ -1846,9 +1841,8 @@ static icpmi_status merge_greedy(icpmi_ctx* c, const float4* recv, const std::ve
         hipLaunchKernelGGL(merge_hash_scatter_kernel, dim3(gblocks), dim3(256), 0, c->stream, maxc, R, mb, (const unsigned*)tcnt, (const unsigned*)slot_of,
                            (const unsigned*)rank_of, recv, cell_pts);
         const double lim = pd_limit(min_dist);
-        static int one_launch = -1; // ICPMI_MERGE_FLAG_ALL=0: the R - 1 launches of r4 (A/B, and the fall-back for sets too large to trust co-dispatch)
-        if (one_launch < 0) { const char* e = getenv("ICPMI_MERGE_FLAG_ALL"); one_launch = e ? atoi(e) : 1; }
-        if (one_launch && span <= (1ll << 22)) {
+        // (sets too large to trust co-dispatch take the R - 1 launches of r4)
+        if (span <= (1ll << 22)) {
             unsigned* status = scratch_get<unsigned>(c, 8, (size_t)span + 2);
             if (!status) return ICPMI_ERR_HIP;
             HIP_TRY(c, hipMemsetAsync(status, 0, ((size_t)span + 2) * sizeof(unsigned), c->stream));

@@ -733,8 +733,7 @@ icpmi_status selfgrid_knn(icpmi_ctx* c, const float4* d_pts, int64_t m, int k, i
 
     // ---- the edge of an A-cell.  What the search pays for is the number of points an average POINT finds in its cell (size-biased occupancy:
     //      sum of squared cell counts / points); the previous build of this handle left that number in the host-mapped page ----
-    static const double target_cfg = [] { const char* e = getenv("ICPMI_SG_TARGET"); return e ? atof(e) : 0.0; }();
-    const double target = target_cfg > 0.0 ? target_cfg : std::max(2.0, 0.8 * (double)k);
+    const double target = std::max(2.0, 0.8 * (double)k);
     volatile unsigned long long* h_sq = c->h_progress ? reinterpret_cast<volatile unsigned long long*>(c->h_progress + ICPMI_PROGRESS_SELF_WORD) : nullptr;
     unsigned long long* d_sq = c->d_progress ? reinterpret_cast<unsigned long long*>(c->d_progress + ICPMI_PROGRESS_SELF_WORD) : nullptr;
     auto make = [&](double cell_d) {

@@ -31,7 +31,7 @@ def _bits(T):
 @pytest.mark.parametrize("checked", [1, 0])
 def test_mapper_mode_leaves_its_graphs_and_comes_back_with_the_same_bits(amd, small_scene, checked):
     """A mapper replaces its map behind every scan: after two graph sets that served one registration each the handle runs its loops
-    eagerly (ICPMI_GRAPH_ADAPT), and returns to graphs when a map is registered against twice.  Checked loops (Counter + Differential:
+    eagerly, and returns to graphs when a map is registered against twice.  Checked loops (Counter + Differential:
     segment graphs) and the Counter-only chain of the shipped configuration (one graph): every pose equals, bit for bit, the pose of a
     handle that never used a graph."""
     sc = small_scene
@@ -204,9 +204,11 @@ print("DIGEST", h.hexdigest(), m)
 
 
 def test_switches_off_same_bits():
-    """The same four scans through registration + the shipped map-update chain in three fresh processes: defaults; no block cache, no
-    graph adaptation, no chain overlap, no octree speculation; and the self-search grid on the mean-occupancy rule only.  One digest over
-    every correction, every provenance vector and the surviving probabilities."""
+    """The same four scans through registration + the shipped map-update chain in two fresh processes: defaults, and without the device
+    block cache (ICPMI_ALLOC_CACHE_MB=0: every array a fresh hipMalloc, nothing handed from one use to the next).  One digest over every
+    correction, every provenance vector and the surviving probabilities.  (Through r5 this test also switched graph adaptation, chain overlap,
+    octree speculation and the fast finish off by environment variables; r6 removed those switches -- the paths they selected are the only
+    ones left, held to the oracle by the rest of the suite.)"""
     def run(extra):
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", _CHILD % ROOT], capture_output=True, text=True, timeout=600, env=env)
@@ -215,10 +217,8 @@ def test_switches_off_same_bits():
         assert line, r.stdout[-500:] + r.stderr[-500:]
         return line[0]
     a = run({})
-    b = run({"ICPMI_ALLOC_CACHE_MB": "0", "ICPMI_GRAPH_ADAPT": "0", "ICPMI_CHAIN_OVERLAP": "0", "ICPMI_OCT_SPECULATE": "0", "ICPMI_SEG_ADAPT": "0",
-             "ICPMI_FAST_FINISH": "0"})
-    c = run({"ICPMI_SELF_SB_TARGET": "0", "ICPMI_SCAN2": "0"})
-    assert a == b == c
+    b = run({"ICPMI_ALLOC_CACHE_MB": "0"})
+    assert a == b
 
 
 def test_self_search_grid_follows_the_density_and_the_neighbours_do_not(amd, oracle):

@@ -3,14 +3,11 @@ ICPMI_S2_WIN; nn.hip: nnk_wg_kernel's tail; loop.hip: win_lookup) may only chang
 
 The NN kernel counts its distances into seven bins around the previous iteration's 16-bit prefix + below + above; when the selected
 rank falls inside, the stand-alone level-0 builder has nothing to do.  Hit or miss the counts are exact: trim limit, pair count and pose
-of every registration must be the bits of a process with ICPMI_SEL_WIN=0 -- and the window must really have served iterations
+of every registration must be the bits of a handle with icpmi_config::sel_window_off = 1 -- and the window must really have served iterations
 (icpmi_debug_counters slots 12 / 13: iterations served by the window / by the full histogram behind a window that missed).
 
-The switch is read once per process, hence subprocesses; the default process is also held to the oracle here and by the rest of the suite."""
-import json
+The default handle is also held to the oracle here and by the rest of the suite."""
 import os
-import subprocess
-import sys
 
 import numpy as np
 import pytest
@@ -25,34 +22,23 @@ def amd():
     import norlab_icp_mapper_amd as pkg
     return pkg
 
-SCRIPT = r"""
-import json, sys
-import numpy as np
-import norlab_icp_mapper_amd as pkg
-k, m, n, graph, minimizer, quant, iters, checked = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), float(sys.argv[6]), int(sys.argv[7]), int(sys.argv[8])
-sc = pkg.synth.make_scene(m=m, n=n)
-out_type = 3 if quant == 0.5 else 4   # MedianDist{factor} / TrimmedDist{ratio}
-icp = pkg.ICPSequence(minimizer=minimizer, knn=k, max_dist=2.0, outliers=[(out_type, 3.0 if out_type == 3 else quant)], max_iterations=iters,
-                      use_differential=checked, use_graph=graph)
-icp.setMap(sc["map"], sc["normals"])
-out = []
-scans = [sc["scan"], sc["scan"][::2].copy(), sc["scan"]]
-for s in scans:
-    T = np.asarray(icp(s), dtype=np.float64)
-    dbg = icp.debugCounters()
-    out.append(dict(T=T.tobytes().hex(), it=int(icp.stats.iterations), pairs=int(icp.stats.pairs),
-                    limit=float(icp.stats.trimmed_limit).hex(), ratio=float(icp.stats.weighted_point_used_ratio).hex(),
-                    win_hit=int(dbg[12]), win_miss=int(dbg[13])))
-print("RESULT " + json.dumps(out))
-"""
-
-
-def run_variant(env_extra, *args):
-    env = dict(os.environ, PYTHONPATH=ROOT, **env_extra)
-    p = subprocess.run([sys.executable, "-c", SCRIPT] + [str(a) for a in args], env=env, capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0, p.stderr[-2000:]
-    line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1]
-    return json.loads(line[len("RESULT "):])
+def run_variant(extra, k, m, n, graph, minimizer, quant, iters, checked):
+    """three registrations on one handle; `extra`: engine fields of icpmi_config (sel_window_off -- an environment switch read once per process
+    through r5, hence this file's subprocesses then; a per-handle field since r6)"""
+    import norlab_icp_mapper_amd as pkg
+    sc = pkg.synth.make_scene(m=m, n=n)
+    out_type = 3 if quant == 0.5 else 4   # MedianDist{factor} / TrimmedDist{ratio}
+    icp = pkg.ICPSequence(minimizer=minimizer, knn=k, max_dist=2.0, outliers=[(out_type, 3.0 if out_type == 3 else quant)], max_iterations=iters,
+                          use_differential=checked, use_graph=graph, **extra)
+    icp.setMap(sc["map"], sc["normals"])
+    out = []
+    for s in [sc["scan"], sc["scan"][::2].copy(), sc["scan"]]:
+        T = np.asarray(icp(s), dtype=np.float64)
+        dbg = icp.debugCounters()
+        out.append(dict(T=T.tobytes().hex(), it=int(icp.stats.iterations), pairs=int(icp.stats.pairs),
+                        limit=float(icp.stats.trimmed_limit).hex(), ratio=float(icp.stats.weighted_point_used_ratio).hex(),
+                        win_hit=int(dbg[12]), win_miss=int(dbg[13])))
+    return out
 
 
 def strip(rs):
@@ -69,11 +55,11 @@ CASES = [(6, 400_000, 50_000, 1, 2, 0.85, 20, 0),   # the documented chain's sha
 
 @pytest.mark.parametrize("case", CASES)
 def test_window_changes_no_bit(case):
-    ref = run_variant({"ICPMI_SEL_WIN": "0"}, *case)
+    ref = run_variant({"sel_window_off": 1}, *case)
     assert all(r["win_hit"] == 0 and r["win_miss"] == 0 for r in ref)
     assert ref[0]["it"] > 5, "the registration must run seeded iterations"
     both = run_variant({}, *case)
-    assert strip(both) == strip(ref), f"defaults differ from the switched-off process: {both} vs {ref}"
+    assert strip(both) == strip(ref), f"defaults differ from the switched-off handle: {both} vs {ref}"
     # the window was looked at in every iteration nnk_wg_kernel served (from iteration 2 on) ...
     # (a segment graph of a checked loop may run dead iterations behind the stop: they return before they count)
     for r in both:
