@@ -154,8 +154,9 @@ typedef struct {
     float   weighted_point_used_ratio; /* sum w / (knn N) == getOverlap()                         */
     float   trimmed_limit;             /* last quantile limit on d^2 (Trimmed / Median), else -1  */
     float   loop_ms;                   /* device time of the iteration loop (HIP events)          */
-    float   nn_ms_avg;                 /* profile mode: mean NN launch time (event-pair gap removed) */
-    int32_t nn_launches;               /* profile mode: number of NN launches averaged            */
+    float   nn_ms_avg;                 /* mean NN launch time: profile mode = HIP events (event-pair gap removed); otherwise device  */
+                                       /* clocks from the NN kernel's first workgroup to the first workgroup of the next kernel       */
+    int32_t nn_launches;               /* number of NN launches averaged                          */
     int64_t hard_queries;              /* NN queries the grid pyramid could not decide (brute pass) */
     int32_t reserved[4];
     float   sensor_noise_overlap;      /* getOverlap() of a reading that carries `simpleSensorNoise` and `normals`

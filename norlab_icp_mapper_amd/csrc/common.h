@@ -225,7 +225,21 @@ struct IcpState {
     // r5: device clocks (wall_clock64, 100 MHz) of the first kernel of the registration's head and of the solve that stopped the loop:
     // stats->loop_ms without a HIP event to wait for (loop_run's fast finish).  t_done == 0: the loop was not stopped by a solve.
     unsigned long long t_start, t_done;
+    // r6: device-clock interval of every NN launch, summed over the registration: opened by the NN kernel's first workgroup, closed by the first
+    // workgroup of whatever kernel runs next (so one kernel boundary is inside) -- icpmi_stats::nn_ms_avg of a loop that is NOT in profile mode,
+    // i.e. bench.py's roofline duration taken from the timed graph replay itself
+    unsigned long long t_nn_begin, t_nn_sum;
+    unsigned nn_count, pad_nn;
 };
+
+#ifdef __HIPCC__
+__device__ __forceinline__ void nn_stamp_open(IcpState* st) { st->t_nn_begin = (unsigned long long)wall_clock64(); }
+__device__ __forceinline__ void nn_stamp_close(IcpState* st)
+{
+    const unsigned long long b = st->t_nn_begin;
+    if (b) { st->t_nn_sum += (unsigned long long)wall_clock64() - b; ++st->nn_count; st->t_nn_begin = 0; }
+}
+#endif
 
 
 // ------------------------------------------------------------------------------------------------
@@ -800,6 +814,7 @@ __device__ inline void init_state_dev(IcpState* st, const float* T0, unsigned se
     st->robust_med = 0.f; st->robust_scale = 1.f; st->vt_valid = 0; st->vt_ratio = -1.f;
     st->pairs = 0; st->wsum = 0; st->hard_count = 0; st->hard_total = 0; st->ticket = 0;
     for (int i = 0; i < 24; ++i) st->dbg[i] = 0;
+    st->t_nn_begin = 0; st->t_nn_sum = 0; st->nn_count = 0;
     st->t_done = 0; // (t_start belongs to the first kernel of the head, which runs BEFORE this when the head is folded into the query sort)
 }
 

@@ -26,6 +26,7 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(const float* __restrict__
                                                        const IcpState* __restrict__ st, unsigned* __restrict__ ghist, int nb_scale = 0)
 {
     if (st->done) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) nn_stamp_close(const_cast<IcpState*>(st));
     if (MODE != 0 && nb_scale != 0 && st->iter + 1 > nb_scale) return;
     if (MODE == 3 && st->iter != 0) return; // berg: the median is taken at iteration 1 only
     __shared__ unsigned h[ICPMI_SEL_BINS];
@@ -58,6 +59,7 @@ __global__ __launch_bounds__(256) void std_part_kernel(const float* __restrict__
                                                        double* __restrict__ part, int nb_scale)
 {
     if (st->done) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) nn_stamp_close(const_cast<IcpState*>(st));
     if (nb_scale != 0 && st->iter + 1 > nb_scale) return;
     __shared__ double sh[256];
     const float mean = PASS == 1 ? st->robust_med : 0.f;
@@ -288,6 +290,7 @@ __global__ __launch_bounds__(256) void sel2_hist0_kernel(const float* __restrict
     d2 += (size_t)blockIdx.y * (size_t)ba.qstride * k;
     hists += (size_t)blockIdx.y * ICPMI_SELHIST_WORDS;
     st += blockIdx.y;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && !st->done) nn_stamp_close(const_cast<IcpState*>(st));
     if (use_win) { // (r5) the NN kernel's window holds the selected element (and that kernel cleared level 1): nothing to do in this launch
         if (st->done) return;
         __shared__ unsigned shw[16];
@@ -367,6 +370,7 @@ __global__ __launch_bounds__(256) void sel2_scan_hist_kernel(const float* __rest
 #pragma unroll
     for (int cpy = 0; cpy < ICPMI_S2_COPIES; ++cpy) cv += hists[ICPMI_S2_C0 + cpy * 256 + threadIdx.x];
     if (st->done) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) nn_stamp_close(const_cast<IcpState*>(st));
     __shared__ unsigned sh[16];
     unsigned prefix, rem, total;
     // (r5) k > 1: the NN kernel's window around the previous prefix first (the stand-alone builder took the same decision from the same words)
@@ -405,6 +409,7 @@ __global__ __launch_bounds__(256) void vt_keys_kernel(const float* __restrict__ 
                                                       unsigned long long* __restrict__ keys, unsigned* __restrict__ vals)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && !st->done) nn_stamp_close(st);
     const float v = i < count ? d2[i] : INFINITY;
     const bool valid = v != INFINITY && v > 0.f;
     if (i < count) { keys[i] = valid ? (unsigned long long)__float_as_uint(v) : 0xffffffffull; vals[i] = 0u; } // invalid entries sort to the end
@@ -702,6 +707,7 @@ __global__ __launch_bounds__(BT) void accumulate_kernel(const float4* __restrict
     for (int u = 0; u < PF; ++u)
         pn[u] = (MIN == ICPMI_MIN_POINT_TO_PLANE && ps[u] >= 0) ? (pnm ? pnm[2 * (size_t)ps[u] + 1] : normals[ps[u]]) : make_float4(0.f, 0.f, 0.f, 0.f);
     if (st->done) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) nn_stamp_close(const_cast<IcpState*>(st));
     float fused_limit = 0.f;
     if (FUSED) {
         // scan of level 1: the selected element's bit pattern is prefix(16) | bin(16)
@@ -1682,8 +1688,12 @@ icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals
             const unsigned long long t0 = c->h_state->t_start, t1 = c->h_state->t_done;
             stats->loop_ms = (t1 > t0) ? (float)((double)(t1 - t0) * 1e-5) : 0.f;
         } else if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) stats->loop_ms = ms;
-        stats->nn_ms_avg = nn_cnt ? nn_ms_sum / nn_cnt : 0.f;
-        stats->nn_launches = nn_cnt;
+        if (profile) { stats->nn_ms_avg = nn_cnt ? nn_ms_sum / nn_cnt : 0.f; stats->nn_launches = nn_cnt; }
+        else { // r6: device clocks (100 MHz) from the NN kernel's first workgroup to the first workgroup of the kernel behind it, summed by the loop itself
+            const unsigned cnt = c->h_state->nn_count;
+            stats->nn_ms_avg = cnt ? (float)((double)c->h_state->t_nn_sum * 1e-5 / (double)cnt) : 0.f;
+            stats->nn_launches = (int32_t)cnt;
+        }
         stats->sensor_noise_overlap = -1.f;
     }
     if (lc.sensor_noise && stats && !c->h_state->error && c->h_state->iter > 0) {

@@ -80,6 +80,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_hard_kernel(const float4* __rest
                                                             float4* __restrict__ match_pt = nullptr, unsigned* __restrict__ hist0 = nullptr)
 {
     if (st->done) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) nn_stamp_close(const_cast<IcpState*>(st));
     const unsigned nh = st->hard_count;
     __shared__ unsigned long long shk[NN_BLOCK / 64];
     __shared__ int shs[NN_BLOCK / 64];
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nnk_kernel(const float4* __restrict_
                                                        const unsigned* __restrict__ only, const unsigned* __restrict__ only_count)
 {
     if (st && st->done) return;
+    if (st && blockIdx.x == 0 && threadIdx.x == 0) nn_stamp_open(st);
     // `only` != nullptr: just the listed queries (the left-overs of the tiled self-search below)
     const int tid = blockIdx.x * NN_BLOCK + threadIdx.x;
     if (only ? tid >= (int)*only_count : tid >= n) return;
@@ -249,6 +251,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nnk_hard_kernel(const float4* __rest
                                                             const unsigned* __restrict__ hard)
 {
     if (st->done) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) nn_stamp_close(const_cast<IcpState*>(st));
     const unsigned nh = st->hard_count;
     __shared__ unsigned long long shk[NN_BLOCK / 64];
     __shared__ int shs[NN_BLOCK / 64];
@@ -448,6 +451,7 @@ __global__ __launch_bounds__(64 * NW) void nn1_wg_kernel(const float4* __restric
         else p = make_float3(r.x, r.y, r.z);
     }
     if (st_done) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) nn_stamp_open(st); // (device clock of this launch: common.h)
     if (tid < ICPMI_MAXLEV * 4) ltab[tid] = ltab_mine;
     if (hist0) {
         for (int t = tid; t < 256; t += NT) lh[t] = 0;
@@ -756,6 +760,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nnk_ml_kernel(const float4* __restri
     constexpr int NB = 4;
     constexpr int NR = (9 + G - 1) / G;
     if (st->done) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) nn_stamp_open(st); // (device clock of this launch: common.h)
     __shared__ uint4 ltab[ICPMI_MAXLEV * 4];
     if (threadIdx.x < ICPMI_MAXLEV * 4) ltab[threadIdx.x] = ltab_g[threadIdx.x];
     const bool allow_self = allow_self_i != 0;
@@ -1070,6 +1075,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KMAX <= 8 ?
     const int qi = lb * Q + slot;
     const bool active = w0 && qi < n;
     if (st->done) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) nn_stamp_open(st); // (device clock of this launch: common.h)
     // the window sits around the prefix the PREVIOUS iteration's selection picked (sel2_scan_hist_kernel ran before this launch)
     const bool use_win = win != nullptr && st->iter > 0;
     const unsigned win_c = st->sel_prefix_l[0];
