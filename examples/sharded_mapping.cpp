@@ -158,6 +158,21 @@ int main(int argc, char** argv)
         for (const auto& id : mapper.cells().getAllCellIds()) cellPts += mapper.cells().retrieveCell(id).getNbPoints();
         std::printf("rank %d: %zu scans in %.3f s, map %ld points, %zu cells holding %zu merged points\n", rank, done, secs, (long)mapper.mapSize(),
                     mapper.cells().getAllCellIds().size(), cellPts);
+        {   // the cells (binned on the device, epoch after epoch) against the reference's loop over what the epochs appended: the
+            // tail of the resident map in append order (Map.cpp:206-229 on the host)
+            const DataPoints whole = mapper.getMap();
+            const size_t tail = cellPts <= whole.getNbPoints() ? cellPts : whole.getNbPoints();
+            DataPoints appendedPts(tail);
+            std::copy(whole.features.begin() + 4 * (whole.getNbPoints() - tail), whole.features.end(), appendedPts.features.begin());
+            size_t cellsSeen = 0; bool same = true;
+            Map::binIntoCells(appendedPts, [&](const std::string& id, DataPoints&& cell) {
+                ++cellsSeen;
+                const DataPoints got = mapper.cells().retrieveCell(id);
+                same = same && got.getNbPoints() == cell.getNbPoints() && got.features == cell.features;
+            });
+            same = same && cellsSeen == mapper.cells().getAllCellIds().size();
+            std::printf("rank %d: cells equal to a host binning of the appended points: %s\n", rank, same ? "yes" : "NO");
+        }
     } catch (const std::exception& e) {
         std::fprintf(stderr, "error: %s\n", e.what());
         return 1;

@@ -452,6 +452,15 @@ icpmi_status icpmi_bin_cells(icpmi_handle h, const float* pts4, int64_t n, float
  *       merged_out4 receives the first merged_capacity points, *merged_n the full count, the status stays ICPMI_OK and
  *       icpmi_staged_merged_points returns the whole set -- replicas never diverge over a host buffer.
  *   icpmi_staged_merged_points  the merged set of the last epoch (out4 == NULL: only *n), kept on the device until the next epoch
+ *   icpmi_staged_bin_cells (r6)  the merged set of the last epoch binned into cubic cells of edge cell_size ON THE DEVICE -- Map.cpp:206-229's
+ *       per-point loop (cell = floor(coordinate / cell_size) per axis, Map.cpp:472-480) feeding RAMCellManager.cpp:13-16 -- and appended,
+ *       cell after cell (cells in the order of their first point, the points of a cell in merged order: what Map::binIntoCells yields on
+ *       the host), to the handle's device-resident CELL LOG.  Returned per cell r < *n_cells: ijk3[3 r ..], counts[r] and offsets[r], the
+ *       position of the cell's run in the log.  Only this table crosses PCIe.  Once per epoch (a second call for the same epoch is an
+ *       ICPMI_ERR_INVALID_ARG); capacity < *n_cells: ICPMI_ERR_INVALID_ARG with *n_cells set and nothing appended; more than 4096 cells
+ *       touched by one epoch: ICPMI_ERR_UNSUPPORTED (fetch icpmi_staged_merged_points and bin on the host).
+ *   icpmi_cell_log_read          `count` points of the log from `offset` (out4 == NULL: only *log_size, the points in the log)
+ *   icpmi_cell_log_clear         forgets the log (CellManager::clearAllCells)
  *   icpmi_stage_discard          drops the scan staged by icpmi_register_prior (e.g. after its registration failed: the rank then
  *                                takes part in the epoch empty-handed and reports its own error afterwards) */
 typedef struct icpmi_comm_id { char bytes[128]; } icpmi_comm_id;
@@ -465,6 +474,10 @@ icpmi_status icpmi_staged_merge_allgather(icpmi_handle h, const float correction
                                           int64_t* accepted_local, int64_t* appended_total, int64_t* new_m, float* merged_out4,
                                           int64_t merged_capacity, int64_t* merged_n);
 icpmi_status icpmi_staged_merged_points(icpmi_handle h, float* out4, int64_t capacity, int64_t* n);
+icpmi_status icpmi_staged_bin_cells(icpmi_handle h, float cell_size, int32_t* ijk3, int64_t* offsets, int64_t* counts, int64_t capacity,
+                                    int64_t* n_cells);
+icpmi_status icpmi_cell_log_read(icpmi_handle h, int64_t offset, int64_t count, float* out4, int64_t* log_size);
+icpmi_status icpmi_cell_log_clear(icpmi_handle h);
 icpmi_status icpmi_stage_discard(icpmi_handle h);
 
 /* ---- plumbing ---- */

@@ -138,6 +138,9 @@ SYMBOLS = [
     ("icpmi_comm_info", C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("icpmi_staged_merge_allgather", C.c_int, [_P, _P, C.c_float, C.c_int32, _P, _P, _P, _P, C.c_int64, _P]),
     ("icpmi_staged_merged_points", C.c_int, [_P, _P, C.c_int64, _P]),
+    ("icpmi_staged_bin_cells", C.c_int, [_P, C.c_float, _P, _P, _P, C.c_int64, _P]),
+    ("icpmi_cell_log_read", C.c_int, [_P, C.c_int64, C.c_int64, _P, _P]),
+    ("icpmi_cell_log_clear", C.c_int, [_P]),
     ("icpmi_stage_discard", C.c_int, [_P]),
     ("icpmi_register_prior", C.c_int, [_P, _P, C.c_int64, _P, _F, C.POINTER(Stats)]),
     ("icpmi_set_reading_scalar", C.c_int, [_P, _P, C.c_int64]),

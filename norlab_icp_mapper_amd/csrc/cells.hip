@@ -1,0 +1,233 @@
+// cells.hip -- the merged set of a map-growth epoch binned into the mapper's cubic cells ON THE DEVICE (r6; VERDICT r5 "missing" 4).
+//
+// Reference: norlab_icp_mapper/Map.cpp:206-229 (`unloadCells`: every point that leaves the local map goes to the cell
+// `toGridCoordinate(x) _ toGridCoordinate(y) _ toGridCoordinate(z)`, Map.cpp:472-480: floor(world / CELL_SIZE), CELL_SIZE = 20 m) and
+// RAMCellManager.cpp:3-31 (id -> cloud).  In the scan-sharded mode (BASELINE config 5) every replica appends the points all
+// ranks accepted in an epoch; r2 - r5 copied that merged set to the host and ran the reference's per-point loop there, a retrieve +
+// concatenate + save per cell and epoch.  Here the merged set never leaves HBM:
+//   * cb_key_kernel      one lane per merged point: ijk, packed key, claim of a slot in a small open-addressing table -- one claim per
+//                        distinct key of a WAVE (a scan's points are spatially coherent: a wave sees one to four cells), with the
+//                        smallest point index and the point count of the key;
+//   * cb_rank_kernel     one workgroup: the occupied slots ordered by their first point (= the order in which the reference's loop would
+//                        have met the cells), the run of every cell in the log (exclusive sum of the counts in that order), the table
+//                        {ijk, count, offset} the host gets;
+//   * cb_sortkey_kernel + the library's stable LSD radix sort (octree.hip) on the cell's rank + cb_gather_kernel: the points cell after
+//     cell, merged order inside a cell (what `Map::binIntoCells` produces on the host), appended to the handle's CELL LOG.
+// The host keeps, per cell id, runs {offset, count} of the log (host/ShardedMapper.h: ResidentCellManager) and fetches a cell's points
+// only when somebody asks for them (icpmi_cell_log_read).  What crosses PCIe per epoch: 16 + 20 bytes per touched cell.
+#include "common.h"
+
+#include <vector>
+
+namespace {
+
+constexpr int CB_SLOTS = 8192;     // hash slots (power of two)
+constexpr int CB_MAXCELLS = 4096;  // distinct cells one epoch may touch on this path (more: the caller bins on the host)
+constexpr int CB_BIAS = 1 << 20;   // cell coordinates in [-2^20, 2^20): +-20 000 km of 20 m cells
+
+struct CbSlot { unsigned long long key; unsigned first; unsigned count; }; // count: points - 1 (filled with ~0, see ops_staged_bin_cells)
+struct CbHeader { unsigned ncells; unsigned bad; unsigned npoints; unsigned overflow; };
+struct CbCell { int i, j, k; unsigned count; unsigned offset; };
+
+__device__ __forceinline__ unsigned cb_hash(unsigned long long k)
+{
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 29;
+    return (unsigned)k;
+}
+
+// slot_of[i]: the table slot of point i's cell (0xffffffff: coordinates outside the range / table full -- the header says so)
+__global__ __launch_bounds__(256) void cb_key_kernel(const float4* __restrict__ pts, int64_t n, float cell, CbSlot* __restrict__ tab,
+                                                     CbHeader* __restrict__ hdr, unsigned* __restrict__ slot_of)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = i < n;
+    unsigned long long key = ~0ull;
+    bool bad = false;
+    if (valid) {
+        const float4 p = pts[i];
+        const float fx = floorf(p.x / cell), fy = floorf(p.y / cell), fz = floorf(p.z / cell); // Map.cpp:472-480
+        const float lim = (float)CB_BIAS;
+        bad = !(fx >= -lim && fx < lim && fy >= -lim && fy < lim && fz >= -lim && fz < lim);    // (catches NaN too)
+        if (!bad)
+            key = ((unsigned long long)((int)fx + CB_BIAS) << 42) | ((unsigned long long)((int)fy + CB_BIAS) << 21) | (unsigned long long)((int)fz + CB_BIAS);
+    }
+    // the lanes of a wave that share a key: the lowest of them claims the slot and adds the group's count
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(valid && !bad);
+    unsigned long long mine = 0;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const unsigned long long lk = __shfl(key, leader, 64);
+        const unsigned long long grp = __ballot(valid && !bad && key == lk);
+        if (key == lk && valid && !bad) mine = grp;
+        todo &= ~grp;
+    }
+    unsigned slot = 0xffffffffu;
+    if (mine && lane == __ffsll((long long)mine) - 1) {
+        unsigned h = cb_hash(key) & (CB_SLOTS - 1);
+        int probe = 0;
+        for (; probe < CB_SLOTS; ++probe) {
+            const unsigned long long prev = atomicCAS(&tab[h].key, ~0ull, key);
+            if (prev == ~0ull || prev == key) break;
+            h = (h + 1) & (CB_SLOTS - 1);
+        }
+        if (probe < CB_SLOTS) {
+            slot = h;
+            atomicMin(&tab[h].first, (unsigned)i);                 // (the group's lowest lane holds its smallest index)
+            atomicAdd(&tab[h].count, (unsigned)__popcll(mine));
+        } else atomicOr(&hdr->overflow, 1u);
+    }
+    if (mine) slot = __shfl(slot, __ffsll((long long)mine) - 1, 64);
+    if (__ballot(bad) && bad) atomicOr(&hdr->bad, 1u);
+    if (valid) slot_of[i] = slot;
+}
+
+// one workgroup: cells in the order of their first point, their runs; rank_of[slot] for the sort key
+__global__ __launch_bounds__(1024) void cb_rank_kernel(const CbSlot* __restrict__ tab, CbHeader* __restrict__ hdr, CbCell* __restrict__ cells,
+                                                       unsigned* __restrict__ rank_of, unsigned npoints)
+{
+    __shared__ unsigned s_first[CB_MAXCELLS], s_count[CB_MAXCELLS], s_slot[CB_MAXCELLS];
+    __shared__ unsigned s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    for (int s = threadIdx.x; s < CB_SLOTS; s += 1024) {
+        const CbSlot e = tab[s];
+        if (e.key != ~0ull) {
+            const unsigned at = atomicAdd(&s_n, 1u);
+            if (at < (unsigned)CB_MAXCELLS) { s_first[at] = e.first; s_count[at] = e.count + 1u; s_slot[at] = (unsigned)s; }
+        }
+    }
+    __syncthreads();
+    const unsigned nc = s_n;
+    if (threadIdx.x == 0) { hdr->ncells = nc; hdr->npoints = npoints; if (nc > (unsigned)CB_MAXCELLS) hdr->overflow = 1u; }
+    if (nc > (unsigned)CB_MAXCELLS) return;
+    for (unsigned t = threadIdx.x; t < nc; t += 1024) {
+        const unsigned f = s_first[t];
+        unsigned rank = 0, off = 0;
+        for (unsigned j = 0; j < nc; ++j) {          // (first points are distinct: a strict order)
+            const bool before = s_first[j] < f;
+            rank += before ? 1u : 0u;
+            off += before ? s_count[j] : 0u;
+        }
+        const CbSlot e = tab[s_slot[t]];
+        CbCell c;
+        c.i = (int)((e.key >> 42) & 0x1fffffu) - CB_BIAS; c.j = (int)((e.key >> 21) & 0x1fffffu) - CB_BIAS; c.k = (int)(e.key & 0x1fffffu) - CB_BIAS;
+        c.count = s_count[t]; c.offset = off;
+        cells[rank] = c;
+        rank_of[s_slot[t]] = rank;
+    }
+}
+
+__global__ __launch_bounds__(256) void cb_sortkey_kernel(const unsigned* __restrict__ slot_of, const unsigned* __restrict__ rank_of, int64_t n,
+                                                         unsigned long long* __restrict__ keys, unsigned* __restrict__ vals)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned s = slot_of[i];
+    keys[i] = s == 0xffffffffu ? 0ull : (unsigned long long)rank_of[s];
+    vals[i] = (unsigned)i;
+}
+
+__global__ __launch_bounds__(256) void cb_gather_kernel(const float4* __restrict__ pts, const unsigned* __restrict__ order, int64_t n,
+                                                        float4* __restrict__ log)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) log[i] = pts[order[i]];
+}
+
+} // namespace
+
+// include/icpmi.h: icpmi_staged_bin_cells
+icpmi_status ops_staged_bin_cells(icpmi_ctx* c, float cell_size, int32_t* ijk3, int64_t* offsets, int64_t* counts, int64_t capacity, int64_t* n_cells)
+{
+    if (n_cells) *n_cells = 0;
+    const int64_t n = c->merged_last_n;
+    if (n == 0) return ICPMI_OK;
+    if (c->merged_binned) { c->last_error = "staged_bin_cells: the merged set of this epoch is in the cell log already"; return ICPMI_ERR_INVALID_ARG; }
+    if (n > 0x7ffffff0ll) { c->last_error = "staged_bin_cells: too many points"; return ICPMI_ERR_UNSUPPORTED; }
+    const int blocks = (int)((n + 255) / 256);
+    const size_t tab_words = (sizeof(CbSlot) * CB_SLOTS + sizeof(CbHeader) + sizeof(CbCell) * CB_MAXCELLS) / sizeof(unsigned) + CB_SLOTS + 16;
+    unsigned* d_tab = scratch_get<unsigned>(c, 3, tab_words);
+    unsigned* d_slot_of = scratch_get<unsigned>(c, 4, (size_t)n + 2);
+    unsigned long long* d_keys = scratch_get<unsigned long long>(c, 0, (size_t)2 * n + 2);
+    unsigned* d_vals = scratch_get<unsigned>(c, 1, (size_t)2 * n + 2);
+    unsigned* d_rs = scratch_get<unsigned>(c, 2, radix_sort_tab_words(n, 12));
+    if (!d_tab || !d_slot_of || !d_keys || !d_vals || !d_rs) return ICPMI_ERR_HIP;
+    CbSlot* tab = reinterpret_cast<CbSlot*>(d_tab);
+    CbHeader* hdr = reinterpret_cast<CbHeader*>(tab + CB_SLOTS);
+    CbCell* cells = reinterpret_cast<CbCell*>(hdr + 1);
+    unsigned* rank_of = reinterpret_cast<unsigned*>(cells + CB_MAXCELLS);
+    const int64_t base = c->cell_log_n;
+    icpmi_status s = ensure_cap_keep(c, &c->d_cell_log, &c->cap_cell_log, (size_t)(base + n) + 1, (size_t)base);
+    if (s != ICPMI_OK) return s;
+    // one fill: key = ~0 (empty), first = ~0 (atomicMin), count = ~0 -- the adds wrap it to (points - 1), the rank kernel reads count + 1
+    HIP_TRY(c, hipMemsetAsync(tab, 0xff, sizeof(CbSlot) * CB_SLOTS, c->stream));
+    HIP_TRY(c, hipMemsetAsync(hdr, 0, sizeof(CbHeader), c->stream));
+    hipLaunchKernelGGL(cb_key_kernel, dim3(blocks), dim3(256), 0, c->stream, (const float4*)c->d_merged, n, cell_size, tab, hdr, d_slot_of);
+    hipLaunchKernelGGL(cb_rank_kernel, dim3(1), dim3(1024), 0, c->stream, (const CbSlot*)tab, hdr, cells, rank_of, (unsigned)n);
+    HIP_TRY(c, hipGetLastError());
+    // the sort needs the number of key bits before the host knows the number of cells: the handle's previous epoch is the guess (a mapper
+    // touches about the same number of cells epoch after epoch), checked against the header below
+    int bits = c->cell_bits_hint > 0 ? c->cell_bits_hint : 6;
+    CbHeader h{};
+    std::vector<CbCell> host_cells;
+    for (int attempt = 0;; ++attempt) {
+        hipLaunchKernelGGL(cb_sortkey_kernel, dim3(blocks), dim3(256), 0, c->stream, (const unsigned*)d_slot_of, (const unsigned*)rank_of, n, d_keys, d_vals);
+        int half = 0;
+        s = radix_sort_pairs(c, d_keys, d_vals, n, bits, d_rs, &half);
+        if (s != ICPMI_OK) return s;
+        hipLaunchKernelGGL(cb_gather_kernel, dim3(blocks), dim3(256), 0, c->stream, (const float4*)c->d_merged, (const unsigned*)(d_vals + (half ? n : 0)), n,
+                           c->d_cell_log + base);
+        HIP_TRY(c, hipGetLastError());
+        if (attempt == 0) { // header + the first cells in one read-back (one stream wait); the rest, if any, in a second
+            constexpr unsigned FIRST = 200;
+            unsigned char buf[sizeof(CbHeader) + sizeof(CbCell) * FIRST];
+            if (read_back(c, buf, hdr, sizeof buf) != ICPMI_OK) return ICPMI_ERR_HIP;
+            memcpy(&h, buf, sizeof h);
+            if (h.bad) { c->last_error = "staged_bin_cells: a merged point is not finite or lies outside +-2^20 cells"; return ICPMI_ERR_INVALID_ARG; }
+            if (h.overflow || h.ncells > (unsigned)CB_MAXCELLS) {
+                c->last_error = "staged_bin_cells: more than 4096 cells touched by one epoch (bin icpmi_staged_merged_points on the host)";
+                return ICPMI_ERR_UNSUPPORTED;
+            }
+            host_cells.resize(h.ncells);
+            const unsigned got = h.ncells < FIRST ? h.ncells : FIRST;
+            if (got) memcpy(host_cells.data(), buf + sizeof(CbHeader), sizeof(CbCell) * got);
+            if (h.ncells > FIRST && read_back(c, host_cells.data() + FIRST, cells + FIRST, sizeof(CbCell) * (h.ncells - FIRST)) != ICPMI_OK) return ICPMI_ERR_HIP;
+        } else HIP_TRY(c, hipStreamSynchronize(c->stream));
+        int need = 6;
+        while ((1u << need) < h.ncells) need += 6;
+        c->cell_bits_hint = need;
+        if (need <= bits) break;
+        bits = need; // the guess was too small: ranks above 2^bits were not ordered -- once more with the bits the header asks for
+    }
+    if (n_cells) *n_cells = (int64_t)h.ncells;
+    if ((int64_t)h.ncells > capacity) { // nothing appended: the caller comes back with room for *n_cells
+        c->last_error = "staged_bin_cells: capacity smaller than the number of cells";
+        return ICPMI_ERR_INVALID_ARG;
+    }
+    for (unsigned r = 0; r < h.ncells; ++r) {
+        if (ijk3) { ijk3[3 * r] = host_cells[r].i; ijk3[3 * r + 1] = host_cells[r].j; ijk3[3 * r + 2] = host_cells[r].k; }
+        if (offsets) offsets[r] = base + (int64_t)host_cells[r].offset;
+        if (counts) counts[r] = (int64_t)host_cells[r].count;
+    }
+    c->cell_log_n = base + n;
+    c->merged_binned = true;
+    return ICPMI_OK;
+}
+
+// include/icpmi.h: icpmi_cell_log_read
+icpmi_status ops_cell_log_read(icpmi_ctx* c, int64_t offset, int64_t count, float* out4, int64_t* log_size)
+{
+    if (log_size) *log_size = c->cell_log_n;
+    if (!out4 || count == 0) return ICPMI_OK;
+    if (offset < 0 || count < 0 || offset + count > c->cell_log_n) { c->last_error = "cell_log_read: range outside the log"; return ICPMI_ERR_INVALID_ARG; }
+    HIP_TRY(c, hipMemcpyAsync(out4, c->d_cell_log + offset, (size_t)count * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return ICPMI_OK;
+}
+
+icpmi_status ops_cell_log_clear(icpmi_ctx* c)
+{
+    c->cell_log_n = 0;
+    return ICPMI_OK;
+}

@@ -576,6 +576,10 @@ struct icpmi_ctx {
     int64_t merge_block = 0;
     long merge_fast_epochs = 0, merge_slow_epochs = 0; // epochs served by the one-collective path / by the count + ready + points path
     int64_t merged_last_n = 0;        // points of the last epoch's merged set, still in d_merged (icpmi_staged_merged_points)
+    // r6 (cells.hip): every merged set binned by icpmi_staged_bin_cells, cell after cell; the host keeps {offset, count} runs per cell id
+    float4* d_cell_log = nullptr; size_t cap_cell_log = 0; int64_t cell_log_n = 0;
+    bool merged_binned = false;       // the merged set of the last epoch is in the log already
+    int cell_bits_hint = 0;           // key bits the previous epoch's cell count needed (the sort is enqueued before the count is known)
     struct SelfGridCtx* sg = nullptr; // sparse block grid of the self k-NN (selfgrid.hip): tables, work lists and the tuning state of the handle's previous build
     bool counted = false;             // created through icpmi_create (not a private handle): counts towards the allocation cache's lifetime (api.hip)
 };
@@ -908,6 +912,9 @@ icpmi_status merge_blocks_reserve(icpmi_ctx* c, int n_ranks); // the exchange bu
 icpmi_status ops_staged_merge_allgather(icpmi_ctx* c, const float correction[16], float min_dist, int normals_knn, int64_t* accepted_local,
                                         int64_t* appended_total, int64_t* new_m, float* merged_out4, int64_t merged_capacity, int64_t* merged_n);
 icpmi_status ops_staged_merged_points(icpmi_ctx* c, float* out4, int64_t capacity, int64_t* n);
+icpmi_status ops_staged_bin_cells(icpmi_ctx* c, float cell_size, int32_t* ijk3, int64_t* offsets, int64_t* counts, int64_t capacity, int64_t* n_cells);
+icpmi_status ops_cell_log_read(icpmi_ctx* c, int64_t offset, int64_t count, float* out4, int64_t* log_size);
+icpmi_status ops_cell_log_clear(icpmi_ctx* c);
 icpmi_status ssn_debug_minstd(icpmi_ctx* c, unsigned seed, unsigned n, unsigned* out);
 icpmi_status ssn_sample_dev(icpmi_ctx* c, const float4* d_in, int64_t n, float ratio, int knn, float max_box, unsigned seed, int* d_order_out,
                             float* d_normals_out, int64_t* n_out, int method = 0, float* d_mean_out = nullptr, int* d_mstart_out = nullptr,

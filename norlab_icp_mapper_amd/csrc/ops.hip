@@ -1987,6 +1987,7 @@ icpmi_status ops_staged_merge_allgather(icpmi_ctx* c, const float correction[16]
     if (merged_n) *merged_n = 0;
     if (new_m) *new_m = c->m > 0 ? c->m_raw : 0;
     c->merged_last_n = 0;
+    c->merged_binned = false;
     // ICPMI_EPOCH_TIMING=1: wall time of the epoch's stages with a stream wait behind each, on stderr (diagnostic; perturbs the overlap)
     static const bool ep_timing = [] { const char* e = getenv("ICPMI_EPOCH_TIMING"); return e && atoi(e) != 0; }();
     auto ep_tick = [&](const char* what) {

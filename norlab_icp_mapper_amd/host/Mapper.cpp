@@ -251,7 +251,8 @@ bool Mapper::mapUpdateIsDue(const TimePoint& now, const Mat4& poseNow, float ove
     const bool updateInFlight = isOnline && mapUpdateFuture.valid() && mapUpdateFuture.wait_for(std::chrono::milliseconds(0)) != std::future_status::ready;
     if (updateInFlight) return false;
     float travelled2 = 0.f;
-    for (int axis = 0; axis < 3; ++axis) {
+    const int euclideanDim = is3D ? 3 : 2;                                   // Mapper.cpp:266-269: topRightCorner(euclideanDim, 1)
+    for (int axis = 0; axis < euclideanDim; ++axis) {
         const float step = poseNow(axis, 3) - lastPoseWhereMapWasUpdated(axis, 3);
         travelled2 += step * step;
     }

@@ -7,11 +7,32 @@
 #include <vector>
 #include <memory>
 #include <string>
+#include <unordered_map>
 
 #include "IcpSequence.h"
 #include "Map.h"
 
 namespace nim {
+
+// The CellManager of a replica (r6): a cell is a list of RUNS {offset, count} of the handle's device-resident cell log
+// (icpmi_staged_bin_cells bins every epoch's merged set on the device; only the {ijk, offset, count} table reaches the host), fetched
+// when somebody asks for the cell.  saveCell / retrieveCell / clearAllCells keep RAMCellManager's meaning (RAMCellManager.cpp:3-31):
+// a cell saved from the host replaces whatever the log held for it.
+class ResidentCellManager : public CellManager {
+public:
+    explicit ResidentCellManager(icpmi_handle handle) : h(handle) {}
+    std::vector<std::string> getAllCellIds() const override;
+    void saveCell(const std::string& cellId, const DataPoints& cell) override { hostCells[cellId] = cell; runs.erase(cellId); }
+    DataPoints retrieveCell(const std::string& cellId) const override;
+    void clearAllCells() override;
+    void addRun(const std::string& cellId, int64_t offset, int64_t count) { runs[cellId].push_back({offset, count}); }
+    int64_t pointsInLog() const;
+private:
+    struct Run { int64_t offset, count; };
+    icpmi_handle h;
+    std::unordered_map<std::string, std::vector<Run>> runs;
+    std::unordered_map<std::string, DataPoints> hostCells;   // cells saved from the host (+ epochs that touched more cells than the device path takes)
+};
 
 class ShardedMapper {
 public:
@@ -32,15 +53,17 @@ public:
     const icpmi_stats& lastIcpStats() const { return icp.stats(); }
     DataPoints getMap() const { return icp.downloadMap(); }
     CellManager& cells() { return *cellManager; }                         // every point the epochs appended, by 20 m cell
+    int64_t lastCellsTouched() const { return cellsTouched; }             // cells the last epoch's merged set fell into
 
 private:
     GpuICPSequence icp;
-    std::unique_ptr<CellManager> cellManager;
+    std::unique_ptr<ResidentCellManager> cellManager;
     float minDist;
     int normalsKnn;
-    int64_t residentSize = 0, acceptedLocal = 0, appended = 0;
+    int64_t residentSize = 0, acceptedLocal = 0, appended = 0, cellsTouched = 0;
     int ranks = 1;                 // size of the communicator (1 until initCommunicator)
-    std::vector<float> merged;     // what all ranks accepted in the last epoch, for the cell manager (kept between epochs)
+    std::vector<float> merged;     // host copy of a merged set: only when an epoch touches more cells than the device path takes
+    std::vector<int32_t> cellIjk; std::vector<int64_t> cellOff, cellCnt;   // the table of the last epoch (kept between epochs)
 };
 
 } // namespace nim

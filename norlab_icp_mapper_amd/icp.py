@@ -703,6 +703,31 @@ class ICPSequence:
             self._check(self._lib.icpmi_staged_merged_points(self._h, out.ctypes.data, n.value, C.byref(n)))
         return out
 
+    def stagedBinCells(self, cell_size=20.0, capacity=4096):
+        """icpmi_staged_bin_cells: the last epoch's merged set binned on the device and appended to the handle's cell log;
+        returns (ijk [c, 3] int32, offsets [c] int64, counts [c] int64), cells in the order of their first point."""
+        ijk = np.empty((int(capacity), 3), dtype=np.int32)
+        off = np.empty(int(capacity), dtype=np.int64)
+        cnt = np.empty(int(capacity), dtype=np.int64)
+        nc = C.c_int64(0)
+        self._check(self._lib.icpmi_staged_bin_cells(self._h, cell_size, ijk.ctypes.data, off.ctypes.data, cnt.ctypes.data, int(capacity), C.byref(nc)))
+        return ijk[:nc.value].copy(), off[:nc.value].copy(), cnt[:nc.value].copy()
+
+    def cellLogSize(self):
+        n = C.c_int64(0)
+        self._check(self._lib.icpmi_cell_log_read(self._h, 0, 0, None, C.byref(n)))
+        return int(n.value)
+
+    def cellLogRead(self, offset, count):
+        """icpmi_cell_log_read: `count` points of the device-resident cell log from `offset`."""
+        out = np.empty((int(count), 4), dtype=np.float32)
+        if count:
+            self._check(self._lib.icpmi_cell_log_read(self._h, int(offset), int(count), out.ctypes.data, None))
+        return out
+
+    def cellLogClear(self):
+        self._check(self._lib.icpmi_cell_log_clear(self._h))
+
     def stageDiscard(self):
         """icpmi_stage_discard: drop the scan staged by registerWithPrior."""
         self._check(self._lib.icpmi_stage_discard(self._h))

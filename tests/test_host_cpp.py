@@ -562,6 +562,7 @@ def test_cpp_sharded_mapper_single_rank(tmp_path):
         assert np.linalg.norm(pose - truth[k + 1][:3, 3]) < 0.05 and 0 < int(r[6]) <= 40
     tail = re.search(r"rank 0: 3 scans in \S+ s, map (\d+) points, (\d+) cells holding (\d+) merged points", out.stdout)
     assert tail and int(tail.group(1)) == size and int(tail.group(3)) == size - len(scans[0]) and int(tail.group(2)) >= 1
+    assert "cells equal to a host binning of the appended points: yes" in out.stdout     # r6: binned on the device (icpmi_staged_bin_cells)
 
 
 @pytest.mark.gpu
@@ -591,3 +592,4 @@ def test_cpp_sharded_mapper_unequal_ranks_through_loopback(tmp_path):
     assert more >= 1
     tail = re.search(r"rank 0: 3 scans in \S+ s, map (\d+) points, (\d+) cells holding (\d+) merged points", out.stdout)
     assert tail and int(tail.group(1)) == size and int(tail.group(3)) == size - len(scans[0])
+    assert "cells equal to a host binning of the appended points: yes" in out.stdout
