@@ -141,7 +141,7 @@ def nn_roofline(pkg, dev, chain, d_map, d_nrm, d_scan, n_scan, m_map, traffic_ke
             **({"traffic_note": traffic_note} if traffic_note else {})}
 
 
-def config4_replay(np, pkg, with_cpu, passes=3):
+def config4_replay(np, pkg, with_cpu, passes=3, epsilon_approx=False):
     """BASELINE config 4: the 14 bundled scans (tests/golden/bundled_scans_all.npz, the reference's examples/data as a fixture) through the C++ host
     shell's Mapper::processInput with the shipped configuration (examples/config.yaml with epsilon 0 and PointToPlane: knn 6, Counter 10,
     DynamicPoints + Octree 0.15 m modules, SurfaceNormal knn 10 + CutAtDescriptorThreshold post filters, update every scan), map resident on the
@@ -159,8 +159,14 @@ def config4_replay(np, pkg, with_cpu, passes=3):
     with tempfile.TemporaryDirectory() as tmp:
         names, traj = c4.write_bundled_dataset(tmp, z)
         cfg = os.path.join(tmp, "config.yaml")
-        open(cfg, "w").write(c4.CONFIG4_YAML)
-        run = subprocess.run([exe, tmp, cfg], capture_output=True, text=True, timeout=600, env=dict(os.environ, NIM_TIMING=str(passes)))
+        yaml = c4.CONFIG4_YAML
+        env4 = dict(os.environ, NIM_TIMING=str(passes))
+        if epsilon_approx:     # the shipped `epsilon: 1` as an approximate search (NIM_EPSILON_APPROX: host/IcpSequence.cpp)
+            assert "epsilon: 0" in yaml
+            yaml = yaml.replace("epsilon: 0", "epsilon: 1")
+            env4["NIM_EPSILON_APPROX"] = "1"
+        open(cfg, "w").write(yaml)
+        run = subprocess.run([exe, tmp, cfg], capture_output=True, text=True, timeout=600, env=env4)
         if run.returncode != 0:
             return {"error": (run.stderr + run.stdout)[-400:]}
         if os.environ.get("ICPMI_SELF_DIAG"):  # (diagnostic lines of the library's self search travel on the harness's stderr)
@@ -711,6 +717,21 @@ def main():
                 extras["docs_knn6"]["pose_err_vs_cpu"] = {"m": e6t, "rad": e6r}
                 extras["docs_knn6"]["cpu_iterations_per_s"] = o6.stats.iterations / o6.stats.seconds_total
             del icp6
+            # the same chain with the matcher's `epsilon: 1` of the SHIPPED configuration (examples/config.yaml:56-60) honoured as libnabo does
+            # (icpmi_config::epsilon_approx): a (1 + epsilon)-approximate search; which valid answer comes back differs from libnabo's
+            try:
+                icp6e = pkg.ICPSequence(device=dev, max_iterations=ITERS_PER_STEP, epsilon=1.0, epsilon_approx=1, **c6)
+                icp6e.setMapDev(d_map.data_ptr(), d_map.shape[0], d_nrm.data_ptr())
+                T6e, el6e, per6e = time_registrations(torch, icp6e, d_scan, max(args.steps // 2, 5), args.warmup)
+                g6et, g6er = pkg.synth.pose_error(T6e, sc["T_gt"])
+                x6t, x6r = pkg.synth.pose_error(T6e, T6)
+                extras["docs_knn6_epsilon1"] = {
+                    "config": "as docs_knn6 with KDTreeMatcher epsilon 1 served as an approximate search (epsilon_approx = 1): cells farther than (k-th distance) / 2 are not visited",
+                    "value": max(args.steps // 2, 5) * ITERS_PER_STEP / el6e, "unit": "iterations/s", "step_ms": step_stats(per6e),
+                    "pose_err_vs_ground_truth": {"m": g6et, "rad": g6er}, "pose_diff_vs_exact_search": {"m": x6t, "rad": x6r}}
+                del icp6e
+            except Exception as e:  # noqa: BLE001
+                extras["docs_knn6_epsilon1"] = {"error": repr(e)}
             # what Mapper::processInput runs (Mapper.cpp:213): Counter 40 + Differential -- a registration of data-dependent length, segment graphs
             icpc = pkg.ICPSequence(device=dev, minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=40, use_differential=1)
             icpc.setMapDev(d_map.data_ptr(), d_map.shape[0], d_nrm.data_ptr())
@@ -873,6 +894,13 @@ def main():
                 extras["config4_replay"] = config4_replay(np, pkg, not args.no_cpu)
             except Exception as e:  # noqa: BLE001
                 extras["config4_replay"] = {"error": repr(e)}
+            try:
+                r4e = config4_replay(np, pkg, False, epsilon_approx=True)
+                if "config" in r4e:
+                    r4e["config"] = r4e["config"].replace("shipped chain with epsilon 0", "shipped chain with its epsilon 1 served as an approximate search (epsilon_approx)")
+                extras["config4_replay_epsilon1"] = r4e
+            except Exception as e:  # noqa: BLE001
+                extras["config4_replay_epsilon1"] = {"error": repr(e)}
             out["chains"] = extras
 
         # ---- CPU baseline: the oracle on this host, bounded sample of the same workload ----

@@ -106,8 +106,9 @@ typedef struct {
     /* matcher: KDTreeMatcher */
     int32_t knn;               /* default 1                                                       */
     float   max_dist;          /* default +inf                                                    */
-    float   epsilon;           /* default 0; > 0 is accepted and served by the EXACT search (a     */
-                               /* valid epsilon-answer, but not libnabo's pick -- SURVEY.md 0.4)   */
+    float   epsilon;           /* default 0; > 0 is served by the EXACT search (a valid epsilon-    */
+                               /* answer, but not libnabo's pick -- SURVEY.md 0.4) unless           */
+                               /* epsilon_approx below asks for libnabo's pruning                   */
     /* outlier filters, applied in order, weights multiply */
     int32_t n_outlier;
     icpmi_outlier outlier[8];
@@ -141,7 +142,13 @@ typedef struct {
                                /* iteration n - 1, < 0 = none (nnk_ml_kernel everywhere).  Same bits either way (tests/test_gpu_knn_wg.py).    */
     int32_t sel_window_off;    /* 1 = the quantile selection of a k > 1 loop always builds its full level-0 histogram (no speculative window, */
                                /* DESIGN_history.md 13.7b).  Same bits either way (tests/test_gpu_sel_window.py).                              */
-    int32_t reserved[5];
+    int32_t epsilon_approx;    /* (r6) 1 = `epsilon` prunes the matcher's search as libnabo's maxError2 does (`new_rd * (1 + epsilon)^2 <         */
+                               /* heap.headValue()`): cells farther than (k-th distance so far) / (1 + epsilon) are not visited, a query is decided  */
+                               /* once its k-th distance is within (1 + epsilon) x the margin of its block.  Every returned distance d_j <=           */
+                               /* (1 + epsilon) x the exact j-th distance (tests/test_gpu_epsilon.py); WHICH valid answer comes back differs from     */
+                               /* libnabo's (its pick depends on the kd-tree's traversal order).  0 (default): the exact search.  k <= 16; filters'   */
+                               /* own searches (PointDistance, SurfaceNormal) stay exact.                                                              */
+    int32_t reserved[4];
 } icpmi_config;
 
 /* What PM::ICPSequence exposes after a call: errorMinimizer->getOverlap() (Mapper.cpp:219) is

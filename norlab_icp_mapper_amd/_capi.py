@@ -54,7 +54,8 @@ class Config(C.Structure):
         ("fuse_solve", C.c_int32),
         ("knn_wg_from", C.c_int32),
         ("sel_window_off", C.c_int32),
-        ("reserved", C.c_int32 * 5),
+        ("epsilon_approx", C.c_int32),
+        ("reserved", C.c_int32 * 4),
     ]
 
 

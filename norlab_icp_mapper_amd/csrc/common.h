@@ -162,6 +162,7 @@ struct LoopCfg {
     int   k;
     float max_dist;        // un-squared; +inf allowed
     float maxr2;           // max_dist^2 (+inf allowed)
+    float inv1e, err2;     // KDTreeMatcher's epsilon when icpmi_config::epsilon_approx asks for it: 1 / (1 + epsilon) and (1 + epsilon)^2; both 1 otherwise
     int   ring_max;        // rings searched on the grid before a query goes to the brute pass
     int   minimizer;
     int   n_out;

@@ -946,6 +946,12 @@ LoopCfg make_loop_cfg(const icpmi_ctx* c, int fixed_iterations)
     lc.k = cfg.knn < 1 ? 1 : cfg.knn;
     lc.max_dist = cfg.max_dist;
     lc.maxr2 = std::isinf(cfg.max_dist) ? INFINITY : cfg.max_dist * cfg.max_dist;
+    lc.inv1e = 1.f; lc.err2 = 1.f;
+    if (cfg.epsilon_approx && cfg.epsilon > 0.f) { // both rounded to the conservative side (a larger pruning radius, a stricter decision)
+        const double e1 = 1.0 + (double)cfg.epsilon;
+        lc.inv1e = (float)(1.0 / e1); if ((double)lc.inv1e < 1.0 / e1) lc.inv1e = nextafterf(lc.inv1e, 2.f);
+        lc.err2 = (float)(e1 * e1); if ((double)lc.err2 > e1 * e1) lc.err2 = nextafterf(lc.err2, 0.f);
+    }
     const int RING_CAP = 16;
     if (std::isfinite(cfg.max_dist) && c->grid.cell > 0.f) {
         const int need = (int)ceilf(cfg.max_dist / c->grid.cell) + 1;

@@ -380,8 +380,10 @@ __global__ __launch_bounds__(64 * NW) void nn1_wg_kernel(const float4* __restric
                                                      const float* __restrict__ Tptr, GridLevels L, float maxr2, int* __restrict__ out_sidx,
                                                      float* __restrict__ out_d2, IcpState* __restrict__ st, unsigned* __restrict__ hard,
                                                      unsigned* __restrict__ hist0, float4* __restrict__ match_pt,
-                                                     const uint4* __restrict__ ltab_g, int unseeded_lev, int seed_pre)
+                                                     const uint4* __restrict__ ltab_g, int unseeded_lev, int seed_pre, float inv1e, float err2)
 {
+    // inv1e = 1 / (1 + epsilon), err2 = (1 + epsilon)^2 (both exactly 1 for the exact search: a multiplication by 1.0f changes no bit): libnabo's
+    // `new_rd * maxError2 < heap.headValue()` -- what lies farther than (best so far) / (1 + epsilon) is not visited (KDTreeMatcher's epsilon)
     static_assert(NW == 3 || NW == 4, "waves per workgroup");
     constexpr int NT = 64 * NW, Q = 64;
     constexpr int NR = 3;                  // rows per lane in role 1b: rr = wave + NW sl
@@ -423,7 +425,7 @@ __global__ __launch_bounds__(64 * NW) void nn1_wg_kernel(const float4* __restric
     {
         const GridParams g0 = L.g[0];
         asm volatile("" ::"s"(queries), "s"(qindex), "s"(out_sidx), "s"(out_d2), "s"(match_pt), "s"(ltab_g), "s"(Tptr), "s"(st), "s"(hist0), "s"(hard));
-        asm volatile("" ::"s"(g0.ox), "s"(g0.oy), "s"(g0.oz), "s"(g0.cell), "s"(g0.inv_cell), "s"(g0.slack), "s"(L.nlev), "s"(maxr2), "s"(unseeded_lev), "s"(seed_pre));
+        asm volatile("" ::"s"(g0.ox), "s"(g0.oy), "s"(g0.oz), "s"(g0.cell), "s"(g0.inv_cell), "s"(g0.slack), "s"(L.nlev), "s"(maxr2), "s"(unseeded_lev), "s"(seed_pre), "s"(inv1e), "s"(err2));
     }
 #endif
     const int wgs = (int)((((long long)n + Q - 1) / Q + 7) / 8 * 8);
@@ -480,7 +482,7 @@ __global__ __launch_bounds__(64 * NW) void nn1_wg_kernel(const float4* __restric
             mfl = fminf(mfl, fminf(fz - floorf(fz), 1.0f - (fz - floorf(fz))));
             if (!(mfl >= 0.f)) mfl = 0.f;
             const float margin = (1.0f + mfl) * gl.cell - 2.0f * gl.slack;
-            if (want && ub * 1.000001f <= margin) {
+            if (want && ub * inv1e * 1.000001f <= margin) {
                 lev0 = lev;
                 best.key = pack_key(ub2, __float_as_uint(qs.w));
                 best.sidx = sp; // level 0 position
@@ -516,7 +518,7 @@ __global__ __launch_bounds__(64 * NW) void nn1_wg_kernel(const float4* __restric
                 float rub2 = INFINITY; // squared pruning radius (with slack), +inf = no pruning
                 if (!prescan && best.key != ~0ull) {
                     const float slack = __uint_as_float(ltab[4 * lv + 1].y);
-                    const float rub = sqrt_up(__uint_as_float((unsigned)(best.key >> 32))) * 1.000001f + slack;
+                    const float rub = sqrt_up(__uint_as_float((unsigned)(best.key >> 32))) * inv1e * 1.000001f + slack;
                     rub2 = rub * rub;
                 }
                 qrec[slot] = make_float4(p.x, p.y, p.z, __int_as_float(lv));
@@ -681,7 +683,7 @@ __global__ __launch_bounds__(64 * NW) void nn1_wg_kernel(const float4* __restric
                 const float m2 = dq.x;
                 const bool covers = dq.y != 0.f;
                 const float bd2 = __uint_as_float((unsigned)(best.key >> 32));
-                decided = (best.key != ~0ull && bd2 <= m2) || m2 > maxr2 || covers;
+                decided = (best.key != ~0ull && bd2 <= m2 * err2) || m2 > maxr2 || covers;
                 if (!decided) { ++lev; did_pre = false; }
             }
         }
@@ -754,7 +756,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nnk_ml_kernel(const float4* __restri
                                                           const float* __restrict__ Tptr, const uint4* __restrict__ ltab_g, int nlev,
                                                           int k, float maxr2, int allow_self_i, int seeded, int* __restrict__ out_sidx,
                                                           float* __restrict__ out_d2, IcpState* __restrict__ st,
-                                                          unsigned* __restrict__ hard, int out_sorted)
+                                                          unsigned* __restrict__ hard, int out_sorted, float inv1e, float err2)
 {
     static_assert(G == 8, "lanes per query");
     constexpr int NB = 4;
@@ -869,7 +871,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nnk_ml_kernel(const float4* __restri
     if (seeded & 1) {
         merge();
         if (bound != ~0ull) { // first level whose block contains the ball of the k-th seed
-            const float ub = sqrtf(__uint_as_float((unsigned)(bound >> 32))) * 1.000001f;
+            const float ub = sqrtf(__uint_as_float((unsigned)(bound >> 32))) * inv1e * 1.000001f;
             for (; lev < nlev - 1; ++lev) {
                 const uint4 a = ltab[4 * lev], b = ltab[4 * lev + 1];
                 const float inv = __uint_as_float(b.x);
@@ -915,7 +917,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nnk_ml_kernel(const float4* __restri
 
         float rub2 = INFINITY;
         if (bound != ~0ull) {
-            const float rub = sqrtf(__uint_as_float((unsigned)(bound >> 32))) * 1.000001f + g.slack;
+            const float rub = sqrtf(__uint_as_float((unsigned)(bound >> 32))) * inv1e * 1.000001f + g.slack;
             rub2 = rub * rub;
         }
         unsigned rs[NR], rn[NR];
@@ -988,7 +990,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nnk_ml_kernel(const float4* __restri
         const float m2 = margin * margin;
         const float kd2 = __uint_as_float((unsigned)(bound >> 32));
         const bool covers = cx - 1 <= 0 && cx + 1 >= g.nx - 1 && cy - 1 <= 0 && cy + 1 >= g.ny - 1 && cz - 1 <= 0 && cz + 1 >= g.nz - 1;
-        decided = (bound != ~0ull && kd2 <= m2) || m2 > maxr2 || covers;
+        decided = (bound != ~0ull && kd2 <= m2 * err2) || m2 > maxr2 || covers;
         ++lev;
     }
 
@@ -1047,7 +1049,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KMAX <= 8 ?
                                                      const float* __restrict__ Tptr, const uint4* __restrict__ ltab_g, int nlev,
                                                      int k, float maxr2, int* __restrict__ out_sidx, float* __restrict__ out_d2,
                                                      IcpState* __restrict__ st, unsigned* __restrict__ hard, int out_sorted, int seed_pre,
-                                                     unsigned long long* __restrict__ win /* speculative level 0 of the fused selection (common.h: ICPMI_S2_WIN), or nullptr */)
+                                                     unsigned long long* __restrict__ win /* speculative level 0 of the fused selection (common.h: ICPMI_S2_WIN), or nullptr */,
+                                                     float inv1e, float err2 /* KDTreeMatcher's epsilon, as in nn1_wg_kernel */)
 {
     constexpr int NW = 4, NT = 64 * NW, Q = 64, NR = 3;
     constexpr int CAP = 14 * Q;   // pieces per pass (> 9 Q: one piece per row always fits)
@@ -1123,7 +1126,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KMAX <= 8 ?
     const unsigned long long maxkey = pack_key(maxr2, 0xffffffffu);
     // first level >= from whose 3 x 3 x 3 block contains the ball of this key's distance around the query
     auto level_for = [&](unsigned long long b, int from) {
-        const float ub = sqrtf(__uint_as_float((unsigned)(b >> 32))) * 1.000001f;
+        const float ub = sqrtf(__uint_as_float((unsigned)(b >> 32))) * inv1e * 1.000001f;
         int l = from;
         for (; l < nlev - 1; ++l) {
             const uint4 a = ltab_g[4 * l], bb = ltab_g[4 * l + 1];
@@ -1154,13 +1157,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KMAX <= 8 ?
 #pragma unroll
             for (int j = 0; j < KMAX; ++j) sq[j] = l0[sp[j] >= 0 ? sp[j] : 0];
             unsigned long long sb = 0ull; // the bound is the farthest of the k; the points themselves are met again in the pass
+            unsigned long long sk[KMAX];
             bool allv = true;
 #pragma unroll
             for (int j = 0; j < KMAX; ++j) {
-                const unsigned long long key = pack_key(sqdist3(p.x, p.y, p.z, sq[j].x, sq[j].y, sq[j].z), __float_as_uint(sq[j].w));
-                if (j < k) { sb = key > sb ? key : sb; allv = allv && sp[j] >= 0; }
+                sk[j] = pack_key(sqdist3(p.x, p.y, p.z, sq[j].x, sq[j].y, sq[j].z), __float_as_uint(sq[j].w));
+                if (j < k) { sb = sk[j] > sb ? sk[j] : sb; allv = allv && sp[j] >= 0; }
             }
             if (allv) seedb = sb;
+            // epsilon > 0: the pass only visits what lies within (bound) / (1 + epsilon) and may not meet the seeds again -- they go into the
+            // k-list themselves (libnabo prunes against a heap that HOLDS its k candidates); the passes then drop what they meet twice
+            if (allv && inv1e != 1.0f) {
+#pragma unroll
+                for (int j = 0; j < KMAX; ++j) if (j < k) insert(sk[j], sp[j], true);
+            }
         }
         if (seedb != ~0ull) {
             lev = level_for(seedb, 0);
@@ -1192,7 +1202,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KMAX <= 8 ?
                 float rub2 = INFINITY;
                 if (!prescan && acc < 0x7f80000000000000ull) { // (a finite radius: the k-th held, or the matcher's maxDist)
                     const float slack = __uint_as_float(ltab[4 * lv + 1].y);
-                    const float rub = sqrt_up(__uint_as_float((unsigned)(acc >> 32))) * 1.000001f + slack;
+                    // (the k-th held shrinks by 1 / (1 + epsilon); the matcher's maxDist does not: libnabo tests `new_rd <= maxRadius2` as it is)
+                    float rad = sqrt_up(__uint_as_float((unsigned)(acc >> 32)));
+                    if (b != ~0ull) rad = fminf(rad, sqrt_up(__uint_as_float((unsigned)(b >> 32))) * inv1e);
+                    const float rub = rad * 1.000001f + slack;
                     rub2 = rub * rub;
                 }
                 qrec[slot] = make_float4(p.x, p.y, p.z, __int_as_float(lv));
@@ -1384,7 +1397,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KMAX <= 8 ?
                     const float margin = fmaxf((1.0f + mf) * g_cell - g_slack, 0.f);
                     const float m2 = margin * margin;
                     const float kd2 = __uint_as_float((unsigned)(b >> 32));
-                    decided = (b != ~0ull && kd2 <= m2) || m2 > maxr2 || covers;
+                    decided = (b != ~0ull && kd2 <= m2 * err2) || m2 > maxr2 || covers;
                     if (!decided) { ++lev; did_pre = false; }
                 }
             }
@@ -1516,7 +1529,7 @@ icpmi_status nn_launch_k1(icpmi_ctx* c, const float4* d_reading, int64_t n, cons
         const int seed_pre = (seeded && c->nn_iter_hint > 1) ? 0 : 1;
 #define LAUNCH_WG(S_)                                                                                                           \
     hipLaunchKernelGGL((nn1_wg_kernel<4, S_>), dim3((int)(((n + 63) / 64 + 7) / 8 * 8), ba.nscan), dim3(256), 0, c->stream,    \
-                       q, qi, ba, d_T, c->levels, lc.maxr2, d_sidx, d_d2, d_state, c->d_hard, h0, mp, c->d_lvl_tab, unseeded_lev, seed_pre)
+                       q, qi, ba, d_T, c->levels, lc.maxr2, d_sidx, d_d2, d_state, c->d_hard, h0, mp, c->d_lvl_tab, unseeded_lev, seed_pre, lc.inv1e, lc.err2)
         if (allow_self) LAUNCH_WG(true); else LAUNCH_WG(false);
 #undef LAUNCH_WG
         const GridParams& top = c->levels.g[c->levels.nlev - 1];
@@ -1565,10 +1578,11 @@ static icpmi_status nnk_launch_t(icpmi_ctx* c, const float4* d_reading, int64_t 
             if (use_wg)
                 hipLaunchKernelGGL((nnk_wg_kernel<KM>), dim3((int)(((n + 63) / 64 + 7) / 8 * 8)), dim3(256), 0, c->stream, q, qi,
                                    (int)n, d_T, c->d_lvl_tab, c->levels.nlev, lc.k, lc.maxr2, d_sidx, d_d2, d_state, c->d_hard, out_sorted, wg_pre,
-                                   c->nn_builds_win ? reinterpret_cast<unsigned long long*>(c->nn_hist0 + ICPMI_S2_WIN) : (unsigned long long*)nullptr);
+                                   c->nn_builds_win ? reinterpret_cast<unsigned long long*>(c->nn_hist0 + ICPMI_S2_WIN) : (unsigned long long*)nullptr,
+                                   lc.inv1e, lc.err2);
             else
             hipLaunchKernelGGL((nnk_ml_kernel<G, KM>), dim3(grid), dim3(NN_BLOCK), 0, c->stream, q, qi, (int)n, d_T, c->d_lvl_tab,
-                               c->levels.nlev, lc.k, lc.maxr2, allow_self, seeded, d_sidx, d_d2, d_state, c->d_hard, out_sorted);
+                               c->levels.nlev, lc.k, lc.maxr2, allow_self, seeded, d_sidx, d_d2, d_state, c->d_hard, out_sorted, lc.inv1e, lc.err2);
             if (!std::isfinite(lc.max_dist) || (top.cell - top.slack) <= lc.max_dist) {
                 hipLaunchKernelGGL(nnk_hard_kernel<KMAX>, dim3(512), dim3(NN_BLOCK), 0, c->stream, d_reading, d_T, c->d_map_sorted,
                                    (int)c->m, lc.k, lc.maxr2, allow_self, d_sidx, d_d2, d_state, c->d_hard);

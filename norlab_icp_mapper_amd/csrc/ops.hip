@@ -803,7 +803,7 @@ static icpmi_status temp_knn(icpmi_ctx* c, TempCtx& t, const float* cloud4, int6
     s = loop_prepare_reading(tc, tc->d_stage_in, n, nullptr);
     if (s != ICPMI_OK) { c->last_error = tc->last_error; return s; }
     LoopCfg lc = make_loop_cfg(tc, 1);
-    lc.k = k; lc.max_dist = INFINITY; lc.maxr2 = INFINITY; lc.ring_max = 6;
+    lc.k = k; lc.max_dist = INFINITY; lc.maxr2 = INFINITY; lc.ring_max = 6; lc.inv1e = 1.f; lc.err2 = 1.f; // (a filter's search: exact whatever the matcher's epsilon)
     const size_t cnt = (size_t)n * k + 1;
     if (ensure_cap(tc, &tc->d_sidx, &tc->cap_sidx, cnt) != ICPMI_OK || ensure_cap(tc, &tc->d_d2, &tc->cap_d2, cnt) != ICPMI_OK ||
         ensure_cap(tc, &tc->d_hard, &tc->cap_hard, (size_t)n + 1) != ICPMI_OK) { c->last_error = tc->last_error; return ICPMI_ERR_HIP; }
@@ -1299,6 +1299,7 @@ icpmi_status chain_point_distance_flags(icpmi_ctx* c, icpmi_ctx* ic, const float
     icpmi_status s = loop_prepare_reading(ic, d_scan, n, nullptr);
     if (s != ICPMI_OK) { c->last_error = ic->last_error; return s; }
     LoopCfg lc = make_loop_cfg(ic, 1);
+    lc.inv1e = 1.f; lc.err2 = 1.f; // (the module's predicate is exact whatever the matcher's epsilon)
     lc.k = 1; lc.n_out = 0; lc.max_dist = min_dist; lc.maxr2 = pd_radius2(lim); // a radius search with maxDist = minDist decides the same predicate
     const size_t cnt = (size_t)n + 1;
     if (ensure_cap(ic, &ic->d_sidx, &ic->cap_sidx, cnt) != ICPMI_OK || ensure_cap(ic, &ic->d_d2, &ic->cap_d2, cnt) != ICPMI_OK ||

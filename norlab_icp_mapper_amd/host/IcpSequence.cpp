@@ -115,6 +115,10 @@ void GpuICPSequence::loadFromYamlNode(const yaml::Node& icp)
         requireKnown(e.second, {"knn", "epsilon", "searchType", "maxDist", "maxDistField"}, "KDTreeMatcher");
         if (e.second["knn"]) cfg.knn = e.second["knn"].as<int>();
         if (e.second["epsilon"]) cfg.epsilon = e.second["epsilon"].as<float>();
+        // NIM_EPSILON_APPROX=1 (deployment knob): `epsilon` prunes the search as libnabo's maxError2 does (icpmi_config::
+        // epsilon_approx); default: the exact search, which is a valid answer for every epsilon
+        static const bool approx = [] { const char* v = std::getenv("NIM_EPSILON_APPROX"); return v && std::atoi(v) != 0; }();
+        cfg.epsilon_approx = approx ? 1 : 0;
         if (e.second["maxDist"]) cfg.max_dist = e.second["maxDist"].as<float>();
     }
     cfg.n_outlier = 0;

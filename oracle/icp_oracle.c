@@ -192,8 +192,10 @@ static inline float sqdist(const float* q, const float* p, int dim)
     return d;
 }
 
+/* err2 = (1 + epsilon)^2: libnabo's maxError2 (nabo/kdtree_cpu.cpp, recurseKnn: `if ((new_rd <= maxRadius2) && (new_rd * maxError2 <
+ * heap.headValue()))`); 1 for the exact search */
 static void kd_search(const orc_kdtree* t, int32_t node, const float* q, float* off, float rd,
-                      float maxr2, int allow_self, knn_heap* h)
+                      float maxr2, int allow_self, knn_heap* h, float err2)
 {
     const kd_node* nd = &t->nodes[node];
     if (nd->dim < 0) {
@@ -210,14 +212,14 @@ static void kd_search(const orc_kdtree* t, int32_t node, const float* q, float* 
     int32_t near_c, far_c;
     if (new_off > 0.f) { near_c = nd->right; far_c = node + 1; }
     else { near_c = node + 1; far_c = nd->right; }
-    kd_search(t, near_c, q, off, rd, maxr2, allow_self, h);
+    kd_search(t, near_c, q, off, rd, maxr2, allow_self, h, err2);
     /* incremental distance to the far half-space (Arya & Mount); a tiny relative slack keeps the
      * prune conservative w.r.t. the fmaf-evaluated point distances */
     const float nrd = rd - old_off * old_off + new_off * new_off;
     const float bound = nrd * (1.0f - 4.0f * FLT_EPSILON) - FLT_MIN;
-    if (bound <= maxr2 && bound <= heap_worst(h)) {
+    if (bound <= maxr2 && (err2 == 1.0f ? bound <= heap_worst(h) : bound * err2 < heap_worst(h))) {
         off[d] = new_off;
-        kd_search(t, far_c, q, off, nrd, maxr2, allow_self, h);
+        kd_search(t, far_c, q, off, nrd, maxr2, allow_self, h, err2);
         off[d] = old_off;
     }
 }
@@ -230,6 +232,15 @@ static void knn_finish(knn_heap* h)
 void orc_kdtree_knn(const orc_kdtree* t, const float* q4, int64_t n, int k, float max_radius,
                     int allow_self, int32_t* ids, float* d2, int nthreads)
 {
+    orc_kdtree_knn_eps(t, q4, n, k, max_radius, 0.f, allow_self, ids, d2, nthreads);
+}
+
+/* KDTreeMatcher{epsilon}: NNS::knn(query, ids, dists2, knn, epsilon, optionFlags, maxRadius) -- an approximate search; WHICH (1 + epsilon)-
+ * answer comes back depends on the traversal order of the tree (libnabo's own, this one's): only the guarantee is common ground */
+void orc_kdtree_knn_eps(const orc_kdtree* t, const float* q4, int64_t n, int k, float max_radius, float epsilon,
+                        int allow_self, int32_t* ids, float* d2, int nthreads)
+{
+    const float err2 = (1.0f + epsilon) * (1.0f + epsilon);
     const float maxr2 = isinf(max_radius) ? INFINITY : max_radius * max_radius;
     (void)nthreads;
 #ifdef _OPENMP
@@ -239,7 +250,7 @@ void orc_kdtree_knn(const orc_kdtree* t, const float* q4, int64_t n, int k, floa
         knn_heap h = { k, 0, ids + (int64_t)k * i, d2 + (int64_t)k * i };
         if (t->m > 0) {
             float off[3] = { 0.f, 0.f, 0.f };
-            kd_search(t, 0, q4 + 4 * i, off, 0.f, maxr2, allow_self, &h);
+            kd_search(t, 0, q4 + 4 * i, off, 0.f, maxr2, allow_self, &h, err2);
         }
         knn_finish(&h);
     }

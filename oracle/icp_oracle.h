@@ -111,6 +111,9 @@ void orc_kdtree_free(orc_kdtree* t);
  * ascending by (d2, id); accepts d2 <= max_radius^2; allow_self==0 rejects d2 <= FLT_EPSILON. */
 void orc_kdtree_knn(const orc_kdtree* t, const float* q4, int64_t n, int k, float max_radius,
                     int allow_self, int32_t* ids, float* d2, int nthreads);
+/* KDTreeMatcher{epsilon}: libnabo's approximate search rule (new_rd * (1 + epsilon)^2 < heap.headValue()) on this tree */
+void orc_kdtree_knn_eps(const orc_kdtree* t, const float* q4, int64_t n, int k, float max_radius, float epsilon,
+                        int allow_self, int32_t* ids, float* d2, int nthreads);
 /* brute-force version with the identical contract (used to validate the kd-tree) */
 void orc_bruteforce_knn(const float* pts4, int64_t m, int dim, const float* q4, int64_t n, int k,
                         float max_radius, int allow_self, int32_t* ids, float* d2);

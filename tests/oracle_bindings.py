@@ -53,6 +53,7 @@ def load():
     lib.orc_kdtree_build.argtypes = [_P, C.c_int64, C.c_int, C.c_int]
     lib.orc_kdtree_free.argtypes = [_P]
     lib.orc_kdtree_knn.argtypes = [_P, _P, C.c_int64, C.c_int, C.c_float, C.c_int, _P, _P, C.c_int]
+    lib.orc_kdtree_knn_eps.argtypes = [_P, _P, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_int, _P, _P, C.c_int]
     lib.orc_bruteforce_knn.argtypes = [_P, C.c_int64, C.c_int, _P, C.c_int64, C.c_int, C.c_float, C.c_int, _P, _P]
     lib.orc_transform.argtypes = [_P, _P, _P, C.c_int64]
     lib.orc_rotate3.argtypes = [_P, _P, _P, C.c_int64]
@@ -151,9 +152,14 @@ def rotate3(T, normals):
     return out
 
 
-def knn(cloud, queries, k=1, max_dist=math.inf, allow_self=True, bucket=8, nthreads=1, brute=False):
+def knn(cloud, queries, k=1, max_dist=math.inf, allow_self=True, bucket=8, nthreads=1, brute=False, epsilon=0.0):
     lib = load(); cloud = _f32(cloud); q = _f32(queries)
     ids = np.empty((q.shape[0], k), dtype=np.int32); d2 = np.empty((q.shape[0], k), dtype=np.float32)
+    if epsilon > 0.0:   # KDTreeMatcher{epsilon}: libnabo's approximate rule on the oracle's tree
+        t = lib.orc_kdtree_build(cloud.ctypes.data, cloud.shape[0], 3, bucket)
+        lib.orc_kdtree_knn_eps(t, q.ctypes.data, q.shape[0], k, max_dist, epsilon, int(allow_self), ids.ctypes.data, d2.ctypes.data, nthreads)
+        lib.orc_kdtree_free(t)
+        return ids, d2
     if brute:
         lib.orc_bruteforce_knn(cloud.ctypes.data, cloud.shape[0], 3, q.ctypes.data, q.shape[0], k, max_dist, int(allow_self),
                                ids.ctypes.data, d2.ctypes.data)
