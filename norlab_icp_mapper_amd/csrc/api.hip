@@ -234,7 +234,7 @@ void icpmi_destroy(icpmi_handle c)
     dev_free(c->d_qsorted); dev_free(c->d_qindex); dev_free(c->d_qkeys); dev_free(c->d_qtile);
     dev_free(c->d_reading); dev_free(c->d_read_normals); dev_free(c->d_stage_in); dev_free(c->d_stage_n3);
     dev_free(c->d_match_pt); dev_free(c->d_lvl_tab); dev_free(c->d_raw); dev_free(c->d_raw_n3); dev_free(c->d_raw_s); dev_free(c->d_src); dev_free(c->d_alt_raw); dev_free(c->d_alt_n3);
-    dev_free(c->d_alt_s); dev_free(c->d_alt_src); dev_free(c->d_stage_s); dev_free(c->d_merge_send); dev_free(c->d_merge_recv); dev_free(c->d_merged); dev_free(c->d_cell_log); dev_free(c->d_comm_cnt); dev_free(c->d_read_noise); dev_free(c->d_read_scalar); dev_free(c->d_map_pn);
+    dev_free(c->d_alt_s); dev_free(c->d_alt_src); dev_free(c->d_stage_s); dev_free(c->d_merge_send); dev_free(c->d_merge_recv); dev_free(c->d_merged); dev_free(c->d_cell_log); dev_free(c->d_raw_dk); dev_free(c->d_comm_cnt); dev_free(c->d_read_noise); dev_free(c->d_read_scalar); dev_free(c->d_map_pn);
     for (int k = 0; k < ICPMI_SCRATCH_SLOTS; ++k) dev_free(c->scratch[k]); dev_free(c->d_scan_map); dev_free(c->d_T16);
     dev_free(c->d_sidx); dev_free(c->d_d2); dev_free(c->d_hard); dev_free(c->d_selhist);
     dev_free(c->d_state);
@@ -304,6 +304,10 @@ icpmi_status icpmi_debug_counters(icpmi_handle h, uint64_t out[24])
     out[17] = (uint64_t)h->raw_view_count; // PointDistance searches served by the raw-frame view of the registration index (no second index)
     out[18] = (uint64_t)(uint32_t)h->ins_count | ((uint64_t)(uint32_t)(h->temp_raw ? h->temp_raw->ins_count : 0) << 32);
     out[19] = (uint64_t)(uint32_t)h->full_count | ((uint64_t)(uint32_t)(h->temp_raw ? h->temp_raw->full_count : 0) << 32);
+    // (r6) SurfaceNormal passes over the resident map of an append-only update: served by the subset search / over the whole map; points the last pass searched
+    out[20] = (uint64_t)h->normals_incremental;
+    out[21] = (uint64_t)h->normals_full;
+    out[22] = (uint64_t)h->normals_last_searched;
 #endif
     return ICPMI_OK;
 }

@@ -579,6 +579,11 @@ struct icpmi_ctx {
     int64_t merged_last_n = 0;        // points of the last epoch's merged set, still in d_merged (icpmi_staged_merged_points)
     // r6 (cells.hip): every merged set binned by icpmi_staged_bin_cells, cell after cell; the host keeps {offset, count} runs per cell id
     float4* d_cell_log = nullptr; size_t cap_cell_log = 0; int64_t cell_log_n = 0;
+    // r6 (ops.hip: surface_normals_dev): d^2 of the k-th neighbour of every resident point as the last SurfaceNormal pass over the resident map found it
+    // (original order) -- an append recomputes only the normals an appended point can have changed.  Valid for the first dk_m points while
+    // dk_epoch == raw_epoch (nobody rewrote the resident copy) and the filter's knn is dk_knn.
+    float* d_raw_dk = nullptr; size_t cap_raw_dk = 0; int64_t dk_m = 0; int dk_knn = 0; uint64_t dk_epoch = ~0ull;
+    long normals_incremental = 0, normals_full = 0; int64_t normals_last_searched = 0;   // diagnostics (icpmi_debug_counters 20 / 21 / 22)
     bool merged_binned = false;       // the merged set of the last epoch is in the log already
     int cell_bits_hint = 0;           // key bits the previous epoch's cell count needed (the sort is enqueued before the count is known)
     struct SelfGridCtx* sg = nullptr; // sparse block grid of the self k-NN (selfgrid.hip): tables, work lists and the tuning state of the handle's previous build
@@ -863,7 +868,10 @@ icpmi_status nn_launch_k(icpmi_ctx* c, const float4* d_reading, int64_t n, const
 icpmi_status nn_ids_to_original(icpmi_ctx* c, const int* d_sidx, int64_t count, int* d_ids);
 // self k-NN of a device cloud through a sparse block grid built for the call (selfgrid.hip): rows of d_sidx / d_d2 in the cloud's order, entries =
 // positions in c->d_map_sorted (w = original index bits), which the call leaves behind for launch_normals / nn_ids_to_original
-icpmi_status selfgrid_knn(icpmi_ctx* c, const float4* d_pts, int64_t m, int k, int* d_sidx, float* d_d2);
+// subset search of an appended cloud (selfgrid.hip): in -- m_old, d_dk (d^2 of the k-th neighbour of the first m_old points, original order);
+// out -- d_list / n_sel: the searched original indices
+struct SelfGridSubset { int64_t m_old = 0; const float* d_dk = nullptr; const unsigned* d_list = nullptr; int64_t n_sel = 0; };
+icpmi_status selfgrid_knn(icpmi_ctx* c, const float4* d_pts, int64_t m, int k, int* d_sidx, float* d_d2, SelfGridSubset* sub = nullptr);
 void selfgrid_destroy(icpmi_ctx* c);
 icpmi_status create_handle(const icpmi_config* cfg, icpmi_handle* out); // icpmi_create without the cache's handle count (private handles)
 icpmi_status loop_run(icpmi_ctx* c, const float4* d_scan, const float* d_normals3, int64_t n, const LoopCfg& lc, bool fixed, float T_out[16],

@@ -91,10 +91,12 @@ template <int KMAX>
 __global__ __launch_bounds__(128) void normals_kernel(const float4* __restrict__ map, const int* __restrict__ sidx, int64_t m, int k,
                                                       float* __restrict__ normals3, float* __restrict__ densities, int dim2,
                                                       float* __restrict__ mean_dist = nullptr, float* __restrict__ eig_values = nullptr,
-                                                      float* __restrict__ eig_vectors = nullptr)
+                                                      float* __restrict__ eig_vectors = nullptr, const unsigned* __restrict__ list = nullptr)
 {
-    const int64_t i = (int64_t)blockIdx.x * 128 + threadIdx.x;
-    if (i >= m) return;
+    // list (r6): an appended cloud -- m entries, the points whose neighbourhood was searched again (surface_normals_dev); otherwise all m points
+    const int64_t t = (int64_t)blockIdx.x * 128 + threadIdx.x;
+    if (t >= m) return;
+    const int64_t i = list ? (int64_t)list[t] : t;
     // (r2: walking the points in cell-sorted order instead -- coherent neighbour gathers, scattered row reads and normal
     // writes -- measured 108 -> 164 us on the octree-ordered 0.9 M-point map and within noise on an append-ordered one: kept
     // in the caller's order)
@@ -240,13 +242,13 @@ __global__ __launch_bounds__(128) void normals_kernel(const float4* __restrict__
 
 // k <= 10 (the shipped SurfaceNormalDataPointsFilter{knn: 10}) and k <= 16 keep the neighbourhood in registers; ICPMI_NORMALS_REG=0: the generic walk
 static void launch_normals(hipStream_t stream, const float4* map, const int* sidx, int64_t m, int k, float* normals3, float* densities, int dim2,
-                           float* mean_dist = nullptr, float* eig_values = nullptr, float* eig_vectors = nullptr)
+                           float* mean_dist = nullptr, float* eig_values = nullptr, float* eig_vectors = nullptr, const unsigned* list = nullptr)
 {
     constexpr int reg = 1;
     const dim3 grid((int)((m + 127) / 128)), block(128);
-    if (reg && k <= 10) hipLaunchKernelGGL(normals_kernel<10>, grid, block, 0, stream, map, sidx, m, k, normals3, densities, dim2, mean_dist, eig_values, eig_vectors);
-    else if (reg && k <= 16) hipLaunchKernelGGL(normals_kernel<16>, grid, block, 0, stream, map, sidx, m, k, normals3, densities, dim2, mean_dist, eig_values, eig_vectors);
-    else hipLaunchKernelGGL(normals_kernel<0>, grid, block, 0, stream, map, sidx, m, k, normals3, densities, dim2, mean_dist, eig_values, eig_vectors);
+    if (reg && k <= 10) hipLaunchKernelGGL(normals_kernel<10>, grid, block, 0, stream, map, sidx, m, k, normals3, densities, dim2, mean_dist, eig_values, eig_vectors, list);
+    else if (reg && k <= 16) hipLaunchKernelGGL(normals_kernel<16>, grid, block, 0, stream, map, sidx, m, k, normals3, densities, dim2, mean_dist, eig_values, eig_vectors, list);
+    else hipLaunchKernelGGL(normals_kernel<0>, grid, block, 0, stream, map, sidx, m, k, normals3, densities, dim2, mean_dist, eig_values, eig_vectors, list);
 }
 
 // ---- fused input filters (Mapper::applyInputFilters): one predicate pass for a run of DistanceLimit / BoundingBox filters ----
@@ -559,6 +561,15 @@ __global__ __launch_bounds__(256) void keep_flag_kernel(const float* __restrict_
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     flag[i] = d2[i] >= lim ? 1u : 0u;
+}
+
+// d^2 of the k-th neighbour of every searched point (the row's last entry; +inf: fewer than k points in the cloud)
+__global__ __launch_bounds__(256) void kth_d2_kernel(const float* __restrict__ d2, int64_t m, int k, const unsigned* __restrict__ list, float* __restrict__ dk)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= m) return;
+    const int64_t i = list ? (int64_t)list[t] : t;
+    dk[i] = d2[(size_t)k * i + (k - 1)];
 }
 
 __global__ __launch_bounds__(256) void flag_to_keep_kernel(const unsigned* __restrict__ flag, int64_t n, uint8_t* __restrict__ keep)
@@ -996,8 +1007,12 @@ icpmi_status ops_dynamic_points_update(icpmi_ctx* c, const icpmi_dynpts_params* 
     return ICPMI_OK;
 }
 
-// SurfaceNormalDataPointsFilter{knn} over a DEVICE cloud into a DEVICE 3 x m array (same kernels as ops_surface_normals)
-static icpmi_status surface_normals_dev(icpmi_ctx* c, const float4* d_pts, int64_t m, int knn, float* d_normals3)
+// SurfaceNormalDataPointsFilter{knn} over a DEVICE cloud into a DEVICE 3 x m array (same kernels as ops_surface_normals).
+// m_old > 0 (r6): d_pts[0 .. m_old) is the cloud this function last ran on (the resident map before an append), d_normals3 still holds its
+// normals and c->d_raw_dk the d^2 of every point's k-th neighbour: only the appended points and the old points an appended point can have
+// entered the neighbourhood of are searched and solved again -- the other normals are what a pass over the whole cloud would write, bit for
+// bit (same neighbours, same coordinates, same sums).  Reference semantics unchanged: Map.cpp:524 applies the filter to the whole map.
+static icpmi_status surface_normals_dev(icpmi_ctx* c, const float4* d_pts, int64_t m, int knn, float* d_normals3, int64_t m_old = 0, bool remember = false)
 {
     TempCtx t;
     icpmi_status s = make_temp(c, t);
@@ -1007,10 +1022,25 @@ static icpmi_status surface_normals_dev(icpmi_ctx* c, const float4* d_pts, int64
     // r6: the sparse block grid (selfgrid.hip) -- index and search in one call
     const size_t cnt = (size_t)m * knn + 1;
     if (ensure_cap(tc, &tc->d_sidx, &tc->cap_sidx, cnt) != ICPMI_OK || ensure_cap(tc, &tc->d_d2, &tc->cap_d2, cnt) != ICPMI_OK) { c->last_error = tc->last_error; return ICPMI_ERR_HIP; }
-    s = selfgrid_knn(tc, d_pts, m, knn, tc->d_sidx, tc->d_d2);
+    const bool track = remember && d_pts == c->d_raw; // (the resident map of an append-only update: remember the k-th distances for the next append;
+                                                      //  a chain program may compact or reorder the points behind its normals pass: not tracked)
+    if (!track) c->dk_m = 0;
+    static const bool inc_on = [] { const char* e = getenv("ICPMI_NORMALS_INCREMENTAL"); return !e || atoi(e) != 0; }(); // 0: every pass over the whole cloud (diagnostic / A-B)
+    const bool incremental = inc_on && track && m_old > 0 && m_old < m && c->d_raw_dk && c->dk_m == m_old && c->dk_knn == knn && c->dk_epoch == c->raw_epoch;
+    if (track && ensure_cap_keep(c, &c->d_raw_dk, &c->cap_raw_dk, (size_t)m + 1, incremental ? (size_t)m_old : 0) != ICPMI_OK) return ICPMI_ERR_HIP;
+    SelfGridSubset sub;
+    sub.m_old = incremental ? m_old : 0; sub.d_dk = c->d_raw_dk;
+    s = selfgrid_knn(tc, d_pts, m, knn, tc->d_sidx, tc->d_d2, incremental ? &sub : nullptr);
     if (s != ICPMI_OK) { c->last_error = tc->last_error; return s; }
+    const unsigned* list = incremental ? sub.d_list : nullptr;
+    const int64_t todo = incremental ? sub.n_sel : m;
     // rows of d_sidx follow the query order = the caller's order, so the normals land in place
-    launch_normals(tc->stream, tc->d_map_sorted, tc->d_sidx, m, knn, d_normals3, (float*)nullptr, c->cfg.is_2d);
+    if (todo > 0) launch_normals(tc->stream, tc->d_map_sorted, tc->d_sidx, todo, knn, d_normals3, (float*)nullptr, c->cfg.is_2d, nullptr, nullptr, nullptr, list);
+    if (track) {
+        if (todo > 0) hipLaunchKernelGGL(kth_d2_kernel, dim3((int)((todo + 255) / 256)), dim3(256), 0, tc->stream, (const float*)tc->d_d2, todo, knn, list, c->d_raw_dk);
+        c->dk_m = m; c->dk_knn = knn; c->dk_epoch = c->raw_epoch;
+        if (incremental) { ++c->normals_incremental; c->normals_last_searched = sub.n_sel; } else { ++c->normals_full; c->normals_last_searched = m; }
+    }
     HIP_TRY(c, hipGetLastError());
     if (tc->stream != c->stream) HIP_TRY(c, hipStreamSynchronize(tc->stream));
     return ICPMI_OK;
@@ -1102,7 +1132,7 @@ icpmi_status ops_map_update_dev(icpmi_ctx* c, const float4* d_scan, int64_t n, c
             if (e == hipSuccess) e = hipGetLastError();
         }
         // SurfaceNormalDataPointsFilter over the grown map (Map.cpp:524 with examples/config.yaml:26-27)
-        if (s == ICPMI_OK && e == hipSuccess && normals_knn > 0) s = surface_normals_dev(c, c->d_raw, m1, normals_knn, c->d_raw_n3);
+        if (s == ICPMI_OK && e == hipSuccess && normals_knn > 0) s = surface_normals_dev(c, c->d_raw, m1, normals_knn, c->d_raw_n3, m0, true); // (m0: an append -- only what it changed)
         // icp.setMap(localPointCloud) (Map.cpp:528): rebuild the index from the resident copy
         // (an append: the first m0 resident points are the cloud the index was built from -- map_insert where it applies)
         c->ins_normals_changed = normals_knn > 0 || !c->has_normals; // (the whole field was recomputed above / had no sorted copy)

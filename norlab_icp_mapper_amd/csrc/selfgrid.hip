@@ -41,6 +41,8 @@ struct SelfGridCtx {
     uint2* d_queue = nullptr; size_t cap_queue = 0;                           // {sorted position, bits of the bound on the k-th d^2} of the queries the tiled pass left
     unsigned* d_inv = nullptr; size_t cap_inv = 0;                            // original index -> sorted position
     float* d_part = nullptr; size_t cap_part = 0;                             // bounding-box partials
+    unsigned* d_dirty = nullptr; size_t cap_dirty = 0;                        // subset search: bitmaps of the cells appended points fell into, per level
+    unsigned char* d_sel = nullptr; size_t cap_sel = 0;                       // ... selected queries by sorted position (m) and by original index (m)
     struct SgState* d_state = nullptr;
     // tuning state: the edge of the previous build and what its points saw (size-biased A-cell occupancy, delivered through the mapped page)
     float cell = 0.f; int64_t m = 0; int k = 0;
@@ -406,7 +408,8 @@ __global__ __launch_bounds__(64) void sg_cell_kernel(SgGrid g, const float4* __r
                                                      const unsigned* __restrict__ tbid, const unsigned* __restrict__ f,
                                                      const unsigned* __restrict__ inv, SgState* __restrict__ st, int k, unsigned m, int packed_ok,
                                                      int* __restrict__ out_sidx, float* __restrict__ out_d2, uint2* __restrict__ queue, unsigned qcap,
-                                                     unsigned long long* __restrict__ sq_mapped)
+                                                     unsigned long long* __restrict__ sq_mapped, const unsigned char* __restrict__ qsel /* by sorted position, or nullptr: all */,
+                                                     const unsigned* __restrict__ wlist /* subset search: the groups of SGQ sorted positions that hold a selected query, [0] = how many */)
 {
     __shared__ unsigned pre[28], cst[27], cpos[64 * SG_R];
     __shared__ uint2 undq[SGQ];
@@ -418,7 +421,15 @@ __global__ __launch_bounds__(64) void sg_cell_kernel(SgGrid g, const float4* __r
         if (lane == 0) { *sq_mapped = sq; st->sq = sq; }
     }
     const unsigned INF_BITS = 0x7f800000u;
-    const unsigned q0 = blockIdx.x * SGQ, q1 = min(q0 + (unsigned)SGQ, m);
+    unsigned grp = blockIdx.x;
+    if (wlist) { if (blockIdx.x >= wlist[0]) return; grp = wlist[1 + blockIdx.x]; }
+    const unsigned q0 = grp * SGQ, q1 = min(q0 + (unsigned)SGQ, m);
+    // a subset search (an appended cloud: only the points whose neighbourhood may have changed): a wave none of whose queries is selected is done
+    int msel = 1;
+    if (qsel) {
+        msel = (q0 + (unsigned)lane < q1) ? (int)qsel[q0 + (unsigned)lane] : 0;
+        if (__ballot(msel != 0) == 0ull) return;
+    }
     // the wave's queries, one trip; what a query needs besides its coordinates is computed by its lane and read with v_readlane below
     const float4 mine = map[min(q0 + (unsigned)lane, m - 1)];
     const float mfx = (mine.x - g.ox) * g.inv_cell, mfy = (mine.y - g.oy) * g.inv_cell, mfz = (mine.z - g.oz) * g.inv_cell;
@@ -435,6 +446,7 @@ __global__ __launch_bounds__(64) void sg_cell_kernel(SgGrid g, const float4* __r
     for (int r = 0; r < SG_R; ++r) { cand[r] = make_float4(0.f, 0.f, 0.f, 0.f); cpay[r] = 0; cval[r] = false; }
     for (unsigned qi = q0; qi < q1; ++qi) {
         const int src = (int)(qi - q0);
+        if (!__builtin_amdgcn_readlane(msel, src)) continue; // (uniform)
         const float mex = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.x), src)), mey = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.y), src)),
                     mez = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.z), src));
         const unsigned orig_q = (unsigned)__builtin_amdgcn_readlane(__float_as_int(mine.w), src);
@@ -666,6 +678,119 @@ __global__ __launch_bounds__(64) void sg_level_kernel(SgGrid g, const float4* __
     if (diag && lane == 0 && lev_sum) atomicAdd(&st->levels, lev_sum); // (ICPMI_SELF_DIAG only: thousands of atomics on one address)
 }
 
+// ---- r6: the subset search of an APPENDED cloud (exact incremental SurfaceNormal: ops.hip surface_normals_dev) ----------------------------------
+// The first m_old points of the cloud are the cloud of the handle's previous call and each of them remembers the d^2 of its k-th neighbour
+// (dk).  A point's k nearest change only if an appended point lies strictly inside that ball (an appended point has the larger index: a tie
+// loses).  Conservative test on the grid of THIS build: level l = the first whose cells (edge cell * 2^l) are at least the ball's radius wide
+// -- then every point of the ball lies in the 3 x 3 x 3 cells of level l around the old point's, and those 27 are looked up in a bitmap of the
+// cells appended points fell into.  A false positive is searched again and finds what it had.
+struct SgLevels {
+    int L, lmin;                    // levels lmin .. L - 1 have a bitmap (the top one is a single cell); a ball narrower than level lmin is tested there
+    unsigned long long off[26];     // first bit of level l (cells per axis at level l: ((na - 1) >> l) + 1)
+};
+
+// one lane per (appended point, level): blockIdx.y = level.  The lanes of a wave that hit the same word (at the coarse levels: all of them)
+// send ONE atomic -- thousands of atomics on one address serialise at 10 - 25 ns each.
+// (the level table lives in device memory: a by-value struct indexed by a run-time level would be copied to scratch)
+__global__ __launch_bounds__(256) void sg_dirty_kernel(const float4* __restrict__ pts, int64_t m_old, int64_t m, SgGrid g, const SgLevels* __restrict__ lvp, unsigned* __restrict__ bits)
+{
+    const int64_t i = m_old + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = i < m;
+    const int l = lvp->lmin + (int)blockIdx.y;
+    unsigned long long b = 0;
+    if (valid) {
+        const float4 p = pts[i];
+        const int a0 = sg_cell_of(p.x, g.ox, g.inv_cell, g.na[0]) >> l, a1 = sg_cell_of(p.y, g.oy, g.inv_cell, g.na[1]) >> l, a2 = sg_cell_of(p.z, g.oz, g.inv_cell, g.na[2]) >> l;
+        const int n0 = ((g.na[0] - 1) >> l) + 1, n1 = ((g.na[1] - 1) >> l) + 1;
+        b = lvp->off[l] + ((unsigned long long)a2 * n1 + (unsigned long long)a1) * n0 + (unsigned long long)a0;
+    }
+    const unsigned word = (unsigned)(b >> 5);
+    unsigned mask = valid ? 1u << (unsigned)(b & 31u) : 0u;
+    unsigned long long todo = __ballot(valid);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const unsigned lw = (unsigned)__builtin_amdgcn_readlane((int)word, leader);
+        const bool same = valid && word == lw;
+        const unsigned long long grp = __ballot(same);
+        unsigned mm = same ? mask : 0u;
+        for (int o = 32; o > 0; o >>= 1) mm |= (unsigned)__shfl_xor((int)mm, o, 64);
+        if (lane == leader) atomicOr(&bits[lw], mm);
+        todo &= ~grp;
+    }
+}
+
+// one lane per SORTED position (neighbouring lanes look up the same words of the bitmaps): a selected point marks its sorted position for the
+// cell kernel and joins the list the normals are solved from (original indices; order irrelevant: one row per point)
+__global__ __launch_bounds__(256) void sg_affected_kernel(const float4* __restrict__ sorted, int64_t m, unsigned m_old, const float* __restrict__ dk, SgGrid g,
+                                                          const SgLevels* __restrict__ lvp, const unsigned* __restrict__ bits,
+                                                          unsigned char* __restrict__ sel_sorted, unsigned* __restrict__ list, unsigned* __restrict__ n_sel)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lv_lmin = lvp->lmin, lv_L = lvp->L;
+    bool hit = false;
+    unsigned orig = 0;
+    if (i < m) {
+        const float4 p = sorted[i];
+        orig = __float_as_uint(p.w);
+        hit = orig >= m_old;
+        if (!hit) {
+            const float d2 = dk[orig];
+            if (!(d2 < INFINITY)) hit = true; // fewer than k points so far: every appended point enters
+            else {
+                const float r = sqrt_up_sg(d2) * 1.00001f + (g.cell * 1e-3f + g.maxabs * 4e-6f);
+                int l = lv_lmin;
+                while (l < lv_L - 1 && g.cell * (float)(1u << l) < r) ++l;
+                const int n0 = ((g.na[0] - 1) >> l) + 1, n1 = ((g.na[1] - 1) >> l) + 1, n2 = ((g.na[2] - 1) >> l) + 1;
+                const unsigned long long off = lvp->off[l];
+                const int c0 = sg_cell_of(p.x, g.ox, g.inv_cell, g.na[0]) >> l, c1 = sg_cell_of(p.y, g.oy, g.inv_cell, g.na[1]) >> l,
+                          c2 = sg_cell_of(p.z, g.oz, g.inv_cell, g.na[2]) >> l;
+                for (int dz = -1; dz <= 1 && !hit; ++dz)
+                    for (int dy = -1; dy <= 1 && !hit; ++dy) {
+                        const int z = c2 + dz, y = c1 + dy;
+                        if (z < 0 || y < 0 || z >= n2 || y >= n1) continue;
+                        const unsigned long long row = off + ((unsigned long long)z * n1 + (unsigned long long)y) * n0;
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            const int x = c0 + dx;
+                            if (x < 0 || x >= n0) continue;
+                            const unsigned long long b = row + (unsigned long long)x;
+                            if (bits[b >> 5] & (1u << (b & 31u))) { hit = true; break; }
+                        }
+                    }
+            }
+        }
+        sel_sorted[i] = hit ? 1 : 0;
+    }
+    const unsigned long long bal = __ballot(hit);
+    if (bal) {
+        const int lane = threadIdx.x & 63;
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(n_sel, (unsigned)__popcll(bal));
+        base = (unsigned)__builtin_amdgcn_readlane((int)base, 0);
+        if (hit) list[base + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = orig;
+    }
+}
+
+// the groups of SGQ consecutive sorted positions (one wave of the cell kernel each) that hold a selected query: wlist[0] = count, then the groups
+__global__ __launch_bounds__(256) void sg_wavelist_kernel(const unsigned char* __restrict__ sel_sorted, unsigned m, unsigned* __restrict__ wlist)
+{
+    static_assert(SGQ == 16, "one uint4 of flags per group");
+    const unsigned gq = blockIdx.x * 256 + threadIdx.x, groups = (m + SGQ - 1) / SGQ;
+    bool any = false;
+    if (gq < groups) {
+        if ((gq + 1) * SGQ <= m) { const uint4 v = reinterpret_cast<const uint4*>(sel_sorted)[gq]; any = (v.x | v.y | v.z | v.w) != 0u; }
+        else for (unsigned i = gq * SGQ; i < m; ++i) any |= sel_sorted[i] != 0;
+    }
+    const unsigned long long bal = __ballot(any);
+    if (bal) {
+        const int lane = threadIdx.x & 63;
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(&wlist[0], (unsigned)__popcll(bal));
+        base = (unsigned)__builtin_amdgcn_readlane((int)base, 0);
+        if (any) wlist[1 + base + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = gq;
+    }
+}
+
 template <typename T>
 icpmi_status sg_cap(icpmi_ctx* c, T** p, size_t* cap, size_t need, bool* fresh = nullptr)
 {
@@ -680,12 +805,15 @@ icpmi_status sg_cap(icpmi_ctx* c, T** p, size_t* cap, size_t need, bool* fresh =
 
 unsigned sg_queue_cap(int64_t m) { const int64_t waves = (m + SGQ - 1) / SGQ; return (unsigned)(((waves + SG_NQ - 1) / SG_NQ) * SGQ); }
 
-void sg_launch_search(icpmi_ctx* c, SelfGridCtx* sg, const SgGrid& g, int k, int64_t m, int* d_sidx, float* d_d2, unsigned long long* sq_mapped, int diag)
+void sg_launch_search(icpmi_ctx* c, SelfGridCtx* sg, const SgGrid& g, int k, int64_t m, int* d_sidx, float* d_d2, unsigned long long* sq_mapped, int diag,
+                      const unsigned char* qsel = nullptr, const unsigned* wlist = nullptr, int64_t n_sel = 0)
 {
-    const unsigned g1 = (unsigned)((m + SGQ - 1) / SGQ), qcap = sg_queue_cap(m);
+    unsigned g1 = (unsigned)((m + SGQ - 1) / SGQ);
+    const unsigned qcap = sg_queue_cap(m);
+    if (wlist) g1 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(g1, n_sel)); // (at most one group per selected query; the kernel reads the real count)
     hipLaunchKernelGGL(sg_cell_kernel, dim3(g1), dim3(64), 0, c->stream, g, (const float4*)c->d_map_sorted, (const unsigned*)sg->d_tstart,
                        (const unsigned*)sg->d_tbid, (const unsigned*)sg->d_f, (const unsigned*)sg->d_inv, sg->d_state, k, (unsigned)m,
-                       m < (1ll << 24) ? 1 : 0, d_sidx, d_d2, sg->d_queue, qcap, sq_mapped);
+                       m < (1ll << 24) ? 1 : 0, d_sidx, d_d2, sg->d_queue, qcap, sq_mapped, qsel, wlist);
     hipLaunchKernelGGL(sg_level_kernel, dim3(8192), dim3(64), 0, c->stream, g, (const float4*)c->d_map_sorted, (const unsigned*)sg->d_tstart,
                        (const unsigned*)sg->d_tbid, (const unsigned*)sg->d_f, (const unsigned*)sg->d_inv, sg->d_state, k, d_sidx, d_d2,
                        (const uint2*)sg->d_queue, qcap, diag);
@@ -699,13 +827,17 @@ void selfgrid_destroy(icpmi_ctx* c)
     if (!sg) return;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dev_free(sg->d_tcnt); dev_free(sg->d_tstart); dev_free(sg->d_tbid); dev_free(sg->d_blist); dev_free(sg->d_f); dev_free(sg->d_coarse);
-    dev_free(sg->d_queue); dev_free(sg->d_inv); dev_free(sg->d_part); dev_free(sg->d_state);
+    dev_free(sg->d_queue); dev_free(sg->d_inv); dev_free(sg->d_part); dev_free(sg->d_state); dev_free(sg->d_dirty); dev_free(sg->d_sel);
     delete sg;
     c->sg = nullptr;
 }
 
-icpmi_status selfgrid_knn(icpmi_ctx* c, const float4* d_pts, int64_t m, int k, int* d_sidx, float* d_d2)
+// sub (may be null): d_pts[0 .. m_old) is the cloud of an earlier call whose k-th neighbour distances are in d_dk (original order): only the
+// appended points and the old points an appended point may have entered the neighbourhood of are searched; their rows of d_sidx / d_d2 are
+// written; sub->d_list (original indices, owned by the handle's grid) says which, sub->n_sel how many.
+icpmi_status selfgrid_knn(icpmi_ctx* c, const float4* d_pts, int64_t m, int k, int* d_sidx, float* d_d2, SelfGridSubset* sub)
 {
+    if (sub) { sub->d_list = nullptr; sub->n_sel = 0; }
     if (m <= 0) return ICPMI_OK;
     if (k < 1 || k > ICPMI_MAX_K) { c->last_error = "self knn: k must be in [1, 32]"; return ICPMI_ERR_INVALID_ARG; }
     if (m > 0x7fffff00ll) { c->last_error = "self knn: cloud too large"; return ICPMI_ERR_UNSUPPORTED; }
@@ -806,8 +938,56 @@ icpmi_status selfgrid_knn(icpmi_ctx* c, const float4* d_pts, int64_t m, int k, i
     }
     sg->cell = g.cell; sg->m = m; sg->k = k; ++sg->seq;
 
+    // ---- the subset of an appended cloud ----
+    const unsigned char* qsel = nullptr;
+    const unsigned* wlist = nullptr;
+    if (sub && sub->m_old > 0 && sub->m_old < m && sub->d_dk) {
+        SgLevels lv{};
+        unsigned long long bits_total = 0;
+        auto cells_at = [&](int l) { return (unsigned long long)(((g.na[0] - 1) >> l) + 1) * (unsigned long long)(((g.na[1] - 1) >> l) + 1) * (unsigned long long)(((g.na[2] - 1) >> l) + 1); };
+        int L = 0;
+        for (; L < 26; ++L) if (cells_at(L) == 1) { ++L; break; }
+        lv.L = L;
+        // fine levels of a huge sparse box are folded into the first level whose bitmaps fit 2^31 bits (256 MB): conservative, rarely needed
+        for (lv.lmin = 0; lv.lmin < L - 1; ++lv.lmin) {
+            bits_total = 0;
+            for (int l = lv.lmin; l < L; ++l) bits_total += cells_at(l);
+            if (bits_total <= (1ull << 31)) break;
+        }
+        bits_total = 0;
+        for (int l = lv.lmin; l < L; ++l) { lv.off[l] = bits_total; bits_total += cells_at(l); }
+        const size_t words = (size_t)((bits_total + 31) / 32) + 128; // + 64 words: the counter of the selection, + 64: the level table
+        // d_sel: [0, m) by sorted position, then (4-byte aligned) the list of the selected original indices
+        const size_t list_at = ((size_t)m + 3) / 4 * 4;
+        const size_t groups = (size_t)((m + SGQ - 1) / SGQ);
+        if (sg_cap(c, &sg->d_dirty, &sg->cap_dirty, words) != ICPMI_OK || sg_cap(c, &sg->d_sel, &sg->cap_sel, list_at + (size_t)4 * (m + groups + 2) + 64) != ICPMI_OK) return ICPMI_ERR_HIP;
+        static_assert(sizeof(SgLevels) <= 64 * sizeof(unsigned), "level table");
+        HIP_TRY(c, hipMemsetAsync(sg->d_dirty, 0, words * sizeof(unsigned), c->stream));
+        unsigned* n_sel = sg->d_dirty + (words - 128);
+        const SgLevels* d_lv = reinterpret_cast<const SgLevels*>(sg->d_dirty + (words - 64));
+        { const icpmi_status us = upload_small(c, sg->d_dirty + (words - 64), &lv, sizeof lv); if (us != ICPMI_OK) return us; }
+        unsigned* list = reinterpret_cast<unsigned*>(sg->d_sel + list_at);
+        const int64_t added = m - sub->m_old;
+        hipLaunchKernelGGL(sg_dirty_kernel, dim3((int)((added + 255) / 256), lv.L - lv.lmin), dim3(256), 0, c->stream, d_pts, sub->m_old, m, g, d_lv, sg->d_dirty);
+        hipLaunchKernelGGL(sg_affected_kernel, dim3(blocks256), dim3(256), 0, c->stream, (const float4*)c->d_map_sorted, m, (unsigned)sub->m_old, sub->d_dk, g, d_lv,
+                           (const unsigned*)sg->d_dirty, sg->d_sel, list, n_sel);
+        HIP_TRY(c, hipGetLastError());
+        unsigned* d_wl = list + m; // [0] = count (cleared here), then the groups
+        HIP_TRY(c, hipMemsetAsync(d_wl, 0, sizeof(unsigned), c->stream));
+        hipLaunchKernelGGL(sg_wavelist_kernel, dim3((int)((groups + 255) / 256)), dim3(256), 0, c->stream, (const unsigned char*)sg->d_sel, (unsigned)m, d_wl);
+        HIP_TRY(c, hipGetLastError());
+        qsel = sg->d_sel; wlist = d_wl;
+        sub->d_list = list;
+        {   // the size of the list: the normals are solved from it (one small read-back)
+            unsigned cnt = 0;
+            if (read_back(c, &cnt, n_sel, sizeof cnt) != ICPMI_OK) return ICPMI_ERR_HIP;
+            sub->n_sel = (int64_t)cnt;
+            if (diag) fprintf(stderr, "[icpmi self-knn] subset: %lld of %lld points searched (%lld appended), levels %d..%d, %llu bitmap bits\n", (long long)sub->n_sel,
+                              (long long)m, (long long)added, lv.lmin, lv.L - 1, bits_total);
+        }
+    }
     // ---- search ----
-    sg_launch_search(c, sg, g, k, m, d_sidx, d_d2, d_sq, diag);
+    sg_launch_search(c, sg, g, k, m, d_sidx, d_d2, d_sq, diag, qsel, wlist, sub ? sub->n_sel : 0);
     HIP_TRY(c, hipGetLastError());
     if (diag) {
         SgState hs{};
