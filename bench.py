@@ -278,6 +278,7 @@ def config5_stream(np, torch, pkg, dev, d_map, d_nrm, d_scans, chain, min_dist, 
             del _os.environ["ICPMI_COMM_LOOPBACK"]; del _os.environ["ICPMI_COMM_LOOPBACK_SHIFT"]
     elif comm is not None and comm[0] == "rccl":
         icp.commInit(comm[1], comm[2], comm[3])
+    icp.cellLogConfigure(cell_size)      # the epoch enqueues the binning of its merged set itself; stagedBinCells collects the table
     eye = np.eye(4, dtype=np.float32)
     # warm-up: one scan's registration + epoch on a throw-away handle state would grow the map; instead the first scan is registered once
     # untimed (graphs, allocations) and its epoch is left to the timed loop

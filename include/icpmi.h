@@ -466,6 +466,9 @@ icpmi_status icpmi_bin_cells(icpmi_handle h, const float* pts4, int64_t n, float
  *       position of the cell's run in the log.  Only this table crosses PCIe.  Once per epoch (a second call for the same epoch is an
  *       ICPMI_ERR_INVALID_ARG); capacity < *n_cells: ICPMI_ERR_INVALID_ARG with *n_cells set and nothing appended; more than 4096 cells
  *       touched by one epoch: ICPMI_ERR_UNSUPPORTED (fetch icpmi_staged_merged_points and bin on the host).
+ *   icpmi_cell_log_configure     cell_size > 0: from now on every epoch enqueues that binning itself, between its merge and its append (the kernels
+ *                                run in the shadow of the index insert); icpmi_staged_bin_cells with the same cell_size then only collects the
+ *                                table.  0: off (the default)
  *   icpmi_cell_log_read          `count` points of the log from `offset` (out4 == NULL: only *log_size, the points in the log)
  *   icpmi_cell_log_clear         forgets the log (CellManager::clearAllCells)
  *   icpmi_stage_discard          drops the scan staged by icpmi_register_prior (e.g. after its registration failed: the rank then
@@ -483,6 +486,7 @@ icpmi_status icpmi_staged_merge_allgather(icpmi_handle h, const float correction
 icpmi_status icpmi_staged_merged_points(icpmi_handle h, float* out4, int64_t capacity, int64_t* n);
 icpmi_status icpmi_staged_bin_cells(icpmi_handle h, float cell_size, int32_t* ijk3, int64_t* offsets, int64_t* counts, int64_t capacity,
                                     int64_t* n_cells);
+icpmi_status icpmi_cell_log_configure(icpmi_handle h, float cell_size);
 icpmi_status icpmi_cell_log_read(icpmi_handle h, int64_t offset, int64_t count, float* out4, int64_t* log_size);
 icpmi_status icpmi_cell_log_clear(icpmi_handle h);
 icpmi_status icpmi_stage_discard(icpmi_handle h);

@@ -140,6 +140,7 @@ SYMBOLS = [
     ("icpmi_staged_merge_allgather", C.c_int, [_P, _P, C.c_float, C.c_int32, _P, _P, _P, _P, C.c_int64, _P]),
     ("icpmi_staged_merged_points", C.c_int, [_P, _P, C.c_int64, _P]),
     ("icpmi_staged_bin_cells", C.c_int, [_P, C.c_float, _P, _P, _P, C.c_int64, _P]),
+    ("icpmi_cell_log_configure", C.c_int, [_P, C.c_float]),
     ("icpmi_cell_log_read", C.c_int, [_P, C.c_int64, C.c_int64, _P, _P]),
     ("icpmi_cell_log_clear", C.c_int, [_P]),
     ("icpmi_stage_discard", C.c_int, [_P]),

@@ -234,7 +234,7 @@ void icpmi_destroy(icpmi_handle c)
     dev_free(c->d_qsorted); dev_free(c->d_qindex); dev_free(c->d_qkeys); dev_free(c->d_qtile);
     dev_free(c->d_reading); dev_free(c->d_read_normals); dev_free(c->d_stage_in); dev_free(c->d_stage_n3);
     dev_free(c->d_match_pt); dev_free(c->d_lvl_tab); dev_free(c->d_raw); dev_free(c->d_raw_n3); dev_free(c->d_raw_s); dev_free(c->d_src); dev_free(c->d_alt_raw); dev_free(c->d_alt_n3);
-    dev_free(c->d_alt_s); dev_free(c->d_alt_src); dev_free(c->d_stage_s); dev_free(c->d_merge_send); dev_free(c->d_merge_recv); dev_free(c->d_merged); dev_free(c->d_cell_log); dev_free(c->d_raw_dk); dev_free(c->d_comm_cnt); dev_free(c->d_read_noise); dev_free(c->d_read_scalar); dev_free(c->d_map_pn);
+    dev_free(c->d_alt_s); dev_free(c->d_alt_src); dev_free(c->d_stage_s); dev_free(c->d_merge_send); dev_free(c->d_merge_recv); dev_free(c->d_merged); dev_free(c->d_cell_log); if (c->h_cells) (void)hipHostFree(c->h_cells); dev_free(c->d_raw_dk); dev_free(c->d_comm_cnt); dev_free(c->d_read_noise); dev_free(c->d_read_scalar); dev_free(c->d_map_pn);
     for (int k = 0; k < ICPMI_SCRATCH_SLOTS; ++k) dev_free(c->scratch[k]); dev_free(c->d_scan_map); dev_free(c->d_T16);
     dev_free(c->d_sidx); dev_free(c->d_d2); dev_free(c->d_hard); dev_free(c->d_selhist);
     dev_free(c->d_state);
@@ -816,6 +816,14 @@ icpmi_status icpmi_staged_bin_cells(icpmi_handle h, float cell_size, int32_t* ij
     CHECK_H(h);
     if (!(cell_size > 0.f) || capacity < 0) { h->last_error = "staged_bin_cells: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
     return ops_staged_bin_cells(h, cell_size, ijk3, offsets, counts, capacity, n_cells);
+}
+
+icpmi_status icpmi_cell_log_configure(icpmi_handle h, float cell_size)
+{
+    CHECK_H(h);
+    if (!(cell_size >= 0.f)) { h->last_error = "cell_log_configure: bad arguments"; return ICPMI_ERR_INVALID_ARG; }
+    h->cell_auto_size = cell_size;
+    return ICPMI_OK;
 }
 
 icpmi_status icpmi_cell_log_read(icpmi_handle h, int64_t offset, int64_t count, float* out4, int64_t* log_size)

@@ -17,6 +17,7 @@
 // only when somebody asks for them (icpmi_cell_log_read).  What crosses PCIe per epoch: 16 + 20 bytes per touched cell.
 #include "common.h"
 
+#include <algorithm>
 #include <vector>
 
 namespace {
@@ -137,14 +138,15 @@ __global__ __launch_bounds__(256) void cb_gather_kernel(const float4* __restrict
 
 } // namespace
 
-// include/icpmi.h: icpmi_staged_bin_cells
-icpmi_status ops_staged_bin_cells(icpmi_ctx* c, float cell_size, int32_t* ijk3, int64_t* offsets, int64_t* counts, int64_t capacity, int64_t* n_cells)
+// Everything up to the read-back, enqueued on the handle's stream: table, sort on `bits` key bits, the points into the log behind `base`, the
+// header + cells on their way into the pinned page h_cells.  *enq describes what was enqueued.
+static icpmi_status cells_enqueue(icpmi_ctx* c, float cell_size, int bits)
 {
-    if (n_cells) *n_cells = 0;
+    c->cells_enq_n = 0;
     const int64_t n = c->merged_last_n;
-    if (n == 0) return ICPMI_OK;
-    if (c->merged_binned) { c->last_error = "staged_bin_cells: the merged set of this epoch is in the cell log already"; return ICPMI_ERR_INVALID_ARG; }
+    if (n <= 0) return ICPMI_OK;
     if (n > 0x7ffffff0ll) { c->last_error = "staged_bin_cells: too many points"; return ICPMI_ERR_UNSUPPORTED; }
+    if (!c->h_cells) HIP_TRY(c, hipHostMalloc((void**)&c->h_cells, sizeof(CbHeader) + sizeof(CbCell) * CB_MAXCELLS, hipHostMallocDefault));
     const int blocks = (int)((n + 255) / 256);
     const size_t tab_words = (sizeof(CbSlot) * CB_SLOTS + sizeof(CbHeader) + sizeof(CbCell) * CB_MAXCELLS) / sizeof(unsigned) + CB_SLOTS + 16;
     unsigned* d_tab = scratch_get<unsigned>(c, 3, tab_words);
@@ -165,39 +167,56 @@ icpmi_status ops_staged_bin_cells(icpmi_ctx* c, float cell_size, int32_t* ijk3, 
     HIP_TRY(c, hipMemsetAsync(hdr, 0, sizeof(CbHeader), c->stream));
     hipLaunchKernelGGL(cb_key_kernel, dim3(blocks), dim3(256), 0, c->stream, (const float4*)c->d_merged, n, cell_size, tab, hdr, d_slot_of);
     hipLaunchKernelGGL(cb_rank_kernel, dim3(1), dim3(1024), 0, c->stream, (const CbSlot*)tab, hdr, cells, rank_of, (unsigned)n);
+    hipLaunchKernelGGL(cb_sortkey_kernel, dim3(blocks), dim3(256), 0, c->stream, (const unsigned*)d_slot_of, (const unsigned*)rank_of, n, d_keys, d_vals);
     HIP_TRY(c, hipGetLastError());
+    int half = 0;
+    s = radix_sort_pairs(c, d_keys, d_vals, n, bits, d_rs, &half);
+    if (s != ICPMI_OK) return s;
+    hipLaunchKernelGGL(cb_gather_kernel, dim3(blocks), dim3(256), 0, c->stream, (const float4*)c->d_merged, (const unsigned*)(d_vals + (half ? n : 0)), n,
+                       c->d_cell_log + base);
+    HIP_TRY(c, hipGetLastError());
+    // header + the cells a sort on `bits` bits can have ordered (more cells than that: the caller sorts again)
+    const size_t ncopy = std::min<size_t>((size_t)1 << bits, (size_t)CB_MAXCELLS);
+    HIP_TRY(c, hipMemcpyAsync(c->h_cells, hdr, sizeof(CbHeader) + sizeof(CbCell) * ncopy, hipMemcpyDeviceToHost, c->stream));
+    c->cells_enq_n = n; c->cells_enq_bits = bits; c->cells_enq_size = cell_size;
+    return ICPMI_OK;
+}
+
+// include/icpmi.h: icpmi_cell_log_configure -- from now on every epoch bins its merged set itself (ops.hip: ops_staged_merge_allgather calls this
+// between the merge and the append: the binning kernels run in the shadow of the index insert, the table rides on the epoch's last wait)
+icpmi_status ops_cells_enqueue_in_epoch(icpmi_ctx* c)
+{
+    if (!(c->cell_auto_size > 0.f)) return ICPMI_OK;
+    return cells_enqueue(c, c->cell_auto_size, c->cell_bits_hint > 0 ? c->cell_bits_hint : 6);
+}
+
+// include/icpmi.h: icpmi_staged_bin_cells
+icpmi_status ops_staged_bin_cells(icpmi_ctx* c, float cell_size, int32_t* ijk3, int64_t* offsets, int64_t* counts, int64_t capacity, int64_t* n_cells)
+{
+    if (n_cells) *n_cells = 0;
+    const int64_t n = c->merged_last_n;
+    if (n == 0) return ICPMI_OK;
+    if (c->merged_binned) { c->last_error = "staged_bin_cells: the merged set of this epoch is in the cell log already"; return ICPMI_ERR_INVALID_ARG; }
     // the sort needs the number of key bits before the host knows the number of cells: the handle's previous epoch is the guess (a mapper
-    // touches about the same number of cells epoch after epoch), checked against the header below
+    // touches about the same number of cells epoch after epoch), checked against the header
     int bits = c->cell_bits_hint > 0 ? c->cell_bits_hint : 6;
+    const int64_t base = c->cell_log_n;
     CbHeader h{};
-    std::vector<CbCell> host_cells;
     for (int attempt = 0;; ++attempt) {
-        hipLaunchKernelGGL(cb_sortkey_kernel, dim3(blocks), dim3(256), 0, c->stream, (const unsigned*)d_slot_of, (const unsigned*)rank_of, n, d_keys, d_vals);
-        int half = 0;
-        s = radix_sort_pairs(c, d_keys, d_vals, n, bits, d_rs, &half);
-        if (s != ICPMI_OK) return s;
-        hipLaunchKernelGGL(cb_gather_kernel, dim3(blocks), dim3(256), 0, c->stream, (const float4*)c->d_merged, (const unsigned*)(d_vals + (half ? n : 0)), n,
-                           c->d_cell_log + base);
-        HIP_TRY(c, hipGetLastError());
-        if (attempt == 0) { // header + the first cells in one read-back (one stream wait); the rest, if any, in a second
-            constexpr unsigned FIRST = 200;
-            unsigned char buf[sizeof(CbHeader) + sizeof(CbCell) * FIRST];
-            if (read_back(c, buf, hdr, sizeof buf) != ICPMI_OK) return ICPMI_ERR_HIP;
-            memcpy(&h, buf, sizeof h);
-            if (h.bad) { c->last_error = "staged_bin_cells: a merged point is not finite or lies outside +-2^20 cells"; return ICPMI_ERR_INVALID_ARG; }
-            if (h.overflow || h.ncells > (unsigned)CB_MAXCELLS) {
-                c->last_error = "staged_bin_cells: more than 4096 cells touched by one epoch (bin icpmi_staged_merged_points on the host)";
-                return ICPMI_ERR_UNSUPPORTED;
-            }
-            host_cells.resize(h.ncells);
-            const unsigned got = h.ncells < FIRST ? h.ncells : FIRST;
-            if (got) memcpy(host_cells.data(), buf + sizeof(CbHeader), sizeof(CbCell) * got);
-            if (h.ncells > FIRST && read_back(c, host_cells.data() + FIRST, cells + FIRST, sizeof(CbCell) * (h.ncells - FIRST)) != ICPMI_OK) return ICPMI_ERR_HIP;
-        } else HIP_TRY(c, hipStreamSynchronize(c->stream));
+        const bool have = c->cells_enq_n == n && c->cells_enq_size == cell_size && (attempt > 0 || c->cells_enq_bits >= bits); // (attempt 0: what the epoch enqueued, if it did)
+        if (!have) { const icpmi_status s = cells_enqueue(c, cell_size, bits); if (s != ICPMI_OK) return s; }
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->cells_enq_n = 0;
+        memcpy(&h, c->h_cells, sizeof h);
+        if (h.bad) { c->last_error = "staged_bin_cells: a merged point is not finite or lies outside +-2^20 cells"; return ICPMI_ERR_INVALID_ARG; }
+        if (h.overflow || h.ncells > (unsigned)CB_MAXCELLS) {
+            c->last_error = "staged_bin_cells: more than 4096 cells touched by one epoch (bin icpmi_staged_merged_points on the host)";
+            return ICPMI_ERR_UNSUPPORTED;
+        }
         int need = 6;
         while ((1u << need) < h.ncells) need += 6;
         c->cell_bits_hint = need;
-        if (need <= bits) break;
+        if (need <= (have ? c->cells_enq_bits : bits) || attempt > 0) break;
         bits = need; // the guess was too small: ranks above 2^bits were not ordered -- once more with the bits the header asks for
     }
     if (n_cells) *n_cells = (int64_t)h.ncells;
@@ -205,6 +224,7 @@ icpmi_status ops_staged_bin_cells(icpmi_ctx* c, float cell_size, int32_t* ijk3, 
         c->last_error = "staged_bin_cells: capacity smaller than the number of cells";
         return ICPMI_ERR_INVALID_ARG;
     }
+    const CbCell* host_cells = reinterpret_cast<const CbCell*>(c->h_cells + sizeof(CbHeader));
     for (unsigned r = 0; r < h.ncells; ++r) {
         if (ijk3) { ijk3[3 * r] = host_cells[r].i; ijk3[3 * r + 1] = host_cells[r].j; ijk3[3 * r + 2] = host_cells[r].k; }
         if (offsets) offsets[r] = base + (int64_t)host_cells[r].offset;

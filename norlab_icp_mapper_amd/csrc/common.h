@@ -586,6 +586,9 @@ struct icpmi_ctx {
     long normals_incremental = 0, normals_full = 0; int64_t normals_last_searched = 0;   // diagnostics (icpmi_debug_counters 20 / 21 / 22)
     bool merged_binned = false;       // the merged set of the last epoch is in the log already
     int cell_bits_hint = 0;           // key bits the previous epoch's cell count needed (the sort is enqueued before the count is known)
+    float cell_auto_size = 0.f;       // > 0 (icpmi_cell_log_configure): every epoch enqueues the binning of its merged set itself, behind the merge
+    unsigned char* h_cells = nullptr; // pinned: header + cell table of the binning in flight
+    int64_t cells_enq_n = 0; int cells_enq_bits = 0; float cells_enq_size = 0.f;   // what is enqueued and not yet collected (n == 0: nothing)
     struct SelfGridCtx* sg = nullptr; // sparse block grid of the self k-NN (selfgrid.hip): tables, work lists and the tuning state of the handle's previous build
     bool counted = false;             // created through icpmi_create (not a private handle): counts towards the allocation cache's lifetime (api.hip)
 };
@@ -924,6 +927,7 @@ icpmi_status ops_staged_merged_points(icpmi_ctx* c, float* out4, int64_t capacit
 icpmi_status ops_staged_bin_cells(icpmi_ctx* c, float cell_size, int32_t* ijk3, int64_t* offsets, int64_t* counts, int64_t capacity, int64_t* n_cells);
 icpmi_status ops_cell_log_read(icpmi_ctx* c, int64_t offset, int64_t count, float* out4, int64_t* log_size);
 icpmi_status ops_cell_log_clear(icpmi_ctx* c);
+icpmi_status ops_cells_enqueue_in_epoch(icpmi_ctx* c);
 icpmi_status ssn_debug_minstd(icpmi_ctx* c, unsigned seed, unsigned n, unsigned* out);
 icpmi_status ssn_sample_dev(icpmi_ctx* c, const float4* d_in, int64_t n, float ratio, int knn, float max_box, unsigned seed, int* d_order_out,
                             float* d_normals_out, int64_t* n_out, int method = 0, float* d_mean_out = nullptr, int* d_mstart_out = nullptr,

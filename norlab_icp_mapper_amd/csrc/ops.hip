@@ -2019,6 +2019,7 @@ icpmi_status ops_staged_merge_allgather(icpmi_ctx* c, const float correction[16]
     if (new_m) *new_m = c->m > 0 ? c->m_raw : 0;
     c->merged_last_n = 0;
     c->merged_binned = false;
+    c->cells_enq_n = 0;
     // ICPMI_EPOCH_TIMING=1: wall time of the epoch's stages with a stream wait behind each, on stderr (diagnostic; perturbs the overlap)
     static const bool ep_timing = [] { const char* e = getenv("ICPMI_EPOCH_TIMING"); return e && atoi(e) != 0; }();
     auto ep_tick = [&](const char* what) {
@@ -2131,6 +2132,12 @@ icpmi_status ops_staged_merge_allgather(icpmi_ctx* c, const float correction[16]
     s = merge_greedy(c, c->d_merge_recv, counts, maxc, min_dist, &acc);
     if (s != ICPMI_OK) return s;
     }
+    // ---- r6: the merged set into the mapper's cells (cells.hip), when the handle was told to (icpmi_cell_log_configure): enqueued here, in
+    //      front of the append, the table collected by icpmi_staged_bin_cells behind the epoch's last wait
+    c->merged_last_n = acc;
+    c->cells_enq_n = 0;
+    { const icpmi_status cs = ops_cells_enqueue_in_epoch(c); if (cs != ICPMI_OK) { c->merged_last_n = 0; return cs; } }
+    c->merged_last_n = 0;
     // ---- every replica appends the same set (all points kept: the distance tests are done), normals, index
     int64_t app = 0, m1 = 0;
     icpmi_status s = ops_map_update_dev(c, c->d_merged, acc, nullptr, 0.f, normals_knn, nullptr, &app, &m1);

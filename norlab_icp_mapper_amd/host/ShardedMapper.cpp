@@ -54,6 +54,7 @@ ShardedMapper::ShardedMapper(const yaml::Node& icpNode, float minDistNewPoint, i
 {
     if (minDistNewPoint < 0.f) throw InvalidParameter("ShardedMapper: minDistNewPoint must be >= 0");
     if (icpNode) icp.loadFromYamlNode(icpNode);
+    GpuICPSequence::check(icp.handle(), icpmi_cell_log_configure(icp.handle(), Map::CELL_SIZE)); // every epoch bins its merged set on the device, behind the merge
     if (icp.hasReadingFilters() || icp.hasReferenceFilters())
         throw InvalidParameter("ShardedMapper: the staged epoch does not run DataPointsFilters inside the ICP chain; filter the scans first");
 }

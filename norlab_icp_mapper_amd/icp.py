@@ -713,6 +713,10 @@ class ICPSequence:
         self._check(self._lib.icpmi_staged_bin_cells(self._h, cell_size, ijk.ctypes.data, off.ctypes.data, cnt.ctypes.data, int(capacity), C.byref(nc)))
         return ijk[:nc.value].copy(), off[:nc.value].copy(), cnt[:nc.value].copy()
 
+    def cellLogConfigure(self, cell_size):
+        """icpmi_cell_log_configure: cell_size > 0 -- every epoch enqueues the binning of its merged set itself; stagedBinCells(cell_size) collects it."""
+        self._check(self._lib.icpmi_cell_log_configure(self._h, float(cell_size)))
+
     def cellLogSize(self):
         n = C.c_int64(0)
         self._check(self._lib.icpmi_cell_log_read(self._h, 0, 0, None, C.byref(n)))

@@ -45,9 +45,12 @@ def _one_epoch(icp, sc):
     return merged
 
 
+@pytest.mark.parametrize("in_epoch", [False, True])
 @pytest.mark.parametrize("cell_size,ranks,shift", [(20.0, 2, 0.5), (5.0, 4, 0.45), (3.0, 3, 0.6)])
-def test_cells_of_an_epoch_match_the_reference_loop(amd, mid_scene, monkeypatch, cell_size, ranks, shift):
+def test_cells_of_an_epoch_match_the_reference_loop(amd, mid_scene, monkeypatch, cell_size, ranks, shift, in_epoch):
     icp = _epoch(amd, mid_scene, monkeypatch, ranks, shift)
+    if in_epoch:
+        icp.cellLogConfigure(cell_size)           # the epoch enqueues the binning behind its merge; stagedBinCells collects the table
     base = 0
     for epoch in range(3):                        # the log grows epoch after epoch; later epochs add little (the map has the points)
         merged = _one_epoch(icp, mid_scene)
