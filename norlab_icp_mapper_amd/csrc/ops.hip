@@ -1030,7 +1030,7 @@ static icpmi_status surface_normals_dev(icpmi_ctx* c, const float4* d_pts, int64
     if (track && ensure_cap_keep(c, &c->d_raw_dk, &c->cap_raw_dk, (size_t)m + 1, incremental ? (size_t)m_old : 0) != ICPMI_OK) return ICPMI_ERR_HIP;
     SelfGridSubset sub;
     sub.m_old = incremental ? m_old : 0; sub.d_dk = c->d_raw_dk;
-    s = selfgrid_knn(tc, d_pts, m, knn, tc->d_sidx, tc->d_d2, incremental ? &sub : nullptr);
+    s = selfgrid_knn(tc, d_pts, m, knn, tc->d_sidx, tc->d_d2, track ? &sub : nullptr); // (tracked: the grid keeps its sorted copy for the next append)
     if (s != ICPMI_OK) { c->last_error = tc->last_error; return s; }
     const unsigned* list = incremental ? sub.d_list : nullptr;
     const int64_t todo = incremental ? sub.n_sel : m;

@@ -42,6 +42,7 @@ struct SelfGridCtx {
     unsigned* d_inv = nullptr; size_t cap_inv = 0;                            // original index -> sorted position
     float* d_part = nullptr; size_t cap_part = 0;                             // bounding-box partials
     unsigned* d_dirty = nullptr; size_t cap_dirty = 0;                        // subset search: bitmaps of the cells appended points fell into, per level
+    float4* d_prev = nullptr; size_t cap_prev = 0; int64_t prev_m = 0;       // the sorted copy of the last TRACKED build (+ room for the next append): the next build of the grown cloud reads it instead of the cloud in the caller's order -- nearly sorted input, coalesced scatter
     unsigned char* d_sel = nullptr; size_t cap_sel = 0;                       // ... selected queries by sorted position (m) and by original index (m)
     struct SgState* d_state = nullptr;
     // tuning state: the edge of the previous build and what its points saw (size-biased A-cell occupancy, delivered through the mapped page)
@@ -234,8 +235,9 @@ __global__ __launch_bounds__(256) void sg_key_kernel(const float4* __restrict__ 
 }
 
 // points into block order (any order inside a block): cursor scatter on T (tstart + 1: common.h, device_exclusive_scan_cursor)
+// keep_w: the input already carries the original index in w (the previous build's sorted copy + the appended tail) instead of being in original order
 __global__ __launch_bounds__(256) void sg_scatter_kernel(const float4* __restrict__ pts, int64_t m, const unsigned* __restrict__ keys,
-                                                         unsigned* __restrict__ cursor, float4* __restrict__ out)
+                                                         unsigned* __restrict__ cursor, float4* __restrict__ out, int keep_w)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool valid = i < m;
@@ -246,7 +248,16 @@ __global__ __launch_bounds__(256) void sg_scatter_kernel(const float4* __restric
     if (r.head) base = atomicAdd(&cursor[hb], (unsigned)r.len);
     base = (unsigned)__shfl((int)base, r.head_lane, 64);
     if (!valid) return;
-    out[base + (unsigned)r.rank] = make_float4(p.x, p.y, p.z, __uint_as_float((unsigned)i));
+    out[base + (unsigned)r.rank] = make_float4(p.x, p.y, p.z, keep_w ? p.w : __uint_as_float((unsigned)i));
+}
+
+// the appended points behind the previous build's sorted copy, w = original index
+__global__ __launch_bounds__(256) void sg_tail_kernel(const float4* __restrict__ pts, int64_t m_old, int64_t m, float4* __restrict__ prev)
+{
+    const int64_t i = m_old + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const float4 p = pts[i];
+    prev[i] = make_float4(p.x, p.y, p.z, __uint_as_float((unsigned)i));
 }
 
 // one wave per occupied block: its points into the Morton order of their A-cells (a counting sort in LDS; the order inside a cell is whatever
@@ -827,7 +838,7 @@ void selfgrid_destroy(icpmi_ctx* c)
     if (!sg) return;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dev_free(sg->d_tcnt); dev_free(sg->d_tstart); dev_free(sg->d_tbid); dev_free(sg->d_blist); dev_free(sg->d_f); dev_free(sg->d_coarse);
-    dev_free(sg->d_queue); dev_free(sg->d_inv); dev_free(sg->d_part); dev_free(sg->d_state); dev_free(sg->d_dirty); dev_free(sg->d_sel);
+    dev_free(sg->d_queue); dev_free(sg->d_inv); dev_free(sg->d_part); dev_free(sg->d_state); dev_free(sg->d_dirty); dev_free(sg->d_sel); dev_free(sg->d_prev);
     delete sg;
     c->sg = nullptr;
 }
@@ -844,11 +855,29 @@ icpmi_status selfgrid_knn(icpmi_ctx* c, const float4* d_pts, int64_t m, int k, i
     if (!c->sg) { c->sg = new (std::nothrow) SelfGridCtx(); if (!c->sg) { c->last_error = "out of host memory"; return ICPMI_ERR_HIP; } }
     SelfGridCtx* sg = c->sg;
     if (!sg->d_state) HIP_TRY(c, dev_malloc((void**)&sg->d_state, sizeof(SgState)));
+    // ---- r6: an appended cloud whose previous sorted copy this grid still holds is built from THAT copy + the appended tail: the points arrive
+    //      nearly in the order they leave in, so the counting sort's atomics and its scatter are coalesced (10 M points: sg_key 0.47 -> , sg_scatter 0.68 -> ms)
+    const float4* src = d_pts;
+    int keep_w = 0;
+    if (sub && sub->m_old > 0 && sub->m_old < m && sg->d_prev && sg->prev_m == sub->m_old) {
+        if ((size_t)m + 16 > sg->cap_prev) { // grow, keeping the sorted copy
+            const size_t want = (size_t)m + (size_t)m / 4 + 64;
+            float4* q = nullptr;
+            HIP_TRY(c, dev_malloc((void**)&q, want * sizeof(float4)));
+            HIP_TRY(c, hipMemcpyAsync(q, sg->d_prev, (size_t)sub->m_old * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, dev_free(sg->d_prev));
+            sg->d_prev = q; sg->cap_prev = want;
+        }
+        hipLaunchKernelGGL(sg_tail_kernel, dim3((int)((m - sub->m_old + 255) / 256)), dim3(256), 0, c->stream, d_pts, sub->m_old, m, sg->d_prev);
+        src = sg->d_prev; keep_w = 1;
+    }
+    sg->prev_m = 0; // (valid again once this build has left its copy behind)
     // ---- bounding box (one read-back: the table sizes depend on it) ----
     const int rblocks = (int)std::min<int64_t>((m + SG_RB - 1) / SG_RB, 256);
     if (sg_cap(c, &sg->d_part, &sg->cap_part, (size_t)rblocks * 6) != ICPMI_OK) return ICPMI_ERR_HIP;
     hipLaunchKernelGGL(sg_reset_kernel, dim3(1), dim3(64), 0, c->stream, sg->d_state);
-    hipLaunchKernelGGL(sg_bbox_kernel, dim3(rblocks), dim3(SG_RB), 0, c->stream, d_pts, m, sg->d_part, sg->d_state);
+    hipLaunchKernelGGL(sg_bbox_kernel, dim3(rblocks), dim3(SG_RB), 0, c->stream, src, m, sg->d_part, sg->d_state);
     HIP_TRY(c, hipGetLastError());
     std::vector<float> part((size_t)rblocks * 6);
     unsigned bad = 0;
@@ -918,11 +947,11 @@ icpmi_status selfgrid_knn(icpmi_ctx* c, const float4* d_pts, int64_t m, int k, i
             ensure_cap(c, &c->d_keys, &c->cap_keys, (size_t)m) != ICPMI_OK || ensure_cap(c, &c->d_map_sorted, &c->cap_map, (size_t)m + 16) != ICPMI_OK)
             return ICPMI_ERR_HIP;
         if (trial > 0) hipLaunchKernelGGL(sg_reset_kernel, dim3(1), dim3(64), 0, c->stream, sg->d_state);
-        hipLaunchKernelGGL(sg_key_kernel, dim3(blocks256), dim3(256), 0, c->stream, d_pts, m, g, c->d_keys, sg->d_tcnt, sg->d_tbid, sg->d_blist, sg->d_state);
+        hipLaunchKernelGGL(sg_key_kernel, dim3(blocks256), dim3(256), 0, c->stream, src, m, g, c->d_keys, sg->d_tcnt, sg->d_tbid, sg->d_blist, sg->d_state);
         HIP_TRY(c, hipGetLastError());
         if (device_exclusive_scan_cursor(c, sg->d_tcnt, sg->d_tstart, g.tsize, (unsigned)m, true) != ICPMI_OK) return ICPMI_ERR_HIP;
         sg->tcnt_clean = true;
-        hipLaunchKernelGGL(sg_scatter_kernel, dim3(blocks256), dim3(256), 0, c->stream, d_pts, m, (const unsigned*)c->d_keys, sg->d_tstart + 1, sg->d_coarse);
+        hipLaunchKernelGGL(sg_scatter_kernel, dim3(blocks256), dim3(256), 0, c->stream, src, m, (const unsigned*)c->d_keys, sg->d_tstart + 1, sg->d_coarse, keep_w);
         hipLaunchKernelGGL(sg_block_sort_kernel, dim3(std::max(1u, std::min(blocks_max, 8192u))), dim3(64), 0, c->stream, (const float4*)sg->d_coarse,
                            c->d_map_sorted, g, (const unsigned*)sg->d_tstart, (const uint4*)sg->d_blist, sg->d_f, sg->d_inv, sg->d_state);
         HIP_TRY(c, hipGetLastError());
@@ -937,6 +966,11 @@ icpmi_status selfgrid_knn(icpmi_ctx* c, const float4* d_pts, int64_t m, int k, i
         cell = next;
     }
     sg->cell = g.cell; sg->m = m; sg->k = k; ++sg->seq;
+    if (sub) { // a tracked cloud (the resident map of append-only updates): leave the sorted copy behind for the build of the next append
+        if (sg_cap(c, &sg->d_prev, &sg->cap_prev, (size_t)m + 16) != ICPMI_OK) return ICPMI_ERR_HIP; // (a reallocation drops the old content: it is rewritten below)
+        HIP_TRY(c, hipMemcpyAsync(sg->d_prev, c->d_map_sorted, (size_t)m * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+        sg->prev_m = m;
+    }
 
     // ---- the subset of an appended cloud ----
     const unsigned char* qsel = nullptr;

@@ -158,3 +158,21 @@ def test_differential_and_bound_checkers_match_scipy(amd, small_scene):
     icp.setMap(sc["map"], sc["normals"])
     icp(sc["scan"])
     assert icp.stats.iterations == 9
+
+
+def test_vanishing_total_weight_is_an_error_on_the_device(amd, oracle):
+    """oracle/DEVIATIONS.md D8 (found by the r6 soak, seed 197 case 1700): a hard-rejecting M-estimator far from the map leaves four pairs that weigh
+    2e-34 ... 7e-19.  The oracle's double sums (and upstream's floats) carry on with the rounding noise of a vanishing H; the device's fixed-point pair
+    sums resolve 2^-40, see a total weight of zero and report the registration as "transformation is not a number".  Pinned here so that the behaviour
+    cannot change unnoticed: the total weight is what it is, the oracle returns a pose, the device raises."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "tools", "data", "soak_case_197_1700.npz"))
+    kw = dict(minimizer=1, knn=10, max_dist=math.inf, outliers=[(4, 0.9), (7, 0.3, 1, 0.0)], max_iterations=1, use_differential=0)
+    o = oracle.OracleICP(oracle.make_config(nthreads=4, **kw)); o.setMap(z["mp"], z["nrm"])
+    err, T = o(z["rd"], None)
+    total_weight = o.stats.weighted_point_used_ratio * 10 * z["rd"].shape[0]
+    assert err == 0 and o.stats.pairs == 4 and 0 < total_weight < 1e-15 and np.isfinite(T).all()
+    icp = amd.ICPSequence(**kw)
+    assert icp.setMap(z["mp"], z["nrm"])
+    with pytest.raises(amd.ConvergenceError, match="not a number"):
+        icp(z["rd"])
+    assert icp.stats.pairs == 4
