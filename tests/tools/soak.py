@@ -83,7 +83,7 @@ for case in range(cases):
             # every pair weighted down to nothing (a hard-rejecting M-estimator far from the map: total weight 7e-19 in seed 197 case 1700): the device's
             # fixed-point pair sums resolve 2^-40, see sum w = 0 and report "transformation is not a number" where the oracle's doubles carry on with the
             # rounding noise of a vanishing H -- ill-posed on every side (oracle/DEVIATIONS.md D8), not comparable
-            if err == 0 and o.stats.weighted_point_used_ratio * k * n < 1e-9:
+            if err == 0 and err_gpu != 0 and icp.stats.pairs > 0 and icp.stats.weighted_point_used_ratio * k * n < 1e-9:   # (the device's statistics of the iteration it gave up in)
                 icp.close(); checked += 1; continue
             assert (err != 0) == (err_gpu != 0), ("error mismatch", err, err_gpu, kw, m, n)
             # fewer than six surviving pairs (a hard-rejecting M-estimator on a seven-point map: tests/tools/data/soak_fail_420.npz,
