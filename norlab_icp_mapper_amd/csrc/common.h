@@ -847,6 +847,7 @@ struct SortHead {
 // ---- cross-TU host entry points ---------------------------------------------------------------
 // keep_prefix: the first keep_prefix points of d_pts are the cloud of the previous build, unchanged and in the same order (an append)
 icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float* d_normals3, int64_t keep_prefix = 0);
+icpmi_status map_patch_normals(icpmi_ctx* c, const unsigned* d_list, int64_t n_list, const float4* d_raw, const float* d_normals3);
 icpmi_status upload_level_table(icpmi_ctx* c); // c->levels -> c->d_lvl_tab (the table the NN kernels copy to LDS)
 icpmi_status device_exclusive_scan(icpmi_ctx* c, unsigned* data, int n, unsigned total);
 icpmi_status device_exclusive_scan_io(icpmi_ctx* c, const unsigned* in, unsigned* out, int n, unsigned total); // in == out allowed

@@ -1045,6 +1045,41 @@ static icpmi_status map_insert(icpmi_ctx* c, const float4* d_pts, int64_t m0, in
     return ICPMI_OK;
 }
 
+// r6: the normals of a FEW resident points changed (ops.hip: surface_normals_dev after an append) -- their sorted copies are found through the
+// point's level-0 cell (the key of key_kernel from the raw coordinates and the index's mean) and rewritten, instead of gathering the whole field again
+__global__ __launch_bounds__(256) void patch_normals_kernel(const unsigned* __restrict__ list, int64_t n_list, const float4* __restrict__ raw,
+                                                            float mx, float my, float mz, GridParams g, const unsigned* __restrict__ cs,
+                                                            const float4* __restrict__ pts0, const float* __restrict__ normals3,
+                                                            float4* __restrict__ nrm, float4* __restrict__ pn)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_list) return;
+    const unsigned orig = list[t];
+    const float4 p = raw[orig];
+    const int cx = cell_of(p.x - mx, g.ox, g.inv_cell, g.nx), cy = cell_of(p.y - my, g.oy, g.inv_cell, g.ny), cz = cell_of(p.z - mz, g.oz, g.inv_cell, g.nz);
+    const unsigned key = (unsigned)((cz * g.ny + cy) * g.nx + cx);
+    const unsigned e = cs[key + 1];
+    for (unsigned np = cs[key]; np < e; ++np)
+        if (__float_as_uint(pts0[np].w) == orig) {
+            const float4 nn = make_float4(normals3[3 * (size_t)orig], normals3[3 * (size_t)orig + 1], normals3[3 * (size_t)orig + 2], 0.f);
+            nrm[np] = nn;
+            if (pn) pn[2 * (size_t)np + 1] = nn;
+            return;
+        }
+    // (not reached: the key is the build's own -- tests/test_gpu_incremental_normals.py registers against the patched index and against a fresh one)
+}
+
+icpmi_status map_patch_normals(icpmi_ctx* c, const unsigned* d_list, int64_t n_list, const float4* d_raw, const float* d_normals3)
+{
+    if (n_list <= 0 || !c->d_normals_sorted || c->m <= 0) return ICPMI_OK;
+    const bool with_pn = c->d_map_pn != nullptr && !c->single_level && c->keep_raw;
+    hipLaunchKernelGGL(patch_normals_kernel, dim3((int)((n_list + 255) / 256)), dim3(256), 0, c->stream, d_list, n_list, d_raw, c->mean[0], c->mean[1], c->mean[2],
+                       c->levels.g[0], (const unsigned*)c->d_cell_start, (const float4*)c->d_map_sorted, d_normals3, c->d_normals_sorted,
+                       with_pn ? c->d_map_pn : (float4*)nullptr);
+    HIP_TRY(c, hipGetLastError());
+    return ICPMI_OK;
+}
+
 icpmi_status map_build(icpmi_ctx* c, const float4* d_pts, int64_t m, const float* d_normals3, int64_t keep_prefix)
 {
     ++c->map_version;

@@ -1012,8 +1012,11 @@ icpmi_status ops_dynamic_points_update(icpmi_ctx* c, const icpmi_dynpts_params* 
 // normals and c->d_raw_dk the d^2 of every point's k-th neighbour: only the appended points and the old points an appended point can have
 // entered the neighbourhood of are searched and solved again -- the other normals are what a pass over the whole cloud would write, bit for
 // bit (same neighbours, same coordinates, same sums).  Reference semantics unchanged: Map.cpp:524 applies the filter to the whole map.
-static icpmi_status surface_normals_dev(icpmi_ctx* c, const float4* d_pts, int64_t m, int knn, float* d_normals3, int64_t m_old = 0, bool remember = false)
+static icpmi_status surface_normals_dev(icpmi_ctx* c, const float4* d_pts, int64_t m, int knn, float* d_normals3, int64_t m_old = 0, bool remember = false,
+                                        const unsigned** changed_list = nullptr, int64_t* changed_n = nullptr)
 {
+    if (changed_list) *changed_list = nullptr;
+    if (changed_n) *changed_n = -1; // (-1: the whole field)
     TempCtx t;
     icpmi_status s = make_temp(c, t);
     if (s != ICPMI_OK) return s;
@@ -1034,6 +1037,7 @@ static icpmi_status surface_normals_dev(icpmi_ctx* c, const float4* d_pts, int64
     if (s != ICPMI_OK) { c->last_error = tc->last_error; return s; }
     const unsigned* list = incremental ? sub.d_list : nullptr;
     const int64_t todo = incremental ? sub.n_sel : m;
+    if (incremental && changed_list && changed_n) { *changed_list = list; *changed_n = todo; } // (valid until the grid's next search)
     // rows of d_sidx follow the query order = the caller's order, so the normals land in place
     if (todo > 0) launch_normals(tc->stream, tc->d_map_sorted, tc->d_sidx, todo, knn, d_normals3, (float*)nullptr, c->cfg.is_2d, nullptr, nullptr, nullptr, list);
     if (track) {
@@ -1132,12 +1136,17 @@ icpmi_status ops_map_update_dev(icpmi_ctx* c, const float4* d_scan, int64_t n, c
             if (e == hipSuccess) e = hipGetLastError();
         }
         // SurfaceNormalDataPointsFilter over the grown map (Map.cpp:524 with examples/config.yaml:26-27)
-        if (s == ICPMI_OK && e == hipSuccess && normals_knn > 0) s = surface_normals_dev(c, c->d_raw, m1, normals_knn, c->d_raw_n3, m0, true); // (m0: an append -- only what it changed)
+        const unsigned* changed = nullptr; int64_t n_changed = -1;
+        if (s == ICPMI_OK && e == hipSuccess && normals_knn > 0) s = surface_normals_dev(c, c->d_raw, m1, normals_knn, c->d_raw_n3, m0, true, &changed, &n_changed); // (m0: an append -- only what it changed)
         // icp.setMap(localPointCloud) (Map.cpp:528): rebuild the index from the resident copy
         // (an append: the first m0 resident points are the cloud the index was built from -- map_insert where it applies)
-        c->ins_normals_changed = normals_knn > 0 || !c->has_normals; // (the whole field was recomputed above / had no sorted copy)
+        // (the whole field was recomputed above / had no sorted copy: the insert gathers every normal again; r6: a FEW were recomputed -- the sorted
+        //  normals move along with their points and the changed ones are patched in afterwards, map_build.hip: map_patch_normals)
+        c->ins_normals_changed = (normals_knn > 0 && n_changed < 0) || !c->has_normals;
+        const bool patch = normals_knn > 0 && n_changed >= 0 && !c->ins_normals_changed;
         if (s == ICPMI_OK && e == hipSuccess) s = map_build(c, c->d_raw, m1, want_n ? c->d_raw_n3 : nullptr, (m0 > 0 && c->m == m0) ? m0 : 0);
         c->ins_normals_changed = false;
+        if (s == ICPMI_OK && e == hipSuccess && patch) s = map_patch_normals(c, changed, n_changed, c->d_raw, c->d_raw_n3);
         if (s == ICPMI_OK) { if (appended) *appended = count; if (new_m) *new_m = m1; }
     }
     if (s != ICPMI_OK) return s;

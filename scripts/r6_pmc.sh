@@ -5,7 +5,7 @@ cd "$GRAFT_REPO_ROOT"; R=$GRAFT_REPO_ROOT/gpurun_out/r6pmc; rm -rf $R; mkdir -p 
 cd /tmp && export TMPDIR=/tmp
 pmc() { local name=$1; shift; local ctr=(); while [ "$1" != "--" ]; do ctr+=("$1"); shift; done; shift
   timeout 600 rocprofv3 --pmc "${ctr[@]}" --output-format csv -d $R/$name -- "$@" > /dev/null 2>$R/$(echo $name | tr / _).err; }
-B="python $GRAFT_REPO_ROOT/bench.py --no-cpu --no-extras --steps 3 --warmup 1"
+B="python $GRAFT_REPO_ROOT/bench.py --no-cpu --no-extras --steps 3 --warmup 1 --min-seconds 0"
 pmc calib/fetch FETCH_SIZE -- $GRAFT_REPO_ROOT/scripts/pmc_calib.bin
 pmc calib/write WRITE_SIZE -- $GRAFT_REPO_ROOT/scripts/pmc_calib.bin
 for wl in "p2p:--chain p2p" "p2plane:--chain p2plane" "knn6:--chain docs_knn6" "map10M:--chain p2p --map-points 10000000 --scale 3.16" "batch8:--chain p2p --batch 8"; do
@@ -57,4 +57,5 @@ import bench
 out["kernel_sources_sha"] = bench.kernel_sources_sha()   # bench.py prints roofline.traffic only while this matches the tree it runs from
 json.dump(out, open("gpurun_out/r6pmc/nn_traffic.json", "w"), indent=1)
 PY
+find gpurun_out/r6pmc -name "*.csv" -delete; find gpurun_out/r6pmc -type d -empty -delete   # (the raw per-dispatch counter files: hundreds of MB; the summaries stay)
 du -sh gpurun_out/r6pmc

@@ -41,6 +41,12 @@ def test_appends_recompute_only_what_changed_dense_scene(amd, mid_scene, knn):
         assert check_against_a_fresh_pass(amd, icp, knn) == m
         c = icp.debugCounters()
         searched.append((int(c[20]), int(c[21]), int(c[22]), m))
+    # the registration index carries the same normals (changed ones patched into the sorted copy, the rest moved along with their points): a
+    # point-to-plane registration against it and against a fresh handle built from the downloaded map + normals are the same bits
+    pts, nrm = icp.getMap(with_normals=True)
+    fresh = amd.ICPSequence(minimizer=2, max_dist=2.0, outliers=[(4, 0.85)], max_iterations=10)
+    assert fresh.setMap(pts, nrm)
+    assert np.array_equal(icp(sc["scan"]), fresh(sc["scan"]))
     assert [s[1] for s in searched] == [1, 1, 1, 1]          # one pass over the whole map (the first), ...
     assert [s[0] for s in searched] == [0, 1, 2, 3]          # ... then the subset path
     assert all(s[2] < s[3] for s in searched[1:]), searched      # and it searched a part of the map only (this scan covers most of the room)
