@@ -99,3 +99,22 @@ def test_epoch_with_normals_and_a_rewritten_map_start_over(amd, mid_scene, monke
     check_against_a_fresh_pass(amd, icp, 10)
     c = icp.debugCounters()
     assert int(c[20]) == 2 and int(c[21]) == 2
+
+
+def test_planar_map_appends(amd):
+    """the mapper's is3D == false (z == 0 everywhere, 2 x 2 normals): the same subset path, the same bits as the whole pass"""
+    rng = np.random.default_rng(9)
+    def ring(n, r, jitter):
+        a = rng.uniform(0, 2 * np.pi, n)
+        xy = np.c_[r * np.cos(a), r * np.sin(a)] + rng.normal(0, jitter, (n, 2))
+        return cloud(np.c_[xy, np.zeros(n)])
+    icp = amd.ICPSequence(minimizer=1, max_dist=2.0, max_iterations=5, is_2d=1)
+    assert icp.setMap(ring(20000, 10.0, 0.02))
+    for r in (10.5, 6.0, 14.0):
+        app, m = icp.mapUpdatePointDistance(ring(3000, r, 0.05), 0.02, normals_knn=8)
+        assert app > 0
+        pts, nrm = icp.getMap(with_normals=True)
+        ref = amd.ICPSequence(minimizer=1, is_2d=1).surfaceNormals(pts, knn=8)
+        assert np.array_equal(nrm, ref) and (nrm[:, 2] == 0).all()
+    c = icp.debugCounters()
+    assert int(c[20]) == 2 and int(c[21]) == 1
