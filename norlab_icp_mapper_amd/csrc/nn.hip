@@ -388,7 +388,10 @@ __global__ __launch_bounds__(64 * NW) void nn1_wg_kernel(const float4* __restric
     constexpr int NT = 64 * NW, Q = 64;
     constexpr int NR = 3;                  // rows per lane in role 1b: rr = wave + NW sl
     constexpr int CAP = 16 * Q;            // pieces per pass (>= 9 Q: one piece per row always fits)
-    constexpr int PLB = 3;                 // log2 of the base piece length: 8 loads in flight per lane and piece
+#ifndef ICPMI_NN1_PLB
+#define ICPMI_NN1_PLB 4
+#endif
+    constexpr int PLB = ICPMI_NN1_PLB;     // log2 of the base piece length: 8 loads in flight per lane and piece (r6: 16 = two batches of eight per lane, so that a workgroup's ~300 pieces of 8 become <= 256 pieces and one round of phase 2: +1 %, A/B in profiles/r6_ab_nn1_plb.txt; 32: -3 %)
     const int n = ba.n[blockIdx.y];
     {
         const size_t qo = (size_t)blockIdx.y * (size_t)ba.qstride;
@@ -1054,7 +1057,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KMAX <= 8 ?
 {
     constexpr int NW = 4, NT = 64 * NW, Q = 64, NR = 3;
     constexpr int CAP = 14 * Q;   // pieces per pass (> 9 Q: one piece per row always fits)
-    constexpr int PLB = 3;
+#ifndef ICPMI_NNK_PLB
+#define ICPMI_NNK_PLB 3
+#endif
+    constexpr int PLB = ICPMI_NNK_PLB;
     constexpr int CAPQ = 24;      // list entries per query and pass (> KMAX).  (48, at three waves per SIMD, for the wide first launches: slower)
     static_assert(CAPQ > KMAX, "a repeated pass must make progress");
     __shared__ uint4 ltab[ICPMI_MAXLEV * 4];
