@@ -375,8 +375,16 @@ __device__ __forceinline__ unsigned wave_incl_scan(unsigned v)
 //   (3)  wave 0 decides and stores.
 // Same keys and exactness rules as the r1 - r3 kernels it replaced: same bits.
 // ------------------------------------------------------------------------------------------------
+#ifndef ICPMI_NN1_WAVES
+#define ICPMI_NN1_WAVES 0
+#endif
+#if ICPMI_NN1_WAVES > 0
+#define NN1_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(ICPMI_NN1_WAVES, ICPMI_NN1_WAVES)))
+#else
+#define NN1_WAVES_ATTR
+#endif
 template <int NW, bool SELF>
-__global__ __launch_bounds__(64 * NW) void nn1_wg_kernel(const float4* __restrict__ queries, const int* __restrict__ qindex, BatchArgs ba,
+__global__ __launch_bounds__(64 * NW) NN1_WAVES_ATTR void nn1_wg_kernel(const float4* __restrict__ queries, const int* __restrict__ qindex, BatchArgs ba,
                                                      const float* __restrict__ Tptr, GridLevels L, float maxr2, int* __restrict__ out_sidx,
                                                      float* __restrict__ out_d2, IcpState* __restrict__ st, unsigned* __restrict__ hard,
                                                      unsigned* __restrict__ hist0, float4* __restrict__ match_pt,
