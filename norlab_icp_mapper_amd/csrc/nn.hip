@@ -375,8 +375,11 @@ __device__ __forceinline__ unsigned wave_incl_scan(unsigned v)
 //   (3)  wave 0 decides and stores.
 // Same keys and exactness rules as the r1 - r3 kernels it replaced: same bits.
 // ------------------------------------------------------------------------------------------------
+// r6: seven waves per SIMD = seven workgroups per CU = 1 792 resident workgroups: the 1 568 of a 100 k-query launch are all resident at once (at six, 32 of
+// them waited for a slot: +0.8 ... 2.4 us per launch).  72 VGPRs without a spill since the query's point and its best-so-far moved into LDS (below);
+// profiles/r6_ab_nn1_plb.txt has the A/B over sizes.  0 = the compiler's choice.
 #ifndef ICPMI_NN1_WAVES
-#define ICPMI_NN1_WAVES 0
+#define ICPMI_NN1_WAVES 7
 #endif
 #if ICPMI_NN1_WAVES > 0
 #define NN1_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(ICPMI_NN1_WAVES, ICPMI_NN1_WAVES)))
@@ -512,6 +515,9 @@ __global__ __launch_bounds__(64 * NW) NN1_WAVES_ATTR void nn1_wg_kernel(const fl
 
     int lev = lev0;
     bool did_pre = false; // this level's own-row pass has run
+    // r6: the query's point and its best so far live in LDS from here on (qrec / qkey / qwin are the query's own slots: phase 2 updates the
+    // key and the winner in place, wave 0 reads them back) -- registers that only wave 0 used and every wave paid for
+    if (w0) { qrec[slot] = make_float4(p.x, p.y, p.z, __int_as_float(lev0)); qkey[slot] = best.key; qwin[slot] = (unsigned)best.sidx; }
     NN_TICK(0);
     __syncthreads(); // ltab / lh visible
     for (;;) {
@@ -523,19 +529,18 @@ __global__ __launch_bounds__(64 * NW) NN1_WAVES_ATTR void nn1_wg_kernel(const fl
             if (lane == 0) { s_any = any ? 1u : 0u; s_total[0] = 0u; s_total[1] = 0u; }
             if (any) {
                 const int lv = run ? lev : 0;
+                const unsigned long long bk = qkey[slot];
                 // a query that holds no bound yet (or a seed too wide for level 0, see seed_pre) first looks at the x-row through
                 // its own cell only; the pass after that prunes with what it found
-                prescan = run && !did_pre && (best.key == ~0ull || (widepre && lev == 0));
+                prescan = run && !did_pre && (bk == ~0ull || (widepre && lev == 0));
                 float rub2 = INFINITY; // squared pruning radius (with slack), +inf = no pruning
-                if (!prescan && best.key != ~0ull) {
+                if (!prescan && bk != ~0ull) {
                     const float slack = __uint_as_float(ltab[4 * lv + 1].y);
-                    const float rub = sqrt_up(__uint_as_float((unsigned)(best.key >> 32))) * inv1e * 1.000001f + slack;
+                    const float rub = sqrt_up(__uint_as_float((unsigned)(bk >> 32))) * inv1e * 1.000001f + slack;
                     rub2 = rub * rub;
                 }
-                qrec[slot] = make_float4(p.x, p.y, p.z, __int_as_float(lv));
+                reinterpret_cast<float*>(&qrec[slot])[3] = __int_as_float(lv);
                 qaux[slot] = make_float2(rub2, __int_as_float((run ? 1 : 0) | (prescan ? 2 : 0)));
-                qkey[slot] = best.key;
-                qwin[slot] = (unsigned)best.sidx;
             }
         }
         __syncthreads();
@@ -687,19 +692,19 @@ __global__ __launch_bounds__(64 * NW) NN1_WAVES_ATTR void nn1_wg_kernel(const fl
         // ---- (3) wave 0 decides
         if (w0 && run) {
             const unsigned long long k2 = qkey[slot];
-            if (k2 != best.key) { best.key = k2; best.sidx = (int)qwin[slot]; }
             if (prescan) did_pre = true;
             else {
                 const float2 dq = qdec[slot];
                 const float m2 = dq.x;
                 const bool covers = dq.y != 0.f;
-                const float bd2 = __uint_as_float((unsigned)(best.key >> 32));
-                decided = (best.key != ~0ull && bd2 <= m2 * err2) || m2 > maxr2 || covers;
+                const float bd2 = __uint_as_float((unsigned)(k2 >> 32));
+                decided = (k2 != ~0ull && bd2 <= m2 * err2) || m2 > maxr2 || covers;
                 if (!decided) { ++lev; did_pre = false; }
             }
         }
         NN_TICK(4);
     }
+    if (w0) { best.key = qkey[slot]; best.sidx = (int)qwin[slot]; }
 
     float bd2 = __uint_as_float((unsigned)(best.key >> 32));
     const bool found = best.key != ~0ull && bd2 <= maxr2;
