@@ -1074,7 +1074,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KMAX <= 8 ?
 #define ICPMI_NNK_PLB 3
 #endif
     constexpr int PLB = ICPMI_NNK_PLB;
-    constexpr int CAPQ = 24;      // list entries per query and pass (> KMAX).  (48, at three waves per SIMD, for the wide first launches: slower)
+#ifndef ICPMI_NNK_CAPQ
+#define ICPMI_NNK_CAPQ 24
+#endif
+    constexpr int CAPQ = ICPMI_NNK_CAPQ;      // list entries per query and pass (> KMAX).  (48, at three waves per SIMD, for the wide first launches: slower)
     static_assert(CAPQ > KMAX, "a repeated pass must make progress");
     __shared__ uint4 ltab[ICPMI_MAXLEV * 4];
     __shared__ uint2 pieces[CAP];                 // {position of the first candidate in its level array, count << 8 | query slot}
