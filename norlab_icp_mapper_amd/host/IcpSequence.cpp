@@ -119,6 +119,10 @@ void GpuICPSequence::loadFromYamlNode(const yaml::Node& icp)
         // epsilon_approx); default: the exact search, which is a valid answer for every epsilon
         static const bool approx = [] { const char* v = std::getenv("NIM_EPSILON_APPROX"); return v && std::atoi(v) != 0; }();
         cfg.epsilon_approx = approx ? 1 : 0;
+        // NIM_KNN_WG_FROM=n (deployment knob, icpmi_config::knn_wg_from): the first iteration (n - 1) of a k > 1 loop the workgroup-cooperative matcher serves;
+        // default 0 = from iteration 2.  Same results either way; which is faster depends on how far the first solve moves the reading
+        static const int wgFrom = [] { const char* v = std::getenv("NIM_KNN_WG_FROM"); return v ? std::atoi(v) : 0; }();
+        cfg.knn_wg_from = wgFrom;
         if (e.second["maxDist"]) cfg.max_dist = e.second["maxDist"].as<float>();
     }
     cfg.n_outlier = 0;
